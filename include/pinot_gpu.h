@@ -1,0 +1,243 @@
+/*
+ * pinot_gpu.h — C ABI of the MI355X-native Pinot segment query executor (libpinot_gpu.so).
+ *
+ * This is the drop-in boundary.  The reference (apachepinot/pinot 1.4.0-SNAPSHOT) is 100 % Java and
+ * has no FFI for this path, so every entry point below names the Java interface it stands in for.  A JNI shim
+ *  binds these 1:1; the same symbols are called by the Python/C++ parity and benchmark drivers.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in any signature; all pointers are HOST pointers unless stated otherwise;
+ *   - every function returns pg_status (0 = ok, <0 = error); the message of the last error on the calling thread is
+ *     returned by pg_last_error() (Java side: thrown as RuntimeException, which BaseCombineOperator wraps with the
+ *     segment name — pinot-core/.../operator/combine/BaseCombineOperator.java:185-199);
+ *   - buffers passed to pg_segment_add_column() are the *exact bytes* of the Pinot index entries (big-endian, as they
+ *     sit in columns.psf behind the 8-byte magic marker; PinotDataBuffer address + long length —
+ *     pinot-segment-spi/.../memory/PinotDataBuffer.java:162-174).  They are copied into HBM during the call and need not
+ *     outlive it;
+ *   - thread-safe and re-entrant: one segment may be queried from many host threads (one worker thread per segment task
+ *     in the reference — BaseCombineOperator.java:97-142); each calling thread gets its own HIP stream and workspace;
+ *   - results are copied into caller-allocated arrays (caller-allocated, callee-filled; JNI Get*ArrayCritical friendly).
+ */
+#ifndef PINOT_GPU_H_
+#define PINOT_GPU_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_ABI_VERSION 1
+
+typedef enum pg_status {
+  PG_OK = 0,
+  PG_ERR_INVALID_ARGUMENT = -1,
+  PG_ERR_UNSUPPORTED = -2,   /* query shape not handled by the GPU path: caller falls back to InstancePlanMakerImplV2 */
+  PG_ERR_DEVICE = -3,        /* HIP error */
+  PG_ERR_OUT_OF_MEMORY = -4,
+  PG_ERR_NOT_FOUND = -5,     /* unknown column */
+  PG_ERR_CANCELLED = -6,     /* EarlyTerminationException equivalent (BaseOperator.java:44-46) */
+  PG_ERR_INTERNAL = -7
+} pg_status;
+
+/* Stored data types (FieldSpec.DataType#getStoredType, pinot-spi/.../data/FieldSpec.java). */
+typedef enum pg_data_type {
+  PG_TYPE_INT = 0,
+  PG_TYPE_LONG = 1,
+  PG_TYPE_FLOAT = 2,
+  PG_TYPE_DOUBLE = 3,
+  PG_TYPE_STRING = 4,
+  PG_TYPE_BYTES = 5
+} pg_data_type;
+
+/* Forward index encodings on the path (ForwardIndexReaderFactory.java:74-109). */
+typedef enum pg_fwd_encoding {
+  /* FixedBitSVForwardIndexReaderV2: dictIds, MSB-first big-endian bit stream, ceil(numDocs*bits/8) bytes. */
+  PG_FWD_DICT_FIXED_BIT = 0,
+  /* FixedByteChunkSVForwardIndexReader (PASS_THROUGH only): 7-int header + chunk offsets + big-endian values. */
+  PG_FWD_RAW_FIXED_BYTE_CHUNK = 1,
+  /* SortedIndexReaderImpl: 2 big-endian ints (startDocId, endDocId inclusive) per dictId; doubles as inverted index. */
+  PG_FWD_DICT_SORTED = 2
+} pg_fwd_encoding;
+
+typedef struct pg_buffer {
+  const void* addr;
+  uint64_t size;
+} pg_buffer;
+
+/*
+ * One column = one DataSource (pinot-segment-spi/.../datasource/DataSource.java): forward index + optional dictionary
+ * + optional inverted index.  Layouts: SURVEY.md §8a rows a12 (fixed-bit), a13 (raw chunk), a14 (dictionary),
+ * a5 (BitmapInvertedIndexReader: (cardinality+1) BE uint32 offsets, then portable-format RoaringBitmap blobs).
+ */
+typedef struct pg_column_desc {
+  const char* name;
+  int32_t data_type;                /* pg_data_type (stored type) */
+  int32_t fwd_encoding;             /* pg_fwd_encoding */
+  int32_t has_dictionary;
+  int32_t cardinality;              /* dictionary length; 0 for raw columns */
+  int32_t bits_per_value;           /* PG_FWD_DICT_FIXED_BIT: PinotDataBitSet.getNumBitsPerValue(cardinality-1) */
+  int32_t is_sorted;                /* DataSourceMetadata#isSorted */
+  int32_t dict_bytes_per_value;     /* 4/8 numeric; padded length for fixed-width STRING/BYTES dictionaries */
+  int32_t reserved0;
+  pg_buffer forward_index;
+  pg_buffer dictionary;             /* sorted big-endian fixed-width values (BaseImmutableDictionary.java:45-58) */
+  pg_buffer inverted_index;         /* size 0 if the column has no inverted index */
+} pg_column_desc;
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Query description = the part of QueryContext the path reads (pinot-core/.../query/request/context/QueryContext.java):
+ * FilterContext tree, group-by identifiers, aggregation functions and the group-by query options.
+ * Literals stay strings exactly as in Predicate (pinot-common/.../request/context/predicate/{Eq,In,Range,...}Predicate.java); the native
+ * PredicateEvaluator layer parses them against the column's stored type (PredicateEvaluatorProvider.java:45-96).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef enum pg_filter_type {   /* FilterContext.Type */
+  PG_FILTER_AND = 0,
+  PG_FILTER_OR = 1,
+  PG_FILTER_NOT = 2,
+  PG_FILTER_PREDICATE = 3,
+  PG_FILTER_CONSTANT_TRUE = 4,
+  PG_FILTER_CONSTANT_FALSE = 5
+} pg_filter_type;
+
+typedef enum pg_predicate_type {  /* Predicate.Type (subset on the path) */
+  PG_PRED_EQ = 0,
+  PG_PRED_NOT_EQ = 1,
+  PG_PRED_IN = 2,
+  PG_PRED_NOT_IN = 3,
+  PG_PRED_RANGE = 4
+} pg_predicate_type;
+
+#define PG_RANGE_UNBOUNDED "*"    /* RangePredicate.UNBOUNDED */
+
+typedef struct pg_filter_node {
+  int32_t type;                          /* pg_filter_type */
+  int32_t n_children;                    /* AND / OR: >=1; NOT: 1 */
+  const struct pg_filter_node* children; /* contiguous array of n_children nodes */
+  /* PG_FILTER_PREDICATE only */
+  int32_t predicate_type;                /* pg_predicate_type */
+  int32_t n_values;                      /* EQ / NOT_EQ: 1; IN / NOT_IN: >=1 */
+  const char* column;                    /* lhs identifier */
+  const char* const* values;             /* literal strings */
+  const char* lower;                     /* RANGE: lower bound or "*" */
+  const char* upper;                     /* RANGE: upper bound or "*" */
+  int32_t lower_inclusive;
+  int32_t upper_inclusive;
+} pg_filter_node;
+
+typedef enum pg_agg_function {   /* AggregationFunctionType (subset named by north_star + AVG for the goldens) */
+  PG_AGG_COUNT = 0,
+  PG_AGG_SUM = 1,
+  PG_AGG_MIN = 2,
+  PG_AGG_MAX = 3,
+  PG_AGG_AVG = 4,
+  PG_AGG_DISTINCTCOUNT = 5,
+  PG_AGG_DISTINCTCOUNTHLL = 6,
+  PG_AGG_MINMAXRANGE = 7
+} pg_agg_function;
+
+typedef struct pg_agg_spec {
+  int32_t function;       /* pg_agg_function */
+  int32_t log2m;          /* DISTINCTCOUNTHLL: 0 => CommonConstants.Helix.DEFAULT_HYPERLOGLOG_LOG2M (8) */
+  const char* column;     /* NULL or "*" for COUNT(*) */
+} pg_agg_spec;
+
+typedef struct pg_query {
+  const pg_filter_node* filter;          /* NULL => MatchAllFilterOperator */
+  int32_t n_group_by;                    /* 0 => AggregationOperator (no GROUP BY) */
+  int32_t n_aggregations;                /* 0 => filter only (used by pg_filter_exec) */
+  const char* const* group_by_columns;
+  const pg_agg_spec* aggregations;
+  /* InstancePlanMakerImplV2.java:75-96 defaults are applied for values <= 0 */
+  int32_t num_groups_limit;                     /* DEFAULT_NUM_GROUPS_LIMIT = 100 000 */
+  int32_t max_initial_result_holder_capacity;   /* DEFAULT_MAX_INITIAL_RESULT_HOLDER_CAPACITY = 10 000 */
+  int32_t flags;                                /* PG_QUERY_* */
+  int32_t reserved0;
+} pg_query;
+
+#define PG_QUERY_FLAG_PROFILE 0x1   /* record per-kernel HIP-event timings into pg_exec_stats */
+
+/* ExecutionStatistics (pinot-core/.../operator/ExecutionStatistics.java) + device timings. */
+typedef struct pg_exec_stats {
+  int64_t num_docs_scanned;
+  int64_t num_entries_scanned_in_filter;
+  int64_t num_entries_scanned_post_filter;
+  int64_t num_total_docs;
+  int32_t num_groups_limit_reached;
+  int32_t stats_exact;            /* 1 if num_entries_scanned_in_filter follows the reference (flat AND shapes) */
+  /* HIP-event timings on the stream the kernels ran on, milliseconds; 0 when not profiled */
+  float device_ms_total;
+  float device_ms_filter;
+  float device_ms_aggregate;      /* fused scan+aggregate kernel when the plan is fused */
+  float device_ms_reduce;
+  float host_ms_plan;
+  float host_ms_total;
+  int64_t algorithmic_bytes;      /* bytes the plan must read once (columns + postings), for roofline accounting */
+} pg_exec_stats;
+
+/* Intermediate result kinds (AggregationFunction#getIntermediateResultColumnType). */
+typedef enum pg_result_kind {
+  PG_RESULT_LONG = 0,      /* COUNT */
+  PG_RESULT_DOUBLE = 1,    /* SUM / MIN / MAX */
+  PG_RESULT_AVG_PAIR = 2,  /* AvgPair(sum, count) */
+  PG_RESULT_MINMAX_PAIR = 3,
+  PG_RESULT_DICTID_SET = 4,/* DISTINCTCOUNT over a dictionary column: set of dictIds (decoded by the caller) */
+  PG_RESULT_HLL = 5        /* HyperLogLog registers, m = 2^log2m bytes per group */
+} pg_result_kind;
+
+typedef struct pg_segment_s* pg_segment_t;
+typedef struct pg_result_s* pg_result_t;
+typedef struct pg_docidset_s* pg_docidset_t;
+
+/* ---- library ---------------------------------------------------------------------------------------------------- */
+int32_t pg_abi_version(void);
+/* Binds the process to a HIP device (one process per GPU).  Fails loudly if no device is present. */
+int32_t pg_init(int32_t device_ordinal);
+int32_t pg_device_count(int32_t* out_count);
+/* Copies the calling thread's last error message into buf (NUL terminated, truncated to cap). Returns its length. */
+int32_t pg_last_error(char* buf, size_t cap);
+
+/* ---- segment life cycle: IndexSegment / ImmutableSegmentLoader.load → pin in HBM; IndexSegment#destroy ------------
+ * (pinot-segment-spi/.../IndexSegment.java:137-142). */
+int32_t pg_segment_create(const char* segment_name, int32_t total_docs, pg_segment_t* out_segment);
+int32_t pg_segment_add_column(pg_segment_t segment, const pg_column_desc* column);
+int32_t pg_segment_num_docs(pg_segment_t segment, int32_t* out_num_docs);
+int32_t pg_segment_device_bytes(pg_segment_t segment, uint64_t* out_bytes);
+int32_t pg_segment_destroy(pg_segment_t segment);
+
+/* ---- FilterOperator + DocIdSetOperator: BaseFilterOperator#nextBlock → FilterBlock#getBlockDocIdSet ----------------
+ * (pinot-core/.../operator/filter/BaseFilterOperator.java, DocIdSetOperator.java:59-86). */
+int32_t pg_filter_exec(pg_segment_t segment, const pg_filter_node* filter, pg_docidset_t* out_docidset);
+int32_t pg_docidset_cardinality(pg_docidset_t set, int64_t* out_cardinality);
+int32_t pg_docidset_num_words(pg_docidset_t set, int64_t* out_num_words);        /* ceil(numDocs/64) */
+int32_t pg_docidset_copy_words(pg_docidset_t set, uint64_t* out_words, int64_t capacity_words);
+int32_t pg_docidset_copy_docids(pg_docidset_t set, int32_t* out_docids, int64_t capacity); /* ascending */
+int32_t pg_docidset_stats(pg_docidset_t set, pg_exec_stats* out_stats);
+int32_t pg_docidset_free(pg_docidset_t set);
+
+/* ---- GroupByOperator / AggregationOperator: Operator#nextBlock → GroupByResultsBlock / AggregationResultsBlock ----
+ * (pinot-core/.../operator/query/GroupByOperator.java:100-140, AggregationOperator.java).  Returns PG_ERR_UNSUPPORTED
+ * when the query shape is outside the GPU path so that GpuInstancePlanMaker can fall back to the default plan. */
+int32_t pg_query_supported(pg_segment_t segment, const pg_query* query);
+int32_t pg_query_exec(pg_segment_t segment, const pg_query* query, pg_result_t* out_result);
+
+int32_t pg_result_num_groups(pg_result_t result, int32_t* out_num_groups);
+/* dictIds of group-by column `col` for every group (GroupKeyGenerator#getGroupKeys; decoding via Dictionary is the
+ * caller's job as in DictionaryBasedGroupKeyGenerator.java:578-606). */
+int32_t pg_result_group_dict_ids(pg_result_t result, int32_t col, int32_t* out_dict_ids, int32_t capacity);
+int32_t pg_result_kind_of(pg_result_t result, int32_t agg, int32_t* out_kind);
+int32_t pg_result_doubles(pg_result_t result, int32_t agg, int32_t component, double* out, int32_t capacity);
+int32_t pg_result_longs(pg_result_t result, int32_t agg, int32_t component, int64_t* out, int32_t capacity);
+/* DISTINCTCOUNT: sizes[g] then the concatenated ascending dictIds of every group */
+int32_t pg_result_set_sizes(pg_result_t result, int32_t agg, int32_t* out_sizes, int32_t capacity);
+int32_t pg_result_set_dict_ids(pg_result_t result, int32_t agg, int32_t* out_dict_ids, int64_t capacity);
+/* DISTINCTCOUNTHLL: num_groups * 2^log2m register bytes, group-major */
+int32_t pg_result_hll_registers(pg_result_t result, int32_t agg, uint8_t* out_registers, int64_t capacity);
+int32_t pg_result_stats(pg_result_t result, pg_exec_stats* out_stats);
+int32_t pg_result_free(pg_result_t result);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PINOT_GPU_H_ */

@@ -1,0 +1,879 @@
+/*
+ * CPU ORACLE — TEST INFRASTRUCTURE ONLY (see po_internal.h).
+ * DocIdSetOperator → ProjectionOperator → GroupByOperator / AggregationOperator and the exported po_* entry points
+ * (same shapes as include/pinot_gpu.h so the parity tests drive both sides with one set of structs).
+ * SURVEY.md §8a rows a10, a11, a15–a23.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <time.h>
+
+#include "po_internal.h"
+
+const char* po_get_error(void);
+int po_raw_parse_header(po_column* c);
+
+#define DEFAULT_NUM_GROUPS_LIMIT 100000
+#define DEFAULT_MAX_INITIAL_RESULT_HOLDER_CAPACITY 10000
+#define DEFAULT_LOG2M 8
+
+/* =====================================================================================================================
+ * segment
+ * ===================================================================================================================== */
+po_column* po_segment_column(po_segment* seg, const char* name) {
+  if (!name) return NULL;
+  for (int i = 0; i < seg->n_columns; i++)
+    if (strcmp(seg->columns[i]->name, name) == 0) return seg->columns[i];
+  return NULL;
+}
+
+int32_t po_abi_version(void) { return PG_ABI_VERSION; }
+int32_t po_init(int32_t d) { (void)d; return PG_OK; }
+int32_t po_device_count(int32_t* n) { *n = 0; return PG_OK; }
+int32_t po_last_error(char* buf, size_t cap) {
+  const char* e = po_get_error();
+  size_t n = strlen(e);
+  if (cap) {
+    size_t k = n < cap - 1 ? n : cap - 1;
+    memcpy(buf, e, k);
+    buf[k] = 0;
+  }
+  return (int32_t)n;
+}
+
+int32_t po_segment_create(const char* name, int32_t total_docs, void** out) {
+  po_segment* s = (po_segment*)po_xcalloc(1, sizeof(*s));
+  s->name = strdup(name ? name : "");
+  s->total_docs = total_docs;
+  *out = s;
+  return PG_OK;
+}
+
+/* The oracle keeps pointers into the caller's buffers (they must outlive the segment). */
+int32_t po_segment_add_column(void* segp, const pg_column_desc* d) {
+  po_segment* seg = (po_segment*)segp;
+  po_column* c = (po_column*)po_xcalloc(1, sizeof(*c));
+  c->name = strdup(d->name);
+  c->data_type = d->data_type;
+  c->fwd_encoding = d->fwd_encoding;
+  c->has_dictionary = d->has_dictionary;
+  c->cardinality = d->cardinality;
+  c->bits_per_value = d->bits_per_value;
+  c->is_sorted = d->is_sorted;
+  c->dict_bytes_per_value = d->dict_bytes_per_value;
+  c->fwd = (const uint8_t*)d->forward_index.addr;
+  c->fwd_len = d->forward_index.size;
+  c->dict = (const uint8_t*)d->dictionary.addr;
+  c->dict_len = d->dictionary.size;
+  c->inv = (const uint8_t*)d->inverted_index.addr;
+  c->inv_len = d->inverted_index.size;
+  c->num_docs = seg->total_docs;
+  if (c->fwd_encoding == PG_FWD_RAW_FIXED_BYTE_CHUNK && po_raw_parse_header(c)) return PG_ERR_UNSUPPORTED;
+  if (c->fwd_encoding == PG_FWD_DICT_FIXED_BIT) {
+    uint64_t need = ((uint64_t)seg->total_docs * (uint64_t)c->bits_per_value + 7) / 8;
+    if (c->fwd_len < need) {
+      po_set_error("forward index of %s is %llu bytes, need %llu", c->name, (unsigned long long)c->fwd_len,
+                   (unsigned long long)need);
+      return PG_ERR_INVALID_ARGUMENT;
+    }
+  }
+  seg->columns = (po_column**)po_xrealloc(seg->columns, sizeof(po_column*) * (size_t)(seg->n_columns + 1));
+  seg->columns[seg->n_columns++] = c;
+  return PG_OK;
+}
+int32_t po_segment_num_docs(void* s, int32_t* out) { *out = ((po_segment*)s)->total_docs; return PG_OK; }
+int32_t po_segment_device_bytes(void* s, uint64_t* out) { (void)s; *out = 0; return PG_OK; }
+int32_t po_segment_destroy(void* segp) {
+  po_segment* seg = (po_segment*)segp;
+  for (int i = 0; i < seg->n_columns; i++) {
+    free(seg->columns[i]->name);
+    free(seg->columns[i]);
+  }
+  free(seg->columns);
+  free(seg->name);
+  free(seg);
+  return PG_OK;
+}
+
+/* =====================================================================================================================
+ * filter-only API (FilterOperator + DocIdSetOperator)
+ * ===================================================================================================================== */
+typedef struct po_docidset_result {
+  po_bitmap* bitmap;
+  int64_t cardinality;
+  int32_t num_docs;
+  pg_exec_stats stats;
+} po_docidset_result;
+
+int32_t po_filter_exec(void* segp, const pg_filter_node* filter, void** out) {
+  po_segment* seg = (po_segment*)segp;
+  po_filter_op* op = po_filter_plan(seg, filter);
+  if (!op) return PG_ERR_INVALID_ARGUMENT;
+  po_docidset* set = po_filter_get_trues(op);
+  if (!set) return PG_ERR_INVALID_ARGUMENT;
+  po_iter* it = set->iterator(set);
+  po_docidset_result* r = (po_docidset_result*)po_xcalloc(1, sizeof(*r));
+  r->bitmap = po_bitmap_new(seg->total_docs);
+  r->num_docs = seg->total_docs;
+  int32_t d;
+  while ((d = it->next(it)) != PO_EOF) {
+    po_bitmap_add(r->bitmap, d);
+    r->cardinality++;
+  }
+  r->stats.num_docs_scanned = r->cardinality;
+  r->stats.num_entries_scanned_in_filter = set->num_entries_scanned(set);
+  r->stats.num_total_docs = seg->total_docs;
+  r->stats.stats_exact = 1;
+  *out = r;
+  return PG_OK;
+}
+int32_t po_docidset_cardinality(void* s, int64_t* out) { *out = ((po_docidset_result*)s)->cardinality; return PG_OK; }
+int32_t po_docidset_num_words(void* s, int64_t* out) {
+  *out = (((po_docidset_result*)s)->num_docs + 63) / 64;
+  return PG_OK;
+}
+int32_t po_docidset_copy_words(void* s, uint64_t* out, int64_t cap) {
+  po_docidset_result* r = (po_docidset_result*)s;
+  int64_t n = (r->num_docs + 63) / 64;
+  if (cap < n) { po_set_error("capacity too small"); return PG_ERR_INVALID_ARGUMENT; }
+  memcpy(out, r->bitmap->words, (size_t)n * 8);
+  return PG_OK;
+}
+int32_t po_docidset_copy_docids(void* s, int32_t* out, int64_t cap) {
+  po_docidset_result* r = (po_docidset_result*)s;
+  if (cap < r->cardinality) { po_set_error("capacity too small"); return PG_ERR_INVALID_ARGUMENT; }
+  int64_t k = 0;
+  for (int64_t p = po_bitmap_next_set(r->bitmap, 0); p >= 0; p = po_bitmap_next_set(r->bitmap, p + 1)) out[k++] = (int32_t)p;
+  return PG_OK;
+}
+int32_t po_docidset_stats(void* s, pg_exec_stats* out) { *out = ((po_docidset_result*)s)->stats; return PG_OK; }
+int32_t po_docidset_free(void* s) {
+  po_docidset_result* r = (po_docidset_result*)s;
+  po_bitmap_free(r->bitmap);
+  free(r);
+  return PG_OK;
+}
+
+/* =====================================================================================================================
+ * group key generation: DictionaryBasedGroupKeyGenerator
+ * ===================================================================================================================== */
+static inline uint32_t hash_common_mix(uint32_t x) { /* fastutil HashCommon.mix */
+  uint32_t h = x * 0x9E3779B9u;
+  return h ^ (h >> 16);
+}
+
+/* IntGroupIdMap, core/query/aggregation/groupby/DictionaryBasedGroupKeyGenerator.java:993-1084 */
+typedef struct int_group_id_map { int32_t* kv; int32_t capacity, mask, max_entries, size; } int_group_id_map;
+static void igm_init(int_group_id_map* m) {
+  m->capacity = 1 << 9;
+  int holder = m->capacity << 1;
+  m->kv = (int32_t*)po_xcalloc((size_t)holder, 4);
+  m->mask = holder - 1;
+  m->max_entries = (int)(m->capacity * 0.75f);
+  m->size = 0;
+}
+static void igm_expand(int_group_id_map* m) {
+  m->capacity <<= 1;
+  int holder = m->capacity << 1;
+  int32_t* old = m->kv;
+  m->kv = (int32_t*)po_xcalloc((size_t)holder, 4);
+  m->mask = holder - 1;
+  m->max_entries <<= 1;
+  int old_index = 0;
+  for (int i = 0; i < m->size; i++) {
+    while (old[old_index] == 0) old_index += 2;
+    int32_t key = old[old_index], value = old[old_index + 1];
+    int ni = (int)((hash_common_mix((uint32_t)key) << 1) & (uint32_t)m->mask);
+    while (m->kv[ni] != 0) ni = (ni + 2) & m->mask;
+    m->kv[ni] = key;
+    m->kv[ni + 1] = value;
+    old_index += 2;
+  }
+  free(old);
+}
+static int32_t igm_get_group_id(int_group_id_map* m, int32_t raw_key, int32_t upper_bound) {
+  int32_t internal = raw_key + 1;
+  int index = (int)((hash_common_mix((uint32_t)internal) << 1) & (uint32_t)m->mask);
+  while (1) {
+    int32_t key = m->kv[index];
+    if (key == internal) return m->kv[index + 1];
+    if (key == 0) {
+      if (m->size < upper_bound) {
+        int32_t gid = m->size++;
+        m->kv[index] = internal;
+        m->kv[index + 1] = gid;
+        if (m->size > m->max_entries) igm_expand(m);
+        return gid;
+      }
+      return PO_INVALID_ID;
+    }
+    index = (index + 2) & m->mask;
+  }
+}
+
+/* Long2IntOpenHashMap stand-in (fastutil; only map semantics matter: putIfAbsent(rawKey, numGroups)) */
+typedef struct long_map { int64_t* keys; int32_t* vals; uint8_t* used; int64_t cap; int32_t size; } long_map;
+static void lm_init(long_map* m) {
+  m->cap = 1024;
+  m->keys = (int64_t*)po_xcalloc((size_t)m->cap, 8);
+  m->vals = (int32_t*)po_xcalloc((size_t)m->cap, 4);
+  m->used = (uint8_t*)po_xcalloc((size_t)m->cap, 1);
+  m->size = 0;
+}
+static uint64_t lm_hash(int64_t k) {
+  uint64_t h = (uint64_t)k * 0x9E3779B97F4A7C15ULL;
+  return h ^ (h >> 32);
+}
+static void lm_grow(long_map* m) {
+  long_map n;
+  n.cap = m->cap * 2;
+  n.keys = (int64_t*)po_xcalloc((size_t)n.cap, 8);
+  n.vals = (int32_t*)po_xcalloc((size_t)n.cap, 4);
+  n.used = (uint8_t*)po_xcalloc((size_t)n.cap, 1);
+  n.size = m->size;
+  for (int64_t i = 0; i < m->cap; i++) {
+    if (!m->used[i]) continue;
+    uint64_t p = lm_hash(m->keys[i]) & (uint64_t)(n.cap - 1);
+    while (n.used[p]) p = (p + 1) & (uint64_t)(n.cap - 1);
+    n.used[p] = 1;
+    n.keys[p] = m->keys[i];
+    n.vals[p] = m->vals[i];
+  }
+  free(m->keys); free(m->vals); free(m->used);
+  *m = n;
+}
+static int32_t lm_get_group_id(long_map* m, int64_t raw_key, int32_t upper_bound) { /* LongMapBasedHolder#getGroupId :652-660 */
+  uint64_t p = lm_hash(raw_key) & (uint64_t)(m->cap - 1);
+  while (m->used[p]) {
+    if (m->keys[p] == raw_key) return m->vals[p];
+    p = (p + 1) & (uint64_t)(m->cap - 1);
+  }
+  if (m->size < upper_bound) {
+    m->used[p] = 1;
+    m->keys[p] = raw_key;
+    m->vals[p] = m->size;
+    int32_t id = m->size++;
+    if ((int64_t)m->size * 4 > m->cap * 3) lm_grow(m);
+    return id;
+  }
+  return PO_INVALID_ID;
+}
+
+enum { HOLDER_ARRAY, HOLDER_INT_MAP, HOLDER_LONG_MAP };
+
+typedef struct group_key_gen {
+  int n_cols;
+  po_column** cols;
+  int32_t* cardinalities;
+  int holder;
+  int32_t global_upper_bound;   /* _globalGroupIdUpperBound */
+  /* array based */
+  uint8_t* flags; int32_t num_keys;
+  int_group_id_map imap;
+  long_map lmap;
+  /* reverse: raw key per group id for map holders */
+  int64_t* raw_key_of_group; int32_t raw_cap;
+} group_key_gen;
+
+/* constructor, DictionaryBasedGroupKeyGenerator.java:106-185 */
+static int gkg_init(group_key_gen* g, int n_cols, po_column** cols, int32_t num_groups_limit, int32_t array_threshold) {
+  memset(g, 0, sizeof(*g));
+  g->n_cols = n_cols;
+  g->cols = cols;
+  g->cardinalities = (int32_t*)po_xcalloc((size_t)n_cols + 1, 4);
+  int64_t product = 1;
+  int long_overflow = 0;
+  for (int i = 0; i < n_cols; i++) {
+    int32_t card = cols[i]->cardinality;
+    g->cardinalities[i] = card;
+    if (!long_overflow) {
+      if (product > INT64_MAX / card) long_overflow = 1;
+      else product *= card;
+    }
+  }
+  if (long_overflow) {
+    po_set_error("ArrayMapBasedHolder (cardinality product > 2^63) is outside the hot path");
+    return -1;
+  }
+  if (product > INT32_MAX) {
+    g->holder = HOLDER_LONG_MAP;
+    g->global_upper_bound = num_groups_limit;
+    lm_init(&g->lmap);
+  } else {
+    g->global_upper_bound = (int32_t)(product < num_groups_limit ? product : num_groups_limit);
+    if (product > array_threshold || num_groups_limit < product) {
+      g->holder = HOLDER_INT_MAP;
+      igm_init(&g->imap);
+    } else {
+      g->holder = HOLDER_ARRAY;
+      g->flags = (uint8_t*)po_xcalloc((size_t)g->global_upper_bound + 1, 1);
+    }
+  }
+  if (g->holder != HOLDER_ARRAY) {
+    g->raw_cap = 1024;
+    g->raw_key_of_group = (int64_t*)po_xmalloc(sizeof(int64_t) * (size_t)g->raw_cap);
+  }
+  return 0;
+}
+
+static void gkg_remember(group_key_gen* g, int32_t gid, int64_t raw) {
+  if (gid < 0) return;
+  if (gid >= g->raw_cap) {
+    while (gid >= g->raw_cap) g->raw_cap *= 2;
+    g->raw_key_of_group = (int64_t*)po_xrealloc(g->raw_key_of_group, sizeof(int64_t) * (size_t)g->raw_cap);
+  }
+  g->raw_key_of_group[gid] = raw;
+}
+
+/* generateKeysForBlock → RawKeyHolder#processSingleValue (:285-354 array, :416-446 int map, :629-640 long map):
+ * rawKey = sum_j dictId_j * prod_{i<j} card_i, built from the last column down */
+static void gkg_generate(group_key_gen* g, int n_docs, int32_t** dict_ids, int32_t* out) {
+  for (int i = 0; i < n_docs; i++) {
+    int64_t raw = 0;
+    for (int j = g->n_cols - 1; j >= 0; j--) raw = raw * g->cardinalities[j] + dict_ids[j][i];
+    int32_t gid;
+    if (g->holder == HOLDER_ARRAY) {
+      gid = (int32_t)raw;
+      if (!g->flags[gid]) { g->flags[gid] = 1; g->num_keys++; }
+    } else if (g->holder == HOLDER_INT_MAP) {
+      int32_t before = g->imap.size;
+      gid = igm_get_group_id(&g->imap, (int32_t)raw, g->global_upper_bound);
+      if (g->imap.size != before) gkg_remember(g, gid, raw);
+    } else {
+      int32_t before = g->lmap.size;
+      gid = lm_get_group_id(&g->lmap, raw, g->global_upper_bound);
+      if (g->lmap.size != before) gkg_remember(g, gid, raw);
+    }
+    out[i] = gid;
+  }
+}
+static int32_t gkg_upper_bound(group_key_gen* g) { /* getCurrentGroupKeyUpperBound */
+  if (g->holder == HOLDER_ARRAY) return g->global_upper_bound;
+  return g->holder == HOLDER_INT_MAP ? g->imap.size : g->lmap.size;
+}
+static int32_t gkg_num_keys(group_key_gen* g) {
+  if (g->holder == HOLDER_ARRAY) return g->num_keys;
+  return g->holder == HOLDER_INT_MAP ? g->imap.size : g->lmap.size;
+}
+
+/* =====================================================================================================================
+ * aggregation functions with their result holders
+ * ===================================================================================================================== */
+typedef struct agg_state {
+  int function;
+  po_column* col;          /* NULL for COUNT(*) */
+  int32_t log2m;
+  int32_t capacity;        /* number of group slots */
+  double* d0;              /* DoubleGroupByResultHolder / sum / min */
+  double* d1;              /* max of MinMaxRangePair */
+  int64_t* l0;             /* AvgPair count */
+  uint8_t* has;            /* ObjectGroupByResultHolder: result != null */
+  po_bitmap** dict_bitmaps;/* DISTINCTCOUNT / HLL over dictionary columns: RoaringBitmap of dictIds */
+  po_hll** hlls;           /* HLL over raw columns */
+} agg_state;
+
+static void agg_ensure_capacity(agg_state* a, int32_t needed) { /* GroupByResultHolder#ensureCapacity */
+  if (needed <= a->capacity) return;
+  int32_t old = a->capacity;
+  int32_t cap = old ? old : 16;
+  while (cap < needed) cap *= 2;
+  a->capacity = cap;
+  double def0 = 0.0, def1 = 0.0;
+  switch (a->function) {
+    case PG_AGG_MIN: def0 = INFINITY; break;                 /* MinAggregationFunction DEFAULT_VALUE */
+    case PG_AGG_MAX: def0 = -INFINITY; break;                /* MaxAggregationFunction.java:37 */
+    default: break;
+  }
+  a->d0 = (double*)po_xrealloc(a->d0, sizeof(double) * (size_t)cap);
+  a->d1 = (double*)po_xrealloc(a->d1, sizeof(double) * (size_t)cap);
+  a->l0 = (int64_t*)po_xrealloc(a->l0, sizeof(int64_t) * (size_t)cap);
+  a->has = (uint8_t*)po_xrealloc(a->has, (size_t)cap);
+  for (int32_t i = old; i < cap; i++) { a->d0[i] = def0; a->d1[i] = def1; a->l0[i] = 0; a->has[i] = 0; }
+  if (a->function == PG_AGG_DISTINCTCOUNT || a->function == PG_AGG_DISTINCTCOUNTHLL) {
+    a->dict_bitmaps = (po_bitmap**)po_xrealloc(a->dict_bitmaps, sizeof(void*) * (size_t)cap);
+    a->hlls = (po_hll**)po_xrealloc(a->hlls, sizeof(void*) * (size_t)cap);
+    for (int32_t i = old; i < cap; i++) { a->dict_bitmaps[i] = NULL; a->hlls[i] = NULL; }
+  }
+}
+
+/* per-block column data = DataBlockCache (core/common/DataBlockCache.java:107-189) */
+typedef struct block_col {
+  po_column* col;
+  int32_t* dict_ids;     /* valid if col->has_dictionary */
+  double* doubles;       /* getDoubleValuesSV */
+  int have_dict_ids, have_doubles;
+} block_col;
+
+static void fetch_dict_ids(block_col* bc, const int32_t* doc_ids, int n) { /* DataFetcher#fetchDictIds */
+  if (bc->have_dict_ids) return;
+  po_fwd_read_dict_ids(bc->col, doc_ids, n, bc->dict_ids);
+  bc->have_dict_ids = 1;
+}
+static void fetch_doubles(block_col* bc, const int32_t* doc_ids, int n) { /* DataFetcher.ColumnValueReader#readDoubleValues :335-386 */
+  if (bc->have_doubles) return;
+  po_column* c = bc->col;
+  if (c->has_dictionary) {
+    fetch_dict_ids(bc, doc_ids, n);
+    for (int i = 0; i < n; i++) bc->doubles[i] = po_dict_get_double(c, bc->dict_ids[i]);
+  } else {
+    switch (c->data_type) {
+      case PG_TYPE_INT: for (int i = 0; i < n; i++) bc->doubles[i] = (double)po_raw_get_int(c, doc_ids[i]); break;
+      case PG_TYPE_LONG: for (int i = 0; i < n; i++) bc->doubles[i] = (double)po_raw_get_long(c, doc_ids[i]); break;
+      case PG_TYPE_FLOAT: for (int i = 0; i < n; i++) bc->doubles[i] = (double)po_raw_get_float(c, doc_ids[i]); break;
+      default: for (int i = 0; i < n; i++) bc->doubles[i] = po_raw_get_double(c, doc_ids[i]); break;
+    }
+  }
+  bc->have_doubles = 1;
+}
+
+static void hll_offer_raw(po_hll* h, po_column* c, int32_t doc_id) {
+  switch (c->data_type) {
+    case PG_TYPE_INT: po_hll_offer_int(h, po_raw_get_int(c, doc_id)); break;
+    case PG_TYPE_LONG: po_hll_offer_long(h, po_raw_get_long(c, doc_id)); break;
+    case PG_TYPE_FLOAT: po_hll_offer_float(h, po_raw_get_float(c, doc_id)); break;
+    default: po_hll_offer_double(h, po_raw_get_double(c, doc_id)); break;
+  }
+}
+
+/* aggregateGroupBySV of each function; group_keys == NULL means the non-group-by `aggregate` (single holder 0).
+ *   COUNT  CountAggregationFunction.java:110-143 (holder += 1 in double)      SUM   SumAggregationFunction.java:160-179
+ *   MIN    MinAggregationFunction.java:163-188 (value < holder)               MAX   MaxAggregationFunction.java:163-188
+ *   AVG    AvgAggregationFunction (AvgPair sum,count)                         MINMAXRANGE MinMaxRangeAggregationFunction
+ *   DISTINCTCOUNT BaseDistinctAggregateAggregationFunction.java:306-345       HLL   DistinctCountHLLAggregationFunction.java:152-222 */
+static void agg_process_block(agg_state* a, block_col* bc, const int32_t* doc_ids, int n, const int32_t* group_keys) {
+  switch (a->function) {
+    case PG_AGG_COUNT:
+      if (!group_keys) { a->d0[0] += n; return; }
+      for (int i = 0; i < n; i++) { int32_t g = group_keys[i]; if (g != PO_INVALID_ID) a->d0[g] += 1; }
+      return;
+    case PG_AGG_SUM: {
+      fetch_doubles(bc, doc_ids, n);
+      if (!group_keys) { /* SumAggregationFunction#aggregate: per-block inner sum, then holder += innerSum */
+        double inner = 0;
+        for (int i = 0; i < n; i++) inner += bc->doubles[i];
+        a->d0[0] = inner + a->d0[0];
+        return;
+      }
+      for (int i = 0; i < n; i++) { int32_t g = group_keys[i]; if (g != PO_INVALID_ID) a->d0[g] = a->d0[g] + bc->doubles[i]; }
+      return;
+    }
+    case PG_AGG_MIN:
+      fetch_doubles(bc, doc_ids, n);
+      for (int i = 0; i < n; i++) {
+        int32_t g = group_keys ? group_keys[i] : 0;
+        if (g != PO_INVALID_ID && bc->doubles[i] < a->d0[g]) a->d0[g] = bc->doubles[i];
+      }
+      return;
+    case PG_AGG_MAX:
+      fetch_doubles(bc, doc_ids, n);
+      for (int i = 0; i < n; i++) {
+        int32_t g = group_keys ? group_keys[i] : 0;
+        if (g != PO_INVALID_ID && bc->doubles[i] > a->d0[g]) a->d0[g] = bc->doubles[i];
+      }
+      return;
+    case PG_AGG_AVG:
+      fetch_doubles(bc, doc_ids, n);
+      if (!group_keys) {
+        double inner = 0;
+        for (int i = 0; i < n; i++) inner += bc->doubles[i];
+        a->d0[0] += inner; a->l0[0] += n; a->has[0] = 1;
+        return;
+      }
+      for (int i = 0; i < n; i++) {
+        int32_t g = group_keys[i];
+        if (g == PO_INVALID_ID) continue;
+        a->d0[g] += bc->doubles[i]; a->l0[g] += 1; a->has[g] = 1;
+      }
+      return;
+    case PG_AGG_MINMAXRANGE:
+      fetch_doubles(bc, doc_ids, n);
+      for (int i = 0; i < n; i++) {
+        int32_t g = group_keys ? group_keys[i] : 0;
+        if (g == PO_INVALID_ID) continue;
+        double v = bc->doubles[i];
+        if (!a->has[g]) { a->d0[g] = v; a->d1[g] = v; a->has[g] = 1; }
+        else { if (v < a->d0[g]) a->d0[g] = v; if (v > a->d1[g]) a->d1[g] = v; }
+      }
+      return;
+    case PG_AGG_DISTINCTCOUNT:
+    case PG_AGG_DISTINCTCOUNTHLL: {
+      po_column* c = a->col;
+      if (c->has_dictionary) {
+        fetch_dict_ids(bc, doc_ids, n);
+        for (int i = 0; i < n; i++) {
+          int32_t g = group_keys ? group_keys[i] : 0;
+          if (g == PO_INVALID_ID) continue;
+          if (!a->dict_bitmaps[g]) a->dict_bitmaps[g] = po_bitmap_new(c->cardinality);
+          po_bitmap_add(a->dict_bitmaps[g], bc->dict_ids[i]);
+        }
+      } else if (a->function == PG_AGG_DISTINCTCOUNTHLL) {
+        for (int i = 0; i < n; i++) {
+          int32_t g = group_keys ? group_keys[i] : 0;
+          if (g == PO_INVALID_ID) continue;
+          if (!a->hlls[g]) a->hlls[g] = po_hll_new(a->log2m);
+          hll_offer_raw(a->hlls[g], c, doc_ids[i]);
+        }
+      }
+      return;
+    }
+    default: return;
+  }
+}
+
+/* DistinctCountHLLAggregationFunction#convertToHyperLogLog :457-466: offer dictionary.get(dictId) for every dictId */
+static po_hll* hll_from_dict_bitmap(const po_bitmap* b, const po_column* c, int32_t log2m) {
+  po_hll* h = po_hll_new(log2m);
+  if (!b) return h;
+  for (int64_t d = po_bitmap_next_set(b, 0); d >= 0 && d < c->cardinality; d = po_bitmap_next_set(b, d + 1)) {
+    switch (c->data_type) {
+      case PG_TYPE_INT: po_hll_offer_int(h, po_dict_get_int(c, (int32_t)d)); break;
+      case PG_TYPE_LONG: po_hll_offer_long(h, po_dict_get_long(c, (int32_t)d)); break;
+      case PG_TYPE_FLOAT: po_hll_offer_float(h, po_dict_get_float(c, (int32_t)d)); break;
+      case PG_TYPE_DOUBLE: po_hll_offer_double(h, po_bef64(c->dict + d * 8)); break;
+      default: {
+        const uint8_t* e = c->dict + d * c->dict_bytes_per_value;
+        int len = c->dict_bytes_per_value;
+        while (len > 0 && e[len - 1] == 0) len--;
+        po_hll_offer_string(h, e, len);
+        break;
+      }
+    }
+  }
+  return h;
+}
+
+/* =====================================================================================================================
+ * results
+ * ===================================================================================================================== */
+typedef struct po_agg_result {
+  int kind;
+  double* d[2];
+  int64_t* l[2];
+  int32_t* set_sizes; int32_t* set_ids; int64_t set_total;
+  uint8_t* hll; int32_t log2m;
+} po_agg_result;
+
+typedef struct po_result_impl {
+  int32_t num_groups, n_group_cols, n_aggs;
+  int32_t** group_dict_ids;
+  po_agg_result* aggs;
+  pg_exec_stats stats;
+} po_result_impl;
+
+static int result_kind(int function) {
+  switch (function) {
+    case PG_AGG_COUNT: return PG_RESULT_LONG;
+    case PG_AGG_AVG: return PG_RESULT_AVG_PAIR;
+    case PG_AGG_MINMAXRANGE: return PG_RESULT_MINMAX_PAIR;
+    case PG_AGG_DISTINCTCOUNT: return PG_RESULT_DICTID_SET;
+    case PG_AGG_DISTINCTCOUNTHLL: return PG_RESULT_HLL;
+    default: return PG_RESULT_DOUBLE;
+  }
+}
+
+static void extract_agg(po_agg_result* r, agg_state* a, int32_t n_groups, const int32_t* gid_of) {
+  r->kind = result_kind(a->function);
+  r->log2m = a->log2m;
+  for (int k = 0; k < 2; k++) {
+    r->d[k] = (double*)po_xcalloc((size_t)n_groups + 1, 8);
+    r->l[k] = (int64_t*)po_xcalloc((size_t)n_groups + 1, 8);
+  }
+  if (r->kind == PG_RESULT_DICTID_SET) {
+    r->set_sizes = (int32_t*)po_xcalloc((size_t)n_groups + 1, 4);
+    int64_t total = 0;
+    for (int32_t i = 0; i < n_groups; i++) {
+      po_bitmap* b = a->dict_bitmaps[gid_of[i]];
+      r->set_sizes[i] = b ? (int32_t)po_bitmap_cardinality(b) : 0;
+      total += r->set_sizes[i];
+    }
+    r->set_total = total;
+    r->set_ids = (int32_t*)po_xcalloc((size_t)total + 1, 4);
+    int64_t k = 0;
+    for (int32_t i = 0; i < n_groups; i++) {
+      po_bitmap* b = a->dict_bitmaps[gid_of[i]];
+      if (!b) continue;
+      for (int64_t d = po_bitmap_next_set(b, 0); d >= 0; d = po_bitmap_next_set(b, d + 1)) r->set_ids[k++] = (int32_t)d;
+    }
+    return;
+  }
+  if (r->kind == PG_RESULT_HLL) {
+    int m = 1 << a->log2m;
+    r->hll = (uint8_t*)po_xcalloc((size_t)n_groups * (size_t)m + 1, 1);
+    for (int32_t i = 0; i < n_groups; i++) {
+      int32_t g = gid_of[i];
+      po_hll* h = a->col->has_dictionary ? hll_from_dict_bitmap(a->dict_bitmaps[g], a->col, a->log2m)
+                                         : (a->hlls[g] ? a->hlls[g] : po_hll_new(a->log2m));
+      memcpy(r->hll + (size_t)i * (size_t)m, h->regs, (size_t)m);
+    }
+    return;
+  }
+  for (int32_t i = 0; i < n_groups; i++) {
+    int32_t g = gid_of[i];
+    switch (a->function) {
+      case PG_AGG_COUNT: r->l[0][i] = (int64_t)a->d0[g]; break;          /* extractGroupByResult: (long) double */
+      case PG_AGG_AVG: r->d[0][i] = a->d0[g]; r->l[0][i] = a->l0[g]; break;
+      case PG_AGG_MINMAXRANGE: r->d[0][i] = a->d0[g]; r->d[1][i] = a->d1[g]; break;
+      default: r->d[0][i] = a->d0[g]; break;
+    }
+  }
+}
+
+/* =====================================================================================================================
+ * query execution: GroupByOperator.getNextBlock (core/operator/query/GroupByOperator.java:100-140),
+ * AggregationOperator.getNextBlock, FastFilteredCountOperator
+ * ===================================================================================================================== */
+static double now_ms(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+int32_t po_query_supported(void* seg, const pg_query* q) { (void)seg; (void)q; return PG_OK; }
+
+int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
+  double t0 = now_ms();
+  po_segment* seg = (po_segment*)segp;
+  int32_t num_groups_limit = q->num_groups_limit > 0 ? q->num_groups_limit : DEFAULT_NUM_GROUPS_LIMIT;
+  int32_t max_init_cap = q->max_initial_result_holder_capacity > 0 ? q->max_initial_result_holder_capacity
+                                                                   : DEFAULT_MAX_INITIAL_RESULT_HOLDER_CAPACITY;
+  int n_aggs = q->n_aggregations, n_gb = q->n_group_by;
+  if (n_aggs <= 0) { po_set_error("query has no aggregation"); return PG_ERR_INVALID_ARGUMENT; }
+
+  po_filter_op* filter_op = po_filter_plan(seg, q->filter);
+  if (!filter_op) return PG_ERR_INVALID_ARGUMENT;
+
+  po_result_impl* res = (po_result_impl*)po_xcalloc(1, sizeof(*res));
+  res->n_aggs = n_aggs;
+  res->n_group_cols = n_gb;
+  res->stats.num_total_docs = seg->total_docs;
+  res->stats.stats_exact = 1;
+
+  /* resolve columns */
+  agg_state* aggs = (agg_state*)po_xcalloc((size_t)n_aggs, sizeof(agg_state));
+  po_column** proj = (po_column**)po_xcalloc((size_t)(n_aggs + n_gb) + 1, sizeof(po_column*));
+  int n_proj = 0;
+  for (int i = 0; i < n_aggs; i++) {
+    const pg_agg_spec* s = &q->aggregations[i];
+    aggs[i].function = s->function;
+    aggs[i].log2m = s->log2m > 0 ? s->log2m : DEFAULT_LOG2M;
+    if (s->function == PG_AGG_COUNT) continue;   /* COUNT(*) takes no input expression */
+    po_column* c = po_segment_column(seg, s->column);
+    if (!c) { po_set_error("column not found: %s", s->column ? s->column : "(null)"); return PG_ERR_NOT_FOUND; }
+    if ((s->function == PG_AGG_DISTINCTCOUNT) && !c->has_dictionary) {
+      po_set_error("DISTINCTCOUNT over a raw column is outside the hot path");
+      return PG_ERR_UNSUPPORTED;
+    }
+    aggs[i].col = c;
+    int seen = 0;
+    for (int k = 0; k < n_proj; k++) seen |= (proj[k] == c);
+    if (!seen) proj[n_proj++] = c;
+  }
+  po_column** gcols = (po_column**)po_xcalloc((size_t)n_gb + 1, sizeof(po_column*));
+  for (int j = 0; j < n_gb; j++) {
+    po_column* c = po_segment_column(seg, q->group_by_columns[j]);
+    if (!c) { po_set_error("column not found: %s", q->group_by_columns[j]); return PG_ERR_NOT_FOUND; }
+    if (!c->has_dictionary) { po_set_error("no-dictionary group-by column %s is outside the hot path", c->name); return PG_ERR_UNSUPPORTED; }
+    gcols[j] = c;
+    int seen = 0;
+    for (int k = 0; k < n_proj; k++) seen |= (proj[k] == c);
+    if (!seen) proj[n_proj++] = c;
+  }
+
+  /* AggregationPlanNode: FastFilteredCountOperator (core/plan/AggregationPlanNode.java:106-108,192-196) */
+  if (n_gb == 0 && n_aggs == 1 && aggs[0].function == PG_AGG_COUNT && po_filter_can_optimize_count(filter_op)) {
+    int32_t count = po_filter_num_matching_docs(filter_op);
+    if (count < 0) return PG_ERR_INVALID_ARGUMENT;
+    res->num_groups = 1;
+    res->aggs = (po_agg_result*)po_xcalloc(1, sizeof(po_agg_result));
+    res->aggs[0].kind = PG_RESULT_LONG;
+    for (int k = 0; k < 2; k++) { res->aggs[0].d[k] = (double*)po_xcalloc(2, 8); res->aggs[0].l[k] = (int64_t*)po_xcalloc(2, 8); }
+    res->aggs[0].l[0][0] = count;
+    res->stats.num_docs_scanned = count;   /* FastFilteredCountOperator#getExecutionStatistics */
+    res->stats.host_ms_total = (float)(now_ms() - t0);
+    *out = res;
+    return PG_OK;
+  }
+
+  /* group key generator + holders (DefaultGroupByExecutor ctor, groupby/DefaultGroupByExecutor.java:79-140) */
+  group_key_gen gkg;
+  if (n_gb > 0) {
+    if (gkg_init(&gkg, n_gb, gcols, num_groups_limit, max_init_cap)) return PG_ERR_UNSUPPORTED;
+    int32_t max_results = gkg.global_upper_bound;
+    int32_t initial = max_results < max_init_cap ? max_results : max_init_cap;
+    for (int i = 0; i < n_aggs; i++) agg_ensure_capacity(&aggs[i], initial > 0 ? initial : 1);
+  } else {
+    for (int i = 0; i < n_aggs; i++) agg_ensure_capacity(&aggs[i], 1);
+  }
+
+  /* DocIdSetOperator + ProjectionOperator loop */
+  po_docidset* set = po_filter_get_trues(filter_op);
+  if (!set) return PG_ERR_INVALID_ARGUMENT;
+  po_iter* it = set->iterator(set);
+  int32_t* doc_ids = (int32_t*)po_xmalloc(sizeof(int32_t) * PO_MAX_DOC_PER_CALL);
+  int32_t* group_keys = (int32_t*)po_xmalloc(sizeof(int32_t) * PO_MAX_DOC_PER_CALL);
+  block_col* bcols = (block_col*)po_xcalloc((size_t)n_proj + 1, sizeof(block_col));
+  for (int k = 0; k < n_proj; k++) {
+    bcols[k].col = proj[k];
+    bcols[k].dict_ids = (int32_t*)po_xmalloc(sizeof(int32_t) * PO_MAX_DOC_PER_CALL);
+    bcols[k].doubles = (double*)po_xmalloc(sizeof(double) * PO_MAX_DOC_PER_CALL);
+  }
+  int32_t** gdict = (int32_t**)po_xcalloc((size_t)n_gb + 1, sizeof(int32_t*));
+  int64_t num_docs_scanned = 0;
+  int32_t cur = 0;
+  while (cur != PO_EOF) {
+    int pos = 0;
+    for (int i = 0; i < PO_MAX_DOC_PER_CALL; i++) {  /* DocIdSetOperator.getNextBlock :74-80 */
+      cur = it->next(it);
+      if (cur == PO_EOF) break;
+      doc_ids[pos++] = cur;
+    }
+    if (pos == 0) break;
+    num_docs_scanned += pos;
+    for (int k = 0; k < n_proj; k++) bcols[k].have_dict_ids = bcols[k].have_doubles = 0;
+    const int32_t* keys = NULL;
+    if (n_gb > 0) {
+      for (int j = 0; j < n_gb; j++) {
+        for (int k = 0; k < n_proj; k++)
+          if (bcols[k].col == gcols[j]) { fetch_dict_ids(&bcols[k], doc_ids, pos); gdict[j] = bcols[k].dict_ids; }
+      }
+      gkg_generate(&gkg, pos, gdict, group_keys);
+      keys = group_keys;
+      int32_t needed = gkg_upper_bound(&gkg);
+      for (int i = 0; i < n_aggs; i++) agg_ensure_capacity(&aggs[i], needed);
+    }
+    for (int i = 0; i < n_aggs; i++) {
+      block_col* bc = NULL;
+      for (int k = 0; k < n_proj; k++) if (bcols[k].col == aggs[i].col) bc = &bcols[k];
+      agg_process_block(&aggs[i], bc, doc_ids, pos, keys);
+    }
+  }
+
+  /* results */
+  int32_t n_groups;
+  int32_t* gid_of;
+  if (n_gb == 0) {
+    n_groups = 1;
+    gid_of = (int32_t*)po_xcalloc(1, 4);
+  } else if (gkg.holder == HOLDER_ARRAY) {
+    n_groups = gkg.num_keys;
+    gid_of = (int32_t*)po_xcalloc((size_t)n_groups + 1, 4);
+    int32_t k = 0;
+    for (int32_t g = 0; g < gkg.global_upper_bound; g++) if (gkg.flags[g]) gid_of[k++] = g;
+  } else {
+    n_groups = gkg_num_keys(&gkg);
+    gid_of = (int32_t*)po_xcalloc((size_t)n_groups + 1, 4);
+    for (int32_t g = 0; g < n_groups; g++) gid_of[g] = g;
+  }
+  res->num_groups = n_groups;
+  res->group_dict_ids = (int32_t**)po_xcalloc((size_t)n_gb + 1, sizeof(int32_t*));
+  for (int j = 0; j < n_gb; j++) res->group_dict_ids[j] = (int32_t*)po_xcalloc((size_t)n_groups + 1, 4);
+  for (int32_t i = 0; i < n_groups && n_gb > 0; i++) {  /* getKeys :578-591: col 0 is least significant */
+    int64_t raw = (gkg.holder == HOLDER_ARRAY) ? gid_of[i] : gkg.raw_key_of_group[gid_of[i]];
+    for (int j = 0; j < n_gb; j++) {
+      res->group_dict_ids[j][i] = (int32_t)(raw % gkg.cardinalities[j]);
+      raw /= gkg.cardinalities[j];
+    }
+  }
+  res->aggs = (po_agg_result*)po_xcalloc((size_t)n_aggs, sizeof(po_agg_result));
+  for (int i = 0; i < n_aggs; i++) {
+    if (n_gb > 0) agg_ensure_capacity(&aggs[i], (gkg.holder == HOLDER_ARRAY ? gkg.global_upper_bound : n_groups) + 1);
+    extract_agg(&res->aggs[i], &aggs[i], n_groups, gid_of);
+  }
+  res->stats.num_docs_scanned = num_docs_scanned;
+  res->stats.num_entries_scanned_in_filter = set->num_entries_scanned(set);
+  res->stats.num_entries_scanned_post_filter = num_docs_scanned * n_proj;
+  if (n_gb > 0) res->stats.num_groups_limit_reached = gkg_num_keys(&gkg) >= num_groups_limit;
+  res->stats.host_ms_total = (float)(now_ms() - t0);
+  *out = res;
+  return PG_OK;
+}
+
+/* ---- accessors ------------------------------------------------------------------------------------------------------------- */
+#define RES(r) ((po_result_impl*)(r))
+static int bad_agg(void* r, int32_t agg) {
+  if (agg < 0 || agg >= RES(r)->n_aggs) { po_set_error("aggregation index out of range"); return 1; }
+  return 0;
+}
+int32_t po_result_num_groups(void* r, int32_t* out) { *out = RES(r)->num_groups; return PG_OK; }
+int32_t po_result_group_dict_ids(void* r, int32_t col, int32_t* out, int32_t cap) {
+  if (col < 0 || col >= RES(r)->n_group_cols || cap < RES(r)->num_groups) { po_set_error("bad column/capacity"); return PG_ERR_INVALID_ARGUMENT; }
+  memcpy(out, RES(r)->group_dict_ids[col], sizeof(int32_t) * (size_t)RES(r)->num_groups);
+  return PG_OK;
+}
+int32_t po_result_kind_of(void* r, int32_t agg, int32_t* out) {
+  if (bad_agg(r, agg)) return PG_ERR_INVALID_ARGUMENT;
+  *out = RES(r)->aggs[agg].kind;
+  return PG_OK;
+}
+int32_t po_result_doubles(void* r, int32_t agg, int32_t comp, double* out, int32_t cap) {
+  if (bad_agg(r, agg) || comp < 0 || comp > 1 || cap < RES(r)->num_groups) return PG_ERR_INVALID_ARGUMENT;
+  memcpy(out, RES(r)->aggs[agg].d[comp], sizeof(double) * (size_t)RES(r)->num_groups);
+  return PG_OK;
+}
+int32_t po_result_longs(void* r, int32_t agg, int32_t comp, int64_t* out, int32_t cap) {
+  if (bad_agg(r, agg) || comp < 0 || comp > 1 || cap < RES(r)->num_groups) return PG_ERR_INVALID_ARGUMENT;
+  memcpy(out, RES(r)->aggs[agg].l[comp], sizeof(int64_t) * (size_t)RES(r)->num_groups);
+  return PG_OK;
+}
+int32_t po_result_set_sizes(void* r, int32_t agg, int32_t* out, int32_t cap) {
+  if (bad_agg(r, agg) || RES(r)->aggs[agg].kind != PG_RESULT_DICTID_SET || cap < RES(r)->num_groups) return PG_ERR_INVALID_ARGUMENT;
+  memcpy(out, RES(r)->aggs[agg].set_sizes, sizeof(int32_t) * (size_t)RES(r)->num_groups);
+  return PG_OK;
+}
+int32_t po_result_set_dict_ids(void* r, int32_t agg, int32_t* out, int64_t cap) {
+  if (bad_agg(r, agg) || RES(r)->aggs[agg].kind != PG_RESULT_DICTID_SET || cap < RES(r)->aggs[agg].set_total) return PG_ERR_INVALID_ARGUMENT;
+  memcpy(out, RES(r)->aggs[agg].set_ids, sizeof(int32_t) * (size_t)RES(r)->aggs[agg].set_total);
+  return PG_OK;
+}
+int32_t po_result_hll_registers(void* r, int32_t agg, uint8_t* out, int64_t cap) {
+  if (bad_agg(r, agg) || RES(r)->aggs[agg].kind != PG_RESULT_HLL) return PG_ERR_INVALID_ARGUMENT;
+  int64_t n = (int64_t)RES(r)->num_groups << RES(r)->aggs[agg].log2m;
+  if (cap < n) return PG_ERR_INVALID_ARGUMENT;
+  memcpy(out, RES(r)->aggs[agg].hll, (size_t)n);
+  return PG_OK;
+}
+int32_t po_result_stats(void* r, pg_exec_stats* out) { *out = RES(r)->stats; return PG_OK; }
+int32_t po_result_free(void* r) {
+  po_result_impl* res = RES(r);
+  for (int i = 0; i < res->n_aggs && res->aggs; i++) {
+    for (int k = 0; k < 2; k++) { free(res->aggs[i].d[k]); free(res->aggs[i].l[k]); }
+    free(res->aggs[i].set_sizes); free(res->aggs[i].set_ids); free(res->aggs[i].hll);
+  }
+  free(res->aggs);
+  for (int j = 0; j < res->n_group_cols && res->group_dict_ids; j++) free(res->group_dict_ids[j]);
+  free(res->group_dict_ids);
+  free(res);
+  return PG_OK;
+}
+
+/* ---- small helpers exported for the golden tests ---------------------------------------------------------------------------- */
+int64_t po_hll_cardinality_from_registers(const uint8_t* regs, int32_t log2m) {
+  po_hll h;
+  h.log2m = log2m;
+  h.m = 1 << log2m;
+  h.regs = (uint8_t*)regs;
+  return po_hll_cardinality(&h);
+}
+void po_hll_registers_for_values(const int64_t* values, int64_t n, int32_t as_int, int32_t log2m, uint8_t* out_regs) {
+  po_hll* h = po_hll_new(log2m);
+  for (int64_t i = 0; i < n; i++) {
+    if (as_int) po_hll_offer_int(h, (int32_t)values[i]); else po_hll_offer_long(h, values[i]);
+  }
+  memcpy(out_regs, h->regs, (size_t)h->m);
+  po_hll_free(h);
+}
+int32_t po_read_fixed_bit(const uint8_t* buf, int32_t bits, int32_t index) {
+  po_column c;
+  memset(&c, 0, sizeof(c));
+  c.fwd = buf;
+  c.bits_per_value = bits;
+  return po_fixedbit_read(&c, index);
+}
+void po_read_fixed_bit_block(const uint8_t* buf, int32_t bits, const int32_t* doc_ids, int32_t n, int32_t* out) {
+  po_column c;
+  memset(&c, 0, sizeof(c));
+  c.fwd = buf;
+  c.bits_per_value = bits;
+  c.fwd_encoding = PG_FWD_DICT_FIXED_BIT;
+  po_fwd_read_dict_ids(&c, doc_ids, n, out);
+}

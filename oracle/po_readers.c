@@ -1,0 +1,321 @@
+/*
+ * CPU ORACLE — TEST INFRASTRUCTURE ONLY (see po_internal.h).
+ * Storage readers of the hot path: SURVEY.md §8a rows a5, a12, a13, a14 and the sorted index.
+ */
+#include <errno.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "po_internal.h"
+
+/* ---- error / alloc helpers ------------------------------------------------------------------------------------------ */
+static __thread char g_err[4096];
+
+void po_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* po_get_error(void) { return g_err; }
+
+void* po_xmalloc(size_t n) {
+  void* p = malloc(n ? n : 1);
+  if (!p) abort();
+  return p;
+}
+void* po_xcalloc(size_t n, size_t sz) {
+  void* p = calloc(n ? n : 1, sz ? sz : 1);
+  if (!p) abort();
+  return p;
+}
+void* po_xrealloc(void* p, size_t n) {
+  void* q = realloc(p, n ? n : 1);
+  if (!q) abort();
+  return q;
+}
+
+/* ---- FixedBitIntReader ------------------------------------------------------------------------------------------------
+ * pinot-segment-local/.../io/reader/impl/FixedBitIntReader.java:27-119 dispatches to one unrolled class per bit width
+ * (e.g. Bit5Reader :375-420); all of them are specialisations of the generic MSB-first read in
+ * pinot-segment-local/.../io/util/PinotDataBitSet.java:74-97 (readInt), restated here once. */
+int32_t po_fixedbit_read(const po_column* c, int32_t index) {
+  int bits = c->bits_per_value;
+  int64_t bit_offset = (int64_t)index * bits;
+  int64_t byte_offset = bit_offset >> 3;
+  int bit_in_first = (int)(bit_offset & 7);
+  const uint8_t* p = c->fwd;
+  int32_t cur = p[byte_offset] & (0xff >> bit_in_first);
+  int left = bits - (8 - bit_in_first);
+  if (left <= 0) return cur >> -left;
+  while (left > 8) {
+    byte_offset++;
+    cur = (cur << 8) | p[byte_offset];
+    left -= 8;
+  }
+  return (cur << left) | (p[byte_offset + 1] >> (8 - left));
+}
+
+/* FixedBitIntReader.BitNReader#read32: 32 values from `bits` big-endian ints starting at index (multiple of 32). */
+static void fixedbit_read32(const po_column* c, int32_t index, int32_t* out) {
+  int bits = c->bits_per_value;
+  const uint8_t* p = c->fwd + ((int64_t)(index >> 3)) * bits;
+  uint32_t mask = (bits == 32) ? 0xFFFFFFFFu : ((1u << bits) - 1u);
+  uint64_t acc = 0;   /* bit accumulator, MSB first */
+  int have = 0;
+  int w = 0;
+  for (int i = 0; i < 32; i++) {
+    while (have < bits) {
+      acc = (acc << 32) | po_be32(p + 4 * w);
+      w++;
+      have += 32;
+    }
+    out[i] = (int32_t)((acc >> (have - bits)) & mask);
+    have -= bits;
+    acc &= (have == 0) ? 0 : ((1ULL << have) - 1);
+  }
+}
+
+/* FixedBitSVForwardIndexReaderV2#readDictIds, pinot-segment-local/.../readers/forward/FixedBitSVForwardIndexReaderV2.java:65-99
+ * (bulk read32 for runs of >= 64 sequential docIds; the checked/unchecked split only guards buffer ends and returns
+ * the same values, so both map onto po_fixedbit_read). */
+void po_fwd_read_dict_ids(const po_column* c, const int32_t* doc_ids, int32_t length, int32_t* out) {
+  if (length <= 0) return;
+  if (c->fwd_encoding == PG_FWD_DICT_SORTED) {
+    /* SortedIndexReaderImpl#readDictIds: per-doc binary search with a moving context */
+    for (int i = 0; i < length; i++) out[i] = po_sorted_get_dict_id(c, doc_ids[i]);
+    return;
+  }
+  int32_t first = doc_ids[0], last = doc_ids[length - 1];
+  int index = 0;
+  if (last - first + 1 == length && length >= 64) {
+    int32_t bulk_start = (first + 31) & (int32_t)0xffffffe0;
+    int32_t bulk_end = last & (int32_t)0xffffffe0;
+    for (int32_t i = first; i < bulk_start; i++) out[index++] = po_fixedbit_read(c, i);
+    for (int32_t i = bulk_start; i < bulk_end; i += 32) {
+      fixedbit_read32(c, i, out + index);
+      index += 32;
+    }
+  }
+  for (int i = index; i < length; i++) out[i] = po_fixedbit_read(c, doc_ids[i]);
+}
+
+/* ---- FixedByteChunkSVForwardIndexReader (PASS_THROUGH) ---------------------------------------------------------------
+ * header parse: BaseChunkForwardIndexReader.java:61-111; value access: FixedByteChunkSVForwardIndexReader.java:53-94
+ * (`_rawData.getInt(docId * Integer.BYTES)`; the reference multiplies in int, so it wraps for docId >= 2^29 — the
+ * oracle uses 64-bit offsets, i.e. restates the intent, and tests stay below that bound). */
+int po_raw_parse_header(po_column* c) {
+  const uint8_t* b = c->fwd;
+  if (c->fwd_len < 16) {
+    po_set_error("raw forward index of %s too short", c->name);
+    return -1;
+  }
+  int32_t version = (int32_t)po_be32(b);
+  c->raw_version = version;
+  c->raw_num_chunks = (int32_t)po_be32(b + 4);
+  c->raw_docs_per_chunk = (int32_t)po_be32(b + 8);
+  c->raw_entry_len = (int32_t)po_be32(b + 12);
+  int32_t data_header_start = 16;
+  if (version > 1) {
+    c->raw_compression = (int32_t)po_be32(b + 20);
+    data_header_start = (int32_t)po_be32(b + 24);
+  } else {
+    c->raw_compression = 1; /* SNAPPY */
+  }
+  if (c->raw_compression != 0) {
+    po_set_error("column %s: compressed raw chunks (type %d) are outside the hot path", c->name, c->raw_compression);
+    return -1;
+  }
+  int off_size = version <= 2 ? 4 : 8;
+  int64_t raw_start = (int64_t)data_header_start + (int64_t)c->raw_num_chunks * off_size;
+  c->raw_data = b + raw_start;
+  return 0;
+}
+int32_t po_raw_get_int(const po_column* c, int32_t d) { return (int32_t)po_be32(c->raw_data + (int64_t)d * 4); }
+int64_t po_raw_get_long(const po_column* c, int32_t d) { return (int64_t)po_be64(c->raw_data + (int64_t)d * 8); }
+float po_raw_get_float(const po_column* c, int32_t d) { return po_bef32(c->raw_data + (int64_t)d * 4); }
+double po_raw_get_double(const po_column* c, int32_t d) { return po_bef64(c->raw_data + (int64_t)d * 8); }
+
+/* ---- SortedIndexReaderImpl, pinot-segment-local/.../readers/sorted/SortedIndexReaderImpl.java:35-110 ----------------- */
+void po_sorted_get_doc_ids(const po_column* c, int32_t dict_id, int32_t* start, int32_t* end) {
+  *start = (int32_t)po_be32(c->fwd + (int64_t)dict_id * 8);
+  *end = (int32_t)po_be32(c->fwd + (int64_t)dict_id * 8 + 4);
+}
+int32_t po_sorted_get_dict_id(const po_column* c, int32_t doc_id) {
+  int32_t lo = 0, hi = c->cardinality - 1;
+  while (lo <= hi) {
+    int32_t mid = (int32_t)(((uint32_t)lo + (uint32_t)hi) >> 1);
+    int32_t s, e;
+    po_sorted_get_doc_ids(c, mid, &s, &e);
+    if (e < doc_id) lo = mid + 1;
+    else if (s > doc_id) hi = mid - 1;
+    else return mid;
+  }
+  return -1;
+}
+
+/* ---- dictionaries: BaseImmutableDictionary.java:124-245, IntDictionary.java:28-80 & siblings -------------------------- */
+int32_t po_dict_get_int(const po_column* c, int32_t id) { return (int32_t)po_be32(c->dict + (int64_t)id * 4); }
+int64_t po_dict_get_long(const po_column* c, int32_t id) { return (int64_t)po_be64(c->dict + (int64_t)id * 8); }
+float po_dict_get_float(const po_column* c, int32_t id) { return po_bef32(c->dict + (int64_t)id * 4); }
+static double dict_raw_double(const po_column* c, int32_t id) { return po_bef64(c->dict + (int64_t)id * 8); }
+
+/* Dictionary#getDoubleValue: (double) of the stored value (IntDictionary.java: getDoubleValue = getInt(dictId)). */
+double po_dict_get_double(const po_column* c, int32_t id) {
+  switch (c->data_type) {
+    case PG_TYPE_INT: return (double)po_dict_get_int(c, id);
+    case PG_TYPE_LONG: return (double)po_dict_get_long(c, id);
+    case PG_TYPE_FLOAT: return (double)po_dict_get_float(c, id);
+    case PG_TYPE_DOUBLE: return dict_raw_double(c, id);
+    default: {
+      /* StringDictionary#getDoubleValue = Double.parseDouble(unpadded string) */
+      char buf[512];
+      int w = c->dict_bytes_per_value;
+      int n = w < 511 ? w : 511;
+      memcpy(buf, c->dict + (int64_t)id * w, (size_t)n);
+      buf[n] = 0;
+      return strtod(buf, NULL);
+    }
+  }
+}
+
+static int parse_i64(const char* s, int64_t lo, int64_t hi, int64_t* out) {
+  /* Integer.parseInt / Long.parseLong: optional sign, decimal digits only, range checked */
+  if (!s || !*s) return -1;
+  errno = 0;
+  char* end = NULL;
+  long long v = strtoll(s, &end, 10);
+  if (errno || *end != 0 || end == s) return -1;
+  for (const char* p = s; *p; p++)
+    if (!((*p >= '0' && *p <= '9') || ((p == s) && (*p == '-' || *p == '+')))) return -1;
+  if (v < lo || v > hi) return -1;
+  *out = v;
+  return 0;
+}
+int po_parse_int(const char* s, int32_t* out) {
+  int64_t v;
+  if (parse_i64(s, INT32_MIN, INT32_MAX, &v)) {
+    po_set_error("NumberFormatException: For input string: \"%s\"", s ? s : "null");
+    return -1;
+  }
+  *out = (int32_t)v;
+  return 0;
+}
+int po_parse_long(const char* s, int64_t* out) {
+  if (parse_i64(s, INT64_MIN, INT64_MAX, out)) {
+    po_set_error("NumberFormatException: For input string: \"%s\"", s ? s : "null");
+    return -1;
+  }
+  return 0;
+}
+int po_parse_double(const char* s, double* out) {
+  if (!s || !*s) goto bad;
+  {
+    char* end = NULL;
+    errno = 0;
+    double v = strtod(s, &end);
+    if (end == s || *end != 0) goto bad;
+    *out = v;
+    return 0;
+  }
+bad:
+  po_set_error("NumberFormatException: For input string: \"%s\"", s ? s : "null");
+  return -1;
+}
+int po_parse_float(const char* s, float* out) {
+  if (!s || !*s) goto bad;
+  {
+    char* end = NULL;
+    float v = strtof(s, &end);
+    if (end == s || *end != 0) goto bad;
+    *out = v;
+    return 0;
+  }
+bad:
+  po_set_error("NumberFormatException: For input string: \"%s\"", s ? s : "null");
+  return -1;
+}
+
+/* ValueReaderComparisons.compareUtf8Bytes with padded entries: compare the unpadded stored value with `s` (byte order
+ * equals code-point order for the BMP/ASCII values the tests use). */
+static int compare_padded_string(const uint8_t* entry, int width, const uint8_t* s, int slen) {
+  int elen = width;
+  while (elen > 0 && entry[elen - 1] == 0) elen--;
+  int n = elen < slen ? elen : slen;
+  for (int i = 0; i < n; i++)
+    if (entry[i] != s[i]) return entry[i] < s[i] ? -1 : 1;
+  return elen == slen ? 0 : (elen < slen ? -1 : 1);
+}
+
+int32_t po_dict_insertion_index_of(const po_column* c, const char* sv) {
+  int32_t low = 0, high = c->cardinality - 1;
+  switch (c->data_type) {
+    case PG_TYPE_INT: {
+      int32_t v;
+      if (po_parse_int(sv, &v)) return INT32_MIN;
+      while (low <= high) {
+        int32_t mid = (int32_t)(((uint32_t)low + (uint32_t)high) >> 1);
+        int32_t mv = po_dict_get_int(c, mid);
+        if (mv < v) low = mid + 1; else if (mv > v) high = mid - 1; else return mid;
+      }
+      return -(low + 1);
+    }
+    case PG_TYPE_LONG: {
+      int64_t v;
+      if (po_parse_long(sv, &v)) return INT32_MIN;
+      while (low <= high) {
+        int32_t mid = (int32_t)(((uint32_t)low + (uint32_t)high) >> 1);
+        int64_t mv = po_dict_get_long(c, mid);
+        if (mv < v) low = mid + 1; else if (mv > v) high = mid - 1; else return mid;
+      }
+      return -(low + 1);
+    }
+    case PG_TYPE_FLOAT: {
+      float v;
+      if (po_parse_float(sv, &v)) return INT32_MIN;
+      while (low <= high) {
+        int32_t mid = (int32_t)(((uint32_t)low + (uint32_t)high) >> 1);
+        float mv = po_dict_get_float(c, mid);
+        if (mv < v) low = mid + 1; else if (mv > v) high = mid - 1; else return mid;
+      }
+      return -(low + 1);
+    }
+    case PG_TYPE_DOUBLE: {
+      double v;
+      if (po_parse_double(sv, &v)) return INT32_MIN;
+      while (low <= high) {
+        int32_t mid = (int32_t)(((uint32_t)low + (uint32_t)high) >> 1);
+        double mv = dict_raw_double(c, mid);
+        if (mv < v) low = mid + 1; else if (mv > v) high = mid - 1; else return mid;
+      }
+      return -(low + 1);
+    }
+    default: {
+      int slen = (int)strlen(sv);
+      int w = c->dict_bytes_per_value;
+      while (low <= high) {
+        int32_t mid = (int32_t)(((uint32_t)low + (uint32_t)high) >> 1);
+        int cmp = compare_padded_string(c->dict + (int64_t)mid * w, w, (const uint8_t*)sv, slen);
+        if (cmp < 0) low = mid + 1; else if (cmp > 0) high = mid - 1; else return mid;
+      }
+      return -(low + 1);
+    }
+  }
+}
+
+/* ---- BitmapInvertedIndexReader#getDocIds, pinot-segment-local/.../readers/BitmapInvertedIndexReader.java:45-62 -------- */
+int po_inv_get_doc_ids_or(const po_column* c, int32_t dict_id, po_bitmap* dst) {
+  if (c->fwd_encoding == PG_FWD_DICT_SORTED) {
+    int32_t s, e;
+    po_sorted_get_doc_ids(c, dict_id, &s, &e);
+    po_bitmap_add_range(dst, s, (int64_t)e + 1);
+    return 0;
+  }
+  uint64_t off_end = ((uint64_t)c->cardinality + 1) * 4;
+  uint64_t first = po_be32(c->inv);                                    /* _firstOffset */
+  uint64_t off = po_be32(c->inv + (uint64_t)dict_id * 4);
+  uint64_t len = po_be32(c->inv + (uint64_t)(dict_id + 1) * 4) - off;
+  const uint8_t* bitmap_buffer = c->inv + off_end;                     /* _bitmapBuffer */
+  return po_roaring_deserialize_or(bitmap_buffer + (off - first), len, dst);
+}

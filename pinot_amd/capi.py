@@ -1,0 +1,214 @@
+"""ctypes mirror of include/pinot_gpu.h.
+
+`NativeApi(lib, prefix)` binds either the product library (libpinot_gpu.so, prefix "pg_") or — in tests only — the CPU
+oracle (oracle/_build/liboracle.so, prefix "po_"), which exports the same entry points over the same structs so that
+parity tests feed both sides byte-identical segments and queries.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+PG_ABI_VERSION = 1
+
+# pg_status
+PG_OK = 0
+PG_ERR_INVALID_ARGUMENT = -1
+PG_ERR_UNSUPPORTED = -2
+PG_ERR_DEVICE = -3
+PG_ERR_OUT_OF_MEMORY = -4
+PG_ERR_NOT_FOUND = -5
+PG_ERR_CANCELLED = -6
+PG_ERR_INTERNAL = -7
+
+DATA_TYPES = {"INT": 0, "LONG": 1, "FLOAT": 2, "DOUBLE": 3, "STRING": 4, "BYTES": 5}
+FWD_DICT_FIXED_BIT = 0
+FWD_RAW_FIXED_BYTE_CHUNK = 1
+FWD_DICT_SORTED = 2
+
+FILTER_AND, FILTER_OR, FILTER_NOT, FILTER_PREDICATE, FILTER_CONSTANT_TRUE, FILTER_CONSTANT_FALSE = range(6)
+PRED_EQ, PRED_NOT_EQ, PRED_IN, PRED_NOT_IN, PRED_RANGE = range(5)
+AGG_FUNCTIONS = {"COUNT": 0, "SUM": 1, "MIN": 2, "MAX": 3, "AVG": 4, "DISTINCTCOUNT": 5, "DISTINCTCOUNTHLL": 6,
+                 "MINMAXRANGE": 7}
+RESULT_LONG, RESULT_DOUBLE, RESULT_AVG_PAIR, RESULT_MINMAX_PAIR, RESULT_DICTID_SET, RESULT_HLL = range(6)
+
+QUERY_FLAG_PROFILE = 0x1
+
+
+class PgBuffer(C.Structure):
+    _fields_ = [("addr", C.c_void_p), ("size", C.c_uint64)]
+
+
+class PgColumnDesc(C.Structure):
+    _fields_ = [
+        ("name", C.c_char_p),
+        ("data_type", C.c_int32),
+        ("fwd_encoding", C.c_int32),
+        ("has_dictionary", C.c_int32),
+        ("cardinality", C.c_int32),
+        ("bits_per_value", C.c_int32),
+        ("is_sorted", C.c_int32),
+        ("dict_bytes_per_value", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("forward_index", PgBuffer),
+        ("dictionary", PgBuffer),
+        ("inverted_index", PgBuffer),
+    ]
+
+
+class PgFilterNode(C.Structure):
+    pass
+
+
+PgFilterNode._fields_ = [
+    ("type", C.c_int32),
+    ("n_children", C.c_int32),
+    ("children", C.POINTER(PgFilterNode)),
+    ("predicate_type", C.c_int32),
+    ("n_values", C.c_int32),
+    ("column", C.c_char_p),
+    ("values", C.POINTER(C.c_char_p)),
+    ("lower", C.c_char_p),
+    ("upper", C.c_char_p),
+    ("lower_inclusive", C.c_int32),
+    ("upper_inclusive", C.c_int32),
+]
+
+
+class PgAggSpec(C.Structure):
+    _fields_ = [("function", C.c_int32), ("log2m", C.c_int32), ("column", C.c_char_p)]
+
+
+class PgQuery(C.Structure):
+    _fields_ = [
+        ("filter", C.POINTER(PgFilterNode)),
+        ("n_group_by", C.c_int32),
+        ("n_aggregations", C.c_int32),
+        ("group_by_columns", C.POINTER(C.c_char_p)),
+        ("aggregations", C.POINTER(PgAggSpec)),
+        ("num_groups_limit", C.c_int32),
+        ("max_initial_result_holder_capacity", C.c_int32),
+        ("flags", C.c_int32),
+        ("reserved0", C.c_int32),
+    ]
+
+
+class PgExecStats(C.Structure):
+    _fields_ = [
+        ("num_docs_scanned", C.c_int64),
+        ("num_entries_scanned_in_filter", C.c_int64),
+        ("num_entries_scanned_post_filter", C.c_int64),
+        ("num_total_docs", C.c_int64),
+        ("num_groups_limit_reached", C.c_int32),
+        ("stats_exact", C.c_int32),
+        ("device_ms_total", C.c_float),
+        ("device_ms_filter", C.c_float),
+        ("device_ms_aggregate", C.c_float),
+        ("device_ms_reduce", C.c_float),
+        ("host_ms_plan", C.c_float),
+        ("host_ms_total", C.c_float),
+        ("algorithmic_bytes", C.c_int64),
+    ]
+
+    def as_dict(self) -> dict:
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class NativeError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"[{status}] {message}")
+        self.status = status
+        self.message = message
+
+
+REPO_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GPU_LIB_PATH = os.path.join(REPO_ROOT, "pinot_amd", "csrc", "libpinot_gpu.so")
+
+# every symbol include/pinot_gpu.h declares (checked by the "not gpu" suite against the built library)
+ABI_SYMBOLS = [
+    "abi_version", "init", "device_count", "last_error",
+    "segment_create", "segment_add_column", "segment_num_docs", "segment_device_bytes", "segment_destroy",
+    "filter_exec", "docidset_cardinality", "docidset_num_words", "docidset_copy_words", "docidset_copy_docids",
+    "docidset_stats", "docidset_free",
+    "query_supported", "query_exec",
+    "result_num_groups", "result_group_dict_ids", "result_kind_of", "result_doubles", "result_longs",
+    "result_set_sizes", "result_set_dict_ids", "result_hll_registers", "result_stats", "result_free",
+]
+
+
+class NativeApi:
+    """Thin typed wrapper over a shared library exporting the pinot_gpu.h entry points under `prefix`."""
+
+    def __init__(self, path: str, prefix: str = "pg_"):
+        self.path = path
+        self.prefix = prefix
+        self.lib = C.CDLL(path, mode=C.RTLD_GLOBAL if prefix == "pg_" else C.RTLD_LOCAL)
+        for sym in ABI_SYMBOLS:
+            fn = getattr(self.lib, prefix + sym)  # AttributeError => missing export
+            fn.restype = C.c_int32
+        self.f("last_error").argtypes = [C.c_char_p, C.c_size_t]
+        self.f("init").argtypes = [C.c_int32]
+        self.f("segment_create").argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]
+        self.f("segment_add_column").argtypes = [C.c_void_p, C.POINTER(PgColumnDesc)]
+        self.f("segment_num_docs").argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        self.f("segment_device_bytes").argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        self.f("segment_destroy").argtypes = [C.c_void_p]
+        self.f("filter_exec").argtypes = [C.c_void_p, C.POINTER(PgFilterNode), C.POINTER(C.c_void_p)]
+        self.f("docidset_cardinality").argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        self.f("docidset_num_words").argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        self.f("docidset_copy_words").argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        self.f("docidset_copy_docids").argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        self.f("docidset_stats").argtypes = [C.c_void_p, C.POINTER(PgExecStats)]
+        self.f("docidset_free").argtypes = [C.c_void_p]
+        self.f("query_supported").argtypes = [C.c_void_p, C.POINTER(PgQuery)]
+        self.f("query_exec").argtypes = [C.c_void_p, C.POINTER(PgQuery), C.POINTER(C.c_void_p)]
+        self.f("result_num_groups").argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        self.f("result_group_dict_ids").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        self.f("result_kind_of").argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+        self.f("result_doubles").argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
+        self.f("result_longs").argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
+        self.f("result_set_sizes").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        self.f("result_set_dict_ids").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+        self.f("result_hll_registers").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+        self.f("result_stats").argtypes = [C.c_void_p, C.POINTER(PgExecStats)]
+        self.f("result_free").argtypes = [C.c_void_p]
+
+    def f(self, name: str):
+        return getattr(self.lib, self.prefix + name)
+
+    def last_error(self) -> str:
+        buf = C.create_string_buffer(4096)
+        self.f("last_error")(buf, 4096)
+        return buf.value.decode("utf-8", "replace")
+
+    def check(self, status: int) -> None:
+        if status != PG_OK:
+            raise NativeError(status, self.last_error())
+
+    def call(self, name: str, *args) -> None:
+        self.check(self.f(name)(*args))
+
+
+def np_buffer(arr: Optional[np.ndarray]) -> PgBuffer:
+    if arr is None or arr.size == 0:
+        return PgBuffer(None, 0)
+    assert arr.dtype == np.uint8 and arr.flags["C_CONTIGUOUS"]
+    return PgBuffer(arr.ctypes.data, arr.nbytes)
+
+
+_gpu_api: Optional[NativeApi] = None
+
+
+def gpu_api() -> NativeApi:
+    """Loads libpinot_gpu.so. Fails loudly when the HIP extension has not been built (no CPU fallback exists)."""
+    global _gpu_api
+    if _gpu_api is None:
+        if not os.path.exists(GPU_LIB_PATH):
+            raise RuntimeError(
+                f"{GPU_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C pinot_amd/csrc`. There is no CPU fallback for the product path.")
+        _gpu_api = NativeApi(GPU_LIB_PATH, "pg_")
+    return _gpu_api

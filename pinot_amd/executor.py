@@ -1,0 +1,340 @@
+"""Host-side mirror of the reference's operator / plan-maker interface for the hot path, on top of the C ABI.
+
+Reference classes mirrored (same names, argument meaning and error behaviour; all under pinot-core/src/main/java/org/
+apache/pinot/core/):
+  plan/maker/PlanMaker.java:37-67, InstancePlanMakerImplV2.java:275-294   → GpuInstancePlanMaker.make_segment_plan_node
+  operator/query/GroupByOperator.java:100-140, AggregationOperator.java   → GpuGroupByOperator / GpuAggregationOperator
+  operator/blocks/results/GroupByResultsBlock.java, AggregationResultsBlock → GroupByResultsBlock / AggregationResultsBlock
+  operator/ExecutionStatistics.java                                        → ExecutionStatistics
+  operator/combine/GroupByCombineOperator.java:102-165,191-222 + data/table/IndexedTable.java:90-120
+                                                                           → GroupByCombineOperator (host merge)
+The Java plug-in is the production host; this module is what the tests and bench.py drive.
+`NativeSegment` works over any library exporting the pinot_gpu.h entry points; the product code only ever passes
+capi.gpu_api() — the oracle binding lives in tests/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import capi
+from .query import CQuery, QueryContext, parse_sql
+from .segment import HostSegment
+
+
+@dataclass
+class ExecutionStatistics:
+    num_docs_scanned: int
+    num_entries_scanned_in_filter: int
+    num_entries_scanned_post_filter: int
+    num_total_docs: int
+
+
+class NativeSegment:
+    """IndexSegment handle: the host segment's buffers registered with (and, for the GPU library, pinned in HBM by) a
+    native library.  `destroy()` mirrors IndexSegment#destroy."""
+
+    def __init__(self, api: capi.NativeApi, host: HostSegment):
+        self.api = api
+        self.host = host
+        self.handle = C.c_void_p()
+        api.call("segment_create", host.name.encode(), host.total_docs, C.byref(self.handle))
+        self._descs = []
+        for col in host.columns.values():
+            d = col.desc()
+            self._descs.append(d)
+            api.call("segment_add_column", self.handle, C.byref(d))
+
+    @property
+    def total_docs(self) -> int:
+        return self.host.total_docs
+
+    def device_bytes(self) -> int:
+        out = C.c_uint64()
+        self.api.call("segment_device_bytes", self.handle, C.byref(out))
+        return out.value
+
+    def destroy(self):
+        if self.handle:
+            self.api.call("segment_destroy", self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    # -- FilterOperator / DocIdSetOperator ------------------------------------------------------------------------
+    def filter(self, q) -> "DocIdSet":
+        qc = parse_sql(q) if isinstance(q, str) else q
+        cq = CQuery(qc)
+        h = C.c_void_p()
+        self.api.call("filter_exec", self.handle, cq.filter_ptr(), C.byref(h))
+        return DocIdSet(self.api, h)
+
+    # -- GroupByOperator / AggregationOperator ---------------------------------------------------------------------
+    def execute(self, q, profile: bool = False) -> "ResultsBlock":
+        qc = parse_sql(q) if isinstance(q, str) else q
+        if profile:
+            qc.flags |= capi.QUERY_FLAG_PROFILE
+        cq = CQuery(qc)
+        h = C.c_void_p()
+        self.api.call("query_exec", self.handle, cq.ptr(), C.byref(h))
+        try:
+            return ResultsBlock.from_native(self.api, h, qc, self.host)
+        finally:
+            self.api.call("result_free", h)
+
+
+class DocIdSet:
+    def __init__(self, api: capi.NativeApi, handle):
+        self.api = api
+        self.handle = handle
+
+    def cardinality(self) -> int:
+        out = C.c_int64()
+        self.api.call("docidset_cardinality", self.handle, C.byref(out))
+        return out.value
+
+    def words(self) -> np.ndarray:
+        n = C.c_int64()
+        self.api.call("docidset_num_words", self.handle, C.byref(n))
+        out = np.zeros(n.value, dtype=np.uint64)
+        self.api.call("docidset_copy_words", self.handle, out.ctypes.data, n.value)
+        return out
+
+    def doc_ids(self) -> np.ndarray:
+        n = self.cardinality()
+        out = np.zeros(n, dtype=np.int32)
+        self.api.call("docidset_copy_docids", self.handle, out.ctypes.data, n)
+        return out
+
+    def stats(self) -> capi.PgExecStats:
+        s = capi.PgExecStats()
+        self.api.call("docidset_stats", self.handle, C.byref(s))
+        return s
+
+    def free(self):
+        if self.handle:
+            self.api.call("docidset_free", self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class ResultsBlock:
+    """GroupByResultsBlock / AggregationResultsBlock: intermediate results per group key.
+
+    `rows` maps the decoded group key tuple (dictionary values, as GroupKeyGenerator#getGroupKeys yields them) to the
+    list of intermediate results, one per aggregation: COUNT → int, SUM/MIN/MAX → float, AVG → (sum, count),
+    MINMAXRANGE → (min, max), DISTINCTCOUNT → frozenset of values, DISTINCTCOUNTHLL → bytes of 2^log2m registers."""
+
+    def __init__(self):
+        self.query: Optional[QueryContext] = None
+        self.group_keys: List[tuple] = []
+        self.group_dict_ids: Optional[np.ndarray] = None   # [n_group_cols, n_groups]
+        self.columns: List[list] = []                       # per aggregation, per group
+        self.stats: Optional[capi.PgExecStats] = None
+
+    @staticmethod
+    def from_native(api: capi.NativeApi, h, qc: QueryContext, host: HostSegment) -> "ResultsBlock":
+        rb = ResultsBlock()
+        rb.query = qc
+        n = C.c_int32()
+        api.call("result_num_groups", h, C.byref(n))
+        ng = n.value
+        ngb = len(qc.group_by)
+        ids = np.zeros((ngb, ng), dtype=np.int32)
+        for j in range(ngb):
+            row = np.zeros(ng, dtype=np.int32)
+            api.call("result_group_dict_ids", h, j, row.ctypes.data, ng)
+            ids[j] = row
+        rb.group_dict_ids = ids
+        dicts = [host.columns[g].dict_values for g in qc.group_by]
+        rb.group_keys = [tuple(dicts[j][ids[j, i]] for j in range(ngb)) for i in range(ng)]
+        for a, spec in enumerate(qc.aggregations):
+            kind = C.c_int32()
+            api.call("result_kind_of", h, a, C.byref(kind))
+            k = kind.value
+            if k == capi.RESULT_LONG:
+                out = np.zeros(ng, dtype=np.int64)
+                api.call("result_longs", h, a, 0, out.ctypes.data, ng)
+                rb.columns.append([int(v) for v in out])
+            elif k == capi.RESULT_DOUBLE:
+                out = np.zeros(ng, dtype=np.float64)
+                api.call("result_doubles", h, a, 0, out.ctypes.data, ng)
+                rb.columns.append([float(v) for v in out])
+            elif k == capi.RESULT_AVG_PAIR:
+                s = np.zeros(ng, dtype=np.float64)
+                c = np.zeros(ng, dtype=np.int64)
+                api.call("result_doubles", h, a, 0, s.ctypes.data, ng)
+                api.call("result_longs", h, a, 0, c.ctypes.data, ng)
+                rb.columns.append([(float(x), int(y)) for x, y in zip(s, c)])
+            elif k == capi.RESULT_MINMAX_PAIR:
+                lo = np.zeros(ng, dtype=np.float64)
+                hi = np.zeros(ng, dtype=np.float64)
+                api.call("result_doubles", h, a, 0, lo.ctypes.data, ng)
+                api.call("result_doubles", h, a, 1, hi.ctypes.data, ng)
+                rb.columns.append([(float(x), float(y)) for x, y in zip(lo, hi)])
+            elif k == capi.RESULT_DICTID_SET:
+                sizes = np.zeros(ng, dtype=np.int32)
+                api.call("result_set_sizes", h, a, sizes.ctypes.data, ng)
+                total = int(sizes.sum())
+                flat = np.zeros(max(total, 1), dtype=np.int32)
+                api.call("result_set_dict_ids", h, a, flat.ctypes.data, total)
+                dv = host.columns[spec.column].dict_values
+                col, pos = [], 0
+                for sz in sizes:
+                    col.append(frozenset(dv[d] for d in flat[pos:pos + sz]))
+                    pos += sz
+                rb.columns.append(col)
+            elif k == capi.RESULT_HLL:
+                m = 1 << (spec.log2m or 8)
+                regs = np.zeros(max(ng * m, 1), dtype=np.uint8)
+                api.call("result_hll_registers", h, a, regs.ctypes.data, ng * m)
+                rb.columns.append([bytes(regs[i * m:(i + 1) * m]) for i in range(ng)])
+            else:
+                raise RuntimeError(f"unknown result kind {k}")
+        st = capi.PgExecStats()
+        api.call("result_stats", h, C.byref(st))
+        rb.stats = st
+        return rb
+
+    # -- conveniences ----------------------------------------------------------------------------------------------
+    def execution_statistics(self) -> ExecutionStatistics:
+        s = self.stats
+        return ExecutionStatistics(s.num_docs_scanned, s.num_entries_scanned_in_filter,
+                                   s.num_entries_scanned_post_filter, s.num_total_docs)
+
+    def rows(self) -> Dict[tuple, list]:
+        return {k: [col[i] for col in self.columns] for i, k in enumerate(self.group_keys)}
+
+    def aggregation_result(self) -> list:
+        """AggregationResultsBlock#getResults for a query without GROUP BY."""
+        assert not self.query.group_by
+        return [col[0] for col in self.columns]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# HyperLogLog cardinality (final result extraction; stream-lib HyperLogLog#cardinality)
+# ----------------------------------------------------------------------------------------------------------------------
+def hll_cardinality(registers: bytes) -> int:
+    m = len(registers)
+    if m == 16:
+        alpha_mm = 0.673 * m * m
+    elif m == 32:
+        alpha_mm = 0.697 * m * m
+    elif m == 64:
+        alpha_mm = 0.709 * m * m
+    else:
+        alpha_mm = (0.7213 / (1 + 1.079 / m)) * m * m
+    s = 0.0
+    zeros = 0.0
+    for v in registers:
+        s += 1.0 / (1 << v)
+        if v == 0:
+            zeros += 1
+    est = alpha_mm * (1 / s)
+    if est <= 2.5 * m:
+        return int(math.floor(m * math.log(m / zeros) + 0.5))
+    return int(math.floor(est + 0.5))
+
+
+def hll_merge(a: bytes, b: bytes) -> bytes:
+    return bytes(max(x, y) for x, y in zip(a, b))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# GroupByCombineOperator + IndexedTable: merge per-segment intermediate results keyed by *values*
+# (dictionaries are per segment; GroupByCombineOperator.java:132-147 decodes before upserting).
+# ----------------------------------------------------------------------------------------------------------------------
+def merge_intermediate(function: str, a, b):
+    """AggregationFunction#merge for the functions on the path."""
+    if function in ("COUNT", "SUM"):
+        return a + b
+    if function == "MIN":
+        return b if b < a else a
+    if function == "MAX":
+        return b if b > a else a
+    if function == "AVG":
+        return (a[0] + b[0], a[1] + b[1])
+    if function == "MINMAXRANGE":
+        return (min(a[0], b[0]), max(a[1], b[1]))
+    if function == "DISTINCTCOUNT":
+        return a | b
+    if function == "DISTINCTCOUNTHLL":
+        return hll_merge(a, b)
+    raise ValueError(function)
+
+
+def extract_final(function: str, v):
+    """AggregationFunction#extractFinalResult."""
+    if function == "AVG":
+        return v[0] / v[1] if v[1] else float("-inf")
+    if function == "MINMAXRANGE":
+        return v[1] - v[0]
+    if function == "DISTINCTCOUNT":
+        return len(v)
+    if function == "DISTINCTCOUNTHLL":
+        return hll_cardinality(v)
+    return v
+
+
+class GroupByCombineOperator:
+    """Host-side merge of per-segment (per-GPU) results: IndexedTable#upsert semantics (key → record, merge per
+    aggregation function).  The RCCL variant for identical key spaces lives in pinot_amd.distributed."""
+
+    def __init__(self, blocks: Sequence[ResultsBlock]):
+        self.blocks = list(blocks)
+
+    def merge(self) -> Dict[tuple, list]:
+        table: Dict[tuple, list] = {}
+        fns = [a.function for a in self.blocks[0].query.aggregations]
+        for b in self.blocks:
+            for key, vals in b.rows().items():
+                cur = table.get(key)
+                if cur is None:
+                    table[key] = list(vals)
+                else:
+                    table[key] = [merge_intermediate(f, x, y) for f, x, y in zip(fns, cur, vals)]
+        return table
+
+    def final(self) -> Dict[tuple, list]:
+        fns = [a.function for a in self.blocks[0].query.aggregations]
+        return {k: [extract_final(f, v) for f, v in zip(fns, vals)] for k, vals in self.merge().items()}
+
+
+class GpuInstancePlanMaker:
+    """PlanMaker for the accelerated path.  `make_segment_plan_node(segment, query)` returns a callable plan node whose
+    run() yields the operator result, or raises NativeError(PG_ERR_UNSUPPORTED) so the caller can fall back to the
+    default plan — the contract the Java GpuInstancePlanMaker follows."""
+
+    def __init__(self):
+        self.api = capi.gpu_api()
+
+    def load_segment(self, host: HostSegment) -> NativeSegment:
+        return NativeSegment(self.api, host)
+
+    def make_segment_plan_node(self, segment: NativeSegment, query):
+        qc = parse_sql(query) if isinstance(query, str) else query
+        cq = CQuery(qc)
+        self.api.call("query_supported", segment.handle, cq.ptr())
+        return _SegmentPlanNode(segment, qc)
+
+
+class _SegmentPlanNode:
+    def __init__(self, segment: NativeSegment, qc: QueryContext):
+        self.segment = segment
+        self.qc = qc
+
+    def run(self) -> ResultsBlock:
+        return self.segment.execute(self.qc)

@@ -1,0 +1,294 @@
+"""Writers (and a few check readers) for the Pinot v3 index-entry byte layouts the hot path reads.
+
+The reference builds segments with SegmentIndexCreationDriverImpl; segment *creation* is out of scope,
+but the executor consumes the exact bytes of these index entries, so tests and the benchmark need to produce them.
+Every writer cites the reference writer/reader whose layout it follows.  All multi-byte fields are big-endian unless
+noted (RoaringBitmap payloads are little-endian inside the big-endian file).
+"""
+from __future__ import annotations
+
+import struct
+from typing import Iterable, List, Sequence, Tuple
+
+import numpy as np
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Fixed-bit forward index (dictIds)
+#   writer: pinot-segment-local/.../io/writer/impl/FixedBitSVForwardIndexWriter.java:42-45  (length = ceil(N*bits/8))
+#   bit order: pinot-segment-local/.../io/util/PinotDataBitSet.java:74-97 (MSB first inside a big-endian byte stream)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def num_bits_per_value(max_value: int) -> int:
+    """PinotDataBitSet.getNumBitsPerValue (pinot-segment-local/.../io/util/PinotDataBitSet.java:61-72)."""
+    if max_value <= 1:
+        return 1
+    return int(max_value).bit_length()
+
+
+def pack_fixed_bit(values: np.ndarray, bits: int) -> np.ndarray:
+    """Packs non-negative ints into the MSB-first bit stream. Returns uint8 array of ceil(N*bits/8) bytes."""
+    assert 1 <= bits <= 31
+    values = np.ascontiguousarray(values, dtype=np.uint32)
+    n = values.shape[0]
+    total_bytes = (n * bits + 7) // 8
+    out = np.zeros(total_bytes, dtype=np.uint8)
+    if n == 0:
+        return out
+    shifts = np.arange(bits - 1, -1, -1, dtype=np.uint32)
+    chunk = 1 << 21  # multiple of 8 => every chunk starts on a byte boundary
+    for start in range(0, n, chunk):
+        v = values[start:start + chunk]
+        b = ((v[:, None] >> shifts[None, :]) & 1).astype(np.uint8).reshape(-1)
+        packed = np.packbits(b)  # big-endian bit order within bytes
+        off = (start * bits) // 8
+        out[off:off + packed.shape[0]] = packed
+    return out
+
+
+def unpack_fixed_bit(buf: np.ndarray, bits: int, n: int) -> np.ndarray:
+    """Check reader (PinotDataBitSet.readInt semantics) used by tests only."""
+    b = np.unpackbits(np.ascontiguousarray(buf, dtype=np.uint8))[: n * bits].reshape(n, bits)
+    weights = (1 << np.arange(bits - 1, -1, -1, dtype=np.int64))
+    return (b.astype(np.int64) * weights).sum(axis=1).astype(np.int32)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Raw fixed-byte chunk forward index, PASS_THROUGH
+#   writer: pinot-segment-local/.../io/writer/impl/BaseChunkForwardIndexWriter.java:131-165 (7-int header, offsets)
+#           FixedByteChunkForwardIndexWriter.java:49-101
+#   reader: .../readers/forward/BaseChunkForwardIndexReader.java:61-111, FixedByteChunkSVForwardIndexReader.java:53-94
+# ----------------------------------------------------------------------------------------------------------------------
+CHUNK_COMPRESSION_PASS_THROUGH = 0  # ChunkCompressionType.PASS_THROUGH.getValue()
+
+_BE_DTYPES = {"INT": ">i4", "LONG": ">i8", "FLOAT": ">f4", "DOUBLE": ">f8"}
+_WIDTHS = {"INT": 4, "LONG": 8, "FLOAT": 4, "DOUBLE": 8}
+
+
+def write_raw_fixed_byte_chunk(values: np.ndarray, data_type: str, version: int = 2,
+                               docs_per_chunk: int = 1000) -> np.ndarray:
+    """Header(version, numChunks, numDocsPerChunk, sizeOfEntry, totalDocs, compressionType, dataHeaderStart=28),
+    chunk start offsets (int for v2, long for v3+), then the big-endian values back to back."""
+    assert version in (2, 3, 4)
+    width = _WIDTHS[data_type]
+    n = int(values.shape[0])
+    if version >= 4 and (docs_per_chunk & (docs_per_chunk - 1)) != 0:
+        docs_per_chunk = 1 << (docs_per_chunk - 1).bit_length()  # normalizeDocsPerChunk
+    num_chunks = (n + docs_per_chunk - 1) // docs_per_chunk
+    off_size = 4 if version == 2 else 8
+    header_size = 7 * 4 + num_chunks * off_size
+    chunk_bytes = docs_per_chunk * width
+    header = struct.pack(">7i", version, num_chunks, docs_per_chunk, width, n, CHUNK_COMPRESSION_PASS_THROUGH, 28)
+    offs = header_size + np.arange(num_chunks, dtype=np.int64) * chunk_bytes
+    if off_size == 4:
+        assert num_chunks == 0 or offs[-1] <= 0x7FFFFFFF, "Integer overflow detected (use raw version 3 or 4)"
+        off_bytes = offs.astype(">i4").tobytes()
+    else:
+        off_bytes = offs.astype(">i8").tobytes()
+    data = np.ascontiguousarray(values).astype(_BE_DTYPES[data_type]).tobytes()
+    out = np.frombuffer(header + off_bytes + data, dtype=np.uint8)
+    return out
+
+
+def parse_raw_fixed_byte_chunk_header(buf: np.ndarray) -> dict:
+    version, num_chunks, docs_per_chunk, size_of_entry = struct.unpack(">4i", bytes(buf[:16]))
+    if version > 1:
+        total_docs, compression, data_header_start = struct.unpack(">3i", bytes(buf[16:28]))
+    else:
+        total_docs, compression, data_header_start = -1, 1, 16
+    off_size = 4 if version <= 2 else 8
+    raw_data_start = data_header_start + num_chunks * off_size
+    return dict(version=version, num_chunks=num_chunks, docs_per_chunk=docs_per_chunk, size_of_entry=size_of_entry,
+                total_docs=total_docs, compression=compression, data_header_start=data_header_start,
+                raw_data_start=raw_data_start)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Dictionaries: sorted big-endian fixed-width values
+#   reader: pinot-segment-local/.../segment/index/readers/BaseImmutableDictionary.java:45-58, IntDictionary.java:28-80
+#   STRING: fixed-width entries padded with 0 bytes (FixedByteValueReaderWriter#getUnpaddedString strips them)
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def write_numeric_dictionary(sorted_values: np.ndarray, data_type: str) -> np.ndarray:
+    return np.frombuffer(np.ascontiguousarray(sorted_values).astype(_BE_DTYPES[data_type]).tobytes(), dtype=np.uint8)
+
+
+def write_string_dictionary(sorted_values: Sequence[str]) -> Tuple[np.ndarray, int]:
+    enc = [s.encode("utf-8") for s in sorted_values]
+    width = max([len(e) for e in enc] + [1])
+    out = np.zeros((len(enc), width), dtype=np.uint8)
+    for i, e in enumerate(enc):
+        out[i, : len(e)] = np.frombuffer(e, dtype=np.uint8)
+    return out.reshape(-1), width
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Sorted forward index: (startDocId, endDocId) inclusive pairs, 2 BE ints per dictId
+#   reader: pinot-segment-local/.../segment/index/readers/sorted/SortedIndexReaderImpl.java:35-60
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def write_sorted_index(dict_ids: np.ndarray, cardinality: int) -> np.ndarray:
+    n = dict_ids.shape[0]
+    starts = np.searchsorted(dict_ids, np.arange(cardinality), side="left")
+    ends = np.searchsorted(dict_ids, np.arange(cardinality), side="right") - 1
+    pairs = np.stack([starts, ends], axis=1).astype(">i4")
+    assert n == 0 or (ends[-1] == n - 1 and starts[0] == 0)
+    return np.frombuffer(pairs.tobytes(), dtype=np.uint8)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# RoaringBitmap portable serialization (RoaringBitmap 1.3.0, pom.xml:798-802; source not in the reference tree).
+# Public format spec: cookie 12346 (no run containers) | 12347 (+ (size-1)<<16, run-flag bitset); descriptive header
+# (key u16, cardinality-1 u16); offset header (always for 12346, only when size >= 4 for 12347); containers:
+# array = sorted u16, bitmap = 1024 LE u64, run = n_runs u16 then (start u16, length-1 u16) pairs.
+# Container choice follows RoaringBitmapWriter.writer() defaults used by the inverted index creators
+# (OnHeapBitmapInvertedIndexCreator.java:41-42): array if cardinality <= 4096 else bitmap, then runOptimize():
+# run container iff 2 + 4*n_runs < current serialized size.
+# ----------------------------------------------------------------------------------------------------------------------
+SERIAL_COOKIE_NO_RUNCONTAINER = 12346
+SERIAL_COOKIE = 12347
+NO_OFFSET_THRESHOLD = 4
+ARRAY_MAX = 4096
+
+
+def _container_payload(lows: np.ndarray, run_compress: bool) -> Tuple[int, bytes]:
+    """lows: sorted unique uint16 values of one container. Returns (kind, bytes): kind 0=array 1=bitmap 2=run."""
+    card = int(lows.shape[0])
+    l32 = lows.astype(np.int32)
+    if card > 1:
+        breaks = np.flatnonzero(np.diff(l32) != 1)
+        n_runs = int(breaks.shape[0]) + 1
+    else:
+        breaks = np.zeros(0, dtype=np.int64)
+        n_runs = 1
+    size_now = 2 * card if card <= ARRAY_MAX else 8192
+    if run_compress and 2 + 4 * n_runs < size_now:
+        starts = np.concatenate([[0], breaks + 1])
+        ends = np.concatenate([breaks, [card - 1]])
+        rs = l32[starts]
+        rl = l32[ends] - rs
+        pairs = np.stack([rs, rl], axis=1).astype("<u2")
+        return 2, struct.pack("<H", n_runs) + pairs.tobytes()
+    if card <= ARRAY_MAX:
+        return 0, lows.astype("<u2").tobytes()
+    bits = np.zeros(65536, dtype=np.uint8)
+    bits[l32] = 1
+    words = np.packbits(bits, bitorder="little").view("<u8")
+    return 1, words.tobytes()
+
+
+def serialize_roaring(doc_ids: np.ndarray, run_compress: bool = True) -> bytes:
+    """doc_ids: sorted unique non-negative int docIds."""
+    doc_ids = np.ascontiguousarray(doc_ids, dtype=np.int64)
+    if doc_ids.shape[0] == 0:
+        return struct.pack("<II", SERIAL_COOKIE_NO_RUNCONTAINER, 0)
+    highs = (doc_ids >> 16).astype(np.int64)
+    keys, starts = np.unique(highs, return_index=True)
+    bounds = list(starts) + [doc_ids.shape[0]]
+    kinds: List[int] = []
+    payloads: List[bytes] = []
+    cards: List[int] = []
+    for i in range(len(keys)):
+        lows = (doc_ids[bounds[i]:bounds[i + 1]] & 0xFFFF).astype(np.uint16)
+        kind, payload = _container_payload(lows, run_compress)
+        kinds.append(kind)
+        payloads.append(payload)
+        cards.append(int(lows.shape[0]))
+    size = len(keys)
+    has_run = any(k == 2 for k in kinds)
+    parts: List[bytes] = []
+    if has_run:
+        parts.append(struct.pack("<I", SERIAL_COOKIE | ((size - 1) << 16)))
+        flags = np.zeros((size + 7) // 8, dtype=np.uint8)
+        for i, k in enumerate(kinds):
+            if k == 2:
+                flags[i >> 3] |= 1 << (i & 7)
+        parts.append(flags.tobytes())
+    else:
+        parts.append(struct.pack("<II", SERIAL_COOKIE_NO_RUNCONTAINER, size))
+    desc = np.empty((size, 2), dtype="<u2")
+    desc[:, 0] = keys.astype(np.uint16)
+    desc[:, 1] = (np.asarray(cards, dtype=np.int64) - 1).astype(np.uint16)
+    parts.append(desc.tobytes())
+    header_len = sum(len(p) for p in parts)
+    with_offsets = (not has_run) or size >= NO_OFFSET_THRESHOLD
+    if with_offsets:
+        header_len += 4 * size
+        offs = np.empty(size, dtype="<u4")
+        pos = header_len
+        for i, p in enumerate(payloads):
+            offs[i] = pos
+            pos += len(p)
+        parts.append(offs.tobytes())
+    parts.extend(payloads)
+    return b"".join(parts)
+
+
+def deserialize_roaring(blob: bytes) -> np.ndarray:
+    """Check reader (tests only): returns sorted docIds."""
+    mv = memoryview(blob)
+    (cookie,) = struct.unpack_from("<I", mv, 0)
+    pos = 4
+    if (cookie & 0xFFFF) == SERIAL_COOKIE:
+        size = (cookie >> 16) + 1
+        flags = np.frombuffer(mv[pos:pos + (size + 7) // 8], dtype=np.uint8)
+        pos += (size + 7) // 8
+        has_run = True
+    else:
+        assert cookie == SERIAL_COOKIE_NO_RUNCONTAINER, cookie
+        (size,) = struct.unpack_from("<I", mv, pos)
+        pos += 4
+        flags = None
+        has_run = False
+    desc = np.frombuffer(mv[pos:pos + 4 * size], dtype="<u2").reshape(size, 2)
+    pos += 4 * size
+    if (not has_run) or size >= NO_OFFSET_THRESHOLD:
+        pos += 4 * size
+    out = []
+    for i in range(size):
+        key = int(desc[i, 0])
+        card = int(desc[i, 1]) + 1
+        is_run = has_run and ((flags[i >> 3] >> (i & 7)) & 1)
+        if is_run:
+            (n_runs,) = struct.unpack_from("<H", mv, pos)
+            pos += 2
+            pairs = np.frombuffer(mv[pos:pos + 4 * n_runs], dtype="<u2").reshape(n_runs, 2).astype(np.int64)
+            pos += 4 * n_runs
+            vals = np.concatenate([np.arange(s, s + l + 1) for s, l in pairs]) if n_runs else np.zeros(0, np.int64)
+        elif card > ARRAY_MAX:
+            words = np.frombuffer(mv[pos:pos + 8192], dtype=np.uint8)
+            pos += 8192
+            vals = np.flatnonzero(np.unpackbits(words, bitorder="little")).astype(np.int64)
+        else:
+            vals = np.frombuffer(mv[pos:pos + 2 * card], dtype="<u2").astype(np.int64)
+            pos += 2 * card
+        out.append(vals + (key << 16))
+    return np.concatenate(out) if out else np.zeros(0, dtype=np.int64)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Bitmap inverted index: (cardinality+1) BE uint32 absolute offsets then the serialized bitmaps
+#   writer: pinot-segment-local/.../segment/creator/impl/inv/BitmapInvertedIndexWriter.java:36-104
+#   reader: pinot-segment-local/.../segment/index/readers/BitmapInvertedIndexReader.java:45-62
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def write_inverted_index(dict_ids: np.ndarray, cardinality: int, run_compress: bool = True) -> np.ndarray:
+    order = np.argsort(dict_ids, kind="stable")
+    sorted_ids = dict_ids[order]
+    bounds = np.searchsorted(sorted_ids, np.arange(cardinality + 1), side="left")
+    blobs = []
+    for d in range(cardinality):
+        docs = order[bounds[d]:bounds[d + 1]]  # ascending because the sort is stable
+        blobs.append(serialize_roaring(docs, run_compress))
+    offsets = np.empty(cardinality + 1, dtype=np.int64)
+    pos = (cardinality + 1) * 4
+    for d, b in enumerate(blobs):
+        offsets[d] = pos
+        pos += len(b)
+    offsets[cardinality] = pos
+    assert pos <= 0xFFFFFFFF, "inverted index larger than 4 GB (BitmapInvertedIndexReader offsets are unsigned int)"
+    head = offsets.astype(">u4").tobytes()
+    return np.frombuffer(head + b"".join(blobs), dtype=np.uint8)

@@ -1,0 +1,120 @@
+"""Host-side segment model: the bytes of one immutable Pinot segment's index entries, column by column.
+
+`build_segment()` plays the role SegmentIndexCreationDriverImpl plays in the reference's tests
+(pinot-core/src/test/.../queries/BaseSingleValueQueriesTest.java:107-131): turn rows into dictionaries, forward
+indexes and inverted indexes in Pinot's byte layouts.  Only what the hot path reads is produced.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import numpy as np
+
+from . import capi, formats
+
+NUMERIC_NP = {"INT": np.int32, "LONG": np.int64, "FLOAT": np.float32, "DOUBLE": np.float64}
+
+
+@dataclass
+class HostColumn:
+    name: str
+    data_type: str                      # stored type: INT / LONG / FLOAT / DOUBLE / STRING
+    fwd_encoding: int
+    has_dictionary: bool
+    cardinality: int
+    bits_per_value: int
+    is_sorted: bool
+    dict_bytes_per_value: int
+    forward_index: np.ndarray
+    dictionary: Optional[np.ndarray] = None
+    inverted_index: Optional[np.ndarray] = None
+    dict_values: Optional[list] = None  # decoded dictionary (python objects / numpy scalars) for result decoding
+    _name_bytes: bytes = b""
+
+    def desc(self) -> capi.PgColumnDesc:
+        self._name_bytes = self.name.encode()
+        return capi.PgColumnDesc(
+            name=self._name_bytes,
+            data_type=capi.DATA_TYPES[self.data_type],
+            fwd_encoding=self.fwd_encoding,
+            has_dictionary=int(self.has_dictionary),
+            cardinality=self.cardinality,
+            bits_per_value=self.bits_per_value,
+            is_sorted=int(self.is_sorted),
+            dict_bytes_per_value=self.dict_bytes_per_value,
+            reserved0=0,
+            forward_index=capi.np_buffer(self.forward_index),
+            dictionary=capi.np_buffer(self.dictionary),
+            inverted_index=capi.np_buffer(self.inverted_index),
+        )
+
+
+@dataclass
+class HostSegment:
+    name: str
+    total_docs: int
+    columns: Dict[str, HostColumn] = field(default_factory=dict)
+
+    def nbytes(self) -> int:
+        t = 0
+        for c in self.columns.values():
+            for b in (c.forward_index, c.dictionary, c.inverted_index):
+                if b is not None:
+                    t += b.nbytes
+        return t
+
+
+def build_column(name: str, values, data_type: str, *, dictionary: bool = True, inverted: bool = False,
+                 raw_version: int = 2, run_compress: bool = True) -> HostColumn:
+    if data_type == "STRING":
+        vals = np.asarray(values, dtype=object)
+        assert dictionary, "raw STRING columns are outside the hot path"
+        uniq = sorted(set(vals.tolist()))  # Java String.compareTo == code-point order for BMP/ASCII test data
+        index = {v: i for i, v in enumerate(uniq)}
+        dict_ids = np.fromiter((index[v] for v in vals.tolist()), dtype=np.int32, count=len(vals))
+        dict_buf, width = formats.write_string_dictionary(uniq)
+        dict_values = list(uniq)
+    else:
+        vals = np.ascontiguousarray(values, dtype=NUMERIC_NP[data_type])
+        if not dictionary:
+            fwd = formats.write_raw_fixed_byte_chunk(vals, data_type, version=raw_version)
+            return HostColumn(name, data_type, capi.FWD_RAW_FIXED_BYTE_CHUNK, False, 0, 0,
+                              bool(np.all(vals[1:] >= vals[:-1])) if len(vals) else True, 0, fwd)
+        uniq, dict_ids = np.unique(vals, return_inverse=True)
+        dict_ids = dict_ids.astype(np.int32)
+        dict_buf = formats.write_numeric_dictionary(uniq, data_type)
+        width = formats._WIDTHS[data_type]
+        dict_values = uniq.tolist()
+    n = len(dict_ids)
+    card = len(dict_values)
+    is_sorted = bool(np.all(dict_ids[1:] >= dict_ids[:-1])) if n else True
+    bits = formats.num_bits_per_value(card - 1)
+    if is_sorted:
+        # SingleValueSortedForwardIndexCreator: the sorted index is forward and inverted index at once
+        fwd = formats.write_sorted_index(dict_ids, card)
+        enc = capi.FWD_DICT_SORTED
+        inv = None
+    else:
+        fwd = formats.pack_fixed_bit(dict_ids, bits)
+        enc = capi.FWD_DICT_FIXED_BIT
+        inv = formats.write_inverted_index(dict_ids, card, run_compress) if inverted else None
+    return HostColumn(name, data_type, enc, True, card, bits, is_sorted, width, fwd, dict_buf, inv, dict_values)
+
+
+def build_segment(name: str, data: Dict[str, Sequence], schema: Dict[str, str], *,
+                  inverted_index_columns: Iterable[str] = (), no_dictionary_columns: Iterable[str] = (),
+                  raw_version: int = 2, run_compress: bool = True) -> HostSegment:
+    inv = set(inverted_index_columns)
+    nodict = set(no_dictionary_columns)
+    total = None
+    seg = HostSegment(name, 0)
+    for col, dtype in schema.items():
+        vals = data[col]
+        if total is None:
+            total = len(vals)
+        assert len(vals) == total, f"column {col}: {len(vals)} rows != {total}"
+        seg.columns[col] = build_column(col, vals, dtype, dictionary=col not in nodict, inverted=col in inv,
+                                        raw_version=raw_version, run_compress=run_compress)
+    seg.total_docs = int(total or 0)
+    return seg
