@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rows scanned/sec of the filter → group-by hot path on 1 B-row synthetic segments (BASELINE.json).
+
+A "step" is one pass of the hot path over one batch of synthetic input = one `pg_query_exec` of the config-3 query
+    SELECT g1, SUM(m), MAX(m) FROM gpuBench WHERE c_inv1 IN (0,1,2,3) AND c_inv2 IN (0,1)
+                                            AND r_int BETWEEN 250000 AND 749999 GROUP BY g1
+over one 1 B-row segment per GPU, columns already resident in HBM (2 inverted-index predicates + 1 raw-INT range scan,
+group by a 100-value dictionary column, SUM/MAX of a raw INT metric), followed — when N > 1 — by the cross-GPU group-by
+merge (RCCL all-reduce of the dense per-group arrays; segments share dictionaries).  Segments shard one per GPU
+(`scaling: weak`), no data-path collective other than that merge.
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (HBM-bound: algorithmic bytes per launch ÷ HIP-event
+kernel time ÷ 8 TB/s) and `cpu_baseline` (the C restatement of the reference algorithm, oracle/, one thread per segment
+as the reference runs it, on a bounded prefix sample of the same segment).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import statistics
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+CFG3_BYTES_PER_ROW = 9.625     # postings 6/8 + r_int 4 + g1 7/8 + m 4
+NORTH_STAR_BYTES_PER_ROW = 10.375
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--docs", type=int, default=int(os.environ.get("PG_BENCH_DOCS", "1000000000")),
+                    help="rows per segment (BASELINE config 3: 1e9)")
+    ap.add_argument("--query", choices=["cfg3", "northstar", "cfg2"], default="cfg3")
+    ap.add_argument("--cpu-sample-docs", type=int, default=100_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from pinot_amd import capi, synth
+    from pinot_amd.executor import NativeSegment
+    from pinot_amd.query import CQuery, parse_sql
+    from pinot_amd.segment import HostSegment
+
+    api = capi.gpu_api()
+    api.call("init", local_rank)
+
+    sql = {"cfg3": synth.QUERY_CFG3, "northstar": synth.QUERY_NORTH_STAR, "cfg2": synth.QUERY_CFG2}[args.query]
+    bytes_per_row = {"cfg3": CFG3_BYTES_PER_ROW, "northstar": NORTH_STAR_BYTES_PER_ROW, "cfg2": 4.0}[args.query]
+    needed = {"cfg3": ["c_inv1", "c_inv2", "r_int", "g1", "m"], "northstar": ["c_inv1", "c_inv2", "r_int", "g1", "g2", "m"],
+              "cfg2": ["r_int"]}[args.query]
+
+    # ---- build this rank's segment (segment index = rank) and pin it in HBM, one column at a time ----------------------
+    t0 = time.time()
+    seg = NativeSegment(api, HostSegment(f"gpuBench_{rank}", args.docs))
+    for name in needed:
+        one = synth.generate_segment(args.docs, segment_index=rank, columns=[name])
+        seg.add_column(one.columns[name], keep_host_buffers=False)
+        del one
+    log(f"segment of {args.docs} docs generated + uploaded in {time.time() - t0:.1f}s, "
+        f"{seg.device_bytes() / 1e9:.2f} GB in HBM")
+
+    qc = parse_sql(sql)
+    qc.flags |= capi.QUERY_FLAG_PROFILE
+    cq = CQuery(qc)
+    n_aggs = len(qc.aggregations)
+    cards = [synth.GPU_BENCH[g].range for g in qc.group_by]
+    G = int(np.prod(cards)) if cards else 1
+    kernel_ms = []
+
+    def step():
+        """One pass of the hot path: segment query on this GPU + cross-GPU merge of the group table."""
+        h = C.c_void_p()
+        api.call("query_exec", seg.handle, cq.ptr(), C.byref(h))
+        n = C.c_int32()
+        api.call("result_num_groups", h, C.byref(n))
+        ng = n.value
+        key = np.zeros(ng, dtype=np.int64)
+        mult = 1
+        ids = np.zeros(ng, dtype=np.int32)
+        for j, card in enumerate(cards):
+            api.call("result_group_dict_ids", h, j, ids.ctypes.data, ng)
+            key += ids.astype(np.int64) * mult
+            mult *= card
+        dense = np.zeros((n_aggs, G), dtype=np.float64)
+        present = np.zeros(G, dtype=np.float64)
+        vals = np.zeros(ng, dtype=np.float64)
+        lvals = np.zeros(ng, dtype=np.int64)
+        for a, spec in enumerate(qc.aggregations):
+            if spec.function == "COUNT":
+                api.call("result_longs", h, a, 0, lvals.ctypes.data, ng)
+                dense[a, key] = lvals
+            else:
+                if spec.function == "MAX":
+                    dense[a, :] = -np.inf
+                api.call("result_doubles", h, a, 0, vals.ctypes.data, ng)
+                dense[a, key] = vals
+        present[key] = 1.0
+        st = capi.PgExecStats()
+        api.call("result_stats", h, C.byref(st))
+        api.call("result_free", h)
+        kernel_ms.append(st.device_ms_aggregate)
+        if world > 1:
+            # GroupByCombineOperator merge over xGMI: identical dictionaries ⇒ dense layout, SUM/COUNT add, MAX max
+            for a, spec in enumerate(qc.aggregations):
+                t = torch.from_numpy(dense[a]).cuda()
+                dist.all_reduce(t, op=dist.ReduceOp.MAX if spec.function == "MAX" else dist.ReduceOp.SUM)
+                dense[a] = t.cpu().numpy()
+        return dense, st
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        dense, st = step()
+    kernel_ms.clear()
+    lat = []
+    sync()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        t1 = time.perf_counter()
+        dense, st = step()
+        lat.append((time.perf_counter() - t1) * 1e3)
+    sync()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_rows = float(args.docs) * world * args.steps
+    value = total_rows / elapsed
+    avg_kernel_ms = sum(kernel_ms) / max(len(kernel_ms), 1)
+    alg_bytes = bytes_per_row * args.docs
+    achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9 if avg_kernel_ms > 0 else 0.0
+    lib_alg = st.algorithmic_bytes
+    out = {
+        "metric": "rows scanned/sec, 1B-row segment filter+groupby (3 predicates, SUM/MAX GROUP BY g1)",
+        "value": value,
+        "unit": "rows/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "p50_query_latency_ms": statistics.median(lat),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int64",
+        "data": "synthetic",
+        "config": {"workload": f"{world} segment(s) x {args.docs} rows, one per GPU; {sql}",
+                   "query": args.query, "rows_per_segment": args.docs, "parallelism": f"segment-per-gpu x{world}",
+                   "matched_docs_per_segment": int(st.num_docs_scanned),
+                   "entries_scanned_in_filter": int(st.num_entries_scanned_in_filter)},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "pg_segment_query_kernel", "kernel_ms": avg_kernel_ms,
+                     "algorithmic_bytes_per_launch": alg_bytes, "library_accounted_bytes": int(lib_alg)},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, sql, dense, cards, qc)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    seg.destroy()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, sql, gpu_dense, cards, qc):
+    """CPU leg: the C restatement of the reference algorithm (oracle/, kind "port"), 1 thread per segment exactly like
+    the reference's combine operator, on a prefix sample of the same segment.  Also cross-checks the GPU result on the
+    sample when the sample is the whole segment."""
+    from pinot_amd import synth
+    from pinot_amd.executor import NativeSegment
+    from tests.oracle_binding import load_oracle
+    sample = min(args.docs, args.cpu_sample_docs)
+    needed = sorted({c for c in synth.CFG3_COLUMNS})
+    host = synth.generate_segment(sample, segment_index=0, columns=needed)
+    ora = NativeSegment(load_oracle(), host)
+    times = []
+    block = None
+    for _ in range(5):
+        t = time.perf_counter()
+        block = ora.execute(sql)
+        times.append(time.perf_counter() - t)
+    med = statistics.median(times)
+    if sample == args.docs:   # full-size parity check against the timed GPU result
+        rows = block.rows()
+        for key, vals in rows.items():
+            k = 0
+            mult = 1
+            for j, card in enumerate(cards):
+                k += int(key[j]) * mult
+                mult *= card
+            for a in range(len(vals)):
+                assert gpu_dense[a, k] == float(vals[a]), (key, a, gpu_dense[a, k], vals[a])
+    ora.destroy()
+    return {"value": sample / med, "unit": "rows/s", "cores": 1, "kind": "port",
+            "sample": f"first {sample} docs of segment 0, same query, median of 5 runs; C restatement of the reference "
+                      f"operators (oracle/), not the JVM", "seconds_per_run": med}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,157 @@
+// Device-side plan layout shared by the host planner (pg_plan.cpp) and the HIP kernels (pg_kernels.hip).
+//
+// Execution model: a segment is cut into tiles of PG_TILE_DOCS consecutive docIds.  A persistent
+// workgroup walks tiles round-robin; per tile it (1) runs the compiled filter program over a small stack of
+// PG_TILE_WORDS-word bitsets held in LDS, (2) optionally stores the resulting match words / popcounts, and
+// (3) streams the group-by and metric columns of the tile, aggregating the matching docs into LDS accumulators.
+#pragma once
+#include <stdint.h>
+
+#define PG_TILE_DOCS 16384
+#define PG_TILE_WORDS 256          // 64-bit words per tile
+#define PG_TILE_QUADS 4096         // 4-doc quads per tile
+#define PG_CHUNK_DOCS 65536        // RoaringBitmap container span
+#define PG_TILES_PER_CHUNK 4
+#define PG_MAX_STACK 6
+#define PG_MAX_GROUP_COLS 8
+#define PG_MAX_SRCS 8
+#define PG_MAX_OPS 16
+#define PG_MAX_STATS 16
+#define PG_BLOCK 256
+
+// ---- filter program --------------------------------------------------------------------------------------------------
+enum PgFOp : int32_t {
+  PG_F_PUSH_POSTINGS = 0,   // push OR of the leaf's posting lists (xor valid mask when exclusive)
+  PG_F_PUSH_RANGES = 1,     // push docId ranges (sorted index / match-all)
+  PG_F_PUSH_SCAN = 2,       // push predicate(column) evaluated for every doc of the tile
+  PG_F_AND_SCAN = 3,        // top &= predicate(column), evaluated only where top has candidates (counts candidates)
+  PG_F_AND = 4,             // pop b, top &= b
+  PG_F_OR = 5,              // pop b, top |= b
+  PG_F_NOT = 6,             // top = ~top & valid
+  PG_F_PUSH_NONE = 7        // push empty set
+};
+
+struct PgFInstr {
+  int32_t op;
+  int32_t arg;   // leaf index
+};
+
+enum PgColKind : int32_t { PG_COL_FIXED_BIT = 0, PG_COL_RAW32 = 1, PG_COL_RAW64 = 2 };
+enum PgValType : int32_t { PG_V_I32 = 0, PG_V_I64 = 1, PG_V_F32 = 2, PG_V_F64 = 3 };
+
+enum PgPredKind : int32_t {
+  PG_P_RANGE = 0,       // inclusive [lo, hi] on the value (typed by val_type) or on the dictId (dictionary columns)
+  PG_P_DICT_LUT = 1,    // dictId bitset lookup (IN / NOT_IN / NOT_EQ on dictionary columns)
+  PG_P_SET = 2          // raw value in sorted set (xor exclusive)
+};
+
+struct PgScanLeaf {
+  const uint8_t* data;      // column bytes, doc 0 at offset 0 (big-endian values / MSB-first bit stream)
+  const uint32_t* lut;      // PG_P_DICT_LUT: ceil(cardinality/32) words
+  const void* set_values;   // PG_P_SET: sorted values in native layout of val_type (int64 / double widened)
+  int64_t lo, hi;           // PG_P_RANGE: integer bounds, or the bit patterns of double bounds
+  int32_t col_kind;
+  int32_t bits;             // PG_COL_FIXED_BIT
+  int32_t val_type;         // PgValType of a raw column
+  int32_t pred_kind;
+  int32_t exclusive;
+  int32_t n_set;
+  int32_t stat_slot;        // PG_F_AND_SCAN: index into stats[] receiving the number of candidates evaluated
+  int32_t pad;
+};
+
+// One RoaringBitmap container re-laid out in HBM: payload 16-byte aligned inside the column's container buffer.
+struct PgContainer {
+  uint64_t offset;   // byte offset into PgPostingLeaf::containers
+  uint32_t n;        // array: cardinality; run: number of runs; bitmap: cardinality
+  uint16_t key;      // docId >> 16
+  uint16_t type;     // 0 array, 1 bitmap, 2 run
+};
+
+struct PgPostingLeaf {
+  const uint8_t* containers;
+  const PgContainer* descs;       // all containers of the column's inverted index
+  const uint32_t* chunk_start;    // CSR over chunks: entries [chunk_start[c], chunk_start[c+1]) of chunk_desc
+  const uint32_t* chunk_desc;     // indices into descs of the leaf's containers that fall in chunk c
+  int32_t exclusive;
+  int32_t pad;
+};
+
+struct PgRangeLeaf {
+  const int32_t* lo;   // inclusive
+  const int32_t* hi;   // inclusive
+  int32_t n;
+  int32_t pad;
+};
+
+// ---- aggregation plan --------------------------------------------------------------------------------------------------
+enum PgAccFn : int32_t { PG_ACC_COUNT = 0, PG_ACC_SUM = 1, PG_ACC_MIN = 2, PG_ACC_MAX = 3 };
+enum PgAggMode : int32_t {
+  PG_AGG_NONE = 0,
+  PG_AGG_SINGLE = 1,   // no GROUP BY: per-thread registers, one flush per workgroup
+  PG_AGG_LDS = 2,      // accumulator table [n_acc][G*R] in LDS, flushed to per-workgroup partials
+  PG_AGG_GLOBAL = 3    // accumulator table [n_acc][G] in HBM, device-scope atomics
+};
+
+struct PgGroupCol {
+  const uint8_t* data;   // fixed-bit dictIds
+  int64_t mult;          // prod of the cardinalities of the previous group columns (col 0 least significant)
+  int32_t bits;
+  int32_t pad;
+};
+
+struct PgValueSrc {
+  const uint8_t* data;
+  const void* dict;      // native-endian dictionary values (val_type) for dictionary columns, else null
+  int32_t col_kind;
+  int32_t bits;
+  int32_t val_type;
+  int32_t pad;
+};
+
+struct PgAccOp {
+  int32_t fn;         // PgAccFn
+  int32_t src;        // index into srcs, -1 for COUNT
+  int32_t is_float;   // accumulate as f64 (SUM) / ordered-key i64 (MIN, MAX)
+  int32_t pad;
+};
+
+struct PgQueryPlan {
+  int32_t num_docs;
+  int32_t n_tiles;
+  int32_t n_instr;
+  int32_t stack_depth;
+  const PgFInstr* instrs;
+  const PgScanLeaf* scans;
+  const PgPostingLeaf* postings;
+  const PgRangeLeaf* ranges;
+  // outputs of the filter stage
+  uint64_t* out_words;              // nullable: ceil(num_docs/64) match words (tile padded)
+  uint32_t* out_tile_counts;        // nullable: matches per tile
+  unsigned long long* stats;        // [PG_MAX_STATS]: slot 0 = matched docs, slots 1.. = candidates per AND_SCAN leaf
+  // aggregation stage
+  int32_t agg_mode;
+  int32_t n_group_cols;
+  int32_t n_srcs;
+  int32_t n_ops;
+  int32_t n_groups;                 // G = product of group cardinalities (1 without GROUP BY)
+  int32_t replicas;                 // R: LDS copies per group (power of two) to spread atomic conflicts
+  int32_t pad0, pad1;
+  PgGroupCol gcols[PG_MAX_GROUP_COLS];
+  PgValueSrc srcs[PG_MAX_SRCS];
+  PgAccOp ops[PG_MAX_OPS];
+  int64_t* partials;                // LDS/SINGLE mode: [gridDim][n_ops][G]; GLOBAL mode: [n_ops][G]
+};
+
+#if defined(__HIPCC__)
+#define PG_HD __host__ __device__
+#else
+#define PG_HD
+#endif
+PG_HD static inline int64_t pg_acc_identity(int32_t fn, int32_t is_float) {
+  // MIN/MAX on floats use order-preserving int64 keys, so the integer identities serve both
+  (void)is_float;
+  if (fn == PG_ACC_MIN) return INT64_MAX;
+  if (fn == PG_ACC_MAX) return INT64_MIN;
+  return 0;
+}

@@ -1,0 +1,327 @@
+// Execution: launches the segment query kernel(s) on the calling thread's stream and assembles results.
+//   GroupByOperator.getNextBlock / AggregationOperator.getNextBlock  (core/operator/query/GroupByOperator.java:100-140)
+//   ExecutionStatistics synthesis                                    (core/operator/query/GroupByOperator.java:148-153,
+//                                                                     core/operator/DocIdSetOperator.java:105-108)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+
+#include "pg_internal.hpp"
+
+extern "C" __global__ void pg_segment_query_kernel(const PgQueryPlan p);
+extern "C" __global__ void pg_reduce_partials_kernel(const int64_t* partials, int64_t* out, int n_wg, int n_ops,
+                                                     int n_groups, const PgAccOp* ops);
+extern "C" __global__ void pg_fill_i64_kernel(int64_t* dst, int64_t n_per_op, int n_ops, const PgAccOp* ops);
+extern "C" __global__ void pg_expand_docids_kernel(const uint64_t* words, const int64_t* tile_offsets, int32_t* out,
+                                                   int n_tiles);
+
+namespace pg {
+
+// ---- errors / device buffers ------------------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& m) { g_last_error = m; }
+const std::string& last_error() { return g_last_error; }
+void fail(int32_t status, const char* fmt, ...) {
+  char buf[2048];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  throw Error(status, buf);
+}
+
+void DeviceBuffer::alloc(size_t n, bool zero) {
+  release();
+  size = (n + 255) & ~(size_t)255;
+  PG_HIP(hipMalloc(&ptr, size));
+  if (zero) PG_HIP(hipMemset(ptr, 0, size));
+}
+void DeviceBuffer::release() {
+  if (ptr) (void)hipFree(ptr);
+  ptr = nullptr;
+  size = 0;
+}
+void DeviceBuffer::upload(const void* src, size_t n, size_t off) {
+  if (n == 0) return;
+  if (off + n > size) fail(PG_ERR_INTERNAL, "upload past the end of a device buffer");
+  PG_HIP(hipMemcpy(static_cast<uint8_t*>(ptr) + off, src, n, hipMemcpyHostToDevice));
+}
+
+// ---- device / per-thread context ------------------------------------------------------------------------------------------------
+static int g_device = -1;
+static int g_num_cus = 256;
+static size_t g_lds_per_cu = 160 * 1024;
+
+void device_init(int ordinal) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    fail(PG_ERR_DEVICE, "no HIP device available (%s): libpinot_gpu has no CPU fallback", hipGetErrorName(e));
+  if (ordinal < 0 || ordinal >= n) fail(PG_ERR_INVALID_ARGUMENT, "device ordinal %d out of range (0..%d)", ordinal, n - 1);
+  PG_HIP(hipSetDevice(ordinal));
+  hipDeviceProp_t prop;
+  PG_HIP(hipGetDeviceProperties(&prop, ordinal));
+  g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  g_lds_per_cu = prop.maxSharedMemoryPerMultiProcessor > 0 ? (size_t)prop.maxSharedMemoryPerMultiProcessor : 160 * 1024;
+  g_device = ordinal;
+  // opt in to large dynamic LDS for the query kernel
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pg_segment_query_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+}
+
+struct ThreadCtx {
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  DeviceBuffer stats, partials, final_table, tile_counts;
+  ~ThreadCtx() {
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+  void ensure() {
+    if (g_device < 0) device_init(0);
+    PG_HIP(hipSetDevice(g_device));
+    if (!stream) {
+      PG_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+      for (auto& e : ev) PG_HIP(hipEventCreate(&e));
+      stats.alloc(PG_MAX_STATS * 8, true);
+    }
+  }
+  static void grow(DeviceBuffer& b, size_t n) { if (b.size < n) b.alloc(n + n / 4); }
+};
+static thread_local ThreadCtx t_ctx;
+
+static double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static std::shared_ptr<CompiledPlan> get_plan(Segment& seg, const pg_filter_node* filter, const pg_query* q) {
+  std::string sig = query_signature(filter, q);
+  {
+    std::lock_guard<std::mutex> g(seg.mu);
+    auto it = seg.plan_cache.find(sig);
+    if (it != seg.plan_cache.end()) return it->second;
+  }
+  auto plan = compile_plan(seg, filter, q);
+  std::lock_guard<std::mutex> g(seg.mu);
+  if (seg.plan_cache.size() > 256) seg.plan_cache.clear();
+  seg.plan_cache[sig] = plan;
+  return plan;
+}
+
+struct LaunchShape { int grid; size_t lds; };
+static LaunchShape launch_shape(const CompiledPlan& P, int n_tiles) {
+  size_t lds = P.lds_bytes + 64;
+  int per_cu = (int)std::min<size_t>(8, std::max<size_t>(1, (g_lds_per_cu - 1024) / (lds + 128)));
+  if (per_cu > 6) per_cu = 6;
+  int grid = std::min(n_tiles, g_num_cus * per_cu);
+  return {std::max(grid, 1), lds};
+}
+
+static void fill_stats(pg_exec_stats& st, const CompiledPlan& P, const Segment& seg, const uint64_t* stats_host) {
+  st.num_docs_scanned = (int64_t)stats_host[0];
+  int64_t in_filter = P.full_scan_entries;
+  for (int i = 1; i < P.n_stat_slots; i++) in_filter += (int64_t)stats_host[i];
+  st.num_entries_scanned_in_filter = in_filter;
+  st.num_entries_scanned_post_filter = st.num_docs_scanned * P.n_projected_columns;
+  st.num_total_docs = seg.total_docs;
+  st.stats_exact = P.stats_exact ? 1 : 0;
+  st.algorithmic_bytes = P.algorithmic_bytes;
+}
+
+static double order_key_to_double(int64_t k) {
+  int64_t b = k ^ ((k >> 63) & 0x7FFFFFFFFFFFFFFFLL);
+  double d;
+  memcpy(&d, &b, 8);
+  return d;
+}
+
+std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
+  const double t0 = now_ms();
+  if (q.n_aggregations <= 0 || !q.aggregations) fail(PG_ERR_INVALID_ARGUMENT, "query has no aggregation");
+  ThreadCtx& ctx = t_ctx;
+  ctx.ensure();
+  auto plan = get_plan(seg, q.filter, &q);
+  CompiledPlan& P = *plan;
+  const double t_plan = now_ms();
+  const bool profile = (q.flags & PG_QUERY_FLAG_PROFILE) != 0;
+
+  PgQueryPlan D = P.dev;
+  const LaunchShape shape = launch_shape(P, seg.n_tiles);
+  const int64_t n_out = (int64_t)D.n_ops * D.n_groups;
+  PG_HIP(hipMemsetAsync(ctx.stats.ptr, 0, PG_MAX_STATS * 8, ctx.stream));
+  D.stats = ctx.stats.as<unsigned long long>();
+  ThreadCtx::grow(ctx.final_table, (size_t)n_out * 8);
+  if (D.agg_mode == PG_AGG_GLOBAL) {
+    D.partials = ctx.final_table.as<int64_t>();
+    int blocks = (int)((n_out + 255) / 256);
+    hipLaunchKernelGGL(pg_fill_i64_kernel, dim3(blocks), dim3(256), 0, ctx.stream, D.partials, (int64_t)D.n_groups,
+                       D.n_ops, P.ops_dev.as<PgAccOp>());
+  } else {
+    ThreadCtx::grow(ctx.partials, (size_t)n_out * 8 * (size_t)shape.grid);
+    D.partials = ctx.partials.as<int64_t>();
+  }
+  if (profile) PG_HIP(hipEventRecord(ctx.ev[0], ctx.stream));
+  if (seg.total_docs > 0) {
+    hipLaunchKernelGGL(pg_segment_query_kernel, dim3(shape.grid), dim3(PG_BLOCK), shape.lds, ctx.stream, D);
+    PG_HIP(hipGetLastError());
+  }
+  if (profile) PG_HIP(hipEventRecord(ctx.ev[1], ctx.stream));
+  std::vector<int64_t> table((size_t)n_out);
+  if (seg.total_docs > 0) {
+    if (D.agg_mode != PG_AGG_GLOBAL) {
+      int blocks = (int)((n_out + 255) / 256);
+      hipLaunchKernelGGL(pg_reduce_partials_kernel, dim3(blocks), dim3(256), 0, ctx.stream, ctx.partials.as<int64_t>(),
+                         ctx.final_table.as<int64_t>(), shape.grid, D.n_ops, D.n_groups, P.ops_dev.as<PgAccOp>());
+      PG_HIP(hipGetLastError());
+    }
+    if (profile) PG_HIP(hipEventRecord(ctx.ev[2], ctx.stream));
+    PG_HIP(hipMemcpyAsync(table.data(), ctx.final_table.ptr, (size_t)n_out * 8, hipMemcpyDeviceToHost, ctx.stream));
+  } else {
+    if (profile) PG_HIP(hipEventRecord(ctx.ev[2], ctx.stream));
+    for (int o = 0; o < D.n_ops; o++)
+      for (int64_t g = 0; g < D.n_groups; g++) table[(size_t)(o * (int64_t)D.n_groups + g)] = pg_acc_identity(D.ops[o].fn, D.ops[o].is_float);
+  }
+  uint64_t stats_host[PG_MAX_STATS];
+  PG_HIP(hipMemcpyAsync(stats_host, ctx.stats.ptr, sizeof(stats_host), hipMemcpyDeviceToHost, ctx.stream));
+  PG_HIP(hipStreamSynchronize(ctx.stream));
+
+  auto res = std::make_unique<Result>();
+  fill_stats(res->stats, P, seg, stats_host);
+  if (profile) {
+    float a = 0, b = 0;
+    PG_HIP(hipEventElapsedTime(&a, ctx.ev[0], ctx.ev[1]));
+    PG_HIP(hipEventElapsedTime(&b, ctx.ev[1], ctx.ev[2]));
+    res->stats.device_ms_aggregate = a;
+    res->stats.device_ms_filter = 0;
+    res->stats.device_ms_reduce = b;
+    res->stats.device_ms_total = a + b;
+  }
+
+  // ---- assemble groups: a group exists iff its hidden COUNT is > 0 (ArrayBasedHolder flags / map entries) ----------------
+  const int64_t G = D.n_groups;
+  int count_op = 0;
+  for (int o = 0; o < D.n_ops; o++) if (D.ops[o].fn == PG_ACC_COUNT) count_op = o;
+  const int64_t* cnt = table.data() + (size_t)count_op * G;
+  std::vector<int64_t> gids;
+  if (q.n_group_by == 0) gids.push_back(0);
+  else for (int64_t g = 0; g < G; g++) if (cnt[g] > 0) gids.push_back(g);
+  const int32_t ng = (int32_t)gids.size();
+  res->num_groups = ng;
+  res->group_dict_ids.resize((size_t)q.n_group_by);
+  for (int j = 0; j < q.n_group_by; j++) {
+    auto& v = res->group_dict_ids[j];
+    v.resize((size_t)ng);
+    int64_t mult = D.gcols[j].mult;
+    int32_t card = P.group_cards[j];
+    for (int32_t i = 0; i < ng; i++) v[i] = (int32_t)((gids[i] / mult) % card);   // getKeys: col 0 least significant
+  }
+  if (q.n_group_by > 0) res->stats.num_groups_limit_reached = ng >= P.num_groups_limit ? 1 : 0;
+
+  auto op_double = [&](int o, int64_t g) -> double {
+    const PgAccOp& op = D.ops[o];
+    int64_t v = table[(size_t)o * G + g];
+    const bool empty = cnt[g] == 0;
+    switch (op.fn) {
+      case PG_ACC_COUNT: return (double)v;
+      case PG_ACC_SUM:
+        if (op.is_float) { double d; memcpy(&d, &v, 8); return d; }
+        return (double)v;
+      case PG_ACC_MIN:
+        if (empty) return INFINITY;    // MinAggregationFunction default holder value
+        return op.is_float ? order_key_to_double(v) : (double)v;
+      default:
+        if (empty) return -INFINITY;   // MaxAggregationFunction.java:37
+        return op.is_float ? order_key_to_double(v) : (double)v;
+    }
+  };
+  res->aggs.resize((size_t)q.n_aggregations);
+  for (int a = 0; a < q.n_aggregations; a++) {
+    const AggOut& ao = P.aggs[a];
+    AggResult& r = res->aggs[a];
+    for (int k = 0; k < 2; k++) { r.d[k].assign((size_t)ng, 0.0); r.l[k].assign((size_t)ng, 0); }
+    switch (ao.function) {
+      case PG_AGG_COUNT:
+        r.kind = PG_RESULT_LONG;
+        for (int32_t i = 0; i < ng; i++) r.l[0][i] = table[(size_t)ao.op_a * G + gids[i]];
+        break;
+      case PG_AGG_AVG:
+        r.kind = PG_RESULT_AVG_PAIR;
+        for (int32_t i = 0; i < ng; i++) { r.d[0][i] = op_double(ao.op_a, gids[i]); r.l[0][i] = table[(size_t)ao.op_b * G + gids[i]]; }
+        break;
+      case PG_AGG_MINMAXRANGE:
+        r.kind = PG_RESULT_MINMAX_PAIR;
+        for (int32_t i = 0; i < ng; i++) { r.d[0][i] = op_double(ao.op_a, gids[i]); r.d[1][i] = op_double(ao.op_b, gids[i]); }
+        break;
+      default:
+        r.kind = PG_RESULT_DOUBLE;
+        for (int32_t i = 0; i < ng; i++) r.d[0][i] = op_double(ao.op_a, gids[i]);
+        break;
+    }
+  }
+  res->stats.host_ms_plan = (float)(t_plan - t0);
+  res->stats.host_ms_total = (float)(now_ms() - t0);
+  return res;
+}
+
+std::unique_ptr<DocIdSet> execute_filter(Segment& seg, const pg_filter_node* filter) {
+  const double t0 = now_ms();
+  ThreadCtx& ctx = t_ctx;
+  ctx.ensure();
+  auto plan = get_plan(seg, filter, nullptr);
+  CompiledPlan& P = *plan;
+  auto out = std::make_unique<DocIdSet>();
+  out->num_docs = seg.total_docs;
+  const size_t n_words = (size_t)std::max(seg.n_tiles, 1) * PG_TILE_WORDS;
+  out->words.alloc(n_words * 8, true);
+  out->tile_counts.assign((size_t)std::max(seg.n_tiles, 1), 0);
+  ThreadCtx::grow(ctx.tile_counts, out->tile_counts.size() * 4);
+  PG_HIP(hipMemsetAsync(ctx.tile_counts.ptr, 0, out->tile_counts.size() * 4, ctx.stream));
+  PG_HIP(hipMemsetAsync(ctx.stats.ptr, 0, PG_MAX_STATS * 8, ctx.stream));
+  PgQueryPlan D = P.dev;
+  D.stats = ctx.stats.as<unsigned long long>();
+  D.out_words = out->words.as<uint64_t>();
+  D.out_tile_counts = ctx.tile_counts.as<uint32_t>();
+  D.agg_mode = PG_AGG_NONE;
+  const LaunchShape shape = launch_shape(P, seg.n_tiles);
+  PG_HIP(hipEventRecord(ctx.ev[0], ctx.stream));
+  if (seg.total_docs > 0) {
+    hipLaunchKernelGGL(pg_segment_query_kernel, dim3(shape.grid), dim3(PG_BLOCK), shape.lds, ctx.stream, D);
+    PG_HIP(hipGetLastError());
+  }
+  PG_HIP(hipEventRecord(ctx.ev[1], ctx.stream));
+  uint64_t stats_host[PG_MAX_STATS];
+  PG_HIP(hipMemcpyAsync(stats_host, ctx.stats.ptr, sizeof(stats_host), hipMemcpyDeviceToHost, ctx.stream));
+  PG_HIP(hipMemcpyAsync(out->tile_counts.data(), ctx.tile_counts.ptr, out->tile_counts.size() * 4, hipMemcpyDeviceToHost, ctx.stream));
+  PG_HIP(hipStreamSynchronize(ctx.stream));
+  fill_stats(out->stats, P, seg, stats_host);
+  out->stats.num_entries_scanned_post_filter = 0;
+  out->cardinality = (int64_t)stats_host[0];
+  float ms = 0;
+  PG_HIP(hipEventElapsedTime(&ms, ctx.ev[0], ctx.ev[1]));
+  out->stats.device_ms_filter = ms;
+  out->stats.device_ms_total = ms;
+  out->stats.host_ms_total = (float)(now_ms() - t0);
+  return out;
+}
+
+void docidset_copy_docids(DocIdSet& s, int32_t* out, int64_t cap) {
+  if (cap < s.cardinality) fail(PG_ERR_INVALID_ARGUMENT, "capacity %lld < cardinality %lld", (long long)cap, (long long)s.cardinality);
+  if (s.cardinality == 0) return;
+  ThreadCtx& ctx = t_ctx;
+  ctx.ensure();
+  const int n_tiles = (int)s.tile_counts.size();
+  std::vector<int64_t> offs((size_t)n_tiles + 1, 0);
+  for (int i = 0; i < n_tiles; i++) offs[(size_t)i + 1] = offs[i] + s.tile_counts[i];
+  DeviceBuffer d_offs = upload_vector(offs);
+  DeviceBuffer d_out((size_t)s.cardinality * 4);
+  int grid = std::min(n_tiles, g_num_cus * 8);
+  hipLaunchKernelGGL(pg_expand_docids_kernel, dim3(grid), dim3(PG_BLOCK), 0, ctx.stream, s.words.as<uint64_t>(),
+                     d_offs.as<int64_t>(), d_out.as<int32_t>(), n_tiles);
+  PG_HIP(hipGetLastError());
+  PG_HIP(hipMemcpyAsync(out, d_out.ptr, (size_t)s.cardinality * 4, hipMemcpyDeviceToHost, ctx.stream));
+  PG_HIP(hipStreamSynchronize(ctx.stream));
+}
+
+}  // namespace pg

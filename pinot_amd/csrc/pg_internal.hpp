@@ -1,0 +1,191 @@
+// Host-side internals of libpinot_gpu.so (below the C ABI in include/pinot_gpu.h).
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/pinot_gpu.h"
+#include "pg_device.h"
+
+namespace pg {
+
+// ---- errors ------------------------------------------------------------------------------------------------------------
+struct Error : std::runtime_error {
+  int32_t status;
+  Error(int32_t s, const std::string& m) : std::runtime_error(m), status(s) {}
+};
+[[noreturn]] void fail(int32_t status, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+void set_last_error(const std::string& msg);
+const std::string& last_error();
+
+#define PG_HIP(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess)                                                                              \
+      ::pg::fail(_e == hipErrorOutOfMemory ? PG_ERR_OUT_OF_MEMORY : PG_ERR_DEVICE, "HIP error %s at %s:%d: %s", \
+                 hipGetErrorName(_e), __FILE__, __LINE__, #expr);                                      \
+  } while (0)
+
+// ---- device memory -------------------------------------------------------------------------------------------------------
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  size_t size = 0;
+  DeviceBuffer() = default;
+  explicit DeviceBuffer(size_t n, bool zero = false) { alloc(n, zero); }
+  DeviceBuffer(const DeviceBuffer&) = delete;
+  DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+  DeviceBuffer(DeviceBuffer&& o) noexcept : ptr(o.ptr), size(o.size) { o.ptr = nullptr; o.size = 0; }
+  DeviceBuffer& operator=(DeviceBuffer&& o) noexcept {
+    if (this != &o) { release(); ptr = o.ptr; size = o.size; o.ptr = nullptr; o.size = 0; }
+    return *this;
+  }
+  ~DeviceBuffer() { release(); }
+  void alloc(size_t n, bool zero = false);
+  void release();
+  void upload(const void* src, size_t n, size_t dst_off = 0);
+  template <typename T> T* as() const { return reinterpret_cast<T*>(ptr); }
+};
+template <typename T>
+DeviceBuffer upload_vector(const std::vector<T>& v) {
+  DeviceBuffer b(v.empty() ? sizeof(T) : v.size() * sizeof(T));
+  if (!v.empty()) b.upload(v.data(), v.size() * sizeof(T));
+  return b;
+}
+
+// ---- segment ----------------------------------------------------------------------------------------------------------------
+struct Column {
+  std::string name;
+  int32_t data_type = 0;
+  int32_t fwd_encoding = 0;
+  bool has_dictionary = false;
+  int32_t cardinality = 0;
+  int32_t bits = 0;
+  bool is_sorted = false;
+  int32_t dict_bytes_per_value = 0;
+  // host copies needed by the planner
+  std::vector<uint8_t> dict_host;               // big-endian dictionary bytes (binary search, as the reference does)
+  std::vector<int32_t> sorted_start, sorted_end; // SortedIndexReaderImpl pairs
+  // device
+  int32_t col_kind = PG_COL_FIXED_BIT;          // layout the kernels see
+  int32_t val_type = PG_V_I32;
+  DeviceBuffer fwd_dev;                         // doc 0 at offset 0, padded to whole tiles
+  DeviceBuffer dict_dev;                        // native-endian values
+  // inverted index (BitmapInvertedIndexReader): containers re-laid out 16-byte aligned
+  bool has_inverted = false;
+  std::vector<PgContainer> descs_host;
+  std::vector<uint32_t> posting_begin;          // cardinality + 1 offsets into descs_host
+  DeviceBuffer containers_dev, descs_dev;
+  uint64_t fwd_bytes_logical = 0;               // bytes of the forward index proper (for algorithmic byte accounting)
+};
+
+struct CompiledPlan;
+
+struct Segment {
+  std::string name;
+  int32_t total_docs = 0;
+  int32_t n_tiles = 0;
+  std::map<std::string, std::unique_ptr<Column>> columns;
+  uint64_t device_bytes = 0;
+  std::mutex mu;
+  std::unordered_map<std::string, std::shared_ptr<CompiledPlan>> plan_cache;
+  Column* find(const char* name);
+};
+
+void segment_add_column(Segment& seg, const pg_column_desc& d);
+
+// ---- predicate evaluation (host): PredicateEvaluatorProvider & factories ---------------------------------------------------
+struct PredEval {
+  int32_t pred_type = 0;
+  bool dictionary_based = false;
+  bool always_true = false, always_false = false;
+  bool exclusive = false;
+  // dictionary based
+  bool is_range = false;
+  int32_t start_dict_id = 0, end_dict_id = 0;   // [start, end)
+  std::vector<uint8_t> match;                   // per dictId
+  std::vector<int32_t> matching, non_matching;  // ascending
+  // raw based
+  int32_t data_type = 0;
+  int64_t lo_i = 0, hi_i = 0;
+  double lo_d = 0, hi_d = 0;
+  std::vector<int64_t> set_i;
+  std::vector<double> set_d;
+};
+PredEval make_pred_eval(const pg_filter_node& p, const Column& col);
+
+// ---- compiled plan ------------------------------------------------------------------------------------------------------------
+enum class OpKind { Empty, MatchAll, Scan, Inverted, Sorted, And, Or, Not };
+
+struct FilterOp {
+  OpKind kind = OpKind::Empty;
+  PredEval eval;
+  Column* col = nullptr;
+  std::vector<std::unique_ptr<FilterOp>> children;
+};
+
+enum class ResultKind { Long, Double, AvgPair, MinMaxPair };
+
+struct AggOut {          // how one requested aggregation maps onto accumulator ops
+  int32_t function;
+  int32_t op_a = -1, op_b = -1;   // indices into ops (AVG: sum,count; MINMAXRANGE: min,max; COUNT: count op)
+  bool is_float = false;
+};
+
+struct CompiledPlan {
+  PgQueryPlan dev{};                 // template; per-execution pointers are patched in
+  std::vector<DeviceBuffer> keep;    // device allocations referenced by dev
+  int32_t n_stat_slots = 1;
+  int64_t full_scan_entries = 0;     // entries contributed by unmasked scans whose count is known (numDocs each)
+  bool stats_exact = true;
+  bool always_empty = false;
+  int32_t n_projected_columns = 0;
+  int64_t algorithmic_bytes = 0;
+  // aggregation
+  std::vector<AggOut> aggs;
+  std::vector<Column*> group_cols;
+  std::vector<int32_t> group_cards;
+  size_t lds_bytes = 0;
+  int32_t num_groups_limit = 0;
+  DeviceBuffer ops_dev;
+};
+
+std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* filter, const pg_query* query);
+std::string query_signature(const pg_filter_node* filter, const pg_query* query);
+
+// ---- results --------------------------------------------------------------------------------------------------------------------
+struct AggResult {
+  int32_t kind = PG_RESULT_DOUBLE;
+  std::vector<double> d[2];
+  std::vector<int64_t> l[2];
+};
+struct Result {
+  int32_t num_groups = 0;
+  std::vector<std::vector<int32_t>> group_dict_ids;
+  std::vector<AggResult> aggs;
+  pg_exec_stats stats{};
+};
+struct DocIdSet {
+  int32_t num_docs = 0;
+  int64_t cardinality = 0;
+  DeviceBuffer words;          // tile padded
+  std::vector<uint32_t> tile_counts;
+  pg_exec_stats stats{};
+};
+
+// execution (pg_exec.hip)
+void device_init(int ordinal);
+std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q);
+std::unique_ptr<DocIdSet> execute_filter(Segment& seg, const pg_filter_node* filter);
+void docidset_copy_docids(DocIdSet& s, int32_t* out, int64_t cap);
+
+}  // namespace pg

@@ -1,0 +1,664 @@
+// Query planning on the host: FilterContext → physical filter operators → tile filter program + aggregation plan.
+//
+// Mirrors (all under pinot-core/src/main/java/org/apache/pinot/core/):
+//   plan/FilterPlanNode.java:88-106,195-320                      constructPhysicalOperator
+//   operator/filter/FilterOperatorUtils.java:74-133              leaf selection Sorted > Inverted > Scan (RANGE skips inverted)
+//   operator/filter/FilterOperatorUtils.java:136-252             AND child pruning + priority reordering
+//   operator/filter/predicate/*PredicateEvaluatorFactory.java    dictionary → dictId sets / [start,end); raw → inclusive bounds
+//   operator/docidsets/AndDocIdSet.java:72-186                   index-based children first, then scans restricted to the
+//                                                                surviving candidates (this is what PG_F_AND_SCAN does)
+//   query/aggregation/groupby/DictionaryBasedGroupKeyGenerator.java:106-185,312-354   raw key = Σ dictId_j · Π card_<j
+#include <algorithm>
+#include <cerrno>
+#include <cmath>
+#include <sstream>
+
+#include "pg_internal.hpp"
+
+namespace pg {
+
+// =====================================================================================================================
+// literal parsing (Integer.parseInt / Long.parseLong / Float.parseFloat / Double.parseDouble)
+// =====================================================================================================================
+static bool parse_i64(const char* s, int64_t lo, int64_t hi, int64_t* out) {
+  if (!s || !*s) return false;
+  const char* p = s;
+  if (*p == '-' || *p == '+') p++;
+  if (!*p) return false;
+  for (const char* q = p; *q; q++)
+    if (*q < '0' || *q > '9') return false;
+  errno = 0;
+  long long v = strtoll(s, nullptr, 10);
+  if (errno || v < lo || v > hi) return false;
+  *out = v;
+  return true;
+}
+static int64_t parse_int_or_fail(const char* s, bool is_long) {
+  int64_t v;
+  if (!parse_i64(s, is_long ? INT64_MIN : INT32_MIN, is_long ? INT64_MAX : INT32_MAX, &v))
+    fail(PG_ERR_INVALID_ARGUMENT, "NumberFormatException: For input string: \"%s\"", s ? s : "null");
+  return v;
+}
+static double parse_double_or_fail(const char* s) {
+  if (!s || !*s) fail(PG_ERR_INVALID_ARGUMENT, "NumberFormatException: empty String");
+  char* end = nullptr;
+  double v = strtod(s, &end);
+  if (end == s || *end) fail(PG_ERR_INVALID_ARGUMENT, "NumberFormatException: For input string: \"%s\"", s);
+  return v;
+}
+static float parse_float_or_fail(const char* s) {
+  if (!s || !*s) fail(PG_ERR_INVALID_ARGUMENT, "NumberFormatException: empty String");
+  char* end = nullptr;
+  float v = strtof(s, &end);
+  if (end == s || *end) fail(PG_ERR_INVALID_ARGUMENT, "NumberFormatException: For input string: \"%s\"", s);
+  return v;
+}
+
+static inline uint32_t be32(const uint8_t* p) {
+  return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+}
+static inline uint64_t be64(const uint8_t* p) { return ((uint64_t)be32(p) << 32) | be32(p + 4); }
+
+// Dictionary#insertionIndexOf: >= 0 when found, else -(insertionPoint + 1) (BaseImmutableDictionary.java:124-245)
+static int32_t dict_insertion_index(const Column& c, const char* sv) {
+  int32_t low = 0, high = c.cardinality - 1;
+  const uint8_t* d = c.dict_host.data();
+  auto search = [&](auto value, auto get) -> int32_t {
+    while (low <= high) {
+      int32_t mid = (int32_t)(((uint32_t)low + (uint32_t)high) >> 1);
+      auto mv = get(mid);
+      if (mv < value) low = mid + 1;
+      else if (mv > value) high = mid - 1;
+      else return mid;
+    }
+    return -(low + 1);
+  };
+  switch (c.data_type) {
+    case PG_TYPE_INT: {
+      int32_t v = (int32_t)parse_int_or_fail(sv, false);
+      return search(v, [&](int32_t i) { return (int32_t)be32(d + (size_t)i * 4); });
+    }
+    case PG_TYPE_LONG: {
+      int64_t v = parse_int_or_fail(sv, true);
+      return search(v, [&](int32_t i) { return (int64_t)be64(d + (size_t)i * 8); });
+    }
+    case PG_TYPE_FLOAT: {
+      float v = parse_float_or_fail(sv);
+      return search(v, [&](int32_t i) { uint32_t u = be32(d + (size_t)i * 4); float f; memcpy(&f, &u, 4); return f; });
+    }
+    case PG_TYPE_DOUBLE: {
+      double v = parse_double_or_fail(sv);
+      return search(v, [&](int32_t i) { uint64_t u = be64(d + (size_t)i * 8); double f; memcpy(&f, &u, 8); return f; });
+    }
+    default: {  // STRING / BYTES fixed-width entries padded with zeros; compare the unpadded bytes
+      const int w = c.dict_bytes_per_value;
+      const size_t slen = strlen(sv);
+      while (low <= high) {
+        int32_t mid = (int32_t)(((uint32_t)low + (uint32_t)high) >> 1);
+        const uint8_t* e = d + (size_t)mid * w;
+        size_t elen = (size_t)w;
+        while (elen > 0 && e[elen - 1] == 0) elen--;
+        size_t n = elen < slen ? elen : slen;
+        int cmp = memcmp(e, sv, n);
+        if (cmp == 0) cmp = elen == slen ? 0 : (elen < slen ? -1 : 1);
+        if (cmp < 0) low = mid + 1;
+        else if (cmp > 0) high = mid - 1;
+        else return mid;
+      }
+      return -(low + 1);
+    }
+  }
+}
+
+PredEval make_pred_eval(const pg_filter_node& p, const Column& col) {
+  PredEval e;
+  e.pred_type = p.predicate_type;
+  e.data_type = col.data_type;
+  const bool is_range = p.predicate_type == PG_PRED_RANGE;
+  if (!is_range && (p.n_values < 1 || !p.values)) fail(PG_ERR_INVALID_ARGUMENT, "predicate on %s has no value", col.name.c_str());
+  if (is_range && (!p.lower || !p.upper)) fail(PG_ERR_INVALID_ARGUMENT, "range predicate on %s without bounds", col.name.c_str());
+  if (col.has_dictionary) {
+    e.dictionary_based = true;
+    const int32_t card = col.cardinality;
+    e.match.assign((size_t)card, 0);
+    switch (p.predicate_type) {
+      case PG_PRED_EQ: {   // EqualsPredicateEvaluatorFactory.java:95-108
+        int32_t idx = dict_insertion_index(col, p.values[0]);
+        if (idx >= 0) { e.match[idx] = 1; if (card == 1) e.always_true = true; }
+        else e.always_false = true;
+        break;
+      }
+      case PG_PRED_NOT_EQ: {
+        int32_t idx = dict_insertion_index(col, p.values[0]);
+        std::fill(e.match.begin(), e.match.end(), 1);
+        e.exclusive = true;
+        if (idx >= 0) { e.match[idx] = 0; if (card == 1) e.always_false = true; }
+        else e.always_true = true;
+        break;
+      }
+      case PG_PRED_IN:
+      case PG_PRED_NOT_IN: {   // InPredicateEvaluatorFactory.java:158-171, NotInPredicateEvaluatorFactory.java:158-171
+        int32_t found = 0;
+        for (int i = 0; i < p.n_values; i++) {
+          int32_t idx = dict_insertion_index(col, p.values[i]);
+          if (idx >= 0 && !e.match[idx]) { e.match[idx] = 1; found++; }
+        }
+        if (p.predicate_type == PG_PRED_IN) {
+          if (found == 0) e.always_false = true;
+          else if (found == card) e.always_true = true;
+        } else {
+          for (auto& m : e.match) m = !m;
+          e.exclusive = true;
+          if (found == 0) e.always_true = true;
+          else if (found == card) e.always_false = true;
+        }
+        break;
+      }
+      case PG_PRED_RANGE: {   // SortedDictionaryBasedRangePredicateEvaluator, RangePredicateEvaluatorFactory.java:126-167
+        e.is_range = true;
+        if (strcmp(p.lower, PG_RANGE_UNBOUNDED) == 0) e.start_dict_id = 0;
+        else {
+          int32_t ins = dict_insertion_index(col, p.lower);
+          e.start_dict_id = ins < 0 ? -(ins + 1) : (p.lower_inclusive ? ins : ins + 1);
+        }
+        if (strcmp(p.upper, PG_RANGE_UNBOUNDED) == 0) e.end_dict_id = card;
+        else {
+          int32_t ins = dict_insertion_index(col, p.upper);
+          e.end_dict_id = ins < 0 ? -(ins + 1) : (p.upper_inclusive ? ins + 1 : ins);
+        }
+        int32_t n = std::max(e.end_dict_id - e.start_dict_id, 0);
+        if (n == 0) e.always_false = true;
+        else if (n == card) e.always_true = true;
+        for (int32_t d = e.start_dict_id; d < e.end_dict_id; d++) e.match[d] = 1;
+        break;
+      }
+      default: fail(PG_ERR_UNSUPPORTED, "predicate type %d", p.predicate_type);
+    }
+    for (int32_t d = 0; d < card; d++) (e.match[d] ? e.matching : e.non_matching).push_back(d);
+    return e;
+  }
+  // raw value based (RangePredicateEvaluatorFactory.java:68-117,331-380 and the Eq/In raw evaluators)
+  const int t = col.data_type;
+  if (t != PG_TYPE_INT && t != PG_TYPE_LONG && t != PG_TYPE_FLOAT && t != PG_TYPE_DOUBLE)
+    fail(PG_ERR_UNSUPPORTED, "raw predicate on column %s of type %d", col.name.c_str(), t);
+  if (is_range) {
+    const bool lo_unb = strcmp(p.lower, PG_RANGE_UNBOUNDED) == 0, hi_unb = strcmp(p.upper, PG_RANGE_UNBOUNDED) == 0;
+    const bool lo_inc = lo_unb || p.lower_inclusive, hi_inc = hi_unb || p.upper_inclusive;
+    if (t == PG_TYPE_INT || t == PG_TYPE_LONG) {
+      const bool is_long = t == PG_TYPE_LONG;
+      int64_t tmin = is_long ? INT64_MIN : INT32_MIN, tmax = is_long ? INT64_MAX : INT32_MAX;
+      int64_t lo = lo_unb ? tmin : parse_int_or_fail(p.lower, is_long);
+      int64_t hi = hi_unb ? tmax : parse_int_or_fail(p.upper, is_long);
+      if (!lo_inc) { if (lo == tmax) fail(PG_ERR_INVALID_ARGUMENT, "Invalid range"); lo += 1; }
+      if (!hi_inc) { if (hi == tmin) fail(PG_ERR_INVALID_ARGUMENT, "Invalid range"); hi -= 1; }
+      e.lo_i = lo; e.hi_i = hi;
+    } else if (t == PG_TYPE_FLOAT) {
+      float lo = lo_unb ? -INFINITY : parse_float_or_fail(p.lower);
+      float hi = hi_unb ? INFINITY : parse_float_or_fail(p.upper);
+      if (!lo_inc) lo = std::nextafter(lo, INFINITY);     // Math.nextUp
+      if (!hi_inc) hi = std::nextafter(hi, -INFINITY);    // Math.nextDown
+      e.lo_d = lo; e.hi_d = hi;
+    } else {
+      double lo = lo_unb ? -INFINITY : parse_double_or_fail(p.lower);
+      double hi = hi_unb ? INFINITY : parse_double_or_fail(p.upper);
+      if (!lo_inc) lo = std::nextafter(lo, (double)INFINITY);
+      if (!hi_inc) hi = std::nextafter(hi, -(double)INFINITY);
+      e.lo_d = lo; e.hi_d = hi;
+    }
+    return e;
+  }
+  e.exclusive = (p.predicate_type == PG_PRED_NOT_EQ || p.predicate_type == PG_PRED_NOT_IN);
+  for (int i = 0; i < p.n_values; i++) {
+    if (t == PG_TYPE_INT) e.set_i.push_back(parse_int_or_fail(p.values[i], false));
+    else if (t == PG_TYPE_LONG) e.set_i.push_back(parse_int_or_fail(p.values[i], true));
+    else if (t == PG_TYPE_FLOAT) e.set_d.push_back((double)parse_float_or_fail(p.values[i]));
+    else e.set_d.push_back(parse_double_or_fail(p.values[i]));
+  }
+  return e;
+}
+
+// =====================================================================================================================
+// physical filter operators
+// =====================================================================================================================
+using OpPtr = std::unique_ptr<FilterOp>;
+static OpPtr make_op(OpKind k) { auto o = std::make_unique<FilterOp>(); o->kind = k; return o; }
+
+static int priority(const FilterOp& op) {   // PrioritizedFilterOperator.java:31-38
+  switch (op.kind) {
+    case OpKind::Sorted: return 0;
+    case OpKind::Inverted: return 100;
+    case OpKind::And: return 300;
+    case OpKind::Or: return 400;
+    case OpKind::Not: return priority(*op.children[0]);
+    case OpKind::Scan: return 500;
+    default: return 10000;
+  }
+}
+
+static OpPtr and_operator(std::vector<OpPtr> ops) {   // getAndFilterOperator
+  std::vector<OpPtr> ch;
+  for (auto& o : ops) {
+    if (o->kind == OpKind::Empty) return make_op(OpKind::Empty);
+    if (o->kind != OpKind::MatchAll) ch.push_back(std::move(o));
+  }
+  if (ch.empty()) return make_op(OpKind::MatchAll);
+  if (ch.size() == 1) return std::move(ch[0]);
+  std::stable_sort(ch.begin(), ch.end(), [](const OpPtr& a, const OpPtr& b) { return priority(*a) < priority(*b); });
+  auto r = make_op(OpKind::And);
+  r->children = std::move(ch);
+  return r;
+}
+static OpPtr or_operator(std::vector<OpPtr> ops) {    // getOrFilterOperator
+  std::vector<OpPtr> ch;
+  for (auto& o : ops) {
+    if (o->kind == OpKind::MatchAll) return make_op(OpKind::MatchAll);
+    if (o->kind != OpKind::Empty) ch.push_back(std::move(o));
+  }
+  if (ch.empty()) return make_op(OpKind::Empty);
+  if (ch.size() == 1) return std::move(ch[0]);
+  auto r = make_op(OpKind::Or);
+  r->children = std::move(ch);
+  return r;
+}
+static OpPtr not_operator(OpPtr child) {              // getNotFilterOperator
+  if (child->kind == OpKind::MatchAll) return make_op(OpKind::Empty);
+  if (child->kind == OpKind::Empty) return make_op(OpKind::MatchAll);
+  auto r = make_op(OpKind::Not);
+  r->children.push_back(std::move(child));
+  return r;
+}
+
+static OpPtr construct(Segment& seg, const pg_filter_node& f) {   // FilterPlanNode#constructPhysicalOperator
+  switch (f.type) {
+    case PG_FILTER_AND:
+    case PG_FILTER_OR: {
+      if (f.n_children < 1 || !f.children) fail(PG_ERR_INVALID_ARGUMENT, "AND/OR without children");
+      std::vector<OpPtr> ch;
+      for (int i = 0; i < f.n_children; i++) ch.push_back(construct(seg, f.children[i]));
+      return f.type == PG_FILTER_AND ? and_operator(std::move(ch)) : or_operator(std::move(ch));
+    }
+    case PG_FILTER_NOT:
+      if (f.n_children != 1 || !f.children) fail(PG_ERR_INVALID_ARGUMENT, "NOT needs exactly one child");
+      return not_operator(construct(seg, f.children[0]));
+    case PG_FILTER_PREDICATE: {
+      Column* col = seg.find(f.column);
+      if (!col) fail(PG_ERR_NOT_FOUND, "column not found: %s", f.column ? f.column : "(null)");
+      PredEval ev = make_pred_eval(f, *col);
+      if (ev.always_false) return make_op(OpKind::Empty);     // getLeafFilterOperator :77-90
+      if (ev.always_true) return make_op(OpKind::MatchAll);
+      const bool sorted_ok = col->is_sorted && col->has_dictionary && !col->sorted_start.empty();
+      OpKind k;
+      if (f.predicate_type == PG_PRED_RANGE) k = sorted_ok ? OpKind::Sorted : OpKind::Scan;
+      else k = sorted_ok ? OpKind::Sorted : (col->has_inverted ? OpKind::Inverted : OpKind::Scan);
+      auto op = make_op(k);
+      op->eval = std::move(ev);
+      op->col = col;
+      return op;
+    }
+    case PG_FILTER_CONSTANT_TRUE: return make_op(OpKind::MatchAll);
+    case PG_FILTER_CONSTANT_FALSE: return make_op(OpKind::Empty);
+    default: fail(PG_ERR_INVALID_ARGUMENT, "bad filter node type %d", f.type);
+  }
+}
+
+// =====================================================================================================================
+// program emission
+// =====================================================================================================================
+struct Emitter {
+  Segment& seg;
+  CompiledPlan& plan;
+  std::vector<PgFInstr> instrs;
+  std::vector<PgScanLeaf> scans;
+  std::vector<PgPostingLeaf> postings;
+  std::vector<PgRangeLeaf> ranges;
+  int sp = 0, max_sp = 0;
+  int64_t alg_bytes = 0;
+  std::vector<Column*> scanned_cols;
+
+  void push() { sp++; max_sp = std::max(max_sp, sp); }
+  template <typename T> const T* keep(const std::vector<T>& v) {
+    plan.keep.push_back(upload_vector(v));
+    return plan.keep.back().as<T>();
+  }
+
+  void emit_ranges(std::vector<int32_t> lo, std::vector<int32_t> hi) {
+    PgRangeLeaf L{};
+    L.n = (int32_t)lo.size();
+    L.lo = keep(lo);
+    L.hi = keep(hi);
+    ranges.push_back(L);
+    instrs.push_back({PG_F_PUSH_RANGES, (int32_t)ranges.size() - 1});
+    push();
+  }
+
+  // SortedIndexBasedFilterOperator#getTrues (operator/filter/SortedIndexBasedFilterOperator.java:57-130)
+  void emit_sorted(const FilterOp& op) {
+    const Column& c = *op.col;
+    const PredEval& e = op.eval;
+    std::vector<int32_t> lo, hi;
+    if (e.is_range) {
+      lo.push_back(c.sorted_start[e.start_dict_id]);
+      hi.push_back(c.sorted_end[e.end_dict_id - 1]);
+    } else {
+      const std::vector<int32_t>& ids = e.exclusive ? e.non_matching : e.matching;
+      std::vector<int32_t> rl, rh;
+      for (int32_t id : ids) {
+        int32_t s = c.sorted_start[id], en = c.sorted_end[id];
+        if (!rl.empty() && s == rh.back() + 1) rh.back() = en;
+        else { rl.push_back(s); rh.push_back(en); }
+      }
+      if (!e.exclusive) { lo = rl; hi = rh; }
+      else {
+        if (rl[0] > 0) { lo.push_back(0); hi.push_back(rl[0] - 1); }
+        for (size_t i = 0; i + 1 < rl.size(); i++) { lo.push_back(rh[i] + 1); hi.push_back(rl[i + 1] - 1); }
+        if (rh.back() < seg.total_docs - 1) { lo.push_back(rh.back() + 1); hi.push_back(seg.total_docs - 1); }
+      }
+    }
+    emit_ranges(std::move(lo), std::move(hi));
+  }
+
+  // InvertedIndexFilterOperator (operator/filter/InvertedIndexFilterOperator.java:60-96): OR of the posting lists of the
+  // (non-)matching dictIds, flipped over [0, numDocs) when exclusive
+  void emit_inverted(const FilterOp& op) {
+    Column& c = *op.col;
+    const PredEval& e = op.eval;
+    const std::vector<int32_t>& ids = e.exclusive ? e.non_matching : e.matching;
+    const int32_t n_chunks = (seg.n_tiles + PG_TILES_PER_CHUNK - 1) / PG_TILES_PER_CHUNK;
+    std::vector<uint32_t> chunk_start((size_t)n_chunks + 2, 0);
+    for (int32_t id : ids)
+      for (uint32_t k = c.posting_begin[id]; k < c.posting_begin[id + 1]; k++) chunk_start[c.descs_host[k].key + 1]++;
+    for (size_t i = 1; i < chunk_start.size(); i++) chunk_start[i] += chunk_start[i - 1];
+    std::vector<uint32_t> chunk_desc(chunk_start.back());
+    std::vector<uint32_t> cursor(chunk_start.begin(), chunk_start.end() - 1);
+    for (int32_t id : ids)
+      for (uint32_t k = c.posting_begin[id]; k < c.posting_begin[id + 1]; k++) {
+        const PgContainer& pc = c.descs_host[k];
+        chunk_desc[cursor[pc.key]++] = k;
+        alg_bytes += pc.type == 1 ? 8192 : (pc.type == 0 ? 2 * (int64_t)pc.n : 4 * (int64_t)pc.n);
+      }
+    PgPostingLeaf L{};
+    L.containers = c.containers_dev.as<uint8_t>();
+    L.descs = c.descs_dev.as<PgContainer>();
+    L.chunk_start = keep(chunk_start);
+    L.chunk_desc = keep(chunk_desc);
+    L.exclusive = e.exclusive ? 1 : 0;
+    postings.push_back(L);
+    instrs.push_back({PG_F_PUSH_POSTINGS, (int32_t)postings.size() - 1});
+    push();
+  }
+
+  void emit_scan(const FilterOp& op, bool masked) {
+    Column& c = *op.col;
+    const PredEval& e = op.eval;
+    PgScanLeaf L{};
+    L.data = c.fwd_dev.as<uint8_t>();
+    L.col_kind = c.col_kind;
+    L.bits = c.bits;
+    L.val_type = c.val_type;
+    if (e.dictionary_based) {
+      if (e.is_range) { L.pred_kind = PG_P_RANGE; L.lo = e.start_dict_id; L.hi = e.end_dict_id - 1; }
+      else if (e.matching.size() == 1) { L.pred_kind = PG_P_RANGE; L.lo = L.hi = e.matching[0]; }
+      else {
+        L.pred_kind = PG_P_DICT_LUT;
+        std::vector<uint32_t> lut(((size_t)c.cardinality + 31) / 32 + 1, 0);
+        for (int32_t d : e.matching) lut[d >> 5] |= 1u << (d & 31);
+        L.lut = keep(lut);
+      }
+    } else if (e.pred_type == PG_PRED_RANGE) {
+      L.pred_kind = PG_P_RANGE;
+      if (c.val_type == PG_V_I32 || c.val_type == PG_V_I64) { L.lo = e.lo_i; L.hi = e.hi_i; }
+      else { memcpy(&L.lo, &e.lo_d, 8); memcpy(&L.hi, &e.hi_d, 8); }
+    } else {
+      L.pred_kind = PG_P_SET;
+      L.exclusive = e.exclusive ? 1 : 0;
+      if (c.val_type == PG_V_I32 || c.val_type == PG_V_I64) { L.n_set = (int32_t)e.set_i.size(); L.set_values = keep(e.set_i); }
+      else { L.n_set = (int32_t)e.set_d.size(); L.set_values = keep(e.set_d); }
+    }
+    if (masked) {
+      if (plan.n_stat_slots >= PG_MAX_STATS) fail(PG_ERR_UNSUPPORTED, "more than %d restricted scans in one filter", PG_MAX_STATS - 1);
+      L.stat_slot = plan.n_stat_slots++;
+    } else {
+      plan.full_scan_entries += seg.total_docs;
+    }
+    if (std::find(scanned_cols.begin(), scanned_cols.end(), &c) == scanned_cols.end()) {
+      scanned_cols.push_back(&c);
+      alg_bytes += (int64_t)c.fwd_bytes_logical;
+    }
+    scans.push_back(L);
+    instrs.push_back({masked ? PG_F_AND_SCAN : PG_F_PUSH_SCAN, (int32_t)scans.size() - 1});
+    if (!masked) push();
+  }
+
+  static bool has_scan(const FilterOp& op) {
+    if (op.kind == OpKind::Scan) return true;
+    for (auto& c : op.children) if (has_scan(*c)) return true;
+    return false;
+  }
+
+  void emit(const FilterOp& op, bool top_level) {
+    switch (op.kind) {
+      case OpKind::Empty: instrs.push_back({PG_F_PUSH_NONE, 0}); push(); break;
+      case OpKind::MatchAll: emit_ranges({0}, {seg.total_docs - 1}); break;
+      case OpKind::Sorted: emit_sorted(op); break;
+      case OpKind::Inverted: emit_inverted(op); break;
+      case OpKind::Scan: emit_scan(op, false); break;
+      case OpKind::Not:
+        emit(*op.children[0], false);
+        instrs.push_back({PG_F_NOT, 0});
+        if (has_scan(op)) plan.stats_exact = false;
+        break;
+      case OpKind::Or:
+        for (size_t i = 0; i < op.children.size(); i++) {
+          emit(*op.children[i], false);
+          if (i) { instrs.push_back({PG_F_OR, 0}); sp--; }
+        }
+        // OrDocIdIterator drains every scan child fully only when the OR itself is drained (top level)
+        if (!top_level && has_scan(op)) plan.stats_exact = false;
+        for (auto& c : op.children) if (c->kind != OpKind::Scan && has_scan(*c)) plan.stats_exact = false;
+        break;
+      case OpKind::And: {
+        // AndDocIdSet.iterator(): index-based children → bitmap; scans applyAnd() on the survivors in list order;
+        // the remaining (nested) children are intersected last.
+        std::vector<const FilterOp*> index_based, scan_based, remaining;
+        for (auto& c : op.children) {
+          if (c->kind == OpKind::Sorted || c->kind == OpKind::Inverted) index_based.push_back(c.get());
+          else if (c->kind == OpKind::Scan) scan_based.push_back(c.get());
+          else remaining.push_back(c.get());
+        }
+        bool first = true;
+        for (auto* c : index_based) {
+          emit(*c, false);
+          if (!first) { instrs.push_back({PG_F_AND, 0}); sp--; }
+          first = false;
+        }
+        if (index_based.empty()) plan.stats_exact = plan.stats_exact && scan_based.empty() && true;
+        for (auto* c : scan_based) {
+          if (first) {
+            emit_scan(*c, false);            // AndDocIdIterator leapfrog in the reference: counts are data dependent
+            plan.stats_exact = false;
+            first = false;
+          } else {
+            emit_scan(*c, true);
+          }
+        }
+        for (auto* c : remaining) {
+          emit(*c, false);
+          if (has_scan(*c)) plan.stats_exact = false;
+          if (!first) { instrs.push_back({PG_F_AND, 0}); sp--; }
+          first = false;
+        }
+        if (!top_level && has_scan(op)) plan.stats_exact = false;
+        break;
+      }
+    }
+  }
+};
+
+// =====================================================================================================================
+// signature (plan cache key)
+// =====================================================================================================================
+static void sig_filter(std::ostringstream& o, const pg_filter_node* f) {
+  if (!f) { o << "*"; return; }
+  o << "(" << f->type;
+  if (f->type == PG_FILTER_PREDICATE) {
+    o << ":" << f->predicate_type << ":" << (f->column ? f->column : "") << ":";
+    if (f->predicate_type == PG_PRED_RANGE)
+      o << (f->lower_inclusive ? "[" : "(") << (f->lower ? f->lower : "") << "," << (f->upper ? f->upper : "")
+        << (f->upper_inclusive ? "]" : ")");
+    else
+      for (int i = 0; i < f->n_values; i++) o << strlen(f->values[i]) << "'" << f->values[i] << ",";
+  }
+  for (int i = 0; i < f->n_children; i++) sig_filter(o, &f->children[i]);
+  o << ")";
+}
+std::string query_signature(const pg_filter_node* filter, const pg_query* q) {
+  std::ostringstream o;
+  sig_filter(o, filter);
+  if (q) {
+    o << "|g";
+    for (int i = 0; i < q->n_group_by; i++) o << ":" << q->group_by_columns[i];
+    o << "|a";
+    for (int i = 0; i < q->n_aggregations; i++)
+      o << ":" << q->aggregations[i].function << "," << (q->aggregations[i].column ? q->aggregations[i].column : "*") << ","
+        << q->aggregations[i].log2m;
+    o << "|" << q->num_groups_limit << "," << q->max_initial_result_holder_capacity;
+  } else {
+    o << "|filter-only";
+  }
+  return o.str();
+}
+
+// =====================================================================================================================
+// plan compilation
+// =====================================================================================================================
+static const int64_t kLdsTableBudget = 48 * 1024;       // bytes of LDS for the accumulator table
+static const int64_t kMaxDenseGroups = 64LL << 20;      // dense HBM table limit (groups)
+
+std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* filter, const pg_query* q) {
+  auto plan = std::make_shared<CompiledPlan>();
+  CompiledPlan& P = *plan;
+  Emitter em{seg, P};
+  OpPtr root = filter ? construct(seg, *filter) : make_op(OpKind::MatchAll);
+  if (root->kind == OpKind::Empty) P.always_empty = true;
+  em.emit(*root, true);
+  if (em.sp != 1) fail(PG_ERR_INTERNAL, "filter program leaves %d entries on the stack", em.sp);
+  if (em.max_sp > PG_MAX_STACK) fail(PG_ERR_UNSUPPORTED, "filter needs %d bitmap stack levels (max %d)", em.max_sp, PG_MAX_STACK);
+
+  PgQueryPlan& D = P.dev;
+  D.num_docs = seg.total_docs;
+  D.n_tiles = seg.n_tiles;
+  D.n_instr = (int32_t)em.instrs.size();
+  D.stack_depth = em.max_sp;
+  D.instrs = em.keep(em.instrs);
+  D.scans = em.keep(em.scans);
+  D.postings = em.keep(em.postings);
+  D.ranges = em.keep(em.ranges);
+  D.agg_mode = PG_AGG_NONE;
+  D.n_groups = 1;
+  D.replicas = 1;
+  P.algorithmic_bytes = em.alg_bytes;
+  P.lds_bytes = (size_t)D.stack_depth * PG_TILE_WORDS * 8;
+  if (!q || q->n_aggregations <= 0) return plan;
+
+  // ---- aggregation plan ------------------------------------------------------------------------------------------
+  P.num_groups_limit = q->num_groups_limit > 0 ? q->num_groups_limit : 100000;
+  if (q->n_group_by > PG_MAX_GROUP_COLS) fail(PG_ERR_UNSUPPORTED, "more than %d group-by columns", PG_MAX_GROUP_COLS);
+  std::vector<Column*> projected;
+  auto project = [&](Column* c) { if (std::find(projected.begin(), projected.end(), c) == projected.end()) projected.push_back(c); };
+  int64_t G = 1;
+  for (int j = 0; j < q->n_group_by; j++) {
+    Column* c = seg.find(q->group_by_columns[j]);
+    if (!c) fail(PG_ERR_NOT_FOUND, "column not found: %s", q->group_by_columns[j] ? q->group_by_columns[j] : "(null)");
+    if (!c->has_dictionary) fail(PG_ERR_UNSUPPORTED, "no-dictionary group-by column %s", c->name.c_str());
+    D.gcols[j].data = c->fwd_dev.as<uint8_t>();
+    D.gcols[j].bits = c->bits;
+    D.gcols[j].mult = G;
+    P.group_cols.push_back(c);
+    P.group_cards.push_back(c->cardinality);
+    if (G > kMaxDenseGroups / std::max(c->cardinality, 1)) fail(PG_ERR_UNSUPPORTED, "group key space too large for the dense GPU path");
+    G *= c->cardinality;
+    project(c);
+  }
+  D.n_group_cols = q->n_group_by;
+  D.n_groups = (int32_t)G;
+
+  std::vector<PgAccOp> ops;
+  std::vector<Column*> srcs;
+  auto src_index = [&](Column* c) {
+    for (size_t i = 0; i < srcs.size(); i++) if (srcs[i] == c) return (int32_t)i;
+    if (srcs.size() >= PG_MAX_SRCS) fail(PG_ERR_UNSUPPORTED, "more than %d aggregated columns", PG_MAX_SRCS);
+    srcs.push_back(c);
+    return (int32_t)srcs.size() - 1;
+  };
+  auto op_index = [&](int32_t fn, int32_t src, bool is_float) {
+    for (size_t i = 0; i < ops.size(); i++) if (ops[i].fn == fn && ops[i].src == src) return (int32_t)i;
+    if (ops.size() >= PG_MAX_OPS) fail(PG_ERR_UNSUPPORTED, "more than %d accumulators", PG_MAX_OPS);
+    ops.push_back({fn, src, is_float ? 1 : 0, 0});
+    return (int32_t)ops.size() - 1;
+  };
+  const int32_t count_op = op_index(PG_ACC_COUNT, -1, false);   // always present: tells which groups exist
+  for (int i = 0; i < q->n_aggregations; i++) {
+    const pg_agg_spec& s = q->aggregations[i];
+    AggOut out{};
+    out.function = s.function;
+    if (s.function == PG_AGG_COUNT) { out.op_a = count_op; P.aggs.push_back(out); continue; }
+    Column* c = seg.find(s.column);
+    if (!c) fail(PG_ERR_NOT_FOUND, "column not found: %s", s.column ? s.column : "(null)");
+    if (s.function == PG_AGG_DISTINCTCOUNT || s.function == PG_AGG_DISTINCTCOUNTHLL)
+      fail(PG_ERR_UNSUPPORTED, "aggregation function %d is not on the GPU path yet", s.function);
+    if (c->data_type > PG_TYPE_DOUBLE) fail(PG_ERR_INVALID_ARGUMENT, "Cannot compute aggregation for non-numeric type: column %s", c->name.c_str());
+    project(c);
+    const int32_t si = src_index(c);
+    const bool fl = c->val_type == PG_V_F32 || c->val_type == PG_V_F64;
+    out.is_float = fl;
+    switch (s.function) {
+      case PG_AGG_SUM: out.op_a = op_index(PG_ACC_SUM, si, fl); break;
+      case PG_AGG_MIN: out.op_a = op_index(PG_ACC_MIN, si, fl); break;
+      case PG_AGG_MAX: out.op_a = op_index(PG_ACC_MAX, si, fl); break;
+      case PG_AGG_AVG: out.op_a = op_index(PG_ACC_SUM, si, fl); out.op_b = count_op; break;
+      case PG_AGG_MINMAXRANGE: out.op_a = op_index(PG_ACC_MIN, si, fl); out.op_b = op_index(PG_ACC_MAX, si, fl); break;
+      default: fail(PG_ERR_UNSUPPORTED, "aggregation function %d", s.function);
+    }
+    P.aggs.push_back(out);
+  }
+  // kernels walk ops grouped by source: stable sort by src and remap
+  std::vector<int32_t> order(ops.size());
+  for (size_t i = 0; i < order.size(); i++) order[i] = (int32_t)i;
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return ops[a].src < ops[b].src; });
+  std::vector<int32_t> remap(ops.size());
+  std::vector<PgAccOp> sorted_ops(ops.size());
+  for (size_t i = 0; i < order.size(); i++) { sorted_ops[i] = ops[order[i]]; remap[order[i]] = (int32_t)i; }
+  for (auto& a : P.aggs) { if (a.op_a >= 0) a.op_a = remap[a.op_a]; if (a.op_b >= 0) a.op_b = remap[a.op_b]; }
+  D.n_ops = (int32_t)sorted_ops.size();
+  for (int i = 0; i < D.n_ops; i++) D.ops[i] = sorted_ops[i];
+  P.ops_dev = upload_vector(sorted_ops);
+  D.n_srcs = (int32_t)srcs.size();
+  for (size_t i = 0; i < srcs.size(); i++) {
+    Column* c = srcs[i];
+    D.srcs[i].data = c->fwd_dev.as<uint8_t>();
+    D.srcs[i].dict = c->has_dictionary ? c->dict_dev.ptr : nullptr;
+    D.srcs[i].col_kind = c->col_kind;
+    D.srcs[i].bits = c->bits;
+    D.srcs[i].val_type = c->val_type;
+  }
+  for (Column* c : projected) P.algorithmic_bytes += (int64_t)c->fwd_bytes_logical;
+  P.n_projected_columns = (int32_t)projected.size();
+
+  const int64_t table_bytes = G * D.n_ops * 8;
+  if (q->n_group_by == 0) {
+    D.agg_mode = PG_AGG_SINGLE;
+    D.replicas = PG_BLOCK;          // one private slot per thread: no atomic conflicts
+  } else if (table_bytes <= kLdsTableBudget) {
+    D.agg_mode = PG_AGG_LDS;
+    int r = 1;
+    while (r < 32 && table_bytes * (r * 2) <= kLdsTableBudget / 2) r *= 2;
+    D.replicas = r;
+  } else {
+    D.agg_mode = PG_AGG_GLOBAL;
+    D.replicas = 1;
+  }
+  if (D.agg_mode != PG_AGG_GLOBAL) P.lds_bytes += (size_t)G * D.replicas * D.n_ops * 8;
+  return plan;
+}
+
+}  // namespace pg

@@ -1,0 +1,238 @@
+// Segment registration: pins the Pinot index entries of one column into HBM (pg_segment_add_column).
+//
+//   forward index   FixedBitSVForwardIndexReaderV2 bytes are uploaded verbatim (MSB-first big-endian bit stream,
+//                   pinot-segment-local/.../readers/forward/FixedBitSVForwardIndexReaderV2.java:65-99); raw
+//                   FixedByteChunkSVForwardIndexReader entries (PASS_THROUGH) are uploaded from `_rawDataStart`
+//                   (BaseChunkForwardIndexReader.java:61-111) so that doc 0 sits on a 256-byte boundary; a sorted
+//                   column's (start,end) pairs are expanded once to the fixed-bit layout.  Values stay big-endian in
+//                   HBM; kernels byte-swap in registers.
+//   dictionary      kept on the host big-endian (binary search like BaseImmutableDictionary.java:124-245) and
+//                   uploaded native-endian for dictionary-encoded metric columns.
+//   inverted index  BitmapInvertedIndexReader.java:45-62 offsets + portable RoaringBitmap blobs are parsed once;
+//                   container payloads are copied 16-byte aligned into one device buffer with a descriptor per
+//                   container (array / bitmap / run are all kept as is).
+#include <algorithm>
+
+#include "pg_internal.hpp"
+
+namespace pg {
+
+static inline uint32_t be32(const uint8_t* p) {
+  return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
+}
+static inline uint64_t be64(const uint8_t* p) { return ((uint64_t)be32(p) << 32) | be32(p + 4); }
+static inline uint16_t le16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+static inline uint32_t le32(const uint8_t* p) {
+  return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+Column* Segment::find(const char* n) {
+  if (!n) return nullptr;
+  auto it = columns.find(n);
+  return it == columns.end() ? nullptr : it->second.get();
+}
+
+static size_t padded_docs(const Segment& seg) { return (size_t)seg.n_tiles * PG_TILE_DOCS; }
+
+static void upload_fixed_bit(Segment& seg, Column& c, const uint8_t* src, uint64_t len) {
+  uint64_t need = ((uint64_t)seg.total_docs * (uint64_t)c.bits + 7) / 8;
+  if (len < need) fail(PG_ERR_INVALID_ARGUMENT, "forward index of %s is %llu bytes, need %llu", c.name.c_str(),
+                       (unsigned long long)len, (unsigned long long)need);
+  size_t alloc = (padded_docs(seg) * (size_t)c.bits + 7) / 8 + 64;  // +64: the kernels read a dword pair past the value
+  c.fwd_dev.alloc(alloc, true);
+  c.fwd_dev.upload(src, need);
+  c.col_kind = PG_COL_FIXED_BIT;
+  c.fwd_bytes_logical = need;
+}
+
+static void parse_inverted_index(Segment& seg, Column& c, const uint8_t* inv, uint64_t len) {
+  const int32_t card = c.cardinality;
+  const uint64_t off_end = ((uint64_t)card + 1) * 4;
+  if (len < off_end) fail(PG_ERR_INVALID_ARGUMENT, "inverted index of %s too short", c.name.c_str());
+  const uint64_t first = be32(inv);
+  const uint8_t* bitmap_buffer = inv + off_end;
+  c.posting_begin.assign((size_t)card + 1, 0);
+  std::vector<uint8_t> staging;
+  staging.reserve(len);
+  const uint32_t max_key = (uint32_t)((padded_docs(seg) + PG_CHUNK_DOCS - 1) / PG_CHUNK_DOCS);
+  for (int32_t d = 0; d < card; d++) {
+    c.posting_begin[d] = (uint32_t)c.descs_host.size();
+    uint64_t off = be32(inv + (uint64_t)d * 4), end = be32(inv + (uint64_t)(d + 1) * 4);
+    if (end < off || off < first || (end - first) > len - off_end)
+      fail(PG_ERR_INVALID_ARGUMENT, "inverted index of %s: bad offsets for dictId %d", c.name.c_str(), d);
+    const uint8_t* blob = bitmap_buffer + (off - first);
+    uint64_t blen = end - off;
+    if (blen < 8) fail(PG_ERR_INVALID_ARGUMENT, "roaring blob too short (%s dictId %d)", c.name.c_str(), d);
+    uint32_t cookie = le32(blob);
+    uint64_t pos = 4;
+    uint32_t size;
+    const uint8_t* run_flags = nullptr;
+    bool has_run = false;
+    if ((cookie & 0xFFFF) == 12347) {
+      size = (cookie >> 16) + 1;
+      run_flags = blob + pos;
+      pos += (size + 7) / 8;
+      has_run = true;
+    } else if (cookie == 12346) {
+      size = le32(blob + pos);
+      pos += 4;
+    } else {
+      fail(PG_ERR_INVALID_ARGUMENT, "roaring: bad cookie %u (%s dictId %d)", cookie, c.name.c_str(), d);
+    }
+    if (pos + 4ULL * size > blen) fail(PG_ERR_INVALID_ARGUMENT, "roaring: truncated header");
+    const uint8_t* desc = blob + pos;
+    pos += 4ULL * size;
+    if (!has_run || size >= 4) pos += 4ULL * size;
+    for (uint32_t i = 0; i < size; i++) {
+      PgContainer pc{};
+      pc.key = le16(desc + 4 * i);
+      uint32_t cardm1 = le16(desc + 4 * i + 2);
+      bool is_run = has_run && ((run_flags[i >> 3] >> (i & 7)) & 1);
+      uint64_t payload;
+      if (is_run) {
+        if (pos + 2 > blen) fail(PG_ERR_INVALID_ARGUMENT, "roaring: truncated run container");
+        pc.n = le16(blob + pos);
+        pos += 2;
+        pc.type = 2;
+        payload = 4ULL * pc.n;
+      } else if (cardm1 + 1 > 4096) {
+        pc.type = 1;
+        pc.n = cardm1 + 1;
+        payload = 8192;
+      } else {
+        pc.type = 0;
+        pc.n = cardm1 + 1;
+        payload = 2ULL * pc.n;
+      }
+      if (pos + payload > blen) fail(PG_ERR_INVALID_ARGUMENT, "roaring: truncated container");
+      if (pc.key >= max_key) fail(PG_ERR_INVALID_ARGUMENT, "roaring: container key %u beyond the segment", pc.key);
+      size_t aligned = (staging.size() + 15) & ~(size_t)15;
+      staging.resize(aligned + payload);
+      memcpy(staging.data() + aligned, blob + pos, payload);
+      pc.offset = aligned;
+      pos += payload;
+      c.descs_host.push_back(pc);
+    }
+  }
+  c.posting_begin[card] = (uint32_t)c.descs_host.size();
+  staging.resize(((staging.size() + 15) & ~(size_t)15) + 16);
+  c.containers_dev.alloc(staging.size());
+  c.containers_dev.upload(staging.data(), staging.size());
+  c.descs_dev = upload_vector(c.descs_host);
+  c.has_inverted = true;
+}
+
+void segment_add_column(Segment& seg, const pg_column_desc& d) {
+  if (!d.name) fail(PG_ERR_INVALID_ARGUMENT, "column name is null");
+  if (seg.columns.count(d.name)) fail(PG_ERR_INVALID_ARGUMENT, "column %s already added", d.name);
+  auto col = std::make_unique<Column>();
+  Column& c = *col;
+  c.name = d.name;
+  c.data_type = d.data_type;
+  c.fwd_encoding = d.fwd_encoding;
+  c.has_dictionary = d.has_dictionary != 0;
+  c.cardinality = d.cardinality;
+  c.bits = d.bits_per_value;
+  c.is_sorted = d.is_sorted != 0;
+  c.dict_bytes_per_value = d.dict_bytes_per_value;
+  const uint8_t* fwd = (const uint8_t*)d.forward_index.addr;
+  const uint64_t fwd_len = d.forward_index.size;
+  if (!fwd && seg.total_docs > 0) fail(PG_ERR_INVALID_ARGUMENT, "column %s has no forward index", d.name);
+
+  switch (c.data_type) {
+    case PG_TYPE_INT: c.val_type = PG_V_I32; break;
+    case PG_TYPE_LONG: c.val_type = PG_V_I64; break;
+    case PG_TYPE_FLOAT: c.val_type = PG_V_F32; break;
+    case PG_TYPE_DOUBLE: c.val_type = PG_V_F64; break;
+    default: c.val_type = PG_V_I32; break;
+  }
+
+  if (c.has_dictionary) {
+    if (c.cardinality <= 0) fail(PG_ERR_INVALID_ARGUMENT, "column %s: dictionary with cardinality %d", d.name, c.cardinality);
+    uint64_t need = (uint64_t)c.cardinality * (uint64_t)c.dict_bytes_per_value;
+    if (d.dictionary.size != need)   // BaseImmutableDictionary.java:52-55 "Buffer size mismatch"
+      fail(PG_ERR_INVALID_ARGUMENT, "Buffer size mismatch: bufferSize = %llu, numValues = %d, numByesPerValue = %d",
+           (unsigned long long)d.dictionary.size, c.cardinality, c.dict_bytes_per_value);
+    const uint8_t* dp = (const uint8_t*)d.dictionary.addr;
+    c.dict_host.assign(dp, dp + need);
+    // native-endian copy for dictionary-encoded metric / value lookups on the device
+    if (c.data_type == PG_TYPE_INT || c.data_type == PG_TYPE_FLOAT) {
+      std::vector<uint32_t> v((size_t)c.cardinality);
+      for (int32_t i = 0; i < c.cardinality; i++) v[i] = be32(dp + (size_t)i * 4);
+      c.dict_dev = upload_vector(v);
+    } else if (c.data_type == PG_TYPE_LONG || c.data_type == PG_TYPE_DOUBLE) {
+      std::vector<uint64_t> v((size_t)c.cardinality);
+      for (int32_t i = 0; i < c.cardinality; i++) v[i] = be64(dp + (size_t)i * 8);
+      c.dict_dev = upload_vector(v);
+    }
+  }
+
+  if (c.fwd_encoding == PG_FWD_DICT_FIXED_BIT) {
+    if (c.bits < 1 || c.bits > 31) fail(PG_ERR_INVALID_ARGUMENT, "column %s: bits_per_value %d", d.name, c.bits);
+    upload_fixed_bit(seg, c, fwd, fwd_len);
+  } else if (c.fwd_encoding == PG_FWD_DICT_SORTED) {
+    if (fwd_len < (uint64_t)c.cardinality * 8) fail(PG_ERR_INVALID_ARGUMENT, "sorted index of %s too short", d.name);
+    c.sorted_start.resize((size_t)c.cardinality);
+    c.sorted_end.resize((size_t)c.cardinality);
+    for (int32_t i = 0; i < c.cardinality; i++) {
+      c.sorted_start[i] = (int32_t)be32(fwd + (size_t)i * 8);
+      c.sorted_end[i] = (int32_t)be32(fwd + (size_t)i * 8 + 4);
+    }
+    // expand to the fixed-bit layout so that projection / group-by see one dictionary-column encoding
+    if (c.bits < 1) {
+      int32_t mv = c.cardinality - 1;
+      c.bits = mv <= 1 ? 1 : 32 - __builtin_clz((uint32_t)mv);
+    }
+    size_t nbytes = ((size_t)seg.total_docs * (size_t)c.bits + 7) / 8;
+    std::vector<uint8_t> packed(nbytes + 8, 0);
+    for (int32_t id = 0; id < c.cardinality; id++) {
+      for (int64_t doc = c.sorted_start[id]; doc <= c.sorted_end[id]; doc++) {
+        int64_t bitpos = doc * c.bits;
+        for (int b = 0; b < c.bits; b++) {
+          if ((id >> (c.bits - 1 - b)) & 1) {
+            int64_t bp = bitpos + b;
+            packed[(size_t)(bp >> 3)] |= (uint8_t)(0x80 >> (bp & 7));
+          }
+        }
+      }
+    }
+    upload_fixed_bit(seg, c, packed.data(), nbytes);
+    c.fwd_bytes_logical = fwd_len;
+  } else if (c.fwd_encoding == PG_FWD_RAW_FIXED_BYTE_CHUNK) {
+    if (fwd_len < 16) fail(PG_ERR_INVALID_ARGUMENT, "raw forward index of %s too short", d.name);
+    int32_t version = (int32_t)be32(fwd);
+    int32_t num_chunks = (int32_t)be32(fwd + 4);
+    int32_t entry_len = (int32_t)be32(fwd + 12);
+    int32_t data_header_start = 16;
+    int32_t compression = 1;  // version 1: SNAPPY
+    if (version > 1) {
+      if (fwd_len < 28) fail(PG_ERR_INVALID_ARGUMENT, "raw forward index of %s too short", d.name);
+      compression = (int32_t)be32(fwd + 20);
+      data_header_start = (int32_t)be32(fwd + 24);
+    }
+    if (compression != 0)
+      fail(PG_ERR_UNSUPPORTED, "column %s: chunk compression type %d (only PASS_THROUGH raw columns are on the GPU path)",
+           d.name, compression);
+    int width = (c.data_type == PG_TYPE_INT || c.data_type == PG_TYPE_FLOAT) ? 4
+                : (c.data_type == PG_TYPE_LONG || c.data_type == PG_TYPE_DOUBLE) ? 8 : 0;
+    if (width == 0 || entry_len != width)
+      fail(PG_ERR_UNSUPPORTED, "column %s: raw type %d / entry length %d is outside the hot path", d.name, c.data_type, entry_len);
+    uint64_t raw_start = (uint64_t)data_header_start + (uint64_t)num_chunks * (version <= 2 ? 4 : 8);
+    uint64_t need = (uint64_t)seg.total_docs * (uint64_t)width;
+    if (raw_start + need > fwd_len) fail(PG_ERR_INVALID_ARGUMENT, "raw forward index of %s truncated", d.name);
+    c.fwd_dev.alloc(padded_docs(seg) * (size_t)width + 64, true);
+    c.fwd_dev.upload(fwd + raw_start, need);
+    c.col_kind = width == 4 ? PG_COL_RAW32 : PG_COL_RAW64;
+    c.fwd_bytes_logical = need;
+  } else {
+    fail(PG_ERR_UNSUPPORTED, "column %s: forward index encoding %d", d.name, c.fwd_encoding);
+  }
+
+  if (d.inverted_index.size > 0 && c.has_dictionary && c.fwd_encoding != PG_FWD_DICT_SORTED)
+    parse_inverted_index(seg, c, (const uint8_t*)d.inverted_index.addr, d.inverted_index.size);
+
+  seg.device_bytes += c.fwd_dev.size + c.dict_dev.size + c.containers_dev.size + c.descs_dev.size;
+  seg.columns.emplace(c.name, std::move(col));
+}
+
+}  // namespace pg

@@ -45,9 +45,22 @@ class NativeSegment:
         api.call("segment_create", host.name.encode(), host.total_docs, C.byref(self.handle))
         self._descs = []
         for col in host.columns.values():
-            d = col.desc()
-            self._descs.append(d)
-            api.call("segment_add_column", self.handle, C.byref(d))
+            self._register(col)
+
+    def _register(self, col):
+        d = col.desc()
+        self._descs.append(d)
+        self.api.call("segment_add_column", self.handle, C.byref(d))
+
+    def add_column(self, col, keep_host_buffers: bool = True):
+        """Registers one more column (streaming upload of big segments: the GPU library copies the bytes into HBM during
+        the call, so the caller may drop the host buffers afterwards with keep_host_buffers=False)."""
+        self._register(col)
+        self.host.columns[col.name] = col
+        if not keep_host_buffers:
+            col.forward_index = None
+            col.inverted_index = None
+            self._descs.pop()
 
     @property
     def total_docs(self) -> int:

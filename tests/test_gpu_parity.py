@@ -1,0 +1,228 @@
+"""GPU parity: libpinot_gpu.so (HIP kernels, through the C ABI) vs the CPU oracle and the reference's golden numbers.
+
+Bit-exact for counts, docId sets, group keys, MIN/MAX and integer-valued SUMs (all sums here stay below 2^53, where the
+reference's sequential double accumulation is exact and order independent — SURVEY.md §7 "Floating SUM parity").
+"""
+import numpy as np
+import pytest
+
+from pinot_amd import synth
+from pinot_amd.executor import NativeSegment
+from pinot_amd.segment import build_segment
+from tests.fixtures import SV_FILTER, sv_segment
+from tests.test_oracle_goldens import AGGREGATION_QUERY, FFC_CASES, RANGE_CASES, check_agg
+
+pytestmark = pytest.mark.gpu
+
+
+def both(gpu_api, oracle_api, host):
+    return NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+
+
+def assert_same_block(g, o, check_stats=True):
+    assert sorted(g.rows().keys()) == sorted(o.rows().keys())
+    gr, orr = g.rows(), o.rows()
+    for k in orr:
+        assert gr[k] == orr[k], (k, gr[k], orr[k])
+    assert g.stats.num_docs_scanned == o.stats.num_docs_scanned
+    assert g.stats.num_total_docs == o.stats.num_total_docs
+    assert g.stats.num_entries_scanned_post_filter == o.stats.num_entries_scanned_post_filter
+    if check_stats and g.stats.stats_exact:
+        assert g.stats.num_entries_scanned_in_filter == o.stats.num_entries_scanned_in_filter
+
+
+# ---- the reference's inner-segment goldens, on the GPU ------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def sv(gpu_api, oracle_api, sv_data):
+    host = sv_segment(sv_data)
+    g, o = both(gpu_api, oracle_api, host)
+    yield g, o
+    g.destroy()
+    o.destroy()
+
+
+def test_golden_aggregation_only(sv):
+    g, _ = sv
+    b = g.execute(AGGREGATION_QUERY)
+    check_agg(b.aggregation_result(), 30000, 32317185437847, 2147419555, 1689277, 28175373944314, 30000)
+    st = b.execution_statistics()
+    assert (st.num_docs_scanned, st.num_entries_scanned_in_filter, st.num_entries_scanned_post_filter,
+            st.num_total_docs) == (30000, 0, 120000, 30000)
+    b = g.execute(AGGREGATION_QUERY + SV_FILTER)
+    check_agg(b.aggregation_result(), 6129, 6875947596072, 999813884, 1980174, 4699510391301, 6129)
+    st = b.execution_statistics()
+    assert (st.num_docs_scanned, st.num_entries_scanned_post_filter, st.num_total_docs) == (6129, 24516, 30000)
+
+
+def test_golden_group_by(sv):
+    g, _ = sv
+    b = g.execute(AGGREGATION_QUERY + " GROUP BY column9")
+    check_agg(b.rows()[(11270,)], 1, 815409257, 1215316262, 1328642550, 788414092, 1)
+    b = g.execute(AGGREGATION_QUERY + SV_FILTER + " GROUP BY column9")
+    check_agg(b.rows()[(242920,)], 3, 4348938306, 407993712, 296467636, 5803888725, 3)
+    b = g.execute(AGGREGATION_QUERY + " GROUP BY column9, column11, column12")
+    check_agg(b.rows()[(1813102948, "P", "HEuxNvH")], 4, 2062187196, 1988589001, 394608493, 4782388964, 4)
+    b = g.execute(AGGREGATION_QUERY + SV_FILTER + " GROUP BY column9, column11, column12")
+    check_agg(b.rows()[(1176631727, "P", "KrNxpdycSiwoRohEiTIlLqDHnx")], 1, 716185211, 489993380, 371110078,
+              487714191, 1)
+
+
+SV_QUERIES = [
+    AGGREGATION_QUERY,
+    AGGREGATION_QUERY + SV_FILTER,
+    AGGREGATION_QUERY + " GROUP BY column9",
+    AGGREGATION_QUERY + SV_FILTER + " GROUP BY column9",
+    AGGREGATION_QUERY + " GROUP BY column9, column11, column12",
+    AGGREGATION_QUERY + SV_FILTER + " GROUP BY column11, column12",
+    "SELECT column11, SUM(column1) FROM testTable GROUP BY column11",
+    "SELECT column11, column12, SUM(column1), MIN(column3), MAX(column17), COUNT(*) FROM testTable GROUP BY column11, column12",
+    "SELECT COUNT(*) FROM testTable WHERE column11 NOT IN ('t', 'P')",
+    "SELECT COUNT(*), SUM(column18) FROM testTable WHERE column6 < 500000000 OR column11 NOT IN ('t', 'P')",
+    "SELECT COUNT(*), MAX(column1) FROM testTable WHERE NOT (column7 IN (1, 2, 3, 5, 8) OR column17 = 635553468)",
+    "SELECT MINMAXRANGE(column6), AVG(column18) FROM testTable WHERE column17 > 1000 AND column18 <= 1000000000 GROUP BY column7",
+    "SELECT COUNT(*) FROM testTable WHERE daysSinceEpoch = 126164076 AND column11 = 'P' AND column1 > 1500000000",
+    "SELECT COUNT(*) FROM testTable WHERE column5 = 'gFuH'",
+    "SELECT COUNT(*) FROM testTable WHERE column5 = 'nope'",
+    "SELECT SUM(column1) FROM testTable WHERE column9 = -1",
+]
+
+
+@pytest.mark.parametrize("q", SV_QUERIES)
+def test_sv_queries_match_oracle(sv, q):
+    g, o = sv
+    assert_same_block(g.execute(q), o.execute(q))
+
+
+@pytest.mark.parametrize("q", SV_QUERIES)
+def test_sv_filters_match_oracle(sv, q):
+    g, o = sv
+    dg, do = g.filter(q), o.filter(q)
+    assert dg.cardinality() == do.cardinality()
+    np.testing.assert_array_equal(dg.words(), do.words())
+    np.testing.assert_array_equal(dg.doc_ids(), do.doc_ids())
+
+
+# ---- FastFilteredCountTest / RangeQueriesTest fixtures on the GPU ---------------------------------------------------------
+@pytest.fixture(scope="module")
+def ffc(gpu_api):
+    i = np.arange(1000)
+    data = {"class": (i % 8).astype(np.int32), "sorted": i.astype(np.int32), "intRangeCol": (1000 - i).astype(np.int32)}
+    host = build_segment("FastFilteredCountTest", data, {"class": "INT", "sorted": "INT", "intRangeCol": "INT"},
+                         inverted_index_columns=["class"])
+    s = NativeSegment(gpu_api, host)
+    yield s
+    s.destroy()
+
+
+@pytest.mark.parametrize("flt,expected", FFC_CASES)
+def test_fast_filtered_count_gpu(ffc, flt, expected):
+    b = ffc.execute("select count(*) from testTable" + flt)
+    assert b.aggregation_result()[0] == expected, flt
+    st = b.execution_statistics()
+    assert st.num_docs_scanned == expected and st.num_total_docs == 1000
+
+
+@pytest.fixture(scope="module")
+def rng_seg(gpu_api):
+    i = np.arange(1000, dtype=np.int64)
+    v = ((100000 + 500) - i * 100) % 100000
+    data = {"dictionarized": v.astype(np.int32), "rawInt": v.astype(np.int32), "rawLong": v.astype(np.int64),
+            "rawFloat": v.astype(np.float32), "rawDouble": v.astype(np.float64)}
+    schema = {"dictionarized": "INT", "rawInt": "INT", "rawLong": "LONG", "rawFloat": "FLOAT", "rawDouble": "DOUBLE"}
+    host = build_segment("RangeQueriesTest", data, schema,
+                         no_dictionary_columns=["rawInt", "rawLong", "rawFloat", "rawDouble"])
+    s = NativeSegment(gpu_api, host)
+    yield s, v
+    s.destroy()
+
+
+@pytest.mark.parametrize("col", ["dictionarized", "rawInt", "rawLong", "rawFloat", "rawDouble"])
+@pytest.mark.parametrize("case", range(len(RANGE_CASES)))
+@pytest.mark.parametrize("bounds", [(250, 500), (0, 99900), (-1, 100000), (20000, 20300), (450, 450)])
+def test_range_queries_gpu(rng_seg, col, case, bounds):
+    seg, v = rng_seg
+    tmpl, fn = RANGE_CASES[case]
+    lo, hi = bounds
+    where = tmpl.format(c=col, lo=lo, hi=hi)
+    m = fn(v, lo, hi)
+    b = seg.execute(f"SELECT COUNT(*), SUM({col}), MIN({col}), MAX({col}) FROM testTable WHERE {where}")
+    r = b.aggregation_result()
+    assert r[0] == int(m.sum()), where
+    if m.any():
+        assert r[1] == float(v[m].sum()) and r[2] == float(v[m].min()) and r[3] == float(v[m].max())
+    else:
+        assert r[1] == 0.0 and r[2] == float("inf") and r[3] == float("-inf")
+    np.testing.assert_array_equal(seg.filter(f"SELECT COUNT(*) FROM t WHERE {where}").doc_ids(), np.flatnonzero(m))
+
+
+# ---- synthetic gpuBench segments: BASELINE.json configs at oracle-checkable sizes ------------------------------------------
+SYNTH_QUERIES = [
+    synth.QUERY_CFG2,
+    synth.QUERY_CFG3,
+    synth.QUERY_NORTH_STAR,
+    "SELECT COUNT(*) FROM gpuBench WHERE c_inv1 IN (0,1,2,3) AND c_inv2 IN (0,1)",
+    "SELECT COUNT(*), SUM(m), MIN(m), MAX(m), AVG(r_int) FROM gpuBench WHERE c_inv1 = 5 AND r_int < 1000",
+    "SELECT g2, COUNT(*), MIN(r_int) FROM gpuBench WHERE c_inv1 NOT IN (1, 7) OR g1 = 99 GROUP BY g2",
+    "SELECT h1, h2, h3, h4, COUNT(*), SUM(m) FROM gpuBench WHERE g1 BETWEEN 10 AND 19 GROUP BY h1, h2, h3, h4",
+    "SELECT g1, SUM(g2), MAX(u) FROM gpuBench WHERE u < 5000 GROUP BY g1",
+    "SELECT COUNT(*) FROM gpuBench WHERE NOT (r_int BETWEEN 10 AND 999989) AND c_inv2 != 3",
+]
+
+
+@pytest.fixture(scope="module", params=[1, 63, 64, 65, 16383, 16384, 16385, 65537, 300_001, 2_500_000])
+def synth_pair(request, gpu_api, oracle_api):
+    host = synth.generate_segment(request.param)
+    g, o = both(gpu_api, oracle_api, host)
+    yield g, o
+    g.destroy()
+    o.destroy()
+
+
+@pytest.mark.parametrize("q", SYNTH_QUERIES)
+def test_synth_queries_match_oracle(synth_pair, q):
+    g, o = synth_pair
+    assert_same_block(g.execute(q), o.execute(q))
+
+
+@pytest.mark.parametrize("q", [synth.QUERY_CFG2, synth.QUERY_CFG3, SYNTH_QUERIES[5], SYNTH_QUERIES[8]])
+def test_synth_docid_sets_match_oracle(synth_pair, q):
+    g, o = synth_pair
+    dg, do = g.filter(q), o.filter(q)
+    np.testing.assert_array_equal(dg.words(), do.words())
+    np.testing.assert_array_equal(dg.doc_ids(), do.doc_ids())
+    assert dg.stats().num_entries_scanned_in_filter == do.stats().num_entries_scanned_in_filter or not dg.stats().stats_exact
+
+
+# ---- array / run / bitmap Roaring containers and exclusive postings ------------------------------------------------------------
+def test_container_kinds(gpu_api, oracle_api):
+    n = 200_000
+    rng = np.random.default_rng(11)
+    runs = (np.arange(n) // 5000) % 7            # long runs → run containers
+    sparse = rng.integers(0, 5000, n)            # ~40 docs per value → array containers
+    dense = rng.integers(0, 3, n)                # bitmap containers
+    data = {"runs": runs.astype(np.int32), "sparse": sparse.astype(np.int32), "dense": dense.astype(np.int32),
+            "v": rng.integers(0, 1000, n).astype(np.int32)}
+    host = build_segment("containers", data, {k: "INT" for k in data}, inverted_index_columns=["runs", "sparse", "dense"],
+                         no_dictionary_columns=["v"])
+    g, o = both(gpu_api, oracle_api, host)
+    qs = ["SELECT COUNT(*), SUM(v) FROM t WHERE runs = 3",
+          "SELECT COUNT(*), SUM(v) FROM t WHERE runs IN (1, 2, 6) AND dense = 1",
+          "SELECT COUNT(*), SUM(v) FROM t WHERE sparse IN (7, 77, 777, 4999) OR runs = 0",
+          "SELECT COUNT(*), SUM(v) FROM t WHERE sparse NOT IN (1, 2, 3) AND dense != 2 AND v < 500",
+          "SELECT dense, COUNT(*), MAX(v) FROM t WHERE sparse = 42 OR sparse = 43 GROUP BY dense"]
+    for q in qs:
+        assert_same_block(g.execute(q), o.execute(q))
+        np.testing.assert_array_equal(g.filter(q).doc_ids(), o.filter(q).doc_ids())
+    g.destroy()
+    o.destroy()
+
+
+def test_unsupported_and_errors(gpu_api, sv):
+    g, _ = sv
+    from pinot_amd.capi import NativeError, PG_ERR_NOT_FOUND, PG_ERR_INVALID_ARGUMENT
+    with pytest.raises(NativeError) as e:
+        g.execute("SELECT COUNT(*) FROM t WHERE nosuchcolumn = 1")
+    assert e.value.status == PG_ERR_NOT_FOUND
+    with pytest.raises(NativeError) as e:
+        g.execute("SELECT COUNT(*) FROM t WHERE column1 = 'abc'")
+    assert e.value.status == PG_ERR_INVALID_ARGUMENT and "NumberFormatException" in e.value.message

@@ -1,0 +1,125 @@
+"""CPU-only checks of the host logic: byte-format writers, SQL front end, synthetic generator, C-ABI exports."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from pinot_amd import capi, formats, synth
+from pinot_amd.query import parse_sql
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# FixedBitIntReaderTest.java:51-81 restated: random values for every bit width 1..31, read back with read / read32
+@pytest.mark.parametrize("bits", range(1, 32))
+def test_fixed_bit_round_trip(oracle_api, bits):
+    rng = np.random.default_rng(bits)
+    n = 1000 + bits
+    vals = rng.integers(0, (1 << bits) - 1, size=n, endpoint=True, dtype=np.int64).astype(np.int32)
+    packed = formats.pack_fixed_bit(vals, bits)
+    assert packed.nbytes == (n * bits + 7) // 8
+    np.testing.assert_array_equal(formats.unpack_fixed_bit(packed, bits, n), vals)
+    buf = np.concatenate([packed, np.zeros(8, np.uint8)])
+    lib = oracle_api.lib
+    for i in list(range(0, 70)) + [n - 2, n - 1]:
+        assert lib.po_read_fixed_bit(buf.ctypes.data, bits, i) == vals[i]
+    docs = np.arange(3, n - 1, dtype=np.int32)         # sequential run >= 64 → bulk read32 path
+    out = np.zeros(len(docs), dtype=np.int32)
+    lib.po_read_fixed_bit_block(buf.ctypes.data, bits, docs.ctypes.data, len(docs), out.ctypes.data)
+    np.testing.assert_array_equal(out, vals[3:n - 1])
+    docs = np.sort(rng.choice(n, size=200, replace=False)).astype(np.int32)
+    out = np.zeros(len(docs), dtype=np.int32)
+    lib.po_read_fixed_bit_block(buf.ctypes.data, bits, docs.ctypes.data, len(docs), out.ctypes.data)
+    np.testing.assert_array_equal(out, vals[docs])
+
+
+def test_num_bits_per_value():
+    # PinotDataBitSet.getNumBitsPerValue javadoc examples (PinotDataBitSet.java:48-58)
+    assert [formats.num_bits_per_value(v) for v in (0, 1, 2, 9, 113)] == [1, 1, 2, 4, 7]
+
+
+@pytest.mark.parametrize("kind", ["array", "bitmap", "run", "mixed", "empty"])
+def test_roaring_round_trip(kind):
+    rng = np.random.default_rng(5)
+    if kind == "array":
+        docs = np.sort(rng.choice(300_000, 3000, replace=False))
+    elif kind == "bitmap":
+        docs = np.sort(rng.choice(200_000, 120_000, replace=False))
+    elif kind == "run":
+        docs = np.concatenate([np.arange(10, 5000), np.arange(70_000, 140_000), np.arange(200_000, 200_003)])
+    elif kind == "mixed":
+        docs = np.unique(np.concatenate([np.arange(0, 66_000), rng.choice(np.arange(131_072, 196_608), 20, replace=False),
+                                         rng.choice(np.arange(262_144, 327_680), 30_000, replace=False)]))
+    else:
+        docs = np.zeros(0, dtype=np.int64)
+    blob = formats.serialize_roaring(docs)
+    np.testing.assert_array_equal(formats.deserialize_roaring(blob), docs)
+    if kind == "run":
+        assert (np.frombuffer(blob[:4], "<u4")[0] & 0xFFFF) == formats.SERIAL_COOKIE
+    if kind == "array":
+        assert np.frombuffer(blob[:4], "<u4")[0] == formats.SERIAL_COOKIE_NO_RUNCONTAINER
+
+
+def test_sql_front_end():
+    q = parse_sql("SELECT COUNT(*), SUM(column1) FROM testTable WHERE column1 > 100000000 AND column3 BETWEEN 20000000 "
+                  "AND 1000000000 AND column5 = 'gFuH' AND (column6 < 500000000 OR column11 NOT IN ('t', 'P')) AND "
+                  "daysSinceEpoch = 126164076 GROUP BY column9 ORDER BY column9 LIMIT 7")
+    assert q.filter.type == "AND" and len(q.filter.children) == 5       # flattened like CalciteSqlParser
+    p0 = q.filter.children[0].predicate
+    assert (p0.type, p0.lower, p0.upper, p0.lower_inclusive) == ("RANGE", "100000000", "*", False)
+    p1 = q.filter.children[1].predicate
+    assert (p1.lower, p1.upper, p1.lower_inclusive, p1.upper_inclusive) == ("20000000", "1000000000", True, True)
+    assert q.filter.children[3].type == "OR"
+    assert q.filter.children[3].children[1].predicate.type == "NOT_IN"
+    assert q.group_by == ["column9"] and q.limit == 7 and [a.function for a in q.aggregations] == ["COUNT", "SUM"]
+    q = parse_sql("select count(*) from t where sorted not between 20 and 980")
+    assert q.filter.type == "NOT" and q.filter.children[0].predicate.type == "RANGE"
+
+
+def test_synth_native_matches_numpy():
+    lib = synth.synth_lib()
+    if lib is None:
+        pytest.skip("libpinot_synth.so not built")
+    n = 150_001
+    a = synth.generate_segment(n, native=True)
+    b = synth.generate_segment(n, native=False)
+    for k in a.columns:
+        np.testing.assert_array_equal(a.columns[k].forward_index, b.columns[k].forward_index, err_msg=k)
+        if a.columns[k].inverted_index is not None:
+            np.testing.assert_array_equal(a.columns[k].inverted_index, b.columns[k].inverted_index, err_msg=k)
+    # prefix property: a smaller segment is the prefix of a bigger one
+    small = synth.values_numpy(synth.GPU_BENCH["g1"], synth.SEED_BASE, 1000)
+    big = synth.values_numpy(synth.GPU_BENCH["g1"], synth.SEED_BASE, 5000)
+    np.testing.assert_array_equal(small, big[:1000])
+    assert 0.48 < np.mean((synth.values_numpy(synth.GPU_BENCH["r_int"], 1, 100000) >= 250000)
+                          & (synth.values_numpy(synth.GPU_BENCH["r_int"], 1, 100000) <= 749999)) < 0.52
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """include/pinot_gpu.h declarations ⊆ exports of libpinot_gpu.so (no compute calls: works without a GPU)."""
+    header = open(os.path.join(ROOT, "include", "pinot_gpu.h")).read()
+    declared = set(re.findall(r"\bint32_t\s+(pg_[a-z_0-9]+)\s*\(", header))
+    assert declared == {"pg_" + s for s in capi.ABI_SYMBOLS}
+    if not os.path.exists(capi.GPU_LIB_PATH):
+        pytest.skip("libpinot_gpu.so not built here")
+    lib = C.CDLL(capi.GPU_LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} is declared in pinot_gpu.h but not exported"
+    lib.pg_abi_version.restype = C.c_int32
+    assert lib.pg_abi_version() == capi.PG_ABI_VERSION
+
+
+def test_gpu_library_fails_loudly_without_device():
+    """No CPU fallback: on a box without a GPU every compute entry point reports PG_ERR_DEVICE."""
+    if not os.path.exists(capi.GPU_LIB_PATH):
+        pytest.skip("libpinot_gpu.so not built here")
+    api = capi.gpu_api()
+    n = C.c_int32(-1)
+    api.call("device_count", C.byref(n))
+    if n.value > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.NativeError) as e:
+        api.call("init", 0)
+    assert e.value.status == capi.PG_ERR_DEVICE and "no CPU fallback" in e.value.message
