@@ -1,0 +1,49 @@
+"""Times a set of queries on one synthetic segment with the library's HIP-event timers (dev tool, not a test)."""
+import argparse
+import ctypes as C
+import statistics
+import sys
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa
+from pinot_amd import capi, synth
+from pinot_amd.executor import NativeSegment
+from pinot_amd.query import CQuery, parse_sql
+from pinot_amd.segment import HostSegment
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--docs", type=int, default=200_000_000)
+ap.add_argument("--reps", type=int, default=10)
+args = ap.parse_args()
+api = capi.gpu_api()
+api.call("init", 0)
+seg = NativeSegment(api, HostSegment("prof", args.docs))
+for name in synth.CFG3_COLUMNS:
+    one = synth.generate_segment(args.docs, columns=[name])
+    seg.add_column(one.columns[name], keep_host_buffers=False)
+
+QUERIES = {
+    "cfg2 count(range scan)": (synth.QUERY_CFG2, 4.0),
+    "postings only count": ("SELECT COUNT(*) FROM t WHERE c_inv1 IN (0,1,2,3) AND c_inv2 IN (0,1)", 0.75),
+    "cfg3 filter only count": ("SELECT COUNT(*) FROM t WHERE c_inv1 IN (0,1,2,3) AND c_inv2 IN (0,1) AND r_int BETWEEN 250000 AND 749999", 4.75),
+    "no filter sum(m) group g1": ("SELECT g1, SUM(m), MAX(m) FROM t GROUP BY g1", 4.875),
+    "no filter sum(m)": ("SELECT SUM(m) FROM t", 4.0),
+    "cfg3": (synth.QUERY_CFG3, 9.625),
+    "northstar": (synth.QUERY_NORTH_STAR, 10.375),
+    "g1 scan eq": ("SELECT COUNT(*) FROM t WHERE g1 = 7", 0.875),
+}
+for name, (sql, bpr) in QUERIES.items():
+    qc = parse_sql(sql)
+    qc.flags |= capi.QUERY_FLAG_PROFILE
+    cq = CQuery(qc)
+    ms = []
+    for i in range(args.reps + 2):
+        h = C.c_void_p()
+        api.call("query_exec", seg.handle, cq.ptr(), C.byref(h))
+        st = capi.PgExecStats()
+        api.call("result_stats", h, C.byref(st))
+        api.call("result_free", h)
+        if i >= 2:
+            ms.append(st.device_ms_aggregate)
+    m = statistics.median(ms)
+    print(f"{name:32s} {m:8.3f} ms  {bpr * args.docs / m / 1e6:8.1f} GB/s  ({bpr * args.docs / m / 1e6 / 80:5.1f}% of 8 TB/s)  matched={st.num_docs_scanned}")
