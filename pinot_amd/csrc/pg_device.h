@@ -18,6 +18,9 @@
 #define PG_MAX_OPS 16
 #define PG_MAX_STATS 16
 #define PG_BLOCK 256
+#ifndef PG_WG_PER_CU
+#define PG_WG_PER_CU 6            // resident workgroups per CU the query kernel is compiled for (__launch_bounds__)
+#endif
 
 // ---- filter program --------------------------------------------------------------------------------------------------
 enum PgFOp : int32_t {
@@ -70,9 +73,8 @@ struct PgContainer {
 
 struct PgPostingLeaf {
   const uint8_t* containers;
-  const PgContainer* descs;       // all containers of the column's inverted index
-  const uint32_t* chunk_start;    // CSR over chunks: entries [chunk_start[c], chunk_start[c+1]) of chunk_desc
-  const uint32_t* chunk_desc;     // indices into descs of the leaf's containers that fall in chunk c
+  const uint32_t* chunk_start;    // CSR over chunks: entries [chunk_start[c], chunk_start[c+1]) of `entries`
+  const PgContainer* entries;     // the leaf's containers grouped by chunk (copied inline: one dependent load less)
   int32_t exclusive;
   int32_t pad;
 };

@@ -113,8 +113,7 @@ static std::shared_ptr<CompiledPlan> get_plan(Segment& seg, const pg_filter_node
 struct LaunchShape { int grid; size_t lds; };
 static LaunchShape launch_shape(const CompiledPlan& P, int n_tiles) {
   size_t lds = P.lds_bytes + 64;
-  int per_cu = (int)std::min<size_t>(8, std::max<size_t>(1, (g_lds_per_cu - 1024) / (lds + 128)));
-  if (per_cu > 6) per_cu = 6;
+  int per_cu = (int)std::min<size_t>(PG_WG_PER_CU, std::max<size_t>(1, (g_lds_per_cu - 1024) / (lds + 128)));
   int grid = std::min(n_tiles, g_num_cus * per_cu);
   return {std::max(grid, 1), lds};
 }
@@ -201,12 +200,12 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
 
   // ---- assemble groups: a group exists iff its hidden COUNT is > 0 (ArrayBasedHolder flags / map entries) ----------------
   const int64_t G = D.n_groups;
-  int count_op = 0;
-  for (int o = 0; o < D.n_ops; o++) if (D.ops[o].fn == PG_ACC_COUNT) count_op = o;
-  const int64_t* cnt = table.data() + (size_t)count_op * G;
+  const int64_t* ex = table.data() + (size_t)P.exist_op * G;
+  const int64_t ex_ident = pg_acc_identity(D.ops[P.exist_op].fn, 0);
+  auto exists = [&](int64_t g) { return ex[g] != ex_ident; };   // COUNT: != 0; MIN/MAX over INT: left its identity
   std::vector<int64_t> gids;
   if (q.n_group_by == 0) gids.push_back(0);
-  else for (int64_t g = 0; g < G; g++) if (cnt[g] > 0) gids.push_back(g);
+  else for (int64_t g = 0; g < G; g++) if (exists(g)) gids.push_back(g);
   const int32_t ng = (int32_t)gids.size();
   res->num_groups = ng;
   res->group_dict_ids.resize((size_t)q.n_group_by);
@@ -222,7 +221,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   auto op_double = [&](int o, int64_t g) -> double {
     const PgAccOp& op = D.ops[o];
     int64_t v = table[(size_t)o * G + g];
-    const bool empty = cnt[g] == 0;
+    const bool empty = !exists(g);
     switch (op.fn) {
       case PG_ACC_COUNT: return (double)v;
       case PG_ACC_SUM:

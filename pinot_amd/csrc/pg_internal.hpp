@@ -156,6 +156,7 @@ struct CompiledPlan {
   std::vector<int32_t> group_cards;
   size_t lds_bytes = 0;
   int32_t num_groups_limit = 0;
+  int32_t exist_op = 0;              // accumulator whose value tells whether a group was touched
   DeviceBuffer ops_dev;
 };
 

@@ -9,18 +9,24 @@
 //   K6    group keys         DictionaryBasedGroupKeyGenerator raw keys          (core/query/aggregation/groupby/DictionaryBasedGroupKeyGenerator.java:312-354)
 //   K7    aggregation        Sum/Count/Min/Max aggregateGroupBySV               (core/query/aggregation/function/SumAggregationFunction.java:160-179 ...)
 //
-// Hardware mapping: the path is HBM-bound integer/bitmap work (no MFMA).  One persistent workgroup per tile stream;
-// every column is read once with 16-byte (raw columns) or dword-pair (bit-packed columns) loads that are contiguous
-// across the wavefront; match bits are assembled with DPP row operations (no LDS round trip) into 64-bit words held in
-// LDS; group accumulators live in LDS (ds_add_u64 / ds_max_i64 / ds_add_f64) and are flushed once per workgroup.
+// Hardware mapping: the path is HBM-bound integer/bitmap work (no MFMA).  Persistent 256-thread workgroups walk 16 384-doc
+// tiles; every column is read once with loads that are contiguous across the wavefront (16 B/lane for raw columns, dword
+// pairs for bit-packed ones) through a wave-uniform tile base (SGPR) + 32-bit lane offset; match bits are assembled with
+// DPP row operations into 64-bit words held in LDS; group accumulators live in LDS (ds_add_u64 / ds_max_i64 / ds_add_f64)
+// and are flushed once per workgroup.  Register use is kept under 64 VGPRs so that 8 workgroups (32 waves) share a CU:
+// occupancy, not instruction-level unrolling, is what hides HBM latency here.
 #include <hip/hip_runtime.h>
 
 #include "pg_device.h"
 
 #define DEVFN __device__ __forceinline__
+// Pointers that were themselves loaded from memory (plan leaves) have no address space the compiler can infer and would
+// be accessed with flat_load; every column / index byte lives in HBM, so say so.
+#define GAS __attribute__((address_space(1)))
+template <typename T> DEVFN const GAS T* gptr(const void* p) { return (const GAS T*)p; }
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 DEVFN uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
-DEVFN uint64_t bswap64(uint64_t x) { return __builtin_bswap64(x); }
 
 // OR across aligned groups of 8 lanes (two quads) with DPP row operations.
 DEVFN uint32_t or_reduce8(uint32_t v) {
@@ -36,117 +42,145 @@ DEVFN uint32_t wave_sum_u32(uint32_t v) {
   return v;
 }
 
-DEVFN uint64_t tile_valid_word(int32_t num_docs, int64_t doc_base) {
-  int64_t rem = (int64_t)num_docs - doc_base;
+DEVFN uint64_t tile_valid_word(int32_t n_valid, int word) {   // n_valid: docs of this tile below numDocs
+  int rem = n_valid - word * 64;
   if (rem >= 64) return ~0ULL;
   if (rem <= 0) return 0ULL;
   return (1ULL << rem) - 1ULL;
 }
+DEVFN uint32_t quad_valid_nibble(int32_t n_valid, int q) {
+  int nv = n_valid - 4 * q;
+  return nv >= 4 ? 0xFu : (nv <= 0 ? 0u : ((1u << nv) - 1u));
+}
 
-// ---- bit-packed (FixedBitSVForwardIndexReaderV2) extraction: 4 consecutive docs starting at doc0 (multiple of 4) ----
-DEVFN void extract4(const uint8_t* __restrict__ data, int64_t doc0, int bits, uint32_t out[4]) {
-  const uint32_t* __restrict__ w = reinterpret_cast<const uint32_t*>(data);
-  const uint32_t mask = (1u << bits) - 1u;
-  if (bits <= 8) {
-    int64_t bitpos = doc0 * bits;
-    int64_t di = bitpos >> 5;
-    int sh = (int)(bitpos & 31);
-    uint64_t win = ((uint64_t)bswap32(w[di]) << 32) | (uint64_t)bswap32(w[di + 1]);
+// ---- bit-packed (FixedBitSVForwardIndexReaderV2) extraction ---------------------------------------------------------------
+// tw: wave-uniform pointer to the tile's first dword (a tile of 16 384 values starts on a dword boundary for any width);
+// q: quad index inside the tile; values 4q .. 4q+3.
+template <bool SMALL>
+DEVFN void extract4(const GAS uint32_t* __restrict__ tw, uint32_t q, uint32_t bits, uint32_t mask, uint32_t out[4]) {
+  if (SMALL) {   // bits <= 8: the four values sit inside one 64-bit window
+    uint32_t bitpos = 4u * q * bits;
+    uint32_t di = bitpos >> 5, sh = bitpos & 31u;
+    uint64_t win = ((uint64_t)bswap32(tw[di]) << 32) | (uint64_t)bswap32(tw[di + 1]);
 #pragma unroll
-    for (int i = 0; i < 4; i++) out[i] = (uint32_t)(win >> (64 - sh - (i + 1) * bits)) & mask;
+    for (int i = 0; i < 4; i++) out[i] = (uint32_t)(win >> (64u - sh - (uint32_t)(i + 1) * bits)) & mask;
   } else {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      int64_t bitpos = (doc0 + i) * bits;
-      int64_t di = bitpos >> 5;
-      int sh = (int)(bitpos & 31);
-      uint64_t win = ((uint64_t)bswap32(w[di]) << 32) | (uint64_t)bswap32(w[di + 1]);
-      out[i] = (uint32_t)(win >> (64 - sh - bits)) & mask;
+      uint32_t bitpos = (4u * q + (uint32_t)i) * bits;
+      uint32_t di = bitpos >> 5, sh = bitpos & 31u;
+      uint64_t win = ((uint64_t)bswap32(tw[di]) << 32) | (uint64_t)bswap32(tw[di + 1]);
+      out[i] = (uint32_t)(win >> (64u - sh - bits)) & mask;
     }
   }
 }
-
-// ---- predicate evaluation ---------------------------------------------------------------------------------------------
-template <int PK>
-DEVFN bool pred_dict(const PgScanLeaf& L, uint32_t d) {
-  if (PK == PG_P_RANGE) return (int64_t)d >= L.lo && (int64_t)d <= L.hi;
-  return (L.lut[d >> 5] >> (d & 31)) & 1u;
+DEVFN const GAS uint32_t* packed_tile_base(const uint8_t* data, int tile, int bits) {
+  return gptr<uint32_t>(data + (size_t)tile * (size_t)(PG_TILE_DOCS / 8) * (size_t)bits);
 }
-template <int PK>
-DEVFN bool pred_i64(const PgScanLeaf& L, int64_t v) {
-  if (PK == PG_P_RANGE) return v >= L.lo && v <= L.hi;
-  const int64_t* s = reinterpret_cast<const int64_t*>(L.set_values);
+
+// ---- predicates ---------------------------------------------------------------------------------------------------------------
+struct RangeI32 { int32_t lo; uint32_t span; bool empty; };
+DEVFN RangeI32 make_range_i32(int64_t lo, int64_t hi) {
+  RangeI32 r;
+  r.empty = hi < lo;
+  r.lo = (int32_t)lo;
+  r.span = (uint32_t)(hi - lo);
+  return r;
+}
+DEVFN bool in_range_i32(const RangeI32& r, int32_t v) { return (uint32_t)(v - r.lo) <= r.span; }
+
+DEVFN bool in_set_i64(const PgScanLeaf& L, int64_t v) {
+  const GAS int64_t* s = gptr<int64_t>(L.set_values);
   bool hit = false;
+#pragma unroll 1
   for (int i = 0; i < L.n_set; i++) hit |= (s[i] == v);
   return hit != (L.exclusive != 0);
 }
-template <int PK>
-DEVFN bool pred_f64(const PgScanLeaf& L, double v) {
-  if (PK == PG_P_RANGE) return v >= __longlong_as_double(L.lo) && v <= __longlong_as_double(L.hi);
-  const double* s = reinterpret_cast<const double*>(L.set_values);
+DEVFN bool in_set_f64(const PgScanLeaf& L, double v) {
+  const GAS double* s = gptr<double>(L.set_values);
   bool hit = false;
+#pragma unroll 1
   for (int i = 0; i < L.n_set; i++) hit |= (s[i] == v);
   return hit != (L.exclusive != 0);
 }
 
-// Evaluates the predicate for the 4 docs of a quad; returns a nibble.
-template <int CK, int VT, int PK>
-DEVFN uint32_t eval_quad(const PgScanLeaf& L, int64_t doc0) {
+// Predicate over the 4 docs of quad q of the tile → nibble.  KIND selects column layout × value type × predicate form.
+enum ScanKind : int {
+  SK_DICT_RANGE_SMALL, SK_DICT_RANGE_WIDE, SK_DICT_LUT_SMALL, SK_DICT_LUT_WIDE,
+  SK_I32_RANGE, SK_I32_SET, SK_F32_RANGE, SK_F32_SET, SK_I64_RANGE, SK_I64_SET, SK_F64_RANGE, SK_F64_SET
+};
+
+template <int KIND>
+DEVFN uint32_t eval_quad(const PgScanLeaf& L, const GAS uint8_t* __restrict__ tb, uint32_t q, const RangeI32& r32) {
   uint32_t r = 0;
-  if (CK == PG_COL_FIXED_BIT) {
+  if (KIND <= SK_DICT_LUT_WIDE) {
     uint32_t d[4];
-    extract4(L.data, doc0, L.bits, d);
+    const uint32_t mask = (1u << L.bits) - 1u;
+    extract4<(KIND == SK_DICT_RANGE_SMALL || KIND == SK_DICT_LUT_SMALL)>((const GAS uint32_t*)tb, q, (uint32_t)L.bits, mask, d);
 #pragma unroll
-    for (int i = 0; i < 4; i++) r |= (uint32_t)pred_dict<PK>(L, d[i]) << i;
-  } else if (CK == PG_COL_RAW32) {
-    uint4 v = *reinterpret_cast<const uint4*>(L.data + doc0 * 4);
+    for (int i = 0; i < 4; i++) {
+      bool m = (KIND == SK_DICT_RANGE_SMALL || KIND == SK_DICT_RANGE_WIDE) ? in_range_i32(r32, (int32_t)d[i])
+                                                                            : (bool)((gptr<uint32_t>(L.lut)[d[i] >> 5] >> (d[i] & 31u)) & 1u);
+      r |= (uint32_t)m << i;
+    }
+  } else if (KIND <= SK_F32_SET) {
+    u32x4 v = *(const GAS u32x4*)(tb + q * 16u);
     uint32_t x[4] = {bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w)};
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      bool m = (VT == PG_V_I32) ? pred_i64<PK>(L, (int64_t)(int32_t)x[i]) : pred_f64<PK>(L, (double)__uint_as_float(x[i]));
+      bool m;
+      if (KIND == SK_I32_RANGE) m = in_range_i32(r32, (int32_t)x[i]);
+      else if (KIND == SK_I32_SET) m = in_set_i64(L, (int64_t)(int32_t)x[i]);
+      else if (KIND == SK_F32_RANGE) { double f = (double)__uint_as_float(x[i]); m = f >= __longlong_as_double(L.lo) && f <= __longlong_as_double(L.hi); }
+      else m = in_set_f64(L, (double)__uint_as_float(x[i]));
       r |= (uint32_t)m << i;
     }
   } else {
-    const uint4* p = reinterpret_cast<const uint4*>(L.data + doc0 * 8);
-    uint4 a = p[0], b = p[1];
+    const GAS u32x4* p = (const GAS u32x4*)(tb + q * 32u);
+    u32x4 a = p[0], b = p[1];
     uint64_t x[4] = {((uint64_t)bswap32(a.x) << 32) | bswap32(a.y), ((uint64_t)bswap32(a.z) << 32) | bswap32(a.w),
                      ((uint64_t)bswap32(b.x) << 32) | bswap32(b.y), ((uint64_t)bswap32(b.z) << 32) | bswap32(b.w)};
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      bool m = (VT == PG_V_I64) ? pred_i64<PK>(L, (int64_t)x[i]) : pred_f64<PK>(L, __longlong_as_double((int64_t)x[i]));
+      bool m;
+      if (KIND == SK_I64_RANGE) m = (int64_t)x[i] >= L.lo && (int64_t)x[i] <= L.hi;
+      else if (KIND == SK_I64_SET) m = in_set_i64(L, (int64_t)x[i]);
+      else if (KIND == SK_F64_RANGE) { double f = __longlong_as_double((int64_t)x[i]); m = f >= __longlong_as_double(L.lo) && f <= __longlong_as_double(L.hi); }
+      else m = in_set_f64(L, __longlong_as_double((int64_t)x[i]));
       r |= (uint32_t)m << i;
     }
   }
   return r;
 }
 
-// Scan leaf over one tile.  MASKED: AND into `words` in place, evaluating only quads with candidates.
-template <int CK, int VT, int PK, bool MASKED>
-DEVFN uint32_t scan_tile(const PgScanLeaf& L, uint32_t* __restrict__ words32, int64_t tile_base, int32_t n_valid) {
+// Scan leaf over one tile.  MASKED: AND into `words32` in place, evaluating only quads that still have candidates
+// (ScanBasedDocIdIterator.applyAnd); returns the number of candidate docs this thread evaluated.
+template <int KIND, bool MASKED>
+DEVFN uint32_t scan_tile(const PgScanLeaf& L, uint32_t* __restrict__ words32, const GAS uint8_t* __restrict__ tb, int32_t n_valid) {
   const int t = threadIdx.x;
-  const int sh = (t & 7) * 4;
+  const uint32_t sh = (uint32_t)(t & 7) * 4u;
+  const RangeI32 r32 = make_range_i32(L.lo, L.hi);
   uint32_t n_cand = 0;
-  constexpr int U = 4;
+  constexpr int U = (KIND == SK_DICT_RANGE_WIDE || KIND == SK_DICT_LUT_WIDE || KIND >= SK_I64_RANGE) ? 1 : 2;
   for (int q0 = t; q0 < PG_TILE_QUADS; q0 += PG_BLOCK * U) {
     uint32_t cand[U], res[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      int q = q0 + u * PG_BLOCK;
-      int nv = n_valid - 4 * q;
-      uint32_t vn = nv >= 4 ? 0xFu : (nv <= 0 ? 0u : ((1u << nv) - 1u));
+      const int q = q0 + u * PG_BLOCK;
+      const uint32_t vn = quad_valid_nibble(n_valid, q);
       cand[u] = MASKED ? ((words32[q >> 3] >> sh) & vn) : vn;
+      if ((KIND == SK_DICT_RANGE_SMALL || KIND == SK_DICT_RANGE_WIDE || KIND == SK_I32_RANGE) && r32.empty) cand[u] = 0;
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      int q = q0 + u * PG_BLOCK;
       res[u] = 0;
-      if (cand[u]) res[u] = eval_quad<CK, VT, PK>(L, tile_base + 4 * (int64_t)q) & cand[u];
+      if (cand[u]) res[u] = eval_quad<KIND>(L, tb, (uint32_t)(q0 + u * PG_BLOCK), r32) & cand[u];
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
-      int q = q0 + u * PG_BLOCK;
+      const int q = q0 + u * PG_BLOCK;
       if (MASKED) n_cand += __popc(cand[u]);
-      uint32_t x = or_reduce8(res[u] << sh);
+      const uint32_t x = or_reduce8(res[u] << sh);
       if ((t & 7) == 0) words32[q >> 3] = x;
     }
   }
@@ -154,41 +188,49 @@ DEVFN uint32_t scan_tile(const PgScanLeaf& L, uint32_t* __restrict__ words32, in
 }
 
 template <bool MASKED>
-DEVFN uint32_t scan_dispatch(const PgScanLeaf& L, uint32_t* words32, int64_t tile_base, int32_t n_valid) {
+DEVFN uint32_t scan_dispatch(const PgScanLeaf& L, uint32_t* words32, int tile, int32_t n_valid) {
   if (L.col_kind == PG_COL_FIXED_BIT) {
-    if (L.pred_kind == PG_P_RANGE) return scan_tile<PG_COL_FIXED_BIT, PG_V_I32, PG_P_RANGE, MASKED>(L, words32, tile_base, n_valid);
-    return scan_tile<PG_COL_FIXED_BIT, PG_V_I32, PG_P_DICT_LUT, MASKED>(L, words32, tile_base, n_valid);
+    const GAS uint8_t* tb = (const GAS uint8_t*)packed_tile_base(L.data, tile, L.bits);
+    if (L.pred_kind == PG_P_RANGE)
+      return L.bits <= 8 ? scan_tile<SK_DICT_RANGE_SMALL, MASKED>(L, words32, tb, n_valid) : scan_tile<SK_DICT_RANGE_WIDE, MASKED>(L, words32, tb, n_valid);
+    return L.bits <= 8 ? scan_tile<SK_DICT_LUT_SMALL, MASKED>(L, words32, tb, n_valid) : scan_tile<SK_DICT_LUT_WIDE, MASKED>(L, words32, tb, n_valid);
   }
   if (L.col_kind == PG_COL_RAW32) {
-    if (L.val_type == PG_V_I32) {
-      if (L.pred_kind == PG_P_RANGE) return scan_tile<PG_COL_RAW32, PG_V_I32, PG_P_RANGE, MASKED>(L, words32, tile_base, n_valid);
-      return scan_tile<PG_COL_RAW32, PG_V_I32, PG_P_SET, MASKED>(L, words32, tile_base, n_valid);
-    }
-    if (L.pred_kind == PG_P_RANGE) return scan_tile<PG_COL_RAW32, PG_V_F32, PG_P_RANGE, MASKED>(L, words32, tile_base, n_valid);
-    return scan_tile<PG_COL_RAW32, PG_V_F32, PG_P_SET, MASKED>(L, words32, tile_base, n_valid);
+    const GAS uint8_t* tb = gptr<uint8_t>(L.data + (size_t)tile * (PG_TILE_DOCS * 4));
+    if (L.val_type == PG_V_I32)
+      return L.pred_kind == PG_P_RANGE ? scan_tile<SK_I32_RANGE, MASKED>(L, words32, tb, n_valid) : scan_tile<SK_I32_SET, MASKED>(L, words32, tb, n_valid);
+    return L.pred_kind == PG_P_RANGE ? scan_tile<SK_F32_RANGE, MASKED>(L, words32, tb, n_valid) : scan_tile<SK_F32_SET, MASKED>(L, words32, tb, n_valid);
   }
-  if (L.val_type == PG_V_I64) {
-    if (L.pred_kind == PG_P_RANGE) return scan_tile<PG_COL_RAW64, PG_V_I64, PG_P_RANGE, MASKED>(L, words32, tile_base, n_valid);
-    return scan_tile<PG_COL_RAW64, PG_V_I64, PG_P_SET, MASKED>(L, words32, tile_base, n_valid);
-  }
-  if (L.pred_kind == PG_P_RANGE) return scan_tile<PG_COL_RAW64, PG_V_F64, PG_P_RANGE, MASKED>(L, words32, tile_base, n_valid);
-  return scan_tile<PG_COL_RAW64, PG_V_F64, PG_P_SET, MASKED>(L, words32, tile_base, n_valid);
+  const GAS uint8_t* tb = gptr<uint8_t>(L.data + (size_t)tile * (PG_TILE_DOCS * 8));
+  if (L.val_type == PG_V_I64)
+    return L.pred_kind == PG_P_RANGE ? scan_tile<SK_I64_RANGE, MASKED>(L, words32, tb, n_valid) : scan_tile<SK_I64_SET, MASKED>(L, words32, tb, n_valid);
+  return L.pred_kind == PG_P_RANGE ? scan_tile<SK_F64_RANGE, MASKED>(L, words32, tb, n_valid) : scan_tile<SK_F64_SET, MASKED>(L, words32, tb, n_valid);
 }
 
 // ---- posting leaf: OR the leaf's RoaringBitmap containers that intersect the tile ----------------------------------------
+// Container descriptors of the chunk are fetched with ONE vector load (lane e holds entry e) and broadcast with readlane,
+// so the dependent chain per leaf is chunk_start → entries → payload regardless of how many postings are OR-ed.
 DEVFN void postings_tile(const PgPostingLeaf& L, uint64_t* __restrict__ dst, int tile, uint64_t valid) {
   const int t = threadIdx.x;
+  const int lane = t & 63;
   const int chunk = tile / PG_TILES_PER_CHUNK;
   const int sub = tile % PG_TILES_PER_CHUNK;
-  const uint32_t cs = L.chunk_start[chunk], ce = L.chunk_start[chunk + 1];
+  const uint32_t cs = gptr<uint32_t>(L.chunk_start)[chunk], ce = gptr<uint32_t>(L.chunk_start)[chunk + 1];
   uint64_t acc = 0;
   bool scatter = false;
-  for (uint32_t e = cs; e < ce; e++) {
-    const PgContainer c = L.descs[L.chunk_desc[e]];
-    if (c.type == 1) {
-      acc |= reinterpret_cast<const uint64_t*>(L.containers + c.offset)[sub * PG_TILE_WORDS + t];
-    } else {
-      scatter = true;
+  for (uint32_t base = cs; base < ce; base += 64) {
+    const uint32_t n = (ce - base) < 64u ? (ce - base) : 64u;
+    u32x4 ent = {0, 0, 0, 0};
+    if ((uint32_t)lane < n) ent = gptr<u32x4>(L.entries)[base + lane];
+    for (uint32_t e = 0; e < n; e++) {
+      const uint32_t off_lo = __builtin_amdgcn_readlane(ent.x, e), off_hi = __builtin_amdgcn_readlane(ent.y, e);
+      const uint32_t kt = __builtin_amdgcn_readlane(ent.w, e);   // key | type << 16
+      if ((kt >> 16) == 1u) {
+        const GAS uint64_t* w = gptr<uint64_t>(L.containers + (((uint64_t)off_hi << 32) | off_lo));
+        acc |= w[sub * PG_TILE_WORDS + t];
+      } else {
+        scatter = true;
+      }
     }
   }
   if (scatter) {  // workgroup-uniform: array / run containers set bits with LDS atomics
@@ -197,9 +239,11 @@ DEVFN void postings_tile(const PgPostingLeaf& L, uint64_t* __restrict__ dst, int
     uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
     const uint32_t lo = (uint32_t)sub * PG_TILE_DOCS, hi = lo + PG_TILE_DOCS;  // low-16 range of this tile
     for (uint32_t e = cs; e < ce; e++) {
-      const PgContainer c = L.descs[L.chunk_desc[e]];
+      const u32x4 ce4 = gptr<u32x4>(L.entries)[e];
+      PgContainer c;
+      c.offset = ((uint64_t)ce4.y << 32) | ce4.x; c.n = ce4.z; c.key = (uint16_t)(ce4.w & 0xFFFF); c.type = (uint16_t)(ce4.w >> 16);
       if (c.type == 0) {
-        const uint16_t* vals = reinterpret_cast<const uint16_t*>(L.containers + c.offset);
+        const GAS uint16_t* vals = gptr<uint16_t>(L.containers + c.offset);
         uint32_t a = 0, b = c.n;  // lower_bound(lo)
         while (a < b) {
           uint32_t m = (a + b) >> 1;
@@ -212,7 +256,7 @@ DEVFN void postings_tile(const PgPostingLeaf& L, uint64_t* __restrict__ dst, int
           atomicOr(&d32[v >> 5], 1u << (v & 31));
         }
       } else if (c.type == 2) {
-        const uint16_t* runs = reinterpret_cast<const uint16_t*>(L.containers + c.offset);
+        const GAS uint16_t* runs = gptr<uint16_t>(L.containers + c.offset);
         for (uint32_t r = t; r < c.n; r += PG_BLOCK) {
           uint32_t s = runs[2 * r], eend = s + runs[2 * r + 1] + 1;  // [s, eend)
           if (eend <= lo || s >= hi) continue;
@@ -240,118 +284,129 @@ DEVFN void ranges_tile(const PgRangeLeaf& L, uint64_t* __restrict__ dst, int64_t
   const int t = threadIdx.x;
   const int64_t wb = tile_base + (int64_t)t * 64, we = wb + 63;
   const int64_t tile_end = tile_base + PG_TILE_DOCS - 1;
-  // first range whose hi >= tile_base (ranges ascending, disjoint)
-  int a = 0, b = L.n;
+  int a = 0, b = L.n;   // first range whose hi >= tile_base (ranges ascending, disjoint)
   while (a < b) {
     int m = (a + b) >> 1;
-    if ((int64_t)L.hi[m] < tile_base) a = m + 1; else b = m;
+    if ((int64_t)gptr<int32_t>(L.hi)[m] < tile_base) a = m + 1; else b = m;
   }
   uint64_t acc = 0;
   for (int r = a; r < L.n; r++) {
-    int64_t lo = L.lo[r], hi = L.hi[r];
+    int64_t lo = gptr<int32_t>(L.lo)[r], hi = gptr<int32_t>(L.hi)[r];
     if (lo > tile_end) break;
     if (hi < wb || lo > we) continue;
     int64_t s = lo > wb ? lo - wb : 0, e = hi < we ? hi - wb : 63;
-    uint64_t m = (~0ULL << s) & (~0ULL >> (63 - e));
-    acc |= m;
+    acc |= (~0ULL << s) & (~0ULL >> (63 - e));
   }
   dst[t] = acc & valid;
 }
 
 // ---- accumulator updates ----------------------------------------------------------------------------------------------
-DEVFN int64_t f64_order_key(double v) {  // order-preserving map double → int64 (for MIN/MAX via integer atomics)
+DEVFN int64_t f64_order_key(double v) {  // order-preserving map double → int64 (MIN/MAX through integer atomics)
   int64_t b = __double_as_longlong(v);
   return b ^ ((b >> 63) & 0x7FFFFFFFFFFFFFFFLL);
 }
-
-template <typename P>
-DEVFN void acc_update(P* slot, int fn, int is_float, int64_t iv, double fv) {
-  if (fn == PG_ACC_COUNT) {
-    atomicAdd(reinterpret_cast<unsigned long long*>(slot), 1ULL);
-  } else if (fn == PG_ACC_SUM) {
-    if (is_float) atomicAdd(reinterpret_cast<double*>(slot), fv);
-    else atomicAdd(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)iv);
-  } else {
-    if (is_float) {
-      if (fv != fv) return;  // Java: NaN > x and NaN < x are false → NaN never replaces the holder
-      iv = f64_order_key(fv);
-    }
-    if (fn == PG_ACC_MIN) atomicMin(reinterpret_cast<long long*>(slot), (long long)iv);
-    else atomicMax(reinterpret_cast<long long*>(slot), (long long)iv);
-  }
+DEVFN void acc_int(int64_t* slot, int fn, int64_t v) {
+  if (fn == PG_ACC_SUM) atomicAdd(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)v);
+  else if (fn == PG_ACC_MIN) atomicMin(reinterpret_cast<long long*>(slot), (long long)v);
+  else atomicMax(reinterpret_cast<long long*>(slot), (long long)v);
+}
+DEVFN void acc_float(int64_t* slot, int fn, double v) {
+  if (fn == PG_ACC_SUM) { atomicAdd(reinterpret_cast<double*>(slot), v); return; }
+  if (v != v) return;   // Java: NaN > x and NaN < x are false → NaN never replaces the holder
+  const int64_t k = f64_order_key(v);
+  if (fn == PG_ACC_MIN) atomicMin(reinterpret_cast<long long*>(slot), (long long)k);
+  else atomicMax(reinterpret_cast<long long*>(slot), (long long)k);
 }
 
-// loads the 4 values of a quad from a metric source as (int64, double) pairs
-DEVFN void load_values4(const PgValueSrc& S, int64_t doc0, uint32_t nib, int64_t iv[4], double fv[4]) {
-  if (S.col_kind == PG_COL_FIXED_BIT) {
-    uint32_t d[4];
-    extract4(S.data, doc0, S.bits, d);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      if (!((nib >> i) & 1)) { iv[i] = 0; fv[i] = 0; continue; }
-      switch (S.val_type) {
-        case PG_V_I32: iv[i] = reinterpret_cast<const int32_t*>(S.dict)[d[i]]; fv[i] = (double)iv[i]; break;
-        case PG_V_I64: iv[i] = reinterpret_cast<const int64_t*>(S.dict)[d[i]]; fv[i] = (double)iv[i]; break;
-        case PG_V_F32: fv[i] = (double)reinterpret_cast<const float*>(S.dict)[d[i]]; iv[i] = 0; break;
-        default: fv[i] = reinterpret_cast<const double*>(S.dict)[d[i]]; iv[i] = 0; break;
-      }
-    }
-  } else if (S.col_kind == PG_COL_RAW32) {
-    uint4 v = *reinterpret_cast<const uint4*>(S.data + doc0 * 4);
-    uint32_t x[4] = {bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w)};
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      if (S.val_type == PG_V_I32) { iv[i] = (int32_t)x[i]; fv[i] = (double)iv[i]; }
-      else { fv[i] = (double)__uint_as_float(x[i]); iv[i] = 0; }
-    }
-  } else {
-    const uint4* p = reinterpret_cast<const uint4*>(S.data + doc0 * 8);
-    uint4 a = p[0], b = p[1];
-    uint64_t x[4] = {((uint64_t)bswap32(a.x) << 32) | bswap32(a.y), ((uint64_t)bswap32(a.z) << 32) | bswap32(a.w),
-                     ((uint64_t)bswap32(b.x) << 32) | bswap32(b.y), ((uint64_t)bswap32(b.z) << 32) | bswap32(b.w)};
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      if (S.val_type == PG_V_I64) { iv[i] = (int64_t)x[i]; fv[i] = (double)iv[i]; }
-      else { fv[i] = __longlong_as_double((int64_t)x[i]); iv[i] = 0; }
-    }
-  }
-}
-
-// Aggregates the matching docs of one tile.  TABLE: accumulator table [n_ops][G*R] (LDS or HBM).
-template <typename TABLE>
-DEVFN void aggregate_tile(const PgQueryPlan& p, const uint32_t* __restrict__ mask32, int64_t tile_base, TABLE* table) {
+// Aggregates the matching docs of one tile into `table` ([n_ops][G*R] int64 slots, LDS or HBM).
+DEVFN void aggregate_tile(const PgQueryPlan& p, const uint32_t* __restrict__ mask32, int tile, int64_t* table) {
   const int t = threadIdx.x;
-  const int sh = (t & 7) * 4;
-  const int R = p.replicas;
-  const int64_t stride = (int64_t)p.n_groups * R;   // slots per op
-  const int rep = t & (R - 1);
+  const uint32_t sh = (uint32_t)(t & 7) * 4u;
+  const uint32_t R = (uint32_t)p.replicas;
+  const uint32_t stride = (uint32_t)p.n_groups * R;   // slots per op
+  const uint32_t rep = (uint32_t)t & (R - 1u);
   for (int q = t; q < PG_TILE_QUADS; q += PG_BLOCK) {
     const uint32_t nib = (mask32[q >> 3] >> sh) & 0xFu;
     if (nib == 0) continue;
-    const int64_t doc0 = tile_base + 4 * (int64_t)q;
-    int64_t key[4] = {0, 0, 0, 0};
+    uint32_t slot[4] = {rep, rep, rep, rep};
     for (int g = 0; g < p.n_group_cols; g++) {
+      const PgGroupCol& gc = p.gcols[g];
+      const GAS uint32_t* tw = packed_tile_base(gc.data, tile, gc.bits);
+      const uint32_t mask = (1u << gc.bits) - 1u;
+      const uint32_t mult = (uint32_t)gc.mult * R;
       uint32_t d[4];
-      extract4(p.gcols[g].data, doc0, p.gcols[g].bits, d);
+      if (gc.bits <= 8) extract4<true>(tw, (uint32_t)q, (uint32_t)gc.bits, mask, d);
+      else extract4<false>(tw, (uint32_t)q, (uint32_t)gc.bits, mask, d);
 #pragma unroll
-      for (int i = 0; i < 4; i++) key[i] += (int64_t)d[i] * p.gcols[g].mult;
+      for (int i = 0; i < 4; i++) slot[i] += d[i] * mult;
     }
-    int64_t slot[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) slot[i] = key[i] * R + rep;
-    int cur_src = -2;
-    int64_t iv[4] = {0, 0, 0, 0};
-    double fv[4] = {0, 0, 0, 0};
-    for (int o = 0; o < p.n_ops; o++) {   // ops are sorted by src on the host
-      const PgAccOp op = p.ops[o];
-      if (op.src != cur_src) {
-        cur_src = op.src;
-        if (cur_src >= 0) load_values4(p.srcs[cur_src], doc0, nib, iv, fv);
-      }
-      TABLE* base = table + (int64_t)o * stride;
+    int o = 0;
+    // COUNT ops (src < 0) come first
+    for (; o < p.n_ops && p.ops[o].src < 0; o++) {
+      int64_t* base = table + (size_t)o * stride;
 #pragma unroll
       for (int i = 0; i < 4; i++)
-        if ((nib >> i) & 1) acc_update(base + slot[i], op.fn, op.is_float, iv[i], fv[i]);
+        if ((nib >> i) & 1u) atomicAdd(reinterpret_cast<unsigned long long*>(base + slot[i]), 1ULL);
+    }
+    while (o < p.n_ops) {
+      const int src = p.ops[o].src;
+      const PgValueSrc& S = p.srcs[src];
+      int o_end = o;
+      while (o_end < p.n_ops && p.ops[o_end].src == src) o_end++;
+      if (S.col_kind == PG_COL_RAW32 || (S.col_kind == PG_COL_FIXED_BIT && (S.val_type == PG_V_I32 || S.val_type == PG_V_F32))) {
+        uint32_t x[4];
+        if (S.col_kind == PG_COL_RAW32) {
+          u32x4 v = *gptr<u32x4>(S.data + (size_t)tile * (PG_TILE_DOCS * 4) + (uint32_t)q * 16u);
+          x[0] = bswap32(v.x); x[1] = bswap32(v.y); x[2] = bswap32(v.z); x[3] = bswap32(v.w);
+        } else {
+          uint32_t d[4];
+          const GAS uint32_t* tw = packed_tile_base(S.data, tile, S.bits);
+          const uint32_t mask = (1u << S.bits) - 1u;
+          if (S.bits <= 8) extract4<true>(tw, (uint32_t)q, (uint32_t)S.bits, mask, d);
+          else extract4<false>(tw, (uint32_t)q, (uint32_t)S.bits, mask, d);
+#pragma unroll
+          for (int i = 0; i < 4; i++) x[i] = ((nib >> i) & 1u) ? gptr<uint32_t>(S.dict)[d[i]] : 0u;
+        }
+        for (int k = o; k < o_end; k++) {
+          const int fn = p.ops[k].fn;
+          int64_t* base = table + (size_t)k * stride;
+          if (S.val_type == PG_V_I32) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) if ((nib >> i) & 1u) acc_int(base + slot[i], fn, (int64_t)(int32_t)x[i]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) if ((nib >> i) & 1u) acc_float(base + slot[i], fn, (double)__uint_as_float(x[i]));
+          }
+        }
+      } else {
+        uint64_t x[4];
+        if (S.col_kind == PG_COL_RAW64) {
+          const GAS u32x4* pp = gptr<u32x4>(S.data + (size_t)tile * (PG_TILE_DOCS * 8) + (uint32_t)q * 32u);
+          u32x4 a = pp[0], b = pp[1];
+          x[0] = ((uint64_t)bswap32(a.x) << 32) | bswap32(a.y); x[1] = ((uint64_t)bswap32(a.z) << 32) | bswap32(a.w);
+          x[2] = ((uint64_t)bswap32(b.x) << 32) | bswap32(b.y); x[3] = ((uint64_t)bswap32(b.z) << 32) | bswap32(b.w);
+        } else {
+          uint32_t d[4];
+          const GAS uint32_t* tw = packed_tile_base(S.data, tile, S.bits);
+          const uint32_t mask = (1u << S.bits) - 1u;
+          if (S.bits <= 8) extract4<true>(tw, (uint32_t)q, (uint32_t)S.bits, mask, d);
+          else extract4<false>(tw, (uint32_t)q, (uint32_t)S.bits, mask, d);
+#pragma unroll
+          for (int i = 0; i < 4; i++) x[i] = ((nib >> i) & 1u) ? gptr<uint64_t>(S.dict)[d[i]] : 0ull;
+        }
+        for (int k = o; k < o_end; k++) {
+          const int fn = p.ops[k].fn;
+          int64_t* base = table + (size_t)k * stride;
+          if (S.val_type == PG_V_I64) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) if ((nib >> i) & 1u) acc_int(base + slot[i], fn, (int64_t)x[i]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) if ((nib >> i) & 1u) acc_float(base + slot[i], fn, __longlong_as_double((int64_t)x[i]));
+          }
+        }
+      }
+      o = o_end;
     }
   }
 }
@@ -360,20 +415,20 @@ DEVFN void aggregate_tile(const PgQueryPlan& p, const uint32_t* __restrict__ mas
 // The segment query kernel: persistent workgroups, tile = wg + k * gridDim.
 // dynamic LDS: [stack_depth][256] u64 filter stack, then the LDS accumulator table (LDS / SINGLE modes)
 // =====================================================================================================================
-extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_segment_query_kernel(const PgQueryPlan p) {
+extern "C" __global__ void __launch_bounds__(PG_BLOCK, PG_WG_PER_CU) pg_segment_query_kernel(const PgQueryPlan p) {
   extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
   __shared__ uint32_t s_stat[PG_MAX_STATS];
   const int t = threadIdx.x;
   uint64_t* stack = smem;
   int64_t* lds_table = reinterpret_cast<int64_t*>(smem + (size_t)p.stack_depth * PG_TILE_WORDS);
   const bool lds_agg = (p.agg_mode == PG_AGG_LDS || p.agg_mode == PG_AGG_SINGLE);
-  const int64_t table_slots = (int64_t)p.n_groups * p.replicas;
+  const uint32_t table_slots = (uint32_t)p.n_groups * (uint32_t)p.replicas;
 
   if (t < PG_MAX_STATS) s_stat[t] = 0;
   if (lds_agg) {
     for (int o = 0; o < p.n_ops; o++) {
       const int64_t ident = pg_acc_identity(p.ops[o].fn, p.ops[o].is_float);
-      for (int64_t i = t; i < table_slots; i += PG_BLOCK) lds_table[o * table_slots + i] = ident;
+      for (uint32_t i = t; i < table_slots; i += PG_BLOCK) lds_table[(size_t)o * table_slots + i] = ident;
     }
   }
   __syncthreads();
@@ -383,7 +438,7 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_segment_query_kernel(c
     const int64_t tile_base = (int64_t)tile * PG_TILE_DOCS;
     const int64_t rem = (int64_t)p.num_docs - tile_base;
     const int32_t n_valid = rem >= PG_TILE_DOCS ? PG_TILE_DOCS : (int32_t)rem;
-    const uint64_t valid = tile_valid_word(p.num_docs, tile_base + (int64_t)t * 64);
+    const uint64_t valid = tile_valid_word(n_valid, t);
 
     // ---- filter program -------------------------------------------------------------------------------------------
     int sp = 0;
@@ -404,14 +459,14 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_segment_query_kernel(c
           break;
         case PG_F_PUSH_SCAN:
           __syncthreads();
-          scan_dispatch<false>(p.scans[ins.arg], reinterpret_cast<uint32_t*>(stack + sp * PG_TILE_WORDS), tile_base, n_valid);
+          scan_dispatch<false>(p.scans[ins.arg], reinterpret_cast<uint32_t*>(stack + sp * PG_TILE_WORDS), tile, n_valid);
           sp++;
           __syncthreads();
           break;
         case PG_F_AND_SCAN: {
           __syncthreads();
           const PgScanLeaf& L = p.scans[ins.arg];
-          uint32_t nc = scan_dispatch<true>(L, reinterpret_cast<uint32_t*>(stack + (sp - 1) * PG_TILE_WORDS), tile_base, n_valid);
+          uint32_t nc = scan_dispatch<true>(L, reinterpret_cast<uint32_t*>(stack + (sp - 1) * PG_TILE_WORDS), tile, n_valid);
           nc = wave_sum_u32(nc);
           if ((t & 63) == 0 && nc) atomicAdd(&s_stat[L.stat_slot], nc);
           __syncthreads();
@@ -443,8 +498,8 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_segment_query_kernel(c
     // ---- aggregation ----------------------------------------------------------------------------------------------
     if (p.agg_mode != PG_AGG_NONE) {
       __syncthreads();   // stack[0] complete for every quad reader
-      if (lds_agg) aggregate_tile<int64_t>(p, reinterpret_cast<const uint32_t*>(stack), tile_base, lds_table);
-      else aggregate_tile<int64_t>(p, reinterpret_cast<const uint32_t*>(stack), tile_base, p.partials);
+      if (lds_agg) aggregate_tile(p, reinterpret_cast<const uint32_t*>(stack), tile, lds_table);
+      else aggregate_tile(p, reinterpret_cast<const uint32_t*>(stack), tile, p.partials);
     }
     __syncthreads();     // before the next tile overwrites the stack
   }

@@ -368,19 +368,18 @@ struct Emitter {
     for (int32_t id : ids)
       for (uint32_t k = c.posting_begin[id]; k < c.posting_begin[id + 1]; k++) chunk_start[c.descs_host[k].key + 1]++;
     for (size_t i = 1; i < chunk_start.size(); i++) chunk_start[i] += chunk_start[i - 1];
-    std::vector<uint32_t> chunk_desc(chunk_start.back());
+    std::vector<PgContainer> entries(chunk_start.back());
     std::vector<uint32_t> cursor(chunk_start.begin(), chunk_start.end() - 1);
     for (int32_t id : ids)
       for (uint32_t k = c.posting_begin[id]; k < c.posting_begin[id + 1]; k++) {
         const PgContainer& pc = c.descs_host[k];
-        chunk_desc[cursor[pc.key]++] = k;
+        entries[cursor[pc.key]++] = pc;
         alg_bytes += pc.type == 1 ? 8192 : (pc.type == 0 ? 2 * (int64_t)pc.n : 4 * (int64_t)pc.n);
       }
     PgPostingLeaf L{};
     L.containers = c.containers_dev.as<uint8_t>();
-    L.descs = c.descs_dev.as<PgContainer>();
     L.chunk_start = keep(chunk_start);
-    L.chunk_desc = keep(chunk_desc);
+    L.entries = keep(entries);
     L.exclusive = e.exclusive ? 1 : 0;
     postings.push_back(L);
     instrs.push_back({PG_F_PUSH_POSTINGS, (int32_t)postings.size() - 1});
@@ -596,7 +595,22 @@ std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* f
     ops.push_back({fn, src, is_float ? 1 : 0, 0});
     return (int32_t)ops.size() - 1;
   };
-  const int32_t count_op = op_index(PG_ACC_COUNT, -1, false);   // always present: tells which groups exist
+  // Which groups exist?  ArrayBasedHolder keeps a flag per raw key; here a group exists iff its COUNT is > 0 or — when the
+  // query has no COUNT/AVG but has a MIN/MAX over an INT source — iff that accumulator left its identity (saves one LDS
+  // atomic per matching doc).
+  bool need_count = false;
+  for (int i = 0; i < q->n_aggregations; i++)
+    need_count |= (q->aggregations[i].function == PG_AGG_COUNT || q->aggregations[i].function == PG_AGG_AVG);
+  bool has_int_minmax = false;
+  for (int i = 0; i < q->n_aggregations && !need_count; i++) {
+    const pg_agg_spec& s = q->aggregations[i];
+    if (s.function == PG_AGG_MIN || s.function == PG_AGG_MAX || s.function == PG_AGG_MINMAXRANGE) {
+      Column* c = seg.find(s.column);
+      if (c && c->val_type == PG_V_I32 && c->data_type == PG_TYPE_INT) has_int_minmax = true;
+    }
+  }
+  if (!has_int_minmax) need_count = true;
+  const int32_t count_op = need_count ? op_index(PG_ACC_COUNT, -1, false) : -1;
   for (int i = 0; i < q->n_aggregations; i++) {
     const pg_agg_spec& s = q->aggregations[i];
     AggOut out{};
@@ -629,6 +643,15 @@ std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* f
   std::vector<PgAccOp> sorted_ops(ops.size());
   for (size_t i = 0; i < order.size(); i++) { sorted_ops[i] = ops[order[i]]; remap[order[i]] = (int32_t)i; }
   for (auto& a : P.aggs) { if (a.op_a >= 0) a.op_a = remap[a.op_a]; if (a.op_b >= 0) a.op_b = remap[a.op_b]; }
+  P.exist_op = -1;
+  for (size_t i = 0; i < sorted_ops.size(); i++) {
+    if (sorted_ops[i].fn == PG_ACC_COUNT) { P.exist_op = (int32_t)i; break; }
+  }
+  if (P.exist_op < 0)
+    for (size_t i = 0; i < sorted_ops.size(); i++)
+      if ((sorted_ops[i].fn == PG_ACC_MIN || sorted_ops[i].fn == PG_ACC_MAX) && !sorted_ops[i].is_float &&
+          srcs[sorted_ops[i].src]->val_type == PG_V_I32) { P.exist_op = (int32_t)i; break; }
+  if (P.exist_op < 0) fail(PG_ERR_INTERNAL, "no existence accumulator");
   D.n_ops = (int32_t)sorted_ops.size();
   for (int i = 0; i < D.n_ops; i++) D.ops[i] = sorted_ops[i];
   P.ops_dev = upload_vector(sorted_ops);
@@ -651,7 +674,8 @@ std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* f
   } else if (table_bytes <= kLdsTableBudget) {
     D.agg_mode = PG_AGG_LDS;
     int r = 1;
-    while (r < 32 && table_bytes * (r * 2) <= kLdsTableBudget / 2) r *= 2;
+    const int64_t per_wg_budget = 20 * 1024 - (int64_t)D.stack_depth * PG_TILE_WORDS * 8;   // 160 KB / 8 workgroups
+    while (r < 32 && table_bytes * (r * 2) <= per_wg_budget) r *= 2;
     D.replicas = r;
   } else {
     D.agg_mode = PG_AGG_GLOBAL;
