@@ -1,9 +1,12 @@
 // Device-side plan layout shared by the host planner (pg_plan.cpp) and the HIP kernels (pg_kernels.hip).
 //
-// Execution model: a segment is cut into tiles of PG_TILE_DOCS consecutive docIds.  A persistent
-// workgroup walks tiles round-robin; per tile it (1) runs the compiled filter program over a small stack of
-// PG_TILE_WORDS-word bitsets held in LDS, (2) optionally stores the resulting match words / popcounts, and
-// (3) streams the group-by and metric columns of the tile, aggregating the matching docs into LDS accumulators.
+// Execution model: a segment is cut into wave tiles of PG_WAVE_DOCS consecutive docIds.  One workgroup of
+// PG_BLOCK threads (16 wavefronts) is resident per CU; its wavefronts walk wave tiles independently (no barrier in the
+// main loop).  Per wave tile a wavefront (1) runs the compiled filter program over a register stack of match masks
+// (one dword per lane = 32 docs per lane in "quad layout": lane L owns quads k*64+L, k = 0..7, of 4 consecutive docs),
+// (2) optionally stores the resulting match words / popcounts, and (3) streams the group-by and metric columns of the
+// tile, aggregating the matching docs into the workgroup's LDS accumulator table.  PG_TILE_DOCS (8 wave tiles) is
+// only the padding / docId-expansion granule.
 #pragma once
 #include <stdint.h>
 
@@ -12,15 +15,17 @@
 #define PG_TILE_QUADS 4096         // 4-doc quads per tile
 #define PG_CHUNK_DOCS 65536        // RoaringBitmap container span
 #define PG_TILES_PER_CHUNK 4
+#define PG_WAVE_DOCS 2048          // docs per wave tile: 64 lanes x 8 quads x 4 docs
+#define PG_WAVE_QUADS 512
+#define PG_WTILES_PER_TILE 8
+#define PG_WTILES_PER_CHUNK 32
+#define PG_WAVES_PER_BLOCK 16
 #define PG_MAX_STACK 6
 #define PG_MAX_GROUP_COLS 8
 #define PG_MAX_SRCS 8
 #define PG_MAX_OPS 16
 #define PG_MAX_STATS 16
-#define PG_BLOCK 256
-#ifndef PG_WG_PER_CU
-#define PG_WG_PER_CU 6            // resident workgroups per CU the query kernel is compiled for (__launch_bounds__)
-#endif
+#define PG_BLOCK 1024             // one 16-wave workgroup per CU: every wave shares one LDS accumulator table
 
 // ---- filter program --------------------------------------------------------------------------------------------------
 enum PgFOp : int32_t {
@@ -31,7 +36,8 @@ enum PgFOp : int32_t {
   PG_F_AND = 4,             // pop b, top &= b
   PG_F_OR = 5,              // pop b, top |= b
   PG_F_NOT = 6,             // top = ~top & valid
-  PG_F_PUSH_NONE = 7        // push empty set
+  PG_F_PUSH_NONE = 7,       // push empty set
+  PG_F_PUSH_ALL = 8         // push every doc of the tile (MatchAllFilterOperator)
 };
 
 struct PgFInstr {
@@ -71,12 +77,18 @@ struct PgContainer {
   uint16_t type;     // 0 array, 1 bitmap, 2 run
 };
 
+#define PG_MAX_DENSE 8
 struct PgPostingLeaf {
   const uint8_t* containers;
   const uint32_t* chunk_start;    // CSR over chunks: entries [chunk_start[c], chunk_start[c+1]) of `entries`
   const PgContainer* entries;     // the leaf's containers grouped by chunk (copied inline: one dependent load less)
   int32_t exclusive;
-  int32_t pad;
+  int32_t has_csr;                // 0: every container of the leaf is served by the dense pointers below
+  // Dense postings: a dictId whose containers of chunks [0, dense_chunks) are all bitmap containers laid out back to
+  // back (8 KB stride) is addressed arithmetically — no descriptor loads on the per-tile path.
+  const uint8_t* dense[PG_MAX_DENSE];
+  int32_t n_dense;
+  int32_t dense_chunks;
 };
 
 struct PgRangeLeaf {
@@ -90,7 +102,7 @@ struct PgRangeLeaf {
 enum PgAccFn : int32_t { PG_ACC_COUNT = 0, PG_ACC_SUM = 1, PG_ACC_MIN = 2, PG_ACC_MAX = 3 };
 enum PgAggMode : int32_t {
   PG_AGG_NONE = 0,
-  PG_AGG_SINGLE = 1,   // no GROUP BY: per-thread registers, one flush per workgroup
+  PG_AGG_SINGLE = 1,   // no GROUP BY: one private LDS slot per thread, one flush per workgroup
   PG_AGG_LDS = 2,      // accumulator table [n_acc][G*R] in LDS, flushed to per-workgroup partials
   PG_AGG_GLOBAL = 3    // accumulator table [n_acc][G] in HBM, device-scope atomics
 };
@@ -120,7 +132,9 @@ struct PgAccOp {
 
 struct PgQueryPlan {
   int32_t num_docs;
-  int32_t n_tiles;
+  int32_t n_tiles;                  // 16 384-doc tiles (allocation / expansion granule)
+  int32_t n_wtiles;                 // 2 048-doc wave tiles
+  int32_t pad_w;
   int32_t n_instr;
   int32_t stack_depth;
   const PgFInstr* instrs;
@@ -132,6 +146,12 @@ struct PgQueryPlan {
   uint32_t* out_tile_counts;        // nullable: matches per tile
   unsigned long long* stats;        // [PG_MAX_STATS]: slot 0 = matched docs, slots 1.. = candidates per AND_SCAN leaf
   // aggregation stage
+  // fast path (pg_fast_query_kernel<SK, AGG>): instrs[0, n_index_instr) is an index-only program (postings / ranges /
+  // AND / OR / NOT), optionally followed by ONE scan leaf of kind fast_scan_kind restricted to its result
+  int32_t n_index_instr;
+  int32_t fast_scan;                // index into scans, -1: none
+  int32_t fast_scan_pushed;         // the scan is the whole filter (PUSH_SCAN): candidates = every doc
+  int32_t pad_f;
   int32_t agg_mode;
   int32_t n_group_cols;
   int32_t n_srcs;

@@ -11,6 +11,9 @@
 #include "pg_internal.hpp"
 
 extern "C" __global__ void pg_segment_query_kernel(const PgQueryPlan p);
+#define PG_DECL_FAST(NAME) extern "C" __global__ void NAME(const PgQueryPlan p);
+PG_DECL_FAST(pg_fast_none_f) PG_DECL_FAST(pg_fast_none_a) PG_DECL_FAST(pg_fast_i32range_f) PG_DECL_FAST(pg_fast_i32range_a)
+PG_DECL_FAST(pg_fast_dictrange_f) PG_DECL_FAST(pg_fast_dictrange_a) PG_DECL_FAST(pg_fast_dictlut_f) PG_DECL_FAST(pg_fast_dictlut_a)
 extern "C" __global__ void pg_reduce_partials_kernel(const int64_t* partials, int64_t* out, int n_wg, int n_ops,
                                                      int n_groups, const PgAccOp* ops);
 extern "C" __global__ void pg_fill_i64_kernel(int64_t* dst, int64_t n_per_op, int n_ops, const PgAccOp* ops);
@@ -66,9 +69,29 @@ void device_init(int ordinal) {
   g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   g_lds_per_cu = prop.maxSharedMemoryPerMultiProcessor > 0 ? (size_t)prop.maxSharedMemoryPerMultiProcessor : 160 * 1024;
   g_device = ordinal;
-  // opt in to large dynamic LDS for the query kernel
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pg_segment_query_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+  // opt in to large dynamic LDS for the query kernels
+  typedef void (*QueryKernel)(const PgQueryPlan);
+  const QueryKernel all[] = {pg_segment_query_kernel, pg_fast_none_f, pg_fast_none_a, pg_fast_i32range_f, pg_fast_i32range_a,
+                             pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a};
+  for (QueryKernel k : all)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
+}
+
+// Kernel selection: the specialised fast kernels when both the filter and the aggregation have the fast shape.
+typedef void (*QueryKernel)(const PgQueryPlan);
+static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char** name) {
+  const bool agg = agg_mode != PG_AGG_NONE;
+  if (P.fast_filter != -2 && (!agg || (P.fast_agg && agg_mode != PG_AGG_GLOBAL))) {
+    switch (P.fast_filter) {
+      case -1: *name = agg ? "pg_fast_none_a" : "pg_fast_none_f"; return agg ? pg_fast_none_a : pg_fast_none_f;
+      case 4: *name = agg ? "pg_fast_i32range_a" : "pg_fast_i32range_f"; return agg ? pg_fast_i32range_a : pg_fast_i32range_f;
+      case 0: *name = agg ? "pg_fast_dictrange_a" : "pg_fast_dictrange_f"; return agg ? pg_fast_dictrange_a : pg_fast_dictrange_f;
+      case 2: *name = agg ? "pg_fast_dictlut_a" : "pg_fast_dictlut_f"; return agg ? pg_fast_dictlut_a : pg_fast_dictlut_f;
+      default: break;
+    }
+  }
+  *name = "pg_segment_query_kernel";
+  return pg_segment_query_kernel;
 }
 
 struct ThreadCtx {
@@ -111,10 +134,10 @@ static std::shared_ptr<CompiledPlan> get_plan(Segment& seg, const pg_filter_node
 }
 
 struct LaunchShape { int grid; size_t lds; };
-static LaunchShape launch_shape(const CompiledPlan& P, int n_tiles) {
+static LaunchShape launch_shape(const CompiledPlan& P, int n_wtiles) {
+  // one 16-wave workgroup per CU; fewer when the segment has fewer wave tiles than that
   size_t lds = P.lds_bytes + 64;
-  int per_cu = (int)std::min<size_t>(PG_WG_PER_CU, std::max<size_t>(1, (g_lds_per_cu - 1024) / (lds + 128)));
-  int grid = std::min(n_tiles, g_num_cus * per_cu);
+  int grid = std::min((n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, g_num_cus);
   return {std::max(grid, 1), lds};
 }
 
@@ -147,7 +170,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   const bool profile = (q.flags & PG_QUERY_FLAG_PROFILE) != 0;
 
   PgQueryPlan D = P.dev;
-  const LaunchShape shape = launch_shape(P, seg.n_tiles);
+  const LaunchShape shape = launch_shape(P, P.dev.n_wtiles);
   const int64_t n_out = (int64_t)D.n_ops * D.n_groups;
   PG_HIP(hipMemsetAsync(ctx.stats.ptr, 0, PG_MAX_STATS * 8, ctx.stream));
   D.stats = ctx.stats.as<unsigned long long>();
@@ -163,14 +186,16 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   }
   if (profile) PG_HIP(hipEventRecord(ctx.ev[0], ctx.stream));
   if (seg.total_docs > 0) {
-    hipLaunchKernelGGL(pg_segment_query_kernel, dim3(shape.grid), dim3(PG_BLOCK), shape.lds, ctx.stream, D);
+    const char* kname = nullptr;
+    QueryKernel kern = select_kernel(P, D.agg_mode, &kname);
+    hipLaunchKernelGGL(kern, dim3(shape.grid), dim3(PG_BLOCK), shape.lds, ctx.stream, D);
     PG_HIP(hipGetLastError());
   }
   if (profile) PG_HIP(hipEventRecord(ctx.ev[1], ctx.stream));
   std::vector<int64_t> table((size_t)n_out);
   if (seg.total_docs > 0) {
     if (D.agg_mode != PG_AGG_GLOBAL) {
-      int blocks = (int)((n_out + 255) / 256);
+      int blocks = (int)((n_out + 3) / 4);   // one wavefront per output slot
       hipLaunchKernelGGL(pg_reduce_partials_kernel, dim3(blocks), dim3(256), 0, ctx.stream, ctx.partials.as<int64_t>(),
                          ctx.final_table.as<int64_t>(), shape.grid, D.n_ops, D.n_groups, P.ops_dev.as<PgAccOp>());
       PG_HIP(hipGetLastError());
@@ -283,10 +308,12 @@ std::unique_ptr<DocIdSet> execute_filter(Segment& seg, const pg_filter_node* fil
   D.out_words = out->words.as<uint64_t>();
   D.out_tile_counts = ctx.tile_counts.as<uint32_t>();
   D.agg_mode = PG_AGG_NONE;
-  const LaunchShape shape = launch_shape(P, seg.n_tiles);
+  const LaunchShape shape = launch_shape(P, P.dev.n_wtiles);
   PG_HIP(hipEventRecord(ctx.ev[0], ctx.stream));
   if (seg.total_docs > 0) {
-    hipLaunchKernelGGL(pg_segment_query_kernel, dim3(shape.grid), dim3(PG_BLOCK), shape.lds, ctx.stream, D);
+    const char* kname = nullptr;
+    QueryKernel kern = select_kernel(P, PG_AGG_NONE, &kname);
+    hipLaunchKernelGGL(kern, dim3(shape.grid), dim3(PG_BLOCK), shape.lds, ctx.stream, D);
     PG_HIP(hipGetLastError());
   }
   PG_HIP(hipEventRecord(ctx.ev[1], ctx.stream));
@@ -316,7 +343,7 @@ void docidset_copy_docids(DocIdSet& s, int32_t* out, int64_t cap) {
   DeviceBuffer d_offs = upload_vector(offs);
   DeviceBuffer d_out((size_t)s.cardinality * 4);
   int grid = std::min(n_tiles, g_num_cus * 8);
-  hipLaunchKernelGGL(pg_expand_docids_kernel, dim3(grid), dim3(PG_BLOCK), 0, ctx.stream, s.words.as<uint64_t>(),
+  hipLaunchKernelGGL(pg_expand_docids_kernel, dim3(grid), dim3(PG_TILE_WORDS), 0, ctx.stream, s.words.as<uint64_t>(),
                      d_offs.as<int64_t>(), d_out.as<int32_t>(), n_tiles);
   PG_HIP(hipGetLastError());
   PG_HIP(hipMemcpyAsync(out, d_out.ptr, (size_t)s.cardinality * 4, hipMemcpyDeviceToHost, ctx.stream));

@@ -9,24 +9,38 @@
 //   K6    group keys         DictionaryBasedGroupKeyGenerator raw keys          (core/query/aggregation/groupby/DictionaryBasedGroupKeyGenerator.java:312-354)
 //   K7    aggregation        Sum/Count/Min/Max aggregateGroupBySV               (core/query/aggregation/function/SumAggregationFunction.java:160-179 ...)
 //
-// Hardware mapping: the path is HBM-bound integer/bitmap work (no MFMA).  Persistent 256-thread workgroups walk 16 384-doc
-// tiles; every column is read once with loads that are contiguous across the wavefront (16 B/lane for raw columns, dword
-// pairs for bit-packed ones) through a wave-uniform tile base (SGPR) + 32-bit lane offset; match bits are assembled with
-// DPP row operations into 64-bit words held in LDS; group accumulators live in LDS (ds_add_u64 / ds_max_i64 / ds_add_f64)
-// and are flushed once per workgroup.  Register use is kept under 64 VGPRs so that 8 workgroups (32 waves) share a CU:
-// occupancy, not instruction-level unrolling, is what hides HBM latency here.
+// Hardware mapping: the path is HBM-bound integer/bitmap work (no MFMA).  One persistent 1024-thread workgroup per CU;
+// each of its 16 wavefronts walks 2 048-doc wave tiles on its own — there is no barrier and no LDS staging in the main
+// loop.  The filter program runs on a register stack of match masks in "quad layout": lane L of the wavefront owns the
+// quads k*64+L (k = 0..7) of 4 consecutive docs, bit 4k+i of its mask dword is doc 4(k*64+L)+i of the tile.  In that
+// layout every forward-index load is contiguous across the wavefront (16 B/lane for raw columns, a dword pair for
+// bit-packed ones) and all quads of a lane are fetched before the first is used (up to 8 KB in flight per wavefront).
+// Posting bitmaps and docId ranges are produced one dword (32 consecutive docs) per lane and transposed into quad layout
+// with 8 ds_bpermute.  Group accumulators live in the workgroup's LDS table (ds_add_u64 / ds_max_i64 / ds_add_f64),
+// shared by the 16 wavefronts and flushed once per workgroup.
 #include <hip/hip_runtime.h>
 
 #include "pg_device.h"
 
 #define DEVFN __device__ __forceinline__
+#ifndef PG_FAST_AGG_B
+#define PG_FAST_AGG_B 4
+#endif
 // Pointers that were themselves loaded from memory (plan leaves) have no address space the compiler can infer and would
 // be accessed with flat_load; every column / index byte lives in HBM, so say so.
 #define GAS __attribute__((address_space(1)))
 template <typename T> DEVFN const GAS T* gptr(const void* p) { return (const GAS T*)p; }
+// Plan descriptors (filter program, leaves) are written by the host before the launch and never by a kernel: reading
+// them through the constant address space lets the compiler use scalar loads (s_load → SGPRs, hoistable out of the tile
+// loop) instead of a chain of vector loads each waited for with vmcnt(0).
+#define CAS __attribute__((address_space(4)))
+template <typename T> DEVFN const CAS T* cptr(const T* p) { return (const CAS T*)p; }
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef u32x2 u32x2_a4 __attribute__((aligned(4)));   // dword-aligned pair (bit-packed windows)
 
 DEVFN uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
+DEVFN int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // OR across aligned groups of 8 lanes (two quads) with DPP row operations.
 DEVFN uint32_t or_reduce8(uint32_t v) {
@@ -42,43 +56,49 @@ DEVFN uint32_t wave_sum_u32(uint32_t v) {
   return v;
 }
 
-DEVFN uint64_t tile_valid_word(int32_t n_valid, int word) {   // n_valid: docs of this tile below numDocs
-  int rem = n_valid - word * 64;
-  if (rem >= 64) return ~0ULL;
-  if (rem <= 0) return 0ULL;
-  return (1ULL << rem) - 1ULL;
-}
-DEVFN uint32_t quad_valid_nibble(int32_t n_valid, int q) {
-  int nv = n_valid - 4 * q;
-  return nv >= 4 ? 0xFu : (nv <= 0 ? 0u : ((1u << nv) - 1u));
-}
-
-// ---- bit-packed (FixedBitSVForwardIndexReaderV2) extraction ---------------------------------------------------------------
-// tw: wave-uniform pointer to the tile's first dword (a tile of 16 384 values starts on a dword boundary for any width);
-// q: quad index inside the tile; values 4q .. 4q+3.
-template <bool SMALL>
-DEVFN void extract4(const GAS uint32_t* __restrict__ tw, uint32_t q, uint32_t bits, uint32_t mask, uint32_t out[4]) {
-  if (SMALL) {   // bits <= 8: the four values sit inside one 64-bit window
-    uint32_t bitpos = 4u * q * bits;
-    uint32_t di = bitpos >> 5, sh = bitpos & 31u;
-    uint64_t win = ((uint64_t)bswap32(tw[di]) << 32) | (uint64_t)bswap32(tw[di + 1]);
+// ---- mask layouts ---------------------------------------------------------------------------------------------------------
+// linear: lane L holds docs 32L .. 32L+31 of the wave tile (bit i = doc 32L+i) — what bitmap containers deliver
+// quad:   lane L holds quads k*64+L, k = 0..7 (bit 4k+i = doc 4(k*64+L)+i)    — what 16 B/lane column loads deliver
+DEVFN uint32_t lin_to_quad(uint32_t w, int lane) {
+  uint32_t out = 0;
+  const uint32_t sh = (uint32_t)(lane & 7) * 4u;
+  const int src0 = lane >> 3;
 #pragma unroll
-    for (int i = 0; i < 4; i++) out[i] = (uint32_t)(win >> (64u - sh - (uint32_t)(i + 1) * bits)) & mask;
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      uint32_t bitpos = (4u * q + (uint32_t)i) * bits;
-      uint32_t di = bitpos >> 5, sh = bitpos & 31u;
-      uint64_t win = ((uint64_t)bswap32(tw[di]) << 32) | (uint64_t)bswap32(tw[di + 1]);
-      out[i] = (uint32_t)(win >> (64u - sh - bits)) & mask;
-    }
+  for (int k = 0; k < 8; k++) {
+    const uint32_t x = (uint32_t)__shfl((int)w, k * 8 + src0, 64);   // dword holding quads 8(k*8+src0) .. +7
+    out |= ((x >> sh) & 0xFu) << (4 * k);
   }
+  return out;
 }
-DEVFN const GAS uint32_t* packed_tile_base(const uint8_t* data, int tile, int bits) {
-  return gptr<uint32_t>(data + (size_t)tile * (size_t)(PG_TILE_DOCS / 8) * (size_t)bits);
+DEVFN uint32_t quad_to_lin(uint32_t m, int lane) {
+  uint32_t out = 0;
+  const uint32_t sh = (uint32_t)(lane & 7) * 4u;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    uint32_t x = ((m >> (4 * k)) & 0xFu) << sh;
+    x = or_reduce8(x);                                                 // lanes 8g..8g+7 hold linear dword k*8+g
+    const uint32_t z = (uint32_t)__shfl((int)x, (lane & 7) * 8, 64);
+    if ((lane >> 3) == k) out = z;
+  }
+  return out;
+}
+DEVFN uint32_t valid_lin_mask(int32_t n_valid, int lane) {   // n_valid: docs of this wave tile below numDocs
+  const int rem = n_valid - lane * 32;
+  return rem >= 32 ? 0xFFFFFFFFu : (rem <= 0 ? 0u : ((1u << rem) - 1u));
+}
+DEVFN uint32_t valid_quad_mask(int32_t n_valid, int lane) {
+  if (n_valid >= PG_WAVE_DOCS) return 0xFFFFFFFFu;
+  uint32_t m = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int nv = n_valid - 4 * (k * 64 + lane);
+    const uint32_t nib = nv >= 4 ? 0xFu : (nv <= 0 ? 0u : ((1u << nv) - 1u));
+    m |= nib << (4 * k);
+  }
+  return m;
 }
 
-// ---- predicates ---------------------------------------------------------------------------------------------------------------
+// ---- predicates -----------------------------------------------------------------------------------------------------------
 struct RangeI32 { int32_t lo; uint32_t span; bool empty; };
 DEVFN RangeI32 make_range_i32(int64_t lo, int64_t hi) {
   RangeI32 r;
@@ -89,14 +109,14 @@ DEVFN RangeI32 make_range_i32(int64_t lo, int64_t hi) {
 }
 DEVFN bool in_range_i32(const RangeI32& r, int32_t v) { return (uint32_t)(v - r.lo) <= r.span; }
 
-DEVFN bool in_set_i64(const PgScanLeaf& L, int64_t v) {
+template <class LeafT> DEVFN bool in_set_i64(const LeafT& L, int64_t v) {
   const GAS int64_t* s = gptr<int64_t>(L.set_values);
   bool hit = false;
 #pragma unroll 1
   for (int i = 0; i < L.n_set; i++) hit |= (s[i] == v);
   return hit != (L.exclusive != 0);
 }
-DEVFN bool in_set_f64(const PgScanLeaf& L, double v) {
+template <class LeafT> DEVFN bool in_set_f64(const LeafT& L, double v) {
   const GAS double* s = gptr<double>(L.set_values);
   bool hit = false;
 #pragma unroll 1
@@ -104,119 +124,179 @@ DEVFN bool in_set_f64(const PgScanLeaf& L, double v) {
   return hit != (L.exclusive != 0);
 }
 
-// Predicate over the 4 docs of quad q of the tile → nibble.  KIND selects column layout × value type × predicate form.
+// KIND selects column layout × value type × predicate form.
 enum ScanKind : int {
   SK_DICT_RANGE_SMALL, SK_DICT_RANGE_WIDE, SK_DICT_LUT_SMALL, SK_DICT_LUT_WIDE,
   SK_I32_RANGE, SK_I32_SET, SK_F32_RANGE, SK_F32_SET, SK_I64_RANGE, SK_I64_SET, SK_F64_RANGE, SK_F64_SET
 };
+DEVFN constexpr bool sk_small(int k) { return k == SK_DICT_RANGE_SMALL || k == SK_DICT_LUT_SMALL; }
+DEVFN constexpr bool sk_dict(int k) { return k <= SK_DICT_LUT_WIDE; }
+DEVFN constexpr bool sk_raw32(int k) { return k >= SK_I32_RANGE && k <= SK_F32_SET; }
+DEVFN constexpr int sk_words(int k) { return sk_small(k) ? 2 : (sk_raw32(k) ? 4 : 8); }   // dwords fetched per quad
 
-template <int KIND>
-DEVFN uint32_t eval_quad(const PgScanLeaf& L, const GAS uint8_t* __restrict__ tb, uint32_t q, const RangeI32& r32) {
-  uint32_t r = 0;
-  if (KIND <= SK_DICT_LUT_WIDE) {
-    uint32_t d[4];
-    const uint32_t mask = (1u << L.bits) - 1u;
-    extract4<(KIND == SK_DICT_RANGE_SMALL || KIND == SK_DICT_LUT_SMALL)>((const GAS uint32_t*)tb, q, (uint32_t)L.bits, mask, d);
+// ---- bit-packed (FixedBitSVForwardIndexReaderV2) access ---------------------------------------------------------------------
+// tw: wave-uniform pointer to the wave tile's first dword (2 048 values start on a dword boundary for any width);
+// q: quad index inside the wave tile (values 4q .. 4q+3).  SMALL (bits <= 8): the four values sit inside one 64-bit
+// window; otherwise one window per value.
+template <bool SMALL>
+DEVFN void load_packed_quad(const GAS uint32_t* __restrict__ tw, uint32_t q, uint32_t bits, uint32_t* r) {
+  if (SMALL) {
+    const uint32_t di = (4u * q * bits) >> 5;
+    const u32x2 v = *(const GAS u32x2_a4*)(tw + di);
+    r[0] = v.x; r[1] = v.y;
+  } else {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      bool m = (KIND == SK_DICT_RANGE_SMALL || KIND == SK_DICT_RANGE_WIDE) ? in_range_i32(r32, (int32_t)d[i])
-                                                                            : (bool)((gptr<uint32_t>(L.lut)[d[i] >> 5] >> (d[i] & 31u)) & 1u);
-      r |= (uint32_t)m << i;
+      const uint32_t di = ((4u * q + (uint32_t)i) * bits) >> 5;
+      const u32x2 v = *(const GAS u32x2_a4*)(tw + di);
+      r[2 * i] = v.x; r[2 * i + 1] = v.y;
     }
-  } else if (KIND <= SK_F32_SET) {
-    u32x4 v = *(const GAS u32x4*)(tb + q * 16u);
-    uint32_t x[4] = {bswap32(v.x), bswap32(v.y), bswap32(v.z), bswap32(v.w)};
+  }
+}
+template <bool SMALL>
+DEVFN void decode_packed_quad(const uint32_t* r, uint32_t q, uint32_t bits, uint32_t mask, uint32_t out[4]) {
+  if (SMALL) {
+    const uint32_t sh = (4u * q * bits) & 31u;
+    const uint64_t win = ((uint64_t)bswap32(r[0]) << 32) | (uint64_t)bswap32(r[1]);
+#pragma unroll
+    for (int i = 0; i < 4; i++) out[i] = (uint32_t)(win >> (64u - sh - (uint32_t)(i + 1) * bits)) & mask;
+  } else {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      bool m;
-      if (KIND == SK_I32_RANGE) m = in_range_i32(r32, (int32_t)x[i]);
-      else if (KIND == SK_I32_SET) m = in_set_i64(L, (int64_t)(int32_t)x[i]);
-      else if (KIND == SK_F32_RANGE) { double f = (double)__uint_as_float(x[i]); m = f >= __longlong_as_double(L.lo) && f <= __longlong_as_double(L.hi); }
-      else m = in_set_f64(L, (double)__uint_as_float(x[i]));
-      r |= (uint32_t)m << i;
+      const uint32_t sh = ((4u * q + (uint32_t)i) * bits) & 31u;
+      const uint64_t win = ((uint64_t)bswap32(r[2 * i]) << 32) | (uint64_t)bswap32(r[2 * i + 1]);
+      out[i] = (uint32_t)(win >> (64u - sh - bits)) & mask;
     }
+  }
+}
+DEVFN const GAS uint32_t* packed_wtile_base(const uint8_t* data, int wtile, int bits) {
+  return gptr<uint32_t>(data + (size_t)wtile * (size_t)(PG_WAVE_DOCS / 8) * (size_t)bits);
+}
+
+template <int KIND, class LeafT>
+DEVFN void load_quad(const LeafT& L, const GAS uint8_t* __restrict__ tb, uint32_t q, uint32_t* r) {
+  if (sk_dict(KIND)) {
+    load_packed_quad<sk_small(KIND)>((const GAS uint32_t*)tb, q, (uint32_t)L.bits, r);
+  } else if (sk_raw32(KIND)) {
+    const u32x4 v = *(const GAS u32x4*)(tb + q * 16u);
+    r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
   } else {
     const GAS u32x4* p = (const GAS u32x4*)(tb + q * 32u);
-    u32x4 a = p[0], b = p[1];
-    uint64_t x[4] = {((uint64_t)bswap32(a.x) << 32) | bswap32(a.y), ((uint64_t)bswap32(a.z) << 32) | bswap32(a.w),
-                     ((uint64_t)bswap32(b.x) << 32) | bswap32(b.y), ((uint64_t)bswap32(b.z) << 32) | bswap32(b.w)};
+    const u32x4 a = p[0], b = p[1];
+    r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+  }
+}
+
+// Predicate over the 4 docs of a fetched quad → nibble.
+template <int KIND, class LeafT>
+DEVFN uint32_t test_quad(const LeafT& L, const uint32_t* r, uint32_t q, const RangeI32& r32) {
+  uint32_t res = 0;
+  if (sk_dict(KIND)) {
+    uint32_t d[4];
+    decode_packed_quad<sk_small(KIND)>(r, q, (uint32_t)L.bits, (1u << L.bits) - 1u, d);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
+      const bool m = (KIND == SK_DICT_RANGE_SMALL || KIND == SK_DICT_RANGE_WIDE)
+                         ? in_range_i32(r32, (int32_t)d[i])
+                         : (bool)((gptr<uint32_t>(L.lut)[d[i] >> 5] >> (d[i] & 31u)) & 1u);
+      res |= (uint32_t)m << i;
+    }
+  } else if (sk_raw32(KIND)) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const uint32_t x = bswap32(r[i]);
       bool m;
-      if (KIND == SK_I64_RANGE) m = (int64_t)x[i] >= L.lo && (int64_t)x[i] <= L.hi;
-      else if (KIND == SK_I64_SET) m = in_set_i64(L, (int64_t)x[i]);
-      else if (KIND == SK_F64_RANGE) { double f = __longlong_as_double((int64_t)x[i]); m = f >= __longlong_as_double(L.lo) && f <= __longlong_as_double(L.hi); }
-      else m = in_set_f64(L, __longlong_as_double((int64_t)x[i]));
-      r |= (uint32_t)m << i;
+      if (KIND == SK_I32_RANGE) m = in_range_i32(r32, (int32_t)x);
+      else if (KIND == SK_I32_SET) m = in_set_i64(L, (int64_t)(int32_t)x);
+      else if (KIND == SK_F32_RANGE) { const double f = (double)__uint_as_float(x); m = f >= __longlong_as_double(L.lo) && f <= __longlong_as_double(L.hi); }
+      else m = in_set_f64(L, (double)__uint_as_float(x));
+      res |= (uint32_t)m << i;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const uint64_t x = ((uint64_t)bswap32(r[2 * i]) << 32) | bswap32(r[2 * i + 1]);
+      bool m;
+      if (KIND == SK_I64_RANGE) m = (int64_t)x >= L.lo && (int64_t)x <= L.hi;
+      else if (KIND == SK_I64_SET) m = in_set_i64(L, (int64_t)x);
+      else if (KIND == SK_F64_RANGE) { const double f = __longlong_as_double((int64_t)x); m = f >= __longlong_as_double(L.lo) && f <= __longlong_as_double(L.hi); }
+      else m = in_set_f64(L, __longlong_as_double((int64_t)x));
+      res |= (uint32_t)m << i;
     }
   }
-  return r;
+  return res;
 }
 
-// Scan leaf over one tile.  MASKED: AND into `words32` in place, evaluating only quads that still have candidates
-// (ScanBasedDocIdIterator.applyAnd); returns the number of candidate docs this thread evaluated.
-template <int KIND, bool MASKED>
-DEVFN uint32_t scan_tile(const PgScanLeaf& L, uint32_t* __restrict__ words32, const GAS uint8_t* __restrict__ tb, int32_t n_valid) {
-  const int t = threadIdx.x;
-  const uint32_t sh = (uint32_t)(t & 7) * 4u;
+// Scan leaf over one wave tile: evaluates the predicate for the docs of `cand` (quad layout) only — the whole tile for a
+// pushed scan, the surviving candidates for a restricted one (ScanBasedDocIdIterator.applyAnd).  All quads of a lane
+// are fetched before the first is tested; quads without a candidate are neither fetched nor tested.
+template <int KIND, class LeafT>
+DEVFN uint32_t scan_wtile(const LeafT& L, uint32_t cand, const GAS uint8_t* __restrict__ tb, int lane) {
+  constexpr int W = sk_words(KIND);
+  constexpr int B = W <= 4 ? 8 : 4;
   const RangeI32 r32 = make_range_i32(L.lo, L.hi);
-  uint32_t n_cand = 0;
-  constexpr int U = (KIND == SK_DICT_RANGE_WIDE || KIND == SK_DICT_LUT_WIDE || KIND >= SK_I64_RANGE) ? 1 : 2;
-  for (int q0 = t; q0 < PG_TILE_QUADS; q0 += PG_BLOCK * U) {
-    uint32_t cand[U], res[U];
+  if ((KIND == SK_DICT_RANGE_SMALL || KIND == SK_DICT_RANGE_WIDE || KIND == SK_I32_RANGE) && r32.empty) return 0;
+  uint32_t res = 0;
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int q = q0 + u * PG_BLOCK;
-      const uint32_t vn = quad_valid_nibble(n_valid, q);
-      cand[u] = MASKED ? ((words32[q >> 3] >> sh) & vn) : vn;
-      if ((KIND == SK_DICT_RANGE_SMALL || KIND == SK_DICT_RANGE_WIDE || KIND == SK_I32_RANGE) && r32.empty) cand[u] = 0;
+  for (int k0 = 0; k0 < 8; k0 += B) {
+    uint32_t r[B][W];
+#pragma unroll
+    for (int u = 0; u < B; u++) {
+#pragma unroll
+      for (int w = 0; w < W; w++) r[u][w] = 0;
+      if ((cand >> (4 * (k0 + u))) & 0xFu) load_quad<KIND>(L, tb, (uint32_t)((k0 + u) * 64 + lane), r[u]);
     }
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      res[u] = 0;
-      if (cand[u]) res[u] = eval_quad<KIND>(L, tb, (uint32_t)(q0 + u * PG_BLOCK), r32) & cand[u];
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const int q = q0 + u * PG_BLOCK;
-      if (MASKED) n_cand += __popc(cand[u]);
-      const uint32_t x = or_reduce8(res[u] << sh);
-      if ((t & 7) == 0) words32[q >> 3] = x;
+    for (int u = 0; u < B; u++) {
+      const uint32_t nib = (cand >> (4 * (k0 + u))) & 0xFu;
+      if (nib) res |= (test_quad<KIND>(L, r[u], (uint32_t)((k0 + u) * 64 + lane), r32) & nib) << (4 * (k0 + u));
     }
   }
-  return n_cand;
+  return res;
 }
 
-template <bool MASKED>
-DEVFN uint32_t scan_dispatch(const PgScanLeaf& L, uint32_t* words32, int tile, int32_t n_valid) {
+template <class LeafT>
+DEVFN uint32_t scan_dispatch(const LeafT& L, uint32_t cand, int wtile, int lane) {
   if (L.col_kind == PG_COL_FIXED_BIT) {
-    const GAS uint8_t* tb = (const GAS uint8_t*)packed_tile_base(L.data, tile, L.bits);
+    const GAS uint8_t* tb = (const GAS uint8_t*)packed_wtile_base(L.data, wtile, L.bits);
     if (L.pred_kind == PG_P_RANGE)
-      return L.bits <= 8 ? scan_tile<SK_DICT_RANGE_SMALL, MASKED>(L, words32, tb, n_valid) : scan_tile<SK_DICT_RANGE_WIDE, MASKED>(L, words32, tb, n_valid);
-    return L.bits <= 8 ? scan_tile<SK_DICT_LUT_SMALL, MASKED>(L, words32, tb, n_valid) : scan_tile<SK_DICT_LUT_WIDE, MASKED>(L, words32, tb, n_valid);
+      return L.bits <= 8 ? scan_wtile<SK_DICT_RANGE_SMALL>(L, cand, tb, lane) : scan_wtile<SK_DICT_RANGE_WIDE>(L, cand, tb, lane);
+    return L.bits <= 8 ? scan_wtile<SK_DICT_LUT_SMALL>(L, cand, tb, lane) : scan_wtile<SK_DICT_LUT_WIDE>(L, cand, tb, lane);
   }
   if (L.col_kind == PG_COL_RAW32) {
-    const GAS uint8_t* tb = gptr<uint8_t>(L.data + (size_t)tile * (PG_TILE_DOCS * 4));
+    const GAS uint8_t* tb = gptr<uint8_t>(L.data + (size_t)wtile * (PG_WAVE_DOCS * 4));
     if (L.val_type == PG_V_I32)
-      return L.pred_kind == PG_P_RANGE ? scan_tile<SK_I32_RANGE, MASKED>(L, words32, tb, n_valid) : scan_tile<SK_I32_SET, MASKED>(L, words32, tb, n_valid);
-    return L.pred_kind == PG_P_RANGE ? scan_tile<SK_F32_RANGE, MASKED>(L, words32, tb, n_valid) : scan_tile<SK_F32_SET, MASKED>(L, words32, tb, n_valid);
+      return L.pred_kind == PG_P_RANGE ? scan_wtile<SK_I32_RANGE>(L, cand, tb, lane) : scan_wtile<SK_I32_SET>(L, cand, tb, lane);
+    return L.pred_kind == PG_P_RANGE ? scan_wtile<SK_F32_RANGE>(L, cand, tb, lane) : scan_wtile<SK_F32_SET>(L, cand, tb, lane);
   }
-  const GAS uint8_t* tb = gptr<uint8_t>(L.data + (size_t)tile * (PG_TILE_DOCS * 8));
+  const GAS uint8_t* tb = gptr<uint8_t>(L.data + (size_t)wtile * (PG_WAVE_DOCS * 8));
   if (L.val_type == PG_V_I64)
-    return L.pred_kind == PG_P_RANGE ? scan_tile<SK_I64_RANGE, MASKED>(L, words32, tb, n_valid) : scan_tile<SK_I64_SET, MASKED>(L, words32, tb, n_valid);
-  return L.pred_kind == PG_P_RANGE ? scan_tile<SK_F64_RANGE, MASKED>(L, words32, tb, n_valid) : scan_tile<SK_F64_SET, MASKED>(L, words32, tb, n_valid);
+    return L.pred_kind == PG_P_RANGE ? scan_wtile<SK_I64_RANGE>(L, cand, tb, lane) : scan_wtile<SK_I64_SET>(L, cand, tb, lane);
+  return L.pred_kind == PG_P_RANGE ? scan_wtile<SK_F64_RANGE>(L, cand, tb, lane) : scan_wtile<SK_F64_SET>(L, cand, tb, lane);
 }
 
-// ---- posting leaf: OR the leaf's RoaringBitmap containers that intersect the tile ----------------------------------------
+// ---- posting leaf: OR the leaf's RoaringBitmap containers that intersect the wave tile (linear layout) ---------------------
 // Container descriptors of the chunk are fetched with ONE vector load (lane e holds entry e) and broadcast with readlane,
 // so the dependent chain per leaf is chunk_start → entries → payload regardless of how many postings are OR-ed.
-DEVFN void postings_tile(const PgPostingLeaf& L, uint64_t* __restrict__ dst, int tile, uint64_t valid) {
-  const int t = threadIdx.x;
-  const int lane = t & 63;
-  const int chunk = tile / PG_TILES_PER_CHUNK;
-  const int sub = tile % PG_TILES_PER_CHUNK;
-  const uint32_t cs = gptr<uint32_t>(L.chunk_start)[chunk], ce = gptr<uint32_t>(L.chunk_start)[chunk + 1];
-  uint64_t acc = 0;
+// Array / run containers set their bits in the wavefront's private 2 048-bit LDS scratch.
+template <class LeafT>
+DEVFN uint32_t postings_wtile(const LeafT& L, int wtile, uint32_t valid_lin, uint32_t* __restrict__ wscratch, int lane) {
+  const int chunk = wtile / PG_WTILES_PER_CHUNK;
+  const int sub = wtile % PG_WTILES_PER_CHUNK;
+  uint32_t acc = 0;
+  if (chunk < L.dense_chunks) {   // wave-uniform: dense bitmap postings, address = base + 8 KB * chunk
+    const uint32_t di = (uint32_t)wtile * 64u + (uint32_t)lane;   // = chunk * 2048 + sub * 64 + lane
+    uint32_t v[PG_MAX_DENSE];
+#pragma unroll
+    for (int j = 0; j < PG_MAX_DENSE; j++) {
+      v[j] = 0;
+      if (j < L.n_dense) v[j] = gptr<uint32_t>(L.dense[j])[di];
+    }
+#pragma unroll
+    for (int j = 0; j < PG_MAX_DENSE; j++) acc |= v[j];
+  }
+  uint32_t cs = 0, ce = 0;
+  if (L.has_csr) { cs = gptr<uint32_t>(L.chunk_start)[chunk]; ce = gptr<uint32_t>(L.chunk_start)[chunk + 1]; }
   bool scatter = false;
   for (uint32_t base = cs; base < ce; base += 64) {
     const uint32_t n = (ce - base) < 64u ? (ce - base) : 64u;
@@ -226,83 +306,83 @@ DEVFN void postings_tile(const PgPostingLeaf& L, uint64_t* __restrict__ dst, int
       const uint32_t off_lo = __builtin_amdgcn_readlane(ent.x, e), off_hi = __builtin_amdgcn_readlane(ent.y, e);
       const uint32_t kt = __builtin_amdgcn_readlane(ent.w, e);   // key | type << 16
       if ((kt >> 16) == 1u) {
-        const GAS uint64_t* w = gptr<uint64_t>(L.containers + (((uint64_t)off_hi << 32) | off_lo));
-        acc |= w[sub * PG_TILE_WORDS + t];
+        const GAS uint32_t* w = gptr<uint32_t>(L.containers + (((uint64_t)off_hi << 32) | off_lo));
+        acc |= w[sub * 64 + lane];
       } else {
         scatter = true;
       }
     }
   }
-  if (scatter) {  // workgroup-uniform: array / run containers set bits with LDS atomics
-    dst[t] = acc;
-    __syncthreads();
-    uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
-    const uint32_t lo = (uint32_t)sub * PG_TILE_DOCS, hi = lo + PG_TILE_DOCS;  // low-16 range of this tile
+  if (scatter) {  // wave-uniform
+    wscratch[lane] = acc;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    const uint32_t lo = (uint32_t)sub * PG_WAVE_DOCS, hi = lo + PG_WAVE_DOCS;  // low-16 range of this wave tile
     for (uint32_t e = cs; e < ce; e++) {
       const u32x4 ce4 = gptr<u32x4>(L.entries)[e];
-      PgContainer c;
-      c.offset = ((uint64_t)ce4.y << 32) | ce4.x; c.n = ce4.z; c.key = (uint16_t)(ce4.w & 0xFFFF); c.type = (uint16_t)(ce4.w >> 16);
-      if (c.type == 0) {
-        const GAS uint16_t* vals = gptr<uint16_t>(L.containers + c.offset);
-        uint32_t a = 0, b = c.n;  // lower_bound(lo)
+      const uint64_t off = ((uint64_t)ce4.y << 32) | ce4.x;
+      const uint32_t n = ce4.z, type = ce4.w >> 16;
+      if (type == 0) {
+        const GAS uint16_t* vals = gptr<uint16_t>(L.containers + off);
+        uint32_t a = 0, b = n;  // lower_bound(lo)
         while (a < b) {
-          uint32_t m = (a + b) >> 1;
+          const uint32_t m = (a + b) >> 1;
           if (vals[m] < lo) a = m + 1; else b = m;
         }
-        for (uint32_t i = a + t; i < c.n; i += PG_BLOCK) {
+        for (uint32_t i = a + lane; i < n; i += 64) {
           uint32_t v = vals[i];
           if (v >= hi) break;
           v -= lo;
-          atomicOr(&d32[v >> 5], 1u << (v & 31));
+          atomicOr(&wscratch[v >> 5], 1u << (v & 31));
         }
-      } else if (c.type == 2) {
-        const GAS uint16_t* runs = gptr<uint16_t>(L.containers + c.offset);
-        for (uint32_t r = t; r < c.n; r += PG_BLOCK) {
+      } else if (type == 2) {
+        const GAS uint16_t* runs = gptr<uint16_t>(L.containers + off);
+        for (uint32_t r = lane; r < n; r += 64) {
           uint32_t s = runs[2 * r], eend = s + runs[2 * r + 1] + 1;  // [s, eend)
           if (eend <= lo || s >= hi) continue;
           s = (s < lo ? lo : s) - lo;
           eend = (eend > hi ? hi : eend) - lo;
-          uint32_t fw = s >> 5, lw = (eend - 1) >> 5;
-          uint32_t fm = 0xFFFFFFFFu << (s & 31), lm = 0xFFFFFFFFu >> (31 - ((eend - 1) & 31));
+          const uint32_t fw = s >> 5, lw = (eend - 1) >> 5;
+          const uint32_t fm = 0xFFFFFFFFu << (s & 31), lm = 0xFFFFFFFFu >> (31 - ((eend - 1) & 31));
           if (fw == lw) {
-            atomicOr(&d32[fw], fm & lm);
+            atomicOr(&wscratch[fw], fm & lm);
           } else {
-            atomicOr(&d32[fw], fm);
-            for (uint32_t w = fw + 1; w < lw; w++) atomicOr(&d32[w], 0xFFFFFFFFu);
-            atomicOr(&d32[lw], lm);
+            atomicOr(&wscratch[fw], fm);
+            for (uint32_t w = fw + 1; w < lw; w++) atomicOr(&wscratch[w], 0xFFFFFFFFu);
+            atomicOr(&wscratch[lw], lm);
           }
         }
       }
     }
-    __syncthreads();
-    acc = dst[t];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    acc = *(volatile uint32_t*)&wscratch[lane];
   }
-  dst[t] = L.exclusive ? ((~acc) & valid) : (acc & valid);
+  return (L.exclusive ? ~acc : acc) & valid_lin;
 }
 
-DEVFN void ranges_tile(const PgRangeLeaf& L, uint64_t* __restrict__ dst, int64_t tile_base, uint64_t valid) {
-  const int t = threadIdx.x;
-  const int64_t wb = tile_base + (int64_t)t * 64, we = wb + 63;
-  const int64_t tile_end = tile_base + PG_TILE_DOCS - 1;
-  int a = 0, b = L.n;   // first range whose hi >= tile_base (ranges ascending, disjoint)
+// docId ranges (sorted index / match-all), linear layout
+template <class LeafT>
+DEVFN uint32_t ranges_wtile(const LeafT& L, int64_t wbase, uint32_t valid_lin, int lane) {
+  const int64_t wb = wbase + (int64_t)lane * 32, we = wb + 31;
+  const int64_t tile_end = wbase + PG_WAVE_DOCS - 1;
+  int a = 0, b = L.n;   // first range whose hi >= wbase (ranges ascending, disjoint)
   while (a < b) {
-    int m = (a + b) >> 1;
-    if ((int64_t)gptr<int32_t>(L.hi)[m] < tile_base) a = m + 1; else b = m;
+    const int m = (a + b) >> 1;
+    if ((int64_t)gptr<int32_t>(L.hi)[m] < wbase) a = m + 1; else b = m;
   }
-  uint64_t acc = 0;
+  uint32_t acc = 0;
   for (int r = a; r < L.n; r++) {
-    int64_t lo = gptr<int32_t>(L.lo)[r], hi = gptr<int32_t>(L.hi)[r];
+    const int64_t lo = gptr<int32_t>(L.lo)[r], hi = gptr<int32_t>(L.hi)[r];
     if (lo > tile_end) break;
     if (hi < wb || lo > we) continue;
-    int64_t s = lo > wb ? lo - wb : 0, e = hi < we ? hi - wb : 63;
-    acc |= (~0ULL << s) & (~0ULL >> (63 - e));
+    const int64_t s = lo > wb ? lo - wb : 0, e = hi < we ? hi - wb : 31;
+    acc |= (0xFFFFFFFFu << s) & (0xFFFFFFFFu >> (31 - e));
   }
-  dst[t] = acc & valid;
+  return acc & valid_lin;
 }
 
-// ---- accumulator updates ----------------------------------------------------------------------------------------------
+// ---- accumulator updates ------------------------------------------------------------------------------------------------
 DEVFN int64_t f64_order_key(double v) {  // order-preserving map double → int64 (MIN/MAX through integer atomics)
-  int64_t b = __double_as_longlong(v);
+  const int64_t b = __double_as_longlong(v);
   return b ^ ((b >> 63) & 0x7FFFFFFFFFFFFFFFLL);
 }
 DEVFN void acc_int(int64_t* slot, int fn, int64_t v) {
@@ -318,35 +398,62 @@ DEVFN void acc_float(int64_t* slot, int fn, double v) {
   else atomicMax(reinterpret_cast<long long*>(slot), (long long)k);
 }
 
-// Aggregates the matching docs of one tile into `table` ([n_ops][G*R] int64 slots, LDS or HBM).
-DEVFN void aggregate_tile(const PgQueryPlan& p, const uint32_t* __restrict__ mask32, int tile, int64_t* table) {
-  const int t = threadIdx.x;
-  const uint32_t sh = (uint32_t)(t & 7) * 4u;
+// Aggregates the matching docs (quad-layout mask m) of one wave tile into `table` ([n_ops][G*R] int64 slots, LDS or HBM).
+// B quads per lane are in flight at a time.
+template <int B>
+DEVFN void aggregate_wtile(const PgQueryPlan& p, uint32_t m, int wtile, int64_t* table, int lane, uint32_t rep) {
   const uint32_t R = (uint32_t)p.replicas;
   const uint32_t stride = (uint32_t)p.n_groups * R;   // slots per op
-  const uint32_t rep = (uint32_t)t & (R - 1u);
-  for (int q = t; q < PG_TILE_QUADS; q += PG_BLOCK) {
-    const uint32_t nib = (mask32[q >> 3] >> sh) & 0xFu;
-    if (nib == 0) continue;
-    uint32_t slot[4] = {rep, rep, rep, rep};
+#pragma unroll
+  for (int k0 = 0; k0 < 8; k0 += B) {
+    const uint32_t mb = B == 8 ? m : ((m >> (4 * k0)) & ((1u << (4 * (B & 7))) - 1u));
+    if (mb == 0) continue;
+    uint32_t slot[B][4];
+#pragma unroll
+    for (int u = 0; u < B; u++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) slot[u][i] = rep;
     for (int g = 0; g < p.n_group_cols; g++) {
       const PgGroupCol& gc = p.gcols[g];
-      const GAS uint32_t* tw = packed_tile_base(gc.data, tile, gc.bits);
-      const uint32_t mask = (1u << gc.bits) - 1u;
+      const GAS uint32_t* tw = packed_wtile_base(gc.data, wtile, gc.bits);
+      const uint32_t bits = (uint32_t)gc.bits, mask = (1u << gc.bits) - 1u;
       const uint32_t mult = (uint32_t)gc.mult * R;
-      uint32_t d[4];
-      if (gc.bits <= 8) extract4<true>(tw, (uint32_t)q, (uint32_t)gc.bits, mask, d);
-      else extract4<false>(tw, (uint32_t)q, (uint32_t)gc.bits, mask, d);
+      if (bits <= 8) {
+        uint32_t r[B][2];
 #pragma unroll
-      for (int i = 0; i < 4; i++) slot[i] += d[i] * mult;
+        for (int u = 0; u < B; u++) {
+          r[u][0] = r[u][1] = 0;
+          if ((mb >> (4 * u)) & 0xFu) load_packed_quad<true>(tw, (uint32_t)((k0 + u) * 64 + lane), bits, r[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < B; u++) {
+          uint32_t d[4];
+          decode_packed_quad<true>(r[u], (uint32_t)((k0 + u) * 64 + lane), bits, mask, d);
+#pragma unroll
+          for (int i = 0; i < 4; i++) slot[u][i] += d[i] * mult;
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < B; u++) {
+          if ((mb >> (4 * u)) & 0xFu) {
+            uint32_t r[8], d[4];
+            load_packed_quad<false>(tw, (uint32_t)((k0 + u) * 64 + lane), bits, r);
+            decode_packed_quad<false>(r, (uint32_t)((k0 + u) * 64 + lane), bits, mask, d);
+#pragma unroll
+            for (int i = 0; i < 4; i++) slot[u][i] += d[i] * mult;
+          }
+        }
+      }
     }
     int o = 0;
     // COUNT ops (src < 0) come first
     for (; o < p.n_ops && p.ops[o].src < 0; o++) {
       int64_t* base = table + (size_t)o * stride;
 #pragma unroll
-      for (int i = 0; i < 4; i++)
-        if ((nib >> i) & 1u) atomicAdd(reinterpret_cast<unsigned long long*>(base + slot[i]), 1ULL);
+      for (int u = 0; u < B; u++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          if ((mb >> (4 * u + i)) & 1u) atomicAdd(reinterpret_cast<unsigned long long*>(base + slot[u][i]), 1ULL);
     }
     while (o < p.n_ops) {
       const int src = p.ops[o].src;
@@ -354,55 +461,97 @@ DEVFN void aggregate_tile(const PgQueryPlan& p, const uint32_t* __restrict__ mas
       int o_end = o;
       while (o_end < p.n_ops && p.ops[o_end].src == src) o_end++;
       if (S.col_kind == PG_COL_RAW32 || (S.col_kind == PG_COL_FIXED_BIT && (S.val_type == PG_V_I32 || S.val_type == PG_V_F32))) {
-        uint32_t x[4];
+        uint32_t x[B][4];
         if (S.col_kind == PG_COL_RAW32) {
-          u32x4 v = *gptr<u32x4>(S.data + (size_t)tile * (PG_TILE_DOCS * 4) + (uint32_t)q * 16u);
-          x[0] = bswap32(v.x); x[1] = bswap32(v.y); x[2] = bswap32(v.z); x[3] = bswap32(v.w);
-        } else {
-          uint32_t d[4];
-          const GAS uint32_t* tw = packed_tile_base(S.data, tile, S.bits);
-          const uint32_t mask = (1u << S.bits) - 1u;
-          if (S.bits <= 8) extract4<true>(tw, (uint32_t)q, (uint32_t)S.bits, mask, d);
-          else extract4<false>(tw, (uint32_t)q, (uint32_t)S.bits, mask, d);
+          const GAS uint8_t* tb = gptr<uint8_t>(S.data + (size_t)wtile * (PG_WAVE_DOCS * 4));
 #pragma unroll
-          for (int i = 0; i < 4; i++) x[i] = ((nib >> i) & 1u) ? gptr<uint32_t>(S.dict)[d[i]] : 0u;
+          for (int u = 0; u < B; u++) {
+            u32x4 v = {0, 0, 0, 0};
+            if ((mb >> (4 * u)) & 0xFu) v = *(const GAS u32x4*)(tb + (uint32_t)((k0 + u) * 64 + lane) * 16u);
+            x[u][0] = v.x; x[u][1] = v.y; x[u][2] = v.z; x[u][3] = v.w;
+          }
+#pragma unroll
+          for (int u = 0; u < B; u++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) x[u][i] = bswap32(x[u][i]);
+        } else {
+          const GAS uint32_t* tw = packed_wtile_base(S.data, wtile, S.bits);
+          const uint32_t bits = (uint32_t)S.bits, mask = (1u << S.bits) - 1u;
+#pragma unroll
+          for (int u = 0; u < B; u++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) x[u][i] = 0;
+            if ((mb >> (4 * u)) & 0xFu) {
+              uint32_t r[8], d[4];
+              const uint32_t q = (uint32_t)((k0 + u) * 64 + lane);
+              if (bits <= 8) { load_packed_quad<true>(tw, q, bits, r); decode_packed_quad<true>(r, q, bits, mask, d); }
+              else { load_packed_quad<false>(tw, q, bits, r); decode_packed_quad<false>(r, q, bits, mask, d); }
+#pragma unroll
+              for (int i = 0; i < 4; i++) x[u][i] = ((mb >> (4 * u + i)) & 1u) ? gptr<uint32_t>(S.dict)[d[i]] : 0u;
+            }
+          }
         }
         for (int k = o; k < o_end; k++) {
           const int fn = p.ops[k].fn;
           int64_t* base = table + (size_t)k * stride;
           if (S.val_type == PG_V_I32) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) if ((nib >> i) & 1u) acc_int(base + slot[i], fn, (int64_t)(int32_t)x[i]);
+            for (int u = 0; u < B; u++)
+#pragma unroll
+              for (int i = 0; i < 4; i++)
+                if ((mb >> (4 * u + i)) & 1u) acc_int(base + slot[u][i], fn, (int64_t)(int32_t)x[u][i]);
           } else {
 #pragma unroll
-            for (int i = 0; i < 4; i++) if ((nib >> i) & 1u) acc_float(base + slot[i], fn, (double)__uint_as_float(x[i]));
+            for (int u = 0; u < B; u++)
+#pragma unroll
+              for (int i = 0; i < 4; i++)
+                if ((mb >> (4 * u + i)) & 1u) acc_float(base + slot[u][i], fn, (double)__uint_as_float(x[u][i]));
           }
         }
       } else {
-        uint64_t x[4];
-        if (S.col_kind == PG_COL_RAW64) {
-          const GAS u32x4* pp = gptr<u32x4>(S.data + (size_t)tile * (PG_TILE_DOCS * 8) + (uint32_t)q * 32u);
-          u32x4 a = pp[0], b = pp[1];
-          x[0] = ((uint64_t)bswap32(a.x) << 32) | bswap32(a.y); x[1] = ((uint64_t)bswap32(a.z) << 32) | bswap32(a.w);
-          x[2] = ((uint64_t)bswap32(b.x) << 32) | bswap32(b.y); x[3] = ((uint64_t)bswap32(b.z) << 32) | bswap32(b.w);
-        } else {
-          uint32_t d[4];
-          const GAS uint32_t* tw = packed_tile_base(S.data, tile, S.bits);
-          const uint32_t mask = (1u << S.bits) - 1u;
-          if (S.bits <= 8) extract4<true>(tw, (uint32_t)q, (uint32_t)S.bits, mask, d);
-          else extract4<false>(tw, (uint32_t)q, (uint32_t)S.bits, mask, d);
+        // 64-bit values: half the quads in flight
 #pragma unroll
-          for (int i = 0; i < 4; i++) x[i] = ((nib >> i) & 1u) ? gptr<uint64_t>(S.dict)[d[i]] : 0ull;
-        }
-        for (int k = o; k < o_end; k++) {
-          const int fn = p.ops[k].fn;
-          int64_t* base = table + (size_t)k * stride;
-          if (S.val_type == PG_V_I64) {
+        for (int h = 0; h < B; h += 2) {
+          uint64_t x[2][4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) if ((nib >> i) & 1u) acc_int(base + slot[i], fn, (int64_t)x[i]);
-          } else {
+          for (int uu = 0; uu < 2; uu++) {
+            const int u = h + uu;
 #pragma unroll
-            for (int i = 0; i < 4; i++) if ((nib >> i) & 1u) acc_float(base + slot[i], fn, __longlong_as_double((int64_t)x[i]));
+            for (int i = 0; i < 4; i++) x[uu][i] = 0;
+            if ((mb >> (4 * u)) & 0xFu) {
+              const uint32_t q = (uint32_t)((k0 + u) * 64 + lane);
+              if (S.col_kind == PG_COL_RAW64) {
+                const GAS u32x4* pp = gptr<u32x4>(S.data + (size_t)wtile * (PG_WAVE_DOCS * 8) + q * 32u);
+                const u32x4 a = pp[0], b = pp[1];
+                x[uu][0] = ((uint64_t)bswap32(a.x) << 32) | bswap32(a.y); x[uu][1] = ((uint64_t)bswap32(a.z) << 32) | bswap32(a.w);
+                x[uu][2] = ((uint64_t)bswap32(b.x) << 32) | bswap32(b.y); x[uu][3] = ((uint64_t)bswap32(b.z) << 32) | bswap32(b.w);
+              } else {
+                uint32_t r[8], d[4];
+                const GAS uint32_t* tw = packed_wtile_base(S.data, wtile, S.bits);
+                const uint32_t bits = (uint32_t)S.bits, mask = (1u << S.bits) - 1u;
+                if (bits <= 8) { load_packed_quad<true>(tw, q, bits, r); decode_packed_quad<true>(r, q, bits, mask, d); }
+                else { load_packed_quad<false>(tw, q, bits, r); decode_packed_quad<false>(r, q, bits, mask, d); }
+#pragma unroll
+                for (int i = 0; i < 4; i++) x[uu][i] = ((mb >> (4 * u + i)) & 1u) ? gptr<uint64_t>(S.dict)[d[i]] : 0ull;
+              }
+            }
+          }
+          for (int k = o; k < o_end; k++) {
+            const int fn = p.ops[k].fn;
+            int64_t* base = table + (size_t)k * stride;
+            if (S.val_type == PG_V_I64) {
+#pragma unroll
+              for (int uu = 0; uu < 2; uu++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                  if ((mb >> (4 * (h + uu) + i)) & 1u) acc_int(base + slot[h + uu][i], fn, (int64_t)x[uu][i]);
+            } else {
+#pragma unroll
+              for (int uu = 0; uu < 2; uu++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                  if ((mb >> (4 * (h + uu) + i)) & 1u) acc_float(base + slot[h + uu][i], fn, __longlong_as_double((int64_t)x[uu][i]));
+            }
           }
         }
       }
@@ -412,15 +561,279 @@ DEVFN void aggregate_tile(const PgQueryPlan& p, const uint32_t* __restrict__ mas
 }
 
 // =====================================================================================================================
-// The segment query kernel: persistent workgroups, tile = wg + k * gridDim.
-// dynamic LDS: [stack_depth][256] u64 filter stack, then the LDS accumulator table (LDS / SINGLE modes)
+// Fast path.  Plans of the shape  [index-only program]  AND  [at most one scan leaf]  →  [LDS-table aggregation over
+// 32-bit sources and <= 8-bit group columns]  run in a kernel specialised at compile time on the scan kind and on
+// whether there is an aggregation table, so that the per-tile code is straight-line: leaf descriptors are hoisted into
+// SGPRs, every load of a stage is issued before the first use, no statistics atomics inside the loop.  Everything else
+// takes the interpreter kernel below.
 // =====================================================================================================================
-extern "C" __global__ void __launch_bounds__(PG_BLOCK, PG_WG_PER_CU) pg_segment_query_kernel(const PgQueryPlan p) {
+struct LinStack {
+  uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
+  DEVFN void push(uint32_t v) { s5 = s4; s4 = s3; s3 = s2; s2 = s1; s1 = s0; s0 = v; }
+  DEVFN void drop() { s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = s5; }
+};
+
+// index-only filter program in linear layout (one dword = 32 consecutive docs per lane)
+DEVFN uint32_t index_program_lin(const PgQueryPlan& p, int wt, int64_t wbase, uint32_t valid_l, uint32_t* wscratch, int lane) {
+  LinStack st;
+  for (int i = 0; i < p.n_index_instr; i++) {
+    const int op = cptr(p.instrs)[i].op, arg = cptr(p.instrs)[i].arg;
+    switch (op) {
+      case PG_F_PUSH_POSTINGS: st.push(postings_wtile(cptr(p.postings)[arg], wt, valid_l, wscratch, lane)); break;
+      case PG_F_PUSH_RANGES: st.push(ranges_wtile(cptr(p.ranges)[arg], wbase, valid_l, lane)); break;
+      case PG_F_PUSH_ALL: st.push(valid_l); break;
+      case PG_F_PUSH_NONE: st.push(0u); break;
+      case PG_F_AND: { const uint32_t b = st.s0; st.drop(); st.s0 &= b; break; }
+      case PG_F_OR: { const uint32_t b = st.s0; st.drop(); st.s0 |= b; break; }
+      case PG_F_NOT: st.s0 = (~st.s0) & valid_l; break;
+      default: break;
+    }
+  }
+  return st.s0;
+}
+
+// LDS-table aggregation of one wave tile for the fast path: group columns of <= 8 bits, 32-bit value sources, slots
+// < 65 536 (two packed per register).  B quads per lane are in flight at a time; the first source's quads are requested
+// before the group columns are decoded.
+template <int B>
+DEVFN void fast_aggregate_wtile(const PgQueryPlan& p, uint32_t mask_all, int wtile, int64_t* __restrict__ table, int lane, uint32_t rep) {
+  const uint32_t R = (uint32_t)p.replicas;
+  const uint32_t stride = (uint32_t)p.n_groups * R;   // slots per op
+  int o_first = 0;
+  while (o_first < p.n_ops && p.ops[o_first].src < 0) o_first++;
+  const bool prefetch0 = o_first < p.n_ops && p.srcs[p.ops[o_first].src].col_kind == PG_COL_RAW32;
+#pragma unroll
+  for (int k0 = 0; k0 < 8; k0 += B) {
+    const uint32_t m = B == 8 ? mask_all : ((mask_all >> (4 * k0)) & ((1u << (4 * (B & 7))) - 1u));
+    if (__ballot(m != 0) == 0) continue;   // wave-uniform
+    uint32_t x[B][4];
+    if (prefetch0) {
+      const GAS uint8_t* tb = gptr<uint8_t>(p.srcs[p.ops[o_first].src].data + (size_t)wtile * (PG_WAVE_DOCS * 4));
+#pragma unroll
+      for (int k = 0; k < B; k++) {
+        u32x4 v = {0, 0, 0, 0};
+        if ((m >> (4 * k)) & 0xFu) v = *(const GAS u32x4*)(tb + (uint32_t)((k0 + k) * 64 + lane) * 16u);
+        x[k][0] = v.x; x[k][1] = v.y; x[k][2] = v.z; x[k][3] = v.w;
+      }
+    }
+    uint32_t sp[B][2];   // packed slots: docs (0,1) and (2,3) of quad k
+#pragma unroll
+    for (int k = 0; k < B; k++) sp[k][0] = sp[k][1] = rep | (rep << 16);
+    for (int g = 0; g < p.n_group_cols; g++) {
+      const PgGroupCol& gc = p.gcols[g];
+      const GAS uint32_t* tw = packed_wtile_base(gc.data, wtile, gc.bits);
+      const uint32_t bits = (uint32_t)gc.bits, mask = (1u << gc.bits) - 1u;
+      const uint32_t mult = (uint32_t)gc.mult * R;
+      uint32_t r[B][2];
+#pragma unroll
+      for (int k = 0; k < B; k++) {
+        r[k][0] = r[k][1] = 0;
+        if ((m >> (4 * k)) & 0xFu) load_packed_quad<true>(tw, (uint32_t)((k0 + k) * 64 + lane), bits, r[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < B; k++) {
+        uint32_t d[4];
+        decode_packed_quad<true>(r[k], (uint32_t)((k0 + k) * 64 + lane), bits, mask, d);
+        sp[k][0] += d[0] * mult + ((d[1] * mult) << 16);
+        sp[k][1] += d[2] * mult + ((d[3] * mult) << 16);
+      }
+    }
+#define PG_SLOT(k, i) ((sp[k][(i) >> 1] >> (((i) & 1) * 16)) & 0xFFFFu)
+    for (int o = 0; o < p.n_ops; o++) {
+      const PgAccOp op = p.ops[o];
+      int64_t* base = table + (size_t)o * stride;
+      if (op.src < 0) {
+#pragma unroll
+        for (int k = 0; k < B; k++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if ((m >> (4 * k + i)) & 1u) atomicAdd(reinterpret_cast<unsigned long long*>(base + PG_SLOT(k, i)), 1ULL);
+        continue;
+      }
+      const bool new_src = (o == 0 || p.ops[o - 1].src != op.src);
+      if (new_src) {
+        const PgValueSrc& S = p.srcs[op.src];
+        if (S.col_kind == PG_COL_RAW32) {
+          if (!(prefetch0 && o == o_first)) {
+            const GAS uint8_t* tb = gptr<uint8_t>(S.data + (size_t)wtile * (PG_WAVE_DOCS * 4));
+#pragma unroll
+            for (int k = 0; k < B; k++) {
+              u32x4 v = {0, 0, 0, 0};
+              if ((m >> (4 * k)) & 0xFu) v = *(const GAS u32x4*)(tb + (uint32_t)((k0 + k) * 64 + lane) * 16u);
+              x[k][0] = v.x; x[k][1] = v.y; x[k][2] = v.z; x[k][3] = v.w;
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < B; k++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) x[k][i] = bswap32(x[k][i]);
+        } else {   // dictionary-encoded 32-bit values
+          const GAS uint32_t* tw = packed_wtile_base(S.data, wtile, S.bits);
+          const uint32_t bits = (uint32_t)S.bits, mask = (1u << S.bits) - 1u;
+#pragma unroll
+          for (int k = 0; k < B; k++) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) x[k][i] = 0;
+            if ((m >> (4 * k)) & 0xFu) {
+              uint32_t r[8], d[4];
+              const uint32_t q = (uint32_t)((k0 + k) * 64 + lane);
+              if (bits <= 8) { load_packed_quad<true>(tw, q, bits, r); decode_packed_quad<true>(r, q, bits, mask, d); }
+              else { load_packed_quad<false>(tw, q, bits, r); decode_packed_quad<false>(r, q, bits, mask, d); }
+#pragma unroll
+              for (int i = 0; i < 4; i++) x[k][i] = ((m >> (4 * k + i)) & 1u) ? gptr<uint32_t>(S.dict)[d[i]] : 0u;
+            }
+          }
+        }
+      }
+      if (!op.is_float) {
+        if (op.fn == PG_ACC_SUM) {
+#pragma unroll
+          for (int k = 0; k < B; k++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+              if ((m >> (4 * k + i)) & 1u)
+                atomicAdd(reinterpret_cast<unsigned long long*>(base + PG_SLOT(k, i)), (unsigned long long)(int64_t)(int32_t)x[k][i]);
+        } else if (op.fn == PG_ACC_MIN) {
+#pragma unroll
+          for (int k = 0; k < B; k++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+              if ((m >> (4 * k + i)) & 1u) atomicMin(reinterpret_cast<long long*>(base + PG_SLOT(k, i)), (long long)(int32_t)x[k][i]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < B; k++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+              if ((m >> (4 * k + i)) & 1u) atomicMax(reinterpret_cast<long long*>(base + PG_SLOT(k, i)), (long long)(int32_t)x[k][i]);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < B; k++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if ((m >> (4 * k + i)) & 1u) acc_float(base + PG_SLOT(k, i), op.fn, (double)__uint_as_float(x[k][i]));
+      }
+    }
+#undef PG_SLOT
+  }
+}
+
+// Shared epilogue: statistics and the flush of the LDS accumulator table into this workgroup's partial table.
+DEVFN void flush_workgroup(const PgQueryPlan& p, const int64_t* lds_table, const uint32_t* s_stat, bool lds_agg, int t) {
+  if (t < PG_MAX_STATS && s_stat[t]) atomicAdd(&p.stats[t], (unsigned long long)s_stat[t]);
+  if (lds_agg) {
+    const int R = p.replicas;
+    const int64_t n_out = (int64_t)p.n_ops * p.n_groups;
+    int64_t* out = p.partials + (int64_t)blockIdx.x * n_out;
+    for (int64_t i = t; i < n_out; i += PG_BLOCK) {
+      const int o = (int)(i / p.n_groups);
+      const PgAccOp op = p.ops[o];
+      const int64_t* src = lds_table + i * R;   // (o * G + g) * R
+      int64_t acc = src[0];
+      if (op.fn == PG_ACC_SUM && op.is_float) {
+        double d = __longlong_as_double(acc);
+        for (int r = 1; r < R; r++) d += __longlong_as_double(src[r]);
+        acc = __double_as_longlong(d);
+      } else if (op.fn == PG_ACC_COUNT || op.fn == PG_ACC_SUM) {
+        for (int r = 1; r < R; r++) acc += src[r];
+      } else if (op.fn == PG_ACC_MIN) {
+        for (int r = 1; r < R; r++) acc = src[r] < acc ? src[r] : acc;
+      } else {
+        for (int r = 1; r < R; r++) acc = src[r] > acc ? src[r] : acc;
+      }
+      out[i] = acc;
+    }
+  }
+}
+
+// SK: ScanKind of the single scan leaf, -1 for none.  AGG: 0 = no accumulator table, 1 = LDS table (LDS / SINGLE modes).
+template <int SK, int AGG>
+__device__ __forceinline__ void fast_query_body(const PgQueryPlan& p) {
   extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
   __shared__ uint32_t s_stat[PG_MAX_STATS];
+  __shared__ uint32_t s_wscratch[PG_WAVES_PER_BLOCK][64];
   const int t = threadIdx.x;
-  uint64_t* stack = smem;
-  int64_t* lds_table = reinterpret_cast<int64_t*>(smem + (size_t)p.stack_depth * PG_TILE_WORDS);
+  const int lane = t & 63;
+  const int wave = uniform(t >> 6);
+  int64_t* lds_table = reinterpret_cast<int64_t*>(smem);
+  if (t < PG_MAX_STATS) s_stat[t] = 0;
+  if (AGG) {
+    const uint32_t table_slots = (uint32_t)p.n_groups * (uint32_t)p.replicas;
+    for (int o = 0; o < p.n_ops; o++) {
+      const int64_t ident = pg_acc_identity(p.ops[o].fn, p.ops[o].is_float);
+      for (uint32_t i = t; i < table_slots; i += PG_BLOCK) lds_table[(size_t)o * table_slots + i] = ident;
+    }
+  }
+  __syncthreads();
+
+  const CAS PgScanLeaf& L = cptr(p.scans)[SK >= 0 ? p.fast_scan : 0];   // only dereferenced when SK >= 0
+  const uint32_t rep = (uint32_t)t & ((uint32_t)p.replicas - 1u);
+  uint32_t my_matched = 0, my_cand = 0;
+  const int wstride = (int)gridDim.x * PG_WAVES_PER_BLOCK;
+  for (int wt = (int)blockIdx.x * PG_WAVES_PER_BLOCK + wave; wt < p.n_wtiles; wt += wstride) {
+    const int64_t wbase = (int64_t)wt * PG_WAVE_DOCS;
+    const int64_t rem = (int64_t)p.num_docs - wbase;
+    const int32_t n_valid = rem >= PG_WAVE_DOCS ? PG_WAVE_DOCS : (int32_t)rem;
+    uint32_t m = valid_quad_mask(n_valid, lane);
+    if (p.n_index_instr > 0)
+      m = lin_to_quad(index_program_lin(p, wt, wbase, valid_lin_mask(n_valid, lane), s_wscratch[wave], lane), lane);
+    if (SK >= 0) {
+      my_cand += (uint32_t)__popc(m);
+      const GAS uint8_t* tb = sk_dict(SK) ? (const GAS uint8_t*)packed_wtile_base(L.data, wt, L.bits)
+                                          : gptr<uint8_t>(L.data + (size_t)wt * (PG_WAVE_DOCS * (sk_raw32(SK) ? 4 : 8)));
+      m = scan_wtile<(SK >= 0 ? SK : 0)>(L, m, tb, lane);
+    }
+    const uint32_t cnt = (uint32_t)__popc(m);
+    my_matched += cnt;
+    if (p.out_words) reinterpret_cast<uint32_t*>(p.out_words)[(int64_t)wt * 64 + lane] = quad_to_lin(m, lane);
+    if (p.out_tile_counts) {
+      const uint32_t wsum = wave_sum_u32(cnt);
+      if (lane == 0 && wsum) atomicAdd(&p.out_tile_counts[wt / PG_WTILES_PER_TILE], wsum);
+    }
+    if (AGG && p.agg_mode != PG_AGG_NONE && __ballot(m != 0)) fast_aggregate_wtile<PG_FAST_AGG_B>(p, m, wt, lds_table, lane, rep);
+  }
+  const uint32_t wsum = wave_sum_u32(my_matched);
+  if (lane == 0 && wsum) atomicAdd(&s_stat[0], wsum);
+  if (SK >= 0 && !p.fast_scan_pushed) {
+    const uint32_t csum = wave_sum_u32(my_cand);
+    if (lane == 0 && csum) atomicAdd(&s_stat[L.stat_slot], csum);
+  }
+  __syncthreads();
+  flush_workgroup(p, lds_table, s_stat, AGG && p.agg_mode != PG_AGG_NONE, t);
+}
+
+#define PG_FAST_KERNEL(NAME, SK, AGG) \
+  extern "C" __global__ void __launch_bounds__(PG_BLOCK) NAME(const PgQueryPlan p) { fast_query_body<SK, AGG>(p); }
+PG_FAST_KERNEL(pg_fast_none_f, -1, 0)
+PG_FAST_KERNEL(pg_fast_none_a, -1, 1)
+PG_FAST_KERNEL(pg_fast_i32range_f, SK_I32_RANGE, 0)
+PG_FAST_KERNEL(pg_fast_i32range_a, SK_I32_RANGE, 1)
+PG_FAST_KERNEL(pg_fast_dictrange_f, SK_DICT_RANGE_SMALL, 0)
+PG_FAST_KERNEL(pg_fast_dictrange_a, SK_DICT_RANGE_SMALL, 1)
+PG_FAST_KERNEL(pg_fast_dictlut_f, SK_DICT_LUT_SMALL, 0)
+PG_FAST_KERNEL(pg_fast_dictlut_a, SK_DICT_LUT_SMALL, 1)
+
+// Register stack of match masks; the top is always s0 (push / pop shift the others), so no dynamic register indexing.
+struct MaskStack {
+  uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0, s5 = 0;
+  DEVFN void push(uint32_t v) { s5 = s4; s4 = s3; s3 = s2; s2 = s1; s1 = s0; s0 = v; }
+  DEVFN void drop() { s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = s5; }
+  DEVFN void pop_and() { const uint32_t b = s0; drop(); s0 &= b; }
+  DEVFN void pop_or() { const uint32_t b = s0; drop(); s0 |= b; }
+};
+
+// =====================================================================================================================
+// The segment query kernel: one persistent 16-wave workgroup per CU; wave tile = (wg*16 + wave) + k * gridDim*16.
+// dynamic LDS: the accumulator table (LDS / SINGLE modes)
+// =====================================================================================================================
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_segment_query_kernel(const PgQueryPlan p) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
+  __shared__ uint32_t s_stat[PG_MAX_STATS];
+  __shared__ uint32_t s_wscratch[PG_WAVES_PER_BLOCK][64];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = uniform(t >> 6);
+  int64_t* lds_table = reinterpret_cast<int64_t*>(smem);
   const bool lds_agg = (p.agg_mode == PG_AGG_LDS || p.agg_mode == PG_AGG_SINGLE);
   const uint32_t table_slots = (uint32_t)p.n_groups * (uint32_t)p.replicas;
 
@@ -433,80 +846,71 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK, PG_WG_PER_CU) pg_segment_
   }
   __syncthreads();
 
+  const uint32_t rep = (uint32_t)t & ((uint32_t)p.replicas - 1u);
   uint32_t my_matched = 0;
-  for (int tile = blockIdx.x; tile < p.n_tiles; tile += gridDim.x) {
-    const int64_t tile_base = (int64_t)tile * PG_TILE_DOCS;
-    const int64_t rem = (int64_t)p.num_docs - tile_base;
-    const int32_t n_valid = rem >= PG_TILE_DOCS ? PG_TILE_DOCS : (int32_t)rem;
-    const uint64_t valid = tile_valid_word(n_valid, t);
+  const int wstride = (int)gridDim.x * PG_WAVES_PER_BLOCK;
+  for (int wt = (int)blockIdx.x * PG_WAVES_PER_BLOCK + wave; wt < p.n_wtiles; wt += wstride) {
+    const int64_t wbase = (int64_t)wt * PG_WAVE_DOCS;
+    const int64_t rem = (int64_t)p.num_docs - wbase;
+    const int32_t n_valid = rem >= PG_WAVE_DOCS ? PG_WAVE_DOCS : (int32_t)rem;
+    const uint32_t valid_q = valid_quad_mask(n_valid, lane);
+    const uint32_t valid_l = valid_lin_mask(n_valid, lane);
 
-    // ---- filter program -------------------------------------------------------------------------------------------
-    int sp = 0;
+    // ---- filter program ---------------------------------------------------------------------------------------------
+    MaskStack st;
     for (int i = 0; i < p.n_instr; i++) {
-      const PgFInstr ins = p.instrs[i];
-      switch (ins.op) {
+      const int fop = cptr(p.instrs)[i].op, farg = cptr(p.instrs)[i].arg;
+      switch (fop) {
         case PG_F_PUSH_POSTINGS:
-          postings_tile(p.postings[ins.arg], stack + sp * PG_TILE_WORDS, tile, valid);
-          sp++;
+          st.push(lin_to_quad(postings_wtile(cptr(p.postings)[farg], wt, valid_l, s_wscratch[wave], lane), lane));
           break;
         case PG_F_PUSH_RANGES:
-          ranges_tile(p.ranges[ins.arg], stack + sp * PG_TILE_WORDS, tile_base, valid);
-          sp++;
+          st.push(lin_to_quad(ranges_wtile(cptr(p.ranges)[farg], wbase, valid_l, lane), lane));
+          break;
+        case PG_F_PUSH_ALL:
+          st.push(valid_q);
           break;
         case PG_F_PUSH_NONE:
-          stack[sp * PG_TILE_WORDS + t] = 0;
-          sp++;
+          st.push(0u);
           break;
         case PG_F_PUSH_SCAN:
-          __syncthreads();
-          scan_dispatch<false>(p.scans[ins.arg], reinterpret_cast<uint32_t*>(stack + sp * PG_TILE_WORDS), tile, n_valid);
-          sp++;
-          __syncthreads();
+          st.push(scan_dispatch(cptr(p.scans)[farg], valid_q, wt, lane));
           break;
         case PG_F_AND_SCAN: {
-          __syncthreads();
-          const PgScanLeaf& L = p.scans[ins.arg];
-          uint32_t nc = scan_dispatch<true>(L, reinterpret_cast<uint32_t*>(stack + (sp - 1) * PG_TILE_WORDS), tile, n_valid);
-          nc = wave_sum_u32(nc);
-          if ((t & 63) == 0 && nc) atomicAdd(&s_stat[L.stat_slot], nc);
-          __syncthreads();
+          const CAS PgScanLeaf& L = cptr(p.scans)[farg];
+          const uint32_t cand = st.s0;
+          const uint32_t nc = wave_sum_u32((uint32_t)__popc(cand));
+          if (nc) {   // wave-uniform
+            st.s0 = scan_dispatch(L, cand, wt, lane);
+            if (lane == 0) atomicAdd(&s_stat[L.stat_slot], nc);
+          }
           break;
         }
-        case PG_F_AND:
-          sp--;
-          stack[(sp - 1) * PG_TILE_WORDS + t] &= stack[sp * PG_TILE_WORDS + t];
-          break;
-        case PG_F_OR:
-          sp--;
-          stack[(sp - 1) * PG_TILE_WORDS + t] |= stack[sp * PG_TILE_WORDS + t];
-          break;
-        case PG_F_NOT:
-          stack[(sp - 1) * PG_TILE_WORDS + t] = (~stack[(sp - 1) * PG_TILE_WORDS + t]) & valid;
-          break;
+        case PG_F_AND: st.pop_and(); break;
+        case PG_F_OR: st.pop_or(); break;
+        case PG_F_NOT: st.s0 = (~st.s0) & valid_q; break;
         default: break;
       }
     }
-    const uint64_t word = stack[t];
-    const uint32_t cnt = (uint32_t)__popcll(word);
+    const uint32_t m = st.s0;
+    const uint32_t cnt = (uint32_t)__popc(m);
     my_matched += cnt;
-    if (p.out_words) p.out_words[(int64_t)tile * PG_TILE_WORDS + t] = word;
+    if (p.out_words) reinterpret_cast<uint32_t*>(p.out_words)[(int64_t)wt * 64 + lane] = quad_to_lin(m, lane);
     if (p.out_tile_counts) {
-      uint32_t wsum = wave_sum_u32(cnt);
-      if ((t & 63) == 0) atomicAdd(&p.out_tile_counts[tile], wsum);
+      const uint32_t wsum = wave_sum_u32(cnt);
+      if (lane == 0 && wsum) atomicAdd(&p.out_tile_counts[wt / PG_WTILES_PER_TILE], wsum);
     }
 
     // ---- aggregation ----------------------------------------------------------------------------------------------
-    if (p.agg_mode != PG_AGG_NONE) {
-      __syncthreads();   // stack[0] complete for every quad reader
-      if (lds_agg) aggregate_tile(p, reinterpret_cast<const uint32_t*>(stack), tile, lds_table);
-      else aggregate_tile(p, reinterpret_cast<const uint32_t*>(stack), tile, p.partials);
+    if (p.agg_mode != PG_AGG_NONE && __ballot(m != 0)) {
+      if (lds_agg) aggregate_wtile<4>(p, m, wt, lds_table, lane, rep);
+      else aggregate_wtile<4>(p, m, wt, p.partials, lane, rep);
     }
-    __syncthreads();     // before the next tile overwrites the stack
   }
 
   // ---- epilogue: statistics and accumulator flush -----------------------------------------------------------------------
-  uint32_t wsum = wave_sum_u32(my_matched);
-  if ((t & 63) == 0 && wsum) atomicAdd(&s_stat[0], wsum);
+  const uint32_t wsum = wave_sum_u32(my_matched);
+  if (lane == 0 && wsum) atomicAdd(&s_stat[0], wsum);
   __syncthreads();
   if (t < PG_MAX_STATS && s_stat[t]) atomicAdd(&p.stats[t], (unsigned long long)s_stat[t]);
 
@@ -535,28 +939,32 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK, PG_WG_PER_CU) pg_segment_
   }
 }
 
-// Combines the per-workgroup partial tables in workgroup order (deterministic): out[op][g].
+// Combines the per-workgroup partial tables: out[op][g].  One wavefront per output slot, lanes stride over the
+// workgroups, fixed butterfly order (deterministic also for floating sums).
 extern "C" __global__ void __launch_bounds__(256) pg_reduce_partials_kernel(const int64_t* __restrict__ partials,
                                                                              int64_t* __restrict__ out, int n_wg,
                                                                              int n_ops, int n_groups,
                                                                              const PgAccOp* __restrict__ ops) {
   const int64_t n_out = (int64_t)n_ops * n_groups;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_out) return;
   const PgAccOp op = ops[i / n_groups];
-  int64_t acc = partials[i];
-  if (op.fn == PG_ACC_SUM && op.is_float) {
-    double d = __longlong_as_double(acc);
-    for (int w = 1; w < n_wg; w++) d += __longlong_as_double(partials[(int64_t)w * n_out + i]);
-    acc = __double_as_longlong(d);
-  } else if (op.fn == PG_ACC_COUNT || op.fn == PG_ACC_SUM) {
-    for (int w = 1; w < n_wg; w++) acc += partials[(int64_t)w * n_out + i];
-  } else if (op.fn == PG_ACC_MIN) {
-    for (int w = 1; w < n_wg; w++) { int64_t v = partials[(int64_t)w * n_out + i]; acc = v < acc ? v : acc; }
-  } else {
-    for (int w = 1; w < n_wg; w++) { int64_t v = partials[(int64_t)w * n_out + i]; acc = v > acc ? v : acc; }
+  const int kind = (op.fn == PG_ACC_SUM && op.is_float) ? 0 : ((op.fn == PG_ACC_COUNT || op.fn == PG_ACC_SUM) ? 1 : (op.fn == PG_ACC_MIN ? 2 : 3));
+  int64_t acc = pg_acc_identity(op.fn, op.is_float);
+  auto combine = [&](int64_t a, int64_t b) -> int64_t {
+    if (kind == 0) return __double_as_longlong(__longlong_as_double(a) + __longlong_as_double(b));
+    if (kind == 1) return a + b;
+    if (kind == 2) return b < a ? b : a;
+    return b > a ? b : a;
+  };
+  for (int w = lane; w < n_wg; w += 64) acc = combine(acc, partials[(int64_t)w * n_out + i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int64_t other = __shfl_xor((long long)acc, off, 64);
+    acc = combine(acc, other);
   }
-  out[i] = acc;
+  if (lane == 0) out[i] = acc;
 }
 
 extern "C" __global__ void __launch_bounds__(256) pg_fill_i64_kernel(int64_t* dst, int64_t n_per_op, int n_ops,
@@ -567,19 +975,19 @@ extern "C" __global__ void __launch_bounds__(256) pg_fill_i64_kernel(int64_t* ds
   dst[i] = pg_acc_identity(op.fn, op.is_float);
 }
 
-// K4: match words → ascending docIds (DocIdSetOperator).  One workgroup per tile; tile_offsets = exclusive prefix of
-// the per-tile match counts.
-extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_expand_docids_kernel(const uint64_t* __restrict__ words,
-                                                                                const int64_t* __restrict__ tile_offsets,
-                                                                                int32_t* __restrict__ out, int n_tiles) {
-  __shared__ uint32_t s_scan[PG_BLOCK];
+// K4: match words → ascending docIds (DocIdSetOperator).  One 256-thread workgroup per 16 384-doc tile; tile_offsets =
+// exclusive prefix of the per-tile match counts.
+extern "C" __global__ void __launch_bounds__(PG_TILE_WORDS) pg_expand_docids_kernel(const uint64_t* __restrict__ words,
+                                                                                     const int64_t* __restrict__ tile_offsets,
+                                                                                     int32_t* __restrict__ out, int n_tiles) {
+  __shared__ uint32_t s_scan[PG_TILE_WORDS];
   const int t = threadIdx.x;
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     uint64_t w = words[(int64_t)tile * PG_TILE_WORDS + t];
     uint32_t c = (uint32_t)__popcll(w);
     s_scan[t] = c;
     __syncthreads();
-    for (int off = 1; off < PG_BLOCK; off <<= 1) {   // Hillis–Steele inclusive scan
+    for (int off = 1; off < PG_TILE_WORDS; off <<= 1) {   // Hillis–Steele inclusive scan
       uint32_t v = (t >= off) ? s_scan[t - off] : 0;
       __syncthreads();
       s_scan[t] += v;

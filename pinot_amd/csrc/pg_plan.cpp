@@ -364,23 +364,53 @@ struct Emitter {
     const PredEval& e = op.eval;
     const std::vector<int32_t>& ids = e.exclusive ? e.non_matching : e.matching;
     const int32_t n_chunks = (seg.n_tiles + PG_TILES_PER_CHUNK - 1) / PG_TILES_PER_CHUNK;
+    // Dense postings: the leading containers of a dictId that are bitmap containers of chunks 0, 1, 2 ... stored back to
+    // back (they are copied in key order at registration) are addressed as base + 8 KB * chunk by the kernels.
+    auto dense_prefix = [&](int32_t id) {
+      int32_t n = 0;
+      for (uint32_t k = c.posting_begin[id]; k < c.posting_begin[id + 1]; k++, n++) {
+        const PgContainer& pc = c.descs_host[k];
+        if (pc.type != 1 || pc.key != (uint16_t)n || pc.offset != c.descs_host[c.posting_begin[id]].offset + (uint64_t)n * 8192) break;
+      }
+      return n;
+    };
+    const int32_t want = std::max(1, (int32_t)(((int64_t)seg.total_docs + PG_CHUNK_DOCS - 1) / PG_CHUNK_DOCS) - 1);
+    std::vector<int32_t> dense_ids;
+    int32_t dense_chunks = 0;
+    for (int32_t id : ids) {
+      if ((int)dense_ids.size() >= PG_MAX_DENSE) break;
+      const int32_t n = dense_prefix(id);
+      if (n >= want) {
+        dense_chunks = dense_ids.empty() ? n : std::min(dense_chunks, n);
+        dense_ids.push_back(id);
+      }
+    }
+    auto is_dense = [&](int32_t id, const PgContainer& pc) {
+      return pc.key < dense_chunks && std::find(dense_ids.begin(), dense_ids.end(), id) != dense_ids.end();
+    };
     std::vector<uint32_t> chunk_start((size_t)n_chunks + 2, 0);
     for (int32_t id : ids)
-      for (uint32_t k = c.posting_begin[id]; k < c.posting_begin[id + 1]; k++) chunk_start[c.descs_host[k].key + 1]++;
+      for (uint32_t k = c.posting_begin[id]; k < c.posting_begin[id + 1]; k++)
+        if (!is_dense(id, c.descs_host[k])) chunk_start[c.descs_host[k].key + 1]++;
     for (size_t i = 1; i < chunk_start.size(); i++) chunk_start[i] += chunk_start[i - 1];
     std::vector<PgContainer> entries(chunk_start.back());
     std::vector<uint32_t> cursor(chunk_start.begin(), chunk_start.end() - 1);
     for (int32_t id : ids)
       for (uint32_t k = c.posting_begin[id]; k < c.posting_begin[id + 1]; k++) {
         const PgContainer& pc = c.descs_host[k];
-        entries[cursor[pc.key]++] = pc;
+        if (!is_dense(id, pc)) entries[cursor[pc.key]++] = pc;
         alg_bytes += pc.type == 1 ? 8192 : (pc.type == 0 ? 2 * (int64_t)pc.n : 4 * (int64_t)pc.n);
       }
     PgPostingLeaf L{};
     L.containers = c.containers_dev.as<uint8_t>();
+    L.has_csr = entries.empty() ? 0 : 1;
     L.chunk_start = keep(chunk_start);
     L.entries = keep(entries);
     L.exclusive = e.exclusive ? 1 : 0;
+    L.n_dense = (int32_t)dense_ids.size();
+    L.dense_chunks = dense_ids.empty() ? 0 : dense_chunks;
+    for (size_t j = 0; j < dense_ids.size(); j++)
+      L.dense[j] = c.containers_dev.as<uint8_t>() + c.descs_host[c.posting_begin[dense_ids[j]]].offset;
     postings.push_back(L);
     instrs.push_back({PG_F_PUSH_POSTINGS, (int32_t)postings.size() - 1});
     push();
@@ -437,7 +467,7 @@ struct Emitter {
   void emit(const FilterOp& op, bool top_level) {
     switch (op.kind) {
       case OpKind::Empty: instrs.push_back({PG_F_PUSH_NONE, 0}); push(); break;
-      case OpKind::MatchAll: emit_ranges({0}, {seg.total_docs - 1}); break;
+      case OpKind::MatchAll: instrs.push_back({PG_F_PUSH_ALL, 0}); push(); break;
       case OpKind::Sorted: emit_sorted(op); break;
       case OpKind::Inverted: emit_inverted(op); break;
       case OpKind::Scan: emit_scan(op, false); break;
@@ -530,7 +560,8 @@ std::string query_signature(const pg_filter_node* filter, const pg_query* q) {
 // =====================================================================================================================
 // plan compilation
 // =====================================================================================================================
-static const int64_t kLdsTableBudget = 48 * 1024;       // bytes of LDS for the accumulator table
+static const int64_t kLdsTableBudget = 144 * 1024;      // bytes of LDS for the accumulator table (one workgroup per CU)
+static const int64_t kLdsReplicaBudget = 96 * 1024;
 static const int64_t kMaxDenseGroups = 64LL << 20;      // dense HBM table limit (groups)
 
 std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* filter, const pg_query* q) {
@@ -546,6 +577,7 @@ std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* f
   PgQueryPlan& D = P.dev;
   D.num_docs = seg.total_docs;
   D.n_tiles = seg.n_tiles;
+  D.n_wtiles = (int32_t)(((int64_t)seg.total_docs + PG_WAVE_DOCS - 1) / PG_WAVE_DOCS);
   D.n_instr = (int32_t)em.instrs.size();
   D.stack_depth = em.max_sp;
   D.instrs = em.keep(em.instrs);
@@ -556,7 +588,37 @@ std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* f
   D.n_groups = 1;
   D.replicas = 1;
   P.algorithmic_bytes = em.alg_bytes;
-  P.lds_bytes = (size_t)D.stack_depth * PG_TILE_WORDS * 8;
+  // ---- fast-path shape of the filter: [index-only program] (AND one scan of a specialised kind) ---------------------------
+  {
+    auto index_op = [](int32_t op) {
+      return op == PG_F_PUSH_POSTINGS || op == PG_F_PUSH_RANGES || op == PG_F_PUSH_ALL || op == PG_F_PUSH_NONE ||
+             op == PG_F_AND || op == PG_F_OR || op == PG_F_NOT;
+    };
+    size_t n_idx = 0;
+    while (n_idx < em.instrs.size() && index_op(em.instrs[n_idx].op)) n_idx++;
+    const size_t rest = em.instrs.size() - n_idx;
+    P.fast_filter = -2;   // -2: interpreter; -1: no scan; >= 0: ScanKind of the single scan
+    D.fast_scan = -1;
+    auto scan_kind = [&](const PgScanLeaf& L) -> int {   // kinds with a specialised kernel (pg_kernels.hip ScanKind values)
+      if (L.col_kind == PG_COL_FIXED_BIT && L.bits <= 8) return L.pred_kind == PG_P_RANGE ? 0 : (L.pred_kind == PG_P_DICT_LUT ? 2 : -2);
+      if (L.col_kind == PG_COL_RAW32 && L.val_type == PG_V_I32 && L.pred_kind == PG_P_RANGE) return 4;
+      return -2;
+    };
+    if (rest == 0) {
+      P.fast_filter = -1;
+      D.n_index_instr = (int32_t)n_idx;
+      if (n_idx == 1 && em.instrs[0].op == PG_F_PUSH_ALL) D.n_index_instr = 0;   // match-all: the valid mask itself
+    } else if (rest == 1 && ((n_idx == 0 && em.instrs[0].op == PG_F_PUSH_SCAN) || (n_idx > 0 && em.instrs[n_idx].op == PG_F_AND_SCAN))) {
+      const int k = scan_kind(em.scans[em.instrs[n_idx].arg]);
+      if (k >= 0) {
+        P.fast_filter = k;
+        D.n_index_instr = (int32_t)n_idx;
+        D.fast_scan = em.instrs[n_idx].arg;
+        D.fast_scan_pushed = n_idx == 0 ? 1 : 0;
+      }
+    }
+  }
+  P.lds_bytes = 0;   // the filter stack lives in registers
   if (!q || q->n_aggregations <= 0) return plan;
 
   // ---- aggregation plan ------------------------------------------------------------------------------------------
@@ -673,15 +735,20 @@ std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* f
     D.replicas = PG_BLOCK;          // one private slot per thread: no atomic conflicts
   } else if (table_bytes <= kLdsTableBudget) {
     D.agg_mode = PG_AGG_LDS;
-    int r = 1;
-    const int64_t per_wg_budget = 20 * 1024 - (int64_t)D.stack_depth * PG_TILE_WORDS * 8;   // 160 KB / 8 workgroups
-    while (r < 32 && table_bytes * (r * 2) <= per_wg_budget) r *= 2;
+    int r = 1;   // replicas spread same-group updates of the 16 wavefronts over distinct LDS addresses
+    while (r < 64 && table_bytes * (r * 2) <= kLdsReplicaBudget) r *= 2;
     D.replicas = r;
   } else {
     D.agg_mode = PG_AGG_GLOBAL;
     D.replicas = 1;
   }
   if (D.agg_mode != PG_AGG_GLOBAL) P.lds_bytes += (size_t)G * D.replicas * D.n_ops * 8;
+  // fast aggregation: LDS table, slots fit 16 bits, <= 8-bit group columns, 32-bit value sources
+  P.fast_agg = D.agg_mode != PG_AGG_GLOBAL && (int64_t)G * D.replicas <= 65536;
+  for (Column* c : P.group_cols) if (c->bits > 8) P.fast_agg = false;
+  for (Column* c : srcs)
+    if (!(c->col_kind == PG_COL_RAW32 || (c->col_kind == PG_COL_FIXED_BIT && (c->val_type == PG_V_I32 || c->val_type == PG_V_F32))))
+      P.fast_agg = false;
   return plan;
 }
 
