@@ -239,17 +239,24 @@ DEVFN uint32_t scan_wtile(const LeafT& L, uint32_t cand, const GAS uint8_t* __re
   uint32_t res = 0;
 #pragma unroll
   for (int k0 = 0; k0 < 8; k0 += B) {
+    // Loads are unconditional (a load under a per-lane branch is waited for inside the branch, which serialises the
+    // batch); lanes whose quad has no candidate re-read quad `lane` of the tile's first KB instead, so no cache line is
+    // touched that candidates do not need.
     uint32_t r[B][W];
 #pragma unroll
     for (int u = 0; u < B; u++) {
-#pragma unroll
-      for (int w = 0; w < W; w++) r[u][w] = 0;
-      if ((cand >> (4 * (k0 + u))) & 0xFu) load_quad<KIND>(L, tb, (uint32_t)((k0 + u) * 64 + lane), r[u]);
+      const uint32_t nib = (cand >> (4 * (k0 + u))) & 0xFu;
+      load_quad<KIND>(L, tb, nib ? (uint32_t)((k0 + u) * 64 + lane) : 0u, r[u]);
     }
 #pragma unroll
     for (int u = 0; u < B; u++) {
       const uint32_t nib = (cand >> (4 * (k0 + u))) & 0xFu;
-      if (nib) res |= (test_quad<KIND>(L, r[u], (uint32_t)((k0 + u) * 64 + lane), r32) & nib) << (4 * (k0 + u));
+      const uint32_t q = nib ? (uint32_t)((k0 + u) * 64 + lane) : 0u;
+      if (KIND == SK_DICT_LUT_SMALL || KIND == SK_DICT_LUT_WIDE || KIND == SK_I32_SET || KIND == SK_F32_SET || KIND == SK_I64_SET || KIND == SK_F64_SET) {
+        if (nib) res |= (test_quad<KIND>(L, r[u], q, r32) & nib) << (4 * (k0 + u));   // these read a LUT / value set
+      } else {
+        res |= (test_quad<KIND>(L, r[u], q, r32) & nib) << (4 * (k0 + u));
+      }
     }
   }
   return res;
@@ -286,12 +293,10 @@ DEVFN uint32_t postings_wtile(const LeafT& L, int wtile, uint32_t valid_lin, uin
   uint32_t acc = 0;
   if (chunk < L.dense_chunks) {   // wave-uniform: dense bitmap postings, address = base + 8 KB * chunk
     const uint32_t di = (uint32_t)wtile * 64u + (uint32_t)lane;   // = chunk * 2048 + sub * 64 + lane
+    // unused pointers repeat dense[0] (OR is idempotent): 8 unconditional loads, no branches
     uint32_t v[PG_MAX_DENSE];
 #pragma unroll
-    for (int j = 0; j < PG_MAX_DENSE; j++) {
-      v[j] = 0;
-      if (j < L.n_dense) v[j] = gptr<uint32_t>(L.dense[j])[di];
-    }
+    for (int j = 0; j < PG_MAX_DENSE; j++) v[j] = gptr<uint32_t>(L.dense[j])[di];
 #pragma unroll
     for (int j = 0; j < PG_MAX_DENSE; j++) acc |= v[j];
   }
@@ -611,8 +616,8 @@ DEVFN void fast_aggregate_wtile(const PgQueryPlan& p, uint32_t mask_all, int wti
       const GAS uint8_t* tb = gptr<uint8_t>(p.srcs[p.ops[o_first].src].data + (size_t)wtile * (PG_WAVE_DOCS * 4));
 #pragma unroll
       for (int k = 0; k < B; k++) {
-        u32x4 v = {0, 0, 0, 0};
-        if ((m >> (4 * k)) & 0xFu) v = *(const GAS u32x4*)(tb + (uint32_t)((k0 + k) * 64 + lane) * 16u);
+        const uint32_t q = ((m >> (4 * k)) & 0xFu) ? (uint32_t)((k0 + k) * 64 + lane) : 0u;
+        const u32x4 v = *(const GAS u32x4*)(tb + q * 16u);
         x[k][0] = v.x; x[k][1] = v.y; x[k][2] = v.z; x[k][3] = v.w;
       }
     }
@@ -627,13 +632,14 @@ DEVFN void fast_aggregate_wtile(const PgQueryPlan& p, uint32_t mask_all, int wti
       uint32_t r[B][2];
 #pragma unroll
       for (int k = 0; k < B; k++) {
-        r[k][0] = r[k][1] = 0;
-        if ((m >> (4 * k)) & 0xFu) load_packed_quad<true>(tw, (uint32_t)((k0 + k) * 64 + lane), bits, r[k]);
+        const uint32_t q = ((m >> (4 * k)) & 0xFu) ? (uint32_t)((k0 + k) * 64 + lane) : 0u;
+        load_packed_quad<true>(tw, q, bits, r[k]);
       }
 #pragma unroll
       for (int k = 0; k < B; k++) {
         uint32_t d[4];
-        decode_packed_quad<true>(r[k], (uint32_t)((k0 + k) * 64 + lane), bits, mask, d);
+        const uint32_t q = ((m >> (4 * k)) & 0xFu) ? (uint32_t)((k0 + k) * 64 + lane) : 0u;
+        decode_packed_quad<true>(r[k], q, bits, mask, d);
         sp[k][0] += d[0] * mult + ((d[1] * mult) << 16);
         sp[k][1] += d[2] * mult + ((d[3] * mult) << 16);
       }
@@ -658,8 +664,8 @@ DEVFN void fast_aggregate_wtile(const PgQueryPlan& p, uint32_t mask_all, int wti
             const GAS uint8_t* tb = gptr<uint8_t>(S.data + (size_t)wtile * (PG_WAVE_DOCS * 4));
 #pragma unroll
             for (int k = 0; k < B; k++) {
-              u32x4 v = {0, 0, 0, 0};
-              if ((m >> (4 * k)) & 0xFu) v = *(const GAS u32x4*)(tb + (uint32_t)((k0 + k) * 64 + lane) * 16u);
+              const uint32_t q = ((m >> (4 * k)) & 0xFu) ? (uint32_t)((k0 + k) * 64 + lane) : 0u;
+              const u32x4 v = *(const GAS u32x4*)(tb + q * 16u);
               x[k][0] = v.x; x[k][1] = v.y; x[k][2] = v.z; x[k][3] = v.w;
             }
           }

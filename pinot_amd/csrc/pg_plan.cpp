@@ -409,8 +409,9 @@ struct Emitter {
     L.exclusive = e.exclusive ? 1 : 0;
     L.n_dense = (int32_t)dense_ids.size();
     L.dense_chunks = dense_ids.empty() ? 0 : dense_chunks;
-    for (size_t j = 0; j < dense_ids.size(); j++)
-      L.dense[j] = c.containers_dev.as<uint8_t>() + c.descs_host[c.posting_begin[dense_ids[j]]].offset;
+    for (size_t j = 0; j < PG_MAX_DENSE; j++)   // unused slots repeat slot 0: the kernels OR all eight unconditionally
+      L.dense[j] = dense_ids.empty() ? c.containers_dev.as<uint8_t>()
+                                     : c.containers_dev.as<uint8_t>() + c.descs_host[c.posting_begin[dense_ids[j < dense_ids.size() ? j : 0]]].offset;
     postings.push_back(L);
     instrs.push_back({PG_F_PUSH_POSTINGS, (int32_t)postings.size() - 1});
     push();
