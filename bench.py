@@ -60,9 +60,9 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from pinot_amd import capi, synth
+    from pinot_amd import capi, distributed as pd, synth
     from pinot_amd.executor import NativeSegment
-    from pinot_amd.query import CQuery, parse_sql
+    from pinot_amd.query import parse_sql
     from pinot_amd.segment import HostSegment
 
     api = capi.gpu_api()
@@ -85,50 +85,18 @@ def main():
 
     qc = parse_sql(sql)
     qc.flags |= capi.QUERY_FLAG_PROFILE
-    cq = CQuery(qc)
-    n_aggs = len(qc.aggregations)
     cards = [synth.GPU_BENCH[g].range for g in qc.group_by]
-    G = int(np.prod(cards)) if cards else 1
     kernel_ms = []
 
     def step():
         """One pass of the hot path: segment query on this GPU + cross-GPU merge of the group table."""
-        h = C.c_void_p()
-        api.call("query_exec", seg.handle, cq.ptr(), C.byref(h))
-        n = C.c_int32()
-        api.call("result_num_groups", h, C.byref(n))
-        ng = n.value
-        key = np.zeros(ng, dtype=np.int64)
-        mult = 1
-        ids = np.zeros(ng, dtype=np.int32)
-        for j, card in enumerate(cards):
-            api.call("result_group_dict_ids", h, j, ids.ctypes.data, ng)
-            key += ids.astype(np.int64) * mult
-            mult *= card
-        dense = np.zeros((n_aggs, G), dtype=np.float64)
-        present = np.zeros(G, dtype=np.float64)
-        vals = np.zeros(ng, dtype=np.float64)
-        lvals = np.zeros(ng, dtype=np.int64)
-        for a, spec in enumerate(qc.aggregations):
-            if spec.function == "COUNT":
-                api.call("result_longs", h, a, 0, lvals.ctypes.data, ng)
-                dense[a, key] = lvals
-            else:
-                if spec.function == "MAX":
-                    dense[a, :] = -np.inf
-                api.call("result_doubles", h, a, 0, vals.ctypes.data, ng)
-                dense[a, key] = vals
-        present[key] = 1.0
-        st = capi.PgExecStats()
-        api.call("result_stats", h, C.byref(st))
-        api.call("result_free", h)
+        block = seg.execute(qc)
+        st = block.stats
         kernel_ms.append(st.device_ms_aggregate)
+        dense = pd.dense_from_block(block, cards)
         if world > 1:
-            # GroupByCombineOperator merge over xGMI: identical dictionaries ⇒ dense layout, SUM/COUNT add, MAX max
-            for a, spec in enumerate(qc.aggregations):
-                t = torch.from_numpy(dense[a]).cuda()
-                dist.all_reduce(t, op=dist.ReduceOp.MAX if spec.function == "MAX" else dist.ReduceOp.SUM)
-                dense[a] = t.cpu().numpy()
+            # GroupByCombineOperator merge over xGMI: identical dictionaries ⇒ dense layout; ≤ 3 RCCL all-reduces
+            pd.all_reduce_tables(dense, device=torch.device("cuda", local_rank))
         return dense, st
 
     def sync():
@@ -179,12 +147,12 @@ def main():
                    "entries_scanned_in_filter": int(st.num_entries_scanned_in_filter)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "pg_segment_query_kernel", "kernel_ms": avg_kernel_ms,
+                     "kernel": st.kernel.decode() or "pg_segment_query_kernel", "kernel_ms": avg_kernel_ms,
                      "algorithmic_bytes_per_launch": alg_bytes, "library_accounted_bytes": int(lib_alg)},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args, sql, dense, cards, qc)
+        out["cpu_baseline"] = cpu_baseline(args, sql, dense, seg)
     if rank == 0:
         print(json.dumps(out), flush=True)
     seg.destroy()
@@ -192,11 +160,11 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, sql, gpu_dense, cards, qc):
+def cpu_baseline(args, sql, gpu_dense, gpu_seg):
     """CPU leg: the C restatement of the reference algorithm (oracle/, kind "port"), 1 thread per segment exactly like
-    the reference's combine operator, on a prefix sample of the same segment.  Also cross-checks the GPU result on the
-    sample when the sample is the whole segment."""
-    from pinot_amd import synth
+    the reference's combine operator, on a prefix sample of the same segment.  Also cross-checks the GPU result when the
+    sample is the whole segment."""
+    from pinot_amd import distributed as pd, synth
     from pinot_amd.executor import NativeSegment
     from tests.oracle_binding import load_oracle
     sample = min(args.docs, args.cpu_sample_docs)
@@ -211,15 +179,8 @@ def cpu_baseline(args, sql, gpu_dense, cards, qc):
         times.append(time.perf_counter() - t)
     med = statistics.median(times)
     if sample == args.docs:   # full-size parity check against the timed GPU result
-        rows = block.rows()
-        for key, vals in rows.items():
-            k = 0
-            mult = 1
-            for j, card in enumerate(cards):
-                k += int(key[j]) * mult
-                mult *= card
-            for a in range(len(vals)):
-                assert gpu_dense[a, k] == float(vals[a]), (key, a, gpu_dense[a, k], vals[a])
+        dicts = [host.columns[g].dict_values for g in block.query.group_by]
+        assert pd.rows_from_dense(gpu_dense, dicts) == block.rows(), "GPU result differs from the oracle"
     ora.destroy()
     return {"value": sample / med, "unit": "rows/s", "cores": 1, "kind": "port",
             "sample": f"first {sample} docs of segment 0, same query, median of 5 runs; C restatement of the reference "

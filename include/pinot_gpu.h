@@ -174,6 +174,7 @@ typedef struct pg_exec_stats {
   float host_ms_plan;
   float host_ms_total;
   int64_t algorithmic_bytes;      /* bytes the plan must read once (columns + postings), for roofline accounting */
+  char kernel[32];                /* name of the segment query kernel that ran (rocprofv3 kernel-trace name) */
 } pg_exec_stats;
 
 /* Intermediate result kinds (AggregationFunction#getIntermediateResultColumnType). */

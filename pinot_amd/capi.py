@@ -111,6 +111,7 @@ class PgExecStats(C.Structure):
         ("host_ms_plan", C.c_float),
         ("host_ms_total", C.c_float),
         ("algorithmic_bytes", C.c_int64),
+        ("kernel", C.c_char * 32),
     ]
 
     def as_dict(self) -> dict:

@@ -174,19 +174,19 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   const int64_t n_out = (int64_t)D.n_ops * D.n_groups;
   PG_HIP(hipMemsetAsync(ctx.stats.ptr, 0, PG_MAX_STATS * 8, ctx.stream));
   D.stats = ctx.stats.as<unsigned long long>();
-  ThreadCtx::grow(ctx.final_table, (size_t)n_out * 8);
+  ThreadCtx::grow(ctx.final_table, (size_t)n_out * 8 + 8);
   if (D.agg_mode == PG_AGG_GLOBAL) {
     D.partials = ctx.final_table.as<int64_t>();
     int blocks = (int)((n_out + 255) / 256);
     hipLaunchKernelGGL(pg_fill_i64_kernel, dim3(blocks), dim3(256), 0, ctx.stream, D.partials, (int64_t)D.n_groups,
                        D.n_ops, P.ops_dev.as<PgAccOp>());
   } else {
-    ThreadCtx::grow(ctx.partials, (size_t)n_out * 8 * (size_t)shape.grid);
+    ThreadCtx::grow(ctx.partials, (size_t)n_out * 8 * (size_t)shape.grid + 8);
     D.partials = ctx.partials.as<int64_t>();
   }
   if (profile) PG_HIP(hipEventRecord(ctx.ev[0], ctx.stream));
+  const char* kname = "";
   if (seg.total_docs > 0) {
-    const char* kname = nullptr;
     QueryKernel kern = select_kernel(P, D.agg_mode, &kname);
     hipLaunchKernelGGL(kern, dim3(shape.grid), dim3(PG_BLOCK), shape.lds, ctx.stream, D);
     PG_HIP(hipGetLastError());
@@ -194,14 +194,14 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   if (profile) PG_HIP(hipEventRecord(ctx.ev[1], ctx.stream));
   std::vector<int64_t> table((size_t)n_out);
   if (seg.total_docs > 0) {
-    if (D.agg_mode != PG_AGG_GLOBAL) {
+    if (D.agg_mode != PG_AGG_GLOBAL && n_out > 0) {
       int blocks = (int)((n_out + 3) / 4);   // one wavefront per output slot
       hipLaunchKernelGGL(pg_reduce_partials_kernel, dim3(blocks), dim3(256), 0, ctx.stream, ctx.partials.as<int64_t>(),
                          ctx.final_table.as<int64_t>(), shape.grid, D.n_ops, D.n_groups, P.ops_dev.as<PgAccOp>());
       PG_HIP(hipGetLastError());
     }
     if (profile) PG_HIP(hipEventRecord(ctx.ev[2], ctx.stream));
-    PG_HIP(hipMemcpyAsync(table.data(), ctx.final_table.ptr, (size_t)n_out * 8, hipMemcpyDeviceToHost, ctx.stream));
+    if (n_out > 0) PG_HIP(hipMemcpyAsync(table.data(), ctx.final_table.ptr, (size_t)n_out * 8, hipMemcpyDeviceToHost, ctx.stream));
   } else {
     if (profile) PG_HIP(hipEventRecord(ctx.ev[2], ctx.stream));
     for (int o = 0; o < D.n_ops; o++)
@@ -213,6 +213,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
 
   auto res = std::make_unique<Result>();
   fill_stats(res->stats, P, seg, stats_host);
+  snprintf(res->stats.kernel, sizeof(res->stats.kernel), "%s", kname);
   if (profile) {
     float a = 0, b = 0;
     PG_HIP(hipEventElapsedTime(&a, ctx.ev[0], ctx.ev[1]));
@@ -225,9 +226,12 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
 
   // ---- assemble groups: a group exists iff its hidden COUNT is > 0 (ArrayBasedHolder flags / map entries) ----------------
   const int64_t G = D.n_groups;
-  const int64_t* ex = table.data() + (size_t)P.exist_op * G;
-  const int64_t ex_ident = pg_acc_identity(D.ops[P.exist_op].fn, 0);
-  auto exists = [&](int64_t g) { return ex[g] != ex_ident; };   // COUNT: != 0; MIN/MAX over INT: left its identity
+  const int64_t matched = (int64_t)stats_host[0];
+  const bool ex_stats = P.exist_op == kCountFromStats;
+  const int64_t* ex = ex_stats ? nullptr : table.data() + (size_t)P.exist_op * G;
+  const int64_t ex_ident = ex_stats ? 0 : pg_acc_identity(D.ops[P.exist_op].fn, 0);
+  auto exists = [&](int64_t g) { return ex_stats ? matched > 0 : ex[g] != ex_ident; };   // COUNT: != 0; MIN/MAX over INT: left its identity
+  auto count_of = [&](int32_t op, int64_t g) { return op == kCountFromStats ? matched : table[(size_t)op * G + g]; };
   std::vector<int64_t> gids;
   if (q.n_group_by == 0) gids.push_back(0);
   else for (int64_t g = 0; g < G; g++) if (exists(g)) gids.push_back(g);
@@ -268,11 +272,11 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
     switch (ao.function) {
       case PG_AGG_COUNT:
         r.kind = PG_RESULT_LONG;
-        for (int32_t i = 0; i < ng; i++) r.l[0][i] = table[(size_t)ao.op_a * G + gids[i]];
+        for (int32_t i = 0; i < ng; i++) r.l[0][i] = count_of(ao.op_a, gids[i]);
         break;
       case PG_AGG_AVG:
         r.kind = PG_RESULT_AVG_PAIR;
-        for (int32_t i = 0; i < ng; i++) { r.d[0][i] = op_double(ao.op_a, gids[i]); r.l[0][i] = table[(size_t)ao.op_b * G + gids[i]]; }
+        for (int32_t i = 0; i < ng; i++) { r.d[0][i] = op_double(ao.op_a, gids[i]); r.l[0][i] = count_of(ao.op_b, gids[i]); }
         break;
       case PG_AGG_MINMAXRANGE:
         r.kind = PG_RESULT_MINMAX_PAIR;
@@ -310,8 +314,8 @@ std::unique_ptr<DocIdSet> execute_filter(Segment& seg, const pg_filter_node* fil
   D.agg_mode = PG_AGG_NONE;
   const LaunchShape shape = launch_shape(P, P.dev.n_wtiles);
   PG_HIP(hipEventRecord(ctx.ev[0], ctx.stream));
+  const char* kname = "";
   if (seg.total_docs > 0) {
-    const char* kname = nullptr;
     QueryKernel kern = select_kernel(P, PG_AGG_NONE, &kname);
     hipLaunchKernelGGL(kern, dim3(shape.grid), dim3(PG_BLOCK), shape.lds, ctx.stream, D);
     PG_HIP(hipGetLastError());
@@ -322,6 +326,7 @@ std::unique_ptr<DocIdSet> execute_filter(Segment& seg, const pg_filter_node* fil
   PG_HIP(hipMemcpyAsync(out->tile_counts.data(), ctx.tile_counts.ptr, out->tile_counts.size() * 4, hipMemcpyDeviceToHost, ctx.stream));
   PG_HIP(hipStreamSynchronize(ctx.stream));
   fill_stats(out->stats, P, seg, stats_host);
+  snprintf(out->stats.kernel, sizeof(out->stats.kernel), "%s", kname);
   out->stats.num_entries_scanned_post_filter = 0;
   out->cardinality = (int64_t)stats_host[0];
   float ms = 0;

@@ -135,6 +135,8 @@ struct FilterOp {
 
 enum class ResultKind { Long, Double, AvgPair, MinMaxPair };
 
+static const int32_t kCountFromStats = -2;   // AggOut::op_a/op_b, CompiledPlan::exist_op: the match count, not a table op
+
 struct AggOut {          // how one requested aggregation maps onto accumulator ops
   int32_t function;
   int32_t op_a = -1, op_b = -1;   // indices into ops (AVG: sum,count; MINMAXRANGE: min,max; COUNT: count op)

@@ -673,7 +673,8 @@ std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* f
     }
   }
   if (!has_int_minmax) need_count = true;
-  const int32_t count_op = need_count ? op_index(PG_ACC_COUNT, -1, false) : -1;
+  // Without GROUP BY the count is the number of matching docs (stats slot 0): no accumulator (kCountFromStats).
+  const int32_t count_op = q->n_group_by == 0 ? kCountFromStats : (need_count ? op_index(PG_ACC_COUNT, -1, false) : -1);
   for (int i = 0; i < q->n_aggregations; i++) {
     const pg_agg_spec& s = q->aggregations[i];
     AggOut out{};
@@ -706,15 +707,15 @@ std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* f
   std::vector<PgAccOp> sorted_ops(ops.size());
   for (size_t i = 0; i < order.size(); i++) { sorted_ops[i] = ops[order[i]]; remap[order[i]] = (int32_t)i; }
   for (auto& a : P.aggs) { if (a.op_a >= 0) a.op_a = remap[a.op_a]; if (a.op_b >= 0) a.op_b = remap[a.op_b]; }
-  P.exist_op = -1;
+  P.exist_op = q->n_group_by == 0 ? kCountFromStats : -1;
   for (size_t i = 0; i < sorted_ops.size(); i++) {
-    if (sorted_ops[i].fn == PG_ACC_COUNT) { P.exist_op = (int32_t)i; break; }
+    if (P.exist_op == -1 && sorted_ops[i].fn == PG_ACC_COUNT) { P.exist_op = (int32_t)i; break; }
   }
-  if (P.exist_op < 0)
+  if (P.exist_op == -1)
     for (size_t i = 0; i < sorted_ops.size(); i++)
       if ((sorted_ops[i].fn == PG_ACC_MIN || sorted_ops[i].fn == PG_ACC_MAX) && !sorted_ops[i].is_float &&
           srcs[sorted_ops[i].src]->val_type == PG_V_I32) { P.exist_op = (int32_t)i; break; }
-  if (P.exist_op < 0) fail(PG_ERR_INTERNAL, "no existence accumulator");
+  if (P.exist_op == -1) fail(PG_ERR_INTERNAL, "no existence accumulator");
   D.n_ops = (int32_t)sorted_ops.size();
   for (int i = 0; i < D.n_ops; i++) D.ops[i] = sorted_ops[i];
   P.ops_dev = upload_vector(sorted_ops);
@@ -731,7 +732,9 @@ std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* f
   P.n_projected_columns = (int32_t)projected.size();
 
   const int64_t table_bytes = G * D.n_ops * 8;
-  if (q->n_group_by == 0) {
+  if (D.n_ops == 0) {
+    D.agg_mode = PG_AGG_NONE;        // COUNT(*) only: nothing to accumulate beyond the match count
+  } else if (q->n_group_by == 0) {
     D.agg_mode = PG_AGG_SINGLE;
     D.replicas = PG_BLOCK;          // one private slot per thread: no atomic conflicts
   } else if (table_bytes <= kLdsTableBudget) {
@@ -743,9 +746,9 @@ std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* f
     D.agg_mode = PG_AGG_GLOBAL;
     D.replicas = 1;
   }
-  if (D.agg_mode != PG_AGG_GLOBAL) P.lds_bytes += (size_t)G * D.replicas * D.n_ops * 8;
+  if (D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE) P.lds_bytes += (size_t)G * D.replicas * D.n_ops * 8;
   // fast aggregation: LDS table, slots fit 16 bits, <= 8-bit group columns, 32-bit value sources
-  P.fast_agg = D.agg_mode != PG_AGG_GLOBAL && (int64_t)G * D.replicas <= 65536;
+  P.fast_agg = D.agg_mode != PG_AGG_GLOBAL && (int64_t)G * D.replicas <= 65536;   // (trivially true without a table)
   for (Column* c : P.group_cols) if (c->bits > 8) P.fast_agg = false;
   for (Column* c : srcs)
     if (!(c->col_kind == PG_COL_RAW32 || (c->col_kind == PG_COL_FIXED_BIT && (c->val_type == PG_V_I32 || c->val_type == PG_V_F32))))

@@ -95,7 +95,11 @@ class NativeSegment:
         qc = parse_sql(q) if isinstance(q, str) else q
         if profile:
             qc.flags |= capi.QUERY_FLAG_PROFILE
-        cq = CQuery(qc)
+        cached = getattr(qc, "_cquery", None)     # the C structs of a QueryContext are reusable across executions
+        if cached is None or cached[0] != qc.flags:
+            cached = (qc.flags, CQuery(qc))
+            qc._cquery = cached
+        cq = cached[1]
         h = C.c_void_p()
         self.api.call("query_exec", self.handle, cq.ptr(), C.byref(h))
         try:
@@ -149,31 +153,32 @@ class ResultsBlock:
 
     `rows` maps the decoded group key tuple (dictionary values, as GroupKeyGenerator#getGroupKeys yields them) to the
     list of intermediate results, one per aggregation: COUNT → int, SUM/MIN/MAX → float, AVG → (sum, count),
-    MINMAXRANGE → (min, max), DISTINCTCOUNT → frozenset of values, DISTINCTCOUNTHLL → bytes of 2^log2m registers."""
+    MINMAXRANGE → (min, max), DISTINCTCOUNT → frozenset of values, DISTINCTCOUNTHLL → bytes of 2^log2m registers.
+    The native arrays are kept as numpy arrays (`arrays`, `group_dict_ids`); the Python-object views (`group_keys`,
+    `columns`) are built on first use so that the benchmark loop does not pay for boxing."""
 
     def __init__(self):
         self.query: Optional[QueryContext] = None
-        self.group_keys: List[tuple] = []
         self.group_dict_ids: Optional[np.ndarray] = None   # [n_group_cols, n_groups]
-        self.columns: List[list] = []                       # per aggregation, per group
+        self.arrays: List[tuple] = []                       # per aggregation: (kind, component arrays...)
         self.stats: Optional[capi.PgExecStats] = None
+        self._host: Optional[HostSegment] = None
+        self._group_keys: Optional[List[tuple]] = None
+        self._columns: Optional[List[list]] = None
 
     @staticmethod
     def from_native(api: capi.NativeApi, h, qc: QueryContext, host: HostSegment) -> "ResultsBlock":
         rb = ResultsBlock()
         rb.query = qc
+        rb._host = host
         n = C.c_int32()
         api.call("result_num_groups", h, C.byref(n))
         ng = n.value
         ngb = len(qc.group_by)
         ids = np.zeros((ngb, ng), dtype=np.int32)
         for j in range(ngb):
-            row = np.zeros(ng, dtype=np.int32)
-            api.call("result_group_dict_ids", h, j, row.ctypes.data, ng)
-            ids[j] = row
+            api.call("result_group_dict_ids", h, j, ids[j].ctypes.data, ng)
         rb.group_dict_ids = ids
-        dicts = [host.columns[g].dict_values for g in qc.group_by]
-        rb.group_keys = [tuple(dicts[j][ids[j, i]] for j in range(ngb)) for i in range(ng)]
         for a, spec in enumerate(qc.aggregations):
             kind = C.c_int32()
             api.call("result_kind_of", h, a, C.byref(kind))
@@ -181,46 +186,80 @@ class ResultsBlock:
             if k == capi.RESULT_LONG:
                 out = np.zeros(ng, dtype=np.int64)
                 api.call("result_longs", h, a, 0, out.ctypes.data, ng)
-                rb.columns.append([int(v) for v in out])
+                rb.arrays.append((k, out))
             elif k == capi.RESULT_DOUBLE:
                 out = np.zeros(ng, dtype=np.float64)
                 api.call("result_doubles", h, a, 0, out.ctypes.data, ng)
-                rb.columns.append([float(v) for v in out])
+                rb.arrays.append((k, out))
             elif k == capi.RESULT_AVG_PAIR:
                 s = np.zeros(ng, dtype=np.float64)
                 c = np.zeros(ng, dtype=np.int64)
                 api.call("result_doubles", h, a, 0, s.ctypes.data, ng)
                 api.call("result_longs", h, a, 0, c.ctypes.data, ng)
-                rb.columns.append([(float(x), int(y)) for x, y in zip(s, c)])
+                rb.arrays.append((k, s, c))
             elif k == capi.RESULT_MINMAX_PAIR:
                 lo = np.zeros(ng, dtype=np.float64)
                 hi = np.zeros(ng, dtype=np.float64)
                 api.call("result_doubles", h, a, 0, lo.ctypes.data, ng)
                 api.call("result_doubles", h, a, 1, hi.ctypes.data, ng)
-                rb.columns.append([(float(x), float(y)) for x, y in zip(lo, hi)])
+                rb.arrays.append((k, lo, hi))
             elif k == capi.RESULT_DICTID_SET:
                 sizes = np.zeros(ng, dtype=np.int32)
                 api.call("result_set_sizes", h, a, sizes.ctypes.data, ng)
                 total = int(sizes.sum())
                 flat = np.zeros(max(total, 1), dtype=np.int32)
                 api.call("result_set_dict_ids", h, a, flat.ctypes.data, total)
-                dv = host.columns[spec.column].dict_values
-                col, pos = [], 0
-                for sz in sizes:
-                    col.append(frozenset(dv[d] for d in flat[pos:pos + sz]))
-                    pos += sz
-                rb.columns.append(col)
+                rb.arrays.append((k, sizes, flat[:total]))
             elif k == capi.RESULT_HLL:
                 m = 1 << (spec.log2m or 8)
                 regs = np.zeros(max(ng * m, 1), dtype=np.uint8)
                 api.call("result_hll_registers", h, a, regs.ctypes.data, ng * m)
-                rb.columns.append([bytes(regs[i * m:(i + 1) * m]) for i in range(ng)])
+                rb.arrays.append((k, regs[:ng * m].reshape(ng, m)))
             else:
                 raise RuntimeError(f"unknown result kind {k}")
         st = capi.PgExecStats()
         api.call("result_stats", h, C.byref(st))
         rb.stats = st
         return rb
+
+    @property
+    def num_groups(self) -> int:
+        return self.group_dict_ids.shape[1] if self.query.group_by else 1
+
+    @property
+    def group_keys(self) -> List[tuple]:
+        if self._group_keys is None:
+            ids = self.group_dict_ids
+            dicts = [self._host.columns[g].dict_values for g in self.query.group_by]
+            ng = self.num_groups
+            self._group_keys = [tuple(dicts[j][ids[j, i]] for j in range(len(dicts))) for i in range(ng)]
+        return self._group_keys
+
+    @property
+    def columns(self) -> List[list]:
+        if self._columns is None:
+            cols = []
+            for spec, arr in zip(self.query.aggregations, self.arrays):
+                k = arr[0]
+                if k == capi.RESULT_LONG:
+                    cols.append([int(v) for v in arr[1]])
+                elif k == capi.RESULT_DOUBLE:
+                    cols.append([float(v) for v in arr[1]])
+                elif k == capi.RESULT_AVG_PAIR:
+                    cols.append([(float(x), int(y)) for x, y in zip(arr[1], arr[2])])
+                elif k == capi.RESULT_MINMAX_PAIR:
+                    cols.append([(float(x), float(y)) for x, y in zip(arr[1], arr[2])])
+                elif k == capi.RESULT_DICTID_SET:
+                    dv = self._host.columns[spec.column].dict_values
+                    col, pos = [], 0
+                    for sz in arr[1]:
+                        col.append(frozenset(dv[d] for d in arr[2][pos:pos + sz]))
+                        pos += sz
+                    cols.append(col)
+                else:
+                    cols.append([bytes(r) for r in arr[1]])
+            self._columns = cols
+        return self._columns
 
     # -- conveniences ----------------------------------------------------------------------------------------------
     def execution_statistics(self) -> ExecutionStatistics:
