@@ -127,6 +127,14 @@ def main():
     alg_bytes = bytes_per_row * args.docs
     achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9 if avg_kernel_ms > 0 else 0.0
     lib_alg = st.algorithmic_bytes
+    # HBM bytes per launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE/WRITE_SIZE, collected in their
+    # own runs and corrected as MI355X_MICROARCH.md §HBM prescribes); committed under profiles/, null when not measured
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            traffic = json.load(f).get(f"{args.query}:{args.docs}", {}).get("traffic_bytes")
+    except OSError:
+        pass
     out = {
         "metric": "rows scanned/sec, 1B-row segment filter+groupby (3 predicates, SUM/MAX GROUP BY g1)",
         "value": value,
@@ -146,7 +154,7 @@ def main():
                    "matched_docs_per_segment": int(st.num_docs_scanned),
                    "entries_scanned_in_filter": int(st.num_entries_scanned_in_filter)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": st.kernel.decode() or "pg_segment_query_kernel", "kernel_ms": avg_kernel_ms,
                      "algorithmic_bytes_per_launch": alg_bytes, "library_accounted_bytes": int(lib_alg)},
     }
