@@ -178,20 +178,26 @@ int32_t pg_result_longs(pg_result_t result, int32_t agg, int32_t component, int6
 }
 int32_t pg_result_set_sizes(pg_result_t result, int32_t agg, int32_t* out_sizes, int32_t capacity) {
   return guarded([&] {
-    (void)agg_of(result, agg); (void)out_sizes; (void)capacity;
-    fail(PG_ERR_UNSUPPORTED, "DISTINCTCOUNT results are not produced by this build");
+    AggResult& a = agg_of(result, agg);
+    REQUIRE(a.kind == PG_RESULT_DICTID_SET, "aggregation is not a DISTINCTCOUNT");
+    REQUIRE(capacity >= result->r->num_groups, "capacity too small");
+    if (!a.set_sizes.empty()) memcpy(out_sizes, a.set_sizes.data(), a.set_sizes.size() * 4);
   });
 }
 int32_t pg_result_set_dict_ids(pg_result_t result, int32_t agg, int32_t* out_dict_ids, int64_t capacity) {
   return guarded([&] {
-    (void)agg_of(result, agg); (void)out_dict_ids; (void)capacity;
-    fail(PG_ERR_UNSUPPORTED, "DISTINCTCOUNT results are not produced by this build");
+    AggResult& a = agg_of(result, agg);
+    REQUIRE(a.kind == PG_RESULT_DICTID_SET, "aggregation is not a DISTINCTCOUNT");
+    REQUIRE(capacity >= (int64_t)a.set_ids.size(), "capacity too small");
+    if (!a.set_ids.empty()) memcpy(out_dict_ids, a.set_ids.data(), a.set_ids.size() * 4);
   });
 }
 int32_t pg_result_hll_registers(pg_result_t result, int32_t agg, uint8_t* out_registers, int64_t capacity) {
   return guarded([&] {
-    (void)agg_of(result, agg); (void)out_registers; (void)capacity;
-    fail(PG_ERR_UNSUPPORTED, "DISTINCTCOUNTHLL results are not produced by this build");
+    AggResult& a = agg_of(result, agg);
+    REQUIRE(a.kind == PG_RESULT_HLL, "aggregation is not a DISTINCTCOUNTHLL");
+    REQUIRE(capacity >= (int64_t)a.hll.size(), "capacity too small");
+    if (!a.hll.empty()) memcpy(out_registers, a.hll.data(), a.hll.size());
   });
 }
 int32_t pg_result_stats(pg_result_t result, pg_exec_stats* out_stats) {

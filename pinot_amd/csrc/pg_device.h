@@ -130,6 +130,25 @@ struct PgAccOp {
   int32_t pad;
 };
 
+// Auxiliary (non-scalar) accumulators, always in HBM, one region per op, zero-initialised per execution:
+//   PG_AUX_DICT_SET  DISTINCTCOUNT over a dictionary column: bitset of dictIds per group, `stride` 32-bit words per group
+//                    (BaseDistinctAggregateAggregationFunction.java:306-345 keeps a RoaringBitmap of dictIds per group)
+//   PG_AUX_HLL_DICT  DISTINCTCOUNTHLL over a dictionary column: 2^log2m one-byte registers per group; (index, rank) of every
+//                    dictionary value is precomputed on the host (`lut`, DistinctCountHLLAggregationFunction.java:457-466
+//                    offers dictionary.get(dictId) for each dictId of the group's bitmap — register max is idempotent, so
+//                    offering every doc's value gives the same registers)
+//   PG_AUX_HLL_RAW   DISTINCTCOUNTHLL over a raw column: hll.offer(value) per doc (:188-221), MurmurHash.hashLong on device
+enum PgAuxKind : int32_t { PG_AUX_DICT_SET = 0, PG_AUX_HLL_DICT = 1, PG_AUX_HLL_RAW = 2 };
+#define PG_MAX_AUX 4
+struct PgAuxOp {
+  int32_t kind;
+  int32_t src;          // index into srcs (column read for the op)
+  int32_t stride;       // DICT_SET: words per group; HLL: registers (bytes) per group = 1 << log2m
+  int32_t log2m;
+  uint32_t* base;       // region of this op (patched per execution)
+  const uint32_t* lut;  // HLL_DICT: per dictId (register index | rank << 16)
+};
+
 struct PgQueryPlan {
   int32_t num_docs;
   int32_t n_tiles;                  // 16 384-doc tiles (allocation / expansion granule)
@@ -158,7 +177,9 @@ struct PgQueryPlan {
   int32_t n_ops;
   int32_t n_groups;                 // G = product of group cardinalities (1 without GROUP BY)
   int32_t replicas;                 // R: LDS copies per group (power of two) to spread atomic conflicts
-  int32_t pad0, pad1;
+  int32_t replica_shift;            // log2(R): group index = slot >> replica_shift
+  int32_t n_aux;
+  PgAuxOp aux[PG_MAX_AUX];
   PgGroupCol gcols[PG_MAX_GROUP_COLS];
   PgValueSrc srcs[PG_MAX_SRCS];
   PgAccOp ops[PG_MAX_OPS];

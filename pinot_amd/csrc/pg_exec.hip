@@ -97,7 +97,7 @@ static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char
 struct ThreadCtx {
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  DeviceBuffer stats, partials, final_table, tile_counts;
+  DeviceBuffer stats, partials, final_table, tile_counts, aux;
   ~ThreadCtx() {
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
@@ -184,6 +184,15 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
     ThreadCtx::grow(ctx.partials, (size_t)n_out * 8 * (size_t)shape.grid + 8);
     D.partials = ctx.partials.as<int64_t>();
   }
+  // auxiliary regions (DISTINCTCOUNT sets / HLL registers): one zeroed HBM region per op
+  size_t aux_total = 0;
+  for (size_t b : P.aux_bytes) aux_total += b;
+  if (aux_total) {
+    ThreadCtx::grow(ctx.aux, aux_total);
+    PG_HIP(hipMemsetAsync(ctx.aux.ptr, 0, aux_total, ctx.stream));
+    size_t off = 0;
+    for (int x = 0; x < D.n_aux; x++) { D.aux[x].base = reinterpret_cast<uint32_t*>(ctx.aux.as<uint8_t>() + off); off += P.aux_bytes[x]; }
+  }
   if (profile) PG_HIP(hipEventRecord(ctx.ev[0], ctx.stream));
   const char* kname = "";
   if (seg.total_docs > 0) {
@@ -209,6 +218,9 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   }
   uint64_t stats_host[PG_MAX_STATS];
   PG_HIP(hipMemcpyAsync(stats_host, ctx.stats.ptr, sizeof(stats_host), hipMemcpyDeviceToHost, ctx.stream));
+  std::vector<uint8_t> aux_host(aux_total);
+  if (aux_total && seg.total_docs > 0)
+    PG_HIP(hipMemcpyAsync(aux_host.data(), ctx.aux.ptr, aux_total, hipMemcpyDeviceToHost, ctx.stream));
   PG_HIP(hipStreamSynchronize(ctx.stream));
 
   auto res = std::make_unique<Result>();
@@ -269,6 +281,35 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
     const AggOut& ao = P.aggs[a];
     AggResult& r = res->aggs[a];
     for (int k = 0; k < 2; k++) { r.d[k].assign((size_t)ng, 0.0); r.l[k].assign((size_t)ng, 0); }
+    if (ao.aux >= 0) {   // DISTINCTCOUNT / DISTINCTCOUNTHLL: extract the groups' regions
+      size_t off = 0;
+      for (int x = 0; x < ao.aux; x++) off += P.aux_bytes[x];
+      const PgAuxOp& A = D.aux[ao.aux];
+      if (A.kind == PG_AUX_DICT_SET) {
+        r.kind = PG_RESULT_DICTID_SET;
+        r.set_sizes.assign((size_t)ng, 0);
+        const uint32_t* words = reinterpret_cast<const uint32_t*>(aux_host.data() + off);
+        for (int32_t i = 0; i < ng; i++) {
+          const uint32_t* w = words + (size_t)gids[i] * A.stride;
+          for (int32_t k = 0; k < A.stride; k++) {
+            uint32_t bitsw = w[k];
+            while (bitsw) {
+              const int b = __builtin_ctz(bitsw);
+              r.set_ids.push_back(k * 32 + b);
+              r.set_sizes[i]++;
+              bitsw &= bitsw - 1;
+            }
+          }
+        }
+      } else {
+        r.kind = PG_RESULT_HLL;
+        r.log2m = ao.log2m;
+        r.hll.resize((size_t)ng * A.stride);
+        for (int32_t i = 0; i < ng; i++)
+          memcpy(r.hll.data() + (size_t)i * A.stride, aux_host.data() + off + (size_t)gids[i] * A.stride, (size_t)A.stride);
+      }
+      continue;
+    }
     switch (ao.function) {
       case PG_AGG_COUNT:
         r.kind = PG_RESULT_LONG;

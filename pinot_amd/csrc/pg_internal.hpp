@@ -86,6 +86,7 @@ struct Column {
   std::vector<uint32_t> posting_begin;          // cardinality + 1 offsets into descs_host
   DeviceBuffer containers_dev, descs_dev;
   uint64_t fwd_bytes_logical = 0;               // bytes of the forward index proper (for algorithmic byte accounting)
+  std::map<int, DeviceBuffer> hll_luts;         // per log2m: (register index | rank << 16) of every dictionary value
 };
 
 struct CompiledPlan;
@@ -141,6 +142,9 @@ struct AggOut {          // how one requested aggregation maps onto accumulator 
   int32_t function;
   int32_t op_a = -1, op_b = -1;   // indices into ops (AVG: sum,count; MINMAXRANGE: min,max; COUNT: count op)
   bool is_float = false;
+  int32_t aux = -1;                // DISTINCTCOUNT / DISTINCTCOUNTHLL: index into PgQueryPlan::aux
+  int32_t log2m = 0;
+  Column* aux_col = nullptr;
 };
 
 struct CompiledPlan {
@@ -162,6 +166,7 @@ struct CompiledPlan {
   int32_t fast_filter = -2;          // -2: interpreter kernel; -1: index-only filter; >= 0: ScanKind of the one scan leaf
   bool fast_agg = true;              // aggregation fits the fast kernels (or there is none)
   DeviceBuffer ops_dev;
+  std::vector<size_t> aux_bytes;     // bytes of each auxiliary region (256-byte multiples)
 };
 
 std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* filter, const pg_query* query);
@@ -172,6 +177,9 @@ struct AggResult {
   int32_t kind = PG_RESULT_DOUBLE;
   std::vector<double> d[2];
   std::vector<int64_t> l[2];
+  std::vector<int32_t> set_sizes, set_ids;   // PG_RESULT_DICTID_SET: per group sizes, concatenated ascending dictIds
+  std::vector<uint8_t> hll;                  // PG_RESULT_HLL: num_groups * 2^log2m registers
+  int32_t log2m = 0;
 };
 struct Result {
   int32_t num_groups = 0;

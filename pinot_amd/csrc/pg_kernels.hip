@@ -403,6 +403,46 @@ DEVFN void acc_float(int64_t* slot, int fn, double v) {
   else atomicMax(reinterpret_cast<long long*>(slot), (long long)k);
 }
 
+// ---- auxiliary accumulators (DISTINCTCOUNT dictId sets, HyperLogLog registers) in HBM ------------------------------------------
+// Both are monotone (bits only get set, registers only grow), so an update first reads the current state and skips the
+// atomic when it would change nothing — after warm-up almost every doc does (a stale read only costs a redundant atomic).
+DEVFN uint32_t murmur_hash_long_dev(int64_t data) {   // stream-lib MurmurHash.hashLong
+  const uint32_t m = 0x5bd1e995u;
+  uint32_t h = 0;
+  uint32_t k = (uint32_t)(uint64_t)data * m;
+  k ^= k >> 24;
+  h ^= k * m;
+  k = (uint32_t)((uint64_t)data >> 32) * m;
+  k ^= k >> 24;
+  h *= m;
+  h ^= k * m;
+  h ^= h >> 13;
+  h *= m;
+  h ^= h >> 15;
+  return h;
+}
+DEVFN uint32_t hll_index_rank_dev(uint32_t x, int log2m) {   // register index | rank << 16
+  const uint32_t j = x >> (32 - log2m);
+  const uint32_t w = (x << log2m) | ((1u << (log2m - 1)) + 1u);
+  return j | ((uint32_t)(__clz((int)w) + 1) << 16);
+}
+DEVFN void set_add(uint32_t* words, uint32_t id) {
+  uint32_t* w = words + (id >> 5);
+  const uint32_t bit = 1u << (id & 31u);
+  if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(w, bit);
+}
+DEVFN void hll_update(uint8_t* regs, uint32_t idx, uint32_t rank) {
+  uint32_t* w = reinterpret_cast<uint32_t*>(regs + (idx & ~3u));
+  const uint32_t sh = (idx & 3u) * 8u;
+  uint32_t cur = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while (((cur >> sh) & 0xFFu) < rank) {
+    const uint32_t nv = (cur & ~(0xFFu << sh)) | (rank << sh);
+    const uint32_t prev = atomicCAS(w, cur, nv);
+    if (prev == cur) break;
+    cur = prev;
+  }
+}
+
 // Aggregates the matching docs (quad-layout mask m) of one wave tile into `table` ([n_ops][G*R] int64 slots, LDS or HBM).
 // B quads per lane are in flight at a time.
 template <int B>
@@ -561,6 +601,50 @@ DEVFN void aggregate_wtile(const PgQueryPlan& p, uint32_t m, int wtile, int64_t*
         }
       }
       o = o_end;
+    }
+    // ---- auxiliary accumulators: DISTINCTCOUNT dictId sets / HyperLogLog registers (HBM regions) ---------------------------
+    for (int xa = 0; xa < p.n_aux; xa++) {
+      const PgAuxOp& A = p.aux[xa];
+      const PgValueSrc& S = p.srcs[A.src];
+#pragma unroll
+      for (int u = 0; u < B; u++) {
+        const uint32_t nib = (mb >> (4 * u)) & 0xFu;
+        if (nib) {
+          const uint32_t q = (uint32_t)((k0 + u) * 64 + lane);
+          int64_t v[4];   // dictId, or the long the value hashes as (Integer/Long value, Float raw int bits, Double raw long bits)
+          if (S.col_kind == PG_COL_FIXED_BIT) {
+            uint32_t r[8], d[4];
+            const GAS uint32_t* tw = packed_wtile_base(S.data, wtile, S.bits);
+            const uint32_t bits = (uint32_t)S.bits, mask = (1u << S.bits) - 1u;
+            if (bits <= 8) { load_packed_quad<true>(tw, q, bits, r); decode_packed_quad<true>(r, q, bits, mask, d); }
+            else { load_packed_quad<false>(tw, q, bits, r); decode_packed_quad<false>(r, q, bits, mask, d); }
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = (int64_t)d[i];
+          } else if (S.col_kind == PG_COL_RAW32) {
+            const u32x4 x = *gptr<u32x4>(S.data + (size_t)wtile * (PG_WAVE_DOCS * 4) + q * 16u);
+            v[0] = (int64_t)(int32_t)bswap32(x.x); v[1] = (int64_t)(int32_t)bswap32(x.y);
+            v[2] = (int64_t)(int32_t)bswap32(x.z); v[3] = (int64_t)(int32_t)bswap32(x.w);
+          } else {
+            const GAS u32x4* pp = gptr<u32x4>(S.data + (size_t)wtile * (PG_WAVE_DOCS * 8) + q * 32u);
+            const u32x4 a = pp[0], b = pp[1];
+            v[0] = (int64_t)(((uint64_t)bswap32(a.x) << 32) | bswap32(a.y)); v[1] = (int64_t)(((uint64_t)bswap32(a.z) << 32) | bswap32(a.w));
+            v[2] = (int64_t)(((uint64_t)bswap32(b.x) << 32) | bswap32(b.y)); v[3] = (int64_t)(((uint64_t)bswap32(b.z) << 32) | bswap32(b.w));
+          }
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            if ((nib >> i) & 1u) {
+              const size_t g = (size_t)(slot[u][i] >> p.replica_shift);
+              if (A.kind == PG_AUX_DICT_SET) {
+                set_add(A.base + g * (size_t)A.stride, (uint32_t)v[i]);
+              } else {
+                const uint32_t e = A.kind == PG_AUX_HLL_DICT ? gptr<uint32_t>(A.lut)[(uint32_t)v[i]]
+                                                              : hll_index_rank_dev(murmur_hash_long_dev(v[i]), A.log2m);
+                hll_update(reinterpret_cast<uint8_t*>(A.base) + g * (size_t)A.stride, e & 0xFFFFu, e >> 16);
+              }
+            }
+          }
+        }
+      }
     }
   }
 }

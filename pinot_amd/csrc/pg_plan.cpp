@@ -561,8 +561,83 @@ std::string query_signature(const pg_filter_node* filter, const pg_query* q) {
 // =====================================================================================================================
 // plan compilation
 // =====================================================================================================================
+// ---- HyperLogLog (stream-lib 2.9.8, not in the reference tree; algorithm restated from SURVEY.md §9) ---------------------
+// offer(o): x = MurmurHash.hash(o); j = x >>> (32 - log2m); r = numberOfLeadingZeros((x << log2m) | (1 << (log2m-1)) + 1) + 1
+// MurmurHash.hash(Integer / Long) = hashLong(value); Float → raw int bits (sign-extended); Double → raw long bits;
+// String / bytes → MurmurHash2 over the bytes with seed -1.
+static uint32_t murmur_hash_long(int64_t data) {
+  const uint32_t m = 0x5bd1e995u;
+  uint32_t h = 0;
+  uint32_t k = (uint32_t)(uint64_t)data * m;
+  k ^= k >> 24;
+  h ^= k * m;
+  k = (uint32_t)((uint64_t)data >> 32) * m;
+  k ^= k >> 24;
+  h *= m;
+  h ^= k * m;
+  h ^= h >> 13;
+  h *= m;
+  h ^= h >> 15;
+  return h;
+}
+static uint32_t murmur_hash_bytes(const uint8_t* data, int32_t length) {
+  const uint32_t m = 0x5bd1e995u;
+  uint32_t h = 0xFFFFFFFFu ^ (uint32_t)length;
+  const int len4 = length >> 2;
+  for (int i = 0; i < len4; i++) {
+    const int i4 = i << 2;
+    uint32_t k = (uint32_t)data[i4] | ((uint32_t)data[i4 + 1] << 8) | ((uint32_t)data[i4 + 2] << 16) | ((uint32_t)data[i4 + 3] << 24);
+    k *= m; k ^= k >> 24; k *= m;
+    h *= m; h ^= k;
+  }
+  const int left = length - (len4 << 2);
+  if (left != 0) {
+    if (left >= 3) h ^= (uint32_t)((int32_t)(int8_t)data[length - 3] << 16);
+    if (left >= 2) h ^= (uint32_t)((int32_t)(int8_t)data[length - 2] << 8);
+    if (left >= 1) h ^= (uint32_t)(int32_t)(int8_t)data[length - 1];
+    h *= m;
+  }
+  h ^= h >> 13;
+  h *= m;
+  h ^= h >> 15;
+  return h;
+}
+static uint32_t hll_index_rank(uint32_t x, int log2m) {   // register index | rank << 16
+  const uint32_t j = x >> (32 - log2m);
+  const uint32_t w = (x << log2m) | ((1u << (log2m - 1)) + 1u);
+  const uint32_t r = (uint32_t)__builtin_clz(w) + 1u;
+  return j | (r << 16);
+}
+// (index, rank) of every dictionary value: what DistinctCountHLLAggregationFunction.java:457-466 computes per dictId.
+static const uint32_t* hll_dict_lut(Column& c, int log2m) {
+  auto it = c.hll_luts.find(log2m);
+  if (it != c.hll_luts.end()) return it->second.as<uint32_t>();
+  std::vector<uint32_t> lut((size_t)c.cardinality);
+  const uint8_t* d = c.dict_host.data();
+  for (int32_t i = 0; i < c.cardinality; i++) {
+    uint32_t x;
+    switch (c.data_type) {
+      case PG_TYPE_INT: x = murmur_hash_long((int64_t)(int32_t)be32(d + (size_t)i * 4)); break;
+      case PG_TYPE_LONG: x = murmur_hash_long((int64_t)be64(d + (size_t)i * 8)); break;
+      case PG_TYPE_FLOAT: x = murmur_hash_long((int64_t)(int32_t)be32(d + (size_t)i * 4)); break;
+      case PG_TYPE_DOUBLE: x = murmur_hash_long((int64_t)be64(d + (size_t)i * 8)); break;
+      default: {
+        const uint8_t* e = d + (size_t)i * c.dict_bytes_per_value;
+        int len = c.dict_bytes_per_value;
+        while (len > 0 && e[len - 1] == 0) len--;
+        x = murmur_hash_bytes(e, len);
+        break;
+      }
+    }
+    lut[i] = hll_index_rank(x, log2m);
+  }
+  auto ins = c.hll_luts.emplace(log2m, upload_vector(lut));
+  return ins.first->second.as<uint32_t>();
+}
+
 static const int64_t kLdsTableBudget = 144 * 1024;      // bytes of LDS for the accumulator table (one workgroup per CU)
 static const int64_t kLdsReplicaBudget = 96 * 1024;
+static const size_t kMaxAuxBytes = (size_t)2 << 30;
 static const int64_t kMaxDenseGroups = 64LL << 20;      // dense HBM table limit (groups)
 
 std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* filter, const pg_query* q) {
@@ -682,8 +757,26 @@ std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* f
     if (s.function == PG_AGG_COUNT) { out.op_a = count_op; P.aggs.push_back(out); continue; }
     Column* c = seg.find(s.column);
     if (!c) fail(PG_ERR_NOT_FOUND, "column not found: %s", s.column ? s.column : "(null)");
-    if (s.function == PG_AGG_DISTINCTCOUNT || s.function == PG_AGG_DISTINCTCOUNTHLL)
-      fail(PG_ERR_UNSUPPORTED, "aggregation function %d is not on the GPU path yet", s.function);
+    if (s.function == PG_AGG_DISTINCTCOUNT || s.function == PG_AGG_DISTINCTCOUNTHLL) {
+      if (D.n_aux >= PG_MAX_AUX) fail(PG_ERR_UNSUPPORTED, "more than %d DISTINCTCOUNT / DISTINCTCOUNTHLL aggregations", PG_MAX_AUX);
+      const bool hll = s.function == PG_AGG_DISTINCTCOUNTHLL;
+      if (!hll && !c->has_dictionary) fail(PG_ERR_UNSUPPORTED, "DISTINCTCOUNT over a raw column is outside the hot path");
+      if (hll && !c->has_dictionary && c->data_type > PG_TYPE_DOUBLE) fail(PG_ERR_UNSUPPORTED, "DISTINCTCOUNTHLL over a raw %d column", c->data_type);
+      const int log2m = s.log2m > 0 ? s.log2m : 8;   // CommonConstants.Helix.DEFAULT_HYPERLOGLOG_LOG2M
+      if (hll && (log2m < 4 || log2m > 16)) fail(PG_ERR_UNSUPPORTED, "DISTINCTCOUNTHLL log2m %d (4..16 on the GPU path)", log2m);
+      project(c);
+      PgAuxOp& A = D.aux[D.n_aux];
+      A.src = src_index(c);
+      A.log2m = hll ? log2m : 0;
+      if (!hll) { A.kind = PG_AUX_DICT_SET; A.stride = (c->cardinality + 31) / 32; }
+      else if (c->has_dictionary) { A.kind = PG_AUX_HLL_DICT; A.stride = 1 << log2m; A.lut = hll_dict_lut(*c, log2m); }
+      else { A.kind = PG_AUX_HLL_RAW; A.stride = 1 << log2m; }
+      out.aux = D.n_aux++;
+      out.log2m = log2m;
+      out.aux_col = c;
+      P.aggs.push_back(out);
+      continue;
+    }
     if (c->data_type > PG_TYPE_DOUBLE) fail(PG_ERR_INVALID_ARGUMENT, "Cannot compute aggregation for non-numeric type: column %s", c->name.c_str());
     project(c);
     const int32_t si = src_index(c);
@@ -732,7 +825,7 @@ std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* f
   P.n_projected_columns = (int32_t)projected.size();
 
   const int64_t table_bytes = G * D.n_ops * 8;
-  if (D.n_ops == 0) {
+  if (D.n_ops == 0 && D.n_aux == 0) {
     D.agg_mode = PG_AGG_NONE;        // COUNT(*) only: nothing to accumulate beyond the match count
   } else if (q->n_group_by == 0) {
     D.agg_mode = PG_AGG_SINGLE;
@@ -746,9 +839,18 @@ std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* f
     D.agg_mode = PG_AGG_GLOBAL;
     D.replicas = 1;
   }
+  D.replica_shift = 0;
+  while ((1 << D.replica_shift) < D.replicas) D.replica_shift++;
   if (D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE) P.lds_bytes += (size_t)G * D.replicas * D.n_ops * 8;
+  // auxiliary regions (HBM): sizes per op, patched into the plan at execution
+  for (int x = 0; x < D.n_aux; x++) {
+    const size_t bytes = D.aux[x].kind == PG_AUX_DICT_SET ? (size_t)G * D.aux[x].stride * 4 : (size_t)G * D.aux[x].stride;
+    if (bytes > kMaxAuxBytes) fail(PG_ERR_UNSUPPORTED, "DISTINCTCOUNT state of %zu bytes exceeds the GPU path's limit", bytes);
+    P.aux_bytes.push_back((bytes + 255) & ~(size_t)255);
+  }
   // fast aggregation: LDS table, slots fit 16 bits, <= 8-bit group columns, 32-bit value sources
   P.fast_agg = D.agg_mode != PG_AGG_GLOBAL && (int64_t)G * D.replicas <= 65536;   // (trivially true without a table)
+  if (D.n_aux > 0) P.fast_agg = false;   // set / HLL accumulators run in the interpreter kernel
   for (Column* c : P.group_cols) if (c->bits > 8) P.fast_agg = false;
   for (Column* c : srcs)
     if (!(c->col_kind == PG_COL_RAW32 || (c->col_kind == PG_COL_FIXED_BIT && (c->val_type == PG_V_I32 || c->val_type == PG_V_F32))))

@@ -87,6 +87,38 @@ SV_QUERIES = [
 ]
 
 
+DISTINCT_QUERIES = [
+    "SELECT DISTINCTCOUNTHLL(column1), DISTINCTCOUNTHLL(column3) FROM testTable",
+    "SELECT DISTINCTCOUNTHLL(column1), DISTINCTCOUNTHLL(column3) FROM testTable" + SV_FILTER,
+    "SELECT DISTINCTCOUNT(column1), DISTINCTCOUNT(column3) FROM testTable",
+    "SELECT DISTINCTCOUNT(column1), DISTINCTCOUNT(column3), COUNT(*), SUM(column6) FROM testTable" + SV_FILTER,
+    "SELECT DISTINCTCOUNT(column11), DISTINCTCOUNTHLL(column12), DISTINCTCOUNTHLL(column5) FROM testTable GROUP BY column7",
+    "SELECT column11, DISTINCTCOUNT(column17), DISTINCTCOUNTHLL(column18), MAX(column1) FROM testTable WHERE column6 < 500000000 GROUP BY column11",
+    "SELECT DISTINCTCOUNTHLL(column1), COUNT(*) FROM testTable GROUP BY column9, column11",
+    "SELECT DISTINCTCOUNT(column9) FROM testTable WHERE column9 = -5",
+]
+
+
+def test_golden_distinct_counts(sv):
+    """InterSegmentAggregationSingleValueQueriesTest.java:261-274 (HLL) and the DISTINCTCOUNT goldens, on the GPU."""
+    from pinot_amd.executor import extract_final
+    g, _ = sv
+    b = g.execute(DISTINCT_QUERIES[0])
+    assert [extract_final("DISTINCTCOUNTHLL", v) for v in b.aggregation_result()] == [5977, 23825]
+    b = g.execute(DISTINCT_QUERIES[1])
+    assert [extract_final("DISTINCTCOUNTHLL", v) for v in b.aggregation_result()] == [1886, 4492]
+    b = g.execute(DISTINCT_QUERIES[2])
+    assert [extract_final("DISTINCTCOUNT", v) for v in b.aggregation_result()] == [6582, 21910]
+    b = g.execute("SELECT DISTINCTCOUNT(column1), DISTINCTCOUNT(column3) FROM testTable" + SV_FILTER)
+    assert [extract_final("DISTINCTCOUNT", v) for v in b.aggregation_result()] == [1872, 4556]
+
+
+@pytest.mark.parametrize("q", DISTINCT_QUERIES)
+def test_distinct_queries_match_oracle(sv, q):
+    g, o = sv
+    assert_same_block(g.execute(q), o.execute(q))
+
+
 @pytest.mark.parametrize("q", SV_QUERIES)
 def test_sv_queries_match_oracle(sv, q):
     g, o = sv
@@ -166,6 +198,9 @@ SYNTH_QUERIES = [
     "SELECT h1, h2, h3, h4, COUNT(*), SUM(m) FROM gpuBench WHERE g1 BETWEEN 10 AND 19 GROUP BY h1, h2, h3, h4",
     "SELECT g1, SUM(g2), MAX(u) FROM gpuBench WHERE u < 5000 GROUP BY g1",
     "SELECT COUNT(*) FROM gpuBench WHERE NOT (r_int BETWEEN 10 AND 999989) AND c_inv2 != 3",
+    "SELECT h1, h2, h3, h4, COUNT(*), DISTINCTCOUNTHLL(u) FROM gpuBench GROUP BY h1, h2, h3, h4",
+    "SELECT g1, DISTINCTCOUNT(g2), DISTINCTCOUNTHLL(m), DISTINCTCOUNTHLL(r_int) FROM gpuBench WHERE c_inv1 IN (1, 2) GROUP BY g1",
+    "SELECT DISTINCTCOUNT(u), DISTINCTCOUNTHLL(u), DISTINCTCOUNTHLL(m) FROM gpuBench WHERE r_int < 300000",
 ]
 
 
