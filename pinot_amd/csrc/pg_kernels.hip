@@ -39,6 +39,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef u32x2 u32x2_a4 __attribute__((aligned(4)));   // dword-aligned pair (bit-packed windows)
 
+// Column and posting bytes are streamed once per query: non-temporal loads (measured +5 points of HBM roofline on cfg 3).
+template <typename T> DEVFN T ldnt(const GAS T* p) { return __builtin_nontemporal_load(p); }
 DEVFN uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
 DEVFN int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
@@ -142,13 +144,13 @@ template <bool SMALL>
 DEVFN void load_packed_quad(const GAS uint32_t* __restrict__ tw, uint32_t q, uint32_t bits, uint32_t* r) {
   if (SMALL) {
     const uint32_t di = (4u * q * bits) >> 5;
-    const u32x2 v = *(const GAS u32x2_a4*)(tw + di);
+    const u32x2 v = ldnt((const GAS u32x2_a4*)(tw + di));
     r[0] = v.x; r[1] = v.y;
   } else {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const uint32_t di = ((4u * q + (uint32_t)i) * bits) >> 5;
-      const u32x2 v = *(const GAS u32x2_a4*)(tw + di);
+      const u32x2 v = ldnt((const GAS u32x2_a4*)(tw + di));
       r[2 * i] = v.x; r[2 * i + 1] = v.y;
     }
   }
@@ -178,11 +180,11 @@ DEVFN void load_quad(const LeafT& L, const GAS uint8_t* __restrict__ tb, uint32_
   if (sk_dict(KIND)) {
     load_packed_quad<sk_small(KIND)>((const GAS uint32_t*)tb, q, (uint32_t)L.bits, r);
   } else if (sk_raw32(KIND)) {
-    const u32x4 v = *(const GAS u32x4*)(tb + q * 16u);
+    const u32x4 v = ldnt((const GAS u32x4*)(tb + q * 16u));
     r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
   } else {
     const GAS u32x4* p = (const GAS u32x4*)(tb + q * 32u);
-    const u32x4 a = p[0], b = p[1];
+    const u32x4 a = ldnt(p), b = ldnt(p + 1);
     r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
   }
 }
@@ -296,7 +298,7 @@ DEVFN uint32_t postings_wtile(const LeafT& L, int wtile, uint32_t valid_lin, uin
     // unused pointers repeat dense[0] (OR is idempotent): 8 unconditional loads, no branches
     uint32_t v[PG_MAX_DENSE];
 #pragma unroll
-    for (int j = 0; j < PG_MAX_DENSE; j++) v[j] = gptr<uint32_t>(L.dense[j])[di];
+    for (int j = 0; j < PG_MAX_DENSE; j++) v[j] = ldnt(gptr<uint32_t>(L.dense[j]) + di);
 #pragma unroll
     for (int j = 0; j < PG_MAX_DENSE; j++) acc |= v[j];
   }
@@ -701,7 +703,7 @@ DEVFN void fast_aggregate_wtile(const PgQueryPlan& p, uint32_t mask_all, int wti
 #pragma unroll
       for (int k = 0; k < B; k++) {
         const uint32_t q = ((m >> (4 * k)) & 0xFu) ? (uint32_t)((k0 + k) * 64 + lane) : 0u;
-        const u32x4 v = *(const GAS u32x4*)(tb + q * 16u);
+        const u32x4 v = ldnt((const GAS u32x4*)(tb + q * 16u));
         x[k][0] = v.x; x[k][1] = v.y; x[k][2] = v.z; x[k][3] = v.w;
       }
     }
@@ -749,7 +751,7 @@ DEVFN void fast_aggregate_wtile(const PgQueryPlan& p, uint32_t mask_all, int wti
 #pragma unroll
             for (int k = 0; k < B; k++) {
               const uint32_t q = ((m >> (4 * k)) & 0xFu) ? (uint32_t)((k0 + k) * 64 + lane) : 0u;
-              const u32x4 v = *(const GAS u32x4*)(tb + q * 16u);
+              const u32x4 v = ldnt((const GAS u32x4*)(tb + q * 16u));
               x[k][0] = v.x; x[k][1] = v.y; x[k][2] = v.z; x[k][3] = v.w;
             }
           }

@@ -57,7 +57,9 @@ QUERY_CFG3 = ("SELECT g1, SUM(m), MAX(m) FROM gpuBench WHERE c_inv1 IN (0,1,2,3)
               "AND r_int BETWEEN 250000 AND 749999 GROUP BY g1 ORDER BY g1 LIMIT 1000")
 QUERY_NORTH_STAR = ("SELECT g1, g2, SUM(m) FROM gpuBench WHERE c_inv1 IN (0,1,2,3) AND c_inv2 IN (0,1) "
                     "AND r_int BETWEEN 250000 AND 749999 GROUP BY g1, g2 ORDER BY g1, g2 LIMIT 10000")
+QUERY_CFG5 = ("SELECT h1, h2, h3, h4, COUNT(*), DISTINCTCOUNTHLL(u) FROM gpuBench GROUP BY h1, h2, h3, h4 LIMIT 20000")
 CFG3_COLUMNS = ["c_inv1", "c_inv2", "r_int", "g1", "g2", "m"]
+CFG5_COLUMNS = ["h1", "h2", "h3", "h4", "u"]
 
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
 

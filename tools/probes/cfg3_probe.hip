@@ -50,6 +50,10 @@ struct Args {
 };
 
 // MODE bit0: masked loads of g1/m (else unconditional, issued with the filter loads); bit1: skip aggregation atomics
+#ifndef NT
+#define NT 0
+#endif
+template <class T> DEVFN T ldg(const T* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
 template <int BLOCK, int MODE>
 __global__ void __launch_bounds__(BLOCK) cfg3_kernel(const Args a) {
   __shared__ long long tab[2][100 * 32];
@@ -64,18 +68,18 @@ __global__ void __launch_bounds__(BLOCK) cfg3_kernel(const Args a) {
     // ---- issue loads
     uint32_t pw[6];
 #pragma unroll
-    for (int i = 0; i < 6; i++) pw[i] = a.post[i][wt * 64 + lane];
+    for (int i = 0; i < 6; i++) pw[i] = ldg(&a.post[i][wt * 64 + lane]);
     u32x4 rv[8];
     const u32x4* rp = a.r_int + wt * 512 + lane;
 #pragma unroll
-    for (int k = 0; k < 8; k++) rv[k] = rp[k * 64];
+    for (int k = 0; k < 8; k++) rv[k] = ldg(&rp[k * 64]);
     u32x4 mv[8];
     u32x2 gv[8];
     const u32x4* mp = a.m + wt * 512 + lane;
     const uint32_t* gp = a.g1 + wt * (2048 * 7 / 32);
     if (!(MODE & 1)) {
 #pragma unroll
-      for (int k = 0; k < 8; k++) mv[k] = mp[k * 64];
+      for (int k = 0; k < 8; k++) mv[k] = ldg(&mp[k * 64]);
 #pragma unroll
       for (int k = 0; k < 8; k++) gv[k] = *(const u32x2_a4*)(gp + ((4u * (k * 64 + lane) * 7u) >> 5));
     }
@@ -96,7 +100,7 @@ __global__ void __launch_bounds__(BLOCK) cfg3_kernel(const Args a) {
     matched += __popc(mm);
     if (MODE & 1) {
 #pragma unroll
-      for (int k = 0; k < 8; k++) { mv[k] = u32x4{0, 0, 0, 0}; if ((mm >> (4 * k)) & 0xF) mv[k] = mp[k * 64]; }
+      for (int k = 0; k < 8; k++) { mv[k] = u32x4{0, 0, 0, 0}; if ((mm >> (4 * k)) & 0xF) mv[k] = ldg(&mp[k * 64]); }
 #pragma unroll
       for (int k = 0; k < 8; k++) { gv[k] = u32x2{0, 0}; if ((mm >> (4 * k)) & 0xF) gv[k] = *(const u32x2_a4*)(gp + ((4u * (k * 64 + lane) * 7u) >> 5)); }
     }

@@ -20,6 +20,10 @@ QUERIES = {
     "cfg3": synth.QUERY_CFG3,
     "northstar": synth.QUERY_NORTH_STAR,
     "g1eq": "SELECT COUNT(*) FROM t WHERE g1 = 7",
+    "cfg5": synth.QUERY_CFG5,
+    "cfg5count": "SELECT h1, h2, h3, h4, COUNT(*) FROM gpuBench GROUP BY h1, h2, h3, h4 LIMIT 20000",
+    "hllonly": "SELECT DISTINCTCOUNTHLL(u) FROM gpuBench",
+    "hllg1": "SELECT g1, DISTINCTCOUNTHLL(u) FROM gpuBench GROUP BY g1",
 }
 ap = argparse.ArgumentParser()
 ap.add_argument("query")
@@ -29,7 +33,7 @@ args = ap.parse_args()
 api = capi.gpu_api()
 api.call("init", 0)
 seg = NativeSegment(api, HostSegment("prof", args.docs))
-for name in synth.CFG3_COLUMNS:
+for name in (synth.CFG5_COLUMNS + ["g1"] if args.query in ("cfg5", "cfg5count", "hllonly", "hllg1") else synth.CFG3_COLUMNS):
     one = synth.generate_segment(args.docs, columns=[name])
     seg.add_column(one.columns[name], keep_host_buffers=False)
 qc = parse_sql(QUERIES[args.query])
