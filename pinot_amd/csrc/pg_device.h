@@ -19,13 +19,15 @@
 #define PG_WAVE_QUADS 512
 #define PG_WTILES_PER_TILE 8
 #define PG_WTILES_PER_CHUNK 32
+#ifndef PG_WAVES_PER_BLOCK
 #define PG_WAVES_PER_BLOCK 16
+#endif
 #define PG_MAX_STACK 6
 #define PG_MAX_GROUP_COLS 8
 #define PG_MAX_SRCS 8
 #define PG_MAX_OPS 16
 #define PG_MAX_STATS 16
-#define PG_BLOCK 1024             // one 16-wave workgroup per CU: every wave shares one LDS accumulator table
+#define PG_BLOCK (PG_WAVES_PER_BLOCK * 64)   // one 16-wave workgroup per CU: every wave shares one LDS accumulator table
 
 // ---- filter program --------------------------------------------------------------------------------------------------
 enum PgFOp : int32_t {

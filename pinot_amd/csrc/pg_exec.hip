@@ -15,7 +15,7 @@ extern "C" __global__ void pg_segment_query_kernel(const PgQueryPlan p);
 PG_DECL_FAST(pg_fast_none_f) PG_DECL_FAST(pg_fast_none_a) PG_DECL_FAST(pg_fast_i32range_f) PG_DECL_FAST(pg_fast_i32range_a)
 PG_DECL_FAST(pg_fast_dictrange_f) PG_DECL_FAST(pg_fast_dictrange_a) PG_DECL_FAST(pg_fast_dictlut_f) PG_DECL_FAST(pg_fast_dictlut_a)
 extern "C" __global__ void pg_reduce_partials_kernel(const int64_t* partials, int64_t* out, int n_wg, int n_ops,
-                                                     int n_groups, const PgAccOp* ops);
+                                                     int n_groups, const PgAccOp* ops, unsigned long long* stats, int reduce);
 extern "C" __global__ void pg_fill_i64_kernel(int64_t* dst, int64_t n_per_op, int n_ops, const PgAccOp* ops);
 extern "C" __global__ void pg_expand_docids_kernel(const uint64_t* words, const int64_t* tile_offsets, int32_t* out,
                                                    int n_tiles);
@@ -98,7 +98,21 @@ struct ThreadCtx {
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   DeviceBuffer stats, partials, final_table, tile_counts, aux;
+  bool stats_dirty = true;      // the stats counters may be non-zero (first use, or a query that failed midway)
+  void* pinned = nullptr;       // page-locked staging for the result copy (pageable copies are staged synchronously)
+  size_t pinned_size = 0;
+  void* pin(size_t n) {
+    if (pinned_size < n) {
+      if (pinned) (void)hipHostFree(pinned);
+      pinned = nullptr;
+      pinned_size = 0;
+      PG_HIP(hipHostMalloc(&pinned, n + n / 4 + 4096, hipHostMallocDefault));
+      pinned_size = n + n / 4 + 4096;
+    }
+    return pinned;
+  }
   ~ThreadCtx() {
+    if (pinned) (void)hipHostFree(pinned);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -172,9 +186,13 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   PgQueryPlan D = P.dev;
   const LaunchShape shape = launch_shape(P, P.dev.n_wtiles);
   const int64_t n_out = (int64_t)D.n_ops * D.n_groups;
-  PG_HIP(hipMemsetAsync(ctx.stats.ptr, 0, PG_MAX_STATS * 8, ctx.stream));
+  // The stats counters are zero on entry: the reduce kernel of the previous query on this stream re-zeroes them after
+  // moving them behind the result table (one device→host copy per query).
+  if (ctx.stats_dirty) PG_HIP(hipMemsetAsync(ctx.stats.ptr, 0, PG_MAX_STATS * 8, ctx.stream));
+  ctx.stats_dirty = true;
   D.stats = ctx.stats.as<unsigned long long>();
-  ThreadCtx::grow(ctx.final_table, (size_t)n_out * 8 + 8);
+  const size_t out_bytes = ((size_t)n_out + PG_MAX_STATS) * 8;
+  ThreadCtx::grow(ctx.final_table, out_bytes);
   if (D.agg_mode == PG_AGG_GLOBAL) {
     D.partials = ctx.final_table.as<int64_t>();
     int blocks = (int)((n_out + 255) / 256);
@@ -193,6 +211,8 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
     size_t off = 0;
     for (int x = 0; x < D.n_aux; x++) { D.aux[x].base = reinterpret_cast<uint32_t*>(ctx.aux.as<uint8_t>() + off); off += P.aux_bytes[x]; }
   }
+  int64_t* host_out = static_cast<int64_t*>(ctx.pin(out_bytes + aux_total));
+  uint8_t* aux_host = reinterpret_cast<uint8_t*>(host_out) + out_bytes;
   if (profile) PG_HIP(hipEventRecord(ctx.ev[0], ctx.stream));
   const char* kname = "";
   if (seg.total_docs > 0) {
@@ -202,26 +222,28 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   }
   if (profile) PG_HIP(hipEventRecord(ctx.ev[1], ctx.stream));
   std::vector<int64_t> table((size_t)n_out);
+  uint64_t stats_host[PG_MAX_STATS] = {0};
   if (seg.total_docs > 0) {
-    if (D.agg_mode != PG_AGG_GLOBAL && n_out > 0) {
-      int blocks = (int)((n_out + 3) / 4);   // one wavefront per output slot
-      hipLaunchKernelGGL(pg_reduce_partials_kernel, dim3(blocks), dim3(256), 0, ctx.stream, ctx.partials.as<int64_t>(),
-                         ctx.final_table.as<int64_t>(), shape.grid, D.n_ops, D.n_groups, P.ops_dev.as<PgAccOp>());
-      PG_HIP(hipGetLastError());
-    }
+    const int reduce = (D.agg_mode != PG_AGG_GLOBAL && n_out > 0) ? 1 : 0;
+    const int blocks = (reduce ? (int)((n_out + 3) / 4) : 0) + 1;   // one wavefront per output slot + the stats block
+    hipLaunchKernelGGL(pg_reduce_partials_kernel, dim3(blocks), dim3(256), 0, ctx.stream, ctx.partials.as<int64_t>(),
+                       ctx.final_table.as<int64_t>(), shape.grid, D.n_ops, D.n_groups, P.ops_dev.as<PgAccOp>(),
+                       ctx.stats.as<unsigned long long>(), reduce);
+    PG_HIP(hipGetLastError());
     if (profile) PG_HIP(hipEventRecord(ctx.ev[2], ctx.stream));
-    if (n_out > 0) PG_HIP(hipMemcpyAsync(table.data(), ctx.final_table.ptr, (size_t)n_out * 8, hipMemcpyDeviceToHost, ctx.stream));
+    PG_HIP(hipMemcpyAsync(host_out, ctx.final_table.ptr, out_bytes, hipMemcpyDeviceToHost, ctx.stream));
+    if (aux_total) PG_HIP(hipMemcpyAsync(aux_host, ctx.aux.ptr, aux_total, hipMemcpyDeviceToHost, ctx.stream));
+    PG_HIP(hipStreamSynchronize(ctx.stream));
+    if (n_out) memcpy(table.data(), host_out, (size_t)n_out * 8);
+    memcpy(stats_host, host_out + n_out, sizeof(stats_host));
+    ctx.stats_dirty = false;    // the reduce kernel left them zero
   } else {
     if (profile) PG_HIP(hipEventRecord(ctx.ev[2], ctx.stream));
+    PG_HIP(hipStreamSynchronize(ctx.stream));
     for (int o = 0; o < D.n_ops; o++)
       for (int64_t g = 0; g < D.n_groups; g++) table[(size_t)(o * (int64_t)D.n_groups + g)] = pg_acc_identity(D.ops[o].fn, D.ops[o].is_float);
+    if (aux_total) memset(aux_host, 0, aux_total);
   }
-  uint64_t stats_host[PG_MAX_STATS];
-  PG_HIP(hipMemcpyAsync(stats_host, ctx.stats.ptr, sizeof(stats_host), hipMemcpyDeviceToHost, ctx.stream));
-  std::vector<uint8_t> aux_host(aux_total);
-  if (aux_total && seg.total_docs > 0)
-    PG_HIP(hipMemcpyAsync(aux_host.data(), ctx.aux.ptr, aux_total, hipMemcpyDeviceToHost, ctx.stream));
-  PG_HIP(hipStreamSynchronize(ctx.stream));
 
   auto res = std::make_unique<Result>();
   fill_stats(res->stats, P, seg, stats_host);
@@ -288,7 +310,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
       if (A.kind == PG_AUX_DICT_SET) {
         r.kind = PG_RESULT_DICTID_SET;
         r.set_sizes.assign((size_t)ng, 0);
-        const uint32_t* words = reinterpret_cast<const uint32_t*>(aux_host.data() + off);
+        const uint32_t* words = reinterpret_cast<const uint32_t*>(aux_host + off);
         for (int32_t i = 0; i < ng; i++) {
           const uint32_t* w = words + (size_t)gids[i] * A.stride;
           for (int32_t k = 0; k < A.stride; k++) {
@@ -306,7 +328,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
         r.log2m = ao.log2m;
         r.hll.resize((size_t)ng * A.stride);
         for (int32_t i = 0; i < ng; i++)
-          memcpy(r.hll.data() + (size_t)i * A.stride, aux_host.data() + off + (size_t)gids[i] * A.stride, (size_t)A.stride);
+          memcpy(r.hll.data() + (size_t)i * A.stride, aux_host + off + (size_t)gids[i] * A.stride, (size_t)A.stride);
       }
       continue;
     }
@@ -348,6 +370,7 @@ std::unique_ptr<DocIdSet> execute_filter(Segment& seg, const pg_filter_node* fil
   ThreadCtx::grow(ctx.tile_counts, out->tile_counts.size() * 4);
   PG_HIP(hipMemsetAsync(ctx.tile_counts.ptr, 0, out->tile_counts.size() * 4, ctx.stream));
   PG_HIP(hipMemsetAsync(ctx.stats.ptr, 0, PG_MAX_STATS * 8, ctx.stream));
+  ctx.stats_dirty = true;
   PgQueryPlan D = P.dev;
   D.stats = ctx.stats.as<unsigned long long>();
   D.out_words = out->words.as<uint64_t>();

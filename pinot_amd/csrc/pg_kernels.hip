@@ -1032,13 +1032,25 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_segment_query_kernel(c
 }
 
 // Combines the per-workgroup partial tables: out[op][g].  One wavefront per output slot, lanes stride over the
-// workgroups, fixed butterfly order (deterministic also for floating sums).
+// workgroups, fixed butterfly order (deterministic also for floating sums).  The last block also moves the statistics
+// counters behind the table (out[n_out .. n_out+PG_MAX_STATS)) and re-zeroes them for the next query on this stream, so
+// that one device→host copy returns everything.
 extern "C" __global__ void __launch_bounds__(256) pg_reduce_partials_kernel(const int64_t* __restrict__ partials,
                                                                              int64_t* __restrict__ out, int n_wg,
                                                                              int n_ops, int n_groups,
-                                                                             const PgAccOp* __restrict__ ops) {
+                                                                             const PgAccOp* __restrict__ ops,
+                                                                             unsigned long long* __restrict__ stats,
+                                                                             int reduce) {
   const int64_t n_out = (int64_t)n_ops * n_groups;
   const int lane = threadIdx.x & 63;
+  if (blockIdx.x == gridDim.x - 1) {
+    if (threadIdx.x < PG_MAX_STATS) {
+      out[n_out + threadIdx.x] = (int64_t)stats[threadIdx.x];
+      stats[threadIdx.x] = 0;
+    }
+    return;
+  }
+  if (!reduce) return;
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_out) return;
   const PgAccOp op = ops[i / n_groups];
