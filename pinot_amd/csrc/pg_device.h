@@ -27,6 +27,7 @@
 #define PG_MAX_SRCS 8
 #define PG_MAX_OPS 16
 #define PG_MAX_STATS 16
+#define PG_GENERIC_BLOCK 512      // interpreter kernel workgroup
 #define PG_BLOCK (PG_WAVES_PER_BLOCK * 64)   // one 16-wave workgroup per CU: every wave shares one LDS accumulator table
 
 // ---- filter program --------------------------------------------------------------------------------------------------

@@ -77,11 +77,16 @@ void device_init(int ordinal) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
 }
 
+static bool uses_fast_kernel(const CompiledPlan& P, int agg_mode) {
+  const bool agg = agg_mode != PG_AGG_NONE;
+  return P.fast_filter != -2 && (!agg || (P.fast_agg && agg_mode != PG_AGG_GLOBAL));
+}
+
 // Kernel selection: the specialised fast kernels when both the filter and the aggregation have the fast shape.
 typedef void (*QueryKernel)(const PgQueryPlan);
 static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char** name) {
   const bool agg = agg_mode != PG_AGG_NONE;
-  if (P.fast_filter != -2 && (!agg || (P.fast_agg && agg_mode != PG_AGG_GLOBAL))) {
+  if (uses_fast_kernel(P, agg_mode)) {
     switch (P.fast_filter) {
       case -1: *name = agg ? "pg_fast_none_a" : "pg_fast_none_f"; return agg ? pg_fast_none_a : pg_fast_none_f;
       case 4: *name = agg ? "pg_fast_i32range_a" : "pg_fast_i32range_f"; return agg ? pg_fast_i32range_a : pg_fast_i32range_f;
@@ -147,12 +152,19 @@ static std::shared_ptr<CompiledPlan> get_plan(Segment& seg, const pg_filter_node
   return plan;
 }
 
-struct LaunchShape { int grid; size_t lds; };
-static LaunchShape launch_shape(const CompiledPlan& P, int n_wtiles) {
-  // one 16-wave workgroup per CU; fewer when the segment has fewer wave tiles than that
+struct LaunchShape { int grid; int block; size_t lds; };
+static LaunchShape launch_shape(const CompiledPlan& P, int n_wtiles, int agg_mode) {
   size_t lds = P.lds_bytes + 64;
-  int grid = std::min((n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, g_num_cus);
-  return {std::max(grid, 1), lds};
+  if (uses_fast_kernel(P, agg_mode)) {
+    // one 16-wave workgroup per CU; fewer when the segment has fewer wave tiles than that
+    int grid = std::min((n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, g_num_cus);
+    return {std::max(grid, 1), PG_BLOCK, lds};
+  }
+  // interpreter kernel: 8-wave workgroups, two per CU when both LDS tables fit
+  const int waves = PG_GENERIC_BLOCK / 64;
+  const int per_cu = (2 * (lds + 4096) <= g_lds_per_cu) ? 2 : 1;
+  int grid = std::min((n_wtiles + waves - 1) / waves, g_num_cus * per_cu);
+  return {std::max(grid, 1), PG_GENERIC_BLOCK, lds};
 }
 
 static void fill_stats(pg_exec_stats& st, const CompiledPlan& P, const Segment& seg, const uint64_t* stats_host) {
@@ -184,7 +196,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   const bool profile = (q.flags & PG_QUERY_FLAG_PROFILE) != 0;
 
   PgQueryPlan D = P.dev;
-  const LaunchShape shape = launch_shape(P, P.dev.n_wtiles);
+  const LaunchShape shape = launch_shape(P, P.dev.n_wtiles, D.agg_mode);
   const int64_t n_out = (int64_t)D.n_ops * D.n_groups;
   // The stats counters are zero on entry: the reduce kernel of the previous query on this stream re-zeroes them after
   // moving them behind the result table (one device→host copy per query).
@@ -217,7 +229,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   const char* kname = "";
   if (seg.total_docs > 0) {
     QueryKernel kern = select_kernel(P, D.agg_mode, &kname);
-    hipLaunchKernelGGL(kern, dim3(shape.grid), dim3(PG_BLOCK), shape.lds, ctx.stream, D);
+    hipLaunchKernelGGL(kern, dim3(shape.grid), dim3(shape.block), shape.lds, ctx.stream, D);
     PG_HIP(hipGetLastError());
   }
   if (profile) PG_HIP(hipEventRecord(ctx.ev[1], ctx.stream));
@@ -376,12 +388,12 @@ std::unique_ptr<DocIdSet> execute_filter(Segment& seg, const pg_filter_node* fil
   D.out_words = out->words.as<uint64_t>();
   D.out_tile_counts = ctx.tile_counts.as<uint32_t>();
   D.agg_mode = PG_AGG_NONE;
-  const LaunchShape shape = launch_shape(P, P.dev.n_wtiles);
+  const LaunchShape shape = launch_shape(P, P.dev.n_wtiles, PG_AGG_NONE);
   PG_HIP(hipEventRecord(ctx.ev[0], ctx.stream));
   const char* kname = "";
   if (seg.total_docs > 0) {
     QueryKernel kern = select_kernel(P, PG_AGG_NONE, &kname);
-    hipLaunchKernelGGL(kern, dim3(shape.grid), dim3(PG_BLOCK), shape.lds, ctx.stream, D);
+    hipLaunchKernelGGL(kern, dim3(shape.grid), dim3(shape.block), shape.lds, ctx.stream, D);
     PG_HIP(hipGetLastError());
   }
   PG_HIP(hipEventRecord(ctx.ev[1], ctx.stream));

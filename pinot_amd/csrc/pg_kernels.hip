@@ -915,13 +915,14 @@ struct MaskStack {
 };
 
 // =====================================================================================================================
-// The segment query kernel: one persistent 16-wave workgroup per CU; wave tile = (wg*16 + wave) + k * gridDim*16.
+// The interpreter kernel (any supported plan): same wave-tile model, runtime dispatch.  512-thread workgroups so that the
+// compiler has 256 VGPRs per lane (no spills); two workgroups per CU when the LDS table allows.
 // dynamic LDS: the accumulator table (LDS / SINGLE modes)
 // =====================================================================================================================
-extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_segment_query_kernel(const PgQueryPlan p) {
+extern "C" __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_segment_query_kernel(const PgQueryPlan p) {
   extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
   __shared__ uint32_t s_stat[PG_MAX_STATS];
-  __shared__ uint32_t s_wscratch[PG_WAVES_PER_BLOCK][64];
+  __shared__ uint32_t s_wscratch[PG_GENERIC_BLOCK / 64][64];
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = uniform(t >> 6);
@@ -933,15 +934,15 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_segment_query_kernel(c
   if (lds_agg) {
     for (int o = 0; o < p.n_ops; o++) {
       const int64_t ident = pg_acc_identity(p.ops[o].fn, p.ops[o].is_float);
-      for (uint32_t i = t; i < table_slots; i += PG_BLOCK) lds_table[(size_t)o * table_slots + i] = ident;
+      for (uint32_t i = t; i < table_slots; i += PG_GENERIC_BLOCK) lds_table[(size_t)o * table_slots + i] = ident;
     }
   }
   __syncthreads();
 
   const uint32_t rep = (uint32_t)t & ((uint32_t)p.replicas - 1u);
   uint32_t my_matched = 0;
-  const int wstride = (int)gridDim.x * PG_WAVES_PER_BLOCK;
-  for (int wt = (int)blockIdx.x * PG_WAVES_PER_BLOCK + wave; wt < p.n_wtiles; wt += wstride) {
+  const int wstride = (int)gridDim.x * (PG_GENERIC_BLOCK / 64);
+  for (int wt = (int)blockIdx.x * (PG_GENERIC_BLOCK / 64) + wave; wt < p.n_wtiles; wt += wstride) {
     const int64_t wbase = (int64_t)wt * PG_WAVE_DOCS;
     const int64_t rem = (int64_t)p.num_docs - wbase;
     const int32_t n_valid = rem >= PG_WAVE_DOCS ? PG_WAVE_DOCS : (int32_t)rem;
@@ -1010,7 +1011,7 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_segment_query_kernel(c
     const int R = p.replicas;
     const int64_t n_out = (int64_t)p.n_ops * p.n_groups;
     int64_t* out = p.partials + (int64_t)blockIdx.x * n_out;
-    for (int64_t i = t; i < n_out; i += PG_BLOCK) {
+    for (int64_t i = t; i < n_out; i += PG_GENERIC_BLOCK) {
       const int o = (int)(i / p.n_groups);
       const PgAccOp op = p.ops[o];
       const int64_t* src = lds_table + i * R;   // (o * G + g) * R
