@@ -148,6 +148,9 @@ struct PgAuxOp {
   int32_t src;          // index into srcs (column read for the op)
   int32_t stride;       // DICT_SET: words per group; HLL: registers (bytes) per group = 1 << log2m
   int32_t log2m;
+  int32_t n_rep;        // replicas of the region (power of two): workgroup b updates replica b & (n_rep-1); small states
+  int32_t pad;          //   (few groups) would otherwise funnel every update of the chip into a handful of L2 lines
+  int64_t rep_bytes;    // bytes of one replica
   uint32_t* base;       // region of this op (patched per execution)
   const uint32_t* lut;  // HLL_DICT: per dictId (register index | rank << 16)
 };

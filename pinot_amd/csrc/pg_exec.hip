@@ -319,6 +319,13 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
       size_t off = 0;
       for (int x = 0; x < ao.aux; x++) off += P.aux_bytes[x];
       const PgAuxOp& A = D.aux[ao.aux];
+      // merge the replicas into replica 0 (set union / register max)
+      for (int rr = 1; rr < A.n_rep; rr++) {
+        uint8_t* dst = aux_host + off;
+        const uint8_t* src = aux_host + off + (size_t)rr * (size_t)A.rep_bytes;
+        if (A.kind == PG_AUX_DICT_SET) for (int64_t b = 0; b < A.rep_bytes; b++) dst[b] |= src[b];
+        else for (int64_t b = 0; b < A.rep_bytes; b++) dst[b] = src[b] > dst[b] ? src[b] : dst[b];
+      }
       if (A.kind == PG_AUX_DICT_SET) {
         r.kind = PG_RESULT_DICTID_SET;
         r.set_sizes.assign((size_t)ng, 0);

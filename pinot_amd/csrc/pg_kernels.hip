@@ -605,42 +605,105 @@ DEVFN void aggregate_wtile(const PgQueryPlan& p, uint32_t m, int wtile, int64_t*
       o = o_end;
     }
     // ---- auxiliary accumulators: DISTINCTCOUNT dictId sets / HyperLogLog registers (HBM regions) ---------------------------
+    // Dictionary sources run in three batched stages over the 4·B docs of the lane — dictIds, (index, rank) look-ups,
+    // current state words — so that 4·B gathers are in flight per lane; only docs that would change the state go on to
+    // the atomic.  Lanes / docs outside the mask use clamped (valid) addresses and are masked at the atomic.
     for (int xa = 0; xa < p.n_aux; xa++) {
-      const PgAuxOp& A = p.aux[xa];
+      PgAuxOp A = p.aux[xa];
+      A.base = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(A.base) + (size_t)(blockIdx.x & (uint32_t)(A.n_rep - 1)) * (size_t)A.rep_bytes);
       const PgValueSrc& S = p.srcs[A.src];
+      if (S.col_kind == PG_COL_FIXED_BIT) {
+        const GAS uint32_t* tw = packed_wtile_base(S.data, wtile, S.bits);
+        const uint32_t bits = (uint32_t)S.bits, mask = (1u << S.bits) - 1u;
+        uint32_t d[B][4];
+        if (bits <= 8) {
+          uint32_t r[B][2];
 #pragma unroll
-      for (int u = 0; u < B; u++) {
-        const uint32_t nib = (mb >> (4 * u)) & 0xFu;
-        if (nib) {
-          const uint32_t q = (uint32_t)((k0 + u) * 64 + lane);
-          int64_t v[4];   // dictId, or the long the value hashes as (Integer/Long value, Float raw int bits, Double raw long bits)
-          if (S.col_kind == PG_COL_FIXED_BIT) {
-            uint32_t r[8], d[4];
-            const GAS uint32_t* tw = packed_wtile_base(S.data, wtile, S.bits);
-            const uint32_t bits = (uint32_t)S.bits, mask = (1u << S.bits) - 1u;
-            if (bits <= 8) { load_packed_quad<true>(tw, q, bits, r); decode_packed_quad<true>(r, q, bits, mask, d); }
-            else { load_packed_quad<false>(tw, q, bits, r); decode_packed_quad<false>(r, q, bits, mask, d); }
+          for (int u = 0; u < B; u++) load_packed_quad<true>(tw, ((mb >> (4 * u)) & 0xFu) ? (uint32_t)((k0 + u) * 64 + lane) : 0u, bits, r[u]);
 #pragma unroll
-            for (int i = 0; i < 4; i++) v[i] = (int64_t)d[i];
-          } else if (S.col_kind == PG_COL_RAW32) {
-            const u32x4 x = *gptr<u32x4>(S.data + (size_t)wtile * (PG_WAVE_DOCS * 4) + q * 16u);
-            v[0] = (int64_t)(int32_t)bswap32(x.x); v[1] = (int64_t)(int32_t)bswap32(x.y);
-            v[2] = (int64_t)(int32_t)bswap32(x.z); v[3] = (int64_t)(int32_t)bswap32(x.w);
-          } else {
-            const GAS u32x4* pp = gptr<u32x4>(S.data + (size_t)wtile * (PG_WAVE_DOCS * 8) + q * 32u);
-            const u32x4 a = pp[0], b = pp[1];
-            v[0] = (int64_t)(((uint64_t)bswap32(a.x) << 32) | bswap32(a.y)); v[1] = (int64_t)(((uint64_t)bswap32(a.z) << 32) | bswap32(a.w));
-            v[2] = (int64_t)(((uint64_t)bswap32(b.x) << 32) | bswap32(b.y)); v[3] = (int64_t)(((uint64_t)bswap32(b.z) << 32) | bswap32(b.w));
-          }
+          for (int u = 0; u < B; u++) decode_packed_quad<true>(r[u], ((mb >> (4 * u)) & 0xFu) ? (uint32_t)((k0 + u) * 64 + lane) : 0u, bits, mask, d[u]);
+        } else {
+          uint32_t r[B][8];
+#pragma unroll
+          for (int u = 0; u < B; u++) load_packed_quad<false>(tw, ((mb >> (4 * u)) & 0xFu) ? (uint32_t)((k0 + u) * 64 + lane) : 0u, bits, r[u]);
+#pragma unroll
+          for (int u = 0; u < B; u++) decode_packed_quad<false>(r[u], ((mb >> (4 * u)) & 0xFu) ? (uint32_t)((k0 + u) * 64 + lane) : 0u, bits, mask, d[u]);
+        }
+        uint32_t* wp[B][4];
+        uint32_t want[B][4];   // DICT_SET: the bit; HLL: rank << shift-in-word, with the shift in the low 5 bits of `sh`
+        uint32_t sh[B][4];
+        if (A.kind == PG_AUX_DICT_SET) {
+#pragma unroll
+          for (int u = 0; u < B; u++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              const size_t g = (size_t)(slot[u][i] >> p.replica_shift);
+              wp[u][i] = A.base + g * (size_t)A.stride + (d[u][i] >> 5);
+              want[u][i] = 1u << (d[u][i] & 31u);
+              sh[u][i] = 0;
+            }
+        } else {
+          uint32_t e[B][4];
+#pragma unroll
+          for (int u = 0; u < B; u++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) e[u][i] = gptr<uint32_t>(A.lut)[d[u][i]];
+#pragma unroll
+          for (int u = 0; u < B; u++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              const size_t g = (size_t)(slot[u][i] >> p.replica_shift);
+              const uint32_t idx = e[u][i] & 0xFFFFu;
+              wp[u][i] = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(A.base) + g * (size_t)A.stride + (idx & ~3u));
+              sh[u][i] = (idx & 3u) * 8u;
+              want[u][i] = e[u][i] >> 16;
+            }
+        }
+        uint32_t cur[B][4];
+#pragma unroll
+        for (int u = 0; u < B; u++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) cur[u][i] = __hip_atomic_load(wp[u][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int u = 0; u < B; u++)
 #pragma unroll
           for (int i = 0; i < 4; i++) {
-            if ((nib >> i) & 1u) {
-              const size_t g = (size_t)(slot[u][i] >> p.replica_shift);
+            if ((mb >> (4 * u + i)) & 1u) {
               if (A.kind == PG_AUX_DICT_SET) {
-                set_add(A.base + g * (size_t)A.stride, (uint32_t)v[i]);
+                if (!(cur[u][i] & want[u][i])) atomicOr(wp[u][i], want[u][i]);
               } else {
-                const uint32_t e = A.kind == PG_AUX_HLL_DICT ? gptr<uint32_t>(A.lut)[(uint32_t)v[i]]
-                                                              : hll_index_rank_dev(murmur_hash_long_dev(v[i]), A.log2m);
+                uint32_t c = cur[u][i];
+                while (((c >> sh[u][i]) & 0xFFu) < want[u][i]) {
+                  const uint32_t nv = (c & ~(0xFFu << sh[u][i])) | (want[u][i] << sh[u][i]);
+                  const uint32_t prev = atomicCAS(wp[u][i], c, nv);
+                  if (prev == c) break;
+                  c = prev;
+                }
+              }
+            }
+          }
+      } else {   // raw column: DISTINCTCOUNTHLL hashes the value on the fly
+#pragma unroll
+        for (int u = 0; u < B; u++) {
+          const uint32_t nib = (mb >> (4 * u)) & 0xFu;
+          if (nib) {
+            const uint32_t q = (uint32_t)((k0 + u) * 64 + lane);
+            int64_t v[4];   // the long the value hashes as (Integer/Long value, Float raw int bits, Double raw long bits)
+            if (S.col_kind == PG_COL_RAW32) {
+              const u32x4 x = *gptr<u32x4>(S.data + (size_t)wtile * (PG_WAVE_DOCS * 4) + q * 16u);
+              v[0] = (int64_t)(int32_t)bswap32(x.x); v[1] = (int64_t)(int32_t)bswap32(x.y);
+              v[2] = (int64_t)(int32_t)bswap32(x.z); v[3] = (int64_t)(int32_t)bswap32(x.w);
+            } else {
+              const GAS u32x4* pp = gptr<u32x4>(S.data + (size_t)wtile * (PG_WAVE_DOCS * 8) + q * 32u);
+              const u32x4 a = pp[0], b = pp[1];
+              v[0] = (int64_t)(((uint64_t)bswap32(a.x) << 32) | bswap32(a.y)); v[1] = (int64_t)(((uint64_t)bswap32(a.z) << 32) | bswap32(a.w));
+              v[2] = (int64_t)(((uint64_t)bswap32(b.x) << 32) | bswap32(b.y)); v[3] = (int64_t)(((uint64_t)bswap32(b.z) << 32) | bswap32(b.w));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              if ((nib >> i) & 1u) {
+                const size_t g = (size_t)(slot[u][i] >> p.replica_shift);
+                const uint32_t e = hll_index_rank_dev(murmur_hash_long_dev(v[i]), A.log2m);
                 hll_update(reinterpret_cast<uint8_t*>(A.base) + g * (size_t)A.stride, e & 0xFFFFu, e >> 16);
               }
             }

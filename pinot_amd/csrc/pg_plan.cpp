@@ -844,9 +844,14 @@ std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* f
   if (D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE) P.lds_bytes += (size_t)G * D.replicas * D.n_ops * 8;
   // auxiliary regions (HBM): sizes per op, patched into the plan at execution
   for (int x = 0; x < D.n_aux; x++) {
-    const size_t bytes = D.aux[x].kind == PG_AUX_DICT_SET ? (size_t)G * D.aux[x].stride * 4 : (size_t)G * D.aux[x].stride;
+    size_t bytes = D.aux[x].kind == PG_AUX_DICT_SET ? (size_t)G * D.aux[x].stride * 4 : (size_t)G * D.aux[x].stride;
     if (bytes > kMaxAuxBytes) fail(PG_ERR_UNSUPPORTED, "DISTINCTCOUNT state of %zu bytes exceeds the GPU path's limit", bytes);
-    P.aux_bytes.push_back((bytes + 255) & ~(size_t)255);
+    bytes = (bytes + 255) & ~(size_t)255;
+    int n_rep = 1;   // replicate small states (up to 256 KB in total, at most one replica per workgroup)
+    while (n_rep < 512 && bytes * (size_t)(n_rep * 2) <= ((size_t)256 << 10)) n_rep *= 2;
+    D.aux[x].n_rep = n_rep;
+    D.aux[x].rep_bytes = (int64_t)bytes;
+    P.aux_bytes.push_back(bytes * (size_t)n_rep);
   }
   // fast aggregation: LDS table, slots fit 16 bits, <= 8-bit group columns, 32-bit value sources
   P.fast_agg = D.agg_mode != PG_AGG_GLOBAL && (int64_t)G * D.replicas <= 65536;   // (trivially true without a table)
