@@ -14,11 +14,12 @@ from pinot_amd.segment import HostSegment
 ap = argparse.ArgumentParser()
 ap.add_argument("--docs", type=int, default=200_000_000)
 ap.add_argument("--reps", type=int, default=10)
+ap.add_argument("--set", choices=["cfg3", "cfg5"], default="cfg3")
 args = ap.parse_args()
 api = capi.gpu_api()
 api.call("init", 0)
 seg = NativeSegment(api, HostSegment("prof", args.docs))
-for name in synth.CFG3_COLUMNS:
+for name in (synth.CFG3_COLUMNS if args.set == "cfg3" else synth.CFG5_COLUMNS):
     one = synth.generate_segment(args.docs, columns=[name])
     seg.add_column(one.columns[name], keep_host_buffers=False)
 
@@ -32,6 +33,16 @@ QUERIES = {
     "northstar": (synth.QUERY_NORTH_STAR, 10.375),
     "g1 scan eq": ("SELECT COUNT(*) FROM t WHERE g1 = 7", 0.875),
 }
+QUERIES5 = {
+    "cfg5": (synth.QUERY_CFG5, 4.375),
+    "cfg5 count only": ("SELECT h1, h2, h3, h4, COUNT(*) FROM t GROUP BY h1, h2, h3, h4 LIMIT 20000", 1.875),
+    "cfg5 hll(u) no group": ("SELECT DISTINCTCOUNTHLL(u) FROM t", 2.5),
+    "cfg5 hll(u) group h1": ("SELECT h1, DISTINCTCOUNTHLL(u) FROM t GROUP BY h1", 3.0),
+    "cfg5 distinctcount(u) group h1": ("SELECT h1, DISTINCTCOUNT(u) FROM t GROUP BY h1", 3.0),
+    "cfg5 count group h1..h3": ("SELECT h1, h2, h3, COUNT(*) FROM t GROUP BY h1, h2, h3 LIMIT 20000", 1.5),
+}
+if args.set == "cfg5":
+    QUERIES = QUERIES5
 for name, (sql, bpr) in QUERIES.items():
     qc = parse_sql(sql)
     qc.flags |= capi.QUERY_FLAG_PROFILE
