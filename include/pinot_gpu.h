@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 1
+#define PG_ABI_VERSION 2
 
 typedef enum pg_status {
   PG_OK = 0,
@@ -156,7 +156,8 @@ typedef struct pg_query {
   int32_t reserved0;
 } pg_query;
 
-#define PG_QUERY_FLAG_PROFILE 0x1   /* record per-kernel HIP-event timings into pg_exec_stats */
+#define PG_QUERY_FLAG_PROFILE 0x1          /* record per-kernel HIP-event timings into pg_exec_stats */
+#define PG_QUERY_FLAG_SKIP_STAR_TREE 0x2   /* QueryContext#isSkipStarTree (query option useStarTree=false) */
 
 /* ExecutionStatistics (pinot-core/.../operator/ExecutionStatistics.java) + device timings. */
 typedef struct pg_exec_stats {
@@ -175,6 +176,8 @@ typedef struct pg_exec_stats {
   float host_ms_total;
   int64_t algorithmic_bytes;      /* bytes the plan must read once (columns + postings), for roofline accounting */
   char kernel[32];                /* name of the segment query kernel that ran (rocprofv3 kernel-trace name) */
+  int32_t star_tree_index;        /* index of the star-tree the query ran on (StarTreeUtils.java:357-436), -1: none */
+  int32_t reserved0;
 } pg_exec_stats;
 
 /* Intermediate result kinds (AggregationFunction#getIntermediateResultColumnType). */
@@ -186,6 +189,42 @@ typedef enum pg_result_kind {
   PG_RESULT_DICTID_SET = 4,/* DISTINCTCOUNT over a dictionary column: set of dictIds (decoded by the caller) */
   PG_RESULT_HLL = 5        /* HyperLogLog registers, m = 2^log2m bytes per group */
 } pg_result_kind;
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Star-tree index (StarTreeV2): a separate doc space of pre-aggregated records plus the tree that selects them.
+ *   star_tree                   the `star_tree.index` entry exactly as OffHeapStarTree reads it — LITTLE-endian: long magic
+ *                               0xBADDA55B00DAD00D, int version 1, int header size, int numDimensions, {int id, int len,
+ *                               bytes}..., int numNodes, then numNodes x 7 ints {dimensionId, dimensionValue, startDocId,
+ *                               endDocId, aggregatedDocId, firstChildId, lastChildId}
+ *                               (pinot-segment-local/.../startree/OffHeapStarTree.java:38-85, OffHeapStarTreeNode.java:30-37,
+ *                               StarTreeBuilderUtils.java:114-250)
+ *   dimension_forward_indexes   FixedBitSVForwardIndexReaderV2 over the star-tree docs, bits = the parent column's
+ *                               bitsPerElement, dictIds of the PARENT segment's dictionary, star stored as 0
+ *                               (StarTreeLoaderUtils.java:70-78, StarTreeV2Constants.java:37-39)
+ *   pairs                       one raw forward index per AggregationFunctionColumnPair ("count__*", "sum__m", ...):
+ *                               LONG for COUNT, DOUBLE for SUM / MIN / MAX (fixed-byte chunk format, PASS_THROUGH), BYTES
+ *                               for DISTINCTCOUNTHLL (var-byte chunk format v2/v3, PASS_THROUGH; every value a serialized
+ *                               HyperLogLog: BE int log2m, BE int 4*ceil(2^log2m/6), RegisterSet words — ObjectSerDeUtils.java
+ *                               :733-767) (StarTreeLoaderUtils.java:81-89, ValueAggregatorFactory#getAggregatedValueType)
+ * The dimensions must already be registered as columns of the segment (their dictionaries are shared).
+ * ------------------------------------------------------------------------------------------------------------------ */
+typedef struct pg_star_tree_pair {
+  int32_t function;        /* pg_agg_function: COUNT / SUM / MIN / MAX / DISTINCTCOUNTHLL */
+  int32_t data_type;       /* pg_data_type of the stored aggregate: LONG / DOUBLE / BYTES */
+  const char* column;      /* "*" for COUNT */
+  pg_buffer forward_index;
+} pg_star_tree_pair;
+
+typedef struct pg_star_tree_desc {
+  int32_t num_docs;                          /* StarTreeV2Metadata#getNumDocs (startree.v2.N.total.docs) */
+  int32_t n_dimensions;                      /* dimensionsSplitOrder */
+  int32_t n_pairs;
+  int32_t max_leaf_records;                  /* informational */
+  const char* const* dimensions;
+  const pg_buffer* dimension_forward_indexes;
+  const pg_star_tree_pair* pairs;
+  pg_buffer star_tree;
+} pg_star_tree_desc;
 
 typedef struct pg_segment_s* pg_segment_t;
 typedef struct pg_result_s* pg_result_t;
@@ -203,6 +242,8 @@ int32_t pg_last_error(char* buf, size_t cap);
  * (pinot-segment-spi/.../IndexSegment.java:137-142). */
 int32_t pg_segment_create(const char* segment_name, int32_t total_docs, pg_segment_t* out_segment);
 int32_t pg_segment_add_column(pg_segment_t segment, const pg_column_desc* column);
+/* StarTreeLoaderUtils#loadStarTreeV2: registers star-tree number `IndexSegment#getStarTrees().size()` of the segment. */
+int32_t pg_segment_add_star_tree(pg_segment_t segment, const pg_star_tree_desc* star_tree);
 int32_t pg_segment_num_docs(pg_segment_t segment, int32_t* out_num_docs);
 int32_t pg_segment_device_bytes(pg_segment_t segment, uint64_t* out_bytes);
 int32_t pg_segment_destroy(pg_segment_t segment);

@@ -12,7 +12,7 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
-PG_ABI_VERSION = 1
+PG_ABI_VERSION = 2
 
 # pg_status
 PG_OK = 0
@@ -36,6 +36,7 @@ AGG_FUNCTIONS = {"COUNT": 0, "SUM": 1, "MIN": 2, "MAX": 3, "AVG": 4, "DISTINCTCO
 RESULT_LONG, RESULT_DOUBLE, RESULT_AVG_PAIR, RESULT_MINMAX_PAIR, RESULT_DICTID_SET, RESULT_HLL = range(6)
 
 QUERY_FLAG_PROFILE = 0x1
+QUERY_FLAG_SKIP_STAR_TREE = 0x2
 
 
 class PgBuffer(C.Structure):
@@ -56,6 +57,23 @@ class PgColumnDesc(C.Structure):
         ("forward_index", PgBuffer),
         ("dictionary", PgBuffer),
         ("inverted_index", PgBuffer),
+    ]
+
+
+class PgStarTreePair(C.Structure):
+    _fields_ = [("function", C.c_int32), ("data_type", C.c_int32), ("column", C.c_char_p), ("forward_index", PgBuffer)]
+
+
+class PgStarTreeDesc(C.Structure):
+    _fields_ = [
+        ("num_docs", C.c_int32),
+        ("n_dimensions", C.c_int32),
+        ("n_pairs", C.c_int32),
+        ("max_leaf_records", C.c_int32),
+        ("dimensions", C.POINTER(C.c_char_p)),
+        ("dimension_forward_indexes", C.POINTER(PgBuffer)),
+        ("pairs", C.POINTER(PgStarTreePair)),
+        ("star_tree", PgBuffer),
     ]
 
 
@@ -112,6 +130,8 @@ class PgExecStats(C.Structure):
         ("host_ms_total", C.c_float),
         ("algorithmic_bytes", C.c_int64),
         ("kernel", C.c_char * 32),
+        ("star_tree_index", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
     def as_dict(self) -> dict:
@@ -131,7 +151,7 @@ GPU_LIB_PATH = os.path.join(REPO_ROOT, "pinot_amd", "csrc", "libpinot_gpu.so")
 # every symbol include/pinot_gpu.h declares (checked by the "not gpu" suite against the built library)
 ABI_SYMBOLS = [
     "abi_version", "init", "device_count", "last_error",
-    "segment_create", "segment_add_column", "segment_num_docs", "segment_device_bytes", "segment_destroy",
+    "segment_create", "segment_add_column", "segment_add_star_tree", "segment_num_docs", "segment_device_bytes", "segment_destroy",
     "filter_exec", "docidset_cardinality", "docidset_num_words", "docidset_copy_words", "docidset_copy_docids",
     "docidset_stats", "docidset_free",
     "query_supported", "query_exec",
@@ -154,6 +174,7 @@ class NativeApi:
         self.f("init").argtypes = [C.c_int32]
         self.f("segment_create").argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]
         self.f("segment_add_column").argtypes = [C.c_void_p, C.POINTER(PgColumnDesc)]
+        self.f("segment_add_star_tree").argtypes = [C.c_void_p, C.POINTER(PgStarTreeDesc)]
         self.f("segment_num_docs").argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         self.f("segment_device_bytes").argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         self.f("segment_destroy").argtypes = [C.c_void_p]

@@ -46,6 +46,8 @@ class NativeSegment:
         self._descs = []
         for col in host.columns.values():
             self._register(col)
+        for st in getattr(host, "star_trees", []):
+            self.add_star_tree(st)
 
     def _register(self, col):
         d = col.desc()
@@ -61,6 +63,11 @@ class NativeSegment:
             col.forward_index = None
             col.inverted_index = None
             self._descs.pop()
+
+    def add_star_tree(self, star_tree):
+        """StarTreeLoaderUtils#loadStarTreeV2: the dimensions must already be registered columns of this segment."""
+        d = star_tree.desc()
+        self.api.call("segment_add_star_tree", self.handle, C.byref(d))
 
     @property
     def total_docs(self) -> int:

@@ -292,3 +292,141 @@ def write_inverted_index(dict_ids: np.ndarray, cardinality: int, run_compress: b
     assert pos <= 0xFFFFFFFF, "inverted index larger than 4 GB (BitmapInvertedIndexReader offsets are unsigned int)"
     head = offsets.astype(">u4").tobytes()
     return np.frombuffer(head + b"".join(blobs), dtype=np.uint8)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Raw var-byte chunk forward index (BYTES / STRING), PASS_THROUGH, writer versions 2 and 3
+#   writer: pinot-segment-local/.../io/writer/impl/VarByteChunkForwardIndexWriter.java:46-158 (chunk = numDocsPerChunk int
+#           offsets relative to the chunk start, 0 for the absent rows of the last chunk, then the values back to back)
+#           BaseChunkForwardIndexWriter.java:131-198 (same 7-int header as the fixed-byte format; sizeOfEntry = longest value)
+#   reader: .../readers/forward/VarByteChunkSVForwardIndexReader.java:158-217
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def write_raw_var_byte_chunk(values: Sequence[bytes], version: int = 2, docs_per_chunk: int = 1000,
+                             longest_entry: int = None) -> np.ndarray:
+    assert version in (2, 3)
+    n = len(values)
+    longest = max([len(v) for v in values] + [0]) if longest_entry is None else longest_entry
+    num_chunks = (n + docs_per_chunk - 1) // docs_per_chunk
+    off_size = 4 if version == 2 else 8
+    header_size = 7 * 4 + num_chunks * off_size
+    chunks = []
+    for c in range(num_chunks):
+        vals = values[c * docs_per_chunk:(c + 1) * docs_per_chunk]
+        offs = np.zeros(docs_per_chunk, dtype=">i4")
+        pos = docs_per_chunk * 4
+        for i, v in enumerate(vals):
+            offs[i] = pos
+            pos += len(v)
+        chunks.append(offs.tobytes() + b"".join(vals))
+    starts, pos = [], header_size
+    for ch in chunks:
+        starts.append(pos)
+        pos += len(ch)
+    header = struct.pack(">7i", version, num_chunks, docs_per_chunk, longest, n, CHUNK_COMPRESSION_PASS_THROUGH, 28)
+    off_bytes = np.asarray(starts, dtype=np.int64).astype(">i4" if off_size == 4 else ">i8").tobytes()
+    return np.frombuffer(header + off_bytes + b"".join(chunks), dtype=np.uint8)
+
+
+def read_raw_var_byte_chunk(buf: np.ndarray) -> List[bytes]:
+    """Check reader: VarByteChunkSVForwardIndexReader#getBytesUncompressed for every docId."""
+    h = parse_raw_fixed_byte_chunk_header(buf)
+    assert h["compression"] == CHUNK_COMPRESSION_PASS_THROUGH
+    b = bytes(buf)
+    off_size = 4 if h["version"] <= 2 else 8
+    fmt = ">i" if off_size == 4 else ">q"
+    starts = [struct.unpack_from(fmt, b, h["data_header_start"] + i * off_size)[0] for i in range(h["num_chunks"])]
+    out = []
+    dpc = h["docs_per_chunk"]
+    for doc in range(h["total_docs"]):
+        c, r = divmod(doc, dpc)
+        cs = starts[c]
+        s = cs + struct.unpack_from(">i", b, cs + 4 * r)[0]
+        chunk_end = starts[c + 1] if c + 1 < h["num_chunks"] else len(b)
+        if r == dpc - 1:
+            e = chunk_end
+        else:
+            nxt = struct.unpack_from(">i", b, cs + 4 * (r + 1))[0]
+            e = chunk_end if nxt == 0 else cs + nxt
+        out.append(b[s:e])
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Serialized HyperLogLog (stream-lib 2.9.8 HyperLogLog#getBytes, wrapped by ObjectSerDeUtils.HYPER_LOG_LOG_SER_DE —
+# pinot-core/.../common/ObjectSerDeUtils.java:733-767): BE int log2m, BE int 4*words, then the RegisterSet words (BE ints),
+# 6 five-bit registers per word, register i at bits 5*(i%6) of word i/6.  SURVEY.md §9; header pinned by
+# pinot-core/src/test/resources/data/rawhllresults.txt (00000008 000000ac).
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def serialize_hll(registers: np.ndarray, log2m: int) -> bytes:
+    m = 1 << log2m
+    regs = np.asarray(registers, dtype=np.uint32)
+    assert regs.shape[0] == m
+    n_words = m // 6 + (0 if m % 6 == 0 else 1)      # RegisterSet.getSizeForCount
+    padded = np.zeros(n_words * 6, dtype=np.uint32)
+    padded[:m] = regs
+    words = np.zeros(n_words, dtype=np.uint32)
+    for k in range(6):
+        words |= padded[k::6] << np.uint32(5 * k)
+    return struct.pack(">ii", log2m, n_words * 4) + words.astype(">u4").tobytes()
+
+
+def deserialize_hll(blob: bytes) -> Tuple[int, np.ndarray]:
+    log2m, nbytes = struct.unpack_from(">ii", blob, 0)
+    words = np.frombuffer(blob, dtype=">u4", count=nbytes // 4, offset=8).astype(np.uint32)
+    m = 1 << log2m
+    regs = np.zeros(len(words) * 6, dtype=np.uint8)
+    for k in range(6):
+        regs[k::6] = (words >> np.uint32(5 * k)) & 0x1F
+    return log2m, regs[:m]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Star-tree index file (`star_tree.index`), LITTLE-endian ("Backward-compatible: star-tree file is always little-endian",
+#   pinot-segment-local/.../startree/StarTreeBuilderUtils.java:114-250; reader OffHeapStarTree.java:38-85,
+#   OffHeapStarTreeNode.java:30-37).  Nodes are written in BFS order, children sorted by dimension value (star = -1 first).
+# ----------------------------------------------------------------------------------------------------------------------
+STAR_TREE_MAGIC = 0xBADDA55B00DAD00D
+STAR_TREE_VERSION = 1
+STAR_NODE_FIELDS = ("dimension_id", "dimension_value", "start_doc_id", "end_doc_id", "aggregated_doc_id",
+                    "first_child_id", "last_child_id")
+
+
+def write_star_tree(dimensions: Sequence[str], nodes: np.ndarray) -> np.ndarray:
+    """`nodes`: int32 [numNodes, 7] in BFS order (STAR_NODE_FIELDS)."""
+    nodes = np.ascontiguousarray(nodes, dtype="<i4")
+    header_size = 20 + sum(8 + len(d.encode("utf-8")) for d in dimensions) + 4
+    parts = [struct.pack("<Qiii", STAR_TREE_MAGIC, STAR_TREE_VERSION, header_size, len(dimensions))]
+    for i, d in enumerate(dimensions):
+        e = d.encode("utf-8")
+        parts.append(struct.pack("<ii", i, len(e)) + e)
+    parts.append(struct.pack("<i", nodes.shape[0]))
+    assert sum(len(p) for p in parts) == header_size
+    return np.frombuffer(b"".join(parts) + nodes.tobytes(), dtype=np.uint8)
+
+
+def read_star_tree(buf) -> Tuple[List[str], np.ndarray]:
+    b = bytes(buf)
+    magic, version, header_size, n_dims = struct.unpack_from("<Qiii", b, 0)
+    if magic != STAR_TREE_MAGIC:
+        raise ValueError("Invalid magic marker in star-tree data buffer")
+    if version != STAR_TREE_VERSION:
+        raise ValueError("Invalid version in star-tree data buffer")
+    off = 20
+    names = [None] * n_dims
+    for _ in range(n_dims):
+        dim_id, n = struct.unpack_from("<ii", b, off)
+        off += 8
+        names[dim_id] = b[off:off + n].decode("utf-8")
+        off += n
+    n_nodes, = struct.unpack_from("<i", b, off)
+    off += 4
+    if off != header_size:
+        raise ValueError("Error loading star-tree, header length mis-match")
+    if off + n_nodes * 28 != len(b):
+        raise ValueError("Error loading star-tree, buffer size mis-match")
+    nodes = np.frombuffer(b, dtype="<i4", count=n_nodes * 7, offset=off).astype(np.int32).reshape(n_nodes, 7)
+    return names, nodes

@@ -55,6 +55,7 @@ class HostSegment:
     name: str
     total_docs: int
     columns: Dict[str, HostColumn] = field(default_factory=dict)
+    star_trees: list = field(default_factory=list)      # List[startree.HostStarTree] (IndexSegment#getStarTrees)
 
     def nbytes(self) -> int:
         t = 0
@@ -118,3 +119,22 @@ def build_segment(name: str, data: Dict[str, Sequence], schema: Dict[str, str], 
                                         raw_version=raw_version, run_compress=run_compress)
     seg.total_docs = int(total or 0)
     return seg
+
+
+def decode_column(col: HostColumn, num_docs: int, dict_ids: bool = False) -> np.ndarray:
+    """Check reader: the per-doc dictIds (dict_ids=True) or values of a column, decoded from its index bytes."""
+    if col.has_dictionary:
+        if col.fwd_encoding == capi.FWD_DICT_SORTED:
+            pairs = np.frombuffer(bytes(col.forward_index), dtype=">i4").reshape(-1, 2)
+            ids = np.zeros(num_docs, dtype=np.int32)
+            for d, (s, e) in enumerate(pairs):
+                ids[s:e + 1] = d
+        else:
+            ids = formats.unpack_fixed_bit(col.forward_index, col.bits_per_value, num_docs)
+        if dict_ids:
+            return ids
+        return np.asarray(col.dict_values)[ids]
+    assert not dict_ids
+    h = formats.parse_raw_fixed_byte_chunk_header(col.forward_index)
+    return np.frombuffer(bytes(col.forward_index), dtype=formats._BE_DTYPES[col.data_type], count=num_docs,
+                         offset=h["raw_data_start"]).astype(NUMERIC_NP[col.data_type])

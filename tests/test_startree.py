@@ -1,0 +1,126 @@
+"""Star-tree index: byte formats and the builder, pinned to the reference's own star-tree fixture
+(tests/golden/startree_airline: built by the reference over airlineStats, extracted by tests/golden/make_startree_airline.py).
+"""
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from pinot_amd import formats, startree
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "startree_airline")
+
+
+def load_fixture():
+    meta = json.load(open(os.path.join(GOLDEN, "meta.json")))
+    blob = np.fromfile(os.path.join(GOLDEN, "star_tree_index"), dtype=np.uint8)
+    im = meta["index_map"]
+
+    def entry(col, kind):
+        off, size = im[f"0.{col}.{kind}.OFFSET"], im[f"0.{col}.{kind}.SIZE"]
+        return blob[off:off + size]
+    return meta, entry
+
+
+def decode_fixture():
+    meta, entry = load_fixture()
+    n = meta["total_docs"]
+    names, nodes = formats.read_star_tree(entry("null", "STAR_TREE"))
+    dims = np.stack([formats.unpack_fixed_bit(entry(d, "FORWARD_INDEX"), meta["columns"][d]["bitsPerElement"], n)
+                     for d in meta["split_order"]], axis=1)
+    cnt_buf, max_buf = entry("count__*", "FORWARD_INDEX"), entry("max__ArrDelay", "FORWARD_INDEX")
+    h = formats.parse_raw_fixed_byte_chunk_header(cnt_buf)
+    counts = np.frombuffer(bytes(cnt_buf), dtype=">i8", count=n, offset=h["raw_data_start"]).astype(np.int64)
+    maxes = np.frombuffer(bytes(max_buf), dtype=">f8", count=n, offset=h["raw_data_start"]).astype(np.float64)
+    return meta, entry, names, nodes, dims, counts, maxes
+
+
+def test_fixture_tree_parses_like_offheap_star_tree():
+    meta, entry, names, nodes, dims, counts, maxes = decode_fixture()
+    assert names == meta["split_order"] == ["AirlineID", "Origin", "Dest"]
+    assert nodes.shape == (666, 7)
+    root = nodes[0]
+    assert root[0] == -1 and root[1] == -1               # dimensionId, dimensionValue of the root (INVALID_ID)
+    assert root[5] == 1                                  # BFS: the root's first child is node 1
+    # raw forward indexes are FixedByteChunk v2, PASS_THROUGH, 1000 docs per chunk
+    h = formats.parse_raw_fixed_byte_chunk_header(entry("count__*", "FORWARD_INDEX"))
+    assert (h["version"], h["num_chunks"], h["docs_per_chunk"], h["size_of_entry"], h["total_docs"], h["compression"]) == \
+        (2, 2, 1000, 8, 1004, 0)
+    # children of every node are sorted by dimension value, star (-1) first; child ranges partition the parent's range
+    for nd in nodes:
+        if nd[5] < 0:
+            continue
+        kids = nodes[nd[5]:nd[6] + 1]
+        assert np.all(np.diff(kids[:, 1]) > 0)
+        assert np.all(kids[:, 0] == nd[0] + 1)
+    # known answers: the root's aggregated doc holds the whole segment
+    agg = root[4]
+    assert counts[agg] == meta["segment_total_docs"] == 313
+    assert maxes[agg] == float(meta["columns"]["ArrDelay"]["maxValue"]) == 343.0
+
+
+def test_builder_reproduces_reference_fixture_byte_for_byte():
+    """Stage 2-4 of the builder (constructStarTree / createAggregatedDocs / serializeTree) re-run over the fixture's base
+    docs must give back the reference's star-tree: tree file and all five forward indexes."""
+    meta, entry, names, nodes, dims, counts, maxes = decode_fixture()
+    root_kids = nodes[nodes[0][5]:nodes[0][6] + 1]
+    n_base = int(max(k[3] for k in root_kids if k[1] != -1))      # the non-star children of the root cover the base docs
+    assert n_base == 306
+    assert int(counts[:n_base].sum()) == 313
+    cards = [meta["columns"][d]["cardinality"] for d in names]
+    st = startree.build_from_base_records(names, cards, dims[:n_base], [("COUNT", "*"), ("MAX", "ArrDelay")],
+                                          [counts[:n_base].tolist(), maxes[:n_base].tolist()],
+                                          max_leaf_records=meta["max_leaf_records"])
+    assert st.num_docs == meta["total_docs"] == 1004
+    assert st.n_base_docs == n_base
+    np.testing.assert_array_equal(st.star_tree, entry("null", "STAR_TREE"))
+    for j, d in enumerate(names):
+        np.testing.assert_array_equal(st.dimension_forward_indexes[j], entry(d, "FORWARD_INDEX"))
+    np.testing.assert_array_equal(st.pairs[0].forward_index, entry("count__*", "FORWARD_INDEX"))
+    np.testing.assert_array_equal(st.pairs[1].forward_index, entry("max__ArrDelay", "FORWARD_INDEX"))
+
+
+def test_star_tree_file_round_trip():
+    meta, entry, names, nodes, *_ = decode_fixture()
+    np.testing.assert_array_equal(formats.write_star_tree(names, nodes), entry("null", "STAR_TREE"))
+    bad = entry("null", "STAR_TREE").copy()
+    bad[0] ^= 1
+    with pytest.raises(ValueError, match="magic"):
+        formats.read_star_tree(bad)
+
+
+def test_var_byte_chunk_and_hll_round_trip():
+    rng = np.random.default_rng(5)
+    vals = [bytes(rng.integers(0, 256, rng.integers(0, 40), dtype=np.uint8)) for _ in range(2503)]
+    for version in (2, 3):
+        buf = formats.write_raw_var_byte_chunk(vals, version=version, docs_per_chunk=1000)
+        assert formats.read_raw_var_byte_chunk(buf) == vals
+    regs = rng.integers(0, 27, 256, dtype=np.uint8)
+    blob = formats.serialize_hll(regs, 8)
+    assert len(blob) == 180 and blob[:8] == bytes.fromhex("00000008000000ac")     # rawhllresults.txt header
+    log2m, back = formats.deserialize_hll(blob)
+    assert log2m == 8
+    np.testing.assert_array_equal(back, regs)
+    # the reference's serialized blobs decode and re-encode to themselves
+    path = os.path.join(os.path.dirname(GOLDEN), "rawhllresults.txt")
+    n = 0
+    for line in open(path):
+        for tok in line.replace(",", " ").split():
+            if len(tok) == 360 and tok.startswith("00000008000000ac"):
+                raw = bytes.fromhex(tok)
+                lg, r = formats.deserialize_hll(raw)
+                assert formats.serialize_hll(r, lg) == raw
+                n += 1
+    assert n > 0
+
+
+def test_java_hashmap_iteration_order():
+    # keys 0..12 + star: capacity 32; star (hash 0xFFFF0000) lands in bucket 0 behind key 0
+    keys = list(range(13)) + [-1]
+    order = [keys[i] for i in startree._java_hashmap_order(keys)]
+    assert order == [0, -1] + list(range(1, 13))
+    # capacity 16: 17 and 1 share bucket 1 in insertion order
+    keys = [1, 5, 17]
+    assert [keys[i] for i in startree._java_hashmap_order(keys)] == [1, 17, 5]
