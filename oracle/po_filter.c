@@ -597,7 +597,7 @@ static po_docidset* notset_new(po_docidset* child, int32_t num_docs) {
 /* =====================================================================================================================
  * filter operators
  * ===================================================================================================================== */
-static po_filter_op* op_new(int kind, int32_t num_docs) {
+po_filter_op* po_op_new(int kind, int32_t num_docs) {
   po_filter_op* op = (po_filter_op*)po_xcalloc(1, sizeof(*op));
   op->kind = kind;
   op->num_docs = num_docs;
@@ -607,18 +607,18 @@ static int op_is_empty(const po_filter_op* op) { return op->kind == PO_OP_EMPTY;
 static int op_is_match_all(const po_filter_op* op) { return op->kind == PO_OP_MATCH_ALL; }
 
 /* FilterOperatorUtils.DefaultImplementation#getLeafFilterOperator, core/operator/filter/FilterOperatorUtils.java:74-133 */
-static po_filter_op* leaf_filter_operator(po_pred_eval* eval, const po_column* col, int32_t num_docs) {
-  if (eval->always_false) return op_new(PO_OP_EMPTY, num_docs);
-  if (eval->always_true) return op_new(PO_OP_MATCH_ALL, num_docs);
+po_filter_op* po_leaf_filter_operator(po_pred_eval* eval, const po_column* col, int32_t num_docs) {
+  if (eval->always_false) return po_op_new(PO_OP_EMPTY, num_docs);
+  if (eval->always_true) return po_op_new(PO_OP_MATCH_ALL, num_docs);
   po_filter_op* op;
   int sorted_ok = col->is_sorted && col->has_dictionary;
   if (eval->pred_type == PG_PRED_RANGE) {
     /* range: Sorted > RangeIndex (none on this path) > Scan — the inverted index is NOT used for RANGE */
-    op = op_new(sorted_ok ? PO_OP_SORTED : PO_OP_SCAN, num_docs);
+    op = po_op_new(sorted_ok ? PO_OP_SORTED : PO_OP_SCAN, num_docs);
   } else {
-    if (sorted_ok) op = op_new(PO_OP_SORTED, num_docs);
-    else if (col->inv_len > 0) op = op_new(PO_OP_INVERTED, num_docs);
-    else op = op_new(PO_OP_SCAN, num_docs);
+    if (sorted_ok) op = po_op_new(PO_OP_SORTED, num_docs);
+    else if (col->inv_len > 0) op = po_op_new(PO_OP_INVERTED, num_docs);
+    else op = po_op_new(PO_OP_SCAN, num_docs);
   }
   op->eval = eval;
   op->col = col;
@@ -630,6 +630,7 @@ static int op_priority(const po_filter_op* op) {
   switch (op->kind) {
     case PO_OP_SORTED: return 0;
     case PO_OP_INVERTED: return 100;
+    case PO_OP_BITMAP: return 100;   /* BitmapBasedFilterOperator: MEDIUM_PRIORITY */
     case PO_OP_AND: return 300;
     case PO_OP_OR: return 400;
     case PO_OP_NOT: return op_priority(op->children[0]);
@@ -638,14 +639,14 @@ static int op_priority(const po_filter_op* op) {
   }
 }
 
-static po_filter_op* and_filter_operator(int n, po_filter_op** ops, int32_t num_docs) { /* :136-158 */
+po_filter_op* po_and_filter_operator(int n, po_filter_op** ops, int32_t num_docs) { /* :136-158 */
   po_filter_op** ch = (po_filter_op**)po_xcalloc((size_t)n + 1, sizeof(po_filter_op*));
   int m = 0;
   for (int i = 0; i < n; i++) {
-    if (op_is_empty(ops[i])) { free(ch); return op_new(PO_OP_EMPTY, num_docs); }
+    if (op_is_empty(ops[i])) { free(ch); return po_op_new(PO_OP_EMPTY, num_docs); }
     if (!op_is_match_all(ops[i])) ch[m++] = ops[i];
   }
-  if (m == 0) { free(ch); return op_new(PO_OP_MATCH_ALL, num_docs); }
+  if (m == 0) { free(ch); return po_op_new(PO_OP_MATCH_ALL, num_docs); }
   if (m == 1) { po_filter_op* r = ch[0]; free(ch); return r; }
   /* reorderAndFilterChildOperators: List.sort by priority (stable) */
   for (int i = 1; i < m; i++) {
@@ -655,31 +656,31 @@ static po_filter_op* and_filter_operator(int n, po_filter_op** ops, int32_t num_
     while (j >= 0 && op_priority(ch[j]) > kp) { ch[j + 1] = ch[j]; j--; }
     ch[j + 1] = key;
   }
-  po_filter_op* op = op_new(PO_OP_AND, num_docs);
+  po_filter_op* op = po_op_new(PO_OP_AND, num_docs);
   op->n_children = m;
   op->children = ch;
   return op;
 }
 
-static po_filter_op* or_filter_operator(int n, po_filter_op** ops, int32_t num_docs) { /* :161-183 */
+po_filter_op* po_or_filter_operator(int n, po_filter_op** ops, int32_t num_docs) { /* :161-183 */
   po_filter_op** ch = (po_filter_op**)po_xcalloc((size_t)n + 1, sizeof(po_filter_op*));
   int m = 0;
   for (int i = 0; i < n; i++) {
-    if (op_is_match_all(ops[i])) { free(ch); return op_new(PO_OP_MATCH_ALL, num_docs); }
+    if (op_is_match_all(ops[i])) { free(ch); return po_op_new(PO_OP_MATCH_ALL, num_docs); }
     if (!op_is_empty(ops[i])) ch[m++] = ops[i];
   }
-  if (m == 0) { free(ch); return op_new(PO_OP_EMPTY, num_docs); }
+  if (m == 0) { free(ch); return po_op_new(PO_OP_EMPTY, num_docs); }
   if (m == 1) { po_filter_op* r = ch[0]; free(ch); return r; }
-  po_filter_op* op = op_new(PO_OP_OR, num_docs);
+  po_filter_op* op = po_op_new(PO_OP_OR, num_docs);
   op->n_children = m;
   op->children = ch;
   return op;
 }
 
-static po_filter_op* not_filter_operator(po_filter_op* child, int32_t num_docs) { /* :186-196 */
-  if (op_is_match_all(child)) return op_new(PO_OP_EMPTY, num_docs);
-  if (op_is_empty(child)) return op_new(PO_OP_MATCH_ALL, num_docs);
-  po_filter_op* op = op_new(PO_OP_NOT, num_docs);
+po_filter_op* po_not_filter_operator(po_filter_op* child, int32_t num_docs) { /* :186-196 */
+  if (op_is_match_all(child)) return po_op_new(PO_OP_EMPTY, num_docs);
+  if (op_is_empty(child)) return po_op_new(PO_OP_MATCH_ALL, num_docs);
+  po_filter_op* op = po_op_new(PO_OP_NOT, num_docs);
   op->n_children = 1;
   op->children = (po_filter_op**)po_xcalloc(1, sizeof(po_filter_op*));
   op->children[0] = child;
@@ -695,10 +696,10 @@ static po_filter_op* construct_physical_operator(po_segment* seg, const pg_filte
       for (int i = 0; i < f->n_children; i++) {
         po_filter_op* c = construct_physical_operator(seg, &f->children[i], num_docs);
         if (!c) { free(ch); return NULL; }
-        if (op_is_empty(c)) { free(ch); return op_new(PO_OP_EMPTY, num_docs); }
+        if (op_is_empty(c)) { free(ch); return po_op_new(PO_OP_EMPTY, num_docs); }
         if (!op_is_match_all(c)) ch[m++] = c;
       }
-      po_filter_op* r = and_filter_operator(m, ch, num_docs);
+      po_filter_op* r = po_and_filter_operator(m, ch, num_docs);
       free(ch);
       return r;
     }
@@ -708,17 +709,17 @@ static po_filter_op* construct_physical_operator(po_segment* seg, const pg_filte
       for (int i = 0; i < f->n_children; i++) {
         po_filter_op* c = construct_physical_operator(seg, &f->children[i], num_docs);
         if (!c) { free(ch); return NULL; }
-        if (op_is_match_all(c)) { free(ch); return op_new(PO_OP_MATCH_ALL, num_docs); }
+        if (op_is_match_all(c)) { free(ch); return po_op_new(PO_OP_MATCH_ALL, num_docs); }
         if (!op_is_empty(c)) ch[m++] = c;
       }
-      po_filter_op* r = or_filter_operator(m, ch, num_docs);
+      po_filter_op* r = po_or_filter_operator(m, ch, num_docs);
       free(ch);
       return r;
     }
     case PG_FILTER_NOT: {
       po_filter_op* c = construct_physical_operator(seg, &f->children[0], num_docs);
       if (!c) return NULL;
-      return not_filter_operator(c, num_docs);
+      return po_not_filter_operator(c, num_docs);
     }
     case PG_FILTER_PREDICATE: {
       po_column* col = po_segment_column(seg, f->column);
@@ -728,10 +729,10 @@ static po_filter_op* construct_physical_operator(po_segment* seg, const pg_filte
       }
       po_pred_eval* eval = po_pred_eval_create(f, col);
       if (!eval) return NULL;
-      return leaf_filter_operator(eval, col, num_docs);
+      return po_leaf_filter_operator(eval, col, num_docs);
     }
-    case PG_FILTER_CONSTANT_TRUE: return op_new(PO_OP_MATCH_ALL, num_docs);
-    case PG_FILTER_CONSTANT_FALSE: return op_new(PO_OP_EMPTY, num_docs);
+    case PG_FILTER_CONSTANT_TRUE: return po_op_new(PO_OP_MATCH_ALL, num_docs);
+    case PG_FILTER_CONSTANT_FALSE: return po_op_new(PO_OP_EMPTY, num_docs);
     default:
       po_set_error("bad filter node type %d", f->type);
       return NULL;
@@ -739,7 +740,7 @@ static po_filter_op* construct_physical_operator(po_segment* seg, const pg_filte
 }
 
 po_filter_op* po_filter_plan(po_segment* seg, const pg_filter_node* filter) { /* FilterPlanNode.run :88-106 */
-  if (!filter) return op_new(PO_OP_MATCH_ALL, seg->total_docs);
+  if (!filter) return po_op_new(PO_OP_MATCH_ALL, seg->total_docs);
   return construct_physical_operator(seg, filter, seg->total_docs);
 }
 
@@ -815,6 +816,7 @@ po_docidset* po_filter_get_trues(po_filter_op* op) {
     case PO_OP_SCAN: return scanset_new(op->eval, op->col, op->num_docs);
     case PO_OP_INVERTED: return inverted_get_trues(op);
     case PO_OP_SORTED: return sorted_get_trues(op);
+    case PO_OP_BITMAP: return bitmapset_new(po_bitmap_clone(op->bitmap), op->num_docs);
     case PO_OP_AND:
     case PO_OP_OR: {
       po_docidset** sets = (po_docidset**)po_xcalloc((size_t)op->n_children + 1, sizeof(po_docidset*));
@@ -889,6 +891,7 @@ int po_filter_can_optimize_count(po_filter_op* op) {
     case PO_OP_EMPTY:
     case PO_OP_MATCH_ALL:
     case PO_OP_INVERTED:
+    case PO_OP_BITMAP:
     case PO_OP_SORTED: return 1;
     case PO_OP_SCAN: return 0;
     default:

@@ -121,3 +121,19 @@ int64_t po_hll_cardinality(const po_hll* h) {
   if (estimate <= (5.0 / 2.0) * m) return (int64_t)floor(m * log(m / zeros) + 0.5);   /* Math.round */
   return (int64_t)floor(estimate + 0.5);
 }
+
+/* HyperLogLog.Builder.build(byte[]) via ObjectSerDeUtils.HYPER_LOG_LOG_SER_DE (core/common/ObjectSerDeUtils.java:733-767):
+ * BE int log2m, BE int byte size, RegisterSet ints; register i = (word[i / 6] >>> (5 * (i % 6))) & 0x1f */
+po_hll* po_hll_deserialize(const uint8_t* blob, int32_t len) {
+  if (len < 8) return NULL;
+  int32_t log2m = (int32_t)po_be32(blob), nbytes = (int32_t)po_be32(blob + 4);
+  if (log2m < 1 || log2m > 30 || nbytes < 0 || 8 + nbytes > len) return NULL;
+  po_hll* h = po_hll_new(log2m);
+  int32_t n_words = nbytes / 4;
+  for (int32_t i = 0; i < h->m; i++) {
+    int32_t w = i / 6;
+    if (w >= n_words) break;
+    h->regs[i] = (uint8_t)((po_be32(blob + 8 + (int64_t)w * 4) >> (5 * (i % 6))) & 0x1f);
+  }
+  return h;
+}

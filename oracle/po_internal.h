@@ -85,12 +85,30 @@ typedef struct po_column {
   int32_t num_docs;
 } po_column;
 
+struct po_star_tree;
 typedef struct po_segment {
   char* name;
   int32_t total_docs;
   int32_t n_columns;
   po_column** columns;
+  int32_t n_star_trees;                 /* IndexSegment#getStarTrees */
+  struct po_star_tree** star_trees;
 } po_segment;
+
+/* StarTreeV2 (pinot-segment-local/.../startree/v2/store/StarTreeLoaderUtils.java:53-128): the tree, its metadata and
+ * one DataSource per dimension / function-column pair over the star-tree doc space. */
+typedef struct po_star_tree {
+  po_segment* space;                    /* star-tree docs: dimension columns (parent dictionaries) + pair columns */
+  int32_t num_docs;
+  int32_t n_dims;
+  char** dims;                          /* dimensionsSplitOrder == OffHeapStarTree#getDimensionNames */
+  int32_t n_pairs;
+  int32_t* pair_functions;              /* pg_agg_function */
+  char** pair_columns;                  /* "*" for COUNT */
+  po_column** pair_cols;                /* columns of `space` named like AggregationFunctionColumnPair#toColumnName */
+  const uint8_t* nodes;                 /* little-endian node array, 7 ints per node */
+  int32_t n_nodes;
+} po_star_tree;
 
 po_column* po_segment_column(po_segment* seg, const char* name);
 
@@ -102,6 +120,8 @@ int32_t po_raw_get_int(const po_column* c, int32_t doc_id);
 int64_t po_raw_get_long(const po_column* c, int32_t doc_id);
 float po_raw_get_float(const po_column* c, int32_t doc_id);
 double po_raw_get_double(const po_column* c, int32_t doc_id);
+/* VarByteChunkSVForwardIndexReader#getBytes (PASS_THROUGH): pointer into the index buffer + length */
+const uint8_t* po_raw_get_bytes(const po_column* c, int32_t doc_id, int32_t* len);
 /* SortedIndexReaderImpl#getDocIds */
 void po_sorted_get_doc_ids(const po_column* c, int32_t dict_id, int32_t* start, int32_t* end_inclusive);
 int32_t po_sorted_get_dict_id(const po_column* c, int32_t doc_id);
@@ -166,7 +186,8 @@ struct po_docidset {
   void* state;
 };
 
-enum { PO_OP_EMPTY, PO_OP_MATCH_ALL, PO_OP_SCAN, PO_OP_INVERTED, PO_OP_SORTED, PO_OP_AND, PO_OP_OR, PO_OP_NOT };
+enum { PO_OP_EMPTY, PO_OP_MATCH_ALL, PO_OP_SCAN, PO_OP_INVERTED, PO_OP_SORTED, PO_OP_AND, PO_OP_OR, PO_OP_NOT,
+       PO_OP_BITMAP /* BitmapBasedFilterOperator over a precomputed bitmap (star-tree traversal result) */ };
 
 struct po_filter_op {
   int kind;
@@ -175,8 +196,19 @@ struct po_filter_op {
   const po_column* col;
   int n_children;
   po_filter_op** children;
+  po_bitmap* bitmap;      /* PO_OP_BITMAP */
 };
 
+/* operator constructors shared with the star-tree filter (po_startree.c) */
+po_filter_op* po_op_new(int kind, int32_t num_docs);
+po_filter_op* po_leaf_filter_operator(po_pred_eval* eval, const po_column* col, int32_t num_docs);
+po_filter_op* po_and_filter_operator(int n, po_filter_op** ops, int32_t num_docs);
+po_filter_op* po_or_filter_operator(int n, po_filter_op** ops, int32_t num_docs);
+po_filter_op* po_not_filter_operator(po_filter_op* child, int32_t num_docs);
+/* StarTreeUtils#createStarTreeBasedProjectOperator + StarTreeFilterOperator: 1 = fit (*out_op is the filter over the
+ * star-tree docs), 0 = not fit for this star-tree, < 0 = pg_status error */
+int po_star_tree_plan(po_segment* seg, po_star_tree* st, const pg_query* q, po_filter_op** out_op);
+int32_t po_star_tree_pair_index(const po_star_tree* st, int32_t function, const char* column);
 /* FilterPlanNode.run */
 po_filter_op* po_filter_plan(po_segment* seg, const pg_filter_node* filter);
 po_docidset* po_filter_get_trues(po_filter_op* op);
@@ -197,6 +229,8 @@ void po_hll_offer_float(po_hll* h, float v);
 void po_hll_offer_double(po_hll* h, double v);
 void po_hll_offer_string(po_hll* h, const uint8_t* s, int32_t len);
 void po_hll_merge(po_hll* dst, const po_hll* src);
+/* ObjectSerDeUtils.HYPER_LOG_LOG_SER_DE#deserialize (HyperLogLog.Builder.build(bytes)); NULL on a malformed blob */
+po_hll* po_hll_deserialize(const uint8_t* blob, int32_t len);
 int64_t po_hll_cardinality(const po_hll* h);
 
 #endif /* PO_INTERNAL_H_ */

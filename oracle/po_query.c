@@ -368,6 +368,7 @@ typedef struct agg_state {
   double* d1;              /* max of MinMaxRangePair */
   int64_t* l0;             /* AvgPair count */
   uint8_t* has;            /* ObjectGroupByResultHolder: result != null */
+  int star;                /* aggregating a star-tree function-column pair column (pre-aggregated values) */
   po_bitmap** dict_bitmaps;/* DISTINCTCOUNT / HLL over dictionary columns: RoaringBitmap of dictIds */
   po_hll** hlls;           /* HLL over raw columns */
 } agg_state;
@@ -443,6 +444,19 @@ static void hll_offer_raw(po_hll* h, po_column* c, int32_t doc_id) {
 static void agg_process_block(agg_state* a, block_col* bc, const int32_t* doc_ids, int n, const int32_t* group_keys) {
   switch (a->function) {
     case PG_AGG_COUNT:
+      if (a->star) { /* star-tree pre-aggregated values: CountAggregationFunction.java:99-106,134-141 */
+        if (!group_keys) {
+          int64_t count = 0;
+          for (int i = 0; i < n; i++) count += po_raw_get_long(a->col, doc_ids[i]);
+          a->d0[0] = a->d0[0] + (double)count;
+          return;
+        }
+        for (int i = 0; i < n; i++) {
+          int32_t g = group_keys[i];
+          if (g != PO_INVALID_ID) a->d0[g] = a->d0[g] + (double)po_raw_get_long(a->col, doc_ids[i]);
+        }
+        return;
+      }
       if (!group_keys) { a->d0[0] += n; return; }
       for (int i = 0; i < n; i++) { int32_t g = group_keys[i]; if (g != PO_INVALID_ID) a->d0[g] += 1; }
       return;
@@ -498,6 +512,19 @@ static void agg_process_block(agg_state* a, block_col* bc, const int32_t* doc_id
     case PG_AGG_DISTINCTCOUNT:
     case PG_AGG_DISTINCTCOUNTHLL: {
       po_column* c = a->col;
+      if (c->data_type == PG_TYPE_BYTES) { /* serialized HyperLogLog (star-tree pair): DistinctCountHLLAggregationFunction.java:158-175 */
+        for (int i = 0; i < n; i++) {
+          int32_t g = group_keys ? group_keys[i] : 0;
+          if (g == PO_INVALID_ID) continue;
+          int32_t len = 0;
+          const uint8_t* blob = po_raw_get_bytes(c, doc_ids[i], &len);
+          po_hll* v = po_hll_deserialize(blob, len);
+          if (!v) continue;
+          if (a->hlls[g]) { po_hll_merge(a->hlls[g], v); po_hll_free(v); }   /* hyperLogLog.addAll(value) */
+          else a->hlls[g] = v;
+        }
+        return;
+      }
       if (c->has_dictionary) {
         fetch_dict_ids(bc, doc_ids, n);
         for (int i = 0; i < n; i++) {
@@ -647,10 +674,11 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
   res->n_group_cols = n_gb;
   res->stats.num_total_docs = seg->total_docs;
   res->stats.stats_exact = 1;
+  res->stats.star_tree_index = -1;
 
   /* resolve columns */
   agg_state* aggs = (agg_state*)po_xcalloc((size_t)n_aggs, sizeof(agg_state));
-  po_column** proj = (po_column**)po_xcalloc((size_t)(n_aggs + n_gb) + 1, sizeof(po_column*));
+  po_column** proj = (po_column**)po_xcalloc((size_t)(n_aggs + n_gb) * 2 + 1, sizeof(po_column*));
   int n_proj = 0;
   for (int i = 0; i < n_aggs; i++) {
     const pg_agg_spec* s = &q->aggregations[i];
@@ -692,6 +720,38 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
     res->stats.host_ms_total = (float)(now_ms() - t0);
     *out = res;
     return PG_OK;
+  }
+
+  /* AggregationFunctionUtils#buildAggregationInfo (:285-307): use a star-tree when the filter result is not empty and one
+   * fits (StarTreeUtils#createStarTreeBasedProjectOperator); the operators then run over the star-tree's doc space. */
+  if (!(q->flags & PG_QUERY_FLAG_SKIP_STAR_TREE) && filter_op->kind != PO_OP_EMPTY) {
+    for (int t = 0; t < seg->n_star_trees; t++) {
+      po_star_tree* st = seg->star_trees[t];
+      po_filter_op* star_op = NULL;
+      int fit = po_star_tree_plan(seg, st, q, &star_op);
+      if (fit < 0) return fit;
+      if (!fit) continue;
+      res->stats.star_tree_index = t;
+      filter_op = star_op;
+      n_proj = 0;
+      for (int i = 0; i < n_aggs; i++) {     /* StarTreeProjectPlanNode: function-column pair columns + group-by columns */
+        const pg_agg_spec* s = &q->aggregations[i];
+        po_column* c = st->pair_cols[po_star_tree_pair_index(st, s->function, s->column)];
+        aggs[i].col = c;
+        aggs[i].star = 1;
+        int seen = 0;
+        for (int k = 0; k < n_proj; k++) seen |= (proj[k] == c);
+        if (!seen) proj[n_proj++] = c;
+      }
+      for (int j = 0; j < n_gb; j++) {
+        po_column* c = po_segment_column(st->space, q->group_by_columns[j]);
+        gcols[j] = c;
+        int seen = 0;
+        for (int k = 0; k < n_proj; k++) seen |= (proj[k] == c);
+        if (!seen) proj[n_proj++] = c;
+      }
+      break;
+    }
   }
 
   /* group key generator + holders (DefaultGroupByExecutor ctor, groupby/DefaultGroupByExecutor.java:79-140) */

@@ -137,6 +137,28 @@ int64_t po_raw_get_long(const po_column* c, int32_t d) { return (int64_t)po_be64
 float po_raw_get_float(const po_column* c, int32_t d) { return po_bef32(c->raw_data + (int64_t)d * 4); }
 double po_raw_get_double(const po_column* c, int32_t d) { return po_bef64(c->raw_data + (int64_t)d * 8); }
 
+/* VarByteChunkSVForwardIndexReader#getBytesUncompressed (:158-217): chunk = numDocsPerChunk BE int offsets relative to the
+ * chunk start (0 for the absent rows of the last chunk), then the values */
+const uint8_t* po_raw_get_bytes(const po_column* c, int32_t doc_id, int32_t* len) {
+  const uint8_t* b = c->fwd;
+  int32_t chunk = doc_id / c->raw_docs_per_chunk, row = doc_id % c->raw_docs_per_chunk;
+  int off_size = c->raw_version <= 2 ? 4 : 8;
+  const uint8_t* offs = c->raw_data - (int64_t)c->raw_num_chunks * off_size;   /* chunk position table */
+  int64_t chunk_start = off_size == 4 ? (int64_t)(int32_t)po_be32(offs + (int64_t)chunk * 4) : (int64_t)po_be64(offs + (int64_t)chunk * 8);
+  int64_t chunk_end = chunk == c->raw_num_chunks - 1
+                          ? (int64_t)c->fwd_len
+                          : (off_size == 4 ? (int64_t)(int32_t)po_be32(offs + (int64_t)(chunk + 1) * 4) : (int64_t)po_be64(offs + (int64_t)(chunk + 1) * 8));
+  int64_t start = chunk_start + (int32_t)po_be32(b + chunk_start + (int64_t)row * 4);
+  int64_t end;
+  if (row == c->raw_docs_per_chunk - 1) end = chunk_end;
+  else {
+    int32_t nxt = (int32_t)po_be32(b + chunk_start + (int64_t)(row + 1) * 4);
+    end = nxt == 0 ? chunk_end : chunk_start + nxt;
+  }
+  *len = (int32_t)(end - start);
+  return b + start;
+}
+
 /* ---- SortedIndexReaderImpl, pinot-segment-local/.../readers/sorted/SortedIndexReaderImpl.java:35-110 ----------------- */
 void po_sorted_get_doc_ids(const po_column* c, int32_t dict_id, int32_t* start, int32_t* end) {
   *start = (int32_t)po_be32(c->fwd + (int64_t)dict_id * 8);

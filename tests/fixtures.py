@@ -19,3 +19,56 @@ SV_FILTER = (" WHERE column1 > 100000000"
 def sv_segment(sv_data, name="testTable_126164076_167572854"):
     data = {k: (v.tolist() if v.dtype.kind == "U" else v) for k, v in sv_data.items()}
     return build_segment(name, data, SV_SCHEMA, inverted_index_columns=SV_INVERTED)
+
+
+# ---- the reference's star-tree fixture as a queryable segment ---------------------------------------------------------
+def airline_star_segment():
+    """tests/golden/startree_airline (a star-tree built by the reference) + a parent segment reconstructed from its base
+    docs: every base doc repeated count__* times with ArrDelay = its max__ArrDelay (the aggregates of the reconstruction
+    equal the original's).  The fixture holds no dictionaries, so the dimensions get identity INT dictionaries
+    (value == dictId)."""
+    import json
+    import os
+    from pinot_amd import formats, startree
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "startree_airline")
+    meta = json.load(open(os.path.join(golden, "meta.json")))
+    blob = np.fromfile(os.path.join(golden, "star_tree_index"), dtype=np.uint8)
+    im = meta["index_map"]
+
+    def entry(col, kind):
+        off, size = im[f"0.{col}.{kind}.OFFSET"], im[f"0.{col}.{kind}.SIZE"]
+        return blob[off:off + size].copy()
+    n = meta["total_docs"]
+    dims = meta["split_order"]
+    names, nodes = formats.read_star_tree(entry("null", "STAR_TREE"))
+    dim_ids = np.stack([formats.unpack_fixed_bit(entry(d, "FORWARD_INDEX"), meta["columns"][d]["bitsPerElement"], n)
+                        for d in dims], axis=1)
+    h = formats.parse_raw_fixed_byte_chunk_header(entry("count__*", "FORWARD_INDEX"))
+    counts = np.frombuffer(bytes(entry("count__*", "FORWARD_INDEX")), dtype=">i8", count=n, offset=h["raw_data_start"]).astype(np.int64)
+    maxes = np.frombuffer(bytes(entry("max__ArrDelay", "FORWARD_INDEX")), dtype=">f8", count=n, offset=h["raw_data_start"])
+    root_kids = nodes[nodes[0][5]:nodes[0][6] + 1]
+    n_base = int(max(k[3] for k in root_kids if k[1] != -1))
+    rep = counts[:n_base]
+    data = {d: np.repeat(dim_ids[:n_base, j], rep).astype(np.int32) for j, d in enumerate(dims)}
+    data["ArrDelay"] = np.repeat(maxes[:n_base].astype(np.int64), rep).astype(np.int32)
+    # shuffle the parent docs (a real segment is not sorted by the split order)
+    perm = np.random.default_rng(11).permutation(len(data["ArrDelay"]))
+    data = {k: v[perm] for k, v in data.items()}
+    seg = build_segment(meta["segment_name"], data, {d: "INT" for d in dims + ["ArrDelay"]})
+    for d in dims:   # identity dictionaries of the fixture's cardinality, so that dictIds are the fixture's
+        card = meta["columns"][d]["cardinality"]
+        col = seg.columns[d]
+        col.cardinality = card
+        col.bits_per_value = formats.num_bits_per_value(card - 1)
+        col.dictionary = formats.write_numeric_dictionary(np.arange(card, dtype=np.int32), "INT")
+        col.dict_values = list(range(card))
+        col.forward_index = formats.pack_fixed_bit(data[d], col.bits_per_value)
+        col.fwd_encoding = 0
+        col.is_sorted = False
+    st = startree.HostStarTree(
+        n, dims, [entry(d, "FORWARD_INDEX") for d in dims],
+        [startree.StarTreePair("COUNT", "*", entry("count__*", "FORWARD_INDEX"), counts.tolist()),
+         startree.StarTreePair("MAX", "ArrDelay", entry("max__ArrDelay", "FORWARD_INDEX"), maxes.tolist())],
+        entry("null", "STAR_TREE"), meta["max_leaf_records"], dim_ids, n_base)
+    seg.star_trees.append(st)
+    return seg, meta

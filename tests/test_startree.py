@@ -124,3 +124,75 @@ def test_java_hashmap_iteration_order():
     # capacity 16: 17 and 1 share bucket 1 in insertion order
     keys = [1, 5, 17]
     assert [keys[i] for i in startree._java_hashmap_order(keys)] == [1, 17, 5]
+
+
+# ---- queries on the reference-built star-tree: star-tree path == non-star-tree path (BaseStarTreeV2Test.java:216-235) ------
+from pinot_amd import capi  # noqa: E402
+from pinot_amd.executor import NativeSegment  # noqa: E402
+from pinot_amd.query import parse_sql  # noqa: E402
+from tests.fixtures import airline_star_segment  # noqa: E402
+
+AIRLINE_QUERIES = [
+    # (sql, uses the star-tree?)
+    ("SELECT COUNT(*), MAX(ArrDelay) FROM t", True),
+    ("SELECT COUNT(*) FROM t GROUP BY AirlineID", True),
+    ("SELECT COUNT(*), MAX(ArrDelay) FROM t GROUP BY Origin", True),
+    ("SELECT MAX(ArrDelay) FROM t GROUP BY Dest", True),
+    ("SELECT COUNT(*), MAX(ArrDelay) FROM t GROUP BY AirlineID, Dest", True),
+    ("SELECT COUNT(*), MAX(ArrDelay) FROM t GROUP BY Dest, Origin, AirlineID", True),
+    ("SELECT COUNT(*), MAX(ArrDelay) FROM t WHERE AirlineID = 3", True),
+    ("SELECT COUNT(*), MAX(ArrDelay) FROM t WHERE AirlineID IN (1, 4, 9) GROUP BY Origin", True),
+    ("SELECT COUNT(*) FROM t WHERE Origin BETWEEN 10 AND 60 GROUP BY AirlineID", True),
+    ("SELECT COUNT(*), MAX(ArrDelay) FROM t WHERE Dest > 50", True),
+    ("SELECT COUNT(*), MAX(ArrDelay) FROM t WHERE Dest > 50 AND Origin < 40", True),
+    ("SELECT COUNT(*) FROM t WHERE Dest != 7 GROUP BY Dest", True),
+    ("SELECT COUNT(*) FROM t WHERE NOT AirlineID IN (0, 2, 5)", True),
+    ("SELECT COUNT(*), MAX(ArrDelay) FROM t WHERE Origin = 5 OR Origin > 80 GROUP BY AirlineID", True),
+    ("SELECT COUNT(*) FROM t WHERE AirlineID NOT IN (0, 1) AND Dest IN (3, 30, 60, 90) AND Origin >= 20 GROUP BY Dest", True),
+    ("SELECT COUNT(*), MAX(ArrDelay) FROM t WHERE AirlineID >= 0", True),      # always-true predicate is dropped
+    ("SELECT COUNT(*) FROM t WHERE AirlineID >= 0", False),                    # FastFilteredCountOperator comes first
+    ("SELECT COUNT(*), MAX(ArrDelay) FROM t WHERE AirlineID = 3 OR Dest = 4", False),   # OR over two columns
+    ("SELECT COUNT(*), MAX(ArrDelay) FROM t WHERE ArrDelay > 0", False),       # predicate column is not a dimension
+    ("SELECT SUM(ArrDelay) FROM t GROUP BY AirlineID", False),                # sum__ArrDelay is not in the tree
+    ("SELECT COUNT(*) FROM t WHERE NOT (AirlineID = 3 AND Dest = 4)", False),  # AND nested under NOT
+]
+
+
+@pytest.fixture(scope="module")
+def airline(oracle_api):
+    host, meta = airline_star_segment()
+    seg = NativeSegment(oracle_api, host)
+    yield seg, host, meta
+    seg.destroy()
+
+
+def run_both(seg, sql):
+    star = seg.execute(parse_sql(sql))
+    qc = parse_sql(sql)
+    qc.flags |= capi.QUERY_FLAG_SKIP_STAR_TREE
+    plain = seg.execute(qc)
+    return star, plain
+
+
+def test_oracle_known_answers_on_reference_star_tree(airline):
+    seg, host, meta = airline
+    b = seg.execute("SELECT COUNT(*), MAX(ArrDelay) FROM t")
+    assert b.aggregation_result() == [313, 343.0]
+    st = b.stats
+    # every dimension is starred: exactly the root's aggregated document is read
+    assert (st.star_tree_index, st.num_docs_scanned, st.num_entries_scanned_in_filter, st.num_total_docs) == (0, 1, 0, 313)
+    assert st.num_entries_scanned_post_filter == 2            # count__* and max__ArrDelay of one doc
+    b = seg.execute("SELECT COUNT(*) FROM t GROUP BY AirlineID")
+    assert sum(v[0] for v in b.rows().values()) == 313 and len(b.rows()) == meta["columns"]["AirlineID"]["cardinality"]
+
+
+@pytest.mark.parametrize("sql,uses_star", AIRLINE_QUERIES)
+def test_oracle_star_tree_equals_plain_path(airline, sql, uses_star):
+    seg, host, meta = airline
+    star, plain = run_both(seg, sql)
+    assert plain.stats.star_tree_index == -1
+    assert star.stats.star_tree_index == (0 if uses_star else -1)
+    assert star.rows() == plain.rows()
+    assert star.stats.num_total_docs == plain.stats.num_total_docs == 313
+    if uses_star:
+        assert star.stats.num_docs_scanned <= meta["total_docs"]
