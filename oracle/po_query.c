@@ -124,6 +124,7 @@ int32_t po_filter_exec(void* segp, const pg_filter_node* filter, void** out) {
   r->stats.num_entries_scanned_in_filter = set->num_entries_scanned(set);
   r->stats.num_total_docs = seg->total_docs;
   r->stats.stats_exact = 1;
+  r->stats.star_tree_index = -1;
   *out = r;
   return PG_OK;
 }

@@ -473,6 +473,12 @@ int po_star_tree_plan(po_segment* seg, po_star_tree* st, const pg_query* q, po_f
   po_bitmap* docs = traverse_star_tree(seg, st, &pm, &gb, &remaining);
   int32_t num_docs = st->num_docs;
   if (!docs) { *out_op = po_op_new(PO_OP_EMPTY, num_docs); return 1; }   /* EmptyFilterOperator */
+  for (int i = 1; i < remaining.n; i++) {   /* deterministic order inside a hash bucket: by name */
+    const char* key = remaining.names[i];
+    int j = i - 1;
+    while (j >= 0 && strcmp(remaining.names[j], key) > 0) { remaining.names[j + 1] = remaining.names[j]; j--; }
+    remaining.names[j + 1] = key;
+  }
   java_hashset_order(remaining.names, remaining.n);
   int cap = 1;
   for (int i = 0; i < remaining.n; i++) for (int k = 0; k < pm.n; k++) if (strcmp(pm.cols[k].column, remaining.names[i]) == 0) cap += pm.cols[k].n;

@@ -75,6 +75,15 @@ int32_t pg_segment_add_column(pg_segment_t segment, const pg_column_desc* column
   });
 }
 
+int32_t pg_segment_add_star_tree(pg_segment_t segment, const pg_star_tree_desc* star_tree) {
+  return guarded([&] {
+    REQUIRE(segment && star_tree, "null argument");
+    std::lock_guard<std::mutex> g(segment->seg.mu);
+    segment_add_star_tree(segment->seg, *star_tree);
+    segment->seg.plan_cache.clear();
+  });
+}
+
 int32_t pg_segment_num_docs(pg_segment_t segment, int32_t* out_num_docs) {
   return guarded([&] { REQUIRE(segment && out_num_docs, "null argument"); *out_num_docs = segment->seg.total_docs; });
 }

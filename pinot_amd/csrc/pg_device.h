@@ -48,7 +48,10 @@ struct PgFInstr {
   int32_t arg;   // leaf index
 };
 
-enum PgColKind : int32_t { PG_COL_FIXED_BIT = 0, PG_COL_RAW32 = 1, PG_COL_RAW64 = 2 };
+enum PgColKind : int32_t {
+  PG_COL_FIXED_BIT = 0, PG_COL_RAW32 = 1, PG_COL_RAW64 = 2,
+  PG_COL_HLL_REGS = 3   // star-tree DISTINCTCOUNTHLL pair: one byte per register, 2^bits registers per doc (transcoded at upload)
+};
 enum PgValType : int32_t { PG_V_I32 = 0, PG_V_I64 = 1, PG_V_F32 = 2, PG_V_F64 = 3 };
 
 enum PgPredKind : int32_t {
@@ -97,6 +100,7 @@ struct PgPostingLeaf {
 struct PgRangeLeaf {
   const int32_t* lo;   // inclusive
   const int32_t* hi;   // inclusive
+  const uint32_t* words;   // non-null: the doc set as match words instead (one dword per 32 docs, whole wave tiles)
   int32_t n;
   int32_t pad;
 };
@@ -141,7 +145,9 @@ struct PgAccOp {
 //                    offers dictionary.get(dictId) for each dictId of the group's bitmap — register max is idempotent, so
 //                    offering every doc's value gives the same registers)
 //   PG_AUX_HLL_RAW   DISTINCTCOUNTHLL over a raw column: hll.offer(value) per doc (:188-221), MurmurHash.hashLong on device
-enum PgAuxKind : int32_t { PG_AUX_DICT_SET = 0, PG_AUX_HLL_DICT = 1, PG_AUX_HLL_RAW = 2 };
+//   PG_AUX_HLL_BYTES DISTINCTCOUNTHLL over a star-tree pair column of serialized HyperLogLogs: register-wise max of the doc's
+//                    registers into the group's (HyperLogLog#addAll, DistinctCountHLLAggregationFunction.java:158-175)
+enum PgAuxKind : int32_t { PG_AUX_DICT_SET = 0, PG_AUX_HLL_DICT = 1, PG_AUX_HLL_RAW = 2, PG_AUX_HLL_BYTES = 3 };
 #define PG_MAX_AUX 4
 struct PgAuxOp {
   int32_t kind;

@@ -227,7 +227,8 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   uint8_t* aux_host = reinterpret_cast<uint8_t*>(host_out) + out_bytes;
   if (profile) PG_HIP(hipEventRecord(ctx.ev[0], ctx.stream));
   const char* kname = "";
-  if (seg.total_docs > 0) {
+  const bool has_docs = P.space_docs > 0;   // docs of the doc space the plan runs on (the segment's or a star-tree's)
+  if (has_docs) {
     QueryKernel kern = select_kernel(P, D.agg_mode, &kname);
     hipLaunchKernelGGL(kern, dim3(shape.grid), dim3(shape.block), shape.lds, ctx.stream, D);
     PG_HIP(hipGetLastError());
@@ -235,7 +236,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   if (profile) PG_HIP(hipEventRecord(ctx.ev[1], ctx.stream));
   std::vector<int64_t> table((size_t)n_out);
   uint64_t stats_host[PG_MAX_STATS] = {0};
-  if (seg.total_docs > 0) {
+  if (has_docs) {
     const int reduce = (D.agg_mode != PG_AGG_GLOBAL && n_out > 0) ? 1 : 0;
     const int blocks = (reduce ? (int)((n_out + 3) / 4) : 0) + 1;   // one wavefront per output slot + the stats block
     hipLaunchKernelGGL(pg_reduce_partials_kernel, dim3(blocks), dim3(256), 0, ctx.stream, ctx.partials.as<int64_t>(),
@@ -259,6 +260,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
 
   auto res = std::make_unique<Result>();
   fill_stats(res->stats, P, seg, stats_host);
+  res->stats.star_tree_index = P.star_tree_index;
   snprintf(res->stats.kernel, sizeof(res->stats.kernel), "%s", kname);
   if (profile) {
     float a = 0, b = 0;
@@ -409,6 +411,7 @@ std::unique_ptr<DocIdSet> execute_filter(Segment& seg, const pg_filter_node* fil
   PG_HIP(hipMemcpyAsync(out->tile_counts.data(), ctx.tile_counts.ptr, out->tile_counts.size() * 4, hipMemcpyDeviceToHost, ctx.stream));
   PG_HIP(hipStreamSynchronize(ctx.stream));
   fill_stats(out->stats, P, seg, stats_host);
+  out->stats.star_tree_index = -1;
   snprintf(out->stats.kernel, sizeof(out->stats.kernel), "%s", kname);
   out->stats.num_entries_scanned_post_filter = 0;
   out->cardinality = (int64_t)stats_host[0];

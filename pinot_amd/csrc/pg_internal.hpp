@@ -87,9 +87,11 @@ struct Column {
   DeviceBuffer containers_dev, descs_dev;
   uint64_t fwd_bytes_logical = 0;               // bytes of the forward index proper (for algorithmic byte accounting)
   std::map<int, DeviceBuffer> hll_luts;         // per log2m: (register index | rank << 16) of every dictionary value
+  int32_t hll_log2m = 0;                        // PG_COL_HLL_REGS: log2m of the serialized HyperLogLogs
 };
 
 struct CompiledPlan;
+struct StarTree;
 
 struct Segment {
   std::string name;
@@ -99,10 +101,31 @@ struct Segment {
   uint64_t device_bytes = 0;
   std::mutex mu;
   std::unordered_map<std::string, std::shared_ptr<CompiledPlan>> plan_cache;
+  std::vector<std::unique_ptr<StarTree>> star_trees;   // IndexSegment#getStarTrees
   Column* find(const char* name);
+  Segment();
+  ~Segment();
+};
+
+// StarTreeV2 (pinot-segment-local/.../startree/v2/store/StarTreeLoaderUtils.java:53-128): the tree (host), and the star-tree
+// docs as a doc space of their own — dimension columns (fixed-bit dictIds of the parent's dictionaries) and one column per
+// function-column pair, pinned in HBM like any other column.
+struct StarTreePair {
+  int32_t function = 0;      // pg_agg_function
+  std::string column;        // "*" for COUNT
+  Column* col = nullptr;     // column of `space` named AggregationFunctionColumnPair#toColumnName
+};
+struct StarTree {
+  Segment space;
+  std::vector<std::string> dims;
+  std::vector<StarTreePair> pairs;
+  std::vector<int32_t> nodes;   // 7 ints per node (OffHeapStarTreeNode), native endian
+  int32_t n_nodes = 0;
+  int pair_index(int32_t function, const char* column) const;
 };
 
 void segment_add_column(Segment& seg, const pg_column_desc& d);
+void segment_add_star_tree(Segment& seg, const pg_star_tree_desc& d);
 
 // ---- predicate evaluation (host): PredicateEvaluatorProvider & factories ---------------------------------------------------
 struct PredEval {
@@ -125,14 +148,24 @@ struct PredEval {
 PredEval make_pred_eval(const pg_filter_node& p, const Column& col);
 
 // ---- compiled plan ------------------------------------------------------------------------------------------------------------
-enum class OpKind { Empty, MatchAll, Scan, Inverted, Sorted, And, Or, Not };
+enum class OpKind { Empty, MatchAll, Scan, Inverted, Sorted, And, Or, Not, Bitmap };
 
 struct FilterOp {
   OpKind kind = OpKind::Empty;
   PredEval eval;
   Column* col = nullptr;
   std::vector<std::unique_ptr<FilterOp>> children;
+  std::vector<int32_t> range_lo, range_hi;   // Bitmap (BitmapBasedFilterOperator): ascending disjoint inclusive docId ranges
 };
+using OpPtr = std::unique_ptr<FilterOp>;
+OpPtr make_filter_op(OpKind k);
+OpPtr and_operator(std::vector<OpPtr> ops);
+OpPtr or_operator(std::vector<OpPtr> ops);
+OpPtr not_operator(OpPtr child);
+OpPtr leaf_operator(PredEval ev, Column* col, int32_t predicate_type);
+// StarTreeUtils#createStarTreeBasedProjectOperator + StarTreeFilterOperator: the filter over the star-tree docs when the
+// query is fit for the star-tree, nullptr otherwise
+OpPtr star_tree_filter(Segment& seg, StarTree& st, const pg_filter_node* filter, const pg_query& q);
 
 enum class ResultKind { Long, Double, AvgPair, MinMaxPair };
 
@@ -142,6 +175,7 @@ struct AggOut {          // how one requested aggregation maps onto accumulator 
   int32_t function;
   int32_t op_a = -1, op_b = -1;   // indices into ops (AVG: sum,count; MINMAXRANGE: min,max; COUNT: count op)
   bool is_float = false;
+  bool star_count = false;         // COUNT over a star-tree: op_a is the SUM of count__* (CountAggregationFunction.java:99-106)
   int32_t aux = -1;                // DISTINCTCOUNT / DISTINCTCOUNTHLL: index into PgQueryPlan::aux
   int32_t log2m = 0;
   Column* aux_col = nullptr;
@@ -167,6 +201,9 @@ struct CompiledPlan {
   bool fast_agg = true;              // aggregation fits the fast kernels (or there is none)
   DeviceBuffer ops_dev;
   std::vector<size_t> aux_bytes;     // bytes of each auxiliary region (256-byte multiples)
+  int32_t star_tree_index = -1;      // the star-tree whose doc space the plan runs on
+  int32_t space_docs = 0;            // docs of that doc space (the segment's own when no star-tree is used)
+  bool non_scan_based = false;       // NonScanBasedAggregationOperator: answered from dictionaries on the host
 };
 
 std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* filter, const pg_query* query);

@@ -369,6 +369,7 @@ DEVFN uint32_t postings_wtile(const LeafT& L, int wtile, uint32_t valid_lin, uin
 // docId ranges (sorted index / match-all), linear layout
 template <class LeafT>
 DEVFN uint32_t ranges_wtile(const LeafT& L, int64_t wbase, uint32_t valid_lin, int lane) {
+  if (L.words) return gptr<uint32_t>(L.words)[(wbase / PG_WAVE_DOCS) * 64 + lane] & valid_lin;   // wave-uniform branch
   const int64_t wb = wbase + (int64_t)lane * 32, we = wb + 31;
   const int64_t tile_end = wbase + PG_WAVE_DOCS - 1;
   int a = 0, b = L.n;   // first range whose hi >= wbase (ranges ascending, disjoint)
@@ -433,6 +434,15 @@ DEVFN void set_add(uint32_t* words, uint32_t id) {
   const uint32_t bit = 1u << (id & 31u);
   if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(w, bit);
 }
+DEVFN uint32_t bytemax4(uint32_t a, uint32_t b) {   // per-byte unsigned max (four HyperLogLog registers)
+  uint32_t r = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const uint32_t x = (a >> (8 * k)) & 0xFFu, y = (b >> (8 * k)) & 0xFFu;
+    r |= (x > y ? x : y) << (8 * k);
+  }
+  return r;
+}
 DEVFN void hll_update(uint8_t* regs, uint32_t idx, uint32_t rank) {
   uint32_t* w = reinterpret_cast<uint32_t*>(regs + (idx & ~3u));
   const uint32_t sh = (idx & 3u) * 8u;
@@ -454,7 +464,7 @@ DEVFN void aggregate_wtile(const PgQueryPlan& p, uint32_t m, int wtile, int64_t*
 #pragma unroll
   for (int k0 = 0; k0 < 8; k0 += B) {
     const uint32_t mb = B == 8 ? m : ((m >> (4 * k0)) & ((1u << (4 * (B & 7))) - 1u));
-    if (mb == 0) continue;
+    if (__ballot(mb != 0) == 0) continue;   // wave-uniform: the HLL-bytes merge below needs every lane of the wavefront
     uint32_t slot[B][4];
 #pragma unroll
     for (int u = 0; u < B; u++)
@@ -612,7 +622,38 @@ DEVFN void aggregate_wtile(const PgQueryPlan& p, uint32_t m, int wtile, int64_t*
       PgAuxOp A = p.aux[xa];
       A.base = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(A.base) + (size_t)(blockIdx.x & (uint32_t)(A.n_rep - 1)) * (size_t)A.rep_bytes);
       const PgValueSrc& S = p.srcs[A.src];
-      if (S.col_kind == PG_COL_FIXED_BIT) {
+      if (A.kind == PG_AUX_HLL_BYTES) {
+        // Serialized HyperLogLogs of a star-tree pair column (one byte per register after upload): HyperLogLog#addAll = register-wise
+        // max.  One matching doc at a time, the whole wavefront on its registers: lane L merges dwords L, L+64, ... of the doc
+        // into the group's registers (read first, CAS only where a register grows).
+        const uint32_t n_dw = (uint32_t)A.stride >> 2;
+        const GAS uint8_t* src = gptr<uint8_t>(S.data);
+#pragma unroll
+        for (int u = 0; u < B; u++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            unsigned long long ball = __ballot((mb >> (4 * u + i)) & 1u);
+            while (ball) {
+              const int l = __builtin_ctzll(ball);
+              ball &= ball - 1;
+              const size_t g = (size_t)((uint32_t)__builtin_amdgcn_readlane((int)slot[u][i], l) >> p.replica_shift);
+              const int64_t doc = (int64_t)wtile * PG_WAVE_DOCS + 4 * ((k0 + u) * 64 + l) + i;
+              const GAS uint32_t* sw = (const GAS uint32_t*)(src + doc * (int64_t)A.stride);
+              uint32_t* dst = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(A.base) + g * (size_t)A.stride);
+              for (uint32_t w = (uint32_t)lane; w < n_dw; w += 64) {
+                const uint32_t v = sw[w];
+                uint32_t cur = __hip_atomic_load(dst + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (;;) {
+                  const uint32_t nv = bytemax4(cur, v);
+                  if (nv == cur) break;
+                  const uint32_t prev = atomicCAS(dst + w, cur, nv);
+                  if (prev == cur) break;
+                  cur = prev;
+                }
+              }
+            }
+          }
+      } else if (S.col_kind == PG_COL_FIXED_BIT) {
         const GAS uint32_t* tw = packed_wtile_base(S.data, wtile, S.bits);
         const uint32_t bits = (uint32_t)S.bits, mask = (1u << S.bits) - 1u;
         uint32_t d[B][4];

@@ -220,13 +220,14 @@ PredEval make_pred_eval(const pg_filter_node& p, const Column& col) {
 // =====================================================================================================================
 // physical filter operators
 // =====================================================================================================================
-using OpPtr = std::unique_ptr<FilterOp>;
-static OpPtr make_op(OpKind k) { auto o = std::make_unique<FilterOp>(); o->kind = k; return o; }
+OpPtr make_filter_op(OpKind k) { auto o = std::make_unique<FilterOp>(); o->kind = k; return o; }
+static OpPtr make_op(OpKind k) { return make_filter_op(k); }
 
 static int priority(const FilterOp& op) {   // PrioritizedFilterOperator.java:31-38
   switch (op.kind) {
     case OpKind::Sorted: return 0;
     case OpKind::Inverted: return 100;
+    case OpKind::Bitmap: return 100;   // BitmapBasedFilterOperator: MEDIUM_PRIORITY
     case OpKind::And: return 300;
     case OpKind::Or: return 400;
     case OpKind::Not: return priority(*op.children[0]);
@@ -235,7 +236,7 @@ static int priority(const FilterOp& op) {   // PrioritizedFilterOperator.java:31
   }
 }
 
-static OpPtr and_operator(std::vector<OpPtr> ops) {   // getAndFilterOperator
+OpPtr and_operator(std::vector<OpPtr> ops) {   // getAndFilterOperator
   std::vector<OpPtr> ch;
   for (auto& o : ops) {
     if (o->kind == OpKind::Empty) return make_op(OpKind::Empty);
@@ -248,7 +249,7 @@ static OpPtr and_operator(std::vector<OpPtr> ops) {   // getAndFilterOperator
   r->children = std::move(ch);
   return r;
 }
-static OpPtr or_operator(std::vector<OpPtr> ops) {    // getOrFilterOperator
+OpPtr or_operator(std::vector<OpPtr> ops) {    // getOrFilterOperator
   std::vector<OpPtr> ch;
   for (auto& o : ops) {
     if (o->kind == OpKind::MatchAll) return make_op(OpKind::MatchAll);
@@ -260,12 +261,26 @@ static OpPtr or_operator(std::vector<OpPtr> ops) {    // getOrFilterOperator
   r->children = std::move(ch);
   return r;
 }
-static OpPtr not_operator(OpPtr child) {              // getNotFilterOperator
+OpPtr not_operator(OpPtr child) {              // getNotFilterOperator
   if (child->kind == OpKind::MatchAll) return make_op(OpKind::Empty);
   if (child->kind == OpKind::Empty) return make_op(OpKind::MatchAll);
   auto r = make_op(OpKind::Not);
   r->children.push_back(std::move(child));
   return r;
+}
+
+// FilterOperatorUtils.DefaultImplementation#getLeafFilterOperator (:74-133): Sorted > Inverted > Scan; RANGE skips the inverted index
+OpPtr leaf_operator(PredEval ev, Column* col, int32_t predicate_type) {
+  if (ev.always_false) return make_op(OpKind::Empty);
+  if (ev.always_true) return make_op(OpKind::MatchAll);
+  const bool sorted_ok = col->is_sorted && col->has_dictionary && !col->sorted_start.empty();
+  OpKind k;
+  if (predicate_type == PG_PRED_RANGE) k = sorted_ok ? OpKind::Sorted : OpKind::Scan;
+  else k = sorted_ok ? OpKind::Sorted : (col->has_inverted ? OpKind::Inverted : OpKind::Scan);
+  auto op = make_op(k);
+  op->eval = std::move(ev);
+  op->col = col;
+  return op;
 }
 
 static OpPtr construct(Segment& seg, const pg_filter_node& f) {   // FilterPlanNode#constructPhysicalOperator
@@ -283,17 +298,7 @@ static OpPtr construct(Segment& seg, const pg_filter_node& f) {   // FilterPlanN
     case PG_FILTER_PREDICATE: {
       Column* col = seg.find(f.column);
       if (!col) fail(PG_ERR_NOT_FOUND, "column not found: %s", f.column ? f.column : "(null)");
-      PredEval ev = make_pred_eval(f, *col);
-      if (ev.always_false) return make_op(OpKind::Empty);     // getLeafFilterOperator :77-90
-      if (ev.always_true) return make_op(OpKind::MatchAll);
-      const bool sorted_ok = col->is_sorted && col->has_dictionary && !col->sorted_start.empty();
-      OpKind k;
-      if (f.predicate_type == PG_PRED_RANGE) k = sorted_ok ? OpKind::Sorted : OpKind::Scan;
-      else k = sorted_ok ? OpKind::Sorted : (col->has_inverted ? OpKind::Inverted : OpKind::Scan);
-      auto op = make_op(k);
-      op->eval = std::move(ev);
-      op->col = col;
-      return op;
+      return leaf_operator(make_pred_eval(f, *col), col, f.predicate_type);
     }
     case PG_FILTER_CONSTANT_TRUE: return make_op(OpKind::MatchAll);
     case PG_FILTER_CONSTANT_FALSE: return make_op(OpKind::Empty);
@@ -316,6 +321,7 @@ struct Emitter {
   std::vector<Column*> scanned_cols;
 
   void push() { sp++; max_sp = std::max(max_sp, sp); }
+  int64_t plan_wtiles() const { return ((int64_t)seg.total_docs + PG_WAVE_DOCS - 1) / PG_WAVE_DOCS; }
   template <typename T> const T* keep(const std::vector<T>& v) {
     plan.keep.push_back(upload_vector(v));
     return plan.keep.back().as<T>();
@@ -324,6 +330,18 @@ struct Emitter {
   void emit_ranges(std::vector<int32_t> lo, std::vector<int32_t> hi) {
     PgRangeLeaf L{};
     L.n = (int32_t)lo.size();
+    if (lo.size() > 64) {   // many ranges (star-tree traversals): hand the kernels match words instead of a range list
+      std::vector<uint32_t> words((size_t)plan_wtiles() * 64 + 64, 0);
+      for (size_t r = 0; r < lo.size(); r++)
+        for (int64_t d = lo[r]; d <= hi[r];) {
+          const int64_t w = d >> 5;
+          const int64_t last = std::min<int64_t>(hi[r], w * 32 + 31);
+          words[(size_t)w] |= (0xFFFFFFFFu << (d & 31)) & (0xFFFFFFFFu >> (31 - (last & 31)));
+          d = last + 1;
+        }
+      L.words = keep(words);
+      alg_bytes += ((int64_t)seg.total_docs + 7) / 8;
+    }
     L.lo = keep(lo);
     L.hi = keep(hi);
     ranges.push_back(L);
@@ -470,6 +488,7 @@ struct Emitter {
       case OpKind::Empty: instrs.push_back({PG_F_PUSH_NONE, 0}); push(); break;
       case OpKind::MatchAll: instrs.push_back({PG_F_PUSH_ALL, 0}); push(); break;
       case OpKind::Sorted: emit_sorted(op); break;
+      case OpKind::Bitmap: emit_ranges(op.range_lo, op.range_hi); break;
       case OpKind::Inverted: emit_inverted(op); break;
       case OpKind::Scan: emit_scan(op, false); break;
       case OpKind::Not:
@@ -491,7 +510,7 @@ struct Emitter {
         // the remaining (nested) children are intersected last.
         std::vector<const FilterOp*> index_based, scan_based, remaining;
         for (auto& c : op.children) {
-          if (c->kind == OpKind::Sorted || c->kind == OpKind::Inverted) index_based.push_back(c.get());
+          if (c->kind == OpKind::Sorted || c->kind == OpKind::Inverted || c->kind == OpKind::Bitmap) index_based.push_back(c.get());
           else if (c->kind == OpKind::Scan) scan_based.push_back(c.get());
           else remaining.push_back(c.get());
         }
@@ -551,7 +570,7 @@ std::string query_signature(const pg_filter_node* filter, const pg_query* q) {
     for (int i = 0; i < q->n_aggregations; i++)
       o << ":" << q->aggregations[i].function << "," << (q->aggregations[i].column ? q->aggregations[i].column : "*") << ","
         << q->aggregations[i].log2m;
-    o << "|" << q->num_groups_limit << "," << q->max_initial_result_holder_capacity;
+    o << "|" << q->num_groups_limit << "," << q->max_initial_result_holder_capacity << "," << (q->flags & PG_QUERY_FLAG_SKIP_STAR_TREE);
   } else {
     o << "|filter-only";
   }
@@ -640,11 +659,44 @@ static const int64_t kLdsReplicaBudget = 96 * 1024;
 static const size_t kMaxAuxBytes = (size_t)2 << 30;
 static const int64_t kMaxDenseGroups = 64LL << 20;      // dense HBM table limit (groups)
 
+// canOptimizeCount (BaseFilterOperator.java:56-82 and overrides): index-only filters whose cardinality needs no scan
+static bool can_optimize_count(const FilterOp& op) {
+  switch (op.kind) {
+    case OpKind::Scan: return false;
+    case OpKind::And: case OpKind::Or: case OpKind::Not:
+      for (auto& c : op.children) if (!can_optimize_count(*c)) return false;
+      return true;
+    default: return true;
+  }
+}
+
+static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, const pg_query* q, const StarTree* st, int star_index);
+
+// `seg`: the segment the query addresses.  AggregationPlanNode#buildNonFilteredAggOperator (:97-127) / GroupByPlanNode: the
+// regular filter is planned first; FastFilteredCountOperator takes a lone COUNT(*) over an index-only filter; otherwise, when the
+// filter result is not empty, the first star-tree the query fits answers it (AggregationFunctionUtils#buildAggregationInfo
+// :285-307) and the operators run over that star-tree's doc space.
 std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* filter, const pg_query* q) {
+  OpPtr root = filter ? construct(seg, *filter) : make_op(OpKind::MatchAll);
+  if (q && q->n_aggregations > 0 && q->aggregations && !(q->flags & PG_QUERY_FLAG_SKIP_STAR_TREE) && !seg.star_trees.empty() &&
+      root->kind != OpKind::Empty) {
+    const bool fast_count = q->n_group_by == 0 && q->n_aggregations == 1 && q->aggregations[0].function == PG_AGG_COUNT &&
+                            can_optimize_count(*root);
+    for (size_t t = 0; t < seg.star_trees.size() && !fast_count; t++) {
+      OpPtr star_root = star_tree_filter(seg, *seg.star_trees[t], filter, *q);
+      if (star_root) return compile_in_space(seg.star_trees[t]->space, std::move(star_root), q, seg.star_trees[t].get(), (int)t);
+    }
+  }
+  return compile_in_space(seg, std::move(root), q, nullptr, -1);
+}
+
+// `seg`: the doc space the operators run over — the segment itself, or a star-tree's docs.
+static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, const pg_query* q, const StarTree* st, int star_index) {
   auto plan = std::make_shared<CompiledPlan>();
   CompiledPlan& P = *plan;
+  P.star_tree_index = star_index;
+  P.space_docs = seg.total_docs;
   Emitter em{seg, P};
-  OpPtr root = filter ? construct(seg, *filter) : make_op(OpKind::MatchAll);
   if (root->kind == OpKind::Empty) P.always_empty = true;
   em.emit(*root, true);
   if (em.sp != 1) fail(PG_ERR_INTERNAL, "filter program leaves %d entries on the stack", em.sp);
@@ -743,7 +795,7 @@ std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* f
   for (int i = 0; i < q->n_aggregations && !need_count; i++) {
     const pg_agg_spec& s = q->aggregations[i];
     if (s.function == PG_AGG_MIN || s.function == PG_AGG_MAX || s.function == PG_AGG_MINMAXRANGE) {
-      Column* c = seg.find(s.column);
+      Column* c = st ? nullptr : seg.find(s.column);
       if (c && c->val_type == PG_V_I32 && c->data_type == PG_TYPE_INT) has_int_minmax = true;
     }
   }
@@ -754,8 +806,32 @@ std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* f
     const pg_agg_spec& s = q->aggregations[i];
     AggOut out{};
     out.function = s.function;
+    if (st) {
+      // StarTreeAggregationExecutor / StarTreeGroupByExecutor: the aggregation reads its function-column pair column
+      Column* pc = st->pairs[(size_t)st->pair_index(s.function, s.column)].col;
+      project(pc);
+      if (s.function == PG_AGG_COUNT) {   // CountAggregationFunction.java:99-106,134-141: sum of the pre-aggregated long counts
+        out.op_a = op_index(PG_ACC_SUM, src_index(pc), false);
+        out.star_count = true;
+        P.aggs.push_back(out);
+        continue;
+      }
+      if (s.function == PG_AGG_DISTINCTCOUNTHLL) {   // serialized HyperLogLogs: register-wise max (addAll)
+        if (D.n_aux >= PG_MAX_AUX) fail(PG_ERR_UNSUPPORTED, "more than %d DISTINCTCOUNT / DISTINCTCOUNTHLL aggregations", PG_MAX_AUX);
+        PgAuxOp& A = D.aux[D.n_aux];
+        A.kind = PG_AUX_HLL_BYTES;
+        A.src = src_index(pc);
+        A.log2m = pc->hll_log2m;
+        A.stride = 1 << pc->hll_log2m;
+        out.aux = D.n_aux++;
+        out.log2m = pc->hll_log2m;
+        out.aux_col = pc;
+        P.aggs.push_back(out);
+        continue;
+      }
+    }
     if (s.function == PG_AGG_COUNT) { out.op_a = count_op; P.aggs.push_back(out); continue; }
-    Column* c = seg.find(s.column);
+    Column* c = st ? st->pairs[(size_t)st->pair_index(s.function, s.column)].col : seg.find(s.column);
     if (!c) fail(PG_ERR_NOT_FOUND, "column not found: %s", s.column ? s.column : "(null)");
     if (s.function == PG_AGG_DISTINCTCOUNT || s.function == PG_AGG_DISTINCTCOUNTHLL) {
       if (D.n_aux >= PG_MAX_AUX) fail(PG_ERR_UNSUPPORTED, "more than %d DISTINCTCOUNT / DISTINCTCOUNTHLL aggregations", PG_MAX_AUX);

@@ -72,3 +72,32 @@ def airline_star_segment():
         entry("null", "STAR_TREE"), meta["max_leaf_records"], dim_ids, n_base)
     seg.star_trees.append(st)
     return seg, meta
+
+
+def synth_star_segment(num_docs=40_000, max_leaf_records=64, skip=("h3",), seed_index=3):
+    """gpuBench docs (BASELINE config 5 columns + a raw metric) with a star-tree over (h1, h2, h3, h4) holding
+    count__*, sum__m, min__m, max__m and distinctCountHLL__u — built by pinot_amd.startree (the builder the reference
+    fixture pins)."""
+    from pinot_amd import startree, synth
+    seg = synth.generate_segment(num_docs, segment_index=seed_index, columns=["h1", "h2", "h3", "h4", "u", "m", "g2"],
+                                 native=False)
+    startree.add_star_tree(seg, ["h1", "h2", "h3", "h4"],
+                           [("COUNT", "*"), ("SUM", "m"), ("MIN", "m"), ("MAX", "m"), ("DISTINCTCOUNTHLL", "u")],
+                           max_leaf_records=max_leaf_records, skip_star_node_creation=skip)
+    return seg
+
+
+SYNTH_STAR_QUERIES = [
+    ("SELECT h1, h2, h3, h4, COUNT(*), DISTINCTCOUNTHLL(u) FROM gpuBench GROUP BY h1, h2, h3, h4 LIMIT 20000", True),   # config 5
+    ("SELECT COUNT(*), SUM(m), MIN(m), MAX(m), DISTINCTCOUNTHLL(u) FROM gpuBench WHERE h2 = 3", True),
+    ("SELECT h1, COUNT(*), SUM(m), DISTINCTCOUNTHLL(u) FROM gpuBench GROUP BY h1", True),
+    ("SELECT h4, SUM(m), MAX(m) FROM gpuBench WHERE h1 IN (1, 2, 3) AND h3 BETWEEN 2 AND 7 GROUP BY h4", True),
+    ("SELECT h2, h4, COUNT(*), MIN(m) FROM gpuBench WHERE h1 != 5 AND h4 > 2 GROUP BY h2, h4", True),
+    ("SELECT COUNT(*), DISTINCTCOUNTHLL(u) FROM gpuBench WHERE h3 = 4 AND h4 = 1", True),
+    ("SELECT h3, COUNT(*) FROM gpuBench WHERE (h2 = 1 OR h2 > 7) AND NOT h4 IN (0, 7) GROUP BY h3", True),
+    ("SELECT SUM(m) FROM gpuBench WHERE h1 = 99", True),            # no matching dictId... the regular filter is already empty
+    ("SELECT h1, DISTINCTCOUNTHLL(u) FROM gpuBench WHERE h4 NOT IN (1, 2) GROUP BY h1", True),
+    ("SELECT g2, COUNT(*) FROM gpuBench GROUP BY g2", False),       # g2 is not a star-tree dimension
+    ("SELECT COUNT(*), AVG(m) FROM gpuBench WHERE h1 = 2", False),  # avg__m is not in the tree
+    ("SELECT h1, DISTINCTCOUNT(u) FROM gpuBench GROUP BY h1", False),
+]

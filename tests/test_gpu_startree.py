@@ -1,0 +1,109 @@
+"""GPU parity for the star-tree path: libpinot_gpu.so through the C ABI vs the CPU oracle, on the
+reference-built star-tree fixture and on star-trees our builder makes over synthetic gpuBench docs (BASELINE config 5 shape:
+4-dimension GROUP BY + COUNT + DISTINCTCOUNTHLL over pre-aggregated docs)."""
+import numpy as np
+import pytest
+
+from pinot_amd import capi
+from pinot_amd.executor import NativeSegment
+from pinot_amd.query import parse_sql
+from tests.fixtures import SYNTH_STAR_QUERIES, airline_star_segment, synth_star_segment
+from tests.test_startree import AIRLINE_QUERIES
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_same(g, o):
+    assert g.stats.star_tree_index == o.stats.star_tree_index
+    assert g.rows() == o.rows()
+    assert g.stats.num_docs_scanned == o.stats.num_docs_scanned
+    assert g.stats.num_total_docs == o.stats.num_total_docs
+    assert g.stats.num_entries_scanned_post_filter == o.stats.num_entries_scanned_post_filter
+    if g.stats.stats_exact:
+        assert g.stats.num_entries_scanned_in_filter == o.stats.num_entries_scanned_in_filter
+
+
+@pytest.fixture(scope="module")
+def airline(gpu_api, oracle_api):
+    host, meta = airline_star_segment()
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    yield g, o, meta
+    g.destroy()
+    o.destroy()
+
+
+def test_known_answers_on_reference_star_tree(airline):
+    g, _, meta = airline
+    b = g.execute("SELECT COUNT(*), MAX(ArrDelay) FROM t")
+    assert b.aggregation_result() == [313, 343.0]
+    st = b.stats
+    assert (st.star_tree_index, st.num_docs_scanned, st.num_entries_scanned_in_filter, st.num_total_docs) == (0, 1, 0, 313)
+    assert st.num_entries_scanned_post_filter == 2
+
+
+@pytest.mark.parametrize("sql,uses_star", AIRLINE_QUERIES)
+def test_reference_star_tree_matches_oracle(airline, sql, uses_star):
+    g, o, _ = airline
+    gb, ob = g.execute(sql), o.execute(sql)
+    assert gb.stats.star_tree_index == (0 if uses_star else -1)
+    assert_same(gb, ob)
+    qc = parse_sql(sql)
+    qc.flags |= capi.QUERY_FLAG_SKIP_STAR_TREE
+    plain = g.execute(qc)
+    assert plain.stats.star_tree_index == -1
+    assert plain.rows() == gb.rows()                     # star-tree == non-star-tree on the GPU as well
+
+
+@pytest.fixture(scope="module", params=[(64, ("h3",)), (10_000, ()), (1, ("h1", "h4"))],
+                ids=["leaf64-skip-h3", "leaf10000", "leaf1-skip-h1-h4"])
+def synth_star(request, gpu_api, oracle_api):
+    host = synth_star_segment(40_000, max_leaf_records=request.param[0], skip=request.param[1])
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    yield g, o, host
+    g.destroy()
+    o.destroy()
+
+
+@pytest.mark.parametrize("sql,uses_star", SYNTH_STAR_QUERIES)
+def test_synthetic_star_tree_matches_oracle(synth_star, sql, uses_star):
+    g, o, host = synth_star
+    assert_same(g.execute(sql), o.execute(sql))
+
+
+def test_config5_star_tree_many_docs(gpu_api, oracle_api):
+    """BASELINE config 5 on a bigger segment: every (h1,h2,h3,h4) combination present, 12 800 groups, HLL registers merged from
+    the pre-aggregated blobs; the star-tree answer equals the flat scan's (hashing 300 k dictionary values on the device)."""
+    from pinot_amd import synth
+    host = synth_star_segment(300_000, max_leaf_records=10_000, skip=())
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    star, ob = g.execute(synth.QUERY_CFG5), o.execute(synth.QUERY_CFG5)
+    assert star.stats.star_tree_index == 0
+    assert_same(star, ob)
+    qc = parse_sql(synth.QUERY_CFG5)
+    qc.flags |= capi.QUERY_FLAG_SKIP_STAR_TREE
+    flat = g.execute(qc)
+    assert flat.stats.star_tree_index == -1 and flat.stats.num_docs_scanned == 300_000
+    assert flat.rows() == star.rows()
+    assert len(star.rows()) == 12_800
+    g.destroy()
+    o.destroy()
+
+
+def test_star_tree_registration_errors(gpu_api):
+    host, _ = airline_star_segment()
+    st = host.star_trees[0]
+    host.star_trees = []
+    seg = NativeSegment(gpu_api, host)
+    bad = st.star_tree.copy()
+    bad[0] ^= 0xFF
+    good = st.star_tree
+    st.star_tree = bad
+    with pytest.raises(capi.NativeError, match="magic"):
+        seg.add_star_tree(st)
+    st.star_tree = good[:-28].copy()
+    with pytest.raises(capi.NativeError, match="size mis-match"):
+        seg.add_star_tree(st)
+    st.star_tree = good
+    seg.add_star_tree(st)
+    assert seg.execute("SELECT COUNT(*), MAX(ArrDelay) FROM t").stats.star_tree_index == 0
+    seg.destroy()

@@ -196,3 +196,36 @@ def test_oracle_star_tree_equals_plain_path(airline, sql, uses_star):
     assert star.stats.num_total_docs == plain.stats.num_total_docs == 313
     if uses_star:
         assert star.stats.num_docs_scanned <= meta["total_docs"]
+
+
+# ---- star-trees built by our builder over synthetic docs: star-tree path == plain path in the oracle ---------------------
+from tests.fixtures import SYNTH_STAR_QUERIES, synth_star_segment  # noqa: E402
+
+
+@pytest.fixture(scope="module", params=[(64, ("h3",)), (10_000, ()), (1, ("h1", "h4"))],
+                ids=["leaf64-skip-h3", "leaf10000", "leaf1-skip-h1-h4"])
+def synth_star(request, oracle_api):
+    host = synth_star_segment(40_000, max_leaf_records=request.param[0], skip=request.param[1])
+    seg = NativeSegment(oracle_api, host)
+    yield seg, host
+    seg.destroy()
+
+
+@pytest.mark.parametrize("sql,uses_star", SYNTH_STAR_QUERIES)
+def test_oracle_synthetic_star_tree_equals_plain_path(synth_star, sql, uses_star):
+    seg, host = synth_star
+    star, plain = run_both(seg, sql)
+    if "h1 = 99" in sql:
+        uses_star = False            # the regular filter is empty: AggregationFunctionUtils#buildAggregationInfo skips the star-tree
+    assert star.stats.star_tree_index == (0 if uses_star else -1)
+    assert plain.stats.star_tree_index == -1
+    assert star.rows() == plain.rows()
+    if uses_star:
+        assert star.stats.num_docs_scanned <= host.star_trees[0].num_docs
+
+
+def test_star_tree_shrinks_the_scan(synth_star):
+    seg, host = synth_star
+    star, plain = run_both(seg, "SELECT h1, COUNT(*), SUM(m) FROM gpuBench GROUP BY h1")
+    assert plain.stats.num_docs_scanned == 40_000
+    assert star.stats.num_docs_scanned < plain.stats.num_docs_scanned
