@@ -723,6 +723,45 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
     return PG_OK;
   }
 
+  /* NonScanBasedAggregationOperator (core/plan/AggregationPlanNode.java:110-120,165-190; core/operator/query/
+   * NonScanBasedAggregationOperator.java:83-150,300-303): match-all filter, no GROUP BY, every aggregation is COUNT or a
+   * dictionary-based function over a dictionary column → answered from the dictionaries, no doc is read */
+  if (n_gb == 0 && filter_op->kind == PO_OP_MATCH_ALL) {
+    int fit = 1;
+    for (int i = 0; i < n_aggs && fit; i++) {
+      int f = aggs[i].function;
+      if (f == PG_AGG_COUNT) continue;
+      fit = aggs[i].col->has_dictionary && (f == PG_AGG_MIN || f == PG_AGG_MAX || f == PG_AGG_MINMAXRANGE ||
+                                            f == PG_AGG_DISTINCTCOUNT || f == PG_AGG_DISTINCTCOUNTHLL) &&
+            (aggs[i].col->data_type <= PG_TYPE_DOUBLE || f == PG_AGG_DISTINCTCOUNT || f == PG_AGG_DISTINCTCOUNTHLL);
+    }
+    if (fit) {
+      int32_t gid0 = 0;
+      res->num_groups = 1;
+      res->aggs = (po_agg_result*)po_xcalloc((size_t)n_aggs, sizeof(po_agg_result));
+      for (int i = 0; i < n_aggs; i++) {
+        agg_state* a = &aggs[i];
+        agg_ensure_capacity(a, 1);
+        po_column* c = a->col;
+        switch (a->function) {
+          case PG_AGG_COUNT: a->d0[0] = (double)seg->total_docs; break;
+          case PG_AGG_MIN: a->d0[0] = po_dict_get_double(c, 0); break;
+          case PG_AGG_MAX: a->d0[0] = po_dict_get_double(c, c->cardinality - 1); break;
+          case PG_AGG_MINMAXRANGE: a->d0[0] = po_dict_get_double(c, 0); a->d1[0] = po_dict_get_double(c, c->cardinality - 1); a->has[0] = 1; break;
+          default: /* DISTINCTCOUNT / DISTINCTCOUNTHLL: every dictionary value */
+            a->dict_bitmaps[0] = po_bitmap_new(c->cardinality);
+            po_bitmap_add_range(a->dict_bitmaps[0], 0, c->cardinality);
+            break;
+        }
+        extract_agg(&res->aggs[i], a, 1, &gid0);
+      }
+      res->stats.num_docs_scanned = seg->total_docs;
+      res->stats.host_ms_total = (float)(now_ms() - t0);
+      *out = res;
+      return PG_OK;
+    }
+  }
+
   /* AggregationFunctionUtils#buildAggregationInfo (:285-307): use a star-tree when the filter result is not empty and one
    * fits (StarTreeUtils#createStarTreeBasedProjectOperator); the operators then run over the star-tree's doc space. */
   if (!(q->flags & PG_QUERY_FLAG_SKIP_STAR_TREE) && filter_op->kind != PO_OP_EMPTY) {

@@ -195,6 +195,49 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   const double t_plan = now_ms();
   const bool profile = (q.flags & PG_QUERY_FLAG_PROFILE) != 0;
 
+  if (P.non_scan_based) {
+    // NonScanBasedAggregationOperator#getNextBlock (core/operator/query/NonScanBasedAggregationOperator.java:83-150): answered
+    // from the dictionaries on the host — no kernel, no doc is read
+    auto res = std::make_unique<Result>();
+    res->num_groups = 1;
+    res->aggs.resize(P.aggs.size());
+    for (size_t a = 0; a < P.aggs.size(); a++) {
+      const AggOut& ao = P.aggs[a];
+      AggResult& r = res->aggs[a];
+      for (int k = 0; k < 2; k++) { r.d[k].assign(1, 0.0); r.l[k].assign(1, 0); }
+      Column* c = ao.aux_col;
+      switch (ao.function) {
+        case PG_AGG_COUNT: r.kind = PG_RESULT_LONG; r.l[0][0] = seg.total_docs; break;
+        case PG_AGG_MIN: r.kind = PG_RESULT_DOUBLE; r.d[0][0] = dictionary_value_as_double(*c, 0); break;
+        case PG_AGG_MAX: r.kind = PG_RESULT_DOUBLE; r.d[0][0] = dictionary_value_as_double(*c, c->cardinality - 1); break;
+        case PG_AGG_MINMAXRANGE:
+          r.kind = PG_RESULT_MINMAX_PAIR;
+          r.d[0][0] = dictionary_value_as_double(*c, 0);
+          r.d[1][0] = dictionary_value_as_double(*c, c->cardinality - 1);
+          break;
+        case PG_AGG_DISTINCTCOUNT:
+          r.kind = PG_RESULT_DICTID_SET;
+          r.set_sizes.assign(1, c->cardinality);
+          r.set_ids.resize((size_t)c->cardinality);
+          for (int32_t d = 0; d < c->cardinality; d++) r.set_ids[(size_t)d] = d;
+          break;
+        default:
+          r.kind = PG_RESULT_HLL;
+          r.log2m = ao.log2m;
+          r.hll.assign((size_t)1 << ao.log2m, 0);
+          hll_registers_of_dictionary(*c, ao.log2m, r.hll.data());
+          break;
+      }
+    }
+    res->stats.num_docs_scanned = seg.total_docs;   // "Set numDocsScanned to numTotalDocs for backward compatibility" (:300-303)
+    res->stats.num_total_docs = seg.total_docs;
+    res->stats.stats_exact = 1;
+    res->stats.star_tree_index = -1;
+    res->stats.host_ms_plan = (float)(t_plan - t0);
+    res->stats.host_ms_total = (float)(now_ms() - t0);
+    return res;
+  }
+
   PgQueryPlan D = P.dev;
   const LaunchShape shape = launch_shape(P, P.dev.n_wtiles, D.agg_mode);
   const int64_t n_out = (int64_t)D.n_ops * D.n_groups;

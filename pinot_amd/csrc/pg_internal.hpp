@@ -206,6 +206,8 @@ struct CompiledPlan {
   bool non_scan_based = false;       // NonScanBasedAggregationOperator: answered from dictionaries on the host
 };
 
+void hll_registers_of_dictionary(Column& c, int log2m, uint8_t* regs);
+double dictionary_value_as_double(const Column& c, int32_t dict_id);
 std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* filter, const pg_query* query);
 std::string query_signature(const pg_filter_node* filter, const pg_query* query);
 

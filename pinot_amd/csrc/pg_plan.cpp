@@ -654,6 +654,41 @@ static const uint32_t* hll_dict_lut(Column& c, int log2m) {
   return ins.first->second.as<uint32_t>();
 }
 
+// HyperLogLog registers after offering every dictionary value (NonScanBasedAggregationOperator#getDistinctCountHLLResult)
+void hll_registers_of_dictionary(Column& c, int log2m, uint8_t* regs) {
+  std::vector<uint32_t> lut((size_t)c.cardinality);
+  const uint8_t* d = c.dict_host.data();
+  memset(regs, 0, (size_t)1 << log2m);
+  for (int32_t i = 0; i < c.cardinality; i++) {
+    uint32_t x;
+    switch (c.data_type) {
+      case PG_TYPE_INT: x = murmur_hash_long((int64_t)(int32_t)be32(d + (size_t)i * 4)); break;
+      case PG_TYPE_LONG: x = murmur_hash_long((int64_t)be64(d + (size_t)i * 8)); break;
+      case PG_TYPE_FLOAT: x = murmur_hash_long((int64_t)(int32_t)be32(d + (size_t)i * 4)); break;
+      case PG_TYPE_DOUBLE: x = murmur_hash_long((int64_t)be64(d + (size_t)i * 8)); break;
+      default: {
+        const uint8_t* e = d + (size_t)i * c.dict_bytes_per_value;
+        int len = c.dict_bytes_per_value;
+        while (len > 0 && e[len - 1] == 0) len--;
+        x = murmur_hash_bytes(e, len);
+        break;
+      }
+    }
+    const uint32_t ir = hll_index_rank(x, log2m);
+    uint8_t& r = regs[ir & 0xFFFFu];
+    if ((ir >> 16) > r) r = (uint8_t)(ir >> 16);
+  }
+}
+double dictionary_value_as_double(const Column& c, int32_t dict_id) {   // Dictionary#getDoubleValue
+  const uint8_t* d = c.dict_host.data();
+  switch (c.data_type) {
+    case PG_TYPE_INT: return (double)(int32_t)be32(d + (size_t)dict_id * 4);
+    case PG_TYPE_LONG: return (double)(int64_t)be64(d + (size_t)dict_id * 8);
+    case PG_TYPE_FLOAT: { uint32_t u = be32(d + (size_t)dict_id * 4); float f; memcpy(&f, &u, 4); return (double)f; }
+    default: { uint64_t u = be64(d + (size_t)dict_id * 8); double f; memcpy(&f, &u, 8); return f; }
+  }
+}
+
 static const int64_t kLdsTableBudget = 144 * 1024;      // bytes of LDS for the accumulator table (one workgroup per CU)
 static const int64_t kLdsReplicaBudget = 96 * 1024;
 static const size_t kMaxAuxBytes = (size_t)2 << 30;
@@ -748,6 +783,36 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
   }
   P.lds_bytes = 0;   // the filter stack lives in registers
   if (!q || q->n_aggregations <= 0) return plan;
+
+  // ---- NonScanBasedAggregationOperator (AggregationPlanNode.java:110-120,165-190): no GROUP BY, match-all filter, every
+  // aggregation answerable from a dictionary (or COUNT).  A lone COUNT(*) is FastFilteredCountOperator's instead. -------------
+  if (!st && q->n_group_by == 0 && root->kind == OpKind::MatchAll &&
+      !(q->n_aggregations == 1 && q->aggregations[0].function == PG_AGG_COUNT)) {
+    bool fit = true;
+    for (int i = 0; i < q->n_aggregations && fit; i++) {
+      const pg_agg_spec& s = q->aggregations[i];
+      if (s.function == PG_AGG_COUNT) continue;
+      Column* c = seg.find(s.column);
+      const bool dict_fn = s.function == PG_AGG_MIN || s.function == PG_AGG_MAX || s.function == PG_AGG_MINMAXRANGE ||
+                           s.function == PG_AGG_DISTINCTCOUNT || s.function == PG_AGG_DISTINCTCOUNTHLL;
+      fit = c && dict_fn && c->has_dictionary &&
+            (c->data_type <= PG_TYPE_DOUBLE || s.function == PG_AGG_DISTINCTCOUNT || s.function == PG_AGG_DISTINCTCOUNTHLL);
+    }
+    if (fit) {
+      P.non_scan_based = true;
+      for (int i = 0; i < q->n_aggregations; i++) {
+        const pg_agg_spec& s = q->aggregations[i];
+        AggOut out{};
+        out.function = s.function;
+        out.log2m = s.log2m > 0 ? s.log2m : 8;
+        out.aux_col = s.function == PG_AGG_COUNT ? nullptr : seg.find(s.column);
+        if (s.function == PG_AGG_DISTINCTCOUNTHLL && (out.log2m < 4 || out.log2m > 16))
+          fail(PG_ERR_UNSUPPORTED, "DISTINCTCOUNTHLL log2m %d (4..16 on the GPU path)", out.log2m);
+        P.aggs.push_back(out);
+      }
+      return plan;
+    }
+  }
 
   // ---- aggregation plan ------------------------------------------------------------------------------------------
   P.num_groups_limit = q->num_groups_limit > 0 ? q->num_groups_limit : 100000;

@@ -54,7 +54,8 @@ def airline_star_segment():
     # shuffle the parent docs (a real segment is not sorted by the split order)
     perm = np.random.default_rng(11).permutation(len(data["ArrDelay"]))
     data = {k: v[perm] for k, v in data.items()}
-    seg = build_segment(meta["segment_name"], data, {d: "INT" for d in dims + ["ArrDelay"]})
+    # ArrDelay as a raw column: with a dictionary, match-all MIN/MAX queries would go to NonScanBasedAggregationOperator
+    seg = build_segment(meta["segment_name"], data, {d: "INT" for d in dims + ["ArrDelay"]}, no_dictionary_columns=["ArrDelay"])
     for d in dims:   # identity dictionaries of the fixture's cardinality, so that dictIds are the fixture's
         card = meta["columns"][d]["cardinality"]
         col = seg.columns[d]

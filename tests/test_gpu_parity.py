@@ -87,6 +87,22 @@ SV_QUERIES = [
 ]
 
 
+NON_SCAN_QUERIES = [
+    "SELECT COUNT(*), MAX(column3), MIN(column6), MINMAXRANGE(column1), DISTINCTCOUNT(column1), DISTINCTCOUNTHLL(column3) FROM testTable",
+    "SELECT MAX(column17) FROM testTable",
+    "SELECT DISTINCTCOUNT(column11), DISTINCTCOUNTHLL(column12), COUNT(*) FROM testTable",
+]
+
+
+@pytest.mark.parametrize("q", NON_SCAN_QUERIES)
+def test_non_scan_based_aggregation_matches_oracle(sv, q):
+    g, o = sv
+    gb, ob = g.execute(q), o.execute(q)
+    assert_same_block(gb, ob)
+    assert (gb.stats.num_docs_scanned, gb.stats.num_entries_scanned_post_filter) == (30000, 0)
+    assert gb.stats.kernel == b""                      # answered from the dictionaries on the host: no kernel ran
+
+
 DISTINCT_QUERIES = [
     "SELECT DISTINCTCOUNTHLL(column1), DISTINCTCOUNTHLL(column3) FROM testTable",
     "SELECT DISTINCTCOUNTHLL(column1), DISTINCTCOUNTHLL(column3) FROM testTable" + SV_FILTER,

@@ -304,3 +304,23 @@ def test_hll_python_matches_oracle(oracle_api):
     regs = np.zeros(256, dtype=np.uint8)
     oracle_api.lib.po_hll_registers_for_values(vals.ctypes.data, len(vals), 1, 8, regs.ctypes.data)
     assert hll_cardinality(bytes(regs)) == oracle_api.lib.po_hll_cardinality_from_registers(regs.ctypes.data, 8)
+
+
+def test_non_scan_based_aggregation_operator(oracle_api, sv_data):
+    """AggregationPlanNode.java:110-120: match-all filter + dictionary-answerable functions → NonScanBasedAggregationOperator,
+    whose ExecutionStatistics are (numTotalDocs, 0, 0, numTotalDocs) (NonScanBasedAggregationOperator.java:300-303)."""
+    from pinot_amd.executor import NativeSegment, extract_final
+    from tests.fixtures import sv_segment
+    seg = NativeSegment(oracle_api, sv_segment(sv_data))
+    b = seg.execute("SELECT COUNT(*), MAX(column3), MIN(column6), MINMAXRANGE(column1), DISTINCTCOUNT(column1), "
+                    "DISTINCTCOUNTHLL(column3) FROM testTable")
+    r = b.aggregation_result()
+    assert r[0] == 30000 and r[1] == 2147419555.0 and r[2] == 1689277.0
+    assert extract_final("DISTINCTCOUNT", r[4]) == 6582 and extract_final("DISTINCTCOUNTHLL", r[5]) == 23825
+    st = b.execution_statistics()
+    assert (st.num_docs_scanned, st.num_entries_scanned_in_filter, st.num_entries_scanned_post_filter,
+            st.num_total_docs) == (30000, 0, 0, 30000)
+    # SUM is not dictionary based: the scan path, with its statistics
+    st = seg.execute("SELECT COUNT(*), SUM(column1) FROM testTable").execution_statistics()
+    assert (st.num_docs_scanned, st.num_entries_scanned_post_filter) == (30000, 30000)
+    seg.destroy()
