@@ -157,7 +157,9 @@ static LaunchShape launch_shape(const CompiledPlan& P, int n_wtiles, int agg_mod
   size_t lds = P.lds_bytes + 64;
   if (uses_fast_kernel(P, agg_mode)) {
     // one 16-wave workgroup per CU; fewer when the segment has fewer wave tiles than that
-    int grid = std::min((n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, g_num_cus);
+    static const int wgs_per_cu = getenv("PG_WGS_PER_CU") ? atoi(getenv("PG_WGS_PER_CU")) : 1;   // tuning knob
+    const int per_cu = ((size_t)wgs_per_cu * (lds + 4096) <= g_lds_per_cu) ? wgs_per_cu : 1;
+    int grid = std::min((n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, g_num_cus * per_cu);
     return {std::max(grid, 1), PG_BLOCK, lds};
   }
   // interpreter kernel: 8-wave workgroups, two per CU when both LDS tables fit

@@ -52,6 +52,19 @@ def main():
     }
     with open(os.path.join(DST, "meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
+    # the whole segment's index_map and per-column metadata (what pinot_amd/segment_dir.py parses), comments dropped
+    keep = ("cardinality", "totalDocs", "dataType", "bitsPerElement", "lengthOfEachEntry", "isSorted", "hasDictionary",
+            "isSingleValues", "maxNumberOfMultiValues", "totalNumberOfEntries")
+    seg_meta = {
+        "segment.total.docs": md["segment.total.docs"][0], "segment.name": md["segment.name"][0],
+        "segment.index.version": md["segment.index.version"][0],
+        "segment.padding.character": md["segment.padding.character"][0],
+        "index_map": {k: v[0] for k, v in properties(os.path.join(SRC, "index_map")).items()},
+        "columns": {k: v[0] for k, v in md.items() if k.startswith("column.") and k.rsplit(".", 1)[1] in keep},
+        "startree": {k: v for k, v in md.items() if k.startswith("startree.")},
+    }
+    with open(os.path.join(DST, "segment_meta.json"), "w") as f:
+        json.dump(seg_meta, f, indent=0, sort_keys=True)
     print(json.dumps(meta, indent=1)[:600])
 
 
