@@ -328,6 +328,15 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   std::vector<int64_t> gids;
   if (q.n_group_by == 0) gids.push_back(0);
   else for (int64_t g = 0; g < G; g++) if (exists(g)) gids.push_back(g);
+  bool limit_reached = q.n_group_by > 0 && (int64_t)gids.size() >= (int64_t)P.num_groups_limit;
+  if (q.n_group_by > 0 && (int64_t)gids.size() > (int64_t)P.num_groups_limit) {
+    // keep the numGroupsLimit groups whose first matching docId is smallest (= the keys the reference admits in docId order)
+    if (P.first_doc_op < 0) fail(PG_ERR_INTERNAL, "plan lacks the first-docId accumulator");
+    const int64_t* first = table.data() + (size_t)P.first_doc_op * G;
+    std::nth_element(gids.begin(), gids.begin() + P.num_groups_limit, gids.end(), [&](int64_t a, int64_t b) { return first[a] < first[b]; });
+    gids.resize((size_t)P.num_groups_limit);
+    std::sort(gids.begin(), gids.end());
+  }
   const int32_t ng = (int32_t)gids.size();
   res->num_groups = ng;
   res->group_dict_ids.resize((size_t)q.n_group_by);
@@ -338,7 +347,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
     int32_t card = P.group_cards[j];
     for (int32_t i = 0; i < ng; i++) v[i] = (int32_t)((gids[i] / mult) % card);   // getKeys: col 0 least significant
   }
-  if (q.n_group_by > 0) res->stats.num_groups_limit_reached = ng >= P.num_groups_limit ? 1 : 0;
+  if (q.n_group_by > 0) res->stats.num_groups_limit_reached = limit_reached ? 1 : 0;
 
   auto op_double = [&](int o, int64_t g) -> double {
     const PgAccOp& op = D.ops[o];

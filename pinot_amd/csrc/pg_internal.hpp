@@ -197,6 +197,7 @@ struct CompiledPlan {
   size_t lds_bytes = 0;
   int32_t num_groups_limit = 0;
   int32_t exist_op = 0;              // accumulator whose value tells whether a group was touched
+  int32_t first_doc_op = -1;         // MIN(docId) per group, present when the key space exceeds numGroupsLimit
   int32_t fast_filter = -2;          // -2: interpreter kernel; -1: index-only filter; >= 0: ScanKind of the one scan leaf
   bool fast_agg = true;              // aggregation fits the fast kernels (or there is none)
   DeviceBuffer ops_dev;

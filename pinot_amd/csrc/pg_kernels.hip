@@ -503,14 +503,24 @@ DEVFN void aggregate_wtile(const PgQueryPlan& p, uint32_t m, int wtile, int64_t*
       }
     }
     int o = 0;
-    // COUNT ops (src < 0) come first
+    // ops without a source column (src < 0) come first: COUNT, and MIN(docId) when numGroupsLimit can bite
     for (; o < p.n_ops && p.ops[o].src < 0; o++) {
       int64_t* base = table + (size_t)o * stride;
+      if (p.ops[o].fn == PG_ACC_COUNT) {
 #pragma unroll
-      for (int u = 0; u < B; u++)
+        for (int u = 0; u < B; u++)
 #pragma unroll
-        for (int i = 0; i < 4; i++)
-          if ((mb >> (4 * u + i)) & 1u) atomicAdd(reinterpret_cast<unsigned long long*>(base + slot[u][i]), 1ULL);
+          for (int i = 0; i < 4; i++)
+            if ((mb >> (4 * u + i)) & 1u) atomicAdd(reinterpret_cast<unsigned long long*>(base + slot[u][i]), 1ULL);
+      } else {
+#pragma unroll
+        for (int u = 0; u < B; u++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if ((mb >> (4 * u + i)) & 1u)
+              atomicMin(reinterpret_cast<long long*>(base + slot[u][i]),
+                        (long long)wtile * PG_WAVE_DOCS + 4 * ((k0 + u) * 64 + lane) + i);
+      }
     }
     while (o < p.n_ops) {
       const int src = p.ops[o].src;

@@ -933,6 +933,12 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
     }
     P.aggs.push_back(out);
   }
+  // numGroupsLimit (InstancePlanMakerImplV2.java:75-96, DictionaryBasedGroupKeyGenerator.java:166-185,416-446): once
+  // `limit` distinct keys have been seen — in docId order — new keys get INVALID_ID and their docs are dropped, while the
+  // admitted groups keep aggregating.  Equivalent without an order of execution: keep the `limit` groups whose FIRST matching
+  // docId is smallest.  Only when the key space can exceed the limit does the plan carry that MIN(docId) accumulator.
+  int32_t first_doc_op_unsorted = -1;
+  if (q->n_group_by > 0 && G > (int64_t)P.num_groups_limit) first_doc_op_unsorted = op_index(PG_ACC_MIN, -1, false);
   // kernels walk ops grouped by source: stable sort by src and remap
   std::vector<int32_t> order(ops.size());
   for (size_t i = 0; i < order.size(); i++) order[i] = (int32_t)i;
@@ -941,13 +947,14 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
   std::vector<PgAccOp> sorted_ops(ops.size());
   for (size_t i = 0; i < order.size(); i++) { sorted_ops[i] = ops[order[i]]; remap[order[i]] = (int32_t)i; }
   for (auto& a : P.aggs) { if (a.op_a >= 0) a.op_a = remap[a.op_a]; if (a.op_b >= 0) a.op_b = remap[a.op_b]; }
+  if (first_doc_op_unsorted >= 0) P.first_doc_op = remap[first_doc_op_unsorted];
   P.exist_op = q->n_group_by == 0 ? kCountFromStats : -1;
   for (size_t i = 0; i < sorted_ops.size(); i++) {
     if (P.exist_op == -1 && sorted_ops[i].fn == PG_ACC_COUNT) { P.exist_op = (int32_t)i; break; }
   }
   if (P.exist_op == -1)
     for (size_t i = 0; i < sorted_ops.size(); i++)
-      if ((sorted_ops[i].fn == PG_ACC_MIN || sorted_ops[i].fn == PG_ACC_MAX) && !sorted_ops[i].is_float &&
+      if ((sorted_ops[i].fn == PG_ACC_MIN || sorted_ops[i].fn == PG_ACC_MAX) && !sorted_ops[i].is_float && sorted_ops[i].src >= 0 &&
           srcs[sorted_ops[i].src]->val_type == PG_V_I32) { P.exist_op = (int32_t)i; break; }
   if (P.exist_op == -1) fail(PG_ERR_INTERNAL, "no existence accumulator");
   D.n_ops = (int32_t)sorted_ops.size();
@@ -997,6 +1004,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
   // fast aggregation: LDS table, slots fit 16 bits, <= 8-bit group columns, 32-bit value sources
   P.fast_agg = D.agg_mode != PG_AGG_GLOBAL && (int64_t)G * D.replicas <= 65536;   // (trivially true without a table)
   if (D.n_aux > 0) P.fast_agg = false;   // set / HLL accumulators run in the interpreter kernel
+  if (P.first_doc_op >= 0) P.fast_agg = false;
   for (Column* c : P.group_cols) if (c->bits > 8) P.fast_agg = false;
   for (Column* c : srcs)
     if (!(c->col_kind == PG_COL_RAW32 || (c->col_kind == PG_COL_FIXED_BIT && (c->val_type == PG_V_I32 || c->val_type == PG_V_F32))))

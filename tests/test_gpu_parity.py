@@ -277,3 +277,40 @@ def test_unsupported_and_errors(gpu_api, sv):
     with pytest.raises(NativeError) as e:
         g.execute("SELECT COUNT(*) FROM t WHERE column1 = 'abc'")
     assert e.value.status == PG_ERR_INVALID_ARGUMENT and "NumberFormatException" in e.value.message
+
+
+# ---- numGroupsLimit: the reference admits the first `limit` distinct keys in docId order -------------------------------------
+LIMIT_CASES = [
+    ("SELECT COUNT(*), SUM(column1), MAX(column3) FROM testTable GROUP BY column9", 50),
+    ("SELECT COUNT(*), MIN(column6) FROM testTable GROUP BY column9, column11", 700),
+    ("SELECT COUNT(*), SUM(column18) FROM testTable WHERE column6 < 900000000 GROUP BY column7", 7),
+    ("SELECT DISTINCTCOUNT(column11), DISTINCTCOUNTHLL(column1), COUNT(*) FROM testTable GROUP BY column17", 20),
+    ("SELECT COUNT(*) FROM testTable GROUP BY column11", 5),        # limit == number of groups: reached, nothing dropped
+    ("SELECT COUNT(*) FROM testTable GROUP BY column11", 4),
+]
+
+
+@pytest.mark.parametrize("q,limit", LIMIT_CASES)
+def test_num_groups_limit_matches_oracle(sv, q, limit):
+    from pinot_amd.query import parse_sql
+    g, o = sv
+    qg, qo = parse_sql(q), parse_sql(q)
+    qg.num_groups_limit = qo.num_groups_limit = limit
+    gb, ob = g.execute(qg), o.execute(qo)
+    assert len(ob.rows()) <= limit
+    assert_same_block(gb, ob)
+    assert gb.stats.num_groups_limit_reached == ob.stats.num_groups_limit_reached == 1
+
+
+def test_num_groups_limit_config5_shape(gpu_api, oracle_api):
+    from pinot_amd.query import parse_sql
+    host = synth.generate_segment(150_000, segment_index=2, columns=synth.CFG5_COLUMNS, native=False)
+    g, o = both(gpu_api, oracle_api, host)
+    for limit in (1000, 12_799, 12_800, 100_000):
+        qg, qo = parse_sql(synth.QUERY_CFG5), parse_sql(synth.QUERY_CFG5)
+        qg.num_groups_limit = qo.num_groups_limit = limit
+        gb, ob = g.execute(qg), o.execute(qo)
+        assert_same_block(gb, ob)
+        assert gb.stats.num_groups_limit_reached == ob.stats.num_groups_limit_reached == (1 if limit <= 12_800 else 0)
+    g.destroy()
+    o.destroy()
