@@ -6,7 +6,7 @@ A "step" is one pass of the hot path over one batch of synthetic input = one `pg
                                             AND r_int BETWEEN 250000 AND 749999 GROUP BY g1
 over one 1 B-row segment per GPU, columns already resident in HBM (2 inverted-index predicates + 1 raw-INT range scan,
 group by a 100-value dictionary column, SUM/MAX of a raw INT metric), followed — when N > 1 — by the cross-GPU group-by
-merge (RCCL all-reduce of the dense per-group arrays; segments share dictionaries).  Segments shard one per GPU
+merge (one RCCL all-gather of the dense per-group arrays + local reduce; segments share dictionaries).  Segments shard one per GPU
 (`scaling: weak`), no data-path collective other than that merge.
 
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (HBM-bound: algorithmic bytes per launch ÷ HIP-event
@@ -95,7 +95,7 @@ def main():
         kernel_ms.append(st.device_ms_aggregate)
         dense = pd.dense_from_block(block, cards)
         if world > 1:
-            # GroupByCombineOperator merge over xGMI: identical dictionaries ⇒ dense layout; ≤ 3 RCCL all-reduces
+            # GroupByCombineOperator merge over xGMI: identical dictionaries ⇒ dense layout; one RCCL all-gather + local reduce
             pd.all_reduce_tables(dense, device=torch.device("cuda", local_rank))
         return dense, st
 

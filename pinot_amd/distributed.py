@@ -10,9 +10,9 @@ Keys must be *values*, not dictIds, because dictionaries are per segment (GroupB
 
   * `DenseGroupTable` + `all_reduce_tables()` — when every segment shares the key space (identical dictionaries, e.g. the
     synthetic gpuBench table, or a caller-supplied global key order): the intermediates are dense `[n_rows, G]` float64 /
-    int64 arrays laid out by raw key Σ dictId_j·Π card_<j, and the merge is at most three collectives (all SUM-like rows
-    in one all-reduce(SUM), all MAX rows in one all-reduce(MAX), all MIN rows in one all-reduce(MIN)) over RCCL/xGMI
-    (`backend="nccl"`) or gloo on CPU.  The payload is a few KB–MB, i.e. latency-bound: fewer, larger collectives.
+    int64 arrays laid out by raw key Σ dictId_j·Π card_<j, and the merge is ONE collective: the SUM-like, MAX and MIN rows
+    are packed into one buffer, all-gathered over RCCL/xGMI (`backend="nccl"`) or gloo on CPU, and reduced locally per row
+    class.  The payload is a few KB–MB, i.e. latency-bound: one small collective beats three all-reduces.
   * `gather_merge()` — the general case: every rank's (key values → intermediates) rows are gathered to rank 0 with
     `gather_object` and upserted with `executor.GroupByCombineOperator` (IndexedTable semantics).  DISTINCTCOUNT sets are
     variable length and always take this form.
@@ -94,20 +94,36 @@ def dense_from_block(block: ResultsBlock, cards: Sequence[int]) -> DenseGroupTab
 
 
 def all_reduce_tables(t: DenseGroupTable, device=None) -> DenseGroupTable:
-    """In-place merge across the default process group: ≤ 3 collectives.  `device` = torch device holding the buffers
+    """In-place merge across the default process group with ONE collective: the SUM / MAX / MIN rows are packed into one
+    buffer, all-gathered (the payload is KBs, i.e. latency-bound: one small collective beats three), and every rank reduces
+    the gathered copies locally with the row class's merge function (SumAggregationFunction#merge `+`,
+    MaxAggregationFunction#merge max, MinAggregationFunction#merge min).  `device` = torch device holding the buffers
     during the collective ("cuda:N" for RCCL over xGMI, None/cpu for gloo)."""
     import torch
     import torch.distributed as dist
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return t
-    for arr, op in ((t.sum_rows, dist.ReduceOp.SUM), (t.max_rows, dist.ReduceOp.MAX), (t.min_rows, dist.ReduceOp.MIN)):
-        if arr.size == 0:
-            continue
-        x = torch.from_numpy(arr)
-        if device is not None:
-            x = x.to(device)
-        dist.all_reduce(x, op=op)
-        arr[...] = x.cpu().numpy()
+    world = dist.get_world_size()
+    n_sum, n_max, n_min = t.sum_rows.shape[0], t.max_rows.shape[0], t.min_rows.shape[0]
+    packed = np.concatenate([t.sum_rows, t.max_rows, t.min_rows], axis=0)
+    x = torch.from_numpy(packed)
+    if device is not None:
+        x = x.to(device)
+    x = x.reshape(-1)
+    gathered = torch.empty(world * x.numel(), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(gathered, x)          # flat buffers: the one form both RCCL and gloo accept
+    gathered = gathered.view(world, packed.shape[0], packed.shape[1])
+    parts = []
+    if n_sum:
+        parts.append(gathered[:, :n_sum].sum(dim=0))
+    if n_max:
+        parts.append(gathered[:, n_sum:n_sum + n_max].amax(dim=0))
+    if n_min:
+        parts.append(gathered[:, n_sum + n_max:].amin(dim=0))
+    merged = torch.cat(parts, dim=0).cpu().numpy()
+    t.sum_rows[...] = merged[:n_sum]
+    t.max_rows[...] = merged[n_sum:n_sum + n_max]
+    t.min_rows[...] = merged[n_sum + n_max:]
     return t
 
 
