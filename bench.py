@@ -155,7 +155,7 @@ def main():
                    "entries_scanned_in_filter": int(st.num_entries_scanned_in_filter)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": st.kernel.decode() or "pg_segment_query_kernel", "kernel_ms": avg_kernel_ms,
+                     "kernel": st.kernel.decode() or "pg_generic_query_l", "kernel_ms": avg_kernel_ms,
                      "algorithmic_bytes_per_launch": alg_bytes, "library_accounted_bytes": int(lib_alg)},
     }
 

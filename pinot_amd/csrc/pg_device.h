@@ -111,7 +111,12 @@ enum PgAggMode : int32_t {
   PG_AGG_NONE = 0,
   PG_AGG_SINGLE = 1,   // no GROUP BY: one private LDS slot per thread, one flush per workgroup
   PG_AGG_LDS = 2,      // accumulator table [n_acc][G*R] in LDS, flushed to per-workgroup partials
-  PG_AGG_GLOBAL = 3    // accumulator table [n_acc][G] in HBM, device-scope atomics
+  PG_AGG_GLOBAL = 3,   // accumulator table [n_acc][G] in HBM, device-scope atomics (memory-side: ~24 G atomics/s on MI355X)
+  // Key space beyond one LDS table: the raw-key range is cut into n_parts ranges of part_groups keys; workgroup b (XCD
+  // b % 8, index i = b / 8 inside it) owns range i % n_parts and walks the tile chunks of ITS XCD together with the other
+  // ranges' workgroups of that XCD — every chunk is fetched from HBM once per XCD and re-read from that XCD's L2 by the other
+  // ranges — aggregating only the docs whose key falls in its range into an LDS table [n_acc][part_groups].
+  PG_AGG_LDS_PART = 4
 };
 
 struct PgGroupCol {
@@ -182,7 +187,7 @@ struct PgQueryPlan {
   int32_t n_index_instr;
   int32_t fast_scan;                // index into scans, -1: none
   int32_t fast_scan_pushed;         // the scan is the whole filter (PUSH_SCAN): candidates = every doc
-  int32_t pad_f;
+  int32_t fast_agg_shape;           // the aggregation has the fast shape (LDS table, <= 8-bit group columns, 32-bit sources)
   int32_t agg_mode;
   int32_t n_group_cols;
   int32_t n_srcs;
@@ -191,6 +196,8 @@ struct PgQueryPlan {
   int32_t replicas;                 // R: LDS copies per group (power of two) to spread atomic conflicts
   int32_t replica_shift;            // log2(R): group index = slot >> replica_shift
   int32_t n_aux;
+  int32_t n_parts;                  // PG_AGG_LDS_PART: key ranges (power of two dividing the workgroups per XCD)
+  int32_t part_groups;              // PG_AGG_LDS_PART: keys per range
   PgAuxOp aux[PG_MAX_AUX];
   PgGroupCol gcols[PG_MAX_GROUP_COLS];
   PgValueSrc srcs[PG_MAX_SRCS];

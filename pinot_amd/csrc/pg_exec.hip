@@ -10,12 +10,15 @@
 
 #include "pg_internal.hpp"
 
-extern "C" __global__ void pg_segment_query_kernel(const PgQueryPlan p);
 #define PG_DECL_FAST(NAME) extern "C" __global__ void NAME(const PgQueryPlan p);
+#define PG_DECL_GENERIC PG_DECL_FAST(pg_generic_query_f) PG_DECL_FAST(pg_generic_query_l) PG_DECL_FAST(pg_generic_query_g)
+PG_DECL_GENERIC
 PG_DECL_FAST(pg_fast_none_f) PG_DECL_FAST(pg_fast_none_a) PG_DECL_FAST(pg_fast_i32range_f) PG_DECL_FAST(pg_fast_i32range_a)
 PG_DECL_FAST(pg_fast_dictrange_f) PG_DECL_FAST(pg_fast_dictrange_a) PG_DECL_FAST(pg_fast_dictlut_f) PG_DECL_FAST(pg_fast_dictlut_a)
 extern "C" __global__ void pg_reduce_partials_kernel(const int64_t* partials, int64_t* out, int n_wg, int n_ops,
                                                      int n_groups, const PgAccOp* ops, unsigned long long* stats, int reduce);
+extern "C" __global__ void pg_reduce_parts_kernel(const int64_t* partials, int64_t* out, int n_wg, int n_ops, int n_groups,
+                                                   int n_parts, int part_groups, const PgAccOp* ops);
 extern "C" __global__ void pg_fill_i64_kernel(int64_t* dst, int64_t n_per_op, int n_ops, const PgAccOp* ops);
 extern "C" __global__ void pg_expand_docids_kernel(const uint64_t* words, const int64_t* tile_offsets, int32_t* out,
                                                    int n_tiles);
@@ -71,13 +74,15 @@ void device_init(int ordinal) {
   g_device = ordinal;
   // opt in to large dynamic LDS for the query kernels
   typedef void (*QueryKernel)(const PgQueryPlan);
-  const QueryKernel all[] = {pg_segment_query_kernel, pg_fast_none_f, pg_fast_none_a, pg_fast_i32range_f, pg_fast_i32range_a,
+  const QueryKernel all[] = {pg_generic_query_f, pg_generic_query_l, pg_generic_query_g, pg_fast_none_f, pg_fast_none_a, pg_fast_i32range_f, pg_fast_i32range_a,
                              pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a};
   for (QueryKernel k : all)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
 }
 
 static bool uses_fast_kernel(const CompiledPlan& P, int agg_mode) {
+  static const bool force_interpreter = getenv("PG_FORCE_INTERPRETER") != nullptr;   // measurement knob
+  if (force_interpreter) return false;
   const bool agg = agg_mode != PG_AGG_NONE;
   return P.fast_filter != -2 && (!agg || (P.fast_agg && agg_mode != PG_AGG_GLOBAL));
 }
@@ -95,8 +100,10 @@ static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char
       default: break;
     }
   }
-  *name = "pg_segment_query_kernel";
-  return pg_segment_query_kernel;
+  if (agg_mode == PG_AGG_NONE) { *name = "pg_generic_query_f"; return pg_generic_query_f; }
+  if (agg_mode == PG_AGG_GLOBAL) { *name = "pg_generic_query_g"; return pg_generic_query_g; }
+  *name = "pg_generic_query_l";
+  return pg_generic_query_l;
 }
 
 struct ThreadCtx {
@@ -161,6 +168,12 @@ static LaunchShape launch_shape(const CompiledPlan& P, int n_wtiles, int agg_mod
     const int per_cu = ((size_t)wgs_per_cu * (lds + 4096) <= g_lds_per_cu) ? wgs_per_cu : 1;
     int grid = std::min((n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, g_num_cus * per_cu);
     return {std::max(grid, 1), PG_BLOCK, lds};
+  }
+  if (P.dev.agg_mode == PG_AGG_LDS_PART && agg_mode == PG_AGG_LDS_PART) {
+    // range-partitioned aggregation: one workgroup per CU, 8 x per_xcd of them with per_xcd a multiple of the range count
+    int per_xcd = std::max(g_num_cus / 8, 1);
+    per_xcd = std::max(per_xcd / P.dev.n_parts, 1) * P.dev.n_parts;
+    return {8 * per_xcd, PG_GENERIC_BLOCK, lds};
   }
   // interpreter kernel: 8-wave workgroups, two per CU when both LDS tables fit
   const int waves = PG_GENERIC_BLOCK / 64;
@@ -255,6 +268,9 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
     int blocks = (int)((n_out + 255) / 256);
     hipLaunchKernelGGL(pg_fill_i64_kernel, dim3(blocks), dim3(256), 0, ctx.stream, D.partials, (int64_t)D.n_groups,
                        D.n_ops, P.ops_dev.as<PgAccOp>());
+  } else if (D.agg_mode == PG_AGG_LDS_PART) {
+    ThreadCtx::grow(ctx.partials, (size_t)D.n_ops * (size_t)D.part_groups * 8 * (size_t)shape.grid + 8);
+    D.partials = ctx.partials.as<int64_t>();
   } else {
     ThreadCtx::grow(ctx.partials, (size_t)n_out * 8 * (size_t)shape.grid + 8);
     D.partials = ctx.partials.as<int64_t>();
@@ -282,7 +298,12 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   std::vector<int64_t> table((size_t)n_out);
   uint64_t stats_host[PG_MAX_STATS] = {0};
   if (has_docs) {
-    const int reduce = (D.agg_mode != PG_AGG_GLOBAL && n_out > 0) ? 1 : 0;
+    if (D.agg_mode == PG_AGG_LDS_PART && n_out > 0) {
+      hipLaunchKernelGGL(pg_reduce_parts_kernel, dim3((unsigned)((n_out + 3) / 4)), dim3(256), 0, ctx.stream, ctx.partials.as<int64_t>(),
+                         ctx.final_table.as<int64_t>(), shape.grid, D.n_ops, D.n_groups, D.n_parts, D.part_groups, P.ops_dev.as<PgAccOp>());
+      PG_HIP(hipGetLastError());
+    }
+    const int reduce = (D.agg_mode != PG_AGG_GLOBAL && D.agg_mode != PG_AGG_LDS_PART && n_out > 0) ? 1 : 0;
     const int blocks = (reduce ? (int)((n_out + 3) / 4) : 0) + 1;   // one wavefront per output slot + the stats block
     hipLaunchKernelGGL(pg_reduce_partials_kernel, dim3(blocks), dim3(256), 0, ctx.stream, ctx.partials.as<int64_t>(),
                        ctx.final_table.as<int64_t>(), shape.grid, D.n_ops, D.n_groups, P.ops_dev.as<PgAccOp>(),

@@ -26,6 +26,9 @@
 #ifndef PG_FAST_AGG_B
 #define PG_FAST_AGG_B 4
 #endif
+#ifndef PG_GENERIC_AGG_B
+#define PG_GENERIC_AGG_B 4   // quads in flight per lane in the interpreter kernels' aggregation (8 spills ~200 VGPRs)
+#endif
 // Pointers that were themselves loaded from memory (plan leaves) have no address space the compiler can infer and would
 // be accessed with flat_load; every column / index byte lives in HBM, so say so.
 #define GAS __attribute__((address_space(1)))
@@ -455,22 +458,217 @@ DEVFN void hll_update(uint8_t* regs, uint32_t idx, uint32_t rank) {
   }
 }
 
-// Aggregates the matching docs (quad-layout mask m) of one wave tile into `table` ([n_ops][G*R] int64 slots, LDS or HBM).
-// B quads per lane are in flight at a time.
+// ---- auxiliary accumulators of one batch of quads (slot[u][i] = table slot of doc i of quad k0+u, mb = the batch's mask) ----
 template <int B>
-DEVFN void aggregate_wtile(const PgQueryPlan& p, uint32_t m, int wtile, int64_t* table, int lane, uint32_t rep) {
+DEVFN void aux_update_batch(const PgQueryPlan& p, uint32_t mb, int k0, int wtile, const uint32_t (&slot_in)[B][4], int lane, uint32_t part_lo) {
+  uint32_t slot[B][4];   // the auxiliary regions are indexed by the GLOBAL group (slots are range-local in PG_AGG_LDS_PART)
+#pragma unroll
+  for (int u = 0; u < B; u++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) slot[u][i] = slot_in[u][i] + (part_lo << p.replica_shift);
+  // ---- auxiliary accumulators: DISTINCTCOUNT dictId sets / HyperLogLog registers (HBM regions) ---------------------------
+  // Dictionary sources run in three batched stages over the 4·B docs of the lane — dictIds, (index, rank) look-ups,
+  // current state words — so that 4·B gathers are in flight per lane; only docs that would change the state go on to
+  // the atomic.  Lanes / docs outside the mask use clamped (valid) addresses and are masked at the atomic.
+  for (int xa = 0; xa < p.n_aux; xa++) {
+    PgAuxOp A = p.aux[xa];
+    A.base = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(A.base) + (size_t)(blockIdx.x & (uint32_t)(A.n_rep - 1)) * (size_t)A.rep_bytes);
+    const PgValueSrc& S = p.srcs[A.src];
+    if (A.kind == PG_AUX_HLL_BYTES) {
+      // Serialized HyperLogLogs of a star-tree pair column (one byte per register after upload): HyperLogLog#addAll = register-wise
+      // max.  One matching doc at a time, the whole wavefront on its registers: lane L merges dwords L, L+64, ... of the doc
+      // into the group's registers (read first, CAS only where a register grows).
+      const uint32_t n_dw = (uint32_t)A.stride >> 2;
+      const GAS uint8_t* src = gptr<uint8_t>(S.data);
+#pragma unroll
+      for (int u = 0; u < B; u++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          unsigned long long ball = __ballot((mb >> (4 * u + i)) & 1u);
+          while (ball) {
+            const int l = __builtin_ctzll(ball);
+            ball &= ball - 1;
+            const size_t g = (size_t)((uint32_t)__builtin_amdgcn_readlane((int)slot[u][i], l) >> p.replica_shift);
+            const int64_t doc = (int64_t)wtile * PG_WAVE_DOCS + 4 * ((k0 + u) * 64 + l) + i;
+            const GAS uint32_t* sw = (const GAS uint32_t*)(src + doc * (int64_t)A.stride);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(A.base) + g * (size_t)A.stride);
+            for (uint32_t w = (uint32_t)lane; w < n_dw; w += 64) {
+              const uint32_t v = sw[w];
+              uint32_t cur = __hip_atomic_load(dst + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              for (;;) {
+                const uint32_t nv = bytemax4(cur, v);
+                if (nv == cur) break;
+                const uint32_t prev = atomicCAS(dst + w, cur, nv);
+                if (prev == cur) break;
+                cur = prev;
+              }
+            }
+          }
+        }
+    } else if (S.col_kind == PG_COL_FIXED_BIT) {
+      const GAS uint32_t* tw = packed_wtile_base(S.data, wtile, S.bits);
+      const uint32_t bits = (uint32_t)S.bits, mask = (1u << S.bits) - 1u;
+      uint32_t d[B][4];
+      if (bits <= 8) {
+        uint32_t r[B][2];
+#pragma unroll
+        for (int u = 0; u < B; u++) load_packed_quad<true>(tw, ((mb >> (4 * u)) & 0xFu) ? (uint32_t)((k0 + u) * 64 + lane) : 0u, bits, r[u]);
+#pragma unroll
+        for (int u = 0; u < B; u++) decode_packed_quad<true>(r[u], ((mb >> (4 * u)) & 0xFu) ? (uint32_t)((k0 + u) * 64 + lane) : 0u, bits, mask, d[u]);
+      } else {
+        uint32_t r[B][8];
+#pragma unroll
+        for (int u = 0; u < B; u++) load_packed_quad<false>(tw, ((mb >> (4 * u)) & 0xFu) ? (uint32_t)((k0 + u) * 64 + lane) : 0u, bits, r[u]);
+#pragma unroll
+        for (int u = 0; u < B; u++) decode_packed_quad<false>(r[u], ((mb >> (4 * u)) & 0xFu) ? (uint32_t)((k0 + u) * 64 + lane) : 0u, bits, mask, d[u]);
+      }
+      uint32_t* wp[B][4];
+      uint32_t want[B][4];   // DICT_SET: the bit; HLL: rank << shift-in-word, with the shift in the low 5 bits of `sh`
+      uint32_t sh[B][4];
+      if (A.kind == PG_AUX_DICT_SET) {
+#pragma unroll
+        for (int u = 0; u < B; u++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const size_t g = (size_t)(slot[u][i] >> p.replica_shift);
+            wp[u][i] = A.base + g * (size_t)A.stride + (d[u][i] >> 5);
+            want[u][i] = 1u << (d[u][i] & 31u);
+            sh[u][i] = 0;
+          }
+      } else {
+        uint32_t e[B][4];
+#pragma unroll
+        for (int u = 0; u < B; u++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) e[u][i] = gptr<uint32_t>(A.lut)[d[u][i]];
+#pragma unroll
+        for (int u = 0; u < B; u++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const size_t g = (size_t)(slot[u][i] >> p.replica_shift);
+            const uint32_t idx = e[u][i] & 0xFFFFu;
+            wp[u][i] = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(A.base) + g * (size_t)A.stride + (idx & ~3u));
+            sh[u][i] = (idx & 3u) * 8u;
+            want[u][i] = e[u][i] >> 16;
+          }
+      }
+      uint32_t cur[B][4];
+#pragma unroll
+      for (int u = 0; u < B; u++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) cur[u][i] = __hip_atomic_load(wp[u][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int u = 0; u < B; u++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          if ((mb >> (4 * u + i)) & 1u) {
+            if (A.kind == PG_AUX_DICT_SET) {
+              if (!(cur[u][i] & want[u][i])) atomicOr(wp[u][i], want[u][i]);
+            } else {
+              uint32_t c = cur[u][i];
+              while (((c >> sh[u][i]) & 0xFFu) < want[u][i]) {
+                const uint32_t nv = (c & ~(0xFFu << sh[u][i])) | (want[u][i] << sh[u][i]);
+                const uint32_t prev = atomicCAS(wp[u][i], c, nv);
+                if (prev == c) break;
+                c = prev;
+              }
+            }
+          }
+        }
+    } else {   // raw column: DISTINCTCOUNTHLL hashes the value on the fly
+#pragma unroll
+      for (int u = 0; u < B; u++) {
+        const uint32_t nib = (mb >> (4 * u)) & 0xFu;
+        if (nib) {
+          const uint32_t q = (uint32_t)((k0 + u) * 64 + lane);
+          int64_t v[4];   // the long the value hashes as (Integer/Long value, Float raw int bits, Double raw long bits)
+          if (S.col_kind == PG_COL_RAW32) {
+            const u32x4 x = *gptr<u32x4>(S.data + (size_t)wtile * (PG_WAVE_DOCS * 4) + q * 16u);
+            v[0] = (int64_t)(int32_t)bswap32(x.x); v[1] = (int64_t)(int32_t)bswap32(x.y);
+            v[2] = (int64_t)(int32_t)bswap32(x.z); v[3] = (int64_t)(int32_t)bswap32(x.w);
+          } else {
+            const GAS u32x4* pp = gptr<u32x4>(S.data + (size_t)wtile * (PG_WAVE_DOCS * 8) + q * 32u);
+            const u32x4 a = pp[0], b = pp[1];
+            v[0] = (int64_t)(((uint64_t)bswap32(a.x) << 32) | bswap32(a.y)); v[1] = (int64_t)(((uint64_t)bswap32(a.z) << 32) | bswap32(a.w));
+            v[2] = (int64_t)(((uint64_t)bswap32(b.x) << 32) | bswap32(b.y)); v[3] = (int64_t)(((uint64_t)bswap32(b.z) << 32) | bswap32(b.w));
+          }
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            if ((nib >> i) & 1u) {
+              const size_t g = (size_t)(slot[u][i] >> p.replica_shift);
+              const uint32_t e = hll_index_rank_dev(murmur_hash_long_dev(v[i]), A.log2m);
+              hll_update(reinterpret_cast<uint8_t*>(A.base) + g * (size_t)A.stride, e & 0xFFFFu, e >> 16);
+            }
+          }
+        }
+      }
+    }
+  }
+
+}
+
+// Aggregates the matching docs (quad-layout mask m) of one wave tile into `table` ([n_ops][G*R] int64 slots, LDS or HBM):
+// group columns of any width, raw 32/64-bit and dictionary-encoded sources.  B quads per lane are in flight at a time; like
+// the filter stage, every load of a stage is issued unconditionally (lanes whose quad has no match re-read quad 0 of the
+// tile) before the first is used — a load under a per-lane branch is waited for inside the branch.
+template <int B>
+DEVFN void aggregate_wtile(const PgQueryPlan& p, uint32_t m, int wtile, int64_t* table, int lane, uint32_t rep, uint32_t part_lo = 0) {
   const uint32_t R = (uint32_t)p.replicas;
-  const uint32_t stride = (uint32_t)p.n_groups * R;   // slots per op
+  const bool part = p.agg_mode == PG_AGG_LDS_PART;
+  const uint32_t stride = part ? (uint32_t)p.part_groups : (uint32_t)p.n_groups * R;   // slots per op
 #pragma unroll
   for (int k0 = 0; k0 < 8; k0 += B) {
-    const uint32_t mb = B == 8 ? m : ((m >> (4 * k0)) & ((1u << (4 * (B & 7))) - 1u));
-    if (__ballot(mb != 0) == 0) continue;   // wave-uniform: the HLL-bytes merge below needs every lane of the wavefront
+    uint32_t mb = B == 8 ? m : ((m >> (4 * k0)) & ((1u << (4 * (B & 7))) - 1u));
+    if (__ballot(mb != 0) == 0) continue;   // wave-uniform: the HLL-bytes merge needs every lane of the wavefront
+    uint32_t qi[B];                         // quad index of each in-flight quad, clamped to 0 where the lane has no match
+#pragma unroll
+    for (int u = 0; u < B; u++) qi[u] = ((mb >> (4 * u)) & 0xFu) ? (uint32_t)((k0 + u) * 64 + lane) : 0u;
     uint32_t slot[B][4];
 #pragma unroll
     for (int u = 0; u < B; u++)
 #pragma unroll
       for (int i = 0; i < 4; i++) slot[u][i] = rep;
-    for (int g = 0; g < p.n_group_cols; g++) {
+    // Up to PG_BATCH_GCOLS narrow group columns are requested together (one memory round trip for the whole key instead of one
+    // per column: with few bytes per load this stage is latency-, not bandwidth-bound), together with the first raw 32-bit
+    // source.  Wider / further columns follow one at a time.
+    constexpr int PG_BATCH_GCOLS = 4;
+    int n_batched = 0;
+    while (n_batched < p.n_group_cols && n_batched < PG_BATCH_GCOLS && p.gcols[n_batched].bits <= 8) n_batched++;
+    int o_first = 0;
+    while (o_first < p.n_ops && p.ops[o_first].src < 0) o_first++;
+    const bool prefetch0 = o_first < p.n_ops && p.srcs[p.ops[o_first].src].col_kind == PG_COL_RAW32;
+    uint32_t x0[B][4];
+    {
+      uint32_t rg[PG_BATCH_GCOLS][B][2];
+#pragma unroll
+      for (int g = 0; g < PG_BATCH_GCOLS; g++)
+        if (g < n_batched) {
+          const GAS uint32_t* tw = packed_wtile_base(p.gcols[g].data, wtile, p.gcols[g].bits);
+#pragma unroll
+          for (int u = 0; u < B; u++) load_packed_quad<true>(tw, qi[u], (uint32_t)p.gcols[g].bits, rg[g][u]);
+        }
+      if (prefetch0) {
+        const GAS uint8_t* tb = gptr<uint8_t>(p.srcs[p.ops[o_first].src].data + (size_t)wtile * (PG_WAVE_DOCS * 4));
+#pragma unroll
+        for (int u = 0; u < B; u++) {
+          const u32x4 v = ldnt((const GAS u32x4*)(tb + qi[u] * 16u));
+          x0[u][0] = v.x; x0[u][1] = v.y; x0[u][2] = v.z; x0[u][3] = v.w;
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < PG_BATCH_GCOLS; g++)
+        if (g < n_batched) {
+          const uint32_t bits = (uint32_t)p.gcols[g].bits, mask = (1u << bits) - 1u, mult = (uint32_t)p.gcols[g].mult * R;
+#pragma unroll
+          for (int u = 0; u < B; u++) {
+            uint32_t d[4];
+            decode_packed_quad<true>(rg[g][u], qi[u], bits, mask, d);
+#pragma unroll
+            for (int i = 0; i < 4; i++) slot[u][i] += d[i] * mult;
+          }
+        }
+    }
+    for (int g = n_batched; g < p.n_group_cols; g++) {
       const PgGroupCol& gc = p.gcols[g];
       const GAS uint32_t* tw = packed_wtile_base(gc.data, wtile, gc.bits);
       const uint32_t bits = (uint32_t)gc.bits, mask = (1u << gc.bits) - 1u;
@@ -478,29 +676,40 @@ DEVFN void aggregate_wtile(const PgQueryPlan& p, uint32_t m, int wtile, int64_t*
       if (bits <= 8) {
         uint32_t r[B][2];
 #pragma unroll
-        for (int u = 0; u < B; u++) {
-          r[u][0] = r[u][1] = 0;
-          if ((mb >> (4 * u)) & 0xFu) load_packed_quad<true>(tw, (uint32_t)((k0 + u) * 64 + lane), bits, r[u]);
-        }
+        for (int u = 0; u < B; u++) load_packed_quad<true>(tw, qi[u], bits, r[u]);
 #pragma unroll
         for (int u = 0; u < B; u++) {
           uint32_t d[4];
-          decode_packed_quad<true>(r[u], (uint32_t)((k0 + u) * 64 + lane), bits, mask, d);
+          decode_packed_quad<true>(r[u], qi[u], bits, mask, d);
 #pragma unroll
           for (int i = 0; i < 4; i++) slot[u][i] += d[i] * mult;
         }
       } else {
+        uint32_t r[B][8];
+#pragma unroll
+        for (int u = 0; u < B; u++) load_packed_quad<false>(tw, qi[u], bits, r[u]);
 #pragma unroll
         for (int u = 0; u < B; u++) {
-          if ((mb >> (4 * u)) & 0xFu) {
-            uint32_t r[8], d[4];
-            load_packed_quad<false>(tw, (uint32_t)((k0 + u) * 64 + lane), bits, r);
-            decode_packed_quad<false>(r, (uint32_t)((k0 + u) * 64 + lane), bits, mask, d);
+          uint32_t d[4];
+          decode_packed_quad<false>(r[u], qi[u], bits, mask, d);
 #pragma unroll
-            for (int i = 0; i < 4; i++) slot[u][i] += d[i] * mult;
-          }
+          for (int i = 0; i < 4; i++) slot[u][i] += d[i] * mult;
         }
       }
+    }
+    if (part) {   // keep only the docs whose key falls in this workgroup's range; slots become range-local
+      uint32_t keep = 0;
+#pragma unroll
+      for (int u = 0; u < B; u++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          slot[u][i] -= part_lo;
+          keep |= (uint32_t)(slot[u][i] < (uint32_t)p.part_groups) << (4 * u + i);
+        }
+      mb &= keep;
+      if (__ballot(mb != 0) == 0) continue;
+#pragma unroll
+      for (int u = 0; u < B; u++) qi[u] = ((mb >> (4 * u)) & 0xFu) ? (uint32_t)((k0 + u) * 64 + lane) : 0u;
     }
     int o = 0;
     // ops without a source column (src < 0) come first: COUNT, and MIN(docId) when numGroupsLimit can bite
@@ -527,15 +736,23 @@ DEVFN void aggregate_wtile(const PgQueryPlan& p, uint32_t m, int wtile, int64_t*
       const PgValueSrc& S = p.srcs[src];
       int o_end = o;
       while (o_end < p.n_ops && p.ops[o_end].src == src) o_end++;
-      if (S.col_kind == PG_COL_RAW32 || (S.col_kind == PG_COL_FIXED_BIT && (S.val_type == PG_V_I32 || S.val_type == PG_V_F32))) {
+      const bool wide_val = S.val_type == PG_V_I64 || S.val_type == PG_V_F64;
+      if (!wide_val) {
+        // ---- 32-bit values: raw big-endian INT / FLOAT, or dictionary-encoded ------------------------------------------------
         uint32_t x[B][4];
         if (S.col_kind == PG_COL_RAW32) {
-          const GAS uint8_t* tb = gptr<uint8_t>(S.data + (size_t)wtile * (PG_WAVE_DOCS * 4));
+          if (prefetch0 && o == o_first) {   // requested together with the group columns (docs later found out of range included)
 #pragma unroll
-          for (int u = 0; u < B; u++) {
-            u32x4 v = {0, 0, 0, 0};
-            if ((mb >> (4 * u)) & 0xFu) v = *(const GAS u32x4*)(tb + (uint32_t)((k0 + u) * 64 + lane) * 16u);
-            x[u][0] = v.x; x[u][1] = v.y; x[u][2] = v.z; x[u][3] = v.w;
+            for (int u = 0; u < B; u++)
+#pragma unroll
+              for (int i = 0; i < 4; i++) x[u][i] = x0[u][i];
+          } else {
+            const GAS uint8_t* tb = gptr<uint8_t>(S.data + (size_t)wtile * (PG_WAVE_DOCS * 4));
+#pragma unroll
+            for (int u = 0; u < B; u++) {
+              const u32x4 v = ldnt((const GAS u32x4*)(tb + qi[u] * 16u));
+              x[u][0] = v.x; x[u][1] = v.y; x[u][2] = v.z; x[u][3] = v.w;
+            }
           }
 #pragma unroll
           for (int u = 0; u < B; u++)
@@ -544,19 +761,24 @@ DEVFN void aggregate_wtile(const PgQueryPlan& p, uint32_t m, int wtile, int64_t*
         } else {
           const GAS uint32_t* tw = packed_wtile_base(S.data, wtile, S.bits);
           const uint32_t bits = (uint32_t)S.bits, mask = (1u << S.bits) - 1u;
+          uint32_t d[B][4];
+          if (bits <= 8) {
+            uint32_t r[B][2];
 #pragma unroll
-          for (int u = 0; u < B; u++) {
+            for (int u = 0; u < B; u++) load_packed_quad<true>(tw, qi[u], bits, r[u]);
 #pragma unroll
-            for (int i = 0; i < 4; i++) x[u][i] = 0;
-            if ((mb >> (4 * u)) & 0xFu) {
-              uint32_t r[8], d[4];
-              const uint32_t q = (uint32_t)((k0 + u) * 64 + lane);
-              if (bits <= 8) { load_packed_quad<true>(tw, q, bits, r); decode_packed_quad<true>(r, q, bits, mask, d); }
-              else { load_packed_quad<false>(tw, q, bits, r); decode_packed_quad<false>(r, q, bits, mask, d); }
+            for (int u = 0; u < B; u++) decode_packed_quad<true>(r[u], qi[u], bits, mask, d[u]);
+          } else {
+            uint32_t r[B][8];
 #pragma unroll
-              for (int i = 0; i < 4; i++) x[u][i] = ((mb >> (4 * u + i)) & 1u) ? gptr<uint32_t>(S.dict)[d[i]] : 0u;
-            }
+            for (int u = 0; u < B; u++) load_packed_quad<false>(tw, qi[u], bits, r[u]);
+#pragma unroll
+            for (int u = 0; u < B; u++) decode_packed_quad<false>(r[u], qi[u], bits, mask, d[u]);
           }
+#pragma unroll
+          for (int u = 0; u < B; u++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) x[u][i] = gptr<uint32_t>(S.dict)[d[u][i]];   // every dictId read is a valid one
         }
         for (int k = o; k < o_end; k++) {
           const int fn = p.ops[k].fn;
@@ -576,191 +798,74 @@ DEVFN void aggregate_wtile(const PgQueryPlan& p, uint32_t m, int wtile, int64_t*
           }
         }
       } else {
-        // 64-bit values: half the quads in flight
+        // ---- 64-bit values: raw big-endian LONG / DOUBLE (32 B per quad), or dictionary-encoded; four quads at a time -------------
+        constexpr int WB = B < 4 ? B : 4;
 #pragma unroll
-        for (int h = 0; h < B; h += 2) {
-          uint64_t x[2][4];
+        for (int h = 0; h < B; h += WB) {
+          if (__ballot(((mb >> (4 * h)) & ((1u << (4 * WB)) - 1u)) != 0) == 0) continue;
+          uint64_t x[WB][4];
+          if (S.col_kind == PG_COL_RAW64) {
+            const GAS uint8_t* tb = gptr<uint8_t>(S.data + (size_t)wtile * (PG_WAVE_DOCS * 8));
+            u32x4 a[WB], b[WB];
 #pragma unroll
-          for (int uu = 0; uu < 2; uu++) {
-            const int u = h + uu;
-#pragma unroll
-            for (int i = 0; i < 4; i++) x[uu][i] = 0;
-            if ((mb >> (4 * u)) & 0xFu) {
-              const uint32_t q = (uint32_t)((k0 + u) * 64 + lane);
-              if (S.col_kind == PG_COL_RAW64) {
-                const GAS u32x4* pp = gptr<u32x4>(S.data + (size_t)wtile * (PG_WAVE_DOCS * 8) + q * 32u);
-                const u32x4 a = pp[0], b = pp[1];
-                x[uu][0] = ((uint64_t)bswap32(a.x) << 32) | bswap32(a.y); x[uu][1] = ((uint64_t)bswap32(a.z) << 32) | bswap32(a.w);
-                x[uu][2] = ((uint64_t)bswap32(b.x) << 32) | bswap32(b.y); x[uu][3] = ((uint64_t)bswap32(b.z) << 32) | bswap32(b.w);
-              } else {
-                uint32_t r[8], d[4];
-                const GAS uint32_t* tw = packed_wtile_base(S.data, wtile, S.bits);
-                const uint32_t bits = (uint32_t)S.bits, mask = (1u << S.bits) - 1u;
-                if (bits <= 8) { load_packed_quad<true>(tw, q, bits, r); decode_packed_quad<true>(r, q, bits, mask, d); }
-                else { load_packed_quad<false>(tw, q, bits, r); decode_packed_quad<false>(r, q, bits, mask, d); }
-#pragma unroll
-                for (int i = 0; i < 4; i++) x[uu][i] = ((mb >> (4 * u + i)) & 1u) ? gptr<uint64_t>(S.dict)[d[i]] : 0ull;
-              }
+            for (int u = 0; u < WB; u++) {
+              const GAS u32x4* pp = (const GAS u32x4*)(tb + qi[h + u] * 32u);
+              a[u] = ldnt(pp);
+              b[u] = ldnt(pp + 1);
             }
+#pragma unroll
+            for (int u = 0; u < WB; u++) {
+              x[u][0] = ((uint64_t)bswap32(a[u].x) << 32) | bswap32(a[u].y); x[u][1] = ((uint64_t)bswap32(a[u].z) << 32) | bswap32(a[u].w);
+              x[u][2] = ((uint64_t)bswap32(b[u].x) << 32) | bswap32(b[u].y); x[u][3] = ((uint64_t)bswap32(b[u].z) << 32) | bswap32(b[u].w);
+            }
+          } else {
+            const GAS uint32_t* tw = packed_wtile_base(S.data, wtile, S.bits);
+            const uint32_t bits = (uint32_t)S.bits, mask = (1u << S.bits) - 1u;
+            uint32_t d[WB][4];
+            if (bits <= 8) {
+              uint32_t r[WB][2];
+#pragma unroll
+              for (int u = 0; u < WB; u++) load_packed_quad<true>(tw, qi[h + u], bits, r[u]);
+#pragma unroll
+              for (int u = 0; u < WB; u++) decode_packed_quad<true>(r[u], qi[h + u], bits, mask, d[u]);
+            } else {
+              uint32_t r[WB][8];
+#pragma unroll
+              for (int u = 0; u < WB; u++) load_packed_quad<false>(tw, qi[h + u], bits, r[u]);
+#pragma unroll
+              for (int u = 0; u < WB; u++) decode_packed_quad<false>(r[u], qi[h + u], bits, mask, d[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < WB; u++)
+#pragma unroll
+              for (int i = 0; i < 4; i++) x[u][i] = gptr<uint64_t>(S.dict)[d[u][i]];
           }
           for (int k = o; k < o_end; k++) {
             const int fn = p.ops[k].fn;
             int64_t* base = table + (size_t)k * stride;
             if (S.val_type == PG_V_I64) {
 #pragma unroll
-              for (int uu = 0; uu < 2; uu++)
+              for (int u = 0; u < WB; u++)
 #pragma unroll
                 for (int i = 0; i < 4; i++)
-                  if ((mb >> (4 * (h + uu) + i)) & 1u) acc_int(base + slot[h + uu][i], fn, (int64_t)x[uu][i]);
+                  if ((mb >> (4 * (h + u) + i)) & 1u) acc_int(base + slot[h + u][i], fn, (int64_t)x[u][i]);
             } else {
 #pragma unroll
-              for (int uu = 0; uu < 2; uu++)
+              for (int u = 0; u < WB; u++)
 #pragma unroll
                 for (int i = 0; i < 4; i++)
-                  if ((mb >> (4 * (h + uu) + i)) & 1u) acc_float(base + slot[h + uu][i], fn, __longlong_as_double((int64_t)x[uu][i]));
+                  if ((mb >> (4 * (h + u) + i)) & 1u) acc_float(base + slot[h + u][i], fn, __longlong_as_double((int64_t)x[u][i]));
             }
           }
         }
       }
       o = o_end;
     }
-    // ---- auxiliary accumulators: DISTINCTCOUNT dictId sets / HyperLogLog registers (HBM regions) ---------------------------
-    // Dictionary sources run in three batched stages over the 4·B docs of the lane — dictIds, (index, rank) look-ups,
-    // current state words — so that 4·B gathers are in flight per lane; only docs that would change the state go on to
-    // the atomic.  Lanes / docs outside the mask use clamped (valid) addresses and are masked at the atomic.
-    for (int xa = 0; xa < p.n_aux; xa++) {
-      PgAuxOp A = p.aux[xa];
-      A.base = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(A.base) + (size_t)(blockIdx.x & (uint32_t)(A.n_rep - 1)) * (size_t)A.rep_bytes);
-      const PgValueSrc& S = p.srcs[A.src];
-      if (A.kind == PG_AUX_HLL_BYTES) {
-        // Serialized HyperLogLogs of a star-tree pair column (one byte per register after upload): HyperLogLog#addAll = register-wise
-        // max.  One matching doc at a time, the whole wavefront on its registers: lane L merges dwords L, L+64, ... of the doc
-        // into the group's registers (read first, CAS only where a register grows).
-        const uint32_t n_dw = (uint32_t)A.stride >> 2;
-        const GAS uint8_t* src = gptr<uint8_t>(S.data);
+    if (p.n_aux > 0) {   // four quads at a time: the three-stage gathers keep 16 addresses + states per lane in registers
+      constexpr int AB = B < 4 ? B : 4;
 #pragma unroll
-        for (int u = 0; u < B; u++)
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            unsigned long long ball = __ballot((mb >> (4 * u + i)) & 1u);
-            while (ball) {
-              const int l = __builtin_ctzll(ball);
-              ball &= ball - 1;
-              const size_t g = (size_t)((uint32_t)__builtin_amdgcn_readlane((int)slot[u][i], l) >> p.replica_shift);
-              const int64_t doc = (int64_t)wtile * PG_WAVE_DOCS + 4 * ((k0 + u) * 64 + l) + i;
-              const GAS uint32_t* sw = (const GAS uint32_t*)(src + doc * (int64_t)A.stride);
-              uint32_t* dst = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(A.base) + g * (size_t)A.stride);
-              for (uint32_t w = (uint32_t)lane; w < n_dw; w += 64) {
-                const uint32_t v = sw[w];
-                uint32_t cur = __hip_atomic_load(dst + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                for (;;) {
-                  const uint32_t nv = bytemax4(cur, v);
-                  if (nv == cur) break;
-                  const uint32_t prev = atomicCAS(dst + w, cur, nv);
-                  if (prev == cur) break;
-                  cur = prev;
-                }
-              }
-            }
-          }
-      } else if (S.col_kind == PG_COL_FIXED_BIT) {
-        const GAS uint32_t* tw = packed_wtile_base(S.data, wtile, S.bits);
-        const uint32_t bits = (uint32_t)S.bits, mask = (1u << S.bits) - 1u;
-        uint32_t d[B][4];
-        if (bits <= 8) {
-          uint32_t r[B][2];
-#pragma unroll
-          for (int u = 0; u < B; u++) load_packed_quad<true>(tw, ((mb >> (4 * u)) & 0xFu) ? (uint32_t)((k0 + u) * 64 + lane) : 0u, bits, r[u]);
-#pragma unroll
-          for (int u = 0; u < B; u++) decode_packed_quad<true>(r[u], ((mb >> (4 * u)) & 0xFu) ? (uint32_t)((k0 + u) * 64 + lane) : 0u, bits, mask, d[u]);
-        } else {
-          uint32_t r[B][8];
-#pragma unroll
-          for (int u = 0; u < B; u++) load_packed_quad<false>(tw, ((mb >> (4 * u)) & 0xFu) ? (uint32_t)((k0 + u) * 64 + lane) : 0u, bits, r[u]);
-#pragma unroll
-          for (int u = 0; u < B; u++) decode_packed_quad<false>(r[u], ((mb >> (4 * u)) & 0xFu) ? (uint32_t)((k0 + u) * 64 + lane) : 0u, bits, mask, d[u]);
-        }
-        uint32_t* wp[B][4];
-        uint32_t want[B][4];   // DICT_SET: the bit; HLL: rank << shift-in-word, with the shift in the low 5 bits of `sh`
-        uint32_t sh[B][4];
-        if (A.kind == PG_AUX_DICT_SET) {
-#pragma unroll
-          for (int u = 0; u < B; u++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-              const size_t g = (size_t)(slot[u][i] >> p.replica_shift);
-              wp[u][i] = A.base + g * (size_t)A.stride + (d[u][i] >> 5);
-              want[u][i] = 1u << (d[u][i] & 31u);
-              sh[u][i] = 0;
-            }
-        } else {
-          uint32_t e[B][4];
-#pragma unroll
-          for (int u = 0; u < B; u++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) e[u][i] = gptr<uint32_t>(A.lut)[d[u][i]];
-#pragma unroll
-          for (int u = 0; u < B; u++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-              const size_t g = (size_t)(slot[u][i] >> p.replica_shift);
-              const uint32_t idx = e[u][i] & 0xFFFFu;
-              wp[u][i] = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(A.base) + g * (size_t)A.stride + (idx & ~3u));
-              sh[u][i] = (idx & 3u) * 8u;
-              want[u][i] = e[u][i] >> 16;
-            }
-        }
-        uint32_t cur[B][4];
-#pragma unroll
-        for (int u = 0; u < B; u++)
-#pragma unroll
-          for (int i = 0; i < 4; i++) cur[u][i] = __hip_atomic_load(wp[u][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int u = 0; u < B; u++)
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            if ((mb >> (4 * u + i)) & 1u) {
-              if (A.kind == PG_AUX_DICT_SET) {
-                if (!(cur[u][i] & want[u][i])) atomicOr(wp[u][i], want[u][i]);
-              } else {
-                uint32_t c = cur[u][i];
-                while (((c >> sh[u][i]) & 0xFFu) < want[u][i]) {
-                  const uint32_t nv = (c & ~(0xFFu << sh[u][i])) | (want[u][i] << sh[u][i]);
-                  const uint32_t prev = atomicCAS(wp[u][i], c, nv);
-                  if (prev == c) break;
-                  c = prev;
-                }
-              }
-            }
-          }
-      } else {   // raw column: DISTINCTCOUNTHLL hashes the value on the fly
-#pragma unroll
-        for (int u = 0; u < B; u++) {
-          const uint32_t nib = (mb >> (4 * u)) & 0xFu;
-          if (nib) {
-            const uint32_t q = (uint32_t)((k0 + u) * 64 + lane);
-            int64_t v[4];   // the long the value hashes as (Integer/Long value, Float raw int bits, Double raw long bits)
-            if (S.col_kind == PG_COL_RAW32) {
-              const u32x4 x = *gptr<u32x4>(S.data + (size_t)wtile * (PG_WAVE_DOCS * 4) + q * 16u);
-              v[0] = (int64_t)(int32_t)bswap32(x.x); v[1] = (int64_t)(int32_t)bswap32(x.y);
-              v[2] = (int64_t)(int32_t)bswap32(x.z); v[3] = (int64_t)(int32_t)bswap32(x.w);
-            } else {
-              const GAS u32x4* pp = gptr<u32x4>(S.data + (size_t)wtile * (PG_WAVE_DOCS * 8) + q * 32u);
-              const u32x4 a = pp[0], b = pp[1];
-              v[0] = (int64_t)(((uint64_t)bswap32(a.x) << 32) | bswap32(a.y)); v[1] = (int64_t)(((uint64_t)bswap32(a.z) << 32) | bswap32(a.w));
-              v[2] = (int64_t)(((uint64_t)bswap32(b.x) << 32) | bswap32(b.y)); v[3] = (int64_t)(((uint64_t)bswap32(b.z) << 32) | bswap32(b.w));
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-              if ((nib >> i) & 1u) {
-                const size_t g = (size_t)(slot[u][i] >> p.replica_shift);
-                const uint32_t e = hll_index_rank_dev(murmur_hash_long_dev(v[i]), A.log2m);
-                hll_update(reinterpret_cast<uint8_t*>(A.base) + g * (size_t)A.stride, e & 0xFFFFu, e >> 16);
-              }
-            }
-          }
-        }
-      }
+      for (int h = 0; h < B; h += AB)
+        aux_update_batch<AB>(p, (mb >> (4 * h)) & ((1u << (4 * AB)) - 1u), k0 + h, wtile, reinterpret_cast<const uint32_t(&)[AB][4]>(slot[h]), lane, part_lo);
     }
   }
 }
@@ -1033,7 +1138,10 @@ struct MaskStack {
 // compiler has 256 VGPRs per lane (no spills); two workgroups per CU when the LDS table allows.
 // dynamic LDS: the accumulator table (LDS / SINGLE modes)
 // =====================================================================================================================
-extern "C" __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_segment_query_kernel(const PgQueryPlan p) {
+// TABLE: 0 = no accumulator table (filter only / COUNT from the match count), 1 = LDS table (LDS / SINGLE / LDS_PART modes),
+// 2 = dense HBM table — three kernels instead of one so that each carries one inlined copy of the aggregation code.
+template <int TABLE>
+__device__ __forceinline__ void generic_query_body(const PgQueryPlan& p) {
   extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
   __shared__ uint32_t s_stat[PG_MAX_STATS];
   __shared__ uint32_t s_wscratch[PG_GENERIC_BLOCK / 64][64];
@@ -1041,8 +1149,9 @@ extern "C" __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_segment_query_
   const int lane = t & 63;
   const int wave = uniform(t >> 6);
   int64_t* lds_table = reinterpret_cast<int64_t*>(smem);
-  const bool lds_agg = (p.agg_mode == PG_AGG_LDS || p.agg_mode == PG_AGG_SINGLE);
-  const uint32_t table_slots = (uint32_t)p.n_groups * (uint32_t)p.replicas;
+  const bool part_agg = p.agg_mode == PG_AGG_LDS_PART;
+  const bool lds_agg = (p.agg_mode == PG_AGG_LDS || p.agg_mode == PG_AGG_SINGLE || part_agg);
+  const uint32_t table_slots = part_agg ? (uint32_t)p.part_groups : (uint32_t)p.n_groups * (uint32_t)p.replicas;
 
   if (t < PG_MAX_STATS) s_stat[t] = 0;
   if (lds_agg) {
@@ -1055,8 +1164,23 @@ extern "C" __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_segment_query_
 
   const uint32_t rep = (uint32_t)t & ((uint32_t)p.replicas - 1u);
   uint32_t my_matched = 0;
-  const int wstride = (int)gridDim.x * (PG_GENERIC_BLOCK / 64);
-  for (int wt = (int)blockIdx.x * (PG_GENERIC_BLOCK / 64) + wave; wt < p.n_wtiles; wt += wstride) {
+  // Tile walk.  Default: workgroup b takes chunks (= one wave tile per wavefront) b, b + grid, ...  Range-partitioned
+  // aggregation: the grid is 8 x per_xcd workgroups, dispatched round-robin over the 8 XCDs (workgroup b runs on XCD b % 8 —
+  // HW_REG_XCC_ID, tools/probes/atomic_scope.hip); XCD x owns the chunks c with c % 8 == x, and the n_parts ranges'
+  // workgroups of that XCD walk the same chunks (HBM once, L2 for the others), per_xcd / n_parts workgroups per range.
+  int chunk0 = (int)blockIdx.x, cstride = (int)gridDim.x;
+  uint32_t part_lo = 0;
+  bool count_stats = true;
+  if (part_agg) {
+    const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3, per_xcd = (int)gridDim.x >> 3;
+    const int range = idx & (p.n_parts - 1), j = idx / p.n_parts, nj = per_xcd / p.n_parts;
+    chunk0 = xcd + 8 * j;
+    cstride = 8 * nj;
+    part_lo = (uint32_t)range * (uint32_t)p.part_groups;
+    count_stats = range == 0;   // every range sees every doc: only range 0 reports the filter statistics
+  }
+  const int wstride = cstride * (PG_GENERIC_BLOCK / 64);
+  for (int wt = chunk0 * (PG_GENERIC_BLOCK / 64) + wave; wt < p.n_wtiles; wt += wstride) {
     const int64_t wbase = (int64_t)wt * PG_WAVE_DOCS;
     const int64_t rem = (int64_t)p.num_docs - wbase;
     const int32_t n_valid = rem >= PG_WAVE_DOCS ? PG_WAVE_DOCS : (int32_t)rem;
@@ -1089,7 +1213,7 @@ extern "C" __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_segment_query_
           const uint32_t nc = wave_sum_u32((uint32_t)__popc(cand));
           if (nc) {   // wave-uniform
             st.s0 = scan_dispatch(L, cand, wt, lane);
-            if (lane == 0) atomicAdd(&s_stat[L.stat_slot], nc);
+            if (lane == 0 && count_stats) atomicAdd(&s_stat[L.stat_slot], nc);
           }
           break;
         }
@@ -1109,24 +1233,29 @@ extern "C" __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_segment_query_
     }
 
     // ---- aggregation ----------------------------------------------------------------------------------------------
-    if (p.agg_mode != PG_AGG_NONE && __ballot(m != 0)) {
-      if (lds_agg) aggregate_wtile<4>(p, m, wt, lds_table, lane, rep);
-      else aggregate_wtile<4>(p, m, wt, p.partials, lane, rep);
+    if (TABLE != 0 && __ballot(m != 0)) {
+      if (TABLE == 1) {
+        if (p.fast_agg_shape) fast_aggregate_wtile<PG_FAST_AGG_B>(p, m, wt, lds_table, lane, rep);
+        else aggregate_wtile<PG_GENERIC_AGG_B>(p, m, wt, lds_table, lane, rep, part_lo);
+      } else {
+        aggregate_wtile<PG_GENERIC_AGG_B>(p, m, wt, p.partials, lane, rep);
+      }
     }
   }
 
   // ---- epilogue: statistics and accumulator flush -----------------------------------------------------------------------
   const uint32_t wsum = wave_sum_u32(my_matched);
-  if (lane == 0 && wsum) atomicAdd(&s_stat[0], wsum);
+  if (lane == 0 && wsum && count_stats) atomicAdd(&s_stat[0], wsum);
   __syncthreads();
   if (t < PG_MAX_STATS && s_stat[t]) atomicAdd(&p.stats[t], (unsigned long long)s_stat[t]);
 
   if (lds_agg) {
     const int R = p.replicas;
-    const int64_t n_out = (int64_t)p.n_ops * p.n_groups;
+    const int groups = part_agg ? p.part_groups : p.n_groups;   // this workgroup's partial table: [n_ops][groups]
+    const int64_t n_out = (int64_t)p.n_ops * groups;
     int64_t* out = p.partials + (int64_t)blockIdx.x * n_out;
     for (int64_t i = t; i < n_out; i += PG_GENERIC_BLOCK) {
-      const int o = (int)(i / p.n_groups);
+      const int o = (int)(i / groups);
       const PgAccOp op = p.ops[o];
       const int64_t* src = lds_table + i * R;   // (o * G + g) * R
       int64_t acc = src[0];
@@ -1145,6 +1274,9 @@ extern "C" __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_segment_query_
     }
   }
 }
+extern "C" __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_generic_query_f(const PgQueryPlan p) { generic_query_body<0>(p); }
+extern "C" __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_generic_query_l(const PgQueryPlan p) { generic_query_body<1>(p); }
+extern "C" __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_generic_query_g(const PgQueryPlan p) { generic_query_body<2>(p); }
 
 // Combines the per-workgroup partial tables: out[op][g].  One wavefront per output slot, lanes stride over the
 // workgroups, fixed butterfly order (deterministic also for floating sums).  The last block also moves the statistics
@@ -1178,6 +1310,38 @@ extern "C" __global__ void __launch_bounds__(256) pg_reduce_partials_kernel(cons
     return b > a ? b : a;
   };
   for (int w = lane; w < n_wg; w += 64) acc = combine(acc, partials[(int64_t)w * n_out + i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int64_t other = __shfl_xor((long long)acc, off, 64);
+    acc = combine(acc, other);
+  }
+  if (lane == 0) out[i] = acc;
+}
+
+// Range-partitioned partials: workgroup b holds [n_ops][part_groups] for range (b >> 3) & (n_parts - 1).  One wavefront per
+// output slot (op, group), lanes stride over the workgroups that own the group's range.
+extern "C" __global__ void __launch_bounds__(256) pg_reduce_parts_kernel(const int64_t* __restrict__ partials,
+                                                                          int64_t* __restrict__ out, int n_wg, int n_ops,
+                                                                          int n_groups, int n_parts, int part_groups,
+                                                                          const PgAccOp* __restrict__ ops) {
+  const int64_t n_out = (int64_t)n_ops * n_groups;
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_out) return;
+  const int o = (int)(i / n_groups), g = (int)(i % n_groups);
+  const int range = g / part_groups, l = g % part_groups;
+  const PgAccOp op = ops[o];
+  const int kind = (op.fn == PG_ACC_SUM && op.is_float) ? 0 : ((op.fn == PG_ACC_COUNT || op.fn == PG_ACC_SUM) ? 1 : (op.fn == PG_ACC_MIN ? 2 : 3));
+  int64_t acc = pg_acc_identity(op.fn, op.is_float);
+  auto combine = [&](int64_t a, int64_t b) -> int64_t {
+    if (kind == 0) return __double_as_longlong(__longlong_as_double(a) + __longlong_as_double(b));
+    if (kind == 1) return a + b;
+    if (kind == 2) return b < a ? b : a;
+    return b > a ? b : a;
+  };
+  const int64_t wg_stride = (int64_t)n_ops * part_groups;
+  for (int w = lane; w < n_wg; w += 64)
+    if (((w >> 3) & (n_parts - 1)) == range) acc = combine(acc, partials[(int64_t)w * wg_stride + (int64_t)o * part_groups + l]);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     const int64_t other = __shfl_xor((long long)acc, off, 64);

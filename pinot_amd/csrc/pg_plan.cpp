@@ -984,12 +984,28 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
     while (r < 64 && table_bytes * (r * 2) <= kLdsReplicaBudget) r *= 2;
     D.replicas = r;
   } else {
-    D.agg_mode = PG_AGG_GLOBAL;
+    // beyond one LDS table: range-partitioned LDS tables when <= 32 ranges cover the key space (LDS atomics sustain ~2e12/s,
+    // memory-side atomics on an HBM table ~2.4e10/s — tools/probes/atomic_scope.hip), else the dense HBM table
+    int parts = 2;
+    while (parts < 32 && table_bytes > kLdsTableBudget * parts) parts *= 2;
+    if (const char* e = getenv("PG_PART_MIN")) parts = std::max(parts, std::min(32, atoi(e)));   // measurement knob
+    // every range's workgroups visit every doc (~3.4e11 doc visits/s measured), so the partitioned form pays off when most
+    // docs reach the aggregation: parts * N / 3.4e11  <  matched * ops / 2.4e10.  Without a filter matched = N is known at
+    // plan time; with one, the dense HBM table stays the choice until the match count is known before the aggregation runs.
+    const bool all_match = root->kind == OpKind::MatchAll;
+    if (table_bytes <= kLdsTableBudget * parts && all_match && parts * 0.07 < (double)std::max(D.n_ops, 1)) {
+      D.agg_mode = PG_AGG_LDS_PART;
+      D.n_parts = parts;
+      D.part_groups = (int32_t)((G + parts - 1) / parts);
+    } else {
+      D.agg_mode = PG_AGG_GLOBAL;
+    }
     D.replicas = 1;
   }
   D.replica_shift = 0;
   while ((1 << D.replica_shift) < D.replicas) D.replica_shift++;
   if (D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE) P.lds_bytes += (size_t)G * D.replicas * D.n_ops * 8;
+  if (D.agg_mode == PG_AGG_LDS_PART) P.lds_bytes += (size_t)D.part_groups * D.n_ops * 8;
   // auxiliary regions (HBM): sizes per op, patched into the plan at execution
   for (int x = 0; x < D.n_aux; x++) {
     size_t bytes = D.aux[x].kind == PG_AUX_DICT_SET ? (size_t)G * D.aux[x].stride * 4 : (size_t)G * D.aux[x].stride;
@@ -1002,13 +1018,14 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
     P.aux_bytes.push_back(bytes * (size_t)n_rep);
   }
   // fast aggregation: LDS table, slots fit 16 bits, <= 8-bit group columns, 32-bit value sources
-  P.fast_agg = D.agg_mode != PG_AGG_GLOBAL && (int64_t)G * D.replicas <= 65536;   // (trivially true without a table)
+  P.fast_agg = D.agg_mode != PG_AGG_GLOBAL && D.agg_mode != PG_AGG_LDS_PART && (int64_t)G * D.replicas <= 65536;   // (trivially true without a table)
   if (D.n_aux > 0) P.fast_agg = false;   // set / HLL accumulators run in the interpreter kernel
   if (P.first_doc_op >= 0) P.fast_agg = false;
   for (Column* c : P.group_cols) if (c->bits > 8) P.fast_agg = false;
   for (Column* c : srcs)
     if (!(c->col_kind == PG_COL_RAW32 || (c->col_kind == PG_COL_FIXED_BIT && (c->val_type == PG_V_I32 || c->val_type == PG_V_F32))))
       P.fast_agg = false;
+  D.fast_agg_shape = (P.fast_agg && (D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE)) ? 1 : 0;
   return plan;
 }
 

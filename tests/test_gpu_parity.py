@@ -314,3 +314,36 @@ def test_num_groups_limit_config5_shape(gpu_api, oracle_api):
         assert gb.stats.num_groups_limit_reached == ob.stats.num_groups_limit_reached == (1 if limit <= 12_800 else 0)
     g.destroy()
     o.destroy()
+
+
+# ---- key spaces beyond one LDS table: range-partitioned LDS aggregation (PG_AGG_LDS_PART) and the dense HBM table ------------
+PART_QUERIES = [
+    "SELECT g1, g2, c_inv1, COUNT(*), SUM(m) FROM gpuBench GROUP BY g1, g2, c_inv1 LIMIT 100000",                 # 40 000 keys
+    "SELECT g1, g2, c_inv1, SUM(m), MAX(m), MIN(r_int) FROM gpuBench WHERE r_int < 125000 GROUP BY g1, g2, c_inv1 LIMIT 100000",
+    "SELECT g1, g2, c_inv1, c_inv2, COUNT(*), AVG(m) FROM gpuBench WHERE c_inv2 IN (0, 3) GROUP BY g1, g2, c_inv1, c_inv2 LIMIT 200000",
+    "SELECT g2, g1, c_inv2, DISTINCTCOUNT(c_inv1), COUNT(*) FROM gpuBench WHERE m > 500000 GROUP BY g2, g1, c_inv2 LIMIT 100000",
+    "SELECT g1, g2, c_inv1, c_inv2, COUNT(*) FROM gpuBench WHERE c_inv1 = 2 AND g1 BETWEEN 10 AND 20 GROUP BY g1, g2, c_inv1, c_inv2 LIMIT 200000",
+]
+
+
+@pytest.fixture(scope="module", params=[1_500, 70_001, 600_000])
+def bench_seg(request, gpu_api, oracle_api):
+    host = synth.generate_segment(request.param, segment_index=5, columns=synth.CFG3_COLUMNS, native=False)
+    g, o = both(gpu_api, oracle_api, host)
+    yield g, o
+    g.destroy()
+    o.destroy()
+
+
+@pytest.mark.parametrize("q", PART_QUERIES)
+def test_partitioned_group_by_matches_oracle(bench_seg, q):
+    g, o = bench_seg
+    assert_same_block(g.execute(q), o.execute(q))
+
+
+def test_partitioned_group_by_with_limit(bench_seg):
+    from pinot_amd.query import parse_sql
+    g, o = bench_seg
+    qg, qo = parse_sql(PART_QUERIES[0]), parse_sql(PART_QUERIES[0])
+    qg.num_groups_limit = qo.num_groups_limit = 1234
+    assert_same_block(g.execute(qg), o.execute(qo))

@@ -14,12 +14,13 @@ from pinot_amd.segment import HostSegment
 ap = argparse.ArgumentParser()
 ap.add_argument("--docs", type=int, default=200_000_000)
 ap.add_argument("--reps", type=int, default=10)
-ap.add_argument("--set", choices=["cfg3", "cfg5"], default="cfg3")
+ap.add_argument("--only", default="", help="substring of the query names to run")
+ap.add_argument("--set", choices=["cfg3", "cfg5", "general"], default="cfg3")
 args = ap.parse_args()
 api = capi.gpu_api()
 api.call("init", 0)
 seg = NativeSegment(api, HostSegment("prof", args.docs))
-for name in (synth.CFG3_COLUMNS if args.set == "cfg3" else synth.CFG5_COLUMNS):
+for name in (synth.CFG5_COLUMNS if args.set == "cfg5" else synth.CFG3_COLUMNS):
     one = synth.generate_segment(args.docs, columns=[name])
     seg.add_column(one.columns[name], keep_host_buffers=False)
 
@@ -41,9 +42,22 @@ QUERIES5 = {
     "cfg5 distinctcount(u) group h1": ("SELECT h1, DISTINCTCOUNT(u) FROM t GROUP BY h1", 3.0),
     "cfg5 count group h1..h3": ("SELECT h1, h2, h3, COUNT(*) FROM t GROUP BY h1, h2, h3 LIMIT 20000", 1.5),
 }
+QUERIES_GENERAL = {   # shapes outside the specialised kernels: several scans, OR of scans, tables beyond LDS
+    "2 scans + group g1": ("SELECT g1, SUM(m) FROM t WHERE r_int BETWEEN 250000 AND 749999 AND m < 524288 GROUP BY g1", 8.875),
+    "postings + 2 scans + group": ("SELECT g1, SUM(m), MAX(m) FROM t WHERE c_inv1 IN (0,1,2,3) AND r_int BETWEEN 250000 AND 749999 AND m < 524288 GROUP BY g1", 9.375),
+    "or of 2 scans count": ("SELECT COUNT(*) FROM t WHERE r_int < 100000 OR m > 900000", 8.0),
+    "dict scan + raw scan": ("SELECT COUNT(*) FROM t WHERE g1 < 50 AND r_int < 500000", 4.875),
+    "group g1,g2,c_inv1 (40k groups)": ("SELECT g1, g2, c_inv1, COUNT(*), SUM(m) FROM t GROUP BY g1, g2, c_inv1 LIMIT 100000", 6.0),
+    "filtered 40k groups": ("SELECT g1, g2, c_inv1, SUM(m) FROM t WHERE r_int < 125000 GROUP BY g1, g2, c_inv1 LIMIT 100000", 10.0),
+    "avg/min/max/count no group": ("SELECT COUNT(*), AVG(m), MIN(r_int), MAX(m) FROM t WHERE c_inv2 = 1", 8.125),
+}
 if args.set == "cfg5":
     QUERIES = QUERIES5
+if args.set == "general":
+    QUERIES = QUERIES_GENERAL
 for name, (sql, bpr) in QUERIES.items():
+    if args.only and args.only not in name:
+        continue
     qc = parse_sql(sql)
     qc.flags |= capi.QUERY_FLAG_PROFILE
     cq = CQuery(qc)
@@ -57,4 +71,7 @@ for name, (sql, bpr) in QUERIES.items():
         if i >= 2:
             ms.append(st.device_ms_aggregate)
     m = statistics.median(ms)
-    print(f"{name:32s} {m:8.3f} ms  {bpr * args.docs / m / 1e6:8.1f} GB/s  ({bpr * args.docs / m / 1e6 / 80:5.1f}% of 8 TB/s)  matched={st.num_docs_scanned}")
+    if m <= 0:
+        print(f"{name:32s} no kernel ran (answered on the host)")
+        continue
+    print(f"{name:32s} {st.kernel.decode():24s} {m:8.3f} ms  {bpr * args.docs / m / 1e6:8.1f} GB/s  ({bpr * args.docs / m / 1e6 / 80:5.1f}% of 8 TB/s)  matched={st.num_docs_scanned}")

@@ -16,10 +16,14 @@ for r in rows:
     print(f"{r[0][:44]:44s} {r[1]:6d} {r[2] / 1e6:10.3f} {r[3] / 1e3:10.2f} {r[4] / 1e3:10.2f} {r[5] / 1e3:10.2f} "
           f"{100.0 * r[2] / total:6.2f} {r[6]:5d} {r[7]:5d} {r[8]:5d} {r[9]:7d} {r[10]:8d} {r[11]:5d}")
 try:
-    pm = list(cur.execute("select name, count(*), avg(value), sum(value) from pmc_events group by name"))
+    pm = list(cur.execute("select kernel_name, counter_name, count(*), avg(value) from "
+                          "(select dispatch_id, kernel_name, counter_name, sum(value) as value from counters_collection "
+                          " group by dispatch_id, kernel_name, counter_name) group by kernel_name, counter_name order by 1, 2"))
     if pm:
-        print("\ncounters (per-dispatch average, all kernels):")
+        print("\ncounters (per-dispatch average, summed over instances):")
         for r in pm:
-            print(f"  {r[0]:32s} n={r[1]:6d} avg={r[2]:.6g} sum={r[3]:.6g}")
+            if r[0].startswith("__amd"):
+                continue
+            print(f"  {r[0][:36]:36s} {r[1]:28s} n={r[2]:5d} avg={r[3]:.6g}")
 except Exception as e:  # noqa
-    pass
+    print("no counters:", e)
