@@ -196,6 +196,8 @@ struct PgQueryPlan {
   int32_t replicas;                 // R: LDS copies per group (power of two) to spread atomic conflicts
   int32_t replica_shift;            // log2(R): group index = slot >> replica_shift
   int32_t n_aux;
+  int32_t n_lin_prefix;             // interpreter kernels: instrs[0, n_lin_prefix) is index-only and leaves one stack entry
+  int32_t pad_l;
   int32_t n_parts;                  // PG_AGG_LDS_PART: key ranges (power of two dividing the workgroups per XCD)
   int32_t part_groups;              // PG_AGG_LDS_PART: keys per range
   PgAuxOp aux[PG_MAX_AUX];

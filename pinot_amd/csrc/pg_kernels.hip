@@ -884,9 +884,9 @@ struct LinStack {
 };
 
 // index-only filter program in linear layout (one dword = 32 consecutive docs per lane)
-DEVFN uint32_t index_program_lin(const PgQueryPlan& p, int wt, int64_t wbase, uint32_t valid_l, uint32_t* wscratch, int lane) {
+DEVFN uint32_t index_program_lin(const PgQueryPlan& p, int n_instr, int wt, int64_t wbase, uint32_t valid_l, uint32_t* wscratch, int lane) {
   LinStack st;
-  for (int i = 0; i < p.n_index_instr; i++) {
+  for (int i = 0; i < n_instr; i++) {
     const int op = cptr(p.instrs)[i].op, arg = cptr(p.instrs)[i].arg;
     switch (op) {
       case PG_F_PUSH_POSTINGS: st.push(postings_wtile(cptr(p.postings)[arg], wt, valid_l, wscratch, lane)); break;
@@ -1087,7 +1087,7 @@ __device__ __forceinline__ void fast_query_body(const PgQueryPlan& p) {
     const int32_t n_valid = rem >= PG_WAVE_DOCS ? PG_WAVE_DOCS : (int32_t)rem;
     uint32_t m = valid_quad_mask(n_valid, lane);
     if (p.n_index_instr > 0)
-      m = lin_to_quad(index_program_lin(p, wt, wbase, valid_lin_mask(n_valid, lane), s_wscratch[wave], lane), lane);
+      m = lin_to_quad(index_program_lin(p, p.n_index_instr, wt, wbase, valid_lin_mask(n_valid, lane), s_wscratch[wave], lane), lane);
     if (SK >= 0) {
       my_cand += (uint32_t)__popc(m);
       const GAS uint8_t* tb = sk_dict(SK) ? (const GAS uint8_t*)packed_wtile_base(L.data, wt, L.bits)
@@ -1189,7 +1189,8 @@ __device__ __forceinline__ void generic_query_body(const PgQueryPlan& p) {
 
     // ---- filter program ---------------------------------------------------------------------------------------------
     MaskStack st;
-    for (int i = 0; i < p.n_instr; i++) {
+    if (p.n_lin_prefix > 0) st.push(lin_to_quad(index_program_lin(p, p.n_lin_prefix, wt, wbase, valid_l, s_wscratch[wave], lane), lane));
+    for (int i = p.n_lin_prefix; i < p.n_instr; i++) {
       const int fop = cptr(p.instrs)[i].op, farg = cptr(p.instrs)[i].arg;
       switch (fop) {
         case PG_F_PUSH_POSTINGS:

@@ -759,6 +759,18 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
     };
     size_t n_idx = 0;
     while (n_idx < em.instrs.size() && index_op(em.instrs[n_idx].op)) n_idx++;
+    {   // the interpreter kernels evaluate the longest index-only prefix that leaves exactly ONE entry on the stack in linear
+        // layout (one dword per 32 docs, one transpose for the whole prefix instead of one per leaf)
+      int depth = 0;
+      size_t best = 0;
+      for (size_t i = 0; i < n_idx; i++) {
+        const int op = em.instrs[i].op;
+        if (op == PG_F_AND || op == PG_F_OR) depth--;
+        else if (op != PG_F_NOT) depth++;
+        if (depth == 1) best = i + 1;
+      }
+      D.n_lin_prefix = (int32_t)best;
+    }
     const size_t rest = em.instrs.size() - n_idx;
     P.fast_filter = -2;   // -2: interpreter; -1: no scan; >= 0: ScanKind of the single scan
     D.fast_scan = -1;
