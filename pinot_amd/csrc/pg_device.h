@@ -27,6 +27,7 @@
 #define PG_MAX_SRCS 8
 #define PG_MAX_OPS 16
 #define PG_MAX_STATS 16
+#define PG_MAX_FAST_SCANS 4
 #define PG_GENERIC_BLOCK 512      // interpreter kernel workgroup
 #define PG_BLOCK (PG_WAVES_PER_BLOCK * 64)   // one 16-wave workgroup per CU: every wave shares one LDS accumulator table
 
@@ -197,7 +198,7 @@ struct PgQueryPlan {
   int32_t replica_shift;            // log2(R): group index = slot >> replica_shift
   int32_t n_aux;
   int32_t n_lin_prefix;             // interpreter kernels: instrs[0, n_lin_prefix) is index-only and leaves one stack entry
-  int32_t pad_l;
+  int32_t n_fast_scans;             // pg_fast_multi_*: instrs[n_index_instr, n_index_instr + n_fast_scans) are scan leaves ANDed in order
   int32_t n_parts;                  // PG_AGG_LDS_PART: key ranges (power of two dividing the workgroups per XCD)
   int32_t part_groups;              // PG_AGG_LDS_PART: keys per range
   PgAuxOp aux[PG_MAX_AUX];

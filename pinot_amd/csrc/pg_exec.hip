@@ -15,6 +15,7 @@
 PG_DECL_GENERIC
 PG_DECL_FAST(pg_fast_none_f) PG_DECL_FAST(pg_fast_none_a) PG_DECL_FAST(pg_fast_i32range_f) PG_DECL_FAST(pg_fast_i32range_a)
 PG_DECL_FAST(pg_fast_dictrange_f) PG_DECL_FAST(pg_fast_dictrange_a) PG_DECL_FAST(pg_fast_dictlut_f) PG_DECL_FAST(pg_fast_dictlut_a)
+PG_DECL_FAST(pg_fast_multi_f) PG_DECL_FAST(pg_fast_multi_a)
 extern "C" __global__ void pg_reduce_partials_kernel(const int64_t* partials, int64_t* out, int n_wg, int n_ops,
                                                      int n_groups, const PgAccOp* ops, unsigned long long* stats, int reduce);
 extern "C" __global__ void pg_reduce_parts_kernel(const int64_t* partials, int64_t* out, int n_wg, int n_ops, int n_groups,
@@ -75,7 +76,7 @@ void device_init(int ordinal) {
   // opt in to large dynamic LDS for the query kernels
   typedef void (*QueryKernel)(const PgQueryPlan);
   const QueryKernel all[] = {pg_generic_query_f, pg_generic_query_l, pg_generic_query_g, pg_fast_none_f, pg_fast_none_a, pg_fast_i32range_f, pg_fast_i32range_a,
-                             pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a};
+                             pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a, pg_fast_multi_f, pg_fast_multi_a};
   for (QueryKernel k : all)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
 }
@@ -97,6 +98,7 @@ static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char
       case 4: *name = agg ? "pg_fast_i32range_a" : "pg_fast_i32range_f"; return agg ? pg_fast_i32range_a : pg_fast_i32range_f;
       case 0: *name = agg ? "pg_fast_dictrange_a" : "pg_fast_dictrange_f"; return agg ? pg_fast_dictrange_a : pg_fast_dictrange_f;
       case 2: *name = agg ? "pg_fast_dictlut_a" : "pg_fast_dictlut_f"; return agg ? pg_fast_dictlut_a : pg_fast_dictlut_f;
+      case 100: *name = agg ? "pg_fast_multi_a" : "pg_fast_multi_f"; return agg ? pg_fast_multi_a : pg_fast_multi_f;
       default: break;
     }
   }

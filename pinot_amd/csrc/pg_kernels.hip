@@ -1113,6 +1113,80 @@ __device__ __forceinline__ void fast_query_body(const PgQueryPlan& p) {
   flush_workgroup(p, lds_table, s_stat, AGG && p.agg_mode != PG_AGG_NONE, t);
 }
 
+// Chain of up to PG_MAX_FAST_SCANS scan leaves, kind dispatched per leaf (wave-uniform): the shape of most multi-predicate
+// filters (several range / IN predicates ANDed, optionally behind inverted-index leaves).
+template <int AGG>
+__device__ __forceinline__ void fast_multi_body(const PgQueryPlan& p) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
+  __shared__ uint32_t s_stat[PG_MAX_STATS];
+  __shared__ uint32_t s_wscratch[PG_WAVES_PER_BLOCK][64];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = uniform(t >> 6);
+  int64_t* lds_table = reinterpret_cast<int64_t*>(smem);
+  if (t < PG_MAX_STATS) s_stat[t] = 0;
+  if (AGG) {
+    const uint32_t table_slots = (uint32_t)p.n_groups * (uint32_t)p.replicas;
+    for (int o = 0; o < p.n_ops; o++) {
+      const int64_t ident = pg_acc_identity(p.ops[o].fn, p.ops[o].is_float);
+      for (uint32_t i = t; i < table_slots; i += PG_BLOCK) lds_table[(size_t)o * table_slots + i] = ident;
+    }
+  }
+  __syncthreads();
+
+  const uint32_t rep = (uint32_t)t & ((uint32_t)p.replicas - 1u);
+  uint32_t my_matched = 0;
+  uint32_t my_cand[PG_MAX_FAST_SCANS] = {0, 0, 0, 0};
+  const int wstride = (int)gridDim.x * PG_WAVES_PER_BLOCK;
+  for (int wt = (int)blockIdx.x * PG_WAVES_PER_BLOCK + wave; wt < p.n_wtiles; wt += wstride) {
+    const int64_t wbase = (int64_t)wt * PG_WAVE_DOCS;
+    const int64_t rem = (int64_t)p.num_docs - wbase;
+    const int32_t n_valid = rem >= PG_WAVE_DOCS ? PG_WAVE_DOCS : (int32_t)rem;
+    uint32_t m = valid_quad_mask(n_valid, lane);
+    if (p.n_index_instr > 0)
+      m = lin_to_quad(index_program_lin(p, p.n_index_instr, wt, wbase, valid_lin_mask(n_valid, lane), s_wscratch[wave], lane), lane);
+#pragma unroll
+    for (int sidx = 0; sidx < PG_MAX_FAST_SCANS; sidx++) {
+      if (sidx < p.n_fast_scans && __ballot(m != 0)) {   // wave-uniform
+        const CAS PgScanLeaf& L = cptr(p.scans)[cptr(p.instrs)[p.n_index_instr + sidx].arg];
+        my_cand[sidx] += (uint32_t)__popc(m);
+        if (L.col_kind == PG_COL_FIXED_BIT) {
+          const GAS uint8_t* tb = (const GAS uint8_t*)packed_wtile_base(L.data, wt, L.bits);
+          m = L.pred_kind == PG_P_RANGE ? scan_wtile<SK_DICT_RANGE_SMALL>(L, m, tb, lane) : scan_wtile<SK_DICT_LUT_SMALL>(L, m, tb, lane);
+        } else if (L.col_kind == PG_COL_RAW32) {
+          const GAS uint8_t* tb = gptr<uint8_t>(L.data + (size_t)wt * (PG_WAVE_DOCS * 4));
+          m = L.val_type == PG_V_I32 ? scan_wtile<SK_I32_RANGE>(L, m, tb, lane) : scan_wtile<SK_F32_RANGE>(L, m, tb, lane);
+        } else {
+          const GAS uint8_t* tb = gptr<uint8_t>(L.data + (size_t)wt * (PG_WAVE_DOCS * 8));
+          m = L.val_type == PG_V_I64 ? scan_wtile<SK_I64_RANGE>(L, m, tb, lane) : scan_wtile<SK_F64_RANGE>(L, m, tb, lane);
+        }
+      }
+    }
+    const uint32_t cnt = (uint32_t)__popc(m);
+    my_matched += cnt;
+    if (p.out_words) reinterpret_cast<uint32_t*>(p.out_words)[(int64_t)wt * 64 + lane] = quad_to_lin(m, lane);
+    if (p.out_tile_counts) {
+      const uint32_t wsum = wave_sum_u32(cnt);
+      if (lane == 0 && wsum) atomicAdd(&p.out_tile_counts[wt / PG_WTILES_PER_TILE], wsum);
+    }
+    if (AGG && p.agg_mode != PG_AGG_NONE && __ballot(m != 0)) fast_aggregate_wtile<PG_FAST_AGG_B>(p, m, wt, lds_table, lane, rep);
+  }
+  const uint32_t wsum = wave_sum_u32(my_matched);
+  if (lane == 0 && wsum) atomicAdd(&s_stat[0], wsum);
+#pragma unroll
+  for (int sidx = 0; sidx < PG_MAX_FAST_SCANS; sidx++) {
+    if (sidx < p.n_fast_scans && !(sidx == 0 && p.fast_scan_pushed)) {
+      const uint32_t csum = wave_sum_u32(my_cand[sidx]);
+      const int slot = cptr(p.scans)[cptr(p.instrs)[p.n_index_instr + sidx].arg].stat_slot;
+      if (lane == 0 && csum) atomicAdd(&s_stat[slot], csum);
+    }
+  }
+  __syncthreads();
+  flush_workgroup(p, lds_table, s_stat, AGG && p.agg_mode != PG_AGG_NONE, t);
+}
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_fast_multi_f(const PgQueryPlan p) { fast_multi_body<0>(p); }
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_fast_multi_a(const PgQueryPlan p) { fast_multi_body<1>(p); }
+
 #define PG_FAST_KERNEL(NAME, SK, AGG) \
   extern "C" __global__ void __launch_bounds__(PG_BLOCK) NAME(const PgQueryPlan p) { fast_query_body<SK, AGG>(p); }
 PG_FAST_KERNEL(pg_fast_none_f, -1, 0)

@@ -792,6 +792,32 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
         D.fast_scan_pushed = n_idx == 0 ? 1 : 0;
       }
     }
+    if (P.fast_filter == -2 && rest >= 1 && rest <= PG_MAX_FAST_SCANS) {
+      // [index-only program] AND scan AND scan ...: a chain of up to 4 scan leaves of the common kinds (<= 8-bit dictionary range /
+      // LUT, raw INT / LONG / FLOAT / DOUBLE range), each restricted to the survivors of the previous one (AndDocIdSet applies
+      // the scan iterators in list order) — pg_fast_multi_* dispatches the kind per leaf at run time
+      auto multi_kind = [&](const PgScanLeaf& L) {
+        if (L.col_kind == PG_COL_FIXED_BIT) return L.bits <= 8 && (L.pred_kind == PG_P_RANGE || L.pred_kind == PG_P_DICT_LUT);
+        return L.pred_kind == PG_P_RANGE;
+      };
+      bool ok = true;
+      for (size_t i = n_idx; i < em.instrs.size() && ok; i++) {
+        const int op = em.instrs[i].op;
+        ok = (op == PG_F_AND_SCAN || (i == 0 && op == PG_F_PUSH_SCAN)) && multi_kind(em.scans[em.instrs[i].arg]);
+      }
+      if (ok && n_idx > 0) {   // the prefix must leave exactly one entry (it does when the program is index ops then AND_SCANs)
+        int depth = 0;
+        for (size_t i = 0; i < n_idx; i++) depth += (em.instrs[i].op == PG_F_AND || em.instrs[i].op == PG_F_OR) ? -1 : (em.instrs[i].op == PG_F_NOT ? 0 : 1);
+        ok = depth == 1;
+      }
+      if (ok) {
+        P.fast_filter = 100;
+        D.n_index_instr = (int32_t)n_idx;
+        D.n_fast_scans = (int32_t)rest;
+        D.fast_scan_pushed = n_idx == 0 ? 1 : 0;
+        if (n_idx == 1 && em.instrs[0].op == PG_F_PUSH_ALL) { /* cannot happen: and_operator drops match-all children */ }
+      }
+    }
   }
   P.lds_bytes = 0;   // the filter stack lives in registers
   if (!q || q->n_aggregations <= 0) return plan;
