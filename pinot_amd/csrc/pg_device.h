@@ -41,7 +41,8 @@ enum PgFOp : int32_t {
   PG_F_OR = 5,              // pop b, top |= b
   PG_F_NOT = 6,             // top = ~top & valid
   PG_F_PUSH_NONE = 7,       // push empty set
-  PG_F_PUSH_ALL = 8         // push every doc of the tile (MatchAllFilterOperator)
+  PG_F_PUSH_ALL = 8,        // push every doc of the tile (MatchAllFilterOperator)
+  PG_F_PUSH_WORDS = 9       // push a precomputed docId set given as match words (range leaf `arg`, one dword per 32 docs)
 };
 
 struct PgFInstr {

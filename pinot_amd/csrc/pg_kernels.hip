@@ -372,7 +372,6 @@ DEVFN uint32_t postings_wtile(const LeafT& L, int wtile, uint32_t valid_lin, uin
 // docId ranges (sorted index / match-all), linear layout
 template <class LeafT>
 DEVFN uint32_t ranges_wtile(const LeafT& L, int64_t wbase, uint32_t valid_lin, int lane) {
-  if (L.words) return gptr<uint32_t>(L.words)[(wbase / PG_WAVE_DOCS) * 64 + lane] & valid_lin;   // wave-uniform branch
   const int64_t wb = wbase + (int64_t)lane * 32, we = wb + 31;
   const int64_t tile_end = wbase + PG_WAVE_DOCS - 1;
   int a = 0, b = L.n;   // first range whose hi >= wbase (ranges ascending, disjoint)
@@ -884,6 +883,7 @@ struct LinStack {
 };
 
 // index-only filter program in linear layout (one dword = 32 consecutive docs per lane)
+template <bool WORDS>   // WORDS: also understands PG_F_PUSH_WORDS (interpreter kernels only: the specialised kernels sit at 128 VGPRs)
 DEVFN uint32_t index_program_lin(const PgQueryPlan& p, int n_instr, int wt, int64_t wbase, uint32_t valid_l, uint32_t* wscratch, int lane) {
   LinStack st;
   for (int i = 0; i < n_instr; i++) {
@@ -891,6 +891,7 @@ DEVFN uint32_t index_program_lin(const PgQueryPlan& p, int n_instr, int wt, int6
     switch (op) {
       case PG_F_PUSH_POSTINGS: st.push(postings_wtile(cptr(p.postings)[arg], wt, valid_l, wscratch, lane)); break;
       case PG_F_PUSH_RANGES: st.push(ranges_wtile(cptr(p.ranges)[arg], wbase, valid_l, lane)); break;
+      case PG_F_PUSH_WORDS: if (WORDS) st.push(gptr<uint32_t>(cptr(p.ranges)[arg].words)[(int64_t)wt * 64 + lane] & valid_l); break;
       case PG_F_PUSH_ALL: st.push(valid_l); break;
       case PG_F_PUSH_NONE: st.push(0u); break;
       case PG_F_AND: { const uint32_t b = st.s0; st.drop(); st.s0 &= b; break; }
@@ -1087,7 +1088,7 @@ __device__ __forceinline__ void fast_query_body(const PgQueryPlan& p) {
     const int32_t n_valid = rem >= PG_WAVE_DOCS ? PG_WAVE_DOCS : (int32_t)rem;
     uint32_t m = valid_quad_mask(n_valid, lane);
     if (p.n_index_instr > 0)
-      m = lin_to_quad(index_program_lin(p, p.n_index_instr, wt, wbase, valid_lin_mask(n_valid, lane), s_wscratch[wave], lane), lane);
+      m = lin_to_quad(index_program_lin<false>(p, p.n_index_instr, wt, wbase, valid_lin_mask(n_valid, lane), s_wscratch[wave], lane), lane);
     if (SK >= 0) {
       my_cand += (uint32_t)__popc(m);
       const GAS uint8_t* tb = sk_dict(SK) ? (const GAS uint8_t*)packed_wtile_base(L.data, wt, L.bits)
@@ -1144,7 +1145,7 @@ __device__ __forceinline__ void fast_multi_body(const PgQueryPlan& p) {
     const int32_t n_valid = rem >= PG_WAVE_DOCS ? PG_WAVE_DOCS : (int32_t)rem;
     uint32_t m = valid_quad_mask(n_valid, lane);
     if (p.n_index_instr > 0)
-      m = lin_to_quad(index_program_lin(p, p.n_index_instr, wt, wbase, valid_lin_mask(n_valid, lane), s_wscratch[wave], lane), lane);
+      m = lin_to_quad(index_program_lin<false>(p, p.n_index_instr, wt, wbase, valid_lin_mask(n_valid, lane), s_wscratch[wave], lane), lane);
 #pragma unroll
     for (int sidx = 0; sidx < PG_MAX_FAST_SCANS; sidx++) {
       if (sidx < p.n_fast_scans && __ballot(m != 0)) {   // wave-uniform
@@ -1263,7 +1264,7 @@ __device__ __forceinline__ void generic_query_body(const PgQueryPlan& p) {
 
     // ---- filter program ---------------------------------------------------------------------------------------------
     MaskStack st;
-    if (p.n_lin_prefix > 0) st.push(lin_to_quad(index_program_lin(p, p.n_lin_prefix, wt, wbase, valid_l, s_wscratch[wave], lane), lane));
+    if (p.n_lin_prefix > 0) st.push(lin_to_quad(index_program_lin<true>(p, p.n_lin_prefix, wt, wbase, valid_l, s_wscratch[wave], lane), lane));
     for (int i = p.n_lin_prefix; i < p.n_instr; i++) {
       const int fop = cptr(p.instrs)[i].op, farg = cptr(p.instrs)[i].arg;
       switch (fop) {
@@ -1272,6 +1273,9 @@ __device__ __forceinline__ void generic_query_body(const PgQueryPlan& p) {
           break;
         case PG_F_PUSH_RANGES:
           st.push(lin_to_quad(ranges_wtile(cptr(p.ranges)[farg], wbase, valid_l, lane), lane));
+          break;
+        case PG_F_PUSH_WORDS:
+          st.push(lin_to_quad(gptr<uint32_t>(cptr(p.ranges)[farg].words)[(int64_t)wt * 64 + lane] & valid_l, lane));
           break;
         case PG_F_PUSH_ALL:
           st.push(valid_q);

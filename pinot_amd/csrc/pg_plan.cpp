@@ -345,7 +345,7 @@ struct Emitter {
     L.lo = keep(lo);
     L.hi = keep(hi);
     ranges.push_back(L);
-    instrs.push_back({PG_F_PUSH_RANGES, (int32_t)ranges.size() - 1});
+    instrs.push_back({L.words ? PG_F_PUSH_WORDS : PG_F_PUSH_RANGES, (int32_t)ranges.size() - 1});
     push();
   }
 
@@ -754,7 +754,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
   // ---- fast-path shape of the filter: [index-only program] (AND one scan of a specialised kind) ---------------------------
   {
     auto index_op = [](int32_t op) {
-      return op == PG_F_PUSH_POSTINGS || op == PG_F_PUSH_RANGES || op == PG_F_PUSH_ALL || op == PG_F_PUSH_NONE ||
+      return op == PG_F_PUSH_POSTINGS || op == PG_F_PUSH_RANGES || op == PG_F_PUSH_WORDS || op == PG_F_PUSH_ALL || op == PG_F_PUSH_NONE ||   // (WORDS: see below)
              op == PG_F_AND || op == PG_F_OR || op == PG_F_NOT;
     };
     size_t n_idx = 0;
@@ -771,7 +771,10 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
       }
       D.n_lin_prefix = (int32_t)best;
     }
-    const size_t rest = em.instrs.size() - n_idx;
+    size_t rest = em.instrs.size() - n_idx;
+    bool has_words = false;   // match-word leaves (star-tree traversals with many ranges) are the interpreter kernels' business
+    for (auto& in : em.instrs) has_words |= in.op == PG_F_PUSH_WORDS;
+    if (has_words) rest = 1000;
     P.fast_filter = -2;   // -2: interpreter; -1: no scan; >= 0: ScanKind of the single scan
     D.fast_scan = -1;
     auto scan_kind = [&](const PgScanLeaf& L) -> int {   // kinds with a specialised kernel (pg_kernels.hip ScanKind values)
