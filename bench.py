@@ -136,7 +136,9 @@ def main():
     except OSError:
         pass
     out = {
-        "metric": "rows scanned/sec, 1B-row segment filter+groupby (3 predicates, SUM/MAX GROUP BY g1)",
+        "metric": {"cfg3": "rows scanned/sec, 1B-row segment filter+groupby (3 predicates, SUM/MAX GROUP BY g1)",
+                   "northstar": "rows scanned/sec, segment filter+groupby (3 predicates, SUM GROUP BY g1, g2)",
+                   "cfg2": "rows scanned/sec, segment range-predicate COUNT(*)"}[args.query],
         "value": value,
         "unit": "rows/s",
         "n_gpus": world,
