@@ -112,18 +112,13 @@ def all_reduce_tables(t: DenseGroupTable, device=None) -> DenseGroupTable:
     x = x.reshape(-1)
     gathered = torch.empty(world * x.numel(), dtype=x.dtype, device=x.device)
     dist.all_gather_into_tensor(gathered, x)          # flat buffers: the one form both RCCL and gloo accept
-    gathered = gathered.view(world, packed.shape[0], packed.shape[1])
-    parts = []
+    g = gathered.cpu().numpy().reshape(world, packed.shape[0], packed.shape[1])   # one D2H; the KB-sized reduce runs on the host
     if n_sum:
-        parts.append(gathered[:, :n_sum].sum(dim=0))
+        t.sum_rows[...] = g[:, :n_sum].sum(axis=0)
     if n_max:
-        parts.append(gathered[:, n_sum:n_sum + n_max].amax(dim=0))
+        t.max_rows[...] = g[:, n_sum:n_sum + n_max].max(axis=0)
     if n_min:
-        parts.append(gathered[:, n_sum + n_max:].amin(dim=0))
-    merged = torch.cat(parts, dim=0).cpu().numpy()
-    t.sum_rows[...] = merged[:n_sum]
-    t.max_rows[...] = merged[n_sum:n_sum + n_max]
-    t.min_rows[...] = merged[n_sum + n_max:]
+        t.min_rows[...] = g[:, n_sum + n_max:].min(axis=0)
     return t
 
 
