@@ -149,13 +149,11 @@ static double now_ms() {
 
 static std::shared_ptr<CompiledPlan> get_plan(Segment& seg, const pg_filter_node* filter, const pg_query* q) {
   std::string sig = query_signature(filter, q);
-  {
-    std::lock_guard<std::mutex> g(seg.mu);
-    auto it = seg.plan_cache.find(sig);
-    if (it != seg.plan_cache.end()) return it->second;
-  }
-  auto plan = compile_plan(seg, filter, q);
+  // compilation stays under the segment's lock: it fills per-column caches (HyperLogLog look-up tables) and uploads leaves
   std::lock_guard<std::mutex> g(seg.mu);
+  auto it = seg.plan_cache.find(sig);
+  if (it != seg.plan_cache.end()) return it->second;
+  auto plan = compile_plan(seg, filter, q);
   if (seg.plan_cache.size() > 256) seg.plan_cache.clear();
   seg.plan_cache[sig] = plan;
   return plan;

@@ -347,3 +347,38 @@ def test_partitioned_group_by_with_limit(bench_seg):
     qg, qo = parse_sql(PART_QUERIES[0]), parse_sql(PART_QUERIES[0])
     qg.num_groups_limit = qo.num_groups_limit = 1234
     assert_same_block(g.execute(qg), o.execute(qo))
+
+
+# ---- one worker thread per segment task, many queries at once (BaseCombineOperator.java:97-142) -----------------------------------
+def test_concurrent_queries_from_many_threads(gpu_api, oracle_api, sv_data):
+    """The ABI is thread-safe and re-entrant: 8 host threads hammer two segments with different queries (each thread gets its own
+    HIP stream and workspaces, plans are cached per segment); every result must equal the oracle's."""
+    import threading
+    host_a = sv_segment(sv_data)
+    host_b = synth.generate_segment(300_000, segment_index=9, columns=synth.CFG3_COLUMNS, native=False)
+    ga, oa = both(gpu_api, oracle_api, host_a)
+    gb, ob = both(gpu_api, oracle_api, host_b)
+    work = [(ga, oa, q) for q in SV_QUERIES[:8] + DISTINCT_QUERIES[:4]] + \
+           [(gb, ob, q) for q in (synth.QUERY_CFG2, synth.QUERY_CFG3, synth.QUERY_NORTH_STAR, PART_QUERIES[0], PART_QUERIES[3])]
+    expected = [(o.execute(q).rows(), o.execute(q).stats.num_docs_scanned) for _, o, q in work]
+    errors = []
+
+    def worker(tid):
+        try:
+            for it in range(40):
+                k = (tid * 7 + it * 3) % len(work)
+                g, _, q = work[k]
+                b = g.execute(q)
+                if b.rows() != expected[k][0] or b.stats.num_docs_scanned != expected[k][1]:
+                    errors.append((tid, it, q))
+        except Exception as e:  # noqa
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+    for s in (ga, oa, gb, ob):
+        s.destroy()
