@@ -977,3 +977,18 @@ void po_read_fixed_bit_block(const uint8_t* buf, int32_t bits, const int32_t* do
   c.fwd_encoding = PG_FWD_DICT_FIXED_BIT;
   po_fwd_read_dict_ids(&c, doc_ids, n, out);
 }
+
+/* test hook: VarByteChunkSVForwardIndexReader#getBytes over a raw var-byte chunk buffer (PASS_THROUGH); returns the length */
+int32_t po_read_var_bytes(const uint8_t* buf, uint64_t len, int32_t doc_id, uint8_t* out, int32_t cap) {
+  po_column c;
+  memset(&c, 0, sizeof(c));
+  c.name = (char*)"raw";
+  c.fwd = buf;
+  c.fwd_len = len;
+  if (po_raw_parse_header(&c)) return -1;
+  int32_t n = 0;
+  const uint8_t* v = po_raw_get_bytes(&c, doc_id, &n);
+  if (n > cap) return -2;
+  memcpy(out, v, (size_t)n);
+  return n;
+}

@@ -31,6 +31,8 @@ def load_oracle() -> capi.NativeApi:
         lib.po_hll_registers_for_values.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
         lib.po_read_fixed_bit.restype = C.c_int32
         lib.po_read_fixed_bit.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        lib.po_read_var_bytes.restype = C.c_int32
+        lib.po_read_var_bytes.argtypes = [C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_int32]
         lib.po_read_fixed_bit_block.restype = None
         lib.po_read_fixed_bit_block.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
     return _api

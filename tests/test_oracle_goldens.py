@@ -324,3 +324,24 @@ def test_non_scan_based_aggregation_operator(oracle_api, sv_data):
     st = seg.execute("SELECT COUNT(*), SUM(column1) FROM testTable").execution_statistics()
     assert (st.num_docs_scanned, st.num_entries_scanned_post_filter) == (30000, 30000)
     seg.destroy()
+
+
+def test_var_byte_raw_v2_golden(oracle_api):
+    """VarByteChunkSVForwardIndexTest.java:152-159,161-178 (testBackwardCompatibilityV2): the reference's legacy blob
+    varByteStringsRaw.v2 (PASS_THROUGH, one partial chunk of 69 905 rows, absent rows' offsets 0) holds 1000 strings
+    data[i % 4] — read by the Python check reader and by the oracle's VarByteChunkSVForwardIndexReader restatement (the format
+    star-tree DISTINCTCOUNTHLL pairs are stored in)."""
+    import ctypes as C
+    import gzip
+    from pinot_amd import formats
+    raw = gzip.open(os.path.join(GOLDEN, "varByteStringsRaw.v2.gz"), "rb").read()
+    blob = np.frombuffer(raw, dtype=np.uint8)
+    h = formats.parse_raw_fixed_byte_chunk_header(blob)
+    assert (h["version"], h["num_chunks"], h["total_docs"], h["compression"], h["size_of_entry"]) == (2, 1, 1000, 0, 11)
+    data = [b"abcdefghijk", b"12456887", b"pqrstuv", b"500"]
+    vals = formats.read_raw_var_byte_chunk(blob)
+    assert len(vals) == 1000 and all(vals[i] == data[i % 4] for i in range(1000))
+    out = C.create_string_buffer(64)
+    for i in (0, 1, 2, 3, 500, 998, 999):
+        n = oracle_api.lib.po_read_var_bytes(blob.ctypes.data, blob.nbytes, i, out, 64)
+        assert out.raw[:n] == data[i % 4]
