@@ -382,3 +382,13 @@ def test_concurrent_queries_from_many_threads(gpu_api, oracle_api, sv_data):
     assert not errors, errors[:3]
     for s in (ga, oa, gb, ob):
         s.destroy()
+
+
+def test_plain_c_caller_of_the_abi():
+    """examples/abi_smoke.c: a C99 program builds Pinot-format bytes by hand (dictionary, fixed-bit forward index, RoaringBitmap
+    inverted index, raw chunk) and drives the C ABI end to end — no Python in the loop."""
+    import subprocess
+    from tests.test_host_formats import _abi_smoke_binary
+    out = subprocess.run([_abi_smoke_binary()], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "abi smoke ok" in out.stdout and "d=20 count=250" in out.stdout and "d=30 count=250" in out.stdout

@@ -149,3 +149,29 @@ def test_headline_kernel_has_no_register_spills():
     for k in ("pg_fast_i32range_a", "pg_fast_i32range_f", "pg_fast_none_a", "pg_fast_none_f"):
         assert usage[k]["ScratchSize [bytes/lane]"] == 0 and usage[k]["VGPRs Spill"] == 0, (k, usage[k])
         assert usage[k]["VGPRs"] <= 128
+
+
+def _abi_smoke_binary():
+    import os
+    import subprocess
+    from pinot_amd import capi
+    exe = os.path.join(capi.REPO_ROOT, "examples", "abi_smoke")
+    src = os.path.join(capi.REPO_ROOT, "examples", "abi_smoke.c")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(capi.REPO_ROOT, "include"),
+                               src, "-L" + os.path.dirname(capi.GPU_LIB_PATH), "-lpinot_gpu", "-Wl,-rpath,$ORIGIN/../pinot_amd/csrc",
+                               "-o", exe])
+    return exe
+
+
+def test_header_is_plain_c_and_links():
+    """include/pinot_gpu.h compiles as C99 with -pedantic -Werror and a C caller links against libpinot_gpu.so; without a GPU
+    pg_init must fail loudly with PG_ERR_DEVICE (there is no CPU fallback)."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("covered by the gpu-marked run of the same binary")
+    out = subprocess.run([_abi_smoke_binary()], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "no CPU fallback" in out.stdout and "pg_init -> -3" in out.stdout
