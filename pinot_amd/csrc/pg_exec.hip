@@ -15,7 +15,7 @@
 PG_DECL_GENERIC
 PG_DECL_FAST(pg_fast_none_f) PG_DECL_FAST(pg_fast_none_a) PG_DECL_FAST(pg_fast_i32range_f) PG_DECL_FAST(pg_fast_i32range_a)
 PG_DECL_FAST(pg_fast_dictrange_f) PG_DECL_FAST(pg_fast_dictrange_a) PG_DECL_FAST(pg_fast_dictlut_f) PG_DECL_FAST(pg_fast_dictlut_a)
-PG_DECL_FAST(pg_fast_multi_f) PG_DECL_FAST(pg_fast_multi_a)
+PG_DECL_FAST(pg_fast_multi_f) PG_DECL_FAST(pg_fast_multi_a) PG_DECL_FAST(pg_fast_multi_w) PG_DECL_FAST(pg_fast_none_w)
 extern "C" __global__ void pg_reduce_partials_kernel(const int64_t* partials, int64_t* out, int n_wg, int n_ops,
                                                      int n_groups, const PgAccOp* ops, unsigned long long* stats, int reduce);
 extern "C" __global__ void pg_reduce_parts_kernel(const int64_t* partials, int64_t* out, int n_wg, int n_ops, int n_groups,
@@ -76,7 +76,7 @@ void device_init(int ordinal) {
   // opt in to large dynamic LDS for the query kernels
   typedef void (*QueryKernel)(const PgQueryPlan);
   const QueryKernel all[] = {pg_generic_query_f, pg_generic_query_l, pg_generic_query_g, pg_fast_none_f, pg_fast_none_a, pg_fast_i32range_f, pg_fast_i32range_a,
-                             pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a, pg_fast_multi_f, pg_fast_multi_a};
+                             pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a, pg_fast_multi_f, pg_fast_multi_a, pg_fast_multi_w, pg_fast_none_w};
   for (QueryKernel k : all)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
 }
@@ -85,7 +85,7 @@ static bool uses_fast_kernel(const CompiledPlan& P, int agg_mode) {
   static const bool force_interpreter = getenv("PG_FORCE_INTERPRETER") != nullptr;   // measurement knob
   if (force_interpreter) return false;
   const bool agg = agg_mode != PG_AGG_NONE;
-  return P.fast_filter != -2 && (!agg || (P.fast_agg && agg_mode != PG_AGG_GLOBAL));
+  return P.fast_filter != -2 && (!agg || ((P.fast_agg || P.wide_agg) && agg_mode != PG_AGG_GLOBAL));
 }
 
 // Kernel selection: the specialised fast kernels when both the filter and the aggregation have the fast shape.
@@ -93,6 +93,11 @@ typedef void (*QueryKernel)(const PgQueryPlan);
 static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char** name) {
   const bool agg = agg_mode != PG_AGG_NONE;
   if (uses_fast_kernel(P, agg_mode)) {
+    if (agg && P.wide_agg) {
+      if (P.fast_filter == -1) { *name = "pg_fast_none_w"; return pg_fast_none_w; }
+      *name = "pg_fast_multi_w";
+      return pg_fast_multi_w;
+    }
     switch (P.fast_filter) {
       case -1: *name = agg ? "pg_fast_none_a" : "pg_fast_none_f"; return agg ? pg_fast_none_a : pg_fast_none_f;
       case 4: *name = agg ? "pg_fast_i32range_a" : "pg_fast_i32range_f"; return agg ? pg_fast_i32range_a : pg_fast_i32range_f;

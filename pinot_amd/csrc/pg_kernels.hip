@@ -26,6 +26,9 @@
 #ifndef PG_FAST_AGG_B
 #define PG_FAST_AGG_B 4
 #endif
+#ifndef PG_WIDE_AGG_B
+#define PG_WIDE_AGG_B 2      // quads in flight in the general aggregator inside the 1024-thread kernels (4 spills ~180 VGPRs)
+#endif
 #ifndef PG_GENERIC_AGG_B
 #define PG_GENERIC_AGG_B 4   // quads in flight per lane in the interpreter kernels' aggregation (8 spills ~200 VGPRs)
 #endif
@@ -610,7 +613,7 @@ DEVFN void aux_update_batch(const PgQueryPlan& p, uint32_t mb, int k0, int wtile
 // group columns of any width, raw 32/64-bit and dictionary-encoded sources.  B quads per lane are in flight at a time; like
 // the filter stage, every load of a stage is issued unconditionally (lanes whose quad has no match re-read quad 0 of the
 // tile) before the first is used — a load under a per-lane branch is waited for inside the branch.
-template <int B>
+template <int B, bool AUX = true>
 DEVFN void aggregate_wtile(const PgQueryPlan& p, uint32_t m, int wtile, int64_t* table, int lane, uint32_t rep, uint32_t part_lo = 0) {
   const uint32_t R = (uint32_t)p.replicas;
   const bool part = p.agg_mode == PG_AGG_LDS_PART;
@@ -860,7 +863,7 @@ DEVFN void aggregate_wtile(const PgQueryPlan& p, uint32_t m, int wtile, int64_t*
       }
       o = o_end;
     }
-    if (p.n_aux > 0) {   // four quads at a time: the three-stage gathers keep 16 addresses + states per lane in registers
+    if (AUX && p.n_aux > 0) {   // four quads at a time: the three-stage gathers keep 16 addresses + states per lane in registers
       constexpr int AB = B < 4 ? B : 4;
 #pragma unroll
       for (int h = 0; h < B; h += AB)
@@ -1102,7 +1105,10 @@ __device__ __forceinline__ void fast_query_body(const PgQueryPlan& p) {
       const uint32_t wsum = wave_sum_u32(cnt);
       if (lane == 0 && wsum) atomicAdd(&p.out_tile_counts[wt / PG_WTILES_PER_TILE], wsum);
     }
-    if (AGG && p.agg_mode != PG_AGG_NONE && __ballot(m != 0)) fast_aggregate_wtile<PG_FAST_AGG_B>(p, m, wt, lds_table, lane, rep);
+    if (AGG && p.agg_mode != PG_AGG_NONE && __ballot(m != 0)) {
+      if (AGG == 2) aggregate_wtile<PG_WIDE_AGG_B, false>(p, m, wt, lds_table, lane, rep);   // any group width, 32/64-bit sources
+      else fast_aggregate_wtile<PG_FAST_AGG_B>(p, m, wt, lds_table, lane, rep);
+    }
   }
   const uint32_t wsum = wave_sum_u32(my_matched);
   if (lane == 0 && wsum) atomicAdd(&s_stat[0], wsum);
@@ -1170,7 +1176,10 @@ __device__ __forceinline__ void fast_multi_body(const PgQueryPlan& p) {
       const uint32_t wsum = wave_sum_u32(cnt);
       if (lane == 0 && wsum) atomicAdd(&p.out_tile_counts[wt / PG_WTILES_PER_TILE], wsum);
     }
-    if (AGG && p.agg_mode != PG_AGG_NONE && __ballot(m != 0)) fast_aggregate_wtile<PG_FAST_AGG_B>(p, m, wt, lds_table, lane, rep);
+    if (AGG && p.agg_mode != PG_AGG_NONE && __ballot(m != 0)) {
+      if (AGG == 2) aggregate_wtile<PG_WIDE_AGG_B, false>(p, m, wt, lds_table, lane, rep);
+      else fast_aggregate_wtile<PG_FAST_AGG_B>(p, m, wt, lds_table, lane, rep);
+    }
   }
   const uint32_t wsum = wave_sum_u32(my_matched);
   if (lane == 0 && wsum) atomicAdd(&s_stat[0], wsum);
@@ -1187,11 +1196,13 @@ __device__ __forceinline__ void fast_multi_body(const PgQueryPlan& p) {
 }
 extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_fast_multi_f(const PgQueryPlan p) { fast_multi_body<0>(p); }
 extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_fast_multi_a(const PgQueryPlan p) { fast_multi_body<1>(p); }
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_fast_multi_w(const PgQueryPlan p) { fast_multi_body<2>(p); }
 
 #define PG_FAST_KERNEL(NAME, SK, AGG) \
   extern "C" __global__ void __launch_bounds__(PG_BLOCK) NAME(const PgQueryPlan p) { fast_query_body<SK, AGG>(p); }
 PG_FAST_KERNEL(pg_fast_none_f, -1, 0)
 PG_FAST_KERNEL(pg_fast_none_a, -1, 1)
+PG_FAST_KERNEL(pg_fast_none_w, -1, 2)
 PG_FAST_KERNEL(pg_fast_i32range_f, SK_I32_RANGE, 0)
 PG_FAST_KERNEL(pg_fast_i32range_a, SK_I32_RANGE, 1)
 PG_FAST_KERNEL(pg_fast_dictrange_f, SK_DICT_RANGE_SMALL, 0)

@@ -793,6 +793,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
         D.n_index_instr = (int32_t)n_idx;
         D.fast_scan = em.instrs[n_idx].arg;
         D.fast_scan_pushed = n_idx == 0 ? 1 : 0;
+        D.n_fast_scans = 1;   // the chain kernels (pg_fast_multi_*) can run the single scan as well
       }
     }
     if (P.fast_filter == -2 && rest >= 1 && rest <= PG_MAX_FAST_SCANS) {
@@ -1067,6 +1068,9 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
     if (!(c->col_kind == PG_COL_RAW32 || (c->col_kind == PG_COL_FIXED_BIT && (c->val_type == PG_V_I32 || c->val_type == PG_V_F32))))
       P.fast_agg = false;
   D.fast_agg_shape = (P.fast_agg && (D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE)) ? 1 : 0;
+  // LDS tables that miss the narrow shape only by column width (group columns > 8 bits, LONG / DOUBLE sources, 64-bit
+  // dictionaries) keep the 1024-thread kernels and run the general aggregator there (pg_fast_none_w / pg_fast_multi_w)
+  P.wide_agg = !P.fast_agg && (D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE) && D.n_aux == 0 && P.first_doc_op < 0;
   return plan;
 }
 

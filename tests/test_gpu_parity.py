@@ -392,3 +392,45 @@ def test_plain_c_caller_of_the_abi():
     out = subprocess.run([_abi_smoke_binary()], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "abi smoke ok" in out.stdout and "d=20 count=250" in out.stdout and "d=30 count=250" in out.stdout
+
+
+# ---- LDS aggregation over wide group columns and 64-bit sources (pg_fast_none_w / pg_fast_multi_w, general aggregator) ----------
+@pytest.fixture(scope="module")
+def wide_seg(gpu_api, oracle_api):
+    rng = np.random.default_rng(21)
+    n = 180_003
+    data = {
+        "k": rng.integers(0, 2000, n).astype(np.int32),            # 11-bit dictionary column
+        "k2": rng.integers(0, 7, n).astype(np.int32),
+        "lm": rng.integers(-10**12, 10**12, n).astype(np.int64),    # raw LONG metric
+        "dm": (rng.integers(-10**6, 10**6, n) * 0.25).astype(np.float64),   # raw DOUBLE, exactly representable sums
+        "fm": (rng.integers(-1000, 1000, n) * 0.5).astype(np.float32),      # raw FLOAT
+        "ld": rng.integers(0, 300, n).astype(np.int64) * 10**10,     # dictionary-encoded LONG
+        "r": rng.integers(0, 1000, n).astype(np.int32),
+        "inv": rng.integers(0, 5, n).astype(np.int32),
+    }
+    host = build_segment("wide", data, {"k": "INT", "k2": "INT", "lm": "LONG", "dm": "DOUBLE", "fm": "FLOAT", "ld": "LONG",
+                                         "r": "INT", "inv": "INT"},
+                         inverted_index_columns=["inv"], no_dictionary_columns=["lm", "dm", "fm", "r"])
+    g, o = both(gpu_api, oracle_api, host)
+    yield g, o
+    g.destroy()
+    o.destroy()
+
+
+WIDE_QUERIES = [
+    "SELECT k, SUM(lm), MIN(lm), MAX(lm), COUNT(*) FROM wide GROUP BY k LIMIT 5000",
+    "SELECT k, SUM(dm), MAX(fm), AVG(ld) FROM wide WHERE r BETWEEN 100 AND 700 GROUP BY k LIMIT 5000",
+    "SELECT k2, SUM(lm), SUM(dm), MINMAXRANGE(fm) FROM wide WHERE inv IN (1, 3) AND r < 900 AND lm > 0 GROUP BY k2",
+    "SELECT SUM(lm), MIN(dm), MAX(ld), COUNT(*) FROM wide WHERE inv = 2",
+    "SELECT k2, k, SUM(ld) FROM wide WHERE r < 300 AND fm > 0 GROUP BY k2, k LIMIT 20000",
+    "SELECT k, MAX(lm) FROM wide WHERE dm BETWEEN -1000 AND 1000 AND lm < 0 GROUP BY k LIMIT 5000",
+]
+
+
+@pytest.mark.parametrize("q", WIDE_QUERIES)
+def test_wide_aggregations_match_oracle(wide_seg, q):
+    g, o = wide_seg
+    gb, ob = g.execute(q), o.execute(q)
+    assert_same_block(gb, ob)
+    assert gb.stats.kernel.decode().startswith(("pg_fast_", "pg_generic_"))

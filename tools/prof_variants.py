@@ -15,7 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--docs", type=int, default=200_000_000)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--only", default="", help="substring of the query names to run")
-ap.add_argument("--set", choices=["cfg3", "cfg5", "general"], default="cfg3")
+ap.add_argument("--set", choices=["cfg3", "cfg5", "general", "wide"], default="cfg3")
 args = ap.parse_args()
 api = capi.gpu_api()
 api.call("init", 0)
@@ -23,6 +23,18 @@ seg = NativeSegment(api, HostSegment("prof", args.docs))
 for name in (synth.CFG5_COLUMNS if args.set == "cfg5" else synth.CFG3_COLUMNS):
     one = synth.generate_segment(args.docs, columns=[name])
     seg.add_column(one.columns[name], keep_host_buffers=False)
+
+if args.set == "wide":
+    # columns the synthetic table lacks: a LONG raw metric and an 11-bit dictionary column (built with numpy: small sizes only)
+    import numpy as np
+    from pinot_amd.segment import build_column
+    n = args.docs
+    mvals = synth.values_numpy(synth.GPU_BENCH["m"], synth.SEED_BASE, n).astype(np.int64)
+    seg.add_column(build_column("m64", mvals * 1000 + 7, "LONG", dictionary=False), keep_host_buffers=False)
+    seg.add_column(build_column("d64", (mvals * 0.5).astype(np.float64), "DOUBLE", dictionary=False), keep_host_buffers=False)
+    w = (synth.values_numpy(synth.GPU_BENCH["u"], synth.SEED_BASE, n) % 2000).astype(np.int32)
+    seg.add_column(build_column("w1", w, "INT"), keep_host_buffers=False)
+    del mvals, w
 
 QUERIES = {
     "cfg2 count(range scan)": (synth.QUERY_CFG2, 4.0),
@@ -51,8 +63,18 @@ QUERIES_GENERAL = {   # shapes outside the specialised kernels: several scans, O
     "filtered 40k groups": ("SELECT g1, g2, c_inv1, SUM(m) FROM t WHERE r_int < 125000 GROUP BY g1, g2, c_inv1 LIMIT 100000", 10.0),
     "avg/min/max/count no group": ("SELECT COUNT(*), AVG(m), MIN(r_int), MAX(m) FROM t WHERE c_inv2 = 1", 8.125),
 }
+QUERIES_WIDE = {   # LDS-table aggregations over 64-bit sources / an 11-bit group column
+    "sum(m64) group g1": ("SELECT g1, SUM(m64), MAX(m64) FROM t GROUP BY g1", 8.875),
+    "cfg3 filter, sum(m64) group g1": ("SELECT g1, SUM(m64) FROM t WHERE c_inv1 IN (0,1,2,3) AND c_inv2 IN (0,1) AND r_int BETWEEN 250000 AND 749999 GROUP BY g1", 13.625),
+    "sum(d64) avg(m) group g1": ("SELECT g1, SUM(d64), AVG(m) FROM t WHERE r_int < 500000 GROUP BY g1", 16.875),
+    "sum(m) group w1 (2000 groups)": ("SELECT w1, SUM(m), COUNT(*) FROM t GROUP BY w1 LIMIT 5000", 5.375),
+    "filtered sum(m64) group w1": ("SELECT w1, SUM(m64) FROM t WHERE r_int BETWEEN 250000 AND 749999 GROUP BY w1 LIMIT 5000", 13.375),
+    "sum(m64) no group": ("SELECT SUM(m64), MIN(m64), COUNT(*) FROM t WHERE c_inv2 = 1", 8.125),
+}
 if args.set == "cfg5":
     QUERIES = QUERIES5
+if args.set == "wide":
+    QUERIES = QUERIES_WIDE
 if args.set == "general":
     QUERIES = QUERIES_GENERAL
 for name, (sql, bpr) in QUERIES.items():
