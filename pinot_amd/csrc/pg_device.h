@@ -162,7 +162,10 @@ struct PgAuxOp {
   int32_t stride;       // DICT_SET: words per group; HLL: registers (bytes) per group = 1 << log2m
   int32_t log2m;
   int32_t n_rep;        // replicas of the region (power of two): workgroup b updates replica b & (n_rep-1); small states
-  int32_t pad;          //   (few groups) would otherwise funnel every update of the chip into a handful of L2 lines
+  int32_t lds_offset;   //   (few groups) would otherwise funnel every update of the chip into a handful of L2 lines
+                        // lds_offset >= 0: the state of ONE workgroup lives in its LDS at this byte offset of the dynamic LDS
+                        // (states up to ~128 KB: LDS atomics instead of memory-side ones); `base` is then the workgroups'
+                        // partial area [grid][rep_bytes] in HBM, merged by pg_reduce_aux_kernel
   int64_t rep_bytes;    // bytes of one replica
   uint32_t* base;       // region of this op (patched per execution)
   const uint32_t* lut;  // HLL_DICT: per dictId (register index | rank << 16)

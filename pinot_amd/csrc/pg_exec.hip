@@ -20,6 +20,7 @@ extern "C" __global__ void pg_reduce_partials_kernel(const int64_t* partials, in
                                                      int n_groups, const PgAccOp* ops, unsigned long long* stats, int reduce);
 extern "C" __global__ void pg_reduce_parts_kernel(const int64_t* partials, int64_t* out, int n_wg, int n_ops, int n_groups,
                                                    int n_parts, int part_groups, const PgAccOp* ops);
+extern "C" __global__ void pg_reduce_aux_kernel(const uint32_t* partials, uint32_t* out, int n_wg, int64_t n_words, int bytewise_max);
 extern "C" __global__ void pg_fill_i64_kernel(int64_t* dst, int64_t n_per_op, int n_ops, const PgAccOp* ops);
 extern "C" __global__ void pg_expand_docids_kernel(const uint64_t* words, const int64_t* tile_offsets, int32_t* out,
                                                    int n_tiles);
@@ -283,11 +284,19 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   // auxiliary regions (DISTINCTCOUNT sets / HLL registers): one zeroed HBM region per op
   size_t aux_total = 0;
   for (size_t b : P.aux_bytes) aux_total += b;
+  std::vector<uint32_t*> aux_final((size_t)D.n_aux, nullptr);
   if (aux_total) {
-    ThreadCtx::grow(ctx.aux, aux_total);
-    PG_HIP(hipMemsetAsync(ctx.aux.ptr, 0, aux_total, ctx.stream));
-    size_t off = 0;
-    for (int x = 0; x < D.n_aux; x++) { D.aux[x].base = reinterpret_cast<uint32_t*>(ctx.aux.as<uint8_t>() + off); off += P.aux_bytes[x]; }
+    // LDS-resident states: the kernel writes one partial per workgroup behind the merged regions
+    const size_t partial_total = P.aux_in_lds ? aux_total * (size_t)shape.grid : 0;
+    ThreadCtx::grow(ctx.aux, aux_total + partial_total);
+    if (!P.aux_in_lds) PG_HIP(hipMemsetAsync(ctx.aux.ptr, 0, aux_total, ctx.stream));
+    size_t off = 0, poff = aux_total;
+    for (int x = 0; x < D.n_aux; x++) {
+      aux_final[(size_t)x] = reinterpret_cast<uint32_t*>(ctx.aux.as<uint8_t>() + off);
+      if (P.aux_in_lds) { D.aux[x].base = reinterpret_cast<uint32_t*>(ctx.aux.as<uint8_t>() + poff); poff += P.aux_bytes[x] * (size_t)shape.grid; }
+      else D.aux[x].base = aux_final[(size_t)x];
+      off += P.aux_bytes[x];
+    }
   }
   int64_t* host_out = static_cast<int64_t*>(ctx.pin(out_bytes + aux_total));
   uint8_t* aux_host = reinterpret_cast<uint8_t*>(host_out) + out_bytes;
@@ -303,6 +312,13 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   std::vector<int64_t> table((size_t)n_out);
   uint64_t stats_host[PG_MAX_STATS] = {0};
   if (has_docs) {
+    if (P.aux_in_lds)
+      for (int x = 0; x < D.n_aux; x++) {
+        const int64_t n_words = (int64_t)P.aux_bytes[(size_t)x] / 4;
+        hipLaunchKernelGGL(pg_reduce_aux_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx.stream, D.aux[x].base,
+                           aux_final[(size_t)x], shape.grid, n_words, D.aux[x].kind == PG_AUX_DICT_SET ? 0 : 1);
+        PG_HIP(hipGetLastError());
+      }
     if (D.agg_mode == PG_AGG_LDS_PART && n_out > 0) {
       hipLaunchKernelGGL(pg_reduce_parts_kernel, dim3((unsigned)((n_out + 3) / 4)), dim3(256), 0, ctx.stream, ctx.partials.as<int64_t>(),
                          ctx.final_table.as<int64_t>(), shape.grid, D.n_ops, D.n_groups, D.n_parts, D.part_groups, P.ops_dev.as<PgAccOp>());

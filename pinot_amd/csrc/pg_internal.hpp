@@ -200,6 +200,7 @@ struct CompiledPlan {
   int32_t first_doc_op = -1;         // MIN(docId) per group, present when the key space exceeds numGroupsLimit
   int32_t fast_filter = -2;          // -2: interpreter kernel; -1: index-only filter; >= 0: ScanKind of the one scan leaf
   bool fast_agg = true;              // aggregation fits the fast kernels (or there is none)
+  bool aux_in_lds = false;           // DISTINCTCOUNT / HLL states live in the workgroups' LDS (merged by pg_reduce_aux_kernel)
   bool wide_agg = false;             // LDS-table aggregation over wide group columns / 64-bit sources: the *_w kernels
   DeviceBuffer ops_dev;
   std::vector<size_t> aux_bytes;     // bytes of each auxiliary region (256-byte multiples)

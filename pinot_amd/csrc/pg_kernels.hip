@@ -474,7 +474,12 @@ DEVFN void aux_update_batch(const PgQueryPlan& p, uint32_t mb, int k0, int wtile
   // the atomic.  Lanes / docs outside the mask use clamped (valid) addresses and are masked at the atomic.
   for (int xa = 0; xa < p.n_aux; xa++) {
     PgAuxOp A = p.aux[xa];
-    A.base = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(A.base) + (size_t)(blockIdx.x & (uint32_t)(A.n_rep - 1)) * (size_t)A.rep_bytes);
+    if (A.lds_offset >= 0) {   // this workgroup's own state in LDS (generic pointer into the LDS aperture: flat atomics)
+      extern __shared__ __attribute__((aligned(16))) uint64_t smem_aux[];
+      A.base = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(smem_aux) + A.lds_offset);
+    } else {
+      A.base = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(A.base) + (size_t)(blockIdx.x & (uint32_t)(A.n_rep - 1)) * (size_t)A.rep_bytes);
+    }
     const PgValueSrc& S = p.srcs[A.src];
     if (A.kind == PG_AUX_HLL_BYTES) {
       // Serialized HyperLogLogs of a star-tree pair column (one byte per register after upload): HyperLogLog#addAll = register-wise
@@ -1246,6 +1251,12 @@ __device__ __forceinline__ void generic_query_body(const PgQueryPlan& p) {
       for (uint32_t i = t; i < table_slots; i += PG_GENERIC_BLOCK) lds_table[(size_t)o * table_slots + i] = ident;
     }
   }
+  if (TABLE == 1)
+    for (int x = 0; x < p.n_aux; x++)
+      if (p.aux[x].lds_offset >= 0) {
+        uint32_t* z = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(smem) + p.aux[x].lds_offset);
+        for (int64_t i = t; i < p.aux[x].rep_bytes / 4; i += PG_GENERIC_BLOCK) z[i] = 0;
+      }
   __syncthreads();
 
   const uint32_t rep = (uint32_t)t & ((uint32_t)p.replicas - 1u);
@@ -1363,6 +1374,13 @@ __device__ __forceinline__ void generic_query_body(const PgQueryPlan& p) {
       out[i] = acc;
     }
   }
+  if (TABLE == 1)   // LDS-resident DISTINCTCOUNT / HLL states: this workgroup's partial, merged by pg_reduce_aux_kernel
+    for (int x = 0; x < p.n_aux; x++)
+      if (p.aux[x].lds_offset >= 0) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(smem) + p.aux[x].lds_offset);
+        uint32_t* dst = p.aux[x].base + (int64_t)blockIdx.x * (p.aux[x].rep_bytes / 4);
+        for (int64_t i = t; i < p.aux[x].rep_bytes / 4; i += PG_GENERIC_BLOCK) dst[i] = src[i];
+      }
 }
 extern "C" __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_generic_query_f(const PgQueryPlan p) { generic_query_body<0>(p); }
 extern "C" __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_generic_query_l(const PgQueryPlan p) { generic_query_body<1>(p); }
@@ -1438,6 +1456,19 @@ extern "C" __global__ void __launch_bounds__(256) pg_reduce_parts_kernel(const i
     acc = combine(acc, other);
   }
   if (lane == 0) out[i] = acc;
+}
+
+// Merges the workgroups' LDS-resident DISTINCTCOUNT / HLL partials: out[w] = OR (sets) or per-byte max (registers) over n_wg.
+extern "C" __global__ void __launch_bounds__(256) pg_reduce_aux_kernel(const uint32_t* __restrict__ partials, uint32_t* __restrict__ out,
+                                                                        int n_wg, int64_t n_words, int bytewise_max) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  uint32_t acc = 0;
+  for (int b = 0; b < n_wg; b++) {
+    const uint32_t v = partials[(int64_t)b * n_words + w];
+    acc = bytewise_max ? bytemax4(acc, v) : (acc | v);
+  }
+  out[w] = acc;
 }
 
 extern "C" __global__ void __launch_bounds__(256) pg_fill_i64_kernel(int64_t* dst, int64_t n_per_op, int n_ops,

@@ -1057,7 +1057,26 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
     while (n_rep < 512 && bytes * (size_t)(n_rep * 2) <= ((size_t)256 << 10)) n_rep *= 2;
     D.aux[x].n_rep = n_rep;
     D.aux[x].rep_bytes = (int64_t)bytes;
+    D.aux[x].lds_offset = -1;
     P.aux_bytes.push_back(bytes * (size_t)n_rep);
+  }
+  // States that fit the workgroup's LDS next to the accumulator table (a DISTINCTCOUNT over <= ~1 M dictIds without GROUP BY,
+  // HyperLogLog registers of <= ~500 groups ...) are kept there: LDS atomics sustain ~2e12/s, memory-side ones 2.4e10/s.
+  {
+    size_t aux_lds = 0;
+    for (int x = 0; x < D.n_aux; x++) aux_lds += (size_t)D.aux[x].rep_bytes;
+    const bool lds_table = D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE;
+    if (D.n_aux > 0 && lds_table && P.lds_bytes + aux_lds <= (size_t)kLdsTableBudget) {
+      size_t off = (P.lds_bytes + 255) & ~(size_t)255;
+      for (int x = 0; x < D.n_aux; x++) {
+        D.aux[x].lds_offset = (int32_t)off;
+        D.aux[x].n_rep = 1;
+        off += (size_t)D.aux[x].rep_bytes;
+        P.aux_bytes[(size_t)x] = (size_t)D.aux[x].rep_bytes;   // the merged state; per-workgroup partials are sized at launch
+      }
+      P.lds_bytes = off;
+      P.aux_in_lds = true;
+    }
   }
   // fast aggregation: LDS table, slots fit 16 bits, <= 8-bit group columns, 32-bit value sources
   P.fast_agg = D.agg_mode != PG_AGG_GLOBAL && D.agg_mode != PG_AGG_LDS_PART && (int64_t)G * D.replicas <= 65536;   // (trivially true without a table)

@@ -52,6 +52,9 @@ QUERIES5 = {
     "cfg5 hll(u) no group": ("SELECT DISTINCTCOUNTHLL(u) FROM t", 2.5),
     "cfg5 hll(u) group h1": ("SELECT h1, DISTINCTCOUNTHLL(u) FROM t GROUP BY h1", 3.0),
     "cfg5 distinctcount(u) group h1": ("SELECT h1, DISTINCTCOUNT(u) FROM t GROUP BY h1", 3.0),
+    "hll(u) where h2<5": ("SELECT DISTINCTCOUNTHLL(u) FROM t WHERE h2 < 5", 3.0),
+    "distinctcount(u) where h2<5": ("SELECT DISTINCTCOUNT(u) FROM t WHERE h2 < 5", 3.0),
+    "hll(u) group h1,h2 (160)": ("SELECT h1, h2, DISTINCTCOUNTHLL(u), COUNT(*) FROM t GROUP BY h1, h2", 3.5),
     "cfg5 count group h1..h3": ("SELECT h1, h2, h3, COUNT(*) FROM t GROUP BY h1, h2, h3 LIMIT 20000", 1.5),
 }
 QUERIES_GENERAL = {   # shapes outside the specialised kernels: several scans, OR of scans, tables beyond LDS
