@@ -168,18 +168,18 @@ static std::shared_ptr<CompiledPlan> get_plan(Segment& seg, const pg_filter_node
 struct LaunchShape { int grid; int block; size_t lds; };
 static LaunchShape launch_shape(const CompiledPlan& P, int n_wtiles, int agg_mode) {
   size_t lds = P.lds_bytes + 64;
+  if (P.dev.agg_mode == PG_AGG_LDS_PART && agg_mode == PG_AGG_LDS_PART) {
+    // range-partitioned aggregation: one workgroup per CU, 8 x per_xcd of them with per_xcd a multiple of the range count
+    int per_xcd = std::max(g_num_cus / 8, 1);
+    per_xcd = std::max(per_xcd / P.dev.n_parts, 1) * P.dev.n_parts;
+    return {8 * per_xcd, uses_fast_kernel(P, agg_mode) ? PG_BLOCK : PG_GENERIC_BLOCK, lds};
+  }
   if (uses_fast_kernel(P, agg_mode)) {
     // one 16-wave workgroup per CU; fewer when the segment has fewer wave tiles than that
     static const int wgs_per_cu = getenv("PG_WGS_PER_CU") ? atoi(getenv("PG_WGS_PER_CU")) : 1;   // tuning knob
     const int per_cu = ((size_t)wgs_per_cu * (lds + 4096) <= g_lds_per_cu) ? wgs_per_cu : 1;
     int grid = std::min((n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, g_num_cus * per_cu);
     return {std::max(grid, 1), PG_BLOCK, lds};
-  }
-  if (P.dev.agg_mode == PG_AGG_LDS_PART && agg_mode == PG_AGG_LDS_PART) {
-    // range-partitioned aggregation: one workgroup per CU, 8 x per_xcd of them with per_xcd a multiple of the range count
-    int per_xcd = std::max(g_num_cus / 8, 1);
-    per_xcd = std::max(per_xcd / P.dev.n_parts, 1) * P.dev.n_parts;
-    return {8 * per_xcd, PG_GENERIC_BLOCK, lds};
   }
   // interpreter kernel: 8-wave workgroups, two per CU when both LDS tables fit
   const int waves = PG_GENERIC_BLOCK / 64;

@@ -1043,10 +1043,11 @@ DEVFN void flush_workgroup(const PgQueryPlan& p, const int64_t* lds_table, const
   if (t < PG_MAX_STATS && s_stat[t]) atomicAdd(&p.stats[t], (unsigned long long)s_stat[t]);
   if (lds_agg) {
     const int R = p.replicas;
-    const int64_t n_out = (int64_t)p.n_ops * p.n_groups;
+    const int groups = p.agg_mode == PG_AGG_LDS_PART ? p.part_groups : p.n_groups;   // this workgroup's table: [n_ops][groups]
+    const int64_t n_out = (int64_t)p.n_ops * groups;
     int64_t* out = p.partials + (int64_t)blockIdx.x * n_out;
     for (int64_t i = t; i < n_out; i += PG_BLOCK) {
-      const int o = (int)(i / p.n_groups);
+      const int o = (int)(i / groups);
       const PgAccOp op = p.ops[o];
       const int64_t* src = lds_table + i * R;   // (o * G + g) * R
       int64_t acc = src[0];
@@ -1077,8 +1078,9 @@ __device__ __forceinline__ void fast_query_body(const PgQueryPlan& p) {
   const int wave = uniform(t >> 6);
   int64_t* lds_table = reinterpret_cast<int64_t*>(smem);
   if (t < PG_MAX_STATS) s_stat[t] = 0;
+  const bool part_agg = AGG == 2 && p.agg_mode == PG_AGG_LDS_PART;
   if (AGG) {
-    const uint32_t table_slots = (uint32_t)p.n_groups * (uint32_t)p.replicas;
+    const uint32_t table_slots = part_agg ? (uint32_t)p.part_groups : (uint32_t)p.n_groups * (uint32_t)p.replicas;
     for (int o = 0; o < p.n_ops; o++) {
       const int64_t ident = pg_acc_identity(p.ops[o].fn, p.ops[o].is_float);
       for (uint32_t i = t; i < table_slots; i += PG_BLOCK) lds_table[(size_t)o * table_slots + i] = ident;
@@ -1089,8 +1091,20 @@ __device__ __forceinline__ void fast_query_body(const PgQueryPlan& p) {
   const CAS PgScanLeaf& L = cptr(p.scans)[SK >= 0 ? p.fast_scan : 0];   // only dereferenced when SK >= 0
   const uint32_t rep = (uint32_t)t & ((uint32_t)p.replicas - 1u);
   uint32_t my_matched = 0, my_cand = 0;
-  const int wstride = (int)gridDim.x * PG_WAVES_PER_BLOCK;
-  for (int wt = (int)blockIdx.x * PG_WAVES_PER_BLOCK + wave; wt < p.n_wtiles; wt += wstride) {
+  // tile walk: see generic_query_body (range-partitioned aggregation lets the ranges' workgroups of an XCD share its chunks)
+  int chunk0 = (int)blockIdx.x, cstride = (int)gridDim.x;
+  uint32_t part_lo = 0;
+  bool count_stats = true;
+  if (part_agg) {
+    const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3, per_xcd = (int)gridDim.x >> 3;
+    const int range = idx & (p.n_parts - 1), j = idx / p.n_parts, nj = per_xcd / p.n_parts;
+    chunk0 = xcd + 8 * j;
+    cstride = 8 * nj;
+    part_lo = (uint32_t)range * (uint32_t)p.part_groups;
+    count_stats = range == 0;
+  }
+  const int wstride = cstride * PG_WAVES_PER_BLOCK;
+  for (int wt = chunk0 * PG_WAVES_PER_BLOCK + wave; wt < p.n_wtiles; wt += wstride) {
     const int64_t wbase = (int64_t)wt * PG_WAVE_DOCS;
     const int64_t rem = (int64_t)p.num_docs - wbase;
     const int32_t n_valid = rem >= PG_WAVE_DOCS ? PG_WAVE_DOCS : (int32_t)rem;
@@ -1111,15 +1125,15 @@ __device__ __forceinline__ void fast_query_body(const PgQueryPlan& p) {
       if (lane == 0 && wsum) atomicAdd(&p.out_tile_counts[wt / PG_WTILES_PER_TILE], wsum);
     }
     if (AGG && p.agg_mode != PG_AGG_NONE && __ballot(m != 0)) {
-      if (AGG == 2) aggregate_wtile<PG_WIDE_AGG_B, false>(p, m, wt, lds_table, lane, rep);   // any group width, 32/64-bit sources
+      if (AGG == 2) aggregate_wtile<PG_WIDE_AGG_B, false>(p, m, wt, lds_table, lane, rep, part_lo);   // any group width, 32/64-bit sources
       else fast_aggregate_wtile<PG_FAST_AGG_B>(p, m, wt, lds_table, lane, rep);
     }
   }
   const uint32_t wsum = wave_sum_u32(my_matched);
-  if (lane == 0 && wsum) atomicAdd(&s_stat[0], wsum);
+  if (lane == 0 && wsum && count_stats) atomicAdd(&s_stat[0], wsum);
   if (SK >= 0 && !p.fast_scan_pushed) {
     const uint32_t csum = wave_sum_u32(my_cand);
-    if (lane == 0 && csum) atomicAdd(&s_stat[L.stat_slot], csum);
+    if (lane == 0 && csum && count_stats) atomicAdd(&s_stat[L.stat_slot], csum);
   }
   __syncthreads();
   flush_workgroup(p, lds_table, s_stat, AGG && p.agg_mode != PG_AGG_NONE, t);

@@ -1090,6 +1090,8 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
   // LDS tables that miss the narrow shape only by column width (group columns > 8 bits, LONG / DOUBLE sources, 64-bit
   // dictionaries) keep the 1024-thread kernels and run the general aggregator there (pg_fast_none_w / pg_fast_multi_w)
   P.wide_agg = !P.fast_agg && (D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE) && D.n_aux == 0 && P.first_doc_op < 0;
+  // range-partitioned tables without a filter scan: pg_fast_none_w walks the partitioned tile order with 16 wavefronts per CU
+  if (D.agg_mode == PG_AGG_LDS_PART && D.n_aux == 0 && P.fast_filter == -1) P.wide_agg = true;
   return plan;
 }
 
