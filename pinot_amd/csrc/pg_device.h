@@ -203,7 +203,7 @@ struct PgQueryPlan {
   int32_t n_aux;
   int32_t n_lin_prefix;             // interpreter kernels: instrs[0, n_lin_prefix) is index-only and leaves one stack entry
   int32_t n_fast_scans;             // pg_fast_multi_*: instrs[n_index_instr, n_index_instr + n_fast_scans) are scan leaves ANDed in order
-  int32_t n_parts;                  // PG_AGG_LDS_PART: key ranges (power of two dividing the workgroups per XCD)
+  int32_t n_parts;                  // PG_AGG_LDS_PART: key ranges (the grid is 8 x a multiple of it)
   int32_t part_groups;              // PG_AGG_LDS_PART: keys per range
   PgAuxOp aux[PG_MAX_AUX];
   PgGroupCol gcols[PG_MAX_GROUP_COLS];

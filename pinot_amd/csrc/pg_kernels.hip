@@ -1097,7 +1097,7 @@ __device__ __forceinline__ void fast_query_body(const PgQueryPlan& p) {
   bool count_stats = true;
   if (part_agg) {
     const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3, per_xcd = (int)gridDim.x >> 3;
-    const int range = idx & (p.n_parts - 1), j = idx / p.n_parts, nj = per_xcd / p.n_parts;
+    const int range = idx % p.n_parts, j = idx / p.n_parts, nj = per_xcd / p.n_parts;
     chunk0 = xcd + 8 * j;
     cstride = 8 * nj;
     part_lo = (uint32_t)range * (uint32_t)p.part_groups;
@@ -1284,7 +1284,7 @@ __device__ __forceinline__ void generic_query_body(const PgQueryPlan& p) {
   bool count_stats = true;
   if (part_agg) {
     const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3, per_xcd = (int)gridDim.x >> 3;
-    const int range = idx & (p.n_parts - 1), j = idx / p.n_parts, nj = per_xcd / p.n_parts;
+    const int range = idx % p.n_parts, j = idx / p.n_parts, nj = per_xcd / p.n_parts;
     chunk0 = xcd + 8 * j;
     cstride = 8 * nj;
     part_lo = (uint32_t)range * (uint32_t)p.part_groups;
@@ -1440,7 +1440,7 @@ extern "C" __global__ void __launch_bounds__(256) pg_reduce_partials_kernel(cons
   if (lane == 0) out[i] = acc;
 }
 
-// Range-partitioned partials: workgroup b holds [n_ops][part_groups] for range (b >> 3) & (n_parts - 1).  One wavefront per
+// Range-partitioned partials: workgroup b holds [n_ops][part_groups] for range (b >> 3) % n_parts.  One wavefront per
 // output slot (op, group), lanes stride over the workgroups that own the group's range.
 extern "C" __global__ void __launch_bounds__(256) pg_reduce_parts_kernel(const int64_t* __restrict__ partials,
                                                                           int64_t* __restrict__ out, int n_wg, int n_ops,
@@ -1463,7 +1463,7 @@ extern "C" __global__ void __launch_bounds__(256) pg_reduce_parts_kernel(const i
   };
   const int64_t wg_stride = (int64_t)n_ops * part_groups;
   for (int w = lane; w < n_wg; w += 64)
-    if (((w >> 3) & (n_parts - 1)) == range) acc = combine(acc, partials[(int64_t)w * wg_stride + (int64_t)o * part_groups + l]);
+    if (((w >> 3) % n_parts) == range) acc = combine(acc, partials[(int64_t)w * wg_stride + (int64_t)o * part_groups + l]);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     const int64_t other = __shfl_xor((long long)acc, off, 64);

@@ -1028,8 +1028,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
   } else {
     // beyond one LDS table: range-partitioned LDS tables when <= 32 ranges cover the key space (LDS atomics sustain ~2e12/s,
     // memory-side atomics on an HBM table ~2.4e10/s — tools/probes/atomic_scope.hip), else the dense HBM table
-    int parts = 2;
-    while (parts < 32 && table_bytes > kLdsTableBudget * parts) parts *= 2;
+    int parts = (int)std::min<int64_t>(32, std::max<int64_t>(2, (table_bytes + kLdsTableBudget - 1) / kLdsTableBudget));
     if (const char* e = getenv("PG_PART_MIN")) parts = std::max(parts, std::min(32, atoi(e)));   // measurement knob
     // every range's workgroups visit every doc (~3.4e11 doc visits/s measured), so the partitioned form pays off when most
     // docs reach the aggregation: parts * N / 3.4e11  <  matched * ops / 2.4e10.  Without a filter matched = N is known at
