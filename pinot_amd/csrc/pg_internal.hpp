@@ -84,6 +84,7 @@ struct Column {
   bool has_inverted = false;
   std::vector<PgContainer> descs_host;
   std::vector<uint32_t> posting_begin;          // cardinality + 1 offsets into descs_host
+  std::vector<int64_t> posting_card;            // docs per dictId (exact: planning estimates filter selectivity from it)
   DeviceBuffer containers_dev, descs_dev;
   uint64_t fwd_bytes_logical = 0;               // bytes of the forward index proper (for algorithmic byte accounting)
   std::map<int, DeviceBuffer> hll_luts;         // per log2m: (register index | rank << 16) of every dictionary value

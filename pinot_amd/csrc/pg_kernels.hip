@@ -1151,8 +1151,9 @@ __device__ __forceinline__ void fast_multi_body(const PgQueryPlan& p) {
   const int wave = uniform(t >> 6);
   int64_t* lds_table = reinterpret_cast<int64_t*>(smem);
   if (t < PG_MAX_STATS) s_stat[t] = 0;
+  const bool part_agg = AGG == 2 && p.agg_mode == PG_AGG_LDS_PART;
   if (AGG) {
-    const uint32_t table_slots = (uint32_t)p.n_groups * (uint32_t)p.replicas;
+    const uint32_t table_slots = part_agg ? (uint32_t)p.part_groups : (uint32_t)p.n_groups * (uint32_t)p.replicas;
     for (int o = 0; o < p.n_ops; o++) {
       const int64_t ident = pg_acc_identity(p.ops[o].fn, p.ops[o].is_float);
       for (uint32_t i = t; i < table_slots; i += PG_BLOCK) lds_table[(size_t)o * table_slots + i] = ident;
@@ -1163,8 +1164,19 @@ __device__ __forceinline__ void fast_multi_body(const PgQueryPlan& p) {
   const uint32_t rep = (uint32_t)t & ((uint32_t)p.replicas - 1u);
   uint32_t my_matched = 0;
   uint32_t my_cand[PG_MAX_FAST_SCANS] = {0, 0, 0, 0};
-  const int wstride = (int)gridDim.x * PG_WAVES_PER_BLOCK;
-  for (int wt = (int)blockIdx.x * PG_WAVES_PER_BLOCK + wave; wt < p.n_wtiles; wt += wstride) {
+  int chunk0 = (int)blockIdx.x, cstride = (int)gridDim.x;   // tile walk: see generic_query_body
+  uint32_t part_lo = 0;
+  bool count_stats = true;
+  if (part_agg) {
+    const int xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3, per_xcd = (int)gridDim.x >> 3;
+    const int range = idx % p.n_parts, j = idx / p.n_parts, nj = per_xcd / p.n_parts;
+    chunk0 = xcd + 8 * j;
+    cstride = 8 * nj;
+    part_lo = (uint32_t)range * (uint32_t)p.part_groups;
+    count_stats = range == 0;
+  }
+  const int wstride = cstride * PG_WAVES_PER_BLOCK;
+  for (int wt = chunk0 * PG_WAVES_PER_BLOCK + wave; wt < p.n_wtiles; wt += wstride) {
     const int64_t wbase = (int64_t)wt * PG_WAVE_DOCS;
     const int64_t rem = (int64_t)p.num_docs - wbase;
     const int32_t n_valid = rem >= PG_WAVE_DOCS ? PG_WAVE_DOCS : (int32_t)rem;
@@ -1196,18 +1208,18 @@ __device__ __forceinline__ void fast_multi_body(const PgQueryPlan& p) {
       if (lane == 0 && wsum) atomicAdd(&p.out_tile_counts[wt / PG_WTILES_PER_TILE], wsum);
     }
     if (AGG && p.agg_mode != PG_AGG_NONE && __ballot(m != 0)) {
-      if (AGG == 2) aggregate_wtile<PG_WIDE_AGG_B, false>(p, m, wt, lds_table, lane, rep);
+      if (AGG == 2) aggregate_wtile<PG_WIDE_AGG_B, false>(p, m, wt, lds_table, lane, rep, part_lo);
       else fast_aggregate_wtile<PG_FAST_AGG_B>(p, m, wt, lds_table, lane, rep);
     }
   }
   const uint32_t wsum = wave_sum_u32(my_matched);
-  if (lane == 0 && wsum) atomicAdd(&s_stat[0], wsum);
+  if (lane == 0 && wsum && count_stats) atomicAdd(&s_stat[0], wsum);
 #pragma unroll
   for (int sidx = 0; sidx < PG_MAX_FAST_SCANS; sidx++) {
     if (sidx < p.n_fast_scans && !(sidx == 0 && p.fast_scan_pushed)) {
       const uint32_t csum = wave_sum_u32(my_cand[sidx]);
       const int slot = cptr(p.scans)[cptr(p.instrs)[p.n_index_instr + sidx].arg].stat_slot;
-      if (lane == 0 && csum) atomicAdd(&s_stat[slot], csum);
+      if (lane == 0 && csum && count_stats) atomicAdd(&s_stat[slot], csum);
     }
   }
   __syncthreads();

@@ -694,6 +694,38 @@ static const int64_t kLdsReplicaBudget = 96 * 1024;
 static const size_t kMaxAuxBytes = (size_t)2 << 30;
 static const int64_t kMaxDenseGroups = 64LL << 20;      // dense HBM table limit (groups)
 
+// Fraction of the docs a filter is expected to pass: exact for index leaves (posting cardinalities, sorted ranges), independence
+// for AND / OR, 1/5 per raw-value scan whose outcome is unknown at plan time.  Only steers a choice between two correct plans.
+static double estimate_selectivity(const FilterOp& op, double n_docs) {
+  if (n_docs <= 0) return 0;
+  switch (op.kind) {
+    case OpKind::Empty: return 0;
+    case OpKind::MatchAll: return 1;
+    case OpKind::Inverted: {
+      double m = 0;
+      for (int32_t id : op.eval.matching) m += (double)op.col->posting_card[(size_t)id];
+      return std::min(1.0, m / n_docs);
+    }
+    case OpKind::Sorted: {
+      double m = 0;
+      for (int32_t id : op.eval.matching) m += (double)(op.col->sorted_end[(size_t)id] - op.col->sorted_start[(size_t)id] + 1);
+      return std::min(1.0, m / n_docs);
+    }
+    case OpKind::Bitmap: {
+      double m = 0;
+      for (size_t i = 0; i < op.range_lo.size(); i++) m += (double)(op.range_hi[i] - op.range_lo[i] + 1);
+      return std::min(1.0, m / n_docs);
+    }
+    case OpKind::Scan:
+      if (op.eval.dictionary_based && op.col->cardinality > 0) return (double)op.eval.matching.size() / op.col->cardinality;   // uniform dictIds
+      return 0.2;   // a raw-value predicate without column statistics: assume it is selective (the dense HBM table is the safe side)
+    case OpKind::And: { double s = 1; for (auto& c : op.children) s *= estimate_selectivity(*c, n_docs); return s; }
+    case OpKind::Or: { double s = 1; for (auto& c : op.children) s *= 1 - estimate_selectivity(*c, n_docs); return 1 - s; }
+    case OpKind::Not: return 1 - estimate_selectivity(*op.children[0], n_docs);
+  }
+  return 0.5;
+}
+
 // canOptimizeCount (BaseFilterOperator.java:56-82 and overrides): index-only filters whose cardinality needs no scan
 static bool can_optimize_count(const FilterOp& op) {
   switch (op.kind) {
@@ -1030,11 +1062,11 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
     // memory-side atomics on an HBM table ~2.4e10/s — tools/probes/atomic_scope.hip), else the dense HBM table
     int parts = (int)std::min<int64_t>(32, std::max<int64_t>(2, (table_bytes + kLdsTableBudget - 1) / kLdsTableBudget));
     if (const char* e = getenv("PG_PART_MIN")) parts = std::max(parts, std::min(32, atoi(e)));   // measurement knob
-    // every range's workgroups visit every doc (~3.4e11 doc visits/s measured), so the partitioned form pays off when most
-    // docs reach the aggregation: parts * N / 3.4e11  <  matched * ops / 2.4e10.  Without a filter matched = N is known at
-    // plan time; with one, the dense HBM table stays the choice until the match count is known before the aggregation runs.
-    const bool all_match = root->kind == OpKind::MatchAll;
-    if (table_bytes <= kLdsTableBudget * parts && all_match && parts * 0.07 < (double)std::max(D.n_ops, 1)) {
+    // every range's workgroups visit every doc (~4e11 doc visits/s measured), the dense HBM table pays per matching doc and
+    // accumulator (memory-side atomics, 2.4e10/s): partition when  parts * N / 4e11  <  matched * ops / 2.4e10, with the
+    // match count estimated from the filter (exact for index leaves)
+    const double sel = estimate_selectivity(*root, (double)seg.total_docs);
+    if (table_bytes <= kLdsTableBudget * parts && parts * 0.06 < sel * (double)std::max(D.n_ops, 1)) {
       D.agg_mode = PG_AGG_LDS_PART;
       D.n_parts = parts;
       D.part_groups = (int32_t)((G + parts - 1) / parts);
@@ -1089,8 +1121,8 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
   // LDS tables that miss the narrow shape only by column width (group columns > 8 bits, LONG / DOUBLE sources, 64-bit
   // dictionaries) keep the 1024-thread kernels and run the general aggregator there (pg_fast_none_w / pg_fast_multi_w)
   P.wide_agg = !P.fast_agg && (D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE) && D.n_aux == 0 && P.first_doc_op < 0;
-  // range-partitioned tables without a filter scan: pg_fast_none_w walks the partitioned tile order with 16 wavefronts per CU
-  if (D.agg_mode == PG_AGG_LDS_PART && D.n_aux == 0 && P.fast_filter == -1) P.wide_agg = true;
+  // range-partitioned tables: pg_fast_none_w / pg_fast_multi_w walk the partitioned tile order with 16 wavefronts per CU
+  if (D.agg_mode == PG_AGG_LDS_PART && D.n_aux == 0 && P.fast_filter != -2 && P.first_doc_op < 0) P.wide_agg = true;
   return plan;
 }
 

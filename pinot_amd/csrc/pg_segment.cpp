@@ -55,6 +55,7 @@ static void parse_inverted_index(Segment& seg, Column& c, const uint8_t* inv, ui
   std::vector<uint8_t> staging;
   staging.reserve(len);
   const uint32_t max_key = (uint32_t)((padded_docs(seg) + PG_CHUNK_DOCS - 1) / PG_CHUNK_DOCS);
+  c.posting_card.assign((size_t)card, 0);
   for (int32_t d = 0; d < card; d++) {
     c.posting_begin[d] = (uint32_t)c.descs_host.size();
     uint64_t off = be32(inv + (uint64_t)d * 4), end = be32(inv + (uint64_t)(d + 1) * 4);
@@ -105,6 +106,8 @@ static void parse_inverted_index(Segment& seg, Column& c, const uint8_t* inv, ui
         payload = 2ULL * pc.n;
       }
       if (pos + payload > blen) fail(PG_ERR_INVALID_ARGUMENT, "roaring: truncated container");
+      if (pc.type == 2) for (uint32_t r = 0; r < pc.n; r++) c.posting_card[(size_t)d] += (int64_t)le16(blob + pos + 4 * r + 2) + 1;
+      else c.posting_card[(size_t)d] += pc.n;
       if (pc.key >= max_key) fail(PG_ERR_INVALID_ARGUMENT, "roaring: container key %u beyond the segment", pc.key);
       size_t aligned = (staging.size() + 15) & ~(size_t)15;
       staging.resize(aligned + payload);
