@@ -1190,7 +1190,8 @@ __device__ __forceinline__ void fast_multi_body(const PgQueryPlan& p) {
         my_cand[sidx] += (uint32_t)__popc(m);
         if (L.col_kind == PG_COL_FIXED_BIT) {
           const GAS uint8_t* tb = (const GAS uint8_t*)packed_wtile_base(L.data, wt, L.bits);
-          m = L.pred_kind == PG_P_RANGE ? scan_wtile<SK_DICT_RANGE_SMALL>(L, m, tb, lane) : scan_wtile<SK_DICT_LUT_SMALL>(L, m, tb, lane);
+          if (L.bits <= 8) m = L.pred_kind == PG_P_RANGE ? scan_wtile<SK_DICT_RANGE_SMALL>(L, m, tb, lane) : scan_wtile<SK_DICT_LUT_SMALL>(L, m, tb, lane);
+          else m = L.pred_kind == PG_P_RANGE ? scan_wtile<SK_DICT_RANGE_WIDE>(L, m, tb, lane) : scan_wtile<SK_DICT_LUT_WIDE>(L, m, tb, lane);
         } else if (L.col_kind == PG_COL_RAW32) {
           const GAS uint8_t* tb = gptr<uint8_t>(L.data + (size_t)wt * (PG_WAVE_DOCS * 4));
           m = L.val_type == PG_V_I32 ? scan_wtile<SK_I32_RANGE>(L, m, tb, lane) : scan_wtile<SK_F32_RANGE>(L, m, tb, lane);

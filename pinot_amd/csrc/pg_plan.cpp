@@ -829,11 +829,11 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
       }
     }
     if (P.fast_filter == -2 && rest >= 1 && rest <= PG_MAX_FAST_SCANS) {
-      // [index-only program] AND scan AND scan ...: a chain of up to 4 scan leaves of the common kinds (<= 8-bit dictionary range /
-      // LUT, raw INT / LONG / FLOAT / DOUBLE range), each restricted to the survivors of the previous one (AndDocIdSet applies
+      // [index-only program] AND scan AND scan ...: a chain of up to 4 scan leaves of the common kinds (dictionary range /
+      // LUT of any width, raw INT / LONG / FLOAT / DOUBLE range), each restricted to the survivors of the previous one (AndDocIdSet applies
       // the scan iterators in list order) — pg_fast_multi_* dispatches the kind per leaf at run time
       auto multi_kind = [&](const PgScanLeaf& L) {
-        if (L.col_kind == PG_COL_FIXED_BIT) return L.bits <= 8 && (L.pred_kind == PG_P_RANGE || L.pred_kind == PG_P_DICT_LUT);
+        if (L.col_kind == PG_COL_FIXED_BIT) return L.pred_kind == PG_P_RANGE || L.pred_kind == PG_P_DICT_LUT;
         return L.pred_kind == PG_P_RANGE;
       };
       bool ok = true;
