@@ -118,8 +118,14 @@ enum PgAggMode : int32_t {
   // b % 8, index i = b / 8 inside it) owns range i % n_parts and walks the tile chunks of ITS XCD together with the other
   // ranges' workgroups of that XCD — every chunk is fetched from HBM once per XCD and re-read from that XCD's L2 by the other
   // ranges — aggregating only the docs whose key falls in its range into an LDS table [n_acc][part_groups].
-  PG_AGG_LDS_PART = 4
+  PG_AGG_LDS_PART = 4,
+  // Large key spaces, one visit per doc: the docs that pass the filter are radix-partitioned by key range into (local key,
+  // values) tuples in HBM — pass 1 counts per (workgroup, bucket), a scan turns the counts into exact offsets, pass 2 scatters —
+  // and every bucket (2^radix_shift keys = one LDS table) is then aggregated from its contiguous tuple range with LDS atomics.
+  PG_AGG_RADIX = 5
 };
+#define PG_MAX_RADIX_BUCKETS 2048
+#define PG_MAX_RADIX_SRCS 4
 
 struct PgGroupCol {
   const uint8_t* data;   // fixed-bit dictIds
@@ -201,6 +207,17 @@ struct PgQueryPlan {
   int32_t replicas;                 // R: LDS copies per group (power of two) to spread atomic conflicts
   int32_t replica_shift;            // log2(R): group index = slot >> replica_shift
   int32_t n_aux;
+  // PG_AGG_RADIX (pointers patched per execution)
+  int32_t radix_shift;              // bucket = key >> radix_shift, local key = key & ((1 << radix_shift) - 1)
+  int32_t radix_buckets;
+  int32_t radix_slices;             // workgroups (slices) per bucket in the aggregation pass
+  int32_t pad_r;
+  const uint32_t* match_words;      // filter result, one dword per 32 docs, whole wave tiles
+  uint32_t* radix_hist;             // [grid][radix_buckets] tuple counts, then exact offsets (bucket major)
+  uint32_t* radix_bucket_start;     // [radix_buckets + 1]
+  uint32_t* radix_keys;             // [matched] local keys
+  uint32_t* radix_docids;           // [matched] docIds, only when the plan carries the MIN(docId) accumulator (numGroupsLimit)
+  int64_t* radix_vals[PG_MAX_RADIX_SRCS];   // [matched] per source: int64 values / double bits
   int32_t n_lin_prefix;             // interpreter kernels: instrs[0, n_lin_prefix) is index-only and leaves one stack entry
   int32_t n_fast_scans;             // pg_fast_multi_*: instrs[n_index_instr, n_index_instr + n_fast_scans) are scan leaves ANDed in order
   int32_t n_parts;                  // PG_AGG_LDS_PART: key ranges (the grid is 8 x a multiple of it)

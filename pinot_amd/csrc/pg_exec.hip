@@ -20,6 +20,11 @@ extern "C" __global__ void pg_reduce_partials_kernel(const int64_t* partials, in
                                                      int n_groups, const PgAccOp* ops, unsigned long long* stats, int reduce);
 extern "C" __global__ void pg_reduce_parts_kernel(const int64_t* partials, int64_t* out, int n_wg, int n_ops, int n_groups,
                                                    int n_parts, int part_groups, const PgAccOp* ops);
+PG_DECL_FAST(pg_radix_count_kernel) PG_DECL_FAST(pg_radix_scatter_kernel) PG_DECL_FAST(pg_radix_aggregate_kernel)
+extern "C" __global__ void pg_radix_offsets_kernel(uint32_t* hist, uint32_t* bucket_total, int n_wg, int n_buckets);
+extern "C" __global__ void pg_radix_bucket_scan_kernel(const uint32_t* bucket_total, uint32_t* bucket_start, int n_buckets);
+extern "C" __global__ void pg_radix_reduce_kernel(const int64_t* partials, int64_t* out, int n_ops, int n_groups, int radix_shift, int slices,
+                                                   const PgAccOp* ops);
 extern "C" __global__ void pg_reduce_aux_kernel(const uint32_t* partials, uint32_t* out, int n_wg, int64_t n_words, int bytewise_max);
 extern "C" __global__ void pg_fill_i64_kernel(int64_t* dst, int64_t n_per_op, int n_ops, const PgAccOp* ops);
 extern "C" __global__ void pg_expand_docids_kernel(const uint64_t* words, const int64_t* tile_offsets, int32_t* out,
@@ -77,7 +82,7 @@ void device_init(int ordinal) {
   // opt in to large dynamic LDS for the query kernels
   typedef void (*QueryKernel)(const PgQueryPlan);
   const QueryKernel all[] = {pg_generic_query_f, pg_generic_query_l, pg_generic_query_g, pg_fast_none_f, pg_fast_none_a, pg_fast_i32range_f, pg_fast_i32range_a,
-                             pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a, pg_fast_multi_f, pg_fast_multi_a, pg_fast_multi_w, pg_fast_none_w};
+                             pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a, pg_fast_multi_f, pg_fast_multi_a, pg_fast_multi_w, pg_fast_none_w, pg_radix_aggregate_kernel};
   for (QueryKernel k : all)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
 }
@@ -118,6 +123,7 @@ struct ThreadCtx {
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   DeviceBuffer stats, partials, final_table, tile_counts, aux;
+  DeviceBuffer words, radix_hist, radix_start, radix_keys, radix_docids, radix_vals[PG_MAX_RADIX_SRCS];   // PG_AGG_RADIX work areas
   bool stats_dirty = true;      // the stats counters may be non-zero (first use, or a query that failed midway)
   void* pinned = nullptr;       // page-locked staging for the result copy (pageable copies are staged synchronously)
   size_t pinned_size = 0;
@@ -277,6 +283,8 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   } else if (D.agg_mode == PG_AGG_LDS_PART) {
     ThreadCtx::grow(ctx.partials, (size_t)D.n_ops * (size_t)D.part_groups * 8 * (size_t)shape.grid + 8);
     D.partials = ctx.partials.as<int64_t>();
+  } else if (D.agg_mode == PG_AGG_RADIX) {
+    // sized where the passes are launched
   } else {
     ThreadCtx::grow(ctx.partials, (size_t)n_out * 8 * (size_t)shape.grid + 8);
     D.partials = ctx.partials.as<int64_t>();
@@ -303,7 +311,50 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   if (profile) PG_HIP(hipEventRecord(ctx.ev[0], ctx.stream));
   const char* kname = "";
   const bool has_docs = P.space_docs > 0;   // docs of the doc space the plan runs on (the segment's or a star-tree's)
-  if (has_docs) {
+  const bool radix = D.agg_mode == PG_AGG_RADIX;
+  if (has_docs && radix) {
+    // ---- radix-partitioned group-by: filter → match words; count; offsets; scatter; per-bucket LDS aggregation; merge ---------
+    kname = "pg_radix_group_by";
+    const size_t n_words = (size_t)D.n_wtiles * 64;
+    ThreadCtx::grow(ctx.words, n_words * 4);
+    PgQueryPlan F = D;
+    F.agg_mode = PG_AGG_NONE;
+    F.out_words = ctx.words.as<uint64_t>();
+    const char* fname = "";
+    const LaunchShape fshape = launch_shape(P, D.n_wtiles, PG_AGG_NONE);
+    hipLaunchKernelGGL(select_kernel(P, PG_AGG_NONE, &fname), dim3(fshape.grid), dim3(fshape.block), fshape.lds, ctx.stream, F);
+    PG_HIP(hipGetLastError());
+    const int rgrid = std::max(1, std::min((D.n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, g_num_cus));
+    ThreadCtx::grow(ctx.radix_hist, (size_t)rgrid * D.radix_buckets * 4);
+    ThreadCtx::grow(ctx.radix_start, ((size_t)D.radix_buckets + 1) * 8);
+    ThreadCtx::grow(ctx.radix_keys, (size_t)P.space_docs * 4 + 256);
+    for (int si = 0; si < D.n_srcs; si++) ThreadCtx::grow(ctx.radix_vals[si], (size_t)P.space_docs * 8 + 256);
+    D.match_words = ctx.words.as<uint32_t>();
+    D.radix_hist = ctx.radix_hist.as<uint32_t>();
+    D.radix_bucket_start = ctx.radix_start.as<uint32_t>();
+    D.radix_keys = ctx.radix_keys.as<uint32_t>();
+    D.radix_docids = nullptr;
+    if (P.first_doc_op >= 0) {
+      ThreadCtx::grow(ctx.radix_docids, (size_t)P.space_docs * 4 + 256);
+      D.radix_docids = ctx.radix_docids.as<uint32_t>();
+    }
+    for (int si = 0; si < D.n_srcs; si++) D.radix_vals[si] = ctx.radix_vals[si].as<int64_t>();
+    D.radix_slices = std::max(1, g_num_cus / D.radix_buckets);
+    const size_t slots = (size_t)1 << D.radix_shift;
+    ThreadCtx::grow(ctx.partials, (size_t)D.radix_buckets * D.radix_slices * D.n_ops * slots * 8 + 8);
+    D.partials = ctx.partials.as<int64_t>();
+    hipLaunchKernelGGL(pg_radix_count_kernel, dim3(rgrid), dim3(PG_BLOCK), 0, ctx.stream, D);
+    uint32_t* bucket_total = D.radix_bucket_start + D.radix_buckets + 1;   // second half of the same buffer
+    hipLaunchKernelGGL(pg_radix_offsets_kernel, dim3((unsigned)((D.radix_buckets + 15) / 16)), dim3(1024), 0, ctx.stream, D.radix_hist,
+                       bucket_total, rgrid, D.radix_buckets);
+    hipLaunchKernelGGL(pg_radix_bucket_scan_kernel, dim3(1), dim3(64), 0, ctx.stream, bucket_total, D.radix_bucket_start, D.radix_buckets);
+    hipLaunchKernelGGL(pg_radix_scatter_kernel, dim3(rgrid), dim3(PG_BLOCK), 0, ctx.stream, D);
+    const int agrid = std::min(D.radix_buckets * D.radix_slices, g_num_cus);
+    hipLaunchKernelGGL(pg_radix_aggregate_kernel, dim3(agrid), dim3(PG_BLOCK), (size_t)D.n_ops * slots * 8 + 64, ctx.stream, D);
+    hipLaunchKernelGGL(pg_radix_reduce_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, ctx.stream, ctx.partials.as<int64_t>(),
+                       ctx.final_table.as<int64_t>(), D.n_ops, D.n_groups, D.radix_shift, D.radix_slices, P.ops_dev.as<PgAccOp>());
+    PG_HIP(hipGetLastError());
+  } else if (has_docs) {
     QueryKernel kern = select_kernel(P, D.agg_mode, &kname);
     hipLaunchKernelGGL(kern, dim3(shape.grid), dim3(shape.block), shape.lds, ctx.stream, D);
     PG_HIP(hipGetLastError());
@@ -324,7 +375,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
                          ctx.final_table.as<int64_t>(), shape.grid, D.n_ops, D.n_groups, D.n_parts, D.part_groups, P.ops_dev.as<PgAccOp>());
       PG_HIP(hipGetLastError());
     }
-    const int reduce = (D.agg_mode != PG_AGG_GLOBAL && D.agg_mode != PG_AGG_LDS_PART && n_out > 0) ? 1 : 0;
+    const int reduce = (D.agg_mode != PG_AGG_GLOBAL && D.agg_mode != PG_AGG_LDS_PART && !radix && n_out > 0) ? 1 : 0;
     const int blocks = (reduce ? (int)((n_out + 3) / 4) : 0) + 1;   // one wavefront per output slot + the stats block
     hipLaunchKernelGGL(pg_reduce_partials_kernel, dim3(blocks), dim3(256), 0, ctx.stream, ctx.partials.as<int64_t>(),
                        ctx.final_table.as<int64_t>(), shape.grid, D.n_ops, D.n_groups, P.ops_dev.as<PgAccOp>(),

@@ -1453,6 +1453,302 @@ extern "C" __global__ void __launch_bounds__(256) pg_reduce_partials_kernel(cons
   if (lane == 0) out[i] = acc;
 }
 
+// =====================================================================================================================
+// Radix-partitioned group-by (PG_AGG_RADIX): pass 1 / pass 2 over the match words, then per-bucket LDS aggregation.
+// =====================================================================================================================
+// raw keys of the 4 docs of B quads: Σ dictId_j · mult_j, one group column at a time (any width)
+template <int B>
+DEVFN void radix_keys_of(const PgQueryPlan& p, const uint32_t (&qi)[B], int wtile, uint32_t (&key)[B][4]) {
+#pragma unroll
+  for (int u = 0; u < B; u++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) key[u][i] = 0;
+  for (int g = 0; g < p.n_group_cols; g++) {
+    const PgGroupCol& gc = p.gcols[g];
+    const GAS uint32_t* tw = packed_wtile_base(gc.data, wtile, gc.bits);
+    const uint32_t bits = (uint32_t)gc.bits, mask = (1u << gc.bits) - 1u, mult = (uint32_t)gc.mult;
+    if (bits <= 8) {
+      uint32_t r[B][2];
+#pragma unroll
+      for (int u = 0; u < B; u++) load_packed_quad<true>(tw, qi[u], bits, r[u]);
+#pragma unroll
+      for (int u = 0; u < B; u++) {
+        uint32_t d[4];
+        decode_packed_quad<true>(r[u], qi[u], bits, mask, d);
+#pragma unroll
+        for (int i = 0; i < 4; i++) key[u][i] += d[i] * mult;
+      }
+    } else {
+      uint32_t r[B][8];
+#pragma unroll
+      for (int u = 0; u < B; u++) load_packed_quad<false>(tw, qi[u], bits, r[u]);
+#pragma unroll
+      for (int u = 0; u < B; u++) {
+        uint32_t d[4];
+        decode_packed_quad<false>(r[u], qi[u], bits, mask, d);
+#pragma unroll
+        for (int i = 0; i < 4; i++) key[u][i] += d[i] * mult;
+      }
+    }
+  }
+}
+
+// PASS 1: count the matching docs per bucket → radix_hist[workgroup][bucket].
+// PASS 2: radix_hist holds exact offsets; every matching doc claims the next slot of its (workgroup, bucket) range with an LDS
+//         counter and writes its local key and the values of every source there.
+template <int PASS>
+__device__ __forceinline__ void radix_pass_body(const PgQueryPlan& p) {
+  __shared__ uint32_t s_cnt[PG_MAX_RADIX_BUCKETS];
+  __shared__ uint32_t s_base[PASS == 2 ? PG_MAX_RADIX_BUCKETS : 1];
+  constexpr int B = 4;
+  const int t = threadIdx.x, lane = t & 63, wave = uniform(t >> 6);
+  const int P = p.radix_buckets;
+  for (int i = t; i < P; i += PG_BLOCK) {
+    s_cnt[i] = 0;
+    if (PASS == 2) s_base[i] = p.radix_bucket_start[i] + p.radix_hist[(int64_t)blockIdx.x * P + i];
+  }
+  __syncthreads();
+  const uint32_t local_mask = (1u << p.radix_shift) - 1u;
+  const int wstride = (int)gridDim.x * PG_WAVES_PER_BLOCK;
+  for (int wt = (int)blockIdx.x * PG_WAVES_PER_BLOCK + wave; wt < p.n_wtiles; wt += wstride) {
+    const int64_t rem = (int64_t)p.num_docs - (int64_t)wt * PG_WAVE_DOCS;
+    const int32_t n_valid = rem >= PG_WAVE_DOCS ? PG_WAVE_DOCS : (int32_t)rem;
+    const uint32_t mlin = gptr<uint32_t>(p.match_words)[(int64_t)wt * 64 + lane] & valid_lin_mask(n_valid, lane);
+    if (__ballot(mlin != 0) == 0) continue;
+    const uint32_t m = lin_to_quad(mlin, lane);
+#pragma unroll
+    for (int k0 = 0; k0 < 8; k0 += B) {
+      const uint32_t mb = (m >> (4 * k0)) & 0xFFFFu;
+      if (__ballot(mb != 0) == 0) continue;
+      uint32_t qi[B];
+#pragma unroll
+      for (int u = 0; u < B; u++) qi[u] = ((mb >> (4 * u)) & 0xFu) ? (uint32_t)((k0 + u) * 64 + lane) : 0u;
+      uint32_t key[B][4];
+      radix_keys_of<B>(p, qi, wt, key);
+      if (PASS == 1) {
+#pragma unroll
+        for (int u = 0; u < B; u++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if ((mb >> (4 * u + i)) & 1u) atomicAdd(&s_cnt[key[u][i] >> p.radix_shift], 1u);
+      } else {
+        uint32_t pos[B][4];
+#pragma unroll
+        for (int u = 0; u < B; u++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            pos[u][i] = 0;
+            if ((mb >> (4 * u + i)) & 1u) {
+              const uint32_t b = key[u][i] >> p.radix_shift;
+              pos[u][i] = s_base[b] + atomicAdd(&s_cnt[b], 1u);
+              p.radix_keys[pos[u][i]] = key[u][i] & local_mask;
+              if (p.radix_docids) p.radix_docids[pos[u][i]] = (uint32_t)wt * PG_WAVE_DOCS + 4u * (uint32_t)((k0 + u) * 64 + lane) + (uint32_t)i;
+            }
+          }
+        for (int si = 0; si < p.n_srcs; si++) {
+          const PgValueSrc& S = p.srcs[si];
+          int64_t* out = p.radix_vals[si];
+          if (S.col_kind == PG_COL_RAW32) {
+            const GAS uint8_t* tb = gptr<uint8_t>(S.data + (size_t)wt * (PG_WAVE_DOCS * 4));
+            u32x4 v[B];
+#pragma unroll
+            for (int u = 0; u < B; u++) v[u] = ldnt((const GAS u32x4*)(tb + qi[u] * 16u));
+#pragma unroll
+            for (int u = 0; u < B; u++) {
+              const uint32_t x[4] = {bswap32(v[u].x), bswap32(v[u].y), bswap32(v[u].z), bswap32(v[u].w)};
+#pragma unroll
+              for (int i = 0; i < 4; i++)
+                if ((mb >> (4 * u + i)) & 1u)
+                  out[pos[u][i]] = S.val_type == PG_V_I32 ? (int64_t)(int32_t)x[i] : __double_as_longlong((double)__uint_as_float(x[i]));
+            }
+          } else if (S.col_kind == PG_COL_RAW64) {
+            const GAS uint8_t* tb = gptr<uint8_t>(S.data + (size_t)wt * (PG_WAVE_DOCS * 8));
+            u32x4 a[B], b[B];
+#pragma unroll
+            for (int u = 0; u < B; u++) {
+              const GAS u32x4* pp = (const GAS u32x4*)(tb + qi[u] * 32u);
+              a[u] = ldnt(pp);
+              b[u] = ldnt(pp + 1);
+            }
+#pragma unroll
+            for (int u = 0; u < B; u++) {
+              const uint64_t x[4] = {((uint64_t)bswap32(a[u].x) << 32) | bswap32(a[u].y), ((uint64_t)bswap32(a[u].z) << 32) | bswap32(a[u].w),
+                                     ((uint64_t)bswap32(b[u].x) << 32) | bswap32(b[u].y), ((uint64_t)bswap32(b[u].z) << 32) | bswap32(b[u].w)};
+#pragma unroll
+              for (int i = 0; i < 4; i++)
+                if ((mb >> (4 * u + i)) & 1u) out[pos[u][i]] = (int64_t)x[i];   // LONG as is, DOUBLE as its bits
+            }
+          } else {   // dictionary-encoded source: dictIds → values
+            const GAS uint32_t* tw = packed_wtile_base(S.data, wt, S.bits);
+            const uint32_t bits = (uint32_t)S.bits, mask = (1u << S.bits) - 1u;
+#pragma unroll
+            for (int u = 0; u < B; u++) {
+              uint32_t r[8], d[4];
+              if (bits <= 8) { load_packed_quad<true>(tw, qi[u], bits, r); decode_packed_quad<true>(r, qi[u], bits, mask, d); }
+              else { load_packed_quad<false>(tw, qi[u], bits, r); decode_packed_quad<false>(r, qi[u], bits, mask, d); }
+#pragma unroll
+              for (int i = 0; i < 4; i++)
+                if ((mb >> (4 * u + i)) & 1u) {
+                  int64_t v;
+                  if (S.val_type == PG_V_I32) v = (int64_t)(int32_t)gptr<uint32_t>(S.dict)[d[i]];
+                  else if (S.val_type == PG_V_F32) v = __double_as_longlong((double)__uint_as_float(gptr<uint32_t>(S.dict)[d[i]]));
+                  else v = (int64_t)gptr<uint64_t>(S.dict)[d[i]];
+                  out[pos[u][i]] = v;
+                }
+            }
+          }
+        }
+      }
+    }
+  }
+  if (PASS == 1) {
+    __syncthreads();
+    for (int i = t; i < P; i += PG_BLOCK) p.radix_hist[(int64_t)blockIdx.x * P + i] = s_cnt[i];
+  }
+}
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_count_kernel(const PgQueryPlan p) { radix_pass_body<1>(p); }
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_scatter_kernel(const PgQueryPlan p) { radix_pass_body<2>(p); }
+
+// Counts → offsets.  Step 1, one wavefront per bucket: hist[wg][b] becomes the exclusive prefix over the workgroups (lanes own
+// consecutive workgroups), total[b] the bucket's size.  Step 2, one wavefront: bucket_start = exclusive scan of the totals.
+// (The scatter pass adds bucket_start[b] when it loads its bases.)
+extern "C" __global__ void __launch_bounds__(1024) pg_radix_offsets_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ bucket_total,
+                                                                           int n_wg, int n_buckets) {
+  const int lane = threadIdx.x & 63;
+  const int b = (int)blockIdx.x * 16 + (int)(threadIdx.x >> 6);
+  if (b >= n_buckets) return;
+  const int per_lane = (n_wg + 63) / 64;
+  uint32_t run_total = 0;
+  // lanes own per_lane consecutive workgroups
+  uint32_t mine = 0;
+  for (int k = 0; k < per_lane; k++) {
+    const int w = lane * per_lane + k;
+    if (w < n_wg) mine += hist[(int64_t)w * n_buckets + b];
+  }
+  uint32_t x = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t y = (uint32_t)__shfl_up((int)x, off, 64);
+    if (lane >= off) x += y;
+  }
+  run_total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+  uint32_t run = x - mine;
+  for (int k = 0; k < per_lane; k++) {
+    const int w = lane * per_lane + k;
+    if (w < n_wg) {
+      const uint32_t c = hist[(int64_t)w * n_buckets + b];
+      hist[(int64_t)w * n_buckets + b] = run;
+      run += c;
+    }
+  }
+  if (lane == 0) bucket_total[b] = run_total;
+}
+extern "C" __global__ void __launch_bounds__(64) pg_radix_bucket_scan_kernel(const uint32_t* __restrict__ bucket_total,
+                                                                             uint32_t* __restrict__ bucket_start, int n_buckets) {
+  const int lane = threadIdx.x;
+  const int per_lane = (n_buckets + 63) / 64;
+  uint32_t mine = 0;
+  for (int k = 0; k < per_lane; k++) {
+    const int b = lane * per_lane + k;
+    if (b < n_buckets) mine += bucket_total[b];
+  }
+  uint32_t x = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t y = (uint32_t)__shfl_up((int)x, off, 64);
+    if (lane >= off) x += y;
+  }
+  uint32_t run = x - mine;
+  for (int k = 0; k < per_lane; k++) {
+    const int b = lane * per_lane + k;
+    if (b < n_buckets) { const uint32_t c = bucket_total[b]; bucket_start[b] = run; run += c; }
+  }
+  if (lane == 63) bucket_start[n_buckets] = run;
+}
+
+// Per-bucket aggregation: work item w = bucket * slices + slice aggregates its share of the bucket's tuples into an LDS table
+// [n_ops][2^radix_shift] and flushes it to partials[w].
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_aggregate_kernel(const PgQueryPlan p) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
+  int64_t* table = reinterpret_cast<int64_t*>(smem);
+  const int t = threadIdx.x;
+  const uint32_t slots = 1u << p.radix_shift;
+  const int n_items = p.radix_buckets * p.radix_slices;
+  for (int w = (int)blockIdx.x; w < n_items; w += (int)gridDim.x) {
+    const int b = w / p.radix_slices, sl = w % p.radix_slices;
+    for (int o = 0; o < p.n_ops; o++) {
+      const int64_t ident = pg_acc_identity(p.ops[o].fn, p.ops[o].is_float);
+      for (uint32_t i = t; i < slots; i += PG_BLOCK) table[(size_t)o * slots + i] = ident;
+    }
+    __syncthreads();
+    const uint32_t start = p.radix_bucket_start[b], total = p.radix_bucket_start[b + 1] - start;
+    const uint32_t per = (total + (uint32_t)p.radix_slices - 1u) / (uint32_t)p.radix_slices;
+    const uint32_t lo = start + (uint32_t)sl * per;
+    const uint32_t hi = lo + per < start + total ? lo + per : start + total;
+    constexpr int U = 4;   // tuples per thread in flight: the loop is a chain of dependent loads otherwise
+    for (uint32_t i0 = lo; i0 < hi; i0 += PG_BLOCK * U) {
+      uint32_t k[U];
+      bool on[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t i = i0 + (uint32_t)u * PG_BLOCK + (uint32_t)t;
+        on[u] = i < hi;
+        k[u] = gptr<uint32_t>(p.radix_keys)[on[u] ? i : lo];
+      }
+      for (int o = 0; o < p.n_ops; o++) {
+        const PgAccOp op = p.ops[o];
+        int64_t* base = table + (size_t)o * slots;
+        if (op.src < 0) {
+          if (op.fn == PG_ACC_COUNT) {
+#pragma unroll
+            for (int u = 0; u < U; u++) if (on[u]) atomicAdd(reinterpret_cast<unsigned long long*>(base + k[u]), 1ULL);
+          } else {   // MIN(docId): which groups numGroupsLimit admits
+#pragma unroll
+            for (int u = 0; u < U; u++)
+              if (on[u]) atomicMin(reinterpret_cast<long long*>(base + k[u]), (long long)gptr<uint32_t>(p.radix_docids)[i0 + (uint32_t)u * PG_BLOCK + (uint32_t)t]);
+          }
+          continue;
+        }
+        int64_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = gptr<int64_t>(p.radix_vals[op.src])[on[u] ? i0 + (uint32_t)u * PG_BLOCK + (uint32_t)t : lo];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (on[u]) {
+            if (op.is_float) acc_float(base + k[u], op.fn, __longlong_as_double(v[u]));
+            else acc_int(base + k[u], op.fn, v[u]);
+          }
+      }
+    }
+    __syncthreads();
+    int64_t* out = p.partials + (int64_t)w * p.n_ops * slots;
+    for (int64_t i = t; i < (int64_t)p.n_ops * slots; i += PG_BLOCK) out[i] = table[i];
+    __syncthreads();
+  }
+}
+
+// out[op][g] = combine over the slices of g's bucket
+extern "C" __global__ void __launch_bounds__(256) pg_radix_reduce_kernel(const int64_t* __restrict__ partials, int64_t* __restrict__ out,
+                                                                          int n_ops, int n_groups, int radix_shift, int slices,
+                                                                          const PgAccOp* __restrict__ ops) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)n_ops * n_groups) return;
+  const int o = (int)(i / n_groups), g = (int)(i % n_groups);
+  const int b = g >> radix_shift, l = g & ((1 << radix_shift) - 1);
+  const int64_t slots = (int64_t)1 << radix_shift;
+  const PgAccOp op = ops[o];
+  const int kind = (op.fn == PG_ACC_SUM && op.is_float) ? 0 : ((op.fn == PG_ACC_COUNT || op.fn == PG_ACC_SUM) ? 1 : (op.fn == PG_ACC_MIN ? 2 : 3));
+  int64_t acc = pg_acc_identity(op.fn, op.is_float);
+  for (int sl = 0; sl < slices; sl++) {
+    const int64_t v = partials[((int64_t)(b * slices + sl) * n_ops + o) * slots + l];
+    if (kind == 0) acc = __double_as_longlong(__longlong_as_double(acc) + __longlong_as_double(v));
+    else if (kind == 1) acc += v;
+    else if (kind == 2) acc = v < acc ? v : acc;
+    else acc = v > acc ? v : acc;
+  }
+  out[i] = acc;
+}
+
 // Range-partitioned partials: workgroup b holds [n_ops][part_groups] for range (b >> 3) % n_parts.  One wavefront per
 // output slot (op, group), lanes stride over the workgroups that own the group's range.
 extern "C" __global__ void __launch_bounds__(256) pg_reduce_parts_kernel(const int64_t* __restrict__ partials,

@@ -1066,7 +1066,26 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
     // accumulator (memory-side atomics, 2.4e10/s): partition when  parts * N / 4e11  <  matched * ops / 2.4e10, with the
     // match count estimated from the filter (exact for index leaves)
     const double sel = estimate_selectivity(*root, (double)seg.total_docs);
-    if (table_bytes <= kLdsTableBudget * parts && parts * 0.06 < sel * (double)std::max(D.n_ops, 1)) {
+    // three ways, cost per doc of the segment (seconds x 1e12, measured rates — profiles/r01_v4_variants_200m.txt):
+    //   dense HBM table       filter pass + memory-side atomics per matching doc and accumulator (2.4e10/s)
+    //   range partitions      every range's workgroups visit every doc (4.2e11 visits/s)
+    //   radix partition       filter pass, two passes over the matches' keys, tuples written and read once, LDS atomics
+    const int n_srcs_radix = (int)srcs.size();
+    int radix_shift = 0;
+    while (((int64_t)2 << radix_shift) * std::max(D.n_ops, 1) * 8 <= kLdsTableBudget) radix_shift++;
+    const int64_t radix_buckets = (G + ((int64_t)1 << radix_shift) - 1) >> radix_shift;
+    const bool radix_ok = D.n_aux == 0 && n_srcs_radix <= PG_MAX_RADIX_SRCS && D.n_ops > 0 &&
+                          radix_buckets <= PG_MAX_RADIX_BUCKETS && !getenv("PG_NO_RADIX");
+    const bool part_ok = table_bytes <= kLdsTableBudget * parts && !getenv("PG_NO_PART");
+    const double ops_d = (double)std::max(D.n_ops, 1);
+    const double cost_global = 1.25 + sel * ops_d * 41.7;
+    const double cost_part = part_ok ? parts * 2.4 : 1e30;
+    const double cost_radix = radix_ok ? 4.0 + sel * ((4.0 + 8.0 * n_srcs_radix) * 0.25 + ops_d * 0.95) : 1e30;   // 200 M rows, 40k keys: 0.92 / 1.78 ms at 12.5 / 100 %
+    if (cost_radix <= cost_part && cost_radix <= cost_global) {
+      D.agg_mode = PG_AGG_RADIX;
+      D.radix_shift = radix_shift;
+      D.radix_buckets = (int32_t)radix_buckets;
+    } else if (cost_part <= cost_global) {
       D.agg_mode = PG_AGG_LDS_PART;
       D.n_parts = parts;
       D.part_groups = (int32_t)((G + parts - 1) / parts);
@@ -1079,6 +1098,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
   while ((1 << D.replica_shift) < D.replicas) D.replica_shift++;
   if (D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE) P.lds_bytes += (size_t)G * D.replicas * D.n_ops * 8;
   if (D.agg_mode == PG_AGG_LDS_PART) P.lds_bytes += (size_t)D.part_groups * D.n_ops * 8;
+  if (D.agg_mode == PG_AGG_RADIX) P.lds_bytes += ((size_t)D.n_ops << D.radix_shift) * 8;
   // auxiliary regions (HBM): sizes per op, patched into the plan at execution
   for (int x = 0; x < D.n_aux; x++) {
     size_t bytes = D.aux[x].kind == PG_AUX_DICT_SET ? (size_t)G * D.aux[x].stride * 4 : (size_t)G * D.aux[x].stride;
@@ -1110,7 +1130,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
     }
   }
   // fast aggregation: LDS table, slots fit 16 bits, <= 8-bit group columns, 32-bit value sources
-  P.fast_agg = D.agg_mode != PG_AGG_GLOBAL && D.agg_mode != PG_AGG_LDS_PART && (int64_t)G * D.replicas <= 65536;   // (trivially true without a table)
+  P.fast_agg = D.agg_mode != PG_AGG_GLOBAL && D.agg_mode != PG_AGG_LDS_PART && D.agg_mode != PG_AGG_RADIX && (int64_t)G * D.replicas <= 65536;   // (trivially true without a table)
   if (D.n_aux > 0) P.fast_agg = false;   // set / HLL accumulators run in the interpreter kernel
   if (P.first_doc_op >= 0) P.fast_agg = false;
   for (Column* c : P.group_cols) if (c->bits > 8) P.fast_agg = false;

@@ -433,4 +433,28 @@ def test_wide_aggregations_match_oracle(wide_seg, q):
     g, o = wide_seg
     gb, ob = g.execute(q), o.execute(q)
     assert_same_block(gb, ob)
-    assert gb.stats.kernel.decode().startswith(("pg_fast_", "pg_generic_"))
+    assert gb.stats.kernel.decode().startswith(("pg_fast_", "pg_generic_", "pg_radix_"))
+
+
+# ---- radix-partitioned group-by (PG_AGG_RADIX): one visit per doc, tuples bucketed by key range, LDS aggregation per bucket ---
+RADIX_QUERIES = [
+    ("SELECT u, COUNT(*) FROM gpuBench GROUP BY u LIMIT 2000000", None),                       # 1 M keys, numGroupsLimit 100 000 bites
+    ("SELECT u, COUNT(*), SUM(h1) FROM gpuBench WHERE h2 IN (1, 2) GROUP BY u LIMIT 2000000", 1_000_000),
+    ("SELECT u, h1, COUNT(*) FROM gpuBench WHERE h2 = 3 AND h3 > 4 GROUP BY u, h1 LIMIT 20000000", 20_000_000),   # 16 M keys
+    ("SELECT h4, u, MAX(h2), MIN(h3), AVG(h1) FROM gpuBench WHERE u < 300000 GROUP BY h4, u LIMIT 100", 50),
+]
+
+
+@pytest.mark.parametrize("q,limit", RADIX_QUERIES)
+def test_radix_group_by_matches_oracle(gpu_api, oracle_api, q, limit):
+    from pinot_amd.query import parse_sql
+    host = synth.generate_segment(260_000, segment_index=4, columns=synth.CFG5_COLUMNS, native=False)
+    g, o = both(gpu_api, oracle_api, host)
+    qg, qo = parse_sql(q), parse_sql(q)
+    if limit:
+        qg.num_groups_limit = qo.num_groups_limit = limit
+    gb, ob = g.execute(qg), o.execute(qo)
+    assert_same_block(gb, ob)
+    assert gb.stats.num_groups_limit_reached == ob.stats.num_groups_limit_reached
+    g.destroy()
+    o.destroy()

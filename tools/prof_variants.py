@@ -55,6 +55,8 @@ QUERIES5 = {
     "hll(u) where h2<5": ("SELECT DISTINCTCOUNTHLL(u) FROM t WHERE h2 < 5", 3.0),
     "distinctcount(u) where h2<5": ("SELECT DISTINCTCOUNT(u) FROM t WHERE h2 < 5", 3.0),
     "hll(u) group h1,h2 (160)": ("SELECT h1, h2, DISTINCTCOUNTHLL(u), COUNT(*) FROM t GROUP BY h1, h2", 3.5),
+    "count group u (1M groups)": ("SELECT u, COUNT(*) FROM t GROUP BY u LIMIT 2000000", 2.5),
+    "count group u,h1 (16M groups)": ("SELECT u, h1, COUNT(*) FROM t WHERE h2 = 3 GROUP BY u, h1 LIMIT 20000000", 3.5),
     "cfg5 count group h1..h3": ("SELECT h1, h2, h3, COUNT(*) FROM t GROUP BY h1, h2, h3 LIMIT 20000", 1.5),
 }
 QUERIES_GENERAL = {   # shapes outside the specialised kernels: several scans, OR of scans, tables beyond LDS
@@ -64,6 +66,8 @@ QUERIES_GENERAL = {   # shapes outside the specialised kernels: several scans, O
     "dict scan + raw scan": ("SELECT COUNT(*) FROM t WHERE g1 < 50 AND r_int < 500000", 4.875),
     "group g1,g2,c_inv1 (40k groups)": ("SELECT g1, g2, c_inv1, COUNT(*), SUM(m) FROM t GROUP BY g1, g2, c_inv1 LIMIT 100000", 6.0),
     "filtered 40k groups": ("SELECT g1, g2, c_inv1, SUM(m) FROM t WHERE r_int < 125000 GROUP BY g1, g2, c_inv1 LIMIT 100000", 10.0),
+    "group g1,g2,c_inv1,c_inv2 (160k)": ("SELECT g1, g2, c_inv1, c_inv2, COUNT(*), SUM(m), MAX(m) FROM t GROUP BY g1, g2, c_inv1, c_inv2 LIMIT 200000", 6.25),
+    "cfg3 filter, 160k groups": ("SELECT g1, g2, c_inv1, c_inv2, SUM(m) FROM t WHERE c_inv1 IN (0,1,2,3) AND c_inv2 IN (0,1) AND r_int BETWEEN 250000 AND 749999 GROUP BY g1, g2, c_inv1, c_inv2 LIMIT 200000", 11.0),
     "avg/min/max/count no group": ("SELECT COUNT(*), AVG(m), MIN(r_int), MAX(m) FROM t WHERE c_inv2 = 1", 8.125),
 }
 QUERIES_WIDE = {   # LDS-table aggregations over 64-bit sources / an 11-bit group column
