@@ -215,9 +215,8 @@ struct PgQueryPlan {
   const uint32_t* match_words;      // filter result, one dword per 32 docs, whole wave tiles
   uint32_t* radix_hist;             // [grid][radix_buckets] tuple counts, then exact offsets (bucket major)
   uint32_t* radix_bucket_start;     // [radix_buckets + 1]
-  uint32_t* radix_keys;             // [matched] local keys
-  uint32_t* radix_docids;           // [matched] docIds, only when the plan carries the MIN(docId) accumulator (numGroupsLimit)
-  int64_t* radix_vals[PG_MAX_RADIX_SRCS];   // [matched] per source: int64 values / double bits
+  uint8_t* radix_tuples;            // [matched] x radix_stride bytes: {u32 local key, u32 docId, 8 bytes per source (int64 / double bits)}
+  int64_t radix_stride;             // 8 without sources, else 8 + 8 * n_srcs rounded up to 16
   int32_t n_lin_prefix;             // interpreter kernels: instrs[0, n_lin_prefix) is index-only and leaves one stack entry
   int32_t n_fast_scans;             // pg_fast_multi_*: instrs[n_index_instr, n_index_instr + n_fast_scans) are scan leaves ANDed in order
   int32_t n_parts;                  // PG_AGG_LDS_PART: key ranges (the grid is 8 x a multiple of it)

@@ -123,7 +123,7 @@ struct ThreadCtx {
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   DeviceBuffer stats, partials, final_table, tile_counts, aux;
-  DeviceBuffer words, radix_hist, radix_start, radix_keys, radix_docids, radix_vals[PG_MAX_RADIX_SRCS];   // PG_AGG_RADIX work areas
+  DeviceBuffer words, radix_hist, radix_start, radix_tuples;   // PG_AGG_RADIX work areas
   bool stats_dirty = true;      // the stats counters may be non-zero (first use, or a query that failed midway)
   void* pinned = nullptr;       // page-locked staging for the result copy (pageable copies are staged synchronously)
   size_t pinned_size = 0;
@@ -327,18 +327,12 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
     const int rgrid = std::max(1, std::min((D.n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, g_num_cus));
     ThreadCtx::grow(ctx.radix_hist, (size_t)rgrid * D.radix_buckets * 4);
     ThreadCtx::grow(ctx.radix_start, ((size_t)D.radix_buckets + 1) * 8);
-    ThreadCtx::grow(ctx.radix_keys, (size_t)P.space_docs * 4 + 256);
-    for (int si = 0; si < D.n_srcs; si++) ThreadCtx::grow(ctx.radix_vals[si], (size_t)P.space_docs * 8 + 256);
+    D.radix_stride = D.n_srcs == 0 ? 8 : ((8 + 8 * (int64_t)D.n_srcs + 15) & ~(int64_t)15);
+    ThreadCtx::grow(ctx.radix_tuples, (size_t)P.space_docs * (size_t)D.radix_stride + 256);
     D.match_words = ctx.words.as<uint32_t>();
     D.radix_hist = ctx.radix_hist.as<uint32_t>();
     D.radix_bucket_start = ctx.radix_start.as<uint32_t>();
-    D.radix_keys = ctx.radix_keys.as<uint32_t>();
-    D.radix_docids = nullptr;
-    if (P.first_doc_op >= 0) {
-      ThreadCtx::grow(ctx.radix_docids, (size_t)P.space_docs * 4 + 256);
-      D.radix_docids = ctx.radix_docids.as<uint32_t>();
-    }
-    for (int si = 0; si < D.n_srcs; si++) D.radix_vals[si] = ctx.radix_vals[si].as<int64_t>();
+    D.radix_tuples = ctx.radix_tuples.as<uint8_t>();
     D.radix_slices = std::max(1, g_num_cus / D.radix_buckets);
     const size_t slots = (size_t)1 << D.radix_shift;
     ThreadCtx::grow(ctx.partials, (size_t)D.radix_buckets * D.radix_slices * D.n_ops * slots * 8 + 8);

@@ -1493,14 +1493,64 @@ DEVFN void radix_keys_of(const PgQueryPlan& p, const uint32_t (&qi)[B], int wtil
   }
 }
 
+// values of one source for the 4 docs of B quads, as the int64 the accumulators take (INT / LONG sign-extended, FLOAT / DOUBLE as
+// the bits of the double) — raw 32/64-bit columns and dictionary-encoded ones
+template <int B>
+DEVFN void radix_source_values(const PgValueSrc& S, const uint32_t (&qi)[B], int wt, int64_t (&out)[B][4]) {
+  if (S.col_kind == PG_COL_RAW32) {
+    const GAS uint8_t* tb = gptr<uint8_t>(S.data + (size_t)wt * (PG_WAVE_DOCS * 4));
+    u32x4 v[B];
+#pragma unroll
+    for (int u = 0; u < B; u++) v[u] = ldnt((const GAS u32x4*)(tb + qi[u] * 16u));
+#pragma unroll
+    for (int u = 0; u < B; u++) {
+      const uint32_t x[4] = {bswap32(v[u].x), bswap32(v[u].y), bswap32(v[u].z), bswap32(v[u].w)};
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        out[u][i] = S.val_type == PG_V_I32 ? (int64_t)(int32_t)x[i] : __double_as_longlong((double)__uint_as_float(x[i]));
+    }
+  } else if (S.col_kind == PG_COL_RAW64) {
+    const GAS uint8_t* tb = gptr<uint8_t>(S.data + (size_t)wt * (PG_WAVE_DOCS * 8));
+    u32x4 a[B], b[B];
+#pragma unroll
+    for (int u = 0; u < B; u++) {
+      const GAS u32x4* pp = (const GAS u32x4*)(tb + qi[u] * 32u);
+      a[u] = ldnt(pp);
+      b[u] = ldnt(pp + 1);
+    }
+#pragma unroll
+    for (int u = 0; u < B; u++) {
+      out[u][0] = (int64_t)(((uint64_t)bswap32(a[u].x) << 32) | bswap32(a[u].y)); out[u][1] = (int64_t)(((uint64_t)bswap32(a[u].z) << 32) | bswap32(a[u].w));
+      out[u][2] = (int64_t)(((uint64_t)bswap32(b[u].x) << 32) | bswap32(b[u].y)); out[u][3] = (int64_t)(((uint64_t)bswap32(b[u].z) << 32) | bswap32(b[u].w));
+    }
+  } else {   // dictionary-encoded: dictIds → values (every dictId read is a valid one: idle lanes re-read quad 0 of the tile)
+    const GAS uint32_t* tw = packed_wtile_base(S.data, wt, S.bits);
+    const uint32_t bits = (uint32_t)S.bits, mask = (1u << S.bits) - 1u;
+#pragma unroll
+    for (int u = 0; u < B; u++) {
+      uint32_t r[8], d[4];
+      if (bits <= 8) { load_packed_quad<true>(tw, qi[u], bits, r); decode_packed_quad<true>(r, qi[u], bits, mask, d); }
+      else { load_packed_quad<false>(tw, qi[u], bits, r); decode_packed_quad<false>(r, qi[u], bits, mask, d); }
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        if (S.val_type == PG_V_I32) out[u][i] = (int64_t)(int32_t)gptr<uint32_t>(S.dict)[d[i]];
+        else if (S.val_type == PG_V_F32) out[u][i] = __double_as_longlong((double)__uint_as_float(gptr<uint32_t>(S.dict)[d[i]]));
+        else out[u][i] = (int64_t)gptr<uint64_t>(S.dict)[d[i]];
+      }
+    }
+  }
+}
+
 // PASS 1: count the matching docs per bucket → radix_hist[workgroup][bucket].
 // PASS 2: radix_hist holds exact offsets; every matching doc claims the next slot of its (workgroup, bucket) range with an LDS
-//         counter and writes its local key and the values of every source there.
+//         counter and writes its tuple there.  Tuples are arrays of structs — {local key, docId} then 8 bytes per source, the
+//         stride a multiple of 16 — so that a tuple goes out in 16-byte stores: with tens of buckets every lane of a store hits
+//         its own cache line, and the number of store instructions is what the pass costs (one 16 B store for key + one value).
 template <int PASS>
 __device__ __forceinline__ void radix_pass_body(const PgQueryPlan& p) {
   __shared__ uint32_t s_cnt[PG_MAX_RADIX_BUCKETS];
   __shared__ uint32_t s_base[PASS == 2 ? PG_MAX_RADIX_BUCKETS : 1];
-  constexpr int B = 4;
+  constexpr int B = PASS == 1 ? 4 : 2;
   const int t = threadIdx.x, lane = t & 63, wave = uniform(t >> 6);
   const int P = p.radix_buckets;
   for (int i = t; i < P; i += PG_BLOCK) {
@@ -1509,6 +1559,7 @@ __device__ __forceinline__ void radix_pass_body(const PgQueryPlan& p) {
   }
   __syncthreads();
   const uint32_t local_mask = (1u << p.radix_shift) - 1u;
+  const uint32_t stride = (uint32_t)p.radix_stride;
   const int wstride = (int)gridDim.x * PG_WAVES_PER_BLOCK;
   for (int wt = (int)blockIdx.x * PG_WAVES_PER_BLOCK + wave; wt < p.n_wtiles; wt += wstride) {
     const int64_t rem = (int64_t)p.num_docs - (int64_t)wt * PG_WAVE_DOCS;
@@ -1518,7 +1569,7 @@ __device__ __forceinline__ void radix_pass_body(const PgQueryPlan& p) {
     const uint32_t m = lin_to_quad(mlin, lane);
 #pragma unroll
     for (int k0 = 0; k0 < 8; k0 += B) {
-      const uint32_t mb = (m >> (4 * k0)) & 0xFFFFu;
+      const uint32_t mb = (m >> (4 * k0)) & ((1u << (4 * B)) - 1u);
       if (__ballot(mb != 0) == 0) continue;
       uint32_t qi[B];
 #pragma unroll
@@ -1532,71 +1583,41 @@ __device__ __forceinline__ void radix_pass_body(const PgQueryPlan& p) {
           for (int i = 0; i < 4; i++)
             if ((mb >> (4 * u + i)) & 1u) atomicAdd(&s_cnt[key[u][i] >> p.radix_shift], 1u);
       } else {
-        uint32_t pos[B][4];
+        uint8_t* tp[B][4];
+        int64_t v0[B][4];
+        if (p.n_srcs > 0) radix_source_values<B>(p.srcs[0], qi, wt, v0);
 #pragma unroll
         for (int u = 0; u < B; u++)
 #pragma unroll
           for (int i = 0; i < 4; i++) {
-            pos[u][i] = 0;
+            tp[u][i] = nullptr;
             if ((mb >> (4 * u + i)) & 1u) {
               const uint32_t b = key[u][i] >> p.radix_shift;
-              pos[u][i] = s_base[b] + atomicAdd(&s_cnt[b], 1u);
-              p.radix_keys[pos[u][i]] = key[u][i] & local_mask;
-              if (p.radix_docids) p.radix_docids[pos[u][i]] = (uint32_t)wt * PG_WAVE_DOCS + 4u * (uint32_t)((k0 + u) * 64 + lane) + (uint32_t)i;
+              tp[u][i] = p.radix_tuples + (size_t)(s_base[b] + atomicAdd(&s_cnt[b], 1u)) * stride;
+              const uint32_t docid = (uint32_t)wt * PG_WAVE_DOCS + 4u * (uint32_t)((k0 + u) * 64 + lane) + (uint32_t)i;
+              if (p.n_srcs > 0) {
+                u32x4 w4 = {key[u][i] & local_mask, docid, (uint32_t)(uint64_t)v0[u][i], (uint32_t)((uint64_t)v0[u][i] >> 32)};
+                *reinterpret_cast<u32x4*>(tp[u][i]) = w4;
+              } else {
+                u32x2 w2 = {key[u][i] & local_mask, docid};
+                *reinterpret_cast<u32x2*>(tp[u][i]) = w2;
+              }
             }
           }
-        for (int si = 0; si < p.n_srcs; si++) {
-          const PgValueSrc& S = p.srcs[si];
-          int64_t* out = p.radix_vals[si];
-          if (S.col_kind == PG_COL_RAW32) {
-            const GAS uint8_t* tb = gptr<uint8_t>(S.data + (size_t)wt * (PG_WAVE_DOCS * 4));
-            u32x4 v[B];
+        for (int si = 1; si < p.n_srcs; si += 2) {   // further sources, two per 16-byte store
+          int64_t va[B][4], vb[B][4];
+          radix_source_values<B>(p.srcs[si], qi, wt, va);
+          const bool two = si + 1 < p.n_srcs;
+          if (two) radix_source_values<B>(p.srcs[si + 1], qi, wt, vb);
 #pragma unroll
-            for (int u = 0; u < B; u++) v[u] = ldnt((const GAS u32x4*)(tb + qi[u] * 16u));
+          for (int u = 0; u < B; u++)
 #pragma unroll
-            for (int u = 0; u < B; u++) {
-              const uint32_t x[4] = {bswap32(v[u].x), bswap32(v[u].y), bswap32(v[u].z), bswap32(v[u].w)};
-#pragma unroll
-              for (int i = 0; i < 4; i++)
-                if ((mb >> (4 * u + i)) & 1u)
-                  out[pos[u][i]] = S.val_type == PG_V_I32 ? (int64_t)(int32_t)x[i] : __double_as_longlong((double)__uint_as_float(x[i]));
-            }
-          } else if (S.col_kind == PG_COL_RAW64) {
-            const GAS uint8_t* tb = gptr<uint8_t>(S.data + (size_t)wt * (PG_WAVE_DOCS * 8));
-            u32x4 a[B], b[B];
-#pragma unroll
-            for (int u = 0; u < B; u++) {
-              const GAS u32x4* pp = (const GAS u32x4*)(tb + qi[u] * 32u);
-              a[u] = ldnt(pp);
-              b[u] = ldnt(pp + 1);
-            }
-#pragma unroll
-            for (int u = 0; u < B; u++) {
-              const uint64_t x[4] = {((uint64_t)bswap32(a[u].x) << 32) | bswap32(a[u].y), ((uint64_t)bswap32(a[u].z) << 32) | bswap32(a[u].w),
-                                     ((uint64_t)bswap32(b[u].x) << 32) | bswap32(b[u].y), ((uint64_t)bswap32(b[u].z) << 32) | bswap32(b[u].w)};
-#pragma unroll
-              for (int i = 0; i < 4; i++)
-                if ((mb >> (4 * u + i)) & 1u) out[pos[u][i]] = (int64_t)x[i];   // LONG as is, DOUBLE as its bits
-            }
-          } else {   // dictionary-encoded source: dictIds → values
-            const GAS uint32_t* tw = packed_wtile_base(S.data, wt, S.bits);
-            const uint32_t bits = (uint32_t)S.bits, mask = (1u << S.bits) - 1u;
-#pragma unroll
-            for (int u = 0; u < B; u++) {
-              uint32_t r[8], d[4];
-              if (bits <= 8) { load_packed_quad<true>(tw, qi[u], bits, r); decode_packed_quad<true>(r, qi[u], bits, mask, d); }
-              else { load_packed_quad<false>(tw, qi[u], bits, r); decode_packed_quad<false>(r, qi[u], bits, mask, d); }
-#pragma unroll
-              for (int i = 0; i < 4; i++)
-                if ((mb >> (4 * u + i)) & 1u) {
-                  int64_t v;
-                  if (S.val_type == PG_V_I32) v = (int64_t)(int32_t)gptr<uint32_t>(S.dict)[d[i]];
-                  else if (S.val_type == PG_V_F32) v = __double_as_longlong((double)__uint_as_float(gptr<uint32_t>(S.dict)[d[i]]));
-                  else v = (int64_t)gptr<uint64_t>(S.dict)[d[i]];
-                  out[pos[u][i]] = v;
-                }
-            }
-          }
+            for (int i = 0; i < 4; i++)
+              if ((mb >> (4 * u + i)) & 1u) {
+                u32x4 w4 = {(uint32_t)(uint64_t)va[u][i], (uint32_t)((uint64_t)va[u][i] >> 32), 0u, 0u};
+                if (two) { w4.z = (uint32_t)(uint64_t)vb[u][i]; w4.w = (uint32_t)((uint64_t)vb[u][i] >> 32); }
+                *reinterpret_cast<u32x4*>(tp[u][i] + 8 + 8 * si) = w4;
+              }
         }
       }
     }
@@ -1686,14 +1707,19 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_aggregate_kernel
     const uint32_t lo = start + (uint32_t)sl * per;
     const uint32_t hi = lo + per < start + total ? lo + per : start + total;
     constexpr int U = 4;   // tuples per thread in flight: the loop is a chain of dependent loads otherwise
+    const uint32_t stride = (uint32_t)p.radix_stride;
     for (uint32_t i0 = lo; i0 < hi; i0 += PG_BLOCK * U) {
-      uint32_t k[U];
+      uint32_t k[U], docid[U];
+      const GAS uint8_t* tp[U];
       bool on[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const uint32_t i = i0 + (uint32_t)u * PG_BLOCK + (uint32_t)t;
         on[u] = i < hi;
-        k[u] = gptr<uint32_t>(p.radix_keys)[on[u] ? i : lo];
+        tp[u] = gptr<uint8_t>(p.radix_tuples + (size_t)(on[u] ? i : lo) * stride);
+        const u32x2 h = *(const GAS u32x2*)tp[u];
+        k[u] = h.x;
+        docid[u] = h.y;
       }
       for (int o = 0; o < p.n_ops; o++) {
         const PgAccOp op = p.ops[o];
@@ -1704,14 +1730,13 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_aggregate_kernel
             for (int u = 0; u < U; u++) if (on[u]) atomicAdd(reinterpret_cast<unsigned long long*>(base + k[u]), 1ULL);
           } else {   // MIN(docId): which groups numGroupsLimit admits
 #pragma unroll
-            for (int u = 0; u < U; u++)
-              if (on[u]) atomicMin(reinterpret_cast<long long*>(base + k[u]), (long long)gptr<uint32_t>(p.radix_docids)[i0 + (uint32_t)u * PG_BLOCK + (uint32_t)t]);
+            for (int u = 0; u < U; u++) if (on[u]) atomicMin(reinterpret_cast<long long*>(base + k[u]), (long long)docid[u]);
           }
           continue;
         }
         int64_t v[U];
 #pragma unroll
-        for (int u = 0; u < U; u++) v[u] = gptr<int64_t>(p.radix_vals[op.src])[on[u] ? i0 + (uint32_t)u * PG_BLOCK + (uint32_t)t : lo];
+        for (int u = 0; u < U; u++) v[u] = *(const GAS int64_t*)(tp[u] + 8 + 8 * op.src);
 #pragma unroll
         for (int u = 0; u < U; u++)
           if (on[u]) {
