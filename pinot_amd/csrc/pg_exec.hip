@@ -324,11 +324,15 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
     const LaunchShape fshape = launch_shape(P, D.n_wtiles, PG_AGG_NONE);
     hipLaunchKernelGGL(select_kernel(P, PG_AGG_NONE, &fname), dim3(fshape.grid), dim3(fshape.block), fshape.lds, ctx.stream, F);
     PG_HIP(hipGetLastError());
+    // the tuple area is sized by the docs that passed the filter, not by the segment (48 B x 2^31 docs would not fit)
+    unsigned long long matched_now = 0;
+    PG_HIP(hipMemcpyAsync(&matched_now, ctx.stats.ptr, 8, hipMemcpyDeviceToHost, ctx.stream));
+    PG_HIP(hipStreamSynchronize(ctx.stream));
     const int rgrid = std::max(1, std::min((D.n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, g_num_cus));
     ThreadCtx::grow(ctx.radix_hist, (size_t)rgrid * D.radix_buckets * 4);
     ThreadCtx::grow(ctx.radix_start, ((size_t)D.radix_buckets + 1) * 8);
     D.radix_stride = D.n_srcs == 0 ? 8 : ((8 + 8 * (int64_t)D.n_srcs + 15) & ~(int64_t)15);
-    ThreadCtx::grow(ctx.radix_tuples, (size_t)P.space_docs * (size_t)D.radix_stride + 256);
+    ThreadCtx::grow(ctx.radix_tuples, (size_t)matched_now * (size_t)D.radix_stride + 256);
     D.match_words = ctx.words.as<uint32_t>();
     D.radix_hist = ctx.radix_hist.as<uint32_t>();
     D.radix_bucket_start = ctx.radix_start.as<uint32_t>();
