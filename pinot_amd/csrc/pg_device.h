@@ -122,7 +122,11 @@ enum PgAggMode : int32_t {
   // Large key spaces, one visit per doc: the docs that pass the filter are radix-partitioned by key range into (local key,
   // values) tuples in HBM — pass 1 counts per (workgroup, bucket), a scan turns the counts into exact offsets, pass 2 scatters —
   // and every bucket (2^radix_shift keys = one LDS table) is then aggregated from its contiguous tuple range with LDS atomics.
-  PG_AGG_RADIX = 5
+  PG_AGG_RADIX = 5,
+  // Key spaces too large for any dense table (Π cardinalities > 64 M: the reference's LongMapBasedHolder territory): the same
+  // radix pipeline on 64-bit raw keys with bucket = hash(key); every bucket is aggregated into an open-addressing hash table in
+  // LDS (keys claimed with ds_cmpst, accumulators updated with LDS atomics) and its occupied slots are appended to the result.
+  PG_AGG_RADIX_HASH = 6
 };
 #define PG_MAX_RADIX_BUCKETS 2048
 #define PG_MAX_RADIX_SRCS 4
@@ -215,8 +219,14 @@ struct PgQueryPlan {
   const uint32_t* match_words;      // filter result, one dword per 32 docs, whole wave tiles
   uint32_t* radix_hist;             // [grid][radix_buckets] tuple counts, then exact offsets (bucket major)
   uint32_t* radix_bucket_start;     // [radix_buckets + 1]
+  int32_t hash_cap;                 // PG_AGG_RADIX_HASH: slots of the per-bucket LDS hash table (power of two)
+  int32_t pad_h;
+  unsigned long long* hash_out_count;   // [0] groups appended, [1] overflow flag (a bucket had more distinct keys than slots)
+  int64_t* hash_out_keys;           // [hash_out_cap] raw keys
+  int64_t* hash_out_acc;            // [n_ops][hash_out_cap]
+  int64_t hash_out_cap;
   uint8_t* radix_tuples;            // [matched] x radix_stride bytes: {u32 local key, u32 docId, 8 bytes per source (int64 / double bits)}
-  int64_t radix_stride;             // 8 without sources, else 8 + 8 * n_srcs rounded up to 16
+  int64_t radix_stride;             // 8 without sources, else 8 + 8 * n_srcs rounded up to 16 (hash: {u64 key, u32 docId, u32 0} + 8 per source)
   int32_t n_lin_prefix;             // interpreter kernels: instrs[0, n_lin_prefix) is index-only and leaves one stack entry
   int32_t n_fast_scans;             // pg_fast_multi_*: instrs[n_index_instr, n_index_instr + n_fast_scans) are scan leaves ANDed in order
   int32_t n_parts;                  // PG_AGG_LDS_PART: key ranges (the grid is 8 x a multiple of it)

@@ -21,6 +21,7 @@ extern "C" __global__ void pg_reduce_partials_kernel(const int64_t* partials, in
 extern "C" __global__ void pg_reduce_parts_kernel(const int64_t* partials, int64_t* out, int n_wg, int n_ops, int n_groups,
                                                    int n_parts, int part_groups, const PgAccOp* ops);
 PG_DECL_FAST(pg_radix_count_kernel) PG_DECL_FAST(pg_radix_scatter_kernel) PG_DECL_FAST(pg_radix_aggregate_kernel)
+PG_DECL_FAST(pg_hash_count_kernel) PG_DECL_FAST(pg_hash_scatter_kernel) PG_DECL_FAST(pg_hash_aggregate_kernel)
 extern "C" __global__ void pg_radix_offsets_kernel(uint32_t* hist, uint32_t* bucket_total, int n_wg, int n_buckets);
 extern "C" __global__ void pg_radix_bucket_scan_kernel(const uint32_t* bucket_total, uint32_t* bucket_start, int n_buckets);
 extern "C" __global__ void pg_radix_reduce_kernel(const int64_t* partials, int64_t* out, int n_ops, int n_groups, int radix_shift, int slices,
@@ -82,7 +83,7 @@ void device_init(int ordinal) {
   // opt in to large dynamic LDS for the query kernels
   typedef void (*QueryKernel)(const PgQueryPlan);
   const QueryKernel all[] = {pg_generic_query_f, pg_generic_query_l, pg_generic_query_g, pg_fast_none_f, pg_fast_none_a, pg_fast_i32range_f, pg_fast_i32range_a,
-                             pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a, pg_fast_multi_f, pg_fast_multi_a, pg_fast_multi_w, pg_fast_none_w, pg_radix_aggregate_kernel};
+                             pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a, pg_fast_multi_f, pg_fast_multi_a, pg_fast_multi_w, pg_fast_none_w, pg_radix_aggregate_kernel, pg_hash_aggregate_kernel};
   for (QueryKernel k : all)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
 }
@@ -123,7 +124,7 @@ struct ThreadCtx {
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   DeviceBuffer stats, partials, final_table, tile_counts, aux;
-  DeviceBuffer words, radix_hist, radix_start, radix_tuples;   // PG_AGG_RADIX work areas
+  DeviceBuffer words, radix_hist, radix_start, radix_tuples, hash_count, hash_keys, hash_acc;   // PG_AGG_RADIX work areas
   bool stats_dirty = true;      // the stats counters may be non-zero (first use, or a query that failed midway)
   void* pinned = nullptr;       // page-locked staging for the result copy (pageable copies are staged synchronously)
   size_t pinned_size = 0;
@@ -311,7 +312,9 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   if (profile) PG_HIP(hipEventRecord(ctx.ev[0], ctx.stream));
   const char* kname = "";
   const bool has_docs = P.space_docs > 0;   // docs of the doc space the plan runs on (the segment's or a star-tree's)
-  const bool radix = D.agg_mode == PG_AGG_RADIX;
+  const bool hashed = D.agg_mode == PG_AGG_RADIX_HASH;
+  const bool radix = D.agg_mode == PG_AGG_RADIX || hashed;
+  int64_t hash_groups = 0;
   if (has_docs && radix) {
     // ---- radix-partitioned group-by: filter → match words; count; offsets; scatter; per-bucket LDS aggregation; merge ---------
     kname = "pg_radix_group_by";
@@ -328,30 +331,56 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
     unsigned long long matched_now = 0;
     PG_HIP(hipMemcpyAsync(&matched_now, ctx.stats.ptr, 8, hipMemcpyDeviceToHost, ctx.stream));
     PG_HIP(hipStreamSynchronize(ctx.stream));
+    if (hashed) {   // buckets sized so that even all-distinct keys half-fill a bucket's table, within [16, 2048]
+      int nb = 16;
+      while (nb < PG_MAX_RADIX_BUCKETS && (unsigned long long)nb * (unsigned long long)(D.hash_cap / 2) < matched_now) nb *= 2;
+      D.radix_buckets = nb;
+    }
     const int rgrid = std::max(1, std::min((D.n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, g_num_cus));
     ThreadCtx::grow(ctx.radix_hist, (size_t)rgrid * D.radix_buckets * 4);
     ThreadCtx::grow(ctx.radix_start, ((size_t)D.radix_buckets + 1) * 8);
-    D.radix_stride = D.n_srcs == 0 ? 8 : ((8 + 8 * (int64_t)D.n_srcs + 15) & ~(int64_t)15);
+    D.radix_stride = hashed ? ((16 + 8 * (int64_t)D.n_srcs + 15) & ~(int64_t)15)
+                            : (D.n_srcs == 0 ? 8 : ((8 + 8 * (int64_t)D.n_srcs + 15) & ~(int64_t)15));
     ThreadCtx::grow(ctx.radix_tuples, (size_t)matched_now * (size_t)D.radix_stride + 256);
     D.match_words = ctx.words.as<uint32_t>();
     D.radix_hist = ctx.radix_hist.as<uint32_t>();
     D.radix_bucket_start = ctx.radix_start.as<uint32_t>();
     D.radix_tuples = ctx.radix_tuples.as<uint8_t>();
-    D.radix_slices = std::max(1, g_num_cus / D.radix_buckets);
-    const size_t slots = (size_t)1 << D.radix_shift;
-    ThreadCtx::grow(ctx.partials, (size_t)D.radix_buckets * D.radix_slices * D.n_ops * slots * 8 + 8);
-    D.partials = ctx.partials.as<int64_t>();
-    hipLaunchKernelGGL(pg_radix_count_kernel, dim3(rgrid), dim3(PG_BLOCK), 0, ctx.stream, D);
     uint32_t* bucket_total = D.radix_bucket_start + D.radix_buckets + 1;   // second half of the same buffer
-    hipLaunchKernelGGL(pg_radix_offsets_kernel, dim3((unsigned)((D.radix_buckets + 15) / 16)), dim3(1024), 0, ctx.stream, D.radix_hist,
-                       bucket_total, rgrid, D.radix_buckets);
-    hipLaunchKernelGGL(pg_radix_bucket_scan_kernel, dim3(1), dim3(64), 0, ctx.stream, bucket_total, D.radix_bucket_start, D.radix_buckets);
-    hipLaunchKernelGGL(pg_radix_scatter_kernel, dim3(rgrid), dim3(PG_BLOCK), 0, ctx.stream, D);
-    const int agrid = std::min(D.radix_buckets * D.radix_slices, g_num_cus);
-    hipLaunchKernelGGL(pg_radix_aggregate_kernel, dim3(agrid), dim3(PG_BLOCK), (size_t)D.n_ops * slots * 8 + 64, ctx.stream, D);
-    hipLaunchKernelGGL(pg_radix_reduce_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, ctx.stream, ctx.partials.as<int64_t>(),
-                       ctx.final_table.as<int64_t>(), D.n_ops, D.n_groups, D.radix_shift, D.radix_slices, P.ops_dev.as<PgAccOp>());
-    PG_HIP(hipGetLastError());
+    if (hashed) {
+      D.hash_out_cap = (int64_t)std::min<unsigned long long>(matched_now, (unsigned long long)D.radix_buckets * (unsigned long long)D.hash_cap) + 1;
+      ThreadCtx::grow(ctx.hash_count, 64);
+      ThreadCtx::grow(ctx.hash_keys, (size_t)D.hash_out_cap * 8);
+      ThreadCtx::grow(ctx.hash_acc, (size_t)D.hash_out_cap * 8 * (size_t)std::max(D.n_ops, 1));
+      PG_HIP(hipMemsetAsync(ctx.hash_count.ptr, 0, 16, ctx.stream));
+      D.hash_out_count = ctx.hash_count.as<unsigned long long>();
+      D.hash_out_keys = ctx.hash_keys.as<int64_t>();
+      D.hash_out_acc = ctx.hash_acc.as<int64_t>();
+      hipLaunchKernelGGL(pg_hash_count_kernel, dim3(rgrid), dim3(PG_BLOCK), 0, ctx.stream, D);
+      hipLaunchKernelGGL(pg_radix_offsets_kernel, dim3((unsigned)((D.radix_buckets + 15) / 16)), dim3(1024), 0, ctx.stream, D.radix_hist,
+                         bucket_total, rgrid, D.radix_buckets);
+      hipLaunchKernelGGL(pg_radix_bucket_scan_kernel, dim3(1), dim3(64), 0, ctx.stream, bucket_total, D.radix_bucket_start, D.radix_buckets);
+      hipLaunchKernelGGL(pg_hash_scatter_kernel, dim3(rgrid), dim3(PG_BLOCK), 0, ctx.stream, D);
+      hipLaunchKernelGGL(pg_hash_aggregate_kernel, dim3(std::min(D.radix_buckets, g_num_cus)), dim3(PG_BLOCK),
+                         (size_t)D.hash_cap * (8 + 8 * (size_t)D.n_ops) + 64, ctx.stream, D);
+      PG_HIP(hipGetLastError());
+      kname = "pg_hash_group_by";
+    } else {
+      D.radix_slices = std::max(1, g_num_cus / D.radix_buckets);
+      const size_t slots = (size_t)1 << D.radix_shift;
+      ThreadCtx::grow(ctx.partials, (size_t)D.radix_buckets * D.radix_slices * D.n_ops * slots * 8 + 8);
+      D.partials = ctx.partials.as<int64_t>();
+      hipLaunchKernelGGL(pg_radix_count_kernel, dim3(rgrid), dim3(PG_BLOCK), 0, ctx.stream, D);
+      hipLaunchKernelGGL(pg_radix_offsets_kernel, dim3((unsigned)((D.radix_buckets + 15) / 16)), dim3(1024), 0, ctx.stream, D.radix_hist,
+                         bucket_total, rgrid, D.radix_buckets);
+      hipLaunchKernelGGL(pg_radix_bucket_scan_kernel, dim3(1), dim3(64), 0, ctx.stream, bucket_total, D.radix_bucket_start, D.radix_buckets);
+      hipLaunchKernelGGL(pg_radix_scatter_kernel, dim3(rgrid), dim3(PG_BLOCK), 0, ctx.stream, D);
+      const int agrid = std::min(D.radix_buckets * D.radix_slices, g_num_cus);
+      hipLaunchKernelGGL(pg_radix_aggregate_kernel, dim3(agrid), dim3(PG_BLOCK), (size_t)D.n_ops * slots * 8 + 64, ctx.stream, D);
+      hipLaunchKernelGGL(pg_radix_reduce_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, ctx.stream, ctx.partials.as<int64_t>(),
+                         ctx.final_table.as<int64_t>(), D.n_ops, D.n_groups, D.radix_shift, D.radix_slices, P.ops_dev.as<PgAccOp>());
+      PG_HIP(hipGetLastError());
+    }
   } else if (has_docs) {
     QueryKernel kern = select_kernel(P, D.agg_mode, &kname);
     hipLaunchKernelGGL(kern, dim3(shape.grid), dim3(shape.block), shape.lds, ctx.stream, D);
@@ -359,6 +388,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   }
   if (profile) PG_HIP(hipEventRecord(ctx.ev[1], ctx.stream));
   std::vector<int64_t> table((size_t)n_out);
+  std::vector<int64_t> hash_keys_host;   // PG_AGG_RADIX_HASH: raw key of every group of the compact table
   uint64_t stats_host[PG_MAX_STATS] = {0};
   if (has_docs) {
     if (P.aux_in_lds)
@@ -386,6 +416,23 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
     if (n_out) memcpy(table.data(), host_out, (size_t)n_out * 8);
     memcpy(stats_host, host_out + n_out, sizeof(stats_host));
     ctx.stats_dirty = false;    // the reduce kernel left them zero
+    if (hashed) {
+      // the occupied slots of every bucket's hash table: raw keys + [n_ops][groups] accumulators → a compact table
+      unsigned long long cnt[2] = {0, 0};
+      PG_HIP(hipMemcpyAsync(cnt, ctx.hash_count.ptr, 16, hipMemcpyDeviceToHost, ctx.stream));
+      PG_HIP(hipStreamSynchronize(ctx.stream));
+      if (cnt[1]) fail(PG_ERR_UNSUPPORTED, "more distinct group keys in one hash bucket than its LDS table holds (%d slots, %d buckets)", D.hash_cap, D.radix_buckets);
+      hash_groups = (int64_t)cnt[0];
+      hash_keys_host.resize((size_t)hash_groups);
+      table.assign((size_t)hash_groups * (size_t)D.n_ops, 0);
+      if (hash_groups) {
+        PG_HIP(hipMemcpyAsync(hash_keys_host.data(), ctx.hash_keys.ptr, (size_t)hash_groups * 8, hipMemcpyDeviceToHost, ctx.stream));
+        for (int o = 0; o < D.n_ops; o++)
+          PG_HIP(hipMemcpyAsync(table.data() + (size_t)o * (size_t)hash_groups, ctx.hash_acc.as<int64_t>() + (size_t)o * (size_t)D.hash_out_cap,
+                                (size_t)hash_groups * 8, hipMemcpyDeviceToHost, ctx.stream));
+        PG_HIP(hipStreamSynchronize(ctx.stream));
+      }
+    }
   } else {
     if (profile) PG_HIP(hipEventRecord(ctx.ev[2], ctx.stream));
     PG_HIP(hipStreamSynchronize(ctx.stream));
@@ -409,7 +456,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   }
 
   // ---- assemble groups: a group exists iff its hidden COUNT is > 0 (ArrayBasedHolder flags / map entries) ----------------
-  const int64_t G = D.n_groups;
+  const int64_t G = hashed ? hash_groups : D.n_groups;   // hashed key space: the compact table of the groups found
   const int64_t matched = (int64_t)stats_host[0];
   const bool ex_stats = P.exist_op == kCountFromStats;
   const int64_t* ex = ex_stats ? nullptr : table.data() + (size_t)P.exist_op * G;
@@ -418,6 +465,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   auto count_of = [&](int32_t op, int64_t g) { return op == kCountFromStats ? matched : table[(size_t)op * G + g]; };
   std::vector<int64_t> gids;
   if (q.n_group_by == 0) gids.push_back(0);
+  else if (hashed) { gids.resize((size_t)G); for (int64_t g = 0; g < G; g++) gids[(size_t)g] = g; }
   else for (int64_t g = 0; g < G; g++) if (exists(g)) gids.push_back(g);
   bool limit_reached = q.n_group_by > 0 && (int64_t)gids.size() >= (int64_t)P.num_groups_limit;
   if (q.n_group_by > 0 && (int64_t)gids.size() > (int64_t)P.num_groups_limit) {
@@ -436,7 +484,10 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
     v.resize((size_t)ng);
     int64_t mult = D.gcols[j].mult;
     int32_t card = P.group_cards[j];
-    for (int32_t i = 0; i < ng; i++) v[i] = (int32_t)((gids[i] / mult) % card);   // getKeys: col 0 least significant
+    for (int32_t i = 0; i < ng; i++) {   // getKeys: col 0 least significant
+      const int64_t raw = hashed ? hash_keys_host[(size_t)gids[i]] : gids[i];
+      v[i] = (int32_t)((raw / mult) % card);
+    }
   }
   if (q.n_group_by > 0) res->stats.num_groups_limit_reached = limit_reached ? 1 : 0;
 

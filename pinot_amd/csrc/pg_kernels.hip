@@ -1493,6 +1493,34 @@ DEVFN void radix_keys_of(const PgQueryPlan& p, const uint32_t (&qi)[B], int wtil
   }
 }
 
+// 64-bit raw keys (PG_AGG_RADIX_HASH): Σ dictId_j · mult_j in int64
+template <int B>
+DEVFN void radix_keys_of64(const PgQueryPlan& p, const uint32_t (&qi)[B], int wtile, uint64_t (&key)[B][4]) {
+#pragma unroll
+  for (int u = 0; u < B; u++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) key[u][i] = 0;
+  for (int g = 0; g < p.n_group_cols; g++) {
+    const PgGroupCol& gc = p.gcols[g];
+    const GAS uint32_t* tw = packed_wtile_base(gc.data, wtile, gc.bits);
+    const uint32_t bits = (uint32_t)gc.bits, mask = (1u << gc.bits) - 1u;
+    const uint64_t mult = (uint64_t)gc.mult;
+#pragma unroll
+    for (int u = 0; u < B; u++) {
+      uint32_t r[8], d[4];
+      if (bits <= 8) { load_packed_quad<true>(tw, qi[u], bits, r); decode_packed_quad<true>(r, qi[u], bits, mask, d); }
+      else { load_packed_quad<false>(tw, qi[u], bits, r); decode_packed_quad<false>(r, qi[u], bits, mask, d); }
+#pragma unroll
+      for (int i = 0; i < 4; i++) key[u][i] += (uint64_t)d[i] * mult;
+    }
+  }
+}
+DEVFN uint64_t radix_mix64(uint64_t x) {   // splitmix64 finaliser: bucket = low bits, LDS slot = bits 16..
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL;
+  x ^= x >> 27; x *= 0x94D049BB133111EBULL;
+  return x ^ (x >> 31);
+}
+
 // values of one source for the 4 docs of B quads, as the int64 the accumulators take (INT / LONG sign-extended, FLOAT / DOUBLE as
 // the bits of the double) — raw 32/64-bit columns and dictionary-encoded ones
 template <int B>
@@ -1546,11 +1574,11 @@ DEVFN void radix_source_values(const PgValueSrc& S, const uint32_t (&qi)[B], int
 //         counter and writes its tuple there.  Tuples are arrays of structs — {local key, docId} then 8 bytes per source, the
 //         stride a multiple of 16 — so that a tuple goes out in 16-byte stores: with tens of buckets every lane of a store hits
 //         its own cache line, and the number of store instructions is what the pass costs (one 16 B store for key + one value).
-template <int PASS>
+template <int PASS, bool HASH>
 __device__ __forceinline__ void radix_pass_body(const PgQueryPlan& p) {
   __shared__ uint32_t s_cnt[PG_MAX_RADIX_BUCKETS];
   __shared__ uint32_t s_base[PASS == 2 ? PG_MAX_RADIX_BUCKETS : 1];
-  constexpr int B = PASS == 1 ? 4 : 2;
+  constexpr int B = PASS == 1 ? (HASH ? 2 : 4) : 2;
   const int t = threadIdx.x, lane = t & 63, wave = uniform(t >> 6);
   const int P = p.radix_buckets;
   for (int i = t; i < P; i += PG_BLOCK) {
@@ -1574,6 +1602,49 @@ __device__ __forceinline__ void radix_pass_body(const PgQueryPlan& p) {
       uint32_t qi[B];
 #pragma unroll
       for (int u = 0; u < B; u++) qi[u] = ((mb >> (4 * u)) & 0xFu) ? (uint32_t)((k0 + u) * 64 + lane) : 0u;
+      if (HASH) {
+        uint64_t key64[B][4];
+        radix_keys_of64<B>(p, qi, wt, key64);
+        const uint32_t bmask = (uint32_t)p.radix_buckets - 1u;
+        if (PASS == 1) {
+#pragma unroll
+          for (int u = 0; u < B; u++)
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+              if ((mb >> (4 * u + i)) & 1u) atomicAdd(&s_cnt[(uint32_t)radix_mix64(key64[u][i]) & bmask], 1u);
+        } else {
+          uint8_t* tp[B][4];
+#pragma unroll
+          for (int u = 0; u < B; u++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+              tp[u][i] = nullptr;
+              if ((mb >> (4 * u + i)) & 1u) {
+                const uint32_t b = (uint32_t)radix_mix64(key64[u][i]) & bmask;
+                tp[u][i] = p.radix_tuples + (size_t)(s_base[b] + atomicAdd(&s_cnt[b], 1u)) * stride;
+                const uint32_t docid = (uint32_t)wt * PG_WAVE_DOCS + 4u * (uint32_t)((k0 + u) * 64 + lane) + (uint32_t)i;
+                u32x4 w4 = {(uint32_t)key64[u][i], (uint32_t)(key64[u][i] >> 32), docid, 0u};
+                *reinterpret_cast<u32x4*>(tp[u][i]) = w4;
+              }
+            }
+          for (int si = 0; si < p.n_srcs; si += 2) {   // sources, two per 16-byte store, behind the 16-byte header
+            int64_t va[B][4], vb[B][4];
+            radix_source_values<B>(p.srcs[si], qi, wt, va);
+            const bool two = si + 1 < p.n_srcs;
+            if (two) radix_source_values<B>(p.srcs[si + 1], qi, wt, vb);
+#pragma unroll
+            for (int u = 0; u < B; u++)
+#pragma unroll
+              for (int i = 0; i < 4; i++)
+                if ((mb >> (4 * u + i)) & 1u) {
+                  u32x4 w4 = {(uint32_t)(uint64_t)va[u][i], (uint32_t)((uint64_t)va[u][i] >> 32), 0u, 0u};
+                  if (two) { w4.z = (uint32_t)(uint64_t)vb[u][i]; w4.w = (uint32_t)((uint64_t)vb[u][i] >> 32); }
+                  *reinterpret_cast<u32x4*>(tp[u][i] + 16 + 8 * si) = w4;
+                }
+          }
+        }
+        continue;
+      }
       uint32_t key[B][4];
       radix_keys_of<B>(p, qi, wt, key);
       if (PASS == 1) {
@@ -1627,8 +1698,79 @@ __device__ __forceinline__ void radix_pass_body(const PgQueryPlan& p) {
     for (int i = t; i < P; i += PG_BLOCK) p.radix_hist[(int64_t)blockIdx.x * P + i] = s_cnt[i];
   }
 }
-extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_count_kernel(const PgQueryPlan p) { radix_pass_body<1>(p); }
-extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_scatter_kernel(const PgQueryPlan p) { radix_pass_body<2>(p); }
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_count_kernel(const PgQueryPlan p) { radix_pass_body<1, false>(p); }
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_scatter_kernel(const PgQueryPlan p) { radix_pass_body<2, false>(p); }
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_hash_count_kernel(const PgQueryPlan p) { radix_pass_body<1, true>(p); }
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_hash_scatter_kernel(const PgQueryPlan p) { radix_pass_body<2, true>(p); }
+
+// Per-bucket hash aggregation: the bucket's tuples go into an open-addressing table in LDS — keys[cap] claimed with a 64-bit
+// compare-and-swap (linear probing), accumulators [n_ops][cap] updated with LDS atomics — whose occupied slots are then appended
+// to the result (one global atomic per wavefront).  A bucket with more distinct keys than slots raises the overflow flag.
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_hash_aggregate_kernel(const PgQueryPlan p) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const uint32_t cap = (uint32_t)p.hash_cap, cmask = cap - 1u;
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
+  int64_t* table = reinterpret_cast<int64_t*>(smem) + cap;
+  const uint32_t stride = (uint32_t)p.radix_stride;
+  const unsigned long long kEmpty = ~0ULL;
+  for (int b = (int)blockIdx.x; b < p.radix_buckets; b += (int)gridDim.x) {
+    for (uint32_t i = t; i < cap; i += PG_BLOCK) keys[i] = kEmpty;
+    for (int o = 0; o < p.n_ops; o++) {
+      const int64_t ident = pg_acc_identity(p.ops[o].fn, p.ops[o].is_float);
+      for (uint32_t i = t; i < cap; i += PG_BLOCK) table[(size_t)o * cap + i] = ident;
+    }
+    __syncthreads();
+    const uint32_t lo = p.radix_bucket_start[b], hi = p.radix_bucket_start[b + 1];
+    for (uint32_t i = lo + (uint32_t)t; i < hi; i += PG_BLOCK) {
+      const GAS uint8_t* tp = gptr<uint8_t>(p.radix_tuples + (size_t)i * stride);
+      const u32x4 h = *(const GAS u32x4*)tp;
+      const unsigned long long key = ((unsigned long long)h.y << 32) | h.x;
+      uint32_t slot = (uint32_t)(radix_mix64(key) >> 16) & cmask;
+      bool found = false;
+      for (uint32_t probes = 0; probes < cap; probes++) {
+        unsigned long long cur = __hip_atomic_load(&keys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (cur == kEmpty) cur = atomicCAS(&keys[slot], kEmpty, key);
+        if (cur == kEmpty || cur == key) { found = true; break; }
+        slot = (slot + 1u) & cmask;
+      }
+      if (!found) { p.hash_out_count[1] = 1; continue; }   // table full: more distinct keys than slots
+      for (int o = 0; o < p.n_ops; o++) {
+        const PgAccOp op = p.ops[o];
+        int64_t* acc = table + (size_t)o * cap + slot;
+        if (op.src < 0) {
+          if (op.fn == PG_ACC_COUNT) atomicAdd(reinterpret_cast<unsigned long long*>(acc), 1ULL);
+          else atomicMin(reinterpret_cast<long long*>(acc), (long long)h.z);   // MIN(docId)
+          continue;
+        }
+        const int64_t v = *(const GAS int64_t*)(tp + 16 + 8 * op.src);
+        if (op.is_float) acc_float(acc, op.fn, __longlong_as_double(v));
+        else acc_int(acc, op.fn, v);
+      }
+    }
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < cap; i0 += PG_BLOCK) {   // append the occupied slots
+      const uint32_t i = i0 + (uint32_t)t;
+      const bool occ = i < cap && keys[i] != kEmpty;
+      const unsigned long long ball = __ballot(occ);
+      if (ball) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&p.hash_out_count[0], (unsigned long long)__popcll(ball));
+        base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 0, 64);
+        if (occ) {
+          const unsigned long long pos = base + (unsigned long long)__popcll(ball & ((1ULL << lane) - 1ULL));
+          if ((int64_t)pos < p.hash_out_cap) {
+            p.hash_out_keys[pos] = (int64_t)keys[i];
+            for (int o = 0; o < p.n_ops; o++) p.hash_out_acc[(int64_t)o * p.hash_out_cap + (int64_t)pos] = table[(size_t)o * cap + i];
+          } else {
+            p.hash_out_count[1] = 1;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
 
 // Counts → offsets.  Step 1, one wavefront per bucket: hist[wg][b] becomes the exclusive prefix over the workgroups (lanes own
 // consecutive workgroups), total[b] the bucket's size.  Step 2, one wavefront: bucket_start = exclusive scan of the totals.

@@ -894,6 +894,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
   std::vector<Column*> projected;
   auto project = [&](Column* c) { if (std::find(projected.begin(), projected.end(), c) == projected.end()) projected.push_back(c); };
   int64_t G = 1;
+  bool huge_key_space = false;
   for (int j = 0; j < q->n_group_by; j++) {
     Column* c = seg.find(q->group_by_columns[j]);
     if (!c) fail(PG_ERR_NOT_FOUND, "column not found: %s", q->group_by_columns[j] ? q->group_by_columns[j] : "(null)");
@@ -903,12 +904,15 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
     D.gcols[j].mult = G;
     P.group_cols.push_back(c);
     P.group_cards.push_back(c->cardinality);
-    if (G > kMaxDenseGroups / std::max(c->cardinality, 1)) fail(PG_ERR_UNSUPPORTED, "group key space too large for the dense GPU path");
+    // beyond any dense table (the reference's LongMapBasedHolder, DictionaryBasedGroupKeyGenerator.java:166-176): 64-bit raw
+    // keys, hash-partitioned and aggregated in LDS hash tables (PG_AGG_RADIX_HASH); keys must stay below 2^62
+    if (G > kMaxDenseGroups / std::max(c->cardinality, 1)) huge_key_space = true;
+    if (G > ((int64_t)1 << 62) / std::max(c->cardinality, 1)) fail(PG_ERR_UNSUPPORTED, "group key space beyond 2^62 (ArrayMapBasedHolder) is outside the GPU path");
     G *= c->cardinality;
     project(c);
   }
   D.n_group_cols = q->n_group_by;
-  D.n_groups = (int32_t)G;
+  D.n_groups = huge_key_space ? 0 : (int32_t)G;
 
   std::vector<PgAccOp> ops;
   std::vector<Column*> srcs;
@@ -1046,6 +1050,19 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
   for (Column* c : projected) P.algorithmic_bytes += (int64_t)c->fwd_bytes_logical;
   P.n_projected_columns = (int32_t)projected.size();
 
+  if (huge_key_space) {
+    if (D.n_aux > 0) fail(PG_ERR_UNSUPPORTED, "DISTINCTCOUNT / DISTINCTCOUNTHLL over a group key space beyond 64 M keys");
+    if ((int)srcs.size() > PG_MAX_RADIX_SRCS) fail(PG_ERR_UNSUPPORTED, "more than %d aggregated columns over a hashed key space", PG_MAX_RADIX_SRCS);
+    D.agg_mode = PG_AGG_RADIX_HASH;
+    D.replicas = 1;
+    D.replica_shift = 0;
+    int cap = 1024;   // slots of the per-bucket LDS hash table: 8 B key + 8 B per accumulator
+    while ((int64_t)cap * 2 * (8 + 8 * (int64_t)D.n_ops) <= kLdsTableBudget) cap *= 2;
+    D.hash_cap = cap;
+    P.lds_bytes = (size_t)cap * (8 + 8 * (size_t)D.n_ops);
+    P.fast_agg = false;
+    return plan;
+  }
   const int64_t table_bytes = G * D.n_ops * 8;
   if (D.n_ops == 0 && D.n_aux == 0) {
     D.agg_mode = PG_AGG_NONE;        // COUNT(*) only: nothing to accumulate beyond the match count

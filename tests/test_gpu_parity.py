@@ -458,3 +458,28 @@ def test_radix_group_by_matches_oracle(gpu_api, oracle_api, q, limit):
     assert gb.stats.num_groups_limit_reached == ob.stats.num_groups_limit_reached
     g.destroy()
     o.destroy()
+
+
+# ---- key spaces beyond any dense table (> 64 M keys, the reference's LongMapBasedHolder): hash-partitioned LDS hash tables ------
+HASH_QUERIES = [
+    ("SELECT u, h1, h2, COUNT(*), SUM(h3) FROM gpuBench GROUP BY u, h1, h2 LIMIT 10000000", 10_000_000),     # 160 M keys
+    ("SELECT u, h1, h2, COUNT(*) FROM gpuBench GROUP BY u, h1, h2 LIMIT 10000000", None),                    # default numGroupsLimit trims
+    ("SELECT h2, u, h1, MIN(h3), MAX(h4), AVG(h3) FROM gpuBench WHERE h4 IN (1, 5) AND u >= 500000 GROUP BY h2, u, h1 LIMIT 10000000", 10_000_000),
+    ("SELECT u, h1, h2, h3, SUM(h4) FROM gpuBench WHERE u = 123456 OR u < 50 GROUP BY u, h1, h2, h3 LIMIT 100", 1_000_000),   # 1.6 G keys
+    ("SELECT u, h1, h2, COUNT(*) FROM gpuBench WHERE h1 = 99 GROUP BY u, h1, h2 LIMIT 10", 1000),           # nothing matches
+]
+
+
+@pytest.mark.parametrize("q,limit", HASH_QUERIES)
+def test_hashed_group_by_matches_oracle(gpu_api, oracle_api, q, limit):
+    from pinot_amd.query import parse_sql
+    host = synth.generate_segment(260_000, segment_index=6, columns=synth.CFG5_COLUMNS, native=False)
+    g, o = both(gpu_api, oracle_api, host)
+    qg, qo = parse_sql(q), parse_sql(q)
+    if limit:
+        qg.num_groups_limit = qo.num_groups_limit = limit
+    gb, ob = g.execute(qg), o.execute(qo)
+    assert_same_block(gb, ob)
+    assert gb.stats.num_groups_limit_reached == ob.stats.num_groups_limit_reached
+    g.destroy()
+    o.destroy()
