@@ -1706,8 +1706,11 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_hash_scatter_kernel(co
 // Per-bucket hash aggregation: the bucket's tuples go into an open-addressing table in LDS — keys[cap] claimed with a 64-bit
 // compare-and-swap (linear probing), accumulators [n_ops][cap] updated with LDS atomics — whose occupied slots are then appended
 // to the result (one global atomic per wavefront).  A bucket with more distinct keys than slots raises the overflow flag.
+#define PG_HASH_MAX_ITERS 16   // hash_cap <= 16 384 slots = 16 sweeps of the 1024-thread workgroup
 extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_hash_aggregate_kernel(const PgQueryPlan p) {
   extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
+  __shared__ uint32_t s_local;
+  __shared__ unsigned long long s_gbase;
   const int t = threadIdx.x, lane = t & 63;
   const uint32_t cap = (uint32_t)p.hash_cap, cmask = cap - 1u;
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
@@ -1749,22 +1752,35 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_hash_aggregate_kernel(
       }
     }
     __syncthreads();
-    for (uint32_t i0 = 0; i0 < cap; i0 += PG_BLOCK) {   // append the occupied slots
-      const uint32_t i = i0 + (uint32_t)t;
+    // append the occupied slots: local positions from an LDS counter, ONE global atomic per bucket (a counter shared by every
+    // wavefront of the chip serialises at ~12 ns per atomic: 131 k of them were 1.6 ms)
+    if (t == 0) s_local = 0;
+    __syncthreads();
+    uint32_t my_pos[PG_HASH_MAX_ITERS];
+#pragma unroll
+    for (int it = 0; it < PG_HASH_MAX_ITERS; it++) {
+      const uint32_t i = (uint32_t)it * PG_BLOCK + (uint32_t)t;
       const bool occ = i < cap && keys[i] != kEmpty;
       const unsigned long long ball = __ballot(occ);
-      if (ball) {
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(&p.hash_out_count[0], (unsigned long long)__popcll(ball));
-        base = ((unsigned long long)(uint32_t)__shfl((int)(base >> 32), 0, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)base, 0, 64);
-        if (occ) {
-          const unsigned long long pos = base + (unsigned long long)__popcll(ball & ((1ULL << lane) - 1ULL));
-          if ((int64_t)pos < p.hash_out_cap) {
-            p.hash_out_keys[pos] = (int64_t)keys[i];
-            for (int o = 0; o < p.n_ops; o++) p.hash_out_acc[(int64_t)o * p.hash_out_cap + (int64_t)pos] = table[(size_t)o * cap + i];
-          } else {
-            p.hash_out_count[1] = 1;
-          }
+      uint32_t wbase = 0;
+      if (ball && lane == 0) wbase = atomicAdd(&s_local, (uint32_t)__popcll(ball));
+      wbase = (uint32_t)__shfl((int)wbase, 0, 64);
+      my_pos[it] = occ ? wbase + (uint32_t)__popcll(ball & ((1ULL << lane) - 1ULL)) : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    if (t == 0) s_gbase = atomicAdd(&p.hash_out_count[0], (unsigned long long)s_local);
+    __syncthreads();
+    const unsigned long long gbase = s_gbase;
+#pragma unroll
+    for (int it = 0; it < PG_HASH_MAX_ITERS; it++) {
+      if (my_pos[it] != 0xFFFFFFFFu) {
+        const uint32_t i = (uint32_t)it * PG_BLOCK + (uint32_t)t;
+        const unsigned long long pos = gbase + my_pos[it];
+        if ((int64_t)pos < p.hash_out_cap) {
+          p.hash_out_keys[pos] = (int64_t)keys[i];
+          for (int o = 0; o < p.n_ops; o++) p.hash_out_acc[(int64_t)o * p.hash_out_cap + (int64_t)pos] = table[(size_t)o * cap + i];
+        } else {
+          p.hash_out_count[1] = 1;
         }
       }
     }

@@ -1057,7 +1057,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
     D.replicas = 1;
     D.replica_shift = 0;
     int cap = 1024;   // slots of the per-bucket LDS hash table: 8 B key + 8 B per accumulator
-    while ((int64_t)cap * 2 * (8 + 8 * (int64_t)D.n_ops) <= kLdsTableBudget) cap *= 2;
+    while (cap < 16384 && (int64_t)cap * 2 * (8 + 8 * (int64_t)D.n_ops) <= kLdsTableBudget) cap *= 2;
     D.hash_cap = cap;
     P.lds_bytes = (size_t)cap * (8 + 8 * (size_t)D.n_ops);
     P.fast_agg = false;
