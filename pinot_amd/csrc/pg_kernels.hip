@@ -1569,6 +1569,92 @@ DEVFN void radix_source_values(const PgValueSrc& S, const uint32_t (&qi)[B], int
   }
 }
 
+// one value of a bit-packed column at in-tile doc index `doc` (any width)
+DEVFN uint32_t packed_value_at(const GAS uint32_t* __restrict__ tw, uint32_t doc, uint32_t bits) {
+  const uint32_t bit0 = doc * bits;
+  const u32x2 v = *(const GAS u32x2_a4*)(tw + (bit0 >> 5));
+  const uint64_t win = ((uint64_t)bswap32(v.x) << 32) | (uint64_t)bswap32(v.y);
+  return (uint32_t)(win >> (64u - (bit0 & 31u) - bits)) & ((1u << bits) - 1u);
+}
+DEVFN int64_t source_value_at(const PgValueSrc& S, int wt, uint32_t doc) {
+  if (S.col_kind == PG_COL_RAW32) {
+    const uint32_t x = bswap32(gptr<uint32_t>(S.data + (size_t)wt * (PG_WAVE_DOCS * 4))[doc]);
+    return S.val_type == PG_V_I32 ? (int64_t)(int32_t)x : __double_as_longlong((double)__uint_as_float(x));
+  }
+  if (S.col_kind == PG_COL_RAW64) {
+    const u32x2 v = gptr<u32x2>(S.data + (size_t)wt * (PG_WAVE_DOCS * 8))[doc];
+    return (int64_t)(((uint64_t)bswap32(v.x) << 32) | bswap32(v.y));
+  }
+  const uint32_t d = packed_value_at(packed_wtile_base(S.data, wt, S.bits), doc, (uint32_t)S.bits);
+  if (S.val_type == PG_V_I32) return (int64_t)(int32_t)gptr<uint32_t>(S.dict)[d];
+  if (S.val_type == PG_V_F32) return __double_as_longlong((double)__uint_as_float(gptr<uint32_t>(S.dict)[d]));
+  return (int64_t)gptr<uint64_t>(S.dict)[d];
+}
+
+// Sparse tiles (at most PG_SELVEC_MAX matching docs): the matches are compacted into a per-wavefront list (the linear mask
+// layout gives ascending docIds) and handled 64 per round with every lane busy — one gather per column and doc — instead of
+// decoding all 2 048 positions of the tile twice (count and scatter pass) for a few dozen matches.
+#define PG_SELVEC_MAX 128
+template <int PASS, bool HASH>
+DEVFN void radix_selvec_tile(const PgQueryPlan& p, uint32_t mlin, uint32_t n_match, int wt, uint32_t* __restrict__ s_cnt,
+                             const uint32_t* __restrict__ s_base, uint16_t* __restrict__ list, int lane) {
+  {
+    const uint32_t c = (uint32_t)__popc(mlin);
+    uint32_t x = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t y = (uint32_t)__shfl_up((int)x, off, 64);
+      if (lane >= off) x += y;
+    }
+    uint32_t pos = x - c, mm = mlin;
+    while (__ballot(mm != 0)) {
+      if (mm) {
+        const uint32_t b = (uint32_t)__ffs((int)mm) - 1u;
+        mm &= mm - 1u;
+        list[pos++] = (uint16_t)((uint32_t)lane * 32u + b);
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t local_mask = (1u << p.radix_shift) - 1u, bmask = (uint32_t)p.radix_buckets - 1u, stride = (uint32_t)p.radix_stride;
+  for (uint32_t r0 = 0; r0 < n_match; r0 += 64) {
+    const bool on = r0 + (uint32_t)lane < n_match;
+    const uint32_t doc = on ? (uint32_t)list[r0 + lane] : (uint32_t)list[0];
+    uint64_t key = 0;
+    for (int g = 0; g < p.n_group_cols; g++)
+      key += (uint64_t)packed_value_at(packed_wtile_base(p.gcols[g].data, wt, p.gcols[g].bits), doc, (uint32_t)p.gcols[g].bits) * (uint64_t)p.gcols[g].mult;
+    const uint32_t b = HASH ? ((uint32_t)radix_mix64(key) & bmask) : ((uint32_t)key >> p.radix_shift);
+    if (PASS == 1) {
+      if (on) atomicAdd(&s_cnt[b], 1u);
+    } else {
+      uint8_t* tp = nullptr;
+      if (on) tp = p.radix_tuples + (size_t)(s_base[b] + atomicAdd(&s_cnt[b], 1u)) * stride;
+      const uint32_t docid = (uint32_t)wt * PG_WAVE_DOCS + doc;
+      if (HASH) {
+        if (on) { u32x4 w4 = {(uint32_t)key, (uint32_t)(key >> 32), docid, 0u}; *reinterpret_cast<u32x4*>(tp) = w4; }
+        for (int si = 0; si < p.n_srcs; si++) {
+          const int64_t v = source_value_at(p.srcs[si], wt, doc);
+          if (on) *reinterpret_cast<int64_t*>(tp + 16 + 8 * si) = v;
+        }
+      } else {
+        if (p.n_srcs > 0) {
+          const int64_t v0 = source_value_at(p.srcs[0], wt, doc);
+          if (on) { u32x4 w4 = {(uint32_t)key & local_mask, docid, (uint32_t)(uint64_t)v0, (uint32_t)((uint64_t)v0 >> 32)}; *reinterpret_cast<u32x4*>(tp) = w4; }
+        } else if (on) {
+          u32x2 w2 = {(uint32_t)key & local_mask, docid};
+          *reinterpret_cast<u32x2*>(tp) = w2;
+        }
+        for (int si = 1; si < p.n_srcs; si++) {
+          const int64_t v = source_value_at(p.srcs[si], wt, doc);
+          if (on) *reinterpret_cast<int64_t*>(tp + 8 + 8 * si) = v;
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();   // the list is rewritten by this wavefront's next sparse tile
+}
+
 // PASS 1: count the matching docs per bucket → radix_hist[workgroup][bucket].
 // PASS 2: radix_hist holds exact offsets; every matching doc claims the next slot of its (workgroup, bucket) range with an LDS
 //         counter and writes its tuple there.  Tuples are arrays of structs — {local key, docId} then 8 bytes per source, the
@@ -1578,6 +1664,7 @@ template <int PASS, bool HASH>
 __device__ __forceinline__ void radix_pass_body(const PgQueryPlan& p) {
   __shared__ uint32_t s_cnt[PG_MAX_RADIX_BUCKETS];
   __shared__ uint32_t s_base[PASS == 2 ? PG_MAX_RADIX_BUCKETS : 1];
+  __shared__ uint16_t s_list[PG_WAVES_PER_BLOCK][PG_SELVEC_MAX];
   constexpr int B = PASS == 1 ? (HASH ? 2 : 4) : 2;
   const int t = threadIdx.x, lane = t & 63, wave = uniform(t >> 6);
   const int P = p.radix_buckets;
@@ -1594,6 +1681,11 @@ __device__ __forceinline__ void radix_pass_body(const PgQueryPlan& p) {
     const int32_t n_valid = rem >= PG_WAVE_DOCS ? PG_WAVE_DOCS : (int32_t)rem;
     const uint32_t mlin = gptr<uint32_t>(p.match_words)[(int64_t)wt * 64 + lane] & valid_lin_mask(n_valid, lane);
     if (__ballot(mlin != 0) == 0) continue;
+    const uint32_t n_match = wave_sum_u32((uint32_t)__popc(mlin));
+    if (n_match <= PG_SELVEC_MAX) {   // wave-uniform
+      radix_selvec_tile<PASS, HASH>(p, mlin, n_match, wt, s_cnt, s_base, s_list[wave], lane);
+      continue;
+    }
     const uint32_t m = lin_to_quad(mlin, lane);
 #pragma unroll
     for (int k0 = 0; k0 < 8; k0 += B) {
