@@ -1594,7 +1594,7 @@ DEVFN int64_t source_value_at(const PgValueSrc& S, int wt, uint32_t doc) {
 // Sparse tiles (at most PG_SELVEC_MAX matching docs): the matches are compacted into a per-wavefront list (the linear mask
 // layout gives ascending docIds) and handled 64 per round with every lane busy — one gather per column and doc — instead of
 // decoding all 2 048 positions of the tile twice (count and scatter pass) for a few dozen matches.
-#define PG_SELVEC_MAX 128
+#define PG_SELVEC_MAX 512
 template <int PASS, bool HASH>
 DEVFN void radix_selvec_tile(const PgQueryPlan& p, uint32_t mlin, uint32_t n_match, int wt, uint32_t* __restrict__ s_cnt,
                              const uint32_t* __restrict__ s_base, uint16_t* __restrict__ list, int lane) {
