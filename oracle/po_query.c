@@ -260,7 +260,8 @@ static int32_t lm_get_group_id(long_map* m, int64_t raw_key, int32_t upper_bound
   return PO_INVALID_ID;
 }
 
-enum { HOLDER_ARRAY, HOLDER_INT_MAP, HOLDER_LONG_MAP };
+enum { HOLDER_ARRAY, HOLDER_INT_MAP, HOLDER_LONG_MAP,
+       HOLDER_RAW_VALUES /* NoDictionarySingleColumnGroupKeyGenerator: value -> group id (Int2IntOpenHashMap / Long2IntOpenHashMap) */ };
 
 typedef struct group_key_gen {
   int n_cols;
@@ -281,6 +282,15 @@ static int gkg_init(group_key_gen* g, int n_cols, po_column** cols, int32_t num_
   memset(g, 0, sizeof(*g));
   g->n_cols = n_cols;
   g->cols = cols;
+  if (n_cols == 1 && !cols[0]->has_dictionary) {   /* NoDictionarySingleColumnGroupKeyGenerator ctor :69-84 */
+    g->holder = HOLDER_RAW_VALUES;
+    g->global_upper_bound = num_groups_limit;
+    g->cardinalities = (int32_t*)po_xcalloc(2, 4);
+    lm_init(&g->lmap);
+    g->raw_cap = 1024;
+    g->raw_key_of_group = (int64_t*)po_xmalloc(sizeof(int64_t) * (size_t)g->raw_cap);
+    return 0;
+  }
   g->cardinalities = (int32_t*)po_xcalloc((size_t)n_cols + 1, 4);
   int64_t product = 1;
   int long_overflow = 0;
@@ -345,6 +355,17 @@ static void gkg_generate(group_key_gen* g, int n_docs, int32_t** dict_ids, int32
       gid = lm_get_group_id(&g->lmap, raw, g->global_upper_bound);
       if (g->lmap.size != before) gkg_remember(g, gid, raw);
     }
+    out[i] = gid;
+  }
+}
+/* NoDictionarySingleColumnGroupKeyGenerator#generateKeysForBlock :88-106 + getKeyForValue :241-265 (INT / LONG) */
+static void gkg_generate_raw(group_key_gen* g, int n_docs, const int32_t* doc_ids, int32_t* out) {
+  const po_column* c = g->cols[0];
+  for (int i = 0; i < n_docs; i++) {
+    int64_t v = c->data_type == PG_TYPE_INT ? (int64_t)po_raw_get_int(c, doc_ids[i]) : po_raw_get_long(c, doc_ids[i]);
+    int32_t before = g->lmap.size;
+    int32_t gid = lm_get_group_id(&g->lmap, v, g->global_upper_bound);
+    if (g->lmap.size != before) gkg_remember(g, gid, v);
     out[i] = gid;
   }
 }
@@ -584,6 +605,7 @@ typedef struct po_agg_result {
 typedef struct po_result_impl {
   int32_t num_groups, n_group_cols, n_aggs;
   int32_t** group_dict_ids;
+  int64_t* group_values;     /* raw-value group keys (one no-dictionary group-by column), else NULL */
   po_agg_result* aggs;
   pg_exec_stats stats;
 } po_result_impl;
@@ -701,7 +723,10 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
   for (int j = 0; j < n_gb; j++) {
     po_column* c = po_segment_column(seg, q->group_by_columns[j]);
     if (!c) { po_set_error("column not found: %s", q->group_by_columns[j]); return PG_ERR_NOT_FOUND; }
-    if (!c->has_dictionary) { po_set_error("no-dictionary group-by column %s is outside the hot path", c->name); return PG_ERR_UNSUPPORTED; }
+    if (!c->has_dictionary && !(n_gb == 1 && (c->data_type == PG_TYPE_INT || c->data_type == PG_TYPE_LONG))) {
+      po_set_error("no-dictionary group-by column %s is outside the hot path (one raw INT / LONG column only)", c->name);
+      return PG_ERR_UNSUPPORTED;
+    }
     gcols[j] = c;
     int seen = 0;
     for (int k = 0; k < n_proj; k++) seen |= (proj[k] == c);
@@ -832,11 +857,15 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
     for (int k = 0; k < n_proj; k++) bcols[k].have_dict_ids = bcols[k].have_doubles = 0;
     const int32_t* keys = NULL;
     if (n_gb > 0) {
-      for (int j = 0; j < n_gb; j++) {
-        for (int k = 0; k < n_proj; k++)
-          if (bcols[k].col == gcols[j]) { fetch_dict_ids(&bcols[k], doc_ids, pos); gdict[j] = bcols[k].dict_ids; }
+      if (gkg.holder == HOLDER_RAW_VALUES) {
+        gkg_generate_raw(&gkg, pos, doc_ids, group_keys);
+      } else {
+        for (int j = 0; j < n_gb; j++) {
+          for (int k = 0; k < n_proj; k++)
+            if (bcols[k].col == gcols[j]) { fetch_dict_ids(&bcols[k], doc_ids, pos); gdict[j] = bcols[k].dict_ids; }
+        }
+        gkg_generate(&gkg, pos, gdict, group_keys);
       }
-      gkg_generate(&gkg, pos, gdict, group_keys);
       keys = group_keys;
       int32_t needed = gkg_upper_bound(&gkg);
       for (int i = 0; i < n_aggs; i++) agg_ensure_capacity(&aggs[i], needed);
@@ -867,7 +896,11 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
   res->num_groups = n_groups;
   res->group_dict_ids = (int32_t**)po_xcalloc((size_t)n_gb + 1, sizeof(int32_t*));
   for (int j = 0; j < n_gb; j++) res->group_dict_ids[j] = (int32_t*)po_xcalloc((size_t)n_groups + 1, 4);
-  for (int32_t i = 0; i < n_groups && n_gb > 0; i++) {  /* getKeys :578-591: col 0 is least significant */
+  if (n_gb > 0 && gkg.holder == HOLDER_RAW_VALUES) {
+    res->group_values = (int64_t*)po_xcalloc((size_t)n_groups + 1, 8);
+    for (int32_t i = 0; i < n_groups; i++) res->group_values[i] = gkg.raw_key_of_group[gid_of[i]];
+  }
+  for (int32_t i = 0; i < n_groups && n_gb > 0 && gkg.holder != HOLDER_RAW_VALUES; i++) {  /* getKeys :578-591: col 0 is least significant */
     int64_t raw = (gkg.holder == HOLDER_ARRAY) ? gid_of[i] : gkg.raw_key_of_group[gid_of[i]];
     for (int j = 0; j < n_gb; j++) {
       res->group_dict_ids[j][i] = (int32_t)(raw % gkg.cardinalities[j]);
@@ -898,6 +931,17 @@ int32_t po_result_num_groups(void* r, int32_t* out) { *out = RES(r)->num_groups;
 int32_t po_result_group_dict_ids(void* r, int32_t col, int32_t* out, int32_t cap) {
   if (col < 0 || col >= RES(r)->n_group_cols || cap < RES(r)->num_groups) { po_set_error("bad column/capacity"); return PG_ERR_INVALID_ARGUMENT; }
   memcpy(out, RES(r)->group_dict_ids[col], sizeof(int32_t) * (size_t)RES(r)->num_groups);
+  return PG_OK;
+}
+int32_t po_result_group_key_type(void* r, int32_t col, int32_t* out) {
+  if (col < 0 || col >= RES(r)->n_group_cols) { po_set_error("group-by column index out of range"); return PG_ERR_INVALID_ARGUMENT; }
+  *out = RES(r)->group_values ? PG_GROUP_KEY_LONG_VALUES : PG_GROUP_KEY_DICT_IDS;
+  return PG_OK;
+}
+int32_t po_result_group_values_long(void* r, int32_t col, int64_t* out, int32_t cap) {
+  if (col != 0 || !RES(r)->group_values) { po_set_error("group-by column has dictIds, not raw values"); return PG_ERR_INVALID_ARGUMENT; }
+  if (cap < RES(r)->num_groups) { po_set_error("capacity too small"); return PG_ERR_INVALID_ARGUMENT; }
+  memcpy(out, RES(r)->group_values, sizeof(int64_t) * (size_t)RES(r)->num_groups);
   return PG_OK;
 }
 int32_t po_result_kind_of(void* r, int32_t agg, int32_t* out) {

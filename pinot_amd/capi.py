@@ -37,6 +37,7 @@ RESULT_LONG, RESULT_DOUBLE, RESULT_AVG_PAIR, RESULT_MINMAX_PAIR, RESULT_DICTID_S
 
 QUERY_FLAG_PROFILE = 0x1
 QUERY_FLAG_SKIP_STAR_TREE = 0x2
+GROUP_KEY_DICT_IDS, GROUP_KEY_LONG_VALUES = 0, 1
 
 
 class PgBuffer(C.Structure):
@@ -155,7 +156,7 @@ ABI_SYMBOLS = [
     "filter_exec", "docidset_cardinality", "docidset_num_words", "docidset_copy_words", "docidset_copy_docids",
     "docidset_stats", "docidset_free",
     "query_supported", "query_exec",
-    "result_num_groups", "result_group_dict_ids", "result_kind_of", "result_doubles", "result_longs",
+    "result_num_groups", "result_group_dict_ids", "result_group_key_type", "result_group_values_long", "result_kind_of", "result_doubles", "result_longs",
     "result_set_sizes", "result_set_dict_ids", "result_hll_registers", "result_stats", "result_free",
 ]
 
@@ -189,6 +190,8 @@ class NativeApi:
         self.f("query_exec").argtypes = [C.c_void_p, C.POINTER(PgQuery), C.POINTER(C.c_void_p)]
         self.f("result_num_groups").argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         self.f("result_group_dict_ids").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        self.f("result_group_key_type").argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+        self.f("result_group_values_long").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
         self.f("result_kind_of").argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         self.f("result_doubles").argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
         self.f("result_longs").argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]

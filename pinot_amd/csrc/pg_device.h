@@ -132,10 +132,11 @@ enum PgAggMode : int32_t {
 #define PG_MAX_RADIX_SRCS 4
 
 struct PgGroupCol {
-  const uint8_t* data;   // fixed-bit dictIds
+  const uint8_t* data;   // fixed-bit dictIds (or the raw big-endian values of a no-dictionary group column)
   int64_t mult;          // prod of the cardinalities of the previous group columns (col 0 least significant)
   int32_t bits;
-  int32_t pad;
+  int32_t col_kind;      // PG_COL_FIXED_BIT (0), or PG_COL_RAW32 / PG_COL_RAW64: the value itself is the key (hash group-by only),
+                         // stored as value ^ 2^63 so that the table's empty marker ~0 is Long.MAX_VALUE
 };
 
 struct PgValueSrc {

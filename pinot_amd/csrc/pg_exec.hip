@@ -421,6 +421,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
       unsigned long long cnt[2] = {0, 0};
       PG_HIP(hipMemcpyAsync(cnt, ctx.hash_count.ptr, 16, hipMemcpyDeviceToHost, ctx.stream));
       PG_HIP(hipStreamSynchronize(ctx.stream));
+      if (cnt[1] == 2) fail(PG_ERR_UNSUPPORTED, "raw group key Long.MAX_VALUE is outside the GPU path");
       if (cnt[1]) fail(PG_ERR_UNSUPPORTED, "more distinct group keys in one hash bucket than its LDS table holds (%d slots, %d buckets)", D.hash_cap, D.radix_buckets);
       hash_groups = (int64_t)cnt[0];
       hash_keys_host.resize((size_t)hash_groups);
@@ -478,8 +479,13 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   }
   const int32_t ng = (int32_t)gids.size();
   res->num_groups = ng;
+  if (P.raw_group) {   // values, not dictIds: key = value ^ 2^63
+    res->raw_group_keys = true;
+    res->group_values.resize((size_t)ng);
+    for (int32_t i = 0; i < ng; i++) res->group_values[(size_t)i] = (int64_t)((uint64_t)hash_keys_host[(size_t)gids[i]] ^ (1ULL << 63));
+  }
   res->group_dict_ids.resize((size_t)q.n_group_by);
-  for (int j = 0; j < q.n_group_by; j++) {
+  for (int j = 0; j < q.n_group_by && !P.raw_group; j++) {
     auto& v = res->group_dict_ids[j];
     v.resize((size_t)ng);
     int64_t mult = D.gcols[j].mult;

@@ -198,6 +198,7 @@ struct CompiledPlan {
   size_t lds_bytes = 0;
   int32_t num_groups_limit = 0;
   int32_t exist_op = 0;              // accumulator whose value tells whether a group was touched
+  bool raw_group = false;            // the single group-by column has no dictionary: keys are values (hash group-by)
   int32_t first_doc_op = -1;         // MIN(docId) per group, present when the key space exceeds numGroupsLimit
   int32_t fast_filter = -2;          // -2: interpreter kernel; -1: index-only filter; >= 0: ScanKind of the one scan leaf
   bool fast_agg = true;              // aggregation fits the fast kernels (or there is none)
@@ -227,6 +228,8 @@ struct AggResult {
 struct Result {
   int32_t num_groups = 0;
   std::vector<std::vector<int32_t>> group_dict_ids;
+  std::vector<int64_t> group_values;   // one no-dictionary group-by column: the groups' values (group_dict_ids stays empty)
+  bool raw_group_keys = false;
   std::vector<AggResult> aggs;
   pg_exec_stats stats{};
 };

@@ -1502,6 +1502,27 @@ DEVFN void radix_keys_of64(const PgQueryPlan& p, const uint32_t (&qi)[B], int wt
     for (int i = 0; i < 4; i++) key[u][i] = 0;
   for (int g = 0; g < p.n_group_cols; g++) {
     const PgGroupCol& gc = p.gcols[g];
+    if (gc.col_kind != PG_COL_FIXED_BIT) {   // no-dictionary group column: key = value ^ 2^63
+      if (gc.col_kind == PG_COL_RAW32) {
+        const GAS uint8_t* tb = gptr<uint8_t>(gc.data + (size_t)wtile * (PG_WAVE_DOCS * 4));
+#pragma unroll
+        for (int u = 0; u < B; u++) {
+          const u32x4 v = ldnt((const GAS u32x4*)(tb + qi[u] * 16u));
+          key[u][0] = (uint64_t)(int64_t)(int32_t)bswap32(v.x) ^ (1ULL << 63); key[u][1] = (uint64_t)(int64_t)(int32_t)bswap32(v.y) ^ (1ULL << 63);
+          key[u][2] = (uint64_t)(int64_t)(int32_t)bswap32(v.z) ^ (1ULL << 63); key[u][3] = (uint64_t)(int64_t)(int32_t)bswap32(v.w) ^ (1ULL << 63);
+        }
+      } else {
+        const GAS uint8_t* tb = gptr<uint8_t>(gc.data + (size_t)wtile * (PG_WAVE_DOCS * 8));
+#pragma unroll
+        for (int u = 0; u < B; u++) {
+          const GAS u32x4* pp = (const GAS u32x4*)(tb + qi[u] * 32u);
+          const u32x4 a = ldnt(pp), b = ldnt(pp + 1);
+          key[u][0] = ((((uint64_t)bswap32(a.x) << 32) | bswap32(a.y))) ^ (1ULL << 63); key[u][1] = ((((uint64_t)bswap32(a.z) << 32) | bswap32(a.w))) ^ (1ULL << 63);
+          key[u][2] = ((((uint64_t)bswap32(b.x) << 32) | bswap32(b.y))) ^ (1ULL << 63); key[u][3] = ((((uint64_t)bswap32(b.z) << 32) | bswap32(b.w))) ^ (1ULL << 63);
+        }
+      }
+      continue;
+    }
     const GAS uint32_t* tw = packed_wtile_base(gc.data, wtile, gc.bits);
     const uint32_t bits = (uint32_t)gc.bits, mask = (1u << gc.bits) - 1u;
     const uint64_t mult = (uint64_t)gc.mult;
@@ -1622,8 +1643,14 @@ DEVFN void radix_selvec_tile(const PgQueryPlan& p, uint32_t mlin, uint32_t n_mat
     const bool on = r0 + (uint32_t)lane < n_match;
     const uint32_t doc = on ? (uint32_t)list[r0 + lane] : (uint32_t)list[0];
     uint64_t key = 0;
-    for (int g = 0; g < p.n_group_cols; g++)
-      key += (uint64_t)packed_value_at(packed_wtile_base(p.gcols[g].data, wt, p.gcols[g].bits), doc, (uint32_t)p.gcols[g].bits) * (uint64_t)p.gcols[g].mult;
+    for (int g = 0; g < p.n_group_cols; g++) {
+      const PgGroupCol& gc = p.gcols[g];
+      if (HASH && gc.col_kind == PG_COL_RAW32) key = (uint64_t)(int64_t)(int32_t)bswap32(gptr<uint32_t>(gc.data + (size_t)wt * (PG_WAVE_DOCS * 4))[doc]) ^ (1ULL << 63);
+      else if (HASH && gc.col_kind == PG_COL_RAW64) {
+        const u32x2 v = gptr<u32x2>(gc.data + (size_t)wt * (PG_WAVE_DOCS * 8))[doc];
+        key = (((uint64_t)bswap32(v.x) << 32) | bswap32(v.y)) ^ (1ULL << 63);
+      } else key += (uint64_t)packed_value_at(packed_wtile_base(gc.data, wt, gc.bits), doc, (uint32_t)gc.bits) * (uint64_t)gc.mult;
+    }
     const uint32_t b = HASH ? ((uint32_t)radix_mix64(key) & bmask) : ((uint32_t)key >> p.radix_shift);
     if (PASS == 1) {
       if (on) atomicAdd(&s_cnt[b], 1u);
@@ -1821,6 +1848,7 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_hash_aggregate_kernel(
       const GAS uint8_t* tp = gptr<uint8_t>(p.radix_tuples + (size_t)i * stride);
       const u32x4 h = *(const GAS u32x4*)tp;
       const unsigned long long key = ((unsigned long long)h.y << 32) | h.x;
+      if (key == kEmpty) { p.hash_out_count[1] = 2; continue; }   // a raw LONG group key of Long.MAX_VALUE collides with the empty marker
       uint32_t slot = (uint32_t)(radix_mix64(key) >> 16) & cmask;
       bool found = false;
       for (uint32_t probes = 0; probes < cap; probes++) {

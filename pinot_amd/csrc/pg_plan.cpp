@@ -898,10 +898,28 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
   for (int j = 0; j < q->n_group_by; j++) {
     Column* c = seg.find(q->group_by_columns[j]);
     if (!c) fail(PG_ERR_NOT_FOUND, "column not found: %s", q->group_by_columns[j] ? q->group_by_columns[j] : "(null)");
-    if (!c->has_dictionary) fail(PG_ERR_UNSUPPORTED, "no-dictionary group-by column %s", c->name.c_str());
+    if (!c->has_dictionary) {
+      // NoDictionarySingleColumnGroupKeyGenerator (core/query/aggregation/groupby/NoDictionarySingleColumnGroupKeyGenerator.java:53-90,
+      // 241-265): one raw INT / LONG column, value -> group id; here the value is the 64-bit key of the hash group-by
+      if (q->n_group_by != 1 || (c->col_kind != PG_COL_RAW32 && c->col_kind != PG_COL_RAW64) ||
+          (c->data_type != PG_TYPE_INT && c->data_type != PG_TYPE_LONG))
+        fail(PG_ERR_UNSUPPORTED, "no-dictionary group-by column %s (one raw INT / LONG column only)", c->name.c_str());
+      D.gcols[j].data = c->fwd_dev.as<uint8_t>();
+      D.gcols[j].bits = 0;
+      D.gcols[j].mult = 1;
+      D.gcols[j].col_kind = c->col_kind;
+      P.group_cols.push_back(c);
+      P.group_cards.push_back(0);
+      P.raw_group = true;
+      huge_key_space = true;
+      G = (int64_t)1 << 40;   // unknown number of distinct values: everything that compares G with a limit sees "large"
+      project(c);
+      continue;
+    }
     D.gcols[j].data = c->fwd_dev.as<uint8_t>();
     D.gcols[j].bits = c->bits;
     D.gcols[j].mult = G;
+    D.gcols[j].col_kind = PG_COL_FIXED_BIT;
     P.group_cols.push_back(c);
     P.group_cards.push_back(c->cardinality);
     // beyond any dense table (the reference's LongMapBasedHolder, DictionaryBasedGroupKeyGenerator.java:166-176): 64-bit raw

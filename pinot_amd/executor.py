@@ -183,8 +183,16 @@ class ResultsBlock:
         ng = n.value
         ngb = len(qc.group_by)
         ids = np.zeros((ngb, ng), dtype=np.int32)
+        rb.group_values = None
         for j in range(ngb):
-            api.call("result_group_dict_ids", h, j, ids[j].ctypes.data, ng)
+            kt = C.c_int32()
+            api.call("result_group_key_type", h, j, C.byref(kt))
+            if kt.value == capi.GROUP_KEY_LONG_VALUES:   # a no-dictionary group-by column: the groups' values themselves
+                vals = np.zeros(ng, dtype=np.int64)
+                api.call("result_group_values_long", h, j, vals.ctypes.data, ng)
+                rb.group_values = vals
+            else:
+                api.call("result_group_dict_ids", h, j, ids[j].ctypes.data, ng)
         rb.group_dict_ids = ids
         for a, spec in enumerate(qc.aggregations):
             kind = C.c_int32()
@@ -235,6 +243,8 @@ class ResultsBlock:
 
     @property
     def group_keys(self) -> List[tuple]:
+        if self._group_keys is None and getattr(self, "group_values", None) is not None:
+            self._group_keys = [(int(v),) for v in self.group_values]
         if self._group_keys is None:
             ids = self.group_dict_ids
             dicts = [self._host.columns[g].dict_values for g in self.query.group_by]
