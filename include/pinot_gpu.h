@@ -106,7 +106,9 @@ typedef enum pg_predicate_type {  /* Predicate.Type (subset on the path) */
   PG_PRED_NOT_EQ = 1,
   PG_PRED_IN = 2,
   PG_PRED_NOT_IN = 3,
-  PG_PRED_RANGE = 4
+  PG_PRED_RANGE = 4,
+  PG_PRED_IS_NULL = 5,       /* BitmapBasedFilterOperator over the column's null value vector (FilterPlanNode.java:298-305); */
+  PG_PRED_IS_NOT_NULL = 6    /* Empty / MatchAll when the column has none (:306-312) */
 } pg_predicate_type;
 
 #define PG_RANGE_UNBOUNDED "*"    /* RangePredicate.UNBOUNDED */
@@ -244,6 +246,16 @@ int32_t pg_segment_create(const char* segment_name, int32_t total_docs, pg_segme
 int32_t pg_segment_add_column(pg_segment_t segment, const pg_column_desc* column);
 /* StarTreeLoaderUtils#loadStarTreeV2: registers star-tree number `IndexSegment#getStarTrees().size()` of the segment. */
 int32_t pg_segment_add_star_tree(pg_segment_t segment, const pg_star_tree_desc* star_tree);
+
+/* NullValueVectorReader#getNullBitmap (pinot-segment-local/.../index/readers/NullValueVectorReaderImpl.java:26-44): the column's
+ * null value vector, one portable-format RoaringBitmap (the `nullvalue_vector` entry of `index_map`, file extension `.bitmap.nullvalue` in v1).  Read by IS_NULL / IS_NOT_NULL only
+ * (query-level null handling is outside the path).  The bytes are copied. */
+int32_t pg_segment_set_null_vector(pg_segment_t segment, const char* column, const void* roaring, uint64_t size);
+
+/* SegmentContext#getQueryableDocIdsSnapshot (upsert validDocIds / queryableDocIds): FilterPlanNode.run ANDs it into every
+ * filter as a BitmapBasedFilterOperator (pinot-core/.../plan/FilterPlanNode.java:88-106).  One portable-format RoaringBitmap,
+ * copied; replaces the previous snapshot; size 0 clears it.  Queries already running keep the snapshot they started with. */
+int32_t pg_segment_set_queryable_doc_ids(pg_segment_t segment, const void* roaring, uint64_t size);
 int32_t pg_segment_num_docs(pg_segment_t segment, int32_t* out_num_docs);
 int32_t pg_segment_device_bytes(pg_segment_t segment, uint64_t* out_bytes);
 int32_t pg_segment_destroy(pg_segment_t segment);

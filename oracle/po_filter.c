@@ -727,6 +727,14 @@ static po_filter_op* construct_physical_operator(po_segment* seg, const pg_filte
         po_set_error("column not found: %s", f->column ? f->column : "(null)");
         return NULL;
       }
+      if (f->predicate_type == PG_PRED_IS_NULL || f->predicate_type == PG_PRED_IS_NOT_NULL) { /* :298-312 */
+        const int not_null = f->predicate_type == PG_PRED_IS_NOT_NULL;
+        if (!col->null_bitmap) return po_op_new(not_null ? PO_OP_MATCH_ALL : PO_OP_EMPTY, num_docs);
+        po_filter_op* op = po_op_new(PO_OP_BITMAP, num_docs);
+        op->bitmap = po_bitmap_clone(col->null_bitmap);
+        op->bitmap_exclusive = not_null;
+        return op;
+      }
       po_pred_eval* eval = po_pred_eval_create(f, col);
       if (!eval) return NULL;
       return po_leaf_filter_operator(eval, col, num_docs);
@@ -740,8 +748,16 @@ static po_filter_op* construct_physical_operator(po_segment* seg, const pg_filte
 }
 
 po_filter_op* po_filter_plan(po_segment* seg, const pg_filter_node* filter) { /* FilterPlanNode.run :88-106 */
-  if (!filter) return po_op_new(PO_OP_MATCH_ALL, seg->total_docs);
-  return construct_physical_operator(seg, filter, seg->total_docs);
+  po_filter_op* valid = NULL;
+  if (seg->queryable_doc_ids) {
+    valid = po_op_new(PO_OP_BITMAP, seg->total_docs);
+    valid->bitmap = po_bitmap_clone(seg->queryable_doc_ids);
+  }
+  if (!filter) return valid ? valid : po_op_new(PO_OP_MATCH_ALL, seg->total_docs);
+  po_filter_op* op = construct_physical_operator(seg, filter, seg->total_docs);
+  if (!op || !valid) return op;
+  po_filter_op* both[2] = {op, valid};
+  return po_and_filter_operator(2, both, seg->total_docs);
 }
 
 /* ---- getTrues / getFalses -------------------------------------------------------------------------------------------------- */
@@ -816,7 +832,11 @@ po_docidset* po_filter_get_trues(po_filter_op* op) {
     case PO_OP_SCAN: return scanset_new(op->eval, op->col, op->num_docs);
     case PO_OP_INVERTED: return inverted_get_trues(op);
     case PO_OP_SORTED: return sorted_get_trues(op);
-    case PO_OP_BITMAP: return bitmapset_new(po_bitmap_clone(op->bitmap), op->num_docs);
+    case PO_OP_BITMAP: { /* BitmapBasedFilterOperator#getTrues :42-49 */
+      po_bitmap* b = po_bitmap_clone(op->bitmap);
+      if (op->bitmap_exclusive) po_bitmap_flip(b, 0, op->num_docs);
+      return bitmapset_new(b, op->num_docs);
+    }
     case PO_OP_AND:
     case PO_OP_OR: {
       po_docidset** sets = (po_docidset**)po_xcalloc((size_t)op->n_children + 1, sizeof(po_docidset*));

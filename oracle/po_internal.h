@@ -83,6 +83,7 @@ typedef struct po_column {
   int32_t raw_version, raw_num_chunks, raw_docs_per_chunk, raw_entry_len, raw_compression;
   const uint8_t* raw_data;   /* _rawData */
   int32_t num_docs;
+  struct po_bitmap* null_bitmap;   /* NullValueVectorReader#getNullBitmap, NULL if the column has no null value vector */
 } po_column;
 
 struct po_star_tree;
@@ -93,6 +94,7 @@ typedef struct po_segment {
   po_column** columns;
   int32_t n_star_trees;                 /* IndexSegment#getStarTrees */
   struct po_star_tree** star_trees;
+  struct po_bitmap* queryable_doc_ids;  /* SegmentContext#getQueryableDocIdsSnapshot, NULL if none */
 } po_segment;
 
 /* StarTreeV2 (pinot-segment-local/.../startree/v2/store/StarTreeLoaderUtils.java:53-128): the tree, its metadata and
@@ -197,6 +199,7 @@ struct po_filter_op {
   int n_children;
   po_filter_op** children;
   po_bitmap* bitmap;      /* PO_OP_BITMAP */
+  int bitmap_exclusive;   /* BitmapBasedFilterOperator._exclusive */
 };
 
 /* operator constructors shared with the star-tree filter (po_startree.c) */

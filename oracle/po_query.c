@@ -81,14 +81,44 @@ int32_t po_segment_add_column(void* segp, const pg_column_desc* d) {
   seg->columns[seg->n_columns++] = c;
   return PG_OK;
 }
+static po_bitmap* roaring_to_bitmap(const void* roaring, uint64_t size, int32_t total_docs) {
+  po_bitmap* b = po_bitmap_new(total_docs);
+  if (po_roaring_deserialize_or((const uint8_t*)roaring, size, b)) { po_bitmap_free(b); return NULL; }
+  return b;
+}
+/* NullValueVectorReaderImpl: the null bitmap of one column */
+int32_t po_segment_set_null_vector(void* segp, const char* column, const void* roaring, uint64_t size) {
+  po_segment* seg = (po_segment*)segp;
+  po_column* c = po_segment_column(seg, column);
+  if (!c) { po_set_error("column not found: %s", column ? column : "(null)"); return PG_ERR_NOT_FOUND; }
+  po_bitmap* b = roaring_to_bitmap(roaring, size, seg->total_docs);
+  if (!b) return PG_ERR_INVALID_ARGUMENT;
+  if (c->null_bitmap) po_bitmap_free(c->null_bitmap);
+  c->null_bitmap = b;
+  return PG_OK;
+}
+/* SegmentContext#getQueryableDocIdsSnapshot */
+int32_t po_segment_set_queryable_doc_ids(void* segp, const void* roaring, uint64_t size) {
+  po_segment* seg = (po_segment*)segp;
+  po_bitmap* b = NULL;
+  if (size) {
+    b = roaring_to_bitmap(roaring, size, seg->total_docs);
+    if (!b) return PG_ERR_INVALID_ARGUMENT;
+  }
+  if (seg->queryable_doc_ids) po_bitmap_free(seg->queryable_doc_ids);
+  seg->queryable_doc_ids = b;
+  return PG_OK;
+}
 int32_t po_segment_num_docs(void* s, int32_t* out) { *out = ((po_segment*)s)->total_docs; return PG_OK; }
 int32_t po_segment_device_bytes(void* s, uint64_t* out) { (void)s; *out = 0; return PG_OK; }
 int32_t po_segment_destroy(void* segp) {
   po_segment* seg = (po_segment*)segp;
   for (int i = 0; i < seg->n_columns; i++) {
     free(seg->columns[i]->name);
+    if (seg->columns[i]->null_bitmap) po_bitmap_free(seg->columns[i]->null_bitmap);
     free(seg->columns[i]);
   }
+  if (seg->queryable_doc_ids) po_bitmap_free(seg->queryable_doc_ids);
   free(seg->columns);
   free(seg->name);
   free(seg);

@@ -193,6 +193,7 @@ static po_pred_eval* star_pred_eval(po_segment* seg, const pg_filter_node* p, in
   po_column* col = po_segment_column(seg, p->column);
   if (!col) { po_set_error("column not found: %s", p->column ? p->column : "(null)"); *err = PG_ERR_NOT_FOUND; return NULL; }
   if (!col->has_dictionary) return NULL;
+  if (p->predicate_type == PG_PRED_IS_NULL || p->predicate_type == PG_PRED_IS_NOT_NULL) return NULL; /* StarTreeUtils.java:333-341 */
   po_pred_eval* e = po_pred_eval_create(p, col);
   if (!e) *err = PG_ERR_INVALID_ARGUMENT;
   return e;

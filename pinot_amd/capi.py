@@ -30,7 +30,7 @@ FWD_RAW_FIXED_BYTE_CHUNK = 1
 FWD_DICT_SORTED = 2
 
 FILTER_AND, FILTER_OR, FILTER_NOT, FILTER_PREDICATE, FILTER_CONSTANT_TRUE, FILTER_CONSTANT_FALSE = range(6)
-PRED_EQ, PRED_NOT_EQ, PRED_IN, PRED_NOT_IN, PRED_RANGE = range(5)
+PRED_EQ, PRED_NOT_EQ, PRED_IN, PRED_NOT_IN, PRED_RANGE, PRED_IS_NULL, PRED_IS_NOT_NULL = range(7)
 AGG_FUNCTIONS = {"COUNT": 0, "SUM": 1, "MIN": 2, "MAX": 3, "AVG": 4, "DISTINCTCOUNT": 5, "DISTINCTCOUNTHLL": 6,
                  "MINMAXRANGE": 7}
 RESULT_LONG, RESULT_DOUBLE, RESULT_AVG_PAIR, RESULT_MINMAX_PAIR, RESULT_DICTID_SET, RESULT_HLL = range(6)
@@ -152,7 +152,7 @@ GPU_LIB_PATH = os.path.join(REPO_ROOT, "pinot_amd", "csrc", "libpinot_gpu.so")
 # every symbol include/pinot_gpu.h declares (checked by the "not gpu" suite against the built library)
 ABI_SYMBOLS = [
     "abi_version", "init", "device_count", "last_error",
-    "segment_create", "segment_add_column", "segment_add_star_tree", "segment_num_docs", "segment_device_bytes", "segment_destroy",
+    "segment_create", "segment_add_column", "segment_add_star_tree", "segment_set_null_vector", "segment_set_queryable_doc_ids", "segment_num_docs", "segment_device_bytes", "segment_destroy",
     "filter_exec", "docidset_cardinality", "docidset_num_words", "docidset_copy_words", "docidset_copy_docids",
     "docidset_stats", "docidset_free",
     "query_supported", "query_exec",
@@ -190,6 +190,8 @@ class NativeApi:
         self.f("query_exec").argtypes = [C.c_void_p, C.POINTER(PgQuery), C.POINTER(C.c_void_p)]
         self.f("result_num_groups").argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         self.f("result_group_dict_ids").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        self.f("segment_set_null_vector").argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
+        self.f("segment_set_queryable_doc_ids").argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
         self.f("result_group_key_type").argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         self.f("result_group_values_long").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
         self.f("result_kind_of").argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]

@@ -83,6 +83,18 @@ int32_t pg_segment_add_star_tree(pg_segment_t segment, const pg_star_tree_desc* 
     segment->seg.plan_cache.clear();
   });
 }
+int32_t pg_segment_set_null_vector(pg_segment_t segment, const char* column, const void* roaring, uint64_t size) {
+  return guarded([&] {
+    REQUIRE(segment && column, "null argument");
+    segment_set_null_vector(segment->seg, column, roaring, size);
+  });
+}
+int32_t pg_segment_set_queryable_doc_ids(pg_segment_t segment, const void* roaring, uint64_t size) {
+  return guarded([&] {
+    REQUIRE(segment, "null argument");
+    segment_set_queryable_doc_ids(segment->seg, roaring, size);
+  });
+}
 
 int32_t pg_segment_num_docs(pg_segment_t segment, int32_t* out_num_docs) {
   return guarded([&] { REQUIRE(segment && out_num_docs, "null argument"); *out_num_docs = segment->seg.total_docs; });

@@ -103,6 +103,9 @@ struct Segment {
   std::mutex mu;
   std::unordered_map<std::string, std::shared_ptr<CompiledPlan>> plan_cache;
   std::vector<std::unique_ptr<StarTree>> star_trees;   // IndexSegment#getStarTrees
+  // doc-id bitmaps handed over as portable RoaringBitmaps, kept as one-posting inverted indexes (the kernels' posting leaf):
+  std::map<std::string, std::shared_ptr<Column>> null_vectors;   // NullValueVectorReader#getNullBitmap per column
+  std::shared_ptr<Column> queryable_doc_ids;                     // SegmentContext#getQueryableDocIdsSnapshot
   Column* find(const char* name);
   Segment();
   ~Segment();
@@ -127,6 +130,8 @@ struct StarTree {
 
 void segment_add_column(Segment& seg, const pg_column_desc& d);
 void segment_add_star_tree(Segment& seg, const pg_star_tree_desc& d);
+void segment_set_null_vector(Segment& seg, const char* column, const void* roaring, uint64_t size);
+void segment_set_queryable_doc_ids(Segment& seg, const void* roaring, uint64_t size);
 
 // ---- predicate evaluation (host): PredicateEvaluatorProvider & factories ---------------------------------------------------
 struct PredEval {
@@ -155,6 +160,7 @@ struct FilterOp {
   OpKind kind = OpKind::Empty;
   PredEval eval;
   Column* col = nullptr;
+  std::shared_ptr<Column> bitmap_col;        // Inverted over a docId bitmap of the segment (null vector, queryableDocIds): keeps it alive
   std::vector<std::unique_ptr<FilterOp>> children;
   std::vector<int32_t> range_lo, range_hi;   // Bitmap (BitmapBasedFilterOperator): ascending disjoint inclusive docId ranges
 };
@@ -185,6 +191,7 @@ struct AggOut {          // how one requested aggregation maps onto accumulator 
 struct CompiledPlan {
   PgQueryPlan dev{};                 // template; per-execution pointers are patched in
   std::vector<DeviceBuffer> keep;    // device allocations referenced by dev
+  std::vector<std::shared_ptr<Column>> pinned;   // doc-id bitmaps (null vectors, queryableDocIds snapshot) the program reads
   int32_t n_stat_slots = 1;
   int64_t full_scan_entries = 0;     // entries contributed by unmasked scans whose count is known (numDocs each)
   bool stats_exact = true;

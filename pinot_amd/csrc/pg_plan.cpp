@@ -283,6 +283,18 @@ OpPtr leaf_operator(PredEval ev, Column* col, int32_t predicate_type) {
   return op;
 }
 
+// BitmapBasedFilterOperator(docIds, exclusive) over a RoaringBitmap the segment holds: the posting leaf of a one-entry inverted
+// index (same priority, same zero numEntriesScannedInFilter, same canOptimizeCount as InvertedIndexFilterOperator)
+static OpPtr bitmap_operator(std::shared_ptr<Column> bitmap, bool exclusive) {
+  auto op = make_op(OpKind::Inverted);
+  op->col = bitmap.get();
+  op->bitmap_col = std::move(bitmap);
+  op->eval.dictionary_based = true;
+  op->eval.exclusive = exclusive;
+  (exclusive ? op->eval.non_matching : op->eval.matching).push_back(0);
+  return op;
+}
+
 static OpPtr construct(Segment& seg, const pg_filter_node& f) {   // FilterPlanNode#constructPhysicalOperator
   switch (f.type) {
     case PG_FILTER_AND:
@@ -298,6 +310,12 @@ static OpPtr construct(Segment& seg, const pg_filter_node& f) {   // FilterPlanN
     case PG_FILTER_PREDICATE: {
       Column* col = seg.find(f.column);
       if (!col) fail(PG_ERR_NOT_FOUND, "column not found: %s", f.column ? f.column : "(null)");
+      if (f.predicate_type == PG_PRED_IS_NULL || f.predicate_type == PG_PRED_IS_NOT_NULL) {   // FilterPlanNode.java:298-312
+        const bool not_null = f.predicate_type == PG_PRED_IS_NOT_NULL;
+        auto it = seg.null_vectors.find(col->name);
+        if (it == seg.null_vectors.end()) return make_op(not_null ? OpKind::MatchAll : OpKind::Empty);
+        return bitmap_operator(it->second, not_null);
+      }
       return leaf_operator(make_pred_eval(f, *col), col, f.predicate_type);
     }
     case PG_FILTER_CONSTANT_TRUE: return make_op(OpKind::MatchAll);
@@ -379,6 +397,7 @@ struct Emitter {
   // (non-)matching dictIds, flipped over [0, numDocs) when exclusive
   void emit_inverted(const FilterOp& op) {
     Column& c = *op.col;
+    if (op.bitmap_col) plan.pinned.push_back(op.bitmap_col);
     const PredEval& e = op.eval;
     const std::vector<int32_t>& ids = e.exclusive ? e.non_matching : e.matching;
     const int32_t n_chunks = (seg.n_tiles + PG_TILES_PER_CHUNK - 1) / PG_TILES_PER_CHUNK;
@@ -512,6 +531,7 @@ struct Emitter {
         for (auto& c : op.children) {
           if (c->kind == OpKind::Sorted || c->kind == OpKind::Inverted || c->kind == OpKind::Bitmap) index_based.push_back(c.get());
           else if (c->kind == OpKind::Scan) scan_based.push_back(c.get());
+          else if (yields_bitmap(*c)) index_based.push_back(c.get());   // a nested AND whose iterator is a RangelessBitmapDocIdIterator
           else remaining.push_back(c.get());
         }
         bool first = true;
@@ -536,10 +556,24 @@ struct Emitter {
           if (!first) { instrs.push_back({PG_F_AND, 0}); sp--; }
           first = false;
         }
-        if (!top_level && has_scan(op)) plan.stats_exact = false;
+        if (!top_level && has_scan(op) && !yields_bitmap(op)) plan.stats_exact = false;
         break;
       }
     }
+  }
+
+  // AndDocIdSet.iterator() (AndDocIdSet.java:125-178) merges index-based and scan children into ONE bitmap, eagerly, when there is
+  // an index-based child next to a scan (or two index-based ones) and nothing else: such an AND nested in an AND (the
+  // queryableDocIds wrapper of FilterPlanNode.run) acts as a bitmap child there, and every scan count stays exact.
+  static bool yields_bitmap(const FilterOp& op) {
+    if (op.kind != OpKind::And) return false;
+    int n_index = 0, n_scan = 0;
+    for (auto& c : op.children) {
+      if (c->kind == OpKind::Sorted || c->kind == OpKind::Inverted || c->kind == OpKind::Bitmap) n_index++;
+      else if (c->kind == OpKind::Scan) n_scan++;
+      else return false;
+    }
+    return (n_index > 0 && n_scan > 0) || n_index > 1;
   }
 };
 
@@ -702,6 +736,7 @@ static double estimate_selectivity(const FilterOp& op, double n_docs) {
     case OpKind::Empty: return 0;
     case OpKind::MatchAll: return 1;
     case OpKind::Inverted: {
+      if (op.bitmap_col && op.eval.exclusive) return std::max(0.0, 1.0 - (double)op.col->posting_card[0] / n_docs);
       double m = 0;
       for (int32_t id : op.eval.matching) m += (double)op.col->posting_card[(size_t)id];
       return std::min(1.0, m / n_docs);
@@ -745,6 +780,12 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
 // :285-307) and the operators run over that star-tree's doc space.
 std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* filter, const pg_query* q) {
   OpPtr root = filter ? construct(seg, *filter) : make_op(OpKind::MatchAll);
+  if (seg.queryable_doc_ids) {   // FilterPlanNode.run (:88-106): AND(filter, BitmapBasedFilterOperator(queryableDocIds))
+    std::vector<OpPtr> both;
+    both.push_back(std::move(root));
+    both.push_back(bitmap_operator(seg.queryable_doc_ids, false));
+    root = and_operator(std::move(both));
+  }
   if (q && q->n_aggregations > 0 && q->aggregations && !(q->flags & PG_QUERY_FLAG_SKIP_STAR_TREE) && !seg.star_trees.empty() &&
       root->kind != OpKind::Empty) {
     const bool fast_count = q->n_group_by == 0 && q->n_aggregations == 1 && q->aggregations[0].function == PG_AGG_COUNT &&

@@ -125,6 +125,38 @@ static void parse_inverted_index(Segment& seg, Column& c, const uint8_t* inv, ui
   c.has_inverted = true;
 }
 
+// One RoaringBitmap of docIds → a column-less inverted index with a single posting list ("dictId 0"): the filter kernels read
+// it through the same posting leaf as BitmapInvertedIndexReader's bitmaps (array / bitmap / run containers decoded on the GPU).
+static std::shared_ptr<Column> bitmap_column(Segment& seg, const std::string& name, const void* roaring, uint64_t size) {
+  if (!roaring || size < 8) fail(PG_ERR_INVALID_ARGUMENT, "%s: not a serialized RoaringBitmap", name.c_str());
+  if (size > 0xFFFFFFF0ULL) fail(PG_ERR_UNSUPPORTED, "%s: bitmap larger than 4 GB", name.c_str());
+  auto col = std::make_shared<Column>();
+  col->name = name;
+  col->cardinality = 1;
+  std::vector<uint8_t> inv(8 + size);
+  const uint32_t offs[2] = {8, (uint32_t)(8 + size)};
+  for (int i = 0; i < 2; i++) for (int b = 0; b < 4; b++) inv[(size_t)i * 4 + b] = (uint8_t)(offs[i] >> (24 - 8 * b));
+  memcpy(inv.data() + 8, roaring, size);
+  parse_inverted_index(seg, *col, inv.data(), inv.size());
+  return col;
+}
+
+void segment_set_null_vector(Segment& seg, const char* column, const void* roaring, uint64_t size) {
+  if (!column || !seg.find(column)) fail(PG_ERR_NOT_FOUND, "column not found: %s", column ? column : "(null)");
+  auto col = bitmap_column(seg, std::string("nullvalue_vector of ") + column, roaring, size);
+  std::lock_guard<std::mutex> g(seg.mu);
+  seg.null_vectors[column] = std::move(col);
+  seg.plan_cache.clear();   // running queries keep their plan, which pins the bitmap it reads
+}
+
+void segment_set_queryable_doc_ids(Segment& seg, const void* roaring, uint64_t size) {
+  std::shared_ptr<Column> col;
+  if (size) col = bitmap_column(seg, "queryableDocIds", roaring, size);
+  std::lock_guard<std::mutex> g(seg.mu);
+  seg.queryable_doc_ids = std::move(col);
+  seg.plan_cache.clear();
+}
+
 void segment_add_column(Segment& seg, const pg_column_desc& d) {
   if (!d.name) fail(PG_ERR_INVALID_ARGUMENT, "column name is null");
   if (seg.columns.count(d.name)) fail(PG_ERR_INVALID_ARGUMENT, "column %s already added", d.name);

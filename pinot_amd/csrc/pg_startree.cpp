@@ -232,6 +232,7 @@ static bool star_pred_eval(Segment& seg, const pg_filter_node& p, PredEval* out)
   Column* col = seg.find(p.column);
   if (!col) fail(PG_ERR_NOT_FOUND, "column not found: %s", p.column ? p.column : "(null)");
   if (!col->has_dictionary) return false;
+  if (p.predicate_type == PG_PRED_IS_NULL || p.predicate_type == PG_PRED_IS_NOT_NULL) return false;   // StarTreeUtils.java:333-341
   *out = make_pred_eval(p, *col);
   return true;
 }

@@ -53,6 +53,18 @@ class NativeSegment:
         d = col.desc()
         self._descs.append(d)
         self.api.call("segment_add_column", self.handle, C.byref(d))
+        nv = getattr(col, "null_vector", None)
+        if nv is not None:
+            self.api.call("segment_set_null_vector", self.handle, col.name.encode(), nv.ctypes.data, nv.nbytes)
+
+    def set_queryable_doc_ids(self, doc_ids):
+        """SegmentContext#getQueryableDocIdsSnapshot (upsert validDocIds): ascending docIds, or None to clear."""
+        if doc_ids is None:
+            self.api.call("segment_set_queryable_doc_ids", self.handle, None, 0)
+            return
+        from . import formats
+        blob = np.frombuffer(formats.serialize_roaring(np.asarray(doc_ids, dtype=np.int64)), dtype=np.uint8)
+        self.api.call("segment_set_queryable_doc_ids", self.handle, blob.ctypes.data, blob.nbytes)
 
     def add_column(self, col, keep_host_buffers: bool = True):
         """Registers one more column (streaming upload of big segments: the GPU library copies the bytes into HBM during

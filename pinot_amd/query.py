@@ -211,6 +211,13 @@ class _Parser:
             self.expect_kw("AND")
             hi = self.literal()
             return FilterContext.pred(Predicate("RANGE", col, [], lo, hi, True, True))
+        if self.kw("IS"):   # IS [NOT] NULL → Predicate.Type.IS_NULL / IS_NOT_NULL (IsNullPredicate, IsNotNullPredicate)
+            self.i += 1
+            not_null = self.kw("NOT")
+            if not_null:
+                self.i += 1
+            self.expect_kw("NULL")
+            return FilterContext.pred(Predicate("IS_NOT_NULL" if not_null else "IS_NULL", col, []))
         negate = False
         if self.kw("NOT"):
             self.i += 1
@@ -347,7 +354,7 @@ _FILTER_TYPES = {"AND": capi.FILTER_AND, "OR": capi.FILTER_OR, "NOT": capi.FILTE
                  "PREDICATE": capi.FILTER_PREDICATE, "CONSTANT_TRUE": capi.FILTER_CONSTANT_TRUE,
                  "CONSTANT_FALSE": capi.FILTER_CONSTANT_FALSE}
 _PRED_TYPES = {"EQ": capi.PRED_EQ, "NOT_EQ": capi.PRED_NOT_EQ, "IN": capi.PRED_IN, "NOT_IN": capi.PRED_NOT_IN,
-               "RANGE": capi.PRED_RANGE}
+               "RANGE": capi.PRED_RANGE, "IS_NULL": capi.PRED_IS_NULL, "IS_NOT_NULL": capi.PRED_IS_NOT_NULL}
 
 
 class CQuery:

@@ -30,6 +30,7 @@ class HostColumn:
     dictionary: Optional[np.ndarray] = None
     inverted_index: Optional[np.ndarray] = None
     dict_values: Optional[list] = None  # decoded dictionary (python objects / numpy scalars) for result decoding
+    null_vector: Optional[np.ndarray] = None  # NullValueVectorReader: serialized RoaringBitmap of the null docIds (uint8 array)
     _name_bytes: bytes = b""
 
     def desc(self) -> capi.PgColumnDesc:

@@ -162,6 +162,9 @@ def load_segment_dir(path: str) -> HostSegment:
             seg.columns[name] = HostColumn(name, dt, capi.FWD_RAW_FIXED_BYTE_CHUNK, False, 0, 0,
                                            m.get("isSorted", "false") == "true", 0, fwd)
 
+    for name, col in seg.columns.items():   # StandardIndexes.NULL_VALUE_VECTOR_ID: one RoaringBitmap of the null docIds
+        col.null_vector = entry(name, "nullvalue_vector")
+
     n_trees = int(props.get("startree.v2.count", ["0"])[0])
     if n_trees and os.path.exists(os.path.join(path, STAR_TREE_INDEX_FILE)):
         blob = np.fromfile(os.path.join(path, STAR_TREE_INDEX_FILE), dtype=np.uint8)
@@ -207,6 +210,7 @@ def write_segment_dir(seg: HostSegment, path: str, padding: str = "\0") -> None:
         put(name, "dictionary", c.dictionary if c.has_dictionary else None)
         put(name, "forward_index", c.forward_index)
         put(name, "inverted_index", c.inverted_index)
+        put(name, "nullvalue_vector", c.null_vector)
         p = f"column.{name}."
         meta += [p + f"cardinality = {c.cardinality}", p + f"totalDocs = {seg.total_docs}",
                  p + f"dataType = {c.data_type}", p + f"bitsPerElement = {c.bits_per_value}",
