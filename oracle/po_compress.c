@@ -1,0 +1,133 @@
+/*
+ * ORACLE — test infrastructure only (see po_internal.h).  Chunk decompressors of the raw forward indexes.
+ *
+ * The reference hands every compressed chunk to a third-party library that is not under /root/reference:
+ *   SNAPPY               snappy-java 1.1.10.x  Snappy.uncompress       (pinot-segment-local/.../io/compression/SnappyDecompressor.java:39-49)
+ *   LZ4                  lz4-java 1.8.0        safeDecompressor()      (.../io/compression/LZ4Decompressor.java:38-49)
+ *   LZ4_LENGTH_PREFIXED  lz4-java              LZ4DecompressorWithLength: 4-byte little-endian decompressed length, then the block
+ *                                              (.../io/compression/LZ4WithLengthDecompressor.java:35-52)
+ * Their algorithms are restated here from the published formats (snappy format_description.txt; LZ4 block format description).
+ * Parity: SNAPPY is pinned by the reference's own blobs fixedByteCompressed.v2, fixedByteSVRDoubles.v1, varByteStringsCompressed.v2
+ * and varByteStrings.v1 (tests/test_oracle_goldens.py); the tree holds no LZ4 blob, so LZ4 is pinned only against liblz4 (through
+ * pyarrow's lz4_raw codec, tests/test_compressed_chunks.py) — "parity unpinned" by the reference itself.
+ * ZSTANDARD and GZIP chunks are not restated (PG_ERR_UNSUPPORTED).
+ */
+#include "po_internal.h"
+
+/* snappy: varint32 uncompressed length, then elements tagged by the low 2 bits: 00 literal, 01/10/11 copies with 1/2/4 offset bytes */
+int64_t po_snappy_uncompressed_length(const uint8_t* src, uint64_t n, uint64_t* header_len) {
+  uint64_t v = 0;
+  for (int i = 0; i < 5 && (uint64_t)i < n; i++) {
+    v |= (uint64_t)(src[i] & 0x7F) << (7 * i);
+    if (!(src[i] & 0x80)) { if (header_len) *header_len = (uint64_t)i + 1; return (int64_t)v; }
+  }
+  return -1;
+}
+
+int64_t po_snappy_uncompress(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) {
+  uint64_t ip = 0;
+  int64_t want = po_snappy_uncompressed_length(src, n, &ip);
+  if (want < 0 || (uint64_t)want > cap) return -1;
+  uint64_t op = 0;
+  while (ip < n) {
+    const uint8_t tag = src[ip++];
+    uint64_t len, offset;
+    switch (tag & 3) {
+      case 0: {
+        len = (uint64_t)(tag >> 2) + 1;
+        if (len > 60) {
+          const int extra = (int)(len - 60);
+          if (ip + (uint64_t)extra > n) return -1;
+          len = 0;
+          for (int i = 0; i < extra; i++) len |= (uint64_t)src[ip + i] << (8 * i);
+          len += 1;
+          ip += (uint64_t)extra;
+        }
+        if (ip + len > n || op + len > (uint64_t)want) return -1;
+        memcpy(dst + op, src + ip, len);
+        ip += len;
+        op += len;
+        continue;
+      }
+      case 1:
+        if (ip + 1 > n) return -1;
+        len = (uint64_t)((tag >> 2) & 7) + 4;
+        offset = ((uint64_t)(tag >> 5) << 8) | src[ip];
+        ip += 1;
+        break;
+      case 2:
+        if (ip + 2 > n) return -1;
+        len = (uint64_t)(tag >> 2) + 1;
+        offset = (uint64_t)src[ip] | ((uint64_t)src[ip + 1] << 8);
+        ip += 2;
+        break;
+      default:
+        if (ip + 4 > n) return -1;
+        len = (uint64_t)(tag >> 2) + 1;
+        offset = (uint64_t)src[ip] | ((uint64_t)src[ip + 1] << 8) | ((uint64_t)src[ip + 2] << 16) | ((uint64_t)src[ip + 3] << 24);
+        ip += 4;
+        break;
+    }
+    if (offset == 0 || offset > op || op + len > (uint64_t)want) return -1;
+    for (uint64_t i = 0; i < len; i++) dst[op + i] = dst[op - offset + i];   /* byte by byte: overlapping copies repeat the pattern */
+    op += len;
+  }
+  return op == (uint64_t)want ? (int64_t)op : -1;
+}
+
+/* LZ4 block: sequences of token (literal length high nibble, match length - 4 low nibble, 15 = more length bytes follow), literals,
+ * 2-byte little-endian offset, extra match length bytes; the last sequence ends after its literals */
+int64_t po_lz4_decompress(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) {
+  uint64_t ip = 0, op = 0;
+  while (ip < n) {
+    const uint8_t token = src[ip++];
+    uint64_t lit = token >> 4;
+    if (lit == 15) {
+      uint8_t b;
+      do {
+        if (ip >= n) return -1;
+        b = src[ip++];
+        lit += b;
+      } while (b == 255);
+    }
+    if (ip + lit > n || op + lit > cap) return -1;
+    memcpy(dst + op, src + ip, lit);
+    ip += lit;
+    op += lit;
+    if (ip >= n) break;   /* end of block */
+    if (ip + 2 > n) return -1;
+    const uint64_t offset = (uint64_t)src[ip] | ((uint64_t)src[ip + 1] << 8);
+    ip += 2;
+    uint64_t mlen = token & 15;
+    if (mlen == 15) {
+      uint8_t b;
+      do {
+        if (ip >= n) return -1;
+        b = src[ip++];
+        mlen += b;
+      } while (b == 255);
+    }
+    mlen += 4;
+    if (offset == 0 || offset > op || op + mlen > cap) return -1;
+    for (uint64_t i = 0; i < mlen; i++) dst[op + i] = dst[op - offset + i];
+    op += mlen;
+  }
+  return (int64_t)op;
+}
+
+/* ChunkDecompressor#decompress of one chunk by ChunkCompressionType value; returns the decompressed length or -1 */
+int64_t po_chunk_decompress(int32_t compression, const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) {
+  switch (compression) {
+    case 0: if (n > cap) return -1; memcpy(dst, src, n); return (int64_t)n;                     /* PASS_THROUGH */
+    case 1: return po_snappy_uncompress(src, n, dst, cap);                                     /* SNAPPY */
+    case 3: return po_lz4_decompress(src, n, dst, cap);                                        /* LZ4 */
+    case 4: {                                                                                  /* LZ4_LENGTH_PREFIXED */
+      if (n < 4) return -1;
+      const uint64_t want = (uint64_t)src[0] | ((uint64_t)src[1] << 8) | ((uint64_t)src[2] << 16) | ((uint64_t)src[3] << 24);
+      if (want > cap) return -1;
+      const int64_t got = po_lz4_decompress(src + 4, n - 4, dst, want);
+      return got == (int64_t)want ? got : -1;
+    }
+    default: return -1;
+  }
+}

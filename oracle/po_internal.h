@@ -63,6 +63,9 @@ int po_bitmap_contains(const po_bitmap* b, int32_t x);
 /* first set bit >= from, or -1 */
 int64_t po_bitmap_next_set(const po_bitmap* b, int64_t from);
 /* ImmutableRoaringBitmap(ByteBuffer): parses the portable serialization into `dst` (OR-ing into it) */
+int64_t po_snappy_uncompress(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap);
+int64_t po_lz4_decompress(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap);
+int64_t po_chunk_decompress(int32_t compression, const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap);
 int po_roaring_deserialize_or(const uint8_t* blob, uint64_t len, po_bitmap* dst);
 int po_roaring_container_stats(const uint8_t* blob, uint64_t len, int* n_array, int* n_bitmap, int* n_run);
 
@@ -82,6 +85,7 @@ typedef struct po_column {
   /* BaseChunkForwardIndexReader fields */
   int32_t raw_version, raw_num_chunks, raw_docs_per_chunk, raw_entry_len, raw_compression;
   const uint8_t* raw_data;   /* _rawData */
+  uint8_t* raw_owned;        /* compressed chunks, decompressed once into the PASS_THROUGH layout (po_raw_parse_header) */
   int32_t num_docs;
   struct po_bitmap* null_bitmap;   /* NullValueVectorReader#getNullBitmap, NULL if the column has no null value vector */
 } po_column;

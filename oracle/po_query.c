@@ -116,6 +116,7 @@ int32_t po_segment_destroy(void* segp) {
   for (int i = 0; i < seg->n_columns; i++) {
     free(seg->columns[i]->name);
     if (seg->columns[i]->null_bitmap) po_bitmap_free(seg->columns[i]->null_bitmap);
+    free(seg->columns[i]->raw_owned);
     free(seg->columns[i]);
   }
   if (seg->queryable_doc_ids) po_bitmap_free(seg->queryable_doc_ids);
@@ -1062,7 +1063,7 @@ int32_t po_read_var_bytes(const uint8_t* buf, uint64_t len, int32_t doc_id, uint
   if (po_raw_parse_header(&c)) return -1;
   int32_t n = 0;
   const uint8_t* v = po_raw_get_bytes(&c, doc_id, &n);
-  if (n > cap) return -2;
-  memcpy(out, v, (size_t)n);
-  return n;
+  if (n <= cap) memcpy(out, v, (size_t)n);
+  free(c.raw_owned);
+  return n > cap ? -2 : n;
 }

@@ -123,11 +123,40 @@ int po_raw_parse_header(po_column* c) {
   } else {
     c->raw_compression = 1; /* SNAPPY */
   }
-  if (c->raw_compression != 0) {
-    po_set_error("column %s: compressed raw chunks (type %d) are outside the hot path", c->name, c->raw_compression);
-    return -1;
-  }
   int off_size = version <= 2 ? 4 : 8;
+  if (c->raw_compression != 0) {
+    /* BaseChunkForwardIndexReader#decompressChunk (:141-163) decompresses the chunk of the docId being read into the reader
+     * context; the values are the same if every chunk is decompressed once, up front, into the PASS_THROUGH layout (version 3
+     * header, 8-byte chunk offsets) the accessors below read. */
+    if (c->raw_compression != 1 && c->raw_compression != 3 && c->raw_compression != 4) {
+      po_set_error("column %s: chunk compression type %d is not restated (SNAPPY / LZ4 / LZ4_LENGTH_PREFIXED are)", c->name, c->raw_compression);
+      return -1;
+    }
+    const int64_t nc = c->raw_num_chunks;
+    const uint64_t cap = (uint64_t)c->raw_docs_per_chunk * (uint64_t)(4 + c->raw_entry_len);
+    const uint64_t head = 28 + (uint64_t)nc * 8;
+    uint8_t* out = (uint8_t*)po_xcalloc(1, head + (uint64_t)nc * cap + 16);
+    uint64_t pos = head;
+    for (int64_t i = 0; i < nc; i++) {
+      const uint8_t* o = b + data_header_start + i * off_size;
+      int64_t start = off_size == 4 ? (int64_t)(int32_t)po_be32(o) : (int64_t)po_be64(o);
+      int64_t end = i == nc - 1 ? (int64_t)c->fwd_len : (off_size == 4 ? (int64_t)(int32_t)po_be32(o + 4) : (int64_t)po_be64(o + 8));
+      if (start < 0 || end < start || (uint64_t)end > c->fwd_len) { free(out); po_set_error("column %s: bad chunk offsets", c->name); return -1; }
+      int64_t got = po_chunk_decompress(c->raw_compression, b + start, (uint64_t)(end - start), out + pos, cap);
+      if (got < 0) { free(out); po_set_error("column %s: chunk %lld does not decompress", c->name, (long long)i); return -1; }
+      for (int k = 0; k < 8; k++) out[28 + i * 8 + k] = (uint8_t)(pos >> (56 - 8 * k));
+      pos += (uint64_t)got;
+    }
+    const uint32_t hdr[7] = {3, (uint32_t)nc, (uint32_t)c->raw_docs_per_chunk, (uint32_t)c->raw_entry_len, (uint32_t)c->num_docs, 0, 28};
+    for (int w = 0; w < 7; w++) for (int k = 0; k < 4; k++) out[w * 4 + k] = (uint8_t)(hdr[w] >> (24 - 8 * k));
+    c->raw_owned = out;
+    c->fwd = out;
+    c->fwd_len = pos;
+    c->raw_version = 3;
+    c->raw_compression = 0;
+    c->raw_data = out + head;
+    return 0;
+  }
   int64_t raw_start = (int64_t)data_header_start + (int64_t)c->raw_num_chunks * off_size;
   c->raw_data = b + raw_start;
   return 0;

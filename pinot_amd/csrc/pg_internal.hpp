@@ -130,6 +130,8 @@ struct StarTree {
 
 void segment_add_column(Segment& seg, const pg_column_desc& d);
 void segment_add_star_tree(Segment& seg, const pg_star_tree_desc& d);
+void decompress_fixed_byte_chunks(int compression, const uint8_t* file, const std::vector<uint64_t>& offs, uint32_t chunk_bytes,
+                                  uint64_t total_bytes, uint8_t* dst, const char* column);
 void segment_set_null_vector(Segment& seg, const char* column, const void* roaring, uint64_t size);
 void segment_set_queryable_doc_ids(Segment& seg, const void* roaring, uint64_t size);
 

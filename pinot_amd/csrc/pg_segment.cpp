@@ -245,18 +245,36 @@ void segment_add_column(Segment& seg, const pg_column_desc& d) {
       compression = (int32_t)be32(fwd + 20);
       data_header_start = (int32_t)be32(fwd + 24);
     }
-    if (compression != 0)
-      fail(PG_ERR_UNSUPPORTED, "column %s: chunk compression type %d (only PASS_THROUGH raw columns are on the GPU path)",
-           d.name, compression);
     int width = (c.data_type == PG_TYPE_INT || c.data_type == PG_TYPE_FLOAT) ? 4
                 : (c.data_type == PG_TYPE_LONG || c.data_type == PG_TYPE_DOUBLE) ? 8 : 0;
     if (width == 0 || entry_len != width)
       fail(PG_ERR_UNSUPPORTED, "column %s: raw type %d / entry length %d is outside the hot path", d.name, c.data_type, entry_len);
-    uint64_t raw_start = (uint64_t)data_header_start + (uint64_t)num_chunks * (version <= 2 ? 4 : 8);
+    const int off_size = version <= 2 ? 4 : 8;
+    uint64_t raw_start = (uint64_t)data_header_start + (uint64_t)num_chunks * (uint64_t)off_size;
     uint64_t need = (uint64_t)seg.total_docs * (uint64_t)width;
-    if (raw_start + need > fwd_len) fail(PG_ERR_INVALID_ARGUMENT, "raw forward index of %s truncated", d.name);
+    if (raw_start > fwd_len || (compression == 0 && raw_start + need > fwd_len))
+      fail(PG_ERR_INVALID_ARGUMENT, "raw forward index of %s truncated", d.name);
     c.fwd_dev.alloc(padded_docs(seg) * (size_t)width + 64, true);
-    c.fwd_dev.upload(fwd + raw_start, need);
+    if (compression == 0) {
+      c.fwd_dev.upload(fwd + raw_start, need);
+    } else {
+      // compressed chunks: uploaded as stored, decompressed in HBM (pg_decompress.hip)
+      const int32_t docs_per_chunk = (int32_t)be32(fwd + 8);
+      if (docs_per_chunk <= 0 || num_chunks < 0 || (int64_t)num_chunks * docs_per_chunk < seg.total_docs)
+        fail(PG_ERR_INVALID_ARGUMENT, "raw forward index of %s: %d chunks of %d docs for %d docs", d.name, num_chunks, docs_per_chunk, seg.total_docs);
+      std::vector<uint64_t> offs((size_t)num_chunks + 1);
+      for (int32_t i = 0; i < num_chunks; i++) {
+        const uint8_t* o = fwd + data_header_start + (uint64_t)i * (uint64_t)off_size;
+        offs[(size_t)i] = off_size == 4 ? (uint64_t)be32(o) : be64(o);
+      }
+      offs[(size_t)num_chunks] = fwd_len;
+      for (int32_t i = 0; i < num_chunks; i++)
+        if (offs[(size_t)i] > offs[(size_t)i + 1] || offs[(size_t)i] < raw_start)
+          fail(PG_ERR_INVALID_ARGUMENT, "raw forward index of %s: bad chunk offsets", d.name);
+      const int32_t used_chunks = (int32_t)(((int64_t)seg.total_docs + docs_per_chunk - 1) / docs_per_chunk);
+      offs.resize((size_t)used_chunks + 1);   // offs[used_chunks]: start of the first unused chunk, or the end of the index
+      decompress_fixed_byte_chunks(compression, fwd, offs, (uint32_t)docs_per_chunk * (uint32_t)width, need, c.fwd_dev.as<uint8_t>(), d.name);
+    }
     c.col_kind = width == 4 ? PG_COL_RAW32 : PG_COL_RAW64;
     c.fwd_bytes_logical = need;
   } else {

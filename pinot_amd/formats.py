@@ -60,18 +60,50 @@ def unpack_fixed_bit(buf: np.ndarray, bits: int, n: int) -> np.ndarray:
 #   reader: .../readers/forward/BaseChunkForwardIndexReader.java:61-111, FixedByteChunkSVForwardIndexReader.java:53-94
 # ----------------------------------------------------------------------------------------------------------------------
 CHUNK_COMPRESSION_PASS_THROUGH = 0  # ChunkCompressionType.PASS_THROUGH.getValue()
+CHUNK_COMPRESSION_SNAPPY, CHUNK_COMPRESSION_LZ4, CHUNK_COMPRESSION_LZ4_LENGTH_PREFIXED = 1, 3, 4
+
+
+def compress_chunk(chunk: bytes, compression: int) -> bytes:
+    """Test writer for ChunkCompressor#compress: libsnappy / liblz4 through pyarrow (raw snappy, raw LZ4 block; the
+    LZ4_LENGTH_PREFIXED form of lz4-java's LZ4CompressorWithLength puts the little-endian decompressed length in front)."""
+    if compression == CHUNK_COMPRESSION_PASS_THROUGH:
+        return chunk
+    import pyarrow as pa
+    if compression == CHUNK_COMPRESSION_SNAPPY:
+        return pa.compress(chunk, codec="snappy", asbytes=True)
+    if compression == CHUNK_COMPRESSION_LZ4:
+        return pa.compress(chunk, codec="lz4_raw", asbytes=True)
+    if compression == CHUNK_COMPRESSION_LZ4_LENGTH_PREFIXED:
+        return struct.pack("<i", len(chunk)) + pa.compress(chunk, codec="lz4_raw", asbytes=True)
+    raise ValueError(f"chunk compression type {compression}")
 
 _BE_DTYPES = {"INT": ">i4", "LONG": ">i8", "FLOAT": ">f4", "DOUBLE": ">f8"}
 _WIDTHS = {"INT": 4, "LONG": 8, "FLOAT": 4, "DOUBLE": 8}
 
 
 def write_raw_fixed_byte_chunk(values: np.ndarray, data_type: str, version: int = 2,
-                               docs_per_chunk: int = 1000) -> np.ndarray:
+                               docs_per_chunk: int = 1000, compression: int = CHUNK_COMPRESSION_PASS_THROUGH) -> np.ndarray:
     """Header(version, numChunks, numDocsPerChunk, sizeOfEntry, totalDocs, compressionType, dataHeaderStart=28),
-    chunk start offsets (int for v2, long for v3+), then the big-endian values back to back."""
+    chunk start offsets (int for v2, long for v3+), then the big-endian values back to back — or, with a compression type,
+    every chunk compressed on its own (BaseChunkForwardIndexWriter#writeChunk :179-198)."""
     assert version in (2, 3, 4)
     width = _WIDTHS[data_type]
     n = int(values.shape[0])
+    if compression != CHUNK_COMPRESSION_PASS_THROUGH:
+        assert version in (2, 3)
+        num_chunks = (n + docs_per_chunk - 1) // docs_per_chunk
+        off_size = 4 if version == 2 else 8
+        data = np.ascontiguousarray(values).astype(_BE_DTYPES[data_type]).tobytes()
+        step = docs_per_chunk * width
+        chunks = [compress_chunk(data[i * step:(i + 1) * step], compression) for i in range(num_chunks)]
+        pos = 7 * 4 + num_chunks * off_size
+        starts = []
+        for ch in chunks:
+            starts.append(pos)
+            pos += len(ch)
+        header = struct.pack(">7i", version, num_chunks, docs_per_chunk, width, n, compression, 28)
+        off_bytes = np.asarray(starts, dtype=np.int64).astype(">i4" if off_size == 4 else ">i8").tobytes()
+        return np.frombuffer(header + off_bytes + b"".join(chunks), dtype=np.uint8)
     if version >= 4 and (docs_per_chunk & (docs_per_chunk - 1)) != 0:
         docs_per_chunk = 1 << (docs_per_chunk - 1).bit_length()  # normalizeDocsPerChunk
     num_chunks = (n + docs_per_chunk - 1) // docs_per_chunk

@@ -68,7 +68,8 @@ class HostSegment:
 
 
 def build_column(name: str, values, data_type: str, *, dictionary: bool = True, inverted: bool = False,
-                 raw_version: int = 2, run_compress: bool = True) -> HostColumn:
+                 raw_version: int = 2, run_compress: bool = True, chunk_compression: int = 0,
+                 docs_per_chunk: int = 1000) -> HostColumn:
     if data_type == "STRING":
         vals = np.asarray(values, dtype=object)
         assert dictionary, "raw STRING columns are outside the hot path"
@@ -80,7 +81,8 @@ def build_column(name: str, values, data_type: str, *, dictionary: bool = True, 
     else:
         vals = np.ascontiguousarray(values, dtype=NUMERIC_NP[data_type])
         if not dictionary:
-            fwd = formats.write_raw_fixed_byte_chunk(vals, data_type, version=raw_version)
+            fwd = formats.write_raw_fixed_byte_chunk(vals, data_type, version=raw_version, docs_per_chunk=docs_per_chunk,
+                                                     compression=chunk_compression)
             return HostColumn(name, data_type, capi.FWD_RAW_FIXED_BYTE_CHUNK, False, 0, 0,
                               bool(np.all(vals[1:] >= vals[:-1])) if len(vals) else True, 0, fwd)
         uniq, dict_ids = np.unique(vals, return_inverse=True)

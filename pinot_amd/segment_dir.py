@@ -12,7 +12,7 @@ star-tree files `star_tree_index` / `star_tree_index_map` (SURVEY.md §8f rank 1
                 (pinot-segment-local/.../startree/v2/store/StarTreeIndexMapUtils.java)
 Reader dispatch follows ForwardIndexReaderFactory.java:74-109: dictionary + sorted → SortedIndexReaderImpl; dictionary SV →
 FixedBitSVForwardIndexReaderV2; raw fixed-width SV → FixedByteChunkSVForwardIndexReader.  Multi-value columns, variable-length
-dictionaries and compressed raw chunks are outside the hot path and are skipped (listed in `HostSegment.skipped`).
+dictionaries and ZSTANDARD / GZIP raw chunks are outside the hot path and are skipped (listed in `HostSegment.skipped`).
 
 Pinned by the reference's own segment metadata (tests/golden/startree_airline/segment_meta.json: the index_map and column
 metadata of a segment the reference built): every entry size follows the layouts this module assumes.
@@ -156,7 +156,8 @@ def load_segment_dir(path: str) -> HostSegment:
                 seg.skipped[name] = "raw variable-length column"
                 continue
             h = formats.parse_raw_fixed_byte_chunk_header(fwd)
-            if h["compression"] != formats.CHUNK_COMPRESSION_PASS_THROUGH:
+            if h["compression"] not in (formats.CHUNK_COMPRESSION_PASS_THROUGH, formats.CHUNK_COMPRESSION_SNAPPY,
+                                        formats.CHUNK_COMPRESSION_LZ4, formats.CHUNK_COMPRESSION_LZ4_LENGTH_PREFIXED):
                 seg.skipped[name] = f"compressed raw chunks (type {h['compression']})"
                 continue
             seg.columns[name] = HostColumn(name, dt, capi.FWD_RAW_FIXED_BYTE_CHUNK, False, 0, 0,
