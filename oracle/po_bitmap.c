@@ -28,6 +28,16 @@ po_bitmap* po_bitmap_new(int64_t universe) {
   return b;
 }
 
+/* a set over a small universe (the dictIds one group has seen): whole 64-bit words, no container rounding */
+po_bitmap* po_bitmap_new_small(int64_t universe) {
+  po_bitmap* b = (po_bitmap*)po_xcalloc(1, sizeof(po_bitmap));
+  b->universe = universe;
+  b->n_words = (universe + 63) / 64;
+  if (b->n_words < 1) b->n_words = 1;
+  b->words = (uint64_t*)po_xcalloc((size_t)b->n_words, 8);
+  return b;
+}
+
 po_bitmap* po_bitmap_clone(const po_bitmap* s) {
   po_bitmap* b = (po_bitmap*)po_xmalloc(sizeof(po_bitmap));
   *b = *s;

@@ -51,6 +51,7 @@ typedef struct po_bitmap {
 } po_bitmap;
 
 po_bitmap* po_bitmap_new(int64_t universe);
+po_bitmap* po_bitmap_new_small(int64_t universe);
 po_bitmap* po_bitmap_clone(const po_bitmap* b);
 void po_bitmap_free(po_bitmap* b);
 void po_bitmap_add(po_bitmap* b, int32_t x);

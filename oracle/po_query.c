@@ -583,7 +583,7 @@ static void agg_process_block(agg_state* a, block_col* bc, const int32_t* doc_id
         for (int i = 0; i < n; i++) {
           int32_t g = group_keys ? group_keys[i] : 0;
           if (g == PO_INVALID_ID) continue;
-          if (!a->dict_bitmaps[g]) a->dict_bitmaps[g] = po_bitmap_new(c->cardinality);
+          if (!a->dict_bitmaps[g]) a->dict_bitmaps[g] = po_bitmap_new_small(c->cardinality);
           po_bitmap_add(a->dict_bitmaps[g], bc->dict_ids[i]);
         }
       } else if (a->function == PG_AGG_DISTINCTCOUNTHLL) {
@@ -685,6 +685,7 @@ static void extract_agg(po_agg_result* r, agg_state* a, int32_t n_groups, const 
       po_hll* h = a->col->has_dictionary ? hll_from_dict_bitmap(a->dict_bitmaps[g], a->col, a->log2m)
                                          : (a->hlls[g] ? a->hlls[g] : po_hll_new(a->log2m));
       memcpy(r->hll + (size_t)i * (size_t)m, h->regs, (size_t)m);
+      if (a->col->has_dictionary || !a->hlls[g]) po_hll_free(h);
     }
     return;
   }
@@ -693,7 +694,10 @@ static void extract_agg(po_agg_result* r, agg_state* a, int32_t n_groups, const 
     switch (a->function) {
       case PG_AGG_COUNT: r->l[0][i] = (int64_t)a->d0[g]; break;          /* extractGroupByResult: (long) double */
       case PG_AGG_AVG: r->d[0][i] = a->d0[g]; r->l[0][i] = a->l0[g]; break;
-      case PG_AGG_MINMAXRANGE: r->d[0][i] = a->d0[g]; r->d[1][i] = a->d1[g]; break;
+      case PG_AGG_MINMAXRANGE:   /* extractAggregationResult / extractGroupByResult (:162-181): no value → new MinMaxRangePair() = (+inf, -inf) */
+        r->d[0][i] = a->has[g] ? a->d0[g] : INFINITY;
+        r->d[1][i] = a->has[g] ? a->d1[g] : -INFINITY;
+        break;
       default: r->d[0][i] = a->d0[g]; break;
     }
   }
@@ -805,7 +809,7 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
           case PG_AGG_MAX: a->d0[0] = po_dict_get_double(c, c->cardinality - 1); break;
           case PG_AGG_MINMAXRANGE: a->d0[0] = po_dict_get_double(c, 0); a->d1[0] = po_dict_get_double(c, c->cardinality - 1); a->has[0] = 1; break;
           default: /* DISTINCTCOUNT / DISTINCTCOUNTHLL: every dictionary value */
-            a->dict_bitmaps[0] = po_bitmap_new(c->cardinality);
+            a->dict_bitmaps[0] = po_bitmap_new_small(c->cardinality);
             po_bitmap_add_range(a->dict_bitmaps[0], 0, c->cardinality);
             break;
         }

@@ -345,3 +345,15 @@ def test_var_byte_raw_v2_golden(oracle_api):
     for i in (0, 1, 2, 3, 500, 998, 999):
         n = oracle_api.lib.po_read_var_bytes(blob.ctypes.data, blob.nbytes, i, out, 64)
         assert out.raw[:n] == data[i % 4]
+
+
+def test_minmaxrange_without_matches_is_the_empty_pair(oracle_api, sv_data):
+    """MinMaxRangeAggregationFunction#extractAggregationResult / #extractGroupByResult (:162-181): a holder that saw no value
+    yields `new MinMaxRangePair()` = (+inf, -inf) (pinot-segment-local/.../customobject/MinMaxRangePair.java:29-31), MIN / MAX their
+    DEFAULT_VALUEs, SUM 0.0, AVG the pair (0.0, 0) — found by the GPU-vs-oracle fuzz (tests/test_fuzz.py)."""
+    seg = NativeSegment(oracle_api, sv_segment(sv_data))
+    b = seg.execute("SELECT MINMAXRANGE(column1), MIN(column1), MAX(column1), SUM(column1), AVG(column1), COUNT(*) FROM testTable "
+                    "WHERE column1 < 0")
+    inf = float("inf")
+    assert b.aggregation_result() == [(inf, -inf), inf, -inf, 0.0, (0.0, 0), 0]
+    seg.destroy()
