@@ -35,11 +35,11 @@ def pack_fixed_bit(values: np.ndarray, bits: int) -> np.ndarray:
     out = np.zeros(total_bytes, dtype=np.uint8)
     if n == 0:
         return out
-    shifts = np.arange(bits - 1, -1, -1, dtype=np.uint32)
     chunk = 1 << 21  # multiple of 8 => every chunk starts on a byte boundary
     for start in range(0, n, chunk):
         v = values[start:start + chunk]
-        b = ((v[:, None] >> shifts[None, :]) & 1).astype(np.uint8).reshape(-1)
+        # the 32 bits of every value MSB first, of which the low `bits` are kept
+        b = np.unpackbits(v.astype(">u4").view(np.uint8).reshape(-1, 4), axis=1)[:, 32 - bits:].reshape(-1)
         packed = np.packbits(b)  # big-endian bit order within bytes
         off = (start * bits) // 8
         out[off:off + packed.shape[0]] = packed

@@ -73,9 +73,9 @@ def build_column(name: str, values, data_type: str, *, dictionary: bool = True, 
     if data_type == "STRING":
         vals = np.asarray(values, dtype=object)
         assert dictionary, "raw STRING columns are outside the hot path"
-        uniq = sorted(set(vals.tolist()))  # Java String.compareTo == code-point order for BMP/ASCII test data
-        index = {v: i for i, v in enumerate(uniq)}
-        dict_ids = np.fromiter((index[v] for v in vals.tolist()), dtype=np.int32, count=len(vals))
+        uq, inv = np.unique(vals.astype(str), return_inverse=True)  # Java String.compareTo == code-point order for BMP/ASCII test data
+        uniq = [str(v) for v in uq.tolist()]
+        dict_ids = inv.astype(np.int32)
         dict_buf, width = formats.write_string_dictionary(uniq)
         dict_values = list(uniq)
     else:
