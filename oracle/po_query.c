@@ -329,7 +329,7 @@ static int gkg_init(group_key_gen* g, int n_cols, po_column** cols, int32_t num_
     int32_t card = cols[i]->cardinality;
     g->cardinalities[i] = card;
     if (!long_overflow) {
-      if (product > INT64_MAX / card) long_overflow = 1;
+      if (card > 0 && product > INT64_MAX / card) long_overflow = 1;   /* card 0: an empty segment (pruned before planning in the reference) */
       else product *= card;
     }
   }

@@ -1,0 +1,121 @@
+"""BASELINE.json's full sizes (10^9-doc segment, config 3 / north star) and the format's maximum (2^31 - 1 docs) on the GPU,
+checked through size-independent properties — the oracle would need minutes per query at these sizes:
+  * linearity      Q over a doc-partitioning pair of filters merges (SUM / COUNT add, MAX is max) into Q over their union
+  * complement     COUNT(F) + COUNT(NOT F) = totalDocs
+  * marginals      the north-star table (g1, g2) summed over g2 is the config-3 table (g1)
+  * idempotence    the same query twice gives identical bytes
+  * two routes     BETWEEN (one range scan, specialised kernel) == the same bounds as two comparisons (scan chain kernel)
+plus an empty segment (totalDocs = 0).  PG_TEST_FULL_DOCS shrinks the big segment for local debugging."""
+import os
+
+import numpy as np
+import pytest
+
+from pinot_amd import synth
+from pinot_amd.executor import NativeSegment
+from pinot_amd.segment import HostSegment, build_segment
+
+FULL_DOCS = int(os.environ.get("PG_TEST_FULL_DOCS", "1000000000"))
+MAX_DOCS = int(os.environ.get("PG_TEST_MAX_DOCS", str((1 << 31) - 1)))
+PRE = "c_inv1 IN (0,1,2,3) AND c_inv2 IN (0,1) AND "
+
+
+def stream_segment(api, num_docs, columns):
+    """pins the columns one at a time so that the host never holds more than one of them"""
+    seg = NativeSegment(api, HostSegment("gpuBench_0", num_docs))
+    for name in columns:
+        one = synth.generate_segment(num_docs, segment_index=0, columns=[name])
+        seg.add_column(one.columns[name], keep_host_buffers=False)
+        del one
+    return seg
+
+
+def merged(a, b):
+    out = {}
+    for rows in (a, b):
+        for k, (s, mx) in rows.items():
+            if k in out:
+                out[k] = [out[k][0] + s, max(out[k][1], mx)]
+            else:
+                out[k] = [s, mx]
+    return out
+
+
+@pytest.mark.gpu
+def test_full_size_segment_properties(gpu_api):
+    seg = stream_segment(gpu_api, FULL_DOCS, ["c_inv1", "c_inv2", "r_int", "g1", "g2", "m"])
+    n = FULL_DOCS
+    q3 = "SELECT g1, SUM(m), MAX(m) FROM gpuBench WHERE " + PRE + "r_int BETWEEN {} AND {} GROUP BY g1 LIMIT 1000"
+    whole = seg.execute(synth.QUERY_CFG3)
+    assert whole.stats.num_total_docs == n
+    rows = whole.rows()
+    assert len(rows) == 100
+    # idempotence
+    again = seg.execute(synth.QUERY_CFG3)
+    assert again.rows() == rows and again.stats.num_docs_scanned == whole.stats.num_docs_scanned
+    # linearity over a partition of the range predicate
+    lo, hi = seg.execute(q3.format(250000, 499999)), seg.execute(q3.format(500000, 749999))
+    assert merged(lo.rows(), hi.rows()) == rows
+    assert lo.stats.num_docs_scanned + hi.stats.num_docs_scanned == whole.stats.num_docs_scanned
+    # the same bounds through the scan-chain kernel
+    two = seg.execute("SELECT g1, SUM(m), MAX(m) FROM gpuBench WHERE " + PRE + "r_int >= 250000 AND r_int <= 749999 GROUP BY g1 LIMIT 1000")
+    assert two.rows() == rows
+    # marginals of the north-star table
+    ns = seg.execute(synth.QUERY_NORTH_STAR).rows()
+    assert len(ns) == 5000
+    marg = {}
+    for (k1, _k2), (s,) in ns.items():
+        marg[(k1,)] = marg.get((k1,), 0.0) + s
+    assert marg == {k: v[0] for k, v in rows.items()}
+    # complement
+    c_in = seg.execute(synth.QUERY_CFG2).aggregation_result()[0]
+    c_out = seg.execute("SELECT COUNT(*) FROM gpuBench WHERE NOT (r_int BETWEEN 250000 AND 749999)").aggregation_result()[0]
+    assert c_in + c_out == n
+    assert abs(c_in / n - 0.5) < 1e-3          # r_int is uniform over [0, 10^6)
+    # every doc belongs to exactly one (c_inv1, c_inv2) posting pair
+    per_pair = seg.execute("SELECT c_inv1, c_inv2, COUNT(*) FROM gpuBench GROUP BY c_inv1, c_inv2 LIMIT 100").rows()
+    assert len(per_pair) == 32 and sum(v[0] for v in per_pair.values()) == n
+    seg.destroy()
+
+
+@pytest.mark.gpu
+def test_maximum_segment_size(gpu_api):
+    """2^31 - 1 docs (docIds are Java ints): doc / byte / bit offsets beyond 32 bits in every kernel that walks the columns"""
+    seg = stream_segment(gpu_api, MAX_DOCS, ["r_int", "g1", "c_inv2"])
+    n = MAX_DOCS
+    c_in = seg.execute(synth.QUERY_CFG2).aggregation_result()[0]
+    c_out = seg.execute("SELECT COUNT(*) FROM gpuBench WHERE r_int < 250000 OR r_int > 749999").aggregation_result()[0]
+    assert c_in + c_out == n and abs(c_in / n - 0.5) < 1e-3
+    g = seg.execute("SELECT g1, COUNT(*), MAX(r_int) FROM gpuBench GROUP BY g1 LIMIT 1000").rows()
+    assert len(g) == 100 and sum(v[0] for v in g.values()) == n
+    assert all(abs(v[0] / n - 0.01) < 1e-4 for v in g.values())
+    lo = seg.execute("SELECT g1, COUNT(*), MAX(r_int) FROM gpuBench WHERE c_inv2 IN (0, 1) GROUP BY g1 LIMIT 1000").rows()
+    hi = seg.execute("SELECT g1, COUNT(*), MAX(r_int) FROM gpuBench WHERE c_inv2 NOT IN (0, 1) GROUP BY g1 LIMIT 1000").rows()
+    assert merged(lo, hi) == g
+    # the last docs of the segment are reachable: the docIds of a selective filter end near numDocs
+    d = seg.filter("SELECT COUNT(*) FROM gpuBench WHERE r_int = 123456 AND c_inv2 = 3")
+    ids = d.doc_ids()
+    assert len(ids) == d.cardinality() and (np.diff(ids) > 0).all() and ids[-1] < n and ids[-1] > n - 50_000_000
+    seg.destroy()
+
+
+@pytest.mark.gpu
+def test_empty_segment(gpu_api, oracle_api):
+    """totalDocs = 0.  The reference never plans such a segment (empty segments are pruned first, and their dictionaries hold no
+    value): raw columns run and give the identities; an empty dictionary is refused at registration, not crashed on."""
+    from pinot_amd import capi
+    data = {"r": np.array([], dtype=np.int32), "m": np.array([], dtype=np.int64)}
+    host = build_segment("empty_0", data, {"r": "INT", "m": "LONG"}, no_dictionary_columns=["r", "m"])
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    for q in ("SELECT COUNT(*), SUM(r), MIN(r), MAX(m), AVG(m), MINMAXRANGE(r) FROM t", "SELECT COUNT(*) FROM t WHERE r > 5",
+              "SELECT r, COUNT(*) FROM t GROUP BY r LIMIT 10", "SELECT m, SUM(r) FROM t WHERE r BETWEEN 1 AND 2 GROUP BY m LIMIT 10"):
+        gb, ob = g.execute(q), o.execute(q)
+        assert gb.rows() == ob.rows(), q
+        assert gb.stats.num_docs_scanned == ob.stats.num_docs_scanned == 0
+    assert g.filter("SELECT COUNT(*) FROM t WHERE r < 3").cardinality() == 0
+    g.destroy()
+    o.destroy()
+    host = build_segment("empty_1", {"a": np.array([], dtype=np.int32)}, {"a": "INT"})
+    with pytest.raises(capi.NativeError) as e:
+        NativeSegment(gpu_api, host)
+    assert e.value.status == capi.PG_ERR_INVALID_ARGUMENT
