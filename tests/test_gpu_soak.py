@@ -1,0 +1,102 @@
+"""Long-running-server behaviour of libpinot_gpu.so: thousands of queries and repeated segment load / destroy cycles must not
+leak HBM or host memory; swapping the upsert queryableDocIds snapshot while other threads query the same segment must give
+every query the answer of one of the snapshots (a running query keeps the plan, and the bitmap, it started with)."""
+import threading
+
+import numpy as np
+import psutil
+import pytest
+
+from pinot_amd import synth
+from pinot_amd.executor import NativeSegment
+from tests.fuzz_queries import Gen, clone, fuzz_segment
+
+
+def _free_hbm():
+    import torch
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info()[0]
+
+
+@pytest.mark.gpu
+def test_no_memory_growth_over_thousands_of_queries(gpu_api):
+    from pinot_amd import capi
+    host, data, _ = fuzz_segment(60_000, seed=9)
+    g = NativeSegment(gpu_api, host)
+    gen = Gen(data, seed=4242)
+    queries = [gen.query() for _ in range(150)]
+
+    def run_all():
+        for q in queries:
+            try:
+                g.execute(clone(q))
+            except capi.NativeError as e:
+                assert e.status == capi.PG_ERR_UNSUPPORTED
+    for _ in range(2):
+        run_all()                      # warm: per-thread workspaces reach their high-water mark, plans are cached
+    free0, rss0 = _free_hbm(), psutil.Process().memory_info().rss
+    for _ in range(20):                # 3 000 queries
+        run_all()
+    free1, rss1 = _free_hbm(), psutil.Process().memory_info().rss
+    assert free0 - free1 < 32 << 20, f"HBM grew by {(free0 - free1) >> 20} MB over 3000 queries"
+    assert rss1 - rss0 < 128 << 20, f"host RSS grew by {(rss1 - rss0) >> 20} MB over 3000 queries"
+    g.destroy()
+
+
+@pytest.mark.gpu
+def test_segment_load_destroy_cycles_return_their_memory(gpu_api):
+    host = synth.generate_segment(400_000, segment_index=2)
+    first = NativeSegment(gpu_api, host)
+    first.execute(synth.QUERY_CFG3)
+    first.destroy()
+    free0, rss0 = _free_hbm(), psutil.Process().memory_info().rss
+    for _ in range(40):
+        seg = NativeSegment(gpu_api, host)
+        seg.execute(synth.QUERY_CFG3)
+        seg.execute(synth.QUERY_CFG5)
+        seg.destroy()
+    free1, rss1 = _free_hbm(), psutil.Process().memory_info().rss
+    assert free0 - free1 < 32 << 20, f"HBM not returned: {(free0 - free1) >> 20} MB after 40 load/destroy cycles"
+    assert rss1 - rss0 < 128 << 20, f"host RSS grew by {(rss1 - rss0) >> 20} MB after 40 load/destroy cycles"
+
+
+@pytest.mark.gpu
+def test_snapshot_swaps_under_concurrent_queries(gpu_api, oracle_api):
+    n = 300_000
+    host = synth.generate_segment(n, segment_index=4, columns=synth.CFG3_COLUMNS)
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    rng = np.random.default_rng(0)
+    snapshots = [np.flatnonzero(rng.random(n) < p) for p in (0.9, 0.5, 0.2)]
+    q = synth.QUERY_CFG3
+    expected = []
+    for ids in snapshots:
+        o.set_queryable_doc_ids(ids)
+        expected.append(o.execute(q).rows())
+    o.destroy()
+    g.set_queryable_doc_ids(snapshots[0])
+    stop = threading.Event()
+    errors, seen = [], set()
+
+    def worker():
+        try:
+            while not stop.is_set():
+                rows = g.execute(q).rows()
+                which = [i for i, e in enumerate(expected) if e == rows]
+                if not which:
+                    errors.append("a query saw a mixture of snapshots")
+                    return
+                seen.add(which[0])
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker) for _ in range(6)]
+    for t in threads:
+        t.start()
+    for i in range(60):
+        g.set_queryable_doc_ids(snapshots[i % 3])
+    stop.set()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]
+    assert len(seen) >= 2
+    g.destroy()
