@@ -117,6 +117,10 @@ def test_gpu_matches_oracle_on_random_queries(gpu_api, oracle_api, fuzz, seed, w
             continue
         try:
             _compare(gb, ob, what)
+            if i % 3 == 0:              # the filter-only entry point (FilterOperator + DocIdSetOperator): same docIds
+                gd, od = g.filter(clone(q)), o.filter(clone(q))
+                assert gd.cardinality() == od.cardinality(), what
+                np.testing.assert_array_equal(gd.doc_ids(), od.doc_ids(), err_msg=what)
         except AssertionError as e:     # keep going: one run reports every disagreement
             mismatches.append(str(e)[:600])
     assert not mismatches, "\n".join(mismatches[:12])
