@@ -230,6 +230,8 @@ struct PgQueryPlan {
   int64_t radix_stride;             // 8 without sources, else 8 + 8 * n_srcs rounded up to 16 (hash: {u64 key, u32 docId, u32 0} + 8 per source)
   int32_t n_lin_prefix;             // interpreter kernels: instrs[0, n_lin_prefix) is index-only and leaves one stack entry
   int32_t n_fast_scans;             // pg_fast_multi_*: instrs[n_index_instr, n_index_instr + n_fast_scans) are scan leaves ANDed in order
+  int32_t tail_posting;             // pg_fast_multi_*: posting leaf ANDed in AFTER the scans (-1: none) — the queryableDocIds bitmap of
+  int32_t tail_pad;                 //   FilterPlanNode.run's outer AND, which must not restrict the inner AND's scans (exact scan counts)
   int32_t n_parts;                  // PG_AGG_LDS_PART: key ranges (the grid is 8 x a multiple of it)
   int32_t part_groups;              // PG_AGG_LDS_PART: keys per range
   PgAuxOp aux[PG_MAX_AUX];

@@ -1201,6 +1201,8 @@ __device__ __forceinline__ void fast_multi_body(const PgQueryPlan& p) {
         }
       }
     }
+    if (p.tail_posting >= 0 && __ballot(m != 0))   // wave-uniform
+      m &= lin_to_quad(postings_wtile(cptr(p.postings)[p.tail_posting], wt, valid_lin_mask(n_valid, lane), s_wscratch[wave], lane), lane);
     const uint32_t cnt = (uint32_t)__popc(m);
     my_matched += cnt;
     if (p.out_words) reinterpret_cast<uint32_t*>(p.out_words)[(int64_t)wt * 64 + lane] = quad_to_lin(m, lane);

@@ -534,6 +534,9 @@ struct Emitter {
           else if (yields_bitmap(*c)) index_based.push_back(c.get());   // a nested AND whose iterator is a RangelessBitmapDocIdIterator
           else remaining.push_back(c.get());
         }
+        // nested ANDs first, plain index leaves after them: AND(AND(index.., scans..), queryableDocIds) then reads
+        // [index..][AND_SCAN..][PUSH_POSTINGS, AND], the form the chain kernels take (set algebra does not care about the order)
+        std::stable_partition(index_based.begin(), index_based.end(), [](const FilterOp* c) { return c->kind == OpKind::And; });
         bool first = true;
         for (auto* c : index_based) {
           emit(*c, false);
@@ -844,7 +847,19 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
       }
       D.n_lin_prefix = (int32_t)best;
     }
-    size_t rest = em.instrs.size() - n_idx;
+    // [index program] AND_SCAN ... AND_SCAN, PUSH_POSTINGS, AND: the nested AND of FilterPlanNode.run followed by the
+    // queryableDocIds bitmap — the chain kernels AND that posting leaf in after the scans (the scans keep their exact counts)
+    size_t n_total = em.instrs.size();
+    D.tail_posting = -1;
+    if (n_idx > 0 && n_total >= n_idx + 3 && em.instrs[n_total - 1].op == PG_F_AND && em.instrs[n_total - 2].op == PG_F_PUSH_POSTINGS) {
+      bool scans_only = true;
+      for (size_t i = n_idx; i + 2 < n_total; i++) scans_only &= em.instrs[i].op == PG_F_AND_SCAN;
+      if (scans_only) {
+        D.tail_posting = em.instrs[n_total - 2].arg;
+        n_total -= 2;
+      }
+    }
+    size_t rest = n_total - n_idx;
     bool has_words = false;   // match-word leaves (star-tree traversals with many ranges) are the interpreter kernels' business
     for (auto& in : em.instrs) has_words |= in.op == PG_F_PUSH_WORDS;
     if (has_words) rest = 1000;
@@ -859,7 +874,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
       P.fast_filter = -1;
       D.n_index_instr = (int32_t)n_idx;
       if (n_idx == 1 && em.instrs[0].op == PG_F_PUSH_ALL) D.n_index_instr = 0;   // match-all: the valid mask itself
-    } else if (rest == 1 && ((n_idx == 0 && em.instrs[0].op == PG_F_PUSH_SCAN) || (n_idx > 0 && em.instrs[n_idx].op == PG_F_AND_SCAN))) {
+    } else if (rest == 1 && D.tail_posting < 0 && ((n_idx == 0 && em.instrs[0].op == PG_F_PUSH_SCAN) || (n_idx > 0 && em.instrs[n_idx].op == PG_F_AND_SCAN))) {
       const int k = scan_kind(em.scans[em.instrs[n_idx].arg]);
       if (k >= 0) {
         P.fast_filter = k;
@@ -878,7 +893,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
         return L.pred_kind == PG_P_RANGE;
       };
       bool ok = true;
-      for (size_t i = n_idx; i < em.instrs.size() && ok; i++) {
+      for (size_t i = n_idx; i < n_total && ok; i++) {
         const int op = em.instrs[i].op;
         ok = (op == PG_F_AND_SCAN || (i == 0 && op == PG_F_PUSH_SCAN)) && multi_kind(em.scans[em.instrs[i].arg]);
       }
@@ -893,9 +908,12 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
         D.n_fast_scans = (int32_t)rest;
         D.fast_scan_pushed = n_idx == 0 ? 1 : 0;
         if (n_idx == 1 && em.instrs[0].op == PG_F_PUSH_ALL) { /* cannot happen: and_operator drops match-all children */ }
+      } else {
+        D.tail_posting = -1;
       }
     }
   }
+  if (P.fast_filter != 100) D.tail_posting = -1;
   P.lds_bytes = 0;   // the filter stack lives in registers
   if (!q || q->n_aggregations <= 0) return plan;
 

@@ -15,7 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--docs", type=int, default=200_000_000)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--only", default="", help="substring of the query names to run")
-ap.add_argument("--set", choices=["cfg3", "cfg5", "general", "wide"], default="cfg3")
+ap.add_argument("--set", choices=["cfg3", "cfg5", "general", "wide", "upsert"], default="cfg3")
 args = ap.parse_args()
 api = capi.gpu_api()
 api.call("init", 0)
@@ -80,6 +80,13 @@ QUERIES_WIDE = {   # LDS-table aggregations over 64-bit sources / an 11-bit grou
     "filtered sum(m64) group w1": ("SELECT w1, SUM(m64) FROM t WHERE r_int BETWEEN 250000 AND 749999 GROUP BY w1 LIMIT 5000", 13.375),
     "sum(m64) no group": ("SELECT SUM(m64), MIN(m64), COUNT(*) FROM t WHERE c_inv2 = 1", 8.125),
 }
+if args.set == "upsert":   # the same shapes behind an upsert queryableDocIds snapshot (90 % of the docs valid): +1 bit per doc
+    import numpy as np
+    rng = np.random.default_rng(0)
+    bits = rng.random(args.docs) < 0.9
+    seg.set_queryable_doc_ids(np.flatnonzero(bits))
+    del bits
+    QUERIES = {k: (sql, bpr + 0.125) for k, (sql, bpr) in QUERIES.items() if k in ("cfg2 count(range scan)", "cfg3 filter only count", "cfg3", "northstar", "no filter sum(m) group g1")}
 if args.set == "cfg5":
     QUERIES = QUERIES5
 if args.set == "wide":
