@@ -27,6 +27,7 @@ extern "C" __global__ void pg_radix_bucket_scan_kernel(const uint32_t* bucket_to
 extern "C" __global__ void pg_radix_reduce_kernel(const int64_t* partials, int64_t* out, int n_ops, int n_groups, int radix_shift, int slices,
                                                    const PgAccOp* ops);
 extern "C" __global__ void pg_reduce_aux_kernel(const uint32_t* partials, uint32_t* out, int n_wg, int64_t n_words, int bytewise_max);
+extern "C" __global__ void pg_radix_reduce_aux_kernel(const uint32_t* partials, uint32_t* out, int slices, int64_t bucket_words, int64_t n_words);
 extern "C" __global__ void pg_fill_i64_kernel(int64_t* dst, int64_t n_per_op, int n_ops, const PgAccOp* ops);
 extern "C" __global__ void pg_expand_docids_kernel(const uint64_t* words, const int64_t* tile_offsets, int32_t* out,
                                                    int n_tiles);
@@ -294,15 +295,21 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   size_t aux_total = 0;
   for (size_t b : P.aux_bytes) aux_total += b;
   std::vector<uint32_t*> aux_final((size_t)D.n_aux, nullptr);
+  const bool radix_aux = D.agg_mode == PG_AGG_RADIX && D.n_aux > 0;   // HLL registers of a bucket in LDS, one partial per work item
+  if (radix_aux) D.radix_slices = std::max(1, g_num_cus / D.radix_buckets);
   if (aux_total) {
     // LDS-resident states: the kernel writes one partial per workgroup behind the merged regions
-    const size_t partial_total = P.aux_in_lds ? aux_total * (size_t)shape.grid : 0;
+    size_t partial_total = P.aux_in_lds ? aux_total * (size_t)shape.grid : 0;
+    const size_t radix_items = (size_t)D.radix_buckets * (size_t)std::max(D.radix_slices, 1);
+    if (radix_aux)
+      for (int x = 0; x < D.n_aux; x++) partial_total += radix_items * ((size_t)D.aux[x].stride << D.radix_shift);
     ThreadCtx::grow(ctx.aux, aux_total + partial_total);
-    if (!P.aux_in_lds) PG_HIP(hipMemsetAsync(ctx.aux.ptr, 0, aux_total, ctx.stream));
+    if (!P.aux_in_lds && !radix_aux) PG_HIP(hipMemsetAsync(ctx.aux.ptr, 0, aux_total, ctx.stream));
     size_t off = 0, poff = aux_total;
     for (int x = 0; x < D.n_aux; x++) {
       aux_final[(size_t)x] = reinterpret_cast<uint32_t*>(ctx.aux.as<uint8_t>() + off);
       if (P.aux_in_lds) { D.aux[x].base = reinterpret_cast<uint32_t*>(ctx.aux.as<uint8_t>() + poff); poff += P.aux_bytes[x] * (size_t)shape.grid; }
+      else if (radix_aux) { D.aux[x].base = reinterpret_cast<uint32_t*>(ctx.aux.as<uint8_t>() + poff); poff += radix_items * ((size_t)D.aux[x].stride << D.radix_shift); }
       else D.aux[x].base = aux_final[(size_t)x];
       off += P.aux_bytes[x];
     }
@@ -376,7 +383,14 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
       hipLaunchKernelGGL(pg_radix_bucket_scan_kernel, dim3(1), dim3(64), 0, ctx.stream, bucket_total, D.radix_bucket_start, D.radix_buckets);
       hipLaunchKernelGGL(pg_radix_scatter_kernel, dim3(rgrid), dim3(PG_BLOCK), 0, ctx.stream, D);
       const int agrid = std::min(D.radix_buckets * D.radix_slices, g_num_cus);
-      hipLaunchKernelGGL(pg_radix_aggregate_kernel, dim3(agrid), dim3(PG_BLOCK), (size_t)D.n_ops * slots * 8 + 64, ctx.stream, D);
+      size_t agg_lds = (size_t)D.n_ops * slots * 8 + 64;
+      for (int x = 0; x < D.n_aux; x++) agg_lds += slots * (size_t)D.aux[x].stride;
+      hipLaunchKernelGGL(pg_radix_aggregate_kernel, dim3(agrid), dim3(PG_BLOCK), agg_lds, ctx.stream, D);
+      for (int x = 0; x < D.n_aux; x++) {
+        const int64_t n_words = (int64_t)D.n_groups * D.aux[x].stride / 4, bucket_words = (int64_t)(slots * (size_t)D.aux[x].stride / 4);
+        hipLaunchKernelGGL(pg_radix_reduce_aux_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx.stream, D.aux[x].base,
+                           aux_final[(size_t)x], D.radix_slices, bucket_words, n_words);
+      }
       hipLaunchKernelGGL(pg_radix_reduce_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, ctx.stream, ctx.partials.as<int64_t>(),
                          ctx.final_table.as<int64_t>(), D.n_ops, D.n_groups, D.radix_shift, D.radix_slices, P.ops_dev.as<PgAccOp>());
       PG_HIP(hipGetLastError());

@@ -1975,12 +1975,18 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_aggregate_kernel
   const int t = threadIdx.x;
   const uint32_t slots = 1u << p.radix_shift;
   const int n_items = p.radix_buckets * p.radix_slices;
+  // DISTINCTCOUNTHLL over INT / LONG values: the bucket's registers [slots][2^log2m] live behind the accumulator table; the
+  // tuple carries the doc's value, hashed here (stream-lib MurmurHash.hashLong, as hll.offer(value) does per doc)
+  uint8_t* const aux_lds = reinterpret_cast<uint8_t*>(table + (size_t)p.n_ops * slots);
+  uint32_t aux_words = 0;
+  for (int x = 0; x < p.n_aux; x++) aux_words += (slots * (uint32_t)p.aux[x].stride) >> 2;
   for (int w = (int)blockIdx.x; w < n_items; w += (int)gridDim.x) {
     const int b = w / p.radix_slices, sl = w % p.radix_slices;
     for (int o = 0; o < p.n_ops; o++) {
       const int64_t ident = pg_acc_identity(p.ops[o].fn, p.ops[o].is_float);
       for (uint32_t i = t; i < slots; i += PG_BLOCK) table[(size_t)o * slots + i] = ident;
     }
+    for (uint32_t i = t; i < aux_words; i += PG_BLOCK) reinterpret_cast<uint32_t*>(aux_lds)[i] = 0u;
     __syncthreads();
     const uint32_t start = p.radix_bucket_start[b], total = p.radix_bucket_start[b + 1] - start;
     const uint32_t per = (total + (uint32_t)p.radix_slices - 1u) / (uint32_t)p.radix_slices;
@@ -2024,12 +2030,47 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_aggregate_kernel
             else acc_int(base + k[u], op.fn, v[u]);
           }
       }
+      uint32_t aux_off = 0;
+      for (int x = 0; x < p.n_aux; x++) {
+        const PgAuxOp& A = p.aux[x];
+        int64_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) v[u] = *(const GAS int64_t*)(tp[u] + 8 + 8 * A.src);
+#pragma unroll
+        for (int u = 0; u < U; u++)
+          if (on[u]) {
+            const uint32_t ir = hll_index_rank_dev(murmur_hash_long_dev(v[u]), A.log2m);
+            hll_update(aux_lds + aux_off + (size_t)k[u] * (uint32_t)A.stride, ir & 0xFFFFu, ir >> 16);
+          }
+        aux_off += slots * (uint32_t)A.stride;
+      }
     }
     __syncthreads();
     int64_t* out = p.partials + (int64_t)w * p.n_ops * slots;
     for (int64_t i = t; i < (int64_t)p.n_ops * slots; i += PG_BLOCK) out[i] = table[i];
+    {
+      uint32_t aux_off = 0;
+      for (int x = 0; x < p.n_aux; x++) {   // this work item's registers → its partial, merged by pg_radix_reduce_aux_kernel
+        const uint32_t n_words = (slots * (uint32_t)p.aux[x].stride) >> 2;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(aux_lds + aux_off);
+        uint32_t* dst = p.aux[x].base + (int64_t)w * n_words;
+        for (uint32_t i = t; i < n_words; i += PG_BLOCK) dst[i] = src[i];
+        aux_off += n_words << 2;
+      }
+    }
     __syncthreads();
   }
+}
+
+// registers of group g = bytewise max over the slices of g's bucket
+extern "C" __global__ void __launch_bounds__(256) pg_radix_reduce_aux_kernel(const uint32_t* __restrict__ partials, uint32_t* __restrict__ out,
+                                                                              int slices, int64_t bucket_words, int64_t n_words) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  const int64_t b = w / bucket_words, l = w % bucket_words;
+  uint32_t acc = 0;
+  for (int sl = 0; sl < slices; sl++) acc = bytemax4(acc, partials[(b * slices + sl) * bucket_words + l]);
+  out[w] = acc;
 }
 
 // out[op][g] = combine over the slices of g's bucket

@@ -1141,11 +1141,40 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
     return plan;
   }
   const int64_t table_bytes = G * D.n_ops * 8;
+  // DISTINCTCOUNTHLL states that do not fit one workgroup's LDS next to the table (config 5 without its star-tree: 12 800 groups
+  // x 256 registers = 3.2 MB): updating them in HBM costs a dependent random read per doc (~23 ps per doc measured).  The radix
+  // pipeline carries the doc's value in the tuple and keeps the registers of one bucket of groups in LDS instead.
+  bool hll_radix = false;
+  int hll_shift = 0;
+  if (q->n_group_by > 0 && D.n_aux > 0 && D.n_ops > 0 && !getenv("PG_NO_RADIX") && !getenv("PG_NO_RADIX_AUX")) {
+    int64_t per_group = (int64_t)D.n_ops * 8, state_bytes = 0;
+    bool ok = (int)srcs.size() <= PG_MAX_RADIX_SRCS;
+    for (int x = 0; x < D.n_aux && ok; x++) {
+      const PgAuxOp& A = D.aux[x];
+      const Column* c = srcs[(size_t)A.src];
+      ok = (A.kind == PG_AUX_HLL_DICT || A.kind == PG_AUX_HLL_RAW) && (c->val_type == PG_V_I32 || c->val_type == PG_V_I64) && A.log2m <= 10;
+      per_group += A.stride;
+      state_bytes += G * (int64_t)A.stride;
+    }
+    if (ok && table_bytes + state_bytes > kLdsTableBudget) {
+      while (((int64_t)2 << hll_shift) * per_group <= kLdsTableBudget) hll_shift++;
+      const int64_t buckets = (G + ((int64_t)1 << hll_shift) - 1) >> hll_shift;
+      const double sel = estimate_selectivity(*root, (double)seg.total_docs);
+      const double cost_radix = 4.0 + sel * ((4.0 + 8.0 * (double)srcs.size()) * 0.25 + (double)D.n_ops * 0.95 + (double)D.n_aux * 1.5);
+      const double cost_hbm = 1.25 + sel * (double)D.n_aux * 20.0;
+      hll_radix = buckets <= PG_MAX_RADIX_BUCKETS && cost_radix < cost_hbm;
+    }
+  }
   if (D.n_ops == 0 && D.n_aux == 0) {
     D.agg_mode = PG_AGG_NONE;        // COUNT(*) only: nothing to accumulate beyond the match count
   } else if (q->n_group_by == 0) {
     D.agg_mode = PG_AGG_SINGLE;
     D.replicas = PG_BLOCK;          // one private slot per thread: no atomic conflicts
+  } else if (hll_radix) {
+    D.agg_mode = PG_AGG_RADIX;
+    D.radix_shift = hll_shift;
+    D.radix_buckets = (int32_t)((G + ((int64_t)1 << hll_shift) - 1) >> hll_shift);
+    D.replicas = 1;
   } else if (table_bytes <= kLdsTableBudget) {
     D.agg_mode = PG_AGG_LDS;
     int r = 1;   // replicas spread same-group updates of the 16 wavefronts over distinct LDS addresses
@@ -1192,7 +1221,10 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
   while ((1 << D.replica_shift) < D.replicas) D.replica_shift++;
   if (D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE) P.lds_bytes += (size_t)G * D.replicas * D.n_ops * 8;
   if (D.agg_mode == PG_AGG_LDS_PART) P.lds_bytes += (size_t)D.part_groups * D.n_ops * 8;
-  if (D.agg_mode == PG_AGG_RADIX) P.lds_bytes += ((size_t)D.n_ops << D.radix_shift) * 8;
+  if (D.agg_mode == PG_AGG_RADIX) {
+    P.lds_bytes += ((size_t)D.n_ops << D.radix_shift) * 8;
+    for (int x = 0; x < D.n_aux; x++) P.lds_bytes += (size_t)D.aux[x].stride << D.radix_shift;
+  }
   // auxiliary regions (HBM): sizes per op, patched into the plan at execution
   for (int x = 0; x < D.n_aux; x++) {
     size_t bytes = D.aux[x].kind == PG_AUX_DICT_SET ? (size_t)G * D.aux[x].stride * 4 : (size_t)G * D.aux[x].stride;
@@ -1200,6 +1232,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
     bytes = (bytes + 255) & ~(size_t)255;
     int n_rep = 1;   // replicate small states (up to 256 KB in total, at most one replica per workgroup)
     while (n_rep < 512 && bytes * (size_t)(n_rep * 2) <= ((size_t)256 << 10)) n_rep *= 2;
+    if (D.agg_mode == PG_AGG_RADIX) n_rep = 1;   // one merged region, written by pg_radix_reduce_aux_kernel
     D.aux[x].n_rep = n_rep;
     D.aux[x].rep_bytes = (int64_t)bytes;
     D.aux[x].lds_offset = -1;
