@@ -1,0 +1,98 @@
+"""The reference's filter-operator unit tests as goldens: AndFilterOperatorTest, OrFilterOperatorTest, NotFilterOperatorTest
+(pinot-core/src/test/java/org/apache/pinot/core/operator/filter/) give explicit docId lists for AND / OR / NOT combinations of
+child operators, including nested AND-in-AND, OR-in-AND and OR-in-OR trees that the SQL front end would flatten.  Each child list
+becomes a 0/1 flag column here, in three physical forms (inverted-index leaf, dictionary scan leaf, raw scan leaf), so that every
+leaf kind must produce the reference's docIds — on the oracle (CPU) and on the HIP path."""
+import itertools
+
+import numpy as np
+import pytest
+
+from pinot_amd.executor import NativeSegment
+from pinot_amd.query import FilterContext, Predicate, QueryContext
+from pinot_amd.segment import build_segment
+
+L1 = [2, 3, 6, 10, 15, 16, 28]
+L1S = [2, 3, 10, 15, 16, 28]            # the two-list tests use a shorter first list
+L2 = [3, 6, 8, 20, 28]
+L3 = [1, 2, 3, 6, 30]
+NOT_LIST = [2, 3, 10, 15, 16, 17, 18, 21, 22, 23, 24, 26, 28]
+
+
+def leaf(i, form):
+    return FilterContext.pred(Predicate("EQ", f"{form}{i}", ["1"]))
+
+
+def cases(form_of):
+    """(name, numDocs, lists, tree builder, expected docIds) — file:line of the golden in the comment"""
+    f = lambda i: leaf(i, form_of(i))   # noqa: E731
+    return [
+        ("and_two", 40, [L1S, L2], lambda: FilterContext.and_([f(1), f(2)]), [3, 28]),                                   # AndFilterOperatorTest.java:36-50
+        ("and_three", 40, [L1, L2, L3], lambda: FilterContext.and_([f(1), f(2), f(3)]), [3, 6]),                         # :53-69
+        ("and_nested", 40, [L1, L2, L3], lambda: FilterContext.and_([FilterContext.and_([f(1), f(2)]), f(3)]), [3, 6]),  # :72-92 testComplex
+        ("and_of_or", 40, [L1, L2, L3], lambda: FilterContext.and_([FilterContext.or_([f(3), f(2)]), f(1)]), [2, 3, 6, 28]),  # :141-163 testComplexWithOr
+        ("or_two", 40, [L1S, L2], lambda: FilterContext.or_([f(1), f(2)]), sorted(set(L1S) | set(L2))),                  # OrFilterOperatorTest.java:38-57
+        ("or_three", 40, [L1, L2, L3], lambda: FilterContext.or_([f(1), f(2), f(3)]), sorted(set(L1) | set(L2) | set(L3))),   # :60-82
+        ("or_nested", 40, [L1, L2, L3], lambda: FilterContext.or_([FilterContext.or_([f(1), f(2)]), f(3)]), sorted(set(L1) | set(L2) | set(L3))),  # :85-111
+        ("or_null_handling_disabled", 10, [[1, 2, 3], [0, 1, 2]], lambda: FilterContext.or_([f(1), f(2)]), [0, 1, 2, 3]),     # :130-143 getTrues
+        ("not", 30, [NOT_LIST], lambda: FilterContext.not_(f(1)), [0, 1, 4, 5, 6, 7, 8, 9, 11, 12, 13, 14, 19, 20, 25, 27, 29]),   # NotFilterOperatorTest.java:35-45
+        ("not_of_or_is_the_falses", 10, [[1, 2, 3], [0, 1, 2]], lambda: FilterContext.not_(FilterContext.or_([f(1), f(2)])), [4, 5, 6, 7, 8, 9]),  # OrFilterOperatorTest.java:142 getFalses
+    ]
+
+
+def segment_for(num_docs, lists):
+    data, schema, inv, raw = {}, {}, [], []
+    for i, ids in enumerate(lists, start=1):
+        flag = np.zeros(num_docs, dtype=np.int32)
+        flag[ids] = 1
+        for form in ("inv", "dic", "raw"):
+            data[f"{form}{i}"] = flag
+            schema[f"{form}{i}"] = "INT"
+        inv.append(f"inv{i}")
+        raw.append(f"raw{i}")
+    return build_segment("filterGoldens_0", data, schema, inverted_index_columns=inv, no_dictionary_columns=raw)
+
+
+FORMS = [("inv",) * 3, ("dic",) * 3, ("raw",) * 3, ("inv", "raw", "dic"), ("raw", "inv", "inv"), ("dic", "dic", "inv")]
+
+
+def run_all(api):
+    for forms in FORMS:
+        for name, n, lists, build, expected in cases(lambda i: forms[i - 1]):
+            seg = NativeSegment(api, segment_for(n, lists))
+            q = QueryContext(table="t", filter=build())
+            d = seg.filter(q)
+            assert d.doc_ids().tolist() == expected, (name, forms)
+            assert d.cardinality() == len(expected)
+            seg.destroy()
+
+
+def test_reference_filter_operator_goldens_oracle(oracle_api):
+    run_all(oracle_api)
+
+
+def test_and_doc_id_set_reordering_golden(oracle_api):
+    """AndFilterOperatorTest#testAndDocIdSetReordering (:94-138): four bitmaps (multiples of 2, 3, 4, 5 below 10 000) in either
+    child order give 0, 60, 120, 180, ..."""
+    n = 10_000
+    data = {f"m{k}": (np.arange(n) % k == 0).astype(np.int32) for k in (2, 3, 4, 5)}
+    host = build_segment("reorder_0", data, {c: "INT" for c in data}, inverted_index_columns=list(data))
+    seg = NativeSegment(oracle_api, host)
+    for order in ((2, 3, 4, 5), (5, 4, 3, 2)):
+        q = QueryContext(table="t", filter=FilterContext.and_([FilterContext.pred(Predicate("EQ", f"m{k}", ["1"])) for k in order]))
+        ids = seg.filter(q).doc_ids()
+        assert ids[:4].tolist() == [0, 60, 120, 180] and ids.tolist() == list(range(0, n, 60))
+    seg.destroy()
+
+
+@pytest.mark.gpu
+def test_reference_filter_operator_goldens_gpu(gpu_api):
+    run_all(gpu_api)
+    n = 10_000
+    data = {f"m{k}": (np.arange(n) % k == 0).astype(np.int32) for k in (2, 3, 4, 5)}
+    host = build_segment("reorder_0", data, {c: "INT" for c in data}, inverted_index_columns=list(data))
+    seg = NativeSegment(gpu_api, host)
+    for order in itertools.permutations((2, 3, 4, 5)):
+        q = QueryContext(table="t", filter=FilterContext.and_([FilterContext.pred(Predicate("EQ", f"m{k}", ["1"])) for k in order]))
+        assert seg.filter(q).doc_ids().tolist() == list(range(0, n, 60))
+    seg.destroy()
