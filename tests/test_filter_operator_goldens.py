@@ -96,3 +96,37 @@ def test_reference_filter_operator_goldens_gpu(gpu_api):
         q = QueryContext(table="t", filter=FilterContext.and_([FilterContext.pred(Predicate("EQ", f"m{k}", ["1"])) for k in order]))
         assert seg.filter(q).doc_ids().tolist() == list(range(0, n, 60))
     seg.destroy()
+
+
+# ---- BitmapCollectionTest (pinot-core/src/test/.../operator/filter/BitmapCollectionTest.java:31-128 and :130-227): and / or
+# cardinalities of two bitmaps under inversion, numDocs = 10 — what FastFilteredCountOperator answers from
+# (BaseFilterOperator#getNumMatchingDocs → BitmapCollection).  A bitmap is the null value vector of a column here: inverted =
+# IS NOT NULL (BitmapBasedFilterOperator exclusive), plain = IS NULL.  (numDocs, left, leftInverted, right, rightInverted, expected)
+AND_CARDINALITY = [(10, [0, 5], False, [0, 4], False, 1), (10, [0, 5], False, [1, 4], False, 0), (10, [0, 5], False, [], False, 0), (10, [], False, [0, 5], False, 0), (10, [], False, [], False, 0), (10, [0, 5], True, [0, 4], False, 1), (10, [0, 5], True, [1, 4], False, 2), (10, [0, 5], True, [], False, 0), (10, [], True, [0, 5], False, 2), (10, [], True, [], False, 0), (10, [0, 5], False, [0, 4], True, 1), (10, [0, 5], False, [1, 4], True, 2), (10, [0, 5], False, [], True, 2), (10, [], False, [], True, 0), (10, [], False, [0, 5], True, 0), (10, [0, 5], True, [0, 4], True, 7), (10, [0, 5], True, [1, 4], True, 6), (10, [0, 5], True, [], True, 8), (10, [], True, [0, 5], True, 8), (10, [], True, [], True, 10)]
+OR_CARDINALITY = [(10, [0, 5], False, [0, 4], False, 3), (10, [0, 5], False, [1, 4], False, 4), (10, [0, 5], False, [], False, 2), (10, [], False, [0, 5], False, 2), (10, [], False, [], False, 0), (10, [0, 5], True, [0, 4], False, 9), (10, [0, 5], True, [1, 4], False, 8), (10, [0, 5], True, [], False, 8), (10, [], True, [0, 5], False, 10), (10, [], True, [], False, 10), (10, [0, 5], False, [0, 4], True, 9), (10, [0, 5], False, [1, 4], True, 8), (10, [0, 5], False, [], True, 10), (10, [], False, [0, 5], True, 8), (10, [], False, [], True, 10), (10, [0, 5], True, [0, 4], True, 9), (10, [0, 5], True, [1, 4], True, 10), (10, [0, 5], True, [], True, 10), (10, [], True, [0, 5], True, 10), (10, [], True, [], True, 10)]
+
+
+def bitmap_collection_cases(api):
+    from pinot_amd import formats
+    for op, table in (("AND", AND_CARDINALITY), ("OR", OR_CARDINALITY)):
+        for n, left, l_inv, right, r_inv, expected in table:
+            host = build_segment("bc_0", {"a": np.arange(n, dtype=np.int32), "b": np.arange(n, dtype=np.int32)}, {"a": "INT", "b": "INT"},
+                                 no_dictionary_columns=["a", "b"])
+            host.columns["a"].null_vector = np.frombuffer(formats.serialize_roaring(np.array(left, dtype=np.int64)), dtype=np.uint8)
+            host.columns["b"].null_vector = np.frombuffer(formats.serialize_roaring(np.array(right, dtype=np.int64)), dtype=np.uint8)
+            seg = NativeSegment(api, host)
+            where = f"a IS {'NOT ' if l_inv else ''}NULL {op} b IS {'NOT ' if r_inv else ''}NULL"
+            b = seg.execute(f"SELECT COUNT(*) FROM t WHERE {where}")
+            assert b.aggregation_result() == [expected], (where, left, right)
+            assert b.stats.num_entries_scanned_in_filter == 0 and b.stats.num_docs_scanned == expected   # FastFilteredCountOperator
+            assert seg.filter(f"SELECT COUNT(*) FROM t WHERE {where}").cardinality() == expected
+            seg.destroy()
+
+
+def test_bitmap_collection_cardinality_goldens_oracle(oracle_api):
+    bitmap_collection_cases(oracle_api)
+
+
+@pytest.mark.gpu
+def test_bitmap_collection_cardinality_goldens_gpu(gpu_api):
+    bitmap_collection_cases(gpu_api)
