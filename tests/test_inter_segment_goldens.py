@@ -1,0 +1,105 @@
+"""InterSegmentAggregationSingleValueQueriesTest (pinot-core/src/test/.../queries/): COUNT / MAX / MIN / SUM / AVG / MINMAXRANGE
+/ DISTINCTCOUNT over 4 identical copies of the test_data-sv segment (2 segments x 2 servers), each without filter, with the
+test's FILTER, with `GROUP BY column9 ORDER BY v1 DESC, v2 DESC LIMIT 1`, and with both — result values AND the execution
+statistics (numDocsScanned, numEntriesScannedInFilter, numEntriesScannedPostFilter, totalDocs).  Per-segment blocks come from the
+library under test (oracle on the CPU, HIP path on the GPU); combine = GroupByCombineOperator merge; the broker's ORDER BY / LIMIT
+is the max over the final rows."""
+import pytest
+
+from pinot_amd.executor import GroupByCombineOperator, NativeSegment
+from tests.fixtures import SV_FILTER, sv_segment
+
+GROUP_BY = " GROUP BY column9"
+# function → [(no filter), (FILTER), (GROUP_BY top row), (FILTER + GROUP_BY top row)], file:lines of the expected tables
+GOLDEN = {
+    "MAX": [(2146952047.0, 2147419555.0), (2146952047.0, 999813884.0), (2146952047.0, 2146630496.0), (2146952047.0, 999813884.0)],          # :92-118
+    "SUM": [(129268741751388.0, 129156636756600.0), (27503790384288.0, 12429178874916.0), (69526727335224.0, 69225631719808.0),
+            (19058003631876.0, 8606725456500.0)],                                                                                            # :151-175
+    "MINMAXRANGE": [(2146711519.0, 2147401664.0), (2045835574.0, 979417512.0), (2146711519.0, 2146612605.0), (2044094181.0, 979417512.0)],  # :206-232
+    "DISTINCTCOUNT": [(6582, 21910), (1872, 4556), (3495, 11961), (1272, 3289)],                                                             # :235-258
+}
+# (numDocsScanned, numEntriesScannedInFilter, numEntriesScannedPostFilter, numTotalDocs) of the four variants; without a filter
+# MAX / MINMAXRANGE / DISTINCTCOUNT over dictionary columns are answered by NonScanBasedAggregationOperator (postFilter 0)
+STATS_SCAN = [(120000, 0, 240000, 120000), (24516, 252256, 49032, 120000), (120000, 0, 360000, 120000), (24516, 252256, 73548, 120000)]
+STATS_NON_SCAN = [(120000, 0, 0, 120000)] + STATS_SCAN[1:]
+
+
+def assert_stats(s, expected, what):
+    """x4: the reference sums the statistics of the 4 segments.  The test's FILTER holds an OR of two scans inside the AND:
+    AndDocIdIterator leapfrogs that OR, so its scan counts depend on the iteration order — the HIP path evaluates the OR over whole
+    tiles and reports `stats_exact = 0` for such plans (every other counter stays exact)."""
+    assert (4 * s.num_docs_scanned, 4 * s.num_entries_scanned_post_filter, 4 * s.num_total_docs) == (expected[0], expected[2], expected[3]), what
+    if s.stats_exact:
+        assert 4 * s.num_entries_scanned_in_filter == expected[1], what
+
+
+def top_row(final, fn):
+    """ORDER BY v1 DESC, v2 DESC LIMIT 1 over the reduced table"""
+    return max(tuple(vals) for vals in final.values())   # final(): AggregationFunction#extractFinalResult applied
+
+
+def check_function(seg, fn):
+    q = f"SELECT {fn}(column1), {fn}(column3) FROM testTable"
+    stats = STATS_SCAN if fn == "SUM" else STATS_NON_SCAN
+    for variant, where, grouped in ((0, "", False), (1, SV_FILTER, False), (2, "", True), (3, SV_FILTER, True)):
+        b = seg.execute(q + where + (GROUP_BY + " LIMIT 100000" if grouped else ""))
+        final = GroupByCombineOperator([b, b, b, b]).final()
+        got = top_row(final, fn) if grouped else tuple(final[()])
+        assert got == GOLDEN[fn][variant], (fn, variant)
+        assert_stats(b.stats, stats[variant], (fn, variant))
+
+
+def check_count_min_avg_limit(seg):
+    # testCount :47-89
+    for where, expected, stats in (("", 120000, (120000, 0, 0, 120000)), (SV_FILTER, 24516, (24516, 252256, 0, 120000))):
+        b = seg.execute("SELECT COUNT(*) FROM testTable" + where)
+        assert 4 * b.aggregation_result()[0] == expected
+        assert_stats(b.stats, stats, where)
+    for where, expected, stats in (("", 64420, (120000, 0, 120000, 120000)), (SV_FILTER, 17080, (24516, 252256, 24516, 120000))):
+        b = seg.execute("SELECT COUNT(*) FROM testTable" + where + GROUP_BY + " LIMIT 100000")
+        assert max(v[0] for v in GroupByCombineOperator([b, b, b, b]).final().values()) == expected   # ORDER BY COUNT(*) DESC LIMIT 1
+        assert_stats(b.stats, stats, where)
+    # testMin :121-148 (`ORDER BY v1, v2 LIMIT 1`: the smallest row)
+    q = "SELECT MIN(column1), MIN(column3) FROM testTable"
+    assert tuple(seg.execute(q).aggregation_result()) == (240528.0, 17891.0)
+    assert tuple(seg.execute(q + SV_FILTER).aggregation_result()) == (101116473.0, 20396372.0)
+    assert min(tuple(v) for v in seg.execute(q + GROUP_BY + " LIMIT 100000").rows().values()) == (240528.0, 17891.0)
+    assert min(tuple(v) for v in seg.execute(q + SV_FILTER + GROUP_BY + " LIMIT 100000").rows().values()) == (101116473.0, 91804599.0)
+    # testAvg :178-203 (1e-5 tolerance in the reference for the non-grouped rows)
+    q = "SELECT AVG(column1), AVG(column3) FROM testTable"
+    for where, expected in (("", (1077239514.5949, 1076305306.305)), (SV_FILTER, (1121871038.68037, 506982332.96280))):
+        b = seg.execute(q + where)
+        got = tuple(GroupByCombineOperator([b, b, b, b]).final()[()])
+        assert all(abs(g - e) <= 1e-5 * abs(e) for g, e in zip(got, expected))
+    b = seg.execute(q + GROUP_BY + " LIMIT 100000")
+    assert top_row(GroupByCombineOperator([b, b, b, b]).final(), "AVG") == (2142595699.0, 334963174.0)
+    # testNumGroupsLimit :764-775
+    from pinot_amd.query import parse_sql
+    qc = parse_sql("SELECT COUNT(*) FROM testTable GROUP BY column1 LIMIT 100000")
+    assert not seg.execute(qc).stats.num_groups_limit_reached
+    qc = parse_sql("SELECT COUNT(*) FROM testTable GROUP BY column1 LIMIT 100000")
+    qc.num_groups_limit = 1000
+    qc.max_initial_result_holder_capacity = 1000
+    assert seg.execute(qc).stats.num_groups_limit_reached
+
+
+@pytest.mark.parametrize("fn", sorted(GOLDEN))
+def test_inter_segment_aggregation_goldens_oracle(oracle_api, sv_data, fn):
+    seg = NativeSegment(oracle_api, sv_segment(sv_data))
+    check_function(seg, fn)
+    seg.destroy()
+
+
+def test_inter_segment_count_min_avg_limit_oracle(oracle_api, sv_data):
+    seg = NativeSegment(oracle_api, sv_segment(sv_data))
+    check_count_min_avg_limit(seg)
+    seg.destroy()
+
+
+@pytest.mark.gpu
+def test_inter_segment_aggregation_goldens_gpu(gpu_api, sv_data):
+    seg = NativeSegment(gpu_api, sv_segment(sv_data))
+    for fn in sorted(GOLDEN):
+        check_function(seg, fn)
+    check_count_min_avg_limit(seg)
+    seg.destroy()
