@@ -130,3 +130,50 @@ def test_bitmap_collection_cardinality_goldens_oracle(oracle_api):
 @pytest.mark.gpu
 def test_bitmap_collection_cardinality_goldens_gpu(gpu_api):
     bitmap_collection_cases(gpu_api)
+
+
+# ---- RangePredicateWithSortedInvertedIndexTest#testInnerSegmentQuery (pinot-core/src/test/.../queries/, :150-188): 30 000 rows,
+# INT_COL = row index (sorted, dictionary → SortedIndexBasedFilterOperator), INT_COL_RAW = row index (sorted, no dictionary → scan);
+# (filter, matching docs, docId ranges)
+SORTED_RANGE_CASES = [
+    ("INT_COL >= 20000", 10000, [(20000, 29999)]),
+    ("INT_COL >= 20000 AND INT_COL_RAW >= 20000", 10000, [(20000, 29999)]),
+    ("INT_COL >= 20000 AND INT_COL <= 23666", 3667, [(20000, 23666)]),
+    ("INT_COL >= 20000 AND INT_COL <= 23666 AND INT_COL_RAW <= 23666", 3667, [(20000, 23666)]),
+    ("INT_COL <= 20000", 20001, [(0, 20000)]),
+    ("INT_COL_RAW = 20000", 1, [(20000, 20000)]),
+    ("(INT_COL >= 15000 AND INT_COL <= 16665) OR (INT_COL >= 18000 AND INT_COL <= 19887)", 3554, [(15000, 16665), (18000, 19887)]),
+]
+
+
+def sorted_range_cases(api):
+    n = 30000
+    rng = np.random.default_rng(12)
+    data = {"INT_COL": np.arange(n, dtype=np.int32), "INT_COL_RAW": np.arange(n, dtype=np.int32),
+            "LONG_COL": rng.integers(-(1 << 62), 1 << 62, n)}
+    host = build_segment("sortedRange_0", data, {"INT_COL": "INT", "INT_COL_RAW": "INT", "LONG_COL": "LONG"},
+                         no_dictionary_columns=["INT_COL_RAW"])
+    assert host.columns["INT_COL"].is_sorted
+    seg = NativeSegment(api, host)
+    for where, count, ranges in SORTED_RANGE_CASES:
+        d = seg.filter(f"SELECT COUNT(*) FROM t WHERE {where}")
+        expected = np.concatenate([np.arange(lo, hi + 1) for lo, hi in ranges])
+        assert d.cardinality() == count == len(expected), where
+        np.testing.assert_array_equal(d.doc_ids(), expected, err_msg=where)
+        got = seg.execute(f"SELECT COUNT(*), MIN(INT_COL), MAX(INT_COL_RAW) FROM t WHERE {where}").aggregation_result()
+        assert got == [count, float(ranges[0][0]), float(ranges[-1][1])], where
+    # :190-226: the sorted range ANDed with a scan over an unsorted LONG column
+    pivot = int(data["LONG_COL"][rng.integers(0, n)])
+    want = np.flatnonzero((data["LONG_COL"] >= pivot) & (np.arange(n) >= 15000) & (np.arange(n) <= 16665))
+    d = seg.filter(f"SELECT COUNT(*) FROM t WHERE INT_COL >= 15000 AND INT_COL <= 16665 AND LONG_COL >= {pivot}")
+    np.testing.assert_array_equal(d.doc_ids(), want)
+    seg.destroy()
+
+
+def test_range_predicate_with_sorted_index_goldens_oracle(oracle_api):
+    sorted_range_cases(oracle_api)
+
+
+@pytest.mark.gpu
+def test_range_predicate_with_sorted_index_goldens_gpu(gpu_api):
+    sorted_range_cases(gpu_api)
