@@ -177,3 +177,34 @@ def test_range_predicate_with_sorted_index_goldens_oracle(oracle_api):
 @pytest.mark.gpu
 def test_range_predicate_with_sorted_index_goldens_gpu(gpu_api):
     sorted_range_cases(gpu_api)
+
+
+# ---- NotOperatorQueriesTest#testRangePredicates / #testCompositePredicates (pinot-core/src/test/.../queries/, :169-188): 1 024 rows,
+# FIRST_INT_COL = i, SECOND_INT_COL = 1000 + i; per-segment COUNT(*) (the LIKE / REGEXP_LIKE cases are outside the path)
+NOT_OPERATOR_CASES = [
+    ("NOT FIRST_INT_COL = 5", 1023), ("NOT FIRST_INT_COL < 5", 1019), ("NOT FIRST_INT_COL > 5", 6),
+    ("FIRST_INT_COL NOT BETWEEN 10 AND 20", 1013), ("NOT FIRST_INT_COL BETWEEN 10 AND 20", 1013),
+    ("NOT (FIRST_INT_COL > 5 AND SECOND_INT_COL < 1009)", 1021), ("NOT FIRST_INT_COL > 5 OR NOT SECOND_INT_COL < 1009", 1021),
+    ("NOT (FIRST_INT_COL < 5 OR SECOND_INT_COL > 2000)", 996), ("NOT FIRST_INT_COL < 5 AND NOT SECOND_INT_COL > 2000", 996),
+]
+
+
+def not_operator_cases(api):
+    i = np.arange(1024, dtype=np.int32)
+    for raw in ((), ("SECOND_INT_COL",), ("FIRST_INT_COL", "SECOND_INT_COL")):   # the reference's layout, then raw forms of the same data
+        host = build_segment("notOperator_0", {"FIRST_INT_COL": i, "SECOND_INT_COL": i + 1000},
+                             {"FIRST_INT_COL": "INT", "SECOND_INT_COL": "INT"}, no_dictionary_columns=list(raw))
+        seg = NativeSegment(api, host)
+        for where, expected in NOT_OPERATOR_CASES:
+            assert seg.execute(f"SELECT COUNT(*) FROM testTable WHERE {where}").aggregation_result() == [expected], (where, raw)
+            assert seg.filter(f"SELECT COUNT(*) FROM testTable WHERE {where}").cardinality() == expected
+        seg.destroy()
+
+
+def test_not_operator_goldens_oracle(oracle_api):
+    not_operator_cases(oracle_api)
+
+
+@pytest.mark.gpu
+def test_not_operator_goldens_gpu(gpu_api):
+    not_operator_cases(gpu_api)
