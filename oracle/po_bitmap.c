@@ -34,13 +34,32 @@ po_bitmap* po_bitmap_new_small(int64_t universe) {
   b->universe = universe;
   b->n_words = (universe + 63) / 64;
   if (b->n_words < 1) b->n_words = 1;
+  if (universe > 4096) {
+    b->cap_sparse = 8;
+    b->sparse = (int32_t*)po_xmalloc(sizeof(int32_t) * (size_t)b->cap_sparse);
+    return b;
+  }
   b->words = (uint64_t*)po_xcalloc((size_t)b->n_words, 8);
   return b;
+}
+
+static void densify(po_bitmap* b) {
+  if (!b->sparse) return;
+  b->words = (uint64_t*)po_xcalloc((size_t)b->n_words, 8);
+  for (int32_t i = 0; i < b->n_sparse; i++) b->words[b->sparse[i] >> 6] |= 1ULL << (b->sparse[i] & 63);
+  free(b->sparse);
+  b->sparse = NULL;
+  b->n_sparse = b->cap_sparse = 0;
 }
 
 po_bitmap* po_bitmap_clone(const po_bitmap* s) {
   po_bitmap* b = (po_bitmap*)po_xmalloc(sizeof(po_bitmap));
   *b = *s;
+  if (s->sparse) {
+    b->sparse = (int32_t*)po_xmalloc(sizeof(int32_t) * (size_t)s->cap_sparse);
+    memcpy(b->sparse, s->sparse, sizeof(int32_t) * (size_t)s->n_sparse);
+    return b;
+  }
   b->words = (uint64_t*)po_xmalloc((size_t)s->n_words * 8);
   memcpy(b->words, s->words, (size_t)s->n_words * 8);
   return b;
@@ -49,13 +68,35 @@ po_bitmap* po_bitmap_clone(const po_bitmap* s) {
 void po_bitmap_free(po_bitmap* b) {
   if (!b) return;
   free(b->words);
+  free(b->sparse);
   free(b);
 }
 
-void po_bitmap_add(po_bitmap* b, int32_t x) { b->words[x >> 6] |= 1ULL << (x & 63); }
+void po_bitmap_add(po_bitmap* b, int32_t x) {
+  if (b->sparse) {
+    int32_t lo = 0, hi = b->n_sparse;
+    while (lo < hi) {
+      int32_t mid = (lo + hi) >> 1;
+      if (b->sparse[mid] < x) lo = mid + 1;
+      else hi = mid;
+    }
+    if (lo < b->n_sparse && b->sparse[lo] == x) return;
+    if ((int64_t)b->n_sparse + 1 > b->n_words) { densify(b); b->words[x >> 6] |= 1ULL << (x & 63); return; }
+    if (b->n_sparse == b->cap_sparse) {
+      b->cap_sparse *= 2;
+      b->sparse = (int32_t*)po_xrealloc(b->sparse, sizeof(int32_t) * (size_t)b->cap_sparse);
+    }
+    memmove(b->sparse + lo + 1, b->sparse + lo, sizeof(int32_t) * (size_t)(b->n_sparse - lo));
+    b->sparse[lo] = x;
+    b->n_sparse++;
+    return;
+  }
+  b->words[x >> 6] |= 1ULL << (x & 63);
+}
 
 void po_bitmap_add_range(po_bitmap* b, int64_t start, int64_t end) {
   if (start >= end) return;
+  densify(b);
   int64_t fw = start >> 6, lw = (end - 1) >> 6;
   uint64_t fm = ~0ULL << (start & 63);
   uint64_t lm = ~0ULL >> (63 - ((end - 1) & 63));
@@ -94,6 +135,7 @@ void po_bitmap_flip(po_bitmap* b, int64_t start, int64_t end) {
 }
 
 int64_t po_bitmap_cardinality(const po_bitmap* b) {
+  if (b->sparse) return b->n_sparse;
   int64_t c = 0;
   for (int64_t i = 0; i < b->n_words; i++) c += __builtin_popcountll(b->words[i]);
   return c;
@@ -106,6 +148,15 @@ int po_bitmap_contains(const po_bitmap* b, int32_t x) {
 
 int64_t po_bitmap_next_set(const po_bitmap* b, int64_t from) {
   if (from < 0) from = 0;
+  if (b->sparse) {
+    int32_t lo = 0, hi = b->n_sparse;
+    while (lo < hi) {
+      int32_t mid = (lo + hi) >> 1;
+      if (b->sparse[mid] < from) lo = mid + 1;
+      else hi = mid;
+    }
+    return lo < b->n_sparse ? b->sparse[lo] : -1;
+  }
   int64_t w = from >> 6;
   if (w >= b->n_words) return -1;
   uint64_t cur = b->words[w] & (~0ULL << (from & 63));

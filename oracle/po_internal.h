@@ -48,6 +48,11 @@ typedef struct po_bitmap {
   uint64_t* words;
   int64_t n_words;
   int64_t universe;   /* number of addressable bits (>= numDocs) */
+  /* po_bitmap_new_small over a large universe starts as a sorted array (a RoaringBitmap array container, in effect): the dictIds
+   * one group has seen are few, and a dense bitset per group over a 1 M-value dictionary would be 125 KB each.  Only add /
+   * add_range / next_set / cardinality / free understand this form; it turns dense once it holds universe / 64 values. */
+  int32_t* sparse;
+  int32_t n_sparse, cap_sparse;
 } po_bitmap;
 
 po_bitmap* po_bitmap_new(int64_t universe);
