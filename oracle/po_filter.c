@@ -5,8 +5,11 @@
  * ExecutionStatistics goldens (e.g. 63064 in InnerSegmentAggregationSingleValueQueriesTest.java:55-58) reproduce.
  *
  * Deliberate deviation (documented in DESIGN.md): OrDocIdSet.iterator() in this reference snapshot never adds
- * BitmapBasedDocIdIterators to its merge list (core/operator/docidsets/OrDocIdSet.java:74-84), so with >= 2 sorted
- * children it would drop the bitmap children from the union; the oracle restates the evident intent (merge them).
+ * BitmapBasedDocIdIterators to its merge list (core/operator/docidsets/OrDocIdSet.java:74-84), so (a) the merge into one
+ * BitmapDocIdIterator happens only with >= 2 SORTED children (`numSorted + 0 > 1`) and (b) in that case the bitmap children
+ * would be dropped from the union.  The oracle follows (a) exactly — the iterator type decides whether an enclosing AND
+ * restricts its scans by the OR (numEntriesScannedInFilter) — and deviates in (b) only: the bitmap children are ORed in, since
+ * dropping them would change query results.
  */
 #include <stdio.h>
 
@@ -544,7 +547,7 @@ static po_iter* orset_iterator(po_docidset* set) {
     }
   }
   po_iter* result;
-  if (n_sorted + n_bitmap > 1) {
+  if (n_sorted > 1) {   /* numSortedDocIdIterators + numBitmapBasedDocIdIterators > 1 with the latter always 0 (see the file header) */
     po_bitmap* doc_ids = po_bitmap_new(cs->num_docs);
     for (int s = 0; s < n_sorted; s++) {
       ranges* r = ((sorted_it_state*)sorted_its[s]->state)->r;

@@ -529,9 +529,8 @@ struct Emitter {
         // the remaining (nested) children are intersected last.
         std::vector<const FilterOp*> index_based, scan_based, remaining;
         for (auto& c : op.children) {
-          if (c->kind == OpKind::Sorted || c->kind == OpKind::Inverted || c->kind == OpKind::Bitmap) index_based.push_back(c.get());
+          if (index_child(*c)) index_based.push_back(c.get());   // leaves, and compound children whose iterator is bitmap based
           else if (c->kind == OpKind::Scan) scan_based.push_back(c.get());
-          else if (yields_bitmap(*c)) index_based.push_back(c.get());   // a nested AND whose iterator is a RangelessBitmapDocIdIterator
           else remaining.push_back(c.get());
         }
         // nested ANDs first, plain index leaves after them: AND(AND(index.., scans..), queryableDocIds) then reads
@@ -565,18 +564,35 @@ struct Emitter {
     }
   }
 
-  // AndDocIdSet.iterator() (AndDocIdSet.java:125-178) merges index-based and scan children into ONE bitmap, eagerly, when there is
-  // an index-based child next to a scan (or two index-based ones) and nothing else: such an AND nested in an AND (the
-  // queryableDocIds wrapper of FilterPlanNode.run) acts as a bitmap child there, and every scan count stays exact.
+  // Which compound operators hand their parent a bitmap-based iterator (the parent AND then restricts its scans by it):
+  //  * AndDocIdSet.iterator() (AndDocIdSet.java:125-178) merges index-based and scan children into ONE RangelessBitmapDocIdIterator,
+  //    eagerly, when there is an index-based child next to a scan (or two index-based ones) and nothing else — the nested AND of
+  //    FilterPlanNode.run's queryableDocIds wrapper; every scan count stays exact;
+  //  * OrDocIdSet.iterator() (OrDocIdSet.java:62-125) merges into a BitmapDocIdIterator only with >= 2 SORTED children and no
+  //    scan / compound child (its bitmap list is never filled in this reference snapshot: `numSorted + 0 > 1`); any other OR is an
+  //    OrDocIdIterator, which an enclosing AND leapfrogs.
+  static bool index_child(const FilterOp& c) {
+    return c.kind == OpKind::Sorted || c.kind == OpKind::Inverted || c.kind == OpKind::Bitmap || yields_bitmap(c);
+  }
   static bool yields_bitmap(const FilterOp& op) {
-    if (op.kind != OpKind::And) return false;
-    int n_index = 0, n_scan = 0;
-    for (auto& c : op.children) {
-      if (c->kind == OpKind::Sorted || c->kind == OpKind::Inverted || c->kind == OpKind::Bitmap) n_index++;
-      else if (c->kind == OpKind::Scan) n_scan++;
-      else return false;
+    if (op.kind == OpKind::And) {
+      int n_index = 0, n_scan = 0;
+      for (auto& c : op.children) {
+        if (index_child(*c)) n_index++;
+        else if (c->kind == OpKind::Scan) n_scan++;
+        else return false;
+      }
+      return (n_index > 0 && n_scan > 0) || n_index > 1;
     }
-    return (n_index > 0 && n_scan > 0) || n_index > 1;
+    if (op.kind == OpKind::Or) {
+      int n_sorted = 0;
+      for (auto& c : op.children) {
+        if (c->kind == OpKind::Sorted) n_sorted++;
+        else if (!index_child(*c)) return false;
+      }
+      return n_sorted > 1;
+    }
+    return false;
   }
 };
 

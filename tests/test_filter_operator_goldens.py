@@ -208,3 +208,41 @@ def test_not_operator_goldens_oracle(oracle_api):
 @pytest.mark.gpu
 def test_not_operator_goldens_gpu(gpu_api):
     not_operator_cases(gpu_api)
+
+
+# ---- OrDocIdSet.iterator() (OrDocIdSet.java:62-125) hands an enclosing AND a bitmap only when it merged >= 2 sorted children:
+# only then are the AND's scans applied to the OR's docs (numEntriesScannedInFilter); any other OR is leapfrogged.
+def or_iterator_typing(api, gpu=False):
+    n = 50_000
+    rng = np.random.default_rng(21)
+    data = {"so": np.sort(rng.integers(0, 200, n)).astype(np.int32), "d": rng.integers(0, 10, n).astype(np.int32),
+            "e": rng.integers(0, 10, n).astype(np.int32), "r": rng.integers(0, 1000, n).astype(np.int32)}
+    host = build_segment("orTyping_0", data, {c: "INT" for c in data}, inverted_index_columns=["d", "e"], no_dictionary_columns=["r"])
+    seg = NativeSegment(api, host)
+    so, d, e, r = (data[c] for c in ("so", "d", "e", "r"))
+    cases = [   # (filter, docs the scan over r is applied to)
+        ("(so < 20 OR so > 150) AND r < 500", (so < 20) | (so > 150)),                 # two sorted leaves: merged bitmap
+        ("(so < 20 OR so > 150 OR d = 3) AND r < 500", (so < 20) | (so > 150) | (d == 3)),   # ... bitmap children ORed in
+        ("(so < 20 OR so > 150) AND d = 3 AND r < 500", ((so < 20) | (so > 150)) & (d == 3)),
+        ("(d = 3 OR e = 4) AND so < 100 AND r < 500", so < 100),                       # no merge: the OR is leapfrogged
+        ("(so < 20 OR d = 3) AND e = 4 AND r < 500", e == 4),                          # one sorted child: no merge either
+    ]
+    results = []
+    for where, cand in cases:
+        b = seg.execute(f"SELECT COUNT(*), SUM(r) FROM t WHERE {where}")
+        results.append((b.aggregation_result(), b.stats.num_entries_scanned_in_filter, b.stats.stats_exact))
+        if not gpu:
+            assert b.stats.num_entries_scanned_in_filter == int(cand.sum()), where
+    seg.destroy()
+    return results
+
+
+def test_or_iterator_typing_oracle(oracle_api):
+    or_iterator_typing(oracle_api)
+
+
+@pytest.mark.gpu
+def test_or_iterator_typing_gpu(gpu_api, oracle_api):
+    for (gr, ge, gx), (orr, oe, _) in zip(or_iterator_typing(gpu_api, gpu=True), or_iterator_typing(oracle_api)):
+        assert gr == orr
+        assert gx and ge == oe

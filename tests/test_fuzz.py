@@ -99,7 +99,7 @@ def test_gpu_matches_oracle_on_random_queries(gpu_api, oracle_api, fuzz, seed, w
         o.set_queryable_doc_ids(valid)
     gen = Gen(data, seed=1000 + seed)
     unsupported, mismatches = [], []
-    n_queries = 120 if seed != 6 else 50
+    n_queries = 200 if seed != 6 else 80
     for i in range(n_queries):
         q = gen.query()
         what = f"seed {seed} #{i} {describe(q)}"
