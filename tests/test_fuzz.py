@@ -41,6 +41,18 @@ def test_oracle_matches_brute_force(oracle_api, fuzz):
                     assert r == float(data[a.column][mask].min()), what
                 elif a.function == "MAX" and mask.any():
                     assert r == float(data[a.column][mask].max()), what
+                elif a.function == "AVG":
+                    assert r == (float(data[a.column][mask].astype(np.float64).sum()), int(mask.sum())), what
+                elif a.function == "MINMAXRANGE":
+                    v = data[a.column][mask]
+                    assert r == ((float(v.min()), float(v.max())) if mask.any() else (float("inf"), float("-inf"))), what
+                elif a.function == "DISTINCTCOUNT":
+                    col = data[a.column].astype(str) if data[a.column].dtype == object else data[a.column]
+                    assert r == frozenset(np.unique(col[mask]).tolist()), what
+                elif a.function == "DISTINCTCOUNTHLL":   # registers after hll.offer(value) for every matching doc (numpy restatement)
+                    from pinot_amd.startree import hll_registers
+                    dt = "LONG" if data[a.column].dtype == np.int64 else "INT"
+                    assert r == bytes(hll_registers(data[a.column][mask], dt, a.log2m or 8)), what
             continue
         limit = q.num_groups_limit or 100_000
         docs = np.flatnonzero(mask)
@@ -67,12 +79,30 @@ def test_oracle_matches_brute_force(oracle_api, fuzz):
         if len(ucode) > limit:
             assert b.stats.num_groups_limit_reached, what
         for j, a in enumerate(q.aggregations):
-            if a.function in ("COUNT", "SUM"):
+            if a.function in ("COUNT", "SUM", "AVG"):
                 vals = np.ones(len(docs)) if a.function == "COUNT" else data[a.column][docs].astype(np.float64)
                 acc = np.bincount(inv, weights=vals, minlength=len(ucode))
+                cnt = np.bincount(inv, minlength=len(ucode))
                 for k, i in want.items():
-                    assert rows[k][j] == (int(acc[i]) if a.function == "COUNT" else float(acc[i])), (what, k)
+                    exp = int(acc[i]) if a.function == "COUNT" else float(acc[i]) if a.function == "SUM" else (float(acc[i]), int(cnt[i]))
+                    assert rows[k][j] == exp, (what, k)
                 checked_groups += 1
+            elif a.function in ("MIN", "MAX", "MINMAXRANGE") and len(docs):
+                v = data[a.column][docs].astype(np.float64)
+                lo = np.full(len(ucode), np.inf)
+                hi = np.full(len(ucode), -np.inf)
+                np.minimum.at(lo, inv, v)
+                np.maximum.at(hi, inv, v)
+                for k, i in want.items():
+                    exp = float(lo[i]) if a.function == "MIN" else float(hi[i]) if a.function == "MAX" else (float(lo[i]), float(hi[i]))
+                    assert rows[k][j] == exp, (what, k)
+            elif a.function == "DISTINCTCOUNT" and len(ucode) <= 3000:
+                col = data[a.column].astype(str) if data[a.column].dtype == object else data[a.column]
+                sets = {}
+                for g, v in zip(inv.tolist(), col[docs].tolist()):
+                    sets.setdefault(g, set()).add(v)
+                for k, i in want.items():
+                    assert rows[k][j] == frozenset(sets[i]), (what, k)
     assert checked_groups > 40
     o.destroy()
 
