@@ -104,6 +104,42 @@ def _decode_dictionary(buf: np.ndarray, data_type: str, card: int, width: int, p
     return [raw[i * width:(i + 1) * width].rstrip(pad).decode("utf-8") for i in range(card)]
 
 
+def load_segment_v1_dir(path: str) -> HostSegment:
+    """The v1 layout (one file per index; V1Constants.Indexes: `<col>.dict`, `<col>.sv.unsorted.fwd`, `<col>.sv.sorted.fwd`,
+    `<col>.bitmap.inv`; ColumnIndexDirectory / FilePerIndexDirectory) — what SegmentV1V2ToV3FormatConverter packs into
+    columns.psf.  The index bytes are the same as in v3, without the 8-byte marker."""
+    props = read_properties(os.path.join(path, METADATA_FILE))
+    total_docs = int(props["segment.total.docs"][0])
+    padding = props.get("segment.padding.character", ["%"])[0]     # V1Constants.Str.LEGACY_STRING_PAD_CHAR when absent
+    padding = "\0" if padding in ("\\u0000", "\\\\u0000", "") else padding
+    seg = HostSegment(props.get("segment.name", ["segment"])[0], total_docs)
+    seg.skipped = {}
+
+    def entry(col: str, ext: str) -> Optional[np.ndarray]:
+        f = os.path.join(path, col + ext)
+        return np.fromfile(f, dtype=np.uint8) if os.path.exists(f) else None
+
+    for name, m in column_metadata(props).items():
+        dt = stored_type(m.get("dataType", ""))
+        card = int(m.get("cardinality", 0))
+        if m.get("isSingleValues", "true") != "true" or m.get("hasDictionary", "true") != "true":
+            seg.skipped[name] = "multi-value or raw column"
+            continue
+        is_sorted = m.get("isSorted", "false") == "true"
+        fwd = entry(name, ".sv.sorted.fwd" if is_sorted else ".sv.unsorted.fwd")
+        dbuf = entry(name, ".dict")
+        width = _FIXED_WIDTH.get(dt, int(m.get("lengthOfEachEntry", 0)))
+        if fwd is None or dbuf is None or dbuf.size != card * width:
+            seg.skipped[name] = "missing index files"
+            continue
+        stored = dt if dt in _FIXED_WIDTH else "STRING"
+        bits = int(m.get("bitsPerElement", formats.num_bits_per_value(card - 1)))
+        seg.columns[name] = HostColumn(name, stored, capi.FWD_DICT_SORTED if is_sorted else capi.FWD_DICT_FIXED_BIT, True, card, bits,
+                                       is_sorted, width, fwd, dbuf, None if is_sorted else entry(name, ".bitmap.inv"),
+                                       _decode_dictionary(dbuf, dt, card, width, padding))
+    return seg
+
+
 def load_segment_dir(path: str) -> HostSegment:
     """ImmutableSegmentLoader.load for the parts the path reads.  `path` is the segment directory or its `v3/` child."""
     if os.path.isdir(os.path.join(path, "v3")):
