@@ -16,8 +16,9 @@ tail -c 600 "$OUT/${TAG}_bench.json"; echo
     python "$R/bench.py" --no-cpu-baseline --no-variants --steps 20 --warmup 5 > "$OUT/${TAG}_bench_under_rocprof.json" 2> /dev/null < /dev/null )
 timeout 60 python tools/rocprof_summary.py "$OUT/${TAG}_prof/x_results.db" > "$OUT/${TAG}_kernel_stats.txt" 2>&1 < /dev/null
 head -6 "$OUT/${TAG}_kernel_stats.txt" | cut -c1-150
-for set in cfg3 general wide cfg5 upsert; do
-  echo "# --set $set" >> "$OUT/${TAG}_variants_200m.txt"
-  timeout 120 python tools/prof_variants.py --set $set --docs 200000000 2>&1 < /dev/null | grep -v amdgpu.ids >> "$OUT/${TAG}_variants_200m.txt"
+for set in cfg3 general cfg5 upsert wide; do
+  docs=200000000; [ $set = wide ] && docs=100000000      # the wide set builds two 64-bit columns with numpy
+  echo "# --set $set --docs $docs" >> "$OUT/${TAG}_variants_200m.txt"
+  timeout 150 python tools/prof_variants.py --set $set --docs $docs 2>&1 < /dev/null | grep -v amdgpu.ids >> "$OUT/${TAG}_variants_200m.txt"
 done
 tail -40 "$OUT/${TAG}_variants_200m.txt" | cut -c1-170
