@@ -20,7 +20,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2])
+@pytest.mark.parametrize("world", [2, 4])
 def test_gloo_group_by_merge(tmp_path, world):
     out = tmp_path / "result.json"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
