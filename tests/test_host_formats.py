@@ -175,3 +175,16 @@ def test_header_is_plain_c_and_links():
     out = subprocess.run([_abi_smoke_binary()], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
     assert "no CPU fallback" in out.stdout and "pg_init -> -3" in out.stdout
+
+
+def test_header_compiles_as_cxx_too(tmp_path):
+    """A JNI shim is as likely to be C++ as C: the header must be usable from both (extern "C" guards, no C-only constructs)."""
+    import subprocess
+    src = tmp_path / "use.cpp"
+    src.write_text('#include "pinot_gpu.h"\n#include <cstdio>\nint main() { pg_query q{}; pg_exec_stats s{}; (void)q; (void)s; '
+                   'std::printf("%d\\n", (int)PG_ABI_VERSION); return pg_abi_version() == PG_ABI_VERSION ? 0 : 1; }\n')
+    exe = tmp_path / "use_cxx"
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(capi.REPO_ROOT, "include"),
+                           str(src), "-L" + os.path.dirname(capi.GPU_LIB_PATH), "-lpinot_gpu",
+                           "-Wl,-rpath," + os.path.dirname(capi.GPU_LIB_PATH), "-o", str(exe)])
+    assert subprocess.run([str(exe)], capture_output=True, text=True).returncode == 0
