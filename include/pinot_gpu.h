@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 2
+#define PG_ABI_VERSION 3
 
 typedef enum pg_status {
   PG_OK = 0,
@@ -160,6 +160,7 @@ typedef struct pg_query {
 
 #define PG_QUERY_FLAG_PROFILE 0x1          /* record per-kernel HIP-event timings into pg_exec_stats */
 #define PG_QUERY_FLAG_SKIP_STAR_TREE 0x2   /* QueryContext#isSkipStarTree (query option useStarTree=false) */
+#define PG_QUERY_FLAG_KEEP_DEVICE_TABLE 0x4 /* keep the dense accumulator table in HBM with the result (pg_result_merge / _all_reduce) */
 
 /* ExecutionStatistics (pinot-core/.../operator/ExecutionStatistics.java) + device timings. */
 typedef struct pg_exec_stats {
@@ -231,10 +232,16 @@ typedef struct pg_star_tree_desc {
 typedef struct pg_segment_s* pg_segment_t;
 typedef struct pg_result_s* pg_result_t;
 typedef struct pg_docidset_s* pg_docidset_t;
+typedef struct pg_cancel_s* pg_cancel_t;
+typedef struct pg_comm_s* pg_comm_t;
 
 /* ---- library ---------------------------------------------------------------------------------------------------- */
 int32_t pg_abi_version(void);
-/* Binds the process to a HIP device (one process per GPU).  Fails loudly if no device is present. */
+/* Selects the DEFAULT HIP device — the one pg_segment_create() pins its segment on (one process per GPU: pg_init(LOCAL_RANK)).
+ * Fails loudly if no device is present.  A server process that spreads its segments over several GPUs — the reference runs
+ * every segment of a server inside one JVM, one worker task per segment (BaseCombineOperator.java:81-142) — names the device
+ * per segment with pg_segment_create_on_device() instead; every entry point then runs on the device of the segment it is
+ * given, on a stream private to the (calling thread, device) pair. */
 int32_t pg_init(int32_t device_ordinal);
 int32_t pg_device_count(int32_t* out_count);
 /* Copies the calling thread's last error message into buf (NUL terminated, truncated to cap). Returns its length. */
@@ -243,6 +250,10 @@ int32_t pg_last_error(char* buf, size_t cap);
 /* ---- segment life cycle: IndexSegment / ImmutableSegmentLoader.load → pin in HBM; IndexSegment#destroy ------------
  * (pinot-segment-spi/.../IndexSegment.java:137-142). */
 int32_t pg_segment_create(const char* segment_name, int32_t total_docs, pg_segment_t* out_segment);
+/* The segment -> GPU map of a multi-GPU server (SURVEY.md §8b "Threading"): the segment's columns, indexes and plans live in
+ * the HBM of `device_ordinal`; queries on it run there whatever device other segments of the process use. */
+int32_t pg_segment_create_on_device(const char* segment_name, int32_t total_docs, int32_t device_ordinal, pg_segment_t* out_segment);
+int32_t pg_segment_device(pg_segment_t segment, int32_t* out_device_ordinal);
 int32_t pg_segment_add_column(pg_segment_t segment, const pg_column_desc* column);
 /* StarTreeLoaderUtils#loadStarTreeV2: registers star-tree number `IndexSegment#getStarTrees().size()` of the segment. */
 int32_t pg_segment_add_star_tree(pg_segment_t segment, const pg_star_tree_desc* star_tree);
@@ -276,6 +287,18 @@ int32_t pg_docidset_free(pg_docidset_t set);
 int32_t pg_query_supported(pg_segment_t segment, const pg_query* query);
 int32_t pg_query_exec(pg_segment_t segment, const pg_query* query, pg_result_t* out_result);
 
+/* ---- cancellation: BaseOperator#nextBlock checks Tracing.ThreadAccountantOps.isInterrupted() and throws
+ * EarlyTerminationException (pinot-core/.../operator/BaseOperator.java:36-53); the scheduler interrupts the worker thread on
+ * timeout / query kill.  Here the Java side owns a token per running query: the interrupting thread calls pg_cancel_request()
+ * (any thread, any time, idempotent); pg_query_exec_cancellable() polls the token before planning, between kernel launches and
+ * while it waits for the device, and returns PG_ERR_CANCELLED (no result) once it is set.  A kernel already running is left
+ * to finish (milliseconds); the calling thread's work areas stay consistent.  `cancel` may be NULL (= pg_query_exec). */
+int32_t pg_cancel_create(pg_cancel_t* out_cancel);
+int32_t pg_cancel_request(pg_cancel_t cancel);
+int32_t pg_cancel_reset(pg_cancel_t cancel);
+int32_t pg_cancel_destroy(pg_cancel_t cancel);
+int32_t pg_query_exec_cancellable(pg_segment_t segment, const pg_query* query, pg_cancel_t cancel, pg_result_t* out_result);
+
 int32_t pg_result_num_groups(pg_result_t result, int32_t* out_num_groups);
 /* dictIds of group-by column `col` for every group (GroupKeyGenerator#getGroupKeys; decoding via Dictionary is the
  * caller's job as in DictionaryBasedGroupKeyGenerator.java:578-606). */
@@ -297,6 +320,37 @@ int32_t pg_result_set_dict_ids(pg_result_t result, int32_t agg, int32_t* out_dic
 int32_t pg_result_hll_registers(pg_result_t result, int32_t agg, uint8_t* out_registers, int64_t capacity);
 int32_t pg_result_stats(pg_result_t result, pg_exec_stats* out_stats);
 int32_t pg_result_free(pg_result_t result);
+
+/* ---- GroupByCombineOperator across segments that share their key space -----------------------------------------------
+ * (pinot-core/.../operator/combine/GroupByCombineOperator.java:102-165,191-222; merge functions SumAggregationFunction.java
+ * :223-233, MaxAggregationFunction.java:237-251, MinAggregationFunction, CountAggregationFunction,
+ * DistinctCountHLLAggregationFunction.java:333-350).  The reference merges by group VALUES because dictionaries are per
+ * segment; when the segments of a table share identical dictionaries for the group-by (and DISTINCTCOUNT) columns — the
+ * caller's responsibility; true for the synthetic gpuBench table and for tables with pre-built global dictionaries — raw
+ * keys are equal across segments and the merge is element-wise over the dense accumulator table the query left in HBM:
+ * `+` for COUNT / SUM limbs, min / max for MIN / MAX, register-wise max for HyperLogLogs, OR for dictId sets.  A query
+ * executed with PG_QUERY_FLAG_KEEP_DEVICE_TABLE keeps that table (and its DISTINCTCOUNT / HLL state) on the device with
+ * the result.  Everything else (different dictionaries, hashed key spaces, numGroupsLimit trimming in effect) returns
+ * PG_ERR_UNSUPPORTED and is merged on the host by values, as IndexedTable#upsert does.
+ *   pg_result_merge       dst <- merge(dst, src), both on the same device (several segments per GPU); ExecutionStatistics add up
+ *   pg_result_all_reduce  every rank of `comm` calls it with its own result of the SAME query; on return each result holds
+ *                         the merged table of all ranks (RCCL all-reduce over xGMI: ncclSum / ncclMin / ncclMax on int64,
+ *                         ncclMax on uint8 registers, one grouped launch; KB..MB payloads, i.e. latency-bound)
+ * After either call the result's accessors (num_groups, dictIds, values, stats) describe the merged table. */
+int32_t pg_result_merge(pg_result_t dst, pg_result_t src);
+int32_t pg_result_all_reduce(pg_result_t result, pg_comm_t comm);
+
+/* RCCL communicators (librccl is loaded on first use; no RCCL symbol is needed by single-GPU callers).
+ *   one process per GPU (bench.py under torch.distributed.run, one JVM per GPU): rank 0 calls pg_comm_get_unique_id and ships
+ *     the PG_COMM_UNIQUE_ID_BYTES bytes to the others out of band; every rank then calls pg_comm_init_rank (collective);
+ *   one process, N GPUs (one JVM per server): pg_comm_init_all creates one communicator per listed device; worker thread i
+ *     uses out_comms[i] with the results of the segments pinned on device_ordinals[i]. */
+#define PG_COMM_UNIQUE_ID_BYTES 128
+int32_t pg_comm_get_unique_id(void* out_unique_id);
+int32_t pg_comm_init_rank(int32_t device_ordinal, int32_t world_size, int32_t rank, const void* unique_id, pg_comm_t* out_comm);
+int32_t pg_comm_init_all(int32_t n_devices, const int32_t* device_ordinals, pg_comm_t* out_comms);
+int32_t pg_comm_world_size(pg_comm_t comm, int32_t* out_world_size);
+int32_t pg_comm_destroy(pg_comm_t comm);
 
 #ifdef __cplusplus
 }

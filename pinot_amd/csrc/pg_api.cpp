@@ -7,6 +7,8 @@ using namespace pg;
 struct pg_segment_s { Segment seg; };
 struct pg_result_s { std::unique_ptr<Result> r; };
 struct pg_docidset_s { std::unique_ptr<DocIdSet> s; };
+struct pg_cancel_s { CancelToken token; };
+struct pg_comm_s { Comm* c = nullptr; };
 
 template <typename F>
 static int32_t guarded(F&& f) {
@@ -53,22 +55,32 @@ int32_t pg_last_error(char* buf, size_t cap) {
   return (int32_t)e.size();
 }
 
+static void segment_create_on(const char* segment_name, int32_t total_docs, int32_t device, pg_segment_t* out_segment) {
+  REQUIRE(out_segment, "out_segment is null");
+  REQUIRE(total_docs >= 0, "total_docs < 0");
+  use_device(device);   // fails loudly without a HIP device / for an ordinal out of range
+  auto s = std::make_unique<pg_segment_s>();
+  s->seg.name = segment_name ? segment_name : "";
+  s->seg.device = device;
+  s->seg.total_docs = total_docs;
+  s->seg.n_tiles = (int32_t)(((int64_t)total_docs + PG_TILE_DOCS - 1) / PG_TILE_DOCS);
+  if (s->seg.n_tiles == 0) s->seg.n_tiles = 1;
+  *out_segment = s.release();
+}
 int32_t pg_segment_create(const char* segment_name, int32_t total_docs, pg_segment_t* out_segment) {
-  return guarded([&] {
-    REQUIRE(out_segment, "out_segment is null");
-    REQUIRE(total_docs >= 0, "total_docs < 0");
-    auto* s = new pg_segment_s();
-    s->seg.name = segment_name ? segment_name : "";
-    s->seg.total_docs = total_docs;
-    s->seg.n_tiles = (int32_t)(((int64_t)total_docs + PG_TILE_DOCS - 1) / PG_TILE_DOCS);
-    if (s->seg.n_tiles == 0) s->seg.n_tiles = 1;
-    *out_segment = s;
-  });
+  return guarded([&] { segment_create_on(segment_name, total_docs, default_device(), out_segment); });
+}
+int32_t pg_segment_create_on_device(const char* segment_name, int32_t total_docs, int32_t device_ordinal, pg_segment_t* out_segment) {
+  return guarded([&] { segment_create_on(segment_name, total_docs, device_ordinal, out_segment); });
+}
+int32_t pg_segment_device(pg_segment_t segment, int32_t* out_device_ordinal) {
+  return guarded([&] { REQUIRE(segment && out_device_ordinal, "null argument"); *out_device_ordinal = segment->seg.device; });
 }
 
 int32_t pg_segment_add_column(pg_segment_t segment, const pg_column_desc* column) {
   return guarded([&] {
     REQUIRE(segment && column, "null argument");
+    use_device(segment->seg.device);
     std::lock_guard<std::mutex> g(segment->seg.mu);
     segment_add_column(segment->seg, *column);
     segment->seg.plan_cache.clear();
@@ -78,6 +90,7 @@ int32_t pg_segment_add_column(pg_segment_t segment, const pg_column_desc* column
 int32_t pg_segment_add_star_tree(pg_segment_t segment, const pg_star_tree_desc* star_tree) {
   return guarded([&] {
     REQUIRE(segment && star_tree, "null argument");
+    use_device(segment->seg.device);
     std::lock_guard<std::mutex> g(segment->seg.mu);
     segment_add_star_tree(segment->seg, *star_tree);
     segment->seg.plan_cache.clear();
@@ -86,12 +99,14 @@ int32_t pg_segment_add_star_tree(pg_segment_t segment, const pg_star_tree_desc* 
 int32_t pg_segment_set_null_vector(pg_segment_t segment, const char* column, const void* roaring, uint64_t size) {
   return guarded([&] {
     REQUIRE(segment && column, "null argument");
+    use_device(segment->seg.device);
     segment_set_null_vector(segment->seg, column, roaring, size);
   });
 }
 int32_t pg_segment_set_queryable_doc_ids(pg_segment_t segment, const void* roaring, uint64_t size) {
   return guarded([&] {
     REQUIRE(segment, "null argument");
+    use_device(segment->seg.device);
     segment_set_queryable_doc_ids(segment->seg, roaring, size);
   });
 }
@@ -105,7 +120,10 @@ int32_t pg_segment_device_bytes(pg_segment_t segment, uint64_t* out_bytes) {
 }
 
 int32_t pg_segment_destroy(pg_segment_t segment) {
-  return guarded([&] { delete segment; });
+  return guarded([&] {
+    if (segment) use_device(segment->seg.device);
+    delete segment;
+  });
 }
 
 int32_t pg_filter_exec(pg_segment_t segment, const pg_filter_node* filter, pg_docidset_t* out_docidset) {
@@ -128,6 +146,7 @@ int32_t pg_docidset_copy_words(pg_docidset_t set, uint64_t* out_words, int64_t c
     REQUIRE(set && (out_words || capacity_words == 0), "null argument");
     int64_t n = ((int64_t)set->s->num_docs + 63) / 64;
     REQUIRE(capacity_words >= n, "capacity too small");
+    use_device(set->s->device);
     if (n) PG_HIP(hipMemcpy(out_words, set->s->words.ptr, (size_t)n * 8, hipMemcpyDeviceToHost));
   });
 }
@@ -141,23 +160,96 @@ int32_t pg_docidset_stats(pg_docidset_t set, pg_exec_stats* out_stats) {
   return guarded([&] { REQUIRE(set && out_stats, "null argument"); *out_stats = set->s->stats; });
 }
 int32_t pg_docidset_free(pg_docidset_t set) {
-  return guarded([&] { delete set; });
+  return guarded([&] {
+    if (set && set->s) use_device(set->s->device);
+    delete set;
+  });
 }
 
 int32_t pg_query_supported(pg_segment_t segment, const pg_query* query) {
   return guarded([&] {
     REQUIRE(segment && query, "null argument");
-    (void)compile_plan(segment->seg, query->filter, query);   // throws PG_ERR_UNSUPPORTED for shapes off the GPU path
+    use_device(segment->seg.device);
+    // compiled under the segment's lock and cached: the pg_query_exec that follows finds the plan (PlanMaker calls supported()
+    // then exec() from many worker threads); throws PG_ERR_UNSUPPORTED for shapes off the GPU path
+    (void)get_plan(segment->seg, query->filter, query);
   });
 }
 
 int32_t pg_query_exec(pg_segment_t segment, const pg_query* query, pg_result_t* out_result) {
   return guarded([&] {
     REQUIRE(segment && query && out_result, "null argument");
-    auto r = execute_query(segment->seg, *query);
+    auto r = execute_query(segment->seg, *query, nullptr);
     auto* h = new pg_result_s();
     h->r = std::move(r);
     *out_result = h;
+  });
+}
+
+int32_t pg_cancel_create(pg_cancel_t* out_cancel) {
+  return guarded([&] { REQUIRE(out_cancel, "null argument"); *out_cancel = new pg_cancel_s(); });
+}
+int32_t pg_cancel_request(pg_cancel_t cancel) {
+  return guarded([&] { REQUIRE(cancel, "null argument"); cancel->token.requested.store(1, std::memory_order_release); });
+}
+int32_t pg_cancel_reset(pg_cancel_t cancel) {
+  return guarded([&] { REQUIRE(cancel, "null argument"); cancel->token.requested.store(0, std::memory_order_release); });
+}
+int32_t pg_cancel_destroy(pg_cancel_t cancel) {
+  return guarded([&] { delete cancel; });
+}
+int32_t pg_query_exec_cancellable(pg_segment_t segment, const pg_query* query, pg_cancel_t cancel, pg_result_t* out_result) {
+  return guarded([&] {
+    REQUIRE(segment && query && out_result, "null argument");
+    auto r = execute_query(segment->seg, *query, cancel ? &cancel->token : nullptr);
+    auto* h = new pg_result_s();
+    h->r = std::move(r);
+    *out_result = h;
+  });
+}
+
+int32_t pg_result_merge(pg_result_t dst, pg_result_t src) {
+  return guarded([&] {
+    REQUIRE(dst && src && dst != src, "null or identical results");
+    result_merge(*dst->r, *src->r);
+  });
+}
+int32_t pg_result_all_reduce(pg_result_t result, pg_comm_t comm) {
+  return guarded([&] {
+    REQUIRE(result && comm && comm->c, "null argument");
+    result_all_reduce(*result->r, *comm->c);
+  });
+}
+int32_t pg_comm_get_unique_id(void* out_unique_id) {
+  return guarded([&] { REQUIRE(out_unique_id, "null argument"); comm_unique_id(out_unique_id); });
+}
+int32_t pg_comm_init_rank(int32_t device_ordinal, int32_t world_size, int32_t rank, const void* unique_id, pg_comm_t* out_comm) {
+  return guarded([&] {
+    REQUIRE(unique_id && out_comm, "null argument");
+    auto h = std::make_unique<pg_comm_s>();
+    h->c = comm_init_rank(device_ordinal, world_size, rank, unique_id);
+    *out_comm = h.release();
+  });
+}
+int32_t pg_comm_init_all(int32_t n_devices, const int32_t* device_ordinals, pg_comm_t* out_comms) {
+  return guarded([&] {
+    REQUIRE(device_ordinals && out_comms && n_devices > 0, "null argument");
+    std::vector<Comm*> cs((size_t)n_devices, nullptr);
+    comm_init_all(n_devices, device_ordinals, cs.data());
+    for (int i = 0; i < n_devices; i++) {
+      auto* h = new pg_comm_s();
+      h->c = cs[(size_t)i];
+      out_comms[i] = h;
+    }
+  });
+}
+int32_t pg_comm_world_size(pg_comm_t comm, int32_t* out_world_size) {
+  return guarded([&] { REQUIRE(comm && comm->c && out_world_size, "null argument"); *out_world_size = comm_world(*comm->c); });
+}
+int32_t pg_comm_destroy(pg_comm_t comm) {
+  return guarded([&] {
+    if (comm) comm_destroy(comm->c);
+    delete comm;
   });
 }
 
@@ -241,7 +333,10 @@ int32_t pg_result_stats(pg_result_t result, pg_exec_stats* out_stats) {
   return guarded([&] { REQUIRE(result && out_stats, "null argument"); *out_stats = result->r->stats; });
 }
 int32_t pg_result_free(pg_result_t result) {
-  return guarded([&] { delete result; });
+  return guarded([&] {
+    if (result && result->r && result->r->dev) use_device(result->r->dev->device);
+    delete result;
+  });
 }
 
 }  // extern "C"

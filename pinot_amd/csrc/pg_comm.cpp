@@ -1,0 +1,186 @@
+// Cross-GPU merge of dense group tables over RCCL (pg_comm_*, pg_result_all_reduce): the one exchange step of the path
+//  — what GroupByCombineOperator.mergeResults does across worker threads
+// (pinot-core/.../operator/combine/GroupByCombineOperator.java:102-165,191-222), for segments pinned one per GPU that share
+// their key space.  Payloads are KBs..MBs (groups x accumulators x 8 B, + 2^log2m register bytes per group), i.e. the
+// collective is latency-bound: every accumulator row goes into ONE grouped RCCL launch (ncclGroupStart/End), in place on
+// the table the query kernels left in HBM; no host round trip, no pickling.
+//
+// librccl is opened on first use (dlopen by soname: inside a process that already loaded RCCL — PyTorch's bundled copy under
+// bench.py — this resolves to that same copy, so there is one RCCL and one HIP runtime per process).  Single-GPU callers never
+// touch it and the library has no link-time dependency on RCCL.
+#include <dlfcn.h>
+
+#include "pg_internal.hpp"
+
+namespace pg {
+
+// ---- the slice of rccl.h this file uses (stable NCCL 2.x ABI) -------------------------------------------------------------------
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef int ncclResult_t;   // 0 = ncclSuccess
+enum { kNcclInt8 = 0, kNcclUint8 = 1, kNcclInt32 = 2, kNcclInt64 = 4 };   // ncclDataType_t
+enum { kNcclSum = 0, kNcclProd = 1, kNcclMax = 2, kNcclMin = 3 };          // ncclRedOp_t
+
+struct Rccl {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static Rccl g_rccl;
+static std::mutex g_rccl_mu;
+
+static Rccl& rccl() {
+  std::lock_guard<std::mutex> g(g_rccl_mu);
+  if (g_rccl.handle) return g_rccl;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* n : names)
+    if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+  if (!h) fail(PG_ERR_DEVICE, "cannot load librccl (%s): the cross-GPU merge needs RCCL", dlerror());
+  Rccl r;
+  r.handle = h;
+  auto sym = [&](const char* name) {
+    void* p = dlsym(h, name);
+    if (!p) fail(PG_ERR_DEVICE, "librccl lacks %s", name);
+    return p;
+  };
+  r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+  r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+  r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+  r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+  r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+  r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+  r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+  r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+  r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+  g_rccl = r;
+  return g_rccl;
+}
+#define PG_NCCL(expr)                                                                                         \
+  do {                                                                                                        \
+    ncclResult_t _r = (expr);                                                                                 \
+    if (_r != 0) ::pg::fail(PG_ERR_DEVICE, "RCCL error %d (%s) at %s:%d: %s", _r, rccl().GetErrorString(_r), __FILE__, __LINE__, #expr); \
+  } while (0)
+
+struct Comm {
+  ncclComm_t comm = nullptr;
+  int device = 0;
+  int world = 1;
+  int rank = 0;
+  DeviceBuffer scratch;   // signature exchange, gathered dictId sets
+};
+
+void comm_unique_id(void* out128) {
+  ncclUniqueId id;
+  memset(&id, 0, sizeof(id));
+  PG_NCCL(rccl().GetUniqueId(&id));
+  memcpy(out128, id.internal, sizeof(id.internal));
+}
+
+Comm* comm_init_rank(int device, int world, int rank, const void* id128) {
+  if (world < 1 || rank < 0 || rank >= world) fail(PG_ERR_INVALID_ARGUMENT, "pg_comm_init_rank: rank %d of %d", rank, world);
+  use_device(device);
+  ncclUniqueId id;
+  memcpy(id.internal, id128, sizeof(id.internal));
+  auto c = std::make_unique<Comm>();
+  c->device = device;
+  c->world = world;
+  c->rank = rank;
+  PG_NCCL(rccl().CommInitRank(&c->comm, world, id, rank));
+  return c.release();
+}
+
+void comm_init_all(int n, const int32_t* devices, Comm** out) {
+  if (n < 1 || n > 64) fail(PG_ERR_INVALID_ARGUMENT, "pg_comm_init_all: %d devices", n);
+  std::vector<int> devs(devices, devices + n);
+  for (int d : devs) use_device(d);   // validates the ordinals, initialises each device
+  std::vector<ncclComm_t> comms((size_t)n, nullptr);
+  PG_NCCL(rccl().CommInitAll(comms.data(), n, devs.data()));
+  for (int i = 0; i < n; i++) {
+    auto c = std::make_unique<Comm>();
+    c->comm = comms[(size_t)i];
+    c->device = devs[(size_t)i];
+    c->world = n;
+    c->rank = i;
+    out[i] = c.release();
+  }
+}
+
+int comm_world(const Comm& c) { return c.world; }
+
+void comm_destroy(Comm* c) {
+  if (!c) return;
+  if (c->comm) {
+    (void)hipSetDevice(c->device);
+    (void)rccl().CommDestroy(c->comm);
+  }
+  delete c;
+}
+
+// Every rank calls this with its own result of the same query.  In place on the retained device table:
+//   row o of the accumulator table   ncclSum (COUNT, SUM limbs) / ncclMin / ncclMax on int64 (float MIN / MAX are order-preserving
+//                                    int64 keys, float SUMs are fixed-point int64 limbs: every merge is exact and order-free)
+//   statistics counters + tail       ncclSum on int64
+//   HyperLogLog registers            ncclMax on uint8
+//   dictId sets                      all-gather + OR (RCCL has no bitwise reduction)
+// preceded by a min / max exchange of the layout signature, so that mismatched tables fail on every rank alike.
+void result_all_reduce(Result& r, Comm& c) {
+  if (!r.dev) fail(PG_ERR_INVALID_ARGUMENT, "pg_result_all_reduce needs a result executed with PG_QUERY_FLAG_KEEP_DEVICE_TABLE");
+  DeviceTable& T = *r.dev;
+  if (T.device != c.device) fail(PG_ERR_INVALID_ARGUMENT, "pg_result_all_reduce: result on device %d, communicator on device %d", T.device, c.device);
+  use_device(T.device);
+  hipStream_t stream = thread_stream(T.device);
+  Rccl& R = rccl();
+  const PgQueryPlan& D = T.plan->dev;
+  device_table_tail_store(T, stream);
+  // ---- layout check: max(sig) and max(-sig) over the ranks must describe one value -----------------------------------------------
+  if (c.scratch.size < 64) c.scratch.alloc(64);
+  const int64_t sig = table_signature(T);
+  int64_t probe[2] = {sig, -sig};
+  PG_HIP(hipMemcpyAsync(c.scratch.ptr, probe, sizeof(probe), hipMemcpyHostToDevice, stream));
+  PG_NCCL(R.AllReduce(c.scratch.ptr, c.scratch.ptr, 2, kNcclInt64, kNcclMax, c.comm, stream));
+  PG_HIP(hipMemcpyAsync(probe, c.scratch.ptr, sizeof(probe), hipMemcpyDeviceToHost, stream));
+  PG_HIP(hipStreamSynchronize(stream));
+  if (probe[0] != sig || probe[1] != -sig)
+    fail(PG_ERR_UNSUPPORTED, "pg_result_all_reduce: the ranks' results do not share their table layout (different key space, aggregations or "
+                             "fixed-point scale): merge on the host by values");
+  // ---- the merge: one grouped launch -------------------------------------------------------------------------------------------------
+  const int64_t G = std::max(D.n_groups, 1);
+  int64_t* table = T.table.as<int64_t>();
+  std::vector<std::pair<size_t, size_t>> set_regions;   // (offset, bytes) of dictId-set regions: gathered, then OR-ed
+  PG_NCCL(R.GroupStart());
+  for (int o = 0; o < D.n_ops && T.n_out > 0; o++) {
+    const int red = D.ops[o].fn == PG_ACC_MIN ? kNcclMin : (D.ops[o].fn == PG_ACC_MAX ? kNcclMax : kNcclSum);
+    if (D.ops[o].fn == PG_ACC_SUM && D.ops[o].is_float == 1)
+      fail(PG_ERR_UNSUPPORTED, "pg_result_all_reduce: a floating-point SUM accumulated in double does not merge exactly");
+    PG_NCCL(R.AllReduce(table + (int64_t)o * G, table + (int64_t)o * G, (size_t)G, kNcclInt64, red, c.comm, stream));
+  }
+  PG_NCCL(R.AllReduce(table + T.n_out, table + T.n_out, PG_MAX_STATS + 2, kNcclInt64, kNcclSum, c.comm, stream));
+  size_t off = 0;
+  for (int x = 0; x < D.n_aux; x++) {
+    const size_t bytes = T.plan->aux_bytes[(size_t)x];
+    uint8_t* region = T.aux.as<uint8_t>() + off;
+    if (D.aux[x].kind == PG_AUX_DICT_SET) set_regions.push_back({off, bytes});
+    else PG_NCCL(R.AllReduce(region, region, bytes, kNcclUint8, kNcclMax, c.comm, stream));
+    off += bytes;
+  }
+  PG_NCCL(R.GroupEnd());
+  for (auto& sr : set_regions) {
+    const size_t need = sr.second * (size_t)c.world;
+    if (c.scratch.size < need) c.scratch.alloc(need);
+    uint8_t* region = T.aux.as<uint8_t>() + sr.first;
+    PG_NCCL(R.AllGather(region, c.scratch.ptr, sr.second, kNcclUint8, c.comm, stream));
+    merge_sets_on_stream(reinterpret_cast<uint32_t*>(region), c.scratch.as<uint32_t>(), (int64_t)(sr.second / 4), c.world, stream);
+  }
+  PG_HIP(hipStreamSynchronize(stream));
+  result_reassemble(r);
+}
+
+}  // namespace pg

@@ -79,6 +79,7 @@ __global__ __launch_bounds__(PG_DC_BLOCK) void pg_decompress_chunks_kernel(const
           if (ip + extra > n) { bad = true; break; }
           uint32_t v = 0;
           for (uint32_t k = 0; k < extra; k++) v |= (uint32_t)s_in[ip + k] << (8 * k);
+          if (uni(v) >= want) { bad = true; break; }   // v + 1 > want (and 0xFFFFFFFF + 1 must not wrap to 0)
           lit = uni(v) + 1;
           ip += extra;
         }
@@ -108,13 +109,14 @@ __global__ __launch_bounds__(PG_DC_BLOCK) void pg_decompress_chunks_kernel(const
           if (ip >= n) { bad = true; break; }
           b = uni(s_in[ip++]);
           lit += b;
+          if (lit > want) { bad = true; break; }   // a length chain cannot exceed the chunk (and must not wrap 32 bits)
         } while (b == 255);
         if (bad) break;
       }
       mlen = token & 15u;   // resolved after the literals: the last sequence of a block has none
     }
     if (lit) {
-      if (ip + lit > n || op + lit > want) { bad = true; break; }
+      if (lit > n - ip || lit > want - op) { bad = true; break; }   // ip <= n, op <= want: no 32-bit wrap for 4-byte snappy lengths
       for (uint32_t i = lane; i < lit; i += 64) s_out[op + i] = s_in[ip + i];
       ip += lit;
       op += lit;
@@ -131,6 +133,7 @@ __global__ __launch_bounds__(PG_DC_BLOCK) void pg_decompress_chunks_kernel(const
           if (ip >= n) { bad = true; break; }
           b = uni(s_in[ip++]);
           mlen += b;
+          if (mlen > want) { bad = true; break; }
         } while (b == 255);
         if (bad) break;
       }
@@ -138,7 +141,7 @@ __global__ __launch_bounds__(PG_DC_BLOCK) void pg_decompress_chunks_kernel(const
       if (offset == 0) { bad = true; break; }
     }
     if (mlen) {
-      if (offset > op || op + mlen > want) { bad = true; break; }
+      if (offset > op || mlen > want - op) { bad = true; break; }
       const uint8_t* window = s_out + (op - offset);
       if (offset >= mlen) {
         for (uint32_t i = lane; i < mlen; i += 64) s_out[op + i] = window[i];

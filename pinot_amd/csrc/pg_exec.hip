@@ -50,11 +50,21 @@ void fail(int32_t status, const char* fmt, ...) {
 void DeviceBuffer::alloc(size_t n, bool zero) {
   release();
   size = (n + 255) & ~(size_t)255;
+  PG_HIP(hipGetDevice(&device));
   PG_HIP(hipMalloc(&ptr, size));
   if (zero) PG_HIP(hipMemset(ptr, 0, size));
 }
 void DeviceBuffer::release() {
-  if (ptr) (void)hipFree(ptr);
+  if (ptr) {
+    int cur = -1;
+    if (hipGetDevice(&cur) == hipSuccess && device >= 0 && cur != device) {
+      (void)hipSetDevice(device);
+      (void)hipFree(ptr);
+      (void)hipSetDevice(cur);
+    } else {
+      (void)hipFree(ptr);
+    }
+  }
   ptr = nullptr;
   size = 0;
 }
@@ -64,30 +74,67 @@ void DeviceBuffer::upload(const void* src, size_t n, size_t off) {
   PG_HIP(hipMemcpy(static_cast<uint8_t*>(ptr) + off, src, n, hipMemcpyHostToDevice));
 }
 
-// ---- device / per-thread context ------------------------------------------------------------------------------------------------
-static int g_device = -1;
-static int g_num_cus = 256;
-static size_t g_lds_per_cu = 160 * 1024;
+// ---- devices / per-thread contexts ------------------------------------------------------------------------------------------
+// One process may hold segments on several GPUs (the reference runs every segment of a server in one JVM, one worker task per
+// segment — BaseCombineOperator.java:81-142): a segment names its device, every entry point makes that device current on the
+// calling thread, and each (thread, device) pair owns a stream, events and work areas.
+#define PG_MAX_DEVICES 32
+struct DeviceInfo {
+  std::atomic<int> ready{0};
+  int num_cus = 256;
+  size_t lds_per_cu = 160 * 1024;
+};
+static DeviceInfo g_devices[PG_MAX_DEVICES];
+static std::mutex g_devices_mu;
+static std::atomic<int> g_default_device{-1};
+static thread_local int t_device = 0;   // the device use_device() made current on this thread
 
-void device_init(int ordinal) {
+static int device_count_or_fail() {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0)
     fail(PG_ERR_DEVICE, "no HIP device available (%s): libpinot_gpu has no CPU fallback", hipGetErrorName(e));
-  if (ordinal < 0 || ordinal >= n) fail(PG_ERR_INVALID_ARGUMENT, "device ordinal %d out of range (0..%d)", ordinal, n - 1);
-  PG_HIP(hipSetDevice(ordinal));
-  hipDeviceProp_t prop;
-  PG_HIP(hipGetDeviceProperties(&prop, ordinal));
-  g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  g_lds_per_cu = prop.maxSharedMemoryPerMultiProcessor > 0 ? (size_t)prop.maxSharedMemoryPerMultiProcessor : 160 * 1024;
-  g_device = ordinal;
-  // opt in to large dynamic LDS for the query kernels
-  typedef void (*QueryKernel)(const PgQueryPlan);
-  const QueryKernel all[] = {pg_generic_query_f, pg_generic_query_l, pg_generic_query_g, pg_fast_none_f, pg_fast_none_a, pg_fast_i32range_f, pg_fast_i32range_a,
-                             pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a, pg_fast_multi_f, pg_fast_multi_a, pg_fast_multi_w, pg_fast_none_w, pg_radix_aggregate_kernel, pg_hash_aggregate_kernel};
-  for (QueryKernel k : all)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
+  return n;
 }
+
+void use_device(int ordinal) {
+  if (ordinal < 0 || ordinal >= PG_MAX_DEVICES) fail(PG_ERR_INVALID_ARGUMENT, "device ordinal %d out of range", ordinal);
+  DeviceInfo& di = g_devices[ordinal];
+  if (!di.ready.load(std::memory_order_acquire)) {
+    std::lock_guard<std::mutex> g(g_devices_mu);
+    if (!di.ready.load(std::memory_order_relaxed)) {
+      const int n = device_count_or_fail();
+      if (ordinal >= n) fail(PG_ERR_INVALID_ARGUMENT, "device ordinal %d out of range (0..%d)", ordinal, n - 1);
+      PG_HIP(hipSetDevice(ordinal));
+      hipDeviceProp_t prop;
+      PG_HIP(hipGetDeviceProperties(&prop, ordinal));
+      di.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+      di.lds_per_cu = prop.maxSharedMemoryPerMultiProcessor > 0 ? (size_t)prop.maxSharedMemoryPerMultiProcessor : 160 * 1024;
+      // opt in to large dynamic LDS for the query kernels (function attributes are per device)
+      typedef void (*QueryKernel)(const PgQueryPlan);
+      const QueryKernel all[] = {pg_generic_query_f, pg_generic_query_l, pg_generic_query_g, pg_fast_none_f, pg_fast_none_a, pg_fast_i32range_f, pg_fast_i32range_a,
+                                 pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a, pg_fast_multi_f, pg_fast_multi_a, pg_fast_multi_w, pg_fast_none_w, pg_radix_aggregate_kernel, pg_hash_aggregate_kernel};
+      for (QueryKernel k : all)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
+      di.ready.store(1, std::memory_order_release);
+    }
+  }
+  PG_HIP(hipSetDevice(ordinal));
+  t_device = ordinal;
+}
+
+void device_init(int ordinal) {
+  const int n = device_count_or_fail();
+  if (ordinal < 0 || ordinal >= n) fail(PG_ERR_INVALID_ARGUMENT, "device ordinal %d out of range (0..%d)", ordinal, n - 1);
+  use_device(ordinal);
+  g_default_device.store(ordinal);
+}
+int default_device() {
+  const int d = g_default_device.load();
+  return d < 0 ? 0 : d;
+}
+static int num_cus() { return g_devices[t_device].num_cus; }
+static size_t lds_per_cu() { return g_devices[t_device].lds_per_cu; }
 
 static bool uses_fast_kernel(const CompiledPlan& P, int agg_mode) {
   static const bool force_interpreter = getenv("PG_FORCE_INTERPRETER") != nullptr;   // measurement knob
@@ -145,8 +192,6 @@ struct ThreadCtx {
     if (stream) (void)hipStreamDestroy(stream);
   }
   void ensure() {
-    if (g_device < 0) device_init(0);
-    PG_HIP(hipSetDevice(g_device));
     if (!stream) {
       PG_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
       for (auto& e : ev) PG_HIP(hipEventCreate(&e));
@@ -155,13 +200,29 @@ struct ThreadCtx {
   }
   static void grow(DeviceBuffer& b, size_t n) { if (b.size < n) b.alloc(n + n / 4); }
 };
-static thread_local ThreadCtx t_ctx;
+struct ThreadCtxSet {
+  std::unique_ptr<ThreadCtx> per_device[PG_MAX_DEVICES];
+  ~ThreadCtxSet() {
+    for (int d = 0; d < PG_MAX_DEVICES; d++)
+      if (per_device[d]) { (void)hipSetDevice(d); per_device[d].reset(); }
+  }
+};
+static thread_local ThreadCtxSet t_ctxs;
+// the calling thread's context on `device`, with that device made current
+static ThreadCtx& ctx_on(int device) {
+  use_device(device);
+  auto& slot = t_ctxs.per_device[device];
+  if (!slot) slot = std::make_unique<ThreadCtx>();
+  slot->ensure();
+  return *slot;
+}
+hipStream_t thread_stream(int device) { return ctx_on(device).stream; }
 
 static double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-static std::shared_ptr<CompiledPlan> get_plan(Segment& seg, const pg_filter_node* filter, const pg_query* q) {
+std::shared_ptr<CompiledPlan> get_plan(Segment& seg, const pg_filter_node* filter, const pg_query* q) {
   std::string sig = query_signature(filter, q);
   // compilation stays under the segment's lock: it fills per-column caches (HyperLogLog look-up tables) and uploads leaves
   std::lock_guard<std::mutex> g(seg.mu);
@@ -178,31 +239,31 @@ static LaunchShape launch_shape(const CompiledPlan& P, int n_wtiles, int agg_mod
   size_t lds = P.lds_bytes + 64;
   if (P.dev.agg_mode == PG_AGG_LDS_PART && agg_mode == PG_AGG_LDS_PART) {
     // range-partitioned aggregation: one workgroup per CU, 8 x per_xcd of them with per_xcd a multiple of the range count
-    int per_xcd = std::max(g_num_cus / 8, 1);
+    int per_xcd = std::max(num_cus() / 8, 1);
     per_xcd = std::max(per_xcd / P.dev.n_parts, 1) * P.dev.n_parts;
     return {8 * per_xcd, uses_fast_kernel(P, agg_mode) ? PG_BLOCK : PG_GENERIC_BLOCK, lds};
   }
   if (uses_fast_kernel(P, agg_mode)) {
     // one 16-wave workgroup per CU; fewer when the segment has fewer wave tiles than that
     static const int wgs_per_cu = getenv("PG_WGS_PER_CU") ? atoi(getenv("PG_WGS_PER_CU")) : 1;   // tuning knob
-    const int per_cu = ((size_t)wgs_per_cu * (lds + 4096) <= g_lds_per_cu) ? wgs_per_cu : 1;
-    int grid = std::min((n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, g_num_cus * per_cu);
+    const int per_cu = ((size_t)wgs_per_cu * (lds + 4096) <= lds_per_cu()) ? wgs_per_cu : 1;
+    int grid = std::min((n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, num_cus() * per_cu);
     return {std::max(grid, 1), PG_BLOCK, lds};
   }
   // interpreter kernel: 8-wave workgroups, two per CU when both LDS tables fit
   const int waves = PG_GENERIC_BLOCK / 64;
-  const int per_cu = (2 * (lds + 4096) <= g_lds_per_cu) ? 2 : 1;
-  int grid = std::min((n_wtiles + waves - 1) / waves, g_num_cus * per_cu);
+  const int per_cu = (2 * (lds + 4096) <= lds_per_cu()) ? 2 : 1;
+  int grid = std::min((n_wtiles + waves - 1) / waves, num_cus() * per_cu);
   return {std::max(grid, 1), PG_GENERIC_BLOCK, lds};
 }
 
-static void fill_stats(pg_exec_stats& st, const CompiledPlan& P, const Segment& seg, const uint64_t* stats_host) {
+static void fill_stats(pg_exec_stats& st, const CompiledPlan& P, int64_t full_scan_entries, int64_t total_docs, const uint64_t* stats_host) {
   st.num_docs_scanned = (int64_t)stats_host[0];
-  int64_t in_filter = P.full_scan_entries;
+  int64_t in_filter = full_scan_entries;
   for (int i = 1; i < P.n_stat_slots; i++) in_filter += (int64_t)stats_host[i];
   st.num_entries_scanned_in_filter = in_filter;
   st.num_entries_scanned_post_filter = st.num_docs_scanned * P.n_projected_columns;
-  st.num_total_docs = seg.total_docs;
+  st.num_total_docs = total_docs;
   st.stats_exact = P.stats_exact ? 1 : 0;
   st.algorithmic_bytes = P.algorithmic_bytes;
 }
@@ -214,14 +275,46 @@ static double order_key_to_double(int64_t k) {
   return d;
 }
 
-std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
+// ---- result assembly: dense accumulator table (+ statistics, + DISTINCTCOUNT / HLL regions) -> groups and intermediates --------
+struct HostTable {
+  std::vector<int64_t> table;            // [n_ops][G] (G = groups of the compact table for hashed key spaces)
+  uint64_t stats[PG_MAX_STATS] = {0};
+  uint8_t* aux = nullptr;                // merged auxiliary regions (replicas are folded in place)
+  bool hashed = false;
+  int64_t hash_groups = 0;
+  std::vector<int64_t> hash_keys;        // PG_AGG_RADIX_HASH: raw key of every group of the compact table
+  int64_t full_scan_entries = 0;
+  int64_t total_docs = 0;
+};
+static void assemble_result(Result& res_out, const CompiledPlan& P, int32_t n_group_by, int32_t n_aggregations, HostTable& H);
+
+static void check_cancel(const CancelToken* c, ThreadCtx* ctx) {
+  if (c && c->requested.load(std::memory_order_acquire)) {
+    if (ctx && ctx->stream) { (void)hipStreamSynchronize(ctx->stream); ctx->stats_dirty = true; }   // let what was launched finish
+    fail(PG_ERR_CANCELLED, "query cancelled (EarlyTerminationException)");
+  }
+}
+// Waits for the stream; with a cancellation token the wait polls it (a running kernel is left to finish: milliseconds).
+static void stream_wait(ThreadCtx& ctx, const CancelToken* c) {
+  if (!c) { PG_HIP(hipStreamSynchronize(ctx.stream)); return; }
+  for (;;) {
+    const hipError_t e = hipStreamQuery(ctx.stream);
+    if (e == hipSuccess) break;
+    if (e != hipErrorNotReady) PG_HIP(e);
+    if (c->requested.load(std::memory_order_acquire)) check_cancel(c, &ctx);
+  }
+  check_cancel(c, &ctx);
+}
+
+std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const CancelToken* cancel) {
   const double t0 = now_ms();
   if (q.n_aggregations <= 0 || !q.aggregations) fail(PG_ERR_INVALID_ARGUMENT, "query has no aggregation");
-  ThreadCtx& ctx = t_ctx;
-  ctx.ensure();
+  check_cancel(cancel, nullptr);
+  ThreadCtx& ctx = ctx_on(seg.device);
   auto plan = get_plan(seg, q.filter, &q);
   CompiledPlan& P = *plan;
   const double t_plan = now_ms();
+  check_cancel(cancel, nullptr);
   const bool profile = (q.flags & PG_QUERY_FLAG_PROFILE) != 0;
 
   if (P.non_scan_based) {
@@ -296,7 +389,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   for (size_t b : P.aux_bytes) aux_total += b;
   std::vector<uint32_t*> aux_final((size_t)D.n_aux, nullptr);
   const bool radix_aux = D.agg_mode == PG_AGG_RADIX && D.n_aux > 0;   // HLL registers of a bucket in LDS, one partial per work item
-  if (radix_aux) D.radix_slices = std::max(1, g_num_cus / D.radix_buckets);
+  if (radix_aux) D.radix_slices = std::max(1, num_cus() / D.radix_buckets);
   if (aux_total) {
     // LDS-resident states: the kernel writes one partial per workgroup behind the merged regions
     size_t partial_total = P.aux_in_lds ? aux_total * (size_t)shape.grid : 0;
@@ -320,6 +413,11 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
   const char* kname = "";
   const bool has_docs = P.space_docs > 0;   // docs of the doc space the plan runs on (the segment's or a star-tree's)
   const bool hashed = D.agg_mode == PG_AGG_RADIX_HASH;
+  const bool keep_table = (q.flags & PG_QUERY_FLAG_KEEP_DEVICE_TABLE) != 0;
+  if (keep_table && (hashed || P.first_doc_op >= 0))
+    fail(PG_ERR_UNSUPPORTED, "PG_QUERY_FLAG_KEEP_DEVICE_TABLE: %s has no dense table that merges element-wise (merge on the host by values)",
+         hashed ? "a hashed key space" : "a key space beyond numGroupsLimit");
+  std::unique_ptr<DeviceTable> kept;
   const bool radix = D.agg_mode == PG_AGG_RADIX || hashed;
   int64_t hash_groups = 0;
   if (has_docs && radix) {
@@ -337,13 +435,13 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
     // the tuple area is sized by the docs that passed the filter, not by the segment (48 B x 2^31 docs would not fit)
     unsigned long long matched_now = 0;
     PG_HIP(hipMemcpyAsync(&matched_now, ctx.stats.ptr, 8, hipMemcpyDeviceToHost, ctx.stream));
-    PG_HIP(hipStreamSynchronize(ctx.stream));
+    stream_wait(ctx, cancel);
     if (hashed) {   // buckets sized so that even all-distinct keys half-fill a bucket's table, within [16, 2048]
       int nb = 16;
       while (nb < PG_MAX_RADIX_BUCKETS && (unsigned long long)nb * (unsigned long long)(D.hash_cap / 2) < matched_now) nb *= 2;
       D.radix_buckets = nb;
     }
-    const int rgrid = std::max(1, std::min((D.n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, g_num_cus));
+    const int rgrid = std::max(1, std::min((D.n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, num_cus()));
     ThreadCtx::grow(ctx.radix_hist, (size_t)rgrid * D.radix_buckets * 4);
     ThreadCtx::grow(ctx.radix_start, ((size_t)D.radix_buckets + 1) * 8);
     D.radix_stride = hashed ? ((16 + 8 * (int64_t)D.n_srcs + 15) & ~(int64_t)15)
@@ -368,12 +466,12 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
                          bucket_total, rgrid, D.radix_buckets);
       hipLaunchKernelGGL(pg_radix_bucket_scan_kernel, dim3(1), dim3(64), 0, ctx.stream, bucket_total, D.radix_bucket_start, D.radix_buckets);
       hipLaunchKernelGGL(pg_hash_scatter_kernel, dim3(rgrid), dim3(PG_BLOCK), 0, ctx.stream, D);
-      hipLaunchKernelGGL(pg_hash_aggregate_kernel, dim3(std::min(D.radix_buckets, g_num_cus)), dim3(PG_BLOCK),
+      hipLaunchKernelGGL(pg_hash_aggregate_kernel, dim3(std::min(D.radix_buckets, num_cus())), dim3(PG_BLOCK),
                          (size_t)D.hash_cap * (8 + 8 * (size_t)D.n_ops) + 64, ctx.stream, D);
       PG_HIP(hipGetLastError());
       kname = "pg_hash_group_by";
     } else {
-      D.radix_slices = std::max(1, g_num_cus / D.radix_buckets);
+      D.radix_slices = std::max(1, num_cus() / D.radix_buckets);
       const size_t slots = (size_t)1 << D.radix_shift;
       ThreadCtx::grow(ctx.partials, (size_t)D.radix_buckets * D.radix_slices * D.n_ops * slots * 8 + 8);
       D.partials = ctx.partials.as<int64_t>();
@@ -382,7 +480,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
                          bucket_total, rgrid, D.radix_buckets);
       hipLaunchKernelGGL(pg_radix_bucket_scan_kernel, dim3(1), dim3(64), 0, ctx.stream, bucket_total, D.radix_bucket_start, D.radix_buckets);
       hipLaunchKernelGGL(pg_radix_scatter_kernel, dim3(rgrid), dim3(PG_BLOCK), 0, ctx.stream, D);
-      const int agrid = std::min(D.radix_buckets * D.radix_slices, g_num_cus);
+      const int agrid = std::min(D.radix_buckets * D.radix_slices, num_cus());
       size_t agg_lds = (size_t)D.n_ops * slots * 8 + 64;
       for (int x = 0; x < D.n_aux; x++) agg_lds += slots * (size_t)D.aux[x].stride;
       hipLaunchKernelGGL(pg_radix_aggregate_kernel, dim3(agrid), dim3(PG_BLOCK), agg_lds, ctx.stream, D);
@@ -426,7 +524,16 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
     if (profile) PG_HIP(hipEventRecord(ctx.ev[2], ctx.stream));
     PG_HIP(hipMemcpyAsync(host_out, ctx.final_table.ptr, out_bytes, hipMemcpyDeviceToHost, ctx.stream));
     if (aux_total) PG_HIP(hipMemcpyAsync(aux_host, ctx.aux.ptr, aux_total, hipMemcpyDeviceToHost, ctx.stream));
-    PG_HIP(hipStreamSynchronize(ctx.stream));
+    if (keep_table) {   // PG_QUERY_FLAG_KEEP_DEVICE_TABLE: the dense table, its counters and states stay in HBM with the result
+      kept = std::make_unique<DeviceTable>();
+      kept->table.alloc(out_bytes + 2 * 8);
+      PG_HIP(hipMemcpyAsync(kept->table.ptr, ctx.final_table.ptr, out_bytes, hipMemcpyDeviceToDevice, ctx.stream));
+      if (aux_total) {
+        kept->aux.alloc(aux_total);
+        PG_HIP(hipMemcpyAsync(kept->aux.ptr, ctx.aux.ptr, aux_total, hipMemcpyDeviceToDevice, ctx.stream));
+      }
+    }
+    stream_wait(ctx, cancel);
     if (n_out) memcpy(table.data(), host_out, (size_t)n_out * 8);
     memcpy(stats_host, host_out + n_out, sizeof(stats_host));
     ctx.stats_dirty = false;    // the reduce kernel left them zero
@@ -456,9 +563,23 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
     if (aux_total) memset(aux_host, 0, aux_total);
   }
 
+  if (keep_table && !has_docs) {   // an empty doc space still yields a (neutral) table to merge with
+    kept = std::make_unique<DeviceTable>();
+    kept->table.alloc(out_bytes + 2 * 8, true);
+    if (n_out) kept->table.upload(table.data(), (size_t)n_out * 8);
+    if (aux_total) kept->aux.alloc(aux_total, true);
+  }
   auto res = std::make_unique<Result>();
-  fill_stats(res->stats, P, seg, stats_host);
-  res->stats.star_tree_index = P.star_tree_index;
+  HostTable H;
+  H.table = std::move(table);
+  memcpy(H.stats, stats_host, sizeof(stats_host));
+  H.aux = aux_host;
+  H.hashed = hashed;
+  H.hash_groups = hash_groups;
+  H.hash_keys = std::move(hash_keys_host);
+  H.full_scan_entries = P.full_scan_entries;
+  H.total_docs = seg.total_docs;
+  assemble_result(*res, P, q.n_group_by, q.n_aggregations, H);
   snprintf(res->stats.kernel, sizeof(res->stats.kernel), "%s", kname);
   if (profile) {
     float a = 0, b = 0;
@@ -469,21 +590,50 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
     res->stats.device_ms_reduce = b;
     res->stats.device_ms_total = a + b;
   }
+  if (kept) {
+    kept->plan = plan;
+    kept->device = seg.device;
+    kept->n_group_by = q.n_group_by;
+    kept->n_aggregations = q.n_aggregations;
+    kept->n_out = n_out;
+    kept->aux_total = aux_total;
+    kept->full_scan_entries = P.full_scan_entries;
+    kept->num_total_docs = seg.total_docs;
+    res->dev = std::move(kept);
+  }
+  res->stats.host_ms_plan = (float)(t_plan - t0);
+  res->stats.host_ms_total = (float)(now_ms() - t0);
+  return res;
+}
 
+static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_by, int32_t n_aggregations, HostTable& H) {
+  const PgQueryPlan& D = P.dev;
+  const bool hashed = H.hashed;
+  std::vector<int64_t>& table = H.table;
+  const pg_exec_stats keep = res.stats;   // timings / kernel name survive a re-assembly after a merge
+  fill_stats(res.stats, P, H.full_scan_entries, H.total_docs, H.stats);
+  res.stats.star_tree_index = P.star_tree_index;
+  res.stats.device_ms_total = keep.device_ms_total; res.stats.device_ms_filter = keep.device_ms_filter;
+  res.stats.device_ms_aggregate = keep.device_ms_aggregate; res.stats.device_ms_reduce = keep.device_ms_reduce;
+  res.stats.host_ms_plan = keep.host_ms_plan; res.stats.host_ms_total = keep.host_ms_total;
+  memcpy(res.stats.kernel, keep.kernel, sizeof(keep.kernel));
+  res.group_dict_ids.clear();
+  res.group_values.clear();
+  res.aggs.clear();
   // ---- assemble groups: a group exists iff its hidden COUNT is > 0 (ArrayBasedHolder flags / map entries) ----------------
-  const int64_t G = hashed ? hash_groups : D.n_groups;   // hashed key space: the compact table of the groups found
-  const int64_t matched = (int64_t)stats_host[0];
+  const int64_t G = hashed ? H.hash_groups : D.n_groups;   // hashed key space: the compact table of the groups found
+  const int64_t matched = (int64_t)H.stats[0];
   const bool ex_stats = P.exist_op == kCountFromStats;
   const int64_t* ex = ex_stats ? nullptr : table.data() + (size_t)P.exist_op * G;
   const int64_t ex_ident = ex_stats ? 0 : pg_acc_identity(D.ops[P.exist_op].fn, 0);
   auto exists = [&](int64_t g) { return ex_stats ? matched > 0 : ex[g] != ex_ident; };   // COUNT: != 0; MIN/MAX over INT: left its identity
   auto count_of = [&](int32_t op, int64_t g) { return op == kCountFromStats ? matched : table[(size_t)op * G + g]; };
   std::vector<int64_t> gids;
-  if (q.n_group_by == 0) gids.push_back(0);
+  if (n_group_by == 0) gids.push_back(0);
   else if (hashed) { gids.resize((size_t)G); for (int64_t g = 0; g < G; g++) gids[(size_t)g] = g; }
   else for (int64_t g = 0; g < G; g++) if (exists(g)) gids.push_back(g);
-  bool limit_reached = q.n_group_by > 0 && (int64_t)gids.size() >= (int64_t)P.num_groups_limit;
-  if (q.n_group_by > 0 && (int64_t)gids.size() > (int64_t)P.num_groups_limit) {
+  bool limit_reached = n_group_by > 0 && (int64_t)gids.size() >= (int64_t)P.num_groups_limit;
+  if (n_group_by > 0 && (int64_t)gids.size() > (int64_t)P.num_groups_limit) {
     // keep the numGroupsLimit groups whose first matching docId is smallest (= the keys the reference admits in docId order)
     if (P.first_doc_op < 0) fail(PG_ERR_INTERNAL, "plan lacks the first-docId accumulator");
     const int64_t* first = table.data() + (size_t)P.first_doc_op * G;
@@ -492,24 +642,24 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
     std::sort(gids.begin(), gids.end());
   }
   const int32_t ng = (int32_t)gids.size();
-  res->num_groups = ng;
+  res.num_groups = ng;
   if (P.raw_group) {   // values, not dictIds: key = value ^ 2^63
-    res->raw_group_keys = true;
-    res->group_values.resize((size_t)ng);
-    for (int32_t i = 0; i < ng; i++) res->group_values[(size_t)i] = (int64_t)((uint64_t)hash_keys_host[(size_t)gids[i]] ^ (1ULL << 63));
+    res.raw_group_keys = true;
+    res.group_values.resize((size_t)ng);
+    for (int32_t i = 0; i < ng; i++) res.group_values[(size_t)i] = (int64_t)((uint64_t)H.hash_keys[(size_t)gids[i]] ^ (1ULL << 63));
   }
-  res->group_dict_ids.resize((size_t)q.n_group_by);
-  for (int j = 0; j < q.n_group_by && !P.raw_group; j++) {
-    auto& v = res->group_dict_ids[j];
+  res.group_dict_ids.resize((size_t)n_group_by);
+  for (int j = 0; j < n_group_by && !P.raw_group; j++) {
+    auto& v = res.group_dict_ids[j];
     v.resize((size_t)ng);
     int64_t mult = D.gcols[j].mult;
     int32_t card = P.group_cards[j];
     for (int32_t i = 0; i < ng; i++) {   // getKeys: col 0 least significant
-      const int64_t raw = hashed ? hash_keys_host[(size_t)gids[i]] : gids[i];
+      const int64_t raw = hashed ? H.hash_keys[(size_t)gids[i]] : gids[i];
       v[i] = (int32_t)((raw / mult) % card);
     }
   }
-  if (q.n_group_by > 0) res->stats.num_groups_limit_reached = limit_reached ? 1 : 0;
+  if (n_group_by > 0) res.stats.num_groups_limit_reached = limit_reached ? 1 : 0;
 
   auto op_double = [&](int o, int64_t g) -> double {
     const PgAccOp& op = D.ops[o];
@@ -528,10 +678,10 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
         return op.is_float ? order_key_to_double(v) : (double)v;
     }
   };
-  res->aggs.resize((size_t)q.n_aggregations);
-  for (int a = 0; a < q.n_aggregations; a++) {
+  res.aggs.resize((size_t)n_aggregations);
+  for (int a = 0; a < n_aggregations; a++) {
     const AggOut& ao = P.aggs[a];
-    AggResult& r = res->aggs[a];
+    AggResult& r = res.aggs[a];
     for (int k = 0; k < 2; k++) { r.d[k].assign((size_t)ng, 0.0); r.l[k].assign((size_t)ng, 0); }
     if (ao.aux >= 0) {   // DISTINCTCOUNT / DISTINCTCOUNTHLL: extract the groups' regions
       size_t off = 0;
@@ -539,15 +689,15 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
       const PgAuxOp& A = D.aux[ao.aux];
       // merge the replicas into replica 0 (set union / register max)
       for (int rr = 1; rr < A.n_rep; rr++) {
-        uint8_t* dst = aux_host + off;
-        const uint8_t* src = aux_host + off + (size_t)rr * (size_t)A.rep_bytes;
+        uint8_t* dst = H.aux + off;
+        const uint8_t* src = H.aux + off + (size_t)rr * (size_t)A.rep_bytes;
         if (A.kind == PG_AUX_DICT_SET) for (int64_t b = 0; b < A.rep_bytes; b++) dst[b] |= src[b];
         else for (int64_t b = 0; b < A.rep_bytes; b++) dst[b] = src[b] > dst[b] ? src[b] : dst[b];
       }
       if (A.kind == PG_AUX_DICT_SET) {
         r.kind = PG_RESULT_DICTID_SET;
         r.set_sizes.assign((size_t)ng, 0);
-        const uint32_t* words = reinterpret_cast<const uint32_t*>(aux_host + off);
+        const uint32_t* words = reinterpret_cast<const uint32_t*>(H.aux + off);
         for (int32_t i = 0; i < ng; i++) {
           const uint32_t* w = words + (size_t)gids[i] * A.stride;
           for (int32_t k = 0; k < A.stride; k++) {
@@ -565,7 +715,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
         r.log2m = ao.log2m;
         r.hll.resize((size_t)ng * A.stride);
         for (int32_t i = 0; i < ng; i++)
-          memcpy(r.hll.data() + (size_t)i * A.stride, aux_host + off + (size_t)gids[i] * A.stride, (size_t)A.stride);
+          memcpy(r.hll.data() + (size_t)i * A.stride, H.aux + off + (size_t)gids[i] * A.stride, (size_t)A.stride);
       }
       continue;
     }
@@ -588,18 +738,121 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q) {
         break;
     }
   }
-  res->stats.host_ms_plan = (float)(t_plan - t0);
-  res->stats.host_ms_total = (float)(now_ms() - t0);
-  return res;
+}
+
+// Rebuilds the host view (groups, intermediates, statistics) of a result from its device table — after a merge.
+void result_reassemble(Result& r) {
+  if (!r.dev) fail(PG_ERR_INVALID_ARGUMENT, "result has no device table (PG_QUERY_FLAG_KEEP_DEVICE_TABLE)");
+  DeviceTable& T = *r.dev;
+  ThreadCtx& ctx = ctx_on(T.device);
+  const size_t out_bytes = ((size_t)T.n_out + PG_MAX_STATS + 2) * 8;
+  int64_t* host_out = static_cast<int64_t*>(ctx.pin(out_bytes + T.aux_total));
+  uint8_t* aux_host = reinterpret_cast<uint8_t*>(host_out) + out_bytes;
+  PG_HIP(hipMemcpyAsync(host_out, T.table.ptr, out_bytes, hipMemcpyDeviceToHost, ctx.stream));
+  if (T.aux_total) PG_HIP(hipMemcpyAsync(aux_host, T.aux.ptr, T.aux_total, hipMemcpyDeviceToHost, ctx.stream));
+  PG_HIP(hipStreamSynchronize(ctx.stream));
+  HostTable H;
+  H.table.assign(host_out, host_out + T.n_out);
+  memcpy(H.stats, host_out + T.n_out, sizeof(H.stats));
+  H.aux = aux_host;
+  H.full_scan_entries = host_out[T.n_out + PG_MAX_STATS];
+  H.total_docs = host_out[T.n_out + PG_MAX_STATS + 1];
+  T.full_scan_entries = H.full_scan_entries;
+  T.num_total_docs = H.total_docs;
+  assemble_result(r, *T.plan, T.n_group_by, T.n_aggregations, H);
+}
+
+// ---- element-wise merge of two dense tables of the same query (GroupByCombineOperator over segments sharing their key space) ----
+extern "C" __global__ void __launch_bounds__(256) pg_merge_tables_kernel(int64_t* __restrict__ dst, const int64_t* __restrict__ src,
+                                                                          int64_t n_out, int64_t n_groups, int64_t n_tail, const PgAccOp* __restrict__ ops) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_out + n_tail) return;
+  if (i >= n_out) { dst[i] += src[i]; return; }   // statistics counters, full-scan entries, total docs
+  const PgAccOp op = ops[i / n_groups];
+  const int64_t a = dst[i], b = src[i];
+  if (op.fn == PG_ACC_MIN) dst[i] = b < a ? b : a;
+  else if (op.fn == PG_ACC_MAX) dst[i] = b > a ? b : a;
+  else if (op.fn == PG_ACC_SUM && op.is_float == 1) dst[i] = __double_as_longlong(__longlong_as_double(a) + __longlong_as_double(b));
+  else dst[i] = a + b;
+}
+extern "C" __global__ void __launch_bounds__(256) pg_merge_aux_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, int64_t n_words,
+                                                                       int n_src, int bytewise_max) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  uint32_t acc = dst[w];
+  for (int k = 0; k < n_src; k++) {
+    const uint32_t v = src[(int64_t)k * n_words + w];
+    if (bytewise_max) {
+      uint32_t r = 0;
+      for (int b = 0; b < 4; b++) {
+        const uint32_t x = (acc >> (8 * b)) & 0xFFu, y = (v >> (8 * b)) & 0xFFu;
+        r |= (x > y ? x : y) << (8 * b);
+      }
+      acc = r;
+    } else {
+      acc |= v;
+    }
+  }
+  dst[w] = acc;
+}
+
+// Layout signature two tables must share to merge element-wise: accumulators, key space, auxiliary states.
+int64_t table_signature(const DeviceTable& T) {
+  const PgQueryPlan& D = T.plan->dev;
+  uint64_t h = 1469598103934665603ULL;
+  auto mix = [&](uint64_t v) { h ^= v; h *= 1099511628211ULL; };
+  mix((uint64_t)T.n_out); mix((uint64_t)D.n_groups); mix((uint64_t)D.n_ops); mix((uint64_t)T.aux_total); mix((uint64_t)T.n_group_by);
+  for (int o = 0; o < D.n_ops; o++) { mix((uint64_t)D.ops[o].fn); mix((uint64_t)D.ops[o].is_float); mix((uint64_t)(uint32_t)D.ops[o].pad); }
+  for (int x = 0; x < D.n_aux; x++) { mix((uint64_t)D.aux[x].kind); mix((uint64_t)D.aux[x].stride); mix((uint64_t)D.aux[x].n_rep); mix((uint64_t)D.aux[x].rep_bytes); }
+  for (size_t a = 0; a < T.plan->aggs.size(); a++) { mix((uint64_t)T.plan->aggs[a].function); mix((uint64_t)(uint32_t)T.plan->aggs[a].op_a); }
+  for (int32_t c : T.plan->group_cards) mix((uint64_t)c);
+  return (int64_t)(h >> 2);   // 62 bits: survives ncclMax / negation
+}
+void device_table_tail_store(DeviceTable& T, hipStream_t stream) {   // full-scan entries + total docs behind the statistics counters
+  const int64_t tail[2] = {T.full_scan_entries, T.num_total_docs};
+  PG_HIP(hipMemcpyAsync(T.table.as<int64_t>() + T.n_out + PG_MAX_STATS, tail, sizeof(tail), hipMemcpyHostToDevice, stream));
+  PG_HIP(hipStreamSynchronize(stream));
+}
+
+void merge_sets_on_stream(uint32_t* dst, const uint32_t* gathered, int64_t n_words, int n_src, hipStream_t stream) {
+  hipLaunchKernelGGL(pg_merge_aux_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, stream, dst, gathered, n_words, n_src, 0);
+  PG_HIP(hipGetLastError());
+}
+
+void result_merge(Result& dst, Result& src) {
+  if (!dst.dev || !src.dev) fail(PG_ERR_INVALID_ARGUMENT, "pg_result_merge needs results executed with PG_QUERY_FLAG_KEEP_DEVICE_TABLE");
+  DeviceTable& A = *dst.dev;
+  DeviceTable& B = *src.dev;
+  if (A.device != B.device) fail(PG_ERR_INVALID_ARGUMENT, "pg_result_merge: results live on devices %d and %d (use pg_result_all_reduce across devices)", A.device, B.device);
+  if (table_signature(A) != table_signature(B))
+    fail(PG_ERR_UNSUPPORTED, "pg_result_merge: the two results do not share their table layout (different key space or aggregations): merge on the host by values");
+  ThreadCtx& ctx = ctx_on(A.device);
+  device_table_tail_store(A, ctx.stream);
+  device_table_tail_store(B, ctx.stream);
+  const int64_t n_tail = PG_MAX_STATS + 2, n = A.n_out + n_tail;
+  hipLaunchKernelGGL(pg_merge_tables_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx.stream, A.table.as<int64_t>(), B.table.as<int64_t>(),
+                     A.n_out, (int64_t)std::max(A.plan->dev.n_groups, 1), n_tail, A.plan->ops_dev.as<PgAccOp>());
+  PG_HIP(hipGetLastError());
+  size_t off = 0;
+  for (int x = 0; x < A.plan->dev.n_aux; x++) {
+    const int64_t n_words = (int64_t)A.plan->aux_bytes[(size_t)x] / 4;
+    hipLaunchKernelGGL(pg_merge_aux_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx.stream,
+                       reinterpret_cast<uint32_t*>(A.aux.as<uint8_t>() + off), reinterpret_cast<const uint32_t*>(B.aux.as<uint8_t>() + off), n_words, 1,
+                       A.plan->dev.aux[x].kind == PG_AUX_DICT_SET ? 0 : 1);
+    PG_HIP(hipGetLastError());
+    off += A.plan->aux_bytes[(size_t)x];
+  }
+  PG_HIP(hipStreamSynchronize(ctx.stream));
+  result_reassemble(dst);
 }
 
 std::unique_ptr<DocIdSet> execute_filter(Segment& seg, const pg_filter_node* filter) {
   const double t0 = now_ms();
-  ThreadCtx& ctx = t_ctx;
-  ctx.ensure();
+  ThreadCtx& ctx = ctx_on(seg.device);
   auto plan = get_plan(seg, filter, nullptr);
   CompiledPlan& P = *plan;
   auto out = std::make_unique<DocIdSet>();
+  out->device = seg.device;
   out->num_docs = seg.total_docs;
   const size_t n_words = (size_t)std::max(seg.n_tiles, 1) * PG_TILE_WORDS;
   out->words.alloc(n_words * 8, true);
@@ -626,7 +879,7 @@ std::unique_ptr<DocIdSet> execute_filter(Segment& seg, const pg_filter_node* fil
   PG_HIP(hipMemcpyAsync(stats_host, ctx.stats.ptr, sizeof(stats_host), hipMemcpyDeviceToHost, ctx.stream));
   PG_HIP(hipMemcpyAsync(out->tile_counts.data(), ctx.tile_counts.ptr, out->tile_counts.size() * 4, hipMemcpyDeviceToHost, ctx.stream));
   PG_HIP(hipStreamSynchronize(ctx.stream));
-  fill_stats(out->stats, P, seg, stats_host);
+  fill_stats(out->stats, P, P.full_scan_entries, seg.total_docs, stats_host);
   out->stats.star_tree_index = -1;
   snprintf(out->stats.kernel, sizeof(out->stats.kernel), "%s", kname);
   out->stats.num_entries_scanned_post_filter = 0;
@@ -642,14 +895,13 @@ std::unique_ptr<DocIdSet> execute_filter(Segment& seg, const pg_filter_node* fil
 void docidset_copy_docids(DocIdSet& s, int32_t* out, int64_t cap) {
   if (cap < s.cardinality) fail(PG_ERR_INVALID_ARGUMENT, "capacity %lld < cardinality %lld", (long long)cap, (long long)s.cardinality);
   if (s.cardinality == 0) return;
-  ThreadCtx& ctx = t_ctx;
-  ctx.ensure();
+  ThreadCtx& ctx = ctx_on(s.device);
   const int n_tiles = (int)s.tile_counts.size();
   std::vector<int64_t> offs((size_t)n_tiles + 1, 0);
   for (int i = 0; i < n_tiles; i++) offs[(size_t)i + 1] = offs[i] + s.tile_counts[i];
   DeviceBuffer d_offs = upload_vector(offs);
   DeviceBuffer d_out((size_t)s.cardinality * 4);
-  int grid = std::min(n_tiles, g_num_cus * 8);
+  int grid = std::min(n_tiles, num_cus() * 8);
   hipLaunchKernelGGL(pg_expand_docids_kernel, dim3(grid), dim3(PG_TILE_WORDS), 0, ctx.stream, s.words.as<uint64_t>(),
                      d_offs.as<int64_t>(), d_out.as<int32_t>(), n_tiles);
   PG_HIP(hipGetLastError());

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime_api.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -37,16 +38,19 @@ const std::string& last_error();
   } while (0)
 
 // ---- device memory -------------------------------------------------------------------------------------------------------
+// Allocated on the device that is current at alloc() time (every entry point first makes the segment's device current) and
+// freed on that same device whatever is current then.
 struct DeviceBuffer {
   void* ptr = nullptr;
   size_t size = 0;
+  int device = -1;
   DeviceBuffer() = default;
   explicit DeviceBuffer(size_t n, bool zero = false) { alloc(n, zero); }
   DeviceBuffer(const DeviceBuffer&) = delete;
   DeviceBuffer& operator=(const DeviceBuffer&) = delete;
-  DeviceBuffer(DeviceBuffer&& o) noexcept : ptr(o.ptr), size(o.size) { o.ptr = nullptr; o.size = 0; }
+  DeviceBuffer(DeviceBuffer&& o) noexcept : ptr(o.ptr), size(o.size), device(o.device) { o.ptr = nullptr; o.size = 0; }
   DeviceBuffer& operator=(DeviceBuffer&& o) noexcept {
-    if (this != &o) { release(); ptr = o.ptr; size = o.size; o.ptr = nullptr; o.size = 0; }
+    if (this != &o) { release(); ptr = o.ptr; size = o.size; device = o.device; o.ptr = nullptr; o.size = 0; }
     return *this;
   }
   ~DeviceBuffer() { release(); }
@@ -96,6 +100,7 @@ struct StarTree;
 
 struct Segment {
   std::string name;
+  int device = 0;                               // HIP device ordinal whose HBM holds the segment (segment -> GPU map)
   int32_t total_docs = 0;
   int32_t n_tiles = 0;
   std::map<std::string, std::unique_ptr<Column>> columns;
@@ -234,7 +239,20 @@ struct AggResult {
   std::vector<uint8_t> hll;                  // PG_RESULT_HLL: num_groups * 2^log2m registers
   int32_t log2m = 0;
 };
+// What pg_result_merge / pg_result_all_reduce need to merge two results of the same query and to re-assemble the groups:
+// the dense accumulator table [n_ops][G] + the statistics counters + the DISTINCTCOUNT / HLL regions, left in HBM.
+struct DeviceTable {
+  std::shared_ptr<CompiledPlan> plan;
+  int device = 0;
+  int32_t n_group_by = 0, n_aggregations = 0;
+  int64_t n_out = 0;            // n_ops * G int64 slots, followed by PG_MAX_STATS statistics counters
+  size_t aux_total = 0;         // bytes of the merged auxiliary regions (replica 0 .. n_rep-1 of every op)
+  DeviceBuffer table, aux;
+  int64_t full_scan_entries = 0;   // summed over the merged segments
+  int64_t num_total_docs = 0;
+};
 struct Result {
+  std::unique_ptr<DeviceTable> dev;    // PG_QUERY_FLAG_KEEP_DEVICE_TABLE
   int32_t num_groups = 0;
   std::vector<std::vector<int32_t>> group_dict_ids;
   std::vector<int64_t> group_values;   // one no-dictionary group-by column: the groups' values (group_dict_ids stays empty)
@@ -243,6 +261,7 @@ struct Result {
   pg_exec_stats stats{};
 };
 struct DocIdSet {
+  int device = 0;
   int32_t num_docs = 0;
   int64_t cardinality = 0;
   DeviceBuffer words;          // tile padded
@@ -250,10 +269,31 @@ struct DocIdSet {
   pg_exec_stats stats{};
 };
 
+// cancellation token (pg_cancel_*): set by any thread, polled by the executing one
+struct CancelToken { std::atomic<int> requested{0}; };
+
 // execution (pg_exec.hip)
-void device_init(int ordinal);
-std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q);
+void device_init(int ordinal);          // pg_init: validates + selects the default device
+int default_device();                   // the device pg_segment_create pins on (0 unless pg_init chose another)
+void use_device(int ordinal);           // makes `ordinal` current on the calling thread, initialising it on first use
+std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const CancelToken* cancel);
+void result_merge(Result& dst, Result& src);
+// RCCL (pg_comm.cpp)
+struct Comm;
+void comm_unique_id(void* out128);
+Comm* comm_init_rank(int device, int world, int rank, const void* id128);
+void comm_init_all(int n, const int32_t* devices, Comm** out);
+int comm_world(const Comm& c);
+void comm_destroy(Comm* c);
+void result_all_reduce(Result& r, Comm& c);
+// shared by result_merge / result_all_reduce (pg_exec.hip): rebuild the host view of a result from its device table
+void result_reassemble(Result& r);
+int64_t table_signature(const DeviceTable& T);
+void device_table_tail_store(DeviceTable& T, hipStream_t stream);
+void merge_sets_on_stream(uint32_t* dst, const uint32_t* gathered, int64_t n_words, int n_src, hipStream_t stream);
+hipStream_t thread_stream(int device);
 std::unique_ptr<DocIdSet> execute_filter(Segment& seg, const pg_filter_node* filter);
+std::shared_ptr<CompiledPlan> get_plan(Segment& seg, const pg_filter_node* filter, const pg_query* q);   // cached, under seg.mu
 void docidset_copy_docids(DocIdSet& s, int32_t* out, int64_t cap);
 
 }  // namespace pg

@@ -146,6 +146,7 @@ void segment_add_star_tree(Segment& seg, const pg_star_tree_desc& d) {
 
   Segment& sp = st->space;
   sp.name = seg.name;
+  sp.device = seg.device;
   sp.total_docs = d.num_docs;
   sp.n_tiles = std::max<int32_t>(1, (int32_t)(((int64_t)d.num_docs + PG_TILE_DOCS - 1) / PG_TILE_DOCS));
   for (int i = 0; i < n_dims; i++) {
