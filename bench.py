@@ -6,8 +6,9 @@ A "step" is one pass of the hot path over one batch of synthetic input = one `pg
                                             AND r_int BETWEEN 250000 AND 749999 GROUP BY g1
 over one 1 B-row segment per GPU, columns already resident in HBM (2 inverted-index predicates + 1 raw-INT range scan,
 group by a 100-value dictionary column, SUM/MAX of a raw INT metric), followed — when N > 1 — by the cross-GPU group-by
-merge (one RCCL all-gather of the dense per-group arrays + local reduce; segments share dictionaries).  Segments shard one per GPU
-(`scaling: weak`), no data-path collective other than that merge.
+merge inside the library (pg_result_all_reduce: one grouped RCCL all-reduce over the dense accumulator table the kernels left
+in HBM; segments share dictionaries).  Segments shard one per GPU (`scaling: weak`), no data-path collective other than that
+merge.  `--gpus N` without a torchrun environment re-executes itself under `python -m torch.distributed.run` with N ranks.
 
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (HBM-bound: algorithmic bytes per launch ÷ HIP-event
 kernel time ÷ 8 TB/s) and `cpu_baseline` (the C restatement of the reference algorithm, oracle/, one thread per segment
@@ -47,8 +48,22 @@ def main():
     ap.add_argument("--query", choices=["cfg3", "northstar", "cfg2"], default="cfg3")
     ap.add_argument("--cpu-sample-docs", type=int, default=100_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-full-check", action="store_true",
+                    help="skip the one full-size oracle run that checks the timed GPU result (about 4 s of CPU per 1e9 rows)")
     ap.add_argument("--no-variants", action="store_true", help="skip the north-star (2-key) variant of the default run")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not launched by torchrun: spawn the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -60,14 +75,36 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world != args.gpus and rank == 0:
+        log(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher decides the rank count")
 
     from pinot_amd import capi, distributed as pd, synth
-    from pinot_amd.executor import NativeSegment
+    from pinot_amd.executor import Comm, NativeSegment
     from pinot_amd.query import parse_sql
     from pinot_amd.segment import HostSegment
 
     api = capi.gpu_api()
     api.call("init", local_rank)
+
+    # the library's own RCCL communicator for the data-path merge: rank 0's unique id travels over the torch process group
+    comm = None
+    merge_kind = "none (1 segment)"
+    if world > 1:
+        try:
+            uid = torch.zeros(capi.COMM_UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid = torch.frombuffer(bytearray(Comm.unique_id(api)), dtype=torch.uint8).cuda()
+            dist.broadcast(uid, src=0)
+            comm = Comm.init_rank(api, local_rank, world, rank, bytes(uid.cpu().numpy().tobytes()))
+            ok = torch.ones(1, device="cuda")
+        except Exception as e:   # noqa: BLE001 — an unusable RCCL setup must not sink the run: fall back to the torch collective
+            log(f"library RCCL communicator unavailable on rank {rank}: {e}")
+            ok = torch.zeros(1, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() < 1:
+            comm = None
+        merge_kind = "pg_result_all_reduce (RCCL inside libpinot_gpu)" if comm is not None else \
+            "torch.distributed all_gather_into_tensor (nccl backend) + host reduce"
 
     sql = {"cfg3": synth.QUERY_CFG3, "northstar": synth.QUERY_NORTH_STAR, "cfg2": synth.QUERY_CFG2}[args.query]
     bytes_per_row = {"cfg3": CFG3_BYTES_PER_ROW, "northstar": NORTH_STAR_BYTES_PER_ROW, "cfg2": 4.0}[args.query]
@@ -89,16 +126,28 @@ def main():
     cards = [synth.GPU_BENCH[g].range for g in qc.group_by]
     kernel_ms = []
 
-    def step():
-        """One pass of the hot path: segment query on this GPU + cross-GPU merge of the group table."""
-        block = seg.execute(qc)
+    def run_query(q, times):
+        """One pass of the hot path: segment query on this GPU + cross-GPU merge of the group table (GroupByCombineOperator over
+        xGMI: identical dictionaries ⇒ the dense accumulator tables merge element-wise, in HBM, in one grouped RCCL launch)."""
+        if comm is not None:
+            nr = seg.execute_native(q, keep_device_table=True)
+            times.append(nr.stats().device_ms_aggregate)     # this rank's kernel, before the merge
+            nr.all_reduce(comm)
+            block = nr.block()
+            nr.free()
+            return block, block.stats
+        block = seg.execute(q)
         st = block.stats
-        kernel_ms.append(st.device_ms_aggregate)
-        dense = pd.dense_from_block(block, cards)
-        if world > 1:
-            # GroupByCombineOperator merge over xGMI: identical dictionaries ⇒ dense layout; one RCCL all-gather + local reduce
+        times.append(st.device_ms_aggregate)
+        if world > 1:   # fallback merge: one all-gather of the packed dense rows + host reduce
+            crd = [synth.GPU_BENCH[g].range for g in q.group_by]
+            dense = pd.dense_from_block(block, crd)
             pd.all_reduce_tables(dense, device=torch.device("cuda", local_rank))
-        return dense, st
+            return dense, st
+        return block, st
+
+    def step():
+        return run_query(qc, kernel_ms)
 
     def sync():
         if world > 1:
@@ -154,6 +203,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{world} segment(s) x {args.docs} rows, one per GPU; {sql}",
                    "query": args.query, "rows_per_segment": args.docs, "parallelism": f"segment-per-gpu x{world}",
+                   "merge": merge_kind,
                    "matched_docs_per_segment": int(st.num_docs_scanned),
                    "entries_scanned_in_filter": int(st.num_entries_scanned_in_filter)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -173,11 +223,9 @@ def main():
         cards_n = [synth.GPU_BENCH[g].range for g in qn.group_by]
 
         def step_n():
-            b = seg.execute(qn)
-            d = pd.dense_from_block(b, cards_n)
-            if world > 1:
-                pd.all_reduce_tables(d, device=torch.device("cuda", local_rank))
-            return b.stats.device_ms_aggregate
+            t = []
+            run_query(qn, t)
+            return t[0]
 
         for _ in range(args.warmup):
             step_n()
@@ -206,10 +254,11 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, sql, gpu_dense, gpu_seg):
+def cpu_baseline(args, sql, gpu_block, gpu_seg):
     """CPU leg: the C restatement of the reference algorithm (oracle/, kind "port"), 1 thread per segment exactly like
-    the reference's combine operator, on a prefix sample of the same segment.  Also cross-checks the GPU result when the
-    sample is the whole segment."""
+    the reference's combine operator, timed on a prefix sample of the same segment; the sample is also run through the GPU
+    library and compared bit for bit.  Unless --no-full-check, ONE more oracle run over the WHOLE segment checks the timed GPU
+    result at full size (group keys, SUM / MAX values, ExecutionStatistics)."""
     from pinot_amd import distributed as pd, synth
     from pinot_amd.executor import NativeSegment
     from tests.oracle_binding import load_oracle
@@ -224,9 +273,10 @@ def cpu_baseline(args, sql, gpu_dense, gpu_seg):
         block = ora.execute(sql)
         times.append(time.perf_counter() - t)
     med = statistics.median(times)
-    if sample == args.docs:   # full-size parity check against the timed GPU result
-        dicts = [host.columns[g].dict_values for g in block.query.group_by]
-        assert pd.rows_from_dense(gpu_dense, dicts) == block.rows(), "GPU result differs from the oracle"
+    full_checked = False
+    if sample == args.docs:   # the sample is the whole segment: check the timed GPU result right away
+        assert gpu_block.rows() == block.rows(), "GPU result differs from the oracle"
+        full_checked = True
     # parity at sample scale in every run: the same prefix segment through the GPU library must equal the oracle bit for bit
     # (group keys, SUM / MAX values, ExecutionStatistics)
     from pinot_amd import capi
@@ -237,7 +287,22 @@ def cpu_baseline(args, sql, gpu_dense, gpu_seg):
         (block.stats.num_docs_scanned, block.stats.num_entries_scanned_in_filter), "ExecutionStatistics differ from the oracle"
     gpu_prefix.destroy()
     ora.destroy()
-    return {"value": sample / med, "unit": "rows/s", "cores": 1, "kind": "port",
+    full_seconds = None
+    if not full_checked and not args.no_full_check:
+        del host
+        full = synth.generate_segment(args.docs, segment_index=0, columns=needed)
+        ora_full = NativeSegment(load_oracle(), full)
+        t = time.perf_counter()
+        fb = ora_full.execute(sql)
+        full_seconds = time.perf_counter() - t
+        assert gpu_block.rows() == fb.rows(), "GPU result at full size differs from the oracle"
+        assert (gpu_block.stats.num_docs_scanned, gpu_block.stats.num_entries_scanned_in_filter) == \
+            (fb.stats.num_docs_scanned, fb.stats.num_entries_scanned_in_filter), "full-size ExecutionStatistics differ from the oracle"
+        ora_full.destroy()
+        del full
+        full_checked = True
+    return {"value": sample / med, "unit": "rows/s", "cores": 1, "kind": "port", "gpu_equals_oracle_at_full_size": full_checked,
+            "full_size_oracle_seconds": full_seconds,
             "sample": f"first {sample} docs of segment 0, same query, median of 5 runs; C restatement of the reference "
                       f"operators (oracle/), not the JVM", "seconds_per_run": med,
             "gpu_equals_oracle_on_sample": True}

@@ -12,7 +12,7 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
-PG_ABI_VERSION = 2
+PG_ABI_VERSION = 3
 
 # pg_status
 PG_OK = 0
@@ -37,6 +37,8 @@ RESULT_LONG, RESULT_DOUBLE, RESULT_AVG_PAIR, RESULT_MINMAX_PAIR, RESULT_DICTID_S
 
 QUERY_FLAG_PROFILE = 0x1
 QUERY_FLAG_SKIP_STAR_TREE = 0x2
+QUERY_FLAG_KEEP_DEVICE_TABLE = 0x4
+COMM_UNIQUE_ID_BYTES = 128
 GROUP_KEY_DICT_IDS, GROUP_KEY_LONG_VALUES = 0, 1
 
 
@@ -159,6 +161,14 @@ ABI_SYMBOLS = [
     "result_num_groups", "result_group_dict_ids", "result_group_key_type", "result_group_values_long", "result_kind_of", "result_doubles", "result_longs",
     "result_set_sizes", "result_set_dict_ids", "result_hll_registers", "result_stats", "result_free",
 ]
+# entry points only the product library has (the CPU oracle is one segment, one thread, no devices): multi-GPU placement,
+# cancellation, the dense cross-segment merge and its RCCL communicators
+GPU_ONLY_SYMBOLS = [
+    "segment_create_on_device", "segment_device",
+    "cancel_create", "cancel_request", "cancel_reset", "cancel_destroy", "query_exec_cancellable",
+    "result_merge", "result_all_reduce",
+    "comm_get_unique_id", "comm_init_rank", "comm_init_all", "comm_world_size", "comm_destroy",
+]
 
 
 class NativeApi:
@@ -168,9 +178,24 @@ class NativeApi:
         self.path = path
         self.prefix = prefix
         self.lib = C.CDLL(path, mode=C.RTLD_GLOBAL if prefix == "pg_" else C.RTLD_LOCAL)
-        for sym in ABI_SYMBOLS:
+        for sym in ABI_SYMBOLS + (GPU_ONLY_SYMBOLS if prefix == "pg_" else []):
             fn = getattr(self.lib, prefix + sym)  # AttributeError => missing export
             fn.restype = C.c_int32
+        if prefix == "pg_":
+            self.f("segment_create_on_device").argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+            self.f("segment_device").argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+            self.f("cancel_create").argtypes = [C.POINTER(C.c_void_p)]
+            self.f("cancel_request").argtypes = [C.c_void_p]
+            self.f("cancel_reset").argtypes = [C.c_void_p]
+            self.f("cancel_destroy").argtypes = [C.c_void_p]
+            self.f("query_exec_cancellable").argtypes = [C.c_void_p, C.POINTER(PgQuery), C.c_void_p, C.POINTER(C.c_void_p)]
+            self.f("result_merge").argtypes = [C.c_void_p, C.c_void_p]
+            self.f("result_all_reduce").argtypes = [C.c_void_p, C.c_void_p]
+            self.f("comm_get_unique_id").argtypes = [C.c_void_p]
+            self.f("comm_init_rank").argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
+            self.f("comm_init_all").argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]
+            self.f("comm_world_size").argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+            self.f("comm_destroy").argtypes = [C.c_void_p]
         self.f("last_error").argtypes = [C.c_char_p, C.c_size_t]
         self.f("init").argtypes = [C.c_int32]
         self.f("segment_create").argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]

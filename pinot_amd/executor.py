@@ -38,11 +38,15 @@ class NativeSegment:
     """IndexSegment handle: the host segment's buffers registered with (and, for the GPU library, pinned in HBM by) a
     native library.  `destroy()` mirrors IndexSegment#destroy."""
 
-    def __init__(self, api: capi.NativeApi, host: HostSegment):
+    def __init__(self, api: capi.NativeApi, host: HostSegment, device: Optional[int] = None):
         self.api = api
         self.host = host
         self.handle = C.c_void_p()
-        api.call("segment_create", host.name.encode(), host.total_docs, C.byref(self.handle))
+        self.device = device
+        if device is None:       # the default device (pg_init)
+            api.call("segment_create", host.name.encode(), host.total_docs, C.byref(self.handle))
+        else:                    # segment -> GPU map of a multi-GPU server process
+            api.call("segment_create_on_device", host.name.encode(), host.total_docs, int(device), C.byref(self.handle))
         self._descs = []
         for col in host.columns.values():
             self._register(col)
@@ -125,6 +129,127 @@ class NativeSegment:
             return ResultsBlock.from_native(self.api, h, qc, self.host)
         finally:
             self.api.call("result_free", h)
+
+    def execute_native(self, q, keep_device_table: bool = True, cancel: "Optional[CancelToken]" = None) -> "NativeResult":
+        """Runs the query and keeps the native result handle (and, with `keep_device_table`, its dense accumulator table in HBM)
+        so that it can be merged in the library: NativeResult.merge / .all_reduce, then .block()."""
+        qc = parse_sql(q) if isinstance(q, str) else q
+        flags = qc.flags | (capi.QUERY_FLAG_KEEP_DEVICE_TABLE if keep_device_table else 0)
+        cache = getattr(qc, "_cquery_native", None)
+        if cache is None or cache[0] != flags:
+            saved = qc.flags
+            qc.flags = flags
+            cache = (flags, CQuery(qc))
+            qc.flags = saved
+            qc._cquery_native = cache
+        h = C.c_void_p()
+        self.api.call("query_exec_cancellable", self.handle, cache[1].ptr(), cancel.handle if cancel is not None else None, C.byref(h))
+        return NativeResult(self.api, h, qc, self.host)
+
+
+class CancelToken:
+    """pg_cancel_t: the interrupting thread calls request(); the executing thread's query returns PG_ERR_CANCELLED
+    (EarlyTerminationException, BaseOperator.java:44-46)."""
+
+    def __init__(self, api: capi.NativeApi):
+        self.api = api
+        self.handle = C.c_void_p()
+        api.call("cancel_create", C.byref(self.handle))
+
+    def request(self):
+        self.api.call("cancel_request", self.handle)
+
+    def reset(self):
+        self.api.call("cancel_reset", self.handle)
+
+    def destroy(self):
+        if self.handle:
+            self.api.call("cancel_destroy", self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+class Comm:
+    """pg_comm_t: an RCCL communicator owned by the library (one per GPU)."""
+
+    def __init__(self, api: capi.NativeApi, handle):
+        self.api = api
+        self.handle = handle
+
+    @staticmethod
+    def unique_id(api: capi.NativeApi) -> bytes:
+        buf = C.create_string_buffer(capi.COMM_UNIQUE_ID_BYTES)
+        api.call("comm_get_unique_id", buf)
+        return buf.raw
+
+    @staticmethod
+    def init_rank(api: capi.NativeApi, device: int, world: int, rank: int, unique_id: bytes) -> "Comm":
+        assert len(unique_id) == capi.COMM_UNIQUE_ID_BYTES
+        h = C.c_void_p()
+        api.call("comm_init_rank", device, world, rank, C.create_string_buffer(unique_id, len(unique_id)), C.byref(h))
+        return Comm(api, h)
+
+    @staticmethod
+    def init_all(api: capi.NativeApi, devices: Sequence[int]) -> "List[Comm]":
+        n = len(devices)
+        devs = (C.c_int32 * n)(*devices)
+        out = (C.c_void_p * n)()
+        api.call("comm_init_all", n, devs, out)
+        return [Comm(api, C.c_void_p(out[i])) for i in range(n)]
+
+    def world_size(self) -> int:
+        n = C.c_int32()
+        self.api.call("comm_world_size", self.handle, C.byref(n))
+        return n.value
+
+    def destroy(self):
+        if self.handle:
+            self.api.call("comm_destroy", self.handle)
+            self.handle = C.c_void_p()
+
+
+class NativeResult:
+    """A pg_result_t kept alive for merging inside the library (GroupByCombineOperator over segments sharing their key
+    space): merge() folds another segment's result of the same query on the same GPU into this one, all_reduce() merges
+    across the GPUs of a communicator over RCCL; block() materialises the (merged) intermediate results."""
+
+    def __init__(self, api: capi.NativeApi, handle, qc: QueryContext, host: HostSegment):
+        self.api = api
+        self.handle = handle
+        self.qc = qc
+        self.host = host
+
+    def merge(self, other: "NativeResult") -> "NativeResult":
+        self.api.call("result_merge", self.handle, other.handle)
+        return self
+
+    def all_reduce(self, comm: Comm) -> "NativeResult":
+        self.api.call("result_all_reduce", self.handle, comm.handle)
+        return self
+
+    def block(self) -> "ResultsBlock":
+        return ResultsBlock.from_native(self.api, self.handle, self.qc, self.host)
+
+    def stats(self) -> capi.PgExecStats:
+        st = capi.PgExecStats()
+        self.api.call("result_stats", self.handle, C.byref(st))
+        return st
+
+    def free(self):
+        if self.handle:
+            self.api.call("result_free", self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class DocIdSet:

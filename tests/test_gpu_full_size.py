@@ -1,5 +1,5 @@
 """BASELINE.json's full sizes (10^9-doc segment, config 3 / north star) and the format's maximum (2^31 - 1 docs) on the GPU,
-checked through size-independent properties — the oracle would need minutes per query at these sizes:
+checked through size-independent properties (and, for the headline queries, against the oracle itself: test_full_size_equals_oracle):
   * linearity      Q over a doc-partitioning pair of filters merges (SUM / COUNT add, MAX is max) into Q over their union
   * complement     COUNT(F) + COUNT(NOT F) = totalDocs
   * marginals      the north-star table (g1, g2) summed over g2 is the config-3 table (g1)
@@ -76,6 +76,23 @@ def test_full_size_segment_properties(gpu_api):
     per_pair = seg.execute("SELECT c_inv1, c_inv2, COUNT(*) FROM gpuBench GROUP BY c_inv1, c_inv2 LIMIT 100").rows()
     assert len(per_pair) == 32 and sum(v[0] for v in per_pair.values()) == n
     seg.destroy()
+
+
+@pytest.mark.gpu
+def test_full_size_equals_oracle(gpu_api, oracle_api):
+    """The headline configurations at BASELINE.json's full size against the oracle itself (about 4 s of CPU per 10^9-row query):
+    config 3, the north-star 2-key variant and config 2's predicate — group keys, SUM / MAX values and ExecutionStatistics."""
+    host = synth.generate_segment(FULL_DOCS, segment_index=0, columns=["c_inv1", "c_inv2", "r_int", "g1", "g2", "m"])
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    for q in (synth.QUERY_CFG3, synth.QUERY_NORTH_STAR, synth.QUERY_CFG2):
+        gb, ob = g.execute(q), o.execute(q)
+        assert gb.rows() == ob.rows(), q
+        assert gb.stats.num_docs_scanned == ob.stats.num_docs_scanned, q
+        assert gb.stats.num_entries_scanned_in_filter == ob.stats.num_entries_scanned_in_filter, q
+        assert gb.stats.num_entries_scanned_post_filter == ob.stats.num_entries_scanned_post_filter, q
+        assert gb.stats.num_total_docs == ob.stats.num_total_docs == FULL_DOCS
+    g.destroy()
+    o.destroy()
 
 
 @pytest.mark.gpu

@@ -1,0 +1,226 @@
+"""One host process, many segments (and, on a multi-GPU box, many GPUs): the reference runs every segment of a server inside
+one JVM, one worker task per segment, and merges the partial group tables (BaseCombineOperator.java:81-142,
+GroupByCombineOperator.java:102-165).  Here: segments pinned with pg_segment_create_on_device, queried from one thread each,
+merged inside the library (pg_result_merge on one device, pg_result_all_reduce over an RCCL communicator across devices) and
+compared with the host GroupByCombineOperator over the oracle's per-segment results.  Plus the cancellation token."""
+import ctypes as C
+import threading
+
+import numpy as np
+import pytest
+
+from pinot_amd import capi, synth
+from pinot_amd.executor import CancelToken, Comm, GroupByCombineOperator, NativeSegment
+from pinot_amd.segment import build_segment
+
+QUERIES = [
+    synth.QUERY_CFG3,
+    synth.QUERY_NORTH_STAR,
+    "SELECT g2, COUNT(*), MIN(r_int), MAX(m), AVG(m), MINMAXRANGE(r_int) FROM gpuBench WHERE c_inv1 = 3 GROUP BY g2",
+    "SELECT COUNT(*), SUM(m), MAX(m) FROM gpuBench WHERE r_int < 1000",
+    "SELECT COUNT(*) FROM gpuBench WHERE c_inv2 IN (1, 2)",
+    "SELECT g1, DISTINCTCOUNT(g2), DISTINCTCOUNTHLL(g2) FROM gpuBench WHERE c_inv1 < 6 GROUP BY g1",
+    "SELECT DISTINCTCOUNT(g1), DISTINCTCOUNTHLL(r_int) FROM gpuBench WHERE r_int > 500000",
+]
+N_SEG = 4
+
+
+def _device_count(api):
+    n = C.c_int32()
+    api.call("device_count", C.byref(n))
+    return n.value
+
+
+def _segments(docs=60_013):
+    return [synth.generate_segment(docs + 17 * i, segment_index=i, columns=synth.CFG3_COLUMNS) for i in range(N_SEG)]
+
+
+@pytest.mark.gpu
+def test_threaded_segments_merge_in_library(gpu_api, oracle_api):
+    """N segments in one process, one querying thread per segment, spread over the visible devices; the partial results are
+    merged in the library and equal the host combine of the oracle's per-segment results (values and ExecutionStatistics)."""
+    n_dev = _device_count(gpu_api)
+    hosts = _segments()
+    gpu = [NativeSegment(gpu_api, h, device=i % n_dev) for i, h in enumerate(hosts)]
+    ora = [NativeSegment(oracle_api, h) for h in hosts]
+    for i, s in enumerate(gpu):
+        d = C.c_int32(-1)
+        gpu_api.call("segment_device", s.handle, C.byref(d))
+        assert d.value == i % n_dev
+    comms = Comm.init_all(gpu_api, list(range(n_dev))) if n_dev > 1 else None
+    for q in QUERIES:
+        results = [None] * N_SEG
+        errors = []
+
+        def work(i):
+            try:
+                results[i] = gpu[i].execute_native(q, keep_device_table=True)
+            except Exception as e:   # noqa: BLE001
+                errors.append(e)
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(N_SEG)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        # per-segment parity first
+        for i in range(N_SEG):
+            assert results[i].block().rows() == ora[i].execute(q).rows(), (q, i)
+        # segments of one device fold into that device's first result ...
+        heads = {}
+        for i in range(N_SEG):
+            d = i % n_dev
+            if d in heads:
+                results[heads[d]].merge(results[i])
+            else:
+                heads[d] = i
+        # ... and the devices' tables are all-reduced over RCCL (one thread per device, as the worker threads of a server would)
+        if comms:
+            ts = [threading.Thread(target=lambda d=d: results[heads[d]].all_reduce(comms[d])) for d in heads]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+        oblocks = [o.execute(q) for o in ora]
+        expect = GroupByCombineOperator(oblocks).merge()
+        for d, i in heads.items():
+            merged = results[i].block()
+            assert merged.rows() == expect, (q, d)
+            assert merged.stats.num_docs_scanned == sum(b.stats.num_docs_scanned for b in oblocks)
+            assert merged.stats.num_entries_scanned_in_filter == sum(b.stats.num_entries_scanned_in_filter for b in oblocks)
+            assert merged.stats.num_total_docs == sum(h.total_docs for h in hosts)
+        for r in results:
+            r.free()
+    for s in gpu + ora:
+        s.destroy()
+    for c in comms or []:
+        c.destroy()
+
+
+@pytest.mark.gpu
+def test_all_reduce_world_of_one(gpu_api, oracle_api):
+    """pg_comm_init_rank / pg_result_all_reduce through RCCL with a single rank: the merged table is the rank's own."""
+    host = synth.generate_segment(50_021, columns=synth.CFG3_COLUMNS)
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    comm = Comm.init_rank(gpu_api, 0, 1, 0, Comm.unique_id(gpu_api))
+    assert comm.world_size() == 1
+    for q in QUERIES:
+        r = g.execute_native(q, keep_device_table=True)
+        before = r.block().rows()
+        r.all_reduce(comm)
+        b = r.block()
+        ob = o.execute(q)
+        assert b.rows() == before == ob.rows(), q
+        assert b.stats.num_entries_scanned_in_filter == ob.stats.num_entries_scanned_in_filter
+        r.free()
+    comm.destroy()
+    g.destroy()
+    o.destroy()
+
+
+@pytest.mark.gpu
+def test_merge_refuses_mismatched_tables(gpu_api):
+    host = synth.generate_segment(20_000, columns=synth.CFG3_COLUMNS)
+    g = NativeSegment(gpu_api, host)
+    a = g.execute_native(synth.QUERY_CFG3)
+    b = g.execute_native(synth.QUERY_NORTH_STAR)
+    with pytest.raises(capi.NativeError) as e:
+        a.merge(b)
+    assert e.value.status == capi.PG_ERR_UNSUPPORTED
+    c = g.execute_native(synth.QUERY_CFG3, keep_device_table=False)
+    with pytest.raises(capi.NativeError) as e:
+        a.merge(c)
+    assert e.value.status == capi.PG_ERR_INVALID_ARGUMENT
+    # a hashed key space has no dense table to keep
+    with pytest.raises(capi.NativeError) as e:
+        g.execute_native("SELECT r_int, COUNT(*) FROM gpuBench GROUP BY r_int LIMIT 10")
+    assert e.value.status == capi.PG_ERR_UNSUPPORTED
+    for r in (a, b, c):
+        r.free()
+    g.destroy()
+
+
+@pytest.mark.gpu
+def test_device_ordinal_out_of_range(gpu_api):
+    h = C.c_void_p()
+    with pytest.raises(capi.NativeError) as e:
+        gpu_api.call("segment_create_on_device", b"x", 10, 4096, C.byref(h))
+    assert e.value.status == capi.PG_ERR_INVALID_ARGUMENT
+    with pytest.raises(capi.NativeError) as e:
+        gpu_api.call("segment_create_on_device", b"x", 10, _device_count(gpu_api), C.byref(h))
+    assert e.value.status == capi.PG_ERR_INVALID_ARGUMENT
+
+
+@pytest.mark.gpu
+def test_cancellation(gpu_api, oracle_api):
+    """A token set before the call cancels it outright; one set from another thread stops a stream of queries with
+    PG_ERR_CANCELLED, and the same thread / segment answers correctly afterwards."""
+    host = synth.generate_segment(2_000_003, columns=synth.CFG3_COLUMNS)
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    expect = o.execute(synth.QUERY_NORTH_STAR).rows()
+    tok = CancelToken(gpu_api)
+    r = g.execute_native(synth.QUERY_NORTH_STAR, keep_device_table=False, cancel=tok)   # not cancelled: runs
+    assert r.block().rows() == expect
+    r.free()
+    tok.request()
+    with pytest.raises(capi.NativeError) as e:
+        g.execute_native(synth.QUERY_NORTH_STAR, keep_device_table=False, cancel=tok)
+    assert e.value.status == capi.PG_ERR_CANCELLED
+    tok.reset()
+    # cancelled from another thread while queries stream
+    state = {"done": 0, "status": None}
+
+    def stream():
+        try:
+            while True:
+                r = g.execute_native("SELECT g1, g2, SUM(m), COUNT(*) FROM gpuBench GROUP BY g1, g2 LIMIT 10000", keep_device_table=False, cancel=tok)
+                r.free()
+                state["done"] += 1
+        except capi.NativeError as err:
+            state["status"] = err.status
+    t = threading.Thread(target=stream)
+    t.start()
+    while state["done"] < 3 and t.is_alive():
+        pass
+    tok.request()
+    t.join(timeout=60)
+    assert not t.is_alive() and state["status"] == capi.PG_ERR_CANCELLED
+    tok.reset()
+    assert g.execute(synth.QUERY_NORTH_STAR).rows() == expect   # the thread contexts are intact
+    r = g.execute_native(synth.QUERY_NORTH_STAR, keep_device_table=False, cancel=tok)
+    assert r.block().rows() == expect
+    r.free()
+    tok.destroy()
+    g.destroy()
+    o.destroy()
+
+
+@pytest.mark.gpu
+def test_concurrent_supported_and_exec(gpu_api, oracle_api):
+    """pg_query_supported and pg_query_exec from many threads on one segment (PlanMaker calls supported() then exec() per
+    worker thread): plans are compiled and cached under the segment's lock."""
+    from pinot_amd.query import CQuery, parse_sql
+    host = synth.generate_segment(100_003, columns=synth.CFG3_COLUMNS)
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    qs = ["SELECT g1, DISTINCTCOUNTHLL(g2), SUM(m) FROM gpuBench WHERE r_int > %d GROUP BY g1" % (1000 * i) for i in range(24)]
+    expect = [o.execute(q).rows() for q in qs]
+    errors = []
+
+    def work(k):
+        try:
+            for i in range(len(qs)):
+                j = (i + k) % len(qs)
+                qc = parse_sql(qs[j])
+                cq = CQuery(qc)
+                gpu_api.call("query_supported", g.handle, cq.ptr())
+                assert g.execute(qc).rows() == expect[j]
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:1]
+    g.destroy()
+    o.destroy()
