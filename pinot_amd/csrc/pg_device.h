@@ -25,7 +25,7 @@
 #define PG_MAX_STACK 6
 #define PG_MAX_GROUP_COLS 8
 #define PG_MAX_SRCS 8
-#define PG_MAX_OPS 16
+#define PG_MAX_OPS 32
 #define PG_MAX_STATS 16
 #define PG_MAX_FAST_SCANS 4
 #define PG_GENERIC_BLOCK 512      // interpreter kernel workgroup
@@ -145,14 +145,28 @@ struct PgValueSrc {
   int32_t col_kind;
   int32_t bits;
   int32_t val_type;
-  int32_t pad;
+  int32_t fx_q;          // FLOAT / DOUBLE sources summed in fixed point: digit j of a value x is digit j (base 2^32) of trunc(|x| * 2^-fx_q)
+};
+
+// How a SUM accumulator takes its values (PgAccOp::is_float).  The reference adds every value to a double in docId order
+// (SumAggregationFunction.java:160-179); any other order of floating additions gives other roundings, so floating SUMs are kept
+// EXACT instead: each value is cut into base-2^32 digits of a fixed-point number whose scale the column's largest magnitude
+// fixes, every digit is summed in its own int64 accumulator ("limb": |digit| < 2^32, < 2^31 docs, so no limb overflows), and the
+// limbs are combined and rounded to double ONCE on the host.  Integer additions commute, so the result does not depend on the
+// order of execution, on the number of workgroups, or on how partial tables are merged (including across GPUs: ncclSum on int64).
+// LONG sources whose sum could leave int64 use two such digits of the value itself.
+enum PgAccValueKind : int32_t {
+  PG_ACCV_INT = 0,         // int64 value (INT / LONG sign-extended); MIN / MAX of integers
+  PG_ACCV_DOUBLE = 1,      // double: MIN / MAX through order-preserving int64 keys; SUM in IEEE double only for columns holding NaN / Inf
+  PG_ACCV_FIXED_DIGIT = 2, // SUM: digit `limb` of the fixed-point image of a FLOAT / DOUBLE value
+  PG_ACCV_LONG_DIGIT = 3   // SUM: digit `limb` (0: low 32 bits unsigned, 1: high 32 bits signed) of a LONG value
 };
 
 struct PgAccOp {
   int32_t fn;         // PgAccFn
   int32_t src;        // index into srcs, -1 for COUNT
-  int32_t is_float;   // accumulate as f64 (SUM) / ordered-key i64 (MIN, MAX)
-  int32_t pad;
+  int32_t is_float;   // PgAccValueKind
+  int32_t limb;       // digit index of a PG_ACCV_FIXED_DIGIT / PG_ACCV_LONG_DIGIT accumulator
 };
 
 // Auxiliary (non-scalar) accumulators, always in HBM, one region per op, zero-initialised per execution:

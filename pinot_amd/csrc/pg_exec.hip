@@ -16,6 +16,7 @@ PG_DECL_GENERIC
 PG_DECL_FAST(pg_fast_none_f) PG_DECL_FAST(pg_fast_none_a) PG_DECL_FAST(pg_fast_i32range_f) PG_DECL_FAST(pg_fast_i32range_a)
 PG_DECL_FAST(pg_fast_dictrange_f) PG_DECL_FAST(pg_fast_dictrange_a) PG_DECL_FAST(pg_fast_dictlut_f) PG_DECL_FAST(pg_fast_dictlut_a)
 PG_DECL_FAST(pg_fast_multi_f) PG_DECL_FAST(pg_fast_multi_a) PG_DECL_FAST(pg_fast_multi_w) PG_DECL_FAST(pg_fast_none_w)
+PG_DECL_FAST(pg_fast_multi_wd) PG_DECL_FAST(pg_fast_none_wd) PG_DECL_FAST(pg_generic_query_ld) PG_DECL_FAST(pg_generic_query_gd)
 extern "C" __global__ void pg_reduce_partials_kernel(const int64_t* partials, int64_t* out, int n_wg, int n_ops,
                                                      int n_groups, const PgAccOp* ops, unsigned long long* stats, int reduce);
 extern "C" __global__ void pg_reduce_parts_kernel(const int64_t* partials, int64_t* out, int n_wg, int n_ops, int n_groups,
@@ -113,7 +114,8 @@ void use_device(int ordinal) {
       // opt in to large dynamic LDS for the query kernels (function attributes are per device)
       typedef void (*QueryKernel)(const PgQueryPlan);
       const QueryKernel all[] = {pg_generic_query_f, pg_generic_query_l, pg_generic_query_g, pg_fast_none_f, pg_fast_none_a, pg_fast_i32range_f, pg_fast_i32range_a,
-                                 pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a, pg_fast_multi_f, pg_fast_multi_a, pg_fast_multi_w, pg_fast_none_w, pg_radix_aggregate_kernel, pg_hash_aggregate_kernel};
+                                 pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a, pg_fast_multi_f, pg_fast_multi_a, pg_fast_multi_w, pg_fast_none_w, pg_fast_multi_wd, pg_fast_none_wd, pg_generic_query_ld, pg_generic_query_gd,
+                                 pg_radix_aggregate_kernel, pg_hash_aggregate_kernel};
       for (QueryKernel k : all)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
       di.ready.store(1, std::memory_order_release);
@@ -149,9 +151,9 @@ static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char
   const bool agg = agg_mode != PG_AGG_NONE;
   if (uses_fast_kernel(P, agg_mode)) {
     if (agg && P.wide_agg) {
-      if (P.fast_filter == -1) { *name = "pg_fast_none_w"; return pg_fast_none_w; }
-      *name = "pg_fast_multi_w";
-      return pg_fast_multi_w;
+      if (P.fast_filter == -1) { *name = P.digit_ops ? "pg_fast_none_wd" : "pg_fast_none_w"; return P.digit_ops ? pg_fast_none_wd : pg_fast_none_w; }
+      *name = P.digit_ops ? "pg_fast_multi_wd" : "pg_fast_multi_w";
+      return P.digit_ops ? pg_fast_multi_wd : pg_fast_multi_w;
     }
     switch (P.fast_filter) {
       case -1: *name = agg ? "pg_fast_none_a" : "pg_fast_none_f"; return agg ? pg_fast_none_a : pg_fast_none_f;
@@ -163,9 +165,9 @@ static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char
     }
   }
   if (agg_mode == PG_AGG_NONE) { *name = "pg_generic_query_f"; return pg_generic_query_f; }
-  if (agg_mode == PG_AGG_GLOBAL) { *name = "pg_generic_query_g"; return pg_generic_query_g; }
-  *name = "pg_generic_query_l";
-  return pg_generic_query_l;
+  if (agg_mode == PG_AGG_GLOBAL) { *name = P.digit_ops ? "pg_generic_query_gd" : "pg_generic_query_g"; return P.digit_ops ? pg_generic_query_gd : pg_generic_query_g; }
+  *name = P.digit_ops ? "pg_generic_query_ld" : "pg_generic_query_l";
+  return P.digit_ops ? pg_generic_query_ld : pg_generic_query_l;
 }
 
 struct ThreadCtx {
@@ -668,7 +670,7 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
     switch (op.fn) {
       case PG_ACC_COUNT: return (double)v;
       case PG_ACC_SUM:
-        if (op.is_float) { double d; memcpy(&d, &v, 8); return d; }
+        if (op.is_float == PG_ACCV_DOUBLE) { double d; memcpy(&d, &v, 8); return d; }
         return (double)v;
       case PG_ACC_MIN:
         if (empty) return INFINITY;    // MinAggregationFunction default holder value
@@ -677,6 +679,13 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
         if (empty) return -INFINITY;   // MaxAggregationFunction.java:37
         return op.is_float ? order_key_to_double(v) : (double)v;
     }
+  };
+  // SUM kept in fixed-point / two-digit limbs: combined and rounded to double once (exact sum, correctly rounded)
+  auto sum_double = [&](const AggOut& ao, int64_t g) -> double {
+    if (ao.sum_limbs <= 0) return op_double(ao.op_a, g);
+    int64_t limbs[4] = {0, 0, 0, 0};
+    for (int j = 0; j < ao.sum_limbs; j++) limbs[j] = table[(size_t)(ao.op_a + j) * G + g];
+    return limbs_to_double(limbs, ao.sum_limbs, ao.fx_q);
   };
   res.aggs.resize((size_t)n_aggregations);
   for (int a = 0; a < n_aggregations; a++) {
@@ -726,7 +735,7 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
         break;
       case PG_AGG_AVG:
         r.kind = PG_RESULT_AVG_PAIR;
-        for (int32_t i = 0; i < ng; i++) { r.d[0][i] = op_double(ao.op_a, gids[i]); r.l[0][i] = count_of(ao.op_b, gids[i]); }
+        for (int32_t i = 0; i < ng; i++) { r.d[0][i] = sum_double(ao, gids[i]); r.l[0][i] = count_of(ao.op_b, gids[i]); }
         break;
       case PG_AGG_MINMAXRANGE:
         r.kind = PG_RESULT_MINMAX_PAIR;
@@ -734,7 +743,8 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
         break;
       default:
         r.kind = PG_RESULT_DOUBLE;
-        for (int32_t i = 0; i < ng; i++) r.d[0][i] = op_double(ao.op_a, gids[i]);
+        if (ao.function == PG_AGG_SUM) for (int32_t i = 0; i < ng; i++) r.d[0][i] = sum_double(ao, gids[i]);
+        else for (int32_t i = 0; i < ng; i++) r.d[0][i] = op_double(ao.op_a, gids[i]);
         break;
     }
   }
@@ -802,7 +812,7 @@ int64_t table_signature(const DeviceTable& T) {
   uint64_t h = 1469598103934665603ULL;
   auto mix = [&](uint64_t v) { h ^= v; h *= 1099511628211ULL; };
   mix((uint64_t)T.n_out); mix((uint64_t)D.n_groups); mix((uint64_t)D.n_ops); mix((uint64_t)T.aux_total); mix((uint64_t)T.n_group_by);
-  for (int o = 0; o < D.n_ops; o++) { mix((uint64_t)D.ops[o].fn); mix((uint64_t)D.ops[o].is_float); mix((uint64_t)(uint32_t)D.ops[o].pad); }
+  for (int o = 0; o < D.n_ops; o++) { mix((uint64_t)D.ops[o].fn); mix((uint64_t)D.ops[o].is_float); mix((uint64_t)(uint32_t)D.ops[o].limb); if (D.ops[o].src >= 0) mix((uint64_t)(uint32_t)D.srcs[D.ops[o].src].fx_q); }
   for (int x = 0; x < D.n_aux; x++) { mix((uint64_t)D.aux[x].kind); mix((uint64_t)D.aux[x].stride); mix((uint64_t)D.aux[x].n_rep); mix((uint64_t)D.aux[x].rep_bytes); }
   for (size_t a = 0; a < T.plan->aggs.size(); a++) { mix((uint64_t)T.plan->aggs[a].function); mix((uint64_t)(uint32_t)T.plan->aggs[a].op_a); }
   for (int32_t c : T.plan->group_cards) mix((uint64_t)c);

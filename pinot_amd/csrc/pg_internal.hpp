@@ -91,6 +91,10 @@ struct Column {
   std::vector<int64_t> posting_card;            // docs per dictId (exact: planning estimates filter selectivity from it)
   DeviceBuffer containers_dev, descs_dev;
   uint64_t fwd_bytes_logical = 0;               // bytes of the forward index proper (for algorithmic byte accounting)
+  // value statistics behind exact SUMs (fixed-point scale, digit count), computed once at registration
+  int32_t fx_exp = 0;                           // FLOAT / DOUBLE: every finite |value| < 2^fx_exp (a multiple of 16)
+  bool has_nonfinite = false;                   // NaN / +-Inf among the values: SUM falls back to IEEE double accumulation
+  uint64_t max_abs_int = 0;                     // LONG: largest |value|
   std::map<int, DeviceBuffer> hll_luts;         // per log2m: (register index | rank << 16) of every dictionary value
   int32_t hll_log2m = 0;                        // PG_COL_HLL_REGS: log2m of the serialized HyperLogLogs
 };
@@ -134,6 +138,7 @@ struct StarTree {
 };
 
 void segment_add_column(Segment& seg, const pg_column_desc& d);
+double limbs_to_double(const int64_t* limbs, int n_limbs, int q);   // sum_j limbs[j] * 2^(32 j + q), correctly rounded (pg_plan.cpp)
 void segment_add_star_tree(Segment& seg, const pg_star_tree_desc& d);
 void decompress_fixed_byte_chunks(int compression, const uint8_t* file, const std::vector<uint64_t>& offs, uint32_t chunk_bytes,
                                   uint64_t total_bytes, uint8_t* dst, const char* column);
@@ -189,6 +194,8 @@ struct AggOut {          // how one requested aggregation maps onto accumulator 
   int32_t function;
   int32_t op_a = -1, op_b = -1;   // indices into ops (AVG: sum,count; MINMAXRANGE: min,max; COUNT: count op)
   bool is_float = false;
+  int32_t sum_limbs = 0;           // SUM / AVG: > 0: the sum is the fixed-point number sum_j ops[op_a + j] * 2^(32 j + fx_q), rounded once
+  int32_t fx_q = 0;
   bool star_count = false;         // COUNT over a star-tree: op_a is the SUM of count__* (CountAggregationFunction.java:99-106)
   int32_t aux = -1;                // DISTINCTCOUNT / DISTINCTCOUNTHLL: index into PgQueryPlan::aux
   int32_t log2m = 0;
@@ -217,6 +224,7 @@ struct CompiledPlan {
   int32_t fast_filter = -2;          // -2: interpreter kernel; -1: index-only filter; >= 0: ScanKind of the one scan leaf
   bool fast_agg = true;              // aggregation fits the fast kernels (or there is none)
   bool aux_in_lds = false;           // DISTINCTCOUNT / HLL states live in the workgroups' LDS (merged by pg_reduce_aux_kernel)
+  bool digit_ops = false;            // some SUM runs on digit accumulators (PgAccValueKind): the *d kernels
   bool wide_agg = false;             // LDS-table aggregation over wide group columns / 64-bit sources: the *_w kernels
   DeviceBuffer ops_dev;
   std::vector<size_t> aux_bytes;     // bytes of each auxiliary region (256-byte multiples)

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include "pg_device.h"
+#include "pg_fixed_point.h"
 
 #define DEVFN __device__ __forceinline__
 #ifndef PG_FAST_AGG_B
@@ -403,6 +404,18 @@ DEVFN void acc_int(int64_t* slot, int fn, int64_t v) {
   else if (fn == PG_ACC_MIN) atomicMin(reinterpret_cast<long long*>(slot), (long long)v);
   else atomicMax(reinterpret_cast<long long*>(slot), (long long)v);
 }
+DEVFN int64_t fx_digit(double x, int q, int limb) { return pg_fx_digit(x, q, limb); }   // pg_fixed_point.h
+DEVFN int64_t long_digit(int64_t v, int limb) { return pg_long_digit(v, limb); }
+// one accumulator update from a double / an int64 value, whatever the accumulator's value kind
+DEVFN void acc_float(int64_t* slot, int fn, double v);
+DEVFN void acc_from_double(int64_t* slot, const PgAccOp& op, double v, int q) {
+  if (op.is_float == PG_ACCV_FIXED_DIGIT) atomicAdd(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)fx_digit(v, q, op.limb));
+  else acc_float(slot, op.fn, v);
+}
+DEVFN void acc_from_int(int64_t* slot, const PgAccOp& op, int64_t v) {
+  if (op.is_float == PG_ACCV_LONG_DIGIT) atomicAdd(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)long_digit(v, op.limb));
+  else acc_int(slot, op.fn, v);
+}
 DEVFN void acc_float(int64_t* slot, int fn, double v) {
   if (fn == PG_ACC_SUM) { atomicAdd(reinterpret_cast<double*>(slot), v); return; }
   if (v != v) return;   // Java: NaN > x and NaN < x are false → NaN never replaces the holder
@@ -618,7 +631,9 @@ DEVFN void aux_update_batch(const PgQueryPlan& p, uint32_t mb, int k0, int wtile
 // group columns of any width, raw 32/64-bit and dictionary-encoded sources.  B quads per lane are in flight at a time; like
 // the filter stage, every load of a stage is issued unconditionally (lanes whose quad has no match re-read quad 0 of the
 // tile) before the first is used — a load under a per-lane branch is waited for inside the branch.
-template <int B, bool AUX = true>
+// DIG: the plan has digit accumulators (exact SUMs of FLOAT / DOUBLE / wide LONG sources, PgAccValueKind); kernels without them are
+// compiled without that code (it costs the others ~40 spilled VGPRs).
+template <int B, bool AUX = true, bool DIG = false>
 DEVFN void aggregate_wtile(const PgQueryPlan& p, uint32_t m, int wtile, int64_t* table, int lane, uint32_t rep, uint32_t part_lo = 0) {
   const uint32_t R = (uint32_t)p.replicas;
   const bool part = p.agg_mode == PG_AGG_LDS_PART;
@@ -788,7 +803,8 @@ DEVFN void aggregate_wtile(const PgQueryPlan& p, uint32_t m, int wtile, int64_t*
             for (int i = 0; i < 4; i++) x[u][i] = gptr<uint32_t>(S.dict)[d[u][i]];   // every dictId read is a valid one
         }
         for (int k = o; k < o_end; k++) {
-          const int fn = p.ops[k].fn;
+          const PgAccOp opk = p.ops[k];
+          const int fn = opk.fn;
           int64_t* base = table + (size_t)k * stride;
           if (S.val_type == PG_V_I32) {
 #pragma unroll
@@ -796,6 +812,14 @@ DEVFN void aggregate_wtile(const PgQueryPlan& p, uint32_t m, int wtile, int64_t*
 #pragma unroll
               for (int i = 0; i < 4; i++)
                 if ((mb >> (4 * u + i)) & 1u) acc_int(base + slot[u][i], fn, (int64_t)(int32_t)x[u][i]);
+          } else if (DIG && opk.is_float == PG_ACCV_FIXED_DIGIT) {   // wave-uniform: the branch stays outside the unrolled loops
+            const int q = S.fx_q, limb = opk.limb;
+#pragma unroll
+            for (int u = 0; u < B; u++)
+#pragma unroll
+              for (int i = 0; i < 4; i++)
+                if ((mb >> (4 * u + i)) & 1u)
+                  atomicAdd(reinterpret_cast<unsigned long long*>(base + slot[u][i]), (unsigned long long)fx_digit((double)__uint_as_float(x[u][i]), q, limb));
           } else {
 #pragma unroll
             for (int u = 0; u < B; u++)
@@ -848,20 +872,36 @@ DEVFN void aggregate_wtile(const PgQueryPlan& p, uint32_t m, int wtile, int64_t*
               for (int i = 0; i < 4; i++) x[u][i] = gptr<uint64_t>(S.dict)[d[u][i]];
           }
           for (int k = o; k < o_end; k++) {
-            const int fn = p.ops[k].fn;
+            const PgAccOp opk = p.ops[k];
             int64_t* base = table + (size_t)k * stride;
-            if (S.val_type == PG_V_I64) {
+            if (DIG && opk.is_float == PG_ACCV_LONG_DIGIT) {   // the value-kind branches are wave-uniform and stay outside the unrolled loops
+              const int limb = opk.limb;
 #pragma unroll
               for (int u = 0; u < WB; u++)
 #pragma unroll
                 for (int i = 0; i < 4; i++)
-                  if ((mb >> (4 * (h + u) + i)) & 1u) acc_int(base + slot[h + u][i], fn, (int64_t)x[u][i]);
+                  if ((mb >> (4 * (h + u) + i)) & 1u)
+                    atomicAdd(reinterpret_cast<unsigned long long*>(base + slot[h + u][i]), (unsigned long long)long_digit((int64_t)x[u][i], limb));
+            } else if (DIG && opk.is_float == PG_ACCV_FIXED_DIGIT) {
+              const int q = S.fx_q, limb = opk.limb;
+#pragma unroll
+              for (int u = 0; u < WB; u++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                  if ((mb >> (4 * (h + u) + i)) & 1u)
+                    atomicAdd(reinterpret_cast<unsigned long long*>(base + slot[h + u][i]), (unsigned long long)fx_digit(__longlong_as_double((int64_t)x[u][i]), q, limb));
+            } else if (S.val_type == PG_V_I64) {
+#pragma unroll
+              for (int u = 0; u < WB; u++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                  if ((mb >> (4 * (h + u) + i)) & 1u) acc_int(base + slot[h + u][i], opk.fn, (int64_t)x[u][i]);
             } else {
 #pragma unroll
               for (int u = 0; u < WB; u++)
 #pragma unroll
                 for (int i = 0; i < 4; i++)
-                  if ((mb >> (4 * (h + u) + i)) & 1u) acc_float(base + slot[h + u][i], fn, __longlong_as_double((int64_t)x[u][i]));
+                  if ((mb >> (4 * (h + u) + i)) & 1u) acc_float(base + slot[h + u][i], opk.fn, __longlong_as_double((int64_t)x[u][i]));
             }
           }
         }
@@ -1051,7 +1091,7 @@ DEVFN void flush_workgroup(const PgQueryPlan& p, const int64_t* lds_table, const
       const PgAccOp op = p.ops[o];
       const int64_t* src = lds_table + i * R;   // (o * G + g) * R
       int64_t acc = src[0];
-      if (op.fn == PG_ACC_SUM && op.is_float) {
+      if (op.fn == PG_ACC_SUM && op.is_float == PG_ACCV_DOUBLE) {
         double d = __longlong_as_double(acc);
         for (int r = 1; r < R; r++) d += __longlong_as_double(src[r]);
         acc = __double_as_longlong(d);
@@ -1078,7 +1118,7 @@ __device__ __forceinline__ void fast_query_body(const PgQueryPlan& p) {
   const int wave = uniform(t >> 6);
   int64_t* lds_table = reinterpret_cast<int64_t*>(smem);
   if (t < PG_MAX_STATS) s_stat[t] = 0;
-  const bool part_agg = AGG == 2 && p.agg_mode == PG_AGG_LDS_PART;
+  const bool part_agg = AGG >= 2 && p.agg_mode == PG_AGG_LDS_PART;
   if (AGG) {
     const uint32_t table_slots = part_agg ? (uint32_t)p.part_groups : (uint32_t)p.n_groups * (uint32_t)p.replicas;
     for (int o = 0; o < p.n_ops; o++) {
@@ -1125,7 +1165,8 @@ __device__ __forceinline__ void fast_query_body(const PgQueryPlan& p) {
       if (lane == 0 && wsum) atomicAdd(&p.out_tile_counts[wt / PG_WTILES_PER_TILE], wsum);
     }
     if (AGG && p.agg_mode != PG_AGG_NONE && __ballot(m != 0)) {
-      if (AGG == 2) aggregate_wtile<PG_WIDE_AGG_B, false>(p, m, wt, lds_table, lane, rep, part_lo);   // any group width, 32/64-bit sources
+      if (AGG == 3) aggregate_wtile<PG_WIDE_AGG_B, false, true>(p, m, wt, lds_table, lane, rep, part_lo);   // + digit accumulators
+      else if (AGG == 2) aggregate_wtile<PG_WIDE_AGG_B, false>(p, m, wt, lds_table, lane, rep, part_lo);   // any group width, 32/64-bit sources
       else fast_aggregate_wtile<PG_FAST_AGG_B>(p, m, wt, lds_table, lane, rep);
     }
   }
@@ -1151,7 +1192,7 @@ __device__ __forceinline__ void fast_multi_body(const PgQueryPlan& p) {
   const int wave = uniform(t >> 6);
   int64_t* lds_table = reinterpret_cast<int64_t*>(smem);
   if (t < PG_MAX_STATS) s_stat[t] = 0;
-  const bool part_agg = AGG == 2 && p.agg_mode == PG_AGG_LDS_PART;
+  const bool part_agg = AGG >= 2 && p.agg_mode == PG_AGG_LDS_PART;
   if (AGG) {
     const uint32_t table_slots = part_agg ? (uint32_t)p.part_groups : (uint32_t)p.n_groups * (uint32_t)p.replicas;
     for (int o = 0; o < p.n_ops; o++) {
@@ -1211,7 +1252,8 @@ __device__ __forceinline__ void fast_multi_body(const PgQueryPlan& p) {
       if (lane == 0 && wsum) atomicAdd(&p.out_tile_counts[wt / PG_WTILES_PER_TILE], wsum);
     }
     if (AGG && p.agg_mode != PG_AGG_NONE && __ballot(m != 0)) {
-      if (AGG == 2) aggregate_wtile<PG_WIDE_AGG_B, false>(p, m, wt, lds_table, lane, rep, part_lo);
+      if (AGG == 3) aggregate_wtile<PG_WIDE_AGG_B, false, true>(p, m, wt, lds_table, lane, rep, part_lo);
+      else if (AGG == 2) aggregate_wtile<PG_WIDE_AGG_B, false>(p, m, wt, lds_table, lane, rep, part_lo);
       else fast_aggregate_wtile<PG_FAST_AGG_B>(p, m, wt, lds_table, lane, rep);
     }
   }
@@ -1231,12 +1273,14 @@ __device__ __forceinline__ void fast_multi_body(const PgQueryPlan& p) {
 extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_fast_multi_f(const PgQueryPlan p) { fast_multi_body<0>(p); }
 extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_fast_multi_a(const PgQueryPlan p) { fast_multi_body<1>(p); }
 extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_fast_multi_w(const PgQueryPlan p) { fast_multi_body<2>(p); }
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_fast_multi_wd(const PgQueryPlan p) { fast_multi_body<3>(p); }
 
 #define PG_FAST_KERNEL(NAME, SK, AGG) \
   extern "C" __global__ void __launch_bounds__(PG_BLOCK) NAME(const PgQueryPlan p) { fast_query_body<SK, AGG>(p); }
 PG_FAST_KERNEL(pg_fast_none_f, -1, 0)
 PG_FAST_KERNEL(pg_fast_none_a, -1, 1)
 PG_FAST_KERNEL(pg_fast_none_w, -1, 2)
+PG_FAST_KERNEL(pg_fast_none_wd, -1, 3)
 PG_FAST_KERNEL(pg_fast_i32range_f, SK_I32_RANGE, 0)
 PG_FAST_KERNEL(pg_fast_i32range_a, SK_I32_RANGE, 1)
 PG_FAST_KERNEL(pg_fast_dictrange_f, SK_DICT_RANGE_SMALL, 0)
@@ -1260,7 +1304,7 @@ struct MaskStack {
 // =====================================================================================================================
 // TABLE: 0 = no accumulator table (filter only / COUNT from the match count), 1 = LDS table (LDS / SINGLE / LDS_PART modes),
 // 2 = dense HBM table — three kernels instead of one so that each carries one inlined copy of the aggregation code.
-template <int TABLE>
+template <int TABLE, bool DIG = false>
 __device__ __forceinline__ void generic_query_body(const PgQueryPlan& p) {
   extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
   __shared__ uint32_t s_stat[PG_MAX_STATS];
@@ -1365,10 +1409,10 @@ __device__ __forceinline__ void generic_query_body(const PgQueryPlan& p) {
     // ---- aggregation ----------------------------------------------------------------------------------------------
     if (TABLE != 0 && __ballot(m != 0)) {
       if (TABLE == 1) {
-        if (p.fast_agg_shape) fast_aggregate_wtile<PG_FAST_AGG_B>(p, m, wt, lds_table, lane, rep);
-        else aggregate_wtile<PG_GENERIC_AGG_B>(p, m, wt, lds_table, lane, rep, part_lo);
+        if (!DIG && p.fast_agg_shape) fast_aggregate_wtile<PG_FAST_AGG_B>(p, m, wt, lds_table, lane, rep);
+        else aggregate_wtile<PG_GENERIC_AGG_B, true, DIG>(p, m, wt, lds_table, lane, rep, part_lo);
       } else {
-        aggregate_wtile<PG_GENERIC_AGG_B>(p, m, wt, p.partials, lane, rep);
+        aggregate_wtile<PG_GENERIC_AGG_B, true, DIG>(p, m, wt, p.partials, lane, rep);
       }
     }
   }
@@ -1389,7 +1433,7 @@ __device__ __forceinline__ void generic_query_body(const PgQueryPlan& p) {
       const PgAccOp op = p.ops[o];
       const int64_t* src = lds_table + i * R;   // (o * G + g) * R
       int64_t acc = src[0];
-      if (op.fn == PG_ACC_SUM && op.is_float) {
+      if (op.fn == PG_ACC_SUM && op.is_float == PG_ACCV_DOUBLE) {
         double d = __longlong_as_double(acc);
         for (int r = 1; r < R; r++) d += __longlong_as_double(src[r]);
         acc = __double_as_longlong(d);
@@ -1414,6 +1458,8 @@ __device__ __forceinline__ void generic_query_body(const PgQueryPlan& p) {
 extern "C" __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_generic_query_f(const PgQueryPlan p) { generic_query_body<0>(p); }
 extern "C" __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_generic_query_l(const PgQueryPlan p) { generic_query_body<1>(p); }
 extern "C" __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_generic_query_g(const PgQueryPlan p) { generic_query_body<2>(p); }
+extern "C" __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_generic_query_ld(const PgQueryPlan p) { generic_query_body<1, true>(p); }
+extern "C" __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_generic_query_gd(const PgQueryPlan p) { generic_query_body<2, true>(p); }
 
 // Combines the per-workgroup partial tables: out[op][g].  One wavefront per output slot, lanes stride over the
 // workgroups, fixed butterfly order (deterministic also for floating sums).  The last block also moves the statistics
@@ -1438,7 +1484,7 @@ extern "C" __global__ void __launch_bounds__(256) pg_reduce_partials_kernel(cons
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_out) return;
   const PgAccOp op = ops[i / n_groups];
-  const int kind = (op.fn == PG_ACC_SUM && op.is_float) ? 0 : ((op.fn == PG_ACC_COUNT || op.fn == PG_ACC_SUM) ? 1 : (op.fn == PG_ACC_MIN ? 2 : 3));
+  const int kind = (op.fn == PG_ACC_SUM && op.is_float == PG_ACCV_DOUBLE) ? 0 : ((op.fn == PG_ACC_COUNT || op.fn == PG_ACC_SUM) ? 1 : (op.fn == PG_ACC_MIN ? 2 : 3));
   int64_t acc = pg_acc_identity(op.fn, op.is_float);
   auto combine = [&](int64_t a, int64_t b) -> int64_t {
     if (kind == 0) return __double_as_longlong(__longlong_as_double(a) + __longlong_as_double(b));
@@ -1869,8 +1915,8 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_hash_aggregate_kernel(
           continue;
         }
         const int64_t v = *(const GAS int64_t*)(tp + 16 + 8 * op.src);
-        if (op.is_float) acc_float(acc, op.fn, __longlong_as_double(v));
-        else acc_int(acc, op.fn, v);
+        if (op.is_float == PG_ACCV_DOUBLE || op.is_float == PG_ACCV_FIXED_DIGIT) acc_from_double(acc, op, __longlong_as_double(v), p.srcs[op.src].fx_q);
+        else acc_from_int(acc, op, v);
       }
     }
     __syncthreads();
@@ -2026,8 +2072,8 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_aggregate_kernel
 #pragma unroll
         for (int u = 0; u < U; u++)
           if (on[u]) {
-            if (op.is_float) acc_float(base + k[u], op.fn, __longlong_as_double(v[u]));
-            else acc_int(base + k[u], op.fn, v[u]);
+            if (op.is_float == PG_ACCV_DOUBLE || op.is_float == PG_ACCV_FIXED_DIGIT) acc_from_double(base + k[u], op, __longlong_as_double(v[u]), p.srcs[op.src].fx_q);
+            else acc_from_int(base + k[u], op, v[u]);
           }
       }
       uint32_t aux_off = 0;
@@ -2083,7 +2129,7 @@ extern "C" __global__ void __launch_bounds__(256) pg_radix_reduce_kernel(const i
   const int b = g >> radix_shift, l = g & ((1 << radix_shift) - 1);
   const int64_t slots = (int64_t)1 << radix_shift;
   const PgAccOp op = ops[o];
-  const int kind = (op.fn == PG_ACC_SUM && op.is_float) ? 0 : ((op.fn == PG_ACC_COUNT || op.fn == PG_ACC_SUM) ? 1 : (op.fn == PG_ACC_MIN ? 2 : 3));
+  const int kind = (op.fn == PG_ACC_SUM && op.is_float == PG_ACCV_DOUBLE) ? 0 : ((op.fn == PG_ACC_COUNT || op.fn == PG_ACC_SUM) ? 1 : (op.fn == PG_ACC_MIN ? 2 : 3));
   int64_t acc = pg_acc_identity(op.fn, op.is_float);
   for (int sl = 0; sl < slices; sl++) {
     const int64_t v = partials[((int64_t)(b * slices + sl) * n_ops + o) * slots + l];
@@ -2108,7 +2154,7 @@ extern "C" __global__ void __launch_bounds__(256) pg_reduce_parts_kernel(const i
   const int o = (int)(i / n_groups), g = (int)(i % n_groups);
   const int range = g / part_groups, l = g % part_groups;
   const PgAccOp op = ops[o];
-  const int kind = (op.fn == PG_ACC_SUM && op.is_float) ? 0 : ((op.fn == PG_ACC_COUNT || op.fn == PG_ACC_SUM) ? 1 : (op.fn == PG_ACC_MIN ? 2 : 3));
+  const int kind = (op.fn == PG_ACC_SUM && op.is_float == PG_ACCV_DOUBLE) ? 0 : ((op.fn == PG_ACC_COUNT || op.fn == PG_ACC_SUM) ? 1 : (op.fn == PG_ACC_MIN ? 2 : 3));
   int64_t acc = pg_acc_identity(op.fn, op.is_float);
   auto combine = [&](int64_t a, int64_t b) -> int64_t {
     if (kind == 0) return __double_as_longlong(__longlong_as_double(a) + __longlong_as_double(b));

@@ -14,6 +14,7 @@
 #include <sstream>
 
 #include "pg_internal.hpp"
+#include "pg_fixed_point.h"
 
 namespace pg {
 
@@ -742,6 +743,8 @@ double dictionary_value_as_double(const Column& c, int32_t dict_id) {   // Dicti
   }
 }
 
+double limbs_to_double(const int64_t* limbs, int n_limbs, int q) { return pg_limbs_to_double(limbs, n_limbs, q); }
+
 static const int64_t kLdsTableBudget = 144 * 1024;      // bytes of LDS for the accumulator table (one workgroup per CU)
 static const int64_t kLdsReplicaBudget = 96 * 1024;
 static const size_t kMaxAuxBytes = (size_t)2 << 30;
@@ -1015,11 +1018,41 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
     srcs.push_back(c);
     return (int32_t)srcs.size() - 1;
   };
-  auto op_index = [&](int32_t fn, int32_t src, bool is_float) {
-    for (size_t i = 0; i < ops.size(); i++) if (ops[i].fn == fn && ops[i].src == src) return (int32_t)i;
+  auto op_index_kind = [&](int32_t fn, int32_t src, int32_t kind, int32_t limb) {
+    for (size_t i = 0; i < ops.size(); i++)
+      if (ops[i].fn == fn && ops[i].src == src && ops[i].is_float == kind && ops[i].limb == limb) return (int32_t)i;
     if (ops.size() >= PG_MAX_OPS) fail(PG_ERR_UNSUPPORTED, "more than %d accumulators", PG_MAX_OPS);
-    ops.push_back({fn, src, is_float ? 1 : 0, 0});
+    ops.push_back({fn, src, kind, limb});
     return (int32_t)ops.size() - 1;
+  };
+  auto op_index = [&](int32_t fn, int32_t src, bool is_float) { return op_index_kind(fn, src, is_float ? PG_ACCV_DOUBLE : PG_ACCV_INT, 0); };
+  // SUM accumulators of a column (see PgAccValueKind): INT, and LONG whose sum cannot leave int64, add into one int64; other LONG
+  // columns into two 32-bit digits; FLOAT / DOUBLE into 3 / 4 fixed-point digits below the column's largest magnitude (96 / 128 bits:
+  // exact for every value within 2^-56 / 2^-59 of that magnitude, truncated below — far inside 1 ulp of the exact sum); a column
+  // holding NaN / Inf keeps the reference's IEEE double addition.
+  std::vector<int32_t> src_fx_q(PG_MAX_SRCS, 0);
+  auto sum_ops = [&](Column* c, int32_t si, AggOut& out) {
+    if (c->val_type == PG_V_I32) { out.op_a = op_index(PG_ACC_SUM, si, false); return; }
+    if (c->val_type == PG_V_I64) {
+      // one int64 holds the sum when docs x largest magnitude stays below 2^63
+      if ((unsigned __int128)c->max_abs_int * (unsigned __int128)std::max(seg.total_docs, 1) < ((unsigned __int128)1 << 63)) {
+        out.op_a = op_index(PG_ACC_SUM, si, false);
+        return;
+      }
+      out.op_a = op_index_kind(PG_ACC_SUM, si, PG_ACCV_LONG_DIGIT, 0);
+      (void)op_index_kind(PG_ACC_SUM, si, PG_ACCV_LONG_DIGIT, 1);
+      out.sum_limbs = 2;
+      out.fx_q = 0;
+      return;
+    }
+    if (c->has_nonfinite) { out.op_a = op_index(PG_ACC_SUM, si, true); return; }
+    const int limbs = c->val_type == PG_V_F32 ? 3 : 4;
+    const int q = c->fx_exp - 32 * limbs + 1;     // |x| * 2^-q < 2^(32 limbs - 1): the top digit stays below 2^31
+    src_fx_q[(size_t)si] = q;
+    out.op_a = op_index_kind(PG_ACC_SUM, si, PG_ACCV_FIXED_DIGIT, 0);
+    for (int j = 1; j < limbs; j++) (void)op_index_kind(PG_ACC_SUM, si, PG_ACCV_FIXED_DIGIT, j);
+    out.sum_limbs = limbs;
+    out.fx_q = q;
   };
   // Which groups exist?  ArrayBasedHolder keeps a flag per raw key; here a group exists iff its COUNT is > 0 or — when the
   // query has no COUNT/AVG but has a MIN/MAX over an INT source — iff that accumulator left its identity (saves one LDS
@@ -1047,7 +1080,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
       Column* pc = st->pairs[(size_t)st->pair_index(s.function, s.column)].col;
       project(pc);
       if (s.function == PG_AGG_COUNT) {   // CountAggregationFunction.java:99-106,134-141: sum of the pre-aggregated long counts
-        out.op_a = op_index(PG_ACC_SUM, src_index(pc), false);
+        sum_ops(pc, src_index(pc), out);   // LONG counts
         out.star_count = true;
         P.aggs.push_back(out);
         continue;
@@ -1095,10 +1128,10 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
     const bool fl = c->val_type == PG_V_F32 || c->val_type == PG_V_F64;
     out.is_float = fl;
     switch (s.function) {
-      case PG_AGG_SUM: out.op_a = op_index(PG_ACC_SUM, si, fl); break;
+      case PG_AGG_SUM: sum_ops(c, si, out); break;
       case PG_AGG_MIN: out.op_a = op_index(PG_ACC_MIN, si, fl); break;
       case PG_AGG_MAX: out.op_a = op_index(PG_ACC_MAX, si, fl); break;
-      case PG_AGG_AVG: out.op_a = op_index(PG_ACC_SUM, si, fl); out.op_b = count_op; break;
+      case PG_AGG_AVG: sum_ops(c, si, out); out.op_b = count_op; break;
       case PG_AGG_MINMAXRANGE: out.op_a = op_index(PG_ACC_MIN, si, fl); out.op_b = op_index(PG_ACC_MAX, si, fl); break;
       default: fail(PG_ERR_UNSUPPORTED, "aggregation function %d", s.function);
     }
@@ -1139,6 +1172,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
     D.srcs[i].col_kind = c->col_kind;
     D.srcs[i].bits = c->bits;
     D.srcs[i].val_type = c->val_type;
+    D.srcs[i].fx_q = src_fx_q[i];
   }
   for (Column* c : projected) P.algorithmic_bytes += (int64_t)c->fwd_bytes_logical;
   P.n_projected_columns = (int32_t)projected.size();
@@ -1275,6 +1309,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
   // fast aggregation: LDS table, slots fit 16 bits, <= 8-bit group columns, 32-bit value sources
   P.fast_agg = D.agg_mode != PG_AGG_GLOBAL && D.agg_mode != PG_AGG_LDS_PART && D.agg_mode != PG_AGG_RADIX && (int64_t)G * D.replicas <= 65536;   // (trivially true without a table)
   if (D.n_aux > 0) P.fast_agg = false;   // set / HLL accumulators run in the interpreter kernel
+  for (auto& o : sorted_ops) if (o.is_float >= PG_ACCV_FIXED_DIGIT) { P.fast_agg = false; P.digit_ops = true; }   // digit accumulators: the general aggregator
   if (P.first_doc_op >= 0) P.fast_agg = false;
   for (Column* c : P.group_cols) if (c->bits > 8) P.fast_agg = false;
   for (Column* c : srcs)

@@ -11,11 +11,53 @@
 //   inverted index  BitmapInvertedIndexReader.java:45-62 offsets + portable RoaringBitmap blobs are parsed once;
 //                   container payloads are copied 16-byte aligned into one device buffer with a descriptor per
 //                   container (array / bitmap / run are all kept as is).
+#include <hip/hip_runtime.h>
+
 #include <algorithm>
+#include <cmath>
 
 #include "pg_internal.hpp"
 
+// Largest magnitude of a raw column, for exact SUMs: out[0] = max |value| (LONG: as uint64; FLOAT / DOUBLE: the bits of the largest
+// finite |double|), out[1] = 1 when a NaN / Inf occurs.  One pass at registration, values big-endian as stored.
+extern "C" __global__ void __launch_bounds__(256) pg_column_magnitude_kernel(const uint8_t* __restrict__ data, int64_t n, int val_type,
+                                                                             unsigned long long* __restrict__ out) {
+  unsigned long long mx = 0, bad = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    unsigned long long a;
+    if (val_type == PG_V_I64) {
+      const unsigned long long v = __builtin_bswap64(reinterpret_cast<const unsigned long long*>(data)[i]);
+      a = (long long)v < 0 ? 0ULL - v : v;
+    } else {
+      double d;
+      if (val_type == PG_V_F32) d = (double)__uint_as_float(__builtin_bswap32(reinterpret_cast<const uint32_t*>(data)[i]));
+      else d = __longlong_as_double((long long)__builtin_bswap64(reinterpret_cast<const unsigned long long*>(data)[i]));
+      a = (unsigned long long)__double_as_longlong(d) & 0x7FFFFFFFFFFFFFFFULL;
+      if (a >= 0x7FF0000000000000ULL) { bad = 1; a = 0; }
+    }
+    mx = a > mx ? a : mx;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(mx, off, 64);
+    mx = o > mx ? o : mx;
+    bad |= __shfl_xor(bad, off, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (mx) atomicMax(&out[0], mx);
+    if (bad) atomicOr(&out[1], 1ULL);
+  }
+}
+
 namespace pg {
+
+// every finite |value| < 2^fx_exp, fx_exp a multiple of 16 (so that segments with similar data choose the same scale and their
+// fixed-point tables merge)
+static int32_t fx_exp_of(double max_abs) {
+  if (!(max_abs > 0)) return 0;
+  int e = 0;
+  (void)std::frexp(max_abs, &e);   // max_abs = f * 2^e, f in [0.5, 1): max_abs < 2^e
+  return (int32_t)(16 * (int)std::floor(((double)e + 15.0) / 16.0));
+}
 
 static inline uint32_t be32(const uint8_t* p) {
   return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3];
@@ -279,6 +321,41 @@ void segment_add_column(Segment& seg, const pg_column_desc& d) {
     c.fwd_bytes_logical = need;
   } else {
     fail(PG_ERR_UNSUPPORTED, "column %s: forward index encoding %d", d.name, c.fwd_encoding);
+  }
+
+  // ---- value statistics for exact SUMs ---------------------------------------------------------------------------------------
+  if (c.has_dictionary && (c.data_type == PG_TYPE_LONG || c.data_type == PG_TYPE_FLOAT || c.data_type == PG_TYPE_DOUBLE)) {
+    const uint8_t* dp = c.dict_host.data();
+    double mx = 0;
+    for (int32_t i = 0; i < c.cardinality; i++) {
+      if (c.data_type == PG_TYPE_LONG) {
+        const int64_t v = (int64_t)be64(dp + (size_t)i * 8);
+        const uint64_t a = v < 0 ? 0ULL - (uint64_t)v : (uint64_t)v;
+        c.max_abs_int = std::max(c.max_abs_int, a);
+      } else {
+        double v;
+        if (c.data_type == PG_TYPE_FLOAT) { uint32_t u = be32(dp + (size_t)i * 4); float f; memcpy(&f, &u, 4); v = (double)f; }
+        else { uint64_t u = be64(dp + (size_t)i * 8); memcpy(&v, &u, 8); }
+        if (std::isfinite(v)) mx = std::max(mx, std::fabs(v));
+        else c.has_nonfinite = true;
+      }
+    }
+    c.fx_exp = fx_exp_of(mx);
+  } else if (!c.has_dictionary && (c.val_type == PG_V_I64 || c.val_type == PG_V_F32 || c.val_type == PG_V_F64) &&
+             (c.col_kind == PG_COL_RAW32 || c.col_kind == PG_COL_RAW64) && seg.total_docs > 0) {
+    DeviceBuffer out(16, true);
+    hipLaunchKernelGGL(pg_column_magnitude_kernel, dim3(1024), dim3(256), 0, 0, c.fwd_dev.as<uint8_t>(), (int64_t)seg.total_docs, c.val_type,
+                       out.as<unsigned long long>());
+    PG_HIP(hipGetLastError());
+    unsigned long long h[2] = {0, 0};
+    PG_HIP(hipMemcpy(h, out.ptr, sizeof(h), hipMemcpyDeviceToHost));
+    if (c.val_type == PG_V_I64) c.max_abs_int = h[0];
+    else {
+      double mx;
+      memcpy(&mx, &h[0], 8);
+      c.fx_exp = fx_exp_of(mx);
+      c.has_nonfinite = h[1] != 0;
+    }
   }
 
   if (d.inverted_index.size > 0 && c.has_dictionary && c.fwd_encoding != PG_FWD_DICT_SORTED)
