@@ -29,7 +29,7 @@ def seg(gpu_api, oracle_api):
     data = {
         "k": rng.integers(0, 2000, N).astype(np.int32),
         "k2": rng.integers(0, 7, N).astype(np.int32),
-        "k3": rng.integers(0, 300, N).astype(np.int32),
+        "k3": rng.integers(0, 40, N).astype(np.int32),
         "r": rng.integers(0, 40_000, N).astype(np.int32),
         "inv": rng.integers(0, 5, N).astype(np.int32),
         "dm": rng.normal(0, 1e3, N),                                    # raw DOUBLE, mixed signs, nothing representable
