@@ -160,6 +160,7 @@ typedef struct pg_query {
 
 #define PG_QUERY_FLAG_PROFILE 0x1          /* record per-kernel HIP-event timings into pg_exec_stats */
 #define PG_QUERY_FLAG_SKIP_STAR_TREE 0x2   /* QueryContext#isSkipStarTree (query option useStarTree=false) */
+#define PG_QUERY_FLAG_APPROX_FILTER_STATS 0x8 /* skip the exact numEntriesScannedInFilter of OR / NOT-over-scan shapes (stats_exact = 0) */
 #define PG_QUERY_FLAG_KEEP_DEVICE_TABLE 0x4 /* keep the dense accumulator table in HBM with the result (pg_result_merge / _all_reduce) */
 
 /* ExecutionStatistics (pinot-core/.../operator/ExecutionStatistics.java) + device timings. */
@@ -169,7 +170,7 @@ typedef struct pg_exec_stats {
   int64_t num_entries_scanned_post_filter;
   int64_t num_total_docs;
   int32_t num_groups_limit_reached;
-  int32_t stats_exact;            /* 1 if num_entries_scanned_in_filter follows the reference (flat AND shapes) */
+  int32_t stats_exact;            /* 1: num_entries_scanned_in_filter is the reference's count (always, unless PG_QUERY_FLAG_APPROX_FILTER_STATS) */
   /* HIP-event timings on the stream the kernels ran on, milliseconds; 0 when not profiled */
   float device_ms_total;
   float device_ms_filter;

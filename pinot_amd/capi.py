@@ -38,6 +38,7 @@ RESULT_LONG, RESULT_DOUBLE, RESULT_AVG_PAIR, RESULT_MINMAX_PAIR, RESULT_DICTID_S
 QUERY_FLAG_PROFILE = 0x1
 QUERY_FLAG_SKIP_STAR_TREE = 0x2
 QUERY_FLAG_KEEP_DEVICE_TABLE = 0x4
+QUERY_FLAG_APPROX_FILTER_STATS = 0x8
 COMM_UNIQUE_ID_BYTES = 128
 GROUP_KEY_DICT_IDS, GROUP_KEY_LONG_VALUES = 0, 1
 

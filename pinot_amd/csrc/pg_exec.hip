@@ -277,6 +277,37 @@ static double order_key_to_double(int64_t k) {
   return d;
 }
 
+// numEntriesScannedInFilter for plans whose count the kernels' counters do not give (CompiledPlan::stats_exact == false): the match
+// bitmap of every Scan / Inverted leaf comes from a filter launch of its own, the reference's iterator automaton runs over the
+// bitmaps on the host (pg_filter_stats.cpp).
+static int64_t exact_entries_scanned(CompiledPlan& P, ThreadCtx& ctx) {
+  StatLeafBits bits;
+  const int32_t n_docs = P.space_docs;
+  for (auto& lf : P.stat_leaves) {
+    CompiledPlan& L = *lf.second;
+    PgQueryPlan D = L.dev;
+    const size_t dev_words = (size_t)std::max(D.n_tiles, 1) * PG_TILE_WORDS;
+    ThreadCtx::grow(ctx.words, dev_words * 8);
+    PG_HIP(hipMemsetAsync(ctx.stats.ptr, 0, PG_MAX_STATS * 8, ctx.stream));
+    ctx.stats_dirty = true;
+    D.stats = ctx.stats.as<unsigned long long>();
+    D.out_words = ctx.words.as<uint64_t>();
+    D.agg_mode = PG_AGG_NONE;
+    HostBits hb;
+    hb.resize_for(n_docs);
+    if (n_docs > 0) {
+      const LaunchShape shape = launch_shape(L, D.n_wtiles, PG_AGG_NONE);
+      const char* kname = "";
+      hipLaunchKernelGGL(select_kernel(L, PG_AGG_NONE, &kname), dim3(shape.grid), dim3(shape.block), shape.lds, ctx.stream, D);
+      PG_HIP(hipGetLastError());
+      PG_HIP(hipMemcpyAsync(hb.w.data(), ctx.words.ptr, (size_t)(((int64_t)n_docs + 63) / 64) * 8, hipMemcpyDeviceToHost, ctx.stream));
+      PG_HIP(hipStreamSynchronize(ctx.stream));
+    }
+    bits.emplace(lf.first, std::move(hb));
+  }
+  return emulate_entries_scanned_in_filter(*P.root_op, bits, n_docs);
+}
+
 // ---- result assembly: dense accumulator table (+ statistics, + DISTINCTCOUNT / HLL regions) -> groups and intermediates --------
 struct HostTable {
   std::vector<int64_t> table;            // [n_ops][G] (G = groups of the compact table for hashed key spaces)
@@ -581,7 +612,16 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
   H.hash_keys = std::move(hash_keys_host);
   H.full_scan_entries = P.full_scan_entries;
   H.total_docs = seg.total_docs;
+  int64_t exact_entries = -1;
+  if (!P.stats_exact && !(q.flags & PG_QUERY_FLAG_APPROX_FILTER_STATS)) {
+    check_cancel(cancel, &ctx);
+    exact_entries = exact_entries_scanned(P, ctx);
+    // the merged tables carry the count in the statistics tail: fold the exact value in as "full scan entries" of this segment
+    H.full_scan_entries = exact_entries;
+    for (int i = 1; i < PG_MAX_STATS; i++) H.stats[i] = 0;
+  }
   assemble_result(*res, P, q.n_group_by, q.n_aggregations, H);
+  if (exact_entries >= 0) res->stats.stats_exact = 1;
   snprintf(res->stats.kernel, sizeof(res->stats.kernel), "%s", kname);
   if (profile) {
     float a = 0, b = 0;
@@ -599,7 +639,9 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
     kept->n_aggregations = q.n_aggregations;
     kept->n_out = n_out;
     kept->aux_total = aux_total;
-    kept->full_scan_entries = P.full_scan_entries;
+    kept->full_scan_entries = exact_entries >= 0 ? exact_entries : P.full_scan_entries;
+    if (exact_entries >= 0)   // the per-scan candidate counters of the kept table are superseded by the exact count
+      PG_HIP(hipMemset(kept->table.as<int64_t>() + n_out + 1, 0, (PG_MAX_STATS - 1) * 8));
     kept->num_total_docs = seg.total_docs;
     res->dev = std::move(kept);
   }
@@ -890,6 +932,10 @@ std::unique_ptr<DocIdSet> execute_filter(Segment& seg, const pg_filter_node* fil
   PG_HIP(hipMemcpyAsync(out->tile_counts.data(), ctx.tile_counts.ptr, out->tile_counts.size() * 4, hipMemcpyDeviceToHost, ctx.stream));
   PG_HIP(hipStreamSynchronize(ctx.stream));
   fill_stats(out->stats, P, P.full_scan_entries, seg.total_docs, stats_host);
+  if (!P.stats_exact) {
+    out->stats.num_entries_scanned_in_filter = exact_entries_scanned(P, ctx);
+    out->stats.stats_exact = 1;
+  }
   out->stats.star_tree_index = -1;
   snprintf(out->stats.kernel, sizeof(out->stats.kernel), "%s", kname);
   out->stats.num_entries_scanned_post_filter = 0;

@@ -165,6 +165,19 @@ struct PredEval {
 };
 PredEval make_pred_eval(const pg_filter_node& p, const Column& col);
 
+// ---- host-side doc-id bitmaps (pg_filter_stats.cpp: numEntriesScannedInFilter of leapfrogged filter shapes) ---------------------
+struct HostBits {
+  std::vector<uint64_t> w;   // ceil(n_docs / 64) + 1 words, bits beyond n_docs clear
+  int64_t n_docs = 0;
+  int64_t next_set(int64_t from) const;   // first set bit >= from, -1 when none
+  int64_t cardinality() const;
+  void resize_for(int64_t docs);
+  void add_range(int64_t lo, int64_t hi_inclusive);
+};
+struct FilterOp;
+using StatLeafBits = std::unordered_map<const FilterOp*, HostBits>;
+int64_t emulate_entries_scanned_in_filter(const FilterOp& root, const StatLeafBits& leaves, int32_t n_docs);
+
 // ---- compiled plan ------------------------------------------------------------------------------------------------------------
 enum class OpKind { Empty, MatchAll, Scan, Inverted, Sorted, And, Or, Not, Bitmap };
 
@@ -208,7 +221,11 @@ struct CompiledPlan {
   std::vector<std::shared_ptr<Column>> pinned;   // doc-id bitmaps (null vectors, queryableDocIds snapshot) the program reads
   int32_t n_stat_slots = 1;
   int64_t full_scan_entries = 0;     // entries contributed by unmasked scans whose count is known (numDocs each)
-  bool stats_exact = true;
+  bool stats_exact = true;           // the kernels' own counters give numEntriesScannedInFilter (flat AND shapes, drained ORs)
+  // otherwise: the physical filter tree and one filter-only plan per Scan / Inverted leaf — their match bitmaps feed the iterator
+  // automaton of pg_filter_stats.cpp, which reproduces the reference's count exactly
+  std::unique_ptr<FilterOp> root_op;
+  std::vector<std::pair<const FilterOp*, std::shared_ptr<CompiledPlan>>> stat_leaves;
   bool always_empty = false;
   int32_t n_projected_columns = 0;
   int64_t algorithmic_bytes = 0;

@@ -821,9 +821,25 @@ std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* f
 }
 
 // `seg`: the doc space the operators run over — the segment itself, or a star-tree's docs.
-static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, const pg_query* q, const StarTree* st, int star_index) {
+static void collect_stat_leaves(const FilterOp& op, std::vector<const FilterOp*>& out) {
+  if (op.kind == OpKind::Scan || op.kind == OpKind::Inverted) out.push_back(&op);
+  for (auto& c : op.children) collect_stat_leaves(*c, out);
+}
+static OpPtr clone_leaf(const FilterOp& op) {
+  auto c = make_op(op.kind);
+  c->eval = op.eval;
+  c->col = op.col;
+  c->bitmap_col = op.bitmap_col;
+  c->range_lo = op.range_lo;
+  c->range_hi = op.range_hi;
+  return c;
+}
+
+static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_owned, const pg_query* q, const StarTree* st, int star_index) {
   auto plan = std::make_shared<CompiledPlan>();
   CompiledPlan& P = *plan;
+  P.root_op = std::move(root_owned);
+  FilterOp* const root = P.root_op.get();
   P.star_tree_index = star_index;
   P.space_docs = seg.total_docs;
   Emitter em{seg, P};
@@ -934,6 +950,16 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
   }
   if (P.fast_filter != 100) D.tail_posting = -1;
   P.lds_bytes = 0;   // the filter stack lives in registers
+  if (!P.stats_exact) {
+    // numEntriesScannedInFilter of this shape depends on how the reference's iterators drive each other: every Scan / Inverted
+    // leaf gets a filter-only plan of its own whose match bitmap feeds the iterator automaton (pg_filter_stats.cpp) at execution
+    std::vector<const FilterOp*> leaves;
+    collect_stat_leaves(*root, leaves);
+    for (const FilterOp* leaf : leaves) {
+      if (leaf->kind == OpKind::Inverted && (leaf->eval.exclusive ? leaf->eval.non_matching : leaf->eval.matching).empty()) continue;
+      P.stat_leaves.push_back({leaf, compile_in_space(seg, clone_leaf(*leaf), nullptr, nullptr, -1)});
+    }
+  }
   if (!q || q->n_aggregations <= 0) return plan;
 
   // ---- NonScanBasedAggregationOperator (AggregationPlanNode.java:110-120,165-190): no GROUP BY, match-all filter, every

@@ -59,7 +59,7 @@ def test_config1_gpu_matches_oracle(gpu_api, oracle_api):
         assert gb.rows() == ob.rows(), q
         assert gb.stats.num_docs_scanned == ob.stats.num_docs_scanned
         assert gb.stats.num_entries_scanned_post_filter == ob.stats.num_entries_scanned_post_filter
-        if gb.stats.stats_exact:
-            assert gb.stats.num_entries_scanned_in_filter == ob.stats.num_entries_scanned_in_filter, q
+        assert gb.stats.stats_exact == 1
+        assert gb.stats.num_entries_scanned_in_filter == ob.stats.num_entries_scanned_in_filter, q
     g.destroy()
     o.destroy()

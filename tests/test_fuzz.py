@@ -115,8 +115,8 @@ def _compare(gb, ob, what):
     assert gb.stats.num_docs_scanned == ob.stats.num_docs_scanned, what
     assert gb.stats.num_entries_scanned_post_filter == ob.stats.num_entries_scanned_post_filter, what
     assert gb.stats.num_groups_limit_reached == ob.stats.num_groups_limit_reached, what
-    if gb.stats.stats_exact:
-        assert gb.stats.num_entries_scanned_in_filter == ob.stats.num_entries_scanned_in_filter, what
+    assert gb.stats.stats_exact == 1, what
+    assert gb.stats.num_entries_scanned_in_filter == ob.stats.num_entries_scanned_in_filter, what
 
 
 @pytest.mark.gpu

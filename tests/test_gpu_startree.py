@@ -19,8 +19,8 @@ def assert_same(g, o):
     assert g.stats.num_docs_scanned == o.stats.num_docs_scanned
     assert g.stats.num_total_docs == o.stats.num_total_docs
     assert g.stats.num_entries_scanned_post_filter == o.stats.num_entries_scanned_post_filter
-    if g.stats.stats_exact:
-        assert g.stats.num_entries_scanned_in_filter == o.stats.num_entries_scanned_in_filter
+    assert g.stats.stats_exact == 1
+    assert g.stats.num_entries_scanned_in_filter == o.stats.num_entries_scanned_in_filter
 
 
 @pytest.fixture(scope="module")

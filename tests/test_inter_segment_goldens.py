@@ -25,12 +25,12 @@ STATS_NON_SCAN = [(120000, 0, 0, 120000)] + STATS_SCAN[1:]
 
 
 def assert_stats(s, expected, what):
-    """x4: the reference sums the statistics of the 4 segments.  The test's FILTER holds an OR of two scans inside the AND:
-    AndDocIdIterator leapfrogs that OR, so its scan counts depend on the iteration order — the HIP path evaluates the OR over whole
-    tiles and reports `stats_exact = 0` for such plans (every other counter stays exact)."""
+    """x4: the reference sums the statistics of the 4 segments.  The test's FILTER holds an OR (scan, inverted) inside the AND:
+    AndDocIdIterator leapfrogs that OR, so its scan count (63064 per segment) is a property of the iterator automaton — the HIP path
+    reproduces it by running that automaton over the leaves' match bitmaps (pg_filter_stats.cpp)."""
     assert (4 * s.num_docs_scanned, 4 * s.num_entries_scanned_post_filter, 4 * s.num_total_docs) == (expected[0], expected[2], expected[3]), what
-    if s.stats_exact:
-        assert 4 * s.num_entries_scanned_in_filter == expected[1], what
+    assert s.stats_exact == 1
+    assert 4 * s.num_entries_scanned_in_filter == expected[1], what
 
 
 def top_row(final, fn):

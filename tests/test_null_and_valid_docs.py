@@ -151,8 +151,8 @@ def _same(gb, ob, q):
         assert gb.aggregation_result() == ob.aggregation_result(), q
     assert gb.stats.num_docs_scanned == ob.stats.num_docs_scanned, q
     assert gb.stats.num_entries_scanned_post_filter == ob.stats.num_entries_scanned_post_filter, q
-    if gb.stats.stats_exact:
-        assert gb.stats.num_entries_scanned_in_filter == ob.stats.num_entries_scanned_in_filter, q
+    assert gb.stats.stats_exact == 1
+    assert gb.stats.num_entries_scanned_in_filter == ob.stats.num_entries_scanned_in_filter, q
 
 
 @pytest.mark.gpu
