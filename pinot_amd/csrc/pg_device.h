@@ -129,6 +129,7 @@ enum PgAggMode : int32_t {
   PG_AGG_RADIX_HASH = 6
 };
 #define PG_MAX_RADIX_BUCKETS 2048
+#define PG_RADIX_INVALID_KEY 0xFFFFFFFFu   // local key of a padding tuple (staged scatter pads every flush to whole lines)
 #define PG_MAX_RADIX_SRCS 4
 
 struct PgGroupCol {
@@ -230,7 +231,8 @@ struct PgQueryPlan {
   int32_t radix_shift;              // bucket = key >> radix_shift, local key = key & ((1 << radix_shift) - 1)
   int32_t radix_buckets;
   int32_t radix_slices;             // workgroups (slices) per bucket in the aggregation pass
-  int32_t pad_r;
+  int32_t radix_stage;              // > 0: tuples per staged flush (pg_radix_scatter_staged_kernel): every wavefront gathers a bucket's tuples
+                                    // in LDS and writes them out radix_stage at a time = whole 128-byte lines; 0: one store per tuple
   const uint32_t* match_words;      // filter result, one dword per 32 docs, whole wave tiles
   uint32_t* radix_hist;             // [grid][radix_buckets] tuple counts, then exact offsets (bucket major)
   uint32_t* radix_bucket_start;     // [radix_buckets + 1]

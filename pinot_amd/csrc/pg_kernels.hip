@@ -1870,6 +1870,201 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_scatter_kernel(c
 extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_hash_count_kernel(const PgQueryPlan p) { radix_pass_body<1, true>(p); }
 extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_hash_scatter_kernel(const PgQueryPlan p) { radix_pass_body<2, true>(p); }
 
+// Staged scatter (PASS 2 of the radix group-by for up to ~64 buckets).  Writing one 16-byte tuple per matching doc straight to its
+// bucket makes every lane of a store hit its own cache line: each partially written line is first FETCHED (write-allocate), so the
+// tuples cross HBM twice and every store waits on a fill (r01: FETCH_SIZE = WRITE_SIZE = tuple bytes, 11 x the wave cycles of the
+// count pass).  Here every wavefront keeps a private staging buffer per bucket in LDS — `stage` tuples = 128 or 256 bytes — claims
+// a slot with a returning LDS add, and when a buffer is full the wavefront writes it out as whole, line-aligned 128-byte lines:
+// no fill, 1/8 .. 1/16 of the store requests.  A (workgroup, bucket) range therefore consists of whole flushes; what a flush does
+// not fill carries PG_RADIX_INVALID_KEY and the aggregation pass skips it.
+// dynamic LDS: [PG_WAVES_PER_BLOCK][buckets] fill counters, then [PG_WAVES_PER_BLOCK][buckets][stage * stride] staging bytes.
+struct RadixStage {
+  uint32_t* fill;        // this wavefront's [buckets] counters
+  uint8_t* buf;          // this wavefront's [buckets][flush_bytes] staging
+  uint32_t* s_cnt;       // workgroup: tuples claimed so far per bucket
+  const uint32_t* s_base;
+  uint8_t* tuples;
+  uint32_t stage, stride, flush_bytes;
+};
+// One round: every lane with `active` appends its tuple (stride bytes in w0 / w1 / w2, 16 bytes each; stride 8 uses w0.x / w0.y).
+DEVFN void radix_stage_emit(const RadixStage& S, bool active, uint32_t b, u32x4 w0, u32x4 w1, u32x4 w2, int lane) {
+  bool pending = active;
+  while (__ballot(pending)) {   // wave-uniform; a second iteration only when some buffer overflowed in this round
+    uint32_t pos = 0;
+    if (pending) pos = atomicAdd(&S.fill[b], 1u);   // same-address LDS adds of one wavefront are serialised: distinct positions
+    if (pending && pos < S.stage) {
+      uint8_t* dst = S.buf + (size_t)b * S.flush_bytes + (size_t)pos * S.stride;
+      if (S.stride == 8) { u32x2 h = {w0.x, w0.y}; *reinterpret_cast<u32x2*>(dst) = h; }
+      else {
+        *reinterpret_cast<u32x4*>(dst) = w0;
+        if (S.stride > 16) *reinterpret_cast<u32x4*>(dst + 16) = w1;
+        if (S.stride > 32) *reinterpret_cast<u32x4*>(dst + 32) = w2;
+      }
+    }
+    const bool filled = pending && pos == S.stage - 1u;   // this lane completed its bucket's buffer
+    if (pending && pos < S.stage) pending = false;
+    unsigned long long flush = __ballot(filled);
+    while (flush) {   // wave-uniform: write the full buffers out, one per iteration, 16 bytes per lane
+      const int l = __builtin_ctzll(flush);
+      flush &= flush - 1;
+      const uint32_t bb = (uint32_t)__builtin_amdgcn_readlane((int)b, l);
+      uint32_t at = 0;
+      if (lane == 0) at = atomicAdd(&S.s_cnt[bb], S.stage);
+      at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+      const uint32_t off = (uint32_t)lane * 16u;
+      if (off < S.flush_bytes) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(S.buf + (size_t)bb * S.flush_bytes + off);
+        *reinterpret_cast<u32x4*>(S.tuples + (size_t)(S.s_base[bb] + at) * S.stride + off) = v;
+      }
+      if (lane == 0) S.fill[bb] = 0;   // overflowed lanes (pos >= stage) claim again in the emptied buffer
+    }
+  }
+}
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_scatter_staged_kernel(const PgQueryPlan p) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
+  __shared__ uint32_t s_cnt[PG_MAX_RADIX_BUCKETS / 16];   // staged scatter serves at most 128 buckets
+  __shared__ uint32_t s_base[PG_MAX_RADIX_BUCKETS / 16];
+  __shared__ uint16_t s_list[PG_WAVES_PER_BLOCK][PG_SELVEC_MAX];
+  constexpr int B = 2;
+  const int t = threadIdx.x, lane = t & 63, wave = uniform(t >> 6);
+  const int P = p.radix_buckets;
+  RadixStage S;
+  S.stage = (uint32_t)p.radix_stage;
+  S.stride = (uint32_t)p.radix_stride;
+  S.flush_bytes = S.stage * S.stride;
+  uint32_t* fill_all = reinterpret_cast<uint32_t*>(smem);
+  uint8_t* buf_all = reinterpret_cast<uint8_t*>(smem) + (((size_t)PG_WAVES_PER_BLOCK * P * 4 + 15) & ~(size_t)15);
+  S.fill = fill_all + (size_t)wave * P;
+  S.buf = buf_all + (size_t)wave * P * S.flush_bytes;
+  S.s_cnt = s_cnt;
+  S.s_base = s_base;
+  S.tuples = p.radix_tuples;
+  for (int i = t; i < P; i += PG_BLOCK) {
+    s_cnt[i] = 0;
+    s_base[i] = p.radix_bucket_start[i] + p.radix_hist[(int64_t)blockIdx.x * P + i];
+  }
+  for (int i = t; i < PG_WAVES_PER_BLOCK * P; i += PG_BLOCK) fill_all[i] = 0;
+  __syncthreads();
+  const uint32_t local_mask = (1u << p.radix_shift) - 1u;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  const int wstride = (int)gridDim.x * PG_WAVES_PER_BLOCK;
+  for (int wt = (int)blockIdx.x * PG_WAVES_PER_BLOCK + wave; wt < p.n_wtiles; wt += wstride) {
+    const int64_t rem = (int64_t)p.num_docs - (int64_t)wt * PG_WAVE_DOCS;
+    const int32_t n_valid = rem >= PG_WAVE_DOCS ? PG_WAVE_DOCS : (int32_t)rem;
+    const uint32_t mlin = gptr<uint32_t>(p.match_words)[(int64_t)wt * 64 + lane] & valid_lin_mask(n_valid, lane);
+    if (__ballot(mlin != 0) == 0) continue;
+    const uint32_t n_match = wave_sum_u32((uint32_t)__popc(mlin));
+    if (n_match <= PG_SELVEC_MAX) {   // sparse tile: compact the matches, one gather per column and doc, every lane busy
+      uint16_t* list = s_list[wave];
+      {
+        const uint32_t c = (uint32_t)__popc(mlin);
+        uint32_t x = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const uint32_t y = (uint32_t)__shfl_up((int)x, off, 64);
+          if (lane >= off) x += y;
+        }
+        uint32_t pos = x - c, mm = mlin;
+        while (__ballot(mm != 0)) {
+          if (mm) {
+            const uint32_t bit = (uint32_t)__ffs((int)mm) - 1u;
+            mm &= mm - 1u;
+            list[pos++] = (uint16_t)((uint32_t)lane * 32u + bit);
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t r0 = 0; r0 < n_match; r0 += 64) {
+        const bool on = r0 + (uint32_t)lane < n_match;
+        const uint32_t doc = on ? (uint32_t)list[r0 + lane] : (uint32_t)list[0];
+        uint32_t key = 0;
+        for (int g = 0; g < p.n_group_cols; g++) {
+          const PgGroupCol& gc = p.gcols[g];
+          key += packed_value_at(packed_wtile_base(gc.data, wt, gc.bits), doc, (uint32_t)gc.bits) * (uint32_t)gc.mult;
+        }
+        int64_t v[PG_MAX_RADIX_SRCS] = {0, 0, 0, 0};
+#pragma unroll
+        for (int si = 0; si < PG_MAX_RADIX_SRCS; si++)
+          if (si < p.n_srcs) v[si] = source_value_at(p.srcs[si], wt, doc);
+        const uint32_t docid = (uint32_t)wt * PG_WAVE_DOCS + doc;
+        u32x4 w0 = {key & local_mask, docid, (uint32_t)(uint64_t)v[0], (uint32_t)((uint64_t)v[0] >> 32)};
+        u32x4 w1 = {(uint32_t)(uint64_t)v[1], (uint32_t)((uint64_t)v[1] >> 32), (uint32_t)(uint64_t)v[2], (uint32_t)((uint64_t)v[2] >> 32)};
+        u32x4 w2 = {(uint32_t)(uint64_t)v[3], (uint32_t)((uint64_t)v[3] >> 32), 0u, 0u};
+        radix_stage_emit(S, on, key >> p.radix_shift, w0, w1, w2, lane);
+      }
+      __builtin_amdgcn_wave_barrier();
+      continue;
+    }
+    const uint32_t m = lin_to_quad(mlin, lane);
+#pragma unroll
+    for (int k0 = 0; k0 < 8; k0 += B) {
+      const uint32_t mb = (m >> (4 * k0)) & ((1u << (4 * B)) - 1u);
+      if (__ballot(mb != 0) == 0) continue;
+      uint32_t qi[B];
+#pragma unroll
+      for (int u = 0; u < B; u++) qi[u] = ((mb >> (4 * u)) & 0xFu) ? (uint32_t)((k0 + u) * 64 + lane) : 0u;
+      uint32_t key[B][4];
+      radix_keys_of<B>(p, qi, wt, key);
+      int64_t v[PG_MAX_RADIX_SRCS][B][4];
+#pragma unroll
+      for (int si = 0; si < PG_MAX_RADIX_SRCS; si++) {
+        if (si < p.n_srcs) radix_source_values<B>(p.srcs[si], qi, wt, v[si]);
+        else {
+#pragma unroll
+          for (int u = 0; u < B; u++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[si][u][i] = 0;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < B; u++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const bool on = ((mb >> (4 * u + i)) & 1u) != 0;
+          if (__ballot(on) == 0) continue;
+          const uint32_t docid = (uint32_t)wt * PG_WAVE_DOCS + 4u * (uint32_t)((k0 + u) * 64 + lane) + (uint32_t)i;
+          u32x4 w0 = {key[u][i] & local_mask, docid, (uint32_t)(uint64_t)v[0][u][i], (uint32_t)((uint64_t)v[0][u][i] >> 32)};
+          u32x4 w1 = {(uint32_t)(uint64_t)v[1][u][i], (uint32_t)((uint64_t)v[1][u][i] >> 32), (uint32_t)(uint64_t)v[2][u][i], (uint32_t)((uint64_t)v[2][u][i] >> 32)};
+          u32x4 w2 = {(uint32_t)(uint64_t)v[3][u][i], (uint32_t)((uint64_t)v[3][u][i] >> 32), 0u, 0u};
+          radix_stage_emit(S, on, key[u][i] >> p.radix_shift, w0, w1, w2, lane);
+        }
+    }
+  }
+  // ---- epilogue: every wavefront writes its partial buffers out as whole flushes (the tail of each is padding), then the workgroup
+  // pads the slots of its ranges that no flush claimed
+  for (int b = 0; b < P; b++) {
+    const uint32_t f = S.fill[b];   // wave-uniform (one value per wavefront and bucket)
+    if (f == 0) continue;
+    uint32_t at = 0;
+    if (lane == 0) at = atomicAdd(&s_cnt[b], S.stage);
+    at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+    const uint32_t off = (uint32_t)lane * 16u;
+    if (off < S.flush_bytes) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(S.buf + (size_t)b * S.flush_bytes + off);
+      // slots >= f of the buffer are stale: mark them as padding (the key is the first dword of a tuple)
+      for (uint32_t k = 0; k < 16; k += (S.stride < 16 ? S.stride : 16)) {
+        const uint32_t byte = off + k;
+        if (byte % S.stride == 0 && byte / S.stride >= f) {
+          if (k == 0) v.x = PG_RADIX_INVALID_KEY; else v.z = PG_RADIX_INVALID_KEY;   // stride 8: two tuples per 16 bytes
+        }
+      }
+      *reinterpret_cast<u32x4*>(S.tuples + (size_t)(s_base[b] + at) * S.stride + off) = v;
+    }
+  }
+  __syncthreads();
+  for (int b = wave; b < P; b += PG_WAVES_PER_BLOCK) {   // unclaimed tail of every (workgroup, bucket) range
+    // the range ends where the next workgroup's begins (radix_hist holds the workgroups' offsets inside the bucket)
+    const uint32_t begin = p.radix_hist[(int64_t)blockIdx.x * P + b];
+    const uint32_t end = blockIdx.x + 1 < gridDim.x ? p.radix_hist[(int64_t)(blockIdx.x + 1) * P + b]
+                                                     : p.radix_bucket_start[b + 1] - p.radix_bucket_start[b];
+    const uint32_t cap = end - begin;
+    const uint32_t used = s_cnt[b];
+    for (uint32_t i = used + (uint32_t)lane; i < cap; i += 64)
+      *reinterpret_cast<uint32_t*>(S.tuples + (size_t)(s_base[b] + i) * S.stride) = PG_RADIX_INVALID_KEY;
+  }
+}
+
 // Per-bucket hash aggregation: the bucket's tuples go into an open-addressing table in LDS — keys[cap] claimed with a 64-bit
 // compare-and-swap (linear probing), accumulators [n_ops][cap] updated with LDS atomics — whose occupied slots are then appended
 // to the result (one global atomic per wavefront).  A bucket with more distinct keys than slots raises the overflow flag.
@@ -1959,8 +2154,14 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_hash_aggregate_kernel(
 // Counts → offsets.  Step 1, one wavefront per bucket: hist[wg][b] becomes the exclusive prefix over the workgroups (lanes own
 // consecutive workgroups), total[b] the bucket's size.  Step 2, one wavefront: bucket_start = exclusive scan of the totals.
 // (The scatter pass adds bucket_start[b] when it loads its bases.)
+// stage > 0 (staged scatter): a (workgroup, bucket) range holds whole flushes of `stage` tuples — each of the workgroup's 16
+// wavefronts may end on a partial one — so c tuples reserve (c / stage + 16) * stage slots; unused slots carry PG_RADIX_INVALID_KEY.
+DEVFN uint32_t radix_capacity(uint32_t c, int stage) {
+  if (stage <= 0 || c == 0) return c;
+  return (c / (uint32_t)stage + (uint32_t)PG_WAVES_PER_BLOCK) * (uint32_t)stage;
+}
 extern "C" __global__ void __launch_bounds__(1024) pg_radix_offsets_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ bucket_total,
-                                                                           int n_wg, int n_buckets) {
+                                                                           int n_wg, int n_buckets, int stage) {
   const int lane = threadIdx.x & 63;
   const int b = (int)blockIdx.x * 16 + (int)(threadIdx.x >> 6);
   if (b >= n_buckets) return;
@@ -1970,7 +2171,7 @@ extern "C" __global__ void __launch_bounds__(1024) pg_radix_offsets_kernel(uint3
   uint32_t mine = 0;
   for (int k = 0; k < per_lane; k++) {
     const int w = lane * per_lane + k;
-    if (w < n_wg) mine += hist[(int64_t)w * n_buckets + b];
+    if (w < n_wg) mine += radix_capacity(hist[(int64_t)w * n_buckets + b], stage);
   }
   uint32_t x = mine;
 #pragma unroll
@@ -1983,7 +2184,7 @@ extern "C" __global__ void __launch_bounds__(1024) pg_radix_offsets_kernel(uint3
   for (int k = 0; k < per_lane; k++) {
     const int w = lane * per_lane + k;
     if (w < n_wg) {
-      const uint32_t c = hist[(int64_t)w * n_buckets + b];
+      const uint32_t c = radix_capacity(hist[(int64_t)w * n_buckets + b], stage);
       hist[(int64_t)w * n_buckets + b] = run;
       run += c;
     }
@@ -2052,6 +2253,7 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_aggregate_kernel
         const u32x2 h = *(const GAS u32x2*)tp[u];
         k[u] = h.x;
         docid[u] = h.y;
+        if (h.x == PG_RADIX_INVALID_KEY) { on[u] = false; k[u] = 0; }   // padding of a staged flush
       }
       for (int o = 0; o < p.n_ops; o++) {
         const PgAccOp op = p.ops[o];

@@ -59,6 +59,8 @@ QUERIES5 = {
     "count group u,h1 (16M groups)": ("SELECT u, h1, COUNT(*) FROM t WHERE h2 = 3 GROUP BY u, h1 LIMIT 20000000", 3.5),
     "hash: group u,h1,h2 where u<20000": ("SELECT u, h1, h2, COUNT(*), SUM(h3) FROM t WHERE u < 20000 GROUP BY u, h1, h2 LIMIT 10000000", 4.0),
     "hash: group u,h1,h2 where h3=1,h4=2": ("SELECT u, h1, h2, COUNT(*) FROM t WHERE h3 = 1 AND h4 = 2 GROUP BY u, h1, h2 LIMIT 10000000", 4.0),
+    "probe radix sum(h3)": ("SELECT h1, h2, h3, h4, COUNT(*), SUM(h3) FROM t GROUP BY h1, h2, h3, h4 LIMIT 20000", 1.875),
+    "probe radix hll(h3)": ("SELECT h1, h2, h3, h4, COUNT(*), DISTINCTCOUNTHLL(h3) FROM t GROUP BY h1, h2, h3, h4 LIMIT 20000", 1.875),
     "cfg5 count group h1..h3": ("SELECT h1, h2, h3, COUNT(*) FROM t GROUP BY h1, h2, h3 LIMIT 20000", 1.5),
 }
 QUERIES_GENERAL = {   # shapes outside the specialised kernels: several scans, OR of scans, tables beyond LDS
