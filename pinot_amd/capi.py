@@ -150,7 +150,8 @@ class NativeError(RuntimeError):
 
 
 REPO_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-GPU_LIB_PATH = os.path.join(REPO_ROOT, "pinot_amd", "csrc", "libpinot_gpu.so")
+# PG_GPU_LIB: measurement knob (kernel variants built next to the product library by tools/build_variants.sh)
+GPU_LIB_PATH = os.environ.get("PG_GPU_LIB") or os.path.join(REPO_ROOT, "pinot_amd", "csrc", "libpinot_gpu.so")
 
 # every symbol include/pinot_gpu.h declares (checked by the "not gpu" suite against the built library)
 ABI_SYMBOLS = [

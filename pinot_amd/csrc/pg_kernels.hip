@@ -27,6 +27,9 @@
 #ifndef PG_FAST_AGG_B
 #define PG_FAST_AGG_B 4
 #endif
+#ifndef PG_SCAN_B
+#define PG_SCAN_B 4
+#endif
 #ifndef PG_WIDE_AGG_B
 #define PG_WIDE_AGG_B 2      // quads in flight in the general aggregator inside the 1024-thread kernels (4 spills ~180 VGPRs)
 #endif
@@ -242,7 +245,9 @@ DEVFN uint32_t test_quad(const LeafT& L, const uint32_t* r, uint32_t q, const Ra
 template <int KIND, class LeafT>
 DEVFN uint32_t scan_wtile(const LeafT& L, uint32_t cand, const GAS uint8_t* __restrict__ tb, int lane) {
   constexpr int W = sk_words(KIND);
-  constexpr int B = W <= 4 ? 8 : 4;
+  // quads in flight per lane: 4 (4 KB per wavefront for a raw INT column).  With 16 wavefronts per CU, 8 in flight measured slower
+  // (cfg 3: 79.8 -> 80.5 % of the HBM roofline; the pure-scan probe 6.5 -> 6.95 TB/s, profiles/r02_scan_bw_probe.txt)
+  constexpr int B = W <= 4 ? PG_SCAN_B : (PG_SCAN_B > 4 ? 4 : PG_SCAN_B);
   const RangeI32 r32 = make_range_i32(L.lo, L.hi);
   if ((KIND == SK_DICT_RANGE_SMALL || KIND == SK_DICT_RANGE_WIDE || KIND == SK_I32_RANGE) && r32.empty) return 0;
   uint32_t res = 0;
