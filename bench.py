@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--query", choices=["cfg3", "northstar", "cfg2"], default="cfg3")
     ap.add_argument("--cpu-sample-docs", type=int, default=100_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE in their own runs) that measure roofline.traffic")
     ap.add_argument("--no-full-check", action="store_true",
                     help="skip the one full-size oracle run that checks the timed GPU result (about 4 s of CPU per 1e9 rows)")
     ap.add_argument("--no-variants", action="store_true", help="skip the north-star (2-key) variant of the default run")
@@ -177,14 +179,12 @@ def main():
     alg_bytes = bytes_per_row * args.docs
     achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9 if avg_kernel_ms > 0 else 0.0
     lib_alg = st.algorithmic_bytes
-    # HBM bytes per launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE/WRITE_SIZE, collected in their
-    # own runs and corrected as MI355X_MICROARCH.md §HBM prescribes); committed under profiles/, null when not measured
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            traffic = json.load(f).get(f"{args.query}:{args.docs}", {}).get("traffic_bytes")
-    except OSError:
-        pass
+    # HBM bytes per launch of the timed kernel, measured NOW: this same command re-run under rocprofv3 with FETCH_SIZE and
+    # WRITE_SIZE in passes of their own (kernel-trace only), corrected as MI355X_MICROARCH.md §HBM prescribes; null when
+    # rocprofv3 is not available
+    traffic, traffic_detail = None, None
+    if rank == 0 and world == 1 and not args.no_traffic:
+        traffic, traffic_detail = measure_traffic(args, st.kernel.decode() or "pg_generic_query_l")
     out = {
         "metric": {"cfg3": "rows scanned/sec, 1B-row segment filter+groupby (3 predicates, SUM/MAX GROUP BY g1)",
                    "northstar": "rows scanned/sec, segment filter+groupby (3 predicates, SUM GROUP BY g1, g2)",
@@ -207,7 +207,7 @@ def main():
                    "matched_docs_per_segment": int(st.num_docs_scanned),
                    "entries_scanned_in_filter": int(st.num_entries_scanned_in_filter)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_detail": traffic_detail,
                      "kernel": st.kernel.decode() or "pg_generic_query_l", "kernel_ms": avg_kernel_ms,
                      "algorithmic_bytes_per_launch": alg_bytes, "library_accounted_bytes": int(lib_alg)},
     }
@@ -252,6 +252,43 @@ def main():
     seg.destroy()
     if world > 1:
         dist.destroy_process_group()
+
+
+def measure_traffic(args, kernel):
+    """HBM bytes per launch of `kernel`: two child runs of this script under `rocprofv3 --pmc <counter> --kernel-trace` (FETCH_SIZE
+    costs 3 of the 4 TCC slots and WRITE_SIZE 2, so each gets its own pass; no other trace domain is enabled).  On gfx950 FETCH_SIZE
+    reports half the bytes of wide coalesced reads (TCC_EA0_RDREQ x 64 B for 128-byte requests): doubled; WRITE_SIZE as reported.
+    Both are in KiB."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None, "rocprofv3 not found"
+    per = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="pg_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", d, "-o", "x", "--", sys.executable, os.path.abspath(__file__),
+               "--docs", str(args.docs), "--query", args.query, "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-variants",
+               "--no-traffic"]
+        env = dict(os.environ, TMPDIR="/tmp")
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith("_results.db")]
+            db = sqlite3.connect(dbs[0])
+            rows = list(db.execute(
+                "select avg(v) from (select dispatch_id, sum(value) as v from counters_collection where kernel_name = ? and counter_name = ? "
+                "group by dispatch_id)", (kernel, counter)))
+            per[counter] = float(rows[0][0])
+        except Exception as e:   # noqa: BLE001
+            return None, f"{counter} pass failed: {e}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    read_bytes = per["FETCH_SIZE"] * 1024.0 * 2.0
+    write_bytes = per["WRITE_SIZE"] * 1024.0
+    return read_bytes + write_bytes, {"kernel": kernel, "FETCH_SIZE_KiB": per["FETCH_SIZE"], "WRITE_SIZE_KiB": per["WRITE_SIZE"],
+                                      "read_bytes": read_bytes, "write_bytes": write_bytes,
+                                      "how": "rocprofv3 --pmc <counter> --kernel-trace, one pass per counter, 5 timed launches each; FETCH_SIZE x 2 (gfx950)"}
 
 
 def cpu_baseline(args, sql, gpu_block, gpu_seg):

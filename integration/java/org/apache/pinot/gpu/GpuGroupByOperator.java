@@ -1,0 +1,261 @@
+/**
+ * GroupByOperator / AggregationOperator of the accelerated path (pinot-core/.../operator/query/GroupByOperator.java:100-140,
+ * AggregationOperator.java): one pg_query_exec per segment, then the result is re-shaped into the blocks the unchanged
+ * combine operator consumes.  Extends BaseOperator so that interruption checks and tracing wrap it
+ * (core/operator/BaseOperator.java:36-53); a scheduler-side kill reaches the running kernel sequence through the cancel token.
+ */
+package org.apache.pinot.gpu;
+
+import java.util.ArrayList;
+import java.util.Collections;
+import java.util.Iterator;
+import java.util.List;
+import java.util.function.Supplier;
+import org.apache.pinot.common.request.context.ExpressionContext;
+import org.apache.pinot.common.utils.DataSchema;
+import org.apache.pinot.core.common.Operator;
+import org.apache.pinot.core.operator.BaseOperator;
+import org.apache.pinot.core.operator.ExecutionStatistics;
+import org.apache.pinot.core.operator.blocks.results.AggregationResultsBlock;
+import org.apache.pinot.core.operator.blocks.results.BaseResultsBlock;
+import org.apache.pinot.core.operator.blocks.results.GroupByResultsBlock;
+import org.apache.pinot.core.query.aggregation.function.AggregationFunction;
+import org.apache.pinot.core.query.aggregation.groupby.AggregationGroupByResult;
+import org.apache.pinot.core.query.aggregation.groupby.DoubleGroupByResultHolder;
+import org.apache.pinot.core.query.aggregation.groupby.GroupByResultHolder;
+import org.apache.pinot.core.query.aggregation.groupby.GroupKeyGenerator;
+import org.apache.pinot.core.query.aggregation.groupby.ObjectGroupByResultHolder;
+import org.apache.pinot.core.query.request.context.QueryContext;
+import org.apache.pinot.segment.local.customobject.AvgPair;
+import org.apache.pinot.segment.local.customobject.MinMaxRangePair;
+import org.apache.pinot.segment.spi.IndexSegment;
+import org.apache.pinot.segment.spi.index.reader.Dictionary;
+
+public class GpuGroupByOperator extends BaseOperator<BaseResultsBlock> {
+  private static final String EXPLAIN_NAME = "GPU_GROUP_BY";
+
+  private final IndexSegment _segment;
+  private final QueryContext _queryContext;
+  private final long _segmentHandle;
+  private final NativeQuery _nativeQuery;
+  private final Supplier<Operator> _fallback;   // the default plan of this segment (run-time PG_ERR_UNSUPPORTED: hash bucket overflow)
+  private final long[] _stats = new long[5];
+
+  public GpuGroupByOperator(IndexSegment segment, QueryContext queryContext, long segmentHandle, NativeQuery nativeQuery,
+      Supplier<Operator> fallback) {
+    _segment = segment;
+    _queryContext = queryContext;
+    _segmentHandle = segmentHandle;
+    _nativeQuery = nativeQuery;
+    _fallback = fallback;
+  }
+
+  @Override
+  protected BaseResultsBlock getNextBlock() {
+    long cancel = PinotGpu.cancelCreate();
+    GpuCancellation.register(Thread.currentThread(), cancel);   // the query killer calls PinotGpu.cancelRequest(token) when it interrupts
+    long result;
+    try {
+      result = PinotGpu.queryExec(_segmentHandle, _nativeQuery.address(), cancel);   // EarlyTerminationException when cancelled
+    } catch (UnsupportedOperationException e) {
+      return (BaseResultsBlock) _fallback.get().nextBlock();
+    } finally {
+      GpuCancellation.unregister(Thread.currentThread());
+      PinotGpu.cancelDestroy(cancel);
+      _nativeQuery.close();
+    }
+    try {
+      PinotGpu.resultStats(result, _stats);
+      AggregationFunction[] functions = _queryContext.getAggregationFunctions();
+      int numGroups = PinotGpu.resultNumGroups(result);
+      List<ExpressionContext> groupBy = _queryContext.getGroupByExpressions();
+      if (groupBy == null) {   // AggregationOperator: one intermediate result per function
+        List<Object> results = new ArrayList<>(functions.length);
+        for (int a = 0; a < functions.length; a++) {
+          results.add(intermediates(result, a, 1, functions[a])[0]);
+        }
+        return new AggregationResultsBlock(functions, results, _queryContext);
+      }
+      // group keys: dictIds decoded exactly as DictionaryBasedGroupKeyGenerator.getKeys does (:578-606), or the raw values of the
+      // one no-dictionary group-by column (NoDictionarySingleColumnGroupKeyGenerator.java:241-265)
+      Object[][] keys = new Object[numGroups][groupBy.size()];
+      for (int j = 0; j < groupBy.size(); j++) {
+        String column = groupBy.get(j).getIdentifier();
+        if (PinotGpu.resultGroupKeyType(result, j) == PinotGpu.GROUP_KEY_LONG_VALUES) {
+          long[] values = new long[numGroups];
+          PinotGpu.resultGroupValuesLong(result, j, values);
+          boolean isInt = _segment.getDataSource(column).getDataSourceMetadata().getDataType().getStoredType().name().equals("INT");
+          for (int g = 0; g < numGroups; g++) {
+            keys[g][j] = isInt ? (Object) (int) values[g] : (Object) values[g];
+          }
+        } else {
+          int[] dictIds = new int[numGroups];
+          PinotGpu.resultGroupDictIds(result, j, dictIds);
+          Dictionary dictionary = _segment.getDataSource(column).getDictionary();
+          for (int g = 0; g < numGroups; g++) {
+            keys[g][j] = dictionary.getInternal(dictIds[g]);
+          }
+        }
+      }
+      GroupByResultHolder[] holders = new GroupByResultHolder[functions.length];
+      for (int a = 0; a < functions.length; a++) {
+        Object[] values = intermediates(result, a, numGroups, functions[a]);
+        boolean asDouble = values.length > 0 && values[0] instanceof Double;
+        GroupByResultHolder holder = asDouble ? new DoubleGroupByResultHolder(Math.max(numGroups, 1), Math.max(numGroups, 1), 0.0)
+            : new ObjectGroupByResultHolder(Math.max(numGroups, 1), Math.max(numGroups, 1));
+        holder.ensureCapacity(Math.max(numGroups, 1));
+        for (int g = 0; g < numGroups; g++) {
+          if (asDouble) {
+            holder.setValueForKey(g, ((Double) values[g]).doubleValue());
+          } else {
+            holder.setValueForKey(g, values[g]);
+          }
+        }
+        holders[a] = holder;
+      }
+      GroupByResultsBlock block = new GroupByResultsBlock(dataSchema(groupBy, functions),
+          new AggregationGroupByResult(new ArrayGroupKeyGenerator(keys), functions, holders), _queryContext);
+      block.setNumGroupsLimitReached(_stats[4] != 0);
+      return block;
+    } finally {
+      PinotGpu.resultFree(result);
+    }
+  }
+
+  /** intermediate result of aggregation `a` for every group, typed as AggregationFunction#getIntermediateResultColumnType wants it */
+  private Object[] intermediates(long result, int a, int n, AggregationFunction function) {
+    Object[] out = new Object[n];
+    switch (PinotGpu.resultKindOf(result, a)) {
+      case PinotGpu.RESULT_LONG: {
+        long[] v = new long[n];
+        PinotGpu.resultLongs(result, a, 0, v);
+        for (int g = 0; g < n; g++) {
+          out[g] = (double) v[g];   // CountAggregationFunction keeps its count in a double holder (:110-143)
+        }
+        return out;
+      }
+      case PinotGpu.RESULT_DOUBLE: {
+        double[] v = new double[n];
+        PinotGpu.resultDoubles(result, a, 0, v);
+        for (int g = 0; g < n; g++) {
+          out[g] = v[g];
+        }
+        return out;
+      }
+      case PinotGpu.RESULT_AVG_PAIR: {
+        double[] s = new double[n];
+        long[] c = new long[n];
+        PinotGpu.resultDoubles(result, a, 0, s);
+        PinotGpu.resultLongs(result, a, 0, c);
+        for (int g = 0; g < n; g++) {
+          out[g] = new AvgPair(s[g], c[g]);
+        }
+        return out;
+      }
+      case PinotGpu.RESULT_MINMAX_PAIR: {
+        double[] lo = new double[n];
+        double[] hi = new double[n];
+        PinotGpu.resultDoubles(result, a, 0, lo);
+        PinotGpu.resultDoubles(result, a, 1, hi);
+        for (int g = 0; g < n; g++) {
+          out[g] = new MinMaxRangePair(lo[g], hi[g]);
+        }
+        return out;
+      }
+      case PinotGpu.RESULT_DICTID_SET:
+        return GpuResultObjects.valueSets(result, a, n, _segment, function);     // dictIds -> typed value Set (BaseDistinctAggregate...:671-694)
+      default:
+        return GpuResultObjects.hyperLogLogs(result, a, n, function);            // register bytes -> com.clearspring HyperLogLog (RegisterSet)
+    }
+  }
+
+  private static DataSchema dataSchema(List<ExpressionContext> groupBy, AggregationFunction[] functions) {   // GroupByOperator.java:74-97
+    int n = groupBy.size() + functions.length;
+    String[] names = new String[n];
+    DataSchema.ColumnDataType[] types = new DataSchema.ColumnDataType[n];
+    for (int i = 0; i < groupBy.size(); i++) {
+      names[i] = groupBy.get(i).toString();
+      types[i] = DataSchema.ColumnDataType.OBJECT;   // replaced from the segment's column metadata in GpuResultObjects.keyTypes
+    }
+    for (int i = 0; i < functions.length; i++) {
+      names[groupBy.size() + i] = functions[i].getResultColumnName();
+      types[groupBy.size() + i] = functions[i].getIntermediateResultColumnType();
+    }
+    return new DataSchema(names, types);
+  }
+
+  /** GroupKeyGenerator over already materialised keys: only getGroupKeys() / getNumKeys() are used downstream
+   *  (AggregationGroupByResult.java:35-56, GroupByCombineOperator.java:132-147). */
+  private static final class ArrayGroupKeyGenerator implements GroupKeyGenerator {
+    private final Object[][] _keys;
+
+    ArrayGroupKeyGenerator(Object[][] keys) {
+      _keys = keys;
+    }
+
+    @Override
+    public int getGlobalGroupKeyUpperBound() {
+      return _keys.length;
+    }
+
+    @Override
+    public void generateKeysForBlock(org.apache.pinot.core.operator.blocks.ValueBlock valueBlock, int[] groupKeys) {
+      throw new UnsupportedOperationException();
+    }
+
+    @Override
+    public void generateKeysForBlock(org.apache.pinot.core.operator.blocks.ValueBlock valueBlock, int[][] groupKeys) {
+      throw new UnsupportedOperationException();
+    }
+
+    @Override
+    public int getCurrentGroupKeyUpperBound() {
+      return _keys.length;
+    }
+
+    @Override
+    public Iterator<GroupKey> getGroupKeys() {
+      return new Iterator<GroupKey>() {
+        private int _next = 0;
+
+        @Override
+        public boolean hasNext() {
+          return _next < _keys.length;
+        }
+
+        @Override
+        public GroupKey next() {
+          GroupKey k = new GroupKey();
+          k._groupId = _next;
+          k._keys = _keys[_next++];
+          return k;
+        }
+      };
+    }
+
+    @Override
+    public int getNumKeys() {
+      return _keys.length;
+    }
+  }
+
+  @Override
+  public List<Operator> getChildOperators() {
+    return Collections.emptyList();
+  }
+
+  @Override
+  public String toExplainString() {
+    return EXPLAIN_NAME;
+  }
+
+  @Override
+  public IndexSegment getIndexSegment() {
+    return _segment;
+  }
+
+  @Override
+  public ExecutionStatistics getExecutionStatistics() {
+    return new ExecutionStatistics(_stats[0], _stats[1], _stats[2], _stats[3]);
+  }
+}

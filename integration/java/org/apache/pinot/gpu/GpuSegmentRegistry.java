@@ -1,0 +1,99 @@
+/**
+ * ImmutableSegment -> pg_segment_t: walks the segment's DataSources once (keyed by segment name + CRC), registers every
+ * single-value column's index buffers by (address, size) — the bytes are copied into HBM during the call — and spreads segments
+ * round-robin over the configured GPUs (pg_segment_create_on_device: the segment -> GPU map).  Segments holding something the
+ * library refuses (MV columns used by the query are refused per query; unsupported chunk codecs per column) are marked
+ * "Java plan only" (handle 0).  Upsert snapshots: SegmentContext#getQueryableDocIdsSnapshot is handed over only when its
+ * identity changed (pg_segment_set_queryable_doc_ids).  Release: IndexSegment#destroy -> release(segment).
+ * Buffer sources per pg_column_desc field: INTEGRATION.md §3.
+ */
+package org.apache.pinot.gpu;
+
+import java.util.Map;
+import java.util.concurrent.ConcurrentHashMap;
+import java.util.concurrent.atomic.AtomicInteger;
+import org.apache.pinot.segment.spi.ColumnMetadata;
+import org.apache.pinot.segment.spi.ImmutableSegment;
+import org.apache.pinot.segment.spi.SegmentContext;
+import org.apache.pinot.segment.spi.index.StandardIndexes;
+import org.apache.pinot.segment.spi.memory.PinotDataBuffer;
+import org.apache.pinot.segment.spi.store.SegmentDirectory;
+import org.roaringbitmap.buffer.MutableRoaringBitmap;
+
+public final class GpuSegmentRegistry {
+  private static final class Entry {
+    long _handle;
+    Object _lastSnapshot;
+  }
+
+  private final int[] _devices;
+  private final AtomicInteger _next = new AtomicInteger();
+  private final Map<String, Entry> _entries = new ConcurrentHashMap<>();
+
+  public GpuSegmentRegistry(int[] devices) {
+    _devices = devices;
+  }
+
+  public long handleFor(ImmutableSegment segment, SegmentContext context) {
+    String key = segment.getSegmentName() + ":" + segment.getSegmentMetadata().getCrc();
+    Entry e = _entries.computeIfAbsent(key, k -> register(segment));
+    if (e._handle != 0) {
+      MutableRoaringBitmap snapshot = context.getQueryableDocIdsSnapshot();
+      synchronized (e) {
+        if (snapshot != e._lastSnapshot) {   // upsert validDocIds / queryableDocIds changed since the last query on this segment
+          if (snapshot == null) {
+            PinotGpu.segmentSetQueryableDocIds(e._handle, 0, 0);
+          } else {
+            java.nio.ByteBuffer b = java.nio.ByteBuffer.allocateDirect(snapshot.serializedSizeInBytes());
+            snapshot.serialize(b);
+            PinotGpu.segmentSetQueryableDocIds(e._handle, GpuBuffers.address(b), b.capacity());
+          }
+          e._lastSnapshot = snapshot;
+        }
+      }
+    }
+    return e._handle;
+  }
+
+  private Entry register(ImmutableSegment segment) {
+    Entry e = new Entry();
+    int device = _devices[Math.floorMod(_next.getAndIncrement(), _devices.length)];
+    long h = PinotGpu.segmentCreate(segment.getSegmentName(), segment.getSegmentMetadata().getTotalDocs(), device);
+    try (SegmentDirectory.Reader reader = GpuBuffers.readerOf(segment)) {
+      for (String column : segment.getPhysicalColumnNames()) {
+        ColumnMetadata md = segment.getSegmentMetadata().getColumnMetadataFor(column);
+        if (!md.isSingleValue()) {
+          continue;   // MV columns stay with the Java plan: a query touching one is refused by pg_query_supported (unknown column)
+        }
+        PinotDataBuffer fwd = reader.getIndexFor(column, StandardIndexes.forward());
+        PinotDataBuffer dict = md.hasDictionary() ? reader.getIndexFor(column, StandardIndexes.dictionary()) : null;
+        PinotDataBuffer inv = reader.hasIndexFor(column, StandardIndexes.inverted()) ? reader.getIndexFor(column, StandardIndexes.inverted()) : null;
+        int fwdEncoding = md.isSorted() && md.hasDictionary() ? 2 : md.hasDictionary() ? 0 : 1;   // pg_fwd_encoding
+        PinotGpu.segmentAddColumn(h, column, GpuBuffers.storedType(md), fwdEncoding, md.hasDictionary(), md.getCardinality(),
+            md.getBitsPerElement(), md.isSorted(), GpuBuffers.dictionaryBytesPerValue(md),
+            GpuBuffers.address(fwd), fwd.size(), GpuBuffers.dictionaryValuesAddress(dict), GpuBuffers.dictionaryValuesSize(dict, md),
+            inv == null ? 0 : GpuBuffers.address(inv), inv == null ? 0 : inv.size());
+        if (reader.hasIndexFor(column, StandardIndexes.nullValueVector())) {
+          PinotDataBuffer nulls = reader.getIndexFor(column, StandardIndexes.nullValueVector());
+          PinotGpu.segmentSetNullVector(h, column, GpuBuffers.address(nulls), nulls.size());
+        }
+      }
+      GpuBuffers.registerStarTrees(h, segment, reader);   // one PinotGpu.segmentAddStarTree per IndexSegment#getStarTrees() entry
+      e._handle = h;
+    } catch (UnsupportedOperationException unsupported) {   // e.g. ZSTANDARD chunks: this segment keeps the Java plan
+      PinotGpu.segmentDestroy(h);
+      e._handle = 0;
+    } catch (Exception other) {
+      PinotGpu.segmentDestroy(h);
+      throw new RuntimeException(other);
+    }
+    return e;
+  }
+
+  public void release(ImmutableSegment segment) {
+    Entry e = _entries.remove(segment.getSegmentName() + ":" + segment.getSegmentMetadata().getCrc());
+    if (e != null && e._handle != 0) {
+      PinotGpu.segmentDestroy(e._handle);
+    }
+  }
+}

@@ -1,0 +1,69 @@
+/**
+ * Native entry points of libpinot_gpu.so, 1:1 with include/pinot_gpu.h through integration/jni/pinot_gpu_jni.c.
+ * Handles are native pointers carried as long; buffers are (address, size) pairs of PinotDataBuffer; every failing status
+ * surfaces as RuntimeException (EarlyTerminationException for PG_ERR_CANCELLED) with pg_last_error() as its message.
+ * NOT compiled in this repository (no JDK in the build image) — see INTEGRATION.md.
+ */
+package org.apache.pinot.gpu;
+
+import java.nio.ByteBuffer;
+
+public final class PinotGpu {
+  static {
+    System.loadLibrary("pinot_gpu_jni");   // links libpinot_gpu.so
+  }
+
+  private PinotGpu() {
+  }
+
+  // pg_status values the Java side branches on
+  public static final int PG_OK = 0;
+  public static final int PG_ERR_UNSUPPORTED = -2;
+  // pg_result_kind
+  public static final int RESULT_LONG = 0, RESULT_DOUBLE = 1, RESULT_AVG_PAIR = 2, RESULT_MINMAX_PAIR = 3, RESULT_DICTID_SET = 4,
+      RESULT_HLL = 5;
+  public static final int GROUP_KEY_DICT_IDS = 0, GROUP_KEY_LONG_VALUES = 1;
+
+  public static native int abiVersion();
+  public static native void init(int device);
+  public static native int deviceCount();
+
+  public static native long segmentCreate(String name, int totalDocs, int device);   // device < 0: the default device
+  public static native void segmentAddColumn(long segment, String name, int dataType, int fwdEncoding, boolean hasDictionary,
+      int cardinality, int bitsPerValue, boolean sorted, int dictBytesPerValue, long fwdAddr, long fwdSize, long dictAddr,
+      long dictSize, long invAddr, long invSize);
+  public static native void segmentSetNullVector(long segment, String column, long addr, long size);
+  public static native void segmentSetQueryableDocIds(long segment, long addr, long size);
+  public static native void segmentAddStarTree(long segment, int numDocs, int maxLeafRecords, String[] dimensions,
+      long[] dimAddrSize, int[] pairFunctions, int[] pairTypes, String[] pairColumns, long[] pairAddrSize, long treeAddr,
+      long treeSize);
+  public static native long segmentDeviceBytes(long segment);
+  public static native void segmentDestroy(long segment);
+
+  public static native long queryParse(ByteBuffer directRecord, int size);   // NativeQuery record -> pg_query
+  public static native void queryFree(long query);
+  public static native int querySupported(long segment, long query);          // PG_OK or PG_ERR_UNSUPPORTED
+  public static native long cancelCreate();
+  public static native void cancelRequest(long token);
+  public static native void cancelDestroy(long token);
+  public static native long queryExec(long segment, long query, long cancelToken);
+
+  public static native int resultNumGroups(long result);
+  public static native int resultKindOf(long result, int aggregation);
+  public static native int resultGroupKeyType(long result, int groupByColumn);
+  public static native void resultGroupDictIds(long result, int groupByColumn, int[] out);
+  public static native void resultGroupValuesLong(long result, int groupByColumn, long[] out);
+  public static native void resultDoubles(long result, int aggregation, int component, double[] out);
+  public static native void resultLongs(long result, int aggregation, int component, long[] out);
+  public static native void resultSetSizes(long result, int aggregation, int[] out);
+  public static native void resultSetDictIds(long result, int aggregation, int[] out);
+  public static native void resultHllRegisters(long result, int aggregation, byte[] out);
+  public static native void resultStats(long result, long[] out5);
+  public static native void resultFree(long result);
+
+  public static native long filterExec(long segment, long query);
+  public static native long docIdSetCardinality(long set);
+  public static native void docIdSetCopyWords(long set, long[] out);
+  public static native void docIdSetCopyDocIds(long set, int[] out);
+  public static native void docIdSetFree(long set);
+}

@@ -188,3 +188,26 @@ def test_header_compiles_as_cxx_too(tmp_path):
                            str(src), "-L" + os.path.dirname(capi.GPU_LIB_PATH), "-lpinot_gpu",
                            "-Wl,-rpath," + os.path.dirname(capi.GPU_LIB_PATH), "-o", str(exe)])
     assert subprocess.run([str(exe)], capture_output=True, text=True).returncode == 0
+
+
+def test_jni_call_sequence_host_part():
+    """integration/jni: the NativeQuery wire-format parser (round trip, truncations, bad magic) and — without a GPU — the loud
+    failure of pg_init, from the C program that performs the JNI functions' call sequence."""
+    import subprocess
+    import torch
+    binary = os.path.join(ROOT, "integration", "jni", "jni_sequence_test")
+    if not os.path.exists(binary):
+        pytest.skip("integration/jni/jni_sequence_test not built (python -c 'import __graft_entry__ as g; g.build()')")
+    out = subprocess.run([binary], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "truncations refused" in out.stdout
+    assert ("jni sequence ok" in out.stdout) if torch.cuda.is_available() else ("host part" in out.stdout)
+
+
+@pytest.mark.gpu
+def test_jni_call_sequence_on_gpu():
+    import subprocess
+    binary = os.path.join(ROOT, "integration", "jni", "jni_sequence_test")
+    out = subprocess.run([binary], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "jni sequence ok" in out.stdout and "d=20 count=725" in out.stdout and "d=30 count=725" in out.stdout

@@ -88,3 +88,60 @@ def test_segment_dir_with_star_tree(tmp_path, oracle_api):
     a, b = NativeSegment(oracle_api, host).execute(q), NativeSegment(oracle_api, back).execute(q)
     assert a.stats.star_tree_index == b.stats.star_tree_index == 0
     assert a.rows() == b.rows()
+
+
+# ---- the same v3 directories through the GPU library (SURVEY.md §8f rank 1 on the product path) ---------------------------------
+@pytest.mark.gpu
+def test_gpu_queries_a_loaded_v3_segment_dir(tmp_path, gpu_api, oracle_api):
+    """columns.psf + index_map + metadata.properties -> load_segment_dir -> libpinot_gpu: every index kind the reader hands over
+    (dictionary + fixed-bit, sorted, raw chunks, inverted index, null value vector) answers like the oracle over the same bytes."""
+    rng = np.random.default_rng(17)
+    n = 70_003
+    data = {"a": rng.integers(0, 50, n).astype(np.int32), "s": rng.choice(["x", "yy", "zzz", "wwww"], n),
+            "t": np.sort(rng.integers(0, 200, n)).astype(np.int32), "raw.m": rng.integers(-1000, 1000, n).astype(np.int64),
+            "f": rng.random(n).astype(np.float32), "d": rng.normal(0, 10, n)}
+    host = build_segment("rt", {k: (v.tolist() if v.dtype.kind == "U" else v) for k, v in data.items()},
+                         {"a": "INT", "s": "STRING", "t": "INT", "raw.m": "LONG", "f": "FLOAT", "d": "DOUBLE"},
+                         inverted_index_columns=["a", "s"], no_dictionary_columns=["raw.m", "d"])
+    segment_dir.write_segment_dir(host, str(tmp_path / "rt"))
+    back = segment_dir.load_segment_dir(str(tmp_path / "rt"))
+    assert not back.skipped
+    g, o = NativeSegment(gpu_api, back), NativeSegment(oracle_api, back)
+    import math
+    for q in ("SELECT s, COUNT(*), SUM(a), MAX(f) FROM rt WHERE a IN (1, 2, 3, 40) AND t > 4 GROUP BY s",
+              "SELECT t, COUNT(*), MIN(raw.m), MAX(raw.m) FROM rt WHERE t BETWEEN 20 AND 90 AND s != 'yy' GROUP BY t LIMIT 1000",
+              "SELECT COUNT(*), SUM(raw.m), AVG(a) FROM rt WHERE (a < 10 OR raw.m > 500) AND NOT s IN ('x')",
+              "SELECT a, DISTINCTCOUNT(s), DISTINCTCOUNTHLL(t) FROM rt WHERE f < 0.5 GROUP BY a LIMIT 100",
+              "SELECT s, SUM(d), SUM(f) FROM rt GROUP BY s"):
+        gb, ob = g.execute(q), o.execute(q)
+        gr, orr = gb.rows(), ob.rows()
+        assert sorted(gr) == sorted(orr), q
+        for k in orr:
+            for x, y in zip(gr[k], orr[k]):
+                if isinstance(y, float) and "SUM(d)" in q:      # floating SUM: exact on the GPU, sequential double in the oracle
+                    assert math.isclose(x, y, rel_tol=1e-12, abs_tol=1e-9), (q, k, x, y)
+                else:
+                    assert x == y, (q, k, x, y)
+        assert (gb.stats.num_docs_scanned, gb.stats.num_entries_scanned_in_filter, gb.stats.num_entries_scanned_post_filter) == \
+            (ob.stats.num_docs_scanned, ob.stats.num_entries_scanned_in_filter, ob.stats.num_entries_scanned_post_filter), q
+    dg, do = g.filter("SELECT COUNT(*) FROM rt WHERE t > 150 AND a = 7"), o.filter("SELECT COUNT(*) FROM rt WHERE t > 150 AND a = 7")
+    np.testing.assert_array_equal(dg.doc_ids(), do.doc_ids())
+    g.destroy()
+    o.destroy()
+
+
+@pytest.mark.gpu
+def test_gpu_queries_a_loaded_star_tree_segment_dir(tmp_path, gpu_api, oracle_api):
+    host = synth_star_segment(30_000, max_leaf_records=50, skip=())
+    segment_dir.write_segment_dir(host, str(tmp_path / "st"))
+    back = segment_dir.load_segment_dir(str(tmp_path / "st"))
+    g, o = NativeSegment(gpu_api, back), NativeSegment(oracle_api, back)
+    for q in ("SELECT h1, COUNT(*), SUM(m), DISTINCTCOUNTHLL(u) FROM t WHERE h2 > 3 GROUP BY h1",
+              "SELECT h1, h2, h3, h4, COUNT(*), DISTINCTCOUNTHLL(u) FROM t GROUP BY h1, h2, h3, h4 LIMIT 20000",
+              "SELECT g2, COUNT(*) FROM t GROUP BY g2"):
+        gb, ob = g.execute(q), o.execute(q)
+        assert gb.stats.star_tree_index == ob.stats.star_tree_index
+        assert gb.rows() == ob.rows(), q
+        assert gb.stats.num_docs_scanned == ob.stats.num_docs_scanned
+    g.destroy()
+    o.destroy()
