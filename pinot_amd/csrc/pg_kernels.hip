@@ -307,7 +307,8 @@ DEVFN uint32_t postings_wtile(const LeafT& L, int wtile, uint32_t valid_lin, uin
   uint32_t acc = 0;
   if (chunk < L.dense_chunks) {   // wave-uniform: dense bitmap postings, address = base + 8 KB * chunk
     const uint32_t di = (uint32_t)wtile * 64u + (uint32_t)lane;   // = chunk * 2048 + sub * 64 + lane
-    // unused pointers repeat dense[0] (OR is idempotent): 8 unconditional loads, no branches
+    // unused pointers repeat dense[0] (OR is idempotent): 8 unconditional loads, no branches (skipping the unused slots with
+    // wave-uniform branches costs the headline kernel its last free VGPRs: 16 bytes of scratch and 8 points of roofline, measured)
     uint32_t v[PG_MAX_DENSE];
 #pragma unroll
     for (int j = 0; j < PG_MAX_DENSE; j++) v[j] = ldnt(gptr<uint32_t>(L.dense[j]) + di);
