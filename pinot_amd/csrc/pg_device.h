@@ -231,8 +231,8 @@ struct PgQueryPlan {
   int32_t radix_shift;              // bucket = key >> radix_shift, local key = key & ((1 << radix_shift) - 1)
   int32_t radix_buckets;
   int32_t radix_slices;             // workgroups (slices) per bucket in the aggregation pass
-  int32_t radix_stage;              // > 0: tuples per staged flush (pg_radix_scatter_staged_kernel): every wavefront gathers a bucket's tuples
-                                    // in LDS and writes them out radix_stage at a time = whole 128-byte lines; 0: one store per tuple
+  int32_t radix_stage;              // > 0: tuples per line of the staged scatter (pg_radix_scatter_packed_kernel: 32): ranges of the tuple area
+                                    // hold whole lines, padded with PG_RADIX_INVALID_KEY; 0: one store per tuple, no padding
   const uint32_t* match_words;      // filter result, one dword per 32 docs, whole wave tiles
   uint32_t* radix_hist;             // [grid][radix_buckets] tuple counts, then exact offsets (bucket major)
   uint32_t* radix_bucket_start;     // [radix_buckets + 1]
@@ -244,6 +244,15 @@ struct PgQueryPlan {
   int64_t hash_out_cap;
   uint8_t* radix_tuples;            // [matched] x radix_stride bytes: {u32 local key, u32 docId, 8 bytes per source (int64 / double bits)}
   int64_t radix_stride;             // 8 without sources, else 8 + 8 * n_srcs rounded up to 16 (hash: {u64 key, u32 docId, u32 0} + 8 per source)
+  // packed 4-byte tuples (radix_packed): the local key in bits [0, radix_shift), then one bit field per source
+  int32_t radix_packed;
+  int32_t pk_pad;
+  int32_t pk_shift[PG_MAX_RADIX_SRCS];   // first bit of source i's field
+  int32_t pk_bits[PG_MAX_RADIX_SRCS];    // its width: log2m + 5 for a HyperLogLog source, the dictionary column's bits otherwise
+  int32_t pk_hll[PG_MAX_RADIX_SRCS];     // > 0: the source feeds a DISTINCTCOUNTHLL of this log2m (field = register index | rank << log2m)
+  const uint32_t* pk_lut[PG_MAX_RADIX_SRCS];   // per dictId (index | rank << 16) of a dictionary-encoded HyperLogLog source
+  int32_t pk_affine[PG_MAX_RADIX_SRCS];        // 1: that source's dictionary is arithmetic, value = pk_base + pk_step x dictId (INT / LONG)
+  int64_t pk_base[PG_MAX_RADIX_SRCS], pk_step[PG_MAX_RADIX_SRCS];
   int32_t n_lin_prefix;             // interpreter kernels: instrs[0, n_lin_prefix) is index-only and leaves one stack entry
   int32_t n_fast_scans;             // pg_fast_multi_*: instrs[n_index_instr, n_index_instr + n_fast_scans) are scan leaves ANDed in order
   int32_t tail_posting;             // pg_fast_multi_*: posting leaf ANDed in AFTER the scans (-1: none) — the queryableDocIds bitmap of

@@ -22,9 +22,9 @@ extern "C" __global__ void pg_reduce_partials_kernel(const int64_t* partials, in
 extern "C" __global__ void pg_reduce_parts_kernel(const int64_t* partials, int64_t* out, int n_wg, int n_ops, int n_groups,
                                                    int n_parts, int part_groups, const PgAccOp* ops);
 PG_DECL_FAST(pg_radix_count_kernel) PG_DECL_FAST(pg_radix_scatter_kernel) PG_DECL_FAST(pg_radix_aggregate_kernel)
-PG_DECL_FAST(pg_radix_scatter_staged_kernel)
+PG_DECL_FAST(pg_radix_scatter_packed_kernel) PG_DECL_FAST(pg_radix_aggregate_packed_kernel)
 PG_DECL_FAST(pg_hash_count_kernel) PG_DECL_FAST(pg_hash_scatter_kernel) PG_DECL_FAST(pg_hash_aggregate_kernel)
-extern "C" __global__ void pg_radix_offsets_kernel(uint32_t* hist, uint32_t* bucket_total, int n_wg, int n_buckets, int stage);
+extern "C" __global__ void pg_radix_offsets_kernel(uint32_t* hist, uint32_t* bucket_total, int n_wg, int n_buckets, int stage, int stage_waves);
 extern "C" __global__ void pg_radix_bucket_scan_kernel(const uint32_t* bucket_total, uint32_t* bucket_start, int n_buckets);
 extern "C" __global__ void pg_radix_reduce_kernel(const int64_t* partials, int64_t* out, int n_ops, int n_groups, int radix_shift, int slices,
                                                    const PgAccOp* ops);
@@ -119,8 +119,8 @@ void use_device(int ordinal) {
                                  pg_radix_aggregate_kernel, pg_hash_aggregate_kernel};
       for (QueryKernel k : all)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
-      // the staged scatter has 17 KB of static LDS next to its staging area (at most 100 KB, pg_exec.hip: radix_stage)
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pg_radix_scatter_staged_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pg_radix_scatter_packed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pg_radix_aggregate_packed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
       (void)hipGetLastError();   // a refused attribute must not surface as the "last error" of a later launch
       di.ready.store(1, std::memory_order_release);
     }
@@ -483,20 +483,17 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
     ThreadCtx::grow(ctx.radix_start, ((size_t)D.radix_buckets + 1) * 8);
     D.radix_stride = hashed ? ((16 + 8 * (int64_t)D.n_srcs + 15) & ~(int64_t)15)
                             : (D.n_srcs == 0 ? 8 : ((8 + 8 * (int64_t)D.n_srcs + 15) & ~(int64_t)15));
-    // Staged scatter (every wavefront gathers a bucket's tuples in LDS and writes whole 128-byte lines): when 16 wavefronts x buckets x
-    // one flush (256, else 128 bytes; a multiple of the tuple stride) fit the workgroup's LDS.  Each (workgroup, bucket) range then
-    // reserves up to 16 flushes of padding.
+    // Packed tuples (one dword per doc, staged per wavefront and bucket in LDS, written as whole 128-byte lines of 32): every
+    // (workgroup, bucket) range then holds whole lines — up to one padded line per wavefront.
     D.radix_stage = 0;
     size_t stage_lds = 0;
-    if (!hashed && !getenv("PG_NO_RADIX_STAGE") && D.radix_buckets <= PG_MAX_RADIX_BUCKETS / 16) {
-      for (int lines = 2; lines >= 1 && !D.radix_stage; lines--) {
-        size_t flush_bytes = (size_t)128 * lines;
-        while (flush_bytes % (size_t)D.radix_stride) flush_bytes += 128;   // 48-byte tuples: 384 / 768
-        const size_t need = (((size_t)PG_WAVES_PER_BLOCK * D.radix_buckets * 4 + 15) & ~(size_t)15) + (size_t)PG_WAVES_PER_BLOCK * D.radix_buckets * flush_bytes;
-        if (need <= (size_t)100 * 1024) { D.radix_stage = (int32_t)(flush_bytes / (size_t)D.radix_stride); stage_lds = need; }
-      }
+    const int stage_waves = D.radix_buckets <= 32 ? PG_WAVES_PER_BLOCK : PG_WAVES_PER_BLOCK / 2;   // the rings of 64 buckets fit for 8 wavefronts
+    if (!hashed && D.radix_packed) {
+      D.radix_stage = 32;
+      D.radix_stride = 4;
+      stage_lds = ((size_t)2 * stage_waves * D.radix_buckets + (size_t)stage_waves * 144 + (size_t)stage_waves * D.radix_buckets * 64) * 4;
     }
-    const size_t pad_tuples = D.radix_stage ? (size_t)rgrid * (size_t)D.radix_buckets * (size_t)PG_WAVES_PER_BLOCK * (size_t)D.radix_stage : 0;
+    const size_t pad_tuples = D.radix_stage ? (size_t)rgrid * (size_t)D.radix_buckets * (size_t)stage_waves * (size_t)D.radix_stage : 0;
     ThreadCtx::grow(ctx.radix_tuples, ((size_t)matched_now + pad_tuples) * (size_t)D.radix_stride + 256);
     D.match_words = ctx.words.as<uint32_t>();
     D.radix_hist = ctx.radix_hist.as<uint32_t>();
@@ -514,7 +511,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
       D.hash_out_acc = ctx.hash_acc.as<int64_t>();
       hipLaunchKernelGGL(pg_hash_count_kernel, dim3(rgrid), dim3(PG_BLOCK), 0, ctx.stream, D);
       hipLaunchKernelGGL(pg_radix_offsets_kernel, dim3((unsigned)((D.radix_buckets + 15) / 16)), dim3(1024), 0, ctx.stream, D.radix_hist,
-                         bucket_total, rgrid, D.radix_buckets, 0);
+                         bucket_total, rgrid, D.radix_buckets, 0, 0);
       hipLaunchKernelGGL(pg_radix_bucket_scan_kernel, dim3(1), dim3(64), 0, ctx.stream, bucket_total, D.radix_bucket_start, D.radix_buckets);
       hipLaunchKernelGGL(pg_hash_scatter_kernel, dim3(rgrid), dim3(PG_BLOCK), 0, ctx.stream, D);
       hipLaunchKernelGGL(pg_hash_aggregate_kernel, dim3(std::min(D.radix_buckets, num_cus())), dim3(PG_BLOCK),
@@ -528,14 +525,15 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
       D.partials = ctx.partials.as<int64_t>();
       hipLaunchKernelGGL(pg_radix_count_kernel, dim3(rgrid), dim3(PG_BLOCK), 0, ctx.stream, D);
       hipLaunchKernelGGL(pg_radix_offsets_kernel, dim3((unsigned)((D.radix_buckets + 15) / 16)), dim3(1024), 0, ctx.stream, D.radix_hist,
-                         bucket_total, rgrid, D.radix_buckets, D.radix_stage);
+                         bucket_total, rgrid, D.radix_buckets, D.radix_stage, stage_waves);
       hipLaunchKernelGGL(pg_radix_bucket_scan_kernel, dim3(1), dim3(64), 0, ctx.stream, bucket_total, D.radix_bucket_start, D.radix_buckets);
-      if (D.radix_stage) hipLaunchKernelGGL(pg_radix_scatter_staged_kernel, dim3(rgrid), dim3(PG_BLOCK), stage_lds, ctx.stream, D);
+      if (D.radix_packed) hipLaunchKernelGGL(pg_radix_scatter_packed_kernel, dim3(rgrid), dim3(stage_waves * 64), stage_lds, ctx.stream, D);
       else hipLaunchKernelGGL(pg_radix_scatter_kernel, dim3(rgrid), dim3(PG_BLOCK), 0, ctx.stream, D);
       const int agrid = std::min(D.radix_buckets * D.radix_slices, num_cus());
       size_t agg_lds = (size_t)D.n_ops * slots * 8 + 64;
       for (int x = 0; x < D.n_aux; x++) agg_lds += slots * (size_t)D.aux[x].stride;
-      hipLaunchKernelGGL(pg_radix_aggregate_kernel, dim3(agrid), dim3(PG_BLOCK), agg_lds, ctx.stream, D);
+      if (D.radix_packed) hipLaunchKernelGGL(pg_radix_aggregate_packed_kernel, dim3(agrid), dim3(PG_BLOCK), agg_lds, ctx.stream, D);
+      else hipLaunchKernelGGL(pg_radix_aggregate_kernel, dim3(agrid), dim3(PG_BLOCK), agg_lds, ctx.stream, D);
       for (int x = 0; x < D.n_aux; x++) {
         const int64_t n_words = (int64_t)D.n_groups * D.aux[x].stride / 4, bucket_words = (int64_t)(slots * (size_t)D.aux[x].stride / 4);
         hipLaunchKernelGGL(pg_radix_reduce_aux_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx.stream, D.aux[x].base,

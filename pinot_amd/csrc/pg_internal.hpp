@@ -95,6 +95,8 @@ struct Column {
   int32_t fx_exp = 0;                           // FLOAT / DOUBLE: every finite |value| < 2^fx_exp (a multiple of 16)
   bool has_nonfinite = false;                   // NaN / +-Inf among the values: SUM falls back to IEEE double accumulation
   uint64_t max_abs_int = 0;                     // LONG: largest |value|
+  bool dict_affine = false;                     // INT / LONG dictionary whose values are base + step x dictId (ids, dense enumerations)
+  int64_t dict_base = 0, dict_step = 0;
   std::map<int, DeviceBuffer> hll_luts;         // per log2m: (register index | rank << 16) of every dictionary value
   int32_t hll_log2m = 0;                        // PG_COL_HLL_REGS: log2m of the serialized HyperLogLogs
 };

@@ -1281,8 +1281,11 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_fast_multi_a(const PgQ
 extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_fast_multi_w(const PgQueryPlan p) { fast_multi_body<2>(p); }
 extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_fast_multi_wd(const PgQueryPlan p) { fast_multi_body<3>(p); }
 
+#ifndef PG_FAST_MIN_WAVES_PER_SIMD
+#define PG_FAST_MIN_WAVES_PER_SIMD 1   // measurement knob: 8 asks for <= 64 VGPRs (two 1024-thread workgroups per CU)
+#endif
 #define PG_FAST_KERNEL(NAME, SK, AGG) \
-  extern "C" __global__ void __launch_bounds__(PG_BLOCK) NAME(const PgQueryPlan p) { fast_query_body<SK, AGG>(p); }
+  extern "C" __global__ void __launch_bounds__(PG_BLOCK, PG_FAST_MIN_WAVES_PER_SIMD) NAME(const PgQueryPlan p) { fast_query_body<SK, AGG>(p); }
 PG_FAST_KERNEL(pg_fast_none_f, -1, 0)
 PG_FAST_KERNEL(pg_fast_none_a, -1, 1)
 PG_FAST_KERNEL(pg_fast_none_w, -1, 2)
@@ -1876,132 +1879,141 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_scatter_kernel(c
 extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_hash_count_kernel(const PgQueryPlan p) { radix_pass_body<1, true>(p); }
 extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_hash_scatter_kernel(const PgQueryPlan p) { radix_pass_body<2, true>(p); }
 
-// Staged scatter (PASS 2 of the radix group-by for up to ~64 buckets).  Writing one 16-byte tuple per matching doc straight to its
-// bucket makes every lane of a store hit its own cache line: each partially written line is first FETCHED (write-allocate), so the
-// tuples cross HBM twice and every store waits on a fill (r01: FETCH_SIZE = WRITE_SIZE = tuple bytes, 11 x the wave cycles of the
-// count pass).  Here every wavefront keeps a private staging buffer per bucket in LDS — `stage` tuples = 128 or 256 bytes — claims
-// a slot with a returning LDS add, and when a buffer is full the wavefront writes it out as whole, line-aligned 128-byte lines:
-// no fill, 1/8 .. 1/16 of the store requests.  A (workgroup, bucket) range therefore consists of whole flushes; what a flush does
-// not fill carries PG_RADIX_INVALID_KEY and the aggregation pass skips it.
-// dynamic LDS: [PG_WAVES_PER_BLOCK][buckets] fill counters, then [PG_WAVES_PER_BLOCK][buckets][stage * stride] staging bytes.
-struct RadixStage {
-  uint32_t* fill;        // this wavefront's [buckets] counters
-  uint8_t* buf;          // this wavefront's [buckets][flush_bytes] staging
-  uint32_t* s_cnt;       // workgroup: tuples claimed so far per bucket
+// =====================================================================================================================
+// Packed radix tuples (PgQueryPlan::radix_packed): when everything the aggregation pass needs from a doc fits 32 bits — the local key
+// (radix_shift bits) and, per source, either the (register index, rank) a DISTINCTCOUNTHLL offers (log2m + 5 bits) or the dictId of a
+// dictionary-encoded source (its value is looked up in the aggregation pass) — a tuple is ONE dword instead of 16+ bytes: a quarter
+// of the bytes written and read back (config 5: 200 M docs x 16 B = 3.2 GB each way → 0.8 GB).
+// The scatter stages them per wavefront and bucket in LDS rings of 64 tuples and writes whole, aligned 128-byte lines of 32 tuples:
+// whole-line flushes stream at ~5.5 TB/s where scattered 16-byte stores reach 0.35 - 2 TB/s (tools/probes/scatter_bw.hip,
+// profiles/r02_scatter_write_probe.txt).  Returning LDS atomics hand out ring positions, eight per lane in flight (one batch of docs)
+// before the first is waited for; flushes are decided once per batch, eight lines per step.
+// A (workgroup, bucket) range of the tuple area holds whole lines; what a line does not fill carries PG_RADIX_INVALID_KEY.
+// dynamic LDS per workgroup: [16 wavefronts][buckets] tail, [16][buckets] head, [16][64 + 8] work list, [16][buckets][64] tuples.
+// =====================================================================================================================
+#define PG_PK_RING 64u       // tuples per ring (two 128-byte lines)
+#define PG_PK_LINE 32u       // tuples per flushed line
+struct PackedStage {
+  uint32_t* tail;        // this wavefront's [buckets]: ring positions handed out so far
+  uint32_t* head;        // this wavefront's [buckets]: ring positions flushed so far (multiple of PG_PK_LINE)
+  uint32_t* work;        // this wavefront's work list: (bucket | line-of-ring << 16) per line to flush
+  uint32_t* ring;        // this wavefront's [buckets][PG_PK_RING] tuples
+  uint32_t* s_cnt;       // workgroup: tuples claimed so far per bucket in the tuple area
   const uint32_t* s_base;
-  uint8_t* tuples;
-  uint32_t stage, stride, flush_bytes;
+  uint32_t* tuples;
+  int buckets;
 };
-// One round: every lane with `active` appends its tuple (stride bytes in w0 / w1 / w2, 16 bytes each; stride 8 uses w0.x / w0.y).
-DEVFN void radix_stage_emit(const RadixStage& S, bool active, uint32_t b, u32x4 w0, u32x4 w1, u32x4 w2, int lane) {
-  bool pending = active;
-  while (__ballot(pending)) {   // wave-uniform; a second iteration only when some buffer overflowed in this round
-    uint32_t pos = 0;
-    if (pending) pos = atomicAdd(&S.fill[b], 1u);   // same-address LDS adds of one wavefront are serialised: distinct positions
-    if (pending && pos < S.stage) {
-      uint8_t* dst = S.buf + (size_t)b * S.flush_bytes + (size_t)pos * S.stride;
-      if (S.stride == 8) { u32x2 h = {w0.x, w0.y}; *reinterpret_cast<u32x2*>(dst) = h; }
-      else {
-        *reinterpret_cast<u32x4*>(dst) = w0;
-        if (S.stride > 16) *reinterpret_cast<u32x4*>(dst + 16) = w1;
-        if (S.stride > 32) *reinterpret_cast<u32x4*>(dst + 32) = w2;
-      }
-    }
-    const bool filled = pending && pos == S.stage - 1u;   // this lane completed its bucket's buffer
-    if (pending && pos < S.stage) pending = false;
-    unsigned long long flush = __ballot(filled);
-    while (flush) {   // wave-uniform: write the full buffers out, one per iteration, 16 bytes per lane
-      const int l = __builtin_ctzll(flush);
-      flush &= flush - 1;
-      const uint32_t bb = (uint32_t)__builtin_amdgcn_readlane((int)b, l);
-      uint32_t at = 0;
-      if (lane == 0) at = atomicAdd(&S.s_cnt[bb], S.stage);
-      at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
-      const uint32_t off = (uint32_t)lane * 16u;
-      if (off < S.flush_bytes) {
-        const u32x4 v = *reinterpret_cast<const u32x4*>(S.buf + (size_t)bb * S.flush_bytes + off);
-        *reinterpret_cast<u32x4*>(S.tuples + (size_t)(S.s_base[bb] + at) * S.stride + off) = v;
-      }
-      if (lane == 0) S.fill[bb] = 0;   // overflowed lanes (pos >= stage) claim again in the emptied buffer
+// Writes out every whole line the wavefront's rings hold (pad_partial: also the partial ones, padded — the epilogue).
+DEVFN void packed_flush(const PackedStage& S, bool pad_partial, int lane) {
+  // lanes 0 .. buckets-1 own one bucket each (buckets <= 64)
+  uint32_t lines = 0, hd = 0, avail = 0;
+  if (lane < S.buckets) {
+    hd = S.head[lane];
+    avail = S.tail[lane] - hd;
+    if (avail > PG_PK_RING) avail = PG_PK_RING;   // positions beyond the ring are claimed but not written yet
+    lines = avail / PG_PK_LINE;
+    if (pad_partial && (avail % PG_PK_LINE)) {
+      for (uint32_t i = avail; i < (lines + 1) * PG_PK_LINE; i++) S.ring[(size_t)lane * PG_PK_RING + ((hd + i) & (PG_PK_RING - 1u))] = PG_RADIX_INVALID_KEY;
+      lines++;
     }
   }
+  if (__ballot(lines != 0) == 0) return;
+  // exclusive scan of `lines` over the lanes → positions in the work list; the owner claims its lines' slots in the tuple area
+  uint32_t x = lines;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t y = (uint32_t)__shfl_up((int)x, off, 64);
+    if (lane >= off) x += y;
+  }
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+  uint32_t at = 0;
+  if (lines) at = atomicAdd(&S.s_cnt[lane], lines * PG_PK_LINE);
+  for (uint32_t i = 0; i < lines; i++) {
+    const uint32_t w = x - lines + i;
+    S.work[2 * w] = (uint32_t)lane | ((((hd / PG_PK_LINE) + i) & 1u) << 16);   // which half of the ring
+    S.work[2 * w + 1] = S.s_base[lane] + at + i * PG_PK_LINE;                  // destination (in tuples)
+  }
+  if (lines) S.head[lane] = hd + lines * PG_PK_LINE;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t l0 = 0; l0 < total; l0 += 8) {   // eight lines per step, 16 bytes per lane
+    const uint32_t li = l0 + (uint32_t)(lane >> 3);
+    if (li < total) {
+      const uint32_t e = S.work[2 * li], dst = S.work[2 * li + 1];
+      const uint32_t b = e & 0xFFFFu, half = e >> 16;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(S.ring + (size_t)b * PG_PK_RING + half * PG_PK_LINE + (uint32_t)(lane & 7) * 4u);
+      *reinterpret_cast<u32x4*>(S.tuples + (size_t)dst + (uint32_t)(lane & 7) * 4u) = v;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
 }
-extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_scatter_staged_kernel(const PgQueryPlan p) {
+// One batch: N tuples per lane (active[j]: the lane has one), positions handed out by N returning LDS adds in flight at once.
+template <int N>
+DEVFN void packed_emit(const PackedStage& S, const bool (&active)[N], const uint32_t (&bucket)[N], const uint32_t (&tuple)[N], int lane) {
+  uint32_t pos[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) pos[j] = active[j] ? atomicAdd(&S.tail[bucket[j]], 1u) : 0u;
+  bool pending[N];
+  bool any_pending = false;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    pending[j] = active[j];
+    if (active[j] && pos[j] - S.head[bucket[j]] < PG_PK_RING) {
+      S.ring[(size_t)bucket[j] * PG_PK_RING + (pos[j] & (PG_PK_RING - 1u))] = tuple[j];
+      pending[j] = false;
+    }
+    any_pending |= pending[j];
+  }
+  packed_flush(S, false, lane);
+  while (__ballot(any_pending)) {   // a ring overflowed in this batch (skewed keys): its claimed positions become writable as lines leave
+    any_pending = false;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      if (pending[j] && pos[j] - S.head[bucket[j]] < PG_PK_RING) {
+        S.ring[(size_t)bucket[j] * PG_PK_RING + (pos[j] & (PG_PK_RING - 1u))] = tuple[j];
+        pending[j] = false;
+      }
+      any_pending |= pending[j];
+    }
+    packed_flush(S, false, lane);
+  }
+}
+// payload of one source for a doc: (register index | rank << log2m) of the value a DISTINCTCOUNTHLL offers, or the dictId
+DEVFN uint32_t packed_hll_payload(uint32_t index_rank, int log2m) { return (index_rank & 0xFFFFu) | ((index_rank >> 16) << log2m); }
+
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_scatter_packed_kernel(const PgQueryPlan p) {
   extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
-  __shared__ uint32_t s_cnt[PG_MAX_RADIX_BUCKETS / 16];   // staged scatter serves at most 128 buckets
-  __shared__ uint32_t s_base[PG_MAX_RADIX_BUCKETS / 16];
-  __shared__ uint16_t s_list[PG_WAVES_PER_BLOCK][PG_SELVEC_MAX];
+  __shared__ uint32_t s_cnt[64];
+  __shared__ uint32_t s_base[64];
   constexpr int B = 2;
-  const int t = threadIdx.x, lane = t & 63, wave = uniform(t >> 6);
+  // 16 wavefronts (up to 32 buckets) or 8 (up to 64: the rings must fit the LDS); the workgroup walks the tiles of count-pass
+  // workgroup blockIdx.x — 16 per sweep — whatever its own width, so that the counted ranges are the ones it fills
+  const int t = threadIdx.x, lane = t & 63, wave = uniform(t >> 6), n_waves = (int)(blockDim.x >> 6);
   const int P = p.radix_buckets;
-  RadixStage S;
-  S.stage = (uint32_t)p.radix_stage;
-  S.stride = (uint32_t)p.radix_stride;
-  S.flush_bytes = S.stage * S.stride;
-  uint32_t* fill_all = reinterpret_cast<uint32_t*>(smem);
-  uint8_t* buf_all = reinterpret_cast<uint8_t*>(smem) + (((size_t)PG_WAVES_PER_BLOCK * P * 4 + 15) & ~(size_t)15);
-  S.fill = fill_all + (size_t)wave * P;
-  S.buf = buf_all + (size_t)wave * P * S.flush_bytes;
+  PackedStage S;
+  uint32_t* base = reinterpret_cast<uint32_t*>(smem);
+  S.tail = base + (size_t)wave * P;
+  S.head = base + (size_t)n_waves * P + (size_t)wave * P;
+  S.work = base + (size_t)2 * n_waves * P + (size_t)wave * 144;
+  S.ring = base + (size_t)2 * n_waves * P + (size_t)n_waves * 144 + (size_t)wave * P * PG_PK_RING;
   S.s_cnt = s_cnt;
   S.s_base = s_base;
-  S.tuples = p.radix_tuples;
-  for (int i = t; i < P; i += PG_BLOCK) {
+  S.tuples = reinterpret_cast<uint32_t*>(p.radix_tuples);
+  S.buckets = P;
+  for (int i = t; i < P; i += (int)blockDim.x) {
     s_cnt[i] = 0;
     s_base[i] = p.radix_bucket_start[i] + p.radix_hist[(int64_t)blockIdx.x * P + i];
   }
-  for (int i = t; i < PG_WAVES_PER_BLOCK * P; i += PG_BLOCK) fill_all[i] = 0;
+  for (int i = t; i < 2 * n_waves * P; i += (int)blockDim.x) base[i] = 0;
   __syncthreads();
   const uint32_t local_mask = (1u << p.radix_shift) - 1u;
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  const int wstride = (int)gridDim.x * PG_WAVES_PER_BLOCK;
-  for (int wt = (int)blockIdx.x * PG_WAVES_PER_BLOCK + wave; wt < p.n_wtiles; wt += wstride) {
+  const int sweep = (int)gridDim.x * PG_WAVES_PER_BLOCK;
+  for (int wt0 = (int)blockIdx.x * PG_WAVES_PER_BLOCK; wt0 < p.n_wtiles; wt0 += sweep)
+  for (int wt = wt0 + wave; wt < wt0 + PG_WAVES_PER_BLOCK && wt < p.n_wtiles; wt += n_waves) {
     const int64_t rem = (int64_t)p.num_docs - (int64_t)wt * PG_WAVE_DOCS;
     const int32_t n_valid = rem >= PG_WAVE_DOCS ? PG_WAVE_DOCS : (int32_t)rem;
     const uint32_t mlin = gptr<uint32_t>(p.match_words)[(int64_t)wt * 64 + lane] & valid_lin_mask(n_valid, lane);
     if (__ballot(mlin != 0) == 0) continue;
-    const uint32_t n_match = wave_sum_u32((uint32_t)__popc(mlin));
-    if (n_match <= PG_SELVEC_MAX) {   // sparse tile: compact the matches, one gather per column and doc, every lane busy
-      uint16_t* list = s_list[wave];
-      {
-        const uint32_t c = (uint32_t)__popc(mlin);
-        uint32_t x = c;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          const uint32_t y = (uint32_t)__shfl_up((int)x, off, 64);
-          if (lane >= off) x += y;
-        }
-        uint32_t pos = x - c, mm = mlin;
-        while (__ballot(mm != 0)) {
-          if (mm) {
-            const uint32_t bit = (uint32_t)__ffs((int)mm) - 1u;
-            mm &= mm - 1u;
-            list[pos++] = (uint16_t)((uint32_t)lane * 32u + bit);
-          }
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      for (uint32_t r0 = 0; r0 < n_match; r0 += 64) {
-        const bool on = r0 + (uint32_t)lane < n_match;
-        const uint32_t doc = on ? (uint32_t)list[r0 + lane] : (uint32_t)list[0];
-        uint32_t key = 0;
-        for (int g = 0; g < p.n_group_cols; g++) {
-          const PgGroupCol& gc = p.gcols[g];
-          key += packed_value_at(packed_wtile_base(gc.data, wt, gc.bits), doc, (uint32_t)gc.bits) * (uint32_t)gc.mult;
-        }
-        int64_t v[PG_MAX_RADIX_SRCS] = {0, 0, 0, 0};
-#pragma unroll
-        for (int si = 0; si < PG_MAX_RADIX_SRCS; si++)
-          if (si < p.n_srcs) v[si] = source_value_at(p.srcs[si], wt, doc);
-        const uint32_t docid = (uint32_t)wt * PG_WAVE_DOCS + doc;
-        u32x4 w0 = {key & local_mask, docid, (uint32_t)(uint64_t)v[0], (uint32_t)((uint64_t)v[0] >> 32)};
-        u32x4 w1 = {(uint32_t)(uint64_t)v[1], (uint32_t)((uint64_t)v[1] >> 32), (uint32_t)(uint64_t)v[2], (uint32_t)((uint64_t)v[2] >> 32)};
-        u32x4 w2 = {(uint32_t)(uint64_t)v[3], (uint32_t)((uint64_t)v[3] >> 32), 0u, 0u};
-        radix_stage_emit(S, on, key >> p.radix_shift, w0, w1, w2, lane);
-      }
-      __builtin_amdgcn_wave_barrier();
-      continue;
-    }
     const uint32_t m = lin_to_quad(mlin, lane);
 #pragma unroll
     for (int k0 = 0; k0 < 8; k0 += B) {
@@ -2012,62 +2024,151 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_scatter_staged_k
       for (int u = 0; u < B; u++) qi[u] = ((mb >> (4 * u)) & 0xFu) ? (uint32_t)((k0 + u) * 64 + lane) : 0u;
       uint32_t key[B][4];
       radix_keys_of<B>(p, qi, wt, key);
-      int64_t v[PG_MAX_RADIX_SRCS][B][4];
+      uint32_t tuple[B * 4];
 #pragma unroll
-      for (int si = 0; si < PG_MAX_RADIX_SRCS; si++) {
-        if (si < p.n_srcs) radix_source_values<B>(p.srcs[si], qi, wt, v[si]);
-        else {
+      for (int u = 0; u < B; u++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) tuple[4 * u + i] = key[u][i] & local_mask;
+      // payload fields: dictIds of the sources, turned into (index, rank) for the HyperLogLog ones
+      for (int si = 0; si < p.n_srcs; si++) {
+        const PgValueSrc& V = p.srcs[si];
+        const int hll_log2m = p.pk_hll[si];   // > 0: the source feeds a DISTINCTCOUNTHLL
+        uint32_t d[B][4];
+        if (V.col_kind == PG_COL_FIXED_BIT) {
+          const GAS uint32_t* tw = packed_wtile_base(V.data, wt, V.bits);
+          const uint32_t bits = (uint32_t)V.bits, mask = (1u << V.bits) - 1u;
+#pragma unroll
+          for (int u = 0; u < B; u++) {
+            uint32_t r[8];
+            if (bits <= 8) { load_packed_quad<true>(tw, qi[u], bits, r); decode_packed_quad<true>(r, qi[u], bits, mask, d[u]); }
+            else { load_packed_quad<false>(tw, qi[u], bits, r); decode_packed_quad<false>(r, qi[u], bits, mask, d[u]); }
+          }
+          if (hll_log2m > 0 && p.pk_affine[si]) {
+            // an arithmetic dictionary (value = base + step x dictId: ids, dense enumerations): the value is computed and hashed here
+            // instead of gathering (index, rank) from a cardinality-sized table (1 M entries: ~0.8 ms of L2 misses per 200 M docs)
+#pragma unroll
+            for (int u = 0; u < B; u++)
+#pragma unroll
+              for (int i = 0; i < 4; i++)
+                d[u][i] = packed_hll_payload(hll_index_rank_dev(murmur_hash_long_dev(p.pk_base[si] + p.pk_step[si] * (int64_t)d[u][i]), hll_log2m), hll_log2m);
+          } else if (hll_log2m > 0) {
+#pragma unroll
+            for (int u = 0; u < B; u++)
+#pragma unroll
+              for (int i = 0; i < 4; i++) d[u][i] = packed_hll_payload(gptr<uint32_t>(p.pk_lut[si])[d[u][i]], hll_log2m);
+          }
+        } else {   // raw INT / LONG value offered to a HyperLogLog: hashed here (stream-lib MurmurHash.hashLong)
+          int64_t v[B][4];
+          radix_source_values<B>(V, qi, wt, v);
 #pragma unroll
           for (int u = 0; u < B; u++)
 #pragma unroll
-            for (int i = 0; i < 4; i++) v[si][u][i] = 0;
+            for (int i = 0; i < 4; i++) d[u][i] = packed_hll_payload(hll_index_rank_dev(murmur_hash_long_dev(v[u][i]), hll_log2m), hll_log2m);
         }
+        const uint32_t sh = (uint32_t)p.pk_shift[si];
+#pragma unroll
+        for (int u = 0; u < B; u++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) tuple[4 * u + i] |= d[u][i] << sh;
       }
+      bool active[B * 4];
+      uint32_t bucket[B * 4];
 #pragma unroll
       for (int u = 0; u < B; u++)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-          const bool on = ((mb >> (4 * u + i)) & 1u) != 0;
-          if (__ballot(on) == 0) continue;
-          const uint32_t docid = (uint32_t)wt * PG_WAVE_DOCS + 4u * (uint32_t)((k0 + u) * 64 + lane) + (uint32_t)i;
-          u32x4 w0 = {key[u][i] & local_mask, docid, (uint32_t)(uint64_t)v[0][u][i], (uint32_t)((uint64_t)v[0][u][i] >> 32)};
-          u32x4 w1 = {(uint32_t)(uint64_t)v[1][u][i], (uint32_t)((uint64_t)v[1][u][i] >> 32), (uint32_t)(uint64_t)v[2][u][i], (uint32_t)((uint64_t)v[2][u][i] >> 32)};
-          u32x4 w2 = {(uint32_t)(uint64_t)v[3][u][i], (uint32_t)((uint64_t)v[3][u][i] >> 32), 0u, 0u};
-          radix_stage_emit(S, on, key[u][i] >> p.radix_shift, w0, w1, w2, lane);
+          active[4 * u + i] = ((mb >> (4 * u + i)) & 1u) != 0;
+          bucket[4 * u + i] = key[u][i] >> p.radix_shift;
         }
+      packed_emit<B * 4>(S, active, bucket, tuple, lane);
     }
   }
-  // ---- epilogue: every wavefront writes its partial buffers out as whole flushes (the tail of each is padding), then the workgroup
-  // pads the slots of its ranges that no flush claimed
-  for (int b = 0; b < P; b++) {
-    const uint32_t f = S.fill[b];   // wave-uniform (one value per wavefront and bucket)
-    if (f == 0) continue;
-    uint32_t at = 0;
-    if (lane == 0) at = atomicAdd(&s_cnt[b], S.stage);
-    at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
-    const uint32_t off = (uint32_t)lane * 16u;
-    if (off < S.flush_bytes) {
-      u32x4 v = *reinterpret_cast<const u32x4*>(S.buf + (size_t)b * S.flush_bytes + off);
-      // slots >= f of the buffer are stale: mark them as padding (the key is the first dword of a tuple)
-      for (uint32_t k = 0; k < 16; k += (S.stride < 16 ? S.stride : 16)) {
-        const uint32_t byte = off + k;
-        if (byte % S.stride == 0 && byte / S.stride >= f) {
-          if (k == 0) v.x = PG_RADIX_INVALID_KEY; else v.z = PG_RADIX_INVALID_KEY;   // stride 8: two tuples per 16 bytes
-        }
-      }
-      *reinterpret_cast<u32x4*>(S.tuples + (size_t)(s_base[b] + at) * S.stride + off) = v;
-    }
-  }
+  packed_flush(S, true, lane);   // the wavefront's partial lines, padded
   __syncthreads();
-  for (int b = wave; b < P; b += PG_WAVES_PER_BLOCK) {   // unclaimed tail of every (workgroup, bucket) range
-    // the range ends where the next workgroup's begins (radix_hist holds the workgroups' offsets inside the bucket)
+  for (int b = wave; b < P; b += n_waves) {   // slots of the workgroup's ranges that no line claimed
     const uint32_t begin = p.radix_hist[(int64_t)blockIdx.x * P + b];
     const uint32_t end = blockIdx.x + 1 < gridDim.x ? p.radix_hist[(int64_t)(blockIdx.x + 1) * P + b]
                                                      : p.radix_bucket_start[b + 1] - p.radix_bucket_start[b];
-    const uint32_t cap = end - begin;
-    const uint32_t used = s_cnt[b];
-    for (uint32_t i = used + (uint32_t)lane; i < cap; i += 64)
-      *reinterpret_cast<uint32_t*>(S.tuples + (size_t)(s_base[b] + i) * S.stride) = PG_RADIX_INVALID_KEY;
+    for (uint32_t i = s_cnt[b] + (uint32_t)lane; i < end - begin; i += 64) S.tuples[(size_t)s_base[b] + i] = PG_RADIX_INVALID_KEY;
+  }
+}
+
+// Aggregation pass over packed tuples: work item w = bucket * slices + slice, as pg_radix_aggregate_kernel; four tuples per 16-byte load.
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_aggregate_packed_kernel(const PgQueryPlan p) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
+  int64_t* table = reinterpret_cast<int64_t*>(smem);
+  const int t = threadIdx.x;
+  const uint32_t slots = 1u << p.radix_shift, local_mask = slots - 1u;
+  const int n_items = p.radix_buckets * p.radix_slices;
+  uint8_t* const aux_lds = reinterpret_cast<uint8_t*>(table + (size_t)p.n_ops * slots);
+  uint32_t aux_words = 0;
+  for (int x = 0; x < p.n_aux; x++) aux_words += (slots * (uint32_t)p.aux[x].stride) >> 2;
+  const uint32_t* tuples = reinterpret_cast<const uint32_t*>(p.radix_tuples);
+  for (int w = (int)blockIdx.x; w < n_items; w += (int)gridDim.x) {
+    const int b = w / p.radix_slices, sl = w % p.radix_slices;
+    for (int o = 0; o < p.n_ops; o++) {
+      const int64_t ident = pg_acc_identity(p.ops[o].fn, p.ops[o].is_float);
+      for (uint32_t i = t; i < slots; i += PG_BLOCK) table[(size_t)o * slots + i] = ident;
+    }
+    for (uint32_t i = t; i < aux_words; i += PG_BLOCK) reinterpret_cast<uint32_t*>(aux_lds)[i] = 0u;
+    __syncthreads();
+    // the bucket's range is a whole number of 32-tuple lines: slices take whole lines, threads 16-byte pieces
+    const uint32_t start = p.radix_bucket_start[b], total_lines = (p.radix_bucket_start[b + 1] - start) / PG_PK_LINE;
+    const uint32_t per = (total_lines + (uint32_t)p.radix_slices - 1u) / (uint32_t)p.radix_slices;
+    const uint32_t lo = start + (uint32_t)sl * per * PG_PK_LINE;
+    uint32_t hi = lo + per * PG_PK_LINE;
+    if (hi > start + total_lines * PG_PK_LINE) hi = start + total_lines * PG_PK_LINE;
+    constexpr int U = 2;   // 16-byte pieces per thread in flight
+    for (uint32_t i0 = lo; i0 < hi; i0 += PG_BLOCK * 4 * U) {
+      u32x4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t i = i0 + ((uint32_t)u * PG_BLOCK + (uint32_t)t) * 4u;
+        const u32x4 inv = {PG_RADIX_INVALID_KEY, PG_RADIX_INVALID_KEY, PG_RADIX_INVALID_KEY, PG_RADIX_INVALID_KEY};
+        v[u] = i < hi ? ldnt((const GAS u32x4*)gptr<uint32_t>(tuples + i)) : inv;
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint32_t tp[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          if (tp[e] == PG_RADIX_INVALID_KEY) continue;
+          const uint32_t k = tp[e] & local_mask;
+          for (int o = 0; o < p.n_ops; o++) {
+            const PgAccOp op = p.ops[o];
+            int64_t* acc = table + (size_t)o * slots + k;
+            if (op.src < 0) { atomicAdd(reinterpret_cast<unsigned long long*>(acc), 1ULL); continue; }   // COUNT (MIN(docId) plans are not packed)
+            const PgValueSrc& V = p.srcs[op.src];
+            const uint32_t d = (tp[e] >> p.pk_shift[op.src]) & ((1u << p.pk_bits[op.src]) - 1u);   // dictId
+            if (V.val_type == PG_V_I32) acc_from_int(acc, op, (int64_t)(int32_t)gptr<uint32_t>(V.dict)[d]);
+            else if (V.val_type == PG_V_I64) acc_from_int(acc, op, (int64_t)gptr<uint64_t>(V.dict)[d]);
+            else if (V.val_type == PG_V_F32) acc_from_double(acc, op, (double)__uint_as_float(gptr<uint32_t>(V.dict)[d]), V.fx_q);
+            else acc_from_double(acc, op, __longlong_as_double((int64_t)gptr<uint64_t>(V.dict)[d]), V.fx_q);
+          }
+          uint32_t aux_off = 0;
+          for (int x = 0; x < p.n_aux; x++) {
+            const PgAuxOp& A = p.aux[x];
+            const uint32_t f = (tp[e] >> p.pk_shift[A.src]) & ((1u << p.pk_bits[A.src]) - 1u);
+            hll_update(aux_lds + aux_off + (size_t)k * (uint32_t)A.stride, f & ((1u << A.log2m) - 1u), f >> A.log2m);
+            aux_off += slots * (uint32_t)A.stride;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    int64_t* out = p.partials + (int64_t)w * p.n_ops * slots;
+    for (int64_t i = t; i < (int64_t)p.n_ops * slots; i += PG_BLOCK) out[i] = table[i];
+    {
+      uint32_t aux_off = 0;
+      for (int x = 0; x < p.n_aux; x++) {
+        const uint32_t n_words = (slots * (uint32_t)p.aux[x].stride) >> 2;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(aux_lds + aux_off);
+        uint32_t* dst = p.aux[x].base + (int64_t)w * n_words;
+        for (uint32_t i = t; i < n_words; i += PG_BLOCK) dst[i] = src[i];
+        aux_off += n_words << 2;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -2160,14 +2261,14 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_hash_aggregate_kernel(
 // Counts → offsets.  Step 1, one wavefront per bucket: hist[wg][b] becomes the exclusive prefix over the workgroups (lanes own
 // consecutive workgroups), total[b] the bucket's size.  Step 2, one wavefront: bucket_start = exclusive scan of the totals.
 // (The scatter pass adds bucket_start[b] when it loads its bases.)
-// stage > 0 (staged scatter): a (workgroup, bucket) range holds whole flushes of `stage` tuples — each of the workgroup's 16
-// wavefronts may end on a partial one — so c tuples reserve (c / stage + 16) * stage slots; unused slots carry PG_RADIX_INVALID_KEY.
-DEVFN uint32_t radix_capacity(uint32_t c, int stage) {
+// stage > 0 (packed tuples): a (workgroup, bucket) range holds whole lines of `stage` tuples — each of the scatter workgroup's
+// `waves` wavefronts may end on a partial one — so c tuples reserve (c / stage + waves) * stage slots; unused slots carry PG_RADIX_INVALID_KEY.
+DEVFN uint32_t radix_capacity(uint32_t c, int stage, int waves) {
   if (stage <= 0 || c == 0) return c;
-  return (c / (uint32_t)stage + (uint32_t)PG_WAVES_PER_BLOCK) * (uint32_t)stage;
+  return (c / (uint32_t)stage + (uint32_t)waves) * (uint32_t)stage;
 }
 extern "C" __global__ void __launch_bounds__(1024) pg_radix_offsets_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ bucket_total,
-                                                                           int n_wg, int n_buckets, int stage) {
+                                                                           int n_wg, int n_buckets, int stage, int stage_waves) {
   const int lane = threadIdx.x & 63;
   const int b = (int)blockIdx.x * 16 + (int)(threadIdx.x >> 6);
   if (b >= n_buckets) return;
@@ -2177,7 +2278,7 @@ extern "C" __global__ void __launch_bounds__(1024) pg_radix_offsets_kernel(uint3
   uint32_t mine = 0;
   for (int k = 0; k < per_lane; k++) {
     const int w = lane * per_lane + k;
-    if (w < n_wg) mine += radix_capacity(hist[(int64_t)w * n_buckets + b], stage);
+    if (w < n_wg) mine += radix_capacity(hist[(int64_t)w * n_buckets + b], stage, stage_waves);
   }
   uint32_t x = mine;
 #pragma unroll
@@ -2190,7 +2291,7 @@ extern "C" __global__ void __launch_bounds__(1024) pg_radix_offsets_kernel(uint3
   for (int k = 0; k < per_lane; k++) {
     const int w = lane * per_lane + k;
     if (w < n_wg) {
-      const uint32_t c = radix_capacity(hist[(int64_t)w * n_buckets + b], stage);
+      const uint32_t c = radix_capacity(hist[(int64_t)w * n_buckets + b], stage, stage_waves);
       hist[(int64_t)w * n_buckets + b] = run;
       run += c;
     }

@@ -1332,6 +1332,36 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
       P.aux_in_lds = true;
     }
   }
+  // Packed 4-byte radix tuples (pg_kernels.hip "Packed radix tuples"): the local key plus, per source, the (index, rank) a
+  // DISTINCTCOUNTHLL offers or the dictId of a dictionary-encoded source, when that fits 32 bits; staged in LDS by at most 32 buckets
+  if (D.agg_mode == PG_AGG_RADIX && P.first_doc_op < 0 && D.radix_buckets <= 64 && !getenv("PG_NO_RADIX_PACKED")) {
+    bool ok = true;
+    int next_bit = D.radix_shift;
+    for (size_t si = 0; si < srcs.size() && ok; si++) {
+      bool by_aux = false, by_op = false;
+      int log2m = 0;
+      for (int x = 0; x < D.n_aux; x++)
+        if (D.aux[x].src == (int32_t)si) {
+          ok = ok && !by_aux && (D.aux[x].kind == PG_AUX_HLL_DICT || D.aux[x].kind == PG_AUX_HLL_RAW);   // one HyperLogLog per source column
+          by_aux = true;
+          log2m = D.aux[x].log2m;
+          D.pk_lut[si] = D.aux[x].kind == PG_AUX_HLL_DICT ? D.aux[x].lut : nullptr;
+        }
+      for (auto& o : sorted_ops) by_op |= o.src == (int32_t)si;
+      const Column* c = srcs[si];
+      if (by_aux && by_op) ok = false;
+      else if (by_aux) {
+        D.pk_hll[si] = log2m;
+        D.pk_bits[si] = log2m + 5;
+        if (c->has_dictionary && c->dict_affine) { D.pk_affine[si] = 1; D.pk_base[si] = c->dict_base; D.pk_step[si] = c->dict_step; }
+      }
+      else if (c->col_kind == PG_COL_FIXED_BIT && c->has_dictionary && c->data_type <= PG_TYPE_DOUBLE) { D.pk_hll[si] = 0; D.pk_bits[si] = c->bits; }
+      else ok = false;
+      D.pk_shift[si] = next_bit;
+      next_bit += D.pk_bits[si];
+    }
+    if (ok && next_bit <= 32) D.radix_packed = 1;
+  }
   // fast aggregation: LDS table, slots fit 16 bits, <= 8-bit group columns, 32-bit value sources
   P.fast_agg = D.agg_mode != PG_AGG_GLOBAL && D.agg_mode != PG_AGG_LDS_PART && D.agg_mode != PG_AGG_RADIX && (int64_t)G * D.replicas <= 65536;   // (trivially true without a table)
   if (D.n_aux > 0) P.fast_agg = false;   // set / HLL accumulators run in the interpreter kernel

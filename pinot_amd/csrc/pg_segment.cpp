@@ -244,6 +244,17 @@ void segment_add_column(Segment& seg, const pg_column_desc& d) {
     }
   }
 
+  if (c.has_dictionary && (c.data_type == PG_TYPE_INT || c.data_type == PG_TYPE_LONG) && c.cardinality >= 2) {
+    // arithmetic dictionary?  (value = base + step x dictId lets kernels compute values instead of gathering them)
+    const uint8_t* dp = c.dict_host.data();
+    auto at = [&](int32_t i) -> int64_t { return c.data_type == PG_TYPE_INT ? (int64_t)(int32_t)be32(dp + (size_t)i * 4) : (int64_t)be64(dp + (size_t)i * 8); };
+    const int64_t base = at(0);
+    const __int128 step = (__int128)at(1) - base;
+    bool affine = step > 0 && step < ((__int128)1 << 40);
+    for (int32_t i = 2; i < c.cardinality && affine; i++) affine = (__int128)at(i) - at(i - 1) == step;
+    if (affine) { c.dict_affine = true; c.dict_base = base; c.dict_step = (int64_t)step; }
+  }
+
   if (c.fwd_encoding == PG_FWD_DICT_FIXED_BIT) {
     if (c.bits < 1 || c.bits > 31) fail(PG_ERR_INVALID_ARGUMENT, "column %s: bits_per_value %d", d.name, c.bits);
     upload_fixed_bit(seg, c, fwd, fwd_len);
