@@ -264,6 +264,14 @@ int32_t pg_segment_add_star_tree(pg_segment_t segment, const pg_star_tree_desc* 
  * (query-level null handling is outside the path).  The bytes are copied. */
 int32_t pg_segment_set_null_vector(pg_segment_t segment, const char* column, const void* roaring, uint64_t size);
 
+/* DataSource#getRangeIndex: the column's `range_index` entry exactly as BitSlicedRangeIndexReader reads it
+ * (pinot-segment-local/.../index/readers/BitSlicedRangeIndexReader.java:41-58): big-endian int version (2) and long min, then a
+ * RoaringBitmap `RangeBitmap` (little-endian bit-sliced index: slice i = rows whose stored value has bit i clear; stored value =
+ * dictId, value - min, or FPOrdering ordinal).  RANGE predicates on the column — and EQ when it has no inverted index — then take
+ * RangeIndexBasedFilterOperator's place in the plan (FilterOperatorUtils.java:99-131; numEntriesScannedInFilter 0) instead of a
+ * scan.  The bytes are copied.  Legacy (version 1, inexact) range indexes are refused: the column keeps its scan leaf. */
+int32_t pg_segment_set_range_index(pg_segment_t segment, const char* column, const void* range_index, uint64_t size);
+
 /* SegmentContext#getQueryableDocIdsSnapshot (upsert validDocIds / queryableDocIds): FilterPlanNode.run ANDs it into every
  * filter as a BitmapBasedFilterOperator (pinot-core/.../plan/FilterPlanNode.java:88-106).  One portable-format RoaringBitmap,
  * copied; replaces the previous snapshot; size 0 clears it.  Queries already running keep the snapshot they started with. */

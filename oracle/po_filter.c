@@ -616,11 +616,13 @@ po_filter_op* po_leaf_filter_operator(po_pred_eval* eval, const po_column* col, 
   po_filter_op* op;
   int sorted_ok = col->is_sorted && col->has_dictionary;
   if (eval->pred_type == PG_PRED_RANGE) {
-    /* range: Sorted > RangeIndex (none on this path) > Scan — the inverted index is NOT used for RANGE */
-    op = po_op_new(sorted_ok ? PO_OP_SORTED : PO_OP_SCAN, num_docs);
+    /* range: Sorted > RangeIndex > Scan — the inverted index is NOT used for RANGE */
+    op = po_op_new(sorted_ok ? PO_OP_SORTED : (col->range_idx ? PO_OP_RANGE_INDEX : PO_OP_SCAN), num_docs);
   } else {
     if (sorted_ok) op = po_op_new(PO_OP_SORTED, num_docs);
     else if (col->inv_len > 0) op = po_op_new(PO_OP_INVERTED, num_docs);
+    /* RangeIndexBasedFilterOperator.canEvaluate (:58-63): EQ over an exact range index */
+    else if (col->range_idx && eval->pred_type == PG_PRED_EQ) op = po_op_new(PO_OP_RANGE_INDEX, num_docs);
     else op = po_op_new(PO_OP_SCAN, num_docs);
   }
   op->eval = eval;
@@ -634,6 +636,7 @@ static int op_priority(const po_filter_op* op) {
     case PO_OP_SORTED: return 0;
     case PO_OP_INVERTED: return 100;
     case PO_OP_BITMAP: return 100;   /* BitmapBasedFilterOperator: MEDIUM_PRIORITY */
+    case PO_OP_RANGE_INDEX: return 200;   /* LOW_PRIORITY, FilterOperatorUtils.java:224-230 */
     case PO_OP_AND: return 300;
     case PO_OP_OR: return 400;
     case PO_OP_NOT: return op_priority(op->children[0]);
@@ -835,6 +838,11 @@ po_docidset* po_filter_get_trues(po_filter_op* op) {
     case PO_OP_SCAN: return scanset_new(op->eval, op->col, op->num_docs);
     case PO_OP_INVERTED: return inverted_get_trues(op);
     case PO_OP_SORTED: return sorted_get_trues(op);
+    case PO_OP_RANGE_INDEX: { /* RangeIndexBasedFilterOperator#getNextBlockWithoutNullHandling :75-82: exact index -> BitmapDocIdSet */
+      po_bitmap* b = po_range_index_matching(op->col, op->eval, op->num_docs);
+      if (!b) return NULL;
+      return bitmapset_new(b, op->num_docs);
+    }
     case PO_OP_BITMAP: { /* BitmapBasedFilterOperator#getTrues :42-49 */
       po_bitmap* b = po_bitmap_clone(op->bitmap);
       if (op->bitmap_exclusive) po_bitmap_flip(b, 0, op->num_docs);
@@ -915,6 +923,7 @@ int po_filter_can_optimize_count(po_filter_op* op) {
     case PO_OP_MATCH_ALL:
     case PO_OP_INVERTED:
     case PO_OP_BITMAP:
+    case PO_OP_RANGE_INDEX:
     case PO_OP_SORTED: return 1;
     case PO_OP_SCAN: return 0;
     default:

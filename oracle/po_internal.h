@@ -94,6 +94,7 @@ typedef struct po_column {
   uint8_t* raw_owned;        /* compressed chunks, decompressed once into the PASS_THROUGH layout (po_raw_parse_header) */
   int32_t num_docs;
   struct po_bitmap* null_bitmap;   /* NullValueVectorReader#getNullBitmap, NULL if the column has no null value vector */
+  const uint8_t* range_idx; uint64_t range_len;   /* DataSource#getRangeIndex: BitSlicedRangeIndexReader bytes, NULL if none */
 } po_column;
 
 struct po_star_tree;
@@ -199,7 +200,10 @@ struct po_docidset {
 };
 
 enum { PO_OP_EMPTY, PO_OP_MATCH_ALL, PO_OP_SCAN, PO_OP_INVERTED, PO_OP_SORTED, PO_OP_AND, PO_OP_OR, PO_OP_NOT,
-       PO_OP_BITMAP /* BitmapBasedFilterOperator over a precomputed bitmap (star-tree traversal result) */ };
+       PO_OP_BITMAP /* BitmapBasedFilterOperator over a precomputed bitmap (star-tree traversal result) */,
+       PO_OP_RANGE_INDEX /* RangeIndexBasedFilterOperator over an exact (bit-sliced) range index */ };
+struct po_pred_eval;
+po_bitmap* po_range_index_matching(const po_column* c, const struct po_pred_eval* e, int32_t num_docs);   /* po_rangeindex.c */
 
 struct po_filter_op {
   int kind;

@@ -97,6 +97,15 @@ int32_t po_segment_set_null_vector(void* segp, const char* column, const void* r
   c->null_bitmap = b;
   return PG_OK;
 }
+/* DataSource#getRangeIndex: the column's `range_index` entry (BitSlicedRangeIndexReader); the bytes are borrowed, like the other indexes */
+int32_t po_segment_set_range_index(void* segp, const char* column, const void* bytes, uint64_t size) {
+  po_segment* seg = (po_segment*)segp;
+  po_column* c = po_segment_column(seg, column);
+  if (!c) { po_set_error("column not found: %s", column ? column : "(null)"); return PG_ERR_NOT_FOUND; }
+  c->range_idx = size ? (const uint8_t*)bytes : NULL;
+  c->range_len = size;
+  return PG_OK;
+}
 /* SegmentContext#getQueryableDocIdsSnapshot */
 int32_t po_segment_set_queryable_doc_ids(void* segp, const void* roaring, uint64_t size) {
   po_segment* seg = (po_segment*)segp;

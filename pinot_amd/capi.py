@@ -156,7 +156,7 @@ GPU_LIB_PATH = os.environ.get("PG_GPU_LIB") or os.path.join(REPO_ROOT, "pinot_am
 # every symbol include/pinot_gpu.h declares (checked by the "not gpu" suite against the built library)
 ABI_SYMBOLS = [
     "abi_version", "init", "device_count", "last_error",
-    "segment_create", "segment_add_column", "segment_add_star_tree", "segment_set_null_vector", "segment_set_queryable_doc_ids", "segment_num_docs", "segment_device_bytes", "segment_destroy",
+    "segment_create", "segment_add_column", "segment_add_star_tree", "segment_set_null_vector", "segment_set_range_index", "segment_set_queryable_doc_ids", "segment_num_docs", "segment_device_bytes", "segment_destroy",
     "filter_exec", "docidset_cardinality", "docidset_num_words", "docidset_copy_words", "docidset_copy_docids",
     "docidset_stats", "docidset_free",
     "query_supported", "query_exec",
@@ -219,6 +219,7 @@ class NativeApi:
         self.f("result_group_dict_ids").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
         self.f("segment_set_null_vector").argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
         self.f("segment_set_queryable_doc_ids").argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        self.f("segment_set_range_index").argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
         self.f("result_group_key_type").argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         self.f("result_group_values_long").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
         self.f("result_kind_of").argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]

@@ -103,6 +103,13 @@ int32_t pg_segment_set_null_vector(pg_segment_t segment, const char* column, con
     segment_set_null_vector(segment->seg, column, roaring, size);
   });
 }
+int32_t pg_segment_set_range_index(pg_segment_t segment, const char* column, const void* range_index, uint64_t size) {
+  return guarded([&] {
+    REQUIRE(segment && column, "null argument");
+    use_device(segment->seg.device);
+    segment_set_range_index(segment->seg, column, range_index, size);
+  });
+}
 int32_t pg_segment_set_queryable_doc_ids(pg_segment_t segment, const void* roaring, uint64_t size) {
   return guarded([&] {
     REQUIRE(segment, "null argument");

@@ -42,7 +42,8 @@ enum PgFOp : int32_t {
   PG_F_NOT = 6,             // top = ~top & valid
   PG_F_PUSH_NONE = 7,       // push empty set
   PG_F_PUSH_ALL = 8,        // push every doc of the tile (MatchAllFilterOperator)
-  PG_F_PUSH_WORDS = 9       // push a precomputed docId set given as match words (range leaf `arg`, one dword per 32 docs)
+  PG_F_PUSH_WORDS = 9,      // push a precomputed docId set given as match words (range leaf `arg`, one dword per 32 docs)
+  PG_F_PUSH_RANGEIDX = 10   // push the rows a bit-sliced range index selects (PgRangeIdxLeaf `arg`): interpreter kernels only
 };
 
 struct PgFInstr {
@@ -104,6 +105,19 @@ struct PgRangeLeaf {
   const int32_t* hi;   // inclusive
   const uint32_t* words;   // non-null: the doc set as match words instead (one dword per 32 docs, whole wave tiles)
   int32_t n;
+  int32_t pad;
+};
+
+// RangeIndexBasedFilterOperator over a bit-sliced range index (RoaringBitmap RangeBitmap): slice s = the rows whose stored value has
+// bit s CLEAR, one container per (2^16-row chunk, slice).  rows with value <= t:  L = all;  for s = 0 .. slices-1:
+// L = bit s of t ? L | slice_s : L & slice_s.  The leaf selects  lte(hi) AND NOT lte(lo_m1).
+struct PgRangeIdxLeaf {
+  const uint8_t* containers;
+  const PgContainer* descs;   // [chunks][n_slices]; type 3: the chunk has no container for the slice (no row there has the bit clear)
+  uint64_t hi;                // has_hi: rows with stored value <= hi
+  uint64_t lo_m1;             // has_lo: minus the rows with stored value <= lo_m1
+  int32_t n_slices;
+  int32_t has_hi, has_lo;
   int32_t pad;
 };
 
@@ -208,6 +222,7 @@ struct PgQueryPlan {
   const PgScanLeaf* scans;
   const PgPostingLeaf* postings;
   const PgRangeLeaf* ranges;
+  const PgRangeIdxLeaf* rangeidx;
   // outputs of the filter stage
   uint64_t* out_words;              // nullable: ceil(num_docs/64) match words (tile padded)
   uint32_t* out_tile_counts;        // nullable: matches per tile

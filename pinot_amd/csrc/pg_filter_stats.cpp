@@ -330,6 +330,11 @@ struct Emu {
         s->leaf_bits = &leaves.at(&op);
         return s;
       }
+      case OpKind::RangeIdx: {   // RangeIndexBasedFilterOperator over an exact index: a BitmapDocIdSet
+        auto s = mk(SetKind::Bitmap);
+        s->leaf_bits = &leaves.at(&op);
+        return s;
+      }
       case OpKind::Sorted: {
         auto s = mk(SetKind::Sorted);
         s->ranges = sorted_ranges(op, n_docs);

@@ -90,6 +90,12 @@ struct Column {
   std::vector<uint32_t> posting_begin;          // cardinality + 1 offsets into descs_host
   std::vector<int64_t> posting_card;            // docs per dictId (exact: planning estimates filter selectivity from it)
   DeviceBuffer containers_dev, descs_dev;
+  // bit-sliced range index (BitSlicedRangeIndexReader over a RoaringBitmap RangeBitmap): one container per (2^16-row chunk, slice)
+  bool has_range_index = false;
+  int32_t ri_slices = 0, ri_chunks = 0;
+  int64_t ri_min = 0;                            // stored value = value - ri_min (raw INT / LONG), dictId, or FPOrdering ordinal
+  uint64_t ri_bytes = 0;
+  DeviceBuffer ri_containers_dev, ri_descs_dev;
   uint64_t fwd_bytes_logical = 0;               // bytes of the forward index proper (for algorithmic byte accounting)
   // value statistics behind exact SUMs (fixed-point scale, digit count), computed once at registration
   int32_t fx_exp = 0;                           // FLOAT / DOUBLE: every finite |value| < 2^fx_exp (a multiple of 16)
@@ -145,6 +151,7 @@ void segment_add_star_tree(Segment& seg, const pg_star_tree_desc& d);
 void decompress_fixed_byte_chunks(int compression, const uint8_t* file, const std::vector<uint64_t>& offs, uint32_t chunk_bytes,
                                   uint64_t total_bytes, uint8_t* dst, const char* column);
 void segment_set_null_vector(Segment& seg, const char* column, const void* roaring, uint64_t size);
+void segment_set_range_index(Segment& seg, const char* column, const void* bytes, uint64_t size);
 void segment_set_queryable_doc_ids(Segment& seg, const void* roaring, uint64_t size);
 
 // ---- predicate evaluation (host): PredicateEvaluatorProvider & factories ---------------------------------------------------
@@ -181,7 +188,7 @@ using StatLeafBits = std::unordered_map<const FilterOp*, HostBits>;
 int64_t emulate_entries_scanned_in_filter(const FilterOp& root, const StatLeafBits& leaves, int32_t n_docs);
 
 // ---- compiled plan ------------------------------------------------------------------------------------------------------------
-enum class OpKind { Empty, MatchAll, Scan, Inverted, Sorted, And, Or, Not, Bitmap };
+enum class OpKind { Empty, MatchAll, Scan, Inverted, Sorted, And, Or, Not, Bitmap, RangeIdx };
 
 struct FilterOp {
   OpKind kind = OpKind::Empty;

@@ -379,6 +379,71 @@ DEVFN uint32_t postings_wtile(const LeafT& L, int wtile, uint32_t valid_lin, uin
   return (L.exclusive ? ~acc : acc) & valid_lin;
 }
 
+// One container's bits of the wave tile `sub` (2 048 docs of its 2^16-row chunk) OR-ed into the wavefront's LDS scratch (array / run
+// containers; bitmap containers are read directly).  The caller zeroes / fences the scratch.
+DEVFN void container_scatter(const GAS uint8_t* payload, uint32_t n, uint32_t type, int sub, uint32_t* __restrict__ wscratch, int lane) {
+  const uint32_t lo = (uint32_t)sub * PG_WAVE_DOCS, hi = lo + PG_WAVE_DOCS;
+  if (type == 0) {
+    const GAS uint16_t* vals = (const GAS uint16_t*)payload;
+    uint32_t a = 0, b = n;
+    while (a < b) {
+      const uint32_t m = (a + b) >> 1;
+      if (vals[m] < lo) a = m + 1; else b = m;
+    }
+    for (uint32_t i = a + lane; i < n; i += 64) {
+      uint32_t v = vals[i];
+      if (v >= hi) break;
+      v -= lo;
+      atomicOr(&wscratch[v >> 5], 1u << (v & 31));
+    }
+  } else if (type == 2) {
+    const GAS uint16_t* runs = (const GAS uint16_t*)payload;
+    for (uint32_t r = lane; r < n; r += 64) {
+      uint32_t s = runs[2 * r], eend = s + runs[2 * r + 1] + 1;
+      if (eend <= lo || s >= hi) continue;
+      s = (s < lo ? lo : s) - lo;
+      eend = (eend > hi ? hi : eend) - lo;
+      const uint32_t fw = s >> 5, lw = (eend - 1) >> 5;
+      const uint32_t fm = 0xFFFFFFFFu << (s & 31), lm = 0xFFFFFFFFu >> (31 - ((eend - 1) & 31));
+      if (fw == lw) atomicOr(&wscratch[fw], fm & lm);
+      else {
+        atomicOr(&wscratch[fw], fm);
+        for (uint32_t w = fw + 1; w < lw; w++) atomicOr(&wscratch[w], 0xFFFFFFFFu);
+        atomicOr(&wscratch[lw], lm);
+      }
+    }
+  }
+}
+
+// Bit-sliced range index leaf (PgRangeIdxLeaf): the descriptors of the chunk's slices arrive with one vector load (lane s holds slice
+// s), each slice's 2 048-bit window is folded into the two running "<= threshold" masks.
+template <class LeafT>
+DEVFN uint32_t rangeidx_wtile(const LeafT& L, int wtile, uint32_t valid_lin, uint32_t* __restrict__ wscratch, int lane) {
+  const int chunk = wtile / PG_WTILES_PER_CHUNK, sub = wtile % PG_WTILES_PER_CHUNK;
+  u32x4 ent = {0u, 0u, 0u, 3u << 16};
+  if (lane < L.n_slices) ent = gptr<u32x4>(L.descs)[(size_t)chunk * (size_t)L.n_slices + (size_t)lane];
+  uint32_t le_hi = 0xFFFFFFFFu, le_lo = 0xFFFFFFFFu;
+  for (int s = 0; s < L.n_slices; s++) {
+    const uint32_t off_lo = __builtin_amdgcn_readlane(ent.x, s), off_hi = __builtin_amdgcn_readlane(ent.y, s);
+    const uint32_t n = __builtin_amdgcn_readlane(ent.z, s), type = __builtin_amdgcn_readlane(ent.w, s) >> 16;
+    const GAS uint8_t* payload = gptr<uint8_t>(L.containers + (((uint64_t)off_hi << 32) | off_lo));
+    uint32_t S = 0;
+    if (type == 1) S = ((const GAS uint32_t*)payload)[sub * 64 + lane];
+    else if (type != 3) {   // wave-uniform
+      wscratch[lane] = 0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      container_scatter(payload, n, type, sub, wscratch, lane);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      S = *(volatile uint32_t*)&wscratch[lane];
+    }
+    le_hi = ((L.hi >> s) & 1ULL) ? (le_hi | S) : (le_hi & S);
+    le_lo = ((L.lo_m1 >> s) & 1ULL) ? (le_lo | S) : (le_lo & S);
+  }
+  uint32_t r = L.has_hi ? le_hi : 0xFFFFFFFFu;
+  if (L.has_lo) r &= ~le_lo;
+  return r & valid_lin;
+}
+
 // docId ranges (sorted index / match-all), linear layout
 template <class LeafT>
 DEVFN uint32_t ranges_wtile(const LeafT& L, int64_t wbase, uint32_t valid_lin, int lane) {
@@ -946,6 +1011,7 @@ DEVFN uint32_t index_program_lin(const PgQueryPlan& p, int n_instr, int wt, int6
       case PG_F_PUSH_POSTINGS: st.push(postings_wtile(cptr(p.postings)[arg], wt, valid_l, wscratch, lane)); break;
       case PG_F_PUSH_RANGES: st.push(ranges_wtile(cptr(p.ranges)[arg], wbase, valid_l, lane)); break;
       case PG_F_PUSH_WORDS: if (WORDS) st.push(gptr<uint32_t>(cptr(p.ranges)[arg].words)[(int64_t)wt * 64 + lane] & valid_l); break;
+      case PG_F_PUSH_RANGEIDX: if (WORDS) st.push(rangeidx_wtile(cptr(p.rangeidx)[arg], wt, valid_l, wscratch, lane)); break;
       case PG_F_PUSH_ALL: st.push(valid_l); break;
       case PG_F_PUSH_NONE: st.push(0u); break;
       case PG_F_AND: { const uint32_t b = st.s0; st.drop(); st.s0 &= b; break; }
@@ -1380,6 +1446,9 @@ __device__ __forceinline__ void generic_query_body(const PgQueryPlan& p) {
           break;
         case PG_F_PUSH_WORDS:
           st.push(lin_to_quad(gptr<uint32_t>(cptr(p.ranges)[farg].words)[(int64_t)wt * 64 + lane] & valid_l, lane));
+          break;
+        case PG_F_PUSH_RANGEIDX:
+          st.push(lin_to_quad(rangeidx_wtile(cptr(p.rangeidx)[farg], wt, valid_l, s_wscratch[wave], lane), lane));
           break;
         case PG_F_PUSH_ALL:
           st.push(valid_q);

@@ -229,6 +229,7 @@ static int priority(const FilterOp& op) {   // PrioritizedFilterOperator.java:31
     case OpKind::Sorted: return 0;
     case OpKind::Inverted: return 100;
     case OpKind::Bitmap: return 100;   // BitmapBasedFilterOperator: MEDIUM_PRIORITY
+    case OpKind::RangeIdx: return 200; // RangeIndexBasedFilterOperator: LOW_PRIORITY (FilterOperatorUtils.java:224-230)
     case OpKind::And: return 300;
     case OpKind::Or: return 400;
     case OpKind::Not: return priority(*op.children[0]);
@@ -276,8 +277,11 @@ OpPtr leaf_operator(PredEval ev, Column* col, int32_t predicate_type) {
   if (ev.always_true) return make_op(OpKind::MatchAll);
   const bool sorted_ok = col->is_sorted && col->has_dictionary && !col->sorted_start.empty();
   OpKind k;
-  if (predicate_type == PG_PRED_RANGE) k = sorted_ok ? OpKind::Sorted : OpKind::Scan;
-  else k = sorted_ok ? OpKind::Sorted : (col->has_inverted ? OpKind::Inverted : OpKind::Scan);
+  // RANGE: Sorted > RangeIndex > Scan; other predicates: Sorted > Inverted > RangeIndex (EQ over an exact range index:
+  // RangeIndexBasedFilterOperator.canEvaluate, RangeIndexBasedFilterOperator.java:58-63) > Scan
+  if (predicate_type == PG_PRED_RANGE) k = sorted_ok ? OpKind::Sorted : (col->has_range_index ? OpKind::RangeIdx : OpKind::Scan);
+  else k = sorted_ok ? OpKind::Sorted
+                     : (col->has_inverted ? OpKind::Inverted : (col->has_range_index && predicate_type == PG_PRED_EQ ? OpKind::RangeIdx : OpKind::Scan));
   auto op = make_op(k);
   op->eval = std::move(ev);
   op->col = col;
@@ -335,6 +339,7 @@ struct Emitter {
   std::vector<PgScanLeaf> scans;
   std::vector<PgPostingLeaf> postings;
   std::vector<PgRangeLeaf> ranges;
+  std::vector<PgRangeIdxLeaf> rangeidx;
   int sp = 0, max_sp = 0;
   int64_t alg_bytes = 0;
   std::vector<Column*> scanned_cols;
@@ -455,6 +460,62 @@ struct Emitter {
     push();
   }
 
+  // RangeIndexBasedFilterOperator#getMatchingDocIds over BitSlicedRangeIndexReader#getMatchingDocIds (:41-246): the predicate's
+  // inclusive bounds in the index's stored domain — dictIds, value - min, FPOrdering ordinals — as  lte(hi) AND NOT lte(lo - 1)
+  static uint64_t fp_ordinal(double v, bool is_float) {   // FPOrdering.ordinalOf
+    if (is_float) {
+      const float f = (float)v;
+      if (f == INFINITY) return 0xFFFFFFFFULL;
+      if (f == -INFINITY || f != f) return 0;
+      uint32_t b;
+      memcpy(&b, &f, 4);
+      b = (b & 0x80000000u) ? (b == 0x80000000u ? 0x80000000u : ~b) : (b ^ 0x80000000u);
+      return b;
+    }
+    if (v == (double)INFINITY) return ~0ULL;
+    if (v == -(double)INFINITY || v != v) return 0;
+    uint64_t b;
+    memcpy(&b, &v, 8);
+    return (b & (1ULL << 63)) ? (b == (1ULL << 63) ? (1ULL << 63) : ~b) : (b ^ (1ULL << 63));
+  }
+  void emit_rangeidx(const FilterOp& op) {
+    const Column& c = *op.col;
+    const PredEval& e = op.eval;
+    const bool eq = e.pred_type == PG_PRED_EQ;
+    const uint64_t range_mask = c.ri_slices == 64 ? ~0ULL : ((1ULL << c.ri_slices) - 1ULL);
+    bool empty = false;
+    uint64_t lo = 0, hi = 0;
+    if (e.dictionary_based) {
+      lo = (uint64_t)(eq ? e.matching[0] : e.start_dict_id);
+      hi = (uint64_t)(eq ? e.matching[0] : e.end_dict_id - 1);
+    } else if (c.val_type == PG_V_I32 || c.val_type == PG_V_I64) {
+      const int64_t lo_v = eq ? e.set_i[0] : e.lo_i, hi_v = eq ? e.set_i[0] : e.hi_i;
+      if (lo_v > hi_v || hi_v < c.ri_min) empty = true;
+      else {
+        lo = (uint64_t)((__int128)std::max(lo_v, c.ri_min) - c.ri_min);
+        hi = (uint64_t)((__int128)hi_v - c.ri_min);
+      }
+    } else {
+      const double lo_v = eq ? e.set_d[0] : e.lo_d, hi_v = eq ? e.set_d[0] : e.hi_d;
+      if (lo_v > hi_v) empty = true;
+      else { lo = fp_ordinal(lo_v, c.val_type == PG_V_F32); hi = fp_ordinal(hi_v, c.val_type == PG_V_F32); }
+    }
+    if (!empty && lo > range_mask) empty = true;   // beyond every stored value
+    if (empty) { instrs.push_back({PG_F_PUSH_NONE, 0}); push(); return; }
+    PgRangeIdxLeaf L{};
+    L.containers = c.ri_containers_dev.as<uint8_t>();
+    L.descs = c.ri_descs_dev.as<PgContainer>();
+    L.n_slices = c.ri_slices;
+    L.has_hi = hi < range_mask ? 1 : 0;
+    L.hi = hi < range_mask ? hi : range_mask;
+    L.has_lo = lo > 0 ? 1 : 0;
+    L.lo_m1 = lo > 0 ? lo - 1 : 0;
+    rangeidx.push_back(L);
+    alg_bytes += (int64_t)c.ri_bytes;
+    instrs.push_back({PG_F_PUSH_RANGEIDX, (int32_t)rangeidx.size() - 1});
+    push();
+  }
+
   void emit_scan(const FilterOp& op, bool masked) {
     Column& c = *op.col;
     const PredEval& e = op.eval;
@@ -510,6 +571,7 @@ struct Emitter {
       case OpKind::Sorted: emit_sorted(op); break;
       case OpKind::Bitmap: emit_ranges(op.range_lo, op.range_hi); break;
       case OpKind::Inverted: emit_inverted(op); break;
+      case OpKind::RangeIdx: emit_rangeidx(op); break;
       case OpKind::Scan: emit_scan(op, false); break;
       case OpKind::Not:
         emit(*op.children[0], false);
@@ -573,7 +635,7 @@ struct Emitter {
   //    scan / compound child (its bitmap list is never filled in this reference snapshot: `numSorted + 0 > 1`); any other OR is an
   //    OrDocIdIterator, which an enclosing AND leapfrogs.
   static bool index_child(const FilterOp& c) {
-    return c.kind == OpKind::Sorted || c.kind == OpKind::Inverted || c.kind == OpKind::Bitmap || yields_bitmap(c);
+    return c.kind == OpKind::Sorted || c.kind == OpKind::Inverted || c.kind == OpKind::Bitmap || c.kind == OpKind::RangeIdx || yields_bitmap(c);
   }
   static bool yields_bitmap(const FilterOp& op) {
     if (op.kind == OpKind::And) {
@@ -773,6 +835,9 @@ static double estimate_selectivity(const FilterOp& op, double n_docs) {
       for (size_t i = 0; i < op.range_lo.size(); i++) m += (double)(op.range_hi[i] - op.range_lo[i] + 1);
       return std::min(1.0, m / n_docs);
     }
+    case OpKind::RangeIdx:
+      if (op.eval.dictionary_based && op.col->cardinality > 0) return (double)op.eval.matching.size() / op.col->cardinality;
+      return 0.3;
     case OpKind::Scan:
       if (op.eval.dictionary_based && op.col->cardinality > 0) return (double)op.eval.matching.size() / op.col->cardinality;   // uniform dictIds
       return 0.2;   // a raw-value predicate without column statistics: assume it is selective (the dense HBM table is the safe side)
@@ -822,7 +887,7 @@ std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* f
 
 // `seg`: the doc space the operators run over — the segment itself, or a star-tree's docs.
 static void collect_stat_leaves(const FilterOp& op, std::vector<const FilterOp*>& out) {
-  if (op.kind == OpKind::Scan || op.kind == OpKind::Inverted) out.push_back(&op);
+  if (op.kind == OpKind::Scan || op.kind == OpKind::Inverted || op.kind == OpKind::RangeIdx) out.push_back(&op);
   for (auto& c : op.children) collect_stat_leaves(*c, out);
 }
 static OpPtr clone_leaf(const FilterOp& op) {
@@ -858,6 +923,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
   D.scans = em.keep(em.scans);
   D.postings = em.keep(em.postings);
   D.ranges = em.keep(em.ranges);
+  D.rangeidx = em.keep(em.rangeidx);
   D.agg_mode = PG_AGG_NONE;
   D.n_groups = 1;
   D.replicas = 1;
@@ -865,7 +931,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
   // ---- fast-path shape of the filter: [index-only program] (AND one scan of a specialised kind) ---------------------------
   {
     auto index_op = [](int32_t op) {
-      return op == PG_F_PUSH_POSTINGS || op == PG_F_PUSH_RANGES || op == PG_F_PUSH_WORDS || op == PG_F_PUSH_ALL || op == PG_F_PUSH_NONE ||   // (WORDS: see below)
+      return op == PG_F_PUSH_POSTINGS || op == PG_F_PUSH_RANGES || op == PG_F_PUSH_WORDS || op == PG_F_PUSH_RANGEIDX || op == PG_F_PUSH_ALL || op == PG_F_PUSH_NONE ||   // (WORDS / RANGEIDX: see below)
              op == PG_F_AND || op == PG_F_OR || op == PG_F_NOT;
     };
     size_t n_idx = 0;
@@ -896,7 +962,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     }
     size_t rest = n_total - n_idx;
     bool has_words = false;   // match-word leaves (star-tree traversals with many ranges) are the interpreter kernels' business
-    for (auto& in : em.instrs) has_words |= in.op == PG_F_PUSH_WORDS;
+    for (auto& in : em.instrs) has_words |= in.op == PG_F_PUSH_WORDS || in.op == PG_F_PUSH_RANGEIDX;   // range-index leaves too
     if (has_words) rest = 1000;
     P.fast_filter = -2;   // -2: interpreter; -1: no scan; >= 0: ScanKind of the single scan
     D.fast_scan = -1;

@@ -191,6 +191,78 @@ void segment_set_null_vector(Segment& seg, const char* column, const void* roari
   seg.plan_cache.clear();   // running queries keep their plan, which pins the bitmap it reads
 }
 
+// DataSource#getRangeIndex: BitSlicedRangeIndexReader bytes (big-endian int version 2, long min) + a RoaringBitmap RangeBitmap
+// (little-endian: u16 cookie 0xF00D, u8 base 2, u8 sliceCount, u16 maxKey, u32 maxRid, maxKey masks of (sliceCount + 7) / 8 bytes, then
+// per chunk and present slice u8 type (0 bitmap / 1 run / 2 array) + container).  RoaringBitmap is not in the reference tree: the
+// format is restated from its published source (pinot_amd/formats.py holds the writer the tests use).
+void segment_set_range_index(Segment& seg, const char* column, const void* bytes, uint64_t size) {
+  Column* c = column ? seg.find(column) : nullptr;
+  if (!c) fail(PG_ERR_NOT_FOUND, "column not found: %s", column ? column : "(null)");
+  const uint8_t* p = static_cast<const uint8_t*>(bytes);
+  if (!p || size < 22) fail(PG_ERR_INVALID_ARGUMENT, "range index of %s too short", column);
+  const int32_t version = (int32_t)be32(p);
+  if (version != 2) fail(PG_ERR_UNSUPPORTED, "range index of %s: version %d (only the exact bit-sliced index, version 2, is on the GPU path)", column, version);
+  const int64_t min = (int64_t)be64(p + 4);
+  const uint8_t* r = p + 12;
+  if (le16(r) != 0xF00D || r[2] != 2) fail(PG_ERR_INVALID_ARGUMENT, "range index of %s: bad RangeBitmap cookie / base", column);
+  const int slices = r[3];
+  const uint32_t max_key = le16(r + 4), max_rid = le32(r + 6);
+  const int bytes_per_mask = (slices + 7) >> 3;
+  if (slices < 1 || slices > 64) fail(PG_ERR_INVALID_ARGUMENT, "range index of %s: %d slices", column, slices);
+  if ((int64_t)max_rid < (int64_t)seg.total_docs) fail(PG_ERR_INVALID_ARGUMENT, "range index of %s covers %u rows, the segment has %d", column, max_rid, seg.total_docs);
+  const uint32_t n_chunks = (uint32_t)((padded_docs(seg) + PG_CHUNK_DOCS - 1) / PG_CHUNK_DOCS);
+  if (max_key > n_chunks) fail(PG_ERR_INVALID_ARGUMENT, "range index of %s: %u chunks beyond the segment", column, max_key);
+  uint64_t pos = 22 + (uint64_t)max_key * (uint64_t)bytes_per_mask;
+  if (pos > size) fail(PG_ERR_INVALID_ARGUMENT, "range index of %s: truncated masks", column);
+  std::vector<PgContainer> descs((size_t)n_chunks * (size_t)slices);
+  for (auto& d : descs) { d.offset = 0; d.n = 0; d.key = 0; d.type = 3; }
+  std::vector<uint8_t> staging;
+  staging.reserve(size);
+  for (uint32_t key = 0; key < max_key; key++) {
+    uint64_t mask = 0;
+    for (int b = 0; b < bytes_per_mask; b++) mask |= (uint64_t)p[22 + (uint64_t)key * bytes_per_mask + b] << (8 * b);
+    for (int s = 0; s < slices; s++) {
+      if (!((mask >> s) & 1)) continue;
+      if (pos + 1 > size) fail(PG_ERR_INVALID_ARGUMENT, "range index of %s: truncated container", column);
+      const int type = p[pos++];
+      PgContainer pc{};
+      pc.key = (uint16_t)key;
+      uint64_t payload;
+      if (type == 0) { pc.type = 1; pc.n = 0; payload = 8192; }
+      else if (type == 1 || type == 2) {
+        if (pos + 2 > size) fail(PG_ERR_INVALID_ARGUMENT, "range index of %s: truncated container", column);
+        pc.n = le16(p + pos);
+        pos += 2;
+        pc.type = type == 1 ? 2 : 0;
+        payload = type == 1 ? 4ULL * pc.n : 2ULL * pc.n;
+      } else {
+        fail(PG_ERR_INVALID_ARGUMENT, "range index of %s: container type %d", column, type);
+      }
+      if (pos + payload > size) fail(PG_ERR_INVALID_ARGUMENT, "range index of %s: truncated container", column);
+      const size_t aligned = (staging.size() + 15) & ~(size_t)15;
+      staging.resize(aligned + payload);
+      memcpy(staging.data() + aligned, p + pos, payload);
+      pc.offset = aligned;
+      pos += payload;
+      descs[(size_t)key * (size_t)slices + (size_t)s] = pc;
+    }
+  }
+  staging.resize(((staging.size() + 15) & ~(size_t)15) + 16);
+  DeviceBuffer cont(staging.size());
+  cont.upload(staging.data(), staging.size());
+  DeviceBuffer dd = upload_vector(descs);
+  std::lock_guard<std::mutex> g(seg.mu);
+  seg.device_bytes += cont.size + dd.size;
+  c->ri_containers_dev = std::move(cont);
+  c->ri_descs_dev = std::move(dd);
+  c->ri_slices = slices;
+  c->ri_chunks = (int32_t)n_chunks;
+  c->ri_min = min;
+  c->ri_bytes = size;
+  c->has_range_index = true;
+  seg.plan_cache.clear();
+}
+
 void segment_set_queryable_doc_ids(Segment& seg, const void* roaring, uint64_t size) {
   std::shared_ptr<Column> col;
   if (size) col = bitmap_column(seg, "queryableDocIds", roaring, size);

@@ -60,6 +60,9 @@ class NativeSegment:
         nv = getattr(col, "null_vector", None)
         if nv is not None:
             self.api.call("segment_set_null_vector", self.handle, col.name.encode(), nv.ctypes.data, nv.nbytes)
+        ri = getattr(col, "range_index", None)
+        if ri is not None:
+            self.api.call("segment_set_range_index", self.handle, col.name.encode(), ri.ctypes.data, ri.nbytes)
 
     def set_queryable_doc_ids(self, doc_ids):
         """SegmentContext#getQueryableDocIdsSnapshot (upsert validDocIds): ascending docIds, or None to clear."""

@@ -307,6 +307,61 @@ def deserialize_roaring(blob: bytes) -> np.ndarray:
 # ----------------------------------------------------------------------------------------------------------------------
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# Bit-sliced range index: BitSlicedRangeIndexCreator (pinot-segment-local/.../creator/impl/inv/BitSlicedRangeIndexCreator.java
+# :38-133) = big-endian {int version 2, long min} + a RoaringBitmap `RangeBitmap` (third-party, little-endian; format restated
+# from the published RoaringBitmap 1.3.0 source, no fixture of it exists in the reference tree):
+#   u16 cookie 0xF00D, u8 base 2, u8 sliceCount, u16 maxKey (2^16-row chunks), u32 maxRid (rows), maxKey x mask[(sliceCount+7)/8],
+#   then per chunk and per slice present in its mask: u8 type (0 bitmap / 1 run / 2 array) + the container
+#   (bitmap: 8192 B; run: u16 n + n x (u16 start, u16 length-1); array: u16 n + n x u16).
+# Slice i holds the rows whose value has bit i CLEAR.  Values: dictIds (dictionary columns), value - min (raw INT / LONG),
+# FPOrdering.ordinalOf (FLOAT / DOUBLE).
+# ----------------------------------------------------------------------------------------------------------------------
+def fp_ordinal(values: np.ndarray) -> np.ndarray:
+    """FPOrdering.ordinalOf for float32 / float64 arrays -> uint64 with the same total (unsigned) order."""
+    if values.dtype == np.float32:
+        bits = values.view(np.uint32).astype(np.uint64)
+        sign, top, allm = np.uint64(0x80000000), np.uint64(0x80000000), np.uint64(0xFFFFFFFF)
+    else:
+        bits = values.astype(np.float64).view(np.uint64)
+        sign, top, allm = np.uint64(1 << 63), np.uint64(1 << 63), np.uint64(0xFFFFFFFFFFFFFFFF)
+    neg = (bits & sign) != 0
+    out = np.where(neg, np.where(bits == top, top, (~bits) & allm), bits ^ sign)
+    out = np.where(np.isposinf(values), allm, out)
+    out = np.where(np.isneginf(values) | np.isnan(values), np.uint64(0), out)
+    return out.astype(np.uint64)
+
+
+def write_range_index(stored: np.ndarray, min_value: int, max_stored: int) -> np.ndarray:
+    """`stored`: uint64 per-row values as the appender receives them (already minus min / ordinals); max_stored: the appender's
+    maxValue (cardinality - 1, max - min, 0xFFFFFFFF or 2^64 - 1)."""
+    stored = np.ascontiguousarray(stored, dtype=np.uint64)
+    n = int(stored.shape[0])
+    slice_count = max(1, int(max_stored).bit_length())       # 64 - numberOfLeadingZeros(maxValue | 1)
+    n_keys = (n + 65535) >> 16
+    bytes_per_mask = (slice_count + 7) >> 3
+    masks = bytearray()
+    containers = bytearray()
+    for key in range(n_keys):
+        chunk = stored[key << 16:(key + 1) << 16]
+        mask = 0
+        for i in range(slice_count):
+            rows = np.flatnonzero(((chunk >> np.uint64(i)) & np.uint64(1)) == 0).astype(np.uint16)
+            if rows.shape[0] == 0:
+                continue
+            mask |= 1 << i
+            kind, payload = _container_payload(rows, True)        # Container#runOptimize picks the smallest form
+            if kind == 1:
+                containers += b"\x00" + payload
+            elif kind == 2:
+                containers += b"\x01" + payload                   # payload starts with the u16 run count
+            else:
+                containers += b"\x02" + struct.pack("<H", int(rows.shape[0])) + payload
+        masks += int(mask).to_bytes(bytes_per_mask, "little")
+    blob = struct.pack(">iq", 2, int(min_value)) + struct.pack("<HBBHI", 0xF00D, 2, slice_count, n_keys, n) + bytes(masks) + bytes(containers)
+    return np.frombuffer(blob, dtype=np.uint8).copy()
+
+
 def write_inverted_index(dict_ids: np.ndarray, cardinality: int, run_compress: bool = True) -> np.ndarray:
     order = np.argsort(dict_ids, kind="stable")
     sorted_ids = dict_ids[order]

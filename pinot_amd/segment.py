@@ -31,6 +31,7 @@ class HostColumn:
     inverted_index: Optional[np.ndarray] = None
     dict_values: Optional[list] = None  # decoded dictionary (python objects / numpy scalars) for result decoding
     null_vector: Optional[np.ndarray] = None  # NullValueVectorReader: serialized RoaringBitmap of the null docIds (uint8 array)
+    range_index: Optional[np.ndarray] = None  # BitSlicedRangeIndexReader bytes (the column's `range_index` entry)
     _name_bytes: bytes = b""
 
     def desc(self) -> capi.PgColumnDesc:
@@ -65,6 +66,22 @@ class HostSegment:
                 if b is not None:
                     t += b.nbytes
         return t
+
+
+def add_range_index(col: HostColumn, values) -> HostColumn:
+    """BitSlicedRangeIndexCreator over the column: dictIds for dictionary columns, value - min for raw INT / LONG, FPOrdering
+    ordinals for raw FLOAT / DOUBLE (the creator's two constructors, BitSlicedRangeIndexCreator.java:55-75)."""
+    if col.has_dictionary:
+        ids = decode_column(col, len(values), dict_ids=True).astype(np.uint64)
+        col.range_index = formats.write_range_index(ids, 0, col.cardinality - 1)
+    elif col.data_type in ("INT", "LONG"):
+        v = np.asarray(values, dtype=np.int64)
+        mn, mx = (int(v.min()), int(v.max())) if len(v) else (0, 0)
+        col.range_index = formats.write_range_index((v - mn).astype(np.uint64), mn, mx - mn)
+    else:
+        v = np.asarray(values, dtype=NUMERIC_NP[col.data_type])
+        col.range_index = formats.write_range_index(formats.fp_ordinal(v), 0, 0xFFFFFFFF if col.data_type == "FLOAT" else (1 << 64) - 1)
+    return col
 
 
 def build_column(name: str, values, data_type: str, *, dictionary: bool = True, inverted: bool = False,
@@ -108,9 +125,10 @@ def build_column(name: str, values, data_type: str, *, dictionary: bool = True, 
 
 def build_segment(name: str, data: Dict[str, Sequence], schema: Dict[str, str], *,
                   inverted_index_columns: Iterable[str] = (), no_dictionary_columns: Iterable[str] = (),
-                  raw_version: int = 2, run_compress: bool = True) -> HostSegment:
+                  range_index_columns: Iterable[str] = (), raw_version: int = 2, run_compress: bool = True) -> HostSegment:
     inv = set(inverted_index_columns)
     nodict = set(no_dictionary_columns)
+    rng_cols = set(range_index_columns)
     total = None
     seg = HostSegment(name, 0)
     for col, dtype in schema.items():
@@ -120,6 +138,8 @@ def build_segment(name: str, data: Dict[str, Sequence], schema: Dict[str, str], 
         assert len(vals) == total, f"column {col}: {len(vals)} rows != {total}"
         seg.columns[col] = build_column(col, vals, dtype, dictionary=col not in nodict, inverted=col in inv,
                                         raw_version=raw_version, run_compress=run_compress)
+        if col in rng_cols:
+            add_range_index(seg.columns[col], vals)
     seg.total_docs = int(total or 0)
     return seg
 

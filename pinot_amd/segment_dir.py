@@ -201,6 +201,9 @@ def load_segment_dir(path: str) -> HostSegment:
 
     for name, col in seg.columns.items():   # StandardIndexes.NULL_VALUE_VECTOR_ID: one RoaringBitmap of the null docIds
         col.null_vector = entry(name, "nullvalue_vector")
+        ri = entry(name, "range_index")   # StandardIndexes.RANGE_ID; only the exact bit-sliced index (BitSlicedRangeIndexCreator.VERSION = 2)
+        if ri is not None and len(ri) >= 4 and int.from_bytes(bytes(ri[:4]), "big") == 2:
+            col.range_index = ri
 
     n_trees = int(props.get("startree.v2.count", ["0"])[0])
     if n_trees and os.path.exists(os.path.join(path, STAR_TREE_INDEX_FILE)):
@@ -248,6 +251,7 @@ def write_segment_dir(seg: HostSegment, path: str, padding: str = "\0") -> None:
         put(name, "forward_index", c.forward_index)
         put(name, "inverted_index", c.inverted_index)
         put(name, "nullvalue_vector", c.null_vector)
+        put(name, "range_index", getattr(c, "range_index", None))
         p = f"column.{name}."
         meta += [p + f"cardinality = {c.cardinality}", p + f"totalDocs = {seg.total_docs}",
                  p + f"dataType = {c.data_type}", p + f"bitsPerElement = {c.bits_per_value}",

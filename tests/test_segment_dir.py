@@ -102,10 +102,11 @@ def test_gpu_queries_a_loaded_v3_segment_dir(tmp_path, gpu_api, oracle_api):
             "f": rng.random(n).astype(np.float32), "d": rng.normal(0, 10, n)}
     host = build_segment("rt", {k: (v.tolist() if v.dtype.kind == "U" else v) for k, v in data.items()},
                          {"a": "INT", "s": "STRING", "t": "INT", "raw.m": "LONG", "f": "FLOAT", "d": "DOUBLE"},
-                         inverted_index_columns=["a", "s"], no_dictionary_columns=["raw.m", "d"])
+                         inverted_index_columns=["a", "s"], no_dictionary_columns=["raw.m", "d"], range_index_columns=["raw.m", "f"])
     segment_dir.write_segment_dir(host, str(tmp_path / "rt"))
     back = segment_dir.load_segment_dir(str(tmp_path / "rt"))
     assert not back.skipped
+    assert back.columns["raw.m"].range_index is not None and back.columns["f"].range_index is not None and back.columns["a"].range_index is None
     g, o = NativeSegment(gpu_api, back), NativeSegment(oracle_api, back)
     import math
     for q in ("SELECT s, COUNT(*), SUM(a), MAX(f) FROM rt WHERE a IN (1, 2, 3, 40) AND t > 4 GROUP BY s",
