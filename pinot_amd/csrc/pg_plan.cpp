@@ -117,6 +117,8 @@ PredEval make_pred_eval(const pg_filter_node& p, const Column& col) {
   e.data_type = col.data_type;
   const bool is_range = p.predicate_type == PG_PRED_RANGE;
   if (!is_range && (p.n_values < 1 || !p.values)) fail(PG_ERR_INVALID_ARGUMENT, "predicate on %s has no value", col.name.c_str());
+  for (int i = 0; !is_range && i < p.n_values; i++)
+    if (!p.values[i]) fail(PG_ERR_INVALID_ARGUMENT, "predicate on %s: value %d is null", col.name.c_str(), i);
   if (is_range && (!p.lower || !p.upper)) fail(PG_ERR_INVALID_ARGUMENT, "range predicate on %s without bounds", col.name.c_str());
   if (col.has_dictionary) {
     e.dictionary_based = true;
@@ -662,30 +664,42 @@ struct Emitter {
 // =====================================================================================================================
 // signature (plan cache key)
 // =====================================================================================================================
+// Every string goes in with its length, so that no two queries share a signature ("a,b" / "c" vs "a" / "b,c" as range bounds);
+// NULL strings are legal here (validation happens in compile_plan) and get their own marker.
+static void sig_str(std::ostringstream& o, const char* s) {
+  if (!s) { o << "~;"; return; }
+  o << strlen(s) << "'" << s << ";";
+}
 static void sig_filter(std::ostringstream& o, const pg_filter_node* f) {
   if (!f) { o << "*"; return; }
   o << "(" << f->type;
   if (f->type == PG_FILTER_PREDICATE) {
-    o << ":" << f->predicate_type << ":" << (f->column ? f->column : "") << ":";
-    if (f->predicate_type == PG_PRED_RANGE)
-      o << (f->lower_inclusive ? "[" : "(") << (f->lower ? f->lower : "") << "," << (f->upper ? f->upper : "")
-        << (f->upper_inclusive ? "]" : ")");
-    else
-      for (int i = 0; i < f->n_values; i++) o << strlen(f->values[i]) << "'" << f->values[i] << ",";
+    o << ":" << f->predicate_type << ":";
+    sig_str(o, f->column);
+    if (f->predicate_type == PG_PRED_RANGE) {
+      o << (f->lower_inclusive ? "[" : "(");
+      sig_str(o, f->lower);
+      sig_str(o, f->upper);
+      o << (f->upper_inclusive ? "]" : ")");
+    } else {
+      o << f->n_values << ":";
+      for (int i = 0; i < f->n_values && f->values; i++) sig_str(o, f->values[i]);
+    }
   }
-  for (int i = 0; i < f->n_children; i++) sig_filter(o, &f->children[i]);
+  for (int i = 0; i < f->n_children && f->children; i++) sig_filter(o, &f->children[i]);
   o << ")";
 }
 std::string query_signature(const pg_filter_node* filter, const pg_query* q) {
   std::ostringstream o;
   sig_filter(o, filter);
   if (q) {
-    o << "|g";
-    for (int i = 0; i < q->n_group_by; i++) o << ":" << q->group_by_columns[i];
-    o << "|a";
-    for (int i = 0; i < q->n_aggregations; i++)
-      o << ":" << q->aggregations[i].function << "," << (q->aggregations[i].column ? q->aggregations[i].column : "*") << ","
-        << q->aggregations[i].log2m;
+    o << "|g" << q->n_group_by << ":";
+    for (int i = 0; i < q->n_group_by && q->group_by_columns; i++) sig_str(o, q->group_by_columns[i]);
+    o << "|a" << q->n_aggregations << ":";
+    for (int i = 0; i < q->n_aggregations && q->aggregations; i++) {
+      o << q->aggregations[i].function << "," << q->aggregations[i].log2m << ",";
+      sig_str(o, q->aggregations[i].column ? q->aggregations[i].column : "*");
+    }
     o << "|" << q->num_groups_limit << "," << q->max_initial_result_holder_capacity << "," << (q->flags & PG_QUERY_FLAG_SKIP_STAR_TREE);
   } else {
     o << "|filter-only";
@@ -873,7 +887,21 @@ std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* f
     both.push_back(bitmap_operator(seg.queryable_doc_ids, false));
     root = and_operator(std::move(both));
   }
-  if (q && q->n_aggregations > 0 && q->aggregations && !(q->flags & PG_QUERY_FLAG_SKIP_STAR_TREE) && !seg.star_trees.empty() &&
+  // AggregationPlanNode#buildNonFilteredAggOperator (:97-127): FastFilteredCountOperator, then NonScanBasedAggregationOperator, then
+  // the star-trees — a match-all MIN / MAX / DISTINCTCOUNT(HLL) over dictionary columns is answered from the dictionaries even when a
+  // star-tree holds the pair (same values; numDocsScanned / star-tree statistics follow the reference)
+  bool non_scan_fit = q && q->n_aggregations > 0 && q->aggregations && q->n_group_by == 0 && root->kind == OpKind::MatchAll &&
+                      !(q->n_aggregations == 1 && q->aggregations[0].function == PG_AGG_COUNT);
+  for (int i = 0; non_scan_fit && i < q->n_aggregations; i++) {
+    const pg_agg_spec& a = q->aggregations[i];
+    if (a.function == PG_AGG_COUNT) continue;
+    Column* c = seg.find(a.column);
+    const bool dict_fn = a.function == PG_AGG_MIN || a.function == PG_AGG_MAX || a.function == PG_AGG_MINMAXRANGE ||
+                         a.function == PG_AGG_DISTINCTCOUNT || a.function == PG_AGG_DISTINCTCOUNTHLL;
+    non_scan_fit = c && dict_fn && c->has_dictionary &&
+                   (c->data_type <= PG_TYPE_DOUBLE || a.function == PG_AGG_DISTINCTCOUNT || a.function == PG_AGG_DISTINCTCOUNTHLL);
+  }
+  if (!non_scan_fit && q && q->n_aggregations > 0 && q->aggregations && !(q->flags & PG_QUERY_FLAG_SKIP_STAR_TREE) && !seg.star_trees.empty() &&
       root->kind != OpKind::Empty) {
     const bool fast_count = q->n_group_by == 0 && q->n_aggregations == 1 && q->aggregations[0].function == PG_AGG_COUNT &&
                             can_optimize_count(*root);
@@ -1066,6 +1094,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
   int64_t G = 1;
   bool huge_key_space = false;
   for (int j = 0; j < q->n_group_by; j++) {
+    if (!q->group_by_columns) fail(PG_ERR_INVALID_ARGUMENT, "group_by_columns is null");
     Column* c = seg.find(q->group_by_columns[j]);
     if (!c) fail(PG_ERR_NOT_FOUND, "column not found: %s", q->group_by_columns[j] ? q->group_by_columns[j] : "(null)");
     if (!c->has_dictionary) {

@@ -329,19 +329,33 @@ void segment_add_column(Segment& seg, const pg_column_desc& d) {
 
   if (c.fwd_encoding == PG_FWD_DICT_FIXED_BIT) {
     if (c.bits < 1 || c.bits > 31) fail(PG_ERR_INVALID_ARGUMENT, "column %s: bits_per_value %d", d.name, c.bits);
+    if (!c.has_dictionary || c.cardinality <= 0) fail(PG_ERR_INVALID_ARGUMENT, "column %s: a fixed-bit forward index needs a dictionary (cardinality %d)", d.name, c.cardinality);
+    if (c.bits < 31 && ((int64_t)1 << c.bits) < (int64_t)c.cardinality)
+      fail(PG_ERR_INVALID_ARGUMENT, "column %s: %d bits per value cannot hold %d dictIds", d.name, c.bits, c.cardinality);
     upload_fixed_bit(seg, c, fwd, fwd_len);
   } else if (c.fwd_encoding == PG_FWD_DICT_SORTED) {
+    // SortedIndexReaderImpl: 2 big-endian ints (startDocId, endDocId inclusive) per dictId.  The pairs come from a file: every one is
+    // checked (inside the segment, ascending, disjoint) before anything is expanded from them.
+    if (!c.has_dictionary || c.cardinality <= 0) fail(PG_ERR_INVALID_ARGUMENT, "sorted index of %s needs a dictionary (cardinality %d)", d.name, c.cardinality);
     if (fwd_len < (uint64_t)c.cardinality * 8) fail(PG_ERR_INVALID_ARGUMENT, "sorted index of %s too short", d.name);
     c.sorted_start.resize((size_t)c.cardinality);
     c.sorted_end.resize((size_t)c.cardinality);
+    int64_t prev_end = -1;
     for (int32_t i = 0; i < c.cardinality; i++) {
-      c.sorted_start[i] = (int32_t)be32(fwd + (size_t)i * 8);
-      c.sorted_end[i] = (int32_t)be32(fwd + (size_t)i * 8 + 4);
+      const int32_t st = (int32_t)be32(fwd + (size_t)i * 8), en = (int32_t)be32(fwd + (size_t)i * 8 + 4);
+      if (st < 0 || en < st || en >= seg.total_docs || (int64_t)st <= prev_end)
+        fail(PG_ERR_INVALID_ARGUMENT, "sorted index of %s: dictId %d has the doc range [%d, %d] (segment of %d docs, previous range ends at %lld)",
+             d.name, i, st, en, seg.total_docs, (long long)prev_end);
+      c.sorted_start[(size_t)i] = st;
+      c.sorted_end[(size_t)i] = en;
+      prev_end = en;
     }
     // expand to the fixed-bit layout so that projection / group-by see one dictionary-column encoding
-    if (c.bits < 1) {
-      int32_t mv = c.cardinality - 1;
-      c.bits = mv <= 1 ? 1 : 32 - __builtin_clz((uint32_t)mv);
+    {
+      const int32_t mv = c.cardinality - 1;
+      const int32_t need_bits = mv <= 1 ? 1 : 32 - __builtin_clz((uint32_t)mv);   // PinotDataBitSet.getNumBitsPerValue(cardinality - 1)
+      if (c.bits < 1) c.bits = need_bits;
+      if (c.bits > 31 || c.bits < need_bits) fail(PG_ERR_INVALID_ARGUMENT, "column %s: bits_per_value %d cannot hold dictIds up to %d", d.name, c.bits, mv);
     }
     size_t nbytes = ((size_t)seg.total_docs * (size_t)c.bits + 7) / 8;
     std::vector<uint8_t> packed(nbytes + 8, 0);

@@ -488,3 +488,54 @@ def test_hashed_group_by_matches_oracle(gpu_api, oracle_api, q, limit):
     assert gb.stats.num_groups_limit_reached == ob.stats.num_groups_limit_reached
     g.destroy()
     o.destroy()
+
+
+# ---- robustness of the boundary (round-1 advisor findings) ------------------------------------------------------------------------
+def test_corrupt_sorted_index_is_refused(gpu_api):
+    """SortedIndexReaderImpl pairs come from a file: a range outside the segment, descending or overlapping ranges, and a
+    bits_per_value too small for the cardinality return PG_ERR_INVALID_ARGUMENT instead of writing past a host buffer."""
+    import ctypes as C
+    from pinot_amd import capi
+    n = 5000
+    vals = np.sort(np.random.default_rng(1).integers(0, 20, n)).astype(np.int32)
+    host = build_segment("s", {"t": vals}, {"t": "INT"})
+    col = host.columns["t"]
+    assert col.fwd_encoding == capi.FWD_DICT_SORTED
+    good = col.forward_index.copy()
+    pairs = np.frombuffer(bytes(good), dtype=">i4").reshape(-1, 2).copy()
+    cases = []
+    p = pairs.copy(); p[3, 1] = n + 100; cases.append(p)           # end beyond the segment
+    p = pairs.copy(); p[2, 0] = -5; cases.append(p)                # negative start
+    p = pairs.copy(); p[5, 0] = p[4, 0]; cases.append(p)           # overlaps the previous range
+    p = pairs.copy(); p[6] = p[6][::-1]; cases.append(p)           # end < start
+    for p in cases:
+        col.forward_index = np.frombuffer(p.astype(">i4").tobytes(), dtype=np.uint8).copy()
+        with pytest.raises(capi.NativeError) as e:
+            NativeSegment(gpu_api, host)
+        assert e.value.status == capi.PG_ERR_INVALID_ARGUMENT and "sorted index" in e.value.message
+    col.forward_index = good
+    col.bits_per_value = 2                                         # 20 dictIds do not fit 2 bits
+    with pytest.raises(capi.NativeError) as e:
+        NativeSegment(gpu_api, host)
+    assert e.value.status == capi.PG_ERR_INVALID_ARGUMENT
+    col.bits_per_value = 5
+    seg = NativeSegment(gpu_api, host)
+    assert seg.execute("SELECT COUNT(*) FROM s WHERE t < 7").aggregation_result()[0] == int((vals < 7).sum())
+    seg.destroy()
+
+
+def test_plan_cache_keys_do_not_collide(gpu_api, oracle_api):
+    """two range queries whose bounds concatenate to the same text ("a,b" / "c" vs "a" / "b,c") must not share a cached plan"""
+    rng = np.random.default_rng(4)
+    words = ["a", "a,b", "a,c", "b", "b,c", "c", "d"]
+    data = {"s": rng.choice(words, 20_000), "g": rng.integers(0, 3, 20_000).astype(np.int32)}
+    host = build_segment("k", {"s": data["s"].tolist(), "g": data["g"]}, {"s": "STRING", "g": "INT"})
+    g, o = both(gpu_api, oracle_api, host)
+    q1 = "SELECT g, COUNT(*) FROM k WHERE s BETWEEN 'a,b' AND 'c' GROUP BY g"
+    q2 = "SELECT g, COUNT(*) FROM k WHERE s BETWEEN 'a' AND 'b,c' GROUP BY g"
+    r1, r2 = g.execute(q1), g.execute(q2)
+    assert_same_block(r1, o.execute(q1))
+    assert_same_block(r2, o.execute(q2))
+    assert r1.rows() != r2.rows()
+    g.destroy()
+    o.destroy()

@@ -107,3 +107,23 @@ def test_star_tree_registration_errors(gpu_api):
     seg.add_star_tree(st)
     assert seg.execute("SELECT COUNT(*), MAX(ArrDelay) FROM t").stats.star_tree_index == 0
     seg.destroy()
+
+
+def test_non_scan_based_operator_precedes_the_star_tree(gpu_api, oracle_api):
+    """AggregationPlanNode#buildNonFilteredAggOperator (:97-127): FastFilteredCount, then NonScanBasedAggregationOperator, then the
+    star-trees.  A match-all DISTINCTCOUNTHLL / MIN / MAX over dictionary columns is answered from the dictionaries even though the
+    star-tree holds distinctCountHLL__u: values and ExecutionStatistics (numDocsScanned = totalDocs, no star-tree) follow the oracle."""
+    host = synth_star_segment(40_000, max_leaf_records=64, skip=("h3",))
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    for sql in ("SELECT DISTINCTCOUNTHLL(u), COUNT(*) FROM gpuBench", "SELECT MIN(h1), MAX(h4), DISTINCTCOUNT(h2) FROM gpuBench",
+                "SELECT DISTINCTCOUNTHLL(u) FROM gpuBench WHERE h1 >= 0"):
+        gb, ob = g.execute(sql), o.execute(sql)
+        assert gb.stats.star_tree_index == ob.stats.star_tree_index == -1, sql
+        assert_same(gb, ob)
+    # with a real filter the star-tree answers
+    sql = "SELECT DISTINCTCOUNTHLL(u), COUNT(*) FROM gpuBench WHERE h2 = 3"
+    gb, ob = g.execute(sql), o.execute(sql)
+    assert gb.stats.star_tree_index == ob.stats.star_tree_index == 0
+    assert_same(gb, ob)
+    g.destroy()
+    o.destroy()
