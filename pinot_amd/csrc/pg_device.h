@@ -279,6 +279,19 @@ struct PgQueryPlan {
   PgValueSrc srcs[PG_MAX_SRCS];
   PgAccOp ops[PG_MAX_OPS];
   int64_t* partials;                // LDS/SINGLE mode: [gridDim][n_ops][G]; GLOBAL mode: [n_ops][G]
+  // Fused dense index program (pg_fast_i32range_d): the whole index-only program is an AND of up to 4 groups, each the OR of dense
+  // bitmap postings (base + 8 KB x chunk; optionally complemented: NOT_IN / NOT_EQ) — 8 pointers in all, unused slots repeat a
+  // pointer of their group.  One load per pointer and tile, issued one tile ahead.
+  int32_t dense_fused;              // 1: dense_ptr / dense_group describe the index program
+  int32_t dense_groups;             // number of AND-ed groups (1..4)
+  int32_t dense_excl;               // bit g: group g is complemented
+  int32_t dense_pad;
+  const uint8_t* dense_ptr[8];
+  int32_t dense_group[8];
+  // pg_fast_i32range_p (pg_kernels_pipe.hip): dense_fused, one or two <= 8-bit group columns and every value accumulator over ONE raw
+  // 32-bit column (srcs[pipe_src])
+  int32_t pipe_fit;
+  int32_t pipe_src;
 };
 
 #if defined(__HIPCC__)

@@ -16,6 +16,8 @@ PG_DECL_GENERIC
 PG_DECL_FAST(pg_fast_none_f) PG_DECL_FAST(pg_fast_none_a) PG_DECL_FAST(pg_fast_i32range_f) PG_DECL_FAST(pg_fast_i32range_a)
 PG_DECL_FAST(pg_fast_dictrange_f) PG_DECL_FAST(pg_fast_dictrange_a) PG_DECL_FAST(pg_fast_dictlut_f) PG_DECL_FAST(pg_fast_dictlut_a)
 PG_DECL_FAST(pg_fast_multi_f) PG_DECL_FAST(pg_fast_multi_a) PG_DECL_FAST(pg_fast_multi_w) PG_DECL_FAST(pg_fast_none_w)
+PG_DECL_FAST(pg_fast_i32range_d) PG_DECL_FAST(pg_fast_i32range_p)
+extern "C" const int pg_pipe_waves_per_block;   // pg_kernels_pipe.hip: wavefronts per workgroup of pg_fast_i32range_p
 PG_DECL_FAST(pg_fast_multi_wd) PG_DECL_FAST(pg_fast_none_wd) PG_DECL_FAST(pg_generic_query_ld) PG_DECL_FAST(pg_generic_query_gd)
 extern "C" __global__ void pg_reduce_partials_kernel(const int64_t* partials, int64_t* out, int n_wg, int n_ops,
                                                      int n_groups, const PgAccOp* ops, unsigned long long* stats, int reduce);
@@ -115,7 +117,7 @@ void use_device(int ordinal) {
       // opt in to large dynamic LDS for the query kernels (function attributes are per device)
       typedef void (*QueryKernel)(const PgQueryPlan);
       const QueryKernel all[] = {pg_generic_query_f, pg_generic_query_l, pg_generic_query_g, pg_fast_none_f, pg_fast_none_a, pg_fast_i32range_f, pg_fast_i32range_a,
-                                 pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a, pg_fast_multi_f, pg_fast_multi_a, pg_fast_multi_w, pg_fast_none_w, pg_fast_multi_wd, pg_fast_none_wd, pg_generic_query_ld, pg_generic_query_gd,
+                                 pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a, pg_fast_multi_f, pg_fast_multi_a, pg_fast_multi_w, pg_fast_none_w, pg_fast_multi_wd, pg_fast_none_wd, pg_generic_query_ld, pg_generic_query_gd, pg_fast_i32range_d, pg_fast_i32range_p,
                                  pg_radix_aggregate_kernel, pg_hash_aggregate_kernel};
       for (QueryKernel k : all)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
@@ -149,7 +151,13 @@ static bool uses_fast_kernel(const CompiledPlan& P, int agg_mode) {
   return P.fast_filter != -2 && (!agg || ((P.fast_agg || P.wide_agg) && agg_mode != PG_AGG_GLOBAL));
 }
 
-// Kernel selection: the specialised fast kernels when both the filter and the aggregation have the fast shape.
+// pg_fast_i32range_p (software-pipelined headline shape, pg_kernels_pipe.hip): its own workgroup size
+static bool uses_pipe_kernel(const CompiledPlan& P, int agg_mode) {
+  static const bool no_pipe = getenv("PG_NO_PIPE") != nullptr || getenv("PG_NO_DENSE_FUSED") != nullptr;   // measurement knob
+  return !no_pipe && uses_fast_kernel(P, agg_mode) && agg_mode == PG_AGG_LDS && !P.wide_agg && P.fast_agg && P.fast_filter == 4 &&
+         P.dev.dense_fused && P.dev.pipe_fit;
+}
+
 typedef void (*QueryKernel)(const PgQueryPlan);
 static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char** name) {
   const bool agg = agg_mode != PG_AGG_NONE;
@@ -159,6 +167,9 @@ static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char
       *name = P.digit_ops ? "pg_fast_multi_wd" : "pg_fast_multi_w";
       return P.digit_ops ? pg_fast_multi_wd : pg_fast_multi_w;
     }
+    static const bool no_dense = getenv("PG_NO_DENSE_FUSED") != nullptr;   // measurement knobs
+    if (uses_pipe_kernel(P, agg_mode)) { *name = "pg_fast_i32range_p"; return pg_fast_i32range_p; }
+    if (agg && P.fast_filter == 4 && P.dev.dense_fused && !no_dense && P.fast_agg && agg_mode == PG_AGG_LDS) { *name = "pg_fast_i32range_d"; return pg_fast_i32range_d; }
     switch (P.fast_filter) {
       case -1: *name = agg ? "pg_fast_none_a" : "pg_fast_none_f"; return agg ? pg_fast_none_a : pg_fast_none_f;
       case 4: *name = agg ? "pg_fast_i32range_a" : "pg_fast_i32range_f"; return agg ? pg_fast_i32range_a : pg_fast_i32range_f;
@@ -248,6 +259,13 @@ static LaunchShape launch_shape(const CompiledPlan& P, int n_wtiles, int agg_mod
     int per_xcd = std::max(num_cus() / 8, 1);
     per_xcd = std::max(per_xcd / P.dev.n_parts, 1) * P.dev.n_parts;
     return {8 * per_xcd, uses_fast_kernel(P, agg_mode) ? PG_BLOCK : PG_GENERIC_BLOCK, lds};
+  }
+  if (uses_pipe_kernel(P, agg_mode)) {
+    static const int wgs_per_cu = getenv("PG_PIPE_WGS_PER_CU") ? atoi(getenv("PG_PIPE_WGS_PER_CU")) : 1;   // tuning knob
+    const int per_cu = ((size_t)wgs_per_cu * (lds + 4096) <= lds_per_cu()) ? wgs_per_cu : 1;
+    const int waves = pg_pipe_waves_per_block;
+    int grid = std::min((n_wtiles + waves - 1) / waves, num_cus() * per_cu);
+    return {std::max(grid, 1), waves * 64, lds};
   }
   if (uses_fast_kernel(P, agg_mode)) {
     // one 16-wave workgroup per CU; fewer when the segment has fewer wave tiles than that

@@ -24,6 +24,12 @@
 #include "pg_fixed_point.h"
 
 #define DEVFN __device__ __forceinline__
+// Kernels are exported with C linkage.  pg_kernels_dense.hip includes this file with PG_KERNEL = static to reuse the device code in a
+// translation unit of its own: the register allocation of the kernels at the 128-VGPR limit turned out to depend on which other
+// kernels share their translation unit (adding pg_fast_i32range_d here put 16 bytes of scratch into pg_fast_i32range_a).
+#ifndef PG_KERNEL
+#define PG_KERNEL extern "C"
+#endif
 #ifndef PG_FAST_AGG_B
 #define PG_FAST_AGG_B 4
 #endif
@@ -1342,16 +1348,16 @@ __device__ __forceinline__ void fast_multi_body(const PgQueryPlan& p) {
   __syncthreads();
   flush_workgroup(p, lds_table, s_stat, AGG && p.agg_mode != PG_AGG_NONE, t);
 }
-extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_fast_multi_f(const PgQueryPlan p) { fast_multi_body<0>(p); }
-extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_fast_multi_a(const PgQueryPlan p) { fast_multi_body<1>(p); }
-extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_fast_multi_w(const PgQueryPlan p) { fast_multi_body<2>(p); }
-extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_fast_multi_wd(const PgQueryPlan p) { fast_multi_body<3>(p); }
+PG_KERNEL __global__ void __launch_bounds__(PG_BLOCK) pg_fast_multi_f(const PgQueryPlan p) { fast_multi_body<0>(p); }
+PG_KERNEL __global__ void __launch_bounds__(PG_BLOCK) pg_fast_multi_a(const PgQueryPlan p) { fast_multi_body<1>(p); }
+PG_KERNEL __global__ void __launch_bounds__(PG_BLOCK) pg_fast_multi_w(const PgQueryPlan p) { fast_multi_body<2>(p); }
+PG_KERNEL __global__ void __launch_bounds__(PG_BLOCK) pg_fast_multi_wd(const PgQueryPlan p) { fast_multi_body<3>(p); }
 
 #ifndef PG_FAST_MIN_WAVES_PER_SIMD
 #define PG_FAST_MIN_WAVES_PER_SIMD 1   // measurement knob: 8 asks for <= 64 VGPRs (two 1024-thread workgroups per CU)
 #endif
 #define PG_FAST_KERNEL(NAME, SK, AGG) \
-  extern "C" __global__ void __launch_bounds__(PG_BLOCK, PG_FAST_MIN_WAVES_PER_SIMD) NAME(const PgQueryPlan p) { fast_query_body<SK, AGG>(p); }
+  PG_KERNEL __global__ void __launch_bounds__(PG_BLOCK, PG_FAST_MIN_WAVES_PER_SIMD) NAME(const PgQueryPlan p) { fast_query_body<SK, AGG>(p); }
 PG_FAST_KERNEL(pg_fast_none_f, -1, 0)
 PG_FAST_KERNEL(pg_fast_none_a, -1, 1)
 PG_FAST_KERNEL(pg_fast_none_w, -1, 2)
@@ -1533,17 +1539,17 @@ __device__ __forceinline__ void generic_query_body(const PgQueryPlan& p) {
         for (int64_t i = t; i < p.aux[x].rep_bytes / 4; i += PG_GENERIC_BLOCK) dst[i] = src[i];
       }
 }
-extern "C" __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_generic_query_f(const PgQueryPlan p) { generic_query_body<0>(p); }
-extern "C" __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_generic_query_l(const PgQueryPlan p) { generic_query_body<1>(p); }
-extern "C" __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_generic_query_g(const PgQueryPlan p) { generic_query_body<2>(p); }
-extern "C" __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_generic_query_ld(const PgQueryPlan p) { generic_query_body<1, true>(p); }
-extern "C" __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_generic_query_gd(const PgQueryPlan p) { generic_query_body<2, true>(p); }
+PG_KERNEL __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_generic_query_f(const PgQueryPlan p) { generic_query_body<0>(p); }
+PG_KERNEL __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_generic_query_l(const PgQueryPlan p) { generic_query_body<1>(p); }
+PG_KERNEL __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_generic_query_g(const PgQueryPlan p) { generic_query_body<2>(p); }
+PG_KERNEL __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_generic_query_ld(const PgQueryPlan p) { generic_query_body<1, true>(p); }
+PG_KERNEL __global__ void __launch_bounds__(PG_GENERIC_BLOCK) pg_generic_query_gd(const PgQueryPlan p) { generic_query_body<2, true>(p); }
 
 // Combines the per-workgroup partial tables: out[op][g].  One wavefront per output slot, lanes stride over the
 // workgroups, fixed butterfly order (deterministic also for floating sums).  The last block also moves the statistics
 // counters behind the table (out[n_out .. n_out+PG_MAX_STATS)) and re-zeroes them for the next query on this stream, so
 // that one device→host copy returns everything.
-extern "C" __global__ void __launch_bounds__(256) pg_reduce_partials_kernel(const int64_t* __restrict__ partials,
+PG_KERNEL __global__ void __launch_bounds__(256) pg_reduce_partials_kernel(const int64_t* __restrict__ partials,
                                                                              int64_t* __restrict__ out, int n_wg,
                                                                              int n_ops, int n_groups,
                                                                              const PgAccOp* __restrict__ ops,
@@ -1943,10 +1949,10 @@ __device__ __forceinline__ void radix_pass_body(const PgQueryPlan& p) {
     for (int i = t; i < P; i += PG_BLOCK) p.radix_hist[(int64_t)blockIdx.x * P + i] = s_cnt[i];
   }
 }
-extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_count_kernel(const PgQueryPlan p) { radix_pass_body<1, false>(p); }
-extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_scatter_kernel(const PgQueryPlan p) { radix_pass_body<2, false>(p); }
-extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_hash_count_kernel(const PgQueryPlan p) { radix_pass_body<1, true>(p); }
-extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_hash_scatter_kernel(const PgQueryPlan p) { radix_pass_body<2, true>(p); }
+PG_KERNEL __global__ void __launch_bounds__(PG_BLOCK) pg_radix_count_kernel(const PgQueryPlan p) { radix_pass_body<1, false>(p); }
+PG_KERNEL __global__ void __launch_bounds__(PG_BLOCK) pg_radix_scatter_kernel(const PgQueryPlan p) { radix_pass_body<2, false>(p); }
+PG_KERNEL __global__ void __launch_bounds__(PG_BLOCK) pg_hash_count_kernel(const PgQueryPlan p) { radix_pass_body<1, true>(p); }
+PG_KERNEL __global__ void __launch_bounds__(PG_BLOCK) pg_hash_scatter_kernel(const PgQueryPlan p) { radix_pass_body<2, true>(p); }
 
 // =====================================================================================================================
 // Packed radix tuples (PgQueryPlan::radix_packed): when everything the aggregation pass needs from a doc fits 32 bits — the local key
@@ -2050,7 +2056,7 @@ DEVFN void packed_emit(const PackedStage& S, const bool (&active)[N], const uint
 // payload of one source for a doc: (register index | rank << log2m) of the value a DISTINCTCOUNTHLL offers, or the dictId
 DEVFN uint32_t packed_hll_payload(uint32_t index_rank, int log2m) { return (index_rank & 0xFFFFu) | ((index_rank >> 16) << log2m); }
 
-extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_scatter_packed_kernel(const PgQueryPlan p) {
+PG_KERNEL __global__ void __launch_bounds__(PG_BLOCK) pg_radix_scatter_packed_kernel(const PgQueryPlan p) {
   extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
   __shared__ uint32_t s_cnt[64];
   __shared__ uint32_t s_base[64];
@@ -2163,7 +2169,7 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_scatter_packed_k
 }
 
 // Aggregation pass over packed tuples: work item w = bucket * slices + slice, as pg_radix_aggregate_kernel; four tuples per 16-byte load.
-extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_aggregate_packed_kernel(const PgQueryPlan p) {
+PG_KERNEL __global__ void __launch_bounds__(PG_BLOCK) pg_radix_aggregate_packed_kernel(const PgQueryPlan p) {
   extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
   int64_t* table = reinterpret_cast<int64_t*>(smem);
   const int t = threadIdx.x;
@@ -2245,7 +2251,7 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_aggregate_packed
 // compare-and-swap (linear probing), accumulators [n_ops][cap] updated with LDS atomics — whose occupied slots are then appended
 // to the result (one global atomic per wavefront).  A bucket with more distinct keys than slots raises the overflow flag.
 #define PG_HASH_MAX_ITERS 16   // hash_cap <= 16 384 slots = 16 sweeps of the 1024-thread workgroup
-extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_hash_aggregate_kernel(const PgQueryPlan p) {
+PG_KERNEL __global__ void __launch_bounds__(PG_BLOCK) pg_hash_aggregate_kernel(const PgQueryPlan p) {
   extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
   __shared__ uint32_t s_local;
   __shared__ unsigned long long s_gbase;
@@ -2336,7 +2342,7 @@ DEVFN uint32_t radix_capacity(uint32_t c, int stage, int waves) {
   if (stage <= 0 || c == 0) return c;
   return (c / (uint32_t)stage + (uint32_t)waves) * (uint32_t)stage;
 }
-extern "C" __global__ void __launch_bounds__(1024) pg_radix_offsets_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ bucket_total,
+PG_KERNEL __global__ void __launch_bounds__(1024) pg_radix_offsets_kernel(uint32_t* __restrict__ hist, uint32_t* __restrict__ bucket_total,
                                                                            int n_wg, int n_buckets, int stage, int stage_waves) {
   const int lane = threadIdx.x & 63;
   const int b = (int)blockIdx.x * 16 + (int)(threadIdx.x >> 6);
@@ -2367,7 +2373,7 @@ extern "C" __global__ void __launch_bounds__(1024) pg_radix_offsets_kernel(uint3
   }
   if (lane == 0) bucket_total[b] = run_total;
 }
-extern "C" __global__ void __launch_bounds__(64) pg_radix_bucket_scan_kernel(const uint32_t* __restrict__ bucket_total,
+PG_KERNEL __global__ void __launch_bounds__(64) pg_radix_bucket_scan_kernel(const uint32_t* __restrict__ bucket_total,
                                                                              uint32_t* __restrict__ bucket_start, int n_buckets) {
   const int lane = threadIdx.x;
   const int per_lane = (n_buckets + 63) / 64;
@@ -2392,7 +2398,7 @@ extern "C" __global__ void __launch_bounds__(64) pg_radix_bucket_scan_kernel(con
 
 // Per-bucket aggregation: work item w = bucket * slices + slice aggregates its share of the bucket's tuples into an LDS table
 // [n_ops][2^radix_shift] and flushes it to partials[w].
-extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_aggregate_kernel(const PgQueryPlan p) {
+PG_KERNEL __global__ void __launch_bounds__(PG_BLOCK) pg_radix_aggregate_kernel(const PgQueryPlan p) {
   extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
   int64_t* table = reinterpret_cast<int64_t*>(smem);
   const int t = threadIdx.x;
@@ -2487,7 +2493,7 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_radix_aggregate_kernel
 }
 
 // registers of group g = bytewise max over the slices of g's bucket
-extern "C" __global__ void __launch_bounds__(256) pg_radix_reduce_aux_kernel(const uint32_t* __restrict__ partials, uint32_t* __restrict__ out,
+PG_KERNEL __global__ void __launch_bounds__(256) pg_radix_reduce_aux_kernel(const uint32_t* __restrict__ partials, uint32_t* __restrict__ out,
                                                                               int slices, int64_t bucket_words, int64_t n_words) {
   const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= n_words) return;
@@ -2498,7 +2504,7 @@ extern "C" __global__ void __launch_bounds__(256) pg_radix_reduce_aux_kernel(con
 }
 
 // out[op][g] = combine over the slices of g's bucket
-extern "C" __global__ void __launch_bounds__(256) pg_radix_reduce_kernel(const int64_t* __restrict__ partials, int64_t* __restrict__ out,
+PG_KERNEL __global__ void __launch_bounds__(256) pg_radix_reduce_kernel(const int64_t* __restrict__ partials, int64_t* __restrict__ out,
                                                                           int n_ops, int n_groups, int radix_shift, int slices,
                                                                           const PgAccOp* __restrict__ ops) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2521,7 +2527,7 @@ extern "C" __global__ void __launch_bounds__(256) pg_radix_reduce_kernel(const i
 
 // Range-partitioned partials: workgroup b holds [n_ops][part_groups] for range (b >> 3) % n_parts.  One wavefront per
 // output slot (op, group), lanes stride over the workgroups that own the group's range.
-extern "C" __global__ void __launch_bounds__(256) pg_reduce_parts_kernel(const int64_t* __restrict__ partials,
+PG_KERNEL __global__ void __launch_bounds__(256) pg_reduce_parts_kernel(const int64_t* __restrict__ partials,
                                                                           int64_t* __restrict__ out, int n_wg, int n_ops,
                                                                           int n_groups, int n_parts, int part_groups,
                                                                           const PgAccOp* __restrict__ ops) {
@@ -2552,7 +2558,7 @@ extern "C" __global__ void __launch_bounds__(256) pg_reduce_parts_kernel(const i
 }
 
 // Merges the workgroups' LDS-resident DISTINCTCOUNT / HLL partials: out[w] = OR (sets) or per-byte max (registers) over n_wg.
-extern "C" __global__ void __launch_bounds__(256) pg_reduce_aux_kernel(const uint32_t* __restrict__ partials, uint32_t* __restrict__ out,
+PG_KERNEL __global__ void __launch_bounds__(256) pg_reduce_aux_kernel(const uint32_t* __restrict__ partials, uint32_t* __restrict__ out,
                                                                         int n_wg, int64_t n_words, int bytewise_max) {
   const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= n_words) return;
@@ -2564,7 +2570,7 @@ extern "C" __global__ void __launch_bounds__(256) pg_reduce_aux_kernel(const uin
   out[w] = acc;
 }
 
-extern "C" __global__ void __launch_bounds__(256) pg_fill_i64_kernel(int64_t* dst, int64_t n_per_op, int n_ops,
+PG_KERNEL __global__ void __launch_bounds__(256) pg_fill_i64_kernel(int64_t* dst, int64_t n_per_op, int n_ops,
                                                                       const PgAccOp* __restrict__ ops) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_per_op * n_ops) return;
@@ -2574,7 +2580,7 @@ extern "C" __global__ void __launch_bounds__(256) pg_fill_i64_kernel(int64_t* ds
 
 // K4: match words → ascending docIds (DocIdSetOperator).  One 256-thread workgroup per 16 384-doc tile; tile_offsets =
 // exclusive prefix of the per-tile match counts.
-extern "C" __global__ void __launch_bounds__(PG_TILE_WORDS) pg_expand_docids_kernel(const uint64_t* __restrict__ words,
+PG_KERNEL __global__ void __launch_bounds__(PG_TILE_WORDS) pg_expand_docids_kernel(const uint64_t* __restrict__ words,
                                                                                      const int64_t* __restrict__ tile_offsets,
                                                                                      int32_t* __restrict__ out, int n_tiles) {
   __shared__ uint32_t s_scan[PG_TILE_WORDS];

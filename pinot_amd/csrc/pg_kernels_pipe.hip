@@ -1,0 +1,247 @@
+// pg_fast_i32range_p: the headline shape as a software pipeline, in a translation unit of its own so that its workgroup can be
+// smaller than the other kernels' (PG_WAVES_PER_BLOCK is this file's own: fewer wavefronts, each with a bigger register budget).
+//
+// Shape (PgQueryPlan::pipe_fit): [AND of <= 4 OR-groups of dense postings] AND raw-INT range → LDS-table aggregation over one or two
+// <= 8-bit group columns and ONE raw INT column (any number of SUM / MIN / MAX / COUNT accumulators over it; floating accumulators
+// stay with pg_fast_i32range_d: hoisted out of the accumulator loop, their 32 doubles and 32 order keys per lane do not fit).
+//
+// pg_fast_i32range_a / _d walk a tile as a dependent chain — postings → scan column → (value, group columns) → LDS atomics — and rely
+// on 16 wavefronts per CU being in different phases to keep HBM busy; the pure-scan probe (profiles/r02_scan_bw_probe.txt) says the
+// memory system prefers FEWER, longer streams (4 wavefronts x 8 KB: 7.33 TB/s; 16 x 8 KB: 6.5 TB/s).  Here every wavefront keeps three
+// tiles in flight instead: while tile i is aggregated out of registers, tile i+1's scan column and tile i+2's postings are
+// travelling, and tile i+1's value / group quads are requested the moment its match mask is known.  Loads return in order, so
+// waiting for the oldest group (vmcnt(N)) leaves the younger ones in flight.  Per lane: 32 (scan) + 32 (value) + 16·NG (group
+// windows) + 8 (postings) registers of load targets — beyond the 128 a 16-wavefront workgroup allows, which is why this kernel runs
+// PG_WAVES_PER_BLOCK <= 8 wavefronts per workgroup.
+//
+// Loads stay restricted to quads with candidates / matches (lanes without re-read quad 0 of the tile, as everywhere else), tiles
+// beyond the segment are clamped to the last tile with an empty mask: the loop body is branch-free apart from the wave-uniform
+// skip of an all-zero aggregation.
+#ifndef PG_WAVES_PER_BLOCK
+#define PG_WAVES_PER_BLOCK 8
+#endif
+#ifndef PG_PIPE_GRAIN
+#define PG_PIPE_GRAIN 8
+#endif
+#define PG_KERNEL template <int PG_NOT_INSTANTIATED> static
+#include "pg_kernels.hip"
+
+extern "C" const int pg_pipe_waves_per_block = PG_WAVES_PER_BLOCK;   // the host launches pg_fast_i32range_p with this many wavefronts
+
+// A wave-uniform pointer pinned into SGPRs: the loads below then take the  global_load v, v_offset, s[base:base+1]  form (one 32-bit
+// offset register per load) instead of loop-carried 64-bit per-lane addresses, which is what strength reduction makes of them otherwise.
+template <typename T> DEVFN const GAS T* sgpr_ptr(const void* ptr) {
+  const uint64_t v = (uint64_t)ptr;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return (const GAS T*)(((uint64_t)hi << 32) | (uint64_t)lo);
+}
+
+template <int NG>
+__device__ __forceinline__ void fast_pipe_i32range_body(const PgQueryPlan& p) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
+  __shared__ uint32_t s_stat[PG_MAX_STATS];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = uniform(t >> 6);
+  int64_t* lds_table = reinterpret_cast<int64_t*>(smem);
+  if (t < PG_MAX_STATS) s_stat[t] = 0;
+  {
+    const uint32_t table_slots = (uint32_t)p.n_groups * (uint32_t)p.replicas;
+    for (int o = 0; o < p.n_ops; o++) {
+      const int64_t ident = pg_acc_identity(p.ops[o].fn, p.ops[o].is_float);
+      for (uint32_t i = t; i < table_slots; i += PG_BLOCK) lds_table[(size_t)o * table_slots + i] = ident;
+    }
+  }
+  __syncthreads();
+  const CAS PgScanLeaf& L = cptr(p.scans)[p.fast_scan];
+  const RangeI32 r32 = make_range_i32(L.lo, L.hi);
+  const uint32_t R = (uint32_t)p.replicas;
+  const uint32_t rep = (uint32_t)t & (R - 1u);
+  const uint32_t stride = (uint32_t)p.n_groups * R;   // slots per op
+  const uint8_t* xdata = p.srcs[p.pipe_src].data;
+  const int last_wt = p.n_wtiles - 1;
+  const int wstride = (int)gridDim.x * PG_WAVES_PER_BLOCK;
+  uint32_t my_matched = 0, my_cand = 0;
+#ifdef PG_PIPE_BLOCKED   // measurement variant: every workgroup walks one contiguous run of tiles
+  const int per_wg = ((p.n_wtiles + (int)gridDim.x - 1) / (int)gridDim.x + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK * PG_WAVES_PER_BLOCK;
+  const int n_wtiles_loop = min(((int)blockIdx.x + 1) * per_wg, p.n_wtiles);
+  const int step = PG_WAVES_PER_BLOCK;
+  const int wt_first = (int)blockIdx.x * per_wg + wave;
+#else
+  const int n_wtiles_loop = p.n_wtiles;
+  const int step = wstride;
+  const int wt_first = (int)blockIdx.x * PG_WAVES_PER_BLOCK + wave;
+#endif
+
+  uint32_t pv[8];          // postings dwords (linear layout)
+  u32x4 a[8];              // scan column quads
+  u32x4 x[8];              // value column quads
+  uint32_t g[NG][8][2];    // group column windows
+
+  auto clamp_tile = [&](int wt) { return wt < last_wt ? wt : last_wt; };
+  auto issue_postings = [&](int wt) {   // dense postings are addressed arithmetically: dword index = tile * 64 + lane
+    const size_t tile_off = (size_t)clamp_tile(wt) * 256u;
+#pragma unroll
+    for (int j = 0; j < 8; j++) pv[j] = ldnt((const GAS uint32_t*)(sgpr_ptr<uint8_t>(p.dense_ptr[j] + tile_off) + (uint32_t)lane * 4u));
+  };
+  auto candidates = [&](int wt) -> uint32_t {   // pv → candidate mask in quad layout; empty beyond the segment
+    const int64_t rem = wt < n_wtiles_loop ? (int64_t)p.num_docs - (int64_t)wt * PG_WAVE_DOCS : 0;
+    const int32_t n_valid = rem >= PG_WAVE_DOCS ? PG_WAVE_DOCS : (rem > 0 ? (int32_t)rem : 0);
+    uint32_t grp[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int gj = p.dense_group[j];
+#pragma unroll
+      for (int k = 0; k < 4; k++) grp[k] |= gj == k ? pv[j] : 0u;
+    }
+    uint32_t lin = valid_lin_mask(n_valid, lane);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (k < p.dense_groups) lin &= ((p.dense_excl >> k) & 1) ? ~grp[k] : grp[k];
+    const uint32_t c = lin_to_quad(lin, lane);
+    my_cand += (uint32_t)__popc(c);
+    return c;
+  };
+  // quads aggregated per pass over the accumulators (8: the whole tile; smaller keeps fewer hoisted slots / values live)
+  constexpr int G = PG_PIPE_GRAIN;
+  auto issue_scan = [&](int wt, uint32_t cand, int k0, int n) {
+    const GAS uint8_t* tb = sgpr_ptr<uint8_t>(L.data + (size_t)clamp_tile(wt) * (PG_WAVE_DOCS * 4));
+#pragma unroll
+    for (int k = k0; k < k0 + n; k++) {
+      const uint32_t q = ((cand >> (4 * k)) & 0xFu) ? (uint32_t)(k * 64 + lane) : 0u;
+      a[k] = ldnt((const GAS u32x4*)(tb + q * 16u));
+    }
+  };
+  auto test_scan = [&](uint32_t cand) -> uint32_t {
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      m |= (uint32_t)in_range_i32(r32, (int32_t)bswap32(a[k].x)) << (4 * k);
+      m |= (uint32_t)in_range_i32(r32, (int32_t)bswap32(a[k].y)) << (4 * k + 1);
+      m |= (uint32_t)in_range_i32(r32, (int32_t)bswap32(a[k].z)) << (4 * k + 2);
+      m |= (uint32_t)in_range_i32(r32, (int32_t)bswap32(a[k].w)) << (4 * k + 3);
+    }
+    m = r32.empty ? 0u : (m & cand);
+    my_matched += (uint32_t)__popc(m);
+    return m;
+  };
+  auto issue_values = [&](int wt, uint32_t m, int k0, int n) {
+    const int wc = clamp_tile(wt);
+    const GAS uint8_t* xb = sgpr_ptr<uint8_t>(xdata + (size_t)wc * (PG_WAVE_DOCS * 4));
+#pragma unroll
+    for (int k = k0; k < k0 + n; k++) {
+      const uint32_t q = ((m >> (4 * k)) & 0xFu) ? (uint32_t)(k * 64 + lane) : 0u;
+      x[k] = ldnt((const GAS u32x4*)(xb + q * 16u));
+    }
+#pragma unroll
+    for (int gi = 0; gi < NG; gi++) {
+      const PgGroupCol& gc = p.gcols[gi];
+      const GAS uint32_t* tw = sgpr_ptr<uint32_t>((const void*)packed_wtile_base(gc.data, wc, gc.bits));
+#pragma unroll
+      for (int k = k0; k < k0 + n; k++) {
+        const uint32_t q = ((m >> (4 * k)) & 0xFu) ? (uint32_t)(k * 64 + lane) : 0u;
+        load_packed_quad<true>(tw, q, (uint32_t)gc.bits, g[gi][k]);
+      }
+    }
+  };
+  auto aggregate = [&](uint32_t m, int k0) {   // quads k0 .. k0+G-1 of the tile whose quads sit in x / g, matches m
+#ifdef PG_PIPE_NO_AGG   // measurement variant (wrong results): the loads alone
+    uint32_t acc = 0;
+#pragma unroll
+    for (int k = k0; k < k0 + G; k++) { acc += x[k].x ^ x[k].y ^ x[k].z ^ x[k].w; for (int gi = 0; gi < NG; gi++) acc += g[gi][k][0] ^ g[gi][k][1]; }
+    if (acc == 0x12345678u) atomicAdd(reinterpret_cast<unsigned long long*>(lds_table), 1ULL);
+    return;
+#endif
+    const uint32_t mg = G == 8 ? m : ((m >> (4 * k0)) & ((1u << (4 * (G & 7))) - 1u));
+    if (__ballot(mg != 0) == 0) return;   // wave-uniform
+    uint32_t sp[G][2];   // packed slots: docs (0,1) and (2,3) of quad k
+#pragma unroll
+    for (int k = 0; k < G; k++) sp[k][0] = sp[k][1] = rep | (rep << 16);
+#pragma unroll
+    for (int gi = 0; gi < NG; gi++) {
+      const PgGroupCol& gc = p.gcols[gi];
+      const uint32_t bits = (uint32_t)gc.bits, mask = (1u << gc.bits) - 1u;
+      const uint32_t mult = (uint32_t)gc.mult * R;
+#pragma unroll
+      for (int k = 0; k < G; k++) {
+        uint32_t d[4];
+        const uint32_t q = ((mg >> (4 * k)) & 0xFu) ? (uint32_t)((k0 + k) * 64 + lane) : 0u;
+        decode_packed_quad<true>(g[gi][k0 + k], q, bits, mask, d);
+        sp[k][0] += d[0] * mult + ((d[1] * mult) << 16);
+        sp[k][1] += d[2] * mult + ((d[3] * mult) << 16);
+      }
+    }
+    uint32_t v[G][4];
+#pragma unroll
+    for (int k = 0; k < G; k++) { v[k][0] = bswap32(x[k0 + k].x); v[k][1] = bswap32(x[k0 + k].y); v[k][2] = bswap32(x[k0 + k].z); v[k][3] = bswap32(x[k0 + k].w); }
+#define PG_SLOT(k, i) ((sp[k][(i) >> 1] >> (((i) & 1) * 16)) & 0xFFFFu)
+    for (int o = 0; o < p.n_ops; o++) {
+      const PgAccOp op = p.ops[o];
+      int64_t* base = lds_table + (size_t)o * stride;
+      if (op.src < 0) {
+#pragma unroll
+        for (int k = 0; k < G; k++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if ((mg >> (4 * k + i)) & 1u) atomicAdd(reinterpret_cast<unsigned long long*>(base + PG_SLOT(k, i)), 1ULL);
+      } else if (op.fn == PG_ACC_SUM) {
+#pragma unroll
+        for (int k = 0; k < G; k++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if ((mg >> (4 * k + i)) & 1u)
+              atomicAdd(reinterpret_cast<unsigned long long*>(base + PG_SLOT(k, i)), (unsigned long long)(int64_t)(int32_t)v[k][i]);
+      } else if (op.fn == PG_ACC_MIN) {
+#pragma unroll
+        for (int k = 0; k < G; k++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if ((mg >> (4 * k + i)) & 1u) atomicMin(reinterpret_cast<long long*>(base + PG_SLOT(k, i)), (long long)(int32_t)v[k][i]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < G; k++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if ((mg >> (4 * k + i)) & 1u) atomicMax(reinterpret_cast<long long*>(base + PG_SLOT(k, i)), (long long)(int32_t)v[k][i]);
+      }
+    }
+#undef PG_SLOT
+  };
+
+  // ---- prologue: tile 0 up to its value loads, tile 1 up to its scan loads, tile 2's postings -------------------------------------
+  int wt_cur = wt_first;
+  int wt_nxt = wt_cur + step, wt_far = wt_nxt + step;
+  issue_postings(wt_cur);
+  uint32_t c0 = candidates(wt_cur);
+  issue_postings(wt_nxt);
+  issue_scan(wt_cur, c0, 0, 8);
+  uint32_t m_cur = test_scan(c0);
+  issue_values(wt_cur, m_cur, 0, 8);
+  uint32_t c_nxt = candidates(wt_nxt);
+  issue_postings(wt_far);
+  issue_scan(wt_nxt, c_nxt, 0, 8);
+  // ---- steady state.  In flight at the top, oldest first: values(cur), postings(far), scan(nxt) — the prologue issues in the same
+  // order (the wait counts the compiler derives at the loop head are the more conservative of the two ways in) ---------------------
+  while (wt_cur < n_wtiles_loop) {
+    if (p.out_words) reinterpret_cast<uint32_t*>(p.out_words)[(int64_t)wt_cur * 64 + lane] = quad_to_lin(m_cur, lane);
+#pragma unroll
+    for (int k0 = 0; k0 < 8; k0 += G) aggregate(m_cur, k0);   // waits for values(cur) only: 16 younger loads stay in flight
+    const uint32_t m_nxt = test_scan(c_nxt);                   // waits for scan(nxt) (and with it postings(far))
+    issue_values(wt_nxt, m_nxt, 0, 8);
+    const uint32_t c_far = candidates(wt_far);
+    issue_postings(wt_far + step);
+    issue_scan(wt_far, c_far, 0, 8);
+    wt_cur = wt_nxt; wt_nxt = wt_far; wt_far += step;
+    m_cur = m_nxt; c_nxt = c_far;
+  }
+  const uint32_t wsum = wave_sum_u32(my_matched);
+  if (lane == 0 && wsum) atomicAdd(&s_stat[0], wsum);
+  const uint32_t csum = wave_sum_u32(my_cand);
+  if (lane == 0 && csum) atomicAdd(&s_stat[L.stat_slot], csum);
+  __syncthreads();
+  flush_workgroup(p, lds_table, s_stat, true, t);
+}
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_fast_i32range_p(const PgQueryPlan p) {
+  if (p.n_group_cols == 1) fast_pipe_i32range_body<1>(p);
+  else fast_pipe_i32range_body<2>(p);
+}

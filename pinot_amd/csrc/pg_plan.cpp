@@ -1043,6 +1043,37 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     }
   }
   if (P.fast_filter != 100) D.tail_posting = -1;
+  // Fused dense index program (pg_fast_i32range_d): the index-only prefix is PUSH_POSTINGS (AND PUSH_POSTINGS)* over leaves that are
+  // entirely dense (no CSR containers, their dense prefix covers every chunk) with at most 8 pointers and 4 leaves in all
+  if (P.fast_filter == 4 && D.n_index_instr > 0 && !D.fast_scan_pushed) {
+    std::vector<int> leaves;
+    bool ok = true;
+    int depth = 0;
+    for (int i = 0; i < D.n_index_instr && ok; i++) {
+      const PgFInstr& in = em.instrs[(size_t)i];
+      if (in.op == PG_F_PUSH_POSTINGS) { leaves.push_back(in.arg); depth++; }
+      else if (in.op == PG_F_AND) depth--;
+      else ok = false;
+    }
+    const int32_t n_chunks = (int32_t)(((int64_t)seg.total_docs + PG_CHUNK_DOCS - 1) / PG_CHUNK_DOCS);
+    int n_ptr = 0;
+    for (int l : leaves) {
+      const PgPostingLeaf& PL = em.postings[(size_t)l];
+      ok = ok && !PL.has_csr && PL.n_dense > 0 && PL.dense_chunks >= n_chunks;
+      n_ptr += PL.n_dense;
+    }
+    if (ok && depth == 1 && !leaves.empty() && leaves.size() <= 4 && n_ptr <= 8) {
+      int j = 0;
+      for (size_t g = 0; g < leaves.size(); g++) {
+        const PgPostingLeaf& PL = em.postings[(size_t)leaves[g]];
+        for (int k = 0; k < PL.n_dense; k++, j++) { D.dense_ptr[j] = PL.dense[k]; D.dense_group[j] = (int32_t)g; }
+        if (PL.exclusive) D.dense_excl |= 1 << g;
+      }
+      for (; j < 8; j++) { D.dense_ptr[j] = D.dense_ptr[0]; D.dense_group[j] = D.dense_group[0]; }   // OR is idempotent
+      D.dense_groups = (int32_t)leaves.size();
+      D.dense_fused = 1;
+    }
+  }
   P.lds_bytes = 0;   // the filter stack lives in registers
   if (!P.stats_exact) {
     // numEntriesScannedInFilter of this shape depends on how the reference's iterators drive each other: every Scan / Inverted
@@ -1467,6 +1498,20 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     if (!(c->col_kind == PG_COL_RAW32 || (c->col_kind == PG_COL_FIXED_BIT && (c->val_type == PG_V_I32 || c->val_type == PG_V_F32))))
       P.fast_agg = false;
   D.fast_agg_shape = (P.fast_agg && (D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE)) ? 1 : 0;
+  // the software-pipelined headline kernel keeps one value column and up to two group columns of a tile in registers
+  D.pipe_fit = 0;
+  D.pipe_src = -1;
+  if (D.dense_fused && P.fast_agg && D.agg_mode == PG_AGG_LDS && D.n_group_cols >= 1 && D.n_group_cols <= 2) {
+    bool ok = true;
+    int src = -1;
+    for (int o = 0; o < D.n_ops && ok; o++) {
+      if (D.ops[o].src < 0) continue;
+      if (D.ops[o].is_float != PG_ACCV_INT) ok = false;
+      if (src >= 0 && D.ops[o].src != src) ok = false;
+      src = D.ops[o].src;
+    }
+    if (ok && src >= 0 && D.srcs[src].col_kind == PG_COL_RAW32) { D.pipe_fit = 1; D.pipe_src = src; }
+  }
   // LDS tables that miss the narrow shape only by column width (group columns > 8 bits, LONG / DOUBLE sources, 64-bit
   // dictionaries) keep the 1024-thread kernels and run the general aggregator there (pg_fast_none_w / pg_fast_multi_w)
   P.wide_agg = !P.fast_agg && (D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE) && D.n_aux == 0 && P.first_doc_op < 0;

@@ -141,8 +141,10 @@ void segment_add_star_tree(Segment& seg, const pg_star_tree_desc& d) {
     if (!leaf && (f[kFirstChildId] <= nd || f[kLastChildId] < f[kFirstChildId] || f[kLastChildId] >= st->n_nodes)) fail(PG_ERR_INVALID_ARGUMENT, "star-tree node %d has bad child ids", nd);
     if (nd > 0 && (f[kDimensionId] < 0 || f[kDimensionId] >= n_dims)) fail(PG_ERR_INVALID_ARGUMENT, "star-tree node %d has bad dimension id", nd);
     if (f[kAggregatedDocId] < 0 || f[kAggregatedDocId] >= d.num_docs) fail(PG_ERR_INVALID_ARGUMENT, "star-tree node %d has bad aggregated docId", nd);
-    // every node's doc range feeds range / match-word leaves: the root's too (its aggregated doc may lie beyond its own range)
-    if (f[kStartDocId] < 0 || f[kEndDocId] > d.num_docs || f[kStartDocId] > f[kEndDocId]) fail(PG_ERR_INVALID_ARGUMENT, "star-tree node %d has a bad doc range", nd);
+    // every node's doc range feeds range / match-word leaves; the builders leave the root's at (-1, -1) (never a leaf's range),
+    // anything else must be a range inside the star-tree's docs
+    const bool unset_root = nd == 0 && f[kStartDocId] == -1 && f[kEndDocId] == -1;
+    if (!unset_root && (f[kStartDocId] < 0 || f[kEndDocId] > d.num_docs || f[kStartDocId] > f[kEndDocId])) fail(PG_ERR_INVALID_ARGUMENT, "star-tree node %d has a bad doc range", nd);
   }
 
   Segment& sp = st->space;

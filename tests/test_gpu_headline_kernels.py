@@ -1,0 +1,56 @@
+"""The two specialisations of the headline shape (SURVEY.md §8a rows a1-a4 + a9-a12 fused: dense inverted-index postings AND a raw-INT
+range scan, LDS-table GROUP BY): pg_fast_i32range_p (software pipeline, 8 wavefronts per workgroup: pg_kernels_pipe.hip) and
+pg_fast_i32range_d (dense index program, 16 wavefronts: pg_kernels_dense.hip).  Which one the planner picks is part of the contract
+(pg_exec_stats.kernel), results and ExecutionStatistics equal the oracle's at every segment size around the pipeline's depth: the
+pipelined kernel keeps three tiles in flight per wavefront, so segments with fewer tiles than wavefronts (700 001 docs), with two
+or three tiles per wavefront (9 000 123 docs: 4 395 tiles over 2 048 wavefronts) and with a ragged last tile exercise its prologue
+and its clamped tail; the smallest sizes keep array containers (CSR postings) and take the interpreted index leaves."""
+import os
+
+import pytest
+
+from pinot_amd import synth
+from pinot_amd.executor import NativeSegment
+
+pytestmark = pytest.mark.gpu
+
+COLUMNS = ["c_inv1", "c_inv2", "r_int", "g1", "g2", "m"]
+PIPE = "pg_fast_i32range_p"
+DENSE = "pg_fast_i32range_d"
+knobs_off = not (os.environ.get("PG_NO_PIPE") or os.environ.get("PG_NO_DENSE_FUSED"))
+
+QUERIES = [
+    (synth.QUERY_CFG3, PIPE),
+    (synth.QUERY_NORTH_STAR, PIPE),
+    ("SELECT g1, COUNT(*), MIN(m), MAX(m), SUM(m) FROM gpuBench WHERE c_inv1 NOT IN (0, 7) AND c_inv2 = 1 "
+     "AND r_int BETWEEN 100 AND 900000 GROUP BY g1 ORDER BY g1 LIMIT 1000", PIPE),
+    ("SELECT g2, g1, COUNT(*), SUM(m) FROM gpuBench WHERE c_inv1 IN (1, 2, 3, 4, 5) AND r_int < 10 GROUP BY g2, g1 "
+     "ORDER BY g2, g1 LIMIT 10000", PIPE),
+    # an empty range after the postings: every tile is skipped
+    ("SELECT g1, SUM(m) FROM gpuBench WHERE c_inv2 IN (0, 1, 2) AND r_int BETWEEN 2000000 AND 3000000 GROUP BY g1 LIMIT 1000", PIPE),
+    # accumulators over two value columns, or COUNT only: the dense kernel
+    ("SELECT g1, SUM(m), MAX(r_int) FROM gpuBench WHERE c_inv1 IN (0, 1) AND r_int > 500000 GROUP BY g1 ORDER BY g1 LIMIT 1000", DENSE),
+    ("SELECT g1, COUNT(*) FROM gpuBench WHERE c_inv1 IN (0, 1) AND r_int > 500000 GROUP BY g1 ORDER BY g1 LIMIT 1000", DENSE),
+    # AVG keeps a DOUBLE sum next to the count: a floating accumulator
+    ("SELECT g1, AVG(m) FROM gpuBench WHERE c_inv1 IN (0, 1) AND r_int > 500000 GROUP BY g1 ORDER BY g1 LIMIT 1000", None),
+]
+
+
+@pytest.fixture(scope="module", params=[1, 2047, 2048, 2049, 4096, 3 * 2048 + 5, 17 * 2048 + 1999, 700_001, 9_000_123])
+def pair(request, gpu_api, oracle_api):
+    host = synth.generate_segment(request.param, segment_index=3, columns=COLUMNS)
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    yield g, o
+    g.destroy()
+    o.destroy()
+
+
+@pytest.mark.parametrize("sql,kernel", QUERIES)
+def test_headline_specialisations_match_oracle(pair, sql, kernel):
+    g, o = pair
+    gb, ob = g.execute(sql), o.execute(sql)
+    assert gb.rows() == ob.rows()
+    for f in ("num_docs_scanned", "num_entries_scanned_in_filter", "num_entries_scanned_post_filter", "num_total_docs"):
+        assert getattr(gb.stats, f) == getattr(ob.stats, f), f
+    if kernel and knobs_off and gb.stats.num_total_docs >= 65536:   # small segments keep sparse (CSR) postings: the interpreted leaves
+        assert gb.stats.kernel.decode() == kernel

@@ -103,6 +103,15 @@ def test_star_tree_registration_errors(gpu_api):
     st.star_tree = good[:-28].copy()
     with pytest.raises(capi.NativeError, match="size mis-match"):
         seg.add_star_tree(st)
+    from pinot_amd.formats import read_star_tree, write_star_tree
+    dims, nodes = read_star_tree(good)
+    assert tuple(nodes[0, 2:4]) == (-1, -1)              # the builders leave the root's doc range unset
+    for lo, hi in ((0, st.num_docs + 1), (-1, 5), (7, 3)):
+        broken = nodes.copy()
+        broken[0, 2:4] = (lo, hi)
+        st.star_tree = write_star_tree(dims, broken)
+        with pytest.raises(capi.NativeError, match="bad doc range"):
+            seg.add_star_tree(st)
     st.star_tree = good
     seg.add_star_tree(st)
     assert seg.execute("SELECT COUNT(*), MAX(ArrDelay) FROM t").stats.star_tree_index == 0

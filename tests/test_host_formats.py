@@ -137,7 +137,10 @@ def test_headline_kernel_has_no_register_spills():
         import pytest
         pytest.skip("library was built without the resource log")
     usage, cur = {}, None
-    for line in open(log):
+    dense = log.replace("pg_kernels.", "pg_kernels_dense.")      # pg_fast_i32range_d lives in its own translation unit
+    pipe = log.replace("pg_kernels.", "pg_kernels_pipe.")        # pg_fast_i32range_p: 8 wavefronts per workgroup, 256 VGPRs each
+    lines = list(open(log)) + (list(open(dense)) if os.path.exists(dense) else []) + (list(open(pipe)) if os.path.exists(pipe) else [])
+    for line in lines:
         m = re.search(r"Function Name: (\w+)", line)
         if m:
             cur = m.group(1)
@@ -149,6 +152,12 @@ def test_headline_kernel_has_no_register_spills():
     for k in ("pg_fast_i32range_a", "pg_fast_i32range_f", "pg_fast_none_a", "pg_fast_none_f"):
         assert usage[k]["ScratchSize [bytes/lane]"] == 0 and usage[k]["VGPRs Spill"] == 0, (k, usage[k])
         assert usage[k]["VGPRs"] <= 128
+    if os.path.exists(dense):
+        d = usage["pg_fast_i32range_d"]
+        assert d["ScratchSize [bytes/lane]"] == 0 and d["VGPRs Spill"] == 0 and d["VGPRs"] <= 128, d
+    if os.path.exists(pipe):
+        d = usage["pg_fast_i32range_p"]
+        assert d["ScratchSize [bytes/lane]"] == 0 and d["VGPRs Spill"] == 0 and d["VGPRs"] <= 256, d
 
 
 def _abi_smoke_binary():
