@@ -6,12 +6,18 @@
  *   LZ4                  lz4-java 1.8.0        safeDecompressor()      (.../io/compression/LZ4Decompressor.java:38-49)
  *   LZ4_LENGTH_PREFIXED  lz4-java              LZ4DecompressorWithLength: 4-byte little-endian decompressed length, then the block
  *                                              (.../io/compression/LZ4WithLengthDecompressor.java:35-52)
- * Their algorithms are restated here from the published formats (snappy format_description.txt; LZ4 block format description).
+ *   GZIP                 java.util.zip (JDK zlib)  Inflater                (.../io/compression/GzipDecompressor.java:38-56)
+ *   ZSTANDARD            zstd-jni 1.5.6-9          Zstd.decompress         (.../io/compression/ZstandardDecompressor.java:36-45)
+ * GZIP and ZSTANDARD are NOT restated: they call the same third-party libraries the reference binds (zlib's uncompress; libzstd's
+ * ZSTD_decompress through dlopen) — pinned by chunks written with Python's zlib and Arrow's zstd codec (tests/test_compressed_chunks.py).
+ * The other algorithms are restated here from the published formats (snappy format_description.txt; LZ4 block format description).
  * Parity: SNAPPY is pinned by the reference's own blobs fixedByteCompressed.v2, fixedByteSVRDoubles.v1, varByteStringsCompressed.v2
  * and varByteStrings.v1 (tests/test_oracle_goldens.py); the tree holds no LZ4 blob, so LZ4 is pinned only against liblz4 (through
  * pyarrow's lz4_raw codec, tests/test_compressed_chunks.py) — "parity unpinned" by the reference itself.
  * ZSTANDARD and GZIP chunks are not restated (PG_ERR_UNSUPPORTED).
  */
+#include <dlfcn.h>
+#include <zlib.h>
 #include "po_internal.h"
 
 /* snappy: varint32 uncompressed length, then elements tagged by the low 2 bits: 00 literal, 01/10/11 copies with 1/2/4 offset bytes */
@@ -127,6 +133,27 @@ int64_t po_chunk_decompress(int32_t compression, const uint8_t* src, uint64_t n,
       if (want > cap) return -1;
       const int64_t got = po_lz4_decompress(src + 4, n - 4, dst, want);
       return got == (int64_t)want ? got : -1;
+    }
+    case 5: {   /* GZIP: zlib stream + big-endian uncompressed length (GzipCompressor.java:41-51, GzipDecompressor.java:38-56) */
+      if (n < 4) return -1;
+      const uint64_t want = ((uint64_t)src[n - 4] << 24) | ((uint64_t)src[n - 3] << 16) | ((uint64_t)src[n - 2] << 8) | (uint64_t)src[n - 1];
+      if (want > cap) return -1;
+      uLongf got = (uLongf)cap;
+      if (uncompress(dst, &got, src, (uLong)(n - 4)) != Z_OK || got != want) return -1;
+      return (int64_t)got;
+    }
+    case 2: {   /* ZSTANDARD: one frame per chunk (ZstandardDecompressor.java:36-45) */
+      static size_t (*zd)(void*, size_t, const void*, size_t) = 0;
+      static unsigned (*ze)(size_t) = 0;
+      if (!zd) {
+        void* h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return -1;
+        *(void**)(&ze) = dlsym(h, "ZSTD_isError");
+        *(void**)(&zd) = dlsym(h, "ZSTD_decompress");
+        if (!zd || !ze) return -1;
+      }
+      const size_t got = zd(dst, cap, src, n);
+      return ze(got) ? -1 : (int64_t)got;
     }
     default: return -1;
   }

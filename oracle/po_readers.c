@@ -128,8 +128,8 @@ int po_raw_parse_header(po_column* c) {
     /* BaseChunkForwardIndexReader#decompressChunk (:141-163) decompresses the chunk of the docId being read into the reader
      * context; the values are the same if every chunk is decompressed once, up front, into the PASS_THROUGH layout (version 3
      * header, 8-byte chunk offsets) the accessors below read. */
-    if (c->raw_compression != 1 && c->raw_compression != 3 && c->raw_compression != 4) {
-      po_set_error("column %s: chunk compression type %d is not restated (SNAPPY / LZ4 / LZ4_LENGTH_PREFIXED are)", c->name, c->raw_compression);
+    if (c->raw_compression < 1 || c->raw_compression > 5) {
+      po_set_error("column %s: chunk compression type %d is not a ChunkCompressionType", c->name, c->raw_compression);
       return -1;
     }
     const int64_t nc = c->raw_num_chunks;

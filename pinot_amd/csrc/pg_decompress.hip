@@ -166,9 +166,12 @@ void decompress_fixed_byte_chunks(int compression, const uint8_t* file, const st
                                   uint64_t total_bytes, uint8_t* dst, const char* column) {
   const int n_chunks = (int)offs.size() - 1;
   if (n_chunks <= 0 || total_bytes == 0) return;
+  if (host_codec(compression)) {   // ZSTANDARD / GZIP: entropy-coded streams, decoded on the host once (pg_host_codecs.cpp)
+    host_decompress_fixed_byte_chunks(compression, file, offs, chunk_bytes, total_bytes, dst, column);
+    return;
+  }
   if (compression != kSnappy && compression != kLz4 && compression != kLz4Len)
-    fail(PG_ERR_UNSUPPORTED, "column %s: chunk compression type %d (PASS_THROUGH, SNAPPY, LZ4 and LZ4_LENGTH_PREFIXED are on the GPU path)",
-         column, compression);
+    fail(PG_ERR_UNSUPPORTED, "column %s: chunk compression type %d is not a ChunkCompressionType", column, compression);
   if (chunk_bytes == 0 || chunk_bytes > PG_DC_MAX_CHUNK_BYTES || (chunk_bytes & 3u))
     fail(PG_ERR_UNSUPPORTED, "column %s: %u-byte chunks (compressed chunks up to %d bytes are decompressed on the GPU)", column,
          chunk_bytes, PG_DC_MAX_CHUNK_BYTES);

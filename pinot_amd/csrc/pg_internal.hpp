@@ -148,6 +148,10 @@ struct StarTree {
 void segment_add_column(Segment& seg, const pg_column_desc& d);
 double limbs_to_double(const int64_t* limbs, int n_limbs, int q);   // sum_j limbs[j] * 2^(32 j + q), correctly rounded (pg_plan.cpp)
 void segment_add_star_tree(Segment& seg, const pg_star_tree_desc& d);
+// ZSTANDARD / GZIP chunks: host decode at registration (pg_host_codecs.cpp)
+bool host_codec(int compression);
+void host_decompress_fixed_byte_chunks(int compression, const uint8_t* file, const std::vector<uint64_t>& offs, uint32_t chunk_bytes,
+                                       uint64_t total_bytes, uint8_t* dst_device, const char* column);
 void decompress_fixed_byte_chunks(int compression, const uint8_t* file, const std::vector<uint64_t>& offs, uint32_t chunk_bytes,
                                   uint64_t total_bytes, uint8_t* dst, const char* column);
 void segment_set_null_vector(Segment& seg, const char* column, const void* roaring, uint64_t size);

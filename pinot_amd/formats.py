@@ -61,6 +61,7 @@ def unpack_fixed_bit(buf: np.ndarray, bits: int, n: int) -> np.ndarray:
 # ----------------------------------------------------------------------------------------------------------------------
 CHUNK_COMPRESSION_PASS_THROUGH = 0  # ChunkCompressionType.PASS_THROUGH.getValue()
 CHUNK_COMPRESSION_SNAPPY, CHUNK_COMPRESSION_LZ4, CHUNK_COMPRESSION_LZ4_LENGTH_PREFIXED = 1, 3, 4
+CHUNK_COMPRESSION_ZSTANDARD, CHUNK_COMPRESSION_GZIP = 2, 5
 
 
 def compress_chunk(chunk: bytes, compression: int) -> bytes:
@@ -75,6 +76,11 @@ def compress_chunk(chunk: bytes, compression: int) -> bytes:
         return pa.compress(chunk, codec="lz4_raw", asbytes=True)
     if compression == CHUNK_COMPRESSION_LZ4_LENGTH_PREFIXED:
         return struct.pack("<i", len(chunk)) + pa.compress(chunk, codec="lz4_raw", asbytes=True)
+    if compression == CHUNK_COMPRESSION_ZSTANDARD:   # ZstandardCompressor: one zstd frame per chunk
+        return pa.compress(chunk, codec="zstd", asbytes=True)
+    if compression == CHUNK_COMPRESSION_GZIP:        # GzipCompressor: java.util.zip.Deflater (zlib stream) + big-endian uncompressed length
+        import zlib
+        return zlib.compress(bytes(chunk)) + struct.pack(">i", len(chunk))
     raise ValueError(f"chunk compression type {compression}")
 
 _BE_DTYPES = {"INT": ">i4", "LONG": ">i8", "FLOAT": ">f4", "DOUBLE": ">f8"}

@@ -16,7 +16,8 @@ from pinot_amd.segment import HostColumn, HostSegment, build_column
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 FIXED = [("fixedByteCompressed.v2", 2000, 100.2356), ("fixedByteSVRDoubles.v1", 10009, 0.0)]
-CODECS = [formats.CHUNK_COMPRESSION_SNAPPY, formats.CHUNK_COMPRESSION_LZ4, formats.CHUNK_COMPRESSION_LZ4_LENGTH_PREFIXED]
+CODECS = [formats.CHUNK_COMPRESSION_SNAPPY, formats.CHUNK_COMPRESSION_LZ4, formats.CHUNK_COMPRESSION_LZ4_LENGTH_PREFIXED,
+          formats.CHUNK_COMPRESSION_ZSTANDARD, formats.CHUNK_COMPRESSION_GZIP]
 
 
 def golden_blob(name):
@@ -103,7 +104,7 @@ def test_oracle_rejects_corrupt_chunks(oracle_api):
         with pytest.raises(capi.NativeError):
             NativeSegment(oracle_api, HostSegment("c", 5000, {"x": col}))
     blob = formats.write_raw_fixed_byte_chunk(vals, "INT").copy()
-    blob[20:24] = np.frombuffer(np.array([2], dtype=">i4").tobytes(), dtype=np.uint8)   # ZSTANDARD
+    blob[20:24] = np.frombuffer(np.array([2], dtype=">i4").tobytes(), dtype=np.uint8)   # claims ZSTANDARD: the bytes are no zstd frame
     col = HostColumn("x", "INT", capi.FWD_RAW_FIXED_BYTE_CHUNK, False, 0, 0, False, 0, blob)
     with pytest.raises(capi.NativeError):
         NativeSegment(oracle_api, HostSegment("c", 5000, {"x": col}))
@@ -168,7 +169,7 @@ def test_gpu_rejects_corrupt_and_unsupported_chunks(gpu_api):
         with pytest.raises(capi.NativeError):
             NativeSegment(gpu_api, HostSegment("c", 5000, {"x": col}))
     blob = formats.write_raw_fixed_byte_chunk(vals, "INT").copy()
-    blob[20:24] = np.frombuffer(np.array([5], dtype=">i4").tobytes(), dtype=np.uint8)   # GZIP
+    blob[20:24] = np.frombuffer(np.array([5], dtype=">i4").tobytes(), dtype=np.uint8)   # claims GZIP: the bytes are no zlib stream
     col = HostColumn("x", "INT", capi.FWD_RAW_FIXED_BYTE_CHUNK, False, 0, 0, False, 0, blob)
     with pytest.raises(capi.NativeError):
         NativeSegment(gpu_api, HostSegment("c", 5000, {"x": col}))
