@@ -312,13 +312,18 @@ int32_t pg_result_num_groups(pg_result_t result, int32_t* out_num_groups);
 /* dictIds of group-by column `col` for every group (GroupKeyGenerator#getGroupKeys; decoding via Dictionary is the
  * caller's job as in DictionaryBasedGroupKeyGenerator.java:578-606). */
 int32_t pg_result_group_dict_ids(pg_result_t result, int32_t col, int32_t* out_dict_ids, int32_t capacity);
-/* A group-by column without a dictionary (NoDictionarySingleColumnGroupKeyGenerator.java:53-90,241-265: one raw INT / LONG
- * column, value -> group id map) has no dictIds: pg_result_group_key_type reports PG_GROUP_KEY_LONG_VALUES for it and the
- * values of the groups come from pg_result_group_values_long (pg_result_group_dict_ids then fails). */
+/* A group-by column without a dictionary has no dictIds (NoDictionarySingleColumnGroupKeyGenerator.java:53-90,238-262: value -> group
+ * id maps per stored type; NoDictionaryMultiColumnGroupKeyGenerator.java:60-130: on-the-fly dictionaries per raw column):
+ * pg_result_group_key_type reports, per group-by column, PG_GROUP_KEY_LONG_VALUES (raw INT / LONG: the groups' values from
+ * pg_result_group_values_long) or PG_GROUP_KEY_DOUBLE_VALUES (raw FLOAT / DOUBLE: pg_result_group_values_double; a FLOAT widened
+ * exactly; keys compare by floatToIntBits / doubleToLongBits as in the fastutil maps: every NaN is one key, -0.0 and 0.0 are two);
+ * pg_result_group_dict_ids fails for such a column.  Dictionary-encoded columns of the same query keep PG_GROUP_KEY_DICT_IDS. */
 #define PG_GROUP_KEY_DICT_IDS 0
 #define PG_GROUP_KEY_LONG_VALUES 1
+#define PG_GROUP_KEY_DOUBLE_VALUES 2
 int32_t pg_result_group_key_type(pg_result_t result, int32_t col, int32_t* out_type);
 int32_t pg_result_group_values_long(pg_result_t result, int32_t col, int64_t* out_values, int32_t capacity);
+int32_t pg_result_group_values_double(pg_result_t result, int32_t col, double* out_values, int32_t capacity);
 int32_t pg_result_kind_of(pg_result_t result, int32_t agg, int32_t* out_kind);
 int32_t pg_result_doubles(pg_result_t result, int32_t agg, int32_t component, double* out, int32_t capacity);
 int32_t pg_result_longs(pg_result_t result, int32_t agg, int32_t component, int64_t* out, int32_t capacity);

@@ -76,8 +76,9 @@ public class GpuGroupByOperator extends BaseOperator<BaseResultsBlock> {
         }
         return new AggregationResultsBlock(functions, results, _queryContext);
       }
-      // group keys: dictIds decoded exactly as DictionaryBasedGroupKeyGenerator.getKeys does (:578-606), or the raw values of the
-      // one no-dictionary group-by column (NoDictionarySingleColumnGroupKeyGenerator.java:241-265)
+      // group keys: dictIds decoded exactly as DictionaryBasedGroupKeyGenerator.getKeys does (:578-606), or the raw values of
+      // no-dictionary group-by columns (NoDictionarySingleColumnGroupKeyGenerator.java:241-265,
+      // NoDictionaryMultiColumnGroupKeyGenerator.java:60-130): LONG values for INT / LONG, DOUBLE values for FLOAT / DOUBLE
       Object[][] keys = new Object[numGroups][groupBy.size()];
       for (int j = 0; j < groupBy.size(); j++) {
         String column = groupBy.get(j).getIdentifier();
@@ -87,6 +88,13 @@ public class GpuGroupByOperator extends BaseOperator<BaseResultsBlock> {
           boolean isInt = _segment.getDataSource(column).getDataSourceMetadata().getDataType().getStoredType().name().equals("INT");
           for (int g = 0; g < numGroups; g++) {
             keys[g][j] = isInt ? (Object) (int) values[g] : (Object) values[g];
+          }
+        } else if (PinotGpu.resultGroupKeyType(result, j) == PinotGpu.GROUP_KEY_DOUBLE_VALUES) {
+          double[] values = new double[numGroups];
+          PinotGpu.resultGroupValuesDouble(result, j, values);
+          boolean isFloat = _segment.getDataSource(column).getDataSourceMetadata().getDataType().getStoredType().name().equals("FLOAT");
+          for (int g = 0; g < numGroups; g++) {
+            keys[g][j] = isFloat ? (Object) (float) values[g] : (Object) values[g];
           }
         } else {
           int[] dictIds = new int[numGroups];

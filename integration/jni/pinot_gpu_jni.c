@@ -159,6 +159,7 @@ JNIEXPORT jint JNICALL Java_org_apache_pinot_gpu_PinotGpu_resultGroupKeyType(JNI
   }
 COPY_OUT(resultGroupDictIds(JNIEnv* env, jclass c, jlong r, jint col, jintArray out), jintArray, int32_t, pg_result_group_dict_ids(RES(r), col, p, n))
 COPY_OUT(resultGroupValuesLong(JNIEnv* env, jclass c, jlong r, jint col, jlongArray out), jlongArray, int64_t, pg_result_group_values_long(RES(r), col, p, n))
+COPY_OUT(resultGroupValuesDouble(JNIEnv* env, jclass c, jlong r, jint col, jdoubleArray out), jdoubleArray, double, pg_result_group_values_double(RES(r), col, p, n))
 COPY_OUT(resultDoubles(JNIEnv* env, jclass c, jlong r, jint agg, jint comp, jdoubleArray out), jdoubleArray, double, pg_result_doubles(RES(r), agg, comp, p, n))
 COPY_OUT(resultLongs(JNIEnv* env, jclass c, jlong r, jint agg, jint comp, jlongArray out), jlongArray, int64_t, pg_result_longs(RES(r), agg, comp, p, n))
 COPY_OUT(resultSetSizes(JNIEnv* env, jclass c, jlong r, jint agg, jintArray out), jintArray, int32_t, pg_result_set_sizes(RES(r), agg, p, n))

@@ -301,7 +301,9 @@ static int32_t lm_get_group_id(long_map* m, int64_t raw_key, int32_t upper_bound
 }
 
 enum { HOLDER_ARRAY, HOLDER_INT_MAP, HOLDER_LONG_MAP,
-       HOLDER_RAW_VALUES /* NoDictionarySingleColumnGroupKeyGenerator: value -> group id (Int2IntOpenHashMap / Long2IntOpenHashMap) */ };
+       HOLDER_RAW_VALUES /* NoDictionarySingleColumnGroupKeyGenerator: value -> group id (Int2IntOpenHashMap / Long2IntOpenHashMap) */,
+       HOLDER_TUPLES /* a raw FLOAT / DOUBLE column (Float2Int / Double2IntOpenHashMap), or NoDictionaryMultiColumnGroupKeyGenerator: per
+                        column a dictId or the value's key (int value, floatToIntBits, doubleToLongBits), the tuple -> group id */ };
 
 typedef struct group_key_gen {
   int n_cols;
@@ -315,6 +317,9 @@ typedef struct group_key_gen {
   long_map lmap;
   /* reverse: raw key per group id for map holders */
   int64_t* raw_key_of_group; int32_t raw_cap;
+  /* HOLDER_TUPLES: n_cols keys per group id, and an open-addressing table of group ids + 1 */
+  int64_t* tuples; int32_t tuple_cap, n_tuples;
+  int32_t* tuple_table; int32_t tuple_table_cap;
 } group_key_gen;
 
 /* constructor, DictionaryBasedGroupKeyGenerator.java:106-185 */
@@ -322,6 +327,21 @@ static int gkg_init(group_key_gen* g, int n_cols, po_column** cols, int32_t num_
   memset(g, 0, sizeof(*g));
   g->n_cols = n_cols;
   g->cols = cols;
+  int any_raw = 0;
+  for (int i = 0; i < n_cols; i++) any_raw |= !cols[i]->has_dictionary;
+  if (any_raw && !(n_cols == 1 && (cols[0]->data_type == PG_TYPE_INT || cols[0]->data_type == PG_TYPE_LONG))) {
+    /* DefaultGroupByExecutor.java:100-118: any group-by expression without a dictionary → the no-dictionary generators; both admit
+     * new keys in docId order until numGroupsLimit (NoDictionaryMultiColumnGroupKeyGenerator.java:60-130,
+     * NoDictionarySingleColumnGroupKeyGenerator.java:238-262) */
+    g->holder = HOLDER_TUPLES;
+    g->global_upper_bound = num_groups_limit;
+    g->cardinalities = (int32_t*)po_xcalloc((size_t)n_cols + 1, 4);
+    g->tuple_cap = 1024;
+    g->tuples = (int64_t*)po_xmalloc(sizeof(int64_t) * (size_t)g->tuple_cap * (size_t)n_cols);
+    g->tuple_table_cap = 4096;
+    g->tuple_table = (int32_t*)po_xcalloc((size_t)g->tuple_table_cap, 4);
+    return 0;
+  }
   if (n_cols == 1 && !cols[0]->has_dictionary) {   /* NoDictionarySingleColumnGroupKeyGenerator ctor :69-84 */
     g->holder = HOLDER_RAW_VALUES;
     g->global_upper_bound = num_groups_limit;
@@ -409,12 +429,65 @@ static void gkg_generate_raw(group_key_gen* g, int n_docs, const int32_t* doc_id
     out[i] = gid;
   }
 }
+/* the key a fastutil map compares: the int / long value, Float.floatToIntBits, Double.doubleToLongBits (one NaN; -0.0 != 0.0) */
+static int64_t raw_key_of_doc(const po_column* c, int32_t doc) {
+  switch (c->data_type) {
+    case PG_TYPE_INT: return (int64_t)po_raw_get_int(c, doc);
+    case PG_TYPE_LONG: return po_raw_get_long(c, doc);
+    case PG_TYPE_FLOAT: { float f = po_raw_get_float(c, doc); uint32_t b; if (f != f) b = 0x7FC00000u; else memcpy(&b, &f, 4); return (int64_t)b; }
+    default: { double d = po_raw_get_double(c, doc); uint64_t b; if (d != d) b = 0x7FF8000000000000ULL; else memcpy(&b, &d, 8); return (int64_t)b; }
+  }
+}
+static uint64_t tuple_hash(const int64_t* t, int n) {
+  uint64_t h = 0x9E3779B97F4A7C15ULL;
+  for (int j = 0; j < n; j++) { h ^= (uint64_t)t[j] + 0x9E3779B97F4A7C15ULL + (h << 6) + (h >> 2); h *= 0xFF51AFD7ED558CCDULL; h ^= h >> 33; }
+  return h;
+}
+static void tuple_table_insert(group_key_gen* g, int32_t gid) {
+  uint64_t p = tuple_hash(g->tuples + (size_t)gid * (size_t)g->n_cols, g->n_cols) & (uint64_t)(g->tuple_table_cap - 1);
+  while (g->tuple_table[p]) p = (p + 1) & (uint64_t)(g->tuple_table_cap - 1);
+  g->tuple_table[p] = gid + 1;
+}
+/* generateKeysForBlock: existing tuple -> its id; a new tuple is admitted while fewer than numGroupsLimit groups exist, else INVALID_ID */
+static void gkg_generate_tuples(group_key_gen* g, int n_docs, const int32_t* doc_ids, int32_t** dict_ids, int32_t* out) {
+  const int nc = g->n_cols;
+  int64_t key[64];
+  for (int i = 0; i < n_docs; i++) {
+    for (int j = 0; j < nc; j++) key[j] = g->cols[j]->has_dictionary ? (int64_t)dict_ids[j][i] : raw_key_of_doc(g->cols[j], doc_ids[i]);
+    uint64_t p = tuple_hash(key, nc) & (uint64_t)(g->tuple_table_cap - 1);
+    int32_t gid = PO_INVALID_ID;
+    while (g->tuple_table[p]) {
+      const int64_t* t = g->tuples + (size_t)(g->tuple_table[p] - 1) * (size_t)nc;
+      if (memcmp(t, key, sizeof(int64_t) * (size_t)nc) == 0) { gid = g->tuple_table[p] - 1; break; }
+      p = (p + 1) & (uint64_t)(g->tuple_table_cap - 1);
+    }
+    if (gid == PO_INVALID_ID && g->n_tuples < g->global_upper_bound) {
+      if (g->n_tuples == g->tuple_cap) {
+        g->tuple_cap *= 2;
+        g->tuples = (int64_t*)po_xrealloc(g->tuples, sizeof(int64_t) * (size_t)g->tuple_cap * (size_t)nc);
+      }
+      gid = g->n_tuples++;
+      memcpy(g->tuples + (size_t)gid * (size_t)nc, key, sizeof(int64_t) * (size_t)nc);
+      if ((int64_t)g->n_tuples * 2 > g->tuple_table_cap) {   /* rehash */
+        free(g->tuple_table);
+        g->tuple_table_cap *= 4;
+        g->tuple_table = (int32_t*)po_xcalloc((size_t)g->tuple_table_cap, 4);
+        for (int32_t k = 0; k < g->n_tuples; k++) tuple_table_insert(g, k);
+      } else {
+        g->tuple_table[p] = gid + 1;
+      }
+    }
+    out[i] = gid;
+  }
+}
 static int32_t gkg_upper_bound(group_key_gen* g) { /* getCurrentGroupKeyUpperBound */
   if (g->holder == HOLDER_ARRAY) return g->global_upper_bound;
+  if (g->holder == HOLDER_TUPLES) return g->n_tuples;
   return g->holder == HOLDER_INT_MAP ? g->imap.size : g->lmap.size;
 }
 static int32_t gkg_num_keys(group_key_gen* g) {
   if (g->holder == HOLDER_ARRAY) return g->num_keys;
+  if (g->holder == HOLDER_TUPLES) return g->n_tuples;
   return g->holder == HOLDER_INT_MAP ? g->imap.size : g->lmap.size;
 }
 
@@ -645,7 +718,9 @@ typedef struct po_agg_result {
 typedef struct po_result_impl {
   int32_t num_groups, n_group_cols, n_aggs;
   int32_t** group_dict_ids;
-  int64_t* group_values;     /* raw-value group keys (one no-dictionary group-by column), else NULL */
+  int64_t* group_values;     /* raw-value group keys (one no-dictionary INT / LONG group-by column), else NULL */
+  int32_t* key_types;        /* HOLDER_TUPLES: PG_GROUP_KEY_* per group-by column, else NULL */
+  int64_t** key_values;      /* HOLDER_TUPLES: per value-keyed column the groups' LONG values / DOUBLE bits */
   po_agg_result* aggs;
   pg_exec_stats stats;
 } po_result_impl;
@@ -767,8 +842,8 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
   for (int j = 0; j < n_gb; j++) {
     po_column* c = po_segment_column(seg, q->group_by_columns[j]);
     if (!c) { po_set_error("column not found: %s", q->group_by_columns[j]); return PG_ERR_NOT_FOUND; }
-    if (!c->has_dictionary && !(n_gb == 1 && (c->data_type == PG_TYPE_INT || c->data_type == PG_TYPE_LONG))) {
-      po_set_error("no-dictionary group-by column %s is outside the hot path (one raw INT / LONG column only)", c->name);
+    if (!c->has_dictionary && c->data_type > PG_TYPE_DOUBLE) {
+      po_set_error("no-dictionary group-by column %s: STRING / BYTES raw keys are outside the hot path", c->name);
       return PG_ERR_UNSUPPORTED;
     }
     gcols[j] = c;
@@ -903,6 +978,13 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
     if (n_gb > 0) {
       if (gkg.holder == HOLDER_RAW_VALUES) {
         gkg_generate_raw(&gkg, pos, doc_ids, group_keys);
+      } else if (gkg.holder == HOLDER_TUPLES) {
+        for (int j = 0; j < n_gb; j++) {
+          if (!gcols[j]->has_dictionary) continue;
+          for (int k = 0; k < n_proj; k++)
+            if (bcols[k].col == gcols[j]) { fetch_dict_ids(&bcols[k], doc_ids, pos); gdict[j] = bcols[k].dict_ids; }
+        }
+        gkg_generate_tuples(&gkg, pos, doc_ids, gdict, group_keys);
       } else {
         for (int j = 0; j < n_gb; j++) {
           for (int k = 0; k < n_proj; k++)
@@ -944,7 +1026,26 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
     res->group_values = (int64_t*)po_xcalloc((size_t)n_groups + 1, 8);
     for (int32_t i = 0; i < n_groups; i++) res->group_values[i] = gkg.raw_key_of_group[gid_of[i]];
   }
-  for (int32_t i = 0; i < n_groups && n_gb > 0 && gkg.holder != HOLDER_RAW_VALUES; i++) {  /* getKeys :578-591: col 0 is least significant */
+  if (n_gb > 0 && gkg.holder == HOLDER_TUPLES) {
+    res->key_types = (int32_t*)po_xcalloc((size_t)n_gb + 1, 4);
+    res->key_values = (int64_t**)po_xcalloc((size_t)n_gb + 1, sizeof(int64_t*));
+    for (int j = 0; j < n_gb; j++) {
+      const po_column* c = gcols[j];
+      if (c->has_dictionary) {
+        res->key_types[j] = PG_GROUP_KEY_DICT_IDS;
+        for (int32_t i = 0; i < n_groups; i++) res->group_dict_ids[j][i] = (int32_t)gkg.tuples[(size_t)gid_of[i] * (size_t)n_gb + (size_t)j];
+        continue;
+      }
+      res->key_types[j] = c->data_type <= PG_TYPE_LONG ? PG_GROUP_KEY_LONG_VALUES : PG_GROUP_KEY_DOUBLE_VALUES;
+      res->key_values[j] = (int64_t*)po_xcalloc((size_t)n_groups + 1, 8);
+      for (int32_t i = 0; i < n_groups; i++) {
+        int64_t k = gkg.tuples[(size_t)gid_of[i] * (size_t)n_gb + (size_t)j];
+        if (c->data_type == PG_TYPE_FLOAT) { uint32_t b = (uint32_t)k; float f; memcpy(&f, &b, 4); double d = (double)f; memcpy(&k, &d, 8); }
+        res->key_values[j][i] = k;
+      }
+    }
+  }
+  for (int32_t i = 0; i < n_groups && n_gb > 0 && gkg.holder != HOLDER_RAW_VALUES && gkg.holder != HOLDER_TUPLES; i++) {  /* getKeys :578-591: col 0 is least significant */
     int64_t raw = (gkg.holder == HOLDER_ARRAY) ? gid_of[i] : gkg.raw_key_of_group[gid_of[i]];
     for (int j = 0; j < n_gb; j++) {
       res->group_dict_ids[j][i] = (int32_t)(raw % gkg.cardinalities[j]);
@@ -979,13 +1080,23 @@ int32_t po_result_group_dict_ids(void* r, int32_t col, int32_t* out, int32_t cap
 }
 int32_t po_result_group_key_type(void* r, int32_t col, int32_t* out) {
   if (col < 0 || col >= RES(r)->n_group_cols) { po_set_error("group-by column index out of range"); return PG_ERR_INVALID_ARGUMENT; }
-  *out = RES(r)->group_values ? PG_GROUP_KEY_LONG_VALUES : PG_GROUP_KEY_DICT_IDS;
+  if (RES(r)->key_types) *out = RES(r)->key_types[col];
+  else *out = RES(r)->group_values ? PG_GROUP_KEY_LONG_VALUES : PG_GROUP_KEY_DICT_IDS;
   return PG_OK;
 }
 int32_t po_result_group_values_long(void* r, int32_t col, int64_t* out, int32_t cap) {
-  if (col != 0 || !RES(r)->group_values) { po_set_error("group-by column has dictIds, not raw values"); return PG_ERR_INVALID_ARGUMENT; }
-  if (cap < RES(r)->num_groups) { po_set_error("capacity too small"); return PG_ERR_INVALID_ARGUMENT; }
-  memcpy(out, RES(r)->group_values, sizeof(int64_t) * (size_t)RES(r)->num_groups);
+  if (col < 0 || col >= RES(r)->n_group_cols || cap < RES(r)->num_groups) { po_set_error("bad column/capacity"); return PG_ERR_INVALID_ARGUMENT; }
+  const int64_t* v = NULL;
+  if (RES(r)->key_types) v = RES(r)->key_types[col] == PG_GROUP_KEY_LONG_VALUES ? RES(r)->key_values[col] : NULL;
+  else if (col == 0) v = RES(r)->group_values;
+  if (!v) { po_set_error("group-by column does not have LONG values"); return PG_ERR_INVALID_ARGUMENT; }
+  memcpy(out, v, sizeof(int64_t) * (size_t)RES(r)->num_groups);
+  return PG_OK;
+}
+int32_t po_result_group_values_double(void* r, int32_t col, double* out, int32_t cap) {
+  if (col < 0 || col >= RES(r)->n_group_cols || cap < RES(r)->num_groups) { po_set_error("bad column/capacity"); return PG_ERR_INVALID_ARGUMENT; }
+  if (!RES(r)->key_types || RES(r)->key_types[col] != PG_GROUP_KEY_DOUBLE_VALUES) { po_set_error("group-by column does not have DOUBLE values"); return PG_ERR_INVALID_ARGUMENT; }
+  memcpy(out, RES(r)->key_values[col], sizeof(double) * (size_t)RES(r)->num_groups);
   return PG_OK;
 }
 int32_t po_result_kind_of(void* r, int32_t agg, int32_t* out) {

@@ -40,7 +40,7 @@ QUERY_FLAG_SKIP_STAR_TREE = 0x2
 QUERY_FLAG_KEEP_DEVICE_TABLE = 0x4
 QUERY_FLAG_APPROX_FILTER_STATS = 0x8
 COMM_UNIQUE_ID_BYTES = 128
-GROUP_KEY_DICT_IDS, GROUP_KEY_LONG_VALUES = 0, 1
+GROUP_KEY_DICT_IDS, GROUP_KEY_LONG_VALUES, GROUP_KEY_DOUBLE_VALUES = 0, 1, 2
 
 
 class PgBuffer(C.Structure):
@@ -160,7 +160,7 @@ ABI_SYMBOLS = [
     "filter_exec", "docidset_cardinality", "docidset_num_words", "docidset_copy_words", "docidset_copy_docids",
     "docidset_stats", "docidset_free",
     "query_supported", "query_exec",
-    "result_num_groups", "result_group_dict_ids", "result_group_key_type", "result_group_values_long", "result_kind_of", "result_doubles", "result_longs",
+    "result_num_groups", "result_group_dict_ids", "result_group_key_type", "result_group_values_long", "result_group_values_double", "result_kind_of", "result_doubles", "result_longs",
     "result_set_sizes", "result_set_dict_ids", "result_hll_registers", "result_stats", "result_free",
 ]
 # entry points only the product library has (the CPU oracle is one segment, one thread, no devices): multi-GPU placement,
@@ -222,6 +222,7 @@ class NativeApi:
         self.f("segment_set_range_index").argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
         self.f("result_group_key_type").argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         self.f("result_group_values_long").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        self.f("result_group_values_double").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
         self.f("result_kind_of").argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         self.f("result_doubles").argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
         self.f("result_longs").argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]

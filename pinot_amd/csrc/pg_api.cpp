@@ -268,7 +268,7 @@ int32_t pg_result_group_dict_ids(pg_result_t result, int32_t col, int32_t* out, 
     REQUIRE(result, "null argument");
     REQUIRE(col >= 0 && col < (int32_t)result->r->group_dict_ids.size(), "group-by column index out of range");
     REQUIRE(capacity >= result->r->num_groups, "capacity too small");
-    REQUIRE(!result->r->raw_group_keys, "group-by column has raw values, not dictIds (pg_result_group_values_long)");
+    REQUIRE(result->r->group_key_type[(size_t)col] == PG_GROUP_KEY_DICT_IDS, "group-by column has raw values, not dictIds (pg_result_group_values_long / _double)");
     const auto& v = result->r->group_dict_ids[col];
     if (!v.empty()) memcpy(out, v.data(), v.size() * 4);
   });
@@ -276,16 +276,28 @@ int32_t pg_result_group_dict_ids(pg_result_t result, int32_t col, int32_t* out, 
 int32_t pg_result_group_key_type(pg_result_t result, int32_t col, int32_t* out_type) {
   return guarded([&] {
     REQUIRE(result && out_type, "null argument");
-    REQUIRE(col >= 0 && col < (int32_t)result->r->group_dict_ids.size(), "group-by column index out of range");
-    *out_type = result->r->raw_group_keys ? PG_GROUP_KEY_LONG_VALUES : PG_GROUP_KEY_DICT_IDS;
+    REQUIRE(col >= 0 && col < (int32_t)result->r->group_key_type.size(), "group-by column index out of range");
+    *out_type = result->r->group_key_type[(size_t)col];
   });
 }
 int32_t pg_result_group_values_long(pg_result_t result, int32_t col, int64_t* out_values, int32_t capacity) {
   return guarded([&] {
     REQUIRE(result, "null argument");
-    REQUIRE(col == 0 && result->r->raw_group_keys, "group-by column has dictIds, not raw values");
+    REQUIRE(col >= 0 && col < (int32_t)result->r->group_key_type.size(), "group-by column index out of range");
+    REQUIRE(result->r->group_key_type[(size_t)col] == PG_GROUP_KEY_LONG_VALUES, "group-by column does not have LONG values");
     REQUIRE(capacity >= result->r->num_groups, "capacity too small");
-    if (!result->r->group_values.empty()) memcpy(out_values, result->r->group_values.data(), result->r->group_values.size() * 8);
+    const auto& v = result->r->group_values[(size_t)col];
+    if (!v.empty()) memcpy(out_values, v.data(), v.size() * 8);
+  });
+}
+int32_t pg_result_group_values_double(pg_result_t result, int32_t col, double* out_values, int32_t capacity) {
+  return guarded([&] {
+    REQUIRE(result, "null argument");
+    REQUIRE(col >= 0 && col < (int32_t)result->r->group_key_type.size(), "group-by column index out of range");
+    REQUIRE(result->r->group_key_type[(size_t)col] == PG_GROUP_KEY_DOUBLE_VALUES, "group-by column does not have DOUBLE values");
+    REQUIRE(capacity >= result->r->num_groups, "capacity too small");
+    const auto& v = result->r->group_values[(size_t)col];
+    if (!v.empty()) memcpy(out_values, v.data(), v.size() * 8);
   });
 }
 static AggResult& agg_of(pg_result_t result, int32_t agg) {

@@ -722,17 +722,30 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
   }
   const int32_t ng = (int32_t)gids.size();
   res.num_groups = ng;
-  if (P.raw_group) {   // values, not dictIds: key = value ^ 2^63
-    res.raw_group_keys = true;
-    res.group_values.resize((size_t)ng);
-    for (int32_t i = 0; i < ng; i++) res.group_values[(size_t)i] = (int64_t)((uint64_t)H.hash_keys[(size_t)gids[i]] ^ (1ULL << 63));
+  res.group_key_type.assign((size_t)n_group_by, PG_GROUP_KEY_DICT_IDS);
+  res.group_values.assign((size_t)n_group_by, {});
+  res.group_dict_ids.assign((size_t)n_group_by, {});
+  if (P.raw_group) {   // one raw INT / LONG column hashed by value: key = value ^ 2^63
+    res.group_key_type[0] = PG_GROUP_KEY_LONG_VALUES;
+    res.group_values[0].resize((size_t)ng);
+    for (int32_t i = 0; i < ng; i++) res.group_values[0][(size_t)i] = (int64_t)((uint64_t)H.hash_keys[(size_t)gids[i]] ^ (1ULL << 63));
   }
-  res.group_dict_ids.resize((size_t)n_group_by);
   for (int j = 0; j < n_group_by && !P.raw_group; j++) {
-    auto& v = res.group_dict_ids[j];
-    v.resize((size_t)ng);
     int64_t mult = D.gcols[j].mult;
     int32_t card = P.group_cards[j];
+    const Column* vd = (size_t)j < P.group_vdict.size() ? P.group_vdict[(size_t)j] : nullptr;
+    if (vd) {   // ids of a virtual dictionary: hand the values over (the caller holds no dictionary for this column)
+      res.group_key_type[(size_t)j] = vd->vdict_kind <= 1 ? PG_GROUP_KEY_LONG_VALUES : PG_GROUP_KEY_DOUBLE_VALUES;
+      auto& v = res.group_values[(size_t)j];
+      v.resize((size_t)ng);
+      for (int32_t i = 0; i < ng; i++) {
+        const int64_t raw = hashed ? H.hash_keys[(size_t)gids[i]] : gids[i];
+        v[(size_t)i] = vdict_value_of_key(vd->vdict_keys[(size_t)((raw / mult) % card)], vd->vdict_kind, nullptr);
+      }
+      continue;
+    }
+    auto& v = res.group_dict_ids[j];
+    v.resize((size_t)ng);
     for (int32_t i = 0; i < ng; i++) {   // getKeys: col 0 least significant
       const int64_t raw = hashed ? H.hash_keys[(size_t)gids[i]] : gids[i];
       v[i] = (int32_t)((raw / mult) % card);
@@ -893,6 +906,7 @@ int64_t table_signature(const DeviceTable& T) {
   for (int x = 0; x < D.n_aux; x++) { mix((uint64_t)D.aux[x].kind); mix((uint64_t)D.aux[x].stride); mix((uint64_t)D.aux[x].n_rep); mix((uint64_t)D.aux[x].rep_bytes); }
   for (size_t a = 0; a < T.plan->aggs.size(); a++) { mix((uint64_t)T.plan->aggs[a].function); mix((uint64_t)(uint32_t)T.plan->aggs[a].op_a); }
   for (int32_t c : T.plan->group_cards) mix((uint64_t)c);
+  for (const Column* vd : T.plan->group_vdict) if (vd) mix(vd->vdict_hash);   // segment-local ids: only equal dictionaries merge
   return (int64_t)(h >> 2);   // 62 bits: survives ncclMax / negation
 }
 void device_table_tail_store(DeviceTable& T, hipStream_t stream) {   // full-scan entries + total docs behind the statistics counters

@@ -104,6 +104,12 @@ struct Column {
   bool dict_affine = false;                     // INT / LONG dictionary whose values are base + step x dictId (ids, dense enumerations)
   int64_t dict_base = 0, dict_step = 0;
   std::map<int, DeviceBuffer> hll_luts;         // per log2m: (register index | rank << 16) of every dictionary value
+  // virtual dictionary of a raw group-by column (pg_vdict.hip): a Column of bit-packed ids whose `vdict_keys` are the distinct values
+  // (order-preserving 64-bit keys, ascending); built at first use, under the segment's lock
+  std::unique_ptr<Column> vdict;
+  std::vector<uint64_t> vdict_keys;
+  int vdict_kind = -1;                          // 0 INT, 1 LONG, 2 FLOAT, 3 DOUBLE (set on the id column)
+  uint64_t vdict_hash = 0;
   int32_t hll_log2m = 0;                        // PG_COL_HLL_REGS: log2m of the serialized HyperLogLogs
 };
 
@@ -146,6 +152,8 @@ struct StarTree {
 };
 
 void segment_add_column(Segment& seg, const pg_column_desc& d);
+void ensure_virtual_dictionary(Segment& seg, Column& c);            // pg_vdict.hip
+int64_t vdict_value_of_key(uint64_t key, int kind, double* as_double);   // the value behind an order-preserving key (FLOAT / DOUBLE: IEEE double bits)
 double limbs_to_double(const int64_t* limbs, int n_limbs, int q);   // sum_j limbs[j] * 2^(32 j + q), correctly rounded (pg_plan.cpp)
 void segment_add_star_tree(Segment& seg, const pg_star_tree_desc& d);
 // ZSTANDARD / GZIP chunks: host decode at registration (pg_host_codecs.cpp)
@@ -249,7 +257,8 @@ struct CompiledPlan {
   size_t lds_bytes = 0;
   int32_t num_groups_limit = 0;
   int32_t exist_op = 0;              // accumulator whose value tells whether a group was touched
-  bool raw_group = false;            // the single group-by column has no dictionary: keys are values (hash group-by)
+  bool raw_group = false;            // the single group-by column is a raw INT / LONG column: keys are values (hash group-by)
+  std::vector<Column*> group_vdict;  // per group-by column: its virtual dictionary (raw column grouped through ids), or null
   int32_t first_doc_op = -1;         // MIN(docId) per group, present when the key space exceeds numGroupsLimit
   int32_t fast_filter = -2;          // -2: interpreter kernel; -1: index-only filter; >= 0: ScanKind of the one scan leaf
   bool fast_agg = true;              // aggregation fits the fast kernels (or there is none)
@@ -293,8 +302,10 @@ struct Result {
   std::unique_ptr<DeviceTable> dev;    // PG_QUERY_FLAG_KEEP_DEVICE_TABLE
   int32_t num_groups = 0;
   std::vector<std::vector<int32_t>> group_dict_ids;
-  std::vector<int64_t> group_values;   // one no-dictionary group-by column: the groups' values (group_dict_ids stays empty)
-  bool raw_group_keys = false;
+  // no-dictionary group-by columns: per column the key type (PG_GROUP_KEY_*) and, for value keys, the groups' values (LONG values,
+  // or the IEEE bits of DOUBLE values); group_dict_ids[col] stays empty for them
+  std::vector<int32_t> group_key_type;
+  std::vector<std::vector<int64_t>> group_values;
   std::vector<AggResult> aggs;
   pg_exec_stats stats{};
 };

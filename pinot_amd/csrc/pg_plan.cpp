@@ -1128,24 +1128,33 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     if (!q->group_by_columns) fail(PG_ERR_INVALID_ARGUMENT, "group_by_columns is null");
     Column* c = seg.find(q->group_by_columns[j]);
     if (!c) fail(PG_ERR_NOT_FOUND, "column not found: %s", q->group_by_columns[j] ? q->group_by_columns[j] : "(null)");
-    if (!c->has_dictionary) {
+    const bool one_raw_int = !c->has_dictionary && q->n_group_by == 1 && (c->col_kind == PG_COL_RAW32 || c->col_kind == PG_COL_RAW64) &&
+                             (c->data_type == PG_TYPE_INT || c->data_type == PG_TYPE_LONG);
+    if (one_raw_int) {
       // NoDictionarySingleColumnGroupKeyGenerator (core/query/aggregation/groupby/NoDictionarySingleColumnGroupKeyGenerator.java:53-90,
       // 241-265): one raw INT / LONG column, value -> group id; here the value is the 64-bit key of the hash group-by
-      if (q->n_group_by != 1 || (c->col_kind != PG_COL_RAW32 && c->col_kind != PG_COL_RAW64) ||
-          (c->data_type != PG_TYPE_INT && c->data_type != PG_TYPE_LONG))
-        fail(PG_ERR_UNSUPPORTED, "no-dictionary group-by column %s (one raw INT / LONG column only)", c->name.c_str());
       D.gcols[j].data = c->fwd_dev.as<uint8_t>();
       D.gcols[j].bits = 0;
       D.gcols[j].mult = 1;
       D.gcols[j].col_kind = c->col_kind;
       P.group_cols.push_back(c);
       P.group_cards.push_back(0);
+      P.group_vdict.push_back(nullptr);
       P.raw_group = true;
       huge_key_space = true;
       G = (int64_t)1 << 40;   // unknown number of distinct values: everything that compares G with a limit sees "large"
       project(c);
       continue;
     }
+    Column* raw = nullptr;
+    if (!c->has_dictionary) {
+      // any other raw key — FLOAT / DOUBLE, or a raw column among several group-by columns (NoDictionaryMultiColumnGroupKeyGenerator's
+      // on-the-fly dictionaries): grouped through the column's virtual dictionary (pg_vdict.hip), like a dictionary column from here on
+      ensure_virtual_dictionary(seg, *c);
+      raw = c;
+      c = c->vdict.get();
+    }
+    P.group_vdict.push_back(raw ? c : nullptr);
     D.gcols[j].data = c->fwd_dev.as<uint8_t>();
     D.gcols[j].bits = c->bits;
     D.gcols[j].mult = G;
@@ -1157,7 +1166,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     if (G > kMaxDenseGroups / std::max(c->cardinality, 1)) huge_key_space = true;
     if (G > ((int64_t)1 << 62) / std::max(c->cardinality, 1)) fail(PG_ERR_UNSUPPORTED, "group key space beyond 2^62 (ArrayMapBasedHolder) is outside the GPU path");
     G *= c->cardinality;
-    project(c);
+    project(raw ? raw : c);
   }
   D.n_group_cols = q->n_group_by;
   D.n_groups = huge_key_space ? 0 : (int32_t)G;

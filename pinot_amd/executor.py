@@ -295,6 +295,17 @@ class DocIdSet:
             pass
 
 
+def _key_repr(v):
+    """Group key component as a dict key: floats keep their sign of zero (-0.0 and 0.0 are two groups in the reference's
+    Float2Int / Double2Int maps, but equal as Python floats) and NaN compares equal to itself."""
+    if isinstance(v, float):
+        if v != v:
+            return "NaN"
+        if v == 0.0:
+            return "-0.0" if math.copysign(1.0, v) < 0 else 0.0
+    return v
+
+
 class ResultsBlock:
     """GroupByResultsBlock / AggregationResultsBlock: intermediate results per group key.
 
@@ -324,15 +335,22 @@ class ResultsBlock:
         ngb = len(qc.group_by)
         ids = np.zeros((ngb, ng), dtype=np.int32)
         rb.group_values = None
+        rb.group_value_columns = {}      # group-by column index -> the groups' values (no-dictionary columns)
         for j in range(ngb):
             kt = C.c_int32()
             api.call("result_group_key_type", h, j, C.byref(kt))
             if kt.value == capi.GROUP_KEY_LONG_VALUES:   # a no-dictionary group-by column: the groups' values themselves
                 vals = np.zeros(ng, dtype=np.int64)
                 api.call("result_group_values_long", h, j, vals.ctypes.data, ng)
-                rb.group_values = vals
+                rb.group_value_columns[j] = vals
+            elif kt.value == capi.GROUP_KEY_DOUBLE_VALUES:
+                vals = np.zeros(ng, dtype=np.float64)
+                api.call("result_group_values_double", h, j, vals.ctypes.data, ng)
+                rb.group_value_columns[j] = vals
             else:
                 api.call("result_group_dict_ids", h, j, ids[j].ctypes.data, ng)
+        if ngb == 1 and 0 in rb.group_value_columns and rb.group_value_columns[0].dtype == np.int64:
+            rb.group_values = rb.group_value_columns[0]
         rb.group_dict_ids = ids
         for a, spec in enumerate(qc.aggregations):
             kind = C.c_int32()
@@ -387,9 +405,17 @@ class ResultsBlock:
             self._group_keys = [(int(v),) for v in self.group_values]
         if self._group_keys is None:
             ids = self.group_dict_ids
-            dicts = [self._host.columns[g].dict_values for g in self.query.group_by]
+            vcols = getattr(self, "group_value_columns", {})
             ng = self.num_groups
-            self._group_keys = [tuple(dicts[j][ids[j, i]] for j in range(len(dicts))) for i in range(ng)]
+            per_col = []
+            for j, g in enumerate(self.query.group_by):
+                if j in vcols:   # raw values; a NaN key is one group: give it a key that compares equal to itself
+                    v = vcols[j]
+                    per_col.append([int(x) for x in v] if v.dtype == np.int64 else [float(x) for x in v])
+                else:
+                    dv = self._host.columns[g].dict_values
+                    per_col.append([dv[ids[j, i]] for i in range(ng)])
+            self._group_keys = [tuple(_key_repr(per_col[j][i]) for j in range(len(per_col))) for i in range(ng)]
         return self._group_keys
 
     @property

@@ -20,16 +20,20 @@ def raw_key_segment(n=150_000, seed=11):
     kl[rng.integers(0, n, 40)] = np.iinfo(np.int64).min
     kl[rng.integers(0, n, 40)] = np.iinfo(np.int64).max - 1
     kw = rng.integers(0, 1 << 40, n).astype(np.int64)            # nearly all distinct: numGroupsLimit trims
+    kf = rng.choice(np.array([0.0, -0.0, 1.5, -2.25, 3.0e10, np.nan, np.inf, -np.inf, 1e-40], dtype=np.float32), n)   # -0.0 / 0.0 are two keys, NaN one
+    kf[rng.integers(0, n, 30)] = np.frombuffer(np.array([0x7FC00001, 0xFFC12345], dtype=np.uint32).tobytes(), dtype=np.float32)[rng.integers(0, 2, 30)]  # other NaN payloads
+    kd = rng.integers(-300, 300, n) * 0.1                        # non-dyadic doubles: the key is the exact bit pattern
+    kd[rng.integers(0, n, 60)] = rng.choice(np.array([np.nan, -0.0, 0.0, 1e300]), 60)
     data = {
-        "ki": ki, "kl": kl, "kw": kw,
+        "ki": ki, "kl": kl, "kw": kw, "kf": kf, "kd": kd,
         "f": rng.integers(0, 20, n).astype(np.int32),
         "r": rng.integers(0, 100_000, n).astype(np.int32),
         "m": rng.integers(-1000, 1 << 20, n).astype(np.int32),
         "ml": rng.integers(-(1 << 40), 1 << 40, n).astype(np.int64),
         "md": rng.integers(-(1 << 30), 1 << 30, n) * 0.25,      # dyadic: double sums are exact in any order
     }
-    schema = {"ki": "INT", "kl": "LONG", "kw": "LONG", "f": "INT", "r": "INT", "m": "INT", "ml": "LONG", "md": "DOUBLE"}
-    host = build_segment("rawKeys_0", data, schema, inverted_index_columns=["f"], no_dictionary_columns=["ki", "kl", "kw", "r", "m", "ml", "md"])
+    schema = {"ki": "INT", "kl": "LONG", "kw": "LONG", "kf": "FLOAT", "kd": "DOUBLE", "f": "INT", "r": "INT", "m": "INT", "ml": "LONG", "md": "DOUBLE"}
+    host = build_segment("rawKeys_0", data, schema, inverted_index_columns=["f"], no_dictionary_columns=["ki", "kl", "kw", "kf", "kd", "r", "m", "ml", "md"])
     return host, data
 
 
@@ -77,12 +81,81 @@ def test_oracle_raw_group_by_matches_numpy(oracle_api):
     o.destroy()
 
 
-def test_oracle_rejects_other_raw_group_by_shapes(oracle_api):
-    host, _ = raw_key_segment(2_000)
+# FLOAT / DOUBLE raw keys (Float2Int / Double2IntOpenHashMap) and any group-by with a raw column among several
+# (NoDictionaryMultiColumnGroupKeyGenerator.java:60-130): (query, numGroupsLimit)
+MULTI_RAW_QUERIES = [
+    ("SELECT kf, COUNT(*), SUM(m) FROM rawKeys GROUP BY kf LIMIT 100000", None),
+    ("SELECT kd, COUNT(*), MAX(ml) FROM rawKeys WHERE f IN (1, 4, 7) GROUP BY kd LIMIT 100000", None),
+    ("SELECT ki, kf, COUNT(*), SUM(m) FROM rawKeys GROUP BY ki, kf LIMIT 1000000", 1_000_000),
+    ("SELECT f, kd, COUNT(*), MIN(m), AVG(md) FROM rawKeys WHERE r BETWEEN 20000 AND 70000 GROUP BY f, kd LIMIT 100000", None),
+    ("SELECT kl, f, ki, SUM(ml) FROM rawKeys GROUP BY kl, f, ki LIMIT 1000000", 1_000_000),
+    ("SELECT ki, kl, COUNT(*) FROM rawKeys GROUP BY ki, kl LIMIT 1000000", 3000),          # numGroupsLimit trims in docId order
+    ("SELECT kd, kf, COUNT(*) FROM rawKeys WHERE r > 1000000 GROUP BY kd, kf LIMIT 10", None),   # nothing matches
+]
+
+
+def key_bits(data, col):
+    """The key the fastutil maps compare: the value for INT / LONG, floatToIntBits / doubleToLongBits for FLOAT / DOUBLE."""
+    v = data[col]
+    if v.dtype == np.float32:
+        b = v.view(np.uint32).astype(np.int64)
+        return np.where(np.isnan(v), 0x7FC00000, b)
+    if v.dtype == np.float64:
+        b = v.view(np.int64)
+        return np.where(np.isnan(v), 0x7FF8000000000000, b)
+    return v.astype(np.int64)
+
+
+def key_repr(data, col, bits):
+    """executor._key_repr of the value behind `bits`."""
+    v = data[col]
+    if v.dtype == np.float32:
+        x = float(np.array([bits], dtype=np.int64).astype(np.uint32).view(np.float32)[0])
+    elif v.dtype == np.float64:
+        x = float(np.array([bits], dtype=np.int64).view(np.float64)[0])
+    else:
+        return int(bits)
+    if x != x:
+        return "NaN"
+    if x == 0.0:
+        return "-0.0" if np.signbit(x) else 0.0
+    return x
+
+
+def test_oracle_multi_column_raw_keys_match_numpy(oracle_api):
+    host, data = raw_key_segment(40_000)
     o = NativeSegment(oracle_api, host)
-    for q in ("SELECT ki, kl, COUNT(*) FROM rawKeys GROUP BY ki, kl LIMIT 10", "SELECT md, COUNT(*) FROM rawKeys GROUP BY md LIMIT 10"):
-        with pytest.raises(capi.NativeError):
-            o.execute(q)
+    for cols, mask, limit in ((["kf"], np.ones(40_000, bool), 100_000), (["ki", "kf"], np.ones(40_000, bool), 100_000),
+                              (["f", "kd"], (data["r"] >= 20000) & (data["r"] <= 70000), 100_000), (["ki", "kl"], np.ones(40_000, bool), 900)):
+        where = " WHERE r BETWEEN 20000 AND 70000" if not mask.all() else ""
+        q = parse_sql(f"SELECT {', '.join(cols)}, COUNT(*), SUM(m) FROM rawKeys{where} GROUP BY {', '.join(cols)} LIMIT 1000000")
+        q.num_groups_limit = limit
+        b = o.execute(q)
+        docs = np.flatnonzero(mask)
+        keys = np.stack([key_bits(data, c)[docs] if c != "f" else data["f"][docs].astype(np.int64) for c in cols], axis=1)
+        want, order = {}, []
+        for d, k in zip(docs, map(tuple, keys)):
+            if k not in want:
+                if len(order) >= limit:
+                    continue
+                want[k] = [0, 0.0]
+                order.append(k)
+            want[k][0] += 1
+            want[k][1] += float(data["m"][d])
+        rows = b.rows()
+        assert len(rows) == len(want), cols
+        assert bool(b.stats.num_groups_limit_reached) == (len(want) >= limit)
+        for k, (cnt, sm) in want.items():
+            kk = tuple(key_repr(data, c, kb) if c != "f" else int(kb) for c, kb in zip(cols, k))
+            assert rows[kk] == [cnt, sm], (cols, kk)
+    o.destroy()
+
+
+def test_oracle_dictionary_string_with_raw_int_keys(oracle_api):
+    host = build_segment("s_0", {"s": np.array(["a", "b", "a"]), "m": np.arange(3, dtype=np.int32)}, {"s": "STRING", "m": "INT"},
+                         no_dictionary_columns=["m"])
+    o = NativeSegment(oracle_api, host)
+    assert len(o.execute("SELECT s, m, COUNT(*) FROM s GROUP BY s, m LIMIT 10").rows()) == 3   # dictionary STRING + raw INT: fine
     o.destroy()
 
 
@@ -107,13 +180,32 @@ def test_gpu_raw_group_by_matches_oracle(gpu_api, oracle_api, q, limit):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("q,limit", MULTI_RAW_QUERIES)
+def test_gpu_virtual_dictionary_group_by_matches_oracle(gpu_api, oracle_api, q, limit):
+    """Raw FLOAT / DOUBLE keys and raw columns among several group-by columns run through the columns' virtual dictionaries
+    (pg_vdict.hip): same groups, same values, same trimming as the oracle's tuple map."""
+    host, _ = raw_key_segment()
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    qg, qo = parse_sql(q), parse_sql(q)
+    if limit:
+        qg.num_groups_limit = qo.num_groups_limit = limit
+    for _ in range(2):   # the second run takes the cached dictionary and the cached plan
+        gb, ob = g.execute(qg), o.execute(qo)
+        gr, orr = gb.rows(), ob.rows()
+        assert len(gr) == len(orr)
+        assert set(gr) == set(orr)
+        for k in orr:
+            assert gr[k] == orr[k], (k, gr[k], orr[k])
+        assert gb.stats.num_docs_scanned == ob.stats.num_docs_scanned
+        assert gb.stats.num_entries_scanned_post_filter == ob.stats.num_entries_scanned_post_filter
+        assert gb.stats.num_groups_limit_reached == ob.stats.num_groups_limit_reached
+    g.destroy()
+    o.destroy()
+
+
+@pytest.mark.gpu
 def test_gpu_raw_group_by_rejections(gpu_api):
     host, data = raw_key_segment(5_000)
-    g = NativeSegment(gpu_api, host)
-    for q in ("SELECT ki, kl, COUNT(*) FROM rawKeys GROUP BY ki, kl LIMIT 10", "SELECT md, COUNT(*) FROM rawKeys GROUP BY md LIMIT 10"):
-        with pytest.raises(capi.NativeError):
-            g.execute(q)
-    g.destroy()
     # Long.MAX_VALUE is the hash table's empty marker: refused, not answered wrongly
     data = dict(data)
     data["kl"] = data["kl"].copy()
