@@ -621,6 +621,17 @@ static void agg_process_block(agg_state* a, block_col* bc, const int32_t* doc_id
       }
       return;
     case PG_AGG_AVG:
+      if (a->col->data_type == PG_TYPE_BYTES) {   /* serialized AvgPair (star-tree pair avg__x): AvgAggregationFunction.java:79-93,117-126 */
+        for (int i = 0; i < n; i++) {
+          int32_t g = group_keys ? group_keys[i] : 0;
+          if (g == PO_INVALID_ID) continue;
+          int32_t len = 0;
+          const uint8_t* blob = po_raw_get_bytes(a->col, doc_ids[i], &len);
+          if (len < 16) continue;
+          a->d0[g] += po_bef64(blob); a->l0[g] += (int64_t)po_be64(blob + 8); a->has[g] = 1;   /* AvgPair#apply(sum, count) */
+        }
+        return;
+      }
       fetch_doubles(bc, doc_ids, n);
       if (!group_keys) {
         double inner = 0;
@@ -635,6 +646,19 @@ static void agg_process_block(agg_state* a, block_col* bc, const int32_t* doc_id
       }
       return;
     case PG_AGG_MINMAXRANGE:
+      if (a->col->data_type == PG_TYPE_BYTES) {   /* serialized MinMaxRangePair (star-tree pair minMaxRange__x): MinMaxRangeAggregationFunction */
+        for (int i = 0; i < n; i++) {
+          int32_t g = group_keys ? group_keys[i] : 0;
+          if (g == PO_INVALID_ID) continue;
+          int32_t len = 0;
+          const uint8_t* blob = po_raw_get_bytes(a->col, doc_ids[i], &len);
+          if (len < 16) continue;
+          const double lo = po_bef64(blob), hi = po_bef64(blob + 8);
+          if (!a->has[g]) { a->d0[g] = lo; a->d1[g] = hi; a->has[g] = 1; }
+          else { if (lo < a->d0[g]) a->d0[g] = lo; if (hi > a->d1[g]) a->d1[g] = hi; }
+        }
+        return;
+      }
       fetch_doubles(bc, doc_ids, n);
       for (int i = 0; i < n; i++) {
         int32_t g = group_keys ? group_keys[i] : 0;

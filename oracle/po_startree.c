@@ -447,10 +447,6 @@ int po_star_tree_plan(po_segment* seg, po_star_tree* st, const pg_query* q, po_f
       const uint8_t* blob = po_raw_get_bytes(st->pair_cols[pi], 0, &len);
       if (len < 8 || (int32_t)po_be32(blob) != (s->log2m > 0 ? s->log2m : 8)) return 0;
     }
-    if (s->function == PG_AGG_AVG || s->function == PG_AGG_MINMAXRANGE) {  /* BYTES pairs (AvgPair / MinMaxRangePair) */
-      po_set_error("star-tree pair of function %d is outside the hot path", s->function);
-      return PG_ERR_UNSUPPORTED;
-    }
   }
   pred_map pm; pm.n = 0; pm.cols = NULL;
   int r = extract_pred_map(seg, q->filter, &pm);

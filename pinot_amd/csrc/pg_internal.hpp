@@ -141,6 +141,7 @@ struct StarTreePair {
   int32_t function = 0;      // pg_agg_function
   std::string column;        // "*" for COUNT
   Column* col = nullptr;     // column of `space` named AggregationFunctionColumnPair#toColumnName
+  Column* col_b = nullptr;   // AVG / MINMAXRANGE pairs (BYTES: AvgPair / MinMaxRangePair) are split in two raw columns: col = sum / min, col_b = count / max
 };
 struct StarTree {
   Segment space;

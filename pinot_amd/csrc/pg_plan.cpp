@@ -1246,6 +1246,26 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
         P.aggs.push_back(out);
         continue;
       }
+      if (s.function == PG_AGG_AVG || s.function == PG_AGG_MINMAXRANGE) {
+        // serialized AvgPair / MinMaxRangePair (AvgAggregationFunction.java:79-93,117-126): sum of the sums + sum of the counts,
+        // min of the mins + max of the maxes — over the pair's two halves (pg_startree.cpp upload_pair16); ONE projected column
+        const StarTreePair& sp = st->pairs[(size_t)st->pair_index(s.function, s.column)];
+        if (!sp.col_b) fail(PG_ERR_UNSUPPORTED, "star-tree pair of function %d is not a BYTES pair", s.function);
+        const int32_t sa = src_index(sp.col), sb = src_index(sp.col_b);
+        out.is_float = true;
+        if (s.function == PG_AGG_AVG) {
+          sum_ops(sp.col, sa, out);
+          AggOut cnt{};
+          sum_ops(sp.col_b, sb, cnt);
+          if (cnt.sum_limbs != 0) fail(PG_ERR_UNSUPPORTED, "star-tree AvgPair counts beyond int64 sums");
+          out.op_b = cnt.op_a;
+        } else {
+          out.op_a = op_index(PG_ACC_MIN, sa, true);
+          out.op_b = op_index(PG_ACC_MAX, sb, true);
+        }
+        P.aggs.push_back(out);
+        continue;
+      }
       if (s.function == PG_AGG_DISTINCTCOUNTHLL) {   // serialized HyperLogLogs: register-wise max (addAll)
         if (D.n_aux >= PG_MAX_AUX) fail(PG_ERR_UNSUPPORTED, "more than %d DISTINCTCOUNT / DISTINCTCOUNTHLL aggregations", PG_MAX_AUX);
         PgAuxOp& A = D.aux[D.n_aux];

@@ -107,6 +107,63 @@ static void upload_hll_pair(Segment& space, Column& c, const uint8_t* fwd, uint6
   c.fwd_bytes_logical = len;
 }
 
+// AvgPair (BE double sum, BE long count: AvgPair#toBytes) / MinMaxRangePair (BE double min, BE double max) stored as BYTES in a
+// var-byte chunk forward index (AvgValueAggregator / MinMaxRangeValueAggregator: 16 bytes per star-tree doc): split into two raw
+// 64-bit columns of the star-tree's doc space, which the kernels aggregate like any SUM / MIN / MAX source.
+static void upload_pair16(Segment& space, const std::string& name, int32_t type_a, int32_t type_b, const char* suffix_a, const char* suffix_b,
+                          const uint8_t* fwd, uint64_t len) {
+  if (len < 28) fail(PG_ERR_INVALID_ARGUMENT, "raw forward index of %s too short", name.c_str());
+  const int32_t version = (int32_t)be32(fwd), num_chunks = (int32_t)be32(fwd + 4), docs_per_chunk = (int32_t)be32(fwd + 8);
+  const int32_t compression = (int32_t)be32(fwd + 20), header_start = (int32_t)be32(fwd + 24);
+  if (version < 2 || version > 3) fail(PG_ERR_UNSUPPORTED, "column %s: var-byte chunk writer version %d", name.c_str(), version);
+  if (compression != 0) fail(PG_ERR_UNSUPPORTED, "column %s: chunk compression type %d (only PASS_THROUGH is on the GPU path)", name.c_str(), compression);
+  const int off_size = version == 2 ? 4 : 8;
+  if (docs_per_chunk <= 0 || (uint64_t)header_start + (uint64_t)num_chunks * off_size > len) fail(PG_ERR_INVALID_ARGUMENT, "raw forward index of %s corrupt", name.c_str());
+  auto chunk_pos = [&](int32_t ch) -> uint64_t {
+    const uint8_t* p = fwd + header_start + (uint64_t)ch * off_size;
+    return off_size == 4 ? (uint64_t)be32(p) : be64(p);
+  };
+  const int32_t n = space.total_docs;
+  // two PASS_THROUGH fixed-byte forward indexes (version 3 header, one chunk), built on the host and registered like any raw column
+  auto blob = [&](int which) {
+    std::vector<uint8_t> b(28 + 8 + (size_t)std::max(n, 1) * 8, 0);
+    const uint32_t hdr[7] = {3u, 1u, (uint32_t)std::max(n, 1), 8u, (uint32_t)n, 0u, 28u};
+    for (int w = 0; w < 7; w++) for (int k = 0; k < 4; k++) b[(size_t)w * 4 + (size_t)k] = (uint8_t)(hdr[w] >> (24 - 8 * k));
+    const uint64_t first = 28 + 8;
+    for (int k = 0; k < 8; k++) b[28 + (size_t)k] = (uint8_t)(first >> (56 - 8 * k));
+    (void)which;
+    return b;
+  };
+  std::vector<uint8_t> a = blob(0), b = blob(1);
+  for (int32_t doc = 0; doc < n; doc++) {
+    const int32_t ch = doc / docs_per_chunk, row = doc % docs_per_chunk;
+    if (ch >= num_chunks) fail(PG_ERR_INVALID_ARGUMENT, "raw forward index of %s truncated", name.c_str());
+    const uint64_t cs = chunk_pos(ch), ce = ch + 1 < num_chunks ? chunk_pos(ch + 1) : len;
+    if (cs + (uint64_t)docs_per_chunk * 4 > len || ce > len) fail(PG_ERR_INVALID_ARGUMENT, "raw forward index of %s corrupt", name.c_str());
+    const uint64_t start = cs + be32(fwd + cs + (uint64_t)row * 4);
+    uint64_t end = ce;
+    if (row != docs_per_chunk - 1) {
+      const uint32_t nxt = be32(fwd + cs + (uint64_t)(row + 1) * 4);
+      if (nxt != 0) end = cs + nxt;
+    }
+    if (end > len || start + 16 > end) fail(PG_ERR_INVALID_ARGUMENT, "serialized pair of %s doc %d is malformed", name.c_str(), doc);
+    memcpy(a.data() + 36 + (size_t)doc * 8, fwd + start, 8);        // stays big-endian, as a raw forward index is
+    memcpy(b.data() + 36 + (size_t)doc * 8, fwd + start + 8, 8);
+  }
+  auto add = [&](const std::vector<uint8_t>& bytes, int32_t type, const char* suffix) {
+    const std::string cn = name + suffix;
+    pg_column_desc cd{};
+    cd.name = cn.c_str();
+    cd.data_type = type;
+    cd.fwd_encoding = PG_FWD_RAW_FIXED_BYTE_CHUNK;
+    cd.forward_index.addr = bytes.data();
+    cd.forward_index.size = bytes.size();
+    segment_add_column(space, cd);
+  };
+  add(a, type_a, suffix_a);
+  add(b, type_b, suffix_b);
+}
+
 void segment_add_star_tree(Segment& seg, const pg_star_tree_desc& d) {
   if (d.n_dimensions <= 0 || !d.dimensions || !d.dimension_forward_indexes || !d.star_tree.addr || d.num_docs < 0 || (d.n_pairs > 0 && !d.pairs))
     fail(PG_ERR_INVALID_ARGUMENT, "bad star-tree descriptor");
@@ -179,6 +236,15 @@ void segment_add_star_tree(Segment& seg, const pg_star_tree_desc& d) {
     sp_pair.function = p.function;
     sp_pair.column = p.function == PG_AGG_COUNT ? "*" : (p.column ? p.column : "");
     const std::string name = std::string(fname) + "__" + sp_pair.column;   // AggregationFunctionColumnPair#toColumnName
+    if (p.data_type == PG_TYPE_BYTES && (p.function == PG_AGG_AVG || p.function == PG_AGG_MINMAXRANGE)) {
+      const bool avg = p.function == PG_AGG_AVG;
+      upload_pair16(sp, name, PG_TYPE_DOUBLE, avg ? PG_TYPE_LONG : PG_TYPE_DOUBLE, avg ? "$sum" : "$min", avg ? "$count" : "$max",
+                    (const uint8_t*)p.forward_index.addr, p.forward_index.size);
+      sp_pair.col = sp.find((name + (avg ? "$sum" : "$min")).c_str());
+      sp_pair.col_b = sp.find((name + (avg ? "$count" : "$max")).c_str());
+      st->pairs.push_back(sp_pair);
+      continue;
+    }
     if (p.data_type == PG_TYPE_BYTES) {
       if (p.function != PG_AGG_DISTINCTCOUNTHLL) fail(PG_ERR_UNSUPPORTED, "star-tree pair %s (BYTES) is outside the hot path", name.c_str());
       auto col = std::make_unique<Column>();
@@ -434,8 +500,6 @@ OpPtr star_tree_filter(Segment& seg, StarTree& st, const pg_filter_node* filter,
     if (s.function == PG_AGG_DISTINCTCOUNT) return nullptr;   // no star-tree value aggregator
     const int pi = st.pair_index(s.function, s.column);
     if (pi < 0) return nullptr;
-    if (s.function == PG_AGG_AVG || s.function == PG_AGG_MINMAXRANGE)
-      fail(PG_ERR_UNSUPPORTED, "star-tree pair of function %d (BYTES pair) is outside the GPU path", s.function);
     // DistinctCountHLLAggregationFunction#canUseStarTree (:373-383): the tree's log2m must equal the query's
     if (s.function == PG_AGG_DISTINCTCOUNTHLL && st.pairs[(size_t)pi].col->hll_log2m != (s.log2m > 0 ? s.log2m : 8)) return nullptr;
   }

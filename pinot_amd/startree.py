@@ -35,8 +35,10 @@ STAR = -1                      # StarTreeNode.ALL
 STAR_IN_FORWARD_INDEX = 0      # StarTreeV2Constants.java:39
 
 # AggregationFunctionType#getName of the functions the path stores (AggregationFunctionColumnPair#toColumnName)
-PAIR_FUNCTION_NAMES = {"COUNT": "count", "SUM": "sum", "MIN": "min", "MAX": "max", "DISTINCTCOUNTHLL": "distinctCountHLL"}
-PAIR_VALUE_TYPES = {"COUNT": "LONG", "SUM": "DOUBLE", "MIN": "DOUBLE", "MAX": "DOUBLE", "DISTINCTCOUNTHLL": "BYTES"}
+PAIR_FUNCTION_NAMES = {"COUNT": "count", "SUM": "sum", "MIN": "min", "MAX": "max", "DISTINCTCOUNTHLL": "distinctCountHLL",
+                       "AVG": "avg", "MINMAXRANGE": "minMaxRange"}
+PAIR_VALUE_TYPES = {"COUNT": "LONG", "SUM": "DOUBLE", "MIN": "DOUBLE", "MAX": "DOUBLE", "DISTINCTCOUNTHLL": "BYTES",
+                    "AVG": "BYTES", "MINMAXRANGE": "BYTES"}   # AvgPair (sum, count) / MinMaxRangePair (min, max): 16 bytes
 DEFAULT_LOG2M = 8              # CommonConstants.Helix.DEFAULT_HYPERLOGLOG_LOG2M
 
 
@@ -159,6 +161,10 @@ class _Agg:
             return 1
         if f == "DISTINCTCOUNTHLL":
             return hll_registers(np.asarray([raw]), self.data_type, self.log2m)
+        if f == "AVG":            # AvgValueAggregator.java:41-47: AvgPair(value, 1)
+            return (float(raw), 1)
+        if f == "MINMAXRANGE":    # MinMaxRangeValueAggregator: MinMaxRangePair(value, value)
+            return (float(raw), float(raw))
         return float(raw)
 
     def apply_raw(self, agg, raw):
@@ -171,6 +177,10 @@ class _Agg:
             return min(agg, float(raw))
         if f == "MAX":
             return max(agg, float(raw))
+        if f == "AVG":
+            return (agg[0] + float(raw), agg[1] + 1)
+        if f == "MINMAXRANGE":
+            return (min(agg[0], float(raw)), max(agg[1], float(raw)))
         return np.maximum(agg, hll_registers(np.asarray([raw]), self.data_type, self.log2m))
 
     def apply_aggregated(self, a, b):
@@ -181,6 +191,10 @@ class _Agg:
             return min(a, b)
         if f == "MAX":
             return max(a, b)
+        if f == "AVG":
+            return (a[0] + b[0], a[1] + b[1])
+        if f == "MINMAXRANGE":
+            return (min(a[0], b[0]), max(a[1], b[1]))
         return np.maximum(a, b)
 
     def clone(self, a):
@@ -394,6 +408,12 @@ def _write_pair(function: str, values: list, log2m: int) -> np.ndarray:
     if function == "DISTINCTCOUNTHLL":
         blobs = [formats.serialize_hll(v, log2m) for v in values]
         return formats.write_raw_var_byte_chunk(blobs, longest_entry=8 + 4 * ((1 << log2m) // 6 + (0 if (1 << log2m) % 6 == 0 else 1)))
+    if function == "AVG":           # AvgPair#toBytes: big-endian double sum, long count
+        import struct
+        return formats.write_raw_var_byte_chunk([struct.pack(">dq", v[0], v[1]) for v in values], longest_entry=16)
+    if function == "MINMAXRANGE":   # MinMaxRangePair#toBytes: big-endian double min, double max
+        import struct
+        return formats.write_raw_var_byte_chunk([struct.pack(">dd", v[0], v[1]) for v in values], longest_entry=16)
     return formats.write_raw_fixed_byte_chunk(np.asarray(values, dtype=np.float64), "DOUBLE")
 
 

@@ -88,6 +88,24 @@ def synth_star_segment(num_docs=40_000, max_leaf_records=64, skip=("h3",), seed_
     return seg
 
 
+def synth_star_pairs_segment(num_docs=30_000, max_leaf_records=100):
+    """A star-tree holding the two 16-byte BYTES pairs: avg__m (AvgPair: sum, count) and minMaxRange__m (MinMaxRangePair)."""
+    from pinot_amd import startree, synth
+    seg = synth.generate_segment(num_docs, segment_index=5, columns=["h1", "h2", "h4", "m", "g2"], native=False)
+    startree.add_star_tree(seg, ["h1", "h2", "h4"], [("COUNT", "*"), ("AVG", "m"), ("MINMAXRANGE", "m"), ("SUM", "m")],
+                           max_leaf_records=max_leaf_records)
+    return seg
+
+
+STAR_PAIR_QUERIES = [
+    ("SELECT COUNT(*), AVG(m), MINMAXRANGE(m) FROM gpuBench", True),
+    ("SELECT h1, AVG(m), SUM(m) FROM gpuBench WHERE h2 IN (1, 2, 5) GROUP BY h1", True),
+    ("SELECT h4, h2, MINMAXRANGE(m), COUNT(*) FROM gpuBench WHERE h1 BETWEEN 3 AND 11 GROUP BY h4, h2", True),
+    ("SELECT AVG(m) FROM gpuBench WHERE h1 = 2 AND h4 != 3", True),
+    ("SELECT h2, AVG(m), MAX(m) FROM gpuBench GROUP BY h2", False),        # max__m is not in this tree
+]
+
+
 SYNTH_STAR_QUERIES = [
     ("SELECT h1, h2, h3, h4, COUNT(*), DISTINCTCOUNTHLL(u) FROM gpuBench GROUP BY h1, h2, h3, h4 LIMIT 20000", True),   # config 5
     ("SELECT COUNT(*), SUM(m), MIN(m), MAX(m), DISTINCTCOUNTHLL(u) FROM gpuBench WHERE h2 = 3", True),

@@ -136,3 +136,17 @@ def test_non_scan_based_operator_precedes_the_star_tree(gpu_api, oracle_api):
     assert_same(gb, ob)
     g.destroy()
     o.destroy()
+
+
+def test_star_tree_avg_and_min_max_range_pairs_on_gpu(gpu_api, oracle_api):
+    """The 16-byte BYTES pairs avg__x / minMaxRange__x: split into two raw columns of the star-tree's doc space at registration, summed
+    (exactly) / min-maxed like any source; one projected column in numEntriesScannedPostFilter, as the reference counts the BYTES column."""
+    from tests.fixtures import STAR_PAIR_QUERIES, synth_star_pairs_segment
+    host = synth_star_pairs_segment()
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    for sql, uses_star in STAR_PAIR_QUERIES:
+        gb, ob = g.execute(sql), o.execute(sql)
+        assert gb.stats.star_tree_index == (0 if uses_star else -1), sql
+        assert_same(gb, ob)
+    g.destroy()
+    o.destroy()

@@ -229,3 +229,24 @@ def test_star_tree_shrinks_the_scan(synth_star):
     star, plain = run_both(seg, "SELECT h1, COUNT(*), SUM(m) FROM gpuBench GROUP BY h1")
     assert plain.stats.num_docs_scanned == 40_000
     assert star.stats.num_docs_scanned < plain.stats.num_docs_scanned
+
+
+def test_star_tree_avg_and_min_max_range_pairs(oracle_api):
+    """avg__m / minMaxRange__m are BYTES pairs (AvgValueAggregator.java:28-83: AvgPair sum + count; MinMaxRangePair min + max): the
+    star-tree answer equals the plain scan's (INT metric: the sums are exact), with the star-tree's ExecutionStatistics."""
+    from pinot_amd import capi
+    from pinot_amd.query import parse_sql
+    from tests.fixtures import STAR_PAIR_QUERIES, synth_star_pairs_segment
+    host = synth_star_pairs_segment()
+    o = NativeSegment(oracle_api, host)
+    for sql, uses_star in STAR_PAIR_QUERIES:
+        b = o.execute(sql)
+        assert b.stats.star_tree_index == (0 if uses_star else -1), sql
+        qc = parse_sql(sql)
+        qc.flags |= capi.QUERY_FLAG_SKIP_STAR_TREE
+        plain = o.execute(qc)
+        assert plain.stats.star_tree_index == -1
+        assert b.rows() == plain.rows(), sql
+        if uses_star:
+            assert b.stats.num_docs_scanned < plain.stats.num_docs_scanned
+    o.destroy()
