@@ -159,7 +159,7 @@ DEVFN constexpr int sk_words(int k) { return sk_small(k) ? 2 : (sk_raw32(k) ? 4 
 template <bool SMALL>
 DEVFN void load_packed_quad(const GAS uint32_t* __restrict__ tw, uint32_t q, uint32_t bits, uint32_t* r) {
   if (SMALL) {
-    const uint32_t di = (4u * q * bits) >> 5;
+    const uint32_t di = __umul24(4u * q, bits) >> 5;   // q < 512, bits <= 8: v_mul_u32_u24 is full rate, v_mul_lo_u32 a quarter
     const u32x2 v = ldnt((const GAS u32x2_a4*)(tw + di));
     r[0] = v.x; r[1] = v.y;
   } else {
@@ -174,10 +174,12 @@ DEVFN void load_packed_quad(const GAS uint32_t* __restrict__ tw, uint32_t q, uin
 template <bool SMALL>
 DEVFN void decode_packed_quad(const uint32_t* r, uint32_t q, uint32_t bits, uint32_t mask, uint32_t out[4]) {
   if (SMALL) {
-    const uint32_t sh = (4u * q * bits) & 31u;
+    const uint32_t sh = __umul24(4u * q, bits) & 31u;
     const uint64_t win = ((uint64_t)bswap32(r[0]) << 32) | (uint64_t)bswap32(r[1]);
+    const uint32_t top = (uint32_t)((win << sh) >> 32);   // one 64-bit shift: the quad's four values now start at bit 31
+    out[0] = top >> (32u - bits);
 #pragma unroll
-    for (int i = 0; i < 4; i++) out[i] = (uint32_t)(win >> (64u - sh - (uint32_t)(i + 1) * bits)) & mask;
+    for (int i = 1; i < 4; i++) out[i] = (top >> (32u - (uint32_t)(i + 1) * bits)) & mask;
   } else {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -1072,8 +1074,8 @@ DEVFN void fast_aggregate_wtile(const PgQueryPlan& p, uint32_t mask_all, int wti
         uint32_t d[4];
         const uint32_t q = ((m >> (4 * k)) & 0xFu) ? (uint32_t)((k0 + k) * 64 + lane) : 0u;
         decode_packed_quad<true>(r[k], q, bits, mask, d);
-        sp[k][0] += d[0] * mult + ((d[1] * mult) << 16);
-        sp[k][1] += d[2] * mult + ((d[3] * mult) << 16);
+        sp[k][0] += __umul24(d[0], mult) + (__umul24(d[1], mult) << 16);   // dictIds < 256, mult x replicas < 65 536
+        sp[k][1] += __umul24(d[2], mult) + (__umul24(d[3], mult) << 16);
       }
     }
 #define PG_SLOT(k, i) ((sp[k][(i) >> 1] >> (((i) & 1) * 16)) & 0xFFFFu)
