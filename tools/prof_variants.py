@@ -15,7 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--docs", type=int, default=200_000_000)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--only", default="", help="substring of the query names to run")
-ap.add_argument("--set", choices=["cfg3", "cfg5", "general", "wide", "upsert"], default="cfg3")
+ap.add_argument("--set", choices=["cfg3", "cfg5", "general", "wide", "upsert", "postings"], default="cfg3")
 args = ap.parse_args()
 api = capi.gpu_api()
 api.call("init", 0)
@@ -35,6 +35,27 @@ if args.set == "wide":
     w = (synth.values_numpy(synth.GPU_BENCH["u"], synth.SEED_BASE, n) % 2000).astype(np.int32)
     seg.add_column(build_column("w1", w, "INT"), keep_host_buffers=False)
     del mvals, w
+
+if args.set == "postings":
+    # inverted indexes whose containers are NOT bitmaps: a 1000-value column (about 65 docs per dictId and 2^16-doc chunk: array
+    # containers) and a column of long runs (run containers); built with numpy / Python: keep --docs around 3e7
+    import numpy as np
+    from pinot_amd.segment import build_column
+    n = args.docs
+    rng = np.random.default_rng(1)
+    seg.add_column(build_column("s1", rng.integers(0, 1000, n).astype(np.int32), "INT", inverted=True), keep_host_buffers=False)
+    seg.add_column(build_column("srun", ((np.arange(n) // 5000) % 50).astype(np.int32), "INT", inverted=True), keep_host_buffers=False)
+
+QUERIES_POSTINGS = {   # bytes per row: the forward-index bytes a scan-only plan would read (postings themselves are tiny here)
+    "array postings: s1 = 5 count": ("SELECT COUNT(*) FROM t WHERE s1 = 5", 0.0),
+    "array postings: s1 IN (3 ids) count": ("SELECT COUNT(*) FROM t WHERE s1 IN (5, 77, 901)", 0.0),
+    "array postings: 40 ids + range + group": ("SELECT g1, SUM(m), MAX(m) FROM t WHERE s1 < 40 AND r_int BETWEEN 250000 AND 749999 GROUP BY g1", 0.0),
+    "array postings NOT IN + group": ("SELECT g1, COUNT(*) FROM t WHERE s1 NOT IN (5, 77, 901) AND c_inv2 = 1 GROUP BY g1", 0.0),
+    "run postings: srun = 7 sum": ("SELECT SUM(m), COUNT(*) FROM t WHERE srun = 7", 0.0),
+    "run postings: srun IN (5 ids) + range + group": ("SELECT g1, SUM(m) FROM t WHERE srun IN (1, 2, 3, 4, 5) AND r_int < 500000 GROUP BY g1", 0.0),
+    "run + array postings": ("SELECT g1, SUM(m) FROM t WHERE srun IN (1, 2, 3, 4, 5) AND s1 < 100 GROUP BY g1", 0.0),
+    "dense postings (reference point)": ("SELECT g1, SUM(m), MAX(m) FROM t WHERE c_inv1 IN (0,1,2,3) AND c_inv2 IN (0,1) AND r_int BETWEEN 250000 AND 749999 GROUP BY g1", 9.625),
+}
 
 QUERIES = {
     "cfg2 count(range scan)": (synth.QUERY_CFG2, 4.0),
@@ -95,6 +116,8 @@ if args.set == "wide":
     QUERIES = QUERIES_WIDE
 if args.set == "general":
     QUERIES = QUERIES_GENERAL
+if args.set == "postings":
+    QUERIES = QUERIES_POSTINGS
 for name, (sql, bpr) in QUERIES.items():
     if args.only and args.only not in name:
         continue
@@ -113,5 +136,8 @@ for name, (sql, bpr) in QUERIES.items():
     m = statistics.median(ms)
     if m <= 0:
         print(f"{name:32s} no kernel ran (answered on the host)")
+        continue
+    if bpr <= 0:   # index-driven: bytes per row of the segment say little; report the time per doc of the segment and per match
+        print(f"{name:46s} {st.kernel.decode():24s} {m * 1e3:8.1f} us  {m * 1e6 / max(st.num_docs_scanned, 1):7.3f} ns per matching doc  matched={st.num_docs_scanned} ({100.0 * st.num_docs_scanned / args.docs:.2f} %)")
         continue
     print(f"{name:32s} {st.kernel.decode():24s} {m:8.3f} ms  {bpr * args.docs / m / 1e6:8.1f} GB/s  ({bpr * args.docs / m / 1e6 / 80:5.1f}% of 8 TB/s)  matched={st.num_docs_scanned}")
