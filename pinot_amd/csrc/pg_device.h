@@ -292,6 +292,12 @@ struct PgQueryPlan {
   // 32-bit column (srcs[pipe_src])
   int32_t pipe_fit;
   int32_t pipe_src;
+  // Interpreter kernels over small doc spaces with expensive per-doc state updates (a star-tree's serialized HyperLogLogs: one
+  // wavefront-wide register merge per matching doc): every wave tile is visited by 2^tile_split_shift wavefronts, each evaluating
+  // the tile's filter and then keeping only its share of the matching docs (a quad slot and a lane class), so that a 13 617-doc
+  // star-tree occupies 224 wavefronts instead of 7.  Share 0 reports the tile's filter statistics and match words.
+  int32_t tile_split_shift;
+  int32_t tile_split_pad;
 };
 
 #if defined(__HIPCC__)

@@ -416,7 +416,16 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
   }
 
   PgQueryPlan D = P.dev;
-  const LaunchShape shape = launch_shape(P, P.dev.n_wtiles, D.agg_mode);
+  // small doc spaces with per-doc state merges (PgQueryPlan::tile_split_shift): up to 32 wavefronts share a wave tile
+  int split_shift = 0;
+  {
+    static const bool no_split = getenv("PG_NO_TILE_SPLIT") != nullptr;   // measurement knob
+    const bool table_mode = D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE || D.agg_mode == PG_AGG_LDS_PART || D.agg_mode == PG_AGG_GLOBAL;
+    if (!no_split && table_mode && D.n_aux > 0 && !uses_fast_kernel(P, D.agg_mode))
+      while (split_shift < 5 && ((int64_t)std::max(P.dev.n_wtiles, 1) << (split_shift + 1)) <= 4096) split_shift++;
+  }
+  D.tile_split_shift = split_shift;
+  const LaunchShape shape = launch_shape(P, P.dev.n_wtiles << split_shift, D.agg_mode);
   const int64_t n_out = (int64_t)D.n_ops * D.n_groups;
   // The stats counters are zero on entry: the reduce kernel of the previous query on this stream re-zeroes them after
   // moving them behind the result table (one device→host copy per query).

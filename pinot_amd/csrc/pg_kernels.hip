@@ -1433,7 +1433,10 @@ __device__ __forceinline__ void generic_query_body(const PgQueryPlan& p) {
     count_stats = range == 0;   // every range sees every doc: only range 0 reports the filter statistics
   }
   const int wstride = cstride * (PG_GENERIC_BLOCK / 64);
-  for (int wt = chunk0 * (PG_GENERIC_BLOCK / 64) + wave; wt < p.n_wtiles; wt += wstride) {
+  const int split_shift = p.tile_split_shift, n_vtiles = p.n_wtiles << split_shift;   // PgQueryPlan::tile_split_shift
+  for (int vt = chunk0 * (PG_GENERIC_BLOCK / 64) + wave; vt < n_vtiles; vt += wstride) {
+    const int wt = vt >> split_shift, share = vt & ((1 << split_shift) - 1);
+    const bool first_share = share == 0;
     const int64_t wbase = (int64_t)wt * PG_WAVE_DOCS;
     const int64_t rem = (int64_t)p.num_docs - wbase;
     const int32_t n_valid = rem >= PG_WAVE_DOCS ? PG_WAVE_DOCS : (int32_t)rem;
@@ -1473,7 +1476,7 @@ __device__ __forceinline__ void generic_query_body(const PgQueryPlan& p) {
           const uint32_t nc = wave_sum_u32((uint32_t)__popc(cand));
           if (nc) {   // wave-uniform
             st.s0 = scan_dispatch(L, cand, wt, lane);
-            if (lane == 0 && count_stats) atomicAdd(&s_stat[L.stat_slot], nc);
+            if (lane == 0 && count_stats && first_share) atomicAdd(&s_stat[L.stat_slot], nc);
           }
           break;
         }
@@ -1483,14 +1486,26 @@ __device__ __forceinline__ void generic_query_body(const PgQueryPlan& p) {
         default: break;
       }
     }
-    const uint32_t m = st.s0;
+    uint32_t m = st.s0;
+    if (first_share) {
+      if (p.out_words) reinterpret_cast<uint32_t*>(p.out_words)[(int64_t)wt * 64 + lane] = quad_to_lin(m, lane);
+      if (p.out_tile_counts) {
+        const uint32_t wsum = wave_sum_u32((uint32_t)__popc(m));
+        if (lane == 0 && wsum) atomicAdd(&p.out_tile_counts[wt / PG_WTILES_PER_TILE], wsum);
+      }
+    }
+    if (split_shift) {   // this wavefront's share of the tile's matches: quad slots k with k = share (mod 8 or fewer), then lane classes
+      const int kbits = split_shift < 3 ? split_shift : 3;
+      const uint32_t kmask = (1u << kbits) - 1u, ksel = (uint32_t)share & kmask;
+      uint32_t keep = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) keep |= (((uint32_t)k & kmask) == ksel ? 0xFu : 0u) << (4 * k);
+      const uint32_t lmask = (1u << (split_shift - kbits)) - 1u;
+      if (((uint32_t)lane & lmask) != ((uint32_t)share >> kbits)) keep = 0;
+      m &= keep;
+    }
     const uint32_t cnt = (uint32_t)__popc(m);
     my_matched += cnt;
-    if (p.out_words) reinterpret_cast<uint32_t*>(p.out_words)[(int64_t)wt * 64 + lane] = quad_to_lin(m, lane);
-    if (p.out_tile_counts) {
-      const uint32_t wsum = wave_sum_u32(cnt);
-      if (lane == 0 && wsum) atomicAdd(&p.out_tile_counts[wt / PG_WTILES_PER_TILE], wsum);
-    }
 
     // ---- aggregation ----------------------------------------------------------------------------------------------
     if (TABLE != 0 && __ballot(m != 0)) {
