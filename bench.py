@@ -120,7 +120,8 @@ def main():
     t0 = time.time()
     seg = NativeSegment(api, HostSegment(f"gpuBench_{rank}", args.docs))
     for name in needed:
-        one = synth.generate_segment(args.docs, segment_index=rank, columns=[name])
+        # N ranks generate at once on one host: each takes its share of the cores
+        one = synth.generate_segment(args.docs, segment_index=rank, columns=[name], threads=max(1, (os.cpu_count() or 8) // max(world, 1)) if world > 1 else 0)
         seg.add_column(one.columns[name], keep_host_buffers=False)
         del one
     log(f"segment of {args.docs} docs generated + uploaded in {time.time() - t0:.1f}s, "
