@@ -503,6 +503,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
     if (hashed) {   // buckets sized so that even all-distinct keys half-fill a bucket's table, within [16, 2048]
       int nb = 16;
       while (nb < PG_MAX_RADIX_BUCKETS && (unsigned long long)nb * (unsigned long long)(D.hash_cap / 2) < matched_now) nb *= 2;
+      if (const char* e = getenv("PG_HASH_FIRST_BUCKETS")) nb = std::max(16, std::min(PG_MAX_RADIX_BUCKETS, atoi(e)));   // test knob: start too low
       D.radix_buckets = nb;
     }
     const int rgrid = std::max(1, std::min((D.n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, num_cus()));
@@ -536,14 +537,35 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
       D.hash_out_count = ctx.hash_count.as<unsigned long long>();
       D.hash_out_keys = ctx.hash_keys.as<int64_t>();
       D.hash_out_acc = ctx.hash_acc.as<int64_t>();
-      hipLaunchKernelGGL(pg_hash_count_kernel, dim3(rgrid), dim3(PG_BLOCK), 0, ctx.stream, D);
-      hipLaunchKernelGGL(pg_radix_offsets_kernel, dim3((unsigned)((D.radix_buckets + 15) / 16)), dim3(1024), 0, ctx.stream, D.radix_hist,
-                         bucket_total, rgrid, D.radix_buckets, 0, 0);
-      hipLaunchKernelGGL(pg_radix_bucket_scan_kernel, dim3(1), dim3(64), 0, ctx.stream, bucket_total, D.radix_bucket_start, D.radix_buckets);
-      hipLaunchKernelGGL(pg_hash_scatter_kernel, dim3(rgrid), dim3(PG_BLOCK), 0, ctx.stream, D);
-      hipLaunchKernelGGL(pg_hash_aggregate_kernel, dim3(std::min(D.radix_buckets, num_cus())), dim3(PG_BLOCK),
-                         (size_t)D.hash_cap * (8 + 8 * (size_t)D.n_ops) + 64, ctx.stream, D);
-      PG_HIP(hipGetLastError());
+      // A bucket whose distinct keys overflow its LDS table (skewed hash ranges: the bucket count above assumes an even spread)
+      // is met with more buckets — four times as many per attempt, up to PG_MAX_RADIX_BUCKETS — instead of a refusal after the work.
+      for (;;) {
+        hipLaunchKernelGGL(pg_hash_count_kernel, dim3(rgrid), dim3(PG_BLOCK), 0, ctx.stream, D);
+        hipLaunchKernelGGL(pg_radix_offsets_kernel, dim3((unsigned)((D.radix_buckets + 15) / 16)), dim3(1024), 0, ctx.stream, D.radix_hist,
+                           bucket_total, rgrid, D.radix_buckets, 0, 0);
+        hipLaunchKernelGGL(pg_radix_bucket_scan_kernel, dim3(1), dim3(64), 0, ctx.stream, bucket_total, D.radix_bucket_start, D.radix_buckets);
+        hipLaunchKernelGGL(pg_hash_scatter_kernel, dim3(rgrid), dim3(PG_BLOCK), 0, ctx.stream, D);
+        hipLaunchKernelGGL(pg_hash_aggregate_kernel, dim3(std::min(D.radix_buckets, num_cus())), dim3(PG_BLOCK),
+                           (size_t)D.hash_cap * (8 + 8 * (size_t)D.n_ops) + 64, ctx.stream, D);
+        PG_HIP(hipGetLastError());
+        if (D.radix_buckets >= PG_MAX_RADIX_BUCKETS) break;
+        unsigned long long flag[2] = {0, 0};
+        PG_HIP(hipMemcpyAsync(flag, ctx.hash_count.ptr, 16, hipMemcpyDeviceToHost, ctx.stream));
+        stream_wait(ctx, cancel);
+        if (flag[1] != 1) break;   // 0: fine; 2: Long.MAX_VALUE key (reported below)
+        D.radix_buckets = std::min(D.radix_buckets * 4, PG_MAX_RADIX_BUCKETS);
+        ThreadCtx::grow(ctx.radix_hist, (size_t)rgrid * D.radix_buckets * 4);
+        ThreadCtx::grow(ctx.radix_start, ((size_t)D.radix_buckets + 1) * 8);
+        D.radix_hist = ctx.radix_hist.as<uint32_t>();
+        D.radix_bucket_start = ctx.radix_start.as<uint32_t>();
+        bucket_total = D.radix_bucket_start + D.radix_buckets + 1;
+        D.hash_out_cap = (int64_t)std::min<unsigned long long>(matched_now, (unsigned long long)D.radix_buckets * (unsigned long long)D.hash_cap) + 1;
+        ThreadCtx::grow(ctx.hash_keys, (size_t)D.hash_out_cap * 8);
+        ThreadCtx::grow(ctx.hash_acc, (size_t)D.hash_out_cap * 8 * (size_t)std::max(D.n_ops, 1));
+        D.hash_out_keys = ctx.hash_keys.as<int64_t>();
+        D.hash_out_acc = ctx.hash_acc.as<int64_t>();
+        PG_HIP(hipMemsetAsync(ctx.hash_count.ptr, 0, 16, ctx.stream));
+      }
       kname = "pg_hash_group_by";
     } else {
       D.radix_slices = std::max(1, num_cus() / D.radix_buckets);
