@@ -1128,8 +1128,9 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     if (!q->group_by_columns) fail(PG_ERR_INVALID_ARGUMENT, "group_by_columns is null");
     Column* c = seg.find(q->group_by_columns[j]);
     if (!c) fail(PG_ERR_NOT_FOUND, "column not found: %s", q->group_by_columns[j] ? q->group_by_columns[j] : "(null)");
+    // (a LONG column that may hold Long.MAX_VALUE — the hash table's empty marker once biased — goes through its virtual dictionary)
     const bool one_raw_int = !c->has_dictionary && q->n_group_by == 1 && (c->col_kind == PG_COL_RAW32 || c->col_kind == PG_COL_RAW64) &&
-                             (c->data_type == PG_TYPE_INT || c->data_type == PG_TYPE_LONG);
+                             (c->data_type == PG_TYPE_INT || (c->data_type == PG_TYPE_LONG && c->max_abs_int < (uint64_t)INT64_MAX));
     if (one_raw_int) {
       // NoDictionarySingleColumnGroupKeyGenerator (core/query/aggregation/groupby/NoDictionarySingleColumnGroupKeyGenerator.java:53-90,
       // 241-265): one raw INT / LONG column, value -> group id; here the value is the 64-bit key of the hash group-by

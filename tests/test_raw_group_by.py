@@ -204,18 +204,22 @@ def test_gpu_virtual_dictionary_group_by_matches_oracle(gpu_api, oracle_api, q, 
 
 
 @pytest.mark.gpu
-def test_gpu_raw_group_by_rejections(gpu_api):
+def test_gpu_raw_long_max_value_key(gpu_api):
     host, data = raw_key_segment(5_000)
-    # Long.MAX_VALUE is the hash table's empty marker: refused, not answered wrongly
+    # Long.MAX_VALUE is the hash table's empty marker once biased: such a column is grouped through its virtual dictionary instead
     data = dict(data)
     data["kl"] = data["kl"].copy()
     data["kl"][17] = np.iinfo(np.int64).max
     schema = {"kl": "LONG", "m": "INT"}
     host2 = build_segment("rawKeys_1", {"kl": data["kl"], "m": data["m"]}, schema, no_dictionary_columns=["kl", "m"])
     g = NativeSegment(gpu_api, host2)
-    with pytest.raises(capi.NativeError):
-        g.execute("SELECT kl, COUNT(*) FROM rawKeys GROUP BY kl LIMIT 10")
+    from tests.oracle_binding import load_oracle
+    o = NativeSegment(load_oracle(), host2)
+    sql = "SELECT kl, COUNT(*), SUM(m) FROM rawKeys GROUP BY kl LIMIT 100000"
+    assert g.execute(sql).rows() == o.execute(sql).rows()
+    assert (np.iinfo(np.int64).max,) in g.execute(sql).rows()
     g.destroy()
+    o.destroy()
 
 
 @pytest.mark.gpu
