@@ -16,7 +16,8 @@ PG_DECL_GENERIC
 PG_DECL_FAST(pg_fast_none_f) PG_DECL_FAST(pg_fast_none_a) PG_DECL_FAST(pg_fast_i32range_f) PG_DECL_FAST(pg_fast_i32range_a)
 PG_DECL_FAST(pg_fast_dictrange_f) PG_DECL_FAST(pg_fast_dictrange_a) PG_DECL_FAST(pg_fast_dictlut_f) PG_DECL_FAST(pg_fast_dictlut_a)
 PG_DECL_FAST(pg_fast_multi_f) PG_DECL_FAST(pg_fast_multi_a) PG_DECL_FAST(pg_fast_multi_w) PG_DECL_FAST(pg_fast_none_w)
-PG_DECL_FAST(pg_fast_i32range_d) PG_DECL_FAST(pg_fast_i32range_p)
+PG_DECL_FAST(pg_fast_i32range_d) PG_DECL_FAST(pg_fast_i32range_p) PG_DECL_FAST(pg_fast_i32range_fp)
+extern "C" const int pg_scan_waves_per_block;   // pg_kernels_scan.hip: wavefronts per workgroup of pg_fast_i32range_fp
 extern "C" const int pg_pipe_waves_per_block;   // pg_kernels_pipe.hip: wavefronts per workgroup of pg_fast_i32range_p
 PG_DECL_FAST(pg_fast_multi_wd) PG_DECL_FAST(pg_fast_none_wd) PG_DECL_FAST(pg_generic_query_ld) PG_DECL_FAST(pg_generic_query_gd)
 extern "C" __global__ void pg_reduce_partials_kernel(const int64_t* partials, int64_t* out, int n_wg, int n_ops,
@@ -151,6 +152,12 @@ static bool uses_fast_kernel(const CompiledPlan& P, int agg_mode) {
   return P.fast_filter != -2 && (!agg || ((P.fast_agg || P.wide_agg) && agg_mode != PG_AGG_GLOBAL));
 }
 
+// pg_fast_i32range_fp (double-buffered raw-INT range scan over the whole segment, filter only: pg_kernels_scan.hip)
+static bool uses_scan_kernel(const CompiledPlan& P, int agg_mode) {
+  static const bool no_scan = getenv("PG_NO_SCAN_PIPE") != nullptr;   // measurement knob
+  return !no_scan && agg_mode == PG_AGG_NONE && uses_fast_kernel(P, agg_mode) && P.fast_filter == 4 && P.dev.n_index_instr == 0 &&
+         P.dev.fast_scan_pushed;
+}
 // pg_fast_i32range_p (software-pipelined headline shape, pg_kernels_pipe.hip): its own workgroup size
 static bool uses_pipe_kernel(const CompiledPlan& P, int agg_mode) {
   static const bool no_pipe = getenv("PG_NO_PIPE") != nullptr || getenv("PG_NO_DENSE_FUSED") != nullptr;   // measurement knob
@@ -169,6 +176,7 @@ static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char
     }
     static const bool no_dense = getenv("PG_NO_DENSE_FUSED") != nullptr;   // measurement knobs
     if (uses_pipe_kernel(P, agg_mode)) { *name = "pg_fast_i32range_p"; return pg_fast_i32range_p; }
+    if (uses_scan_kernel(P, agg_mode)) { *name = "pg_fast_i32range_fp"; return pg_fast_i32range_fp; }
     if (agg && P.fast_filter == 4 && P.dev.dense_fused && !no_dense && P.fast_agg && agg_mode == PG_AGG_LDS) { *name = "pg_fast_i32range_d"; return pg_fast_i32range_d; }
     switch (P.fast_filter) {
       case -1: *name = agg ? "pg_fast_none_a" : "pg_fast_none_f"; return agg ? pg_fast_none_a : pg_fast_none_f;
@@ -259,6 +267,12 @@ static LaunchShape launch_shape(const CompiledPlan& P, int n_wtiles, int agg_mod
     int per_xcd = std::max(num_cus() / 8, 1);
     per_xcd = std::max(per_xcd / P.dev.n_parts, 1) * P.dev.n_parts;
     return {8 * per_xcd, uses_fast_kernel(P, agg_mode) ? PG_BLOCK : PG_GENERIC_BLOCK, lds};
+  }
+  if (uses_scan_kernel(P, agg_mode)) {
+    static const int wgs_per_cu = getenv("PG_SCAN_WGS_PER_CU") ? atoi(getenv("PG_SCAN_WGS_PER_CU")) : 1;   // tuning knob
+    const int waves = pg_scan_waves_per_block;
+    int grid = std::min((n_wtiles + waves - 1) / waves, num_cus() * std::max(wgs_per_cu, 1));
+    return {std::max(grid, 1), waves * 64, 0};
   }
   if (uses_pipe_kernel(P, agg_mode)) {
     static const int wgs_per_cu = getenv("PG_PIPE_WGS_PER_CU") ? atoi(getenv("PG_PIPE_WGS_PER_CU")) : 1;   // tuning knob

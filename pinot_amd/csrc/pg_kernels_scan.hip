@@ -1,0 +1,78 @@
+// pg_fast_i32range_fp: BASELINE config 2 — a raw-INT range predicate over the whole segment, COUNT(*) (or the match words of a filter-only
+// pass) — as a double-buffered stream on FOUR wavefronts per workgroup.
+//
+// The pure-scan probe (profiles/r02_scan_bw_probe.txt) streams 7.33 TB/s with 4 wavefronts x 8 KB in flight per CU and 6.5-6.95 TB/s
+// with 16: the memory system prefers fewer, longer streams.  pg_fast_i32range_f (16 wavefronts, 4 KB batches, load → test → load) sits
+// at the 16-wavefront figure.  This kernel keeps a whole 8 KB tile per wavefront in flight at all times instead: tile i+1's eight
+// quads are requested before tile i's are tested, so the ~200 VALU instructions of a tile's test hide behind the next tile's loads
+// even with one wavefront per SIMD.  In a translation unit of its own for its workgroup size (see pg_kernels_pipe.hip).
+#ifndef PG_WAVES_PER_BLOCK
+#define PG_WAVES_PER_BLOCK 4
+#endif
+#define PG_KERNEL template <int PG_NOT_INSTANTIATED> static
+#include "pg_kernels.hip"
+
+extern "C" const int pg_scan_waves_per_block = PG_WAVES_PER_BLOCK;   // the host launches pg_fast_i32range_fp with this many wavefronts
+
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_fast_i32range_fp(const PgQueryPlan p) {
+  __shared__ uint32_t s_stat[PG_MAX_STATS];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = uniform(t >> 6);
+  if (t < PG_MAX_STATS) s_stat[t] = 0;
+  __syncthreads();
+  const CAS PgScanLeaf& L = cptr(p.scans)[p.fast_scan];
+  const RangeI32 r32 = make_range_i32(L.lo, L.hi);
+  const int step = (int)gridDim.x * PG_WAVES_PER_BLOCK;
+  const int last_wt = p.n_wtiles - 1;
+  uint32_t my_matched = 0;
+
+  auto issue = [&](int wt, u32x4 (&a)[8]) {   // the whole tile, unconditionally (a pushed scan visits every doc); clamped beyond the segment
+    const int wc = wt < last_wt ? wt : last_wt;
+    const uint64_t base = (uint64_t)L.data + (uint64_t)wc * (PG_WAVE_DOCS * 4);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
+    const GAS uint8_t* tb = (const GAS uint8_t*)(((uint64_t)hi << 32) | (uint64_t)lo);
+#pragma unroll
+    for (int k = 0; k < 8; k++) a[k] = ldnt((const GAS u32x4*)(tb + (uint32_t)(k * 64 + lane) * 16u));
+  };
+  auto finish = [&](int wt, const u32x4 (&a)[8]) {
+    const int64_t rem = (int64_t)p.num_docs - (int64_t)wt * PG_WAVE_DOCS;
+    const int32_t n_valid = rem >= PG_WAVE_DOCS ? PG_WAVE_DOCS : (rem > 0 ? (int32_t)rem : 0);
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      m |= (uint32_t)in_range_i32(r32, (int32_t)bswap32(a[k].x)) << (4 * k);
+      m |= (uint32_t)in_range_i32(r32, (int32_t)bswap32(a[k].y)) << (4 * k + 1);
+      m |= (uint32_t)in_range_i32(r32, (int32_t)bswap32(a[k].z)) << (4 * k + 2);
+      m |= (uint32_t)in_range_i32(r32, (int32_t)bswap32(a[k].w)) << (4 * k + 3);
+    }
+    m = r32.empty ? 0u : (m & valid_quad_mask(n_valid, lane));
+    const uint32_t cnt = (uint32_t)__popc(m);
+    my_matched += cnt;
+    if (p.out_words) reinterpret_cast<uint32_t*>(p.out_words)[(int64_t)wt * 64 + lane] = quad_to_lin(m, lane);
+    if (p.out_tile_counts) {
+      const uint32_t wsum = wave_sum_u32(cnt);
+      if (lane == 0 && wsum) atomicAdd(&p.out_tile_counts[wt / PG_WTILES_PER_TILE], wsum);
+    }
+  };
+
+  u32x4 a0[8], a1[8];
+  int wt = (int)blockIdx.x * PG_WAVES_PER_BLOCK + wave;
+  if (wt < p.n_wtiles) {
+    issue(wt, a0);
+    for (;;) {
+      issue(wt + step, a1);          // harmless (clamped) past the end
+      finish(wt, a0);
+      wt += step;
+      if (wt >= p.n_wtiles) break;
+      issue(wt + step, a0);
+      finish(wt, a1);
+      wt += step;
+      if (wt >= p.n_wtiles) break;
+    }
+  }
+  const uint32_t wsum = wave_sum_u32(my_matched);
+  if (lane == 0 && wsum) atomicAdd(&s_stat[0], wsum);
+  __syncthreads();
+  if (t < PG_MAX_STATS && s_stat[t]) atomicAdd(&p.stats[t], (unsigned long long)s_stat[t]);
+}

@@ -17,9 +17,12 @@ pytestmark = pytest.mark.gpu
 COLUMNS = ["c_inv1", "c_inv2", "r_int", "g1", "g2", "m"]
 PIPE = "pg_fast_i32range_p"
 DENSE = "pg_fast_i32range_d"
+SCAN = "pg_fast_i32range_fp"      # BASELINE config 2: raw-INT range over the whole segment, COUNT(*) (pg_kernels_scan.hip)
 knobs_off = not (os.environ.get("PG_NO_PIPE") or os.environ.get("PG_NO_DENSE_FUSED"))
 
 QUERIES = [
+    (synth.QUERY_CFG2, SCAN),
+    ("SELECT COUNT(*) FROM gpuBench WHERE r_int > 999990", SCAN),
     (synth.QUERY_CFG3, PIPE),
     (synth.QUERY_NORTH_STAR, PIPE),
     ("SELECT g1, COUNT(*), MIN(m), MAX(m), SUM(m) FROM gpuBench WHERE c_inv1 NOT IN (0, 7) AND c_inv2 = 1 "
@@ -52,5 +55,7 @@ def test_headline_specialisations_match_oracle(pair, sql, kernel):
     assert gb.rows() == ob.rows()
     for f in ("num_docs_scanned", "num_entries_scanned_in_filter", "num_entries_scanned_post_filter", "num_total_docs"):
         assert getattr(gb.stats, f) == getattr(ob.stats, f), f
-    if kernel and knobs_off and gb.stats.num_total_docs >= 65536:   # small segments keep sparse (CSR) postings: the interpreted leaves
+    if kernel == SCAN and not os.environ.get("PG_NO_SCAN_PIPE"):
+        assert gb.stats.kernel.decode() == kernel                   # no index involved: every segment size takes it
+    elif kernel and knobs_off and gb.stats.num_total_docs >= 65536:   # small segments keep sparse (CSR) postings: the interpreted leaves
         assert gb.stats.kernel.decode() == kernel

@@ -155,6 +155,20 @@ def test_headline_kernel_has_no_register_spills():
     if os.path.exists(dense):
         d = usage["pg_fast_i32range_d"]
         assert d["ScratchSize [bytes/lane]"] == 0 and d["VGPRs Spill"] == 0 and d["VGPRs"] <= 128, d
+    scan = log.replace("pg_kernels.", "pg_kernels_scan.")
+    if os.path.exists(scan):
+        su, cur = {}, None
+        for line in open(scan):
+            m = re.search(r"Function Name: (\w+)", line)
+            if m:
+                cur = m.group(1)
+                su[cur] = {}
+            for key in ("VGPRs", "ScratchSize [bytes/lane]", "VGPRs Spill"):
+                m = re.search(re.escape(key) + r": (\d+)", line)
+                if m and cur:
+                    su[cur].setdefault(key, int(m.group(1)))
+        d = su["pg_fast_i32range_fp"]
+        assert d["ScratchSize [bytes/lane]"] == 0 and d["VGPRs Spill"] == 0, d
     if os.path.exists(pipe):
         d = usage["pg_fast_i32range_p"]
         assert d["ScratchSize [bytes/lane]"] == 0 and d["VGPRs Spill"] == 0 and d["VGPRs"] <= 256, d
