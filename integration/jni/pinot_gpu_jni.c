@@ -7,7 +7,8 @@
  * pinot-core/.../operator/combine/BaseCombineOperator.java:185-199); PG_ERR_CANCELLED becomes EarlyTerminationException
  * (pinot-core/.../operator/BaseOperator.java:44-46).
  *
- * Needs a JDK (<jni.h>): there is none in the image this repository is built in, so this file is NOT part of build(); the plain-C
+ * Needs <jni.h>: there is no JDK in the image this repository is built in; build() compiles this file against the stand-in stub/jni.h
+ * and runs it under the fake JNIEnv of jni_fake_env_test.c (type-checked and exercised, not JVM-linked).  The plain-C
  * half it relies on (pinot_gpu_shim.c) and the exact call sequence it performs are compiled and tested by jni_sequence_test.c.
  * Build on a JDK host:
  *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../../include pinot_gpu_jni.c pinot_gpu_shim.c \

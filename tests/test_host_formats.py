@@ -234,3 +234,25 @@ def test_jni_call_sequence_on_gpu():
     out = subprocess.run([binary], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "jni sequence ok" in out.stdout and "d=20 count=725" in out.stdout and "d=30 count=725" in out.stdout
+
+
+def test_jni_functions_under_a_fake_env_host_part():
+    """integration/jni/pinot_gpu_jni.c itself — compiled against the stand-in <jni.h> — called through a fake JNIEnv: queryParse from a
+    direct buffer, IllegalArgumentException on a corrupt record and, without a GPU, the RuntimeException pg_init's refusal becomes."""
+    import subprocess
+    import torch
+    binary = os.path.join(ROOT, "integration", "jni", "jni_fake_env_test")
+    if not os.path.exists(binary):
+        pytest.skip("integration/jni/jni_fake_env_test not built (python -c 'import __graft_entry__ as g; g.build()')")
+    out = subprocess.run([binary], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert ("jni under the fake env ok" in out.stdout) if torch.cuda.is_available() else ("no CPU fallback" in out.stdout and "host part" in out.stdout)
+
+
+@pytest.mark.gpu
+def test_jni_functions_under_a_fake_env_on_gpu():
+    import subprocess
+    binary = os.path.join(ROOT, "integration", "jni", "jni_fake_env_test")
+    out = subprocess.run([binary], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "jni under the fake env ok" in out.stdout and "d=20 count=725" in out.stdout and "d=30 count=725" in out.stdout
