@@ -344,6 +344,17 @@ int32_t pg_result_hll_registers(pg_result_t result, int32_t agg, uint8_t* out_re
   return guarded([&] {
     AggResult& a = agg_of(result, agg);
     REQUIRE(a.kind == PG_RESULT_HLL, "aggregation is not a DISTINCTCOUNTHLL");
+    if (a.hll_regs) {   // registers still in the page-locked block the device wrote: gather the groups (runs of ids in one copy)
+      const size_t ng = a.hll_gids.size(), stride = (size_t)a.hll_stride;
+      REQUIRE(capacity >= (int64_t)(ng * stride), "capacity too small");
+      for (size_t i = 0; i < ng;) {
+        size_t j = i + 1;
+        while (j < ng && a.hll_gids[j] == a.hll_gids[j - 1] + 1) j++;
+        memcpy(out_registers + i * stride, a.hll_regs + (size_t)a.hll_gids[i] * stride, (j - i) * stride);
+        i = j;
+      }
+      return;
+    }
     REQUIRE(capacity >= (int64_t)a.hll.size(), "capacity too small");
     if (!a.hll.empty()) memcpy(out_registers, a.hll.data(), a.hll.size());
   });

@@ -349,6 +349,7 @@ struct HostTable {
   std::vector<int64_t> table;            // [n_ops][G] (G = groups of the compact table for hashed key spaces)
   uint64_t stats[PG_MAX_STATS] = {0};
   uint8_t* aux = nullptr;                // merged auxiliary regions (replicas are folded in place)
+  std::shared_ptr<PinnedBlock> aux_block; // set when `aux` lies in a block the result may keep (see AggResult::hll_block)
   bool hashed = false;
   int64_t hash_groups = 0;
   std::vector<int64_t> hash_keys;        // PG_AGG_RADIX_HASH: raw key of every group of the compact table
@@ -373,6 +374,38 @@ static void stream_wait(ThreadCtx& ctx, const CancelToken* c) {
     if (c->requested.load(std::memory_order_acquire)) check_cancel(c, &ctx);
   }
   check_cancel(c, &ctx);
+}
+
+namespace {
+std::mutex g_pinned_mu;
+std::vector<std::pair<void*, size_t>> g_pinned_pool;   // parked blocks (at most 8)
+}
+PinnedBlock::~PinnedBlock() {
+  if (!ptr) return;
+  {
+    std::lock_guard<std::mutex> g(g_pinned_mu);
+    if (g_pinned_pool.size() < 8 && size <= ((size_t)256 << 20)) { g_pinned_pool.emplace_back(ptr, size); return; }
+  }
+  (void)hipHostFree(ptr);
+}
+std::shared_ptr<PinnedBlock> acquire_pinned(size_t bytes) {
+  auto b = std::make_shared<PinnedBlock>();
+  {
+    std::lock_guard<std::mutex> g(g_pinned_mu);
+    size_t best = g_pinned_pool.size();
+    for (size_t i = 0; i < g_pinned_pool.size(); i++)
+      if (g_pinned_pool[i].second >= bytes && (best == g_pinned_pool.size() || g_pinned_pool[i].second < g_pinned_pool[best].second)) best = i;
+    if (best < g_pinned_pool.size()) {
+      b->ptr = g_pinned_pool[best].first;
+      b->size = g_pinned_pool[best].second;
+      g_pinned_pool.erase(g_pinned_pool.begin() + (long)best);
+      return b;
+    }
+  }
+  const size_t want = bytes + bytes / 4 + 4096;
+  PG_HIP(hipHostMalloc(&b->ptr, want, hipHostMallocPortable));
+  b->size = want;
+  return b;
 }
 
 std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const CancelToken* cancel) {
@@ -485,7 +518,10 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
       off += P.aux_bytes[x];
     }
   }
-  int64_t* host_out = static_cast<int64_t*>(ctx.pin(out_bytes + aux_total));
+  // MBs of auxiliary state (HyperLogLog registers of thousands of groups) land in a pooled page-locked block the result keeps
+  std::shared_ptr<PinnedBlock> out_block;
+  if (aux_total >= ((size_t)1 << 20)) out_block = acquire_pinned(out_bytes + aux_total);
+  int64_t* host_out = static_cast<int64_t*>(out_block ? out_block->ptr : ctx.pin(out_bytes + aux_total));
   uint8_t* aux_host = reinterpret_cast<uint8_t*>(host_out) + out_bytes;
   if (profile) PG_HIP(hipEventRecord(ctx.ev[0], ctx.stream));
   const char* kname = "";
@@ -612,6 +648,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
     PG_HIP(hipGetLastError());
   }
   if (profile) PG_HIP(hipEventRecord(ctx.ev[1], ctx.stream));
+  double t_queued_at = 0, t_synced = 0;   // PG_TRACE_HOST: host-side timeline of one query
   std::vector<int64_t> table((size_t)n_out);
   std::vector<int64_t> hash_keys_host;   // PG_AGG_RADIX_HASH: raw key of every group of the compact table
   uint64_t stats_host[PG_MAX_STATS] = {0};
@@ -646,7 +683,10 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
         PG_HIP(hipMemcpyAsync(kept->aux.ptr, ctx.aux.ptr, aux_total, hipMemcpyDeviceToDevice, ctx.stream));
       }
     }
+    const double t_queued = now_ms();
     stream_wait(ctx, cancel);
+    t_synced = now_ms();
+    t_queued_at = t_queued;
     if (n_out) memcpy(table.data(), host_out, (size_t)n_out * 8);
     memcpy(stats_host, host_out + n_out, sizeof(stats_host));
     ctx.stats_dirty = false;    // the reduce kernel left them zero
@@ -687,6 +727,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
   H.table = std::move(table);
   memcpy(H.stats, stats_host, sizeof(stats_host));
   H.aux = aux_host;
+  H.aux_block = out_block;
   H.hashed = hashed;
   H.hash_groups = hash_groups;
   H.hash_keys = std::move(hash_keys_host);
@@ -700,7 +741,14 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
     H.full_scan_entries = exact_entries;
     for (int i = 1; i < PG_MAX_STATS; i++) H.stats[i] = 0;
   }
+  const double t_before_assembly = now_ms();
   assemble_result(*res, P, q.n_group_by, q.n_aggregations, H);
+  {
+    static const bool trace = getenv("PG_TRACE_HOST") != nullptr;   // debugging knob: where the host time of a query goes
+    if (trace)
+      fprintf(stderr, "[pg] %s: plan %.3f ms, queue %.3f, wait %.3f, unpack %.3f, assembly %.3f\n", kname, t_plan - t0, t_queued_at - t_plan,
+              t_synced - t_queued_at, t_before_assembly - t_synced, now_ms() - t_before_assembly);
+  }
   if (exact_entries >= 0) res->stats.stats_exact = 1;
   snprintf(res->stats.kernel, sizeof(res->stats.kernel), "%s", kname);
   if (profile) {
@@ -791,6 +839,11 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
     }
     auto& v = res.group_dict_ids[j];
     v.resize((size_t)ng);
+    if (!hashed && G <= (int64_t)0x7FFFFFFF) {   // dense key space: 32-bit arithmetic (a 64-bit division costs several times as much)
+      const uint32_t m32 = (uint32_t)mult, c32 = (uint32_t)card;
+      for (int32_t i = 0; i < ng; i++) v[i] = (int32_t)(((uint32_t)gids[i] / m32) % c32);
+      continue;
+    }
     for (int32_t i = 0; i < ng; i++) {   // getKeys: col 0 least significant
       const int64_t raw = hashed ? H.hash_keys[(size_t)gids[i]] : gids[i];
       v[i] = (int32_t)((raw / mult) % card);
@@ -857,9 +910,24 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
       } else {
         r.kind = PG_RESULT_HLL;
         r.log2m = ao.log2m;
-        r.hll.resize((size_t)ng * A.stride);
-        for (int32_t i = 0; i < ng; i++)
-          memcpy(r.hll.data() + (size_t)i * A.stride, H.aux + off + (size_t)gids[i] * A.stride, (size_t)A.stride);
+        // runs of consecutive group ids are appended with one copy each (a full key space is one copy; no zero-fill first)
+        if (H.aux_block) {   // big states stay in the page-locked block the device wrote them to
+          r.hll.clear();
+          r.hll_block = H.aux_block;
+          r.hll_regs = H.aux + off;
+          r.hll_stride = A.stride;
+          r.hll_gids.assign(gids.begin(), gids.end());
+          continue;
+        }
+        r.hll.clear();
+        r.hll.reserve((size_t)ng * A.stride);
+        const uint8_t* regs = H.aux + off;
+        for (int32_t i = 0; i < ng;) {
+          int32_t j = i + 1;
+          while (j < ng && gids[j] == gids[j - 1] + 1) j++;
+          r.hll.insert(r.hll.end(), regs + (size_t)gids[i] * A.stride, regs + ((size_t)gids[j - 1] + 1) * A.stride);
+          i = j;
+        }
       }
       continue;
     }

@@ -279,12 +279,25 @@ std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* f
 std::string query_signature(const pg_filter_node* filter, const pg_query* query);
 
 // ---- results --------------------------------------------------------------------------------------------------------------------
+// Page-locked host blocks for result copies that a result may keep (pooled: hipHostMalloc costs more than a query)
+struct PinnedBlock {
+  void* ptr = nullptr;
+  size_t size = 0;
+  ~PinnedBlock();   // back to the pool
+};
+std::shared_ptr<PinnedBlock> acquire_pinned(size_t bytes);
 struct AggResult {
   int32_t kind = PG_RESULT_DOUBLE;
   std::vector<double> d[2];
   std::vector<int64_t> l[2];
   std::vector<int32_t> set_sizes, set_ids;   // PG_RESULT_DICTID_SET: per group sizes, concatenated ascending dictIds
-  std::vector<uint8_t> hll;                  // PG_RESULT_HLL: num_groups * 2^log2m registers
+  std::vector<uint8_t> hll;                  // PG_RESULT_HLL: num_groups * 2^log2m registers, or — big states —
+  // the registers stay where the device wrote them: a page-locked block shared with the result (copying 3.3 MB of freshly DMA'd,
+  // cache-cold bytes costs more than the kernel that produced them); group i's registers = hll_regs + hll_gids[i] * hll_stride
+  std::shared_ptr<struct PinnedBlock> hll_block;
+  const uint8_t* hll_regs = nullptr;
+  int64_t hll_stride = 0;
+  std::vector<int64_t> hll_gids;
   int32_t log2m = 0;
 };
 // What pg_result_merge / pg_result_all_reduce need to merge two results of the same query and to re-assemble the groups:

@@ -385,7 +385,7 @@ class ResultsBlock:
                 rb.arrays.append((k, sizes, flat[:total]))
             elif k == capi.RESULT_HLL:
                 m = 1 << (spec.log2m or 8)
-                regs = np.zeros(max(ng * m, 1), dtype=np.uint8)
+                regs = np.empty(max(ng * m, 1), dtype=np.uint8)
                 api.call("result_hll_registers", h, a, regs.ctypes.data, ng * m)
                 rb.arrays.append((k, regs[:ng * m].reshape(ng, m)))
             else:
