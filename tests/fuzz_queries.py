@@ -132,6 +132,23 @@ class Gen:
         return q
 
 
+    def raw_key_query(self):
+        """query() with GROUP BY over at least one no-dictionary column: a FLOAT / DOUBLE key alone, or raw and dictionary columns mixed."""
+        q = self.query()
+        raw = ["rk", "rl", "rf", "rd"]
+        if self.rng.random() < 0.3:
+            q.group_by = [["rf", "rd"][self.rng.integers(0, 2)]]
+        else:
+            k_raw = int(self.rng.integers(1, 3))
+            k_dict = int(self.rng.integers(0, 3)) if k_raw > 1 else int(self.rng.integers(1, 3))
+            q.group_by = list(self.rng.choice(raw, size=k_raw, replace=False)) + list(self.rng.choice(DICT_GROUP, size=k_dict, replace=False))
+            self.rng.shuffle(q.group_by)
+        q.has_group_by = True
+        q.aggregations = [a for a in q.aggregations if a.function not in ("DISTINCTCOUNT", "DISTINCTCOUNTHLL")] or [AggregationSpec("COUNT", None)]
+        q.num_groups_limit = int(self.rng.choice([0, 0, 40, 700, 5000]))
+        return q
+
+
 def clone(q: QueryContext) -> QueryContext:
     c = QueryContext(table=q.table, filter=q.filter, group_by=list(q.group_by), aggregations=list(q.aggregations), limit=q.limit,
                      num_groups_limit=q.num_groups_limit, has_group_by=q.has_group_by)
@@ -185,7 +202,7 @@ def eval_filter(t: FilterContext, data, nulls, n):
         v = v.astype(str)
     if p.type in ("EQ", "NOT_EQ", "IN", "NOT_IN"):
         vals = [_typed(data[p.column], s) for s in p.values]
-        m = np.isin(v, np.array(vals, dtype=v.dtype))
+        m = np.isin(v, np.array(vals) if v.dtype.kind == "U" else np.array(vals, dtype=v.dtype))   # (a fixed-width cast would truncate 'k25z' to 'k25')
         return m if p.type in ("EQ", "IN") else ~m
     m = np.ones(n, bool)
     if p.lower != UNBOUNDED:

@@ -17,6 +17,88 @@ def fuzz():
     return fuzz_segment()
 
 
+def check_against_brute_force(b, q, data, nulls, n, what):
+    """One oracle result against a numpy evaluation of the same query; returns the number of aggregations whose groups were checked."""
+    checked_groups = 0
+    mask = eval_filter(q.filter, data, nulls, n) if q.filter else np.ones(n, bool)
+    non_scan = b.stats.num_docs_scanned != int(mask.sum()) and not q.filter   # NonScanBased answers scan nothing
+    if not non_scan:
+        assert b.stats.num_docs_scanned == int(mask.sum()), what
+    if not q.group_by:
+        for a, r in zip(q.aggregations, b.aggregation_result()):
+            if a.function == "COUNT":
+                assert r == int(mask.sum()), what
+            elif a.function == "SUM":
+                assert r == float(data[a.column][mask].astype(np.float64).sum()), what
+            elif a.function == "MIN" and mask.any():
+                assert r == float(data[a.column][mask].min()), what
+            elif a.function == "MAX" and mask.any():
+                assert r == float(data[a.column][mask].max()), what
+            elif a.function == "AVG":
+                assert r == (float(data[a.column][mask].astype(np.float64).sum()), int(mask.sum())), what
+            elif a.function == "MINMAXRANGE":
+                v = data[a.column][mask]
+                assert r == ((float(v.min()), float(v.max())) if mask.any() else (float("inf"), float("-inf"))), what
+            elif a.function == "DISTINCTCOUNT":
+                col = data[a.column].astype(str) if data[a.column].dtype == object else data[a.column]
+                assert r == frozenset(np.unique(col[mask]).tolist()), what
+            elif a.function == "DISTINCTCOUNTHLL":   # registers after hll.offer(value) for every matching doc (numpy restatement)
+                from pinot_amd.startree import hll_registers
+                dt = "LONG" if data[a.column].dtype == np.int64 else "INT"
+                assert r == bytes(hll_registers(data[a.column][mask], dt, a.log2m or 8)), what
+        return 0
+    limit = q.num_groups_limit or 100_000
+    docs = np.flatnonzero(mask)
+    code = np.zeros(len(docs), dtype=np.int64)
+    uniques = []
+    for gcol in q.group_by:
+        col = data[gcol].astype(str) if data[gcol].dtype == object else data[gcol]
+        uq, inv = np.unique(col[docs], return_inverse=True)
+        uniques.append(uq)
+        code = code * len(uq) + inv
+    ucode, first_pos, inv = np.unique(code, return_index=True, return_inverse=True)
+    order = np.argsort(first_pos)                 # groups in order of first appearance (docId order)
+    kept = set(order[:limit].tolist())
+
+    def key_of(c):
+        parts = []
+        for uq in reversed(uniques):
+            c, r = divmod(c, len(uq))
+            parts.append(uq[r].item() if hasattr(uq[r], "item") else uq[r])
+        return tuple(reversed(parts))
+    want = {key_of(int(ucode[i])): i for i in kept}
+    rows = b.rows()
+    assert set(rows) == set(want), what
+    if len(ucode) > limit:
+        assert b.stats.num_groups_limit_reached, what
+    for j, a in enumerate(q.aggregations):
+        if a.function in ("COUNT", "SUM", "AVG"):
+            vals = np.ones(len(docs)) if a.function == "COUNT" else data[a.column][docs].astype(np.float64)
+            acc = np.bincount(inv, weights=vals, minlength=len(ucode))
+            cnt = np.bincount(inv, minlength=len(ucode))
+            for k, i in want.items():
+                exp = int(acc[i]) if a.function == "COUNT" else float(acc[i]) if a.function == "SUM" else (float(acc[i]), int(cnt[i]))
+                assert rows[k][j] == exp, (what, k)
+            checked_groups += 1
+        elif a.function in ("MIN", "MAX", "MINMAXRANGE") and len(docs):
+            v = data[a.column][docs].astype(np.float64)
+            lo = np.full(len(ucode), np.inf)
+            hi = np.full(len(ucode), -np.inf)
+            np.minimum.at(lo, inv, v)
+            np.maximum.at(hi, inv, v)
+            for k, i in want.items():
+                exp = float(lo[i]) if a.function == "MIN" else float(hi[i]) if a.function == "MAX" else (float(lo[i]), float(hi[i]))
+                assert rows[k][j] == exp, (what, k)
+        elif a.function == "DISTINCTCOUNT" and len(ucode) <= 3000:
+            col = data[a.column].astype(str) if data[a.column].dtype == object else data[a.column]
+            sets = {}
+            for g, v in zip(inv.tolist(), col[docs].tolist()):
+                sets.setdefault(g, set()).add(v)
+            for k, i in want.items():
+                assert rows[k][j] == frozenset(sets[i]), (what, k)
+    return checked_groups
+
+
 def test_oracle_matches_brute_force(oracle_api, fuzz):
     host, data, nulls = fuzz
     n = host.total_docs
@@ -25,85 +107,23 @@ def test_oracle_matches_brute_force(oracle_api, fuzz):
     checked_groups = 0
     for i in range(150):
         q = gen.query()
-        mask = eval_filter(q.filter, data, nulls, n) if q.filter else np.ones(n, bool)
-        b = o.execute(clone(q))
-        what = f"#{i} {describe(q)}"
-        non_scan = b.stats.num_docs_scanned != int(mask.sum()) and not q.filter   # NonScanBased answers scan nothing
-        if not non_scan:
-            assert b.stats.num_docs_scanned == int(mask.sum()), what
-        if not q.group_by:
-            for a, r in zip(q.aggregations, b.aggregation_result()):
-                if a.function == "COUNT":
-                    assert r == int(mask.sum()), what
-                elif a.function == "SUM":
-                    assert r == float(data[a.column][mask].astype(np.float64).sum()), what
-                elif a.function == "MIN" and mask.any():
-                    assert r == float(data[a.column][mask].min()), what
-                elif a.function == "MAX" and mask.any():
-                    assert r == float(data[a.column][mask].max()), what
-                elif a.function == "AVG":
-                    assert r == (float(data[a.column][mask].astype(np.float64).sum()), int(mask.sum())), what
-                elif a.function == "MINMAXRANGE":
-                    v = data[a.column][mask]
-                    assert r == ((float(v.min()), float(v.max())) if mask.any() else (float("inf"), float("-inf"))), what
-                elif a.function == "DISTINCTCOUNT":
-                    col = data[a.column].astype(str) if data[a.column].dtype == object else data[a.column]
-                    assert r == frozenset(np.unique(col[mask]).tolist()), what
-                elif a.function == "DISTINCTCOUNTHLL":   # registers after hll.offer(value) for every matching doc (numpy restatement)
-                    from pinot_amd.startree import hll_registers
-                    dt = "LONG" if data[a.column].dtype == np.int64 else "INT"
-                    assert r == bytes(hll_registers(data[a.column][mask], dt, a.log2m or 8)), what
-            continue
-        limit = q.num_groups_limit or 100_000
-        docs = np.flatnonzero(mask)
-        code = np.zeros(len(docs), dtype=np.int64)
-        uniques = []
-        for gcol in q.group_by:
-            col = data[gcol].astype(str) if data[gcol].dtype == object else data[gcol]
-            uq, inv = np.unique(col[docs], return_inverse=True)
-            uniques.append(uq)
-            code = code * len(uq) + inv
-        ucode, first_pos, inv = np.unique(code, return_index=True, return_inverse=True)
-        order = np.argsort(first_pos)                 # groups in order of first appearance (docId order)
-        kept = set(order[:limit].tolist())
-
-        def key_of(c):
-            parts = []
-            for uq in reversed(uniques):
-                c, r = divmod(c, len(uq))
-                parts.append(uq[r].item() if hasattr(uq[r], "item") else uq[r])
-            return tuple(reversed(parts))
-        want = {key_of(int(ucode[i])): i for i in kept}
-        rows = b.rows()
-        assert set(rows) == set(want), what
-        if len(ucode) > limit:
-            assert b.stats.num_groups_limit_reached, what
-        for j, a in enumerate(q.aggregations):
-            if a.function in ("COUNT", "SUM", "AVG"):
-                vals = np.ones(len(docs)) if a.function == "COUNT" else data[a.column][docs].astype(np.float64)
-                acc = np.bincount(inv, weights=vals, minlength=len(ucode))
-                cnt = np.bincount(inv, minlength=len(ucode))
-                for k, i in want.items():
-                    exp = int(acc[i]) if a.function == "COUNT" else float(acc[i]) if a.function == "SUM" else (float(acc[i]), int(cnt[i]))
-                    assert rows[k][j] == exp, (what, k)
-                checked_groups += 1
-            elif a.function in ("MIN", "MAX", "MINMAXRANGE") and len(docs):
-                v = data[a.column][docs].astype(np.float64)
-                lo = np.full(len(ucode), np.inf)
-                hi = np.full(len(ucode), -np.inf)
-                np.minimum.at(lo, inv, v)
-                np.maximum.at(hi, inv, v)
-                for k, i in want.items():
-                    exp = float(lo[i]) if a.function == "MIN" else float(hi[i]) if a.function == "MAX" else (float(lo[i]), float(hi[i]))
-                    assert rows[k][j] == exp, (what, k)
-            elif a.function == "DISTINCTCOUNT" and len(ucode) <= 3000:
-                col = data[a.column].astype(str) if data[a.column].dtype == object else data[a.column]
-                sets = {}
-                for g, v in zip(inv.tolist(), col[docs].tolist()):
-                    sets.setdefault(g, set()).add(v)
-                for k, i in want.items():
-                    assert rows[k][j] == frozenset(sets[i]), (what, k)
+        checked_groups += check_against_brute_force(o.execute(clone(q)), q, data, nulls, n, f"#{i} {describe(q)}")
     assert checked_groups > 40
+    o.destroy()
+
+
+def test_oracle_raw_key_groups_match_brute_force(oracle_api, fuzz):
+    """GROUP BY over no-dictionary columns — FLOAT / DOUBLE keys, raw columns among several keys (the reference's
+    NoDictionaryMultiColumnGroupKeyGenerator) — against numpy, numGroupsLimit trimming included."""
+    host, data, nulls = fuzz
+    n = host.total_docs
+    o = NativeSegment(oracle_api, host)
+    gen = Gen(data, seed=303)
+    checked_groups = 0
+    for i in range(60):
+        q = gen.raw_key_query()
+        checked_groups += check_against_brute_force(o.execute(clone(q)), q, data, nulls, n, f"#{i} {describe(q)}")
+    assert checked_groups > 20
     o.destroy()
 
 
@@ -230,6 +250,27 @@ def test_gpu_star_tree_matches_oracle_on_random_queries(gpu_api, oracle_api):
         gb, ob = g.execute(clone(q)), o.execute(clone(q))
         try:
             assert gb.stats.star_tree_index == ob.stats.star_tree_index, what
+            _compare(gb, ob, what)
+        except AssertionError as e:
+            mismatches.append(str(e)[:600])
+    assert not mismatches, "\n".join(mismatches[:12])
+    g.destroy()
+    o.destroy()
+
+
+@pytest.mark.gpu
+def test_gpu_raw_key_groups_match_oracle_on_random_queries(gpu_api, oracle_api, fuzz):
+    """The raw-key generator (FLOAT / DOUBLE keys, raw and dictionary columns mixed, numGroupsLimit): virtual dictionaries on the
+    device against the oracle's tuple map — groups, values, statistics."""
+    host, data, nulls = fuzz
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    gen = Gen(data, seed=int(os.environ.get("PG_FUZZ_SEED_BASE", "1000")) + 77)
+    mismatches = []
+    for i in range(120):
+        q = gen.raw_key_query()
+        what = f"raw keys #{i} {describe(q)}"
+        gb, ob = g.execute(clone(q)), o.execute(clone(q))
+        try:
             _compare(gb, ob, what)
         except AssertionError as e:
             mismatches.append(str(e)[:600])
