@@ -55,7 +55,9 @@ typedef enum pg_data_type {
 typedef enum pg_fwd_encoding {
   /* FixedBitSVForwardIndexReaderV2: dictIds, MSB-first big-endian bit stream, ceil(numDocs*bits/8) bytes. */
   PG_FWD_DICT_FIXED_BIT = 0,
-  /* FixedByteChunkSVForwardIndexReader (PASS_THROUGH only): 7-int header + chunk offsets + big-endian values. */
+  /* FixedByteChunkSVForwardIndexReader: 7-int header + chunk offsets + big-endian values; chunks as written by any
+   * ChunkCompressionType — PASS_THROUGH verbatim, SNAPPY / LZ4 / LZ4_LENGTH_PREFIXED decompressed in HBM, ZSTANDARD / GZIP decoded
+   * on the host during pg_segment_add_column (libzstd.so.1 bound at run time: PG_ERR_UNSUPPORTED without it). */
   PG_FWD_RAW_FIXED_BYTE_CHUNK = 1,
   /* SortedIndexReaderImpl: 2 big-endian ints (startDocId, endDocId inclusive) per dictId; doubles as inverted index. */
   PG_FWD_DICT_SORTED = 2
@@ -209,11 +211,13 @@ typedef enum pg_result_kind {
  *                               LONG for COUNT, DOUBLE for SUM / MIN / MAX (fixed-byte chunk format, PASS_THROUGH), BYTES
  *                               for DISTINCTCOUNTHLL (var-byte chunk format v2/v3, PASS_THROUGH; every value a serialized
  *                               HyperLogLog: BE int log2m, BE int 4*ceil(2^log2m/6), RegisterSet words — ObjectSerDeUtils.java
- *                               :733-767) (StarTreeLoaderUtils.java:81-89, ValueAggregatorFactory#getAggregatedValueType)
+ *                               :733-767); BYTES for AVG / MINMAXRANGE (16 bytes per value: AvgPair = BE double sum + BE long
+ *                               count, MinMaxRangePair = BE double min + BE double max)
+ *                               (StarTreeLoaderUtils.java:81-89, ValueAggregatorFactory#getAggregatedValueType)
  * The dimensions must already be registered as columns of the segment (their dictionaries are shared).
  * ------------------------------------------------------------------------------------------------------------------ */
 typedef struct pg_star_tree_pair {
-  int32_t function;        /* pg_agg_function: COUNT / SUM / MIN / MAX / DISTINCTCOUNTHLL */
+  int32_t function;        /* pg_agg_function: COUNT / SUM / MIN / MAX / DISTINCTCOUNTHLL / AVG / MINMAXRANGE */
   int32_t data_type;       /* pg_data_type of the stored aggregate: LONG / DOUBLE / BYTES */
   const char* column;      /* "*" for COUNT */
   pg_buffer forward_index;
