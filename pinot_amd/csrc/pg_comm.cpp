@@ -155,11 +155,12 @@ void result_all_reduce(Result& r, Comm& c) {
   const int64_t G = std::max(D.n_groups, 1);
   int64_t* table = T.table.as<int64_t>();
   std::vector<std::pair<size_t, size_t>> set_regions;   // (offset, bytes) of dictId-set regions: gathered, then OR-ed
+  for (int o = 0; o < D.n_ops; o++)   // refusals before the group opens: an exception between GroupStart and GroupEnd would leave it open
+    if (D.ops[o].fn == PG_ACC_SUM && D.ops[o].is_float == 1)
+      fail(PG_ERR_UNSUPPORTED, "pg_result_all_reduce: a floating-point SUM accumulated in double (a column holding NaN / Inf) does not merge exactly");
   PG_NCCL(R.GroupStart());
   for (int o = 0; o < D.n_ops && T.n_out > 0; o++) {
     const int red = D.ops[o].fn == PG_ACC_MIN ? kNcclMin : (D.ops[o].fn == PG_ACC_MAX ? kNcclMax : kNcclSum);
-    if (D.ops[o].fn == PG_ACC_SUM && D.ops[o].is_float == 1)
-      fail(PG_ERR_UNSUPPORTED, "pg_result_all_reduce: a floating-point SUM accumulated in double does not merge exactly");
     PG_NCCL(R.AllReduce(table + (int64_t)o * G, table + (int64_t)o * G, (size_t)G, kNcclInt64, red, c.comm, stream));
   }
   PG_NCCL(R.AllReduce(table + T.n_out, table + T.n_out, PG_MAX_STATS + 2, kNcclInt64, kNcclSum, c.comm, stream));
