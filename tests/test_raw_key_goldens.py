@@ -1,0 +1,62 @@
+"""The reference's golden numbers on a re-encoded segment: the same docs with the INT group-by columns stored WITHOUT a dictionary.
+
+InnerSegmentAggregationSingleValueQueriesTest's expectations (`:96-153`) are stated on groups' VALUES, so they hold whatever the
+encoding of the key columns: with column1 / column6 / column9 raw, DefaultGroupByExecutor picks
+NoDictionarySingleColumnGroupKeyGenerator (one key) or NoDictionaryMultiColumnGroupKeyGenerator (a raw column among several,
+`DefaultGroupByExecutor.java:100-118`) instead of DictionaryBasedGroupKeyGenerator — and must return the same groups, the same
+intermediate results and the same ExecutionStatistics (the filter columns keep their dictionaries and indexes).  This pins the oracle's
+no-dictionary generators — and, through the GPU tests, the virtual dictionaries of the HIP path — to the reference's own numbers."""
+import pytest
+
+from pinot_amd.executor import NativeSegment
+from pinot_amd.segment import build_segment
+from tests.fixtures import SV_FILTER, SV_INVERTED, SV_SCHEMA
+from tests.test_oracle_goldens import AGGREGATION_QUERY, check_agg, check_stats
+
+RAW_KEYS = ["column9", "column6"]     # group-by columns only: column1 / column3 / column7 of SV_FILTER keep their scans / indexes
+
+
+def raw_key_segment(sv_data):
+    data = {k: (v.tolist() if v.dtype.kind == "U" else v) for k, v in sv_data.items()}
+    return build_segment("testTable_rawKeys", data, SV_SCHEMA, inverted_index_columns=[c for c in SV_INVERTED if c not in RAW_KEYS],
+                         no_dictionary_columns=RAW_KEYS)
+
+
+GOLDENS = [
+    # (GROUP BY, key, (count, sum1, max3, min6, avg_sum, avg_count), post-filter entries) — unfiltered, then with SV_FILTER
+    (" GROUP BY column9", (11270,), (1, 815409257, 1215316262, 1328642550, 788414092, 1), 150000,
+     (242920,), (3, 4348938306, 407993712, 296467636, 5803888725, 3), 30645),
+    (" GROUP BY column9, column11, column12", (1813102948, "P", "HEuxNvH"), (4, 2062187196, 1988589001, 394608493, 4782388964, 4), 210000,
+     (1176631727, "P", "KrNxpdycSiwoRohEiTIlLqDHnx"), (1, 716185211, 489993380, 371110078, 487714191, 1), 42903),
+    (" GROUP BY column1, column6, column9, column11, column12", (484569489, 16200443, 1159557463, "P", "MaztCmmxxgguBUxPti"),
+     (2, 969138978, 995355481, 16200443, 2222394270, 2), 210000,
+     (1318761745, 353175528, 1172307870, "P", "HEuxNvH"), (2, 2637523490, 557154208, 353175528, 2427862396, 2), 42903),
+]
+
+
+def run_goldens(seg):
+    for gb, key, agg, post, fkey, fagg, fpost in GOLDENS:
+        b = seg.execute(AGGREGATION_QUERY + gb)
+        check_stats(b, 30000, 0, post, 30000)
+        check_agg(b.rows()[key], *agg)
+        b = seg.execute(AGGREGATION_QUERY + SV_FILTER + gb)
+        check_stats(b, 6129, 63064, fpost, 30000)
+        check_agg(b.rows()[fkey], *fagg)
+
+
+def test_oracle_raw_keys_reproduce_the_reference_goldens(oracle_api, sv_data):
+    seg = NativeSegment(oracle_api, raw_key_segment(sv_data))
+    run_goldens(seg)
+    seg.destroy()
+
+
+@pytest.mark.gpu
+def test_gpu_raw_keys_reproduce_the_reference_goldens(gpu_api, oracle_api, sv_data):
+    host = raw_key_segment(sv_data)
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    run_goldens(g)
+    for gb, *_ in GOLDENS:          # and every group, not only the asserted one
+        for flt in ("", SV_FILTER):
+            assert g.execute(AGGREGATION_QUERY + flt + gb).rows() == o.execute(AGGREGATION_QUERY + flt + gb).rows()
+    g.destroy()
+    o.destroy()
