@@ -60,3 +60,37 @@ def test_gpu_raw_keys_reproduce_the_reference_goldens(gpu_api, oracle_api, sv_da
             assert g.execute(AGGREGATION_QUERY + flt + gb).rows() == o.execute(AGGREGATION_QUERY + flt + gb).rows()
     g.destroy()
     o.destroy()
+
+
+# ---- the same goldens over compressed raw chunks: every ChunkCompressionType must decode to the reference's docs ----------------------
+def compressed_segment(sv_data, codec):
+    """column1 / column3 / column6 / column7 (the aggregated and filtered INT columns) as raw chunks written with `codec`."""
+    from pinot_amd.segment import build_column
+    host = raw_key_segment(sv_data)
+    for c in ("column1", "column3", "column6", "column7"):
+        host.columns[c] = build_column(c, sv_data[c], "INT", dictionary=False, chunk_compression=codec, docs_per_chunk=1000)
+    return host
+
+
+def aggregation_goldens(seg):   # InnerSegmentAggregationSingleValueQueriesTest.java:43-60
+    b = seg.execute(AGGREGATION_QUERY)
+    assert b.stats.num_docs_scanned == 30000
+    check_agg(b.aggregation_result(), 30000, 32317185437847, 2147419555, 1689277, 28175373944314, 30000)
+    b = seg.execute(AGGREGATION_QUERY + SV_FILTER)
+    assert b.stats.num_docs_scanned == 6129
+    check_agg(b.aggregation_result(), 6129, 6875947596072, 999813884, 1980174, 4699510391301, 6129)
+
+
+@pytest.mark.parametrize("codec", [1, 2, 3, 4, 5], ids=["SNAPPY", "ZSTANDARD", "LZ4", "LZ4_LENGTH_PREFIXED", "GZIP"])
+def test_oracle_goldens_over_compressed_chunks(oracle_api, sv_data, codec):
+    seg = NativeSegment(oracle_api, compressed_segment(sv_data, codec))
+    aggregation_goldens(seg)
+    seg.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("codec", [1, 2, 3, 4, 5], ids=["SNAPPY", "ZSTANDARD", "LZ4", "LZ4_LENGTH_PREFIXED", "GZIP"])
+def test_gpu_goldens_over_compressed_chunks(gpu_api, sv_data, codec):
+    seg = NativeSegment(gpu_api, compressed_segment(sv_data, codec))
+    aggregation_goldens(seg)
+    seg.destroy()
