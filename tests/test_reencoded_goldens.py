@@ -94,3 +94,83 @@ def test_gpu_goldens_over_compressed_chunks(gpu_api, sv_data, codec):
     seg = NativeSegment(gpu_api, compressed_segment(sv_data, codec))
     aggregation_goldens(seg)
     seg.destroy()
+
+
+# ---- the same goldens through a star-tree over (column9, column11, column12) holding count / sum / max / min and the AVG pair ------------
+def star_tree_segment(sv_data):
+    from pinot_amd import startree
+    from tests.fixtures import sv_segment
+    host = sv_segment(sv_data)
+    startree.add_star_tree(host, ["column9", "column11", "column12"],
+                           [("COUNT", "*"), ("SUM", "column1"), ("MAX", "column3"), ("MIN", "column6"), ("AVG", "column7"), ("MINMAXRANGE", "column3")],
+                           max_leaf_records=10)
+    return host
+
+
+def star_tree_goldens(seg):
+    """InnerSegmentAggregationSingleValueQueriesTest.java:96-133 without the filter (its columns are no star-tree dimensions): the
+    pre-aggregated docs must add up to the reference's groups — COUNT, SUM, MAX, MIN and the serialized AvgPair alike."""
+    b = seg.execute(AGGREGATION_QUERY + " GROUP BY column9")
+    assert b.stats.star_tree_index == 0 and b.stats.num_docs_scanned < 30000
+    check_agg(b.rows()[(11270,)], 1, 815409257, 1215316262, 1328642550, 788414092, 1)
+    b = seg.execute(AGGREGATION_QUERY + " GROUP BY column9, column11, column12")
+    assert b.stats.star_tree_index == 0
+    check_agg(b.rows()[(1813102948, "P", "HEuxNvH")], 4, 2062187196, 1988589001, 394608493, 4782388964, 4)
+    b = seg.execute(AGGREGATION_QUERY)      # root: one pre-aggregated doc
+    assert b.stats.star_tree_index == 0 and b.stats.num_docs_scanned == 1
+    check_agg(b.aggregation_result(), 30000, 32317185437847, 2147419555, 1689277, 28175373944314, 30000)
+    b = seg.execute("SELECT MINMAXRANGE(column3), AVG(column7) FROM testTable WHERE column11 = 'P'")
+    assert b.stats.star_tree_index == 0
+    return b.aggregation_result()
+
+
+def test_oracle_goldens_through_a_star_tree(oracle_api, sv_data):
+    from pinot_amd import capi
+    from pinot_amd.query import parse_sql
+    seg = NativeSegment(oracle_api, star_tree_segment(sv_data))
+    star = star_tree_goldens(seg)
+    q = parse_sql("SELECT MINMAXRANGE(column3), AVG(column7) FROM testTable WHERE column11 = 'P'")
+    q.flags |= capi.QUERY_FLAG_SKIP_STAR_TREE
+    assert seg.execute(q).aggregation_result() == star      # the pairs add up to what the plain scan computes
+    seg.destroy()
+
+
+@pytest.mark.gpu
+def test_gpu_goldens_through_a_star_tree(gpu_api, oracle_api, sv_data):
+    host = star_tree_segment(sv_data)
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    assert star_tree_goldens(g) == star_tree_goldens(o)
+    g.destroy()
+    o.destroy()
+
+
+# ---- and behind a range index on the filter's range columns ------------------------------------------------------------------------------
+def range_index_segment(sv_data):
+    data = {k: (v.tolist() if v.dtype.kind == "U" else v) for k, v in sv_data.items()}
+    return build_segment("testTable_rangeIdx", data, SV_SCHEMA, inverted_index_columns=SV_INVERTED, range_index_columns=["column1", "column3"])
+
+
+def range_index_goldens(seg):
+    """:43-60 with `column1 > 100000000` and `column3 BETWEEN ...` answered by RangeIndexBasedFilterOperator: same docs, same values;
+    the two leaves scan nothing, so numEntriesScannedInFilter is what the remaining scan leaves count."""
+    b = seg.execute(AGGREGATION_QUERY + SV_FILTER)
+    assert b.stats.num_docs_scanned == 6129 and b.stats.num_entries_scanned_in_filter < 63064
+    check_agg(b.aggregation_result(), 6129, 6875947596072, 999813884, 1980174, 4699510391301, 6129)
+    b = seg.execute(AGGREGATION_QUERY + SV_FILTER + " GROUP BY column9")
+    check_agg(b.rows()[(242920,)], 3, 4348938306, 407993712, 296467636, 5803888725, 3)
+    return b.stats.num_entries_scanned_in_filter
+
+
+def test_oracle_goldens_behind_a_range_index(oracle_api, sv_data):
+    seg = NativeSegment(oracle_api, range_index_segment(sv_data))
+    range_index_goldens(seg)
+    seg.destroy()
+
+
+@pytest.mark.gpu
+def test_gpu_goldens_behind_a_range_index(gpu_api, oracle_api, sv_data):
+    host = range_index_segment(sv_data)
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    assert range_index_goldens(g) == range_index_goldens(o)
+    g.destroy()
+    o.destroy()
