@@ -174,3 +174,33 @@ def test_gpu_goldens_behind_a_range_index(gpu_api, oracle_api, sv_data):
     assert range_index_goldens(g) == range_index_goldens(o)
     g.destroy()
     o.destroy()
+
+
+# ---- and with the summed columns widened: column1 as raw DOUBLE (fixed-point digit accumulators), column7 as raw LONG ---------------------
+def widened_segment(sv_data):
+    import numpy as np
+    data = {k: (v.tolist() if v.dtype.kind == "U" else v) for k, v in sv_data.items()}
+    data["column1"] = np.asarray(sv_data["column1"], dtype=np.float64)     # every INT is an exact double: the sums stay the reference's
+    data["column7"] = np.asarray(sv_data["column7"], dtype=np.int64)
+    schema = dict(SV_SCHEMA, column1="DOUBLE", column7="LONG")
+    return build_segment("testTable_widened", data, schema, inverted_index_columns=[c for c in SV_INVERTED if c != "column7"],
+                         no_dictionary_columns=["column1", "column7"])
+
+
+def widened_goldens(seg):
+    aggregation_goldens(seg)
+    b = seg.execute(AGGREGATION_QUERY + " GROUP BY column9, column11, column12")
+    check_agg(b.rows()[(1813102948, "P", "HEuxNvH")], 4, 2062187196, 1988589001, 394608493, 4782388964, 4)
+
+
+def test_oracle_goldens_with_double_and_long_sums(oracle_api, sv_data):
+    seg = NativeSegment(oracle_api, widened_segment(sv_data))
+    widened_goldens(seg)
+    seg.destroy()
+
+
+@pytest.mark.gpu
+def test_gpu_goldens_with_double_and_long_sums(gpu_api, sv_data):
+    seg = NativeSegment(gpu_api, widened_segment(sv_data))
+    widened_goldens(seg)
+    seg.destroy()
