@@ -204,3 +204,37 @@ def test_gpu_goldens_with_double_and_long_sums(gpu_api, sv_data):
     seg = NativeSegment(gpu_api, widened_segment(sv_data))
     widened_goldens(seg)
     seg.destroy()
+
+
+# ---- DISTINCTCOUNTHLL over RAW columns: values hashed on the fly (MurmurHash.hashLong) instead of through the dictionary ---------------------
+def test_oracle_hll_goldens_over_raw_columns(oracle_api, sv_data):
+    """InnerSegmentAggregationSingleValueQueriesTest#testDistinctCountHLL's cardinalities (5977 / 23825; 1886 / 4492 behind the filter's
+    first predicates are asserted in test_oracle_goldens) do not depend on the encoding: with column1 / column3 stored raw the registers
+    come from hashing the values themselves."""
+    from pinot_amd.executor import extract_final
+    seg = NativeSegment(oracle_api, widened_int_raw_segment(sv_data))
+    b = seg.execute("SELECT DISTINCTCOUNTHLL(column1), DISTINCTCOUNTHLL(column3) FROM testTable")
+    assert [extract_final("DISTINCTCOUNTHLL", v) for v in b.aggregation_result()] == [5977, 23825]
+    b = seg.execute("SELECT DISTINCTCOUNTHLL(column1), DISTINCTCOUNTHLL(column3) FROM testTable" + SV_FILTER)   # :268-274
+    assert [extract_final("DISTINCTCOUNTHLL", v) for v in b.aggregation_result()] == [1886, 4492]
+    seg.destroy()
+
+
+def widened_int_raw_segment(sv_data):
+    data = {k: (v.tolist() if v.dtype.kind == "U" else v) for k, v in sv_data.items()}
+    return build_segment("testTable_rawHll", data, SV_SCHEMA, inverted_index_columns=SV_INVERTED, no_dictionary_columns=["column1", "column3"])
+
+
+@pytest.mark.gpu
+def test_gpu_hll_goldens_over_raw_columns(gpu_api, oracle_api, sv_data):
+    from pinot_amd.executor import extract_final
+    host = widened_int_raw_segment(sv_data)
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    b = g.execute("SELECT DISTINCTCOUNTHLL(column1), DISTINCTCOUNTHLL(column3) FROM testTable")
+    assert [extract_final("DISTINCTCOUNTHLL", v) for v in b.aggregation_result()] == [5977, 23825]
+    b = g.execute("SELECT DISTINCTCOUNTHLL(column1), DISTINCTCOUNTHLL(column3) FROM testTable" + SV_FILTER)
+    assert [extract_final("DISTINCTCOUNTHLL", v) for v in b.aggregation_result()] == [1886, 4492]
+    q = "SELECT DISTINCTCOUNTHLL(column1), DISTINCTCOUNTHLL(column3), COUNT(*) FROM testTable GROUP BY column9"
+    assert g.execute(q).rows() == o.execute(q).rows()
+    g.destroy()
+    o.destroy()
