@@ -145,6 +145,29 @@ enum PgAggMode : int32_t {
 #define PG_MAX_RADIX_BUCKETS 2048
 #define PG_RADIX_INVALID_KEY 0xFFFFFFFFu   // local key of a padding tuple (staged scatter pads every flush to whole lines)
 #define PG_MAX_RADIX_SRCS 4
+// Partition pipeline v2 (pg_kernels_part.hip): count-free radix partitioning into chunked per-(workgroup, bucket) streams of
+// bit-packed tuples, whole 128-byte lines only; see the header of pg_kernels_part.hip.
+#define PG_P2_CHUNK 256            // tuples per chunk (1 KB per plane)
+#define PG_P2_LINE 32              // tuples per 128-byte line of a plane
+#define PG_P2_MAX_PLANES 4         // dwords per tuple
+#define PG_P2_MAX_BUCKETS 256
+#define PG_P2_WAVES 4              // wavefronts per scatter workgroup
+#define PG_P2_POOL 512             // chunk ids a scatter workgroup holds in LDS (ring)
+#define PG_P2_BATCH 128            // chunk ids claimed per global atomic
+#define PG_P2_LIST 2048            // chunk-list window of an aggregation work item (LDS)
+#define PG_P2_MAX_LINES (PG_P2_WAVES * 4 * 256 / PG_P2_LINE + PG_P2_MAX_BUCKETS)   // whole lines one round can complete
+// p2_ctrl (dwords): [0] chunks claimed, [1] error flag, then the chunk index built between the scatter and the aggregation pass
+#define PG_P2_CTRL_COUNTS 16                                   // [buckets] chunks per bucket
+#define PG_P2_CTRL_STARTS (PG_P2_CTRL_COUNTS + PG_P2_MAX_BUCKETS)        // [buckets + 1] exclusive prefix
+#define PG_P2_CTRL_CURSOR (PG_P2_CTRL_STARTS + PG_P2_MAX_BUCKETS + 16)   // [buckets] fill cursors
+#define PG_P2_CTRL_DWORDS (PG_P2_CTRL_CURSOR + PG_P2_MAX_BUCKETS + 16)
+#define PG_P2_AGG_THREADS 1024
+enum PgP2FieldKind : int32_t {
+  PG_P2_F_HLL = 0,      // (register index | rank << log2m) of the value a DISTINCTCOUNTHLL offers
+  PG_P2_F_DICTID = 1,   // dictId of a dictionary-encoded source (value looked up in the aggregation pass)
+  PG_P2_F_RAW32 = 2,    // raw 32-bit value minus the column's minimum (INT), or the bits of a FLOAT
+  PG_P2_F_RAW64 = 3     // raw 64-bit value: two whole planes (low dword, high dword)
+};
 
 struct PgGroupCol {
   const uint8_t* data;   // fixed-bit dictIds (or the raw big-endian values of a no-dictionary group column)
@@ -268,6 +291,23 @@ struct PgQueryPlan {
   const uint32_t* pk_lut[PG_MAX_RADIX_SRCS];   // per dictId (index | rank << 16) of a dictionary-encoded HyperLogLog source
   int32_t pk_affine[PG_MAX_RADIX_SRCS];        // 1: that source's dictionary is arithmetic, value = pk_base + pk_step x dictId (INT / LONG)
   int64_t pk_base[PG_MAX_RADIX_SRCS], pk_step[PG_MAX_RADIX_SRCS];
+  // partition pipeline v2 (p2 = 1; pg_kernels_part.hip): a tuple is p2_planes dwords, stored as planes (structure of arrays) of
+  // chunked streams; plane 0 holds the local key in bits [0, radix_shift) and never uses bit 31 (0xFFFFFFFF = padding); source i's
+  // field sits in plane p2_fplane[i] at bit pk_shift[i], pk_bits[i] wide (PG_P2_F_RAW64: planes p2_fplane[i], p2_fplane[i] + 1)
+  int32_t p2;
+  int32_t p2_planes;
+  int32_t p2_docid_plane;           // plane carrying the docId (MIN(docId) of numGroupsLimit trimming), -1: none
+  int32_t p2_capacity;              // chunks of the tuple area; chunk index p2_capacity is the spill chunk (overflow = internal error)
+  int32_t p2_fplane[PG_MAX_RADIX_SRCS];
+  int32_t p2_fkind[PG_MAX_RADIX_SRCS];
+  int64_t p2_fbias[PG_MAX_RADIX_SRCS];   // PG_P2_F_RAW32 over INT: stored field = value - bias
+  uint32_t* p2_tuples;              // [p2_planes][(p2_capacity + 1) * PG_P2_CHUNK] dwords
+  int64_t p2_plane_stride;          // dwords per plane
+  uint32_t* p2_meta;                // [p2_capacity]: owner bucket | filled lines << 16; 0xFFFFFFFF: chunk never handed out
+  uint32_t* p2_ctrl;                // [0] chunks claimed so far, [1] error flag, [PG_P2_CTRL_*] the chunk index's counters
+  uint32_t* p2_list;                // [p2_capacity] chunk records grouped by bucket: chunk id | filled lines << 27
+  int32_t p2_fast_a;                // 1: the scatter's batched loader fits (<= 4 group columns: the first <= 24 bits, the others <= 8;
+  int32_t p2_pad;                   //    at most one source, bit-packed <= 24 bits or raw 32-bit)
   int32_t n_lin_prefix;             // interpreter kernels: instrs[0, n_lin_prefix) is index-only and leaves one stack entry
   int32_t n_fast_scans;             // pg_fast_multi_*: instrs[n_index_instr, n_index_instr + n_fast_scans) are scan leaves ANDed in order
   int32_t tail_posting;             // pg_fast_multi_*: posting leaf ANDed in AFTER the scans (-1: none) — the queryableDocIds bitmap of

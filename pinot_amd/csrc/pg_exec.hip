@@ -27,6 +27,11 @@ extern "C" __global__ void pg_reduce_parts_kernel(const int64_t* partials, int64
 PG_DECL_FAST(pg_radix_count_kernel) PG_DECL_FAST(pg_radix_scatter_kernel) PG_DECL_FAST(pg_radix_aggregate_kernel)
 PG_DECL_FAST(pg_radix_scatter_packed_kernel) PG_DECL_FAST(pg_radix_aggregate_packed_kernel)
 PG_DECL_FAST(pg_hash_count_kernel) PG_DECL_FAST(pg_hash_scatter_kernel) PG_DECL_FAST(pg_hash_aggregate_kernel)
+PG_DECL_FAST(pg_p2_scatter_1) PG_DECL_FAST(pg_p2_scatter_2) PG_DECL_FAST(pg_p2_scatter_3) PG_DECL_FAST(pg_p2_scatter_4)
+PG_DECL_FAST(pg_p2_scatter_1f) PG_DECL_FAST(pg_p2_scatter_2f) PG_DECL_FAST(pg_p2_scatter_1f_key) PG_DECL_FAST(pg_p2_scatter_1f_hll)
+PG_DECL_FAST(pg_p2_aggregate_1) PG_DECL_FAST(pg_p2_aggregate_2) PG_DECL_FAST(pg_p2_aggregate_3) PG_DECL_FAST(pg_p2_aggregate_4)
+PG_DECL_FAST(pg_p2_index_count_kernel) PG_DECL_FAST(pg_p2_index_scan_kernel) PG_DECL_FAST(pg_p2_index_fill_kernel)
+extern "C" const int pg_p2_round_quads[5];   // pg_kernels_part.hip: quads per lane and round of the scatter kernel, by plane count
 extern "C" __global__ void pg_radix_offsets_kernel(uint32_t* hist, uint32_t* bucket_total, int n_wg, int n_buckets, int stage, int stage_waves);
 extern "C" __global__ void pg_radix_bucket_scan_kernel(const uint32_t* bucket_total, uint32_t* bucket_start, int n_buckets);
 extern "C" __global__ void pg_radix_reduce_kernel(const int64_t* partials, int64_t* out, int n_ops, int n_groups, int radix_shift, int slices,
@@ -119,7 +124,9 @@ void use_device(int ordinal) {
       typedef void (*QueryKernel)(const PgQueryPlan);
       const QueryKernel all[] = {pg_generic_query_f, pg_generic_query_l, pg_generic_query_g, pg_fast_none_f, pg_fast_none_a, pg_fast_i32range_f, pg_fast_i32range_a,
                                  pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a, pg_fast_multi_f, pg_fast_multi_a, pg_fast_multi_w, pg_fast_none_w, pg_fast_multi_wd, pg_fast_none_wd, pg_generic_query_ld, pg_generic_query_gd, pg_fast_i32range_d, pg_fast_i32range_p,
-                                 pg_radix_aggregate_kernel, pg_hash_aggregate_kernel};
+                                 pg_radix_aggregate_kernel, pg_hash_aggregate_kernel,
+                                 pg_p2_scatter_1, pg_p2_scatter_2, pg_p2_scatter_3, pg_p2_scatter_4, pg_p2_scatter_1f, pg_p2_scatter_2f, pg_p2_scatter_1f_key, pg_p2_scatter_1f_hll,
+                                 pg_p2_aggregate_1, pg_p2_aggregate_2, pg_p2_aggregate_3, pg_p2_aggregate_4};
       for (QueryKernel k : all)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pg_radix_scatter_packed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
@@ -198,6 +205,8 @@ struct ThreadCtx {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   DeviceBuffer stats, partials, final_table, tile_counts, aux;
   DeviceBuffer words, radix_hist, radix_start, radix_tuples, hash_count, hash_keys, hash_acc;   // PG_AGG_RADIX work areas
+  DeviceBuffer p2_meta, p2_list, p2_ctrl;   // partition pipeline v2: chunk records, the same grouped by bucket, counters (PG_P2_CTRL_*)
+  uint32_t* p2_ctrl_host = nullptr;   // page-locked copy of p2_ctrl
   bool stats_dirty = true;      // the stats counters may be non-zero (first use, or a query that failed midway)
   void* pinned = nullptr;       // page-locked staging for the result copy (pageable copies are staged synchronously)
   size_t pinned_size = 0;
@@ -213,6 +222,7 @@ struct ThreadCtx {
   }
   ~ThreadCtx() {
     if (pinned) (void)hipHostFree(pinned);
+    if (p2_ctrl_host) (void)hipHostFree(p2_ctrl_host);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -501,6 +511,8 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
   std::vector<uint32_t*> aux_final((size_t)D.n_aux, nullptr);
   const bool radix_aux = D.agg_mode == PG_AGG_RADIX && D.n_aux > 0;   // HLL registers of a bucket in LDS, one partial per work item
   if (radix_aux) D.radix_slices = std::max(1, num_cus() / D.radix_buckets);
+  // partition pipeline v2: up to two work items per CU; fewer when the matches are few (set before the aggregation launch)
+  if (D.agg_mode == PG_AGG_RADIX && D.p2) D.radix_slices = std::max(1, 2 * num_cus() / D.radix_buckets);
   if (aux_total) {
     // LDS-resident states: the kernel writes one partial per workgroup behind the merged regions
     size_t partial_total = P.aux_in_lds ? aux_total * (size_t)shape.grid : 0;
@@ -534,7 +546,90 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
   std::unique_ptr<DeviceTable> kept;
   const bool radix = D.agg_mode == PG_AGG_RADIX || hashed;
   int64_t hash_groups = 0;
-  if (has_docs && radix) {
+  bool p2_ran = false;
+  if (has_docs && radix && D.p2) {
+    // ---- partition pipeline v2 (pg_kernels_part.hip): [filter → match words;] ONE scatter pass into chunked per-bucket streams of
+    //      bit-packed tuples; per-bucket LDS aggregation; merge of the slices ------------------------------------------------------------
+    kname = "pg_part_group_by";
+    p2_ran = true;
+    unsigned long long matched_now = (unsigned long long)P.space_docs;
+    D.match_words = nullptr;
+    if (!P.match_all) {
+      const size_t n_words = (size_t)D.n_wtiles * 64;
+      ThreadCtx::grow(ctx.words, n_words * 4);
+      PgQueryPlan F = D;
+      F.agg_mode = PG_AGG_NONE;
+      F.out_words = ctx.words.as<uint64_t>();
+      const char* fname = "";
+      const LaunchShape fshape = launch_shape(P, D.n_wtiles, PG_AGG_NONE);
+      hipLaunchKernelGGL(select_kernel(P, PG_AGG_NONE, &fname), dim3(fshape.grid), dim3(fshape.block), fshape.lds, ctx.stream, F);
+      PG_HIP(hipGetLastError());
+      // the tuple area is sized by the docs that passed the filter
+      PG_HIP(hipMemcpyAsync(&matched_now, ctx.stats.ptr, 8, hipMemcpyDeviceToHost, ctx.stream));
+      stream_wait(ctx, cancel);
+      D.match_words = ctx.words.as<uint32_t>();
+    }
+    const int T = D.p2_planes, NB = D.radix_buckets, Q = pg_p2_round_quads[T];
+    const size_t nbp = (size_t)((NB + 63) & ~63);
+    (void)nbp;
+    const size_t round_tuples = (size_t)PG_P2_WAVES * (size_t)Q * 256;
+    const size_t s_lds = ((size_t)6 * PG_P2_MAX_BUCKETS + PG_P2_POOL + 8 + 2 * (round_tuples / PG_P2_LINE + (size_t)NB + 1) + (size_t)T * round_tuples +
+                          (size_t)T * (size_t)NB * PG_P2_LINE) * 4;
+    static const int p2_wgs = getenv("PG_P2_WGS_PER_CU") ? atoi(getenv("PG_P2_WGS_PER_CU")) : 4;   // tuning knob
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(p2_wgs, 1), (lds_per_cu() - 1024) / (s_lds + 512)));
+    const int quartets = (D.n_wtiles + PG_P2_WAVES - 1) / PG_P2_WAVES;
+    const int sgrid = std::max(1, std::min(quartets, num_cus() * per_cu));
+    // chunks: the tuples themselves, one partly filled chunk + one padded line per (workgroup, bucket), the ids a workgroup claimed
+    // ahead and did not use
+    const size_t cap = (size_t)(matched_now / PG_P2_CHUNK) + 1 + (size_t)sgrid * (2 * (size_t)NB + PG_P2_BATCH) + 64;
+    if (cap >= ((size_t)1 << 27)) fail(PG_ERR_UNSUPPORTED, "partition pipeline: %zu chunks", cap);
+    D.p2_capacity = (int32_t)cap;
+    D.p2_plane_stride = (int64_t)(cap + 1) * PG_P2_CHUNK;
+    ThreadCtx::grow(ctx.radix_tuples, (size_t)D.p2_plane_stride * 4 * (size_t)T + 256);
+    ThreadCtx::grow(ctx.p2_meta, cap * 4 + 64);
+    ThreadCtx::grow(ctx.p2_list, cap * 4 + 64);
+    if (!ctx.p2_ctrl.ptr) ctx.p2_ctrl.alloc((size_t)PG_P2_CTRL_DWORDS * 4, true);
+    if (!ctx.p2_ctrl_host) PG_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx.p2_ctrl_host), 64, hipHostMallocDefault));
+    PG_HIP(hipMemsetAsync(ctx.p2_meta.ptr, 0xFF, cap * 4, ctx.stream));
+    PG_HIP(hipMemsetAsync(ctx.p2_ctrl.ptr, 0, (size_t)PG_P2_CTRL_DWORDS * 4, ctx.stream));
+    D.p2_tuples = ctx.radix_tuples.as<uint32_t>();
+    D.p2_meta = ctx.p2_meta.as<uint32_t>();
+    D.p2_list = ctx.p2_list.as<uint32_t>();
+    D.p2_ctrl = ctx.p2_ctrl.as<uint32_t>();
+    static const QueryKernel scatter_k[5] = {nullptr, pg_p2_scatter_1, pg_p2_scatter_2, pg_p2_scatter_3, pg_p2_scatter_4};
+    static const QueryKernel scatter_fast_k[3] = {nullptr, pg_p2_scatter_1f, pg_p2_scatter_2f};
+    static const QueryKernel aggregate_k[5] = {nullptr, pg_p2_aggregate_1, pg_p2_aggregate_2, pg_p2_aggregate_3, pg_p2_aggregate_4};
+    // every work item should see >= 64 K tuples (its table is zeroed, flushed and merged whatever it aggregates)
+    const int slices_max = D.radix_slices;
+    D.radix_slices = (int)std::max<unsigned long long>(1, std::min<unsigned long long>((unsigned long long)slices_max, matched_now / ((unsigned long long)NB * 65536ULL)));
+    const size_t slots = (size_t)1 << D.radix_shift;
+    ThreadCtx::grow(ctx.partials, (size_t)NB * D.radix_slices * D.n_ops * slots * 8 + 8);
+    D.partials = ctx.partials.as<int64_t>();
+    QueryKernel sk = D.p2_fast_a && T <= 2 ? scatter_fast_k[T] : scatter_k[T];
+    if (D.p2_fast_a && T == 1 && D.n_srcs == 0) sk = pg_p2_scatter_1f_key;
+    if (D.p2_fast_a && T == 1 && D.n_srcs == 1 && D.p2_fkind[0] == PG_P2_F_HLL && D.pk_affine[0] == 2 && D.srcs[0].col_kind == PG_COL_FIXED_BIT) sk = pg_p2_scatter_1f_hll;
+    hipLaunchKernelGGL(sk, dim3(sgrid), dim3(PG_P2_WAVES * 64), s_lds, ctx.stream, D);
+    PG_HIP(hipGetLastError());
+    {   // the chunk records grouped by bucket (counting sort): count, scan, fill
+      const int igrid = (int)std::max<size_t>(1, std::min<size_t>((size_t)num_cus(), (cap + 4095) / 4096));
+      hipLaunchKernelGGL(pg_p2_index_count_kernel, dim3(igrid), dim3(1024), 0, ctx.stream, D);
+      hipLaunchKernelGGL(pg_p2_index_scan_kernel, dim3(1), dim3(PG_P2_MAX_BUCKETS), 0, ctx.stream, D);
+      hipLaunchKernelGGL(pg_p2_index_fill_kernel, dim3(igrid), dim3(1024), 0, ctx.stream, D);
+      PG_HIP(hipGetLastError());
+    }
+    const int agrid = std::min(NB * D.radix_slices, num_cus());
+    hipLaunchKernelGGL(aggregate_k[T], dim3(agrid), dim3(PG_P2_AGG_THREADS), P.lds_bytes + 64, ctx.stream, D);
+    PG_HIP(hipGetLastError());
+    for (int x = 0; x < D.n_aux; x++) {
+      const int64_t n_words = (int64_t)D.n_groups * D.aux[x].stride / 4, bucket_words = (int64_t)(slots * (size_t)D.aux[x].stride / 4);
+      hipLaunchKernelGGL(pg_radix_reduce_aux_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx.stream, D.aux[x].base,
+                         aux_final[(size_t)x], D.radix_slices, bucket_words, n_words);
+    }
+    hipLaunchKernelGGL(pg_radix_reduce_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, ctx.stream, ctx.partials.as<int64_t>(),
+                       ctx.final_table.as<int64_t>(), D.n_ops, D.n_groups, D.radix_shift, D.radix_slices, P.ops_dev.as<PgAccOp>());
+    PG_HIP(hipGetLastError());
+    PG_HIP(hipMemcpyAsync(ctx.p2_ctrl_host, ctx.p2_ctrl.ptr, 8, hipMemcpyDeviceToHost, ctx.stream));
+  } else if (has_docs && radix) {
     // ---- radix-partitioned group-by: filter → match words; count; offsets; scatter; per-bucket LDS aggregation; merge ---------
     kname = "pg_radix_group_by";
     const size_t n_words = (size_t)D.n_wtiles * 64;
@@ -690,6 +785,8 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
     if (n_out) memcpy(table.data(), host_out, (size_t)n_out * 8);
     memcpy(stats_host, host_out + n_out, sizeof(stats_host));
     ctx.stats_dirty = false;    // the reduce kernel left them zero
+    if (p2_ran && ctx.p2_ctrl_host[1])
+      fail(PG_ERR_INTERNAL, "partition pipeline ran out of chunks (%u claimed, %d sized)", ctx.p2_ctrl_host[0], D.p2_capacity);
     if (hashed) {
       // the occupied slots of every bucket's hash table: raw keys + [n_ops][groups] accumulators → a compact table
       unsigned long long cnt[2] = {0, 0};

@@ -101,6 +101,8 @@ struct Column {
   int32_t fx_exp = 0;                           // FLOAT / DOUBLE: every finite |value| < 2^fx_exp (a multiple of 16)
   bool has_nonfinite = false;                   // NaN / +-Inf among the values: SUM falls back to IEEE double accumulation
   uint64_t max_abs_int = 0;                     // LONG: largest |value|
+  bool has_int_range = false;                   // raw INT / LONG: smallest and largest value (tuple packing of the partition pipeline)
+  int64_t int_min = 0, int_max = 0;
   bool dict_affine = false;                     // INT / LONG dictionary whose values are base + step x dictId (ids, dense enumerations)
   int64_t dict_base = 0, dict_step = 0;
   std::map<int, DeviceBuffer> hll_luts;         // per log2m: (register index | rank << 16) of every dictionary value
@@ -249,6 +251,7 @@ struct CompiledPlan {
   std::unique_ptr<FilterOp> root_op;
   std::vector<std::pair<const FilterOp*, std::shared_ptr<CompiledPlan>>> stat_leaves;
   bool always_empty = false;
+  bool match_all = false;            // the filter is MatchAllFilterOperator: no filter pass in front of the partition pipeline
   int32_t n_projected_columns = 0;
   int64_t algorithmic_bytes = 0;
   // aggregation

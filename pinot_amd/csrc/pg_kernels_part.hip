@@ -1,0 +1,861 @@
+// Partition pipeline v2 — group-by over key spaces beyond one LDS table (PG_AGG_RADIX with PgQueryPlan::p2), a translation unit
+// of its own (256-thread scatter workgroups; the kernels of pg_kernels.hip become uninstantiated templates here).
+//
+// Reference work: DictionaryBasedGroupKeyGenerator's map-based holders (core/query/aggregation/groupby/
+// DictionaryBasedGroupKeyGenerator.java:416-446,629-668,993-1084) + the aggregateGroupBySV loops of the aggregation functions
+// (SumAggregationFunction.java:160-179, CountAggregationFunction.java:110-143, Min/MaxAggregationFunction.java:163-188,
+// DistinctCountHLLAggregationFunction.java:152-222): raw key = Σ dictId_j · Π card_i, one holder update per matching doc.
+//
+// Design (what round 2's radix passes did in three reads of the keys and 16-byte tuples is one read and 4-byte tuples here):
+//   * ONE pass over the segment.  No counting pass: output space is handed out in chunks of PG_P2_CHUNK tuples from a global
+//     counter (claimed PG_P2_BATCH at a time into a ring in LDS), every (workgroup, bucket) stream is a list of chunks recorded in
+//     `p2_meta` (owner bucket | filled lines); the aggregation pass finds a bucket's chunks by scanning that small array.
+//   * A tuple is `planes` dwords, bit-packed by the planner: the key's low radix_shift bits, then per source the
+//     (register index, rank) a DISTINCTCOUNTHLL offers, a dictId, a raw INT minus the column's minimum (as many bits as the column's
+//     range needs) or a whole 64-bit value.  The planner lowers radix_shift (more buckets) when that makes a tuple fit one dword.
+//     Planes are stored as structure of arrays, so every store and every load is a dword-coalesced stream whatever the tuple width.
+//   * The scatter workgroup (4 wavefronts, 4 workgroups per CU) sorts a round of 1 024·Q docs by bucket in LDS — a returning
+//     ds_add per doc yields its rank, one wavefront turns the histogram into offsets, the tuples are written to their sorted
+//     positions — and then copies every bucket's run out as WHOLE 128-byte lines (32 tuples); what does not fill a line waits in a
+//     per-bucket leftover line in LDS for the next round.  Whole aligned lines stream at ~5.5 TB/s with no fetch
+//     (profiles/r02_scatter_write_probe.txt); partial ones do not.
+//   * The aggregation pass keeps a bucket's accumulators in LDS ([n_ops][2^radix_shift] int64) and HyperLogLog registers as one
+//     DWORD each, so that an offer is a single non-returning ds_max_u32 (round 2 kept bytes and paid a read + compare-and-swap chain
+//     per tuple); partials are flushed as bytes and merged by pg_radix_reduce_aux_kernel / pg_radix_reduce_kernel as before.
+#ifndef PG_WAVES_PER_BLOCK
+#define PG_WAVES_PER_BLOCK 4
+#endif
+#define PG_KERNEL template <int PG_NOT_INSTANTIATED> static
+#include "pg_kernels.hip"
+
+#define P2_THREADS (PG_P2_WAVES * 64)
+
+// ---- one source's field for the 4 docs of Q quads ----------------------------------------------------------------------------
+template <int Q, bool WIDE>
+DEVFN void p2_field(const PgQueryPlan& p, int si, const uint32_t (&qi)[Q], int wt, uint32_t (&f)[Q][4], uint32_t (&fh)[Q][4]) {
+  const PgValueSrc& V = p.srcs[si];
+  const int kind = p.p2_fkind[si];
+  if (V.col_kind == PG_COL_FIXED_BIT) {
+    const GAS uint32_t* tw = packed_wtile_base(V.data, wt, V.bits);
+    const uint32_t bits = (uint32_t)V.bits, mask = (1u << V.bits) - 1u;
+    if (bits <= 8) {
+      uint32_t r[Q][2];
+#pragma unroll
+      for (int u = 0; u < Q; u++) load_packed_quad<true>(tw, qi[u], bits, r[u]);
+#pragma unroll
+      for (int u = 0; u < Q; u++) decode_packed_quad<true>(r[u], qi[u], bits, mask, f[u]);
+    } else {
+#pragma unroll
+      for (int u = 0; u < Q; u++) {
+        uint32_t r[8];
+        load_packed_quad<false>(tw, qi[u], bits, r);
+        decode_packed_quad<false>(r, qi[u], bits, mask, f[u]);
+      }
+    }
+    if (kind == PG_P2_F_HLL) {
+      const int log2m = p.pk_hll[si];
+      if (p.pk_affine[si]) {   // arithmetic dictionary: the value is computed and hashed, no cardinality-sized gather
+#pragma unroll
+        for (int u = 0; u < Q; u++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            f[u][i] = packed_hll_payload(hll_index_rank_dev(murmur_hash_long_dev(p.pk_base[si] + p.pk_step[si] * (int64_t)f[u][i]), log2m), log2m);
+      } else {
+#pragma unroll
+        for (int u = 0; u < Q; u++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) f[u][i] = packed_hll_payload(gptr<uint32_t>(p.pk_lut[si])[f[u][i]], log2m);
+      }
+    }
+    return;
+  }
+  if (V.col_kind == PG_COL_RAW32) {
+    const GAS uint8_t* tb = gptr<uint8_t>(V.data + (size_t)wt * (PG_WAVE_DOCS * 4));
+    u32x4 v[Q];
+#pragma unroll
+    for (int u = 0; u < Q; u++) v[u] = ldnt((const GAS u32x4*)(tb + qi[u] * 16u));
+#pragma unroll
+    for (int u = 0; u < Q; u++) { f[u][0] = bswap32(v[u].x); f[u][1] = bswap32(v[u].y); f[u][2] = bswap32(v[u].z); f[u][3] = bswap32(v[u].w); }
+    if (kind == PG_P2_F_HLL) {   // hll.offer(value): Integer → hashLong((long) v), Float → raw int bits (MurmurHash.hash(Object))
+      const int log2m = p.pk_hll[si];
+#pragma unroll
+      for (int u = 0; u < Q; u++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+          f[u][i] = packed_hll_payload(hll_index_rank_dev(murmur_hash_long_dev((int64_t)(int32_t)f[u][i]), log2m), log2m);
+    } else if (V.val_type == PG_V_I32) {
+      const uint32_t bias = (uint32_t)p.p2_fbias[si];
+#pragma unroll
+      for (int u = 0; u < Q; u++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) f[u][i] -= bias;
+    }
+    return;
+  }
+  // PG_COL_RAW64
+  if (!WIDE && kind != PG_P2_F_HLL) return;   // a one-plane tuple carries no whole 64-bit value
+  const GAS uint8_t* tb = gptr<uint8_t>(V.data + (size_t)wt * (PG_WAVE_DOCS * 8));
+#pragma unroll
+  for (int u = 0; u < Q; u++) {
+    const GAS u32x4* pp = (const GAS u32x4*)(tb + qi[u] * 32u);
+    const u32x4 a = ldnt(pp), b = ldnt(pp + 1);
+    fh[u][0] = bswap32(a.x); f[u][0] = bswap32(a.y); fh[u][1] = bswap32(a.z); f[u][1] = bswap32(a.w);
+    fh[u][2] = bswap32(b.x); f[u][2] = bswap32(b.y); fh[u][3] = bswap32(b.z); f[u][3] = bswap32(b.w);
+  }
+  if (kind == PG_P2_F_HLL) {
+    const int log2m = p.pk_hll[si];
+#pragma unroll
+    for (int u = 0; u < Q; u++)
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        f[u][i] = packed_hll_payload(hll_index_rank_dev(murmur_hash_long_dev((int64_t)(((uint64_t)fh[u][i] << 32) | f[u][i])), log2m), log2m);
+  }
+}
+
+// ---- batched loader of the scatter's phase A ("fast A") ---------------------------------------------------------------------------
+// The generic key / field functions above walk the plan's columns in a runtime loop: load, wait, decode, next column — one HBM round
+// trip per column and batch, ~10 per round (rocprof, round 3: 1.28 ms per 200 M docs, latency-bound).  Plans of the common shape
+// (PgQueryPlan::p2_fast_a: <= 4 group columns, the first <= 24 bits, the others <= 8 bits; at most one source, bit-packed <= 24 bits
+// or raw 32-bit) instead issue EVERY load of a batch of two quads back to back, and the loads of a round's first batch are requested
+// before the previous round's bookkeeping phases, so they travel while the workgroup sorts and writes.
+// inclusive prefix sum across the wavefront with DPP row operations (no LDS round trips: six dependent ds_bpermute per __shfl_up scan
+// were ~600 cycles of the serial bookkeeping phase)
+DEVFN uint32_t p2_wave_scan(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);    // row_shr:1 (zero beyond the row)
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);    // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);    // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);    // row_shr:8: inclusive within each row of 16
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+  return x;
+}
+// stream-lib MurmurHash.hashLong((long) v) for an INT value: the high word is 0 or -1, its contribution a constant
+DEVFN uint32_t p2_murmur_int(int32_t v) {
+  const uint32_t m = 0x5bd1e995u;
+  uint32_t k = (uint32_t)v * m;
+  k ^= k >> 24;
+  uint32_t h = k * m;
+  constexpr uint32_t km = 0u - 0x5bd1e995u;                 // 0xFFFFFFFF * m
+  constexpr uint32_t hi_neg = (km ^ (km >> 24)) * 0x5bd1e995u;
+  h *= m;
+  h ^= v < 0 ? hi_neg : 0u;
+  h ^= h >> 13;
+  h *= m;
+  h ^= h >> 15;
+  return h;
+}
+
+typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
+#define P2_QA 2
+// Load targets are vector VALUES (never arrays written through a pointer: round 3's first cut passed uint32_t* into the loaders and the
+// compiler kept the windows in scratch, waiting for every load right after issuing it).
+struct P2Raw {
+  u32x4 g0[P2_QA];      // group column 0: a 64-bit window in .xy (<= 8 bits) or a 128-bit window (9..24 bits) per quad
+  u32x2 g[3][P2_QA];    // group columns 1..3: 64-bit windows
+  u32x4 s0[P2_QA];      // the source: 64- / 128-bit window of a bit-packed column, or the four raw 32-bit values
+};
+DEVFN u32x2 p2_ld2(const GAS uint32_t* __restrict__ tw, uint32_t q, uint32_t bits) {   // <= 8 bits: the quad lies in one 64-bit window
+  return ldnt((const GAS u32x2_a4*)(tw + (__umul24(4u * q, bits) >> 5)));
+}
+DEVFN u32x4 p2_ld4(const GAS uint32_t* __restrict__ tw, uint32_t q, uint32_t bits) {   // 9..24 bits: four values (<= 96 bits) start within the first dword
+  return ldnt((const GAS u32x4_a4*)(tw + (__umul24(4u * q, bits) >> 5)));   // q < 512, bits <= 32
+}
+DEVFN void p2_dec2(u32x2 r, uint32_t q, uint32_t bits, uint32_t mask, uint32_t (&out)[4]) {
+  const uint32_t sh = __umul24(4u * q, bits) & 31u;
+  const uint64_t win = ((uint64_t)bswap32(r.x) << 32) | (uint64_t)bswap32(r.y);
+  const uint32_t top = (uint32_t)((win << sh) >> 32);   // the quad's four values now start at bit 31
+  out[0] = top >> (32u - bits);
+#pragma unroll
+  for (int i = 1; i < 4; i++) out[i] = (top >> (32u - (uint32_t)(i + 1) * bits)) & mask;
+}
+DEVFN void p2_dec4(u32x4 r, uint32_t q, uint32_t bits, uint32_t mask, uint32_t (&out)[4]) {
+  const uint32_t sh0 = __umul24(4u * q, bits) & 31u;
+  const uint32_t w0 = bswap32(r.x), w1 = bswap32(r.y), w2 = bswap32(r.z), w3 = bswap32(r.w);
+  // the window shifted left by sh0 (funnel shifts): value i now starts at the wave-uniform bit i * bits
+  const uint32_t n0 = (uint32_t)((((uint64_t)w0 << 32) | w1) >> (32u - sh0)), n1 = (uint32_t)((((uint64_t)w1 << 32) | w2) >> (32u - sh0));
+  const uint32_t n2 = (uint32_t)((((uint64_t)w2 << 32) | w3) >> (32u - sh0)), n3 = w3 << sh0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const uint32_t st = (uint32_t)i * bits, j = st >> 5, o = st & 31u;   // wave-uniform
+    const uint32_t a = j == 0 ? n0 : (j == 1 ? n1 : n2), b = j == 0 ? n1 : (j == 1 ? n2 : n3);
+    const uint64_t win = ((uint64_t)a << 32) | (uint64_t)b;
+    out[i] = (uint32_t)(win >> (64u - o - bits)) & mask;
+  }
+}
+// Every load target is written by ONE load instruction on every path (a value assembled from a load's components, or loaded in one
+// of two branches, makes the compiler wait for the load where the paths join): column 0 and the source always take a 128-bit window
+// (columns are padded, the over-read of a <= 8-bit column stays inside), the source's address is selected, not branched on.
+DEVFN void p2_issue(const PgQueryPlan& p, const uint32_t (&qi)[P2_QA], int wt, P2Raw& raw) {
+  {
+    const PgGroupCol& gc = p.gcols[0];
+    const GAS uint32_t* tw = packed_wtile_base(gc.data, wt, gc.bits);
+#pragma unroll
+    for (int u = 0; u < P2_QA; u++) raw.g0[u] = p2_ld4(tw, qi[u], (uint32_t)gc.bits);
+  }
+#pragma unroll
+  for (int g = 1; g < 4; g++)
+    if (g < p.n_group_cols) {
+      const PgGroupCol& gc = p.gcols[g];
+      const GAS uint32_t* tw = packed_wtile_base(gc.data, wt, gc.bits);
+#pragma unroll
+      for (int u = 0; u < P2_QA; u++) raw.g[g - 1][u] = p2_ld2(tw, qi[u], (uint32_t)gc.bits);
+    }
+  if (p.n_srcs > 0) {
+    const PgValueSrc& V = p.srcs[0];
+    const bool packed = V.col_kind == PG_COL_FIXED_BIT;   // else PG_COL_RAW32
+    const uint32_t bits = packed ? (uint32_t)V.bits : 32u;   // a raw 32-bit column is a 32-bit packed one: window = the quad's 16 bytes
+    const GAS uint32_t* tw = gptr<uint32_t>(V.data + (size_t)wt * (size_t)(PG_WAVE_DOCS / 8) * (size_t)bits);
+#pragma unroll
+    for (int u = 0; u < P2_QA; u++) raw.s0[u] = p2_ld4(tw, qi[u], bits);
+  }
+}
+// keys and plane dwords of the batch's 8 docs per lane
+// SRC: 0 no source; 1 a bit-packed dictionary column offered to a HyperLogLog through an INT arithmetic dictionary (config 5: no
+// look-up, four multiplies per hash); 2 any other source the loader takes
+template <int T, int SRC>
+DEVFN void p2_decode(const PgQueryPlan& p, const P2Raw& raw, const uint32_t (&qi)[P2_QA], uint32_t local_mask, uint32_t (&key)[P2_QA * 4],
+                     uint32_t (&d)[T][P2_QA * 4]) {
+  {
+    const PgGroupCol& gc = p.gcols[0];
+    const uint32_t bits = (uint32_t)gc.bits, mask = (1u << gc.bits) - 1u;
+#pragma unroll
+    for (int u = 0; u < P2_QA; u++) {
+      uint32_t v[4];
+      if (bits <= 8) p2_dec2((u32x2){raw.g0[u].x, raw.g0[u].y}, qi[u], bits, mask, v);
+      else p2_dec4(raw.g0[u], qi[u], bits, mask, v);
+#pragma unroll
+      for (int i = 0; i < 4; i++) key[4 * u + i] = v[i];   // mult of column 0 is 1
+    }
+  }
+#pragma unroll
+  for (int g = 1; g < 4; g++)
+    if (g < p.n_group_cols) {
+      const PgGroupCol& gc = p.gcols[g];
+      const uint32_t bits = (uint32_t)gc.bits, mask = (1u << gc.bits) - 1u, mult = (uint32_t)gc.mult;
+#pragma unroll
+      for (int u = 0; u < P2_QA; u++) {
+        uint32_t v[4];
+        p2_dec2(raw.g[g - 1][u], qi[u], bits, mask, v);
+#pragma unroll
+        for (int i = 0; i < 4; i++) key[4 * u + i] += __umul24(v[i], mult);   // mult < 2^24 (fast-A condition)
+      }
+    }
+#pragma unroll
+  for (int j = 0; j < P2_QA * 4; j++) {
+    d[0][j] = key[j] & local_mask;
+#pragma unroll
+    for (int pl = 1; pl < T; pl++) d[pl][j] = 0;
+  }
+  if (SRC == 1) {
+    const PgValueSrc& V = p.srcs[0];
+    const uint32_t bits = (uint32_t)V.bits, mask = (1u << V.bits) - 1u;
+    const int log2m = p.pk_hll[0];
+    const uint32_t b32 = (uint32_t)p.pk_base[0], s32 = (uint32_t)p.pk_step[0], sh = (uint32_t)p.pk_shift[0];
+#pragma unroll
+    for (int u = 0; u < P2_QA; u++) {
+      uint32_t v[4];
+      if (bits <= 8) p2_dec2((u32x2){raw.s0[u].x, raw.s0[u].y}, qi[u], bits, mask, v);
+      else p2_dec4(raw.s0[u], qi[u], bits, mask, v);
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        d[0][4 * u + i] |= packed_hll_payload(hll_index_rank_dev(p2_murmur_int((int32_t)(b32 + __umul24(s32, v[i]))), log2m), log2m) << sh;
+    }
+  } else if (SRC == 2 && p.n_srcs > 0) {
+    const PgValueSrc& V = p.srcs[0];
+    const int kind = p.p2_fkind[0];
+    uint32_t f[P2_QA * 4];
+    if (V.col_kind == PG_COL_FIXED_BIT) {
+      const uint32_t bits = (uint32_t)V.bits, mask = (1u << V.bits) - 1u;
+#pragma unroll
+      for (int u = 0; u < P2_QA; u++) {
+        uint32_t v[4];
+        if (bits <= 8) p2_dec2((u32x2){raw.s0[u].x, raw.s0[u].y}, qi[u], bits, mask, v);
+        else p2_dec4(raw.s0[u], qi[u], bits, mask, v);
+#pragma unroll
+        for (int i = 0; i < 4; i++) f[4 * u + i] = v[i];
+      }
+      if (kind == PG_P2_F_HLL) {
+        const int log2m = p.pk_hll[0];
+        if (p.pk_affine[0] == 2) {   // INT dictionary, value = base + step x dictId with a 24-bit step: 32-bit arithmetic, 4 multiplies
+          const uint32_t b32 = (uint32_t)p.pk_base[0], s32 = (uint32_t)p.pk_step[0];
+#pragma unroll
+          for (int j = 0; j < P2_QA * 4; j++)
+            f[j] = packed_hll_payload(hll_index_rank_dev(p2_murmur_int((int32_t)(b32 + __umul24(s32, f[j]))), log2m), log2m);
+        } else if (p.pk_affine[0]) {
+#pragma unroll
+          for (int j = 0; j < P2_QA * 4; j++)
+            f[j] = packed_hll_payload(hll_index_rank_dev(murmur_hash_long_dev(p.pk_base[0] + p.pk_step[0] * (int64_t)f[j]), log2m), log2m);
+        } else {   // gathers first (all in flight), payloads after
+          uint32_t ir[P2_QA * 4];
+#pragma unroll
+          for (int j = 0; j < P2_QA * 4; j++) ir[j] = gptr<uint32_t>(p.pk_lut[0])[f[j]];
+#pragma unroll
+          for (int j = 0; j < P2_QA * 4; j++) f[j] = packed_hll_payload(ir[j], log2m);
+        }
+      }
+    } else {   // raw 32-bit values
+#pragma unroll
+      for (int u = 0; u < P2_QA; u++) {
+        f[4 * u] = bswap32(raw.s0[u].x); f[4 * u + 1] = bswap32(raw.s0[u].y); f[4 * u + 2] = bswap32(raw.s0[u].z); f[4 * u + 3] = bswap32(raw.s0[u].w);
+      }
+      if (kind == PG_P2_F_HLL) {
+        const int log2m = p.pk_hll[0];
+#pragma unroll
+        for (int j = 0; j < P2_QA * 4; j++)
+          f[j] = packed_hll_payload(hll_index_rank_dev(p2_murmur_int((int32_t)f[j]), log2m), log2m);
+      } else if (V.val_type == PG_V_I32) {
+        const uint32_t bias = (uint32_t)p.p2_fbias[0];
+#pragma unroll
+        for (int j = 0; j < P2_QA * 4; j++) f[j] -= bias;
+      }
+    }
+    const int fpl = p.p2_fplane[0];
+    const uint32_t sh = (uint32_t)p.pk_shift[0];
+#pragma unroll
+    for (int pl = 0; pl < T; pl++)
+      if (pl == fpl) {
+#pragma unroll
+        for (int j = 0; j < P2_QA * 4; j++) d[pl][j] |= f[j] << sh;
+      }
+  }
+}
+// generic (any plan the pipeline takes): the runtime-loop key / field functions
+template <int T>
+DEVFN void p2_decode_generic(const PgQueryPlan& p, const uint32_t (&qi)[P2_QA], int wt, uint32_t local_mask, uint32_t (&key)[P2_QA * 4],
+                             uint32_t (&d)[T][P2_QA * 4]) {
+  uint32_t k2[P2_QA][4];
+  radix_keys_of<P2_QA>(p, qi, wt, k2);
+#pragma unroll
+  for (int u = 0; u < P2_QA; u++)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      key[4 * u + i] = k2[u][i];
+      d[0][4 * u + i] = k2[u][i] & local_mask;
+#pragma unroll
+      for (int pl = 1; pl < T; pl++) d[pl][4 * u + i] = 0;
+    }
+  for (int si = 0; si < p.n_srcs; si++) {
+    uint32_t f[P2_QA][4], fh[P2_QA][4];
+    p2_field<P2_QA, (T > 1)>(p, si, qi, wt, f, fh);
+    const int fpl = p.p2_fplane[si];
+    const uint32_t sh = (uint32_t)p.pk_shift[si];
+    const bool wide = T > 1 && p.p2_fkind[si] == PG_P2_F_RAW64;
+#pragma unroll
+    for (int pl = 0; pl < T; pl++) {
+      if (pl == fpl) {
+#pragma unroll
+        for (int u = 0; u < P2_QA; u++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) d[pl][4 * u + i] |= f[u][i] << sh;
+      }
+      if (wide && pl == fpl + 1) {
+#pragma unroll
+        for (int u = 0; u < P2_QA; u++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) d[pl][4 * u + i] = fh[u][i];
+      }
+    }
+  }
+}
+
+// LDS of a scatter workgroup (dwords): hist, off, cnt, lo_cnt, cur, left [NBp each] | pool [PG_P2_POOL] | ctrl [8] |
+// lines [R / 32 + NB + 1][2] | sorted [T][R] | lo [T][NB][32]
+struct P2Stage {
+  uint32_t *hist, *off, *cnt, *lo_cnt, *cur, *left, *pool, *ctrl, *lines, *sorted, *lo;
+  uint32_t nbp;
+};
+
+// quad-layout match mask of wavefront `wave`'s tile of quartet g (0 beyond the segment)
+DEVFN uint32_t p2_tile_mask(const PgQueryPlan& p, int g, int n_quartets, int wave, int lane) {
+  const int wt_raw = g * PG_P2_WAVES + wave;
+  if (g >= n_quartets || wt_raw >= p.n_wtiles) return 0u;   // wave-uniform
+  const int64_t rem = (int64_t)p.num_docs - (int64_t)wt_raw * PG_WAVE_DOCS;
+  const int32_t n_valid = rem >= PG_WAVE_DOCS ? PG_WAVE_DOCS : (int32_t)rem;
+  if (p.match_words) return lin_to_quad(gptr<uint32_t>(p.match_words)[(int64_t)wt_raw * 64 + lane] & valid_lin_mask(n_valid, lane), lane);
+  return valid_quad_mask(n_valid, lane);
+}
+DEVFN int p2_tile_of(const PgQueryPlan& p, int g, int wave) {   // the tile whose columns the wavefront reads (clamped: loads stay in bounds)
+  const int wt_raw = g * PG_P2_WAVES + wave;
+  return wt_raw < p.n_wtiles ? wt_raw : p.n_wtiles - 1;
+}
+// mb8: a batch's 8 mask bits; kq: its first quad slot.  Quads without a matching doc re-read quad 0 (a line the tile needs anyway).
+DEVFN void p2_quads_of(int lane, uint32_t mb8, int kq, uint32_t (&qi)[P2_QA]) {
+#pragma unroll
+  for (int u = 0; u < P2_QA; u++) qi[u] = ((mb8 >> (4 * u)) & 0xFu) ? (uint32_t)((kq + u) * 64 + lane) : 0u;
+}
+
+template <int T, int Q, bool FAST, int SRC>
+__device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
+  constexpr int NBATCH = Q / P2_QA;               // quads per lane and round: Q, decoded in batches of P2_QA
+  constexpr uint32_t R = PG_P2_WAVES * Q * 256;   // tuples per round
+  constexpr uint32_t CH = PG_P2_CHUNK;
+  const int t = threadIdx.x, lane = t & 63, wave = uniform(t >> 6);
+  const int NB = p.radix_buckets;
+  P2Stage S;
+  S.nbp = (uint32_t)((NB + 63) & ~63);   // buckets the bookkeeping wavefront visits
+  constexpr uint32_t NBA = PG_P2_MAX_BUCKETS;   // array stride: compile-time, so that the array bases are constants, not SGPRs
+  uint32_t* base = reinterpret_cast<uint32_t*>(smem);
+  S.hist = base; S.off = S.hist + NBA; S.cnt = S.off + NBA; S.lo_cnt = S.cnt + NBA; S.cur = S.lo_cnt + NBA; S.left = S.cur + NBA;
+  S.pool = S.left + NBA; S.ctrl = S.pool + PG_P2_POOL; S.lines = S.ctrl + 8; S.sorted = S.lines + 2u * (R / PG_P2_LINE + (uint32_t)NB + 1u); S.lo = S.sorted + (size_t)T * R;
+  for (uint32_t i = (uint32_t)t; i < 6u * NBA; i += P2_THREADS) base[i] = 0;
+  if (t < 8) S.ctrl[t] = 0;
+  // MatchAllFilterOperator: no filter pass ran in front — every doc matches (ExecutionStatistics.numDocsScanned)
+  if (!p.match_words && blockIdx.x == 0 && t == 0) atomicAdd(p.stats, (unsigned long long)p.num_docs);
+  __syncthreads();
+  const uint32_t local_mask = (1u << p.radix_shift) - 1u;
+  const size_t lo_plane = (size_t)NB * PG_P2_LINE;
+  uint32_t* const tuples = p.p2_tuples;
+  const int n_quartets = (p.n_wtiles + PG_P2_WAVES - 1) / PG_P2_WAVES;
+  // round sequence of this workgroup: (quartet g, quad slots k0 .. k0 + Q - 1), g = blockIdx.x, blockIdx.x + gridDim.x, ...
+  int g = (int)blockIdx.x;
+  uint32_t m = p2_tile_mask(p, g, n_quartets, wave, lane);
+  int k0 = 0;
+  P2Raw raw;   // the loads of the round's first batch, requested one round ahead
+  if (FAST) {
+    uint32_t qi[P2_QA];
+    p2_quads_of(lane, m & 0xFFu, 0, qi);
+    p2_issue(p, qi, p2_tile_of(p, g, wave), raw);
+  }
+  while (g < n_quartets) {   // workgroup-uniform
+    const int wt = p2_tile_of(p, g, wave);
+    const uint32_t mb = (m >> (4 * k0)) & (Q == 8 ? 0xFFFFFFFFu : ((1u << (4 * (Q & 7))) - 1u));
+    uint32_t d[T][Q * 4];
+    uint32_t br[Q * 4];
+    // ---- A: tuples of this wavefront's Q quads per lane; histogram + rank in one returning LDS add ---------------------------------
+#pragma unroll
+    for (int h = 0; h < NBATCH; h++) {
+      uint32_t qi[P2_QA];
+      p2_quads_of(lane, (mb >> (h * P2_QA * 4)) & 0xFFu, k0 + h * P2_QA, qi);
+      uint32_t key[P2_QA * 4], dd[T][P2_QA * 4];
+      if (FAST) {
+        if (h > 0) p2_issue(p, qi, wt, raw);
+        p2_decode<T, SRC>(p, raw, qi, local_mask, key, dd);
+      } else {
+        p2_decode_generic<T>(p, qi, wt, local_mask, key, dd);
+      }
+      if (T > 1 && p.p2_docid_plane >= 0) {
+#pragma unroll
+        for (int pl = 1; pl < T; pl++)
+          if (pl == p.p2_docid_plane) {
+#pragma unroll
+            for (int j = 0; j < P2_QA * 4; j++)
+              dd[pl][j] = (uint32_t)wt * PG_WAVE_DOCS + 4u * (uint32_t)((k0 + h * P2_QA + (j >> 2)) * 64 + lane) + (uint32_t)(j & 3);
+          }
+      }
+#pragma unroll
+      for (int j = 0; j < P2_QA * 4; j++) {
+#pragma unroll
+        for (int pl = 0; pl < T; pl++) d[pl][h * P2_QA * 4 + j] = dd[pl][j];
+        const uint32_t b = key[j] >> p.radix_shift;
+        br[h * P2_QA * 4 + j] = 0xFFFFFFFFu;
+        if ((mb >> (h * P2_QA * 4 + j)) & 1u) br[h * P2_QA * 4 + j] = (b << 16) | atomicAdd(&S.hist[b], 1u);
+      }
+    }
+    // next round: its mask, and (FAST) the loads of its first batch — in flight across the phases below
+    int g_next = g, k0_next = k0 + Q;
+    uint32_t m_next = m;
+    if (k0_next >= 8) { k0_next = 0; g_next = g + (int)gridDim.x; m_next = p2_tile_mask(p, g_next, n_quartets, wave, lane); }
+    if (FAST) {
+      uint32_t qi[P2_QA];
+      p2_quads_of(lane, (m_next >> (4 * k0_next)) & 0xFFu, k0_next, qi);
+      p2_issue(p, qi, p2_tile_of(p, g_next, wave), raw);
+    }
+    __syncthreads();
+    // ---- B: wavefront 0: histogram → offsets; the round's whole lines with their sources and destinations; chunk ids ------------------
+    if (wave == 0) {
+      uint32_t carry = 0, need = 0;
+      for (uint32_t v = 0; v < S.nbp; v += 64u) {
+        const uint32_t b = v + (uint32_t)lane;
+        const uint32_t n = S.hist[b];
+        const uint32_t x = p2_wave_scan(n);
+        S.off[b] = carry + x - n;
+        S.cnt[b] = n;
+        S.hist[b] = 0;
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+        const uint32_t out = (S.lo_cnt[b] + n) & ~(PG_P2_LINE - 1u), lf = S.left[b];
+        if (out > lf) need += (out - lf + CH - 1u) / CH;
+      }
+      need = (uint32_t)__builtin_amdgcn_readlane((int)p2_wave_scan(need), 63);
+      {   // the ring holds the chunk ids this round can take
+        const uint32_t head = S.ctrl[0];
+        uint32_t tail = S.ctrl[1];
+        if (need > PG_P2_POOL - PG_P2_BATCH) need = PG_P2_POOL - PG_P2_BATCH;   // at most R / CHUNK + buckets (272)
+        while (tail - head < need) {   // wave-uniform
+          uint32_t basec = 0;
+          if (lane == 0) basec = atomicAdd(p.p2_ctrl, (uint32_t)PG_P2_BATCH);
+          basec = (uint32_t)__builtin_amdgcn_readfirstlane((int)basec);
+          for (uint32_t i = (uint32_t)lane; i < PG_P2_BATCH; i += 64u) S.pool[(tail + i) & (PG_P2_POOL - 1u)] = basec + i;
+          tail += PG_P2_BATCH;
+        }
+        if (lane == 0) S.ctrl[1] = tail;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      uint32_t line_carry = 0;
+      for (uint32_t v = 0; v < S.nbp; v += 64u) {
+        const uint32_t b = v + (uint32_t)lane;
+        const uint32_t n = S.cnt[b], lo_n = S.lo_cnt[b], o = S.off[b];
+        const uint32_t n_lines = (lo_n + n) >> 5;
+        const uint32_t x = p2_wave_scan(n_lines);
+        const uint32_t at = line_carry + x - n_lines;
+        line_carry += (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+        uint32_t c = S.cur[b], l = S.left[b];
+        for (uint32_t i = 0; i < n_lines; i++) {   // per lane: 0..2 lines unless the keys are skewed
+          if (l == 0) {   // next chunk of the stream, recorded as full (the epilogue rewrites a stream's last record)
+            uint32_t id = S.pool[atomicAdd(&S.ctrl[0], 1u) & (PG_P2_POOL - 1u)];
+            if (id >= (uint32_t)p.p2_capacity) { p.p2_ctrl[1] = 1u; id = (uint32_t)p.p2_capacity; }   // spill chunk + error flag
+            else p.p2_meta[id] = b | ((uint32_t)(CH / PG_P2_LINE) << 16);
+            c = id * CH;
+            l = CH;
+          }
+          // line i of the bucket's run: destination | (run start in `sorted` (13 bits), bucket (8), line (8))
+          *reinterpret_cast<u32x2*>(S.lines + 2u * (at + i)) = (u32x2){c, o | (b << 13) | (i << 21)};
+          c += PG_P2_LINE; l -= PG_P2_LINE;
+        }
+        if (n_lines) { S.cur[b] = c; S.left[b] = l; }
+      }
+      if (lane == 0) S.ctrl[2] = line_carry;
+    }
+    __syncthreads();
+    // ---- C: tuples to their sorted positions (offsets first, all in flight; then the stores) --------------------------------------------
+    {
+      uint32_t pos[Q * 4];
+#pragma unroll
+      for (int j = 0; j < Q * 4; j++) pos[j] = S.off[br[j] == 0xFFFFFFFFu ? 0u : (br[j] >> 16)];
+#pragma unroll
+      for (int j = 0; j < Q * 4; j++)
+        if (br[j] != 0xFFFFFFFFu) {
+#pragma unroll
+          for (int pl = 0; pl < T; pl++) S.sorted[(size_t)pl * R + pos[j] + (br[j] & 0xFFFFu)] = d[pl][j];
+        }
+    }
+    __syncthreads();
+    // ---- D1: whole lines out: a half wavefront per line (32 tuples = 128 bytes per plane), four lines per step ----------------------------
+    {
+      const uint32_t n_lines = S.ctrl[2];
+      const uint32_t li = (uint32_t)lane & 31u, hw = (uint32_t)(wave * 2 + (lane >> 5));
+      constexpr uint32_t NH = PG_P2_WAVES * 2u;
+      for (uint32_t e0 = hw; e0 < n_lines; e0 += 4u * NH) {
+        u32x2 e[4];
+        uint32_t lo_n[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t ei = e0 + (uint32_t)k * NH;
+          e[k] = *reinterpret_cast<const u32x2*>(S.lines + 2u * (ei < n_lines ? ei : e0));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) lo_n[k] = S.lo_cnt[(e[k].y >> 13) & 0xFFu];
+        uint32_t x[4][T];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t o = e[k].y & 0x1FFFu, b = (e[k].y >> 13) & 0xFFu, v = (e[k].y >> 21) * PG_P2_LINE + li;
+#pragma unroll
+          for (int pl = 0; pl < T; pl++)
+            x[k][pl] = v < lo_n[k] ? S.lo[(size_t)pl * lo_plane + (size_t)b * PG_P2_LINE + v] : S.sorted[(size_t)pl * R + o + v - lo_n[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (e0 + (uint32_t)k * NH < n_lines) {
+#pragma unroll
+            for (int pl = 0; pl < T; pl++) tuples[(size_t)pl * (size_t)p.p2_plane_stride + e[k].x + li] = x[k][pl];
+          }
+      }
+    }
+    __syncthreads();
+    // ---- D2: what did not fill a line is the bucket's leftover for the next round (a half wavefront per bucket, four per step) -----------
+    {
+      const uint32_t li = (uint32_t)lane & 31u, hw = (uint32_t)(wave * 2 + (lane >> 5));
+      constexpr uint32_t NH = PG_P2_WAVES * 2u;
+      for (uint32_t b0 = hw; b0 < (uint32_t)NB; b0 += 4u * NH) {
+        uint32_t n[4], lo_n[4], o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t b = b0 + (uint32_t)k * NH;
+          const bool on = b < (uint32_t)NB;
+          n[k] = on ? S.cnt[b] : 0u;
+          lo_n[k] = on ? S.lo_cnt[b] : 0u;
+          o[k] = on ? S.off[b] : 0u;
+        }
+        uint32_t x[4][T];
+        uint32_t at[4];
+        bool st[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t total = lo_n[k] + n[k], out = total & ~(PG_P2_LINE - 1u), rem = total & (PG_P2_LINE - 1u);
+          // out == 0: the new tuples join the leftover; else the run's tail (all new tuples: out >= 32 > lo_n) is the next leftover
+          st[k] = n[k] != 0 && (out == 0 ? li < n[k] : li < rem);
+          const uint32_t src = out == 0 ? o[k] + li : o[k] + out + li - lo_n[k];
+          at[k] = out == 0 ? lo_n[k] + li : li;
+#pragma unroll
+          for (int pl = 0; pl < T; pl++) x[k][pl] = S.sorted[(size_t)pl * R + (st[k] ? src : 0u)];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t b = b0 + (uint32_t)k * NH;
+          if (st[k]) {
+#pragma unroll
+            for (int pl = 0; pl < T; pl++) S.lo[(size_t)pl * lo_plane + (size_t)b * PG_P2_LINE + at[k]] = x[k][pl];
+          }
+          if (li == 0 && n[k] != 0) S.lo_cnt[b] = (lo_n[k] + n[k]) & (PG_P2_LINE - 1u);
+        }
+      }
+    }
+    // no barrier here: the next round's phase A touches only `hist` (reset in B); its barrier orders D2 before the next B
+    g = g_next; k0 = k0_next; m = m_next;
+  }
+  // ---- epilogue: leftover lines padded with PG_RADIX_INVALID_KEY, the last chunk of every stream recorded with its true fill --------
+  __syncthreads();
+  if (wave == 0) {
+    const uint32_t head = S.ctrl[0];
+    uint32_t tail = S.ctrl[1];
+    while (tail - head < (uint32_t)NB) {
+      uint32_t basec = 0;
+      if (lane == 0) basec = atomicAdd(p.p2_ctrl, (uint32_t)PG_P2_BATCH);
+      basec = (uint32_t)__builtin_amdgcn_readfirstlane((int)basec);
+      for (uint32_t i = (uint32_t)lane; i < PG_P2_BATCH; i += 64u) S.pool[(tail + i) & (PG_P2_POOL - 1u)] = basec + i;
+      tail += PG_P2_BATCH;
+    }
+    if (lane == 0) S.ctrl[1] = tail;
+  }
+  __syncthreads();
+  for (uint32_t b = (uint32_t)(wave * 2 + (lane >> 5)); b < (uint32_t)NB; b += PG_P2_WAVES * 2u) {   // a half wavefront per bucket
+    const uint32_t lo_n = S.lo_cnt[b], li = (uint32_t)lane & 31u;
+    uint32_t c = S.cur[b], l = S.left[b];
+    if (lo_n > 0) {
+      if (l == 0) {
+        uint32_t id = 0;
+        if (li == 0) {
+          id = S.pool[atomicAdd(&S.ctrl[0], 1u) & (PG_P2_POOL - 1u)];
+          if (id >= (uint32_t)p.p2_capacity) { p.p2_ctrl[1] = 1u; id = (uint32_t)p.p2_capacity; }
+        }
+        id = (uint32_t)__shfl((int)id, lane & 32, 64);
+        c = id * CH;
+        l = CH;
+      }
+      const uint32_t* lob = S.lo + (size_t)b * PG_P2_LINE;
+#pragma unroll
+      for (int pl = 0; pl < T; pl++) {
+        const uint32_t x = li < lo_n ? lob[(size_t)pl * lo_plane + li] : (pl == 0 ? PG_RADIX_INVALID_KEY : 0u);
+        tuples[(size_t)pl * (size_t)p.p2_plane_stride + c + li] = x;
+      }
+      c += PG_P2_LINE; l -= PG_P2_LINE;
+    }
+    if (li == 0 && c != 0 && (l > 0 || lo_n > 0)) {   // the stream's last chunk: its true fill (a chunk the main loop filled exactly keeps "full")
+      const uint32_t id = (c - 1u) / CH;
+      if (id < (uint32_t)p.p2_capacity) p.p2_meta[id] = b | (((CH - l) / PG_P2_LINE) << 16);
+    }
+  }
+}
+
+#define P2_SCATTER(NAME, T, Q, FAST, SRC) \
+  extern "C" __global__ void __launch_bounds__(P2_THREADS, 4) NAME(const PgQueryPlan p) { p2_scatter_body<T, Q, FAST, SRC>(p); }
+P2_SCATTER(pg_p2_scatter_1, 1, 4, false, 2)
+P2_SCATTER(pg_p2_scatter_2, 2, 4, false, 2)
+P2_SCATTER(pg_p2_scatter_3, 3, 2, false, 2)
+P2_SCATTER(pg_p2_scatter_4, 4, 2, false, 2)
+P2_SCATTER(pg_p2_scatter_1f, 1, 4, true, 2)
+P2_SCATTER(pg_p2_scatter_2f, 2, 4, true, 2)
+P2_SCATTER(pg_p2_scatter_1f_key, 1, 4, true, 0)   // key only (COUNT over a big key space)
+P2_SCATTER(pg_p2_scatter_1f_hll, 1, 4, true, 1)   // config 5
+extern "C" const int pg_p2_round_quads[5] = {0, 4, 4, 2, 2};   // Q per plane count (the host sizes the LDS with it)
+
+// ---- chunk index: the chunk records grouped by bucket (counting sort of p2_meta), three small launches ------------------------------
+extern "C" __global__ void __launch_bounds__(1024) pg_p2_index_count_kernel(const PgQueryPlan p) {
+  __shared__ uint32_t s_hist[PG_P2_MAX_BUCKETS];
+  const int t = threadIdx.x;
+  if (t < PG_P2_MAX_BUCKETS) s_hist[t] = 0;
+  __syncthreads();
+  uint32_t n_alloc = p.p2_ctrl[0];
+  if (n_alloc > (uint32_t)p.p2_capacity) n_alloc = (uint32_t)p.p2_capacity;
+  for (uint32_t i = blockIdx.x * 1024u + (uint32_t)t; i < n_alloc; i += gridDim.x * 1024u) {
+    const uint32_t mt = p.p2_meta[i];
+    if ((mt & 0xFFFFu) < (uint32_t)p.radix_buckets && (mt >> 16) != 0) atomicAdd(&s_hist[mt & 0xFFFFu], 1u);
+  }
+  __syncthreads();
+  if (t < p.radix_buckets && s_hist[t]) atomicAdd(&p.p2_ctrl[PG_P2_CTRL_COUNTS + t], s_hist[t]);
+}
+extern "C" __global__ void __launch_bounds__(PG_P2_MAX_BUCKETS) pg_p2_index_scan_kernel(const PgQueryPlan p) {
+  __shared__ uint32_t s_c[PG_P2_MAX_BUCKETS];
+  const int t = threadIdx.x;
+  s_c[t] = t < p.radix_buckets ? p.p2_ctrl[PG_P2_CTRL_COUNTS + t] : 0u;
+  __syncthreads();
+  if (t == 0) {
+    uint32_t run = 0;
+    for (int b = 0; b < p.radix_buckets; b++) {
+      p.p2_ctrl[PG_P2_CTRL_STARTS + b] = run;
+      p.p2_ctrl[PG_P2_CTRL_CURSOR + b] = run;
+      run += s_c[b];
+    }
+    p.p2_ctrl[PG_P2_CTRL_STARTS + p.radix_buckets] = run;
+  }
+}
+extern "C" __global__ void __launch_bounds__(1024) pg_p2_index_fill_kernel(const PgQueryPlan p) {
+  __shared__ uint32_t s_hist[PG_P2_MAX_BUCKETS], s_base[PG_P2_MAX_BUCKETS];
+  const int t = threadIdx.x;
+  uint32_t n_alloc = p.p2_ctrl[0];
+  if (n_alloc > (uint32_t)p.p2_capacity) n_alloc = (uint32_t)p.p2_capacity;
+  // the workgroup's share of the records is a contiguous range: count, claim one range per bucket, then place
+  const uint32_t per = (n_alloc + gridDim.x - 1u) / gridDim.x;
+  const uint32_t lo = blockIdx.x * per;
+  uint32_t hi = lo + per;
+  if (hi > n_alloc) hi = n_alloc;
+  if (t < PG_P2_MAX_BUCKETS) s_hist[t] = 0;
+  __syncthreads();
+  for (uint32_t i = lo + (uint32_t)t; i < hi; i += 1024u) {
+    const uint32_t mt = p.p2_meta[i];
+    if ((mt & 0xFFFFu) < (uint32_t)p.radix_buckets && (mt >> 16) != 0) atomicAdd(&s_hist[mt & 0xFFFFu], 1u);
+  }
+  __syncthreads();
+  if (t < p.radix_buckets) {
+    s_base[t] = s_hist[t] ? atomicAdd(&p.p2_ctrl[PG_P2_CTRL_CURSOR + t], s_hist[t]) : 0u;
+    s_hist[t] = 0;
+  }
+  __syncthreads();
+  for (uint32_t i = lo + (uint32_t)t; i < hi; i += 1024u) {
+    const uint32_t mt = p.p2_meta[i];
+    const uint32_t b = mt & 0xFFFFu;
+    if (b < (uint32_t)p.radix_buckets && (mt >> 16) != 0) p.p2_list[s_base[b] + atomicAdd(&s_hist[b], 1u)] = i | ((mt >> 16) << 27);
+  }
+}
+
+// ---- aggregation pass ------------------------------------------------------------------------------------------------------------
+// work item w = bucket * slices + slice aggregates its share of the bucket's chunk list: windows of PG_P2_LIST records are copied into
+// LDS, one wavefront per chunk (4 tuples per lane and plane), the loads of the wavefront's next two chunks in flight meanwhile.
+template <int T>
+DEVFN uint32_t p2_pick(const u32x4 (&v)[T], int pl, int e) {
+  uint32_t x = 0;
+#pragma unroll
+  for (int q = 0; q < T; q++) {
+    const uint32_t y = e == 0 ? v[q].x : (e == 1 ? v[q].y : (e == 2 ? v[q].z : v[q].w));
+    if (q == pl) x = y;
+  }
+  return x;
+}
+
+template <int T>
+DEVFN void p2_fetch(const GAS uint32_t* tuples, size_t plane_stride, const uint32_t* list, uint32_t n_list, uint32_t ci, int lane, u32x4 (&v)[T]) {
+  const u32x4 inv = {PG_RADIX_INVALID_KEY, PG_RADIX_INVALID_KEY, PG_RADIX_INVALID_KEY, PG_RADIX_INVALID_KEY};
+  if (ci >= n_list) {   // wave-uniform
+#pragma unroll
+    for (int pl = 0; pl < T; pl++) v[pl] = inv;
+    return;
+  }
+  const uint32_t e = list[ci];
+  const size_t at = (size_t)(e & 0x7FFFFFFu) * PG_P2_CHUNK + (size_t)lane * 4u;
+  const bool on = (uint32_t)(lane >> 3) < (e >> 27);
+#pragma unroll
+  for (int pl = 0; pl < T; pl++) v[pl] = on ? ldnt((const GAS u32x4*)(tuples + (size_t)pl * plane_stride + at)) : inv;
+}
+template <int T>
+DEVFN void p2_consume(const PgQueryPlan& p, const u32x4 (&cur)[T], int64_t* table, uint32_t* aux_lds, uint32_t slots, uint32_t local_mask) {
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const uint32_t d0 = p2_pick<T>(cur, 0, e);
+    if (d0 == PG_RADIX_INVALID_KEY) continue;
+    const uint32_t k = d0 & local_mask;
+    for (int o = 0; o < p.n_ops; o++) {
+      const PgAccOp op = p.ops[o];
+      int64_t* acc = table + (size_t)o * slots + k;
+      if (op.src < 0) {
+        if (op.fn == PG_ACC_COUNT) atomicAdd(reinterpret_cast<unsigned long long*>(acc), 1ULL);
+        else atomicMin(reinterpret_cast<long long*>(acc), (long long)p2_pick<T>(cur, p.p2_docid_plane, e));   // MIN(docId)
+        continue;
+      }
+      const PgValueSrc& V = p.srcs[op.src];
+      const int kind = p.p2_fkind[op.src], fpl = p.p2_fplane[op.src];
+      const uint32_t bits = (uint32_t)p.pk_bits[op.src];
+      uint32_t f = p2_pick<T>(cur, fpl, e) >> p.pk_shift[op.src];
+      if (bits < 32u) f &= (1u << bits) - 1u;
+      if (kind == PG_P2_F_DICTID) {
+        if (V.val_type == PG_V_I32) acc_from_int(acc, op, (int64_t)(int32_t)gptr<uint32_t>(V.dict)[f]);
+        else if (V.val_type == PG_V_I64) acc_from_int(acc, op, (int64_t)gptr<uint64_t>(V.dict)[f]);
+        else if (V.val_type == PG_V_F32) acc_from_double(acc, op, (double)__uint_as_float(gptr<uint32_t>(V.dict)[f]), V.fx_q);
+        else acc_from_double(acc, op, __longlong_as_double((int64_t)gptr<uint64_t>(V.dict)[f]), V.fx_q);
+      } else if (kind == PG_P2_F_RAW32) {
+        if (V.val_type == PG_V_I32) acc_from_int(acc, op, (int64_t)(int32_t)(f + (uint32_t)p.p2_fbias[op.src]));
+        else acc_from_double(acc, op, (double)__uint_as_float(f), V.fx_q);
+      } else {   // PG_P2_F_RAW64
+        const uint64_t v64 = ((uint64_t)p2_pick<T>(cur, fpl + 1, e) << 32) | (uint64_t)f;
+        if (V.val_type == PG_V_I64) acc_from_int(acc, op, (int64_t)v64);
+        else acc_from_double(acc, op, __longlong_as_double((int64_t)v64), V.fx_q);
+      }
+    }
+    uint32_t aux_off = 0;
+    for (int x = 0; x < p.n_aux; x++) {
+      const PgAuxOp& A = p.aux[x];
+      uint32_t f = p2_pick<T>(cur, p.p2_fplane[A.src], e) >> p.pk_shift[A.src];
+      f &= (1u << p.pk_bits[A.src]) - 1u;
+      atomicMax(&aux_lds[aux_off + (k << A.log2m) + (f & ((1u << A.log2m) - 1u))], f >> A.log2m);
+      aux_off += slots << A.log2m;
+    }
+  }
+}
+
+template <int T>
+__device__ __forceinline__ void p2_aggregate_body(const PgQueryPlan& p) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
+  int64_t* table = reinterpret_cast<int64_t*>(smem);
+  const int t = threadIdx.x, lane = t & 63, wave = uniform(t >> 6);
+  constexpr uint32_t WAVES = PG_P2_AGG_THREADS / 64;
+  const uint32_t slots = 1u << p.radix_shift, local_mask = slots - 1u;
+  uint32_t* const aux_lds = reinterpret_cast<uint32_t*>(table + (size_t)p.n_ops * slots);
+  uint32_t aux_dwords = 0;
+  for (int x = 0; x < p.n_aux; x++) aux_dwords += slots << p.aux[x].log2m;
+  uint32_t* const list = aux_lds + aux_dwords;
+  const int n_items = p.radix_buckets * p.radix_slices;
+  const GAS uint32_t* const tuples = gptr<uint32_t>(p.p2_tuples);
+  const size_t plane_stride = (size_t)p.p2_plane_stride;
+  for (int w = (int)blockIdx.x; w < n_items; w += (int)gridDim.x) {
+    const uint32_t b = (uint32_t)(w / p.radix_slices), sl = (uint32_t)(w % p.radix_slices);
+    for (int o = 0; o < p.n_ops; o++) {
+      const int64_t ident = pg_acc_identity(p.ops[o].fn, p.ops[o].is_float);
+      for (uint32_t i = (uint32_t)t; i < slots; i += PG_P2_AGG_THREADS) table[(size_t)o * slots + i] = ident;
+    }
+    for (uint32_t i = (uint32_t)t; i < aux_dwords; i += PG_P2_AGG_THREADS) aux_lds[i] = 0u;
+    const uint32_t bstart = gptr<uint32_t>(p.p2_ctrl)[PG_P2_CTRL_STARTS + b], bend = gptr<uint32_t>(p.p2_ctrl)[PG_P2_CTRL_STARTS + b + 1];
+    const uint32_t per = (bend - bstart + (uint32_t)p.radix_slices - 1u) / (uint32_t)p.radix_slices;
+    const uint32_t lo_i = bstart + sl * per;
+    uint32_t hi_i = lo_i + per;
+    if (hi_i > bend) hi_i = bend;
+    for (uint32_t win = lo_i; win < hi_i; win += PG_P2_LIST) {
+      __syncthreads();   // the table is initialised / the previous window's list is done with
+      const uint32_t n_list = hi_i - win < PG_P2_LIST ? hi_i - win : PG_P2_LIST;
+      for (uint32_t i = (uint32_t)t; i < n_list; i += PG_P2_AGG_THREADS) list[i] = gptr<uint32_t>(p.p2_list)[win + i];
+      __syncthreads();
+      // three chunks per wavefront in flight (loads return in order: consuming c0 leaves c1 / c2 travelling); ONE call site of the
+      // consumer — three copies of it made the compiler keep the plan in scratch (1 848 bytes per lane)
+      u32x4 c0[T], c1[T], c2[T];
+      p2_fetch<T>(tuples, plane_stride, list, n_list, (uint32_t)wave, lane, c0);
+      p2_fetch<T>(tuples, plane_stride, list, n_list, (uint32_t)wave + WAVES, lane, c1);
+      for (uint32_t ci = (uint32_t)wave; ci < n_list; ci += WAVES) {
+        p2_fetch<T>(tuples, plane_stride, list, n_list, ci + 2u * WAVES, lane, c2);
+        p2_consume<T>(p, c0, table, aux_lds, slots, local_mask);
+#pragma unroll
+        for (int pl = 0; pl < T; pl++) { c0[pl] = c1[pl]; c1[pl] = c2[pl]; }
+      }
+    }
+    __syncthreads();
+    int64_t* out = p.partials + (int64_t)w * p.n_ops * slots;
+    for (int64_t i = t; i < (int64_t)p.n_ops * slots; i += PG_P2_AGG_THREADS) out[i] = table[i];
+    {
+      uint32_t aux_off = 0;
+      for (int x = 0; x < p.n_aux; x++) {   // registers leave as bytes: [slots][2^log2m], merged bytewise by pg_radix_reduce_aux_kernel
+        const uint32_t n_words = (slots << p.aux[x].log2m) >> 2;
+        const uint32_t* src = aux_lds + aux_off;
+        uint32_t* dst = p.aux[x].base + (int64_t)w * n_words;
+        for (uint32_t i = (uint32_t)t; i < n_words; i += PG_P2_AGG_THREADS)
+          dst[i] = src[4 * i] | (src[4 * i + 1] << 8) | (src[4 * i + 2] << 16) | (src[4 * i + 3] << 24);
+        aux_off += slots << p.aux[x].log2m;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+#define P2_AGGREGATE(NAME, T) \
+  extern "C" __global__ void __launch_bounds__(PG_P2_AGG_THREADS) NAME(const PgQueryPlan p) { p2_aggregate_body<T>(p); }
+P2_AGGREGATE(pg_p2_aggregate_1, 1)
+P2_AGGREGATE(pg_p2_aggregate_2, 2)
+P2_AGGREGATE(pg_p2_aggregate_3, 3)
+P2_AGGREGATE(pg_p2_aggregate_4, 4)

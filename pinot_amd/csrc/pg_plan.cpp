@@ -928,6 +928,152 @@ static OpPtr clone_leaf(const FilterOp& op) {
   return c;
 }
 
+// Partition pipeline v2 (pg_kernels_part.hip) for a PG_AGG_RADIX plan: bit-packs what the aggregation pass needs from a doc into
+// 1..4 dwords and chooses the bucket width.  Per group the aggregation workgroup keeps n_ops int64 accumulators and one DWORD per
+// HyperLogLog register in LDS (a single ds_max_u32 per offer); radix_shift is the largest width whose table fits — lowered (more
+// buckets, up to PG_P2_MAX_BUCKETS) when that lets a tuple fit ONE dword, which halves the bytes written and read back.
+// Returns false when the shape is outside the pipeline (the round-2 radix passes then run).
+static bool plan_partition_v2(CompiledPlan& P, PgQueryPlan& D, const std::vector<Column*>& srcs, const std::vector<PgAccOp>& ops, int64_t G) {
+  if (getenv("PG_NO_P2")) return false;
+  if ((int)srcs.size() > PG_MAX_RADIX_SRCS) return false;
+  int64_t per_group = (int64_t)ops.size() * 8;
+  for (int x = 0; x < D.n_aux; x++) {
+    if (D.aux[x].kind != PG_AUX_HLL_DICT && D.aux[x].kind != PG_AUX_HLL_RAW) return false;
+    per_group += (int64_t)4 << D.aux[x].log2m;
+  }
+  if (per_group <= 0) return false;
+  const int64_t budget = kLdsTableBudget - (int64_t)PG_P2_LIST * 4 - 256;
+  int shift_max = 0;
+  while (shift_max < 24 && ((int64_t)2 << shift_max) * per_group <= budget) shift_max++;
+  if (((int64_t)1 << shift_max) * per_group > budget) return false;
+  struct Field { int kind, bits; int64_t bias; };
+  std::vector<Field> fields(srcs.size());
+  bool any_wide = false;
+  int small_bits = 0;
+  for (size_t si = 0; si < srcs.size(); si++) {
+    const Column* c = srcs[si];
+    int n_aux_here = 0, log2m = 0;
+    bool by_op = false;
+    for (int x = 0; x < D.n_aux; x++)
+      if (D.aux[x].src == (int32_t)si) { n_aux_here++; log2m = D.aux[x].log2m; D.pk_lut[si] = D.aux[x].kind == PG_AUX_HLL_DICT ? D.aux[x].lut : nullptr; }
+    for (auto& o : ops) by_op |= o.src == (int32_t)si;
+    if (n_aux_here > 1 || (n_aux_here == 1 && by_op)) return false;   // one consumer per source column
+    Field f{0, 0, 0};
+    D.pk_hll[si] = 0;
+    D.pk_affine[si] = 0;
+    if (n_aux_here == 1) {
+      if (!(c->val_type == PG_V_I32 || c->val_type == PG_V_I64) && c->has_dictionary) return false;   // dictionary LUTs exist for any type, but keep to what is tested
+      if (!c->has_dictionary && c->data_type > PG_TYPE_DOUBLE) return false;
+      if (!c->has_dictionary && (c->val_type == PG_V_F32 || c->val_type == PG_V_F64)) return false;     // Float / Double offers hash other bits: HBM-register path
+      f = {PG_P2_F_HLL, log2m + 5, 0};
+      D.pk_hll[si] = log2m;
+      if (c->has_dictionary && c->dict_affine) {
+        D.pk_affine[si] = 1;
+        D.pk_base[si] = c->dict_base;
+        D.pk_step[si] = c->dict_step;
+        // INT dictionary with a small positive step: base + step x dictId in 32-bit arithmetic (every value is an int by definition)
+        if (c->val_type == PG_V_I32 && c->dict_step > 0 && c->dict_step < (1 << 24) && c->bits <= 24) D.pk_affine[si] = 2;
+      }
+    } else if (c->col_kind == PG_COL_FIXED_BIT && c->has_dictionary && c->data_type <= PG_TYPE_DOUBLE) {
+      f = {PG_P2_F_DICTID, c->bits, 0};
+    } else if (c->col_kind == PG_COL_RAW32 && c->val_type == PG_V_I32) {
+      f = {PG_P2_F_RAW32, 32, 0};
+      if (c->has_int_range) {
+        const uint64_t range = (uint64_t)(c->int_max - c->int_min);
+        int b = 1;
+        while (b < 32 && (range >> b) != 0) b++;
+        f = {PG_P2_F_RAW32, b, c->int_min};
+      }
+    } else if (c->col_kind == PG_COL_RAW32 && c->val_type == PG_V_F32) {
+      f = {PG_P2_F_RAW32, 32, 0};
+    } else if (c->col_kind == PG_COL_RAW64 && (c->val_type == PG_V_I64 || c->val_type == PG_V_F64)) {
+      f = {PG_P2_F_RAW64, 64, 0};
+      any_wide = true;
+    } else {
+      return false;
+    }
+    fields[si] = f;
+    if (f.bits < 64) small_bits += f.bits;
+  }
+  const bool need_docid = P.first_doc_op >= 0;
+  auto buckets_of = [&](int shift) { return (G + ((int64_t)1 << shift) - 1) >> shift; };
+  // one dword: the key's low bits + every field within 31 bits (bit 31 of plane 0 marks padding)
+  int shift = -1, planes = 0;
+  if (!any_wide && !need_docid)
+    for (int sft = shift_max; sft >= 0 && buckets_of(sft) <= PG_P2_MAX_BUCKETS; sft--)
+      if (sft + small_bits <= 31) { shift = sft; planes = 1; break; }
+  std::vector<int> fplane(srcs.size(), 0), fshift(srcs.size(), 0);
+  int docid_plane = -1;
+  if (planes == 1) {
+    int next_bit = shift;
+    for (size_t si = 0; si < srcs.size(); si++) { fplane[si] = 0; fshift[si] = next_bit; next_bit += fields[si].bits; }
+  } else {
+    // several planes: first-fit of the fields into dwords (plane 0 keeps bit 31 clear), 64-bit values and the docId in planes of
+    // their own; among the bucket widths down to shift_max - 3 the one with the fewest planes wins (a narrower key may free the bits
+    // that save a plane), the widest among equals
+    auto layout = [&](int sft, std::vector<int>& pl_of, std::vector<int>& sh_of, int& dpl) -> int {
+      int used[PG_P2_MAX_PLANES + 2] = {0};
+      used[0] = sft;
+      int n_pl = 1;
+      for (size_t si = 0; si < srcs.size(); si++) {
+        if (fields[si].bits == 64) continue;
+        int pl = 0;
+        while (pl < PG_P2_MAX_PLANES && used[pl] + fields[si].bits > (pl == 0 ? 31 : 32)) pl++;
+        if (pl >= PG_P2_MAX_PLANES) return 99;
+        pl_of[si] = pl; sh_of[si] = used[pl]; used[pl] += fields[si].bits;
+        n_pl = std::max(n_pl, pl + 1);
+      }
+      for (size_t si = 0; si < srcs.size(); si++) {
+        if (fields[si].bits != 64) continue;
+        pl_of[si] = n_pl; sh_of[si] = 0;
+        n_pl += 2;
+      }
+      dpl = -1;
+      if (need_docid) dpl = n_pl++;
+      return n_pl;
+    };
+    int best = 99;
+    for (int sft = shift_max; sft >= 0 && sft >= shift_max - 3; sft--) {
+      if (sft > 31 || buckets_of(sft) > PG_P2_MAX_BUCKETS) continue;
+      std::vector<int> pl_of(srcs.size(), 0), sh_of(srcs.size(), 0);
+      int dpl = -1;
+      const int n_pl = layout(sft, pl_of, sh_of, dpl);
+      if (n_pl > PG_P2_MAX_PLANES || buckets_of(sft) * n_pl > PG_P2_MAX_BUCKETS) continue;
+      if (n_pl < best) { best = n_pl; shift = sft; planes = n_pl; fplane = pl_of; fshift = sh_of; docid_plane = dpl; }
+    }
+    if (best == 99) return false;
+  }
+  const int64_t nb = buckets_of(shift);
+  if (nb * planes > PG_P2_MAX_BUCKETS) return false;   // the scatter workgroup's leftover lines: [planes][buckets][32] dwords of LDS
+  D.p2 = 1;
+  D.p2_planes = planes;
+  D.p2_docid_plane = docid_plane;
+  // the scatter's batched loader (pg_kernels_part.hip "fast A"): <= 4 bit-packed group columns, the first <= 24 bits wide and the
+  // others <= 8; at most one source, bit-packed <= 24 bits or raw 32-bit; one or two planes
+  {
+    bool fast = planes <= 2 && D.n_group_cols >= 1 && D.n_group_cols <= 4 && srcs.size() <= 1 && !getenv("PG_P2_NO_FAST_A");
+    for (int g = 0; g < D.n_group_cols && fast; g++)
+      fast = D.gcols[g].col_kind == PG_COL_FIXED_BIT && D.gcols[g].bits <= (g == 0 ? 24 : 8) && (g > 0 || D.gcols[g].mult == 1) &&
+             D.gcols[g].mult < (1 << 24);
+    if (fast && srcs.size() == 1) {
+      const Column* c = srcs[0];
+      fast = (c->col_kind == PG_COL_FIXED_BIT && c->bits <= 24) || c->col_kind == PG_COL_RAW32;
+    }
+    D.p2_fast_a = fast ? 1 : 0;
+  }
+  D.radix_shift = shift;
+  D.radix_buckets = (int32_t)nb;
+  D.radix_packed = 0;
+  for (size_t si = 0; si < srcs.size(); si++) {
+    D.p2_fplane[si] = fplane[si];
+    D.p2_fkind[si] = fields[si].kind;
+    D.p2_fbias[si] = fields[si].bias;
+    D.pk_shift[si] = fshift[si];
+    D.pk_bits[si] = fields[si].bits == 64 ? 32 : fields[si].bits;
+  }
+  return true;
+}
+
 static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_owned, const pg_query* q, const StarTree* st, int star_index) {
   auto plan = std::make_shared<CompiledPlan>();
   CompiledPlan& P = *plan;
@@ -937,6 +1083,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
   P.space_docs = seg.total_docs;
   Emitter em{seg, P};
   if (root->kind == OpKind::Empty) P.always_empty = true;
+  P.match_all = root->kind == OpKind::MatchAll;
   em.emit(*root, true);
   if (em.sp != 1) fail(PG_ERR_INTERNAL, "filter program leaves %d entries on the stack", em.sp);
   if (em.max_sp > PG_MAX_STACK) fail(PG_ERR_UNSUPPORTED, "filter needs %d bitmap stack levels (max %d)", em.max_sp, PG_MAX_STACK);
@@ -1449,13 +1596,15 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     }
     D.replicas = 1;
   }
+  if (D.agg_mode == PG_AGG_RADIX) (void)plan_partition_v2(P, D, srcs, sorted_ops, G);
   D.replica_shift = 0;
   while ((1 << D.replica_shift) < D.replicas) D.replica_shift++;
   if (D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE) P.lds_bytes += (size_t)G * D.replicas * D.n_ops * 8;
   if (D.agg_mode == PG_AGG_LDS_PART) P.lds_bytes += (size_t)D.part_groups * D.n_ops * 8;
   if (D.agg_mode == PG_AGG_RADIX) {
     P.lds_bytes += ((size_t)D.n_ops << D.radix_shift) * 8;
-    for (int x = 0; x < D.n_aux; x++) P.lds_bytes += (size_t)D.aux[x].stride << D.radix_shift;
+    for (int x = 0; x < D.n_aux; x++) P.lds_bytes += ((size_t)D.aux[x].stride << D.radix_shift) * (D.p2 ? 4 : 1);   // p2: one dword per register
+    if (D.p2) P.lds_bytes += (size_t)PG_P2_LIST * 4;
   }
   // auxiliary regions (HBM): sizes per op, patched into the plan at execution
   for (int x = 0; x < D.n_aux; x++) {
@@ -1490,7 +1639,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
   }
   // Packed 4-byte radix tuples (pg_kernels.hip "Packed radix tuples"): the local key plus, per source, the (index, rank) a
   // DISTINCTCOUNTHLL offers or the dictId of a dictionary-encoded source, when that fits 32 bits; staged in LDS by at most 32 buckets
-  if (D.agg_mode == PG_AGG_RADIX && P.first_doc_op < 0 && D.radix_buckets <= 64 && !getenv("PG_NO_RADIX_PACKED")) {
+  if (D.agg_mode == PG_AGG_RADIX && !D.p2 && P.first_doc_op < 0 && D.radix_buckets <= 64 && !getenv("PG_NO_RADIX_PACKED")) {
     bool ok = true;
     int next_bit = D.radix_shift;
     for (size_t si = 0; si < srcs.size() && ok; si++) {
@@ -1516,7 +1665,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
       D.pk_shift[si] = next_bit;
       next_bit += D.pk_bits[si];
     }
-    if (ok && next_bit <= 32) D.radix_packed = 1;
+    if (ok && next_bit < 32) D.radix_packed = 1;   // bit 31 stays clear: a tuple never equals PG_RADIX_INVALID_KEY (the padding marker)
   }
   // fast aggregation: LDS table, slots fit 16 bits, <= 8-bit group columns, 32-bit value sources
   P.fast_agg = D.agg_mode != PG_AGG_GLOBAL && D.agg_mode != PG_AGG_LDS_PART && D.agg_mode != PG_AGG_RADIX && (int64_t)G * D.replicas <= 65536;   // (trivially true without a table)

@@ -48,6 +48,28 @@ extern "C" __global__ void __launch_bounds__(256) pg_column_magnitude_kernel(con
   }
 }
 
+// Smallest and largest value of a raw INT / LONG column (out[0] = min, out[1] = max, both initialised by the caller): the partition
+// pipeline packs such a value into a tuple as (value - min) in as many bits as the column's range needs.
+extern "C" __global__ void __launch_bounds__(256) pg_column_int_range_kernel(const uint8_t* __restrict__ data, int64_t n, int val_type,
+                                                                             long long* __restrict__ out) {
+  long long mn = INT64_MAX, mx = INT64_MIN;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const long long v = val_type == PG_V_I64 ? (long long)__builtin_bswap64(reinterpret_cast<const unsigned long long*>(data)[i])
+                                             : (long long)(int32_t)__builtin_bswap32(reinterpret_cast<const uint32_t*>(data)[i]);
+    mn = v < mn ? v : mn;
+    mx = v > mx ? v : mx;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const long long a = __shfl_xor(mn, off, 64), b = __shfl_xor(mx, off, 64);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+  }
+  if ((threadIdx.x & 63) == 0 && mn <= mx) {
+    atomicMin(&out[0], mn);
+    atomicMax(&out[1], mx);
+  }
+}
+
 namespace pg {
 
 // every finite |value| < 2^fx_exp, fx_exp a multiple of 16 (so that segments with similar data choose the same scale and their
@@ -453,6 +475,19 @@ void segment_add_column(Segment& seg, const pg_column_desc& d) {
       c.fx_exp = fx_exp_of(mx);
       c.has_nonfinite = h[1] != 0;
     }
+  }
+
+  if (!c.has_dictionary && (c.val_type == PG_V_I32 || c.val_type == PG_V_I64) && (c.col_kind == PG_COL_RAW32 || c.col_kind == PG_COL_RAW64) &&
+      seg.total_docs > 0) {
+    const long long init[2] = {INT64_MAX, INT64_MIN};
+    DeviceBuffer out(16);
+    out.upload(init, sizeof(init));
+    hipLaunchKernelGGL(pg_column_int_range_kernel, dim3(1024), dim3(256), 0, 0, c.fwd_dev.as<uint8_t>(), (int64_t)seg.total_docs, c.val_type,
+                       out.as<long long>());
+    PG_HIP(hipGetLastError());
+    long long h[2] = {0, 0};
+    PG_HIP(hipMemcpy(h, out.ptr, sizeof(h), hipMemcpyDeviceToHost));
+    if (h[0] <= h[1]) { c.has_int_range = true; c.int_min = h[0]; c.int_max = h[1]; }
   }
 
   if (d.inverted_index.size > 0 && c.has_dictionary && c.fwd_encoding != PG_FWD_DICT_SORTED)

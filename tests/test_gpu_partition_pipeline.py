@@ -1,0 +1,199 @@
+"""GPU parity of the partition pipeline (pinot_amd/csrc/pg_kernels_part.hip: group-by over key spaces beyond one LDS table) vs the
+CPU oracle: every tuple shape the planner packs (one dword with HyperLogLog (index, rank) / dictIds / a raw INT minus the column's
+minimum; several planes with whole 32- and 64-bit values; the docId plane of numGroupsLimit trimming), bucket counts on both sides of
+64, skewed keys (one bucket takes everything), segment sizes around the round / line / chunk boundaries, filtered and unfiltered.
+
+Reference semantics: DictionaryBasedGroupKeyGenerator.java:416-446 (map-based holders), DefaultGroupByExecutor.java:191-220,
+DistinctCountHLLAggregationFunction.java:152-222 — bit-exact counts, group keys, MIN / MAX, integer SUMs, HyperLogLog registers.
+"""
+import numpy as np
+import pytest
+
+from pinot_amd import synth
+from pinot_amd.executor import NativeSegment
+from pinot_amd.query import parse_sql
+from pinot_amd.segment import build_segment
+
+pytestmark = pytest.mark.gpu
+
+
+def both(gpu_api, oracle_api, host):
+    return NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+
+
+def same(g, o):
+    gr, orr = g.rows(), o.rows()
+    assert sorted(gr.keys()) == sorted(orr.keys())
+    for k in orr:
+        assert gr[k] == orr[k], (k, gr[k], orr[k])
+    assert g.stats.num_docs_scanned == o.stats.num_docs_scanned
+    assert g.stats.num_entries_scanned_in_filter == o.stats.num_entries_scanned_in_filter
+    assert g.stats.num_groups_limit_reached == o.stats.num_groups_limit_reached
+
+
+def run(g, o, sql, limit=None, kernel="pg_part_group_by"):
+    qg, qo = parse_sql(sql), parse_sql(sql)
+    if limit:
+        qg.num_groups_limit = qo.num_groups_limit = limit
+    gb, ob = g.execute(qg), o.execute(qo)
+    same(gb, ob)
+    if kernel and gb.stats.num_docs_scanned > 0:
+        assert gb.stats.kernel.decode() == kernel, gb.stats.kernel
+    return gb
+
+
+# ---- BASELINE config 5 (flat): 12 800 groups x 256 HyperLogLog registers: one dword per doc (9-bit local key... + 13-bit payload) -----
+@pytest.mark.parametrize("n", [1, 31, 33, 2047, 2049, 4097, 16_385, 150_001, 1_000_003])
+def test_config5_sizes(gpu_api, oracle_api, n):
+    host = synth.generate_segment(n, segment_index=2, columns=synth.CFG5_COLUMNS, native=(n > 200_000))
+    g, o = both(gpu_api, oracle_api, host)
+    run(g, o, synth.QUERY_CFG5, limit=100_000)
+    run(g, o, "SELECT h1, h2, h3, h4, COUNT(*), DISTINCTCOUNTHLL(u) FROM gpuBench WHERE h2 < 5 AND u > 1000 GROUP BY h1, h2, h3, h4 LIMIT 20000",
+        limit=100_000)
+    g.destroy()
+    o.destroy()
+
+
+CFG5_SHAPES = [
+    # key only (1 M keys, 64 buckets)
+    ("SELECT u, COUNT(*) FROM gpuBench GROUP BY u LIMIT 2000000", 2_000_000),
+    # key + one small dictId
+    ("SELECT u, COUNT(*), SUM(h1) FROM gpuBench WHERE h2 IN (1, 2) GROUP BY u LIMIT 2000000", 2_000_000),
+    # 16 M keys behind a selective filter
+    ("SELECT u, h1, COUNT(*) FROM gpuBench WHERE h2 = 3 AND h3 > 4 GROUP BY u, h1 LIMIT 20000000", 20_000_000),
+    # numGroupsLimit bites: the docId plane (MIN(docId) per group)
+    ("SELECT u, COUNT(*) FROM gpuBench GROUP BY u LIMIT 2000000", 1000),
+    ("SELECT h4, u, MAX(h2), MIN(h3), AVG(h1) FROM gpuBench WHERE u < 300000 GROUP BY h4, u LIMIT 100", 50),
+    # two HyperLogLogs + a SUM over a third column
+    ("SELECT h1, h2, h3, h4, DISTINCTCOUNTHLL(u), COUNT(*) FROM gpuBench WHERE h1 < 8 GROUP BY h1, h2, h3, h4 LIMIT 20000", 100_000),
+]
+
+
+@pytest.fixture(scope="module")
+def cfg5_seg(gpu_api, oracle_api):
+    host = synth.generate_segment(300_007, segment_index=4, columns=synth.CFG5_COLUMNS, native=False)
+    g, o = both(gpu_api, oracle_api, host)
+    yield g, o
+    g.destroy()
+    o.destroy()
+
+
+@pytest.mark.parametrize("q,limit", CFG5_SHAPES)
+def test_config5_shapes(cfg5_seg, q, limit):
+    g, o = cfg5_seg
+    run(g, o, q, limit, kernel=None)   # 16 M keys x 8 bytes need > 256 buckets: the planner's other routes answer those
+
+
+def test_config5_shapes_use_the_pipeline(cfg5_seg):
+    g, _ = cfg5_seg
+    for q, _limit in (CFG5_SHAPES[0], CFG5_SHAPES[5]):
+        assert g.execute(q).stats.kernel.decode() == "pg_part_group_by", q
+
+
+# ---- value columns of every kind: raw INT (range-packed), raw LONG / DOUBLE (two planes), raw FLOAT, dictionary LONG / DOUBLE ---------
+@pytest.fixture(scope="module")
+def wide_seg(gpu_api, oracle_api):
+    rng = np.random.default_rng(5)
+    n = 200_003
+    data = {
+        "k": rng.integers(0, 30_000, n).astype(np.int32),                 # 15-bit dictionary column: 30 000 keys
+        "k2": rng.integers(0, 9, n).astype(np.int32),
+        "ri": rng.integers(-5000, 60_000, n).astype(np.int32),             # raw INT, 17-bit range, negative minimum
+        "rbig": rng.integers(-2**31, 2**31 - 1, n).astype(np.int32),       # raw INT using all 32 bits
+        "lm": rng.integers(-10**12, 10**12, n).astype(np.int64),           # raw LONG
+        "dm": (rng.integers(-10**6, 10**6, n) * 0.25).astype(np.float64),  # raw DOUBLE
+        "fm": (rng.integers(-1000, 1000, n) * 0.5).astype(np.float32),     # raw FLOAT
+        "ld": rng.integers(0, 300, n).astype(np.int64) * 10**10,            # dictionary LONG
+        "dd": (rng.integers(0, 500, n) * 0.125).astype(np.float64),        # dictionary DOUBLE
+        "r": rng.integers(0, 1000, n).astype(np.int32),
+    }
+    host = build_segment("wide", data, {"k": "INT", "k2": "INT", "ri": "INT", "rbig": "INT", "lm": "LONG", "dm": "DOUBLE", "fm": "FLOAT",
+                                         "ld": "LONG", "dd": "DOUBLE", "r": "INT"},
+                         no_dictionary_columns=["ri", "rbig", "lm", "dm", "fm", "r"])
+    g, o = both(gpu_api, oracle_api, host)
+    yield g, o
+    g.destroy()
+    o.destroy()
+
+
+WIDE_SHAPES = [
+    "SELECT k, COUNT(*), SUM(ri), MIN(ri), MAX(ri) FROM wide GROUP BY k LIMIT 100000",                       # one dword: key + 17 bits
+    "SELECT k, k2, SUM(ri) FROM wide WHERE r < 700 GROUP BY k, k2 LIMIT 1000000",                             # 270 000 keys, filtered
+    "SELECT k, SUM(rbig), MAX(rbig), COUNT(*) FROM wide GROUP BY k LIMIT 100000",                             # two planes: key | 32-bit value
+    "SELECT k, SUM(lm), MIN(lm) FROM wide GROUP BY k LIMIT 100000",                                           # three planes: 64-bit value
+    "SELECT k, SUM(dm), MAX(dm), MIN(fm), SUM(fm) FROM wide WHERE r BETWEEN 100 AND 900 GROUP BY k LIMIT 100000",   # DOUBLE + FLOAT: four planes
+    "SELECT k, SUM(ld), MAX(dd), AVG(ri) FROM wide GROUP BY k LIMIT 100000",                                  # dictionary LONG / DOUBLE: dictIds
+    "SELECT k, k2, MINMAXRANGE(ri), AVG(lm) FROM wide WHERE lm > 0 GROUP BY k, k2 LIMIT 1000000",
+]
+
+
+@pytest.mark.parametrize("q", WIDE_SHAPES)
+def test_value_kinds(wide_seg, q):
+    g, o = wide_seg
+    run(g, o, q, limit=1_000_000, kernel=None)
+
+
+def test_value_kinds_use_the_pipeline(wide_seg):
+    g, _ = wide_seg
+    for q in WIDE_SHAPES[:4]:
+        assert g.execute(q).stats.kernel.decode() == "pg_part_group_by", q
+
+
+def test_trimmed_wide(wide_seg):
+    g, o = wide_seg
+    run(g, o, "SELECT k, SUM(ri), COUNT(*) FROM wide GROUP BY k LIMIT 100000", limit=777, kernel=None)
+    run(g, o, "SELECT k, SUM(lm) FROM wide WHERE r < 500 GROUP BY k LIMIT 100000", limit=5000, kernel=None)
+
+
+# ---- skew: every doc in one group / one bucket, a few hot keys among many cold ones, runs longer than a chunk ---------------------------
+@pytest.mark.parametrize("pattern", ["one_key", "one_bucket", "hot_and_cold", "sorted_keys"])
+def test_skewed_keys(gpu_api, oracle_api, pattern):
+    rng = np.random.default_rng(9)
+    n = 120_011
+    card = 40_000
+    if pattern == "one_key":
+        k = np.full(n, 31_337, dtype=np.int32)
+    elif pattern == "one_bucket":
+        k = rng.integers(8192, 8192 + 100, n).astype(np.int32)
+    elif pattern == "hot_and_cold":
+        k = np.where(rng.random(n) < 0.9, 7, rng.integers(0, card, n)).astype(np.int32)
+    else:
+        k = np.sort(rng.integers(0, card, n)).astype(np.int32)
+    k[:card] = np.arange(card, dtype=np.int32)   # the dictionary holds every key
+    v = rng.integers(0, 1 << 20, n).astype(np.int32)
+    u = rng.integers(0, 50_000, n).astype(np.int32)
+    host = build_segment("skew", {"k": k, "v": v, "u": u}, {"k": "INT", "v": "INT", "u": "INT"}, no_dictionary_columns=["v"])
+    g, o = both(gpu_api, oracle_api, host)
+    run(g, o, "SELECT k, COUNT(*), SUM(v), MAX(v) FROM skew GROUP BY k LIMIT 100000", limit=100_000)
+    run(g, o, "SELECT k, COUNT(*), DISTINCTCOUNTHLL(u) FROM skew GROUP BY k LIMIT 100000", limit=100_000, kernel=None)
+    run(g, o, "SELECT k, SUM(v) FROM skew WHERE v < 300000 GROUP BY k LIMIT 100000", limit=100_000)
+    g.destroy()
+    o.destroy()
+
+
+def test_many_buckets(gpu_api, oracle_api):
+    """800 000 keys x 3 accumulators: 196 buckets (the scatter keeps per-bucket state for up to 256)."""
+    rng = np.random.default_rng(3)
+    n = 400_000
+    a = rng.integers(0, 800, n).astype(np.int32)
+    b = rng.integers(0, 1000, n).astype(np.int32)
+    v = rng.integers(0, 100, n).astype(np.int32)
+    a[:800] = np.arange(800)
+    b[:1000] = np.arange(1000)
+    host = build_segment("mb", {"a": a, "b": b, "v": v}, {"a": "INT", "b": "INT", "v": "INT"})
+    g, o = both(gpu_api, oracle_api, host)
+    run(g, o, "SELECT a, b, COUNT(*), SUM(v), MAX(v) FROM mb GROUP BY a, b LIMIT 3000000", limit=3_000_000)
+    run(g, o, "SELECT a, b, COUNT(*), SUM(v), MAX(v) FROM mb WHERE v < 10 GROUP BY a, b LIMIT 3000000", limit=3_000_000)
+    g.destroy()
+    o.destroy()
+
+
+def test_round2_passes_still_agree(gpu_api, oracle_api, monkeypatch):
+    """PG_NO_P2 keeps the round-2 radix passes reachable (shapes outside the pipeline take them): same results."""
+    host = synth.generate_segment(90_001, segment_index=7, columns=synth.CFG5_COLUMNS, native=False)
+    monkeypatch.setenv("PG_NO_P2", "1")
+    g, o = both(gpu_api, oracle_api, host)
+    gb = run(g, o, synth.QUERY_CFG5, limit=100_000, kernel=None)
+    assert gb.stats.kernel.decode() == "pg_radix_group_by"
+    g.destroy()
+    o.destroy()
