@@ -188,7 +188,7 @@ def main():
     # rocprofv3 is not available
     traffic, traffic_detail = None, None
     if rank == 0 and world == 1 and not args.no_traffic:
-        traffic, traffic_detail = measure_traffic(args, st.kernel.decode() or "pg_generic_query_l")
+        traffic, traffic_detail = measure_traffic(args.query, args.docs, st.kernel.decode() or "pg_generic_query_l")
     out = {
         "metric": {"cfg3": "rows scanned/sec, 1B-row segment filter+groupby (3 predicates, SUM/MAX GROUP BY g1)",
                    "northstar": "rows scanned/sec, segment filter+groupby (3 predicates, SUM GROUP BY g1, g2)",
@@ -250,6 +250,13 @@ def main():
             "roofline_frac": NORTH_STAR_BYTES_PER_ROW * args.docs / (k_n * 1e-3) / 1e9 / HBM_PEAK_GBS if k_n > 0 else 0.0,
             "algorithmic_bytes_per_launch": NORTH_STAR_BYTES_PER_ROW * args.docs}
 
+    if args.query == "cfg3" and not args.no_variants and rank == 0 and world == 1:
+        # BASELINE configs 2 and 5 next to the headline (same timing discipline, their own segments): every default run carries them
+        seg.destroy()
+        seg = None
+        out["cfg2"] = extra_block(api, args, "cfg2", min(args.docs, 100_000_000), 4.0, ["r_int"], synth.QUERY_CFG2)
+        out["cfg5_flat"] = extra_block(api, args, "cfg5", args.docs, 4.375, list(synth.CFG5_COLUMNS), synth.QUERY_CFG5)
+        out["cfg5_star_tree"] = star_tree_leg(api, args, parent_docs=400_000)
     if args.query == "cfg5" and rank == 0:
         out["star_tree_route"] = star_tree_leg(api, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.query != "cfg5":
@@ -258,19 +265,80 @@ def main():
         out["cpu_baseline"] = cpu_baseline_cfg5(args, sql)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    seg.destroy()
+    if seg is not None:
+        seg.destroy()
     if world > 1:
         dist.destroy_process_group()
 
 
-def star_tree_leg(api, args):
+def extra_block(api, args, query, docs, bytes_per_row, columns, sql):
+    """One more BASELINE configuration inside the default run: its own segment of `docs` rows pinned in HBM, `steps` timed executions
+    after `warmup`, HIP-event kernel time → roofline fraction, HBM traffic from the PMC passes (child runs), and an oracle equality
+    flag — the whole segment for config 2 (0.3 s of CPU), a 10 M-row prefix for config 5 (its oracle needs minutes at 1 B rows) plus
+    a full-size invariant (the groups' counts add up to the segment's rows)."""
+    from pinot_amd import capi, synth
+    from pinot_amd.executor import NativeSegment
+    from pinot_amd.query import parse_sql
+    from pinot_amd.segment import HostSegment
+    from tests.oracle_binding import load_oracle
+    t0 = time.time()
+    seg = NativeSegment(api, HostSegment(f"gpuBench_{query}", docs))
+    for name in columns:
+        one = synth.generate_segment(docs, segment_index=0, columns=[name])
+        seg.add_column(one.columns[name], keep_host_buffers=False)
+        del one
+    q = parse_sql(sql)
+    q.flags |= capi.QUERY_FLAG_PROFILE
+    steps = max(5, args.steps // 2)
+    kms, lat = [], []
+    block = None
+    for i in range(args.warmup + steps):
+        t = time.perf_counter()
+        block = seg.execute(q)
+        if i >= args.warmup:
+            lat.append((time.perf_counter() - t) * 1e3)
+            kms.append(block.stats.device_ms_aggregate)
+    k = sum(kms) / len(kms)
+    kernel = block.stats.kernel.decode()
+    res = {"query": sql, "rows": docs, "steps": steps, "kernel": kernel, "kernel_ms": k, "ms_per_step": sum(lat) / len(lat),
+           "p50_query_latency_ms": statistics.median(lat), "value": docs / (sum(lat) / len(lat) * 1e-3), "unit": "rows/s",
+           "algorithmic_bytes_per_launch": bytes_per_row * docs,
+           "roofline_frac": bytes_per_row * docs / (k * 1e-3) / 1e9 / HBM_PEAK_GBS if k > 0 else 0.0}
+    # oracle equality
+    sample = docs if query == "cfg2" else min(docs, 10_000_000)
+    host = synth.generate_segment(sample, segment_index=0, columns=columns)
+    ora = NativeSegment(load_oracle(), host)
+    ob = ora.execute(sql)
+    if sample == docs:
+        res["gpu_equals_oracle_at_full_size"] = block.rows() == ob.rows() and block.stats.num_docs_scanned == ob.stats.num_docs_scanned
+    else:
+        gp = NativeSegment(api, host)
+        gb = gp.execute(sql)
+        res["gpu_equals_oracle_on_sample"] = gb.rows() == ob.rows()
+        res["oracle_sample_rows"] = sample
+        gp.destroy()
+        rows = block.rows()
+        res["full_size_invariant"] = {"sum_of_group_counts": int(sum(v[0] for v in rows.values())), "rows": docs, "groups": len(rows)}
+    ora.destroy()
+    del host
+    seg.destroy()
+    if not args.no_traffic:
+        traffic, detail = measure_traffic(query, docs, kernel)
+        res["traffic"] = traffic
+        res["traffic_over_algorithmic"] = traffic / (bytes_per_row * docs) if traffic else None
+        res["traffic_detail"] = detail
+    res["wall_s"] = time.time() - t0
+    return res
+
+
+def star_tree_leg(api, args, parent_docs=2_000_000):
     """BASELINE config 5 as stated: the same query answered from a star-tree over (h1, h2, h3, h4) holding count__* and
     distinctCountHLL__u.  The route reads the star-tree's pre-aggregated docs only, so its latency is the same for a 2 M-doc and a
     1 B-doc parent: measured on a 2 M-doc parent (the host-side tree builder is test tooling, not sized for 1 B rows)."""
     from pinot_amd import capi, startree, synth
     from pinot_amd.executor import NativeSegment
     from pinot_amd.query import parse_sql
-    parent = synth.generate_segment(2_000_000, segment_index=0, columns=list(synth.CFG5_COLUMNS), native=False)
+    parent = synth.generate_segment(parent_docs, segment_index=0, columns=list(synth.CFG5_COLUMNS), native=False)
     startree.add_star_tree(parent, ["h1", "h2", "h3", "h4"], [("COUNT", "*"), ("DISTINCTCOUNTHLL", "u")], max_leaf_records=10000)
     seg = NativeSegment(api, parent)
     q = parse_sql(synth.QUERY_CFG5)
@@ -313,7 +381,7 @@ def cpu_baseline_cfg5(args, sql):
             "sample": f"first {sample} docs of segment 0, flat config-5 query, median of 3 runs; C restatement of the reference operators (oracle/)"}
 
 
-def measure_traffic(args, kernel):
+def measure_traffic(query, docs, kernel):
     """HBM bytes per launch of `kernel`: two child runs of this script under `rocprofv3 --pmc <counter> --kernel-trace` (FETCH_SIZE
     costs 3 of the 4 TCC slots and WRITE_SIZE 2, so each gets its own pass; no other trace domain is enabled).  On gfx950 FETCH_SIZE
     reports half the bytes of wide coalesced reads (TCC_EA0_RDREQ x 64 B for 128-byte requests): doubled; WRITE_SIZE as reported.
@@ -328,7 +396,7 @@ def measure_traffic(args, kernel):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="pg_pmc_", dir="/tmp")
         cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "-d", d, "-o", "x", "--", sys.executable, os.path.abspath(__file__),
-               "--docs", str(args.docs), "--query", args.query, "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-variants",
+               "--docs", str(docs), "--query", query, "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-variants",
                "--no-traffic"]
         env = dict(os.environ, TMPDIR="/tmp")
         try:
@@ -337,7 +405,8 @@ def measure_traffic(args, kernel):
             db = sqlite3.connect(dbs[0])
             if kernel.endswith("_group_by"):   # a pipeline of kernels (radix / hash group-by): all of them, per query execution
                 rows = list(db.execute("select sum(value) from counters_collection where counter_name = ? and (kernel_name like 'pg_radix%' "
-                                       "or kernel_name like 'pg_hash%' or kernel_name like 'pg_fast_%_f' or kernel_name like 'pg_generic_query_f')", (counter,)))
+                                       "or kernel_name like 'pg_p2%' or kernel_name like 'pg_hash%' or kernel_name like 'pg_fast_%_f' "
+                                       "or kernel_name like 'pg_generic_query_f')", (counter,)))
                 per[counter] = float(rows[0][0]) / 7.0    # 2 warm-up + 5 timed executions in the child run
             else:
                 rows = list(db.execute(

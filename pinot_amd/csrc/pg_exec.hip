@@ -30,6 +30,7 @@ PG_DECL_FAST(pg_hash_count_kernel) PG_DECL_FAST(pg_hash_scatter_kernel) PG_DECL_
 PG_DECL_FAST(pg_p2_scatter_1) PG_DECL_FAST(pg_p2_scatter_2) PG_DECL_FAST(pg_p2_scatter_3) PG_DECL_FAST(pg_p2_scatter_4)
 PG_DECL_FAST(pg_p2_scatter_1f) PG_DECL_FAST(pg_p2_scatter_2f) PG_DECL_FAST(pg_p2_scatter_1f_key) PG_DECL_FAST(pg_p2_scatter_1f_hll)
 PG_DECL_FAST(pg_p2_aggregate_1) PG_DECL_FAST(pg_p2_aggregate_2) PG_DECL_FAST(pg_p2_aggregate_3) PG_DECL_FAST(pg_p2_aggregate_4)
+PG_DECL_FAST(pg_p2_aggregate_1n) PG_DECL_FAST(pg_p2_aggregate_2n) PG_DECL_FAST(pg_p2_aggregate_3n) PG_DECL_FAST(pg_p2_aggregate_4n)
 PG_DECL_FAST(pg_p2_index_count_kernel) PG_DECL_FAST(pg_p2_index_scan_kernel) PG_DECL_FAST(pg_p2_index_fill_kernel)
 extern "C" const int pg_p2_round_quads[5];   // pg_kernels_part.hip: quads per lane and round of the scatter kernel, by plane count
 extern "C" __global__ void pg_radix_offsets_kernel(uint32_t* hist, uint32_t* bucket_total, int n_wg, int n_buckets, int stage, int stage_waves);
@@ -126,7 +127,8 @@ void use_device(int ordinal) {
                                  pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a, pg_fast_multi_f, pg_fast_multi_a, pg_fast_multi_w, pg_fast_none_w, pg_fast_multi_wd, pg_fast_none_wd, pg_generic_query_ld, pg_generic_query_gd, pg_fast_i32range_d, pg_fast_i32range_p,
                                  pg_radix_aggregate_kernel, pg_hash_aggregate_kernel,
                                  pg_p2_scatter_1, pg_p2_scatter_2, pg_p2_scatter_3, pg_p2_scatter_4, pg_p2_scatter_1f, pg_p2_scatter_2f, pg_p2_scatter_1f_key, pg_p2_scatter_1f_hll,
-                                 pg_p2_aggregate_1, pg_p2_aggregate_2, pg_p2_aggregate_3, pg_p2_aggregate_4};
+                                 pg_p2_aggregate_1, pg_p2_aggregate_2, pg_p2_aggregate_3, pg_p2_aggregate_4,
+                                 pg_p2_aggregate_1n, pg_p2_aggregate_2n, pg_p2_aggregate_3n, pg_p2_aggregate_4n};
       for (QueryKernel k : all)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pg_radix_scatter_packed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
@@ -599,6 +601,9 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
     static const QueryKernel scatter_k[5] = {nullptr, pg_p2_scatter_1, pg_p2_scatter_2, pg_p2_scatter_3, pg_p2_scatter_4};
     static const QueryKernel scatter_fast_k[3] = {nullptr, pg_p2_scatter_1f, pg_p2_scatter_2f};
     static const QueryKernel aggregate_k[5] = {nullptr, pg_p2_aggregate_1, pg_p2_aggregate_2, pg_p2_aggregate_3, pg_p2_aggregate_4};
+    static const QueryKernel aggregate_nogather_k[5] = {nullptr, pg_p2_aggregate_1n, pg_p2_aggregate_2n, pg_p2_aggregate_3n, pg_p2_aggregate_4n};
+    bool gathers = false;   // a source travelling as a dictId is looked up in the aggregation pass
+    for (int si = 0; si < D.n_srcs; si++) gathers |= D.p2_fkind[si] == PG_P2_F_DICTID;
     // every work item should see >= 64 K tuples (its table is zeroed, flushed and merged whatever it aggregates)
     const int slices_max = D.radix_slices;
     D.radix_slices = (int)std::max<unsigned long long>(1, std::min<unsigned long long>((unsigned long long)slices_max, matched_now / ((unsigned long long)NB * 65536ULL)));
@@ -618,7 +623,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
       PG_HIP(hipGetLastError());
     }
     const int agrid = std::min(NB * D.radix_slices, num_cus());
-    hipLaunchKernelGGL(aggregate_k[T], dim3(agrid), dim3(PG_P2_AGG_THREADS), P.lds_bytes + 64, ctx.stream, D);
+    hipLaunchKernelGGL(gathers ? aggregate_k[T] : aggregate_nogather_k[T], dim3(agrid), dim3(PG_P2_AGG_THREADS), P.lds_bytes + 64, ctx.stream, D);
     PG_HIP(hipGetLastError());
     for (int x = 0; x < D.n_aux; x++) {
       const int64_t n_words = (int64_t)D.n_groups * D.aux[x].stride / 4, bucket_words = (int64_t)(slots * (size_t)D.aux[x].stride / 4);

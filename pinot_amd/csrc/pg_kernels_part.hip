@@ -733,22 +733,25 @@ DEVFN uint32_t p2_pick(const u32x4 (&v)[T], int pl, int e) {
   return x;
 }
 
+// Loads one chunk's tuples of this lane (4 per plane) and returns whether the lane has any.  The load targets are touched by nothing
+// but the load (a select between the loaded value and a constant is a USE: the compiler then waits for the load on the spot); lanes
+// beyond the chunk's filled lines re-read its first line and are masked by the returned flag.
 template <int T>
-DEVFN void p2_fetch(const GAS uint32_t* tuples, size_t plane_stride, const uint32_t* list, uint32_t n_list, uint32_t ci, int lane, u32x4 (&v)[T]) {
-  const u32x4 inv = {PG_RADIX_INVALID_KEY, PG_RADIX_INVALID_KEY, PG_RADIX_INVALID_KEY, PG_RADIX_INVALID_KEY};
-  if (ci >= n_list) {   // wave-uniform
-#pragma unroll
-    for (int pl = 0; pl < T; pl++) v[pl] = inv;
-    return;
-  }
+DEVFN bool p2_fetch(const GAS uint32_t* tuples, size_t plane_stride, const uint32_t* list, uint32_t n_list, uint32_t ci, int lane, u32x4 (&v)[T]) {
+  if (ci >= n_list) return false;   // wave-uniform; v stays undefined and is never consumed
   const uint32_t e = list[ci];
-  const size_t at = (size_t)(e & 0x7FFFFFFu) * PG_P2_CHUNK + (size_t)lane * 4u;
   const bool on = (uint32_t)(lane >> 3) < (e >> 27);
+  const size_t at = (size_t)(e & 0x7FFFFFFu) * PG_P2_CHUNK + (size_t)(on ? lane : (lane & 7)) * 4u;
 #pragma unroll
-  for (int pl = 0; pl < T; pl++) v[pl] = on ? ldnt((const GAS u32x4*)(tuples + (size_t)pl * plane_stride + at)) : inv;
+  for (int pl = 0; pl < T; pl++) v[pl] = ldnt((const GAS u32x4*)(tuples + (size_t)pl * plane_stride + at));
+  return on;
 }
-template <int T>
-DEVFN void p2_consume(const PgQueryPlan& p, const u32x4 (&cur)[T], int64_t* table, uint32_t* aux_lds, uint32_t slots, uint32_t local_mask) {
+// GATHER: some source travels as a dictId and is looked up here.  Without such a source the consumer issues no global load at all, so
+// the wait in front of it is for the OLDEST chunk only and the younger two keep travelling (any gather drains them: vmcnt counts
+// in order).
+template <int T, bool GATHER>
+DEVFN void p2_consume(const PgQueryPlan& p, const u32x4 (&cur)[T], bool on, int64_t* table, uint32_t* aux_lds, uint32_t slots, uint32_t local_mask) {
+  if (!on) return;
 #pragma unroll
   for (int e = 0; e < 4; e++) {
     const uint32_t d0 = p2_pick<T>(cur, 0, e);
@@ -758,7 +761,8 @@ DEVFN void p2_consume(const PgQueryPlan& p, const u32x4 (&cur)[T], int64_t* tabl
       const PgAccOp op = p.ops[o];
       int64_t* acc = table + (size_t)o * slots + k;
       if (op.src < 0) {
-        if (op.fn == PG_ACC_COUNT) atomicAdd(reinterpret_cast<unsigned long long*>(acc), 1ULL);
+        // COUNT: a work item sees < 2^32 tuples, so the slot's low dword takes the add (ds_add_u32: half the data of ds_add_u64)
+        if (op.fn == PG_ACC_COUNT) atomicAdd(reinterpret_cast<uint32_t*>(acc), 1u);
         else atomicMin(reinterpret_cast<long long*>(acc), (long long)p2_pick<T>(cur, p.p2_docid_plane, e));   // MIN(docId)
         continue;
       }
@@ -767,7 +771,7 @@ DEVFN void p2_consume(const PgQueryPlan& p, const u32x4 (&cur)[T], int64_t* tabl
       const uint32_t bits = (uint32_t)p.pk_bits[op.src];
       uint32_t f = p2_pick<T>(cur, fpl, e) >> p.pk_shift[op.src];
       if (bits < 32u) f &= (1u << bits) - 1u;
-      if (kind == PG_P2_F_DICTID) {
+      if (GATHER && kind == PG_P2_F_DICTID) {
         if (V.val_type == PG_V_I32) acc_from_int(acc, op, (int64_t)(int32_t)gptr<uint32_t>(V.dict)[f]);
         else if (V.val_type == PG_V_I64) acc_from_int(acc, op, (int64_t)gptr<uint64_t>(V.dict)[f]);
         else if (V.val_type == PG_V_F32) acc_from_double(acc, op, (double)__uint_as_float(gptr<uint32_t>(V.dict)[f]), V.fx_q);
@@ -792,7 +796,7 @@ DEVFN void p2_consume(const PgQueryPlan& p, const u32x4 (&cur)[T], int64_t* tabl
   }
 }
 
-template <int T>
+template <int T, bool GATHER>
 __device__ __forceinline__ void p2_aggregate_body(const PgQueryPlan& p) {
   extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
   int64_t* table = reinterpret_cast<int64_t*>(smem);
@@ -823,16 +827,15 @@ __device__ __forceinline__ void p2_aggregate_body(const PgQueryPlan& p) {
       const uint32_t n_list = hi_i - win < PG_P2_LIST ? hi_i - win : PG_P2_LIST;
       for (uint32_t i = (uint32_t)t; i < n_list; i += PG_P2_AGG_THREADS) list[i] = gptr<uint32_t>(p.p2_list)[win + i];
       __syncthreads();
-      // three chunks per wavefront in flight (loads return in order: consuming c0 leaves c1 / c2 travelling); ONE call site of the
-      // consumer — three copies of it made the compiler keep the plan in scratch (1 848 bytes per lane)
-      u32x4 c0[T], c1[T], c2[T];
-      p2_fetch<T>(tuples, plane_stride, list, n_list, (uint32_t)wave, lane, c0);
-      p2_fetch<T>(tuples, plane_stride, list, n_list, (uint32_t)wave + WAVES, lane, c1);
-      for (uint32_t ci = (uint32_t)wave; ci < n_list; ci += WAVES) {
-        p2_fetch<T>(tuples, plane_stride, list, n_list, ci + 2u * WAVES, lane, c2);
-        p2_consume<T>(p, c0, table, aux_lds, slots, local_mask);
-#pragma unroll
-        for (int pl = 0; pl < T; pl++) { c0[pl] = c1[pl]; c1[pl] = c2[pl]; }
+      // two chunks per wavefront in flight, NO register rotation (a copy c0 = c1 reads the younger load's target: the compiler then
+      // waits for every load in flight); the loop is unrolled by two, each half consuming one buffer while the other travels
+      u32x4 c0[T], c1[T];
+      bool on0 = p2_fetch<T>(tuples, plane_stride, list, n_list, (uint32_t)wave, lane, c0), on1 = false;
+      for (uint32_t ci = (uint32_t)wave; ci < n_list; ci += 2u * WAVES) {
+        on1 = p2_fetch<T>(tuples, plane_stride, list, n_list, ci + WAVES, lane, c1);
+        p2_consume<T, GATHER>(p, c0, on0, table, aux_lds, slots, local_mask);
+        on0 = p2_fetch<T>(tuples, plane_stride, list, n_list, ci + 2u * WAVES, lane, c0);
+        p2_consume<T, GATHER>(p, c1, on1, table, aux_lds, slots, local_mask);
       }
     }
     __syncthreads();
@@ -853,9 +856,13 @@ __device__ __forceinline__ void p2_aggregate_body(const PgQueryPlan& p) {
   }
 }
 
-#define P2_AGGREGATE(NAME, T) \
-  extern "C" __global__ void __launch_bounds__(PG_P2_AGG_THREADS) NAME(const PgQueryPlan p) { p2_aggregate_body<T>(p); }
-P2_AGGREGATE(pg_p2_aggregate_1, 1)
-P2_AGGREGATE(pg_p2_aggregate_2, 2)
-P2_AGGREGATE(pg_p2_aggregate_3, 3)
-P2_AGGREGATE(pg_p2_aggregate_4, 4)
+#define P2_AGGREGATE(NAME, T, GATHER) \
+  extern "C" __global__ void __launch_bounds__(PG_P2_AGG_THREADS) NAME(const PgQueryPlan p) { p2_aggregate_body<T, GATHER>(p); }
+P2_AGGREGATE(pg_p2_aggregate_1, 1, true)
+P2_AGGREGATE(pg_p2_aggregate_2, 2, true)
+P2_AGGREGATE(pg_p2_aggregate_3, 3, true)
+P2_AGGREGATE(pg_p2_aggregate_4, 4, true)
+P2_AGGREGATE(pg_p2_aggregate_1n, 1, false)
+P2_AGGREGATE(pg_p2_aggregate_2n, 2, false)
+P2_AGGREGATE(pg_p2_aggregate_3n, 3, false)
+P2_AGGREGATE(pg_p2_aggregate_4n, 4, false)

@@ -438,7 +438,7 @@ def test_wide_aggregations_match_oracle(wide_seg, q):
     g, o = wide_seg
     gb, ob = g.execute(q), o.execute(q)
     assert_same_block(gb, ob)
-    assert gb.stats.kernel.decode().startswith(("pg_fast_", "pg_generic_", "pg_radix_"))
+    assert gb.stats.kernel.decode().startswith(("pg_fast_", "pg_generic_", "pg_radix_", "pg_part_"))
 
 
 # ---- radix-partitioned group-by (PG_AGG_RADIX): one visit per doc, tuples bucketed by key range, LDS aggregation per bucket ---
