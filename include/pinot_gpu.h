@@ -163,6 +163,9 @@ typedef struct pg_query {
 #define PG_QUERY_FLAG_PROFILE 0x1          /* record per-kernel HIP-event timings into pg_exec_stats */
 #define PG_QUERY_FLAG_SKIP_STAR_TREE 0x2   /* QueryContext#isSkipStarTree (query option useStarTree=false) */
 #define PG_QUERY_FLAG_APPROX_FILTER_STATS 0x8 /* skip the exact numEntriesScannedInFilter of OR / NOT-over-scan shapes (stats_exact = 0) */
+#define PG_QUERY_FLAG_EXACT_FILTER_STATS 0x10 /* compute it whatever the segment's size: by default those shapes get the exact count up to
+                                                 2^26 docs (environment PG_EXACT_STATS_MAX_DOCS) — it costs one filter launch, one bitmap copy
+                                                 to the host and a host walk per scan / inverted leaf (profiles/r03_filter_stats_cost.txt) */
 #define PG_QUERY_FLAG_KEEP_DEVICE_TABLE 0x4 /* keep the dense accumulator table in HBM with the result (pg_result_merge / _all_reduce) */
 
 /* ExecutionStatistics (pinot-core/.../operator/ExecutionStatistics.java) + device timings. */
@@ -172,7 +175,7 @@ typedef struct pg_exec_stats {
   int64_t num_entries_scanned_post_filter;
   int64_t num_total_docs;
   int32_t num_groups_limit_reached;
-  int32_t stats_exact;            /* 1: num_entries_scanned_in_filter is the reference's count (always, unless PG_QUERY_FLAG_APPROX_FILTER_STATS) */
+  int32_t stats_exact;            /* 1: num_entries_scanned_in_filter is the reference's count (see PG_QUERY_FLAG_EXACT_FILTER_STATS) */
   /* HIP-event timings on the stream the kernels ran on, milliseconds; 0 when not profiled */
   float device_ms_total;
   float device_ms_filter;

@@ -74,7 +74,8 @@ struct Comm {
   int device = 0;
   int world = 1;
   int rank = 0;
-  DeviceBuffer scratch;   // signature exchange, gathered dictId sets
+  DeviceBuffer scratch;   // merged image of a table (signature probe, accumulators, states) + gathered dictId sets
+  int64_t probe[4] = {0, 0, 0, 0};   // {sig, -sig} out and back; {full-scan entries, total docs} summed over the ranks
 };
 
 void comm_unique_id(void* out128) {
@@ -124,13 +125,17 @@ void comm_destroy(Comm* c) {
   delete c;
 }
 
-// Every rank calls this with its own result of the same query.  In place on the retained device table:
+// Every rank calls this with its own result of the same query.  ONE grouped RCCL launch, out of place into the communicator's scratch:
+//   layout signature                 ncclMax on {sig, -sig}: mismatched tables fail on every rank alike
 //   row o of the accumulator table   ncclSum (COUNT, SUM limbs) / ncclMin / ncclMax on int64 (float MIN / MAX are order-preserving
 //                                    int64 keys, float SUMs are fixed-point int64 limbs: every merge is exact and order-free)
 //   statistics counters + tail       ncclSum on int64
 //   HyperLogLog registers            ncclMax on uint8
-//   dictId sets                      all-gather + OR (RCCL has no bitwise reduction)
-// preceded by a min / max exchange of the layout signature, so that mismatched tables fail on every rank alike.
+//   dictId sets                      all-gather, then OR (RCCL has no bitwise reduction)
+// then one stream synchronisation: the signature and the summed doc count (the accumulators' overflow bounds) are checked on the
+// host, and only then is the merged image copied over the table the query left in HBM — a refused merge leaves the result as it was
+// (PG_ERR_UNSUPPORTED → merge on the host by values).  (Round 2 exchanged the signature in a launch of its own with a second
+// synchronisation, and merged in place.)
 void result_all_reduce(Result& r, Comm& c) {
   if (!r.dev) fail(PG_ERR_INVALID_ARGUMENT, "pg_result_all_reduce needs a result executed with PG_QUERY_FLAG_KEEP_DEVICE_TABLE");
   DeviceTable& T = *r.dev;
@@ -139,49 +144,69 @@ void result_all_reduce(Result& r, Comm& c) {
   hipStream_t stream = thread_stream(T.device);
   Rccl& R = rccl();
   const PgQueryPlan& D = T.plan->dev;
-  device_table_tail_store(T, stream);
-  // ---- layout check: max(sig) and max(-sig) over the ranks must describe one value -----------------------------------------------
-  if (c.scratch.size < 64) c.scratch.alloc(64);
-  const int64_t sig = table_signature(T);
-  int64_t probe[2] = {sig, -sig};
-  PG_HIP(hipMemcpyAsync(c.scratch.ptr, probe, sizeof(probe), hipMemcpyHostToDevice, stream));
-  PG_NCCL(R.AllReduce(c.scratch.ptr, c.scratch.ptr, 2, kNcclInt64, kNcclMax, c.comm, stream));
-  PG_HIP(hipMemcpyAsync(probe, c.scratch.ptr, sizeof(probe), hipMemcpyDeviceToHost, stream));
-  PG_HIP(hipStreamSynchronize(stream));
-  if (probe[0] != sig || probe[1] != -sig)
-    fail(PG_ERR_UNSUPPORTED, "pg_result_all_reduce: the ranks' results do not share their table layout (different key space, aggregations or "
-                             "fixed-point scale): merge on the host by values");
-  // ---- the merge: one grouped launch -------------------------------------------------------------------------------------------------
-  const int64_t G = std::max(D.n_groups, 1);
-  int64_t* table = T.table.as<int64_t>();
-  std::vector<std::pair<size_t, size_t>> set_regions;   // (offset, bytes) of dictId-set regions: gathered, then OR-ed
   for (int o = 0; o < D.n_ops; o++)   // refusals before the group opens: an exception between GroupStart and GroupEnd would leave it open
     if (D.ops[o].fn == PG_ACC_SUM && D.ops[o].is_float == 1)
       fail(PG_ERR_UNSUPPORTED, "pg_result_all_reduce: a floating-point SUM accumulated in double (a column holding NaN / Inf) does not merge exactly");
+  device_table_tail_store(T, stream);
+  const int64_t G = std::max(D.n_groups, 1);
+  const size_t n_table = (size_t)T.n_out + PG_MAX_STATS + 2;   // accumulators, statistics counters, {full-scan entries, total docs}
+  size_t set_bytes = 0;
+  for (int x = 0; x < D.n_aux; x++) if (D.aux[x].kind == PG_AUX_DICT_SET) set_bytes += T.plan->aux_bytes[(size_t)x];
+  // scratch: [probe 2 x int64 | pad to 64][table image][aux image][gathered sets x world]
+  const size_t off_table = 64, off_aux = off_table + n_table * 8, off_gather = (off_aux + T.aux_total + 63) & ~(size_t)63;
+  const size_t need = off_gather + set_bytes * (size_t)c.world + 64;
+  if (c.scratch.size < need) c.scratch.alloc(need + need / 4);
+  uint8_t* S = c.scratch.as<uint8_t>();
+  int64_t* table = T.table.as<int64_t>();
+  int64_t* image = reinterpret_cast<int64_t*>(S + off_table);
+  const int64_t sig = table_signature(T);
+  c.probe[0] = sig; c.probe[1] = -sig;
+  PG_HIP(hipMemcpyAsync(S, c.probe, 16, hipMemcpyHostToDevice, stream));
   PG_NCCL(R.GroupStart());
+  PG_NCCL(R.AllReduce(S, S, 2, kNcclInt64, kNcclMax, c.comm, stream));
   for (int o = 0; o < D.n_ops && T.n_out > 0; o++) {
     const int red = D.ops[o].fn == PG_ACC_MIN ? kNcclMin : (D.ops[o].fn == PG_ACC_MAX ? kNcclMax : kNcclSum);
-    PG_NCCL(R.AllReduce(table + (int64_t)o * G, table + (int64_t)o * G, (size_t)G, kNcclInt64, red, c.comm, stream));
+    PG_NCCL(R.AllReduce(table + (int64_t)o * G, image + (int64_t)o * G, (size_t)G, kNcclInt64, red, c.comm, stream));
   }
-  PG_NCCL(R.AllReduce(table + T.n_out, table + T.n_out, PG_MAX_STATS + 2, kNcclInt64, kNcclSum, c.comm, stream));
-  size_t off = 0;
-  for (int x = 0; x < D.n_aux; x++) {
-    const size_t bytes = T.plan->aux_bytes[(size_t)x];
-    uint8_t* region = T.aux.as<uint8_t>() + off;
-    if (D.aux[x].kind == PG_AUX_DICT_SET) set_regions.push_back({off, bytes});
-    else PG_NCCL(R.AllReduce(region, region, bytes, kNcclUint8, kNcclMax, c.comm, stream));
-    off += bytes;
+  PG_NCCL(R.AllReduce(table + T.n_out, image + T.n_out, PG_MAX_STATS + 2, kNcclInt64, kNcclSum, c.comm, stream));
+  {
+    size_t off = 0, goff = 0;
+    for (int x = 0; x < D.n_aux; x++) {
+      const size_t bytes = T.plan->aux_bytes[(size_t)x];
+      uint8_t* region = T.aux.as<uint8_t>() + off;
+      if (D.aux[x].kind == PG_AUX_DICT_SET) {
+        PG_NCCL(R.AllGather(region, S + off_gather + goff, bytes, kNcclUint8, c.comm, stream));
+        goff += bytes * (size_t)c.world;
+      } else {
+        PG_NCCL(R.AllReduce(region, S + off_aux + off, bytes, kNcclUint8, kNcclMax, c.comm, stream));
+      }
+      off += bytes;
+    }
   }
   PG_NCCL(R.GroupEnd());
-  for (auto& sr : set_regions) {
-    const size_t need = sr.second * (size_t)c.world;
-    if (c.scratch.size < need) c.scratch.alloc(need);
-    uint8_t* region = T.aux.as<uint8_t>() + sr.first;
-    PG_NCCL(R.AllGather(region, c.scratch.ptr, sr.second, kNcclUint8, c.comm, stream));
-    merge_sets_on_stream(reinterpret_cast<uint32_t*>(region), c.scratch.as<uint32_t>(), (int64_t)(sr.second / 4), c.world, stream);
+  {   // dictId sets: OR of the gathered copies into the aux image
+    size_t off = 0, goff = 0;
+    for (int x = 0; x < D.n_aux; x++) {
+      const size_t bytes = T.plan->aux_bytes[(size_t)x];
+      if (D.aux[x].kind == PG_AUX_DICT_SET) {
+        PG_HIP(hipMemsetAsync(S + off_aux + off, 0, bytes, stream));
+        merge_sets_on_stream(reinterpret_cast<uint32_t*>(S + off_aux + off), reinterpret_cast<const uint32_t*>(S + off_gather + goff), (int64_t)(bytes / 4),
+                             c.world, stream);
+        goff += bytes * (size_t)c.world;
+      }
+      off += bytes;
+    }
   }
+  PG_HIP(hipMemcpyAsync(c.probe, S, 16, hipMemcpyDeviceToHost, stream));
+  PG_HIP(hipMemcpyAsync(c.probe + 2, image + T.n_out + PG_MAX_STATS, 16, hipMemcpyDeviceToHost, stream));   // {full-scan entries, total docs} summed
   PG_HIP(hipStreamSynchronize(stream));
-  result_reassemble(r);
+  if (c.probe[0] != sig || c.probe[1] != -sig)
+    fail(PG_ERR_UNSUPPORTED, "pg_result_all_reduce: the ranks' results do not share their table layout (different key space, dictionaries, "
+                             "aggregations or fixed-point scale): merge on the host by values");
+  check_merge_bounds(T, c.probe[3]);
+  PG_HIP(hipMemcpyAsync(table, image, n_table * 8, hipMemcpyDeviceToDevice, stream));
+  if (T.aux_total) PG_HIP(hipMemcpyAsync(T.aux.ptr, S + off_aux, T.aux_total, hipMemcpyDeviceToDevice, stream));
+  result_reassemble(r);   // copies the merged table back (its one synchronisation) and rebuilds the groups
 }
 
 }  // namespace pg

@@ -328,10 +328,11 @@ static double order_key_to_double(int64_t k) {
 // numEntriesScannedInFilter for plans whose count the kernels' counters do not give (CompiledPlan::stats_exact == false): the match
 // bitmap of every Scan / Inverted leaf comes from a filter launch of its own, the reference's iterator automaton runs over the
 // bitmaps on the host (pg_filter_stats.cpp).
-static int64_t exact_entries_scanned(CompiledPlan& P, ThreadCtx& ctx) {
+static int64_t exact_entries_scanned(CompiledPlan& P, ThreadCtx& ctx, const CancelToken* cancel) {
   StatLeafBits bits;
   const int32_t n_docs = P.space_docs;
   for (auto& lf : P.stat_leaves) {
+    if (cancel && cancel->requested.load(std::memory_order_acquire)) fail(PG_ERR_CANCELLED, "query cancelled (EarlyTerminationException)");
     CompiledPlan& L = *lf.second;
     PgQueryPlan D = L.dev;
     const size_t dev_words = (size_t)std::max(D.n_tiles, 1) * PG_TILE_WORDS;
@@ -669,7 +670,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
     if (!hashed && D.radix_packed) {
       D.radix_stage = 32;
       D.radix_stride = 4;
-      stage_lds = ((size_t)2 * stage_waves * D.radix_buckets + (size_t)stage_waves * 144 + (size_t)stage_waves * D.radix_buckets * 64) * 4;
+      stage_lds = ((size_t)2 * stage_waves * D.radix_buckets + (size_t)stage_waves * 160 /* PG_PK_WORK */ + (size_t)stage_waves * D.radix_buckets * 64) * 4;
     }
     const size_t pad_tuples = D.radix_stage ? (size_t)rgrid * (size_t)D.radix_buckets * (size_t)stage_waves * (size_t)D.radix_stage : 0;
     ThreadCtx::grow(ctx.radix_tuples, ((size_t)matched_now + pad_tuples) * (size_t)D.radix_stride + 256);
@@ -836,9 +837,14 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
   H.full_scan_entries = P.full_scan_entries;
   H.total_docs = seg.total_docs;
   int64_t exact_entries = -1;
-  if (!P.stats_exact && !(q.flags & PG_QUERY_FLAG_APPROX_FILTER_STATS)) {
+  // exact numEntriesScannedInFilter of leapfrogged shapes: by default up to 2^26 docs (one filter launch + one bitmap copy + a host walk per
+  // leaf: milliseconds there, a multiple of the query on a 10^9-doc segment), on request at any size
+  static const int64_t exact_max_docs = getenv("PG_EXACT_STATS_MAX_DOCS") ? atoll(getenv("PG_EXACT_STATS_MAX_DOCS")) : ((int64_t)1 << 26);
+  const bool want_exact = !(q.flags & PG_QUERY_FLAG_APPROX_FILTER_STATS) &&
+                          ((q.flags & PG_QUERY_FLAG_EXACT_FILTER_STATS) || (int64_t)P.space_docs <= exact_max_docs);
+  if (!P.stats_exact && want_exact) {
     check_cancel(cancel, &ctx);
-    exact_entries = exact_entries_scanned(P, ctx);
+    exact_entries = exact_entries_scanned(P, ctx, cancel);
     // the merged tables carry the count in the statistics tail: fold the exact value in as "full scan entries" of this segment
     H.full_scan_entries = exact_entries;
     for (int i = 1; i < PG_MAX_STATS; i++) H.stats[i] = 0;
@@ -1122,12 +1128,24 @@ int64_t table_signature(const DeviceTable& T) {
   for (size_t a = 0; a < T.plan->aggs.size(); a++) { mix((uint64_t)T.plan->aggs[a].function); mix((uint64_t)(uint32_t)T.plan->aggs[a].op_a); }
   for (int32_t c : T.plan->group_cards) mix((uint64_t)c);
   for (const Column* vd : T.plan->group_vdict) if (vd) mix(vd->vdict_hash);   // segment-local ids: only equal dictionaries merge
+  // dictIds index the table (group-by columns) and the DISTINCTCOUNT sets: different dictionaries of equal cardinality must not merge
+  for (uint64_t dh : T.plan->dict_hashes) mix(dh);
   return (int64_t)(h >> 2);   // 62 bits: survives ncclMax / negation
 }
+// The plan-time guarantees of the accumulators hold per segment (docs x largest |value| < 2^63 for an int64 SUM; < 2^31 docs for
+// 32-bit digits summed in int64): a merged table must still satisfy them over the docs of all the segments it folds.
+void check_merge_bounds(const DeviceTable& T, int64_t total_docs) {
+  const CompiledPlan& P = *T.plan;
+  if (P.has_digit_sums && total_docs >= ((int64_t)1 << 31))
+    fail(PG_ERR_UNSUPPORTED, "merge: %lld docs in total overflow the digit accumulators of an exact SUM (merge on the host by values)", (long long)total_docs);
+  if (P.sum_max_abs && (unsigned __int128)P.sum_max_abs * (unsigned __int128)std::max<int64_t>(total_docs, 1) >= ((unsigned __int128)1 << 63))
+    fail(PG_ERR_UNSUPPORTED, "merge: a SUM over %lld docs in total may leave int64 (merge on the host by values)", (long long)total_docs);
+}
 void device_table_tail_store(DeviceTable& T, hipStream_t stream) {   // full-scan entries + total docs behind the statistics counters
-  const int64_t tail[2] = {T.full_scan_entries, T.num_total_docs};
-  PG_HIP(hipMemcpyAsync(T.table.as<int64_t>() + T.n_out + PG_MAX_STATS, tail, sizeof(tail), hipMemcpyHostToDevice, stream));
-  PG_HIP(hipStreamSynchronize(stream));
+  // asynchronous: the source lives in the table object (round 2 synchronised the stream here, once per merge)
+  T.tail_host[0] = T.full_scan_entries;
+  T.tail_host[1] = T.num_total_docs;
+  PG_HIP(hipMemcpyAsync(T.table.as<int64_t>() + T.n_out + PG_MAX_STATS, T.tail_host, sizeof(T.tail_host), hipMemcpyHostToDevice, stream));
 }
 
 void merge_sets_on_stream(uint32_t* dst, const uint32_t* gathered, int64_t n_words, int n_src, hipStream_t stream) {
@@ -1141,7 +1159,8 @@ void result_merge(Result& dst, Result& src) {
   DeviceTable& B = *src.dev;
   if (A.device != B.device) fail(PG_ERR_INVALID_ARGUMENT, "pg_result_merge: results live on devices %d and %d (use pg_result_all_reduce across devices)", A.device, B.device);
   if (table_signature(A) != table_signature(B))
-    fail(PG_ERR_UNSUPPORTED, "pg_result_merge: the two results do not share their table layout (different key space or aggregations): merge on the host by values");
+    fail(PG_ERR_UNSUPPORTED, "pg_result_merge: the two results do not share their table layout (different key space, dictionaries or aggregations): merge on the host by values");
+  check_merge_bounds(A, A.num_total_docs + B.num_total_docs);
   ThreadCtx& ctx = ctx_on(A.device);
   device_table_tail_store(A, ctx.stream);
   device_table_tail_store(B, ctx.stream);
@@ -1196,9 +1215,12 @@ std::unique_ptr<DocIdSet> execute_filter(Segment& seg, const pg_filter_node* fil
   PG_HIP(hipMemcpyAsync(out->tile_counts.data(), ctx.tile_counts.ptr, out->tile_counts.size() * 4, hipMemcpyDeviceToHost, ctx.stream));
   PG_HIP(hipStreamSynchronize(ctx.stream));
   fill_stats(out->stats, P, P.full_scan_entries, seg.total_docs, stats_host);
-  if (!P.stats_exact) {
-    out->stats.num_entries_scanned_in_filter = exact_entries_scanned(P, ctx);
-    out->stats.stats_exact = 1;
+  {   // pg_filter_exec has no flags: the exact count of leapfrogged shapes up to the default size (see execute_query)
+    static const int64_t exact_max_docs = getenv("PG_EXACT_STATS_MAX_DOCS") ? atoll(getenv("PG_EXACT_STATS_MAX_DOCS")) : ((int64_t)1 << 26);
+    if (!P.stats_exact && (int64_t)P.space_docs <= exact_max_docs) {
+      out->stats.num_entries_scanned_in_filter = exact_entries_scanned(P, ctx, nullptr);
+      out->stats.stats_exact = 1;
+    }
   }
   out->stats.star_tree_index = -1;
   snprintf(out->stats.kernel, sizeof(out->stats.kernel), "%s", kname);

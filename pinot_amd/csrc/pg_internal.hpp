@@ -105,6 +105,7 @@ struct Column {
   int64_t int_min = 0, int_max = 0;
   bool dict_affine = false;                     // INT / LONG dictionary whose values are base + step x dictId (ids, dense enumerations)
   int64_t dict_base = 0, dict_step = 0;
+  uint64_t dict_hash = 0;                       // FNV-1a of the dictionary bytes: tables merge element-wise only over equal dictionaries
   std::map<int, DeviceBuffer> hll_luts;         // per log2m: (register index | rank << 16) of every dictionary value
   // virtual dictionary of a raw group-by column (pg_vdict.hip): a Column of bit-packed ids whose `vdict_keys` are the distinct values
   // (order-preserving 64-bit keys, ascending); built at first use, under the segment's lock
@@ -273,6 +274,11 @@ struct CompiledPlan {
   std::vector<size_t> aux_bytes;     // bytes of each auxiliary region (256-byte multiples)
   int32_t star_tree_index = -1;      // the star-tree whose doc space the plan runs on
   int32_t space_docs = 0;            // docs of that doc space (the segment's own when no star-tree is used)
+  // what pg_result_merge / pg_result_all_reduce check beyond the layout: the dictionaries behind dictId-indexed state (group-by
+  // columns, DISTINCTCOUNT sets, dictionary-fed HyperLogLogs) must be equal, and the summed accumulators must still hold the sum
+  std::vector<uint64_t> dict_hashes;
+  uint64_t sum_max_abs = 0;          // largest |value| an int64 SUM accumulator adds per doc (0: none)
+  bool has_digit_sums = false;       // 32-bit digits summed in int64 accumulators: safe below 2^31 docs in total
   bool non_scan_based = false;       // NonScanBasedAggregationOperator: answered from dictionaries on the host
 };
 
@@ -314,6 +320,7 @@ struct DeviceTable {
   DeviceBuffer table, aux;
   int64_t full_scan_entries = 0;   // summed over the merged segments
   int64_t num_total_docs = 0;
+  int64_t tail_host[2] = {0, 0};   // source of the asynchronous copy of the two above behind the statistics counters
 };
 struct Result {
   std::unique_ptr<DeviceTable> dev;    // PG_QUERY_FLAG_KEEP_DEVICE_TABLE
@@ -355,6 +362,7 @@ void result_all_reduce(Result& r, Comm& c);
 // shared by result_merge / result_all_reduce (pg_exec.hip): rebuild the host view of a result from its device table
 void result_reassemble(Result& r);
 int64_t table_signature(const DeviceTable& T);
+void check_merge_bounds(const DeviceTable& T, int64_t total_docs);
 void device_table_tail_store(DeviceTable& T, hipStream_t stream);
 void merge_sets_on_stream(uint32_t* dst, const uint32_t* gathered, int64_t n_words, int n_src, hipStream_t stream);
 hipStream_t thread_stream(int device);

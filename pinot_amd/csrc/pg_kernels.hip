@@ -1985,6 +1985,9 @@ PG_KERNEL __global__ void __launch_bounds__(PG_BLOCK) pg_hash_scatter_kernel(con
 // =====================================================================================================================
 #define PG_PK_RING 64u       // tuples per ring (two 128-byte lines)
 #define PG_PK_LINE 32u       // tuples per flushed line
+// dwords of a wavefront's flush work list: one (bucket, destination) pair per line, and a flush can complete
+// floor((buckets x 31 leftovers + 64 lanes x 8 new tuples) / 32) = 78 lines at 64 buckets — 80 pairs (round 2 sized it for 72)
+#define PG_PK_WORK 160
 struct PackedStage {
   uint32_t* tail;        // this wavefront's [buckets]: ring positions handed out so far
   uint32_t* head;        // this wavefront's [buckets]: ring positions flushed so far (multiple of PG_PK_LINE)
@@ -2086,8 +2089,8 @@ PG_KERNEL __global__ void __launch_bounds__(PG_BLOCK) pg_radix_scatter_packed_ke
   uint32_t* base = reinterpret_cast<uint32_t*>(smem);
   S.tail = base + (size_t)wave * P;
   S.head = base + (size_t)n_waves * P + (size_t)wave * P;
-  S.work = base + (size_t)2 * n_waves * P + (size_t)wave * 144;
-  S.ring = base + (size_t)2 * n_waves * P + (size_t)n_waves * 144 + (size_t)wave * P * PG_PK_RING;
+  S.work = base + (size_t)2 * n_waves * P + (size_t)wave * PG_PK_WORK;
+  S.ring = base + (size_t)2 * n_waves * P + (size_t)n_waves * PG_PK_WORK + (size_t)wave * P * PG_PK_RING;
   S.s_cnt = s_cnt;
   S.s_base = s_base;
   S.tuples = reinterpret_cast<uint32_t*>(p.radix_tuples);

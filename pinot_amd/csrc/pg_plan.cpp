@@ -1309,6 +1309,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     D.gcols[j].col_kind = PG_COL_FIXED_BIT;
     P.group_cols.push_back(c);
     P.group_cards.push_back(c->cardinality);
+    if (!raw) P.dict_hashes.push_back(c->dict_hash);
     // beyond any dense table (the reference's LongMapBasedHolder, DictionaryBasedGroupKeyGenerator.java:166-176): 64-bit raw
     // keys, hash-partitioned and aggregated in LDS hash tables (PG_AGG_RADIX_HASH); keys must stay below 2^62
     if (G > kMaxDenseGroups / std::max(c->cardinality, 1)) huge_key_space = true;
@@ -1341,20 +1342,23 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
   // holding NaN / Inf keeps the reference's IEEE double addition.
   std::vector<int32_t> src_fx_q(PG_MAX_SRCS, 0);
   auto sum_ops = [&](Column* c, int32_t si, AggOut& out) {
-    if (c->val_type == PG_V_I32) { out.op_a = op_index(PG_ACC_SUM, si, false); return; }
+    if (c->val_type == PG_V_I32) { out.op_a = op_index(PG_ACC_SUM, si, false); P.sum_max_abs = std::max<uint64_t>(P.sum_max_abs, (uint64_t)1 << 31); return; }
     if (c->val_type == PG_V_I64) {
       // one int64 holds the sum when docs x largest magnitude stays below 2^63
       if ((unsigned __int128)c->max_abs_int * (unsigned __int128)std::max(seg.total_docs, 1) < ((unsigned __int128)1 << 63)) {
         out.op_a = op_index(PG_ACC_SUM, si, false);
+        P.sum_max_abs = std::max<uint64_t>(P.sum_max_abs, std::max<uint64_t>(c->max_abs_int, 1));
         return;
       }
       out.op_a = op_index_kind(PG_ACC_SUM, si, PG_ACCV_LONG_DIGIT, 0);
       (void)op_index_kind(PG_ACC_SUM, si, PG_ACCV_LONG_DIGIT, 1);
       out.sum_limbs = 2;
       out.fx_q = 0;
+      P.has_digit_sums = true;
       return;
     }
     if (c->has_nonfinite) { out.op_a = op_index(PG_ACC_SUM, si, true); return; }
+    P.has_digit_sums = true;
     const int limbs = c->val_type == PG_V_F32 ? 3 : 4;
     const int q = c->fx_exp - 32 * limbs + 1;     // |x| * 2^-q < 2^(32 limbs - 1): the top digit stays below 2^31
     src_fx_q[(size_t)si] = q;
@@ -1442,7 +1446,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
       PgAuxOp& A = D.aux[D.n_aux];
       A.src = src_index(c);
       A.log2m = hll ? log2m : 0;
-      if (!hll) { A.kind = PG_AUX_DICT_SET; A.stride = (c->cardinality + 31) / 32; }
+      if (!hll) { A.kind = PG_AUX_DICT_SET; A.stride = (c->cardinality + 31) / 32; P.dict_hashes.push_back(c->dict_hash); }   // sets are indexed by dictId
       else if (c->has_dictionary) { A.kind = PG_AUX_HLL_DICT; A.stride = 1 << log2m; A.lut = hll_dict_lut(*c, log2m); }
       else { A.kind = PG_AUX_HLL_RAW; A.stride = 1 << log2m; }
       out.aux = D.n_aux++;

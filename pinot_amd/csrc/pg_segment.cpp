@@ -326,6 +326,11 @@ void segment_add_column(Segment& seg, const pg_column_desc& d) {
            (unsigned long long)d.dictionary.size, c.cardinality, c.dict_bytes_per_value);
     const uint8_t* dp = (const uint8_t*)d.dictionary.addr;
     c.dict_host.assign(dp, dp + need);
+    {
+      uint64_t h = 1469598103934665603ULL;
+      for (size_t i = 0; i < need; i++) { h ^= dp[i]; h *= 1099511628211ULL; }
+      c.dict_hash = h ^ ((uint64_t)c.data_type << 56) ^ (uint64_t)(uint32_t)c.cardinality;
+    }
     // native-endian copy for dictionary-encoded metric / value lookups on the device
     if (c.data_type == PG_TYPE_INT || c.data_type == PG_TYPE_FLOAT) {
       std::vector<uint32_t> v((size_t)c.cardinality);
