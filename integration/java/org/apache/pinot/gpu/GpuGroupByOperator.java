@@ -121,7 +121,7 @@ public class GpuGroupByOperator extends BaseOperator<BaseResultsBlock> {
         }
         holders[a] = holder;
       }
-      GroupByResultsBlock block = new GroupByResultsBlock(dataSchema(groupBy, functions),
+      GroupByResultsBlock block = new GroupByResultsBlock(dataSchema(groupBy, functions, GpuResultObjects.keyTypes(_segment, groupBy)),
           new AggregationGroupByResult(new ArrayGroupKeyGenerator(keys), functions, holders), _queryContext);
       block.setNumGroupsLimitReached(_stats[4] != 0);
       return block;
@@ -177,13 +177,13 @@ public class GpuGroupByOperator extends BaseOperator<BaseResultsBlock> {
     }
   }
 
-  private static DataSchema dataSchema(List<ExpressionContext> groupBy, AggregationFunction[] functions) {   // GroupByOperator.java:74-97
+  private static DataSchema dataSchema(List<ExpressionContext> groupBy, AggregationFunction[] functions, DataSchema.ColumnDataType[] keyTypes) {   // GroupByOperator.java:74-97
     int n = groupBy.size() + functions.length;
     String[] names = new String[n];
     DataSchema.ColumnDataType[] types = new DataSchema.ColumnDataType[n];
     for (int i = 0; i < groupBy.size(); i++) {
       names[i] = groupBy.get(i).toString();
-      types[i] = DataSchema.ColumnDataType.OBJECT;   // replaced from the segment's column metadata in GpuResultObjects.keyTypes
+      types[i] = keyTypes[i];
     }
     for (int i = 0; i < functions.length; i++) {
       names[groupBy.size() + i] = functions[i].getResultColumnName();

@@ -7,6 +7,11 @@
  *
  *   pinot.server.query.executor.plan.maker.class=org.apache.pinot.gpu.GpuInstancePlanMaker
  *   pinot.server.gpu.devices=0,1,2,3,4,5,6,7      # segments are spread round-robin over these GPUs (segment -> GPU map)
+ *   pinot.server.gpu.library.merge=true           # one RCCL communicator per GPU (pg_comm_init_all) for tables whose segments share
+ *                                                 # their dictionaries: a combine operator may then fold the per-GPU partial tables with
+ *                                                 # PinotGpu.resultMerge (same GPU) / resultAllReduce (across GPUs) before decoding groups;
+ *                                                 # UnsupportedOperationException (different dictionaries, hashed key spaces, trimming)
+ *                                                 # means: merge by values in IndexedTable, as GroupByCombineOperator always does
  */
 package org.apache.pinot.gpu;
 
@@ -21,6 +26,8 @@ import org.apache.pinot.spi.env.PinotConfiguration;
 
 public class GpuInstancePlanMaker extends InstancePlanMakerImplV2 {
   private GpuSegmentRegistry _registry;
+  private int[] _devices;
+  private long[] _comms;   // null unless pinot.server.gpu.library.merge: _comms[i] is the communicator of _devices[i]
 
   @Override
   public void init(PinotConfiguration config) {
@@ -32,6 +39,22 @@ public class GpuInstancePlanMaker extends InstancePlanMakerImplV2 {
     }
     PinotGpu.init(ordinals[0]);
     _registry = new GpuSegmentRegistry(ordinals);
+    _devices = ordinals;
+    if (Boolean.parseBoolean(config.getProperty("pinot.server.gpu.library.merge", "false")) && ordinals.length > 1) {
+      long[] comms = new long[ordinals.length];
+      PinotGpu.commInitAll(ordinals, comms);   // RuntimeException when librccl cannot be loaded: the server then fails fast at start-up
+      _comms = comms;
+    }
+  }
+
+  /** The RCCL communicator of `device` for PinotGpu.resultAllReduce, or 0 when the library merge is not configured. */
+  public long communicatorOf(int device) {
+    for (int i = 0; _comms != null && i < _devices.length; i++) {
+      if (_devices[i] == device) {
+        return _comms[i];
+      }
+    }
+    return 0;
   }
 
   @Override

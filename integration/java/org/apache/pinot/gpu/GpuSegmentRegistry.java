@@ -73,6 +73,16 @@ public final class GpuSegmentRegistry {
             md.getBitsPerElement(), md.isSorted(), GpuBuffers.dictionaryBytesPerValue(md),
             GpuBuffers.address(fwd), fwd.size(), GpuBuffers.dictionaryValuesAddress(dict), GpuBuffers.dictionaryValuesSize(dict, md),
             inv == null ? 0 : GpuBuffers.address(inv), inv == null ? 0 : inv.size());
+        if (reader.hasIndexFor(column, StandardIndexes.range())) {
+          // DataSource#getRangeIndex: RANGE predicates then take RangeIndexBasedFilterOperator's place in the plan
+          // (FilterOperatorUtils.java:99-131); a legacy (version 1) index is refused by the library: the column keeps its scan leaf
+          PinotDataBuffer range = reader.getIndexFor(column, StandardIndexes.range());
+          try {
+            PinotGpu.segmentSetRangeIndex(h, column, GpuBuffers.address(range), range.size());
+          } catch (UnsupportedOperationException legacy) {
+            // BitSlicedRangeIndexReader.java:41-58 reads version 2 only; RangeIndexReaderImpl (version 1) answers on the Java side
+          }
+        }
         if (reader.hasIndexFor(column, StandardIndexes.nullValueVector())) {
           PinotDataBuffer nulls = reader.getIndexFor(column, StandardIndexes.nullValueVector());
           PinotGpu.segmentSetNullVector(h, column, GpuBuffers.address(nulls), nulls.size());

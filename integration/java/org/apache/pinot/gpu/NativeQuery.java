@@ -78,6 +78,21 @@ public final class NativeQuery implements AutoCloseable {
     return new NativeQuery(PinotGpu.queryParse(b, b.position()));
   }
 
+  /** pg_agg_function of a star-tree function-column pair's function type; -1 for functions the GPU path never reads. */
+  static int functionCode(org.apache.pinot.segment.spi.AggregationFunctionType type) {
+    switch (type) {
+      case COUNT: return 0;
+      case SUM: return 1;
+      case MIN: return 2;
+      case MAX: return 3;
+      case AVG: return 4;
+      case DISTINCTCOUNT: return 5;
+      case DISTINCTCOUNTHLL: return 6;
+      case MINMAXRANGE: return 7;
+      default: return -1;
+    }
+  }
+
   private static int function(AggregationFunction f) {
     switch (f.getType()) {
       case COUNT: return 0;

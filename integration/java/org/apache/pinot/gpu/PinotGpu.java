@@ -34,6 +34,8 @@ public final class PinotGpu {
       long dictSize, long invAddr, long invSize);
   public static native void segmentSetNullVector(long segment, String column, long addr, long size);
   public static native void segmentSetQueryableDocIds(long segment, long addr, long size);
+  public static native void segmentSetRangeIndex(long segment, String column, long addr, long size);   // the `range_index` entry (version 2)
+  public static native long directBufferAddress(ByteBuffer direct);   // GetDirectBufferAddress: GpuBuffers.address
   public static native void segmentAddStarTree(long segment, int numDocs, int maxLeafRecords, String[] dimensions,
       long[] dimAddrSize, int[] pairFunctions, int[] pairTypes, String[] pairColumns, long[] pairAddrSize, long treeAddr,
       long treeSize);
@@ -45,6 +47,7 @@ public final class PinotGpu {
   public static native int querySupported(long segment, long query);          // PG_OK or PG_ERR_UNSUPPORTED
   public static native long cancelCreate();
   public static native void cancelRequest(long token);
+  public static native void cancelReset(long token);
   public static native void cancelDestroy(long token);
   public static native long queryExec(long segment, long query, long cancelToken);
 
@@ -61,6 +64,19 @@ public final class PinotGpu {
   public static native void resultHllRegisters(long result, int aggregation, byte[] out);
   public static native void resultStats(long result, long[] out5);
   public static native void resultFree(long result);
+
+  // GroupByCombineOperator in the library: results executed with QUERY_FLAG_KEEP_DEVICE_TABLE over segments that share their
+  // dictionaries merge element-wise in HBM; UnsupportedOperationException -> merge by values (IndexedTable) as usual
+  public static final int QUERY_FLAG_SKIP_STAR_TREE = 0x2, QUERY_FLAG_KEEP_DEVICE_TABLE = 0x4, QUERY_FLAG_APPROX_FILTER_STATS = 0x8,
+      QUERY_FLAG_EXACT_FILTER_STATS = 0x10;
+  public static final int COMM_UNIQUE_ID_BYTES = 128;
+  public static native void resultMerge(long dst, long src);                 // same device
+  public static native void resultAllReduce(long result, long comm);         // collective over the communicator's ranks (RCCL)
+  public static native void commGetUniqueId(byte[] out128);                  // rank 0, one process per GPU
+  public static native long commInitRank(int device, int worldSize, int rank, byte[] uniqueId128);
+  public static native void commInitAll(int[] devices, long[] outComms);     // one process, N GPUs: outComms[i] for devices[i]
+  public static native int commWorldSize(long comm);
+  public static native void commDestroy(long comm);
 
   public static native long filterExec(long segment, long query);
   public static native long docIdSetCardinality(long set);

@@ -54,11 +54,25 @@ static void f_SetLongArrayRegion(JNIEnv* env, jlongArray a, jsize start, jsize l
 static void* f_GetPrimitiveArrayCritical(JNIEnv* env, jarray a, jboolean* c) { (void)env; if (c) *c = 0; pins++; return a->data; }
 static void f_ReleasePrimitiveArrayCritical(JNIEnv* env, jarray a, void* p, jint mode) { (void)env; (void)mode; if (p == a->data) pins--; }
 static void* f_GetDirectBufferAddress(JNIEnv* env, jobject b) { (void)env; return b->kind == K_BUFFER ? b->data : NULL; }
+#define F_SET_REGION(NAME, T)                                                                                                \
+  static void NAME(JNIEnv* env, jarray a, jsize start, jsize len, const T* buf) {                                            \
+    (void)env;                                                                                                               \
+    if (start < 0 || len < 0 || start + len > a->length) { snprintf(pending_class, sizeof pending_class, "java/lang/ArrayIndexOutOfBoundsException"); return; } \
+    memcpy((T*)a->data + start, buf, (size_t)len * sizeof(T));                                                               \
+  }
+F_SET_REGION(f_SetIntArrayRegion, jint)
+F_SET_REGION(f_SetDoubleArrayRegion, jdouble)
+F_SET_REGION(f_SetByteArrayRegion, jbyte)
+static void f_GetByteArrayRegion(JNIEnv* env, jbyteArray a, jsize start, jsize len, jbyte* buf) {
+  (void)env;
+  if (start < 0 || len < 0 || start + len > a->length) { snprintf(pending_class, sizeof pending_class, "java/lang/ArrayIndexOutOfBoundsException"); return; }
+  memcpy(buf, (jbyte*)a->data + start, (size_t)len);
+}
 
 static const struct JNINativeInterface_ fake_functions = {
   f_FindClass, f_ThrowNew, f_GetStringUTFChars, f_ReleaseStringUTFChars, f_GetArrayLength, f_GetObjectArrayElement, f_GetIntArrayElements,
   f_GetLongArrayElements, f_ReleaseIntArrayElements, f_ReleaseLongArrayElements, f_SetLongArrayRegion, f_GetPrimitiveArrayCritical,
-  f_ReleasePrimitiveArrayCritical, f_GetDirectBufferAddress,
+  f_ReleasePrimitiveArrayCritical, f_GetDirectBufferAddress, f_SetIntArrayRegion, f_SetDoubleArrayRegion, f_SetByteArrayRegion, f_GetByteArrayRegion,
 };
 
 static int pending(void) { return pending_class[0] != 0; }
@@ -90,9 +104,9 @@ static void w_predicate(record* r, int type, const char* column, int n_values, c
   w_str(r, lower); w_str(r, upper); w_i32(r, 1); w_i32(r, 1);
 }
 /* SELECT d, COUNT(*), SUM(m), MAX(m) FROM t WHERE d IN (20, 30) AND m BETWEEN 100 AND 2999 GROUP BY d — NativeQuery.java's record */
-static void build_record(record* r) {
+static void build_record(record* r, int32_t flags) {
   r->n = 0;
-  w_i32(r, PGSHIM_QUERY_MAGIC); w_i32(r, 0); w_i32(r, 0); w_i32(r, 0);
+  w_i32(r, PGSHIM_QUERY_MAGIC); w_i32(r, flags); w_i32(r, 0); w_i32(r, 0);
   w_i32(r, 1); w_i32(r, 3); w_i32(r, 1); w_i32(r, 0);
   w_str(r, "d");
   w_i32(r, PG_AGG_COUNT); w_i32(r, 0); w_str(r, "*");
@@ -113,7 +127,7 @@ int main(void) {
 
   /* queryParse from a direct buffer, and its IllegalArgumentException */
   static record rec;
-  build_record(&rec);
+  build_record(&rec, 0);
   jobject direct = new_direct_buffer(rec.b);
   const jlong q = Java_org_apache_pinot_gpu_PinotGpu_queryParse(env, cls, direct, (jint)rec.n);
   if (!q || pending()) return fail("queryParse");
@@ -199,10 +213,64 @@ int main(void) {
   Java_org_apache_pinot_gpu_PinotGpu_resultLongs(env, cls, res, 0, 0, new_array(1, sizeof(jlong)));
   ok = ok && pending() && pins == 0;
   clear_pending();
-  /* cancellation: EarlyTerminationException, as BaseOperator#nextBlock throws it */
+  /* cancellation: EarlyTerminationException, as BaseOperator#nextBlock throws it; a reset token serves the next query */
   Java_org_apache_pinot_gpu_PinotGpu_cancelRequest(env, cls, cancel);
   ok = ok && Java_org_apache_pinot_gpu_PinotGpu_queryExec(env, cls, seg, q, cancel) == 0 && strstr(pending_class, "EarlyTerminationException") != NULL;
   clear_pending();
+  Java_org_apache_pinot_gpu_PinotGpu_cancelReset(env, cls, cancel);
+  {
+    const jlong again = Java_org_apache_pinot_gpu_PinotGpu_queryExec(env, cls, seg, q, cancel);
+    ok = ok && again != 0 && !pending();
+    if (again) Java_org_apache_pinot_gpu_PinotGpu_resultFree(env, cls, again);
+  }
+  /* directBufferAddress: what GpuBuffers.address(PinotDataBuffer) takes from a one-byte view; a non-direct object throws */
+  ok = ok && Java_org_apache_pinot_gpu_PinotGpu_directBufferAddress(env, cls, direct) == (jlong)(intptr_t)rec.b && !pending();
+  ok = ok && Java_org_apache_pinot_gpu_PinotGpu_directBufferAddress(env, cls, new_string("heap")) == 0 && strcmp(pending_class, "java/lang/IllegalArgumentException") == 0;
+  clear_pending();
+  /* a range index that does not parse: the library's message in a RuntimeException, the column keeps its scan leaf */
+  Java_org_apache_pinot_gpu_PinotGpu_segmentSetRangeIndex(env, cls, seg, new_string("m"), (jlong)(intptr_t)raw, 16);
+  ok = ok && pending() && pins == 0;
+  clear_pending();
+  /* GroupByCombineOperator in the library: two results of the same query kept in HBM (PG_QUERY_FLAG_KEEP_DEVICE_TABLE) merge element-wise;
+     a world-of-one communicator (pg_comm_init_all over device 0) all-reduces a result onto itself */
+  {
+    static record rec_keep;
+    build_record(&rec_keep, PG_QUERY_FLAG_KEEP_DEVICE_TABLE);
+    const jlong qk = Java_org_apache_pinot_gpu_PinotGpu_queryParse(env, cls, new_direct_buffer(rec_keep.b), (jint)rec_keep.n);
+    const jlong ra = Java_org_apache_pinot_gpu_PinotGpu_queryExec(env, cls, seg, qk, 0), rb = Java_org_apache_pinot_gpu_PinotGpu_queryExec(env, cls, seg, qk, 0);
+    ok = ok && qk && ra && rb && !pending();
+    Java_org_apache_pinot_gpu_PinotGpu_resultMerge(env, cls, ra, rb);
+    ok = ok && !pending();
+    jlongArray merged = new_array(ng, sizeof(jlong));
+    Java_org_apache_pinot_gpu_PinotGpu_resultLongs(env, cls, ra, 0, 0, merged);
+    for (int g = 0; g < ng; g++) ok = ok && ((jlong*)merged->data)[g] == 2 * ((jlong*)counts->data)[g];
+    jintArray devs = new_array(1, sizeof(jint));
+    jlongArray comms = new_array(1, sizeof(jlong));
+    Java_org_apache_pinot_gpu_PinotGpu_commInitAll(env, cls, devs, comms);
+    if (pending()) {   /* no librccl on this host: the binding surfaced the library's error; nothing else to check here */
+      printf("commInitAll: %s (%s)\n", pending_class, pending_message);
+      clear_pending();
+    } else {
+      const jlong comm = ((jlong*)comms->data)[0];
+      ok = ok && comm != 0 && Java_org_apache_pinot_gpu_PinotGpu_commWorldSize(env, cls, comm) == 1;
+      Java_org_apache_pinot_gpu_PinotGpu_resultAllReduce(env, cls, rb, comm);
+      ok = ok && !pending();
+      Java_org_apache_pinot_gpu_PinotGpu_resultLongs(env, cls, rb, 0, 0, merged);
+      for (int g = 0; g < ng; g++) ok = ok && ((jlong*)merged->data)[g] == ((jlong*)counts->data)[g];
+      jbyteArray uid = new_array(PG_COMM_UNIQUE_ID_BYTES, sizeof(jbyte));
+      Java_org_apache_pinot_gpu_PinotGpu_commGetUniqueId(env, cls, uid);
+      ok = ok && !pending();
+      Java_org_apache_pinot_gpu_PinotGpu_commGetUniqueId(env, cls, new_array(8, sizeof(jbyte)));
+      ok = ok && strcmp(pending_class, "java/lang/IllegalArgumentException") == 0;
+      clear_pending();
+      Java_org_apache_pinot_gpu_PinotGpu_commDestroy(env, cls, comm);
+      ok = ok && !pending();
+    }
+    Java_org_apache_pinot_gpu_PinotGpu_resultFree(env, cls, ra);
+    Java_org_apache_pinot_gpu_PinotGpu_resultFree(env, cls, rb);
+    Java_org_apache_pinot_gpu_PinotGpu_queryFree(env, cls, qk);
+    ok = ok && !pending() && pins == 0;
+  }
   Java_org_apache_pinot_gpu_PinotGpu_cancelDestroy(env, cls, cancel);
   Java_org_apache_pinot_gpu_PinotGpu_resultFree(env, cls, res);
   Java_org_apache_pinot_gpu_PinotGpu_queryFree(env, cls, q);

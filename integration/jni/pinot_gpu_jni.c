@@ -2,7 +2,8 @@
  * pinot_gpu_jni.c — JNI binding of libpinot_gpu.so for org.apache.pinot.gpu.PinotGpu (integration/java).  One JNI function per
  * pg_* entry point, no logic of its own: handles travel as jlong, buffers as (address, size) pairs of PinotDataBuffer
  * (pinot-segment-spi/.../memory/PinotDataBuffer.java:162-174 — columns exceed 2 GB, so no int-sized ByteBuffer views), results
- * are copied into caller-allocated primitive arrays (Get/ReleasePrimitiveArrayCritical), a status < 0 becomes a
+ * are copied into caller-allocated primitive arrays (through a native staging buffer + Set<Type>ArrayRegion: the pg_* accessors may
+ * launch kernels and synchronise a stream, which must not happen inside a Get/ReleasePrimitiveArrayCritical region), a status < 0 becomes a
  * RuntimeException carrying pg_last_error() (which BaseCombineOperator wraps with the segment name,
  * pinot-core/.../operator/combine/BaseCombineOperator.java:185-199); PG_ERR_CANCELLED becomes EarlyTerminationException
  * (pinot-core/.../operator/BaseOperator.java:44-46).
@@ -113,6 +114,21 @@ JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpu_segmentAddStarTree(JNI
   (*env)->ReleaseIntArrayElements(env, pairTypes, pt, JNI_ABORT);
   CHECK(st);
 }
+/* DataSource#getRangeIndex: the `range_index` entry as BitSlicedRangeIndexReader reads it (BitSlicedRangeIndexReader.java:41-58) */
+JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpu_segmentSetRangeIndex(JNIEnv* env, jclass c, jlong seg, jstring column, jlong addr, jlong size) {
+  (void)c;
+  const char* n = (*env)->GetStringUTFChars(env, column, NULL);
+  const int32_t st = pg_segment_set_range_index(SEG(seg), n, (const void*)(intptr_t)addr, (uint64_t)size);
+  (*env)->ReleaseStringUTFChars(env, column, n);
+  CHECK(st);
+}
+/* native address of a direct ByteBuffer: GpuBuffers takes PinotDataBuffer addresses from one-byte views (toDirectByteBuffer(0, 1)) */
+JNIEXPORT jlong JNICALL Java_org_apache_pinot_gpu_PinotGpu_directBufferAddress(JNIEnv* env, jclass c, jobject directBuffer) {
+  (void)c;
+  void* p = directBuffer ? (*env)->GetDirectBufferAddress(env, directBuffer) : NULL;
+  if (!p) { jclass x = (*env)->FindClass(env, "java/lang/IllegalArgumentException"); if (x) (*env)->ThrowNew(env, x, "not a direct buffer"); return 0; }
+  return (jlong)(intptr_t)p;
+}
 JNIEXPORT jlong JNICALL Java_org_apache_pinot_gpu_PinotGpu_segmentDeviceBytes(JNIEnv* env, jclass c, jlong seg) {
   (void)c; uint64_t b = 0; CHECK_RET(pg_segment_device_bytes(SEG(seg), &b), 0); return (jlong)b;
 }
@@ -137,6 +153,7 @@ JNIEXPORT jint JNICALL Java_org_apache_pinot_gpu_PinotGpu_querySupported(JNIEnv*
 }
 JNIEXPORT jlong JNICALL Java_org_apache_pinot_gpu_PinotGpu_cancelCreate(JNIEnv* env, jclass c) { (void)c; pg_cancel_t t = NULL; CHECK_RET(pg_cancel_create(&t), 0); return (jlong)(intptr_t)t; }
 JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpu_cancelRequest(JNIEnv* env, jclass c, jlong t) { (void)c; CHECK(pg_cancel_request((pg_cancel_t)(intptr_t)t)); }
+JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpu_cancelReset(JNIEnv* env, jclass c, jlong t) { (void)c; CHECK(pg_cancel_reset((pg_cancel_t)(intptr_t)t)); }
 JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpu_cancelDestroy(JNIEnv* env, jclass c, jlong t) { (void)c; CHECK(pg_cancel_destroy((pg_cancel_t)(intptr_t)t)); }
 JNIEXPORT jlong JNICALL Java_org_apache_pinot_gpu_PinotGpu_queryExec(JNIEnv* env, jclass c, jlong seg, jlong q, jlong cancel) {
   (void)c;
@@ -149,23 +166,29 @@ JNIEXPORT jlong JNICALL Java_org_apache_pinot_gpu_PinotGpu_queryExec(JNIEnv* env
 JNIEXPORT jint JNICALL Java_org_apache_pinot_gpu_PinotGpu_resultNumGroups(JNIEnv* env, jclass c, jlong r) { (void)c; int32_t n = 0; CHECK_RET(pg_result_num_groups(RES(r), &n), 0); return n; }
 JNIEXPORT jint JNICALL Java_org_apache_pinot_gpu_PinotGpu_resultKindOf(JNIEnv* env, jclass c, jlong r, jint agg) { (void)c; int32_t k = 0; CHECK_RET(pg_result_kind_of(RES(r), agg, &k), 0); return k; }
 JNIEXPORT jint JNICALL Java_org_apache_pinot_gpu_PinotGpu_resultGroupKeyType(JNIEnv* env, jclass c, jlong r, jint col) { (void)c; int32_t k = 0; CHECK_RET(pg_result_group_key_type(RES(r), col, &k), 0); return k; }
-#define COPY_OUT(NAME, JARR, CTYPE, CALL)                                                                      \
+/* Copy-out accessors: the native call fills a malloc'd staging buffer (it may block: kernels, stream synchronisation, device copies —
+ * the JNI specification forbids that between Get/ReleasePrimitiveArrayCritical), then one Set<Type>ArrayRegion moves the bytes. */
+#include <stdlib.h>
+#define COPY_OUT(NAME, JTYPE, CTYPE, SETREGION, CALL)                                                          \
   JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpu_##NAME {                                            \
     (void)c;                                                                                                    \
+    if (!out) { jclass x = (*env)->FindClass(env, "java/lang/NullPointerException"); if (x) (*env)->ThrowNew(env, x, "output array"); return; } \
     const jsize n = (*env)->GetArrayLength(env, out);                                                           \
-    CTYPE* p = (CTYPE*)(*env)->GetPrimitiveArrayCritical(env, out, NULL);                                       \
+    CTYPE* p = (CTYPE*)malloc((size_t)(n > 0 ? n : 1) * sizeof(CTYPE));                                         \
+    if (!p) { jclass x = (*env)->FindClass(env, "java/lang/OutOfMemoryError"); if (x) (*env)->ThrowNew(env, x, "staging buffer"); return; } \
     const int32_t st = CALL;                                                                                    \
-    (*env)->ReleasePrimitiveArrayCritical(env, out, p, 0);                                                      \
+    if (st >= 0) (*env)->SETREGION(env, out, 0, n, (const JTYPE*)p);                                            \
+    free(p);                                                                                                    \
     CHECK(st);                                                                                                  \
   }
-COPY_OUT(resultGroupDictIds(JNIEnv* env, jclass c, jlong r, jint col, jintArray out), jintArray, int32_t, pg_result_group_dict_ids(RES(r), col, p, n))
-COPY_OUT(resultGroupValuesLong(JNIEnv* env, jclass c, jlong r, jint col, jlongArray out), jlongArray, int64_t, pg_result_group_values_long(RES(r), col, p, n))
-COPY_OUT(resultGroupValuesDouble(JNIEnv* env, jclass c, jlong r, jint col, jdoubleArray out), jdoubleArray, double, pg_result_group_values_double(RES(r), col, p, n))
-COPY_OUT(resultDoubles(JNIEnv* env, jclass c, jlong r, jint agg, jint comp, jdoubleArray out), jdoubleArray, double, pg_result_doubles(RES(r), agg, comp, p, n))
-COPY_OUT(resultLongs(JNIEnv* env, jclass c, jlong r, jint agg, jint comp, jlongArray out), jlongArray, int64_t, pg_result_longs(RES(r), agg, comp, p, n))
-COPY_OUT(resultSetSizes(JNIEnv* env, jclass c, jlong r, jint agg, jintArray out), jintArray, int32_t, pg_result_set_sizes(RES(r), agg, p, n))
-COPY_OUT(resultSetDictIds(JNIEnv* env, jclass c, jlong r, jint agg, jintArray out), jintArray, int32_t, pg_result_set_dict_ids(RES(r), agg, p, (int64_t)n))
-COPY_OUT(resultHllRegisters(JNIEnv* env, jclass c, jlong r, jint agg, jbyteArray out), jbyteArray, uint8_t, pg_result_hll_registers(RES(r), agg, p, (int64_t)n))
+COPY_OUT(resultGroupDictIds(JNIEnv* env, jclass c, jlong r, jint col, jintArray out), jint, int32_t, SetIntArrayRegion, pg_result_group_dict_ids(RES(r), col, p, n))
+COPY_OUT(resultGroupValuesLong(JNIEnv* env, jclass c, jlong r, jint col, jlongArray out), jlong, int64_t, SetLongArrayRegion, pg_result_group_values_long(RES(r), col, p, n))
+COPY_OUT(resultGroupValuesDouble(JNIEnv* env, jclass c, jlong r, jint col, jdoubleArray out), jdouble, double, SetDoubleArrayRegion, pg_result_group_values_double(RES(r), col, p, n))
+COPY_OUT(resultDoubles(JNIEnv* env, jclass c, jlong r, jint agg, jint comp, jdoubleArray out), jdouble, double, SetDoubleArrayRegion, pg_result_doubles(RES(r), agg, comp, p, n))
+COPY_OUT(resultLongs(JNIEnv* env, jclass c, jlong r, jint agg, jint comp, jlongArray out), jlong, int64_t, SetLongArrayRegion, pg_result_longs(RES(r), agg, comp, p, n))
+COPY_OUT(resultSetSizes(JNIEnv* env, jclass c, jlong r, jint agg, jintArray out), jint, int32_t, SetIntArrayRegion, pg_result_set_sizes(RES(r), agg, p, n))
+COPY_OUT(resultSetDictIds(JNIEnv* env, jclass c, jlong r, jint agg, jintArray out), jint, int32_t, SetIntArrayRegion, pg_result_set_dict_ids(RES(r), agg, p, (int64_t)n))
+COPY_OUT(resultHllRegisters(JNIEnv* env, jclass c, jlong r, jint agg, jbyteArray out), jbyte, uint8_t, SetByteArrayRegion, pg_result_hll_registers(RES(r), agg, p, (int64_t)n))
 /* out[0..4] = numDocsScanned, numEntriesScannedInFilter, numEntriesScannedPostFilter, numTotalDocs, numGroupsLimitReached */
 JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpu_resultStats(JNIEnv* env, jclass c, jlong r, jlongArray out) {
   (void)c;
@@ -180,10 +203,55 @@ JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpu_resultFree(JNIEnv* env
 JNIEXPORT jlong JNICALL Java_org_apache_pinot_gpu_PinotGpu_filterExec(JNIEnv* env, jclass c, jlong seg, jlong q) {
   (void)c;
   pg_docidset_t s = NULL;
+  if (!q) { jclass x = (*env)->FindClass(env, "java/lang/NullPointerException"); if (x) (*env)->ThrowNew(env, x, "query"); return 0; }
   CHECK_RET(pg_filter_exec(SEG(seg), pgshim_query_get((const pgshim_query*)(intptr_t)q)->filter, &s), 0);
   return (jlong)(intptr_t)s;
 }
 JNIEXPORT jlong JNICALL Java_org_apache_pinot_gpu_PinotGpu_docIdSetCardinality(JNIEnv* env, jclass c, jlong s) { (void)c; int64_t n = 0; CHECK_RET(pg_docidset_cardinality(SET(s), &n), 0); return n; }
-COPY_OUT(docIdSetCopyWords(JNIEnv* env, jclass c, jlong s, jlongArray out), jlongArray, uint64_t, pg_docidset_copy_words(SET(s), p, (int64_t)n))
-COPY_OUT(docIdSetCopyDocIds(JNIEnv* env, jclass c, jlong s, jintArray out), jintArray, int32_t, pg_docidset_copy_docids(SET(s), p, (int64_t)n))
+COPY_OUT(docIdSetCopyWords(JNIEnv* env, jclass c, jlong s, jlongArray out), jlong, uint64_t, SetLongArrayRegion, pg_docidset_copy_words(SET(s), p, (int64_t)n))
+COPY_OUT(docIdSetCopyDocIds(JNIEnv* env, jclass c, jlong s, jintArray out), jint, int32_t, SetIntArrayRegion, pg_docidset_copy_docids(SET(s), p, (int64_t)n))
 JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpu_docIdSetFree(JNIEnv* env, jclass c, jlong s) { (void)c; CHECK(pg_docidset_free(SET(s))); }
+
+/* ---- GroupByCombineOperator in the library: segments sharing their key space merge element-wise in HBM (pinot_gpu.h) ------------------ */
+#define COMM(h) ((pg_comm_t)(intptr_t)(h))
+JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpu_resultMerge(JNIEnv* env, jclass c, jlong dst, jlong src) { (void)c; CHECK(pg_result_merge(RES(dst), RES(src))); }
+JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpu_resultAllReduce(JNIEnv* env, jclass c, jlong r, jlong comm) { (void)c; CHECK(pg_result_all_reduce(RES(r), COMM(comm))); }
+JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpu_commGetUniqueId(JNIEnv* env, jclass c, jbyteArray out) {
+  (void)c;
+  uint8_t id[PG_COMM_UNIQUE_ID_BYTES];
+  if (!out || (*env)->GetArrayLength(env, out) < PG_COMM_UNIQUE_ID_BYTES) {
+    jclass x = (*env)->FindClass(env, "java/lang/IllegalArgumentException"); if (x) (*env)->ThrowNew(env, x, "unique id needs 128 bytes"); return;
+  }
+  CHECK(pg_comm_get_unique_id(id));
+  (*env)->SetByteArrayRegion(env, out, 0, PG_COMM_UNIQUE_ID_BYTES, (const jbyte*)id);
+}
+JNIEXPORT jlong JNICALL Java_org_apache_pinot_gpu_PinotGpu_commInitRank(JNIEnv* env, jclass c, jint device, jint world, jint rank, jbyteArray uniqueId) {
+  (void)c;
+  uint8_t id[PG_COMM_UNIQUE_ID_BYTES];
+  if (!uniqueId || (*env)->GetArrayLength(env, uniqueId) < PG_COMM_UNIQUE_ID_BYTES) {
+    jclass x = (*env)->FindClass(env, "java/lang/IllegalArgumentException"); if (x) (*env)->ThrowNew(env, x, "unique id needs 128 bytes"); return 0;
+  }
+  (*env)->GetByteArrayRegion(env, uniqueId, 0, PG_COMM_UNIQUE_ID_BYTES, (jbyte*)id);
+  pg_comm_t comm = NULL;
+  CHECK_RET(pg_comm_init_rank(device, world, rank, id, &comm), 0);
+  return (jlong)(intptr_t)comm;
+}
+/* one communicator per listed device (one JVM, N GPUs): outComms[i] belongs to devices[i] */
+JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpu_commInitAll(JNIEnv* env, jclass c, jintArray devices, jlongArray outComms) {
+  (void)c;
+  const jsize n = (*env)->GetArrayLength(env, devices);
+  if (n < 1 || n > 64 || (*env)->GetArrayLength(env, outComms) < n) {
+    jclass x = (*env)->FindClass(env, "java/lang/IllegalArgumentException"); if (x) (*env)->ThrowNew(env, x, "1..64 devices and as many output slots"); return;
+  }
+  jint* d = (*env)->GetIntArrayElements(env, devices, NULL);
+  int32_t ords[64];
+  for (jsize i = 0; i < n; i++) ords[i] = d[i];
+  (*env)->ReleaseIntArrayElements(env, devices, d, JNI_ABORT);
+  pg_comm_t comms[64];
+  CHECK(pg_comm_init_all(n, ords, comms));
+  jlong handles[64];
+  for (jsize i = 0; i < n; i++) handles[i] = (jlong)(intptr_t)comms[i];
+  (*env)->SetLongArrayRegion(env, outComms, 0, n, handles);
+}
+JNIEXPORT jint JNICALL Java_org_apache_pinot_gpu_PinotGpu_commWorldSize(JNIEnv* env, jclass c, jlong comm) { (void)c; int32_t w = 0; CHECK_RET(pg_comm_world_size(COMM(comm), &w), 0); return w; }
+JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpu_commDestroy(JNIEnv* env, jclass c, jlong comm) { (void)c; CHECK(pg_comm_destroy(COMM(comm))); }
