@@ -164,8 +164,8 @@ typedef struct pg_query {
 #define PG_QUERY_FLAG_SKIP_STAR_TREE 0x2   /* QueryContext#isSkipStarTree (query option useStarTree=false) */
 #define PG_QUERY_FLAG_APPROX_FILTER_STATS 0x8 /* skip the exact numEntriesScannedInFilter of OR / NOT-over-scan shapes (stats_exact = 0) */
 #define PG_QUERY_FLAG_EXACT_FILTER_STATS 0x10 /* compute it whatever the segment's size: by default those shapes get the exact count up to
-                                                 2^26 docs (environment PG_EXACT_STATS_MAX_DOCS) — it costs one filter launch, one bitmap copy
-                                                 to the host and a host walk per scan / inverted leaf (profiles/r03_filter_stats_cost.txt) */
+                                                 2^22 docs (environment PG_EXACT_STATS_MAX_DOCS) — it costs one filter launch, one bitmap copy
+                                                 to the host and a host walk per scan / inverted leaf: 0.2 - 3 s per 10^8 docs against 0.3 ms for the query (profiles/r03_filter_stats_cost.txt) */
 #define PG_QUERY_FLAG_KEEP_DEVICE_TABLE 0x4 /* keep the dense accumulator table in HBM with the result (pg_result_merge / _all_reduce) */
 
 /* ExecutionStatistics (pinot-core/.../operator/ExecutionStatistics.java) + device timings. */

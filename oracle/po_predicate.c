@@ -171,15 +171,18 @@ static po_pred_eval* create_raw_based(const pg_filter_node* p, const po_column* 
       float lo = -INFINITY, hi = INFINITY;
       if (!lo_unb && po_parse_float(p->lower, &lo)) goto fail;
       if (!hi_unb && po_parse_float(p->upper, &hi)) goto fail;
-      if (!lo_inc) lo = next_up_f(lo);
-      if (!hi_inc) hi = next_down_f(hi);
+      /* FloatRawValueBasedRangePredicateEvaluator (:449-456): checkArgument(nextUp(lower) > lower) / (nextDown(upper) < upper) —
+       * false for an exclusive bound at its infinity and for NaN */
+      if (!lo_inc) { const float n = next_up_f(lo); if (!(n > lo)) { po_set_error("Invalid range"); goto fail; } lo = n; }
+      if (!hi_inc) { const float n = next_down_f(hi); if (!(n < hi)) { po_set_error("Invalid range"); goto fail; } hi = n; }
       e->lo_f = lo; e->hi_f = hi;
     } else {
       double lo = -INFINITY, hi = INFINITY;
       if (!lo_unb && po_parse_double(p->lower, &lo)) goto fail;
       if (!hi_unb && po_parse_double(p->upper, &hi)) goto fail;
-      if (!lo_inc) lo = nextafter(lo, INFINITY);
-      if (!hi_inc) hi = nextafter(hi, -INFINITY);
+      /* DoubleRawValueBasedRangePredicateEvaluator: the same checkArgument pair */
+      if (!lo_inc) { const double n = nextafter(lo, INFINITY); if (!(n > lo)) { po_set_error("Invalid range"); goto fail; } lo = n; }
+      if (!hi_inc) { const double n = nextafter(hi, -INFINITY); if (!(n < hi)) { po_set_error("Invalid range"); goto fail; } hi = n; }
       e->lo_d = lo; e->hi_d = hi;
     }
     return e;

@@ -837,9 +837,9 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
   H.full_scan_entries = P.full_scan_entries;
   H.total_docs = seg.total_docs;
   int64_t exact_entries = -1;
-  // exact numEntriesScannedInFilter of leapfrogged shapes: by default up to 2^26 docs (one filter launch + one bitmap copy + a host walk per
+  // exact numEntriesScannedInFilter of leapfrogged shapes: by default up to 2^22 docs (one filter launch + one bitmap copy + a host walk per
   // leaf: milliseconds there, a multiple of the query on a 10^9-doc segment), on request at any size
-  static const int64_t exact_max_docs = getenv("PG_EXACT_STATS_MAX_DOCS") ? atoll(getenv("PG_EXACT_STATS_MAX_DOCS")) : ((int64_t)1 << 26);
+  static const int64_t exact_max_docs = getenv("PG_EXACT_STATS_MAX_DOCS") ? atoll(getenv("PG_EXACT_STATS_MAX_DOCS")) : ((int64_t)1 << 22);
   const bool want_exact = !(q.flags & PG_QUERY_FLAG_APPROX_FILTER_STATS) &&
                           ((q.flags & PG_QUERY_FLAG_EXACT_FILTER_STATS) || (int64_t)P.space_docs <= exact_max_docs);
   if (!P.stats_exact && want_exact) {
@@ -1216,7 +1216,7 @@ std::unique_ptr<DocIdSet> execute_filter(Segment& seg, const pg_filter_node* fil
   PG_HIP(hipStreamSynchronize(ctx.stream));
   fill_stats(out->stats, P, P.full_scan_entries, seg.total_docs, stats_host);
   {   // pg_filter_exec has no flags: the exact count of leapfrogged shapes up to the default size (see execute_query)
-    static const int64_t exact_max_docs = getenv("PG_EXACT_STATS_MAX_DOCS") ? atoll(getenv("PG_EXACT_STATS_MAX_DOCS")) : ((int64_t)1 << 26);
+    static const int64_t exact_max_docs = getenv("PG_EXACT_STATS_MAX_DOCS") ? atoll(getenv("PG_EXACT_STATS_MAX_DOCS")) : ((int64_t)1 << 22);
     if (!P.stats_exact && (int64_t)P.space_docs <= exact_max_docs) {
       out->stats.num_entries_scanned_in_filter = exact_entries_scanned(P, ctx, nullptr);
       out->stats.stats_exact = 1;

@@ -198,14 +198,16 @@ PredEval make_pred_eval(const pg_filter_node& p, const Column& col) {
     } else if (t == PG_TYPE_FLOAT) {
       float lo = lo_unb ? -INFINITY : parse_float_or_fail(p.lower);
       float hi = hi_unb ? INFINITY : parse_float_or_fail(p.upper);
-      if (!lo_inc) lo = std::nextafter(lo, INFINITY);     // Math.nextUp
-      if (!hi_inc) hi = std::nextafter(hi, -INFINITY);    // Math.nextDown
+      // Math.nextUp / nextDown + checkArgument (RangePredicateEvaluatorFactory.java:449-456): an exclusive bound at its infinity (or NaN)
+      // is "Invalid range", not an empty match
+      if (!lo_inc) { const float n = std::nextafter(lo, INFINITY); if (!(n > lo)) fail(PG_ERR_INVALID_ARGUMENT, "Invalid range"); lo = n; }
+      if (!hi_inc) { const float n = std::nextafter(hi, -INFINITY); if (!(n < hi)) fail(PG_ERR_INVALID_ARGUMENT, "Invalid range"); hi = n; }
       e.lo_d = lo; e.hi_d = hi;
     } else {
       double lo = lo_unb ? -INFINITY : parse_double_or_fail(p.lower);
       double hi = hi_unb ? INFINITY : parse_double_or_fail(p.upper);
-      if (!lo_inc) lo = std::nextafter(lo, (double)INFINITY);
-      if (!hi_inc) hi = std::nextafter(hi, -(double)INFINITY);
+      if (!lo_inc) { const double n = std::nextafter(lo, (double)INFINITY); if (!(n > lo)) fail(PG_ERR_INVALID_ARGUMENT, "Invalid range"); lo = n; }
+      if (!hi_inc) { const double n = std::nextafter(hi, -(double)INFINITY); if (!(n < hi)) fail(PG_ERR_INVALID_ARGUMENT, "Invalid range"); hi = n; }
       e.lo_d = lo; e.hi_d = hi;
     }
     return e;

@@ -284,6 +284,20 @@ def test_unsupported_and_errors(gpu_api, sv):
     assert e.value.status == PG_ERR_INVALID_ARGUMENT and "NumberFormatException" in e.value.message
 
 
+def test_exclusive_bound_at_infinity_is_an_invalid_range_gpu(gpu_api):
+    """RangePredicateEvaluatorFactory.java:449-456: checkArgument(nextUp(lower) > lower) — the planner refuses what the reference refuses."""
+    from pinot_amd import capi
+    from tests.test_oracle_goldens import INVALID_RANGES, invalid_range_segment
+    seg = invalid_range_segment(gpu_api)
+    for where in INVALID_RANGES:
+        with pytest.raises(capi.NativeError) as e:
+            seg.execute(f"SELECT COUNT(*) FROM inf WHERE {where}")
+        assert e.value.status == capi.PG_ERR_INVALID_ARGUMENT and "Invalid range" in e.value.message, where
+    assert seg.execute("SELECT COUNT(*) FROM inf WHERE d >= 'Infinity'").aggregation_result() == [0]
+    assert seg.execute("SELECT COUNT(*) FROM inf WHERE f >= '-Infinity'").aggregation_result() == [1000]
+    seg.destroy()
+
+
 # ---- numGroupsLimit: the reference admits the first `limit` distinct keys in docId order -------------------------------------
 LIMIT_CASES = [
     ("SELECT COUNT(*), SUM(column1), MAX(column3) FROM testTable GROUP BY column9", 50),

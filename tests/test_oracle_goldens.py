@@ -357,3 +357,26 @@ def test_minmaxrange_without_matches_is_the_empty_pair(oracle_api, sv_data):
     inf = float("inf")
     assert b.aggregation_result() == [(inf, -inf), inf, -inf, 0.0, (0.0, 0), 0]
     seg.destroy()
+
+
+# ---- RangePredicateEvaluatorFactory.java:449-456: an exclusive FLOAT / DOUBLE bound at its infinity is "Invalid range" ------------------
+def invalid_range_segment(api):
+    v = (np.arange(1000) * 0.5).astype(np.float32)
+    host = build_segment("inf", {"f": v, "d": v.astype(np.float64)}, {"f": "FLOAT", "d": "DOUBLE"}, no_dictionary_columns=["f", "d"])
+    return NativeSegment(api, host)
+
+
+INVALID_RANGES = ["f > 'Infinity'", "d > 'Infinity'", "f < '-Infinity'", "d < '-Infinity'"]
+
+
+def test_exclusive_bound_at_infinity_is_an_invalid_range(oracle_api):
+    from pinot_amd import capi
+    seg = invalid_range_segment(oracle_api)
+    for where in INVALID_RANGES:
+        with pytest.raises(capi.NativeError) as e:   # Preconditions.checkArgument(nextUp(lower) > lower, "Invalid range: %s", ...)
+            seg.execute(f"SELECT COUNT(*) FROM inf WHERE {where}")
+        assert e.value.status == capi.PG_ERR_INVALID_ARGUMENT and "Invalid range" in e.value.message, where
+    # inclusive bounds at infinity are fine: nothing matches / everything matches
+    assert seg.execute("SELECT COUNT(*) FROM inf WHERE d >= 'Infinity'").aggregation_result() == [0]
+    assert seg.execute("SELECT COUNT(*) FROM inf WHERE f >= '-Infinity'").aggregation_result() == [1000]
+    seg.destroy()
