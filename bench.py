@@ -341,18 +341,31 @@ def star_tree_leg(api, args, parent_docs=2_000_000):
     parent = synth.generate_segment(parent_docs, segment_index=0, columns=list(synth.CFG5_COLUMNS), native=False)
     startree.add_star_tree(parent, ["h1", "h2", "h3", "h4"], [("COUNT", "*"), ("DISTINCTCOUNTHLL", "u")], max_leaf_records=10000)
     seg = NativeSegment(api, parent)
-    q = parse_sql(synth.QUERY_CFG5)
-    q.flags |= capi.QUERY_FLAG_PROFILE
-    lat, dev, lib = [], [], []
-    for i in range(args.warmup + args.steps):
-        t = time.perf_counter()
-        b = seg.execute(q)
-        if i >= args.warmup:
-            lat.append((time.perf_counter() - t) * 1e3)
-            dev.append(b.stats.device_ms_total)
-            lib.append(b.stats.host_ms_total)      # pg_query_exec wall time (planning, launches, device, copy back, assembly)
-    out = {"star_tree_docs": int(parent.star_trees[0].num_docs), "groups": len(b.rows()), "star_tree_index": int(b.stats.star_tree_index),
-           "p50_query_latency_ms": statistics.median(lat), "library_ms": statistics.median(lib), "device_ms": statistics.median(dev),
+    def timed(flags):
+        q = parse_sql(synth.QUERY_CFG5)
+        q.flags |= capi.QUERY_FLAG_PROFILE | flags
+        lat, dev, lib = [], [], []
+        b = None
+        for i in range(args.warmup + args.steps):
+            t = time.perf_counter()
+            b = seg.execute(q)
+            if i >= args.warmup:
+                lat.append((time.perf_counter() - t) * 1e3)
+                dev.append(b.stats.device_ms_total)
+                lib.append(b.stats.host_ms_total)      # pg_query_exec wall time (planning, launches, device, copy back, assembly)
+        return b, statistics.median(lat), statistics.median(lib), statistics.median(dev)
+
+    # the query as BASELINE states it returns DISTINCTCOUNTHLL values: with PG_QUERY_FLAG_FINAL_DISTINCT the registers stay in HBM and the
+    # cardinalities come back (the headline latency); the intermediate form (registers, what a cross-segment merge needs) is timed beside it
+    bf, lat_f, lib_f, dev_f = timed(capi.QUERY_FLAG_FINAL_DISTINCT)
+    b, lat_i, lib_i, dev_i = timed(0)
+    from pinot_amd.executor import hll_cardinality
+    inter = b.rows()
+    final_ok = all(bf.rows()[k] == [v[0], hll_cardinality(v[1])] for k, v in inter.items()) and len(bf.rows()) == len(inter)
+    out = {"star_tree_docs": int(parent.star_trees[0].num_docs), "groups": len(inter), "star_tree_index": int(b.stats.star_tree_index),
+           "p50_query_latency_ms": lat_f, "library_ms": lib_f, "device_ms": dev_f,
+           "final_values_equal_cardinality_of_registers": bool(final_ok),
+           "intermediate_registers": {"p50_query_latency_ms": lat_i, "library_ms": lib_i, "device_ms": dev_i},
            "kernel": b.stats.kernel.decode(),
            "docs_scanned": int(b.stats.num_docs_scanned), "parent_docs": parent.total_docs}
     seg.destroy()

@@ -166,6 +166,10 @@ typedef struct pg_query {
 #define PG_QUERY_FLAG_EXACT_FILTER_STATS 0x10 /* compute it whatever the segment's size: by default those shapes get the exact count up to
                                                  2^22 docs (environment PG_EXACT_STATS_MAX_DOCS) — it costs one filter launch, one bitmap copy
                                                  to the host and a host walk per scan / inverted leaf: 0.2 - 3 s per 10^8 docs against 0.3 ms for the query (profiles/r03_filter_stats_cost.txt) */
+#define PG_QUERY_FLAG_FINAL_DISTINCT 0x20  /* DISTINCTCOUNT / DISTINCTCOUNTHLL come back as their FINAL value (PG_RESULT_LONG: the set's size, HyperLogLog#cardinality —
+                                              AggregationFunction#extractFinalResult), not as the intermediate set / registers: for a caller that
+                                              merges nothing afterwards (one segment, or after pg_result_merge / _all_reduce).  The states stay in
+                                              HBM; two integers per group come back (3.3 MB of registers -> 200 KB on BASELINE config 5) */
 #define PG_QUERY_FLAG_KEEP_DEVICE_TABLE 0x4 /* keep the dense accumulator table in HBM with the result (pg_result_merge / _all_reduce) */
 
 /* ExecutionStatistics (pinot-core/.../operator/ExecutionStatistics.java) + device timings. */

@@ -43,6 +43,46 @@ extern "C" __global__ void pg_fill_i64_kernel(int64_t* dst, int64_t n_per_op, in
 extern "C" __global__ void pg_expand_docids_kernel(const uint64_t* words, const int64_t* tile_offsets, int32_t* out,
                                                    int n_tiles);
 
+// DISTINCTCOUNT / DISTINCTCOUNTHLL final values without moving the states (PG_QUERY_FLAG_FINAL_DISTINCT): one wavefront per group folds
+// the group's state into its final value — a dictId set into its size; 2^log2m HyperLogLog registers through stream-lib's
+// HyperLogLog#cardinality: registerSum = Σ 1.0 / (1 << register) is accumulated as the INTEGER Σ 2^(40 - register) (every
+// term and every partial sum of the Java loop is a multiple of 2^-40 far below 2^53, so the integer sum IS that double sum, whatever the
+// order), estimate = alphaMM * (1 / registerSum) in IEEE double (division and multiplication are correctly rounded here as in Java),
+// and the small-range branch round(m * ln(m / zeros)) — one of m + 1 values — comes from a table the host filled with its libm.
+// A star-tree answer of BASELINE config 5 then copies 100 KB back instead of 3.3 MB of registers.
+extern "C" __global__ void __launch_bounds__(256) pg_aux_finish_kernel(const uint32_t* __restrict__ region, int kind, int words_per_group,
+                                                                       int n_groups, double alpha_mm, int m,
+                                                                       const long long* __restrict__ small_range, long long* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int g = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  if (g >= n_groups) return;
+  const uint32_t* w = region + (int64_t)g * words_per_group;
+  unsigned long long a = 0, z = 0;
+  for (int i = lane; i < words_per_group; i += 64) {
+    const uint32_t x = w[i];
+    if (kind == PG_AUX_DICT_SET) {
+      a += (unsigned long long)__popc(x);
+    } else {
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const uint32_t r = (x >> (8 * b)) & 0xFFu;
+        a += 1ULL << (40u - (r > 40u ? 40u : r));
+        z += r == 0u ? 1ULL : 0ULL;
+      }
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_xor(a, off, 64);
+    z += __shfl_xor(z, off, 64);
+  }
+  if (lane != 0) return;
+  if (kind == PG_AUX_DICT_SET) { out[g] = (long long)a; return; }
+  const double register_sum = ldexp((double)a, -40);
+  const double estimate = alpha_mm * (1.0 / register_sum);
+  if (estimate <= (5.0 / 2.0) * (double)m) out[g] = small_range[z < (unsigned long long)m ? z : (unsigned long long)m];
+  else out[g] = (long long)floor(estimate + 0.5);
+}
+
 namespace pg {
 
 // ---- errors / device buffers ------------------------------------------------------------------------------------------------
@@ -207,6 +247,9 @@ struct ThreadCtx {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   DeviceBuffer stats, partials, final_table, tile_counts, aux;
   DeviceBuffer words, radix_hist, radix_start, radix_tuples, hash_count, hash_keys, hash_acc;   // PG_AGG_RADIX work areas
+  DeviceBuffer aux_summary;   // PG_QUERY_FLAG_FINAL_DISTINCT: [n_aux][G] final values
+  DeviceBuffer hll_small[17];  // per log2m: round(m * ln(m / zeros)), zeros = 0 .. m
+  double hll_alpha_mm[17] = {0};
   DeviceBuffer p2_meta, p2_list, p2_ctrl;   // partition pipeline v2: chunk records, the same grouped by bucket, counters (PG_P2_CTRL_*)
   uint32_t* p2_ctrl_host = nullptr;   // page-locked copy of p2_ctrl
   bool stats_dirty = true;      // the stats counters may be non-zero (first use, or a query that failed midway)
@@ -362,6 +405,7 @@ struct HostTable {
   std::vector<int64_t> table;            // [n_ops][G] (G = groups of the compact table for hashed key spaces)
   uint64_t stats[PG_MAX_STATS] = {0};
   uint8_t* aux = nullptr;                // merged auxiliary regions (replicas are folded in place)
+  const uint64_t* aux_summary = nullptr; // PG_QUERY_FLAG_FINAL_DISTINCT: [n_aux][G] final values instead of `aux`
   std::shared_ptr<PinnedBlock> aux_block; // set when `aux` lies in a block the result may keep (see AggResult::hll_block)
   bool hashed = false;
   int64_t hash_groups = 0;
@@ -370,6 +414,7 @@ struct HostTable {
   int64_t total_docs = 0;
 };
 static void assemble_result(Result& res_out, const CompiledPlan& P, int32_t n_group_by, int32_t n_aggregations, HostTable& H);
+static void hll_small_range_table(int log2m, std::vector<long long>& t, double& alpha_mm);
 
 static void check_cancel(const CancelToken* c, ThreadCtx* ctx) {
   if (c && c->requested.load(std::memory_order_acquire)) {
@@ -534,9 +579,15 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
     }
   }
   // MBs of auxiliary state (HyperLogLog registers of thousands of groups) land in a pooled page-locked block the result keeps
+  // PG_QUERY_FLAG_FINAL_DISTINCT: the states stay in HBM, one final value per group and aggregation comes back (pg_aux_finish_kernel)
+  bool final_distinct = (q.flags & PG_QUERY_FLAG_FINAL_DISTINCT) != 0 && D.n_aux > 0 && !(q.flags & PG_QUERY_FLAG_KEEP_DEVICE_TABLE) &&
+                        D.agg_mode != PG_AGG_RADIX_HASH && P.space_docs > 0;
+  for (int x = 0; x < D.n_aux; x++) final_distinct = final_distinct && D.aux[x].n_rep == 1;
+  const size_t summary_bytes = final_distinct ? (size_t)D.n_aux * (size_t)std::max(D.n_groups, 1) * 8 : 0;
+  const size_t host_aux_bytes = final_distinct ? summary_bytes : aux_total;
   std::shared_ptr<PinnedBlock> out_block;
-  if (aux_total >= ((size_t)1 << 20)) out_block = acquire_pinned(out_bytes + aux_total);
-  int64_t* host_out = static_cast<int64_t*>(out_block ? out_block->ptr : ctx.pin(out_bytes + aux_total));
+  if (host_aux_bytes >= ((size_t)1 << 20)) out_block = acquire_pinned(out_bytes + host_aux_bytes);
+  int64_t* host_out = static_cast<int64_t*>(out_block ? out_block->ptr : ctx.pin(out_bytes + host_aux_bytes));
   uint8_t* aux_host = reinterpret_cast<uint8_t*>(host_out) + out_bytes;
   if (profile) PG_HIP(hipEventRecord(ctx.ev[0], ctx.stream));
   const char* kname = "";
@@ -774,7 +825,25 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
     PG_HIP(hipGetLastError());
     if (profile) PG_HIP(hipEventRecord(ctx.ev[2], ctx.stream));
     PG_HIP(hipMemcpyAsync(host_out, ctx.final_table.ptr, out_bytes, hipMemcpyDeviceToHost, ctx.stream));
-    if (aux_total) PG_HIP(hipMemcpyAsync(aux_host, ctx.aux.ptr, aux_total, hipMemcpyDeviceToHost, ctx.stream));
+    if (final_distinct) {
+      const int G1 = std::max(D.n_groups, 1);
+      ThreadCtx::grow(ctx.aux_summary, summary_bytes);
+      for (int x = 0; x < D.n_aux; x++) {
+        const bool set = D.aux[x].kind == PG_AUX_DICT_SET;
+        const int words = set ? D.aux[x].stride : D.aux[x].stride / 4, lm = set ? 0 : D.aux[x].log2m;
+        if (!set && !ctx.hll_small[lm].ptr) {
+          std::vector<long long> t;
+          hll_small_range_table(lm, t, ctx.hll_alpha_mm[lm]);
+          ctx.hll_small[lm] = upload_vector(t);
+        }
+        hipLaunchKernelGGL(pg_aux_finish_kernel, dim3((unsigned)((G1 + 3) / 4)), dim3(256), 0, ctx.stream, aux_final[(size_t)x], D.aux[x].kind, words, G1,
+                           ctx.hll_alpha_mm[lm], 1 << lm, ctx.hll_small[lm].as<long long>(), ctx.aux_summary.as<long long>() + (size_t)x * (size_t)G1);
+      }
+      PG_HIP(hipGetLastError());
+      PG_HIP(hipMemcpyAsync(aux_host, ctx.aux_summary.ptr, summary_bytes, hipMemcpyDeviceToHost, ctx.stream));
+    } else if (aux_total) {
+      PG_HIP(hipMemcpyAsync(aux_host, ctx.aux.ptr, aux_total, hipMemcpyDeviceToHost, ctx.stream));
+    }
     if (keep_table) {   // PG_QUERY_FLAG_KEEP_DEVICE_TABLE: the dense table, its counters and states stay in HBM with the result
       kept = std::make_unique<DeviceTable>();
       kept->table.alloc(out_bytes + 2 * 8);
@@ -816,7 +885,8 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
     PG_HIP(hipStreamSynchronize(ctx.stream));
     for (int o = 0; o < D.n_ops; o++)
       for (int64_t g = 0; g < D.n_groups; g++) table[(size_t)(o * (int64_t)D.n_groups + g)] = pg_acc_identity(D.ops[o].fn, D.ops[o].is_float);
-    if (aux_total) memset(aux_host, 0, aux_total);
+    if (host_aux_bytes) memset(aux_host, 0, host_aux_bytes);
+    // (final_distinct: an empty HyperLogLog has cardinality round(m * ln(m / m)) = 0, an empty set size 0: the zeroes stand)
   }
 
   if (keep_table && !has_docs) {   // an empty doc space still yields a (neutral) table to merge with
@@ -829,8 +899,9 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
   HostTable H;
   H.table = std::move(table);
   memcpy(H.stats, stats_host, sizeof(stats_host));
-  H.aux = aux_host;
-  H.aux_block = out_block;
+  H.aux = final_distinct ? nullptr : aux_host;
+  H.aux_summary = final_distinct ? reinterpret_cast<const uint64_t*>(aux_host) : nullptr;
+  H.aux_block = final_distinct ? nullptr : out_block;
   H.hashed = hashed;
   H.hash_groups = hash_groups;
   H.hash_keys = std::move(hash_keys_host);
@@ -886,6 +957,19 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
   return res;
 }
 
+// The small-range branch of HyperLogLog#cardinality, round(m * ln(m / zeros)), for zeros = 0 .. m (host libm; Math.round = floor(x + 0.5)),
+// and alphaMM — what pg_aux_finish_kernel needs besides the registers
+static void hll_small_range_table(int log2m, std::vector<long long>& t, double& alpha_mm) {
+  const int m = 1 << log2m;
+  if (m == 16) alpha_mm = 0.673 * m * m;
+  else if (m == 32) alpha_mm = 0.697 * m * m;
+  else if (m == 64) alpha_mm = 0.709 * m * m;
+  else alpha_mm = (0.7213 / (1 + 1.079 / m)) * m * m;
+  t.assign((size_t)m + 1, 0);
+  for (int v = 1; v <= m; v++) t[(size_t)v] = (long long)std::floor(m * std::log(m / (double)v) + 0.5);
+  t[0] = INT64_MAX;   // Math.round(+Infinity) = Long.MAX_VALUE (cannot occur: estimate <= 2.5 m implies zero registers exist)
+}
+
 static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_by, int32_t n_aggregations, HostTable& H) {
   const PgQueryPlan& D = P.dev;
   const bool hashed = H.hashed;
@@ -911,7 +995,10 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
   std::vector<int64_t> gids;
   if (n_group_by == 0) gids.push_back(0);
   else if (hashed) { gids.resize((size_t)G); for (int64_t g = 0; g < G; g++) gids[(size_t)g] = g; }
-  else for (int64_t g = 0; g < G; g++) if (exists(g)) gids.push_back(g);
+  else {
+    gids.reserve((size_t)std::min<int64_t>(G, 1 << 20));
+    for (int64_t g = 0; g < G; g++) if (exists(g)) gids.push_back(g);
+  }
   bool limit_reached = n_group_by > 0 && (int64_t)gids.size() >= (int64_t)P.num_groups_limit;
   if (n_group_by > 0 && (int64_t)gids.size() > (int64_t)P.num_groups_limit) {
     // keep the numGroupsLimit groups whose first matching docId is smallest (= the keys the reference admits in docId order)
@@ -948,8 +1035,21 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
     auto& v = res.group_dict_ids[j];
     v.resize((size_t)ng);
     if (!hashed && G <= (int64_t)0x7FFFFFFF) {   // dense key space: 32-bit arithmetic (a 64-bit division costs several times as much)
+      // ids ascend: digit j of g + 1 follows from digit j of g without a division (an odometer: (low part, digit) advance together);
+      // gaps between existing groups fall back to the division.  12 800 groups x 4 columns were 100 k divisions, ~0.1 ms
       const uint32_t m32 = (uint32_t)mult, c32 = (uint32_t)card;
-      for (int32_t i = 0; i < ng; i++) v[i] = (int32_t)(((uint32_t)gids[i] / m32) % c32);
+      uint32_t prev = 0xFFFFFFFFu, low = 0, digit = 0;   // low = g % mult, digit = (g / mult) % card
+      for (int32_t i = 0; i < ng; i++) {
+        const uint32_t g = (uint32_t)gids[i];
+        if (g == prev + 1u && prev != 0xFFFFFFFFu) {
+          if (++low == m32) { low = 0; if (++digit == c32) digit = 0; }
+        } else {
+          low = g % m32;
+          digit = (g / m32) % c32;
+        }
+        prev = g;
+        v[i] = (int32_t)digit;
+      }
       continue;
     }
     for (int32_t i = 0; i < ng; i++) {   // getKeys: col 0 least significant
@@ -988,6 +1088,12 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
     const AggOut& ao = P.aggs[a];
     AggResult& r = res.aggs[a];
     for (int k = 0; k < 2; k++) { r.d[k].assign((size_t)ng, 0.0); r.l[k].assign((size_t)ng, 0); }
+    if (ao.aux >= 0 && H.aux_summary) {   // PG_QUERY_FLAG_FINAL_DISTINCT: the final value from the device's two integers per group
+      const uint64_t* sm = H.aux_summary + (size_t)ao.aux * (size_t)std::max(D.n_groups, 1);
+      r.kind = PG_RESULT_LONG;
+      for (int32_t i = 0; i < ng; i++) r.l[0][i] = (int64_t)sm[(size_t)gids[i]];
+      continue;
+    }
     if (ao.aux >= 0) {   // DISTINCTCOUNT / DISTINCTCOUNTHLL: extract the groups' regions
       size_t off = 0;
       for (int x = 0; x < ao.aux; x++) off += P.aux_bytes[x];
