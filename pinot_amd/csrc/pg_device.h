@@ -332,6 +332,11 @@ struct PgQueryPlan {
   // 32-bit column (srcs[pipe_src])
   int32_t pipe_fit;
   int32_t pipe_src;
+  // the pipeline's other shapes (pg_pipe_*, round 3): pipe_general = 1 + which stages the filter has; pipe_tail: the dense bitmap ANDed
+  // in after the scan (upsert queryableDocIds snapshot), chunk stride 8 KB like the dense postings
+  int32_t pipe_general;
+  int32_t pipe_has_index, pipe_has_scan, pipe_pad;
+  const uint8_t* pipe_tail;
   // Interpreter kernels over small doc spaces with expensive per-doc state updates (a star-tree's serialized HyperLogLogs: one
   // wavefront-wide register merge per matching doc): every wave tile is visited by 2^tile_split_shift wavefronts, each evaluating
   // the tile's filter and then keeping only its share of the matching docs (a quad slot and a lane class), so that a 13 617-doc

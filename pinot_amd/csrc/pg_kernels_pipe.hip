@@ -245,3 +245,253 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_fast_i32range_p(const 
   if (p.n_group_cols == 1) fast_pipe_i32range_body<1>(p);
   else fast_pipe_i32range_body<2>(p);
 }
+
+// =====================================================================================================================================
+// The same software pipeline for the neighbouring shapes (round 3) — everything that aggregates ONE raw INT column into an LDS table over
+// one or two <= 8-bit group columns, whatever the filter's outer shape:
+//   HAS_INDEX  the index-only program is the fused dense form (<= 4 AND-ed OR-groups of dense postings), else there is none
+//   HAS_SCAN   one raw-INT range scan restricted to the index result (or the whole filter when there is no index)
+//   TAIL       one more dense bitmap ANDed in AFTER the scan: the upsert queryableDocIds snapshot of FilterPlanNode.run's outer AND, which
+//              must not restrict the scan's candidates (numEntriesScannedInFilter stays the reference's)
+// pg_fast_i32range_p above is (index, scan, no tail) and stays as it was measured.  With a scan the stage structure is the same (three
+// tiles in flight); without one, the registers the scan quads took hold a SECOND set of value / group quads: tile i + 1's loads are
+// requested before tile i is aggregated (the loop is unrolled by two: no register rotation, see pg_kernels_part.hip on why a copy of a
+// load target drains the pipeline).
+// =====================================================================================================================================
+template <int NG, bool HAS_INDEX, bool HAS_SCAN, bool TAIL>
+__device__ __forceinline__ void pipe_general_body(const PgQueryPlan& p) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
+  __shared__ uint32_t s_stat[PG_MAX_STATS];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = uniform(t >> 6);
+  int64_t* lds_table = reinterpret_cast<int64_t*>(smem);
+  if (t < PG_MAX_STATS) s_stat[t] = 0;
+  {
+    const uint32_t table_slots = (uint32_t)p.n_groups * (uint32_t)p.replicas;
+    for (int o = 0; o < p.n_ops; o++) {
+      const int64_t ident = pg_acc_identity(p.ops[o].fn, p.ops[o].is_float);
+      for (uint32_t i = t; i < table_slots; i += PG_BLOCK) lds_table[(size_t)o * table_slots + i] = ident;
+    }
+  }
+  __syncthreads();
+  const CAS PgScanLeaf& L = cptr(p.scans)[HAS_SCAN ? p.fast_scan : 0];   // only dereferenced when HAS_SCAN
+  const RangeI32 r32 = HAS_SCAN ? make_range_i32(L.lo, L.hi) : RangeI32{0, 0u, false};
+  const uint32_t R = (uint32_t)p.replicas;
+  const uint32_t rep = (uint32_t)t & (R - 1u);
+  const uint32_t stride = (uint32_t)p.n_groups * R;   // slots per op
+  const uint8_t* xdata = p.srcs[p.pipe_src].data;
+  const int last_wt = p.n_wtiles - 1;
+  const int step = (int)gridDim.x * PG_WAVES_PER_BLOCK;
+  const int n_wtiles_loop = p.n_wtiles;
+  const int wt_first = (int)blockIdx.x * PG_WAVES_PER_BLOCK + wave;
+  uint32_t my_matched = 0, my_cand = 0;
+
+  uint32_t pv[8];          // postings dwords (linear layout)
+  uint32_t pt = 0;         // tail bitmap dword (linear layout)
+  auto clamp_tile = [&](int wt) { return wt < last_wt ? wt : last_wt; };
+  auto issue_postings = [&](int wt) {
+    const size_t tile_off = (size_t)clamp_tile(wt) * 256u;
+    if (HAS_INDEX) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) pv[j] = ldnt((const GAS uint32_t*)(sgpr_ptr<uint8_t>(p.dense_ptr[j] + tile_off) + (uint32_t)lane * 4u));
+    }
+    if (TAIL) pt = ldnt((const GAS uint32_t*)(sgpr_ptr<uint8_t>(p.pipe_tail + tile_off) + (uint32_t)lane * 4u));
+  };
+  // candidate mask of the index program in quad layout (every valid doc without one); tq: the tail bitmap in quad layout
+  auto candidates = [&](int wt, uint32_t& tq) -> uint32_t {
+    const int64_t rem = wt < n_wtiles_loop ? (int64_t)p.num_docs - (int64_t)wt * PG_WAVE_DOCS : 0;
+    const int32_t n_valid = rem >= PG_WAVE_DOCS ? PG_WAVE_DOCS : (rem > 0 ? (int32_t)rem : 0);
+    uint32_t c;
+    if (HAS_INDEX) {
+      uint32_t grp[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int gj = p.dense_group[j];
+#pragma unroll
+        for (int k = 0; k < 4; k++) grp[k] |= gj == k ? pv[j] : 0u;
+      }
+      uint32_t lin = valid_lin_mask(n_valid, lane);
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (k < p.dense_groups) lin &= ((p.dense_excl >> k) & 1) ? ~grp[k] : grp[k];
+      c = lin_to_quad(lin, lane);
+    } else {
+      c = valid_quad_mask(n_valid, lane);
+    }
+    tq = TAIL ? lin_to_quad(pt & valid_lin_mask(n_valid, lane), lane) : 0xFFFFFFFFu;
+    return c;
+  };
+  auto issue_values = [&](int wt, uint32_t m, u32x4 (&x)[8], uint32_t (&g)[NG][8][2]) {
+    const int wc = clamp_tile(wt);
+    const GAS uint8_t* xb = sgpr_ptr<uint8_t>(xdata + (size_t)wc * (PG_WAVE_DOCS * 4));
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const uint32_t q = ((m >> (4 * k)) & 0xFu) ? (uint32_t)(k * 64 + lane) : 0u;
+      x[k] = ldnt((const GAS u32x4*)(xb + q * 16u));
+    }
+#pragma unroll
+    for (int gi = 0; gi < NG; gi++) {
+      const PgGroupCol& gc = p.gcols[gi];
+      const GAS uint32_t* tw = sgpr_ptr<uint32_t>((const void*)packed_wtile_base(gc.data, wc, gc.bits));
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const uint32_t q = ((m >> (4 * k)) & 0xFu) ? (uint32_t)(k * 64 + lane) : 0u;
+        load_packed_quad<true>(tw, q, (uint32_t)gc.bits, g[gi][k]);
+      }
+    }
+  };
+  auto aggregate = [&](uint32_t mg, const u32x4 (&x)[8], const uint32_t (&g)[NG][8][2]) {   // the whole tile whose quads sit in x / g
+    if (__ballot(mg != 0) == 0) return;   // wave-uniform
+    uint32_t sp[8][2];   // packed slots: docs (0,1) and (2,3) of quad k
+#pragma unroll
+    for (int k = 0; k < 8; k++) sp[k][0] = sp[k][1] = rep | (rep << 16);
+#pragma unroll
+    for (int gi = 0; gi < NG; gi++) {
+      const PgGroupCol& gc = p.gcols[gi];
+      const uint32_t bits = (uint32_t)gc.bits, mask = (1u << gc.bits) - 1u;
+      const uint32_t mult = (uint32_t)gc.mult * R;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        uint32_t d[4];
+        const uint32_t q = ((mg >> (4 * k)) & 0xFu) ? (uint32_t)(k * 64 + lane) : 0u;
+        decode_packed_quad<true>(g[gi][k], q, bits, mask, d);
+        sp[k][0] += d[0] * mult + ((d[1] * mult) << 16);
+        sp[k][1] += d[2] * mult + ((d[3] * mult) << 16);
+      }
+    }
+    uint32_t v[8][4];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { v[k][0] = bswap32(x[k].x); v[k][1] = bswap32(x[k].y); v[k][2] = bswap32(x[k].z); v[k][3] = bswap32(x[k].w); }
+#define PG_SLOT(k, i) ((sp[k][(i) >> 1] >> (((i) & 1) * 16)) & 0xFFFFu)
+    for (int o = 0; o < p.n_ops; o++) {
+      const PgAccOp op = p.ops[o];
+      int64_t* base = lds_table + (size_t)o * stride;
+      if (op.src < 0) {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if ((mg >> (4 * k + i)) & 1u) atomicAdd(reinterpret_cast<unsigned long long*>(base + PG_SLOT(k, i)), 1ULL);
+      } else if (op.fn == PG_ACC_SUM) {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if ((mg >> (4 * k + i)) & 1u)
+              atomicAdd(reinterpret_cast<unsigned long long*>(base + PG_SLOT(k, i)), (unsigned long long)(int64_t)(int32_t)v[k][i]);
+      } else if (op.fn == PG_ACC_MIN) {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if ((mg >> (4 * k + i)) & 1u) atomicMin(reinterpret_cast<long long*>(base + PG_SLOT(k, i)), (long long)(int32_t)v[k][i]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if ((mg >> (4 * k + i)) & 1u) atomicMax(reinterpret_cast<long long*>(base + PG_SLOT(k, i)), (long long)(int32_t)v[k][i]);
+      }
+    }
+#undef PG_SLOT
+  };
+
+  if (HAS_SCAN) {
+    // ---- three tiles in flight: tile i aggregated out of registers, tile i + 1's scan quads and tile i + 2's bitmaps travelling ----
+    u32x4 a[8], x[8];
+    uint32_t g[NG][8][2];
+    auto issue_scan = [&](int wt, uint32_t cand) {
+      const GAS uint8_t* tb = sgpr_ptr<uint8_t>(L.data + (size_t)clamp_tile(wt) * (PG_WAVE_DOCS * 4));
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const uint32_t q = ((cand >> (4 * k)) & 0xFu) ? (uint32_t)(k * 64 + lane) : 0u;
+        a[k] = ldnt((const GAS u32x4*)(tb + q * 16u));
+      }
+    };
+    auto test_scan = [&](uint32_t cand, uint32_t tq) -> uint32_t {
+      uint32_t m = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        m |= (uint32_t)in_range_i32(r32, (int32_t)bswap32(a[k].x)) << (4 * k);
+        m |= (uint32_t)in_range_i32(r32, (int32_t)bswap32(a[k].y)) << (4 * k + 1);
+        m |= (uint32_t)in_range_i32(r32, (int32_t)bswap32(a[k].z)) << (4 * k + 2);
+        m |= (uint32_t)in_range_i32(r32, (int32_t)bswap32(a[k].w)) << (4 * k + 3);
+      }
+      my_cand += (uint32_t)__popc(cand);
+      m = r32.empty ? 0u : (m & cand & tq);
+      my_matched += (uint32_t)__popc(m);
+      return m;
+    };
+    int wt_cur = wt_first, wt_nxt = wt_cur + step, wt_far = wt_nxt + step;
+    uint32_t tq0 = 0, tq_nxt = 0, tq_far = 0;
+    if (HAS_INDEX || TAIL) issue_postings(wt_cur);
+    uint32_t c0 = candidates(wt_cur, tq0);
+    if (HAS_INDEX || TAIL) issue_postings(wt_nxt);
+    issue_scan(wt_cur, c0);
+    uint32_t m_cur = test_scan(c0, tq0);
+    issue_values(wt_cur, m_cur, x, g);
+    uint32_t c_nxt = candidates(wt_nxt, tq_nxt);
+    if (HAS_INDEX || TAIL) issue_postings(wt_far);
+    issue_scan(wt_nxt, c_nxt);
+    while (wt_cur < n_wtiles_loop) {
+      if (p.out_words) reinterpret_cast<uint32_t*>(p.out_words)[(int64_t)wt_cur * 64 + lane] = quad_to_lin(m_cur, lane);
+      aggregate(m_cur, x, g);                                      // waits for values(cur) only
+      const uint32_t m_nxt = test_scan(c_nxt, tq_nxt);             // waits for scan(nxt)
+      issue_values(wt_nxt, m_nxt, x, g);
+      const uint32_t c_far = candidates(wt_far, tq_far);
+      if (HAS_INDEX || TAIL) issue_postings(wt_far + step);
+      issue_scan(wt_far, c_far);
+      wt_cur = wt_nxt; wt_nxt = wt_far; wt_far += step;
+      m_cur = m_nxt; c_nxt = c_far; tq_nxt = tq_far;
+    }
+  } else {
+    // ---- two sets of value / group quads: tile i + 1's loads are requested before tile i is aggregated ----------------------------------
+    u32x4 xa[8], xb[8];
+    uint32_t ga[NG][8][2], gb[NG][8][2];
+    int wt_a = wt_first;
+    uint32_t tq = 0;
+    if (HAS_INDEX || TAIL) issue_postings(wt_a);
+    uint32_t m_a = candidates(wt_a, tq) & tq;
+    if (HAS_INDEX || TAIL) issue_postings(wt_a + step);
+    issue_values(wt_a, m_a, xa, ga);
+    while (wt_a < n_wtiles_loop) {
+      const int wt_b = wt_a + step;
+      const uint32_t m_b = candidates(wt_b, tq) & tq;
+      if (HAS_INDEX || TAIL) issue_postings(wt_b + step);
+      issue_values(wt_b, m_b, xb, gb);
+      my_matched += (uint32_t)__popc(m_a);
+      if (p.out_words) reinterpret_cast<uint32_t*>(p.out_words)[(int64_t)wt_a * 64 + lane] = quad_to_lin(m_a, lane);
+      aggregate(m_a, xa, ga);                                      // waits for values(a): values(b) and the next bitmaps keep travelling
+      wt_a = wt_b + step;
+      m_a = candidates(wt_a, tq) & tq;
+      if (HAS_INDEX || TAIL) issue_postings(wt_a + step);
+      issue_values(wt_a, m_a, xa, ga);
+      if (wt_b < n_wtiles_loop) {   // wave-uniform
+        my_matched += (uint32_t)__popc(m_b);
+        if (p.out_words) reinterpret_cast<uint32_t*>(p.out_words)[(int64_t)wt_b * 64 + lane] = quad_to_lin(m_b, lane);
+      }
+      aggregate(m_b, xb, gb);
+    }
+  }
+  const uint32_t wsum = wave_sum_u32(my_matched);
+  if (lane == 0 && wsum) atomicAdd(&s_stat[0], wsum);
+  if (HAS_SCAN && !p.fast_scan_pushed) {
+    const uint32_t csum = wave_sum_u32(my_cand);
+    if (lane == 0 && csum) atomicAdd(&s_stat[L.stat_slot], csum);
+  }
+  __syncthreads();
+  flush_workgroup(p, lds_table, s_stat, true, t);
+}
+#define PG_PIPE_KERNEL(NAME, IDX, SCAN, TAILF) \
+  extern "C" __global__ void __launch_bounds__(PG_BLOCK) NAME(const PgQueryPlan p) { \
+    if (p.n_group_cols == 1) pipe_general_body<1, IDX, SCAN, TAILF>(p); \
+    else pipe_general_body<2, IDX, SCAN, TAILF>(p); \
+  }
+PG_PIPE_KERNEL(pg_pipe_scan, false, true, false)            // the range scan is the whole filter
+PG_PIPE_KERNEL(pg_pipe_scan_tail, false, true, true)        // ... behind an upsert snapshot
+PG_PIPE_KERNEL(pg_pipe_index_scan_tail, true, true, true)   // config 3 behind an upsert snapshot
+PG_PIPE_KERNEL(pg_pipe_none, false, false, false)           // no filter
+PG_PIPE_KERNEL(pg_pipe_tail, false, false, true)            // only the upsert snapshot
+PG_PIPE_KERNEL(pg_pipe_index, true, false, false)           // inverted-index leaves only
+PG_PIPE_KERNEL(pg_pipe_index_tail, true, false, true)

@@ -1194,7 +1194,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
   if (P.fast_filter != 100) D.tail_posting = -1;
   // Fused dense index program (pg_fast_i32range_d): the index-only prefix is PUSH_POSTINGS (AND PUSH_POSTINGS)* over leaves that are
   // entirely dense (no CSR containers, their dense prefix covers every chunk) with at most 8 pointers and 4 leaves in all
-  if (P.fast_filter == 4 && D.n_index_instr > 0 && !D.fast_scan_pushed) {
+  if ((P.fast_filter == 4 || P.fast_filter == -1 || P.fast_filter == 100) && D.n_index_instr > 0 && !D.fast_scan_pushed) {
     std::vector<int> leaves;
     bool ok = true;
     int depth = 0;
@@ -1696,6 +1696,47 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
       src = D.ops[o].src;
     }
     if (ok && src >= 0 && D.srcs[src].col_kind == PG_COL_RAW32) { D.pipe_fit = 1; D.pipe_src = src; }
+  }
+  if (P.fast_filter != 4) D.pipe_fit = 0;   // pg_fast_i32range_p itself: dense index program AND one raw-INT range scan
+  // The pipeline's other shapes (pg_pipe_*): the same aggregation behind no filter at all, a lone range scan, index leaves only, and any of
+  // them (or the headline shape) followed by the upsert snapshot's bitmap
+  D.pipe_general = 0;
+  if (!D.pipe_fit && P.fast_agg && D.agg_mode == PG_AGG_LDS && D.n_group_cols >= 1 && D.n_group_cols <= 2 && !getenv("PG_NO_PIPE_GENERAL")) {
+    bool ok = true;
+    int src = -1;
+    for (int o = 0; o < D.n_ops && ok; o++) {
+      if (D.ops[o].src < 0) continue;
+      if (D.ops[o].is_float != PG_ACCV_INT) ok = false;
+      if (src >= 0 && D.ops[o].src != src) ok = false;
+      src = D.ops[o].src;
+    }
+    ok = ok && src >= 0 && D.srcs[src].col_kind == PG_COL_RAW32;
+    const int32_t n_chunks = (int32_t)(((int64_t)seg.total_docs + PG_CHUNK_DOCS - 1) / PG_CHUNK_DOCS);
+    const bool index_ok = D.n_index_instr == 0 || D.dense_fused;   // no index program, or the fused dense form
+    bool has_scan = false, has_tail = false;
+    if (P.fast_filter == -1) {
+      ok = ok && index_ok;
+    } else if (P.fast_filter == 4) {
+      has_scan = true;
+      ok = ok && D.fast_scan_pushed && D.n_index_instr == 0;   // with a dense index program it is pg_fast_i32range_p; any other index: not here
+    } else if (P.fast_filter == 100 && D.n_fast_scans == 1 && D.tail_posting >= 0) {
+      const PgScanLeaf& SL = em.scans[(size_t)em.instrs[(size_t)D.n_index_instr].arg];
+      const PgPostingLeaf& TL = em.postings[(size_t)D.tail_posting];
+      has_scan = true;
+      has_tail = true;
+      ok = ok && index_ok && SL.col_kind == PG_COL_RAW32 && SL.val_type == PG_V_I32 && SL.pred_kind == PG_P_RANGE &&
+           !TL.has_csr && TL.n_dense == 1 && TL.dense_chunks >= n_chunks && !TL.exclusive;
+      if (ok) { D.fast_scan = em.instrs[(size_t)D.n_index_instr].arg; D.pipe_tail = TL.dense[0]; }
+    } else {
+      ok = false;
+    }
+    if (ok) {
+      D.pipe_general = 1;
+      D.pipe_src = src;
+      D.pipe_has_index = D.n_index_instr > 0 ? 1 : 0;
+      D.pipe_has_scan = has_scan ? 1 : 0;
+      if (!has_tail) D.pipe_tail = nullptr;
+    }
   }
   // LDS tables that miss the narrow shape only by column width (group columns > 8 bits, LONG / DOUBLE sources, 64-bit
   // dictionaries) keep the 1024-thread kernels and run the general aggregator there (pg_fast_none_w / pg_fast_multi_w)

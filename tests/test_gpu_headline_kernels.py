@@ -36,6 +36,13 @@ QUERIES = [
     ("SELECT g1, COUNT(*) FROM gpuBench WHERE c_inv1 IN (0, 1) AND r_int > 500000 GROUP BY g1 ORDER BY g1 LIMIT 1000", DENSE),
     # AVG keeps a DOUBLE sum next to the count: a floating accumulator
     ("SELECT g1, AVG(m) FROM gpuBench WHERE c_inv1 IN (0, 1) AND r_int > 500000 GROUP BY g1 ORDER BY g1 LIMIT 1000", None),
+    # the pipeline's other filter shapes (pg_pipe_*, round 3): no filter, a lone range scan, inverted-index leaves only
+    ("SELECT g1, SUM(m), MAX(m) FROM gpuBench GROUP BY g1 LIMIT 1000", "pg_pipe_none"),
+    ("SELECT g1, g2, COUNT(*), MIN(m) FROM gpuBench GROUP BY g1, g2 LIMIT 10000", "pg_pipe_none"),
+    ("SELECT g1, g2, SUM(m) FROM gpuBench WHERE r_int BETWEEN 250000 AND 749999 GROUP BY g1, g2 LIMIT 10000", "pg_pipe_scan"),
+    ("SELECT g1, SUM(m), COUNT(*) FROM gpuBench WHERE r_int < 7 GROUP BY g1 LIMIT 1000", "pg_pipe_scan"),
+    ("SELECT g1, SUM(m) FROM gpuBench WHERE c_inv1 IN (0, 1, 2, 3) AND c_inv2 IN (0, 1) GROUP BY g1 LIMIT 1000", "pg_pipe_index"),
+    ("SELECT g2, g1, MAX(m), COUNT(*) FROM gpuBench WHERE c_inv1 NOT IN (3, 4) GROUP BY g2, g1 LIMIT 10000", "pg_pipe_index"),
 ]
 
 
@@ -59,3 +66,35 @@ def test_headline_specialisations_match_oracle(pair, sql, kernel):
         assert gb.stats.kernel.decode() == kernel                   # no index involved: every segment size takes it
     elif kernel and knobs_off and gb.stats.num_total_docs >= 65536:   # small segments keep sparse (CSR) postings: the interpreted leaves
         assert gb.stats.kernel.decode() == kernel
+
+
+# ---- behind an upsert queryableDocIds snapshot (FilterPlanNode.run's outer AND): the same pipeline with the snapshot's bitmap ANDed in after
+# the scan — the scan's candidates, and with them numEntriesScannedInFilter, stay the reference's ----------------------------------------
+UPSERT_QUERIES = [
+    (synth.QUERY_CFG3, "pg_pipe_index_scan_tail"),
+    (synth.QUERY_NORTH_STAR, "pg_pipe_index_scan_tail"),
+    ("SELECT g1, SUM(m), MAX(m) FROM gpuBench GROUP BY g1 LIMIT 1000", "pg_pipe_index"),          # the snapshot is the only (index) leaf
+    ("SELECT g1, SUM(m) FROM gpuBench WHERE r_int BETWEEN 250000 AND 749999 GROUP BY g1 LIMIT 1000", None),
+    ("SELECT g1, COUNT(*), SUM(m) FROM gpuBench WHERE c_inv2 = 1 GROUP BY g1 LIMIT 1000", None),
+]
+
+
+@pytest.mark.parametrize("n", [2049, 700_001, 3_000_017])
+def test_pipeline_behind_an_upsert_snapshot(gpu_api, oracle_api, n):
+    import numpy as np
+    host = synth.generate_segment(n, segment_index=5, columns=COLUMNS)
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    rng = np.random.default_rng(n)
+    for keep in (0.9, 0.5, 0.02):
+        ids = np.flatnonzero(rng.random(n) < keep)
+        g.set_queryable_doc_ids(ids)
+        o.set_queryable_doc_ids(ids)
+        for sql, kernel in UPSERT_QUERIES:
+            gb, ob = g.execute(sql), o.execute(sql)
+            assert gb.rows() == ob.rows(), (sql, keep)
+            for f in ("num_docs_scanned", "num_entries_scanned_in_filter", "num_entries_scanned_post_filter", "num_total_docs"):
+                assert getattr(gb.stats, f) == getattr(ob.stats, f), (f, sql, keep)
+            if kernel and knobs_off and n >= 65536 and keep >= 0.5:   # dense snapshots are bitmap containers: the arithmetic (dense) form
+                assert gb.stats.kernel.decode() == kernel, (sql, keep, gb.stats.kernel)
+    g.destroy()
+    o.destroy()
