@@ -335,7 +335,8 @@ struct PgQueryPlan {
   // the pipeline's other shapes (pg_pipe_*, round 3): pipe_general = 1 + which stages the filter has; pipe_tail: the dense bitmap ANDed
   // in after the scan (upsert queryableDocIds snapshot), chunk stride 8 KB like the dense postings
   int32_t pipe_general;
-  int32_t pipe_has_index, pipe_has_scan, pipe_pad;
+  int32_t pipe_has_index, pipe_has_scan;
+  int32_t pipe_vscan;               // >= 0: index of the second scan leaf, a range over the value column tested on the value quads (-1: none)
   const uint8_t* pipe_tail;
   // Interpreter kernels over small doc spaces with expensive per-doc state updates (a star-tree's serialized HyperLogLogs: one
   // wavefront-wide register merge per matching doc): every wave tile is visited by 2^tile_split_shift wavefronts, each evaluating

@@ -18,7 +18,8 @@ PG_DECL_FAST(pg_fast_dictrange_f) PG_DECL_FAST(pg_fast_dictrange_a) PG_DECL_FAST
 PG_DECL_FAST(pg_fast_multi_f) PG_DECL_FAST(pg_fast_multi_a) PG_DECL_FAST(pg_fast_multi_w) PG_DECL_FAST(pg_fast_none_w)
 PG_DECL_FAST(pg_fast_i32range_d) PG_DECL_FAST(pg_fast_i32range_p) PG_DECL_FAST(pg_fast_i32range_fp)
 PG_DECL_FAST(pg_pipe_scan) PG_DECL_FAST(pg_pipe_scan_tail) PG_DECL_FAST(pg_pipe_index_scan_tail) PG_DECL_FAST(pg_pipe_none) PG_DECL_FAST(pg_pipe_tail)
-PG_DECL_FAST(pg_pipe_index) PG_DECL_FAST(pg_pipe_index_tail)
+PG_DECL_FAST(pg_pipe_index) PG_DECL_FAST(pg_pipe_index_tail) PG_DECL_FAST(pg_pipe_index2) PG_DECL_FAST(pg_pipe_index2_tail)
+PG_DECL_FAST(pg_pipe_scan_vscan) PG_DECL_FAST(pg_pipe_index_scan_vscan)
 extern "C" const int pg_scan_waves_per_block;   // pg_kernels_scan.hip: wavefronts per workgroup of pg_fast_i32range_fp
 extern "C" const int pg_pipe_waves_per_block;   // pg_kernels_pipe.hip: wavefronts per workgroup of pg_fast_i32range_p
 PG_DECL_FAST(pg_fast_multi_wd) PG_DECL_FAST(pg_fast_none_wd) PG_DECL_FAST(pg_generic_query_ld) PG_DECL_FAST(pg_generic_query_gd)
@@ -166,7 +167,7 @@ void use_device(int ordinal) {
       // opt in to large dynamic LDS for the query kernels (function attributes are per device)
       typedef void (*QueryKernel)(const PgQueryPlan);
       const QueryKernel all[] = {pg_generic_query_f, pg_generic_query_l, pg_generic_query_g, pg_fast_none_f, pg_fast_none_a, pg_fast_i32range_f, pg_fast_i32range_a,
-                                 pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a, pg_fast_multi_f, pg_fast_multi_a, pg_fast_multi_w, pg_fast_none_w, pg_fast_multi_wd, pg_fast_none_wd, pg_generic_query_ld, pg_generic_query_gd, pg_fast_i32range_d, pg_fast_i32range_p, pg_pipe_scan, pg_pipe_scan_tail, pg_pipe_index_scan_tail, pg_pipe_none, pg_pipe_tail, pg_pipe_index, pg_pipe_index_tail,
+                                 pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a, pg_fast_multi_f, pg_fast_multi_a, pg_fast_multi_w, pg_fast_none_w, pg_fast_multi_wd, pg_fast_none_wd, pg_generic_query_ld, pg_generic_query_gd, pg_fast_i32range_d, pg_fast_i32range_p, pg_pipe_scan, pg_pipe_scan_tail, pg_pipe_index_scan_tail, pg_pipe_none, pg_pipe_tail, pg_pipe_index, pg_pipe_index_tail, pg_pipe_index2, pg_pipe_index2_tail, pg_pipe_scan_vscan, pg_pipe_index_scan_vscan,
                                  pg_radix_aggregate_kernel, pg_hash_aggregate_kernel,
                                  pg_p2_scatter_1, pg_p2_scatter_2, pg_p2_scatter_3, pg_p2_scatter_4, pg_p2_scatter_1f, pg_p2_scatter_2f, pg_p2_scatter_1f_key, pg_p2_scatter_1f_hll,
                                  pg_p2_aggregate_1, pg_p2_aggregate_2, pg_p2_aggregate_3, pg_p2_aggregate_4,
@@ -233,12 +234,22 @@ static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char
     static const bool no_dense = getenv("PG_NO_DENSE_FUSED") != nullptr;   // measurement knobs
     if (uses_pipe_general(P, agg_mode)) {
       const bool idx = P.dev.pipe_has_index != 0, scan = P.dev.pipe_has_scan != 0, tail = P.dev.pipe_tail != nullptr;
+      if (scan && P.dev.pipe_vscan >= 0) {
+        *name = idx ? "pg_pipe_index_scan_vscan" : "pg_pipe_scan_vscan";
+        return idx ? pg_pipe_index_scan_vscan : pg_pipe_scan_vscan;
+      }
       if (scan) {
         if (idx) { *name = "pg_pipe_index_scan_tail"; return pg_pipe_index_scan_tail; }   // (index + scan without a tail is pg_fast_i32range_p)
         *name = tail ? "pg_pipe_scan_tail" : "pg_pipe_scan";
         return tail ? pg_pipe_scan_tail : pg_pipe_scan;
       }
-      if (idx) { *name = tail ? "pg_pipe_index_tail" : "pg_pipe_index"; return tail ? pg_pipe_index_tail : pg_pipe_index; }
+      if (idx) {
+        int n_ptr = 0;   // distinct dense posting pointers (the planner pads the eight slots with repeats of slot 0)
+        for (int j = 0; j < 8; j++) if (j == 0 || P.dev.dense_ptr[j] != P.dev.dense_ptr[0] || P.dev.dense_group[j] != P.dev.dense_group[0]) n_ptr = j + 1;
+        if (n_ptr <= 2) { *name = tail ? "pg_pipe_index2_tail" : "pg_pipe_index2"; return tail ? pg_pipe_index2_tail : pg_pipe_index2; }
+        *name = tail ? "pg_pipe_index_tail" : "pg_pipe_index";
+        return tail ? pg_pipe_index_tail : pg_pipe_index;
+      }
       *name = tail ? "pg_pipe_tail" : "pg_pipe_none";
       return tail ? pg_pipe_tail : pg_pipe_none;
     }

@@ -253,12 +253,15 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_fast_i32range_p(const 
 //   HAS_SCAN   one raw-INT range scan restricted to the index result (or the whole filter when there is no index)
 //   TAIL       one more dense bitmap ANDed in AFTER the scan: the upsert queryableDocIds snapshot of FilterPlanNode.run's outer AND, which
 //              must not restrict the scan's candidates (numEntriesScannedInFilter stays the reference's)
+//   VSCAN      a second range scan, over the VALUE column itself (WHERE ... AND m < x ... SUM(m)): tested on the value quads when they
+//              arrive, no load of its own; its candidates are the first scan's matches (AndDocIdSet applies scans in list order)
+//   NP         dense posting pointers loaded per tile (2 when the index program has at most two: the snapshot alone, a single IN)
 // pg_fast_i32range_p above is (index, scan, no tail) and stays as it was measured.  With a scan the stage structure is the same (three
 // tiles in flight); without one, the registers the scan quads took hold a SECOND set of value / group quads: tile i + 1's loads are
 // requested before tile i is aggregated (the loop is unrolled by two: no register rotation, see pg_kernels_part.hip on why a copy of a
 // load target drains the pipeline).
 // =====================================================================================================================================
-template <int NG, bool HAS_INDEX, bool HAS_SCAN, bool TAIL>
+template <int NG, bool HAS_INDEX, bool HAS_SCAN, bool TAIL, bool VSCAN = false, int NP = 8>
 __device__ __forceinline__ void pipe_general_body(const PgQueryPlan& p) {
   extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
   __shared__ uint32_t s_stat[PG_MAX_STATS];
@@ -287,14 +290,17 @@ __device__ __forceinline__ void pipe_general_body(const PgQueryPlan& p) {
   const int wt_first = (int)blockIdx.x * PG_WAVES_PER_BLOCK + wave;
   uint32_t my_matched = 0, my_cand = 0;
 
-  uint32_t pv[8];          // postings dwords (linear layout)
+  uint32_t pv[NP];         // postings dwords (linear layout)
   uint32_t pt = 0;         // tail bitmap dword (linear layout)
+  uint32_t my_cand2 = 0;   // VSCAN: candidates of the second scan
+  const CAS PgScanLeaf& L2 = cptr(p.scans)[VSCAN ? p.pipe_vscan : 0];
+  const RangeI32 r32b = VSCAN ? make_range_i32(L2.lo, L2.hi) : RangeI32{0, 0u, false};
   auto clamp_tile = [&](int wt) { return wt < last_wt ? wt : last_wt; };
   auto issue_postings = [&](int wt) {
     const size_t tile_off = (size_t)clamp_tile(wt) * 256u;
     if (HAS_INDEX) {
 #pragma unroll
-      for (int j = 0; j < 8; j++) pv[j] = ldnt((const GAS uint32_t*)(sgpr_ptr<uint8_t>(p.dense_ptr[j] + tile_off) + (uint32_t)lane * 4u));
+      for (int j = 0; j < NP; j++) pv[j] = ldnt((const GAS uint32_t*)(sgpr_ptr<uint8_t>(p.dense_ptr[j] + tile_off) + (uint32_t)lane * 4u));
     }
     if (TAIL) pt = ldnt((const GAS uint32_t*)(sgpr_ptr<uint8_t>(p.pipe_tail + tile_off) + (uint32_t)lane * 4u));
   };
@@ -306,7 +312,7 @@ __device__ __forceinline__ void pipe_general_body(const PgQueryPlan& p) {
     if (HAS_INDEX) {
       uint32_t grp[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
+      for (int j = 0; j < NP; j++) {
         const int gj = p.dense_group[j];
 #pragma unroll
         for (int k = 0; k < 4; k++) grp[k] |= gj == k ? pv[j] : 0u;
@@ -420,6 +426,20 @@ __device__ __forceinline__ void pipe_general_body(const PgQueryPlan& p) {
       }
       my_cand += (uint32_t)__popc(cand);
       m = r32.empty ? 0u : (m & cand & tq);
+      if (!VSCAN) my_matched += (uint32_t)__popc(m);
+      return m;
+    };
+    auto value_scan = [&](uint32_t m1) -> uint32_t {   // the second scan, on the value quads of the current tile
+      uint32_t m = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        m |= (uint32_t)in_range_i32(r32b, (int32_t)bswap32(x[k].x)) << (4 * k);
+        m |= (uint32_t)in_range_i32(r32b, (int32_t)bswap32(x[k].y)) << (4 * k + 1);
+        m |= (uint32_t)in_range_i32(r32b, (int32_t)bswap32(x[k].z)) << (4 * k + 2);
+        m |= (uint32_t)in_range_i32(r32b, (int32_t)bswap32(x[k].w)) << (4 * k + 3);
+      }
+      my_cand2 += (uint32_t)__popc(m1);
+      m = r32b.empty ? 0u : (m & m1);
       my_matched += (uint32_t)__popc(m);
       return m;
     };
@@ -435,6 +455,7 @@ __device__ __forceinline__ void pipe_general_body(const PgQueryPlan& p) {
     if (HAS_INDEX || TAIL) issue_postings(wt_far);
     issue_scan(wt_nxt, c_nxt);
     while (wt_cur < n_wtiles_loop) {
+      if (VSCAN) m_cur = value_scan(m_cur);                        // waits for values(cur), as the aggregation does
       if (p.out_words) reinterpret_cast<uint32_t*>(p.out_words)[(int64_t)wt_cur * 64 + lane] = quad_to_lin(m_cur, lane);
       aggregate(m_cur, x, g);                                      // waits for values(cur) only
       const uint32_t m_nxt = test_scan(c_nxt, tq_nxt);             // waits for scan(nxt)
@@ -480,13 +501,17 @@ __device__ __forceinline__ void pipe_general_body(const PgQueryPlan& p) {
     const uint32_t csum = wave_sum_u32(my_cand);
     if (lane == 0 && csum) atomicAdd(&s_stat[L.stat_slot], csum);
   }
+  if (VSCAN) {
+    const uint32_t csum = wave_sum_u32(my_cand2);
+    if (lane == 0 && csum) atomicAdd(&s_stat[L2.stat_slot], csum);
+  }
   __syncthreads();
   flush_workgroup(p, lds_table, s_stat, true, t);
 }
-#define PG_PIPE_KERNEL(NAME, IDX, SCAN, TAILF) \
+#define PG_PIPE_KERNEL(NAME, IDX, SCAN, TAILF, ...) \
   extern "C" __global__ void __launch_bounds__(PG_BLOCK) NAME(const PgQueryPlan p) { \
-    if (p.n_group_cols == 1) pipe_general_body<1, IDX, SCAN, TAILF>(p); \
-    else pipe_general_body<2, IDX, SCAN, TAILF>(p); \
+    if (p.n_group_cols == 1) pipe_general_body<1, IDX, SCAN, TAILF, ##__VA_ARGS__>(p); \
+    else pipe_general_body<2, IDX, SCAN, TAILF, ##__VA_ARGS__>(p); \
   }
 PG_PIPE_KERNEL(pg_pipe_scan, false, true, false)            // the range scan is the whole filter
 PG_PIPE_KERNEL(pg_pipe_scan_tail, false, true, true)        // ... behind an upsert snapshot
@@ -495,3 +520,7 @@ PG_PIPE_KERNEL(pg_pipe_none, false, false, false)           // no filter
 PG_PIPE_KERNEL(pg_pipe_tail, false, false, true)            // only the upsert snapshot
 PG_PIPE_KERNEL(pg_pipe_index, true, false, false)           // inverted-index leaves only
 PG_PIPE_KERNEL(pg_pipe_index_tail, true, false, true)
+PG_PIPE_KERNEL(pg_pipe_index2, true, false, false, false, 2)        // ... with at most two dense posting pointers (one leaf: the snapshot alone)
+PG_PIPE_KERNEL(pg_pipe_index2_tail, true, false, true, false, 2)
+PG_PIPE_KERNEL(pg_pipe_scan_vscan, false, true, false, true)        // range scan AND a range on the value column
+PG_PIPE_KERNEL(pg_pipe_index_scan_vscan, true, true, false, true)   // dense index AND range scan AND a range on the value column

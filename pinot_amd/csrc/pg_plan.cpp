@@ -1714,7 +1714,17 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     const int32_t n_chunks = (int32_t)(((int64_t)seg.total_docs + PG_CHUNK_DOCS - 1) / PG_CHUNK_DOCS);
     const bool index_ok = D.n_index_instr == 0 || D.dense_fused;   // no index program, or the fused dense form
     bool has_scan = false, has_tail = false;
-    if (P.fast_filter == -1) {
+    D.pipe_vscan = -1;
+    if (P.fast_filter == 100 && D.n_fast_scans == 2 && D.tail_posting < 0 && src >= 0 && ok) {
+      // [index] AND range(raw INT a) AND range(value column): the second scan is tested on the value quads
+      const int i1 = em.instrs[(size_t)D.n_index_instr].arg, i2 = em.instrs[(size_t)D.n_index_instr + 1].arg;
+      const PgScanLeaf& S1 = em.scans[(size_t)i1];
+      const PgScanLeaf& S2 = em.scans[(size_t)i2];
+      auto raw_i32_range = [](const PgScanLeaf& S) { return S.col_kind == PG_COL_RAW32 && S.val_type == PG_V_I32 && S.pred_kind == PG_P_RANGE; };
+      has_scan = true;
+      ok = index_ok && raw_i32_range(S1) && raw_i32_range(S2) && S2.data == D.srcs[src].data;
+      if (ok) { D.fast_scan = i1; D.pipe_vscan = i2; }
+    } else if (P.fast_filter == -1) {
       ok = ok && index_ok;
     } else if (P.fast_filter == 4) {
       has_scan = true;
@@ -1736,6 +1746,8 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
       D.pipe_has_index = D.n_index_instr > 0 ? 1 : 0;
       D.pipe_has_scan = has_scan ? 1 : 0;
       if (!has_tail) D.pipe_tail = nullptr;
+    } else {
+      D.pipe_vscan = -1;
     }
   }
   // LDS tables that miss the narrow shape only by column width (group columns > 8 bits, LONG / DOUBLE sources, 64-bit
