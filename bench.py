@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--no-full-check", action="store_true",
                     help="skip the one full-size oracle run that checks the timed GPU result (about 4 s of CPU per 1e9 rows)")
     ap.add_argument("--no-variants", action="store_true", help="skip the north-star (2-key) variant of the default run")
+    ap.add_argument("--require-library-merge", action="store_true",
+                    help="N > 1: exit non-zero when the library's own RCCL communicator cannot be created on every rank, instead of "
+                         "falling back to the torch collective + host reduce")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -93,7 +96,9 @@ def main():
     # the library's own RCCL communicator for the data-path merge: rank 0's unique id travels over the torch process group
     comm = None
     merge_kind = "none (1 segment)"
+    merge_diag = None
     if world > 1:
+        comm_error = ""
         try:
             uid = torch.zeros(capi.COMM_UNIQUE_ID_BYTES, dtype=torch.uint8, device="cuda")
             if rank == 0:
@@ -103,10 +108,32 @@ def main():
             ok = torch.ones(1, device="cuda")
         except Exception as e:   # noqa: BLE001 — an unusable RCCL setup must not sink the run: fall back to the torch collective
             log(f"library RCCL communicator unavailable on rank {rank}: {e}")
+            comm_error = f"{type(e).__name__}: {e}"
             ok = torch.zeros(1, device="cuda")
+        # which ranks hold a library communicator (all of them, or the run falls back / stops): on record in config.merge_diagnostics
+        flags = [torch.zeros(1, device="cuda") for _ in range(world)]
+        dist.all_gather(flags, ok)
+        errors = [None] * world
+        dist.all_gather_object(errors, comm_error)
+        try:
+            rccl_version = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:   # noqa: BLE001
+            rccl_version = "unknown"
+        merge_diag = {"ranks_with_library_communicator": [r for r in range(world) if flags[r].item() >= 1],
+                      "errors": {str(r): e for r, e in enumerate(errors) if e}, "rccl_version": rccl_version,
+                      "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+        if rank == 0:
+            log(f"library communicator on ranks {merge_diag['ranks_with_library_communicator']} of {world}, RCCL {rccl_version}")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if ok.item() < 1:
+            if comm is not None:
+                comm.destroy()
             comm = None
+            if args.require_library_merge:
+                if rank == 0:
+                    log(f"--require-library-merge: no library communicator on every rank: {merge_diag}")
+                dist.destroy_process_group()
+                raise SystemExit(3)
         merge_kind = "pg_result_all_reduce (RCCL inside libpinot_gpu)" if comm is not None else \
             "torch.distributed all_gather_into_tensor (nccl backend) + host reduce"
 
@@ -208,7 +235,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": f"{world} segment(s) x {args.docs} rows, one per GPU; {sql}",
                    "query": args.query, "rows_per_segment": args.docs, "parallelism": f"segment-per-gpu x{world}",
-                   "merge": merge_kind,
+                   "merge": merge_kind, "merge_diagnostics": merge_diag,
                    "matched_docs_per_segment": int(st.num_docs_scanned),
                    "entries_scanned_in_filter": int(st.num_entries_scanned_in_filter)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -250,6 +277,8 @@ def main():
             "roofline_frac": NORTH_STAR_BYTES_PER_ROW * args.docs / (k_n * 1e-3) / 1e9 / HBM_PEAK_GBS if k_n > 0 else 0.0,
             "algorithmic_bytes_per_launch": NORTH_STAR_BYTES_PER_ROW * args.docs}
 
+    if args.query == "cfg3" and rank == 0 and world == 1:
+        out["merge_world_of_one"] = world_of_one_merge(api, seg, qc, local_rank)
     if args.query == "cfg3" and not args.no_variants and rank == 0 and world == 1:
         # BASELINE configs 2 and 5 next to the headline (same timing discipline, their own segments): every default run carries them
         seg.destroy()
@@ -269,6 +298,32 @@ def main():
         seg.destroy()
     if world > 1:
         dist.destroy_process_group()
+
+
+def world_of_one_merge(api, seg, qc, device):
+    """Latency of the library merge itself with nothing to exchange: pg_result_all_reduce over a communicator of ONE rank (the grouped
+    RCCL launch, the signature check on the host, the commit and the reassembly of the rows), on the headline query's result — what a
+    rank pays per query for the collective path before any xGMI transfer.  The result must equal the unmerged one."""
+    from pinot_amd.executor import Comm
+    try:
+        comm = Comm.init_rank(api, device, 1, 0, Comm.unique_id(api))
+    except Exception as e:   # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+    ms = []
+    same = True
+    plain = seg.execute(qc).rows()
+    for i in range(12):
+        nr = seg.execute_native(qc, keep_device_table=True)
+        t = time.perf_counter()
+        nr.all_reduce(comm)
+        ms.append((time.perf_counter() - t) * 1e3)
+        if i == 0:
+            same = nr.block().rows() == plain
+        nr.free()
+    comm.destroy()
+    ms = ms[2:]
+    return {"p50_ms": statistics.median(ms), "min_ms": min(ms), "max_ms": max(ms), "equals_unmerged_result": bool(same),
+            "what": "pg_result_all_reduce, communicator of 1 rank, config 3 result (dense table of 100 groups x 2 accumulators + counts)"}
 
 
 def extra_block(api, args, query, docs, bytes_per_row, columns, sql):

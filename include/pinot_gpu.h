@@ -60,7 +60,12 @@ typedef enum pg_fwd_encoding {
    * on the host during pg_segment_add_column (libzstd.so.1 bound at run time: PG_ERR_UNSUPPORTED without it). */
   PG_FWD_RAW_FIXED_BYTE_CHUNK = 1,
   /* SortedIndexReaderImpl: 2 big-endian ints (startDocId, endDocId inclusive) per dictId; doubles as inverted index. */
-  PG_FWD_DICT_SORTED = 2
+  PG_FWD_DICT_SORTED = 2,
+  /* FixedBitMVForwardIndexReader (multi-value dictionary column, .../readers/forward/FixedBitMVForwardIndexReader.java:57-76):
+   * numChunks big-endian int chunk offsets | row-start bitmap of total_number_of_entries bits (MSB first, one set bit per doc) |
+   * the dictIds of all docs back to back, bits_per_value each, MSB-first bit stream.  numDocsPerChunk =
+   * ceil(2048 / (total_number_of_entries / numDocs)) with the reader's integer division. */
+  PG_FWD_DICT_FIXED_BIT_MV = 3
 } pg_fwd_encoding;
 
 typedef struct pg_buffer {
@@ -82,7 +87,7 @@ typedef struct pg_column_desc {
   int32_t bits_per_value;           /* PG_FWD_DICT_FIXED_BIT: PinotDataBitSet.getNumBitsPerValue(cardinality-1) */
   int32_t is_sorted;                /* DataSourceMetadata#isSorted */
   int32_t dict_bytes_per_value;     /* 4/8 numeric; padded length for fixed-width STRING/BYTES dictionaries */
-  int32_t reserved0;
+  int32_t total_number_of_entries;  /* ColumnMetadata#getTotalNumberOfEntries: PG_FWD_DICT_FIXED_BIT_MV only (>= numDocs), else 0 */
   pg_buffer forward_index;
   pg_buffer dictionary;             /* sorted big-endian fixed-width values (BaseImmutableDictionary.java:45-58) */
   pg_buffer inverted_index;         /* size 0 if the column has no inverted index */
@@ -138,7 +143,17 @@ typedef enum pg_agg_function {   /* AggregationFunctionType (subset named by nor
   PG_AGG_AVG = 4,
   PG_AGG_DISTINCTCOUNT = 5,
   PG_AGG_DISTINCTCOUNTHLL = 6,
-  PG_AGG_MINMAXRANGE = 7
+  PG_AGG_MINMAXRANGE = 7,
+  /* the multi-value forms (CountMV / SumMV / MinMV / MaxMV / AvgMV / MinMaxRangeMV / DistinctCountMV / DistinctCountHLLMV
+   * AggregationFunction.java): every value of every matching doc is aggregated; intermediate results as their single-value forms */
+  PG_AGG_COUNTMV = 8,
+  PG_AGG_SUMMV = 9,
+  PG_AGG_MINMV = 10,
+  PG_AGG_MAXMV = 11,
+  PG_AGG_AVGMV = 12,
+  PG_AGG_MINMAXRANGEMV = 13,
+  PG_AGG_DISTINCTCOUNTMV = 14,
+  PG_AGG_DISTINCTCOUNTHLLMV = 15
 } pg_agg_function;
 
 typedef struct pg_agg_spec {

@@ -36,6 +36,9 @@ typedef struct scan_state {
   int32_t buf_i[PO_SCAN_BATCH];
   int32_t first_mismatch, cursor, next_doc_id;
   int64_t num_entries_scanned;
+  /* MVScanDocIdIterator: DictIdMatcher's buffer of _maxNumValuesPerMVEntry ints and the reader context */
+  int32_t* mv_buf;
+  po_mv_ctx mv_ctx;
 } scan_state;
 
 /* ValueMatcher#doesValueMatch (:213-291) */
@@ -130,6 +133,41 @@ static po_bitmap* scan_apply_and(po_iter* it, const po_bitmap* doc_ids) {
     }
     s->num_entries_scanned += limit;
   }
+  return result;
+}
+
+/* ---- MVScanDocIdIterator, core/operator/dociditerators/MVScanDocIdIterator.java -------------------------------------------------
+ * DictIdMatcher#doesValueMatch (:184-192): read the doc's dictIds, count ALL of them, then PredicateEvaluator#applyMV
+ * (BaseDictionaryBasedPredicateEvaluator.java:164-180: exclusive predicates need every value to pass, the others any value) */
+static int mvscan_does_value_match(scan_state* s, int32_t doc_id) {
+  const int32_t length = po_mv_get_dict_ids(s->col, doc_id, s->mv_buf, &s->mv_ctx);
+  s->num_entries_scanned += length;
+  if (s->eval->exclusive) {
+    for (int32_t i = 0; i < length; i++)
+      if (!po_pred_apply_dict(s->eval, s->mv_buf[i])) return 0;
+    return 1;
+  }
+  for (int32_t i = 0; i < length; i++)
+    if (po_pred_apply_dict(s->eval, s->mv_buf[i])) return 1;
+  return 0;
+}
+static int32_t mvscan_next(po_iter* it) { /* :65-77 */
+  scan_state* s = (scan_state*)it->state;
+  while (s->next_doc_id < s->num_docs) {
+    const int32_t d = s->next_doc_id++;
+    if (mvscan_does_value_match(s, d)) return d;
+  }
+  return PO_EOF;
+}
+static int32_t mvscan_advance(po_iter* it, int32_t target) { /* :80-83 */
+  ((scan_state*)it->state)->next_doc_id = target;
+  return mvscan_next(it);
+}
+static po_bitmap* mvscan_apply_and(po_iter* it, const po_bitmap* doc_ids) { /* applyAnd :86-117: every candidate doc, one by one */
+  scan_state* s = (scan_state*)it->state;
+  po_bitmap* result = po_bitmap_new(doc_ids->universe);
+  for (int64_t pos = po_bitmap_next_set(doc_ids, 0); pos >= 0; pos = po_bitmap_next_set(doc_ids, pos + 1))
+    if (mvscan_does_value_match(s, (int32_t)pos)) po_bitmap_add(result, (int32_t)pos);
   return result;
 }
 
@@ -360,7 +398,14 @@ static po_docidset* scanset_new(const po_pred_eval* eval, const po_column* col, 
   st->eval = eval;
   st->col = col;
   st->num_docs = num_docs;
-  po_iter* it = iter_new(PO_IT_SCAN, scan_next, scan_advance, st);
+  po_iter* it;
+  if (col->is_mv) {   /* ScanBasedFilterOperator#getTrues :61-65: MVScanDocIdSet for a multi-value column */
+    st->mv_buf = (int32_t*)po_xmalloc(sizeof(int32_t) * (size_t)(col->mv_max_values + 1));
+    st->mv_ctx = (po_mv_ctx)PO_MV_CTX_INIT;
+    it = iter_new(PO_IT_SCAN, mvscan_next, mvscan_advance, st);
+  } else {
+    it = iter_new(PO_IT_SCAN, scan_next, scan_advance, st);
+  }
   return set_new(PO_SET_SCAN, scanset_iterator, scanset_entries, it);
 }
 
@@ -472,7 +517,7 @@ static po_iter* andset_iterator(po_docidset* set) {
     for (int s = 0; s < n_scan; s++) {
       po_bitmap* next;
       if (po_bitmap_next_set(doc_ids, 0) < 0) next = po_bitmap_new(cs->num_docs); /* docIds.isEmpty() */
-      else next = scan_apply_and(scan_its[s], doc_ids);
+      else next = ((scan_state*)scan_its[s]->state)->col->is_mv ? mvscan_apply_and(scan_its[s], doc_ids) : scan_apply_and(scan_its[s], doc_ids);
       po_bitmap_free(doc_ids);
       doc_ids = next;
     }
@@ -640,7 +685,7 @@ static int op_priority(const po_filter_op* op) {
     case PO_OP_AND: return 300;
     case PO_OP_OR: return 400;
     case PO_OP_NOT: return op_priority(op->children[0]);
-    case PO_OP_SCAN: return 500;
+    case PO_OP_SCAN: return op->col && op->col->is_mv ? 550 : 500;   /* getScanBasedFilterPriority :253-265: multi-value scans last */
     default: return 10000;
   }
 }

@@ -69,6 +69,11 @@ int32_t po_segment_add_column(void* segp, const pg_column_desc* d) {
   c->inv_len = d->inverted_index.size;
   c->num_docs = seg->total_docs;
   if (c->fwd_encoding == PG_FWD_RAW_FIXED_BYTE_CHUNK && po_raw_parse_header(c)) return PG_ERR_UNSUPPORTED;
+  if (c->fwd_encoding == PG_FWD_DICT_FIXED_BIT_MV) {
+    c->total_entries = d->total_number_of_entries;
+    if (!c->has_dictionary) { po_set_error("raw multi-value column %s is outside the hot path", c->name); return PG_ERR_UNSUPPORTED; }
+    if (po_mv_parse(c)) return PG_ERR_INVALID_ARGUMENT;
+  }
   if (c->fwd_encoding == PG_FWD_DICT_FIXED_BIT) {
     uint64_t need = ((uint64_t)seg->total_docs * (uint64_t)c->bits_per_value + 7) / 8;
     if (c->fwd_len < need) {
@@ -491,6 +496,85 @@ static int32_t gkg_num_keys(group_key_gen* g) {
   return g->holder == HOLDER_INT_MAP ? g->imap.size : g->lmap.size;
 }
 
+/* generateKeysForBlock(ValueBlock, int[][]) → RawKeyHolder#processMultiValue (:357-368 array, :449-459 int map, :648-660 long map) over
+ * getIntRawKeys / getLongRawKeys (:504-573, :714-780): one raw key per combination of the doc's values, built from the last column
+ * down — a single-value column (or a multi-value entry of one value) multiplies every key so far, a multi-value entry of k values
+ * replaces the keys so far by k copies, copy j carrying value j.  Repeated values of a doc repeat their keys.
+ * mv_off / mv_ids: per multi-value column the block's entries (offsets of n_docs + 1, dictIds back to back), NULL for single-value
+ * columns.  out_off has n_docs + 1 entries; *out / *out_cap grow as needed. */
+static void gkg_generate_mv(group_key_gen* g, int n_docs, int32_t** dict_ids, int32_t** mv_off, int32_t** mv_ids, int32_t* out_off,
+                            int32_t** out, int32_t* out_cap) {
+  int64_t* raw = NULL;
+  int32_t raw_cap = 0, total = 0;
+  for (int i = 0; i < n_docs; i++) {
+    int32_t n_keys = 0;     /* 0: still the single rawKey */
+    int64_t raw_key = 0;
+    for (int j = g->n_cols - 1; j >= 0; j--) {
+      const int64_t card = g->cardinalities[j];
+      const int single = mv_off[j] == NULL;
+      const int32_t n_values = single ? 1 : mv_off[j][i + 1] - mv_off[j][i];
+      if (single || n_values == 1) {
+        const int32_t d = single ? dict_ids[j][i] : mv_ids[j][mv_off[j][i]];
+        if (n_keys == 0) raw_key = raw_key * card + d;
+        else for (int32_t k = 0; k < n_keys; k++) raw[k] = raw[k] * card + d;
+      } else {
+        const int32_t* vals = mv_ids[j] + mv_off[j][i];
+        const int32_t cur = n_keys == 0 ? 1 : n_keys, next = cur * n_values;
+        if (next > raw_cap) { raw_cap = next * 2; raw = (int64_t*)po_xrealloc(raw, sizeof(int64_t) * (size_t)raw_cap); }
+        if (n_keys == 0) raw[0] = raw_key;
+        for (int32_t v = n_values - 1; v >= 0; v--)          /* copy v = the keys so far extended by value v (copy 0 last: in place) */
+          for (int32_t k = 0; k < cur; k++) raw[v * cur + k] = raw[k] * card + vals[v];
+        n_keys = next;
+      }
+    }
+    if (n_keys == 0) {
+      if (1 > raw_cap) { raw_cap = 16; raw = (int64_t*)po_xrealloc(raw, sizeof(int64_t) * (size_t)raw_cap); }
+      raw[0] = raw_key;
+      n_keys = 1;
+    }
+    if (total + n_keys > *out_cap) {
+      *out_cap = (total + n_keys) * 2;
+      *out = (int32_t*)po_xrealloc(*out, sizeof(int32_t) * (size_t)*out_cap);
+    }
+    out_off[i] = total;
+    for (int32_t k = 0; k < n_keys; k++) {
+      int32_t gid;
+      if (g->holder == HOLDER_ARRAY) {
+        gid = (int32_t)raw[k];
+        if (!g->flags[gid]) { g->flags[gid] = 1; g->num_keys++; }
+      } else if (g->holder == HOLDER_INT_MAP) {
+        int32_t before = g->imap.size;
+        gid = igm_get_group_id(&g->imap, (int32_t)raw[k], g->global_upper_bound);
+        if (g->imap.size != before) gkg_remember(g, gid, raw[k]);
+      } else {
+        int32_t before = g->lmap.size;
+        gid = lm_get_group_id(&g->lmap, raw[k], g->global_upper_bound);
+        if (g->lmap.size != before) gkg_remember(g, gid, raw[k]);
+      }
+      (*out)[total++] = gid;
+    }
+  }
+  out_off[n_docs] = total;
+  free(raw);
+}
+
+/* the single-value function a multi-value function extends (CountMV extends Count, SumMV extends Sum, ...): holders, merge and
+ * result extraction are the parent's */
+static int sv_function_of(int f) {
+  switch (f) {
+    case PG_AGG_COUNTMV: return PG_AGG_COUNT;
+    case PG_AGG_SUMMV: return PG_AGG_SUM;
+    case PG_AGG_MINMV: return PG_AGG_MIN;
+    case PG_AGG_MAXMV: return PG_AGG_MAX;
+    case PG_AGG_AVGMV: return PG_AGG_AVG;
+    case PG_AGG_MINMAXRANGEMV: return PG_AGG_MINMAXRANGE;
+    case PG_AGG_DISTINCTCOUNTMV: return PG_AGG_DISTINCTCOUNT;
+    case PG_AGG_DISTINCTCOUNTHLLMV: return PG_AGG_DISTINCTCOUNTHLL;
+    default: return f;
+  }
+}
+static int is_mv_function(int f) { return f >= PG_AGG_COUNTMV && f <= PG_AGG_DISTINCTCOUNTHLLMV; }
+
 /* =====================================================================================================================
  * aggregation functions with their result holders
  * ===================================================================================================================== */
@@ -515,7 +599,7 @@ static void agg_ensure_capacity(agg_state* a, int32_t needed) { /* GroupByResult
   while (cap < needed) cap *= 2;
   a->capacity = cap;
   double def0 = 0.0, def1 = 0.0;
-  switch (a->function) {
+  switch (sv_function_of(a->function)) {
     case PG_AGG_MIN: def0 = INFINITY; break;                 /* MinAggregationFunction DEFAULT_VALUE */
     case PG_AGG_MAX: def0 = -INFINITY; break;                /* MaxAggregationFunction.java:37 */
     default: break;
@@ -525,7 +609,7 @@ static void agg_ensure_capacity(agg_state* a, int32_t needed) { /* GroupByResult
   a->l0 = (int64_t*)po_xrealloc(a->l0, sizeof(int64_t) * (size_t)cap);
   a->has = (uint8_t*)po_xrealloc(a->has, (size_t)cap);
   for (int32_t i = old; i < cap; i++) { a->d0[i] = def0; a->d1[i] = def1; a->l0[i] = 0; a->has[i] = 0; }
-  if (a->function == PG_AGG_DISTINCTCOUNT || a->function == PG_AGG_DISTINCTCOUNTHLL) {
+  if (sv_function_of(a->function) == PG_AGG_DISTINCTCOUNT || sv_function_of(a->function) == PG_AGG_DISTINCTCOUNTHLL) {
     a->dict_bitmaps = (po_bitmap**)po_xrealloc(a->dict_bitmaps, sizeof(void*) * (size_t)cap);
     a->hlls = (po_hll**)po_xrealloc(a->hlls, sizeof(void*) * (size_t)cap);
     for (int32_t i = old; i < cap; i++) { a->dict_bitmaps[i] = NULL; a->hlls[i] = NULL; }
@@ -538,7 +622,35 @@ typedef struct block_col {
   int32_t* dict_ids;     /* valid if col->has_dictionary */
   double* doubles;       /* getDoubleValuesSV */
   int have_dict_ids, have_doubles;
+  /* multi-value column: getDictionaryIdsMV / getDoubleValuesMV / getNumMVEntries of the block — offsets of n + 1, entries back to back;
+   * the reader context lives as long as the column's ColumnValueReader (DataFetcher.java:317-333) */
+  int32_t* mv_off; int32_t* mv_ids; double* mv_doubles; int32_t mv_cap;
+  int have_mv, have_mv_doubles;
+  po_mv_ctx mv_ctx;
 } block_col;
+
+static void fetch_mv_dict_ids(block_col* bc, const int32_t* doc_ids, int n) { /* DataFetcher.ColumnValueReader#readDictIdsMV :418-425 */
+  if (bc->have_mv) return;
+  po_column* c = bc->col;
+  int32_t total = 0;
+  for (int i = 0; i < n; i++) {
+    if (total + c->mv_max_values > bc->mv_cap) {
+      bc->mv_cap = (total + c->mv_max_values) * 2 + 16;
+      bc->mv_ids = (int32_t*)po_xrealloc(bc->mv_ids, sizeof(int32_t) * (size_t)bc->mv_cap);
+      bc->mv_doubles = (double*)po_xrealloc(bc->mv_doubles, sizeof(double) * (size_t)bc->mv_cap);
+    }
+    bc->mv_off[i] = total;
+    total += po_mv_get_dict_ids(c, doc_ids[i], bc->mv_ids + total, &bc->mv_ctx);
+  }
+  bc->mv_off[n] = total;
+  bc->have_mv = 1;
+}
+static void fetch_mv_doubles(block_col* bc, const int32_t* doc_ids, int n) { /* readDoubleValuesMV: dictionary.readDoubleValues per entry */
+  if (bc->have_mv_doubles) return;
+  fetch_mv_dict_ids(bc, doc_ids, n);
+  for (int32_t k = 0; k < bc->mv_off[n]; k++) bc->mv_doubles[k] = po_dict_get_double(bc->col, bc->mv_ids[k]);
+  bc->have_mv_doubles = 1;
+}
 
 static void fetch_dict_ids(block_col* bc, const int32_t* doc_ids, int n) { /* DataFetcher#fetchDictIds */
   if (bc->have_dict_ids) return;
@@ -571,60 +683,58 @@ static void hll_offer_raw(po_hll* h, po_column* c, int32_t doc_id) {
   }
 }
 
-/* aggregateGroupBySV of each function; group_keys == NULL means the non-group-by `aggregate` (single holder 0).
+/* aggregate / aggregateGroupBySV / aggregateGroupByMV of each function.  group_keys == NULL and mvk_off == NULL: the non-group-by
+ * `aggregate` (single holder 0); mvk_off != NULL: the block's group keys are lists (a multi-value group-by column: every key of a doc
+ * receives the doc's value, in list order).
  *   COUNT  CountAggregationFunction.java:110-143 (holder += 1 in double)      SUM   SumAggregationFunction.java:160-179
  *   MIN    MinAggregationFunction.java:163-188 (value < holder)               MAX   MaxAggregationFunction.java:163-188
  *   AVG    AvgAggregationFunction (AvgPair sum,count)                         MINMAXRANGE MinMaxRangeAggregationFunction
- *   DISTINCTCOUNT BaseDistinctAggregateAggregationFunction.java:306-345       HLL   DistinctCountHLLAggregationFunction.java:152-222 */
-static void agg_process_block(agg_state* a, block_col* bc, const int32_t* doc_ids, int n, const int32_t* group_keys) {
+ *   DISTINCTCOUNT BaseDistinctAggregateAggregationFunction.java:306-345       HLL   DistinctCountHLLAggregationFunction.java:152-222
+ *   the *MV forms: CountMV / SumMV / MinMV / MaxMV / AvgMV / MinMaxRangeMV AggregationFunction.java (whole files), DISTINCTCOUNTMV /
+ *   DISTINCTCOUNTHLLMV: the dictId bitmap takes every dictId of the doc */
+#define FOR_EACH_GROUP(i, g)                                                                                             \
+  for (int32_t gk_ = 0, gk_n_ = mvk_off ? mvk_off[(i) + 1] - mvk_off[(i)] : 1; gk_ < gk_n_; gk_++)                        \
+    for (int32_t g = mvk_off ? mvk[mvk_off[(i)] + gk_] : (group_keys ? group_keys[(i)] : 0), once_ = 1; once_ && g != PO_INVALID_ID; once_ = 0)
+static void agg_process_block(agg_state* a, block_col* bc, const int32_t* doc_ids, int n, const int32_t* group_keys,
+                              const int32_t* mvk_off, const int32_t* mvk) {
+  const int grouped = group_keys != NULL || mvk_off != NULL;
   switch (a->function) {
     case PG_AGG_COUNT:
       if (a->star) { /* star-tree pre-aggregated values: CountAggregationFunction.java:99-106,134-141 */
-        if (!group_keys) {
+        if (!grouped) {
           int64_t count = 0;
           for (int i = 0; i < n; i++) count += po_raw_get_long(a->col, doc_ids[i]);
           a->d0[0] = a->d0[0] + (double)count;
           return;
         }
-        for (int i = 0; i < n; i++) {
-          int32_t g = group_keys[i];
-          if (g != PO_INVALID_ID) a->d0[g] = a->d0[g] + (double)po_raw_get_long(a->col, doc_ids[i]);
-        }
+        for (int i = 0; i < n; i++) FOR_EACH_GROUP(i, g) a->d0[g] = a->d0[g] + (double)po_raw_get_long(a->col, doc_ids[i]);
         return;
       }
-      if (!group_keys) { a->d0[0] += n; return; }
-      for (int i = 0; i < n; i++) { int32_t g = group_keys[i]; if (g != PO_INVALID_ID) a->d0[g] += 1; }
+      if (!grouped) { a->d0[0] += n; return; }
+      for (int i = 0; i < n; i++) FOR_EACH_GROUP(i, g) a->d0[g] += 1;
       return;
     case PG_AGG_SUM: {
       fetch_doubles(bc, doc_ids, n);
-      if (!group_keys) { /* SumAggregationFunction#aggregate: per-block inner sum, then holder += innerSum */
+      if (!grouped) { /* SumAggregationFunction#aggregate: per-block inner sum, then holder += innerSum */
         double inner = 0;
         for (int i = 0; i < n; i++) inner += bc->doubles[i];
         a->d0[0] = inner + a->d0[0];
         return;
       }
-      for (int i = 0; i < n; i++) { int32_t g = group_keys[i]; if (g != PO_INVALID_ID) a->d0[g] = a->d0[g] + bc->doubles[i]; }
+      for (int i = 0; i < n; i++) FOR_EACH_GROUP(i, g) a->d0[g] = a->d0[g] + bc->doubles[i];
       return;
     }
     case PG_AGG_MIN:
       fetch_doubles(bc, doc_ids, n);
-      for (int i = 0; i < n; i++) {
-        int32_t g = group_keys ? group_keys[i] : 0;
-        if (g != PO_INVALID_ID && bc->doubles[i] < a->d0[g]) a->d0[g] = bc->doubles[i];
-      }
+      for (int i = 0; i < n; i++) FOR_EACH_GROUP(i, g) if (bc->doubles[i] < a->d0[g]) a->d0[g] = bc->doubles[i];
       return;
     case PG_AGG_MAX:
       fetch_doubles(bc, doc_ids, n);
-      for (int i = 0; i < n; i++) {
-        int32_t g = group_keys ? group_keys[i] : 0;
-        if (g != PO_INVALID_ID && bc->doubles[i] > a->d0[g]) a->d0[g] = bc->doubles[i];
-      }
+      for (int i = 0; i < n; i++) FOR_EACH_GROUP(i, g) if (bc->doubles[i] > a->d0[g]) a->d0[g] = bc->doubles[i];
       return;
     case PG_AGG_AVG:
       if (a->col->data_type == PG_TYPE_BYTES) {   /* serialized AvgPair (star-tree pair avg__x): AvgAggregationFunction.java:79-93,117-126 */
-        for (int i = 0; i < n; i++) {
-          int32_t g = group_keys ? group_keys[i] : 0;
-          if (g == PO_INVALID_ID) continue;
+        for (int i = 0; i < n; i++) FOR_EACH_GROUP(i, g) {
           int32_t len = 0;
           const uint8_t* blob = po_raw_get_bytes(a->col, doc_ids[i], &len);
           if (len < 16) continue;
@@ -633,23 +743,17 @@ static void agg_process_block(agg_state* a, block_col* bc, const int32_t* doc_id
         return;
       }
       fetch_doubles(bc, doc_ids, n);
-      if (!group_keys) {
+      if (!grouped) {
         double inner = 0;
         for (int i = 0; i < n; i++) inner += bc->doubles[i];
         a->d0[0] += inner; a->l0[0] += n; a->has[0] = 1;
         return;
       }
-      for (int i = 0; i < n; i++) {
-        int32_t g = group_keys[i];
-        if (g == PO_INVALID_ID) continue;
-        a->d0[g] += bc->doubles[i]; a->l0[g] += 1; a->has[g] = 1;
-      }
+      for (int i = 0; i < n; i++) FOR_EACH_GROUP(i, g) { a->d0[g] += bc->doubles[i]; a->l0[g] += 1; a->has[g] = 1; }
       return;
     case PG_AGG_MINMAXRANGE:
       if (a->col->data_type == PG_TYPE_BYTES) {   /* serialized MinMaxRangePair (star-tree pair minMaxRange__x): MinMaxRangeAggregationFunction */
-        for (int i = 0; i < n; i++) {
-          int32_t g = group_keys ? group_keys[i] : 0;
-          if (g == PO_INVALID_ID) continue;
+        for (int i = 0; i < n; i++) FOR_EACH_GROUP(i, g) {
           int32_t len = 0;
           const uint8_t* blob = po_raw_get_bytes(a->col, doc_ids[i], &len);
           if (len < 16) continue;
@@ -660,9 +764,7 @@ static void agg_process_block(agg_state* a, block_col* bc, const int32_t* doc_id
         return;
       }
       fetch_doubles(bc, doc_ids, n);
-      for (int i = 0; i < n; i++) {
-        int32_t g = group_keys ? group_keys[i] : 0;
-        if (g == PO_INVALID_ID) continue;
+      for (int i = 0; i < n; i++) FOR_EACH_GROUP(i, g) {
         double v = bc->doubles[i];
         if (!a->has[g]) { a->d0[g] = v; a->d1[g] = v; a->has[g] = 1; }
         else { if (v < a->d0[g]) a->d0[g] = v; if (v > a->d1[g]) a->d1[g] = v; }
@@ -672,9 +774,7 @@ static void agg_process_block(agg_state* a, block_col* bc, const int32_t* doc_id
     case PG_AGG_DISTINCTCOUNTHLL: {
       po_column* c = a->col;
       if (c->data_type == PG_TYPE_BYTES) { /* serialized HyperLogLog (star-tree pair): DistinctCountHLLAggregationFunction.java:158-175 */
-        for (int i = 0; i < n; i++) {
-          int32_t g = group_keys ? group_keys[i] : 0;
-          if (g == PO_INVALID_ID) continue;
+        for (int i = 0; i < n; i++) FOR_EACH_GROUP(i, g) {
           int32_t len = 0;
           const uint8_t* blob = po_raw_get_bytes(c, doc_ids[i], &len);
           po_hll* v = po_hll_deserialize(blob, len);
@@ -686,22 +786,93 @@ static void agg_process_block(agg_state* a, block_col* bc, const int32_t* doc_id
       }
       if (c->has_dictionary) {
         fetch_dict_ids(bc, doc_ids, n);
-        for (int i = 0; i < n; i++) {
-          int32_t g = group_keys ? group_keys[i] : 0;
-          if (g == PO_INVALID_ID) continue;
+        for (int i = 0; i < n; i++) FOR_EACH_GROUP(i, g) {
           if (!a->dict_bitmaps[g]) a->dict_bitmaps[g] = po_bitmap_new_small(c->cardinality);
           po_bitmap_add(a->dict_bitmaps[g], bc->dict_ids[i]);
         }
       } else if (a->function == PG_AGG_DISTINCTCOUNTHLL) {
-        for (int i = 0; i < n; i++) {
-          int32_t g = group_keys ? group_keys[i] : 0;
-          if (g == PO_INVALID_ID) continue;
+        for (int i = 0; i < n; i++) FOR_EACH_GROUP(i, g) {
           if (!a->hlls[g]) a->hlls[g] = po_hll_new(a->log2m);
           hll_offer_raw(a->hlls[g], c, doc_ids[i]);
         }
       }
       return;
     }
+    /* ---- the multi-value forms ------------------------------------------------------------------------------------------------- */
+    case PG_AGG_COUNTMV: {   /* CountMVAggregationFunction.java:62-96: getNumMVEntries */
+      fetch_mv_dict_ids(bc, doc_ids, n);
+      if (!grouped) {
+        int64_t count = 0;
+        for (int i = 0; i < n; i++) count += bc->mv_off[i + 1] - bc->mv_off[i];
+        a->d0[0] = a->d0[0] + (double)count;
+        return;
+      }
+      for (int i = 0; i < n; i++) FOR_EACH_GROUP(i, g) a->d0[g] = a->d0[g] + (bc->mv_off[i + 1] - bc->mv_off[i]);
+      return;
+    }
+    case PG_AGG_SUMMV:       /* SumMVAggregationFunction.java:41-84: sum = holder; sum += value for every value; holder = sum */
+      fetch_mv_doubles(bc, doc_ids, n);
+      if (!grouped) {
+        double sum = a->d0[0];
+        for (int32_t k = 0; k < bc->mv_off[n]; k++) sum += bc->mv_doubles[k];
+        a->d0[0] = sum;
+        return;
+      }
+      for (int i = 0; i < n; i++) FOR_EACH_GROUP(i, g) {
+        double sum = a->d0[g];
+        for (int32_t k = bc->mv_off[i]; k < bc->mv_off[i + 1]; k++) sum += bc->mv_doubles[k];
+        a->d0[g] = sum;
+      }
+      return;
+    case PG_AGG_MINMV:       /* MinMVAggregationFunction.java:41-93 */
+      fetch_mv_doubles(bc, doc_ids, n);
+      for (int i = 0; i < n; i++) FOR_EACH_GROUP(i, g)
+        for (int32_t k = bc->mv_off[i]; k < bc->mv_off[i + 1]; k++) if (bc->mv_doubles[k] < a->d0[g]) a->d0[g] = bc->mv_doubles[k];
+      return;
+    case PG_AGG_MAXMV:       /* MaxMVAggregationFunction.java */
+      fetch_mv_doubles(bc, doc_ids, n);
+      for (int i = 0; i < n; i++) FOR_EACH_GROUP(i, g)
+        for (int32_t k = bc->mv_off[i]; k < bc->mv_off[i + 1]; k++) if (bc->mv_doubles[k] > a->d0[g]) a->d0[g] = bc->mv_doubles[k];
+      return;
+    case PG_AGG_AVGMV:       /* AvgMVAggregationFunction.java:41-95: block sum + count (aggregate), per-doc sum + count (group-by) */
+      fetch_mv_doubles(bc, doc_ids, n);
+      if (!grouped) {
+        double sum = 0.0;
+        for (int32_t k = 0; k < bc->mv_off[n]; k++) sum += bc->mv_doubles[k];
+        a->d0[0] += sum; a->l0[0] += bc->mv_off[n]; a->has[0] = 1;
+        return;
+      }
+      for (int i = 0; i < n; i++) FOR_EACH_GROUP(i, g) {
+        double sum = 0.0;
+        for (int32_t k = bc->mv_off[i]; k < bc->mv_off[i + 1]; k++) sum += bc->mv_doubles[k];
+        a->d0[g] += sum; a->l0[g] += bc->mv_off[i + 1] - bc->mv_off[i]; a->has[g] = 1;
+      }
+      return;
+    case PG_AGG_MINMAXRANGEMV: {   /* MinMaxRangeMVAggregationFunction.java:41-106: (min, max) of the block / the doc, then the pair update */
+      fetch_mv_doubles(bc, doc_ids, n);
+      if (!grouped) {
+        double lo = INFINITY, hi = -INFINITY;
+        for (int32_t k = 0; k < bc->mv_off[n]; k++) { if (bc->mv_doubles[k] < lo) lo = bc->mv_doubles[k]; if (bc->mv_doubles[k] > hi) hi = bc->mv_doubles[k]; }
+        if (!a->has[0]) { a->d0[0] = lo; a->d1[0] = hi; a->has[0] = 1; }
+        else { if (lo < a->d0[0]) a->d0[0] = lo; if (hi > a->d1[0]) a->d1[0] = hi; }
+        return;
+      }
+      for (int i = 0; i < n; i++) FOR_EACH_GROUP(i, g) {
+        double lo = INFINITY, hi = -INFINITY;
+        for (int32_t k = bc->mv_off[i]; k < bc->mv_off[i + 1]; k++) { if (bc->mv_doubles[k] < lo) lo = bc->mv_doubles[k]; if (bc->mv_doubles[k] > hi) hi = bc->mv_doubles[k]; }
+        if (!a->has[g]) { a->d0[g] = lo; a->d1[g] = hi; a->has[g] = 1; }
+        else { if (lo < a->d0[g]) a->d0[g] = lo; if (hi > a->d1[g]) a->d1[g] = hi; }
+      }
+      return;
+    }
+    case PG_AGG_DISTINCTCOUNTMV:
+    case PG_AGG_DISTINCTCOUNTHLLMV:   /* dictionary-encoded: RoaringBitmap#add(int[]) of the doc's dictIds */
+      fetch_mv_dict_ids(bc, doc_ids, n);
+      for (int i = 0; i < n; i++) FOR_EACH_GROUP(i, g) {
+        if (!a->dict_bitmaps[g]) a->dict_bitmaps[g] = po_bitmap_new_small(a->col->cardinality);
+        for (int32_t k = bc->mv_off[i]; k < bc->mv_off[i + 1]; k++) po_bitmap_add(a->dict_bitmaps[g], bc->mv_ids[k]);
+      }
+      return;
     default: return;
   }
 }
@@ -750,7 +921,7 @@ typedef struct po_result_impl {
 } po_result_impl;
 
 static int result_kind(int function) {
-  switch (function) {
+  switch (sv_function_of(function)) {
     case PG_AGG_COUNT: return PG_RESULT_LONG;
     case PG_AGG_AVG: return PG_RESULT_AVG_PAIR;
     case PG_AGG_MINMAXRANGE: return PG_RESULT_MINMAX_PAIR;
@@ -799,7 +970,7 @@ static void extract_agg(po_agg_result* r, agg_state* a, int32_t n_groups, const 
   }
   for (int32_t i = 0; i < n_groups; i++) {
     int32_t g = gid_of[i];
-    switch (a->function) {
+    switch (sv_function_of(a->function)) {
       case PG_AGG_COUNT: r->l[0][i] = (int64_t)a->d0[g]; break;          /* extractGroupByResult: (long) double */
       case PG_AGG_AVG: r->d[0][i] = a->d0[g]; r->l[0][i] = a->l0[g]; break;
       case PG_AGG_MINMAXRANGE:   /* extractAggregationResult / extractGroupByResult (:162-181): no value → new MinMaxRangePair() = (+inf, -inf) */
@@ -857,12 +1028,17 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
       po_set_error("DISTINCTCOUNT over a raw column is outside the hot path");
       return PG_ERR_UNSUPPORTED;
     }
+    if (is_mv_function(s->function) != (c->is_mv != 0)) {   /* BlockValSet#getDoubleValuesSV / MV on the wrong kind of column throws */
+      po_set_error("aggregation %d over %s column %s", s->function, c->is_mv ? "multi-value" : "single-value", c->name);
+      return PG_ERR_INVALID_ARGUMENT;
+    }
     aggs[i].col = c;
     int seen = 0;
     for (int k = 0; k < n_proj; k++) seen |= (proj[k] == c);
     if (!seen) proj[n_proj++] = c;
   }
   po_column** gcols = (po_column**)po_xcalloc((size_t)n_gb + 1, sizeof(po_column*));
+  int mv_group_by = 0;   /* DefaultGroupByExecutor._hasMVGroupByExpression */
   for (int j = 0; j < n_gb; j++) {
     po_column* c = po_segment_column(seg, q->group_by_columns[j]);
     if (!c) { po_set_error("column not found: %s", q->group_by_columns[j]); return PG_ERR_NOT_FOUND; }
@@ -871,10 +1047,14 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
       return PG_ERR_UNSUPPORTED;
     }
     gcols[j] = c;
+    mv_group_by |= c->is_mv;
     int seen = 0;
     for (int k = 0; k < n_proj; k++) seen |= (proj[k] == c);
     if (!seen) proj[n_proj++] = c;
   }
+  if (mv_group_by)
+    for (int j = 0; j < n_gb; j++)
+      if (!gcols[j]->has_dictionary) { po_set_error("multi-value group-by next to a no-dictionary column is outside the hot path"); return PG_ERR_UNSUPPORTED; }
 
   /* AggregationPlanNode: FastFilteredCountOperator (core/plan/AggregationPlanNode.java:106-108,192-196) */
   if (n_gb == 0 && n_aggs == 1 && aggs[0].function == PG_AGG_COUNT && po_filter_can_optimize_count(filter_op)) {
@@ -897,8 +1077,9 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
   if (n_gb == 0 && filter_op->kind == PO_OP_MATCH_ALL) {
     int fit = 1;
     for (int i = 0; i < n_aggs && fit; i++) {
-      int f = aggs[i].function;
-      if (f == PG_AGG_COUNT) continue;
+      int f = sv_function_of(aggs[i].function);   /* DICTIONARY_BASED_FUNCTIONS holds MINMV / MAXMV / MINMAXRANGEMV / DISTINCTCOUNT(HLL)MV as well */
+      if (aggs[i].function == PG_AGG_COUNT) continue;
+      if (aggs[i].function == PG_AGG_COUNTMV || aggs[i].function == PG_AGG_SUMMV || aggs[i].function == PG_AGG_AVGMV) { fit = 0; break; }
       fit = aggs[i].col->has_dictionary && (f == PG_AGG_MIN || f == PG_AGG_MAX || f == PG_AGG_MINMAXRANGE ||
                                             f == PG_AGG_DISTINCTCOUNT || f == PG_AGG_DISTINCTCOUNTHLL) &&
             (aggs[i].col->data_type <= PG_TYPE_DOUBLE || f == PG_AGG_DISTINCTCOUNT || f == PG_AGG_DISTINCTCOUNTHLL);
@@ -911,7 +1092,7 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
         agg_state* a = &aggs[i];
         agg_ensure_capacity(a, 1);
         po_column* c = a->col;
-        switch (a->function) {
+        switch (sv_function_of(a->function)) {
           case PG_AGG_COUNT: a->d0[0] = (double)seg->total_docs; break;
           case PG_AGG_MIN: a->d0[0] = po_dict_get_double(c, 0); break;
           case PG_AGG_MAX: a->d0[0] = po_dict_get_double(c, c->cardinality - 1); break;
@@ -984,7 +1165,16 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
     bcols[k].col = proj[k];
     bcols[k].dict_ids = (int32_t*)po_xmalloc(sizeof(int32_t) * PO_MAX_DOC_PER_CALL);
     bcols[k].doubles = (double*)po_xmalloc(sizeof(double) * PO_MAX_DOC_PER_CALL);
+    if (proj[k]->is_mv) {
+      bcols[k].mv_off = (int32_t*)po_xmalloc(sizeof(int32_t) * (PO_MAX_DOC_PER_CALL + 1));
+      bcols[k].mv_ctx = (po_mv_ctx)PO_MV_CTX_INIT;
+    }
   }
+  int32_t** gmv_off = (int32_t**)po_xcalloc((size_t)n_gb + 1, sizeof(int32_t*));
+  int32_t** gmv_ids = (int32_t**)po_xcalloc((size_t)n_gb + 1, sizeof(int32_t*));
+  int32_t* mvk_off = mv_group_by ? (int32_t*)po_xmalloc(sizeof(int32_t) * (PO_MAX_DOC_PER_CALL + 1)) : NULL;
+  int32_t* mvk = NULL;
+  int32_t mvk_cap = 0;
   int32_t** gdict = (int32_t**)po_xcalloc((size_t)n_gb + 1, sizeof(int32_t*));
   int64_t num_docs_scanned = 0;
   int32_t cur = 0;
@@ -997,9 +1187,19 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
     }
     if (pos == 0) break;
     num_docs_scanned += pos;
-    for (int k = 0; k < n_proj; k++) bcols[k].have_dict_ids = bcols[k].have_doubles = 0;
+    for (int k = 0; k < n_proj; k++) bcols[k].have_dict_ids = bcols[k].have_doubles = bcols[k].have_mv = bcols[k].have_mv_doubles = 0;
     const int32_t* keys = NULL;
-    if (n_gb > 0) {
+    if (n_gb > 0 && mv_group_by) {   /* DefaultGroupByExecutor#process :150-158: generateKeysForBlock(valueBlock, _mvGroupKeys) */
+      for (int j = 0; j < n_gb; j++)
+        for (int k = 0; k < n_proj; k++) {
+          if (bcols[k].col != gcols[j]) continue;
+          if (gcols[j]->is_mv) { fetch_mv_dict_ids(&bcols[k], doc_ids, pos); gmv_off[j] = bcols[k].mv_off; gmv_ids[j] = bcols[k].mv_ids; }
+          else { fetch_dict_ids(&bcols[k], doc_ids, pos); gdict[j] = bcols[k].dict_ids; gmv_off[j] = NULL; }
+        }
+      gkg_generate_mv(&gkg, pos, gdict, gmv_off, gmv_ids, mvk_off, &mvk, &mvk_cap);
+      int32_t needed = gkg_upper_bound(&gkg);
+      for (int i = 0; i < n_aggs; i++) agg_ensure_capacity(&aggs[i], needed);
+    } else if (n_gb > 0) {
       if (gkg.holder == HOLDER_RAW_VALUES) {
         gkg_generate_raw(&gkg, pos, doc_ids, group_keys);
       } else if (gkg.holder == HOLDER_TUPLES) {
@@ -1023,7 +1223,7 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
     for (int i = 0; i < n_aggs; i++) {
       block_col* bc = NULL;
       for (int k = 0; k < n_proj; k++) if (bcols[k].col == aggs[i].col) bc = &bcols[k];
-      agg_process_block(&aggs[i], bc, doc_ids, pos, keys);
+      agg_process_block(&aggs[i], bc, doc_ids, pos, keys, mv_group_by ? mvk_off : NULL, mvk);
     }
   }
 

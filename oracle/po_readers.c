@@ -101,6 +101,80 @@ void po_fwd_read_dict_ids(const po_column* c, const int32_t* doc_ids, int32_t le
   for (int i = index; i < length; i++) out[i] = po_fixedbit_read(c, doc_ids[i]);
 }
 
+/* ---- FixedBitMVForwardIndexReader -------------------------------------------------------------------------------------
+ * pinot-segment-local/.../segment/index/readers/forward/FixedBitMVForwardIndexReader.java:57-76 (layout), :94-131 (getDictIdMV);
+ * PinotDataBitSet#getNextSetBitOffset / getNextNthSetBitOffset (pinot-segment-local/.../io/util/PinotDataBitSet.java) — bits are
+ * MSB first within a byte. */
+int po_mv_parse(po_column* c) {
+  const int32_t num_docs = c->num_docs, num_values = c->total_entries;
+  if (num_docs <= 0 || num_values < num_docs) {
+    po_set_error("multi-value column %s: %d values over %d docs", c->name, num_values, num_docs);
+    return -1;
+  }
+  c->is_mv = 1;
+  c->mv_docs_per_chunk = (int32_t)ceilf((float)2048 / (float)(num_values / num_docs));   /* :62 (PREFERRED_NUM_VALUES_PER_CHUNK, int division) */
+  const int64_t num_chunks = ((int64_t)num_docs + c->mv_docs_per_chunk - 1) / c->mv_docs_per_chunk;
+  const int64_t bitmap_size = ((int64_t)num_values + 7) / 8;
+  const int64_t raw_size = ((int64_t)num_values * c->bits_per_value + 7) / 8;
+  if ((int64_t)c->fwd_len < num_chunks * 4 + bitmap_size + raw_size) {
+    po_set_error("multi-value forward index of %s is %llu bytes, need %lld", c->name, (unsigned long long)c->fwd_len,
+                 (long long)(num_chunks * 4 + bitmap_size + raw_size));
+    return -1;
+  }
+  c->mv_chunk_offsets = c->fwd;
+  c->mv_bitmap = c->fwd + num_chunks * 4;
+  c->mv_raw = c->mv_bitmap + bitmap_size;
+  /* getMaxNumberOfMultiValues: the longest gap between row starts */
+  int32_t prev = -1, longest = 0;
+  for (int32_t i = 0; i < num_values; i++) {
+    if (c->mv_bitmap[i >> 3] & (0x80 >> (i & 7))) {
+      if (prev >= 0 && i - prev > longest) longest = i - prev;
+      prev = i;
+    }
+  }
+  if (prev >= 0 && num_values - prev > longest) longest = num_values - prev;
+  c->mv_max_values = longest;
+  return 0;
+}
+static inline int mv_bit(const po_column* c, int32_t i) { return (c->mv_bitmap[i >> 3] >> (7 - (i & 7))) & 1; }
+static int32_t mv_next_set_bit(const po_column* c, int32_t from) {          /* getNextSetBitOffset(bitOffset) */
+  while (!mv_bit(c, from)) from++;
+  return from;
+}
+static int32_t mv_next_nth_set_bit(const po_column* c, int32_t from, int32_t n) {   /* getNextNthSetBitOffset(bitOffset, n), n >= 1 */
+  for (;; from++) {
+    if (mv_bit(c, from) && --n == 0) return from;
+  }
+}
+static int32_t mv_fixedbit(const po_column* c, int32_t index) {   /* FixedBitIntReaderWriter#readInt over the raw data view */
+  po_column v;
+  memset(&v, 0, sizeof(v));
+  v.fwd = c->mv_raw;
+  v.bits_per_value = c->bits_per_value;
+  return po_fixedbit_read(&v, index);
+}
+int32_t po_mv_get_dict_ids(const po_column* c, int32_t doc_id, int32_t* buf, po_mv_ctx* ctx) {
+  int32_t start;
+  if (doc_id == ctx->doc_id + 1) {
+    start = ctx->end_offset;
+  } else {
+    const int32_t chunk = doc_id / c->mv_docs_per_chunk;
+    if (doc_id > ctx->doc_id && chunk == ctx->doc_id / c->mv_docs_per_chunk) {   /* same chunk (a fresh context: -1 / n == 0, as in Java) */
+      start = mv_next_nth_set_bit(c, ctx->end_offset + 1, doc_id - ctx->doc_id - 1);
+    } else {
+      const int32_t chunk_offset = (int32_t)po_be32(c->mv_chunk_offsets + (int64_t)chunk * 4);
+      const int32_t in_chunk = doc_id % c->mv_docs_per_chunk;
+      start = in_chunk == 0 ? chunk_offset : mv_next_nth_set_bit(c, chunk_offset + 1, in_chunk);
+    }
+  }
+  const int32_t end = doc_id == c->num_docs - 1 ? c->total_entries : mv_next_set_bit(c, start + 1);
+  const int32_t n = end - start;
+  for (int32_t i = 0; i < n; i++) buf[i] = mv_fixedbit(c, start + i);
+  ctx->doc_id = doc_id;
+  ctx->end_offset = end;
+  return n;
+}
+
 /* ---- FixedByteChunkSVForwardIndexReader (PASS_THROUGH) ---------------------------------------------------------------
  * header parse: BaseChunkForwardIndexReader.java:61-111; value access: FixedByteChunkSVForwardIndexReader.java:53-94
  * (`_rawData.getInt(docId * Integer.BYTES)`; the reference multiplies in int, so it wraps for docId >= 2^29 — the

@@ -28,11 +28,15 @@ DATA_TYPES = {"INT": 0, "LONG": 1, "FLOAT": 2, "DOUBLE": 3, "STRING": 4, "BYTES"
 FWD_DICT_FIXED_BIT = 0
 FWD_RAW_FIXED_BYTE_CHUNK = 1
 FWD_DICT_SORTED = 2
+FWD_DICT_FIXED_BIT_MV = 3
 
 FILTER_AND, FILTER_OR, FILTER_NOT, FILTER_PREDICATE, FILTER_CONSTANT_TRUE, FILTER_CONSTANT_FALSE = range(6)
 PRED_EQ, PRED_NOT_EQ, PRED_IN, PRED_NOT_IN, PRED_RANGE, PRED_IS_NULL, PRED_IS_NOT_NULL = range(7)
 AGG_FUNCTIONS = {"COUNT": 0, "SUM": 1, "MIN": 2, "MAX": 3, "AVG": 4, "DISTINCTCOUNT": 5, "DISTINCTCOUNTHLL": 6,
-                 "MINMAXRANGE": 7}
+                 "MINMAXRANGE": 7, "COUNTMV": 8, "SUMMV": 9, "MINMV": 10, "MAXMV": 11, "AVGMV": 12, "MINMAXRANGEMV": 13,
+                 "DISTINCTCOUNTMV": 14, "DISTINCTCOUNTHLLMV": 15}
+MV_TO_SV_FUNCTION = {"COUNTMV": "COUNT", "SUMMV": "SUM", "MINMV": "MIN", "MAXMV": "MAX", "AVGMV": "AVG", "MINMAXRANGEMV": "MINMAXRANGE",
+                     "DISTINCTCOUNTMV": "DISTINCTCOUNT", "DISTINCTCOUNTHLLMV": "DISTINCTCOUNTHLL"}
 RESULT_LONG, RESULT_DOUBLE, RESULT_AVG_PAIR, RESULT_MINMAX_PAIR, RESULT_DICTID_SET, RESULT_HLL = range(6)
 
 QUERY_FLAG_PROFILE = 0x1
@@ -59,7 +63,7 @@ class PgColumnDesc(C.Structure):
         ("bits_per_value", C.c_int32),
         ("is_sorted", C.c_int32),
         ("dict_bytes_per_value", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("total_number_of_entries", C.c_int32),
         ("forward_index", PgBuffer),
         ("dictionary", PgBuffer),
         ("inverted_index", PgBuffer),
@@ -116,7 +120,7 @@ class PgQuery(C.Structure):
         ("num_groups_limit", C.c_int32),
         ("max_initial_result_holder_capacity", C.c_int32),
         ("flags", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("total_number_of_entries", C.c_int32),
     ]
 
 
@@ -137,7 +141,7 @@ class PgExecStats(C.Structure):
         ("algorithmic_bytes", C.c_int64),
         ("kernel", C.c_char * 32),
         ("star_tree_index", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("total_number_of_entries", C.c_int32),
     ]
 
     def as_dict(self) -> dict:

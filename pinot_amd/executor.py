@@ -493,7 +493,8 @@ def hll_merge(a: bytes, b: bytes) -> bytes:
 # (dictionaries are per segment; GroupByCombineOperator.java:132-147 decodes before upserting).
 # ----------------------------------------------------------------------------------------------------------------------
 def merge_intermediate(function: str, a, b):
-    """AggregationFunction#merge for the functions on the path."""
+    """AggregationFunction#merge for the functions on the path (the *MV forms merge like their single-value forms)."""
+    function = capi.MV_TO_SV_FUNCTION.get(function, function)
     if function in ("COUNT", "SUM"):
         return a + b
     if function == "MIN":
@@ -513,6 +514,7 @@ def merge_intermediate(function: str, a, b):
 
 def extract_final(function: str, v):
     """AggregationFunction#extractFinalResult."""
+    function = capi.MV_TO_SV_FUNCTION.get(function, function)
     if function == "AVG":
         return v[0] / v[1] if v[1] else float("-inf")
     if function == "MINMAXRANGE":

@@ -368,6 +368,60 @@ def write_range_index(stored: np.ndarray, min_value: int, max_stored: int) -> np
     return np.frombuffer(blob, dtype=np.uint8).copy()
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# Multi-value dictionary forward index
+#   writer: pinot-segment-local/.../io/writer/impl/FixedBitMVForwardIndexWriter.java:76-157 (chunk offset header | row-start bitmap |
+#           bit-packed dictIds; docsPerChunk = ceil(2048 / (float)(totalNumValues / numDocs)), the division an integer one)
+#   reader: .../readers/forward/FixedBitMVForwardIndexReader.java:57-76
+# ----------------------------------------------------------------------------------------------------------------------
+
+
+def mv_docs_per_chunk(num_docs: int, total_values: int) -> int:
+    avg = total_values // num_docs   # int / int in both the writer and the reader
+    return int(np.ceil(np.float32(2048) / np.float32(avg)))
+
+
+def write_fixed_bit_mv(dict_ids: np.ndarray, lengths: np.ndarray, bits: int) -> np.ndarray:
+    """`dict_ids`: the dictIds of all docs back to back; `lengths`: values per doc (>= 1 each, as the segment creator guarantees)."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    n, total = len(lengths), int(lengths.sum())
+    assert n > 0 and total == len(dict_ids) and int(lengths.min()) >= 1
+    per_chunk = mv_docs_per_chunk(n, total)
+    starts = np.zeros(n, dtype=np.int64)
+    np.cumsum(lengths[:-1], out=starts[1:])
+    header = starts[::per_chunk].astype(">i4").tobytes()
+    assert len(header) == 4 * ((n + per_chunk - 1) // per_chunk)
+    bitmap = np.zeros((total + 7) // 8 * 8, dtype=np.uint8)
+    bitmap[starts] = 1
+    return np.frombuffer(header + np.packbits(bitmap).tobytes()[:(total + 7) // 8] + pack_fixed_bit(dict_ids, bits).tobytes(), dtype=np.uint8)
+
+
+def read_fixed_bit_mv(buf: np.ndarray, num_docs: int, total_values: int, bits: int):
+    """Check reader: (dictIds back to back, start offset per doc + total)."""
+    per_chunk = mv_docs_per_chunk(num_docs, total_values)
+    off = 4 * ((num_docs + per_chunk - 1) // per_chunk)
+    nb = (total_values + 7) // 8
+    starts = np.flatnonzero(np.unpackbits(np.asarray(buf[off:off + nb], dtype=np.uint8))[:total_values])
+    assert len(starts) == num_docs
+    ids = unpack_fixed_bit(np.asarray(buf[off + nb:], dtype=np.uint8), bits, total_values)
+    return ids, np.append(starts, total_values).astype(np.int64)
+
+
+def write_inverted_index_mv(dict_ids: np.ndarray, doc_of_value: np.ndarray, cardinality: int, run_compress: bool = True) -> np.ndarray:
+    """BitmapInvertedIndexWriter over a multi-value column: per dictId the docs holding it at least once
+    (OffHeapBitmapInvertedIndexCreator#add(int[] dictIds, int length): the bitmaps absorb a doc's repeated values)."""
+    pairs = np.unique(np.stack([np.asarray(dict_ids, dtype=np.int64), np.asarray(doc_of_value, dtype=np.int64)], axis=1), axis=0)
+    bounds = np.searchsorted(pairs[:, 0], np.arange(cardinality + 1), side="left")
+    blobs = [serialize_roaring(pairs[bounds[d]:bounds[d + 1], 1], run_compress) for d in range(cardinality)]
+    offsets = np.empty(cardinality + 1, dtype=np.int64)
+    pos = (cardinality + 1) * 4
+    for d, b in enumerate(blobs):
+        offsets[d] = pos
+        pos += len(b)
+    offsets[cardinality] = pos
+    return np.frombuffer(offsets.astype(">u4").tobytes() + b"".join(blobs), dtype=np.uint8)
+
+
 def write_inverted_index(dict_ids: np.ndarray, cardinality: int, run_compress: bool = True) -> np.ndarray:
     order = np.argsort(dict_ids, kind="stable")
     sorted_ids = dict_ids[order]

@@ -32,6 +32,7 @@ class HostColumn:
     dict_values: Optional[list] = None  # decoded dictionary (python objects / numpy scalars) for result decoding
     null_vector: Optional[np.ndarray] = None  # NullValueVectorReader: serialized RoaringBitmap of the null docIds (uint8 array)
     range_index: Optional[np.ndarray] = None  # BitSlicedRangeIndexReader bytes (the column's `range_index` entry)
+    total_number_of_entries: int = 0    # multi-value columns: values over all docs (ColumnMetadata#getTotalNumberOfEntries)
     _name_bytes: bytes = b""
 
     def desc(self) -> capi.PgColumnDesc:
@@ -45,7 +46,7 @@ class HostColumn:
             bits_per_value=self.bits_per_value,
             is_sorted=int(self.is_sorted),
             dict_bytes_per_value=self.dict_bytes_per_value,
-            reserved0=0,
+            total_number_of_entries=int(self.total_number_of_entries),
             forward_index=capi.np_buffer(self.forward_index),
             dictionary=capi.np_buffer(self.dictionary),
             inverted_index=capi.np_buffer(self.inverted_index),
@@ -121,6 +122,38 @@ def build_column(name: str, values, data_type: str, *, dictionary: bool = True, 
         enc = capi.FWD_DICT_FIXED_BIT
         inv = formats.write_inverted_index(dict_ids, card, run_compress) if inverted else None
     return HostColumn(name, data_type, enc, True, card, bits, is_sorted, width, fwd, dict_buf, inv, dict_values)
+
+
+def build_mv_column(name: str, rows: Sequence[Sequence], data_type: str, *, inverted: bool = False, run_compress: bool = True) -> HostColumn:
+    """A multi-value dictionary column (MultiValueUnsortedForwardIndexCreator + BitmapInvertedIndexWriter): `rows[doc]` is the doc's
+    values, duplicates and order kept; an empty row takes the default null value like the segment creator does
+    (FieldSpec#getDefaultNullValue: Integer.MIN_VALUE / Long.MIN_VALUE / -inf / "null")."""
+    default = {"INT": -(1 << 31), "LONG": -(1 << 63), "FLOAT": float("-inf"), "DOUBLE": float("-inf"), "STRING": "null"}[data_type]
+    rows = [list(r) if len(r) else [default] for r in rows]
+    lengths = np.array([len(r) for r in rows], dtype=np.int64)
+    flat = [v for r in rows for v in r]
+    if data_type == "STRING":
+        uq, inv = np.unique(np.asarray(flat, dtype=object).astype(str), return_inverse=True)
+        dict_values = [str(v) for v in uq.tolist()]
+        dict_buf, width = formats.write_string_dictionary(dict_values)
+    else:
+        uq, inv = np.unique(np.ascontiguousarray(flat, dtype=NUMERIC_NP[data_type]), return_inverse=True)
+        dict_values = uq.tolist()
+        dict_buf, width = formats.write_numeric_dictionary(uq, data_type), formats._WIDTHS[data_type]
+    dict_ids = inv.astype(np.int32)
+    card = len(dict_values)
+    bits = formats.num_bits_per_value(card - 1)
+    fwd = formats.write_fixed_bit_mv(dict_ids, lengths, bits)
+    inv_buf = formats.write_inverted_index_mv(dict_ids, np.repeat(np.arange(len(rows)), lengths), card, run_compress) if inverted else None
+    col = HostColumn(name, data_type, capi.FWD_DICT_FIXED_BIT_MV, True, card, bits, False, width, fwd, dict_buf, inv_buf, dict_values)
+    col.total_number_of_entries = int(lengths.sum())
+    return col
+
+
+def decode_mv_column(col: HostColumn, num_docs: int):
+    """Check reader: per doc the list of dictIds."""
+    ids, starts = formats.read_fixed_bit_mv(col.forward_index, num_docs, col.total_number_of_entries, col.bits_per_value)
+    return [ids[starts[d]:starts[d + 1]] for d in range(num_docs)]
 
 
 def build_segment(name: str, data: Dict[str, Sequence], schema: Dict[str, str], *,

@@ -1,0 +1,87 @@
+"""A small table with multi-value columns and a brute-force evaluator over its rows, in the style of
+DictionaryBasedGroupKeyGeneratorTest.java:163-200 (build random rows, run the real operators, compare with a plain loop).
+
+The reference tree holds no multi-value avro fixture, so the oracle's multi-value paths are pinned by this brute force (and by the
+reader / writer round trips in test_host_formats.py), NOT by reference golden numbers: "parity unpinned by goldens" for the MV rows."""
+import math
+
+import numpy as np
+
+from pinot_amd.segment import HostSegment, build_column, build_mv_column
+
+WORDS = ["ant", "bee", "cat", "dog", "eel", "fox", "gnu", "hen", "ibis", "jay", "koi", "lynx"]
+
+
+def make_rows(n, seed=7, empty_rows=True):
+    rng = np.random.default_rng(seed)
+    rows = []
+    for d in range(n):
+        k1 = int(rng.integers(0 if empty_rows else 1, 5))
+        k2 = int(rng.integers(1, 4))
+        rows.append({
+            "s1": int(rng.integers(0, 7)),                                   # single-value dictionary INT
+            "s2": WORDS[int(rng.integers(0, 5))],                            # single-value dictionary STRING
+            "m": int(rng.integers(-1000, 1000)),                             # raw INT metric
+            "mv1": [int(v) for v in rng.integers(0, 40, k1)],                # multi-value INT (duplicates within a doc happen), inverted index
+            "mv2": [WORDS[int(v)] for v in rng.integers(0, len(WORDS), k2)],  # multi-value STRING, scan only
+            "mv3": [int(v) * 1000003 for v in rng.integers(0, 9, int(rng.integers(1, 3)))],   # multi-value LONG
+        })
+    return rows
+
+
+def build(rows, name="mvTable") -> HostSegment:
+    seg = HostSegment(name, len(rows))
+    seg.columns["s1"] = build_column("s1", [r["s1"] for r in rows], "INT", inverted=True)
+    seg.columns["s2"] = build_column("s2", [r["s2"] for r in rows], "STRING")
+    seg.columns["m"] = build_column("m", [r["m"] for r in rows], "INT", dictionary=False)
+    seg.columns["mv1"] = build_mv_column("mv1", [r["mv1"] for r in rows], "INT", inverted=True)
+    seg.columns["mv2"] = build_mv_column("mv2", [r["mv2"] for r in rows], "STRING")
+    seg.columns["mv3"] = build_mv_column("mv3", [r["mv3"] for r in rows], "LONG")
+    return seg
+
+
+INT_DEFAULT = -(1 << 31)
+
+
+def values_of(row, col):
+    v = row[col]
+    if isinstance(v, list):
+        return v if v else [INT_DEFAULT]     # the segment creator stores the default null value for an empty entry
+    return [v]
+
+
+def brute_force(rows, where, group_by, aggs):
+    """`where(row) -> bool`; `group_by`: column names (multi-value columns expand to every combination, repeats kept);
+    `aggs`: (function, column) pairs.  Returns {key tuple: [intermediate results]} like ResultsBlock.rows()."""
+    out = {}
+    for r in rows:
+        if not where(r):
+            continue
+        keys = [()]
+        for g in group_by:
+            keys = [k + (v,) for k in keys for v in values_of(r, g)]
+        for k in keys:
+            acc = out.setdefault(k, [None] * len(aggs))
+            for i, (fn, col) in enumerate(aggs):
+                vals = values_of(r, col) if col else []
+                if fn == "COUNT":
+                    acc[i] = (acc[i] or 0) + 1
+                elif fn == "COUNTMV":
+                    acc[i] = (acc[i] or 0) + len(vals)
+                elif fn in ("SUM", "SUMMV"):
+                    acc[i] = (acc[i] or 0.0) + float(sum(vals))
+                elif fn in ("MIN", "MINMV"):
+                    acc[i] = min([acc[i]] + [float(v) for v in vals]) if acc[i] is not None else float(min(vals))
+                elif fn in ("MAX", "MAXMV"):
+                    acc[i] = max([acc[i]] + [float(v) for v in vals]) if acc[i] is not None else float(max(vals))
+                elif fn in ("AVG", "AVGMV"):
+                    s, c = acc[i] or (0.0, 0)
+                    acc[i] = (s + float(sum(vals)), c + len(vals))
+                elif fn in ("MINMAXRANGE", "MINMAXRANGEMV"):
+                    lo, hi = acc[i] or (math.inf, -math.inf)
+                    acc[i] = (min(lo, float(min(vals))), max(hi, float(max(vals))))
+                elif fn in ("DISTINCTCOUNT", "DISTINCTCOUNTMV"):
+                    acc[i] = (acc[i] or frozenset()) | frozenset(vals)
+                else:
+                    raise ValueError(fn)
+    return out

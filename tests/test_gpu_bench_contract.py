@@ -39,6 +39,9 @@ def test_bench_line_on_a_small_segment():
     assert d["cfg5_flat"]["kernel"] == "pg_part_group_by"
     st = d["cfg5_star_tree"]
     assert st["groups"] == 12800 and st["star_tree_index"] == 0 and st["device_ms"] > 0
+    # the library merge with nothing to exchange (communicator of one rank): its latency is on record, its result the unmerged one
+    m = d["merge_world_of_one"]
+    assert m.get("error") is None and m["p50_ms"] > 0 and m["equals_unmerged_result"] is True
 
 
 def test_bench_under_torchrun_with_one_rank():
