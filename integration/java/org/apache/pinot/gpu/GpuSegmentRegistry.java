@@ -1,8 +1,8 @@
 /**
  * ImmutableSegment -> pg_segment_t: walks the segment's DataSources once (keyed by segment name + CRC), registers every
- * single-value column's index buffers by (address, size) — the bytes are copied into HBM during the call — and spreads segments
+ * column's index buffers by (address, size) — the bytes are copied into HBM during the call — and spreads segments
  * round-robin over the configured GPUs (pg_segment_create_on_device: the segment -> GPU map).  Segments holding something the
- * library refuses (MV columns used by the query are refused per query; unsupported chunk codecs per column) are marked
+ * library refuses (raw multi-value columns are skipped: a query touching one is refused; unsupported chunk codecs per column) are marked
  * "Java plan only" (handle 0).  Upsert snapshots: SegmentContext#getQueryableDocIdsSnapshot is handed over only when its
  * identity changed (pg_segment_set_queryable_doc_ids).  Release: IndexSegment#destroy -> release(segment).
  * Buffer sources per pg_column_desc field: INTEGRATION.md §3.
@@ -62,16 +62,17 @@ public final class GpuSegmentRegistry {
     try (SegmentDirectory.Reader reader = GpuBuffers.readerOf(segment)) {
       for (String column : segment.getPhysicalColumnNames()) {
         ColumnMetadata md = segment.getSegmentMetadata().getColumnMetadataFor(column);
-        if (!md.isSingleValue()) {
-          continue;   // MV columns stay with the Java plan: a query touching one is refused by pg_query_supported (unknown column)
+        if (!md.isSingleValue() && !md.hasDictionary()) {
+          continue;   // raw multi-value columns stay with the Java plan: a query touching one is refused by pg_query_supported (unknown column)
         }
         PinotDataBuffer fwd = reader.getIndexFor(column, StandardIndexes.forward());
         PinotDataBuffer dict = md.hasDictionary() ? reader.getIndexFor(column, StandardIndexes.dictionary()) : null;
         PinotDataBuffer inv = reader.hasIndexFor(column, StandardIndexes.inverted()) ? reader.getIndexFor(column, StandardIndexes.inverted()) : null;
-        int fwdEncoding = md.isSorted() && md.hasDictionary() ? 2 : md.hasDictionary() ? 0 : 1;   // pg_fwd_encoding
+        // pg_fwd_encoding: 3 = FixedBitMVForwardIndexReader (dictionary-encoded multi-value column, ForwardIndexReaderFactory.java:92-96)
+        int fwdEncoding = !md.isSingleValue() ? 3 : md.isSorted() && md.hasDictionary() ? 2 : md.hasDictionary() ? 0 : 1;
         PinotGpu.segmentAddColumn(h, column, GpuBuffers.storedType(md), fwdEncoding, md.hasDictionary(), md.getCardinality(),
             md.getBitsPerElement(), md.isSorted(), GpuBuffers.dictionaryBytesPerValue(md),
-            GpuBuffers.address(fwd), fwd.size(), GpuBuffers.dictionaryValuesAddress(dict), GpuBuffers.dictionaryValuesSize(dict, md),
+            md.isSingleValue() ? 0 : md.getTotalNumberOfEntries(), GpuBuffers.address(fwd), fwd.size(), GpuBuffers.dictionaryValuesAddress(dict), GpuBuffers.dictionaryValuesSize(dict, md),
             inv == null ? 0 : GpuBuffers.address(inv), inv == null ? 0 : inv.size());
         if (reader.hasIndexFor(column, StandardIndexes.range())) {
           // DataSource#getRangeIndex: RANGE predicates then take RangeIndexBasedFilterOperator's place in the plan

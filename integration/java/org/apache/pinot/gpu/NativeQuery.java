@@ -103,6 +103,15 @@ public final class NativeQuery implements AutoCloseable {
       case DISTINCTCOUNT: return 5;
       case DISTINCTCOUNTHLL: return f instanceof DistinctCountHLLAggregationFunction ? 6 : -1;
       case MINMAXRANGE: return 7;
+      // the multi-value forms (pg_agg_function 8..15): every entry of every matching doc
+      case COUNTMV: return 8;
+      case SUMMV: return 9;
+      case MINMV: return 10;
+      case MAXMV: return 11;
+      case AVGMV: return 12;
+      case MINMAXRANGEMV: return 13;
+      case DISTINCTCOUNTMV: return 14;
+      case DISTINCTCOUNTHLLMV: return 15;
       default: return -1;
     }
   }

@@ -30,8 +30,8 @@ public final class PinotGpu {
 
   public static native long segmentCreate(String name, int totalDocs, int device);   // device < 0: the default device
   public static native void segmentAddColumn(long segment, String name, int dataType, int fwdEncoding, boolean hasDictionary,
-      int cardinality, int bitsPerValue, boolean sorted, int dictBytesPerValue, long fwdAddr, long fwdSize, long dictAddr,
-      long dictSize, long invAddr, long invSize);
+      int cardinality, int bitsPerValue, boolean sorted, int dictBytesPerValue, int totalNumberOfEntries, long fwdAddr, long fwdSize,
+      long dictAddr, long dictSize, long invAddr, long invSize);   // totalNumberOfEntries: multi-value columns (fwdEncoding 3), else 0
   public static native void segmentSetNullVector(long segment, String column, long addr, long size);
   public static native void segmentSetQueryableDocIds(long segment, long addr, long size);
   public static native void segmentSetRangeIndex(long segment, String column, long addr, long size);   // the `range_index` entry (version 2)

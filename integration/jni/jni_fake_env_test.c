@@ -170,15 +170,15 @@ int main(void) {
 
   const jlong seg = Java_org_apache_pinot_gpu_PinotGpu_segmentCreate(env, cls, new_string("jni_fake_env"), N_DOCS, 0);
   if (!seg || pending()) return fail("segmentCreate");
-  Java_org_apache_pinot_gpu_PinotGpu_segmentAddColumn(env, cls, seg, new_string("d"), PG_TYPE_INT, PG_FWD_DICT_FIXED_BIT, 1, 4, 2, 0, 4,
+  Java_org_apache_pinot_gpu_PinotGpu_segmentAddColumn(env, cls, seg, new_string("d"), PG_TYPE_INT, PG_FWD_DICT_FIXED_BIT, 1, 4, 2, 0, 4, 0,
                                                       (jlong)(intptr_t)fwd, (jlong)sizeof fwd, (jlong)(intptr_t)dict, (jlong)sizeof dict, (jlong)(intptr_t)inv, (jlong)pos);
   if (pending()) return fail("segmentAddColumn(d)");
-  Java_org_apache_pinot_gpu_PinotGpu_segmentAddColumn(env, cls, seg, new_string("m"), PG_TYPE_INT, PG_FWD_RAW_FIXED_BYTE_CHUNK, 0, 0, 0, 0, 0,
+  Java_org_apache_pinot_gpu_PinotGpu_segmentAddColumn(env, cls, seg, new_string("m"), PG_TYPE_INT, PG_FWD_RAW_FIXED_BYTE_CHUNK, 0, 0, 0, 0, 0, 0,
                                                       (jlong)(intptr_t)raw, (jlong)sizeof raw, 0, 0, 0, 0);
   if (pending()) return fail("segmentAddColumn(m)");
   if (Java_org_apache_pinot_gpu_PinotGpu_segmentDeviceBytes(env, cls, seg) <= 0 || pending()) return fail("segmentDeviceBytes");
   /* a column that does not parse: RuntimeException with the library's message, nothing left pinned */
-  Java_org_apache_pinot_gpu_PinotGpu_segmentAddColumn(env, cls, seg, new_string("broken"), PG_TYPE_INT, PG_FWD_RAW_FIXED_BYTE_CHUNK, 0, 0, 0, 0, 0,
+  Java_org_apache_pinot_gpu_PinotGpu_segmentAddColumn(env, cls, seg, new_string("broken"), PG_TYPE_INT, PG_FWD_RAW_FIXED_BYTE_CHUNK, 0, 0, 0, 0, 0, 0,
                                                       (jlong)(intptr_t)raw, 8, 0, 0, 0, 0);
   if (!pending() || pins != 0) return fail("segmentAddColumn(broken) should throw");
   clear_pending();

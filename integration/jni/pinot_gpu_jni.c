@@ -56,13 +56,14 @@ JNIEXPORT jlong JNICALL Java_org_apache_pinot_gpu_PinotGpu_segmentCreate(JNIEnv*
 }
 JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpu_segmentAddColumn(JNIEnv* env, jclass c, jlong seg, jstring name, jint dataType,
     jint fwdEncoding, jboolean hasDictionary, jint cardinality, jint bitsPerValue, jboolean sorted, jint dictBytesPerValue,
-    jlong fwdAddr, jlong fwdSize, jlong dictAddr, jlong dictSize, jlong invAddr, jlong invSize) {
+    jint totalNumberOfEntries, jlong fwdAddr, jlong fwdSize, jlong dictAddr, jlong dictSize, jlong invAddr, jlong invSize) {
   (void)c;
   pg_column_desc d;
   memset(&d, 0, sizeof d);
   d.name = (*env)->GetStringUTFChars(env, name, NULL);
   d.data_type = dataType; d.fwd_encoding = fwdEncoding; d.has_dictionary = hasDictionary; d.cardinality = cardinality;
   d.bits_per_value = bitsPerValue; d.is_sorted = sorted; d.dict_bytes_per_value = dictBytesPerValue;
+  d.total_number_of_entries = totalNumberOfEntries;   /* multi-value columns (PG_FWD_DICT_FIXED_BIT_MV): ColumnMetadata#getTotalNumberOfEntries */
   d.forward_index = BUF(fwdAddr, fwdSize); d.dictionary = BUF(dictAddr, dictSize); d.inverted_index = BUF(invAddr, invSize);
   const int32_t st = pg_segment_add_column(SEG(seg), &d);
   (*env)->ReleaseStringUTFChars(env, name, d.name);

@@ -75,7 +75,9 @@ struct PgScanLeaf {
   int32_t exclusive;
   int32_t n_set;
   int32_t stat_slot;        // PG_F_AND_SCAN: index into stats[] receiving the number of candidates evaluated
-  int32_t pad;
+  int32_t mv;               // 1: a multi-value dictionary column (pg_mv_query_* only): `data` is the bit stream of ALL entries, `set_values`
+                            // points at the docs' first entries (int32 [numDocs + 1]); a doc passes when ANY entry passes the dictId test,
+                            // ALL entries when `exclusive` (applyMV); stats[stat_slot] receives the ENTRIES of the candidates evaluated
 };
 
 // One RoaringBitmap container re-laid out in HBM: payload 16-byte aligned inside the column's container buffer.
@@ -344,6 +346,14 @@ struct PgQueryPlan {
   // star-tree occupies 224 wavefronts instead of 7.  Share 0 reports the tile's filter statistics and match words.
   int32_t tile_split_shift;
   int32_t tile_split_pad;
+  // Multi-value columns (pg_kernels_mv.hip, appended so that the single-value kernels see the layout they were tuned on): per group
+  // column / value source the docs' first entries (int32 [numDocs + 1]) when it is a multi-value column — its `data` is then the bit
+  // stream of all entries — else null.  mv_src_len[i] = 1: the source's value is the doc's NUMBER of entries (COUNTMV / AVGMV's count).
+  const int32_t* mv_gcol_offsets[PG_MAX_GROUP_COLS];
+  const int32_t* mv_src_offsets[PG_MAX_SRCS];
+  int32_t mv_src_len[PG_MAX_SRCS];
+  int32_t mv;                       // 1: the plan touches a multi-value column: pg_mv_query_* run it
+  int32_t mv_pad;
 };
 
 #if defined(__HIPCC__)

@@ -20,6 +20,7 @@ PG_DECL_FAST(pg_fast_i32range_d) PG_DECL_FAST(pg_fast_i32range_p) PG_DECL_FAST(p
 PG_DECL_FAST(pg_pipe_scan) PG_DECL_FAST(pg_pipe_scan_tail) PG_DECL_FAST(pg_pipe_index_scan_tail) PG_DECL_FAST(pg_pipe_none) PG_DECL_FAST(pg_pipe_tail)
 PG_DECL_FAST(pg_pipe_index) PG_DECL_FAST(pg_pipe_index_tail) PG_DECL_FAST(pg_pipe_index2) PG_DECL_FAST(pg_pipe_index2_tail)
 PG_DECL_FAST(pg_pipe_scan_vscan) PG_DECL_FAST(pg_pipe_index_scan_vscan)
+PG_DECL_FAST(pg_mv_query_f) PG_DECL_FAST(pg_mv_query_l) PG_DECL_FAST(pg_mv_query_g)   // pg_kernels_mv.hip
 extern "C" const int pg_scan_waves_per_block;   // pg_kernels_scan.hip: wavefronts per workgroup of pg_fast_i32range_fp
 extern "C" const int pg_pipe_waves_per_block;   // pg_kernels_pipe.hip: wavefronts per workgroup of pg_fast_i32range_p
 PG_DECL_FAST(pg_fast_multi_wd) PG_DECL_FAST(pg_fast_none_wd) PG_DECL_FAST(pg_generic_query_ld) PG_DECL_FAST(pg_generic_query_gd)
@@ -167,7 +168,7 @@ void use_device(int ordinal) {
       // opt in to large dynamic LDS for the query kernels (function attributes are per device)
       typedef void (*QueryKernel)(const PgQueryPlan);
       const QueryKernel all[] = {pg_generic_query_f, pg_generic_query_l, pg_generic_query_g, pg_fast_none_f, pg_fast_none_a, pg_fast_i32range_f, pg_fast_i32range_a,
-                                 pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a, pg_fast_multi_f, pg_fast_multi_a, pg_fast_multi_w, pg_fast_none_w, pg_fast_multi_wd, pg_fast_none_wd, pg_generic_query_ld, pg_generic_query_gd, pg_fast_i32range_d, pg_fast_i32range_p, pg_pipe_scan, pg_pipe_scan_tail, pg_pipe_index_scan_tail, pg_pipe_none, pg_pipe_tail, pg_pipe_index, pg_pipe_index_tail, pg_pipe_index2, pg_pipe_index2_tail, pg_pipe_scan_vscan, pg_pipe_index_scan_vscan,
+                                 pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a, pg_fast_multi_f, pg_fast_multi_a, pg_fast_multi_w, pg_fast_none_w, pg_fast_multi_wd, pg_fast_none_wd, pg_generic_query_ld, pg_generic_query_gd, pg_fast_i32range_d, pg_fast_i32range_p, pg_pipe_scan, pg_pipe_scan_tail, pg_pipe_index_scan_tail, pg_pipe_none, pg_pipe_tail, pg_pipe_index, pg_pipe_index_tail, pg_pipe_index2, pg_pipe_index2_tail, pg_pipe_scan_vscan, pg_pipe_index_scan_vscan, pg_mv_query_f, pg_mv_query_l, pg_mv_query_g,
                                  pg_radix_aggregate_kernel, pg_hash_aggregate_kernel,
                                  pg_p2_scatter_1, pg_p2_scatter_2, pg_p2_scatter_3, pg_p2_scatter_4, pg_p2_scatter_1f, pg_p2_scatter_2f, pg_p2_scatter_1f_key, pg_p2_scatter_1f_hll,
                                  pg_p2_aggregate_1, pg_p2_aggregate_2, pg_p2_aggregate_3, pg_p2_aggregate_4,
@@ -199,7 +200,7 @@ static size_t lds_per_cu() { return g_devices[t_device].lds_per_cu; }
 
 static bool uses_fast_kernel(const CompiledPlan& P, int agg_mode) {
   static const bool force_interpreter = getenv("PG_FORCE_INTERPRETER") != nullptr;   // measurement knob
-  if (force_interpreter) return false;
+  if (force_interpreter || P.dev.mv) return false;   // multi-value plans: pg_mv_query_* (the interpreter's frame)
   const bool agg = agg_mode != PG_AGG_NONE;
   return P.fast_filter != -2 && (!agg || ((P.fast_agg || P.wide_agg) && agg_mode != PG_AGG_GLOBAL));
 }
@@ -264,6 +265,12 @@ static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char
       case 100: *name = agg ? "pg_fast_multi_a" : "pg_fast_multi_f"; return agg ? pg_fast_multi_a : pg_fast_multi_f;
       default: break;
     }
+  }
+  if (P.dev.mv) {   // a multi-value column in the filter, the group key or an aggregation (pg_kernels_mv.hip)
+    if (agg_mode == PG_AGG_NONE) { *name = "pg_mv_query_f"; return pg_mv_query_f; }
+    if (agg_mode == PG_AGG_GLOBAL) { *name = "pg_mv_query_g"; return pg_mv_query_g; }
+    *name = "pg_mv_query_l";
+    return pg_mv_query_l;
   }
   if (agg_mode == PG_AGG_NONE) { *name = "pg_generic_query_f"; return pg_generic_query_f; }
   if (agg_mode == PG_AGG_GLOBAL) { *name = P.digit_ops ? "pg_generic_query_gd" : "pg_generic_query_g"; return P.digit_ops ? pg_generic_query_gd : pg_generic_query_g; }

@@ -76,8 +76,21 @@ struct ScanIt : It {
   int64_t next_doc = 0;
   std::vector<int32_t> batch;
   size_t cursor = 0;
-  ScanIt(const HostBits& bits, Counter& counter) : m(bits), c(counter) { kind = ItKind::Scan; }
+  // MVScanDocIdIterator (MVScanDocIdIterator.java:65-117) when `mv_off` is set — the docs' first entries: it steps doc by doc, no
+  // batches, and counts every ENTRY of every doc it evaluates
+  const int32_t* mv_off = nullptr;
+  ScanIt(const HostBits& bits, Counter& counter, const int32_t* mv_offsets = nullptr) : m(bits), c(counter), mv_off(mv_offsets) { kind = ItKind::Scan; }
+  int32_t mv_next() {
+    const int64_t n = m.n_docs;
+    if (next_doc >= n) return kEof;
+    const int64_t p = m.next_set(next_doc);
+    const int64_t last = p < 0 ? n : p + 1;   // docs [next_doc, last) are evaluated
+    c.entries += (int64_t)mv_off[last] - (int64_t)mv_off[next_doc];
+    next_doc = last;
+    return p < 0 ? kEof : (int32_t)p;
+  }
   int32_t next() override {   // :76-98 — whole batches of up to 256 docs until one holds a match
+    if (mv_off) return mv_next();
     if (cursor >= batch.size()) {
       batch.clear();
       cursor = 0;
@@ -100,6 +113,7 @@ struct ScanIt : It {
     return batch[cursor++];
   }
   int32_t advance(int32_t target) override {   // :101-112 — doc by doc from the target to the first match
+    if (mv_off) { next_doc = target; return mv_next(); }
     batch.clear();
     cursor = 0;
     next_doc = target;
@@ -116,7 +130,15 @@ struct ScanIt : It {
     return (int32_t)p;
   }
   void apply_and(HostBits& doc_ids_io) {   // :115-142 — every candidate is evaluated once
-    c.entries += doc_ids_io.cardinality();
+    if (mv_off) {
+      for (size_t i = 0; i < doc_ids_io.w.size(); i++)
+        for (uint64_t x = doc_ids_io.w[i]; x; x &= x - 1) {
+          const int64_t d = (int64_t)i * 64 + __builtin_ctzll(x);
+          if (d < m.n_docs) c.entries += mv_off[d + 1] - mv_off[d];
+        }
+    } else {
+      c.entries += doc_ids_io.cardinality();
+    }
     for (size_t i = 0; i < doc_ids_io.w.size(); i++) doc_ids_io.w[i] &= m.w[i];
   }
 };
@@ -286,6 +308,7 @@ enum class SetKind { Empty, MatchAll, Scan, Bitmap, Sorted, And, Or, Not };
 struct Set {
   SetKind kind = SetKind::Empty;
   const HostBits* leaf_bits = nullptr;                       // Scan: match bitmap; Bitmap: the doc set
+  const int32_t* mv_off = nullptr;                           // Scan over a multi-value column: the docs' first entries
   std::shared_ptr<HostBits> owned;                           // Bitmap built here (flips, range lists)
   std::vector<std::pair<int32_t, int32_t>> ranges;           // Sorted
   std::vector<std::unique_ptr<Set>> children;                // And / Or / Not
@@ -322,7 +345,12 @@ struct Emu {
     switch (op.kind) {
       case OpKind::Empty: return mk(SetKind::Empty);
       case OpKind::MatchAll: return mk(SetKind::MatchAll);
-      case OpKind::Scan: { auto s = mk(SetKind::Scan); s->leaf_bits = &leaves.at(&op); return s; }
+      case OpKind::Scan: {
+        auto s = mk(SetKind::Scan);
+        s->leaf_bits = &leaves.at(&op);
+        if (op.col && op.col->is_mv) s->mv_off = op.col->mv_offsets_host.data();
+        return s;
+      }
       case OpKind::Inverted: {
         const std::vector<int32_t>& ids = op.eval.exclusive ? op.eval.non_matching : op.eval.matching;
         if (ids.empty()) return mk(SetKind::Empty);   // InvertedIndexFilterOperator: no dictId to look up
@@ -424,7 +452,7 @@ struct Emu {
       case SetKind::MatchAll: return std::make_unique<MatchAllIt>(n_docs);
       case SetKind::Scan:
         counters.push_back(std::make_unique<Counter>());
-        return std::make_unique<ScanIt>(*s.leaf_bits, *counters.back());
+        return std::make_unique<ScanIt>(*s.leaf_bits, *counters.back(), s.mv_off);
       case SetKind::Bitmap: return std::make_unique<BitmapIt>(s.owned ? s.owned : clone_bits(*s.leaf_bits));
       case SetKind::Sorted: return std::make_unique<SortedIt>(s.ranges);
       case SetKind::Not: return std::make_unique<NotIt>(iterator(*s.children[0]), n_docs);

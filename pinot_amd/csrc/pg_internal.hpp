@@ -114,6 +114,14 @@ struct Column {
   int vdict_kind = -1;                          // 0 INT, 1 LONG, 2 FLOAT, 3 DOUBLE (set on the id column)
   uint64_t vdict_hash = 0;
   int32_t hll_log2m = 0;                        // PG_COL_HLL_REGS: log2m of the serialized HyperLogLogs
+  // multi-value dictionary column (FixedBitMVForwardIndexReader): fwd_dev holds the dictIds of all docs back to back (the bit stream
+  // of the index's raw-data section), mv_offsets_dev the first entry of every doc (numDocs + 1 ints: the row-start bitmap expanded
+  // once at registration, instead of the reader's chunk-offset + bitmap walk per doc)
+  bool is_mv = false;
+  int32_t total_entries = 0;                    // ColumnMetadata#getTotalNumberOfEntries
+  int32_t max_entries_per_doc = 0;              // ColumnMetadata#getMaxNumberOfMultiValues
+  DeviceBuffer mv_offsets_dev;
+  std::vector<int32_t> mv_offsets_host;         // the same offsets for the host-side statistics automaton (pg_filter_stats.cpp)
 };
 
 struct CompiledPlan;

@@ -225,6 +225,23 @@ PredEval make_pred_eval(const pg_filter_node& p, const Column& col) {
 // =====================================================================================================================
 // physical filter operators
 // =====================================================================================================================
+// the single-value function a multi-value aggregation function extends (CountMVAggregationFunction extends CountAggregationFunction, ...):
+// intermediate results, merges and final results are the parent's; only what is aggregated per doc differs
+static int32_t sv_function_of(int32_t f) {
+  switch (f) {
+    case PG_AGG_COUNTMV: return PG_AGG_COUNT;
+    case PG_AGG_SUMMV: return PG_AGG_SUM;
+    case PG_AGG_MINMV: return PG_AGG_MIN;
+    case PG_AGG_MAXMV: return PG_AGG_MAX;
+    case PG_AGG_AVGMV: return PG_AGG_AVG;
+    case PG_AGG_MINMAXRANGEMV: return PG_AGG_MINMAXRANGE;
+    case PG_AGG_DISTINCTCOUNTMV: return PG_AGG_DISTINCTCOUNT;
+    case PG_AGG_DISTINCTCOUNTHLLMV: return PG_AGG_DISTINCTCOUNTHLL;
+    default: return f;
+  }
+}
+static bool is_mv_function(int32_t f) { return f >= PG_AGG_COUNTMV && f <= PG_AGG_DISTINCTCOUNTHLLMV; }
+
 OpPtr make_filter_op(OpKind k) { auto o = std::make_unique<FilterOp>(); o->kind = k; return o; }
 static OpPtr make_op(OpKind k) { return make_filter_op(k); }
 
@@ -237,7 +254,7 @@ static int priority(const FilterOp& op) {   // PrioritizedFilterOperator.java:31
     case OpKind::And: return 300;
     case OpKind::Or: return 400;
     case OpKind::Not: return priority(*op.children[0]);
-    case OpKind::Scan: return 500;
+    case OpKind::Scan: return op.col && op.col->is_mv ? 550 : 500;   // getScanBasedFilterPriority (FilterOperatorUtils.java:253-265): multi-value scans last
     default: return 10000;
   }
 }
@@ -547,11 +564,18 @@ struct Emitter {
       if (c.val_type == PG_V_I32 || c.val_type == PG_V_I64) { L.n_set = (int32_t)e.set_i.size(); L.set_values = keep(e.set_i); }
       else { L.n_set = (int32_t)e.set_d.size(); L.set_values = keep(e.set_d); }
     }
+    if (c.is_mv) {   // MVScanDocIdIterator: ANY entry passes (ALL for the exclusive predicates); every entry of an evaluated doc counts
+      if (!e.dictionary_based) fail(PG_ERR_UNSUPPORTED, "raw multi-value column %s", c.name.c_str());
+      L.mv = 1;
+      L.exclusive = e.exclusive ? 1 : 0;
+      L.set_values = c.mv_offsets_dev.ptr;
+      plan.dev.mv = 1;
+    }
     if (masked) {
       if (plan.n_stat_slots >= PG_MAX_STATS) fail(PG_ERR_UNSUPPORTED, "more than %d restricted scans in one filter", PG_MAX_STATS - 1);
       L.stat_slot = plan.n_stat_slots++;
     } else {
-      plan.full_scan_entries += seg.total_docs;
+      plan.full_scan_entries += c.is_mv ? c.total_entries : seg.total_docs;
     }
     if (std::find(scanned_cols.begin(), scanned_cols.end(), &c) == scanned_cols.end()) {
       scanned_cols.push_back(&c);
@@ -898,10 +922,11 @@ std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* f
     const pg_agg_spec& a = q->aggregations[i];
     if (a.function == PG_AGG_COUNT) continue;
     Column* c = seg.find(a.column);
-    const bool dict_fn = a.function == PG_AGG_MIN || a.function == PG_AGG_MAX || a.function == PG_AGG_MINMAXRANGE ||
-                         a.function == PG_AGG_DISTINCTCOUNT || a.function == PG_AGG_DISTINCTCOUNTHLL;
-    non_scan_fit = c && dict_fn && c->has_dictionary &&
-                   (c->data_type <= PG_TYPE_DOUBLE || a.function == PG_AGG_DISTINCTCOUNT || a.function == PG_AGG_DISTINCTCOUNTHLL);
+    const int32_t f = sv_function_of(a.function);   // DICTIONARY_BASED_FUNCTIONS holds the MV forms of these as well (AggregationPlanNode.java:51-55)
+    const bool dict_fn = a.function != PG_AGG_COUNTMV && (f == PG_AGG_MIN || f == PG_AGG_MAX || f == PG_AGG_MINMAXRANGE ||
+                                                          f == PG_AGG_DISTINCTCOUNT || f == PG_AGG_DISTINCTCOUNTHLL);
+    non_scan_fit = c && dict_fn && c->has_dictionary && is_mv_function(a.function) == c->is_mv &&
+                   (c->data_type <= PG_TYPE_DOUBLE || f == PG_AGG_DISTINCTCOUNT || f == PG_AGG_DISTINCTCOUNTHLL);
   }
   if (!non_scan_fit && q && q->n_aggregations > 0 && q->aggregations && !(q->flags & PG_QUERY_FLAG_SKIP_STAR_TREE) && !seg.star_trees.empty() &&
       root->kind != OpKind::Empty) {
@@ -1191,6 +1216,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
       }
     }
   }
+  if (D.mv) P.fast_filter = -2;   // a multi-value scan leaf: the interpreter's frame only (pg_mv_query_*)
   if (P.fast_filter != 100) D.tail_posting = -1;
   // Fused dense index program (pg_fast_i32range_d): the index-only prefix is PUSH_POSTINGS (AND PUSH_POSTINGS)* over leaves that are
   // entirely dense (no CSR containers, their dense prefix covers every chunk) with at most 8 pointers and 4 leaves in all
@@ -1245,20 +1271,21 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
       const pg_agg_spec& s = q->aggregations[i];
       if (s.function == PG_AGG_COUNT) continue;
       Column* c = seg.find(s.column);
-      const bool dict_fn = s.function == PG_AGG_MIN || s.function == PG_AGG_MAX || s.function == PG_AGG_MINMAXRANGE ||
-                           s.function == PG_AGG_DISTINCTCOUNT || s.function == PG_AGG_DISTINCTCOUNTHLL;
-      fit = c && dict_fn && c->has_dictionary &&
-            (c->data_type <= PG_TYPE_DOUBLE || s.function == PG_AGG_DISTINCTCOUNT || s.function == PG_AGG_DISTINCTCOUNTHLL);
+      const int32_t f = sv_function_of(s.function);
+      const bool dict_fn = s.function != PG_AGG_COUNTMV && (f == PG_AGG_MIN || f == PG_AGG_MAX || f == PG_AGG_MINMAXRANGE ||
+                                                            f == PG_AGG_DISTINCTCOUNT || f == PG_AGG_DISTINCTCOUNTHLL);
+      fit = c && dict_fn && c->has_dictionary && is_mv_function(s.function) == c->is_mv &&
+            (c->data_type <= PG_TYPE_DOUBLE || f == PG_AGG_DISTINCTCOUNT || f == PG_AGG_DISTINCTCOUNTHLL);
     }
     if (fit) {
       P.non_scan_based = true;
       for (int i = 0; i < q->n_aggregations; i++) {
         const pg_agg_spec& s = q->aggregations[i];
         AggOut out{};
-        out.function = s.function;
+        out.function = sv_function_of(s.function);
         out.log2m = s.log2m > 0 ? s.log2m : 8;
         out.aux_col = s.function == PG_AGG_COUNT ? nullptr : seg.find(s.column);
-        if (s.function == PG_AGG_DISTINCTCOUNTHLL && (out.log2m < 4 || out.log2m > 16))
+        if (out.function == PG_AGG_DISTINCTCOUNTHLL && (out.log2m < 4 || out.log2m > 16))
           fail(PG_ERR_UNSUPPORTED, "DISTINCTCOUNTHLL log2m %d (4..16 on the GPU path)", out.log2m);
         P.aggs.push_back(out);
       }
@@ -1296,6 +1323,14 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
       project(c);
       continue;
     }
+    if (c->is_mv) {   // DictionaryBasedGroupKeyGenerator#processMultiValue: every entry of the doc is a key digit (Cartesian over such columns)
+      if (st) fail(PG_ERR_UNSUPPORTED, "multi-value group-by column %s over a star-tree", c->name.c_str());
+      int n_mv = 0;
+      for (int k = 0; k < j; k++) n_mv += D.mv_gcol_offsets[k] != nullptr;
+      if (n_mv >= 2) fail(PG_ERR_UNSUPPORTED, "more than two multi-value group-by columns");
+      D.mv_gcol_offsets[j] = c->mv_offsets_dev.as<int32_t>();
+      D.mv = 1;
+    }
     Column* raw = nullptr;
     if (!c->has_dictionary) {
       // any other raw key — FLOAT / DOUBLE, or a raw column among several group-by columns (NoDictionaryMultiColumnGroupKeyGenerator's
@@ -1324,12 +1359,18 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
 
   std::vector<PgAccOp> ops;
   std::vector<Column*> srcs;
-  auto src_index = [&](Column* c) {
-    for (size_t i = 0; i < srcs.size(); i++) if (srcs[i] == c) return (int32_t)i;
+  std::vector<int> src_is_len;   // per source: 1 = the NUMBER of entries of a multi-value column (COUNTMV, AVGMV's count), not its values
+  auto src_index_kind = [&](Column* c, int len) {
+    for (size_t i = 0; i < srcs.size(); i++) if (srcs[i] == c && src_is_len[i] == len) return (int32_t)i;
     if (srcs.size() >= PG_MAX_SRCS) fail(PG_ERR_UNSUPPORTED, "more than %d aggregated columns", PG_MAX_SRCS);
     srcs.push_back(c);
+    src_is_len.push_back(len);
     return (int32_t)srcs.size() - 1;
   };
+  auto src_index = [&](Column* c) { return src_index_kind(c, 0); };
+  // a multi-value function or column anywhere in the query: pg_mv_query_* (one doc at a time) run the plan
+  for (int i = 0; i < q->n_aggregations; i++)
+    if (is_mv_function(q->aggregations[i].function)) D.mv = 1;
   auto op_index_kind = [&](int32_t fn, int32_t src, int32_t kind, int32_t limb) {
     for (size_t i = 0; i < ops.size(); i++)
       if (ops[i].fn == fn && ops[i].src == src && ops[i].is_float == kind && ops[i].limb == limb) return (int32_t)i;
@@ -1375,6 +1416,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
   bool need_count = false;
   for (int i = 0; i < q->n_aggregations; i++)
     need_count |= (q->aggregations[i].function == PG_AGG_COUNT || q->aggregations[i].function == PG_AGG_AVG);
+  if (D.mv) need_count = true;   // a group exists iff its hidden COUNT is > 0: the one existence test the multi-value kernels are checked with
   bool has_int_minmax = false;
   for (int i = 0; i < q->n_aggregations && !need_count; i++) {
     const pg_agg_spec& s = q->aggregations[i];
@@ -1437,9 +1479,21 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     if (s.function == PG_AGG_COUNT) { out.op_a = count_op; P.aggs.push_back(out); continue; }
     Column* c = st ? st->pairs[(size_t)st->pair_index(s.function, s.column)].col : seg.find(s.column);
     if (!c) fail(PG_ERR_NOT_FOUND, "column not found: %s", s.column ? s.column : "(null)");
-    if (s.function == PG_AGG_DISTINCTCOUNT || s.function == PG_AGG_DISTINCTCOUNTHLL) {
+    // BlockValSet#getDoubleValuesSV over a multi-value column (and ...MV over a single-value one) throws in the reference
+    if (is_mv_function(s.function) != c->is_mv)
+      fail(PG_ERR_INVALID_ARGUMENT, "aggregation function %d over the %s column %s", s.function, c->is_mv ? "multi-value" : "single-value", c->name.c_str());
+    const int32_t fn_sv = sv_function_of(s.function);
+    out.function = fn_sv;   // intermediate results, merges and the wire format are the single-value function's
+    if (c->is_mv && s.function == PG_AGG_COUNTMV) {   // CountMVAggregationFunction.java:62-96: sum of getNumMVEntries
+      project(c);
+      out.op_a = op_index(PG_ACC_SUM, src_index_kind(c, 1), false);
+      P.sum_max_abs = std::max<uint64_t>(P.sum_max_abs, (uint64_t)std::max(c->max_entries_per_doc, 1));
+      P.aggs.push_back(out);
+      continue;
+    }
+    if (fn_sv == PG_AGG_DISTINCTCOUNT || fn_sv == PG_AGG_DISTINCTCOUNTHLL) {
       if (D.n_aux >= PG_MAX_AUX) fail(PG_ERR_UNSUPPORTED, "more than %d DISTINCTCOUNT / DISTINCTCOUNTHLL aggregations", PG_MAX_AUX);
-      const bool hll = s.function == PG_AGG_DISTINCTCOUNTHLL;
+      const bool hll = fn_sv == PG_AGG_DISTINCTCOUNTHLL;
       if (!hll && !c->has_dictionary) fail(PG_ERR_UNSUPPORTED, "DISTINCTCOUNT over a raw column is outside the hot path");
       if (hll && !c->has_dictionary && c->data_type > PG_TYPE_DOUBLE) fail(PG_ERR_UNSUPPORTED, "DISTINCTCOUNTHLL over a raw %d column", c->data_type);
       const int log2m = s.log2m > 0 ? s.log2m : 8;   // CommonConstants.Helix.DEFAULT_HYPERLOGLOG_LOG2M
@@ -1462,7 +1516,22 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     const int32_t si = src_index(c);
     const bool fl = c->val_type == PG_V_F32 || c->val_type == PG_V_F64;
     out.is_float = fl;
-    switch (s.function) {
+    if (c->is_mv && (fn_sv == PG_AGG_SUM || fn_sv == PG_AGG_AVG)) {
+      // SumMV / AvgMV: the doc's entries are summed in int64 on the device, then added once per key.  Floating entries would need the
+      // digit accumulators per ENTRY: kept with the Java plan for now
+      if (fl) fail(PG_ERR_UNSUPPORTED, "SUMMV / AVGMV over the FLOAT / DOUBLE column %s", c->name.c_str());
+      const unsigned __int128 worst = (unsigned __int128)std::max<uint64_t>(c->val_type == PG_V_I32 ? (uint64_t)1 << 31 : c->max_abs_int, 1) *
+                                      (unsigned __int128)std::max(c->total_entries, 1);
+      if (worst >= ((unsigned __int128)1 << 63)) fail(PG_ERR_UNSUPPORTED, "SUMMV over %s may leave int64", c->name.c_str());
+      out.op_a = op_index(PG_ACC_SUM, si, false);
+      // what one doc can add to a group (the merge's overflow bound multiplies it by the docs)
+      P.sum_max_abs = std::max<uint64_t>(P.sum_max_abs, (uint64_t)std::min<unsigned __int128>((unsigned __int128)std::max<uint64_t>(c->val_type == PG_V_I32 ? (uint64_t)1 << 31 : c->max_abs_int, 1) *
+                                                                                              (unsigned __int128)std::max(c->max_entries_per_doc, 1), (unsigned __int128)1 << 62));
+      if (fn_sv == PG_AGG_AVG) out.op_b = op_index(PG_ACC_SUM, src_index_kind(c, 1), false);   // AvgMV: count += values.length
+      P.aggs.push_back(out);
+      continue;
+    }
+    switch (fn_sv) {
       case PG_AGG_SUM: sum_ops(c, si, out); break;
       case PG_AGG_MIN: out.op_a = op_index(PG_ACC_MIN, si, fl); break;
       case PG_AGG_MAX: out.op_a = op_index(PG_ACC_MAX, si, fl); break;
@@ -1508,6 +1577,18 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     D.srcs[i].bits = c->bits;
     D.srcs[i].val_type = c->val_type;
     D.srcs[i].fx_q = src_fx_q[i];
+    if (c->is_mv) {
+      D.mv_src_offsets[i] = c->mv_offsets_dev.as<int32_t>();
+      D.mv_src_len[i] = src_is_len[i];
+      D.mv = 1;
+    }
+  }
+  if (D.mv) {
+    // the multi-value kernels take dense key spaces (an LDS or HBM table) and admit every key: beyond that, the Java plan
+    if (huge_key_space) fail(PG_ERR_UNSUPPORTED, "multi-value query over a group key space beyond 64 M keys");
+    if (q->n_group_by > 0 && G > (int64_t)P.num_groups_limit) fail(PG_ERR_UNSUPPORTED, "multi-value query whose key space (%lld) exceeds numGroupsLimit", (long long)G);
+    if (P.has_digit_sums) fail(PG_ERR_UNSUPPORTED, "multi-value query next to a floating / wide LONG SUM");
+    if (st) fail(PG_ERR_UNSUPPORTED, "multi-value query over a star-tree");
   }
   for (Column* c : projected) P.algorithmic_bytes += (int64_t)c->fwd_bytes_logical;
   P.n_projected_columns = (int32_t)projected.size();
@@ -1531,7 +1612,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
   // pipeline carries the doc's value in the tuple and keeps the registers of one bucket of groups in LDS instead.
   bool hll_radix = false;
   int hll_shift = 0;
-  if (q->n_group_by > 0 && D.n_aux > 0 && D.n_ops > 0 && !getenv("PG_NO_RADIX") && !getenv("PG_NO_RADIX_AUX")) {
+  if (q->n_group_by > 0 && D.n_aux > 0 && D.n_ops > 0 && !D.mv && !getenv("PG_NO_RADIX") && !getenv("PG_NO_RADIX_AUX")) {
     int64_t per_group = (int64_t)D.n_ops * 8, state_bytes = 0;
     bool ok = (int)srcs.size() <= PG_MAX_RADIX_SRCS;
     for (int x = 0; x < D.n_aux && ok; x++) {
@@ -1600,6 +1681,10 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     } else {
       D.agg_mode = PG_AGG_GLOBAL;
     }
+    D.replicas = 1;
+  }
+  if (D.mv && (D.agg_mode == PG_AGG_RADIX || D.agg_mode == PG_AGG_LDS_PART)) {   // pg_mv_query_*: an LDS table or the dense HBM table
+    D.agg_mode = PG_AGG_GLOBAL;
     D.replicas = 1;
   }
   if (D.agg_mode == PG_AGG_RADIX) (void)plan_partition_v2(P, D, srcs, sorted_ops, G);
@@ -1755,6 +1840,16 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
   P.wide_agg = !P.fast_agg && (D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE) && D.n_aux == 0 && P.first_doc_op < 0;
   // range-partitioned tables: pg_fast_none_w / pg_fast_multi_w walk the partitioned tile order with 16 wavefronts per CU
   if (D.agg_mode == PG_AGG_LDS_PART && D.n_aux == 0 && P.fast_filter != -2 && P.first_doc_op < 0) P.wide_agg = true;
+  if (D.mv) {   // none of the single-value specialisations reads a multi-value column
+    P.fast_filter = -2;
+    P.fast_agg = false;
+    P.wide_agg = false;
+    D.fast_agg_shape = 0;
+    D.pipe_fit = 0;
+    D.pipe_general = 0;
+    D.dense_fused = 0;
+    D.tile_split_shift = 0;
+  }
   return plan;
 }
 

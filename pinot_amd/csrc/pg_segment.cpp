@@ -360,6 +360,46 @@ void segment_add_column(Segment& seg, const pg_column_desc& d) {
     if (c.bits < 31 && ((int64_t)1 << c.bits) < (int64_t)c.cardinality)
       fail(PG_ERR_INVALID_ARGUMENT, "column %s: %d bits per value cannot hold %d dictIds", d.name, c.bits, c.cardinality);
     upload_fixed_bit(seg, c, fwd, fwd_len);
+  } else if (c.fwd_encoding == PG_FWD_DICT_FIXED_BIT_MV) {
+    // FixedBitMVForwardIndexReader.java:57-76: chunk offset header | row-start bitmap (MSB first, one set bit per doc) | bit-packed dictIds.
+    // The header only accelerates the reader's per-doc walk; here every doc's first entry is expanded once from the bitmap.
+    if (c.bits < 1 || c.bits > 31) fail(PG_ERR_INVALID_ARGUMENT, "column %s: bits_per_value %d", d.name, c.bits);
+    if (!c.has_dictionary || c.cardinality <= 0) fail(PG_ERR_UNSUPPORTED, "column %s: raw multi-value columns are outside the hot path", d.name);
+    const int64_t num_docs = seg.total_docs, num_values = d.total_number_of_entries;
+    if (num_docs <= 0 || num_values < num_docs) fail(PG_ERR_INVALID_ARGUMENT, "multi-value column %s: %lld entries over %lld docs", d.name, (long long)num_values, (long long)num_docs);
+    const int64_t per_chunk = (int64_t)std::ceil((float)2048 / (float)(num_values / num_docs));   // the reader's integer division
+    const int64_t num_chunks = (num_docs + per_chunk - 1) / per_chunk;
+    const uint64_t bitmap_bytes = ((uint64_t)num_values + 7) / 8, raw_bytes = ((uint64_t)num_values * (uint64_t)c.bits + 7) / 8;
+    const uint64_t need = (uint64_t)num_chunks * 4 + bitmap_bytes + raw_bytes;
+    if (fwd_len < need) fail(PG_ERR_INVALID_ARGUMENT, "multi-value forward index of %s is %llu bytes, need %llu", d.name, (unsigned long long)fwd_len, (unsigned long long)need);
+    const uint8_t* bitmap = fwd + (uint64_t)num_chunks * 4;
+    std::vector<int32_t>& off = c.mv_offsets_host;
+    off.reserve((size_t)num_docs + 1);
+    for (int64_t byte = 0; byte < (int64_t)bitmap_bytes; byte++) {
+      uint32_t b = bitmap[byte];
+      while (b) {
+        const int lead = __builtin_clz(b) - 24;   // MSB first
+        const int64_t pos = byte * 8 + lead;
+        if (pos < num_values) off.push_back((int32_t)pos);
+        b &= ~(0x80u >> lead);
+      }
+    }
+    if ((int64_t)off.size() != num_docs || off[0] != 0)
+      fail(PG_ERR_INVALID_ARGUMENT, "multi-value forward index of %s: %zu row starts for %lld docs", d.name, off.size(), (long long)num_docs);
+    off.push_back((int32_t)num_values);
+    for (int64_t i = 0; i < num_docs; i++) c.max_entries_per_doc = std::max(c.max_entries_per_doc, off[(size_t)i + 1] - off[(size_t)i]);
+    // the chunk offset header must agree with the bitmap (both come from a file)
+    for (int64_t ch = 0; ch < num_chunks; ch++)
+      if ((int32_t)be32(fwd + (size_t)ch * 4) != off[(size_t)(ch * per_chunk)])
+        fail(PG_ERR_INVALID_ARGUMENT, "multi-value forward index of %s: chunk %lld starts at entry %d, its first doc at %d", d.name, (long long)ch,
+             (int32_t)be32(fwd + (size_t)ch * 4), off[(size_t)(ch * per_chunk)]);
+    c.is_mv = true;
+    c.total_entries = (int32_t)num_values;
+    c.fwd_dev.alloc((size_t)raw_bytes + 64, true);   // +64: the kernels read a dword pair past the value
+    c.fwd_dev.upload(bitmap + bitmap_bytes, raw_bytes);
+    c.mv_offsets_dev = upload_vector(off);
+    c.col_kind = PG_COL_FIXED_BIT;
+    c.fwd_bytes_logical = need;
   } else if (c.fwd_encoding == PG_FWD_DICT_SORTED) {
     // SortedIndexReaderImpl: 2 big-endian ints (startDocId, endDocId inclusive) per dictId.  The pairs come from a file: every one is
     // checked (inside the segment, ascending, disjoint) before anything is expanded from them.
@@ -498,7 +538,7 @@ void segment_add_column(Segment& seg, const pg_column_desc& d) {
   if (d.inverted_index.size > 0 && c.has_dictionary && c.fwd_encoding != PG_FWD_DICT_SORTED)
     parse_inverted_index(seg, c, (const uint8_t*)d.inverted_index.addr, d.inverted_index.size);
 
-  seg.device_bytes += c.fwd_dev.size + c.dict_dev.size + c.containers_dev.size + c.descs_dev.size;
+  seg.device_bytes += c.fwd_dev.size + c.dict_dev.size + c.containers_dev.size + c.descs_dev.size + c.mv_offsets_dev.size;
   seg.columns.emplace(c.name, std::move(col));
 }
 
