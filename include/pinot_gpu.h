@@ -65,7 +65,12 @@ typedef enum pg_fwd_encoding {
    * numChunks big-endian int chunk offsets | row-start bitmap of total_number_of_entries bits (MSB first, one set bit per doc) |
    * the dictIds of all docs back to back, bits_per_value each, MSB-first bit stream.  numDocsPerChunk =
    * ceil(2048 / (total_number_of_entries / numDocs)) with the reader's integer division. */
-  PG_FWD_DICT_FIXED_BIT_MV = 3
+  PG_FWD_DICT_FIXED_BIT_MV = 3,
+  /* VarByteChunkSVForwardIndexReader (raw STRING / BYTES column, writer versions 2 and 3): the 7-int header and chunk offsets of the
+   * fixed-byte format, each chunk = numDocsPerChunk big-endian int offsets relative to the chunk start (0 for the absent rows of the
+   * last chunk) followed by the values back to back.  PASS_THROUGH chunks only on the GPU path.  Such a column can be a GROUP BY key
+   * (NoDictionarySingleColumnGroupKeyGenerator.java:132-140 / NoDictionaryMultiColumnGroupKeyGenerator's on-the-fly dictionaries). */
+  PG_FWD_RAW_VAR_BYTE_CHUNK = 4
 } pg_fwd_encoding;
 
 typedef struct pg_buffer {
@@ -347,6 +352,13 @@ int32_t pg_result_group_dict_ids(pg_result_t result, int32_t col, int32_t* out_d
 #define PG_GROUP_KEY_DICT_IDS 0
 #define PG_GROUP_KEY_LONG_VALUES 1
 #define PG_GROUP_KEY_DOUBLE_VALUES 2
+/* raw STRING / BYTES column: the groups' values as byte strings — pg_result_group_values_bytes_size gives the total length,
+ * pg_result_group_values_bytes fills out_offsets[0 .. numGroups] (offsets[g + 1] - offsets[g] = length of group g's value) and the
+ * values back to back (a STRING is its UTF-8 bytes, as the forward index stores it) */
+#define PG_GROUP_KEY_BYTES_VALUES 3
+int32_t pg_result_group_values_bytes_size(pg_result_t result, int32_t col, uint64_t* out_total_bytes);
+int32_t pg_result_group_values_bytes(pg_result_t result, int32_t col, int64_t* out_offsets, int32_t offsets_capacity, uint8_t* out_bytes,
+                                     uint64_t bytes_capacity);
 int32_t pg_result_group_key_type(pg_result_t result, int32_t col, int32_t* out_type);
 int32_t pg_result_group_values_long(pg_result_t result, int32_t col, int64_t* out_values, int32_t capacity);
 int32_t pg_result_group_values_double(pg_result_t result, int32_t col, double* out_values, int32_t capacity);

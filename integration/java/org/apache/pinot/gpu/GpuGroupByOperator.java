@@ -96,6 +96,17 @@ public class GpuGroupByOperator extends BaseOperator<BaseResultsBlock> {
           for (int g = 0; g < numGroups; g++) {
             keys[g][j] = isFloat ? (Object) (float) values[g] : (Object) values[g];
           }
+        } else if (PinotGpu.resultGroupKeyType(result, j) == PinotGpu.GROUP_KEY_BYTES_VALUES) {
+          // a raw STRING / BYTES column (NoDictionarySingleColumnGroupKeyGenerator.java:132-140): String keys, ByteArray keys for BYTES
+          long[] offsets = new long[numGroups + 1];
+          byte[] bytes = new byte[(int) PinotGpu.resultGroupValuesBytesSize(result, j)];
+          PinotGpu.resultGroupValuesBytes(result, j, offsets, bytes);
+          boolean isString = _segment.getDataSource(column).getDataSourceMetadata().getDataType().getStoredType().name().equals("STRING");
+          for (int g = 0; g < numGroups; g++) {
+            int from = (int) offsets[g], to = (int) offsets[g + 1];
+            keys[g][j] = isString ? (Object) new String(bytes, from, to - from, java.nio.charset.StandardCharsets.UTF_8)
+                : (Object) new org.apache.pinot.spi.utils.ByteArray(java.util.Arrays.copyOfRange(bytes, from, to));
+          }
         } else {
           int[] dictIds = new int[numGroups];
           PinotGpu.resultGroupDictIds(result, j, dictIds);

@@ -69,7 +69,9 @@ public final class GpuSegmentRegistry {
         PinotDataBuffer dict = md.hasDictionary() ? reader.getIndexFor(column, StandardIndexes.dictionary()) : null;
         PinotDataBuffer inv = reader.hasIndexFor(column, StandardIndexes.inverted()) ? reader.getIndexFor(column, StandardIndexes.inverted()) : null;
         // pg_fwd_encoding: 3 = FixedBitMVForwardIndexReader (dictionary-encoded multi-value column, ForwardIndexReaderFactory.java:92-96)
-        int fwdEncoding = !md.isSingleValue() ? 3 : md.isSorted() && md.hasDictionary() ? 2 : md.hasDictionary() ? 0 : 1;
+        // 4 = VarByteChunkSVForwardIndexReader (raw STRING / BYTES: a GROUP BY key at most), 1 = FixedByteChunkSVForwardIndexReader
+        boolean varByte = !md.hasDictionary() && !md.getDataType().getStoredType().isFixedWidth();
+        int fwdEncoding = !md.isSingleValue() ? 3 : md.isSorted() && md.hasDictionary() ? 2 : md.hasDictionary() ? 0 : varByte ? 4 : 1;
         PinotGpu.segmentAddColumn(h, column, GpuBuffers.storedType(md), fwdEncoding, md.hasDictionary(), md.getCardinality(),
             md.getBitsPerElement(), md.isSorted(), GpuBuffers.dictionaryBytesPerValue(md),
             md.isSingleValue() ? 0 : md.getTotalNumberOfEntries(), GpuBuffers.address(fwd), fwd.size(), GpuBuffers.dictionaryValuesAddress(dict), GpuBuffers.dictionaryValuesSize(dict, md),

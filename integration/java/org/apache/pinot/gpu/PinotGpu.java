@@ -22,7 +22,7 @@ public final class PinotGpu {
   // pg_result_kind
   public static final int RESULT_LONG = 0, RESULT_DOUBLE = 1, RESULT_AVG_PAIR = 2, RESULT_MINMAX_PAIR = 3, RESULT_DICTID_SET = 4,
       RESULT_HLL = 5;
-  public static final int GROUP_KEY_DICT_IDS = 0, GROUP_KEY_LONG_VALUES = 1, GROUP_KEY_DOUBLE_VALUES = 2;
+  public static final int GROUP_KEY_DICT_IDS = 0, GROUP_KEY_LONG_VALUES = 1, GROUP_KEY_DOUBLE_VALUES = 2, GROUP_KEY_BYTES_VALUES = 3;
 
   public static native int abiVersion();
   public static native void init(int device);
@@ -57,6 +57,8 @@ public final class PinotGpu {
   public static native void resultGroupDictIds(long result, int groupByColumn, int[] out);
   public static native void resultGroupValuesLong(long result, int groupByColumn, long[] out);
   public static native void resultGroupValuesDouble(long result, int groupByColumn, double[] out);
+  public static native long resultGroupValuesBytesSize(long result, int groupByColumn);                 // raw STRING / BYTES keys: total bytes,
+  public static native void resultGroupValuesBytes(long result, int groupByColumn, long[] offsets, byte[] out);   // offsets (groups + 1), values
   public static native void resultDoubles(long result, int aggregation, int component, double[] out);
   public static native void resultLongs(long result, int aggregation, int component, long[] out);
   public static native void resultSetSizes(long result, int aggregation, int[] out);

@@ -185,6 +185,29 @@ JNIEXPORT jint JNICALL Java_org_apache_pinot_gpu_PinotGpu_resultGroupKeyType(JNI
 COPY_OUT(resultGroupDictIds(JNIEnv* env, jclass c, jlong r, jint col, jintArray out), jint, int32_t, SetIntArrayRegion, pg_result_group_dict_ids(RES(r), col, p, n))
 COPY_OUT(resultGroupValuesLong(JNIEnv* env, jclass c, jlong r, jint col, jlongArray out), jlong, int64_t, SetLongArrayRegion, pg_result_group_values_long(RES(r), col, p, n))
 COPY_OUT(resultGroupValuesDouble(JNIEnv* env, jclass c, jlong r, jint col, jdoubleArray out), jdouble, double, SetDoubleArrayRegion, pg_result_group_values_double(RES(r), col, p, n))
+/* raw STRING / BYTES group keys: resultGroupValuesBytesSize, then offsets (numGroups + 1 longs) and the values back to back */
+JNIEXPORT jlong JNICALL Java_org_apache_pinot_gpu_PinotGpu_resultGroupValuesBytesSize(JNIEnv* env, jclass c, jlong r, jint col) {
+  (void)c;
+  uint64_t total = 0;
+  CHECK_RET(pg_result_group_values_bytes_size(RES(r), col, &total), 0);
+  return (jlong)total;
+}
+JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpu_resultGroupValuesBytes(JNIEnv* env, jclass c, jlong r, jint col, jlongArray offsets, jbyteArray out) {
+  (void)c;
+  if (!offsets || !out) { jclass x = (*env)->FindClass(env, "java/lang/NullPointerException"); if (x) (*env)->ThrowNew(env, x, "output array"); return; }
+  const jsize n_off = (*env)->GetArrayLength(env, offsets), n_bytes = (*env)->GetArrayLength(env, out);
+  int64_t* po = (int64_t*)malloc((size_t)(n_off > 0 ? n_off : 1) * sizeof(int64_t));
+  uint8_t* pb = (uint8_t*)malloc((size_t)(n_bytes > 0 ? n_bytes : 1));
+  if (!po || !pb) { free(po); free(pb); jclass x = (*env)->FindClass(env, "java/lang/OutOfMemoryError"); if (x) (*env)->ThrowNew(env, x, "staging buffer"); return; }
+  const int32_t st = pg_result_group_values_bytes(RES(r), col, po, (int32_t)n_off, pb, (uint64_t)n_bytes);
+  if (st >= 0) {
+    (*env)->SetLongArrayRegion(env, offsets, 0, n_off, (const jlong*)po);
+    (*env)->SetByteArrayRegion(env, out, 0, n_bytes, (const jbyte*)pb);
+  }
+  free(po);
+  free(pb);
+  CHECK(st);
+}
 COPY_OUT(resultDoubles(JNIEnv* env, jclass c, jlong r, jint agg, jint comp, jdoubleArray out), jdouble, double, SetDoubleArrayRegion, pg_result_doubles(RES(r), agg, comp, p, n))
 COPY_OUT(resultLongs(JNIEnv* env, jclass c, jlong r, jint agg, jint comp, jlongArray out), jlong, int64_t, SetLongArrayRegion, pg_result_longs(RES(r), agg, comp, p, n))
 COPY_OUT(resultSetSizes(JNIEnv* env, jclass c, jlong r, jint agg, jintArray out), jint, int32_t, SetIntArrayRegion, pg_result_set_sizes(RES(r), agg, p, n))

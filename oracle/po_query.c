@@ -68,7 +68,7 @@ int32_t po_segment_add_column(void* segp, const pg_column_desc* d) {
   c->inv = (const uint8_t*)d->inverted_index.addr;
   c->inv_len = d->inverted_index.size;
   c->num_docs = seg->total_docs;
-  if (c->fwd_encoding == PG_FWD_RAW_FIXED_BYTE_CHUNK && po_raw_parse_header(c)) return PG_ERR_UNSUPPORTED;
+  if ((c->fwd_encoding == PG_FWD_RAW_FIXED_BYTE_CHUNK || c->fwd_encoding == PG_FWD_RAW_VAR_BYTE_CHUNK) && po_raw_parse_header(c)) return PG_ERR_UNSUPPORTED;
   if (c->fwd_encoding == PG_FWD_DICT_FIXED_BIT_MV) {
     c->total_entries = d->total_number_of_entries;
     if (!c->has_dictionary) { po_set_error("raw multi-value column %s is outside the hot path", c->name); return PG_ERR_UNSUPPORTED; }
@@ -305,6 +305,51 @@ static int32_t lm_get_group_id(long_map* m, int64_t raw_key, int32_t upper_bound
   return PO_INVALID_ID;
 }
 
+/* BaseOnTheFlyDictionary for STRING / BYTES (NoDictionaryMultiColumnGroupKeyGenerator's per-column value -> id maps,
+ * Object2IntOpenHashMap in NoDictionarySingleColumnGroupKeyGenerator.java:132-140): ids in first-seen order; values borrowed from the
+ * forward index buffer */
+typedef struct bytes_dict { const uint8_t** vals; int32_t* lens; int32_t n, cap; int32_t* table; int32_t table_cap; } bytes_dict;
+static uint64_t bytes_hash(const uint8_t* p, int32_t n) {
+  uint64_t h = 1469598103934665603ULL;
+  for (int32_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ULL; }
+  return h ^ (h >> 29);
+}
+static int32_t bytes_dict_index(bytes_dict* d, const uint8_t* p, int32_t n) {
+  if (!d->table) {
+    d->table_cap = 1024;
+    d->table = (int32_t*)po_xcalloc((size_t)d->table_cap, 4);
+    d->cap = 256;
+    d->vals = (const uint8_t**)po_xmalloc(sizeof(void*) * (size_t)d->cap);
+    d->lens = (int32_t*)po_xmalloc(4 * (size_t)d->cap);
+  }
+  uint64_t pos = bytes_hash(p, n) & (uint64_t)(d->table_cap - 1);
+  while (d->table[pos]) {
+    const int32_t id = d->table[pos] - 1;
+    if (d->lens[id] == n && memcmp(d->vals[id], p, (size_t)n) == 0) return id;
+    pos = (pos + 1) & (uint64_t)(d->table_cap - 1);
+  }
+  if (d->n == d->cap) {
+    d->cap *= 2;
+    d->vals = (const uint8_t**)po_xrealloc(d->vals, sizeof(void*) * (size_t)d->cap);
+    d->lens = (int32_t*)po_xrealloc(d->lens, 4 * (size_t)d->cap);
+  }
+  const int32_t id = d->n++;
+  d->vals[id] = p;
+  d->lens[id] = n;
+  d->table[pos] = id + 1;
+  if ((int64_t)d->n * 2 > d->table_cap) {   /* rehash */
+    free(d->table);
+    d->table_cap *= 4;
+    d->table = (int32_t*)po_xcalloc((size_t)d->table_cap, 4);
+    for (int32_t k = 0; k < d->n; k++) {
+      uint64_t q = bytes_hash(d->vals[k], d->lens[k]) & (uint64_t)(d->table_cap - 1);
+      while (d->table[q]) q = (q + 1) & (uint64_t)(d->table_cap - 1);
+      d->table[q] = k + 1;
+    }
+  }
+  return id;
+}
+
 enum { HOLDER_ARRAY, HOLDER_INT_MAP, HOLDER_LONG_MAP,
        HOLDER_RAW_VALUES /* NoDictionarySingleColumnGroupKeyGenerator: value -> group id (Int2IntOpenHashMap / Long2IntOpenHashMap) */,
        HOLDER_TUPLES /* a raw FLOAT / DOUBLE column (Float2Int / Double2IntOpenHashMap), or NoDictionaryMultiColumnGroupKeyGenerator: per
@@ -325,6 +370,7 @@ typedef struct group_key_gen {
   /* HOLDER_TUPLES: n_cols keys per group id, and an open-addressing table of group ids + 1 */
   int64_t* tuples; int32_t tuple_cap, n_tuples;
   int32_t* tuple_table; int32_t tuple_table_cap;
+  bytes_dict* bytes_dicts;      /* HOLDER_TUPLES: per raw STRING / BYTES column its on-the-fly dictionary (the tuple holds the id) */
 } group_key_gen;
 
 /* constructor, DictionaryBasedGroupKeyGenerator.java:106-185 */
@@ -345,6 +391,7 @@ static int gkg_init(group_key_gen* g, int n_cols, po_column** cols, int32_t num_
     g->tuples = (int64_t*)po_xmalloc(sizeof(int64_t) * (size_t)g->tuple_cap * (size_t)n_cols);
     g->tuple_table_cap = 4096;
     g->tuple_table = (int32_t*)po_xcalloc((size_t)g->tuple_table_cap, 4);
+    g->bytes_dicts = (bytes_dict*)po_xcalloc((size_t)n_cols + 1, sizeof(bytes_dict));
     return 0;
   }
   if (n_cols == 1 && !cols[0]->has_dictionary) {   /* NoDictionarySingleColumnGroupKeyGenerator ctor :69-84 */
@@ -458,7 +505,15 @@ static void gkg_generate_tuples(group_key_gen* g, int n_docs, const int32_t* doc
   const int nc = g->n_cols;
   int64_t key[64];
   for (int i = 0; i < n_docs; i++) {
-    for (int j = 0; j < nc; j++) key[j] = g->cols[j]->has_dictionary ? (int64_t)dict_ids[j][i] : raw_key_of_doc(g->cols[j], doc_ids[i]);
+    for (int j = 0; j < nc; j++) {
+      const po_column* c = g->cols[j];
+      if (c->has_dictionary) key[j] = (int64_t)dict_ids[j][i];
+      else if (c->data_type > PG_TYPE_DOUBLE) {   /* STRING / BYTES: the on-the-fly dictionary's id of the value */
+        int32_t len = 0;
+        const uint8_t* v = po_raw_get_bytes(c, doc_ids[i], &len);
+        key[j] = bytes_dict_index(&g->bytes_dicts[j], v, len);
+      } else key[j] = raw_key_of_doc(c, doc_ids[i]);
+    }
     uint64_t p = tuple_hash(key, nc) & (uint64_t)(g->tuple_table_cap - 1);
     int32_t gid = PO_INVALID_ID;
     while (g->tuple_table[p]) {
@@ -916,6 +971,8 @@ typedef struct po_result_impl {
   int64_t* group_values;     /* raw-value group keys (one no-dictionary INT / LONG group-by column), else NULL */
   int32_t* key_types;        /* HOLDER_TUPLES: PG_GROUP_KEY_* per group-by column, else NULL */
   int64_t** key_values;      /* HOLDER_TUPLES: per value-keyed column the groups' LONG values / DOUBLE bits */
+  uint8_t** key_bytes;       /* HOLDER_TUPLES: per raw STRING / BYTES column the groups' values back to back, */
+  int64_t** key_bytes_off;   /*   and their offsets (num_groups + 1) */
   po_agg_result* aggs;
   pg_exec_stats stats;
 } po_result_impl;
@@ -1042,8 +1099,8 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
   for (int j = 0; j < n_gb; j++) {
     po_column* c = po_segment_column(seg, q->group_by_columns[j]);
     if (!c) { po_set_error("column not found: %s", q->group_by_columns[j]); return PG_ERR_NOT_FOUND; }
-    if (!c->has_dictionary && c->data_type > PG_TYPE_DOUBLE) {
-      po_set_error("no-dictionary group-by column %s: STRING / BYTES raw keys are outside the hot path", c->name);
+    if (!c->has_dictionary && c->data_type > PG_TYPE_DOUBLE && c->fwd_encoding != PG_FWD_RAW_VAR_BYTE_CHUNK) {
+      po_set_error("no-dictionary group-by column %s is not a raw var-byte column", c->name);
       return PG_ERR_UNSUPPORTED;
     }
     gcols[j] = c;
@@ -1260,6 +1317,27 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
         for (int32_t i = 0; i < n_groups; i++) res->group_dict_ids[j][i] = (int32_t)gkg.tuples[(size_t)gid_of[i] * (size_t)n_gb + (size_t)j];
         continue;
       }
+      if (c->data_type > PG_TYPE_DOUBLE) {   /* the groups' byte strings, back to back */
+        res->key_types[j] = PG_GROUP_KEY_BYTES_VALUES;
+        if (!res->key_bytes) {
+          res->key_bytes = (uint8_t**)po_xcalloc((size_t)n_gb + 1, sizeof(uint8_t*));
+          res->key_bytes_off = (int64_t**)po_xcalloc((size_t)n_gb + 1, sizeof(int64_t*));
+        }
+        const bytes_dict* bd = &gkg.bytes_dicts[j];
+        int64_t total = 0;
+        res->key_bytes_off[j] = (int64_t*)po_xcalloc((size_t)n_groups + 2, 8);
+        for (int32_t i = 0; i < n_groups; i++) {
+          res->key_bytes_off[j][i] = total;
+          total += bd->lens[gkg.tuples[(size_t)gid_of[i] * (size_t)n_gb + (size_t)j]];
+        }
+        res->key_bytes_off[j][n_groups] = total;
+        res->key_bytes[j] = (uint8_t*)po_xmalloc((size_t)total + 1);
+        for (int32_t i = 0; i < n_groups; i++) {
+          const int64_t id = gkg.tuples[(size_t)gid_of[i] * (size_t)n_gb + (size_t)j];
+          memcpy(res->key_bytes[j] + res->key_bytes_off[j][i], bd->vals[id], (size_t)bd->lens[id]);
+        }
+        continue;
+      }
       res->key_types[j] = c->data_type <= PG_TYPE_LONG ? PG_GROUP_KEY_LONG_VALUES : PG_GROUP_KEY_DOUBLE_VALUES;
       res->key_values[j] = (int64_t*)po_xcalloc((size_t)n_groups + 1, 8);
       for (int32_t i = 0; i < n_groups; i++) {
@@ -1315,6 +1393,22 @@ int32_t po_result_group_values_long(void* r, int32_t col, int64_t* out, int32_t 
   else if (col == 0) v = RES(r)->group_values;
   if (!v) { po_set_error("group-by column does not have LONG values"); return PG_ERR_INVALID_ARGUMENT; }
   memcpy(out, v, sizeof(int64_t) * (size_t)RES(r)->num_groups);
+  return PG_OK;
+}
+int32_t po_result_group_values_bytes_size(void* r, int32_t col, uint64_t* out) {
+  if (col < 0 || col >= RES(r)->n_group_cols || !RES(r)->key_types || RES(r)->key_types[col] != PG_GROUP_KEY_BYTES_VALUES) {
+    po_set_error("group-by column does not have BYTES values");
+    return PG_ERR_INVALID_ARGUMENT;
+  }
+  *out = (uint64_t)RES(r)->key_bytes_off[col][RES(r)->num_groups];
+  return PG_OK;
+}
+int32_t po_result_group_values_bytes(void* r, int32_t col, int64_t* out_off, int32_t off_cap, uint8_t* out_bytes, uint64_t cap) {
+  uint64_t total = 0;
+  if (po_result_group_values_bytes_size(r, col, &total)) return PG_ERR_INVALID_ARGUMENT;
+  if (off_cap < RES(r)->num_groups + 1 || cap < total) { po_set_error("capacity too small"); return PG_ERR_INVALID_ARGUMENT; }
+  memcpy(out_off, RES(r)->key_bytes_off[col], sizeof(int64_t) * ((size_t)RES(r)->num_groups + 1));
+  memcpy(out_bytes, RES(r)->key_bytes[col], (size_t)total);
   return PG_OK;
 }
 int32_t po_result_group_values_double(void* r, int32_t col, double* out, int32_t cap) {

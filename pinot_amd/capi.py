@@ -29,6 +29,7 @@ FWD_DICT_FIXED_BIT = 0
 FWD_RAW_FIXED_BYTE_CHUNK = 1
 FWD_DICT_SORTED = 2
 FWD_DICT_FIXED_BIT_MV = 3
+FWD_RAW_VAR_BYTE_CHUNK = 4
 
 FILTER_AND, FILTER_OR, FILTER_NOT, FILTER_PREDICATE, FILTER_CONSTANT_TRUE, FILTER_CONSTANT_FALSE = range(6)
 PRED_EQ, PRED_NOT_EQ, PRED_IN, PRED_NOT_IN, PRED_RANGE, PRED_IS_NULL, PRED_IS_NOT_NULL = range(7)
@@ -46,7 +47,7 @@ QUERY_FLAG_APPROX_FILTER_STATS = 0x8
 QUERY_FLAG_EXACT_FILTER_STATS = 0x10
 QUERY_FLAG_FINAL_DISTINCT = 0x20
 COMM_UNIQUE_ID_BYTES = 128
-GROUP_KEY_DICT_IDS, GROUP_KEY_LONG_VALUES, GROUP_KEY_DOUBLE_VALUES = 0, 1, 2
+GROUP_KEY_DICT_IDS, GROUP_KEY_LONG_VALUES, GROUP_KEY_DOUBLE_VALUES, GROUP_KEY_BYTES_VALUES = 0, 1, 2, 3
 
 
 class PgBuffer(C.Structure):
@@ -166,7 +167,8 @@ ABI_SYMBOLS = [
     "filter_exec", "docidset_cardinality", "docidset_num_words", "docidset_copy_words", "docidset_copy_docids",
     "docidset_stats", "docidset_free",
     "query_supported", "query_exec",
-    "result_num_groups", "result_group_dict_ids", "result_group_key_type", "result_group_values_long", "result_group_values_double", "result_kind_of", "result_doubles", "result_longs",
+    "result_num_groups", "result_group_dict_ids", "result_group_key_type", "result_group_values_long", "result_group_values_double",
+    "result_group_values_bytes_size", "result_group_values_bytes", "result_kind_of", "result_doubles", "result_longs",
     "result_set_sizes", "result_set_dict_ids", "result_hll_registers", "result_stats", "result_free",
 ]
 # entry points only the product library has (the CPU oracle is one segment, one thread, no devices): multi-GPU placement,
@@ -229,6 +231,8 @@ class NativeApi:
         self.f("result_group_key_type").argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         self.f("result_group_values_long").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
         self.f("result_group_values_double").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        self.f("result_group_values_bytes_size").argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_uint64)]
+        self.f("result_group_values_bytes").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_uint64]
         self.f("result_kind_of").argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
         self.f("result_doubles").argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
         self.f("result_longs").argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]

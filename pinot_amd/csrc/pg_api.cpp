@@ -300,6 +300,29 @@ int32_t pg_result_group_values_double(pg_result_t result, int32_t col, double* o
     if (!v.empty()) memcpy(out_values, v.data(), v.size() * 8);
   });
 }
+int32_t pg_result_group_values_bytes_size(pg_result_t result, int32_t col, uint64_t* out_total_bytes) {
+  return guarded([&] {
+    REQUIRE(result && out_total_bytes, "null argument");
+    REQUIRE(col >= 0 && col < (int32_t)result->r->group_key_type.size(), "group-by column index out of range");
+    REQUIRE(result->r->group_key_type[(size_t)col] == PG_GROUP_KEY_BYTES_VALUES, "group-by column does not have BYTES values");
+    *out_total_bytes = (uint64_t)result->r->group_bytes[(size_t)col].size();
+  });
+}
+int32_t pg_result_group_values_bytes(pg_result_t result, int32_t col, int64_t* out_offsets, int32_t offsets_capacity, uint8_t* out_bytes,
+                                     uint64_t bytes_capacity) {
+  return guarded([&] {
+    REQUIRE(result && out_offsets, "null argument");
+    REQUIRE(col >= 0 && col < (int32_t)result->r->group_key_type.size(), "group-by column index out of range");
+    REQUIRE(result->r->group_key_type[(size_t)col] == PG_GROUP_KEY_BYTES_VALUES, "group-by column does not have BYTES values");
+    const auto& b = result->r->group_bytes[(size_t)col];
+    const auto& o = result->r->group_bytes_off[(size_t)col];
+    REQUIRE(offsets_capacity >= result->r->num_groups + 1 && bytes_capacity >= b.size(), "capacity too small");
+    REQUIRE(out_bytes || b.empty(), "null argument");
+    if (o.empty()) out_offsets[0] = 0;   // no group
+    else memcpy(out_offsets, o.data(), o.size() * 8);
+    if (!b.empty()) memcpy(out_bytes, b.data(), b.size());
+  });
+}
 static AggResult& agg_of(pg_result_t result, int32_t agg) {
   if (!result) fail(PG_ERR_INVALID_ARGUMENT, "null result");
   if (agg < 0 || agg >= (int32_t)result->r->aggs.size()) fail(PG_ERR_INVALID_ARGUMENT, "aggregation index out of range");

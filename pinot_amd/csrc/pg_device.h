@@ -53,7 +53,9 @@ struct PgFInstr {
 
 enum PgColKind : int32_t {
   PG_COL_FIXED_BIT = 0, PG_COL_RAW32 = 1, PG_COL_RAW64 = 2,
-  PG_COL_HLL_REGS = 3   // star-tree DISTINCTCOUNTHLL pair: one byte per register, 2^bits registers per doc (transcoded at upload)
+  PG_COL_HLL_REGS = 3,  // star-tree DISTINCTCOUNTHLL pair: one byte per register, 2^bits registers per doc (transcoded at upload)
+  PG_COL_VAR_BYTES = 4  // raw STRING / BYTES column: values back to back + int64 offsets (no query kernel reads it: GROUP BY goes through
+                        // its virtual dictionary, pg_vdict.hip)
 };
 enum PgValType : int32_t { PG_V_I32 = 0, PG_V_I64 = 1, PG_V_F32 = 2, PG_V_F64 = 3 };
 

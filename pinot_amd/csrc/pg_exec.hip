@@ -1048,6 +1048,8 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
   res.num_groups = ng;
   res.group_key_type.assign((size_t)n_group_by, PG_GROUP_KEY_DICT_IDS);
   res.group_values.assign((size_t)n_group_by, {});
+  res.group_bytes.assign((size_t)n_group_by, {});
+  res.group_bytes_off.assign((size_t)n_group_by, {});
   res.group_dict_ids.assign((size_t)n_group_by, {});
   if (P.raw_group) {   // one raw INT / LONG column hashed by value: key = value ^ 2^63
     res.group_key_type[0] = PG_GROUP_KEY_LONG_VALUES;
@@ -1058,6 +1060,28 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
     int64_t mult = D.gcols[j].mult;
     int32_t card = P.group_cards[j];
     const Column* vd = (size_t)j < P.group_vdict.size() ? P.group_vdict[(size_t)j] : nullptr;
+    if (vd && vd->vdict_kind == 4) {   // raw STRING / BYTES: the groups' byte strings from the virtual dictionary's values
+      res.group_key_type[(size_t)j] = PG_GROUP_KEY_BYTES_VALUES;
+      auto& bytes = res.group_bytes[(size_t)j];
+      auto& boff = res.group_bytes_off[(size_t)j];
+      boff.resize((size_t)ng + 1);
+      int64_t total = 0;
+      for (int32_t i = 0; i < ng; i++) {
+        const int64_t raw = hashed ? H.hash_keys[(size_t)gids[i]] : gids[i];
+        const size_t id = (size_t)((raw / mult) % card);
+        boff[(size_t)i] = total;
+        total += vd->vdict_bytes_off[id + 1] - vd->vdict_bytes_off[id];
+      }
+      boff[(size_t)ng] = total;
+      bytes.resize((size_t)total);
+      for (int32_t i = 0; i < ng; i++) {
+        const int64_t raw = hashed ? H.hash_keys[(size_t)gids[i]] : gids[i];
+        const size_t id = (size_t)((raw / mult) % card);
+        if (boff[(size_t)i + 1] > boff[(size_t)i])
+          memcpy(bytes.data() + boff[(size_t)i], vd->vdict_bytes.data() + vd->vdict_bytes_off[id], (size_t)(boff[(size_t)i + 1] - boff[(size_t)i]));
+      }
+      continue;
+    }
     if (vd) {   // ids of a virtual dictionary: hand the values over (the caller holds no dictionary for this column)
       res.group_key_type[(size_t)j] = vd->vdict_kind <= 1 ? PG_GROUP_KEY_LONG_VALUES : PG_GROUP_KEY_DOUBLE_VALUES;
       auto& v = res.group_values[(size_t)j];

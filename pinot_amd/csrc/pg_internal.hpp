@@ -117,6 +117,13 @@ struct Column {
   // multi-value dictionary column (FixedBitMVForwardIndexReader): fwd_dev holds the dictIds of all docs back to back (the bit stream
   // of the index's raw-data section), mv_offsets_dev the first entry of every doc (numDocs + 1 ints: the row-start bitmap expanded
   // once at registration, instead of the reader's chunk-offset + bitmap walk per doc)
+  // raw STRING / BYTES column (VarByteChunkSVForwardIndexReader): fwd_dev = the values back to back (chunk headers dropped at
+  // registration), vb_offsets_dev = int64 [numDocs + 1]
+  DeviceBuffer vb_offsets_dev;
+  uint64_t vb_total_bytes = 0;
+  // ... and, on its virtual dictionary (vdict_kind 4): the distinct values back to back in id order + offsets (cardinality + 1)
+  std::vector<uint8_t> vdict_bytes;
+  std::vector<int64_t> vdict_bytes_off;
   bool is_mv = false;
   int32_t total_entries = 0;                    // ColumnMetadata#getTotalNumberOfEntries
   int32_t max_entries_per_doc = 0;              // ColumnMetadata#getMaxNumberOfMultiValues
@@ -338,6 +345,8 @@ struct Result {
   // or the IEEE bits of DOUBLE values); group_dict_ids[col] stays empty for them
   std::vector<int32_t> group_key_type;
   std::vector<std::vector<int64_t>> group_values;
+  std::vector<std::vector<uint8_t>> group_bytes;        // PG_GROUP_KEY_BYTES_VALUES: the groups' values back to back,
+  std::vector<std::vector<int64_t>> group_bytes_off;    //   offsets (num_groups + 1)
   std::vector<AggResult> aggs;
   pg_exec_stats stats{};
 };

@@ -539,6 +539,7 @@ struct Emitter {
 
   void emit_scan(const FilterOp& op, bool masked) {
     Column& c = *op.col;
+    if (c.col_kind == PG_COL_VAR_BYTES) fail(PG_ERR_UNSUPPORTED, "predicate over the raw STRING / BYTES column %s", c.name.c_str());
     const PredEval& e = op.eval;
     PgScanLeaf L{};
     L.data = c.fwd_dev.as<uint8_t>();

@@ -439,6 +439,52 @@ void segment_add_column(Segment& seg, const pg_column_desc& d) {
     }
     upload_fixed_bit(seg, c, packed.data(), nbytes);
     c.fwd_bytes_logical = fwd_len;
+  } else if (c.fwd_encoding == PG_FWD_RAW_VAR_BYTE_CHUNK) {
+    // VarByteChunkSVForwardIndexReader.java:158-217 (writer versions 2 / 3): per chunk numDocsPerChunk BE int offsets relative to the chunk
+    // start (0 for the absent rows of the last chunk), then the values.  The values are re-laid back to back with one int64 offset
+    // per doc: what a device kernel can index.  Only a GROUP BY reads such a column (through its virtual dictionary).
+    if (c.has_dictionary || (c.data_type != PG_TYPE_STRING && c.data_type != PG_TYPE_BYTES))
+      fail(PG_ERR_INVALID_ARGUMENT, "column %s: a var-byte chunk forward index belongs to a raw STRING / BYTES column", d.name);
+    if (fwd_len < 28) fail(PG_ERR_INVALID_ARGUMENT, "raw forward index of %s too short", d.name);
+    const int32_t version = (int32_t)be32(fwd), num_chunks = (int32_t)be32(fwd + 4), per_chunk = (int32_t)be32(fwd + 8);
+    if (version != 2 && version != 3) fail(PG_ERR_UNSUPPORTED, "column %s: var-byte chunk writer version %d", d.name, version);
+    const int32_t compression = (int32_t)be32(fwd + 20), header_start = (int32_t)be32(fwd + 24);
+    if (compression != 0) fail(PG_ERR_UNSUPPORTED, "column %s: compressed var-byte chunks (type %d) are outside the GPU path", d.name, compression);
+    const int off_size = version == 2 ? 4 : 8;
+    if (per_chunk <= 0 || num_chunks < 0 || (int64_t)num_chunks * per_chunk < seg.total_docs || header_start < 28 ||
+        (uint64_t)header_start + (uint64_t)num_chunks * (uint64_t)off_size > fwd_len)
+      fail(PG_ERR_INVALID_ARGUMENT, "raw forward index of %s: %d chunks of %d docs for %d docs", d.name, num_chunks, per_chunk, seg.total_docs);
+    std::vector<int64_t> off((size_t)seg.total_docs + 1, 0);
+    std::vector<uint8_t> blob;
+    blob.reserve((size_t)fwd_len);
+    for (int32_t ch = 0; ch < num_chunks && (int64_t)ch * per_chunk < seg.total_docs; ch++) {
+      auto chunk_pos = [&](int32_t i) -> uint64_t {
+        if (i == num_chunks) return fwd_len;
+        const uint8_t* o = fwd + header_start + (uint64_t)i * (uint64_t)off_size;
+        return off_size == 4 ? (uint64_t)be32(o) : be64(o);
+      };
+      const uint64_t start = chunk_pos(ch), end = chunk_pos(ch + 1);
+      if (start > end || end > fwd_len || end - start < (uint64_t)per_chunk * 4) fail(PG_ERR_INVALID_ARGUMENT, "raw forward index of %s: bad chunk offsets", d.name);
+      const uint8_t* cb = fwd + start;
+      const uint64_t clen = end - start;
+      const int32_t rows = (int32_t)std::min<int64_t>(per_chunk, (int64_t)seg.total_docs - (int64_t)ch * per_chunk);
+      for (int32_t r = 0; r < rows; r++) {
+        const uint64_t vs = be32(cb + (size_t)r * 4);
+        uint64_t ve = clen;                                       // getValueEndOffset: the last row, or a following absent row (offset 0)
+        if (r + 1 < per_chunk) { const uint64_t nx = be32(cb + (size_t)(r + 1) * 4); if (nx != 0) ve = nx; }
+        if (vs < (uint64_t)per_chunk * 4 || ve < vs || ve > clen) fail(PG_ERR_INVALID_ARGUMENT, "raw forward index of %s: bad value offsets in chunk %d", d.name, ch);
+        const size_t doc = (size_t)ch * (size_t)per_chunk + (size_t)r;
+        off[doc] = (int64_t)blob.size();
+        blob.insert(blob.end(), cb + vs, cb + ve);
+      }
+    }
+    off[(size_t)seg.total_docs] = (int64_t)blob.size();
+    c.vb_total_bytes = blob.size();
+    c.fwd_dev.alloc(blob.size() + 64, true);
+    if (!blob.empty()) c.fwd_dev.upload(blob.data(), blob.size());
+    c.vb_offsets_dev = upload_vector(off);
+    c.col_kind = PG_COL_VAR_BYTES;
+    c.fwd_bytes_logical = fwd_len;
   } else if (c.fwd_encoding == PG_FWD_RAW_FIXED_BYTE_CHUNK) {
     if (fwd_len < 16) fail(PG_ERR_INVALID_ARGUMENT, "raw forward index of %s too short", d.name);
     int32_t version = (int32_t)be32(fwd);
@@ -538,7 +584,7 @@ void segment_add_column(Segment& seg, const pg_column_desc& d) {
   if (d.inverted_index.size > 0 && c.has_dictionary && c.fwd_encoding != PG_FWD_DICT_SORTED)
     parse_inverted_index(seg, c, (const uint8_t*)d.inverted_index.addr, d.inverted_index.size);
 
-  seg.device_bytes += c.fwd_dev.size + c.dict_dev.size + c.containers_dev.size + c.descs_dev.size + c.mv_offsets_dev.size;
+  seg.device_bytes += c.fwd_dev.size + c.dict_dev.size + c.containers_dev.size + c.descs_dev.size + c.mv_offsets_dev.size + c.vb_offsets_dev.size;
   seg.columns.emplace(c.name, std::move(col));
 }
 

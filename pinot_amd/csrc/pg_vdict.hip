@@ -11,11 +11,20 @@
 // mix of raw and dictionary columns is one composite key.  Equality follows the fastutil maps: FLOAT / DOUBLE keys compare by
 // floatToIntBits / doubleToLongBits (every NaN is one key, -0.0 and 0.0 are two).
 //
+// Raw STRING / BYTES columns (NoDictionarySingleColumnGroupKeyGenerator.java:132-140: Object2IntOpenHashMap of the values;
+// NoDictionaryMultiColumnGroupKeyGenerator's String / Bytes on-the-fly dictionaries) take the same route with a 64-bit HASH of the
+// value as the key: equality is all a group key needs, so ids follow hash order, not value order.  A hash is not an identity, so the
+// build proves it one: every doc's bytes are compared with the bytes of its id's representative doc (the smallest docId holding the
+// hash), and two different values under one hash (≈ n² / 2^65) fail the build (PG_ERR_UNSUPPORTED: the Java plan groups that column)
+// instead of merging two groups.  The distinct values themselves (the representatives' bytes, in id order) are copied to the host once
+// and handed back as the groups' keys.
+//
 // Load-path work (one pass to build keys, a device radix sort, one pass to assign ids): rocPRIM provides the sort and the unique.
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_select.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 #include "pg_internal.hpp"
 
@@ -47,6 +56,50 @@ __global__ void pg_vdict_keys_kernel(const uint8_t* __restrict__ raw, int width,
   if (width == 4) v = __builtin_bswap32(reinterpret_cast<const uint32_t*>(raw)[i]);
   else v = __builtin_bswap64(reinterpret_cast<const uint64_t*>(raw)[i]);
   keys[i] = key_of_bits(v, kind);
+}
+
+// 64-bit hash of a byte string: two FNV-1a lanes over even / odd bytes, mixed (splitmix64 finaliser) with the length
+__global__ void pg_vdict_hash_kernel(const uint8_t* __restrict__ blob, const int64_t* __restrict__ off, uint64_t* __restrict__ keys, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t s = off[i], e = off[i + 1];
+  uint64_t a = 1469598103934665603ULL, b = 0x9E3779B97F4A7C15ULL;
+  for (int64_t k = s; k < e; k++) {
+    const uint64_t x = blob[k];
+    a = (a ^ x) * 1099511628211ULL;
+    b = (b + x + (b << 6) + (b >> 2)) * 0xFF51AFD7ED558CCDULL;
+  }
+  uint64_t h = a ^ (b + (uint64_t)(e - s) * 0xC2B2AE3D27D4EB4FULL);
+  h ^= h >> 30; h *= 0xBF58476D1CE4E5B9ULL; h ^= h >> 27; h *= 0x94D049BB133111EBULL; h ^= h >> 31;
+  keys[i] = h;
+}
+// representative doc of every id: the smallest docId holding it
+__global__ void pg_vdict_rep_kernel(const uint32_t* __restrict__ ids, uint32_t* __restrict__ rep, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) atomicMin(&rep[ids[i]], (uint32_t)i);
+}
+// every doc's bytes against its representative's: flag[0] != 0 ⇒ two values share a hash
+__global__ void pg_vdict_verify_kernel(const uint8_t* __restrict__ blob, const int64_t* __restrict__ off, const uint32_t* __restrict__ ids,
+                                       const uint32_t* __restrict__ rep, uint32_t* __restrict__ flag, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t r = rep[ids[i]];
+  if (r == i) return;
+  const int64_t s = off[i], len = off[i + 1] - s, rs = off[r];
+  bool same = len == off[r + 1] - rs;
+  for (int64_t k = 0; same && k < len; k++) same = blob[s + k] == blob[rs + k];
+  if (!same) atomicOr(flag, 1u);
+}
+__global__ void pg_vdict_value_len_kernel(const int64_t* __restrict__ off, const uint32_t* __restrict__ rep, int64_t* __restrict__ len, uint32_t card) {
+  const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d < card) len[d] = off[rep[d] + 1] - off[rep[d]];
+}
+__global__ void pg_vdict_value_copy_kernel(const uint8_t* __restrict__ blob, const int64_t* __restrict__ off, const uint32_t* __restrict__ rep,
+                                           const int64_t* __restrict__ out_off, uint8_t* __restrict__ out, uint32_t card) {
+  const uint32_t d = blockIdx.x;   // one workgroup per distinct value
+  if (d >= card) return;
+  const int64_t s = off[rep[d]], len = off[rep[d] + 1] - s, o = out_off[d];
+  for (int64_t k = threadIdx.x; k < len; k += blockDim.x) out[o + k] = blob[s + k];
 }
 
 __global__ void pg_vdict_ids_kernel(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ distinct, uint32_t card,
@@ -107,9 +160,10 @@ int64_t vdict_value_of_key(uint64_t key, int kind, double* as_double) {
 // Builds c.vdict (idempotent; the caller holds the segment's lock).  The segment's device is current.
 void ensure_virtual_dictionary(Segment& seg, Column& c) {
   if (c.vdict) return;
-  if (c.has_dictionary || (c.col_kind != PG_COL_RAW32 && c.col_kind != PG_COL_RAW64) || c.data_type > PG_TYPE_DOUBLE)
-    fail(PG_ERR_UNSUPPORTED, "no-dictionary group-by column %s: only raw INT / LONG / FLOAT / DOUBLE columns get a virtual dictionary", c.name.c_str());
-  const int kind = c.data_type == PG_TYPE_INT ? 0 : c.data_type == PG_TYPE_LONG ? 1 : c.data_type == PG_TYPE_FLOAT ? 2 : 3;
+  const bool var_bytes = c.col_kind == PG_COL_VAR_BYTES;
+  if (c.has_dictionary || (!var_bytes && ((c.col_kind != PG_COL_RAW32 && c.col_kind != PG_COL_RAW64) || c.data_type > PG_TYPE_DOUBLE)))
+    fail(PG_ERR_UNSUPPORTED, "no-dictionary group-by column %s: only raw INT / LONG / FLOAT / DOUBLE / STRING / BYTES columns get a virtual dictionary", c.name.c_str());
+  const int kind = var_bytes ? 4 : c.data_type == PG_TYPE_INT ? 0 : c.data_type == PG_TYPE_LONG ? 1 : c.data_type == PG_TYPE_FLOAT ? 2 : 3;
   const int width = c.col_kind == PG_COL_RAW32 ? 4 : 8;
   const int64_t n = seg.total_docs;
   auto vd = std::make_unique<Column>();
@@ -122,7 +176,8 @@ void ensure_virtual_dictionary(Segment& seg, Column& c) {
   if (n > 0) {
     DeviceBuffer keys((size_t)n * 8), sorted((size_t)n * 8), count(8, true);
     const unsigned grid = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(pg_vdict_keys_kernel, dim3(grid), dim3(256), 0, 0, c.fwd_dev.as<uint8_t>(), width, kind, keys.as<uint64_t>(), n);
+    if (var_bytes) hipLaunchKernelGGL(pg_vdict_hash_kernel, dim3(grid), dim3(256), 0, 0, c.fwd_dev.as<uint8_t>(), c.vb_offsets_dev.as<int64_t>(), keys.as<uint64_t>(), n);
+    else hipLaunchKernelGGL(pg_vdict_keys_kernel, dim3(grid), dim3(256), 0, 0, c.fwd_dev.as<uint8_t>(), width, kind, keys.as<uint64_t>(), n);
     PG_HIP(hipGetLastError());
     size_t tmp_bytes = 0;
     PG_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, keys.as<uint64_t>(), sorted.as<uint64_t>(), (size_t)n));
@@ -157,18 +212,50 @@ void ensure_virtual_dictionary(Segment& seg, Column& c) {
     const int64_t n_dwords = (int64_t)(padded / PG_WAVE_DOCS) * 64 * bits;
     hipLaunchKernelGGL(pg_vdict_pack_kernel, dim3((unsigned)((n_dwords + 255) / 256)), dim3(256), 0, 0, ids, n, bits, vd->fwd_dev.as<uint32_t>(), n_dwords);
     PG_HIP(hipGetLastError());
+    if (var_bytes) {
+      // the hash is an identity on this column?  representatives, then every doc against its representative
+      DeviceBuffer rep((size_t)card * 4), flag(8, true);
+      PG_HIP(hipMemset(rep.ptr, 0xFF, (size_t)card * 4));
+      hipLaunchKernelGGL(pg_vdict_rep_kernel, dim3(grid), dim3(256), 0, 0, ids, rep.as<uint32_t>(), n);
+      hipLaunchKernelGGL(pg_vdict_verify_kernel, dim3(grid), dim3(256), 0, 0, c.fwd_dev.as<uint8_t>(), c.vb_offsets_dev.as<int64_t>(), ids, rep.as<uint32_t>(),
+                         flag.as<uint32_t>(), n);
+      PG_HIP(hipGetLastError());
+      uint32_t collided = 0;
+      PG_HIP(hipMemcpy(&collided, flag.ptr, 4, hipMemcpyDeviceToHost));
+      if (collided) fail(PG_ERR_UNSUPPORTED, "column %s: two distinct values share a 64-bit hash; its GROUP BY stays with the Java plan", c.name.c_str());
+      // the distinct values in id order: lengths, exclusive scan, gather; copied to the host once (the groups' keys come from here)
+      DeviceBuffer len(((size_t)card + 1) * 8, true), out_off(((size_t)card + 1) * 8, true);
+      hipLaunchKernelGGL(pg_vdict_value_len_kernel, dim3((card + 255) / 256), dim3(256), 0, 0, c.vb_offsets_dev.as<int64_t>(), rep.as<uint32_t>(), len.as<int64_t>(), card);
+      size_t s_bytes = 0;
+      PG_HIP(rocprim::exclusive_scan(nullptr, s_bytes, len.as<int64_t>(), out_off.as<int64_t>(), (int64_t)0, (size_t)card + 1, rocprim::plus<int64_t>()));
+      {
+        DeviceBuffer tmp(std::max<size_t>(s_bytes, 16));
+        PG_HIP(rocprim::exclusive_scan(tmp.ptr, s_bytes, len.as<int64_t>(), out_off.as<int64_t>(), (int64_t)0, (size_t)card + 1, rocprim::plus<int64_t>()));
+      }
+      vd->vdict_bytes_off.resize((size_t)card + 1);
+      PG_HIP(hipMemcpy(vd->vdict_bytes_off.data(), out_off.ptr, ((size_t)card + 1) * 8, hipMemcpyDeviceToHost));
+      const int64_t total = vd->vdict_bytes_off[card];
+      DeviceBuffer values((size_t)std::max<int64_t>(total, 1));
+      hipLaunchKernelGGL(pg_vdict_value_copy_kernel, dim3(card), dim3(64), 0, 0, c.fwd_dev.as<uint8_t>(), c.vb_offsets_dev.as<int64_t>(), rep.as<uint32_t>(),
+                         out_off.as<int64_t>(), values.as<uint8_t>(), card);
+      PG_HIP(hipGetLastError());
+      vd->vdict_bytes.resize((size_t)total);
+      if (total > 0) PG_HIP(hipMemcpy(vd->vdict_bytes.data(), values.ptr, (size_t)total, hipMemcpyDeviceToHost));
+    }
     PG_HIP(hipDeviceSynchronize());
     seg.device_bytes += bytes;
   } else {
     vd->bits = 1;
     vd->cardinality = 1;
     vd->fwd_dev.alloc(64, true);
-    distinct_host.push_back(key_of_bits(0, kind));
+    distinct_host.push_back(kind == 4 ? 0 : key_of_bits(0, kind));
+    if (kind == 4) vd->vdict_bytes_off.assign(2, 0);
   }
   vd->vdict_kind = kind;
   vd->vdict_keys = std::move(distinct_host);
   uint64_t h = 1469598103934665603ULL;
   for (uint64_t k : vd->vdict_keys) { h ^= k; h *= 1099511628211ULL; }
+  for (uint8_t b : vd->vdict_bytes) { h ^= b; h *= 1099511628211ULL; }   // var-byte keys: the values themselves (ids follow hash order)
   vd->vdict_hash = h;
   c.vdict = std::move(vd);
 }

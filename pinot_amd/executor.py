@@ -347,6 +347,19 @@ class ResultsBlock:
                 vals = np.zeros(ng, dtype=np.float64)
                 api.call("result_group_values_double", h, j, vals.ctypes.data, ng)
                 rb.group_value_columns[j] = vals
+            elif kt.value == capi.GROUP_KEY_BYTES_VALUES:   # a raw STRING / BYTES group-by column: the groups' byte strings
+                total = C.c_uint64()
+                api.call("result_group_values_bytes_size", h, j, C.byref(total))
+                offs = np.zeros(ng + 1, dtype=np.int64)
+                blob = np.zeros(max(int(total.value), 1), dtype=np.uint8)
+                api.call("result_group_values_bytes", h, j, offs.ctypes.data, ng + 1, blob.ctypes.data, int(total.value))
+                raw = blob.tobytes()
+                vals = np.empty(ng, dtype=object)
+                is_string = host.columns[qc.group_by[j]].data_type == "STRING"
+                for i in range(ng):
+                    v = raw[offs[i]:offs[i + 1]]
+                    vals[i] = v.decode("utf-8") if is_string else v
+                rb.group_value_columns[j] = vals
             else:
                 api.call("result_group_dict_ids", h, j, ids[j].ctypes.data, ng)
         if ngb == 1 and 0 in rb.group_value_columns and rb.group_value_columns[0].dtype == np.int64:
@@ -411,7 +424,7 @@ class ResultsBlock:
             for j, g in enumerate(self.query.group_by):
                 if j in vcols:   # raw values; a NaN key is one group: give it a key that compares equal to itself
                     v = vcols[j]
-                    per_col.append([int(x) for x in v] if v.dtype == np.int64 else [float(x) for x in v])
+                    per_col.append(list(v) if v.dtype == object else ([int(x) for x in v] if v.dtype == np.int64 else [float(x) for x in v]))
                 else:
                     dv = self._host.columns[g].dict_values
                     per_col.append([dv[ids[j, i]] for i in range(ng)])

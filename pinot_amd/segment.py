@@ -88,9 +88,13 @@ def add_range_index(col: HostColumn, values) -> HostColumn:
 def build_column(name: str, values, data_type: str, *, dictionary: bool = True, inverted: bool = False,
                  raw_version: int = 2, run_compress: bool = True, chunk_compression: int = 0,
                  docs_per_chunk: int = 1000) -> HostColumn:
+    if data_type in ("STRING", "BYTES") and not dictionary:
+        # raw var-byte column (VarByteChunkForwardIndexWriter, PASS_THROUGH): a GROUP BY key at most on this path
+        blobs = [v.encode("utf-8") if isinstance(v, str) else bytes(v) for v in values]
+        fwd = formats.write_raw_var_byte_chunk(blobs, version=raw_version, docs_per_chunk=docs_per_chunk)
+        return HostColumn(name, data_type, capi.FWD_RAW_VAR_BYTE_CHUNK, False, 0, 0, False, 0, fwd)
     if data_type == "STRING":
         vals = np.asarray(values, dtype=object)
-        assert dictionary, "raw STRING columns are outside the hot path"
         uq, inv = np.unique(vals.astype(str), return_inverse=True)  # Java String.compareTo == code-point order for BMP/ASCII test data
         uniq = [str(v) for v in uq.tolist()]
         dict_ids = inv.astype(np.int32)
