@@ -1038,6 +1038,8 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
   bool limit_reached = n_group_by > 0 && (int64_t)gids.size() >= (int64_t)P.num_groups_limit;
   if (n_group_by > 0 && (int64_t)gids.size() > (int64_t)P.num_groups_limit) {
     // keep the numGroupsLimit groups whose first matching docId is smallest (= the keys the reference admits in docId order)
+    if (P.dev.mv)   // which keys the reference admits depends on the entry order inside the docs: left to the Java plan
+      fail(PG_ERR_UNSUPPORTED, "multi-value group-by found %zu groups, more than numGroupsLimit (%d)", gids.size(), P.num_groups_limit);
     if (P.first_doc_op < 0) fail(PG_ERR_INTERNAL, "plan lacks the first-docId accumulator");
     const int64_t* first = table.data() + (size_t)P.first_doc_op * G;
     std::nth_element(gids.begin(), gids.begin() + P.num_groups_limit, gids.end(), [&](int64_t a, int64_t b) { return first[a] < first[b]; });

@@ -1547,7 +1547,9 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
   // admitted groups keep aggregating.  Equivalent without an order of execution: keep the `limit` groups whose FIRST matching
   // docId is smallest.  Only when the key space can exceed the limit does the plan carry that MIN(docId) accumulator.
   int32_t first_doc_op_unsorted = -1;
-  if (q->n_group_by > 0 && G > (int64_t)P.num_groups_limit) first_doc_op_unsorted = op_index(PG_ACC_MIN, -1, false);
+  // (multi-value plans carry no such accumulator — a doc admits several keys, in entry order: a result with more groups than the limit
+  // is refused at execution instead, pg_exec.hip)
+  if (q->n_group_by > 0 && G > (int64_t)P.num_groups_limit && !D.mv) first_doc_op_unsorted = op_index(PG_ACC_MIN, -1, false);
   // kernels walk ops grouped by source: stable sort by src and remap
   std::vector<int32_t> order(ops.size());
   for (size_t i = 0; i < order.size(); i++) order[i] = (int32_t)i;
@@ -1587,7 +1589,6 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
   if (D.mv) {
     // the multi-value kernels take dense key spaces (an LDS or HBM table) and admit every key: beyond that, the Java plan
     if (huge_key_space) fail(PG_ERR_UNSUPPORTED, "multi-value query over a group key space beyond 64 M keys");
-    if (q->n_group_by > 0 && G > (int64_t)P.num_groups_limit) fail(PG_ERR_UNSUPPORTED, "multi-value query whose key space (%lld) exceeds numGroupsLimit", (long long)G);
     if (P.has_digit_sums) fail(PG_ERR_UNSUPPORTED, "multi-value query next to a floating / wide LONG SUM");
     if (st) fail(PG_ERR_UNSUPPORTED, "multi-value query over a star-tree");
   }

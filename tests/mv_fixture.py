@@ -25,6 +25,7 @@ def make_rows(n, seed=7, empty_rows=True):
             "mv1": [int(v) for v in rng.integers(0, 40, k1)],                # multi-value INT (duplicates within a doc happen), inverted index
             "mv2": [WORDS[int(v)] for v in rng.integers(0, len(WORDS), k2)],  # multi-value STRING, scan only
             "mv3": [int(v) * 1000003 for v in rng.integers(0, 9, int(rng.integers(1, 3)))],   # multi-value LONG
+            "mvh": [int(v) for v in rng.integers(0, 30000, int(rng.integers(1, 4)))],          # multi-value INT, many distinct values
         })
     return rows
 
@@ -37,6 +38,7 @@ def build(rows, name="mvTable") -> HostSegment:
     seg.columns["mv1"] = build_mv_column("mv1", [r["mv1"] for r in rows], "INT", inverted=True)
     seg.columns["mv2"] = build_mv_column("mv2", [r["mv2"] for r in rows], "STRING")
     seg.columns["mv3"] = build_mv_column("mv3", [r["mv3"] for r in rows], "LONG")
+    seg.columns["mvh"] = build_mv_column("mvh", [r["mvh"] for r in rows], "INT")
     return seg
 
 

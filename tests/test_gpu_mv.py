@@ -51,6 +51,11 @@ QUERIES = [
     f"SELECT mv2, {MV_AGGS} FROM mvTable GROUP BY mv2 LIMIT 100",
     f"SELECT mv1, s2, {MV_AGGS} FROM mvTable WHERE s1 = 2 GROUP BY mv1, s2 LIMIT 10000",
     "SELECT s2, SUMMV(mv3), AVGMV(mv3), COUNTMV(mv3) FROM mvTable GROUP BY s2 LIMIT 100",         # LONG entries
+    # ---- key spaces beyond one LDS table: the dense HBM table (pg_mv_query_g), DISTINCTCOUNT states in HBM ------------------------------
+    "SELECT mvh, s1, COUNT(*), SUM(m), MAXMV(mv1) FROM mvTable GROUP BY mvh, s1 LIMIT 1000000",
+    "SELECT mvh, mv2, COUNT(*), COUNTMV(mv3) FROM mvTable WHERE s1 IN (1, 2, 3, 4) GROUP BY mvh, mv2 LIMIT 1000000",
+    "SELECT mv1, s1, DISTINCTCOUNTMV(mvh), DISTINCTCOUNT(s2) FROM mvTable GROUP BY mv1, s1 LIMIT 100000",
+    "SELECT DISTINCTCOUNTMV(mvh), DISTINCTCOUNTHLLMV(mvh), SUMMV(mvh) FROM mvTable WHERE mv2 != 'ant'",
     # ---- answered from the dictionaries (NonScanBasedAggregationOperator) -------------------------------------------------------
     "SELECT MINMV(mv3), MAXMV(mv3), MINMAXRANGEMV(mv1), DISTINCTCOUNTMV(mv2), COUNT(*) FROM mvTable",
 ]
@@ -79,10 +84,13 @@ def test_the_multi_value_kernels_run_them(pair):
     if g.total_docs < 2049:
         pytest.skip("tiny segments: literals missing from the dictionaries turn leaves into Empty / MatchAll")
     for sql, kernel in (("SELECT COUNT(*), SUM(m) FROM mvTable WHERE mv2 = 'cat'", "pg_mv_query_l"),
+                        ("SELECT mvh, s1, COUNT(*), SUM(m) FROM mvTable GROUP BY mvh, s1 LIMIT 1000000", "pg_mv_query_g" if g.total_docs >= 50_000 else None),
                         ("SELECT mv1, COUNT(*) FROM mvTable GROUP BY mv1 LIMIT 1000", "pg_mv_query_l"),
                         ("SELECT s1, SUMMV(mv1) FROM mvTable WHERE s1 < 3 GROUP BY s1 LIMIT 1000", "pg_mv_query_l"),
                         ("SELECT COUNT(*), SUM(m) FROM mvTable WHERE mv1 IN (1, 2, 3)", None)):   # inverted index only: nothing multi-value is read
         k = g.execute(sql).stats.kernel.decode()
+        if kernel is None and "mvh" in sql:
+            continue
         assert (k == kernel) if kernel else not k.startswith("pg_mv_query"), (sql, k)
 
 
@@ -95,6 +103,20 @@ def test_filter_only_api_over_a_multi_value_column(pair):
         assert gs.stats().num_entries_scanned_in_filter == os_.stats().num_entries_scanned_in_filter, where
         gs.free()
         os_.free()
+
+
+def test_more_groups_than_num_groups_limit_is_left_to_the_java_plan(pair):
+    g, o = pair
+    if g.total_docs < 50_000:
+        pytest.skip("needs more groups than the limit")
+    from pinot_amd.query import parse_sql
+    q = parse_sql("SELECT mvh, s1, COUNT(*) FROM mvTable GROUP BY mvh, s1 LIMIT 1000000")
+    q.num_groups_limit = 5000
+    with pytest.raises(capi.NativeError):
+        g.execute(q)
+    q = parse_sql("SELECT mvh, s1, COUNT(*) FROM mvTable GROUP BY mvh, s1 LIMIT 1000000")
+    q.num_groups_limit = 100_000         # the key space (210 000) may exceed the limit as long as the groups found (80 000) do not
+    assert g.execute(q).rows() == o.execute(q).rows()
 
 
 UNSUPPORTED = [
