@@ -277,16 +277,22 @@ def main():
             "roofline_frac": NORTH_STAR_BYTES_PER_ROW * args.docs / (k_n * 1e-3) / 1e9 / HBM_PEAK_GBS if k_n > 0 else 0.0,
             "algorithmic_bytes_per_launch": NORTH_STAR_BYTES_PER_ROW * args.docs}
 
-    if args.query == "cfg3" and rank == 0 and world == 1:
+    if args.query == "cfg3" and rank == 0 and world == 1 and not args.no_variants:
         out["merge_world_of_one"] = world_of_one_merge(api, seg, qc, local_rank)
     if args.query == "cfg3" and not args.no_variants and rank == 0 and world == 1:
         # BASELINE configs 2 and 5 next to the headline (same timing discipline, their own segments): every default run carries them
         seg.destroy()
         seg = None
+        t_blocks = time.time()
         out["cfg2"] = extra_block(api, args, "cfg2", min(args.docs, 100_000_000), 4.0, ["r_int"], synth.QUERY_CFG2)
+        log(f"cfg2 block {time.time() - t_blocks:.1f}s")
+        t_blocks = time.time()
         out["cfg5_flat"] = extra_block(api, args, "cfg5", args.docs, 4.375, list(synth.CFG5_COLUMNS), synth.QUERY_CFG5)
+        log(f"cfg5_flat block {time.time() - t_blocks:.1f}s")
+        t_blocks = time.time()
         out["cfg5_star_tree"] = star_tree_leg(api, args, parent_docs=400_000)
-    if args.query == "cfg5" and rank == 0:
+        log(f"cfg5_star_tree block {time.time() - t_blocks:.1f}s")
+    if args.query == "cfg5" and rank == 0 and not args.no_variants:   # (not in the PMC child runs: they only need the flat query's kernels)
         out["star_tree_route"] = star_tree_leg(api, args)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.query != "cfg5":
         out["cpu_baseline"] = cpu_baseline(args, sql, dense, seg)
@@ -415,8 +421,8 @@ def star_tree_leg(api, args, parent_docs=2_000_000):
     bf, lat_f, lib_f, dev_f = timed(capi.QUERY_FLAG_FINAL_DISTINCT)
     b, lat_i, lib_i, dev_i = timed(0)
     from pinot_amd.executor import hll_cardinality
-    inter = b.rows()
-    final_ok = all(bf.rows()[k] == [v[0], hll_cardinality(v[1])] for k, v in inter.items()) and len(bf.rows()) == len(inter)
+    inter, final = b.rows(), bf.rows()   # (rows() assembles a dict per call: once each)
+    final_ok = len(final) == len(inter) and all(final[k] == [v[0], hll_cardinality(v[1])] for k, v in inter.items())
     out = {"star_tree_docs": int(parent.star_trees[0].num_docs), "groups": len(inter), "star_tree_index": int(b.stats.star_tree_index),
            "p50_query_latency_ms": lat_f, "library_ms": lib_f, "device_ms": dev_f,
            "final_values_equal_cardinality_of_registers": bool(final_ok),
