@@ -125,17 +125,21 @@ void comm_destroy(Comm* c) {
   delete c;
 }
 
-// Every rank calls this with its own result of the same query.  ONE grouped RCCL launch, out of place into the communicator's scratch:
-//   layout signature                 ncclMax on {sig, -sig}: mismatched tables fail on every rank alike
+// Every rank calls this with its own result of the same query.  Two launches:
+//   1. the probe — its shape does not depend on the table, so it is safe whatever the ranks hold: ncclMax on {sig, -sig} (the layout's
+//      signature, dictionary contents included) and ncclSum on {full-scan entries, total docs}; one stream synchronisation, then the
+//      host checks that every rank holds the same layout and that the SUM rows cannot overflow for the merged doc count.  A refusal
+//      (PG_ERR_UNSUPPORTED -> merge on the host by values) happens HERE, on every rank alike, before any table byte moves.
+//      Earlier in round 3 the probe rode inside the data launch to save a synchronisation.  Reading the code again: ranks that disagree
+//      on the layout would then enqueue collectives of different counts and sizes inside one group, which NCCL / RCCL leaves undefined
+//      (in practice a hang) — the very case the probe exists for.  Not observed: every run so far had a world of one.
+//   2. ONE grouped RCCL launch over the table, out of place into the communicator's scratch, then committed on the stream:
 //   row o of the accumulator table   ncclSum (COUNT, SUM limbs) / ncclMin / ncclMax on int64 (float MIN / MAX are order-preserving
 //                                    int64 keys, float SUMs are fixed-point int64 limbs: every merge is exact and order-free)
 //   statistics counters + tail       ncclSum on int64
 //   HyperLogLog registers            ncclMax on uint8
 //   dictId sets                      all-gather, then OR (RCCL has no bitwise reduction)
-// then one stream synchronisation: the signature and the summed doc count (the accumulators' overflow bounds) are checked on the
-// host, and only then is the merged image copied over the table the query left in HBM — a refused merge leaves the result as it was
-// (PG_ERR_UNSUPPORTED → merge on the host by values).  (Round 2 exchanged the signature in a launch of its own with a second
-// synchronisation, and merged in place.)
+//      followed by the copy of the merged image over the table the query left in HBM and the reassembly's synchronisation.
 void result_all_reduce(Result& r, Comm& c) {
   if (!r.dev) fail(PG_ERR_INVALID_ARGUMENT, "pg_result_all_reduce needs a result executed with PG_QUERY_FLAG_KEEP_DEVICE_TABLE");
   DeviceTable& T = *r.dev;
@@ -152,18 +156,30 @@ void result_all_reduce(Result& r, Comm& c) {
   const size_t n_table = (size_t)T.n_out + PG_MAX_STATS + 2;   // accumulators, statistics counters, {full-scan entries, total docs}
   size_t set_bytes = 0;
   for (int x = 0; x < D.n_aux; x++) if (D.aux[x].kind == PG_AUX_DICT_SET) set_bytes += T.plan->aux_bytes[(size_t)x];
-  // scratch: [probe 2 x int64 | pad to 64][table image][aux image][gathered sets x world]
+  // scratch: [probe 4 x int64 | pad to 64][table image][aux image][gathered sets x world]
   const size_t off_table = 64, off_aux = off_table + n_table * 8, off_gather = (off_aux + T.aux_total + 63) & ~(size_t)63;
   const size_t need = off_gather + set_bytes * (size_t)c.world + 64;
   if (c.scratch.size < need) c.scratch.alloc(need + need / 4);
   uint8_t* S = c.scratch.as<uint8_t>();
   int64_t* table = T.table.as<int64_t>();
   int64_t* image = reinterpret_cast<int64_t*>(S + off_table);
+  // ---- 1. the probe ---------------------------------------------------------------------------------------------------------------
   const int64_t sig = table_signature(T);
   c.probe[0] = sig; c.probe[1] = -sig;
   PG_HIP(hipMemcpyAsync(S, c.probe, 16, hipMemcpyHostToDevice, stream));
+  PG_HIP(hipMemcpyAsync(S + 16, table + T.n_out + PG_MAX_STATS, 16, hipMemcpyDeviceToDevice, stream));   // {full-scan entries, total docs}
   PG_NCCL(R.GroupStart());
   PG_NCCL(R.AllReduce(S, S, 2, kNcclInt64, kNcclMax, c.comm, stream));
+  PG_NCCL(R.AllReduce(S + 16, S + 16, 2, kNcclInt64, kNcclSum, c.comm, stream));
+  PG_NCCL(R.GroupEnd());
+  PG_HIP(hipMemcpyAsync(c.probe, S, 32, hipMemcpyDeviceToHost, stream));
+  PG_HIP(hipStreamSynchronize(stream));
+  if (c.probe[0] != sig || c.probe[1] != -sig)
+    fail(PG_ERR_UNSUPPORTED, "pg_result_all_reduce: the ranks' results do not share their table layout (different key space, dictionaries, "
+                             "aggregations or fixed-point scale): merge on the host by values");
+  check_merge_bounds(T, c.probe[3]);
+  // ---- 2. the table (every rank now known to hold the same layout) ------------------------------------------------------------------
+  PG_NCCL(R.GroupStart());
   for (int o = 0; o < D.n_ops && T.n_out > 0; o++) {
     const int red = D.ops[o].fn == PG_ACC_MIN ? kNcclMin : (D.ops[o].fn == PG_ACC_MAX ? kNcclMax : kNcclSum);
     PG_NCCL(R.AllReduce(table + (int64_t)o * G, image + (int64_t)o * G, (size_t)G, kNcclInt64, red, c.comm, stream));
@@ -197,13 +213,6 @@ void result_all_reduce(Result& r, Comm& c) {
       off += bytes;
     }
   }
-  PG_HIP(hipMemcpyAsync(c.probe, S, 16, hipMemcpyDeviceToHost, stream));
-  PG_HIP(hipMemcpyAsync(c.probe + 2, image + T.n_out + PG_MAX_STATS, 16, hipMemcpyDeviceToHost, stream));   // {full-scan entries, total docs} summed
-  PG_HIP(hipStreamSynchronize(stream));
-  if (c.probe[0] != sig || c.probe[1] != -sig)
-    fail(PG_ERR_UNSUPPORTED, "pg_result_all_reduce: the ranks' results do not share their table layout (different key space, dictionaries, "
-                             "aggregations or fixed-point scale): merge on the host by values");
-  check_merge_bounds(T, c.probe[3]);
   PG_HIP(hipMemcpyAsync(table, image, n_table * 8, hipMemcpyDeviceToDevice, stream));
   if (T.aux_total) PG_HIP(hipMemcpyAsync(T.aux.ptr, S + off_aux, T.aux_total, hipMemcpyDeviceToDevice, stream));
   result_reassemble(r);   // copies the merged table back (its one synchronisation) and rebuilds the groups
