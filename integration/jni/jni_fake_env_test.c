@@ -63,16 +63,22 @@ static void* f_GetDirectBufferAddress(JNIEnv* env, jobject b) { (void)env; retur
 F_SET_REGION(f_SetIntArrayRegion, jint)
 F_SET_REGION(f_SetDoubleArrayRegion, jdouble)
 F_SET_REGION(f_SetByteArrayRegion, jbyte)
-static void f_GetByteArrayRegion(JNIEnv* env, jbyteArray a, jsize start, jsize len, jbyte* buf) {
-  (void)env;
-  if (start < 0 || len < 0 || start + len > a->length) { snprintf(pending_class, sizeof pending_class, "java/lang/ArrayIndexOutOfBoundsException"); return; }
-  memcpy(buf, (jbyte*)a->data + start, (size_t)len);
-}
+#define F_GET_REGION(NAME, T)                                                                                                \
+  static void NAME(JNIEnv* env, jarray a, jsize start, jsize len, T* buf) {                                                  \
+    (void)env;                                                                                                               \
+    if (start < 0 || len < 0 || start + len > a->length) { snprintf(pending_class, sizeof pending_class, "java/lang/ArrayIndexOutOfBoundsException"); return; } \
+    memcpy(buf, (T*)a->data + start, (size_t)len * sizeof(T));                                                               \
+  }
+F_GET_REGION(f_GetByteArrayRegion, jbyte)
+F_GET_REGION(f_GetIntArrayRegion, jint)
+F_GET_REGION(f_GetLongArrayRegion, jlong)
+F_GET_REGION(f_GetDoubleArrayRegion, jdouble)
 
 static const struct JNINativeInterface_ fake_functions = {
   f_FindClass, f_ThrowNew, f_GetStringUTFChars, f_ReleaseStringUTFChars, f_GetArrayLength, f_GetObjectArrayElement, f_GetIntArrayElements,
   f_GetLongArrayElements, f_ReleaseIntArrayElements, f_ReleaseLongArrayElements, f_SetLongArrayRegion, f_GetPrimitiveArrayCritical,
   f_ReleasePrimitiveArrayCritical, f_GetDirectBufferAddress, f_SetIntArrayRegion, f_SetDoubleArrayRegion, f_SetByteArrayRegion, f_GetByteArrayRegion,
+  f_GetIntArrayRegion, f_GetLongArrayRegion, f_GetDoubleArrayRegion,
 };
 
 static int pending(void) { return pending_class[0] != 0; }

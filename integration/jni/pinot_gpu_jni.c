@@ -167,24 +167,27 @@ JNIEXPORT jlong JNICALL Java_org_apache_pinot_gpu_PinotGpu_queryExec(JNIEnv* env
 JNIEXPORT jint JNICALL Java_org_apache_pinot_gpu_PinotGpu_resultNumGroups(JNIEnv* env, jclass c, jlong r) { (void)c; int32_t n = 0; CHECK_RET(pg_result_num_groups(RES(r), &n), 0); return n; }
 JNIEXPORT jint JNICALL Java_org_apache_pinot_gpu_PinotGpu_resultKindOf(JNIEnv* env, jclass c, jlong r, jint agg) { (void)c; int32_t k = 0; CHECK_RET(pg_result_kind_of(RES(r), agg, &k), 0); return k; }
 JNIEXPORT jint JNICALL Java_org_apache_pinot_gpu_PinotGpu_resultGroupKeyType(JNIEnv* env, jclass c, jlong r, jint col) { (void)c; int32_t k = 0; CHECK_RET(pg_result_group_key_type(RES(r), col, &k), 0); return k; }
-/* Copy-out accessors: the native call fills a malloc'd staging buffer (it may block: kernels, stream synchronisation, device copies —
- * the JNI specification forbids that between Get/ReleasePrimitiveArrayCritical), then one Set<Type>ArrayRegion moves the bytes. */
+/* Copy-out accessors: the native call fills a staging buffer (it may block: kernels, stream synchronisation, device copies — the JNI
+ * specification forbids that between Get/ReleasePrimitiveArrayCritical), then one Set<Type>ArrayRegion moves the bytes.  The accessors
+ * write only as many elements as the result holds, which may be fewer than the caller's array: the staging buffer therefore starts as a
+ * copy of the array (Get<Type>ArrayRegion), so the elements the accessor leaves alone come back unchanged — never heap garbage. */
 #include <stdlib.h>
-#define COPY_OUT(NAME, JTYPE, CTYPE, SETREGION, CALL)                                                          \
+#define COPY_OUT(NAME, JTYPE, CTYPE, GETREGION, SETREGION, CALL)                                                         \
   JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpu_##NAME {                                            \
     (void)c;                                                                                                    \
     if (!out) { jclass x = (*env)->FindClass(env, "java/lang/NullPointerException"); if (x) (*env)->ThrowNew(env, x, "output array"); return; } \
     const jsize n = (*env)->GetArrayLength(env, out);                                                           \
     CTYPE* p = (CTYPE*)malloc((size_t)(n > 0 ? n : 1) * sizeof(CTYPE));                                         \
     if (!p) { jclass x = (*env)->FindClass(env, "java/lang/OutOfMemoryError"); if (x) (*env)->ThrowNew(env, x, "staging buffer"); return; } \
+    (*env)->GETREGION(env, out, 0, n, (JTYPE*)p);                                                               \
     const int32_t st = CALL;                                                                                    \
     if (st >= 0) (*env)->SETREGION(env, out, 0, n, (const JTYPE*)p);                                            \
     free(p);                                                                                                    \
     CHECK(st);                                                                                                  \
   }
-COPY_OUT(resultGroupDictIds(JNIEnv* env, jclass c, jlong r, jint col, jintArray out), jint, int32_t, SetIntArrayRegion, pg_result_group_dict_ids(RES(r), col, p, n))
-COPY_OUT(resultGroupValuesLong(JNIEnv* env, jclass c, jlong r, jint col, jlongArray out), jlong, int64_t, SetLongArrayRegion, pg_result_group_values_long(RES(r), col, p, n))
-COPY_OUT(resultGroupValuesDouble(JNIEnv* env, jclass c, jlong r, jint col, jdoubleArray out), jdouble, double, SetDoubleArrayRegion, pg_result_group_values_double(RES(r), col, p, n))
+COPY_OUT(resultGroupDictIds(JNIEnv* env, jclass c, jlong r, jint col, jintArray out), jint, int32_t, GetIntArrayRegion, SetIntArrayRegion, pg_result_group_dict_ids(RES(r), col, p, n))
+COPY_OUT(resultGroupValuesLong(JNIEnv* env, jclass c, jlong r, jint col, jlongArray out), jlong, int64_t, GetLongArrayRegion, SetLongArrayRegion, pg_result_group_values_long(RES(r), col, p, n))
+COPY_OUT(resultGroupValuesDouble(JNIEnv* env, jclass c, jlong r, jint col, jdoubleArray out), jdouble, double, GetDoubleArrayRegion, SetDoubleArrayRegion, pg_result_group_values_double(RES(r), col, p, n))
 /* raw STRING / BYTES group keys: resultGroupValuesBytesSize, then offsets (numGroups + 1 longs) and the values back to back */
 JNIEXPORT jlong JNICALL Java_org_apache_pinot_gpu_PinotGpu_resultGroupValuesBytesSize(JNIEnv* env, jclass c, jlong r, jint col) {
   (void)c;
@@ -196,10 +199,11 @@ JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpu_resultGroupValuesBytes
   (void)c;
   if (!offsets || !out) { jclass x = (*env)->FindClass(env, "java/lang/NullPointerException"); if (x) (*env)->ThrowNew(env, x, "output array"); return; }
   const jsize n_off = (*env)->GetArrayLength(env, offsets), n_bytes = (*env)->GetArrayLength(env, out);
-  int64_t* po = (int64_t*)malloc((size_t)(n_off > 0 ? n_off : 1) * sizeof(int64_t));
-  uint8_t* pb = (uint8_t*)malloc((size_t)(n_bytes > 0 ? n_bytes : 1));
+  int64_t* po = (int64_t*)calloc((size_t)(n_off > 0 ? n_off : 1), sizeof(int64_t));
+  uint8_t* pb = (uint8_t*)calloc((size_t)(n_bytes > 0 ? n_bytes : 1), 1);
   if (!po || !pb) { free(po); free(pb); jclass x = (*env)->FindClass(env, "java/lang/OutOfMemoryError"); if (x) (*env)->ThrowNew(env, x, "staging buffer"); return; }
   const int32_t st = pg_result_group_values_bytes(RES(r), col, po, (int32_t)n_off, pb, (uint64_t)n_bytes);
+  if (po && pb) { (*env)->GetLongArrayRegion(env, offsets, 0, n_off, (jlong*)po); (*env)->GetByteArrayRegion(env, out, 0, n_bytes, (jbyte*)pb); }
   if (st >= 0) {
     (*env)->SetLongArrayRegion(env, offsets, 0, n_off, (const jlong*)po);
     (*env)->SetByteArrayRegion(env, out, 0, n_bytes, (const jbyte*)pb);
@@ -208,11 +212,11 @@ JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpu_resultGroupValuesBytes
   free(pb);
   CHECK(st);
 }
-COPY_OUT(resultDoubles(JNIEnv* env, jclass c, jlong r, jint agg, jint comp, jdoubleArray out), jdouble, double, SetDoubleArrayRegion, pg_result_doubles(RES(r), agg, comp, p, n))
-COPY_OUT(resultLongs(JNIEnv* env, jclass c, jlong r, jint agg, jint comp, jlongArray out), jlong, int64_t, SetLongArrayRegion, pg_result_longs(RES(r), agg, comp, p, n))
-COPY_OUT(resultSetSizes(JNIEnv* env, jclass c, jlong r, jint agg, jintArray out), jint, int32_t, SetIntArrayRegion, pg_result_set_sizes(RES(r), agg, p, n))
-COPY_OUT(resultSetDictIds(JNIEnv* env, jclass c, jlong r, jint agg, jintArray out), jint, int32_t, SetIntArrayRegion, pg_result_set_dict_ids(RES(r), agg, p, (int64_t)n))
-COPY_OUT(resultHllRegisters(JNIEnv* env, jclass c, jlong r, jint agg, jbyteArray out), jbyte, uint8_t, SetByteArrayRegion, pg_result_hll_registers(RES(r), agg, p, (int64_t)n))
+COPY_OUT(resultDoubles(JNIEnv* env, jclass c, jlong r, jint agg, jint comp, jdoubleArray out), jdouble, double, GetDoubleArrayRegion, SetDoubleArrayRegion, pg_result_doubles(RES(r), agg, comp, p, n))
+COPY_OUT(resultLongs(JNIEnv* env, jclass c, jlong r, jint agg, jint comp, jlongArray out), jlong, int64_t, GetLongArrayRegion, SetLongArrayRegion, pg_result_longs(RES(r), agg, comp, p, n))
+COPY_OUT(resultSetSizes(JNIEnv* env, jclass c, jlong r, jint agg, jintArray out), jint, int32_t, GetIntArrayRegion, SetIntArrayRegion, pg_result_set_sizes(RES(r), agg, p, n))
+COPY_OUT(resultSetDictIds(JNIEnv* env, jclass c, jlong r, jint agg, jintArray out), jint, int32_t, GetIntArrayRegion, SetIntArrayRegion, pg_result_set_dict_ids(RES(r), agg, p, (int64_t)n))
+COPY_OUT(resultHllRegisters(JNIEnv* env, jclass c, jlong r, jint agg, jbyteArray out), jbyte, uint8_t, GetByteArrayRegion, SetByteArrayRegion, pg_result_hll_registers(RES(r), agg, p, (int64_t)n))
 /* out[0..4] = numDocsScanned, numEntriesScannedInFilter, numEntriesScannedPostFilter, numTotalDocs, numGroupsLimitReached */
 JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpu_resultStats(JNIEnv* env, jclass c, jlong r, jlongArray out) {
   (void)c;
@@ -232,8 +236,8 @@ JNIEXPORT jlong JNICALL Java_org_apache_pinot_gpu_PinotGpu_filterExec(JNIEnv* en
   return (jlong)(intptr_t)s;
 }
 JNIEXPORT jlong JNICALL Java_org_apache_pinot_gpu_PinotGpu_docIdSetCardinality(JNIEnv* env, jclass c, jlong s) { (void)c; int64_t n = 0; CHECK_RET(pg_docidset_cardinality(SET(s), &n), 0); return n; }
-COPY_OUT(docIdSetCopyWords(JNIEnv* env, jclass c, jlong s, jlongArray out), jlong, uint64_t, SetLongArrayRegion, pg_docidset_copy_words(SET(s), p, (int64_t)n))
-COPY_OUT(docIdSetCopyDocIds(JNIEnv* env, jclass c, jlong s, jintArray out), jint, int32_t, SetIntArrayRegion, pg_docidset_copy_docids(SET(s), p, (int64_t)n))
+COPY_OUT(docIdSetCopyWords(JNIEnv* env, jclass c, jlong s, jlongArray out), jlong, uint64_t, GetLongArrayRegion, SetLongArrayRegion, pg_docidset_copy_words(SET(s), p, (int64_t)n))
+COPY_OUT(docIdSetCopyDocIds(JNIEnv* env, jclass c, jlong s, jintArray out), jint, int32_t, GetIntArrayRegion, SetIntArrayRegion, pg_docidset_copy_docids(SET(s), p, (int64_t)n))
 JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpu_docIdSetFree(JNIEnv* env, jclass c, jlong s) { (void)c; CHECK(pg_docidset_free(SET(s))); }
 
 /* ---- GroupByCombineOperator in the library: segments sharing their key space merge element-wise in HBM (pinot_gpu.h) ------------------ */
@@ -263,6 +267,7 @@ JNIEXPORT jlong JNICALL Java_org_apache_pinot_gpu_PinotGpu_commInitRank(JNIEnv* 
 /* one communicator per listed device (one JVM, N GPUs): outComms[i] belongs to devices[i] */
 JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpu_commInitAll(JNIEnv* env, jclass c, jintArray devices, jlongArray outComms) {
   (void)c;
+  if (!devices || !outComms) { jclass x = (*env)->FindClass(env, "java/lang/NullPointerException"); if (x) (*env)->ThrowNew(env, x, "devices / outComms"); return; }
   const jsize n = (*env)->GetArrayLength(env, devices);
   if (n < 1 || n > 64 || (*env)->GetArrayLength(env, outComms) < n) {
     jclass x = (*env)->FindClass(env, "java/lang/IllegalArgumentException"); if (x) (*env)->ThrowNew(env, x, "1..64 devices and as many output slots"); return;

@@ -75,7 +75,9 @@ struct Comm {
   int world = 1;
   int rank = 0;
   DeviceBuffer scratch;   // merged image of a table (signature probe, accumulators, states) + gathered dictId sets
-  int64_t probe[4] = {0, 0, 0, 0};   // {sig, -sig} out and back; {full-scan entries, total docs} summed over the ranks
+  // the probe, out and back: ncclMax over {sig, -sig, largest per-doc |value| of an int64 SUM, digit sums present, a rank refuses
+  // (IEEE-double SUM)}; ncclSum over {full-scan entries, total docs}
+  int64_t probe[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 void comm_unique_id(void* out128) {
@@ -127,12 +129,16 @@ void comm_destroy(Comm* c) {
 
 // Every rank calls this with its own result of the same query.  Two launches:
 //   1. the probe — its shape does not depend on the table, so it is safe whatever the ranks hold: ncclMax on {sig, -sig} (the layout's
-//      signature, dictionary contents included) and ncclSum on {full-scan entries, total docs}; one stream synchronisation, then the
-//      host checks that every rank holds the same layout and that the SUM rows cannot overflow for the merged doc count.  A refusal
-//      (PG_ERR_UNSUPPORTED -> merge on the host by values) happens HERE, on every rank alike, before any table byte moves.
+//      signature, dictionary contents included), on the overflow guards of the summed accumulators {largest per-doc |value|, digit sums}
+//      and on a "some rank must refuse" flag; ncclSum on {full-scan entries, total docs}; one stream synchronisation, then the host
+//      checks that every rank holds the same layout and that the SUM rows cannot overflow for the merged doc count.  EVERY refusal
+//      (PG_ERR_UNSUPPORTED -> merge on the host by values) is decided HERE, after the probe, from REDUCED values only — so every rank
+//      decides alike and none enters the table launch alone.  (Round 3 had two rank-local decisions in this function — the IEEE-double
+//      SUM refusal in front of the probe and the overflow bound evaluated on the rank's own value range — either of which leaves the
+//      other ranks waiting in a collective: ADVICE r3.)
 //      Earlier in round 3 the probe rode inside the data launch to save a synchronisation.  Reading the code again: ranks that disagree
 //      on the layout would then enqueue collectives of different counts and sizes inside one group, which NCCL / RCCL leaves undefined
-//      (in practice a hang) — the very case the probe exists for.  Not observed: every run so far had a world of one.
+//      (in practice a hang) — the very case the probe exists for.
 //   2. ONE grouped RCCL launch over the table, out of place into the communicator's scratch, then committed on the stream:
 //   row o of the accumulator table   ncclSum (COUNT, SUM limbs) / ncclMin / ncclMax on int64 (float MIN / MAX are order-preserving
 //                                    int64 keys, float SUMs are fixed-point int64 limbs: every merge is exact and order-free)
@@ -148,15 +154,15 @@ void result_all_reduce(Result& r, Comm& c) {
   hipStream_t stream = thread_stream(T.device);
   Rccl& R = rccl();
   const PgQueryPlan& D = T.plan->dev;
-  for (int o = 0; o < D.n_ops; o++)   // refusals before the group opens: an exception between GroupStart and GroupEnd would leave it open
-    if (D.ops[o].fn == PG_ACC_SUM && D.ops[o].is_float == 1)
-      fail(PG_ERR_UNSUPPORTED, "pg_result_all_reduce: a floating-point SUM accumulated in double (a column holding NaN / Inf) does not merge exactly");
+  int64_t refuse_local = 0;   // decided rank-locally, acted upon only after the probe (on the reduced flag)
+  for (int o = 0; o < D.n_ops; o++)
+    if (D.ops[o].fn == PG_ACC_SUM && D.ops[o].is_float == 1) refuse_local = 1;
   device_table_tail_store(T, stream);
   const int64_t G = std::max(D.n_groups, 1);
   const size_t n_table = (size_t)T.n_out + PG_MAX_STATS + 2;   // accumulators, statistics counters, {full-scan entries, total docs}
   size_t set_bytes = 0;
   for (int x = 0; x < D.n_aux; x++) if (D.aux[x].kind == PG_AUX_DICT_SET) set_bytes += T.plan->aux_bytes[(size_t)x];
-  // scratch: [probe 4 x int64 | pad to 64][table image][aux image][gathered sets x world]
+  // scratch: [probe 7 x int64 | pad to 64][table image][aux image][gathered sets x world]
   const size_t off_table = 64, off_aux = off_table + n_table * 8, off_gather = (off_aux + T.aux_total + 63) & ~(size_t)63;
   const size_t need = off_gather + set_bytes * (size_t)c.world + 64;
   if (c.scratch.size < need) c.scratch.alloc(need + need / 4);
@@ -166,18 +172,26 @@ void result_all_reduce(Result& r, Comm& c) {
   // ---- 1. the probe ---------------------------------------------------------------------------------------------------------------
   const int64_t sig = table_signature(T);
   c.probe[0] = sig; c.probe[1] = -sig;
-  PG_HIP(hipMemcpyAsync(S, c.probe, 16, hipMemcpyHostToDevice, stream));
-  PG_HIP(hipMemcpyAsync(S + 16, table + T.n_out + PG_MAX_STATS, 16, hipMemcpyDeviceToDevice, stream));   // {full-scan entries, total docs}
+  c.probe[2] = (int64_t)std::min<uint64_t>(T.sum_max_abs, (uint64_t)INT64_MAX);
+  c.probe[3] = T.has_digit_sums ? 1 : 0;
+  c.probe[4] = refuse_local;
+  PG_HIP(hipMemcpyAsync(S, c.probe, 40, hipMemcpyHostToDevice, stream));
+  PG_HIP(hipMemcpyAsync(S + 40, table + T.n_out + PG_MAX_STATS, 16, hipMemcpyDeviceToDevice, stream));   // {full-scan entries, total docs}
   PG_NCCL(R.GroupStart());
-  PG_NCCL(R.AllReduce(S, S, 2, kNcclInt64, kNcclMax, c.comm, stream));
-  PG_NCCL(R.AllReduce(S + 16, S + 16, 2, kNcclInt64, kNcclSum, c.comm, stream));
+  PG_NCCL(R.AllReduce(S, S, 5, kNcclInt64, kNcclMax, c.comm, stream));
+  PG_NCCL(R.AllReduce(S + 40, S + 40, 2, kNcclInt64, kNcclSum, c.comm, stream));
   PG_NCCL(R.GroupEnd());
-  PG_HIP(hipMemcpyAsync(c.probe, S, 32, hipMemcpyDeviceToHost, stream));
+  PG_HIP(hipMemcpyAsync(c.probe, S, 56, hipMemcpyDeviceToHost, stream));
   PG_HIP(hipStreamSynchronize(stream));
+  // from here on every value is the same on every rank: all of them refuse, or none does
   if (c.probe[0] != sig || c.probe[1] != -sig)
     fail(PG_ERR_UNSUPPORTED, "pg_result_all_reduce: the ranks' results do not share their table layout (different key space, dictionaries, "
                              "aggregations or fixed-point scale): merge on the host by values");
-  check_merge_bounds(T, c.probe[3]);
+  if (c.probe[4])
+    fail(PG_ERR_UNSUPPORTED, "pg_result_all_reduce: a floating-point SUM accumulated in double (a column holding NaN / Inf) does not merge exactly");
+  check_merge_bounds((uint64_t)c.probe[2], c.probe[3] != 0, c.probe[6]);
+  T.sum_max_abs = (uint64_t)c.probe[2];   // the merged table's bound, for later merges
+  T.has_digit_sums = c.probe[3] != 0;
   // ---- 2. the table (every rank now known to hold the same layout) ------------------------------------------------------------------
   PG_NCCL(R.GroupStart());
   for (int o = 0; o < D.n_ops && T.n_out > 0; o++) {

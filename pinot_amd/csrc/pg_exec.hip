@@ -630,7 +630,10 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
   const bool has_docs = P.space_docs > 0;   // docs of the doc space the plan runs on (the segment's or a star-tree's)
   const bool hashed = D.agg_mode == PG_AGG_RADIX_HASH;
   const bool keep_table = (q.flags & PG_QUERY_FLAG_KEEP_DEVICE_TABLE) != 0;
-  if (keep_table && (hashed || P.first_doc_op >= 0))
+  // (a multi-value plan carries no first-docId accumulator: a key space that CAN exceed numGroupsLimit would be trimmed per segment by
+  // the reference and only after the merge here — so such tables never enter the element-wise merges: ADVICE r3)
+  const bool mv_beyond_limit = D.mv && q.n_group_by > 0 && (int64_t)D.n_groups > (int64_t)P.num_groups_limit;
+  if (keep_table && (hashed || P.first_doc_op >= 0 || mv_beyond_limit))
     fail(PG_ERR_UNSUPPORTED, "PG_QUERY_FLAG_KEEP_DEVICE_TABLE: %s has no dense table that merges element-wise (merge on the host by values)",
          hashed ? "a hashed key space" : "a key space beyond numGroupsLimit");
   std::unique_ptr<DeviceTable> kept;
@@ -986,6 +989,8 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
     if (exact_entries >= 0)   // the per-scan candidate counters of the kept table are superseded by the exact count
       PG_HIP(hipMemset(kept->table.as<int64_t>() + n_out + 1, 0, (PG_MAX_STATS - 1) * 8));
     kept->num_total_docs = seg.total_docs;
+    kept->sum_max_abs = P.sum_max_abs;
+    kept->has_digit_sums = P.has_digit_sums;
     res->dev = std::move(kept);
   }
   res->stats.host_ms_plan = (float)(t_plan - t0);
@@ -1302,11 +1307,11 @@ int64_t table_signature(const DeviceTable& T) {
 }
 // The plan-time guarantees of the accumulators hold per segment (docs x largest |value| < 2^63 for an int64 SUM; < 2^31 docs for
 // 32-bit digits summed in int64): a merged table must still satisfy them over the docs of all the segments it folds.
-void check_merge_bounds(const DeviceTable& T, int64_t total_docs) {
-  const CompiledPlan& P = *T.plan;
-  if (P.has_digit_sums && total_docs >= ((int64_t)1 << 31))
+// The bound is a property of the merged TABLE (largest per-doc magnitude over everything folded into it), not of one plan.
+void check_merge_bounds(uint64_t sum_max_abs, bool has_digit_sums, int64_t total_docs) {
+  if (has_digit_sums && total_docs >= ((int64_t)1 << 31))
     fail(PG_ERR_UNSUPPORTED, "merge: %lld docs in total overflow the digit accumulators of an exact SUM (merge on the host by values)", (long long)total_docs);
-  if (P.sum_max_abs && (unsigned __int128)P.sum_max_abs * (unsigned __int128)std::max<int64_t>(total_docs, 1) >= ((unsigned __int128)1 << 63))
+  if (sum_max_abs && (unsigned __int128)sum_max_abs * (unsigned __int128)std::max<int64_t>(total_docs, 1) >= ((unsigned __int128)1 << 63))
     fail(PG_ERR_UNSUPPORTED, "merge: a SUM over %lld docs in total may leave int64 (merge on the host by values)", (long long)total_docs);
 }
 void device_table_tail_store(DeviceTable& T, hipStream_t stream) {   // full-scan entries + total docs behind the statistics counters
@@ -1328,7 +1333,12 @@ void result_merge(Result& dst, Result& src) {
   if (A.device != B.device) fail(PG_ERR_INVALID_ARGUMENT, "pg_result_merge: results live on devices %d and %d (use pg_result_all_reduce across devices)", A.device, B.device);
   if (table_signature(A) != table_signature(B))
     fail(PG_ERR_UNSUPPORTED, "pg_result_merge: the two results do not share their table layout (different key space, dictionaries or aggregations): merge on the host by values");
-  check_merge_bounds(A, A.num_total_docs + B.num_total_docs);
+  // the larger of the two tables' per-doc magnitudes bounds the merged sums; the merged table keeps it for later merges
+  const uint64_t merged_max_abs = std::max(A.sum_max_abs, B.sum_max_abs);
+  const bool merged_digits = A.has_digit_sums || B.has_digit_sums;
+  check_merge_bounds(merged_max_abs, merged_digits, A.num_total_docs + B.num_total_docs);
+  A.sum_max_abs = merged_max_abs;
+  A.has_digit_sums = merged_digits;
   ThreadCtx& ctx = ctx_on(A.device);
   device_table_tail_store(A, ctx.stream);
   device_table_tail_store(B, ctx.stream);

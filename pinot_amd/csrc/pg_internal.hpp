@@ -336,6 +336,11 @@ struct DeviceTable {
   int64_t full_scan_entries = 0;   // summed over the merged segments
   int64_t num_total_docs = 0;
   int64_t tail_host[2] = {0, 0};   // source of the asynchronous copy of the two above behind the statistics counters
+  // overflow guards of the summed accumulators, carried by the TABLE (a merged table folds segments with different value ranges:
+  // the plan of its first segment no longer bounds what it holds): largest |value| an int64 SUM adds per doc over every segment
+  // folded in so far, and whether 32-bit digits are summed in int64 accumulators
+  uint64_t sum_max_abs = 0;
+  bool has_digit_sums = false;
 };
 struct Result {
   std::unique_ptr<DeviceTable> dev;    // PG_QUERY_FLAG_KEEP_DEVICE_TABLE
@@ -379,7 +384,7 @@ void result_all_reduce(Result& r, Comm& c);
 // shared by result_merge / result_all_reduce (pg_exec.hip): rebuild the host view of a result from its device table
 void result_reassemble(Result& r);
 int64_t table_signature(const DeviceTable& T);
-void check_merge_bounds(const DeviceTable& T, int64_t total_docs);
+void check_merge_bounds(uint64_t sum_max_abs, bool has_digit_sums, int64_t total_docs);
 void device_table_tail_store(DeviceTable& T, hipStream_t stream);
 void merge_sets_on_stream(uint32_t* dst, const uint32_t* gathered, int64_t n_words, int n_src, hipStream_t stream);
 hipStream_t thread_stream(int device);

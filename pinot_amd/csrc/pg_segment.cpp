@@ -365,6 +365,10 @@ void segment_add_column(Segment& seg, const pg_column_desc& d) {
     // The header only accelerates the reader's per-doc walk; here every doc's first entry is expanded once from the bitmap.
     if (c.bits < 1 || c.bits > 31) fail(PG_ERR_INVALID_ARGUMENT, "column %s: bits_per_value %d", d.name, c.bits);
     if (!c.has_dictionary || c.cardinality <= 0) fail(PG_ERR_UNSUPPORTED, "column %s: raw multi-value columns are outside the hot path", d.name);
+    // ForwardIndexReaderFactory.java:82-86 looks for FixedBitMVEntryDictForwardIndexReader's marker FIRST (the MV_ENTRY_DICT format:
+    // per-doc ids into a dictionary of distinct entry lists) — a different layout, left to the Java plan (refused, not misparsed)
+    if (fwd_len > 4 && be32(fwd) == 0xffabcdefu)
+      fail(PG_ERR_UNSUPPORTED, "column %s: MV_ENTRY_DICT forward index (FixedBitMVEntryDictForwardIndexReader) is outside the hot path", d.name);
     const int64_t num_docs = seg.total_docs, num_values = d.total_number_of_entries;
     if (num_docs <= 0 || num_values < num_docs) fail(PG_ERR_INVALID_ARGUMENT, "multi-value column %s: %lld entries over %lld docs", d.name, (long long)num_values, (long long)num_docs);
     const int64_t per_chunk = (int64_t)std::ceil((float)2048 / (float)(num_values / num_docs));   // the reader's integer division
