@@ -356,6 +356,25 @@ struct PgQueryPlan {
   int32_t mv_src_len[PG_MAX_SRCS];
   int32_t mv;                       // 1: the plan touches a multi-value column: pg_mv_query_* run it
   int32_t mv_pad;
+  // Oct-layout kernels (pg_kernels_oct.hip, round 4): <= 4 group columns of <= 8 bits, COUNT at most among the ops and ONE DISTINCTCOUNTHLL /
+  // DISTINCTCOUNT state.  oct = 1: the state lives in the workgroup's LDS (pg_oct_l*, the layout of pg_generic_query_l); oct = 2: pruned
+  // offers (pg_oct_p*): survivors of the group floors go to the tuple stream, the partition pipeline aggregates them pass by pass.
+  int32_t oct;
+  int32_t oct_src;                  // index into srcs of the state's column
+  int32_t oct_src_kind;             // 0 none; 1 bit-packed dictIds of an arithmetic INT dictionary (hashed from constants); 2 dictIds through
+                                    // the per-dictId (index | rank << 16) table; 3 raw INT values; 4 dictIds as they are (DISTINCTCOUNT)
+  int32_t oct_log2m;
+  uint32_t oct_c0, oct_c1;          // kind 1: (uint32) value x m = oct_c0 + dictId x oct_c1  (m = 0x5bd1e995, MurmurHash's multiplier)
+  int32_t oct_nonneg;               // kind 1: every dictionary value is >= 0 (the high word of (long) value hashes to nothing)
+  int32_t oct_base, oct_step;       // kind 1 otherwise: value = oct_base + oct_step x dictId
+  int32_t oct_t0, oct_t1;           // oct = 2: the wave tiles [t0, t1) of this pass
+  int32_t oct_pad;
+  const uint32_t* oct_lut;          // kind 2
+  const uint8_t* oct_floor;         // oct = 2: [n_groups] smallest register of every group so far (dword padded)
+  uint32_t* oct_counts;             // oct = 2: [grid][n_groups] 32-bit COUNT partials of this pass
+  uint32_t* oct_stream;             // oct = 2: survivor entries, key << (log2m + 5) | index | rank << log2m; PG_RADIX_INVALID_KEY = padding
+  uint32_t* oct_cursor;             // [0] entries claimed (blocks of 1 024), [1] overflow flag
+  int64_t oct_stream_cap;           // entries the stream holds
 };
 
 #if defined(__HIPCC__)

@@ -36,6 +36,12 @@ PG_DECL_FAST(pg_p2_scatter_1f) PG_DECL_FAST(pg_p2_scatter_2f) PG_DECL_FAST(pg_p2
 PG_DECL_FAST(pg_p2_aggregate_1) PG_DECL_FAST(pg_p2_aggregate_2) PG_DECL_FAST(pg_p2_aggregate_3) PG_DECL_FAST(pg_p2_aggregate_4)
 PG_DECL_FAST(pg_p2_aggregate_1n) PG_DECL_FAST(pg_p2_aggregate_2n) PG_DECL_FAST(pg_p2_aggregate_3n) PG_DECL_FAST(pg_p2_aggregate_4n)
 PG_DECL_FAST(pg_p2_index_count_kernel) PG_DECL_FAST(pg_p2_index_scan_kernel) PG_DECL_FAST(pg_p2_index_fill_kernel)
+PG_DECL_FAST(pg_p2_scatter_stream)
+// pg_kernels_oct.hip: oct-layout DISTINCTCOUNTHLL / DISTINCTCOUNT kernels (LDS-resident states; pruned offers) and their small helpers
+PG_DECL_FAST(pg_oct_l) PG_DECL_FAST(pg_oct_lm) PG_DECL_FAST(pg_oct_p) PG_DECL_FAST(pg_oct_pm)
+extern "C" __global__ void pg_oct_floor_kernel(const uint32_t* regs, uint8_t* floors, int n_groups, int log2m);
+extern "C" __global__ void pg_oct_merge_aux_kernel(const uint32_t* partials, uint32_t* out, int slices, int64_t bucket_words, int64_t n_words);
+extern "C" __global__ void pg_oct_reduce_counts_kernel(const uint32_t* counts, int64_t* out, int n_parts, int n_groups);
 extern "C" const int pg_p2_round_quads[5];   // pg_kernels_part.hip: quads per lane and round of the scatter kernel, by plane count
 extern "C" __global__ void pg_radix_offsets_kernel(uint32_t* hist, uint32_t* bucket_total, int n_wg, int n_buckets, int stage, int stage_waves);
 extern "C" __global__ void pg_radix_bucket_scan_kernel(const uint32_t* bucket_total, uint32_t* bucket_start, int n_buckets);
@@ -287,6 +293,7 @@ struct ThreadCtx {
   DeviceBuffer hll_small[17];  // per log2m: round(m * ln(m / zeros)), zeros = 0 .. m
   double hll_alpha_mm[17] = {0};
   DeviceBuffer p2_meta, p2_list, p2_ctrl;   // partition pipeline v2: chunk records, the same grouped by bucket, counters (PG_P2_CTRL_*)
+  DeviceBuffer oct_floor, oct_counts, oct_stream, oct_cursor;   // pruned-offer passes (pg_kernels_oct.hip)
   uint32_t* p2_ctrl_host = nullptr;   // page-locked copy of p2_ctrl
   bool stats_dirty = true;      // the stats counters may be non-zero (first use, or a query that failed midway)
   void* pinned = nullptr;       // page-locked staging for the result copy (pageable copies are staged synchronously)
@@ -502,6 +509,160 @@ std::shared_ptr<PinnedBlock> acquire_pinned(size_t bytes) {
   return b;
 }
 
+// ---- pruned-offer passes (pg_kernels_oct.hip, PgQueryPlan::oct == 2) ---------------------------------------------------------------------
+// GROUP BY over a key space whose 32-bit COUNTs fit LDS, with ONE DISTINCTCOUNTHLL whose registers do not (config 5 flat).  The doc space is
+// walked in passes of growing size; per pass: pg_oct_p (COUNT in LDS, offers that cannot raise a register of their group dropped, survivors
+// -> tuple stream) -> pg_p2_scatter_stream -> chunk index -> pg_p2_aggregate_1n (registers of a bucket of groups in LDS) ->
+// pg_oct_merge_aux_kernel (max into the registers of the passes before) -> pg_oct_floor_kernel (the groups' smallest registers: the next
+// pass's floors).  Everything is queued on the stream without a host round trip; areas are sized for "every offer of the pass survives".
+static std::vector<int> oct_pass_bounds(int n_wtiles) {
+  std::vector<double> frac;
+  if (const char* e = getenv("PG_OCT_PASSES")) {   // test / measurement knob: cumulative fractions, e.g. "0.02,0.08,0.3,1"
+    for (const char* c = e; *c;) {
+      char* end = nullptr;
+      const double v = strtod(c, &end);
+      if (end == c) break;
+      frac.push_back(v);
+      c = *end == ',' ? end + 1 : end;
+    }
+  }
+  if (frac.empty()) {
+    const int64_t docs = (int64_t)n_wtiles * PG_WAVE_DOCS;
+    if (docs >= ((int64_t)32 << 20)) frac = {0.02, 0.08, 0.30, 1.0};
+    else if (docs >= ((int64_t)4 << 20)) frac = {0.05, 0.25, 1.0};
+    else if (docs >= ((int64_t)1 << 18)) frac = {0.10, 1.0};
+    else frac = {1.0};
+  }
+  std::vector<int> b;
+  int prev = 0;
+  for (double f : frac) {
+    int t = (int)std::llround(f * n_wtiles);
+    t = std::max(prev + 1, std::min(t, n_wtiles));
+    if (t > n_wtiles) break;
+    b.push_back(t);
+    prev = t;
+    if (t == n_wtiles) break;
+  }
+  if (b.empty() || b.back() != n_wtiles) b.push_back(n_wtiles);
+  return b;
+}
+
+static void run_oct_pruned(CompiledPlan& P, PgQueryPlan& D, ThreadCtx& ctx, const CancelToken* cancel, const std::vector<uint32_t*>& aux_final, int64_t n_out) {
+  const size_t G = (size_t)D.n_groups, G_pad = (G + 3) & ~(size_t)3;
+  const int NB = D.radix_buckets, Q = pg_p2_round_quads[1];
+  D.match_words = nullptr;
+  if (!P.match_all) {   // the filter's match words first (one launch, no host round trip: nothing here is sized by the match count)
+    ThreadCtx::grow(ctx.words, (size_t)D.n_wtiles * 64 * 4);
+    PgQueryPlan F = D;
+    F.agg_mode = PG_AGG_NONE;
+    F.out_words = ctx.words.as<uint64_t>();
+    const char* fname = "";
+    const LaunchShape fshape = launch_shape(P, D.n_wtiles, PG_AGG_NONE);
+    hipLaunchKernelGGL(select_kernel(P, PG_AGG_NONE, &fname), dim3(fshape.grid), dim3(fshape.block), fshape.lds, ctx.stream, F);
+    PG_HIP(hipGetLastError());
+    D.match_words = ctx.words.as<uint32_t>();
+  }
+  const std::vector<int> bounds = oct_pass_bounds(D.n_wtiles);
+  const int n_pass = (int)bounds.size();
+  int max_tiles = 0;
+  for (int i = 0, prev = 0; i < n_pass; prev = bounds[(size_t)i], i++) max_tiles = std::max(max_tiles, bounds[(size_t)i] - prev);
+  const int ogrid_max = std::max(1, std::min((max_tiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, num_cus()));
+  // the survivor stream: every doc of the largest pass + one partly filled block per wavefront
+  const size_t stream_cap = (size_t)max_tiles * PG_WAVE_DOCS + ((size_t)ogrid_max * PG_WAVES_PER_BLOCK + 2) * 1024;
+  if (stream_cap >= ((size_t)1 << 32)) fail(PG_ERR_UNSUPPORTED, "pruned-offer pass of %zu entries", stream_cap);
+  ThreadCtx::grow(ctx.oct_stream, stream_cap * 4 + 256);
+  ThreadCtx::grow(ctx.oct_floor, G_pad + 256);
+  ThreadCtx::grow(ctx.oct_counts, (size_t)n_pass * (size_t)ogrid_max * G * 4 + 256);
+  if (!ctx.oct_cursor.ptr) ctx.oct_cursor.alloc(256, true);
+  PG_HIP(hipMemsetAsync(ctx.oct_floor.ptr, 0, G_pad, ctx.stream));
+  // the registers accumulate over the passes (max): they start from zero
+  const size_t aux_bytes = P.aux_bytes[0];
+  PG_HIP(hipMemsetAsync(aux_final[0], 0, aux_bytes, ctx.stream));
+  // partition pipeline areas for the largest pass
+  const size_t round_tuples = (size_t)PG_P2_WAVES * (size_t)Q * 256;
+  const size_t s_lds = ((size_t)6 * PG_P2_MAX_BUCKETS + PG_P2_POOL + 8 + 2 * (round_tuples / PG_P2_LINE + (size_t)NB + 1) + round_tuples + (size_t)NB * PG_P2_LINE) * 4;
+  static const int p2_wgs = getenv("PG_P2_WGS_PER_CU") ? atoi(getenv("PG_P2_WGS_PER_CU")) : 4;
+  const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(p2_wgs, 1), (lds_per_cu() - 1024) / (s_lds + 512)));
+  const int sgrid_max = num_cus() * per_cu;
+  const size_t cap = stream_cap / PG_P2_CHUNK + 1 + (size_t)sgrid_max * (2 * (size_t)NB + PG_P2_BATCH) + 64;
+  if (cap >= ((size_t)1 << 27)) fail(PG_ERR_UNSUPPORTED, "partition pipeline: %zu chunks", cap);
+  D.p2_capacity = (int32_t)cap;
+  D.p2_plane_stride = (int64_t)(cap + 1) * PG_P2_CHUNK;
+  ThreadCtx::grow(ctx.radix_tuples, (size_t)D.p2_plane_stride * 4 + 256);
+  ThreadCtx::grow(ctx.p2_meta, cap * 4 + 64);
+  ThreadCtx::grow(ctx.p2_list, cap * 4 + 64);
+  if (!ctx.p2_ctrl.ptr) ctx.p2_ctrl.alloc((size_t)PG_P2_CTRL_DWORDS * 4, true);
+  if (!ctx.p2_ctrl_host) PG_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx.p2_ctrl_host), 256, hipHostMallocDefault));
+  memset(ctx.p2_ctrl_host, 0, 256);
+  D.p2_tuples = ctx.radix_tuples.as<uint32_t>();
+  D.p2_meta = ctx.p2_meta.as<uint32_t>();
+  D.p2_list = ctx.p2_list.as<uint32_t>();
+  D.p2_ctrl = ctx.p2_ctrl.as<uint32_t>();
+  D.oct_floor = ctx.oct_floor.as<uint8_t>();
+  D.oct_stream = ctx.oct_stream.as<uint32_t>();
+  D.oct_cursor = ctx.oct_cursor.as<uint32_t>();
+  D.oct_stream_cap = (int64_t)stream_cap;
+  const int slices_max = std::max(D.radix_slices, 1);   // what the partial register areas were sized for
+  const size_t slots = (size_t)1 << D.radix_shift;
+  const size_t o_lds = G * 4 + G_pad + 64;
+  int parts = 0;   // per-workgroup COUNT partials written so far
+  for (int pass = 0, t0 = 0; pass < n_pass; t0 = bounds[(size_t)pass], pass++) {
+    check_cancel(cancel, &ctx);
+    const int t1 = bounds[(size_t)pass], tiles = t1 - t0;
+    const int ogrid = std::max(1, std::min((tiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, num_cus()));
+    PG_HIP(hipMemsetAsync(ctx.oct_cursor.ptr, 0, 8, ctx.stream));
+    PgQueryPlan O = D;
+    O.oct_t0 = t0;
+    O.oct_t1 = t1;
+    O.oct_counts = ctx.oct_counts.as<uint32_t>() + (size_t)parts * G;
+    hipLaunchKernelGGL(D.match_words ? pg_oct_pm : pg_oct_p, dim3(ogrid), dim3(PG_BLOCK), o_lds, ctx.stream, O);
+    PG_HIP(hipGetLastError());
+    parts += ogrid;
+    // the survivors through the partition pipeline (sized for all of the pass's docs; the stream's true length is read on the device)
+    const size_t pass_entries = (size_t)tiles * PG_WAVE_DOCS + ((size_t)ogrid * PG_WAVES_PER_BLOCK + 2) * 1024;
+    const size_t pass_cap = std::min(cap, pass_entries / PG_P2_CHUNK + 1 + (size_t)sgrid_max * (2 * (size_t)NB + PG_P2_BATCH) + 64);
+    PG_HIP(hipMemsetAsync(ctx.p2_meta.ptr, 0xFF, pass_cap * 4, ctx.stream));
+    PG_HIP(hipMemsetAsync(ctx.p2_ctrl.ptr, 0, (size_t)PG_P2_CTRL_DWORDS * 4, ctx.stream));
+    PgQueryPlan S = O;
+    S.match_words = nullptr;
+    S.n_ops = 0;   // COUNT is pg_oct_p's: the aggregation pass sees HyperLogLog offers only
+    S.p2_capacity = (int32_t)pass_cap;
+    // later passes keep a fraction of their offers (floors): fewer scatter workgroups and aggregation slices for them
+    const double keep = pass == 0 ? 1.0 : (pass == 1 ? 0.75 : 0.25);
+    const size_t est = (size_t)((double)tiles * PG_WAVE_DOCS * keep) + 1;
+    const int quartets = (int)((pass_entries / PG_WAVE_DOCS + PG_P2_WAVES) / PG_P2_WAVES);
+    const int sgrid = std::max(1, std::min(std::min(quartets, sgrid_max), (int)(est / (round_tuples * 2)) + 1));
+    S.radix_slices = (int)std::max<size_t>(1, std::min<size_t>((size_t)slices_max, est / ((size_t)NB * 65536)));
+    hipLaunchKernelGGL(pg_p2_scatter_stream, dim3(sgrid), dim3(PG_P2_WAVES * 64), s_lds, ctx.stream, S);
+    PG_HIP(hipGetLastError());
+    const int igrid = (int)std::max<size_t>(1, std::min<size_t>((size_t)num_cus(), (pass_cap + 4095) / 4096));
+    hipLaunchKernelGGL(pg_p2_index_count_kernel, dim3(igrid), dim3(1024), 0, ctx.stream, S);
+    hipLaunchKernelGGL(pg_p2_index_scan_kernel, dim3(1), dim3(PG_P2_MAX_BUCKETS), 0, ctx.stream, S);
+    hipLaunchKernelGGL(pg_p2_index_fill_kernel, dim3(igrid), dim3(1024), 0, ctx.stream, S);
+    PG_HIP(hipGetLastError());
+    const int agrid = std::min(NB * S.radix_slices, num_cus());
+    hipLaunchKernelGGL(pg_p2_aggregate_1n, dim3(agrid), dim3(PG_P2_AGG_THREADS), P.lds_bytes + 64, ctx.stream, S);
+    PG_HIP(hipGetLastError());
+    const int64_t n_words = (int64_t)G * D.aux[0].stride / 4, bucket_words = (int64_t)(slots * (size_t)D.aux[0].stride / 4);
+    hipLaunchKernelGGL(pg_oct_merge_aux_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx.stream, S.aux[0].base, aux_final[0],
+                       S.radix_slices, bucket_words, n_words);
+    if (pass + 1 < n_pass)
+      hipLaunchKernelGGL(pg_oct_floor_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, ctx.stream, aux_final[0], ctx.oct_floor.as<uint8_t>(), (int)G,
+                         D.aux[0].log2m);
+    PG_HIP(hipGetLastError());
+    // error flags of this pass: p2_ctrl {chunks claimed, out of chunks}, cursor {entries, stream overflow}
+    PG_HIP(hipMemcpyAsync(ctx.p2_ctrl_host + 4 + 4 * std::min(pass, 14), ctx.p2_ctrl.ptr, 8, hipMemcpyDeviceToHost, ctx.stream));
+    PG_HIP(hipMemcpyAsync(ctx.p2_ctrl_host + 6 + 4 * std::min(pass, 14), ctx.oct_cursor.ptr, 8, hipMemcpyDeviceToHost, ctx.stream));
+  }
+  // COUNT row of the table = the passes' per-workgroup counters (the plan has at most this one accumulator)
+  if (D.n_ops == 1) {
+    hipLaunchKernelGGL(pg_oct_reduce_counts_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, ctx.stream, ctx.oct_counts.as<uint32_t>(),
+                       ctx.final_table.as<int64_t>(), parts, (int)G);
+    PG_HIP(hipGetLastError());
+  }
+  (void)n_out;
+}
+
 std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const CancelToken* cancel) {
   const double t0 = now_ms();
   if (q.n_aggregations <= 0 || !q.aggregations) fail(PG_ERR_INVALID_ARGUMENT, "query has no aggregation");
@@ -565,8 +726,13 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
     if (!no_split && table_mode && D.n_aux > 0 && !uses_fast_kernel(P, D.agg_mode))
       while (split_shift < 5 && ((int64_t)std::max(P.dev.n_wtiles, 1) << (split_shift + 1)) <= 4096) split_shift++;
   }
+  // oct-layout kernels (pg_kernels_oct.hip): one 16-wavefront workgroup per CU, no tile splitting
+  static const bool no_oct = getenv("PG_NO_OCT_EXEC") != nullptr;   // measurement knob: plans keep D.oct, the round-3 kernels run them
+  const bool oct_lds = D.oct == 1 && !no_oct, oct_pruned = D.oct == 2 && !no_oct && D.agg_mode == PG_AGG_RADIX && D.p2;
+  if (oct_lds) split_shift = 0;
   D.tile_split_shift = split_shift;
-  const LaunchShape shape = launch_shape(P, P.dev.n_wtiles << split_shift, D.agg_mode);
+  LaunchShape shape = launch_shape(P, P.dev.n_wtiles << split_shift, D.agg_mode);
+  if (oct_lds) shape = {std::max(1, std::min((P.dev.n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, num_cus())), PG_BLOCK, P.lds_bytes + 64};
   const int64_t n_out = (int64_t)D.n_ops * D.n_groups;
   // The stats counters are zero on entry: the reduce kernel of the previous query on this stream re-zeroes them after
   // moving them behind the result table (one device→host copy per query).
@@ -640,7 +806,11 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
   const bool radix = D.agg_mode == PG_AGG_RADIX || hashed;
   int64_t hash_groups = 0;
   bool p2_ran = false;
-  if (has_docs && radix && D.p2) {
+  if (has_docs && oct_pruned) {
+    kname = "pg_oct_pruned_group_by";
+    p2_ran = true;
+    run_oct_pruned(P, D, ctx, cancel, aux_final, n_out);
+  } else if (has_docs && radix && D.p2) {
     // ---- partition pipeline v2 (pg_kernels_part.hip): [filter → match words;] ONE scatter pass into chunked per-bucket streams of
     //      bit-packed tuples; per-bucket LDS aggregation; merge of the slices ------------------------------------------------------------
     kname = "pg_part_group_by";
@@ -682,7 +852,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
     ThreadCtx::grow(ctx.p2_meta, cap * 4 + 64);
     ThreadCtx::grow(ctx.p2_list, cap * 4 + 64);
     if (!ctx.p2_ctrl.ptr) ctx.p2_ctrl.alloc((size_t)PG_P2_CTRL_DWORDS * 4, true);
-    if (!ctx.p2_ctrl_host) PG_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx.p2_ctrl_host), 64, hipHostMallocDefault));
+    if (!ctx.p2_ctrl_host) PG_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx.p2_ctrl_host), 256, hipHostMallocDefault));
     PG_HIP(hipMemsetAsync(ctx.p2_meta.ptr, 0xFF, cap * 4, ctx.stream));
     PG_HIP(hipMemsetAsync(ctx.p2_ctrl.ptr, 0, (size_t)PG_P2_CTRL_DWORDS * 4, ctx.stream));
     D.p2_tuples = ctx.radix_tuples.as<uint32_t>();
@@ -833,6 +1003,23 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
                          ctx.final_table.as<int64_t>(), D.n_ops, D.n_groups, D.radix_shift, D.radix_slices, P.ops_dev.as<PgAccOp>());
       PG_HIP(hipGetLastError());
     }
+  } else if (has_docs && oct_lds) {
+    // ---- LDS-resident DISTINCTCOUNTHLL / DISTINCTCOUNT next to a small key (pg_kernels_oct.hip): [filter -> match words;] one pass ----
+    D.match_words = nullptr;
+    if (!P.match_all) {
+      ThreadCtx::grow(ctx.words, (size_t)D.n_wtiles * 64 * 4);
+      PgQueryPlan F = D;
+      F.agg_mode = PG_AGG_NONE;
+      F.out_words = ctx.words.as<uint64_t>();
+      const char* fname = "";
+      const LaunchShape fshape = launch_shape(P, D.n_wtiles, PG_AGG_NONE);
+      hipLaunchKernelGGL(select_kernel(P, PG_AGG_NONE, &fname), dim3(fshape.grid), dim3(fshape.block), fshape.lds, ctx.stream, F);
+      PG_HIP(hipGetLastError());
+      D.match_words = ctx.words.as<uint32_t>();
+    }
+    kname = D.match_words ? "pg_oct_lm" : "pg_oct_l";
+    hipLaunchKernelGGL(D.match_words ? pg_oct_lm : pg_oct_l, dim3(shape.grid), dim3(shape.block), shape.lds, ctx.stream, D);
+    PG_HIP(hipGetLastError());
   } else if (has_docs) {
     QueryKernel kern = select_kernel(P, D.agg_mode, &kname);
     hipLaunchKernelGGL(kern, dim3(shape.grid), dim3(shape.block), shape.lds, ctx.stream, D);
@@ -901,6 +1088,11 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
     ctx.stats_dirty = false;    // the reduce kernel left them zero
     if (p2_ran && ctx.p2_ctrl_host[1])
       fail(PG_ERR_INTERNAL, "partition pipeline ran out of chunks (%u claimed, %d sized)", ctx.p2_ctrl_host[0], D.p2_capacity);
+    if (oct_pruned)
+      for (int k = 0; k < 15; k++) {
+        const uint32_t* f = ctx.p2_ctrl_host + 4 + 4 * k;
+        if (f[1] || f[3]) fail(PG_ERR_INTERNAL, "pruned-offer pass %d: %s (%u chunks, %u stream entries)", k, f[1] ? "out of chunks" : "survivor stream overflow", f[0], f[2]);
+      }
     if (hashed) {
       // the occupied slots of every bucket's hash table: raw keys + [n_ops][groups] accumulators → a compact table
       unsigned long long cnt[2] = {0, 0};

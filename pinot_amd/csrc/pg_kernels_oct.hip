@@ -1,0 +1,525 @@
+// "Oct layout" kernels — DISTINCTCOUNTHLL / DISTINCTCOUNT next to a small group key, VALU-lean (round 4).
+//
+// Reference work: DistinctCountHLLAggregationFunction#aggregateGroupBySV (core/query/aggregation/function/
+// DistinctCountHLLAggregationFunction.java:152-222: hll.offer(value) per doc into the group's HyperLogLog), BaseDistinctAggregate-
+// AggregationFunction's dictId bitmaps (:306-345), CountAggregationFunction#aggregateGroupBySV (:110-143) and the raw keys of
+// DictionaryBasedGroupKeyGenerator (:312-354, key = sum dictId_j x prod card_i) over <= 8-bit dictionary columns.
+//
+// Why another kernel family.  These shapes move few bytes per doc (config 5: 4.375 B) and are bound by instruction issue, not by HBM
+// (profiles/r03_n_sq_counters_cfg5_200m.txt: 121 VALU per doc in the partition scatter; the interpreter spends 1.9 k VALU per wave tile
+// visit on `hll(u) GROUP BY h1`).  The quad layout of the other kernels (lane L owns quads k*64+L of 4 docs) makes a lane fetch a 64-bit
+// window and run a 64-bit shift for FOUR values of a 4-bit column.  Here lane L owns the 8 CONSECUTIVE docs 8L .. 8L+7 of a 512-doc
+// sub-tile: 8 values of a b-bit column are exactly b bytes at byte offset b x L — for b = 4 one dword per lane and 8 bit-field
+// extracts, for any width one byte permute (v_perm_b32: alignment + endianness in one instruction, its selector a per-lane constant)
+// per dword and compile-time field positions after it.  A wave tile (2 048 docs, the unit of match words and tile padding) is four
+// sub-tiles; two sub-tiles' loads are in flight per wavefront.
+//
+// The hash.  stream-lib's MurmurHash.hashLong of an INT value v is  h = k x m^2 ^ C;  h ^= h >>> 13;  h *= m;  h ^= h >>> 15  with
+// k = (v x m) ^ ((v x m) >>> 24) and C a constant of the sign of v.  For an arithmetic dictionary (value = base + step x dictId, found at
+// registration) v x m = base x m + dictId x (step x m) is two full-rate 24-bit multiply-adds of constants; two 32-bit multiplies
+// (quarter rate) remain.
+//
+// Two back ends:
+//   pg_oct_l / _lm   states fit the workgroup's LDS (planner: CompiledPlan::aux_in_lds, e.g. 160 groups x 256 one-byte registers):
+//                    a register is read first and compare-and-swapped only when the offer would raise it; DISTINCTCOUNT sets take
+//                    ds_or_b32; COUNT the low dword of its int64 slot.  Same LDS layout, partial areas and merge kernels as
+//                    pg_generic_query_l, which ran these plans before (5.6 % of the roofline).
+//   pg_oct_p / _pm   key space fits LDS but the registers do not (config 5 flat: 12 800 groups x 256 registers = 3.2 MB): PRUNED OFFERS.
+//                    A HyperLogLog register only ever grows, so an offer (group, index, rank) with rank <= floor[group] — the smallest
+//                    register of the group after the docs aggregated so far — cannot change anything and is dropped on the spot; only
+//                    the survivors travel through the partition pipeline (pg_kernels_part.hip).  The segment is walked in a few
+//                    passes of growing size (2 %, 6 %, 22 %, 70 % of the docs); after each pass the registers are merged and the
+//                    floors recomputed, so later passes drop ~82 % / ~95 % of their offers (13.7 % of all offers survive for uniformly
+//                    distributed values; a group whose values are few keeps floor 0 and loses nothing but speed).  COUNT needs every
+//                    doc and is kept in an LDS table of 32-bit counters by this kernel, flushed once per pass.
+//                    Survivors are appended to a tuple stream in HBM (key << payload bits | index | rank << log2m) in blocks of 1 024
+//                    entries claimed per wavefront with one global atomic; the stream is the input of pg_p2_scatter_stream.
+#define PG_KERNEL template <int PG_NOT_INSTANTIATED> static
+#include "pg_kernels.hip"
+
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+typedef u32x3 u32x3_a4 __attribute__((aligned(4)));
+typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
+
+#define OCT_SUB_DOCS 512          // docs per sub-tile: 64 lanes x 8
+#define OCT_SUBS_PER_WTILE 4
+#define OCT_STREAM_BLOCK 1024     // entries a wavefront claims per global atomic
+
+// byte permute: result byte i = byte sel[i] of the 8 bytes {hi (4..7), lo (0..3)}
+DEVFN uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+DEVFN uint32_t bfe(uint32_t x, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(x, off, width); }
+DEVFN uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+DEVFN uint32_t mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
+DEVFN uint32_t mad24(uint32_t a, uint32_t b, uint32_t c) { return __umul24(a, b) + c; }
+
+// selector that turns the little-endian dword pair {w[k+1], w[k]} into the big-endian dword starting at byte `bs` of w[k]
+DEVFN uint32_t oct_selector(uint32_t bs) { return (bs << 24) | ((bs + 1u) << 16) | ((bs + 2u) << 8) | (bs + 3u); }
+
+// The 8 values of a B-bit column whose lane window starts at the most significant bit of n[0] (big-endian dwords)
+template <int B, int ND>
+DEVFN void oct_fields(const uint32_t (&n)[ND], uint32_t (&out)[8]) {
+  constexpr uint32_t mask = B >= 32 ? 0xFFFFFFFFu : ((1u << B) - 1u);
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int p = i * B, k = p >> 5, o = p & 31;
+    if (o + B <= 32) out[i] = bfe(n[k], (uint32_t)(32 - o - B), (uint32_t)B);
+    else out[i] = alignbit(n[k], n[k + 1 < ND ? k + 1 : k], (uint32_t)(64 - o - B)) & mask;
+  }
+}
+// group column (<= 8 bits): raw = the 3 dwords from the lane's dword-aligned window start
+template <int B>
+DEVFN void oct_decode_small(const u32x3 raw, uint32_t sel, uint32_t (&out)[8]) {
+  if (B <= 4) {
+    uint32_t n[1] = {perm(raw.y, raw.x, sel)};
+    oct_fields<B, 1>(n, out);
+  } else {
+    uint32_t n[2] = {perm(raw.y, raw.x, sel), perm(raw.z, raw.y, sel)};
+    oct_fields<B, 2>(n, out);
+  }
+}
+DEVFN void oct_decode_group(int bits, const u32x3 raw, uint32_t sel, uint32_t (&out)[8]) {
+  switch (bits) {   // wave-uniform
+    case 1: oct_decode_small<1>(raw, sel, out); break;
+    case 2: oct_decode_small<2>(raw, sel, out); break;
+    case 3: oct_decode_small<3>(raw, sel, out); break;
+    case 4: oct_decode_small<4>(raw, sel, out); break;
+    case 5: oct_decode_small<5>(raw, sel, out); break;
+    case 6: oct_decode_small<6>(raw, sel, out); break;
+    case 7: oct_decode_small<7>(raw, sel, out); break;
+    default: oct_decode_small<8>(raw, sel, out); break;
+  }
+}
+// source column (<= 24 bits): raw = 8 dwords from the lane's dword-aligned window start (8 x 24 bits + 3 bytes of misalignment = 27 bytes)
+template <int B>
+DEVFN void oct_decode_wide(const u32x4 a, const u32x4 b, uint32_t sel, uint32_t (&out)[8]) {
+  constexpr int ND = (8 * B + 31) / 32;   // big-endian dwords the 8 fields span
+  const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  uint32_t n[ND];
+#pragma unroll
+  for (int k = 0; k < ND; k++) n[k] = perm(w[k + 1 < 8 ? k + 1 : k], w[k], sel);
+  oct_fields<B, ND>(n, out);
+}
+DEVFN void oct_decode_source(int bits, const u32x4 a, const u32x4 b, uint32_t sel, uint32_t (&out)[8]) {
+  switch (bits) {   // wave-uniform
+#define OCT_CASE(B) case B: oct_decode_wide<B>(a, b, sel, out); break;
+    OCT_CASE(1) OCT_CASE(2) OCT_CASE(3) OCT_CASE(4) OCT_CASE(5) OCT_CASE(6) OCT_CASE(7) OCT_CASE(8) OCT_CASE(9) OCT_CASE(10) OCT_CASE(11)
+    OCT_CASE(12) OCT_CASE(13) OCT_CASE(14) OCT_CASE(15) OCT_CASE(16) OCT_CASE(17) OCT_CASE(18) OCT_CASE(19) OCT_CASE(20) OCT_CASE(21)
+    OCT_CASE(22) OCT_CASE(23)
+#undef OCT_CASE
+    default: oct_decode_wide<24>(a, b, sel, out); break;
+  }
+}
+
+// source kinds (PgQueryPlan::oct_src_kind)
+enum { OCT_SRC_NONE = 0, OCT_SRC_AFFINE = 1, OCT_SRC_LUT = 2, OCT_SRC_RAW32 = 3, OCT_SRC_DICTID = 4 };
+
+// tail of stream-lib MurmurHash.hashLong for an INT value whose first product k0 = (uint32) v x m is given; sign = v < 0
+DEVFN uint32_t oct_murmur_tail(uint32_t k0, uint32_t c_sign) {
+  constexpr uint32_t m = 0x5bd1e995u, m2 = m * m;
+  uint32_t k = k0 ^ (k0 >> 24);
+  uint32_t h = k * m2;
+  h ^= c_sign;
+  h ^= h >> 13;
+  h *= m;
+  h ^= h >> 15;
+  return h;
+}
+DEVFN constexpr uint32_t oct_hi_neg() {   // contribution of a high word of all ones: ((0xFFFFFFFF x m) ^ (… >>> 24)) x m
+  constexpr uint32_t m = 0x5bd1e995u, km = 0u - m;
+  return (km ^ (km >> 24)) * m;
+}
+
+struct OctRaw {
+  u32x3 g[4];     // group columns: 3 dwords from the lane's window start
+  u32x4 s0, s1;   // the source: 8 dwords from its window start, or the 8 raw 32-bit values
+  uint32_t mw;    // match word holding the lane's 8 mask bits (MASKED)
+};
+
+struct OctLane {   // per-lane constants of the columns
+  uint32_t goff[4], gsel[4];   // byte offset (dword aligned) of the lane's window inside a sub-tile, permute selector
+  uint32_t soff, ssel;
+};
+
+template <bool MASKED>
+DEVFN void oct_issue(const PgQueryPlan& p, const OctLane& ln, int wt, int sub, int lane, OctRaw& raw) {
+#pragma unroll
+  for (int g = 0; g < 4; g++)
+    if (g < p.n_group_cols) {
+      const PgGroupCol& gc = p.gcols[g];
+      const GAS uint8_t* base = gptr<uint8_t>(gc.data) + (size_t)wt * (size_t)(PG_WAVE_DOCS / 8) * (size_t)gc.bits + (size_t)sub * (size_t)(OCT_SUB_DOCS / 8) * (size_t)gc.bits;
+      raw.g[g] = ldnt((const GAS u32x3_a4*)(base + ln.goff[g]));
+    }
+  if (p.oct_src_kind != OCT_SRC_NONE) {
+    const PgValueSrc& V = p.srcs[p.oct_src];
+    const uint32_t bits = p.oct_src_kind == OCT_SRC_RAW32 ? 32u : (uint32_t)V.bits;
+    const GAS uint8_t* base = gptr<uint8_t>(V.data) + (size_t)wt * (size_t)(PG_WAVE_DOCS / 8) * (size_t)bits + (size_t)sub * (size_t)(OCT_SUB_DOCS / 8) * (size_t)bits;
+    const GAS u32x4_a4* q = (const GAS u32x4_a4*)(base + ln.soff);
+    raw.s0 = ldnt(q);
+    raw.s1 = ldnt(q + 1);
+  }
+  if (MASKED) raw.mw = gptr<uint32_t>(p.match_words)[(size_t)wt * 64 + (size_t)sub * 16 + (size_t)(lane >> 2)];
+}
+
+// keys and per-doc source items (HyperLogLog: index | rank << log2m; DISTINCTCOUNT: the dictId) of the lane's 8 docs
+DEVFN void oct_decode(const PgQueryPlan& p, const OctLane& ln, const OctRaw& raw, uint32_t (&key)[8], uint32_t (&item)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; j++) key[j] = 0;
+#pragma unroll
+  for (int g = 0; g < 4; g++)
+    if (g < p.n_group_cols) {
+      uint32_t v[8];
+      oct_decode_group(p.gcols[g].bits, raw.g[g], ln.gsel[g], v);
+      if (g == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) key[j] = v[j];   // mult of column 0 is 1
+      } else {
+        const uint32_t mult = (uint32_t)p.gcols[g].mult;
+#pragma unroll
+        for (int j = 0; j < 8; j++) key[j] = mad24(v[j], mult, key[j]);   // dictId < 2^8, mult < 2^24 (planner)
+      }
+    }
+  const int kind = p.oct_src_kind;
+  if (kind == OCT_SRC_NONE) return;
+  uint32_t id[8];
+  if (kind == OCT_SRC_RAW32) {
+    const uint32_t w[8] = {raw.s0.x, raw.s0.y, raw.s0.z, raw.s0.w, raw.s1.x, raw.s1.y, raw.s1.z, raw.s1.w};
+#pragma unroll
+    for (int j = 0; j < 8; j++) id[j] = bswap32(w[j]);
+  } else {
+    oct_decode_source(p.srcs[p.oct_src].bits, raw.s0, raw.s1, ln.ssel, id);
+  }
+  if (kind == OCT_SRC_DICTID) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) item[j] = id[j];
+    return;
+  }
+  const uint32_t log2m = (uint32_t)p.oct_log2m;
+  if (kind == OCT_SRC_LUT) {   // any dictionary: (index | rank << 16) per dictId, computed on the host at plan time; gathers first
+    uint32_t ir[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) ir[j] = gptr<uint32_t>(p.oct_lut)[id[j]];
+#pragma unroll
+    for (int j = 0; j < 8; j++) item[j] = (ir[j] & 0xFFFFu) | ((ir[j] >> 16) << log2m);
+    return;
+  }
+  uint32_t h[8];
+  if (kind == OCT_SRC_AFFINE) {
+    const uint32_t c0 = p.oct_c0, c1lo = p.oct_c1 & 0xFFFFFFu, c1hi = p.oct_c1 >> 24;
+    if (p.oct_nonneg) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) h[j] = oct_murmur_tail(mad24(id[j], c1lo, c0) + (mul24(id[j], c1hi) << 24), 0u);
+    } else {
+      const uint32_t base = (uint32_t)p.oct_base, step = (uint32_t)p.oct_step;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int32_t v = (int32_t)mad24(id[j], step, base);
+        h[j] = oct_murmur_tail(mad24(id[j], c1lo, c0) + (mul24(id[j], c1hi) << 24), (uint32_t)(v >> 31) & oct_hi_neg());
+      }
+    }
+  } else {   // raw INT values: hll.offer(Integer) = hashLong((long) v)
+#pragma unroll
+    for (int j = 0; j < 8; j++) h[j] = oct_murmur_tail(id[j] * 0x5bd1e995u, (uint32_t)((int32_t)id[j] >> 31) & oct_hi_neg());
+  }
+  const uint32_t tail = (1u << (log2m - 1u)) + 1u;
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const uint32_t idx = h[j] >> (32u - log2m);
+    const uint32_t w = (h[j] << log2m) | tail;
+    item[j] = idx | ((uint32_t)(__clz((int)w) + 1) << log2m);
+  }
+}
+
+DEVFN uint32_t oct_mask8(const PgQueryPlan& p, int wt, int sub, int lane, uint32_t mw, bool masked) {
+  const int64_t first = (int64_t)wt * PG_WAVE_DOCS + (int64_t)sub * OCT_SUB_DOCS + 8 * lane;
+  const int64_t rem = (int64_t)p.num_docs - first;
+  uint32_t m = rem >= 8 ? 0xFFu : (rem <= 0 ? 0u : ((1u << (uint32_t)rem) - 1u));
+  if (masked) m &= mw >> (8u * ((uint32_t)lane & 3u));
+  return m;
+}
+
+DEVFN void oct_lane_setup(const PgQueryPlan& p, int lane, OctLane& ln) {
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    ln.goff[g] = 0;
+    ln.gsel[g] = oct_selector(0);
+    if (g < p.n_group_cols) {
+      const uint32_t bo = (uint32_t)lane * (uint32_t)p.gcols[g].bits;
+      ln.goff[g] = bo & ~3u;
+      ln.gsel[g] = oct_selector(bo & 3u);
+    }
+  }
+  ln.soff = 0;
+  ln.ssel = oct_selector(0);
+  if (p.oct_src_kind != OCT_SRC_NONE) {
+    const uint32_t bits = p.oct_src_kind == OCT_SRC_RAW32 ? 32u : (uint32_t)p.srcs[p.oct_src].bits;
+    const uint32_t bo = (uint32_t)lane * bits;
+    ln.soff = bo & ~3u;
+    ln.ssel = oct_selector(bo & 3u);
+  }
+}
+
+// one HyperLogLog register (a byte in LDS) raised to `rank`
+DEVFN void oct_raise_register(uint32_t* lds_words, uint32_t byte_addr, uint32_t rank) {
+  uint32_t* w = lds_words + (byte_addr >> 2);
+  const uint32_t sh = (byte_addr & 3u) * 8u;
+  uint32_t cur = *reinterpret_cast<volatile uint32_t*>(w);
+  while (((cur >> sh) & 0xFFu) < rank) {
+    const uint32_t nv = (cur & ~(0xFFu << sh)) | (rank << sh);
+    const uint32_t prev = atomicCAS(w, cur, nv);
+    if (prev == cur) break;
+    cur = prev;
+  }
+}
+
+// ---- back end L: the states live in this workgroup's LDS ---------------------------------------------------------------------------
+DEVFN void oct_apply_lds(const PgQueryPlan& p, uint32_t m8, const uint32_t (&key)[8], const uint32_t (&item)[8], int64_t* table, uint32_t* aux_words,
+                         uint32_t rep) {
+  const uint32_t rshift = (uint32_t)p.replica_shift;
+  if (p.n_ops > 0) {   // COUNT: the low dword of the int64 slot takes the add (a workgroup sees < 2^31 docs)
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if ((m8 >> j) & 1u) atomicAdd(reinterpret_cast<uint32_t*>(table + (((size_t)key[j] << rshift) + rep)), 1u);
+  }
+  if (p.n_aux == 0) return;
+  const uint32_t stride = (uint32_t)p.aux[0].stride;
+  if (p.oct_src_kind == OCT_SRC_DICTID) {   // DISTINCTCOUNT: bit dictId of the group's set
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if ((m8 >> j) & 1u) atomicOr(aux_words + (size_t)key[j] * stride + (item[j] >> 5), 1u << (item[j] & 31u));
+    return;
+  }
+  const uint32_t log2m = (uint32_t)p.oct_log2m, imask = (1u << log2m) - 1u;
+  uint32_t addr[8], cur[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) addr[j] = key[j] * stride + (item[j] & imask);
+  const volatile uint8_t* regs = reinterpret_cast<const volatile uint8_t*>(aux_words);
+#pragma unroll
+  for (int j = 0; j < 8; j++) cur[j] = regs[addr[j]];   // reads first, all in flight
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const uint32_t rank = item[j] >> log2m;
+    const bool need = ((m8 >> j) & 1u) && rank > cur[j];
+    if (__builtin_amdgcn_ballot_w64(need)) {   // wave-uniform: after warm-up most slots raise nothing
+      if (need) oct_raise_register(aux_words, addr[j], rank);
+    }
+  }
+}
+
+template <bool MASKED>
+__device__ __forceinline__ void oct_body_lds(const PgQueryPlan& p) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = uniform(t >> 6);
+  int64_t* table = reinterpret_cast<int64_t*>(smem);
+  const uint32_t table_slots = (uint32_t)p.n_groups * (uint32_t)p.replicas;
+  for (int o = 0; o < p.n_ops; o++) {
+    const int64_t ident = pg_acc_identity(p.ops[o].fn, p.ops[o].is_float);
+    for (uint32_t i = (uint32_t)t; i < table_slots; i += PG_BLOCK) table[(size_t)o * table_slots + i] = ident;
+  }
+  uint32_t* aux_words = reinterpret_cast<uint32_t*>(smem);
+  if (p.n_aux > 0) {
+    aux_words = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(smem) + p.aux[0].lds_offset);
+    for (int64_t i = t; i < p.aux[0].rep_bytes / 4; i += PG_BLOCK) aux_words[i] = 0;
+  }
+  // MatchAllFilterOperator: no filter pass ran in front — every doc matches (ExecutionStatistics.numDocsScanned)
+  if (!MASKED && blockIdx.x == 0 && t == 0) atomicAdd(p.stats, (unsigned long long)p.num_docs);
+  __syncthreads();
+  OctLane ln;
+  oct_lane_setup(p, lane, ln);
+  const uint32_t rep = (uint32_t)t & ((uint32_t)p.replicas - 1u);
+  // sub-tile sequence of this wavefront: u = 0, 1, 2, ... -> wave tile first + (u >> 2) x step, sub-tile u & 3
+  const int first = (int)blockIdx.x * PG_WAVES_PER_BLOCK + wave, step = (int)gridDim.x * PG_WAVES_PER_BLOCK;
+  const int n_mine = first < p.n_wtiles ? (p.n_wtiles - first + step - 1) / step : 0;
+  const int n_sub = n_mine * OCT_SUBS_PER_WTILE;
+  const int last_wt = p.n_wtiles - 1;
+  auto wt_of = [&](int u) { const int w = first + (u >> 2) * step; return w < p.n_wtiles ? w : last_wt; };   // clamped: loads stay in bounds
+  OctRaw ra, rb;
+  if (n_sub > 0) oct_issue<MASKED>(p, ln, wt_of(0), 0, lane, ra);
+  for (int u = 0; u < n_sub; u += 2) {   // two buffers, no register rotation (a copy of a load target waits for every load in flight)
+    oct_issue<MASKED>(p, ln, wt_of(u + 1), (u + 1) & 3, lane, rb);
+    {
+      uint32_t key[8], item[8];
+      oct_decode(p, ln, ra, key, item);
+      const uint32_t m8 = oct_mask8(p, wt_of(u), u & 3, lane, ra.mw, MASKED);
+      oct_apply_lds(p, m8, key, item, table, aux_words, rep);
+    }
+    oct_issue<MASKED>(p, ln, wt_of(u + 2), (u + 2) & 3, lane, ra);
+    {
+      uint32_t key[8], item[8];
+      oct_decode(p, ln, rb, key, item);
+      const uint32_t m8 = (u + 1 < n_sub) ? oct_mask8(p, wt_of(u + 1), (u + 1) & 3, lane, rb.mw, MASKED) : 0u;
+      oct_apply_lds(p, m8, key, item, table, aux_words, rep);
+    }
+  }
+  __syncthreads();
+  // flush: the partial table [n_ops][G] (replicas folded) and the states, as pg_generic_query_l leaves them
+  {
+    const int R = p.replicas;
+    const int64_t n_out = (int64_t)p.n_ops * p.n_groups;
+    int64_t* out = p.partials + (int64_t)blockIdx.x * n_out;
+    for (int64_t i = t; i < n_out; i += PG_BLOCK) {
+      const int64_t* src = table + i * R;
+      int64_t acc = src[0];
+      for (int r = 1; r < R; r++) acc += src[r];   // COUNT only
+      out[i] = acc;
+    }
+  }
+  if (p.n_aux > 0) {
+    uint32_t* dst = p.aux[0].base + (int64_t)blockIdx.x * (p.aux[0].rep_bytes / 4);
+    for (int64_t i = t; i < p.aux[0].rep_bytes / 4; i += PG_BLOCK) dst[i] = aux_words[i];
+  }
+}
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_oct_l(const PgQueryPlan p) { oct_body_lds<false>(p); }
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_oct_lm(const PgQueryPlan p) { oct_body_lds<true>(p); }
+
+// ---- back end P: pruned offers ---------------------------------------------------------------------------------------------------------
+// LDS: counts u32 [G] | floors u8 [G] (padded to dwords)
+struct OctStream {
+  uint32_t base;   // first entry of the wavefront's current block (wave-uniform)
+  uint32_t used;   // entries of it written so far
+  bool have;
+};
+// inclusive prefix sum across the wavefront (DPP row operations, no LDS)
+DEVFN uint32_t oct_wave_scan(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);
+  return x;
+}
+DEVFN uint32_t oct_claim_block(const PgQueryPlan& p, int lane) {
+  uint32_t b = 0;
+  if (lane == 0) b = atomicAdd(p.oct_cursor, (uint32_t)OCT_STREAM_BLOCK);
+  b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+  if ((int64_t)b + OCT_STREAM_BLOCK > p.oct_stream_cap) {   // cannot happen when the host sized the stream (docs of the pass + a block per wavefront)
+    if (lane == 0) p.oct_cursor[1] = 1u;
+    b = 0;   // keeps the stores in bounds; the host fails the query on the flag
+  }
+  return b;
+}
+DEVFN void oct_apply_pruned(const PgQueryPlan& p, uint32_t m8, const uint32_t (&key)[8], const uint32_t (&item)[8], uint32_t* counts,
+                            const volatile uint8_t* floors, OctStream& st, int lane) {
+  const uint32_t log2m = (uint32_t)p.oct_log2m, pbits = log2m + 5u;
+  uint32_t fl[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) fl[j] = floors[key[j]];
+#pragma unroll
+  for (int j = 0; j < 8; j++)
+    if ((m8 >> j) & 1u) atomicAdd(counts + key[j], 1u);
+  uint32_t surv = 0;   // bit j: doc j's offer can still raise a register of its group
+#pragma unroll
+  for (int j = 0; j < 8; j++) surv |= (uint32_t)((item[j] >> log2m) > fl[j]) << j;
+  surv &= m8;
+  const uint32_t n_mine = (uint32_t)__builtin_popcount(surv);
+  const uint32_t incl = oct_wave_scan(n_mine);
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  if (total == 0) return;   // wave-uniform
+  // room in the current block; a sub-tile's survivors (<= 512) may straddle into one new block
+  uint32_t room = st.have ? (uint32_t)OCT_STREAM_BLOCK - st.used : 0u;
+  uint32_t base0 = st.base + st.used, base1 = 0;
+  if (total > room) {
+    base1 = oct_claim_block(p, lane);
+    st.base = base1;
+    st.used = total - room;
+    st.have = true;
+  } else {
+    st.used += total;
+  }
+  uint32_t at = incl - n_mine;   // this lane's first position among the sub-tile's survivors
+#pragma unroll
+  for (int j = 0; j < 8; j++)
+    if ((surv >> j) & 1u) {
+      const uint32_t pos = at < room ? base0 + at : base1 + (at - room);
+      p.oct_stream[pos] = (key[j] << pbits) | item[j];
+      at++;
+    }
+}
+
+template <bool MASKED>
+__device__ __forceinline__ void oct_body_pruned(const PgQueryPlan& p) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = uniform(t >> 6);
+  uint32_t* counts = reinterpret_cast<uint32_t*>(smem);
+  const uint32_t G = (uint32_t)p.n_groups;
+  uint32_t* floor_words = counts + G;
+  for (uint32_t i = (uint32_t)t; i < G; i += PG_BLOCK) counts[i] = 0;
+  for (uint32_t i = (uint32_t)t; i < (G + 3u) / 4u; i += PG_BLOCK) floor_words[i] = gptr<uint32_t>(p.oct_floor)[i];
+  const int t0 = p.oct_t0, t1 = p.oct_t1;   // wave tiles of this pass
+  if (!MASKED && blockIdx.x == 0 && t == 0) {
+    const int64_t lo = (int64_t)t0 * PG_WAVE_DOCS, hi = (int64_t)t1 * PG_WAVE_DOCS;
+    atomicAdd(p.stats, (unsigned long long)((hi < p.num_docs ? hi : (int64_t)p.num_docs) - lo));
+  }
+  __syncthreads();
+  const volatile uint8_t* floors = reinterpret_cast<const volatile uint8_t*>(floor_words);
+  OctLane ln;
+  oct_lane_setup(p, lane, ln);
+  const int first = t0 + (int)blockIdx.x * PG_WAVES_PER_BLOCK + wave, step = (int)gridDim.x * PG_WAVES_PER_BLOCK;
+  const int n_mine = first < t1 ? (t1 - first + step - 1) / step : 0;
+  const int n_sub = n_mine * OCT_SUBS_PER_WTILE;
+  const int last_wt = t1 - 1;
+  auto wt_of = [&](int u) { const int w = first + (u >> 2) * step; return w < t1 ? w : last_wt; };
+  OctStream st;
+  st.base = 0; st.used = 0; st.have = false;
+  OctRaw ra, rb;
+  if (n_sub > 0) oct_issue<MASKED>(p, ln, wt_of(0), 0, lane, ra);
+  for (int u = 0; u < n_sub; u += 2) {
+    oct_issue<MASKED>(p, ln, wt_of(u + 1), (u + 1) & 3, lane, rb);
+    {
+      uint32_t key[8], item[8];
+      oct_decode(p, ln, ra, key, item);
+      const uint32_t m8 = oct_mask8(p, wt_of(u), u & 3, lane, ra.mw, MASKED);
+      oct_apply_pruned(p, m8, key, item, counts, floors, st, lane);
+    }
+    oct_issue<MASKED>(p, ln, wt_of(u + 2), (u + 2) & 3, lane, ra);
+    {
+      uint32_t key[8], item[8];
+      oct_decode(p, ln, rb, key, item);
+      const uint32_t m8 = (u + 1 < n_sub) ? oct_mask8(p, wt_of(u + 1), (u + 1) & 3, lane, rb.mw, MASKED) : 0u;
+      oct_apply_pruned(p, m8, key, item, counts, floors, st, lane);
+    }
+  }
+  // the rest of the wavefront's last block is padding
+  if (st.have)
+    for (uint32_t i = st.used + (uint32_t)lane; i < (uint32_t)OCT_STREAM_BLOCK; i += 64u) p.oct_stream[st.base + i] = PG_RADIX_INVALID_KEY;
+  __syncthreads();
+  uint32_t* out = p.oct_counts + (size_t)blockIdx.x * G;
+  for (uint32_t i = (uint32_t)t; i < G; i += PG_BLOCK) out[i] = counts[i];
+}
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_oct_p(const PgQueryPlan p) { oct_body_pruned<false>(p); }
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_oct_pm(const PgQueryPlan p) { oct_body_pruned<true>(p); }
+
+// floor[g] = the smallest register of group g (one wavefront per group; registers are bytes, 2^log2m per group, log2m >= 4)
+extern "C" __global__ void __launch_bounds__(256) pg_oct_floor_kernel(const uint32_t* __restrict__ regs, uint8_t* __restrict__ floors, int n_groups, int log2m) {
+  const int g = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  if (g >= n_groups) return;
+  const int n_words = 1 << (log2m - 2);
+  uint32_t mn = 0xFFu;
+  for (int w = lane; w < n_words; w += 64) {
+    const uint32_t x = regs[(size_t)g * n_words + w];
+#pragma unroll
+    for (int b = 0; b < 4; b++) { const uint32_t y = (x >> (8 * b)) & 0xFFu; mn = y < mn ? y : mn; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mn, off, 64); mn = o < mn ? o : mn; }
+  if (lane == 0) floors[g] = (uint8_t)mn;
+}
+// registers of group g = bytewise max of what the table holds and the slices of g's bucket (the passes accumulate)
+extern "C" __global__ void __launch_bounds__(256) pg_oct_merge_aux_kernel(const uint32_t* __restrict__ partials, uint32_t* __restrict__ out, int slices,
+                                                                           int64_t bucket_words, int64_t n_words) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  const int64_t b = w / bucket_words, l = w % bucket_words;
+  uint32_t acc = out[w];
+  for (int sl = 0; sl < slices; sl++) acc = bytemax4(acc, partials[(b * slices + sl) * bucket_words + l]);
+  out[w] = acc;
+}
+// COUNT row of the final table = sum of the passes' per-workgroup counters
+extern "C" __global__ void __launch_bounds__(256) pg_oct_reduce_counts_kernel(const uint32_t* __restrict__ counts, int64_t* __restrict__ out, int n_parts,
+                                                                               int n_groups) {
+  const int g = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (g >= n_groups) return;
+  int64_t acc = 0;
+  for (int k = 0; k < n_parts; k++) acc += (int64_t)counts[(size_t)k * n_groups + g];
+  out[g] = acc;
+}

@@ -319,6 +319,31 @@ DEVFN void p2_decode(const PgQueryPlan& p, const P2Raw& raw, const uint32_t (&qi
       }
   }
 }
+// SRC == 3: the docs are the entries of the survivor stream pg_oct_p leaves (pg_kernels_oct.hip): one dword per entry,
+// key << payload bits | payload, PG_RADIX_INVALID_KEY = padding.  A "tile" is 2 048 consecutive entries, a quad four of them.
+DEVFN void p2_issue_stream(const PgQueryPlan& p, const uint32_t (&qi)[P2_QA], int wt, P2Raw& raw) {
+  const GAS uint32_t* tw = gptr<uint32_t>(p.oct_stream) + (size_t)wt * PG_WAVE_DOCS;
+#pragma unroll
+  for (int u = 0; u < P2_QA; u++) raw.s0[u] = ldnt((const GAS u32x4*)(tw + 4u * qi[u]));
+}
+// returns the batch's validity bits (entry != padding)
+DEVFN uint32_t p2_decode_stream(const PgQueryPlan& p, const P2Raw& raw, uint32_t local_mask, uint32_t (&key)[P2_QA * 4], uint32_t (&d)[1][P2_QA * 4]) {
+  const uint32_t pbits = (uint32_t)p.pk_bits[0], pmask = (1u << pbits) - 1u, sh = (uint32_t)p.pk_shift[0];
+  uint32_t valid = 0;
+#pragma unroll
+  for (int u = 0; u < P2_QA; u++) {
+    const uint32_t t4[4] = {raw.s0[u].x, raw.s0[u].y, raw.s0[u].z, raw.s0[u].w};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const uint32_t t = t4[i];
+      valid |= (uint32_t)(t != PG_RADIX_INVALID_KEY) << (4 * u + i);
+      const uint32_t k = t == PG_RADIX_INVALID_KEY ? 0u : (t >> pbits);
+      key[4 * u + i] = k;
+      d[0][4 * u + i] = (k & local_mask) | ((t & pmask) << sh);
+    }
+  }
+  return valid;
+}
 // generic (any plan the pipeline takes): the runtime-loop key / field functions
 template <int T>
 DEVFN void p2_decode_generic(const PgQueryPlan& p, const uint32_t (&qi)[P2_QA], int wt, uint32_t local_mask, uint32_t (&key)[P2_QA * 4],
@@ -365,18 +390,18 @@ struct P2Stage {
   uint32_t nbp;
 };
 
-// quad-layout match mask of wavefront `wave`'s tile of quartet g (0 beyond the segment)
-DEVFN uint32_t p2_tile_mask(const PgQueryPlan& p, int g, int n_quartets, int wave, int lane) {
+// quad-layout match mask of wavefront `wave`'s tile of quartet g (0 beyond the doc space: the segment, or — stream mode — the tuple stream)
+DEVFN uint32_t p2_tile_mask(const PgQueryPlan& p, int g, int n_quartets, int wave, int lane, int n_wtiles, int64_t num_docs) {
   const int wt_raw = g * PG_P2_WAVES + wave;
-  if (g >= n_quartets || wt_raw >= p.n_wtiles) return 0u;   // wave-uniform
-  const int64_t rem = (int64_t)p.num_docs - (int64_t)wt_raw * PG_WAVE_DOCS;
+  if (g >= n_quartets || wt_raw >= n_wtiles) return 0u;   // wave-uniform
+  const int64_t rem = num_docs - (int64_t)wt_raw * PG_WAVE_DOCS;
   const int32_t n_valid = rem >= PG_WAVE_DOCS ? PG_WAVE_DOCS : (int32_t)rem;
   if (p.match_words) return lin_to_quad(gptr<uint32_t>(p.match_words)[(int64_t)wt_raw * 64 + lane] & valid_lin_mask(n_valid, lane), lane);
   return valid_quad_mask(n_valid, lane);
 }
-DEVFN int p2_tile_of(const PgQueryPlan& p, int g, int wave) {   // the tile whose columns the wavefront reads (clamped: loads stay in bounds)
+DEVFN int p2_tile_of(int g, int wave, int n_wtiles) {   // the tile whose columns the wavefront reads (clamped: loads stay in bounds)
   const int wt_raw = g * PG_P2_WAVES + wave;
-  return wt_raw < p.n_wtiles ? wt_raw : p.n_wtiles - 1;
+  return wt_raw < n_wtiles ? wt_raw : (n_wtiles > 0 ? n_wtiles - 1 : 0);
 }
 // mb8: a batch's 8 mask bits; kq: its first quad slot.  Quads without a matching doc re-read quad 0 (a line the tile needs anyway).
 DEVFN void p2_quads_of(int lane, uint32_t mb8, int kq, uint32_t (&qi)[P2_QA]) {
@@ -400,25 +425,33 @@ __device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
   S.pool = S.left + NBA; S.ctrl = S.pool + PG_P2_POOL; S.lines = S.ctrl + 8; S.sorted = S.lines + 2u * (R / PG_P2_LINE + (uint32_t)NB + 1u); S.lo = S.sorted + (size_t)T * R;
   for (uint32_t i = (uint32_t)t; i < 6u * NBA; i += P2_THREADS) base[i] = 0;
   if (t < 8) S.ctrl[t] = 0;
+  constexpr bool STREAM = SRC == 3;   // the doc space is the survivor stream of pg_oct_p: its length is on the device
   // MatchAllFilterOperator: no filter pass ran in front — every doc matches (ExecutionStatistics.numDocsScanned)
-  if (!p.match_words && blockIdx.x == 0 && t == 0) atomicAdd(p.stats, (unsigned long long)p.num_docs);
+  if (!STREAM && !p.match_words && blockIdx.x == 0 && t == 0) atomicAdd(p.stats, (unsigned long long)p.num_docs);
   __syncthreads();
   const uint32_t local_mask = (1u << p.radix_shift) - 1u;
   const size_t lo_plane = (size_t)NB * PG_P2_LINE;
   uint32_t* const tuples = p.p2_tuples;
-  const int n_quartets = (p.n_wtiles + PG_P2_WAVES - 1) / PG_P2_WAVES;
+  int64_t num_docs = (int64_t)p.num_docs;
+  int n_wtiles = p.n_wtiles;
+  if (STREAM) {
+    num_docs = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)gptr<uint32_t>(p.oct_cursor)[0]);
+    n_wtiles = (int)((num_docs + PG_WAVE_DOCS - 1) / PG_WAVE_DOCS);
+  }
+  const int n_quartets = (n_wtiles + PG_P2_WAVES - 1) / PG_P2_WAVES;
   // round sequence of this workgroup: (quartet g, quad slots k0 .. k0 + Q - 1), g = blockIdx.x, blockIdx.x + gridDim.x, ...
   int g = (int)blockIdx.x;
-  uint32_t m = p2_tile_mask(p, g, n_quartets, wave, lane);
+  uint32_t m = p2_tile_mask(p, g, n_quartets, wave, lane, n_wtiles, num_docs);
   int k0 = 0;
   P2Raw raw;   // the loads of the round's first batch, requested one round ahead
   if (FAST) {
     uint32_t qi[P2_QA];
     p2_quads_of(lane, m & 0xFFu, 0, qi);
-    p2_issue(p, qi, p2_tile_of(p, g, wave), raw);
+    if (STREAM) p2_issue_stream(p, qi, p2_tile_of(g, wave, n_wtiles), raw);
+    else p2_issue(p, qi, p2_tile_of(g, wave, n_wtiles), raw);
   }
   while (g < n_quartets) {   // workgroup-uniform
-    const int wt = p2_tile_of(p, g, wave);
+    const int wt = p2_tile_of(g, wave, n_wtiles);
     const uint32_t mb = (m >> (4 * k0)) & (Q == 8 ? 0xFFFFFFFFu : ((1u << (4 * (Q & 7))) - 1u));
     uint32_t d[T][Q * 4];
     uint32_t br[Q * 4];
@@ -428,7 +461,11 @@ __device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
       uint32_t qi[P2_QA];
       p2_quads_of(lane, (mb >> (h * P2_QA * 4)) & 0xFFu, k0 + h * P2_QA, qi);
       uint32_t key[P2_QA * 4], dd[T][P2_QA * 4];
-      if (FAST) {
+      uint32_t vm = 0xFFu;   // stream mode: the batch's entries that are not padding
+      if (STREAM) {
+        if (h > 0) p2_issue_stream(p, qi, wt, raw);
+        vm = p2_decode_stream(p, raw, local_mask, key, reinterpret_cast<uint32_t(&)[1][P2_QA * 4]>(dd));
+      } else if (FAST) {
         if (h > 0) p2_issue(p, qi, wt, raw);
         p2_decode<T, SRC>(p, raw, qi, local_mask, key, dd);
       } else {
@@ -449,17 +486,18 @@ __device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
         for (int pl = 0; pl < T; pl++) d[pl][h * P2_QA * 4 + j] = dd[pl][j];
         const uint32_t b = key[j] >> p.radix_shift;
         br[h * P2_QA * 4 + j] = 0xFFFFFFFFu;
-        if ((mb >> (h * P2_QA * 4 + j)) & 1u) br[h * P2_QA * 4 + j] = (b << 16) | atomicAdd(&S.hist[b], 1u);
+        if (((mb >> (h * P2_QA * 4 + j)) & 1u) && ((vm >> j) & 1u)) br[h * P2_QA * 4 + j] = (b << 16) | atomicAdd(&S.hist[b], 1u);
       }
     }
     // next round: its mask, and (FAST) the loads of its first batch — in flight across the phases below
     int g_next = g, k0_next = k0 + Q;
     uint32_t m_next = m;
-    if (k0_next >= 8) { k0_next = 0; g_next = g + (int)gridDim.x; m_next = p2_tile_mask(p, g_next, n_quartets, wave, lane); }
+    if (k0_next >= 8) { k0_next = 0; g_next = g + (int)gridDim.x; m_next = p2_tile_mask(p, g_next, n_quartets, wave, lane, n_wtiles, num_docs); }
     if (FAST) {
       uint32_t qi[P2_QA];
       p2_quads_of(lane, (m_next >> (4 * k0_next)) & 0xFFu, k0_next, qi);
-      p2_issue(p, qi, p2_tile_of(p, g_next, wave), raw);
+      if (STREAM) p2_issue_stream(p, qi, p2_tile_of(g_next, wave, n_wtiles), raw);
+      else p2_issue(p, qi, p2_tile_of(g_next, wave, n_wtiles), raw);
     }
     __syncthreads();
     // ---- B: wavefront 0: histogram → offsets; the round's whole lines with their sources and destinations; chunk ids ------------------
@@ -658,6 +696,7 @@ P2_SCATTER(pg_p2_scatter_1f, 1, 4, true, 2)
 P2_SCATTER(pg_p2_scatter_2f, 2, 4, true, 2)
 P2_SCATTER(pg_p2_scatter_1f_key, 1, 4, true, 0)   // key only (COUNT over a big key space)
 P2_SCATTER(pg_p2_scatter_1f_hll, 1, 4, true, 1)   // config 5
+P2_SCATTER(pg_p2_scatter_stream, 1, 4, true, 3)   // the survivors of the pruned-offer passes (pg_oct_p)
 extern "C" const int pg_p2_round_quads[5] = {0, 4, 4, 2, 2};   // Q per plane count (the host sizes the LDS with it)
 
 // ---- chunk index: the chunk records grouped by bucket (counting sort of p2_meta), three small launches ------------------------------

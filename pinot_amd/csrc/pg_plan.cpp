@@ -956,6 +956,63 @@ static OpPtr clone_leaf(const FilterOp& op) {
   return c;
 }
 
+// Oct-layout kernels (pg_kernels_oct.hip): <= 4 group columns of <= 8 bits, COUNT at most among the accumulators, and ONE DISTINCTCOUNTHLL /
+// DISTINCTCOUNT state over a bit-packed (<= 24 bits) dictionary column or a raw INT column.  oct = 1: the state already lives in the
+// workgroup's LDS (aux_in_lds: the plan pg_generic_query_l ran before round 4); oct = 2: the partition pipeline's plan whose key space
+// (32-bit COUNTs + one floor byte per group) fits LDS — the pruned-offer passes.  Called once every other decision of the plan is taken.
+static void plan_oct(CompiledPlan& P, PgQueryPlan& D, const std::vector<Column*>& srcs, int64_t G, int64_t total_docs) {
+  D.oct = 0;
+  if (getenv("PG_NO_OCT")) return;   // measurement / test knob: the round-3 kernels
+  if (D.mv || P.first_doc_op >= 0 || D.n_aux != 1 || srcs.size() != 1 || D.n_group_cols > 4 || D.n_ops > 1) return;
+  for (int g = 0; g < D.n_group_cols; g++)
+    if (D.gcols[g].col_kind != PG_COL_FIXED_BIT || D.gcols[g].bits < 1 || D.gcols[g].bits > 8 || D.gcols[g].mult >= ((int64_t)1 << 24) ||
+        D.mv_gcol_offsets[g] != nullptr)
+      return;
+  for (int o = 0; o < D.n_ops; o++)
+    if (D.ops[o].fn != PG_ACC_COUNT || D.ops[o].src >= 0) return;
+  const PgAuxOp& A = D.aux[0];
+  const Column* c = srcs[(size_t)A.src];
+  if (c->is_mv) return;
+  int kind = 0;
+  if (A.kind == PG_AUX_DICT_SET) {
+    if (c->col_kind != PG_COL_FIXED_BIT || c->bits < 1 || c->bits > 24) return;
+    kind = 4;
+  } else if (A.kind == PG_AUX_HLL_DICT) {
+    if (c->col_kind != PG_COL_FIXED_BIT || c->bits < 1 || c->bits > 24 || !c->has_dictionary) return;
+    if (c->val_type == PG_V_I32 && c->dict_affine && c->dict_step > 0 && c->dict_step < ((int64_t)1 << 24) && !getenv("PG_OCT_NO_AFFINE")) {
+      kind = 1;
+      const uint32_t m = 0x5bd1e995u;
+      D.oct_c0 = (uint32_t)(int32_t)c->dict_base * m;
+      D.oct_c1 = (uint32_t)c->dict_step * m;
+      D.oct_nonneg = c->dict_base >= 0 ? 1 : 0;
+      D.oct_base = (int32_t)c->dict_base;
+      D.oct_step = (int32_t)c->dict_step;
+    } else {
+      if (!A.lut) return;
+      kind = 2;
+      D.oct_lut = A.lut;
+    }
+  } else if (A.kind == PG_AUX_HLL_RAW) {
+    if (c->col_kind != PG_COL_RAW32 || c->val_type != PG_V_I32) return;
+    kind = 3;
+  } else {
+    return;
+  }
+  D.oct_src = A.src;
+  D.oct_src_kind = kind;
+  D.oct_log2m = A.log2m;
+  if (P.aux_in_lds && (D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE) && A.lds_offset >= 0) {
+    D.oct = 1;
+    return;
+  }
+  // pruned offers: HyperLogLog only, one-dword tuples of the partition pipeline, counters + floors of the whole key space in LDS
+  const int64_t min_docs = getenv("PG_OCT_MIN_DOCS") ? atoll(getenv("PG_OCT_MIN_DOCS")) : ((int64_t)1 << 20);
+  if (D.agg_mode == PG_AGG_RADIX && D.p2 && D.p2_planes == 1 && kind != 4 && D.n_group_cols >= 1 && total_docs >= min_docs &&
+      G * 4 + ((G + 3) & ~(int64_t)3) + 256 <= kLdsTableBudget && G < ((int64_t)1 << (31 - (A.log2m + 5))) && D.pk_bits[0] == A.log2m + 5 &&
+      D.p2_fkind[0] == PG_P2_F_HLL && !getenv("PG_NO_OCT_PRUNE"))
+    D.oct = 2;
+}
+
 // Partition pipeline v2 (pg_kernels_part.hip) for a PG_AGG_RADIX plan: bit-packs what the aggregation pass needs from a doc into
 // 1..4 dwords and chooses the bucket width.  Per group the aggregation workgroup keeps n_ops int64 accumulators and one DWORD per
 // HyperLogLog register in LDS (a single ds_max_u32 per offer); radix_shift is the largest width whose table fits — lowered (more
@@ -1760,6 +1817,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     }
     if (ok && next_bit < 32) D.radix_packed = 1;   // bit 31 stays clear: a tuple never equals PG_RADIX_INVALID_KEY (the padding marker)
   }
+  plan_oct(P, D, srcs, G, seg.total_docs);
   // fast aggregation: LDS table, slots fit 16 bits, <= 8-bit group columns, 32-bit value sources
   P.fast_agg = D.agg_mode != PG_AGG_GLOBAL && D.agg_mode != PG_AGG_LDS_PART && D.agg_mode != PG_AGG_RADIX && (int64_t)G * D.replicas <= 65536;   // (trivially true without a table)
   if (D.n_aux > 0) P.fast_agg = false;   // set / HLL accumulators run in the interpreter kernel

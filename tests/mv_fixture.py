@@ -1,8 +1,10 @@
 """A small table with multi-value columns and a brute-force evaluator over its rows, in the style of
 DictionaryBasedGroupKeyGeneratorTest.java:163-200 (build random rows, run the real operators, compare with a plain loop).
 
-The reference tree holds no multi-value avro fixture, so the oracle's multi-value paths are pinned by this brute force (and by the
-reader / writer round trips in test_host_formats.py), NOT by reference golden numbers: "parity unpinned by goldens" for the MV rows."""
+The reference tree holds no multi-value AVRO fixture (test_data-mv.avro is absent), so the oracle's multi-value paths are exercised
+over random rows against this brute force (and by the reader / writer round trips in test_host_formats.py).  Reference-held NUMBERS for
+multi-value group-by and the *MV functions do exist — MultiValueRawQueriesTest builds a formulaic table with hard-coded expectations —
+and are asserted in tests/test_mv_reference_goldens.py (round 4; round 3 wrongly stated there were none)."""
 import math
 
 import numpy as np

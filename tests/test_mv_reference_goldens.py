@@ -1,0 +1,107 @@
+"""Multi-value group-by and the *MV functions pinned by the REFERENCE's own numbers.
+
+MultiValueRawQueriesTest (pinot-core/src/test/java/org/apache/pinot/queries/MultiValueRawQueriesTest.java) builds a FORMULAIC table —
+no avro fixture needed (:170-200): per segment 10 unique records x 2 duplicates, record i holds svIntCol = base + i and {base + i,
+base + i + 100} in every multi-value column; segment 1 has base 0, segment 2 base 1000; getBrokerResponse serves every segment twice
+(BaseQueriesTest.java:131-175: "equivalent to querying 4 ... index segments").  Each raw column (mvRawIntCol ...) has a dictionary twin
+(mvIntCol ...) holding the same values, and the test itself asserts raw == dictionary for every number, so the expectations stated on
+the raw columns ARE the expectations of the dictionary columns this path reads (raw multi-value forward indexes: see DESIGN §7).
+
+Asserted here, on the oracle (CPU suite) and on the HIP path (GPU suite):
+  :1189-1213   no filter:            COUNTMV 160, SUMMV 88720, MINMV 0, MAXMV 1109, AVGMV 554.5
+  :1255-1283   WHERE mv > 1000:      COUNTMV 80,  SUMMV 84360, MINMV 1000, MAXMV 1109, AVGMV 1054.5
+  :1291-1345   GROUP BY mvIntCol [, mvDoubleCol] ORDER BY keys LIMIT 10 -> keys (0 | 0, 0.0 / 0, 100.0 / ...), COUNTMV 8 each
+  :1396-1660   GROUP BY svIntCol, mvLongCol [, mvIntCol] ORDER BY svIntCol: 10 rows, svIntCol 0,0,1,1,.. (0,0,0,0,1,.. with three keys),
+               COUNTMV 8, MAXMV - MINMV = 100, the multi-value keys = svIntCol or svIntCol + 100 (validateAggregateWithGroupByQueryResults
+               :1719-1790) — plus the exact per-group numbers those rows imply (SUMMV 8 i + 400 etc.), derived, marked as such.
+Floating SUMMV / AVGMV run on the oracle only (the GPU path leaves them to the Java plan).
+"""
+import pytest
+
+from pinot_amd.executor import GroupByCombineOperator, NativeSegment
+from pinot_amd.segment import HostSegment, build_column, build_mv_column
+
+MV_OFFSET = 100
+TYPES = {"Int": "INT", "Long": "LONG", "Float": "FLOAT", "Double": "DOUBLE"}
+
+
+def reference_segment(base, name):
+    """generateRecords(baseValue) + createSegment (:170-216): the dictionary-encoded columns."""
+    values = [base + i for i in range(10)] * 2          # NUM_DUPLICATES_PER_RECORDS copies of the 10 unique records, in that order
+    seg = HostSegment(name, len(values))
+    seg.columns["svIntCol"] = build_column("svIntCol", values, "INT")
+    for t, dtype in TYPES.items():
+        cast = float if dtype in ("FLOAT", "DOUBLE") else int
+        seg.columns[f"mv{t}Col"] = build_mv_column(f"mv{t}Col", [[cast(v), cast(v + MV_OFFSET)] for v in values], dtype)
+    seg.columns["mvStringCol"] = build_mv_column("mvStringCol", [[str(v), str(v + MV_OFFSET)] for v in values], "STRING")
+    return seg
+
+
+def broker(segs, sql):
+    """getBrokerResponse: every segment on two servers, GroupByCombineOperator + the broker's final results."""
+    blocks = [s.execute(sql) for s in segs]
+    return GroupByCombineOperator(blocks + blocks).final()
+
+
+def five(col):
+    return f"COUNTMV({col}), SUMMV({col}), MINMV({col}), MAXMV({col}), AVGMV({col})"
+
+
+def check(segs, floating_sums):
+    sum_types = list(TYPES) if floating_sums else ["Int", "Long"]
+    # ---- testAggregateQueries / validateAggregateQueryResults :1105-1213 ---------------------------------------------------------------
+    for t in sum_types:
+        assert broker(segs, f"SELECT {five(f'mv{t}Col')} FROM testTable")[()] == [160, 88720.0, 0.0, 1109.0, 554.5], t
+    for t in TYPES:   # the functions the GPU path takes for every type
+        c = f"mv{t}Col"
+        assert broker(segs, f"SELECT COUNTMV({c}), MINMV({c}), MAXMV({c}) FROM testTable")[()] == [160, 0.0, 1109.0], t
+    assert broker(segs, "SELECT COUNTMV(mvStringCol) FROM testTable")[()] == [160]          # :1141-1160
+    # ---- testAggregateWithFilterQueries :1217-1283 ----------------------------------------------------------------------------------------
+    assert broker(segs, f"SELECT {five('mvIntCol')} FROM testTable WHERE mvIntCol > 1000")[()] == [80, 84360.0, 1000.0, 1109.0, 1054.5]
+    if floating_sums:
+        assert broker(segs, f"SELECT {five('mvDoubleCol')} FROM testTable WHERE mvDoubleCol > 1000.0")[()] == [80, 84360.0, 1000.0, 1109.0, 1054.5]
+    assert broker(segs, "SELECT COUNTMV(mvDoubleCol), MINMV(mvDoubleCol), MAXMV(mvDoubleCol) FROM testTable WHERE mvDoubleCol > 1000.0")[()] == [80, 1000.0, 1109.0]
+    # ---- testAggregateWithGroupByQueries :1291-1345: one and two multi-value keys, ORDER BY the keys LIMIT 10 ---------------------------------
+    rows = broker(segs, "SELECT mvIntCol, COUNTMV(mvLongCol) FROM testTable GROUP BY mvIntCol LIMIT 1000")
+    assert [(k[0], v) for k, v in sorted(rows.items())[:10]] == [(i, [8]) for i in range(10)]
+    assert len(rows) == 40 and all(v == [8] for v in rows.values())   # derived: every one of the 40 values is held by 4 docs x 2 entries
+    rows = broker(segs, "SELECT mvIntCol, COUNTMV(mvStringCol) FROM testTable GROUP BY mvIntCol LIMIT 1000")   # :1312-1331 (a STRING column counted)
+    assert [(k[0], v) for k, v in sorted(rows.items())[:10]] == [(i, [8]) for i in range(10)]
+    rows = broker(segs, "SELECT mvIntCol, mvDoubleCol, COUNTMV(mvLongCol) FROM testTable GROUP BY mvIntCol, mvDoubleCol LIMIT 1000")
+    first10 = sorted(rows.items())[:10]
+    assert [k for k, _ in first10] == [(0, 0.0), (0, 100.0), (1, 1.0), (1, 101.0), (2, 2.0), (2, 102.0), (3, 3.0), (3, 103.0), (4, 4.0), (4, 104.0)]
+    assert all(v == [8] for _, v in first10)
+    # ---- :1396-1530: GROUP BY svIntCol, one multi-value key; validateAggregateWithGroupByQueryResults :1719-1790 ---------------------------------
+    for t in sum_types:
+        rows = broker(segs, f"SELECT svIntCol, mvLongCol, {five(f'mv{t}Col')} FROM testTable GROUP BY svIntCol, mvLongCol LIMIT 1000")
+        first10 = sorted(rows.items())[:10]
+        assert [k[0] for k, _ in first10] == [0, 0, 1, 1, 2, 2, 3, 3, 4, 4]
+        for (sv, mv), (count, total, lo, hi, avg) in first10:
+            assert count == 8 and hi - lo == float(MV_OFFSET) and mv in (sv, sv + MV_OFFSET)           # the reference's assertions
+            assert (total, lo, hi, avg) == (8.0 * sv + 400.0, float(sv), float(sv + MV_OFFSET), sv + 50.0)   # derived from the table's formula
+    # ---- :1532-1660: three keys, two of them multi-value ----------------------------------------------------------------------------------
+    for t in sum_types:
+        rows = broker(segs, f"SELECT svIntCol, mvIntCol, mvLongCol, {five(f'mv{t}Col')} FROM testTable GROUP BY svIntCol, mvIntCol, mvLongCol LIMIT 1000")
+        first10 = sorted(rows.items())[:10]
+        assert [k[0] for k, _ in first10] == [0, 0, 0, 0, 1, 1, 1, 1, 2, 2]
+        for (sv, a, b), (count, total, lo, hi, avg) in first10:
+            assert count == 8 and hi - lo == float(MV_OFFSET) and a in (sv, sv + MV_OFFSET) and b in (sv, sv + MV_OFFSET)
+            assert (total, lo, hi, avg) == (8.0 * sv + 400.0, float(sv), float(sv + MV_OFFSET), sv + 50.0)
+    rows = broker(segs, "SELECT svIntCol, mvIntCol, mvLongCol, COUNTMV(mvStringCol) FROM testTable GROUP BY svIntCol, mvIntCol, mvLongCol LIMIT 1000")
+    assert [k[0] for k, _ in sorted(rows.items())[:10]] == [0, 0, 0, 0, 1, 1, 1, 1, 2, 2]
+    assert all(v == [8] for v in rows.values())
+
+
+def test_multi_value_reference_goldens_oracle(oracle_api):
+    segs = [NativeSegment(oracle_api, reference_segment(0, "testSegment1")), NativeSegment(oracle_api, reference_segment(1000, "testSegment2"))]
+    check(segs, floating_sums=True)
+    for s in segs:
+        s.destroy()
+
+
+@pytest.mark.gpu
+def test_multi_value_reference_goldens_gpu(gpu_api):
+    segs = [NativeSegment(gpu_api, reference_segment(0, "testSegment1")), NativeSegment(gpu_api, reference_segment(1000, "testSegment2"))]
+    check(segs, floating_sums=False)
+    for s in segs:
+        s.destroy()

@@ -1,7 +1,9 @@
 """Multi-value columns in the CPU oracle: FixedBitMVForwardIndexReader, MVScanDocIdIterator + applyMV,
 DictionaryBasedGroupKeyGenerator#processMultiValue (Cartesian expansion, repeats kept) and the *MV aggregation functions, checked
-against a brute force over the rows (DictionaryBasedGroupKeyGeneratorTest.java:163-200 style).  There is no multi-value golden in
-the reference tree for this path: these rows of the parity table are pinned by brute force only."""
+against a brute force over the rows (DictionaryBasedGroupKeyGeneratorTest.java:163-200 style) on random data.  The reference's own
+multi-value numbers (MultiValueRawQueriesTest's formulaic table: COUNTMV / SUMMV / MINMV / MAXMV / AVGMV with and without filters and
+multi-value group keys) are asserted in tests/test_mv_reference_goldens.py; filters over multi-value columns, DISTINCTCOUNTMV and the
+entries-scanned statistics have no reference number and stay pinned by this brute force."""
 import numpy as np
 import pytest
 
