@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--docs", type=int, default=int(os.environ.get("PG_BENCH_DOCS", "1000000000")),
                     help="rows per segment (BASELINE config 3: 1e9)")
+    ap.add_argument("--no-validation", action="store_true", help="N > 1: skip the parity checks of the merged table (multi_gpu_validation)")
     ap.add_argument("--query", choices=["cfg3", "northstar", "cfg2", "cfg5"], default="cfg3",
                     help="cfg5: BASELINE config 5 — 4-dim GROUP BY (12 800 groups) + DISTINCTCOUNTHLL, flat segment timed like the others, "
                          "plus the star-tree route's latency (its cost does not depend on the parent segment's size)")
@@ -277,6 +278,11 @@ def main():
             "roofline_frac": NORTH_STAR_BYTES_PER_ROW * args.docs / (k_n * 1e-3) / 1e9 / HBM_PEAK_GBS if k_n > 0 else 0.0,
             "algorithmic_bytes_per_launch": NORTH_STAR_BYTES_PER_ROW * args.docs}
 
+    if world > 1 and not args.no_validation:
+        # N > 1: the line must carry its own parity flags — every rank takes part, rank 0 reports
+        v = validate_multi_gpu(api, args, seg, qc, sql, needed, comm, dense, rank, world, local_rank)
+        if rank == 0:
+            out["multi_gpu_validation"] = v
     if args.query == "cfg3" and rank == 0 and world == 1 and not args.no_variants:
         out["merge_world_of_one"] = world_of_one_merge(api, seg, qc, local_rank)
     if args.query == "cfg3" and not args.no_variants and rank == 0 and world == 1:
@@ -304,6 +310,71 @@ def main():
         seg.destroy()
     if world > 1:
         dist.destroy_process_group()
+
+
+def validate_multi_gpu(api, args, seg, qc, sql, columns, comm, merged, rank, world, local_rank):
+    """Parity of an N-GPU step, checked inside the run that is timed (no timing here):
+      merged_equals_elementwise_merge   the table the timed step returned (pg_result_all_reduce over RCCL, or the fallback) against an
+                                        independent merge of the ranks' UNMERGED results: every rank's rows gathered by torch.distributed
+                                        (gather_object) and upserted by value on rank 0 (GroupByCombineOperator: IndexedTable semantics)
+      merged_equals_oracle_on_prefix    the same pipeline (segment query per rank + library merge) on the first `sample` rows of every
+                                        rank's segment against the CPU oracle's per-segment blocks combined by value
+    Both are False when any rank disagrees; the flags travel in the JSON line (multi_gpu_validation)."""
+    import torch.distributed as dist
+    from pinot_amd import synth
+    from pinot_amd.executor import GroupByCombineOperator, NativeSegment
+    from pinot_amd.query import parse_sql
+    from tests.oracle_binding import load_oracle
+    out = {}
+    # ---- (1) the timed result against the by-value merge of the unmerged per-rank results ------------------------------------------------
+    own = seg.execute(parse_sql(sql))
+    rows_all = [None] * world   # (all_gather_object: the collective this script already relies on under the nccl backend)
+    dist.all_gather_object(rows_all, own.rows())
+    merged_rows = merged.rows() if hasattr(merged, "rows") else None
+    # (the torch fallback merge hands back a DenseGroupTable, not rows: the flag is then null and `library_merge` false)
+    if rank == 0:
+        fns = [a.function for a in own.query.aggregations]
+        expect = {}
+        from pinot_amd.executor import merge_intermediate
+        for rows in rows_all:
+            for k, vals in rows.items():
+                if k in expect:
+                    expect[k] = [merge_intermediate(f, a, b) for f, a, b in zip(fns, expect[k], vals)]
+                else:
+                    expect[k] = list(vals)
+        out["merged_equals_elementwise_merge"] = None if merged_rows is None else bool(merged_rows == expect)
+        out["groups"] = len(expect)
+    # ---- (2) the pipeline on a prefix of every segment against the oracle ---------------------------------------------------------------------
+    sample = min(args.docs, 10_000_000)
+    host = synth.generate_segment(sample, segment_index=rank, columns=columns,
+                                  threads=max(1, (os.cpu_count() or 8) // max(world, 1)))
+    gp = NativeSegment(api, host)
+    q = parse_sql(sql)
+    if comm is not None:
+        nr = gp.execute_native(q, keep_device_table=True)
+        nr.all_reduce(comm)
+        got = nr.block().rows()
+        nr.free()
+    else:
+        got = None
+    ora = NativeSegment(load_oracle(), host)
+    ob = ora.execute(sql)
+    oracle_rows, got_all = [None] * world, [None] * world
+    dist.all_gather_object(oracle_rows, ob.rows())
+    dist.all_gather_object(got_all, got)
+    if rank == 0:
+        fns = [a.function for a in ob.query.aggregations]
+        from pinot_amd.executor import merge_intermediate
+        expect = {}
+        for rows in oracle_rows:
+            for k, vals in rows.items():
+                expect[k] = [merge_intermediate(f, a, b) for f, a, b in zip(fns, expect[k], vals)] if k in expect else list(vals)
+        out["merged_equals_oracle_on_prefix"] = bool(comm is not None and all(g == expect for g in got_all))   # EVERY rank holds the merged table
+        out["oracle_prefix_rows_per_segment"] = sample
+        out["library_merge"] = comm is not None
+    gp.destroy()
+    ora.destroy()
+    return out
 
 
 def world_of_one_merge(api, seg, qc, device):

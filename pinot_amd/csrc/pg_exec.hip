@@ -39,8 +39,9 @@ PG_DECL_FAST(pg_p2_index_count_kernel) PG_DECL_FAST(pg_p2_index_scan_kernel) PG_
 PG_DECL_FAST(pg_p2_scatter_stream)
 // pg_kernels_oct.hip: oct-layout DISTINCTCOUNTHLL / DISTINCTCOUNT kernels (LDS-resident states; pruned offers) and their small helpers
 PG_DECL_FAST(pg_oct_l) PG_DECL_FAST(pg_oct_lm) PG_DECL_FAST(pg_oct_p) PG_DECL_FAST(pg_oct_pm)
-extern "C" __global__ void pg_oct_floor_kernel(const uint32_t* regs, uint8_t* floors, int n_groups, int log2m);
-extern "C" __global__ void pg_oct_merge_aux_kernel(const uint32_t* partials, uint32_t* out, int slices, int64_t bucket_words, int64_t n_words);
+extern "C" __global__ void pg_oct_merge_floor_kernel(const uint32_t* partials, uint32_t* regs, uint8_t* floors, int n_groups, int log2m, int radix_shift,
+                                                      int slices);
+extern "C" __global__ void pg_oct_pass_reset_kernel(uint32_t* p2_meta, int64_t n_meta, uint32_t* p2_ctrl, uint32_t* cursor);
 extern "C" __global__ void pg_oct_reduce_counts_kernel(const uint32_t* counts, int64_t* out, int n_parts, int n_groups);
 extern "C" const int pg_p2_round_quads[5];   // pg_kernels_part.hip: quads per lane and round of the scatter kernel, by plane count
 extern "C" __global__ void pg_radix_offsets_kernel(uint32_t* hist, uint32_t* bucket_total, int n_wg, int n_buckets, int stage, int stage_waves);
@@ -594,6 +595,8 @@ static void run_oct_pruned(CompiledPlan& P, PgQueryPlan& D, ThreadCtx& ctx, cons
   if (!ctx.p2_ctrl.ptr) ctx.p2_ctrl.alloc((size_t)PG_P2_CTRL_DWORDS * 4, true);
   if (!ctx.p2_ctrl_host) PG_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx.p2_ctrl_host), 256, hipHostMallocDefault));
   memset(ctx.p2_ctrl_host, 0, 256);
+  PG_HIP(hipMemsetAsync(ctx.p2_ctrl.ptr, 0, (size_t)PG_P2_CTRL_DWORDS * 4, ctx.stream));   // incl. the error flag: sticky over the passes
+  PG_HIP(hipMemsetAsync(ctx.oct_cursor.ptr, 0, 8, ctx.stream));
   D.p2_tuples = ctx.radix_tuples.as<uint32_t>();
   D.p2_meta = ctx.p2_meta.as<uint32_t>();
   D.p2_list = ctx.p2_list.as<uint32_t>();
@@ -610,28 +613,27 @@ static void run_oct_pruned(CompiledPlan& P, PgQueryPlan& D, ThreadCtx& ctx, cons
     check_cancel(cancel, &ctx);
     const int t1 = bounds[(size_t)pass], tiles = t1 - t0;
     const int ogrid = std::max(1, std::min((tiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, num_cus()));
-    PG_HIP(hipMemsetAsync(ctx.oct_cursor.ptr, 0, 8, ctx.stream));
     PgQueryPlan O = D;
     O.oct_t0 = t0;
     O.oct_t1 = t1;
     O.oct_counts = ctx.oct_counts.as<uint32_t>() + (size_t)parts * G;
+    // the survivors go through the partition pipeline (sized for all of the pass's docs; the stream's true length is read on the device)
+    const size_t pass_entries = (size_t)tiles * PG_WAVE_DOCS + ((size_t)ogrid * PG_WAVES_PER_BLOCK + 2) * 1024;
+    const size_t pass_cap = std::min(cap, pass_entries / PG_P2_CHUNK + 1 + (size_t)sgrid_max * (2 * (size_t)NB + PG_P2_BATCH) + 64);
+    hipLaunchKernelGGL(pg_oct_pass_reset_kernel, dim3((unsigned)std::min<size_t>(1024, (pass_cap + 255) / 256 + 2)), dim3(256), 0, ctx.stream,
+                       ctx.p2_meta.as<uint32_t>(), (int64_t)pass_cap, ctx.p2_ctrl.as<uint32_t>(), ctx.oct_cursor.as<uint32_t>());
     hipLaunchKernelGGL(D.match_words ? pg_oct_pm : pg_oct_p, dim3(ogrid), dim3(PG_BLOCK), o_lds, ctx.stream, O);
     PG_HIP(hipGetLastError());
     parts += ogrid;
-    // the survivors through the partition pipeline (sized for all of the pass's docs; the stream's true length is read on the device)
-    const size_t pass_entries = (size_t)tiles * PG_WAVE_DOCS + ((size_t)ogrid * PG_WAVES_PER_BLOCK + 2) * 1024;
-    const size_t pass_cap = std::min(cap, pass_entries / PG_P2_CHUNK + 1 + (size_t)sgrid_max * (2 * (size_t)NB + PG_P2_BATCH) + 64);
-    PG_HIP(hipMemsetAsync(ctx.p2_meta.ptr, 0xFF, pass_cap * 4, ctx.stream));
-    PG_HIP(hipMemsetAsync(ctx.p2_ctrl.ptr, 0, (size_t)PG_P2_CTRL_DWORDS * 4, ctx.stream));
     PgQueryPlan S = O;
     S.match_words = nullptr;
     S.n_ops = 0;   // COUNT is pg_oct_p's: the aggregation pass sees HyperLogLog offers only
     S.p2_capacity = (int32_t)pass_cap;
-    // later passes keep a fraction of their offers (floors): fewer scatter workgroups and aggregation slices for them
+    // later passes keep a fraction of their offers (floors): fewer aggregation slices for them (the scatter sizes itself on the device)
     const double keep = pass == 0 ? 1.0 : (pass == 1 ? 0.75 : 0.25);
     const size_t est = (size_t)((double)tiles * PG_WAVE_DOCS * keep) + 1;
     const int quartets = (int)((pass_entries / PG_WAVE_DOCS + PG_P2_WAVES) / PG_P2_WAVES);
-    const int sgrid = std::max(1, std::min(std::min(quartets, sgrid_max), (int)(est / (round_tuples * 2)) + 1));
+    const int sgrid = std::max(1, std::min(quartets, sgrid_max));
     S.radix_slices = (int)std::max<size_t>(1, std::min<size_t>((size_t)slices_max, est / ((size_t)NB * 65536)));
     hipLaunchKernelGGL(pg_p2_scatter_stream, dim3(sgrid), dim3(PG_P2_WAVES * 64), s_lds, ctx.stream, S);
     PG_HIP(hipGetLastError());
@@ -643,17 +645,13 @@ static void run_oct_pruned(CompiledPlan& P, PgQueryPlan& D, ThreadCtx& ctx, cons
     const int agrid = std::min(NB * S.radix_slices, num_cus());
     hipLaunchKernelGGL(pg_p2_aggregate_1n, dim3(agrid), dim3(PG_P2_AGG_THREADS), P.lds_bytes + 64, ctx.stream, S);
     PG_HIP(hipGetLastError());
-    const int64_t n_words = (int64_t)G * D.aux[0].stride / 4, bucket_words = (int64_t)(slots * (size_t)D.aux[0].stride / 4);
-    hipLaunchKernelGGL(pg_oct_merge_aux_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, ctx.stream, S.aux[0].base, aux_final[0],
-                       S.radix_slices, bucket_words, n_words);
-    if (pass + 1 < n_pass)
-      hipLaunchKernelGGL(pg_oct_floor_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, ctx.stream, aux_final[0], ctx.oct_floor.as<uint8_t>(), (int)G,
-                         D.aux[0].log2m);
+    hipLaunchKernelGGL(pg_oct_merge_floor_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, ctx.stream, S.aux[0].base, aux_final[0],
+                       ctx.oct_floor.as<uint8_t>(), (int)G, D.aux[0].log2m, D.radix_shift, S.radix_slices);
     PG_HIP(hipGetLastError());
-    // error flags of this pass: p2_ctrl {chunks claimed, out of chunks}, cursor {entries, stream overflow}
-    PG_HIP(hipMemcpyAsync(ctx.p2_ctrl_host + 4 + 4 * std::min(pass, 14), ctx.p2_ctrl.ptr, 8, hipMemcpyDeviceToHost, ctx.stream));
-    PG_HIP(hipMemcpyAsync(ctx.p2_ctrl_host + 6 + 4 * std::min(pass, 14), ctx.oct_cursor.ptr, 8, hipMemcpyDeviceToHost, ctx.stream));
   }
+  // the error flags of all the passes: p2_ctrl {chunks claimed by the last pass, out of chunks}, cursor {entries of the last pass, overflow}
+  PG_HIP(hipMemcpyAsync(ctx.p2_ctrl_host + 4, ctx.p2_ctrl.ptr, 8, hipMemcpyDeviceToHost, ctx.stream));
+  PG_HIP(hipMemcpyAsync(ctx.p2_ctrl_host + 6, ctx.oct_cursor.ptr, 8, hipMemcpyDeviceToHost, ctx.stream));
   // COUNT row of the table = the passes' per-workgroup counters (the plan has at most this one accumulator)
   if (D.n_ops == 1) {
     hipLaunchKernelGGL(pg_oct_reduce_counts_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, ctx.stream, ctx.oct_counts.as<uint32_t>(),
@@ -1088,11 +1086,10 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
     ctx.stats_dirty = false;    // the reduce kernel left them zero
     if (p2_ran && ctx.p2_ctrl_host[1])
       fail(PG_ERR_INTERNAL, "partition pipeline ran out of chunks (%u claimed, %d sized)", ctx.p2_ctrl_host[0], D.p2_capacity);
-    if (oct_pruned)
-      for (int k = 0; k < 15; k++) {
-        const uint32_t* f = ctx.p2_ctrl_host + 4 + 4 * k;
-        if (f[1] || f[3]) fail(PG_ERR_INTERNAL, "pruned-offer pass %d: %s (%u chunks, %u stream entries)", k, f[1] ? "out of chunks" : "survivor stream overflow", f[0], f[2]);
-      }
+    if (oct_pruned) {
+      const uint32_t* f = ctx.p2_ctrl_host + 4;
+      if (f[1] || f[3]) fail(PG_ERR_INTERNAL, "pruned-offer passes: %s (last pass: %u chunks, %u stream entries)", f[1] ? "out of chunks" : "survivor stream overflow", f[0], f[2]);
+    }
     if (hashed) {
       // the occupied slots of every bucket's hash table: raw keys + [n_ops][groups] accumulators → a compact table
       unsigned long long cnt[2] = {0, 0};

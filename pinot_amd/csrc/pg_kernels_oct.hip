@@ -489,30 +489,36 @@ __device__ __forceinline__ void oct_body_pruned(const PgQueryPlan& p) {
 extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_oct_p(const PgQueryPlan p) { oct_body_pruned<false>(p); }
 extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_oct_pm(const PgQueryPlan p) { oct_body_pruned<true>(p); }
 
-// floor[g] = the smallest register of group g (one wavefront per group; registers are bytes, 2^log2m per group, log2m >= 4)
-extern "C" __global__ void __launch_bounds__(256) pg_oct_floor_kernel(const uint32_t* __restrict__ regs, uint8_t* __restrict__ floors, int n_groups, int log2m) {
+// After a pass: registers of group g = bytewise max of what the table holds and the slices of g's bucket (the passes accumulate), and
+// floor[g] = the smallest of them — the next pass's pruning threshold.  One wavefront per group; registers are bytes, 2^log2m per group.
+extern "C" __global__ void __launch_bounds__(256) pg_oct_merge_floor_kernel(const uint32_t* __restrict__ partials, uint32_t* __restrict__ regs,
+                                                                             uint8_t* __restrict__ floors, int n_groups, int log2m, int radix_shift,
+                                                                             int slices) {
   const int g = (int)(blockIdx.x * 4 + (threadIdx.x >> 6)), lane = threadIdx.x & 63;
   if (g >= n_groups) return;
   const int n_words = 1 << (log2m - 2);
+  const int64_t slots = (int64_t)1 << radix_shift;
+  const int64_t b = g >> radix_shift, local = g & (slots - 1);
   uint32_t mn = 0xFFu;
   for (int w = lane; w < n_words; w += 64) {
-    const uint32_t x = regs[(size_t)g * n_words + w];
+    uint32_t acc = regs[(size_t)g * n_words + w];
+    for (int sl = 0; sl < slices; sl++) acc = bytemax4(acc, partials[((b * slices + sl) * slots + local) * n_words + w]);
+    regs[(size_t)g * n_words + w] = acc;
 #pragma unroll
-    for (int b = 0; b < 4; b++) { const uint32_t y = (x >> (8 * b)) & 0xFFu; mn = y < mn ? y : mn; }
+    for (int k = 0; k < 4; k++) { const uint32_t y = (acc >> (8 * k)) & 0xFFu; mn = y < mn ? y : mn; }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mn, off, 64); mn = o < mn ? o : mn; }
   if (lane == 0) floors[g] = (uint8_t)mn;
 }
-// registers of group g = bytewise max of what the table holds and the slices of g's bucket (the passes accumulate)
-extern "C" __global__ void __launch_bounds__(256) pg_oct_merge_aux_kernel(const uint32_t* __restrict__ partials, uint32_t* __restrict__ out, int slices,
-                                                                           int64_t bucket_words, int64_t n_words) {
-  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= n_words) return;
-  const int64_t b = w / bucket_words, l = w % bucket_words;
-  uint32_t acc = out[w];
-  for (int sl = 0; sl < slices; sl++) acc = bytemax4(acc, partials[(b * slices + sl) * bucket_words + l]);
-  out[w] = acc;
+// Before a pass: the chunk records unowned, the chunk and stream cursors and the chunk index's counters zero; the error flags
+// (p2_ctrl[1], cursor[1]) stay as they are — they are read once, after the last pass.
+extern "C" __global__ void __launch_bounds__(256) pg_oct_pass_reset_kernel(uint32_t* __restrict__ p2_meta, int64_t n_meta, uint32_t* __restrict__ p2_ctrl,
+                                                                            uint32_t* __restrict__ cursor) {
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = i0; i < n_meta; i += step) p2_meta[i] = 0xFFFFFFFFu;
+  if (i0 == 0) { p2_ctrl[0] = 0; cursor[0] = 0; }
+  if (i0 >= PG_P2_CTRL_COUNTS && i0 < PG_P2_CTRL_DWORDS) p2_ctrl[i0] = 0;
 }
 // COUNT row of the final table = sum of the passes' per-workgroup counters
 extern "C" __global__ void __launch_bounds__(256) pg_oct_reduce_counts_kernel(const uint32_t* __restrict__ counts, int64_t* __restrict__ out, int n_parts,

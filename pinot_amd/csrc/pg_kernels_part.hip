@@ -29,6 +29,9 @@
 #include "pg_kernels.hip"
 
 #define P2_THREADS (PG_P2_WAVES * 64)
+#ifndef PG_P2_STREAM_MIN_QUARTETS
+#define PG_P2_STREAM_MIN_QUARTETS 4
+#endif
 
 // ---- one source's field for the 4 docs of Q quads ----------------------------------------------------------------------------
 template <int Q, bool WIDE>
@@ -439,7 +442,16 @@ __device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
     n_wtiles = (int)((num_docs + PG_WAVE_DOCS - 1) / PG_WAVE_DOCS);
   }
   const int n_quartets = (n_wtiles + PG_P2_WAVES - 1) / PG_P2_WAVES;
-  // round sequence of this workgroup: (quartet g, quad slots k0 .. k0 + Q - 1), g = blockIdx.x, blockIdx.x + gridDim.x, ...
+  // round sequence of this workgroup: (quartet g, quad slots k0 .. k0 + Q - 1), g = blockIdx.x, blockIdx.x + gstride, ...
+  // Stream mode: the host sized the grid for "every offer of the pass survives"; a workgroup that took one quartet of a short stream would
+  // leave NB chunks of one or two lines each (the aggregation pass then reads mostly padding).  Only as many workgroups as give each
+  // at least PG_P2_STREAM_MIN_QUARTETS quartets (32 K entries: ~6 lines per bucket at 157 buckets) take part; the others leave at once.
+  int gstride = (int)gridDim.x;
+  if (STREAM) {
+    const int want = (n_quartets + PG_P2_STREAM_MIN_QUARTETS - 1) / PG_P2_STREAM_MIN_QUARTETS;
+    gstride = want < gstride ? (want > 0 ? want : 1) : gstride;
+    if ((int)blockIdx.x >= gstride) return;   // workgroup-uniform, before any further barrier
+  }
   int g = (int)blockIdx.x;
   uint32_t m = p2_tile_mask(p, g, n_quartets, wave, lane, n_wtiles, num_docs);
   int k0 = 0;
@@ -492,7 +504,7 @@ __device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
     // next round: its mask, and (FAST) the loads of its first batch — in flight across the phases below
     int g_next = g, k0_next = k0 + Q;
     uint32_t m_next = m;
-    if (k0_next >= 8) { k0_next = 0; g_next = g + (int)gridDim.x; m_next = p2_tile_mask(p, g_next, n_quartets, wave, lane, n_wtiles, num_docs); }
+    if (k0_next >= 8) { k0_next = 0; g_next = g + gstride; m_next = p2_tile_mask(p, g_next, n_quartets, wave, lane, n_wtiles, num_docs); }
     if (FAST) {
       uint32_t qi[P2_QA];
       p2_quads_of(lane, (m_next >> (4 * k0_next)) & 0xFFu, k0_next, qi);

@@ -1006,6 +1006,11 @@ static void plan_oct(CompiledPlan& P, PgQueryPlan& D, const std::vector<Column*>
     return;
   }
   // pruned offers: HyperLogLog only, one-dword tuples of the partition pipeline, counters + floors of the whole key space in LDS
+  // Pruning pays when the groups' registers fill up (floors rise): a source with few distinct values leaves registers at zero for ever
+  // and every offer survives every pass — 3 x the cost of the plain partition pipeline (profiles/r04_a: DISTINCTCOUNTHLL over a 16-value
+  // column).  What is known at plan time is the column's cardinality / value range: at least 16 values per register.
+  const int64_t distinct_hint = c->has_dictionary ? (int64_t)c->cardinality : (c->has_int_range ? c->int_max - c->int_min : 0);
+  if (distinct_hint < ((int64_t)16 << A.log2m) && !getenv("PG_OCT_ANY_CARDINALITY")) return;
   const int64_t min_docs = getenv("PG_OCT_MIN_DOCS") ? atoll(getenv("PG_OCT_MIN_DOCS")) : ((int64_t)1 << 20);
   if (D.agg_mode == PG_AGG_RADIX && D.p2 && D.p2_planes == 1 && kind != 4 && D.n_group_cols >= 1 && total_docs >= min_docs &&
       G * 4 + ((G + 3) & ~(int64_t)3) + 256 <= kLdsTableBudget && G < ((int64_t)1 << (31 - (A.log2m + 5))) && D.pk_bits[0] == A.log2m + 5 &&

@@ -41,6 +41,22 @@ def main():
                 failures.append(("dense", q))
             if merged_gather != expect:
                 failures.append(("gather", q))
+    # bench.py's own N > 1 parity check (multi_gpu_validation), with the oracle as the per-rank executor and no library communicator:
+    # the by-value merge of the ranks' unmerged rows must accept the right table and reject a wrong one
+    import types
+    import bench
+    args = types.SimpleNamespace(docs=docs + 17 * rank)
+    q = synth.QUERY_CFG3
+    merged_rows = pd.gather_merge(mine.execute(q))          # rank 0 holds the merged rows
+    merged_rows = merged_rows if rank == 0 else {}
+    v = bench.validate_multi_gpu(api, args, mine, None, q, list(synth.CFG3_COLUMNS), None, types.SimpleNamespace(rows=lambda: merged_rows), rank, world, 0)
+    wrong = dict(list(merged_rows.items())[1:])
+    w = bench.validate_multi_gpu(api, args, mine, None, q, list(synth.CFG3_COLUMNS), None, types.SimpleNamespace(rows=lambda: wrong), rank, world, 0)
+    if rank == 0:
+        if v.get("merged_equals_elementwise_merge") is not True or v.get("library_merge") is not False:
+            failures.append(("bench validation accepts the merged table", str(v)))
+        if w.get("merged_equals_elementwise_merge") is not False:
+            failures.append(("bench validation rejects a wrong table", str(w)))
     if rank == 0:
         with open(out_path, "w") as f:
             json.dump({"failures": failures, "world": world}, f)

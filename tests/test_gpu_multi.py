@@ -118,6 +118,86 @@ def test_all_reduce_world_of_one(gpu_api, oracle_api):
     o.destroy()
 
 
+def _all_reduce_in_threads(results, comms, timeout=120):
+    """One thread per device calls pg_result_all_reduce, as the worker threads of a server would.  Returns the per-rank outcome:
+    None (merged) or the NativeError status.  A hang (some rank alone in a collective) fails the test through the join timeout."""
+    outcome = [None] * len(results)
+
+    def work(i):
+        try:
+            results[i].all_reduce(comms[i])
+        except capi.NativeError as e:
+            outcome[i] = e.status
+    ts = [threading.Thread(target=work, args=(i,), daemon=True) for i in range(len(results))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=timeout)
+    assert not any(t.is_alive() for t in ts), "a rank is stuck inside pg_result_all_reduce: the others left the collective"
+    return outcome
+
+
+@pytest.mark.gpu
+def test_all_reduce_two_devices(gpu_api, oracle_api):
+    """The one exchange step of the path on real links: pg_comm_init_all over two GPUs of one process, pg_result_all_reduce from one
+    thread per device against GroupByCombineOperator over the oracle's blocks (GroupByCombineOperator.java:102-165) — sums, MIN / MAX,
+    HyperLogLog registers (ncclMax on bytes) and DISTINCTCOUNT dictId sets (all-gather + OR) — and the refusals: ranks that disagree
+    on a dictionary, on the kind of a SUM accumulator, or whose merged SUM could leave int64 must ALL get PG_ERR_UNSUPPORTED, none may
+    enter the table launch alone, and the communicator must still work afterwards.  Skipped below two devices."""
+    if _device_count(gpu_api) < 2:
+        pytest.skip("needs two GPUs in one process")
+    comms = Comm.init_all(gpu_api, [0, 1])
+    hosts = [synth.generate_segment(60_013 + 17 * i, segment_index=i, columns=synth.CFG3_COLUMNS) for i in range(2)]
+    gpu = [NativeSegment(gpu_api, h, device=i) for i, h in enumerate(hosts)]
+    ora = [NativeSegment(oracle_api, h) for h in hosts]
+    for q in QUERIES:
+        results = [gpu[i].execute_native(q, keep_device_table=True) for i in range(2)]
+        assert _all_reduce_in_threads(results, comms) == [None, None], q
+        expect = GroupByCombineOperator([o.execute(q) for o in ora]).merge()
+        for r in results:
+            assert r.block().rows() == expect, q   # every rank holds the merged table
+            r.free()
+    # ---- refusals, on every rank alike ------------------------------------------------------------------------------------------------
+    rng = np.random.default_rng(3)
+    n = 40_000
+
+    def seg_of(device, g_values, m_values, name):
+        data = {"g": g_values.astype(np.int32), "m": m_values}
+        schema = {"g": "INT", "m": "LONG" if m_values.dtype == np.int64 else "DOUBLE"}
+        return NativeSegment(gpu_api, build_segment(name, data, schema, no_dictionary_columns=["m"]), device=device)
+    g_a = rng.integers(0, 50, n)
+    small = rng.integers(-1000, 1000, n).astype(np.int64)
+    cases = {
+        # same cardinality, different dictionary contents: the layout signature hashes the dictionaries
+        "dictionary": (seg_of(0, g_a, small, "a0"), seg_of(1, g_a + 1000, small, "a1")),
+        # a rank whose column holds NaN accumulates its SUM in IEEE double: signature mismatch, not a rank-local early throw
+        "double sum on one rank": (seg_of(0, g_a, small.astype(np.float64), "b0"),
+                                   seg_of(1, g_a, np.where(np.arange(n) == 7, np.nan, small.astype(np.float64)), "b1")),
+        # rank-local value ranges: rank 0's bound alone passes, rank 1's values make the merged SUM overflow-prone
+        "overflow bound": (seg_of(0, g_a, small, "c0"), seg_of(1, g_a, (small + (1 << 62) // n * 3).astype(np.int64), "c1")),
+    }
+    q = "SELECT g, SUM(m), COUNT(*) FROM t GROUP BY g LIMIT 1000"
+    for what, (s0, s1) in cases.items():
+        results = [s0.execute_native(q, keep_device_table=True), s1.execute_native(q, keep_device_table=True)]
+        got = _all_reduce_in_threads(results, comms)
+        assert got == [capi.PG_ERR_UNSUPPORTED, capi.PG_ERR_UNSUPPORTED], (what, got)
+        for r in results:
+            r.free()
+        s0.destroy()
+        s1.destroy()
+    # the communicator survives the refusals
+    results = [gpu[i].execute_native(synth.QUERY_CFG3, keep_device_table=True) for i in range(2)]
+    assert _all_reduce_in_threads(results, comms) == [None, None]
+    expect = GroupByCombineOperator([o.execute(synth.QUERY_CFG3) for o in ora]).merge()
+    assert all(r.block().rows() == expect for r in results)
+    for r in results:
+        r.free()
+    for s in gpu + ora:
+        s.destroy()
+    for c in comms:
+        c.destroy()
+
+
 @pytest.mark.gpu
 def test_merge_refuses_mismatched_tables(gpu_api):
     host = synth.generate_segment(20_000, columns=synth.CFG3_COLUMNS)

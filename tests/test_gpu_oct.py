@@ -77,9 +77,9 @@ LDS_SHAPES = [
     "SELECT g6, COUNT(*), DISTINCTCOUNTHLL(ur) FROM oct GROUP BY g6 LIMIT 1000",
     "SELECT g7, COUNT(*), DISTINCTCOUNTHLL(us) FROM oct GROUP BY g7 LIMIT 1000",
     "SELECT g8, COUNT(*), DISTINCTCOUNTHLL(ua) FROM oct GROUP BY g8 LIMIT 1000",
-    "SELECT g2, g1, g4, g3, COUNT(*), DISTINCTCOUNTHLL(ul) FROM oct GROUP BY g2, g1, g4, g3 LIMIT 1000",
+    "SELECT g2, g1, g4, g3, COUNT(*), DISTINCTCOUNTHLL(ul, 6) FROM oct GROUP BY g2, g1, g4, g3 LIMIT 1000",   # 480 groups x 64 registers
     # no GROUP BY
-    "SELECT DISTINCTCOUNTHLL(ua), COUNT(*) FROM oct",
+    "SELECT DISTINCTCOUNTHLL(ua), COUNT(*) FROM oct WHERE r >= 0",
     "SELECT DISTINCTCOUNTHLL(ur) FROM oct WHERE g4 < 9",
     # log2m
     "SELECT g1, DISTINCTCOUNTHLL(ua, 12), COUNT(*) FROM oct GROUP BY g1 LIMIT 10",
@@ -173,12 +173,29 @@ def test_pruned_offers_skew_and_empty_registers(gpu_api, oracle_api, monkeypatch
     k1[rng.random(n) < 0.5] = 17                                    # one heavy group
     k2 = rng.integers(0, 120, n).astype(np.int32)                    # 200 x 120 = 24 000 keys x 256 registers: beyond LDS
     v = rng.integers(0, 10**6, n).astype(np.int32)
-    v[k2 < 40] = v[k2 < 40] % 5                                      # a third of the groups sees 5 distinct values
+    v[k2 < 40] = v[k2 < 40] % 5                                      # a third of the groups sees 5 distinct values (floor 0 for ever)
     data = {"k1": k1, "k2": k2, "v": v, "vr": v.copy(), "r": rng.integers(0, 100, n).astype(np.int32)}
     host = build_segment("skew", data, {k: "INT" for k in data}, no_dictionary_columns=["vr", "r"])
     g, o = both(gpu_api, oracle_api, host)
     run(g, o, "SELECT k1, k2, COUNT(*), DISTINCTCOUNTHLL(v) FROM skew GROUP BY k1, k2 LIMIT 100000", kernels=("pg_oct_pruned_group_by",))
     run(g, o, "SELECT k1, k2, COUNT(*), DISTINCTCOUNTHLL(vr) FROM skew WHERE r < 70 GROUP BY k1, k2 LIMIT 100000", kernels=("pg_oct_pruned_group_by",))
+    g.destroy()
+    o.destroy()
+
+
+def test_pruned_offers_need_many_distinct_values(gpu_api, oracle_api, monkeypatch):
+    """A source of few distinct values (16 here) never fills the registers: the planner keeps the plain partition pipeline; the knob
+    PG_OCT_ANY_CARDINALITY forces the passes (every offer survives every pass) and the result is the same."""
+    monkeypatch.setenv("PG_OCT_MIN_DOCS", "0")
+    host = synth.generate_segment(120_001, segment_index=8, columns=synth.CFG5_COLUMNS, native=False)
+    sql = "SELECT h1, h2, h3, h4, COUNT(*), DISTINCTCOUNTHLL(h3) FROM gpuBench GROUP BY h1, h2, h3, h4 LIMIT 20000"
+    g, o = both(gpu_api, oracle_api, host)
+    run(g, o, sql, kernels=("pg_part_group_by",))
+    g.destroy()
+    monkeypatch.setenv("PG_OCT_ANY_CARDINALITY", "1")
+    monkeypatch.setenv("PG_OCT_PASSES", "0.1,0.5,1")
+    g = NativeSegment(gpu_api, host)
+    run(g, o, sql, kernels=("pg_oct_pruned_group_by",))
     g.destroy()
     o.destroy()
 
