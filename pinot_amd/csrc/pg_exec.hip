@@ -569,11 +569,12 @@ static void run_oct_pruned(CompiledPlan& P, PgQueryPlan& D, ThreadCtx& ctx, cons
   for (int i = 0, prev = 0; i < n_pass; prev = bounds[(size_t)i], i++) max_tiles = std::max(max_tiles, bounds[(size_t)i] - prev);
   const int ogrid_max = std::max(1, std::min((max_tiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, num_cus()));
   // the survivor stream: every doc of the largest pass + one partly filled block per wavefront
-  const size_t stream_cap = (size_t)max_tiles * PG_WAVE_DOCS + ((size_t)ogrid_max * PG_WAVES_PER_BLOCK + 2) * 1024;
+  const size_t stream_cap = (size_t)max_tiles * PG_WAVE_DOCS + ((size_t)ogrid_max * PG_WAVES_PER_BLOCK * 2 + 2) * 256;
   if (stream_cap >= ((size_t)1 << 32)) fail(PG_ERR_UNSUPPORTED, "pruned-offer pass of %zu entries", stream_cap);
   ThreadCtx::grow(ctx.oct_stream, stream_cap * 4 + 256);
   ThreadCtx::grow(ctx.oct_floor, G_pad + 256);
-  ThreadCtx::grow(ctx.oct_counts, (size_t)n_pass * (size_t)ogrid_max * G * 4 + 256);
+  ThreadCtx::grow(ctx.oct_counts, (size_t)ogrid_max * G * 4 + 256);
+  PG_HIP(hipMemsetAsync(ctx.oct_counts.ptr, 0, (size_t)ogrid_max * G * 4, ctx.stream));   // the passes add their COUNT partials row by row
   if (!ctx.oct_cursor.ptr) ctx.oct_cursor.alloc(256, true);
   PG_HIP(hipMemsetAsync(ctx.oct_floor.ptr, 0, G_pad, ctx.stream));
   // the registers accumulate over the passes (max): they start from zero
@@ -607,7 +608,7 @@ static void run_oct_pruned(CompiledPlan& P, PgQueryPlan& D, ThreadCtx& ctx, cons
   D.oct_stream_cap = (int64_t)stream_cap;
   const int slices_max = std::max(D.radix_slices, 1);   // what the partial register areas were sized for
   const size_t slots = (size_t)1 << D.radix_shift;
-  const size_t o_lds = G * 4 + G_pad + 64;
+  const size_t o_lds = ((G * 4 + G_pad + 15) & ~(size_t)15) + (size_t)PG_WAVES_PER_BLOCK * 1024 * 4 + 64;   // counts | floors | a 1 024-entry ring per wavefront
   int parts = 0;   // per-workgroup COUNT partials written so far
   for (int pass = 0, t0 = 0; pass < n_pass; t0 = bounds[(size_t)pass], pass++) {
     check_cancel(cancel, &ctx);
@@ -616,15 +617,15 @@ static void run_oct_pruned(CompiledPlan& P, PgQueryPlan& D, ThreadCtx& ctx, cons
     PgQueryPlan O = D;
     O.oct_t0 = t0;
     O.oct_t1 = t1;
-    O.oct_counts = ctx.oct_counts.as<uint32_t>() + (size_t)parts * G;
+    O.oct_counts = ctx.oct_counts.as<uint32_t>();
     // the survivors go through the partition pipeline (sized for all of the pass's docs; the stream's true length is read on the device)
-    const size_t pass_entries = (size_t)tiles * PG_WAVE_DOCS + ((size_t)ogrid * PG_WAVES_PER_BLOCK + 2) * 1024;
+    const size_t pass_entries = (size_t)tiles * PG_WAVE_DOCS + ((size_t)ogrid * PG_WAVES_PER_BLOCK * 2 + 2) * 256;
     const size_t pass_cap = std::min(cap, pass_entries / PG_P2_CHUNK + 1 + (size_t)sgrid_max * (2 * (size_t)NB + PG_P2_BATCH) + 64);
     hipLaunchKernelGGL(pg_oct_pass_reset_kernel, dim3((unsigned)std::min<size_t>(1024, (pass_cap + 255) / 256 + 2)), dim3(256), 0, ctx.stream,
                        ctx.p2_meta.as<uint32_t>(), (int64_t)pass_cap, ctx.p2_ctrl.as<uint32_t>(), ctx.oct_cursor.as<uint32_t>());
     hipLaunchKernelGGL(D.match_words ? pg_oct_pm : pg_oct_p, dim3(ogrid), dim3(PG_BLOCK), o_lds, ctx.stream, O);
     PG_HIP(hipGetLastError());
-    parts += ogrid;
+    parts = std::max(parts, ogrid);
     PgQueryPlan S = O;
     S.match_words = nullptr;
     S.n_ops = 0;   // COUNT is pg_oct_p's: the aggregation pass sees HyperLogLog offers only
@@ -654,7 +655,7 @@ static void run_oct_pruned(CompiledPlan& P, PgQueryPlan& D, ThreadCtx& ctx, cons
   PG_HIP(hipMemcpyAsync(ctx.p2_ctrl_host + 6, ctx.oct_cursor.ptr, 8, hipMemcpyDeviceToHost, ctx.stream));
   // COUNT row of the table = the passes' per-workgroup counters (the plan has at most this one accumulator)
   if (D.n_ops == 1) {
-    hipLaunchKernelGGL(pg_oct_reduce_counts_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, ctx.stream, ctx.oct_counts.as<uint32_t>(),
+    hipLaunchKernelGGL(pg_oct_reduce_counts_kernel, dim3((unsigned)((G + 63) / 64)), dim3(256), 0, ctx.stream, ctx.oct_counts.as<uint32_t>(),
                        ctx.final_table.as<int64_t>(), parts, (int)G);
     PG_HIP(hipGetLastError());
   }

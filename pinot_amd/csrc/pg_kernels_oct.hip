@@ -43,7 +43,7 @@ typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
 
 #define OCT_SUB_DOCS 512          // docs per sub-tile: 64 lanes x 8
 #define OCT_SUBS_PER_WTILE 4
-#define OCT_STREAM_BLOCK 1024     // entries a wavefront claims per global atomic
+#define OCT_STREAM_BLOCK 256      // entries a wavefront claims per global atomic and writes with one 16-byte store per lane
 
 // byte permute: result byte i = byte sel[i] of the 8 bytes {hi (4..7), lo (0..3)}
 DEVFN uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
@@ -271,6 +271,48 @@ DEVFN void oct_raise_register(uint32_t* lds_words, uint32_t byte_addr, uint32_t 
   }
 }
 
+// HyperLogLog registers are bytes: a register is raised by compare-and-swap on its dword.  Batched over four of the lane's docs — four
+// dword reads in flight, then four compare-and-swaps in flight for the docs whose rank beats the register as read — so a sub-tile costs four
+// LDS round trips whatever the number of raises (one read + one CAS chain per doc measured 58 % of the wave's time waiting,
+// profiles/r04_b_sq_oct_l.txt; all eight docs at once spilled 96 bytes per lane); a CAS that lost against another writer of the same
+// dword is retried in a (rare) serial loop.
+template <int J0>
+DEVFN void oct_raise_four(uint32_t m8, const uint32_t (&key)[8], const uint32_t (&item)[8], uint32_t* aux_words, uint32_t stride, uint32_t log2m) {
+  const uint32_t imask = (1u << log2m) - 1u;
+  uint32_t addr[4], w[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) addr[j] = key[J0 + j] * stride + (item[J0 + j] & imask);
+  volatile uint32_t* words = aux_words;
+#pragma unroll
+  for (int j = 0; j < 4; j++) w[j] = words[addr[j] >> 2];   // reads first, all in flight
+  uint32_t need = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t sh = (addr[j] & 3u) * 8u;
+    need |= (uint32_t)((((m8 >> (J0 + j)) & 1u) != 0) && (item[J0 + j] >> log2m) > ((w[j] >> sh) & 0xFFu)) << j;
+  }
+  if (__builtin_amdgcn_ballot_w64(need != 0) == 0) return;   // wave-uniform: after warm-up most sub-tiles raise nothing
+  uint32_t prev[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    prev[j] = w[j];
+    if ((need >> j) & 1u) {
+      const uint32_t sh = (addr[j] & 3u) * 8u;
+      prev[j] = atomicCAS(aux_words + (addr[j] >> 2), w[j], (w[j] & ~(0xFFu << sh)) | ((item[J0 + j] >> log2m) << sh));
+    }
+  }
+  uint32_t again = 0;   // lost against another writer of the dword (same register or a neighbour) and still below the rank
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint32_t sh = (addr[j] & 3u) * 8u;
+    again |= (uint32_t)(((need >> j) & 1u) && prev[j] != w[j] && ((prev[j] >> sh) & 0xFFu) < (item[J0 + j] >> log2m)) << j;
+  }
+  if (__builtin_amdgcn_ballot_w64(again != 0) == 0) return;
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+    if ((again >> j) & 1u) oct_raise_register(aux_words, addr[j], item[J0 + j] >> log2m);
+}
+
 // ---- back end L: the states live in this workgroup's LDS ---------------------------------------------------------------------------
 DEVFN void oct_apply_lds(const PgQueryPlan& p, uint32_t m8, const uint32_t (&key)[8], const uint32_t (&item)[8], int64_t* table, uint32_t* aux_words,
                          uint32_t rep) {
@@ -288,21 +330,13 @@ DEVFN void oct_apply_lds(const PgQueryPlan& p, uint32_t m8, const uint32_t (&key
       if ((m8 >> j) & 1u) atomicOr(aux_words + (size_t)key[j] * stride + (item[j] >> 5), 1u << (item[j] & 31u));
     return;
   }
-  const uint32_t log2m = (uint32_t)p.oct_log2m, imask = (1u << log2m) - 1u;
-  uint32_t addr[8], cur[8];
-#pragma unroll
-  for (int j = 0; j < 8; j++) addr[j] = key[j] * stride + (item[j] & imask);
-  const volatile uint8_t* regs = reinterpret_cast<const volatile uint8_t*>(aux_words);
-#pragma unroll
-  for (int j = 0; j < 8; j++) cur[j] = regs[addr[j]];   // reads first, all in flight
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
-    const uint32_t rank = item[j] >> log2m;
-    const bool need = ((m8 >> j) & 1u) && rank > cur[j];
-    if (__builtin_amdgcn_ballot_w64(need)) {   // wave-uniform: after warm-up most slots raise nothing
-      if (need) oct_raise_register(aux_words, addr[j], rank);
-    }
-  }
+  // HyperLogLog registers are bytes: a register is raised by compare-and-swap on its dword.  Everything is batched over the lane's 8 docs —
+  // 8 dword reads in flight, then 8 compare-and-swaps in flight for the docs whose rank beats the register as read — so a sub-tile costs
+  // two LDS round trips whatever the number of raises (one read + one CAS chain per doc measured 58 % of the wave's time waiting,
+  // profiles/r04_b_sq_oct_l.txt); a CAS that lost against another writer of the same dword is retried in a (rare) serial loop.
+  const uint32_t log2m = (uint32_t)p.oct_log2m;
+  oct_raise_four<0>(m8, key, item, aux_words, stride, log2m);
+  oct_raise_four<4>(m8, key, item, aux_words, stride, log2m);
 }
 
 template <bool MASKED>
@@ -372,11 +406,17 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_oct_l(const PgQueryPla
 extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_oct_lm(const PgQueryPlan p) { oct_body_lds<true>(p); }
 
 // ---- back end P: pruned offers ---------------------------------------------------------------------------------------------------------
-// LDS: counts u32 [G] | floors u8 [G] (padded to dwords)
+// LDS: counts u32 [G] | floors u8 [G] (padded to dwords) | per wavefront a ring of OCT_RING survivor entries.
+// Survivors are appended to the wavefront's ring (ds_write) and leave in whole blocks of OCT_STREAM_BLOCK = 256 entries — one coalesced
+// 16-byte store per lane — into a block of the stream claimed with one global atomic; the NEXT block is claimed as soon as one is used,
+// so the atomic's return is not waited for where it is issued.  (The first cut stored every survivor with a store of its own, 8 store
+// instructions per sub-tile between the pipelined column loads, and claimed blocks on demand: 3 x the time of pg_oct_l over the same docs,
+// WAIT_INST 46 % — profiles/r04_b_*.)
+#define OCT_RING 1024
 struct OctStream {
-  uint32_t base;   // first entry of the wavefront's current block (wave-uniform)
-  uint32_t used;   // entries of it written so far
-  bool have;
+  uint32_t head, tail;   // entries appended / flushed so far (wave-uniform)
+  uint32_t next;         // lane 0: the pre-claimed block's first entry (the atomic's return value, read at the next flush)
+  bool have_next;
 };
 // inclusive prefix sum across the wavefront (DPP row operations, no LDS)
 DEVFN uint32_t oct_wave_scan(uint32_t x) {
@@ -388,18 +428,31 @@ DEVFN uint32_t oct_wave_scan(uint32_t x) {
   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);
   return x;
 }
-DEVFN uint32_t oct_claim_block(const PgQueryPlan& p, int lane) {
+DEVFN uint32_t oct_claim_issue(const PgQueryPlan& p, int lane) {   // the value is lane 0's; nothing waits for it here
   uint32_t b = 0;
   if (lane == 0) b = atomicAdd(p.oct_cursor, (uint32_t)OCT_STREAM_BLOCK);
-  b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
-  if ((int64_t)b + OCT_STREAM_BLOCK > p.oct_stream_cap) {   // cannot happen when the host sized the stream (docs of the pass + a block per wavefront)
+  return b;
+}
+DEVFN uint32_t oct_claim_take(const PgQueryPlan& p, uint32_t pending, int lane) {
+  uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)pending);
+  if ((int64_t)b + OCT_STREAM_BLOCK > p.oct_stream_cap) {   // cannot happen when the host sized the stream (docs of the pass + two blocks per wavefront)
     if (lane == 0) p.oct_cursor[1] = 1u;
     b = 0;   // keeps the stores in bounds; the host fails the query on the flag
   }
   return b;
 }
+// one block of the ring -> the stream
+DEVFN void oct_flush_block(const PgQueryPlan& p, uint32_t* ring, OctStream& st, int lane) {
+  if (!st.have_next) st.next = oct_claim_issue(p, lane);
+  const uint32_t base = oct_claim_take(p, st.next, lane);
+  const u32x4 v = *reinterpret_cast<const u32x4*>(ring + (st.tail & (OCT_RING - 1u)) + 4u * (uint32_t)lane);
+  *reinterpret_cast<u32x4*>(p.oct_stream + base + 4u * (uint32_t)lane) = v;
+  st.tail += OCT_STREAM_BLOCK;
+  st.next = oct_claim_issue(p, lane);
+  st.have_next = true;
+}
 DEVFN void oct_apply_pruned(const PgQueryPlan& p, uint32_t m8, const uint32_t (&key)[8], const uint32_t (&item)[8], uint32_t* counts,
-                            const volatile uint8_t* floors, OctStream& st, int lane) {
+                            const volatile uint8_t* floors, uint32_t* ring, OctStream& st, int lane) {
   const uint32_t log2m = (uint32_t)p.oct_log2m, pbits = log2m + 5u;
   uint32_t fl[8];
 #pragma unroll
@@ -415,25 +468,15 @@ DEVFN void oct_apply_pruned(const PgQueryPlan& p, uint32_t m8, const uint32_t (&
   const uint32_t incl = oct_wave_scan(n_mine);
   const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
   if (total == 0) return;   // wave-uniform
-  // room in the current block; a sub-tile's survivors (<= 512) may straddle into one new block
-  uint32_t room = st.have ? (uint32_t)OCT_STREAM_BLOCK - st.used : 0u;
-  uint32_t base0 = st.base + st.used, base1 = 0;
-  if (total > room) {
-    base1 = oct_claim_block(p, lane);
-    st.base = base1;
-    st.used = total - room;
-    st.have = true;
-  } else {
-    st.used += total;
-  }
-  uint32_t at = incl - n_mine;   // this lane's first position among the sub-tile's survivors
+  uint32_t at = st.head + incl - n_mine;   // this lane's first ring position
 #pragma unroll
   for (int j = 0; j < 8; j++)
     if ((surv >> j) & 1u) {
-      const uint32_t pos = at < room ? base0 + at : base1 + (at - room);
-      p.oct_stream[pos] = (key[j] << pbits) | item[j];
+      ring[at & (OCT_RING - 1u)] = (key[j] << pbits) | item[j];
       at++;
     }
+  st.head += total;
+  while (st.head - st.tail >= (uint32_t)OCT_STREAM_BLOCK) oct_flush_block(p, ring, st, lane);   // wave-uniform; <= 3 blocks (512 + 255 entries)
 }
 
 template <bool MASKED>
@@ -459,8 +502,9 @@ __device__ __forceinline__ void oct_body_pruned(const PgQueryPlan& p) {
   const int n_sub = n_mine * OCT_SUBS_PER_WTILE;
   const int last_wt = t1 - 1;
   auto wt_of = [&](int u) { const int w = first + (u >> 2) * step; return w < t1 ? w : last_wt; };
+  uint32_t* ring = counts + ((G + (G + 3u) / 4u + 3u) & ~3u) + (uint32_t)wave * OCT_RING;   // 16-byte aligned: blocks leave with ds_read_b128
   OctStream st;
-  st.base = 0; st.used = 0; st.have = false;
+  st.head = 0; st.tail = 0; st.next = 0; st.have_next = false;
   OctRaw ra, rb;
   if (n_sub > 0) oct_issue<MASKED>(p, ln, wt_of(0), 0, lane, ra);
   for (int u = 0; u < n_sub; u += 2) {
@@ -469,22 +513,30 @@ __device__ __forceinline__ void oct_body_pruned(const PgQueryPlan& p) {
       uint32_t key[8], item[8];
       oct_decode(p, ln, ra, key, item);
       const uint32_t m8 = oct_mask8(p, wt_of(u), u & 3, lane, ra.mw, MASKED);
-      oct_apply_pruned(p, m8, key, item, counts, floors, st, lane);
+      oct_apply_pruned(p, m8, key, item, counts, floors, ring, st, lane);
     }
     oct_issue<MASKED>(p, ln, wt_of(u + 2), (u + 2) & 3, lane, ra);
     {
       uint32_t key[8], item[8];
       oct_decode(p, ln, rb, key, item);
       const uint32_t m8 = (u + 1 < n_sub) ? oct_mask8(p, wt_of(u + 1), (u + 1) & 3, lane, rb.mw, MASKED) : 0u;
-      oct_apply_pruned(p, m8, key, item, counts, floors, st, lane);
+      oct_apply_pruned(p, m8, key, item, counts, floors, ring, st, lane);
     }
   }
-  // the rest of the wavefront's last block is padding
-  if (st.have)
-    for (uint32_t i = st.used + (uint32_t)lane; i < (uint32_t)OCT_STREAM_BLOCK; i += 64u) p.oct_stream[st.base + i] = PG_RADIX_INVALID_KEY;
+  // what is left in the ring leaves as one block padded with PG_RADIX_INVALID_KEY; a pre-claimed block nobody filled is all padding
+  if (st.head != st.tail) {   // wave-uniform; fewer than a block
+    for (uint32_t i = st.head + (uint32_t)lane; i < st.tail + (uint32_t)OCT_STREAM_BLOCK; i += 64u) ring[i & (OCT_RING - 1u)] = PG_RADIX_INVALID_KEY;
+    oct_flush_block(p, ring, st, lane);
+  }
+  if (st.have_next) {
+    const uint32_t base = oct_claim_take(p, st.next, lane);
+    *reinterpret_cast<u32x4*>(p.oct_stream + base + 4u * (uint32_t)lane) =
+        (u32x4){PG_RADIX_INVALID_KEY, PG_RADIX_INVALID_KEY, PG_RADIX_INVALID_KEY, PG_RADIX_INVALID_KEY};
+  }
   __syncthreads();
+  // COUNT partials accumulate over the passes: workgroup b of every pass adds into row b (zeroed once per query)
   uint32_t* out = p.oct_counts + (size_t)blockIdx.x * G;
-  for (uint32_t i = (uint32_t)t; i < G; i += PG_BLOCK) out[i] = counts[i];
+  for (uint32_t i = (uint32_t)t; i < G; i += PG_BLOCK) out[i] += counts[i];
 }
 extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_oct_p(const PgQueryPlan p) { oct_body_pruned<false>(p); }
 extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_oct_pm(const PgQueryPlan p) { oct_body_pruned<true>(p); }
@@ -520,12 +572,17 @@ extern "C" __global__ void __launch_bounds__(256) pg_oct_pass_reset_kernel(uint3
   if (i0 == 0) { p2_ctrl[0] = 0; cursor[0] = 0; }
   if (i0 >= PG_P2_CTRL_COUNTS && i0 < PG_P2_CTRL_DWORDS) p2_ctrl[i0] = 0;
 }
-// COUNT row of the final table = sum of the passes' per-workgroup counters
+// COUNT row of the final table = sum of the workgroups' counters.  64 consecutive groups per block (coalesced rows), the partial rows
+// split over the block's four wavefronts, folded through LDS.
 extern "C" __global__ void __launch_bounds__(256) pg_oct_reduce_counts_kernel(const uint32_t* __restrict__ counts, int64_t* __restrict__ out, int n_parts,
                                                                                int n_groups) {
-  const int g = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (g >= n_groups) return;
-  int64_t acc = 0;
-  for (int k = 0; k < n_parts; k++) acc += (int64_t)counts[(size_t)k * n_groups + g];
-  out[g] = acc;
+  __shared__ unsigned long long s_acc[4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int g = (int)blockIdx.x * 64 + lane;
+  unsigned long long acc = 0;
+  if (g < n_groups)
+    for (int k = wv; k < n_parts; k += 4) acc += (unsigned long long)counts[(size_t)k * n_groups + g];
+  s_acc[wv][lane] = acc;
+  __syncthreads();
+  if (wv == 0 && g < n_groups) out[g] = (int64_t)(s_acc[0][lane] + s_acc[1][lane] + s_acc[2][lane] + s_acc[3][lane]);
 }

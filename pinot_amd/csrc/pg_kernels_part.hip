@@ -30,7 +30,7 @@
 
 #define P2_THREADS (PG_P2_WAVES * 64)
 #ifndef PG_P2_STREAM_MIN_QUARTETS
-#define PG_P2_STREAM_MIN_QUARTETS 4
+#define PG_P2_STREAM_MIN_QUARTETS 2
 #endif
 
 // ---- one source's field for the 4 docs of Q quads ----------------------------------------------------------------------------
@@ -445,7 +445,8 @@ __device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
   // round sequence of this workgroup: (quartet g, quad slots k0 .. k0 + Q - 1), g = blockIdx.x, blockIdx.x + gstride, ...
   // Stream mode: the host sized the grid for "every offer of the pass survives"; a workgroup that took one quartet of a short stream would
   // leave NB chunks of one or two lines each (the aggregation pass then reads mostly padding).  Only as many workgroups as give each
-  // at least PG_P2_STREAM_MIN_QUARTETS quartets (32 K entries: ~6 lines per bucket at 157 buckets) take part; the others leave at once.
+  // at least PG_P2_STREAM_MIN_QUARTETS quartets take part; the others leave at once (4 quartets per workgroup measured slower: a round
+  // costs ~10 us of latency whatever it holds, profiles/r04_b_kernels__cfg5_.txt).
   int gstride = (int)gridDim.x;
   if (STREAM) {
     const int want = (n_quartets + PG_P2_STREAM_MIN_QUARTETS - 1) / PG_P2_STREAM_MIN_QUARTETS;

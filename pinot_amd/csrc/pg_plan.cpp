@@ -1013,7 +1013,7 @@ static void plan_oct(CompiledPlan& P, PgQueryPlan& D, const std::vector<Column*>
   if (distinct_hint < ((int64_t)16 << A.log2m) && !getenv("PG_OCT_ANY_CARDINALITY")) return;
   const int64_t min_docs = getenv("PG_OCT_MIN_DOCS") ? atoll(getenv("PG_OCT_MIN_DOCS")) : ((int64_t)1 << 20);
   if (D.agg_mode == PG_AGG_RADIX && D.p2 && D.p2_planes == 1 && kind != 4 && D.n_group_cols >= 1 && total_docs >= min_docs &&
-      G * 4 + ((G + 3) & ~(int64_t)3) + 256 <= kLdsTableBudget && G < ((int64_t)1 << (31 - (A.log2m + 5))) && D.pk_bits[0] == A.log2m + 5 &&
+      G * 4 + ((G + 3) & ~(int64_t)3) + 16 * 4096 + 512 <= 156 * 1024 &&   /* counters + floors + the wavefronts' survivor rings */ G < ((int64_t)1 << (31 - (A.log2m + 5))) && D.pk_bits[0] == A.log2m + 5 &&
       D.p2_fkind[0] == PG_P2_F_HLL && !getenv("PG_NO_OCT_PRUNE"))
     D.oct = 2;
 }

@@ -172,6 +172,20 @@ def test_headline_kernel_has_no_register_spills():
     if os.path.exists(pipe):
         d = usage["pg_fast_i32range_p"]
         assert d["ScratchSize [bytes/lane]"] == 0 and d["VGPRs Spill"] == 0 and d["VGPRs"] <= 256, d
+    octl = log.replace("pg_kernels.", "pg_kernels_oct.")           # round 4: 16 wavefronts per workgroup, two sub-tiles' loads in flight
+    if os.path.exists(octl):
+        ou, cur = {}, None
+        for line in open(octl):
+            m = re.search(r"Function Name: (\w+)", line)
+            if m:
+                cur = m.group(1)
+                ou[cur] = {}
+            for key in ("VGPRs", "ScratchSize [bytes/lane]", "VGPRs Spill"):
+                m = re.search(re.escape(key) + r": (\d+)", line)
+                if m and cur:
+                    ou[cur].setdefault(key, int(m.group(1)))
+        for k in ("pg_oct_l", "pg_oct_lm", "pg_oct_p", "pg_oct_pm"):   # batching all 8 compare-and-swaps of a lane spilled 96 B
+            assert ou[k]["ScratchSize [bytes/lane]"] == 0 and ou[k]["VGPRs"] <= 128, (k, ou[k])
 
 
 def _abi_smoke_binary():

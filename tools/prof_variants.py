@@ -14,7 +14,7 @@ from pinot_amd.segment import HostSegment
 ap = argparse.ArgumentParser()
 ap.add_argument("--docs", type=int, default=200_000_000)
 ap.add_argument("--reps", type=int, default=10)
-ap.add_argument("--only", default="", help="substring of the query names to run")
+ap.add_argument("--only", default="", help="substring of the query names to run (a leading '=' asks for the exact name)")
 ap.add_argument("--set", choices=["cfg3", "cfg5", "general", "wide", "upsert", "postings"], default="cfg3")
 args = ap.parse_args()
 api = capi.gpu_api()
@@ -119,7 +119,7 @@ if args.set == "general":
 if args.set == "postings":
     QUERIES = QUERIES_POSTINGS
 for name, (sql, bpr) in QUERIES.items():
-    if args.only and args.only not in name:
+    if args.only and (args.only[1:] != name if args.only.startswith("=") else args.only not in name):
         continue
     qc = parse_sql(sql)
     qc.flags |= capi.QUERY_FLAG_PROFILE
