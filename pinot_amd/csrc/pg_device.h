@@ -166,6 +166,11 @@ enum PgAggMode : int32_t {
 #define PG_P2_CTRL_CURSOR (PG_P2_CTRL_STARTS + PG_P2_MAX_BUCKETS + 16)   // [buckets] fill cursors
 #define PG_P2_CTRL_DWORDS (PG_P2_CTRL_CURSOR + PG_P2_MAX_BUCKETS + 16)
 #define PG_P2_AGG_THREADS 1024
+// pruned-offer passes (pg_kernels_oct.hip): the survivor stream's control block (dwords)
+#define PG_OCT_MAX_REGIONS 1024
+#define PG_OCT_CTRL_COUNTS 16
+#define PG_OCT_CTRL_TILE_START (PG_OCT_CTRL_COUNTS + PG_OCT_MAX_REGIONS + 16)
+#define PG_OCT_CTRL_DWORDS (PG_OCT_CTRL_TILE_START + PG_OCT_MAX_REGIONS + 16)
 enum PgP2FieldKind : int32_t {
   PG_P2_F_HLL = 0,      // (register index | rank << log2m) of the value a DISTINCTCOUNTHLL offers
   PG_P2_F_DICTID = 1,   // dictId of a dictionary-encoded source (value looked up in the aggregation pass)
@@ -373,8 +378,11 @@ struct PgQueryPlan {
   const uint8_t* oct_floor;         // oct = 2: [n_groups] smallest register of every group so far (dword padded)
   uint32_t* oct_counts;             // oct = 2: [grid][n_groups] 32-bit COUNT partials of this pass
   uint32_t* oct_stream;             // oct = 2: survivor entries, key << (log2m + 5) | index | rank << log2m; PG_RADIX_INVALID_KEY = padding
-  uint32_t* oct_cursor;             // [0] entries claimed (blocks of 1 024), [1] overflow flag
-  int64_t oct_stream_cap;           // entries the stream holds
+  uint32_t* oct_cursor;             // control block: [1] overflow flag, [PG_OCT_CTRL_COUNTS + w] entries region w holds (a multiple of 256),
+                                    //   [PG_OCT_CTRL_TILE_START + w] its first 2 048-entry tile in the numbering across the regions
+  int64_t oct_stream_cap;           // entries the stream holds (oct_n_regions x oct_region)
+  int32_t oct_region;               // entries per region: the docs of a pg_oct_p workgroup in this pass + a padding block per wavefront
+  int32_t oct_n_regions;            // regions = workgroups of pg_oct_p in this pass
 };
 
 #if defined(__HIPCC__)

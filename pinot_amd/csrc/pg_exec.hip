@@ -42,6 +42,7 @@ PG_DECL_FAST(pg_oct_l) PG_DECL_FAST(pg_oct_lm) PG_DECL_FAST(pg_oct_p) PG_DECL_FA
 extern "C" __global__ void pg_oct_merge_floor_kernel(const uint32_t* partials, uint32_t* regs, uint8_t* floors, int n_groups, int log2m, int radix_shift,
                                                       int slices);
 extern "C" __global__ void pg_oct_pass_reset_kernel(uint32_t* p2_meta, int64_t n_meta, uint32_t* p2_ctrl, uint32_t* cursor);
+extern "C" __global__ void pg_oct_stream_index_kernel(uint32_t* ctrl, int n_regions);
 extern "C" __global__ void pg_oct_reduce_counts_kernel(const uint32_t* counts, int64_t* out, int n_parts, int n_groups);
 extern "C" const int pg_p2_round_quads[5];   // pg_kernels_part.hip: quads per lane and round of the scatter kernel, by plane count
 extern "C" __global__ void pg_radix_offsets_kernel(uint32_t* hist, uint32_t* bucket_total, int n_wg, int n_buckets, int stage, int stage_waves);
@@ -568,14 +569,24 @@ static void run_oct_pruned(CompiledPlan& P, PgQueryPlan& D, ThreadCtx& ctx, cons
   int max_tiles = 0;
   for (int i = 0, prev = 0; i < n_pass; prev = bounds[(size_t)i], i++) max_tiles = std::max(max_tiles, bounds[(size_t)i] - prev);
   const int ogrid_max = std::max(1, std::min((max_tiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, num_cus()));
-  // the survivor stream: every doc of the largest pass + one partly filled block per wavefront
-  const size_t stream_cap = (size_t)max_tiles * PG_WAVE_DOCS + ((size_t)ogrid_max * PG_WAVES_PER_BLOCK * 2 + 2) * 256;
+  // the survivor stream: one region per pg_oct_p workgroup, sized for "every offer of the workgroup's docs survives" + a padded block per wavefront
+  auto region_of = [&](int tiles, int ogrid) {
+    const size_t tiles_per_wg = (size_t)((tiles + ogrid * PG_WAVES_PER_BLOCK - 1) / (ogrid * PG_WAVES_PER_BLOCK)) * PG_WAVES_PER_BLOCK;
+    return tiles_per_wg * PG_WAVE_DOCS + (size_t)PG_WAVES_PER_BLOCK * 256;   // a multiple of 2 048
+  };
+  if (ogrid_max > PG_OCT_MAX_REGIONS) fail(PG_ERR_INTERNAL, "pruned-offer passes: %d workgroups", ogrid_max);
+  size_t stream_cap = 0;
+  for (int i = 0, prev = 0; i < n_pass; prev = bounds[(size_t)i], i++) {
+    const int tiles = bounds[(size_t)i] - prev;
+    const int og = std::max(1, std::min((tiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, num_cus()));
+    stream_cap = std::max(stream_cap, region_of(tiles, og) * (size_t)og);
+  }
   if (stream_cap >= ((size_t)1 << 32)) fail(PG_ERR_UNSUPPORTED, "pruned-offer pass of %zu entries", stream_cap);
   ThreadCtx::grow(ctx.oct_stream, stream_cap * 4 + 256);
   ThreadCtx::grow(ctx.oct_floor, G_pad + 256);
   ThreadCtx::grow(ctx.oct_counts, (size_t)ogrid_max * G * 4 + 256);
   PG_HIP(hipMemsetAsync(ctx.oct_counts.ptr, 0, (size_t)ogrid_max * G * 4, ctx.stream));   // the passes add their COUNT partials row by row
-  if (!ctx.oct_cursor.ptr) ctx.oct_cursor.alloc(256, true);
+  if (!ctx.oct_cursor.ptr) ctx.oct_cursor.alloc((size_t)PG_OCT_CTRL_DWORDS * 4, true);
   PG_HIP(hipMemsetAsync(ctx.oct_floor.ptr, 0, G_pad, ctx.stream));
   // the registers accumulate over the passes (max): they start from zero
   const size_t aux_bytes = P.aux_bytes[0];
@@ -618,14 +629,17 @@ static void run_oct_pruned(CompiledPlan& P, PgQueryPlan& D, ThreadCtx& ctx, cons
     O.oct_t0 = t0;
     O.oct_t1 = t1;
     O.oct_counts = ctx.oct_counts.as<uint32_t>();
-    // the survivors go through the partition pipeline (sized for all of the pass's docs; the stream's true length is read on the device)
-    const size_t pass_entries = (size_t)tiles * PG_WAVE_DOCS + ((size_t)ogrid * PG_WAVES_PER_BLOCK * 2 + 2) * 256;
+    O.oct_region = (int32_t)region_of(tiles, ogrid);
+    O.oct_n_regions = ogrid;
+    // the survivors go through the partition pipeline (sized for all of the pass's docs; the regions' true fills are read on the device)
+    const size_t pass_entries = (size_t)O.oct_region * (size_t)ogrid;
     const size_t pass_cap = std::min(cap, pass_entries / PG_P2_CHUNK + 1 + (size_t)sgrid_max * (2 * (size_t)NB + PG_P2_BATCH) + 64);
     hipLaunchKernelGGL(pg_oct_pass_reset_kernel, dim3((unsigned)std::min<size_t>(1024, (pass_cap + 255) / 256 + 2)), dim3(256), 0, ctx.stream,
                        ctx.p2_meta.as<uint32_t>(), (int64_t)pass_cap, ctx.p2_ctrl.as<uint32_t>(), ctx.oct_cursor.as<uint32_t>());
     hipLaunchKernelGGL(D.match_words ? pg_oct_pm : pg_oct_p, dim3(ogrid), dim3(PG_BLOCK), o_lds, ctx.stream, O);
     PG_HIP(hipGetLastError());
     parts = std::max(parts, ogrid);
+    hipLaunchKernelGGL(pg_oct_stream_index_kernel, dim3(1), dim3(256), 0, ctx.stream, ctx.oct_cursor.as<uint32_t>(), ogrid);
     PgQueryPlan S = O;
     S.match_words = nullptr;
     S.n_ops = 0;   // COUNT is pg_oct_p's: the aggregation pass sees HyperLogLog offers only

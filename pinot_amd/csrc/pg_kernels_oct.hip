@@ -160,7 +160,7 @@ DEVFN void oct_issue(const PgQueryPlan& p, const OctLane& ln, int wt, int sub, i
   if (MASKED) raw.mw = gptr<uint32_t>(p.match_words)[(size_t)wt * 64 + (size_t)sub * 16 + (size_t)(lane >> 2)];
 }
 
-// keys and per-doc source items (HyperLogLog: index | rank << log2m; DISTINCTCOUNT: the dictId) of the lane's 8 docs
+// keys and raw source items (dictIds / raw values) of the lane's 8 docs: everything that reads the load buffer
 DEVFN void oct_decode(const PgQueryPlan& p, const OctLane& ln, const OctRaw& raw, uint32_t (&key)[8], uint32_t (&item)[8]) {
 #pragma unroll
   for (int j = 0; j < 8; j++) key[j] = 0;
@@ -180,19 +180,23 @@ DEVFN void oct_decode(const PgQueryPlan& p, const OctLane& ln, const OctRaw& raw
     }
   const int kind = p.oct_src_kind;
   if (kind == OCT_SRC_NONE) return;
-  uint32_t id[8];
   if (kind == OCT_SRC_RAW32) {
     const uint32_t w[8] = {raw.s0.x, raw.s0.y, raw.s0.z, raw.s0.w, raw.s1.x, raw.s1.y, raw.s1.z, raw.s1.w};
 #pragma unroll
-    for (int j = 0; j < 8; j++) id[j] = bswap32(w[j]);
+    for (int j = 0; j < 8; j++) item[j] = bswap32(w[j]);
   } else {
-    oct_decode_source(p.srcs[p.oct_src].bits, raw.s0, raw.s1, ln.ssel, id);
+    oct_decode_source(p.srcs[p.oct_src].bits, raw.s0, raw.s1, ln.ssel, item);
   }
-  if (kind == OCT_SRC_DICTID) {
+}
+// item[] in: the docs' dictIds / raw values (oct_decode); out: what the back end applies — HyperLogLog index | rank << log2m, or the dictId.
+// Nothing here touches a load buffer: the caller re-requests the buffer between oct_decode and this.
+DEVFN void oct_finish(const PgQueryPlan& p, const uint32_t (&key)[8], uint32_t (&item)[8]) {
+  (void)key;
+  const int kind = p.oct_src_kind;
+  if (kind == OCT_SRC_NONE || kind == OCT_SRC_DICTID) return;
+  uint32_t id[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) item[j] = id[j];
-    return;
-  }
+  for (int j = 0; j < 8; j++) id[j] = item[j];
   const uint32_t log2m = (uint32_t)p.oct_log2m;
   if (kind == OCT_SRC_LUT) {   // any dictionary: (index | rank << 16) per dictId, computed on the host at plan time; gathers first
     uint32_t ir[8];
@@ -366,21 +370,27 @@ __device__ __forceinline__ void oct_body_lds(const PgQueryPlan& p) {
   const int n_sub = n_mine * OCT_SUBS_PER_WTILE;
   const int last_wt = p.n_wtiles - 1;
   auto wt_of = [&](int u) { const int w = first + (u >> 2) * step; return w < p.n_wtiles ? w : last_wt; };   // clamped: loads stay in bounds
+  // Two load buffers; a buffer is re-requested (two sub-tiles ahead) right AFTER it has been decoded, never before: hipcc waits for
+  // every load in flight (s_waitcnt vmcnt(0)) where the decode's wave-uniform switch consumes a buffer, so loads requested just before a
+  // decode were waited for on the spot — no overlap at all inside a wavefront (r04_b: 58 % of the wave's cycles waiting).  Requested
+  // after the decode they travel during this sub-tile's hash / LDS phase and the whole next sub-tile.
   OctRaw ra, rb;
-  if (n_sub > 0) oct_issue<MASKED>(p, ln, wt_of(0), 0, lane, ra);
-  for (int u = 0; u < n_sub; u += 2) {   // two buffers, no register rotation (a copy of a load target waits for every load in flight)
-    oct_issue<MASKED>(p, ln, wt_of(u + 1), (u + 1) & 3, lane, rb);
+  if (n_sub > 0) { oct_issue<MASKED>(p, ln, wt_of(0), 0, lane, ra); oct_issue<MASKED>(p, ln, wt_of(1), 1, lane, rb); }
+  for (int u = 0; u < n_sub; u += 2) {
     {
       uint32_t key[8], item[8];
       oct_decode(p, ln, ra, key, item);
       const uint32_t m8 = oct_mask8(p, wt_of(u), u & 3, lane, ra.mw, MASKED);
+      oct_issue<MASKED>(p, ln, wt_of(u + 2), (u + 2) & 3, lane, ra);
+      oct_finish(p, key, item);
       oct_apply_lds(p, m8, key, item, table, aux_words, rep);
     }
-    oct_issue<MASKED>(p, ln, wt_of(u + 2), (u + 2) & 3, lane, ra);
     {
       uint32_t key[8], item[8];
       oct_decode(p, ln, rb, key, item);
-      const uint32_t m8 = (u + 1 < n_sub) ? oct_mask8(p, wt_of(u + 1), (u + 1) & 3, lane, rb.mw, MASKED) : 0u;
+      const uint32_t m8 = oct_mask8(p, wt_of(u + 1), (u + 1) & 3, lane, rb.mw, MASKED);
+      oct_issue<MASKED>(p, ln, wt_of(u + 3), (u + 3) & 3, lane, rb);
+      oct_finish(p, key, item);
       oct_apply_lds(p, m8, key, item, table, aux_words, rep);
     }
   }
@@ -415,8 +425,6 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_oct_lm(const PgQueryPl
 #define OCT_RING 1024
 struct OctStream {
   uint32_t head, tail;   // entries appended / flushed so far (wave-uniform)
-  uint32_t next;         // lane 0: the pre-claimed block's first entry (the atomic's return value, read at the next flush)
-  bool have_next;
 };
 // inclusive prefix sum across the wavefront (DPP row operations, no LDS)
 DEVFN uint32_t oct_wave_scan(uint32_t x) {
@@ -428,31 +436,23 @@ DEVFN uint32_t oct_wave_scan(uint32_t x) {
   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);
   return x;
 }
-DEVFN uint32_t oct_claim_issue(const PgQueryPlan& p, int lane) {   // the value is lane 0's; nothing waits for it here
-  uint32_t b = 0;
-  if (lane == 0) b = atomicAdd(p.oct_cursor, (uint32_t)OCT_STREAM_BLOCK);
-  return b;
-}
-DEVFN uint32_t oct_claim_take(const PgQueryPlan& p, uint32_t pending, int lane) {
-  uint32_t b = (uint32_t)__builtin_amdgcn_readfirstlane((int)pending);
-  if ((int64_t)b + OCT_STREAM_BLOCK > p.oct_stream_cap) {   // cannot happen when the host sized the stream (docs of the pass + two blocks per wavefront)
+// one block of the ring -> the workgroup's region of the stream.  The region's fill cursor lives in LDS (only this workgroup writes the
+// region): a claim is one returning ds_add.  (A cursor in HBM shared by all workgroups serialised the claims at ~60 ns each — the passes
+// spent 80 % of their time queueing on it, profiles/r04_c_kernels__cfg5_.txt.)
+DEVFN void oct_flush_block(const PgQueryPlan& p, uint32_t* ring, uint32_t* s_cur, uint32_t region_base, OctStream& st, int lane) {
+  uint32_t pos = 0;
+  if (lane == 0) pos = atomicAdd(s_cur, (uint32_t)OCT_STREAM_BLOCK);
+  pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos);
+  if (pos + (uint32_t)OCT_STREAM_BLOCK > (uint32_t)p.oct_region) {   // cannot happen: the host sized the region for "every offer survives"
     if (lane == 0) p.oct_cursor[1] = 1u;
-    b = 0;   // keeps the stores in bounds; the host fails the query on the flag
+    pos = 0;   // keeps the store in bounds; the host fails the query on the flag
   }
-  return b;
-}
-// one block of the ring -> the stream
-DEVFN void oct_flush_block(const PgQueryPlan& p, uint32_t* ring, OctStream& st, int lane) {
-  if (!st.have_next) st.next = oct_claim_issue(p, lane);
-  const uint32_t base = oct_claim_take(p, st.next, lane);
   const u32x4 v = *reinterpret_cast<const u32x4*>(ring + (st.tail & (OCT_RING - 1u)) + 4u * (uint32_t)lane);
-  *reinterpret_cast<u32x4*>(p.oct_stream + base + 4u * (uint32_t)lane) = v;
+  *reinterpret_cast<u32x4*>(p.oct_stream + region_base + pos + 4u * (uint32_t)lane) = v;
   st.tail += OCT_STREAM_BLOCK;
-  st.next = oct_claim_issue(p, lane);
-  st.have_next = true;
 }
 DEVFN void oct_apply_pruned(const PgQueryPlan& p, uint32_t m8, const uint32_t (&key)[8], const uint32_t (&item)[8], uint32_t* counts,
-                            const volatile uint8_t* floors, uint32_t* ring, OctStream& st, int lane) {
+                            const volatile uint8_t* floors, uint32_t* ring, uint32_t* s_cur, uint32_t region_base, OctStream& st, int lane) {
   const uint32_t log2m = (uint32_t)p.oct_log2m, pbits = log2m + 5u;
   uint32_t fl[8];
 #pragma unroll
@@ -476,18 +476,20 @@ DEVFN void oct_apply_pruned(const PgQueryPlan& p, uint32_t m8, const uint32_t (&
       at++;
     }
   st.head += total;
-  while (st.head - st.tail >= (uint32_t)OCT_STREAM_BLOCK) oct_flush_block(p, ring, st, lane);   // wave-uniform; <= 3 blocks (512 + 255 entries)
+  while (st.head - st.tail >= (uint32_t)OCT_STREAM_BLOCK) oct_flush_block(p, ring, s_cur, region_base, st, lane);   // wave-uniform; <= 3 blocks
 }
 
 template <bool MASKED>
 __device__ __forceinline__ void oct_body_pruned(const PgQueryPlan& p) {
   extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
+  __shared__ uint32_t s_cur;   // entries of this workgroup's stream region claimed so far
   const int t = threadIdx.x, lane = t & 63, wave = uniform(t >> 6);
   uint32_t* counts = reinterpret_cast<uint32_t*>(smem);
   const uint32_t G = (uint32_t)p.n_groups;
   uint32_t* floor_words = counts + G;
   for (uint32_t i = (uint32_t)t; i < G; i += PG_BLOCK) counts[i] = 0;
   for (uint32_t i = (uint32_t)t; i < (G + 3u) / 4u; i += PG_BLOCK) floor_words[i] = gptr<uint32_t>(p.oct_floor)[i];
+  if (t == 0) s_cur = 0;
   const int t0 = p.oct_t0, t1 = p.oct_t1;   // wave tiles of this pass
   if (!MASKED && blockIdx.x == 0 && t == 0) {
     const int64_t lo = (int64_t)t0 * PG_WAVE_DOCS, hi = (int64_t)t1 * PG_WAVE_DOCS;
@@ -503,37 +505,36 @@ __device__ __forceinline__ void oct_body_pruned(const PgQueryPlan& p) {
   const int last_wt = t1 - 1;
   auto wt_of = [&](int u) { const int w = first + (u >> 2) * step; return w < t1 ? w : last_wt; };
   uint32_t* ring = counts + ((G + (G + 3u) / 4u + 3u) & ~3u) + (uint32_t)wave * OCT_RING;   // 16-byte aligned: blocks leave with ds_read_b128
+  const uint32_t region_base = (uint32_t)blockIdx.x * (uint32_t)p.oct_region;
   OctStream st;
-  st.head = 0; st.tail = 0; st.next = 0; st.have_next = false;
-  OctRaw ra, rb;
-  if (n_sub > 0) oct_issue<MASKED>(p, ln, wt_of(0), 0, lane, ra);
+  st.head = 0; st.tail = 0;
+  OctRaw ra, rb;   // (the ordering of requests and decodes: see oct_body_lds)
+  if (n_sub > 0) { oct_issue<MASKED>(p, ln, wt_of(0), 0, lane, ra); oct_issue<MASKED>(p, ln, wt_of(1), 1, lane, rb); }
   for (int u = 0; u < n_sub; u += 2) {
-    oct_issue<MASKED>(p, ln, wt_of(u + 1), (u + 1) & 3, lane, rb);
     {
       uint32_t key[8], item[8];
       oct_decode(p, ln, ra, key, item);
       const uint32_t m8 = oct_mask8(p, wt_of(u), u & 3, lane, ra.mw, MASKED);
-      oct_apply_pruned(p, m8, key, item, counts, floors, ring, st, lane);
+      oct_issue<MASKED>(p, ln, wt_of(u + 2), (u + 2) & 3, lane, ra);
+      oct_finish(p, key, item);
+      oct_apply_pruned(p, m8, key, item, counts, floors, ring, &s_cur, region_base, st, lane);
     }
-    oct_issue<MASKED>(p, ln, wt_of(u + 2), (u + 2) & 3, lane, ra);
     {
       uint32_t key[8], item[8];
       oct_decode(p, ln, rb, key, item);
-      const uint32_t m8 = (u + 1 < n_sub) ? oct_mask8(p, wt_of(u + 1), (u + 1) & 3, lane, rb.mw, MASKED) : 0u;
-      oct_apply_pruned(p, m8, key, item, counts, floors, ring, st, lane);
+      const uint32_t m8 = oct_mask8(p, wt_of(u + 1), (u + 1) & 3, lane, rb.mw, MASKED);
+      oct_issue<MASKED>(p, ln, wt_of(u + 3), (u + 3) & 3, lane, rb);
+      oct_finish(p, key, item);
+      oct_apply_pruned(p, m8, key, item, counts, floors, ring, &s_cur, region_base, st, lane);
     }
   }
-  // what is left in the ring leaves as one block padded with PG_RADIX_INVALID_KEY; a pre-claimed block nobody filled is all padding
+  // what is left in the ring leaves as one block padded with PG_RADIX_INVALID_KEY
   if (st.head != st.tail) {   // wave-uniform; fewer than a block
     for (uint32_t i = st.head + (uint32_t)lane; i < st.tail + (uint32_t)OCT_STREAM_BLOCK; i += 64u) ring[i & (OCT_RING - 1u)] = PG_RADIX_INVALID_KEY;
-    oct_flush_block(p, ring, st, lane);
-  }
-  if (st.have_next) {
-    const uint32_t base = oct_claim_take(p, st.next, lane);
-    *reinterpret_cast<u32x4*>(p.oct_stream + base + 4u * (uint32_t)lane) =
-        (u32x4){PG_RADIX_INVALID_KEY, PG_RADIX_INVALID_KEY, PG_RADIX_INVALID_KEY, PG_RADIX_INVALID_KEY};
+    oct_flush_block(p, ring, &s_cur, region_base, st, lane);
   }
   __syncthreads();
+  if (t == 0) p.oct_cursor[PG_OCT_CTRL_COUNTS + blockIdx.x] = s_cur;   // the region's fill, a multiple of the block
   // COUNT partials accumulate over the passes: workgroup b of every pass adds into row b (zeroed once per query)
   uint32_t* out = p.oct_counts + (size_t)blockIdx.x * G;
   for (uint32_t i = (uint32_t)t; i < G; i += PG_BLOCK) out[i] += counts[i];
@@ -563,13 +564,27 @@ extern "C" __global__ void __launch_bounds__(256) pg_oct_merge_floor_kernel(cons
   for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)mn, off, 64); mn = o < mn ? o : mn; }
   if (lane == 0) floors[g] = (uint8_t)mn;
 }
+// After pg_oct_p: the regions' tiles numbered across the regions (exclusive prefix of ceil(fill / 2 048)); one small block.
+extern "C" __global__ void __launch_bounds__(256) pg_oct_stream_index_kernel(uint32_t* __restrict__ ctrl, int n_regions) {
+  __shared__ uint32_t s_tiles[PG_OCT_MAX_REGIONS];
+  const int t = threadIdx.x;
+  for (int i = t; i < n_regions; i += 256) s_tiles[i] = (ctrl[PG_OCT_CTRL_COUNTS + i] + PG_WAVE_DOCS - 1) / PG_WAVE_DOCS;
+  __syncthreads();
+  if (t == 0) {
+    uint32_t run = 0;
+    for (int i = 0; i < n_regions; i++) { ctrl[PG_OCT_CTRL_TILE_START + i] = run; run += s_tiles[i]; }
+    ctrl[PG_OCT_CTRL_TILE_START + n_regions] = run;
+    ctrl[0] = run;   // tiles of the stream (diagnostics)
+  }
+}
 // Before a pass: the chunk records unowned, the chunk and stream cursors and the chunk index's counters zero; the error flags
 // (p2_ctrl[1], cursor[1]) stay as they are — they are read once, after the last pass.
 extern "C" __global__ void __launch_bounds__(256) pg_oct_pass_reset_kernel(uint32_t* __restrict__ p2_meta, int64_t n_meta, uint32_t* __restrict__ p2_ctrl,
                                                                             uint32_t* __restrict__ cursor) {
   const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = i0; i < n_meta; i += step) p2_meta[i] = 0xFFFFFFFFu;
-  if (i0 == 0) { p2_ctrl[0] = 0; cursor[0] = 0; }
+  if (i0 == 0) p2_ctrl[0] = 0;
+  (void)cursor;
   if (i0 >= PG_P2_CTRL_COUNTS && i0 < PG_P2_CTRL_DWORDS) p2_ctrl[i0] = 0;
 }
 // COUNT row of the final table = sum of the workgroups' counters.  64 consecutive groups per block (coalesced rows), the partial rows

@@ -324,8 +324,30 @@ DEVFN void p2_decode(const PgQueryPlan& p, const P2Raw& raw, const uint32_t (&qi
 }
 // SRC == 3: the docs are the entries of the survivor stream pg_oct_p leaves (pg_kernels_oct.hip): one dword per entry,
 // key << payload bits | payload, PG_RADIX_INVALID_KEY = padding.  A "tile" is 2 048 consecutive entries, a quad four of them.
-DEVFN void p2_issue_stream(const PgQueryPlan& p, const uint32_t (&qi)[P2_QA], int wt, P2Raw& raw) {
-  const GAS uint32_t* tw = gptr<uint32_t>(p.oct_stream) + (size_t)wt * PG_WAVE_DOCS;
+// The stream is one REGION per pg_oct_p workgroup (oct_region entries each, filled from its start; the fill counts sit in the control
+// block): no global cursor — 27 K claims on one address cost 1.6 ms, profiles/r04_c_kernels__cfg5_.txt.  The regions' 2 048-entry tiles are
+// numbered through a prefix array (pg_oct_stream_index_kernel): virtual tile v -> region w = the last with tile_start[w] <= v.
+template <bool ON> struct P2StreamLds { };
+template <> struct P2StreamLds<true> { uint32_t tile_start[PG_OCT_MAX_REGIONS + 4]; };
+struct P2StreamTile { uint32_t base; int32_t n_valid; };
+DEVFN P2StreamTile p2_stream_tile(const PgQueryPlan& p, const uint32_t* tile_start, int v, int n_vtiles) {
+  P2StreamTile r;
+  r.base = 0; r.n_valid = 0;
+  if (v >= n_vtiles) return r;   // wave-uniform
+  int lo = 0, hi = p.oct_n_regions;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((int)tile_start[mid] <= v) lo = mid; else hi = mid;
+  }
+  const uint32_t tile = (uint32_t)v - tile_start[lo];
+  const uint32_t count = gptr<uint32_t>(p.oct_cursor)[PG_OCT_CTRL_COUNTS + lo];
+  const uint32_t left = count - tile * PG_WAVE_DOCS;
+  r.base = (uint32_t)lo * (uint32_t)p.oct_region + tile * PG_WAVE_DOCS;
+  r.n_valid = left >= PG_WAVE_DOCS ? PG_WAVE_DOCS : (int32_t)left;
+  return r;
+}
+DEVFN void p2_issue_stream(const PgQueryPlan& p, const uint32_t (&qi)[P2_QA], uint32_t base, P2Raw& raw) {
+  const GAS uint32_t* tw = gptr<uint32_t>(p.oct_stream) + base;
 #pragma unroll
   for (int u = 0; u < P2_QA; u++) raw.s0[u] = ldnt((const GAS u32x4*)(tw + 4u * qi[u]));
 }
@@ -435,11 +457,15 @@ __device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
   const uint32_t local_mask = (1u << p.radix_shift) - 1u;
   const size_t lo_plane = (size_t)NB * PG_P2_LINE;
   uint32_t* const tuples = p.p2_tuples;
-  int64_t num_docs = (int64_t)p.num_docs;
+  const int64_t num_docs = (int64_t)p.num_docs;
   int n_wtiles = p.n_wtiles;
+  __shared__ P2StreamLds<STREAM> s_stream;
+  const uint32_t* tile_start = reinterpret_cast<const uint32_t*>(&s_stream);
   if (STREAM) {
-    num_docs = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)gptr<uint32_t>(p.oct_cursor)[0]);
-    n_wtiles = (int)((num_docs + PG_WAVE_DOCS - 1) / PG_WAVE_DOCS);
+    uint32_t* ts = reinterpret_cast<uint32_t*>(&s_stream);
+    for (int i = t; i <= p.oct_n_regions; i += P2_THREADS) ts[i] = gptr<uint32_t>(p.oct_cursor)[PG_OCT_CTRL_TILE_START + i];
+    __syncthreads();
+    n_wtiles = (int)tile_start[p.oct_n_regions];   // the stream's tiles, numbered across the regions
   }
   const int n_quartets = (n_wtiles + PG_P2_WAVES - 1) / PG_P2_WAVES;
   // round sequence of this workgroup: (quartet g, quad slots k0 .. k0 + Q - 1), g = blockIdx.x, blockIdx.x + gstride, ...
@@ -454,13 +480,14 @@ __device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
     if ((int)blockIdx.x >= gstride) return;   // workgroup-uniform, before any further barrier
   }
   int g = (int)blockIdx.x;
-  uint32_t m = p2_tile_mask(p, g, n_quartets, wave, lane, n_wtiles, num_docs);
+  P2StreamTile stile = STREAM ? p2_stream_tile(p, tile_start, g * PG_P2_WAVES + wave, g < n_quartets ? n_wtiles : 0) : P2StreamTile{0u, 0};
+  uint32_t m = STREAM ? valid_quad_mask(stile.n_valid, lane) : p2_tile_mask(p, g, n_quartets, wave, lane, n_wtiles, num_docs);
   int k0 = 0;
   P2Raw raw;   // the loads of the round's first batch, requested one round ahead
   if (FAST) {
     uint32_t qi[P2_QA];
     p2_quads_of(lane, m & 0xFFu, 0, qi);
-    if (STREAM) p2_issue_stream(p, qi, p2_tile_of(g, wave, n_wtiles), raw);
+    if (STREAM) p2_issue_stream(p, qi, stile.base, raw);
     else p2_issue(p, qi, p2_tile_of(g, wave, n_wtiles), raw);
   }
   while (g < n_quartets) {   // workgroup-uniform
@@ -476,7 +503,7 @@ __device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
       uint32_t key[P2_QA * 4], dd[T][P2_QA * 4];
       uint32_t vm = 0xFFu;   // stream mode: the batch's entries that are not padding
       if (STREAM) {
-        if (h > 0) p2_issue_stream(p, qi, wt, raw);
+        if (h > 0) p2_issue_stream(p, qi, stile.base, raw);
         vm = p2_decode_stream(p, raw, local_mask, key, reinterpret_cast<uint32_t(&)[1][P2_QA * 4]>(dd));
       } else if (FAST) {
         if (h > 0) p2_issue(p, qi, wt, raw);
@@ -505,11 +532,21 @@ __device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
     // next round: its mask, and (FAST) the loads of its first batch — in flight across the phases below
     int g_next = g, k0_next = k0 + Q;
     uint32_t m_next = m;
-    if (k0_next >= 8) { k0_next = 0; g_next = g + gstride; m_next = p2_tile_mask(p, g_next, n_quartets, wave, lane, n_wtiles, num_docs); }
+    P2StreamTile stile_next = stile;
+    if (k0_next >= 8) {
+      k0_next = 0;
+      g_next = g + gstride;
+      if (STREAM) {
+        stile_next = p2_stream_tile(p, tile_start, g_next * PG_P2_WAVES + wave, g_next < n_quartets ? n_wtiles : 0);
+        m_next = valid_quad_mask(stile_next.n_valid, lane);
+      } else {
+        m_next = p2_tile_mask(p, g_next, n_quartets, wave, lane, n_wtiles, num_docs);
+      }
+    }
     if (FAST) {
       uint32_t qi[P2_QA];
       p2_quads_of(lane, (m_next >> (4 * k0_next)) & 0xFFu, k0_next, qi);
-      if (STREAM) p2_issue_stream(p, qi, p2_tile_of(g_next, wave, n_wtiles), raw);
+      if (STREAM) p2_issue_stream(p, qi, stile_next.base, raw);
       else p2_issue(p, qi, p2_tile_of(g_next, wave, n_wtiles), raw);
     }
     __syncthreads();
@@ -653,7 +690,7 @@ __device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
       }
     }
     // no barrier here: the next round's phase A touches only `hist` (reset in B); its barrier orders D2 before the next B
-    g = g_next; k0 = k0_next; m = m_next;
+    g = g_next; k0 = k0_next; m = m_next; stile = stile_next;
   }
   // ---- epilogue: leftover lines padded with PG_RADIX_INVALID_KEY, the last chunk of every stream recorded with its true fill --------
   __syncthreads();

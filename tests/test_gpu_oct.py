@@ -169,9 +169,9 @@ def test_pruned_offers_skew_and_empty_registers(gpu_api, oracle_api, monkeypatch
     monkeypatch.setenv("PG_OCT_PASSES", "0.05,0.2,1")
     rng = np.random.default_rng(9)
     n = 400_003
-    k1 = rng.integers(0, 200, n).astype(np.int32)
+    k1 = rng.integers(0, 150, n).astype(np.int32)
     k1[rng.random(n) < 0.5] = 17                                    # one heavy group
-    k2 = rng.integers(0, 120, n).astype(np.int32)                    # 200 x 120 = 24 000 keys x 256 registers: beyond LDS
+    k2 = rng.integers(0, 100, n).astype(np.int32)                    # 150 x 100 = 15 000 keys x 256 registers: beyond LDS; counters + floors fit
     v = rng.integers(0, 10**6, n).astype(np.int32)
     v[k2 < 40] = v[k2 < 40] % 5                                      # a third of the groups sees 5 distinct values (floor 0 for ever)
     data = {"k1": k1, "k2": k2, "v": v, "vr": v.copy(), "r": rng.integers(0, 100, n).astype(np.int32)}
