@@ -164,7 +164,10 @@ enum PgAggMode : int32_t {
 #define PG_P2_CTRL_COUNTS 16                                   // [buckets] chunks per bucket
 #define PG_P2_CTRL_STARTS (PG_P2_CTRL_COUNTS + PG_P2_MAX_BUCKETS)        // [buckets + 1] exclusive prefix
 #define PG_P2_CTRL_CURSOR (PG_P2_CTRL_STARTS + PG_P2_MAX_BUCKETS + 16)   // [buckets] fill cursors
-#define PG_P2_CTRL_DWORDS (PG_P2_CTRL_CURSOR + PG_P2_MAX_BUCKETS + 16)
+#define PG_P2_CTRL_STRIPE0 (PG_P2_CTRL_CURSOR + PG_P2_MAX_BUCKETS + 16)   // chunk-id cursors, one per stripe, each in a 128-byte line of its own
+#define PG_P2_STRIPES 64
+#define PG_P2_STRIPE_DWORDS 32
+#define PG_P2_CTRL_DWORDS (PG_P2_CTRL_STRIPE0 + PG_P2_STRIPES * PG_P2_STRIPE_DWORDS)
 #define PG_P2_AGG_THREADS 1024
 // pruned-offer passes (pg_kernels_oct.hip): the survivor stream's control block (dwords)
 #define PG_OCT_MAX_REGIONS 1024
@@ -306,7 +309,10 @@ struct PgQueryPlan {
   int32_t p2;
   int32_t p2_planes;
   int32_t p2_docid_plane;           // plane carrying the docId (MIN(docId) of numGroupsLimit trimming), -1: none
-  int32_t p2_capacity;              // chunks of the tuple area; chunk index p2_capacity is the spill chunk (overflow = internal error)
+  int32_t p2_capacity;              // chunks of the tuple area (= PG_P2_STRIPES x p2_stripe_cap); chunk index p2_capacity is the spill chunk
+                                    // (overflow = internal error).  Chunk ids are handed out per STRIPE: scatter workgroup b claims from the
+                                    // cursor of stripe b % PG_P2_STRIPES, ids stripe x p2_stripe_cap + ... — one cursor for the whole grid
+                                    // serialised the claims at ~60 ns each (profiles/r04_c_kernels__cfg5_.txt)
   int32_t p2_fplane[PG_MAX_RADIX_SRCS];
   int32_t p2_fkind[PG_MAX_RADIX_SRCS];
   int64_t p2_fbias[PG_MAX_RADIX_SRCS];   // PG_P2_F_RAW32 over INT: stored field = value - bias
@@ -381,6 +387,8 @@ struct PgQueryPlan {
   uint32_t* oct_cursor;             // control block: [1] overflow flag, [PG_OCT_CTRL_COUNTS + w] entries region w holds (a multiple of 256),
                                     //   [PG_OCT_CTRL_TILE_START + w] its first 2 048-entry tile in the numbering across the regions
   int64_t oct_stream_cap;           // entries the stream holds (oct_n_regions x oct_region)
+  int32_t p2_stripe_cap;            // chunk ids per stripe
+  int32_t p2_stripe_pad;
   int32_t oct_region;               // entries per region: the docs of a pg_oct_p workgroup in this pass + a padding block per wavefront
   int32_t oct_n_regions;            // regions = workgroups of pg_oct_p in this pass
 };

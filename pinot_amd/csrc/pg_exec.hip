@@ -511,6 +511,18 @@ std::shared_ptr<PinnedBlock> acquire_pinned(size_t bytes) {
   return b;
 }
 
+// Chunk capacity of the partition pipeline's tuple area under the striped allocator: scatter workgroup b claims ids from stripe
+// b % PG_P2_STRIPES, so every stripe must hold what ITS workgroups can need — their share of the tuples (+ 25 %: matches are spread
+// over the interleaved quartets, not perfectly), a partly filled chunk and a padded line per bucket, the ids claimed ahead.
+static size_t p2_stripe_capacity(size_t tuples, int sgrid, int nb, size_t round_tuples, size_t min_wg_tuples) {
+  const size_t stripes_used = (size_t)std::min(sgrid, PG_P2_STRIPES);
+  const size_t wgs_per_stripe = ((size_t)sgrid + stripes_used - 1) / stripes_used;
+  size_t per_wg_tuples = (tuples + (size_t)sgrid - 1) / (size_t)sgrid;
+  per_wg_tuples = std::max(per_wg_tuples + per_wg_tuples / 4 + round_tuples, min_wg_tuples);
+  const size_t per_wg_chunks = per_wg_tuples / PG_P2_CHUNK + 2 * (size_t)nb + PG_P2_BATCH + 8;
+  return wgs_per_stripe * per_wg_chunks;
+}
+
 // ---- pruned-offer passes (pg_kernels_oct.hip, PgQueryPlan::oct == 2) ---------------------------------------------------------------------
 // GROUP BY over a key space whose 32-bit COUNTs fit LDS, with ONE DISTINCTCOUNTHLL whose registers do not (config 5 flat).  The doc space is
 // walked in passes of growing size; per pass: pg_oct_p (COUNT in LDS, offers that cannot raise a register of their group dropped, survivors
@@ -597,7 +609,9 @@ static void run_oct_pruned(CompiledPlan& P, PgQueryPlan& D, ThreadCtx& ctx, cons
   static const int p2_wgs = getenv("PG_P2_WGS_PER_CU") ? atoi(getenv("PG_P2_WGS_PER_CU")) : 4;
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(p2_wgs, 1), (lds_per_cu() - 1024) / (s_lds + 512)));
   const int sgrid_max = num_cus() * per_cu;
-  const size_t cap = stream_cap / PG_P2_CHUNK + 1 + (size_t)sgrid_max * (2 * (size_t)NB + PG_P2_BATCH) + 64;
+  // (a stream scatter workgroup takes at least PG_P2_STREAM_MIN_QUARTETS = 2 quartets of 8 192 entries when the stream is short)
+  const size_t min_wg_tuples = (size_t)2 * PG_P2_WAVES * PG_WAVE_DOCS + round_tuples;
+  const size_t cap = p2_stripe_capacity(stream_cap, sgrid_max, NB, round_tuples, min_wg_tuples) * PG_P2_STRIPES;
   if (cap >= ((size_t)1 << 27)) fail(PG_ERR_UNSUPPORTED, "partition pipeline: %zu chunks", cap);
   D.p2_capacity = (int32_t)cap;
   D.p2_plane_stride = (int64_t)(cap + 1) * PG_P2_CHUNK;
@@ -633,7 +647,10 @@ static void run_oct_pruned(CompiledPlan& P, PgQueryPlan& D, ThreadCtx& ctx, cons
     O.oct_n_regions = ogrid;
     // the survivors go through the partition pipeline (sized for all of the pass's docs; the regions' true fills are read on the device)
     const size_t pass_entries = (size_t)O.oct_region * (size_t)ogrid;
-    const size_t pass_cap = std::min(cap, pass_entries / PG_P2_CHUNK + 1 + (size_t)sgrid_max * (2 * (size_t)NB + PG_P2_BATCH) + 64);
+    const int quartets = (int)((pass_entries / PG_WAVE_DOCS + PG_P2_WAVES) / PG_P2_WAVES);
+    const int sgrid = std::max(1, std::min(quartets, sgrid_max));
+    const size_t pass_stripe_cap = std::min(cap / PG_P2_STRIPES, p2_stripe_capacity(pass_entries, sgrid, NB, round_tuples, min_wg_tuples));
+    const size_t pass_cap = pass_stripe_cap * PG_P2_STRIPES;
     hipLaunchKernelGGL(pg_oct_pass_reset_kernel, dim3((unsigned)std::min<size_t>(1024, (pass_cap + 255) / 256 + 2)), dim3(256), 0, ctx.stream,
                        ctx.p2_meta.as<uint32_t>(), (int64_t)pass_cap, ctx.p2_ctrl.as<uint32_t>(), ctx.oct_cursor.as<uint32_t>());
     hipLaunchKernelGGL(D.match_words ? pg_oct_pm : pg_oct_p, dim3(ogrid), dim3(PG_BLOCK), o_lds, ctx.stream, O);
@@ -644,12 +661,14 @@ static void run_oct_pruned(CompiledPlan& P, PgQueryPlan& D, ThreadCtx& ctx, cons
     S.match_words = nullptr;
     S.n_ops = 0;   // COUNT is pg_oct_p's: the aggregation pass sees HyperLogLog offers only
     S.p2_capacity = (int32_t)pass_cap;
+    S.p2_stripe_cap = (int32_t)pass_stripe_cap;
     // later passes keep a fraction of their offers (floors): fewer aggregation slices for them (the scatter sizes itself on the device)
     const double keep = pass == 0 ? 1.0 : (pass == 1 ? 0.75 : 0.25);
     const size_t est = (size_t)((double)tiles * PG_WAVE_DOCS * keep) + 1;
-    const int quartets = (int)((pass_entries / PG_WAVE_DOCS + PG_P2_WAVES) / PG_P2_WAVES);
-    const int sgrid = std::max(1, std::min(quartets, sgrid_max));
-    S.radix_slices = (int)std::max<size_t>(1, std::min<size_t>((size_t)slices_max, est / ((size_t)NB * 65536)));
+    // every pass takes all the slices: a short stream still leaves a chunk or two per (scatter workgroup, bucket), and a work item walks
+    // its chunks one wavefront each — 157 work items over 490 half-empty chunks took 157 us (profiles/r04_d_kernels__cfg5_.txt)
+    (void)est;
+    S.radix_slices = slices_max;
     hipLaunchKernelGGL(pg_p2_scatter_stream, dim3(sgrid), dim3(PG_P2_WAVES * 64), s_lds, ctx.stream, S);
     PG_HIP(hipGetLastError());
     const int igrid = (int)std::max<size_t>(1, std::min<size_t>((size_t)num_cus(), (pass_cap + 4095) / 4096));
@@ -857,9 +876,11 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
     const int sgrid = std::max(1, std::min(quartets, num_cus() * per_cu));
     // chunks: the tuples themselves, one partly filled chunk + one padded line per (workgroup, bucket), the ids a workgroup claimed
     // ahead and did not use
-    const size_t cap = (size_t)(matched_now / PG_P2_CHUNK) + 1 + (size_t)sgrid * (2 * (size_t)NB + PG_P2_BATCH) + 64;
+    const size_t stripe_cap = p2_stripe_capacity((size_t)matched_now, sgrid, NB, round_tuples, 0);
+    const size_t cap = stripe_cap * PG_P2_STRIPES;
     if (cap >= ((size_t)1 << 27)) fail(PG_ERR_UNSUPPORTED, "partition pipeline: %zu chunks", cap);
     D.p2_capacity = (int32_t)cap;
+    D.p2_stripe_cap = (int32_t)stripe_cap;
     D.p2_plane_stride = (int64_t)(cap + 1) * PG_P2_CHUNK;
     ThreadCtx::grow(ctx.radix_tuples, (size_t)D.p2_plane_stride * 4 * (size_t)T + 256);
     ThreadCtx::grow(ctx.p2_meta, cap * 4 + 64);

@@ -434,6 +434,15 @@ DEVFN void p2_quads_of(int lane, uint32_t mb8, int kq, uint32_t (&qi)[P2_QA]) {
   for (int u = 0; u < P2_QA; u++) qi[u] = ((mb8 >> (4 * u)) & 0xFu) ? (uint32_t)((kq + u) * 64 + lane) : 0u;
 }
 
+// PG_P2_BATCH chunk ids from this workgroup's stripe into the LDS ring (wavefront 0); ids beyond the stripe become the spill chunk
+DEVFN void p2_claim_batch(const PgQueryPlan& p, uint32_t* pool, uint32_t tail, int lane) {
+  const uint32_t stripe = blockIdx.x & (PG_P2_STRIPES - 1u), cap_s = (uint32_t)p.p2_stripe_cap;
+  uint32_t basec = 0;
+  if (lane == 0) basec = atomicAdd(p.p2_ctrl + PG_P2_CTRL_STRIPE0 + stripe * PG_P2_STRIPE_DWORDS, (uint32_t)PG_P2_BATCH);
+  basec = (uint32_t)__builtin_amdgcn_readfirstlane((int)basec);
+  for (uint32_t i = (uint32_t)lane; i < PG_P2_BATCH; i += 64u)
+    pool[(tail + i) & (PG_P2_POOL - 1u)] = basec + i < cap_s ? stripe * cap_s + basec + i : (uint32_t)p.p2_capacity;
+}
 template <int T, int Q, bool FAST, int SRC>
 __device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
   extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
@@ -570,10 +579,7 @@ __device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
         uint32_t tail = S.ctrl[1];
         if (need > PG_P2_POOL - PG_P2_BATCH) need = PG_P2_POOL - PG_P2_BATCH;   // at most R / CHUNK + buckets (272)
         while (tail - head < need) {   // wave-uniform
-          uint32_t basec = 0;
-          if (lane == 0) basec = atomicAdd(p.p2_ctrl, (uint32_t)PG_P2_BATCH);
-          basec = (uint32_t)__builtin_amdgcn_readfirstlane((int)basec);
-          for (uint32_t i = (uint32_t)lane; i < PG_P2_BATCH; i += 64u) S.pool[(tail + i) & (PG_P2_POOL - 1u)] = basec + i;
+          p2_claim_batch(p, S.pool, tail, lane);
           tail += PG_P2_BATCH;
         }
         if (lane == 0) S.ctrl[1] = tail;
@@ -698,10 +704,7 @@ __device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
     const uint32_t head = S.ctrl[0];
     uint32_t tail = S.ctrl[1];
     while (tail - head < (uint32_t)NB) {
-      uint32_t basec = 0;
-      if (lane == 0) basec = atomicAdd(p.p2_ctrl, (uint32_t)PG_P2_BATCH);
-      basec = (uint32_t)__builtin_amdgcn_readfirstlane((int)basec);
-      for (uint32_t i = (uint32_t)lane; i < PG_P2_BATCH; i += 64u) S.pool[(tail + i) & (PG_P2_POOL - 1u)] = basec + i;
+      p2_claim_batch(p, S.pool, tail, lane);
       tail += PG_P2_BATCH;
     }
     if (lane == 0) S.ctrl[1] = tail;
@@ -755,8 +758,7 @@ extern "C" __global__ void __launch_bounds__(1024) pg_p2_index_count_kernel(cons
   const int t = threadIdx.x;
   if (t < PG_P2_MAX_BUCKETS) s_hist[t] = 0;
   __syncthreads();
-  uint32_t n_alloc = p.p2_ctrl[0];
-  if (n_alloc > (uint32_t)p.p2_capacity) n_alloc = (uint32_t)p.p2_capacity;
+  const uint32_t n_alloc = (uint32_t)p.p2_capacity;   // ids are handed out per stripe: the records of unclaimed ids stay 0xFFFFFFFF
   for (uint32_t i = blockIdx.x * 1024u + (uint32_t)t; i < n_alloc; i += gridDim.x * 1024u) {
     const uint32_t mt = p.p2_meta[i];
     if ((mt & 0xFFFFu) < (uint32_t)p.radix_buckets && (mt >> 16) != 0) atomicAdd(&s_hist[mt & 0xFFFFu], 1u);
@@ -782,8 +784,7 @@ extern "C" __global__ void __launch_bounds__(PG_P2_MAX_BUCKETS) pg_p2_index_scan
 extern "C" __global__ void __launch_bounds__(1024) pg_p2_index_fill_kernel(const PgQueryPlan p) {
   __shared__ uint32_t s_hist[PG_P2_MAX_BUCKETS], s_base[PG_P2_MAX_BUCKETS];
   const int t = threadIdx.x;
-  uint32_t n_alloc = p.p2_ctrl[0];
-  if (n_alloc > (uint32_t)p.p2_capacity) n_alloc = (uint32_t)p.p2_capacity;
+  const uint32_t n_alloc = (uint32_t)p.p2_capacity;   // ids are handed out per stripe: the records of unclaimed ids stay 0xFFFFFFFF
   // the workgroup's share of the records is a contiguous range: count, claim one range per bucket, then place
   const uint32_t per = (n_alloc + gridDim.x - 1u) / gridDim.x;
   const uint32_t lo = blockIdx.x * per;
