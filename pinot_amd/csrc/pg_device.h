@@ -388,7 +388,7 @@ struct PgQueryPlan {
                                     //   [PG_OCT_CTRL_TILE_START + w] its first 2 048-entry tile in the numbering across the regions
   int64_t oct_stream_cap;           // entries the stream holds (oct_n_regions x oct_region)
   int32_t p2_stripe_cap;            // chunk ids per stripe
-  int32_t p2_stripe_pad;
+  int32_t p2_byte_regs;             // 1: the aggregation pass keeps HyperLogLog registers as bytes and no accumulator table (pruned-offer passes)
   int32_t oct_region;               // entries per region: the docs of a pg_oct_p workgroup in this pass + a padding block per wavefront
   int32_t oct_n_regions;            // regions = workgroups of pg_oct_p in this pass
 };

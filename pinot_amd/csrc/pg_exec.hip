@@ -36,7 +36,7 @@ PG_DECL_FAST(pg_p2_scatter_1f) PG_DECL_FAST(pg_p2_scatter_2f) PG_DECL_FAST(pg_p2
 PG_DECL_FAST(pg_p2_aggregate_1) PG_DECL_FAST(pg_p2_aggregate_2) PG_DECL_FAST(pg_p2_aggregate_3) PG_DECL_FAST(pg_p2_aggregate_4)
 PG_DECL_FAST(pg_p2_aggregate_1n) PG_DECL_FAST(pg_p2_aggregate_2n) PG_DECL_FAST(pg_p2_aggregate_3n) PG_DECL_FAST(pg_p2_aggregate_4n)
 PG_DECL_FAST(pg_p2_index_count_kernel) PG_DECL_FAST(pg_p2_index_scan_kernel) PG_DECL_FAST(pg_p2_index_fill_kernel)
-PG_DECL_FAST(pg_p2_scatter_stream)
+PG_DECL_FAST(pg_p2_scatter_stream) PG_DECL_FAST(pg_p2_aggregate_1b)
 // pg_kernels_oct.hip: oct-layout DISTINCTCOUNTHLL / DISTINCTCOUNT kernels (LDS-resident states; pruned offers) and their small helpers
 PG_DECL_FAST(pg_oct_l) PG_DECL_FAST(pg_oct_lm) PG_DECL_FAST(pg_oct_p) PG_DECL_FAST(pg_oct_pm)
 extern "C" __global__ void pg_oct_merge_floor_kernel(const uint32_t* partials, uint32_t* regs, uint8_t* floors, int n_groups, int log2m, int radix_shift,
@@ -677,7 +677,7 @@ static void run_oct_pruned(CompiledPlan& P, PgQueryPlan& D, ThreadCtx& ctx, cons
     hipLaunchKernelGGL(pg_p2_index_fill_kernel, dim3(igrid), dim3(1024), 0, ctx.stream, S);
     PG_HIP(hipGetLastError());
     const int agrid = std::min(NB * S.radix_slices, num_cus());
-    hipLaunchKernelGGL(pg_p2_aggregate_1n, dim3(agrid), dim3(PG_P2_AGG_THREADS), P.lds_bytes + 64, ctx.stream, S);
+    hipLaunchKernelGGL(D.p2_byte_regs ? pg_p2_aggregate_1b : pg_p2_aggregate_1n, dim3(agrid), dim3(PG_P2_AGG_THREADS), P.lds_bytes + 64, ctx.stream, S);
     PG_HIP(hipGetLastError());
     hipLaunchKernelGGL(pg_oct_merge_floor_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, ctx.stream, S.aux[0].base, aux_final[0],
                        ctx.oct_floor.as<uint8_t>(), (int)G, D.aux[0].log2m, D.radix_shift, S.radix_slices);
@@ -760,7 +760,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
   }
   // oct-layout kernels (pg_kernels_oct.hip): one 16-wavefront workgroup per CU, no tile splitting
   static const bool no_oct = getenv("PG_NO_OCT_EXEC") != nullptr;   // measurement knob: plans keep D.oct, the round-3 kernels run them
-  const bool oct_lds = D.oct == 1 && !no_oct, oct_pruned = D.oct == 2 && !no_oct && D.agg_mode == PG_AGG_RADIX && D.p2;
+  const bool oct_lds = D.oct == 1 && !no_oct, oct_pruned = D.oct == 2 && (!no_oct || D.p2_byte_regs) && D.agg_mode == PG_AGG_RADIX && D.p2;
   if (oct_lds) split_shift = 0;
   D.tile_split_shift = split_shift;
   LaunchShape shape = launch_shape(P, P.dev.n_wtiles << split_shift, D.agg_mode);

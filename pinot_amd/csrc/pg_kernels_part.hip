@@ -956,3 +956,95 @@ P2_AGGREGATE(pg_p2_aggregate_1n, 1, false)
 P2_AGGREGATE(pg_p2_aggregate_2n, 2, false)
 P2_AGGREGATE(pg_p2_aggregate_3n, 3, false)
 P2_AGGREGATE(pg_p2_aggregate_4n, 4, false)
+
+// ---- aggregation pass of the pruned-offer passes (pg_kernels_oct.hip): HyperLogLog offers only (COUNT is kept by pg_oct_p), registers as
+// BYTES — 512 groups x 256 registers per bucket instead of 82 as dwords, i.e. 25 buckets instead of 157 for config 5: the stream scatter
+// fills whole lines and chunks, the chunk lists are short.  A survivor beat its group's floor but mostly not its own register: the
+// register's dword is read first (four tuples per lane in flight), compare-and-swapped only where the rank is higher, and a lost CAS
+// (another writer of the dword) is retried serially — rare.
+DEVFN void p2_raise_byte(uint32_t* words, uint32_t byte_addr, uint32_t rank) {
+  uint32_t* w = words + (byte_addr >> 2);
+  const uint32_t sh = (byte_addr & 3u) * 8u;
+  uint32_t cur = *reinterpret_cast<volatile uint32_t*>(w);
+  while (((cur >> sh) & 0xFFu) < rank) {
+    const uint32_t nv = (cur & ~(0xFFu << sh)) | (rank << sh);
+    const uint32_t prev = atomicCAS(w, cur, nv);
+    if (prev == cur) break;
+    cur = prev;
+  }
+}
+DEVFN void p2_consume_bytes(const PgQueryPlan& p, const u32x4 cur, bool on, uint32_t* words, uint32_t local_mask) {
+  const uint32_t log2m = (uint32_t)p.aux[0].log2m, imask = (1u << log2m) - 1u, sh0 = (uint32_t)p.pk_shift[0], fmask = (1u << p.pk_bits[0]) - 1u;
+  const uint32_t t4[4] = {cur.x, cur.y, cur.z, cur.w};
+  uint32_t addr[4], rank[4], w[4];
+  uint32_t valid = 0;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const bool v = on && t4[e] != PG_RADIX_INVALID_KEY;
+    valid |= (uint32_t)v << e;
+    const uint32_t f = (t4[e] >> sh0) & fmask;
+    addr[e] = v ? (((t4[e] & local_mask) << log2m) + (f & imask)) : 0u;
+    rank[e] = f >> log2m;
+  }
+  volatile uint32_t* vw = words;
+#pragma unroll
+  for (int e = 0; e < 4; e++) w[e] = vw[addr[e] >> 2];
+  uint32_t need = 0;
+#pragma unroll
+  for (int e = 0; e < 4; e++) need |= (uint32_t)(((valid >> e) & 1u) && rank[e] > ((w[e] >> ((addr[e] & 3u) * 8u)) & 0xFFu)) << e;
+  if (__builtin_amdgcn_ballot_w64(need != 0) == 0) return;   // wave-uniform
+  uint32_t prev[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    prev[e] = w[e];
+    if ((need >> e) & 1u) {
+      const uint32_t sh = (addr[e] & 3u) * 8u;
+      prev[e] = atomicCAS(words + (addr[e] >> 2), w[e], (w[e] & ~(0xFFu << sh)) | (rank[e] << sh));
+    }
+  }
+  uint32_t again = 0;
+#pragma unroll
+  for (int e = 0; e < 4; e++) again |= (uint32_t)(((need >> e) & 1u) && prev[e] != w[e] && ((prev[e] >> ((addr[e] & 3u) * 8u)) & 0xFFu) < rank[e]) << e;
+  if (__builtin_amdgcn_ballot_w64(again != 0) == 0) return;
+#pragma unroll
+  for (int e = 0; e < 4; e++)
+    if ((again >> e) & 1u) p2_raise_byte(words, addr[e], rank[e]);
+}
+extern "C" __global__ void __launch_bounds__(PG_P2_AGG_THREADS) pg_p2_aggregate_1b(const PgQueryPlan p) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = uniform(t >> 6);
+  constexpr uint32_t WAVES = PG_P2_AGG_THREADS / 64;
+  const uint32_t slots = 1u << p.radix_shift, local_mask = slots - 1u;
+  uint32_t* const words = reinterpret_cast<uint32_t*>(smem);
+  const uint32_t n_words = (slots << p.aux[0].log2m) >> 2;   // one byte per register
+  uint32_t* const list = words + n_words;
+  const int n_items = p.radix_buckets * p.radix_slices;
+  const GAS uint32_t* const tuples = gptr<uint32_t>(p.p2_tuples);
+  for (int w = (int)blockIdx.x; w < n_items; w += (int)gridDim.x) {
+    const uint32_t b = (uint32_t)(w / p.radix_slices), sl = (uint32_t)(w % p.radix_slices);
+    for (uint32_t i = (uint32_t)t; i < n_words; i += PG_P2_AGG_THREADS) words[i] = 0u;
+    const uint32_t bstart = gptr<uint32_t>(p.p2_ctrl)[PG_P2_CTRL_STARTS + b], bend = gptr<uint32_t>(p.p2_ctrl)[PG_P2_CTRL_STARTS + b + 1];
+    const uint32_t per = (bend - bstart + (uint32_t)p.radix_slices - 1u) / (uint32_t)p.radix_slices;
+    const uint32_t lo_i = bstart + sl * per;
+    uint32_t hi_i = lo_i + per;
+    if (hi_i > bend) hi_i = bend;
+    for (uint32_t win = lo_i; win < hi_i; win += PG_P2_LIST) {
+      __syncthreads();   // the registers are zeroed / the previous window's list is done with
+      const uint32_t n_list = hi_i - win < PG_P2_LIST ? hi_i - win : PG_P2_LIST;
+      for (uint32_t i = (uint32_t)t; i < n_list; i += PG_P2_AGG_THREADS) list[i] = gptr<uint32_t>(p.p2_list)[win + i];
+      __syncthreads();
+      u32x4 c0[1], c1[1];   // two chunks per wavefront in flight, no register rotation (see p2_aggregate_body)
+      bool on0 = p2_fetch<1>(tuples, 0, list, n_list, (uint32_t)wave, lane, c0), on1 = false;
+      for (uint32_t ci = (uint32_t)wave; ci < n_list; ci += 2u * WAVES) {
+        on1 = p2_fetch<1>(tuples, 0, list, n_list, ci + WAVES, lane, c1);
+        p2_consume_bytes(p, c0[0], on0, words, local_mask);
+        on0 = p2_fetch<1>(tuples, 0, list, n_list, ci + 2u * WAVES, lane, c0);
+        p2_consume_bytes(p, c1[0], ci + WAVES < n_list ? on1 : false, words, local_mask);
+      }
+    }
+    __syncthreads();
+    uint32_t* dst = p.aux[0].base + (int64_t)w * n_words;
+    for (uint32_t i = (uint32_t)t; i < n_words; i += PG_P2_AGG_THREADS) dst[i] = words[i];
+    __syncthreads();
+  }
+}

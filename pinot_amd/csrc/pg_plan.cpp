@@ -1014,8 +1014,25 @@ static void plan_oct(CompiledPlan& P, PgQueryPlan& D, const std::vector<Column*>
   const int64_t min_docs = getenv("PG_OCT_MIN_DOCS") ? atoll(getenv("PG_OCT_MIN_DOCS")) : ((int64_t)1 << 20);
   if (D.agg_mode == PG_AGG_RADIX && D.p2 && D.p2_planes == 1 && kind != 4 && D.n_group_cols >= 1 && total_docs >= min_docs &&
       G * 4 + ((G + 3) & ~(int64_t)3) + 16 * 4096 + 512 <= 156 * 1024 &&   /* counters + floors + the wavefronts' survivor rings */ G < ((int64_t)1 << (31 - (A.log2m + 5))) && D.pk_bits[0] == A.log2m + 5 &&
-      D.p2_fkind[0] == PG_P2_F_HLL && !getenv("PG_NO_OCT_PRUNE"))
+      D.p2_fkind[0] == PG_P2_F_HLL && !getenv("PG_NO_OCT_PRUNE")) {
     D.oct = 2;
+    // The aggregation pass of the pruned passes sees HyperLogLog offers only (COUNT stays in pg_oct_p's LDS table) and keeps the registers
+    // as BYTES: a bucket is as many groups as fill the LDS with one byte per register — 512 groups x 256 registers, 25 buckets for
+    // config 5 instead of 157 with an accumulator slot and dword registers per group.  Re-cut the key accordingly.
+    if (!getenv("PG_OCT_DWORD_REGS")) {
+      const int64_t budget = kLdsTableBudget - (int64_t)PG_P2_LIST * 4 - 256;
+      int shift = 0;
+      while (shift < 24 && ((int64_t)2 << shift) * (int64_t)A.stride <= budget && shift + 1 + (A.log2m + 5) <= 31) shift++;
+      const int64_t nb = (G + ((int64_t)1 << shift) - 1) >> shift;
+      if (shift > D.radix_shift && nb >= 1) {
+        D.radix_shift = shift;
+        D.radix_buckets = (int32_t)nb;
+        D.pk_shift[0] = shift;   // plane 0: the local key's bits, then the (index, rank) field
+        D.p2_byte_regs = 1;
+        P.lds_bytes = ((size_t)A.stride << shift) + (size_t)PG_P2_LIST * 4;
+      }
+    }
+  }
 }
 
 // Partition pipeline v2 (pg_kernels_part.hip) for a PG_AGG_RADIX plan: bit-packs what the aggregation pass needs from a doc into

@@ -5,6 +5,8 @@ PASSES = [
     ["SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_WAVES", "SQ_BUSY_CYCLES"],
 ]
 setname, only, docs = sys.argv[1], sys.argv[2], sys.argv[3]
+per_dispatch = sys.argv[4] if len(sys.argv) > 4 else ""   # kernel name: its counters dispatch by dispatch (last 8 dispatches)
+per = {}
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {}
 for counters in PASSES:
@@ -18,8 +20,15 @@ for counters in PASSES:
     db = sqlite3.connect(dbs[0])
     for k, c, v, n in db.execute("select kernel_name, counter_name, sum(value), count(distinct dispatch_id) from counters_collection where kernel_name like 'pg_%' group by kernel_name, counter_name"):
         out.setdefault(k, {})[c] = v / max(n, 1)
+    if per_dispatch:
+        for did, c, v in db.execute("select dispatch_id, counter_name, sum(value) from counters_collection where kernel_name = ? group by dispatch_id, counter_name order by dispatch_id", (per_dispatch,)):
+            per.setdefault(c, []).append(v)
     shutil.rmtree(d, ignore_errors=True)
 for k, cs in sorted(out.items()):
     print(k)
     for c, v in cs.items():
         print(f"    {c:24s} {v:16.0f}")
+if per_dispatch:
+    print("per dispatch (last 8):", per_dispatch)
+    for c, vs in per.items():
+        print(f"    {c:24s} " + " ".join(f"{v:13.0f}" for v in vs[-8:]))
