@@ -70,7 +70,16 @@ typedef enum pg_fwd_encoding {
    * fixed-byte format, each chunk = numDocsPerChunk big-endian int offsets relative to the chunk start (0 for the absent rows of the
    * last chunk) followed by the values back to back.  PASS_THROUGH chunks only on the GPU path.  Such a column can be a GROUP BY key
    * (NoDictionarySingleColumnGroupKeyGenerator.java:132-140 / NoDictionaryMultiColumnGroupKeyGenerator's on-the-fly dictionaries). */
-  PG_FWD_RAW_VAR_BYTE_CHUNK = 4
+  PG_FWD_RAW_VAR_BYTE_CHUNK = 4,
+  /* FixedByteChunkMVForwardIndexReader (raw, i.e. no-dictionary, multi-value column of INT / LONG / FLOAT / DOUBLE, writer versions
+   * 2 and 3 — .../readers/forward/FixedByteChunkMVForwardIndexReader.java:35-140, written by MultiValueFixedByteRawIndexCreator through
+   * VarByteChunkForwardIndexWriter#putIntMV ...): the var-byte chunk layout above whose value of doc d is
+   * ArraySerDeUtils.serialize…ArrayWithLength = big-endian int numValues, then the values big-endian.  total_number_of_entries as for
+   * PG_FWD_DICT_FIXED_BIT_MV.  PASS_THROUGH, LZ4, LZ4_LENGTH_PREFIXED, ZSTANDARD and GZIP chunks (decoded on the host at registration);
+   * V4 / V5 chunk formats (VarByteChunkForwardIndexReaderV4) and SNAPPY are refused with PG_ERR_UNSUPPORTED.  The column answers
+   * multi-value filters, GROUP BY keys and the *MV aggregations exactly like its dictionary-encoded twin would
+   * (MultiValueRawQueriesTest asserts that equality query by query); DISTINCTCOUNTMV over it stays with the Java plan. */
+  PG_FWD_RAW_MV_FIXED_BYTE_CHUNK = 5
 } pg_fwd_encoding;
 
 typedef struct pg_buffer {

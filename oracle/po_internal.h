@@ -97,6 +97,8 @@ typedef struct po_column {
   const uint8_t* range_idx; uint64_t range_len;   /* DataSource#getRangeIndex: BitSlicedRangeIndexReader bytes, NULL if none */
   /* FixedBitMVForwardIndexReader fields (PG_FWD_DICT_FIXED_BIT_MV): _numValues, _numDocsPerChunk, the three views of the buffer,
    * and ColumnMetadata#getMaxNumberOfMultiValues (found by one walk over the row-start bitmap when the column is added) */
+  int32_t raw_mv;            /* the column came as a raw multi-value forward index (FixedByteChunkMVForwardIndexReader): see po_raw_mv_attach */
+  uint8_t* mv_owned_fwd; uint8_t* mv_owned_dict;
   int32_t is_mv, total_entries, mv_docs_per_chunk, mv_max_values;
   const uint8_t* mv_chunk_offsets; const uint8_t* mv_bitmap; const uint8_t* mv_raw;
 } po_column;
@@ -136,6 +138,7 @@ void po_fwd_read_dict_ids(const po_column* c, const int32_t* doc_ids, int32_t le
 typedef struct po_mv_ctx { int32_t doc_id, end_offset; } po_mv_ctx;
 #define PO_MV_CTX_INIT {-1, 0}
 int po_mv_parse(po_column* c);
+int po_raw_mv_attach(po_column* c);
 int32_t po_mv_get_dict_ids(const po_column* c, int32_t doc_id, int32_t* buf, po_mv_ctx* ctx);
 /* FixedByteChunkSVForwardIndexReader#getInt/getLong/getFloat/getDouble (PASS_THROUGH) */
 int32_t po_raw_get_int(const po_column* c, int32_t doc_id);

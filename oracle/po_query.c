@@ -69,6 +69,16 @@ int32_t po_segment_add_column(void* segp, const pg_column_desc* d) {
   c->inv_len = d->inverted_index.size;
   c->num_docs = seg->total_docs;
   if ((c->fwd_encoding == PG_FWD_RAW_FIXED_BYTE_CHUNK || c->fwd_encoding == PG_FWD_RAW_VAR_BYTE_CHUNK) && po_raw_parse_header(c)) return PG_ERR_UNSUPPORTED;
+  if (c->fwd_encoding == PG_FWD_RAW_MV_FIXED_BYTE_CHUNK) {   /* FixedByteChunkMVForwardIndexReader: po_readers.c */
+    if (po_raw_mv_attach(c)) return PG_ERR_INVALID_ARGUMENT;
+    if (d->total_number_of_entries > 0 && d->total_number_of_entries != c->total_entries) {
+      po_set_error("raw multi-value index of %s holds %d entries, the metadata says %d", c->name, c->total_entries, d->total_number_of_entries);
+      return PG_ERR_INVALID_ARGUMENT;
+    }
+    seg->columns = (po_column**)po_xrealloc(seg->columns, sizeof(po_column*) * (size_t)(seg->n_columns + 1));
+    seg->columns[seg->n_columns++] = c;
+    return PG_OK;
+  }
   if (c->fwd_encoding == PG_FWD_DICT_FIXED_BIT_MV) {
     c->total_entries = d->total_number_of_entries;
     if (!c->has_dictionary) { po_set_error("raw multi-value column %s is outside the hot path", c->name); return PG_ERR_UNSUPPORTED; }
@@ -131,6 +141,8 @@ int32_t po_segment_destroy(void* segp) {
     free(seg->columns[i]->name);
     if (seg->columns[i]->null_bitmap) po_bitmap_free(seg->columns[i]->null_bitmap);
     free(seg->columns[i]->raw_owned);
+    free(seg->columns[i]->mv_owned_fwd);
+    free(seg->columns[i]->mv_owned_dict);
     free(seg->columns[i]);
   }
   if (seg->queryable_doc_ids) po_bitmap_free(seg->queryable_doc_ids);
@@ -1085,6 +1097,10 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
       po_set_error("DISTINCTCOUNT over a raw column is outside the hot path");
       return PG_ERR_UNSUPPORTED;
     }
+    if (c->raw_mv && sv_function_of(s->function) == PG_AGG_DISTINCTCOUNT) {   /* its intermediate is a VALUE set: not built (po_raw_mv_attach) */
+      po_set_error("DISTINCTCOUNTMV over the raw multi-value column %s is outside the hot path", c->name);
+      return PG_ERR_UNSUPPORTED;
+    }
     if (is_mv_function(s->function) != (c->is_mv != 0)) {   /* BlockValSet#getDoubleValuesSV / MV on the wrong kind of column throws */
       po_set_error("aggregation %d over %s column %s", s->function, c->is_mv ? "multi-value" : "single-value", c->name);
       return PG_ERR_INVALID_ARGUMENT;
@@ -1137,7 +1153,7 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
       int f = sv_function_of(aggs[i].function);   /* DICTIONARY_BASED_FUNCTIONS holds MINMV / MAXMV / MINMAXRANGEMV / DISTINCTCOUNT(HLL)MV as well */
       if (aggs[i].function == PG_AGG_COUNT) continue;
       if (aggs[i].function == PG_AGG_COUNTMV || aggs[i].function == PG_AGG_SUMMV || aggs[i].function == PG_AGG_AVGMV) { fit = 0; break; }
-      fit = aggs[i].col->has_dictionary && (f == PG_AGG_MIN || f == PG_AGG_MAX || f == PG_AGG_MINMAXRANGE ||
+      fit = aggs[i].col->has_dictionary && !aggs[i].col->raw_mv && (f == PG_AGG_MIN || f == PG_AGG_MAX || f == PG_AGG_MINMAXRANGE ||
                                             f == PG_AGG_DISTINCTCOUNT || f == PG_AGG_DISTINCTCOUNTHLL) &&
             (aggs[i].col->data_type <= PG_TYPE_DOUBLE || f == PG_AGG_DISTINCTCOUNT || f == PG_AGG_DISTINCTCOUNTHLL);
     }

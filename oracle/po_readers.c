@@ -262,6 +262,109 @@ const uint8_t* po_raw_get_bytes(const po_column* c, int32_t doc_id, int32_t* len
   return b + start;
 }
 
+/* ---- FixedByteChunkMVForwardIndexReader (raw multi-value column of INT / LONG / FLOAT / DOUBLE) --------------------------------
+ * pinot-segment-local/.../readers/forward/FixedByteChunkMVForwardIndexReader.java:35-140: slice(docId) is the var-byte chunk value of the
+ * doc (sliceBytesUncompressed :118-131 = the offsets walk of po_raw_get_bytes above; compressed chunks through getChunkBuffer), and
+ * ArraySerDeUtils.deserialize…ArrayWithLength reads a big-endian int numValues followed by the values big-endian
+ * (pinot-segment-local/.../utils/ArraySerDeUtils.java); getNumValuesMV = slice.getInt().
+ *
+ * The oracle's multi-value operators (mvscan_*, gkg_generate_mv, the *MV branches of agg_process_block) are written over dictIds.  A raw
+ * column is attached to them through an equivalent dictionary encoding built here from the values this reader returns — sorted distinct
+ * values (the order SegmentDictionaryCreator would give them) and the docs' ids in FixedBitMVForwardIndexReader's layout — instead of a
+ * second copy of those operators over raw values.  What this does NOT restate separately are the raw-value predicate evaluators and the
+ * NoDictionary…GroupKeyGenerators over multi-value blocks: their RESULTS are pinned by MultiValueRawQueriesTest, which asserts raw ==
+ * dictionary twin for every query it runs (tests/test_mv_reference_goldens.py).  `raw_mv` keeps the two differences that are visible:
+ * no NonScanBasedAggregationOperator (no dictionary to answer from), DISTINCTCOUNTMV refused (its intermediate is a VALUE set). */
+static uint64_t raw_mv_key(int32_t data_type, const uint8_t* p) {   /* order-preserving 64-bit image of a stored value */
+  if (data_type == PG_TYPE_INT) return (uint64_t)(int64_t)(int32_t)po_be32(p) ^ (1ULL << 63);
+  if (data_type == PG_TYPE_LONG) return po_be64(p) ^ (1ULL << 63);
+  if (data_type == PG_TYPE_FLOAT) { const uint32_t f = po_be32(p); return (f >> 31) ? (uint64_t)(uint32_t)~f : (uint64_t)(f ^ 0x80000000u); }
+  const uint64_t f = po_be64(p);
+  return (f >> 63) ? ~f : (f ^ (1ULL << 63));
+}
+static int cmp_u64(const void* a, const void* b) {
+  const uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+int po_raw_mv_attach(po_column* c) {
+  if (c->has_dictionary || c->data_type > PG_TYPE_DOUBLE) { po_set_error("column %s: raw multi-value index of a dictionary / non-numeric column", c->name); return -1; }
+  if (po_raw_parse_header(c)) return -1;
+  const int width = (c->data_type == PG_TYPE_INT || c->data_type == PG_TYPE_FLOAT) ? 4 : 8;
+  const int32_t n_docs = c->num_docs;
+  if (n_docs <= 0) { po_set_error("raw multi-value column %s of %d docs", c->name, n_docs); return -1; }
+  /* pass 1: getNumValuesMV of every doc */
+  int64_t total = 0;
+  int32_t* starts = (int32_t*)po_xcalloc((size_t)n_docs + 1, sizeof(int32_t));
+  for (int32_t d = 0; d < n_docs; d++) {
+    int32_t len = 0;
+    const uint8_t* v = po_raw_get_bytes(c, d, &len);
+    if (len < 4) { free(starts); po_set_error("raw multi-value index of %s: doc %d has %d bytes", c->name, d, len); return -1; }
+    const int64_t n = (int64_t)(int32_t)po_be32(v);
+    if (n <= 0 || n * width + 4 != len) { free(starts); po_set_error("raw multi-value index of %s: doc %d: %lld values in %d bytes", c->name, d, (long long)n, len); return -1; }
+    starts[d] = (int32_t)total;
+    total += n;
+  }
+  starts[n_docs] = (int32_t)total;
+  /* pass 2: the values (deserialize…ArrayWithLength) as keys; dictionary = sorted distinct */
+  uint64_t* keys = (uint64_t*)po_xcalloc((size_t)total, sizeof(uint64_t));
+  for (int32_t d = 0; d < n_docs; d++) {
+    int32_t len = 0;
+    const uint8_t* v = po_raw_get_bytes(c, d, &len);
+    const int32_t n = starts[d + 1] - starts[d];
+    for (int32_t i = 0; i < n; i++) keys[starts[d] + i] = raw_mv_key(c->data_type, v + 4 + (int64_t)i * width);
+  }
+  uint64_t* sorted = (uint64_t*)po_xcalloc((size_t)total, sizeof(uint64_t));
+  memcpy(sorted, keys, (size_t)total * sizeof(uint64_t));
+  qsort(sorted, (size_t)total, sizeof(uint64_t), cmp_u64);
+  int64_t card = 0;
+  for (int64_t i = 0; i < total; i++) if (i == 0 || sorted[i] != sorted[i - 1]) sorted[card++] = sorted[i];
+  int bits = 1;
+  while (bits < 31 && ((int64_t)1 << bits) < card) bits++;
+  uint8_t* dict = (uint8_t*)po_xcalloc((size_t)card * (size_t)width + 8, 1);
+  for (int64_t i = 0; i < card; i++) {
+    uint64_t raw;
+    const uint64_t k = sorted[i];
+    if (c->data_type == PG_TYPE_INT || c->data_type == PG_TYPE_LONG) raw = k ^ (1ULL << 63);
+    else if (c->data_type == PG_TYPE_FLOAT) { const uint32_t kk = (uint32_t)k; raw = (kk >> 31) ? (kk ^ 0x80000000u) : (uint32_t)~kk; }
+    else raw = (k >> 63) ? (k ^ (1ULL << 63)) : ~k;
+    for (int b = 0; b < width; b++) dict[i * width + b] = (uint8_t)(raw >> (8 * (width - 1 - b)));
+  }
+  const int64_t per_chunk = (int64_t)ceilf((float)2048 / (float)(total / n_docs));
+  const int64_t num_chunks = ((int64_t)n_docs + per_chunk - 1) / per_chunk;
+  const int64_t bitmap_size = (total + 7) / 8, raw_size = (total * bits + 7) / 8;
+  uint8_t* fwd = (uint8_t*)po_xcalloc((size_t)(num_chunks * 4 + bitmap_size + raw_size + 8), 1);
+  for (int64_t ch = 0; ch < num_chunks; ch++) {
+    const uint32_t o = (uint32_t)starts[ch * per_chunk];
+    fwd[ch * 4] = (uint8_t)(o >> 24); fwd[ch * 4 + 1] = (uint8_t)(o >> 16); fwd[ch * 4 + 2] = (uint8_t)(o >> 8); fwd[ch * 4 + 3] = (uint8_t)o;
+  }
+  uint8_t* bm = fwd + num_chunks * 4;
+  for (int32_t d = 0; d < n_docs; d++) bm[starts[d] >> 3] |= (uint8_t)(0x80u >> (starts[d] & 7));
+  uint8_t* packed = bm + bitmap_size;
+  for (int64_t e = 0; e < total; e++) {
+    int64_t lo = 0, hi = card - 1;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (sorted[mid] < keys[e]) lo = mid + 1; else hi = mid; }
+    const uint32_t id = (uint32_t)lo;
+    const int64_t bit0 = e * bits;
+    for (int b = 0; b < bits; b++)
+      if ((id >> (bits - 1 - b)) & 1u) packed[(bit0 + b) >> 3] |= (uint8_t)(0x80u >> ((bit0 + b) & 7));
+  }
+  free(keys); free(sorted); free(starts);
+  c->raw_mv = 1;
+  c->mv_owned_fwd = fwd;
+  c->mv_owned_dict = dict;
+  c->has_dictionary = 1;
+  c->cardinality = (int32_t)card;
+  c->bits_per_value = bits;
+  c->dict_bytes_per_value = width;
+  c->dict = dict;
+  c->dict_len = (uint64_t)card * (uint64_t)width;
+  c->fwd = fwd;
+  c->fwd_len = (uint64_t)(num_chunks * 4 + bitmap_size + raw_size);
+  c->fwd_encoding = PG_FWD_DICT_FIXED_BIT_MV;
+  c->total_entries = (int32_t)total;
+  return po_mv_parse(c);
+}
+
 /* ---- SortedIndexReaderImpl, pinot-segment-local/.../readers/sorted/SortedIndexReaderImpl.java:35-110 ----------------- */
 void po_sorted_get_doc_ids(const po_column* c, int32_t dict_id, int32_t* start, int32_t* end) {
   *start = (int32_t)po_be32(c->fwd + (int64_t)dict_id * 8);

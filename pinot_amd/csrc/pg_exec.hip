@@ -529,6 +529,7 @@ static size_t p2_stripe_capacity(size_t tuples, int sgrid, int nb, size_t round_
 // -> tuple stream) -> pg_p2_scatter_stream -> chunk index -> pg_p2_aggregate_1n (registers of a bucket of groups in LDS) ->
 // pg_oct_merge_aux_kernel (max into the registers of the passes before) -> pg_oct_floor_kernel (the groups' smallest registers: the next
 // pass's floors).  Everything is queued on the stream without a host round trip; areas are sized for "every offer of the pass survives".
+static long long tiles_docs(int t0, int t1) { return (long long)(t1 - t0) * PG_WAVE_DOCS; }
 static std::vector<int> oct_pass_bounds(int n_wtiles) {
   std::vector<double> frac;
   if (const char* e = getenv("PG_OCT_PASSES")) {   // test / measurement knob: cumulative fractions, e.g. "0.02,0.08,0.3,1"
@@ -682,6 +683,22 @@ static void run_oct_pruned(CompiledPlan& P, PgQueryPlan& D, ThreadCtx& ctx, cons
     hipLaunchKernelGGL(pg_oct_merge_floor_kernel, dim3((unsigned)((G + 3) / 4)), dim3(256), 0, ctx.stream, S.aux[0].base, aux_final[0],
                        ctx.oct_floor.as<uint8_t>(), (int)G, D.aux[0].log2m, D.radix_shift, S.radix_slices);
     PG_HIP(hipGetLastError());
+    {
+      static const bool trace = getenv("PG_TRACE_OCT") != nullptr;   // debugging knob (synchronises): what each pass left in the stream
+      if (trace) {
+        uint32_t tiles = 0;
+        std::vector<uint8_t> fl(G);
+        PG_HIP(hipStreamSynchronize(ctx.stream));
+        PG_HIP(hipMemcpy(&tiles, ctx.oct_cursor.ptr, 4, hipMemcpyDeviceToHost));
+        PG_HIP(hipMemcpy(fl.data(), ctx.oct_floor.ptr, G, hipMemcpyDeviceToHost));
+        uint64_t hist[8] = {0};
+        for (uint8_t f : fl) hist[f < 7 ? f : 7]++;
+        fprintf(stderr, "[pg] pruned pass %d: tiles [%d, %d) = %lld docs, %d workgroups, region %d, stream tiles %u (<= %lld entries); floors after the pass:"
+                        " %llu %llu %llu %llu %llu %llu %llu %llu+\n", pass, t0, t1, (long long)tiles_docs(t0, t1), ogrid, O.oct_region, tiles, (long long)tiles * PG_WAVE_DOCS,
+                (unsigned long long)hist[0], (unsigned long long)hist[1], (unsigned long long)hist[2], (unsigned long long)hist[3], (unsigned long long)hist[4],
+                (unsigned long long)hist[5], (unsigned long long)hist[6], (unsigned long long)hist[7]);
+      }
+    }
   }
   // the error flags of all the passes: p2_ctrl {chunks claimed by the last pass, out of chunks}, cursor {entries of the last pass, overflow}
   PG_HIP(hipMemcpyAsync(ctx.p2_ctrl_host + 4, ctx.p2_ctrl.ptr, 8, hipMemcpyDeviceToHost, ctx.stream));

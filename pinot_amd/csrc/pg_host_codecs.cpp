@@ -58,7 +58,74 @@ bool inflate_chunk(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t want) 
   return ok;
 }
 
+// LZ4 block format (lz4-java's fast decompressor, .../io/compression/LZ4Decompressor.java: one block per chunk, decompressed size known to
+// the caller as an upper bound here): token = literal length (high nibble) | match length - 4 (low nibble), 255-continued lengths,
+// little-endian 16-bit match offset; the last sequence has literals only.  Returns the bytes produced, -1 on malformed input.
+int64_t lz4_block(const uint8_t* src, uint64_t n, uint8_t* dst, uint64_t cap) {
+  uint64_t ip = 0, op = 0;
+  while (ip < n) {
+    const uint32_t token = src[ip++];
+    uint64_t lit = token >> 4;
+    if (lit == 15) { uint8_t b; do { if (ip >= n) return -1; b = src[ip++]; lit += b; } while (b == 255); }
+    if (ip + lit > n || op + lit > cap) return -1;
+    std::memcpy(dst + op, src + ip, lit);
+    ip += lit; op += lit;
+    if (ip >= n) break;   // last sequence: literals only
+    if (ip + 2 > n) return -1;
+    const uint64_t off = (uint64_t)src[ip] | ((uint64_t)src[ip + 1] << 8);
+    ip += 2;
+    uint64_t len = (token & 15u) + 4;
+    if ((token & 15u) == 15) { uint8_t b; do { if (ip >= n) return -1; b = src[ip++]; len += b; } while (b == 255); }
+    if (off == 0 || off > op || op + len > cap) return -1;
+    for (uint64_t k = 0; k < len; k++) dst[op + k] = dst[op - off + k];   // overlapping copies repeat their window
+    op += len;
+  }
+  return (int64_t)op;
+}
+
 }  // namespace
+
+std::vector<uint8_t> host_decompress_chunk(int compression, const uint8_t* src, uint64_t n, uint64_t capacity, const char* column) {
+  std::vector<uint8_t> out;
+  switch (compression) {
+    case 0:   // PASS_THROUGH
+      out.assign(src, src + n);
+      return out;
+    case 3: {   // LZ4
+      out.resize(capacity);
+      const int64_t got = lz4_block(src, n, out.data(), capacity);
+      if (got < 0) fail(PG_ERR_INVALID_ARGUMENT, "column %s: malformed LZ4 chunk", column);
+      out.resize((size_t)got);
+      return out;
+    }
+    case 4: {   // LZ4_LENGTH_PREFIXED: little-endian int decompressed length, then the block (LZ4WithLengthDecompressor.java)
+      if (n < 4) fail(PG_ERR_INVALID_ARGUMENT, "column %s: LZ4_LENGTH_PREFIXED chunk of %llu bytes", column, (unsigned long long)n);
+      const uint64_t want = (uint64_t)src[0] | ((uint64_t)src[1] << 8) | ((uint64_t)src[2] << 16) | ((uint64_t)src[3] << 24);
+      if (want > capacity) fail(PG_ERR_INVALID_ARGUMENT, "column %s: chunk states %llu bytes, at most %llu fit", column, (unsigned long long)want, (unsigned long long)capacity);
+      out.resize(want);
+      if (lz4_block(src + 4, n - 4, out.data(), want) != (int64_t)want) fail(PG_ERR_INVALID_ARGUMENT, "column %s: malformed LZ4 chunk", column);
+      return out;
+    }
+    case 2: {   // ZSTANDARD
+      if (!zstd_lib().decompress || !zstd_lib().is_error) fail(PG_ERR_UNSUPPORTED, "column %s: ZSTANDARD chunks need libzstd.so.1, which this host does not have", column);
+      out.resize(capacity);
+      const size_t got = zstd_lib().decompress(out.data(), capacity, src, n);
+      if (zstd_lib().is_error(got)) fail(PG_ERR_INVALID_ARGUMENT, "column %s: malformed ZSTANDARD chunk", column);
+      out.resize(got);
+      return out;
+    }
+    case 5: {   // GZIP: zlib stream + the decompressed length as a big-endian int
+      if (n < 4) fail(PG_ERR_INVALID_ARGUMENT, "column %s: GZIP chunk of %llu bytes", column, (unsigned long long)n);
+      const uint64_t want = ((uint64_t)src[n - 4] << 24) | ((uint64_t)src[n - 3] << 16) | ((uint64_t)src[n - 2] << 8) | (uint64_t)src[n - 1];
+      if (want > capacity) fail(PG_ERR_INVALID_ARGUMENT, "column %s: chunk states %llu bytes, at most %llu fit", column, (unsigned long long)want, (unsigned long long)capacity);
+      out.resize(want);
+      if (!inflate_chunk(src, n, out.data(), want)) fail(PG_ERR_INVALID_ARGUMENT, "column %s: malformed GZIP chunk", column);
+      return out;
+    }
+    default:
+      fail(PG_ERR_UNSUPPORTED, "column %s: ChunkCompressionType %d of a var-byte chunk is outside the GPU path", column, compression);
+  }
+}
 
 bool host_codec(int compression) { return compression == 2 || compression == 5; }
 

@@ -125,6 +125,13 @@ struct Column {
   std::vector<uint8_t> vdict_bytes;
   std::vector<int64_t> vdict_bytes_off;
   bool is_mv = false;
+  // raw (no-dictionary) multi-value column (FixedByteChunkMVForwardIndexReader): the values are turned into a dictionary-encoded
+  // multi-value column ONCE at registration — sorted distinct values + bit-packed ids in the FixedBitMV layout — kept in `vdict`
+  // (complete at registration, unlike a single-value column's lazily built one); the planner resolves the column to it for filters,
+  // group keys and aggregation sources, and hands the group keys back as values.  has_dictionary stays false on THIS column: the
+  // dictionary-only operators (NonScanBasedAggregationOperator) do not apply to a raw column.
+  bool raw_mv = false;
+  Column* public_col = nullptr;                 // on the internal twin: the column the segment knows by name (statistics count it once)
   int32_t total_entries = 0;                    // ColumnMetadata#getTotalNumberOfEntries
   int32_t max_entries_per_doc = 0;              // ColumnMetadata#getMaxNumberOfMultiValues
   DeviceBuffer mv_offsets_dev;
@@ -179,6 +186,8 @@ void segment_add_star_tree(Segment& seg, const pg_star_tree_desc& d);
 bool host_codec(int compression);
 void host_decompress_fixed_byte_chunks(int compression, const uint8_t* file, const std::vector<uint64_t>& offs, uint32_t chunk_bytes,
                                        uint64_t total_bytes, uint8_t* dst_device, const char* column);
+// one var-byte chunk of any supported ChunkCompressionType -> its bytes (at most `capacity`); PG_ERR_UNSUPPORTED / INVALID_ARGUMENT otherwise
+std::vector<uint8_t> host_decompress_chunk(int compression, const uint8_t* src, uint64_t n, uint64_t capacity, const char* column);
 void decompress_fixed_byte_chunks(int compression, const uint8_t* file, const std::vector<uint64_t>& offs, uint32_t chunk_bytes,
                                   uint64_t total_bytes, uint8_t* dst, const char* column);
 void segment_set_null_vector(Segment& seg, const char* column, const void* roaring, uint64_t size);

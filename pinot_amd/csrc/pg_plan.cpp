@@ -342,6 +342,9 @@ static OpPtr construct(Segment& seg, const pg_filter_node& f) {   // FilterPlanN
         if (it == seg.null_vectors.end()) return make_op(not_null ? OpKind::MatchAll : OpKind::Empty);
         return bitmap_operator(it->second, not_null);
       }
+      // a raw multi-value column is evaluated on its internal dictionary-encoded twin (built at registration): the same docs match, and
+      // the scan counts the same entries (MVScanDocIdIterator over a raw column counts entries as well)
+      if (col->raw_mv) col = col->vdict.get();
       return leaf_operator(make_pred_eval(f, *col), col, f.predicate_type);
     }
     case PG_FILTER_CONSTANT_TRUE: return make_op(OpKind::MatchAll);
@@ -1377,7 +1380,10 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
   P.num_groups_limit = q->num_groups_limit > 0 ? q->num_groups_limit : 100000;
   if (q->n_group_by > PG_MAX_GROUP_COLS) fail(PG_ERR_UNSUPPORTED, "more than %d group-by columns", PG_MAX_GROUP_COLS);
   std::vector<Column*> projected;
-  auto project = [&](Column* c) { if (std::find(projected.begin(), projected.end(), c) == projected.end()) projected.push_back(c); };
+  auto project = [&](Column* c) {
+    if (c->public_col) c = c->public_col;   // the internal twin of a raw multi-value column counts as that column
+    if (std::find(projected.begin(), projected.end(), c) == projected.end()) projected.push_back(c);
+  };
   int64_t G = 1;
   bool huge_key_space = false;
   for (int j = 0; j < q->n_group_by; j++) {
@@ -1403,6 +1409,11 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
       project(c);
       continue;
     }
+    Column* raw = nullptr;
+    if (c->raw_mv) {   // NoDictionary…GroupKeyGenerator over a raw multi-value column: grouped through the twin's ids, keys handed back as values
+      raw = c;
+      c = c->vdict.get();
+    }
     if (c->is_mv) {   // DictionaryBasedGroupKeyGenerator#processMultiValue: every entry of the doc is a key digit (Cartesian over such columns)
       if (st) fail(PG_ERR_UNSUPPORTED, "multi-value group-by column %s over a star-tree", c->name.c_str());
       int n_mv = 0;
@@ -1411,7 +1422,6 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
       D.mv_gcol_offsets[j] = c->mv_offsets_dev.as<int32_t>();
       D.mv = 1;
     }
-    Column* raw = nullptr;
     if (!c->has_dictionary) {
       // any other raw key — FLOAT / DOUBLE, or a raw column among several group-by columns (NoDictionaryMultiColumnGroupKeyGenerator's
       // on-the-fly dictionaries): grouped through the column's virtual dictionary (pg_vdict.hip), like a dictionary column from here on
@@ -1559,6 +1569,12 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     if (s.function == PG_AGG_COUNT) { out.op_a = count_op; P.aggs.push_back(out); continue; }
     Column* c = st ? st->pairs[(size_t)st->pair_index(s.function, s.column)].col : seg.find(s.column);
     if (!c) fail(PG_ERR_NOT_FOUND, "column not found: %s", s.column ? s.column : "(null)");
+    if (c->raw_mv) {
+      // the *MV functions read the values through the twin's dictionary; DISTINCTCOUNTMV would hand back ids of a dictionary the caller
+      // does not have (BaseDistinctAggregateAggregationFunction keeps value sets for raw columns): the Java plan answers it
+      if (sv_function_of(s.function) == PG_AGG_DISTINCTCOUNT) fail(PG_ERR_UNSUPPORTED, "DISTINCTCOUNTMV over the raw multi-value column %s", c->name.c_str());
+      c = c->vdict.get();
+    }
     // BlockValSet#getDoubleValuesSV over a multi-value column (and ...MV over a single-value one) throws in the reference
     if (is_mv_function(s.function) != c->is_mv)
       fail(PG_ERR_INVALID_ARGUMENT, "aggregation function %d over the %s column %s", s.function, c->is_mv ? "multi-value" : "single-value", c->name.c_str());

@@ -293,6 +293,52 @@ void segment_set_queryable_doc_ids(Segment& seg, const void* roaring, uint64_t s
   seg.plan_cache.clear();
 }
 
+// VarByteChunkForwardIndexWriter's layout (writer versions 2 / 3; readers VarByteChunkSVForwardIndexReader.java:158-217,
+// FixedByteChunkMVForwardIndexReader.java:104-140): 7 big-endian ints {version, numChunks, numDocsPerChunk, lengthOfLongestEntry, totalDocs,
+// compressionType, dataHeaderStart}, the chunks' file offsets (int for version 2, long for 3), and per chunk numDocsPerChunk big-endian
+// int offsets relative to the chunk start (0 for the absent rows of the last chunk) followed by the values.  Calls `each(doc, ptr, len)`
+// for every doc; compressed chunks are decoded on the host (pg_host_codecs.cpp).
+template <typename F>
+static void walk_var_byte_chunks(const Segment& seg, const uint8_t* fwd, uint64_t fwd_len, const char* name, bool pass_through_only, F each) {
+  if (fwd_len < 28) fail(PG_ERR_INVALID_ARGUMENT, "raw forward index of %s too short", name);
+  const int32_t version = (int32_t)be32(fwd), num_chunks = (int32_t)be32(fwd + 4), per_chunk = (int32_t)be32(fwd + 8);
+  if (version != 2 && version != 3) fail(PG_ERR_UNSUPPORTED, "column %s: var-byte chunk writer version %d", name, version);
+  const int32_t longest = (int32_t)be32(fwd + 12), compression = (int32_t)be32(fwd + 20), header_start = (int32_t)be32(fwd + 24);
+  if (compression != 0 && pass_through_only)
+    fail(PG_ERR_UNSUPPORTED, "column %s: compressed var-byte chunks (type %d) are outside the GPU path", name, compression);
+  const int off_size = version == 2 ? 4 : 8;
+  if (per_chunk <= 0 || num_chunks < 0 || longest < 0 || (int64_t)num_chunks * per_chunk < seg.total_docs || header_start < 28 ||
+      (uint64_t)header_start + (uint64_t)num_chunks * (uint64_t)off_size > fwd_len)
+    fail(PG_ERR_INVALID_ARGUMENT, "raw forward index of %s: %d chunks of %d docs for %d docs", name, num_chunks, per_chunk, seg.total_docs);
+  const uint64_t max_chunk = (uint64_t)per_chunk * (4ULL + (uint64_t)longest);   // BaseChunkForwardIndexWriter's chunkSize
+  for (int32_t ch = 0; ch < num_chunks && (int64_t)ch * per_chunk < seg.total_docs; ch++) {
+    auto chunk_pos = [&](int32_t i) -> uint64_t {
+      if (i == num_chunks) return fwd_len;
+      const uint8_t* o = fwd + header_start + (uint64_t)i * (uint64_t)off_size;
+      return off_size == 4 ? (uint64_t)be32(o) : be64(o);
+    };
+    const uint64_t start = chunk_pos(ch), end = chunk_pos(ch + 1);
+    if (start > end || end > fwd_len) fail(PG_ERR_INVALID_ARGUMENT, "raw forward index of %s: bad chunk offsets", name);
+    std::vector<uint8_t> plain;
+    const uint8_t* cb = fwd + start;
+    uint64_t clen = end - start;
+    if (compression != 0) {
+      plain = host_decompress_chunk(compression, cb, clen, max_chunk, name);
+      cb = plain.data();
+      clen = plain.size();
+    }
+    if (clen < (uint64_t)per_chunk * 4) fail(PG_ERR_INVALID_ARGUMENT, "raw forward index of %s: chunk %d is %llu bytes", name, ch, (unsigned long long)clen);
+    const int32_t rows = (int32_t)std::min<int64_t>(per_chunk, (int64_t)seg.total_docs - (int64_t)ch * per_chunk);
+    for (int32_t r = 0; r < rows; r++) {
+      const uint64_t vs = be32(cb + (size_t)r * 4);
+      uint64_t ve = clen;                                       // getValueEndOffset: the last row, or a following absent row (offset 0)
+      if (r + 1 < per_chunk) { const uint64_t nx = be32(cb + (size_t)(r + 1) * 4); if (nx != 0) ve = nx; }
+      if (vs < (uint64_t)per_chunk * 4 || ve < vs || ve > clen) fail(PG_ERR_INVALID_ARGUMENT, "raw forward index of %s: bad value offsets in chunk %d", name, ch);
+      each((int64_t)ch * per_chunk + r, cb + vs, ve - vs);
+    }
+  }
+}
+
 void segment_add_column(Segment& seg, const pg_column_desc& d) {
   if (!d.name) fail(PG_ERR_INVALID_ARGUMENT, "column name is null");
   if (seg.columns.count(d.name)) fail(PG_ERR_INVALID_ARGUMENT, "column %s already added", d.name);
@@ -489,6 +535,105 @@ void segment_add_column(Segment& seg, const pg_column_desc& d) {
     c.vb_offsets_dev = upload_vector(off);
     c.col_kind = PG_COL_VAR_BYTES;
     c.fwd_bytes_logical = fwd_len;
+  } else if (c.fwd_encoding == PG_FWD_RAW_MV_FIXED_BYTE_CHUNK) {
+    // FixedByteChunkMVForwardIndexReader: doc d's value = ArraySerDeUtils.serialize…ArrayWithLength: big-endian int numValues, then the
+    // values big-endian.  The column becomes a dictionary-encoded multi-value column here, once: sorted distinct values (what the segment
+    // creator would have written as the dictionary: same order, same bytes) and the docs' ids in FixedBitMVForwardIndexReader's layout,
+    // registered through the ordinary path as this column's internal twin (c.vdict).
+    if (c.has_dictionary || c.data_type > PG_TYPE_DOUBLE)
+      fail(PG_ERR_UNSUPPORTED, "column %s: a raw multi-value forward index of fixed-width values belongs to a no-dictionary INT / LONG / FLOAT / DOUBLE column", d.name);
+    const int width = (c.data_type == PG_TYPE_INT || c.data_type == PG_TYPE_FLOAT) ? 4 : 8;
+    const int64_t num_docs = seg.total_docs;
+    std::vector<int32_t> starts;
+    starts.reserve((size_t)num_docs + 1);
+    std::vector<uint64_t> keys;   // order-preserving 64-bit keys of all entries, docs back to back (pg_vdict.hip's key encoding)
+    auto key_of = [&](const uint8_t* p) -> uint64_t {
+      if (c.data_type == PG_TYPE_INT) return (uint64_t)(int64_t)(int32_t)be32(p) ^ (1ULL << 63);
+      if (c.data_type == PG_TYPE_LONG) return be64(p) ^ (1ULL << 63);
+      if (c.data_type == PG_TYPE_FLOAT) { const uint32_t f = be32(p); return (f >> 31) ? (uint64_t)(uint32_t)~f : (uint64_t)(f ^ 0x80000000u); }
+      const uint64_t f = be64(p);
+      return (f >> 63) ? ~f : (f ^ (1ULL << 63));
+    };
+    walk_var_byte_chunks(seg, fwd, fwd_len, d.name, false, [&](int64_t doc, const uint8_t* p, uint64_t len) {
+      (void)doc;
+      if (len < 4) fail(PG_ERR_INVALID_ARGUMENT, "raw multi-value index of %s: a value of %llu bytes", d.name, (unsigned long long)len);
+      const uint32_t n = be32(p);
+      if ((uint64_t)n * (uint64_t)width + 4 != len || n == 0)   // (an empty array is stored as the default null value: one entry)
+        fail(PG_ERR_INVALID_ARGUMENT, "raw multi-value index of %s: %u values in %llu bytes", d.name, n, (unsigned long long)len);
+      if (keys.size() + n > 0x7FFFFFFFu) fail(PG_ERR_UNSUPPORTED, "raw multi-value index of %s: more than 2^31 entries", d.name);
+      starts.push_back((int32_t)keys.size());
+      for (uint32_t i = 0; i < n; i++) keys.push_back(key_of(p + 4 + (size_t)i * (size_t)width));
+    });
+    if ((int64_t)starts.size() != num_docs || num_docs <= 0) fail(PG_ERR_INVALID_ARGUMENT, "raw multi-value index of %s: %zu docs, the segment has %lld", d.name, starts.size(), (long long)num_docs);
+    if (d.total_number_of_entries > 0 && (int64_t)keys.size() != (int64_t)d.total_number_of_entries)
+      fail(PG_ERR_INVALID_ARGUMENT, "raw multi-value index of %s holds %zu entries, the metadata says %d", d.name, keys.size(), d.total_number_of_entries);
+    std::vector<uint64_t> distinct(keys);
+    std::sort(distinct.begin(), distinct.end());
+    distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+    const int32_t card = (int32_t)distinct.size();
+    int bits = 1;
+    while (bits < 31 && ((int64_t)1 << bits) < (int64_t)card) bits++;
+    // the dictionary: the values big-endian in key order (= value order: what SegmentDictionaryCreator writes)
+    std::vector<uint8_t> dict((size_t)card * (size_t)width);
+    for (int32_t i = 0; i < card; i++) {
+      double unused;
+      const int64_t v = vdict_value_of_key(distinct[(size_t)i], c.data_type == PG_TYPE_INT ? 0 : c.data_type == PG_TYPE_LONG ? 1 : c.data_type == PG_TYPE_FLOAT ? 2 : 3, &unused);
+      uint64_t raw;   // the stored bits
+      if (c.data_type == PG_TYPE_FLOAT) { const uint64_t k = distinct[(size_t)i]; const uint32_t kk = (uint32_t)k; raw = (kk >> 31) ? (kk ^ 0x80000000u) : (uint32_t)~kk; }
+      else raw = (uint64_t)v;   // INT / LONG: the value; DOUBLE: its IEEE bits
+      for (int b = 0; b < width; b++) dict[(size_t)i * (size_t)width + (size_t)b] = (uint8_t)(raw >> (8 * (width - 1 - b)));
+    }
+    // FixedBitMVForwardIndexReader's layout: chunk offsets | row-start bitmap | bit-packed ids
+    const int64_t num_values = (int64_t)keys.size();
+    const int64_t per_chunk = (int64_t)std::ceil((float)2048 / (float)(num_values / num_docs));
+    const int64_t num_chunks = (num_docs + per_chunk - 1) / per_chunk;
+    const uint64_t bitmap_bytes = ((uint64_t)num_values + 7) / 8, raw_bytes = ((uint64_t)num_values * (uint64_t)bits + 7) / 8;
+    std::vector<uint8_t> twin((size_t)num_chunks * 4 + bitmap_bytes + raw_bytes, 0);
+    for (int64_t ch = 0; ch < num_chunks; ch++) {
+      const uint32_t o = (uint32_t)starts[(size_t)(ch * per_chunk)];
+      twin[(size_t)ch * 4] = (uint8_t)(o >> 24); twin[(size_t)ch * 4 + 1] = (uint8_t)(o >> 16); twin[(size_t)ch * 4 + 2] = (uint8_t)(o >> 8); twin[(size_t)ch * 4 + 3] = (uint8_t)o;
+    }
+    uint8_t* bm = twin.data() + (size_t)num_chunks * 4;
+    for (int64_t dd = 0; dd < num_docs; dd++) { const int64_t pos = starts[(size_t)dd]; bm[pos >> 3] |= (uint8_t)(0x80u >> (pos & 7)); }
+    uint8_t* packed = bm + bitmap_bytes;
+    for (int64_t e = 0; e < num_values; e++) {
+      const uint32_t id = (uint32_t)(std::lower_bound(distinct.begin(), distinct.end(), keys[(size_t)e]) - distinct.begin());
+      const int64_t bit0 = e * bits;
+      for (int b = 0; b < bits; b++)
+        if ((id >> (bits - 1 - b)) & 1u) packed[(bit0 + b) >> 3] |= (uint8_t)(0x80u >> ((bit0 + b) & 7));
+    }
+    const std::string twin_name = std::string(d.name) + "$ids";
+    pg_column_desc td{};
+    td.name = twin_name.c_str();
+    td.data_type = c.data_type;
+    td.fwd_encoding = PG_FWD_DICT_FIXED_BIT_MV;
+    td.has_dictionary = 1;
+    td.cardinality = card;
+    td.bits_per_value = bits;
+    td.is_sorted = 0;
+    td.dict_bytes_per_value = width;
+    td.total_number_of_entries = (int32_t)num_values;
+    td.forward_index.addr = twin.data();
+    td.forward_index.size = twin.size();
+    td.dictionary.addr = dict.data();
+    td.dictionary.size = dict.size();
+    segment_add_column(seg, td);
+    {
+      std::lock_guard<std::mutex> g(seg.mu);
+      auto it = seg.columns.find(twin_name);
+      c.vdict = std::move(it->second);
+      seg.columns.erase(it);
+    }
+    c.vdict->vdict_keys = std::move(distinct);
+    c.vdict->vdict_kind = c.data_type == PG_TYPE_INT ? 0 : c.data_type == PG_TYPE_LONG ? 1 : c.data_type == PG_TYPE_FLOAT ? 2 : 3;
+    c.vdict->vdict_hash = c.vdict->dict_hash;
+    c.vdict->public_col = &c;
+    c.raw_mv = true;
+    c.is_mv = true;
+    c.total_entries = (int32_t)num_values;
+    c.max_entries_per_doc = c.vdict->max_entries_per_doc;
+    c.fwd_bytes_logical = fwd_len;
+    c.vdict->fwd_bytes_logical = fwd_len;
   } else if (c.fwd_encoding == PG_FWD_RAW_FIXED_BYTE_CHUNK) {
     if (fwd_len < 16) fail(PG_ERR_INVALID_ARGUMENT, "raw forward index of %s too short", d.name);
     int32_t version = (int32_t)be32(fwd);

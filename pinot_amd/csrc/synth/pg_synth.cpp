@@ -93,6 +93,28 @@ void pgs_fill_fixed_bit(uint8_t* out, int64_t n, int bits, uint64_t seed, uint64
   });
 }
 
+// the same layout for the docs [first, first + n) of the segment, packed from bit 0 of `out` (doc-sharded oracle runs of the full-size tests)
+void pgs_fill_fixed_bit_from(uint8_t* out, int64_t first, int64_t n, int bits, uint64_t seed, uint64_t salt, uint32_t range, int threads) {
+  const uint64_t key = col_key_of(seed, salt);
+  const int64_t blk = 1 << 20;
+  const int64_t total_bytes = (n * bits + 7) / 8;
+  parallel_for((n + blk - 1) / blk, threads, [&](int64_t b) {
+    int64_t s = b * blk, e = std::min(n, (b + 1) * blk);
+    uint8_t* p = out + (s * bits) / 8;
+    uint64_t acc = 0;
+    int have = 0;
+    for (int64_t d = s; d < e; d++) {
+      acc = (acc << bits) | value_at(key, (uint64_t)(first + d), range);
+      have += bits;
+      while (have >= 8) {
+        *p++ = (uint8_t)(acc >> (have - 8));
+        have -= 8;
+      }
+    }
+    if (have > 0 && p < out + total_bytes) *p = (uint8_t)(acc << (8 - have));
+  });
+}
+
 // raw fixed-byte chunk forward index (PASS_THROUGH).  Returns the total size; fills `out` when non-null.
 int64_t pgs_raw_int_index(uint8_t* out, int64_t n, uint64_t seed, uint64_t salt, uint32_t range, int version,
                           int docs_per_chunk, int threads) {

@@ -476,6 +476,33 @@ def write_raw_var_byte_chunk(values: Sequence[bytes], version: int = 2, docs_per
     return np.frombuffer(header + off_bytes + b"".join(chunks), dtype=np.uint8)
 
 
+def write_raw_mv_fixed_byte_chunk(rows: Sequence[Sequence], data_type: str, version: int = 2, docs_per_chunk: int = 1000,
+                                  compression: int = 0) -> np.ndarray:
+    """Raw (no-dictionary) multi-value forward index of a fixed-width type: MultiValueFixedByteRawIndexCreator ->
+    VarByteChunkForwardIndexWriter#putIntMV ... (.../creator/impl/fwd/MultiValueFixedByteRawIndexCreator.java:77-84): the var-byte chunk
+    layout whose value of a doc is ArraySerDeUtils.serialize…ArrayWithLength = big-endian int numValues + the values big-endian;
+    lengthOfLongestEntry = 4 + maxNumberOfMultiValueElements x size.  `compression`: a ChunkCompressionType applied chunk by chunk."""
+    np_t = {"INT": ">i4", "LONG": ">i8", "FLOAT": ">f4", "DOUBLE": ">f8"}[data_type]
+    values = [struct.pack(">i", len(r)) + np.asarray(r, dtype=np_t).tobytes() for r in rows]
+    longest = 4 + max(len(r) for r in rows) * np.dtype(np_t).itemsize
+    if compression == 0:
+        return write_raw_var_byte_chunk(values, version=version, docs_per_chunk=docs_per_chunk, longest_entry=longest)
+    plain = bytes(write_raw_var_byte_chunk(values, version=version, docs_per_chunk=docs_per_chunk, longest_entry=longest))
+    h = parse_raw_fixed_byte_chunk_header(np.frombuffer(plain, dtype=np.uint8))
+    off_size = 4 if version == 2 else 8
+    fmt = ">i" if off_size == 4 else ">q"
+    starts = [struct.unpack_from(fmt, plain, h["data_header_start"] + i * off_size)[0] for i in range(h["num_chunks"])] + [len(plain)]
+    chunks = [compress_chunk(plain[starts[i]:starts[i + 1]], compression) for i in range(h["num_chunks"])]
+    header_size = 28 + h["num_chunks"] * off_size
+    pos, offs = header_size, []
+    for ch in chunks:
+        offs.append(pos)
+        pos += len(ch)
+    header = struct.pack(">7i", version, h["num_chunks"], docs_per_chunk, longest, len(rows), compression, 28)
+    off_bytes = np.asarray(offs, dtype=np.int64).astype(">i4" if off_size == 4 else ">i8").tobytes()
+    return np.frombuffer(header + off_bytes + b"".join(chunks), dtype=np.uint8)
+
+
 def read_raw_var_byte_chunk(buf: np.ndarray) -> List[bytes]:
     """Check reader: VarByteChunkSVForwardIndexReader#getBytesUncompressed for every docId."""
     h = parse_raw_fixed_byte_chunk_header(buf)

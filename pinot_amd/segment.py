@@ -128,6 +128,19 @@ def build_column(name: str, values, data_type: str, *, dictionary: bool = True, 
     return HostColumn(name, data_type, enc, True, card, bits, is_sorted, width, fwd, dict_buf, inv, dict_values)
 
 
+def build_raw_mv_column(name: str, rows: Sequence[Sequence], data_type: str, *, compression: int = 0, version: int = 2) -> HostColumn:
+    """A raw (no-dictionary) multi-value column of INT / LONG / FLOAT / DOUBLE (MultiValueFixedByteRawIndexCreator); an empty row takes
+    the default null value like the segment creator does.  `dict_values` (sorted distinct values) serves the CHECK side only: the oracle
+    reports group keys of such a column as ids of its internal dictionary."""
+    default = {"INT": -(1 << 31), "LONG": -(1 << 63), "FLOAT": float("-inf"), "DOUBLE": float("-inf")}[data_type]
+    rows = [list(r) if len(r) else [default] for r in rows]
+    fwd = formats.write_raw_mv_fixed_byte_chunk(rows, data_type, version=version, compression=compression)
+    flat = np.ascontiguousarray([v for r in rows for v in r], dtype=NUMERIC_NP[data_type])
+    col = HostColumn(name, data_type, capi.FWD_RAW_MV_FIXED_BYTE_CHUNK, False, 0, 0, False, 0, fwd, None, None, np.unique(flat).tolist())
+    col.total_number_of_entries = int(len(flat))
+    return col
+
+
 def build_mv_column(name: str, rows: Sequence[Sequence], data_type: str, *, inverted: bool = False, run_compress: bool = True) -> HostColumn:
     """A multi-value dictionary column (MultiValueUnsortedForwardIndexCreator + BitmapInvertedIndexWriter): `rows[doc]` is the doc's
     values, duplicates and order kept; an empty row takes the default null value like the segment creator does

@@ -92,6 +92,9 @@ def synth_lib():
         lib.pgs_fill_values.restype = None
         lib.pgs_fill_fixed_bit.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int]
         lib.pgs_fill_fixed_bit.restype = None
+        if hasattr(lib, "pgs_fill_fixed_bit_from"):
+            lib.pgs_fill_fixed_bit_from.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int]
+            lib.pgs_fill_fixed_bit_from.restype = None
         lib.pgs_raw_int_index.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int]
         lib.pgs_raw_int_index.restype = C.c_int64
         lib.pgs_inverted_begin.argtypes = [C.c_int64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int, C.POINTER(C.c_int64)]
@@ -138,6 +141,26 @@ def _column_native(lib, col: SynthColumn, seed: int, n: int, raw_version: int, t
         lib.pgs_inverted_end(h)
     return HostColumn(col.name, "INT", capi.FWD_DICT_FIXED_BIT, True, col.range, bits, False, 4, fwd,
                       _identity_dictionary(col.range), inv, list(range(col.range)))
+
+
+def generate_doc_range(first_doc: int, num_docs: int, segment_index: int = 0, columns: Optional[Iterable[str]] = None, threads: int = 0,
+                       name: Optional[str] = None) -> HostSegment:
+    """The docs [first_doc, first_doc + num_docs) of gpuBench segment `segment_index` as a segment of their own (dictionary columns only:
+    the doc-sharded oracle runs of the full-size tests).  Values are a pure function of (segment, column, docId)."""
+    seed = SEED_BASE ^ segment_index
+    lib = synth_lib()
+    seg = HostSegment(name or f"gpuBench_{segment_index}_from_{first_doc}", num_docs)
+    for col in [GPU_BENCH[c] for c in (columns or [])]:
+        assert col.kind != "raw" and not col.inverted, "generate_doc_range: dictionary columns without an inverted index"
+        bits = formats.num_bits_per_value(col.range - 1)
+        if lib is not None and hasattr(lib, "pgs_fill_fixed_bit_from"):
+            fwd = np.zeros((num_docs * bits + 7) // 8, dtype=np.uint8)
+            lib.pgs_fill_fixed_bit_from(fwd.ctypes.data, first_doc, num_docs, bits, seed, col.salt, col.range, threads if threads > 0 else lib.pgs_default_threads())
+        else:
+            fwd = formats.pack_fixed_bit(values_numpy(col, seed, num_docs, start=first_doc), bits)
+        seg.columns[col.name] = HostColumn(col.name, "INT", capi.FWD_DICT_FIXED_BIT, True, col.range, bits, False, 4, fwd,
+                                           _identity_dictionary(col.range), None, list(range(col.range)))
+    return seg
 
 
 def generate_segment(num_docs: int, segment_index: int = 0, columns: Optional[Iterable[str]] = None,

@@ -9,7 +9,7 @@ import math
 
 import numpy as np
 
-from pinot_amd.segment import HostSegment, build_column, build_mv_column
+from pinot_amd.segment import HostSegment, build_column, build_mv_column, build_raw_mv_column
 
 WORDS = ["ant", "bee", "cat", "dog", "eel", "fox", "gnu", "hen", "ibis", "jay", "koi", "lynx"]
 
@@ -41,6 +41,20 @@ def build(rows, name="mvTable") -> HostSegment:
     seg.columns["mv2"] = build_mv_column("mv2", [r["mv2"] for r in rows], "STRING")
     seg.columns["mv3"] = build_mv_column("mv3", [r["mv3"] for r in rows], "LONG")
     seg.columns["mvh"] = build_mv_column("mvh", [r["mvh"] for r in rows], "INT")
+    return seg
+
+
+def build_with_raw_twins(rows, name="mvTable", compression=(0, 3, 4, 2, 5)) -> HostSegment:
+    """The same table plus raw (no-dictionary) twins of the numeric multi-value columns, FixedByteChunkMVForwardIndexReader's format
+    under every ChunkCompressionType the path reads: r1 = mv1 (INT), r3 = mv3 (LONG), rh = mvh (INT), rf / rd = mv1 / 4 as FLOAT / DOUBLE.
+    Every query over a raw twin must return what the dictionary column returns (MultiValueRawQueriesTest's own criterion)."""
+    seg = build(rows, name)
+    seg.columns["r1"] = build_raw_mv_column("r1", [r["mv1"] for r in rows], "INT", compression=compression[0])
+    seg.columns["r3"] = build_raw_mv_column("r3", [r["mv3"] for r in rows], "LONG", compression=compression[1])
+    seg.columns["rh"] = build_raw_mv_column("rh", [r["mvh"] for r in rows], "INT", compression=compression[2])
+    seg.columns["rf"] = build_raw_mv_column("rf", [[v / 4.0 for v in r["mv1"]] for r in rows], "FLOAT", compression=compression[3])
+    seg.columns["rd"] = build_raw_mv_column("rd", [[v / 4.0 for v in r["mv1"]] for r in rows], "DOUBLE", compression=compression[4])
+    seg.columns["fd"] = build_mv_column("fd", [[v / 4.0 for v in r["mv1"]] for r in rows], "DOUBLE")   # dictionary twin of rf / rd
     return seg
 
 

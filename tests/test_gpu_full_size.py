@@ -136,3 +136,42 @@ def test_empty_segment(gpu_api, oracle_api):
     with pytest.raises(capi.NativeError) as e:
         NativeSegment(gpu_api, host)
     assert e.value.status == capi.PG_ERR_INVALID_ARGUMENT
+
+
+@pytest.mark.gpu
+def test_full_size_config5_equals_doc_sharded_oracle(gpu_api, oracle_api):
+    """BASELINE config 5 (flat) at full size against the oracle: the oracle needs ~4 minutes of one core for 10^9 docs,
+    so the doc space is cut into shards that run on the host's cores at once and merge the way GroupByCombineOperator merges segments —
+    COUNT adds (CountAggregationFunction#merge), HyperLogLog registers take the maximum (HyperLogLog#addAll,
+    DistinctCountHLLAggregationFunction#merge).  Every group key, every count and every one of the 12 800 x 256 registers must match;
+    the GPU side runs the pruned-offer passes (pg_kernels_oct.hip)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from pinot_amd.executor import merge_intermediate
+    n = FULL_DOCS
+    seg = stream_segment(gpu_api, n, synth.CFG5_COLUMNS)
+    gb = seg.execute(synth.QUERY_CFG5)
+    got = gb.rows()
+    assert gb.stats.num_docs_scanned == n and gb.stats.num_total_docs == n
+    if n >= (1 << 20):
+        assert gb.stats.kernel.decode() == "pg_oct_pruned_group_by"
+    seg.destroy()
+    shards = max(4, min(32, (os.cpu_count() or 8)))
+    bounds = [n * k // shards for k in range(shards + 1)]
+
+    def shard(k):
+        host = synth.generate_doc_range(bounds[k], bounds[k + 1] - bounds[k], segment_index=0, columns=synth.CFG5_COLUMNS, threads=1)
+        o = NativeSegment(oracle_api, host)
+        rows = o.execute(synth.QUERY_CFG5).rows()
+        o.destroy()
+        return rows
+    with ThreadPoolExecutor(max_workers=shards) as pool:
+        parts = list(pool.map(shard, range(shards)))
+    fns = ["COUNT", "DISTINCTCOUNTHLL"]
+    expect = {}
+    for rows in parts:
+        for k, vals in rows.items():
+            expect[k] = [merge_intermediate(f, a, b) for f, a, b in zip(fns, expect[k], vals)] if k in expect else list(vals)
+    assert sorted(got) == sorted(expect)
+    assert sum(v[0] for v in got.values()) == n
+    bad = [k for k in expect if got[k] != expect[k]]
+    assert not bad, (len(bad), bad[:3])

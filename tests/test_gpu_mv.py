@@ -151,3 +151,62 @@ def test_merge_of_multi_value_results(gpu_api, oracle_api):
     want = GroupByCombineOperator([w.execute(sql)]).final()
     w.destroy()
     assert GroupByCombineOperator(blocks).final() == want
+
+
+# ---- raw (no-dictionary) multi-value columns: FixedByteChunkMVForwardIndexReader (round 4) ------------------------------------------------
+# (query over the raw twin, the same query over the dictionary column): equal rows — the criterion of MultiValueRawQueriesTest — and
+# GPU == oracle on the raw query itself, ExecutionStatistics included.  Empty rows hold the default null value (-2^31 / -inf).
+RAW_PAIRS = [
+    ("SELECT COUNT(*), SUM(m) FROM mvTable WHERE r1 BETWEEN 10 AND 19", "SELECT COUNT(*), SUM(m) FROM mvTable WHERE mv1 BETWEEN 10 AND 19"),
+    ("SELECT COUNT(*), SUM(m) FROM mvTable WHERE r3 > 4000000 AND r1 NOT IN (1, 2, 3)", "SELECT COUNT(*), SUM(m) FROM mvTable WHERE mv3 > 4000000 AND mv1 NOT IN (1, 2, 3)"),
+    ("SELECT COUNT(*) FROM mvTable WHERE r1 = -2147483648 OR rd < 1.5", "SELECT COUNT(*) FROM mvTable WHERE mv1 = -2147483648 OR fd < 1.5"),
+    ("SELECT r1, COUNT(*), SUM(m), MAX(m) FROM mvTable GROUP BY r1 LIMIT 1000", "SELECT mv1, COUNT(*), SUM(m), MAX(m) FROM mvTable GROUP BY mv1 LIMIT 1000"),
+    ("SELECT s1, r3, COUNT(*), MIN(m) FROM mvTable WHERE s1 IN (0, 1, 2, 3) GROUP BY s1, r3 LIMIT 1000", "SELECT s1, mv3, COUNT(*), MIN(m) FROM mvTable WHERE s1 IN (0, 1, 2, 3) GROUP BY s1, mv3 LIMIT 1000"),
+    ("SELECT r1, mv2, COUNT(*), SUM(m) FROM mvTable WHERE s1 < 4 GROUP BY r1, mv2 LIMIT 10000", "SELECT mv1, mv2, COUNT(*), SUM(m) FROM mvTable WHERE s1 < 4 GROUP BY mv1, mv2 LIMIT 10000"),
+    ("SELECT rd, s2, COUNT(*) FROM mvTable GROUP BY rd, s2 LIMIT 10000", "SELECT fd, s2, COUNT(*) FROM mvTable GROUP BY fd, s2 LIMIT 10000"),
+    ("SELECT s1, COUNTMV(r1), SUMMV(r1), MINMV(r3), MAXMV(r3), AVGMV(r1), MINMAXRANGEMV(r3), DISTINCTCOUNTHLLMV(r1), COUNT(*) FROM mvTable WHERE r1 NOT IN (3, 4) GROUP BY s1 LIMIT 100",
+     "SELECT s1, COUNTMV(mv1), SUMMV(mv1), MINMV(mv3), MAXMV(mv3), AVGMV(mv1), MINMAXRANGEMV(mv3), DISTINCTCOUNTHLLMV(mv1), COUNT(*) FROM mvTable WHERE mv1 NOT IN (3, 4) GROUP BY s1 LIMIT 100"),
+    ("SELECT COUNTMV(rf), MINMV(rf), MAXMV(rd), MINMAXRANGEMV(rd) FROM mvTable WHERE s1 > 2", "SELECT COUNTMV(fd), MINMV(fd), MAXMV(fd), MINMAXRANGEMV(fd) FROM mvTable WHERE s1 > 2"),
+    ("SELECT rh, s1, COUNT(*), SUM(m), MAXMV(r1) FROM mvTable GROUP BY rh, s1 LIMIT 1000000", "SELECT mvh, s1, COUNT(*), SUM(m), MAXMV(mv1) FROM mvTable GROUP BY mvh, s1 LIMIT 1000000"),
+    ("SELECT SUMMV(rh), DISTINCTCOUNTHLLMV(rh) FROM mvTable WHERE mv2 != 'ant'", "SELECT SUMMV(mvh), DISTINCTCOUNTHLLMV(mvh) FROM mvTable WHERE mv2 != 'ant'"),
+]
+
+
+@pytest.fixture(scope="module", params=[1, 300, 2049, 30_000])
+def raw_pair(request, gpu_api, oracle_api):
+    host = mv.build_with_raw_twins(mv.make_rows(request.param, seed=7 + request.param))
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    yield g, o
+    g.destroy()
+    o.destroy()
+
+
+@pytest.mark.parametrize("raw_sql,dict_sql", RAW_PAIRS)
+def test_raw_multi_value_columns(raw_pair, raw_sql, dict_sql):
+    g, o = raw_pair
+    gb, ob = g.execute(raw_sql), o.execute(raw_sql)
+    assert gb.rows() == ob.rows()
+    for f in STATS:
+        assert getattr(gb.stats, f) == getattr(ob.stats, f), f
+    assert gb.rows() == g.execute(dict_sql).rows()          # raw == dictionary twin, on the GPU ...
+    assert ob.rows() == o.execute(dict_sql).rows()          # ... and in the oracle
+
+
+def test_raw_multi_value_without_filter_is_scanned_not_answered_from_a_dictionary(raw_pair):
+    """MINMV / MAXMV over a dictionary column without a filter come from the dictionary (NonScanBasedAggregationOperator: no entry is
+    read); the raw twin has no dictionary: the same values, a scan's statistics."""
+    g, o = raw_pair
+    raw, dic = "SELECT MINMV(r3), MAXMV(r3), COUNT(*) FROM mvTable", "SELECT MINMV(mv3), MAXMV(mv3), COUNT(*) FROM mvTable"
+    gb, ob = g.execute(raw), o.execute(raw)
+    assert gb.rows() == ob.rows() == g.execute(dic).rows()
+    for f in STATS:
+        assert getattr(gb.stats, f) == getattr(ob.stats, f), f
+    assert gb.stats.num_entries_scanned_post_filter > 0 and g.execute(dic).stats.num_entries_scanned_post_filter == 0
+
+
+def test_distinctcountmv_over_a_raw_column_is_left_to_the_java_plan(raw_pair):
+    g, o = raw_pair
+    for api_seg in (g, o):
+        with pytest.raises(capi.NativeError) as e:
+            api_seg.execute("SELECT DISTINCTCOUNTMV(r1) FROM mvTable WHERE s1 = 1")
+        assert e.value.status == capi.PG_ERR_UNSUPPORTED

@@ -19,7 +19,7 @@ Floating SUMMV / AVGMV run on the oracle only (the GPU path leaves them to the J
 import pytest
 
 from pinot_amd.executor import GroupByCombineOperator, NativeSegment
-from pinot_amd.segment import HostSegment, build_column, build_mv_column
+from pinot_amd.segment import HostSegment, build_column, build_mv_column, build_raw_mv_column
 
 MV_OFFSET = 100
 TYPES = {"Int": "INT", "Long": "LONG", "Float": "FLOAT", "Double": "DOUBLE"}
@@ -34,6 +34,12 @@ def reference_segment(base, name):
         cast = float if dtype in ("FLOAT", "DOUBLE") else int
         seg.columns[f"mv{t}Col"] = build_mv_column(f"mv{t}Col", [[cast(v), cast(v + MV_OFFSET)] for v in values], dtype)
     seg.columns["mvStringCol"] = build_mv_column("mvStringCol", [[str(v), str(v + MV_OFFSET)] for v in values], "STRING")
+    # the raw (no-dictionary) twins: setNoDictionaryColumns(mvRawIntCol ...), :112-116 — FixedByteChunkMVForwardIndexReader columns;
+    # LZ4 is what a dimension column gets by default, PASS_THROUGH / ZSTANDARD / GZIP for the byte format's other branches
+    comp = {"Int": 3, "Long": 0, "Float": 2, "Double": 5}
+    for t, dtype in TYPES.items():
+        cast = float if dtype in ("FLOAT", "DOUBLE") else int
+        seg.columns[f"mvRaw{t}Col"] = build_raw_mv_column(f"mvRaw{t}Col", [[cast(v), cast(v + MV_OFFSET)] for v in values], dtype, compression=comp[t])
     return seg
 
 
@@ -92,9 +98,54 @@ def check(segs, floating_sums):
     assert all(v == [8] for v in rows.values())
 
 
+def check_raw(segs, floating_sums):
+    """The reference's queries as it writes them: over the RAW columns, next to their dictionary twins (every assertion of the test is
+    `dictionary value == raw value == constant`)."""
+    sum_types = list(TYPES) if floating_sums else ["Int", "Long"]
+    for t in sum_types:   # :1105-1213
+        both = f"SELECT {five(f'mv{t}Col')}, {five(f'mvRaw{t}Col')} FROM testTable"
+        assert broker(segs, both)[()] == [160, 88720.0, 0.0, 1109.0, 554.5] * 2, t
+    for t in TYPES:
+        c = f"mvRaw{t}Col"
+        assert broker(segs, f"SELECT COUNTMV({c}), MINMV({c}), MAXMV({c}) FROM testTable")[()] == [160, 0.0, 1109.0], t
+    # :1217-1283 WHERE mvRawIntCol > 1000 / mvRawDoubleCol > 1000.0
+    assert broker(segs, f"SELECT {five('mvIntCol')}, {five('mvRawIntCol')} FROM testTable WHERE mvRawIntCol > 1000")[()] == [80, 84360.0, 1000.0, 1109.0, 1054.5] * 2
+    assert broker(segs, "SELECT COUNTMV(mvRawDoubleCol), MINMV(mvRawDoubleCol), MAXMV(mvDoubleCol) FROM testTable WHERE mvRawDoubleCol > 1000.0")[()] == [80, 1000.0, 1109.0]
+    # :1291-1345 GROUP BY mvRawIntCol [, mvRawDoubleCol | mvDoubleCol]
+    rows = broker(segs, "SELECT mvRawIntCol, COUNTMV(mvRawLongCol) FROM testTable GROUP BY mvRawIntCol LIMIT 1000")
+    assert [(k[0], v) for k, v in sorted(rows.items())[:10]] == [(i, [8]) for i in range(10)] and len(rows) == 40
+    for second in ("mvRawDoubleCol", "mvDoubleCol"):
+        rows = broker(segs, f"SELECT mvRawIntCol, {second}, COUNTMV(mvRawLongCol) FROM testTable GROUP BY mvRawIntCol, {second} LIMIT 1000")
+        first10 = sorted(rows.items())[:10]
+        assert [k for k, _ in first10] == [(0, 0.0), (0, 100.0), (1, 1.0), (1, 101.0), (2, 2.0), (2, 102.0), (3, 3.0), (3, 103.0), (4, 4.0), (4, 104.0)]
+        assert all(v == [8] for _, v in first10)
+    # :1396-1530 GROUP BY svIntCol, mvRawLongCol / mvRawIntCol
+    for t in sum_types:
+        key = "mvRawLongCol" if t == "Int" else "mvRawIntCol"
+        rows = broker(segs, f"SELECT svIntCol, {key}, {five(f'mv{t}Col')}, {five(f'mvRaw{t}Col')} FROM testTable GROUP BY svIntCol, {key} LIMIT 1000")
+        first10 = sorted(rows.items())[:10]
+        assert [k[0] for k, _ in first10] == [0, 0, 1, 1, 2, 2, 3, 3, 4, 4]
+        for (sv, mv), vals in first10:
+            assert vals[:5] == vals[5:] and mv in (sv, sv + MV_OFFSET)                                # dictionary == raw (the reference's assertion)
+            assert vals[:5] == [8, 8.0 * sv + 400.0, float(sv), float(sv + MV_OFFSET), sv + 50.0]
+    # :1532-1660 three keys, one dictionary and one raw multi-value key
+    rows = broker(segs, f"SELECT svIntCol, mvIntCol, mvRawIntCol, {five('mvLongCol')}, {five('mvRawLongCol')} FROM testTable GROUP BY svIntCol, mvIntCol, mvRawIntCol LIMIT 1000")
+    first10 = sorted(rows.items())[:10]
+    assert [k[0] for k, _ in first10] == [0, 0, 0, 0, 1, 1, 1, 1, 2, 2]
+    for (sv, a, b), vals in first10:
+        assert vals[:5] == vals[5:] == [8, 8.0 * sv + 400.0, float(sv), float(sv + MV_OFFSET), sv + 50.0]
+        assert a in (sv, sv + MV_OFFSET) and b in (sv, sv + MV_OFFSET)
+    # two RAW multi-value keys (:1662-1700)
+    rows = broker(segs, "SELECT svIntCol, mvRawLongCol, mvRawFloatCol, COUNTMV(mvRawIntCol), MINMV(mvRawIntCol), MAXMV(mvIntCol) FROM testTable GROUP BY svIntCol, mvRawLongCol, mvRawFloatCol LIMIT 1000")
+    first10 = sorted(rows.items())[:10]
+    assert [k[0] for k, _ in first10] == [0, 0, 0, 0, 1, 1, 1, 1, 2, 2]
+    assert all(v == [8, float(k[0]), float(k[0] + MV_OFFSET)] for k, v in first10)
+
+
 def test_multi_value_reference_goldens_oracle(oracle_api):
     segs = [NativeSegment(oracle_api, reference_segment(0, "testSegment1")), NativeSegment(oracle_api, reference_segment(1000, "testSegment2"))]
     check(segs, floating_sums=True)
+    check_raw(segs, floating_sums=True)
     for s in segs:
         s.destroy()
 
@@ -103,5 +154,6 @@ def test_multi_value_reference_goldens_oracle(oracle_api):
 def test_multi_value_reference_goldens_gpu(gpu_api):
     segs = [NativeSegment(gpu_api, reference_segment(0, "testSegment1")), NativeSegment(gpu_api, reference_segment(1000, "testSegment2"))]
     check(segs, floating_sums=False)
+    check_raw(segs, floating_sums=False)
     for s in segs:
         s.destroy()

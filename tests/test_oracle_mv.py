@@ -155,3 +155,22 @@ def test_reader_context_paths():
         col = build_mv_column("x", rows, "INT")
         dec = decode_mv_column(col, n)
         assert [[col.dict_values[i] for i in d] for d in dec] == rows
+
+
+# ---- raw (no-dictionary) multi-value columns: FixedByteChunkMVForwardIndexReader's format in the oracle ------------------------------------
+def test_raw_multi_value_reader_matches_the_brute_force():
+    """The oracle over raw twins of the multi-value columns (every ChunkCompressionType of the var-byte chunk layout) against the brute
+    force over the rows: filters with their numEntriesScannedInFilter, multi-value group keys, the *MV functions."""
+    from tests.oracle_binding import load_oracle
+    rows = mv.make_rows(N, seed=23)
+    for r in rows:
+        r["r1"], r["r3"], r["rh"] = r["mv1"], r["mv3"], r["mvh"]
+    seg = NativeSegment(load_oracle(), mv.build_with_raw_twins(rows))
+    b = seg.execute("SELECT COUNT(*), SUM(m) FROM mvTable WHERE r1 BETWEEN 10 AND 19")
+    match = [r for r in rows if any(10 <= v <= 19 for v in mv.values_of(r, "r1"))]
+    assert b.rows()[()] == [len(match), float(sum(r["m"] for r in match))]
+    assert b.stats.num_entries_scanned_in_filter == sum(len(mv.values_of(r, "r1")) for r in rows)
+    want = mv.brute_force(rows, lambda r: r["s1"] < 4, ["r1", "s1"], [("COUNT", None), ("SUMMV", "r3"), ("MAXMV", "rh")])
+    got = seg.execute("SELECT r1, s1, COUNT(*), SUMMV(r3), MAXMV(rh) FROM mvTable WHERE s1 < 4 GROUP BY r1, s1 LIMIT 100000").rows()
+    assert got == want
+    seg.destroy()
