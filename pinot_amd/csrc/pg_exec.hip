@@ -530,7 +530,11 @@ static size_t p2_stripe_capacity(size_t tuples, int sgrid, int nb, size_t round_
 // pg_oct_merge_aux_kernel (max into the registers of the passes before) -> pg_oct_floor_kernel (the groups' smallest registers: the next
 // pass's floors).  Everything is queued on the stream without a host round trip; areas are sized for "every offer of the pass survives".
 static long long tiles_docs(int t0, int t1) { return (long long)(t1 - t0) * PG_WAVE_DOCS; }
-static std::vector<int> oct_pass_bounds(int n_wtiles) {
+// Pass boundaries.  What makes a floor rise is the number of offers a REGISTER has seen: after ~6 offers per register hardly any register of
+// a group is empty (floor >= 1: half of the offers are dropped), after ~24 the floors sit at 2-3, after ~96 at 4-5.  So the passes end
+// where the docs seen so far amount to 6 / 24 / 96 offers per register — 20 M / 79 M / 315 M docs for config 5's 12 800 x 256 registers,
+// i.e. 2 % / 8 % / 30 % of 10^9 docs (13.7 % of all offers survive) but 10 % / 40 % of 2 x 10^8 (41 %: profiles/r04_g_pruned_passes.txt).
+static std::vector<int> oct_pass_bounds(int n_wtiles, int64_t registers) {
   std::vector<double> frac;
   if (const char* e = getenv("PG_OCT_PASSES")) {   // test / measurement knob: cumulative fractions, e.g. "0.02,0.08,0.3,1"
     for (const char* c = e; *c;) {
@@ -542,11 +546,12 @@ static std::vector<int> oct_pass_bounds(int n_wtiles) {
     }
   }
   if (frac.empty()) {
-    const int64_t docs = (int64_t)n_wtiles * PG_WAVE_DOCS;
-    if (docs >= ((int64_t)32 << 20)) frac = {0.02, 0.08, 0.30, 1.0};
-    else if (docs >= ((int64_t)4 << 20)) frac = {0.05, 0.25, 1.0};
-    else if (docs >= ((int64_t)1 << 18)) frac = {0.10, 1.0};
-    else frac = {1.0};
+    const double docs = (double)n_wtiles * PG_WAVE_DOCS;
+    for (double per_register : {6.0, 24.0, 96.0}) {
+      const double f = per_register * (double)registers / docs;
+      if (f < 0.6) frac.push_back(f);   // a pass that would leave less than 40 % of the docs to the next one is folded into the last
+    }
+    frac.push_back(1.0);
   }
   std::vector<int> b;
   int prev = 0;
@@ -577,7 +582,7 @@ static void run_oct_pruned(CompiledPlan& P, PgQueryPlan& D, ThreadCtx& ctx, cons
     PG_HIP(hipGetLastError());
     D.match_words = ctx.words.as<uint32_t>();
   }
-  const std::vector<int> bounds = oct_pass_bounds(D.n_wtiles);
+  const std::vector<int> bounds = oct_pass_bounds(D.n_wtiles, (int64_t)G << D.aux[0].log2m);
   const int n_pass = (int)bounds.size();
   int max_tiles = 0;
   for (int i = 0, prev = 0; i < n_pass; prev = bounds[(size_t)i], i++) max_tiles = std::max(max_tiles, bounds[(size_t)i] - prev);

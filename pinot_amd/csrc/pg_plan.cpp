@@ -1014,7 +1014,9 @@ static void plan_oct(CompiledPlan& P, PgQueryPlan& D, const std::vector<Column*>
   // column).  What is known at plan time is the column's cardinality / value range: at least 16 values per register.
   const int64_t distinct_hint = c->has_dictionary ? (int64_t)c->cardinality : (c->has_int_range ? c->int_max - c->int_min : 0);
   if (distinct_hint < ((int64_t)16 << A.log2m) && !getenv("PG_OCT_ANY_CARDINALITY")) return;
-  const int64_t min_docs = getenv("PG_OCT_MIN_DOCS") ? atoll(getenv("PG_OCT_MIN_DOCS")) : ((int64_t)1 << 20);
+  // ... and enough docs: the floors only rise once a register has seen several offers (pg_exec.hip, oct_pass_bounds) — below ~16 offers
+  // per register over the whole segment the passes would forward nearly everything
+  const int64_t min_docs = getenv("PG_OCT_MIN_DOCS") ? atoll(getenv("PG_OCT_MIN_DOCS")) : std::max<int64_t>((int64_t)1 << 20, 16 * (G << A.log2m));
   if (D.agg_mode == PG_AGG_RADIX && D.p2 && D.p2_planes == 1 && kind != 4 && D.n_group_cols >= 1 && total_docs >= min_docs &&
       G * 4 + ((G + 3) & ~(int64_t)3) + 16 * 4096 + 512 <= 156 * 1024 &&   /* counters + floors + the wavefronts' survivor rings */ G < ((int64_t)1 << (31 - (A.log2m + 5))) && D.pk_bits[0] == A.log2m + 5 &&
       D.p2_fkind[0] == PG_P2_F_HLL && !getenv("PG_NO_OCT_PRUNE")) {

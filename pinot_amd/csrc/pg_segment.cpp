@@ -617,9 +617,8 @@ void segment_add_column(Segment& seg, const pg_column_desc& d) {
     td.forward_index.size = twin.size();
     td.dictionary.addr = dict.data();
     td.dictionary.size = dict.size();
-    segment_add_column(seg, td);
+    segment_add_column(seg, td);   // (the caller holds the segment's lock: pg_segment_add_column)
     {
-      std::lock_guard<std::mutex> g(seg.mu);
       auto it = seg.columns.find(twin_name);
       c.vdict = std::move(it->second);
       seg.columns.erase(it);
