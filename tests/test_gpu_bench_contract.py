@@ -36,7 +36,9 @@ def test_bench_line_on_a_small_segment():
         b = d[key]
         assert b["kernel_ms"] > 0 and 0 < b["roofline_frac"] < 1 and b["rows"] == 3000000
         assert b.get("gpu_equals_oracle_at_full_size", b.get("gpu_equals_oracle_on_sample")) is True
-    assert d["cfg5_flat"]["kernel"] == "pg_oct_pruned_group_by"   # 3 M docs >= 2^20: the pruned-offer passes (pg_kernels_oct.hip)
+    # 3 M docs are under 16 offers per HLL register (12 800 groups x 256): the partition pipeline; the 10^9-doc run takes the pruned-offer
+    # passes (pg_kernels_oct.hip; tests/test_gpu_full_size.py asserts that name)
+    assert d["cfg5_flat"]["kernel"] == "pg_part_group_by"
     st = d["cfg5_star_tree"]
     assert st["groups"] == 12800 and st["star_tree_index"] == 0 and st["device_ms"] > 0
     # the library merge with nothing to exchange (communicator of one rank): its latency is on record, its result the unmerged one

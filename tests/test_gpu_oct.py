@@ -200,15 +200,17 @@ def test_pruned_offers_need_many_distinct_values(gpu_api, oracle_api, monkeypatc
     o.destroy()
 
 
-def test_pruned_offers_default_threshold(gpu_api, oracle_api):
-    """Without the knobs a small segment keeps the partition pipeline, a segment of >= 2^20 docs takes the pruned passes."""
-    small = synth.generate_segment(50_000, segment_index=6, columns=synth.CFG5_COLUMNS, native=False)
-    g, o = both(gpu_api, oracle_api, small)
+def test_pruned_offers_default_threshold(gpu_api, oracle_api, monkeypatch):
+    """Without the knobs a segment with fewer than 16 offers per register (12 800 groups x 256 registers: 52 M docs) keeps the partition
+    pipeline — its floors would not rise; with the threshold lowered the same docs take the pruned passes and answer the same.  (The
+    default's positive side is the full-size test: tests/test_gpu_full_size.py.)"""
+    seg = synth.generate_segment(1_200_000, segment_index=6, columns=synth.CFG5_COLUMNS, native=True)
+    g, o = both(gpu_api, oracle_api, seg)
     run(g, o, synth.QUERY_CFG5, kernels=("pg_part_group_by",))
     g.destroy()
-    o.destroy()
-    big = synth.generate_segment(1_200_000, segment_index=6, columns=synth.CFG5_COLUMNS, native=True)
-    g, o = both(gpu_api, oracle_api, big)
+    monkeypatch.setenv("PG_OCT_MIN_DOCS", "1000000")
+    g = NativeSegment(gpu_api, seg)   # (plans are cached per segment: a new one sees the knob)
     run(g, o, synth.QUERY_CFG5, kernels=("pg_oct_pruned_group_by",))
     g.destroy()
     o.destroy()
+
