@@ -379,7 +379,7 @@ struct PgQueryPlan {
   int32_t oct_nonneg;               // kind 1: every dictionary value is >= 0 (the high word of (long) value hashes to nothing)
   int32_t oct_base, oct_step;       // kind 1 otherwise: value = oct_base + oct_step x dictId
   int32_t oct_t0, oct_t1;           // oct = 2: the wave tiles [t0, t1) of this pass
-  int32_t oct_pad;
+  int32_t oct_dword;                // oct = 1, HyperLogLog: the workgroup's registers are dwords in LDS (ds_max_u32), packed to bytes at the flush
   const uint32_t* oct_lut;          // kind 2
   const uint8_t* oct_floor;         // oct = 2: [n_groups] smallest register of every group so far (dword padded)
   uint32_t* oct_counts;             // oct = 2: [grid][n_groups] 32-bit COUNT partials of this pass

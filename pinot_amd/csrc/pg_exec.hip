@@ -786,7 +786,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
   if (oct_lds) split_shift = 0;
   D.tile_split_shift = split_shift;
   LaunchShape shape = launch_shape(P, P.dev.n_wtiles << split_shift, D.agg_mode);
-  if (oct_lds) shape = {std::max(1, std::min((P.dev.n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, num_cus())), PG_BLOCK, P.lds_bytes + 64};
+  if (oct_lds) shape = {std::max(1, std::min((P.dev.n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, num_cus())), PG_BLOCK, (D.oct_dword ? (size_t)D.aux[0].lds_offset + (size_t)D.aux[0].rep_bytes * 4 : P.lds_bytes) + 64};
   const int64_t n_out = (int64_t)D.n_ops * D.n_groups;
   // The stats counters are zero on entry: the reduce kernel of the previous query on this stream re-zeroes them after
   // moving them behind the result table (one device→host copy per query).

@@ -339,6 +339,13 @@ DEVFN void oct_apply_lds(const PgQueryPlan& p, uint32_t m8, const uint32_t (&key
   // two LDS round trips whatever the number of raises (one read + one CAS chain per doc measured 58 % of the wave's time waiting,
   // profiles/r04_b_sq_oct_l.txt); a CAS that lost against another writer of the same dword is retried in a (rare) serial loop.
   const uint32_t log2m = (uint32_t)p.oct_log2m;
+  if (p.oct_dword) {   // room for a dword per register (planner): one ds_max_u32 per offer, nothing returned
+    const uint32_t imask = (1u << log2m) - 1u;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      if ((m8 >> j) & 1u) atomicMax(aux_words + (key[j] * stride + (item[j] & imask)), item[j] >> log2m);
+    return;
+  }
   oct_raise_four<0>(m8, key, item, aux_words, stride, log2m);
   oct_raise_four<4>(m8, key, item, aux_words, stride, log2m);
 }
@@ -356,7 +363,8 @@ __device__ __forceinline__ void oct_body_lds(const PgQueryPlan& p) {
   uint32_t* aux_words = reinterpret_cast<uint32_t*>(smem);
   if (p.n_aux > 0) {
     aux_words = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(smem) + p.aux[0].lds_offset);
-    for (int64_t i = t; i < p.aux[0].rep_bytes / 4; i += PG_BLOCK) aux_words[i] = 0;
+    const int64_t n_words = p.oct_dword ? p.aux[0].rep_bytes : p.aux[0].rep_bytes / 4;
+    for (int64_t i = t; i < n_words; i += PG_BLOCK) aux_words[i] = 0;
   }
   // MatchAllFilterOperator: no filter pass ran in front — every doc matches (ExecutionStatistics.numDocsScanned)
   if (!MASKED && blockIdx.x == 0 && t == 0) atomicAdd(p.stats, (unsigned long long)p.num_docs);
@@ -409,7 +417,14 @@ __device__ __forceinline__ void oct_body_lds(const PgQueryPlan& p) {
   }
   if (p.n_aux > 0) {
     uint32_t* dst = p.aux[0].base + (int64_t)blockIdx.x * (p.aux[0].rep_bytes / 4);
-    for (int64_t i = t; i < p.aux[0].rep_bytes / 4; i += PG_BLOCK) dst[i] = aux_words[i];
+    if (p.oct_dword) {   // dword registers -> the byte registers everything downstream reads
+      for (int64_t i = t; i < p.aux[0].rep_bytes / 4; i += PG_BLOCK) {
+        const u32x4 r = *reinterpret_cast<const u32x4*>(aux_words + 4 * i);
+        dst[i] = r.x | (r.y << 8) | (r.z << 16) | (r.w << 24);
+      }
+    } else {
+      for (int64_t i = t; i < p.aux[0].rep_bytes / 4; i += PG_BLOCK) dst[i] = aux_words[i];
+    }
   }
 }
 extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_oct_l(const PgQueryPlan p) { oct_body_lds<false>(p); }

@@ -965,6 +965,7 @@ static OpPtr clone_leaf(const FilterOp& op) {
 // (32-bit COUNTs + one floor byte per group) fits LDS — the pruned-offer passes.  Called once every other decision of the plan is taken.
 static void plan_oct(CompiledPlan& P, PgQueryPlan& D, const std::vector<Column*>& srcs, int64_t G, int64_t total_docs) {
   D.oct = 0;
+  D.oct_dword = 0;
   if (getenv("PG_NO_OCT")) return;   // measurement / test knob: the round-3 kernels
   if (D.mv || P.first_doc_op >= 0 || D.n_aux != 1 || srcs.size() != 1 || D.n_group_cols > 4 || D.n_ops > 1) return;
   for (int g = 0; g < D.n_group_cols; g++)
@@ -1006,6 +1007,9 @@ static void plan_oct(CompiledPlan& P, PgQueryPlan& D, const std::vector<Column*>
   D.oct_log2m = A.log2m;
   if (P.aux_in_lds && (D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE) && A.lds_offset >= 0) {
     D.oct = 1;
+    // HyperLogLog registers as DWORDS while they live in LDS, if the key space leaves room for four bytes per register (<= ~140 groups
+    // of 256 registers): an offer is one ds_max_u32 without a return instead of a read, a compare and a compare-and-swap on the byte's dword
+    D.oct_dword = kind != 4 && (int64_t)A.lds_offset + A.rep_bytes * 4 + 64 <= 156 * 1024 && !getenv("PG_OCT_BYTE_REGS") ? 1 : 0;
     return;
   }
   // pruned offers: HyperLogLog only, one-dword tuples of the partition pipeline, counters + floors of the whole key space in LDS

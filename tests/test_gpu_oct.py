@@ -128,6 +128,17 @@ def test_round3_kernels_agree(gpu_api, oracle_api, monkeypatch):
     o.destroy()
 
 
+def test_byte_registers_in_lds_agree(gpu_api, oracle_api, monkeypatch):
+    """PG_OCT_BYTE_REGS: key spaces small enough for dword registers in LDS (ds_max_u32 offers) run with byte registers (compare-and-swap)
+    instead — the layout larger key spaces use; the A/B knob of the variants table."""
+    monkeypatch.setenv("PG_OCT_BYTE_REGS", "1")
+    g, o = both(gpu_api, oracle_api, make_host(100_003, seed=5))
+    for sql in (LDS_SHAPES[0], LDS_SHAPES[2], LDS_SHAPES[8], LDS_SHAPES[10], LDS_SHAPES[13]):
+        run(g, o, sql, kernels=("pg_oct_l", "pg_oct_lm"))
+    g.destroy()
+    o.destroy()
+
+
 # ---- pruned offers ---------------------------------------------------------------------------------------------------------------------
 PRUNED_SHAPES = [
     synth.QUERY_CFG5,

@@ -2,6 +2,7 @@
 import argparse
 import ctypes as C
 import statistics
+import time
 import sys
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,7 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--docs", type=int, default=200_000_000)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--only", default="", help="substring of the query names to run (a leading '=' asks for the exact name)")
-ap.add_argument("--set", choices=["cfg3", "cfg5", "general", "wide", "upsert", "postings"], default="cfg3")
+ap.add_argument("--set", choices=["cfg3", "cfg5", "general", "wide", "upsert", "postings", "mv", "strings"], default="cfg3")
 args = ap.parse_args()
 api = capi.gpu_api()
 api.call("init", 0)
@@ -35,6 +36,37 @@ if args.set == "wide":
     w = (synth.values_numpy(synth.GPU_BENCH["u"], synth.SEED_BASE, n) % 2000).astype(np.int32)
     seg.add_column(build_column("w1", w, "INT"), keep_host_buffers=False)
     del mvals, w
+
+MV_BYTES = {}
+if args.set == "mv":
+    # multi-value dictionary columns (FixedBitMVForwardIndexReader layout) next to the synthetic table's columns, built with numpy:
+    # mv1 — 1000 values, 1-5 entries per doc; mv2 — 20 values, 1-3 entries per doc; keep --docs around 5e7 (17 s of packing per column)
+    import numpy as np
+    from pinot_amd import formats
+    from pinot_amd.segment import HostColumn
+    n = args.docs
+    rng = np.random.default_rng(2)
+    for cname, card, hi in (("mv1", 1000, 6), ("mv2", 20, 4)):
+        lengths = rng.integers(1, hi, n).astype(np.int64)
+        total = int(lengths.sum())
+        ids = rng.integers(0, card, total).astype(np.int32)
+        bits = formats.num_bits_per_value(card - 1)
+        col = HostColumn(cname, "INT", capi.FWD_DICT_FIXED_BIT_MV, True, card, bits, False, 4, formats.write_fixed_bit_mv(ids, lengths, bits),
+                         formats.write_numeric_dictionary(np.arange(card, dtype=np.int32), "INT"), None, None)
+        col.total_number_of_entries = total
+        seg.add_column(col, keep_host_buffers=False)
+        MV_BYTES[cname] = (total * bits / 8 + total / 8) / n   # entries + the row-start bitmap, per doc
+        del lengths, ids, col
+
+if args.set == "strings":
+    # a raw (no-dictionary) STRING column, var-byte chunks V4: 5000 distinct 10-byte values; Python builds the values: keep --docs around 2e7
+    import numpy as np
+    from pinot_amd.segment import build_column
+    n = args.docs
+    rng = np.random.default_rng(3)
+    vals = [f"city_{i:05d}" for i in rng.integers(0, 5000, n)]
+    seg.add_column(build_column("s", vals, "STRING", dictionary=False), keep_host_buffers=False)
+    del vals
 
 if args.set == "postings":
     # inverted indexes whose containers are NOT bitmaps: a 1000-value column (about 65 docs per dictId and 2^16-doc chunk: array
@@ -82,6 +114,8 @@ QUERIES5 = {
     "hash: group u,h1,h2 where h3=1,h4=2": ("SELECT u, h1, h2, COUNT(*) FROM t WHERE h3 = 1 AND h4 = 2 GROUP BY u, h1, h2 LIMIT 10000000", 4.0),
     "probe radix sum(h3)": ("SELECT h1, h2, h3, h4, COUNT(*), SUM(h3) FROM t GROUP BY h1, h2, h3, h4 LIMIT 20000", 1.875),
     "probe radix hll(h3)": ("SELECT h1, h2, h3, h4, COUNT(*), DISTINCTCOUNTHLL(h3) FROM t GROUP BY h1, h2, h3, h4 LIMIT 20000", 1.875),
+    "cfg5 final values": (synth.QUERY_CFG5 + " /*final*/", 4.375),
+    "hll(u) group h1,h2 final": ("SELECT h1, h2, DISTINCTCOUNTHLL(u), COUNT(*) FROM t GROUP BY h1, h2 /*final*/", 3.5),
     "cfg5 count group h1..h3": ("SELECT h1, h2, h3, COUNT(*) FROM t GROUP BY h1, h2, h3 LIMIT 20000", 1.5),
 }
 QUERIES_GENERAL = {   # shapes outside the specialised kernels: several scans, OR of scans, tables beyond LDS
@@ -103,6 +137,26 @@ QUERIES_WIDE = {   # LDS-table aggregations over 64-bit sources / an 11-bit grou
     "filtered sum(m64) group w1": ("SELECT w1, SUM(m64) FROM t WHERE r_int BETWEEN 250000 AND 749999 GROUP BY w1 LIMIT 5000", 13.375),
     "sum(m64) no group": ("SELECT SUM(m64), MIN(m64), COUNT(*) FROM t WHERE c_inv2 = 1", 8.125),
 }
+if args.set == "mv":
+    b1, b2 = MV_BYTES["mv1"], MV_BYTES["mv2"]
+    QUERIES = {   # bytes per row: every entry of the multi-value columns read + the single-value columns
+        "mv scan: mv1 = 7 count": ("SELECT COUNT(*) FROM t WHERE mv1 = 7", b1),
+        "mv scan: mv1 between + sum group g1": ("SELECT g1, SUM(m), COUNT(*) FROM t WHERE mv1 BETWEEN 100 AND 199 GROUP BY g1", b1 + 4.875),
+        "mv scan NOT IN + sv scan": ("SELECT COUNT(*), SUM(m) FROM t WHERE mv2 NOT IN (1, 2, 3) AND r_int < 500000", b2 + 8.0),
+        "group by mv2": ("SELECT mv2, COUNT(*), SUM(m) FROM t GROUP BY mv2 LIMIT 100", b2 + 4.0),
+        "group by mv1 (1000)": ("SELECT mv1, COUNT(*), MAX(m) FROM t GROUP BY mv1 LIMIT 2000", b1 + 4.0),
+        "group by mv2, g1": ("SELECT mv2, g1, COUNT(*), SUM(m) FROM t GROUP BY mv2, g1 LIMIT 10000", b2 + 4.875),
+        "group by mv1, mv2 (cartesian)": ("SELECT mv1, mv2, COUNT(*) FROM t WHERE r_int < 250000 GROUP BY mv1, mv2 LIMIT 100000", b1 + b2 + 4.0),
+        "summv/countmv/maxmv group g1": ("SELECT g1, SUMMV(mv1), COUNTMV(mv1), MAXMV(mv1) FROM t GROUP BY g1", b1 + 0.875),
+        "avgmv/minmaxrangemv no group": ("SELECT AVGMV(mv1), MINMAXRANGEMV(mv1), COUNT(*) FROM t WHERE c_inv2 = 1", b1 + 0.125),
+        "distinctcountmv(mv1) group g1": ("SELECT g1, DISTINCTCOUNTMV(mv1) FROM t GROUP BY g1", b1 + 0.875),
+        "distinctcounthllmv(mv1)": ("SELECT DISTINCTCOUNTHLLMV(mv1) FROM t WHERE r_int < 500000", b1 + 4.0),
+    }
+if args.set == "strings":
+    QUERIES = {   # 14 bytes per row: a 10-byte value and its 4-byte offset
+        "group by raw string": ("SELECT s, COUNT(*), SUM(m) FROM t GROUP BY s LIMIT 10000", 18.0),
+        "group by raw string, g1": ("SELECT s, g1, COUNT(*) FROM t WHERE r_int < 500000 GROUP BY s, g1 LIMIT 1000000", 18.875),
+    }
 if args.set == "upsert":   # the same shapes behind an upsert queryableDocIds snapshot (90 % of the docs valid): +1 bit per doc
     import numpy as np
     rng = np.random.default_rng(0)
@@ -121,19 +175,25 @@ if args.set == "postings":
 for name, (sql, bpr) in QUERIES.items():
     if args.only and (args.only[1:] != name if args.only.startswith("=") else args.only not in name):
         continue
-    qc = parse_sql(sql)
+    qc = parse_sql(sql.replace(" /*final*/", ""))
     qc.flags |= capi.QUERY_FLAG_PROFILE
+    if "/*final*/" in sql:
+        qc.flags |= capi.QUERY_FLAG_FINAL_DISTINCT
     cq = CQuery(qc)
-    ms = []
+    ms, wall = [], []
     for i in range(args.reps + 2):
         h = C.c_void_p()
+        t0 = time.perf_counter()
         api.call("query_exec", seg.handle, cq.ptr(), C.byref(h))
+        wall.append((time.perf_counter() - t0) * 1e3)
         st = capi.PgExecStats()
         api.call("result_stats", h, C.byref(st))
         api.call("result_free", h)
         if i >= 2:
             ms.append(st.device_ms_aggregate)
     m = statistics.median(ms)
+    if args.set == "strings" or "/*final*/" in sql:   # what the first use costs (virtual dictionary build) and the call as the host sees it
+        print(f"{name:32s} wall: first call {wall[0]:9.3f} ms, second {wall[1]:8.3f} ms, median of the rest {statistics.median(wall[2:]):8.3f} ms")
     if m <= 0:
         print(f"{name:32s} no kernel ran (answered on the host)")
         continue
