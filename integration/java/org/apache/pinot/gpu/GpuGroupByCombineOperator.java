@@ -1,0 +1,146 @@
+/**
+ * GroupByCombineOperator with the library merge in front (pinot-core/.../operator/combine/GroupByCombineOperator.java:100-160): when
+ * every segment operator of the query is a GpuGroupByOperator, the per-segment accumulator tables stay in HBM
+ * (QUERY_FLAG_KEEP_DEVICE_TABLE), tables of one GPU are folded there (pg_result_merge), the per-GPU tables are folded over RCCL
+ * (pg_result_all_reduce: every rank ends with the merged table) and ONE table is decoded.  What the unchanged combine code then sees is
+ * one non-empty results block and empty ones: IndexedTable upserts, trimming, ordering and the instance response are the reference's.
+ *
+ * The library refuses what it cannot merge by dictId — segments with different dictionaries, hashed key spaces, trimmed tables
+ * (UnsupportedOperationException, decided on every rank alike before any exchange: pg_comm.cpp): the tables that did not fold are
+ * decoded one by one and merged by values, which is what GroupByCombineOperator always does.
+ *
+ * The seam: CombinePlanNode#getCombineOperator (core/plan/CombinePlanNode.java:140-145) constructs GroupByCombineOperator itself and
+ * InstancePlanMakerImplV2#makeInstancePlan (:171-198) keeps its option handling private, so a plan maker cannot substitute the combine
+ * operator; INTEGRATION.md §4.2 shows the four-line patch of getCombineOperator that constructs this class.
+ */
+package org.apache.pinot.gpu;
+
+import java.util.ArrayList;
+import java.util.List;
+import java.util.Map;
+import java.util.TreeMap;
+import java.util.concurrent.ExecutionException;
+import java.util.concurrent.ExecutorService;
+import java.util.concurrent.Future;
+import org.apache.pinot.core.common.Operator;
+import org.apache.pinot.core.operator.blocks.results.BaseResultsBlock;
+import org.apache.pinot.core.operator.combine.GroupByCombineOperator;
+import org.apache.pinot.core.query.request.context.QueryContext;
+
+public class GpuGroupByCombineOperator extends GroupByCombineOperator {
+  private static final String EXPLAIN_NAME = "GPU_COMBINE_GROUP_BY";
+
+  private final List<Operator> _segmentOperators;
+  private final ExecutorService _workers;
+
+  public GpuGroupByCombineOperator(List<Operator> operators, QueryContext queryContext, ExecutorService executorService) {
+    super(operators, queryContext, executorService);
+    _segmentOperators = operators;
+    _workers = executorService;
+  }
+
+  /** CombinePlanNode's test: the library merge applies when every segment runs on the accelerated path. */
+  public static boolean applies(List<Operator> operators) {
+    if (GpuInstancePlanMaker.current() == null || operators.size() < 2) {
+      return false;
+    }
+    for (Operator operator : operators) {
+      if (!(operator instanceof GpuGroupByOperator)) {
+        return false;
+      }
+    }
+    return true;
+  }
+
+  @Override
+  public String toExplainString() {
+    return EXPLAIN_NAME;
+  }
+
+  @Override
+  protected BaseResultsBlock getNextBlock() {
+    if (applies(_segmentOperators)) {
+      foldInLibrary();
+    }
+    return super.getNextBlock();   // upserts the (now mostly empty) segment blocks into the IndexedTable, trims, orders
+  }
+
+  private void foldInLibrary() {
+    GpuInstancePlanMaker maker = GpuInstancePlanMaker.current();
+    int n = _segmentOperators.size();
+    GpuGroupByOperator[] ops = new GpuGroupByOperator[n];
+    long[] results = new long[n];
+    for (int i = 0; i < n; i++) {
+      ops[i] = (GpuGroupByOperator) _segmentOperators.get(i);
+      results[i] = ops[i].execute();   // 0: refused at run time (hash bucket overflow) — that operator answers with its Java plan
+    }
+    // tables of one GPU fold into the first table of that GPU; a table the library refuses to fold stays a head of its own
+    Map<Integer, List<Integer>> headsOfDevice = new TreeMap<>();
+    for (int i = 0; i < n; i++) {
+      if (results[i] == 0) {
+        continue;
+      }
+      List<Integer> heads = headsOfDevice.computeIfAbsent(ops[i].device(), d -> new ArrayList<>());
+      boolean folded = false;
+      for (int head : heads) {
+        try {
+          PinotGpu.resultMerge(results[head], results[i]);
+          folded = true;
+          break;
+        } catch (UnsupportedOperationException differentDictionaries) {
+          // pg_result_merge checks the layout signature (dictionary contents included) before it touches either table
+        }
+      }
+      if (folded) {
+        PinotGpu.resultFree(results[i]);
+        results[i] = 0;
+        ops[i].adoptFolded();
+      } else {
+        heads.add(i);
+      }
+    }
+    // one table per GPU of the communicator: fold across the GPUs; every rank calls from a thread of its own (the collective returns
+    // when all ranks joined), and every rank ends with the merged table — rank 0's is decoded, the others are dropped
+    boolean onePerDevice = headsOfDevice.size() == maker.numDevices() && headsOfDevice.size() > 1;
+    for (List<Integer> heads : headsOfDevice.values()) {
+      onePerDevice &= heads.size() == 1;
+    }
+    if (onePerDevice) {
+      List<Integer> ranks = new ArrayList<>();
+      List<Future<?>> calls = new ArrayList<>();
+      for (Map.Entry<Integer, List<Integer>> e : headsOfDevice.entrySet()) {
+        int head = e.getValue().get(0);
+        long comm = maker.communicatorOf(e.getKey());
+        ranks.add(head);
+        calls.add(_workers.submit(() -> PinotGpu.resultAllReduce(results[head], comm)));
+      }
+      boolean reduced = true;
+      for (Future<?> call : calls) {
+        try {
+          call.get();
+        } catch (ExecutionException e) {
+          if (!(e.getCause() instanceof UnsupportedOperationException)) {   // the refusal is collective: every rank threw it
+            throw new RuntimeException(e.getCause());
+          }
+          reduced = false;
+        } catch (InterruptedException e) {
+          Thread.currentThread().interrupt();
+          throw new RuntimeException(e);
+        }
+      }
+      if (reduced) {
+        for (int r = 1; r < ranks.size(); r++) {
+          int i = ranks.get(r);
+          PinotGpu.resultFree(results[i]);
+          results[i] = 0;
+          ops[i].adoptFolded();
+        }
+      }
+    }
+    for (int i = 0; i < n; i++) {
+      if (results[i] != 0) {
+        ops[i].adopt(results[i]);   // decoded (and freed) by the operator's getNextBlock inside the unchanged combine loop
+      }
+    }
+  }
+}

@@ -40,9 +40,19 @@ public class GpuGroupByOperator extends BaseOperator<BaseResultsBlock> {
   private final NativeQuery _nativeQuery;
   private final Supplier<Operator> _fallback;   // the default plan of this segment (run-time PG_ERR_UNSUPPORTED: hash bucket overflow)
   private final long[] _stats = new long[5];
+  private final int _device;
+  private long _adopted;
+  private boolean _folded;
+  private boolean _refused;
 
   public GpuGroupByOperator(IndexSegment segment, QueryContext queryContext, long segmentHandle, NativeQuery nativeQuery,
       Supplier<Operator> fallback) {
+    this(segment, queryContext, segmentHandle, nativeQuery, fallback, 0);
+  }
+
+  public GpuGroupByOperator(IndexSegment segment, QueryContext queryContext, long segmentHandle, NativeQuery nativeQuery,
+      Supplier<Operator> fallback, int device) {
+    _device = device;
     _segment = segment;
     _queryContext = queryContext;
     _segmentHandle = segmentHandle;
@@ -52,20 +62,60 @@ public class GpuGroupByOperator extends BaseOperator<BaseResultsBlock> {
 
   @Override
   protected BaseResultsBlock getNextBlock() {
+    if (_folded) {   // this segment's table went into another operator's (GpuGroupByCombineOperator): nothing of its own to add
+      List<ExpressionContext> groupBy = _queryContext.getGroupByExpressions();
+      return new GroupByResultsBlock(
+          dataSchema(groupBy, _queryContext.getAggregationFunctions(), GpuResultObjects.keyTypes(_segment, groupBy)), _queryContext);
+    }
+    long result = _adopted;
+    _adopted = 0;
+    if (result == 0 && !_refused) {
+      result = execute();
+    }
+    return _refused ? (BaseResultsBlock) _fallback.get().nextBlock() : blockOf(result);
+  }
+
+  /**
+   * One pg_query_exec over this operator's segment; the caller owns the result handle (0: refused at run time).  GpuGroupByCombineOperator calls this on
+   * operators whose query record carries QUERY_FLAG_KEEP_DEVICE_TABLE, folds the tables in the library and decodes one of them with
+   * blockOf; the statistics of THIS segment are read here, before any merge, for getExecutionStatistics.
+   */
+  long execute() {
     long cancel = PinotGpu.cancelCreate();
     GpuCancellation.register(Thread.currentThread(), cancel);   // the query killer calls PinotGpu.cancelRequest(token) when it interrupts
-    long result;
     try {
-      result = PinotGpu.queryExec(_segmentHandle, _nativeQuery.address(), cancel);   // EarlyTerminationException when cancelled
-    } catch (UnsupportedOperationException e) {
-      return (BaseResultsBlock) _fallback.get().nextBlock();
+      long result = PinotGpu.queryExec(_segmentHandle, _nativeQuery.address(), cancel);   // EarlyTerminationException when cancelled
+      PinotGpu.resultStats(result, _stats);
+      return result;
+    } catch (UnsupportedOperationException e) {   // run-time PG_ERR_UNSUPPORTED: getNextBlock answers with the segment's default plan
+      _refused = true;
+      return 0;
     } finally {
       GpuCancellation.unregister(Thread.currentThread());
       PinotGpu.cancelDestroy(cancel);
       _nativeQuery.close();
     }
+  }
+
+  /** A result executed earlier (execute) becomes what the next getNextBlock decodes: the combine operator's by-values route. */
+  void adopt(long result) {
+    _adopted = result;
+  }
+
+  /** This segment's table was folded into another operator's result (pg_result_merge / pg_result_all_reduce). */
+  void adoptFolded() {
+    _folded = true;
+  }
+
+  int device() {
+    return _device;
+  }
+
+  /** Decodes `result` (this segment's, or a library merge over segments sharing its dictionaries) into a results block and frees it. */
+  BaseResultsBlock blockOf(long result) {
     try {
-      PinotGpu.resultStats(result, _stats);
+      long[] stats = new long[5];
+      PinotGpu.resultStats(result, stats);
       AggregationFunction[] functions = _queryContext.getAggregationFunctions();
       int numGroups = PinotGpu.resultNumGroups(result);
       List<ExpressionContext> groupBy = _queryContext.getGroupByExpressions();
@@ -137,7 +187,7 @@ public class GpuGroupByOperator extends BaseOperator<BaseResultsBlock> {
       }
       GroupByResultsBlock block = new GroupByResultsBlock(dataSchema(groupBy, functions, GpuResultObjects.keyTypes(_segment, groupBy)),
           new AggregationGroupByResult(new ArrayGroupKeyGenerator(keys), functions, holders), _queryContext);
-      block.setNumGroupsLimitReached(_stats[4] != 0);
+      block.setNumGroupsLimitReached(stats[4] != 0);
       return block;
     } finally {
       PinotGpu.resultFree(result);

@@ -8,8 +8,8 @@
  *   pinot.server.query.executor.plan.maker.class=org.apache.pinot.gpu.GpuInstancePlanMaker
  *   pinot.server.gpu.devices=0,1,2,3,4,5,6,7      # segments are spread round-robin over these GPUs (segment -> GPU map)
  *   pinot.server.gpu.library.merge=true           # one RCCL communicator per GPU (pg_comm_init_all) for tables whose segments share
- *                                                 # their dictionaries: a combine operator may then fold the per-GPU partial tables with
- *                                                 # PinotGpu.resultMerge (same GPU) / resultAllReduce (across GPUs) before decoding groups;
+ *                                                 # their dictionaries: GpuGroupByCombineOperator folds the per-segment tables with
+ *                                                 # PinotGpu.resultMerge (same GPU) / resultAllReduce (across GPUs) before one decode;
  *                                                 # UnsupportedOperationException (different dictionaries, hashed key spaces, trimming)
  *                                                 # means: merge by values in IndexedTable, as GroupByCombineOperator always does
  */
@@ -28,6 +28,16 @@ public class GpuInstancePlanMaker extends InstancePlanMakerImplV2 {
   private GpuSegmentRegistry _registry;
   private int[] _devices;
   private long[] _comms;   // null unless pinot.server.gpu.library.merge: _comms[i] is the communicator of _devices[i]
+  private static volatile GpuInstancePlanMaker _current;   // the server's plan maker once the library merge is configured
+
+  /** The plan maker GpuGroupByCombineOperator takes its communicators from; null when the library merge is not configured. */
+  public static GpuInstancePlanMaker current() {
+    return _current;
+  }
+
+  public int numDevices() {
+    return _devices.length;
+  }
 
   @Override
   public void init(PinotConfiguration config) {
@@ -44,6 +54,7 @@ public class GpuInstancePlanMaker extends InstancePlanMakerImplV2 {
       long[] comms = new long[ordinals.length];
       PinotGpu.commInitAll(ordinals, comms);   // RuntimeException when librccl cannot be loaded: the server then fails fast at start-up
       _comms = comms;
+      _current = this;
     }
   }
 
@@ -64,11 +75,14 @@ public class GpuInstancePlanMaker extends InstancePlanMakerImplV2 {
         && !queryContext.isNullHandlingEnabled()) {
       long handle = _registry.handleFor((ImmutableSegment) segment, segmentContext);   // pins the columns in HBM on first use; 0: Java plan only
       if (handle != 0) {
-        NativeQuery nativeQuery = NativeQuery.from(queryContext);
+        // with the library merge configured the group-by tables stay in HBM for GpuGroupByCombineOperator (PinotGpu.resultMerge /
+        // resultAllReduce); without the combine patch the operators decode them one by one as before
+        boolean keep = _comms != null && queryContext.getGroupByExpressions() != null;
+        NativeQuery nativeQuery = NativeQuery.from(queryContext, keep ? PinotGpu.QUERY_FLAG_KEEP_DEVICE_TABLE : 0);
         if (nativeQuery != null) {
           if (PinotGpu.querySupported(handle, nativeQuery.address()) == PinotGpu.PG_OK) {
             return () -> new GpuGroupByOperator(segment, queryContext, handle, nativeQuery,
-                () -> super.makeSegmentPlanNode(segmentContext, queryContext).run());
+                () -> super.makeSegmentPlanNode(segmentContext, queryContext).run(), _registry.deviceOf(handle));
           }
           nativeQuery.close();
         }

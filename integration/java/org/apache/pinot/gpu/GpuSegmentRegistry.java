@@ -29,6 +29,7 @@ public final class GpuSegmentRegistry {
   private final int[] _devices;
   private final AtomicInteger _next = new AtomicInteger();
   private final Map<String, Entry> _entries = new ConcurrentHashMap<>();
+  private final Map<Long, Integer> _deviceOfHandle = new ConcurrentHashMap<>();
 
   public GpuSegmentRegistry(int[] devices) {
     _devices = devices;
@@ -62,8 +63,8 @@ public final class GpuSegmentRegistry {
     try (SegmentDirectory.Reader reader = GpuBuffers.readerOf(segment)) {
       for (String column : segment.getPhysicalColumnNames()) {
         ColumnMetadata md = segment.getSegmentMetadata().getColumnMetadataFor(column);
-        if (!md.isSingleValue() && !md.hasDictionary()) {
-          continue;   // raw multi-value columns stay with the Java plan: a query touching one is refused by pg_query_supported (unknown column)
+        if (!md.isSingleValue() && !md.hasDictionary() && !md.getDataType().getStoredType().isFixedWidth()) {
+          continue;   // raw multi-value STRING / BYTES columns stay with the Java plan: a query touching one is refused (unknown column)
         }
         PinotDataBuffer fwd = reader.getIndexFor(column, StandardIndexes.forward());
         PinotDataBuffer dict = md.hasDictionary() ? reader.getIndexFor(column, StandardIndexes.dictionary()) : null;
@@ -71,7 +72,10 @@ public final class GpuSegmentRegistry {
         // pg_fwd_encoding: 3 = FixedBitMVForwardIndexReader (dictionary-encoded multi-value column, ForwardIndexReaderFactory.java:92-96)
         // 4 = VarByteChunkSVForwardIndexReader (raw STRING / BYTES: a GROUP BY key at most), 1 = FixedByteChunkSVForwardIndexReader
         boolean varByte = !md.hasDictionary() && !md.getDataType().getStoredType().isFixedWidth();
-        int fwdEncoding = !md.isSingleValue() ? 3 : md.isSorted() && md.hasDictionary() ? 2 : md.hasDictionary() ? 0 : varByte ? 4 : 1;
+        // 5 = FixedByteChunkMVForwardIndexReader (raw multi-value INT / LONG / FLOAT / DOUBLE, ForwardIndexReaderFactory.java:104-108):
+        // read once at registration into a dictionary-encoded twin (pg_segment.cpp), group keys come back as values
+        int fwdEncoding = !md.isSingleValue() ? (md.hasDictionary() ? 3 : 5)
+            : md.isSorted() && md.hasDictionary() ? 2 : md.hasDictionary() ? 0 : varByte ? 4 : 1;
         try {
           PinotGpu.segmentAddColumn(h, column, GpuBuffers.storedType(md), fwdEncoding, md.hasDictionary(), md.getCardinality(),
               md.getBitsPerElement(), md.isSorted(), GpuBuffers.dictionaryBytesPerValue(md),
@@ -105,6 +109,7 @@ public final class GpuSegmentRegistry {
       }
       GpuBuffers.registerStarTrees(h, segment, reader);   // one PinotGpu.segmentAddStarTree per IndexSegment#getStarTrees() entry
       e._handle = h;
+      _deviceOfHandle.put(h, device);
     } catch (UnsupportedOperationException unsupported) {   // e.g. ZSTANDARD chunks: this segment keeps the Java plan
       PinotGpu.segmentDestroy(h);
       e._handle = 0;
@@ -115,9 +120,16 @@ public final class GpuSegmentRegistry {
     return e;
   }
 
+  /** The GPU a registered segment's columns are pinned on (pg_segment_create_on_device). */
+  public int deviceOf(long handle) {
+    Integer device = _deviceOfHandle.get(handle);
+    return device == null ? _devices[0] : device;
+  }
+
   public void release(ImmutableSegment segment) {
     Entry e = _entries.remove(segment.getSegmentName() + ":" + segment.getSegmentMetadata().getCrc());
     if (e != null && e._handle != 0) {
+      _deviceOfHandle.remove(e._handle);
       PinotGpu.segmentDestroy(e._handle);
     }
   }

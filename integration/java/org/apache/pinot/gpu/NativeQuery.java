@@ -46,13 +46,18 @@ public final class NativeQuery implements AutoCloseable {
   }
 
   public static NativeQuery from(QueryContext q) {
+    return from(q, 0);
+  }
+
+  /** `extraFlags`: PinotGpu.QUERY_FLAG_* ORed into the record (GpuGroupByCombineOperator asks for QUERY_FLAG_KEEP_DEVICE_TABLE). */
+  public static NativeQuery from(QueryContext q, int extraFlags) {
     ByteBuffer b = ByteBuffer.allocateDirect(estimate(q)).order(ByteOrder.LITTLE_ENDIAN);
     List<ExpressionContext> groupBy = q.getGroupByExpressions();
     AggregationFunction[] aggs = q.getAggregationFunctions();
     if (aggs == null || aggs.length == 0) {
       return null;
     }
-    b.putInt(MAGIC).putInt(q.isSkipStarTree() ? FLAG_SKIP_STAR_TREE : 0).putInt(q.getNumGroupsLimit())
+    b.putInt(MAGIC).putInt((q.isSkipStarTree() ? FLAG_SKIP_STAR_TREE : 0) | extraFlags).putInt(q.getNumGroupsLimit())
         .putInt(q.getMaxInitialResultHolderCapacity()).putInt(groupBy == null ? 0 : groupBy.size()).putInt(aggs.length)
         .putInt(q.getFilter() == null ? 0 : 1).putInt(0);
     if (groupBy != null) {

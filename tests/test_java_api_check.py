@@ -46,8 +46,10 @@ MUTATIONS = [
     ("GpuSegmentRegistry.java", "md.getTotalNumberOfEntries()", "md.getTotalNumberOfEntries(1)", "no overload matches (arity)"),
     ("GpuInstancePlanMaker.java", "QueryContextUtils.isAggregationQuery(queryContext)", "QueryContextUtils.isAggregationQuery(segment)",
      "no overload matches (types)"),
-    ("GpuGroupByOperator.java", "block.setNumGroupsLimitReached(_stats[4] != 0);", "block.setNumGroupsLimitReached(_stats[4]);",
+    ("GpuGroupByOperator.java", "block.setNumGroupsLimitReached(stats[4] != 0);", "block.setNumGroupsLimitReached(stats[4]);",
      "no overload matches (types)"),
+    ("GpuGroupByCombineOperator.java", "super(operators, queryContext, executorService);", "super(operators, queryContext);", "no constructor matches"),
+    ("GpuGroupByCombineOperator.java", "return super.getNextBlock();", "return super.getNextResultsBlock();", "no method `getNextResultsBlock`"),
 ]
 
 

@@ -1192,6 +1192,18 @@ class BodyWalker:
                 j = i + 1
                 sk = self.w.resolve(self.k.extends[0], self.k) if self.k.extends else None
                 cur_k, cur = sk, (self.k.extends[0] if self.k.extends else None)
+                if j < end and t[j][1] == "(":   # explicit constructor invocation: super(args)
+                    args, j = self.args_of(j, scope)
+                    if sk is not None:
+                        m, mk, why = self.c.pick([(c, sk) for c in sk.ctors], args, self.k)
+                        if m is None and (sk.ctors or args):
+                            self.c.err(self.jf, "super(%s): no constructor matches (%s); declared: %s" % (
+                                ", ".join(str(a) for a in args), why, "; ".join("(" + ", ".join(p[0] for p in c.params) + ")" for c in sk.ctors) or "none"))
+                        else:
+                            self.c.ok("super/%d of %s" % (len(args), sk.fq()))
+                    else:
+                        self.c.external += 1
+                    cur = None
             else:
                 v = scope.get(x) if scope else None
                 if (scope and self.in_scope(scope, x)) and not (i + 1 < end and t[i + 1][1] == "("):
