@@ -469,7 +469,21 @@ static void check_cancel(const CancelToken* c, ThreadCtx* ctx) {
 }
 // Waits for the stream; with a cancellation token the wait polls it (a running kernel is left to finish: milliseconds).
 static void stream_wait(ThreadCtx& ctx, const CancelToken* c) {
-  if (!c) { PG_HIP(hipStreamSynchronize(ctx.stream)); return; }
+  if (!c) {
+    // short queries: poll for a while before blocking — a blocking wait is woken by an interrupt, microseconds after the stream drained
+    // (config 2 is a 62 us kernel; PG_NO_SPIN_WAIT is the A/B knob)
+    static const bool no_spin = getenv("PG_NO_SPIN_WAIT") != nullptr;
+    if (!no_spin) {
+      const double until = now_ms() + 0.3;
+      do {
+        const hipError_t e = hipStreamQuery(ctx.stream);
+        if (e == hipSuccess) return;
+        if (e != hipErrorNotReady) PG_HIP(e);
+      } while (now_ms() < until);
+    }
+    PG_HIP(hipStreamSynchronize(ctx.stream));
+    return;
+  }
   for (;;) {
     const hipError_t e = hipStreamQuery(ctx.stream);
     if (e == hipSuccess) break;
@@ -1101,12 +1115,17 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
     }
     const int reduce = (D.agg_mode != PG_AGG_GLOBAL && D.agg_mode != PG_AGG_LDS_PART && !radix && n_out > 0) ? 1 : 0;
     const int blocks = (reduce ? (int)((n_out + 3) / 4) : 0) + 1;   // one wavefront per output slot + the stats block
+    // Small tables whose every slot this kernel writes go straight into the pinned result block (mapped into the device's address space:
+    // the stores cross the bus as they retire) — no copy command behind the kernel, one launch less on the query's critical path
+    // (config 2: profiles/r04_j_small_query_latency.txt).
+    static const bool no_direct = getenv("PG_NO_DIRECT_RESULT") != nullptr;   // A/B knob
+    const bool direct_out = !no_direct && !keep_table && (reduce || n_out == 0) && out_bytes <= ((size_t)64 << 10);
     hipLaunchKernelGGL(pg_reduce_partials_kernel, dim3(blocks), dim3(256), 0, ctx.stream, ctx.partials.as<int64_t>(),
-                       ctx.final_table.as<int64_t>(), shape.grid, D.n_ops, D.n_groups, P.ops_dev.as<PgAccOp>(),
+                       direct_out ? host_out : ctx.final_table.as<int64_t>(), shape.grid, D.n_ops, D.n_groups, P.ops_dev.as<PgAccOp>(),
                        ctx.stats.as<unsigned long long>(), reduce);
     PG_HIP(hipGetLastError());
     if (profile) PG_HIP(hipEventRecord(ctx.ev[2], ctx.stream));
-    PG_HIP(hipMemcpyAsync(host_out, ctx.final_table.ptr, out_bytes, hipMemcpyDeviceToHost, ctx.stream));
+    if (!direct_out) PG_HIP(hipMemcpyAsync(host_out, ctx.final_table.ptr, out_bytes, hipMemcpyDeviceToHost, ctx.stream));
     if (final_distinct) {
       const int G1 = std::max(D.n_groups, 1);
       ThreadCtx::grow(ctx.aux_summary, summary_bytes);

@@ -89,14 +89,16 @@ DEVFN void mv_aggregate_wtile(const PgQueryPlan& p, uint32_t m, int wt, int64_t*
     const int64_t doc = (int64_t)wt * PG_WAVE_DOCS + in_tile;
     MvKeys K;
     K.base = rep; K.combos = 1; K.n = 0;
+    K.start[0] = K.start[1] = 0; K.len[0] = K.len[1] = 1; K.mult[0] = K.mult[1] = 0; K.bits[0] = K.bits[1] = 1; K.data[0] = K.data[1] = nullptr;
     for (int g = 0; g < p.n_group_cols; g++) {
       const PgGroupCol& gc = p.gcols[g];
       const uint32_t mult = (uint32_t)gc.mult * R;
       if (p.mv_gcol_offsets[g]) {
         const GAS int32_t* off = gptr<int32_t>(p.mv_gcol_offsets[g]);
         const uint32_t s = (uint32_t)off[doc], e = (uint32_t)off[doc + 1];
-        const int j = K.n < 2 ? K.n : 1;
-        K.start[j] = s; K.len[j] = e - s; K.mult[j] = mult; K.bits[j] = (uint32_t)gc.bits; K.data[j] = gc.data;
+        // (constant indices: a run-time index into the struct's arrays puts them into scratch memory — 72 bytes per lane in round 3)
+        if (K.n == 0) { K.start[0] = s; K.len[0] = e - s; K.mult[0] = mult; K.bits[0] = (uint32_t)gc.bits; K.data[0] = gc.data; }
+        else          { K.start[1] = s; K.len[1] = e - s; K.mult[1] = mult; K.bits[1] = (uint32_t)gc.bits; K.data[1] = gc.data; }
         K.combos *= e - s;
         K.n++;
       } else {
