@@ -17,6 +17,7 @@ PG_DECL_FAST(pg_fast_none_f) PG_DECL_FAST(pg_fast_none_a) PG_DECL_FAST(pg_fast_i
 PG_DECL_FAST(pg_fast_dictrange_f) PG_DECL_FAST(pg_fast_dictrange_a) PG_DECL_FAST(pg_fast_dictlut_f) PG_DECL_FAST(pg_fast_dictlut_a)
 PG_DECL_FAST(pg_fast_multi_f) PG_DECL_FAST(pg_fast_multi_a) PG_DECL_FAST(pg_fast_multi_w) PG_DECL_FAST(pg_fast_none_w)
 PG_DECL_FAST(pg_fast_i32range_d) PG_DECL_FAST(pg_fast_i32range_p) PG_DECL_FAST(pg_fast_i32range_fp)
+PG_DECL_FAST(pg_pipe_w_none) PG_DECL_FAST(pg_pipe_w_index) PG_DECL_FAST(pg_pipe_w_scan) PG_DECL_FAST(pg_pipe_w_index_scan)
 PG_DECL_FAST(pg_pipe_scan) PG_DECL_FAST(pg_pipe_scan_tail) PG_DECL_FAST(pg_pipe_index_scan_tail) PG_DECL_FAST(pg_pipe_none) PG_DECL_FAST(pg_pipe_tail)
 PG_DECL_FAST(pg_pipe_index) PG_DECL_FAST(pg_pipe_index_tail) PG_DECL_FAST(pg_pipe_index2) PG_DECL_FAST(pg_pipe_index2_tail)
 PG_DECL_FAST(pg_pipe_scan_vscan) PG_DECL_FAST(pg_pipe_index_scan_vscan)
@@ -176,7 +177,7 @@ void use_device(int ordinal) {
       // opt in to large dynamic LDS for the query kernels (function attributes are per device)
       typedef void (*QueryKernel)(const PgQueryPlan);
       const QueryKernel all[] = {pg_generic_query_f, pg_generic_query_l, pg_generic_query_g, pg_fast_none_f, pg_fast_none_a, pg_fast_i32range_f, pg_fast_i32range_a,
-                                 pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a, pg_fast_multi_f, pg_fast_multi_a, pg_fast_multi_w, pg_fast_none_w, pg_fast_multi_wd, pg_fast_none_wd, pg_generic_query_ld, pg_generic_query_gd, pg_fast_i32range_d, pg_fast_i32range_p, pg_pipe_scan, pg_pipe_scan_tail, pg_pipe_index_scan_tail, pg_pipe_none, pg_pipe_tail, pg_pipe_index, pg_pipe_index_tail, pg_pipe_index2, pg_pipe_index2_tail, pg_pipe_scan_vscan, pg_pipe_index_scan_vscan, pg_mv_query_f, pg_mv_query_l, pg_mv_query_g,
+                                 pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a, pg_fast_multi_f, pg_fast_multi_a, pg_fast_multi_w, pg_fast_none_w, pg_fast_multi_wd, pg_fast_none_wd, pg_generic_query_ld, pg_generic_query_gd, pg_fast_i32range_d, pg_fast_i32range_p, pg_pipe_scan, pg_pipe_scan_tail, pg_pipe_index_scan_tail, pg_pipe_none, pg_pipe_tail, pg_pipe_index, pg_pipe_index_tail, pg_pipe_index2, pg_pipe_index2_tail, pg_pipe_scan_vscan, pg_pipe_index_scan_vscan, pg_pipe_w_none, pg_pipe_w_index, pg_pipe_w_scan, pg_pipe_w_index_scan, pg_mv_query_f, pg_mv_query_l, pg_mv_query_g,
                                  pg_radix_aggregate_kernel, pg_hash_aggregate_kernel,
                                  pg_p2_scatter_1, pg_p2_scatter_2, pg_p2_scatter_3, pg_p2_scatter_4, pg_p2_scatter_1f, pg_p2_scatter_2f, pg_p2_scatter_1f_key, pg_p2_scatter_1f_hll,
                                  pg_p2_aggregate_1, pg_p2_aggregate_2, pg_p2_aggregate_3, pg_p2_aggregate_4,
@@ -224,9 +225,13 @@ static bool uses_pipe_general(const CompiledPlan& P, int agg_mode) {   // pg_pip
   static const bool no_pipe = getenv("PG_NO_PIPE") != nullptr;   // measurement knob
   return !no_pipe && uses_fast_kernel(P, agg_mode) && agg_mode == PG_AGG_LDS && !P.wide_agg && P.fast_agg && P.dev.pipe_general;
 }
+static bool uses_pipe_wide(const CompiledPlan& P, int agg_mode) {   // pg_pipe_w_*: raw LONG values / group columns of 9 .. 16 bits
+  static const bool no_pipe = getenv("PG_NO_PIPE") != nullptr;   // measurement knob
+  return !no_pipe && uses_fast_kernel(P, agg_mode) && (agg_mode == PG_AGG_LDS || agg_mode == PG_AGG_SINGLE) && P.wide_agg && P.dev.pipe_wide;
+}
 static bool uses_pipe_kernel(const CompiledPlan& P, int agg_mode) {
   static const bool no_pipe = getenv("PG_NO_PIPE") != nullptr || getenv("PG_NO_DENSE_FUSED") != nullptr;   // measurement knob
-  if (uses_pipe_general(P, agg_mode)) return true;
+  if (uses_pipe_general(P, agg_mode) || uses_pipe_wide(P, agg_mode)) return true;
   return !no_pipe && uses_fast_kernel(P, agg_mode) && agg_mode == PG_AGG_LDS && !P.wide_agg && P.fast_agg && P.fast_filter == 4 &&
          P.dev.dense_fused && P.dev.pipe_fit;
 }
@@ -235,6 +240,11 @@ typedef void (*QueryKernel)(const PgQueryPlan);
 static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char** name) {
   const bool agg = agg_mode != PG_AGG_NONE;
   if (uses_fast_kernel(P, agg_mode)) {
+    if (agg && uses_pipe_wide(P, agg_mode)) {
+      const bool idx = P.dev.pipe_has_index != 0, scan = P.dev.pipe_has_scan != 0;
+      *name = scan ? (idx ? "pg_pipe_w_index_scan" : "pg_pipe_w_scan") : (idx ? "pg_pipe_w_index" : "pg_pipe_w_none");
+      return scan ? (idx ? pg_pipe_w_index_scan : pg_pipe_w_scan) : (idx ? pg_pipe_w_index : pg_pipe_w_none);
+    }
     if (agg && P.wide_agg) {
       if (P.fast_filter == -1) { *name = P.digit_ops ? "pg_fast_none_wd" : "pg_fast_none_w"; return P.digit_ops ? pg_fast_none_wd : pg_fast_none_w; }
       *name = P.digit_ops ? "pg_fast_multi_wd" : "pg_fast_multi_w";

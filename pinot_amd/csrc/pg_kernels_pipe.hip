@@ -524,3 +524,276 @@ PG_PIPE_KERNEL(pg_pipe_index2, true, false, false, false, 2)        // ... with 
 PG_PIPE_KERNEL(pg_pipe_index2_tail, true, false, true, false, 2)
 PG_PIPE_KERNEL(pg_pipe_scan_vscan, false, true, false, true)        // range scan AND a range on the value column
 PG_PIPE_KERNEL(pg_pipe_index_scan_vscan, true, true, false, true)   // dense index AND range scan AND a range on the value column
+
+// =====================================================================================================================================
+// The pipeline for WIDE columns (round 4): a raw LONG value column (8 bytes per doc) and / or group columns of 9 .. 16 bits — the shapes
+// pg_fast_none_w / pg_fast_multi_w walked as a dependent chain (46-57 % of 8 TB/s, profiles/r03_m_variants_wide_100m.txt).  Every value
+// accumulator reads ONE raw INT or LONG column; zero to two group columns of <= 16 bits; integer accumulators (SumAggregationFunction
+// .java:160-179 over LONG sources: exact in int64 while the planner's bound holds).
+//
+// The unit in flight is HALF a wave tile (four quads, 1024 docs): a LONG column's quad is 32 bytes per lane, so half a tile is the 32
+// load-target registers a whole tile of a 32-bit column takes, and the two halves are the two buffers of the software pipeline — half
+// B is requested before half A is aggregated, the next tile's half A before half B is.  A lane's 32 bytes are two 16-byte loads at a lane
+// stride of 32 bytes: 6.3 TB/s against 6.6-6.9 TB/s fully coalesced; 64 contiguous bytes per lane (an "8 docs per lane" ownership) drops
+// to 4.0 TB/s (profiles/r04_lane_stride_probe.txt), which is why this kernel keeps the quad layout.  The filter stages run per whole
+// tile as in pipe_general_body: dense postings, one raw-INT range scan.  Group columns take three-dword windows (4 x 16 bits + 31 bits
+// of misalignment).
+// =====================================================================================================================================
+typedef uint32_t u32x3w __attribute__((ext_vector_type(3)));
+typedef u32x3w u32x3w_a4 __attribute__((aligned(4)));
+DEVFN void load_packed_quad_mid(const GAS uint32_t* __restrict__ tw, uint32_t q, uint32_t bits, uint32_t (&r)[3]) {
+  const uint32_t di = __umul24(4u * q, bits) >> 5;   // q < 512, bits <= 16
+  const u32x3w v = ldnt((const GAS u32x3w_a4*)(tw + di));
+  r[0] = v.x; r[1] = v.y; r[2] = v.z;
+}
+DEVFN void decode_packed_quad_mid(const uint32_t (&r)[3], uint32_t q, uint32_t bits, uint32_t mask, uint32_t (&out)[4]) {
+  const uint32_t sh = __umul24(4u * q, bits) & 31u;
+  const uint32_t w0 = bswap32(r[0]), w1 = bswap32(r[1]), w2 = bswap32(r[2]);
+  // the quad's 4 x bits <= 64 bits, left-aligned: (w0:w1:w2) << sh, upper 64 bits (two funnel shifts)
+  const uint32_t hi = __builtin_amdgcn_alignbit(w0, w1, 32u - sh), lo = __builtin_amdgcn_alignbit(w1, w2, 32u - sh);
+  const uint32_t h = sh ? hi : w0, l = sh ? lo : w1;   // alignbit by 32 is a shift by 0 of the LOW operand
+  const uint64_t top = ((uint64_t)h << 32) | (uint64_t)l;
+#pragma unroll
+  for (int i = 0; i < 4; i++) out[i] = (uint32_t)(top >> (64u - (uint32_t)(i + 1) * bits)) & mask;
+}
+
+template <int VW, bool HAS_INDEX, bool HAS_SCAN>
+__device__ __forceinline__ void pipe_wide_body(const PgQueryPlan& p) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
+  __shared__ uint32_t s_stat[PG_MAX_STATS];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = uniform(t >> 6);
+  int64_t* lds_table = reinterpret_cast<int64_t*>(smem);
+  if (t < PG_MAX_STATS) s_stat[t] = 0;
+  {
+    const uint32_t table_slots = (uint32_t)p.n_groups * (uint32_t)p.replicas;
+    for (int o = 0; o < p.n_ops; o++) {
+      const int64_t ident = pg_acc_identity(p.ops[o].fn, p.ops[o].is_float);
+      for (uint32_t i = t; i < table_slots; i += PG_BLOCK) lds_table[(size_t)o * table_slots + i] = ident;
+    }
+  }
+  __syncthreads();
+  const CAS PgScanLeaf& L = cptr(p.scans)[HAS_SCAN ? p.fast_scan : 0];   // only dereferenced when HAS_SCAN
+  const RangeI32 r32 = HAS_SCAN ? make_range_i32(L.lo, L.hi) : RangeI32{0, 0u, false};
+  const uint32_t R = (uint32_t)p.replicas;
+  const uint32_t rep = (uint32_t)t & (R - 1u);
+  const uint32_t stride = (uint32_t)p.n_groups * R;   // slots per op
+  const uint8_t* xdata = p.pipe_src >= 0 ? p.srcs[p.pipe_src].data : p.gcols[0].data;   // COUNT only: no value column is read
+  const bool has_value = p.pipe_src >= 0;
+  const int ng = p.n_group_cols;
+  const int last_wt = p.n_wtiles - 1;
+  const int step = (int)gridDim.x * PG_WAVES_PER_BLOCK;
+  const int n_wtiles_loop = p.n_wtiles;
+  const int wt_first = (int)blockIdx.x * PG_WAVES_PER_BLOCK + wave;
+  uint32_t my_matched = 0, my_cand = 0;
+
+  uint32_t pv[8];
+  auto clamp_tile = [&](int wt) { return wt < last_wt ? wt : last_wt; };
+  auto issue_postings = [&](int wt) {
+    if (!HAS_INDEX) return;
+    const size_t tile_off = (size_t)clamp_tile(wt) * 256u;
+#pragma unroll
+    for (int j = 0; j < 8; j++) pv[j] = ldnt((const GAS uint32_t*)(sgpr_ptr<uint8_t>(p.dense_ptr[j] + tile_off) + (uint32_t)lane * 4u));
+  };
+  auto candidates = [&](int wt) -> uint32_t {   // index program -> candidate mask in quad layout (every valid doc without one)
+    const int64_t rem = wt < n_wtiles_loop ? (int64_t)p.num_docs - (int64_t)wt * PG_WAVE_DOCS : 0;
+    const int32_t n_valid = rem >= PG_WAVE_DOCS ? PG_WAVE_DOCS : (rem > 0 ? (int32_t)rem : 0);
+    if (!HAS_INDEX) return valid_quad_mask(n_valid, lane);
+    uint32_t grp[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int gj = p.dense_group[j];
+#pragma unroll
+      for (int k = 0; k < 4; k++) grp[k] |= gj == k ? pv[j] : 0u;
+    }
+    uint32_t lin = valid_lin_mask(n_valid, lane);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (k < p.dense_groups) lin &= ((p.dense_excl >> k) & 1) ? ~grp[k] : grp[k];
+    return lin_to_quad(lin, lane);
+  };
+  // value / group quads of half `h` (quads 4h .. 4h+3) of tile wt, restricted to quads with matches
+  auto issue_half = [&](int wt, uint32_t m, int h, u32x4 (&x)[4][VW], uint32_t (&g)[2][4][3]) {
+    const int wc = clamp_tile(wt);
+    if (has_value) {
+      const GAS uint8_t* xb = sgpr_ptr<uint8_t>(xdata + (size_t)wc * (size_t)(PG_WAVE_DOCS * 4 * VW));
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int kk = 4 * h + k;
+        const uint32_t q = ((m >> (4 * kk)) & 0xFu) ? (uint32_t)(kk * 64 + lane) : 0u;
+#pragma unroll
+        for (int w = 0; w < VW; w++) x[k][w] = ldnt((const GAS u32x4*)(xb + q * (16u * VW) + 16u * w));
+      }
+    }
+#pragma unroll
+    for (int gi = 0; gi < 2; gi++)
+      if (gi < ng) {   // wave-uniform
+        const PgGroupCol& gc = p.gcols[gi];
+        const GAS uint32_t* tw = sgpr_ptr<uint32_t>((const void*)packed_wtile_base(gc.data, wc, gc.bits));
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const int kk = 4 * h + k;
+          const uint32_t q = ((m >> (4 * kk)) & 0xFu) ? (uint32_t)(kk * 64 + lane) : 0u;
+          load_packed_quad_mid(tw, q, (uint32_t)gc.bits, g[gi][k]);
+        }
+      }
+  };
+  auto aggregate_half = [&](uint32_t m, int h, const u32x4 (&x)[4][VW], const uint32_t (&g)[2][4][3]) {
+    const uint32_t mg = (m >> (16 * h)) & 0xFFFFu;
+    if (__ballot(mg != 0) == 0) return;   // wave-uniform
+    uint32_t slot[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int i = 0; i < 4; i++) slot[k][i] = rep;
+#pragma unroll
+    for (int gi = 0; gi < 2; gi++)
+      if (gi < ng) {
+        const PgGroupCol& gc = p.gcols[gi];
+        const uint32_t bits = (uint32_t)gc.bits, mask = (1u << gc.bits) - 1u;
+        const uint32_t mult = (uint32_t)gc.mult * R;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          uint32_t d[4];
+          const int kk = 4 * h + k;
+          const uint32_t q = ((mg >> (4 * k)) & 0xFu) ? (uint32_t)(kk * 64 + lane) : 0u;
+          decode_packed_quad_mid(g[gi][k], q, bits, mask, d);
+#pragma unroll
+          for (int i = 0; i < 4; i++) slot[k][i] += d[i] * mult;   // < 65536 slots: the planner's bound on n_groups x replicas
+        }
+      }
+    int64_t v[4][4];
+    if (has_value) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (VW == 1) {
+          v[k][0] = (int64_t)(int32_t)bswap32(x[k][0].x); v[k][1] = (int64_t)(int32_t)bswap32(x[k][0].y);
+          v[k][2] = (int64_t)(int32_t)bswap32(x[k][0].z); v[k][3] = (int64_t)(int32_t)bswap32(x[k][0].w);
+        } else {
+          v[k][0] = (int64_t)(((uint64_t)bswap32(x[k][0].x) << 32) | (uint64_t)bswap32(x[k][0].y));
+          v[k][1] = (int64_t)(((uint64_t)bswap32(x[k][0].z) << 32) | (uint64_t)bswap32(x[k][0].w));
+          v[k][2] = (int64_t)(((uint64_t)bswap32(x[k][VW - 1].x) << 32) | (uint64_t)bswap32(x[k][VW - 1].y));
+          v[k][3] = (int64_t)(((uint64_t)bswap32(x[k][VW - 1].z) << 32) | (uint64_t)bswap32(x[k][VW - 1].w));
+        }
+      }
+    }
+    for (int o = 0; o < p.n_ops; o++) {
+      const PgAccOp op = p.ops[o];
+      int64_t* base = lds_table + (size_t)o * stride;
+      if (op.src < 0) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if ((mg >> (4 * k + i)) & 1u) atomicAdd(reinterpret_cast<unsigned long long*>(base + slot[k][i]), 1ULL);
+      } else if (op.fn == PG_ACC_SUM) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if ((mg >> (4 * k + i)) & 1u) atomicAdd(reinterpret_cast<unsigned long long*>(base + slot[k][i]), (unsigned long long)v[k][i]);
+      } else if (op.fn == PG_ACC_MIN) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if ((mg >> (4 * k + i)) & 1u) atomicMin(reinterpret_cast<long long*>(base + slot[k][i]), (long long)v[k][i]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+            if ((mg >> (4 * k + i)) & 1u) atomicMax(reinterpret_cast<long long*>(base + slot[k][i]), (long long)v[k][i]);
+      }
+    }
+  };
+
+  u32x4 xa[4][VW], xb[4][VW];
+  uint32_t ga[2][4][3], gb[2][4][3];
+  if (HAS_SCAN) {
+    // per tile: scan quads of the NEXT tile and the bitmaps of the one after travel while the current tile's halves are aggregated
+    u32x4 a[8];
+    auto issue_scan = [&](int wt, uint32_t cand) {
+      const GAS uint8_t* tb = sgpr_ptr<uint8_t>(L.data + (size_t)clamp_tile(wt) * (PG_WAVE_DOCS * 4));
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const uint32_t q = ((cand >> (4 * k)) & 0xFu) ? (uint32_t)(k * 64 + lane) : 0u;
+        a[k] = ldnt((const GAS u32x4*)(tb + q * 16u));
+      }
+    };
+    auto test_scan = [&](uint32_t cand) -> uint32_t {
+      uint32_t m = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        m |= (uint32_t)in_range_i32(r32, (int32_t)bswap32(a[k].x)) << (4 * k);
+        m |= (uint32_t)in_range_i32(r32, (int32_t)bswap32(a[k].y)) << (4 * k + 1);
+        m |= (uint32_t)in_range_i32(r32, (int32_t)bswap32(a[k].z)) << (4 * k + 2);
+        m |= (uint32_t)in_range_i32(r32, (int32_t)bswap32(a[k].w)) << (4 * k + 3);
+      }
+      my_cand += (uint32_t)__popc(cand);
+      m = r32.empty ? 0u : (m & cand);
+      my_matched += (uint32_t)__popc(m);
+      return m;
+    };
+    int wt_cur = wt_first, wt_nxt = wt_cur + step, wt_far = wt_nxt + step;
+    issue_postings(wt_cur);
+    uint32_t c0 = candidates(wt_cur);
+    issue_postings(wt_nxt);
+    issue_scan(wt_cur, c0);
+    uint32_t m_cur = test_scan(c0);
+    issue_half(wt_cur, m_cur, 0, xa, ga);
+    uint32_t c_nxt = candidates(wt_nxt);
+    issue_postings(wt_far);
+    issue_scan(wt_nxt, c_nxt);
+    while (wt_cur < n_wtiles_loop) {
+      if (p.out_words) reinterpret_cast<uint32_t*>(p.out_words)[(int64_t)wt_cur * 64 + lane] = quad_to_lin(m_cur, lane);
+      issue_half(wt_cur, m_cur, 1, xb, gb);
+      aggregate_half(m_cur, 0, xa, ga);                   // waits for half A of the current tile; scan(nxt), bitmaps(far), half B travel
+      const uint32_t m_nxt = test_scan(c_nxt);            // waits for scan(nxt)
+      issue_half(wt_nxt, m_nxt, 0, xa, ga);
+      const uint32_t c_far = candidates(wt_far);
+      issue_postings(wt_far + step);
+      issue_scan(wt_far, c_far);
+      aggregate_half(m_cur, 1, xb, gb);                   // waits for half B (older than everything requested since)
+      wt_cur = wt_nxt; wt_nxt = wt_far; wt_far += step;
+      m_cur = m_nxt; c_nxt = c_far;
+    }
+  } else {
+    int wt = wt_first;
+    issue_postings(wt);
+    uint32_t m = candidates(wt);
+    issue_postings(wt + step);
+    issue_half(wt, m, 0, xa, ga);
+    while (wt < n_wtiles_loop) {
+      my_matched += (uint32_t)__popc(m);
+      if (p.out_words) reinterpret_cast<uint32_t*>(p.out_words)[(int64_t)wt * 64 + lane] = quad_to_lin(m, lane);
+      issue_half(wt, m, 1, xb, gb);
+      aggregate_half(m, 0, xa, ga);
+      const int wt_n = wt + step;
+      const uint32_t m_n = candidates(wt_n);              // waits for the bitmaps of tile wt_n (older than half B)
+      issue_postings(wt_n + step);
+      issue_half(wt_n, m_n, 0, xa, ga);
+      aggregate_half(m, 1, xb, gb);
+      wt = wt_n;
+      m = m_n;
+    }
+  }
+  const uint32_t wsum = wave_sum_u32(my_matched);
+  if (lane == 0 && wsum) atomicAdd(&s_stat[0], wsum);
+  if (HAS_SCAN && !p.fast_scan_pushed) {
+    const uint32_t csum = wave_sum_u32(my_cand);
+    if (lane == 0 && csum) atomicAdd(&s_stat[L.stat_slot], csum);
+  }
+  __syncthreads();
+  flush_workgroup(p, lds_table, s_stat, true, t);
+}
+#define PG_PIPE_WIDE_KERNEL(NAME, IDX, SCAN) \
+  extern "C" __global__ void __launch_bounds__(PG_BLOCK) NAME(const PgQueryPlan p) { \
+    if (p.pipe_wide == 2) pipe_wide_body<2, IDX, SCAN>(p); \
+    else pipe_wide_body<1, IDX, SCAN>(p); \
+  }
+PG_PIPE_WIDE_KERNEL(pg_pipe_w_none, false, false)
+PG_PIPE_WIDE_KERNEL(pg_pipe_w_index, true, false)
+PG_PIPE_WIDE_KERNEL(pg_pipe_w_scan, false, true)
+PG_PIPE_WIDE_KERNEL(pg_pipe_w_index_scan, true, true)

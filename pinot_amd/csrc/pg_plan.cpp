@@ -1944,6 +1944,42 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
   P.wide_agg = !P.fast_agg && (D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE) && D.n_aux == 0 && P.first_doc_op < 0;
   // range-partitioned tables: pg_fast_none_w / pg_fast_multi_w walk the partitioned tile order with 16 wavefronts per CU
   if (D.agg_mode == PG_AGG_LDS_PART && D.n_aux == 0 && P.fast_filter != -2 && P.first_doc_op < 0) P.wide_agg = true;
+  // ... and of those the ones the wide pipeline takes (pg_pipe_w_*, pg_kernels_pipe.hip): integer accumulators over ONE raw INT / LONG column
+  // (or COUNT alone), zero to two group columns of <= 16 bits, behind no filter, a fused dense index program, a lone raw-INT range scan, or both
+  D.pipe_wide = 0;
+  if (P.wide_agg && !P.digit_ops && (D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE) && D.n_group_cols <= 2 &&
+      (int64_t)G * D.replicas <= 65536 && !getenv("PG_NO_PIPE_WIDE")) {
+    bool ok = true;
+    int src = -1;
+    for (int o = 0; o < D.n_ops && ok; o++) {
+      if (D.ops[o].src < 0) continue;
+      if (D.ops[o].is_float != PG_ACCV_INT) ok = false;
+      if (src >= 0 && D.ops[o].src != src) ok = false;
+      src = D.ops[o].src;
+    }
+    for (int o = 0; o < D.n_ops && ok; o++) ok = D.ops[o].fn == PG_ACC_COUNT || D.ops[o].fn == PG_ACC_SUM || D.ops[o].fn == PG_ACC_MIN || D.ops[o].fn == PG_ACC_MAX;
+    for (int g = 0; g < D.n_group_cols && ok; g++)
+      ok = D.gcols[g].col_kind == PG_COL_FIXED_BIT && D.gcols[g].bits >= 1 && D.gcols[g].bits <= 16 && D.mv_gcol_offsets[g] == nullptr;
+    int vw = 1;
+    if (ok && src >= 0) {
+      const Column* c = srcs[(size_t)src];
+      if (D.srcs[src].col_kind == PG_COL_RAW32 && c->val_type == PG_V_I32) vw = 1;
+      else if (D.srcs[src].col_kind == PG_COL_RAW64 && c->val_type == PG_V_I64) vw = 2;
+      else ok = false;
+    }
+    if (ok && D.n_group_cols == 0 && src < 0) ok = false;   // COUNT alone without GROUP BY: nothing to pipeline
+    const bool index_ok = D.n_index_instr == 0 || D.dense_fused;
+    bool has_scan = false;
+    if (P.fast_filter == -1) ok = ok && index_ok;
+    else if (P.fast_filter == 4) { has_scan = true; ok = ok && ((D.n_index_instr == 0 && D.fast_scan_pushed) || D.dense_fused); }
+    else ok = false;
+    if (ok) {
+      D.pipe_wide = vw;
+      D.pipe_src = src;
+      D.pipe_has_index = D.n_index_instr > 0 ? 1 : 0;
+      D.pipe_has_scan = has_scan ? 1 : 0;
+    }
+  }
   if (D.mv) {   // none of the single-value specialisations reads a multi-value column
     P.fast_filter = -2;
     P.fast_agg = false;
@@ -1951,6 +1987,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     D.fast_agg_shape = 0;
     D.pipe_fit = 0;
     D.pipe_general = 0;
+    D.pipe_wide = 0;
     D.dense_fused = 0;
     D.tile_split_shift = 0;
   }

@@ -452,7 +452,66 @@ def test_wide_aggregations_match_oracle(wide_seg, q):
     g, o = wide_seg
     gb, ob = g.execute(q), o.execute(q)
     assert_same_block(gb, ob)
-    assert gb.stats.kernel.decode().startswith(("pg_fast_", "pg_generic_", "pg_radix_", "pg_part_"))
+    assert gb.stats.kernel.decode().startswith(("pg_fast_", "pg_pipe_w_", "pg_generic_", "pg_radix_", "pg_part_"))
+
+
+# ---- the wide pipeline (pg_pipe_w_*): raw LONG / INT values, group columns of up to 16 bits, behind no filter / dense index / range scan ----
+PIPE_WIDE_QUERIES = [
+    ("SELECT k, SUM(lm), MIN(lm), MAX(lm), COUNT(*) FROM wide GROUP BY k LIMIT 5000", "pg_pipe_w_none"),
+    ("SELECT k, COUNT(*) FROM wide GROUP BY k LIMIT 5000", "pg_pipe_w_none"),                              # no value column at all
+    ("SELECT k2, SUM(lm), MAX(lm) FROM wide GROUP BY k2", "pg_pipe_w_none"),                               # narrow key, LONG values
+    ("SELECT k2, SUM(lm) FROM wide WHERE inv IN (1, 3) GROUP BY k2", "pg_pipe_w_index"),
+    ("SELECT SUM(lm), MIN(lm), COUNT(*) FROM wide WHERE inv = 2", "pg_pipe_w_index"),                      # no GROUP BY
+    ("SELECT SUM(lm), MAX(lm) FROM wide", "pg_pipe_w_none"),
+    ("SELECT k, SUM(r), COUNT(*) FROM wide WHERE r BETWEEN 100 AND 700 GROUP BY k LIMIT 5000", "pg_pipe_w_scan"),   # INT values, 11-bit key
+    ("SELECT k, SUM(lm), MIN(lm) FROM wide WHERE r BETWEEN 100 AND 700 GROUP BY k LIMIT 5000", "pg_pipe_w_scan"),
+    ("SELECT k2, MAX(lm), COUNT(*) FROM wide WHERE inv NOT IN (0, 4) AND r < 500 GROUP BY k2", "pg_pipe_w_index_scan"),
+    ("SELECT k, k2, SUM(lm) FROM wide WHERE inv = 2 AND r >= 250 GROUP BY k, k2 LIMIT 20000", None),          # 14 000 groups: whichever table mode
+    ("SELECT k, SUM(lm) FROM wide WHERE r > 5000 GROUP BY k LIMIT 5000", None),                                # nothing matches
+]
+
+
+@pytest.mark.parametrize("q,kernel", PIPE_WIDE_QUERIES)
+def test_wide_pipeline_matches_oracle(wide_seg, q, kernel):
+    g, o = wide_seg
+    gb, ob = g.execute(q), o.execute(q)
+    assert_same_block(gb, ob)
+    if kernel and gb.stats.num_docs_scanned > 0:
+        assert gb.stats.kernel.decode() == kernel
+
+
+@pytest.mark.parametrize("n", [1, 5, 1023, 1025, 2047, 2048, 2049, 4096, 6145, 40_000])
+def test_wide_pipeline_sizes(gpu_api, oracle_api, n):
+    """Segments of fewer tiles than the pipeline keeps in flight, ragged last halves."""
+    rng = np.random.default_rng(n)
+    data = {"k": rng.integers(0, 600, n).astype(np.int32), "k2": rng.integers(0, 3, n).astype(np.int32),
+            "lm": rng.integers(-10**11, 10**11, n).astype(np.int64), "r": rng.integers(0, 1000, n).astype(np.int32),
+            "inv": rng.integers(0, 3, n).astype(np.int32)}   # (sums stay below 2^53: the domain where the reference's double sums are exact)
+    host = build_segment("ws", data, {"k": "INT", "k2": "INT", "lm": "LONG", "r": "INT", "inv": "INT"}, inverted_index_columns=["inv"],
+                         no_dictionary_columns=["lm", "r"])
+    g, o = both(gpu_api, oracle_api, host)
+    for q in ("SELECT k, SUM(lm), MIN(lm), MAX(lm), COUNT(*) FROM ws GROUP BY k LIMIT 5000",
+              "SELECT k, k2, SUM(lm) FROM ws WHERE r < 700 GROUP BY k, k2 LIMIT 5000",
+              "SELECT k2, SUM(r), MAX(r) FROM ws WHERE inv = 1 AND r >= 100 GROUP BY k2",
+              "SELECT MIN(lm), COUNT(*) FROM ws WHERE inv != 0"):
+        assert_same_block(g.execute(q), o.execute(q))
+    g.destroy()
+    o.destroy()
+
+
+def test_wide_pipeline_knob(gpu_api, oracle_api, monkeypatch):
+    """PG_NO_PIPE_WIDE: the same plans on the 16-wavefront walk (pg_fast_none_w / pg_fast_multi_w), the A/B knob of the variants table."""
+    monkeypatch.setenv("PG_NO_PIPE_WIDE", "1")
+    rng = np.random.default_rng(4)
+    n = 30_001
+    data = {"k": rng.integers(0, 900, n).astype(np.int32), "lm": rng.integers(-10**9, 10**9, n).astype(np.int64)}
+    host = build_segment("wk", data, {"k": "INT", "lm": "LONG"}, no_dictionary_columns=["lm"])
+    g, o = both(gpu_api, oracle_api, host)
+    gb = g.execute("SELECT k, SUM(lm) FROM wk GROUP BY k LIMIT 5000")
+    assert_same_block(gb, o.execute("SELECT k, SUM(lm) FROM wk GROUP BY k LIMIT 5000"))
+    assert gb.stats.kernel.decode() == "pg_fast_none_w"
+    g.destroy()
+    o.destroy()
 
 
 # ---- radix-partitioned group-by (PG_AGG_RADIX): one visit per doc, tuples bucketed by key range, LDS aggregation per bucket ---
