@@ -531,9 +531,9 @@ PG_PIPE_KERNEL(pg_pipe_index_scan_vscan, true, true, false, true)   // dense ind
 // accumulator reads ONE raw INT or LONG column; zero to two group columns of <= 16 bits; integer accumulators (SumAggregationFunction
 // .java:160-179 over LONG sources: exact in int64 while the planner's bound holds).
 //
-// The unit in flight is HALF a wave tile (four quads, 1024 docs): a LONG column's quad is 32 bytes per lane, so half a tile is the 32
-// load-target registers a whole tile of a 32-bit column takes, and the two halves are the two buffers of the software pipeline — half
-// B is requested before half A is aggregated, the next tile's half A before half B is.  A lane's 32 bytes are two 16-byte loads at a lane
+// The unit in flight is a QUARTER of a wave tile (two quads, 512 docs): a LONG column's quad is 32 bytes per lane, so the four quarters
+// of a tile are the 64 load-target registers two tiles of a 32-bit column take; the quarters are the four buffers of the software
+// pipeline — three travel while one is aggregated.  A lane's 32 bytes are two 16-byte loads at a lane
 // stride of 32 bytes: 6.3 TB/s against 6.6-6.9 TB/s fully coalesced; 64 contiguous bytes per lane (an "8 docs per lane" ownership) drops
 // to 4.0 TB/s (profiles/r04_lane_stride_probe.txt), which is why this kernel keeps the quad layout.  The filter stages run per whole
 // tile as in pipe_general_body: dense postings, one raw-INT range scan.  Group columns take three-dword windows (4 x 16 bits + 31 bits
@@ -557,7 +557,12 @@ DEVFN void decode_packed_quad_mid(const uint32_t (&r)[3], uint32_t q, uint32_t b
   for (int i = 0; i < 4; i++) out[i] = (uint32_t)(top >> (64u - (uint32_t)(i + 1) * bits)) & mask;
 }
 
-template <int VW, bool HAS_INDEX, bool HAS_SCAN>
+// Every lambda is always_inline: one left out of line takes the plan by address, and hipcc then copies the whole kernel argument (2 KB per
+// lane) into scratch memory and reads it from there.
+// VW: dwords per value (0: no value column — COUNT alone); NG: group columns.  Both compile-time: a wave-uniform run-time branch around the
+// first use of a load target makes hipcc wait for EVERY load in flight there (s_waitcnt vmcnt(0)) — the first cut of this kernel, with
+// `if (gi < n_group_cols)` around the decodes, had no wait count above 3 and ran slower with four buffers than with two.
+template <int VW, int NG, bool HAS_INDEX, bool HAS_SCAN>
 __device__ __forceinline__ void pipe_wide_body(const PgQueryPlan& p) {
   extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
   __shared__ uint32_t s_stat[PG_MAX_STATS];
@@ -569,7 +574,7 @@ __device__ __forceinline__ void pipe_wide_body(const PgQueryPlan& p) {
   {
     const uint32_t table_slots = (uint32_t)p.n_groups * (uint32_t)p.replicas;
     for (int o = 0; o < p.n_ops; o++) {
-      const int64_t ident = pg_acc_identity(p.ops[o].fn, p.ops[o].is_float);
+      const int64_t ident = pg_acc_identity(p.ops[uniform(o)].fn, p.ops[uniform(o)].is_float);
       for (uint32_t i = t; i < table_slots; i += PG_BLOCK) lds_table[(size_t)o * table_slots + i] = ident;
     }
   }
@@ -579,9 +584,10 @@ __device__ __forceinline__ void pipe_wide_body(const PgQueryPlan& p) {
   const uint32_t R = (uint32_t)p.replicas;
   const uint32_t rep = (uint32_t)t & (R - 1u);
   const uint32_t stride = (uint32_t)p.n_groups * R;   // slots per op
-  const uint8_t* xdata = p.pipe_src >= 0 ? p.srcs[p.pipe_src].data : p.gcols[0].data;   // COUNT only: no value column is read
-  const bool has_value = p.pipe_src >= 0;
-  const int ng = p.n_group_cols;
+  constexpr int XW = VW > 0 ? VW : 1;       // (array extents; with VW == 0 nothing is loaded into them)
+  constexpr int GN = NG > 0 ? NG : 1;
+  constexpr bool has_value = VW > 0;
+  const uint8_t* xdata = has_value ? p.srcs[p.pipe_src].data : nullptr;
   const int last_wt = p.n_wtiles - 1;
   const int step = (int)gridDim.x * PG_WAVES_PER_BLOCK;
   const int n_wtiles_loop = p.n_wtiles;
@@ -589,14 +595,14 @@ __device__ __forceinline__ void pipe_wide_body(const PgQueryPlan& p) {
   uint32_t my_matched = 0, my_cand = 0;
 
   uint32_t pv[8];
-  auto clamp_tile = [&](int wt) { return wt < last_wt ? wt : last_wt; };
-  auto issue_postings = [&](int wt) {
+  auto clamp_tile = [&](int wt) __attribute__((always_inline)) { return wt < last_wt ? wt : last_wt; };
+  auto issue_postings = [&](int wt) __attribute__((always_inline)) {
     if (!HAS_INDEX) return;
     const size_t tile_off = (size_t)clamp_tile(wt) * 256u;
 #pragma unroll
     for (int j = 0; j < 8; j++) pv[j] = ldnt((const GAS uint32_t*)(sgpr_ptr<uint8_t>(p.dense_ptr[j] + tile_off) + (uint32_t)lane * 4u));
   };
-  auto candidates = [&](int wt) -> uint32_t {   // index program -> candidate mask in quad layout (every valid doc without one)
+  auto candidates = [&](int wt) __attribute__((always_inline)) -> uint32_t {   // index program -> candidate mask in quad layout (every valid doc without one)
     const int64_t rem = wt < n_wtiles_loop ? (int64_t)p.num_docs - (int64_t)wt * PG_WAVE_DOCS : 0;
     const int32_t n_valid = rem >= PG_WAVE_DOCS ? PG_WAVE_DOCS : (rem > 0 ? (int32_t)rem : 0);
     if (!HAS_INDEX) return valid_quad_mask(n_valid, lane);
@@ -613,95 +619,117 @@ __device__ __forceinline__ void pipe_wide_body(const PgQueryPlan& p) {
       if (k < p.dense_groups) lin &= ((p.dense_excl >> k) & 1) ? ~grp[k] : grp[k];
     return lin_to_quad(lin, lane);
   };
-  // value / group quads of half `h` (quads 4h .. 4h+3) of tile wt, restricted to quads with matches
-  auto issue_half = [&](int wt, uint32_t m, int h, u32x4 (&x)[4][VW], uint32_t (&g)[2][4][3]) {
+  // value / group quads of part `h` (quads NQ h .. NQ h + NQ - 1) of tile wt, restricted to quads with matches
+  constexpr int NQ = 2;   // quads per part: a QUARTER of a tile — four buffers, three of them in flight while one is aggregated
+  auto issue_part = [&](int wt, uint32_t m, int h, u32x4 (&x)[NQ][XW], uint32_t (&g)[GN][NQ][3]) __attribute__((always_inline)) {
     const int wc = clamp_tile(wt);
     if (has_value) {
       const GAS uint8_t* xb = sgpr_ptr<uint8_t>(xdata + (size_t)wc * (size_t)(PG_WAVE_DOCS * 4 * VW));
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int kk = 4 * h + k;
+      for (int k = 0; k < NQ; k++) {
+        const int kk = NQ * h + k;
         const uint32_t q = ((m >> (4 * kk)) & 0xFu) ? (uint32_t)(kk * 64 + lane) : 0u;
 #pragma unroll
         for (int w = 0; w < VW; w++) x[k][w] = ldnt((const GAS u32x4*)(xb + q * (16u * VW) + 16u * w));
       }
     }
 #pragma unroll
-    for (int gi = 0; gi < 2; gi++)
-      if (gi < ng) {   // wave-uniform
+    for (int gi = 0; gi < NG; gi++) {
+      {
         const PgGroupCol& gc = p.gcols[gi];
         const GAS uint32_t* tw = sgpr_ptr<uint32_t>((const void*)packed_wtile_base(gc.data, wc, gc.bits));
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const int kk = 4 * h + k;
+        for (int k = 0; k < NQ; k++) {
+          const int kk = NQ * h + k;
           const uint32_t q = ((m >> (4 * kk)) & 0xFu) ? (uint32_t)(kk * 64 + lane) : 0u;
           load_packed_quad_mid(tw, q, (uint32_t)gc.bits, g[gi][k]);
         }
       }
+    }
   };
-  auto aggregate_half = [&](uint32_t m, int h, const u32x4 (&x)[4][VW], const uint32_t (&g)[2][4][3]) {
-    const uint32_t mg = (m >> (16 * h)) & 0xFFFFu;
+  // no GROUP BY: SUM / MIN / MAX / COUNT of the lane's docs stay in registers for the whole kernel and are folded once at the end (the one
+  // group's few replica slots would take every lane's atomics: 44 % of 8 TB/s; folding per part across the wavefront: 33 %,
+  // profiles/r04_o_variants_wide_100m.txt)
+  int64_t lane_sum = 0, lane_min = INT64_MAX, lane_max = INT64_MIN;
+  uint32_t lane_cnt = 0;
+  auto aggregate_part = [&](uint32_t m, int h, const u32x4 (&x)[NQ][XW], const uint32_t (&g)[GN][NQ][3]) __attribute__((always_inline)) {
+    const uint32_t mg = (m >> (4 * NQ * h)) & ((1u << (4 * NQ)) - 1u);
     if (__ballot(mg != 0) == 0) return;   // wave-uniform
-    uint32_t slot[4][4];
+    uint32_t slot[NQ][4];
 #pragma unroll
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < NQ; k++)
 #pragma unroll
       for (int i = 0; i < 4; i++) slot[k][i] = rep;
 #pragma unroll
-    for (int gi = 0; gi < 2; gi++)
-      if (gi < ng) {
+    for (int gi = 0; gi < NG; gi++) {
+      {
         const PgGroupCol& gc = p.gcols[gi];
         const uint32_t bits = (uint32_t)gc.bits, mask = (1u << gc.bits) - 1u;
         const uint32_t mult = (uint32_t)gc.mult * R;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < NQ; k++) {
           uint32_t d[4];
-          const int kk = 4 * h + k;
+          const int kk = NQ * h + k;
           const uint32_t q = ((mg >> (4 * k)) & 0xFu) ? (uint32_t)(kk * 64 + lane) : 0u;
           decode_packed_quad_mid(g[gi][k], q, bits, mask, d);
 #pragma unroll
           for (int i = 0; i < 4; i++) slot[k][i] += d[i] * mult;   // < 65536 slots: the planner's bound on n_groups x replicas
         }
       }
-    int64_t v[4][4];
+    }
+    int64_t v[NQ][4] = {};
     if (has_value) {
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
+      for (int k = 0; k < NQ; k++) {
         if (VW == 1) {
           v[k][0] = (int64_t)(int32_t)bswap32(x[k][0].x); v[k][1] = (int64_t)(int32_t)bswap32(x[k][0].y);
           v[k][2] = (int64_t)(int32_t)bswap32(x[k][0].z); v[k][3] = (int64_t)(int32_t)bswap32(x[k][0].w);
         } else {
           v[k][0] = (int64_t)(((uint64_t)bswap32(x[k][0].x) << 32) | (uint64_t)bswap32(x[k][0].y));
           v[k][1] = (int64_t)(((uint64_t)bswap32(x[k][0].z) << 32) | (uint64_t)bswap32(x[k][0].w));
-          v[k][2] = (int64_t)(((uint64_t)bswap32(x[k][VW - 1].x) << 32) | (uint64_t)bswap32(x[k][VW - 1].y));
-          v[k][3] = (int64_t)(((uint64_t)bswap32(x[k][VW - 1].z) << 32) | (uint64_t)bswap32(x[k][VW - 1].w));
+          v[k][2] = (int64_t)(((uint64_t)bswap32(x[k][XW - 1].x) << 32) | (uint64_t)bswap32(x[k][XW - 1].y));
+          v[k][3] = (int64_t)(((uint64_t)bswap32(x[k][XW - 1].z) << 32) | (uint64_t)bswap32(x[k][XW - 1].w));
         }
       }
     }
+    if (NG == 0) {
+      lane_cnt += (uint32_t)__popc(mg);
+#pragma unroll
+      for (int k = 0; k < NQ; k++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const bool on = ((mg >> (4 * k + i)) & 1u) != 0;
+          const int64_t y = v[k][i];
+          lane_sum += on ? y : 0;
+          lane_min = on && y < lane_min ? y : lane_min;
+          lane_max = on && y > lane_max ? y : lane_max;
+        }
+      return;
+    }
     for (int o = 0; o < p.n_ops; o++) {
-      const PgAccOp op = p.ops[o];
+      const PgAccOp op = p.ops[uniform(o)];   // (a scalar index: a vector one makes hipcc copy the whole plan into scratch memory)
       int64_t* base = lds_table + (size_t)o * stride;
       if (op.src < 0) {
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < NQ; k++)
 #pragma unroll
           for (int i = 0; i < 4; i++)
             if ((mg >> (4 * k + i)) & 1u) atomicAdd(reinterpret_cast<unsigned long long*>(base + slot[k][i]), 1ULL);
       } else if (op.fn == PG_ACC_SUM) {
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < NQ; k++)
 #pragma unroll
           for (int i = 0; i < 4; i++)
             if ((mg >> (4 * k + i)) & 1u) atomicAdd(reinterpret_cast<unsigned long long*>(base + slot[k][i]), (unsigned long long)v[k][i]);
       } else if (op.fn == PG_ACC_MIN) {
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < NQ; k++)
 #pragma unroll
           for (int i = 0; i < 4; i++)
             if ((mg >> (4 * k + i)) & 1u) atomicMin(reinterpret_cast<long long*>(base + slot[k][i]), (long long)v[k][i]);
       } else {
 #pragma unroll
-        for (int k = 0; k < 4; k++)
+        for (int k = 0; k < NQ; k++)
 #pragma unroll
           for (int i = 0; i < 4; i++)
             if ((mg >> (4 * k + i)) & 1u) atomicMax(reinterpret_cast<long long*>(base + slot[k][i]), (long long)v[k][i]);
@@ -709,12 +737,16 @@ __device__ __forceinline__ void pipe_wide_body(const PgQueryPlan& p) {
     }
   };
 
-  u32x4 xa[4][VW], xb[4][VW];
-  uint32_t ga[2][4][3], gb[2][4][3];
+  // four part buffers; at the top of a tile's iteration parts 0 .. 2 of the tile are in flight, part 3 is requested first, and each
+  // buffer is re-requested for the NEXT tile right after it has been aggregated — three parts travel while one is aggregated (with two
+  // half-tile buffers the oldest request was one aggregation old when it was needed: 59 % of the wave cycles waiting,
+  // profiles/r04_l_sq_w_none.txt)
+  u32x4 x0[NQ][XW], x1[NQ][XW], x2[NQ][XW], x3[NQ][XW];
+  uint32_t g0[GN][NQ][3], g1[GN][NQ][3], g2[GN][NQ][3], g3[GN][NQ][3];
   if (HAS_SCAN) {
-    // per tile: scan quads of the NEXT tile and the bitmaps of the one after travel while the current tile's halves are aggregated
+    // per tile: scan quads of the NEXT tile and the bitmaps of the one after travel while the current tile's parts are aggregated
     u32x4 a[8];
-    auto issue_scan = [&](int wt, uint32_t cand) {
+    auto issue_scan = [&](int wt, uint32_t cand) __attribute__((always_inline)) {
       const GAS uint8_t* tb = sgpr_ptr<uint8_t>(L.data + (size_t)clamp_tile(wt) * (PG_WAVE_DOCS * 4));
 #pragma unroll
       for (int k = 0; k < 8; k++) {
@@ -722,7 +754,7 @@ __device__ __forceinline__ void pipe_wide_body(const PgQueryPlan& p) {
         a[k] = ldnt((const GAS u32x4*)(tb + q * 16u));
       }
     };
-    auto test_scan = [&](uint32_t cand) -> uint32_t {
+    auto test_scan = [&](uint32_t cand) __attribute__((always_inline)) -> uint32_t {
       uint32_t m = 0;
 #pragma unroll
       for (int k = 0; k < 8; k++) {
@@ -742,20 +774,26 @@ __device__ __forceinline__ void pipe_wide_body(const PgQueryPlan& p) {
     issue_postings(wt_nxt);
     issue_scan(wt_cur, c0);
     uint32_t m_cur = test_scan(c0);
-    issue_half(wt_cur, m_cur, 0, xa, ga);
+    issue_part(wt_cur, m_cur, 0, x0, g0);
+    issue_part(wt_cur, m_cur, 1, x1, g1);
+    issue_part(wt_cur, m_cur, 2, x2, g2);
     uint32_t c_nxt = candidates(wt_nxt);
     issue_postings(wt_far);
     issue_scan(wt_nxt, c_nxt);
     while (wt_cur < n_wtiles_loop) {
       if (p.out_words) reinterpret_cast<uint32_t*>(p.out_words)[(int64_t)wt_cur * 64 + lane] = quad_to_lin(m_cur, lane);
-      issue_half(wt_cur, m_cur, 1, xb, gb);
-      aggregate_half(m_cur, 0, xa, ga);                   // waits for half A of the current tile; scan(nxt), bitmaps(far), half B travel
-      const uint32_t m_nxt = test_scan(c_nxt);            // waits for scan(nxt)
-      issue_half(wt_nxt, m_nxt, 0, xa, ga);
+      issue_part(wt_cur, m_cur, 3, x3, g3);
+      aggregate_part(m_cur, 0, x0, g0);
+      const uint32_t m_nxt = test_scan(c_nxt);            // waits for scan(nxt) (requested a whole tile ago)
+      issue_part(wt_nxt, m_nxt, 0, x0, g0);
       const uint32_t c_far = candidates(wt_far);
       issue_postings(wt_far + step);
       issue_scan(wt_far, c_far);
-      aggregate_half(m_cur, 1, xb, gb);                   // waits for half B (older than everything requested since)
+      aggregate_part(m_cur, 1, x1, g1);
+      issue_part(wt_nxt, m_nxt, 1, x1, g1);
+      aggregate_part(m_cur, 2, x2, g2);
+      issue_part(wt_nxt, m_nxt, 2, x2, g2);
+      aggregate_part(m_cur, 3, x3, g3);
       wt_cur = wt_nxt; wt_nxt = wt_far; wt_far += step;
       m_cur = m_nxt; c_nxt = c_far;
     }
@@ -764,19 +802,43 @@ __device__ __forceinline__ void pipe_wide_body(const PgQueryPlan& p) {
     issue_postings(wt);
     uint32_t m = candidates(wt);
     issue_postings(wt + step);
-    issue_half(wt, m, 0, xa, ga);
+    issue_part(wt, m, 0, x0, g0);
+    issue_part(wt, m, 1, x1, g1);
+    issue_part(wt, m, 2, x2, g2);
     while (wt < n_wtiles_loop) {
       my_matched += (uint32_t)__popc(m);
       if (p.out_words) reinterpret_cast<uint32_t*>(p.out_words)[(int64_t)wt * 64 + lane] = quad_to_lin(m, lane);
-      issue_half(wt, m, 1, xb, gb);
-      aggregate_half(m, 0, xa, ga);
+      issue_part(wt, m, 3, x3, g3);
+      aggregate_part(m, 0, x0, g0);
       const int wt_n = wt + step;
-      const uint32_t m_n = candidates(wt_n);              // waits for the bitmaps of tile wt_n (older than half B)
+      const uint32_t m_n = candidates(wt_n);              // waits for the bitmaps of tile wt_n (requested a whole tile ago)
       issue_postings(wt_n + step);
-      issue_half(wt_n, m_n, 0, xa, ga);
-      aggregate_half(m, 1, xb, gb);
+      issue_part(wt_n, m_n, 0, x0, g0);
+      aggregate_part(m, 1, x1, g1);
+      issue_part(wt_n, m_n, 1, x1, g1);
+      aggregate_part(m, 2, x2, g2);
+      issue_part(wt_n, m_n, 2, x2, g2);
+      aggregate_part(m, 3, x3, g3);
       wt = wt_n;
       m = m_n;
+    }
+  }
+  if (NG == 0) {
+    for (int o = 0; o < p.n_ops; o++) {
+      const PgAccOp op = p.ops[uniform(o)];
+      const int kind = op.src < 0 || op.fn == PG_ACC_SUM ? 0 : (op.fn == PG_ACC_MIN ? 1 : 2);
+      int64_t acc = op.src < 0 ? (int64_t)lane_cnt : (kind == 0 ? lane_sum : (kind == 1 ? lane_min : lane_max));
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const int64_t y = __shfl_xor((long long)acc, off, 64);
+        acc = kind == 0 ? acc + y : (kind == 1 ? (y < acc ? y : acc) : (y > acc ? y : acc));
+      }
+      int64_t* slot = lds_table + (size_t)o * stride + rep;
+      if (lane == 0) {
+        if (kind == 0) atomicAdd(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)acc);
+        else if (kind == 1) atomicMin(reinterpret_cast<long long*>(slot), (long long)acc);
+        else atomicMax(reinterpret_cast<long long*>(slot), (long long)acc);
+      }
     }
   }
   const uint32_t wsum = wave_sum_u32(my_matched);
@@ -786,14 +848,44 @@ __device__ __forceinline__ void pipe_wide_body(const PgQueryPlan& p) {
     if (lane == 0 && csum) atomicAdd(&s_stat[L.stat_slot], csum);
   }
   __syncthreads();
-  flush_workgroup(p, lds_table, s_stat, true, t);
-}
-#define PG_PIPE_WIDE_KERNEL(NAME, IDX, SCAN) \
-  extern "C" __global__ void __launch_bounds__(PG_BLOCK) NAME(const PgQueryPlan p) { \
-    if (p.pipe_wide == 2) pipe_wide_body<2, IDX, SCAN>(p); \
-    else pipe_wide_body<1, IDX, SCAN>(p); \
+  // statistics and the flush of the LDS table into this workgroup's partial table — flush_workgroup's work with the accumulator loop
+  // outermost: its per-thread p.ops[i / groups] is a vector index into the kernel argument, which made hipcc copy the whole plan (2 KB
+  // per lane) into scratch memory in the kernels with an index program
+  if (t < PG_MAX_STATS && s_stat[t]) atomicAdd(&p.stats[t], (unsigned long long)s_stat[t]);
+  {
+    const int groups = p.n_groups;
+    int64_t* out = p.partials + (int64_t)blockIdx.x * ((int64_t)p.n_ops * groups);
+    for (int o = 0; o < p.n_ops; o++) {
+      const int fn = p.ops[uniform(o)].fn;   // integer accumulators only (planner)
+      for (int gq = t; gq < groups; gq += PG_BLOCK) {
+        const int64_t* src = lds_table + ((size_t)o * (size_t)groups + (size_t)gq) * R;
+        int64_t acc = src[0];
+        if (fn == PG_ACC_COUNT || fn == PG_ACC_SUM) { for (uint32_t r = 1; r < R; r++) acc += src[r]; }
+        else if (fn == PG_ACC_MIN) { for (uint32_t r = 1; r < R; r++) acc = src[r] < acc ? src[r] : acc; }
+        else { for (uint32_t r = 1; r < R; r++) acc = src[r] > acc ? src[r] : acc; }
+        out[(size_t)o * (size_t)groups + (size_t)gq] = acc;
+      }
+    }
   }
-PG_PIPE_WIDE_KERNEL(pg_pipe_w_none, false, false)
-PG_PIPE_WIDE_KERNEL(pg_pipe_w_index, true, false)
-PG_PIPE_WIDE_KERNEL(pg_pipe_w_scan, false, true)
-PG_PIPE_WIDE_KERNEL(pg_pipe_w_index_scan, true, true)
+}
+#define PG_PIPE_WIDE_KERNEL(NAME, VWV, IDX, SCAN) \
+  extern "C" __global__ void __launch_bounds__(PG_BLOCK) NAME(const PgQueryPlan p) { \
+    const int ng = p.n_group_cols; \
+    if (ng == 0 && (VWV) != 0) pipe_wide_body<VWV, ((VWV) != 0 ? 0 : 1), IDX, SCAN>(p); \
+    else if (ng <= 1) pipe_wide_body<VWV, 1, IDX, SCAN>(p); \
+    else pipe_wide_body<VWV, 2, IDX, SCAN>(p); \
+  }
+// one kernel per value width (0: COUNT alone; 1: raw INT; 2: raw LONG) and filter shape: three bodies each (with all eight widths x group
+// counts in one kernel hipcc kept the plan in scratch memory in the kernels with an index program)
+PG_PIPE_WIDE_KERNEL(pg_pipe_w0_none, 0, false, false)
+PG_PIPE_WIDE_KERNEL(pg_pipe_w0_index, 0, true, false)
+PG_PIPE_WIDE_KERNEL(pg_pipe_w0_scan, 0, false, true)
+PG_PIPE_WIDE_KERNEL(pg_pipe_w0_index_scan, 0, true, true)
+PG_PIPE_WIDE_KERNEL(pg_pipe_w32_none, 1, false, false)
+PG_PIPE_WIDE_KERNEL(pg_pipe_w32_index, 1, true, false)
+PG_PIPE_WIDE_KERNEL(pg_pipe_w32_scan, 1, false, true)
+PG_PIPE_WIDE_KERNEL(pg_pipe_w32_index_scan, 1, true, true)
+PG_PIPE_WIDE_KERNEL(pg_pipe_w64_none, 2, false, false)
+PG_PIPE_WIDE_KERNEL(pg_pipe_w64_index, 2, true, false)
+PG_PIPE_WIDE_KERNEL(pg_pipe_w64_scan, 2, false, true)
+PG_PIPE_WIDE_KERNEL(pg_pipe_w64_index_scan, 2, true, true)

@@ -452,20 +452,20 @@ def test_wide_aggregations_match_oracle(wide_seg, q):
     g, o = wide_seg
     gb, ob = g.execute(q), o.execute(q)
     assert_same_block(gb, ob)
-    assert gb.stats.kernel.decode().startswith(("pg_fast_", "pg_pipe_w_", "pg_generic_", "pg_radix_", "pg_part_"))
+    assert gb.stats.kernel.decode().startswith(("pg_fast_", "pg_pipe_w", "pg_generic_", "pg_radix_", "pg_part_"))
 
 
 # ---- the wide pipeline (pg_pipe_w_*): raw LONG / INT values, group columns of up to 16 bits, behind no filter / dense index / range scan ----
 PIPE_WIDE_QUERIES = [
-    ("SELECT k, SUM(lm), MIN(lm), MAX(lm), COUNT(*) FROM wide GROUP BY k LIMIT 5000", "pg_pipe_w_none"),
-    ("SELECT k, COUNT(*) FROM wide GROUP BY k LIMIT 5000", "pg_pipe_w_none"),                              # no value column at all
-    ("SELECT k2, SUM(lm), MAX(lm) FROM wide GROUP BY k2", "pg_pipe_w_none"),                               # narrow key, LONG values
-    ("SELECT k2, SUM(lm) FROM wide WHERE inv IN (1, 3) GROUP BY k2", "pg_pipe_w_index"),
-    ("SELECT SUM(lm), MIN(lm), COUNT(*) FROM wide WHERE inv = 2", "pg_pipe_w_index"),                      # no GROUP BY
-    ("SELECT SUM(lm), MAX(lm) FROM wide", "pg_pipe_w_none"),
-    ("SELECT k, SUM(r), COUNT(*) FROM wide WHERE r BETWEEN 100 AND 700 GROUP BY k LIMIT 5000", "pg_pipe_w_scan"),   # INT values, 11-bit key
-    ("SELECT k, SUM(lm), MIN(lm) FROM wide WHERE r BETWEEN 100 AND 700 GROUP BY k LIMIT 5000", "pg_pipe_w_scan"),
-    ("SELECT k2, MAX(lm), COUNT(*) FROM wide WHERE inv NOT IN (0, 4) AND r < 500 GROUP BY k2", "pg_pipe_w_index_scan"),
+    ("SELECT k, SUM(lm), MIN(lm), MAX(lm), COUNT(*) FROM wide GROUP BY k LIMIT 5000", "pg_pipe_w64_none"),
+    ("SELECT k, COUNT(*) FROM wide GROUP BY k LIMIT 5000", "pg_pipe_w0_none"),                              # no value column at all
+    ("SELECT k2, SUM(lm), MAX(lm) FROM wide GROUP BY k2", "pg_pipe_w64_none"),                               # narrow key, LONG values
+    ("SELECT k2, SUM(lm) FROM wide WHERE inv IN (1, 3) GROUP BY k2", "pg_pipe_w64_index"),
+    ("SELECT SUM(lm), MIN(lm), COUNT(*) FROM wide WHERE inv = 2", "pg_pipe_w64_index"),                      # no GROUP BY
+    ("SELECT SUM(lm), MAX(lm) FROM wide", "pg_pipe_w64_none"),
+    ("SELECT k, SUM(r), COUNT(*) FROM wide WHERE r BETWEEN 100 AND 700 GROUP BY k LIMIT 5000", "pg_pipe_w32_scan"),   # INT values, 11-bit key
+    ("SELECT k, SUM(lm), MIN(lm) FROM wide WHERE r BETWEEN 100 AND 700 GROUP BY k LIMIT 5000", "pg_pipe_w64_scan"),
+    ("SELECT k2, MAX(lm), COUNT(*) FROM wide WHERE inv NOT IN (0, 4) AND r < 500 GROUP BY k2", "pg_pipe_w64_index_scan"),
     ("SELECT k, k2, SUM(lm) FROM wide WHERE inv = 2 AND r >= 250 GROUP BY k, k2 LIMIT 20000", None),          # 14 000 groups: whichever table mode
     ("SELECT k, SUM(lm) FROM wide WHERE r > 5000 GROUP BY k LIMIT 5000", None),                                # nothing matches
 ]
