@@ -20,6 +20,7 @@ PG_DECL_FAST(pg_fast_i32range_d) PG_DECL_FAST(pg_fast_i32range_p) PG_DECL_FAST(p
 PG_DECL_FAST(pg_pipe_w0_none) PG_DECL_FAST(pg_pipe_w0_index) PG_DECL_FAST(pg_pipe_w0_scan) PG_DECL_FAST(pg_pipe_w0_index_scan)
 PG_DECL_FAST(pg_pipe_w32_none) PG_DECL_FAST(pg_pipe_w32_index) PG_DECL_FAST(pg_pipe_w32_scan) PG_DECL_FAST(pg_pipe_w32_index_scan)
 PG_DECL_FAST(pg_pipe_w64_none) PG_DECL_FAST(pg_pipe_w64_index) PG_DECL_FAST(pg_pipe_w64_scan) PG_DECL_FAST(pg_pipe_w64_index_scan)
+PG_DECL_FAST(pg_pipe_wd_none) PG_DECL_FAST(pg_pipe_wd_index) PG_DECL_FAST(pg_pipe_wd_scan) PG_DECL_FAST(pg_pipe_wd_index_scan)
 PG_DECL_FAST(pg_pipe_scan) PG_DECL_FAST(pg_pipe_scan_tail) PG_DECL_FAST(pg_pipe_index_scan_tail) PG_DECL_FAST(pg_pipe_none) PG_DECL_FAST(pg_pipe_tail)
 PG_DECL_FAST(pg_pipe_index) PG_DECL_FAST(pg_pipe_index_tail) PG_DECL_FAST(pg_pipe_index2) PG_DECL_FAST(pg_pipe_index2_tail)
 PG_DECL_FAST(pg_pipe_scan_vscan) PG_DECL_FAST(pg_pipe_index_scan_vscan)
@@ -179,7 +180,7 @@ void use_device(int ordinal) {
       // opt in to large dynamic LDS for the query kernels (function attributes are per device)
       typedef void (*QueryKernel)(const PgQueryPlan);
       const QueryKernel all[] = {pg_generic_query_f, pg_generic_query_l, pg_generic_query_g, pg_fast_none_f, pg_fast_none_a, pg_fast_i32range_f, pg_fast_i32range_a,
-                                 pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a, pg_fast_multi_f, pg_fast_multi_a, pg_fast_multi_w, pg_fast_none_w, pg_fast_multi_wd, pg_fast_none_wd, pg_generic_query_ld, pg_generic_query_gd, pg_fast_i32range_d, pg_fast_i32range_p, pg_pipe_scan, pg_pipe_scan_tail, pg_pipe_index_scan_tail, pg_pipe_none, pg_pipe_tail, pg_pipe_index, pg_pipe_index_tail, pg_pipe_index2, pg_pipe_index2_tail, pg_pipe_scan_vscan, pg_pipe_index_scan_vscan, pg_pipe_w0_none, pg_pipe_w0_index, pg_pipe_w0_scan, pg_pipe_w0_index_scan, pg_pipe_w32_none, pg_pipe_w32_index, pg_pipe_w32_scan, pg_pipe_w32_index_scan, pg_pipe_w64_none, pg_pipe_w64_index, pg_pipe_w64_scan, pg_pipe_w64_index_scan, pg_mv_query_f, pg_mv_query_l, pg_mv_query_g,
+                                 pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a, pg_fast_multi_f, pg_fast_multi_a, pg_fast_multi_w, pg_fast_none_w, pg_fast_multi_wd, pg_fast_none_wd, pg_generic_query_ld, pg_generic_query_gd, pg_fast_i32range_d, pg_fast_i32range_p, pg_pipe_scan, pg_pipe_scan_tail, pg_pipe_index_scan_tail, pg_pipe_none, pg_pipe_tail, pg_pipe_index, pg_pipe_index_tail, pg_pipe_index2, pg_pipe_index2_tail, pg_pipe_scan_vscan, pg_pipe_index_scan_vscan, pg_pipe_w0_none, pg_pipe_w0_index, pg_pipe_w0_scan, pg_pipe_w0_index_scan, pg_pipe_w32_none, pg_pipe_w32_index, pg_pipe_w32_scan, pg_pipe_w32_index_scan, pg_pipe_w64_none, pg_pipe_w64_index, pg_pipe_w64_scan, pg_pipe_w64_index_scan, pg_pipe_wd_none, pg_pipe_wd_index, pg_pipe_wd_scan, pg_pipe_wd_index_scan, pg_mv_query_f, pg_mv_query_l, pg_mv_query_g,
                                  pg_radix_aggregate_kernel, pg_hash_aggregate_kernel,
                                  pg_p2_scatter_1, pg_p2_scatter_2, pg_p2_scatter_3, pg_p2_scatter_4, pg_p2_scatter_1f, pg_p2_scatter_2f, pg_p2_scatter_1f_key, pg_p2_scatter_1f_hll,
                                  pg_p2_aggregate_1, pg_p2_aggregate_2, pg_p2_aggregate_3, pg_p2_aggregate_4,
@@ -244,10 +245,11 @@ static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char
   if (uses_fast_kernel(P, agg_mode)) {
     if (agg && uses_pipe_wide(P, agg_mode)) {
       // one kernel per value width (no value column / raw INT / raw LONG) and filter shape
-      static const struct { const char* name; QueryKernel fn; } kWide[3][4] = {
+      static const struct { const char* name; QueryKernel fn; } kWide[4][4] = {
           {{"pg_pipe_w0_none", pg_pipe_w0_none}, {"pg_pipe_w0_index", pg_pipe_w0_index}, {"pg_pipe_w0_scan", pg_pipe_w0_scan}, {"pg_pipe_w0_index_scan", pg_pipe_w0_index_scan}},
           {{"pg_pipe_w32_none", pg_pipe_w32_none}, {"pg_pipe_w32_index", pg_pipe_w32_index}, {"pg_pipe_w32_scan", pg_pipe_w32_scan}, {"pg_pipe_w32_index_scan", pg_pipe_w32_index_scan}},
-          {{"pg_pipe_w64_none", pg_pipe_w64_none}, {"pg_pipe_w64_index", pg_pipe_w64_index}, {"pg_pipe_w64_scan", pg_pipe_w64_scan}, {"pg_pipe_w64_index_scan", pg_pipe_w64_index_scan}}};
+          {{"pg_pipe_w64_none", pg_pipe_w64_none}, {"pg_pipe_w64_index", pg_pipe_w64_index}, {"pg_pipe_w64_scan", pg_pipe_w64_scan}, {"pg_pipe_w64_index_scan", pg_pipe_w64_index_scan}},
+          {{"pg_pipe_wd_none", pg_pipe_wd_none}, {"pg_pipe_wd_index", pg_pipe_wd_index}, {"pg_pipe_wd_scan", pg_pipe_wd_scan}, {"pg_pipe_wd_index_scan", pg_pipe_wd_index_scan}}};
       const int vw = P.dev.pipe_src >= 0 ? P.dev.pipe_wide : 0;
       const int shape = (P.dev.pipe_has_scan ? 2 : 0) + (P.dev.pipe_has_index ? 1 : 0);
       *name = kWide[vw][shape].name;

@@ -559,10 +559,11 @@ DEVFN void decode_packed_quad_mid(const uint32_t (&r)[3], uint32_t q, uint32_t b
 
 // Every lambda is always_inline: one left out of line takes the plan by address, and hipcc then copies the whole kernel argument (2 KB per
 // lane) into scratch memory and reads it from there.
-// VW: dwords per value (0: no value column — COUNT alone); NG: group columns.  Both compile-time: a wave-uniform run-time branch around the
+// VK: the value column — 0: none (COUNT alone), 1: raw INT, 2: raw LONG, 3: raw DOUBLE (SUMs as fixed-point digits, pg_fixed_point.h: one
+// int64 accumulator per base-2^32 digit; MIN / MAX through order-preserving int64 keys, NaN never replaces); NG: group columns.  Both compile-time: a wave-uniform run-time branch around the
 // first use of a load target makes hipcc wait for EVERY load in flight there (s_waitcnt vmcnt(0)) — the first cut of this kernel, with
 // `if (gi < n_group_cols)` around the decodes, had no wait count above 3 and ran slower with four buffers than with two.
-template <int VW, int NG, bool HAS_INDEX, bool HAS_SCAN>
+template <int VK, int NG, bool HAS_INDEX, bool HAS_SCAN>
 __device__ __forceinline__ void pipe_wide_body(const PgQueryPlan& p) {
   extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
   __shared__ uint32_t s_stat[PG_MAX_STATS];
@@ -584,6 +585,8 @@ __device__ __forceinline__ void pipe_wide_body(const PgQueryPlan& p) {
   const uint32_t R = (uint32_t)p.replicas;
   const uint32_t rep = (uint32_t)t & (R - 1u);
   const uint32_t stride = (uint32_t)p.n_groups * R;   // slots per op
+  constexpr int VW = VK == 0 ? 0 : (VK == 1 ? 1 : 2);   // dwords per value
+  constexpr bool DBL = VK == 3;
   constexpr int XW = VW > 0 ? VW : 1;       // (array extents; with VW == 0 nothing is loaded into them)
   constexpr int GN = NG > 0 ? NG : 1;
   constexpr bool has_value = VW > 0;
@@ -650,7 +653,8 @@ __device__ __forceinline__ void pipe_wide_body(const PgQueryPlan& p) {
   // no GROUP BY: SUM / MIN / MAX / COUNT of the lane's docs stay in registers for the whole kernel and are folded once at the end (the one
   // group's few replica slots would take every lane's atomics: 44 % of 8 TB/s; folding per part across the wavefront: 33 %,
   // profiles/r04_o_variants_wide_100m.txt)
-  int64_t lane_sum = 0, lane_min = INT64_MAX, lane_max = INT64_MIN;
+  int64_t lane_sum = 0, lane_min = INT64_MAX, lane_max = INT64_MIN;   // (DOUBLE values: order keys in lane_min / lane_max)
+  int64_t lane_dig[4] = {0, 0, 0, 0};                                  // DOUBLE sums: the lane's digit sums
   uint32_t lane_cnt = 0;
   auto aggregate_part = [&](uint32_t m, int h, const u32x4 (&x)[NQ][XW], const uint32_t (&g)[GN][NQ][3]) __attribute__((always_inline)) {
     const uint32_t mg = (m >> (4 * NQ * h)) & ((1u << (4 * NQ)) - 1u);
@@ -692,8 +696,50 @@ __device__ __forceinline__ void pipe_wide_body(const PgQueryPlan& p) {
         }
       }
     }
+    // DOUBLE values: digit j (base 2^32) of X = trunc(|x| 2^-q) is bits [32 j, 32 j + 32) of the 53-bit mantissa m shifted by s = exponent - q,
+    // i.e. a 32-bit window of (0 : m_hi : m_lo : 0) at bit offset t = 32 j - s.  t mod 32 is the same for every j, so the three windows that
+    // can hold mantissa bits are cut ONCE per doc (three funnel shifts) and a digit is a select by (j - ceil(s / 32)) — 32-bit operations
+    // only (the first cut shifted the 64-bit mantissa per digit: 84 VALU per doc, profiles/r04_q_*).
+    const int fxq = DBL ? p.srcs[p.pipe_src].fx_q : 0;
+    // the three windows of value bits b, the digit index j0 of the first, the sign mask (computed where they are used: once per doc)
+    auto windows = [&](uint64_t b, uint32_t (&w)[3], int& j0, uint64_t& neg) __attribute__((always_inline)) {
+      const uint32_t bh = (uint32_t)(b >> 32), ml = (uint32_t)b;
+      const int e = (int)((bh >> 20) & 0x7FFu);
+      const uint32_t mh = (bh & 0xFFFFFu) | (e ? (1u << 20) : 0u);
+      const int sft = (e ? e - 1075 : -1074) - fxq;             // X = m * 2^sft
+      j0 = sft >> 5;                                            // floor(sft / 32): digit j0 holds m's bit 0 at bit (sft & 31)
+      const uint32_t r = (32u - ((uint32_t)sft & 31u)) & 31u;   // window offset inside a dword: t mod 32 with t = 32 j - sft
+      const bool whole = r == 0u;
+      w[0] = whole ? ml : __builtin_amdgcn_alignbit(ml, 0u, r);
+      w[1] = whole ? mh : __builtin_amdgcn_alignbit(mh, ml, r);
+      w[2] = whole ? 0u : __builtin_amdgcn_alignbit(0u, mh, r);
+      neg = (uint64_t)(int64_t)((int32_t)bh >> 31);             // all ones for negative values
+    };
     if (NG == 0) {
       lane_cnt += (uint32_t)__popc(mg);
+      if (DBL) {
+#pragma unroll
+        for (int k = 0; k < NQ; k++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const bool on = ((mg >> (4 * k + i)) & 1u) != 0;
+            const double y = __longlong_as_double(v[k][i]);
+            const int64_t key = f64_order_key(y);
+            uint32_t w[3];
+            int j0;
+            uint64_t neg;
+            windows((uint64_t)v[k][i], w, j0, neg);
+#pragma unroll
+            for (int l = 0; l < 4; l++) {
+              const int d = l - j0;
+              const uint32_t u = d == 0 ? w[0] : (d == 1 ? w[1] : (d == 2 ? w[2] : 0u));
+              lane_dig[l] += on ? (int64_t)(((uint64_t)u ^ neg) - neg) : 0;
+            }
+            lane_min = on && y == y && key < lane_min ? key : lane_min;
+            lane_max = on && y == y && key > lane_max ? key : lane_max;
+          }
+        return;
+      }
 #pragma unroll
       for (int k = 0; k < NQ; k++)
 #pragma unroll
@@ -715,6 +761,42 @@ __device__ __forceinline__ void pipe_wide_body(const PgQueryPlan& p) {
 #pragma unroll
           for (int i = 0; i < 4; i++)
             if ((mg >> (4 * k + i)) & 1u) atomicAdd(reinterpret_cast<unsigned long long*>(base + slot[k][i]), 1ULL);
+      } else if (DBL && op.fn == PG_ACC_SUM) {
+        // the four digit accumulators of the column are consecutive rows of the table (planner): a value touches at most three of them —
+        // the rows dj .. dj + 2 — so the doc issues its (non-zero) windows to those rows once, at limb 0's turn; no select per accumulator
+        if (op.limb != 0) continue;
+#pragma unroll
+        for (int k = 0; k < NQ; k++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const bool on = ((mg >> (4 * k + i)) & 1u) != 0;
+            uint32_t w[3];
+            int j0;
+            uint64_t neg;
+            windows((uint64_t)v[k][i], w, j0, neg);
+            if (on) {   // one exec-mask change per doc: the three updates below are unconditional (a window outside rows 0 .. 3 adds 0 to a clamped row)
+#pragma unroll
+              for (int d = 0; d < 3; d++) {
+                const int row = j0 + d;
+                const bool in = (uint32_t)row < 4u;
+                const uint32_t rc = in ? (uint32_t)row : 0u;
+                const uint64_t val = in ? (((uint64_t)w[d] ^ neg) - neg) : 0ULL;
+                atomicAdd(reinterpret_cast<unsigned long long*>(base + rc * stride + slot[k][i]), (unsigned long long)val);
+              }
+            }
+          }
+      } else if (DBL) {                          // MIN / MAX of doubles: order-preserving keys; NaN never replaces the holder (Java: NaN < x is false)
+        const bool is_min = op.fn == PG_ACC_MIN;
+#pragma unroll
+        for (int k = 0; k < NQ; k++)
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const double y = __longlong_as_double(v[k][i]);
+            if (((mg >> (4 * k + i)) & 1u) && y == y) {
+              if (is_min) atomicMin(reinterpret_cast<long long*>(base + slot[k][i]), (long long)f64_order_key(y));
+              else atomicMax(reinterpret_cast<long long*>(base + slot[k][i]), (long long)f64_order_key(y));
+            }
+          }
       } else if (op.fn == PG_ACC_SUM) {
 #pragma unroll
         for (int k = 0; k < NQ; k++)
@@ -828,6 +910,7 @@ __device__ __forceinline__ void pipe_wide_body(const PgQueryPlan& p) {
       const PgAccOp op = p.ops[uniform(o)];
       const int kind = op.src < 0 || op.fn == PG_ACC_SUM ? 0 : (op.fn == PG_ACC_MIN ? 1 : 2);
       int64_t acc = op.src < 0 ? (int64_t)lane_cnt : (kind == 0 ? lane_sum : (kind == 1 ? lane_min : lane_max));
+      if (DBL && op.src >= 0 && kind == 0) acc = op.limb == 0 ? lane_dig[0] : (op.limb == 1 ? lane_dig[1] : (op.limb == 2 ? lane_dig[2] : lane_dig[3]));
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) {
         const int64_t y = __shfl_xor((long long)acc, off, 64);
@@ -868,14 +951,14 @@ __device__ __forceinline__ void pipe_wide_body(const PgQueryPlan& p) {
     }
   }
 }
-#define PG_PIPE_WIDE_KERNEL(NAME, VWV, IDX, SCAN) \
+#define PG_PIPE_WIDE_KERNEL(NAME, VKV, IDX, SCAN) \
   extern "C" __global__ void __launch_bounds__(PG_BLOCK) NAME(const PgQueryPlan p) { \
     const int ng = p.n_group_cols; \
-    if (ng == 0 && (VWV) != 0) pipe_wide_body<VWV, ((VWV) != 0 ? 0 : 1), IDX, SCAN>(p); \
-    else if (ng <= 1) pipe_wide_body<VWV, 1, IDX, SCAN>(p); \
-    else pipe_wide_body<VWV, 2, IDX, SCAN>(p); \
+    if (ng == 0 && (VKV) != 0) pipe_wide_body<VKV, ((VKV) != 0 ? 0 : 1), IDX, SCAN>(p); \
+    else if (ng <= 1) pipe_wide_body<VKV, 1, IDX, SCAN>(p); \
+    else pipe_wide_body<VKV, 2, IDX, SCAN>(p); \
   }
-// one kernel per value width (0: COUNT alone; 1: raw INT; 2: raw LONG) and filter shape: three bodies each (with all eight widths x group
+// one kernel per value kind (0: COUNT alone; raw INT; raw LONG; raw DOUBLE) and filter shape: three bodies each (with all the widths x group
 // counts in one kernel hipcc kept the plan in scratch memory in the kernels with an index program)
 PG_PIPE_WIDE_KERNEL(pg_pipe_w0_none, 0, false, false)
 PG_PIPE_WIDE_KERNEL(pg_pipe_w0_index, 0, true, false)
@@ -889,3 +972,7 @@ PG_PIPE_WIDE_KERNEL(pg_pipe_w64_none, 2, false, false)
 PG_PIPE_WIDE_KERNEL(pg_pipe_w64_index, 2, true, false)
 PG_PIPE_WIDE_KERNEL(pg_pipe_w64_scan, 2, false, true)
 PG_PIPE_WIDE_KERNEL(pg_pipe_w64_index_scan, 2, true, true)
+PG_PIPE_WIDE_KERNEL(pg_pipe_wd_none, 3, false, false)
+PG_PIPE_WIDE_KERNEL(pg_pipe_wd_index, 3, true, false)
+PG_PIPE_WIDE_KERNEL(pg_pipe_wd_scan, 3, false, true)
+PG_PIPE_WIDE_KERNEL(pg_pipe_wd_index_scan, 3, true, true)

@@ -1947,26 +1947,38 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
   // ... and of those the ones the wide pipeline takes (pg_pipe_w_*, pg_kernels_pipe.hip): integer accumulators over ONE raw INT / LONG column
   // (or COUNT alone), zero to two group columns of <= 16 bits, behind no filter, a fused dense index program, a lone raw-INT range scan, or both
   D.pipe_wide = 0;
-  if (P.wide_agg && !P.digit_ops && (D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE) && D.n_group_cols <= 2 &&
+  if (P.wide_agg && (D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE) && D.n_group_cols <= 2 &&
       (int64_t)G * D.replicas <= 65536 && !getenv("PG_NO_PIPE_WIDE")) {
     bool ok = true;
     int src = -1;
     for (int o = 0; o < D.n_ops && ok; o++) {
       if (D.ops[o].src < 0) continue;
-      if (D.ops[o].is_float != PG_ACCV_INT) ok = false;
       if (src >= 0 && D.ops[o].src != src) ok = false;
       src = D.ops[o].src;
     }
     for (int o = 0; o < D.n_ops && ok; o++) ok = D.ops[o].fn == PG_ACC_COUNT || D.ops[o].fn == PG_ACC_SUM || D.ops[o].fn == PG_ACC_MIN || D.ops[o].fn == PG_ACC_MAX;
     for (int g = 0; g < D.n_group_cols && ok; g++)
       ok = D.gcols[g].col_kind == PG_COL_FIXED_BIT && D.gcols[g].bits >= 1 && D.gcols[g].bits <= 16 && D.mv_gcol_offsets[g] == nullptr;
-    int vw = 1;
+    int vw = 1;   // value kind of pg_pipe_w*: 1 raw INT, 2 raw LONG, 3 raw DOUBLE
     if (ok && src >= 0) {
       const Column* c = srcs[(size_t)src];
       if (D.srcs[src].col_kind == PG_COL_RAW32 && c->val_type == PG_V_I32) vw = 1;
       else if (D.srcs[src].col_kind == PG_COL_RAW64 && c->val_type == PG_V_I64) vw = 2;
+      else if (D.srcs[src].col_kind == PG_COL_RAW64 && c->val_type == PG_V_F64 && !getenv("PG_NO_PIPE_WIDE_DOUBLE")) vw = 3;
       else ok = false;
     }
+    // accumulator kinds: integers in int64; DOUBLE sums as fixed-point digits (a column with NaN / Inf keeps IEEE additions: not here),
+    // DOUBLE MIN / MAX through order keys
+    for (int o = 0; o < D.n_ops && ok; o++) {
+      if (D.ops[o].src < 0) continue;
+      if (vw == 3) ok = D.ops[o].fn == PG_ACC_SUM ? (D.ops[o].is_float == PG_ACCV_FIXED_DIGIT && D.ops[o].limb >= 0 && D.ops[o].limb < 4) : D.ops[o].is_float == PG_ACCV_DOUBLE;
+      else ok = D.ops[o].is_float == PG_ACCV_INT;
+    }
+    // ... and the four digit accumulators of a DOUBLE sum are consecutive rows, limb 0 first (the kernel addresses rows limb0 + j)
+    for (int o = 0; o < D.n_ops && ok && vw == 3; o++)
+      if (D.ops[o].src >= 0 && D.ops[o].fn == PG_ACC_SUM && D.ops[o].limb == 0)
+        for (int j = 1; j < 4 && ok; j++)
+          ok = o + j < D.n_ops && D.ops[o + j].fn == PG_ACC_SUM && D.ops[o + j].src == D.ops[o].src && D.ops[o + j].is_float == PG_ACCV_FIXED_DIGIT && D.ops[o + j].limb == j;
     if (ok && D.n_group_cols == 0 && src < 0) ok = false;   // COUNT alone without GROUP BY: nothing to pipeline
     const bool index_ok = D.n_index_instr == 0 || D.dense_fused;
     bool has_scan = false;

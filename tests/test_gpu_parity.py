@@ -466,6 +466,11 @@ PIPE_WIDE_QUERIES = [
     ("SELECT k, SUM(r), COUNT(*) FROM wide WHERE r BETWEEN 100 AND 700 GROUP BY k LIMIT 5000", "pg_pipe_w32_scan"),   # INT values, 11-bit key
     ("SELECT k, SUM(lm), MIN(lm) FROM wide WHERE r BETWEEN 100 AND 700 GROUP BY k LIMIT 5000", "pg_pipe_w64_scan"),
     ("SELECT k2, MAX(lm), COUNT(*) FROM wide WHERE inv NOT IN (0, 4) AND r < 500 GROUP BY k2", "pg_pipe_w64_index_scan"),
+    ("SELECT k, SUM(dm), MIN(dm), MAX(dm), COUNT(*) FROM wide GROUP BY k LIMIT 5000", "pg_pipe_wd_none"),      # raw DOUBLE: digit sums, order-key MIN / MAX
+    ("SELECT k2, AVG(dm) FROM wide GROUP BY k2", "pg_pipe_wd_none"),
+    ("SELECT k2, SUM(dm) FROM wide WHERE inv IN (1, 3) AND r < 900 GROUP BY k2", "pg_pipe_wd_index_scan"),
+    ("SELECT SUM(dm), MAX(dm), COUNT(*) FROM wide WHERE r BETWEEN 100 AND 700", "pg_pipe_wd_scan"),             # no GROUP BY: lane-held digit sums
+    ("SELECT k, MINMAXRANGE(dm) FROM wide WHERE inv = 4 GROUP BY k LIMIT 5000", "pg_pipe_wd_index"),
     ("SELECT k, k2, SUM(lm) FROM wide WHERE inv = 2 AND r >= 250 GROUP BY k, k2 LIMIT 20000", None),          # 14 000 groups: whichever table mode
     ("SELECT k, SUM(lm) FROM wide WHERE r > 5000 GROUP BY k LIMIT 5000", None),                                # nothing matches
 ]
@@ -486,14 +491,21 @@ def test_wide_pipeline_sizes(gpu_api, oracle_api, n):
     rng = np.random.default_rng(n)
     data = {"k": rng.integers(0, 600, n).astype(np.int32), "k2": rng.integers(0, 3, n).astype(np.int32),
             "lm": rng.integers(-10**11, 10**11, n).astype(np.int64), "r": rng.integers(0, 1000, n).astype(np.int32),
-            "inv": rng.integers(0, 3, n).astype(np.int32)}   # (sums stay below 2^53: the domain where the reference's double sums are exact)
-    host = build_segment("ws", data, {"k": "INT", "k2": "INT", "lm": "LONG", "r": "INT", "inv": "INT"}, inverted_index_columns=["inv"],
-                         no_dictionary_columns=["lm", "r"])
+            "inv": rng.integers(0, 3, n).astype(np.int32),   # (sums stay below 2^53: the domain where the reference's double sums are exact)
+            "dd": (rng.integers(-10**6, 10**6, n) * 0.25).astype(np.float64),
+            "dn": np.where(rng.random(n) < 0.2, np.nan, rng.integers(-50, 50, n) * 1.5).astype(np.float64)}   # NaN never replaces a MIN / MAX holder
+    data["dn"][::7] = np.inf
+    host = build_segment("ws", data, {"k": "INT", "k2": "INT", "lm": "LONG", "r": "INT", "inv": "INT", "dd": "DOUBLE", "dn": "DOUBLE"},
+                         inverted_index_columns=["inv"], no_dictionary_columns=["lm", "r", "dd", "dn"])
     g, o = both(gpu_api, oracle_api, host)
     for q in ("SELECT k, SUM(lm), MIN(lm), MAX(lm), COUNT(*) FROM ws GROUP BY k LIMIT 5000",
               "SELECT k, k2, SUM(lm) FROM ws WHERE r < 700 GROUP BY k, k2 LIMIT 5000",
               "SELECT k2, SUM(r), MAX(r) FROM ws WHERE inv = 1 AND r >= 100 GROUP BY k2",
-              "SELECT MIN(lm), COUNT(*) FROM ws WHERE inv != 0"):
+              "SELECT MIN(lm), COUNT(*) FROM ws WHERE inv != 0",
+              "SELECT k, SUM(dd), MIN(dd), COUNT(*) FROM ws WHERE r < 800 GROUP BY k LIMIT 5000",
+              "SELECT SUM(dd), MAX(dd) FROM ws WHERE inv = 2",
+              "SELECT k2, MIN(dn), MAX(dn), COUNT(*) FROM ws GROUP BY k2",
+              "SELECT MIN(dn), MAX(dn) FROM ws WHERE r >= 300"):
         assert_same_block(g.execute(q), o.execute(q))
     g.destroy()
     o.destroy()

@@ -133,6 +133,8 @@ QUERIES_WIDE = {   # LDS-table aggregations over 64-bit sources / an 11-bit grou
     "sum(m64) group g1": ("SELECT g1, SUM(m64), MAX(m64) FROM t GROUP BY g1", 8.875),
     "cfg3 filter, sum(m64) group g1": ("SELECT g1, SUM(m64) FROM t WHERE c_inv1 IN (0,1,2,3) AND c_inv2 IN (0,1) AND r_int BETWEEN 250000 AND 749999 GROUP BY g1", 13.625),
     "sum(d64) avg(m) group g1": ("SELECT g1, SUM(d64), AVG(m) FROM t WHERE r_int < 500000 GROUP BY g1", 16.875),
+    "sum(d64) max(d64) group g1": ("SELECT g1, SUM(d64), MAX(d64) FROM t GROUP BY g1", 8.875),
+    "filtered sum(d64) group g1": ("SELECT g1, SUM(d64), COUNT(*) FROM t WHERE r_int BETWEEN 250000 AND 749999 GROUP BY g1", 12.875),
     "sum(m) group w1 (2000 groups)": ("SELECT w1, SUM(m), COUNT(*) FROM t GROUP BY w1 LIMIT 5000", 5.375),
     "filtered sum(m64) group w1": ("SELECT w1, SUM(m64) FROM t WHERE r_int BETWEEN 250000 AND 749999 GROUP BY w1 LIMIT 5000", 13.375),
     "sum(m64) no group": ("SELECT SUM(m64), MIN(m64), COUNT(*) FROM t WHERE c_inv2 = 1", 8.125),
