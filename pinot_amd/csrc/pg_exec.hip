@@ -119,7 +119,13 @@ void DeviceBuffer::alloc(size_t n, bool zero) {
   size = (n + 255) & ~(size_t)255;
   PG_HIP(hipGetDevice(&device));
   PG_HIP(hipMalloc(&ptr, size));
-  if (zero) PG_HIP(hipMemset(ptr, 0, size));
+  if (zero) {
+    // hipMemset on device memory is asynchronous (legacy default stream) and the per-thread streams are non-blocking: without the wait a
+    // kernel launched next on such a stream could run BEFORE the fill and have its output zeroed afterwards (seen once in ~10^3 filter
+    // calls with four processes sharing the GPU: pg_docidset_copy_docids returned zeros for a set of cardinality 2)
+    PG_HIP(hipMemset(ptr, 0, size));
+    PG_HIP(hipStreamSynchronize(nullptr));
+  }
 }
 void DeviceBuffer::release() {
   if (ptr) {
@@ -1272,8 +1278,10 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
     kept->n_out = n_out;
     kept->aux_total = aux_total;
     kept->full_scan_entries = exact_entries >= 0 ? exact_entries : P.full_scan_entries;
-    if (exact_entries >= 0)   // the per-scan candidate counters of the kept table are superseded by the exact count
-      PG_HIP(hipMemset(kept->table.as<int64_t>() + n_out + 1, 0, (PG_MAX_STATS - 1) * 8));
+    if (exact_entries >= 0) {   // the per-scan candidate counters of the kept table are superseded by the exact count
+      PG_HIP(hipMemsetAsync(kept->table.as<int64_t>() + n_out + 1, 0, (PG_MAX_STATS - 1) * 8, ctx.stream));   // (stream-ordered behind the copy into the kept table)
+      PG_HIP(hipStreamSynchronize(ctx.stream));
+    }
     kept->num_total_docs = seg.total_docs;
     kept->sum_max_abs = P.sum_max_abs;
     kept->has_digit_sums = P.has_digit_sums;

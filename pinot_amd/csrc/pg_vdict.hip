@@ -216,6 +216,7 @@ void ensure_virtual_dictionary(Segment& seg, Column& c) {
       // the hash is an identity on this column?  representatives, then every doc against its representative
       DeviceBuffer rep((size_t)card * 4), flag(8, true);
       PG_HIP(hipMemset(rep.ptr, 0xFF, (size_t)card * 4));
+      PG_HIP(hipStreamSynchronize(nullptr));   // (the fill runs on the legacy default stream, the kernels below on a non-blocking one)
       hipLaunchKernelGGL(pg_vdict_rep_kernel, dim3(grid), dim3(256), 0, 0, ids, rep.as<uint32_t>(), n);
       hipLaunchKernelGGL(pg_vdict_verify_kernel, dim3(grid), dim3(256), 0, 0, c.fwd_dev.as<uint8_t>(), c.vb_offsets_dev.as<int64_t>(), ids, rep.as<uint32_t>(),
                          flag.as<uint32_t>(), n);
