@@ -354,7 +354,7 @@ struct PgQueryPlan {
   int32_t pipe_vscan;               // >= 0: index of the second scan leaf, a range over the value column tested on the value quads (-1: none)
   const uint8_t* pipe_tail;
   int32_t pipe_wide;                // pg_pipe_w*: value kind of the one source column (1: raw INT, 2: raw LONG, 3: raw DOUBLE); 0: not this family
-  int32_t pipe_wide_pad;
+  int32_t mv_no_windows;            // measurement knob (PG_MV_NO_WINDOWS): multi-value scan leaves walk doc by doc as in round 3
   // Interpreter kernels over small doc spaces with expensive per-doc state updates (a star-tree's serialized HyperLogLogs: one
   // wavefront-wide register merge per matching doc): every wave tile is visited by 2^tile_split_shift wavefronts, each evaluating
   // the tile's filter and then keeping only its share of the matching docs (a quad slot and a lane class), so that a 13 617-doc

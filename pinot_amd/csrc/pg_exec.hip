@@ -193,6 +193,8 @@ void use_device(int ordinal) {
                                  pg_p2_aggregate_1n, pg_p2_aggregate_2n, pg_p2_aggregate_3n, pg_p2_aggregate_4n};
       for (QueryKernel k : all)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
+      for (QueryKernel k : {pg_mv_query_f, pg_mv_query_l, pg_mv_query_g})   // 10.5 KB of static LDS (per-wavefront entry bitmaps): the planner's 144 KB still fit
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 12288);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pg_radix_scatter_packed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pg_radix_aggregate_packed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
       (void)hipGetLastError();   // a refused attribute must not surface as the "last error" of a later launch

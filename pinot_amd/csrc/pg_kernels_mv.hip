@@ -57,6 +57,86 @@ DEVFN uint32_t mv_scan_wtile(const LeafT& L, uint32_t cand, int wt, int lane, ui
   return out;
 }
 
+// The same over a FULL wave tile, ENTRY-parallel (round 4).  The doc-by-doc walk above is a chain of dependent loads — a lane's 32 docs one
+// after the other, every entry an 8-byte load of its own — and 128 instructions per entry once the compiler has predicated its loops: 0.70 ms
+// for a 5 x 10^7-doc scan, 3.7 % of 8 TB/s (profiles/r04_i_variants_mv_50m.txt; a first rewrite that walked a quad's entries out of a 32-byte
+// register window was no better: 0.60 ms, 12 300 wave instructions per tile, profiles/r04_u_*).  A tile's entries are one contiguous run of
+// the stream, so the wavefront tests them 64 at a time — lane L the entry base + L: neighbouring lanes read neighbouring bits, one ballot
+// per 64 entries — and keeps the pass bits as a bitmap in LDS; a doc then is a bit range [row start, row end) of that bitmap: ANY entry
+// passes = the range is not zero, ALL = it is all ones.  Tiles with more than PG_MV_TILE_ENTRIES entries keep the walk above.
+#define PG_MV_TILE_ENTRIES 8192
+typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+template <class LeafT>
+DEVFN uint32_t mv_scan_wtile_bitmap(const LeafT& L, uint32_t cand, int wt, int lane, uint32_t& entries, uint32_t* bm /* [PG_MV_TILE_ENTRIES / 32 + 2] */,
+                                    bool& taken) {
+  const GAS int32_t* off = gptr<int32_t>(L.set_values) + (size_t)wt * PG_WAVE_DOCS;
+  const uint32_t E0 = (uint32_t)__builtin_amdgcn_readfirstlane(off[0]), E1 = (uint32_t)__builtin_amdgcn_readfirstlane(off[PG_WAVE_DOCS]);
+  const uint32_t n_e = E1 - E0;
+  taken = n_e <= (uint32_t)PG_MV_TILE_ENTRIES;
+  if (!taken) return 0u;   // wave-uniform
+  const uint32_t bits = (uint32_t)L.bits, vmask = (1u << bits) - 1u;
+  const uint32_t lo = (uint32_t)L.lo, span = (uint32_t)(L.hi - L.lo);
+  const bool lut = L.pred_kind == PG_P_DICT_LUT, all = L.exclusive != 0;
+  // row starts of the lane's eight quads (16 bytes each, requested together)
+  i32x4 o[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) o[k] = *(const GAS i32x4*)(off + 4 * (k * 64 + lane));
+  // ---- entry phase: pass bits of entries E0 .. E1 - 1 -> bm -------------------------------------------------------------------------------
+  const GAS uint32_t* stream = gptr<uint32_t>(L.data);
+  for (uint32_t base = 0; base < n_e; base += 256u) {   // four ballots per iteration: four loads in flight
+    uint32_t dv[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t idx = min(base + 64u * (uint32_t)u + (uint32_t)lane, n_e - 1u);   // (lanes beyond the run re-read its last entry)
+      const uint64_t bit0 = (uint64_t)(E0 + idx) * bits;
+      const u32x2 v = *(const GAS u32x2_a4*)(stream + (bit0 >> 5));
+      const uint64_t win = ((uint64_t)bswap32(v.x) << 32) | (uint64_t)bswap32(v.y);
+      dv[u] = (uint32_t)(win >> (64u - (uint32_t)(bit0 & 31u) - bits)) & vmask;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const uint32_t idx = base + 64u * (uint32_t)u + (uint32_t)lane;
+      const uint32_t d = dv[u];
+      const bool pass = (lut ? ((gptr<uint32_t>(L.lut)[d >> 5] >> (d & 31u)) & 1u) != 0 : (d - lo) <= span) && idx < n_e;
+      const uint64_t m = __ballot(pass);
+      if (lane < 2) bm[(base >> 5) + 2u * (uint32_t)u + (uint32_t)lane] = lane ? (uint32_t)(m >> 32) : (uint32_t)m;   // (beyond the run: zeros)
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  // ---- doc phase: a candidate doc is the bit range [row start, row end) ---------------------------------------------------------------------
+  const volatile uint32_t* vb = bm;
+  uint32_t out = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const uint32_t c4 = (cand >> (4 * k)) & 0xFu;
+    // end of the quad's rows = the next lane's first row start (lane 63: lane 0 of the next quad, or the next tile)
+    const int32_t next_q = k < 7 ? __builtin_amdgcn_readfirstlane(o[k < 7 ? k + 1 : 7].x) : (int32_t)E1;
+    int32_t o4 = __shfl_down(o[k].x, 1, 64);
+    if (lane == 63) o4 = next_q;
+    const uint32_t rs[5] = {(uint32_t)o[k].x - E0, (uint32_t)o[k].y - E0, (uint32_t)o[k].z - E0, (uint32_t)o[k].w - E0, (uint32_t)o4 - E0};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (!((c4 >> i) & 1u)) continue;
+      uint32_t sb = rs[i];
+      const uint32_t eb = rs[i + 1];
+      entries += eb - sb;
+      bool any_pass = false, all_pass = true;
+      while (sb < eb) {   // 32 bits of the row at a time (one pass for rows of up to 32 entries)
+        const uint32_t n = min(eb - sb, 32u);
+        const uint32_t w0 = vb[sb >> 5], w1 = vb[(sb >> 5) + 1u];
+        const uint32_t x = (uint32_t)((((uint64_t)w1 << 32) | (uint64_t)w0) >> (sb & 31u));
+        const uint32_t full = n == 32u ? 0xFFFFFFFFu : ((1u << n) - 1u);
+        any_pass |= (x & full) != 0u;
+        all_pass &= (x & full) == full;
+        sb += n;
+      }
+      out |= (uint32_t)(all ? all_pass : any_pass) << (4 * k + i);
+    }
+  }
+  return out;
+}
+
 struct MvKeys {   // the multi-value group columns' entries of one doc (the planner admits at most two such columns)
   uint32_t base;        // slot of the single-value part of the key (replica included)
   uint32_t combos;      // keys of the doc
@@ -189,6 +269,7 @@ __device__ __forceinline__ void mv_query_body(const PgQueryPlan& p) {
   extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
   __shared__ uint32_t s_stat[PG_MAX_STATS];
   __shared__ uint32_t s_wscratch[PG_GENERIC_BLOCK / 64][64];
+  __shared__ uint32_t s_mvbits[PG_GENERIC_BLOCK / 64][PG_MV_TILE_ENTRIES / 32 + 8];   // per wavefront: pass bits of a tile's entries (mv_scan_wtile_bitmap)
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = uniform(t >> 6);
@@ -235,7 +316,14 @@ __device__ __forceinline__ void mv_query_body(const PgQueryPlan& p) {
         case PG_F_PUSH_SCAN: {
           const CAS PgScanLeaf& L = cptr(p.scans)[farg];
           uint32_t ignored = 0;   // every doc is evaluated: the planner counted the column's entries already
-          st.push(L.mv ? mv_scan_wtile(L, valid_q, wt, lane, ignored) : scan_dispatch(L, valid_q, wt, lane));
+          if (L.mv) {
+            bool taken = false;
+            uint32_t mm = 0;
+            if (n_valid == PG_WAVE_DOCS && !p.mv_no_windows) mm = mv_scan_wtile_bitmap(L, valid_q, wt, lane, ignored, s_mvbits[wave], taken);
+            st.push(taken ? mm : mv_scan_wtile(L, valid_q, wt, lane, ignored));
+          } else {
+            st.push(scan_dispatch(L, valid_q, wt, lane));
+          }
           break;
         }
         case PG_F_AND_SCAN: {
@@ -245,7 +333,10 @@ __device__ __forceinline__ void mv_query_body(const PgQueryPlan& p) {
           if (nc) {   // wave-uniform
             if (L.mv) {
               uint32_t entries = 0;
-              st.s0 = mv_scan_wtile(L, cand, wt, lane, entries);
+              bool taken = false;
+              uint32_t mm = 0;
+              if (n_valid == PG_WAVE_DOCS && !p.mv_no_windows) mm = mv_scan_wtile_bitmap(L, cand, wt, lane, entries, s_mvbits[wave], taken);
+              st.s0 = taken ? mm : mv_scan_wtile(L, cand, wt, lane, entries);
               const uint32_t ne = wave_sum_u32(entries);
               if (lane == 0) atomicAdd(&s_stat[L.stat_slot], ne);
             } else {

@@ -1992,6 +1992,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
       D.pipe_has_scan = has_scan ? 1 : 0;
     }
   }
+  D.mv_no_windows = getenv("PG_MV_NO_WINDOWS") ? 1 : 0;
   if (D.mv) {   // none of the single-value specialisations reads a multi-value column
     P.fast_filter = -2;
     P.fast_agg = false;
