@@ -554,7 +554,7 @@ def measure_traffic(query, docs, kernel):
             db = sqlite3.connect(dbs[0])
             if kernel.endswith("_group_by"):   # a pipeline of kernels (radix / hash group-by): all of them, per query execution
                 rows = list(db.execute("select sum(value) from counters_collection where counter_name = ? and (kernel_name like 'pg_radix%' "
-                                       "or kernel_name like 'pg_p2%' or kernel_name like 'pg_hash%' or kernel_name like 'pg_fast_%_f' "
+                                       "or kernel_name like 'pg_p2%' or kernel_name like 'pg_oct%' or kernel_name like 'pg_hash%' or kernel_name like 'pg_fast_%_f' "
                                        "or kernel_name like 'pg_generic_query_f')", (counter,)))
                 per[counter] = float(rows[0][0]) / 7.0    # 2 warm-up + 5 timed executions in the child run
             else:
