@@ -379,6 +379,14 @@ int32_t pg_result_set_sizes(pg_result_t result, int32_t agg, int32_t* out_sizes,
 int32_t pg_result_set_dict_ids(pg_result_t result, int32_t agg, int32_t* out_dict_ids, int64_t capacity);
 /* DISTINCTCOUNTHLL: num_groups * 2^log2m register bytes, group-major */
 int32_t pg_result_hll_registers(pg_result_t result, int32_t agg, uint8_t* out_registers, int64_t capacity);
+/* The result as the bytes of a DataTableImplV4 carrying INTERMEDIATE results — what GroupByResultsBlock#getDataTable
+ * (pinot-core/.../operator/blocks/results/GroupByResultsBlock.java:186-236) / AggregationResultsBlock#getDataTable (:104-155) build and
+ * DataTableImplV4#toBytes (pinot-common/.../common/datatable/DataTableImplV4.java:422-517) writes: group keys as typed columns (STRING
+ * through the table's string dictionary), COUNT as LONG, SUM / MIN / MAX as DOUBLE, AVG / MINMAXRANGE / DISTINCTCOUNT / DISTINCTCOUNTHLL as
+ * serialized objects (ObjectSerDeUtils: AvgPair, MinMaxRangePair, typed value sets, HyperLogLog).  Rows come in the result's group order,
+ * set elements ascending, no metadata entries (DataTableFactory.getDataTable(bytes) reads it).  out == NULL asks for the size only.
+ * Not for results executed with PG_QUERY_FLAG_FINAL_DISTINCT (those are final values). */
+int32_t pg_result_data_table_v4(pg_result_t result, uint8_t* out, int64_t capacity, int64_t* out_size);
 int32_t pg_result_stats(pg_result_t result, pg_exec_stats* out_stats);
 int32_t pg_result_free(pg_result_t result);
 

@@ -64,6 +64,9 @@ public final class PinotGpu {
   public static native void resultSetSizes(long result, int aggregation, int[] out);
   public static native void resultSetDictIds(long result, int aggregation, int[] out);
   public static native void resultHllRegisters(long result, int aggregation, byte[] out);
+  // the (merged) intermediate results as DataTableImplV4 bytes: DataTableFactory.getDataTable(ByteBuffer.wrap(bytes)) reads them
+  public static native long resultDataTableV4Size(long result);
+  public static native void resultDataTableV4(long result, byte[] out);
   public static native void resultStats(long result, long[] out5);
   public static native void resultFree(long result);
 

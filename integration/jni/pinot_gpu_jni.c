@@ -217,6 +217,15 @@ COPY_OUT(resultLongs(JNIEnv* env, jclass c, jlong r, jint agg, jint comp, jlongA
 COPY_OUT(resultSetSizes(JNIEnv* env, jclass c, jlong r, jint agg, jintArray out), jint, int32_t, GetIntArrayRegion, SetIntArrayRegion, pg_result_set_sizes(RES(r), agg, p, n))
 COPY_OUT(resultSetDictIds(JNIEnv* env, jclass c, jlong r, jint agg, jintArray out), jint, int32_t, GetIntArrayRegion, SetIntArrayRegion, pg_result_set_dict_ids(RES(r), agg, p, (int64_t)n))
 COPY_OUT(resultHllRegisters(JNIEnv* env, jclass c, jlong r, jint agg, jbyteArray out), jbyte, uint8_t, GetByteArrayRegion, SetByteArrayRegion, pg_result_hll_registers(RES(r), agg, p, (int64_t)n))
+/* The result's DataTableImplV4 bytes (pg_result_data_table_v4): size first, then into a byte[] of that size — DataTableFactory.getDataTable(bytes)
+ * on the Java side gives the DataTable a results block hands to InstanceResponseOperator without boxing a group */
+JNIEXPORT jlong JNICALL Java_org_apache_pinot_gpu_PinotGpu_resultDataTableV4Size(JNIEnv* env, jclass c, jlong r) {
+  (void)c;
+  int64_t n = 0;
+  CHECK_RET(pg_result_data_table_v4(RES(r), NULL, 0, &n), 0);
+  return (jlong)n;
+}
+COPY_OUT(resultDataTableV4(JNIEnv* env, jclass c, jlong r, jbyteArray out), jbyte, uint8_t, GetByteArrayRegion, SetByteArrayRegion, pg_result_data_table_v4(RES(r), p, (int64_t)n, &(int64_t){0}))
 /* out[0..4] = numDocsScanned, numEntriesScannedInFilter, numEntriesScannedPostFilter, numTotalDocs, numGroupsLimitReached */
 JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpu_resultStats(JNIEnv* env, jclass c, jlong r, jlongArray out) {
   (void)c;

@@ -177,7 +177,7 @@ ABI_SYMBOLS = [
 GPU_ONLY_SYMBOLS = [
     "segment_create_on_device", "segment_device",
     "cancel_create", "cancel_request", "cancel_reset", "cancel_destroy", "query_exec_cancellable",
-    "result_merge", "result_all_reduce",
+    "result_merge", "result_all_reduce", "result_data_table_v4",
     "comm_get_unique_id", "comm_init_rank", "comm_init_all", "comm_world_size", "comm_destroy",
 ]
 
@@ -202,6 +202,7 @@ class NativeApi:
             self.f("query_exec_cancellable").argtypes = [C.c_void_p, C.POINTER(PgQuery), C.c_void_p, C.POINTER(C.c_void_p)]
             self.f("result_merge").argtypes = [C.c_void_p, C.c_void_p]
             self.f("result_all_reduce").argtypes = [C.c_void_p, C.c_void_p]
+            self.f("result_data_table_v4").argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
             self.f("comm_get_unique_id").argtypes = [C.c_void_p]
             self.f("comm_init_rank").argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
             self.f("comm_init_all").argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]

@@ -337,6 +337,7 @@ int32_t pg_result_doubles(pg_result_t result, int32_t agg, int32_t component, do
     REQUIRE(component >= 0 && component < 2, "component out of range");
     REQUIRE(capacity >= result->r->num_groups, "capacity too small");
     if (!a.d[component].empty()) memcpy(out, a.d[component].data(), a.d[component].size() * 8);
+    else if (result->r->num_groups > 0) memset(out, 0, (size_t)result->r->num_groups * 8);   // a component the result kind does not have
   });
 }
 int32_t pg_result_longs(pg_result_t result, int32_t agg, int32_t component, int64_t* out, int32_t capacity) {
@@ -345,6 +346,7 @@ int32_t pg_result_longs(pg_result_t result, int32_t agg, int32_t component, int6
     REQUIRE(component >= 0 && component < 2, "component out of range");
     REQUIRE(capacity >= result->r->num_groups, "capacity too small");
     if (!a.l[component].empty()) memcpy(out, a.l[component].data(), a.l[component].size() * 8);
+    else if (result->r->num_groups > 0) memset(out, 0, (size_t)result->r->num_groups * 8);
   });
 }
 int32_t pg_result_set_sizes(pg_result_t result, int32_t agg, int32_t* out_sizes, int32_t capacity) {
@@ -380,6 +382,16 @@ int32_t pg_result_hll_registers(pg_result_t result, int32_t agg, uint8_t* out_re
     }
     REQUIRE(capacity >= (int64_t)a.hll.size(), "capacity too small");
     if (!a.hll.empty()) memcpy(out_registers, a.hll.data(), a.hll.size());
+  });
+}
+int32_t pg_result_data_table_v4(pg_result_t result, uint8_t* out, int64_t capacity, int64_t* out_size) {
+  return guarded([&] {
+    REQUIRE(result && out_size, "null argument");
+    const std::vector<uint8_t> b = result_data_table_v4(*result->r);
+    *out_size = (int64_t)b.size();
+    if (!out) return;                              // size query
+    REQUIRE(capacity >= (int64_t)b.size(), "capacity too small");
+    memcpy(out, b.data(), b.size());
   });
 }
 int32_t pg_result_stats(pg_result_t result, pg_exec_stats* out_stats) {

@@ -1255,6 +1255,24 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
   }
   const double t_before_assembly = now_ms();
   assemble_result(*res, P, q.n_group_by, q.n_aggregations, H);
+  {   // the columns' names, types and host dictionaries, for pg_result_data_table_v4
+    auto column_of = [&](const char* name, ResultColumn& rc) {
+      rc.name = name ? name : "*";
+      Column* c = name ? seg.find(name) : nullptr;
+      if (c) {
+        rc.data_type = c->data_type;
+        if (c->has_dictionary && !c->dict_host.empty()) { rc.dict = c->dict_host.data(); rc.dict_width = c->dict_bytes_per_value; }
+      }
+    };
+    res->schema_keys.resize((size_t)q.n_group_by);
+    for (int j = 0; j < q.n_group_by; j++) column_of(q.group_by_columns[j], res->schema_keys[(size_t)j]);
+    res->schema_aggs.resize((size_t)q.n_aggregations);
+    for (int a = 0; a < q.n_aggregations; a++) {
+      const char* col = q.aggregations[a].column;
+      column_of(col && strcmp(col, "*") != 0 ? col : nullptr, res->schema_aggs[(size_t)a]);
+      res->schema_aggs[(size_t)a].function = q.aggregations[a].function;
+    }
+  }
   {
     static const bool trace = getenv("PG_TRACE_HOST") != nullptr;   // debugging knob: where the host time of a query goes
     if (trace)
@@ -1450,10 +1468,13 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
   for (int a = 0; a < n_aggregations; a++) {
     const AggOut& ao = P.aggs[a];
     AggResult& r = res.aggs[a];
-    for (int k = 0; k < 2; k++) { r.d[k].assign((size_t)ng, 0.0); r.l[k].assign((size_t)ng, 0); }
+    // only the components the result kind has are sized (all four were filled with zeros for every aggregation: 0.8 MB per query for
+    // config 5's 12 800 groups, a third of the star-tree route's assembly time)
+    for (int k = 0; k < 2; k++) { r.d[k].clear(); r.l[k].clear(); }
     if (ao.aux >= 0 && H.aux_summary) {   // PG_QUERY_FLAG_FINAL_DISTINCT: the final value from the device's two integers per group
       const uint64_t* sm = H.aux_summary + (size_t)ao.aux * (size_t)std::max(D.n_groups, 1);
       r.kind = PG_RESULT_LONG;
+      r.l[0].resize((size_t)ng);
       for (int32_t i = 0; i < ng; i++) r.l[0][i] = (int64_t)sm[(size_t)gids[i]];
       continue;
     }
@@ -1511,18 +1532,24 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
     switch (ao.function) {
       case PG_AGG_COUNT:
         r.kind = PG_RESULT_LONG;
+        r.l[0].resize((size_t)ng);
         for (int32_t i = 0; i < ng; i++) r.l[0][i] = count_of(ao.op_a, gids[i]);
         break;
       case PG_AGG_AVG:
         r.kind = PG_RESULT_AVG_PAIR;
+        r.d[0].resize((size_t)ng);
+        r.l[0].resize((size_t)ng);
         for (int32_t i = 0; i < ng; i++) { r.d[0][i] = sum_double(ao, gids[i]); r.l[0][i] = count_of(ao.op_b, gids[i]); }
         break;
       case PG_AGG_MINMAXRANGE:
         r.kind = PG_RESULT_MINMAX_PAIR;
+        r.d[0].resize((size_t)ng);
+        r.d[1].resize((size_t)ng);
         for (int32_t i = 0; i < ng; i++) { r.d[0][i] = op_double(ao.op_a, gids[i]); r.d[1][i] = op_double(ao.op_b, gids[i]); }
         break;
       default:
         r.kind = PG_RESULT_DOUBLE;
+        r.d[0].resize((size_t)ng);
         if (ao.function == PG_AGG_SUM) for (int32_t i = 0; i < ng; i++) r.d[0][i] = sum_double(ao, gids[i]);
         else for (int32_t i = 0; i < ng; i++) r.d[0][i] = op_double(ao.op_a, gids[i]);
         break;

@@ -351,7 +351,17 @@ struct DeviceTable {
   uint64_t sum_max_abs = 0;
   bool has_digit_sums = false;
 };
+// What a data table needs to know about a result column (pg_datatable.cpp): the name, the column's stored type and its dictionary on
+// the host (a pointer into the segment's Column: the segment outlives its results)
+struct ResultColumn {
+  std::string name;                 // group-by column / the aggregation's argument ("*" for COUNT)
+  int32_t data_type = 0;            // pg_data_type of the column
+  int32_t function = -1;            // pg_agg_function (aggregations)
+  const uint8_t* dict = nullptr;    // big-endian dictionary values, dict_width bytes each
+  int32_t dict_width = 0;
+};
 struct Result {
+  std::vector<ResultColumn> schema_keys, schema_aggs;
   std::unique_ptr<DeviceTable> dev;    // PG_QUERY_FLAG_KEEP_DEVICE_TABLE
   int32_t num_groups = 0;
   std::vector<std::vector<int32_t>> group_dict_ids;
@@ -382,6 +392,7 @@ int default_device();                   // the device pg_segment_create pins on 
 void use_device(int ordinal);           // makes `ordinal` current on the calling thread, initialising it on first use
 std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const CancelToken* cancel);
 void result_merge(Result& dst, Result& src);
+std::vector<uint8_t> result_data_table_v4(const Result& r);   // pg_datatable.cpp
 // RCCL (pg_comm.cpp)
 struct Comm;
 void comm_unique_id(void* out128);

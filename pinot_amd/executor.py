@@ -243,6 +243,14 @@ class NativeResult:
         self.api.call("result_stats", self.handle, C.byref(st))
         return st
 
+    def data_table_v4(self) -> bytes:
+        """The (merged) intermediate results as DataTableImplV4 bytes (pg_result_data_table_v4)."""
+        size = C.c_int64(0)
+        self.api.call("result_data_table_v4", self.handle, None, 0, C.byref(size))
+        buf = (C.c_uint8 * max(size.value, 1))()
+        self.api.call("result_data_table_v4", self.handle, buf, size.value, C.byref(size))
+        return bytes(buf[:size.value])
+
     def free(self):
         if self.handle:
             self.api.call("result_free", self.handle)
