@@ -66,10 +66,25 @@ public class GpuGroupByCombineOperator extends GroupByCombineOperator {
   }
 
   private void foldInLibrary() {
+    int n = _segmentOperators.size();
+    long[] results = new long[n];
+    try {
+      foldInLibrary(results);
+    } catch (RuntimeException e) {   // cancelled (EarlyTerminationException) or failed midway: nothing native may outlive the query
+      for (int i = 0; i < n; i++) {
+        if (results[i] != 0) {
+          PinotGpu.resultFree(results[i]);
+          results[i] = 0;
+        }
+      }
+      throw e;
+    }
+  }
+
+  private void foldInLibrary(long[] results) {
     GpuInstancePlanMaker maker = GpuInstancePlanMaker.current();
     int n = _segmentOperators.size();
     GpuGroupByOperator[] ops = new GpuGroupByOperator[n];
-    long[] results = new long[n];
     for (int i = 0; i < n; i++) {
       ops[i] = (GpuGroupByOperator) _segmentOperators.get(i);
       results[i] = ops[i].execute();   // 0: refused at run time (hash bucket overflow) — that operator answers with its Java plan
