@@ -511,6 +511,28 @@ def test_wide_pipeline_sizes(gpu_api, oracle_api, n):
     o.destroy()
 
 
+@pytest.mark.parametrize("card", [300, 1000, 2000, 4000, 8000, 16000])
+def test_wide_pipeline_key_widths(gpu_api, oracle_api, card):
+    """Group columns of 9 .. 14 bits (three-dword windows, every misalignment of a quad's 4 x bits inside them); with a second, narrow
+    column in front and behind."""
+    rng = np.random.default_rng(card)
+    n = 50_021
+    data = {"k": rng.integers(0, card, n).astype(np.int32), "k2": rng.integers(0, 3, n).astype(np.int32),
+            "lm": rng.integers(-10**9, 10**9, n).astype(np.int64), "r": rng.integers(0, 1000, n).astype(np.int32)}
+    host = build_segment("wk", data, {"k": "INT", "k2": "INT", "lm": "LONG", "r": "INT"}, no_dictionary_columns=["lm", "r"])
+    g, o = both(gpu_api, oracle_api, host)
+    gb = g.execute("SELECT k, MAX(r) FROM wk GROUP BY k LIMIT 100000")
+    assert_same_block(gb, o.execute("SELECT k, MAX(r) FROM wk GROUP BY k LIMIT 100000"))
+    assert gb.stats.kernel.decode() == "pg_pipe_w32_none"
+    qs = ["SELECT k, MIN(r), MAX(r) FROM wk WHERE r BETWEEN 100 AND 899 GROUP BY k LIMIT 100000"]
+    if card <= 2000:
+        qs += ["SELECT k, k2, SUM(lm), COUNT(*) FROM wk GROUP BY k, k2 LIMIT 100000", "SELECT k2, k, MAX(lm) FROM wk WHERE r < 500 GROUP BY k2, k LIMIT 100000"]
+    for q in qs:
+        assert_same_block(g.execute(q), o.execute(q))
+    g.destroy()
+    o.destroy()
+
+
 def test_wide_pipeline_knob(gpu_api, oracle_api, monkeypatch):
     """PG_NO_PIPE_WIDE: the same plans on the 16-wavefront walk (pg_fast_none_w / pg_fast_multi_w), the A/B knob of the variants table."""
     monkeypatch.setenv("PG_NO_PIPE_WIDE", "1")
