@@ -17,6 +17,10 @@ PG_DECL_FAST(pg_fast_none_f) PG_DECL_FAST(pg_fast_none_a) PG_DECL_FAST(pg_fast_i
 PG_DECL_FAST(pg_fast_dictrange_f) PG_DECL_FAST(pg_fast_dictrange_a) PG_DECL_FAST(pg_fast_dictlut_f) PG_DECL_FAST(pg_fast_dictlut_a)
 PG_DECL_FAST(pg_fast_multi_f) PG_DECL_FAST(pg_fast_multi_a) PG_DECL_FAST(pg_fast_multi_w) PG_DECL_FAST(pg_fast_none_w)
 PG_DECL_FAST(pg_fast_i32range_d) PG_DECL_FAST(pg_fast_i32range_p) PG_DECL_FAST(pg_fast_i32range_fp)
+PG_DECL_FAST(pg_dense_count_1) PG_DECL_FAST(pg_dense_count_2) PG_DECL_FAST(pg_dense_count_3) PG_DECL_FAST(pg_dense_count_4)
+PG_DECL_FAST(pg_dense_count_5) PG_DECL_FAST(pg_dense_count_6) PG_DECL_FAST(pg_dense_count_7) PG_DECL_FAST(pg_dense_count_8)
+PG_DECL_FAST(pg_dict_count_1) PG_DECL_FAST(pg_dict_count_2) PG_DECL_FAST(pg_dict_count_3) PG_DECL_FAST(pg_dict_count_4)
+PG_DECL_FAST(pg_dict_count_5) PG_DECL_FAST(pg_dict_count_6) PG_DECL_FAST(pg_dict_count_7) PG_DECL_FAST(pg_dict_count_8)
 PG_DECL_FAST(pg_pipe_w0_none) PG_DECL_FAST(pg_pipe_w0_index) PG_DECL_FAST(pg_pipe_w0_scan) PG_DECL_FAST(pg_pipe_w0_index_scan)
 PG_DECL_FAST(pg_pipe_w32_none) PG_DECL_FAST(pg_pipe_w32_index) PG_DECL_FAST(pg_pipe_w32_scan) PG_DECL_FAST(pg_pipe_w32_index_scan)
 PG_DECL_FAST(pg_pipe_w64_none) PG_DECL_FAST(pg_pipe_w64_index) PG_DECL_FAST(pg_pipe_w64_scan) PG_DECL_FAST(pg_pipe_w64_index_scan)
@@ -1119,8 +1123,33 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
     hipLaunchKernelGGL(D.match_words ? pg_oct_lm : pg_oct_l, dim3(shape.grid), dim3(shape.block), shape.lds, ctx.stream, D);
     PG_HIP(hipGetLastError());
   } else if (has_docs) {
-    QueryKernel kern = select_kernel(P, D.agg_mode, &kname);
-    hipLaunchKernelGGL(kern, dim3(shape.grid), dim3(shape.block), shape.lds, ctx.stream, D);
+    // COUNT(*) behind an index-only filter of dense postings: the bitmap stream (pg_dense_count_*), not the tile walk
+    static const bool no_dense_count = getenv("PG_NO_DENSE_COUNT") != nullptr;   // A/B knob
+    int n_ptr = 0;   // distinct dense posting pointers (the planner pads the eight slots with repeats of slot 0)
+    for (int j = 0; j < 8; j++) if (j == 0 || D.dense_ptr[j] != D.dense_ptr[0] || D.dense_group[j] != D.dense_group[0]) n_ptr = j + 1;
+    if (!no_dense_count && D.agg_mode == PG_AGG_NONE && !D.out_words && !D.out_tile_counts && uses_fast_kernel(P, PG_AGG_NONE) && P.fast_filter == -1 &&
+        D.dense_fused && D.n_index_instr > 0 && !D.mv) {
+      static const QueryKernel kCount[8] = {pg_dense_count_1, pg_dense_count_2, pg_dense_count_3, pg_dense_count_4,
+                                            pg_dense_count_5, pg_dense_count_6, pg_dense_count_7, pg_dense_count_8};
+      const int64_t n_q = ((int64_t)D.num_docs + 127) >> 7;
+      static const int wgs_per_cu = getenv("PG_DENSE_COUNT_WGS") ? atoi(getenv("PG_DENSE_COUNT_WGS")) : 1;   // tuning knob
+      const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n_q + 2047) / 2048, (int64_t)num_cus() * std::max(wgs_per_cu, 1)));
+      kname = "pg_dense_count";
+      hipLaunchKernelGGL(kCount[n_ptr - 1], dim3(grid), dim3(1024), 0, ctx.stream, D);
+    } else if (!no_dense_count && D.agg_mode == PG_AGG_NONE && !D.out_words && !D.out_tile_counts && uses_fast_kernel(P, PG_AGG_NONE) &&
+               (P.fast_filter == 0 || P.fast_filter == 2) && D.n_index_instr == 0 && D.fast_scan_pushed && !D.mv) {
+      // COUNT(*) behind one scan of a <= 8-bit dictionary column over the whole segment: the bit stream, 32 docs per thread (pg_dict_count_*)
+      static const QueryKernel kDict[8] = {pg_dict_count_1, pg_dict_count_2, pg_dict_count_3, pg_dict_count_4,
+                                           pg_dict_count_5, pg_dict_count_6, pg_dict_count_7, pg_dict_count_8};
+      const int bits = std::min(std::max(P.fast_scan_bits, 1), 8);
+      const int64_t n_g = ((int64_t)D.num_docs + 31) >> 5;
+      const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n_g + 2047) / 2048, (int64_t)num_cus()));
+      kname = "pg_dict_count";
+      hipLaunchKernelGGL(kDict[bits - 1], dim3(grid), dim3(1024), 0, ctx.stream, D);
+    } else {
+      QueryKernel kern = select_kernel(P, D.agg_mode, &kname);
+      hipLaunchKernelGGL(kern, dim3(shape.grid), dim3(shape.block), shape.lds, ctx.stream, D);
+    }
     PG_HIP(hipGetLastError());
   }
   if (profile) PG_HIP(hipEventRecord(ctx.ev[1], ctx.stream));

@@ -275,6 +275,7 @@ struct CompiledPlan {
   // automaton of pg_filter_stats.cpp, which reproduces the reference's count exactly
   std::unique_ptr<FilterOp> root_op;
   std::vector<std::pair<const FilterOp*, std::shared_ptr<CompiledPlan>>> stat_leaves;
+  int32_t fast_scan_bits = 0;        // bits per value of the single scan leaf's column (pg_dict_count_* is chosen by it)
   bool always_empty = false;
   bool match_all = false;            // the filter is MatchAllFilterOperator: no filter pass in front of the partition pipeline
   int32_t n_projected_columns = 0;

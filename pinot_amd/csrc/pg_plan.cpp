@@ -1272,6 +1272,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
         P.fast_filter = k;
         D.n_index_instr = (int32_t)n_idx;
         D.fast_scan = em.instrs[n_idx].arg;
+        P.fast_scan_bits = em.scans[(size_t)D.fast_scan].bits;
         D.fast_scan_pushed = n_idx == 0 ? 1 : 0;
         D.n_fast_scans = 1;   // the chain kernels (pg_fast_multi_*) can run the single scan as well
       }

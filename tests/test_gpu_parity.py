@@ -455,6 +455,48 @@ def test_wide_aggregations_match_oracle(wide_seg, q):
     assert gb.stats.kernel.decode().startswith(("pg_fast_", "pg_pipe_w", "pg_generic_", "pg_radix_", "pg_part_"))
 
 
+# ---- COUNT(*) behind an index-only filter of dense postings: the bitmap stream (pg_dense_count_*) --------------------------------------
+@pytest.mark.parametrize("n", [151_072, 151_073, 151_103, 151_104, 151_105, 151_199, 151_200, 217_001])
+def test_dense_count_stream(gpu_api, oracle_api, n):
+    """FastFilteredCountOperator's shape over bitmap containers: IN / NOT IN / AND of two columns, every tail length of the last 128-doc
+    group; the last 2^16-doc chunk holds > 4096 docs per dictId so that its containers are bitmaps too (else the leaf is not 'dense')."""
+    rng = np.random.default_rng(n)
+    data = {"a": rng.integers(0, 4, n).astype(np.int32), "b": rng.integers(0, 3, n).astype(np.int32), "r": rng.integers(0, 100, n).astype(np.int32)}
+    host = build_segment("dc", data, {"a": "INT", "b": "INT", "r": "INT"}, inverted_index_columns=["a", "b"], no_dictionary_columns=["r"])
+    g, o = both(gpu_api, oracle_api, host)
+    for where, dense in (("a IN (0, 2)", True), ("a = 1", True), ("a NOT IN (3)", True), ("a IN (0, 1, 2) AND b = 1", True), ("a != 0 AND b != 2", True),
+                         ("a = 1 AND r < 50", False)):
+        q = f"SELECT COUNT(*) FROM dc WHERE {where}"
+        gb, ob = g.execute(q), o.execute(q)
+        assert_same_block(gb, ob)
+        assert gb.stats.num_entries_scanned_in_filter == ob.stats.num_entries_scanned_in_filter
+        assert (gb.stats.kernel.decode() == "pg_dense_count") == dense, (where, gb.stats.kernel)
+    g.destroy()
+    o.destroy()
+
+
+@pytest.mark.parametrize("card", [2, 3, 5, 12, 20, 50, 100, 200])
+def test_dict_count_stream(gpu_api, oracle_api, card):
+    """COUNT(*) behind ONE scan of a dictionary column of 1 .. 8 bits (no inverted index): the bit stream, 32 docs per thread — EQ / range /
+    IN / NOT IN, ragged tails, nothing matching."""
+    rng = np.random.default_rng(card)
+    for n in (1, 31, 32, 33, 2047, 70_001):
+        data = {"d": rng.integers(0, card, n).astype(np.int32) * 3, "r": rng.integers(0, 100, n).astype(np.int32)}
+        host = build_segment("dd", data, {"d": "INT", "r": "INT"}, no_dictionary_columns=["r"])
+        g, o = both(gpu_api, oracle_api, host)
+        top = 3 * (card - 1)
+        for where, stream in ((f"d = {top}", True), ("d BETWEEN 3 AND 30", True), (f"d IN (0, 6, {top})", True), (f"d NOT IN (3, {top})", True),
+                              ("d > 100000", True), ("d >= 3 AND r < 50", False)):
+            q = f"SELECT COUNT(*) FROM dd WHERE {where}"
+            gb, ob = g.execute(q), o.execute(q)
+            assert_same_block(gb, ob)
+            assert gb.stats.num_entries_scanned_in_filter == ob.stats.num_entries_scanned_in_filter, where
+            if n >= 2047 and 0 < gb.stats.num_docs_scanned < n:   # (a predicate no / every dictionary value satisfies never reaches a scan kernel)
+                assert (gb.stats.kernel.decode() == "pg_dict_count") == stream, (where, n, gb.stats.kernel)
+        g.destroy()
+        o.destroy()
+
+
 # ---- the wide pipeline (pg_pipe_w_*): raw LONG / INT values, group columns of up to 16 bits, behind no filter / dense index / range scan ----
 PIPE_WIDE_QUERIES = [
     ("SELECT k, SUM(lm), MIN(lm), MAX(lm), COUNT(*) FROM wide GROUP BY k LIMIT 5000", "pg_pipe_w64_none"),
