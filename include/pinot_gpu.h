@@ -199,6 +199,12 @@ typedef struct pg_query {
                                               AggregationFunction#extractFinalResult), not as the intermediate set / registers: for a caller that
                                               merges nothing afterwards (one segment, or after pg_result_merge / _all_reduce).  The states stay in
                                               HBM; two integers per group come back (3.3 MB of registers -> 200 KB on BASELINE config 5) */
+#define PG_QUERY_FLAG_NULL_HANDLING 0x40   /* QueryContext#isNullHandlingEnabled.  Taken when it cannot change the answer — no column the query reads
+                                              (filter, GROUP BY, aggregation arguments) holds a null in this segment, which is also when the reference
+                                              keeps its ordinary plan (AggregationPlanNode.java:104-121 hasNullValues, StarTreeUtils.java:381-400) — and
+                                              refused (PG_ERR_UNSUPPORTED: the Java plan answers) otherwise: null-aware filters (three-valued AND / OR /
+                                              NOT), null group keys and null-skipping aggregations are not on the GPU path.  An aggregation without
+                                              GROUP BY that matches no doc is refused as well: its SUM / MIN / MAX results would be null */
 #define PG_QUERY_FLAG_KEEP_DEVICE_TABLE 0x4 /* keep the dense accumulator table in HBM with the result (pg_result_merge / _all_reduce) */
 
 /* ExecutionStatistics (pinot-core/.../operator/ExecutionStatistics.java) + device timings. */

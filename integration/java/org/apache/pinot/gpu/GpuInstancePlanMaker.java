@@ -71,8 +71,9 @@ public class GpuInstancePlanMaker extends InstancePlanMakerImplV2 {
   @Override
   public PlanNode makeSegmentPlanNode(SegmentContext segmentContext, QueryContext queryContext) {
     IndexSegment segment = segmentContext.getIndexSegment();
-    if (segment instanceof ImmutableSegment && QueryContextUtils.isAggregationQuery(queryContext)
-        && !queryContext.isNullHandlingEnabled()) {
+    // (enableNullHandling travels in the query record: the library takes the query when none of its columns holds a null in this
+    // segment — the case in which AggregationPlanNode keeps its ordinary plan, AggregationPlanNode.java:104-121 — and refuses otherwise)
+    if (segment instanceof ImmutableSegment && QueryContextUtils.isAggregationQuery(queryContext)) {
       long handle = _registry.handleFor((ImmutableSegment) segment, segmentContext);   // pins the columns in HBM on first use; 0: Java plan only
       if (handle != 0) {
         // with the library merge configured the group-by tables stay in HBM for GpuGroupByCombineOperator (PinotGpu.resultMerge /

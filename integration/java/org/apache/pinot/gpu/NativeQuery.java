@@ -29,6 +29,8 @@ public final class NativeQuery implements AutoCloseable {
   private static final int F_AND = 0, F_OR = 1, F_NOT = 2, F_PREDICATE = 3, F_TRUE = 4, F_FALSE = 5;
   private static final int P_EQ = 0, P_NOT_EQ = 1, P_IN = 2, P_NOT_IN = 3, P_RANGE = 4, P_IS_NULL = 5, P_IS_NOT_NULL = 6;
   private static final int FLAG_SKIP_STAR_TREE = 0x2;
+  // PG_QUERY_FLAG_NULL_HANDLING: pg_query_supported refuses unless no column the query reads holds a null in the segment
+  private static final int FLAG_NULL_HANDLING = 0x40;
 
   private final long _address;
 
@@ -57,7 +59,7 @@ public final class NativeQuery implements AutoCloseable {
     if (aggs == null || aggs.length == 0) {
       return null;
     }
-    b.putInt(MAGIC).putInt((q.isSkipStarTree() ? FLAG_SKIP_STAR_TREE : 0) | extraFlags).putInt(q.getNumGroupsLimit())
+    b.putInt(MAGIC).putInt((q.isSkipStarTree() ? FLAG_SKIP_STAR_TREE : 0) | (q.isNullHandlingEnabled() ? FLAG_NULL_HANDLING : 0) | extraFlags).putInt(q.getNumGroupsLimit())
         .putInt(q.getMaxInitialResultHolderCapacity()).putInt(groupBy == null ? 0 : groupBy.size()).putInt(aggs.length)
         .putInt(q.getFilter() == null ? 0 : 1).putInt(0);
     if (groupBy != null) {

@@ -73,7 +73,7 @@ public final class PinotGpu {
   // GroupByCombineOperator in the library: results executed with QUERY_FLAG_KEEP_DEVICE_TABLE over segments that share their
   // dictionaries merge element-wise in HBM; UnsupportedOperationException -> merge by values (IndexedTable) as usual
   public static final int QUERY_FLAG_SKIP_STAR_TREE = 0x2, QUERY_FLAG_KEEP_DEVICE_TABLE = 0x4, QUERY_FLAG_APPROX_FILTER_STATS = 0x8,
-      QUERY_FLAG_EXACT_FILTER_STATS = 0x10;
+      QUERY_FLAG_EXACT_FILTER_STATS = 0x10, QUERY_FLAG_FINAL_DISTINCT = 0x20, QUERY_FLAG_NULL_HANDLING = 0x40;
   public static final int COMM_UNIQUE_ID_BYTES = 128;
   public static native void resultMerge(long dst, long src);                 // same device
   public static native void resultAllReduce(long result, long comm);         // collective over the communicator's ranks (RCCL)

@@ -1061,7 +1061,34 @@ static double now_ms(void) {
   return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
-int32_t po_query_supported(void* seg, const pg_query* q) { (void)seg; (void)q; return PG_OK; }
+int32_t po_result_free(void* r);
+/* PG_QUERY_FLAG_NULL_HANDLING (QueryContext#isNullHandlingEnabled): this restatement covers the case in which null handling cannot change
+ * the answer — no column the query reads holds a null in the segment, which is when the reference keeps its ordinary plan
+ * (AggregationPlanNode.java:104-121 hasNullValues, StarTreeUtils.java:381-400) — and refuses the rest like the product path does: null-aware
+ * filters, null group keys and null-skipping aggregations are restated nowhere in this repository. */
+static int null_check_column(po_segment* seg, const char* name) {
+  if (!name || !strcmp(name, "*")) return 0;
+  po_column* c = po_segment_column(seg, name);
+  if (c && c->null_bitmap && po_bitmap_cardinality(c->null_bitmap) > 0) {
+    po_set_error("enableNullHandling over column %s, which holds nulls in this segment", name);
+    return 1;
+  }
+  return 0;
+}
+static int null_check_filter(po_segment* seg, const pg_filter_node* f) {
+  if (!f) return 0;
+  if (f->type == PG_FILTER_PREDICATE) return null_check_column(seg, f->column);
+  for (int i = 0; i < f->n_children; i++) if (null_check_filter(seg, &f->children[i])) return 1;
+  return 0;
+}
+static int null_handling_refused(po_segment* seg, const pg_query* q) {
+  if (!(q->flags & PG_QUERY_FLAG_NULL_HANDLING)) return 0;
+  if (null_check_filter(seg, q->filter)) return 1;
+  for (int i = 0; i < q->n_group_by; i++) if (null_check_column(seg, q->group_by_columns[i])) return 1;
+  for (int i = 0; i < q->n_aggregations; i++) if (null_check_column(seg, q->aggregations[i].column)) return 1;
+  return 0;
+}
+int32_t po_query_supported(void* seg, const pg_query* q) { return null_handling_refused((po_segment*)seg, q) ? PG_ERR_UNSUPPORTED : PG_OK; }
 
 int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
   double t0 = now_ms();
@@ -1071,6 +1098,7 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
                                                                    : DEFAULT_MAX_INITIAL_RESULT_HOLDER_CAPACITY;
   int n_aggs = q->n_aggregations, n_gb = q->n_group_by;
   if (n_aggs <= 0) { po_set_error("query has no aggregation"); return PG_ERR_INVALID_ARGUMENT; }
+  if (null_handling_refused(seg, q)) return PG_ERR_UNSUPPORTED;
 
   po_filter_op* filter_op = po_filter_plan(seg, q->filter);
   if (!filter_op) return PG_ERR_INVALID_ARGUMENT;
@@ -1380,6 +1408,12 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
   res->stats.num_entries_scanned_post_filter = num_docs_scanned * n_proj;
   if (n_gb > 0) res->stats.num_groups_limit_reached = gkg_num_keys(&gkg) >= num_groups_limit;
   res->stats.host_ms_total = (float)(now_ms() - t0);
+  if ((q->flags & PG_QUERY_FLAG_NULL_HANDLING) && n_gb == 0 && num_docs_scanned == 0) {
+    /* AggregationOperator under null handling over no doc: SUM / MIN / MAX extract null — not restated (see null_handling_refused) */
+    po_result_free(res);
+    po_set_error("enableNullHandling: no doc matches — the aggregations' results are null");
+    return PG_ERR_UNSUPPORTED;
+  }
   *out = res;
   return PG_OK;
 }

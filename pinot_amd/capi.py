@@ -47,6 +47,7 @@ QUERY_FLAG_KEEP_DEVICE_TABLE = 0x4
 QUERY_FLAG_APPROX_FILTER_STATS = 0x8
 QUERY_FLAG_EXACT_FILTER_STATS = 0x10
 QUERY_FLAG_FINAL_DISTINCT = 0x20
+QUERY_FLAG_NULL_HANDLING = 0x40
 COMM_UNIQUE_ID_BYTES = 128
 GROUP_KEY_DICT_IDS, GROUP_KEY_LONG_VALUES, GROUP_KEY_DOUBLE_VALUES, GROUP_KEY_BYTES_VALUES = 0, 1, 2, 3
 

@@ -179,6 +179,7 @@ int32_t pg_query_supported(pg_segment_t segment, const pg_query* query) {
     use_device(segment->seg.device);
     // compiled under the segment's lock and cached: the pg_query_exec that follows finds the plan (PlanMaker calls supported()
     // then exec() from many worker threads); throws PG_ERR_UNSUPPORTED for shapes off the GPU path
+    check_null_handling(segment->seg, *query);
     (void)get_plan(segment->seg, query->filter, query);
   });
 }

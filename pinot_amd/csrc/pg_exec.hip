@@ -768,6 +768,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
   if (q.n_aggregations <= 0 || !q.aggregations) fail(PG_ERR_INVALID_ARGUMENT, "query has no aggregation");
   check_cancel(cancel, nullptr);
   ThreadCtx& ctx = ctx_on(seg.device);
+  check_null_handling(seg, q);
   auto plan = get_plan(seg, q.filter, &q);
   CompiledPlan& P = *plan;
   const double t_plan = now_ms();
@@ -1282,6 +1283,8 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
     H.full_scan_entries = exact_entries;
     for (int i = 1; i < PG_MAX_STATS; i++) H.stats[i] = 0;
   }
+  if ((q.flags & PG_QUERY_FLAG_NULL_HANDLING) && q.n_group_by == 0 && H.stats[0] == 0)
+    fail(PG_ERR_UNSUPPORTED, "enableNullHandling: no doc matches — the aggregations' results are null (the Java plan answers)");
   const double t_before_assembly = now_ms();
   assemble_result(*res, P, q.n_group_by, q.n_aggregations, H);
   {   // the columns' names, types and host dictionaries, for pg_result_data_table_v4

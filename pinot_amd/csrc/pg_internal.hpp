@@ -394,6 +394,7 @@ void use_device(int ordinal);           // makes `ordinal` current on the callin
 std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const CancelToken* cancel);
 void result_merge(Result& dst, Result& src);
 std::vector<uint8_t> result_data_table_v4(const Result& r);   // pg_datatable.cpp
+void check_null_handling(Segment& seg, const pg_query& q);     // pg_plan.cpp: PG_QUERY_FLAG_NULL_HANDLING
 // RCCL (pg_comm.cpp)
 struct Comm;
 void comm_unique_id(void* out128);

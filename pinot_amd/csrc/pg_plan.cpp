@@ -719,6 +719,29 @@ static void sig_filter(std::ostringstream& o, const pg_filter_node* f) {
   for (int i = 0; i < f->n_children && f->children; i++) sig_filter(o, &f->children[i]);
   o << ")";
 }
+// PG_QUERY_FLAG_NULL_HANDLING: refuse unless no column the query reads holds a null in this segment (then null handling cannot change
+// the answer and the reference itself keeps its ordinary plan: AggregationPlanNode.java:104-121, StarTreeUtils.java:381-400)
+static void null_check_column(Segment& seg, const char* name) {
+  if (!name || !strcmp(name, "*")) return;
+  auto it = seg.null_vectors.find(name);
+  if (it == seg.null_vectors.end() || !it->second) return;
+  const Column& nv = *it->second;
+  if (!nv.posting_card.empty() && nv.posting_card[0] > 0)
+    fail(PG_ERR_UNSUPPORTED, "enableNullHandling over column %s, which holds %lld nulls in this segment", name, (long long)nv.posting_card[0]);
+}
+static void null_check_filter(Segment& seg, const pg_filter_node* f) {
+  if (!f) return;
+  if (f->type == PG_FILTER_PREDICATE) { null_check_column(seg, f->column); return; }
+  for (int i = 0; i < f->n_children; i++) null_check_filter(seg, &f->children[i]);
+}
+void check_null_handling(Segment& seg, const pg_query& q) {
+  if (!(q.flags & PG_QUERY_FLAG_NULL_HANDLING)) return;
+  std::lock_guard<std::mutex> g(seg.mu);
+  null_check_filter(seg, q.filter);
+  for (int i = 0; i < q.n_group_by; i++) null_check_column(seg, q.group_by_columns[i]);
+  for (int i = 0; i < q.n_aggregations; i++) null_check_column(seg, q.aggregations[i].column);
+}
+
 std::string query_signature(const pg_filter_node* filter, const pg_query* q) {
   std::ostringstream o;
   sig_filter(o, filter);
