@@ -79,7 +79,13 @@ typedef enum pg_fwd_encoding {
    * V4 / V5 chunk formats (VarByteChunkForwardIndexReaderV4) and SNAPPY are refused with PG_ERR_UNSUPPORTED.  The column answers
    * multi-value filters, GROUP BY keys and the *MV aggregations exactly like its dictionary-encoded twin would
    * (MultiValueRawQueriesTest asserts that equality query by query); DISTINCTCOUNTMV over it stays with the Java plan. */
-  PG_FWD_RAW_MV_FIXED_BYTE_CHUNK = 5
+  PG_FWD_RAW_MV_FIXED_BYTE_CHUNK = 5,
+  /* VarByteChunkMVForwardIndexReader (raw multi-value STRING column, writer versions 2 and 3 —
+   * .../readers/forward/VarByteChunkMVForwardIndexReader.java, written by MultiValueVarByteRawIndexCreator): the same var-byte chunk layout;
+   * the value of doc d is ArraySerDeUtils.serializeStringArray (.../utils/ArraySerDeUtils.java:282-292): big-endian int numValues, numValues
+   * big-endian int lengths, then the UTF-8 bytes.  Handled like encoding 5 (a dictionary-encoded twin built at registration, group keys back
+   * as byte strings: PG_GROUP_KEY_BYTES_VALUES); raw multi-value BYTES columns are refused. */
+  PG_FWD_RAW_MV_VAR_BYTE_CHUNK = 6
 } pg_fwd_encoding;
 
 typedef struct pg_buffer {

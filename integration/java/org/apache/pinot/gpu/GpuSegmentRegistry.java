@@ -63,8 +63,8 @@ public final class GpuSegmentRegistry {
     try (SegmentDirectory.Reader reader = GpuBuffers.readerOf(segment)) {
       for (String column : segment.getPhysicalColumnNames()) {
         ColumnMetadata md = segment.getSegmentMetadata().getColumnMetadataFor(column);
-        if (!md.isSingleValue() && !md.hasDictionary() && !md.getDataType().getStoredType().isFixedWidth()) {
-          continue;   // raw multi-value STRING / BYTES columns stay with the Java plan: a query touching one is refused (unknown column)
+        if (!md.isSingleValue() && !md.hasDictionary() && md.getDataType().getStoredType().name().equals("BYTES")) {
+          continue;   // raw multi-value BYTES columns stay with the Java plan: a query touching one is refused (unknown column)
         }
         PinotDataBuffer fwd = reader.getIndexFor(column, StandardIndexes.forward());
         PinotDataBuffer dict = md.hasDictionary() ? reader.getIndexFor(column, StandardIndexes.dictionary()) : null;
@@ -74,7 +74,8 @@ public final class GpuSegmentRegistry {
         boolean varByte = !md.hasDictionary() && !md.getDataType().getStoredType().isFixedWidth();
         // 5 = FixedByteChunkMVForwardIndexReader (raw multi-value INT / LONG / FLOAT / DOUBLE, ForwardIndexReaderFactory.java:104-108):
         // read once at registration into a dictionary-encoded twin (pg_segment.cpp), group keys come back as values
-        int fwdEncoding = !md.isSingleValue() ? (md.hasDictionary() ? 3 : 5)
+        // 6 = VarByteChunkMVForwardIndexReader (raw multi-value STRING), read the same way
+        int fwdEncoding = !md.isSingleValue() ? (md.hasDictionary() ? 3 : md.getDataType().getStoredType().isFixedWidth() ? 5 : 6)
             : md.isSorted() && md.hasDictionary() ? 2 : md.hasDictionary() ? 0 : varByte ? 4 : 1;
         try {
           PinotGpu.segmentAddColumn(h, column, GpuBuffers.storedType(md), fwdEncoding, md.hasDictionary(), md.getCardinality(),

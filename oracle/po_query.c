@@ -69,8 +69,8 @@ int32_t po_segment_add_column(void* segp, const pg_column_desc* d) {
   c->inv_len = d->inverted_index.size;
   c->num_docs = seg->total_docs;
   if ((c->fwd_encoding == PG_FWD_RAW_FIXED_BYTE_CHUNK || c->fwd_encoding == PG_FWD_RAW_VAR_BYTE_CHUNK) && po_raw_parse_header(c)) return PG_ERR_UNSUPPORTED;
-  if (c->fwd_encoding == PG_FWD_RAW_MV_FIXED_BYTE_CHUNK) {   /* FixedByteChunkMVForwardIndexReader: po_readers.c */
-    if (po_raw_mv_attach(c)) return PG_ERR_INVALID_ARGUMENT;
+  if (c->fwd_encoding == PG_FWD_RAW_MV_FIXED_BYTE_CHUNK || c->fwd_encoding == PG_FWD_RAW_MV_VAR_BYTE_CHUNK) {   /* FixedByteChunkMV / VarByteChunkMV readers: po_readers.c */
+    if (c->fwd_encoding == PG_FWD_RAW_MV_VAR_BYTE_CHUNK ? po_raw_mv_attach_strings(c) : po_raw_mv_attach(c)) return PG_ERR_INVALID_ARGUMENT;
     if (d->total_number_of_entries > 0 && d->total_number_of_entries != c->total_entries) {
       po_set_error("raw multi-value index of %s holds %d entries, the metadata says %d", c->name, c->total_entries, d->total_number_of_entries);
       return PG_ERR_INVALID_ARGUMENT;

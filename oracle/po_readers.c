@@ -365,6 +365,95 @@ int po_raw_mv_attach(po_column* c) {
   return po_mv_parse(c);
 }
 
+/* VarByteChunkMVForwardIndexReader over STRING values (.../readers/forward/VarByteChunkMVForwardIndexReader.java; getStringMV =
+ * ArraySerDeUtils.deserializeStringArray, .../utils/ArraySerDeUtils.java:282-307: int numValues, numValues int lengths, the UTF-8 bytes): the
+ * column is read once into a dictionary-encoded twin like the fixed-width form above — distinct strings in byte order as a zero-padded
+ * fixed-width dictionary, ids in FixedBitMVForwardIndexReader's layout.  Group keys are reported as ids of that dictionary (the tests
+ * decode them through the host model's sorted distinct values). */
+typedef struct { const uint8_t* p; int32_t len; } po_str;
+static int cmp_str(const void* a, const void* b) {
+  const po_str* x = (const po_str*)a; const po_str* y = (const po_str*)b;
+  const int32_t n = x->len < y->len ? x->len : y->len;
+  const int c = n ? memcmp(x->p, y->p, (size_t)n) : 0;
+  return c ? c : (x->len < y->len ? -1 : (x->len > y->len ? 1 : 0));
+}
+int po_raw_mv_attach_strings(po_column* c) {
+  if (c->has_dictionary || c->data_type != PG_TYPE_STRING) { po_set_error("column %s: raw multi-value var-byte index of a dictionary / non-STRING column", c->name); return -1; }
+  if (po_raw_parse_header(c)) return -1;
+  const int32_t n_docs = c->num_docs;
+  if (n_docs <= 0) { po_set_error("raw multi-value column %s of %d docs", c->name, n_docs); return -1; }
+  int64_t total = 0;
+  int32_t* starts = (int32_t*)po_xcalloc((size_t)n_docs + 1, sizeof(int32_t));
+  for (int32_t d = 0; d < n_docs; d++) {
+    int32_t len = 0;
+    const uint8_t* v = po_raw_get_bytes(c, d, &len);
+    const int64_t n = len >= 4 ? (int64_t)(int32_t)po_be32(v) : 0;
+    if (n <= 0 || 4 + n * 4 > len) { free(starts); po_set_error("raw multi-value index of %s: doc %d: %lld values in %d bytes", c->name, d, (long long)n, len); return -1; }
+    starts[d] = (int32_t)total;
+    total += n;
+  }
+  starts[n_docs] = (int32_t)total;
+  po_str* vals = (po_str*)po_xcalloc((size_t)total, sizeof(po_str));
+  for (int32_t d = 0; d < n_docs; d++) {
+    int32_t len = 0;
+    const uint8_t* v = po_raw_get_bytes(c, d, &len);
+    const int32_t n = starts[d + 1] - starts[d];
+    int64_t at = 4 + (int64_t)n * 4;
+    for (int32_t i = 0; i < n; i++) {
+      const int32_t l = (int32_t)po_be32(v + 4 + (int64_t)i * 4);
+      if (l < 0 || at + l > len) { free(vals); free(starts); po_set_error("raw multi-value index of %s: doc %d: value lengths beyond %d bytes", c->name, d, len); return -1; }
+      vals[starts[d] + i].p = v + at;
+      vals[starts[d] + i].len = l;
+      at += l;
+    }
+  }
+  po_str* sorted = (po_str*)po_xcalloc((size_t)total, sizeof(po_str));
+  memcpy(sorted, vals, (size_t)total * sizeof(po_str));
+  qsort(sorted, (size_t)total, sizeof(po_str), cmp_str);
+  int64_t card = 0;
+  int32_t width = 1;
+  for (int64_t i = 0; i < total; i++) if (i == 0 || cmp_str(&sorted[i], &sorted[card - 1]) != 0) sorted[card++] = sorted[i];
+  for (int64_t i = 0; i < card; i++) if (sorted[i].len > width) width = sorted[i].len;
+  int bits = 1;
+  while (bits < 31 && ((int64_t)1 << bits) < card) bits++;
+  uint8_t* dict = (uint8_t*)po_xcalloc((size_t)card * (size_t)width + 8, 1);
+  for (int64_t i = 0; i < card; i++) memcpy(dict + i * width, sorted[i].p, (size_t)sorted[i].len);
+  const int64_t per_chunk = (int64_t)ceilf((float)2048 / (float)(total / n_docs));
+  const int64_t num_chunks = ((int64_t)n_docs + per_chunk - 1) / per_chunk;
+  const int64_t bitmap_size = (total + 7) / 8, raw_size = (total * bits + 7) / 8;
+  uint8_t* fwd = (uint8_t*)po_xcalloc((size_t)(num_chunks * 4 + bitmap_size + raw_size + 8), 1);
+  for (int64_t ch = 0; ch < num_chunks; ch++) {
+    const uint32_t o = (uint32_t)starts[ch * per_chunk];
+    fwd[ch * 4] = (uint8_t)(o >> 24); fwd[ch * 4 + 1] = (uint8_t)(o >> 16); fwd[ch * 4 + 2] = (uint8_t)(o >> 8); fwd[ch * 4 + 3] = (uint8_t)o;
+  }
+  uint8_t* bm = fwd + num_chunks * 4;
+  for (int32_t d = 0; d < n_docs; d++) bm[starts[d] >> 3] |= (uint8_t)(0x80u >> (starts[d] & 7));
+  uint8_t* packed = bm + bitmap_size;
+  for (int64_t e = 0; e < total; e++) {
+    int64_t lo = 0, hi = card - 1;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (cmp_str(&sorted[mid], &vals[e]) < 0) lo = mid + 1; else hi = mid; }
+    const uint32_t id = (uint32_t)lo;
+    const int64_t bit0 = e * bits;
+    for (int b = 0; b < bits; b++)
+      if ((id >> (bits - 1 - b)) & 1u) packed[(bit0 + b) >> 3] |= (uint8_t)(0x80u >> ((bit0 + b) & 7));
+  }
+  free(vals); free(sorted); free(starts);
+  c->raw_mv = 1;
+  c->mv_owned_fwd = fwd;
+  c->mv_owned_dict = dict;
+  c->has_dictionary = 1;
+  c->cardinality = (int32_t)card;
+  c->bits_per_value = bits;
+  c->dict_bytes_per_value = width;
+  c->dict = dict;
+  c->dict_len = (uint64_t)card * (uint64_t)width;
+  c->fwd = fwd;
+  c->fwd_len = (uint64_t)(num_chunks * 4 + bitmap_size + raw_size);
+  c->fwd_encoding = PG_FWD_DICT_FIXED_BIT_MV;
+  c->total_entries = (int32_t)total;
+  return po_mv_parse(c);
+}
+
 /* ---- SortedIndexReaderImpl, pinot-segment-local/.../readers/sorted/SortedIndexReaderImpl.java:35-110 ----------------- */
 void po_sorted_get_doc_ids(const po_column* c, int32_t dict_id, int32_t* start, int32_t* end) {
   *start = (int32_t)po_be32(c->fwd + (int64_t)dict_id * 8);

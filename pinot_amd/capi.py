@@ -31,6 +31,7 @@ FWD_DICT_SORTED = 2
 FWD_DICT_FIXED_BIT_MV = 3
 FWD_RAW_VAR_BYTE_CHUNK = 4
 FWD_RAW_MV_FIXED_BYTE_CHUNK = 5
+FWD_RAW_MV_VAR_BYTE_CHUNK = 6
 
 FILTER_AND, FILTER_OR, FILTER_NOT, FILTER_PREDICATE, FILTER_CONSTANT_TRUE, FILTER_CONSTANT_FALSE = range(6)
 PRED_EQ, PRED_NOT_EQ, PRED_IN, PRED_NOT_IN, PRED_RANGE, PRED_IS_NULL, PRED_IS_NOT_NULL = range(7)

@@ -535,6 +535,104 @@ void segment_add_column(Segment& seg, const pg_column_desc& d) {
     c.vb_offsets_dev = upload_vector(off);
     c.col_kind = PG_COL_VAR_BYTES;
     c.fwd_bytes_logical = fwd_len;
+  } else if (c.fwd_encoding == PG_FWD_RAW_MV_VAR_BYTE_CHUNK) {
+    // VarByteChunkMVForwardIndexReader over STRING values: doc d's value = ArraySerDeUtils.serializeStringArray — int numValues, numValues
+    // int lengths, the UTF-8 bytes.  As for the fixed-width form below the column becomes a dictionary-encoded multi-value column once, here:
+    // the distinct strings in byte order as a fixed-width, zero-padded STRING dictionary (what SegmentDictionaryCreator writes), ids in
+    // FixedBitMVForwardIndexReader's layout; group keys go back as the byte strings (virtual dictionary kind 4).
+    if (c.has_dictionary || c.data_type != PG_TYPE_STRING)
+      fail(PG_ERR_UNSUPPORTED, "column %s: a raw multi-value var-byte forward index is taken for no-dictionary STRING columns only", d.name);
+    const int64_t num_docs = seg.total_docs;
+    std::vector<int32_t> starts;
+    std::vector<std::string> vals;   // all entries, docs back to back
+    walk_var_byte_chunks(seg, fwd, fwd_len, d.name, false, [&](int64_t doc, const uint8_t* p, uint64_t len) {
+      (void)doc;
+      if (len < 4) fail(PG_ERR_INVALID_ARGUMENT, "raw multi-value index of %s: a value of %llu bytes", d.name, (unsigned long long)len);
+      const uint32_t n = be32(p);
+      if (n == 0 || 4 + (uint64_t)n * 4 > len) fail(PG_ERR_INVALID_ARGUMENT, "raw multi-value index of %s: %u values in %llu bytes", d.name, n, (unsigned long long)len);
+      if (vals.size() + n > 0x7FFFFFFFu) fail(PG_ERR_UNSUPPORTED, "raw multi-value index of %s: more than 2^31 entries", d.name);
+      starts.push_back((int32_t)vals.size());
+      uint64_t at = 4 + (uint64_t)n * 4;
+      for (uint32_t i = 0; i < n; i++) {
+        const uint64_t l = be32(p + 4 + (size_t)i * 4);
+        if (at + l > len) fail(PG_ERR_INVALID_ARGUMENT, "raw multi-value index of %s: value lengths beyond the doc's %llu bytes", d.name, (unsigned long long)len);
+        vals.emplace_back(reinterpret_cast<const char*>(p + at), (size_t)l);
+        at += l;
+      }
+      if (at != len) fail(PG_ERR_INVALID_ARGUMENT, "raw multi-value index of %s: %llu bytes used of %llu", d.name, (unsigned long long)at, (unsigned long long)len);
+    });
+    if ((int64_t)starts.size() != num_docs || num_docs <= 0) fail(PG_ERR_INVALID_ARGUMENT, "raw multi-value index of %s: %zu docs, the segment has %lld", d.name, starts.size(), (long long)num_docs);
+    if (d.total_number_of_entries > 0 && (int64_t)vals.size() != (int64_t)d.total_number_of_entries)
+      fail(PG_ERR_INVALID_ARGUMENT, "raw multi-value index of %s holds %zu entries, the metadata says %d", d.name, vals.size(), d.total_number_of_entries);
+    std::vector<std::string> distinct(vals);
+    std::sort(distinct.begin(), distinct.end());
+    distinct.erase(std::unique(distinct.begin(), distinct.end()), distinct.end());
+    const int32_t card = (int32_t)distinct.size();
+    int bits = 1;
+    while (bits < 31 && ((int64_t)1 << bits) < (int64_t)card) bits++;
+    size_t width = 1;
+    for (const std::string& v : distinct) {
+      width = std::max(width, v.size());
+      if (!v.empty() && v.back() == '\0') fail(PG_ERR_UNSUPPORTED, "column %s: a value ending in a zero byte cannot live in a padded dictionary", d.name);
+    }
+    std::vector<uint8_t> dict((size_t)card * width, 0);
+    std::vector<uint8_t> vbytes;
+    std::vector<int64_t> voff((size_t)card + 1, 0);
+    for (int32_t i = 0; i < card; i++) {
+      memcpy(dict.data() + (size_t)i * width, distinct[(size_t)i].data(), distinct[(size_t)i].size());
+      vbytes.insert(vbytes.end(), distinct[(size_t)i].begin(), distinct[(size_t)i].end());
+      voff[(size_t)i + 1] = (int64_t)vbytes.size();
+    }
+    const int64_t num_values = (int64_t)vals.size();
+    const int64_t per_chunk = (int64_t)std::ceil((float)2048 / (float)(num_values / num_docs));
+    const int64_t num_chunks = (num_docs + per_chunk - 1) / per_chunk;
+    const uint64_t bitmap_bytes = ((uint64_t)num_values + 7) / 8, raw_bytes = ((uint64_t)num_values * (uint64_t)bits + 7) / 8;
+    std::vector<uint8_t> twin((size_t)num_chunks * 4 + bitmap_bytes + raw_bytes, 0);
+    for (int64_t ch = 0; ch < num_chunks; ch++) {
+      const uint32_t o = (uint32_t)starts[(size_t)(ch * per_chunk)];
+      twin[(size_t)ch * 4] = (uint8_t)(o >> 24); twin[(size_t)ch * 4 + 1] = (uint8_t)(o >> 16); twin[(size_t)ch * 4 + 2] = (uint8_t)(o >> 8); twin[(size_t)ch * 4 + 3] = (uint8_t)o;
+    }
+    uint8_t* bm = twin.data() + (size_t)num_chunks * 4;
+    for (int64_t dd = 0; dd < num_docs; dd++) { const int64_t pos = starts[(size_t)dd]; bm[pos >> 3] |= (uint8_t)(0x80u >> (pos & 7)); }
+    uint8_t* packed = bm + bitmap_bytes;
+    for (int64_t e = 0; e < num_values; e++) {
+      const uint32_t id = (uint32_t)(std::lower_bound(distinct.begin(), distinct.end(), vals[(size_t)e]) - distinct.begin());
+      const int64_t bit0 = e * bits;
+      for (int b = 0; b < bits; b++)
+        if ((id >> (bits - 1 - b)) & 1u) packed[(bit0 + b) >> 3] |= (uint8_t)(0x80u >> ((bit0 + b) & 7));
+    }
+    const std::string twin_name = std::string(d.name) + "$ids";
+    pg_column_desc td{};
+    td.name = twin_name.c_str();
+    td.data_type = PG_TYPE_STRING;
+    td.fwd_encoding = PG_FWD_DICT_FIXED_BIT_MV;
+    td.has_dictionary = 1;
+    td.cardinality = card;
+    td.bits_per_value = bits;
+    td.is_sorted = 0;
+    td.dict_bytes_per_value = (int32_t)width;
+    td.total_number_of_entries = (int32_t)num_values;
+    td.forward_index.addr = twin.data();
+    td.forward_index.size = twin.size();
+    td.dictionary.addr = dict.data();
+    td.dictionary.size = dict.size();
+    segment_add_column(seg, td);   // (the caller holds the segment's lock: pg_segment_add_column)
+    {
+      auto it = seg.columns.find(twin_name);
+      c.vdict = std::move(it->second);
+      seg.columns.erase(it);
+    }
+    c.vdict->vdict_kind = 4;
+    c.vdict->vdict_bytes = std::move(vbytes);
+    c.vdict->vdict_bytes_off = std::move(voff);
+    c.vdict->vdict_hash = c.vdict->dict_hash;
+    c.vdict->public_col = &c;
+    c.raw_mv = true;
+    c.is_mv = true;
+    c.total_entries = (int32_t)num_values;
+    c.max_entries_per_doc = c.vdict->max_entries_per_doc;
+    c.fwd_bytes_logical = fwd_len;
+    c.vdict->fwd_bytes_logical = fwd_len;
   } else if (c.fwd_encoding == PG_FWD_RAW_MV_FIXED_BYTE_CHUNK) {
     // FixedByteChunkMVForwardIndexReader: doc d's value = ArraySerDeUtils.serialize…ArrayWithLength: big-endian int numValues, then the
     // values big-endian.  The column becomes a dictionary-encoded multi-value column here, once: sorted distinct values (what the segment

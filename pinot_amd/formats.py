@@ -503,6 +503,17 @@ def write_raw_mv_fixed_byte_chunk(rows: Sequence[Sequence], data_type: str, vers
     return np.frombuffer(header + off_bytes + b"".join(chunks), dtype=np.uint8)
 
 
+def write_raw_mv_var_byte_chunk(rows: Sequence[Sequence[str]], version: int = 2, docs_per_chunk: int = 1000) -> np.ndarray:
+    """Raw (no-dictionary) multi-value STRING forward index: MultiValueVarByteRawIndexCreator -> VarByteChunkForwardIndexWriter#putStringMV: the
+    var-byte chunk layout whose value of a doc is ArraySerDeUtils.serializeStringArray (.../utils/ArraySerDeUtils.java:282-292) = int numValues,
+    numValues int lengths, the UTF-8 bytes."""
+    values = []
+    for r in rows:
+        enc = [v.encode("utf-8") for v in r]
+        values.append(struct.pack(">i", len(enc)) + b"".join(struct.pack(">i", len(e)) for e in enc) + b"".join(enc))
+    return write_raw_var_byte_chunk(values, version=version, docs_per_chunk=docs_per_chunk, longest_entry=max(len(v) for v in values))
+
+
 def read_raw_var_byte_chunk(buf: np.ndarray) -> List[bytes]:
     """Check reader: VarByteChunkSVForwardIndexReader#getBytesUncompressed for every docId."""
     h = parse_raw_fixed_byte_chunk_header(buf)

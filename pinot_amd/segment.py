@@ -132,6 +132,13 @@ def build_raw_mv_column(name: str, rows: Sequence[Sequence], data_type: str, *, 
     """A raw (no-dictionary) multi-value column of INT / LONG / FLOAT / DOUBLE (MultiValueFixedByteRawIndexCreator); an empty row takes
     the default null value like the segment creator does.  `dict_values` (sorted distinct values) serves the CHECK side only: the oracle
     reports group keys of such a column as ids of its internal dictionary."""
+    if data_type == "STRING":   # VarByteChunkMVForwardIndexReader (MultiValueVarByteRawIndexCreator); the default null value is "null"
+        rows = [[str(v) for v in r] if len(r) else ["null"] for r in rows]
+        fwd = formats.write_raw_mv_var_byte_chunk(rows, version=version)
+        flat_s = [v for r in rows for v in r]
+        col = HostColumn(name, data_type, capi.FWD_RAW_MV_VAR_BYTE_CHUNK, False, 0, 0, False, 0, fwd, None, None, sorted(set(flat_s)))
+        col.total_number_of_entries = len(flat_s)
+        return col
     default = {"INT": -(1 << 31), "LONG": -(1 << 63), "FLOAT": float("-inf"), "DOUBLE": float("-inf")}[data_type]
     rows = [list(r) if len(r) else [default] for r in rows]
     fwd = formats.write_raw_mv_fixed_byte_chunk(rows, data_type, version=version, compression=compression)

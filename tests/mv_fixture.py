@@ -55,6 +55,7 @@ def build_with_raw_twins(rows, name="mvTable", compression=(0, 3, 4, 2, 5)) -> H
     seg.columns["rf"] = build_raw_mv_column("rf", [[v / 4.0 for v in r["mv1"]] for r in rows], "FLOAT", compression=compression[3])
     seg.columns["rd"] = build_raw_mv_column("rd", [[v / 4.0 for v in r["mv1"]] for r in rows], "DOUBLE", compression=compression[4])
     seg.columns["fd"] = build_mv_column("fd", [[v / 4.0 for v in r["mv1"]] for r in rows], "DOUBLE")   # dictionary twin of rf / rd
+    seg.columns["rs"] = build_raw_mv_column("rs", [r["mv2"] for r in rows], "STRING")   # VarByteChunkMVForwardIndexReader: raw twin of mv2
     return seg
 
 

@@ -169,6 +169,14 @@ RAW_PAIRS = [
     ("SELECT COUNTMV(rf), MINMV(rf), MAXMV(rd), MINMAXRANGEMV(rd) FROM mvTable WHERE s1 > 2", "SELECT COUNTMV(fd), MINMV(fd), MAXMV(fd), MINMAXRANGEMV(fd) FROM mvTable WHERE s1 > 2"),
     ("SELECT rh, s1, COUNT(*), SUM(m), MAXMV(r1) FROM mvTable GROUP BY rh, s1 LIMIT 1000000", "SELECT mvh, s1, COUNT(*), SUM(m), MAXMV(mv1) FROM mvTable GROUP BY mvh, s1 LIMIT 1000000"),
     ("SELECT SUMMV(rh), DISTINCTCOUNTHLLMV(rh) FROM mvTable WHERE mv2 != 'ant'", "SELECT SUMMV(mvh), DISTINCTCOUNTHLLMV(mvh) FROM mvTable WHERE mv2 != 'ant'"),
+    # raw multi-value STRING (VarByteChunkMVForwardIndexReader)
+    ("SELECT COUNT(*), SUM(m) FROM mvTable WHERE rs = 'cat'", "SELECT COUNT(*), SUM(m) FROM mvTable WHERE mv2 = 'cat'"),
+    ("SELECT COUNT(*), SUM(m) FROM mvTable WHERE rs IN ('ant', 'lynx', 'zebra') AND r1 < 30", "SELECT COUNT(*), SUM(m) FROM mvTable WHERE mv2 IN ('ant', 'lynx', 'zebra') AND mv1 < 30"),
+    ("SELECT COUNT(*), MAX(m) FROM mvTable WHERE rs NOT IN ('ant', 'bee', 'cat')", "SELECT COUNT(*), MAX(m) FROM mvTable WHERE mv2 NOT IN ('ant', 'bee', 'cat')"),
+    ("SELECT rs, COUNT(*), SUM(m) FROM mvTable GROUP BY rs LIMIT 100", "SELECT mv2, COUNT(*), SUM(m) FROM mvTable GROUP BY mv2 LIMIT 100"),
+    ("SELECT s1, rs, COUNT(*), MIN(m) FROM mvTable WHERE s1 IN (0, 1, 2, 3) GROUP BY s1, rs LIMIT 1000", "SELECT s1, mv2, COUNT(*), MIN(m) FROM mvTable WHERE s1 IN (0, 1, 2, 3) GROUP BY s1, mv2 LIMIT 1000"),
+    ("SELECT rs, r1, COUNT(*) FROM mvTable WHERE rs != 'dog' GROUP BY rs, r1 LIMIT 10000", "SELECT mv2, mv1, COUNT(*) FROM mvTable WHERE mv2 != 'dog' GROUP BY mv2, mv1 LIMIT 10000"),
+    ("SELECT s2, COUNTMV(rs), COUNT(*) FROM mvTable GROUP BY s2 LIMIT 100", "SELECT s2, COUNTMV(mv2), COUNT(*) FROM mvTable GROUP BY s2 LIMIT 100"),
 ]
 
 

@@ -40,6 +40,8 @@ def reference_segment(base, name):
     for t, dtype in TYPES.items():
         cast = float if dtype in ("FLOAT", "DOUBLE") else int
         seg.columns[f"mvRaw{t}Col"] = build_raw_mv_column(f"mvRaw{t}Col", [[cast(v), cast(v + MV_OFFSET)] for v in values], dtype, compression=comp[t])
+    # mvRawStringCol (:95,:112,:189): VarByteChunkMVForwardIndexReader
+    seg.columns["mvRawStringCol"] = build_raw_mv_column("mvRawStringCol", [[str(v), str(v + MV_OFFSET)] for v in values], "STRING")
     return seg
 
 
@@ -140,6 +142,17 @@ def check_raw(segs, floating_sums):
     first10 = sorted(rows.items())[:10]
     assert [k[0] for k, _ in first10] == [0, 0, 0, 0, 1, 1, 1, 1, 2, 2]
     assert all(v == [8, float(k[0]), float(k[0] + MV_OFFSET)] for k, v in first10)
+    # testNonAggregateMVGroupBy :455-482 groups by svIntCol, mvRawFloatCol, mvRawDoubleCol, mvRawStringCol and expects the strings
+    # "0", "100", "0", "100", ... "1", "101" next to svIntCol 0 ... 1: three multi-value keys are beyond this path (two at most), so the
+    # expectation is asserted on its projections — svIntCol x mvRawStringCol, and mvRawFloatCol x mvRawStringCol
+    rows = broker(segs, "SELECT svIntCol, mvRawStringCol, COUNT(*) FROM testTable GROUP BY svIntCol, mvRawStringCol LIMIT 1000")
+    assert rows == broker(segs, "SELECT svIntCol, mvStringCol, COUNT(*) FROM testTable GROUP BY svIntCol, mvStringCol LIMIT 1000")
+    # (COUNT(*): 2 duplicate docs x 2 servers = 4 per key; COUNTMV counts the docs' 2 entries each: the reference's 8)
+    assert sorted(rows.items())[:4] == [((0, "0"), [4]), ((0, "100"), [4]), ((1, "1"), [4]), ((1, "101"), [4])] and len(rows) == 40
+    rows = broker(segs, "SELECT mvRawFloatCol, mvRawStringCol, COUNTMV(mvRawStringCol) FROM testTable GROUP BY mvRawFloatCol, mvRawStringCol LIMIT 1000")
+    assert sorted(rows.items())[:4] == [((0.0, "0"), [8]), ((0.0, "100"), [8]), ((1.0, "1"), [8]), ((1.0, "101"), [8])]
+    assert broker(segs, "SELECT COUNT(*) FROM testTable WHERE mvRawStringCol = '1005'")[()] == [4]
+    assert broker(segs, "SELECT COUNT(*) FROM testTable WHERE mvRawStringCol IN ('3', '103', '1109') AND mvRawIntCol < 1000")[()] == [4]
 
 
 def test_multi_value_reference_goldens_oracle(oracle_api):
