@@ -137,17 +137,23 @@ DEVFN uint32_t mv_scan_wtile_bitmap(const LeafT& L, uint32_t cand, int wt, int l
   return out;
 }
 
-struct MvKeys {   // the multi-value group columns' entries of one doc (the planner admits at most two such columns)
+#define PG_MV_MAX_GROUP_COLS 4
+struct MvKeys {   // the multi-value group columns' entries of one doc (the planner admits at most PG_MV_MAX_GROUP_COLS such columns)
   uint32_t base;        // slot of the single-value part of the key (replica included)
   uint32_t combos;      // keys of the doc
-  uint32_t start[2], len[2], mult[2], bits[2];
-  const uint8_t* data[2];
+  uint32_t start[PG_MV_MAX_GROUP_COLS], len[PG_MV_MAX_GROUP_COLS], mult[PG_MV_MAX_GROUP_COLS], bits[PG_MV_MAX_GROUP_COLS];
+  const uint8_t* data[PG_MV_MAX_GROUP_COLS];
   int n;
 };
-DEVFN uint32_t mv_key_slot(const MvKeys& K, uint32_t c) {
-  uint32_t slot = K.base;
-  if (K.n > 0) { const uint32_t i0 = K.n > 1 ? c % K.len[0] : c; slot += mv_entry_at(K.data[0], K.start[0] + i0, K.bits[0]) * K.mult[0]; }
-  if (K.n > 1) slot += mv_entry_at(K.data[1], K.start[1] + c / K.len[0], K.bits[1]) * K.mult[1];
+DEVFN uint32_t mv_key_slot(const MvKeys& K, uint32_t c) {   // combination c of the doc: digit j = (c / (len_0 ... len_{j-1})) mod len_j
+  uint32_t slot = K.base, r = c;
+#pragma unroll
+  for (int j = 0; j < PG_MV_MAX_GROUP_COLS; j++)
+    if (j < K.n) {
+      const uint32_t i = j + 1 < K.n ? r % K.len[j] : r;
+      r = j + 1 < K.n ? r / K.len[j] : 0u;
+      slot += mv_entry_at(K.data[j], K.start[j] + i, K.bits[j]) * K.mult[j];
+    }
   return slot;
 }
 
@@ -169,7 +175,8 @@ DEVFN void mv_aggregate_wtile(const PgQueryPlan& p, uint32_t m, int wt, int64_t*
     const int64_t doc = (int64_t)wt * PG_WAVE_DOCS + in_tile;
     MvKeys K;
     K.base = rep; K.combos = 1; K.n = 0;
-    K.start[0] = K.start[1] = 0; K.len[0] = K.len[1] = 1; K.mult[0] = K.mult[1] = 0; K.bits[0] = K.bits[1] = 1; K.data[0] = K.data[1] = nullptr;
+#pragma unroll
+    for (int j = 0; j < PG_MV_MAX_GROUP_COLS; j++) { K.start[j] = 0; K.len[j] = 1; K.mult[j] = 0; K.bits[j] = 1; K.data[j] = nullptr; }
     for (int g = 0; g < p.n_group_cols; g++) {
       const PgGroupCol& gc = p.gcols[g];
       const uint32_t mult = (uint32_t)gc.mult * R;
@@ -177,8 +184,9 @@ DEVFN void mv_aggregate_wtile(const PgQueryPlan& p, uint32_t m, int wt, int64_t*
         const GAS int32_t* off = gptr<int32_t>(p.mv_gcol_offsets[g]);
         const uint32_t s = (uint32_t)off[doc], e = (uint32_t)off[doc + 1];
         // (constant indices: a run-time index into the struct's arrays puts them into scratch memory — 72 bytes per lane in round 3)
-        if (K.n == 0) { K.start[0] = s; K.len[0] = e - s; K.mult[0] = mult; K.bits[0] = (uint32_t)gc.bits; K.data[0] = gc.data; }
-        else          { K.start[1] = s; K.len[1] = e - s; K.mult[1] = mult; K.bits[1] = (uint32_t)gc.bits; K.data[1] = gc.data; }
+#pragma unroll
+        for (int j = 0; j < PG_MV_MAX_GROUP_COLS; j++)
+          if (K.n == j) { K.start[j] = s; K.len[j] = e - s; K.mult[j] = mult; K.bits[j] = (uint32_t)gc.bits; K.data[j] = gc.data; }
         K.combos *= e - s;
         K.n++;
       } else {

@@ -1448,7 +1448,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
       if (st) fail(PG_ERR_UNSUPPORTED, "multi-value group-by column %s over a star-tree", c->name.c_str());
       int n_mv = 0;
       for (int k = 0; k < j; k++) n_mv += D.mv_gcol_offsets[k] != nullptr;
-      if (n_mv >= 2) fail(PG_ERR_UNSUPPORTED, "more than two multi-value group-by columns");
+      if (n_mv >= 4) fail(PG_ERR_UNSUPPORTED, "more than four multi-value group-by columns");   // PG_MV_MAX_GROUP_COLS (pg_kernels_mv.hip)
       D.mv_gcol_offsets[j] = c->mv_offsets_dev.as<int32_t>();
       D.mv = 1;
     }

@@ -45,6 +45,9 @@ QUERIES = [
     "SELECT mv1, mv2, COUNT(*), SUM(m) FROM mvTable WHERE s1 IN (0, 1, 2, 3) GROUP BY mv1, mv2 LIMIT 10000",
     "SELECT mv3, s1, mv1, COUNT(*), DISTINCTCOUNT(s2) FROM mvTable WHERE mv2 = 'fox' GROUP BY mv3, s1, mv1 LIMIT 100000",
     "SELECT mv1, DISTINCTCOUNTHLL(m), DISTINCTCOUNTHLL(s1) FROM mvTable WHERE mv1 < 12 GROUP BY mv1 LIMIT 1000",
+    # three and four multi-value keys (MultiValueRawQueriesTest.java:455-540 groups by three)
+    "SELECT mv1, mv2, mv3, COUNT(*), SUM(m) FROM mvTable WHERE s1 < 3 GROUP BY mv1, mv2, mv3 LIMIT 1000000",
+    "SELECT mv3, s1, mv2, mv1, COUNT(*), COUNTMV(mv3) FROM mvTable WHERE s1 IN (1, 4) GROUP BY mv3, s1, mv2, mv1 LIMIT 1000000",
     # ---- the *MV functions: no GROUP BY, single-value keys, multi-value keys ------------------------------------------------------
     f"SELECT {MV_AGGS} FROM mvTable WHERE s1 IN (1, 2, 3)",
     f"SELECT s1, {MV_AGGS} FROM mvTable WHERE mv1 NOT IN (3, 4) GROUP BY s1 LIMIT 100",
@@ -177,6 +180,9 @@ RAW_PAIRS = [
     ("SELECT s1, rs, COUNT(*), MIN(m) FROM mvTable WHERE s1 IN (0, 1, 2, 3) GROUP BY s1, rs LIMIT 1000", "SELECT s1, mv2, COUNT(*), MIN(m) FROM mvTable WHERE s1 IN (0, 1, 2, 3) GROUP BY s1, mv2 LIMIT 1000"),
     ("SELECT rs, r1, COUNT(*) FROM mvTable WHERE rs != 'dog' GROUP BY rs, r1 LIMIT 10000", "SELECT mv2, mv1, COUNT(*) FROM mvTable WHERE mv2 != 'dog' GROUP BY mv2, mv1 LIMIT 10000"),
     ("SELECT s2, COUNTMV(rs), COUNT(*) FROM mvTable GROUP BY s2 LIMIT 100", "SELECT s2, COUNTMV(mv2), COUNT(*) FROM mvTable GROUP BY s2 LIMIT 100"),
+    # four multi-value keys, all raw: INT, STRING, LONG, DOUBLE
+    ("SELECT r1, rs, r3, rd, COUNT(*), SUM(m) FROM mvTable WHERE s1 = 2 GROUP BY r1, rs, r3, rd LIMIT 1000000",
+     "SELECT mv1, mv2, mv3, fd, COUNT(*), SUM(m) FROM mvTable WHERE s1 = 2 GROUP BY mv1, mv2, mv3, fd LIMIT 1000000"),
 ]
 
 

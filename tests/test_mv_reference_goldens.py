@@ -142,9 +142,27 @@ def check_raw(segs, floating_sums):
     first10 = sorted(rows.items())[:10]
     assert [k[0] for k, _ in first10] == [0, 0, 0, 0, 1, 1, 1, 1, 2, 2]
     assert all(v == [8, float(k[0]), float(k[0] + MV_OFFSET)] for k, v in first10)
-    # testNonAggregateMVGroupBy :455-482 groups by svIntCol, mvRawFloatCol, mvRawDoubleCol, mvRawStringCol and expects the strings
-    # "0", "100", "0", "100", ... "1", "101" next to svIntCol 0 ... 1: three multi-value keys are beyond this path (two at most), so the
-    # expectation is asserted on its projections — svIntCol x mvRawStringCol, and mvRawFloatCol x mvRawStringCol
+    # testNonAggregateMVGroupBy :455-482: GROUP BY svIntCol, mvRawFloatCol, mvRawDoubleCol, mvRawStringCol ORDER BY the same LIMIT 10 (three
+    # raw multi-value keys; the reference's query carries no aggregation — COUNT(*) stands in, the keys are what is asserted)
+    rows = broker(segs, "SELECT svIntCol, mvRawFloatCol, mvRawDoubleCol, mvRawStringCol, COUNT(*) FROM testTable "
+                        "GROUP BY svIntCol, mvRawFloatCol, mvRawDoubleCol, mvRawStringCol LIMIT 10000")
+    first10 = sorted(rows)[:10]
+    assert [k[0] for k in first10] == [0, 0, 0, 0, 0, 0, 0, 0, 1, 1]
+    assert [k[1] for k in first10] == [0.0, 0.0, 0.0, 0.0, 100.0, 100.0, 100.0, 100.0, 1.0, 1.0]
+    assert [k[2] for k in first10] == [0.0, 0.0, 100.0, 100.0, 0.0, 0.0, 100.0, 100.0, 1.0, 1.0]
+    assert [k[3] for k in first10] == ["0", "100", "0", "100", "0", "100", "0", "100", "1", "101"]
+    # :484-511 GROUP BY mvRawIntCol, mvRawDoubleCol, mvRawStringCol ORDER BY the same LIMIT 20, and :513-540 ORDER BY string, int, double LIMIT 10
+    rows = broker(segs, "SELECT mvRawIntCol, mvRawDoubleCol, mvRawStringCol, COUNT(*) FROM testTable GROUP BY mvRawIntCol, mvRawDoubleCol, mvRawStringCol LIMIT 10000")
+    first20 = sorted(rows)[:20]
+    assert [k[0] for k in first20] == [0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4]
+    assert [k[1] for k in first20] == [0.0, 0.0, 100.0, 100.0, 1.0, 1.0, 101.0, 101.0, 2.0, 2.0, 102.0, 102.0, 3.0, 3.0, 103.0, 103.0, 4.0, 4.0, 104.0, 104.0]
+    assert [k[2] for k in first20] == ["0", "100", "0", "100", "1", "101", "1", "101", "102", "2", "102", "2", "103", "3", "103", "3", "104", "4", "104", "4"]
+    by_string = sorted(rows, key=lambda k: (k[2], k[0], k[1]))[:10]
+    assert [k[0] for k in by_string] == [0, 0, 100, 100, 1, 1, 101, 101, 0, 0]
+    assert [k[1] for k in by_string] == [0.0, 100.0, 0.0, 100.0, 1.0, 101.0, 1.0, 101.0, 0.0, 100.0]
+    assert [k[2] for k in by_string] == ["0", "0", "0", "0", "1", "1", "1", "1", "100", "100"]
+    assert rows == broker(segs, "SELECT mvIntCol, mvDoubleCol, mvStringCol, COUNT(*) FROM testTable GROUP BY mvIntCol, mvDoubleCol, mvStringCol LIMIT 10000")
+    # ... and its two-key projections
     rows = broker(segs, "SELECT svIntCol, mvRawStringCol, COUNT(*) FROM testTable GROUP BY svIntCol, mvRawStringCol LIMIT 1000")
     assert rows == broker(segs, "SELECT svIntCol, mvStringCol, COUNT(*) FROM testTable GROUP BY svIntCol, mvStringCol LIMIT 1000")
     # (COUNT(*): 2 duplicate docs x 2 servers = 4 per key; COUNTMV counts the docs' 2 entries each: the reference's 8)
