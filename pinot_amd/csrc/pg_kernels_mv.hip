@@ -210,6 +210,11 @@ DEVFN void mv_aggregate_wtile(const PgQueryPlan& p, uint32_t m, int wt, int64_t*
           if (p.mv_src_len[op.src]) {
             v = (int64_t)(e - s);
             as_double = false;
+          } else if (op.is_float == PG_ACCV_FIXED_DIGIT) {   // SUMMV / AVGMV over FLOAT / DOUBLE entries: digit `limb` of every entry, summed in int64
+            v = 0;
+            for (uint32_t k = s; k < e; k++)
+              v += fx_digit(__longlong_as_double(mv_dict_value(S, mv_entry_at(S.data, k, (uint32_t)S.bits))), S.fx_q, op.limb);
+            as_double = false;
           } else if (!as_double) {   // SUM / MIN / MAX of the doc's entries in int64, then one update per key
             v = op.fn == PG_ACC_SUM ? 0 : (op.fn == PG_ACC_MIN ? INT64_MAX : INT64_MIN);
             for (uint32_t k = s; k < e; k++) {
@@ -226,9 +231,12 @@ DEVFN void mv_aggregate_wtile(const PgQueryPlan& p, uint32_t m, int wt, int64_t*
           }
         }
       }
+      const bool mv_source = op.src >= 0 && p.mv_src_offsets[op.src] != nullptr;
       for (uint32_t c = 0; c < K.combos; c++) {
         int64_t* slot = base + mv_key_slot(K, c);
         if (op.src < 0) atomicAdd(reinterpret_cast<unsigned long long*>(slot), 1ULL);   // COUNT
+        else if (!mv_source && op.is_float == PG_ACCV_FIXED_DIGIT) acc_from_double(slot, op, __longlong_as_double(v), p.srcs[op.src].fx_q);   // a single-value FLOAT / DOUBLE SUM next to multi-value columns
+        else if (!mv_source && op.is_float == PG_ACCV_LONG_DIGIT) acc_from_int(slot, op, v);
         else if (as_double) acc_float(slot, op.fn, __longlong_as_double(v));
         else acc_int(slot, op.fn, v);
       }

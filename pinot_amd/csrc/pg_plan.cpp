@@ -1645,7 +1645,13 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     if (c->is_mv && (fn_sv == PG_AGG_SUM || fn_sv == PG_AGG_AVG)) {
       // SumMV / AvgMV: the doc's entries are summed in int64 on the device, then added once per key.  Floating entries would need the
       // digit accumulators per ENTRY: kept with the Java plan for now
-      if (fl) fail(PG_ERR_UNSUPPORTED, "SUMMV / AVGMV over the FLOAT / DOUBLE column %s", c->name.c_str());
+      if (fl) {   // FLOAT / DOUBLE entries: the fixed-point digit accumulators of sum_ops, every entry of the doc cut into its digits (pg_kernels_mv.hip)
+        if (c->has_nonfinite) fail(PG_ERR_UNSUPPORTED, "SUMMV / AVGMV over %s, which holds NaN / Inf", c->name.c_str());
+        sum_ops(c, si, out);
+        if (fn_sv == PG_AGG_AVG) out.op_b = op_index(PG_ACC_SUM, src_index_kind(c, 1), false);   // AvgMV: count += values.length
+        P.aggs.push_back(out);
+        continue;
+      }
       const unsigned __int128 worst = (unsigned __int128)std::max<uint64_t>(c->val_type == PG_V_I32 ? (uint64_t)1 << 31 : c->max_abs_int, 1) *
                                       (unsigned __int128)std::max(c->total_entries, 1);
       if (worst >= ((unsigned __int128)1 << 63)) fail(PG_ERR_UNSUPPORTED, "SUMMV over %s may leave int64", c->name.c_str());
@@ -1714,7 +1720,6 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
   if (D.mv) {
     // the multi-value kernels take dense key spaces (an LDS or HBM table) and admit every key: beyond that, the Java plan
     if (huge_key_space) fail(PG_ERR_UNSUPPORTED, "multi-value query over a group key space beyond 64 M keys");
-    if (P.has_digit_sums) fail(PG_ERR_UNSUPPORTED, "multi-value query next to a floating / wide LONG SUM");
     if (st) fail(PG_ERR_UNSUPPORTED, "multi-value query over a star-tree");
   }
   for (Column* c : projected) P.algorithmic_bytes += (int64_t)c->fwd_bytes_logical;

@@ -206,6 +206,41 @@ def test_raw_multi_value_columns(raw_pair, raw_sql, dict_sql):
     assert ob.rows() == o.execute(dict_sql).rows()          # ... and in the oracle
 
 
+FLOATING_MV_SUMS = [   # SUMMV / AVGMV over FLOAT / DOUBLE entries: fixed-point digit accumulators, every entry cut into its digits
+    ("SELECT s1, SUMMV(rd), AVGMV(rf), COUNT(*) FROM mvTable WHERE r1 NOT IN (3, 4) GROUP BY s1 LIMIT 100",
+     "SELECT s1, SUMMV(fd), AVGMV(fd), COUNT(*) FROM mvTable WHERE mv1 NOT IN (3, 4) GROUP BY s1 LIMIT 100"),
+    ("SELECT SUMMV(rf), AVGMV(rd), SUM(m) FROM mvTable WHERE s1 > 2", "SELECT SUMMV(fd), AVGMV(fd), SUM(m) FROM mvTable WHERE s1 > 2"),
+    ("SELECT rs, SUMMV(rd), MAXMV(rd) FROM mvTable GROUP BY rs LIMIT 100", "SELECT mv2, SUMMV(fd), MAXMV(fd) FROM mvTable GROUP BY mv2 LIMIT 100"),
+    ("SELECT mv1, mv2, SUMMV(fd), AVGMV(fd) FROM mvTable WHERE s1 < 4 GROUP BY mv1, mv2 LIMIT 10000", None),
+]
+
+
+@pytest.mark.parametrize("n", [300, 30_000])
+def test_floating_summv(gpu_api, oracle_api, n):
+    """No empty rows here: an empty FLOAT / DOUBLE row holds the default null value -inf, and a column with NaN / Inf keeps the reference's
+    IEEE additions — SUMMV over it is left to the Java plan (asserted below on the fixture that has them)."""
+    host = mv.build_with_raw_twins(mv.make_rows(n, seed=11 + n, empty_rows=False))
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    for raw_sql, dict_sql in FLOATING_MV_SUMS:
+        gb, ob = g.execute(raw_sql), o.execute(raw_sql)
+        assert gb.rows() == ob.rows(), raw_sql
+        for f in STATS:
+            assert getattr(gb.stats, f) == getattr(ob.stats, f), f
+        if dict_sql:
+            assert gb.rows() == g.execute(dict_sql).rows()
+    g.destroy()
+    o.destroy()
+
+
+def test_floating_summv_over_non_finite_entries_is_left_to_the_java_plan(raw_pair):
+    g, _ = raw_pair
+    if g.total_docs < 300:
+        pytest.skip("the one-doc table has no empty row")
+    with pytest.raises(capi.NativeError) as e:
+        g.execute("SELECT SUMMV(rd) FROM mvTable WHERE s1 = 1")
+    assert e.value.status == capi.PG_ERR_UNSUPPORTED and "NaN / Inf" in str(e.value)
+
+
 def test_raw_multi_value_without_filter_is_scanned_not_answered_from_a_dictionary(raw_pair):
     """MINMV / MAXMV over a dictionary column without a filter come from the dictionary (NonScanBasedAggregationOperator: no entry is
     read); the raw twin has no dictionary: the same values, a scan's statistics."""

@@ -184,7 +184,7 @@ def test_multi_value_reference_goldens_oracle(oracle_api):
 @pytest.mark.gpu
 def test_multi_value_reference_goldens_gpu(gpu_api):
     segs = [NativeSegment(gpu_api, reference_segment(0, "testSegment1")), NativeSegment(gpu_api, reference_segment(1000, "testSegment2"))]
-    check(segs, floating_sums=False)
-    check_raw(segs, floating_sums=False)
+    check(segs, floating_sums=True)       # (SUMMV / AVGMV over FLOAT / DOUBLE entries run on the device since round 4: digit accumulators)
+    check_raw(segs, floating_sums=True)
     for s in segs:
         s.destroy()
