@@ -114,9 +114,15 @@ public final class GpuBuffers {
     if (dictionary == null) {
       return 0;
     }
+    // a variable-length STRING dictionary (VarLengthValueReader.isVarLengthValueBuffer: ".vl;" + version 1) travels whole: the library turns it
+    // into the padded form at registration (pg_segment.cpp)
+    if (dictionary.size() >= 20 && dictionary.getByte(0) == '.' && dictionary.getByte(1) == 'v' && dictionary.getByte(2) == 'l'
+        && dictionary.getByte(3) == ';' && dictionary.getInt(4) == 1) {
+      return dictionary.size();
+    }
     long expected = (long) md.getCardinality() * dictionaryBytesPerValue(md);
     if (dictionary.size() < expected) {
-      throw new UnsupportedOperationException("dictionary of " + md.getColumnName() + " is not fixed-width (variable-length dictionaries are outside the GPU path)");
+      throw new UnsupportedOperationException("dictionary of " + md.getColumnName() + " is neither fixed-width nor a variable-length value buffer");
     }
     return expected;
   }

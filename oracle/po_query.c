@@ -68,6 +68,31 @@ int32_t po_segment_add_column(void* segp, const pg_column_desc* d) {
   c->inv = (const uint8_t*)d->inverted_index.addr;
   c->inv_len = d->inverted_index.size;
   c->num_docs = seg->total_docs;
+  /* a variable-length STRING dictionary (VarLengthValueReader: ".vl;", int version 1, int numValues, int dataSectionStartOffset, numValues + 1
+   * absolute int offsets, the values; recognised by its magic like BaseImmutableDictionary.java:58-66 does) is read into the fixed-width,
+   * zero-padded form the readers below index */
+  if (c->has_dictionary && c->data_type == PG_TYPE_STRING && c->dict && c->dict_len >= 20 && !memcmp(c->dict, ".vl;", 4) && po_be32(c->dict + 4) == 1) {
+    const uint32_t n = po_be32(c->dict + 8), start = po_be32(c->dict + 12);
+    if ((int64_t)n != (int64_t)c->cardinality || (uint64_t)start + ((uint64_t)n + 1) * 4 > c->dict_len) {
+      po_set_error("variable-length dictionary of %s: %u values, cardinality %d", c->name, n, c->cardinality);
+      return PG_ERR_INVALID_ARGUMENT;
+    }
+    uint32_t width = 1;
+    for (uint32_t i = 0; i < n; i++) {
+      const uint32_t a = po_be32(c->dict + start + (uint64_t)i * 4), b = po_be32(c->dict + start + (uint64_t)(i + 1) * 4);
+      if (b < a || b > c->dict_len) { po_set_error("variable-length dictionary of %s: bad offsets", c->name); return PG_ERR_INVALID_ARGUMENT; }
+      if (b - a > width) width = b - a;
+    }
+    uint8_t* padded = (uint8_t*)po_xcalloc((size_t)n * width + 8, 1);
+    for (uint32_t i = 0; i < n; i++) {
+      const uint32_t a = po_be32(c->dict + start + (uint64_t)i * 4), b = po_be32(c->dict + start + (uint64_t)(i + 1) * 4);
+      memcpy(padded + (size_t)i * width, c->dict + a, b - a);
+    }
+    c->mv_owned_dict = padded;
+    c->dict = padded;
+    c->dict_len = (uint64_t)n * width;
+    c->dict_bytes_per_value = (int32_t)width;
+  }
   if ((c->fwd_encoding == PG_FWD_RAW_FIXED_BYTE_CHUNK || c->fwd_encoding == PG_FWD_RAW_VAR_BYTE_CHUNK) && po_raw_parse_header(c)) return PG_ERR_UNSUPPORTED;
   if (c->fwd_encoding == PG_FWD_RAW_MV_FIXED_BYTE_CHUNK || c->fwd_encoding == PG_FWD_RAW_MV_VAR_BYTE_CHUNK) {   /* FixedByteChunkMV / VarByteChunkMV readers: po_readers.c */
     if (c->fwd_encoding == PG_FWD_RAW_MV_VAR_BYTE_CHUNK ? po_raw_mv_attach_strings(c) : po_raw_mv_attach(c)) return PG_ERR_INVALID_ARGUMENT;

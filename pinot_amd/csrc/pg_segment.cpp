@@ -366,11 +366,37 @@ void segment_add_column(Segment& seg, const pg_column_desc& d) {
 
   if (c.has_dictionary) {
     if (c.cardinality <= 0) fail(PG_ERR_INVALID_ARGUMENT, "column %s: dictionary with cardinality %d", d.name, c.cardinality);
-    uint64_t need = (uint64_t)c.cardinality * (uint64_t)c.dict_bytes_per_value;
-    if (d.dictionary.size != need)   // BaseImmutableDictionary.java:52-55 "Buffer size mismatch"
-      fail(PG_ERR_INVALID_ARGUMENT, "Buffer size mismatch: bufferSize = %llu, numValues = %d, numByesPerValue = %d",
-           (unsigned long long)d.dictionary.size, c.cardinality, c.dict_bytes_per_value);
     const uint8_t* dp = (const uint8_t*)d.dictionary.addr;
+    uint64_t dict_size = d.dictionary.size;
+    // A variable-length STRING dictionary (useVarLengthDictionary: VarLengthValueWriter.java:78-108 / VarLengthValueReader.java — ".vl;", int
+    // version 1, int numValues, int dataSectionStartOffset, numValues + 1 absolute int offsets, the values; the reference recognises it by
+    // the same magic, BaseImmutableDictionary.java:58-66) becomes the fixed-width zero-padded form here, once: everything downstream
+    // (binary search of predicate values, group key decode, data tables) reads padded entries.
+    std::vector<uint8_t> padded;
+    if (c.data_type == PG_TYPE_STRING && dp && dict_size >= 20 && !memcmp(dp, ".vl;", 4) && be32(dp + 4) == 1) {
+      const uint32_t n = be32(dp + 8), start = be32(dp + 12);
+      if ((int64_t)n != (int64_t)c.cardinality || (uint64_t)start + ((uint64_t)n + 1) * 4 > dict_size)
+        fail(PG_ERR_INVALID_ARGUMENT, "variable-length dictionary of %s: %u values at %u in %llu bytes, cardinality %d", d.name, n, start, (unsigned long long)dict_size, c.cardinality);
+      size_t width = 1;
+      for (uint32_t i = 0; i < n; i++) {
+        const uint64_t a = be32(dp + start + (size_t)i * 4), b = be32(dp + start + (size_t)(i + 1) * 4);
+        if (b < a || b > dict_size) fail(PG_ERR_INVALID_ARGUMENT, "variable-length dictionary of %s: bad offsets of value %u", d.name, i);
+        if (b > a && dp[b - 1] == 0) fail(PG_ERR_UNSUPPORTED, "column %s: a dictionary value ending in a zero byte cannot be padded", d.name);
+        width = std::max(width, (size_t)(b - a));
+      }
+      padded.assign((size_t)n * width, 0);
+      for (uint32_t i = 0; i < n; i++) {
+        const uint64_t a = be32(dp + start + (size_t)i * 4), b = be32(dp + start + (size_t)(i + 1) * 4);
+        memcpy(padded.data() + (size_t)i * width, dp + a, (size_t)(b - a));
+      }
+      dp = padded.data();
+      dict_size = padded.size();
+      c.dict_bytes_per_value = (int32_t)width;
+    }
+    uint64_t need = (uint64_t)c.cardinality * (uint64_t)c.dict_bytes_per_value;
+    if (dict_size != need)   // BaseImmutableDictionary.java:52-55 "Buffer size mismatch"
+      fail(PG_ERR_INVALID_ARGUMENT, "Buffer size mismatch: bufferSize = %llu, numValues = %d, numByesPerValue = %d",
+           (unsigned long long)dict_size, c.cardinality, c.dict_bytes_per_value);
     c.dict_host.assign(dp, dp + need);
     {
       uint64_t h = 1469598103934665603ULL;

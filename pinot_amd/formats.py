@@ -503,6 +503,20 @@ def write_raw_mv_fixed_byte_chunk(rows: Sequence[Sequence], data_type: str, vers
     return np.frombuffer(header + off_bytes + b"".join(chunks), dtype=np.uint8)
 
 
+def write_var_length_string_dictionary(values: Sequence[str]) -> np.ndarray:
+    """A variable-length STRING dictionary (SegmentDictionaryCreator with useVarLengthDictionary -> VarLengthValueWriter.java:78-130): ".vl;",
+    int version 1, int numValues, int dataSectionStartOffset = 16, numValues + 1 absolute offsets, the UTF-8 values; `values` sorted."""
+    enc = [v.encode("utf-8") for v in values]
+    n = len(enc)
+    pos = 16 + 4 * (n + 1)
+    offs = []
+    for e in enc:
+        offs.append(pos)
+        pos += len(e)
+    offs.append(pos)
+    return np.frombuffer(b".vl;" + struct.pack(">iii", 1, n, 16) + b"".join(struct.pack(">i", o) for o in offs) + b"".join(enc), dtype=np.uint8)
+
+
 def write_raw_mv_var_byte_chunk(rows: Sequence[Sequence[str]], version: int = 2, docs_per_chunk: int = 1000) -> np.ndarray:
     """Raw (no-dictionary) multi-value STRING forward index: MultiValueVarByteRawIndexCreator -> VarByteChunkForwardIndexWriter#putStringMV: the
     var-byte chunk layout whose value of a doc is ArraySerDeUtils.serializeStringArray (.../utils/ArraySerDeUtils.java:282-292) = int numValues,
