@@ -83,9 +83,8 @@ public final class GpuSegmentRegistry {
               md.isSingleValue() ? 0 : md.getTotalNumberOfEntries(), GpuBuffers.address(fwd), fwd.size(), GpuBuffers.dictionaryValuesAddress(dict), GpuBuffers.dictionaryValuesSize(dict, md),
               inv == null ? 0 : GpuBuffers.address(inv), inv == null ? 0 : inv.size());
         } catch (RuntimeException perColumn) {
-          // Multi-value and var-byte columns come in layouts the library does not read (MV_ENTRY_DICT forward indexes —
-          // ForwardIndexReaderFactory.java:82-86 checks FixedBitMVEntryDictForwardIndexReader.MAGIC_MARKER first; V4 / V5 var-byte chunks;
-          // CLP): such a column is SKIPPED, not fatal — the segment keeps serving every query that does not touch it, and a query that
+          // Multi-value and var-byte columns come in layouts the library does not read (V4 / V5 var-byte chunks, CLP; the MV_ENTRY_DICT
+          // forward index — ForwardIndexReaderFactory.java:82-86 — is read since round 4): such a column is SKIPPED, not fatal — the segment keeps serving every query that does not touch it, and a query that
           // does is refused by pg_query_supported (unknown column) and answered by the Java plan.  (Round 3 rethrew here: one such
           // column made every query of the segment fail, ADVICE r3.)  Single-value fixed-width columns keep the strict behaviour below.
           if (md.isSingleValue() && !varByte) {

@@ -140,6 +140,7 @@ typedef struct po_mv_ctx { int32_t doc_id, end_offset; } po_mv_ctx;
 int po_mv_parse(po_column* c);
 int po_raw_mv_attach(po_column* c);
 int po_raw_mv_attach_strings(po_column* c);
+int po_mv_entry_dict_attach(po_column* c);
 int32_t po_mv_get_dict_ids(const po_column* c, int32_t doc_id, int32_t* buf, po_mv_ctx* ctx);
 /* FixedByteChunkSVForwardIndexReader#getInt/getLong/getFloat/getDouble (PASS_THROUGH) */
 int32_t po_raw_get_int(const po_column* c, int32_t doc_id);

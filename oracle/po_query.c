@@ -107,7 +107,13 @@ int32_t po_segment_add_column(void* segp, const pg_column_desc* d) {
   if (c->fwd_encoding == PG_FWD_DICT_FIXED_BIT_MV) {
     c->total_entries = d->total_number_of_entries;
     if (!c->has_dictionary) { po_set_error("raw multi-value column %s is outside the hot path", c->name); return PG_ERR_UNSUPPORTED; }
-    if (po_mv_parse(c)) return PG_ERR_INVALID_ARGUMENT;
+    if (c->fwd_len > 4 && po_be32(c->fwd) == 0xffabcdefu) {   /* ForwardIndexReaderFactory.java:82-86 checks this marker first */
+      if (po_mv_entry_dict_attach(c)) return PG_ERR_INVALID_ARGUMENT;
+      if (d->total_number_of_entries > 0 && d->total_number_of_entries != c->total_entries) {
+        po_set_error("MV_ENTRY_DICT forward index of %s expands to %d entries, the metadata says %d", c->name, c->total_entries, d->total_number_of_entries);
+        return PG_ERR_INVALID_ARGUMENT;
+      }
+    } else if (po_mv_parse(c)) return PG_ERR_INVALID_ARGUMENT;
   }
   if (c->fwd_encoding == PG_FWD_DICT_FIXED_BIT) {
     uint64_t need = ((uint64_t)seg->total_docs * (uint64_t)c->bits_per_value + 7) / 8;

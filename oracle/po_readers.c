@@ -136,6 +136,71 @@ int po_mv_parse(po_column* c) {
   c->mv_max_values = longest;
   return 0;
 }
+/* FixedBitMVEntryDictForwardIndexReader (.../readers/forward/FixedBitMVEntryDictForwardIndexReader.java; the MV_ENTRY_DICT format of
+ * FixedBitMVEntryDictForwardIndexWriter.java:80-130): header magic 0xffabcdef, short version 1, byte bitsPerValue, byte bitsPerId, int
+ * uniqueEntries, int totalValues, int offsetBufferOffset, int valueBufferOffset; then three PinotDataBitSet arrays — the docs' entry ids,
+ * the entries' start offsets, the entries' dictIds.  getDictIdMV(doc) = values[offsets[id] .. offsets[id + 1]).  Read once into
+ * FixedBitMVForwardIndexReader's layout (owned), which the rest of this file walks. */
+static uint32_t bitset_read(const uint8_t* base, int64_t index, int bits) {   /* PinotDataBitSet#readInt */
+  uint32_t v = 0;
+  const int64_t bit0 = index * bits;
+  for (int b = 0; b < bits; b++) { const int64_t at = bit0 + b; v = (v << 1) | ((base[at >> 3] >> (7 - (at & 7))) & 1u); }
+  return v;
+}
+int po_mv_entry_dict_attach(po_column* c) {
+  const uint8_t* f = c->fwd;
+  if (c->fwd_len < 24 || po_be32(f) != 0xffabcdefu || (po_be32(f + 4) >> 16) != 1u) { po_set_error("column %s: not an MV_ENTRY_DICT forward index of version 1", c->name); return -1; }
+  const int bits_v = f[6], bits_id = f[7];
+  const int64_t n_unique = (int32_t)po_be32(f + 8), n_total = (int32_t)po_be32(f + 12), off_at = (int32_t)po_be32(f + 16), val_at = (int32_t)po_be32(f + 20);
+  int bits_off = 1;
+  while (bits_off < 31 && ((int64_t)1 << bits_off) <= n_total) bits_off++;
+  const int64_t nd = c->num_docs;
+  if (bits_v != c->bits_per_value || n_unique <= 0 || off_at != 24 + (nd * bits_id + 7) / 8 || val_at != off_at + ((n_unique + 1) * bits_off + 7) / 8 ||
+      (uint64_t)val_at + (uint64_t)((n_total * bits_v + 7) / 8) > c->fwd_len) {
+    po_set_error("MV_ENTRY_DICT forward index of %s: inconsistent header", c->name);
+    return -1;
+  }
+  int64_t total = 0;
+  int32_t* starts = (int32_t*)po_xcalloc((size_t)nd + 1, sizeof(int32_t));
+  for (int64_t d = 0; d < nd; d++) {
+    const uint32_t id = bitset_read(f + 24, d, bits_id);
+    const int64_t a = bitset_read(f + off_at, id, bits_off), b = bitset_read(f + off_at, (int64_t)id + 1, bits_off);
+    if ((int64_t)id >= n_unique || b <= a || b > n_total) { free(starts); po_set_error("MV_ENTRY_DICT forward index of %s: bad entry of doc %lld", c->name, (long long)d); return -1; }
+    starts[d] = (int32_t)total;
+    total += b - a;
+  }
+  starts[nd] = (int32_t)total;
+  const int bits = c->bits_per_value;
+  const int64_t per_chunk = (int64_t)ceilf((float)2048 / (float)(total / nd));
+  const int64_t num_chunks = (nd + per_chunk - 1) / per_chunk;
+  const int64_t bitmap_size = (total + 7) / 8, raw_size = (total * bits + 7) / 8;
+  uint8_t* fwd = (uint8_t*)po_xcalloc((size_t)(num_chunks * 4 + bitmap_size + raw_size + 8), 1);
+  for (int64_t ch = 0; ch < num_chunks; ch++) {
+    const uint32_t o = (uint32_t)starts[ch * per_chunk];
+    fwd[ch * 4] = (uint8_t)(o >> 24); fwd[ch * 4 + 1] = (uint8_t)(o >> 16); fwd[ch * 4 + 2] = (uint8_t)(o >> 8); fwd[ch * 4 + 3] = (uint8_t)o;
+  }
+  uint8_t* bm = fwd + num_chunks * 4;
+  uint8_t* packed = bm + bitmap_size;
+  int64_t e = 0;
+  for (int64_t d = 0; d < nd; d++) {
+    bm[starts[d] >> 3] |= (uint8_t)(0x80u >> (starts[d] & 7));
+    const uint32_t id = bitset_read(f + 24, d, bits_id);
+    const int64_t a = bitset_read(f + off_at, id, bits_off), b = bitset_read(f + off_at, (int64_t)id + 1, bits_off);
+    for (int64_t k = a; k < b; k++, e++) {
+      const uint32_t v = bitset_read(f + val_at, k, bits_v);
+      const int64_t bit0 = e * bits;
+      for (int bb = 0; bb < bits; bb++)
+        if ((v >> (bits - 1 - bb)) & 1u) packed[(bit0 + bb) >> 3] |= (uint8_t)(0x80u >> ((bit0 + bb) & 7));
+    }
+  }
+  free(starts);
+  c->mv_owned_fwd = fwd;
+  c->fwd = fwd;
+  c->fwd_len = (uint64_t)(num_chunks * 4 + bitmap_size + raw_size);
+  c->total_entries = (int32_t)total;
+  return po_mv_parse(c);
+}
+
 static inline int mv_bit(const po_column* c, int32_t i) { return (c->mv_bitmap[i >> 3] >> (7 - (i & 7))) & 1; }
 static int32_t mv_next_set_bit(const po_column* c, int32_t from) {          /* getNextSetBitOffset(bitOffset) */
   while (!mv_bit(c, from)) from++;

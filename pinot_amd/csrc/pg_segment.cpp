@@ -439,8 +439,65 @@ void segment_add_column(Segment& seg, const pg_column_desc& d) {
     if (!c.has_dictionary || c.cardinality <= 0) fail(PG_ERR_UNSUPPORTED, "column %s: raw multi-value columns are outside the hot path", d.name);
     // ForwardIndexReaderFactory.java:82-86 looks for FixedBitMVEntryDictForwardIndexReader's marker FIRST (the MV_ENTRY_DICT format:
     // per-doc ids into a dictionary of distinct entry lists) — a different layout, left to the Java plan (refused, not misparsed)
-    if (fwd_len > 4 && be32(fwd) == 0xffabcdefu)
-      fail(PG_ERR_UNSUPPORTED, "column %s: MV_ENTRY_DICT forward index (FixedBitMVEntryDictForwardIndexReader) is outside the hot path", d.name);
+    if (fwd_len > 4 && be32(fwd) == 0xffabcdefu) {
+      // FixedBitMVEntryDictForwardIndexReader.java (written by FixedBitMVEntryDictForwardIndexWriter.java:80-130): 24-byte header — magic,
+      // short version 1, byte bitsPerValue, byte bitsPerId, int uniqueEntries, int totalValues, int offsetBufferOffset, int valueBufferOffset —
+      // then three MSB-first fixed-bit arrays: the docs' entry ids, the entries' start offsets (unique + 1), the entries' dictIds.  Expanded
+      // once, here, into what the kernels read for every multi-value column: the docs' dictIds back to back + every doc's first entry.
+      if (fwd_len < 24 || (be32(fwd + 4) >> 16) != 1u) fail(PG_ERR_UNSUPPORTED, "column %s: MV_ENTRY_DICT forward index version %u", d.name, fwd_len < 24 ? 0u : be32(fwd + 4) >> 16);
+      const int bits_v = fwd[6], bits_id = fwd[7];
+      const int64_t n_unique = (int32_t)be32(fwd + 8), n_total = (int32_t)be32(fwd + 12), off_at = (int32_t)be32(fwd + 16), val_at = (int32_t)be32(fwd + 20);
+      int bits_off = 1;
+      while (bits_off < 31 && ((int64_t)1 << bits_off) <= n_total) bits_off++;   // PinotDataBitSet.getNumBitsPerValue(numTotalValues)
+      const int64_t nd = seg.total_docs;
+      if (bits_v != c.bits || bits_id < 1 || bits_id > 31 || n_unique <= 0 || n_total < n_unique || off_at != 24 + (nd * bits_id + 7) / 8 ||
+          val_at != off_at + ((n_unique + 1) * bits_off + 7) / 8 || (uint64_t)val_at + (uint64_t)((n_total * bits_v + 7) / 8) > fwd_len)
+        fail(PG_ERR_INVALID_ARGUMENT, "MV_ENTRY_DICT forward index of %s: inconsistent header (%d / %d bits, %lld entries, %lld values)", d.name, bits_v, bits_id,
+             (long long)n_unique, (long long)n_total);
+      auto read_bits = [](const uint8_t* base, int64_t index, int bits) -> uint32_t {   // PinotDataBitSet#readInt
+        uint32_t v = 0;
+        const int64_t bit0 = index * bits;
+        for (int b = 0; b < bits; b++) { const int64_t at = bit0 + b; v = (v << 1) | ((base[at >> 3] >> (7 - (at & 7))) & 1u); }
+        return v;
+      };
+      std::vector<int32_t>& off = c.mv_offsets_host;
+      off.reserve((size_t)nd + 1);
+      int64_t total = 0;
+      for (int64_t doc = 0; doc < nd; doc++) {
+        const uint32_t id = read_bits(fwd + 24, doc, bits_id);
+        if ((int64_t)id >= n_unique) fail(PG_ERR_INVALID_ARGUMENT, "MV_ENTRY_DICT forward index of %s: entry id %u of %lld", d.name, id, (long long)n_unique);
+        const int64_t a = read_bits(fwd + off_at, id, bits_off), b = read_bits(fwd + off_at, (int64_t)id + 1, bits_off);
+        if (b <= a || b > n_total) fail(PG_ERR_INVALID_ARGUMENT, "MV_ENTRY_DICT forward index of %s: entry %u spans [%lld, %lld)", d.name, id, (long long)a, (long long)b);
+        off.push_back((int32_t)total);
+        total += b - a;
+        if (total > 0x7FFFFFFF) fail(PG_ERR_UNSUPPORTED, "multi-value column %s: more than 2^31 entries", d.name);
+        c.max_entries_per_doc = std::max(c.max_entries_per_doc, (int32_t)(b - a));
+      }
+      off.push_back((int32_t)total);
+      if (d.total_number_of_entries > 0 && total != d.total_number_of_entries)
+        fail(PG_ERR_INVALID_ARGUMENT, "MV_ENTRY_DICT forward index of %s expands to %lld entries, the metadata says %d", d.name, (long long)total, d.total_number_of_entries);
+      std::vector<uint8_t> stream((size_t)((total * c.bits + 7) / 8) + 8, 0);
+      int64_t e = 0;
+      for (int64_t doc = 0; doc < nd; doc++) {
+        const uint32_t id = read_bits(fwd + 24, doc, bits_id);
+        const int64_t a = read_bits(fwd + off_at, id, bits_off), b = read_bits(fwd + off_at, (int64_t)id + 1, bits_off);
+        for (int64_t k = a; k < b; k++, e++) {
+          const uint32_t v = read_bits(fwd + val_at, k, bits_v);
+          if ((int64_t)v >= c.cardinality) fail(PG_ERR_INVALID_ARGUMENT, "MV_ENTRY_DICT forward index of %s: dictId %u of %d", d.name, v, c.cardinality);
+          const int64_t bit0 = e * c.bits;
+          for (int bb = 0; bb < c.bits; bb++)
+            if ((v >> (c.bits - 1 - bb)) & 1u) stream[(size_t)((bit0 + bb) >> 3)] |= (uint8_t)(0x80u >> ((bit0 + bb) & 7));
+        }
+      }
+      const uint64_t raw_bytes = ((uint64_t)total * (uint64_t)c.bits + 7) / 8;
+      c.is_mv = true;
+      c.total_entries = (int32_t)total;
+      c.fwd_dev.alloc((size_t)raw_bytes + 64, true);
+      c.fwd_dev.upload(stream.data(), raw_bytes);
+      c.mv_offsets_dev = upload_vector(off);
+      c.col_kind = PG_COL_FIXED_BIT;
+      c.fwd_bytes_logical = fwd_len;
+    } else {
     const int64_t num_docs = seg.total_docs, num_values = d.total_number_of_entries;
     if (num_docs <= 0 || num_values < num_docs) fail(PG_ERR_INVALID_ARGUMENT, "multi-value column %s: %lld entries over %lld docs", d.name, (long long)num_values, (long long)num_docs);
     const int64_t per_chunk = (int64_t)std::ceil((float)2048 / (float)(num_values / num_docs));   // the reader's integer division
@@ -476,6 +533,7 @@ void segment_add_column(Segment& seg, const pg_column_desc& d) {
     c.mv_offsets_dev = upload_vector(off);
     c.col_kind = PG_COL_FIXED_BIT;
     c.fwd_bytes_logical = need;
+    }
   } else if (c.fwd_encoding == PG_FWD_DICT_SORTED) {
     // SortedIndexReaderImpl: 2 big-endian ints (startDocId, endDocId inclusive) per dictId.  The pairs come from a file: every one is
     // checked (inside the segment, ascending, disjoint) before anything is expanded from them.

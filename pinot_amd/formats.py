@@ -396,6 +396,31 @@ def write_fixed_bit_mv(dict_ids: np.ndarray, lengths: np.ndarray, bits: int) -> 
     return np.frombuffer(header + np.packbits(bitmap).tobytes()[:(total + 7) // 8] + pack_fixed_bit(dict_ids, bits).tobytes(), dtype=np.uint8)
 
 
+def write_fixed_bit_mv_entry_dict(dict_ids: np.ndarray, lengths: np.ndarray, bits: int) -> np.ndarray:
+    """The MV_ENTRY_DICT forward index (FixedBitMVEntryDictForwardIndexWriter.java:80-130): distinct entry lists get ids in first-seen order;
+    header (magic 0xffabcdef, short version 1, byte bitsPerValue, byte bitsPerId, int uniqueEntries, int totalValues, int offsetBufferOffset,
+    int valueBufferOffset), then the docs' ids, the entries' start offsets (unique + 1) and the entries' dictIds as MSB-first bit arrays."""
+    lengths = np.asarray(lengths, dtype=np.int64)
+    starts = np.concatenate([[0], np.cumsum(lengths)])
+    entry_ids, entries, ids = {}, [], []
+    for d in range(len(lengths)):
+        e = tuple(int(v) for v in dict_ids[starts[d]:starts[d + 1]])
+        if e not in entry_ids:
+            entry_ids[e] = len(entries)
+            entries.append(e)
+        ids.append(entry_ids[e])
+    n_unique, n_total = len(entries), sum(len(e) for e in entries)
+    bits_id, bits_off = num_bits_per_value(n_unique - 1), num_bits_per_value(n_total)
+    offs = np.concatenate([[0], np.cumsum([len(e) for e in entries])]).astype(np.int64)
+    id_buf = pack_fixed_bit(np.asarray(ids), bits_id).tobytes()
+    off_buf = pack_fixed_bit(offs, bits_off).tobytes()
+    val_buf = pack_fixed_bit(np.asarray([v for e in entries for v in e]), bits).tobytes()
+    off_at = 24 + len(id_buf)
+    val_at = off_at + len(off_buf)
+    header = struct.pack(">IhBBiiii", 0xFFABCDEF, 1, bits, bits_id, n_unique, n_total, off_at, val_at)
+    return np.frombuffer(header + id_buf + off_buf + val_buf, dtype=np.uint8)
+
+
 def read_fixed_bit_mv(buf: np.ndarray, num_docs: int, total_values: int, bits: int):
     """Check reader: (dictIds back to back, start offset per doc + total)."""
     per_chunk = mv_docs_per_chunk(num_docs, total_values)
