@@ -397,8 +397,13 @@ static LaunchShape launch_shape(const CompiledPlan& P, int n_wtiles, int agg_mod
   if (P.dev.agg_mode == PG_AGG_LDS_PART && agg_mode == PG_AGG_LDS_PART) {
     // range-partitioned aggregation: one workgroup per CU, 8 x per_xcd of them with per_xcd a multiple of the range count
     int per_xcd = std::max(num_cus() / 8, 1);
-    per_xcd = std::max(per_xcd / P.dev.n_parts, 1) * P.dev.n_parts;
-    return {8 * per_xcd, uses_fast_kernel(P, agg_mode) ? PG_BLOCK : PG_GENERIC_BLOCK, lds};
+    const int block = uses_fast_kernel(P, agg_mode) ? PG_BLOCK : PG_GENERIC_BLOCK;
+    // (a small doc space — a star-tree's pre-aggregated docs — does not need every CU: a workgroup without tiles still fills and flushes its table)
+    const int chunks = (n_wtiles + block / 64 - 1) / (block / 64);
+    static const bool no_clamp = getenv("PG_NO_PART_GRID_CLAMP") != nullptr;   // measurement knob
+    int per_range = std::max(per_xcd / P.dev.n_parts, 1);
+    if (!no_clamp) per_range = std::max(1, std::min(per_range, (chunks + 7) / 8));
+    return {8 * per_range * P.dev.n_parts, block, lds};
   }
   if (uses_scan_kernel(P, agg_mode)) {
     static const int wgs_per_cu = getenv("PG_SCAN_WGS_PER_CU") ? atoi(getenv("PG_SCAN_WGS_PER_CU")) : 1;   // tuning knob
@@ -819,13 +824,21 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
   }
 
   PgQueryPlan D = P.dev;
-  // small doc spaces with per-doc state merges (PgQueryPlan::tile_split_shift): up to 32 wavefronts share a wave tile
+  // small doc spaces with per-doc state merges (PgQueryPlan::tile_split_shift): up to 128 wavefronts share a wave tile
   int split_shift = 0;
   {
     static const bool no_split = getenv("PG_NO_TILE_SPLIT") != nullptr;   // measurement knob
     const bool table_mode = D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE || D.agg_mode == PG_AGG_LDS_PART || D.agg_mode == PG_AGG_GLOBAL;
     if (!no_split && table_mode && D.n_aux > 0 && !uses_fast_kernel(P, D.agg_mode))
-      while (split_shift < 5 && ((int64_t)std::max(P.dev.n_wtiles, 1) << (split_shift + 1)) <= 4096) split_shift++;
+    {
+      // (serialized-HyperLogLog merges — a star-tree's pair column — are a serial chain of loads and compare-and-swaps per wavefront: 16 docs
+      // each; the other states take one atomic per doc and stop at 64 docs per wavefront)
+      static const int knob = getenv("PG_TILE_SPLIT_MAX") ? atoi(getenv("PG_TILE_SPLIT_MAX")) : -1;   // tuning knob (≤ 9: 8 quad slots x 64 lanes)
+      bool merges = false;
+      for (int x = 0; x < D.n_aux; x++) merges |= D.aux[x].kind == PG_AUX_HLL_BYTES;
+      const int max_split = knob >= 0 ? knob : (merges ? 7 : 5);
+      while (split_shift < max_split && ((int64_t)std::max(P.dev.n_wtiles, 1) << (split_shift + 1)) <= 4096) split_shift++;
+    }
   }
   // oct-layout kernels (pg_kernels_oct.hip): one 16-wavefront workgroup per CU, no tile splitting
   static const bool no_oct = getenv("PG_NO_OCT_EXEC") != nullptr;   // measurement knob: plans keep D.oct, the round-3 kernels run them
@@ -1167,7 +1180,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
         PG_HIP(hipGetLastError());
       }
     if (D.agg_mode == PG_AGG_LDS_PART && n_out > 0) {
-      hipLaunchKernelGGL(pg_reduce_parts_kernel, dim3((unsigned)((n_out + 3) / 4)), dim3(256), 0, ctx.stream, ctx.partials.as<int64_t>(),
+      hipLaunchKernelGGL(pg_reduce_parts_kernel, dim3((unsigned)((n_out + 63) / 64)), dim3(256), 0, ctx.stream, ctx.partials.as<int64_t>(),
                          ctx.final_table.as<int64_t>(), shape.grid, D.n_ops, D.n_groups, D.n_parts, D.part_groups, P.ops_dev.as<PgAccOp>());
       PG_HIP(hipGetLastError());
     }

@@ -585,21 +585,36 @@ DEVFN void aux_update_batch(const PgQueryPlan& p, uint32_t mb, int k0, int wtile
         for (int i = 0; i < 4; i++) {
           unsigned long long ball = __ballot((mb >> (4 * u + i)) & 1u);
           while (ball) {
-            const int l = __builtin_ctzll(ball);
-            ball &= ball - 1;
-            const size_t g = (size_t)((uint32_t)__builtin_amdgcn_readlane((int)slot[u][i], l) >> p.replica_shift);
-            const int64_t doc = (int64_t)wtile * PG_WAVE_DOCS + 4 * ((k0 + u) * 64 + l) + i;
-            const GAS uint32_t* sw = (const GAS uint32_t*)(src + doc * (int64_t)A.stride);
-            uint32_t* dst = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(A.base) + g * (size_t)A.stride);
+            // four docs in flight (their loads are independent); short of four, the first is repeated — max is idempotent
+            const GAS uint32_t* sw[4];
+            uint32_t* dst[4];
+            int l0 = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              int l = l0;
+              if (j == 0 || ball) { l = __builtin_ctzll(ball); ball &= ball - 1; }
+              if (j == 0) l0 = l;
+              const size_t g = (size_t)((uint32_t)__builtin_amdgcn_readlane((int)slot[u][i], l) >> p.replica_shift);
+              const int64_t doc = (int64_t)wtile * PG_WAVE_DOCS + 4 * ((k0 + u) * 64 + l) + i;
+              sw[j] = (const GAS uint32_t*)(src + doc * (int64_t)A.stride);
+              dst[j] = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(A.base) + g * (size_t)A.stride);
+            }
             for (uint32_t w = (uint32_t)lane; w < n_dw; w += 64) {
-              const uint32_t v = sw[w];
-              uint32_t cur = __hip_atomic_load(dst + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              for (;;) {
-                const uint32_t nv = bytemax4(cur, v);
-                if (nv == cur) break;
-                const uint32_t prev = atomicCAS(dst + w, cur, nv);
-                if (prev == cur) break;
-                cur = prev;
+              uint32_t v[4], cur[4];
+#pragma unroll
+              for (int j = 0; j < 4; j++) v[j] = sw[j][w];
+#pragma unroll
+              for (int j = 0; j < 4; j++) cur[j] = __hip_atomic_load(dst[j] + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+              for (int j = 0; j < 4; j++) {
+                uint32_t c = cur[j];
+                for (;;) {
+                  const uint32_t nv = bytemax4(c, v[j]);
+                  if (nv == c) break;
+                  const uint32_t prev = atomicCAS(dst[j] + w, c, nv);
+                  if (prev == c) break;
+                  c = prev;
+                }
               }
             }
           }
@@ -2545,17 +2560,19 @@ PG_KERNEL __global__ void __launch_bounds__(256) pg_radix_reduce_kernel(const in
   out[i] = acc;
 }
 
-// Range-partitioned partials: workgroup b holds [n_ops][part_groups] for range (b >> 3) % n_parts.  One wavefront per
-// output slot (op, group), lanes stride over the workgroups that own the group's range.
+// Range-partitioned partials: workgroup b holds [n_ops][part_groups] for range (b >> 3) % n_parts.  64 output slots (op, group)
+// per workgroup — neighbouring lanes read neighbouring slots of the same workgroup's table — and its four wavefronts split the
+// workgroups that own the slots' range, eight loads in flight each.
 PG_KERNEL __global__ void __launch_bounds__(256) pg_reduce_parts_kernel(const int64_t* __restrict__ partials,
                                                                           int64_t* __restrict__ out, int n_wg, int n_ops,
                                                                           int n_groups, int n_parts, int part_groups,
                                                                           const PgAccOp* __restrict__ ops) {
   const int64_t n_out = (int64_t)n_ops * n_groups;
-  const int lane = threadIdx.x & 63;
-  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= n_out) return;
-  const int o = (int)(i / n_groups), g = (int)(i % n_groups);
+  __shared__ int64_t s_acc[4][64];
+  const int lane = threadIdx.x & 63, quarter = threadIdx.x >> 6;   // wavefront q takes the workgroups j = q (mod 4) of the slot's range
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  const bool live = i < n_out;
+  const int o = live ? (int)(i / n_groups) : 0, g = live ? (int)(i % n_groups) : 0;
   const int range = g / part_groups, l = g % part_groups;
   const PgAccOp op = ops[o];
   const int kind = (op.fn == PG_ACC_SUM && op.is_float == PG_ACCV_DOUBLE) ? 0 : ((op.fn == PG_ACC_COUNT || op.fn == PG_ACC_SUM) ? 1 : (op.fn == PG_ACC_MIN ? 2 : 3));
@@ -2567,14 +2584,19 @@ PG_KERNEL __global__ void __launch_bounds__(256) pg_reduce_parts_kernel(const in
     return b > a ? b : a;
   };
   const int64_t wg_stride = (int64_t)n_ops * part_groups;
-  for (int w = lane; w < n_wg; w += 64)
-    if (((w >> 3) % n_parts) == range) acc = combine(acc, partials[(int64_t)w * wg_stride + (int64_t)o * part_groups + l]);
+  const int64_t* src = partials + (int64_t)o * part_groups + l;
+  const int per_range = (n_wg >> 3) / n_parts;   // launch_shape: the grid is 8 x per_range x n_parts
+  for (int j = quarter; j < per_range; j += 4) {
+    const int64_t w0 = 8 * ((int64_t)range + (int64_t)n_parts * j);
+    int64_t v[8];
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const int64_t other = __shfl_xor((long long)acc, off, 64);
-    acc = combine(acc, other);
+    for (int x = 0; x < 8; x++) v[x] = src[(w0 + x) * wg_stride];
+#pragma unroll
+    for (int x = 0; x < 8; x++) acc = combine(acc, v[x]);
   }
-  if (lane == 0) out[i] = acc;
+  s_acc[quarter][lane] = acc;
+  __syncthreads();
+  if (quarter == 0 && live) out[i] = combine(combine(s_acc[0][lane], s_acc[1][lane]), combine(s_acc[2][lane], s_acc[3][lane]));
 }
 
 // Merges the workgroups' LDS-resident DISTINCTCOUNT / HLL partials: out[w] = OR (sets) or per-byte max (registers) over n_wg.
