@@ -44,7 +44,7 @@ PG_DECL_FAST(pg_p2_scatter_1f) PG_DECL_FAST(pg_p2_scatter_2f) PG_DECL_FAST(pg_p2
 PG_DECL_FAST(pg_p2_aggregate_1) PG_DECL_FAST(pg_p2_aggregate_2) PG_DECL_FAST(pg_p2_aggregate_3) PG_DECL_FAST(pg_p2_aggregate_4)
 PG_DECL_FAST(pg_p2_aggregate_1n) PG_DECL_FAST(pg_p2_aggregate_2n) PG_DECL_FAST(pg_p2_aggregate_3n) PG_DECL_FAST(pg_p2_aggregate_4n)
 PG_DECL_FAST(pg_p2_index_count_kernel) PG_DECL_FAST(pg_p2_index_scan_kernel) PG_DECL_FAST(pg_p2_index_fill_kernel)
-PG_DECL_FAST(pg_p2_scatter_stream) PG_DECL_FAST(pg_p2_aggregate_1b)
+PG_DECL_FAST(pg_p2_scatter_stream) PG_DECL_FAST(pg_p2_aggregate_1b) PG_DECL_FAST(pg_p2_aggregate_1s) PG_DECL_FAST(pg_p2_aggregate_2s)
 // pg_kernels_oct.hip: oct-layout DISTINCTCOUNTHLL / DISTINCTCOUNT kernels (LDS-resident states; pruned offers) and their small helpers
 PG_DECL_FAST(pg_oct_l) PG_DECL_FAST(pg_oct_lm) PG_DECL_FAST(pg_oct_p) PG_DECL_FAST(pg_oct_pm)
 extern "C" __global__ void pg_oct_merge_floor_kernel(const uint32_t* partials, uint32_t* regs, uint8_t* floors, int n_groups, int log2m, int radix_shift,
@@ -194,7 +194,7 @@ void use_device(int ordinal) {
                                  pg_radix_aggregate_kernel, pg_hash_aggregate_kernel,
                                  pg_p2_scatter_1, pg_p2_scatter_2, pg_p2_scatter_3, pg_p2_scatter_4, pg_p2_scatter_1f, pg_p2_scatter_2f, pg_p2_scatter_1f_key, pg_p2_scatter_1f_hll,
                                  pg_p2_aggregate_1, pg_p2_aggregate_2, pg_p2_aggregate_3, pg_p2_aggregate_4,
-                                 pg_p2_aggregate_1n, pg_p2_aggregate_2n, pg_p2_aggregate_3n, pg_p2_aggregate_4n};
+                                 pg_p2_aggregate_1n, pg_p2_aggregate_2n, pg_p2_aggregate_3n, pg_p2_aggregate_4n, pg_p2_aggregate_1s, pg_p2_aggregate_2s};
       for (QueryKernel k : all)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
       for (QueryKernel k : {pg_mv_query_f, pg_mv_query_l, pg_mv_query_g})   // 10.5 KB of static LDS (per-wavefront entry bitmaps): the planner's 144 KB still fit
@@ -689,7 +689,6 @@ static void run_oct_pruned(CompiledPlan& P, PgQueryPlan& D, ThreadCtx& ctx, cons
   D.oct_cursor = ctx.oct_cursor.as<uint32_t>();
   D.oct_stream_cap = (int64_t)stream_cap;
   const int slices_max = std::max(D.radix_slices, 1);   // what the partial register areas were sized for
-  const size_t slots = (size_t)1 << D.radix_shift;
   const size_t o_lds = ((G * 4 + G_pad + 15) & ~(size_t)15) + (size_t)PG_WAVES_PER_BLOCK * 1024 * 4 + 64;   // counts | floors | a 1 024-entry ring per wavefront
   int parts = 0;   // per-workgroup COUNT partials written so far
   for (int pass = 0, t0 = 0; pass < n_pass; t0 = bounds[(size_t)pass], pass++) {
@@ -1000,7 +999,16 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
       PG_HIP(hipGetLastError());
     }
     const int agrid = std::min(NB * D.radix_slices, num_cus());
-    hipLaunchKernelGGL(gathers ? aggregate_k[T] : aggregate_nogather_k[T], dim3(agrid), dim3(PG_P2_AGG_THREADS), P.lds_bytes + 64, ctx.stream, D);
+    // COUNT(*) and SUM / MIN / MAX of raw INT fields only: the consumer with the ops' descriptors in scalar registers (pg_p2_aggregate_*s)
+    static const bool no_simple = getenv("PG_NO_P2_SIMPLE") != nullptr;   // A/B knob
+    bool simple = !no_simple && !gathers && D.n_aux == 0 && T <= 2 && D.n_ops <= 4;
+    for (int o = 0; o < D.n_ops && simple; o++) {
+      const PgAccOp& op = D.ops[o];
+      if (op.src < 0) simple = op.fn == PG_ACC_COUNT || (op.fn == PG_ACC_MIN && D.p2_docid_plane >= 0);
+      else simple = D.p2_fkind[op.src] == PG_P2_F_RAW32 && D.srcs[op.src].val_type == PG_V_I32 && op.is_float == PG_ACCV_INT && op.fn != PG_ACC_COUNT;
+    }
+    const QueryKernel ak = simple ? (T == 1 ? pg_p2_aggregate_1s : pg_p2_aggregate_2s) : (gathers ? aggregate_k[T] : aggregate_nogather_k[T]);
+    hipLaunchKernelGGL(ak, dim3(agrid), dim3(PG_P2_AGG_THREADS), P.lds_bytes + 64, ctx.stream, D);
     PG_HIP(hipGetLastError());
     for (int x = 0; x < D.n_aux; x++) {
       const int64_t n_words = (int64_t)D.n_groups * D.aux[x].stride / 4, bucket_words = (int64_t)(slots * (size_t)D.aux[x].stride / 4);

@@ -886,7 +886,36 @@ DEVFN void p2_consume(const PgQueryPlan& p, const u32x4 (&cur)[T], bool on, int6
   }
 }
 
-template <int T, bool GATHER>
+// The common accumulator shapes — COUNT(*) and SUM / MIN / MAX over raw INT fields, no auxiliary states — with the ops' descriptors read
+// once into scalar registers: p2_consume's walk over p.ops / p.srcs / pk_* costs ~63 scalar instructions and 8 scalar loads per wavefront
+// and tuple (profiles/r04_ab_*: the pass was SALU-bound at 1.4 TB/s of tuples).
+#define PG_P2_SIMPLE_OPS 4
+#define PG_P2_SIMPLE_DOCID 4   // P2SimpleOp::fn of the MIN(docId) accumulator of numGroupsLimit trimming
+struct P2SimpleOp { int32_t fn, plane; uint32_t shift, mask, bias; };
+template <int T>
+DEVFN void p2_consume_simple(const P2SimpleOp (&so)[PG_P2_SIMPLE_OPS], int n_ops, const u32x4 (&cur)[T], bool on, int64_t* table, uint32_t slots, uint32_t local_mask) {
+  if (!on) return;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const uint32_t d0 = p2_pick<T>(cur, 0, e);
+    if (d0 == PG_RADIX_INVALID_KEY) continue;
+    const uint32_t k = d0 & local_mask;
+#pragma unroll
+    for (int o = 0; o < PG_P2_SIMPLE_OPS; o++) {
+      if (o >= n_ops) break;
+      int64_t* acc = table + (size_t)o * slots + k;
+      if (so[o].fn == PG_ACC_COUNT) { atomicAdd(reinterpret_cast<uint32_t*>(acc), 1u); continue; }   // (a work item sees < 2^32 tuples)
+      if (so[o].fn == PG_P2_SIMPLE_DOCID) { atomicMin(reinterpret_cast<long long*>(acc), (long long)p2_pick<T>(cur, so[o].plane, e)); continue; }   // MIN(docId)
+      const uint32_t f = ((T == 1 ? d0 : p2_pick<T>(cur, so[o].plane, e)) >> so[o].shift) & so[o].mask;
+      const int64_t v = (int64_t)(int32_t)(f + so[o].bias);
+      if (so[o].fn == PG_ACC_SUM) atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)v);
+      else if (so[o].fn == PG_ACC_MIN) atomicMin(reinterpret_cast<long long*>(acc), (long long)v);
+      else atomicMax(reinterpret_cast<long long*>(acc), (long long)v);
+    }
+  }
+}
+
+template <int T, bool GATHER, bool SIMPLE = false>
 __device__ __forceinline__ void p2_aggregate_body(const PgQueryPlan& p) {
   extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
   int64_t* table = reinterpret_cast<int64_t*>(smem);
@@ -900,6 +929,19 @@ __device__ __forceinline__ void p2_aggregate_body(const PgQueryPlan& p) {
   const int n_items = p.radix_buckets * p.radix_slices;
   const GAS uint32_t* const tuples = gptr<uint32_t>(p.p2_tuples);
   const size_t plane_stride = (size_t)p.p2_plane_stride;
+  P2SimpleOp so[PG_P2_SIMPLE_OPS];
+  if (SIMPLE) {
+#pragma unroll
+    for (int o = 0; o < PG_P2_SIMPLE_OPS; o++) {
+      const int oo = o < p.n_ops ? o : 0, src = p.ops[oo].src < 0 ? 0 : p.ops[oo].src;
+      const uint32_t bits = (uint32_t)p.pk_bits[src];
+      so[o].fn = p.ops[oo].src < 0 ? (p.ops[oo].fn == PG_ACC_COUNT ? PG_ACC_COUNT : PG_P2_SIMPLE_DOCID) : p.ops[oo].fn;
+      so[o].plane = p.ops[oo].src < 0 ? p.p2_docid_plane : p.p2_fplane[src];
+      so[o].shift = (uint32_t)p.pk_shift[src];
+      so[o].mask = bits < 32u ? (1u << bits) - 1u : 0xFFFFFFFFu;
+      so[o].bias = (uint32_t)p.p2_fbias[src];
+    }
+  }
   for (int w = (int)blockIdx.x; w < n_items; w += (int)gridDim.x) {
     const uint32_t b = (uint32_t)(w / p.radix_slices), sl = (uint32_t)(w % p.radix_slices);
     for (int o = 0; o < p.n_ops; o++) {
@@ -923,9 +965,11 @@ __device__ __forceinline__ void p2_aggregate_body(const PgQueryPlan& p) {
       bool on0 = p2_fetch<T>(tuples, plane_stride, list, n_list, (uint32_t)wave, lane, c0), on1 = false;
       for (uint32_t ci = (uint32_t)wave; ci < n_list; ci += 2u * WAVES) {
         on1 = p2_fetch<T>(tuples, plane_stride, list, n_list, ci + WAVES, lane, c1);
-        p2_consume<T, GATHER>(p, c0, on0, table, aux_lds, slots, local_mask);
+        if (SIMPLE) p2_consume_simple<T>(so, p.n_ops, c0, on0, table, slots, local_mask);
+        else p2_consume<T, GATHER>(p, c0, on0, table, aux_lds, slots, local_mask);
         on0 = p2_fetch<T>(tuples, plane_stride, list, n_list, ci + 2u * WAVES, lane, c0);
-        p2_consume<T, GATHER>(p, c1, on1, table, aux_lds, slots, local_mask);
+        if (SIMPLE) p2_consume_simple<T>(so, p.n_ops, c1, on1, table, slots, local_mask);
+        else p2_consume<T, GATHER>(p, c1, on1, table, aux_lds, slots, local_mask);
       }
     }
     __syncthreads();
@@ -956,6 +1000,10 @@ P2_AGGREGATE(pg_p2_aggregate_1n, 1, false)
 P2_AGGREGATE(pg_p2_aggregate_2n, 2, false)
 P2_AGGREGATE(pg_p2_aggregate_3n, 3, false)
 P2_AGGREGATE(pg_p2_aggregate_4n, 4, false)
+#define P2_AGGREGATE_SIMPLE(NAME, T) \
+  extern "C" __global__ void __launch_bounds__(PG_P2_AGG_THREADS) NAME(const PgQueryPlan p) { p2_aggregate_body<T, false, true>(p); }
+P2_AGGREGATE_SIMPLE(pg_p2_aggregate_1s, 1)
+P2_AGGREGATE_SIMPLE(pg_p2_aggregate_2s, 2)
 
 // ---- aggregation pass of the pruned-offer passes (pg_kernels_oct.hip): HyperLogLog offers only (COUNT is kept by pg_oct_p), registers as
 // BYTES — 512 groups x 256 registers per bucket instead of 82 as dwords, i.e. 25 buckets instead of 157 for config 5: the stream scatter
