@@ -44,7 +44,7 @@ PG_DECL_FAST(pg_p2_scatter_1f) PG_DECL_FAST(pg_p2_scatter_2f) PG_DECL_FAST(pg_p2
 PG_DECL_FAST(pg_p2_aggregate_1) PG_DECL_FAST(pg_p2_aggregate_2) PG_DECL_FAST(pg_p2_aggregate_3) PG_DECL_FAST(pg_p2_aggregate_4)
 PG_DECL_FAST(pg_p2_aggregate_1n) PG_DECL_FAST(pg_p2_aggregate_2n) PG_DECL_FAST(pg_p2_aggregate_3n) PG_DECL_FAST(pg_p2_aggregate_4n)
 PG_DECL_FAST(pg_p2_index_count_kernel) PG_DECL_FAST(pg_p2_index_scan_kernel) PG_DECL_FAST(pg_p2_index_fill_kernel)
-PG_DECL_FAST(pg_p2_scatter_stream) PG_DECL_FAST(pg_p2_aggregate_1b) PG_DECL_FAST(pg_p2_aggregate_1s) PG_DECL_FAST(pg_p2_aggregate_2s)
+PG_DECL_FAST(pg_p2_scatter_stream) PG_DECL_FAST(pg_p2_aggregate_1b) PG_DECL_FAST(pg_p2_aggregate_1s) PG_DECL_FAST(pg_p2_aggregate_2s) PG_DECL_FAST(pg_p2_aggregate_1sg) PG_DECL_FAST(pg_p2_aggregate_2sg)
 // pg_kernels_oct.hip: oct-layout DISTINCTCOUNTHLL / DISTINCTCOUNT kernels (LDS-resident states; pruned offers) and their small helpers
 PG_DECL_FAST(pg_oct_l) PG_DECL_FAST(pg_oct_lm) PG_DECL_FAST(pg_oct_p) PG_DECL_FAST(pg_oct_pm)
 extern "C" __global__ void pg_oct_merge_floor_kernel(const uint32_t* partials, uint32_t* regs, uint8_t* floors, int n_groups, int log2m, int radix_shift,
@@ -194,7 +194,7 @@ void use_device(int ordinal) {
                                  pg_radix_aggregate_kernel, pg_hash_aggregate_kernel,
                                  pg_p2_scatter_1, pg_p2_scatter_2, pg_p2_scatter_3, pg_p2_scatter_4, pg_p2_scatter_1f, pg_p2_scatter_2f, pg_p2_scatter_1f_key, pg_p2_scatter_1f_hll,
                                  pg_p2_aggregate_1, pg_p2_aggregate_2, pg_p2_aggregate_3, pg_p2_aggregate_4,
-                                 pg_p2_aggregate_1n, pg_p2_aggregate_2n, pg_p2_aggregate_3n, pg_p2_aggregate_4n, pg_p2_aggregate_1s, pg_p2_aggregate_2s};
+                                 pg_p2_aggregate_1n, pg_p2_aggregate_2n, pg_p2_aggregate_3n, pg_p2_aggregate_4n, pg_p2_aggregate_1s, pg_p2_aggregate_2s, pg_p2_aggregate_1sg, pg_p2_aggregate_2sg};
       for (QueryKernel k : all)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
       for (QueryKernel k : {pg_mv_query_f, pg_mv_query_l, pg_mv_query_g})   // 10.5 KB of static LDS (per-wavefront entry bitmaps): the planner's 144 KB still fit
@@ -1001,13 +1001,18 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
     const int agrid = std::min(NB * D.radix_slices, num_cus());
     // COUNT(*) and SUM / MIN / MAX of raw INT fields only: the consumer with the ops' descriptors in scalar registers (pg_p2_aggregate_*s)
     static const bool no_simple = getenv("PG_NO_P2_SIMPLE") != nullptr;   // A/B knob
-    bool simple = !no_simple && !gathers && D.n_aux == 0 && T <= 2 && D.n_ops <= 4;
+    bool simple = !no_simple && D.n_aux == 0 && T <= 2 && D.n_ops <= 4;
     for (int o = 0; o < D.n_ops && simple; o++) {
       const PgAccOp& op = D.ops[o];
       if (op.src < 0) simple = op.fn == PG_ACC_COUNT || (op.fn == PG_ACC_MIN && D.p2_docid_plane >= 0);
-      else simple = D.p2_fkind[op.src] == PG_P2_F_RAW32 && D.srcs[op.src].val_type == PG_V_I32 && op.is_float == PG_ACCV_INT && op.fn != PG_ACC_COUNT;
+      else {
+        const int kind = D.p2_fkind[op.src], vt = D.srcs[op.src].val_type;
+        simple = op.is_float == PG_ACCV_INT && op.fn != PG_ACC_COUNT &&
+                 ((kind == PG_P2_F_RAW32 && vt == PG_V_I32) || (kind == PG_P2_F_DICTID && (vt == PG_V_I32 || vt == PG_V_I64)));
+      }
     }
-    const QueryKernel ak = simple ? (T == 1 ? pg_p2_aggregate_1s : pg_p2_aggregate_2s) : (gathers ? aggregate_k[T] : aggregate_nogather_k[T]);
+    static const QueryKernel aggregate_simple_k[2][3] = {{nullptr, pg_p2_aggregate_1s, pg_p2_aggregate_2s}, {nullptr, pg_p2_aggregate_1sg, pg_p2_aggregate_2sg}};
+    const QueryKernel ak = simple ? aggregate_simple_k[gathers ? 1 : 0][T] : (gathers ? aggregate_k[T] : aggregate_nogather_k[T]);
     hipLaunchKernelGGL(ak, dim3(agrid), dim3(PG_P2_AGG_THREADS), P.lds_bytes + 64, ctx.stream, D);
     PG_HIP(hipGetLastError());
     for (int x = 0; x < D.n_aux; x++) {

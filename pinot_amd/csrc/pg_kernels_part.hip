@@ -891,10 +891,27 @@ DEVFN void p2_consume(const PgQueryPlan& p, const u32x4 (&cur)[T], bool on, int6
 // and tuple (profiles/r04_ab_*: the pass was SALU-bound at 1.4 TB/s of tuples).
 #define PG_P2_SIMPLE_OPS 4
 #define PG_P2_SIMPLE_DOCID 4   // P2SimpleOp::fn of the MIN(docId) accumulator of numGroupsLimit trimming
-struct P2SimpleOp { int32_t fn, plane; uint32_t shift, mask, bias; };
-template <int T>
+struct P2SimpleOp { int32_t fn, plane; uint32_t shift, mask, bias; int32_t vt; const GAS uint8_t* dict; };   // vt: 0 raw INT field, 1 / 2 dictId of an INT / LONG dictionary
+template <int T, bool GATHER>
 DEVFN void p2_consume_simple(const P2SimpleOp (&so)[PG_P2_SIMPLE_OPS], int n_ops, const u32x4 (&cur)[T], bool on, int64_t* table, uint32_t slots, uint32_t local_mask) {
   if (!on) return;
+  // dictionary look-ups of the lane's four tuples first, all in flight (padding tuples look up dictId 0), the LDS atomics after
+  int64_t gv[4][PG_P2_SIMPLE_OPS];
+  if (GATHER) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const uint32_t d0 = p2_pick<T>(cur, 0, e);
+#pragma unroll
+      for (int o = 0; o < PG_P2_SIMPLE_OPS; o++) {
+        gv[e][o] = 0;
+        if (o < n_ops && so[o].vt != 0) {
+          const uint32_t f = d0 == PG_RADIX_INVALID_KEY ? 0u : ((T == 1 ? d0 : p2_pick<T>(cur, so[o].plane, e)) >> so[o].shift) & so[o].mask;
+          if (so[o].vt == 1) gv[e][o] = (int64_t)(int32_t)((const GAS uint32_t*)so[o].dict)[f];
+          else gv[e][o] = (int64_t)((const GAS uint64_t*)so[o].dict)[f];
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int e = 0; e < 4; e++) {
     const uint32_t d0 = p2_pick<T>(cur, 0, e);
@@ -907,7 +924,8 @@ DEVFN void p2_consume_simple(const P2SimpleOp (&so)[PG_P2_SIMPLE_OPS], int n_ops
       if (so[o].fn == PG_ACC_COUNT) { atomicAdd(reinterpret_cast<uint32_t*>(acc), 1u); continue; }   // (a work item sees < 2^32 tuples)
       if (so[o].fn == PG_P2_SIMPLE_DOCID) { atomicMin(reinterpret_cast<long long*>(acc), (long long)p2_pick<T>(cur, so[o].plane, e)); continue; }   // MIN(docId)
       const uint32_t f = ((T == 1 ? d0 : p2_pick<T>(cur, so[o].plane, e)) >> so[o].shift) & so[o].mask;
-      const int64_t v = (int64_t)(int32_t)(f + so[o].bias);
+      int64_t v = (int64_t)(int32_t)(f + so[o].bias);
+      if (GATHER && so[o].vt != 0) v = gv[e][o];
       if (so[o].fn == PG_ACC_SUM) atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)v);
       else if (so[o].fn == PG_ACC_MIN) atomicMin(reinterpret_cast<long long*>(acc), (long long)v);
       else atomicMax(reinterpret_cast<long long*>(acc), (long long)v);
@@ -940,6 +958,8 @@ __device__ __forceinline__ void p2_aggregate_body(const PgQueryPlan& p) {
       so[o].shift = (uint32_t)p.pk_shift[src];
       so[o].mask = bits < 32u ? (1u << bits) - 1u : 0xFFFFFFFFu;
       so[o].bias = (uint32_t)p.p2_fbias[src];
+      so[o].vt = p.p2_fkind[src] == PG_P2_F_DICTID ? (p.srcs[src].val_type == PG_V_I32 ? 1 : 2) : 0;
+      so[o].dict = gptr<uint8_t>(p.srcs[src].dict);
     }
   }
   for (int w = (int)blockIdx.x; w < n_items; w += (int)gridDim.x) {
@@ -965,10 +985,10 @@ __device__ __forceinline__ void p2_aggregate_body(const PgQueryPlan& p) {
       bool on0 = p2_fetch<T>(tuples, plane_stride, list, n_list, (uint32_t)wave, lane, c0), on1 = false;
       for (uint32_t ci = (uint32_t)wave; ci < n_list; ci += 2u * WAVES) {
         on1 = p2_fetch<T>(tuples, plane_stride, list, n_list, ci + WAVES, lane, c1);
-        if (SIMPLE) p2_consume_simple<T>(so, p.n_ops, c0, on0, table, slots, local_mask);
+        if (SIMPLE) p2_consume_simple<T, GATHER>(so, p.n_ops, c0, on0, table, slots, local_mask);
         else p2_consume<T, GATHER>(p, c0, on0, table, aux_lds, slots, local_mask);
         on0 = p2_fetch<T>(tuples, plane_stride, list, n_list, ci + 2u * WAVES, lane, c0);
-        if (SIMPLE) p2_consume_simple<T>(so, p.n_ops, c1, on1, table, slots, local_mask);
+        if (SIMPLE) p2_consume_simple<T, GATHER>(so, p.n_ops, c1, on1, table, slots, local_mask);
         else p2_consume<T, GATHER>(p, c1, on1, table, aux_lds, slots, local_mask);
       }
     }
@@ -1000,10 +1020,12 @@ P2_AGGREGATE(pg_p2_aggregate_1n, 1, false)
 P2_AGGREGATE(pg_p2_aggregate_2n, 2, false)
 P2_AGGREGATE(pg_p2_aggregate_3n, 3, false)
 P2_AGGREGATE(pg_p2_aggregate_4n, 4, false)
-#define P2_AGGREGATE_SIMPLE(NAME, T) \
-  extern "C" __global__ void __launch_bounds__(PG_P2_AGG_THREADS) NAME(const PgQueryPlan p) { p2_aggregate_body<T, false, true>(p); }
-P2_AGGREGATE_SIMPLE(pg_p2_aggregate_1s, 1)
-P2_AGGREGATE_SIMPLE(pg_p2_aggregate_2s, 2)
+#define P2_AGGREGATE_SIMPLE(NAME, T, GATHER) \
+  extern "C" __global__ void __launch_bounds__(PG_P2_AGG_THREADS) NAME(const PgQueryPlan p) { p2_aggregate_body<T, GATHER, true>(p); }
+P2_AGGREGATE_SIMPLE(pg_p2_aggregate_1s, 1, false)
+P2_AGGREGATE_SIMPLE(pg_p2_aggregate_2s, 2, false)
+P2_AGGREGATE_SIMPLE(pg_p2_aggregate_1sg, 1, true)
+P2_AGGREGATE_SIMPLE(pg_p2_aggregate_2sg, 2, true)
 
 // ---- aggregation pass of the pruned-offer passes (pg_kernels_oct.hip): HyperLogLog offers only (COUNT is kept by pg_oct_p), registers as
 // BYTES — 512 groups x 256 registers per bucket instead of 82 as dwords, i.e. 25 buckets instead of 157 for config 5: the stream scatter

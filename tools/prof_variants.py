@@ -124,6 +124,7 @@ QUERIES_GENERAL = {   # shapes outside the specialised kernels: several scans, O
     "or of 2 scans count": ("SELECT COUNT(*) FROM t WHERE r_int < 100000 OR m > 900000", 8.0),
     "dict scan + raw scan": ("SELECT COUNT(*) FROM t WHERE g1 < 50 AND r_int < 500000", 4.875),
     "group g1,g2,c_inv1 (40k groups)": ("SELECT g1, g2, c_inv1, COUNT(*), SUM(m) FROM t GROUP BY g1, g2, c_inv1 LIMIT 100000", 6.0),
+    "40k groups, sum of a dictionary column": ("SELECT g1, g2, c_inv1, COUNT(*), SUM(c_inv2), MAX(c_inv2) FROM t GROUP BY g1, g2, c_inv1 LIMIT 100000", 2.25),
     "filtered 40k groups": ("SELECT g1, g2, c_inv1, SUM(m) FROM t WHERE r_int < 125000 GROUP BY g1, g2, c_inv1 LIMIT 100000", 10.0),
     "group g1,g2,c_inv1,c_inv2 (160k)": ("SELECT g1, g2, c_inv1, c_inv2, COUNT(*), SUM(m), MAX(m) FROM t GROUP BY g1, g2, c_inv1, c_inv2 LIMIT 200000", 6.25),
     "cfg3 filter, 160k groups": ("SELECT g1, g2, c_inv1, c_inv2, SUM(m) FROM t WHERE c_inv1 IN (0,1,2,3) AND c_inv2 IN (0,1) AND r_int BETWEEN 250000 AND 749999 GROUP BY g1, g2, c_inv1, c_inv2 LIMIT 200000", 11.0),
