@@ -205,12 +205,15 @@ typedef struct pg_query {
                                               AggregationFunction#extractFinalResult), not as the intermediate set / registers: for a caller that
                                               merges nothing afterwards (one segment, or after pg_result_merge / _all_reduce).  The states stay in
                                               HBM; two integers per group come back (3.3 MB of registers -> 200 KB on BASELINE config 5) */
-#define PG_QUERY_FLAG_NULL_HANDLING 0x40   /* QueryContext#isNullHandlingEnabled.  Taken when it cannot change the answer — no column the query reads
-                                              (filter, GROUP BY, aggregation arguments) holds a null in this segment, which is also when the reference
-                                              keeps its ordinary plan (AggregationPlanNode.java:104-121 hasNullValues, StarTreeUtils.java:381-400) — and
-                                              refused (PG_ERR_UNSUPPORTED: the Java plan answers) otherwise: null-aware filters (three-valued AND / OR /
-                                              NOT), null group keys and null-skipping aggregations are not on the GPU path.  An aggregation without
-                                              GROUP BY that matches no doc is refused as well: its SUM / MIN / MAX results would be null */
+#define PG_QUERY_FLAG_NULL_HANDLING 0x40   /* QueryContext#isNullHandlingEnabled (query option enableNullHandling=true).  Filters are evaluated in
+                                              three-valued logic (see pg_filter_exec_flags); an aggregation skips the docs whose argument is null
+                                              (NullableSingleInputAggregationFunction#forEachNotNull) — COUNT(col) counts the values, SUM / MIN / MAX / AVG /
+                                              MINMAXRANGE over no value are NULL (pg_result_agg_nulls), the distinct counts an empty set; a null is a
+                                              group key of its own (pg_result_group_key_nulls).  A star-tree answers only when no column the query reads
+                                              holds a null (StarTreeUtils.java:381-418); a lone COUNT(*) over an index-only filter is still
+                                              FastFilteredCountOperator, which knows no nulls (AggregationPlanNode.java:104-108).  Refused
+                                              (PG_ERR_UNSUPPORTED: the Java plan answers): nulls in a multi-value column or in a no-dictionary
+                                              group-by column, more than 3 nullable group-by columns, PG_QUERY_FLAG_KEEP_DEVICE_TABLE next to nulls */
 #define PG_QUERY_FLAG_KEEP_DEVICE_TABLE 0x4 /* keep the dense accumulator table in HBM with the result (pg_result_merge / _all_reduce) */
 
 /* ExecutionStatistics (pinot-core/.../operator/ExecutionStatistics.java) + device timings. */
@@ -335,6 +338,12 @@ int32_t pg_segment_destroy(pg_segment_t segment);
 /* ---- FilterOperator + DocIdSetOperator: BaseFilterOperator#nextBlock → FilterBlock#getBlockDocIdSet ----------------
  * (pinot-core/.../operator/filter/BaseFilterOperator.java, DocIdSetOperator.java:59-86). */
 int32_t pg_filter_exec(pg_segment_t segment, const pg_filter_node* filter, pg_docidset_t* out_docidset);
+/* The same under query options: `flags` takes PG_QUERY_FLAG_NULL_HANDLING (QueryContext#isNullHandlingEnabled) — the filter tree's getTrues
+ * in three-valued logic: a column predicate is true where it holds and the value is not null (BaseColumnFilterOperator.java:45-72), NOT
+ * matches where its child is false, not where it is null (BaseFilterOperator.java:105-122, AndFilterOperator.java:62-90,
+ * OrFilterOperator.java:61-87, NotFilterOperator.java:52-63); an always-true predicate matches the docs that hold a value
+ * (FilterOperatorUtils.java:78-88).  Other flags are ignored. */
+int32_t pg_filter_exec_flags(pg_segment_t segment, const pg_filter_node* filter, int32_t flags, pg_docidset_t* out_docidset);
 int32_t pg_docidset_cardinality(pg_docidset_t set, int64_t* out_cardinality);
 int32_t pg_docidset_num_words(pg_docidset_t set, int64_t* out_num_words);        /* ceil(numDocs/64) */
 int32_t pg_docidset_copy_words(pg_docidset_t set, uint64_t* out_words, int64_t capacity_words);
@@ -399,6 +408,12 @@ int32_t pg_result_hll_registers(pg_result_t result, int32_t agg, uint8_t* out_re
  * set elements ascending, no metadata entries (DataTableFactory.getDataTable(bytes) reads it).  out == NULL asks for the size only.
  * Not for results executed with PG_QUERY_FLAG_FINAL_DISTINCT (those are final values). */
 int32_t pg_result_data_table_v4(pg_result_t result, uint8_t* out, int64_t capacity, int64_t* out_size);
+/* Query-level null handling (PG_QUERY_FLAG_NULL_HANDLING): out[g] = 1 where group g's result of aggregation `agg` is NULL — SUM / MIN / MAX /
+ * AVG / MINMAXRANGE that saw no non-null value (the reference's holders stay null: SumAggregationFunction.java:100-131,180-215) — the value
+ * arrays hold 0 there; all 0 without the flag.  pg_result_group_key_nulls: out[g] = 1 where group g's key in group-by column `col` is NULL
+ * (the dictId / value arrays hold 0 there). */
+int32_t pg_result_agg_nulls(pg_result_t result, int32_t agg, uint8_t* out, int32_t capacity);
+int32_t pg_result_group_key_nulls(pg_result_t result, int32_t col, uint8_t* out, int32_t capacity);
 int32_t pg_result_stats(pg_result_t result, pg_exec_stats* out_stats);
 int32_t pg_result_free(pg_result_t result);
 

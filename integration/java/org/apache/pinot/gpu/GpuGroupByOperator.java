@@ -125,7 +125,8 @@ public class GpuGroupByOperator extends BaseOperator<BaseResultsBlock> {
           // AggregationFunction#extractAggregationResult's type (INTEGRATION.md §4 table): COUNT / COUNTMV hand a Long to
           // CountAggregationFunction#merge(Long, Long) and AggregationResultsBlock's `(long) result` (:165-166) — a Double there is a
           // ClassCastException (VERDICT r3); every other RESULT_* kind already is the function's intermediate object
-          results.add(intermediates(result, a, 1, functions[a], false)[0]);
+          // enableNullHandling: SUM / MIN / MAX / AVG / MINMAXRANGE over no value extract null (SumAggregationFunction.java:215-222)
+          results.add(isNull(result, a, 1)[0] ? null : intermediates(result, a, 1, functions[a], false)[0]);
         }
         return new AggregationResultsBlock(functions, results, _queryContext);
       }
@@ -169,10 +170,30 @@ public class GpuGroupByOperator extends BaseOperator<BaseResultsBlock> {
           }
         }
       }
+      if (_queryContext.isNullHandlingEnabled()) {   // a null is a group key of its own (the value-based key generators hold a null key)
+        for (int j = 0; j < groupBy.size(); j++) {
+          byte[] keyNulls = new byte[numGroups];
+          PinotGpu.resultGroupKeyNulls(result, j, keyNulls);
+          for (int g = 0; g < numGroups; g++) {
+            if (keyNulls[g] != 0) {
+              keys[g][j] = null;
+            }
+          }
+        }
+      }
       GroupByResultHolder[] holders = new GroupByResultHolder[functions.length];
       for (int a = 0; a < functions.length; a++) {
         Object[] values = intermediates(result, a, numGroups, functions[a], true);
-        boolean asDouble = values.length > 0 && values[0] instanceof Double;
+        boolean[] nulls = isNull(result, a, numGroups);
+        // under null handling SUM / MIN / MAX keep Double OBJECTS in an ObjectGroupByResultHolder, null where no value was seen
+        // (SumAggregationFunction.java:80-84,180-215); COUNT stays in its DoubleGroupByResultHolder
+        boolean nullable = _queryContext.isNullHandlingEnabled() && PinotGpu.resultKindOf(result, a) == PinotGpu.RESULT_DOUBLE;
+        for (int g = 0; g < numGroups; g++) {
+          if (nulls[g]) {
+            values[g] = null;
+          }
+        }
+        boolean asDouble = !nullable && values.length > 0 && values[0] instanceof Double;
         GroupByResultHolder holder = asDouble ? new DoubleGroupByResultHolder(Math.max(numGroups, 1), Math.max(numGroups, 1), 0.0)
             : new ObjectGroupByResultHolder(Math.max(numGroups, 1), Math.max(numGroups, 1));
         holder.ensureCapacity(Math.max(numGroups, 1));
@@ -201,6 +222,19 @@ public class GpuGroupByOperator extends BaseOperator<BaseResultsBlock> {
    *   forHolder = false  the OBJECT AggregationFunction#extractAggregationResult returns, i.e. getIntermediateResultColumnType
    *                      (COUNT: a Long, CountAggregationFunction.java:178-180,193-195)
    */
+  /** enableNullHandling: which of aggregation `a`'s results are NULL (none without the query option). */
+  private boolean[] isNull(long result, int a, int n) {
+    boolean[] out = new boolean[n];
+    if (_queryContext.isNullHandlingEnabled()) {
+      byte[] flags = new byte[n];
+      PinotGpu.resultAggNulls(result, a, flags);
+      for (int g = 0; g < n; g++) {
+        out[g] = flags[g] != 0;
+      }
+    }
+    return out;
+  }
+
   private Object[] intermediates(long result, int a, int n, AggregationFunction function, boolean forHolder) {
     Object[] out = new Object[n];
     switch (PinotGpu.resultKindOf(result, a)) {

@@ -71,14 +71,16 @@ public class GpuInstancePlanMaker extends InstancePlanMakerImplV2 {
   @Override
   public PlanNode makeSegmentPlanNode(SegmentContext segmentContext, QueryContext queryContext) {
     IndexSegment segment = segmentContext.getIndexSegment();
-    // (enableNullHandling travels in the query record: the library takes the query when none of its columns holds a null in this
-    // segment — the case in which AggregationPlanNode keeps its ordinary plan, AggregationPlanNode.java:104-121 — and refuses otherwise)
+    // (enableNullHandling travels in the query record: three-valued filters, null-skipping aggregations and null group keys are answered by
+    // the library — results and keys come back with NULL flags, GpuGroupByOperator#blockOf; it refuses nulls in multi-value columns and in
+    // no-dictionary group-by columns)
     if (segment instanceof ImmutableSegment && QueryContextUtils.isAggregationQuery(queryContext)) {
       long handle = _registry.handleFor((ImmutableSegment) segment, segmentContext);   // pins the columns in HBM on first use; 0: Java plan only
       if (handle != 0) {
         // with the library merge configured the group-by tables stay in HBM for GpuGroupByCombineOperator (PinotGpu.resultMerge /
         // resultAllReduce); without the combine patch the operators decode them one by one as before
-        boolean keep = _comms != null && queryContext.getGroupByExpressions() != null;
+        // (a null-handling result is joined on the host from its null partitions: no device table to keep — those merge by values in Java)
+        boolean keep = _comms != null && queryContext.getGroupByExpressions() != null && !queryContext.isNullHandlingEnabled();
         NativeQuery nativeQuery = NativeQuery.from(queryContext, keep ? PinotGpu.QUERY_FLAG_KEEP_DEVICE_TABLE : 0);
         if (nativeQuery != null) {
           if (PinotGpu.querySupported(handle, nativeQuery.address()) == PinotGpu.PG_OK) {

@@ -64,6 +64,9 @@ public final class PinotGpu {
   public static native void resultSetSizes(long result, int aggregation, int[] out);
   public static native void resultSetDictIds(long result, int aggregation, int[] out);
   public static native void resultHllRegisters(long result, int aggregation, byte[] out);
+  // enableNullHandling: out[g] = 1 where group g's result of the aggregation / key of the group-by column is NULL
+  public static native void resultAggNulls(long result, int aggregation, byte[] out);
+  public static native void resultGroupKeyNulls(long result, int groupByColumn, byte[] out);
   // the (merged) intermediate results as DataTableImplV4 bytes: DataTableFactory.getDataTable(ByteBuffer.wrap(bytes)) reads them
   public static native long resultDataTableV4Size(long result);
   public static native void resultDataTableV4(long result, byte[] out);

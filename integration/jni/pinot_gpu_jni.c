@@ -217,6 +217,9 @@ COPY_OUT(resultLongs(JNIEnv* env, jclass c, jlong r, jint agg, jint comp, jlongA
 COPY_OUT(resultSetSizes(JNIEnv* env, jclass c, jlong r, jint agg, jintArray out), jint, int32_t, GetIntArrayRegion, SetIntArrayRegion, pg_result_set_sizes(RES(r), agg, p, n))
 COPY_OUT(resultSetDictIds(JNIEnv* env, jclass c, jlong r, jint agg, jintArray out), jint, int32_t, GetIntArrayRegion, SetIntArrayRegion, pg_result_set_dict_ids(RES(r), agg, p, (int64_t)n))
 COPY_OUT(resultHllRegisters(JNIEnv* env, jclass c, jlong r, jint agg, jbyteArray out), jbyte, uint8_t, GetByteArrayRegion, SetByteArrayRegion, pg_result_hll_registers(RES(r), agg, p, (int64_t)n))
+/* enableNullHandling: 1 where the group's result / key is NULL (pg_result_agg_nulls, pg_result_group_key_nulls) */
+COPY_OUT(resultAggNulls(JNIEnv* env, jclass c, jlong r, jint agg, jbyteArray out), jbyte, uint8_t, GetByteArrayRegion, SetByteArrayRegion, pg_result_agg_nulls(RES(r), agg, p, n))
+COPY_OUT(resultGroupKeyNulls(JNIEnv* env, jclass c, jlong r, jint col, jbyteArray out), jbyte, uint8_t, GetByteArrayRegion, SetByteArrayRegion, pg_result_group_key_nulls(RES(r), col, p, n))
 /* The result's DataTableImplV4 bytes (pg_result_data_table_v4): size first, then into a byte[] of that size — DataTableFactory.getDataTable(bytes)
  * on the Java side gives the DataTable a results block hands to InstanceResponseOperator without boxing a group */
 JNIEXPORT jlong JNICALL Java_org_apache_pinot_gpu_PinotGpu_resultDataTableV4Size(JNIEnv* env, jclass c, jlong r) {

@@ -739,13 +739,19 @@ po_filter_op* po_not_filter_operator(po_filter_op* child, int32_t num_docs) { /*
 }
 
 /* FilterPlanNode#constructPhysicalOperator, core/plan/FilterPlanNode.java:195-320 */
-static po_filter_op* construct_physical_operator(po_segment* seg, const pg_filter_node* f, int32_t num_docs) {
+static void set_null_handling(po_filter_op* op, int on) {   /* every operator of the tree is built with the query's flag */
+  if (!op) return;
+  op->null_handling = on;
+  for (int i = 0; i < op->n_children; i++) set_null_handling(op->children[i], on);
+}
+
+static po_filter_op* construct_physical_operator(po_segment* seg, const pg_filter_node* f, int32_t num_docs, int nh) {
   switch (f->type) {
     case PG_FILTER_AND: {
       po_filter_op** ch = (po_filter_op**)po_xcalloc((size_t)f->n_children + 1, sizeof(po_filter_op*));
       int m = 0;
       for (int i = 0; i < f->n_children; i++) {
-        po_filter_op* c = construct_physical_operator(seg, &f->children[i], num_docs);
+        po_filter_op* c = construct_physical_operator(seg, &f->children[i], num_docs, nh);
         if (!c) { free(ch); return NULL; }
         if (op_is_empty(c)) { free(ch); return po_op_new(PO_OP_EMPTY, num_docs); }
         if (!op_is_match_all(c)) ch[m++] = c;
@@ -758,7 +764,7 @@ static po_filter_op* construct_physical_operator(po_segment* seg, const pg_filte
       po_filter_op** ch = (po_filter_op**)po_xcalloc((size_t)f->n_children + 1, sizeof(po_filter_op*));
       int m = 0;
       for (int i = 0; i < f->n_children; i++) {
-        po_filter_op* c = construct_physical_operator(seg, &f->children[i], num_docs);
+        po_filter_op* c = construct_physical_operator(seg, &f->children[i], num_docs, nh);
         if (!c) { free(ch); return NULL; }
         if (op_is_match_all(c)) { free(ch); return po_op_new(PO_OP_MATCH_ALL, num_docs); }
         if (!op_is_empty(c)) ch[m++] = c;
@@ -768,7 +774,7 @@ static po_filter_op* construct_physical_operator(po_segment* seg, const pg_filte
       return r;
     }
     case PG_FILTER_NOT: {
-      po_filter_op* c = construct_physical_operator(seg, &f->children[0], num_docs);
+      po_filter_op* c = construct_physical_operator(seg, &f->children[0], num_docs, nh);
       if (!c) return NULL;
       return po_not_filter_operator(c, num_docs);
     }
@@ -788,6 +794,13 @@ static po_filter_op* construct_physical_operator(po_segment* seg, const pg_filte
       }
       po_pred_eval* eval = po_pred_eval_create(f, col);
       if (!eval) return NULL;
+      /* FilterOperatorUtils.java:78-88: an always-true predicate under null handling matches the docs that hold a value */
+      if (nh && eval->always_true && !eval->always_false && col->null_bitmap && po_bitmap_cardinality(col->null_bitmap) > 0) {
+        po_filter_op* op = po_op_new(PO_OP_BITMAP, num_docs);
+        op->bitmap = po_bitmap_clone(col->null_bitmap);
+        op->bitmap_exclusive = 1;
+        return op;
+      }
       return po_leaf_filter_operator(eval, col, num_docs);
     }
     case PG_FILTER_CONSTANT_TRUE: return po_op_new(PO_OP_MATCH_ALL, num_docs);
@@ -798,17 +811,20 @@ static po_filter_op* construct_physical_operator(po_segment* seg, const pg_filte
   }
 }
 
-po_filter_op* po_filter_plan(po_segment* seg, const pg_filter_node* filter) { /* FilterPlanNode.run :88-106 */
+po_filter_op* po_filter_plan(po_segment* seg, const pg_filter_node* filter, int null_handling) { /* FilterPlanNode.run :88-106 */
   po_filter_op* valid = NULL;
   if (seg->queryable_doc_ids) {
     valid = po_op_new(PO_OP_BITMAP, seg->total_docs);
     valid->bitmap = po_bitmap_clone(seg->queryable_doc_ids);
   }
   if (!filter) return valid ? valid : po_op_new(PO_OP_MATCH_ALL, seg->total_docs);
-  po_filter_op* op = construct_physical_operator(seg, filter, seg->total_docs);
-  if (!op || !valid) return op;
-  po_filter_op* both[2] = {op, valid};
-  return po_and_filter_operator(2, both, seg->total_docs);
+  po_filter_op* op = construct_physical_operator(seg, filter, seg->total_docs, null_handling);
+  if (op && valid) {
+    po_filter_op* both[2] = {op, valid};
+    op = po_and_filter_operator(2, both, seg->total_docs);
+  }
+  set_null_handling(op, null_handling);
+  return op;
 }
 
 /* ---- getTrues / getFalses -------------------------------------------------------------------------------------------------- */
@@ -876,7 +892,37 @@ static po_docidset* inverted_get_trues(po_filter_op* op) {
   return bitmapset_new(b, op->num_docs);
 }
 
+/* BaseColumnFilterOperator (Scan / Inverted / Sorted / RangeIndex leaves), core/operator/filter/BaseColumnFilterOperator.java:45-72: under
+ * null handling the docs whose value is null are neither true nor false */
+static int is_column_leaf(const po_filter_op* op) {
+  return op->kind == PO_OP_SCAN || op->kind == PO_OP_INVERTED || op->kind == PO_OP_SORTED || op->kind == PO_OP_RANGE_INDEX;
+}
+static const po_bitmap* op_null_bitmap(const po_filter_op* op) {   /* getNullBitmap: non-null and non-empty, else none */
+  if (!is_column_leaf(op) || !op->col) return NULL;
+  const po_column* c = op->col;
+  return c->null_bitmap && po_bitmap_cardinality(c->null_bitmap) > 0 ? c->null_bitmap : NULL;
+}
+static po_docidset* op_get_nulls(po_filter_op* op) {   /* getNulls: BaseFilterOperator.java:98-100 (empty), BaseColumnFilterOperator.java:56-64 */
+  const po_bitmap* nb = op_null_bitmap(op);
+  return nb ? bitmapset_new(po_bitmap_clone(nb), op->num_docs) : emptyset_new();
+}
+static po_docidset* trues_without_null_handling(po_filter_op* op);
+
 po_docidset* po_filter_get_trues(po_filter_op* op) {
+  const po_bitmap* nb = op->null_handling ? op_null_bitmap(op) : NULL;
+  if (nb) {   /* excludeNulls: AndDocIdSet(block, flip(nullBitmap)) */
+    po_docidset* sets[2];
+    sets[0] = trues_without_null_handling(op);
+    if (!sets[0]) return NULL;
+    po_bitmap* b = po_bitmap_clone(nb);
+    po_bitmap_flip(b, 0, op->num_docs);
+    sets[1] = bitmapset_new(b, op->num_docs);
+    return compoundset_new(PO_SET_AND, andset_iterator, 2, sets, op->num_docs);
+  }
+  return trues_without_null_handling(op);
+}
+
+static po_docidset* trues_without_null_handling(po_filter_op* op) {
   switch (op->kind) {
     case PO_OP_EMPTY: return emptyset_new();
     case PO_OP_MATCH_ALL: return matchallset_new(op->num_docs);
@@ -924,6 +970,14 @@ static po_docidset* op_get_falses(po_filter_op* op) {
         if (!t) { free(sets); return NULL; }
         if (t->kind == PO_SET_EMPTY) { free(sets); return matchallset_new(op->num_docs); }
         if (t->kind == PO_SET_MATCH_ALL) continue;
+        if (op->null_handling) {   /* :72-78: the child's nulls are not false either */
+          po_docidset* nu = op_get_nulls(op->children[i]);
+          if (nu->kind != PO_SET_EMPTY) {
+            po_docidset* both[2] = {t, nu};
+            sets[m++] = compoundset_new(PO_SET_OR, orset_iterator, 2, both, op->num_docs);
+            continue;
+          }
+        }
         sets[m++] = t;
       }
       po_docidset* r;
@@ -941,6 +995,14 @@ static po_docidset* op_get_falses(po_filter_op* op) {
         if (!t) { free(sets); return NULL; }
         if (t->kind == PO_SET_MATCH_ALL) { free(sets); return emptyset_new(); }
         if (t->kind == PO_SET_EMPTY) continue;
+        if (op->null_handling) {   /* :71-77 */
+          po_docidset* nu = op_get_nulls(op->children[i]);
+          if (nu->kind != PO_SET_EMPTY) {
+            po_docidset* both[2] = {t, nu};
+            sets[m++] = compoundset_new(PO_SET_OR, orset_iterator, 2, both, op->num_docs);
+            continue;
+          }
+        }
         sets[m++] = t;
       }
       po_docidset* r;
@@ -954,6 +1016,13 @@ static po_docidset* op_get_falses(po_filter_op* op) {
       po_docidset* t = po_filter_get_trues(op);
       if (!t) return NULL;
       if (t->kind == PO_SET_MATCH_ALL) return emptyset_new();
+      if (op->null_handling) {   /* :110-116 */
+        po_docidset* nu = op_get_nulls(op);
+        if (nu->kind != PO_SET_EMPTY) {
+          po_docidset* both[2] = {t, nu};
+          return notset_new(compoundset_new(PO_SET_OR, orset_iterator, 2, both, op->num_docs), op->num_docs);
+        }
+      }
       if (t->kind == PO_SET_EMPTY) return matchallset_new(op->num_docs);
       return notset_new(t, op->num_docs);
     }
@@ -980,7 +1049,12 @@ int po_filter_can_optimize_count(po_filter_op* op) {
 
 /* getNumMatchingDocs: and/or cardinalities of the children's bitmaps (BitmapCollection) == cardinality of the set */
 int32_t po_filter_num_matching_docs(po_filter_op* op) {
+  /* getNumMatchingDocs / getBitmaps answer from the operators' bitmaps, which know no nulls (InvertedIndexFilterOperator.java:103-131,
+   * AndFilterOperator.java:99-110): under null handling FastFilteredCountOperator still counts the docs whose stored default value matches */
+  const int nh = op->null_handling;
+  set_null_handling(op, 0);
   po_docidset* t = po_filter_get_trues(op);
+  set_null_handling(op, nh);
   if (!t) return -1;
   po_iter* it = t->iterator(t);
   int32_t n = 0;

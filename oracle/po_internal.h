@@ -228,6 +228,7 @@ struct po_filter_op {
   po_filter_op** children;
   po_bitmap* bitmap;      /* PO_OP_BITMAP */
   int bitmap_exclusive;   /* BitmapBasedFilterOperator._exclusive */
+  int null_handling;      /* BaseFilterOperator._nullHandlingEnabled (QueryContext#isNullHandlingEnabled) */
 };
 
 /* operator constructors shared with the star-tree filter (po_startree.c) */
@@ -241,7 +242,7 @@ po_filter_op* po_not_filter_operator(po_filter_op* child, int32_t num_docs);
 int po_star_tree_plan(po_segment* seg, po_star_tree* st, const pg_query* q, po_filter_op** out_op);
 int32_t po_star_tree_pair_index(const po_star_tree* st, int32_t function, const char* column);
 /* FilterPlanNode.run */
-po_filter_op* po_filter_plan(po_segment* seg, const pg_filter_node* filter);
+po_filter_op* po_filter_plan(po_segment* seg, const pg_filter_node* filter, int null_handling);
 po_docidset* po_filter_get_trues(po_filter_op* op);
 int po_filter_can_optimize_count(po_filter_op* op);
 int32_t po_filter_num_matching_docs(po_filter_op* op);

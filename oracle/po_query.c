@@ -193,9 +193,9 @@ typedef struct po_docidset_result {
   pg_exec_stats stats;
 } po_docidset_result;
 
-int32_t po_filter_exec(void* segp, const pg_filter_node* filter, void** out) {
+int32_t po_filter_exec_flags(void* segp, const pg_filter_node* filter, int32_t flags, void** out) {
   po_segment* seg = (po_segment*)segp;
-  po_filter_op* op = po_filter_plan(seg, filter);
+  po_filter_op* op = po_filter_plan(seg, filter, (flags & PG_QUERY_FLAG_NULL_HANDLING) != 0);
   if (!op) return PG_ERR_INVALID_ARGUMENT;
   po_docidset* set = po_filter_get_trues(op);
   if (!set) return PG_ERR_INVALID_ARGUMENT;
@@ -216,6 +216,7 @@ int32_t po_filter_exec(void* segp, const pg_filter_node* filter, void** out) {
   *out = r;
   return PG_OK;
 }
+int32_t po_filter_exec(void* segp, const pg_filter_node* filter, void** out) { return po_filter_exec_flags(segp, filter, 0, out); }
 int32_t po_docidset_cardinality(void* s, int64_t* out) { *out = ((po_docidset_result*)s)->cardinality; return PG_OK; }
 int32_t po_docidset_num_words(void* s, int64_t* out) {
   *out = (((po_docidset_result*)s)->num_docs + 63) / 64;
@@ -679,12 +680,14 @@ static int is_mv_function(int f) { return f >= PG_AGG_COUNTMV && f <= PG_AGG_DIS
 typedef struct agg_state {
   int function;
   po_column* col;          /* NULL for COUNT(*) */
+  po_column* null_col;     /* COUNT(col) under null handling: the column whose nulls are not counted */
   int32_t log2m;
   int32_t capacity;        /* number of group slots */
   double* d0;              /* DoubleGroupByResultHolder / sum / min */
   double* d1;              /* max of MinMaxRangePair */
   int64_t* l0;             /* AvgPair count */
   uint8_t* has;            /* ObjectGroupByResultHolder: result != null */
+  uint8_t* nn;             /* null handling: a non-null value reached the group (its result is not null) */
   int star;                /* aggregating a star-tree function-column pair column (pre-aggregated values) */
   po_bitmap** dict_bitmaps;/* DISTINCTCOUNT / HLL over dictionary columns: RoaringBitmap of dictIds */
   po_hll** hlls;           /* HLL over raw columns */
@@ -706,7 +709,8 @@ static void agg_ensure_capacity(agg_state* a, int32_t needed) { /* GroupByResult
   a->d1 = (double*)po_xrealloc(a->d1, sizeof(double) * (size_t)cap);
   a->l0 = (int64_t*)po_xrealloc(a->l0, sizeof(int64_t) * (size_t)cap);
   a->has = (uint8_t*)po_xrealloc(a->has, (size_t)cap);
-  for (int32_t i = old; i < cap; i++) { a->d0[i] = def0; a->d1[i] = def1; a->l0[i] = 0; a->has[i] = 0; }
+  a->nn = (uint8_t*)po_xrealloc(a->nn, (size_t)cap);
+  for (int32_t i = old; i < cap; i++) { a->d0[i] = def0; a->d1[i] = def1; a->l0[i] = 0; a->has[i] = 0; a->nn[i] = 0; }
   if (sv_function_of(a->function) == PG_AGG_DISTINCTCOUNT || sv_function_of(a->function) == PG_AGG_DISTINCTCOUNTHLL) {
     a->dict_bitmaps = (po_bitmap**)po_xrealloc(a->dict_bitmaps, sizeof(void*) * (size_t)cap);
     a->hlls = (po_hll**)po_xrealloc(a->hlls, sizeof(void*) * (size_t)cap);
@@ -1006,6 +1010,7 @@ typedef struct po_agg_result {
   int64_t* l[2];
   int32_t* set_sizes; int32_t* set_ids; int64_t set_total;
   uint8_t* hll; int32_t log2m;
+  uint8_t* nulls;            /* null handling: 1 where the group's result is null (NULL: none is) */
 } po_agg_result;
 
 typedef struct po_result_impl {
@@ -1016,6 +1021,7 @@ typedef struct po_result_impl {
   int64_t** key_values;      /* HOLDER_TUPLES: per value-keyed column the groups' LONG values / DOUBLE bits */
   uint8_t** key_bytes;       /* HOLDER_TUPLES: per raw STRING / BYTES column the groups' values back to back, */
   int64_t** key_bytes_off;   /*   and their offsets (num_groups + 1) */
+  uint8_t** key_nulls;       /* null handling: per group-by column 1 where the group's key is null (NULL: no null key) */
   po_agg_result* aggs;
   pg_exec_stats stats;
 } po_result_impl;
@@ -1093,10 +1099,9 @@ static double now_ms(void) {
 }
 
 int32_t po_result_free(void* r);
-/* PG_QUERY_FLAG_NULL_HANDLING (QueryContext#isNullHandlingEnabled): this restatement covers the case in which null handling cannot change
- * the answer — no column the query reads holds a null in the segment, which is when the reference keeps its ordinary plan
- * (AggregationPlanNode.java:104-121 hasNullValues, StarTreeUtils.java:381-400) — and refuses the rest like the product path does: null-aware
- * filters, null group keys and null-skipping aggregations are restated nowhere in this repository. */
+/* PG_QUERY_FLAG_NULL_HANDLING (QueryContext#isNullHandlingEnabled), restated natively (doc at a time, like everything in this oracle): filters
+ * in three-valued logic (po_filter.c), aggregations that skip the docs whose argument is null and are null over no value, null group keys.
+ * null_check_* below answer "does the query read a column that holds a null" — which is when a star-tree may not answer (StarTreeUtils.java:381-418). */
 static int null_check_column(po_segment* seg, const char* name) {
   if (!name || !strcmp(name, "*")) return 0;
   po_column* c = po_segment_column(seg, name);
@@ -1112,11 +1117,29 @@ static int null_check_filter(po_segment* seg, const pg_filter_node* f) {
   for (int i = 0; i < f->n_children; i++) if (null_check_filter(seg, &f->children[i])) return 1;
   return 0;
 }
+static const po_bitmap* col_nulls(const po_column* c) {   /* NullValueVectorReader#getNullBitmap, non-empty */
+  return c && c->null_bitmap && po_bitmap_cardinality(c->null_bitmap) > 0 ? c->null_bitmap : NULL;
+}
+/* What the restatement of query-level null handling leaves out (refused like the product path refuses it): nulls in multi-value columns and
+ * in no-dictionary group-by columns, nulls in a group-by column next to a multi-value group-by column. */
 static int null_handling_refused(po_segment* seg, const pg_query* q) {
   if (!(q->flags & PG_QUERY_FLAG_NULL_HANDLING)) return 0;
-  if (null_check_filter(seg, q->filter)) return 1;
-  for (int i = 0; i < q->n_group_by; i++) if (null_check_column(seg, q->group_by_columns[i])) return 1;
-  for (int i = 0; i < q->n_aggregations; i++) if (null_check_column(seg, q->aggregations[i].column)) return 1;
+  int mv_gb = 0, null_gb = 0;
+  for (int i = 0; i < q->n_group_by; i++) {
+    po_column* c = po_segment_column(seg, q->group_by_columns[i]);
+    if (!c) continue;
+    mv_gb |= c->is_mv;
+    if (col_nulls(c)) {
+      null_gb = 1;
+      if (c->is_mv || !c->has_dictionary) { po_set_error("enableNullHandling: nulls in the %s group-by column %s", c->is_mv ? "multi-value" : "no-dictionary", c->name); return 1; }
+    }
+  }
+  if (mv_gb && null_gb) { po_set_error("enableNullHandling: null group keys next to a multi-value group-by column"); return 1; }
+  for (int i = 0; i < q->n_aggregations; i++) {
+    const char* name = q->aggregations[i].column;
+    po_column* c = name && strcmp(name, "*") ? po_segment_column(seg, name) : NULL;
+    if (c && col_nulls(c) && c->is_mv) { po_set_error("enableNullHandling: nulls in the multi-value column %s", c->name); return 1; }
+  }
   return 0;
 }
 int32_t po_query_supported(void* seg, const pg_query* q) { return null_handling_refused((po_segment*)seg, q) ? PG_ERR_UNSUPPORTED : PG_OK; }
@@ -1131,7 +1154,7 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
   if (n_aggs <= 0) { po_set_error("query has no aggregation"); return PG_ERR_INVALID_ARGUMENT; }
   if (null_handling_refused(seg, q)) return PG_ERR_UNSUPPORTED;
 
-  po_filter_op* filter_op = po_filter_plan(seg, q->filter);
+  po_filter_op* filter_op = po_filter_plan(seg, q->filter, (q->flags & PG_QUERY_FLAG_NULL_HANDLING) != 0);
   if (!filter_op) return PG_ERR_INVALID_ARGUMENT;
 
   po_result_impl* res = (po_result_impl*)po_xcalloc(1, sizeof(*res));
@@ -1149,7 +1172,14 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
     const pg_agg_spec* s = &q->aggregations[i];
     aggs[i].function = s->function;
     aggs[i].log2m = s->log2m > 0 ? s->log2m : DEFAULT_LOG2M;
-    if (s->function == PG_AGG_COUNT) continue;   /* COUNT(*) takes no input expression */
+    if (s->function == PG_AGG_COUNT) {   /* COUNT(*) takes no input expression; COUNT(col) under null handling counts the values that are
+                                          * not null (CountAggregationFunction.java:88-98,118-131) */
+      if ((q->flags & PG_QUERY_FLAG_NULL_HANDLING) && s->column && strcmp(s->column, "*")) {
+        po_column* cc = po_segment_column(seg, s->column);
+        if (cc && col_nulls(cc) && !cc->is_mv) aggs[i].null_col = cc;
+      }
+      continue;
+    }
     po_column* c = po_segment_column(seg, s->column);
     if (!c) { po_set_error("column not found: %s", s->column ? s->column : "(null)"); return PG_ERR_NOT_FOUND; }
     if ((s->function == PG_AGG_DISTINCTCOUNT) && !c->has_dictionary) {
@@ -1189,7 +1219,11 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
       if (!gcols[j]->has_dictionary) { po_set_error("multi-value group-by next to a no-dictionary column is outside the hot path"); return PG_ERR_UNSUPPORTED; }
 
   /* AggregationPlanNode: FastFilteredCountOperator (core/plan/AggregationPlanNode.java:106-108,192-196) */
-  if (n_gb == 0 && n_aggs == 1 && aggs[0].function == PG_AGG_COUNT && po_filter_can_optimize_count(filter_op)) {
+  /* AggregationPlanNode.java:104-121: hasNullValues — null handling on and an aggregation argument with nulls — keeps the scanning plan */
+  const int nh = (q->flags & PG_QUERY_FLAG_NULL_HANDLING) != 0;
+  int has_null_values = 0;
+  for (int i = 0; i < n_aggs && nh; i++) has_null_values |= col_nulls(aggs[i].col) != NULL || aggs[i].null_col != NULL;
+  if (n_gb == 0 && n_aggs == 1 && aggs[0].function == PG_AGG_COUNT && !has_null_values && po_filter_can_optimize_count(filter_op)) {
     int32_t count = po_filter_num_matching_docs(filter_op);
     if (count < 0) return PG_ERR_INVALID_ARGUMENT;
     res->num_groups = 1;
@@ -1206,7 +1240,7 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
   /* NonScanBasedAggregationOperator (core/plan/AggregationPlanNode.java:110-120,165-190; core/operator/query/
    * NonScanBasedAggregationOperator.java:83-150,300-303): match-all filter, no GROUP BY, every aggregation is COUNT or a
    * dictionary-based function over a dictionary column → answered from the dictionaries, no doc is read */
-  if (n_gb == 0 && filter_op->kind == PO_OP_MATCH_ALL) {
+  if (n_gb == 0 && filter_op->kind == PO_OP_MATCH_ALL && !has_null_values) {
     int fit = 1;
     for (int i = 0; i < n_aggs && fit; i++) {
       int f = sv_function_of(aggs[i].function);   /* DICTIONARY_BASED_FUNCTIONS holds MINMV / MAXMV / MINMAXRANGEMV / DISTINCTCOUNT(HLL)MV as well */
@@ -1245,7 +1279,14 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
 
   /* AggregationFunctionUtils#buildAggregationInfo (:285-307): use a star-tree when the filter result is not empty and one
    * fits (StarTreeUtils#createStarTreeBasedProjectOperator); the operators then run over the star-tree's doc space. */
-  if (!(q->flags & PG_QUERY_FLAG_SKIP_STAR_TREE) && filter_op->kind != PO_OP_EMPTY) {
+  /* StarTreeUtils.java:381-418: under null handling a star-tree answers only if no column the query reads holds a null in this segment */
+  int star_tree_blocked = 0;
+  if (q->flags & PG_QUERY_FLAG_NULL_HANDLING) {
+    star_tree_blocked = null_check_filter(seg, q->filter);
+    for (int i = 0; i < q->n_group_by && !star_tree_blocked; i++) star_tree_blocked = null_check_column(seg, q->group_by_columns[i]);
+    for (int i = 0; i < q->n_aggregations && !star_tree_blocked; i++) star_tree_blocked = null_check_column(seg, q->aggregations[i].column);
+  }
+  if (!(q->flags & PG_QUERY_FLAG_SKIP_STAR_TREE) && filter_op->kind != PO_OP_EMPTY && !star_tree_blocked) {
     for (int t = 0; t < seg->n_star_trees; t++) {
       po_star_tree* st = seg->star_trees[t];
       po_filter_op* star_op = NULL;
@@ -1276,9 +1317,25 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
   }
 
   /* group key generator + holders (DefaultGroupByExecutor ctor, groupby/DefaultGroupByExecutor.java:79-140) */
+  /* null handling: a null is a group key of its own (the reference generates the keys from VALUES then: DefaultGroupByExecutor.java:106-120,
+   * NoDictionary*GroupKeyGenerator with a null key).  Restated over the dictIds: a nullable column takes one more id, `cardinality`, for null. */
+  const po_bitmap** gnull = (const po_bitmap**)po_xcalloc((size_t)n_gb + 1, sizeof(po_bitmap*));
+  po_column* gaug = (po_column*)po_xcalloc((size_t)n_gb + 1, sizeof(po_column));
+  po_column** gkg_cols = (po_column**)po_xcalloc((size_t)n_gb + 1, sizeof(po_column*));
+  int32_t** gbuf = (int32_t**)po_xcalloc((size_t)n_gb + 1, sizeof(int32_t*));
+  for (int j = 0; j < n_gb; j++) {
+    gkg_cols[j] = gcols[j];
+    if (!nh || res->stats.star_tree_index >= 0) continue;
+    gnull[j] = col_nulls(gcols[j]);
+    if (!gnull[j]) continue;
+    gaug[j] = *gcols[j];
+    gaug[j].cardinality += 1;
+    gkg_cols[j] = &gaug[j];
+    gbuf[j] = (int32_t*)po_xmalloc(sizeof(int32_t) * PO_MAX_DOC_PER_CALL);
+  }
   group_key_gen gkg;
   if (n_gb > 0) {
-    if (gkg_init(&gkg, n_gb, gcols, num_groups_limit, max_init_cap)) return PG_ERR_UNSUPPORTED;
+    if (gkg_init(&gkg, n_gb, gkg_cols, num_groups_limit, max_init_cap)) return PG_ERR_UNSUPPORTED;
     int32_t max_results = gkg.global_upper_bound;
     int32_t initial = max_results < max_init_cap ? max_results : max_init_cap;
     for (int i = 0; i < n_aggs; i++) agg_ensure_capacity(&aggs[i], initial > 0 ? initial : 1);
@@ -1308,6 +1365,10 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
   int32_t* mvk = NULL;
   int32_t mvk_cap = 0;
   int32_t** gdict = (int32_t**)po_xcalloc((size_t)n_gb + 1, sizeof(int32_t*));
+  int32_t* cdocs = (int32_t*)po_xmalloc(sizeof(int32_t) * PO_MAX_DOC_PER_CALL);     /* null handling: the block's docs whose argument is not null */
+  int32_t* ckeys = (int32_t*)po_xmalloc(sizeof(int32_t) * PO_MAX_DOC_PER_CALL);
+  int32_t* cdict = (int32_t*)po_xmalloc(sizeof(int32_t) * PO_MAX_DOC_PER_CALL);
+  double* cdoubles = (double*)po_xmalloc(sizeof(double) * PO_MAX_DOC_PER_CALL);
   int64_t num_docs_scanned = 0;
   int32_t cur = 0;
   while (cur != PO_EOF) {
@@ -1339,12 +1400,20 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
           if (!gcols[j]->has_dictionary) continue;
           for (int k = 0; k < n_proj; k++)
             if (bcols[k].col == gcols[j]) { fetch_dict_ids(&bcols[k], doc_ids, pos); gdict[j] = bcols[k].dict_ids; }
+          if (gnull[j]) {
+            for (int i = 0; i < pos; i++) gbuf[j][i] = po_bitmap_contains(gnull[j], doc_ids[i]) ? gcols[j]->cardinality : gdict[j][i];
+            gdict[j] = gbuf[j];
+          }
         }
         gkg_generate_tuples(&gkg, pos, doc_ids, gdict, group_keys);
       } else {
         for (int j = 0; j < n_gb; j++) {
           for (int k = 0; k < n_proj; k++)
             if (bcols[k].col == gcols[j]) { fetch_dict_ids(&bcols[k], doc_ids, pos); gdict[j] = bcols[k].dict_ids; }
+          if (gnull[j]) {
+            for (int i = 0; i < pos; i++) gbuf[j][i] = po_bitmap_contains(gnull[j], doc_ids[i]) ? gcols[j]->cardinality : gdict[j][i];
+            gdict[j] = gbuf[j];
+          }
         }
         gkg_generate(&gkg, pos, gdict, group_keys);
       }
@@ -1355,7 +1424,28 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
     for (int i = 0; i < n_aggs; i++) {
       block_col* bc = NULL;
       for (int k = 0; k < n_proj; k++) if (bcols[k].col == aggs[i].col) bc = &bcols[k];
+      /* null handling: the docs whose argument is null are skipped (NullableSingleInputAggregationFunction#forEachNotNull / foldNotNull: the
+       * non-null ranges of the block in order; the per-range inner sums of SUM / AVG without GROUP BY are folded here in one pass over the
+       * non-null docs — the same value whenever the partial sums are exact) */
+      const po_bitmap* an = (nh && res->stats.star_tree_index < 0) ? col_nulls(aggs[i].null_col ? aggs[i].null_col : aggs[i].col) : NULL;
+      if (an && !mv_group_by) {
+        int cn = 0;
+        for (int d = 0; d < pos; d++)
+          if (!po_bitmap_contains(an, doc_ids[d])) { cdocs[cn] = doc_ids[d]; if (keys) ckeys[cn] = keys[d]; cn++; }
+        if (cn == 0) continue;
+        block_col tmp;
+        memset(&tmp, 0, sizeof(tmp));
+        if (bc) { tmp.col = bc->col; tmp.dict_ids = cdict; tmp.doubles = cdoubles; }
+        agg_process_block(&aggs[i], bc ? &tmp : NULL, cdocs, cn, keys ? ckeys : NULL, NULL, NULL);
+        if (keys) { for (int d = 0; d < cn; d++) if (ckeys[d] != PO_INVALID_ID) aggs[i].nn[ckeys[d]] = 1; }
+        else aggs[i].nn[0] = 1;
+        continue;
+      }
       agg_process_block(&aggs[i], bc, doc_ids, pos, keys, mv_group_by ? mvk_off : NULL, mvk);
+      if (nh && !mv_group_by) {   /* no nulls in the argument: every group a doc reached holds a value */
+        if (keys) { for (int d = 0; d < pos; d++) if (keys[d] != PO_INVALID_ID) aggs[i].nn[keys[d]] = 1; }
+        else aggs[i].nn[0] = 1;
+      }
     }
   }
 
@@ -1429,22 +1519,34 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
       raw /= gkg.cardinalities[j];
     }
   }
+  for (int j = 0; j < n_gb; j++) {   /* the id one past the dictionary is the null key */
+    if (!gnull[j]) continue;
+    if (!res->key_nulls) res->key_nulls = (uint8_t**)po_xcalloc((size_t)n_gb + 1, sizeof(uint8_t*));
+    res->key_nulls[j] = (uint8_t*)po_xcalloc((size_t)n_groups + 1, 1);
+    for (int32_t i = 0; i < n_groups; i++)
+      if (res->group_dict_ids[j][i] == gcols[j]->cardinality) { res->key_nulls[j][i] = 1; res->group_dict_ids[j][i] = 0; }
+  }
   res->aggs = (po_agg_result*)po_xcalloc((size_t)n_aggs, sizeof(po_agg_result));
   for (int i = 0; i < n_aggs; i++) {
     if (n_gb > 0) agg_ensure_capacity(&aggs[i], (gkg.holder == HOLDER_ARRAY ? gkg.global_upper_bound : n_groups) + 1);
     extract_agg(&res->aggs[i], &aggs[i], n_groups, gid_of);
+    /* null handling: SUM / MIN / MAX / AVG / MINMAXRANGE of no value are null (the holders stay null: SumAggregationFunction.java:100-131,
+     * 180-215; COUNT is 0, the distinct counts an empty set) */
+    const int f = sv_function_of(aggs[i].function);
+    if (nh && res->stats.star_tree_index < 0 && !mv_group_by && (f == PG_AGG_SUM || f == PG_AGG_MIN || f == PG_AGG_MAX || f == PG_AGG_AVG || f == PG_AGG_MINMAXRANGE)) {
+      res->aggs[i].nulls = (uint8_t*)po_xcalloc((size_t)n_groups + 1, 1);
+      for (int32_t g = 0; g < n_groups; g++)
+        if (!aggs[i].nn[gid_of[g]]) {
+          res->aggs[i].nulls[g] = 1;
+          for (int k = 0; k < 2; k++) { res->aggs[i].d[k][g] = 0; res->aggs[i].l[k][g] = 0; }
+        }
+    }
   }
   res->stats.num_docs_scanned = num_docs_scanned;
   res->stats.num_entries_scanned_in_filter = set->num_entries_scanned(set);
   res->stats.num_entries_scanned_post_filter = num_docs_scanned * n_proj;
   if (n_gb > 0) res->stats.num_groups_limit_reached = gkg_num_keys(&gkg) >= num_groups_limit;
   res->stats.host_ms_total = (float)(now_ms() - t0);
-  if ((q->flags & PG_QUERY_FLAG_NULL_HANDLING) && n_gb == 0 && num_docs_scanned == 0) {
-    /* AggregationOperator under null handling over no doc: SUM / MIN / MAX extract null — not restated (see null_handling_refused) */
-    po_result_free(res);
-    po_set_error("enableNullHandling: no doc matches — the aggregations' results are null");
-    return PG_ERR_UNSUPPORTED;
-  }
   *out = res;
   return PG_OK;
 }
@@ -1530,16 +1632,30 @@ int32_t po_result_hll_registers(void* r, int32_t agg, uint8_t* out, int64_t cap)
   memcpy(out, RES(r)->aggs[agg].hll, (size_t)n);
   return PG_OK;
 }
+int32_t po_result_agg_nulls(void* r, int32_t agg, uint8_t* out, int32_t cap) {
+  if (bad_agg(r, agg) || cap < RES(r)->num_groups) { po_set_error("bad aggregation/capacity"); return PG_ERR_INVALID_ARGUMENT; }
+  if (RES(r)->aggs[agg].nulls) memcpy(out, RES(r)->aggs[agg].nulls, (size_t)RES(r)->num_groups);
+  else memset(out, 0, (size_t)RES(r)->num_groups);
+  return PG_OK;
+}
+int32_t po_result_group_key_nulls(void* r, int32_t col, uint8_t* out, int32_t cap) {
+  if (col < 0 || col >= RES(r)->n_group_cols || cap < RES(r)->num_groups) { po_set_error("bad column/capacity"); return PG_ERR_INVALID_ARGUMENT; }
+  if (RES(r)->key_nulls && RES(r)->key_nulls[col]) memcpy(out, RES(r)->key_nulls[col], (size_t)RES(r)->num_groups);
+  else memset(out, 0, (size_t)RES(r)->num_groups);
+  return PG_OK;
+}
 int32_t po_result_stats(void* r, pg_exec_stats* out) { *out = RES(r)->stats; return PG_OK; }
 int32_t po_result_free(void* r) {
   po_result_impl* res = RES(r);
   for (int i = 0; i < res->n_aggs && res->aggs; i++) {
     for (int k = 0; k < 2; k++) { free(res->aggs[i].d[k]); free(res->aggs[i].l[k]); }
-    free(res->aggs[i].set_sizes); free(res->aggs[i].set_ids); free(res->aggs[i].hll);
+    free(res->aggs[i].set_sizes); free(res->aggs[i].set_ids); free(res->aggs[i].hll); free(res->aggs[i].nulls);
   }
   free(res->aggs);
   for (int j = 0; j < res->n_group_cols && res->group_dict_ids; j++) free(res->group_dict_ids[j]);
   free(res->group_dict_ids);
+  for (int j = 0; j < res->n_group_cols && res->key_nulls; j++) free(res->key_nulls[j]);
+  free(res->key_nulls);
   free(res);
   return PG_OK;
 }

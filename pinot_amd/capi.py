@@ -167,12 +167,12 @@ GPU_LIB_PATH = os.environ.get("PG_GPU_LIB") or os.path.join(REPO_ROOT, "pinot_am
 ABI_SYMBOLS = [
     "abi_version", "init", "device_count", "last_error",
     "segment_create", "segment_add_column", "segment_add_star_tree", "segment_set_null_vector", "segment_set_range_index", "segment_set_queryable_doc_ids", "segment_num_docs", "segment_device_bytes", "segment_destroy",
-    "filter_exec", "docidset_cardinality", "docidset_num_words", "docidset_copy_words", "docidset_copy_docids",
+    "filter_exec", "filter_exec_flags", "docidset_cardinality", "docidset_num_words", "docidset_copy_words", "docidset_copy_docids",
     "docidset_stats", "docidset_free",
     "query_supported", "query_exec",
     "result_num_groups", "result_group_dict_ids", "result_group_key_type", "result_group_values_long", "result_group_values_double",
     "result_group_values_bytes_size", "result_group_values_bytes", "result_kind_of", "result_doubles", "result_longs",
-    "result_set_sizes", "result_set_dict_ids", "result_hll_registers", "result_stats", "result_free",
+    "result_set_sizes", "result_set_dict_ids", "result_hll_registers", "result_agg_nulls", "result_group_key_nulls", "result_stats", "result_free",
 ]
 # entry points only the product library has (the CPU oracle is one segment, one thread, no devices): multi-GPU placement,
 # cancellation, the dense cross-segment merge and its RCCL communicators
@@ -219,6 +219,7 @@ class NativeApi:
         self.f("segment_device_bytes").argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         self.f("segment_destroy").argtypes = [C.c_void_p]
         self.f("filter_exec").argtypes = [C.c_void_p, C.POINTER(PgFilterNode), C.POINTER(C.c_void_p)]
+        self.f("filter_exec_flags").argtypes = [C.c_void_p, C.POINTER(PgFilterNode), C.c_int32, C.POINTER(C.c_void_p)]
         self.f("docidset_cardinality").argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         self.f("docidset_num_words").argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
         self.f("docidset_copy_words").argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
@@ -243,6 +244,8 @@ class NativeApi:
         self.f("result_set_sizes").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
         self.f("result_set_dict_ids").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
         self.f("result_hll_registers").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+        self.f("result_agg_nulls").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        self.f("result_group_key_nulls").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
         self.f("result_stats").argtypes = [C.c_void_p, C.POINTER(PgExecStats)]
         self.f("result_free").argtypes = [C.c_void_p]
 

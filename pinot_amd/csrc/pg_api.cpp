@@ -133,14 +133,17 @@ int32_t pg_segment_destroy(pg_segment_t segment) {
   });
 }
 
-int32_t pg_filter_exec(pg_segment_t segment, const pg_filter_node* filter, pg_docidset_t* out_docidset) {
+int32_t pg_filter_exec_flags(pg_segment_t segment, const pg_filter_node* filter, int32_t flags, pg_docidset_t* out_docidset) {
   return guarded([&] {
     REQUIRE(segment && out_docidset, "null argument");
-    auto s = execute_filter(segment->seg, filter);
+    auto s = execute_filter(segment->seg, filter, flags);
     auto* h = new pg_docidset_s();
     h->s = std::move(s);
     *out_docidset = h;
   });
+}
+int32_t pg_filter_exec(pg_segment_t segment, const pg_filter_node* filter, pg_docidset_t* out_docidset) {
+  return pg_filter_exec_flags(segment, filter, 0, out_docidset);
 }
 int32_t pg_docidset_cardinality(pg_docidset_t set, int64_t* out) {
   return guarded([&] { REQUIRE(set && out, "null argument"); *out = set->s->cardinality; });
@@ -393,6 +396,24 @@ int32_t pg_result_data_table_v4(pg_result_t result, uint8_t* out, int64_t capaci
     if (!out) return;                              // size query
     REQUIRE(capacity >= (int64_t)b.size(), "capacity too small");
     memcpy(out, b.data(), b.size());
+  });
+}
+int32_t pg_result_agg_nulls(pg_result_t result, int32_t agg, uint8_t* out, int32_t capacity) {
+  return guarded([&] {
+    REQUIRE(result && out, "null argument");
+    const Result& r = *result->r;
+    REQUIRE(agg >= 0 && agg < (int32_t)r.aggs.size() && capacity >= r.num_groups, "bad aggregation / capacity");
+    if ((size_t)agg < r.agg_nulls.size() && !r.agg_nulls[(size_t)agg].empty()) memcpy(out, r.agg_nulls[(size_t)agg].data(), (size_t)r.num_groups);
+    else memset(out, 0, (size_t)r.num_groups);
+  });
+}
+int32_t pg_result_group_key_nulls(pg_result_t result, int32_t col, uint8_t* out, int32_t capacity) {
+  return guarded([&] {
+    REQUIRE(result && out, "null argument");
+    const Result& r = *result->r;
+    REQUIRE(col >= 0 && col < (int32_t)r.group_key_type.size() && capacity >= r.num_groups, "bad column / capacity");
+    if ((size_t)col < r.key_nulls.size() && !r.key_nulls[(size_t)col].empty()) memcpy(out, r.key_nulls[(size_t)col].data(), (size_t)r.num_groups);
+    else memset(out, 0, (size_t)r.num_groups);
   });
 }
 int32_t pg_result_stats(pg_result_t result, pg_exec_stats* out_stats) {

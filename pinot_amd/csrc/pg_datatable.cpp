@@ -115,6 +115,8 @@ std::string dict_bytes(const ResultColumn& c, int32_t id, bool strip_padding) {
 std::vector<uint8_t> result_data_table_v4(const Result& r) {
   const int n_keys = (int)r.schema_keys.size(), n_aggs = (int)r.schema_aggs.size();
   if (n_aggs != (int)r.aggs.size()) fail(PG_ERR_INVALID_ARGUMENT, "result carries no schema (not produced by pg_query_exec)");
+  for (const auto& v : r.agg_nulls) if (!v.empty()) fail(PG_ERR_UNSUPPORTED, "data table of a result with NULL values (enableNullHandling): the null vectors of DataTableImplV4 are not written");
+  for (const auto& v : r.key_nulls) if (!v.empty()) fail(PG_ERR_UNSUPPORTED, "data table of a result with NULL keys (enableNullHandling): the null vectors of DataTableImplV4 are not written");
   const int32_t n_rows = n_keys ? r.num_groups : 1;
   // ---- schema -------------------------------------------------------------------------------------------------------------------------
   std::vector<std::string> names;

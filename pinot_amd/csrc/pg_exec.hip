@@ -379,13 +379,13 @@ static double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-std::shared_ptr<CompiledPlan> get_plan(Segment& seg, const pg_filter_node* filter, const pg_query* q) {
-  std::string sig = query_signature(filter, q);
+std::shared_ptr<CompiledPlan> get_plan(Segment& seg, const pg_filter_node* filter, const pg_query* q, int32_t flags) {
+  std::string sig = query_signature(filter, q, flags);
   // compilation stays under the segment's lock: it fills per-column caches (HyperLogLog look-up tables) and uploads leaves
   std::lock_guard<std::mutex> g(seg.mu);
   auto it = seg.plan_cache.find(sig);
   if (it != seg.plan_cache.end()) return it->second;
-  auto plan = compile_plan(seg, filter, q);
+  auto plan = compile_plan(seg, filter, q, flags);
   if (seg.plan_cache.size() > 256) seg.plan_cache.clear();
   seg.plan_cache[sig] = plan;
   return plan;
@@ -767,12 +767,32 @@ static void run_oct_pruned(CompiledPlan& P, PgQueryPlan& D, ThreadCtx& ctx, cons
   (void)n_out;
 }
 
-std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const CancelToken* cancel) {
+// the columns' names, types and host dictionaries, for pg_result_data_table_v4
+void fill_result_schema(Segment& seg, const pg_query& q, Result& r) {
+  Result* res = &r;
+    auto column_of = [&](const char* name, ResultColumn& rc) {
+      rc.name = name ? name : "*";
+      Column* c = name ? seg.find(name) : nullptr;
+      if (c) {
+        rc.data_type = c->data_type;
+        if (c->has_dictionary && !c->dict_host.empty()) { rc.dict = c->dict_host.data(); rc.dict_width = c->dict_bytes_per_value; }
+      }
+    };
+    res->schema_keys.resize((size_t)q.n_group_by);
+    for (int j = 0; j < q.n_group_by; j++) column_of(q.group_by_columns[j], res->schema_keys[(size_t)j]);
+    res->schema_aggs.resize((size_t)q.n_aggregations);
+    for (int a = 0; a < q.n_aggregations; a++) {
+      const char* col = q.aggregations[a].column;
+      column_of(col && strcmp(col, "*") != 0 ? col : nullptr, res->schema_aggs[(size_t)a]);
+      res->schema_aggs[(size_t)a].function = q.aggregations[a].function;
+    }
+  }
+
+std::unique_ptr<Result> execute_query_plain(Segment& seg, const pg_query& q, const CancelToken* cancel) {
   const double t0 = now_ms();
   if (q.n_aggregations <= 0 || !q.aggregations) fail(PG_ERR_INVALID_ARGUMENT, "query has no aggregation");
   check_cancel(cancel, nullptr);
   ThreadCtx& ctx = ctx_on(seg.device);
-  check_null_handling(seg, q);
   auto plan = get_plan(seg, q.filter, &q);
   CompiledPlan& P = *plan;
   const double t_plan = now_ms();
@@ -1309,28 +1329,9 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
     H.full_scan_entries = exact_entries;
     for (int i = 1; i < PG_MAX_STATS; i++) H.stats[i] = 0;
   }
-  if ((q.flags & PG_QUERY_FLAG_NULL_HANDLING) && q.n_group_by == 0 && H.stats[0] == 0)
-    fail(PG_ERR_UNSUPPORTED, "enableNullHandling: no doc matches — the aggregations' results are null (the Java plan answers)");
   const double t_before_assembly = now_ms();
   assemble_result(*res, P, q.n_group_by, q.n_aggregations, H);
-  {   // the columns' names, types and host dictionaries, for pg_result_data_table_v4
-    auto column_of = [&](const char* name, ResultColumn& rc) {
-      rc.name = name ? name : "*";
-      Column* c = name ? seg.find(name) : nullptr;
-      if (c) {
-        rc.data_type = c->data_type;
-        if (c->has_dictionary && !c->dict_host.empty()) { rc.dict = c->dict_host.data(); rc.dict_width = c->dict_bytes_per_value; }
-      }
-    };
-    res->schema_keys.resize((size_t)q.n_group_by);
-    for (int j = 0; j < q.n_group_by; j++) column_of(q.group_by_columns[j], res->schema_keys[(size_t)j]);
-    res->schema_aggs.resize((size_t)q.n_aggregations);
-    for (int a = 0; a < q.n_aggregations; a++) {
-      const char* col = q.aggregations[a].column;
-      column_of(col && strcmp(col, "*") != 0 ? col : nullptr, res->schema_aggs[(size_t)a]);
-      res->schema_aggs[(size_t)a].function = q.aggregations[a].function;
-    }
-  }
+  fill_result_schema(seg, q, *res);
   {
     static const bool trace = getenv("PG_TRACE_HOST") != nullptr;   // debugging knob: where the host time of a query goes
     if (trace)
@@ -1740,10 +1741,10 @@ void result_merge(Result& dst, Result& src) {
   result_reassemble(dst);
 }
 
-std::unique_ptr<DocIdSet> execute_filter(Segment& seg, const pg_filter_node* filter) {
+std::unique_ptr<DocIdSet> execute_filter(Segment& seg, const pg_filter_node* filter, int32_t flags) {
   const double t0 = now_ms();
   ThreadCtx& ctx = ctx_on(seg.device);
-  auto plan = get_plan(seg, filter, nullptr);
+  auto plan = get_plan(seg, filter, nullptr, flags);
   CompiledPlan& P = *plan;
   auto out = std::make_unique<DocIdSet>();
   out->device = seg.device;

@@ -309,8 +309,8 @@ struct CompiledPlan {
 
 void hll_registers_of_dictionary(Column& c, int log2m, uint8_t* regs);
 double dictionary_value_as_double(const Column& c, int32_t dict_id);
-std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* filter, const pg_query* query);
-std::string query_signature(const pg_filter_node* filter, const pg_query* query);
+std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* filter, const pg_query* query, int32_t flags = 0);   // flags: of a filter-only plan (query == nullptr)
+std::string query_signature(const pg_filter_node* filter, const pg_query* query, int32_t flags = 0);
 
 // ---- results --------------------------------------------------------------------------------------------------------------------
 // Page-locked host blocks for result copies that a result may keep (pooled: hipHostMalloc costs more than a query)
@@ -373,6 +373,8 @@ struct Result {
   std::vector<std::vector<uint8_t>> group_bytes;        // PG_GROUP_KEY_BYTES_VALUES: the groups' values back to back,
   std::vector<std::vector<int64_t>> group_bytes_off;    //   offsets (num_groups + 1)
   std::vector<AggResult> aggs;
+  // PG_QUERY_FLAG_NULL_HANDLING: per aggregation / per group-by column, 1 where the group's result / key is NULL (empty vector: none is)
+  std::vector<std::vector<uint8_t>> agg_nulls, key_nulls;
   pg_exec_stats stats{};
 };
 struct DocIdSet {
@@ -391,10 +393,15 @@ struct CancelToken { std::atomic<int> requested{0}; };
 void device_init(int ordinal);          // pg_init: validates + selects the default device
 int default_device();                   // the device pg_segment_create pins on (0 unless pg_init chose another)
 void use_device(int ordinal);           // makes `ordinal` current on the calling thread, initialising it on first use
-std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const CancelToken* cancel);
+std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const CancelToken* cancel);         // pg_nullaware.cpp: query-level null handling above ...
+// internal query flag (never set by callers: pg_query_exec masks it): the query is a part of a null-partitioned one — its filter is evaluated in
+// three-valued logic even where the reference's FastFilteredCountOperator would not (a lone COUNT(*) over an index-only filter)
+constexpr int32_t kQueryFlagNullPartition = 0x40000000;
+std::unique_ptr<Result> execute_query_plain(Segment& seg, const pg_query& q, const CancelToken* cancel);   // ... the executor proper (pg_exec.hip)
+void fill_result_schema(Segment& seg, const pg_query& q, Result& r);
 void result_merge(Result& dst, Result& src);
 std::vector<uint8_t> result_data_table_v4(const Result& r);   // pg_datatable.cpp
-void check_null_handling(Segment& seg, const pg_query& q);     // pg_plan.cpp: PG_QUERY_FLAG_NULL_HANDLING
+void check_null_handling(Segment& seg, const pg_query& q);     // pg_nullaware.cpp: what PG_QUERY_FLAG_NULL_HANDLING leaves to the Java plan
 // RCCL (pg_comm.cpp)
 struct Comm;
 void comm_unique_id(void* out128);
@@ -410,8 +417,8 @@ void check_merge_bounds(uint64_t sum_max_abs, bool has_digit_sums, int64_t total
 void device_table_tail_store(DeviceTable& T, hipStream_t stream);
 void merge_sets_on_stream(uint32_t* dst, const uint32_t* gathered, int64_t n_words, int n_src, hipStream_t stream);
 hipStream_t thread_stream(int device);
-std::unique_ptr<DocIdSet> execute_filter(Segment& seg, const pg_filter_node* filter);
-std::shared_ptr<CompiledPlan> get_plan(Segment& seg, const pg_filter_node* filter, const pg_query* q);   // cached, under seg.mu
+std::unique_ptr<DocIdSet> execute_filter(Segment& seg, const pg_filter_node* filter, int32_t flags = 0);   // flags: PG_QUERY_FLAG_NULL_HANDLING
+std::shared_ptr<CompiledPlan> get_plan(Segment& seg, const pg_filter_node* filter, const pg_query* q, int32_t flags = 0);   // cached, under seg.mu
 void docidset_copy_docids(DocIdSet& s, int32_t* out, int64_t cap);
 
 }  // namespace pg

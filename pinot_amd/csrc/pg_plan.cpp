@@ -9,6 +9,7 @@
 //                                                                surviving candidates (this is what PG_F_AND_SCAN does)
 //   query/aggregation/groupby/DictionaryBasedGroupKeyGenerator.java:106-185,312-354   raw key = Σ dictId_j · Π card_<j
 #include <algorithm>
+#include <functional>
 #include <cerrno>
 #include <cmath>
 #include <sstream>
@@ -321,18 +322,28 @@ static OpPtr bitmap_operator(std::shared_ptr<Column> bitmap, bool exclusive) {
   return op;
 }
 
-static OpPtr construct(Segment& seg, const pg_filter_node& f) {   // FilterPlanNode#constructPhysicalOperator
+// the column's null value vector when it holds a null (NullValueVectorReader#getNullBitmap non-null and non-empty), nullptr otherwise
+static std::shared_ptr<Column> null_vector_of(Segment& seg, const Column* col) {
+  if (!col) return nullptr;
+  const Column* named = col->public_col ? col->public_col : col;
+  auto it = seg.null_vectors.find(named->name);
+  if (it == seg.null_vectors.end() || !it->second) return nullptr;
+  const Column& nv = *it->second;
+  return !nv.posting_card.empty() && nv.posting_card[0] > 0 ? it->second : nullptr;
+}
+
+static OpPtr construct(Segment& seg, const pg_filter_node& f, bool nh) {   // FilterPlanNode#constructPhysicalOperator
   switch (f.type) {
     case PG_FILTER_AND:
     case PG_FILTER_OR: {
       if (f.n_children < 1 || !f.children) fail(PG_ERR_INVALID_ARGUMENT, "AND/OR without children");
       std::vector<OpPtr> ch;
-      for (int i = 0; i < f.n_children; i++) ch.push_back(construct(seg, f.children[i]));
+      for (int i = 0; i < f.n_children; i++) ch.push_back(construct(seg, f.children[i], nh));
       return f.type == PG_FILTER_AND ? and_operator(std::move(ch)) : or_operator(std::move(ch));
     }
     case PG_FILTER_NOT:
       if (f.n_children != 1 || !f.children) fail(PG_ERR_INVALID_ARGUMENT, "NOT needs exactly one child");
-      return not_operator(construct(seg, f.children[0]));
+      return not_operator(construct(seg, f.children[0], nh));
     case PG_FILTER_PREDICATE: {
       Column* col = seg.find(f.column);
       if (!col) fail(PG_ERR_NOT_FOUND, "column not found: %s", f.column ? f.column : "(null)");
@@ -345,11 +356,104 @@ static OpPtr construct(Segment& seg, const pg_filter_node& f) {   // FilterPlanN
       // a raw multi-value column is evaluated on its internal dictionary-encoded twin (built at registration): the same docs match, and
       // the scan counts the same entries (MVScanDocIdIterator over a raw column counts entries as well)
       if (col->raw_mv) col = col->vdict.get();
-      return leaf_operator(make_pred_eval(f, *col), col, f.predicate_type);
+      PredEval ev = make_pred_eval(f, *col);
+      // FilterOperatorUtils.java:78-88: under null handling an always-true predicate matches the docs that hold a value
+      if (nh && ev.always_true && !ev.always_false)
+        if (auto nv = null_vector_of(seg, col)) return bitmap_operator(nv, true);
+      return leaf_operator(std::move(ev), col, f.predicate_type);
     }
     case PG_FILTER_CONSTANT_TRUE: return make_op(OpKind::MatchAll);
     case PG_FILTER_CONSTANT_FALSE: return make_op(OpKind::Empty);
     default: fail(PG_ERR_INVALID_ARGUMENT, "bad filter node type %d", f.type);
+  }
+}
+
+// ---- query-level null handling (QueryContext#isNullHandlingEnabled) ------------------------------------------------------------------
+// The reference evaluates the operator tree in three-valued logic through getTrues / getNulls / getFalses: a column leaf (Scan / Inverted /
+// Sorted / RangeIndex: BaseColumnFilterOperator.java:45-72) is true where its predicate holds AND the value is not null, null where the value
+// is null; AND / OR / NOT / bitmap leaves have no nulls of their own (BaseFilterOperator.java:98-100); falses = NOT(trues OR nulls)
+// (BaseFilterOperator.java:105-122), AND / OR build theirs from their children's trues and nulls (AndFilterOperator.java:62-90,
+// OrFilterOperator.java:61-87), NOT swaps the two (NotFilterOperator.java:52-63).  nh_trues / nh_falses restate that as a rewrite into the
+// two-valued operators the emitter knows (the docId sets the reference builds are And / Or / Not sets over bitmaps as well).
+static bool column_leaf(const FilterOp& op) {
+  return (op.kind == OpKind::Scan || op.kind == OpKind::Inverted || op.kind == OpKind::Sorted || op.kind == OpKind::RangeIdx) && !op.bitmap_col;
+}
+static OpPtr node_of(OpKind k, std::vector<OpPtr> ch) {
+  auto r = make_op(k);
+  r->children = std::move(ch);
+  return r;
+}
+static OpPtr nh_falses(Segment& seg, OpPtr op);
+static OpPtr nh_trues(Segment& seg, OpPtr op) {
+  switch (op->kind) {
+    case OpKind::And:
+    case OpKind::Or: {
+      const OpKind k = op->kind;
+      std::vector<OpPtr> ch;
+      for (auto& c : op->children) ch.push_back(nh_trues(seg, std::move(c)));
+      return node_of(k, std::move(ch));
+    }
+    case OpKind::Not:
+      if (op->children[0]->kind == OpKind::Empty) return make_op(OpKind::MatchAll);   // isResultEmpty
+      return nh_falses(seg, std::move(op->children[0]));
+    default:
+      if (column_leaf(*op))
+        if (auto nv = null_vector_of(seg, op->col)) {   // excludeNulls: AndDocIdSet(block, flip(nullBitmap))
+          std::vector<OpPtr> ch;
+          ch.push_back(std::move(op));
+          ch.push_back(bitmap_operator(nv, true));
+          return node_of(OpKind::And, std::move(ch));
+        }
+      return op;
+  }
+}
+static OpPtr nh_falses(Segment& seg, OpPtr op) {
+  switch (op->kind) {
+    case OpKind::Not: return nh_trues(seg, std::move(op->children[0]));
+    case OpKind::And:
+    case OpKind::Or: {
+      const bool is_and = op->kind == OpKind::And;
+      std::vector<OpPtr> xs;
+      for (auto& c : op->children) {
+        std::shared_ptr<Column> nv = column_leaf(*c) ? null_vector_of(seg, c->col) : nullptr;
+        OpPtr t = nh_trues(seg, std::move(c));
+        if (is_and) {
+          if (t->kind == OpKind::Empty) return make_op(OpKind::MatchAll);
+          if (t->kind == OpKind::MatchAll) continue;
+        } else {
+          if (t->kind == OpKind::MatchAll) return make_op(OpKind::Empty);
+          if (t->kind == OpKind::Empty) continue;
+        }
+        if (nv) {   // the child's nulls are not false either
+          std::vector<OpPtr> both;
+          both.push_back(std::move(t));
+          both.push_back(bitmap_operator(nv, false));
+          t = node_of(OpKind::Or, std::move(both));
+        }
+        xs.push_back(std::move(t));
+      }
+      if (xs.empty()) return make_op(is_and ? OpKind::Empty : OpKind::MatchAll);
+      OpPtr inner = xs.size() == 1 ? std::move(xs[0]) : node_of(is_and ? OpKind::And : OpKind::Or, std::move(xs));
+      std::vector<OpPtr> one;
+      one.push_back(std::move(inner));
+      return node_of(OpKind::Not, std::move(one));
+    }
+    default: {
+      std::shared_ptr<Column> nv = column_leaf(*op) ? null_vector_of(seg, op->col) : nullptr;
+      OpPtr t = nh_trues(seg, std::move(op));
+      if (t->kind == OpKind::MatchAll) return make_op(OpKind::Empty);
+      if (nv) {
+        std::vector<OpPtr> both;
+        both.push_back(std::move(t));
+        both.push_back(bitmap_operator(nv, false));
+        t = node_of(OpKind::Or, std::move(both));
+      } else if (t->kind == OpKind::Empty) {
+        return make_op(OpKind::MatchAll);
+      }
+      std::vector<OpPtr> one;
+      one.push_back(std::move(t));
+      return node_of(OpKind::Not, std::move(one));
+    }
   }
 }
 
@@ -719,32 +823,10 @@ static void sig_filter(std::ostringstream& o, const pg_filter_node* f) {
   for (int i = 0; i < f->n_children && f->children; i++) sig_filter(o, &f->children[i]);
   o << ")";
 }
-// PG_QUERY_FLAG_NULL_HANDLING: refuse unless no column the query reads holds a null in this segment (then null handling cannot change
-// the answer and the reference itself keeps its ordinary plan: AggregationPlanNode.java:104-121, StarTreeUtils.java:381-400)
-static void null_check_column(Segment& seg, const char* name) {
-  if (!name || !strcmp(name, "*")) return;
-  auto it = seg.null_vectors.find(name);
-  if (it == seg.null_vectors.end() || !it->second) return;
-  const Column& nv = *it->second;
-  if (!nv.posting_card.empty() && nv.posting_card[0] > 0)
-    fail(PG_ERR_UNSUPPORTED, "enableNullHandling over column %s, which holds %lld nulls in this segment", name, (long long)nv.posting_card[0]);
-}
-static void null_check_filter(Segment& seg, const pg_filter_node* f) {
-  if (!f) return;
-  if (f->type == PG_FILTER_PREDICATE) { null_check_column(seg, f->column); return; }
-  for (int i = 0; i < f->n_children; i++) null_check_filter(seg, &f->children[i]);
-}
-void check_null_handling(Segment& seg, const pg_query& q) {
-  if (!(q.flags & PG_QUERY_FLAG_NULL_HANDLING)) return;
-  std::lock_guard<std::mutex> g(seg.mu);
-  null_check_filter(seg, q.filter);
-  for (int i = 0; i < q.n_group_by; i++) null_check_column(seg, q.group_by_columns[i]);
-  for (int i = 0; i < q.n_aggregations; i++) null_check_column(seg, q.aggregations[i].column);
-}
-
-std::string query_signature(const pg_filter_node* filter, const pg_query* q) {
+std::string query_signature(const pg_filter_node* filter, const pg_query* q, int32_t flags) {
   std::ostringstream o;
   sig_filter(o, filter);
+  o << "|nh" << (((q ? q->flags : flags) & PG_QUERY_FLAG_NULL_HANDLING) ? 1 : 0) << (((q ? q->flags : flags) & kQueryFlagNullPartition) ? 1 : 0);
   if (q) {
     o << "|g" << q->n_group_by << ":";
     for (int i = 0; i < q->n_group_by && q->group_by_columns; i++) sig_str(o, q->group_by_columns[i]);
@@ -932,13 +1014,23 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root, 
 // regular filter is planned first; FastFilteredCountOperator takes a lone COUNT(*) over an index-only filter; otherwise, when the
 // filter result is not empty, the first star-tree the query fits answers it (AggregationFunctionUtils#buildAggregationInfo
 // :285-307) and the operators run over that star-tree's doc space.
-std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* filter, const pg_query* q) {
-  OpPtr root = filter ? construct(seg, *filter) : make_op(OpKind::MatchAll);
+std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* filter, const pg_query* q, int32_t flags) {
+  const bool nh = ((q ? q->flags : flags) & PG_QUERY_FLAG_NULL_HANDLING) != 0;
+  OpPtr root = filter ? construct(seg, *filter, nh) : make_op(OpKind::MatchAll);
   if (seg.queryable_doc_ids) {   // FilterPlanNode.run (:88-106): AND(filter, BitmapBasedFilterOperator(queryableDocIds))
     std::vector<OpPtr> both;
     both.push_back(std::move(root));
     both.push_back(bitmap_operator(seg.queryable_doc_ids, false));
     root = and_operator(std::move(both));
+  }
+  // the root's getTrues in three-valued logic, as two-valued operators — except under FastFilteredCountOperator, which asks the operators for
+  // getNumMatchingDocs / getBitmaps: those know no nulls (AggregationPlanNode.java:104-108, InvertedIndexFilterOperator.java:103-131,
+  // AndFilterOperator.java:99-110), so a lone COUNT(*) over an index-only filter counts the docs whose stored default value matches as well
+  if (nh) {
+    const bool fast_count = q && q->n_group_by == 0 && q->n_aggregations == 1 && q->aggregations && q->aggregations[0].function == PG_AGG_COUNT &&
+                            (!q->aggregations[0].column || !strcmp(q->aggregations[0].column, "*") || !null_vector_of(seg, seg.find(q->aggregations[0].column))) &&
+                            can_optimize_count(*root) && !(q->flags & kQueryFlagNullPartition);
+    if (!fast_count) root = nh_trues(seg, std::move(root));
   }
   // AggregationPlanNode#buildNonFilteredAggOperator (:97-127): FastFilteredCountOperator, then NonScanBasedAggregationOperator, then
   // the star-trees — a match-all MIN / MAX / DISTINCTCOUNT(HLL) over dictionary columns is answered from the dictionaries even when a
@@ -955,8 +1047,24 @@ std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* f
     non_scan_fit = c && dict_fn && c->has_dictionary && is_mv_function(a.function) == c->is_mv &&
                    (c->data_type <= PG_TYPE_DOUBLE || f == PG_AGG_DISTINCTCOUNT || f == PG_AGG_DISTINCTCOUNTHLL);
   }
+  // StarTreeUtils.java:381-418: under null handling a star-tree answers only if no column the query reads holds a null in this segment
+  bool star_tree_blocked = false;
+  if (nh && q && !seg.star_trees.empty()) {
+    std::function<bool(const pg_filter_node*)> filter_has_nulls = [&](const pg_filter_node* f) -> bool {
+      if (!f) return false;
+      if (f->type == PG_FILTER_PREDICATE) return f->column && null_vector_of(seg, seg.find(f->column)) != nullptr;
+      for (int i = 0; i < f->n_children; i++) if (filter_has_nulls(&f->children[i])) return true;
+      return false;
+    };
+    star_tree_blocked = filter_has_nulls(filter);
+    for (int i = 0; i < q->n_group_by && !star_tree_blocked; i++) star_tree_blocked = null_vector_of(seg, seg.find(q->group_by_columns[i])) != nullptr;
+    for (int i = 0; i < q->n_aggregations && !star_tree_blocked; i++) {
+      const char* c = q->aggregations[i].column;
+      star_tree_blocked = c && strcmp(c, "*") != 0 && null_vector_of(seg, seg.find(c)) != nullptr;
+    }
+  }
   if (!non_scan_fit && q && q->n_aggregations > 0 && q->aggregations && !(q->flags & PG_QUERY_FLAG_SKIP_STAR_TREE) && !seg.star_trees.empty() &&
-      root->kind != OpKind::Empty) {
+      root->kind != OpKind::Empty && !star_tree_blocked) {
     const bool fast_count = q->n_group_by == 0 && q->n_aggregations == 1 && q->aggregations[0].function == PG_AGG_COUNT &&
                             can_optimize_count(*root);
     for (size_t t = 0; t < seg.star_trees.size() && !fast_count; t++) {

@@ -109,11 +109,14 @@ class NativeSegment:
             pass
 
     # -- FilterOperator / DocIdSetOperator ------------------------------------------------------------------------
-    def filter(self, q) -> "DocIdSet":
+    def filter(self, q, null_handling: bool = False) -> "DocIdSet":
         qc = parse_sql(q) if isinstance(q, str) else q
         cq = CQuery(qc)
         h = C.c_void_p()
-        self.api.call("filter_exec", self.handle, cq.filter_ptr(), C.byref(h))
+        if null_handling or (qc.flags & capi.QUERY_FLAG_NULL_HANDLING):   # enableNullHandling=true: three-valued filter
+            self.api.call("filter_exec_flags", self.handle, cq.filter_ptr(), capi.QUERY_FLAG_NULL_HANDLING, C.byref(h))
+        else:
+            self.api.call("filter_exec", self.handle, cq.filter_ptr(), C.byref(h))
         return DocIdSet(self.api, h)
 
     # -- GroupByOperator / AggregationOperator ---------------------------------------------------------------------
@@ -411,6 +414,19 @@ class ResultsBlock:
                 rb.arrays.append((k, regs[:ng * m].reshape(ng, m)))
             else:
                 raise RuntimeError(f"unknown result kind {k}")
+        # enableNullHandling: which results / group keys are NULL (all zero without the flag: not asked for then)
+        rb.agg_nulls, rb.key_nulls = {}, {}
+        if qc.flags & capi.QUERY_FLAG_NULL_HANDLING:
+            for a in range(len(qc.aggregations)):
+                f = np.zeros(max(ng, 1), dtype=np.uint8)
+                api.call("result_agg_nulls", h, a, f.ctypes.data, ng)
+                if f[:ng].any():
+                    rb.agg_nulls[a] = f[:ng].astype(bool)
+            for j in range(ngb):
+                f = np.zeros(max(ng, 1), dtype=np.uint8)
+                api.call("result_group_key_nulls", h, j, f.ctypes.data, ng)
+                if f[:ng].any():
+                    rb.key_nulls[j] = f[:ng].astype(bool)
         st = capi.PgExecStats()
         api.call("result_stats", h, C.byref(st))
         rb.stats = st
@@ -436,7 +452,8 @@ class ResultsBlock:
                 else:
                     dv = self._host.columns[g].dict_values
                     per_col.append([dv[ids[j, i]] for i in range(ng)])
-            self._group_keys = [tuple(_key_repr(per_col[j][i]) for j in range(len(per_col))) for i in range(ng)]
+            kn = getattr(self, "key_nulls", {})
+            self._group_keys = [tuple(None if (j in kn and kn[j][i]) else _key_repr(per_col[j][i]) for j in range(len(per_col))) for i in range(ng)]
         return self._group_keys
 
     @property
@@ -462,6 +479,8 @@ class ResultsBlock:
                     cols.append(col)
                 else:
                     cols.append([bytes(r) for r in arr[1]])
+            for a, flags in getattr(self, "agg_nulls", {}).items():   # enableNullHandling: a NULL result
+                cols[a] = [None if flags[i] else v for i, v in enumerate(cols[a])]
             self._columns = cols
         return self._columns
 

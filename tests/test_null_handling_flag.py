@@ -1,7 +1,7 @@
-"""PG_QUERY_FLAG_NULL_HANDLING (QueryContext#isNullHandlingEnabled): taken when no column the query reads holds a null in the segment —
-the case in which the reference keeps its ordinary plan (AggregationPlanNode.java:104-121 hasNullValues, StarTreeUtils.java:381-400) and null
-handling cannot change the answer — refused otherwise (null-aware filters / keys / aggregations stay with the Java plan), as is an
-aggregation without GROUP BY over no doc (its SUM / MIN / MAX would be null).  Oracle on the CPU; the HIP path against it in the gpu tests."""
+"""PG_QUERY_FLAG_NULL_HANDLING (QueryContext#isNullHandlingEnabled) where it cannot change the answer — no column the query reads holds a null
+in the segment: the reference keeps its ordinary plan then (AggregationPlanNode.java:104-121 hasNullValues, StarTreeUtils.java:381-400), fast
+paths and star-trees included — and what is refused (nulls in multi-value columns / no-dictionary group-by columns).  The null-aware filters,
+aggregations and keys themselves: tests/test_null_handling_filters.py, tests/test_null_handling_aggregations.py."""
 import pytest
 
 from pinot_amd import capi
@@ -18,13 +18,16 @@ TAKEN = [
     "SELECT COUNT(*) FROM nulls",
     "SELECT MIN(g), MAX(g) FROM nulls",                        # NonScanBasedAggregationOperator stays (no nulls in g)
 ]
-REFUSED = [
+NULL_AWARE = [   # columns with nulls: answered in three-valued logic / with NULL results (compared with the oracle in the gpu test)
     "SELECT g, SUM(m) FROM nulls WHERE d IN (1, 2, 3) GROUP BY g LIMIT 1000",        # a filter column with nulls
     "SELECT d, COUNT(*) FROM nulls GROUP BY d LIMIT 1000",                            # a group-by column with nulls
     "SELECT g, SUM(r) FROM nulls GROUP BY g LIMIT 1000",                              # an aggregation argument with nulls
     "SELECT COUNT(*) FROM nulls WHERE d IS NULL",
     "SELECT g, COUNT(*) FROM nulls WHERE NOT (r < 500) GROUP BY g LIMIT 1000",
     "SELECT SUM(m), MAX(m) FROM nulls WHERE g > 1000",                                # no GROUP BY, nothing matches: null results
+]
+REFUSED = [
+    "SELECT r, COUNT(*) FROM nulls GROUP BY r LIMIT 100000",                          # a no-dictionary group-by column with nulls
 ]
 
 
@@ -43,6 +46,7 @@ def check(api_segment, plain_segment=None):
             api_segment.execute(flagged(sql))
         assert e.value.status == capi.PG_ERR_UNSUPPORTED and "enableNullHandling" in str(e.value), sql
         api_segment.execute(parse_sql(sql))   # the same query without the flag runs
+    assert api_segment.execute(flagged("SELECT SUM(m), MAX(m) FROM nulls WHERE g > 1000")).aggregation_result() == [None, None]
 
 
 def test_oracle_takes_and_refuses(oracle_api):
@@ -63,6 +67,8 @@ def test_gpu_takes_and_refuses_like_the_oracle(gpu_api, oracle_api):
         gb, ob = g.execute(flagged(sql)), o.execute(flagged(sql))
         assert gb.rows() == ob.rows() and gb.stats.num_docs_scanned == ob.stats.num_docs_scanned
         assert gb.stats.num_entries_scanned_in_filter == ob.stats.num_entries_scanned_in_filter
+    for sql in NULL_AWARE:
+        assert g.execute(flagged(sql)).rows() == o.execute(flagged(sql)).rows(), sql
     assert g.execute(flagged("SELECT g, SUM(m) FROM nulls WHERE g > 1000 GROUP BY g LIMIT 10")).rows() == {}
     g.destroy()
     o.destroy()
