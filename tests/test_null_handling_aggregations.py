@@ -192,3 +192,63 @@ def test_gpu_refuses_what_is_not_partitioned(gpu_api):
         seg.execute(q)
     assert e.value.status == capi.PG_ERR_UNSUPPORTED
     seg.destroy()
+
+
+# ---- NullHandlingEnabledQueriesTest (pinot-core/src/test/java/org/apache/pinot/queries/NullHandlingEnabledQueriesTest.java): its small tables
+# with their expected rows.  Selection queries there; their filters' doc sets and the group-by tables are what is asserted here. -----------------
+INT_MIN = -2147483648
+
+
+def small_table(rows, names=("column1", "column2"), inverted=()):
+    """rows of one or two INT columns, None = null (stored as the default null value of an INT dimension)"""
+    cols = list(zip(*rows)) if isinstance(rows[0], tuple) else [tuple(rows)]
+    data, nulls = {}, {}
+    for name, values in zip(names, cols):
+        data[name] = np.array([INT_MIN if v is None else v for v in values], dtype=np.int32)
+        nulls[name] = np.array([i for i, v in enumerate(values) if v is None], dtype=np.int64)
+    host = build_segment("testTable_0", data, {k: "INT" for k in data}, inverted_index_columns=list(inverted))
+    for name, ids in nulls.items():
+        if len(ids):
+            host.columns[name].null_vector = np.frombuffer(formats.serialize_roaring(ids), dtype=np.uint8)
+    return host
+
+
+SEVEN = [(None, None), (None, 1), (1, -1), (-1, None), (-1, 1), (1, None), (None, -1)]   # testOrFiltering / testNotAndFiltering / testNotOrFiltering
+
+
+def reference_small_cases(api):
+    def docs(host, where):
+        seg = NativeSegment(api, host)
+        got = seg.filter(f"SELECT COUNT(*) FROM testTable WHERE {where}", null_handling=True).doc_ids().tolist()
+        seg.destroy()
+        return got
+    assert docs(small_table(SEVEN), "column1 > 0 OR column2 < 0") == [2, 5, 6]                       # :987-1010: 3 rows
+    assert docs(small_table([None, -1, 1], names=("column1",)), "NOT column1 = 1") == [1]             # :1013-1030: the row -1
+    assert docs(small_table(SEVEN), "NOT (column1 > 0 AND column2 < 0)") == [1, 3, 4]                  # :1033-1056: 3 rows
+    assert docs(small_table(SEVEN), "NOT (column1 > 0 OR column2 < 0)") == [4]                         # :1059-1083: the row (-1, 1)
+    assert docs(small_table([None, INT_MIN], names=("column1",)), f"column1 = {INT_MIN}") == [1]      # :967-984: not the null
+    assert docs(small_table([None, 0, 1], names=("column1",), inverted=["column1"]), "column1 = 0") == [1]   # :903-922 (BOOLEAN false = 0, inverted index)
+    assert docs(small_table([-1, None], names=("column1",)), "column1 < 0") == [0]                   # :947-964
+    # :153-176 GROUP BY column COUNT(*): {2: 2, 1: 1, null: 3}
+    seg = NativeSegment(api, small_table([None, None, None, 1, 2, 2], names=("column1",)))
+    assert seg.execute(flagged("SELECT column1, COUNT(*) FROM testTable GROUP BY column1 LIMIT 10")).rows() == {(2,): [2], (1,): [1], (None,): [3]}
+    seg.destroy()
+    # :777-804 two columns: five groups, Integer.MIN_VALUE is not null
+    seg = NativeSegment(api, small_table([(None, None), (None, 1), (None, 1), (1, 1), (1, None), (1, INT_MIN)]))
+    assert seg.execute(flagged("SELECT column1, column2, COUNT(*) FROM testTable GROUP BY column1, column2 LIMIT 10")).rows() == \
+        {(None, None): [1], (None, 1): [2], (1, 1): [1], (1, None): [1], (1, INT_MIN): [1]}
+    seg.destroy()
+    # :544-597 DISTINCTCOUNT skips the null
+    seg = NativeSegment(api, small_table([(None, 7), (1, 7)]))
+    assert seg.execute(flagged("SELECT DISTINCTCOUNT(column1) FROM testTable")).aggregation_result() == [frozenset({1})]
+    assert seg.execute(flagged("SELECT column2, DISTINCTCOUNT(column1) FROM testTable GROUP BY column2 LIMIT 10")).rows() == {(7,): [frozenset({1})]}
+    seg.destroy()
+
+
+def test_oracle_reproduces_null_handling_enabled_queries_test(oracle_api):
+    reference_small_cases(oracle_api)
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_null_handling_enabled_queries_test(gpu_api):
+    reference_small_cases(gpu_api)
