@@ -181,6 +181,55 @@ def test_gpu_matches_oracle_on_random_queries(gpu_api, oracle_api, fuzz, seed, w
     o.destroy()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,with_valid_docs", [(0, False), (1, True)])
+def test_gpu_matches_oracle_on_random_queries_under_null_handling(gpu_api, oracle_api, fuzz, seed, with_valid_docs):
+    """The same random queries with enableNullHandling: `ci` (dictionary, inverted index: a filter and group-by column) and `r` (raw: a filter
+    column and an aggregation argument) hold nulls.  The oracle evaluates getTrues / getNulls / getFalses and skips nulls doc at a time; the HIP
+    path rewrites the filter tree and joins IS [NOT] NULL partitions: two constructions of the same semantics."""
+    host, data, nulls = fuzz
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    if with_valid_docs:
+        valid = np.flatnonzero(np.random.default_rng(seed).random(host.total_docs) < 0.8)
+        g.set_queryable_doc_ids(valid)
+        o.set_queryable_doc_ids(valid)
+    gen = Gen(data, seed=7000 + seed)
+    unsupported, mismatches, with_nulls = [], [], 0
+    n_queries = 160
+    for i in range(n_queries):
+        q = gen.query()
+        what = f"null handling, seed {seed} #{i} {describe(q)}"
+        oq, gq = clone(q), clone(q)
+        oq.flags |= capi.QUERY_FLAG_NULL_HANDLING
+        gq.flags |= capi.QUERY_FLAG_NULL_HANDLING
+        try:
+            ob = o.execute(oq)
+        except capi.NativeError:
+            with pytest.raises(capi.NativeError):
+                g.execute(gq)
+            continue
+        try:
+            gb = g.execute(gq)
+        except capi.NativeError as e:
+            assert e.status == capi.PG_ERR_UNSUPPORTED, (what, e)
+            unsupported.append((what, str(e)))
+            continue
+        try:
+            gr, orr = gb.rows(), ob.rows()
+            assert gr == orr, what
+            assert gb.stats.num_docs_scanned == ob.stats.num_docs_scanned, what
+            with_nulls += any(None in k for k in orr) or any(v is None for row in orr.values() for v in row)
+            if i % 3 == 0:
+                np.testing.assert_array_equal(g.filter(clone(q), null_handling=True).doc_ids(), o.filter(clone(q), null_handling=True).doc_ids(), err_msg=what)
+        except AssertionError as e:
+            mismatches.append(str(e)[:600])
+    assert not mismatches, "\n".join(mismatches[:12])
+    assert len(unsupported) <= n_queries // 5, unsupported
+    assert with_nulls > 10
+    g.destroy()
+    o.destroy()
+
+
 # ---- star-tree: random queries over the dimensions; star-tree answer == plain answer (BaseStarTreeV2Test's differential) ------
 def _star_query(rng):
     from pinot_amd.query import AggregationSpec, FilterContext, Predicate, QueryContext, UNBOUNDED
