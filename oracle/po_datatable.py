@@ -140,14 +140,74 @@ def column_offsets(types: List[str]) -> Tuple[List[int], int]:
     return offs, size
 
 
-def build_data_table_v4(names: List[str], types: List[str], rows: List[list]) -> bytes:
+NULL_TYPE_VALUE = 100   # CustomObject.NULL_TYPE_VALUE: a null OBJECT (DataTableBuilder#setColumn(int, null))
+NULL_PLACEHOLDER = {"INT": 0, "LONG": 0, "FLOAT": 0.0, "DOUBLE": 0.0, "STRING": "", "BYTES": b""}   # CommonConstants.NullValuePlaceHolder
+
+
+def serialize_null_row_ids(row_ids: List[int]) -> bytes:
+    """RoaringBitmap#serialize of a bitmap built with add(): portable format, array containers up to 4 096 values, bitmap containers beyond,
+    no run containers (nobody calls runOptimize on these)."""
+    conts: Dict[int, List[int]] = {}
+    for r in row_ids:
+        conts.setdefault(r >> 16, []).append(r & 0xFFFF)
+    keys = sorted(conts)
+    out = struct.pack("<II", 12346, len(keys))
+    for k in keys:
+        out += struct.pack("<HH", k, len(conts[k]) - 1)
+    pos = 8 + 8 * len(keys)
+    for k in keys:
+        out += struct.pack("<I", pos)
+        pos += 8192 if len(conts[k]) > 4096 else 2 * len(conts[k])
+    for k in keys:
+        vals = conts[k]
+        if len(vals) <= 4096:
+            out += struct.pack(f"<{len(vals)}H", *vals)
+        else:
+            words = [0] * 1024
+            for v in vals:
+                words[v >> 6] |= 1 << (v & 63)
+            out += struct.pack("<1024Q", *words)
+    return out
+
+
+def deserialize_null_row_ids(b: bytes) -> List[int]:
+    cookie, n = struct.unpack_from("<II", b, 0)
+    assert cookie == 12346, cookie
+    out, descs = [], [struct.unpack_from("<HH", b, 8 + 4 * i) for i in range(n)]
+    offs = [struct.unpack_from("<I", b, 8 + 4 * n + 4 * i)[0] for i in range(n)]
+    for (key, card_m1), off in zip(descs, offs):
+        card = card_m1 + 1
+        if card <= 4096:
+            out += [(key << 16) | v for v in struct.unpack_from(f"<{card}H", b, off)]
+        else:
+            words = struct.unpack_from("<1024Q", b, off)
+            out += [(key << 16) | (w * 64 + bit) for w in range(1024) for bit in range(64) if (words[w] >> bit) & 1]
+    return out
+
+
+def build_data_table_v4(names: List[str], types: List[str], rows: List[list], null_handling: bool = False, group_by: bool = True) -> bytes:
     """DataTableBuilderV4: startRow / setColumn per stored type / finishRow / build, then DataTableImplV4#toBytes with no exceptions and no
-    metadata.  Row values by column type: INT / LONG ints, FLOAT / DOUBLE floats, STRING str, BYTES bytes, OBJECT one of the classes above."""
+    metadata.  Row values by column type: INT / LONG ints, FLOAT / DOUBLE floats, STRING str, BYTES bytes, OBJECT one of the classes above.
+    null_handling (GroupByResultsBlock.java:196-222, AggregationResultsBlock.java:118-140): a None travels as the type's placeholder with its
+    row id in the column's null bitmap (a None OBJECT as NULL_TYPE_VALUE; the aggregation-only block marks it in the bitmap as well, the
+    group-by block does not), and every column's bitmap — (position, length) in the fixed-size part, the bytes in the variable-size part —
+    follows the rows (DataTableBuilderV4#setNullRowIds)."""
     fixed, var = bytearray(), bytearray()
     dictionary: Dict[str, int] = {}
-    for row in rows:
+    null_rows: List[List[int]] = [[] for _ in types]
+    for row_id, row in enumerate(rows):
         assert len(row) == len(types)
-        for t, v in zip(types, row):
+        for c, (t, v) in enumerate(zip(types, row)):
+            if v is None:
+                assert null_handling
+                if t == "OBJECT":
+                    if not group_by:
+                        null_rows[c].append(row_id)
+                    fixed += struct.pack(">ii", len(var), 0)
+                    var += struct.pack(">i", NULL_TYPE_VALUE)
+                    continue
+                null_rows[c].append(row_id)
+                v = NULL_PLACEHOLDER[t]
             if t == "INT":
                 fixed += struct.pack(">i", v)
             elif t == "LONG":
@@ -167,6 +227,15 @@ def build_data_table_v4(names: List[str], types: List[str], rows: List[list]) ->
                 var += struct.pack(">i", kind) + b
             else:
                 raise ValueError(t)
+    if null_handling:
+        for ids in null_rows:
+            fixed += struct.pack(">i", len(var))
+            if not ids:
+                fixed += struct.pack(">i", 0)
+            else:
+                b = serialize_null_row_ids(ids)
+                fixed += struct.pack(">i", len(b))
+                var += b
     exceptions = struct.pack(">i", 0)
     dict_bytes = struct.pack(">i", len(dictionary)) + b"".join(struct.pack(">i", len(s.encode())) + s.encode() for s in dictionary)   # insertion order = id order
     schema = struct.pack(">i", len(names)) + b"".join(struct.pack(">i", len(n.encode())) + n.encode() for n in names) + \
@@ -221,7 +290,9 @@ def parse_data_table_v4(b: bytes) -> dict:
             s, p = read_str(p)
             types.append(s)
     offs, row_size = column_offsets(types)
-    assert fx_n == n_rows * row_size, (fx_n, n_rows, row_size)
+    # DataTableImplV4#getNullRowIds: with null handling, (position, length) of every column's null bitmap follows the rows
+    has_nulls = fx_n == n_rows * row_size + 8 * len(types)
+    assert has_nulls or fx_n == n_rows * row_size, (fx_n, n_rows, row_size)
     var = b[va_s:va_s + va_n]
     rows = []
     for r in range(n_rows):
@@ -244,12 +315,21 @@ def parse_data_table_v4(b: bytes) -> dict:
             elif t == "OBJECT":   # getCustomObject: position, size; the object type int sits in front of the bytes
                 pos, ln = struct.unpack_from(">ii", b, base + o)
                 kind = struct.unpack_from(">i", var, pos)[0]
-                row.append(deserialize_object(kind, bytes(var[pos + 4:pos + 4 + ln])))
+                row.append(None if kind == NULL_TYPE_VALUE else deserialize_object(kind, bytes(var[pos + 4:pos + 4 + ln])))
             else:
                 raise ValueError(t)
         rows.append(row)
+    null_row_ids = None
+    if has_nulls:
+        null_row_ids = []
+        for c, t in enumerate(types):
+            pos, ln = struct.unpack_from(">ii", b, fx_s + n_rows * row_size + 8 * c)
+            ids = deserialize_null_row_ids(bytes(var[pos:pos + ln])) if ln else []
+            null_row_ids.append(ids)
+            for r in ids:
+                rows[r][c] = None
     p = va_s + va_n
     meta_len = struct.unpack_from(">i", b, p)[0]
     assert p + 4 + meta_len == len(b), (p, meta_len, len(b))
     n_meta = struct.unpack_from(">i", b, p + 4)[0]
-    return {"names": names, "types": types, "rows": rows, "exceptions": exceptions, "metadata_entries": n_meta}
+    return {"names": names, "types": types, "rows": rows, "exceptions": exceptions, "metadata_entries": n_meta, "null_row_ids": null_row_ids}

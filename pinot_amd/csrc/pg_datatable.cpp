@@ -115,8 +115,6 @@ std::string dict_bytes(const ResultColumn& c, int32_t id, bool strip_padding) {
 std::vector<uint8_t> result_data_table_v4(const Result& r) {
   const int n_keys = (int)r.schema_keys.size(), n_aggs = (int)r.schema_aggs.size();
   if (n_aggs != (int)r.aggs.size()) fail(PG_ERR_INVALID_ARGUMENT, "result carries no schema (not produced by pg_query_exec)");
-  for (const auto& v : r.agg_nulls) if (!v.empty()) fail(PG_ERR_UNSUPPORTED, "data table of a result with NULL values (enableNullHandling): the null vectors of DataTableImplV4 are not written");
-  for (const auto& v : r.key_nulls) if (!v.empty()) fail(PG_ERR_UNSUPPORTED, "data table of a result with NULL keys (enableNullHandling): the null vectors of DataTableImplV4 are not written");
   const int32_t n_rows = n_keys ? r.num_groups : 1;
   // ---- schema -------------------------------------------------------------------------------------------------------------------------
   std::vector<std::string> names;
@@ -159,11 +157,27 @@ std::vector<uint8_t> result_data_table_v4(const Result& r) {
   };
   fixed.b.reserve((size_t)n_rows * (size_t)row_size);
   std::vector<int64_t> set_pos((size_t)n_aggs, 0);   // running offsets into the concatenated dictId sets
+  // enableNullHandling (GroupByResultsBlock.java:196-222, AggregationResultsBlock.java:118-140): a null value travels as its column type's
+  // placeholder (NullValuePlaceHolder: 0 / "" / empty bytes) with its row id in the column's null bitmap, a null OBJECT as CustomObject's
+  // NULL_TYPE_VALUE with no bytes; the bitmaps follow the rows (DataTableBuilderV4#setNullRowIds)
+  std::vector<std::vector<int32_t>> null_rows((size_t)n_cols);
+  auto key_is_null = [&](int j, int32_t i) { return (size_t)j < r.key_nulls.size() && !r.key_nulls[(size_t)j].empty() && r.key_nulls[(size_t)j][(size_t)i]; };
+  auto agg_is_null = [&](int a, int32_t i) { return (size_t)a < r.agg_nulls.size() && !r.agg_nulls[(size_t)a].empty() && r.agg_nulls[(size_t)a][(size_t)i]; };
   for (int32_t i = 0; i < n_rows; i++) {
     for (int j = 0; j < n_keys; j++) {
       const ResultColumn& k = r.schema_keys[(size_t)j];
       const ColType t = types[(size_t)j];
       const int32_t kt = r.group_key_type.empty() ? PG_GROUP_KEY_DICT_IDS : r.group_key_type[(size_t)j];
+      if (key_is_null(j, i)) {
+        null_rows[(size_t)j].push_back(i);
+        switch (t) {
+          case C_INT: case C_FLOAT: fixed.i32(0); break;
+          case C_LONG: case C_DOUBLE: fixed.i64(0); break;
+          case C_STRING: fixed.i32(string_id(std::string())); break;
+          default: var_bytes(nullptr, 0); break;
+        }
+        continue;
+      }
       if (kt == PG_GROUP_KEY_DICT_IDS) {
         if (!k.dict) fail(PG_ERR_INTERNAL, "group-by column %s has no dictionary on the host", k.name.c_str());
         const int32_t id = r.group_dict_ids[(size_t)j][(size_t)i];
@@ -198,6 +212,17 @@ std::vector<uint8_t> result_data_table_v4(const Result& r) {
         var.i32(type);
         var.bytes(payload.b.data(), payload.size());
       };
+      if (agg_is_null(a, i)) {
+        if (ar.kind == PG_RESULT_DOUBLE) { null_rows[(size_t)(n_keys + a)].push_back(i); fixed.f64(0.0); }
+        else {   // OBJECT: DataTableBuilder#setColumn(int, null)
+          if (n_keys == 0) null_rows[(size_t)(n_keys + a)].push_back(i);   // (AggregationResultsBlock marks every null result; GroupByResultsBlock only the non-OBJECT ones)
+          fixed.i32((int32_t)var.size());
+          fixed.i32(0);
+          var.i32(100);   // CustomObject.NULL_TYPE_VALUE
+          if (ar.kind == PG_RESULT_DICTID_SET) set_pos[(size_t)a] += ar.set_sizes[(size_t)i];
+        }
+        continue;
+      }
       switch (ar.kind) {
         case PG_RESULT_LONG: fixed.i64(ar.l[0][(size_t)i]); break;
         case PG_RESULT_DOUBLE: fixed.f64(ar.d[0][(size_t)i]); break;
@@ -240,6 +265,41 @@ std::vector<uint8_t> result_data_table_v4(const Result& r) {
         }
         default: fail(PG_ERR_INTERNAL, "result kind %d in a data table", ar.kind);
       }
+    }
+  }
+  if (r.null_handling) {   // (the combined block's table exists even without rows: the trailer is written then as well)
+    for (int c = 0; c < n_cols; c++) {
+      fixed.i32((int32_t)var.size());
+      const std::vector<int32_t>& rows = null_rows[(size_t)c];
+      if (rows.empty()) { fixed.i32(0); continue; }
+      // RoaringBitmap#serialize (portable format; bitmaps built with add() hold array containers up to 4 096 values, bitmap containers beyond,
+      // never run containers): cookie 12346, container count, (key, cardinality - 1) pairs, offsets, containers — little-endian
+      Out rb;
+      auto le16 = [&](uint32_t v) { rb.b.push_back((uint8_t)v); rb.b.push_back((uint8_t)(v >> 8)); };
+      auto le32 = [&](uint32_t v) { le16(v & 0xFFFFu); le16(v >> 16); };
+      std::vector<std::pair<uint32_t, std::pair<size_t, size_t>>> conts;   // key, [first, last) into rows
+      for (size_t x = 0; x < rows.size();) {
+        size_t y = x;
+        while (y < rows.size() && ((uint32_t)rows[y] >> 16) == ((uint32_t)rows[x] >> 16)) y++;
+        conts.push_back({(uint32_t)rows[x] >> 16, {x, y}});
+        x = y;
+      }
+      le32(12346u);
+      le32((uint32_t)conts.size());
+      for (auto& ct : conts) { le16(ct.first); le16((uint32_t)(ct.second.second - ct.second.first - 1)); }
+      uint32_t pos = 8 + 8 * (uint32_t)conts.size();
+      for (auto& ct : conts) { le32(pos); const size_t card = ct.second.second - ct.second.first; pos += card > 4096 ? 8192u : 2u * (uint32_t)card; }
+      for (auto& ct : conts) {
+        const size_t card = ct.second.second - ct.second.first;
+        if (card <= 4096) for (size_t x = ct.second.first; x < ct.second.second; x++) le16((uint32_t)rows[x] & 0xFFFFu);
+        else {
+          std::vector<uint64_t> words(1024, 0);
+          for (size_t x = ct.second.first; x < ct.second.second; x++) { const uint32_t v = (uint32_t)rows[x] & 0xFFFFu; words[v >> 6] |= 1ull << (v & 63); }
+          for (uint64_t w : words) { le32((uint32_t)w); le32((uint32_t)(w >> 32)); }
+        }
+      }
+      fixed.i32((int32_t)rb.size());
+      var.bytes(rb.b.data(), rb.size());
     }
   }
   // ---- sections -----------------------------------------------------------------------------------------------------------------------

@@ -375,6 +375,7 @@ struct Result {
   std::vector<AggResult> aggs;
   // PG_QUERY_FLAG_NULL_HANDLING: per aggregation / per group-by column, 1 where the group's result / key is NULL (empty vector: none is)
   std::vector<std::vector<uint8_t>> agg_nulls, key_nulls;
+  bool null_handling = false;   // the query ran with PG_QUERY_FLAG_NULL_HANDLING (its data table carries the columns' null bitmaps)
   pg_exec_stats stats{};
 };
 struct DocIdSet {

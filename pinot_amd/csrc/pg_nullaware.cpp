@@ -333,6 +333,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q_in, const 
   if (null_keys.empty()) {
     auto r = run_joined(seg, q, cancel, false);
     if (null_args || r->schema_aggs.empty()) fill_result_schema(seg, q, *r);
+    r->null_handling = true;
     return r;
   }
   // 2^k partitions of the matching docs by which of the nullable group-by columns are null
@@ -378,6 +379,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q_in, const 
   out->stats.num_groups_limit_reached = out->num_groups >= limit ? 1 : 0;
   out->stats.stats_exact = 0;   // the filter ran once per partition: numEntriesScannedInFilter is the first partition's
   fill_result_schema(seg, q, *out);
+  out->null_handling = true;
   return out;
 }
 

@@ -69,3 +69,38 @@ def test_register_set_sizes(log2m, words):
 def test_column_offsets():
     offs, size = dt.column_offsets(["INT", "STRING", "LONG", "FLOAT", "OBJECT", "DOUBLE", "BYTES"])
     assert offs == [0, 4, 8, 16, 20, 28, 36] and size == 44
+
+
+def test_null_row_ids_round_trip_and_known_bytes():
+    """enableNullHandling: placeholders + per-column null bitmaps behind the rows (DataTableBuilderV4#setNullRowIds, GroupByResultsBlock.java:196-222)"""
+    names, types = ["k", "s", "sum(m)", "avg(m)"], ["INT", "STRING", "DOUBLE", "OBJECT"]
+    rows = [[7, "a", 1.5, dt.AvgPair((3.0, 2))], [None, None, None, None], [9, "b", None, dt.AvgPair((1.0, 1))]]
+    b = dt.build_data_table_v4(names, types, rows, null_handling=True)
+    p = dt.parse_data_table_v4(b)
+    assert p["rows"] == rows and p["null_row_ids"] == [[1], [1], [1, 2], []]   # a null OBJECT of a group-by block is NULL_TYPE_VALUE, not a bitmap entry
+    # the trailer: 4 columns x (position, length); an array container of one value is 8 + 4 + 4 + 2 = 18 bytes
+    h = struct.unpack_from(">13i", b, 0)
+    fixed = b[h[9]:h[9] + h[10]]
+    row_size = 4 + 4 + 8 + 8
+    assert len(fixed) == 3 * row_size + 4 * 8
+    trailer = struct.unpack_from(">8i", fixed, 3 * row_size)
+    assert trailer[1] == 18 and trailer[3] == 18 and trailer[5] == 20 and trailer[7] == 0
+    # the aggregation-only block marks a null OBJECT in the bitmap as well (AggregationResultsBlock.java:124-130)
+    b = dt.build_data_table_v4(["sum(m)", "avg(m)"], ["DOUBLE", "OBJECT"], [[None, None]], null_handling=True, group_by=False)
+    assert dt.parse_data_table_v4(b)["null_row_ids"] == [[0], [0]]
+    # no nulls: the trailer is still there, all lengths 0
+    b = dt.build_data_table_v4(["k"], ["INT"], [[1], [2]], null_handling=True)
+    assert dt.parse_data_table_v4(b)["null_row_ids"] == [[]]
+
+
+def test_null_bitmap_containers():
+    ids = list(range(0, 10000, 2)) + [70000, 70001] + list(range(131072, 131072 + 5000))
+    b = dt.serialize_null_row_ids(ids)
+    assert dt.deserialize_null_row_ids(b) == ids
+    cookie, n = struct.unpack_from("<II", b, 0)
+    assert (cookie, n) == (12346, 3)
+    # container 0: 5 000 values > 4 096 -> a bitmap container (8 192 bytes); container 1: array of 2; container 2: bitmap
+    assert len(b) == 8 + 3 * 4 + 3 * 4 + 8192 + 4 + 8192
+    from pinot_amd import formats
+    import numpy as np
+    assert formats.deserialize_roaring(b).tolist() == ids   # the segment-side reader of the same portable format agrees

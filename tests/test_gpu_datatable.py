@@ -123,3 +123,50 @@ def test_final_values_are_refused(seg):
     with pytest.raises(capi.NativeError):
         nr.data_table_v4()
     nr.free()
+
+
+# ---- enableNullHandling: placeholders, NULL_TYPE_VALUE objects and the columns' null bitmaps behind the rows ---------------------------------
+NULL_QUERIES = [
+    "SELECT gi, COUNT(*), SUM(m), MIN(m), AVG(m) FROM dt GROUP BY gi LIMIT 100",          # gi and m hold nulls: NULL key, NULL results
+    "SELECT gs, gi, COUNT(*), MAX(m), MINMAXRANGE(m) FROM dt GROUP BY gs, gi LIMIT 100",   # a NULL STRING key ("" placeholder in the dictionary)
+    "SELECT COUNT(*), SUM(m), AVG(m), MAX(m) FROM dt WHERE c > 1000",                      # one row of NULLs (and a 0)
+    "SELECT gl, COUNT(*), SUM(u) FROM dt GROUP BY gl LIMIT 100",                           # null handling, no null anywhere: empty bitmaps
+    "SELECT gi, COUNT(*) FROM dt WHERE c > 1000 GROUP BY gi LIMIT 100",                    # no rows
+]
+
+
+def test_data_table_with_null_vectors(gpu_api):
+    from pinot_amd import capi, formats
+    host = make_host()
+    n = host.total_docs
+    rng = np.random.default_rng(5)
+    for c, frac in (("gi", 0.1), ("gs", 0.2), ("m", 0.3)):
+        host.columns[c].null_vector = np.frombuffer(formats.serialize_roaring(np.flatnonzero(rng.random(n) < frac)), dtype=np.uint8)
+    s = NativeSegment(gpu_api, host)
+    for sql in NULL_QUERIES:
+        q = parse_sql(sql)
+        q.flags |= capi.QUERY_FLAG_NULL_HANDLING
+        nr = s.execute_native(q, keep_device_table=False)
+        got = nr.data_table_v4()
+        block = nr.block()
+        names = list(q.group_by) + [("count(*)" if a.function == "COUNT" else f"{FN[a.function]}({a.column})") for a in q.aggregations]
+        types = [host.columns[g].data_type for g in q.group_by] + \
+            ["LONG" if a.function == "COUNT" else ("DOUBLE" if a.function in ("SUM", "MIN", "MAX") else "OBJECT") for a in q.aggregations]
+        rows = []
+        keys = block.group_keys if q.group_by else [()]
+        for i, k in enumerate(keys):
+            row = [None if v is None else (float(v) if t in ("FLOAT", "DOUBLE") else (int(v) if t in ("INT", "LONG") else v)) for v, t in zip(k, types)]
+            for a, col in zip(q.aggregations, block.columns):
+                v = col[i]
+                if v is not None and a.function == "AVG":
+                    v = dt.AvgPair(v)
+                elif v is not None and a.function == "MINMAXRANGE":
+                    v = dt.MinMaxRangePair(v)
+                row.append(v)
+            rows.append(row)
+        want = dt.build_data_table_v4(names, types, rows, null_handling=True, group_by=bool(q.group_by))
+        assert got == want, sql
+        p = dt.parse_data_table_v4(got)
+        assert p["rows"] == rows and p["null_row_ids"] is not None, sql
+        nr.free()
+    s.destroy()
