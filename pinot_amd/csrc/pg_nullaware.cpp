@@ -13,6 +13,7 @@
 //     IS NOT NULL; their group lists are disjoint and are concatenated, the keys of S flagged NULL.
 // The filter itself is three-valued inside the planner (pg_plan.cpp, nh_trues / nh_falses).  The CPU oracle restates the same semantics doc
 // at a time (oracle/po_query.c), which is what the parity tests compare this composition with.
+#include <cstdint>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -190,6 +191,8 @@ std::unique_ptr<Result> run_joined(Segment& seg, const pg_query& q, const Cancel
         d.aggs.push_back(s);
       }
     d.finish(q, true);
+    // the main query decides which groups exist (numGroupsLimit admits keys in docId order over ALL the matching docs): a sub-query trims nothing
+    d.q.num_groups_limit = INT32_MAX;
     subs.push_back(execute_query_plain(seg, d.q, cancel));
     const Result& S = *subs.back();
     if (!agg_only)

@@ -100,3 +100,59 @@ def test_snapshot_swaps_under_concurrent_queries(gpu_api, oracle_api):
     assert not errors, errors[:3]
     assert len(seen) >= 2
     g.destroy()
+
+
+@pytest.mark.gpu
+def test_null_handling_queries_from_several_threads(gpu_api, oracle_api):
+    """The null-aware path runs several GPU queries per call and joins them on the host (pg_nullaware.cpp): eight threads over one segment,
+    every answer the oracle's; no memory growth over the repeats."""
+    from pinot_amd import capi
+    host, data, _ = fuzz_segment(60_000, seed=13)
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    gen = Gen(data, seed=777)
+    cases = []
+    for _ in range(60):
+        q = gen.query()
+        oq = clone(q)
+        oq.flags |= capi.QUERY_FLAG_NULL_HANDLING
+        try:
+            cases.append((q, o.execute(oq).rows()))
+        except capi.NativeError:
+            pass
+    o.destroy()
+    errors = []
+
+    def worker(k):
+        try:
+            for rep in range(6):
+                for i, (q, want) in enumerate(cases):
+                    if (i + k) % 2:
+                        continue
+                    gq = clone(q)
+                    gq.flags |= capi.QUERY_FLAG_NULL_HANDLING
+                    try:
+                        got = g.execute(gq).rows()
+                    except capi.NativeError as e:
+                        assert e.status == capi.PG_ERR_UNSUPPORTED
+                        continue
+                    assert got == want, i
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e)[:300])
+    for k in range(2):
+        worker(k)     # warm up: plans cached, per-thread workspaces at their high-water mark
+    import time
+
+    def threaded_phase():
+        threads = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        time.sleep(0.5)    # (the threads' contexts — streams, work areas — are released by their thread-local destructors)
+        return _free_hbm()
+    free1 = threaded_phase()
+    assert not errors, errors[:3]
+    free2 = threaded_phase()
+    assert not errors, errors[:3]
+    assert free1 - free2 < 256 << 20, f"HBM grew by {(free1 - free2) >> 20} MB over a second round of eight threads"
+    g.destroy()

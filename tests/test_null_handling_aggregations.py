@@ -172,6 +172,14 @@ def test_gpu_equals_oracle(gpu_api, oracle_api):
         a, b = g.execute(flagged(sql)), o.execute(flagged(sql))
         assert a.rows() == b.rows(), sql
         assert a.stats.num_docs_scanned == b.stats.num_docs_scanned, sql
+    # numGroupsLimit: the groups are the first N keys in docId order over ALL the matching docs — the joined sub-queries (other doc sets) trim nothing
+    for limit in (7, 20):
+        for sql in ("SELECT g, SUM(m), DISTINCTCOUNT(a), COUNT(*) FROM t GROUP BY g LIMIT 1000", "SELECT g, z, MAX(w), COUNT(x) FROM t WHERE r < 900 GROUP BY g, z LIMIT 1000"):
+            qa, qb = flagged(sql), flagged(sql)
+            qa.num_groups_limit = qb.num_groups_limit = limit
+            a, b = g.execute(qa), o.execute(qb)
+            assert a.rows() == b.rows() and len(a.rows()) == limit, (sql, limit)
+            assert a.stats.num_groups_limit_reached == b.stats.num_groups_limit_reached == 1
     # FINAL_DISTINCT travels through the joins
     q = flagged("SELECT g, DISTINCTCOUNT(w), DISTINCTCOUNTHLL(x), COUNT(*) FROM t GROUP BY g LIMIT 1000")
     q.flags |= capi.QUERY_FLAG_FINAL_DISTINCT
