@@ -91,8 +91,17 @@ const uint8_t* hll_row(const AggResult& a, int32_t i, size_t m) {
   return a.hll.data() + (size_t)i * m;
 }
 
-// appends group `i` of `src` (or, i < 0, "no value") to `dst`
-void append_agg(AggResult& dst, const AggResult* src, int32_t i, int32_t kind, int32_t log2m) {
+// start of every group's ids in a PG_RESULT_DICTID_SET result's concatenated set (empty for the other kinds)
+std::vector<int64_t> set_offsets(const AggResult& a) {
+  std::vector<int64_t> off;
+  if (a.kind != PG_RESULT_DICTID_SET) return off;
+  off.resize(a.set_sizes.size() + 1, 0);
+  for (size_t g = 0; g < a.set_sizes.size(); g++) off[g + 1] = off[g] + a.set_sizes[g];
+  return off;
+}
+
+// appends group `i` of `src` (or, i < 0, "no value") to `dst`; `set_off` = set_offsets(*src)
+void append_agg(AggResult& dst, const AggResult* src, int32_t i, int32_t kind, int32_t log2m, const std::vector<int64_t>& set_off) {
   dst.kind = kind;
   dst.log2m = log2m;
   switch (kind) {
@@ -109,8 +118,7 @@ void append_agg(AggResult& dst, const AggResult* src, int32_t i, int32_t kind, i
     case PG_RESULT_DICTID_SET: {
       int32_t n = 0;
       if (src && i >= 0) {
-        int64_t off = 0;
-        for (int32_t g = 0; g < i; g++) off += src->set_sizes[(size_t)g];
+        const int64_t off = set_off[(size_t)i];
         n = src->set_sizes[(size_t)i];
         dst.set_ids.insert(dst.set_ids.end(), src->set_ids.begin() + off, src->set_ids.begin() + off + n);
       }
@@ -224,6 +232,7 @@ std::unique_ptr<Result> run_joined(Segment& seg, const pg_query& q, const Cancel
     const int32_t kind = src_r.num_groups > 0 ? src.kind : kind_of(q, fn);
     std::vector<uint8_t> nulls;
     bool any_null = false;
+    const std::vector<int64_t> set_off = set_offsets(src);
     for (int32_t i = 0; i < ng; i++) {
       int32_t si = i;
       bool empty = false;
@@ -233,7 +242,7 @@ std::unique_ptr<Result> run_joined(Segment& seg, const pg_query& q, const Cancel
         if (it == sub_index[(size_t)k].end()) empty = true;
         else si = it->second;
       }
-      append_agg(dst, empty ? nullptr : &src, empty ? -1 : si, kind, log2m);
+      append_agg(dst, empty ? nullptr : &src, empty ? -1 : si, kind, log2m, set_off);
       const bool is_null = empty && null_over_nothing(fn);
       nulls.push_back(is_null ? 1 : 0);
       any_null |= is_null;
@@ -282,7 +291,8 @@ void append_groups(Result& out, const Result& part, const pg_query& q, const std
     if (!pn.empty() && an.empty()) an.assign((size_t)before, 0);
     if (!an.empty()) { if (pn.empty()) an.insert(an.end(), (size_t)n, 0); else an.insert(an.end(), pn.begin(), pn.begin() + n); }
     const int32_t log2m = src.log2m ? src.log2m : (q.aggregations[a].log2m > 0 ? q.aggregations[a].log2m : 8);
-    for (int32_t i = 0; i < n; i++) append_agg(dst, &src, i, src.kind, log2m);
+    const std::vector<int64_t> set_off = set_offsets(src);
+    for (int32_t i = 0; i < n; i++) append_agg(dst, &src, i, src.kind, log2m, set_off);
     if (n == 0 && before == 0) { dst.kind = src.kind; dst.log2m = log2m; }
   }
   out.num_groups = before + n;
