@@ -212,8 +212,8 @@ typedef struct pg_query {
                                               group key of its own (pg_result_group_key_nulls).  A star-tree answers only when no column the query reads
                                               holds a null (StarTreeUtils.java:381-418); a lone COUNT(*) over an index-only filter is still
                                               FastFilteredCountOperator, which knows no nulls (AggregationPlanNode.java:104-108).  Refused
-                                              (PG_ERR_UNSUPPORTED: the Java plan answers): nulls in a multi-value column or in a no-dictionary
-                                              group-by column, more than 3 nullable group-by columns, PG_QUERY_FLAG_KEEP_DEVICE_TABLE next to nulls */
+                                              (PG_ERR_UNSUPPORTED: the Java plan answers): nulls in a multi-value column, more than 3 nullable
+                                              group-by columns, more groups than numGroupsLimit across their null partitions, PG_QUERY_FLAG_KEEP_DEVICE_TABLE next to nulls */
 #define PG_QUERY_FLAG_KEEP_DEVICE_TABLE 0x4 /* keep the dense accumulator table in HBM with the result (pg_result_merge / _all_reduce) */
 
 /* ExecutionStatistics (pinot-core/.../operator/ExecutionStatistics.java) + device timings. */

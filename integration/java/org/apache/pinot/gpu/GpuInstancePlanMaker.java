@@ -72,8 +72,7 @@ public class GpuInstancePlanMaker extends InstancePlanMakerImplV2 {
   public PlanNode makeSegmentPlanNode(SegmentContext segmentContext, QueryContext queryContext) {
     IndexSegment segment = segmentContext.getIndexSegment();
     // (enableNullHandling travels in the query record: three-valued filters, null-skipping aggregations and null group keys are answered by
-    // the library — results and keys come back with NULL flags, GpuGroupByOperator#blockOf; it refuses nulls in multi-value columns and in
-    // no-dictionary group-by columns)
+    // the library — results and keys come back with NULL flags, GpuGroupByOperator#blockOf; it refuses nulls in multi-value columns)
     if (segment instanceof ImmutableSegment && QueryContextUtils.isAggregationQuery(queryContext)) {
       long handle = _registry.handleFor((ImmutableSegment) segment, segmentContext);   // pins the columns in HBM on first use; 0: Java plan only
       if (handle != 0) {

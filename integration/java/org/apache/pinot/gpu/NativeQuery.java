@@ -30,7 +30,7 @@ public final class NativeQuery implements AutoCloseable {
   private static final int P_EQ = 0, P_NOT_EQ = 1, P_IN = 2, P_NOT_IN = 3, P_RANGE = 4, P_IS_NULL = 5, P_IS_NOT_NULL = 6;
   private static final int FLAG_SKIP_STAR_TREE = 0x2;
   // PG_QUERY_FLAG_NULL_HANDLING: three-valued filters, null-skipping aggregations, null group keys (pg_query_supported refuses nulls in
-  // multi-value columns / no-dictionary group-by columns)
+  // multi-value columns)
   private static final int FLAG_NULL_HANDLING = 0x40;
 
   private final long _address;

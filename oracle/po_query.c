@@ -415,16 +415,21 @@ typedef struct group_key_gen {
   int64_t* tuples; int32_t tuple_cap, n_tuples;
   int32_t* tuple_table; int32_t tuple_table_cap;
   bytes_dict* bytes_dicts;      /* HOLDER_TUPLES: per raw STRING / BYTES column its on-the-fly dictionary (the tuple holds the id) */
+  int tuple_w;                  /* int64 slots per tuple: n_cols, or n_cols + 1 under null handling (the last slot = bit mask of the null raw columns) */
+  const po_bitmap** raw_nulls;  /* null handling: per no-dictionary column its null bitmap (NULL: none) */
 } group_key_gen;
 
 /* constructor, DictionaryBasedGroupKeyGenerator.java:106-185 */
-static int gkg_init(group_key_gen* g, int n_cols, po_column** cols, int32_t num_groups_limit, int32_t array_threshold) {
+static int gkg_init(group_key_gen* g, int n_cols, po_column** cols, int32_t num_groups_limit, int32_t array_threshold, const po_bitmap** raw_nulls) {
   memset(g, 0, sizeof(*g));
   g->n_cols = n_cols;
   g->cols = cols;
-  int any_raw = 0;
+  g->tuple_w = n_cols;
+  int any_raw = 0, any_raw_null = 0;
   for (int i = 0; i < n_cols; i++) any_raw |= !cols[i]->has_dictionary;
-  if (any_raw && !(n_cols == 1 && (cols[0]->data_type == PG_TYPE_INT || cols[0]->data_type == PG_TYPE_LONG))) {
+  for (int i = 0; i < n_cols && raw_nulls; i++) any_raw_null |= !cols[i]->has_dictionary && raw_nulls[i] != NULL;
+  if (any_raw_null) { g->raw_nulls = raw_nulls; g->tuple_w = n_cols + 1; }   /* a null raw value: key 0 + its bit in the mask slot */
+  if (any_raw && (any_raw_null || !(n_cols == 1 && (cols[0]->data_type == PG_TYPE_INT || cols[0]->data_type == PG_TYPE_LONG)))) {
     /* DefaultGroupByExecutor.java:100-118: any group-by expression without a dictionary → the no-dictionary generators; both admit
      * new keys in docId order until numGroupsLimit (NoDictionaryMultiColumnGroupKeyGenerator.java:60-130,
      * NoDictionarySingleColumnGroupKeyGenerator.java:238-262) */
@@ -432,7 +437,7 @@ static int gkg_init(group_key_gen* g, int n_cols, po_column** cols, int32_t num_
     g->global_upper_bound = num_groups_limit;
     g->cardinalities = (int32_t*)po_xcalloc((size_t)n_cols + 1, 4);
     g->tuple_cap = 1024;
-    g->tuples = (int64_t*)po_xmalloc(sizeof(int64_t) * (size_t)g->tuple_cap * (size_t)n_cols);
+    g->tuples = (int64_t*)po_xmalloc(sizeof(int64_t) * (size_t)g->tuple_cap * (size_t)g->tuple_w);
     g->tuple_table_cap = 4096;
     g->tuple_table = (int32_t*)po_xcalloc((size_t)g->tuple_table_cap, 4);
     g->bytes_dicts = (bytes_dict*)po_xcalloc((size_t)n_cols + 1, sizeof(bytes_dict));
@@ -540,38 +545,41 @@ static uint64_t tuple_hash(const int64_t* t, int n) {
   return h;
 }
 static void tuple_table_insert(group_key_gen* g, int32_t gid) {
-  uint64_t p = tuple_hash(g->tuples + (size_t)gid * (size_t)g->n_cols, g->n_cols) & (uint64_t)(g->tuple_table_cap - 1);
+  uint64_t p = tuple_hash(g->tuples + (size_t)gid * (size_t)g->tuple_w, g->tuple_w) & (uint64_t)(g->tuple_table_cap - 1);
   while (g->tuple_table[p]) p = (p + 1) & (uint64_t)(g->tuple_table_cap - 1);
   g->tuple_table[p] = gid + 1;
 }
 /* generateKeysForBlock: existing tuple -> its id; a new tuple is admitted while fewer than numGroupsLimit groups exist, else INVALID_ID */
 static void gkg_generate_tuples(group_key_gen* g, int n_docs, const int32_t* doc_ids, int32_t** dict_ids, int32_t* out) {
-  const int nc = g->n_cols;
-  int64_t key[64];
+  const int nc = g->n_cols, tw = g->tuple_w;
+  int64_t key[65];
   for (int i = 0; i < n_docs; i++) {
+    int64_t null_mask = 0;
     for (int j = 0; j < nc; j++) {
       const po_column* c = g->cols[j];
       if (c->has_dictionary) key[j] = (int64_t)dict_ids[j][i];
+      else if (g->raw_nulls && g->raw_nulls[j] && po_bitmap_contains(g->raw_nulls[j], doc_ids[i])) { key[j] = 0; null_mask |= (int64_t)1 << j; }
       else if (c->data_type > PG_TYPE_DOUBLE) {   /* STRING / BYTES: the on-the-fly dictionary's id of the value */
         int32_t len = 0;
         const uint8_t* v = po_raw_get_bytes(c, doc_ids[i], &len);
         key[j] = bytes_dict_index(&g->bytes_dicts[j], v, len);
       } else key[j] = raw_key_of_doc(c, doc_ids[i]);
     }
-    uint64_t p = tuple_hash(key, nc) & (uint64_t)(g->tuple_table_cap - 1);
+    if (tw > nc) key[nc] = null_mask;
+    uint64_t p = tuple_hash(key, tw) & (uint64_t)(g->tuple_table_cap - 1);
     int32_t gid = PO_INVALID_ID;
     while (g->tuple_table[p]) {
-      const int64_t* t = g->tuples + (size_t)(g->tuple_table[p] - 1) * (size_t)nc;
-      if (memcmp(t, key, sizeof(int64_t) * (size_t)nc) == 0) { gid = g->tuple_table[p] - 1; break; }
+      const int64_t* t = g->tuples + (size_t)(g->tuple_table[p] - 1) * (size_t)tw;
+      if (memcmp(t, key, sizeof(int64_t) * (size_t)tw) == 0) { gid = g->tuple_table[p] - 1; break; }
       p = (p + 1) & (uint64_t)(g->tuple_table_cap - 1);
     }
     if (gid == PO_INVALID_ID && g->n_tuples < g->global_upper_bound) {
       if (g->n_tuples == g->tuple_cap) {
         g->tuple_cap *= 2;
-        g->tuples = (int64_t*)po_xrealloc(g->tuples, sizeof(int64_t) * (size_t)g->tuple_cap * (size_t)nc);
+        g->tuples = (int64_t*)po_xrealloc(g->tuples, sizeof(int64_t) * (size_t)g->tuple_cap * (size_t)tw);
       }
       gid = g->n_tuples++;
-      memcpy(g->tuples + (size_t)gid * (size_t)nc, key, sizeof(int64_t) * (size_t)nc);
+      memcpy(g->tuples + (size_t)gid * (size_t)tw, key, sizeof(int64_t) * (size_t)tw);
       if ((int64_t)g->n_tuples * 2 > g->tuple_table_cap) {   /* rehash */
         free(g->tuple_table);
         g->tuple_table_cap *= 4;
@@ -1131,7 +1139,7 @@ static int null_handling_refused(po_segment* seg, const pg_query* q) {
     mv_gb |= c->is_mv;
     if (col_nulls(c)) {
       null_gb = 1;
-      if (c->is_mv || !c->has_dictionary) { po_set_error("enableNullHandling: nulls in the %s group-by column %s", c->is_mv ? "multi-value" : "no-dictionary", c->name); return 1; }
+      if (c->is_mv) { po_set_error("enableNullHandling: nulls in the multi-value group-by column %s", c->name); return 1; }
     }
   }
   if (mv_gb && null_gb) { po_set_error("enableNullHandling: null group keys next to a multi-value group-by column"); return 1; }
@@ -1323,9 +1331,11 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
   po_column* gaug = (po_column*)po_xcalloc((size_t)n_gb + 1, sizeof(po_column));
   po_column** gkg_cols = (po_column**)po_xcalloc((size_t)n_gb + 1, sizeof(po_column*));
   int32_t** gbuf = (int32_t**)po_xcalloc((size_t)n_gb + 1, sizeof(int32_t*));
+  const po_bitmap** rnull = (const po_bitmap**)po_xcalloc((size_t)n_gb + 1, sizeof(po_bitmap*));   /* no-dictionary columns: a mask slot in the tuple */
   for (int j = 0; j < n_gb; j++) {
     gkg_cols[j] = gcols[j];
     if (!nh || res->stats.star_tree_index >= 0) continue;
+    if (!gcols[j]->has_dictionary) { rnull[j] = col_nulls(gcols[j]); continue; }
     gnull[j] = col_nulls(gcols[j]);
     if (!gnull[j]) continue;
     gaug[j] = *gcols[j];
@@ -1335,7 +1345,7 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
   }
   group_key_gen gkg;
   if (n_gb > 0) {
-    if (gkg_init(&gkg, n_gb, gkg_cols, num_groups_limit, max_init_cap)) return PG_ERR_UNSUPPORTED;
+    if (gkg_init(&gkg, n_gb, gkg_cols, num_groups_limit, max_init_cap, rnull)) return PG_ERR_UNSUPPORTED;
     int32_t max_results = gkg.global_upper_bound;
     int32_t initial = max_results < max_init_cap ? max_results : max_init_cap;
     for (int i = 0; i < n_aggs; i++) agg_ensure_capacity(&aggs[i], initial > 0 ? initial : 1);
@@ -1479,7 +1489,7 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
       const po_column* c = gcols[j];
       if (c->has_dictionary) {
         res->key_types[j] = PG_GROUP_KEY_DICT_IDS;
-        for (int32_t i = 0; i < n_groups; i++) res->group_dict_ids[j][i] = (int32_t)gkg.tuples[(size_t)gid_of[i] * (size_t)n_gb + (size_t)j];
+        for (int32_t i = 0; i < n_groups; i++) res->group_dict_ids[j][i] = (int32_t)gkg.tuples[(size_t)gid_of[i] * (size_t)gkg.tuple_w + (size_t)j];
         continue;
       }
       if (c->data_type > PG_TYPE_DOUBLE) {   /* the groups' byte strings, back to back */
@@ -1493,12 +1503,12 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
         res->key_bytes_off[j] = (int64_t*)po_xcalloc((size_t)n_groups + 2, 8);
         for (int32_t i = 0; i < n_groups; i++) {
           res->key_bytes_off[j][i] = total;
-          total += bd->lens[gkg.tuples[(size_t)gid_of[i] * (size_t)n_gb + (size_t)j]];
+          total += bd->lens[gkg.tuples[(size_t)gid_of[i] * (size_t)gkg.tuple_w + (size_t)j]];
         }
         res->key_bytes_off[j][n_groups] = total;
         res->key_bytes[j] = (uint8_t*)po_xmalloc((size_t)total + 1);
         for (int32_t i = 0; i < n_groups; i++) {
-          const int64_t id = gkg.tuples[(size_t)gid_of[i] * (size_t)n_gb + (size_t)j];
+          const int64_t id = gkg.tuples[(size_t)gid_of[i] * (size_t)gkg.tuple_w + (size_t)j];
           memcpy(res->key_bytes[j] + res->key_bytes_off[j][i], bd->vals[id], (size_t)bd->lens[id]);
         }
         continue;
@@ -1506,7 +1516,7 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
       res->key_types[j] = c->data_type <= PG_TYPE_LONG ? PG_GROUP_KEY_LONG_VALUES : PG_GROUP_KEY_DOUBLE_VALUES;
       res->key_values[j] = (int64_t*)po_xcalloc((size_t)n_groups + 1, 8);
       for (int32_t i = 0; i < n_groups; i++) {
-        int64_t k = gkg.tuples[(size_t)gid_of[i] * (size_t)n_gb + (size_t)j];
+        int64_t k = gkg.tuples[(size_t)gid_of[i] * (size_t)gkg.tuple_w + (size_t)j];
         if (c->data_type == PG_TYPE_FLOAT) { uint32_t b = (uint32_t)k; float f; memcpy(&f, &b, 4); double d = (double)f; memcpy(&k, &d, 8); }
         res->key_values[j][i] = k;
       }
@@ -1518,6 +1528,13 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
       res->group_dict_ids[j][i] = (int32_t)(raw % gkg.cardinalities[j]);
       raw /= gkg.cardinalities[j];
     }
+  }
+  for (int j = 0; j < n_gb && n_gb > 0 && gkg.holder == HOLDER_TUPLES && gkg.tuple_w > n_gb; j++) {   /* the mask slot: null raw keys */
+    if (!rnull[j]) continue;
+    if (!res->key_nulls) res->key_nulls = (uint8_t**)po_xcalloc((size_t)n_gb + 1, sizeof(uint8_t*));
+    res->key_nulls[j] = (uint8_t*)po_xcalloc((size_t)n_groups + 1, 1);
+    for (int32_t i = 0; i < n_groups; i++)
+      res->key_nulls[j][i] = (uint8_t)((gkg.tuples[(size_t)gid_of[i] * (size_t)gkg.tuple_w + (size_t)n_gb] >> j) & 1);
   }
   for (int j = 0; j < n_gb; j++) {   /* the id one past the dictionary is the null key */
     if (!gnull[j]) continue;

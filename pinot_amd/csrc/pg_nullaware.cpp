@@ -255,7 +255,7 @@ std::unique_ptr<Result> run_joined(Segment& seg, const pg_query& q, const Cancel
 }
 
 // appends the groups of `part` (GROUP BY over the columns `kept` of the original GROUP BY; the others are NULL in every group) to `out`
-void append_groups(Result& out, const Result& part, const pg_query& q, const std::vector<int>& kept, Segment& seg) {
+void append_groups(Result& out, const Result& part, const pg_query& q, const std::vector<int>& kept, bool first_partition) {
   const int32_t n = part.num_groups;
   const int32_t before = out.num_groups;
   for (int j = 0; j < q.n_group_by; j++) {
@@ -265,13 +265,20 @@ void append_groups(Result& out, const Result& part, const pg_query& q, const std
     std::vector<uint8_t>& kn = out.key_nulls[(size_t)j];
     if (dropped && kn.empty()) kn.assign((size_t)before, 0);
     if (!kn.empty() || dropped) kn.insert(kn.end(), (size_t)n, dropped ? 1 : 0);
-    // the key arrays: a dropped column is a dictionary column here (check_null_handling): dictId 0 under the NULL flag
+    // the key arrays: a dropped column holds a placeholder under the NULL flag — dictId 0, value 0, an empty byte string (the key types are
+    // those of the first partition, which keeps every column)
     if (dropped) {
-      out.group_dict_ids[(size_t)j].insert(out.group_dict_ids[(size_t)j].end(), (size_t)n, 0);
+      const int32_t t = out.group_key_type[(size_t)j];
+      if (t == PG_GROUP_KEY_DICT_IDS) out.group_dict_ids[(size_t)j].insert(out.group_dict_ids[(size_t)j].end(), (size_t)n, 0);
+      else if (t == PG_GROUP_KEY_BYTES_VALUES) {
+        auto& off = out.group_bytes_off[(size_t)j];
+        if (off.empty()) off.push_back(0);
+        off.insert(off.end(), (size_t)n, off.back());
+      } else out.group_values[(size_t)j].insert(out.group_values[(size_t)j].end(), (size_t)n, 0);
       continue;
     }
     const int32_t t = part.group_key_type[(size_t)kj];
-    if (before == 0) out.group_key_type[(size_t)j] = t;
+    if (first_partition) out.group_key_type[(size_t)j] = t;
     if (out.group_key_type[(size_t)j] != t) fail(PG_ERR_INTERNAL, "null handling: group key types differ between the null partitions");
     if (t == PG_GROUP_KEY_DICT_IDS) out.group_dict_ids[(size_t)j].insert(out.group_dict_ids[(size_t)j].end(), part.group_dict_ids[(size_t)kj].begin(), part.group_dict_ids[(size_t)kj].begin() + n);
     else if (t == PG_GROUP_KEY_BYTES_VALUES) {
@@ -288,15 +295,16 @@ void append_groups(Result& out, const Result& part, const pg_query& q, const std
     const AggResult& src = part.aggs[(size_t)a];
     std::vector<uint8_t>& an = out.agg_nulls[(size_t)a];
     const std::vector<uint8_t>& pn = part.agg_nulls.empty() ? std::vector<uint8_t>() : part.agg_nulls[(size_t)a];
-    if (!pn.empty() && an.empty()) an.assign((size_t)before, 0);
-    if (!an.empty()) { if (pn.empty()) an.insert(an.end(), (size_t)n, 0); else an.insert(an.end(), pn.begin(), pn.begin() + n); }
+    if (!pn.empty() || !an.empty()) {   // (flags exist once any partition brought one: zeros for the groups before and the partitions without)
+      an.resize((size_t)before, 0);
+      if (pn.empty()) an.insert(an.end(), (size_t)n, 0); else an.insert(an.end(), pn.begin(), pn.begin() + n);
+    }
     const int32_t log2m = src.log2m ? src.log2m : (q.aggregations[a].log2m > 0 ? q.aggregations[a].log2m : 8);
     const std::vector<int64_t> set_off = set_offsets(src);
     for (int32_t i = 0; i < n; i++) append_agg(dst, &src, i, src.kind, log2m, set_off);
     if (n == 0 && before == 0) { dst.kind = src.kind; dst.log2m = log2m; }
   }
   out.num_groups = before + n;
-  (void)seg;
 }
 
 }  // namespace
@@ -314,8 +322,7 @@ void check_null_handling(Segment& seg, const pg_query& q) {
     if (!has_nulls(seg, q.group_by_columns[j])) continue;
     null_keys++;
     any_nulls = true;
-    if (c->is_mv || !c->has_dictionary)
-      fail(PG_ERR_UNSUPPORTED, "enableNullHandling: nulls in the %s group-by column %s", c->is_mv ? "multi-value" : "no-dictionary", c->name.c_str());
+    if (c->is_mv) fail(PG_ERR_UNSUPPORTED, "enableNullHandling: nulls in the multi-value group-by column %s", c->name.c_str());
   }
   if (null_keys > 3) fail(PG_ERR_UNSUPPORTED, "enableNullHandling: %d group-by columns hold nulls (at most 3 are partitioned)", null_keys);
   if (null_keys && mv_keys) fail(PG_ERR_UNSUPPORTED, "enableNullHandling: null group keys next to a multi-value group-by column");
@@ -382,8 +389,8 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q_in, const 
       out->stats.host_ms_total += part->stats.host_ms_total;
       out->stats.device_ms_total += part->stats.device_ms_total;
     }
+    append_groups(*out, *part, q, kept, s == 0);
     first = false;
-    append_groups(*out, *part, q, kept, seg);
   }
   // the reference admits the first numGroupsLimit keys in docId order over ALL the docs; which ones that is across the partitions is not
   // restated: refuse rather than return another subset

@@ -439,7 +439,8 @@ class ResultsBlock:
     @property
     def group_keys(self) -> List[tuple]:
         if self._group_keys is None and getattr(self, "group_values", None) is not None:
-            self._group_keys = [(int(v),) for v in self.group_values]
+            kn = getattr(self, "key_nulls", {}).get(0)
+            self._group_keys = [(None if (kn is not None and kn[i]) else int(v),) for i, v in enumerate(self.group_values)]
         if self._group_keys is None:
             ids = self.group_dict_ids
             vcols = getattr(self, "group_value_columns", {})

@@ -61,8 +61,6 @@ def check_reference_expectations(seg):
 
 @pytest.mark.parametrize("dictionary", [True, False])
 def test_oracle_reproduces_null_enabled_queries_test(oracle_api, dictionary):
-    if not dictionary:
-        pytest.skip("GROUP BY over a no-dictionary column with nulls is not restated")
     seg = NativeSegment(oracle_api, reference_table(dictionary))
     check_reference_expectations(seg)
     seg.destroy()
@@ -125,6 +123,9 @@ QUERIES = [
     "SELECT a, COUNT(*) FROM t WHERE a IS NULL GROUP BY a LIMIT 10",                            # only the NULL group
     "SELECT a, COUNT(*) FROM t WHERE a IS NOT NULL AND a < 3 GROUP BY a LIMIT 10",
     "SELECT b, SUM(m) FROM t WHERE g > 1000 GROUP BY b LIMIT 10",                               # no group at all
+    "SELECT r, COUNT(*), SUM(z) FROM t WHERE g < 5 GROUP BY r LIMIT 100000",                    # a no-dictionary INT key with nulls
+    "SELECT x, COUNT(*), MAX(m) FROM t WHERE g = 1 GROUP BY x LIMIT 100000",                    # a no-dictionary DOUBLE key with nulls
+    "SELECT a, r, COUNT(*), SUM(w) FROM t WHERE g < 3 GROUP BY a, r LIMIT 100000",              # dictionary and no-dictionary NULL keys together
 ]
 
 
@@ -158,8 +159,9 @@ def test_oracle_runs_every_query(oracle_api):
 
 
 @pytest.mark.gpu
-def test_gpu_reproduces_null_enabled_queries_test(gpu_api):
-    seg = NativeSegment(gpu_api, reference_table(True))
+@pytest.mark.parametrize("dictionary", [True, False])
+def test_gpu_reproduces_null_enabled_queries_test(gpu_api, dictionary):
+    seg = NativeSegment(gpu_api, reference_table(dictionary))
     check_reference_expectations(seg)
     seg.destroy()
 

@@ -1,6 +1,6 @@
 """PG_QUERY_FLAG_NULL_HANDLING (QueryContext#isNullHandlingEnabled) where it cannot change the answer — no column the query reads holds a null
 in the segment: the reference keeps its ordinary plan then (AggregationPlanNode.java:104-121 hasNullValues, StarTreeUtils.java:381-400), fast
-paths and star-trees included — and what is refused (nulls in multi-value columns / no-dictionary group-by columns).  The null-aware filters,
+paths and star-trees included — (what is refused: nulls in multi-value columns).  The null-aware filters,
 aggregations and keys themselves: tests/test_null_handling_filters.py, tests/test_null_handling_aggregations.py."""
 import pytest
 
@@ -25,10 +25,9 @@ NULL_AWARE = [   # columns with nulls: answered in three-valued logic / with NUL
     "SELECT COUNT(*) FROM nulls WHERE d IS NULL",
     "SELECT g, COUNT(*) FROM nulls WHERE NOT (r < 500) GROUP BY g LIMIT 1000",
     "SELECT SUM(m), MAX(m) FROM nulls WHERE g > 1000",                                # no GROUP BY, nothing matches: null results
+    "SELECT r, COUNT(*) FROM nulls WHERE g < 4 GROUP BY r LIMIT 100000",              # a no-dictionary group-by column with nulls
 ]
-REFUSED = [
-    "SELECT r, COUNT(*) FROM nulls GROUP BY r LIMIT 100000",                          # a no-dictionary group-by column with nulls
-]
+REFUSED = []   # (nulls in multi-value columns: tests/test_null_handling_aggregations.py)
 
 
 def flagged(sql):
