@@ -244,7 +244,8 @@ JNIEXPORT jlong JNICALL Java_org_apache_pinot_gpu_PinotGpu_filterExec(JNIEnv* en
   (void)c;
   pg_docidset_t s = NULL;
   if (!q) { jclass x = (*env)->FindClass(env, "java/lang/NullPointerException"); if (x) (*env)->ThrowNew(env, x, "query"); return 0; }
-  CHECK_RET(pg_filter_exec(SEG(seg), pgshim_query_get((const pgshim_query*)(intptr_t)q)->filter, &s), 0);
+  const pg_query* pq = pgshim_query_get((const pgshim_query*)(intptr_t)q);
+  CHECK_RET(pg_filter_exec_flags(SEG(seg), pq->filter, pq->flags, &s), 0);   /* the query record's enableNullHandling: three-valued getTrues */
   return (jlong)(intptr_t)s;
 }
 JNIEXPORT jlong JNICALL Java_org_apache_pinot_gpu_PinotGpu_docIdSetCardinality(JNIEnv* env, jclass c, jlong s) { (void)c; int64_t n = 0; CHECK_RET(pg_docidset_cardinality(SET(s), &n), 0); return n; }
