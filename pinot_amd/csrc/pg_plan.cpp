@@ -1048,8 +1048,8 @@ std::shared_ptr<CompiledPlan> compile_plan(Segment& seg, const pg_filter_node* f
                    (c->data_type <= PG_TYPE_DOUBLE || f == PG_AGG_DISTINCTCOUNT || f == PG_AGG_DISTINCTCOUNTHLL);
   }
   // StarTreeUtils.java:381-418: under null handling a star-tree answers only if no column the query reads holds a null in this segment
-  bool star_tree_blocked = false;
-  if (nh && q && !seg.star_trees.empty()) {
+  bool star_tree_blocked = nh && q && (q->flags & kQueryFlagNullPartition) != 0;   // a part of a query that reads a column with nulls
+  if (nh && q && !seg.star_trees.empty() && !star_tree_blocked) {
     std::function<bool(const pg_filter_node*)> filter_has_nulls = [&](const pg_filter_node* f) -> bool {
       if (!f) return false;
       if (f->type == PG_FILTER_PREDICATE) return f->column && null_vector_of(seg, seg.find(f->column)) != nullptr;
