@@ -262,3 +262,40 @@ def test_oracle_reproduces_null_handling_enabled_queries_test(oracle_api):
 @pytest.mark.gpu
 def test_gpu_reproduces_null_handling_enabled_queries_test(gpu_api):
     reference_small_cases(gpu_api)
+
+
+# ---- AllNullQueriesTest (pinot-core/src/test/java/org/apache/pinot/queries/AllNullQueriesTest.java:86-97 the table — 1 000 records whose one
+# column is null everywhere — and :336-363, :443-468, :470-497, :538-582, :584-601 the expectations; its broker serves the segment 4 times) -----
+def all_null_cases(api, data_type, dictionary):
+    n = 1000
+    values = np.zeros(n, dtype={"INT": np.int32, "LONG": np.int64, "FLOAT": np.float32, "DOUBLE": np.float64}[data_type])
+    host = build_segment("testTable_0", {"column": values}, {"column": data_type}, no_dictionary_columns=[] if dictionary else ["column"])
+    host.columns["column"].null_vector = np.frombuffer(formats.serialize_roaring(np.arange(n)), dtype=np.uint8)
+    seg = NativeSegment(api, host)
+    assert seg.execute(flagged("SELECT COUNT(*), COUNT(column), MIN(column), MAX(column) FROM testTable")).aggregation_result() == [1000, 0, None, None]
+    assert seg.execute(flagged("SELECT COUNT(column), MIN(column), MAX(column), AVG(column), SUM(column) FROM testTable")).aggregation_result() == \
+        [0, None, None, None, None]
+    assert seg.execute(flagged("SELECT column, COUNT(*) FROM testTable GROUP BY column LIMIT 1000")).rows() == {(None,): [1000]}
+    assert seg.execute(flagged("SELECT column, AVG(column), MAX(column) FROM testTable GROUP BY column LIMIT 20")).rows() == {(None,): [None, None]}
+    assert seg.execute(flagged("SELECT COUNT(column), MIN(column), MAX(column), SUM(column) FROM testTable WHERE column = 69")).aggregation_result() == \
+        [0, None, None, None]
+    assert seg.filter("SELECT COUNT(*) FROM testTable WHERE column IS NULL", null_handling=True).cardinality() == 1000
+    assert seg.filter("SELECT COUNT(*) FROM testTable WHERE column IS NOT NULL", null_handling=True).cardinality() == 0
+    assert seg.filter("SELECT COUNT(*) FROM testTable WHERE column > 69", null_handling=True).cardinality() == 0
+    # (not in the reference's test: NOT over a no-dictionary predicate leaves out the nulls; over a dictionary whose values cannot match, the
+    # predicate is EmptyFilterOperator — two-valued — and its NOT matches every doc: FilterOperatorUtils.java:76-78,186-196)
+    assert seg.filter("SELECT COUNT(*) FROM testTable WHERE NOT column > 69", null_handling=True).cardinality() == (1000 if dictionary else 0)
+    seg.destroy()
+
+
+@pytest.mark.parametrize("data_type", ["INT", "LONG", "FLOAT", "DOUBLE"])
+@pytest.mark.parametrize("dictionary", [True, False])
+def test_oracle_reproduces_all_null_queries_test(oracle_api, data_type, dictionary):
+    all_null_cases(oracle_api, data_type, dictionary)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("data_type", ["INT", "LONG", "FLOAT", "DOUBLE"])
+@pytest.mark.parametrize("dictionary", [True, False])
+def test_gpu_reproduces_all_null_queries_test(gpu_api, data_type, dictionary):
+    all_null_cases(gpu_api, data_type, dictionary)
