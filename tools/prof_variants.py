@@ -109,6 +109,7 @@ QUERIES5 = {
     "distinctcount(u) where h2<5": ("SELECT DISTINCTCOUNT(u) FROM t WHERE h2 < 5", 3.0),
     "hll(u) group h1,h2 (160)": ("SELECT h1, h2, DISTINCTCOUNTHLL(u), COUNT(*) FROM t GROUP BY h1, h2", 3.5),
     "count group u (1M groups)": ("SELECT u, COUNT(*) FROM t GROUP BY u LIMIT 2000000", 2.5),
+    "count group u (1M groups), numGroupsLimit 2M": ("SELECT u, COUNT(*) FROM t GROUP BY u LIMIT 2000000 /*limit=2000000*/", 2.5),
     "count group u,h1 (16M groups)": ("SELECT u, h1, COUNT(*) FROM t WHERE h2 = 3 GROUP BY u, h1 LIMIT 20000000", 3.5),
     "hash: group u,h1,h2 where u<20000": ("SELECT u, h1, h2, COUNT(*), SUM(h3) FROM t WHERE u < 20000 GROUP BY u, h1, h2 LIMIT 10000000", 4.0),
     "hash: group u,h1,h2 where h3=1,h4=2": ("SELECT u, h1, h2, COUNT(*) FROM t WHERE h3 = 1 AND h4 = 2 GROUP BY u, h1, h2 LIMIT 10000000", 4.0),
@@ -127,6 +128,7 @@ QUERIES_GENERAL = {   # shapes outside the specialised kernels: several scans, O
     "40k groups, sum of a dictionary column": ("SELECT g1, g2, c_inv1, COUNT(*), SUM(c_inv2), MAX(c_inv2) FROM t GROUP BY g1, g2, c_inv1 LIMIT 100000", 2.25),
     "filtered 40k groups": ("SELECT g1, g2, c_inv1, SUM(m) FROM t WHERE r_int < 125000 GROUP BY g1, g2, c_inv1 LIMIT 100000", 10.0),
     "group g1,g2,c_inv1,c_inv2 (160k)": ("SELECT g1, g2, c_inv1, c_inv2, COUNT(*), SUM(m), MAX(m) FROM t GROUP BY g1, g2, c_inv1, c_inv2 LIMIT 200000", 6.25),
+    "160k groups, numGroupsLimit 200k": ("SELECT g1, g2, c_inv1, c_inv2, COUNT(*), SUM(m), MAX(m) FROM t GROUP BY g1, g2, c_inv1, c_inv2 LIMIT 200000 /*limit=200000*/", 6.25),
     "cfg3 filter, 160k groups": ("SELECT g1, g2, c_inv1, c_inv2, SUM(m) FROM t WHERE c_inv1 IN (0,1,2,3) AND c_inv2 IN (0,1) AND r_int BETWEEN 250000 AND 749999 GROUP BY g1, g2, c_inv1, c_inv2 LIMIT 200000", 11.0),
     "avg/min/max/count no group": ("SELECT COUNT(*), AVG(m), MIN(r_int), MAX(m) FROM t WHERE c_inv2 = 1", 8.125),
 }
@@ -178,7 +180,11 @@ if args.set == "postings":
 for name, (sql, bpr) in QUERIES.items():
     if args.only and (args.only[1:] != name if args.only.startswith("=") else args.only not in name):
         continue
-    qc = parse_sql(sql.replace(" /*final*/", ""))
+    import re as _re
+    lim = _re.search(r" /\*limit=(\d+)\*/", sql)   # numGroupsLimit of the row (default 100 000: rows beyond it carry the docId plane of the trimming)
+    qc = parse_sql(_re.sub(r" /\*limit=\d+\*/", "", sql).replace(" /*final*/", ""))
+    if lim:
+        qc.num_groups_limit = int(lim.group(1))
     qc.flags |= capi.QUERY_FLAG_PROFILE
     if "/*final*/" in sql:
         qc.flags |= capi.QUERY_FLAG_FINAL_DISTINCT
