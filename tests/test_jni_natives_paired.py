@@ -41,3 +41,46 @@ def test_every_native_has_its_jni_function():
     assert not wrong, f"parameter counts differ (java, jni): {wrong}"
     extra = sorted(set(jni) - set(natives))
     assert not extra, f"JNI functions PinotGpu does not declare: {extra}"
+
+
+def test_every_pinotgpu_call_site_names_a_declared_method_with_that_arity():
+    """`PinotGpu.name(args)` in the other Java sources: the method exists in PinotGpu.java and takes that many arguments (javac's "cannot find
+    symbol" / "method cannot be applied" for this class, without javac)."""
+    src_dir = os.path.dirname(JAVA)
+    pg = open(JAVA).read()
+    declared = {}
+    for m in re.finditer(r"(?:public|static|private)[\w\s<>\[\]]*?\s(\w+)\s*\(([^)]*)\)\s*(?:throws [\w., ]+)?\s*[;{]", pg):
+        declared.setdefault(m.group(1), set()).add(len([p for p in m.group(2).split(",") if p.strip()]))
+
+    def split_args(s):
+        depth, n, cur = 0, 0, ""
+        for ch in s:
+            if ch in "([{<":
+                depth += 1
+            elif ch in ")]}>":
+                depth -= 1
+            if ch == "," and depth == 0:
+                n += 1
+                cur = ""
+            else:
+                cur += ch
+        return n + (1 if cur.strip() else 0)
+    problems = []
+    for name in sorted(os.listdir(src_dir)):
+        if not name.endswith(".java") or name == "PinotGpu.java":
+            continue
+        text = re.sub(r"/\*.*?\*/", "", open(os.path.join(src_dir, name)).read(), flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        for m in re.finditer(r"PinotGpu\.(\w+)\s*\(", text):
+            method = m.group(1)
+            i, depth = m.end(), 1
+            while depth and i < len(text):
+                depth += text[i] in "(" and 1 or 0
+                depth -= text[i] in ")" and 1 or 0
+                i += 1
+            n_args = split_args(text[m.end():i - 1])
+            if method not in declared:
+                problems.append(f"{name}: PinotGpu.{method} is not declared")
+            elif n_args not in declared[method]:
+                problems.append(f"{name}: PinotGpu.{method} called with {n_args} arguments, declared with {sorted(declared[method])}")
+    assert not problems, problems
