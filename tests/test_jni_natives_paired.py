@@ -43,6 +43,62 @@ def test_every_native_has_its_jni_function():
     assert not extra, f"JNI functions PinotGpu does not declare: {extra}"
 
 
+def _declared_methods(path):
+    text = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    out = {}
+    for m in re.finditer(r"(?:public|static|private|protected)[\w\s<>\[\],.?]*?\s(\w+)\s*\(([^)]*)\)\s*(?:throws [\w., ]+)?\s*[;{]", text):
+        params = m.group(2)
+        depth, n, cur = 0, 0, ""
+        for ch in params:
+            depth += ch in "<(" and 1 or 0
+            depth -= ch in ">)" and 1 or 0
+            if ch == "," and depth == 0:
+                n += 1
+                cur = ""
+            else:
+                cur += ch
+        out.setdefault(m.group(1), set()).add(n + (1 if cur.strip() else 0))
+    return out
+
+
+def test_static_calls_between_the_plugin_classes_resolve():
+    """`OtherClass.method(args)` between the classes of integration/java: declared there, with that many parameters."""
+    src_dir = os.path.dirname(JAVA)
+    classes = {n[:-5]: _declared_methods(os.path.join(src_dir, n)) for n in os.listdir(src_dir) if n.endswith(".java")}
+    problems = []
+    for name in sorted(classes):
+        text = re.sub(r"/\*.*?\*/", "", open(os.path.join(src_dir, name + ".java")).read(), flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        text = re.sub(r'"(?:[^"\\]|\\.)*"', '""', text)
+        for other in classes:
+            if other == name:
+                continue
+            for m in re.finditer(r"(?<![\w.])" + other + r"\.(\w+)\s*\(", text):
+                method = m.group(1)
+                i, depth = m.end(), 1
+                while depth and i < len(text):
+                    depth += text[i] == "(" and 1 or 0
+                    depth -= text[i] == ")" and 1 or 0
+                    i += 1
+                args = text[m.end():i - 1]
+                d2, n, cur = 0, 0, ""
+                for ch in args:
+                    d2 += ch in "([{" and 1 or 0
+                    d2 -= ch in ")]}" and 1 or 0
+                    if ch == "," and d2 == 0:
+                        n += 1
+                        cur = ""
+                    else:
+                        cur += ch
+                n_args = n + (1 if cur.strip() else 0)
+                if method not in classes[other]:
+                    problems.append(f"{name}.java: {other}.{method} is not declared")
+                elif n_args not in classes[other][method]:
+                    problems.append(f"{name}.java: {other}.{method} called with {n_args} arguments, declared with {sorted(classes[other][method])}")
+    assert not problems, problems
+
+
 def test_every_pinotgpu_call_site_names_a_declared_method_with_that_arity():
     """`PinotGpu.name(args)` in the other Java sources: the method exists in PinotGpu.java and takes that many arguments (javac's "cannot find
     symbol" / "method cannot be applied" for this class, without javac)."""
