@@ -237,6 +237,70 @@ int main(void) {
   Java_org_apache_pinot_gpu_PinotGpu_segmentSetRangeIndex(env, cls, seg, new_string("m"), (jlong)(intptr_t)raw, 16);
   ok = ok && pending() && pins == 0;
   clear_pending();
+  /* raw STRING group keys (resultGroupValuesBytes handed back the caller's empty arrays): a no-dictionary STRING column in the
+     var-byte chunk layout (VarByteChunkForwardIndexWriter, v2, PASS_THROUGH), SELECT s, COUNT(*) FROM t GROUP BY s — the keys come back
+     through resultGroupValuesBytesSize + resultGroupValuesBytes as offsets[numGroups + 1] and the values back to back */
+  {
+    static const char* const names[3] = {"a", "bb", "ccc"};
+    enum { PER_CHUNK = 1000, CHUNKS = N_DOCS / PER_CHUNK };
+    static uint8_t var[28 + 4 * CHUNKS + N_DOCS * 4 + N_DOCS * 3];
+    const uint32_t vh[7] = {2, CHUNKS, PER_CHUNK, 3, N_DOCS, 0, 28};
+    for (int i = 0; i < 7; i++) put_be32(var + 4 * i, vh[i]);
+    size_t vpos = 28 + 4 * CHUNKS;
+    for (int ch = 0; ch < CHUNKS; ch++) {
+      put_be32(var + 28 + 4 * ch, (uint32_t)vpos);
+      uint8_t* base = var + vpos;
+      size_t at = 4 * PER_CHUNK;
+      for (int k = 0; k < PER_CHUNK; k++) {
+        const char* v = names[(ch * PER_CHUNK + k) % 3];
+        put_be32(base + 4 * k, (uint32_t)at);
+        memcpy(base + at, v, strlen(v));
+        at += strlen(v);
+      }
+      vpos += at;
+    }
+    Java_org_apache_pinot_gpu_PinotGpu_segmentAddColumn(env, cls, seg, new_string("s"), PG_TYPE_STRING, PG_FWD_RAW_VAR_BYTE_CHUNK, 0, 0, 0, 0, 0, 0,
+                                                        (jlong)(intptr_t)var, (jlong)vpos, 0, 0, 0, 0);
+    ok = ok && !pending();
+    static record rs;
+    rs.n = 0;
+    w_i32(&rs, PGSHIM_QUERY_MAGIC); w_i32(&rs, 0); w_i32(&rs, 0); w_i32(&rs, 0);
+    w_i32(&rs, 1); w_i32(&rs, 1); w_i32(&rs, 0); w_i32(&rs, 0);
+    w_str(&rs, "s");
+    w_i32(&rs, PG_AGG_COUNT); w_i32(&rs, 0); w_str(&rs, "*");
+    const jlong qs = Java_org_apache_pinot_gpu_PinotGpu_queryParse(env, cls, new_direct_buffer(rs.b), (jint)rs.n);
+    const jlong rr = qs ? Java_org_apache_pinot_gpu_PinotGpu_queryExec(env, cls, seg, qs, 0) : 0;
+    ok = ok && qs && rr && !pending();
+    if (rr) {
+      const jint n_keys = Java_org_apache_pinot_gpu_PinotGpu_resultNumGroups(env, cls, rr);
+      const jlong total = Java_org_apache_pinot_gpu_PinotGpu_resultGroupValuesBytesSize(env, cls, rr, 0);
+      ok = ok && n_keys == 3 && total == 6 && !pending();
+      jlongArray offs = new_array(n_keys + 1, sizeof(jlong)), cnt = new_array(n_keys, sizeof(jlong));
+      jbyteArray bytes = new_array((jsize)total, sizeof(jbyte));
+      Java_org_apache_pinot_gpu_PinotGpu_resultGroupValuesBytes(env, cls, rr, 0, offs, bytes);
+      Java_org_apache_pinot_gpu_PinotGpu_resultLongs(env, cls, rr, 0, 0, cnt);
+      ok = ok && !pending() && pins == 0 && ((jlong*)offs->data)[0] == 0 && ((jlong*)offs->data)[n_keys] == total;
+      int seen = 0;
+      for (int g = 0; g < n_keys && ok; g++) {
+        const jlong b0 = ((jlong*)offs->data)[g], b1 = ((jlong*)offs->data)[g + 1];
+        const int len = (int)(b1 - b0);
+        ok = ok && len >= 1 && len <= 3 && memcmp((const char*)bytes->data + b0, names[len - 1], (size_t)len) == 0;
+        int64_t want = 0;
+        for (int doc = 0; doc < N_DOCS; doc++) want += (doc % 3) == len - 1;
+        ok = ok && ((jlong*)cnt->data)[g] == want;
+        printf("s=%.*s count=%lld\n", len, (const char*)bytes->data + b0, (long long)((jlong*)cnt->data)[g]);
+        seen |= 1 << (len - 1);
+      }
+      ok = ok && seen == 7;
+      /* a byte array that is too short: the library's capacity check, as an exception */
+      Java_org_apache_pinot_gpu_PinotGpu_resultGroupValuesBytes(env, cls, rr, 0, offs, new_array(2, sizeof(jbyte)));
+      ok = ok && pending() && pins == 0;
+      clear_pending();
+      Java_org_apache_pinot_gpu_PinotGpu_resultFree(env, cls, rr);
+    }
+    if (qs) Java_org_apache_pinot_gpu_PinotGpu_queryFree(env, cls, qs);
+    if (!ok) return fail("raw STRING group keys through resultGroupValuesBytes");
+  }
   /* GroupByCombineOperator in the library: two results of the same query kept in HBM (PG_QUERY_FLAG_KEEP_DEVICE_TABLE) merge element-wise;
      a world-of-one communicator (pg_comm_init_all over device 0) all-reduces a result onto itself */
   {

@@ -202,8 +202,9 @@ JNIEXPORT void JNICALL Java_org_apache_pinot_gpu_PinotGpu_resultGroupValuesBytes
   int64_t* po = (int64_t*)calloc((size_t)(n_off > 0 ? n_off : 1), sizeof(int64_t));
   uint8_t* pb = (uint8_t*)calloc((size_t)(n_bytes > 0 ? n_bytes : 1), 1);
   if (!po || !pb) { free(po); free(pb); jclass x = (*env)->FindClass(env, "java/lang/OutOfMemoryError"); if (x) (*env)->ThrowNew(env, x, "staging buffer"); return; }
+  /* the staging buffers start zeroed (calloc) and are written by the library, THEN copied out: nothing may touch them in between
+   * (round 4 read the caller's still-empty arrays over the filled buffers here, so every raw STRING / BYTES key came back empty) */
   const int32_t st = pg_result_group_values_bytes(RES(r), col, po, (int32_t)n_off, pb, (uint64_t)n_bytes);
-  if (po && pb) { (*env)->GetLongArrayRegion(env, offsets, 0, n_off, (jlong*)po); (*env)->GetByteArrayRegion(env, out, 0, n_bytes, (jbyte*)pb); }
   if (st >= 0) {
     (*env)->SetLongArrayRegion(env, offsets, 0, n_off, (const jlong*)po);
     (*env)->SetByteArrayRegion(env, out, 0, n_bytes, (const jbyte*)pb);

@@ -39,10 +39,17 @@ static std::mutex g_rccl_mu;
 static Rccl& rccl() {
   std::lock_guard<std::mutex> g(g_rccl_mu);
   if (g_rccl.handle) return g_rccl;
+  // PG_RCCL_LIBRARY names the collective library to bind instead of the system's RCCL: any shared object with the NCCL 2.x C ABI
+  // (a site's own RCCL build; tests/fake_rccl — N ranks of one process on ONE device — on one-GPU boxes).  Read once, here.
+  const char* override_path = getenv("PG_RCCL_LIBRARY");
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void* h = nullptr;
+  if (override_path && override_path[0]) {
+    h = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
+    if (!h) fail(PG_ERR_DEVICE, "cannot load PG_RCCL_LIBRARY=%s (%s)", override_path, dlerror());
+  }
   for (const char* n : names)
-    if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h && (h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
   if (!h) fail(PG_ERR_DEVICE, "cannot load librccl (%s): the cross-GPU merge needs RCCL", dlerror());
   Rccl r;
   r.handle = h;

@@ -1,0 +1,158 @@
+"""Worker of tests/test_gpu_fake_rccl.py: one process, WORLD ranks (threads), every rank's segment and communicator on device 0, the
+collectives served by the test double (PG_RCCL_LIBRARY=tests/fake_rccl/libfake_rccl.so).  Runs the body of
+test_all_reduce_two_devices (tests/test_gpu_multi.py) with WORLD ranks: pg_result_all_reduce against GroupByCombineOperator over the
+oracle's blocks (GroupByCombineOperator.java:102-165, IndexedTable.java:90-120), the refusals on every rank, the survival of the
+communicator, both ways of creating it.  Prints one JSON line; any assertion kills the process (non-zero exit)."""
+import ctypes as C
+import json
+import os
+import sys
+import threading
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from pinot_amd import capi, synth   # noqa: E402
+from pinot_amd.executor import Comm, GroupByCombineOperator, NativeSegment   # noqa: E402
+from pinot_amd.segment import build_segment   # noqa: E402
+from tests.oracle_binding import load_oracle   # noqa: E402
+from tests.test_gpu_multi import QUERIES   # noqa: E402
+
+CFG5_QUERIES = [
+    synth.QUERY_CFG5,
+    "SELECT h1, DISTINCTCOUNT(u), DISTINCTCOUNTHLL(u), COUNT(*) FROM gpuBench GROUP BY h1",
+    "SELECT h1, h2, MIN(u), MAX(u), SUM(u) FROM gpuBench WHERE h3 < 5 GROUP BY h1, h2 LIMIT 1000",
+]
+
+
+def all_reduce_in_threads(results, comms, timeout=120):
+    outcome = [None] * len(results)
+
+    def work(i):
+        try:
+            results[i].all_reduce(comms[i])
+        except capi.NativeError as e:
+            outcome[i] = e.status
+    ts = [threading.Thread(target=work, args=(i,), daemon=True) for i in range(len(results))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=timeout)
+    assert not any(t.is_alive() for t in ts), "a rank is stuck inside pg_result_all_reduce"
+    return outcome
+
+
+def execute_in_threads(segs, q):
+    """One querying thread per rank, as the worker threads of a server (BaseCombineOperator.java:97-142)."""
+    out = [None] * len(segs)
+    errors = []
+
+    def work(i):
+        try:
+            out[i] = segs[i].execute_native(q, keep_device_table=True)
+        except Exception as e:   # noqa: BLE001
+            errors.append(e)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(len(segs))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    return out
+
+
+def check_merges(api, ora_api, comms, world, columns, queries, docs):
+    hosts = [synth.generate_segment(docs + 17 * i, segment_index=i, columns=columns) for i in range(world)]
+    gpu = [NativeSegment(api, h, device=0) for h in hosts]
+    ora = [NativeSegment(ora_api, h) for h in hosts]
+    n = 0
+    for q in queries:
+        results = execute_in_threads(gpu, q)
+        assert all_reduce_in_threads(results, comms) == [None] * world, q
+        oblocks = [o.execute(q) for o in ora]
+        expect = GroupByCombineOperator(oblocks).merge()
+        for r in results:
+            b = r.block()
+            assert b.rows() == expect, q   # every rank holds the merged table
+            assert b.stats.num_docs_scanned == sum(x.stats.num_docs_scanned for x in oblocks)
+            assert b.stats.num_entries_scanned_in_filter == sum(x.stats.num_entries_scanned_in_filter for x in oblocks)
+            assert b.stats.num_total_docs == sum(h.total_docs for h in hosts)
+            r.free()
+        n += 1
+    for s in gpu + ora:
+        s.destroy()
+    return n
+
+
+def check_refusals(api, comms, world):
+    """Ranks that disagree on a dictionary, on the kind of a SUM accumulator, or whose merged SUM could leave int64: EVERY rank gets
+    PG_ERR_UNSUPPORTED — the deviant is the LAST rank, so with world 8 seven ranks agree among themselves and must still refuse."""
+    rng = np.random.default_rng(3)
+    n = 40_000
+
+    def seg_of(g_values, m_values, name):
+        data = {"g": g_values.astype(np.int32), "m": m_values}
+        schema = {"g": "INT", "m": "LONG" if m_values.dtype == np.int64 else "DOUBLE"}
+        return NativeSegment(api, build_segment(name, data, schema, no_dictionary_columns=["m"]), device=0)
+    g_a = rng.integers(0, 50, n)
+    small = rng.integers(-1000, 1000, n).astype(np.int64)
+    as_double = small.astype(np.float64)
+    cases = {
+        "dictionary": lambda last: seg_of(g_a + 1000, small, "a") if last else seg_of(g_a, small, "a"),
+        "double sum on one rank": lambda last: seg_of(g_a, np.where(np.arange(n) == 7, np.nan, as_double), "b") if last else seg_of(g_a, as_double, "b"),
+        "overflow bound": lambda last: seg_of(g_a, (small + (1 << 62) // n * 3).astype(np.int64), "c") if last else seg_of(g_a, small, "c"),
+    }
+    q = "SELECT g, SUM(m), COUNT(*) FROM t GROUP BY g LIMIT 1000"
+    for what, make in cases.items():
+        segs = [make(i == world - 1) for i in range(world)]
+        results = [s.execute_native(q, keep_device_table=True) for s in segs]
+        got = all_reduce_in_threads(results, comms)
+        assert got == [capi.PG_ERR_UNSUPPORTED] * world, (what, got)
+        for r in results:
+            r.free()
+        for s in segs:
+            s.destroy()
+    return len(cases)
+
+
+def main():
+    world = int(sys.argv[1])
+    fake_path = os.environ["PG_RCCL_LIBRARY"]
+    import torch  # noqa: F401  (initialises the ROCm runtime the same way bench.py does)
+    api = capi.gpu_api()
+    api.call("init", 0)
+    ora_api = load_oracle()
+    comms = Comm.init_all(api, [0] * world)
+    assert all(c.world_size() == world for c in comms)
+    merged = check_merges(api, ora_api, comms, world, synth.CFG3_COLUMNS, QUERIES, 60_013)
+    merged += check_merges(api, ora_api, comms, world, synth.CFG5_COLUMNS, CFG5_QUERIES, 150_011)
+    refused = check_refusals(api, comms, world)
+    merged += check_merges(api, ora_api, comms, world, synth.CFG3_COLUMNS, [synth.QUERY_CFG3], 30_011)   # the communicator survives the refusals
+    for c in comms:
+        c.destroy()
+    # the other way in: one pg_comm_init_rank per rank (collective), as one process per GPU would
+    uid = Comm.unique_id(api)
+    by_rank = [None] * world
+
+    def init(r):
+        by_rank[r] = Comm.init_rank(api, 0, world, r, uid)
+    ts = [threading.Thread(target=init, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=60)
+    assert all(c is not None for c in by_rank)
+    merged += check_merges(api, ora_api, by_rank, world, synth.CFG3_COLUMNS, [synth.QUERY_NORTH_STAR], 30_011)
+    for c in by_rank:
+        c.destroy()
+    fake = C.CDLL(fake_path)
+    for f in ("fake_rccl_lonely_ranks", "fake_rccl_mismatched_collectives", "fake_rccl_collectives"):
+        getattr(fake, f).restype = C.c_int64
+    print(json.dumps({"world": world, "merged_queries": merged, "refusal_cases": refused, "lonely_ranks": fake.fake_rccl_lonely_ranks(),
+                      "mismatched_collectives": fake.fake_rccl_mismatched_collectives(), "collectives": fake.fake_rccl_collectives()}))
+
+
+if __name__ == "__main__":
+    main()
