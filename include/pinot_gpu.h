@@ -293,6 +293,10 @@ typedef struct pg_comm_s* pg_comm_t;
 
 /* ---- library ---------------------------------------------------------------------------------------------------- */
 int32_t pg_abi_version(void);
+/* Tuning / measurement knobs are PG_* environment variables (pinot_amd/csrc/pg_internal.hpp: struct Knobs lists every one), read ONCE at
+ * pg_init (or at the first call that needs them).  pg_options_reload re-reads the environment: for A/B measurements and tests that flip
+ * a knob inside one process.  It must not run concurrently with queries; a server never needs it. */
+int32_t pg_options_reload(void);
 /* Selects the DEFAULT HIP device — the one pg_segment_create() pins its segment on (one process per GPU: pg_init(LOCAL_RANK)).
  * Fails loudly if no device is present.  A server process that spreads its segments over several GPUs — the reference runs
  * every segment of a server inside one JVM, one worker task per segment (BaseCombineOperator.java:81-142) — names the device

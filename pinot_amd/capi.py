@@ -181,6 +181,7 @@ GPU_ONLY_SYMBOLS = [
     "cancel_create", "cancel_request", "cancel_reset", "cancel_destroy", "query_exec_cancellable",
     "result_merge", "result_all_reduce", "result_data_table_v4",
     "comm_get_unique_id", "comm_init_rank", "comm_init_all", "comm_world_size", "comm_destroy",
+    "options_reload",
 ]
 
 
@@ -210,6 +211,7 @@ class NativeApi:
             self.f("comm_init_all").argtypes = [C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_void_p)]
             self.f("comm_world_size").argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
             self.f("comm_destroy").argtypes = [C.c_void_p]
+            self.f("options_reload").argtypes = []
         self.f("last_error").argtypes = [C.c_char_p, C.c_size_t]
         self.f("init").argtypes = [C.c_int32]
         self.f("segment_create").argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]

@@ -1,6 +1,44 @@
 // C ABI entry points of libpinot_gpu.so (include/pinot_gpu.h).  Every exception becomes a status code plus a
 // thread-local message (pg_last_error), which the JNI shim rethrows as RuntimeException.
 #include "pg_internal.hpp"
+#include <mutex>
+
+namespace pg {
+static Knobs g_knobs;
+static std::once_flag g_knobs_once;
+static void knobs_read(Knobs& k) {
+  k = Knobs();
+  auto flag = [](const char* name) { return getenv(name) != nullptr; };
+  auto num = [](const char* name, int64_t dflt) { const char* e = getenv(name); return e ? (int64_t)atoll(e) : dflt; };
+  auto str = [](const char* name) { const char* e = getenv(name); return std::string(e ? e : ""); };
+  k.no_oct = flag("PG_NO_OCT"); k.oct_no_affine = flag("PG_OCT_NO_AFFINE"); k.oct_byte_regs = flag("PG_OCT_BYTE_REGS");
+  k.oct_any_cardinality = flag("PG_OCT_ANY_CARDINALITY"); k.no_oct_prune = flag("PG_NO_OCT_PRUNE"); k.oct_dword_regs = flag("PG_OCT_DWORD_REGS");
+  k.no_p2 = flag("PG_NO_P2"); k.p2_no_fast_a = flag("PG_P2_NO_FAST_A"); k.no_p2_oct = flag("PG_NO_P2_OCT"); k.no_radix = flag("PG_NO_RADIX");
+  k.no_radix_aux = flag("PG_NO_RADIX_AUX"); k.no_part = flag("PG_NO_PART"); k.no_radix_packed = flag("PG_NO_RADIX_PACKED");
+  k.no_pipe_general = flag("PG_NO_PIPE_GENERAL"); k.no_pipe_wide = flag("PG_NO_PIPE_WIDE"); k.no_pipe_wide_double = flag("PG_NO_PIPE_WIDE_DOUBLE");
+  k.mv_no_windows = flag("PG_MV_NO_WINDOWS");
+  k.oct_min_docs = num("PG_OCT_MIN_DOCS", -1); k.part_min = (int)num("PG_PART_MIN", -1);
+  k.force_interpreter = flag("PG_FORCE_INTERPRETER"); k.no_scan_pipe = flag("PG_NO_SCAN_PIPE"); k.no_pipe = flag("PG_NO_PIPE");
+  k.no_dense_fused = flag("PG_NO_DENSE_FUSED"); k.no_part_grid_clamp = flag("PG_NO_PART_GRID_CLAMP"); k.no_spin_wait = flag("PG_NO_SPIN_WAIT");
+  k.trace_oct = flag("PG_TRACE_OCT"); k.no_tile_split = flag("PG_NO_TILE_SPLIT"); k.no_oct_exec = flag("PG_NO_OCT_EXEC");
+  k.no_p2_simple = flag("PG_NO_P2_SIMPLE"); k.no_dense_count = flag("PG_NO_DENSE_COUNT"); k.no_direct_result = flag("PG_NO_DIRECT_RESULT");
+  k.trace_host = flag("PG_TRACE_HOST");
+  k.scan_wgs_per_cu = (int)num("PG_SCAN_WGS_PER_CU", 1); k.pipe_wgs_per_cu = (int)num("PG_PIPE_WGS_PER_CU", 1); k.wgs_per_cu = (int)num("PG_WGS_PER_CU", 1);
+  k.p2_wgs_per_cu = (int)num("PG_P2_WGS_PER_CU", 4); k.dense_count_wgs = (int)num("PG_DENSE_COUNT_WGS", 1); k.tile_split_max = (int)num("PG_TILE_SPLIT_MAX", -1);
+  k.hash_first_buckets = (int)num("PG_HASH_FIRST_BUCKETS", -1);
+  k.exact_stats_max_docs = num("PG_EXACT_STATS_MAX_DOCS", (int64_t)1 << 22);
+  k.oct_passes = str("PG_OCT_PASSES"); k.rccl_library = str("PG_RCCL_LIBRARY");
+}
+const Knobs& knobs() {
+  std::call_once(g_knobs_once, [] { knobs_read(g_knobs); });
+  return g_knobs;
+}
+void knobs_reload() {
+  (void)knobs();
+  knobs_read(g_knobs);
+}
+}  // namespace pg
+
 
 using namespace pg;
 
@@ -33,7 +71,14 @@ extern "C" {
 int32_t pg_abi_version(void) { return PG_ABI_VERSION; }
 
 int32_t pg_init(int32_t device_ordinal) {
-  return guarded([&] { device_init(device_ordinal); });
+  return guarded([&] {
+    (void)knobs();   // the PG_* environment is read here, once
+    device_init(device_ordinal);
+  });
+}
+
+int32_t pg_options_reload(void) {
+  return guarded([&] { knobs_reload(); });
 }
 
 int32_t pg_device_count(int32_t* out_count) {

@@ -40,8 +40,8 @@ static Rccl& rccl() {
   std::lock_guard<std::mutex> g(g_rccl_mu);
   if (g_rccl.handle) return g_rccl;
   // PG_RCCL_LIBRARY names the collective library to bind instead of the system's RCCL: any shared object with the NCCL 2.x C ABI
-  // (a site's own RCCL build; tests/fake_rccl — N ranks of one process on ONE device — on one-GPU boxes).  Read once, here.
-  const char* override_path = getenv("PG_RCCL_LIBRARY");
+  // (a site's own RCCL build; tests/fake_rccl — N ranks of one process on ONE device — on one-GPU boxes).
+  const char* override_path = knobs().rccl_library.empty() ? nullptr : knobs().rccl_library.c_str();
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void* h = nullptr;
   if (override_path && override_path[0]) {

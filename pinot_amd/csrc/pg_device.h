@@ -322,7 +322,9 @@ struct PgQueryPlan {
   uint32_t* p2_ctrl;                // [0] chunks claimed so far, [1] error flag, [PG_P2_CTRL_*] the chunk index's counters
   uint32_t* p2_list;                // [p2_capacity] chunk records grouped by bucket: chunk id | filled lines << 27
   int32_t p2_fast_a;                // 1: the scatter's batched loader fits (<= 4 group columns: the first <= 24 bits, the others <= 8;
-  int32_t p2_pad;                   //    at most one source, bit-packed <= 24 bits or raw 32-bit)
+  int32_t p2_oct_a;                 //    at most one source, bit-packed <= 24 bits or raw 32-bit).  p2_oct_a: the oct-layout phase A fits
+                                    //    (pg_p2_scatter_o*: one plane, fixed-bit group columns <= 8 bits — the first <= 24 —, no source / one
+                                    //    raw INT / one <= 24-bit dictId field) — taken by plans without a filter pass in front
   int32_t n_lin_prefix;             // interpreter kernels: instrs[0, n_lin_prefix) is index-only and leaves one stack entry
   int32_t n_fast_scans;             // pg_fast_multi_*: instrs[n_index_instr, n_index_instr + n_fast_scans) are scan leaves ANDed in order
   int32_t tail_posting;             // pg_fast_multi_*: posting leaf ANDed in AFTER the scans (-1: none) — the queryableDocIds bitmap of

@@ -41,6 +41,8 @@ PG_DECL_FAST(pg_radix_scatter_packed_kernel) PG_DECL_FAST(pg_radix_aggregate_pac
 PG_DECL_FAST(pg_hash_count_kernel) PG_DECL_FAST(pg_hash_scatter_kernel) PG_DECL_FAST(pg_hash_aggregate_kernel)
 PG_DECL_FAST(pg_p2_scatter_1) PG_DECL_FAST(pg_p2_scatter_2) PG_DECL_FAST(pg_p2_scatter_3) PG_DECL_FAST(pg_p2_scatter_4)
 PG_DECL_FAST(pg_p2_scatter_1f) PG_DECL_FAST(pg_p2_scatter_2f) PG_DECL_FAST(pg_p2_scatter_1f_key) PG_DECL_FAST(pg_p2_scatter_1f_hll)
+PG_DECL_FAST(pg_p2_scatter_o_key) PG_DECL_FAST(pg_p2_scatter_o_raw) PG_DECL_FAST(pg_p2_scatter_o_dict)
+PG_DECL_FAST(pg_p2_scatter_ow_key) PG_DECL_FAST(pg_p2_scatter_ow_raw) PG_DECL_FAST(pg_p2_scatter_ow_dict)
 PG_DECL_FAST(pg_p2_aggregate_1) PG_DECL_FAST(pg_p2_aggregate_2) PG_DECL_FAST(pg_p2_aggregate_3) PG_DECL_FAST(pg_p2_aggregate_4)
 PG_DECL_FAST(pg_p2_aggregate_1n) PG_DECL_FAST(pg_p2_aggregate_2n) PG_DECL_FAST(pg_p2_aggregate_3n) PG_DECL_FAST(pg_p2_aggregate_4n)
 PG_DECL_FAST(pg_p2_index_count_kernel) PG_DECL_FAST(pg_p2_index_scan_kernel) PG_DECL_FAST(pg_p2_index_fill_kernel)
@@ -193,6 +195,7 @@ void use_device(int ordinal) {
                                  pg_fast_dictrange_f, pg_fast_dictrange_a, pg_fast_dictlut_f, pg_fast_dictlut_a, pg_fast_multi_f, pg_fast_multi_a, pg_fast_multi_w, pg_fast_none_w, pg_fast_multi_wd, pg_fast_none_wd, pg_generic_query_ld, pg_generic_query_gd, pg_fast_i32range_d, pg_fast_i32range_p, pg_pipe_scan, pg_pipe_scan_tail, pg_pipe_index_scan_tail, pg_pipe_none, pg_pipe_tail, pg_pipe_index, pg_pipe_index_tail, pg_pipe_index2, pg_pipe_index2_tail, pg_pipe_scan_vscan, pg_pipe_index_scan_vscan, pg_pipe_w0_none, pg_pipe_w0_index, pg_pipe_w0_scan, pg_pipe_w0_index_scan, pg_pipe_w32_none, pg_pipe_w32_index, pg_pipe_w32_scan, pg_pipe_w32_index_scan, pg_pipe_w64_none, pg_pipe_w64_index, pg_pipe_w64_scan, pg_pipe_w64_index_scan, pg_pipe_wd_none, pg_pipe_wd_index, pg_pipe_wd_scan, pg_pipe_wd_index_scan, pg_mv_query_f, pg_mv_query_l, pg_mv_query_g,
                                  pg_radix_aggregate_kernel, pg_hash_aggregate_kernel,
                                  pg_p2_scatter_1, pg_p2_scatter_2, pg_p2_scatter_3, pg_p2_scatter_4, pg_p2_scatter_1f, pg_p2_scatter_2f, pg_p2_scatter_1f_key, pg_p2_scatter_1f_hll,
+                                 pg_p2_scatter_o_key, pg_p2_scatter_o_raw, pg_p2_scatter_o_dict, pg_p2_scatter_ow_key, pg_p2_scatter_ow_raw, pg_p2_scatter_ow_dict,
                                  pg_p2_aggregate_1, pg_p2_aggregate_2, pg_p2_aggregate_3, pg_p2_aggregate_4,
                                  pg_p2_aggregate_1n, pg_p2_aggregate_2n, pg_p2_aggregate_3n, pg_p2_aggregate_4n, pg_p2_aggregate_1s, pg_p2_aggregate_2s, pg_p2_aggregate_1sg, pg_p2_aggregate_2sg};
       for (QueryKernel k : all)
@@ -223,7 +226,7 @@ static int num_cus() { return g_devices[t_device].num_cus; }
 static size_t lds_per_cu() { return g_devices[t_device].lds_per_cu; }
 
 static bool uses_fast_kernel(const CompiledPlan& P, int agg_mode) {
-  static const bool force_interpreter = getenv("PG_FORCE_INTERPRETER") != nullptr;   // measurement knob
+  const bool force_interpreter = knobs().force_interpreter;   // measurement knob
   if (force_interpreter || P.dev.mv) return false;   // multi-value plans: pg_mv_query_* (the interpreter's frame)
   const bool agg = agg_mode != PG_AGG_NONE;
   return P.fast_filter != -2 && (!agg || ((P.fast_agg || P.wide_agg) && agg_mode != PG_AGG_GLOBAL));
@@ -231,21 +234,21 @@ static bool uses_fast_kernel(const CompiledPlan& P, int agg_mode) {
 
 // pg_fast_i32range_fp (double-buffered raw-INT range scan over the whole segment, filter only: pg_kernels_scan.hip)
 static bool uses_scan_kernel(const CompiledPlan& P, int agg_mode) {
-  static const bool no_scan = getenv("PG_NO_SCAN_PIPE") != nullptr;   // measurement knob
+  const bool no_scan = knobs().no_scan_pipe;   // measurement knob
   return !no_scan && agg_mode == PG_AGG_NONE && uses_fast_kernel(P, agg_mode) && P.fast_filter == 4 && P.dev.n_index_instr == 0 &&
          P.dev.fast_scan_pushed;
 }
 // pg_fast_i32range_p (software-pipelined headline shape, pg_kernels_pipe.hip): its own workgroup size
 static bool uses_pipe_general(const CompiledPlan& P, int agg_mode) {   // pg_pipe_*: the pipeline's other filter shapes
-  static const bool no_pipe = getenv("PG_NO_PIPE") != nullptr;   // measurement knob
+  const bool no_pipe = knobs().no_pipe;   // measurement knob
   return !no_pipe && uses_fast_kernel(P, agg_mode) && agg_mode == PG_AGG_LDS && !P.wide_agg && P.fast_agg && P.dev.pipe_general;
 }
 static bool uses_pipe_wide(const CompiledPlan& P, int agg_mode) {   // pg_pipe_w_*: raw LONG values / group columns of 9 .. 16 bits
-  static const bool no_pipe = getenv("PG_NO_PIPE") != nullptr;   // measurement knob
+  const bool no_pipe = knobs().no_pipe;   // measurement knob
   return !no_pipe && uses_fast_kernel(P, agg_mode) && (agg_mode == PG_AGG_LDS || agg_mode == PG_AGG_SINGLE) && P.wide_agg && P.dev.pipe_wide;
 }
 static bool uses_pipe_kernel(const CompiledPlan& P, int agg_mode) {
-  static const bool no_pipe = getenv("PG_NO_PIPE") != nullptr || getenv("PG_NO_DENSE_FUSED") != nullptr;   // measurement knob
+  const bool no_pipe = knobs().no_pipe || knobs().no_dense_fused;   // measurement knobs
   if (uses_pipe_general(P, agg_mode) || uses_pipe_wide(P, agg_mode)) return true;
   return !no_pipe && uses_fast_kernel(P, agg_mode) && agg_mode == PG_AGG_LDS && !P.wide_agg && P.fast_agg && P.fast_filter == 4 &&
          P.dev.dense_fused && P.dev.pipe_fit;
@@ -272,7 +275,7 @@ static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char
       *name = P.digit_ops ? "pg_fast_multi_wd" : "pg_fast_multi_w";
       return P.digit_ops ? pg_fast_multi_wd : pg_fast_multi_w;
     }
-    static const bool no_dense = getenv("PG_NO_DENSE_FUSED") != nullptr;   // measurement knobs
+    const bool no_dense = knobs().no_dense_fused;   // measurement knob
     if (uses_pipe_general(P, agg_mode)) {
       const bool idx = P.dev.pipe_has_index != 0, scan = P.dev.pipe_has_scan != 0, tail = P.dev.pipe_tail != nullptr;
       if (scan && P.dev.pipe_vscan >= 0) {
@@ -400,19 +403,19 @@ static LaunchShape launch_shape(const CompiledPlan& P, int n_wtiles, int agg_mod
     const int block = uses_fast_kernel(P, agg_mode) ? PG_BLOCK : PG_GENERIC_BLOCK;
     // (a small doc space — a star-tree's pre-aggregated docs — does not need every CU: a workgroup without tiles still fills and flushes its table)
     const int chunks = (n_wtiles + block / 64 - 1) / (block / 64);
-    static const bool no_clamp = getenv("PG_NO_PART_GRID_CLAMP") != nullptr;   // measurement knob
+    const bool no_clamp = knobs().no_part_grid_clamp;   // measurement knob
     int per_range = std::max(per_xcd / P.dev.n_parts, 1);
     if (!no_clamp) per_range = std::max(1, std::min(per_range, (chunks + 7) / 8));
     return {8 * per_range * P.dev.n_parts, block, lds};
   }
   if (uses_scan_kernel(P, agg_mode)) {
-    static const int wgs_per_cu = getenv("PG_SCAN_WGS_PER_CU") ? atoi(getenv("PG_SCAN_WGS_PER_CU")) : 1;   // tuning knob
+    const int wgs_per_cu = knobs().scan_wgs_per_cu;   // tuning knob
     const int waves = pg_scan_waves_per_block;
     int grid = std::min((n_wtiles + waves - 1) / waves, num_cus() * std::max(wgs_per_cu, 1));
     return {std::max(grid, 1), waves * 64, 0};
   }
   if (uses_pipe_kernel(P, agg_mode)) {
-    static const int wgs_per_cu = getenv("PG_PIPE_WGS_PER_CU") ? atoi(getenv("PG_PIPE_WGS_PER_CU")) : 1;   // tuning knob
+    const int wgs_per_cu = knobs().pipe_wgs_per_cu;   // tuning knob
     const int per_cu = ((size_t)wgs_per_cu * (lds + 4096) <= lds_per_cu()) ? wgs_per_cu : 1;
     const int waves = pg_pipe_waves_per_block;
     int grid = std::min((n_wtiles + waves - 1) / waves, num_cus() * per_cu);
@@ -420,7 +423,7 @@ static LaunchShape launch_shape(const CompiledPlan& P, int n_wtiles, int agg_mod
   }
   if (uses_fast_kernel(P, agg_mode)) {
     // one 16-wave workgroup per CU; fewer when the segment has fewer wave tiles than that
-    static const int wgs_per_cu = getenv("PG_WGS_PER_CU") ? atoi(getenv("PG_WGS_PER_CU")) : 1;   // tuning knob
+    const int wgs_per_cu = knobs().wgs_per_cu;   // tuning knob
     const int per_cu = ((size_t)wgs_per_cu * (lds + 4096) <= lds_per_cu()) ? wgs_per_cu : 1;
     int grid = std::min((n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, num_cus() * per_cu);
     return {std::max(grid, 1), PG_BLOCK, lds};
@@ -509,7 +512,7 @@ static void stream_wait(ThreadCtx& ctx, const CancelToken* c) {
   if (!c) {
     // short queries: poll for a while before blocking — a blocking wait is woken by an interrupt, microseconds after the stream drained
     // (config 2 is a 62 us kernel; PG_NO_SPIN_WAIT is the A/B knob)
-    static const bool no_spin = getenv("PG_NO_SPIN_WAIT") != nullptr;
+    const bool no_spin = knobs().no_spin_wait;
     if (!no_spin) {
       const double until = now_ms() + 0.3;
       do {
@@ -587,7 +590,7 @@ static long long tiles_docs(int t0, int t1) { return (long long)(t1 - t0) * PG_W
 // i.e. 2 % / 8 % / 30 % of 10^9 docs (13.7 % of all offers survive) but 10 % / 40 % of 2 x 10^8 (41 %: profiles/r04_g_pruned_passes.txt).
 static std::vector<int> oct_pass_bounds(int n_wtiles, int64_t registers) {
   std::vector<double> frac;
-  if (const char* e = getenv("PG_OCT_PASSES")) {   // test / measurement knob: cumulative fractions, e.g. "0.02,0.08,0.3,1"
+  if (const char* e = knobs().oct_passes.empty() ? nullptr : knobs().oct_passes.c_str()) {   // test / measurement knob: cumulative fractions, e.g. "0.02,0.08,0.3,1"
     for (const char* c = e; *c;) {
       char* end = nullptr;
       const double v = strtod(c, &end);
@@ -663,7 +666,7 @@ static void run_oct_pruned(CompiledPlan& P, PgQueryPlan& D, ThreadCtx& ctx, cons
   // partition pipeline areas for the largest pass
   const size_t round_tuples = (size_t)PG_P2_WAVES * (size_t)Q * 256;
   const size_t s_lds = ((size_t)6 * PG_P2_MAX_BUCKETS + PG_P2_POOL + 8 + 2 * (round_tuples / PG_P2_LINE + (size_t)NB + 1) + round_tuples + (size_t)NB * PG_P2_LINE) * 4;
-  static const int p2_wgs = getenv("PG_P2_WGS_PER_CU") ? atoi(getenv("PG_P2_WGS_PER_CU")) : 4;
+  const int p2_wgs = knobs().p2_wgs_per_cu;
   const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(p2_wgs, 1), (lds_per_cu() - 1024) / (s_lds + 512)));
   const int sgrid_max = num_cus() * per_cu;
   // (a stream scatter workgroup takes at least PG_P2_STREAM_MIN_QUARTETS = 2 quartets of 8 192 entries when the stream is short)
@@ -739,7 +742,7 @@ static void run_oct_pruned(CompiledPlan& P, PgQueryPlan& D, ThreadCtx& ctx, cons
                        ctx.oct_floor.as<uint8_t>(), (int)G, D.aux[0].log2m, D.radix_shift, S.radix_slices);
     PG_HIP(hipGetLastError());
     {
-      static const bool trace = getenv("PG_TRACE_OCT") != nullptr;   // debugging knob (synchronises): what each pass left in the stream
+      const bool trace = knobs().trace_oct;   // debugging knob (synchronises): what each pass left in the stream
       if (trace) {
         uint32_t tiles = 0;
         std::vector<uint8_t> fl(G);
@@ -846,13 +849,13 @@ std::unique_ptr<Result> execute_query_plain(Segment& seg, const pg_query& q, con
   // small doc spaces with per-doc state merges (PgQueryPlan::tile_split_shift): up to 128 wavefronts share a wave tile
   int split_shift = 0;
   {
-    static const bool no_split = getenv("PG_NO_TILE_SPLIT") != nullptr;   // measurement knob
+    const bool no_split = knobs().no_tile_split;   // measurement knob
     const bool table_mode = D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE || D.agg_mode == PG_AGG_LDS_PART || D.agg_mode == PG_AGG_GLOBAL;
     if (!no_split && table_mode && D.n_aux > 0 && !uses_fast_kernel(P, D.agg_mode))
     {
       // (serialized-HyperLogLog merges — a star-tree's pair column — are a serial chain of loads and compare-and-swaps per wavefront: 16 docs
       // each; the other states take one atomic per doc and stop at 64 docs per wavefront)
-      static const int knob = getenv("PG_TILE_SPLIT_MAX") ? atoi(getenv("PG_TILE_SPLIT_MAX")) : -1;   // tuning knob (≤ 9: 8 quad slots x 64 lanes)
+      const int knob = knobs().tile_split_max;   // tuning knob (≤ 9: 8 quad slots x 64 lanes)
       bool merges = false;
       for (int x = 0; x < D.n_aux; x++) merges |= D.aux[x].kind == PG_AUX_HLL_BYTES;
       const int max_split = knob >= 0 ? knob : (merges ? 7 : 5);
@@ -860,7 +863,7 @@ std::unique_ptr<Result> execute_query_plain(Segment& seg, const pg_query& q, con
     }
   }
   // oct-layout kernels (pg_kernels_oct.hip): one 16-wavefront workgroup per CU, no tile splitting
-  static const bool no_oct = getenv("PG_NO_OCT_EXEC") != nullptr;   // measurement knob: plans keep D.oct, the round-3 kernels run them
+  const bool no_oct = knobs().no_oct_exec;   // measurement knob: plans keep D.oct, the round-3 kernels run them
   const bool oct_lds = D.oct == 1 && !no_oct, oct_pruned = D.oct == 2 && (!no_oct || D.p2_byte_regs) && D.agg_mode == PG_AGG_RADIX && D.p2;
   if (oct_lds) split_shift = 0;
   D.tile_split_shift = split_shift;
@@ -971,7 +974,7 @@ std::unique_ptr<Result> execute_query_plain(Segment& seg, const pg_query& q, con
     const size_t round_tuples = (size_t)PG_P2_WAVES * (size_t)Q * 256;
     const size_t s_lds = ((size_t)6 * PG_P2_MAX_BUCKETS + PG_P2_POOL + 8 + 2 * (round_tuples / PG_P2_LINE + (size_t)NB + 1) + (size_t)T * round_tuples +
                           (size_t)T * (size_t)NB * PG_P2_LINE) * 4;
-    static const int p2_wgs = getenv("PG_P2_WGS_PER_CU") ? atoi(getenv("PG_P2_WGS_PER_CU")) : 4;   // tuning knob
+    const int p2_wgs = knobs().p2_wgs_per_cu;   // tuning knob
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(p2_wgs, 1), (lds_per_cu() - 1024) / (s_lds + 512)));
     const int quartets = (D.n_wtiles + PG_P2_WAVES - 1) / PG_P2_WAVES;
     const int sgrid = std::max(1, std::min(quartets, num_cus() * per_cu));
@@ -1009,6 +1012,12 @@ std::unique_ptr<Result> execute_query_plain(Segment& seg, const pg_query& q, con
     QueryKernel sk = D.p2_fast_a && T <= 2 ? scatter_fast_k[T] : scatter_k[T];
     if (D.p2_fast_a && T == 1 && D.n_srcs == 0) sk = pg_p2_scatter_1f_key;
     if (D.p2_fast_a && T == 1 && D.n_srcs == 1 && D.p2_fkind[0] == PG_P2_F_HLL && D.pk_affine[0] == 2 && D.srcs[0].col_kind == PG_COL_FIXED_BIT) sk = pg_p2_scatter_1f_hll;
+    if (D.p2_oct_a && T == 1 && P.match_all) {   // no filter pass in front: the oct-layout phase A
+      static const QueryKernel oct_k[2][3] = {{pg_p2_scatter_o_key, pg_p2_scatter_o_raw, pg_p2_scatter_o_dict},
+                                              {pg_p2_scatter_ow_key, pg_p2_scatter_ow_raw, pg_p2_scatter_ow_dict}};
+      const int osk = D.n_srcs == 0 ? 0 : (D.p2_fkind[0] == PG_P2_F_RAW32 ? 1 : 2);
+      sk = oct_k[D.gcols[0].bits > 8 ? 1 : 0][osk];
+    }
     hipLaunchKernelGGL(sk, dim3(sgrid), dim3(PG_P2_WAVES * 64), s_lds, ctx.stream, D);
     PG_HIP(hipGetLastError());
     {   // the chunk records grouped by bucket (counting sort): count, scan, fill
@@ -1020,7 +1029,7 @@ std::unique_ptr<Result> execute_query_plain(Segment& seg, const pg_query& q, con
     }
     const int agrid = std::min(NB * D.radix_slices, num_cus());
     // COUNT(*) and SUM / MIN / MAX of raw INT fields only: the consumer with the ops' descriptors in scalar registers (pg_p2_aggregate_*s)
-    static const bool no_simple = getenv("PG_NO_P2_SIMPLE") != nullptr;   // A/B knob
+    const bool no_simple = knobs().no_p2_simple;   // A/B knob
     bool simple = !no_simple && D.n_aux == 0 && T <= 2 && D.n_ops <= 4;
     for (int o = 0; o < D.n_ops && simple; o++) {
       const PgAccOp& op = D.ops[o];
@@ -1063,7 +1072,7 @@ std::unique_ptr<Result> execute_query_plain(Segment& seg, const pg_query& q, con
     if (hashed) {   // buckets sized so that even all-distinct keys half-fill a bucket's table, within [16, 2048]
       int nb = 16;
       while (nb < PG_MAX_RADIX_BUCKETS && (unsigned long long)nb * (unsigned long long)(D.hash_cap / 2) < matched_now) nb *= 2;
-      if (const char* e = getenv("PG_HASH_FIRST_BUCKETS")) nb = std::max(16, std::min(PG_MAX_RADIX_BUCKETS, atoi(e)));   // test knob: start too low
+      if (knobs().hash_first_buckets >= 0) nb = std::max(16, std::min(PG_MAX_RADIX_BUCKETS, knobs().hash_first_buckets));   // test knob: start too low
       D.radix_buckets = nb;
     }
     const int rgrid = std::max(1, std::min((D.n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, num_cus()));
@@ -1171,7 +1180,7 @@ std::unique_ptr<Result> execute_query_plain(Segment& seg, const pg_query& q, con
     PG_HIP(hipGetLastError());
   } else if (has_docs) {
     // COUNT(*) behind an index-only filter of dense postings: the bitmap stream (pg_dense_count_*), not the tile walk
-    static const bool no_dense_count = getenv("PG_NO_DENSE_COUNT") != nullptr;   // A/B knob
+    const bool no_dense_count = knobs().no_dense_count;   // A/B knob
     int n_ptr = 0;   // distinct dense posting pointers (the planner pads the eight slots with repeats of slot 0)
     for (int j = 0; j < 8; j++) if (j == 0 || D.dense_ptr[j] != D.dense_ptr[0] || D.dense_group[j] != D.dense_group[0]) n_ptr = j + 1;
     if (!no_dense_count && D.agg_mode == PG_AGG_NONE && !D.out_words && !D.out_tile_counts && uses_fast_kernel(P, PG_AGG_NONE) && P.fast_filter == -1 &&
@@ -1179,7 +1188,7 @@ std::unique_ptr<Result> execute_query_plain(Segment& seg, const pg_query& q, con
       static const QueryKernel kCount[8] = {pg_dense_count_1, pg_dense_count_2, pg_dense_count_3, pg_dense_count_4,
                                             pg_dense_count_5, pg_dense_count_6, pg_dense_count_7, pg_dense_count_8};
       const int64_t n_q = ((int64_t)D.num_docs + 127) >> 7;
-      static const int wgs_per_cu = getenv("PG_DENSE_COUNT_WGS") ? atoi(getenv("PG_DENSE_COUNT_WGS")) : 1;   // tuning knob
+      const int wgs_per_cu = knobs().dense_count_wgs;   // tuning knob
       const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((n_q + 2047) / 2048, (int64_t)num_cus() * std::max(wgs_per_cu, 1)));
       kname = "pg_dense_count";
       hipLaunchKernelGGL(kCount[n_ptr - 1], dim3(grid), dim3(1024), 0, ctx.stream, D);
@@ -1222,7 +1231,7 @@ std::unique_ptr<Result> execute_query_plain(Segment& seg, const pg_query& q, con
     // Small tables whose every slot this kernel writes go straight into the pinned result block (mapped into the device's address space:
     // the stores cross the bus as they retire) — no copy command behind the kernel, one launch less on the query's critical path
     // (config 2: profiles/r04_j_small_query_latency.txt).
-    static const bool no_direct = getenv("PG_NO_DIRECT_RESULT") != nullptr;   // A/B knob
+    const bool no_direct = knobs().no_direct_result;   // A/B knob
     const bool direct_out = !no_direct && !keep_table && (reduce || n_out == 0) && out_bytes <= ((size_t)64 << 10);
     hipLaunchKernelGGL(pg_reduce_partials_kernel, dim3(blocks), dim3(256), 0, ctx.stream, ctx.partials.as<int64_t>(),
                        direct_out ? host_out : ctx.final_table.as<int64_t>(), shape.grid, D.n_ops, D.n_groups, P.ops_dev.as<PgAccOp>(),
@@ -1319,7 +1328,7 @@ std::unique_ptr<Result> execute_query_plain(Segment& seg, const pg_query& q, con
   int64_t exact_entries = -1;
   // exact numEntriesScannedInFilter of leapfrogged shapes: by default up to 2^22 docs (one filter launch + one bitmap copy + a host walk per
   // leaf: milliseconds there, a multiple of the query on a 10^9-doc segment), on request at any size
-  static const int64_t exact_max_docs = getenv("PG_EXACT_STATS_MAX_DOCS") ? atoll(getenv("PG_EXACT_STATS_MAX_DOCS")) : ((int64_t)1 << 22);
+  const int64_t exact_max_docs = knobs().exact_stats_max_docs;
   const bool want_exact = !(q.flags & PG_QUERY_FLAG_APPROX_FILTER_STATS) &&
                           ((q.flags & PG_QUERY_FLAG_EXACT_FILTER_STATS) || (int64_t)P.space_docs <= exact_max_docs);
   if (!P.stats_exact && want_exact) {
@@ -1333,7 +1342,7 @@ std::unique_ptr<Result> execute_query_plain(Segment& seg, const pg_query& q, con
   assemble_result(*res, P, q.n_group_by, q.n_aggregations, H);
   fill_result_schema(seg, q, *res);
   {
-    static const bool trace = getenv("PG_TRACE_HOST") != nullptr;   // debugging knob: where the host time of a query goes
+    const bool trace = knobs().trace_host;   // debugging knob: where the host time of a query goes
     if (trace)
       fprintf(stderr, "[pg] %s: plan %.3f ms, queue %.3f, wait %.3f, unpack %.3f, assembly %.3f\n", kname, t_plan - t0, t_queued_at - t_plan,
               t_synced - t_queued_at, t_before_assembly - t_synced, now_ms() - t_before_assembly);
@@ -1776,7 +1785,7 @@ std::unique_ptr<DocIdSet> execute_filter(Segment& seg, const pg_filter_node* fil
   PG_HIP(hipStreamSynchronize(ctx.stream));
   fill_stats(out->stats, P, P.full_scan_entries, seg.total_docs, stats_host);
   {   // pg_filter_exec has no flags: the exact count of leapfrogged shapes up to the default size (see execute_query)
-    static const int64_t exact_max_docs = getenv("PG_EXACT_STATS_MAX_DOCS") ? atoll(getenv("PG_EXACT_STATS_MAX_DOCS")) : ((int64_t)1 << 22);
+    const int64_t exact_max_docs = knobs().exact_stats_max_docs;
     if (!P.stats_exact && (int64_t)P.space_docs <= exact_max_docs) {
       out->stats.num_entries_scanned_in_filter = exact_entries_scanned(P, ctx, nullptr);
       out->stats.stats_exact = 1;

@@ -422,4 +422,28 @@ std::unique_ptr<DocIdSet> execute_filter(Segment& seg, const pg_filter_node* fil
 std::shared_ptr<CompiledPlan> get_plan(Segment& seg, const pg_filter_node* filter, const pg_query* q, int32_t flags = 0);   // cached, under seg.mu
 void docidset_copy_docids(DocIdSet& s, int32_t* out, int64_t cap);
 
+
+// ---- measurement / test / tuning knobs ------------------------------------------------------------------------------------------------
+// Every PG_* environment variable the library honours, read ONCE (at pg_init, or on first use) into this struct — round 4 had 44 getenv
+// calls in the planner and the executor, several of them per plan or per query.  pg_options_reload() re-reads the environment: the A/B
+// measurements (tools/) and the tests that compare two kernels inside one process call it after changing a variable; it must not run
+// concurrently with queries.  Flags are "variable present"; integers keep `unset` (-1) when absent.
+struct Knobs {
+  // planner (pg_plan.cpp)
+  bool no_oct = false, oct_no_affine = false, oct_byte_regs = false, oct_any_cardinality = false, no_oct_prune = false, oct_dword_regs = false;
+  bool no_p2 = false, p2_no_fast_a = false, no_p2_oct = false, no_radix = false, no_radix_aux = false, no_part = false, no_radix_packed = false;
+  bool no_pipe_general = false, no_pipe_wide = false, no_pipe_wide_double = false, mv_no_windows = false;
+  int64_t oct_min_docs = -1;
+  int part_min = -1;
+  // executor (pg_exec.hip)
+  bool force_interpreter = false, no_scan_pipe = false, no_pipe = false, no_dense_fused = false, no_part_grid_clamp = false, no_spin_wait = false;
+  bool trace_oct = false, no_tile_split = false, no_oct_exec = false, no_p2_simple = false, no_dense_count = false, no_direct_result = false, trace_host = false;
+  int scan_wgs_per_cu = 1, pipe_wgs_per_cu = 1, wgs_per_cu = 1, p2_wgs_per_cu = 4, dense_count_wgs = 1, tile_split_max = -1, hash_first_buckets = -1;
+  int64_t exact_stats_max_docs = (int64_t)1 << 22;
+  std::string oct_passes;      // PG_OCT_PASSES: cumulative fractions, e.g. "0.02,0.08,0.3,1"
+  // pg_comm.cpp
+  std::string rccl_library;    // PG_RCCL_LIBRARY: the collective library to bind instead of the system's RCCL
+};
+const Knobs& knobs();
+void knobs_reload();
 }  // namespace pg

@@ -27,6 +27,7 @@
 #endif
 #define PG_KERNEL template <int PG_NOT_INSTANTIATED> static
 #include "pg_kernels.hip"
+#include "pg_oct_layout.h"
 
 #define P2_THREADS (PG_P2_WAVES * 64)
 #ifndef PG_P2_STREAM_MIN_QUARTETS
@@ -408,6 +409,106 @@ DEVFN void p2_decode_generic(const PgQueryPlan& p, const uint32_t (&qi)[P2_QA], 
   }
 }
 
+// ---- oct-layout phase A (round 5) ---------------------------------------------------------------------------------------------------
+// The quad-layout loaders above cut run-time-width fields out of 64- / 128-bit windows: 72 VALU per doc for the whole scatter, 15 of them
+// v_readlane / v_writelane of 111 spilled SGPRs (profiles/r04_ab_partition_aggregate_simple.txt).  Plans WITHOUT a filter pass in front
+// (PgQueryPlan::p2_oct_a: no match words; group columns <= 8 bits, the first <= 24; no source, a raw INT or a <= 24-bit dictId field; one
+// plane) read their columns in the oct layout instead (pg_oct_layout.h): lane L owns docs 8L .. 8L+7 of a 512-doc sub-tile, a round is two
+// sub-tiles per wavefront (16 docs per lane, as Q = 4 quads), field positions are compile-time after one byte permute per dword.
+// OSK: 0 no source, 1 raw 32-bit INT (minus the column's minimum), 2 bit-packed dictIds (<= 24 bits).
+struct P2OctRaw {
+  u32x4 g0a, g0b;   // G0WIDE: column 0, 8 dwords from the lane's window start
+  u32x3 g[4];       // <= 8-bit group columns: 3 dwords
+  u32x4 s0, s1;     // the source: 8 dwords from its window start, or the lane's 8 raw values
+};
+struct P2OctLane { uint32_t goff[4], gsel[4], soff, ssel; };
+template <int OSK>
+DEVFN void p2o_lane_setup(const PgQueryPlan& p, int lane, P2OctLane& ln) {
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    ln.goff[g] = 0;
+    ln.gsel[g] = oct_selector(0);
+    if (g < p.n_group_cols) {
+      const uint32_t bo = (uint32_t)lane * (uint32_t)p.gcols[g].bits;
+      ln.goff[g] = bo & ~3u;
+      ln.gsel[g] = oct_selector(bo & 3u);
+    }
+  }
+  const uint32_t sbits = OSK == 1 ? 32u : (OSK == 2 ? (uint32_t)p.srcs[0].bits : 0u);
+  const uint32_t bo = (uint32_t)lane * sbits;
+  ln.soff = bo & ~3u;
+  ln.ssel = oct_selector(bo & 3u);
+}
+template <bool G0WIDE, int OSK>
+DEVFN void p2o_issue(const PgQueryPlan& p, const P2OctLane& ln, int wt, int sub, P2OctRaw& raw) {
+  const size_t at = (size_t)wt * (size_t)(PG_WAVE_DOCS / 8) + (size_t)sub * (size_t)(OCT_SUB_DOCS / 8);   // x bits = the sub-tile's byte offset
+  {
+    const PgGroupCol& gc = p.gcols[0];
+    const GAS uint8_t* base = gptr<uint8_t>(gc.data) + at * (size_t)gc.bits + ln.goff[0];
+    if (G0WIDE) { raw.g0a = ldnt((const GAS u32x4_a4*)base); raw.g0b = ldnt((const GAS u32x4_a4*)base + 1); }
+    else raw.g[0] = ldnt((const GAS u32x3_a4*)base);
+  }
+#pragma unroll
+  for (int g = 1; g < 4; g++)
+    if (g < p.n_group_cols) {
+      const PgGroupCol& gc = p.gcols[g];
+      raw.g[g] = ldnt((const GAS u32x3_a4*)(gptr<uint8_t>(gc.data) + at * (size_t)gc.bits + ln.goff[g]));
+    }
+  if (OSK != 0) {
+    const PgValueSrc& V = p.srcs[0];
+    const uint32_t bits = OSK == 1 ? 32u : (uint32_t)V.bits;
+    const GAS u32x4_a4* q = (const GAS u32x4_a4*)(gptr<uint8_t>(V.data) + at * (size_t)bits + ln.soff);
+    raw.s0 = ldnt(q);
+    raw.s1 = ldnt(q + 1);
+  }
+}
+// keys and plane-0 dwords of the lane's 8 docs
+template <bool G0WIDE, int OSK>
+DEVFN void p2o_decode(const PgQueryPlan& p, const P2OctLane& ln, const P2OctRaw& raw, uint32_t local_mask, uint32_t (&key)[8], uint32_t (&d)[8]) {
+  {
+    uint32_t v[8];
+    if (G0WIDE) oct_decode_source(p.gcols[0].bits, raw.g0a, raw.g0b, ln.gsel[0], v);
+    else oct_decode_group(p.gcols[0].bits, raw.g[0], ln.gsel[0], v);
+#pragma unroll
+    for (int j = 0; j < 8; j++) key[j] = v[j];   // mult of column 0 is 1
+  }
+#pragma unroll
+  for (int g = 1; g < 4; g++)
+    if (g < p.n_group_cols) {
+      uint32_t v[8];
+      oct_decode_group(p.gcols[g].bits, raw.g[g], ln.gsel[g], v);
+      const uint32_t mult = (uint32_t)p.gcols[g].mult;
+#pragma unroll
+      for (int j = 0; j < 8; j++) key[j] = mad24(v[j], mult, key[j]);   // dictId < 2^8, mult < 2^24 (planner)
+    }
+  if (OSK == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) d[j] = key[j] & local_mask;
+    return;
+  }
+  uint32_t f[8];
+  if (OSK == 1) {
+    const uint32_t w[8] = {raw.s0.x, raw.s0.y, raw.s0.z, raw.s0.w, raw.s1.x, raw.s1.y, raw.s1.z, raw.s1.w};
+    const uint32_t bias = (uint32_t)p.p2_fbias[0];
+#pragma unroll
+    for (int j = 0; j < 8; j++) f[j] = bswap32(w[j]) - bias;
+  } else {
+    oct_decode_source(p.srcs[0].bits, raw.s0, raw.s1, ln.ssel, f);
+  }
+  const uint32_t sh = (uint32_t)p.pk_shift[0];
+#pragma unroll
+  for (int j = 0; j < 8; j++) d[j] = (key[j] & local_mask) | (f[j] << sh);
+}
+// validity of the lane's 8 docs of sub-tile `sub` of the tile wavefront `wave` owns in quartet g (0 beyond the segment)
+DEVFN uint32_t p2o_mask8(int g, int n_quartets, int wave, int lane, int sub, int n_wtiles, int64_t num_docs) {
+  const int wt_raw = g * PG_P2_WAVES + wave;
+  if (g >= n_quartets || wt_raw >= n_wtiles) return 0u;   // wave-uniform
+  const int64_t rem = num_docs - ((int64_t)wt_raw * PG_WAVE_DOCS + (int64_t)sub * OCT_SUB_DOCS);   // wave-uniform
+  if (rem >= OCT_SUB_DOCS) return 0xFFu;
+  const int64_t r = rem - 8 * lane;
+  return r >= 8 ? 0xFFu : (r <= 0 ? 0u : ((1u << (uint32_t)r) - 1u));
+}
+
 // LDS of a scatter workgroup (dwords): hist, off, cnt, lo_cnt, cur, left [NBp each] | pool [PG_P2_POOL] | ctrl [8] |
 // lines [R / 32 + NB + 1][2] | sorted [T][R] | lo [T][NB][32]
 struct P2Stage {
@@ -443,8 +544,9 @@ DEVFN void p2_claim_batch(const PgQueryPlan& p, uint32_t* pool, uint32_t tail, i
   for (uint32_t i = (uint32_t)lane; i < PG_P2_BATCH; i += 64u)
     pool[(tail + i) & (PG_P2_POOL - 1u)] = basec + i < cap_s ? stripe * cap_s + basec + i : (uint32_t)p.p2_capacity;
 }
-template <int T, int Q, bool FAST, int SRC>
+template <int T, int Q, bool FAST, int SRC, int OCT = 0, bool G0WIDE = false, int OSK = 0>
 __device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
+  static_assert(OCT == 0 || (T == 1 && Q == 4 && !FAST), "the oct-layout phase A: one plane, two sub-tiles (16 docs) per lane and round");
   extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
   constexpr int NBATCH = Q / P2_QA;               // quads per lane and round: Q, decoded in batches of P2_QA
   constexpr uint32_t R = PG_P2_WAVES * Q * 256;   // tuples per round
@@ -493,6 +595,14 @@ __device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
   uint32_t m = STREAM ? valid_quad_mask(stile.n_valid, lane) : p2_tile_mask(p, g, n_quartets, wave, lane, n_wtiles, num_docs);
   int k0 = 0;
   P2Raw raw;   // the loads of the round's first batch, requested one round ahead
+  P2OctLane oln;
+  P2OctRaw or0, or1;   // OCT: the round's two sub-tiles, each re-requested (for the next round) right after its decode
+  if (OCT) {
+    p2o_lane_setup<OSK>(p, lane, oln);
+    const int wt0 = p2_tile_of(g, wave, n_wtiles);
+    p2o_issue<G0WIDE, OSK>(p, oln, wt0, 0, or0);
+    p2o_issue<G0WIDE, OSK>(p, oln, wt0, 1, or1);
+  }
   if (FAST) {
     uint32_t qi[P2_QA];
     p2_quads_of(lane, m & 0xFFu, 0, qi);
@@ -504,9 +614,30 @@ __device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
     const uint32_t mb = (m >> (4 * k0)) & (Q == 8 ? 0xFFFFFFFFu : ((1u << (4 * (Q & 7))) - 1u));
     uint32_t d[T][Q * 4];
     uint32_t br[Q * 4];
+    if (OCT) {
+      // ---- A (oct layout): sub-tiles 2 sp, 2 sp + 1 of the tile (sp = k0 / 4); the next round's loads leave right after each decode ------
+      int gn = g, kn = k0 + Q;
+      if (kn >= 8) { kn = 0; gn = g + gstride; }
+      const int wtn = p2_tile_of(gn, wave, n_wtiles);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; s2++) {
+        const int sub = (k0 >> 2) * 2 + s2;
+        const uint32_t m8 = p2o_mask8(g, n_quartets, wave, lane, sub, n_wtiles, num_docs);
+        uint32_t key[8], dd[8];
+        p2o_decode<G0WIDE, OSK>(p, oln, s2 == 0 ? or0 : or1, local_mask, key, dd);
+        p2o_issue<G0WIDE, OSK>(p, oln, wtn, (kn >> 2) * 2 + s2, s2 == 0 ? or0 : or1);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          d[0][s2 * 8 + j] = dd[j];
+          const uint32_t b = key[j] >> p.radix_shift;
+          br[s2 * 8 + j] = 0xFFFFFFFFu;
+          if ((m8 >> j) & 1u) br[s2 * 8 + j] = (b << 16) | atomicAdd(&S.hist[b], 1u);
+        }
+      }
+    }
     // ---- A: tuples of this wavefront's Q quads per lane; histogram + rank in one returning LDS add ---------------------------------
 #pragma unroll
-    for (int h = 0; h < NBATCH; h++) {
+    for (int h = 0; h < (OCT ? 0 : NBATCH); h++) {
       uint32_t qi[P2_QA];
       p2_quads_of(lane, (mb >> (h * P2_QA * 4)) & 0xFFu, k0 + h * P2_QA, qi);
       uint32_t key[P2_QA * 4], dd[T][P2_QA * 4];
@@ -750,6 +881,15 @@ P2_SCATTER(pg_p2_scatter_2f, 2, 4, true, 2)
 P2_SCATTER(pg_p2_scatter_1f_key, 1, 4, true, 0)   // key only (COUNT over a big key space)
 P2_SCATTER(pg_p2_scatter_1f_hll, 1, 4, true, 1)   // config 5
 P2_SCATTER(pg_p2_scatter_stream, 1, 4, true, 3)   // the survivors of the pruned-offer passes (pg_oct_p)
+// oct-layout phase A (plans without a filter pass, PgQueryPlan::p2_oct_a): [first group column <= 8 / <= 24 bits] x [no source, raw INT, dictIds]
+#define P2_SCATTER_OCT(NAME, G0WIDE, OSK) \
+  extern "C" __global__ void __launch_bounds__(P2_THREADS, 4) NAME(const PgQueryPlan p) { p2_scatter_body<1, 4, false, 2, 1, G0WIDE, OSK>(p); }
+P2_SCATTER_OCT(pg_p2_scatter_o_key, false, 0)
+P2_SCATTER_OCT(pg_p2_scatter_o_raw, false, 1)
+P2_SCATTER_OCT(pg_p2_scatter_o_dict, false, 2)
+P2_SCATTER_OCT(pg_p2_scatter_ow_key, true, 0)
+P2_SCATTER_OCT(pg_p2_scatter_ow_raw, true, 1)
+P2_SCATTER_OCT(pg_p2_scatter_ow_dict, true, 2)
 extern "C" const int pg_p2_round_quads[5] = {0, 4, 4, 2, 2};   // Q per plane count (the host sizes the LDS with it)
 
 // ---- chunk index: the chunk records grouped by bucket (counting sort of p2_meta), three small launches ------------------------------

@@ -1097,7 +1097,7 @@ static OpPtr clone_leaf(const FilterOp& op) {
 static void plan_oct(CompiledPlan& P, PgQueryPlan& D, const std::vector<Column*>& srcs, int64_t G, int64_t total_docs) {
   D.oct = 0;
   D.oct_dword = 0;
-  if (getenv("PG_NO_OCT")) return;   // measurement / test knob: the round-3 kernels
+  if (knobs().no_oct) return;   // measurement / test knob: the round-3 kernels
   if (D.mv || P.first_doc_op >= 0 || D.n_aux != 1 || srcs.size() != 1 || D.n_group_cols > 4 || D.n_ops > 1) return;
   for (int g = 0; g < D.n_group_cols; g++)
     if (D.gcols[g].col_kind != PG_COL_FIXED_BIT || D.gcols[g].bits < 1 || D.gcols[g].bits > 8 || D.gcols[g].mult >= ((int64_t)1 << 24) ||
@@ -1114,7 +1114,7 @@ static void plan_oct(CompiledPlan& P, PgQueryPlan& D, const std::vector<Column*>
     kind = 4;
   } else if (A.kind == PG_AUX_HLL_DICT) {
     if (c->col_kind != PG_COL_FIXED_BIT || c->bits < 1 || c->bits > 24 || !c->has_dictionary) return;
-    if (c->val_type == PG_V_I32 && c->dict_affine && c->dict_step > 0 && c->dict_step < ((int64_t)1 << 24) && !getenv("PG_OCT_NO_AFFINE")) {
+    if (c->val_type == PG_V_I32 && c->dict_affine && c->dict_step > 0 && c->dict_step < ((int64_t)1 << 24) && !knobs().oct_no_affine) {
       kind = 1;
       const uint32_t m = 0x5bd1e995u;
       D.oct_c0 = (uint32_t)(int32_t)c->dict_base * m;
@@ -1140,7 +1140,7 @@ static void plan_oct(CompiledPlan& P, PgQueryPlan& D, const std::vector<Column*>
     D.oct = 1;
     // HyperLogLog registers as DWORDS while they live in LDS, if the key space leaves room for four bytes per register (<= ~140 groups
     // of 256 registers): an offer is one ds_max_u32 without a return instead of a read, a compare and a compare-and-swap on the byte's dword
-    D.oct_dword = kind != 4 && (int64_t)A.lds_offset + A.rep_bytes * 4 + 64 <= 156 * 1024 && !getenv("PG_OCT_BYTE_REGS") ? 1 : 0;
+    D.oct_dword = kind != 4 && (int64_t)A.lds_offset + A.rep_bytes * 4 + 64 <= 156 * 1024 && !knobs().oct_byte_regs ? 1 : 0;
     return;
   }
   // pruned offers: HyperLogLog only, one-dword tuples of the partition pipeline, counters + floors of the whole key space in LDS
@@ -1148,18 +1148,18 @@ static void plan_oct(CompiledPlan& P, PgQueryPlan& D, const std::vector<Column*>
   // and every offer survives every pass — 3 x the cost of the plain partition pipeline (profiles/r04_a: DISTINCTCOUNTHLL over a 16-value
   // column).  What is known at plan time is the column's cardinality / value range: at least 16 values per register.
   const int64_t distinct_hint = c->has_dictionary ? (int64_t)c->cardinality : (c->has_int_range ? c->int_max - c->int_min : 0);
-  if (distinct_hint < ((int64_t)16 << A.log2m) && !getenv("PG_OCT_ANY_CARDINALITY")) return;
+  if (distinct_hint < ((int64_t)16 << A.log2m) && !knobs().oct_any_cardinality) return;
   // ... and enough docs: the floors only rise once a register has seen several offers (pg_exec.hip, oct_pass_bounds) — below ~16 offers
   // per register over the whole segment the passes would forward nearly everything
-  const int64_t min_docs = getenv("PG_OCT_MIN_DOCS") ? atoll(getenv("PG_OCT_MIN_DOCS")) : std::max<int64_t>((int64_t)1 << 20, 16 * (G << A.log2m));
+  const int64_t min_docs = knobs().oct_min_docs >= 0 ? knobs().oct_min_docs : std::max<int64_t>((int64_t)1 << 20, 16 * (G << A.log2m));
   if (D.agg_mode == PG_AGG_RADIX && D.p2 && D.p2_planes == 1 && kind != 4 && D.n_group_cols >= 1 && total_docs >= min_docs &&
       G * 4 + ((G + 3) & ~(int64_t)3) + 16 * 4096 + 512 <= 156 * 1024 &&   /* counters + floors + the wavefronts' survivor rings */ G < ((int64_t)1 << (31 - (A.log2m + 5))) && D.pk_bits[0] == A.log2m + 5 &&
-      D.p2_fkind[0] == PG_P2_F_HLL && !getenv("PG_NO_OCT_PRUNE")) {
+      D.p2_fkind[0] == PG_P2_F_HLL && !knobs().no_oct_prune) {
     D.oct = 2;
     // The aggregation pass of the pruned passes sees HyperLogLog offers only (COUNT stays in pg_oct_p's LDS table) and keeps the registers
     // as BYTES: a bucket is as many groups as fill the LDS with one byte per register — 512 groups x 256 registers, 25 buckets for
     // config 5 instead of 157 with an accumulator slot and dword registers per group.  Re-cut the key accordingly.
-    if (!getenv("PG_OCT_DWORD_REGS")) {
+    if (!knobs().oct_dword_regs) {
       const int64_t budget = kLdsTableBudget - (int64_t)PG_P2_LIST * 4 - 256;
       int shift = 0;
       while (shift < 24 && ((int64_t)2 << shift) * (int64_t)A.stride <= budget && shift + 1 + (A.log2m + 5) <= 31) shift++;
@@ -1181,7 +1181,7 @@ static void plan_oct(CompiledPlan& P, PgQueryPlan& D, const std::vector<Column*>
 // buckets, up to PG_P2_MAX_BUCKETS) when that lets a tuple fit ONE dword, which halves the bytes written and read back.
 // Returns false when the shape is outside the pipeline (the round-2 radix passes then run).
 static bool plan_partition_v2(CompiledPlan& P, PgQueryPlan& D, const std::vector<Column*>& srcs, const std::vector<PgAccOp>& ops, int64_t G) {
-  if (getenv("PG_NO_P2")) return false;
+  if (knobs().no_p2) return false;
   if ((int)srcs.size() > PG_MAX_RADIX_SRCS) return false;
   int64_t per_group = (int64_t)ops.size() * 8;
   for (int x = 0; x < D.n_aux; x++) {
@@ -1298,7 +1298,7 @@ static bool plan_partition_v2(CompiledPlan& P, PgQueryPlan& D, const std::vector
   // the scatter's batched loader (pg_kernels_part.hip "fast A"): <= 4 bit-packed group columns, the first <= 24 bits wide and the
   // others <= 8; at most one source, bit-packed <= 24 bits or raw 32-bit; one or two planes
   {
-    bool fast = planes <= 2 && D.n_group_cols >= 1 && D.n_group_cols <= 4 && srcs.size() <= 1 && !getenv("PG_P2_NO_FAST_A");
+    bool fast = planes <= 2 && D.n_group_cols >= 1 && D.n_group_cols <= 4 && srcs.size() <= 1 && !knobs().p2_no_fast_a;
     for (int g = 0; g < D.n_group_cols && fast; g++)
       fast = D.gcols[g].col_kind == PG_COL_FIXED_BIT && D.gcols[g].bits <= (g == 0 ? 24 : 8) && (g > 0 || D.gcols[g].mult == 1) &&
              D.gcols[g].mult < (1 << 24);
@@ -1307,6 +1307,14 @@ static bool plan_partition_v2(CompiledPlan& P, PgQueryPlan& D, const std::vector
       fast = (c->col_kind == PG_COL_FIXED_BIT && c->bits <= 24) || c->col_kind == PG_COL_RAW32;
     }
     D.p2_fast_a = fast ? 1 : 0;
+    // the oct-layout phase A (pg_p2_scatter_o*): a subset of the above — one plane, the source not a HyperLogLog offer
+    bool oct = fast && planes == 1 && !knobs().no_p2_oct;
+    if (oct && srcs.size() == 1) {
+      const Column* c = srcs[0];
+      oct = (fields[0].kind == PG_P2_F_RAW32 && c->col_kind == PG_COL_RAW32 && c->val_type == PG_V_I32) ||
+            (fields[0].kind == PG_P2_F_DICTID && c->col_kind == PG_COL_FIXED_BIT && c->bits <= 24);
+    }
+    D.p2_oct_a = oct ? 1 : 0;
   }
   D.radix_shift = shift;
   D.radix_buckets = (int32_t)nb;
@@ -1852,7 +1860,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
   // pipeline carries the doc's value in the tuple and keeps the registers of one bucket of groups in LDS instead.
   bool hll_radix = false;
   int hll_shift = 0;
-  if (q->n_group_by > 0 && D.n_aux > 0 && D.n_ops > 0 && !D.mv && !getenv("PG_NO_RADIX") && !getenv("PG_NO_RADIX_AUX")) {
+  if (q->n_group_by > 0 && D.n_aux > 0 && D.n_ops > 0 && !D.mv && !knobs().no_radix && !knobs().no_radix_aux) {
     int64_t per_group = (int64_t)D.n_ops * 8, state_bytes = 0;
     bool ok = (int)srcs.size() <= PG_MAX_RADIX_SRCS;
     for (int x = 0; x < D.n_aux && ok; x++) {
@@ -1890,7 +1898,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     // beyond one LDS table: range-partitioned LDS tables when <= 32 ranges cover the key space (LDS atomics sustain ~2e12/s,
     // memory-side atomics on an HBM table ~2.4e10/s — tools/probes/atomic_scope.hip), else the dense HBM table
     int parts = (int)std::min<int64_t>(32, std::max<int64_t>(2, (table_bytes + kLdsTableBudget - 1) / kLdsTableBudget));
-    if (const char* e = getenv("PG_PART_MIN")) parts = std::max(parts, std::min(32, atoi(e)));   // measurement knob
+    if (knobs().part_min >= 0) parts = std::max(parts, std::min(32, knobs().part_min));   // measurement knob
     // every range's workgroups visit every doc (~4e11 doc visits/s measured), the dense HBM table pays per matching doc and
     // accumulator (memory-side atomics, 2.4e10/s): partition when  parts * N / 4e11  <  matched * ops / 2.4e10, with the
     // match count estimated from the filter (exact for index leaves)
@@ -1904,8 +1912,8 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     while (((int64_t)2 << radix_shift) * std::max(D.n_ops, 1) * 8 <= kLdsTableBudget) radix_shift++;
     const int64_t radix_buckets = (G + ((int64_t)1 << radix_shift) - 1) >> radix_shift;
     const bool radix_ok = D.n_aux == 0 && n_srcs_radix <= PG_MAX_RADIX_SRCS && D.n_ops > 0 &&
-                          radix_buckets <= PG_MAX_RADIX_BUCKETS && !getenv("PG_NO_RADIX");
-    const bool part_ok = table_bytes <= kLdsTableBudget * parts && !getenv("PG_NO_PART");
+                          radix_buckets <= PG_MAX_RADIX_BUCKETS && !knobs().no_radix;
+    const bool part_ok = table_bytes <= kLdsTableBudget * parts && !knobs().no_part;
     const double ops_d = (double)std::max(D.n_ops, 1);
     const double cost_global = 1.25 + sel * ops_d * 41.7;
     const double cost_part = part_ok ? parts * 2.4 : 1e30;
@@ -1970,7 +1978,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
   }
   // Packed 4-byte radix tuples (pg_kernels.hip "Packed radix tuples"): the local key plus, per source, the (index, rank) a
   // DISTINCTCOUNTHLL offers or the dictId of a dictionary-encoded source, when that fits 32 bits; staged in LDS by at most 32 buckets
-  if (D.agg_mode == PG_AGG_RADIX && !D.p2 && P.first_doc_op < 0 && D.radix_buckets <= 64 && !getenv("PG_NO_RADIX_PACKED")) {
+  if (D.agg_mode == PG_AGG_RADIX && !D.p2 && P.first_doc_op < 0 && D.radix_buckets <= 64 && !knobs().no_radix_packed) {
     bool ok = true;
     int next_bit = D.radix_shift;
     for (size_t si = 0; si < srcs.size() && ok; si++) {
@@ -2027,7 +2035,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
   // The pipeline's other shapes (pg_pipe_*): the same aggregation behind no filter at all, a lone range scan, index leaves only, and any of
   // them (or the headline shape) followed by the upsert snapshot's bitmap
   D.pipe_general = 0;
-  if (!D.pipe_fit && P.fast_agg && D.agg_mode == PG_AGG_LDS && D.n_group_cols >= 1 && D.n_group_cols <= 2 && !getenv("PG_NO_PIPE_GENERAL")) {
+  if (!D.pipe_fit && P.fast_agg && D.agg_mode == PG_AGG_LDS && D.n_group_cols >= 1 && D.n_group_cols <= 2 && !knobs().no_pipe_general) {
     bool ok = true;
     int src = -1;
     for (int o = 0; o < D.n_ops && ok; o++) {
@@ -2085,7 +2093,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
   // (or COUNT alone), zero to two group columns of <= 16 bits, behind no filter, a fused dense index program, a lone raw-INT range scan, or both
   D.pipe_wide = 0;
   if (P.wide_agg && (D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE) && D.n_group_cols <= 2 &&
-      (int64_t)G * D.replicas <= 65536 && !getenv("PG_NO_PIPE_WIDE")) {
+      (int64_t)G * D.replicas <= 65536 && !knobs().no_pipe_wide) {
     bool ok = true;
     int src = -1;
     for (int o = 0; o < D.n_ops && ok; o++) {
@@ -2101,7 +2109,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
       const Column* c = srcs[(size_t)src];
       if (D.srcs[src].col_kind == PG_COL_RAW32 && c->val_type == PG_V_I32) vw = 1;
       else if (D.srcs[src].col_kind == PG_COL_RAW64 && c->val_type == PG_V_I64) vw = 2;
-      else if (D.srcs[src].col_kind == PG_COL_RAW64 && c->val_type == PG_V_F64 && !getenv("PG_NO_PIPE_WIDE_DOUBLE")) vw = 3;
+      else if (D.srcs[src].col_kind == PG_COL_RAW64 && c->val_type == PG_V_F64 && !knobs().no_pipe_wide_double) vw = 3;
       else ok = false;
     }
     // accumulator kinds: integers in int64; DOUBLE sums as fixed-point digits (a column with NaN / Inf keeps IEEE additions: not here),
@@ -2129,7 +2137,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
       D.pipe_has_scan = has_scan ? 1 : 0;
     }
   }
-  D.mv_no_windows = getenv("PG_MV_NO_WINDOWS") ? 1 : 0;
+  D.mv_no_windows = knobs().mv_no_windows ? 1 : 0;
   if (D.mv) {   // none of the single-value specialisations reads a multi-value column
     P.fast_filter = -2;
     P.fast_agg = false;

@@ -34,3 +34,16 @@ def gpu_api():
 def sv_data():
     z = np.load(os.path.join(ROOT, "tests", "golden", "test_data_sv.npz"))
     return {k: z[k] for k in z.files}
+
+
+@pytest.fixture
+def gpu_knobs(monkeypatch, gpu_api):
+    """Sets PG_* knobs for one test: the library reads its environment once (pg_init), so a changed variable takes effect through
+    pg_options_reload; the previous environment is restored (and re-read) afterwards."""
+    def set_knobs(**kv):
+        for k, v in kv.items():
+            monkeypatch.setenv(k, str(v))
+        gpu_api.call("options_reload")
+    yield set_knobs
+    monkeypatch.undo()
+    gpu_api.call("options_reload")

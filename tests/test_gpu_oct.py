@@ -118,9 +118,9 @@ def test_lds_resident_sizes(gpu_api, oracle_api, n):
     o.destroy()
 
 
-def test_round3_kernels_agree(gpu_api, oracle_api, monkeypatch):
+def test_round3_kernels_agree(gpu_api, oracle_api, gpu_knobs):
     """PG_NO_OCT: the interpreter runs the same plans (the A/B knob of the variants table)."""
-    monkeypatch.setenv("PG_NO_OCT", "1")
+    gpu_knobs(PG_NO_OCT="1")
     g, o = both(gpu_api, oracle_api, make_host(50_001, seed=3))
     gb = run(g, o, LDS_SHAPES[0], kernels=None)
     assert gb.stats.kernel.decode() == "pg_generic_query_l"
@@ -128,10 +128,10 @@ def test_round3_kernels_agree(gpu_api, oracle_api, monkeypatch):
     o.destroy()
 
 
-def test_byte_registers_in_lds_agree(gpu_api, oracle_api, monkeypatch):
+def test_byte_registers_in_lds_agree(gpu_api, oracle_api, gpu_knobs):
     """PG_OCT_BYTE_REGS: key spaces small enough for dword registers in LDS (ds_max_u32 offers) run with byte registers (compare-and-swap)
     instead — the layout larger key spaces use; the A/B knob of the variants table."""
-    monkeypatch.setenv("PG_OCT_BYTE_REGS", "1")
+    gpu_knobs(PG_OCT_BYTE_REGS="1")
     g, o = both(gpu_api, oracle_api, make_host(100_003, seed=5))
     for sql in (LDS_SHAPES[0], LDS_SHAPES[2], LDS_SHAPES[8], LDS_SHAPES[10], LDS_SHAPES[13]):
         run(g, o, sql, kernels=("pg_oct_l", "pg_oct_lm"))
@@ -150,9 +150,9 @@ PRUNED_SHAPES = [
 
 @pytest.mark.parametrize("passes", ["1", "0.5,1", "0.1,0.4,1", "0.02,0.08,0.3,1", "0.01,0.02,0.05,0.3,1"])
 @pytest.mark.parametrize("n", [2049, 300_007])
-def test_pruned_offers_config5(gpu_api, oracle_api, monkeypatch, passes, n):
-    monkeypatch.setenv("PG_OCT_MIN_DOCS", "0")
-    monkeypatch.setenv("PG_OCT_PASSES", passes)
+def test_pruned_offers_config5(gpu_api, oracle_api, gpu_knobs, passes, n):
+    gpu_knobs(PG_OCT_MIN_DOCS="0")
+    gpu_knobs(PG_OCT_PASSES=passes)
     host = synth.generate_segment(n, segment_index=3, columns=synth.CFG5_COLUMNS, native=(n > 200_000))
     g, o = both(gpu_api, oracle_api, host)
     for sql in PRUNED_SHAPES:
@@ -162,9 +162,9 @@ def test_pruned_offers_config5(gpu_api, oracle_api, monkeypatch, passes, n):
 
 
 @pytest.mark.parametrize("n", [1, 31, 513, 4097, 16_385, 1_000_003])
-def test_pruned_offers_sizes(gpu_api, oracle_api, monkeypatch, n):
-    monkeypatch.setenv("PG_OCT_MIN_DOCS", "0")
-    monkeypatch.setenv("PG_OCT_PASSES", "0.05,0.25,1")
+def test_pruned_offers_sizes(gpu_api, oracle_api, gpu_knobs, n):
+    gpu_knobs(PG_OCT_MIN_DOCS="0")
+    gpu_knobs(PG_OCT_PASSES="0.05,0.25,1")
     host = synth.generate_segment(n, segment_index=5, columns=synth.CFG5_COLUMNS, native=(n > 200_000))
     g, o = both(gpu_api, oracle_api, host)
     run(g, o, PRUNED_SHAPES[0], kernels=("pg_oct_pruned_group_by",))
@@ -173,11 +173,11 @@ def test_pruned_offers_sizes(gpu_api, oracle_api, monkeypatch, n):
     o.destroy()
 
 
-def test_pruned_offers_skew_and_empty_registers(gpu_api, oracle_api, monkeypatch):
+def test_pruned_offers_skew_and_empty_registers(gpu_api, oracle_api, gpu_knobs):
     """Groups whose values are few keep registers at zero (floor 0: nothing is ever pruned there), one group takes half of the docs, the
     source's dictionary is not arithmetic (table route) in one query and raw INT in the other."""
-    monkeypatch.setenv("PG_OCT_MIN_DOCS", "0")
-    monkeypatch.setenv("PG_OCT_PASSES", "0.05,0.2,1")
+    gpu_knobs(PG_OCT_MIN_DOCS="0")
+    gpu_knobs(PG_OCT_PASSES="0.05,0.2,1")
     rng = np.random.default_rng(9)
     n = 400_003
     k1 = rng.integers(0, 150, n).astype(np.int32)
@@ -194,24 +194,24 @@ def test_pruned_offers_skew_and_empty_registers(gpu_api, oracle_api, monkeypatch
     o.destroy()
 
 
-def test_pruned_offers_need_many_distinct_values(gpu_api, oracle_api, monkeypatch):
+def test_pruned_offers_need_many_distinct_values(gpu_api, oracle_api, gpu_knobs):
     """A source of few distinct values (16 here) never fills the registers: the planner keeps the plain partition pipeline; the knob
     PG_OCT_ANY_CARDINALITY forces the passes (every offer survives every pass) and the result is the same."""
-    monkeypatch.setenv("PG_OCT_MIN_DOCS", "0")
+    gpu_knobs(PG_OCT_MIN_DOCS="0")
     host = synth.generate_segment(120_001, segment_index=8, columns=synth.CFG5_COLUMNS, native=False)
     sql = "SELECT h1, h2, h3, h4, COUNT(*), DISTINCTCOUNTHLL(h3) FROM gpuBench GROUP BY h1, h2, h3, h4 LIMIT 20000"
     g, o = both(gpu_api, oracle_api, host)
     run(g, o, sql, kernels=("pg_part_group_by",))
     g.destroy()
-    monkeypatch.setenv("PG_OCT_ANY_CARDINALITY", "1")
-    monkeypatch.setenv("PG_OCT_PASSES", "0.1,0.5,1")
+    gpu_knobs(PG_OCT_ANY_CARDINALITY="1")
+    gpu_knobs(PG_OCT_PASSES="0.1,0.5,1")
     g = NativeSegment(gpu_api, host)
     run(g, o, sql, kernels=("pg_oct_pruned_group_by",))
     g.destroy()
     o.destroy()
 
 
-def test_pruned_offers_default_threshold(gpu_api, oracle_api, monkeypatch):
+def test_pruned_offers_default_threshold(gpu_api, oracle_api, gpu_knobs):
     """Without the knobs a segment with fewer than 16 offers per register (12 800 groups x 256 registers: 52 M docs) keeps the partition
     pipeline — its floors would not rise; with the threshold lowered the same docs take the pruned passes and answer the same.  (The
     default's positive side is the full-size test: tests/test_gpu_full_size.py.)"""
@@ -219,7 +219,7 @@ def test_pruned_offers_default_threshold(gpu_api, oracle_api, monkeypatch):
     g, o = both(gpu_api, oracle_api, seg)
     run(g, o, synth.QUERY_CFG5, kernels=("pg_part_group_by",))
     g.destroy()
-    monkeypatch.setenv("PG_OCT_MIN_DOCS", "1000000")
+    gpu_knobs(PG_OCT_MIN_DOCS="1000000")
     g = NativeSegment(gpu_api, seg)   # (plans are cached per segment: a new one sees the knob)
     run(g, o, synth.QUERY_CFG5, kernels=("pg_oct_pruned_group_by",))
     g.destroy()

@@ -575,9 +575,9 @@ def test_wide_pipeline_key_widths(gpu_api, oracle_api, card):
     o.destroy()
 
 
-def test_wide_pipeline_knob(gpu_api, oracle_api, monkeypatch):
+def test_wide_pipeline_knob(gpu_api, oracle_api, gpu_knobs):
     """PG_NO_PIPE_WIDE: the same plans on the 16-wavefront walk (pg_fast_none_w / pg_fast_multi_w), the A/B knob of the variants table."""
-    monkeypatch.setenv("PG_NO_PIPE_WIDE", "1")
+    gpu_knobs(PG_NO_PIPE_WIDE="1")
     rng = np.random.default_rng(4)
     n = 30_001
     data = {"k": rng.integers(0, 900, n).astype(np.int32), "lm": rng.integers(-10**9, 10**9, n).astype(np.int64)}

@@ -188,12 +188,54 @@ def test_many_buckets(gpu_api, oracle_api):
     o.destroy()
 
 
-def test_round2_passes_still_agree(gpu_api, oracle_api, monkeypatch):
+def test_round2_passes_still_agree(gpu_api, oracle_api, gpu_knobs):
     """PG_NO_P2 keeps the round-2 radix passes reachable (shapes outside the pipeline take them): same results."""
     host = synth.generate_segment(90_001, segment_index=7, columns=synth.CFG5_COLUMNS, native=False)
-    monkeypatch.setenv("PG_NO_P2", "1")
+    gpu_knobs(PG_NO_P2="1")
     g, o = both(gpu_api, oracle_api, host)
     gb = run(g, o, synth.QUERY_CFG5, limit=100_000, kernel=None)
     assert gb.stats.kernel.decode() == "pg_radix_group_by"
+    g.destroy()
+    o.destroy()
+
+
+# ---- oct-layout phase A (round 5: pg_p2_scatter_o*, plans without a filter pass): every kernel variant, segment sizes around the sub-tile
+#      (512 docs), tile (2 048) and round (4 x 1 024) boundaries, against the oracle and against the quad-layout kernels (PG_NO_P2_OCT) ----
+OCT_SHAPES = [
+    # <= 8-bit group columns (1..4 of them), raw INT source (the "40 k / 160 k groups" rows of the variants table)
+    ("SELECT g1, g2, c_inv1, COUNT(*), SUM(m) FROM gpuBench GROUP BY g1, g2, c_inv1 LIMIT 100000", 100_000),
+    ("SELECT g1, g2, c_inv1, c_inv2, COUNT(*), SUM(m), MAX(m) FROM gpuBench GROUP BY g1, g2, c_inv1, c_inv2 LIMIT 200000", 200_000),
+    # no source: COUNT over the key
+    ("SELECT g1, g2, c_inv1, COUNT(*) FROM gpuBench GROUP BY g1, g2, c_inv1 LIMIT 100000", 100_000),
+    # dictId source (<= 8 bits, and 20 bits)
+    ("SELECT g1, g2, c_inv1, COUNT(*), SUM(c_inv2), MAX(c_inv2) FROM gpuBench GROUP BY g1, g2, c_inv1 LIMIT 100000", 100_000),
+    ("SELECT g1, g2, c_inv1, MIN(u), MAX(u) FROM gpuBench GROUP BY g1, g2, c_inv1 LIMIT 100000", 100_000),
+    # first group column wider than 8 bits: key only, + small columns, + sources
+    ("SELECT u, COUNT(*) FROM gpuBench GROUP BY u LIMIT 2000000", 2_000_000),
+    ("SELECT u, c_inv2, COUNT(*) FROM gpuBench GROUP BY u, c_inv2 LIMIT 5000000", 5_000_000),
+    ("SELECT u, COUNT(*), SUM(g1) FROM gpuBench GROUP BY u LIMIT 2000000", 2_000_000),
+]
+OCT_COLUMNS = ["c_inv1", "c_inv2", "g1", "g2", "m", "u"]
+
+
+@pytest.mark.parametrize("n", [1, 7, 9, 511, 513, 1025, 2047, 2049, 4095, 4097, 8193, 100_003, 1_000_003])
+def test_oct_scatter_sizes(gpu_api, oracle_api, n):
+    host = synth.generate_segment(n, segment_index=3, columns=OCT_COLUMNS, native=(n > 200_000))
+    g, o = both(gpu_api, oracle_api, host)
+    for q, limit in OCT_SHAPES[:2] + OCT_SHAPES[5:6]:
+        run(g, o, q, limit)
+    g.destroy()
+    o.destroy()
+
+
+def test_oct_scatter_shapes_and_the_quad_kernels_agree(gpu_api, oracle_api, gpu_knobs):
+    host = synth.generate_segment(777_001, segment_index=5, columns=OCT_COLUMNS, native=True)
+    g, o = both(gpu_api, oracle_api, host)
+    oct_rows = [run(g, o, q, limit).rows() for q, limit in OCT_SHAPES]
+    g.destroy()
+    gpu_knobs(PG_NO_P2_OCT="1")
+    g = NativeSegment(gpu_api, host)   # (plans are cached per segment: a new one sees the knob)
+    for (q, limit), rows in zip(OCT_SHAPES, oct_rows):
+        assert run(g, o, q, limit).rows() == rows, q
     g.destroy()
     o.destroy()

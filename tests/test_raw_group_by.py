@@ -223,12 +223,12 @@ def test_gpu_raw_long_max_value_key(gpu_api):
 
 
 @pytest.mark.gpu
-def test_gpu_hash_group_by_retries_with_more_buckets(gpu_api, oracle_api, monkeypatch):
+def test_gpu_hash_group_by_retries_with_more_buckets(gpu_api, oracle_api, gpu_knobs):
     """A hash bucket whose distinct keys overflow its LDS table is met with four times as many buckets, not with an error after the
     work: start the nearly-all-distinct key column at 16 buckets (PG_HASH_FIRST_BUCKETS), far too few for 150 000 keys."""
     host, _ = raw_key_segment()
     g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
-    monkeypatch.setenv("PG_HASH_FIRST_BUCKETS", "16")
+    gpu_knobs(PG_HASH_FIRST_BUCKETS="16")
     qg, qo = parse_sql("SELECT kw, COUNT(*), SUM(m) FROM rawKeys GROUP BY kw LIMIT 1000000"), parse_sql("SELECT kw, COUNT(*), SUM(m) FROM rawKeys GROUP BY kw LIMIT 1000000")
     qg.num_groups_limit = qo.num_groups_limit = 1_000_000
     gb, ob = g.execute(qg), o.execute(qo)
