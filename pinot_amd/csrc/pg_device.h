@@ -167,7 +167,8 @@ enum PgAggMode : int32_t {
 #define PG_P2_CTRL_STRIPE0 (PG_P2_CTRL_CURSOR + PG_P2_MAX_BUCKETS + 16)   // chunk-id cursors, one per stripe, each in a 128-byte line of its own
 #define PG_P2_STRIPES 64
 #define PG_P2_STRIPE_DWORDS 32
-#define PG_P2_CTRL_DWORDS (PG_P2_CTRL_STRIPE0 + PG_P2_STRIPES * PG_P2_STRIPE_DWORDS)
+#define PG_P2_CTRL_TIMING (PG_P2_CTRL_STRIPE0 + PG_P2_STRIPES * PG_P2_STRIPE_DWORDS)   // 16 x uint64: cycles per phase (PG_P2_TIMING variant)
+#define PG_P2_CTRL_DWORDS (PG_P2_CTRL_TIMING + 32)
 #define PG_P2_AGG_THREADS 1024
 // pruned-offer passes (pg_kernels_oct.hip): the survivor stream's control block (dwords)
 #define PG_OCT_MAX_REGIONS 1024

@@ -1020,6 +1020,19 @@ std::unique_ptr<Result> execute_query_plain(Segment& seg, const pg_query& q, con
     }
     hipLaunchKernelGGL(sk, dim3(sgrid), dim3(PG_P2_WAVES * 64), s_lds, ctx.stream, D);
     PG_HIP(hipGetLastError());
+#ifdef PG_P2_TIMING
+    {   // measurement variant: cycles per phase of the scatter's round, summed over the wavefronts
+      unsigned long long tm[13];
+      PG_HIP(hipMemcpyAsync(tm, D.p2_ctrl + PG_P2_CTRL_TIMING, sizeof(tm), hipMemcpyDeviceToHost, ctx.stream));
+      PG_HIP(hipStreamSynchronize(ctx.stream));
+      static const char* names[13] = {"A(rest)", "wait1", "B", "wait2", "C", "wait3", "D1", "wait4", "D2", "A:loads+decode0", "A:ranks0", "A:decode1", "A:ranks1"};
+      unsigned long long sum = 0;
+      for (int i = 0; i < 13; i++) sum += tm[i];
+      fprintf(stderr, "p2 scatter phases (%% of wavefront time, grid %d):", sgrid);
+      for (int i = 0; i < 13; i++) fprintf(stderr, " %s %.1f", names[i], 100.0 * (double)tm[i] / (double)std::max<unsigned long long>(sum, 1));
+      fprintf(stderr, "  | ticks per wavefront %.0f\n", (double)sum / ((double)sgrid * PG_P2_WAVES));
+    }
+#endif
     {   // the chunk records grouped by bucket (counting sort): count, scan, fill
       const int igrid = (int)std::max<size_t>(1, std::min<size_t>((size_t)num_cus(), (cap + 4095) / 4096));
       hipLaunchKernelGGL(pg_p2_index_count_kernel, dim3(igrid), dim3(1024), 0, ctx.stream, D);

@@ -439,25 +439,32 @@ DEVFN void p2o_lane_setup(const PgQueryPlan& p, int lane, P2OctLane& ln) {
   ln.soff = bo & ~3u;
   ln.ssel = oct_selector(bo & 3u);
 }
+// A wave-uniform address pinned into SGPRs: the loads take the  global_load v, v_offset, s[base:base+1]  form; otherwise the compiler hoists
+// one 64-bit per-lane address per column out of the round loop (2 VGPRs each) and the kernel spills.
+DEVFN const GAS uint8_t* p2o_sgpr(const GAS uint8_t* ptr) {
+  const uint64_t v = (uint64_t)ptr;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return (const GAS uint8_t*)(((uint64_t)hi << 32) | (uint64_t)lo);
+}
 template <bool G0WIDE, int OSK>
 DEVFN void p2o_issue(const PgQueryPlan& p, const P2OctLane& ln, int wt, int sub, P2OctRaw& raw) {
   const size_t at = (size_t)wt * (size_t)(PG_WAVE_DOCS / 8) + (size_t)sub * (size_t)(OCT_SUB_DOCS / 8);   // x bits = the sub-tile's byte offset
   {
     const PgGroupCol& gc = p.gcols[0];
-    const GAS uint8_t* base = gptr<uint8_t>(gc.data) + at * (size_t)gc.bits + ln.goff[0];
-    if (G0WIDE) { raw.g0a = ldnt((const GAS u32x4_a4*)base); raw.g0b = ldnt((const GAS u32x4_a4*)base + 1); }
-    else raw.g[0] = ldnt((const GAS u32x3_a4*)base);
+    const GAS uint8_t* base = p2o_sgpr(gptr<uint8_t>(gc.data) + at * (size_t)gc.bits);
+    if (G0WIDE) { raw.g0a = ldnt((const GAS u32x4_a4*)(base + ln.goff[0])); raw.g0b = ldnt((const GAS u32x4_a4*)(base + ln.goff[0]) + 1); }
+    else raw.g[0] = ldnt((const GAS u32x3_a4*)(base + ln.goff[0]));
   }
 #pragma unroll
   for (int g = 1; g < 4; g++)
     if (g < p.n_group_cols) {
       const PgGroupCol& gc = p.gcols[g];
-      raw.g[g] = ldnt((const GAS u32x3_a4*)(gptr<uint8_t>(gc.data) + at * (size_t)gc.bits + ln.goff[g]));
+      raw.g[g] = ldnt((const GAS u32x3_a4*)(p2o_sgpr(gptr<uint8_t>(gc.data) + at * (size_t)gc.bits) + ln.goff[g]));
     }
   if (OSK != 0) {
     const PgValueSrc& V = p.srcs[0];
     const uint32_t bits = OSK == 1 ? 32u : (uint32_t)V.bits;
-    const GAS u32x4_a4* q = (const GAS u32x4_a4*)(gptr<uint8_t>(V.data) + at * (size_t)bits + ln.soff);
+    const GAS u32x4_a4* q = (const GAS u32x4_a4*)(p2o_sgpr(gptr<uint8_t>(V.data) + at * (size_t)bits) + ln.soff);
     raw.s0 = ldnt(q);
     raw.s1 = ldnt(q + 1);
   }
@@ -509,6 +516,13 @@ DEVFN uint32_t p2o_mask8(int g, int n_quartets, int wave, int lane, int sub, int
   return r >= 8 ? 0xFFu : (r <= 0 ? 0u : ((1u << (uint32_t)r) - 1u));
 }
 
+// PG_P2_TIMING (measurement variant only, tools/build_variants.sh): cycles per phase of the scatter's round, summed over the wavefronts
+// (s_memtime; slot 2 k = phase k, slot 2 k + 1 = the wait at the barrier behind it) -> p2_ctrl[PG_P2_CTRL_TIMING ..], printed by the host
+#ifdef PG_P2_TIMING
+#define P2_TICK(SLOT) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if (lane == 0) atomicAdd(&s_time[SLOT], now_ - tick_); tick_ = now_; } while (0)
+#else
+#define P2_TICK(SLOT) do { } while (0)
+#endif
 // LDS of a scatter workgroup (dwords): hist, off, cnt, lo_cnt, cur, left [NBp each] | pool [PG_P2_POOL] | ctrl [8] |
 // lines [R / 32 + NB + 1][2] | sorted [T][R] | lo [T][NB][32]
 struct P2Stage {
@@ -561,6 +575,11 @@ __device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
   S.pool = S.left + NBA; S.ctrl = S.pool + PG_P2_POOL; S.lines = S.ctrl + 8; S.sorted = S.lines + 2u * (R / PG_P2_LINE + (uint32_t)NB + 1u); S.lo = S.sorted + (size_t)T * R;
   for (uint32_t i = (uint32_t)t; i < 6u * NBA; i += P2_THREADS) base[i] = 0;
   if (t < 8) S.ctrl[t] = 0;
+#ifdef PG_P2_TIMING
+  __shared__ unsigned long long s_time[16];
+  if (t < 16) s_time[t] = 0;
+  unsigned long long tick_ = __builtin_amdgcn_s_memtime();
+#endif
   constexpr bool STREAM = SRC == 3;   // the doc space is the survivor stream of pg_oct_p: its length is on the device
   // MatchAllFilterOperator: no filter pass ran in front — every doc matches (ExecutionStatistics.numDocsScanned)
   if (!STREAM && !p.match_words && blockIdx.x == 0 && t == 0) atomicAdd(p.stats, (unsigned long long)p.num_docs);
@@ -615,7 +634,7 @@ __device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
     uint32_t d[T][Q * 4];
     uint32_t br[Q * 4];
     if (OCT) {
-      // ---- A (oct layout): sub-tiles 2 sp, 2 sp + 1 of the tile (sp = k0 / 4); the next round's loads leave right after each decode ------
+      // ---- A (oct layout): sub-tiles 2 sp, 2 sp + 1 of the tile (sp = k0 / 4) ------------------------------------------------------------
       int gn = g, kn = k0 + Q;
       if (kn >= 8) { kn = 0; gn = g + gstride; }
       const int wtn = p2_tile_of(gn, wave, n_wtiles);
@@ -625,7 +644,14 @@ __device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
         const uint32_t m8 = p2o_mask8(g, n_quartets, wave, lane, sub, n_wtiles, num_docs);
         uint32_t key[8], dd[8];
         p2o_decode<G0WIDE, OSK>(p, oln, s2 == 0 ? or0 : or1, local_mask, key, dd);
-        p2o_issue<G0WIDE, OSK>(p, oln, wtn, (kn >> 2) * 2 + s2, s2 == 0 ? or0 : or1);
+#ifdef PG_P2_TIMING
+        { const uint32_t probe_ = key[0] + dd[7]; asm volatile("" :: "v"(probe_)); }   // the decode's results exist here (the loads have arrived)
+        P2_TICK(9 + 2 * s2);
+#endif
+        // (rank atomics issued unconditionally — a trash counter per lane for docs beyond the segment, so that the eight returning LDS
+        // atomics leave back to back instead of one wait each — were built and measured: 27 spilled VGPRs at four workgroups per CU,
+        // 1.04 ms against 0.92 ms per 2 x 10^8 docs on the 40 k-group row, 0.98 ms at three workgroups per CU;
+        // profiles/r05_partition_scatter_experiments.txt)
 #pragma unroll
         for (int j = 0; j < 8; j++) {
           d[0][s2 * 8 + j] = dd[j];
@@ -633,7 +659,16 @@ __device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
           br[s2 * 8 + j] = 0xFFFFFFFFu;
           if ((m8 >> j) & 1u) br[s2 * 8 + j] = (b << 16) | atomicAdd(&S.hist[b], 1u);
         }
+#ifdef PG_P2_TIMING
+        { const uint32_t probe_ = br[s2 * 8] + br[s2 * 8 + 7]; asm volatile("" :: "v"(probe_)); }   // the ranks have returned
+        P2_TICK(10 + 2 * s2);
+#endif
       }
+      // the next round's loads, in flight across the phases below (requested only now: with a buffer re-requested right after its
+      // decode both buffers and the second sub-tile's temporaries were live together — 27 spilled VGPRs, whose reloads are VMEM
+      // operations that make every wait a vmcnt(0))
+      p2o_issue<G0WIDE, OSK>(p, oln, wtn, (kn >> 2) * 2, or0);
+      p2o_issue<G0WIDE, OSK>(p, oln, wtn, (kn >> 2) * 2 + 1, or1);
     }
     // ---- A: tuples of this wavefront's Q quads per lane; histogram + rank in one returning LDS add ---------------------------------
 #pragma unroll
@@ -689,7 +724,9 @@ __device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
       if (STREAM) p2_issue_stream(p, qi, stile_next.base, raw);
       else p2_issue(p, qi, p2_tile_of(g_next, wave, n_wtiles), raw);
     }
+    P2_TICK(0);
     __syncthreads();
+    P2_TICK(1);
     // ---- B: wavefront 0: histogram → offsets; the round's whole lines with their sources and destinations; chunk ids ------------------
     if (wave == 0) {
       uint32_t carry = 0, need = 0;
@@ -742,7 +779,9 @@ __device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
       }
       if (lane == 0) S.ctrl[2] = line_carry;
     }
+    P2_TICK(2);
     __syncthreads();
+    P2_TICK(3);
     // ---- C: tuples to their sorted positions (offsets first, all in flight; then the stores) --------------------------------------------
     {
       uint32_t pos[Q * 4];
@@ -755,7 +794,9 @@ __device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
           for (int pl = 0; pl < T; pl++) S.sorted[(size_t)pl * R + pos[j] + (br[j] & 0xFFFFu)] = d[pl][j];
         }
     }
+    P2_TICK(4);
     __syncthreads();
+    P2_TICK(5);
     // ---- D1: whole lines out: a half wavefront per line (32 tuples = 128 bytes per plane), four lines per step ----------------------------
     {
       const uint32_t n_lines = S.ctrl[2];
@@ -787,7 +828,9 @@ __device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
           }
       }
     }
+    P2_TICK(6);
     __syncthreads();
+    P2_TICK(7);
     // ---- D2: what did not fill a line is the bucket's leftover for the next round (a half wavefront per bucket, four per step) -----------
     {
       const uint32_t li = (uint32_t)lane & 31u, hw = (uint32_t)(wave * 2 + (lane >> 5));
@@ -828,7 +871,12 @@ __device__ __forceinline__ void p2_scatter_body(const PgQueryPlan& p) {
     }
     // no barrier here: the next round's phase A touches only `hist` (reset in B); its barrier orders D2 before the next B
     g = g_next; k0 = k0_next; m = m_next; stile = stile_next;
+    P2_TICK(8);
   }
+#ifdef PG_P2_TIMING
+  __syncthreads();
+  if (t < 13) atomicAdd(reinterpret_cast<unsigned long long*>(p.p2_ctrl + PG_P2_CTRL_TIMING) + t, s_time[t]);
+#endif
   // ---- epilogue: leftover lines padded with PG_RADIX_INVALID_KEY, the last chunk of every stream recorded with its true fill --------
   __syncthreads();
   if (wave == 0) {
@@ -882,14 +930,14 @@ P2_SCATTER(pg_p2_scatter_1f_key, 1, 4, true, 0)   // key only (COUNT over a big 
 P2_SCATTER(pg_p2_scatter_1f_hll, 1, 4, true, 1)   // config 5
 P2_SCATTER(pg_p2_scatter_stream, 1, 4, true, 3)   // the survivors of the pruned-offer passes (pg_oct_p)
 // oct-layout phase A (plans without a filter pass, PgQueryPlan::p2_oct_a): [first group column <= 8 / <= 24 bits] x [no source, raw INT, dictIds]
-#define P2_SCATTER_OCT(NAME, G0WIDE, OSK) \
-  extern "C" __global__ void __launch_bounds__(P2_THREADS, 4) NAME(const PgQueryPlan p) { p2_scatter_body<1, 4, false, 2, 1, G0WIDE, OSK>(p); }
-P2_SCATTER_OCT(pg_p2_scatter_o_key, false, 0)
-P2_SCATTER_OCT(pg_p2_scatter_o_raw, false, 1)
-P2_SCATTER_OCT(pg_p2_scatter_o_dict, false, 2)
-P2_SCATTER_OCT(pg_p2_scatter_ow_key, true, 0)
-P2_SCATTER_OCT(pg_p2_scatter_ow_raw, true, 1)
-P2_SCATTER_OCT(pg_p2_scatter_ow_dict, true, 2)
+#define P2_SCATTER_OCT(NAME, G0WIDE, OSK, WGS) \
+  extern "C" __global__ void __launch_bounds__(P2_THREADS, WGS) NAME(const PgQueryPlan p) { p2_scatter_body<1, 4, false, 2, 1, G0WIDE, OSK>(p); }
+P2_SCATTER_OCT(pg_p2_scatter_o_key, false, 0, 4)
+P2_SCATTER_OCT(pg_p2_scatter_o_raw, false, 1, 4)
+P2_SCATTER_OCT(pg_p2_scatter_o_dict, false, 2, 4)
+P2_SCATTER_OCT(pg_p2_scatter_ow_key, true, 0, 4)
+P2_SCATTER_OCT(pg_p2_scatter_ow_raw, true, 1, 4)
+P2_SCATTER_OCT(pg_p2_scatter_ow_dict, true, 2, 4)
 extern "C" const int pg_p2_round_quads[5] = {0, 4, 4, 2, 2};   // Q per plane count (the host sizes the LDS with it)
 
 // ---- chunk index: the chunk records grouped by bucket (counting sort of p2_meta), three small launches ------------------------------
@@ -1121,6 +1169,8 @@ __device__ __forceinline__ void p2_aggregate_body(const PgQueryPlan& p) {
       __syncthreads();
       // two chunks per wavefront in flight, NO register rotation (a copy c0 = c1 reads the younger load's target: the compiler then
       // waits for every load in flight); the loop is unrolled by two, each half consuming one buffer while the other travels
+      // (three chunks per wavefront in flight instead of two were measured for the lean consumer: no change — 318 us against 317 us on the
+      // 40 k-group row, profiles/r05_partition_scatter_experiments.txt)
       u32x4 c0[T], c1[T];
       bool on0 = p2_fetch<T>(tuples, plane_stride, list, n_list, (uint32_t)wave, lane, c0), on1 = false;
       for (uint32_t ci = (uint32_t)wave; ci < n_list; ci += 2u * WAVES) {
