@@ -497,6 +497,18 @@ struct HostTable {
   std::vector<int64_t> hash_keys;        // PG_AGG_RADIX_HASH: raw key of every group of the compact table
   int64_t full_scan_entries = 0;
   int64_t total_docs = 0;
+  // numGroupsLimit decided by a prefix pass (execute_limit_by_prefix): the first matching docId of every group that occurs in the prefix
+  // (INT64_MAX elsewhere) and the limit itself — the plan that filled `table` carries neither
+  const int64_t* admit_first = nullptr;
+  int32_t admit_limit = 0;
+};
+// What execute_query_impl does beside the plain query: stop after `doc_limit` docs of the doc space; hand the raw table over instead of
+// assembling groups; trim to numGroupsLimit by another pass's first docIds.
+struct LimitAdmission { const int64_t* first; int32_t limit; };
+struct ExecOptions {
+  int64_t doc_limit = 0;
+  HostTable* raw_out = nullptr;
+  const LimitAdmission* admit = nullptr;
 };
 static void assemble_result(Result& res_out, const CompiledPlan& P, int32_t n_group_by, int32_t n_aggregations, HostTable& H);
 static void hll_small_range_table(int log2m, std::vector<long long>& t, double& alpha_mm);
@@ -791,7 +803,71 @@ void fill_result_schema(Segment& seg, const pg_query& q, Result& r) {
     }
   }
 
+static std::unique_ptr<Result> execute_query_impl(Segment& seg, const pg_query& q, const CancelToken* cancel, const ExecOptions& opt);
+
+// numGroupsLimit without a docId per tuple.  The reference admits groups in docId order until `limit` exist
+// (DictionaryBasedGroupKeyGenerator.java:416-446); equivalent: keep the `limit` groups whose FIRST matching docId is smallest.  Plans
+// whose key space exceeds the limit therefore carry a MIN(docId) accumulator — in the partition pipeline a second plane that doubles
+// every tuple (COUNT over 10^6 groups: 1.50 ms per 2 x 10^8 docs against 0.80 ms with the limit raised, profiles/r04_ab_*).  But only the
+// groups' ORDER of first appearance matters, and the first `limit` groups all appear early: run the MIN(docId) plan (COUNT(*) only) over
+// a doc PREFIX; if it holds >= limit groups, every group outside it starts later than all of them, so the prefix's first docIds decide
+// the admission exactly — and the whole segment is then aggregated by the plan WITHOUT the accumulator (one-plane tuples), its table
+// trimmed by the prefix's order.  A prefix with fewer groups is grown 8 x; past a quarter of the segment the one-pass plan runs.
+static std::unique_ptr<Result> execute_limit_by_prefix(Segment& seg, const pg_query& q, const CompiledPlan& P, const CancelToken* cancel) {
+  const int32_t limit = P.num_groups_limit;
+  const int64_t G = P.dev.n_groups;
+  pg_query qm = q;
+  qm.num_groups_limit = INT32_MAX;
+  auto pm = get_plan(seg, qm.filter, &qm);
+  if (pm->first_doc_op >= 0 || pm->dev.agg_mode != PG_AGG_RADIX || !pm->dev.p2 || (int64_t)pm->dev.n_groups != G || pm->non_scan_based) return nullptr;
+  pg_agg_spec count_star;
+  memset(&count_star, 0, sizeof(count_star));
+  count_star.function = PG_AGG_COUNT;
+  count_star.column = "*";
+  pg_query qp = q;
+  qp.aggregations = &count_star;
+  qp.n_aggregations = 1;
+  qp.flags &= PG_QUERY_FLAG_PROFILE | PG_QUERY_FLAG_SKIP_STAR_TREE | PG_QUERY_FLAG_APPROX_FILTER_STATS;
+  qp.flags |= PG_QUERY_FLAG_APPROX_FILTER_STATS;   // the prefix's statistics are not the query's
+  auto pp = get_plan(seg, qp.filter, &qp);
+  if (pp->first_doc_op < 0 || pp->dev.agg_mode != PG_AGG_RADIX || !pp->dev.p2 || (int64_t)pp->dev.n_groups != G || pp->space_docs != P.space_docs) return nullptr;
+  const int64_t ident = pg_acc_identity(PG_ACC_MIN, 0);
+  HostTable raw;
+  float prefix_ms = 0;
+  bool decided = false;
+  for (int64_t np = std::max<int64_t>(knobs().limit_prefix_min_docs, 16 * (int64_t)limit); np * 4 <= (int64_t)P.space_docs; np *= 8) {
+    np = (np + PG_WAVE_DOCS - 1) / PG_WAVE_DOCS * PG_WAVE_DOCS;
+    ExecOptions o;
+    o.doc_limit = np;
+    o.raw_out = &raw;
+    auto r = execute_query_impl(seg, qp, cancel, o);
+    prefix_ms += r->stats.device_ms_total;
+    const int64_t* first = raw.table.data() + (size_t)pp->first_doc_op * (size_t)G;
+    int64_t found = 0;
+    for (int64_t g = 0; g < G && found < limit; g++) found += first[g] != ident;
+    if (found >= limit) { decided = true; break; }
+  }
+  if (!decided) return nullptr;
+  LimitAdmission adm{raw.table.data() + (size_t)pp->first_doc_op * (size_t)G, limit};
+  ExecOptions o;
+  o.admit = &adm;
+  auto res = execute_query_impl(seg, qm, cancel, o);
+  res->stats.device_ms_aggregate += prefix_ms;   // the prefix pass is part of the query's device time
+  res->stats.device_ms_total += prefix_ms;
+  return res;
+}
+
 std::unique_ptr<Result> execute_query_plain(Segment& seg, const pg_query& q, const CancelToken* cancel) {
+  if (q.n_group_by > 0 && q.n_aggregations > 0 && q.aggregations && !(q.flags & PG_QUERY_FLAG_KEEP_DEVICE_TABLE) && !knobs().no_limit_prefix) {
+    auto plan = get_plan(seg, q.filter, &q);
+    const CompiledPlan& P = *plan;
+    if (P.first_doc_op >= 0 && P.dev.agg_mode == PG_AGG_RADIX && P.dev.p2 && !P.dev.mv && P.star_tree_index < 0 && !P.non_scan_based)
+      if (auto r = execute_limit_by_prefix(seg, q, P, cancel)) return r;
+  }
+  return execute_query_impl(seg, q, cancel, ExecOptions());
+}
+
+static std::unique_ptr<Result> execute_query_impl(Segment& seg, const pg_query& q, const CancelToken* cancel, const ExecOptions& opt) {
   const double t0 = now_ms();
   if (q.n_aggregations <= 0 || !q.aggregations) fail(PG_ERR_INVALID_ARGUMENT, "query has no aggregation");
   check_cancel(cancel, nullptr);
@@ -846,6 +922,12 @@ std::unique_ptr<Result> execute_query_plain(Segment& seg, const pg_query& q, con
   }
 
   PgQueryPlan D = P.dev;
+  int64_t space_docs = P.space_docs;
+  if (opt.doc_limit > 0 && opt.doc_limit < space_docs) {   // a doc prefix (the partition pipeline honours D.num_docs / D.n_wtiles everywhere)
+    space_docs = opt.doc_limit;
+    D.num_docs = (decltype(D.num_docs))opt.doc_limit;
+    D.n_wtiles = (int32_t)((opt.doc_limit + PG_WAVE_DOCS - 1) / PG_WAVE_DOCS);
+  }
   // small doc spaces with per-doc state merges (PgQueryPlan::tile_split_shift): up to 128 wavefronts share a wave tile
   int split_shift = 0;
   {
@@ -859,7 +941,7 @@ std::unique_ptr<Result> execute_query_plain(Segment& seg, const pg_query& q, con
       bool merges = false;
       for (int x = 0; x < D.n_aux; x++) merges |= D.aux[x].kind == PG_AUX_HLL_BYTES;
       const int max_split = knob >= 0 ? knob : (merges ? 7 : 5);
-      while (split_shift < max_split && ((int64_t)std::max(P.dev.n_wtiles, 1) << (split_shift + 1)) <= 4096) split_shift++;
+      while (split_shift < max_split && ((int64_t)std::max(D.n_wtiles, 1) << (split_shift + 1)) <= 4096) split_shift++;
     }
   }
   // oct-layout kernels (pg_kernels_oct.hip): one 16-wavefront workgroup per CU, no tile splitting
@@ -867,8 +949,8 @@ std::unique_ptr<Result> execute_query_plain(Segment& seg, const pg_query& q, con
   const bool oct_lds = D.oct == 1 && !no_oct, oct_pruned = D.oct == 2 && (!no_oct || D.p2_byte_regs) && D.agg_mode == PG_AGG_RADIX && D.p2;
   if (oct_lds) split_shift = 0;
   D.tile_split_shift = split_shift;
-  LaunchShape shape = launch_shape(P, P.dev.n_wtiles << split_shift, D.agg_mode);
-  if (oct_lds) shape = {std::max(1, std::min((P.dev.n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, num_cus())), PG_BLOCK, (D.oct_dword ? (size_t)D.aux[0].lds_offset + (size_t)D.aux[0].rep_bytes * 4 : P.lds_bytes) + 64};
+  LaunchShape shape = launch_shape(P, D.n_wtiles << split_shift, D.agg_mode);
+  if (oct_lds) shape = {std::max(1, std::min((D.n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, num_cus())), PG_BLOCK, (D.oct_dword ? (size_t)D.aux[0].lds_offset + (size_t)D.aux[0].rep_bytes * 4 : P.lds_bytes) + 64};
   const int64_t n_out = (int64_t)D.n_ops * D.n_groups;
   // The stats counters are zero on entry: the reduce kernel of the previous query on this stream re-zeroes them after
   // moving them behind the result table (one device→host copy per query).
@@ -919,7 +1001,7 @@ std::unique_ptr<Result> execute_query_plain(Segment& seg, const pg_query& q, con
   // MBs of auxiliary state (HyperLogLog registers of thousands of groups) land in a pooled page-locked block the result keeps
   // PG_QUERY_FLAG_FINAL_DISTINCT: the states stay in HBM, one final value per group and aggregation comes back (pg_aux_finish_kernel)
   bool final_distinct = (q.flags & PG_QUERY_FLAG_FINAL_DISTINCT) != 0 && D.n_aux > 0 && !(q.flags & PG_QUERY_FLAG_KEEP_DEVICE_TABLE) &&
-                        D.agg_mode != PG_AGG_RADIX_HASH && P.space_docs > 0;
+                        D.agg_mode != PG_AGG_RADIX_HASH && space_docs > 0;
   for (int x = 0; x < D.n_aux; x++) final_distinct = final_distinct && D.aux[x].n_rep == 1;
   const size_t summary_bytes = final_distinct ? (size_t)D.n_aux * (size_t)std::max(D.n_groups, 1) * 8 : 0;
   const size_t host_aux_bytes = final_distinct ? summary_bytes : aux_total;
@@ -929,7 +1011,7 @@ std::unique_ptr<Result> execute_query_plain(Segment& seg, const pg_query& q, con
   uint8_t* aux_host = reinterpret_cast<uint8_t*>(host_out) + out_bytes;
   if (profile) PG_HIP(hipEventRecord(ctx.ev[0], ctx.stream));
   const char* kname = "";
-  const bool has_docs = P.space_docs > 0;   // docs of the doc space the plan runs on (the segment's or a star-tree's)
+  const bool has_docs = space_docs > 0;   // docs of the doc space the plan runs on (the segment's or a star-tree's)
   const bool hashed = D.agg_mode == PG_AGG_RADIX_HASH;
   const bool keep_table = (q.flags & PG_QUERY_FLAG_KEEP_DEVICE_TABLE) != 0;
   // (a multi-value plan carries no first-docId accumulator: a key space that CAN exceed numGroupsLimit would be trimmed per segment by
@@ -951,7 +1033,7 @@ std::unique_ptr<Result> execute_query_plain(Segment& seg, const pg_query& q, con
     //      bit-packed tuples; per-bucket LDS aggregation; merge of the slices ------------------------------------------------------------
     kname = "pg_part_group_by";
     p2_ran = true;
-    unsigned long long matched_now = (unsigned long long)P.space_docs;
+    unsigned long long matched_now = (unsigned long long)space_docs;
     D.match_words = nullptr;
     if (!P.match_all) {
       const size_t n_words = (size_t)D.n_wtiles * 64;
@@ -1338,6 +1420,19 @@ std::unique_ptr<Result> execute_query_plain(Segment& seg, const pg_query& q, con
   H.hash_keys = std::move(hash_keys_host);
   H.full_scan_entries = P.full_scan_entries;
   H.total_docs = seg.total_docs;
+  if (opt.admit) { H.admit_first = opt.admit->first; H.admit_limit = opt.admit->limit; }
+  if (opt.raw_out) {   // the caller wants the table, not groups (execute_limit_by_prefix)
+    if (profile) {
+      float a = 0, b = 0;
+      PG_HIP(hipEventElapsedTime(&a, ctx.ev[0], ctx.ev[1]));
+      PG_HIP(hipEventElapsedTime(&b, ctx.ev[1], ctx.ev[2]));
+      res->stats.device_ms_aggregate = a;
+      res->stats.device_ms_reduce = b;
+      res->stats.device_ms_total = a + b;
+    }
+    *opt.raw_out = std::move(H);
+    return res;
+  }
   int64_t exact_entries = -1;
   // exact numEntriesScannedInFilter of leapfrogged shapes: by default up to 2^22 docs (one filter launch + one bitmap copy + a host walk per
   // leaf: milliseconds there, a multiple of the query on a 10^9-doc segment), on request at any size
@@ -1435,15 +1530,16 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
     gids.reserve((size_t)std::min<int64_t>(G, 1 << 20));
     for (int64_t g = 0; g < G; g++) if (exists(g)) gids.push_back(g);
   }
-  bool limit_reached = n_group_by > 0 && (int64_t)gids.size() >= (int64_t)P.num_groups_limit;
-  if (n_group_by > 0 && (int64_t)gids.size() > (int64_t)P.num_groups_limit) {
+  const int64_t groups_limit = H.admit_first ? (int64_t)H.admit_limit : (int64_t)P.num_groups_limit;
+  bool limit_reached = n_group_by > 0 && (int64_t)gids.size() >= groups_limit;
+  if (n_group_by > 0 && (int64_t)gids.size() > groups_limit) {
     // keep the numGroupsLimit groups whose first matching docId is smallest (= the keys the reference admits in docId order)
     if (P.dev.mv)   // which keys the reference admits depends on the entry order inside the docs: left to the Java plan
       fail(PG_ERR_UNSUPPORTED, "multi-value group-by found %zu groups, more than numGroupsLimit (%d)", gids.size(), P.num_groups_limit);
-    if (P.first_doc_op < 0) fail(PG_ERR_INTERNAL, "plan lacks the first-docId accumulator");
-    const int64_t* first = table.data() + (size_t)P.first_doc_op * G;
-    std::nth_element(gids.begin(), gids.begin() + P.num_groups_limit, gids.end(), [&](int64_t a, int64_t b) { return first[a] < first[b]; });
-    gids.resize((size_t)P.num_groups_limit);
+    if (P.first_doc_op < 0 && !H.admit_first) fail(PG_ERR_INTERNAL, "plan lacks the first-docId accumulator");
+    const int64_t* first = H.admit_first ? H.admit_first : table.data() + (size_t)P.first_doc_op * G;
+    std::nth_element(gids.begin(), gids.begin() + groups_limit, gids.end(), [&](int64_t a, int64_t b) { return first[a] < first[b]; });
+    gids.resize((size_t)groups_limit);
     std::sort(gids.begin(), gids.end());
   }
   const int32_t ng = (int32_t)gids.size();

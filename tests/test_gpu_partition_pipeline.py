@@ -239,3 +239,38 @@ def test_oct_scatter_shapes_and_the_quad_kernels_agree(gpu_api, oracle_api, gpu_
         assert run(g, o, q, limit).rows() == rows, q
     g.destroy()
     o.destroy()
+
+
+# ---- numGroupsLimit by a prefix pass (round 5, pg_exec.hip execute_limit_by_prefix): the first `limit` groups in docId order are decided
+#      on a doc prefix, the segment is aggregated without the docId plane.  Reference: DictionaryBasedGroupKeyGenerator.java:416-446 ------
+def _limit_cases(rng, n):
+    uniform = rng.integers(0, 200_000, n).astype(np.int32)
+    slow = (np.arange(n) // 7).astype(np.int32) % 200_000          # groups appear one every 7 docs: the first prefixes hold too few
+    late = np.where(np.arange(n) < n // 2, rng.integers(0, 50, n), rng.integers(0, 200_000, n)).astype(np.int32)   # 50 groups, then the flood
+    return {"uniform": uniform, "slow": slow, "late": late}
+
+
+@pytest.mark.parametrize("pattern", ["uniform", "slow", "late"])
+@pytest.mark.parametrize("limit", [100, 5000])
+def test_limit_by_prefix(gpu_api, oracle_api, gpu_knobs, pattern, limit):
+    """The prefix (4 096 docs at first here, grown 8 x while it holds fewer than `limit` groups, abandoned past a quarter of the segment)
+    decides the admitted groups; same rows, same numGroupsLimitReached as the oracle and as the one-pass plan (PG_NO_LIMIT_PREFIX)."""
+    rng = np.random.default_rng(11)
+    n = 600_011
+    k = _limit_cases(rng, n)[pattern]
+    k[-200_000:] = np.maximum(k[-200_000:], np.arange(200_000, dtype=np.int32) * (pattern != "slow"))   # the dictionary holds 200 000 keys
+    v = rng.integers(0, 1 << 20, n).astype(np.int32)
+    r = rng.integers(0, 1000, n).astype(np.int32)
+    host = build_segment("lim", {"k": k, "v": v, "r": r}, {"k": "INT", "v": "INT", "r": "INT"}, no_dictionary_columns=["v", "r"])
+    gpu_knobs(PG_LIMIT_PREFIX_MIN_DOCS="4096")
+    g, o = both(gpu_api, oracle_api, host)
+    qs = ["SELECT k, COUNT(*), SUM(v), MAX(v) FROM lim GROUP BY k LIMIT 1000000",
+          "SELECT k, SUM(v) FROM lim WHERE r < 400 GROUP BY k LIMIT 1000000"]
+    rows = [run(g, o, q, limit=limit).rows() for q in qs]
+    g.destroy()
+    gpu_knobs(PG_NO_LIMIT_PREFIX="1")
+    g = NativeSegment(gpu_api, host)
+    for q, want in zip(qs, rows):
+        assert run(g, o, q, limit=limit).rows() == want
+    g.destroy()
+    o.destroy()
