@@ -819,7 +819,11 @@ static std::unique_ptr<Result> execute_limit_by_prefix(Segment& seg, const pg_qu
   pg_query qm = q;
   qm.num_groups_limit = INT32_MAX;
   auto pm = get_plan(seg, qm.filter, &qm);
-  if (pm->first_doc_op >= 0 || pm->dev.agg_mode != PG_AGG_RADIX || !pm->dev.p2 || (int64_t)pm->dev.n_groups != G || pm->non_scan_based) return nullptr;
+  const bool trace = knobs().trace_host;
+  if (pm->first_doc_op >= 0 || pm->dev.agg_mode != PG_AGG_RADIX || !pm->dev.p2 || (int64_t)pm->dev.n_groups != G || pm->non_scan_based) {
+    if (trace) fprintf(stderr, "[pg] limit by prefix: the plan without the limit is not a partition-pipeline plan (mode %d, p2 %d)\n", pm->dev.agg_mode, pm->dev.p2);
+    return nullptr;
+  }
   pg_agg_spec count_star;
   memset(&count_star, 0, sizeof(count_star));
   count_star.function = PG_AGG_COUNT;
@@ -830,7 +834,10 @@ static std::unique_ptr<Result> execute_limit_by_prefix(Segment& seg, const pg_qu
   qp.flags &= PG_QUERY_FLAG_PROFILE | PG_QUERY_FLAG_SKIP_STAR_TREE | PG_QUERY_FLAG_APPROX_FILTER_STATS;
   qp.flags |= PG_QUERY_FLAG_APPROX_FILTER_STATS;   // the prefix's statistics are not the query's
   auto pp = get_plan(seg, qp.filter, &qp);
-  if (pp->first_doc_op < 0 || pp->dev.agg_mode != PG_AGG_RADIX || !pp->dev.p2 || (int64_t)pp->dev.n_groups != G || pp->space_docs != P.space_docs) return nullptr;
+  if (pp->first_doc_op < 0 || pp->dev.agg_mode != PG_AGG_RADIX || !pp->dev.p2 || (int64_t)pp->dev.n_groups != G || pp->space_docs != P.space_docs) {
+    if (trace) fprintf(stderr, "[pg] limit by prefix: the prefix plan is not a partition-pipeline plan (mode %d, p2 %d, first-doc op %d)\n", pp->dev.agg_mode, pp->dev.p2, pp->first_doc_op);
+    return nullptr;
+  }
   const int64_t ident = pg_acc_identity(PG_ACC_MIN, 0);
   HostTable raw;
   float prefix_ms = 0;
@@ -845,6 +852,7 @@ static std::unique_ptr<Result> execute_limit_by_prefix(Segment& seg, const pg_qu
     const int64_t* first = raw.table.data() + (size_t)pp->first_doc_op * (size_t)G;
     int64_t found = 0;
     for (int64_t g = 0; g < G && found < limit; g++) found += first[g] != ident;
+    if (trace) fprintf(stderr, "[pg] limit by prefix: %lld docs hold %s%lld groups (limit %d)\n", (long long)np, found >= limit ? ">= " : "", (long long)found, limit);
     if (found >= limit) { decided = true; break; }
   }
   if (!decided) return nullptr;
@@ -854,6 +862,7 @@ static std::unique_ptr<Result> execute_limit_by_prefix(Segment& seg, const pg_qu
   auto res = execute_query_impl(seg, qm, cancel, o);
   res->stats.device_ms_aggregate += prefix_ms;   // the prefix pass is part of the query's device time
   res->stats.device_ms_total += prefix_ms;
+  snprintf(res->stats.kernel, sizeof(res->stats.kernel), "pg_part_group_by_prefix");
   return res;
 }
 

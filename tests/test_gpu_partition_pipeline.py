@@ -256,7 +256,7 @@ def test_limit_by_prefix(gpu_api, oracle_api, gpu_knobs, pattern, limit):
     """The prefix (4 096 docs at first here, grown 8 x while it holds fewer than `limit` groups, abandoned past a quarter of the segment)
     decides the admitted groups; same rows, same numGroupsLimitReached as the oracle and as the one-pass plan (PG_NO_LIMIT_PREFIX)."""
     rng = np.random.default_rng(11)
-    n = 600_011
+    n = 1_200_011
     k = _limit_cases(rng, n)[pattern]
     k[-200_000:] = np.maximum(k[-200_000:], np.arange(200_000, dtype=np.int32) * (pattern != "slow"))   # the dictionary holds 200 000 keys
     v = rng.integers(0, 1 << 20, n).astype(np.int32)
@@ -266,11 +266,13 @@ def test_limit_by_prefix(gpu_api, oracle_api, gpu_knobs, pattern, limit):
     g, o = both(gpu_api, oracle_api, host)
     qs = ["SELECT k, COUNT(*), SUM(v), MAX(v) FROM lim GROUP BY k LIMIT 1000000",
           "SELECT k, SUM(v) FROM lim WHERE r < 400 GROUP BY k LIMIT 1000000"]
-    rows = [run(g, o, q, limit=limit).rows() for q in qs]
+    # "late": 50 groups in the first half of the segment — no prefix up to a quarter of it holds `limit` groups: the one-pass plan answers
+    expect = "pg_part_group_by" if pattern == "late" else "pg_part_group_by_prefix"
+    rows = [run(g, o, q, limit=limit, kernel=expect).rows() for q in qs]
     g.destroy()
     gpu_knobs(PG_NO_LIMIT_PREFIX="1")
     g = NativeSegment(gpu_api, host)
     for q, want in zip(qs, rows):
-        assert run(g, o, q, limit=limit).rows() == want
+        assert run(g, o, q, limit=limit, kernel="pg_part_group_by").rows() == want
     g.destroy()
     o.destroy()
