@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PG_ABI_VERSION 3
+#define PG_ABI_VERSION 4
 
 typedef enum pg_status {
   PG_OK = 0,
@@ -182,6 +182,22 @@ typedef struct pg_agg_spec {
   const char* column;     /* NULL or "*" for COUNT(*) */
 } pg_agg_spec;
 
+/* One ORDER BY expression of a group-by query, as TableResizer resolves it (pinot-core/.../core/data/table/TableResizer.java:129-161):
+ * a group-by expression (GroupByExpressionExtractor: the key's VALUE) or an aggregation (AggregationFunctionExtractor: the function's
+ * FINAL result — COUNT a long, SUM / MIN / MAX / AVG / MINMAXRANGE a double, DISTINCTCOUNT the set's size, DISTINCTCOUNTHLL the
+ * cardinality).  Post-aggregation expressions (SUM(a) + SUM(b)) and literals are not carried: such queries leave n_order_by = 0 and are
+ * simply not trimmed per segment (trimming only ever DROPS groups the broker would drop anyway). */
+typedef enum pg_order_by_kind {
+  PG_ORDER_BY_GROUP_KEY = 0,     /* index: position in group_by_columns */
+  PG_ORDER_BY_AGGREGATION = 1    /* index: position in aggregations */
+} pg_order_by_kind;
+typedef struct pg_order_by {
+  int32_t kind;        /* pg_order_by_kind */
+  int32_t index;
+  int32_t ascending;   /* OrderByExpressionContext#isAsc */
+  int32_t nulls_last;  /* OrderByExpressionContext#isNullsLast (read under PG_QUERY_FLAG_NULL_HANDLING only) */
+} pg_order_by;
+
 typedef struct pg_query {
   const pg_filter_node* filter;          /* NULL => MatchAllFilterOperator */
   int32_t n_group_by;                    /* 0 => AggregationOperator (no GROUP BY) */
@@ -192,7 +208,16 @@ typedef struct pg_query {
   int32_t num_groups_limit;                     /* DEFAULT_NUM_GROUPS_LIMIT = 100 000 */
   int32_t max_initial_result_holder_capacity;   /* DEFAULT_MAX_INITIAL_RESULT_HOLDER_CAPACITY = 10 000 */
   int32_t flags;                                /* PG_QUERY_* */
-  int32_t reserved0;
+  /* Segment-level group trim (GroupByOperator.java:120-133, ABI 4): when the query has ORDER BY expressions, min_segment_group_trim_size > 0
+   * (InstancePlanMakerImplV2 "min.segment.group.trim.size" / query option minSegmentGroupTrimSize; the reference's default is -1: off) and
+   * the segment holds more groups than trimSize = max(5 x limit, min_segment_group_trim_size) (GroupByUtils.getTableCapacity :45-57), only
+   * the trimSize groups that sort first under the ORDER BY come back (TableResizer#trimInSegmentResults :327-351; which of several
+   * groups TIED at the cut survive is unspecified there — a heap — and here).  numGroupsLimitReached is decided before the trim.
+   * Dense key spaces without DISTINCTCOUNT / HLL state select the survivors on the device: only they cross PCIe. */
+  int32_t n_order_by;                           /* 0 => no ORDER BY (no trim) */
+  const pg_order_by* order_by;
+  int32_t limit;                                /* QueryContext#getLimit (read with n_order_by > 0 only) */
+  int32_t min_segment_group_trim_size;          /* <= 0: the segment's groups are never trimmed */
 } pg_query;
 
 #define PG_QUERY_FLAG_PROFILE 0x1          /* record per-kernel HIP-event timings into pg_exec_stats */

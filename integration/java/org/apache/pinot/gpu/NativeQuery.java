@@ -11,8 +11,11 @@ import java.nio.ByteBuffer;
 import java.nio.ByteOrder;
 import java.nio.charset.StandardCharsets;
 import java.util.List;
+import org.apache.commons.lang3.tuple.Pair;
 import org.apache.pinot.common.request.context.ExpressionContext;
 import org.apache.pinot.common.request.context.FilterContext;
+import org.apache.pinot.common.request.context.FunctionContext;
+import org.apache.pinot.common.request.context.OrderByExpressionContext;
 import org.apache.pinot.common.request.context.predicate.EqPredicate;
 import org.apache.pinot.common.request.context.predicate.InPredicate;
 import org.apache.pinot.common.request.context.predicate.NotEqPredicate;
@@ -24,7 +27,7 @@ import org.apache.pinot.core.query.aggregation.function.DistinctCountHLLAggregat
 import org.apache.pinot.core.query.request.context.QueryContext;
 
 public final class NativeQuery implements AutoCloseable {
-  private static final int MAGIC = 0x31514750;
+  private static final int MAGIC = 0x32514750;   // "PGQ2": + ORDER BY block, LIMIT, minSegmentGroupTrimSize
   // pg_filter_type / pg_predicate_type / pg_agg_function
   private static final int F_AND = 0, F_OR = 1, F_NOT = 2, F_PREDICATE = 3, F_TRUE = 4, F_FALSE = 5;
   private static final int P_EQ = 0, P_NOT_EQ = 1, P_IN = 2, P_NOT_IN = 3, P_RANGE = 4, P_IS_NULL = 5, P_IS_NOT_NULL = 6;
@@ -60,9 +63,14 @@ public final class NativeQuery implements AutoCloseable {
     if (aggs == null || aggs.length == 0) {
       return null;
     }
+    // Segment-level group trim (GroupByOperator.java:120-133): the ORDER BY expressions as TableResizer resolves them (TableResizer.java:
+    // 129-161) — a group-by expression or an aggregation of the query.  Anything else (post-aggregations, literals, filtered aggregations)
+    // leaves the block empty: the segment's groups then come back untrimmed, which only keeps groups the broker would drop anyway.
+    int[] orderBy = groupBy == null ? null : orderBy(q, groupBy);
     b.putInt(MAGIC).putInt((q.isSkipStarTree() ? FLAG_SKIP_STAR_TREE : 0) | (q.isNullHandlingEnabled() ? FLAG_NULL_HANDLING : 0) | extraFlags).putInt(q.getNumGroupsLimit())
         .putInt(q.getMaxInitialResultHolderCapacity()).putInt(groupBy == null ? 0 : groupBy.size()).putInt(aggs.length)
-        .putInt(q.getFilter() == null ? 0 : 1).putInt(0);
+        .putInt(q.getFilter() == null ? 0 : 1).putInt(orderBy == null ? 0 : orderBy.length / 4);
+    b.putInt(q.getLimit()).putInt(orderBy == null ? -1 : q.getMinSegmentGroupTrimSize());
     if (groupBy != null) {
       for (ExpressionContext e : groupBy) {
         if (e.getType() != ExpressionContext.Type.IDENTIFIER) {
@@ -80,10 +88,49 @@ public final class NativeQuery implements AutoCloseable {
       b.putInt(fn).putInt(0);   // log2m 0: DEFAULT_HYPERLOGLOG_LOG2M (a literal second argument is not expressible here)
       putString(b, args.isEmpty() ? "*" : args.get(0).getIdentifier());
     }
+    if (orderBy != null) {
+      for (int v : orderBy) {
+        b.putInt(v);
+      }
+    }
     if (q.getFilter() != null && !putFilter(b, q.getFilter())) {
       return null;
     }
     return new NativeQuery(PinotGpu.queryParse(b, b.position()));
+  }
+
+  /** {kind, index, ascending, nullsLast} per ORDER BY expression (pg_order_by), or null when the query has none or one the record cannot carry. */
+  private static int[] orderBy(QueryContext q, List<ExpressionContext> groupBy) {
+    List<OrderByExpressionContext> orderBy = q.getOrderByExpressions();
+    if (orderBy == null || orderBy.isEmpty() || q.getMinSegmentGroupTrimSize() <= 0) {
+      return null;
+    }
+    int[] out = new int[4 * orderBy.size()];
+    for (int i = 0; i < orderBy.size(); i++) {
+      OrderByExpressionContext o = orderBy.get(i);
+      ExpressionContext e = o.getExpression();
+      int kind;
+      int index = groupBy.indexOf(e);
+      if (index >= 0) {
+        kind = 0;   // PG_ORDER_BY_GROUP_KEY
+      } else {
+        FunctionContext f = e.getFunction();
+        if (f == null || f.getType() != FunctionContext.Type.AGGREGATION) {
+          return null;
+        }
+        Integer a = q.getFilteredAggregationsIndexMap().get(Pair.of(f, null));
+        if (a == null) {
+          return null;
+        }
+        kind = 1;   // PG_ORDER_BY_AGGREGATION
+        index = a;
+      }
+      out[4 * i] = kind;
+      out[4 * i + 1] = index;
+      out[4 * i + 2] = o.isAsc() ? 1 : 0;
+      out[4 * i + 3] = o.isNullsLast() ? 1 : 0;
+    }
+    return out;
   }
 
   /** pg_agg_function of a star-tree function-column pair's function type; -1 for functions the GPU path never reads. */

@@ -114,6 +114,7 @@ static void build_record(record* r, int32_t flags) {
   r->n = 0;
   w_i32(r, PGSHIM_QUERY_MAGIC); w_i32(r, flags); w_i32(r, 0); w_i32(r, 0);
   w_i32(r, 1); w_i32(r, 3); w_i32(r, 1); w_i32(r, 0);
+  w_i32(r, 10); w_i32(r, -1);   /* limit, minSegmentGroupTrimSize (off) */
   w_str(r, "d");
   w_i32(r, PG_AGG_COUNT); w_i32(r, 0); w_str(r, "*");
   w_i32(r, PG_AGG_SUM); w_i32(r, 0); w_str(r, "m");
@@ -266,6 +267,7 @@ int main(void) {
     rs.n = 0;
     w_i32(&rs, PGSHIM_QUERY_MAGIC); w_i32(&rs, 0); w_i32(&rs, 0); w_i32(&rs, 0);
     w_i32(&rs, 1); w_i32(&rs, 1); w_i32(&rs, 0); w_i32(&rs, 0);
+    w_i32(&rs, 10); w_i32(&rs, -1);
     w_str(&rs, "s");
     w_i32(&rs, PG_AGG_COUNT); w_i32(&rs, 0); w_str(&rs, "*");
     const jlong qs = Java_org_apache_pinot_gpu_PinotGpu_queryParse(env, cls, new_direct_buffer(rs.b), (jint)rs.n);

@@ -39,15 +39,19 @@ static void w_predicate(record* r, int predicate_type, const char* column, int n
   for (int i = 0; i < n_values; i++) w_str(r, values[i]);
   w_str(r, lower); w_str(r, upper); w_i32(r, lower_inclusive); w_i32(r, upper_inclusive);
 }
-/* SELECT d, COUNT(*), SUM(m), MAX(m) FROM t WHERE d IN (20, 30) AND m BETWEEN 100 AND 2999 GROUP BY d */
+/* SELECT d, COUNT(*), SUM(m), MAX(m) FROM t WHERE d IN (20, 30) AND m BETWEEN 100 AND 2999 GROUP BY d ORDER BY SUM(m) DESC, d LIMIT 7
+ * with minSegmentGroupTrimSize 3 (the order-by block of PGQ2: segment-level group trim) */
 static void build_record(record* r) {
   r->n = 0;
   w_i32(r, PGSHIM_QUERY_MAGIC); w_i32(r, 0); w_i32(r, 0); w_i32(r, 0);
-  w_i32(r, 1); w_i32(r, 3); w_i32(r, 1); w_i32(r, 0);
+  w_i32(r, 1); w_i32(r, 3); w_i32(r, 1); w_i32(r, 2);
+  w_i32(r, 7); w_i32(r, 3);
   w_str(r, "d");
   w_i32(r, PG_AGG_COUNT); w_i32(r, 0); w_str(r, "*");
   w_i32(r, PG_AGG_SUM); w_i32(r, 0); w_str(r, "m");
   w_i32(r, PG_AGG_MAX); w_i32(r, 0); w_str(r, "m");
+  w_i32(r, PG_ORDER_BY_AGGREGATION); w_i32(r, 1); w_i32(r, 0); w_i32(r, 0);
+  w_i32(r, PG_ORDER_BY_GROUP_KEY); w_i32(r, 0); w_i32(r, 1); w_i32(r, 1);
   w_i32(r, PG_FILTER_AND); w_i32(r, 2);
   const char* in_values[2] = {"20", "30"};
   w_predicate(r, PG_PRED_IN, "d", 2, in_values, NULL, NULL, 0, 0);
@@ -70,7 +74,9 @@ int main(void) {
   char err[256];
   if (pgshim_query_parse(rec.b, rec.n, &nq, err, sizeof err) != PG_OK) { fprintf(stderr, "parse: %s\n", err); return 1; }
   const pg_query* q = pgshim_query_get(nq);
-  int ok = q->n_group_by == 1 && strcmp(q->group_by_columns[0], "d") == 0 && q->n_aggregations == 3 &&
+  int ok = q->n_group_by == 1 && strcmp(q->group_by_columns[0], "d") == 0 && q->n_aggregations == 3 && q->n_order_by == 2 && q->limit == 7 &&
+           q->min_segment_group_trim_size == 3 && q->order_by[0].kind == PG_ORDER_BY_AGGREGATION && q->order_by[0].index == 1 &&
+           q->order_by[0].ascending == 0 && q->order_by[1].kind == PG_ORDER_BY_GROUP_KEY && q->order_by[1].nulls_last == 1 &&
            q->aggregations[1].function == PG_AGG_SUM && strcmp(q->aggregations[1].column, "m") == 0 && q->filter &&
            q->filter->type == PG_FILTER_AND && q->filter->n_children == 2 && q->filter->children[0].predicate_type == PG_PRED_IN &&
            q->filter->children[0].n_values == 2 && strcmp(q->filter->children[0].values[1], "30") == 0 &&

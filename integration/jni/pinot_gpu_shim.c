@@ -82,7 +82,7 @@ static void rd_node(reader* r, pg_filter_node* node, int depth) {
 
 int32_t pgshim_query_parse(const void* record, uint64_t size, pgshim_query** out_query, char* err, size_t err_cap) {
   if (err && err_cap) err[0] = 0;
-  if (!record || !out_query || size < 32) {
+  if (!record || !out_query || size < 40) {
     if (err && err_cap) snprintf(err, err_cap, "NativeQuery record: null or shorter than its header");
     return PG_ERR_INVALID_ARGUMENT;
   }
@@ -100,8 +100,11 @@ int32_t pgshim_query_parse(const void* record, uint64_t size, pgshim_query** out
   q->q.n_group_by = rd_i32(&r);
   q->q.n_aggregations = rd_i32(&r);
   const int32_t has_filter = rd_i32(&r);
-  (void)rd_i32(&r);
-  if (!r.failed && (q->q.n_group_by < 0 || q->q.n_group_by > 64 || q->q.n_aggregations < 0 || q->q.n_aggregations > 256)) fail(&r, "bad counts");
+  q->q.n_order_by = rd_i32(&r);
+  q->q.limit = rd_i32(&r);
+  q->q.min_segment_group_trim_size = rd_i32(&r);
+  if (!r.failed && (q->q.n_group_by < 0 || q->q.n_group_by > 64 || q->q.n_aggregations < 0 || q->q.n_aggregations > 256 || q->q.n_order_by < 0 || q->q.n_order_by > 64))
+    fail(&r, "bad counts");
   if (!r.failed && q->q.n_group_by) {
     const char** g = (const char**)arena_alloc(&r, sizeof(char*) * (size_t)q->q.n_group_by);
     for (int32_t i = 0; g && i < q->q.n_group_by && !r.failed; i++) g[i] = rd_string(&r);
@@ -115,6 +118,19 @@ int32_t pgshim_query_parse(const void* record, uint64_t size, pgshim_query** out
       a[i].column = rd_string(&r);
     }
     q->q.aggregations = a;
+  }
+  if (!r.failed && q->q.n_order_by) {
+    pg_order_by* ob = (pg_order_by*)arena_alloc(&r, sizeof(pg_order_by) * (size_t)q->q.n_order_by);
+    for (int32_t i = 0; ob && i < q->q.n_order_by && !r.failed; i++) {
+      ob[i].kind = rd_i32(&r);
+      ob[i].index = rd_i32(&r);
+      ob[i].ascending = rd_i32(&r);
+      ob[i].nulls_last = rd_i32(&r);
+      if (!r.failed && (ob[i].kind < PG_ORDER_BY_GROUP_KEY || ob[i].kind > PG_ORDER_BY_AGGREGATION || ob[i].index < 0 ||
+                        ob[i].index >= (ob[i].kind == PG_ORDER_BY_GROUP_KEY ? q->q.n_group_by : q->q.n_aggregations)))
+        fail(&r, "bad order-by expression");
+    }
+    q->q.order_by = ob;
   }
   if (!r.failed && has_filter) {
     pg_filter_node* root = (pg_filter_node*)arena_alloc(&r, sizeof(pg_filter_node));

@@ -4,9 +4,12 @@
  * little-endian record; pgshim_query_parse() turns that record into a pg_query (+ pg_filter_node tree, strings) owned by one
  * allocation.  Compiled and tested without a JVM (integration/jni/jni_sequence_test.c); pinot_gpu_jni.c adds the JNIEnv glue.
  *
- * record := int32 magic 0x31514750 ("PGQ1"), int32 flags, int32 numGroupsLimit, int32 maxInitialResultHolderCapacity,
- *           int32 nGroupBy, int32 nAggregations, int32 hasFilter, int32 reserved,
- *           nGroupBy x string, nAggregations x { int32 function, int32 log2m, string column }, [node]
+ * record := int32 magic 0x32514750 ("PGQ2"), int32 flags, int32 numGroupsLimit, int32 maxInitialResultHolderCapacity,
+ *           int32 nGroupBy, int32 nAggregations, int32 hasFilter, int32 nOrderBy,
+ *           int32 limit, int32 minSegmentGroupTrimSize,
+ *           nGroupBy x string, nAggregations x { int32 function, int32 log2m, string column },
+ *           nOrderBy x { int32 kind (pg_order_by_kind), int32 index, int32 ascending, int32 nullsLast }, [node]
+ *           (PGQ1 had neither the order-by block nor limit / minSegmentGroupTrimSize: segment-level group trim, GroupByOperator.java:120-133)
  * node   := int32 type (pg_filter_type), int32 nChildren,
  *           type == PREDICATE: int32 predicateType, int32 nValues, string column, nValues x string, string lower, string upper,
  *                              int32 lowerInclusive, int32 upperInclusive
@@ -24,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PGSHIM_QUERY_MAGIC 0x31514750
+#define PGSHIM_QUERY_MAGIC 0x32514750
 
 typedef struct pgshim_query pgshim_query;
 /* PG_OK or PG_ERR_INVALID_ARGUMENT (message in err, NUL terminated).  The record may be released after the call. */

@@ -4,6 +4,8 @@
  * (same shapes as include/pinot_gpu.h so the parity tests drive both sides with one set of structs).
  * SURVEY.md §8a rows a10, a11, a15–a23.
  */
+#define _GNU_SOURCE   /* qsort_r */
+#include <stdlib.h>
 #include <math.h>
 #include <stdio.h>
 #include <time.h>
@@ -1097,6 +1099,64 @@ static void extract_agg(po_agg_result* r, agg_state* a, int32_t n_groups, const 
 }
 
 /* =====================================================================================================================
+ * segment-level group trim: GroupByOperator.java:120-133 -> GroupByUtils.getTableCapacity (core/util/GroupByUtils.java:45-57) ->
+ * TableResizer#trimInSegmentResults (core/data/table/TableResizer.java:327-351) with the comparator of its constructor (:88-128, without
+ * null handling) over the extractors of :129-161 / :406-445: a group-by expression's VALUE, an aggregation's extractFinalResult.
+ * The reference keeps a heap of `size` records; which records TIED with the last one kept survive depends on the heap — here a stable
+ * sort decides (tests put a unique value at the cut).
+ * ===================================================================================================================== */
+typedef struct order_value { int type; int64_t l; double d; const uint8_t* b; int32_t blen; } order_value;   /* type 0 long / int, 1 double, 2 bytes */
+typedef struct order_ctx { const order_value* v; int n_ob; const int* asc; } order_ctx;
+static int double_compare_java(double a, double b) {   /* Double.compare: -0.0 < 0.0, NaN above everything and equal to itself */
+  if (a < b) return -1;
+  if (a > b) return 1;
+  int64_t x, y;
+  memcpy(&x, &a, 8); memcpy(&y, &b, 8);
+  if (a != a) x = INT64_MAX;   /* doubleToLongBits canonicalises NaN */
+  if (b != b) y = INT64_MAX;
+  return x == y ? 0 : (x < y ? -1 : 1);
+}
+static int order_cmp(const void* pa, const void* pb, void* ctxp) {
+  const order_ctx* c = (const order_ctx*)ctxp;
+  const int32_t ia = *(const int32_t*)pa, ib = *(const int32_t*)pb;
+  for (int k = 0; k < c->n_ob; k++) {
+    const order_value* a = &c->v[(size_t)ia * (size_t)c->n_ob + (size_t)k];
+    const order_value* b = &c->v[(size_t)ib * (size_t)c->n_ob + (size_t)k];
+    int r;
+    if (a->type == 0) r = a->l < b->l ? -1 : (a->l > b->l ? 1 : 0);
+    else if (a->type == 1) r = double_compare_java(a->d, b->d);
+    else {
+      const int32_t n = a->blen < b->blen ? a->blen : b->blen;
+      r = n ? memcmp(a->b, b->b, (size_t)n) : 0;   /* (String.compareTo orders UTF-16 units; equal to this byte order below U+10000) */
+      if (r == 0) r = a->blen < b->blen ? -1 : (a->blen > b->blen ? 1 : 0);
+    }
+    if (r != 0) return c->asc[k] ? r : -r;
+  }
+  return ia < ib ? -1 : (ia > ib ? 1 : 0);   /* stable */
+}
+/* AggregationFunction#extractFinalResult of group `g`: COUNT Long; SUM / MIN / MAX Double; AVG sum / count (AvgAggregationFunction.java:
+ * DEFAULT_FINAL_RESULT -inf for count 0); MINMAXRANGE max - min; DISTINCTCOUNT the set's size (Integer); DISTINCTCOUNTHLL cardinality (Long) */
+static order_value agg_final_value(agg_state* a, int32_t g) {
+  order_value v;
+  memset(&v, 0, sizeof(v));
+  switch (sv_function_of(a->function)) {
+    case PG_AGG_COUNT: v.type = 0; v.l = (int64_t)a->d0[g]; break;
+    case PG_AGG_AVG: v.type = 1; v.d = a->l0[g] == 0 ? -INFINITY : a->d0[g] / (double)a->l0[g]; break;
+    case PG_AGG_MINMAXRANGE: v.type = 1; v.d = a->has[g] ? a->d1[g] - a->d0[g] : -INFINITY - INFINITY; break;
+    case PG_AGG_DISTINCTCOUNT: v.type = 0; v.l = a->dict_bitmaps[g] ? po_bitmap_cardinality(a->dict_bitmaps[g]) : 0; break;
+    case PG_AGG_DISTINCTCOUNTHLL: {
+      v.type = 0;
+      po_hll* h = a->col->has_dictionary ? hll_from_dict_bitmap(a->dict_bitmaps[g], a->col, a->log2m) : (a->hlls[g] ? a->hlls[g] : po_hll_new(a->log2m));
+      v.l = po_hll_cardinality(h);
+      if (a->col->has_dictionary || !a->hlls[g]) po_hll_free(h);
+      break;
+    }
+    default: v.type = 1; v.d = a->d0[g]; break;
+  }
+  return v;
+}
+
+/* =====================================================================================================================
  * query execution: GroupByOperator.getNextBlock (core/operator/query/GroupByOperator.java:100-140),
  * AggregationOperator.getNextBlock, FastFilteredCountOperator
  * ===================================================================================================================== */
@@ -1150,9 +1210,24 @@ static int null_handling_refused(po_segment* seg, const pg_query* q) {
   }
   return 0;
 }
-int32_t po_query_supported(void* seg, const pg_query* q) { return null_handling_refused((po_segment*)seg, q) ? PG_ERR_UNSUPPORTED : PG_OK; }
+/* the product library leaves these to the Java plan; the oracle refuses them alike so that the two sides answer the same queries */
+static int trim_refused(const pg_query* q) {
+  if (!(q->n_group_by > 0 && q->n_order_by > 0 && q->order_by && q->min_segment_group_trim_size > 0)) return 0;
+  if (q->flags & PG_QUERY_FLAG_NULL_HANDLING) { po_set_error("segment-level group trim under enableNullHandling"); return 1; }
+  for (int32_t i = 0; i < q->n_order_by; i++)
+    if (q->order_by[i].kind == PG_ORDER_BY_AGGREGATION && q->order_by[i].index >= 0 && q->order_by[i].index < q->n_aggregations) {
+      const int f = q->aggregations[q->order_by[i].index].function;
+      if (!(f == PG_AGG_COUNT || f == PG_AGG_SUM || f == PG_AGG_MIN || f == PG_AGG_MAX || f == PG_AGG_AVG || f == PG_AGG_MINMAXRANGE)) {
+        po_set_error("segment-level group trim ordered by aggregation function %d", f);
+        return 1;
+      }
+    }
+  return 0;
+}
+int32_t po_query_supported(void* seg, const pg_query* q) { return (null_handling_refused((po_segment*)seg, q) || trim_refused(q)) ? PG_ERR_UNSUPPORTED : PG_OK; }
 
 int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
+  if (trim_refused(q)) return PG_ERR_UNSUPPORTED;
   double t0 = now_ms();
   po_segment* seg = (po_segment*)segp;
   int32_t num_groups_limit = q->num_groups_limit > 0 ? q->num_groups_limit : DEFAULT_NUM_GROUPS_LIMIT;
@@ -1474,6 +1549,57 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
     n_groups = gkg_num_keys(&gkg);
     gid_of = (int32_t*)po_xcalloc((size_t)n_groups + 1, 4);
     for (int32_t g = 0; g < n_groups; g++) gid_of[g] = g;
+  }
+  /* GroupByOperator.java:120-133: ORDER BY + minSegmentGroupTrimSize > 0 + more groups than trimSize -> keep the trimSize groups that sort first */
+  if (n_gb > 0 && q->n_order_by > 0 && q->order_by && q->min_segment_group_trim_size > 0) {
+    const int64_t by_limit = (int64_t)q->limit * 5;   /* GroupByUtils.getTableCapacity */
+    const int32_t trim_size = by_limit > INT32_MAX ? INT32_MAX : ((int32_t)by_limit > q->min_segment_group_trim_size ? (int32_t)by_limit : q->min_segment_group_trim_size);
+    if (n_groups > trim_size) {
+      const int n_ob = q->n_order_by;
+      order_value* vals = (order_value*)po_xcalloc((size_t)n_groups * (size_t)n_ob + 1, sizeof(order_value));
+      int* asc = (int*)po_xcalloc((size_t)n_ob + 1, sizeof(int));
+      for (int k = 0; k < n_ob; k++) {
+        const pg_order_by* ob = &q->order_by[k];
+        asc[k] = ob->ascending != 0;
+        if (ob->kind == PG_ORDER_BY_AGGREGATION) {
+          if (ob->index < 0 || ob->index >= n_aggs) { free(vals); free(asc); free(gid_of); po_set_error("ORDER BY aggregation %d of %d", ob->index, n_aggs); return PG_ERR_INVALID_ARGUMENT; }
+          agg_ensure_capacity(&aggs[ob->index], (gkg.holder == HOLDER_ARRAY ? gkg.global_upper_bound : n_groups) + 1);
+          for (int32_t i = 0; i < n_groups; i++) vals[(size_t)i * (size_t)n_ob + (size_t)k] = agg_final_value(&aggs[ob->index], gid_of[i]);
+          continue;
+        }
+        if (ob->index < 0 || ob->index >= n_gb) { free(vals); free(asc); free(gid_of); po_set_error("ORDER BY group-by expression %d of %d", ob->index, n_gb); return PG_ERR_INVALID_ARGUMENT; }
+        const int j = ob->index;
+        const po_column* c = gcols[j];
+        for (int32_t i = 0; i < n_groups; i++) {
+          order_value* v = &vals[(size_t)i * (size_t)n_ob + (size_t)k];
+          const int32_t g = gid_of[i];
+          if (gkg.holder == HOLDER_RAW_VALUES) { v->type = 0; v->l = gkg.raw_key_of_group[g]; continue; }
+          if (gkg.holder == HOLDER_TUPLES) {
+            const int64_t t = gkg.tuples[(size_t)g * (size_t)gkg.tuple_w + (size_t)j];
+            if (c->has_dictionary || c->data_type <= PG_TYPE_LONG) { v->type = 0; v->l = t; }   /* dictIds order as the values do (sorted dictionaries) */
+            else if (c->data_type == PG_TYPE_FLOAT) { uint32_t b = (uint32_t)t; float f; memcpy(&f, &b, 4); v->type = 1; v->d = (double)f; }
+            else if (c->data_type == PG_TYPE_DOUBLE) { v->type = 1; memcpy(&v->d, &t, 8); }
+            else { v->type = 2; v->b = gkg.bytes_dicts[j].vals[t]; v->blen = gkg.bytes_dicts[j].lens[t]; }
+            continue;
+          }
+          int64_t raw = (gkg.holder == HOLDER_ARRAY) ? g : gkg.raw_key_of_group[g];   /* getKeys :578-591: column 0 is least significant */
+          for (int jj = 0; jj < j; jj++) raw /= gkg.cardinalities[jj];
+          v->type = 0;
+          v->l = raw % gkg.cardinalities[j];
+        }
+      }
+      int32_t* order = (int32_t*)po_xcalloc((size_t)n_groups + 1, 4);
+      for (int32_t i = 0; i < n_groups; i++) order[i] = i;
+      order_ctx octx = {vals, n_ob, asc};
+      qsort_r(order, (size_t)n_groups, 4, order_cmp, &octx);
+      /* the survivors in group-id order again (the order of the result's rows carries no meaning) */
+      uint8_t* keep = (uint8_t*)po_xcalloc((size_t)n_groups + 1, 1);
+      for (int32_t i = 0; i < trim_size; i++) keep[order[i]] = 1;
+      int32_t k2 = 0;
+      for (int32_t i = 0; i < n_groups; i++) if (keep[i]) gid_of[k2++] = gid_of[i];
+      n_groups = k2;
+      free(keep); free(order); free(vals); free(asc);
+    }
   }
   res->num_groups = n_groups;
   res->group_dict_ids = (int32_t**)po_xcalloc((size_t)n_gb + 1, sizeof(int32_t*));

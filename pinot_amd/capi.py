@@ -12,7 +12,7 @@ from typing import List, Optional, Sequence
 
 import numpy as np
 
-PG_ABI_VERSION = 3
+PG_ABI_VERSION = 4
 
 # pg_status
 PG_OK = 0
@@ -114,6 +114,13 @@ class PgAggSpec(C.Structure):
     _fields_ = [("function", C.c_int32), ("log2m", C.c_int32), ("column", C.c_char_p)]
 
 
+ORDER_BY_GROUP_KEY, ORDER_BY_AGGREGATION = 0, 1
+
+
+class PgOrderBy(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("index", C.c_int32), ("ascending", C.c_int32), ("nulls_last", C.c_int32)]
+
+
 class PgQuery(C.Structure):
     _fields_ = [
         ("filter", C.POINTER(PgFilterNode)),
@@ -124,7 +131,10 @@ class PgQuery(C.Structure):
         ("num_groups_limit", C.c_int32),
         ("max_initial_result_holder_capacity", C.c_int32),
         ("flags", C.c_int32),
-        ("total_number_of_entries", C.c_int32),
+        ("n_order_by", C.c_int32),
+        ("order_by", C.POINTER(PgOrderBy)),
+        ("limit", C.c_int32),
+        ("min_segment_group_trim_size", C.c_int32),
     ]
 
 

@@ -410,3 +410,32 @@ PG_HD static inline int64_t pg_acc_identity(int32_t fn, int32_t is_float) {
   if (fn == PG_ACC_MAX) return INT64_MIN;
   return 0;
 }
+
+// ---- segment-level group trim on the device (pg_kernels_trim.hip) ----------------------------------------------------------------------
+// ctrl (uint32 words): [0] groups that exist, [1] survivors below the threshold written, [2] tie-class members written, [3] overflow flag,
+// [4] need_eq (places left for the tie class), [5] n_lt (survivors below the threshold), [8 + 4 p .. ] state of pass p: prefix lo, prefix hi,
+// remaining, pad; [64 + 256 p ..] histogram of pass p
+#define PG_TRIM_CTRL_STATE 8
+#define PG_TRIM_CTRL_HIST 64
+#define PG_TRIM_CTRL_WORDS (PG_TRIM_CTRL_HIST + 8 * 256)
+
+struct PgTrimArgs {
+  const int64_t* table;     // [n_ops][G]
+  int64_t G;
+  int32_t n_ops;
+  int32_t exist_op;         // the op whose row tells whether a group exists (COUNT != 0, or MIN / MAX off its identity)
+  int64_t exist_ident;
+  int32_t key_op;           // >= 0: the key is that row's int64; -1: the key is digit (g / key_mult) % key_card of the raw key
+  int32_t descending;
+  int64_t key_mult;
+  int64_t key_card;
+  uint64_t* keys;           // [G] scratch
+  uint32_t* ctrl;           // [PG_TRIM_CTRL_WORDS], zeroed by the caller
+  int32_t k;                // trimSize
+  int32_t cap;              // rows of the compact block (>= k)
+  int32_t take_whole_tie_class;   // several ORDER BY expressions: the host finishes the selection
+  int32_t pad;
+  int64_t* out_gids;        // [cap]
+  int64_t* out_table;       // [n_ops][cap]
+};
+

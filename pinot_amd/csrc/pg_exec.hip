@@ -254,6 +254,7 @@ static bool uses_pipe_kernel(const CompiledPlan& P, int agg_mode) {
          P.dev.dense_fused && P.dev.pipe_fit;
 }
 
+extern "C" void pg_trim_launch(const PgTrimArgs* args, int grid, hipStream_t stream);
 typedef void (*QueryKernel)(const PgQueryPlan);
 static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char** name) {
   const bool agg = agg_mode != PG_AGG_NONE;
@@ -327,6 +328,7 @@ struct ThreadCtx {
   DeviceBuffer stats, partials, final_table, tile_counts, aux;
   DeviceBuffer words, radix_hist, radix_start, radix_tuples, hash_count, hash_keys, hash_acc;   // PG_AGG_RADIX work areas
   DeviceBuffer aux_summary;   // PG_QUERY_FLAG_FINAL_DISTINCT: [n_aux][G] final values
+  DeviceBuffer trim_keys, trim_ctrl, trim_out;   // segment-level group trim on the device: [G] keys, counters, the compact block
   DeviceBuffer hll_small[17];  // per log2m: round(m * ln(m / zeros)), zeros = 0 .. m
   double hll_alpha_mm[17] = {0};
   DeviceBuffer p2_meta, p2_list, p2_ctrl;   // partition pipeline v2: chunk records, the same grouped by bucket, counters (PG_P2_CTRL_*)
@@ -501,6 +503,7 @@ struct HostTable {
   // (INT64_MAX elsewhere) and the limit itself — the plan that filled `table` carries neither
   const int64_t* admit_first = nullptr;
   int32_t admit_limit = 0;
+  int64_t groups_found = -1;             // >= 0: the table was trimmed on the device; the groups the segment held before that
 };
 // What execute_query_impl does beside the plain query: stop after `doc_limit` docs of the doc space; hand the raw table over instead of
 // assembling groups; trim to numGroupsLimit by another pass's first docIds.
@@ -1316,6 +1319,7 @@ static std::unique_ptr<Result> execute_query_impl(Segment& seg, const pg_query& 
   double t_queued_at = 0, t_synced = 0;   // PG_TRACE_HOST: host-side timeline of one query
   std::vector<int64_t> table((size_t)n_out);
   std::vector<int64_t> hash_keys_host;   // PG_AGG_RADIX_HASH: raw key of every group of the compact table
+  int64_t compact_groups = -1, groups_found = -1;   // the device trimmed the dense table: rows of the compact table (keys in hash_keys_host), groups that existed
   uint64_t stats_host[PG_MAX_STATS] = {0};
   if (has_docs) {
     if (P.aux_in_lds)
@@ -1342,7 +1346,66 @@ static std::unique_ptr<Result> execute_query_impl(Segment& seg, const pg_query& 
                        ctx.stats.as<unsigned long long>(), reduce);
     PG_HIP(hipGetLastError());
     if (profile) PG_HIP(hipEventRecord(ctx.ev[2], ctx.stream));
-    if (!direct_out) PG_HIP(hipMemcpyAsync(host_out, ctx.final_table.ptr, out_bytes, hipMemcpyDeviceToHost, ctx.stream));
+    // Segment-level group trim on the device (pg_kernels_trim.hip): dense tables without auxiliary state whose first ORDER BY expression is
+    // a dictionary group column or an int64 accumulator row, and far more slots than trimSize: the survivors are selected in HBM and only
+    // their rows are copied.  Everything else copies the table and trims at assembly.
+    int trim_cap = 0, trim_key_op = -1;
+    bool trim_whole_class = false;
+    if (P.trim_size > 0 && !hashed && D.n_aux == 0 && P.first_doc_op < 0 && !opt.admit && !opt.raw_out && !keep_table && !direct_out &&
+        P.exist_op >= 0 && !D.mv && !knobs().no_device_trim && (int64_t)D.n_groups >= 8 * ((int64_t)P.trim_size + 4096)) {
+      const pg_order_by& ob = P.order_by[0];
+      bool ok = true;
+      if (ob.kind == PG_ORDER_BY_GROUP_KEY) {
+        ok = !P.raw_group && !((size_t)ob.index < P.group_vdict.size() && P.group_vdict[(size_t)ob.index]);
+      } else {
+        const AggOut& ao = P.aggs[(size_t)ob.index];
+        const bool plain_row = ao.op_a >= 0 && ao.sum_limbs <= 0 &&
+                               (ao.function == PG_AGG_COUNT || D.ops[ao.op_a].is_float == PG_ACCV_INT ||
+                                ((ao.function == PG_AGG_MIN || ao.function == PG_AGG_MAX) && D.ops[ao.op_a].is_float == PG_ACCV_DOUBLE));
+        ok = plain_row && (ao.function == PG_AGG_COUNT || ao.function == PG_AGG_SUM || ao.function == PG_AGG_MIN || ao.function == PG_AGG_MAX);
+        trim_key_op = ok ? ao.op_a : -1;
+      }
+      if (ok) {
+        trim_whole_class = P.order_by.size() > 1;
+        trim_cap = P.trim_size + 4096;
+      }
+    }
+    if (trim_cap > 0) {
+      const pg_order_by& ob = P.order_by[0];
+      ThreadCtx::grow(ctx.trim_keys, (size_t)D.n_groups * 8);
+      ThreadCtx::grow(ctx.trim_out, (size_t)(D.n_ops + 1) * (size_t)trim_cap * 8);
+      if (!ctx.trim_ctrl.ptr) ctx.trim_ctrl.alloc((size_t)PG_TRIM_CTRL_WORDS * 4, true);
+      PG_HIP(hipMemsetAsync(ctx.trim_ctrl.ptr, 0, (size_t)PG_TRIM_CTRL_WORDS * 4, ctx.stream));
+      PgTrimArgs ta;
+      memset(&ta, 0, sizeof(ta));
+      ta.table = ctx.final_table.as<int64_t>();
+      ta.G = D.n_groups;
+      ta.n_ops = D.n_ops;
+      ta.exist_op = P.exist_op;
+      ta.exist_ident = pg_acc_identity(D.ops[P.exist_op].fn, 0);
+      ta.key_op = trim_key_op;
+      ta.descending = ob.ascending ? 0 : 1;
+      ta.key_mult = ob.kind == PG_ORDER_BY_GROUP_KEY ? D.gcols[ob.index].mult : 1;
+      ta.key_card = ob.kind == PG_ORDER_BY_GROUP_KEY ? P.group_cards[ob.index] : 1;
+      ta.keys = ctx.trim_keys.as<uint64_t>();
+      ta.ctrl = ctx.trim_ctrl.as<uint32_t>();
+      ta.k = P.trim_size;
+      ta.cap = trim_cap;
+      ta.take_whole_tie_class = trim_whole_class ? 1 : 0;
+      ta.out_table = ctx.trim_out.as<int64_t>();
+      ta.out_gids = ctx.trim_out.as<int64_t>() + (size_t)D.n_ops * (size_t)trim_cap;
+      const int tgrid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)num_cus() * 4, ((int64_t)D.n_groups + 1023) / 1024));
+      pg_trim_launch(&ta, tgrid, ctx.stream);
+      PG_HIP(hipGetLastError());
+      if (profile) PG_HIP(hipEventRecord(ctx.ev[2], ctx.stream));   // the selection is part of the query's device time
+      // compact block | statistics | counters, where the whole table would have gone
+      const size_t block_words = (size_t)(D.n_ops + 1) * (size_t)trim_cap;
+      PG_HIP(hipMemcpyAsync(host_out, ctx.trim_out.ptr, block_words * 8, hipMemcpyDeviceToHost, ctx.stream));
+      PG_HIP(hipMemcpyAsync(host_out + block_words, ctx.final_table.as<int64_t>() + n_out, (size_t)PG_MAX_STATS * 8, hipMemcpyDeviceToHost, ctx.stream));
+      PG_HIP(hipMemcpyAsync(host_out + block_words + PG_MAX_STATS, ctx.trim_ctrl.ptr, 32, hipMemcpyDeviceToHost, ctx.stream));
+    } else if (!direct_out) {
+      PG_HIP(hipMemcpyAsync(host_out, ctx.final_table.ptr, out_bytes, hipMemcpyDeviceToHost, ctx.stream));
+    }
     if (final_distinct) {
       const int G1 = std::max(D.n_groups, 1);
       ThreadCtx::grow(ctx.aux_summary, summary_bytes);
@@ -1375,8 +1438,35 @@ static std::unique_ptr<Result> execute_query_impl(Segment& seg, const pg_query& 
     stream_wait(ctx, cancel);
     t_synced = now_ms();
     t_queued_at = t_queued;
-    if (n_out) memcpy(table.data(), host_out, (size_t)n_out * 8);
-    memcpy(stats_host, host_out + n_out, sizeof(stats_host));
+    if (trim_cap > 0) {
+      const size_t block_words = (size_t)(D.n_ops + 1) * (size_t)trim_cap;
+      const uint32_t* tc = reinterpret_cast<const uint32_t*>(host_out + block_words + PG_MAX_STATS);
+      memcpy(stats_host, host_out + block_words, sizeof(stats_host));
+      if (tc[3]) {   // the tie class of several ORDER BY expressions did not fit the block: the whole table after all
+        PG_HIP(hipMemcpyAsync(host_out, ctx.final_table.ptr, (size_t)n_out * 8, hipMemcpyDeviceToHost, ctx.stream));
+        stream_wait(ctx, cancel);
+        if (n_out) memcpy(table.data(), host_out, (size_t)n_out * 8);
+      } else {
+        const int64_t n_exist = tc[0];
+        const int64_t n_sel = trim_whole_class ? (int64_t)tc[5] + (int64_t)tc[2] : std::min<int64_t>(P.trim_size, n_exist);
+        // survivors in group-id order (the device appends them as its wavefronts come by)
+        std::vector<int32_t> perm((size_t)n_sel);
+        for (int64_t i = 0; i < n_sel; i++) perm[(size_t)i] = (int32_t)i;
+        const int64_t* gsel = host_out + (size_t)D.n_ops * (size_t)trim_cap;
+        std::sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) { return gsel[x] < gsel[y]; });
+        hash_keys_host.resize((size_t)n_sel);
+        table.assign((size_t)n_sel * (size_t)D.n_ops, 0);
+        for (int64_t i = 0; i < n_sel; i++) {
+          hash_keys_host[(size_t)i] = gsel[perm[(size_t)i]];
+          for (int o = 0; o < D.n_ops; o++) table[(size_t)o * (size_t)n_sel + (size_t)i] = host_out[(size_t)o * (size_t)trim_cap + (size_t)perm[(size_t)i]];
+        }
+        compact_groups = n_sel;
+        groups_found = n_exist;
+      }
+    } else {
+      if (n_out) memcpy(table.data(), host_out, (size_t)n_out * 8);
+      memcpy(stats_host, host_out + n_out, sizeof(stats_host));
+    }
     ctx.stats_dirty = false;    // the reduce kernel left them zero
     if (p2_ran && ctx.p2_ctrl_host[1])
       fail(PG_ERR_INTERNAL, "partition pipeline ran out of chunks (%u claimed, %d sized)", ctx.p2_ctrl_host[0], D.p2_capacity);
@@ -1424,8 +1514,9 @@ static std::unique_ptr<Result> execute_query_impl(Segment& seg, const pg_query& 
   H.aux = final_distinct ? nullptr : aux_host;
   H.aux_summary = final_distinct ? reinterpret_cast<const uint64_t*>(aux_host) : nullptr;
   H.aux_block = final_distinct ? nullptr : out_block;
-  H.hashed = hashed;
-  H.hash_groups = hash_groups;
+  H.hashed = hashed || compact_groups >= 0;   // a table trimmed on the device reads like a hashed one: compact rows + the raw key of each
+  H.hash_groups = compact_groups >= 0 ? compact_groups : hash_groups;
+  H.groups_found = groups_found;
   H.hash_keys = std::move(hash_keys_host);
   H.full_scan_entries = P.full_scan_entries;
   H.total_docs = seg.total_docs;
@@ -1540,7 +1631,7 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
     for (int64_t g = 0; g < G; g++) if (exists(g)) gids.push_back(g);
   }
   const int64_t groups_limit = H.admit_first ? (int64_t)H.admit_limit : (int64_t)P.num_groups_limit;
-  bool limit_reached = n_group_by > 0 && (int64_t)gids.size() >= groups_limit;
+  bool limit_reached = n_group_by > 0 && (H.groups_found >= 0 ? H.groups_found : (int64_t)gids.size()) >= groups_limit;
   if (n_group_by > 0 && (int64_t)gids.size() > groups_limit) {
     // keep the numGroupsLimit groups whose first matching docId is smallest (= the keys the reference admits in docId order)
     if (P.dev.mv)   // which keys the reference admits depends on the entry order inside the docs: left to the Java plan
@@ -1550,6 +1641,111 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
     std::nth_element(gids.begin(), gids.begin() + groups_limit, gids.end(), [&](int64_t a, int64_t b) { return first[a] < first[b]; });
     gids.resize((size_t)groups_limit);
     std::sort(gids.begin(), gids.end());
+  }
+  auto op_double = [&](int o, int64_t g) -> double {
+    const PgAccOp& op = D.ops[o];
+    int64_t v = table[(size_t)o * G + g];
+    const bool empty = !exists(g);
+    switch (op.fn) {
+      case PG_ACC_COUNT: return (double)v;
+      case PG_ACC_SUM:
+        if (op.is_float == PG_ACCV_DOUBLE) { double d; memcpy(&d, &v, 8); return d; }
+        return (double)v;
+      case PG_ACC_MIN:
+        if (empty) return INFINITY;    // MinAggregationFunction default holder value
+        return op.is_float ? order_key_to_double(v) : (double)v;
+      default:
+        if (empty) return -INFINITY;   // MaxAggregationFunction.java:37
+        return op.is_float ? order_key_to_double(v) : (double)v;
+    }
+  };
+  // SUM kept in fixed-point / two-digit limbs: combined and rounded to double once (exact sum, correctly rounded)
+  auto sum_double = [&](const AggOut& ao, int64_t g) -> double {
+    if (ao.sum_limbs <= 0) return op_double(ao.op_a, g);
+    int64_t limbs[4] = {0, 0, 0, 0};
+    for (int j = 0; j < ao.sum_limbs; j++) limbs[j] = table[(size_t)(ao.op_a + j) * G + g];
+    return limbs_to_double(limbs, ao.sum_limbs, ao.fx_q);
+  };
+  // ---- segment-level group trim (GroupByOperator.java:120-133 -> TableResizer#trimInSegmentResults :327-351): more groups than trimSize and
+  //      an ORDER BY: keep the trimSize groups that sort first.  Order-by values as the extractors of TableResizer.java:406-445 give them:
+  //      a group key's value, an aggregation's final result (COUNT long; SUM / MIN / MAX double; AVG sum / count; MINMAXRANGE max - min).
+  //      (Tables trimmed on the device arrive here already compact — device_trim below — and pass through: ng <= trimSize.)
+  if (n_group_by > 0 && P.trim_size > 0 && (int64_t)gids.size() > (int64_t)P.trim_size) {
+    struct OV { int type; int64_t l; double d; const uint8_t* b; int64_t blen; };
+    const size_t n = gids.size(), n_ob = P.order_by.size();
+    std::vector<OV> vals(n * n_ob);
+    for (size_t k = 0; k < n_ob; k++) {
+      const pg_order_by& ob = P.order_by[k];
+      if (ob.kind == PG_ORDER_BY_AGGREGATION) {
+        const AggOut& ao = P.aggs[(size_t)ob.index];
+        for (size_t i = 0; i < n; i++) {
+          OV& v = vals[i * n_ob + k];
+          const int64_t g = gids[i];
+          v = OV{1, 0, 0.0, nullptr, 0};
+          switch (ao.function) {
+            case PG_AGG_COUNT: v.type = 0; v.l = count_of(ao.op_a, g); break;
+            case PG_AGG_SUM: v.d = sum_double(ao, g); break;
+            case PG_AGG_AVG: { const int64_t c = count_of(ao.op_b, g); v.d = c == 0 ? -INFINITY : sum_double(ao, g) / (double)c; break; }
+            case PG_AGG_MINMAXRANGE: v.d = op_double(ao.op_b, g) - op_double(ao.op_a, g); break;
+            default: v.d = op_double(ao.op_a, g); break;   // MIN / MAX
+          }
+        }
+        continue;
+      }
+      const int j = ob.index;
+      const Column* vd = (size_t)j < P.group_vdict.size() ? P.group_vdict[(size_t)j] : nullptr;
+      for (size_t i = 0; i < n; i++) {
+        OV& v = vals[i * n_ob + k];
+        v = OV{0, 0, 0.0, nullptr, 0};
+        if (P.raw_group) { v.l = (int64_t)((uint64_t)H.hash_keys[(size_t)gids[i]] ^ (1ULL << 63)); continue; }
+        const int64_t raw = hashed ? H.hash_keys[(size_t)gids[i]] : gids[i];
+        const int64_t id = (raw / D.gcols[j].mult) % P.group_cards[j];
+        if (!vd) { v.l = id; continue; }   // a sorted dictionary: dictIds order as the values do
+        if (vd->vdict_kind == 4) {
+          v.type = 2;
+          v.b = vd->vdict_bytes.data() + vd->vdict_bytes_off[(size_t)id];
+          v.blen = vd->vdict_bytes_off[(size_t)id + 1] - vd->vdict_bytes_off[(size_t)id];
+        } else if (vd->vdict_kind <= 1) {
+          v.l = vdict_value_of_key(vd->vdict_keys[(size_t)id], vd->vdict_kind, nullptr);
+        } else {
+          v.type = 1;
+          (void)vdict_value_of_key(vd->vdict_keys[(size_t)id], vd->vdict_kind, &v.d);
+        }
+      }
+    }
+    auto dcmp = [](double a, double b) {   // Double.compare
+      if (a < b) return -1;
+      if (a > b) return 1;
+      int64_t x, y;
+      memcpy(&x, &a, 8); memcpy(&y, &b, 8);
+      if (a != a) x = INT64_MAX;
+      if (b != b) y = INT64_MAX;
+      return x == y ? 0 : (x < y ? -1 : 1);
+    };
+    std::vector<int32_t> order(n);
+    for (size_t i = 0; i < n; i++) order[i] = (int32_t)i;
+    auto before = [&](int32_t ia, int32_t ib) {
+      for (size_t k = 0; k < n_ob; k++) {
+        const OV& a = vals[(size_t)ia * n_ob + k];
+        const OV& b = vals[(size_t)ib * n_ob + k];
+        int r;
+        if (a.type == 0) r = a.l < b.l ? -1 : (a.l > b.l ? 1 : 0);
+        else if (a.type == 1) r = dcmp(a.d, b.d);
+        else {
+          const int64_t m = std::min(a.blen, b.blen);
+          r = m ? memcmp(a.b, b.b, (size_t)m) : 0;
+          if (r == 0) r = a.blen < b.blen ? -1 : (a.blen > b.blen ? 1 : 0);
+        }
+        if (r != 0) return P.order_by[k].ascending ? r < 0 : r > 0;
+      }
+      return ia < ib;
+    };
+    std::nth_element(order.begin(), order.begin() + P.trim_size, order.end(), before);
+    order.resize((size_t)P.trim_size);
+    std::sort(order.begin(), order.end());
+    std::vector<int64_t> kept_gids(order.size());
+    for (size_t i = 0; i < order.size(); i++) kept_gids[i] = gids[(size_t)order[i]];
+    gids.swap(kept_gids);
   }
   const int32_t ng = (int32_t)gids.size();
   res.num_groups = ng;
@@ -1626,30 +1822,6 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
   }
   if (n_group_by > 0) res.stats.num_groups_limit_reached = limit_reached ? 1 : 0;
 
-  auto op_double = [&](int o, int64_t g) -> double {
-    const PgAccOp& op = D.ops[o];
-    int64_t v = table[(size_t)o * G + g];
-    const bool empty = !exists(g);
-    switch (op.fn) {
-      case PG_ACC_COUNT: return (double)v;
-      case PG_ACC_SUM:
-        if (op.is_float == PG_ACCV_DOUBLE) { double d; memcpy(&d, &v, 8); return d; }
-        return (double)v;
-      case PG_ACC_MIN:
-        if (empty) return INFINITY;    // MinAggregationFunction default holder value
-        return op.is_float ? order_key_to_double(v) : (double)v;
-      default:
-        if (empty) return -INFINITY;   // MaxAggregationFunction.java:37
-        return op.is_float ? order_key_to_double(v) : (double)v;
-    }
-  };
-  // SUM kept in fixed-point / two-digit limbs: combined and rounded to double once (exact sum, correctly rounded)
-  auto sum_double = [&](const AggOut& ao, int64_t g) -> double {
-    if (ao.sum_limbs <= 0) return op_double(ao.op_a, g);
-    int64_t limbs[4] = {0, 0, 0, 0};
-    for (int j = 0; j < ao.sum_limbs; j++) limbs[j] = table[(size_t)(ao.op_a + j) * G + g];
-    return limbs_to_double(limbs, ao.sum_limbs, ao.fx_q);
-  };
   res.aggs.resize((size_t)n_aggregations);
   for (int a = 0; a < n_aggregations; a++) {
     const AggOut& ao = P.aggs[a];

@@ -286,6 +286,10 @@ struct CompiledPlan {
   std::vector<int32_t> group_cards;
   size_t lds_bytes = 0;
   int32_t num_groups_limit = 0;
+  // segment-level group trim (GroupByOperator.java:120-133): the ORDER BY expressions and trimSize = max(5 x limit, minSegmentGroupTrimSize);
+  // 0: no trim.  Applied at result assembly (pg_exec.hip trim_groups), on the device first where the table allows (device_trim).
+  std::vector<pg_order_by> order_by;
+  int32_t trim_size = 0;
   int32_t exist_op = 0;              // accumulator whose value tells whether a group was touched
   bool raw_group = false;            // the single group-by column is a raw INT / LONG column: keys are values (hash group-by)
   std::vector<Column*> group_vdict;  // per group-by column: its virtual dictionary (raw column grouped through ids), or null
@@ -437,7 +441,7 @@ struct Knobs {
   int part_min = -1;
   // executor (pg_exec.hip)
   bool force_interpreter = false, no_scan_pipe = false, no_pipe = false, no_dense_fused = false, no_part_grid_clamp = false, no_spin_wait = false;
-  bool trace_oct = false, no_tile_split = false, no_oct_exec = false, no_p2_simple = false, no_dense_count = false, no_direct_result = false, trace_host = false, no_limit_prefix = false;
+  bool trace_oct = false, no_tile_split = false, no_oct_exec = false, no_p2_simple = false, no_dense_count = false, no_direct_result = false, trace_host = false, no_limit_prefix = false, no_device_trim = false;
   int scan_wgs_per_cu = 1, pipe_wgs_per_cu = 1, wgs_per_cu = 1, p2_wgs_per_cu = 4, dense_count_wgs = 1, tile_split_max = -1, hash_first_buckets = -1;
   int64_t exact_stats_max_docs = (int64_t)1 << 22;
   int64_t limit_prefix_min_docs = (int64_t)1 << 20;   // PG_LIMIT_PREFIX_MIN_DOCS: smallest doc prefix of the numGroupsLimit admission pass (tests lower it)

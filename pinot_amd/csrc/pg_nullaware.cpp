@@ -333,6 +333,8 @@ void check_null_handling(Segment& seg, const pg_query& q) {
     Column* c = seg.find(name);
     if (c && c->is_mv) fail(PG_ERR_UNSUPPORTED, "enableNullHandling: nulls in the multi-value column %s", c->name.c_str());
   }
+  if (q.n_group_by > 0 && q.n_order_by > 0 && q.order_by && q.min_segment_group_trim_size > 0)
+    fail(PG_ERR_UNSUPPORTED, "segment-level group trim under enableNullHandling (null order-by values, TableResizer.java:98-116) is left to the Java plan");
   if (any_nulls && (q.flags & PG_QUERY_FLAG_KEEP_DEVICE_TABLE))
     fail(PG_ERR_UNSUPPORTED, "enableNullHandling over columns with nulls: the result is joined on the host, no device table to keep");
 }

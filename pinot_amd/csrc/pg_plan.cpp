@@ -836,6 +836,10 @@ std::string query_signature(const pg_filter_node* filter, const pg_query* q, int
       sig_str(o, q->aggregations[i].column ? q->aggregations[i].column : "*");
     }
     o << "|" << q->num_groups_limit << "," << q->max_initial_result_holder_capacity << "," << (q->flags & PG_QUERY_FLAG_SKIP_STAR_TREE);
+    if (q->n_group_by > 0 && q->n_order_by > 0 && q->order_by && q->min_segment_group_trim_size > 0) {
+      o << "|trim" << q->limit << "," << q->min_segment_group_trim_size;
+      for (int32_t i = 0; i < q->n_order_by; i++) o << ";" << q->order_by[i].kind << "," << q->order_by[i].index << "," << (q->order_by[i].ascending != 0);
+    }
   } else {
     o << "|filter-only";
   }
@@ -1524,6 +1528,27 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
 
   // ---- aggregation plan ------------------------------------------------------------------------------------------
   P.num_groups_limit = q->num_groups_limit > 0 ? q->num_groups_limit : 100000;
+  if (q->n_group_by > 0 && q->n_order_by > 0 && q->order_by && q->min_segment_group_trim_size > 0) {
+    // GroupByOperator.java:120-133 / GroupByUtils.getTableCapacity :45-57
+    if (q->flags & PG_QUERY_FLAG_NULL_HANDLING)
+      fail(PG_ERR_UNSUPPORTED, "segment-level group trim under enableNullHandling (null order-by values, TableResizer.java:98-116) is left to the Java plan");
+    for (int32_t i = 0; i < q->n_order_by; i++) {
+      const pg_order_by& ob = q->order_by[i];
+      if (ob.kind == PG_ORDER_BY_GROUP_KEY) {
+        if (ob.index < 0 || ob.index >= q->n_group_by) fail(PG_ERR_INVALID_ARGUMENT, "ORDER BY group-by expression %d of %d", ob.index, q->n_group_by);
+      } else if (ob.kind == PG_ORDER_BY_AGGREGATION) {
+        if (ob.index < 0 || ob.index >= q->n_aggregations) fail(PG_ERR_INVALID_ARGUMENT, "ORDER BY aggregation %d of %d", ob.index, q->n_aggregations);
+        const int f = q->aggregations[ob.index].function;
+        if (!(f == PG_AGG_COUNT || f == PG_AGG_SUM || f == PG_AGG_MIN || f == PG_AGG_MAX || f == PG_AGG_AVG || f == PG_AGG_MINMAXRANGE))
+          fail(PG_ERR_UNSUPPORTED, "segment-level group trim ordered by aggregation function %d (distinct counts, multi-value functions) is left to the Java plan", f);
+      } else {
+        fail(PG_ERR_INVALID_ARGUMENT, "ORDER BY expression kind %d", ob.kind);
+      }
+      P.order_by.push_back(ob);
+    }
+    const int64_t by_limit = (int64_t)std::max(q->limit, 0) * 5;
+    P.trim_size = by_limit > INT32_MAX ? INT32_MAX : std::max((int32_t)by_limit, q->min_segment_group_trim_size);
+  }
   if (q->n_group_by > PG_MAX_GROUP_COLS) fail(PG_ERR_UNSUPPORTED, "more than %d group-by columns", PG_MAX_GROUP_COLS);
   std::vector<Column*> projected;
   auto project = [&](Column* c) {

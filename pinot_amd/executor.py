@@ -125,8 +125,9 @@ class NativeSegment:
         if profile:
             qc.flags |= capi.QUERY_FLAG_PROFILE
         cached = getattr(qc, "_cquery", None)     # the C structs of a QueryContext are reusable across executions
-        if cached is None or cached[0] != qc.flags:
-            cached = (qc.flags, CQuery(qc))
+        key = (qc.flags, qc.num_groups_limit, qc.limit, qc.min_segment_group_trim_size)
+        if cached is None or cached[0] != key:
+            cached = (key, CQuery(qc))
             qc._cquery = cached
         cq = cached[1]
         h = C.c_void_p()
@@ -142,10 +143,11 @@ class NativeSegment:
         qc = parse_sql(q) if isinstance(q, str) else q
         flags = qc.flags | (capi.QUERY_FLAG_KEEP_DEVICE_TABLE if keep_device_table else 0)
         cache = getattr(qc, "_cquery_native", None)
-        if cache is None or cache[0] != flags:
+        key = (flags, qc.num_groups_limit, qc.limit, qc.min_segment_group_trim_size)
+        if cache is None or cache[0] != key:
             saved = qc.flags
             qc.flags = flags
-            cache = (flags, CQuery(qc))
+            cache = (key, CQuery(qc))
             qc.flags = saved
             qc._cquery_native = cache
         h = C.c_void_p()

@@ -98,6 +98,22 @@ class QueryContext:
     max_initial_result_holder_capacity: int = 0
     flags: int = 0
     has_group_by: bool = False
+    min_segment_group_trim_size: int = -1   # InstancePlanMakerImplV2.DEFAULT_MIN_SEGMENT_GROUP_TRIM_SIZE: the segment's groups are not trimmed
+
+    def resolved_order_by(self) -> "Optional[List[Tuple[int, int, bool]]]":
+        """(kind, index, ascending) per ORDER BY expression as TableResizer resolves them (TableResizer.java:129-161): a group-by expression
+        or an aggregation of the select list; None when some expression is neither (post-aggregations, literals: not carried by the ABI)."""
+        out = []
+        norm = lambda t: re.sub(r"\s+", "", t).upper()   # noqa: E731
+        aggs = [norm(f"{a.function}({a.column or '*'}{',' + str(a.log2m) if a.log2m else ''})") for a in self.aggregations]
+        for text, asc in self.order_by:
+            if text in self.group_by:
+                out.append((capi.ORDER_BY_GROUP_KEY, self.group_by.index(text), asc))
+            elif norm(text) in aggs:
+                out.append((capi.ORDER_BY_AGGREGATION, aggs.index(norm(text)), asc))
+            else:
+                return None
+        return out
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -387,6 +403,17 @@ class CQuery:
         self.query.num_groups_limit = q.num_groups_limit
         self.query.max_initial_result_holder_capacity = q.max_initial_result_holder_capacity
         self.query.flags = q.flags
+        # segment-level group trim (GroupByOperator.java:120-133): ORDER BY + LIMIT + minSegmentGroupTrimSize travel with group-by queries
+        ob = q.resolved_order_by() if (ng and q.order_by) else None
+        self.query.limit = q.limit
+        self.query.min_segment_group_trim_size = q.min_segment_group_trim_size
+        if ob:
+            arr = (capi.PgOrderBy * len(ob))()
+            for i, (kind, index, asc) in enumerate(ob):
+                arr[i].kind, arr[i].index, arr[i].ascending, arr[i].nulls_last = kind, index, int(asc), int(asc)   # NULLS LAST for ASC is the SQL default
+            self._keep.append(arr)
+            self.query.order_by = arr
+            self.query.n_order_by = len(ob)
 
     def _fill(self, node: capi.PgFilterNode, f: FilterContext):
         node.type = _FILTER_TYPES[f.type]

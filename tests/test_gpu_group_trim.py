@@ -1,0 +1,114 @@
+"""Segment-level group trim on the GPU (GroupByOperator.java:120-133 -> TableResizer#trimInSegmentResults): the library's result is a
+valid trim of its own untrimmed result (tests/trim_model.py), equals the oracle's where the ORDER BY is a total order, and is the same
+whether the survivors are selected on the device (pg_kernels_trim.hip: dense tables far larger than trimSize) or at assembly."""
+import numpy as np
+import pytest
+
+from pinot_amd import capi, synth
+from pinot_amd.executor import NativeSegment
+from pinot_amd.query import parse_sql
+from tests.test_group_trim import QUERIES
+from tests.trim_model import assert_valid_trim, trim_size
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def segs(gpu_api, oracle_api):
+    host = synth.generate_segment(150_001, segment_index=9, columns=["g1", "g2", "m", "u"], native=False)
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    yield g, o
+    g.destroy()
+    o.destroy()
+
+
+@pytest.mark.parametrize("sql", QUERIES)
+@pytest.mark.parametrize("min_trim", [1, 333])
+def test_trim_small_tables(segs, sql, min_trim):
+    g, o = segs
+    full = g.execute(parse_sql(sql)).rows()
+    assert full == o.execute(parse_sql(sql)).rows()
+    qc, qo = parse_sql(sql), parse_sql(sql)
+    qc.min_segment_group_trim_size = qo.min_segment_group_trim_size = min_trim
+    gb, ob = g.execute(qc), o.execute(qo)
+    assert_valid_trim(qc, full, gb.rows())
+    if sql.count(",") >= 4 or "ORDER BY u" in sql or ", u" in sql.split("ORDER BY")[1]:   # the ORDER BY ends in a group key: a total order
+        assert gb.rows() == ob.rows()
+    assert gb.stats.num_groups_limit_reached == ob.stats.num_groups_limit_reached
+    assert gb.stats.num_docs_scanned == ob.stats.num_docs_scanned
+
+
+BIG = [
+    # one expression, unique values (a group key): the device selects exactly trimSize survivors
+    ("SELECT u, COUNT(*), SUM(m) FROM gpuBench GROUP BY u ORDER BY u DESC LIMIT 10", 1, True),
+    ("SELECT u, COUNT(*), SUM(m) FROM gpuBench GROUP BY u ORDER BY u LIMIT 1000", 1, True),
+    # SUM(m) then the key: a tiny tie class rides along, the host finishes
+    ("SELECT u, COUNT(*), SUM(m), MAX(m) FROM gpuBench GROUP BY u ORDER BY SUM(m) DESC, u LIMIT 10", 1, True),
+    ("SELECT u, MIN(m), MAX(m) FROM gpuBench WHERE g1 < 90 GROUP BY u ORDER BY MAX(m), u DESC LIMIT 50", 600, True),
+    # COUNT(*) over 10^6 groups of ~2.5 docs: the tie class at the cut holds tens of thousands of groups — beyond the block: the whole table
+    # comes back after all and the assembly trims (same answer)
+    ("SELECT u, COUNT(*) FROM gpuBench GROUP BY u ORDER BY COUNT(*) DESC, u LIMIT 10", 1, True),
+    # a single expression with ties at the cut: any of the tied groups may survive (checked against the model only)
+    ("SELECT u, COUNT(*) FROM gpuBench GROUP BY u ORDER BY COUNT(*) DESC LIMIT 10", 1, False),
+    ("SELECT g2, u, COUNT(*), SUM(m) FROM gpuBench GROUP BY g2, u ORDER BY u, g2 DESC LIMIT 40", 1, True),
+]
+
+
+@pytest.fixture(scope="module")
+def big(gpu_api, oracle_api):
+    host = synth.generate_segment(2_500_003, segment_index=10, columns=["g1", "g2", "m", "u"], native=True)
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    yield g, o, host
+    g.destroy()
+    o.destroy()
+
+
+@pytest.mark.parametrize("sql,min_trim,total_order", BIG)
+def test_trim_on_the_device(big, gpu_api, gpu_knobs, sql, min_trim, total_order):
+    g, o, host = big
+    limit = 60_000_000 if "g2, u" in sql else 2_000_000    # numGroupsLimit above the key space: no docId plane in the way
+    def q(trim):
+        qc = parse_sql(sql)
+        qc.num_groups_limit = limit
+        qc.min_segment_group_trim_size = trim
+        return qc
+    full = g.execute(q(-1)).rows()
+    qc = q(min_trim)
+    got = g.execute(qc)
+    assert_valid_trim(qc, full, got.rows())
+    if total_order:
+        assert got.rows() == o.execute(q(min_trim)).rows()
+    # the same through the assembly-time trim alone
+    gpu_knobs(PG_NO_DEVICE_TRIM="1")
+    g2 = NativeSegment(gpu_api, host)
+    again = g2.execute(q(min_trim))
+    assert_valid_trim(qc, full, again.rows())
+    if total_order:
+        assert again.rows() == got.rows()
+    assert again.stats.num_groups_limit_reached == got.stats.num_groups_limit_reached
+    g2.destroy()
+
+
+def test_trim_after_num_groups_limit(big):
+    """numGroupsLimit first (docId order, numGroupsLimitReached), the trim among the admitted groups after it — GroupByOperator.java:113-133."""
+    g, o, _ = big
+    sql = "SELECT u, COUNT(*), SUM(m) FROM gpuBench GROUP BY u ORDER BY SUM(m) DESC, u LIMIT 10"
+    qc, qo = parse_sql(sql), parse_sql(sql)
+    for x in (qc, qo):
+        x.num_groups_limit = 5000
+        x.min_segment_group_trim_size = 100
+    gb, ob = g.execute(qc), o.execute(qo)
+    assert gb.rows() == ob.rows() and len(gb.rows()) == 100
+    assert gb.stats.num_groups_limit_reached == ob.stats.num_groups_limit_reached == 1
+
+
+def test_trim_refusals(segs):
+    g, _ = segs
+    for sql, flags in (("SELECT g1, COUNT(*) FROM gpuBench GROUP BY g1 ORDER BY COUNT(*) LIMIT 1", capi.QUERY_FLAG_NULL_HANDLING),
+                       ("SELECT g1, DISTINCTCOUNT(g2) FROM gpuBench GROUP BY g1 ORDER BY DISTINCTCOUNT(g2) LIMIT 1", 0)):
+        qc = parse_sql(sql)
+        qc.min_segment_group_trim_size = 1
+        qc.flags |= flags
+        with pytest.raises(capi.NativeError) as e:
+            g.execute(qc)
+        assert e.value.status == capi.PG_ERR_UNSUPPORTED
