@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--no-full-check", action="store_true",
                     help="skip the one full-size oracle run that checks the timed GPU result (about 4 s of CPU per 1e9 rows)")
     ap.add_argument("--no-variants", action="store_true", help="skip the north-star (2-key) variant of the default run")
+    ap.add_argument("--no-concurrency", action="store_true", help="skip the concurrent-callers block of the default run")
     ap.add_argument("--require-library-merge", action="store_true",
                     help="N > 1: exit non-zero when the library's own RCCL communicator cannot be created on every rank, instead of "
                          "falling back to the torch collective + host reduce")
@@ -285,6 +286,10 @@ def main():
             out["multi_gpu_validation"] = v
     if args.query == "cfg3" and rank == 0 and world == 1 and not args.no_variants:
         out["merge_world_of_one"] = world_of_one_merge(api, seg, qc, local_rank)
+    if args.query == "cfg3" and not args.no_variants and rank == 0 and world == 1 and not args.no_concurrency:
+        t_blocks = time.time()
+        out["concurrency"] = concurrency_block(api, args, bg_seg=seg, bg_sql=synth.QUERY_CFG3)
+        log(f"concurrency block {time.time() - t_blocks:.1f}s")
     if args.query == "cfg3" and not args.no_variants and rank == 0 and world == 1:
         # BASELINE configs 2 and 5 next to the headline (same timing discipline, their own segments): every default run carries them
         seg.destroy()
@@ -401,6 +406,69 @@ def world_of_one_merge(api, seg, qc, device):
     ms = ms[2:]
     return {"p50_ms": statistics.median(ms), "min_ms": min(ms), "max_ms": max(ms), "equals_unmerged_result": bool(same),
             "what": "pg_result_all_reduce, communicator of 1 rank, config 3 result (dense table of 100 groups x 2 accumulators + counts)"}
+
+
+def concurrency_block(api, args, bg_seg=None, bg_sql=None, threads=(1, 4, 16, 64), seconds=1.0):
+    """Many callers at once — the reference runs one worker thread per segment and query (BaseCombineOperator.java:97-142), the
+    boundary gives every (thread, device) pair its own stream: N NATIVE host threads (pinot_amd/csrc/synth/pg_callers.cpp: no
+    interpreter in the loop) call pg_query_exec on one segment for `seconds`; QPS, p50 and p99 per thread count for BASELINE config 2
+    (10^8 rows, a 62 us kernel), the star-tree route of config 5 (launch-bound) and config 3 at 10^8 rows (a 0.15 ms kernel); then 16
+    callers of each again while ONE more thread loops the headline's 10^9-row query (`bg_seg`) in the background."""
+    import ctypes as C
+    import numpy as np
+    from pinot_amd import capi, startree, synth
+    from pinot_amd.executor import NativeSegment
+    from pinot_amd.query import CQuery, parse_sql
+    lib = synth.synth_lib()
+    if lib is None or not hasattr(lib, "pgs_concurrent_callers"):
+        return {"skipped": "libpinot_synth.so lacks pgs_concurrent_callers"}
+    fn = lib.pgs_concurrent_callers
+    fn.restype = C.c_double
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int64,
+                   C.POINTER(C.c_int64), C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+    exec_addr = C.cast(api.f("query_exec"), C.c_void_p).value
+    free_addr = C.cast(api.f("result_free"), C.c_void_p).value
+    docs = min(args.docs, 100_000_000)
+    parent = synth.generate_segment(400_000, segment_index=0, columns=list(synth.CFG5_COLUMNS), native=False)
+    startree.add_star_tree(parent, ["h1", "h2", "h3", "h4"], [("COUNT", "*"), ("DISTINCTCOUNTHLL", "u")], max_leaf_records=10000)
+    q5 = parse_sql(synth.QUERY_CFG5)
+    q5.flags |= capi.QUERY_FLAG_FINAL_DISTINCT
+    workloads = [("cfg2_1e8", NativeSegment(api, synth.generate_segment(docs, columns=["r_int"])), parse_sql(synth.QUERY_CFG2)),
+                 ("cfg5_star_tree", NativeSegment(api, parent), q5),
+                 ("cfg3_1e8", NativeSegment(api, synth.generate_segment(docs, columns=synth.CFG3_COLUMNS)), parse_sql(synth.QUERY_CFG3))]
+    cap = 1 << 20
+    lat = np.empty(cap, dtype=np.float32)
+    bg_cq = CQuery(parse_sql(bg_sql)) if bg_seg is not None else None
+
+    def run(seg, cq, n, background):
+        n_done, bg_done, err = C.c_int64(), C.c_int64(), C.c_int32()
+        window = fn(exec_addr, free_addr, seg.handle, C.cast(cq.ptr(), C.c_void_p), n, 0.25, seconds, lat.ctypes.data, cap, C.byref(n_done),
+                    bg_seg.handle if background else None, C.cast(bg_cq.ptr(), C.c_void_p) if background else None, C.byref(bg_done), C.byref(err))
+        if window < 0:
+            return {"threads": n, "error": int(err.value)}
+        v = np.sort(lat[:min(n_done.value, cap)])
+        r = {"threads": n, "qps": n_done.value / window, "p50_ms": float(v[len(v) // 2]) if len(v) else None,
+             "p99_ms": float(v[min(len(v) - 1, int(len(v) * 0.99))]) if len(v) else None, "calls": int(n_done.value)}
+        if background:
+            r["background_scans_per_s"] = bg_done.value / window
+        return r
+
+    out = {"how": f"native caller threads, {seconds:.1f} s per point after 0.25 s warm-up, one GPU, one segment per workload; "
+                  "latency = pg_query_exec call to return", "workloads": {}}
+    for name, seg, qc in workloads:
+        cq = CQuery(qc)
+        points = [run(seg, cq, n, False) for n in threads]
+        w = {"query": " ".join(str(x) for x in (qc.group_by, [a.function for a in qc.aggregations])), "points": points}
+        one = next((p for p in points if p.get("threads") == 1 and "qps" in p), None)
+        sixteen = next((p for p in points if p.get("threads") == 16 and "qps" in p), None)
+        if one and sixteen:
+            w["qps_16_over_1"] = sixteen["qps"] / one["qps"]
+        if bg_seg is not None:
+            w["with_1e9_row_scan_in_background"] = run(seg, cq, 16, True)
+        out["workloads"][name] = w
+    for _, seg, _ in workloads:
+        seg.destroy()
+    return out
 
 
 def extra_block(api, args, query, docs, bytes_per_row, columns, sql):

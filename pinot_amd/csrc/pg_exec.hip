@@ -5,7 +5,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <cmath>
 
 #include "pg_internal.hpp"
@@ -527,14 +530,21 @@ static void stream_wait(ThreadCtx& ctx, const CancelToken* c) {
   if (!c) {
     // short queries: poll for a while before blocking — a blocking wait is woken by an interrupt, microseconds after the stream drained
     // (config 2 is a 62 us kernel; PG_NO_SPIN_WAIT is the A/B knob)
+    // At most four callers poll at a time: with 64 callers every one of them polling (hipStreamQuery takes the runtime's locks, and the
+    // pollers outnumber the cores) 16.9 k queries/s at 16 callers fell to 5.4 k at 64 with a p99 of 80 ms (profiles/r05_concurrency.txt);
+    // the others block at once and are woken by the interrupt.
+    static std::atomic<int> pollers{0};
     const bool no_spin = knobs().no_spin_wait;
-    if (!no_spin) {
+    if (!no_spin && pollers.fetch_add(1, std::memory_order_acq_rel) < 4) {
       const double until = now_ms() + 0.3;
       do {
         const hipError_t e = hipStreamQuery(ctx.stream);
-        if (e == hipSuccess) return;
-        if (e != hipErrorNotReady) PG_HIP(e);
+        if (e == hipSuccess) { pollers.fetch_sub(1, std::memory_order_acq_rel); return; }
+        if (e != hipErrorNotReady) { pollers.fetch_sub(1, std::memory_order_acq_rel); PG_HIP(e); }
       } while (now_ms() < until);
+      pollers.fetch_sub(1, std::memory_order_acq_rel);
+    } else if (!no_spin) {
+      pollers.fetch_sub(1, std::memory_order_acq_rel);
     }
     PG_HIP(hipStreamSynchronize(ctx.stream));
     return;
@@ -879,7 +889,44 @@ std::unique_ptr<Result> execute_query_plain(Segment& seg, const pg_query& q, con
   return execute_query_impl(seg, q, cancel, ExecOptions());
 }
 
+// Per-device admission: at most `max_inflight` queries between submission and result on one GPU, the others wait on a condition
+// variable (no polling).  A query of this path fills the whole GPU, so throughput peaks at ~4 callers (profiles/r05_concurrency.txt:
+// config 2 17.3 k queries/s at 4 callers, 16.7 k at 16); at 64 callers — more than the host has cores for the runtime's waits — it fell to
+// 5.3 k queries/s with a p99 of 78 ms.  The reference bounds its workers the same way (a fixed pool of query worker threads,
+// BaseCombineOperator.java:97-142 runs at most maxExecutionThreads tasks per query).  PG_MAX_INFLIGHT (default 16; <= 0: no bound).
+namespace {
+struct Admission {   // first come, first served, ONE wake-up per finished query: a plain counter + notify_one starved callers (p99 84 ms
+  std::mutex mu;     // next to a p50 of 0.8 ms at 64 callers), tickets + notify_all woke every sleeper per query (16.6 k -> 7.3 k queries/s)
+  int inflight = 0;
+  struct Waiter { std::condition_variable cv; bool go = false; };
+  std::deque<Waiter*> queue;
+};
+Admission g_admission[PG_MAX_DEVICES];
+struct AdmissionGuard {
+  Admission* a = nullptr;
+  AdmissionGuard(int device, int limit) {
+    if (limit <= 0 || device < 0 || device >= PG_MAX_DEVICES) return;
+    a = &g_admission[device];
+    std::unique_lock<std::mutex> lk(a->mu);
+    if (a->inflight < limit && a->queue.empty()) { a->inflight++; return; }
+    Admission::Waiter w;
+    a->queue.push_back(&w);
+    w.cv.wait(lk, [&] { return w.go; });   // the finishing query handed its slot over (inflight stays as it was)
+  }
+  ~AdmissionGuard() {
+    if (!a) return;
+    std::lock_guard<std::mutex> lk(a->mu);
+    if (a->queue.empty()) { a->inflight--; return; }
+    Admission::Waiter* w = a->queue.front();
+    a->queue.pop_front();
+    w->go = true;
+    w->cv.notify_one();
+  }
+};
+}  // namespace
+
 static std::unique_ptr<Result> execute_query_impl(Segment& seg, const pg_query& q, const CancelToken* cancel, const ExecOptions& opt) {
+  AdmissionGuard admitted(seg.device, knobs().max_inflight);
   const double t0 = now_ms();
   if (q.n_aggregations <= 0 || !q.aggregations) fail(PG_ERR_INVALID_ARGUMENT, "query has no aggregation");
   check_cancel(cancel, nullptr);
