@@ -22,6 +22,7 @@ import java.util.TreeMap;
 import java.util.concurrent.ExecutionException;
 import java.util.concurrent.ExecutorService;
 import java.util.concurrent.Future;
+import java.util.concurrent.locks.ReentrantLock;
 import org.apache.pinot.core.common.Operator;
 import org.apache.pinot.core.operator.blocks.results.BaseResultsBlock;
 import org.apache.pinot.core.operator.combine.GroupByCombineOperator;
@@ -29,6 +30,12 @@ import org.apache.pinot.core.query.request.context.QueryContext;
 
 public class GpuGroupByCombineOperator extends GroupByCombineOperator {
   private static final String EXPLAIN_NAME = "GPU_COMBINE_GROUP_BY";
+
+  // One cross-GPU merge at a time per server: the communicators are per device and server-wide, pg_result_all_reduce keeps per-communicator
+  // state (probe, scratch) and every rank must enter the collectives of ONE query in the same order — two queries reducing at once would
+  // interleave them differently on different ranks, which RCCL leaves as a hang (ADVICE r4; the library now also fails loudly when a
+  // communicator is entered twice: pg_comm.cpp).  Held from the first submit until every rank's call has returned.
+  private static final ReentrantLock COLLECTIVE = new ReentrantLock();
 
   private final List<Operator> _segmentOperators;
   private final ExecutorService _workers;
@@ -59,10 +66,21 @@ public class GpuGroupByCombineOperator extends GroupByCombineOperator {
 
   @Override
   protected BaseResultsBlock getNextBlock() {
-    if (applies(_segmentOperators)) {
+    boolean folded = applies(_segmentOperators);
+    if (folded) {
       foldInLibrary();
     }
-    return super.getNextBlock();   // upserts the (now mostly empty) segment blocks into the IndexedTable, trims, orders
+    try {
+      return super.getNextBlock();   // upserts the (now mostly empty) segment blocks into the IndexedTable, trims, orders
+    } finally {
+      // a combine that stopped early (time-out, cancellation, another segment's exception) never asked some operators for their block:
+      // their adopted native results — HBM tables included — are freed here, not leaked (ADVICE r4)
+      if (folded) {
+        for (Operator operator : _segmentOperators) {
+          ((GpuGroupByOperator) operator).releaseAdopted();
+        }
+      }
+    }
   }
 
   private void foldInLibrary() {
@@ -85,14 +103,36 @@ public class GpuGroupByCombineOperator extends GroupByCombineOperator {
     GpuInstancePlanMaker maker = GpuInstancePlanMaker.current();
     int n = _segmentOperators.size();
     GpuGroupByOperator[] ops = new GpuGroupByOperator[n];
+    // one worker task per segment, as BaseCombineOperator runs them (BaseCombineOperator.java:97-142): the segments' queries overlap on
+    // their GPUs' streams; every task is waited for before anything is thrown, so no native call outlives this method
+    List<Future<Long>> executions = new ArrayList<>(n);
     for (int i = 0; i < n; i++) {
       ops[i] = (GpuGroupByOperator) _segmentOperators.get(i);
-      results[i] = ops[i].execute();   // 0: refused at run time (hash bucket overflow) — that operator answers with its Java plan
+      GpuGroupByOperator op = ops[i];
+      executions.add(_workers.submit(op::execute));   // 0: refused at run time (hash bucket overflow) — that operator answers with its Java plan
+    }
+    RuntimeException failed = null;
+    for (int i = 0; i < n; i++) {
+      try {
+        results[i] = executions.get(i).get();
+      } catch (ExecutionException e) {
+        if (failed == null) {
+          failed = e.getCause() instanceof RuntimeException ? (RuntimeException) e.getCause() : new RuntimeException(e.getCause());
+        }
+      } catch (InterruptedException e) {
+        Thread.currentThread().interrupt();
+        if (failed == null) {
+          failed = new RuntimeException(e);
+        }
+      }
+    }
+    if (failed != null) {
+      throw failed;   // (the caller frees what did come back)
     }
     // tables of one GPU fold into the first table of that GPU; a table the library refuses to fold stays a head of its own
     Map<Integer, List<Integer>> headsOfDevice = new TreeMap<>();
     for (int i = 0; i < n; i++) {
-      if (results[i] == 0) {
+      if (results[i] == 0 || !ops[i].tableKept()) {   // refused, or answered without a device table: merges by values below
         continue;
       }
       List<Integer> heads = headsOfDevice.computeIfAbsent(ops[i].device(), d -> new ArrayList<>());
@@ -123,25 +163,47 @@ public class GpuGroupByCombineOperator extends GroupByCombineOperator {
     if (onePerDevice) {
       List<Integer> ranks = new ArrayList<>();
       List<Future<?>> calls = new ArrayList<>();
-      for (Map.Entry<Integer, List<Integer>> e : headsOfDevice.entrySet()) {
-        int head = e.getValue().get(0);
-        long comm = maker.communicatorOf(e.getKey());
-        ranks.add(head);
-        calls.add(_workers.submit(() -> PinotGpu.resultAllReduce(results[head], comm)));
-      }
       boolean reduced = true;
-      for (Future<?> call : calls) {
-        try {
-          call.get();
-        } catch (ExecutionException e) {
-          if (!(e.getCause() instanceof UnsupportedOperationException)) {   // the refusal is collective: every rank threw it
-            throw new RuntimeException(e.getCause());
-          }
-          reduced = false;
-        } catch (InterruptedException e) {
-          Thread.currentThread().interrupt();
-          throw new RuntimeException(e);
+      RuntimeException collectiveFailed = null;
+      COLLECTIVE.lock();
+      try {
+        for (Map.Entry<Integer, List<Integer>> e : headsOfDevice.entrySet()) {
+          int head = e.getValue().get(0);
+          long comm = maker.communicatorOf(e.getKey());
+          ranks.add(head);
+          calls.add(_workers.submit(() -> PinotGpu.resultAllReduce(results[head], comm)));
         }
+        boolean interrupted = false;
+        for (Future<?> call : calls) {   // EVERY rank's call is waited for — through interrupts too — before the lock goes and before anything is thrown
+          for (;;) {
+            try {
+              call.get();
+              break;
+            } catch (ExecutionException e) {
+              if (!(e.getCause() instanceof UnsupportedOperationException)) {   // the refusal is collective: every rank threw it
+                if (collectiveFailed == null) {
+                  collectiveFailed = new RuntimeException(e.getCause());
+                }
+              }
+              reduced = false;
+              break;
+            } catch (InterruptedException e) {
+              interrupted = true;   // the ranks are inside a collective: leaving now would strand them (and the communicators)
+            }
+          }
+        }
+        if (interrupted) {
+          Thread.currentThread().interrupt();
+          reduced = false;
+          if (collectiveFailed == null) {
+            collectiveFailed = new RuntimeException(new InterruptedException("interrupted during the cross-GPU merge"));
+          }
+        }
+      } finally {
+        COLLECTIVE.unlock();
+      }
+      if (collectiveFailed != null) {
+        throw collectiveFailed;
       }
       if (reduced) {
         for (int r = 1; r < ranks.size(); r++) {

@@ -44,6 +44,7 @@ public class GpuGroupByOperator extends BaseOperator<BaseResultsBlock> {
   private long _adopted;
   private boolean _folded;
   private boolean _refused;
+  private boolean _tableKept;   // the result in hand was executed with QUERY_FLAG_KEEP_DEVICE_TABLE: the library can fold it (pg_result_merge)
 
   public GpuGroupByOperator(IndexSegment segment, QueryContext queryContext, long segmentHandle, NativeQuery nativeQuery,
       Supplier<Operator> fallback) {
@@ -84,7 +85,25 @@ public class GpuGroupByOperator extends BaseOperator<BaseResultsBlock> {
     long cancel = PinotGpu.cancelCreate();
     GpuCancellation.register(Thread.currentThread(), cancel);   // the query killer calls PinotGpu.cancelRequest(token) when it interrupts
     try {
-      long result = PinotGpu.queryExec(_segmentHandle, _nativeQuery.address(), cancel);   // EarlyTerminationException when cancelled
+      long result;
+      try {
+        result = PinotGpu.queryExec(_segmentHandle, _nativeQuery.address(), cancel);   // EarlyTerminationException when cancelled
+        _tableKept = _nativeQuery.keepsDeviceTable();
+      } catch (UnsupportedOperationException keepRefused) {
+        // QUERY_FLAG_KEEP_DEVICE_TABLE is refused at run time for tables that do not merge element-wise (hashed key spaces, key spaces
+        // beyond numGroupsLimit, multi-value tables beyond the limit: pg_exec.hip) — shapes the GPU answers perfectly well WITHOUT the flag.
+        // Run the same query again without it; the result then merges by values in the unchanged combine loop (ADVICE r4).
+        if (!_nativeQuery.keepsDeviceTable()) {
+          throw keepRefused;
+        }
+        try (NativeQuery plain = NativeQuery.from(_queryContext, 0)) {
+          if (plain == null) {
+            throw keepRefused;
+          }
+          result = PinotGpu.queryExec(_segmentHandle, plain.address(), cancel);
+          _tableKept = false;
+        }
+      }
       PinotGpu.resultStats(result, _stats);
       return result;
     } catch (UnsupportedOperationException e) {   // run-time PG_ERR_UNSUPPORTED: getNextBlock answers with the segment's default plan
@@ -94,6 +113,19 @@ public class GpuGroupByOperator extends BaseOperator<BaseResultsBlock> {
       GpuCancellation.unregister(Thread.currentThread());
       PinotGpu.cancelDestroy(cancel);
       _nativeQuery.close();
+    }
+  }
+
+  /** Whether the result execute() returned last kept its dense table in HBM (only such results enter pg_result_merge / _all_reduce). */
+  boolean tableKept() {
+    return _tableKept;
+  }
+
+  /** Frees a result adopted for a getNextBlock that never came (the combine stopped early: time-out, cancellation, another segment's failure). */
+  void releaseAdopted() {
+    if (_adopted != 0) {
+      PinotGpu.resultFree(_adopted);
+      _adopted = 0;
     }
   }
 

@@ -36,10 +36,19 @@ public final class NativeQuery implements AutoCloseable {
   // multi-value columns)
   private static final int FLAG_NULL_HANDLING = 0x40;
 
-  private final long _address;
+  private static final int FLAG_KEEP_DEVICE_TABLE = 0x4;   // PG_QUERY_FLAG_KEEP_DEVICE_TABLE
 
-  private NativeQuery(long address) {
+  private final long _address;
+  private final int _flags;
+
+  private NativeQuery(long address, int flags) {
     _address = address;
+    _flags = flags;
+  }
+
+  /** The record asked for the dense accumulator table to stay in HBM with the result (GpuGroupByCombineOperator's library merge). */
+  public boolean keepsDeviceTable() {
+    return (_flags & FLAG_KEEP_DEVICE_TABLE) != 0;
   }
 
   public long address() {
@@ -96,7 +105,7 @@ public final class NativeQuery implements AutoCloseable {
     if (q.getFilter() != null && !putFilter(b, q.getFilter())) {
       return null;
     }
-    return new NativeQuery(PinotGpu.queryParse(b, b.position()));
+    return new NativeQuery(PinotGpu.queryParse(b, b.position()), extraFlags);
   }
 
   /** {kind, index, ascending, nullsLast} per ORDER BY expression (pg_order_by), or null when the query has none or one the record cannot carry. */

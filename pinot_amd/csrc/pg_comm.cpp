@@ -10,6 +10,8 @@
 // touch it and the library has no link-time dependency on RCCL.
 #include <dlfcn.h>
 
+#include <atomic>
+
 #include "pg_internal.hpp"
 
 namespace pg {
@@ -85,6 +87,19 @@ struct Comm {
   // the probe, out and back: ncclMax over {sig, -sig, largest per-doc |value| of an int64 SUM, digit sums present, a rank refuses
   // (IEEE-double SUM)}; ncclSum over {full-scan entries, total docs}
   int64_t probe[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // One pg_result_all_reduce at a time per communicator: `probe` and `scratch` are per-communicator state, and two merges entering at
+  // once would enqueue their collectives in different orders on different ranks (a hang in RCCL).  The CALLER serialises whole merges
+  // across all ranks (GpuGroupByCombineOperator's COLLECTIVE lock); a per-communicator lock here could only deadlock two of them
+  // against each other.  What the library does is refuse loudly instead of corrupting silently.
+  std::atomic<bool> busy{false};
+};
+struct CommBusy {
+  Comm& c;
+  explicit CommBusy(Comm& comm) : c(comm) {
+    if (c.busy.exchange(true, std::memory_order_acq_rel))
+      fail(PG_ERR_INVALID_ARGUMENT, "pg_result_all_reduce: the communicator of device %d is inside another merge (serialise the merges of one communicator set)", c.device);
+  }
+  ~CommBusy() { c.busy.store(false, std::memory_order_release); }
 };
 
 void comm_unique_id(void* out128) {
@@ -157,6 +172,7 @@ void result_all_reduce(Result& r, Comm& c) {
   if (!r.dev) fail(PG_ERR_INVALID_ARGUMENT, "pg_result_all_reduce needs a result executed with PG_QUERY_FLAG_KEEP_DEVICE_TABLE");
   DeviceTable& T = *r.dev;
   if (T.device != c.device) fail(PG_ERR_INVALID_ARGUMENT, "pg_result_all_reduce: result on device %d, communicator on device %d", T.device, c.device);
+  CommBusy in_use(c);
   use_device(T.device);
   hipStream_t stream = thread_stream(T.device);
   Rccl& R = rccl();

@@ -115,6 +115,8 @@ std::string dict_bytes(const ResultColumn& c, int32_t id, bool strip_padding) {
 std::vector<uint8_t> result_data_table_v4(const Result& r) {
   const int n_keys = (int)r.schema_keys.size(), n_aggs = (int)r.schema_aggs.size();
   if (n_aggs != (int)r.aggs.size()) fail(PG_ERR_INVALID_ARGUMENT, "result carries no schema (not produced by pg_query_exec)");
+  // the schema's dictionaries live in the segment's columns: a result outlives its segment, its data table cannot
+  if (r.schema_segment.expired()) fail(PG_ERR_INVALID_ARGUMENT, "pg_result_data_table_v4: the result's segment was destroyed (its dictionaries give the keys their values)");
   const int32_t n_rows = n_keys ? r.num_groups : 1;
   // ---- schema -------------------------------------------------------------------------------------------------------------------------
   std::vector<std::string> names;
@@ -122,7 +124,9 @@ std::vector<uint8_t> result_data_table_v4(const Result& r) {
   for (const ResultColumn& k : r.schema_keys) { names.push_back(k.name); types.push_back(key_type(k.data_type)); }
   for (int a = 0; a < n_aggs; a++) {
     const ResultColumn& c = r.schema_aggs[(size_t)a];
-    const bool count_star = c.function == PG_AGG_COUNT;
+    // CountAggregationFunction#getResultColumnName (:64-66): "count(*)" whatever the argument — unless null handling is on, where COUNT(col)
+    // counts the non-null values of col and keeps its argument: "count(col)"
+    const bool count_star = c.function == PG_AGG_COUNT && (!r.schema_null_handling || c.name == "*");
     names.push_back(count_star ? std::string("count(*)") : std::string(function_name(c.function)) + "(" + c.name + ")");
     switch (r.aggs[(size_t)a].kind) {
       case PG_RESULT_LONG:
@@ -311,6 +315,9 @@ std::vector<uint8_t> result_data_table_v4(const Result& r) {
   for (const std::string& s : names) schema.str(s);
   for (ColType t : types) schema.str(type_name(t));
   metadata.i32(0);
+  // every offset and length below is an int32 (DataTableImplV4's header): sizes are checked BEFORE they are narrowed
+  if ((uint64_t)13 * 4 + exceptions.size() + dictionary.size() + schema.size() + fixed.size() + var.size() + metadata.size() + 4 > 0x7FFFFFF0ull)
+    fail(PG_ERR_UNSUPPORTED, "data table beyond 2 GB");
   Out out;
   const int32_t header = 13 * 4;
   int32_t off = header;
@@ -329,7 +336,6 @@ std::vector<uint8_t> result_data_table_v4(const Result& r) {
   out.bytes(var.b.data(), var.size());
   out.i32((int32_t)metadata.size());
   out.bytes(metadata.b.data(), metadata.size());
-  if ((uint64_t)fixed.size() + var.size() > 0x7FFFFFF0ull) fail(PG_ERR_UNSUPPORTED, "data table beyond 2 GB");
   return std::move(out.b);
 }
 

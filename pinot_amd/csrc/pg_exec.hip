@@ -814,6 +814,8 @@ void fill_result_schema(Segment& seg, const pg_query& q, Result& r) {
       column_of(col && strcmp(col, "*") != 0 ? col : nullptr, res->schema_aggs[(size_t)a]);
       res->schema_aggs[(size_t)a].function = q.aggregations[a].function;
     }
+    res->schema_segment = seg.alive;
+    res->schema_null_handling = (q.flags & PG_QUERY_FLAG_NULL_HANDLING) != 0;
   }
 
 static std::unique_ptr<Result> execute_query_impl(Segment& seg, const pg_query& q, const CancelToken* cancel, const ExecOptions& opt);

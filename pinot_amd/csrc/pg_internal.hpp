@@ -147,6 +147,7 @@ struct Segment {
   int32_t total_docs = 0;
   int32_t n_tiles = 0;
   std::map<std::string, std::unique_ptr<Column>> columns;
+  std::shared_ptr<int> alive = std::make_shared<int>(1);   // results keep a weak reference: their schema points into the columns' host dictionaries
   uint64_t device_bytes = 0;
   std::mutex mu;
   std::unordered_map<std::string, std::shared_ptr<CompiledPlan>> plan_cache;
@@ -367,6 +368,8 @@ struct ResultColumn {
 };
 struct Result {
   std::vector<ResultColumn> schema_keys, schema_aggs;
+  std::weak_ptr<int> schema_segment;   // the segment whose dictionaries the schema points into (pg_result_data_table_v4 refuses once it is destroyed)
+  bool schema_null_handling = false;   // enableNullHandling: COUNT(col) keeps its argument in the column name (CountAggregationFunction.java:64-66)
   std::unique_ptr<DeviceTable> dev;    // PG_QUERY_FLAG_KEEP_DEVICE_TABLE
   int32_t num_groups = 0;
   std::vector<std::vector<int32_t>> group_dict_ids;

@@ -132,6 +132,7 @@ NULL_QUERIES = [
     "SELECT COUNT(*), SUM(m), AVG(m), MAX(m) FROM dt WHERE c > 1000",                      # one row of NULLs (and a 0)
     "SELECT gl, COUNT(*), SUM(u) FROM dt GROUP BY gl LIMIT 100",                           # null handling, no null anywhere: empty bitmaps
     "SELECT gi, COUNT(*) FROM dt WHERE c > 1000 GROUP BY gi LIMIT 100",                    # no rows
+    "SELECT gi, COUNT(m), COUNT(*), SUM(m) FROM dt GROUP BY gi LIMIT 100",                 # COUNT(col): "count(m)" in the schema, non-null values counted
 ]
 
 
@@ -149,7 +150,8 @@ def test_data_table_with_null_vectors(gpu_api):
         nr = s.execute_native(q, keep_device_table=False)
         got = nr.data_table_v4()
         block = nr.block()
-        names = list(q.group_by) + [("count(*)" if a.function == "COUNT" else f"{FN[a.function]}({a.column})") for a in q.aggregations]
+        # enableNullHandling: COUNT(col) keeps its argument in the column name (CountAggregationFunction.java:64-66)
+        names = list(q.group_by) + [("count(*)" if a.function == "COUNT" and not a.column else f"{FN.get(a.function, 'count')}({a.column})") for a in q.aggregations]
         types = [host.columns[g].data_type for g in q.group_by] + \
             ["LONG" if a.function == "COUNT" else ("DOUBLE" if a.function in ("SUM", "MIN", "MAX") else "OBJECT") for a in q.aggregations]
         rows = []
