@@ -70,6 +70,29 @@ extern "C" __global__ void __launch_bounds__(256) pg_column_int_range_kernel(con
   }
 }
 
+// Largest dictId of a bit-packed forward index (PinotDataBitSet layout: value i at bit i x bits, most significant bit first).  A forward
+// index whose width leaves room above the cardinality (7 bits, 100 values) can HOLD dictIds the dictionary does not have — a corrupt or
+// mismatched file; the reference would throw ArrayIndexOutOfBoundsException on the first such doc, the kernels here would index past a
+// dictionary or an LDS table.  Checked once, at registration: one pass over the column at HBM speed.
+extern "C" __global__ void __launch_bounds__(256) pg_column_max_dict_id_kernel(const uint8_t* __restrict__ data, int64_t n, int bits,
+                                                                                unsigned int* __restrict__ out) {
+  unsigned int mx = 0;
+  const uint64_t mask = (1ULL << bits) - 1ULL;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t bit = (uint64_t)i * (uint64_t)bits;
+    const uint8_t* p = data + (bit >> 3);   // (the buffer is padded by 64 bytes: the 8-byte window stays inside)
+    uint64_t w = 0;
+    for (int k = 0; k < 8; k++) w = (w << 8) | p[k];
+    const unsigned int v = (unsigned int)((w >> (64 - bits - (int)(bit & 7))) & mask);
+    mx = v > mx ? v : mx;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned int o = __shfl_xor(mx, off, 64);
+    mx = o > mx ? o : mx;
+  }
+  if ((threadIdx.x & 63) == 0 && mx) atomicMax(out, mx);
+}
+
 namespace pg {
 
 // every finite |value| < 2^fx_exp, fx_exp a multiple of 16 (so that segments with similar data choose the same scale and their
@@ -107,6 +130,16 @@ static void upload_fixed_bit(Segment& seg, Column& c, const uint8_t* src, uint64
   c.fwd_dev.upload(src, need);
   c.col_kind = PG_COL_FIXED_BIT;
   c.fwd_bytes_logical = need;
+  if (seg.total_docs > 0 && c.cardinality > 0 && (c.bits >= 31 || ((int64_t)1 << c.bits) > (int64_t)c.cardinality)) {   // room above the cardinality
+    DeviceBuffer out(4, true);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(2048, ((int64_t)seg.total_docs + 255) / 256));
+    hipLaunchKernelGGL(pg_column_max_dict_id_kernel, dim3(grid), dim3(256), 0, 0, c.fwd_dev.as<uint8_t>(), (int64_t)seg.total_docs, c.bits, out.as<unsigned int>());
+    PG_HIP(hipGetLastError());
+    unsigned int mx = 0;
+    PG_HIP(hipMemcpy(&mx, out.ptr, 4, hipMemcpyDeviceToHost));
+    if ((int64_t)mx >= (int64_t)c.cardinality)
+      fail(PG_ERR_INVALID_ARGUMENT, "forward index of %s holds dictId %u, the dictionary has %d values", c.name.c_str(), mx, c.cardinality);
+  }
 }
 
 static void parse_inverted_index(Segment& seg, Column& c, const uint8_t* inv, uint64_t len) {

@@ -8,7 +8,7 @@ from pinot_amd import capi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_LIB = os.path.join(ORACLE_DIR, "_build", "liboracle.so")
+ORACLE_LIB = os.environ.get("PO_ORACLE_LIB") or os.path.join(ORACLE_DIR, "_build", "liboracle.so")   # PO_ORACLE_LIB: the sanitizer build (tools/sanitize.sh)
 
 _api = None
 
