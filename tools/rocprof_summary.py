@@ -6,9 +6,14 @@ import sys
 
 db = sqlite3.connect(sys.argv[1])
 cur = db.cursor()
+# One row per (kernel, launch shape): the same kernel launched for two queries — pg_fast_i32range_p runs BASELINE config 3 (100 groups) and the
+# north-star variant (5 000 groups) in one bench run — differs in its dynamic LDS size / grid, and averaging the two under one name hid the
+# headline kernel's own duration.  `--by-name` gives the old one-row-per-name table.
+by_name = "--by-name" in sys.argv
+group = "name" if by_name else "name, lds_size, grid_x, workgroup_x"
 rows = list(cur.execute(
     "select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start), max(vgpr_count), "
-    "max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(grid_x), max(workgroup_x) from kernels group by name order by 3 desc"))
+    f"max(accum_vgpr_count), max(sgpr_count), max(lds_size), max(grid_x), max(workgroup_x) from kernels group by {group} order by 3 desc"))
 total = sum(r[2] for r in rows) or 1
 print(f"{'kernel':44s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'%':>6s} "
       f"{'vgpr':>5s} {'agpr':>5s} {'sgpr':>5s} {'lds':>7s} {'grid':>8s} {'wg':>5s}")
