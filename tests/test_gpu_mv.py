@@ -259,3 +259,15 @@ def test_distinctcountmv_over_a_raw_column_is_left_to_the_java_plan(raw_pair):
         with pytest.raises(capi.NativeError) as e:
             api_seg.execute("SELECT DISTINCTCOUNTMV(r1) FROM mvTable WHERE s1 = 1")
         assert e.value.status == capi.PG_ERR_UNSUPPORTED
+
+
+def test_the_doc_by_doc_walk_still_agrees(gpu_api, oracle_api, gpu_knobs):
+    """PG_MV_NO_WINDOWS: the entry-parallel scan leaves are off — the doc-by-doc walk answers every query alike (it stays the path of partial
+    tiles and of runs beyond 8 192 entries)."""
+    gpu_knobs(PG_MV_NO_WINDOWS="1")
+    host = mv.build(mv.make_rows(20_000, seed=77))
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    for sql in QUERIES:
+        assert g.execute(sql).rows() == o.execute(sql).rows(), sql
+    g.destroy()
+    o.destroy()
