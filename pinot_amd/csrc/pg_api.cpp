@@ -22,7 +22,7 @@ static void knobs_read(Knobs& k) {
   k.no_dense_fused = flag("PG_NO_DENSE_FUSED"); k.no_part_grid_clamp = flag("PG_NO_PART_GRID_CLAMP"); k.no_spin_wait = flag("PG_NO_SPIN_WAIT");
   k.trace_oct = flag("PG_TRACE_OCT"); k.no_tile_split = flag("PG_NO_TILE_SPLIT"); k.no_oct_exec = flag("PG_NO_OCT_EXEC");
   k.no_p2_simple = flag("PG_NO_P2_SIMPLE"); k.no_dense_count = flag("PG_NO_DENSE_COUNT"); k.no_direct_result = flag("PG_NO_DIRECT_RESULT");
-  k.trace_host = flag("PG_TRACE_HOST"); k.no_limit_prefix = flag("PG_NO_LIMIT_PREFIX"); k.no_device_trim = flag("PG_NO_DEVICE_TRIM");
+  k.trace_host = flag("PG_TRACE_HOST"); k.no_limit_prefix = flag("PG_NO_LIMIT_PREFIX"); k.no_device_trim = flag("PG_NO_DEVICE_TRIM"); k.no_fused_finish = flag("PG_NO_FUSED_FINISH");
   k.scan_wgs_per_cu = (int)num("PG_SCAN_WGS_PER_CU", 1); k.pipe_wgs_per_cu = (int)num("PG_PIPE_WGS_PER_CU", 1); k.wgs_per_cu = (int)num("PG_WGS_PER_CU", 1);
   k.p2_wgs_per_cu = (int)num("PG_P2_WGS_PER_CU", 4); k.dense_count_wgs = (int)num("PG_DENSE_COUNT_WGS", 1); k.tile_split_max = (int)num("PG_TILE_SPLIT_MAX", -1);
   k.hash_first_buckets = (int)num("PG_HASH_FIRST_BUCKETS", -1);

@@ -291,6 +291,11 @@ struct CompiledPlan {
   // 0: no trim.  Applied at result assembly (pg_exec.hip trim_groups), on the device first where the table allows (device_trim).
   std::vector<pg_order_by> order_by;
   int32_t trim_size = 0;
+  // result assembly, dense key spaces in which EVERY group exists (a star-tree's pre-aggregated docs, low-cardinality group-bys): the groups'
+  // dictIds per group-by column are a function of the plan alone — decoded once, copied afterwards (12 800 groups x 4 columns were ~20 us of the
+  // star-tree route's 55 us of assembly).  Filled under full_keys_once by the first result that needs them.
+  mutable std::once_flag full_keys_once;
+  mutable std::vector<std::vector<int32_t>> full_keys;
   int32_t exist_op = 0;              // accumulator whose value tells whether a group was touched
   bool raw_group = false;            // the single group-by column is a raw INT / LONG column: keys are values (hash group-by)
   std::vector<Column*> group_vdict;  // per group-by column: its virtual dictionary (raw column grouped through ids), or null
@@ -444,7 +449,7 @@ struct Knobs {
   int part_min = -1;
   // executor (pg_exec.hip)
   bool force_interpreter = false, no_scan_pipe = false, no_pipe = false, no_dense_fused = false, no_part_grid_clamp = false, no_spin_wait = false;
-  bool trace_oct = false, no_tile_split = false, no_oct_exec = false, no_p2_simple = false, no_dense_count = false, no_direct_result = false, trace_host = false, no_limit_prefix = false, no_device_trim = false;
+  bool trace_oct = false, no_tile_split = false, no_oct_exec = false, no_p2_simple = false, no_dense_count = false, no_direct_result = false, trace_host = false, no_limit_prefix = false, no_device_trim = false, no_fused_finish = false;
   int max_inflight = 16;   // PG_MAX_INFLIGHT: queries between submission and result per device (<= 0: unbounded)
   int scan_wgs_per_cu = 1, pipe_wgs_per_cu = 1, wgs_per_cu = 1, p2_wgs_per_cu = 4, dense_count_wgs = 1, tile_split_max = -1, hash_first_buckets = -1;
   int64_t exact_stats_max_docs = (int64_t)1 << 22;
