@@ -373,6 +373,8 @@ static bool uses_pipe_kernel(const CompiledPlan& P, int agg_mode) {
 }
 
 extern "C" void pg_trim_launch(const PgTrimArgs* args, int grid, hipStream_t stream);
+extern "C" void pg_trim_launch_keys(const PgTrimArgs* args, int grid, hipStream_t stream);
+extern "C" void pg_trim_launch_select(const PgTrimArgs* args, int grid, hipStream_t stream);
 typedef void (*QueryKernel)(const PgQueryPlan);
 static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char** name) {
   const bool agg = agg_mode != PG_AGG_NONE;
@@ -632,6 +634,11 @@ struct ExecOptions {
   int64_t doc_limit = 0;
   HostTable* raw_out = nullptr;
   const LimitAdmission* admit = nullptr;
+  // the same admission without the tables leaving HBM (dense tables without auxiliary state): the prefix pass turns its first-docId row into
+  // selection keys on the device and reports only how many groups it found; the pass over the segment then selects the `limit` groups with
+  // the smallest keys and copies their rows alone (pg_kernels_trim.hip; 10^6 groups: 2 x 8 MB + 8 MB of tables -> 2.4 MB)
+  int64_t* prefix_groups_out = nullptr;
+  int32_t admit_on_device = 0;   // numGroupsLimit to apply with the keys the prefix pass left in the thread's context
 };
 static void assemble_result(Result& res_out, const CompiledPlan& P, int32_t n_group_by, int32_t n_aggregations, HostTable& H);
 static void hll_small_range_table(int log2m, std::vector<long long>& t, double& alpha_mm);
@@ -974,23 +981,29 @@ static std::unique_ptr<Result> execute_limit_by_prefix(Segment& seg, const pg_qu
   HostTable raw;
   float prefix_ms = 0;
   bool decided = false;
+  // dense tables without auxiliary state: nothing but the admitted groups' rows leaves HBM (ExecOptions::admit_on_device)
+  const bool on_device = pm->dev.n_aux == 0 && pp->dev.n_aux == 0 && !knobs().no_device_trim && (int64_t)limit * 2 + 64 <= G;
   for (int64_t np = std::max<int64_t>(knobs().limit_prefix_min_docs, 16 * (int64_t)limit); np * 4 <= (int64_t)P.space_docs; np *= 8) {
     np = (np + PG_WAVE_DOCS - 1) / PG_WAVE_DOCS * PG_WAVE_DOCS;
     ExecOptions o;
     o.doc_limit = np;
-    o.raw_out = &raw;
+    int64_t found = 0;
+    if (on_device) o.prefix_groups_out = &found;
+    else o.raw_out = &raw;
     auto r = execute_query_impl(seg, qp, cancel, o);
     prefix_ms += r->stats.device_ms_total;
-    const int64_t* first = raw.table.data() + (size_t)pp->first_doc_op * (size_t)G;
-    int64_t found = 0;
-    for (int64_t g = 0; g < G && found < limit; g++) found += first[g] != ident;
+    if (!on_device) {
+      const int64_t* first = raw.table.data() + (size_t)pp->first_doc_op * (size_t)G;
+      for (int64_t g = 0; g < G && found < limit; g++) found += first[g] != ident;
+    }
     if (trace) fprintf(stderr, "[pg] limit by prefix: %lld docs hold %s%lld groups (limit %d)\n", (long long)np, found >= limit ? ">= " : "", (long long)found, limit);
     if (found >= limit) { decided = true; break; }
   }
   if (!decided) return nullptr;
-  LimitAdmission adm{raw.table.data() + (size_t)pp->first_doc_op * (size_t)G, limit};
+  LimitAdmission adm{on_device ? nullptr : raw.table.data() + (size_t)pp->first_doc_op * (size_t)G, limit};
   ExecOptions o;
-  o.admit = &adm;
+  if (on_device) o.admit_on_device = limit;
+  else o.admit = &adm;
   auto res = execute_query_impl(seg, qm, cancel, o);
   res->stats.device_ms_aggregate += prefix_ms;   // the prefix pass is part of the query's device time
   res->stats.device_ms_total += prefix_ms;
@@ -1565,7 +1578,41 @@ static std::unique_ptr<Result> execute_query_impl(Segment& seg, const pg_query& 
     // their rows are copied.  Everything else copies the table and trims at assembly.
     int trim_cap = 0, trim_key_op = -1;
     bool trim_whole_class = false;
-    if (P.trim_size > 0 && !hashed && D.n_aux == 0 && P.first_doc_op < 0 && !opt.admit && !opt.raw_out && !keep_table && !direct_out &&
+    const int tgrid_adm = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)num_cus() * 4, ((int64_t)D.n_groups + 1023) / 1024));
+    if (opt.prefix_groups_out) {   // prefix pass of the admission: keys of its first-docId row stay in the context, the count of its groups comes back
+      ThreadCtx::grow(ctx.trim_keys, (size_t)D.n_groups * 8);
+      if (!ctx.trim_ctrl.ptr) ctx.trim_ctrl.alloc((size_t)PG_TRIM_CTRL_WORDS * 4, true);
+      PG_HIP(hipMemsetAsync(ctx.trim_ctrl.ptr, 0, (size_t)PG_TRIM_CTRL_WORDS * 4, ctx.stream));
+      PgTrimArgs ta;
+      memset(&ta, 0, sizeof(ta));
+      ta.table = ctx.final_table.as<int64_t>();
+      ta.G = D.n_groups;
+      ta.n_ops = D.n_ops;
+      ta.exist_op = P.first_doc_op;
+      ta.exist_ident = pg_acc_identity(PG_ACC_MIN, 0);
+      ta.key_op = P.first_doc_op;
+      ta.key_mult = 1; ta.key_card = 1;
+      ta.keys = ctx.trim_keys.as<uint64_t>();
+      ta.ctrl = ctx.trim_ctrl.as<uint32_t>();
+      pg_trim_launch_keys(&ta, tgrid_adm, ctx.stream);
+      PG_HIP(hipGetLastError());
+      if (profile) PG_HIP(hipEventRecord(ctx.ev[2], ctx.stream));
+      PG_HIP(hipMemcpyAsync(host_out, ctx.trim_ctrl.ptr, 8, hipMemcpyDeviceToHost, ctx.stream));
+      PG_HIP(hipMemcpyAsync(host_out + 1, ctx.final_table.as<int64_t>() + n_out, (size_t)PG_MAX_STATS * 8, hipMemcpyDeviceToHost, ctx.stream));
+    }
+    bool admission_select = false, admission_own = false;
+    if (opt.admit_on_device > 0 && !hashed && D.n_aux == 0 && !keep_table) {   // the pass over the segment: rows of the `limit` smallest keys
+      admission_select = true;
+      trim_cap = opt.admit_on_device;
+    }
+    // a one-pass plan that carries its own MIN(docId) row (no prefix pass applied): the same selection over that row — the host's nth_element
+    // over 10^6 first docIds was 8.6 ms of a 13.8 ms query, behind 24 MB of table copies (profiles/r05_num_groups_limit_latency.txt)
+    if (!admission_select && !opt.prefix_groups_out && !opt.admit && !opt.raw_out && P.first_doc_op >= 0 && !hashed && D.n_aux == 0 && !keep_table && !D.mv &&
+        !direct_out && !knobs().no_device_trim && (int64_t)P.num_groups_limit * 2 + 64 <= (int64_t)D.n_groups) {
+      admission_select = admission_own = true;
+      trim_cap = P.num_groups_limit;
+    }
+    if (!admission_select && !opt.prefix_groups_out && P.trim_size > 0 && !hashed && D.n_aux == 0 && P.first_doc_op < 0 && !opt.admit && !opt.raw_out && !keep_table && !direct_out &&
         P.exist_op >= 0 && !D.mv && !knobs().no_device_trim && (int64_t)D.n_groups >= 8 * ((int64_t)P.trim_size + 4096)) {
       const pg_order_by& ob = P.order_by[0];
       bool ok = true;
@@ -1584,32 +1631,47 @@ static std::unique_ptr<Result> execute_query_impl(Segment& seg, const pg_query& 
         trim_cap = P.trim_size + 4096;
       }
     }
-    if (trim_cap > 0) {
-      const pg_order_by& ob = P.order_by[0];
+    if (opt.prefix_groups_out) {
+      // (nothing of the table is copied: the caller only wants the count)
+    } else if (trim_cap > 0) {
       ThreadCtx::grow(ctx.trim_keys, (size_t)D.n_groups * 8);
       ThreadCtx::grow(ctx.trim_out, (size_t)(D.n_ops + 1) * (size_t)trim_cap * 8);
       if (!ctx.trim_ctrl.ptr) ctx.trim_ctrl.alloc((size_t)PG_TRIM_CTRL_WORDS * 4, true);
-      PG_HIP(hipMemsetAsync(ctx.trim_ctrl.ptr, 0, (size_t)PG_TRIM_CTRL_WORDS * 4, ctx.stream));
       PgTrimArgs ta;
       memset(&ta, 0, sizeof(ta));
       ta.table = ctx.final_table.as<int64_t>();
       ta.G = D.n_groups;
       ta.n_ops = D.n_ops;
-      ta.exist_op = P.exist_op;
-      ta.exist_ident = pg_acc_identity(D.ops[P.exist_op].fn, 0);
-      ta.key_op = trim_key_op;
-      ta.descending = ob.ascending ? 0 : 1;
-      ta.key_mult = ob.kind == PG_ORDER_BY_GROUP_KEY ? D.gcols[ob.index].mult : 1;
-      ta.key_card = ob.kind == PG_ORDER_BY_GROUP_KEY ? P.group_cards[ob.index] : 1;
       ta.keys = ctx.trim_keys.as<uint64_t>();
       ta.ctrl = ctx.trim_ctrl.as<uint32_t>();
-      ta.k = P.trim_size;
       ta.cap = trim_cap;
-      ta.take_whole_tie_class = trim_whole_class ? 1 : 0;
       ta.out_table = ctx.trim_out.as<int64_t>();
       ta.out_gids = ctx.trim_out.as<int64_t>() + (size_t)D.n_ops * (size_t)trim_cap;
-      const int tgrid = (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)num_cus() * 4, ((int64_t)D.n_groups + 1023) / 1024));
-      pg_trim_launch(&ta, tgrid, ctx.stream);
+      const int tgrid = tgrid_adm;
+      if (admission_own) {      // keys = this table's own first-docId row
+        PG_HIP(hipMemsetAsync(ctx.trim_ctrl.ptr, 0, (size_t)PG_TRIM_CTRL_WORDS * 4, ctx.stream));
+        ta.exist_op = ta.key_op = P.first_doc_op;
+        ta.exist_ident = pg_acc_identity(PG_ACC_MIN, 0);
+        ta.key_mult = 1; ta.key_card = 1;
+        ta.k = trim_cap;
+        pg_trim_launch(&ta, tgrid, ctx.stream);
+      } else if (admission_select) {   // keys, histogram of their first byte and the group count are the prefix pass's (same thread, same stream)
+        ta.k = opt.admit_on_device;
+        ta.key_mult = 1; ta.key_card = 1;
+        pg_trim_launch_select(&ta, tgrid, ctx.stream);
+      } else {
+        const pg_order_by& ob = P.order_by[0];
+        PG_HIP(hipMemsetAsync(ctx.trim_ctrl.ptr, 0, (size_t)PG_TRIM_CTRL_WORDS * 4, ctx.stream));
+        ta.exist_op = P.exist_op;
+        ta.exist_ident = pg_acc_identity(D.ops[P.exist_op].fn, 0);
+        ta.key_op = trim_key_op;
+        ta.descending = ob.ascending ? 0 : 1;
+        ta.key_mult = ob.kind == PG_ORDER_BY_GROUP_KEY ? D.gcols[ob.index].mult : 1;
+        ta.key_card = ob.kind == PG_ORDER_BY_GROUP_KEY ? P.group_cards[ob.index] : 1;
+        ta.k = P.trim_size;
+        ta.take_whole_tie_class = trim_whole_class ? 1 : 0;
+        pg_trim_launch(&ta, tgrid, ctx.stream);
+      }
       PG_HIP(hipGetLastError());
       if (profile) PG_HIP(hipEventRecord(ctx.ev[2], ctx.stream));   // the selection is part of the query's device time
       // compact block | statistics | counters, where the whole table would have gone
@@ -1654,7 +1716,10 @@ static std::unique_ptr<Result> execute_query_impl(Segment& seg, const pg_query& 
     stream_wait(ctx, cancel);
     t_synced = now_ms();
     t_queued_at = t_queued;
-    if (trim_cap > 0) {
+    if (opt.prefix_groups_out) {
+      *opt.prefix_groups_out = (int64_t)reinterpret_cast<const uint32_t*>(host_out)[0];
+      memcpy(stats_host, host_out + 1, sizeof(stats_host));
+    } else if (trim_cap > 0) {
       const size_t block_words = (size_t)(D.n_ops + 1) * (size_t)trim_cap;
       const uint32_t* tc = reinterpret_cast<const uint32_t*>(host_out + block_words + PG_MAX_STATS);
       memcpy(stats_host, host_out + block_words, sizeof(stats_host));
@@ -1664,12 +1729,22 @@ static std::unique_ptr<Result> execute_query_impl(Segment& seg, const pg_query& 
         if (n_out) memcpy(table.data(), host_out, (size_t)n_out * 8);
       } else {
         const int64_t n_exist = tc[0];
-        const int64_t n_sel = trim_whole_class ? (int64_t)tc[5] + (int64_t)tc[2] : std::min<int64_t>(P.trim_size, n_exist);
-        // survivors in group-id order (the device appends them as its wavefronts come by)
-        std::vector<int32_t> perm((size_t)n_sel);
-        for (int64_t i = 0; i < n_sel; i++) perm[(size_t)i] = (int32_t)i;
+        const int64_t n_sel = trim_whole_class ? (int64_t)tc[5] + (int64_t)tc[2] : std::min<int64_t>(admission_select ? trim_cap : P.trim_size, n_exist);
+        // survivors in group-id order (the device appends them as its wavefronts come by): a two-pass 16-bit radix sort of their positions —
+        // std::sort with an indirect comparison took several milliseconds for the 100 000 groups of a default numGroupsLimit
         const int64_t* gsel = host_out + (size_t)D.n_ops * (size_t)trim_cap;
-        std::sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) { return gsel[x] < gsel[y]; });
+        std::vector<int32_t> perm((size_t)n_sel), tmp((size_t)n_sel);
+        for (int64_t i = 0; i < n_sel; i++) tmp[(size_t)i] = (int32_t)i;
+        for (int pass = 0; pass < 2; pass++) {
+          std::vector<uint32_t> count((size_t)65537, 0u);
+          const std::vector<int32_t>& src = pass == 0 ? tmp : perm;
+          std::vector<int32_t>& dst = pass == 0 ? perm : tmp;
+          const int shift = 16 * pass;
+          for (int64_t i = 0; i < n_sel; i++) count[(size_t)(((uint64_t)gsel[src[(size_t)i]] >> shift) & 0xFFFFu) + 1]++;
+          for (size_t b = 1; b <= 65536; b++) count[b] += count[b - 1];
+          for (int64_t i = 0; i < n_sel; i++) dst[count[(size_t)(((uint64_t)gsel[src[(size_t)i]] >> shift) & 0xFFFFu)]++] = src[(size_t)i];
+        }
+        perm.swap(tmp);   // (dense key spaces are below 2^31 groups: 32 bits of the group id order them)
         hash_keys_host.resize((size_t)n_sel);
         table.assign((size_t)n_sel * (size_t)D.n_ops, 0);
         for (int64_t i = 0; i < n_sel; i++) {
@@ -1737,6 +1812,18 @@ static std::unique_ptr<Result> execute_query_impl(Segment& seg, const pg_query& 
   H.full_scan_entries = P.full_scan_entries;
   H.total_docs = seg.total_docs;
   if (opt.admit) { H.admit_first = opt.admit->first; H.admit_limit = opt.admit->limit; }
+  if (opt.admit_on_device > 0) H.admit_limit = opt.admit_on_device;   // (the rows that came back ARE the admitted groups)
+  if (opt.prefix_groups_out) {   // the caller wanted the count only
+    if (profile) {
+      float a = 0, b = 0;
+      PG_HIP(hipEventElapsedTime(&a, ctx.ev[0], ctx.ev[1]));
+      PG_HIP(hipEventElapsedTime(&b, ctx.ev[1], ctx.ev[2]));
+      res->stats.device_ms_aggregate = a;
+      res->stats.device_ms_reduce = b;
+      res->stats.device_ms_total = a + b;
+    }
+    return res;
+  }
   if (opt.raw_out) {   // the caller wants the table, not groups (execute_limit_by_prefix)
     if (profile) {
       float a = 0, b = 0;
@@ -1849,7 +1936,7 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
     gids.reserve((size_t)std::min<int64_t>(G, 1 << 20));
     for (int64_t g = 0; g < G; g++) if (exists(g)) gids.push_back(g);
   }
-  const int64_t groups_limit = H.admit_first ? (int64_t)H.admit_limit : (int64_t)P.num_groups_limit;
+  const int64_t groups_limit = H.admit_limit > 0 ? (int64_t)H.admit_limit : (int64_t)P.num_groups_limit;
   bool limit_reached = n_group_by > 0 && (H.groups_found >= 0 ? H.groups_found : (int64_t)gids.size()) >= groups_limit;
   if (n_group_by > 0 && (int64_t)gids.size() > groups_limit) {
     // keep the numGroupsLimit groups whose first matching docId is smallest (= the keys the reference admits in docId order)

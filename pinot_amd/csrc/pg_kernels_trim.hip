@@ -126,9 +126,18 @@ extern "C" __global__ void __launch_bounds__(256) pg_trim_select_kernel(const Pg
   }
 }
 
-extern "C" void pg_trim_launch(const PgTrimArgs* args, int grid, hipStream_t stream) {
+// keys: one key per group + the first histogram; select: the seven remaining radix passes and the gather.  Two calls because the keys may come
+// from ANOTHER table than the rows (numGroupsLimit by a prefix pass, pg_exec.hip: the keys are the prefix's first docIds, the rows the segment's).
+extern "C" void pg_trim_launch_keys(const PgTrimArgs* args, int grid, hipStream_t stream) {
   const PgTrimArgs a = *args;
   hipLaunchKernelGGL(pg_trim_keys_kernel, dim3(grid), dim3(256), 0, stream, a);
+}
+extern "C" void pg_trim_launch_select(const PgTrimArgs* args, int grid, hipStream_t stream) {
+  const PgTrimArgs a = *args;
   for (int p = 1; p <= 7; p++) hipLaunchKernelGGL(pg_trim_pass_kernel, dim3(grid), dim3(256), 0, stream, a, p);
   hipLaunchKernelGGL(pg_trim_select_kernel, dim3(grid), dim3(256), 0, stream, a);
+}
+extern "C" void pg_trim_launch(const PgTrimArgs* args, int grid, hipStream_t stream) {
+  pg_trim_launch_keys(args, grid, stream);
+  pg_trim_launch_select(args, grid, stream);
 }

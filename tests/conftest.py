@@ -42,7 +42,10 @@ def gpu_knobs(monkeypatch, gpu_api):
     pg_options_reload; the previous environment is restored (and re-read) afterwards."""
     def set_knobs(**kv):
         for k, v in kv.items():
-            monkeypatch.setenv(k, str(v))
+            if v is None:            # flags are "variable present": None removes it
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, str(v))
         gpu_api.call("options_reload")
     yield set_knobs
     monkeypatch.undo()

@@ -275,4 +275,10 @@ def test_limit_by_prefix(gpu_api, oracle_api, gpu_knobs, pattern, limit):
     for q, want in zip(qs, rows):
         assert run(g, o, q, limit=limit, kernel="pg_part_group_by").rows() == want
     g.destroy()
+    # the admission on the host (tables copied, first docIds compared there) instead of the selection on the device
+    gpu_knobs(PG_NO_LIMIT_PREFIX=None, PG_NO_DEVICE_TRIM="1")
+    g = NativeSegment(gpu_api, host)
+    for q, want in zip(qs, rows):
+        assert run(g, o, q, limit=limit, kernel=expect).rows() == want
+    g.destroy()
     o.destroy()
