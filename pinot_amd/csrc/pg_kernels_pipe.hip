@@ -36,6 +36,13 @@ template <typename T> DEVFN const GAS T* sgpr_ptr(const void* ptr) {
   return (const GAS T*)(((uint64_t)hi << 32) | (uint64_t)lo);
 }
 
+// the tile's match word of this lane (PgQueryPlan::out_words), addressed SGPR base + 32-bit lane offset: a per-lane 64-bit address kept
+// across the main loop cost two vector registers the index-only kernels do not have (they spilled it)
+DEVFN void store_match_word(const void* out_words, int wt, int lane, uint32_t word) {
+  GAS uint32_t* tile = const_cast<GAS uint32_t*>(sgpr_ptr<uint32_t>((const uint8_t*)out_words + (size_t)wt * 256u));
+  *(GAS uint32_t*)((GAS uint8_t*)tile + (uint32_t)lane * 4u) = word;
+}
+
 template <int NG>
 __device__ __forceinline__ void fast_pipe_i32range_body(const PgQueryPlan& p) {
   extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
@@ -482,7 +489,7 @@ __device__ __forceinline__ void pipe_general_body(const PgQueryPlan& p) {
       if (HAS_INDEX || TAIL) issue_postings(wt_b + step);
       issue_values(wt_b, m_b, xb, gb);
       my_matched += (uint32_t)__popc(m_a);
-      if (p.out_words) reinterpret_cast<uint32_t*>(p.out_words)[(int64_t)wt_a * 64 + lane] = quad_to_lin(m_a, lane);
+      if (p.out_words) store_match_word(p.out_words, wt_a, lane, quad_to_lin(m_a, lane));
       aggregate(m_a, xa, ga);                                      // waits for values(a): values(b) and the next bitmaps keep travelling
       wt_a = wt_b + step;
       m_a = candidates(wt_a, tq) & tq;
@@ -490,7 +497,7 @@ __device__ __forceinline__ void pipe_general_body(const PgQueryPlan& p) {
       issue_values(wt_a, m_a, xa, ga);
       if (wt_b < n_wtiles_loop) {   // wave-uniform
         my_matched += (uint32_t)__popc(m_b);
-        if (p.out_words) reinterpret_cast<uint32_t*>(p.out_words)[(int64_t)wt_b * 64 + lane] = quad_to_lin(m_b, lane);
+        if (p.out_words) store_match_word(p.out_words, wt_b, lane, quad_to_lin(m_b, lane));
       }
       aggregate(m_b, xb, gb);
     }
@@ -653,6 +660,17 @@ __device__ __forceinline__ void pipe_wide_body(const PgQueryPlan& p) {
   // no GROUP BY: SUM / MIN / MAX / COUNT of the lane's docs stay in registers for the whole kernel and are folded once at the end (the one
   // group's few replica slots would take every lane's atomics: 44 % of 8 TB/s; folding per part across the wavefront: 33 %,
   // profiles/r04_o_variants_wide_100m.txt)
+  // DOUBLE values: the rows of the column's accumulators (-1: the query has none of that kind)
+  int wd_row_cnt = -1, wd_row_sum = -1, wd_row_min = -1, wd_row_max = -1;
+  if (DBL)
+    for (int o = 0; o < p.n_ops; o++) {
+      const PgAccOp op = p.ops[uniform(o)];
+      if (op.src < 0) wd_row_cnt = o;
+      else if (op.fn == PG_ACC_SUM) { if (op.limb == 0) wd_row_sum = o; }
+      else if (op.fn == PG_ACC_MIN) wd_row_min = o;
+      else wd_row_max = o;
+    }
+  wd_row_cnt = uniform(wd_row_cnt); wd_row_sum = uniform(wd_row_sum); wd_row_min = uniform(wd_row_min); wd_row_max = uniform(wd_row_max);
   int64_t lane_sum = 0, lane_min = INT64_MAX, lane_max = INT64_MIN;   // (DOUBLE values: order keys in lane_min / lane_max)
   int64_t lane_dig[4] = {0, 0, 0, 0};                                  // DOUBLE sums: the lane's digit sums
   uint32_t lane_cnt = 0;
@@ -677,7 +695,7 @@ __device__ __forceinline__ void pipe_wide_body(const PgQueryPlan& p) {
           const uint32_t q = ((mg >> (4 * k)) & 0xFu) ? (uint32_t)(kk * 64 + lane) : 0u;
           decode_packed_quad_mid(g[gi][k], q, bits, mask, d);
 #pragma unroll
-          for (int i = 0; i < 4; i++) slot[k][i] += d[i] * mult;   // < 65536 slots: the planner's bound on n_groups x replicas
+          for (int i = 0; i < 4; i++) slot[k][i] += __umul24(d[i], mult);   // < 65536 slots (the planner's bound on n_groups x replicas): a 24-bit multiply-add
         }
       }
     }
@@ -708,11 +726,11 @@ __device__ __forceinline__ void pipe_wide_body(const PgQueryPlan& p) {
       const uint32_t mh = (bh & 0xFFFFFu) | (e ? (1u << 20) : 0u);
       const int sft = (e ? e - 1075 : -1074) - fxq;             // X = m * 2^sft
       j0 = sft >> 5;                                            // floor(sft / 32): digit j0 holds m's bit 0 at bit (sft & 31)
-      const uint32_t r = (32u - ((uint32_t)sft & 31u)) & 31u;   // window offset inside a dword: t mod 32 with t = 32 j - sft
-      const bool whole = r == 0u;
-      w[0] = whole ? ml : __builtin_amdgcn_alignbit(ml, 0u, r);
-      w[1] = whole ? mh : __builtin_amdgcn_alignbit(mh, ml, r);
-      w[2] = whole ? 0u : __builtin_amdgcn_alignbit(0u, mh, r);
+      const uint32_t sl = (uint32_t)sft & 31u;                  // the windows are (0 : mh : ml) << sl, cut at dword boundaries
+      const uint64_t low = (((uint64_t)mh << 32) | (uint64_t)ml) << sl;
+      w[0] = (uint32_t)low;
+      w[1] = (uint32_t)(low >> 32);
+      w[2] = (mh >> 1) >> (31u - sl);                           // mh >> (32 - sl) without the shift by 32 (sl = 0: nothing spills over)
       neg = (uint64_t)(int64_t)((int32_t)bh >> 31);             // all ones for negative values
     };
     if (NG == 0) {
@@ -752,6 +770,45 @@ __device__ __forceinline__ void pipe_wide_body(const PgQueryPlan& p) {
         }
       return;
     }
+    if (DBL) {
+      // DOUBLE values, doc by doc: the accumulators of ONE double column are at most COUNT, the four digit rows of its SUM, MIN and MAX (the
+      // planner shares equal accumulators), so a doc's work is four wave-uniform tests on row offsets instead of a loop over the accumulators
+      // with the docs inside.  hipcc hoisted everything a doc derives from its value — windows, signs, order keys: 10 registers x 8 docs —
+      // out of that loop, which is what pushed pg_pipe_wd_scan / pg_pipe_wd_index_scan into scratch memory (156 / 328 bytes per lane,
+      // profiles/r04: VERDICT r4 #8); here those values live for one doc.
+#pragma unroll
+      for (int k = 0; k < NQ; k++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          if (!((mg >> (4 * k + i)) & 1u)) continue;   // one exec-mask change per doc
+          int64_t* cell = lds_table + slot[k][i];
+          if (wd_row_cnt >= 0) atomicAdd(reinterpret_cast<unsigned long long*>(cell + (uint32_t)wd_row_cnt * stride), 1ULL);
+          if (wd_row_sum >= 0) {
+            uint32_t w[3];
+            int j0;
+            uint64_t neg;
+            windows((uint64_t)v[k][i], w, j0, neg);
+            int64_t* digits = cell + (uint32_t)wd_row_sum * stride;
+#pragma unroll
+            for (int d = 0; d < 3; d++) {   // a window outside rows 0 .. 3 adds 0 to row 0
+              const int row = j0 + d;
+              const bool in = (uint32_t)row < 4u;
+              const uint32_t u = in ? w[d] : 0u;
+              // (24-bit multiplies: a row index x at most 65536 slots; v_mul_lo_u32 runs at a quarter of the rate)
+              atomicAdd(reinterpret_cast<unsigned long long*>(digits + __umul24(in ? (uint32_t)row : 0u, stride)), (unsigned long long)(((uint64_t)u ^ neg) - neg));
+            }
+          }
+          if (wd_row_min >= 0 || wd_row_max >= 0) {   // order-preserving keys; NaN never replaces the holder (Java: NaN < x is false)
+            const double y = __longlong_as_double(v[k][i]);
+            if (y == y) {
+              const long long key = (long long)f64_order_key(y);
+              if (wd_row_min >= 0) atomicMin(reinterpret_cast<long long*>(cell + (uint32_t)wd_row_min * stride), key);
+              if (wd_row_max >= 0) atomicMax(reinterpret_cast<long long*>(cell + (uint32_t)wd_row_max * stride), key);
+            }
+          }
+        }
+      return;
+    }
     for (int o = 0; o < p.n_ops; o++) {
       const PgAccOp op = p.ops[uniform(o)];   // (a scalar index: a vector one makes hipcc copy the whole plan into scratch memory)
       int64_t* base = lds_table + (size_t)o * stride;
@@ -761,42 +818,6 @@ __device__ __forceinline__ void pipe_wide_body(const PgQueryPlan& p) {
 #pragma unroll
           for (int i = 0; i < 4; i++)
             if ((mg >> (4 * k + i)) & 1u) atomicAdd(reinterpret_cast<unsigned long long*>(base + slot[k][i]), 1ULL);
-      } else if (DBL && op.fn == PG_ACC_SUM) {
-        // the four digit accumulators of the column are consecutive rows of the table (planner): a value touches at most three of them —
-        // the rows dj .. dj + 2 — so the doc issues its (non-zero) windows to those rows once, at limb 0's turn; no select per accumulator
-        if (op.limb != 0) continue;
-#pragma unroll
-        for (int k = 0; k < NQ; k++)
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const bool on = ((mg >> (4 * k + i)) & 1u) != 0;
-            uint32_t w[3];
-            int j0;
-            uint64_t neg;
-            windows((uint64_t)v[k][i], w, j0, neg);
-            if (on) {   // one exec-mask change per doc: the three updates below are unconditional (a window outside rows 0 .. 3 adds 0 to a clamped row)
-#pragma unroll
-              for (int d = 0; d < 3; d++) {
-                const int row = j0 + d;
-                const bool in = (uint32_t)row < 4u;
-                const uint32_t rc = in ? (uint32_t)row : 0u;
-                const uint64_t val = in ? (((uint64_t)w[d] ^ neg) - neg) : 0ULL;
-                atomicAdd(reinterpret_cast<unsigned long long*>(base + rc * stride + slot[k][i]), (unsigned long long)val);
-              }
-            }
-          }
-      } else if (DBL) {                          // MIN / MAX of doubles: order-preserving keys; NaN never replaces the holder (Java: NaN < x is false)
-        const bool is_min = op.fn == PG_ACC_MIN;
-#pragma unroll
-        for (int k = 0; k < NQ; k++)
-#pragma unroll
-          for (int i = 0; i < 4; i++) {
-            const double y = __longlong_as_double(v[k][i]);
-            if (((mg >> (4 * k + i)) & 1u) && y == y) {
-              if (is_min) atomicMin(reinterpret_cast<long long*>(base + slot[k][i]), (long long)f64_order_key(y));
-              else atomicMax(reinterpret_cast<long long*>(base + slot[k][i]), (long long)f64_order_key(y));
-            }
-          }
       } else if (op.fn == PG_ACC_SUM) {
 #pragma unroll
         for (int k = 0; k < NQ; k++)

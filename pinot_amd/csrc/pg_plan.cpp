@@ -1102,13 +1102,26 @@ static void plan_oct(CompiledPlan& P, PgQueryPlan& D, const std::vector<Column*>
   D.oct = 0;
   D.oct_dword = 0;
   if (knobs().no_oct) return;   // measurement / test knob: the round-3 kernels
-  if (D.mv || P.first_doc_op >= 0 || D.n_aux != 1 || srcs.size() != 1 || D.n_group_cols > 4 || D.n_ops > 1) return;
+  const bool count_only = D.n_aux == 0 && srcs.empty() && D.n_ops == 1 && D.n_group_cols >= 1;   // COUNT(*) GROUP BY: no source column at all
+  if (D.mv || P.first_doc_op >= 0 || (!count_only && (D.n_aux != 1 || srcs.size() != 1)) || D.n_group_cols > 4 || D.n_ops > 1) return;
   for (int g = 0; g < D.n_group_cols; g++)
     if (D.gcols[g].col_kind != PG_COL_FIXED_BIT || D.gcols[g].bits < 1 || D.gcols[g].bits > 8 || D.gcols[g].mult >= ((int64_t)1 << 24) ||
         D.mv_gcol_offsets[g] != nullptr)
       return;
   for (int o = 0; o < D.n_ops; o++)
     if (D.ops[o].fn != PG_ACC_COUNT || D.ops[o].src >= 0) return;
+  if (count_only) {
+    // The lane-owns-8-docs decode without a source: the group columns cost one dword load per 8 docs and column instead of the quad
+    // layout's one per 4, and COUNT is the same ds_add.  Only where the table is LDS-resident and the segment large enough for one
+    // 16-wavefront workgroup per CU to have work (PG_OCT_COUNT_MIN_DOCS).
+    if (knobs().no_oct_count || total_docs < knobs().oct_count_min_docs || !P.match_all) return;   // behind a filter the fused filter + COUNT kernels win (no mask pass)
+    if (D.agg_mode != PG_AGG_LDS && D.agg_mode != PG_AGG_SINGLE) return;
+    D.oct_src = -1;
+    D.oct_src_kind = 0;
+    D.oct_log2m = 0;
+    D.oct = 1;
+    return;
+  }
   const PgAuxOp& A = D.aux[0];
   const Column* c = srcs[(size_t)A.src];
   if (c->is_mv) return;

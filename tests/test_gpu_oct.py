@@ -225,3 +225,34 @@ def test_pruned_offers_default_threshold(gpu_api, oracle_api, gpu_knobs):
     g.destroy()
     o.destroy()
 
+
+
+COUNT_ONLY_SHAPES = [
+    "SELECT g4, COUNT(*) FROM oct GROUP BY g4 LIMIT 1000",
+    "SELECT g1, g2, g3, g4, COUNT(*) FROM oct GROUP BY g1, g2, g3, g4 LIMIT 1000",
+    "SELECT g8, g6, COUNT(*) FROM oct GROUP BY g8, g6 LIMIT 100000",                      # 8 000 groups: no replicas
+    "SELECT g8, g7, COUNT(*) FROM oct GROUP BY g8, g7 LIMIT 100000",                      # 20 000 groups: beyond one LDS table, not this route
+    "SELECT g5, g6, COUNT(*) FROM oct WHERE r BETWEEN 100 AND 600 GROUP BY g5, g6 LIMIT 1000",   # behind a filter: the fused kernels, not this route
+    "SELECT g3, COUNT(*) FROM oct WHERE g1 = 0 OR g2 = 2 GROUP BY g3 LIMIT 1000",
+]
+
+
+@pytest.mark.parametrize("n", [1, 9, 2049, 200_003])
+def test_count_only_group_by_in_the_oct_layout(gpu_api, oracle_api, gpu_knobs, n):
+    """COUNT(*) GROUP BY <= 4 columns of <= 8 bits: the oct-layout decode without a source column (plan_oct, count_only); the default
+    threshold keeps small segments on the quad kernels, so the test lowers it — and the quad kernels give the same rows."""
+    gpu_knobs(PG_OCT_COUNT_MIN_DOCS="0")
+    g, o = both(gpu_api, oracle_api, make_host(n, seed=n + 5))
+    rows = []
+    for sql in COUNT_ONLY_SHAPES:
+        rows.append(run(g, o, sql, kernels=None if "g8, g7" in sql or "WHERE" in sql else ("pg_oct_l",)).rows())
+    g.destroy()
+    o.destroy()
+    gpu_knobs(PG_NO_OCT_COUNT="1")   # plans are cached per segment: a fresh one
+    g, o = both(gpu_api, oracle_api, make_host(n, seed=n + 5))
+    for sql, r in zip(COUNT_ONLY_SHAPES, rows):
+        gb = run(g, o, sql, kernels=None)
+        assert gb.stats.num_docs_scanned == 0 or not gb.stats.kernel.decode().startswith("pg_oct")
+        assert gb.rows() == r
+    g.destroy()
+    o.destroy()

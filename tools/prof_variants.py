@@ -102,6 +102,9 @@ QUERIES = {
 QUERIES5 = {
     "cfg5": (synth.QUERY_CFG5, 4.375),
     "cfg5 count only": ("SELECT h1, h2, h3, h4, COUNT(*) FROM t GROUP BY h1, h2, h3, h4 LIMIT 20000", 1.875),
+    "count only group h1 (16)": ("SELECT h1, COUNT(*) FROM t GROUP BY h1", 0.5),
+    "count only group h1,h2 (160)": ("SELECT h1, h2, COUNT(*) FROM t GROUP BY h1, h2", 1.0),
+    "count only group h1,h2 where h3<3": ("SELECT h1, h2, COUNT(*) FROM t WHERE h3 < 3 GROUP BY h1, h2", 1.5),
     "cfg5 hll(u) no group": ("SELECT DISTINCTCOUNTHLL(u) FROM t", 2.5),
     "cfg5 hll(u) group h1": ("SELECT h1, DISTINCTCOUNTHLL(u) FROM t GROUP BY h1", 3.0),
     "cfg5 distinctcount(u) group h1": ("SELECT h1, DISTINCTCOUNT(u) FROM t GROUP BY h1", 3.0),
