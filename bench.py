@@ -471,6 +471,27 @@ def concurrency_block(api, args, bg_seg=None, bg_sql=None, threads=(1, 4, 16, 64
     return out
 
 
+def abi_call_latency(api, seg, qc, warmup, steps):
+    """p50 of the C-ABI call alone — pg_query_exec entry to return, the result handle freed outside the timed region — which is what the
+    reference-side caller (the JNI stub of INTEGRATION.md) pays; seg.execute() below it also walks the result into Python objects."""
+    from pinot_amd.query import CQuery
+    cq = CQuery(qc)
+    exec_fn, free_fn = api.f("query_exec"), api.f("result_free")
+    ptr = cq.ptr()
+    lat = []
+    for i in range(warmup + steps):
+        h = C.c_void_p()
+        t = time.perf_counter()
+        rc = exec_fn(seg.handle, ptr, C.byref(h))
+        dt = (time.perf_counter() - t) * 1e3
+        if rc != 0:
+            raise RuntimeError(f"pg_query_exec failed with {rc}")
+        free_fn(h)
+        if i >= warmup:
+            lat.append(dt)
+    return statistics.median(lat)
+
+
 def extra_block(api, args, query, docs, bytes_per_row, columns, sql):
     """One more BASELINE configuration inside the default run: its own segment of `docs` rows pinned in HBM, `steps` timed executions
     after `warmup`, HIP-event kernel time → roofline fraction, HBM traffic from the PMC passes (child runs), and an oracle equality
@@ -505,7 +526,7 @@ def extra_block(api, args, query, docs, bytes_per_row, columns, sql):
     k = sum(kms) / len(kms)
     kernel = block.stats.kernel.decode()
     res = {"query": sql, "rows": docs, "steps": steps, "kernel": kernel, "kernel_ms": k, "ms_per_step": sum(lat) / len(lat),
-           "p50_query_latency_ms": statistics.median(lat), "value": docs / (sum(lat) / len(lat) * 1e-3), "unit": "rows/s",
+           "p50_query_latency_ms": statistics.median(lat), "p50_abi_call_ms": abi_call_latency(api, seg, parse_sql(sql), args.warmup, max(steps, 20)), "value": docs / (sum(lat) / len(lat) * 1e-3), "unit": "rows/s",
            "algorithmic_bytes_per_launch": bytes_per_row * docs,
            "roofline_frac": bytes_per_row * docs / (k * 1e-3) / 1e9 / HBM_PEAK_GBS if k > 0 else 0.0}
     # oracle equality
@@ -563,13 +584,19 @@ def star_tree_leg(api, args, parent_docs=2_000_000):
     # cardinalities come back (the headline latency); the intermediate form (registers, what a cross-segment merge needs) is timed beside it
     bf, lat_f, lib_f, dev_f = timed(capi.QUERY_FLAG_FINAL_DISTINCT)
     b, lat_i, lib_i, dev_i = timed(0)
+    q_abi = parse_sql(synth.QUERY_CFG5)        # without the profiling events: the call as the JNI stub issues it
+    q_abi.flags |= capi.QUERY_FLAG_FINAL_DISTINCT
+    abi_f = abi_call_latency(api, seg, q_abi, args.warmup, max(args.steps, 50))
+    abi_i = abi_call_latency(api, seg, parse_sql(synth.QUERY_CFG5), args.warmup, max(args.steps, 50))
     from pinot_amd.executor import hll_cardinality
     inter, final = b.rows(), bf.rows()   # (rows() assembles a dict per call: once each)
     final_ok = len(final) == len(inter) and all(final[k] == [v[0], hll_cardinality(v[1])] for k, v in inter.items())
     out = {"star_tree_docs": int(parent.star_trees[0].num_docs), "groups": len(inter), "star_tree_index": int(b.stats.star_tree_index),
-           "p50_query_latency_ms": lat_f, "library_ms": lib_f, "device_ms": dev_f,
+           "p50_query_latency_ms": lat_f, "p50_abi_call_ms": abi_f, "library_ms": lib_f, "device_ms": dev_f,
+           "latency_how": "p50_query_latency_ms: Python binding, call + result walked into Python objects, profiling events on; "
+                          "p50_abi_call_ms: pg_query_exec entry to return through ctypes, no events (the JNI caller's cost)",
            "final_values_equal_cardinality_of_registers": bool(final_ok),
-           "intermediate_registers": {"p50_query_latency_ms": lat_i, "library_ms": lib_i, "device_ms": dev_i},
+           "intermediate_registers": {"p50_query_latency_ms": lat_i, "p50_abi_call_ms": abi_i, "library_ms": lib_i, "device_ms": dev_i},
            "kernel": b.stats.kernel.decode(),
            "docs_scanned": int(b.stats.num_docs_scanned), "parent_docs": parent.total_docs}
     seg.destroy()

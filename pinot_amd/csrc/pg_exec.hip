@@ -51,7 +51,7 @@ PG_DECL_FAST(pg_p2_aggregate_1n) PG_DECL_FAST(pg_p2_aggregate_2n) PG_DECL_FAST(p
 PG_DECL_FAST(pg_p2_index_count_kernel) PG_DECL_FAST(pg_p2_index_scan_kernel) PG_DECL_FAST(pg_p2_index_fill_kernel)
 PG_DECL_FAST(pg_p2_scatter_stream) PG_DECL_FAST(pg_p2_aggregate_1b) PG_DECL_FAST(pg_p2_aggregate_1s) PG_DECL_FAST(pg_p2_aggregate_2s) PG_DECL_FAST(pg_p2_aggregate_1sg) PG_DECL_FAST(pg_p2_aggregate_2sg)
 // pg_kernels_oct.hip: oct-layout DISTINCTCOUNTHLL / DISTINCTCOUNT kernels (LDS-resident states; pruned offers) and their small helpers
-PG_DECL_FAST(pg_oct_l) PG_DECL_FAST(pg_oct_lm) PG_DECL_FAST(pg_oct_p) PG_DECL_FAST(pg_oct_pm)
+PG_DECL_FAST(pg_oct_l) PG_DECL_FAST(pg_oct_lm) PG_DECL_FAST(pg_oct_c) PG_DECL_FAST(pg_oct_p) PG_DECL_FAST(pg_oct_pm)
 extern "C" __global__ void pg_oct_merge_floor_kernel(const uint32_t* partials, uint32_t* regs, uint8_t* floors, int n_groups, int log2m, int radix_shift,
                                                       int slices);
 extern "C" __global__ void pg_oct_pass_reset_kernel(uint32_t* p2_meta, int64_t n_meta, uint32_t* p2_ctrl, uint32_t* cursor);
@@ -1465,8 +1465,9 @@ static std::unique_ptr<Result> execute_query_impl(Segment& seg, const pg_query& 
       PG_HIP(hipGetLastError());
       D.match_words = ctx.words.as<uint32_t>();
     }
-    kname = D.match_words ? "pg_oct_lm" : "pg_oct_l";
-    hipLaunchKernelGGL(D.match_words ? pg_oct_lm : pg_oct_l, dim3(shape.grid), dim3(shape.block), shape.lds, ctx.stream, D);
+    const bool count_only = D.oct_src_kind == 0 && D.n_aux == 0 && !D.match_words && D.n_group_cols >= 1 && !knobs().no_oct_count_kernel;   // plan_oct: COUNT(*) alone
+    kname = count_only ? "pg_oct_c" : (D.match_words ? "pg_oct_lm" : "pg_oct_l");
+    hipLaunchKernelGGL(count_only ? pg_oct_c : (D.match_words ? pg_oct_lm : pg_oct_l), dim3(shape.grid), dim3(shape.block), shape.lds, ctx.stream, D);
     PG_HIP(hipGetLastError());
   } else if (has_docs) {
     // COUNT(*) behind an index-only filter of dense postings: the bitmap stream (pg_dense_count_*), not the tile walk

@@ -446,6 +446,7 @@ struct Knobs {
   bool no_p2 = false, p2_no_fast_a = false, no_p2_oct = false, no_radix = false, no_radix_aux = false, no_part = false, no_radix_packed = false;
   bool no_pipe_general = false, no_pipe_wide = false, no_pipe_wide_double = false, mv_no_windows = false;
   int64_t oct_min_docs = -1;
+  bool no_oct_count_kernel = false;                // PG_NO_OCT_COUNT_KERNEL: those plans run pg_oct_l (two load buffers) instead of pg_oct_c (four)
   bool no_oct_count = false;                       // PG_NO_OCT_COUNT: COUNT(*)-only group-bys stay on the quad-layout kernels
   int64_t oct_count_min_docs = (int64_t)1 << 22;   // PG_OCT_COUNT_MIN_DOCS
   int part_min = -1;

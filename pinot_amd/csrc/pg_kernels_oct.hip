@@ -207,6 +207,127 @@ __device__ __forceinline__ void oct_body_lds(const PgQueryPlan& p) {
 extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_oct_l(const PgQueryPlan p) { oct_body_lds<false>(p); }
 extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_oct_lm(const PgQueryPlan p) { oct_body_lds<true>(p); }
 
+// ---- back end C: COUNT(*) alone, no filter in front (round 5) ----------------------------------------------------------------------------
+// SELECT dims, COUNT(*) GROUP BY dims reads 0.4 - 2 bytes per doc: with two load buffers per wavefront (oct_body_lds) a CU has ~30 KB in
+// flight and the kernel waits for HBM half of its cycles at 43 % VALU use (profiles/r05_sq_count_only_oct.txt).  Here the group-column
+// count is compile-time, a buffer is only the group columns' dwords (no source, no match word), and FOUR buffers rotate: the load of
+// sub-tile u + 4 is requested where sub-tile u has been decoded.
+// Buffers of NW dwords per column — two when every group column has <= 4 bits (8 values: 4 bytes + 3 of misalignment), three up to 8 bits —
+// so that four of them fit beside the decode's registers under the 128 a 16-wavefront workgroup leaves each lane (three for 3-4 wide columns).
+typedef uint32_t u32x2o __attribute__((ext_vector_type(2)));
+typedef u32x2o u32x2o_a4 __attribute__((aligned(4)));
+template <int NG, int NW> struct OctRawG { uint32_t g[NG][NW]; };
+template <int NG, int NW>
+DEVFN void octc_issue(const PgQueryPlan& p, const OctLane& ln, int wt, int sub, OctRawG<NG, NW>& raw) {
+#pragma unroll
+  for (int g = 0; g < NG; g++) {
+    const PgGroupCol& gc = p.gcols[g];
+    const GAS uint8_t* base = gptr<uint8_t>(gc.data) + (size_t)wt * (size_t)(PG_WAVE_DOCS / 8) * (size_t)gc.bits + (size_t)sub * (size_t)(OCT_SUB_DOCS / 8) * (size_t)gc.bits;
+    if (NW == 2) {
+      const u32x2o v = ldnt((const GAS u32x2o_a4*)(base + ln.goff[g]));
+      raw.g[g][0] = v.x; raw.g[g][1] = v.y;
+    } else {
+      const u32x3 v = ldnt((const GAS u32x3_a4*)(base + ln.goff[g]));
+      raw.g[g][0] = v.x; raw.g[g][1] = v.y; raw.g[g][NW - 1] = v.z;
+    }
+  }
+}
+template <int NG, int NW>
+DEVFN void octc_slots(const PgQueryPlan& p, const OctLane& ln, const OctRawG<NG, NW>& raw, uint32_t rep, uint32_t (&slot)[8]) {
+  const uint32_t rshift = (uint32_t)p.replica_shift;
+#pragma unroll
+  for (int g = 0; g < NG; g++) {
+    uint32_t v[8];
+    u32x3 w;
+    w.x = raw.g[g][0]; w.y = raw.g[g][1]; w.z = raw.g[g][NW - 1];   // (NW == 2: .z is never read, the widths are <= 4)
+    if (NW == 2) {
+      switch (p.gcols[g].bits) {   // wave-uniform
+        case 1: oct_decode_small<1>(w, ln.gsel[g], v); break;
+        case 2: oct_decode_small<2>(w, ln.gsel[g], v); break;
+        case 3: oct_decode_small<3>(w, ln.gsel[g], v); break;
+        default: oct_decode_small<4>(w, ln.gsel[g], v); break;
+      }
+    } else {
+      oct_decode_group(p.gcols[g].bits, w, ln.gsel[g], v);
+    }
+    const uint32_t mult = (uint32_t)p.gcols[g].mult << rshift;   // the table fits LDS: every product fits 24 bits
+#pragma unroll
+    for (int j = 0; j < 8; j++) slot[j] = g == 0 ? mad24(v[j], mult, rep) : mad24(v[j], mult, slot[j]);
+  }
+}
+template <int NG, int NW>
+__device__ __forceinline__ void oct_body_count(const PgQueryPlan& p) {
+  // load buffers in rotation.  More than four did not pay: 6 buffers for 4 columns 0.147 ms against 0.118 over 2 x 10^8 docs, 12 buffers for 1 - 2
+  // columns within 5 % of four (the unrolled round outgrows the instruction cache; profiles/r05_count_only_oct.txt)
+  constexpr int DEPTH = NG * NW > 8 ? 3 : 4;
+  extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
+  const int t = threadIdx.x, lane = t & 63, wave = uniform(t >> 6);
+  int64_t* table = reinterpret_cast<int64_t*>(smem);
+  const uint32_t table_slots = (uint32_t)p.n_groups * (uint32_t)p.replicas;
+  for (uint32_t i = (uint32_t)t; i < table_slots; i += PG_BLOCK) table[i] = 0;
+  if (blockIdx.x == 0 && t == 0) atomicAdd(p.stats, (unsigned long long)p.num_docs);   // MatchAllFilterOperator: every doc matches
+  __syncthreads();
+  OctLane ln;
+  oct_lane_setup(p, lane, ln);
+  const uint32_t rep = (uint32_t)t & ((uint32_t)p.replicas - 1u);
+  const int first = (int)blockIdx.x * PG_WAVES_PER_BLOCK + wave, step = (int)gridDim.x * PG_WAVES_PER_BLOCK;
+  const int n_mine = first < p.n_wtiles ? (p.n_wtiles - first + step - 1) / step : 0;
+  const int n_sub = n_mine * OCT_SUBS_PER_WTILE;
+  const int last_wt = p.n_wtiles - 1;
+  auto wt_of = [&](int u) __attribute__((always_inline)) { const int w = first + (u >> 2) * step; return w < p.n_wtiles ? w : last_wt; };   // clamped: loads stay in bounds
+  auto turn = [&](OctRawG<NG, NW>& r, int u) __attribute__((always_inline)) {
+    if (u >= n_sub) return;   // wave-uniform (three buffers: the last round is partial)
+    uint32_t slot[8];
+    octc_slots<NG, NW>(p, ln, r, rep, slot);
+    octc_issue<NG, NW>(p, ln, wt_of(u + DEPTH), (u + DEPTH) & 3, r);
+    const int64_t rem = (int64_t)p.num_docs - ((int64_t)wt_of(u) * PG_WAVE_DOCS + (int64_t)(u & 3) * OCT_SUB_DOCS);
+    if (rem >= OCT_SUB_DOCS) {   // wave-uniform: a whole sub-tile, no lane masks
+#pragma unroll
+      for (int j = 0; j < 8; j++) atomicAdd(reinterpret_cast<uint32_t*>(table + slot[j]), 1u);   // low dword: a workgroup sees < 2^31 docs
+    } else {
+      const uint32_t m8 = oct_mask8(p, wt_of(u), u & 3, lane, 0u, false);
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        if ((m8 >> j) & 1u) atomicAdd(reinterpret_cast<uint32_t*>(table + slot[j]), 1u);
+    }
+  };
+  OctRawG<NG, NW> r[DEPTH];
+  if (n_sub > 0) {
+#pragma unroll
+    for (int k = 0; k < DEPTH; k++) octc_issue<NG, NW>(p, ln, wt_of(k), k & 3, r[k]);
+  }
+  for (int u = 0; u < n_sub; u += DEPTH) {
+#pragma unroll
+    for (int k = 0; k < DEPTH; k++) turn(r[k], u + k);
+  }
+  __syncthreads();
+  {   // flush: the partial table [G] (replicas folded), as pg_oct_l leaves it
+    const int R = p.replicas;
+    int64_t* out = p.partials + (int64_t)blockIdx.x * (int64_t)p.n_groups;
+    for (int64_t i = t; i < p.n_groups; i += PG_BLOCK) {
+      const int64_t* src = table + i * R;
+      int64_t acc = src[0];
+      for (int r = 1; r < R; r++) acc += src[r];
+      out[i] = acc;
+    }
+  }
+}
+template <int NW>
+__device__ __forceinline__ void oct_count_dispatch(const PgQueryPlan& p) {
+  switch (p.n_group_cols) {   // wave-uniform
+    case 1: oct_body_count<1, NW>(p); break;
+    case 2: oct_body_count<2, NW>(p); break;
+    case 3: oct_body_count<3, NW>(p); break;
+    default: oct_body_count<4, NW>(p); break;
+  }
+}
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_oct_c(const PgQueryPlan p) {
+  bool narrow = true;
+  for (int g = 0; g < p.n_group_cols; g++) narrow = narrow && p.gcols[g].bits <= 4;
+  if (narrow) oct_count_dispatch<2>(p);
+  else oct_count_dispatch<3>(p);
+}
+
 // ---- back end P: pruned offers ---------------------------------------------------------------------------------------------------------
 // LDS: counts u32 [G] | floors u8 [G] (padded to dwords) | per wavefront a ring of OCT_RING survivor entries.
 // Survivors are appended to the wavefront's ring (ds_write) and leave in whole blocks of OCT_STREAM_BLOCK = 256 entries — one coalesced

@@ -229,30 +229,53 @@ def test_pruned_offers_default_threshold(gpu_api, oracle_api, gpu_knobs):
 
 COUNT_ONLY_SHAPES = [
     "SELECT g4, COUNT(*) FROM oct GROUP BY g4 LIMIT 1000",
-    "SELECT g1, g2, g3, g4, COUNT(*) FROM oct GROUP BY g1, g2, g3, g4 LIMIT 1000",
-    "SELECT g8, g6, COUNT(*) FROM oct GROUP BY g8, g6 LIMIT 100000",                      # 8 000 groups: no replicas
+    "SELECT g1, g2, g3, g4, COUNT(*) FROM oct GROUP BY g1, g2, g3, g4 LIMIT 1000",            # four columns of <= 4 bits: two-dword buffers
+    "SELECT g8, g6, COUNT(*) FROM oct GROUP BY g8, g6 LIMIT 100000",                      # 8 000 groups: no replicas; three-dword buffers
+    "SELECT g5, g6, g2, COUNT(*) FROM oct GROUP BY g5, g6, g2 LIMIT 100000",              # three wide columns: three buffers in rotation
     "SELECT g8, g7, COUNT(*) FROM oct GROUP BY g8, g7 LIMIT 100000",                      # 20 000 groups: beyond one LDS table, not this route
     "SELECT g5, g6, COUNT(*) FROM oct WHERE r BETWEEN 100 AND 600 GROUP BY g5, g6 LIMIT 1000",   # behind a filter: the fused kernels, not this route
     "SELECT g3, COUNT(*) FROM oct WHERE g1 = 0 OR g2 = 2 GROUP BY g3 LIMIT 1000",
 ]
 
 
+def _count_only_kernels(sql):
+    return None if "g8, g7" in sql or "WHERE" in sql else ("pg_oct_c",)
+
+
 @pytest.mark.parametrize("n", [1, 9, 2049, 200_003])
 def test_count_only_group_by_in_the_oct_layout(gpu_api, oracle_api, gpu_knobs, n):
-    """COUNT(*) GROUP BY <= 4 columns of <= 8 bits: the oct-layout decode without a source column (plan_oct, count_only); the default
-    threshold keeps small segments on the quad kernels, so the test lowers it — and the quad kernels give the same rows."""
+    """COUNT(*) GROUP BY <= 4 columns of <= 8 bits over every doc: the oct-layout decode without a source column (plan_oct, count_only ->
+    pg_oct_c, four load buffers); the default threshold keeps small segments on the quad kernels, so the test lowers it — and pg_oct_l (two
+    buffers) and the quad kernels give the same rows."""
     gpu_knobs(PG_OCT_COUNT_MIN_DOCS="0")
     g, o = both(gpu_api, oracle_api, make_host(n, seed=n + 5))
-    rows = []
-    for sql in COUNT_ONLY_SHAPES:
-        rows.append(run(g, o, sql, kernels=None if "g8, g7" in sql or "WHERE" in sql else ("pg_oct_l",)).rows())
+    rows = [run(g, o, sql, kernels=_count_only_kernels(sql)).rows() for sql in COUNT_ONLY_SHAPES]
+    for knob, names in (("PG_NO_OCT_COUNT_KERNEL", ("pg_oct_l",)), ("PG_NO_OCT_COUNT", None)):
+        g.destroy()
+        o.destroy()
+        gpu_knobs(**{knob: "1"})   # plans are cached per segment: a fresh one
+        g, o = both(gpu_api, oracle_api, make_host(n, seed=n + 5))
+        for sql, r in zip(COUNT_ONLY_SHAPES, rows):
+            gb = run(g, o, sql, kernels=names if _count_only_kernels(sql) else None)
+            if names is None:
+                assert gb.stats.num_docs_scanned == 0 or not gb.stats.kernel.decode().startswith("pg_oct")
+            assert gb.rows() == r
     g.destroy()
     o.destroy()
-    gpu_knobs(PG_NO_OCT_COUNT="1")   # plans are cached per segment: a fresh one
-    g, o = both(gpu_api, oracle_api, make_host(n, seed=n + 5))
-    for sql, r in zip(COUNT_ONLY_SHAPES, rows):
-        gb = run(g, o, sql, kernels=None)
-        assert gb.stats.num_docs_scanned == 0 or not gb.stats.kernel.decode().startswith("pg_oct")
-        assert gb.rows() == r
+
+
+@pytest.mark.parametrize("n", [9_030_011, 26_000_001])
+def test_count_only_rotation_over_many_tiles(gpu_api, oracle_api, n):
+    """Enough docs for every wavefront to own several wave tiles (16 wavefronts x 256 workgroups x 2048 docs = 8.4 M docs per round): the
+    buffers' rotation, its partial last round with three buffers, the clamped loads past the last tile and the ragged last sub-tile."""
+    from pinot_amd import synth
+    host = synth.generate_segment(n, segment_index=2, columns=["h1", "h2", "h3", "h4", "g1", "g2"])
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    for sql in ("SELECT h1, h2, h3, h4, COUNT(*) FROM t GROUP BY h1, h2, h3, h4 LIMIT 20000",
+                "SELECT h3, COUNT(*) FROM t GROUP BY h3",
+                "SELECT g1, COUNT(*) FROM t GROUP BY g1 LIMIT 1000",
+                "SELECT g1, g2, COUNT(*) FROM t GROUP BY g1, g2 LIMIT 10000",
+                "SELECT g2, h1, h2, COUNT(*) FROM t GROUP BY g2, h1, h2 LIMIT 10000"):
+        run(g, o, sql, kernels=("pg_oct_c",))
     g.destroy()
     o.destroy()
