@@ -127,7 +127,97 @@ DEVFN void oct_apply_lds(const PgQueryPlan& p, uint32_t m8, const uint32_t (&key
   oct_raise_four<4>(m8, key, item, aux_words, stride, log2m);
 }
 
-template <bool MASKED>
+typedef uint32_t u32x2o __attribute__((ext_vector_type(2)));
+typedef u32x2o u32x2o_a4 __attribute__((aligned(4)));
+// Load buffers sized at compile time (back ends L and P): NW dwords per group column (2 when every width is <= 4 bits, else 3) and SW dwords
+// of the source (6 up to 21 bits: 8 x 21 bits + 3 bytes of misalignment = 24 bytes; 8 for wider dictionaries and raw INT values) — 15 registers
+// for config 5 against OctRaw's 21, which is what lets THREE buffers rotate inside the 128 registers a 16-wavefront workgroup leaves a lane.
+// With two, a buffer was requested one turn (decode + hash + pruning, ~2 us with four wavefronts per SIMD) before it was needed: about the
+// latency of HBM under load, and the waves waited 52 % of their cycles at 61 % VALU use (profiles/r04_f_sq_counters_cfg5_200m.txt).
+template <int NW, int SW> struct OctRawS { uint32_t g[4][NW]; uint32_t s[SW]; uint32_t mw; };
+template <bool MASKED, int NW, int SW>
+DEVFN void octs_issue(const PgQueryPlan& p, const OctLane& ln, int wt, int sub, int lane, OctRawS<NW, SW>& raw) {
+#pragma unroll
+  for (int g = 0; g < 4; g++)
+    if (g < p.n_group_cols) {
+      const PgGroupCol& gc = p.gcols[g];
+      const GAS uint8_t* base = gptr<uint8_t>(gc.data) + (size_t)wt * (size_t)(PG_WAVE_DOCS / 8) * (size_t)gc.bits + (size_t)sub * (size_t)(OCT_SUB_DOCS / 8) * (size_t)gc.bits;
+      if (NW == 2) {
+        const u32x2o v = ldnt((const GAS u32x2o_a4*)(base + ln.goff[g]));
+        raw.g[g][0] = v.x; raw.g[g][1] = v.y;
+      } else {
+        const u32x3 v = ldnt((const GAS u32x3_a4*)(base + ln.goff[g]));
+        raw.g[g][0] = v.x; raw.g[g][1] = v.y; raw.g[g][NW - 1] = v.z;
+      }
+    }
+  if (p.oct_src_kind != OCT_SRC_NONE) {   // (COUNT(*) alone: no source column)
+    const PgValueSrc& V = p.srcs[p.oct_src];
+    const uint32_t bits = p.oct_src_kind == OCT_SRC_RAW32 ? 32u : (uint32_t)V.bits;
+    const GAS uint8_t* base = gptr<uint8_t>(V.data) + (size_t)wt * (size_t)(PG_WAVE_DOCS / 8) * (size_t)bits + (size_t)sub * (size_t)(OCT_SUB_DOCS / 8) * (size_t)bits;
+    const u32x4 a = ldnt((const GAS u32x4_a4*)(base + ln.soff));
+    raw.s[0] = a.x; raw.s[1] = a.y; raw.s[2] = a.z; raw.s[3] = a.w;
+    if (SW == 6) {
+      const u32x2o b = ldnt((const GAS u32x2o_a4*)(base + ln.soff + 16u));
+      raw.s[4] = b.x; raw.s[SW - 1] = b.y;
+    } else {
+      const u32x4 b = ldnt((const GAS u32x4_a4*)(base + ln.soff + 16u));
+      raw.s[4] = b.x; raw.s[5] = b.y; raw.s[SW - 2] = b.z; raw.s[SW - 1] = b.w;
+    }
+  }
+  if (MASKED) raw.mw = gptr<uint32_t>(p.match_words)[(size_t)wt * 64 + (size_t)sub * 16 + (size_t)(lane >> 2)];
+}
+// oct_decode over the sized buffer: keys and raw source items of the lane's 8 docs
+template <int NW, int SW>
+DEVFN void octs_decode(const PgQueryPlan& p, const OctLane& ln, const OctRawS<NW, SW>& raw, uint32_t (&key)[8], uint32_t (&item)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; j++) key[j] = 0;
+#pragma unroll
+  for (int g = 0; g < 4; g++)
+    if (g < p.n_group_cols) {
+      uint32_t v[8];
+      u32x3 w;
+      w.x = raw.g[g][0]; w.y = raw.g[g][1]; w.z = raw.g[g][NW - 1];   // (NW == 2: .z is never read, the widths are <= 4)
+      if (NW == 2) {
+        switch (p.gcols[g].bits) {   // wave-uniform
+          case 1: oct_decode_small<1>(w, ln.gsel[g], v); break;
+          case 2: oct_decode_small<2>(w, ln.gsel[g], v); break;
+          case 3: oct_decode_small<3>(w, ln.gsel[g], v); break;
+          default: oct_decode_small<4>(w, ln.gsel[g], v); break;
+        }
+      } else {
+        oct_decode_group(p.gcols[g].bits, w, ln.gsel[g], v);
+      }
+      if (g == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) key[j] = v[j];   // mult of column 0 is 1
+      } else {
+        const uint32_t mult = (uint32_t)p.gcols[g].mult;
+#pragma unroll
+        for (int j = 0; j < 8; j++) key[j] = mad24(v[j], mult, key[j]);
+      }
+    }
+  if (p.oct_src_kind == OCT_SRC_NONE) return;
+  u32x4 a, b;
+  a.x = raw.s[0]; a.y = raw.s[1]; a.z = raw.s[2]; a.w = raw.s[3];
+  b.x = raw.s[4]; b.y = raw.s[5]; b.z = raw.s[SW - 2]; b.w = raw.s[SW - 1];   // (SW == 6: .z / .w are never read, the width is <= 21)
+  if (SW == 8 && p.oct_src_kind == OCT_SRC_RAW32) {
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int j = 0; j < 8; j++) item[j] = bswap32(w[j]);
+  } else if (SW == 6) {
+    switch (p.srcs[p.oct_src].bits) {   // wave-uniform; <= 21
+#define OCT_CASE(B) case B: oct_decode_wide<B>(a, b, ln.ssel, item); break;
+      OCT_CASE(1) OCT_CASE(2) OCT_CASE(3) OCT_CASE(4) OCT_CASE(5) OCT_CASE(6) OCT_CASE(7) OCT_CASE(8) OCT_CASE(9) OCT_CASE(10) OCT_CASE(11)
+      OCT_CASE(12) OCT_CASE(13) OCT_CASE(14) OCT_CASE(15) OCT_CASE(16) OCT_CASE(17) OCT_CASE(18) OCT_CASE(19) OCT_CASE(20)
+#undef OCT_CASE
+      default: oct_decode_wide<21>(a, b, ln.ssel, item); break;
+    }
+  } else {
+    oct_decode_source(p.srcs[p.oct_src].bits, a, b, ln.ssel, item);
+  }
+}
+
+template <bool MASKED, int NW, int SW>
 __device__ __forceinline__ void oct_body_lds(const PgQueryPlan& p) {
   extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
   const int t = threadIdx.x, lane = t & 63, wave = uniform(t >> 6);
@@ -155,29 +245,29 @@ __device__ __forceinline__ void oct_body_lds(const PgQueryPlan& p) {
   const int n_sub = n_mine * OCT_SUBS_PER_WTILE;
   const int last_wt = p.n_wtiles - 1;
   auto wt_of = [&](int u) { const int w = first + (u >> 2) * step; return w < p.n_wtiles ? w : last_wt; };   // clamped: loads stay in bounds
-  // Two load buffers; a buffer is re-requested (two sub-tiles ahead) right AFTER it has been decoded, never before: hipcc waits for
+  // Load buffers in rotation; a buffer is re-requested (DEPTH sub-tiles ahead) right AFTER it has been decoded, never before: hipcc waits for
   // every load in flight (s_waitcnt vmcnt(0)) where the decode's wave-uniform switch consumes a buffer, so loads requested just before a
   // decode were waited for on the spot — no overlap at all inside a wavefront (r04_b: 58 % of the wave's cycles waiting).  Requested
-  // after the decode they travel during this sub-tile's hash / LDS phase and the whole next sub-tile.
-  OctRaw ra, rb;
-  if (n_sub > 0) { oct_issue<MASKED>(p, ln, wt_of(0), 0, lane, ra); oct_issue<MASKED>(p, ln, wt_of(1), 1, lane, rb); }
-  for (int u = 0; u < n_sub; u += 2) {
-    {
-      uint32_t key[8], item[8];
-      oct_decode(p, ln, ra, key, item);
-      const uint32_t m8 = oct_mask8(p, wt_of(u), u & 3, lane, ra.mw, MASKED);
-      oct_issue<MASKED>(p, ln, wt_of(u + 2), (u + 2) & 3, lane, ra);
-      oct_finish(p, key, item);
-      oct_apply_lds(p, m8, key, item, table, aux_words, rep);
-    }
-    {
-      uint32_t key[8], item[8];
-      oct_decode(p, ln, rb, key, item);
-      const uint32_t m8 = oct_mask8(p, wt_of(u + 1), (u + 1) & 3, lane, rb.mw, MASKED);
-      oct_issue<MASKED>(p, ln, wt_of(u + 3), (u + 3) & 3, lane, rb);
-      oct_finish(p, key, item);
-      oct_apply_lds(p, m8, key, item, table, aux_words, rep);
-    }
+  // after the decode they travel during this sub-tile's hash / LDS phase and the next DEPTH - 1 sub-tiles.  Three buffers where their
+  // compile-time size (OctRawS) leaves room, else two.
+  constexpr int DEPTH = (4 * NW + SW) * 3 <= 48 ? 3 : 2;
+  OctRawS<NW, SW> r[DEPTH];
+  auto turn = [&](OctRawS<NW, SW>& raw, int u) __attribute__((always_inline)) {
+    if (u >= n_sub) return;   // wave-uniform: n_sub is a multiple of 4, the last round of three is partial
+    uint32_t key[8], item[8];
+    octs_decode<NW, SW>(p, ln, raw, key, item);
+    const uint32_t m8 = oct_mask8(p, wt_of(u), u & 3, lane, raw.mw, MASKED);
+    octs_issue<MASKED, NW, SW>(p, ln, wt_of(u + DEPTH), (u + DEPTH) & 3, lane, raw);
+    oct_finish(p, key, item);
+    oct_apply_lds(p, m8, key, item, table, aux_words, rep);
+  };
+  if (n_sub > 0) {
+#pragma unroll
+    for (int k = 0; k < DEPTH; k++) octs_issue<MASKED, NW, SW>(p, ln, wt_of(k), k & 3, lane, r[k]);
+  }
+  for (int u = 0; u < n_sub; u += DEPTH) {
+#pragma unroll
+    for (int k = 0; k < DEPTH; k++) turn(r[k], u + k);
   }
   __syncthreads();
   // flush: the partial table [n_ops][G] (replicas folded) and the states, as pg_generic_query_l leaves them
@@ -204,8 +294,18 @@ __device__ __forceinline__ void oct_body_lds(const PgQueryPlan& p) {
     }
   }
 }
-extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_oct_l(const PgQueryPlan p) { oct_body_lds<false>(p); }
-extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_oct_lm(const PgQueryPlan p) { oct_body_lds<true>(p); }
+template <bool MASKED>
+__device__ __forceinline__ void oct_lds_dispatch(const PgQueryPlan& p) {
+  bool narrow = true;   // wave-uniform
+  for (int g = 0; g < p.n_group_cols; g++) narrow = narrow && p.gcols[g].bits <= 4;
+  const bool short_source = p.oct_src_kind == OCT_SRC_NONE || (p.oct_src_kind != OCT_SRC_RAW32 && p.srcs[p.oct_src].bits <= 21);
+  if (narrow && short_source) oct_body_lds<MASKED, 2, 6>(p);
+  else if (narrow) oct_body_lds<MASKED, 2, 8>(p);
+  else if (short_source) oct_body_lds<MASKED, 3, 6>(p);
+  else oct_body_lds<MASKED, 3, 8>(p);
+}
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_oct_l(const PgQueryPlan p) { oct_lds_dispatch<false>(p); }
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_oct_lm(const PgQueryPlan p) { oct_lds_dispatch<true>(p); }
 
 // ---- back end C: COUNT(*) alone, no filter in front (round 5) ----------------------------------------------------------------------------
 // SELECT dims, COUNT(*) GROUP BY dims reads 0.4 - 2 bytes per doc: with two load buffers per wavefront (oct_body_lds) a CU has ~30 KB in
@@ -214,8 +314,6 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_oct_lm(const PgQueryPl
 // sub-tile u + 4 is requested where sub-tile u has been decoded.
 // Buffers of NW dwords per column — two when every group column has <= 4 bits (8 values: 4 bytes + 3 of misalignment), three up to 8 bits —
 // so that four of them fit beside the decode's registers under the 128 a 16-wavefront workgroup leaves each lane (three for 3-4 wide columns).
-typedef uint32_t u32x2o __attribute__((ext_vector_type(2)));
-typedef u32x2o u32x2o_a4 __attribute__((aligned(4)));
 template <int NG, int NW> struct OctRawG { uint32_t g[NG][NW]; };
 template <int NG, int NW>
 DEVFN void octc_issue(const PgQueryPlan& p, const OctLane& ln, int wt, int sub, OctRawG<NG, NW>& raw) {
@@ -392,93 +490,6 @@ DEVFN void oct_apply_pruned(const PgQueryPlan& p, uint32_t m8, const uint32_t (&
     }
   st.head += total;
   while (st.head - st.tail >= (uint32_t)OCT_STREAM_BLOCK) oct_flush_block(p, ring, s_cur, region_base, st, lane);   // wave-uniform; <= 3 blocks
-}
-
-// Load buffers of the pruned passes, sized at compile time: NW dwords per group column (2 when every width is <= 4 bits, else 3) and SW dwords
-// of the source (6 up to 21 bits: 8 x 21 bits + 3 bytes of misalignment = 24 bytes; 8 for wider dictionaries and raw INT values) — 15 registers
-// for config 5 against OctRaw's 21, which is what lets THREE buffers rotate inside the 128 registers a 16-wavefront workgroup leaves a lane.
-// With two, a buffer was requested one turn (decode + hash + pruning, ~2 us with four wavefronts per SIMD) before it was needed: about the
-// latency of HBM under load, and the waves waited 52 % of their cycles at 61 % VALU use (profiles/r04_f_sq_counters_cfg5_200m.txt).
-template <int NW, int SW> struct OctRawS { uint32_t g[4][NW]; uint32_t s[SW]; uint32_t mw; };
-template <bool MASKED, int NW, int SW>
-DEVFN void octs_issue(const PgQueryPlan& p, const OctLane& ln, int wt, int sub, int lane, OctRawS<NW, SW>& raw) {
-#pragma unroll
-  for (int g = 0; g < 4; g++)
-    if (g < p.n_group_cols) {
-      const PgGroupCol& gc = p.gcols[g];
-      const GAS uint8_t* base = gptr<uint8_t>(gc.data) + (size_t)wt * (size_t)(PG_WAVE_DOCS / 8) * (size_t)gc.bits + (size_t)sub * (size_t)(OCT_SUB_DOCS / 8) * (size_t)gc.bits;
-      if (NW == 2) {
-        const u32x2o v = ldnt((const GAS u32x2o_a4*)(base + ln.goff[g]));
-        raw.g[g][0] = v.x; raw.g[g][1] = v.y;
-      } else {
-        const u32x3 v = ldnt((const GAS u32x3_a4*)(base + ln.goff[g]));
-        raw.g[g][0] = v.x; raw.g[g][1] = v.y; raw.g[g][NW - 1] = v.z;
-      }
-    }
-  {
-    const PgValueSrc& V = p.srcs[p.oct_src];
-    const uint32_t bits = p.oct_src_kind == OCT_SRC_RAW32 ? 32u : (uint32_t)V.bits;
-    const GAS uint8_t* base = gptr<uint8_t>(V.data) + (size_t)wt * (size_t)(PG_WAVE_DOCS / 8) * (size_t)bits + (size_t)sub * (size_t)(OCT_SUB_DOCS / 8) * (size_t)bits;
-    const u32x4 a = ldnt((const GAS u32x4_a4*)(base + ln.soff));
-    raw.s[0] = a.x; raw.s[1] = a.y; raw.s[2] = a.z; raw.s[3] = a.w;
-    if (SW == 6) {
-      const u32x2o b = ldnt((const GAS u32x2o_a4*)(base + ln.soff + 16u));
-      raw.s[4] = b.x; raw.s[SW - 1] = b.y;
-    } else {
-      const u32x4 b = ldnt((const GAS u32x4_a4*)(base + ln.soff + 16u));
-      raw.s[4] = b.x; raw.s[5] = b.y; raw.s[SW - 2] = b.z; raw.s[SW - 1] = b.w;
-    }
-  }
-  if (MASKED) raw.mw = gptr<uint32_t>(p.match_words)[(size_t)wt * 64 + (size_t)sub * 16 + (size_t)(lane >> 2)];
-}
-// oct_decode over the sized buffer: keys and raw source items of the lane's 8 docs
-template <int NW, int SW>
-DEVFN void octs_decode(const PgQueryPlan& p, const OctLane& ln, const OctRawS<NW, SW>& raw, uint32_t (&key)[8], uint32_t (&item)[8]) {
-#pragma unroll
-  for (int j = 0; j < 8; j++) key[j] = 0;
-#pragma unroll
-  for (int g = 0; g < 4; g++)
-    if (g < p.n_group_cols) {
-      uint32_t v[8];
-      u32x3 w;
-      w.x = raw.g[g][0]; w.y = raw.g[g][1]; w.z = raw.g[g][NW - 1];   // (NW == 2: .z is never read, the widths are <= 4)
-      if (NW == 2) {
-        switch (p.gcols[g].bits) {   // wave-uniform
-          case 1: oct_decode_small<1>(w, ln.gsel[g], v); break;
-          case 2: oct_decode_small<2>(w, ln.gsel[g], v); break;
-          case 3: oct_decode_small<3>(w, ln.gsel[g], v); break;
-          default: oct_decode_small<4>(w, ln.gsel[g], v); break;
-        }
-      } else {
-        oct_decode_group(p.gcols[g].bits, w, ln.gsel[g], v);
-      }
-      if (g == 0) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) key[j] = v[j];   // mult of column 0 is 1
-      } else {
-        const uint32_t mult = (uint32_t)p.gcols[g].mult;
-#pragma unroll
-        for (int j = 0; j < 8; j++) key[j] = mad24(v[j], mult, key[j]);
-      }
-    }
-  u32x4 a, b;
-  a.x = raw.s[0]; a.y = raw.s[1]; a.z = raw.s[2]; a.w = raw.s[3];
-  b.x = raw.s[4]; b.y = raw.s[5]; b.z = raw.s[SW - 2]; b.w = raw.s[SW - 1];   // (SW == 6: .z / .w are never read, the width is <= 21)
-  if (SW == 8 && p.oct_src_kind == OCT_SRC_RAW32) {
-    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-    for (int j = 0; j < 8; j++) item[j] = bswap32(w[j]);
-  } else if (SW == 6) {
-    switch (p.srcs[p.oct_src].bits) {   // wave-uniform; <= 21
-#define OCT_CASE(B) case B: oct_decode_wide<B>(a, b, ln.ssel, item); break;
-      OCT_CASE(1) OCT_CASE(2) OCT_CASE(3) OCT_CASE(4) OCT_CASE(5) OCT_CASE(6) OCT_CASE(7) OCT_CASE(8) OCT_CASE(9) OCT_CASE(10) OCT_CASE(11)
-      OCT_CASE(12) OCT_CASE(13) OCT_CASE(14) OCT_CASE(15) OCT_CASE(16) OCT_CASE(17) OCT_CASE(18) OCT_CASE(19) OCT_CASE(20)
-#undef OCT_CASE
-      default: oct_decode_wide<21>(a, b, ln.ssel, item); break;
-    }
-  } else {
-    oct_decode_source(p.srcs[p.oct_src].bits, a, b, ln.ssel, item);
-  }
 }
 
 template <bool MASKED, int NW, int SW>
