@@ -19,7 +19,7 @@ PG_DECL_GENERIC
 PG_DECL_FAST(pg_fast_none_f) PG_DECL_FAST(pg_fast_none_a) PG_DECL_FAST(pg_fast_i32range_f) PG_DECL_FAST(pg_fast_i32range_a)
 PG_DECL_FAST(pg_fast_dictrange_f) PG_DECL_FAST(pg_fast_dictrange_a) PG_DECL_FAST(pg_fast_dictlut_f) PG_DECL_FAST(pg_fast_dictlut_a)
 PG_DECL_FAST(pg_fast_multi_f) PG_DECL_FAST(pg_fast_multi_a) PG_DECL_FAST(pg_fast_multi_w) PG_DECL_FAST(pg_fast_none_w)
-PG_DECL_FAST(pg_fast_i32range_d) PG_DECL_FAST(pg_fast_i32range_p) PG_DECL_FAST(pg_fast_i32range_fp)
+PG_DECL_FAST(pg_fast_i32range_d) PG_DECL_FAST(pg_fast_i32range_p) PG_DECL_FAST(pg_fast_i32range_fp) PG_DECL_FAST(pg_fast_i32range_s)
 PG_DECL_FAST(pg_dense_count_1) PG_DECL_FAST(pg_dense_count_2) PG_DECL_FAST(pg_dense_count_3) PG_DECL_FAST(pg_dense_count_4)
 PG_DECL_FAST(pg_dense_count_5) PG_DECL_FAST(pg_dense_count_6) PG_DECL_FAST(pg_dense_count_7) PG_DECL_FAST(pg_dense_count_8)
 PG_DECL_FAST(pg_dict_count_1) PG_DECL_FAST(pg_dict_count_2) PG_DECL_FAST(pg_dict_count_3) PG_DECL_FAST(pg_dict_count_4)
@@ -34,6 +34,8 @@ PG_DECL_FAST(pg_pipe_scan_vscan) PG_DECL_FAST(pg_pipe_index_scan_vscan)
 PG_DECL_FAST(pg_mv_query_f) PG_DECL_FAST(pg_mv_query_l) PG_DECL_FAST(pg_mv_query_g)   // pg_kernels_mv.hip
 extern "C" const int pg_scan_waves_per_block;   // pg_kernels_scan.hip: wavefronts per workgroup of pg_fast_i32range_fp
 extern "C" const int pg_pipe_waves_per_block;   // pg_kernels_pipe.hip: wavefronts per workgroup of pg_fast_i32range_p
+extern "C" const int pg_spec_waves_per_block;   // pg_kernels_spec.hip: pg_fast_i32range_s (4 loader + 8 consumer wavefronts)
+extern "C" int pg_spec_stage_bytes(int bits0, int bits1);
 PG_DECL_FAST(pg_fast_multi_wd) PG_DECL_FAST(pg_fast_none_wd) PG_DECL_FAST(pg_generic_query_ld) PG_DECL_FAST(pg_generic_query_gd)
 extern "C" __global__ void pg_reduce_partials_kernel(const int64_t* partials, int64_t* out, int n_wg, int n_ops,
                                                      int n_groups, const PgAccOp* ops, unsigned long long* stats, int reduce);
@@ -372,6 +374,15 @@ static bool uses_pipe_kernel(const CompiledPlan& P, int agg_mode) {
          P.dev.dense_fused && P.dev.pipe_fit;
 }
 
+// pg_fast_i32range_s (pg_kernels_spec.hip): the same plans as pg_fast_i32range_p with loader / consumer wavefronts — PG_WAVE_SPECIALISED only
+static size_t spec_stage_bytes(const CompiledPlan& P) {
+  return ((size_t)pg_spec_stage_bytes(P.dev.gcols[0].bits, P.dev.n_group_cols > 1 ? P.dev.gcols[1].bits : 0) + 15) & ~(size_t)15;
+}
+static bool uses_spec_kernel(const CompiledPlan& P, int agg_mode) {
+  if (!knobs().wave_specialised || !uses_pipe_kernel(P, agg_mode) || uses_pipe_general(P, agg_mode) || uses_pipe_wide(P, agg_mode)) return false;
+  return P.dev.n_group_cols >= 1 && P.dev.n_group_cols <= 2 && P.lds_bytes + 128 + 2 * spec_stage_bytes(P) + 512 * (size_t)P.dev.n_ops <= lds_per_cu();
+}
+
 extern "C" void pg_trim_launch(const PgTrimArgs* args, int grid, hipStream_t stream);
 extern "C" void pg_trim_launch_keys(const PgTrimArgs* args, int grid, hipStream_t stream);
 extern "C" void pg_trim_launch_select(const PgTrimArgs* args, int grid, hipStream_t stream);
@@ -418,6 +429,7 @@ static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char
       *name = tail ? "pg_pipe_tail" : "pg_pipe_none";
       return tail ? pg_pipe_tail : pg_pipe_none;
     }
+    if (uses_spec_kernel(P, agg_mode)) { *name = "pg_fast_i32range_s"; return pg_fast_i32range_s; }
     if (uses_pipe_kernel(P, agg_mode)) { *name = "pg_fast_i32range_p"; return pg_fast_i32range_p; }
     if (uses_scan_kernel(P, agg_mode)) { *name = "pg_fast_i32range_fp"; return pg_fast_i32range_fp; }
     if (agg && P.fast_filter == 4 && P.dev.dense_fused && !no_dense && P.fast_agg && agg_mode == PG_AGG_LDS) { *name = "pg_fast_i32range_d"; return pg_fast_i32range_d; }
@@ -538,6 +550,8 @@ static LaunchShape launch_shape(const CompiledPlan& P, int n_wtiles, int agg_mod
     int grid = std::min((n_wtiles + waves - 1) / waves, num_cus() * std::max(wgs_per_cu, 1));
     return {std::max(grid, 1), waves * 64, 0};
   }
+  if (uses_spec_kernel(P, agg_mode))   // one 12-wavefront workgroup per CU walking tiles b, b + grid, ...; table + two stage buffers in LDS
+    return {std::max(1, std::min(n_wtiles, num_cus())), pg_spec_waves_per_block * 64, lds + 64 + 2 * spec_stage_bytes(P) + 512 * (size_t)P.dev.n_ops};   // (+ 64 trash slots per accumulator)
   if (uses_pipe_kernel(P, agg_mode)) {
     const int wgs_per_cu = knobs().pipe_wgs_per_cu;   // tuning knob
     const int per_cu = ((size_t)wgs_per_cu * (lds + 4096) <= lds_per_cu()) ? wgs_per_cu : 1;

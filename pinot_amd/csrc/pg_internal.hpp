@@ -453,6 +453,7 @@ struct Knobs {
   // executor (pg_exec.hip)
   bool force_interpreter = false, no_scan_pipe = false, no_pipe = false, no_dense_fused = false, no_part_grid_clamp = false, no_spin_wait = false;
   bool trace_oct = false, no_tile_split = false, no_oct_exec = false, no_p2_simple = false, no_dense_count = false, no_direct_result = false, trace_host = false, no_limit_prefix = false, no_device_trim = false, no_fused_finish = false;
+  bool wave_specialised = false;   // PG_WAVE_SPECIALISED: pg_fast_i32range_s instead of pg_fast_i32range_p (experiment, profiles/r05_wave_specialised.txt)
   int max_inflight = 16;   // PG_MAX_INFLIGHT: queries between submission and result per device (<= 0: unbounded)
   int scan_wgs_per_cu = 1, pipe_wgs_per_cu = 1, wgs_per_cu = 1, p2_wgs_per_cu = 4, dense_count_wgs = 1, tile_split_max = -1, hash_first_buckets = -1;
   int64_t exact_stats_max_docs = (int64_t)1 << 22;

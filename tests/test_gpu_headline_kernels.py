@@ -112,3 +112,30 @@ def test_pipeline_behind_an_upsert_snapshot(gpu_api, oracle_api, n):
                 assert gb.stats.kernel.decode() == kernel, (sql, keep, gb.stats.kernel)
     g.destroy()
     o.destroy()
+
+
+# ---- pg_fast_i32range_s: the same plans with loader / consumer wavefronts (pg_kernels_spec.hip, PG_WAVE_SPECIALISED) ------------------------
+@pytest.mark.parametrize("n", [2049, 70_001, 700_001, 9_030_011])
+def test_wave_specialised_variant_matches_oracle(gpu_api, oracle_api, gpu_knobs, n):
+    """Every query pg_fast_i32range_p takes, through the 4-loader / 8-consumer kernel: results, statistics and the tile walk's edges — fewer
+    tiles than workgroups, an odd and an even number of stages per workgroup (9 030 011 docs: 4 410 tiles over 256 workgroups, 17 or 18
+    each), a ragged last tile."""
+    gpu_knobs(PG_WAVE_SPECIALISED="1")
+    host = synth.generate_segment(n, segment_index=3, columns=COLUMNS)
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    ran = 0
+    for sql, kernel in QUERIES:
+        if kernel != PIPE:
+            continue
+        qc = parse_sql(sql)
+        qc.flags |= capi.QUERY_FLAG_EXACT_FILTER_STATS
+        gb, ob = g.execute(qc), o.execute(sql)
+        assert gb.rows() == ob.rows(), sql
+        for f in ("num_docs_scanned", "num_entries_scanned_in_filter", "num_entries_scanned_post_filter", "num_total_docs"):
+            assert getattr(gb.stats, f) == getattr(ob.stats, f), (f, sql)
+        if knobs_off and n >= 700_001:   # (smaller segments: the planner keeps other kernels; two stage buffers beside a large table: pg_fast_i32range_p)
+            assert gb.stats.kernel.decode() in ("pg_fast_i32range_s", PIPE), sql
+            ran += gb.stats.kernel.decode() == "pg_fast_i32range_s"
+    assert n < 700_001 or ran >= 3
+    g.destroy()
+    o.destroy()
