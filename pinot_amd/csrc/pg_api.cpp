@@ -27,7 +27,8 @@ static void knobs_read(Knobs& k) {
   k.scan_wgs_per_cu = (int)num("PG_SCAN_WGS_PER_CU", 1); k.pipe_wgs_per_cu = (int)num("PG_PIPE_WGS_PER_CU", 1); k.wgs_per_cu = (int)num("PG_WGS_PER_CU", 1);
   k.p2_wgs_per_cu = (int)num("PG_P2_WGS_PER_CU", 4); k.dense_count_wgs = (int)num("PG_DENSE_COUNT_WGS", 1); k.tile_split_max = (int)num("PG_TILE_SPLIT_MAX", -1);
   k.hash_first_buckets = (int)num("PG_HASH_FIRST_BUCKETS", -1);
-  k.max_inflight = (int)num("PG_MAX_INFLIGHT", 16); k.wave_specialised = flag("PG_WAVE_SPECIALISED");
+  k.max_inflight = (int)num("PG_MAX_INFLIGHT", 16); k.wave_specialised = flag("PG_WAVE_SPECIALISED"); k.no_wave_specialised = flag("PG_NO_WAVE_SPECIALISED");
+  k.wave_specialised_min_permille = (int)num("PG_WAVE_SPECIALISED_MIN_PERMILLE", 150);
   k.exact_stats_max_docs = num("PG_EXACT_STATS_MAX_DOCS", (int64_t)1 << 22);
   k.limit_prefix_min_docs = std::max<int64_t>(PG_WAVE_DOCS, num("PG_LIMIT_PREFIX_MIN_DOCS", (int64_t)1 << 20));
   k.oct_passes = str("PG_OCT_PASSES"); k.rccl_library = str("PG_RCCL_LIBRARY");

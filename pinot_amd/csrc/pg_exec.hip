@@ -379,7 +379,10 @@ static size_t spec_stage_bytes(const CompiledPlan& P) {
   return ((size_t)pg_spec_stage_bytes(P.dev.gcols[0].bits, P.dev.n_group_cols > 1 ? P.dev.gcols[1].bits : 0) + 15) & ~(size_t)15;
 }
 static bool uses_spec_kernel(const CompiledPlan& P, int agg_mode) {
-  if (!knobs().wave_specialised || !uses_pipe_kernel(P, agg_mode) || uses_pipe_general(P, agg_mode) || uses_pipe_wide(P, agg_mode)) return false;
+  if (knobs().no_wave_specialised || !uses_pipe_kernel(P, agg_mode) || uses_pipe_general(P, agg_mode) || uses_pipe_wide(P, agg_mode)) return false;
+  // it streams every column whole (84 % of 8 TB/s whatever the filter); pg_fast_i32range_p skips the quads without candidates and wins below
+  // ~15 % candidates — the rate the plan's last execution counted decides, a plan's first execution takes pg_fast_i32range_p
+  if (!knobs().wave_specialised && P.observed_candidate_permille.load(std::memory_order_relaxed) < knobs().wave_specialised_min_permille) return false;
   return P.dev.n_group_cols >= 1 && P.dev.n_group_cols <= 2 && P.lds_bytes + 128 + 2 * spec_stage_bytes(P) + 512 * (size_t)P.dev.n_ops <= lds_per_cu();
 }
 
@@ -1928,6 +1931,11 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
   double ta1 = 0, ta2 = 0;
   const pg_exec_stats keep = res.stats;   // timings / kernel name survive a re-assembly after a merge
   fill_stats(res.stats, P, H.full_scan_entries, H.total_docs, H.stats);
+  if (P.dev.pipe_fit && H.total_docs > 0) {   // (see uses_spec_kernel)
+    int64_t cand = 0;
+    for (int i = 1; i < P.n_stat_slots; i++) cand += (int64_t)H.stats[i];
+    P.observed_candidate_permille.store((int)std::min<int64_t>(1000, cand * 1000 / H.total_docs), std::memory_order_relaxed);
+  }
   res.stats.star_tree_index = P.star_tree_index;
   res.stats.device_ms_total = keep.device_ms_total; res.stats.device_ms_filter = keep.device_ms_filter;
   res.stats.device_ms_aggregate = keep.device_ms_aggregate; res.stats.device_ms_reduce = keep.device_ms_reduce;

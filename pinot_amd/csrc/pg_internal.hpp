@@ -270,6 +270,9 @@ struct CompiledPlan {
   std::vector<DeviceBuffer> keep;    // device allocations referenced by dev
   std::vector<std::shared_ptr<Column>> pinned;   // doc-id bitmaps (null vectors, queryableDocIds snapshot) the program reads
   int32_t n_stat_slots = 1;
+  // candidates of the scan leaf per 1000 docs as the last execution counted them (-1: never run) — pg_fast_i32range_s streams every column
+  // whole, pg_fast_i32range_p skips the quads without candidates: which of the two runs follows what the plan's filter lets through
+  mutable std::atomic<int> observed_candidate_permille{-1};
   int64_t full_scan_entries = 0;     // entries contributed by unmasked scans whose count is known (numDocs each)
   bool stats_exact = true;           // the kernels' own counters give numEntriesScannedInFilter (flat AND shapes, drained ORs)
   // otherwise: the physical filter tree and one filter-only plan per Scan / Inverted leaf — their match bitmaps feed the iterator
@@ -453,7 +456,8 @@ struct Knobs {
   // executor (pg_exec.hip)
   bool force_interpreter = false, no_scan_pipe = false, no_pipe = false, no_dense_fused = false, no_part_grid_clamp = false, no_spin_wait = false;
   bool trace_oct = false, no_tile_split = false, no_oct_exec = false, no_p2_simple = false, no_dense_count = false, no_direct_result = false, trace_host = false, no_limit_prefix = false, no_device_trim = false, no_fused_finish = false;
-  bool wave_specialised = false;   // PG_WAVE_SPECIALISED: pg_fast_i32range_s instead of pg_fast_i32range_p (experiment, profiles/r05_wave_specialised.txt)
+  bool wave_specialised = false, no_wave_specialised = false;   // PG_WAVE_SPECIALISED: pg_fast_i32range_s whatever the filter lets through; PG_NO_WAVE_SPECIALISED: never
+  int wave_specialised_min_permille = 150;                     // PG_WAVE_SPECIALISED_MIN_PERMILLE: ... by default from this candidate rate on (profiles/r05_wave_specialised.txt)
   int max_inflight = 16;   // PG_MAX_INFLIGHT: queries between submission and result per device (<= 0: unbounded)
   int scan_wgs_per_cu = 1, pipe_wgs_per_cu = 1, wgs_per_cu = 1, p2_wgs_per_cu = 4, dense_count_wgs = 1, tile_split_max = -1, hash_first_buckets = -1;
   int64_t exact_stats_max_docs = (int64_t)1 << 22;

@@ -20,6 +20,12 @@
 #include "pg_kernels.hip"
 
 #define SPEC_LOADERS 4
+#ifndef SPEC_TILES
+#define SPEC_TILES 2   // wave tiles per stage: one barrier per 4 096 docs, two independent quad rows per consumer wavefront
+#endif
+#ifndef SPEC_SETS
+#define SPEC_SETS 2    // stages of loads in flight per loader wavefront (register sets).  Three: 1 % at best, and beyond 168 registers (3 wavefronts per SIMD) with two tiles
+#endif
 #define SPEC_CONSUMERS 8
 // stage buffer, per wave tile, byte offsets
 #define SPEC_OFF_LIN 0u                       // the index program's result: 64 dwords, linear layout (computed by a loader wavefront)
@@ -27,8 +33,8 @@
 #define SPEC_OFF_VAL (256u + 2048u)           // 2 048 raw INT values
 #define SPEC_OFF_G0 (256u + 2048u + 8192u)    // bits x 256 bytes + 16 (the packed-quad window reads one dword past its values)
 extern "C" const int pg_spec_waves_per_block = PG_WAVES_PER_BLOCK;
-// bytes of one stage buffer, SPEC_TILES = 2 wave tiles (the host sizes the launch's LDS with it: table + 2 stages)
-extern "C" int pg_spec_stage_bytes(int bits0, int bits1) { return 2 * (((int)SPEC_OFF_G0 + bits0 * 256 + 16 + (bits1 > 0 ? bits1 * 256 + 16 : 0) + 15) & ~15); }   // SPEC_TILES tiles
+// bytes of one stage buffer, SPEC_TILES wave tiles (the host sizes the launch's LDS with it: table + 2 stages)
+extern "C" int pg_spec_stage_bytes(int bits0, int bits1) { return SPEC_TILES * (((int)SPEC_OFF_G0 + bits0 * 256 + 16 + (bits1 > 0 ? bits1 * 256 + 16 : 0) + 15) & ~15); }
 
 // Workgroup barrier that waits for this wavefront's LDS operations only.  __syncthreads() is a workgroup-scope release fence in front of
 // s_barrier — s_waitcnt vmcnt(0) as well — which would drain the loaders' two stages of global loads at every stage.
@@ -53,7 +59,6 @@ struct SpecTile {
   u32x4 col[4];
   u32x4 grp;
 };
-#define SPEC_TILES 2   // wave tiles per stage: one barrier per 4 096 docs, two independent quad rows per consumer wavefront
 struct SpecStage { SpecTile tile[SPEC_TILES]; uint32_t post[8]; };
 // what a consumer lane reads of one wave tile: everything up front, one LDS round trip per stage
 template <int NG> struct SpecQuad {
@@ -123,7 +128,7 @@ __device__ __forceinline__ void spec_body(const PgQueryPlan& p) {
         __builtin_amdgcn_sched_barrier(0);
       }
       {
-        const int i = sidx * SPEC_TILES + (w & 1);
+        const int i = sidx * SPEC_TILES + (w % SPEC_TILES);
         const int wt = (int)blockIdx.x + (i < n_mine ? i : n_mine - 1) * grid;
 #pragma unroll
         for (int j = 0; j < 8; j++) st.post[j] = ldnt((const GAS uint32_t*)(spec_sgpr_ptr<uint8_t>(p.dense_ptr[j] + (size_t)wt * 256u) + (uint32_t)lane * 4u));
@@ -166,7 +171,7 @@ __device__ __forceinline__ void spec_body(const PgQueryPlan& p) {
     };
     // loaders 0 and 1: the index program of tile w of the stage over this lane's 32 docs (linear layout), into the tile's buffer
     auto publish_lin = [&](uint8_t* stage, const SpecStage& st, int sidx) __attribute__((always_inline)) {
-      if (w >= SPEC_TILES) return;   // wave-uniform (loaders 2 and 3 loaded the same dwords: their loads keep every loader's wait counts alike)
+      if (w >= SPEC_TILES) return;   // wave-uniform (the other loaders loaded dwords too: their loads keep every loader's wait counts alike)
       const int i = sidx * SPEC_TILES + w;
       const int wt = (int)blockIdx.x + i * grid;
       const int64_t rem = i < n_mine ? (int64_t)p.num_docs - (int64_t)wt * PG_WAVE_DOCS : 0;   // (the second tile of an odd last stage: empty)
@@ -185,39 +190,33 @@ __device__ __forceinline__ void spec_body(const PgQueryPlan& p) {
       *reinterpret_cast<uint32_t*>(stage + (uint32_t)w * tile_bytes + SPEC_OFF_LIN + (uint32_t)lane * 4u) = lin;
       ld_cand += (uint32_t)__popc(lin);   // the scan leaf's candidates (numEntriesScannedInFilter), counted where the whole dword is at hand
     };
-    // THREE stages of loads in flight per loader (3 x 18 loads, 3 x 48 registers): with two, 80 KB per CU were in flight against the ~160 KB of
-    // pg_fast_i32range_p's eight wavefronts, and the loaders waited for HBM where they publish (1.68 ms; profiles/r05_wave_specialised.txt).
-    // The LDS buffers stay two: buffer = stage & 1.
-    SpecStage sa, sb, sc;
-    auto buf_of = [&](int st) __attribute__((always_inline)) { return stage0 + (uint32_t)(st & 1) * stage_bytes; };
-    if (n_stages > 0) { issue(0, sa); issue(1, sb); issue(2, sc); }
-    // Whole triples of stages in the loop, the rest behind it: a conditional half INSIDE the loop gives the compiler a path on which a younger
-    // stage's loads are older at the loop head, and it then waits for all of them.
+    // SPEC_SETS stages of loads in flight per loader (a register set each).  With two sets of two tiles 80 KB per CU were in flight against the
+    // ~160 KB of pg_fast_i32range_p's eight wavefronts; the LDS buffers stay two: buffer = stage & 1.
+    SpecStage st[SPEC_SETS];
+    auto buf_of = [&](int sg) __attribute__((always_inline)) { return stage0 + (uint32_t)(sg & 1) * stage_bytes; };
+    if (n_stages > 0) {
+#pragma unroll
+      for (int k = 0; k < SPEC_SETS; k++) issue(k, st[k]);
+    }
+    // Whole rounds of SPEC_SETS stages in the loop, the rest behind it: a conditional part INSIDE the loop gives the compiler a path on which a
+    // younger stage's loads are older at the loop head, and it then waits for all of them.
     int s = 0;
-    for (; s + 2 < n_stages; s += 3) {
-      publish(buf_of(s), sa);                  // waits for stage s's loads only: the two younger stages stay in flight
-      publish_lin(buf_of(s), sa, s);
-      issue(s + 3, sa);
-      spec_barrier();                          // barrier s: its buffer holds stage s
-      publish(buf_of(s + 1), sb);
-      publish_lin(buf_of(s + 1), sb, s + 1);
-      issue(s + 4, sb);
-      spec_barrier();                          // barrier s + 1
-      publish(buf_of(s + 2), sc);
-      publish_lin(buf_of(s + 2), sc, s + 2);
-      issue(s + 5, sc);
-      spec_barrier();                          // barrier s + 2
+    for (; s + SPEC_SETS - 1 < n_stages; s += SPEC_SETS) {
+#pragma unroll
+      for (int k = 0; k < SPEC_SETS; k++) {
+        publish(buf_of(s + k), st[k]);         // waits for stage s + k's loads only: the younger stages stay in flight
+        publish_lin(buf_of(s + k), st[k], s + k);
+        issue(s + k + SPEC_SETS, st[k]);
+        spec_barrier();                        // barrier s + k: its buffer holds the stage
+      }
     }
-    if (s < n_stages) {                        // workgroup-uniform
-      publish(buf_of(s), sa);
-      publish_lin(buf_of(s), sa, s);
-      spec_barrier();
-    }
-    if (s + 1 < n_stages) {
-      publish(buf_of(s + 1), sb);
-      publish_lin(buf_of(s + 1), sb, s + 1);
-      spec_barrier();
-    }
+#pragma unroll
+    for (int k = 0; k < SPEC_SETS - 1; k++)
+      if (s + k < n_stages) {                  // workgroup-uniform
+        publish(buf_of(s + k), st[k]);
+        publish_lin(buf_of(s + k), st[k], s + k);
+        spec_barrier();
+      }
     const uint32_t csum = wave_sum_u32(ld_cand);
     if (lane == 0 && csum) atomicAdd(&s_stat[L.stat_slot], csum);
   } else {

@@ -139,3 +139,31 @@ def test_wave_specialised_variant_matches_oracle(gpu_api, oracle_api, gpu_knobs,
     assert n < 700_001 or ran >= 3
     g.destroy()
     o.destroy()
+
+
+def test_kernel_follows_the_candidate_rate_of_the_last_execution(gpu_api, oracle_api, gpu_knobs):
+    """pg_fast_i32range_s streams every column whole, pg_fast_i32range_p skips quads without candidates: a plan's first execution takes
+    pg_fast_i32range_p, later ones follow the candidate rate it counted (>= 15 %: config 3 lets 25 % through); PG_NO_WAVE_SPECIALISED pins
+    pg_fast_i32range_p.  Results are the oracle's either way."""
+    if not knobs_off:
+        pytest.skip("kernel-selection knobs set")
+    host = synth.generate_segment(3_000_017, segment_index=4, columns=COLUMNS)
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    selective = ("SELECT g1, SUM(m), MAX(m) FROM gpuBench WHERE c_inv1 = 0 AND c_inv2 = 0 AND r_int BETWEEN 250000 AND 749999 "
+                 "GROUP BY g1 ORDER BY g1 LIMIT 1000")
+    for sql, later in ((synth.QUERY_CFG3, "pg_fast_i32range_s"), (selective, PIPE)):
+        qc = parse_sql(sql)
+        ob = o.execute(sql)
+        kernels = []
+        for _ in range(3):
+            gb = g.execute(qc)
+            assert gb.rows() == ob.rows()
+            assert gb.stats.num_entries_scanned_in_filter == ob.stats.num_entries_scanned_in_filter
+            kernels.append(gb.stats.kernel.decode())
+        assert kernels == [PIPE, later, later], (sql, kernels)
+    g.destroy()
+    o.destroy()
+    gpu_knobs(PG_NO_WAVE_SPECIALISED="1")
+    g = NativeSegment(gpu_api, host)
+    assert [g.execute(synth.QUERY_CFG3).stats.kernel.decode() for _ in range(3)] == [PIPE] * 3
+    g.destroy()

@@ -97,6 +97,13 @@ QUERIES = {
     "no filter sum(m)": ("SELECT SUM(m) FROM t", 4.0),
     "cfg3": (synth.QUERY_CFG3, 9.625),
     "northstar": (synth.QUERY_NORTH_STAR, 10.375),
+    # the headline shape at other index selectivities (candidates of the range scan as a fraction of the docs): pg_fast_i32range_p skips the
+    # quads without candidates, pg_fast_i32range_s streams everything
+    "sel 3%": ("SELECT g1, SUM(m), MAX(m) FROM t WHERE c_inv1 = 0 AND c_inv2 = 0 AND r_int BETWEEN 250000 AND 749999 GROUP BY g1", 9.625),
+    "sel 6%": ("SELECT g1, SUM(m), MAX(m) FROM t WHERE c_inv1 IN (0,1) AND c_inv2 = 0 AND r_int BETWEEN 250000 AND 749999 GROUP BY g1", 9.625),
+    "sel 12%": ("SELECT g1, SUM(m), MAX(m) FROM t WHERE c_inv1 IN (0,1,2,3) AND c_inv2 = 0 AND r_int BETWEEN 250000 AND 749999 GROUP BY g1", 9.625),
+    "sel 50%": ("SELECT g1, SUM(m), MAX(m) FROM t WHERE c_inv1 IN (0,1,2,3) AND c_inv2 NOT IN (3) AND r_int BETWEEN 250000 AND 749999 GROUP BY g1", 9.625),
+    "sel 75% all match": ("SELECT g1, SUM(m), MAX(m) FROM t WHERE c_inv1 NOT IN (7) AND c_inv2 NOT IN (3) AND r_int BETWEEN 0 AND 2000000 GROUP BY g1", 9.625),
     "g1 scan eq": ("SELECT COUNT(*) FROM t WHERE g1 = 7", 0.875),
 }
 QUERIES5 = {
