@@ -19,7 +19,7 @@ PG_DECL_GENERIC
 PG_DECL_FAST(pg_fast_none_f) PG_DECL_FAST(pg_fast_none_a) PG_DECL_FAST(pg_fast_i32range_f) PG_DECL_FAST(pg_fast_i32range_a)
 PG_DECL_FAST(pg_fast_dictrange_f) PG_DECL_FAST(pg_fast_dictrange_a) PG_DECL_FAST(pg_fast_dictlut_f) PG_DECL_FAST(pg_fast_dictlut_a)
 PG_DECL_FAST(pg_fast_multi_f) PG_DECL_FAST(pg_fast_multi_a) PG_DECL_FAST(pg_fast_multi_w) PG_DECL_FAST(pg_fast_none_w)
-PG_DECL_FAST(pg_fast_i32range_d) PG_DECL_FAST(pg_fast_i32range_p) PG_DECL_FAST(pg_fast_i32range_fp) PG_DECL_FAST(pg_fast_i32range_s)
+PG_DECL_FAST(pg_fast_i32range_d) PG_DECL_FAST(pg_fast_i32range_p) PG_DECL_FAST(pg_fast_i32range_fp) PG_DECL_FAST(pg_fast_i32range_s) PG_DECL_FAST(pg_spec_none) PG_DECL_FAST(pg_spec_scan) PG_DECL_FAST(pg_spec_index)
 PG_DECL_FAST(pg_dense_count_1) PG_DECL_FAST(pg_dense_count_2) PG_DECL_FAST(pg_dense_count_3) PG_DECL_FAST(pg_dense_count_4)
 PG_DECL_FAST(pg_dense_count_5) PG_DECL_FAST(pg_dense_count_6) PG_DECL_FAST(pg_dense_count_7) PG_DECL_FAST(pg_dense_count_8)
 PG_DECL_FAST(pg_dict_count_1) PG_DECL_FAST(pg_dict_count_2) PG_DECL_FAST(pg_dict_count_3) PG_DECL_FAST(pg_dict_count_4)
@@ -320,6 +320,8 @@ void use_device(int ordinal) {
                                  pg_p2_aggregate_1n, pg_p2_aggregate_2n, pg_p2_aggregate_3n, pg_p2_aggregate_4n, pg_p2_aggregate_1s, pg_p2_aggregate_2s, pg_p2_aggregate_1sg, pg_p2_aggregate_2sg};
       for (QueryKernel k : all)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
+      for (QueryKernel k : {pg_fast_i32range_s, pg_spec_none, pg_spec_scan, pg_spec_index})
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
       for (QueryKernel k : {pg_mv_query_f, pg_mv_query_l, pg_mv_query_g})   // 10.5 KB of static LDS (per-wavefront entry bitmaps): the planner's 144 KB still fit
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 12288);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pg_radix_scatter_packed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
@@ -378,13 +380,38 @@ static bool uses_pipe_kernel(const CompiledPlan& P, int agg_mode) {
 static size_t spec_stage_bytes(const CompiledPlan& P) {
   return ((size_t)pg_spec_stage_bytes(P.dev.gcols[0].bits, P.dev.n_group_cols > 1 ? P.dev.gcols[1].bits : 0) + 15) & ~(size_t)15;
 }
-static bool uses_spec_kernel(const CompiledPlan& P, int agg_mode) {
-  if (knobs().no_wave_specialised || !uses_pipe_kernel(P, agg_mode) || uses_pipe_general(P, agg_mode) || uses_pipe_wide(P, agg_mode)) return false;
-  // it streams every column whole (84 % of 8 TB/s whatever the filter); pg_fast_i32range_p skips the quads without candidates and wins below
-  // ~15 % candidates — the rate the plan's last execution counted decides, a plan's first execution takes pg_fast_i32range_p
-  if (!knobs().wave_specialised && P.observed_candidate_permille.load(std::memory_order_relaxed) < knobs().wave_specialised_min_permille) return false;
-  return P.dev.n_group_cols >= 1 && P.dev.n_group_cols <= 2 && P.lds_bytes + 128 + 2 * spec_stage_bytes(P) + 512 * (size_t)P.dev.n_ops <= lds_per_cu();
+// Which plans: pg_fast_i32range_p's (index AND scan) and the pipeline's general shapes without a tail bitmap or a second scan (none / scan /
+// index).  It streams every column whole (84-92 % of 8 TB/s whatever the filter); the pipelined kernels request only the quads that hold a
+// candidate / a match and win where the filter is selective — so the candidate rate the plan's LAST execution counted decides (a plan's first
+// execution takes the pipelined kernel): >= 15 % candidates behind the index.  The general shapes: only when forced (below).
+static int spec_shape(const CompiledPlan& P, int agg_mode) {   // 0: no; 1 index + scan; 2 none; 3 scan; 4 index
+  if (knobs().no_wave_specialised || !uses_pipe_kernel(P, agg_mode) || uses_pipe_wide(P, agg_mode)) return 0;
+  if (P.dev.n_group_cols < 1 || P.dev.n_group_cols > 2 || P.lds_bytes + 256 + 2 * spec_stage_bytes(P) + 512 * (size_t)P.dev.n_ops > (size_t)160 * 1024 - 8192) return 0;   // (the dynamic-LDS limit device_init asks for)
+  const bool force = knobs().wave_specialised;
+  const int cand = P.observed_candidate_permille.load(std::memory_order_relaxed), match = P.observed_match_permille.load(std::memory_order_relaxed);
+  const int min_cand = knobs().wave_specialised_min_permille;
+  if (uses_pipe_general(P, agg_mode)) {
+    if (P.dev.pipe_tail != nullptr || P.dev.pipe_vscan >= 0) return 0;
+    const bool idx = P.dev.pipe_has_index != 0, scan = P.dev.pipe_has_scan != 0;
+    if (idx && scan) return 0;   // (behind an upsert snapshot: pg_pipe_index_scan_tail)
+    // Measured over 10^9 docs (profiles/r05_wave_specialised.txt): no filter 1.096 ms against pg_pipe_none's 0.926, a lone scan 1.394 = 1.394, index
+    // only 1.017 against 0.918 — these shapes stream 5 - 9 bytes per doc and EVERY candidate matches, so the eight consumers' LDS atomics, not
+    // the stream, are the long path.  Only when forced (tests, measurements).
+    (void)match;
+    if (!force) return 0;
+    return !idx && !scan ? 2 : (scan ? 3 : 4);
+  }
+  return force || cand >= min_cand ? 1 : 0;
 }
+// One decision per execution: the rates move under concurrent executions of the same plan, and the launch shape (12 wavefronts, stage buffers)
+// and the kernel must agree.  execute_query_plain pins it before it sizes the launch.
+struct SpecPin { const CompiledPlan* plan = nullptr; int agg_mode = 0, shape = 0; };
+static thread_local SpecPin t_spec_pin;
+static int pinned_spec_shape(const CompiledPlan& P, int agg_mode) {
+  if (t_spec_pin.plan == &P && t_spec_pin.agg_mode == agg_mode) return t_spec_pin.shape;
+  return 0;   // not pinned: the pipelined kernels
+}
+static bool uses_spec_kernel(const CompiledPlan& P, int agg_mode) { return pinned_spec_shape(P, agg_mode) != 0; }
 
 extern "C" void pg_trim_launch(const PgTrimArgs* args, int grid, hipStream_t stream);
 extern "C" void pg_trim_launch_keys(const PgTrimArgs* args, int grid, hipStream_t stream);
@@ -411,6 +438,13 @@ static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char
       return P.digit_ops ? pg_fast_multi_wd : pg_fast_multi_w;
     }
     const bool no_dense = knobs().no_dense_fused;   // measurement knob
+    switch (pinned_spec_shape(P, agg_mode)) {
+      case 1: *name = "pg_fast_i32range_s"; return pg_fast_i32range_s;
+      case 2: *name = "pg_spec_none"; return pg_spec_none;
+      case 3: *name = "pg_spec_scan"; return pg_spec_scan;
+      case 4: *name = "pg_spec_index"; return pg_spec_index;
+      default: break;
+    }
     if (uses_pipe_general(P, agg_mode)) {
       const bool idx = P.dev.pipe_has_index != 0, scan = P.dev.pipe_has_scan != 0, tail = P.dev.pipe_tail != nullptr;
       if (scan && P.dev.pipe_vscan >= 0) {
@@ -432,7 +466,6 @@ static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char
       *name = tail ? "pg_pipe_tail" : "pg_pipe_none";
       return tail ? pg_pipe_tail : pg_pipe_none;
     }
-    if (uses_spec_kernel(P, agg_mode)) { *name = "pg_fast_i32range_s"; return pg_fast_i32range_s; }
     if (uses_pipe_kernel(P, agg_mode)) { *name = "pg_fast_i32range_p"; return pg_fast_i32range_p; }
     if (uses_scan_kernel(P, agg_mode)) { *name = "pg_fast_i32range_fp"; return pg_fast_i32range_fp; }
     if (agg && P.fast_filter == 4 && P.dev.dense_fused && !no_dense && P.fast_agg && agg_mode == PG_AGG_LDS) { *name = "pg_fast_i32range_d"; return pg_fast_i32range_d; }
@@ -1157,6 +1190,7 @@ static std::unique_ptr<Result> execute_query_impl(Segment& seg, const pg_query& 
   const bool oct_lds = D.oct == 1 && !no_oct, oct_pruned = D.oct == 2 && (!no_oct || D.p2_byte_regs) && D.agg_mode == PG_AGG_RADIX && D.p2;
   if (oct_lds) split_shift = 0;
   D.tile_split_shift = split_shift;
+  t_spec_pin = {&P, D.agg_mode, spec_shape(P, D.agg_mode)};   // (cleared when the query has been submitted: the plan may die before this thread's next query)
   LaunchShape shape = launch_shape(P, D.n_wtiles << split_shift, D.agg_mode);
   if (oct_lds) shape = {std::max(1, std::min((D.n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, num_cus())), PG_BLOCK, (D.oct_dword ? (size_t)D.aux[0].lds_offset + (size_t)D.aux[0].rep_bytes * 4 : P.lds_bytes) + 64};
   const int64_t n_out = (int64_t)D.n_ops * D.n_groups;
@@ -1931,10 +1965,11 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
   double ta1 = 0, ta2 = 0;
   const pg_exec_stats keep = res.stats;   // timings / kernel name survive a re-assembly after a merge
   fill_stats(res.stats, P, H.full_scan_entries, H.total_docs, H.stats);
-  if (P.dev.pipe_fit && H.total_docs > 0) {   // (see uses_spec_kernel)
+  if ((P.dev.pipe_fit || P.dev.pipe_general) && H.total_docs > 0) {   // (see spec_shape)
     int64_t cand = 0;
     for (int i = 1; i < P.n_stat_slots; i++) cand += (int64_t)H.stats[i];
     P.observed_candidate_permille.store((int)std::min<int64_t>(1000, cand * 1000 / H.total_docs), std::memory_order_relaxed);
+    P.observed_match_permille.store((int)std::min<int64_t>(1000, (int64_t)H.stats[0] * 1000 / H.total_docs), std::memory_order_relaxed);
   }
   res.stats.star_tree_index = P.star_tree_index;
   res.stats.device_ms_total = keep.device_ms_total; res.stats.device_ms_filter = keep.device_ms_filter;

@@ -272,7 +272,7 @@ struct CompiledPlan {
   int32_t n_stat_slots = 1;
   // candidates of the scan leaf per 1000 docs as the last execution counted them (-1: never run) — pg_fast_i32range_s streams every column
   // whole, pg_fast_i32range_p skips the quads without candidates: which of the two runs follows what the plan's filter lets through
-  mutable std::atomic<int> observed_candidate_permille{-1};
+  mutable std::atomic<int> observed_candidate_permille{-1}, observed_match_permille{-1};
   int64_t full_scan_entries = 0;     // entries contributed by unmasked scans whose count is known (numDocs each)
   bool stats_exact = true;           // the kernels' own counters give numEntriesScannedInFilter (flat AND shapes, drained ORs)
   // otherwise: the physical filter tree and one filter-only plan per Scan / Inverted leaf — their match bitmaps feed the iterator

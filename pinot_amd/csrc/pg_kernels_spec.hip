@@ -67,8 +67,11 @@ template <int NG> struct SpecQuad {
   uint32_t win[NG][2];
 };
 
-template <int NG>
+// HAS_INDEX: the fused dense index program (else every valid doc is a candidate); HAS_SCAN: one raw-INT range scan restricted to the candidates
+// (else every candidate matches) — pipe_general_body's shapes without the tail / value-scan extras (pg_spec_none / _scan / _index).
+template <int NG, bool HAS_INDEX, bool HAS_SCAN>
 __device__ __forceinline__ void spec_body(const PgQueryPlan& p) {
+  constexpr int NCOL = HAS_SCAN ? 4 : 2;   // 1 KB rows of (scan column |) value column per loader and tile
   extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
   __shared__ uint32_t s_stat[PG_MAX_STATS];
   const int t = threadIdx.x;
@@ -88,7 +91,7 @@ __device__ __forceinline__ void spec_body(const PgQueryPlan& p) {
   const uint32_t tile_bytes = (off_g1 + (NG > 1 ? bits1 * 256u + 16u : 0u) + 15u) & ~15u;
   const uint32_t stage_bytes = tile_bytes * SPEC_TILES;
   uint8_t* stage0 = reinterpret_cast<uint8_t*>(smem) + (((size_t)p.n_ops * table_slots * 8u + 15u) & ~(size_t)15u);
-  const CAS PgScanLeaf& L = cptr(p.scans)[p.fast_scan];
+  const CAS PgScanLeaf& L = cptr(p.scans)[HAS_SCAN ? p.fast_scan : 0];   // only dereferenced when HAS_SCAN
   const int grid = (int)gridDim.x;
   const int n_mine = (int)blockIdx.x < p.n_wtiles ? (p.n_wtiles - (int)blockIdx.x + grid - 1) / grid : 0;   // tiles blockIdx.x, + grid, ...
   const int n_stages = (n_mine + SPEC_TILES - 1) / SPEC_TILES;   // stage s: tiles SPEC_TILES s .. of this workgroup's sequence
@@ -98,7 +101,7 @@ __device__ __forceinline__ void spec_body(const PgQueryPlan& p) {
     // ---- loaders ------------------------------------------------------------------------------------------------------------------
     const int w = wave;
     const uint8_t* xdata = p.srcs[p.pipe_src].data;
-    const RangeI32 r32 = make_range_i32(L.lo, L.hi);
+    const RangeI32 r32 = HAS_SCAN ? make_range_i32(L.lo, L.hi) : RangeI32{0, 0u, false};
     uint32_t ld_cand = 0;
     const int ggi = (w >> 1) < NG ? (w >> 1) : 0;   // this loader's group column (loaders without one repeat column 0's first 16 bytes)
     const uint32_t goff = (uint32_t)(w & 1) * 1024u + (uint32_t)lane * 16u;
@@ -115,9 +118,9 @@ __device__ __forceinline__ void spec_body(const PgQueryPlan& p) {
         SpecTile& tl = st.tile[tt];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
+        for (int s = 0; s < NCOL; s++) {
           const int n = 4 * s + w;
-          const uint8_t* base = (n < 8 ? L.data : xdata) + (size_t)wt * (PG_WAVE_DOCS * 4) + (size_t)(n & 7) * 1024u;
+          const uint8_t* base = (HAS_SCAN && n < 8 ? L.data : xdata) + (size_t)wt * (PG_WAVE_DOCS * 4) + (size_t)(n & 7) * 1024u;
           tl.col[s] = ldnt((const GAS u32x4*)(spec_sgpr_ptr<uint8_t>(base) + (uint32_t)lane * 16u));
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -127,7 +130,7 @@ __device__ __forceinline__ void spec_body(const PgQueryPlan& p) {
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-      {
+      if (HAS_INDEX) {
         const int i = sidx * SPEC_TILES + (w % SPEC_TILES);
         const int wt = (int)blockIdx.x + (i < n_mine ? i : n_mine - 1) * grid;
 #pragma unroll
@@ -140,7 +143,7 @@ __device__ __forceinline__ void spec_body(const PgQueryPlan& p) {
       {
         uint32_t acc = 0;
 #pragma unroll
-        for (int tt = 0; tt < SPEC_TILES; tt++) { for (int k = 0; k < 4; k++) acc += st.tile[tt].col[k].x ^ st.tile[tt].col[k].w; acc += st.tile[tt].grp.x; }
+        for (int tt = 0; tt < SPEC_TILES; tt++) { for (int k = 0; k < NCOL; k++) acc += st.tile[tt].col[k].x ^ st.tile[tt].col[k].w; acc += st.tile[tt].grp.x; }
         if (acc == 0x12345678u) *reinterpret_cast<uint32_t*>(stage) = acc;
         return;
       }
@@ -152,19 +155,21 @@ __device__ __forceinline__ void spec_body(const PgQueryPlan& p) {
         // rows 0 .. 7 are the scan column: the loader holds quad (row, lane) — exactly what consumer `row`'s lane reads — and tests the range
         // there; four result bits per lane go to LDS instead of the row's 1 KB (the consumers' path is the long one: 20 VALU instructions and a
         // 16-byte LDS read per quad row less on it, on wavefronts that otherwise wait for HBM)
+        if (HAS_SCAN) {
 #pragma unroll
-        for (int s = 0; s < 2; s++) {
-          const u32x4 a = tl.col[s];
-          uint32_t m = (uint32_t)in_range_i32(r32, (int32_t)bswap32(a.x)) | ((uint32_t)in_range_i32(r32, (int32_t)bswap32(a.y)) << 1) |
-                       ((uint32_t)in_range_i32(r32, (int32_t)bswap32(a.z)) << 2) | ((uint32_t)in_range_i32(r32, (int32_t)bswap32(a.w)) << 3);
-          m = r32.empty ? 0u : m;
-          *reinterpret_cast<uint32_t*>(buf + SPEC_OFF_RNG + (uint32_t)(4 * s + w) * 256u + (uint32_t)lane * 4u) = m;
+          for (int s = 0; s < 2; s++) {
+            const u32x4 a = tl.col[s];
+            uint32_t m = (uint32_t)in_range_i32(r32, (int32_t)bswap32(a.x)) | ((uint32_t)in_range_i32(r32, (int32_t)bswap32(a.y)) << 1) |
+                         ((uint32_t)in_range_i32(r32, (int32_t)bswap32(a.z)) << 2) | ((uint32_t)in_range_i32(r32, (int32_t)bswap32(a.w)) << 3);
+            m = r32.empty ? 0u : m;
+            *reinterpret_cast<uint32_t*>(buf + SPEC_OFF_RNG + (uint32_t)(4 * s + w) * 256u + (uint32_t)lane * 4u) = m;
+          }
         }
 #pragma unroll
-        for (int s = 2; s < 4; s++) {   // the value column: host byte order already (four bswaps per quad row less for the consumers)
+        for (int s = HAS_SCAN ? 2 : 0; s < NCOL; s++) {   // the value column: host byte order already (four bswaps per quad row less for the consumers)
           u32x4 v = tl.col[s];
           v.x = bswap32(v.x); v.y = bswap32(v.y); v.z = bswap32(v.z); v.w = bswap32(v.w);
-          *reinterpret_cast<u32x4*>(buf + SPEC_OFF_VAL + (uint32_t)(4 * s + w - 8) * 1024u + (uint32_t)lane * 16u) = v;
+          *reinterpret_cast<u32x4*>(buf + SPEC_OFF_VAL + (uint32_t)(4 * s + w - (HAS_SCAN ? 8 : 0)) * 1024u + (uint32_t)lane * 16u) = v;
         }
         *reinterpret_cast<u32x4*>(buf + (ggi == 0 ? SPEC_OFF_G0 : off_g1) + geff) = tl.grp;
       }
@@ -176,49 +181,52 @@ __device__ __forceinline__ void spec_body(const PgQueryPlan& p) {
       const int wt = (int)blockIdx.x + i * grid;
       const int64_t rem = i < n_mine ? (int64_t)p.num_docs - (int64_t)wt * PG_WAVE_DOCS : 0;   // (the second tile of an odd last stage: empty)
       const int32_t n_valid = rem >= PG_WAVE_DOCS ? PG_WAVE_DOCS : (rem > 0 ? (int32_t)rem : 0);
-      uint32_t grp[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const int gj = p.dense_group[j];
-#pragma unroll
-        for (int k = 0; k < 4; k++) grp[k] |= gj == k ? st.post[j] : 0u;
-      }
       uint32_t lin = valid_lin_mask(n_valid, lane);
+      if (HAS_INDEX) {
+        uint32_t grp[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int k = 0; k < 4; k++)
-        if (k < p.dense_groups) lin &= ((p.dense_excl >> k) & 1) ? ~grp[k] : grp[k];
+        for (int j = 0; j < 8; j++) {
+          const int gj = p.dense_group[j];
+#pragma unroll
+          for (int k = 0; k < 4; k++) grp[k] |= gj == k ? st.post[j] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (k < p.dense_groups) lin &= ((p.dense_excl >> k) & 1) ? ~grp[k] : grp[k];
+      }
       *reinterpret_cast<uint32_t*>(stage + (uint32_t)w * tile_bytes + SPEC_OFF_LIN + (uint32_t)lane * 4u) = lin;
       ld_cand += (uint32_t)__popc(lin);   // the scan leaf's candidates (numEntriesScannedInFilter), counted where the whole dword is at hand
     };
     // SPEC_SETS stages of loads in flight per loader (a register set each).  With two sets of two tiles 80 KB per CU were in flight against the
     // ~160 KB of pg_fast_i32range_p's eight wavefronts; the LDS buffers stay two: buffer = stage & 1.
-    SpecStage st[SPEC_SETS];
+    constexpr int SETS = HAS_SCAN ? SPEC_SETS : 2 * SPEC_SETS;   // (without a scan column a stage is half the bytes: twice the stages in flight)
+    SpecStage st[SETS];
     auto buf_of = [&](int sg) __attribute__((always_inline)) { return stage0 + (uint32_t)(sg & 1) * stage_bytes; };
     if (n_stages > 0) {
 #pragma unroll
-      for (int k = 0; k < SPEC_SETS; k++) issue(k, st[k]);
+      for (int k = 0; k < SETS; k++) issue(k, st[k]);
     }
     // Whole rounds of SPEC_SETS stages in the loop, the rest behind it: a conditional part INSIDE the loop gives the compiler a path on which a
     // younger stage's loads are older at the loop head, and it then waits for all of them.
     int s = 0;
-    for (; s + SPEC_SETS - 1 < n_stages; s += SPEC_SETS) {
+    for (; s + SETS - 1 < n_stages; s += SETS) {
 #pragma unroll
-      for (int k = 0; k < SPEC_SETS; k++) {
+      for (int k = 0; k < SETS; k++) {
         publish(buf_of(s + k), st[k]);         // waits for stage s + k's loads only: the younger stages stay in flight
         publish_lin(buf_of(s + k), st[k], s + k);
-        issue(s + k + SPEC_SETS, st[k]);
+        issue(s + k + SETS, st[k]);
         spec_barrier();                        // barrier s + k: its buffer holds the stage
       }
     }
 #pragma unroll
-    for (int k = 0; k < SPEC_SETS - 1; k++)
+    for (int k = 0; k < SETS - 1; k++)
       if (s + k < n_stages) {                  // workgroup-uniform
         publish(buf_of(s + k), st[k]);
         publish_lin(buf_of(s + k), st[k], s + k);
         spec_barrier();
       }
     const uint32_t csum = wave_sum_u32(ld_cand);
-    if (lane == 0 && csum) atomicAdd(&s_stat[L.stat_slot], csum);
+    if (HAS_SCAN && !p.fast_scan_pushed && lane == 0 && csum) atomicAdd(&s_stat[L.stat_slot], csum);   // (a pushed scan covers the segment: the host adds numDocs)
   } else {
     // ---- consumers: wavefront c aggregates quad row c (quads 64 c .. 64 c + 63) of every tile ------------------------------------------------
     const int c = wave - SPEC_LOADERS;
@@ -241,7 +249,7 @@ __device__ __forceinline__ void spec_body(const PgQueryPlan& p) {
     const int has_out_words = uniform(p.out_words != nullptr ? 1 : 0);
     auto fetch = [&](const uint8_t* buf, SpecQuad<NG>& d) __attribute__((always_inline)) {
       d.lin = *reinterpret_cast<const uint32_t*>(buf + SPEC_OFF_LIN + (q >> 3) * 4u);   // 8 lanes share a dword: a broadcast
-      d.rng = *reinterpret_cast<const uint32_t*>(buf + SPEC_OFF_RNG + q * 4u);
+      d.rng = HAS_SCAN ? *reinterpret_cast<const uint32_t*>(buf + SPEC_OFF_RNG + q * 4u) : 0xFu;
       d.val = *reinterpret_cast<const u32x4*>(buf + SPEC_OFF_VAL + q * 16u);
 #pragma unroll
       for (int gi = 0; gi < NG; gi++) {
@@ -378,7 +386,12 @@ __device__ __forceinline__ void spec_body(const PgQueryPlan& p) {
     }
   }
 }
-extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_fast_i32range_s(const PgQueryPlan p) {
-  if (p.n_group_cols == 1) spec_body<1>(p);
-  else spec_body<2>(p);
-}
+#define PG_SPEC_KERNEL(NAME, IDX, SCAN) \
+  extern "C" __global__ void __launch_bounds__(PG_BLOCK) NAME(const PgQueryPlan p) { \
+    if (p.n_group_cols == 1) spec_body<1, IDX, SCAN>(p); \
+    else spec_body<2, IDX, SCAN>(p); \
+  }
+PG_SPEC_KERNEL(pg_fast_i32range_s, true, true)   // the headline shape: dense index program AND range scan
+PG_SPEC_KERNEL(pg_spec_none, false, false)       // no filter
+PG_SPEC_KERNEL(pg_spec_scan, false, true)        // the range scan is the whole filter
+PG_SPEC_KERNEL(pg_spec_index, true, false)       // inverted-index leaves only

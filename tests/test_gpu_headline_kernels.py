@@ -167,3 +167,35 @@ def test_kernel_follows_the_candidate_rate_of_the_last_execution(gpu_api, oracle
     g = NativeSegment(gpu_api, host)
     assert [g.execute(synth.QUERY_CFG3).stats.kernel.decode() for _ in range(3)] == [PIPE] * 3
     g.destroy()
+
+
+GENERAL_SPEC = [
+    ("SELECT g1, SUM(m), MAX(m) FROM gpuBench GROUP BY g1 LIMIT 1000", "pg_spec_none"),
+    ("SELECT g1, g2, COUNT(*), MIN(m) FROM gpuBench GROUP BY g1, g2 LIMIT 10000", "pg_spec_none"),
+    ("SELECT g1, g2, SUM(m) FROM gpuBench WHERE r_int BETWEEN 250000 AND 749999 GROUP BY g1, g2 LIMIT 10000", "pg_spec_scan"),
+    ("SELECT g1, SUM(m), COUNT(*) FROM gpuBench WHERE r_int < 7 GROUP BY g1 LIMIT 1000", "pg_spec_scan"),
+    ("SELECT g1, SUM(m) FROM gpuBench WHERE c_inv1 IN (0, 1, 2, 3) AND c_inv2 IN (0, 1) GROUP BY g1 LIMIT 1000", "pg_spec_index"),
+    ("SELECT g2, g1, MAX(m), COUNT(*) FROM gpuBench WHERE c_inv1 NOT IN (3, 4) GROUP BY g2, g1 LIMIT 10000", "pg_spec_index"),
+    ("SELECT g1, MIN(m), SUM(m) FROM gpuBench WHERE c_inv1 IN (0, 1, 2, 3) GROUP BY g1 LIMIT 1000", "pg_spec_index"),
+]
+
+
+@pytest.mark.parametrize("n", [2049, 700_001, 9_030_011])
+def test_wave_specialised_general_shapes(gpu_api, oracle_api, gpu_knobs, n):
+    """The pipeline's general shapes (no filter, a lone range scan, index leaves only) through the loader / consumer kernels — forced: they
+    are not faster there (every candidate matches: the consumers' LDS atomics are the long path) and never chosen; results and statistics are
+    the oracle's."""
+    gpu_knobs(PG_WAVE_SPECIALISED="1")
+    host = synth.generate_segment(n, segment_index=6, columns=COLUMNS)
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    for sql, kernel in GENERAL_SPEC:
+        qc = parse_sql(sql)
+        qc.flags |= capi.QUERY_FLAG_EXACT_FILTER_STATS
+        gb, ob = g.execute(qc), o.execute(sql)
+        assert gb.rows() == ob.rows(), sql
+        for f in ("num_docs_scanned", "num_entries_scanned_in_filter", "num_entries_scanned_post_filter", "num_total_docs"):
+            assert getattr(gb.stats, f) == getattr(ob.stats, f), (f, sql)
+        if knobs_off and n >= 700_001:
+            assert gb.stats.kernel.decode() == kernel, sql
+    g.destroy()
+    o.destroy()

@@ -95,6 +95,8 @@ QUERIES = {
     "cfg3 filter only count": ("SELECT COUNT(*) FROM t WHERE c_inv1 IN (0,1,2,3) AND c_inv2 IN (0,1) AND r_int BETWEEN 250000 AND 749999", 4.75),
     "no filter sum(m) group g1": ("SELECT g1, SUM(m), MAX(m) FROM t GROUP BY g1", 4.875),
     "no filter sum(m)": ("SELECT SUM(m) FROM t", 4.0),
+    "range scan, sum(m) group g1": ("SELECT g1, SUM(m), MAX(m) FROM t WHERE r_int BETWEEN 250000 AND 749999 GROUP BY g1", 8.875),
+    "index only, sum(m) group g1": ("SELECT g1, SUM(m), MAX(m) FROM t WHERE c_inv1 IN (0,1,2,3) AND c_inv2 IN (0,1) GROUP BY g1", 5.625),
     "cfg3": (synth.QUERY_CFG3, 9.625),
     "northstar": (synth.QUERY_NORTH_STAR, 10.375),
     # the headline shape at other index selectivities (candidates of the range scan as a fraction of the docs): pg_fast_i32range_p skips the
