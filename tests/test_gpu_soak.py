@@ -18,6 +18,13 @@ def _free_hbm():
     return torch.cuda.mem_get_info()[0]
 
 
+def _hbm_is_ours():
+    """Free HBM is a property of the device: under pytest-xdist the other workers' segments come and go on the same GPU (a 26 M-doc segment next
+    door read as a 7 GB 'leak'), so the HBM-growth assertions only hold when this process has the device to itself — as in the driver's run."""
+    import os
+    return not os.environ.get("PYTEST_XDIST_WORKER")
+
+
 @pytest.mark.gpu
 def test_no_memory_growth_over_thousands_of_queries(gpu_api):
     from pinot_amd import capi
@@ -38,7 +45,7 @@ def test_no_memory_growth_over_thousands_of_queries(gpu_api):
     for _ in range(20):                # 3 000 queries
         run_all()
     free1, rss1 = _free_hbm(), psutil.Process().memory_info().rss
-    assert free0 - free1 < 32 << 20, f"HBM grew by {(free0 - free1) >> 20} MB over 3000 queries"
+    assert not _hbm_is_ours() or free0 - free1 < 32 << 20, f"HBM grew by {(free0 - free1) >> 20} MB over 3000 queries"
     assert rss1 - rss0 < 128 << 20, f"host RSS grew by {(rss1 - rss0) >> 20} MB over 3000 queries"
     g.destroy()
 
@@ -56,7 +63,7 @@ def test_segment_load_destroy_cycles_return_their_memory(gpu_api):
         seg.execute(synth.QUERY_CFG5)
         seg.destroy()
     free1, rss1 = _free_hbm(), psutil.Process().memory_info().rss
-    assert free0 - free1 < 32 << 20, f"HBM not returned: {(free0 - free1) >> 20} MB after 40 load/destroy cycles"
+    assert not _hbm_is_ours() or free0 - free1 < 32 << 20, f"HBM not returned: {(free0 - free1) >> 20} MB after 40 load/destroy cycles"
     assert rss1 - rss0 < 128 << 20, f"host RSS grew by {(rss1 - rss0) >> 20} MB after 40 load/destroy cycles"
 
 
@@ -154,5 +161,5 @@ def test_null_handling_queries_from_several_threads(gpu_api, oracle_api):
     assert not errors, errors[:3]
     free2 = threaded_phase()
     assert not errors, errors[:3]
-    assert free1 - free2 < 256 << 20, f"HBM grew by {(free1 - free2) >> 20} MB over a second round of eight threads"
+    assert not _hbm_is_ours() or free1 - free2 < 256 << 20, f"HBM grew by {(free1 - free2) >> 20} MB over a second round of eight threads"
     g.destroy()
