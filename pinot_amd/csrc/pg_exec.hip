@@ -19,7 +19,7 @@ PG_DECL_GENERIC
 PG_DECL_FAST(pg_fast_none_f) PG_DECL_FAST(pg_fast_none_a) PG_DECL_FAST(pg_fast_i32range_f) PG_DECL_FAST(pg_fast_i32range_a)
 PG_DECL_FAST(pg_fast_dictrange_f) PG_DECL_FAST(pg_fast_dictrange_a) PG_DECL_FAST(pg_fast_dictlut_f) PG_DECL_FAST(pg_fast_dictlut_a)
 PG_DECL_FAST(pg_fast_multi_f) PG_DECL_FAST(pg_fast_multi_a) PG_DECL_FAST(pg_fast_multi_w) PG_DECL_FAST(pg_fast_none_w)
-PG_DECL_FAST(pg_fast_i32range_d) PG_DECL_FAST(pg_fast_i32range_p) PG_DECL_FAST(pg_fast_i32range_fp) PG_DECL_FAST(pg_fast_i32range_s) PG_DECL_FAST(pg_spec_none) PG_DECL_FAST(pg_spec_scan) PG_DECL_FAST(pg_spec_index)
+PG_DECL_FAST(pg_fast_i32range_d) PG_DECL_FAST(pg_fast_i32range_p) PG_DECL_FAST(pg_fast_i32range_fp) PG_DECL_FAST(pg_fast_i32range_s) PG_DECL_FAST(pg_spec_none) PG_DECL_FAST(pg_spec_scan) PG_DECL_FAST(pg_spec_index) PG_DECL_FAST(pg_fast_i32range_st)
 PG_DECL_FAST(pg_dense_count_1) PG_DECL_FAST(pg_dense_count_2) PG_DECL_FAST(pg_dense_count_3) PG_DECL_FAST(pg_dense_count_4)
 PG_DECL_FAST(pg_dense_count_5) PG_DECL_FAST(pg_dense_count_6) PG_DECL_FAST(pg_dense_count_7) PG_DECL_FAST(pg_dense_count_8)
 PG_DECL_FAST(pg_dict_count_1) PG_DECL_FAST(pg_dict_count_2) PG_DECL_FAST(pg_dict_count_3) PG_DECL_FAST(pg_dict_count_4)
@@ -320,7 +320,7 @@ void use_device(int ordinal) {
                                  pg_p2_aggregate_1n, pg_p2_aggregate_2n, pg_p2_aggregate_3n, pg_p2_aggregate_4n, pg_p2_aggregate_1s, pg_p2_aggregate_2s, pg_p2_aggregate_1sg, pg_p2_aggregate_2sg};
       for (QueryKernel k : all)
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
-      for (QueryKernel k : {pg_fast_i32range_s, pg_spec_none, pg_spec_scan, pg_spec_index})
+      for (QueryKernel k : {pg_fast_i32range_s, pg_fast_i32range_st, pg_spec_none, pg_spec_scan, pg_spec_index})
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
       for (QueryKernel k : {pg_mv_query_f, pg_mv_query_l, pg_mv_query_g})   // 10.5 KB of static LDS (per-wavefront entry bitmaps): the planner's 144 KB still fit
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 12288);
@@ -384,16 +384,17 @@ static size_t spec_stage_bytes(const CompiledPlan& P) {
 // index).  It streams every column whole (84-92 % of 8 TB/s whatever the filter); the pipelined kernels request only the quads that hold a
 // candidate / a match and win where the filter is selective — so the candidate rate the plan's LAST execution counted decides (a plan's first
 // execution takes the pipelined kernel): >= 15 % candidates behind the index.  The general shapes: only when forced (below).
-static int spec_shape(const CompiledPlan& P, int agg_mode) {   // 0: no; 1 index + scan; 2 none; 3 scan; 4 index
+static int spec_shape(const CompiledPlan& P, int agg_mode) {   // 0: no; 1 index + scan; 2 none; 3 scan; 4 index; 5 index + scan + upsert snapshot
   if (knobs().no_wave_specialised || !uses_pipe_kernel(P, agg_mode) || uses_pipe_wide(P, agg_mode)) return 0;
   if (P.dev.n_group_cols < 1 || P.dev.n_group_cols > 2 || P.lds_bytes + 256 + 2 * spec_stage_bytes(P) + 512 * (size_t)P.dev.n_ops > (size_t)160 * 1024 - 8192) return 0;   // (the dynamic-LDS limit device_init asks for)
   const bool force = knobs().wave_specialised;
   const int cand = P.observed_candidate_permille.load(std::memory_order_relaxed), match = P.observed_match_permille.load(std::memory_order_relaxed);
   const int min_cand = knobs().wave_specialised_min_permille;
   if (uses_pipe_general(P, agg_mode)) {
-    if (P.dev.pipe_tail != nullptr || P.dev.pipe_vscan >= 0) return 0;
     const bool idx = P.dev.pipe_has_index != 0, scan = P.dev.pipe_has_scan != 0;
-    if (idx && scan) return 0;   // (behind an upsert snapshot: pg_pipe_index_scan_tail)
+    if (P.dev.pipe_vscan >= 0) return 0;
+    if (idx && scan && P.dev.pipe_tail != nullptr) return force || cand >= min_cand ? 5 : 0;   // the headline shape behind an upsert snapshot (pg_pipe_index_scan_tail)
+    if (P.dev.pipe_tail != nullptr || (idx && scan)) return 0;
     // Measured over 10^9 docs (profiles/r05_wave_specialised.txt): no filter 1.096 ms against pg_pipe_none's 0.926, a lone scan 1.394 = 1.394, index
     // only 1.017 against 0.918 — these shapes stream 5 - 9 bytes per doc and EVERY candidate matches, so the eight consumers' LDS atomics, not
     // the stream, are the long path.  Only when forced (tests, measurements).
@@ -443,6 +444,7 @@ static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char
       case 2: *name = "pg_spec_none"; return pg_spec_none;
       case 3: *name = "pg_spec_scan"; return pg_spec_scan;
       case 4: *name = "pg_spec_index"; return pg_spec_index;
+      case 5: *name = "pg_fast_i32range_st"; return pg_fast_i32range_st;
       default: break;
     }
     if (uses_pipe_general(P, agg_mode)) {

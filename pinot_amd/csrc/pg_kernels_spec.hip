@@ -59,7 +59,7 @@ struct SpecTile {
   u32x4 col[4];
   u32x4 grp;
 };
-struct SpecStage { SpecTile tile[SPEC_TILES]; uint32_t post[8]; };
+struct SpecStage { SpecTile tile[SPEC_TILES]; uint32_t post[8]; uint32_t tail; };
 // what a consumer lane reads of one wave tile: everything up front, one LDS round trip per stage
 template <int NG> struct SpecQuad {
   uint32_t lin, rng;
@@ -69,7 +69,9 @@ template <int NG> struct SpecQuad {
 
 // HAS_INDEX: the fused dense index program (else every valid doc is a candidate); HAS_SCAN: one raw-INT range scan restricted to the candidates
 // (else every candidate matches) — pipe_general_body's shapes without the tail / value-scan extras (pg_spec_none / _scan / _index).
-template <int NG, bool HAS_INDEX, bool HAS_SCAN>
+// HAS_TAIL: one more dense bitmap ANDed in AFTER the scan — the upsert queryableDocIds snapshot of FilterPlanNode.run's outer AND, which must not
+// restrict the scan's candidates (numEntriesScannedInFilter stays the reference's): the loader counts the candidates, then masks them.
+template <int NG, bool HAS_INDEX, bool HAS_SCAN, bool HAS_TAIL = false>
 __device__ __forceinline__ void spec_body(const PgQueryPlan& p) {
   constexpr int NCOL = HAS_SCAN ? 4 : 2;   // 1 KB rows of (scan column |) value column per loader and tile
   extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
@@ -139,6 +141,12 @@ __device__ __forceinline__ void spec_body(const PgQueryPlan& p) {
         for (int j = 0; j < 8; j++) st.post[j] = *(const GAS uint32_t*)(spec_sgpr_ptr<uint8_t>(p.dense_ptr[j] + (size_t)wt * 256u) + (uint32_t)lane * 4u);
         __builtin_amdgcn_sched_barrier(0);
       }
+      if (HAS_TAIL) {
+        const int i = sidx * SPEC_TILES + (w % SPEC_TILES);
+        const int wt = (int)blockIdx.x + (i < n_mine ? i : n_mine - 1) * grid;
+        st.tail = *(const GAS uint32_t*)(spec_sgpr_ptr<uint8_t>(p.pipe_tail + (size_t)wt * 256u) + (uint32_t)lane * 4u);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     };
     auto publish = [&](uint8_t* stage, const SpecStage& st) __attribute__((always_inline)) {
 #ifdef PG_SPEC_NO_PUBLISH   // measurement variant (wrong results): the loads are waited for, nothing is written to LDS
@@ -196,7 +204,7 @@ __device__ __forceinline__ void spec_body(const PgQueryPlan& p) {
         for (int k = 0; k < 4; k++)
           if (k < p.dense_groups) lin &= ((p.dense_excl >> k) & 1) ? ~grp[k] : grp[k];
       }
-      *reinterpret_cast<uint32_t*>(stage + (uint32_t)w * tile_bytes + SPEC_OFF_LIN + (uint32_t)lane * 4u) = lin;
+      *reinterpret_cast<uint32_t*>(stage + (uint32_t)w * tile_bytes + SPEC_OFF_LIN + (uint32_t)lane * 4u) = HAS_TAIL ? lin & st.tail : lin;
       ld_cand += (uint32_t)__popc(lin);   // the scan leaf's candidates (numEntriesScannedInFilter), counted where the whole dword is at hand
     };
     // SPEC_SETS stages of loads in flight per loader (a register set each).  With two sets of two tiles 80 KB per CU were in flight against the
@@ -397,3 +405,8 @@ PG_SPEC_KERNEL(pg_fast_i32range_s, true, true)   // the headline shape: dense in
 PG_SPEC_KERNEL(pg_spec_none, false, false)       // no filter
 PG_SPEC_KERNEL(pg_spec_scan, false, true)        // the range scan is the whole filter
 PG_SPEC_KERNEL(pg_spec_index, true, false)       // inverted-index leaves only
+#undef PG_SPEC_KERNEL
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_fast_i32range_st(const PgQueryPlan p) {   // the headline shape behind an upsert snapshot
+  if (p.n_group_cols == 1) spec_body<1, true, true, true>(p);
+  else spec_body<2, true, true, true>(p);
+}

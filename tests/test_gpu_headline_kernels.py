@@ -109,7 +109,8 @@ def test_pipeline_behind_an_upsert_snapshot(gpu_api, oracle_api, n):
             for f in ("num_docs_scanned", "num_entries_scanned_in_filter", "num_entries_scanned_post_filter", "num_total_docs"):
                 assert getattr(gb.stats, f) == getattr(ob.stats, f), (f, sql, keep)
             if kernel and knobs_off and n >= 65536 and keep >= 0.5:   # dense snapshots are bitmap containers: the arithmetic (dense) form
-                assert gb.stats.kernel.decode() == kernel, (sql, keep, gb.stats.kernel)
+                # (a plan that has run before may have moved to the loader / consumer kernel: the candidate rate of its last execution decides)
+                assert gb.stats.kernel.decode() in (kernel, "pg_fast_i32range_st"), (sql, keep, gb.stats.kernel)
     g.destroy()
     o.destroy()
 
@@ -137,6 +138,20 @@ def test_wave_specialised_variant_matches_oracle(gpu_api, oracle_api, gpu_knobs,
             assert gb.stats.kernel.decode() in ("pg_fast_i32range_s", PIPE), sql
             ran += gb.stats.kernel.decode() == "pg_fast_i32range_s"
     assert n < 700_001 or ran >= 3
+    # ... and behind an upsert snapshot (pg_fast_i32range_st): the snapshot masks the matches, not the scan's candidates
+    import numpy as np
+    rng = np.random.default_rng(n)
+    for keep in (0.7, 0.03):
+        ids = np.flatnonzero(rng.random(n) < keep)
+        g.set_queryable_doc_ids(ids)
+        o.set_queryable_doc_ids(ids)
+        for sql in (synth.QUERY_CFG3, synth.QUERY_NORTH_STAR):
+            gb, ob = g.execute(sql), o.execute(sql)
+            assert gb.rows() == ob.rows(), (sql, keep)
+            for f in ("num_docs_scanned", "num_entries_scanned_in_filter", "num_entries_scanned_post_filter", "num_total_docs"):
+                assert getattr(gb.stats, f) == getattr(ob.stats, f), (f, sql, keep)
+            if knobs_off and n >= 700_001 and keep >= 0.5 and sql == synth.QUERY_CFG3:
+                assert gb.stats.kernel.decode() == "pg_fast_i32range_st", (sql, keep, gb.stats.kernel)
     g.destroy()
     o.destroy()
 
