@@ -137,7 +137,7 @@ __device__ __forceinline__ void spec_body(const PgQueryPlan& p) {
         const int wt = (int)blockIdx.x + (i < n_mine ? i : n_mine - 1) * grid;
 #pragma unroll
         // (plain loads, not non-temporal ones: two loader wavefronts request each tile's posting dwords, the second should find them in L2 —
-        // streaming loads left 1.027 x the algorithmic bytes in the HBM counters, profiles/r05_zz_bench.json)
+        // streaming loads left 1.027 x the algorithmic bytes in the HBM counters, profiles/r05_wave_specialised.txt)
         for (int j = 0; j < 8; j++) st.post[j] = *(const GAS uint32_t*)(spec_sgpr_ptr<uint8_t>(p.dense_ptr[j] + (size_t)wt * 256u) + (uint32_t)lane * 4u);
         __builtin_amdgcn_sched_barrier(0);
       }
