@@ -1,20 +1,24 @@
-// pg_fast_i32range_s: the headline shape with SPECIALISED wavefronts (round 5, VERDICT r4 #4b) — an experiment behind PG_WAVE_SPECIALISED,
-// measured against pg_fast_i32range_p in profiles/r05_wave_specialised.txt.
+// pg_fast_i32range_s: the headline shape with SPECIALISED wavefronts (round 5, VERDICT r4 #4b).  Steps, measurement variants and SQ counters:
+// profiles/r05_wave_specialised.txt; the default where the plan's last execution counted >= 15 % candidates (pg_exec.hip, spec_shape).
 //
 // pg_fast_i32range_p (pg_kernels_pipe.hip) runs 8 identical wavefronts per CU, each streaming AND aggregating; it sits at the stream its own
-// loads reach with 8 wavefronts (81-83 % of 8 TB/s; 84 % with the aggregation compiled out), while the same loads issued by FOUR wavefronts
-// reach 90 % (profiles/r02_scan_bw_probe.txt, r02_ab_pipeline.txt: the memory system prefers fewer, longer streams).  Four wavefronts cannot
+// loads reach with 8 wavefronts (80-84 % of 8 TB/s; 84 % with the aggregation compiled out), while the same loads issued by FOUR wavefronts
+// reach 88-90 % (profiles/r02_scan_bw_probe.txt, r02_ab_pipeline.txt: the memory system prefers fewer, longer streams).  Four wavefronts cannot
 // hide the LDS atomics themselves, hence this split of one 12-wavefront workgroup per CU:
-//   * 4 LOADER wavefronts stream whole wave tiles (2 048 docs: 8 posting bitmaps, the scan column, the value column, the group columns) from
-//     HBM into registers two stages ahead and copy the oldest stage into one of two LDS stage buffers — no filtering, no branches, every load
-//     a full coalesced row;
-//   * 8 CONSUMER wavefronts, one per quad row of the tile (256 docs, 4 per lane), read their slice of the stage out of LDS, evaluate the index
-//     program and the range predicate, and aggregate into the workgroup's LDS table — the reference's SVScanDocIdIterator.java:213-291 +
-//     SumAggregationFunction.java:160-179 loop, as in pg_fast_i32range_p, without a single global load.
-// One barrier per stage: behind barrier i the consumers read buffer i & 1 while the loaders fill buffer (i + 1) & 1; a buffer is refilled
-// only behind the next barrier, which the consumers reach after they have finished it.
+//   * 4 LOADER wavefronts stream whole wave tiles (2 048 docs) from HBM into registers — the scan column, the value column and the group
+//     columns as full coalesced 1 KB rows, SPEC_SETS stages of SPEC_TILES tiles in flight — and hand the oldest stage to the consumers through
+//     one of two LDS stage buffers.  What a loader holds whole it evaluates on the way: the index program over the tile's posting dwords, once
+//     per tile (-> 64 candidate dwords, linear layout); the range predicate on the scan quads (-> 4 result bits per lane: the scan column
+//     never goes through LDS); the value column's byte swaps; the candidate count (numEntriesScannedInFilter);
+//   * 8 CONSUMER wavefronts, one per quad row of a tile (256 docs, 4 per lane), read stage s + 1's slices out of LDS (candidate dword, range
+//     bits, value quad, group windows) and then aggregate stage s's out of registers: match = candidates AND range bits, group decode, LDS
+//     atomics into the workgroup's table — unpredicated: a doc that does not match aims at a per-lane trash slot behind its accumulator's row.
+//     The reference's loop (SVScanDocIdIterator.java:213-291 + SumAggregationFunction.java:160-179), without a single global load.
+// One barrier per stage, fenced on the LDS address space only: behind barrier s the consumers read buffer s & 1 while the loaders fill buffer
+// (s + 1) & 1; a buffer is refilled only behind the next barrier, which the consumers reach after their reads of it have completed.
 //
-// Same plan, same results, same statistics as pg_fast_i32range_p (tests/test_gpu_headline_kernels.py runs both).
+// Same plans, same results, same statistics as pg_fast_i32range_p (tests/test_gpu_headline_kernels.py runs both, and the general shapes the
+// template also instantiates).  pg_fast_i32range_p stays the kernel of selective filters: it requests only the quads that hold a candidate.
 #define PG_WAVES_PER_BLOCK 12
 #define PG_KERNEL template <int PG_NOT_INSTANTIATED> static
 #include "pg_kernels.hip"
@@ -37,7 +41,7 @@ extern "C" const int pg_spec_waves_per_block = PG_WAVES_PER_BLOCK;
 extern "C" int pg_spec_stage_bytes(int bits0, int bits1) { return SPEC_TILES * (((int)SPEC_OFF_G0 + bits0 * 256 + 16 + (bits1 > 0 ? bits1 * 256 + 16 : 0) + 15) & ~15); }
 
 // Workgroup barrier that waits for this wavefront's LDS operations only.  __syncthreads() is a workgroup-scope release fence in front of
-// s_barrier — s_waitcnt vmcnt(0) as well — which would drain the loaders' two stages of global loads at every stage.
+// s_barrier — s_waitcnt vmcnt(0) as well — which would drain the loaders' stages of global loads at every barrier.
 // (Fences on the LDS address space alone — not asm with a "memory" clobber: that made the compiler re-read every plan field from the kernel
 // argument behind each barrier, 48 scalar loads per tile, each one a stall — profiles/r05_wave_specialised.txt.)
 DEVFN void spec_barrier() {
@@ -53,8 +57,9 @@ template <typename T> DEVFN const GAS T* spec_sgpr_ptr(const void* ptr) {
 }
 
 // what a loader wavefront holds of one wave tile: 4 rows of the scan / value columns, 1 row of a group column — and of ONE tile of the stage
-// (tile w & 1 for loader w) the 8 posting dwords of its lane's 32 docs: loaders 0 and 1 evaluate the index program there, once per tile, as
-// pg_fast_i32range_p does; evaluated by the consumers it ran once per QUAD ROW — 8 x 64 VALU instructions per tile (first cut, 2.35 ms)
+// (tile w % SPEC_TILES for loader w) the 8 posting dwords of its lane's 32 docs (+ the upsert snapshot's): loaders 0 .. SPEC_TILES - 1 evaluate
+// the index program there, once per tile, as pg_fast_i32range_p does; evaluated by the consumers it ran once per QUAD ROW — 8 x 64 VALU
+// instructions per tile (first cut, 2.35 ms)
 struct SpecTile {
   u32x4 col[4];
   u32x4 grp;
