@@ -192,11 +192,24 @@ void segment_add_star_tree(Segment& seg, const pg_star_tree_desc& d) {
   if (st->n_nodes <= 0 || off + (uint64_t)st->n_nodes * 28 != len) fail(PG_ERR_INVALID_ARGUMENT, "Error loading star-tree, buffer size mis-match");
   st->nodes.resize((size_t)st->n_nodes * 7);
   for (size_t i = 0; i < st->nodes.size(); i++) st->nodes[i] = le32(t + off + i * 4);
+  std::vector<uint8_t> has_parent((size_t)st->n_nodes, 0);
   for (int32_t nd = 0; nd < st->n_nodes; nd++) {   // the traversal trusts these
     const int32_t* f = &st->nodes[(size_t)nd * 7];
     const bool leaf = f[kFirstChildId] == -1;
     if (!leaf && (f[kFirstChildId] <= nd || f[kLastChildId] < f[kFirstChildId] || f[kLastChildId] >= st->n_nodes)) fail(PG_ERR_INVALID_ARGUMENT, "star-tree node %d has bad child ids", nd);
+    // the root splits on no dimension (OffHeapStarTreeNode: -1), every other node on one of the tree's; a node's children split on the NEXT
+    // dimension and belong to it alone — the traversal indexes dims[dimensionId + 1] and walks child ranges breadth first: a root with a
+    // flipped dimension id walked off the array (found by the malformed-buffer fuzz, round 5), shared children would multiply the walk
+    if (nd == 0 && f[kDimensionId] != -1) fail(PG_ERR_INVALID_ARGUMENT, "star-tree root has dimension id %d", f[kDimensionId]);
     if (nd > 0 && (f[kDimensionId] < 0 || f[kDimensionId] >= n_dims)) fail(PG_ERR_INVALID_ARGUMENT, "star-tree node %d has bad dimension id", nd);
+    if (!leaf) {
+      if (f[kDimensionId] + 1 >= n_dims) fail(PG_ERR_INVALID_ARGUMENT, "star-tree node %d splits past the last dimension", nd);
+      for (int32_t c = f[kFirstChildId]; c <= f[kLastChildId]; c++) {
+        if (has_parent[(size_t)c]) fail(PG_ERR_INVALID_ARGUMENT, "star-tree node %d has two parents", c);
+        has_parent[(size_t)c] = 1;
+        if (st->nodes[(size_t)c * 7 + kDimensionId] != f[kDimensionId] + 1) fail(PG_ERR_INVALID_ARGUMENT, "star-tree node %d: child %d is not on the next dimension", nd, c);
+      }
+    }
     if (f[kAggregatedDocId] < 0 || f[kAggregatedDocId] >= d.num_docs) fail(PG_ERR_INVALID_ARGUMENT, "star-tree node %d has bad aggregated docId", nd);
     // every node's doc range feeds range / match-word leaves; the builders leave the root's at (-1, -1) (never a leaf's range),
     // anything else must be a range inside the star-tree's docs
@@ -444,7 +457,7 @@ static bool traverse(Segment& seg, const StarTree& st, const PredMap& pm, const 
       if (F(node, kEndDocId) > F(node, kStartDocId)) doc_ranges.emplace_back(F(node, kStartDocId), F(node, kEndDocId));
       continue;
     }
-    if (dim + 1 >= (int32_t)st.dims.size()) fail(PG_ERR_INVALID_ARGUMENT, "star-tree node %d splits past the last dimension", node);
+    if (dim < -1 || dim + 1 >= (int32_t)st.dims.size()) fail(PG_ERR_INVALID_ARGUMENT, "star-tree node %d splits past the last dimension", node);
     const std::string& child_dim = st.dims[(size_t)dim + 1];
     const int32_t first = F(node, kFirstChildId), last = F(node, kLastChildId);
     int32_t star = -1;   // getChildForDimensionValue(ALL): children are sorted by value, the star child comes first

@@ -69,6 +69,13 @@ def main():
     tally = {"registrations": 0, "ok": 0, "invalid": 0, "unsupported": 0, "queries": 0, "query_refused": 0}
     budget = int(os.environ.get("FUZZ_MAX_MUTATIONS", "100000"))
 
+    last = {"what": ""}
+
+    def note(what):   # FUZZ_TRACE=1: the case in flight goes to stderr (a crash then names it)
+        last["what"] = what
+        if os.environ.get("FUZZ_TRACE"):
+            print(what, file=sys.stderr, flush=True)
+
     def classify(status):
         assert status in OK_STATUSES, f"status {status}: {api.last_error()}"
         tally["registrations"] += 1
@@ -127,6 +134,102 @@ def main():
             c2 = copy.copy(base)
             c2.forward_index = m
             try_column(c2, ["SELECT COUNT(*), SUM(ri) FROM t WHERE ri > 0"])
+    # multi-value columns (round 5): FixedBitMVForwardIndexReader's header + row-start bitmap + entries, the raw chunked
+    # multi-value formats, their inverted indexes — mutated buffers, then queries whose kernels walk the entries
+    from tests import mv_fixture as mvf
+    mv_host = mvf.build_with_raw_twins(mvf.make_rows(1500, seed=5))
+    mv_n = mv_host.total_docs
+
+    def try_mv_column(col, queries):
+        seg = NativeSegment(api, HostSegment("fuzz_mv", mv_n))
+        d = col.desc()
+        status = api.f("segment_add_column")(seg.handle, C.byref(d))
+        classify(status)
+        if status == capi.PG_OK:
+            seg.host.columns[col.name] = col
+            for q in queries:
+                try:
+                    seg.execute(q)
+                    tally["queries"] += 1
+                except capi.NativeError as e:
+                    assert e.status in OK_STATUSES, (q, e)
+                    tally["query_refused"] += 1
+                except Exception:   # noqa: BLE001
+                    tally["queries"] += 1
+        seg.destroy()
+    for name in ("mv1", "mv2", "mv3", "r1", "r3", "rd", "rs"):
+        col = mv_host.columns[name]
+        numeric = col.data_type != "STRING"
+        qs = [f"SELECT COUNT(*) FROM t WHERE {name} = " + ("7" if numeric else "'cat'"), f"SELECT COUNTMV({name}), COUNT(*) FROM t"]
+        if col.has_dictionary:
+            qs.append(f"SELECT {name}, COUNT(*) FROM t GROUP BY {name} LIMIT 100000")
+        for attr in ("forward_index", "dictionary", "inverted_index"):
+            buf = getattr(col, attr)
+            if buf is None or len(buf) == 0:
+                continue
+            for what, m in mutations(np.asarray(buf, dtype=np.uint8), rng, n_random=16):
+                c2 = copy.copy(col)
+                setattr(c2, attr, m)
+                note(f"mv {name}.{attr} {what}")
+                try_mv_column(c2, qs)
+        for field, values in (("cardinality", (0, 1, col.cardinality + 1)), ("bits_per_value", (0, 33)), ("total_number_of_entries", (0, 1, 2**31 - 1))):
+            if not hasattr(col, field):
+                continue
+            for v in values:
+                c2 = copy.copy(col)
+                setattr(c2, field, v)
+                note(f"mv {name}.{field} = {v}")
+                try_mv_column(c2, qs[:2])
+    # star-tree buffers through pg_segment_add_star_tree: the serialized tree (StarTreeV2 node records), the dimensions' forward indexes, the
+    # function-column pairs' raw forward indexes — then the query the tree answers
+    from pinot_amd import startree, synth
+    st_parent = synth.generate_segment(20_000, segment_index=1, columns=list(synth.CFG5_COLUMNS), native=False)
+    startree.add_star_tree(st_parent, ["h1", "h2", "h3", "h4"], [("COUNT", "*"), ("DISTINCTCOUNTHLL", "u")], max_leaf_records=100)
+    tree = st_parent.star_trees[0]
+    st_parent.star_trees = []
+    st_queries = [synth.QUERY_CFG5, "SELECT h1, COUNT(*) FROM t WHERE h2 = 3 GROUP BY h1"]
+
+    def try_star_tree(t2):
+        seg = NativeSegment(api, st_parent)
+        d = t2.desc()
+        status = api.f("segment_add_star_tree")(seg.handle, C.byref(d))
+        classify(status)
+        if status == capi.PG_OK:
+            for q in st_queries:
+                try:
+                    seg.execute(q)
+                    tally["queries"] += 1
+                except capi.NativeError as e:
+                    assert e.status in OK_STATUSES, (q, e)
+                    tally["query_refused"] += 1
+                except Exception:   # noqa: BLE001
+                    tally["queries"] += 1
+        seg.destroy()
+    for what, m in mutations(np.asarray(tree.star_tree, dtype=np.uint8), rng, n_random=60):
+        t2 = copy.copy(tree)
+        t2.star_tree = m
+        note(f"star-tree nodes {what}")
+        try_star_tree(t2)
+    for di in range(len(tree.dimension_forward_indexes)):
+        for what, m in mutations(np.asarray(tree.dimension_forward_indexes[di], dtype=np.uint8), rng, n_random=8):
+            t2 = copy.copy(tree)
+            t2.dimension_forward_indexes = list(tree.dimension_forward_indexes)
+            t2.dimension_forward_indexes[di] = m
+            note(f"star-tree dim {di} {what}")
+            try_star_tree(t2)
+    for pi in range(len(tree.pairs)):
+        for what, m in mutations(np.asarray(tree.pairs[pi].forward_index, dtype=np.uint8), rng, n_random=12):
+            t2 = copy.copy(tree)
+            t2.pairs = [copy.copy(pp) for pp in tree.pairs]
+            t2.pairs[pi].forward_index = m
+            note(f"star-tree pair {pi} {what}")
+            try_star_tree(t2)
+    for field, values in (("num_docs", (0, 1, tree.num_docs + 1, 2**31 - 1)), ("max_leaf_records", (0, 1))):
+        for v in values:
+            t2 = copy.copy(tree)
+            setattr(t2, field, v)
+            note(f"star-tree {field} = {v}")
+            try_star_tree(t2)
     # bitmaps and the range index through their setters
     seg = NativeSegment(api, host)
     nulls = np.frombuffer(formats.serialize_roaring(np.arange(0, N, 7, dtype=np.int64)), dtype=np.uint8)
