@@ -788,7 +788,7 @@ static long long tiles_docs(int t0, int t1) { return (long long)(t1 - t0) * PG_W
 // Pass boundaries.  What makes a floor rise is the number of offers a REGISTER has seen: after ~6 offers per register hardly any register of
 // a group is empty (floor >= 1: half of the offers are dropped), after ~24 the floors sit at 2-3, after ~96 at 4-5.  So the passes end
 // where the docs seen so far amount to 6 / 24 / 96 offers per register — 20 M / 79 M / 315 M docs for config 5's 12 800 x 256 registers,
-// i.e. 2 % / 8 % / 30 % of 10^9 docs (13.7 % of all offers survive) but 10 % / 40 % of 2 x 10^8 (41 %: profiles/r04_g_pruned_passes.txt).
+// i.e. 2 % / 8 % / 30 % of 10^9 docs (13.7 % of all offers survive) but 10 % / 40 % of 2 x 10^8 (41 %: profiles/r04_h_pruned_passes.txt).
 static std::vector<int> oct_pass_bounds(int n_wtiles, int64_t registers) {
   std::vector<double> frac;
   if (const char* e = knobs().oct_passes.empty() ? nullptr : knobs().oct_passes.c_str()) {   // test / measurement knob: cumulative fractions, e.g. "0.02,0.08,0.3,1"

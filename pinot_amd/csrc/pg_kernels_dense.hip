@@ -123,7 +123,7 @@ __device__ __forceinline__ void dense_count_body(const PgQueryPlan& p) {
     combine(a, q);
   }
   // ONE update of the counter per workgroup: same-address global atomics retire one by one (~10 ns each on this part — with an atomic per
-  // wavefront of 2 048 small workgroups they were 0.15 of the kernel's 0.16 ms, profiles/r04_z_dense_count.txt)
+  // wavefront of 2 048 small workgroups they were 0.15 of the kernel's 0.16 ms, profiles/r04_z_count_streams.txt)
   __shared__ uint32_t s_cnt;
   if (threadIdx.x == 0) s_cnt = 0;
   __syncthreads();

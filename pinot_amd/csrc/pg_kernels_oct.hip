@@ -55,7 +55,7 @@ DEVFN void oct_raise_register(uint32_t* lds_words, uint32_t byte_addr, uint32_t 
 // HyperLogLog registers are bytes: a register is raised by compare-and-swap on its dword.  Batched over four of the lane's docs — four
 // dword reads in flight, then four compare-and-swaps in flight for the docs whose rank beats the register as read — so a sub-tile costs four
 // LDS round trips whatever the number of raises (one read + one CAS chain per doc measured 58 % of the wave's time waiting,
-// profiles/r04_b_sq_oct_l.txt; all eight docs at once spilled 96 bytes per lane); a CAS that lost against another writer of the same
+// profiles/r04_b_sq_counters_oct_l_200m.txt; all eight docs at once spilled 96 bytes per lane); a CAS that lost against another writer of the same
 // dword is retried in a (rare) serial loop.
 template <int J0>
 DEVFN void oct_raise_four(uint32_t m8, const uint32_t (&key)[8], const uint32_t (&item)[8], uint32_t* aux_words, uint32_t stride, uint32_t log2m) {
@@ -114,7 +114,7 @@ DEVFN void oct_apply_lds(const PgQueryPlan& p, uint32_t m8, const uint32_t (&key
   // HyperLogLog registers are bytes: a register is raised by compare-and-swap on its dword.  Everything is batched over the lane's 8 docs —
   // 8 dword reads in flight, then 8 compare-and-swaps in flight for the docs whose rank beats the register as read — so a sub-tile costs
   // two LDS round trips whatever the number of raises (one read + one CAS chain per doc measured 58 % of the wave's time waiting,
-  // profiles/r04_b_sq_oct_l.txt); a CAS that lost against another writer of the same dword is retried in a (rare) serial loop.
+  // profiles/r04_b_sq_counters_oct_l_200m.txt); a CAS that lost against another writer of the same dword is retried in a (rare) serial loop.
   const uint32_t log2m = (uint32_t)p.oct_log2m;
   if (p.oct_dword) {   // room for a dword per register (planner): one ds_max_u32 per offer, nothing returned
     const uint32_t imask = (1u << log2m) - 1u;
