@@ -51,3 +51,22 @@ def test_wave_specialised_stage_layout_exports():
             assert got % tile(b0, b1) == 0 and got // tile(b0, b1) in (1, 2, 3, 4), (b0, b1, got)
     # config 3 (one 7-bit key): table (100 groups x 2 accumulators x 32 replicas + trash) + two stages must fit the 152 KB the launch may ask for
     assert 100 * 2 * 32 * 8 + 2 * 64 * 8 + 2 * lib.pg_spec_stage_bytes(7, 0) < 160 * 1024 - 8192
+
+
+def test_documents_cite_things_that_exist():
+    """Test files, tool scripts and pg_* names (kernels, ABI functions, structs) the documents put in backticks exist in the tree."""
+    src = ""
+    for f in glob.glob(os.path.join(ROOT, "pinot_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "pinot_amd", "csrc", "synth", "*")):
+        if os.path.isfile(f) and not f.endswith((".o", ".so", ".log")):
+            src += open(f, errors="ignore").read()
+    src += open(os.path.join(ROOT, "include", "pinot_gpu.h")).read()
+    bad = set()
+    for doc in ("DESIGN.md", "README.md", "INTEGRATION.md"):
+        text = open(os.path.join(ROOT, doc)).read()
+        for m in re.finditer(r"`((?:tests|tools)/[A-Za-z0-9_/.]+\.(?:py|sh|hip))`", text):
+            if not os.path.exists(os.path.join(ROOT, m.group(1))):
+                bad.add((doc, m.group(1)))
+        for m in re.finditer(r"`(pg_[a-z0-9_]+)`", text):
+            if not m.group(1).endswith("_") and m.group(1) not in src:
+                bad.add((doc, m.group(1)))
+    assert not bad, sorted(bad)
