@@ -121,6 +121,20 @@ Column* Segment::find(const char* n) {
 
 static size_t padded_docs(const Segment& seg) { return (size_t)seg.n_tiles * PG_TILE_DOCS; }
 
+// the n bit-packed dictIds c.fwd_dev holds (a single-value column's docs, a multi-value column's entries) against the dictionary's cardinality
+// (pg_column_max_dict_id_kernel)
+static void check_dict_ids(const Column& c, int64_t n) {
+  if (n <= 0 || c.cardinality <= 0 || !(c.bits >= 31 || ((int64_t)1 << c.bits) > (int64_t)c.cardinality)) return;   // no room above the cardinality
+  DeviceBuffer out(4, true);
+  const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(2048, (n + 255) / 256));
+  hipLaunchKernelGGL(pg_column_max_dict_id_kernel, dim3(grid), dim3(256), 0, 0, c.fwd_dev.as<uint8_t>(), n, c.bits, out.as<unsigned int>());
+  PG_HIP(hipGetLastError());
+  unsigned int mx = 0;
+  PG_HIP(hipMemcpy(&mx, out.ptr, 4, hipMemcpyDeviceToHost));
+  if ((int64_t)mx >= (int64_t)c.cardinality)
+    fail(PG_ERR_INVALID_ARGUMENT, "forward index of %s holds dictId %u, the dictionary has %d values", c.name.c_str(), mx, c.cardinality);
+}
+
 static void upload_fixed_bit(Segment& seg, Column& c, const uint8_t* src, uint64_t len) {
   uint64_t need = ((uint64_t)seg.total_docs * (uint64_t)c.bits + 7) / 8;
   if (len < need) fail(PG_ERR_INVALID_ARGUMENT, "forward index of %s is %llu bytes, need %llu", c.name.c_str(),
@@ -130,16 +144,7 @@ static void upload_fixed_bit(Segment& seg, Column& c, const uint8_t* src, uint64
   c.fwd_dev.upload(src, need);
   c.col_kind = PG_COL_FIXED_BIT;
   c.fwd_bytes_logical = need;
-  if (seg.total_docs > 0 && c.cardinality > 0 && (c.bits >= 31 || ((int64_t)1 << c.bits) > (int64_t)c.cardinality)) {   // room above the cardinality
-    DeviceBuffer out(4, true);
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(2048, ((int64_t)seg.total_docs + 255) / 256));
-    hipLaunchKernelGGL(pg_column_max_dict_id_kernel, dim3(grid), dim3(256), 0, 0, c.fwd_dev.as<uint8_t>(), (int64_t)seg.total_docs, c.bits, out.as<unsigned int>());
-    PG_HIP(hipGetLastError());
-    unsigned int mx = 0;
-    PG_HIP(hipMemcpy(&mx, out.ptr, 4, hipMemcpyDeviceToHost));
-    if ((int64_t)mx >= (int64_t)c.cardinality)
-      fail(PG_ERR_INVALID_ARGUMENT, "forward index of %s holds dictId %u, the dictionary has %d values", c.name.c_str(), mx, c.cardinality);
-  }
+  check_dict_ids(c, (int64_t)seg.total_docs);
 }
 
 static void parse_inverted_index(Segment& seg, Column& c, const uint8_t* inv, uint64_t len) {
@@ -563,6 +568,7 @@ void segment_add_column(Segment& seg, const pg_column_desc& d) {
     c.total_entries = (int32_t)num_values;
     c.fwd_dev.alloc((size_t)raw_bytes + 64, true);   // +64: the kernels read a dword pair past the value
     c.fwd_dev.upload(bitmap + bitmap_bytes, raw_bytes);
+    check_dict_ids(c, num_values);   // (the entries index dictionaries, look-up tables and LDS group tables exactly as a single-value column's docs do)
     c.mv_offsets_dev = upload_vector(off);
     c.col_kind = PG_COL_FIXED_BIT;
     c.fwd_bytes_logical = need;

@@ -271,3 +271,32 @@ def test_the_doc_by_doc_walk_still_agrees(gpu_api, oracle_api, gpu_knobs):
         assert g.execute(sql).rows() == o.execute(sql).rows(), sql
     g.destroy()
     o.destroy()
+
+
+def test_entries_beyond_the_dictionary_are_refused_at_registration(gpu_api):
+    """A multi-value forward index whose width leaves room above the cardinality (6 bits, 41 values) can hold dictIds the dictionary does not
+    have — a corrupt or mismatched file.  The entries index dictionaries, look-up tables and LDS group tables exactly as a single-value
+    column's docs do, so they are checked the same way, once, at registration (pg_segment.cpp, check_dict_ids)."""
+    import copy
+    import ctypes as C
+    from pinot_amd import capi
+    from pinot_amd.segment import HostSegment
+    host = mv.build(mv.make_rows(3000, seed=31))
+    good = host.columns["mv1"]
+    assert good.cardinality == 41 and good.bits_per_value == 6   # 40 values + the default null value of empty docs
+    seg = NativeSegment(gpu_api, HostSegment("mv_ids", host.total_docs))
+    bad = copy.copy(good)
+    fi = np.array(good.forward_index, dtype=np.uint8, copy=True)
+    fi[-10:-8] = 0xFF                          # two bytes of ones inside the packed entries: one 6-bit entry becomes 63, the dictionary has 41 values
+    bad.forward_index = fi
+    d = bad.desc()
+    status = gpu_api.f("segment_add_column")(seg.handle, C.byref(d))
+    assert status == capi.PG_ERR_INVALID_ARGUMENT and "dictId" in gpu_api.last_error(), (status, gpu_api.last_error())
+    low = copy.copy(good)
+    low.cardinality = 17                       # metadata that disagrees with the entries (ids up to 40) — and with the dictionary buffer
+    d = low.desc()
+    status = gpu_api.f("segment_add_column")(seg.handle, C.byref(d))
+    assert status == capi.PG_ERR_INVALID_ARGUMENT, (status, gpu_api.last_error())
+    d = good.desc()
+    assert gpu_api.f("segment_add_column")(seg.handle, C.byref(d)) == capi.PG_OK
+    seg.destroy()
