@@ -20,6 +20,8 @@ PG_DECL_FAST(pg_fast_none_f) PG_DECL_FAST(pg_fast_none_a) PG_DECL_FAST(pg_fast_i
 PG_DECL_FAST(pg_fast_dictrange_f) PG_DECL_FAST(pg_fast_dictrange_a) PG_DECL_FAST(pg_fast_dictlut_f) PG_DECL_FAST(pg_fast_dictlut_a)
 PG_DECL_FAST(pg_fast_multi_f) PG_DECL_FAST(pg_fast_multi_a) PG_DECL_FAST(pg_fast_multi_w) PG_DECL_FAST(pg_fast_none_w)
 PG_DECL_FAST(pg_fast_i32range_d) PG_DECL_FAST(pg_fast_i32range_p) PG_DECL_FAST(pg_fast_i32range_fp) PG_DECL_FAST(pg_fast_i32range_s) PG_DECL_FAST(pg_spec_none) PG_DECL_FAST(pg_spec_scan) PG_DECL_FAST(pg_spec_index) PG_DECL_FAST(pg_fast_i32range_st)
+// pg_kernels_specd.hip: the loader / consumer frame over dictionary-encoded scan / value columns (_r raw INT values, _a arithmetic dictionary, _g gathered)
+PG_DECL_FAST(pg_fast_dictrange_s_r) PG_DECL_FAST(pg_fast_dictrange_st_r) PG_DECL_FAST(pg_specd_none_r) PG_DECL_FAST(pg_specd_scan_r) PG_DECL_FAST(pg_specd_index_r) PG_DECL_FAST(pg_fast_dictrange_s_a) PG_DECL_FAST(pg_fast_dictrange_st_a) PG_DECL_FAST(pg_specd_none_a) PG_DECL_FAST(pg_specd_scan_a) PG_DECL_FAST(pg_specd_index_a) PG_DECL_FAST(pg_fast_dictrange_s_g) PG_DECL_FAST(pg_fast_dictrange_st_g) PG_DECL_FAST(pg_specd_none_g) PG_DECL_FAST(pg_specd_scan_g) PG_DECL_FAST(pg_specd_index_g)
 PG_DECL_FAST(pg_dense_count_1) PG_DECL_FAST(pg_dense_count_2) PG_DECL_FAST(pg_dense_count_3) PG_DECL_FAST(pg_dense_count_4)
 PG_DECL_FAST(pg_dense_count_5) PG_DECL_FAST(pg_dense_count_6) PG_DECL_FAST(pg_dense_count_7) PG_DECL_FAST(pg_dense_count_8)
 PG_DECL_FAST(pg_dict_count_1) PG_DECL_FAST(pg_dict_count_2) PG_DECL_FAST(pg_dict_count_3) PG_DECL_FAST(pg_dict_count_4)
@@ -36,6 +38,8 @@ extern "C" const int pg_scan_waves_per_block;   // pg_kernels_scan.hip: wavefron
 extern "C" const int pg_pipe_waves_per_block;   // pg_kernels_pipe.hip: wavefronts per workgroup of pg_fast_i32range_p
 extern "C" const int pg_spec_waves_per_block;   // pg_kernels_spec.hip: pg_fast_i32range_s (4 loader + 8 consumer wavefronts)
 extern "C" int pg_spec_stage_bytes(int bits0, int bits1);
+extern "C" const int pg_specd_waves_per_block;   // pg_kernels_specd.hip: pg_fast_dictrange_s family (dictionary-encoded scan / value columns)
+extern "C" int pg_specd_stage_bytes(int scan_bits, int value_bits, int bits0, int bits1);
 PG_DECL_FAST(pg_fast_multi_wd) PG_DECL_FAST(pg_fast_none_wd) PG_DECL_FAST(pg_generic_query_ld) PG_DECL_FAST(pg_generic_query_gd)
 extern "C" __global__ void pg_reduce_partials_kernel(const int64_t* partials, int64_t* out, int n_wg, int n_ops,
                                                      int n_groups, const PgAccOp* ops, unsigned long long* stats, int reduce);
@@ -322,6 +326,8 @@ void use_device(int ordinal) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
       for (QueryKernel k : {pg_fast_i32range_s, pg_fast_i32range_st, pg_spec_none, pg_spec_scan, pg_spec_index})
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
+      for (QueryKernel k : {pg_fast_dictrange_s_r, pg_fast_dictrange_st_r, pg_specd_none_r, pg_specd_scan_r, pg_specd_index_r, pg_fast_dictrange_s_a, pg_fast_dictrange_st_a, pg_specd_none_a, pg_specd_scan_a, pg_specd_index_a, pg_fast_dictrange_s_g, pg_fast_dictrange_st_g, pg_specd_none_g, pg_specd_scan_g, pg_specd_index_g})
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
       for (QueryKernel k : {pg_mv_query_f, pg_mv_query_l, pg_mv_query_g})   // 10.5 KB of static LDS (per-wavefront entry bitmaps): the planner's 144 KB still fit
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 12288);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pg_radix_scatter_packed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
@@ -359,6 +365,14 @@ static bool uses_scan_kernel(const CompiledPlan& P, int agg_mode) {
   const bool no_scan = knobs().no_scan_pipe;   // measurement knob
   return !no_scan && agg_mode == PG_AGG_NONE && uses_fast_kernel(P, agg_mode) && P.fast_filter == 4 && P.dev.n_index_instr == 0 &&
          P.dev.fast_scan_pushed;
+}
+// pg_fast_dictrange_s family (pg_kernels_specd.hip): the loader / consumer frame over dictionary-encoded scan / value columns — decided at plan
+// time (PgQueryPlan::specd), whatever the filter lets through
+static bool uses_specd(const CompiledPlan& P, int agg_mode) {
+  return P.dev.specd && agg_mode == PG_AGG_LDS && uses_fast_kernel(P, agg_mode) && P.fast_agg && !P.wide_agg && !knobs().no_specd;
+}
+static size_t specd_stage_bytes(const CompiledPlan& P) {
+  return ((size_t)pg_specd_stage_bytes(P.dev.specd_sbits, P.dev.specd_vbits, P.dev.gcols[0].bits, P.dev.n_group_cols > 1 ? P.dev.gcols[1].bits : 0) + 15) & ~(size_t)15;
 }
 // pg_fast_i32range_p (software-pipelined headline shape, pg_kernels_pipe.hip): its own workgroup size
 static bool uses_pipe_general(const CompiledPlan& P, int agg_mode) {   // pg_pipe_*: the pipeline's other filter shapes
@@ -437,6 +451,16 @@ static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char
       if (P.fast_filter == -1) { *name = P.digit_ops ? "pg_fast_none_wd" : "pg_fast_none_w"; return P.digit_ops ? pg_fast_none_wd : pg_fast_none_w; }
       *name = P.digit_ops ? "pg_fast_multi_wd" : "pg_fast_multi_w";
       return P.digit_ops ? pg_fast_multi_wd : pg_fast_multi_w;
+    }
+    if (uses_specd(P, agg_mode)) {
+      // one kernel per value kind (raw INT / arithmetic dictionary / gathered dictionary) and filter shape
+      static const struct { const char* name; QueryKernel fn; } kSpecd[3][5] = {
+          {{"pg_specd_none_r", pg_specd_none_r}, {"pg_specd_index_r", pg_specd_index_r}, {"pg_specd_scan_r", pg_specd_scan_r}, {"pg_fast_dictrange_s_r", pg_fast_dictrange_s_r}, {"pg_fast_dictrange_st_r", pg_fast_dictrange_st_r}},
+          {{"pg_specd_none_a", pg_specd_none_a}, {"pg_specd_index_a", pg_specd_index_a}, {"pg_specd_scan_a", pg_specd_scan_a}, {"pg_fast_dictrange_s_a", pg_fast_dictrange_s_a}, {"pg_fast_dictrange_st_a", pg_fast_dictrange_st_a}},
+          {{"pg_specd_none_g", pg_specd_none_g}, {"pg_specd_index_g", pg_specd_index_g}, {"pg_specd_scan_g", pg_specd_scan_g}, {"pg_fast_dictrange_s_g", pg_fast_dictrange_s_g}, {"pg_fast_dictrange_st_g", pg_fast_dictrange_st_g}}};
+      const int shape = P.dev.pipe_tail != nullptr ? 4 : (P.dev.pipe_has_scan ? 2 : 0) + (P.dev.pipe_has_index ? 1 : 0);
+      *name = kSpecd[P.dev.specd_vkind - 1][shape].name;
+      return kSpecd[P.dev.specd_vkind - 1][shape].fn;
     }
     const bool no_dense = knobs().no_dense_fused;   // measurement knob
     switch (pinned_spec_shape(P, agg_mode)) {
@@ -587,6 +611,10 @@ static LaunchShape launch_shape(const CompiledPlan& P, int n_wtiles, int agg_mod
     const int waves = pg_scan_waves_per_block;
     int grid = std::min((n_wtiles + waves - 1) / waves, num_cus() * std::max(wgs_per_cu, 1));
     return {std::max(grid, 1), waves * 64, 0};
+  }
+  if (uses_specd(P, agg_mode)) {   // one 16-wavefront workgroup per CU; behind the table and its trash slots a private strip of LDS per wavefront
+    const int waves = pg_specd_waves_per_block;
+    return {std::max(1, std::min((n_wtiles + waves - 1) / waves, num_cus())), waves * 64, lds + 64 + specd_stage_bytes(P) + 512 * (size_t)P.dev.n_ops};
   }
   if (uses_spec_kernel(P, agg_mode))   // one 12-wavefront workgroup per CU walking tiles b, b + grid, ...; table + two stage buffers in LDS
     return {std::max(1, std::min(n_wtiles, num_cus())), pg_spec_waves_per_block * 64, lds + 64 + 2 * spec_stage_bytes(P) + 512 * (size_t)P.dev.n_ops};   // (+ 64 trash slots per accumulator)

@@ -1,0 +1,359 @@
+// pg_fast_dictrange_s: the headline shape over Pinot's DEFAULT encoding (round 6) — the scan column and / or the value column
+// are dictionary-encoded: fixed-bit dictId streams (FixedBitSVForwardIndexReaderV2.java:65-99), the range predicate is a dictId interval
+// [start, end) found by binary search in the sorted dictionary at plan time (RangePredicateEvaluatorFactory.java:126-167) and the aggregated
+// value is dictionary.get(dictId) (DataFetcher.java:335-386).
+//
+// Design: 16 independent wavefronts per CU, NO barrier in the main loop, each with a PRIVATE strip of LDS that serves as its transposition
+// buffer.  A wavefront walks wave tiles (2 048 docs) as four sub-tiles of 512 docs:
+//   * stream: the sub-tile's bytes of every column — 64 x bits bytes, contiguous — arrive as coalesced 16 B / lane loads (a 20-bit column:
+//     80 lanes' worth, two instructions), two sub-tiles in flight per wavefront (~110 KB per CU), and are stored to the strip as they are;
+//     the tile's posting dwords (linear layout: 32 docs per lane) arrive once per tile and the dense index program runs over them at once;
+//   * transpose by address: lane L owns docs 8 L .. 8 L + 7 of the sub-tile (oct layout).  Field j of any width <= 24 bits (or 32: raw INT) is
+//     read WITHOUT a branch on the width: bit P = (8 L + j) x bits of the strip's MSB-first stream, the dword pair that holds it is read at a
+//     per-lane address, one byte permute (per-lane selector) puts the 4 bytes from byte P >> 3 on into big-endian order, and the field then
+//     starts (j x bits) & 7 bits below the top — the same for every lane: one shift, one mask.  (A switch over the widths with compile-time field
+//     positions is a chain of taken scalar branches per sub-tile: 870 cycles for 50 vector instructions, profiles/r06_specd_steps.txt; an LDS
+//     read at an address that is not dword aligned is served one lane per cycle, tools/probes/lds_unaligned.hip.)
+//   * filter: range test on the 8 dictIds (or raw values) AND the candidates' byte of the linear dword (one ds_bpermute per sub-tile);
+//   * aggregate in proportion to the MATCHES: one ballot per doc position ranks the matching docs, they are compacted into a selection list
+//     (uint16 per match, in the strip) and the list is walked 64 docs at a time with every lane busy — value dictId and group dictIds gathered
+//     from the strip (the same two-dword window with per-lane positions), value = raw | base + step x dictId (arithmetic dictionaries, found at
+//     registration) | dictionary[dictId] (gathered from the L2-resident native-endian copy, applied one sub-tile later), ONE LDS atomic per
+//     accumulator and 64 matches.  The position-wise form (8 docs per lane, misses aimed at a trash slot) issued 16 atomics per sub-tile
+//     whatever matched and kept the CU's LDS pipe busy 60 % of the time at 47 % of the roofline.
+// The first cut of this file was the loader / consumer frame of pg_fast_i32range_s with these consumers (4 + 8 wavefronts, one barrier per two
+// tiles): 44-47 % of 8 TB/s whatever the consumers did — each stage was a chain of three LDS round trips on every consumer at the same time,
+// between two rendezvous of all twelve wavefronts.  Independent wavefronts overlap one another's round trips instead.
+// Bytes per doc: (scan bits + value bits + group bits) / 8 + postings — 6.625 B for config 3 with 20-bit r_int / m against 9.625 raw.
+#define PG_WAVES_PER_BLOCK 16
+#define PG_KERNEL template <int PG_NOT_INSTANTIATED> static
+#include "pg_kernels.hip"
+#include "pg_oct_layout.h"
+
+#define SD_PAD 16u                                      // a field's dword pair may reach one dword past the column's last byte
+#define SD_LIST_BYTES ((OCT_SUB_DOCS + 64u) * 2u)       // a wavefront's selection list: 512 uint16 entries + a dummy entry per lane
+__host__ __device__ static inline uint32_t sd_region(uint32_t bits) { return bits ? (bits * 64u + SD_PAD + 15u) & ~15u : 0u; }
+extern "C" const int pg_specd_waves_per_block = PG_WAVES_PER_BLOCK;
+// bytes of the launch's LDS behind the table and its trash slots: one strip per wavefront (the sub-tile's column bytes + the selection list)
+extern "C" int pg_specd_stage_bytes(int scan_bits, int value_bits, int bits0, int bits1) {
+  const int strip = (int)(sd_region((uint32_t)scan_bits) + sd_region((uint32_t)value_bits) + sd_region((uint32_t)bits0) + sd_region((uint32_t)bits1) + SD_LIST_BYTES);
+  return PG_WAVES_PER_BLOCK * strip + 16;
+}
+
+template <typename T> DEVFN const GAS T* sd_sgpr_ptr(const void* ptr) {
+  const uint64_t v = (uint64_t)ptr;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return (const GAS T*)(((uint64_t)hi << 32) | (uint64_t)lo);
+}
+DEVFN uint32_t or_reduce4(uint32_t v) {   // OR across aligned groups of 4 lanes
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+  return v;
+}
+
+// the loads of one sub-tile in flight: two 16-byte pieces per lane of the scan and the value column (64 x bits <= 2 048 bytes), one of a group column
+template <int NG> struct SdSub { u32x4 sc[2], va[2], g[NG]; };
+// SD_V_GATHER: dictionary look-ups issued for one sub-tile and applied behind the next (the first rounds of its selection list)
+#define SD_PEND 2
+struct SdPend { uint32_t slot[SD_PEND]; int32_t v[SD_PEND]; int n; };
+
+// value kinds (PgQueryPlan::specd_vkind)
+enum { SD_V_RAW32 = 1, SD_V_AFFINE = 2, SD_V_GATHER = 3 };
+
+// HAS_INDEX: the fused dense index program (else every valid doc is a candidate); HAS_SCAN: one range scan (dictId interval of a fixed-bit
+// column, or raw INT range) restricted to the candidates; HAS_TAIL: the upsert queryableDocIds snapshot ANDed in after the candidates have been
+// counted (FilterPlanNode.run's outer AND); VK: how a dictId of the value column becomes the value.
+template <int NG, bool HAS_INDEX, bool HAS_SCAN, bool HAS_TAIL, int VK>
+__device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
+  __shared__ uint32_t s_stat[PG_MAX_STATS];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = uniform(t >> 6);
+  int64_t* lds_table = reinterpret_cast<int64_t*>(smem);
+  if (t < PG_MAX_STATS) s_stat[t] = 0;
+  const uint32_t real_slots = (uint32_t)p.n_groups * (uint32_t)p.replicas;
+  const uint32_t table_slots = real_slots + 64u;   // + one trash slot per lane behind every accumulator's row (the dead lanes of a list's last round)
+  for (int o = 0; o < p.n_ops; o++) {
+    const int64_t ident = pg_acc_identity(p.ops[o].fn, p.ops[o].is_float);
+    for (uint32_t i = t; i < table_slots; i += PG_BLOCK) lds_table[(size_t)o * table_slots + i] = ident;
+  }
+  const uint32_t sbits = HAS_SCAN ? (uint32_t)uniform(p.specd_sbits) : 0u, vbits = (uint32_t)uniform(p.specd_vbits);
+  uint32_t gbits[NG];
+#pragma unroll
+  for (int gi = 0; gi < NG; gi++) gbits[gi] = (uint32_t)uniform(p.gcols[gi].bits);
+  // this wavefront's strip: [scan bytes][value bytes][group bytes ...][selection list]
+  const uint32_t off_val = sd_region(sbits), off_g0 = off_val + sd_region(vbits), off_g1 = off_g0 + sd_region(gbits[0]);
+  const uint32_t off_list = off_g1 + (NG > 1 ? sd_region(gbits[NG - 1]) : 0u);
+  const uint32_t strip_bytes = off_list + SD_LIST_BYTES;
+  uint8_t* strip = reinterpret_cast<uint8_t*>(smem) + (((size_t)p.n_ops * table_slots * 8u + 15u) & ~(size_t)15u) + (uint32_t)wave * strip_bytes;
+  uint16_t* my_list = reinterpret_cast<uint16_t*>(strip + off_list);
+  const CAS PgScanLeaf& L = cptr(p.scans)[HAS_SCAN ? p.fast_scan : 0];   // only dereferenced when HAS_SCAN
+  // tiles of this wavefront: blockIdx.x * 16 + wave, + gridDim.x * 16, ...
+  const int step = (int)gridDim.x * PG_WAVES_PER_BLOCK;
+  const int first = (int)blockIdx.x * PG_WAVES_PER_BLOCK + wave;
+  const int n_mine = first < p.n_wtiles ? (p.n_wtiles - first + step - 1) / step : 0;
+  const uint8_t* xdata = p.srcs[p.pipe_src].data;
+  const uint8_t* sdata = HAS_SCAN ? L.data : xdata;
+
+  const uint32_t R = (uint32_t)p.replicas;
+  const uint32_t rep = (uint32_t)t & (R - 1u);
+  const uint32_t stride = table_slots;
+  const uint32_t trash_slot = real_slots + (uint32_t)lane;
+  // per-lane constants of the scan fields: LDS address of the dword pair, byte selector, and the (wave-uniform) shift
+  uint32_t sc_at[8], sc_sel[8], sc_sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const uint32_t P = mul24((uint32_t)lane * 8u + (uint32_t)j, sbits);
+    sc_at[j] = (P >> 5) << 2;
+    sc_sel[j] = oct_selector((P >> 3) & 3u);
+    sc_sh[j] = (uint32_t)uniform((int)(32u - (((uint32_t)j * sbits) & 7u) - (sbits > 24u ? 32u : sbits)));   // (raw INT: 32 bits, byte aligned)
+  }
+  const uint32_t sc_mask = sbits >= 32u ? 0xFFFFFFFFu : (1u << sbits) - 1u;
+  // the 16-byte pieces this lane carries of a sub-tile: piece q of a column covers bytes [1024 q + 16 lane, + 16) of its 64 x bits
+  const uint32_t pc = (uint32_t)lane * 16u;
+  bool s_on[2], v_on[2], g_on[NG];
+#pragma unroll
+  for (int q = 0; q < 2; q++) { s_on[q] = pc + 1024u * q < 64u * sbits; v_on[q] = pc + 1024u * q < 64u * vbits; }
+#pragma unroll
+  for (int gi = 0; gi < NG; gi++) g_on[gi] = pc < 64u * gbits[gi];
+  const uint32_t lin_sh = ((uint32_t)lane & 3u) * 8u;
+  const RangeI32 r32 = HAS_SCAN ? make_range_i32(L.lo, L.hi) : RangeI32{0, 0u, false};
+  uint32_t my_matched = 0, my_cand = 0;
+  // the accumulators as 2-bit codes in one 64-bit scalar (0 COUNT, 1 SUM, 2 MIN, 3 MAX)
+  const int n_ops = uniform(p.n_ops);
+  uint64_t ops_code = 0;
+  for (int o = 0; o < n_ops; o++) {
+    const PgAccOp op = p.ops[uniform(o)];
+    ops_code |= (uint64_t)(op.src < 0 ? 0u : (op.fn == PG_ACC_SUM ? 1u : (op.fn == PG_ACC_MIN ? 2u : 3u))) << (2 * o);
+  }
+  ops_code = ((uint64_t)(uint32_t)uniform((int)(uint32_t)(ops_code >> 32)) << 32) | (uint64_t)(uint32_t)uniform((int)(uint32_t)ops_code);
+  const int has_out_words = uniform(p.out_words != nullptr ? 1 : 0);
+  const uint32_t vbase = (uint32_t)uniform(p.specd_base), vstep = (uint32_t)uniform(p.specd_step);
+  const GAS int32_t* vdict = VK == SD_V_GATHER ? sd_sgpr_ptr<int32_t>(p.srcs[p.pipe_src].dict) : nullptr;
+  uint32_t gmul[NG];
+#pragma unroll
+  for (int gi = 0; gi < NG; gi++) gmul[gi] = (uint32_t)uniform((int)((uint32_t)p.gcols[gi].mult * R));
+  const uint32_t list_dummy = OCT_SUB_DOCS + (uint32_t)lane;
+  __syncthreads();
+
+  // ---- the stream ------------------------------------------------------------------------------------------------------------------------
+  auto tile_of = [&](int k) __attribute__((always_inline)) { return first + (k < n_mine ? k : n_mine - 1) * step; };   // (past the end: the last tile again, never consumed)
+  // Lanes past a column's bytes re-read its first 16 bytes of the sub-tile (a line the wavefront requests anyway): no load sits under a branch.
+  auto issue_sub = [&](int k, int sub, SdSub<NG>& r) __attribute__((always_inline)) {
+    const int wt = tile_of(k);
+    __builtin_amdgcn_sched_barrier(0);
+    if (HAS_SCAN) {
+      const uint8_t* base = sdata + ((size_t)wt * 4u + (size_t)sub) * 64u * (size_t)sbits;
+#pragma unroll
+      for (int q = 0; q < 2; q++) r.sc[q] = ldnt((const GAS u32x4*)(sd_sgpr_ptr<uint8_t>(base) + (s_on[q] ? pc + 1024u * q : 0u)));
+    }
+    {
+      const uint8_t* base = xdata + ((size_t)wt * 4u + (size_t)sub) * 64u * (size_t)vbits;
+#pragma unroll
+      for (int q = 0; q < 2; q++) r.va[q] = ldnt((const GAS u32x4*)(sd_sgpr_ptr<uint8_t>(base) + (v_on[q] ? pc + 1024u * q : 0u)));
+    }
+#pragma unroll
+    for (int gi = 0; gi < NG; gi++) {
+      const uint8_t* base = p.gcols[gi].data + ((size_t)wt * 4u + (size_t)sub) * 64u * (size_t)gbits[gi];
+      r.g[gi] = ldnt((const GAS u32x4*)(sd_sgpr_ptr<uint8_t>(base) + (g_on[gi] ? pc : 0u)));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto store_sub = [&](const SdSub<NG>& r) __attribute__((always_inline)) {
+    if (HAS_SCAN) {
+#pragma unroll
+      for (int q = 0; q < 2; q++) if (s_on[q]) *reinterpret_cast<u32x4*>(strip + pc + 1024u * q) = r.sc[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) if (v_on[q]) *reinterpret_cast<u32x4*>(strip + off_val + pc + 1024u * q) = r.va[q];
+#pragma unroll
+    for (int gi = 0; gi < NG; gi++) if (g_on[gi]) *reinterpret_cast<u32x4*>(strip + (gi == 0 ? off_g0 : off_g1) + pc) = r.g[gi];
+  };
+  uint32_t post[8], tail = 0;
+  auto issue_post = [&](int k) __attribute__((always_inline)) {
+    const int wt = tile_of(k);
+    if (HAS_INDEX) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) post[j] = ldnt((const GAS uint32_t*)(sd_sgpr_ptr<uint8_t>(p.dense_ptr[j] + (size_t)wt * 256u) + (uint32_t)lane * 4u));
+    }
+    if (HAS_TAIL) tail = ldnt((const GAS uint32_t*)(sd_sgpr_ptr<uint8_t>(p.pipe_tail + (size_t)wt * 256u) + (uint32_t)lane * 4u));
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // the index program over this lane's 32 docs of tile k (linear layout); counts the scan's candidates
+  auto tile_candidates = [&](int k) __attribute__((always_inline)) -> uint32_t {
+    const int wt = first + k * step;
+    const int64_t rem = (int64_t)p.num_docs - (int64_t)wt * PG_WAVE_DOCS;
+    const int32_t n_valid = rem >= PG_WAVE_DOCS ? PG_WAVE_DOCS : (rem > 0 ? (int32_t)rem : 0);
+    uint32_t lin = valid_lin_mask(n_valid, lane);
+    if (HAS_INDEX) {
+      uint32_t grp[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const int gj = p.dense_group[j];
+#pragma unroll
+        for (int q = 0; q < 4; q++) grp[q] |= gj == q ? post[j] : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (q < p.dense_groups) lin &= ((p.dense_excl >> q) & 1) ? ~grp[q] : grp[q];
+    }
+    my_cand += (uint32_t)__popc(lin);   // the scan leaf's candidates (numEntriesScannedInFilter)
+    return HAS_TAIL ? lin & tail : lin;
+  };
+
+  // ---- filter and aggregation of the sub-tile in the strip --------------------------------------------------------------------------------
+  // one field of a column's bytes in the strip: doc `doc` of the sub-tile, width <= 24 (or 32: raw INT)
+  auto field_at = [&](const uint8_t* col, uint32_t doc, uint32_t bits) __attribute__((always_inline)) -> uint32_t {
+    const uint32_t P = mul24(doc, bits);
+    const u32x2 w = *reinterpret_cast<const u32x2_a4*>(col + ((P >> 5) << 2));
+    const uint32_t s8 = (P >> 3) & 3u;   // the field's first byte inside the pair
+    const uint32_t be = perm(w.y, w.x, perm(s8, s8, 0u) + 0x00010203u);   // (oct_selector(s8): s8 in every byte + 0, 1, 2, 3 — a 24-bit multiply would cut the constant)
+    return bits >= 32u ? be : bfe(be, 32u - (P & 7u) - bits, bits);
+  };
+  auto value_of = [&](uint32_t id) __attribute__((always_inline)) -> int32_t {
+    if (VK == SD_V_RAW32) return (int32_t)id;
+    if (VK == SD_V_AFFINE) return (int32_t)mad24(id, vstep, vbase);   // dictId, step < 2^24 (planner); the sum wraps to the int value
+    return vdict[id];
+  };
+  auto apply = [&](uint32_t slot, int32_t v) __attribute__((always_inline)) {
+    for (int o = 0; o < n_ops; o++) {
+      const uint32_t code = (uint32_t)(ops_code >> (2 * o)) & 3u;   // 0 COUNT, 1 SUM, 2 MIN, 3 MAX
+      int64_t* base = lds_table + (size_t)o * stride;
+      if (code == 0u) atomicAdd(reinterpret_cast<unsigned long long*>(base + slot), 1ULL);
+      else if (code == 1u) atomicAdd(reinterpret_cast<unsigned long long*>(base + slot), (unsigned long long)(int64_t)v);
+      else if (code == 2u) atomicMin(reinterpret_cast<long long*>(base + slot), (long long)v);
+      else atomicMax(reinterpret_cast<long long*>(base + slot), (long long)v);
+    }
+  };
+  SdPend pend;
+  pend.n = 0;
+  auto flush_pending = [&]() __attribute__((always_inline)) {   // SD_V_GATHER: the look-ups of the previous sub-tile's first rounds have travelled since
+#pragma unroll
+    for (int r = 0; r < SD_PEND; r++)
+      if (r < pend.n) apply(pend.slot[r], pend.v[r]);
+    pend.n = 0;
+  };
+  auto consume = [&](int k, int sub, uint32_t lin) __attribute__((always_inline)) {
+    // candidates of this lane's 8 docs: byte (lane & 3) of linear dword 16 sub + (lane >> 2) (docs past the segment: none)
+    const uint32_t cd = (uint32_t)__builtin_amdgcn_ds_bpermute((sub * 16 + (lane >> 2)) * 4, (int)lin);
+    uint32_t m = (cd >> lin_sh) & 0xFFu;
+    if (HAS_SCAN) {
+      uint32_t rm = 0;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const u32x2 w = *reinterpret_cast<const u32x2_a4*>(strip + sc_at[j]);
+        const uint32_t id = (perm(w.y, w.x, sc_sel[j]) >> sc_sh[j]) & sc_mask;
+        rm |= (uint32_t)in_range_i32(r32, (int32_t)id) << j;
+      }
+      m &= r32.empty ? 0u : rm;
+    }
+    my_matched += (uint32_t)__popc(m);
+    if (has_out_words) {   // the tile's match words, linear layout: lanes 4 g .. 4 g + 3 hold the bytes of dword 16 sub + g
+      const int wt = first + k * step;
+      const uint32_t word = or_reduce4(m << lin_sh);
+      if ((lane & 3) == 0) reinterpret_cast<uint32_t*>(p.out_words)[(int64_t)wt * 64 + (int64_t)(sub * 16 + (lane >> 2))] = word;
+    }
+#ifdef PG_SD_NO_TABLE   // measurement variant (wrong results): the filter alone
+    return;
+#endif
+    // ranks in position-major order (any order serves: the accumulators commute)
+    uint32_t total = 0;
+    uint32_t rank[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint64_t b = __builtin_amdgcn_ballot_w64(((m >> j) & 1u) != 0u);
+      rank[j] = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+      total += (uint32_t)__builtin_popcountll(b);
+    }
+    total = (uint32_t)uniform((int)total);
+    if (VK == SD_V_GATHER) flush_pending();
+    if (total == 0u) return;
+    const bool all = total == OCT_SUB_DOCS;   // wave-uniform: no list needed (entry i = doc i)
+    if (!all) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) my_list[((m >> j) & 1u) ? rank[j] : list_dummy] = (uint16_t)((uint32_t)lane * 8u + (uint32_t)j);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (a wavefront's LDS operations execute in order: the reads below see the writes above)
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    int round = 0;
+    for (uint32_t at = 0; at < total; at += 64u, round++) {
+      const uint32_t idx = at + (uint32_t)lane;
+      const bool live = idx < total;
+      const uint32_t doc = all ? idx : (live ? (uint32_t)my_list[idx] : 0u);
+      const uint32_t vid = field_at(strip + off_val, doc, vbits);
+      uint32_t slot = rep;
+#pragma unroll
+      for (int gi = 0; gi < NG; gi++) slot = mad24(field_at(strip + (gi == 0 ? off_g0 : off_g1), doc, gbits[gi]), gmul[gi], slot);   // < 65536 slots (planner)
+      slot = live ? slot : trash_slot;
+      const int32_t v = value_of(live ? vid : 0u);
+      if (VK == SD_V_GATHER && round < SD_PEND) {   // applied one sub-tile later (no run-time index into the registers)
+#pragma unroll
+        for (int r = 0; r < SD_PEND; r++)
+          if (round == r) { pend.slot[r] = slot; pend.v[r] = v; }
+        pend.n = round + 1;
+      } else {
+        apply(slot, v);
+      }
+    }
+  };
+
+  // ---- main loop: one tile per iteration, sub-tiles 0 .. 3 through two register sets; sub-tile (k, s + 2) is requested where (k, s) is stored ----
+  if (n_mine > 0) {
+    SdSub<NG> ra, rb;
+    issue_post(0);
+    issue_sub(0, 0, ra);
+    issue_sub(0, 1, rb);
+    for (int k = 0; k < n_mine; k++) {
+      const uint32_t lin = tile_candidates(k);   // (waits for tile k's posting dwords only: the sub-tiles behind them stay in flight)
+      issue_post(k + 1);
+      store_sub(ra); issue_sub(k, 2, ra); consume(k, 0, lin);
+      store_sub(rb); issue_sub(k, 3, rb); consume(k, 1, lin);
+      store_sub(ra); issue_sub(k + 1, 0, ra); consume(k, 2, lin);
+      store_sub(rb); issue_sub(k + 1, 1, rb); consume(k, 3, lin);
+    }
+    if (VK == SD_V_GATHER) flush_pending();
+  }
+  {
+    const uint32_t wsum = wave_sum_u32(my_matched), csum = wave_sum_u32(my_cand);
+    if (lane == 0 && wsum) atomicAdd(&s_stat[0], wsum);
+    if (HAS_SCAN && !p.fast_scan_pushed && lane == 0 && csum) atomicAdd(&s_stat[L.stat_slot], csum);   // (a pushed scan covers the segment: the host adds numDocs)
+  }
+  __syncthreads();
+  // statistics and this workgroup's partial table [n_ops][n_groups], replicas folded
+  if (t < PG_MAX_STATS && s_stat[t]) atomicAdd(&p.stats[t], (unsigned long long)s_stat[t]);
+  {
+    const int Rr = p.replicas, groups = p.n_groups;
+    int64_t* out = p.partials + (int64_t)blockIdx.x * ((int64_t)p.n_ops * groups);
+    for (int o = 0; o < p.n_ops; o++) {
+      const int fn = p.ops[uniform(o)].fn;   // integer accumulators only (planner)
+      for (int gq = t; gq < groups; gq += PG_BLOCK) {
+        const int64_t* src = lds_table + (size_t)o * table_slots + (size_t)gq * Rr;
+        int64_t acc = src[0];
+        if (fn == PG_ACC_COUNT || fn == PG_ACC_SUM) { for (int r = 1; r < Rr; r++) acc += src[r]; }
+        else if (fn == PG_ACC_MIN) { for (int r = 1; r < Rr; r++) acc = src[r] < acc ? src[r] : acc; }
+        else { for (int r = 1; r < Rr; r++) acc = src[r] > acc ? src[r] : acc; }
+        out[(size_t)o * groups + gq] = acc;
+      }
+    }
+  }
+}
+
+// one kernel per filter shape and value kind; the group-column count is a wave-uniform branch between two bodies
+#define PG_SPECD_KERNEL(NAME, IDX, SCAN, TAIL, VK) \
+  extern "C" __global__ void __launch_bounds__(PG_BLOCK) NAME(const PgQueryPlan p) { \
+    if (p.n_group_cols == 1) specd_body<1, IDX, SCAN, TAIL, VK>(p); \
+    else specd_body<2, IDX, SCAN, TAIL, VK>(p); \
+  }
+#define PG_SPECD_FAMILY(SUFFIX, VK) \
+  PG_SPECD_KERNEL(pg_fast_dictrange_s##SUFFIX, true, true, false, VK)     /* the headline shape: dense index program AND range scan */ \
+  PG_SPECD_KERNEL(pg_fast_dictrange_st##SUFFIX, true, true, true, VK)     /* ... behind an upsert snapshot */ \
+  PG_SPECD_KERNEL(pg_specd_none##SUFFIX, false, false, false, VK)         /* no filter */ \
+  PG_SPECD_KERNEL(pg_specd_scan##SUFFIX, false, true, false, VK)          /* the range scan is the whole filter */ \
+  PG_SPECD_KERNEL(pg_specd_index##SUFFIX, true, false, false, VK)         /* inverted-index leaves only */
+PG_SPECD_FAMILY(_r, SD_V_RAW32)    // value column raw INT (the scan column is dictionary-encoded)
+PG_SPECD_FAMILY(_a, SD_V_AFFINE)   // value = base + step x dictId
+PG_SPECD_FAMILY(_g, SD_V_GATHER)   // value = dictionary[dictId]
+#undef PG_SPECD_FAMILY
+#undef PG_SPECD_KERNEL

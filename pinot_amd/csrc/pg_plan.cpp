@@ -2122,6 +2122,92 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
       D.pipe_vscan = -1;
     }
   }
+  // pg_fast_dictrange_s family (pg_kernels_specd.hip, round 6): the same shapes — [dense index program] [AND one range scan] [AND the upsert
+  // snapshot], one or two <= 8-bit group columns, integer accumulators over ONE INT column — where the scan column and / or the value column is
+  // dictionary-encoded (Pinot's default, DictionaryIndexConfig.java:32): the range is a dictId interval over the fixed-bit stream
+  // (RangePredicateEvaluatorFactory.java:126-167), the value dictionary.get(dictId) (DataFetcher.java:335-386) — computed for an arithmetic
+  // dictionary, gathered from the native-endian copy otherwise.  Raw scan AND raw value stay with pg_fast_i32range_* / pg_pipe_*.
+  D.specd = 0;
+  if (!D.pipe_fit && !D.pipe_general && P.fast_agg && D.agg_mode == PG_AGG_LDS && D.n_group_cols >= 1 && D.n_group_cols <= 2 && !knobs().no_specd) {
+    bool ok = true;
+    int src = -1;
+    for (int o = 0; o < D.n_ops && ok; o++) {
+      if (D.ops[o].src < 0) continue;
+      if (D.ops[o].is_float != PG_ACCV_INT) ok = false;
+      if (src >= 0 && D.ops[o].src != src) ok = false;
+      src = D.ops[o].src;
+    }
+    ok = ok && src >= 0;
+    for (int g = 0; g < D.n_group_cols && ok; g++) ok = D.gcols[g].col_kind == PG_COL_FIXED_BIT && D.gcols[g].bits >= 1 && D.gcols[g].bits <= 8 && D.mv_gcol_offsets[g] == nullptr;
+    int vkind = 0, vbits = 0;
+    int64_t vbase = 0, vstep = 0;
+    if (ok) {
+      const Column* c = srcs[(size_t)src];
+      if (D.mv_src_offsets[src] != nullptr || D.mv_src_len[src]) ok = false;
+      else if (D.srcs[src].col_kind == PG_COL_RAW32 && c->val_type == PG_V_I32) { vkind = 1; vbits = 32; }
+      else if (D.srcs[src].col_kind == PG_COL_FIXED_BIT && c->has_dictionary && c->data_type == PG_TYPE_INT && c->bits >= 1 && c->bits <= 24) {
+        vbits = c->bits;
+        if (c->dict_affine && c->dict_step > 0 && c->dict_step < ((int64_t)1 << 24) && !knobs().specd_no_affine) { vkind = 2; vbase = c->dict_base; vstep = c->dict_step; }
+        else if (D.srcs[src].dict != nullptr) vkind = 3;
+        else ok = false;
+      } else ok = false;
+    }
+    const int32_t n_chunks = (int32_t)(((int64_t)seg.total_docs + PG_CHUNK_DOCS - 1) / PG_CHUNK_DOCS);
+    const bool index_ok = D.n_index_instr == 0 || D.dense_fused;
+    bool has_scan = false, has_tail = false;
+    int scan_leaf = -1, sbits = 0;
+    const uint8_t* tail = nullptr;
+    if (!ok) {
+    } else if (P.fast_filter == -1) {
+      ok = index_ok;
+    } else if ((P.fast_filter == 0 || P.fast_filter == 4 || (P.fast_filter == 100 && D.n_fast_scans == 1)) && (size_t)D.n_index_instr < em.instrs.size()) {
+      scan_leaf = em.instrs[(size_t)D.n_index_instr].arg;
+      const PgScanLeaf& SL = em.scans[(size_t)scan_leaf];
+      has_scan = true;
+      ok = index_ok && SL.pred_kind == PG_P_RANGE && !SL.mv &&
+           ((SL.col_kind == PG_COL_RAW32 && SL.val_type == PG_V_I32) || (SL.col_kind == PG_COL_FIXED_BIT && SL.bits >= 1 && SL.bits <= 24));
+      sbits = SL.col_kind == PG_COL_RAW32 ? 32 : SL.bits;
+      if (ok && P.fast_filter == 100 && D.tail_posting >= 0) {   // the upsert snapshot behind index AND scan
+        const PgPostingLeaf& TL = em.postings[(size_t)D.tail_posting];
+        has_tail = true;
+        ok = D.n_index_instr > 0 && !TL.has_csr && TL.n_dense == 1 && TL.dense_chunks >= n_chunks && !TL.exclusive;
+        tail = TL.dense[0];
+      }
+    } else {
+      ok = false;
+    }
+    if (ok && vkind == 1 && (!has_scan || sbits == 32)) ok = false;   // raw scan and raw value: the kernels of rounds 2-5
+    // table + a trash slot per lane and accumulator + one strip per wavefront (the sub-tile's column bytes + the selection list) inside the
+    // dynamic-LDS limit (device_init asks for 160 KB - 8 KB): fewer replicas where the default table would not leave room (the list walk keeps
+    // every lane on a replica of its own down to R = 64; below, lanes share)
+    if (ok) {
+      auto region = [](int bits) { return bits > 0 ? (size_t)((bits * 64 + 16 + 15) & ~15) : (size_t)0; };
+      const size_t strip = (has_scan ? region(sbits) : 0) + region(vbits) + region(D.gcols[0].bits) + (D.n_group_cols > 1 ? region(D.gcols[1].bits) : 0) + (512 + 64) * 2;
+      const size_t fixed = 256 + 16 * strip + 16 + 512 * (size_t)D.n_ops;
+      const size_t limit = (size_t)160 * 1024 - 8192;
+      const size_t per_replica = (size_t)G * (size_t)D.n_ops * 8;
+      while (D.replicas > 1 && per_replica * (size_t)D.replicas + fixed > limit) {
+        D.replicas /= 2;
+        P.lds_bytes -= per_replica * (size_t)D.replicas;
+      }
+      D.replica_shift = 0;
+      while ((1 << D.replica_shift) < D.replicas) D.replica_shift++;
+      if (P.lds_bytes + fixed > limit) ok = false;
+    }
+    if (ok) {
+      D.specd = 1;
+      D.specd_vkind = vkind;
+      D.specd_sbits = has_scan ? sbits : 0;
+      D.specd_vbits = vbits;
+      D.specd_base = (int32_t)vbase;
+      D.specd_step = (int32_t)vstep;
+      D.pipe_src = src;
+      D.pipe_has_index = D.n_index_instr > 0 ? 1 : 0;
+      D.pipe_has_scan = has_scan ? 1 : 0;
+      D.pipe_tail = has_tail ? tail : nullptr;
+      if (has_scan) D.fast_scan = scan_leaf;
+    }
+  }
   // LDS tables that miss the narrow shape only by column width (group columns > 8 bits, LONG / DOUBLE sources, 64-bit
   // dictionaries) keep the 1024-thread kernels and run the general aggregator there (pg_fast_none_w / pg_fast_multi_w)
   P.wide_agg = !P.fast_agg && (D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE) && D.n_aux == 0 && P.first_doc_op < 0;
@@ -2184,6 +2270,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     D.pipe_fit = 0;
     D.pipe_general = 0;
     D.pipe_wide = 0;
+    D.specd = 0;
     D.dense_fused = 0;
     D.tile_split_shift = 0;
   }

@@ -27,11 +27,14 @@ class SynthColumn:
     kind: str            # "dict" (fixed-bit dictIds, INT identity dictionary) or "raw" (INT, PASS_THROUGH chunks)
     range: int           # cardinality for dict columns, exclusive upper bound of values for raw columns
     inverted: bool = False
+    like: str = ""       # non-empty: the column repeats that column's values doc for doc (its dictionary-encoded twin)
+    dictionary: str = "identity"   # "identity": value = dictId (what the segment creator builds when every value of [0, range) occurs);
+                                   # "sparse": a sorted INT dictionary that is NOT arithmetic (sparse_dictionary below): values are gathered
 
     @property
     def salt(self) -> int:
         h = 1469598103934665603
-        for ch in self.name.encode():
+        for ch in (self.like or self.name).encode():
             h = ((h ^ ch) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
         return h
 
@@ -48,6 +51,13 @@ GPU_BENCH_COLUMNS: List[SynthColumn] = [
     SynthColumn("h3", "dict", 10),
     SynthColumn("h4", "dict", 8),
     SynthColumn("u", "dict", 1_000_000),
+    # config 3 in Pinot's DEFAULT encoding (DictionaryIndexConfig.java:32: every column has a dictionary unless the table config says otherwise):
+    # the same docs as r_int / m, as 20-bit dictId streams.  With every value of the range present the sorted dictionary is [0, range).
+    SynthColumn("r_int_d", "dict", 1_000_000, like="r_int"),
+    SynthColumn("m_d", "dict", 1 << 20, like="m"),
+    # ... and with dictionaries that are not arithmetic progressions: the range is a dictId interval found by binary search, SUM / MAX gather
+    SynthColumn("r_int_s", "dict", 1_000_000, like="r_int", dictionary="sparse"),
+    SynthColumn("m_s", "dict", 1 << 20, like="m", dictionary="sparse"),
 ]
 GPU_BENCH = {c.name: c for c in GPU_BENCH_COLUMNS}
 
@@ -59,6 +69,14 @@ QUERY_NORTH_STAR = ("SELECT g1, g2, SUM(m) FROM gpuBench WHERE c_inv1 IN (0,1,2,
                     "AND r_int BETWEEN 250000 AND 749999 GROUP BY g1, g2 ORDER BY g1, g2 LIMIT 10000")
 QUERY_CFG5 = ("SELECT h1, h2, h3, h4, COUNT(*), DISTINCTCOUNTHLL(u) FROM gpuBench GROUP BY h1, h2, h3, h4 LIMIT 20000")
 CFG3_COLUMNS = ["c_inv1", "c_inv2", "r_int", "g1", "g2", "m"]
+# config 3 / north-star over the dictionary-encoded twins (identity dictionaries: the rows equal QUERY_CFG3's / QUERY_NORTH_STAR's)
+QUERY_CFG3_DICT = QUERY_CFG3.replace("r_int", "r_int_d").replace("(m)", "(m_d)")
+QUERY_NORTH_STAR_DICT = QUERY_NORTH_STAR.replace("r_int", "r_int_d").replace("(m)", "(m_d)")
+# ... and over the sparse dictionaries: value = sparse_dictionary(card)[dictId] ~ 3 x dictId, so the same dictId interval is [750000, 2249999]
+QUERY_CFG3_SPARSE = ("SELECT g1, SUM(m_s), MAX(m_s) FROM gpuBench WHERE c_inv1 IN (0,1,2,3) AND c_inv2 IN (0,1) "
+                     "AND r_int_s BETWEEN 750000 AND 2249999 GROUP BY g1 ORDER BY g1 LIMIT 1000")
+CFG3_DICT_COLUMNS = ["c_inv1", "c_inv2", "r_int_d", "g1", "g2", "m_d"]
+CFG3_SPARSE_COLUMNS = ["c_inv1", "c_inv2", "r_int_s", "g1", "g2", "m_s"]
 CFG5_COLUMNS = ["h1", "h2", "h3", "h4", "u"]
 
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
@@ -107,8 +125,23 @@ def synth_lib():
     return _lib
 
 
+def sparse_dictionary(card: int) -> np.ndarray:
+    """A sorted INT dictionary that is no arithmetic progression: 3 x dictId + one pseudo-random bit."""
+    ids = np.arange(card, dtype=np.uint64)
+    return (3 * ids + (((ids * np.uint64(0x9E3779B1)) >> np.uint64(31)) & np.uint64(1))).astype(np.int32)
+
+
+def _dictionary_values(col: SynthColumn) -> np.ndarray:
+    return sparse_dictionary(col.range) if col.dictionary == "sparse" else np.arange(col.range, dtype=np.int32)
+
+
 def _identity_dictionary(card: int) -> np.ndarray:
     return formats.write_numeric_dictionary(np.arange(card, dtype=np.int32), "INT")
+
+
+def _dictionary(col: SynthColumn):
+    values = _dictionary_values(col)
+    return formats.write_numeric_dictionary(values, "INT"), (list(range(col.range)) if col.dictionary == "identity" else values.tolist())
 
 
 def _column_numpy(col: SynthColumn, seed: int, n: int, raw_version: int) -> HostColumn:
@@ -119,8 +152,8 @@ def _column_numpy(col: SynthColumn, seed: int, n: int, raw_version: int) -> Host
     bits = formats.num_bits_per_value(col.range - 1)
     fwd = formats.pack_fixed_bit(vals, bits)
     inv = formats.write_inverted_index(vals, col.range) if col.inverted else None
-    return HostColumn(col.name, "INT", capi.FWD_DICT_FIXED_BIT, True, col.range, bits, False, 4, fwd,
-                      _identity_dictionary(col.range), inv, list(range(col.range)))
+    dict_bytes, dict_values = _dictionary(col)
+    return HostColumn(col.name, "INT", capi.FWD_DICT_FIXED_BIT, True, col.range, bits, False, 4, fwd, dict_bytes, inv, dict_values)
 
 
 def _column_native(lib, col: SynthColumn, seed: int, n: int, raw_version: int, threads: int) -> HostColumn:
@@ -139,8 +172,8 @@ def _column_native(lib, col: SynthColumn, seed: int, n: int, raw_version: int, t
         inv = np.empty(total.value, dtype=np.uint8)
         lib.pgs_inverted_fill(h, inv.ctypes.data)
         lib.pgs_inverted_end(h)
-    return HostColumn(col.name, "INT", capi.FWD_DICT_FIXED_BIT, True, col.range, bits, False, 4, fwd,
-                      _identity_dictionary(col.range), inv, list(range(col.range)))
+    dict_bytes, dict_values = _dictionary(col)
+    return HostColumn(col.name, "INT", capi.FWD_DICT_FIXED_BIT, True, col.range, bits, False, 4, fwd, dict_bytes, inv, dict_values)
 
 
 def generate_doc_range(first_doc: int, num_docs: int, segment_index: int = 0, columns: Optional[Iterable[str]] = None, threads: int = 0,
@@ -158,8 +191,8 @@ def generate_doc_range(first_doc: int, num_docs: int, segment_index: int = 0, co
             lib.pgs_fill_fixed_bit_from(fwd.ctypes.data, first_doc, num_docs, bits, seed, col.salt, col.range, threads if threads > 0 else lib.pgs_default_threads())
         else:
             fwd = formats.pack_fixed_bit(values_numpy(col, seed, num_docs, start=first_doc), bits)
-        seg.columns[col.name] = HostColumn(col.name, "INT", capi.FWD_DICT_FIXED_BIT, True, col.range, bits, False, 4, fwd,
-                                           _identity_dictionary(col.range), None, list(range(col.range)))
+        dict_bytes, dict_values = _dictionary(col)
+        seg.columns[col.name] = HostColumn(col.name, "INT", capi.FWD_DICT_FIXED_BIT, True, col.range, bits, False, 4, fwd, dict_bytes, None, dict_values)
     return seg
 
 

@@ -1,0 +1,115 @@
+"""Config 3 in Pinot's DEFAULT encoding: the scan column and the value column are
+dictionary-encoded — fixed-bit dictId streams (FixedBitSVForwardIndexReaderV2.java:65-99), the range predicate is a dictId interval
+(RangePredicateEvaluatorFactory.java:126-167), SUM / MIN / MAX read dictionary.get(dictId) (DataFetcher.java:335-386).  The pg_fast_dictrange_s
+family (pg_kernels_specd.hip) runs these plans: _a computes the value of an arithmetic dictionary, _g gathers it, _r reads a raw value column
+next to a dictionary-encoded scan column.  Results and ExecutionStatistics equal the oracle's at the four sizes of
+test_wave_specialised_variant_matches_oracle (fewer tiles than workgroups, odd and even stage counts, a ragged last tile), and the rows over
+the identity dictionaries equal the rows of the raw-column query over the same docs."""
+import os
+
+import numpy as np
+import pytest
+
+from pinot_amd import capi, synth
+from pinot_amd.executor import NativeSegment
+from pinot_amd.query import parse_sql
+
+pytestmark = pytest.mark.gpu
+
+COLUMNS = ["c_inv1", "c_inv2", "r_int", "g1", "g2", "m", "r_int_d", "m_d", "r_int_s", "m_s"]
+knobs_off = not (os.environ.get("PG_NO_SPECD") or os.environ.get("PG_SPECD_NO_AFFINE") or os.environ.get("PG_NO_DENSE_FUSED") or os.environ.get("PG_FORCE_INTERPRETER"))
+IDX = "c_inv1 IN (0,1,2,3) AND c_inv2 IN (0,1)"
+
+QUERIES = [
+    (synth.QUERY_CFG3_DICT, "pg_fast_dictrange_s_a"),
+    (synth.QUERY_NORTH_STAR_DICT, "pg_fast_dictrange_s_a"),
+    (synth.QUERY_CFG3_SPARSE, "pg_fast_dictrange_s_g"),
+    (f"SELECT g2, COUNT(*), MIN(m_s), MAX(m_s), SUM(m_s) FROM gpuBench WHERE {IDX} AND r_int_s BETWEEN 750000 AND 2249999 "
+     "GROUP BY g2 ORDER BY g2 LIMIT 10000", "pg_fast_dictrange_s_g"),
+    (f"SELECT g1, g2, COUNT(*), SUM(m_s) FROM gpuBench WHERE {IDX} AND r_int_s BETWEEN 750000 AND 2249999 "
+     "GROUP BY g1, g2 ORDER BY g1, g2 LIMIT 10000", "pg_fast_dictrange_s_g"),
+    # one side raw, the other dictionary-encoded
+    (f"SELECT g1, SUM(m_d), MAX(m_d) FROM gpuBench WHERE {IDX} AND r_int BETWEEN 250000 AND 749999 GROUP BY g1 ORDER BY g1 LIMIT 1000", "pg_fast_dictrange_s_a"),
+    (f"SELECT g1, SUM(m), MIN(m) FROM gpuBench WHERE {IDX} AND r_int_d BETWEEN 250000 AND 749999 GROUP BY g1 ORDER BY g1 LIMIT 1000", "pg_fast_dictrange_s_r"),
+    (f"SELECT g2, g1, COUNT(*), SUM(m_d) FROM gpuBench WHERE {IDX} AND r_int_s > 1000000 GROUP BY g2, g1 ORDER BY g2, g1 LIMIT 10000", "pg_fast_dictrange_s_a"),
+    # complemented posting groups, an equality (a one-dictId interval), ranges open at one end, a value outside the dictionary
+    ("SELECT g1, COUNT(*), MIN(m_d), MAX(m_d), SUM(m_d) FROM gpuBench WHERE c_inv1 NOT IN (0, 7) AND c_inv2 = 1 AND r_int_d BETWEEN 100 AND 900000 "
+     "GROUP BY g1 ORDER BY g1 LIMIT 1000", "pg_fast_dictrange_s_a"),
+    ("SELECT g1, SUM(m_s) FROM gpuBench WHERE c_inv1 IN (1, 2, 3, 4, 5) AND r_int_d < 10 GROUP BY g1 ORDER BY g1 LIMIT 1000", "pg_fast_dictrange_s_g"),
+    ("SELECT g1, SUM(m_d), COUNT(*) FROM gpuBench WHERE c_inv2 IN (0, 1, 2) AND r_int_d = 4711 GROUP BY g1 ORDER BY g1 LIMIT 1000", "pg_fast_dictrange_s_a"),
+    ("SELECT g1, SUM(m_d) FROM gpuBench WHERE c_inv2 IN (0, 1, 2) AND r_int_s = 14135 GROUP BY g1 ORDER BY g1 LIMIT 1000", None),   # 14135 may be no dictionary value
+    ("SELECT g1, MAX(m_s) FROM gpuBench WHERE c_inv2 IN (0, 1, 2) AND r_int_d >= 999990 GROUP BY g1 ORDER BY g1 LIMIT 1000", "pg_fast_dictrange_s_g"),
+    ("SELECT g1, SUM(m_d) FROM gpuBench WHERE c_inv2 IN (0, 1, 2) AND r_int_d BETWEEN 2000000 AND 3000000 GROUP BY g1 LIMIT 1000", None),   # empty interval
+    # the family's other filter shapes: a lone range scan, inverted-index leaves only, no filter
+    ("SELECT g1, g2, SUM(m_d) FROM gpuBench WHERE r_int_d BETWEEN 250000 AND 749999 GROUP BY g1, g2 ORDER BY g1, g2 LIMIT 10000", "pg_specd_scan_a"),
+    ("SELECT g1, SUM(m_s), COUNT(*) FROM gpuBench WHERE r_int_s < 21 GROUP BY g1 ORDER BY g1 LIMIT 1000", "pg_specd_scan_g"),
+    ("SELECT g1, SUM(m), COUNT(*) FROM gpuBench WHERE r_int_d > 500000 GROUP BY g1 ORDER BY g1 LIMIT 1000", "pg_specd_scan_r"),
+    ("SELECT g1, SUM(m_d), MAX(m_d) FROM gpuBench WHERE r_int BETWEEN 250000 AND 749999 GROUP BY g1 ORDER BY g1 LIMIT 1000", "pg_specd_scan_a"),
+    (f"SELECT g1, SUM(m_d) FROM gpuBench WHERE {IDX} GROUP BY g1 ORDER BY g1 LIMIT 1000", "pg_specd_index_a"),
+    ("SELECT g2, g1, MAX(m_s), COUNT(*) FROM gpuBench WHERE c_inv1 NOT IN (3, 4) GROUP BY g2, g1 ORDER BY g2, g1 LIMIT 10000", "pg_specd_index_g"),
+    ("SELECT g1, SUM(m_d), MAX(m_d) FROM gpuBench GROUP BY g1 ORDER BY g1 LIMIT 1000", "pg_specd_none_a"),
+    ("SELECT g1, g2, COUNT(*), MIN(m_s) FROM gpuBench GROUP BY g1, g2 ORDER BY g1, g2 LIMIT 10000", "pg_specd_none_g"),
+    # a scan over a <= 8-bit dictionary column in front of a dictionary-encoded value
+    ("SELECT g1, SUM(m_d) FROM gpuBench WHERE g2 BETWEEN 10 AND 30 GROUP BY g1 ORDER BY g1 LIMIT 1000", "pg_specd_scan_a"),
+]
+STATS = ("num_docs_scanned", "num_entries_scanned_in_filter", "num_entries_scanned_post_filter", "num_total_docs")
+
+
+@pytest.fixture(scope="module", params=[1, 2049, 70_001, 700_001, 9_030_011])
+def pair(request, gpu_api, oracle_api):
+    host = synth.generate_segment(request.param, segment_index=3, columns=COLUMNS)
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    yield g, o
+    g.destroy()
+    o.destroy()
+
+
+@pytest.mark.parametrize("sql,kernel", QUERIES)
+def test_dictionary_encoded_headline_matches_oracle(pair, sql, kernel):
+    g, o = pair
+    qc = parse_sql(sql)
+    qc.flags |= capi.QUERY_FLAG_EXACT_FILTER_STATS
+    gb, ob = g.execute(qc), o.execute(sql)
+    assert gb.rows() == ob.rows()
+    for f in STATS:
+        assert getattr(gb.stats, f) == getattr(ob.stats, f), f
+    if kernel and knobs_off and gb.stats.num_total_docs >= 700_001:   # small segments keep sparse (CSR) postings: the interpreted leaves
+        assert gb.stats.kernel.decode() == kernel
+    gb2 = g.execute(qc)   # the plan's second execution (cached plan, observed rates): the same kernel, the same answer
+    assert gb2.rows() == ob.rows()
+    if kernel and knobs_off and gb.stats.num_total_docs >= 700_001:
+        assert gb2.stats.kernel.decode() == kernel
+
+
+def test_identity_dictionaries_give_the_raw_columns_rows(pair):
+    """r_int_d / m_d hold the docs of r_int / m: the dictionary-encoded query returns the raw query's rows (and statistics)."""
+    g, _ = pair
+    for raw, enc in ((synth.QUERY_CFG3, synth.QUERY_CFG3_DICT), (synth.QUERY_NORTH_STAR, synth.QUERY_NORTH_STAR_DICT)):
+        a, b = g.execute(raw), g.execute(enc)
+        assert a.rows() == b.rows()
+        for f in STATS:
+            assert getattr(a.stats, f) == getattr(b.stats, f), f
+
+
+@pytest.mark.parametrize("n", [2049, 700_001, 3_000_017])
+def test_dictionary_encoded_headline_behind_an_upsert_snapshot(gpu_api, oracle_api, n):
+    """FilterPlanNode.run's outer AND with queryableDocIds: the snapshot is ANDed in after the scan's candidates have been counted."""
+    host = synth.generate_segment(n, segment_index=5, columns=COLUMNS)
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    rng = np.random.default_rng(n)
+    for keep in (0.9, 0.5, 0.02):
+        ids = np.flatnonzero(rng.random(n) < keep)
+        g.set_queryable_doc_ids(ids)
+        o.set_queryable_doc_ids(ids)
+        for sql, kernel in ((synth.QUERY_CFG3_DICT, "pg_fast_dictrange_st_a"), (synth.QUERY_CFG3_SPARSE, "pg_fast_dictrange_st_g"),
+                            (synth.QUERY_NORTH_STAR_DICT, "pg_fast_dictrange_st_a"),
+                            ("SELECT g1, SUM(m_d) FROM gpuBench WHERE r_int_d BETWEEN 250000 AND 749999 GROUP BY g1 LIMIT 1000", None),
+                            ("SELECT g1, SUM(m_s), MAX(m_s) FROM gpuBench GROUP BY g1 LIMIT 1000", None)):
+            gb, ob = g.execute(sql), o.execute(sql)
+            assert gb.rows() == ob.rows(), (sql, keep)
+            for f in STATS:
+                assert getattr(gb.stats, f) == getattr(ob.stats, f), (f, sql, keep)
+            if kernel and knobs_off and n >= 65536 and keep >= 0.5:   # dense snapshots are bitmap containers: the arithmetic (dense) form
+                assert gb.stats.kernel.decode() == kernel, (sql, keep)
+    g.destroy()
+    o.destroy()

@@ -16,12 +16,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--docs", type=int, default=200_000_000)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--only", default="", help="substring of the query names to run (a leading '=' asks for the exact name)")
-ap.add_argument("--set", choices=["cfg3", "cfg5", "general", "wide", "upsert", "postings", "mv", "strings"], default="cfg3")
+ap.add_argument("--set", choices=["cfg3", "cfg5", "general", "wide", "upsert", "postings", "mv", "strings", "dict"], default="cfg3")
 args = ap.parse_args()
 api = capi.gpu_api()
 api.call("init", 0)
 seg = NativeSegment(api, HostSegment("prof", args.docs))
-for name in (synth.CFG5_COLUMNS if args.set == "cfg5" else synth.CFG3_COLUMNS):
+DICT_COLUMNS = synth.CFG3_COLUMNS + ["r_int_d", "m_d", "r_int_s", "m_s"]   # --set dict: config 3's columns + their dictionary-encoded twins
+for name in (synth.CFG5_COLUMNS if args.set == "cfg5" else (DICT_COLUMNS if args.set == "dict" else synth.CFG3_COLUMNS)):
     one = synth.generate_segment(args.docs, columns=[name])
     seg.add_column(one.columns[name], keep_host_buffers=False)
 
@@ -159,6 +160,27 @@ QUERIES_WIDE = {   # LDS-table aggregations over 64-bit sources / an 11-bit grou
     "filtered sum(m64) group w1": ("SELECT w1, SUM(m64) FROM t WHERE r_int BETWEEN 250000 AND 749999 GROUP BY w1 LIMIT 5000", 13.375),
     "sum(m64) no group": ("SELECT SUM(m64), MIN(m64), COUNT(*) FROM t WHERE c_inv2 = 1", 8.125),
 }
+QUERIES_DICT = {   # config 3 in Pinot's default encoding: 20-bit dictId streams for the scan column and the value column (2.5 B/row each)
+    "cfg3 raw (reference point)": (synth.QUERY_CFG3, 9.625),
+    "cfg3 dict": (synth.QUERY_CFG3_DICT, 6.625),
+    "northstar dict": (synth.QUERY_NORTH_STAR_DICT, 7.375),
+    "cfg3 sparse dictionaries (gather)": (synth.QUERY_CFG3_SPARSE, 6.625),
+    "northstar sparse, count sum": ("SELECT g1, g2, COUNT(*), SUM(m_s) FROM t WHERE c_inv1 IN (0,1,2,3) AND c_inv2 IN (0,1) AND r_int_s BETWEEN 750000 AND 2249999 GROUP BY g1, g2 LIMIT 10000", 7.375),
+    "raw scan, dict value": ("SELECT g1, SUM(m_d), MAX(m_d) FROM t WHERE c_inv1 IN (0,1,2,3) AND c_inv2 IN (0,1) AND r_int BETWEEN 250000 AND 749999 GROUP BY g1", 8.125),
+    "dict scan, raw value": ("SELECT g1, SUM(m), MAX(m) FROM t WHERE c_inv1 IN (0,1,2,3) AND c_inv2 IN (0,1) AND r_int_d BETWEEN 250000 AND 749999 GROUP BY g1", 8.125),
+    "no filter sum(m_d) group g1": ("SELECT g1, SUM(m_d), MAX(m_d) FROM t GROUP BY g1", 3.375),
+    "no filter sum(m_s) group g1": ("SELECT g1, SUM(m_s), MAX(m_s) FROM t GROUP BY g1", 3.375),
+    "index only, sum(m_d) group g1": ("SELECT g1, SUM(m_d), MAX(m_d) FROM t WHERE c_inv1 IN (0,1,2,3) AND c_inv2 IN (0,1) GROUP BY g1", 4.125),
+    "dict range scan, sum(m_d) group g1": ("SELECT g1, SUM(m_d), MAX(m_d) FROM t WHERE r_int_d BETWEEN 250000 AND 749999 GROUP BY g1", 5.875),
+    "dict sel 3%": ("SELECT g1, SUM(m_d), MAX(m_d) FROM t WHERE c_inv1 = 0 AND c_inv2 = 0 AND r_int_d BETWEEN 250000 AND 749999 GROUP BY g1", 6.625),
+    "dict sel 50%": ("SELECT g1, SUM(m_d), MAX(m_d) FROM t WHERE c_inv1 IN (0,1,2,3) AND c_inv2 NOT IN (3) AND r_int_d BETWEEN 250000 AND 749999 GROUP BY g1", 6.625),
+    "dict sel 75% all match": ("SELECT g1, SUM(m_d), MAX(m_d) FROM t WHERE c_inv1 NOT IN (7) AND c_inv2 NOT IN (3) AND r_int_d BETWEEN 0 AND 2000000 GROUP BY g1", 6.625),
+    "sparse sel 75% all match": ("SELECT g1, SUM(m_s), MAX(m_s) FROM t WHERE c_inv1 NOT IN (7) AND c_inv2 NOT IN (3) AND r_int_s BETWEEN 0 AND 9000000 GROUP BY g1", 6.625),
+    "dict filter only count": ("SELECT COUNT(*) FROM t WHERE c_inv1 IN (0,1,2,3) AND c_inv2 IN (0,1) AND r_int_d BETWEEN 250000 AND 749999", 3.25),
+    "no group: dict filter, sum(m_d)": ("SELECT SUM(m_d), MAX(m_d) FROM t WHERE c_inv1 IN (0,1,2,3) AND c_inv2 IN (0,1) AND r_int_d BETWEEN 250000 AND 749999", 5.75),
+}
+if args.set == "dict":
+    QUERIES = QUERIES_DICT
 if args.set == "mv":
     b1, b2 = MV_BYTES["mv1"], MV_BYTES["mv2"]
     QUERIES = {   # bytes per row: every entry of the multi-value columns read + the single-value columns
