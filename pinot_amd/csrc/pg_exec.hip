@@ -612,9 +612,11 @@ static LaunchShape launch_shape(const CompiledPlan& P, int n_wtiles, int agg_mod
     int grid = std::min((n_wtiles + waves - 1) / waves, num_cus() * std::max(wgs_per_cu, 1));
     return {std::max(grid, 1), waves * 64, 0};
   }
-  if (uses_specd(P, agg_mode)) {   // one 16-wavefront workgroup per CU; behind the table and its trash slots a private strip of LDS per wavefront
+  if (uses_specd(P, agg_mode)) {   // behind the table and its trash slots a private strip of LDS per wavefront; two workgroups per CU where their LDS fits
     const int waves = pg_specd_waves_per_block;
-    return {std::max(1, std::min((n_wtiles + waves - 1) / waves, num_cus())), waves * 64, lds + 64 + specd_stage_bytes(P) + 512 * (size_t)P.dev.n_ops};
+    const size_t need = lds + 64 + specd_stage_bytes(P) + 512 * (size_t)P.dev.n_ops;
+    const int per_cu = knobs().specd_wgs_per_cu > 0 ? ((size_t)knobs().specd_wgs_per_cu * (need + 1024) <= lds_per_cu() ? knobs().specd_wgs_per_cu : 1) : 1;
+    return {std::max(1, std::min((n_wtiles + waves - 1) / waves, num_cus() * per_cu)), waves * 64, need};
   }
   if (uses_spec_kernel(P, agg_mode))   // one 12-wavefront workgroup per CU walking tiles b, b + grid, ...; table + two stage buffers in LDS
     return {std::max(1, std::min(n_wtiles, num_cus())), pg_spec_waves_per_block * 64, lds + 64 + 2 * spec_stage_bytes(P) + 512 * (size_t)P.dev.n_ops};   // (+ 64 trash slots per accumulator)

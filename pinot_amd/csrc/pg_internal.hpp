@@ -448,6 +448,7 @@ struct Knobs {
   bool no_oct = false, oct_no_affine = false, oct_byte_regs = false, oct_any_cardinality = false, no_oct_prune = false, oct_dword_regs = false;
   bool no_p2 = false, p2_no_fast_a = false, no_p2_oct = false, no_radix = false, no_radix_aux = false, no_part = false, no_radix_packed = false;
   bool no_pipe_general = false, no_pipe_wide = false, no_pipe_wide_double = false, mv_no_windows = false;
+  int specd_wgs_per_cu = 1;   // PG_SPECD_WGS_PER_CU: workgroups of the pg_fast_dictrange_s family per CU (where their LDS fits)
   bool no_specd = false, specd_no_affine = false;   // PG_NO_SPECD: no pg_fast_dictrange_s family; PG_SPECD_NO_AFFINE: arithmetic dictionaries are gathered like any other
   int64_t oct_min_docs = -1;
   bool no_oct_count_kernel = false;                // PG_NO_OCT_COUNT_KERNEL: those plans run pg_oct_l (two load buffers) instead of pg_oct_c (four)

@@ -25,7 +25,16 @@
 // tiles): 44-47 % of 8 TB/s whatever the consumers did — each stage was a chain of three LDS round trips on every consumer at the same time,
 // between two rendezvous of all twelve wavefronts.  Independent wavefronts overlap one another's round trips instead.
 // Bytes per doc: (scan bits + value bits + group bits) / 8 + postings — 6.625 B for config 3 with 20-bit r_int / m against 9.625 raw.
-#define PG_WAVES_PER_BLOCK 16
+#ifndef SD_WAVES
+#define SD_WAVES 16     // wavefronts per workgroup
+#endif
+#ifndef SD_SETS
+#define SD_SETS 1       // sub-tiles of loads in flight per wavefront (register sets); 2: measured the same, and the scan fields' eight LDS reads then serialise on one register pair
+#endif
+#ifndef SD_MIN_WAVES_PER_SIMD
+#define SD_MIN_WAVES_PER_SIMD 4   // register budget: 4 -> 128 VGPRs, 5 -> 96, 6 -> 80 (two workgroups per CU where their LDS fits)
+#endif
+#define PG_WAVES_PER_BLOCK SD_WAVES
 #define PG_KERNEL template <int PG_NOT_INSTANTIATED> static
 #include "pg_kernels.hip"
 #include "pg_oct_layout.h"
@@ -203,10 +212,13 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
   };
 
   // ---- filter and aggregation of the sub-tile in the strip --------------------------------------------------------------------------------
-  // one field of a column's bytes in the strip: doc `doc` of the sub-tile, width <= 24 (or 32: raw INT)
-  auto field_at = [&](const uint8_t* col, uint32_t doc, uint32_t bits) __attribute__((always_inline)) -> uint32_t {
+  // one field of a column's bytes in the strip: doc `doc` of the sub-tile, width <= 24 (or 32: raw INT) — the dword pair is requested by
+  // field_pair (every field of a round first: one LDS round trip), cut by field_of
+  auto field_pair = [&](const uint8_t* col, uint32_t doc, uint32_t bits) __attribute__((always_inline)) -> u32x2 {
+    return *reinterpret_cast<const u32x2_a4*>(col + ((mul24(doc, bits) >> 5) << 2));
+  };
+  auto field_of = [&](u32x2 w, uint32_t doc, uint32_t bits) __attribute__((always_inline)) -> uint32_t {
     const uint32_t P = mul24(doc, bits);
-    const u32x2 w = *reinterpret_cast<const u32x2_a4*>(col + ((P >> 5) << 2));
     const uint32_t s8 = (P >> 3) & 3u;   // the field's first byte inside the pair
     const uint32_t be = perm(w.y, w.x, perm(s8, s8, 0u) + 0x00010203u);   // (oct_selector(s8): s8 in every byte + 0, 1, 2, 3 — a 24-bit multiply would cut the constant)
     return bits >= 32u ? be : bfe(be, 32u - (P & 7u) - bits, bits);
@@ -240,10 +252,13 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
     uint32_t m = (cd >> lin_sh) & 0xFFu;
     if (HAS_SCAN) {
       uint32_t rm = 0;
+      u32x2 w[8];   // all eight pairs requested before the first is used (one LDS round trip, not eight)
+#pragma unroll
+      for (int j = 0; j < 8; j++) w[j] = *reinterpret_cast<const u32x2_a4*>(strip + sc_at[j]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 8; j++) {
-        const u32x2 w = *reinterpret_cast<const u32x2_a4*>(strip + sc_at[j]);
-        const uint32_t id = (perm(w.y, w.x, sc_sel[j]) >> sc_sh[j]) & sc_mask;
+        const uint32_t id = (perm(w[j].y, w[j].x, sc_sel[j]) >> sc_sh[j]) & sc_mask;
         rm |= (uint32_t)in_range_i32(r32, (int32_t)id) << j;
       }
       m &= r32.empty ? 0u : rm;
@@ -257,35 +272,38 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
 #ifdef PG_SD_NO_TABLE   // measurement variant (wrong results): the filter alone
     return;
 #endif
-    // ranks in position-major order (any order serves: the accumulators commute)
+    // the selection list in position-major order (any order serves: the accumulators commute): one ballot per doc position ranks its matches;
+    // a doc that does not match writes to the lane's dummy entry
     uint32_t total = 0;
-    uint32_t rank[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-      const uint64_t b = __builtin_amdgcn_ballot_w64(((m >> j) & 1u) != 0u);
-      rank[j] = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+      const bool hit = ((m >> j) & 1u) != 0u;
+      const uint64_t b = __builtin_amdgcn_ballot_w64(hit);
+      const uint32_t rank = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+      my_list[hit ? rank : list_dummy] = (uint16_t)((uint32_t)lane * 8u + (uint32_t)j);
       total += (uint32_t)__builtin_popcountll(b);
     }
     total = (uint32_t)uniform((int)total);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (a wavefront's LDS operations execute in order: the reads below see the writes above)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (VK == SD_V_GATHER) flush_pending();
     if (total == 0u) return;
-    const bool all = total == OCT_SUB_DOCS;   // wave-uniform: no list needed (entry i = doc i)
-    if (!all) {
-#pragma unroll
-      for (int j = 0; j < 8; j++) my_list[((m >> j) & 1u) ? rank[j] : list_dummy] = (uint16_t)((uint32_t)lane * 8u + (uint32_t)j);
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (a wavefront's LDS operations execute in order: the reads below see the writes above)
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
+    const bool all = false;
     int round = 0;
     for (uint32_t at = 0; at < total; at += 64u, round++) {
       const uint32_t idx = at + (uint32_t)lane;
       const bool live = idx < total;
       const uint32_t doc = all ? idx : (live ? (uint32_t)my_list[idx] : 0u);
-      const uint32_t vid = field_at(strip + off_val, doc, vbits);
+      const u32x2 wv = field_pair(strip + off_val, doc, vbits);
+      u32x2 wg[NG];
+#pragma unroll
+      for (int gi = 0; gi < NG; gi++) wg[gi] = field_pair(strip + (gi == 0 ? off_g0 : off_g1), doc, gbits[gi]);
+      __builtin_amdgcn_sched_barrier(0);
+      const uint32_t vid = field_of(wv, doc, vbits);
       uint32_t slot = rep;
 #pragma unroll
-      for (int gi = 0; gi < NG; gi++) slot = mad24(field_at(strip + (gi == 0 ? off_g0 : off_g1), doc, gbits[gi]), gmul[gi], slot);   // < 65536 slots (planner)
+      for (int gi = 0; gi < NG; gi++) slot = mad24(field_of(wg[gi], doc, gbits[gi]), gmul[gi], slot);   // < 65536 slots (planner)
       slot = live ? slot : trash_slot;
       const int32_t v = value_of(live ? vid : 0u);
       if (VK == SD_V_GATHER && round < SD_PEND) {   // applied one sub-tile later (no run-time index into the registers)
@@ -299,10 +317,12 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
     }
   };
 
-  // ---- main loop: one tile per iteration, sub-tiles 0 .. 3 through two register sets; sub-tile (k, s + 2) is requested where (k, s) is stored ----
+  // ---- main loop: one tile per iteration, sub-tiles 0 .. 3.  SD_SETS = 2: two register sets, sub-tile (k, s + 2) is requested where (k, s) is
+  // stored; SD_SETS = 1: one set — the next sub-tile travels while this one is filtered and aggregated (twice the wavefronts fit then) --------
   if (n_mine > 0) {
-    SdSub<NG> ra, rb;
     issue_post(0);
+#if SD_SETS == 2
+    SdSub<NG> ra, rb;
     issue_sub(0, 0, ra);
     issue_sub(0, 1, rb);
     for (int k = 0; k < n_mine; k++) {
@@ -313,6 +333,18 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
       store_sub(ra); issue_sub(k + 1, 0, ra); consume(k, 2, lin);
       store_sub(rb); issue_sub(k + 1, 1, rb); consume(k, 3, lin);
     }
+#else
+    SdSub<NG> ra;
+    issue_sub(0, 0, ra);
+    for (int k = 0; k < n_mine; k++) {
+      const uint32_t lin = tile_candidates(k);
+      issue_post(k + 1);
+      store_sub(ra); issue_sub(k, 1, ra); consume(k, 0, lin);
+      store_sub(ra); issue_sub(k, 2, ra); consume(k, 1, lin);
+      store_sub(ra); issue_sub(k, 3, ra); consume(k, 2, lin);
+      store_sub(ra); issue_sub(k + 1, 0, ra); consume(k, 3, lin);
+    }
+#endif
     if (VK == SD_V_GATHER) flush_pending();
   }
   {
@@ -342,7 +374,7 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
 
 // one kernel per filter shape and value kind; the group-column count is a wave-uniform branch between two bodies
 #define PG_SPECD_KERNEL(NAME, IDX, SCAN, TAIL, VK) \
-  extern "C" __global__ void __launch_bounds__(PG_BLOCK) NAME(const PgQueryPlan p) { \
+  extern "C" __global__ void __launch_bounds__(PG_BLOCK, SD_MIN_WAVES_PER_SIMD) NAME(const PgQueryPlan p) { \
     if (p.n_group_cols == 1) specd_body<1, IDX, SCAN, TAIL, VK>(p); \
     else specd_body<2, IDX, SCAN, TAIL, VK>(p); \
   }

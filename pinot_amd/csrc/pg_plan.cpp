@@ -17,6 +17,7 @@
 #include "pg_internal.hpp"
 #include "pg_fixed_point.h"
 
+extern "C" const int pg_specd_waves_per_block;   // pg_kernels_specd.hip
 namespace pg {
 
 // =====================================================================================================================
@@ -2183,9 +2184,12 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     if (ok) {
       auto region = [](int bits) { return bits > 0 ? (size_t)((bits * 64 + 16 + 15) & ~15) : (size_t)0; };
       const size_t strip = (has_scan ? region(sbits) : 0) + region(vbits) + region(D.gcols[0].bits) + (D.n_group_cols > 1 ? region(D.gcols[1].bits) : 0) + (512 + 64) * 2;
-      const size_t fixed = 256 + 16 * strip + 16 + 512 * (size_t)D.n_ops;
-      const size_t limit = (size_t)160 * 1024 - 8192;
+      const size_t fixed = 256 + (size_t)pg_specd_waves_per_block * strip + 16 + 512 * (size_t)D.n_ops;
+      const size_t limit_one = (size_t)160 * 1024 - 8192;
       const size_t per_replica = (size_t)G * (size_t)D.n_ops * 8;
+      // several workgroups per CU (PG_SPECD_WGS_PER_CU) where a table of >= 8 replicas leaves room for them
+      const size_t wgs = (size_t)std::max(1, knobs().specd_wgs_per_cu);
+      const size_t limit = wgs > 1 && per_replica * std::min<size_t>(8, (size_t)D.replicas) + fixed + 1024 <= (size_t)160 * 1024 / wgs ? (size_t)160 * 1024 / wgs - 1024 : limit_one;
       while (D.replicas > 1 && per_replica * (size_t)D.replicas + fixed > limit) {
         D.replicas /= 2;
         P.lds_bytes -= per_replica * (size_t)D.replicas;
