@@ -144,6 +144,32 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
 #pragma unroll
   for (int gi = 0; gi < NG; gi++) gmul[gi] = (uint32_t)uniform((int)((uint32_t)p.gcols[gi].mult * R));
   const uint32_t list_dummy = OCT_SUB_DOCS + (uint32_t)lane;
+  // the dense index program as three scalar bit masks over the eight pointer slots: live (a real pointer), first (opens a group), and excl —
+  // bit j: the group that is CLOSED behind slot j is complemented (bit 7: the last group)
+  uint32_t idx_live = 0u, idx_first = 0u, idx_excl = 0u;
+  if (HAS_INDEX) {
+    // (compile-time slot indices only: a run-time index into the kernel argument makes hipcc copy it to scratch memory)
+    bool pad = true;   // slots from the top down that repeat slot 0: the planner's padding
+    uint32_t live = 1u;
+#pragma unroll
+    for (int j = 7; j >= 1; j--) {
+      pad = pad && p.dense_ptr[j] == p.dense_ptr[0] && p.dense_group[j] == p.dense_group[0];
+      if (!pad) live |= 1u << j;
+    }
+    idx_live = live;
+    int last_g = -1;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int gj = p.dense_group[j];
+      if (((live >> j) & 1u) && gj != last_g) {
+        idx_first |= 1u << j;
+        if (j > 0 && ((p.dense_excl >> last_g) & 1)) idx_excl |= 1u << (j - 1);
+        last_g = gj;
+      }
+    }
+    if ((p.dense_excl >> last_g) & 1) idx_excl |= 1u << 7;
+    idx_live = (uint32_t)uniform((int)idx_live); idx_first = (uint32_t)uniform((int)idx_first); idx_excl = (uint32_t)uniform((int)idx_excl);
+  }
   __syncthreads();
 
   // ---- the stream ------------------------------------------------------------------------------------------------------------------------
@@ -196,16 +222,21 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
     const int32_t n_valid = rem >= PG_WAVE_DOCS ? PG_WAVE_DOCS : (rem > 0 ? (int32_t)rem : 0);
     uint32_t lin = valid_lin_mask(n_valid, lane);
     if (HAS_INDEX) {
-      uint32_t grp[4] = {0u, 0u, 0u, 0u};
+      // the planner lays the eight pointers out group after group (slots past the last real pointer repeat slot 0 and are not looked at): a
+      // running OR, folded into the result where the group changes — two scalar bit tests per slot.  (Selecting every slot into four group
+      // registers by compare masks kept 32 64-bit masks alive: ~180 instructions and 64 spilled-SGPR reloads per tile.)
+      uint32_t acc = 0u;
 #pragma unroll
       for (int j = 0; j < 8; j++) {
-        const int gj = p.dense_group[j];
-#pragma unroll
-        for (int q = 0; q < 4; q++) grp[q] |= gj == q ? post[j] : 0u;
+        if ((idx_live >> j) & 1u) {          // wave-uniform
+          if ((idx_first >> j) & 1u) {       // slot j opens a group: close the previous one
+            if (j > 0) lin &= ((idx_excl >> (j - 1)) & 1u) ? ~acc : acc;
+            acc = 0u;
+          }
+          acc |= post[j];
+        }
       }
-#pragma unroll
-      for (int q = 0; q < 4; q++)
-        if (q < p.dense_groups) lin &= ((p.dense_excl >> q) & 1) ? ~grp[q] : grp[q];
+      lin &= ((idx_excl >> 7) & 1u) ? ~acc : acc;
     }
     my_cand += (uint32_t)__popc(lin);   // the scan leaf's candidates (numEntriesScannedInFilter)
     return HAS_TAIL ? lin & tail : lin;
