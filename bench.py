@@ -31,6 +31,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 CFG3_BYTES_PER_ROW = 9.625     # postings 6/8 + r_int 4 + g1 7/8 + m 4
 NORTH_STAR_BYTES_PER_ROW = 10.375
+CFG3_DICT_BYTES_PER_ROW = 6.625   # config 3 in Pinot's default encoding: postings 6/8 + r_int_d 20/8 + g1 7/8 + m_d 20/8
 
 
 def log(msg):
@@ -46,7 +47,7 @@ def main():
     ap.add_argument("--docs", type=int, default=int(os.environ.get("PG_BENCH_DOCS", "1000000000")),
                     help="rows per segment (BASELINE config 3: 1e9)")
     ap.add_argument("--no-validation", action="store_true", help="N > 1: skip the parity checks of the merged table (multi_gpu_validation)")
-    ap.add_argument("--query", choices=["cfg3", "northstar", "cfg2", "cfg5"], default="cfg3",
+    ap.add_argument("--query", choices=["cfg3", "northstar", "cfg2", "cfg5", "cfg3_dict", "cfg3_sparse"], default="cfg3",
                     help="cfg5: BASELINE config 5 — 4-dim GROUP BY (12 800 groups) + DISTINCTCOUNTHLL, flat segment timed like the others, "
                          "plus the star-tree route's latency (its cost does not depend on the parent segment's size)")
     ap.add_argument("--cpu-sample-docs", type=int, default=100_000_000)
@@ -139,11 +140,14 @@ def main():
         merge_kind = "pg_result_all_reduce (RCCL inside libpinot_gpu)" if comm is not None else \
             "torch.distributed all_gather_into_tensor (nccl backend) + host reduce"
 
-    sql = {"cfg3": synth.QUERY_CFG3, "northstar": synth.QUERY_NORTH_STAR, "cfg2": synth.QUERY_CFG2, "cfg5": synth.QUERY_CFG5}[args.query]
+    sql = {"cfg3": synth.QUERY_CFG3, "northstar": synth.QUERY_NORTH_STAR, "cfg2": synth.QUERY_CFG2, "cfg5": synth.QUERY_CFG5,
+           "cfg3_dict": synth.QUERY_CFG3_DICT, "cfg3_sparse": synth.QUERY_CFG3_SPARSE}[args.query]
     # cfg 5 flat = h1..h4 (4+4+4+3 bits) + u (20 bits) = 4.375 B/row
-    bytes_per_row = {"cfg3": CFG3_BYTES_PER_ROW, "northstar": NORTH_STAR_BYTES_PER_ROW, "cfg2": 4.0, "cfg5": 4.375}[args.query]
+    bytes_per_row = {"cfg3": CFG3_BYTES_PER_ROW, "northstar": NORTH_STAR_BYTES_PER_ROW, "cfg2": 4.0, "cfg5": 4.375,
+                     "cfg3_dict": CFG3_DICT_BYTES_PER_ROW, "cfg3_sparse": CFG3_DICT_BYTES_PER_ROW}[args.query]
     needed = {"cfg3": ["c_inv1", "c_inv2", "r_int", "g1", "m"], "northstar": ["c_inv1", "c_inv2", "r_int", "g1", "g2", "m"],
-              "cfg2": ["r_int"], "cfg5": list(synth.CFG5_COLUMNS)}[args.query]
+              "cfg2": ["r_int"], "cfg5": list(synth.CFG5_COLUMNS), "cfg3_dict": ["c_inv1", "c_inv2", "r_int_d", "g1", "m_d"],
+              "cfg3_sparse": ["c_inv1", "c_inv2", "r_int_s", "g1", "m_s"]}[args.query]
 
     # ---- build this rank's segment (segment index = rank) and pin it in HBM, one column at a time ----------------------
     t0 = time.time()
@@ -222,7 +226,9 @@ def main():
         "metric": {"cfg3": "rows scanned/sec, 1B-row segment filter+groupby (3 predicates, SUM/MAX GROUP BY g1)",
                    "northstar": "rows scanned/sec, segment filter+groupby (3 predicates, SUM GROUP BY g1, g2)",
                    "cfg2": "rows scanned/sec, segment range-predicate COUNT(*)",
-                   "cfg5": "rows scanned/sec, 4-dim GROUP BY (12 800 groups) + DISTINCTCOUNTHLL, flat segment"}[args.query],
+                   "cfg5": "rows scanned/sec, 4-dim GROUP BY (12 800 groups) + DISTINCTCOUNTHLL, flat segment",
+                   "cfg3_dict": "rows scanned/sec, config 3 over dictionary-encoded scan and value columns (Pinot's default encoding)",
+                   "cfg3_sparse": "rows scanned/sec, config 3 over dictionary-encoded columns whose dictionaries are not arithmetic"}[args.query],
         "value": value,
         "unit": "rows/s",
         "n_gpus": world,
@@ -292,11 +298,23 @@ def main():
         log(f"concurrency block {time.time() - t_blocks:.1f}s")
     if args.query == "cfg3" and not args.no_variants and rank == 0 and world == 1:
         # BASELINE configs 2 and 5 next to the headline (same timing discipline, their own segments): every default run carries them
+        headline_rows = dense.rows() if hasattr(dense, "rows") else None
         seg.destroy()
         seg = None
         t_blocks = time.time()
         out["cfg2"] = extra_block(api, args, "cfg2", min(args.docs, 100_000_000), 4.0, ["r_int"], synth.QUERY_CFG2)
         log(f"cfg2 block {time.time() - t_blocks:.1f}s")
+        t_blocks = time.time()
+        # config 3 in Pinot's DEFAULT encoding (DictionaryIndexConfig.java:32): the same docs, r_int and m as 20-bit dictId streams — the range is
+        # a dictId interval, SUM / MAX read dictionary.get(dictId).  Identity dictionaries (every value of the range occurs at this size), so
+        # the rows must equal the headline's; then the same with dictionaries that are not arithmetic (values gathered)
+        out["cfg3_dict"] = extra_block(api, args, "cfg3_dict", args.docs, CFG3_DICT_BYTES_PER_ROW, ["c_inv1", "c_inv2", "r_int_d", "g1", "m_d"],
+                                       synth.QUERY_CFG3_DICT, same_rows_as=headline_rows)
+        log(f"cfg3_dict block {time.time() - t_blocks:.1f}s")
+        t_blocks = time.time()
+        out["cfg3_sparse_dictionaries"] = extra_block(api, args, "cfg3_sparse", args.docs, CFG3_DICT_BYTES_PER_ROW,
+                                                      ["c_inv1", "c_inv2", "r_int_s", "g1", "m_s"], synth.QUERY_CFG3_SPARSE)
+        log(f"cfg3_sparse block {time.time() - t_blocks:.1f}s")
         t_blocks = time.time()
         out["cfg5_flat"] = extra_block(api, args, "cfg5", args.docs, 4.375, list(synth.CFG5_COLUMNS), synth.QUERY_CFG5)
         log(f"cfg5_flat block {time.time() - t_blocks:.1f}s")
@@ -492,7 +510,7 @@ def abi_call_latency(api, seg, qc, warmup, steps):
     return statistics.median(lat)
 
 
-def extra_block(api, args, query, docs, bytes_per_row, columns, sql):
+def extra_block(api, args, query, docs, bytes_per_row, columns, sql, same_rows_as=None):
     """One more BASELINE configuration inside the default run: its own segment of `docs` rows pinned in HBM, `steps` timed executions
     after `warmup`, HIP-event kernel time → roofline fraction, HBM traffic from the PMC passes (child runs), and an oracle equality
     flag — the whole segment for config 2 (0.3 s of CPU), a 10 M-row prefix for config 5 (its oracle needs minutes at 1 B rows) plus
@@ -543,7 +561,10 @@ def extra_block(api, args, query, docs, bytes_per_row, columns, sql):
         res["oracle_sample_rows"] = sample
         gp.destroy()
         rows = block.rows()
-        res["full_size_invariant"] = {"sum_of_group_counts": int(sum(v[0] for v in rows.values())), "rows": docs, "groups": len(rows)}
+        if query == "cfg5":
+            res["full_size_invariant"] = {"sum_of_group_counts": int(sum(v[0] for v in rows.values())), "rows": docs, "groups": len(rows)}
+        if same_rows_as is not None:   # the same docs under another encoding: the headline's rows (checked against the oracle at full size)
+            res["rows_equal_the_raw_column_query_at_full_size"] = bool(rows == same_rows_as)
     ora.destroy()
     del host
     seg.destroy()
@@ -677,7 +698,7 @@ def cpu_baseline(args, sql, gpu_block, gpu_seg):
     from pinot_amd.executor import NativeSegment
     from tests.oracle_binding import load_oracle
     sample = min(args.docs, args.cpu_sample_docs)
-    needed = sorted({c for c in synth.CFG3_COLUMNS})
+    needed = sorted({c for c in synth.CFG3_COLUMNS} | ({"r_int_d", "m_d"} if args.query == "cfg3_dict" else set()) | ({"r_int_s", "m_s"} if args.query == "cfg3_sparse" else set()))
     host = synth.generate_segment(sample, segment_index=0, columns=needed)
     ora = NativeSegment(load_oracle(), host)
     times = []

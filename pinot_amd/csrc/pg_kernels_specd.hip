@@ -31,6 +31,13 @@
 #ifndef SD_SETS
 #define SD_SETS 1       // sub-tiles of loads in flight per wavefront (register sets); 2: measured the same, and the scan fields' eight LDS reads then serialise on one register pair
 #endif
+#ifndef SD_DMA
+#define SD_DMA 0        // 1: the columns' bytes go global memory -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write_b128),
+#endif                  //    into one of two column areas of the strip; 0: through registers into a single area.  Measured the same within the
+                        //    run-to-run spread (+0..3 % with non-temporal DMA, profiles/r06_specd_steps.txt) for twice the LDS: not the default
+#ifndef SD_DMA_AUX
+#define SD_DMA_AUX 0    // cache policy bits of the LDS-DMA loads (2: non-temporal)
+#endif
 #ifndef SD_MIN_WAVES_PER_SIMD
 #define SD_MIN_WAVES_PER_SIMD 4   // register budget: 4 -> 128 VGPRs, 5 -> 96, 6 -> 80 (two workgroups per CU where their LDS fits)
 #endif
@@ -43,9 +50,10 @@
 #define SD_LIST_BYTES ((OCT_SUB_DOCS + 64u) * 2u)       // a wavefront's selection list: 512 uint16 entries + a dummy entry per lane
 __host__ __device__ static inline uint32_t sd_region(uint32_t bits) { return bits ? (bits * 64u + SD_PAD + 15u) & ~15u : 0u; }
 extern "C" const int pg_specd_waves_per_block = PG_WAVES_PER_BLOCK;
+extern "C" const int pg_specd_column_areas = SD_DMA ? 2 : 1;   // column areas per strip (the planner sizes the launch's LDS with it)
 // bytes of the launch's LDS behind the table and its trash slots: one strip per wavefront (the sub-tile's column bytes + the selection list)
 extern "C" int pg_specd_stage_bytes(int scan_bits, int value_bits, int bits0, int bits1) {
-  const int strip = (int)(sd_region((uint32_t)scan_bits) + sd_region((uint32_t)value_bits) + sd_region((uint32_t)bits0) + sd_region((uint32_t)bits1) + SD_LIST_BYTES);
+  const int strip = (SD_DMA ? 2 : 1) * (int)(sd_region((uint32_t)scan_bits) + sd_region((uint32_t)value_bits) + sd_region((uint32_t)bits0) + sd_region((uint32_t)bits1)) + (int)SD_LIST_BYTES;
   return PG_WAVES_PER_BLOCK * strip + 16;
 }
 
@@ -91,9 +99,10 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
   uint32_t gbits[NG];
 #pragma unroll
   for (int gi = 0; gi < NG; gi++) gbits[gi] = (uint32_t)uniform(p.gcols[gi].bits);
-  // this wavefront's strip: [scan bytes][value bytes][group bytes ...][selection list]
+  // this wavefront's strip: one or two column areas [scan bytes][value bytes][group bytes ...], then the selection list
   const uint32_t off_val = sd_region(sbits), off_g0 = off_val + sd_region(vbits), off_g1 = off_g0 + sd_region(gbits[0]);
-  const uint32_t off_list = off_g1 + (NG > 1 ? sd_region(gbits[NG - 1]) : 0u);
+  const uint32_t area_bytes = off_g1 + (NG > 1 ? sd_region(gbits[NG - 1]) : 0u);   // one sub-tile's column bytes
+  const uint32_t off_list = (SD_DMA ? 2u : 1u) * area_bytes;
   const uint32_t strip_bytes = off_list + SD_LIST_BYTES;
   uint8_t* strip = reinterpret_cast<uint8_t*>(smem) + (((size_t)p.n_ops * table_slots * 8u + 15u) & ~(size_t)15u) + (uint32_t)wave * strip_bytes;
   uint16_t* my_list = reinterpret_cast<uint16_t*>(strip + off_list);
@@ -205,6 +214,29 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
 #pragma unroll
     for (int gi = 0; gi < NG; gi++) if (g_on[gi]) *reinterpret_cast<u32x4*>(strip + (gi == 0 ? off_g0 : off_g1) + pc) = r.g[gi];
   };
+#if SD_DMA
+  typedef __attribute__((address_space(3))) uint8_t LdsByte;
+  // sub-tile (k, sub) of every column straight into column area `area` of the strip: lane l's 16 bytes land at piece base + 16 l
+  auto dma_sub = [&](int k, int sub, uint32_t area) __attribute__((always_inline)) {
+    const int wt = tile_of(k);
+    LdsByte* dst = (LdsByte*)(strip + area * area_bytes);
+    if (HAS_SCAN) {
+      const GAS uint8_t* src = gptr<uint8_t>(sdata + ((size_t)wt * 4u + (size_t)sub) * 64u * (size_t)sbits) + pc;
+#pragma unroll
+      for (int q = 0; q < 2; q++) if (s_on[q]) __builtin_amdgcn_global_load_lds(src + 1024u * q, dst + 1024u * q, 16, 0, SD_DMA_AUX);
+    }
+    {
+      const GAS uint8_t* src = gptr<uint8_t>(xdata + ((size_t)wt * 4u + (size_t)sub) * 64u * (size_t)vbits) + pc;
+#pragma unroll
+      for (int q = 0; q < 2; q++) if (v_on[q]) __builtin_amdgcn_global_load_lds(src + 1024u * q, dst + off_val + 1024u * q, 16, 0, SD_DMA_AUX);
+    }
+#pragma unroll
+    for (int gi = 0; gi < NG; gi++) {
+      const GAS uint8_t* src = gptr<uint8_t>(p.gcols[gi].data + ((size_t)wt * 4u + (size_t)sub) * 64u * (size_t)gbits[gi]) + pc;
+      if (g_on[gi]) __builtin_amdgcn_global_load_lds(src, dst + (gi == 0 ? off_g0 : off_g1), 16, 0, SD_DMA_AUX);
+    }
+  };
+#endif
   uint32_t post[8], tail = 0;
   auto issue_post = [&](int k) __attribute__((always_inline)) {
     const int wt = tile_of(k);
@@ -277,7 +309,7 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
       if (r < pend.n) apply(pend.slot[r], pend.v[r]);
     pend.n = 0;
   };
-  auto consume = [&](int k, int sub, uint32_t lin) __attribute__((always_inline)) {
+  auto consume = [&](int k, int sub, uint32_t lin, const uint8_t* cols) __attribute__((always_inline)) {   // cols: the sub-tile's column area
     // candidates of this lane's 8 docs: byte (lane & 3) of linear dword 16 sub + (lane >> 2) (docs past the segment: none)
     const uint32_t cd = (uint32_t)__builtin_amdgcn_ds_bpermute((sub * 16 + (lane >> 2)) * 4, (int)lin);
     uint32_t m = (cd >> lin_sh) & 0xFFu;
@@ -285,7 +317,7 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
       uint32_t rm = 0;
       u32x2 w[8];   // all eight pairs requested before the first is used (one LDS round trip, not eight)
 #pragma unroll
-      for (int j = 0; j < 8; j++) w[j] = *reinterpret_cast<const u32x2_a4*>(strip + sc_at[j]);
+      for (int j = 0; j < 8; j++) w[j] = *reinterpret_cast<const u32x2_a4*>(cols + sc_at[j]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 8; j++) {
@@ -293,6 +325,17 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
         rm |= (uint32_t)in_range_i32(r32, (int32_t)id) << j;
       }
       m &= r32.empty ? 0u : rm;
+#ifdef PG_SD_TWICE   // measurement variant: the scan fields decoded and tested a second time (what do ~56 more vector instructions per sub-tile cost?)
+      {
+        uint32_t rm2 = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          const uint32_t id = (perm(w[j].x, w[j].y, sc_sel[j] ^ 0x01010101u) >> sc_sh[j]) & sc_mask;
+          rm2 |= (uint32_t)in_range_i32(r32, (int32_t)id + 1) << j;
+        }
+        if (rm2 == 0x12345u) m ^= 1u;
+      }
+#endif
     }
     my_matched += (uint32_t)__popc(m);
     if (has_out_words) {   // the tile's match words, linear layout: lanes 4 g .. 4 g + 3 hold the bytes of dword 16 sub + g
@@ -326,10 +369,10 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
       const uint32_t idx = at + (uint32_t)lane;
       const bool live = idx < total;
       const uint32_t doc = all ? idx : (live ? (uint32_t)my_list[idx] : 0u);
-      const u32x2 wv = field_pair(strip + off_val, doc, vbits);
+      const u32x2 wv = field_pair(cols + off_val, doc, vbits);
       u32x2 wg[NG];
 #pragma unroll
-      for (int gi = 0; gi < NG; gi++) wg[gi] = field_pair(strip + (gi == 0 ? off_g0 : off_g1), doc, gbits[gi]);
+      for (int gi = 0; gi < NG; gi++) wg[gi] = field_pair(cols + (gi == 0 ? off_g0 : off_g1), doc, gbits[gi]);
       __builtin_amdgcn_sched_barrier(0);
       const uint32_t vid = field_of(wv, doc, vbits);
       uint32_t slot = rep;
@@ -352,17 +395,31 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
   // stored; SD_SETS = 1: one set — the next sub-tile travels while this one is filtered and aggregated (twice the wavefronts fit then) --------
   if (n_mine > 0) {
     issue_post(0);
-#if SD_SETS == 2
+#if SD_DMA
+    // sub-tile u lands in column area u & 1 while sub-tile u - 1 is filtered and aggregated out of the other; what has to have landed is waited
+    // for with vmcnt(0) just before the next request goes out (the posting dwords and the dictionary look-ups in flight are older than that)
+    dma_sub(0, 0, 0u);
+    for (int k = 0; k < n_mine; k++) {
+      const uint32_t lin = tile_candidates(k);
+      issue_post(k + 1);
+#pragma unroll
+      for (int sub = 0; sub < 4; sub++) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched: sub-tile (k, sub) is in its area
+        if (sub < 3) dma_sub(k, sub + 1, (uint32_t)((sub + 1) & 1)); else dma_sub(k + 1, 0, 0u);
+        consume(k, sub, lin, strip + (uint32_t)(sub & 1) * area_bytes);
+      }
+    }
+#elif SD_SETS == 2
     SdSub<NG> ra, rb;
     issue_sub(0, 0, ra);
     issue_sub(0, 1, rb);
     for (int k = 0; k < n_mine; k++) {
       const uint32_t lin = tile_candidates(k);   // (waits for tile k's posting dwords only: the sub-tiles behind them stay in flight)
       issue_post(k + 1);
-      store_sub(ra); issue_sub(k, 2, ra); consume(k, 0, lin);
-      store_sub(rb); issue_sub(k, 3, rb); consume(k, 1, lin);
-      store_sub(ra); issue_sub(k + 1, 0, ra); consume(k, 2, lin);
-      store_sub(rb); issue_sub(k + 1, 1, rb); consume(k, 3, lin);
+      store_sub(ra); issue_sub(k, 2, ra); consume(k, 0, lin, strip);
+      store_sub(rb); issue_sub(k, 3, rb); consume(k, 1, lin, strip);
+      store_sub(ra); issue_sub(k + 1, 0, ra); consume(k, 2, lin, strip);
+      store_sub(rb); issue_sub(k + 1, 1, rb); consume(k, 3, lin, strip);
     }
 #else
     SdSub<NG> ra;
@@ -370,10 +427,10 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
     for (int k = 0; k < n_mine; k++) {
       const uint32_t lin = tile_candidates(k);
       issue_post(k + 1);
-      store_sub(ra); issue_sub(k, 1, ra); consume(k, 0, lin);
-      store_sub(ra); issue_sub(k, 2, ra); consume(k, 1, lin);
-      store_sub(ra); issue_sub(k, 3, ra); consume(k, 2, lin);
-      store_sub(ra); issue_sub(k + 1, 0, ra); consume(k, 3, lin);
+      store_sub(ra); issue_sub(k, 1, ra); consume(k, 0, lin, strip);
+      store_sub(ra); issue_sub(k, 2, ra); consume(k, 1, lin, strip);
+      store_sub(ra); issue_sub(k, 3, ra); consume(k, 2, lin, strip);
+      store_sub(ra); issue_sub(k + 1, 0, ra); consume(k, 3, lin, strip);
     }
 #endif
     if (VK == SD_V_GATHER) flush_pending();

@@ -17,7 +17,7 @@
 #include "pg_internal.hpp"
 #include "pg_fixed_point.h"
 
-extern "C" const int pg_specd_waves_per_block;   // pg_kernels_specd.hip
+extern "C" const int pg_specd_waves_per_block, pg_specd_column_areas;   // pg_kernels_specd.hip
 namespace pg {
 
 // =====================================================================================================================
@@ -2183,7 +2183,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     // every lane on a replica of its own down to R = 64; below, lanes share)
     if (ok) {
       auto region = [](int bits) { return bits > 0 ? (size_t)((bits * 64 + 16 + 15) & ~15) : (size_t)0; };
-      const size_t strip = (has_scan ? region(sbits) : 0) + region(vbits) + region(D.gcols[0].bits) + (D.n_group_cols > 1 ? region(D.gcols[1].bits) : 0) + (512 + 64) * 2;
+      const size_t strip = (size_t)pg_specd_column_areas * ((has_scan ? region(sbits) : 0) + region(vbits) + region(D.gcols[0].bits) + (D.n_group_cols > 1 ? region(D.gcols[1].bits) : 0)) + (512 + 64) * 2;
       const size_t fixed = 256 + (size_t)pg_specd_waves_per_block * strip + 16 + 512 * (size_t)D.n_ops;
       const size_t limit_one = (size_t)160 * 1024 - 8192;
       const size_t per_replica = (size_t)G * (size_t)D.n_ops * 8;
