@@ -19,7 +19,9 @@ import java.util.ArrayList;
 import java.util.List;
 import java.util.Map;
 import java.util.TreeMap;
+import java.util.concurrent.CancellationException;
 import java.util.concurrent.ExecutionException;
+import java.util.concurrent.atomic.AtomicReferenceArray;
 import java.util.concurrent.ExecutorService;
 import java.util.concurrent.Future;
 import java.util.concurrent.locks.ReentrantLock;
@@ -104,26 +106,58 @@ public class GpuGroupByCombineOperator extends GroupByCombineOperator {
     int n = _segmentOperators.size();
     GpuGroupByOperator[] ops = new GpuGroupByOperator[n];
     // one worker task per segment, as BaseCombineOperator runs them (BaseCombineOperator.java:97-142): the segments' queries overlap on
-    // their GPUs' streams; every task is waited for before anything is thrown, so no native call outlives this method
+    // their GPUs' streams.  EVERY task is waited for — through interrupts too — before anything is thrown, so no native call outlives this
+    // method and every result that came back sits in results[] for the caller to free.  The cancel tokens of the running queries are
+    // registered under the POOL threads (GpuGroupByOperator#execute), which the query killer does not know: when it interrupts THIS thread
+    // (time-out, kill), the interrupt is handed on to them — GpuCancellation.cancel(runner) — and the tasks that have not started are cancelled.
     List<Future<Long>> executions = new ArrayList<>(n);
+    AtomicReferenceArray<Thread> runners = new AtomicReferenceArray<>(n);
     for (int i = 0; i < n; i++) {
       ops[i] = (GpuGroupByOperator) _segmentOperators.get(i);
       GpuGroupByOperator op = ops[i];
-      executions.add(_workers.submit(op::execute));   // 0: refused at run time (hash bucket overflow) — that operator answers with its Java plan
+      int slot = i;
+      executions.add(_workers.submit(() -> {   // 0: refused at run time (hash bucket overflow) — that operator answers with its Java plan
+        runners.set(slot, Thread.currentThread());
+        try {
+          return op.execute();
+        } finally {
+          runners.set(slot, null);
+        }
+      }));
     }
     RuntimeException failed = null;
+    boolean interrupted = false;
     for (int i = 0; i < n; i++) {
-      try {
-        results[i] = executions.get(i).get();
-      } catch (ExecutionException e) {
-        if (failed == null) {
-          failed = e.getCause() instanceof RuntimeException ? (RuntimeException) e.getCause() : new RuntimeException(e.getCause());
+      for (;;) {
+        try {
+          results[i] = executions.get(i).get();
+          break;
+        } catch (ExecutionException e) {
+          if (failed == null) {
+            failed = e.getCause() instanceof RuntimeException ? (RuntimeException) e.getCause() : new RuntimeException(e.getCause());
+          }
+          break;
+        } catch (CancellationException e) {   // cancelled below before it started: nothing ran, nothing to free
+          break;
+        } catch (InterruptedException e) {
+          if (!interrupted) {
+            interrupted = true;
+            for (int j = 0; j < n; j++) {
+              executions.get(j).cancel(false);           // not started yet: never will; running: left to its cancel token
+              Thread runner = runners.get(j);
+              if (runner != null) {
+                GpuCancellation.cancel(runner);          // EarlyTerminationException inside pg_query_exec: the task ends promptly
+              }
+            }
+          }
+          // keep waiting: the running tasks own native results and HBM tables until they return
         }
-      } catch (InterruptedException e) {
-        Thread.currentThread().interrupt();
-        if (failed == null) {
-          failed = new RuntimeException(e);
-        }
+      }
+    }
+    if (interrupted) {
+      Thread.currentThread().interrupt();
+      if (failed == null) {
+        failed = new RuntimeException(new InterruptedException("interrupted while the segments' GPU queries were running"));
       }
     }
     if (failed != null) {

@@ -1105,7 +1105,18 @@ static void extract_agg(po_agg_result* r, agg_state* a, int32_t n_groups, const 
  * The reference keeps a heap of `size` records; which records TIED with the last one kept survive depends on the heap — here a stable
  * sort decides (tests put a unique value at the cut).
  * ===================================================================================================================== */
-typedef struct order_value { int type; int64_t l; double d; const uint8_t* b; int32_t blen; } order_value;   /* type 0 long / int, 1 double, 2 bytes */
+typedef struct order_value { int type; int64_t l; double d; const uint8_t* b; int32_t blen; } order_value;   /* type 0 long / int, 1 double, 2 BYTES, 3 STRING */
+/* String.compareTo (TableResizer's comparators on STRING keys) orders UTF-16 code units; UTF-8 byte order differs only where a supplementary
+ * character (lead byte F0..F4: surrogates D800..DFFF) meets U+E000..U+FFFF (lead byte EE / EF), which sort behind it in UTF-16 */
+static int utf16_unit_order(const uint8_t* a, int32_t alen, const uint8_t* b, int32_t blen) {
+  const int32_t n = alen < blen ? alen : blen;
+  for (int32_t i = 0; i < n; i++) {
+    if (a[i] == b[i]) continue;
+    const int x = a[i] == 0xEE || a[i] == 0xEF ? a[i] + 0x10 : a[i], y = b[i] == 0xEE || b[i] == 0xEF ? b[i] + 0x10 : b[i];
+    return x < y ? -1 : 1;
+  }
+  return alen < blen ? -1 : (alen > blen ? 1 : 0);
+}
 typedef struct order_ctx { const order_value* v; int n_ob; const int* asc; } order_ctx;
 static int double_compare_java(double a, double b) {   /* Double.compare: -0.0 < 0.0, NaN above everything and equal to itself */
   if (a < b) return -1;
@@ -1125,9 +1136,10 @@ static int order_cmp(const void* pa, const void* pb, void* ctxp) {
     int r;
     if (a->type == 0) r = a->l < b->l ? -1 : (a->l > b->l ? 1 : 0);
     else if (a->type == 1) r = double_compare_java(a->d, b->d);
+    else if (a->type == 3) r = utf16_unit_order(a->b, a->blen, b->b, b->blen);
     else {
       const int32_t n = a->blen < b->blen ? a->blen : b->blen;
-      r = n ? memcmp(a->b, b->b, (size_t)n) : 0;   /* (String.compareTo orders UTF-16 units; equal to this byte order below U+10000) */
+      r = n ? memcmp(a->b, b->b, (size_t)n) : 0;   /* ByteArray.compare: unsigned bytes */
       if (r == 0) r = a->blen < b->blen ? -1 : (a->blen > b->blen ? 1 : 0);
     }
     if (r != 0) return c->asc[k] ? r : -r;
@@ -1579,7 +1591,7 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
             if (c->has_dictionary || c->data_type <= PG_TYPE_LONG) { v->type = 0; v->l = t; }   /* dictIds order as the values do (sorted dictionaries) */
             else if (c->data_type == PG_TYPE_FLOAT) { uint32_t b = (uint32_t)t; float f; memcpy(&f, &b, 4); v->type = 1; v->d = (double)f; }
             else if (c->data_type == PG_TYPE_DOUBLE) { v->type = 1; memcpy(&v->d, &t, 8); }
-            else { v->type = 2; v->b = gkg.bytes_dicts[j].vals[t]; v->blen = gkg.bytes_dicts[j].lens[t]; }
+            else { v->type = c->data_type == PG_TYPE_STRING ? 3 : 2; v->b = gkg.bytes_dicts[j].vals[t]; v->blen = gkg.bytes_dicts[j].lens[t]; }
             continue;
           }
           int64_t raw = (gkg.holder == HOLDER_ARRAY) ? g : gkg.raw_key_of_group[g];   /* getKeys :578-591: column 0 is least significant */

@@ -1,11 +1,18 @@
 // C ABI entry points of libpinot_gpu.so (include/pinot_gpu.h).  Every exception becomes a status code plus a
 // thread-local message (pg_last_error), which the JNI shim rethrows as RuntimeException.
 #include "pg_internal.hpp"
+#include <atomic>
+#include <deque>
+#include <memory>
 #include <mutex>
 
 namespace pg {
-static Knobs g_knobs;
-static std::once_flag g_knobs_once;
+// The current knobs are an immutable record behind an atomic pointer; pg_options_reload publishes a NEW record and leaves the old ones alive
+// (a few hundred bytes each, reloads are rare): a query thread that read knobs() a moment ago keeps a valid reference — no lock on the
+// query path, no use-after-free of the std::string members.
+static std::mutex g_knobs_mu;
+static std::deque<std::unique_ptr<Knobs>> g_knobs_all;
+static std::atomic<const Knobs*> g_knobs_cur{nullptr};
 static void knobs_read(Knobs& k) {
   k = Knobs();
   auto flag = [](const char* name) { return getenv(name) != nullptr; };
@@ -34,13 +41,26 @@ static void knobs_read(Knobs& k) {
   k.limit_prefix_min_docs = std::max<int64_t>(PG_WAVE_DOCS, num("PG_LIMIT_PREFIX_MIN_DOCS", (int64_t)1 << 20));
   k.oct_passes = str("PG_OCT_PASSES"); k.rccl_library = str("PG_RCCL_LIBRARY");
 }
+static const Knobs* knobs_publish() {   // g_knobs_mu held
+  auto k = std::make_unique<Knobs>();
+  knobs_read(*k);
+  const Knobs* p = k.get();
+  g_knobs_all.push_back(std::move(k));
+  g_knobs_cur.store(p, std::memory_order_release);
+  return p;
+}
 const Knobs& knobs() {
-  std::call_once(g_knobs_once, [] { knobs_read(g_knobs); });
-  return g_knobs;
+  const Knobs* k = g_knobs_cur.load(std::memory_order_acquire);
+  if (!k) {
+    std::lock_guard<std::mutex> g(g_knobs_mu);
+    k = g_knobs_cur.load(std::memory_order_acquire);
+    if (!k) k = knobs_publish();
+  }
+  return *k;
 }
 void knobs_reload() {
-  (void)knobs();
-  knobs_read(g_knobs);
+  std::lock_guard<std::mutex> g(g_knobs_mu);
+  (void)knobs_publish();
 }
 }  // namespace pg
 

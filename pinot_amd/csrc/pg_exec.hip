@@ -2067,7 +2067,19 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
   //      a group key's value, an aggregation's final result (COUNT long; SUM / MIN / MAX double; AVG sum / count; MINMAXRANGE max - min).
   //      (Tables trimmed on the device arrive here already compact — device_trim below — and pass through: ng <= trimSize.)
   if (n_group_by > 0 && P.trim_size > 0 && (int64_t)gids.size() > (int64_t)P.trim_size) {
-    struct OV { int type; int64_t l; double d; const uint8_t* b; int64_t blen; };
+    struct OV { int type; int64_t l; double d; const uint8_t* b; int64_t blen; };   // type 0 long, 1 double, 2 BYTES (unsigned bytes), 3 STRING
+    // String.compareTo orders UTF-16 code units (TableResizer's comparators on STRING keys); the UTF-8 byte order differs only where a
+    // supplementary character (lead byte F0..F4: surrogates D800..DFFF in UTF-16) meets U+E000..U+FFFF (lead byte EE / EF): those two
+    // lead bytes sort behind F0..F4
+    auto utf16_unit_order = [](const uint8_t* a, int64_t alen, const uint8_t* b, int64_t blen) {
+      const int64_t m = std::min(alen, blen);
+      for (int64_t i = 0; i < m; i++) {
+        if (a[i] == b[i]) continue;
+        const int x = a[i] == 0xEE || a[i] == 0xEF ? a[i] + 0x10 : a[i], y = b[i] == 0xEE || b[i] == 0xEF ? b[i] + 0x10 : b[i];
+        return x < y ? -1 : 1;
+      }
+      return alen < blen ? -1 : (alen > blen ? 1 : 0);
+    };
     const size_t n = gids.size(), n_ob = P.order_by.size();
     std::vector<OV> vals(n * n_ob);
     for (size_t k = 0; k < n_ob; k++) {
@@ -2098,7 +2110,7 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
         const int64_t id = (raw / D.gcols[j].mult) % P.group_cards[j];
         if (!vd) { v.l = id; continue; }   // a sorted dictionary: dictIds order as the values do
         if (vd->vdict_kind == 4) {
-          v.type = 2;
+          v.type = vd->data_type == PG_TYPE_STRING ? 3 : 2;
           v.b = vd->vdict_bytes.data() + vd->vdict_bytes_off[(size_t)id];
           v.blen = vd->vdict_bytes_off[(size_t)id + 1] - vd->vdict_bytes_off[(size_t)id];
         } else if (vd->vdict_kind <= 1) {
@@ -2127,6 +2139,7 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
         int r;
         if (a.type == 0) r = a.l < b.l ? -1 : (a.l > b.l ? 1 : 0);
         else if (a.type == 1) r = dcmp(a.d, b.d);
+        else if (a.type == 3) r = utf16_unit_order(a.b, a.blen, b.b, b.blen);
         else {
           const int64_t m = std::min(a.blen, b.blen);
           r = m ? memcmp(a.b, b.b, (size_t)m) : 0;

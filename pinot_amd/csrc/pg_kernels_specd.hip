@@ -70,10 +70,6 @@ DEVFN uint32_t or_reduce4(uint32_t v) {   // OR across aligned groups of 4 lanes
 
 // the loads of one sub-tile in flight: two 16-byte pieces per lane of the scan and the value column (64 x bits <= 2 048 bytes), one of a group column
 template <int NG> struct SdSub { u32x4 sc[2], va[2], g[NG]; };
-// SD_V_GATHER: dictionary look-ups issued for one sub-tile and applied behind the next (the first rounds of its selection list)
-#define SD_PEND 2
-struct SdPend { uint32_t slot[SD_PEND]; int32_t v[SD_PEND]; int n; };
-
 // value kinds (PgQueryPlan::specd_vkind)
 enum { SD_V_RAW32 = 1, SD_V_AFFINE = 2, SD_V_GATHER = 3 };
 
@@ -301,13 +297,15 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
       else atomicMax(reinterpret_cast<long long*>(base + slot), (long long)v);
     }
   };
-  SdPend pend;
-  pend.n = 0;
-  auto flush_pending = [&]() __attribute__((always_inline)) {   // SD_V_GATHER: the look-ups of the previous sub-tile's first rounds have travelled since
-#pragma unroll
-    for (int r = 0; r < SD_PEND; r++)
-      if (r < pend.n) apply(pend.slot[r], pend.v[r]);
-    pend.n = 0;
+  // SD_V_GATHER: the look-ups of a sub-tile's first two rounds are applied behind the NEXT sub-tile's filter (they travel meanwhile); plain
+  // scalars, not an indexed struct: hipcc kept the struct in scratch memory
+  uint32_t pend_slot0 = 0, pend_slot1 = 0;
+  int32_t pend_v0 = 0, pend_v1 = 0;
+  int pend_n = 0;
+  auto flush_pending = [&]() __attribute__((always_inline)) {
+    if (pend_n > 0) apply(pend_slot0, pend_v0);
+    if (pend_n > 1) apply(pend_slot1, pend_v1);
+    pend_n = 0;
   };
   auto consume = [&](int k, int sub, uint32_t lin, const uint8_t* cols) __attribute__((always_inline)) {   // cols: the sub-tile's column area
     // candidates of this lane's 8 docs: byte (lane & 3) of linear dword 16 sub + (lane >> 2) (docs past the segment: none)
@@ -380,11 +378,9 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
       for (int gi = 0; gi < NG; gi++) slot = mad24(field_of(wg[gi], doc, gbits[gi]), gmul[gi], slot);   // < 65536 slots (planner)
       slot = live ? slot : trash_slot;
       const int32_t v = value_of(live ? vid : 0u);
-      if (VK == SD_V_GATHER && round < SD_PEND) {   // applied one sub-tile later (no run-time index into the registers)
-#pragma unroll
-        for (int r = 0; r < SD_PEND; r++)
-          if (round == r) { pend.slot[r] = slot; pend.v[r] = v; }
-        pend.n = round + 1;
+      if (VK == SD_V_GATHER && round < 2) {   // applied one sub-tile later
+        if (round == 0) { pend_slot0 = slot; pend_v0 = v; } else { pend_slot1 = slot; pend_v1 = v; }
+        pend_n = round + 1;
       } else {
         apply(slot, v);
       }

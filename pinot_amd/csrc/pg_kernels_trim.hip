@@ -11,8 +11,8 @@
 // block's capacity; beyond it the host falls back to the full table) and the host finishes the selection with the full comparator
 // (pg_exec.hip, assemble_result).
 //
-// Keys (smaller sorts first; a descending expression complements the key): a dictionary group column's dictId digit of the raw key
-// (sorted dictionaries: dictIds order as the values do); an int64 accumulator row (COUNT, integer SUM / MIN / MAX, and the
+// Keys (smaller sorts first): a dictionary group column's dictId digit of the raw key (sorted dictionaries: dictIds order as the values do;
+// descending: cardinality - 1 - dictId); an int64 accumulator row (COUNT, integer SUM / MIN / MAX, and the
 // order-preserving keys of floating MIN / MAX) biased by 2^63.  An int64 order REFINES the order of the doubles the reference compares
 // ((double) v is monotone): it only decides what the reference leaves tied.
 #include <hip/hip_runtime.h>
@@ -32,10 +32,18 @@ extern "C" __global__ void __launch_bounds__(256) pg_trim_keys_kernel(const PgTr
     const bool ex = a.table[(int64_t)a.exist_op * a.G + g] != a.exist_ident;
     uint64_t key = ~0ULL;
     if (ex) {
-      if (a.key_op >= 0) key = (uint64_t)a.table[(int64_t)a.key_op * a.G + g] ^ (1ULL << 63);
-      else key = (uint64_t)((g / a.key_mult) % a.key_card);
-      if (a.descending) key = ~key;
-      if (key == ~0ULL) key = ~0ULL - 1;   // the all-ones key marks "no such group": the largest real key gives way by one (ties stay ties)
+      if (a.key_op >= 0) {
+        key = (uint64_t)a.table[(int64_t)a.key_op * a.G + g] ^ (1ULL << 63);
+        if (a.descending) key = ~key;
+        // the all-ones key marks "no such group".  A real row that maps onto it (Long.MAX_VALUE ascending, Long.MIN_VALUE descending) cannot be
+        // told from the next key without merging two tie classes: the overflow flag sends the query to the whole-table path on the host
+        if (key == ~0ULL) { a.ctrl[3] = 1u; key = ~0ULL - 1; }
+      } else {
+        // a group column's dictId digit: descending = counted from the top of the dictionary (complementing the 64-bit key would turn dictId 0
+        // into the all-ones marker — and clamping that made dictId 0 and dictId 1 one tie class)
+        const uint64_t digit = (uint64_t)((g / a.key_mult) % a.key_card);
+        key = a.descending ? (uint64_t)a.key_card - 1u - digit : digit;
+      }
       mine++;
       atomicAdd(&s_hist[key >> 56], 1u);
     }

@@ -51,12 +51,17 @@ BIG = [
     # a single expression with ties at the cut: any of the tied groups may survive (checked against the model only)
     ("SELECT u, COUNT(*) FROM gpuBench GROUP BY u ORDER BY COUNT(*) DESC LIMIT 10", 1, False),
     ("SELECT g2, u, COUNT(*), SUM(m) FROM gpuBench GROUP BY g2, u ORDER BY u, g2 DESC LIMIT 40", 1, True),
+    # ORDER BY a low-cardinality group column DESC with the cut between its dictIds 1 and 0: ~465 000 groups exist under
+    # each value, trimSize 450 000 — every survivor must carry the larger value.  (Complementing the 64-bit key turned dictId 0 into the
+    # "no such group" marker, and the clamp behind it gave dictIds 0 and 1 one key: groups of value 0 displaced groups of value 1.)
+    ("SELECT c_inv2, u, COUNT(*) FROM gpuBench WHERE c_inv2 IN (0, 1) GROUP BY c_inv2, u ORDER BY c_inv2 DESC LIMIT 90000", 1, False),
+    ("SELECT c_inv2, u, COUNT(*) FROM gpuBench WHERE c_inv2 IN (0, 1) GROUP BY c_inv2, u ORDER BY c_inv2 LIMIT 90000", 1, False),
 ]
 
 
 @pytest.fixture(scope="module")
 def big(gpu_api, oracle_api):
-    host = synth.generate_segment(2_500_003, segment_index=10, columns=["g1", "g2", "m", "u"], native=True)
+    host = synth.generate_segment(2_500_003, segment_index=10, columns=["g1", "g2", "m", "u", "c_inv2"], native=True)
     g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
     yield g, o, host
     g.destroy()
@@ -66,7 +71,7 @@ def big(gpu_api, oracle_api):
 @pytest.mark.parametrize("sql,min_trim,total_order", BIG)
 def test_trim_on_the_device(big, gpu_api, gpu_knobs, sql, min_trim, total_order):
     g, o, host = big
-    limit = 60_000_000 if "g2, u" in sql else 2_000_000    # numGroupsLimit above the key space: no docId plane in the way
+    limit = 60_000_000 if ("g2, u" in sql or "c_inv2, u" in sql) else 2_000_000    # numGroupsLimit above the key space: no docId plane in the way
     def q(trim):
         qc = parse_sql(sql)
         qc.num_groups_limit = limit
@@ -112,3 +117,21 @@ def test_trim_refusals(segs):
         with pytest.raises(capi.NativeError) as e:
             g.execute(qc)
         assert e.value.status == capi.PG_ERR_UNSUPPORTED
+
+
+def test_raw_string_keys_order_as_java_strings(gpu_api, oracle_api):
+    """Assembly-time trim ordered by a raw STRING key (virtual dictionary): String.compareTo's UTF-16 code unit order, not UTF-8 byte order
+    (tests/test_group_trim.py pins the oracle to Java's order)."""
+    from pinot_amd.segment import build_segment
+    keys = ["a", "a\ue000", "a\U0001f600", "a\uffff", "a\U00010000", "b", "a\ud7ff", "\uff5e", "\U0002f800", "zz"] + [f"k{i:03d}" for i in range(40)]
+    rng = np.random.default_rng(5)
+    n = 4000
+    data = {"s": np.array([keys[i] for i in rng.integers(0, len(keys), n)], dtype=object), "v": rng.integers(0, 100, n).astype(np.int32)}
+    host = build_segment("rawu", data, {"s": "STRING", "v": "INT"}, no_dictionary_columns=["s", "v"])
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    for sql in ("SELECT s, COUNT(*) FROM rawu GROUP BY s ORDER BY s DESC LIMIT 2", "SELECT s, COUNT(*), SUM(v) FROM rawu GROUP BY s ORDER BY s LIMIT 9"):
+        qc, qo = parse_sql(sql), parse_sql(sql)
+        qc.min_segment_group_trim_size = qo.min_segment_group_trim_size = 1
+        assert g.execute(qc).rows() == o.execute(qo).rows()
+    g.destroy()
+    o.destroy()

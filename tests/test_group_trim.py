@@ -72,6 +72,27 @@ def test_raw_group_keys_order_by_value(oracle_api):
     s.destroy()
 
 
+def test_raw_string_keys_order_as_java_strings(oracle_api):
+    """String.compareTo orders UTF-16 code units (TableResizer's comparators): a supplementary character (surrogates D800..DFFF) sorts BEFORE
+    U+E000..U+FFFF although its UTF-8 bytes (F0..) sort after theirs (EE / EF).  The trim under ORDER BY a raw STRING key keeps the first
+    trimSize keys of THAT order."""
+    keys = ["a", "a\ue000", "a\U0001f600", "a\uffff", "a\U00010000", "b", "a\ud7ff", "\uff5e", "\U0002f800", "zz"] + [f"k{i:03d}" for i in range(40)]
+    rng = np.random.default_rng(5)
+    n = 4000
+    data = {"s": np.array([keys[i] for i in rng.integers(0, len(keys), n)], dtype=object), "v": rng.integers(0, 100, n).astype(np.int32)}
+    host = build_segment("rawu", data, {"s": "STRING", "v": "INT"}, no_dictionary_columns=["s", "v"])
+    s = NativeSegment(oracle_api, host)
+    for sql, reverse in (("SELECT s, COUNT(*) FROM rawu GROUP BY s ORDER BY s DESC LIMIT 2", True), ("SELECT s, COUNT(*) FROM rawu GROUP BY s ORDER BY s LIMIT 9", False)):
+        full = s.execute(parse_sql(sql)).rows()
+        assert len(full) == len(keys)
+        qc = parse_sql(sql)
+        qc.min_segment_group_trim_size = 1
+        got = s.execute(qc).rows()
+        java_order = sorted((k[0] for k in full), key=lambda x: x.encode("utf-16-be"), reverse=reverse)   # UTF-16 big-endian bytes order as code units do
+        assert sorted(k[0] for k in got) == sorted(java_order[:trim_size(qc)])
+    s.destroy()
+
+
 def test_order_by_resolution_and_c_structs():
     qc = parse_sql("SELECT a, b, COUNT(*), SUM(x) FROM t GROUP BY a, b ORDER BY SUM(x) DESC, b, count(*) LIMIT 12")
     assert qc.resolved_order_by() == [(capi.ORDER_BY_AGGREGATION, 1, False), (capi.ORDER_BY_GROUP_KEY, 1, True), (capi.ORDER_BY_AGGREGATION, 0, True)]

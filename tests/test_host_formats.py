@@ -186,6 +186,23 @@ def test_headline_kernel_has_no_register_spills():
                     ou[cur].setdefault(key, int(m.group(1)))
         for k in ("pg_oct_l", "pg_oct_lm", "pg_oct_p", "pg_oct_pm", "pg_oct_c"):   # batching all 8 compare-and-swaps of a lane spilled 96 B
             assert ou[k]["ScratchSize [bytes/lane]"] == 0 and ou[k]["VGPRs"] <= 128, (k, ou[k])
+    # round 6: the dictionary-encoded headline family — 16 independent wavefronts per workgroup: 128 registers, no spilled vector register
+    specd = log.replace("pg_kernels.", "pg_kernels_specd.")
+    if os.path.exists(specd):
+        du, cur = {}, None
+        for line in open(specd):
+            m = re.search(r"Function Name: (\w+)", line)
+            if m:
+                cur = m.group(1)
+                du[cur] = {}
+            for key in ("VGPRs", "ScratchSize [bytes/lane]", "VGPRs Spill"):
+                m = re.search(re.escape(key) + r": (\d+)", line)
+                if m and cur:
+                    du[cur].setdefault(key, int(m.group(1)))
+        for k, u in du.items():
+            assert u["VGPRs Spill"] == 0 and u["VGPRs"] <= 128, (k, u)
+        for k in ("pg_fast_dictrange_s_a", "pg_fast_dictrange_s_r", "pg_specd_scan_a", "pg_specd_index_a", "pg_specd_none_a"):
+            assert du[k]["ScratchSize [bytes/lane]"] == 0, (k, du[k])
     # round 5: the loader / consumer kernels — 12 wavefronts per workgroup, 3 per SIMD: 168 registers; three register sets of two tiles as
     # arrays spilled (1.89 ms against 1.44), and the DOUBLE variants of the wide pipeline no longer touch scratch memory
     spec = log.replace("pg_kernels.", "pg_kernels_spec.")
@@ -289,3 +306,19 @@ def test_jni_functions_under_a_fake_env_on_gpu():
     out = subprocess.run([binary], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "jni under the fake env ok" in out.stdout and "d=20 count=725" in out.stdout and "d=30 count=725" in out.stdout
+
+
+def test_library_exports_exactly_the_header():
+    """Boundary hygiene: the dynamic symbols of libpinot_gpu.so are the functions include/pinot_gpu.h declares — no kernel host
+    stub, no launch helper shared between translation units (pinot_amd/csrc/libpinot_gpu.map)."""
+    import os
+    import re
+    import subprocess
+    from pinot_amd import capi
+    lib = os.path.join(capi.REPO_ROOT, "pinot_amd", "csrc", "libpinot_gpu.so")
+    header = open(os.path.join(capi.REPO_ROOT, "include", "pinot_gpu.h")).read()
+    declared = set(re.findall(r"\b(pg_[a-z0-9_]+)\(", header))
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], check=True, capture_output=True, text=True).stdout
+    exported = {line.split()[-1].split("@")[0] for line in out.splitlines() if line.split()}
+    assert {s for s in exported if s.startswith("pg_")} == declared
+    assert not {s for s in exported if not s.startswith("pg_") and not s.startswith("_")}, exported - declared

@@ -9,7 +9,7 @@ while [ $# -ge 2 ]; do
   mk=$(echo "$flags" | grep -o 'PIPE_WAVES=[0-9]*' || true)   # make variable (wavefronts per workgroup of pg_fast_i32range_p), not a -D flag
   flags=${flags/$mk/}
   d=$(mktemp -d)
-  cp $R/pinot_amd/csrc/*.hip $R/pinot_amd/csrc/*.cpp $R/pinot_amd/csrc/*.h $R/pinot_amd/csrc/*.hpp $R/pinot_amd/csrc/Makefile $d/
+  cp $R/pinot_amd/csrc/*.map $R/pinot_amd/csrc/*.hip $R/pinot_amd/csrc/*.cpp $R/pinot_amd/csrc/*.h $R/pinot_amd/csrc/*.hpp $R/pinot_amd/csrc/Makefile $d/
   mkdir -p $d/../../include $d/synth; cp $R/include/pinot_gpu.h $d/../../include/ 2>/dev/null || true
   sed -i "s#\.\./\.\./include/pinot_gpu.h#$R/include/pinot_gpu.h#" $d/pg_internal.hpp $d/Makefile
   ld=$(echo "$flags" | grep -o -- '-fsanitize=[a-z,]*' | head -1 || true)   # sanitizer variants: the runtime is linked too
