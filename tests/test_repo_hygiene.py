@@ -34,25 +34,6 @@ def test_every_cited_profile_exists():
     assert not missing, sorted(set(missing))
 
 
-def test_wave_specialised_stage_layout_exports():
-    """pg_spec_stage_bytes (the host sizes the launch's LDS with it) = tiles per stage x (candidate dwords 256 + range bits 2048 + value column
-    8192 + per group column bits x 256 + 16), each tile rounded up to 16 bytes; the kernel runs 12 wavefronts per workgroup."""
-    lib = C.CDLL(capi.GPU_LIB_PATH)
-    lib.pg_spec_stage_bytes.restype = C.c_int
-    lib.pg_spec_stage_bytes.argtypes = [C.c_int, C.c_int]
-    assert C.c_int.in_dll(lib, "pg_spec_waves_per_block").value == 12
-
-    def tile(b0, b1):
-        n = 256 + 2048 + 8192 + b0 * 256 + 16 + (b1 * 256 + 16 if b1 > 0 else 0)
-        return (n + 15) & ~15
-    for b0 in range(1, 9):
-        for b1 in range(0, 9):
-            got = lib.pg_spec_stage_bytes(b0, b1)
-            assert got % tile(b0, b1) == 0 and got // tile(b0, b1) in (1, 2, 3, 4), (b0, b1, got)
-    # config 3 (one 7-bit key): table (100 groups x 2 accumulators x 32 replicas + trash) + two stages must fit the 152 KB the launch may ask for
-    assert 100 * 2 * 32 * 8 + 2 * 64 * 8 + 2 * lib.pg_spec_stage_bytes(7, 0) < 160 * 1024 - 8192
-
-
 def test_documents_cite_things_that_exist():
     """Test files, tool scripts and pg_* names (kernels, ABI functions, structs) the documents put in backticks exist in the tree."""
     src = ""
