@@ -86,7 +86,7 @@ struct Comm {
   DeviceBuffer scratch;   // merged image of a table (signature probe, accumulators, states) + gathered dictId sets
   // the probe, out and back: ncclMax over {sig, -sig, largest per-doc |value| of an int64 SUM, digit sums present, a rank refuses
   // (IEEE-double SUM)}; ncclSum over {full-scan entries, total docs}
-  int64_t probe[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t probe[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // [7 .. 9]: {key-space-free signature, its negation, a rank cannot re-key} (ncclMax)
   // One pg_result_all_reduce at a time per communicator: `probe` and `scratch` are per-communicator state, and two merges entering at
   // once would enqueue their collectives in different orders on different ranks (a hang in RCCL).  The CALLER serialises whole merges
   // across all ranks (GpuGroupByCombineOperator's COLLECTIVE lock); a per-communicator lock here could only deadlock two of them
@@ -149,6 +149,165 @@ void comm_destroy(Comm* c) {
   delete c;
 }
 
+// ---- value-keyed merge: segments with DIFFERENT group-by dictionaries (every real Pinot table: one dictionary per segment and column) -----
+// GroupByCombineOperator merges by VALUE for exactly that reason (GroupByCombineOperator.java:135-144 keys its IndexedTable by the groups'
+// values, DictionaryBasedGroupKeyGenerator.java:578-606 turns dictIds back into values before the merge).  Here: the ranks all-gather the
+// group-by columns' dictionaries (KBs), every rank builds the SAME sorted union per column, re-keys its dense table into the union's key space
+// on the device (pg_remap_table_kernel: one scatter) and the ordinary grouped all-reduce runs over the re-keyed tables.  The merged result
+// presents its groups by value (PG_GROUP_KEY_*_VALUES), as raw group-by columns do.
+//
+// The signature WITHOUT the key space (cardinalities, dictionary contents, table size): equal on all ranks <=> the tables differ at most in
+// their group-by dictionaries.
+static int64_t layout_signature(const DeviceTable& T) {
+  const PgQueryPlan& D = T.plan->dev;
+  uint64_t h = 1469598103934665603ULL;
+  auto mix = [&](uint64_t v) { h ^= v; h *= 1099511628211ULL; };
+  mix(0x756e696f6eULL); mix((uint64_t)D.n_ops); mix((uint64_t)T.n_group_by); mix((uint64_t)T.n_aggregations);
+  for (int o = 0; o < D.n_ops; o++) { mix((uint64_t)D.ops[o].fn); mix((uint64_t)D.ops[o].is_float); mix((uint64_t)(uint32_t)D.ops[o].limb); if (D.ops[o].src >= 0) mix((uint64_t)(uint32_t)D.srcs[D.ops[o].src].fx_q); }
+  for (size_t a = 0; a < T.plan->aggs.size(); a++) { mix((uint64_t)T.plan->aggs[a].function); mix((uint64_t)(uint32_t)T.plan->aggs[a].op_a); }
+  for (const Column* c : T.plan->group_cols) mix(c ? (uint64_t)c->data_type : 99u);
+  return (int64_t)(h >> 2);
+}
+// Can THIS rank's table be re-keyed: a dense key space over dictionary-encoded group-by columns of a type whose values order as bytes / numbers,
+// no auxiliary state indexed by group (HyperLogLog registers could follow, dictId sets of ANOTHER column's dictionary could not).
+static bool union_eligible(const DeviceTable& T) {
+  const CompiledPlan& P = *T.plan;
+  const PgQueryPlan& D = P.dev;
+  if (T.keys || T.n_group_by < 1 || T.n_group_by > PG_MAX_GROUP_COLS || D.n_aux != 0 || P.raw_group || D.mv) return false;
+  if (D.agg_mode == PG_AGG_RADIX_HASH || (int64_t)D.n_ops * (int64_t)std::max(D.n_groups, 1) != T.n_out) return false;
+  if ((int)P.group_cols.size() != T.n_group_by || (int)P.group_cards.size() != T.n_group_by) return false;
+  for (int j = 0; j < T.n_group_by; j++) {
+    const Column* c = P.group_cols[(size_t)j];
+    if (!c || !c->has_dictionary || c->is_mv || ((size_t)j < P.group_vdict.size() && P.group_vdict[(size_t)j])) return false;
+    if (c->data_type > PG_TYPE_BYTES || c->dict_bytes_per_value <= 0 || c->dict_host.size() != (size_t)c->cardinality * (size_t)c->dict_bytes_per_value) return false;
+    if (c->cardinality != P.group_cards[(size_t)j]) return false;
+  }
+  return true;
+}
+static inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3]; }
+static inline uint64_t be64(const uint8_t* p) { return ((uint64_t)be32(p) << 32) | be32(p + 4); }
+// one dictionary value as the key the union sorts by: numbers as order-preserving 64-bit keys (pg_vdict.hip's), strings as their bytes
+static uint64_t union_number_key(const uint8_t* p, int32_t data_type) {
+  if (data_type == PG_TYPE_INT) return (uint64_t)(int64_t)(int32_t)be32(p) ^ (1ULL << 63);
+  if (data_type == PG_TYPE_LONG) return be64(p) ^ (1ULL << 63);
+  if (data_type == PG_TYPE_FLOAT) { const uint32_t f = be32(p); return (uint64_t)((f >> 31) ? ~f : (f ^ 0x80000000u)); }
+  const uint64_t d = be64(p);
+  return (d >> 63) ? ~d : (d ^ (1ULL << 63));
+}
+// Steps 1-5 of the value-keyed merge; leaves T re-keyed (T.keys set, T.table / T.n_out in the union's key space).  Every decision is taken
+// from gathered data, so every rank takes it alike.
+static void union_key_space(DeviceTable& T, Comm& c, Rccl& R, hipStream_t stream) {
+  const CompiledPlan& P = *T.plan;
+  const PgQueryPlan& D = P.dev;
+  const int nc = T.n_group_by, W = c.world;
+  // ---- 1. cardinalities and value widths of every rank's dictionaries -----------------------------------------------------------------
+  const size_t meta_bytes = 64;   // 8 x {cardinality, bytes per value}
+  std::vector<int32_t> meta(16, 0);
+  for (int j = 0; j < nc; j++) { meta[(size_t)(2 * j)] = P.group_cols[(size_t)j]->cardinality; meta[(size_t)(2 * j + 1)] = P.group_cols[(size_t)j]->dict_bytes_per_value; }
+  if (c.scratch.size < meta_bytes * (size_t)(W + 1)) c.scratch.alloc(meta_bytes * (size_t)(W + 1) + 4096);
+  uint8_t* S = c.scratch.as<uint8_t>();
+  PG_HIP(hipMemcpyAsync(S, meta.data(), meta_bytes, hipMemcpyHostToDevice, stream));
+  PG_NCCL(R.AllGather(S, S + meta_bytes, meta_bytes, kNcclUint8, c.comm, stream));
+  std::vector<int32_t> all_meta((size_t)W * 16);
+  PG_HIP(hipMemcpyAsync(all_meta.data(), S + meta_bytes, meta_bytes * (size_t)W, hipMemcpyDeviceToHost, stream));
+  PG_HIP(hipStreamSynchronize(stream));
+  auto card_of = [&](int r, int j) { return (int64_t)all_meta[(size_t)r * 16 + (size_t)(2 * j)]; };
+  auto width_of = [&](int r, int j) { return (int64_t)all_meta[(size_t)r * 16 + (size_t)(2 * j + 1)]; };
+  // ---- 2. the dictionaries themselves, padded to the largest of each column ----------------------------------------------------------------
+  std::vector<size_t> col_off((size_t)nc + 1, 0);
+  for (int j = 0; j < nc; j++) {
+    int64_t mx = 0;
+    for (int r = 0; r < W; r++) {
+      if (card_of(r, j) <= 0 || width_of(r, j) <= 0) fail(PG_ERR_UNSUPPORTED, "pg_result_all_reduce: rank %d holds no dictionary for group-by column %d: merge on the host by values", r, j);
+      mx = std::max(mx, card_of(r, j) * width_of(r, j));
+    }
+    col_off[(size_t)j + 1] = col_off[(size_t)j] + (((size_t)mx + 15) & ~(size_t)15);
+  }
+  const size_t per_rank = col_off[(size_t)nc];
+  if (per_rank * (size_t)(W + 1) > ((size_t)1 << 30)) fail(PG_ERR_UNSUPPORTED, "pg_result_all_reduce: %zu bytes of group-by dictionaries per rank: merge on the host by values", per_rank);
+  if (c.scratch.size < per_rank * (size_t)(W + 1) + 64) c.scratch.alloc(per_rank * (size_t)(W + 1) + 4096);
+  S = c.scratch.as<uint8_t>();
+  std::vector<uint8_t> mine(per_rank, 0);
+  for (int j = 0; j < nc; j++) memcpy(mine.data() + col_off[(size_t)j], P.group_cols[(size_t)j]->dict_host.data(), P.group_cols[(size_t)j]->dict_host.size());
+  PG_HIP(hipMemcpyAsync(S, mine.data(), per_rank, hipMemcpyHostToDevice, stream));
+  PG_NCCL(R.AllGather(S, S + per_rank, per_rank, kNcclUint8, c.comm, stream));
+  std::vector<uint8_t> all(per_rank * (size_t)W);
+  PG_HIP(hipMemcpyAsync(all.data(), S + per_rank, per_rank * (size_t)W, hipMemcpyDeviceToHost, stream));
+  PG_HIP(hipStreamSynchronize(stream));
+  // ---- 3. the union per column (identical on every rank) and this rank's dictId -> union id maps ----------------------------------------------
+  auto keys = std::make_unique<UnionKeys>();
+  std::vector<int32_t> maps;
+  std::vector<int64_t> geo((size_t)nc * 3, 0);
+  int64_t G2 = 1;
+  for (int j = 0; j < nc; j++) {
+    const Column* mc = P.group_cols[(size_t)j];
+    const int32_t dt = mc->data_type;
+    auto u = std::make_unique<Column>();
+    u->name = mc->name;
+    u->data_type = dt;
+    const size_t map_at = maps.size();
+    maps.resize(map_at + (size_t)mc->cardinality);
+    if (dt <= PG_TYPE_DOUBLE) {
+      std::vector<uint64_t> ks;
+      for (int r = 0; r < W; r++) {
+        if (width_of(r, j) != (dt == PG_TYPE_INT || dt == PG_TYPE_FLOAT ? 4 : 8)) fail(PG_ERR_UNSUPPORTED, "pg_result_all_reduce: rank %d stores column %s %lld bytes wide", r, mc->name.c_str(), (long long)width_of(r, j));
+        const uint8_t* d = all.data() + (size_t)r * per_rank + col_off[(size_t)j];
+        for (int64_t i = 0; i < card_of(r, j); i++) ks.push_back(union_number_key(d + (size_t)i * (size_t)width_of(r, j), dt));
+      }
+      std::sort(ks.begin(), ks.end());
+      ks.erase(std::unique(ks.begin(), ks.end()), ks.end());
+      u->vdict_kind = dt == PG_TYPE_INT ? 0 : (dt == PG_TYPE_LONG ? 1 : (dt == PG_TYPE_FLOAT ? 2 : 3));
+      for (int32_t i = 0; i < mc->cardinality; i++) {
+        const uint64_t k = union_number_key(mc->dict_host.data() + (size_t)i * (size_t)mc->dict_bytes_per_value, dt);
+        maps[map_at + (size_t)i] = (int32_t)(std::lower_bound(ks.begin(), ks.end(), k) - ks.begin());
+      }
+      u->cardinality = (int32_t)ks.size();
+      u->vdict_keys = std::move(ks);
+    } else {   // STRING (entries padded with zero bytes: BaseImmutableDictionary) / BYTES: the values' bytes, ordered as unsigned bytes
+      std::vector<std::string> vs;
+      auto value_at = [&](const uint8_t* d, int64_t i, int64_t w) {
+        size_t n = (size_t)w;
+        if (dt == PG_TYPE_STRING) while (n > 0 && d[(size_t)i * (size_t)w + n - 1] == 0) n--;
+        return std::string(reinterpret_cast<const char*>(d + (size_t)i * (size_t)w), n);
+      };
+      for (int r = 0; r < W; r++) {
+        const uint8_t* d = all.data() + (size_t)r * per_rank + col_off[(size_t)j];
+        for (int64_t i = 0; i < card_of(r, j); i++) vs.push_back(value_at(d, i, width_of(r, j)));
+      }
+      std::sort(vs.begin(), vs.end());
+      vs.erase(std::unique(vs.begin(), vs.end()), vs.end());
+      u->vdict_kind = 4;
+      u->vdict_bytes_off.assign(1, 0);
+      for (const std::string& v : vs) { u->vdict_bytes.insert(u->vdict_bytes.end(), v.begin(), v.end()); u->vdict_bytes_off.push_back((int64_t)u->vdict_bytes.size()); }
+      for (int32_t i = 0; i < mc->cardinality; i++)
+        maps[map_at + (size_t)i] = (int32_t)(std::lower_bound(vs.begin(), vs.end(), value_at(mc->dict_host.data(), i, mc->dict_bytes_per_value)) - vs.begin());
+      u->cardinality = (int32_t)vs.size();
+    }
+    geo[(size_t)(3 * j)] = mc->cardinality;
+    geo[(size_t)(3 * j + 1)] = G2;
+    geo[(size_t)(3 * j + 2)] = (int64_t)map_at;
+    keys->cards.push_back(u->cardinality);
+    keys->mults.push_back(G2);
+    if (G2 > ((int64_t)1 << 40) / std::max(u->cardinality, 1)) G2 = (int64_t)1 << 40; else G2 *= u->cardinality;
+    keys->dicts.push_back(std::move(u));
+  }
+  // ---- 4. the union's dense table must stay a table ------------------------------------------------------------------------------------
+  if (G2 > ((int64_t)1 << 26) || (int64_t)D.n_ops * G2 > ((int64_t)1 << 27))
+    fail(PG_ERR_UNSUPPORTED, "pg_result_all_reduce: the union of the ranks' dictionaries spans %lld keys x %d accumulators: merge on the host by values", (long long)G2, D.n_ops);
+  keys->n_groups = G2;
+  // ---- 5. re-key this rank's table on the device ------------------------------------------------------------------------------------------
+  const int64_t G = std::max(D.n_groups, 1), n_out2 = (int64_t)D.n_ops * G2;
+  DeviceBuffer fresh;
+  fresh.alloc(((size_t)n_out2 + PG_MAX_STATS + 2) * 8 + 2 * 8);
+  DeviceBuffer dmaps = upload_vector(maps), dgeo = upload_vector(geo);
+  remap_table_on_stream(T.table.as<int64_t>(), fresh.as<int64_t>(), G, G2, D.n_ops, nc, dmaps.as<int32_t>(), dgeo.as<int64_t>(), P.ops_dev.as<PgAccOp>(), stream);
+  PG_HIP(hipMemcpyAsync(fresh.as<int64_t>() + n_out2, T.table.as<int64_t>() + T.n_out, (size_t)(PG_MAX_STATS + 2) * 8, hipMemcpyDeviceToDevice, stream));
+  PG_HIP(hipStreamSynchronize(stream));   // (the maps' buffers die with this scope)
+  T.table = std::move(fresh);
+  T.n_out = n_out2;
+  T.keys = std::move(keys);
+}
+
 // Every rank calls this with its own result of the same query.  Two launches:
 //   1. the probe — its shape does not depend on the table, so it is safe whatever the ranks hold: ncclMax on {sig, -sig} (the layout's
 //      signature, dictionary contents included), on the overflow guards of the summed accumulators {largest per-doc |value|, digit sums}
@@ -180,14 +339,16 @@ void result_all_reduce(Result& r, Comm& c) {
   int64_t refuse_local = 0;   // decided rank-locally, acted upon only after the probe (on the reduced flag)
   for (int o = 0; o < D.n_ops; o++)
     if (D.ops[o].fn == PG_ACC_SUM && D.ops[o].is_float == 1) refuse_local = 1;
+  if (T.keys) refuse_local = 1;   // already re-keyed by an earlier merge: further merges go by values on the host
   device_table_tail_store(T, stream);
-  const int64_t G = std::max(D.n_groups, 1);
-  const size_t n_table = (size_t)T.n_out + PG_MAX_STATS + 2;   // accumulators, statistics counters, {full-scan entries, total docs}
+  int64_t G = std::max(D.n_groups, 1);
+  size_t n_table = (size_t)T.n_out + PG_MAX_STATS + 2;   // accumulators, statistics counters, {full-scan entries, total docs}
   size_t set_bytes = 0;
   for (int x = 0; x < D.n_aux; x++) if (D.aux[x].kind == PG_AUX_DICT_SET) set_bytes += T.plan->aux_bytes[(size_t)x];
   // scratch: [probe 7 x int64 | pad to 64][table image][aux image][gathered sets x world]
-  const size_t off_table = 64, off_aux = off_table + n_table * 8, off_gather = (off_aux + T.aux_total + 63) & ~(size_t)63;
-  const size_t need = off_gather + set_bytes * (size_t)c.world + 64;
+  const size_t off_table = 128;
+  size_t off_aux = off_table + n_table * 8, off_gather = (off_aux + T.aux_total + 63) & ~(size_t)63;
+  size_t need = off_gather + set_bytes * (size_t)c.world + 64;
   if (c.scratch.size < need) c.scratch.alloc(need + need / 4);
   uint8_t* S = c.scratch.as<uint8_t>();
   int64_t* table = T.table.as<int64_t>();
@@ -198,23 +359,43 @@ void result_all_reduce(Result& r, Comm& c) {
   c.probe[2] = (int64_t)std::min<uint64_t>(T.sum_max_abs, (uint64_t)INT64_MAX);
   c.probe[3] = T.has_digit_sums ? 1 : 0;
   c.probe[4] = refuse_local;
+  const int64_t lsig = layout_signature(T);
+  c.probe[7] = lsig; c.probe[8] = -lsig;
+  c.probe[9] = union_eligible(T) ? 0 : 1;
   PG_HIP(hipMemcpyAsync(S, c.probe, 40, hipMemcpyHostToDevice, stream));
   PG_HIP(hipMemcpyAsync(S + 40, table + T.n_out + PG_MAX_STATS, 16, hipMemcpyDeviceToDevice, stream));   // {full-scan entries, total docs}
+  PG_HIP(hipMemcpyAsync(S + 56, c.probe + 7, 24, hipMemcpyHostToDevice, stream));
   PG_NCCL(R.GroupStart());
   PG_NCCL(R.AllReduce(S, S, 5, kNcclInt64, kNcclMax, c.comm, stream));
   PG_NCCL(R.AllReduce(S + 40, S + 40, 2, kNcclInt64, kNcclSum, c.comm, stream));
+  PG_NCCL(R.AllReduce(S + 56, S + 56, 3, kNcclInt64, kNcclMax, c.comm, stream));
   PG_NCCL(R.GroupEnd());
-  PG_HIP(hipMemcpyAsync(c.probe, S, 56, hipMemcpyDeviceToHost, stream));
+  PG_HIP(hipMemcpyAsync(c.probe, S, 80, hipMemcpyDeviceToHost, stream));
   PG_HIP(hipStreamSynchronize(stream));
-  // from here on every value is the same on every rank: all of them refuse, or none does
-  if (c.probe[0] != sig || c.probe[1] != -sig)
-    fail(PG_ERR_UNSUPPORTED, "pg_result_all_reduce: the ranks' results do not share their table layout (different key space, dictionaries, "
-                             "aggregations or fixed-point scale): merge on the host by values");
+  // from here on every value is the same on every rank: all of them refuse, all of them re-key, or none does
+  const bool same_layout = c.probe[0] == sig && c.probe[1] == -sig;
+  const bool same_but_keys = c.probe[7] == lsig && c.probe[8] == -lsig && c.probe[9] == 0;
+  if (!same_layout && !same_but_keys)
+    fail(PG_ERR_UNSUPPORTED, "pg_result_all_reduce: the ranks' results do not share their table layout (different aggregations, fixed-point scale, or a "
+                             "key space that does not re-key by value: hashed / raw / multi-value keys, distinct-count states): merge on the host by values");
   if (c.probe[4])
     fail(PG_ERR_UNSUPPORTED, "pg_result_all_reduce: a floating-point SUM accumulated in double (a column holding NaN / Inf) does not merge exactly");
   check_merge_bounds((uint64_t)c.probe[2], c.probe[3] != 0, c.probe[6]);
   T.sum_max_abs = (uint64_t)c.probe[2];   // the merged table's bound, for later merges
   T.has_digit_sums = c.probe[3] != 0;
+  if (!same_layout) {
+    // different group-by dictionaries: into the union's key space first (collective: two all-gathers), then the launch below as ever
+    union_key_space(T, c, R, stream);
+    G = T.keys->n_groups;
+    n_table = (size_t)T.n_out + PG_MAX_STATS + 2;
+    off_aux = off_table + n_table * 8;
+    off_gather = (off_aux + T.aux_total + 63) & ~(size_t)63;
+    need = off_gather + 64;
+    if (c.scratch.size < need) c.scratch.alloc(need + need / 4);
+    S = c.scratch.as<uint8_t>();
+    table = T.table.as<int64_t>();
+    image = reinterpret_cast<int64_t*>(S + off_table);
+  }
   // ---- 2. the table (every rank now known to hold the same layout) ------------------------------------------------------------------
   PG_NCCL(R.GroupStart());
   for (int o = 0; o < D.n_ops && T.n_out > 0; o++) {

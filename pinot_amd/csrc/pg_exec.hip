@@ -708,6 +708,7 @@ struct HostTable {
   const int64_t* admit_first = nullptr;
   int32_t admit_limit = 0;
   int64_t groups_found = -1;             // >= 0: the table was trimmed on the device; the groups the segment held before that
+  const UnionKeys* keys = nullptr;       // the table's key space is a union of several segments' dictionaries (DeviceTable::keys)
 };
 // What execute_query_impl does beside the plain query: stop after `doc_limit` docs of the doc space; hand the raw table over instead of
 // assembling groups; trim to numGroupsLimit by another pass's first docIds.
@@ -2012,7 +2013,14 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
   res.group_values.clear();
   res.aggs.clear();
   // ---- assemble groups: a group exists iff its hidden COUNT is > 0 (ArrayBasedHolder flags / map entries) ----------------
-  const int64_t G = hashed ? H.hash_groups : D.n_groups;   // hashed key space: the compact table of the groups found
+  const int64_t G = hashed ? H.hash_groups : (H.keys ? H.keys->n_groups : D.n_groups);   // hashed key space: the compact table of the groups found
+  // key space of the table: the plan's own (the segment's dictionaries), or the union a value-keyed merge built (pg_comm.cpp)
+  auto key_mult = [&](int j) -> int64_t { return H.keys ? H.keys->mults[(size_t)j] : D.gcols[j].mult; };
+  auto key_card = [&](int j) -> int32_t { return H.keys ? H.keys->cards[(size_t)j] : P.group_cards[(size_t)j]; };
+  auto key_vdict = [&](int j) -> const Column* {
+    if (H.keys) return H.keys->dicts[(size_t)j].get();
+    return (size_t)j < P.group_vdict.size() ? P.group_vdict[(size_t)j] : nullptr;
+  };
   const int64_t matched = (int64_t)H.stats[0];
   const bool ex_stats = P.exist_op == kCountFromStats;
   const int64_t* ex = ex_stats ? nullptr : table.data() + (size_t)P.exist_op * G;
@@ -2101,13 +2109,13 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
         continue;
       }
       const int j = ob.index;
-      const Column* vd = (size_t)j < P.group_vdict.size() ? P.group_vdict[(size_t)j] : nullptr;
+      const Column* vd = key_vdict(j);
       for (size_t i = 0; i < n; i++) {
         OV& v = vals[i * n_ob + k];
         v = OV{0, 0, 0.0, nullptr, 0};
         if (P.raw_group) { v.l = (int64_t)((uint64_t)H.hash_keys[(size_t)gids[i]] ^ (1ULL << 63)); continue; }
         const int64_t raw = hashed ? H.hash_keys[(size_t)gids[i]] : gids[i];
-        const int64_t id = (raw / D.gcols[j].mult) % P.group_cards[j];
+        const int64_t id = (raw / key_mult(j)) % key_card(j);
         if (!vd) { v.l = id; continue; }   // a sorted dictionary: dictIds order as the values do
         if (vd->vdict_kind == 4) {
           v.type = vd->data_type == PG_TYPE_STRING ? 3 : 2;
@@ -2170,9 +2178,9 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
     for (int32_t i = 0; i < ng; i++) res.group_values[0][(size_t)i] = (int64_t)((uint64_t)H.hash_keys[(size_t)gids[i]] ^ (1ULL << 63));
   }
   for (int j = 0; j < n_group_by && !P.raw_group; j++) {
-    int64_t mult = D.gcols[j].mult;
-    int32_t card = P.group_cards[j];
-    const Column* vd = (size_t)j < P.group_vdict.size() ? P.group_vdict[(size_t)j] : nullptr;
+    int64_t mult = key_mult(j);
+    int32_t card = key_card(j);
+    const Column* vd = key_vdict(j);
     if (vd && vd->vdict_kind == 4) {   // raw STRING / BYTES: the groups' byte strings from the virtual dictionary's values
       res.group_key_type[(size_t)j] = PG_GROUP_KEY_BYTES_VALUES;
       auto& bytes = res.group_bytes[(size_t)j];
@@ -2206,7 +2214,7 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
       continue;
     }
     auto& v = res.group_dict_ids[j];
-    if (!hashed && (int64_t)ng == G && G <= (int64_t)1 << 22) {   // every group of the key space exists: the columns' dictIds come from the plan's cache
+    if (!hashed && !H.keys && (int64_t)ng == G && G <= (int64_t)1 << 22) {   // every group of the key space exists: the columns' dictIds come from the plan's cache
       std::call_once(P.full_keys_once, [&] {
         P.full_keys.assign((size_t)n_group_by, {});
         for (int jj = 0; jj < n_group_by; jj++) {
@@ -2363,6 +2371,7 @@ void result_reassemble(Result& r) {
   H.total_docs = host_out[T.n_out + PG_MAX_STATS + 1];
   T.full_scan_entries = H.full_scan_entries;
   T.num_total_docs = H.total_docs;
+  H.keys = T.keys.get();
   assemble_result(r, *T.plan, T.n_group_by, T.n_aggregations, H);
 }
 
@@ -2431,6 +2440,34 @@ void device_table_tail_store(DeviceTable& T, hipStream_t stream) {   // full-sca
   PG_HIP(hipMemcpyAsync(T.table.as<int64_t>() + T.n_out + PG_MAX_STATS, T.tail_host, sizeof(T.tail_host), hipMemcpyHostToDevice, stream));
 }
 
+extern "C" __global__ void __launch_bounds__(256) pg_remap_fill_kernel(int64_t* __restrict__ dst, int64_t n_groups, int n_ops, const PgAccOp* __restrict__ ops) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_groups * n_ops) return;
+  const PgAccOp op = ops[i / n_groups];
+  dst[i] = pg_acc_identity(op.fn, op.is_float);
+}
+// group g of the plan's key space -> group of the union's: digit j of g through column j's dictId map (maps back to back, column 0 first)
+extern "C" __global__ void __launch_bounds__(256) pg_remap_table_kernel(const int64_t* __restrict__ src, int64_t* __restrict__ dst, int64_t G, int64_t G2,
+                                                                         int n_ops, int n_cols, const int32_t* __restrict__ maps, const int64_t* __restrict__ geo) {
+  // geo: per column {old cardinality, new multiplier, offset of its map}
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= G) return;
+  int64_t rest = g, g2 = 0;
+  for (int j = 0; j < n_cols; j++) {
+    const int64_t card = geo[3 * j], digit = rest % card;
+    rest /= card;
+    g2 += (int64_t)maps[geo[3 * j + 2] + digit] * geo[3 * j + 1];
+  }
+  for (int o = 0; o < n_ops; o++) dst[(int64_t)o * G2 + g2] = src[(int64_t)o * G + g];   // (a group that does not exist carries the identities)
+}
+// the value-keyed merge's re-keying (pg_comm.cpp, union_key_space): identities everywhere, then every group of the plan's key space to its place
+void remap_table_on_stream(const int64_t* src, int64_t* dst, int64_t G, int64_t G2, int n_ops, int n_cols, const int32_t* maps, const int64_t* geo,
+                           const PgAccOp* ops, hipStream_t stream) {
+  const int64_t n_out2 = (int64_t)n_ops * G2;
+  hipLaunchKernelGGL(pg_remap_fill_kernel, dim3((unsigned)((n_out2 + 255) / 256)), dim3(256), 0, stream, dst, G2, n_ops, ops);
+  hipLaunchKernelGGL(pg_remap_table_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, stream, src, dst, G, G2, n_ops, n_cols, maps, geo);
+  PG_HIP(hipGetLastError());
+}
 void merge_sets_on_stream(uint32_t* dst, const uint32_t* gathered, int64_t n_words, int n_src, hipStream_t stream) {
   hipLaunchKernelGGL(pg_merge_aux_kernel, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, stream, dst, gathered, n_words, n_src, 0);
   PG_HIP(hipGetLastError());
@@ -2441,6 +2478,7 @@ void result_merge(Result& dst, Result& src) {
   DeviceTable& A = *dst.dev;
   DeviceTable& B = *src.dev;
   if (A.device != B.device) fail(PG_ERR_INVALID_ARGUMENT, "pg_result_merge: results live on devices %d and %d (use pg_result_all_reduce across devices)", A.device, B.device);
+  if (A.keys || B.keys) fail(PG_ERR_UNSUPPORTED, "pg_result_merge: a table already merged by value (union key space) merges further on the host by values");
   if (table_signature(A) != table_signature(B))
     fail(PG_ERR_UNSUPPORTED, "pg_result_merge: the two results do not share their table layout (different key space, dictionaries or aggregations): merge on the host by values");
   // the larger of the two tables' per-doc magnitudes bounds the merged sums; the merged table keeps it for later merges

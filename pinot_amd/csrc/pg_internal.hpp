@@ -349,8 +349,19 @@ struct AggResult {
 };
 // What pg_result_merge / pg_result_all_reduce need to merge two results of the same query and to re-assemble the groups:
 // the dense accumulator table [n_ops][G] + the statistics counters + the DISTINCTCOUNT / HLL regions, left in HBM.
+// The key space of a table merged BY VALUE across segments whose group-by dictionaries differ (pg_comm.cpp, union_key_space): per group-by
+// column the sorted union of the ranks' dictionaries — kept as a virtual dictionary (Column::vdict_kind / vdict_keys / vdict_bytes), so the
+// assembly hands the groups' VALUES over as it does for raw group-by columns — and the dense layout over the unions' cardinalities
+// (column 0 least significant, as in the plan's own key space).
+struct UnionKeys {
+  std::vector<std::unique_ptr<Column>> dicts;
+  std::vector<int32_t> cards;
+  std::vector<int64_t> mults;
+  int64_t n_groups = 1;
+};
 struct DeviceTable {
   std::shared_ptr<CompiledPlan> plan;
+  std::unique_ptr<UnionKeys> keys;   // set once the table has been re-keyed by pg_result_all_reduce (null: the plan's own key space)
   int device = 0;
   int32_t n_group_by = 0, n_aggregations = 0;
   int64_t n_out = 0;            // n_ops * G int64 slots, followed by PG_MAX_STATS statistics counters
@@ -432,6 +443,8 @@ int64_t table_signature(const DeviceTable& T);
 void check_merge_bounds(uint64_t sum_max_abs, bool has_digit_sums, int64_t total_docs);
 void device_table_tail_store(DeviceTable& T, hipStream_t stream);
 void merge_sets_on_stream(uint32_t* dst, const uint32_t* gathered, int64_t n_words, int n_src, hipStream_t stream);
+void remap_table_on_stream(const int64_t* src, int64_t* dst, int64_t G, int64_t G2, int n_ops, int n_cols, const int32_t* maps, const int64_t* geo,
+                           const PgAccOp* ops, hipStream_t stream);
 hipStream_t thread_stream(int device);
 std::unique_ptr<DocIdSet> execute_filter(Segment& seg, const pg_filter_node* filter, int32_t flags = 0);   // flags: PG_QUERY_FLAG_NULL_HANDLING
 std::shared_ptr<CompiledPlan> get_plan(Segment& seg, const pg_filter_node* filter, const pg_query* q, int32_t flags = 0);   // cached, under seg.mu

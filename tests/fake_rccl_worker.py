@@ -87,7 +87,7 @@ def check_merges(api, ora_api, comms, world, columns, queries, docs):
 
 
 def check_refusals(api, comms, world):
-    """Ranks that disagree on a dictionary, on the kind of a SUM accumulator, or whose merged SUM could leave int64: EVERY rank gets
+    """Ranks that disagree on the dictionary behind a DISTINCTCOUNT's dictId sets, on the kind of a SUM accumulator, or whose merged SUM could leave int64: EVERY rank gets
     PG_ERR_UNSUPPORTED — the deviant is the LAST rank, so with world 8 seven ranks agree among themselves and must still refuse."""
     rng = np.random.default_rng(3)
     n = 40_000
@@ -104,8 +104,11 @@ def check_refusals(api, comms, world):
         "double sum on one rank": lambda last: seg_of(g_a, np.where(np.arange(n) == 7, np.nan, as_double), "b") if last else seg_of(g_a, as_double, "b"),
         "overflow bound": lambda last: seg_of(g_a, (small + (1 << 62) // n * 3).astype(np.int64), "c") if last else seg_of(g_a, small, "c"),
     }
-    q = "SELECT g, SUM(m), COUNT(*) FROM t GROUP BY g LIMIT 1000"
+    q_sum = "SELECT g, SUM(m), COUNT(*) FROM t GROUP BY g LIMIT 1000"
+    # (different group-by dictionaries alone no longer refuse: check_value_keyed_merges; dictId SETS over different dictionaries still do)
+    queries = {"dictionary": "SELECT g, DISTINCTCOUNT(g), COUNT(*) FROM t GROUP BY g LIMIT 1000"}
     for what, make in cases.items():
+        q = queries.get(what, q_sum)
         segs = [make(i == world - 1) for i in range(world)]
         results = [s.execute_native(q, keep_device_table=True) for s in segs]
         got = all_reduce_in_threads(results, comms)
@@ -115,6 +118,54 @@ def check_refusals(api, comms, world):
         for s in segs:
             s.destroy()
     return len(cases)
+
+
+def check_value_keyed_merges(api, ora_api, comms, world):
+    """Every rank's segment has dictionaries of its OWN (as every real Pinot segment does): partially overlapping, disjoint and of different
+    cardinalities, INT / LONG / DOUBLE / STRING group-by columns.  pg_result_all_reduce re-keys the tables into the union of the dictionaries
+    and merges by value: the rows equal GroupByCombineOperator over the oracle's blocks (GroupByCombineOperator.java:135-144,
+    IndexedTable.java:90-120) on every rank."""
+    rng = np.random.default_rng(11)
+    n = 30_000
+    shapes = {
+        "overlapping": lambda r: (30 * r, 50 + 7 * r),          # [30 r, 30 r + 50 + 7 r): neighbours share some values, cardinalities differ
+        "disjoint": lambda r: (1000 * r, 40),
+        "nested": lambda r: (0, 20 + 15 * r),                    # rank 0's dictionary is a prefix of every other
+    }
+    queries = [
+        "SELECT d, COUNT(*), SUM(m), MIN(v), MAX(v) FROM t GROUP BY d LIMIT 100000",
+        "SELECT s, d, COUNT(*), SUM(m) FROM t WHERE v < 700 GROUP BY s, d LIMIT 100000",
+        "SELECT l, AVG(m), MINMAXRANGE(v) FROM t GROUP BY l LIMIT 100000",
+        "SELECT f, s, MAX(m), COUNT(*) FROM t GROUP BY f, s LIMIT 100000",
+    ]
+    merged = 0
+    for what, shape in shapes.items():
+        hosts = []
+        for r in range(world):
+            lo, card = shape(r)
+            ids = rng.integers(lo, lo + card, n)
+            data = {"d": (ids * 3 - 17).astype(np.int32), "l": ids.astype(np.int64) * 10**10 - 5, "f": (ids % 23).astype(np.float64) / 4.0 - 1.5,
+                    "s": np.array([f"city_{x % 37:03d}_{'x' * (x % 5)}" for x in ids], dtype=object),
+                    "m": rng.integers(-10**6, 10**6, n).astype(np.int64), "v": rng.integers(0, 1000, n).astype(np.int32)}
+            hosts.append(build_segment(f"own_dicts_{what}_{r}", data, {"d": "INT", "l": "LONG", "f": "DOUBLE", "s": "STRING", "m": "LONG", "v": "INT"},
+                                       no_dictionary_columns=["m"]))
+        gpu = [NativeSegment(api, h, device=0) for h in hosts]
+        ora = [NativeSegment(ora_api, h) for h in hosts]
+        for q in queries:
+            results = execute_in_threads(gpu, q)
+            assert all_reduce_in_threads(results, comms) == [None] * world, (what, q)
+            oblocks = [o.execute(q) for o in ora]
+            expect = GroupByCombineOperator(oblocks).merge()
+            for r in results:
+                b = r.block()
+                assert b.rows() == expect, (what, q)
+                assert b.stats.num_docs_scanned == sum(x.stats.num_docs_scanned for x in oblocks)
+                assert b.stats.num_total_docs == n * world
+                r.free()
+            merged += 1
+        for s_ in gpu + ora:
+            s_.destroy()
+    return merged
 
 
 def main():
@@ -129,6 +180,7 @@ def main():
     merged = check_merges(api, ora_api, comms, world, synth.CFG3_COLUMNS, QUERIES, 60_013)
     merged += check_merges(api, ora_api, comms, world, synth.CFG5_COLUMNS, CFG5_QUERIES, 150_011)
     refused = check_refusals(api, comms, world)
+    value_keyed = check_value_keyed_merges(api, ora_api, comms, world)
     merged += check_merges(api, ora_api, comms, world, synth.CFG3_COLUMNS, [synth.QUERY_CFG3], 30_011)   # the communicator survives the refusals
     for c in comms:
         c.destroy()
@@ -150,7 +202,7 @@ def main():
     fake = C.CDLL(fake_path)
     for f in ("fake_rccl_lonely_ranks", "fake_rccl_mismatched_collectives", "fake_rccl_collectives"):
         getattr(fake, f).restype = C.c_int64
-    print(json.dumps({"world": world, "merged_queries": merged, "refusal_cases": refused, "lonely_ranks": fake.fake_rccl_lonely_ranks(),
+    print(json.dumps({"world": world, "merged_queries": merged, "refusal_cases": refused, "value_keyed_merges": value_keyed, "lonely_ranks": fake.fake_rccl_lonely_ranks(),
                       "mismatched_collectives": fake.fake_rccl_mismatched_collectives(), "collectives": fake.fake_rccl_collectives()}))
 
 
