@@ -151,13 +151,99 @@ void comm_destroy(Comm* c) {
 
 // ---- value-keyed merge: segments with DIFFERENT group-by dictionaries (every real Pinot table: one dictionary per segment and column) -----
 // GroupByCombineOperator merges by VALUE for exactly that reason (GroupByCombineOperator.java:135-144 keys its IndexedTable by the groups'
-// values, DictionaryBasedGroupKeyGenerator.java:578-606 turns dictIds back into values before the merge).  Here: the ranks all-gather the
-// group-by columns' dictionaries (KBs), every rank builds the SAME sorted union per column, re-keys its dense table into the union's key space
-// on the device (pg_remap_table_kernel: one scatter) and the ordinary grouped all-reduce runs over the re-keyed tables.  The merged result
-// presents its groups by value (PG_GROUP_KEY_*_VALUES), as raw group-by columns do.
-//
-// The signature WITHOUT the key space (cardinalities, dictionary contents, table size): equal on all ranks <=> the tables differ at most in
-// their group-by dictionaries.
+// values, DictionaryBasedGroupKeyGenerator.java:578-606 turns dictIds back into values before the merge).  Here a table's key space is
+// described by one KeyDict per group-by column — the sorted distinct VALUES its ids stand for, from the segment's dictionary or from the union
+// an earlier merge built; tables whose KeyDicts differ are re-keyed into the sorted union per column on the device (pg_remap_table_kernel:
+// one scatter) and then merge element-wise like tables that share their dictionaries: pg_result_merge for two tables of one GPU (the
+// segments of a server's GPU, folded one after the other), pg_result_all_reduce across GPUs (the KeyDicts all-gathered first).  A re-keyed
+// result presents its groups by value (PG_GROUP_KEY_*_VALUES), as raw group-by columns do.
+struct KeyDict {
+  int32_t data_type = 0;
+  std::vector<uint64_t> num;       // INT / LONG / FLOAT / DOUBLE: order-preserving 64-bit keys (pg_vdict.hip's), ascending
+  std::vector<std::string> str;    // STRING (padding stripped) / BYTES: the values' bytes, ascending as unsigned bytes
+  size_t size() const { return data_type <= PG_TYPE_DOUBLE ? num.size() : str.size(); }
+};
+static inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3]; }
+static inline uint64_t be64(const uint8_t* p) { return ((uint64_t)be32(p) << 32) | be32(p + 4); }
+static uint64_t number_key(const uint8_t* p, int32_t data_type) {
+  if (data_type == PG_TYPE_INT) return (uint64_t)(int64_t)(int32_t)be32(p) ^ (1ULL << 63);
+  if (data_type == PG_TYPE_LONG) return be64(p) ^ (1ULL << 63);
+  if (data_type == PG_TYPE_FLOAT) { const uint32_t f = be32(p); return (uint64_t)((f >> 31) ? ~f : (f ^ 0x80000000u)); }
+  const uint64_t d = be64(p);
+  return (d >> 63) ? ~d : (d ^ (1ULL << 63));
+}
+// the KeyDict behind group-by column j of a table, in the order of the table's ids (a segment's dictionary is sorted by value — for STRING
+// by String.compareTo, which is not byte order above U+FFFF —, so `order[id]` = position of id's value in the sorted KeyDict)
+static KeyDict key_dict_of(const DeviceTable& T, int j, std::vector<int32_t>* order) {
+  KeyDict k;
+  if (T.keys) {   // already a union: sorted by construction
+    const Column& u = *T.keys->dicts[(size_t)j];
+    k.data_type = u.data_type;
+    if (u.vdict_kind == 4) {
+      for (size_t i = 0; i + 1 < u.vdict_bytes_off.size(); i++)
+        k.str.emplace_back(reinterpret_cast<const char*>(u.vdict_bytes.data()) + u.vdict_bytes_off[i], (size_t)(u.vdict_bytes_off[i + 1] - u.vdict_bytes_off[i]));
+    } else {
+      k.num = u.vdict_keys;
+    }
+    if (order) { order->resize(k.size()); for (size_t i = 0; i < k.size(); i++) (*order)[i] = (int32_t)i; }
+    return k;
+  }
+  const Column& c = *T.plan->group_cols[(size_t)j];
+  k.data_type = c.data_type;
+  const size_t w = (size_t)c.dict_bytes_per_value;
+  std::vector<int32_t> ids((size_t)c.cardinality);
+  for (int32_t i = 0; i < c.cardinality; i++) ids[(size_t)i] = i;
+  if (c.data_type <= PG_TYPE_DOUBLE) {
+    std::vector<uint64_t> raw((size_t)c.cardinality);
+    for (int32_t i = 0; i < c.cardinality; i++) raw[(size_t)i] = number_key(c.dict_host.data() + (size_t)i * w, c.data_type);
+    std::sort(ids.begin(), ids.end(), [&](int32_t x, int32_t y) { return raw[(size_t)x] < raw[(size_t)y]; });
+    for (int32_t id : ids) k.num.push_back(raw[(size_t)id]);
+  } else {
+    std::vector<std::string> raw((size_t)c.cardinality);
+    for (int32_t i = 0; i < c.cardinality; i++) {
+      size_t n = w;
+      if (c.data_type == PG_TYPE_STRING) while (n > 0 && c.dict_host[(size_t)i * w + n - 1] == 0) n--;   // (BaseImmutableDictionary pads with zero bytes)
+      raw[(size_t)i].assign(reinterpret_cast<const char*>(c.dict_host.data()) + (size_t)i * w, n);
+    }
+    std::sort(ids.begin(), ids.end(), [&](int32_t x, int32_t y) { return raw[(size_t)x] < raw[(size_t)y]; });
+    for (int32_t id : ids) k.str.push_back(raw[(size_t)id]);
+  }
+  if (order) { order->assign((size_t)c.cardinality, 0); for (size_t pos = 0; pos < ids.size(); pos++) (*order)[(size_t)ids[pos]] = (int32_t)pos; }
+  return k;
+}
+static bool same_key_dict(const KeyDict& a, const KeyDict& b) { return a.data_type == b.data_type && a.num == b.num && a.str == b.str; }
+// the sorted union of several KeyDicts of one column, as the virtual dictionary the assembly reads
+static std::unique_ptr<Column> union_column(const std::vector<const KeyDict*>& parts, const std::string& name, KeyDict* merged) {
+  KeyDict u;
+  u.data_type = parts[0]->data_type;
+  for (const KeyDict* p : parts) {
+    if (p->data_type != u.data_type) fail(PG_ERR_UNSUPPORTED, "merge by value: column %s is stored with different types", name.c_str());
+    u.num.insert(u.num.end(), p->num.begin(), p->num.end());
+    u.str.insert(u.str.end(), p->str.begin(), p->str.end());
+  }
+  std::sort(u.num.begin(), u.num.end()); u.num.erase(std::unique(u.num.begin(), u.num.end()), u.num.end());
+  std::sort(u.str.begin(), u.str.end()); u.str.erase(std::unique(u.str.begin(), u.str.end()), u.str.end());
+  auto c = std::make_unique<Column>();
+  c->name = name;
+  c->data_type = u.data_type;
+  c->cardinality = (int32_t)u.size();
+  if (u.data_type <= PG_TYPE_DOUBLE) {
+    c->vdict_kind = u.data_type == PG_TYPE_INT ? 0 : (u.data_type == PG_TYPE_LONG ? 1 : (u.data_type == PG_TYPE_FLOAT ? 2 : 3));
+    c->vdict_keys = u.num;
+  } else {
+    c->vdict_kind = 4;
+    c->vdict_bytes_off.assign(1, 0);
+    for (const std::string& v : u.str) { c->vdict_bytes.insert(c->vdict_bytes.end(), v.begin(), v.end()); c->vdict_bytes_off.push_back((int64_t)c->vdict_bytes.size()); }
+  }
+  *merged = std::move(u);
+  return c;
+}
+static int32_t position_in(const KeyDict& u, const KeyDict& from, size_t i) {
+  if (u.data_type <= PG_TYPE_DOUBLE) return (int32_t)(std::lower_bound(u.num.begin(), u.num.end(), from.num[i]) - u.num.begin());
+  return (int32_t)(std::lower_bound(u.str.begin(), u.str.end(), from.str[i]) - u.str.begin());
+}
+// The signature WITHOUT the key space (cardinalities, dictionary contents, table size): equal <=> the tables differ at most in their
+// group-by dictionaries.
 static int64_t layout_signature(const DeviceTable& T) {
   const PgQueryPlan& D = T.plan->dev;
   uint64_t h = 1469598103934665603ULL;
@@ -168,14 +254,15 @@ static int64_t layout_signature(const DeviceTable& T) {
   for (const Column* c : T.plan->group_cols) mix(c ? (uint64_t)c->data_type : 99u);
   return (int64_t)(h >> 2);
 }
-// Can THIS rank's table be re-keyed: a dense key space over dictionary-encoded group-by columns of a type whose values order as bytes / numbers,
-// no auxiliary state indexed by group (HyperLogLog registers could follow, dictId sets of ANOTHER column's dictionary could not).
+// Can this table be re-keyed: a dense key space over dictionary-encoded group-by columns, no auxiliary state indexed by group or by another
+// column's dictIds (HyperLogLog registers could follow; dictId sets over different dictionaries could not).
 static bool union_eligible(const DeviceTable& T) {
   const CompiledPlan& P = *T.plan;
   const PgQueryPlan& D = P.dev;
-  if (T.keys || T.n_group_by < 1 || T.n_group_by > PG_MAX_GROUP_COLS || D.n_aux != 0 || P.raw_group || D.mv) return false;
-  if (D.agg_mode == PG_AGG_RADIX_HASH || (int64_t)D.n_ops * (int64_t)std::max(D.n_groups, 1) != T.n_out) return false;
+  if (T.n_group_by < 1 || T.n_group_by > PG_MAX_GROUP_COLS || D.n_aux != 0 || P.raw_group || D.mv || D.agg_mode == PG_AGG_RADIX_HASH) return false;
   if ((int)P.group_cols.size() != T.n_group_by || (int)P.group_cards.size() != T.n_group_by) return false;
+  if (T.keys) return (int64_t)D.n_ops * T.keys->n_groups == T.n_out;
+  if ((int64_t)D.n_ops * (int64_t)std::max(D.n_groups, 1) != T.n_out) return false;
   for (int j = 0; j < T.n_group_by; j++) {
     const Column* c = P.group_cols[(size_t)j];
     if (!c || !c->has_dictionary || c->is_mv || ((size_t)j < P.group_vdict.size() && P.group_vdict[(size_t)j])) return false;
@@ -184,119 +271,29 @@ static bool union_eligible(const DeviceTable& T) {
   }
   return true;
 }
-static inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | (uint32_t)p[3]; }
-static inline uint64_t be64(const uint8_t* p) { return ((uint64_t)be32(p) << 32) | be32(p + 4); }
-// one dictionary value as the key the union sorts by: numbers as order-preserving 64-bit keys (pg_vdict.hip's), strings as their bytes
-static uint64_t union_number_key(const uint8_t* p, int32_t data_type) {
-  if (data_type == PG_TYPE_INT) return (uint64_t)(int64_t)(int32_t)be32(p) ^ (1ULL << 63);
-  if (data_type == PG_TYPE_LONG) return be64(p) ^ (1ULL << 63);
-  if (data_type == PG_TYPE_FLOAT) { const uint32_t f = be32(p); return (uint64_t)((f >> 31) ? ~f : (f ^ 0x80000000u)); }
-  const uint64_t d = be64(p);
-  return (d >> 63) ? ~d : (d ^ (1ULL << 63));
-}
-// Steps 1-5 of the value-keyed merge; leaves T re-keyed (T.keys set, T.table / T.n_out in the union's key space).  Every decision is taken
-// from gathered data, so every rank takes it alike.
-static void union_key_space(DeviceTable& T, Comm& c, Rccl& R, hipStream_t stream) {
+// Re-keys T into the union key space `keys` (one union Column + merged KeyDict per column): every group of T's present key space to its place.
+static void rekey_table(DeviceTable& T, std::unique_ptr<UnionKeys> keys, const std::vector<KeyDict>& merged, hipStream_t stream) {
   const CompiledPlan& P = *T.plan;
   const PgQueryPlan& D = P.dev;
-  const int nc = T.n_group_by, W = c.world;
-  // ---- 1. cardinalities and value widths of every rank's dictionaries -----------------------------------------------------------------
-  const size_t meta_bytes = 64;   // 8 x {cardinality, bytes per value}
-  std::vector<int32_t> meta(16, 0);
-  for (int j = 0; j < nc; j++) { meta[(size_t)(2 * j)] = P.group_cols[(size_t)j]->cardinality; meta[(size_t)(2 * j + 1)] = P.group_cols[(size_t)j]->dict_bytes_per_value; }
-  if (c.scratch.size < meta_bytes * (size_t)(W + 1)) c.scratch.alloc(meta_bytes * (size_t)(W + 1) + 4096);
-  uint8_t* S = c.scratch.as<uint8_t>();
-  PG_HIP(hipMemcpyAsync(S, meta.data(), meta_bytes, hipMemcpyHostToDevice, stream));
-  PG_NCCL(R.AllGather(S, S + meta_bytes, meta_bytes, kNcclUint8, c.comm, stream));
-  std::vector<int32_t> all_meta((size_t)W * 16);
-  PG_HIP(hipMemcpyAsync(all_meta.data(), S + meta_bytes, meta_bytes * (size_t)W, hipMemcpyDeviceToHost, stream));
-  PG_HIP(hipStreamSynchronize(stream));
-  auto card_of = [&](int r, int j) { return (int64_t)all_meta[(size_t)r * 16 + (size_t)(2 * j)]; };
-  auto width_of = [&](int r, int j) { return (int64_t)all_meta[(size_t)r * 16 + (size_t)(2 * j + 1)]; };
-  // ---- 2. the dictionaries themselves, padded to the largest of each column ----------------------------------------------------------------
-  std::vector<size_t> col_off((size_t)nc + 1, 0);
-  for (int j = 0; j < nc; j++) {
-    int64_t mx = 0;
-    for (int r = 0; r < W; r++) {
-      if (card_of(r, j) <= 0 || width_of(r, j) <= 0) fail(PG_ERR_UNSUPPORTED, "pg_result_all_reduce: rank %d holds no dictionary for group-by column %d: merge on the host by values", r, j);
-      mx = std::max(mx, card_of(r, j) * width_of(r, j));
-    }
-    col_off[(size_t)j + 1] = col_off[(size_t)j] + (((size_t)mx + 15) & ~(size_t)15);
-  }
-  const size_t per_rank = col_off[(size_t)nc];
-  if (per_rank * (size_t)(W + 1) > ((size_t)1 << 30)) fail(PG_ERR_UNSUPPORTED, "pg_result_all_reduce: %zu bytes of group-by dictionaries per rank: merge on the host by values", per_rank);
-  if (c.scratch.size < per_rank * (size_t)(W + 1) + 64) c.scratch.alloc(per_rank * (size_t)(W + 1) + 4096);
-  S = c.scratch.as<uint8_t>();
-  std::vector<uint8_t> mine(per_rank, 0);
-  for (int j = 0; j < nc; j++) memcpy(mine.data() + col_off[(size_t)j], P.group_cols[(size_t)j]->dict_host.data(), P.group_cols[(size_t)j]->dict_host.size());
-  PG_HIP(hipMemcpyAsync(S, mine.data(), per_rank, hipMemcpyHostToDevice, stream));
-  PG_NCCL(R.AllGather(S, S + per_rank, per_rank, kNcclUint8, c.comm, stream));
-  std::vector<uint8_t> all(per_rank * (size_t)W);
-  PG_HIP(hipMemcpyAsync(all.data(), S + per_rank, per_rank * (size_t)W, hipMemcpyDeviceToHost, stream));
-  PG_HIP(hipStreamSynchronize(stream));
-  // ---- 3. the union per column (identical on every rank) and this rank's dictId -> union id maps ----------------------------------------------
-  auto keys = std::make_unique<UnionKeys>();
+  const int nc = T.n_group_by;
   std::vector<int32_t> maps;
   std::vector<int64_t> geo((size_t)nc * 3, 0);
-  int64_t G2 = 1;
+  int64_t G = 1;
   for (int j = 0; j < nc; j++) {
-    const Column* mc = P.group_cols[(size_t)j];
-    const int32_t dt = mc->data_type;
-    auto u = std::make_unique<Column>();
-    u->name = mc->name;
-    u->data_type = dt;
+    std::vector<int32_t> order;
+    const KeyDict mine = key_dict_of(T, j, &order);
     const size_t map_at = maps.size();
-    maps.resize(map_at + (size_t)mc->cardinality);
-    if (dt <= PG_TYPE_DOUBLE) {
-      std::vector<uint64_t> ks;
-      for (int r = 0; r < W; r++) {
-        if (width_of(r, j) != (dt == PG_TYPE_INT || dt == PG_TYPE_FLOAT ? 4 : 8)) fail(PG_ERR_UNSUPPORTED, "pg_result_all_reduce: rank %d stores column %s %lld bytes wide", r, mc->name.c_str(), (long long)width_of(r, j));
-        const uint8_t* d = all.data() + (size_t)r * per_rank + col_off[(size_t)j];
-        for (int64_t i = 0; i < card_of(r, j); i++) ks.push_back(union_number_key(d + (size_t)i * (size_t)width_of(r, j), dt));
-      }
-      std::sort(ks.begin(), ks.end());
-      ks.erase(std::unique(ks.begin(), ks.end()), ks.end());
-      u->vdict_kind = dt == PG_TYPE_INT ? 0 : (dt == PG_TYPE_LONG ? 1 : (dt == PG_TYPE_FLOAT ? 2 : 3));
-      for (int32_t i = 0; i < mc->cardinality; i++) {
-        const uint64_t k = union_number_key(mc->dict_host.data() + (size_t)i * (size_t)mc->dict_bytes_per_value, dt);
-        maps[map_at + (size_t)i] = (int32_t)(std::lower_bound(ks.begin(), ks.end(), k) - ks.begin());
-      }
-      u->cardinality = (int32_t)ks.size();
-      u->vdict_keys = std::move(ks);
-    } else {   // STRING (entries padded with zero bytes: BaseImmutableDictionary) / BYTES: the values' bytes, ordered as unsigned bytes
-      std::vector<std::string> vs;
-      auto value_at = [&](const uint8_t* d, int64_t i, int64_t w) {
-        size_t n = (size_t)w;
-        if (dt == PG_TYPE_STRING) while (n > 0 && d[(size_t)i * (size_t)w + n - 1] == 0) n--;
-        return std::string(reinterpret_cast<const char*>(d + (size_t)i * (size_t)w), n);
-      };
-      for (int r = 0; r < W; r++) {
-        const uint8_t* d = all.data() + (size_t)r * per_rank + col_off[(size_t)j];
-        for (int64_t i = 0; i < card_of(r, j); i++) vs.push_back(value_at(d, i, width_of(r, j)));
-      }
-      std::sort(vs.begin(), vs.end());
-      vs.erase(std::unique(vs.begin(), vs.end()), vs.end());
-      u->vdict_kind = 4;
-      u->vdict_bytes_off.assign(1, 0);
-      for (const std::string& v : vs) { u->vdict_bytes.insert(u->vdict_bytes.end(), v.begin(), v.end()); u->vdict_bytes_off.push_back((int64_t)u->vdict_bytes.size()); }
-      for (int32_t i = 0; i < mc->cardinality; i++)
-        maps[map_at + (size_t)i] = (int32_t)(std::lower_bound(vs.begin(), vs.end(), value_at(mc->dict_host.data(), i, mc->dict_bytes_per_value)) - vs.begin());
-      u->cardinality = (int32_t)vs.size();
-    }
-    geo[(size_t)(3 * j)] = mc->cardinality;
-    geo[(size_t)(3 * j + 1)] = G2;
+    maps.resize(map_at + order.size());
+    std::vector<int32_t> pos(mine.size());
+    for (size_t i = 0; i < mine.size(); i++) pos[i] = position_in(merged[(size_t)j], mine, i);
+    for (size_t id = 0; id < order.size(); id++) maps[map_at + id] = pos[(size_t)order[id]];
+    geo[(size_t)(3 * j)] = (int64_t)order.size();
+    geo[(size_t)(3 * j + 1)] = keys->mults[(size_t)j];
     geo[(size_t)(3 * j + 2)] = (int64_t)map_at;
-    keys->cards.push_back(u->cardinality);
-    keys->mults.push_back(G2);
-    if (G2 > ((int64_t)1 << 40) / std::max(u->cardinality, 1)) G2 = (int64_t)1 << 40; else G2 *= u->cardinality;
-    keys->dicts.push_back(std::move(u));
+    G *= (int64_t)order.size();
   }
-  // ---- 4. the union's dense table must stay a table ------------------------------------------------------------------------------------
-  if (G2 > ((int64_t)1 << 26) || (int64_t)D.n_ops * G2 > ((int64_t)1 << 27))
-    fail(PG_ERR_UNSUPPORTED, "pg_result_all_reduce: the union of the ranks' dictionaries spans %lld keys x %d accumulators: merge on the host by values", (long long)G2, D.n_ops);
-  keys->n_groups = G2;
-  // ---- 5. re-key this rank's table on the device ------------------------------------------------------------------------------------------
-  const int64_t G = std::max(D.n_groups, 1), n_out2 = (int64_t)D.n_ops * G2;
+  const int64_t G2 = keys->n_groups, n_out2 = (int64_t)D.n_ops * G2;
+  if ((int64_t)D.n_ops * G != T.n_out) fail(PG_ERR_INTERNAL, "merge by value: table of %lld slots over a key space of %lld", (long long)T.n_out, (long long)G);
   DeviceBuffer fresh;
   fresh.alloc(((size_t)n_out2 + PG_MAX_STATS + 2) * 8 + 2 * 8);
   DeviceBuffer dmaps = upload_vector(maps), dgeo = upload_vector(geo);
@@ -306,6 +303,138 @@ static void union_key_space(DeviceTable& T, Comm& c, Rccl& R, hipStream_t stream
   T.table = std::move(fresh);
   T.n_out = n_out2;
   T.keys = std::move(keys);
+}
+// the union key space over several tables' KeyDicts per column ([table][column]); refuses (PG_ERR_UNSUPPORTED) where its dense table would
+// stop being a table — from the same inputs on every rank, so every rank refuses alike
+static std::unique_ptr<UnionKeys> union_of(const std::vector<std::vector<KeyDict>>& tables, const std::vector<std::string>& names, int n_ops, std::vector<KeyDict>* merged) {
+  auto keys = std::make_unique<UnionKeys>();
+  const size_t nc = names.size();
+  merged->resize(nc);
+  int64_t G2 = 1;
+  for (size_t j = 0; j < nc; j++) {
+    std::vector<const KeyDict*> parts;
+    for (const auto& t : tables) parts.push_back(&t[j]);
+    auto u = union_column(parts, names[j], &(*merged)[j]);
+    keys->cards.push_back(u->cardinality);
+    keys->mults.push_back(G2);
+    G2 = G2 > ((int64_t)1 << 40) / std::max(u->cardinality, 1) ? (int64_t)1 << 40 : G2 * u->cardinality;
+    keys->dicts.push_back(std::move(u));
+  }
+  if (G2 > ((int64_t)1 << 26) || (int64_t)n_ops * G2 > ((int64_t)1 << 27))
+    fail(PG_ERR_UNSUPPORTED, "merge by value: the union of the dictionaries spans %lld keys x %d accumulators: merge on the host by values", (long long)G2, n_ops);
+  keys->n_groups = G2;
+  return keys;
+}
+// pg_result_merge's part (pg_exec.hip calls it when the signatures differ): two tables of ONE device; true when both were brought into one key space
+bool merge_rekey_by_value(DeviceTable& A, DeviceTable& B, hipStream_t stream) {
+  if (layout_signature(A) != layout_signature(B) || !union_eligible(A) || !union_eligible(B)) return false;
+  const int nc = A.n_group_by;
+  std::vector<std::vector<KeyDict>> tables(2);
+  std::vector<std::string> names;
+  bool same = true;
+  for (int j = 0; j < nc; j++) {
+    tables[0].push_back(key_dict_of(A, j, nullptr));
+    tables[1].push_back(key_dict_of(B, j, nullptr));
+    names.push_back(A.plan->group_cols[(size_t)j]->name);
+    same = same && same_key_dict(tables[0][(size_t)j], tables[1][(size_t)j]);
+  }
+  (void)same;   // (equal values in another id order — an unsorted STRING dictionary above U+FFFF — still re-key: the ids differ)
+  std::vector<KeyDict> merged;
+  auto ka = union_of(tables, names, A.plan->dev.n_ops, &merged);
+  auto kb = std::make_unique<UnionKeys>();
+  for (int j = 0; j < nc; j++) {   // B gets its own copy of the union's columns
+    auto c = std::make_unique<Column>();
+    const Column& u = *ka->dicts[(size_t)j];
+    c->name = u.name; c->data_type = u.data_type; c->cardinality = u.cardinality; c->vdict_kind = u.vdict_kind;
+    c->vdict_keys = u.vdict_keys; c->vdict_bytes = u.vdict_bytes; c->vdict_bytes_off = u.vdict_bytes_off;
+    kb->dicts.push_back(std::move(c));
+  }
+  kb->cards = ka->cards; kb->mults = ka->mults; kb->n_groups = ka->n_groups;
+  rekey_table(A, std::move(ka), merged, stream);
+  rekey_table(B, std::move(kb), merged, stream);
+  return true;
+}
+// pg_result_all_reduce's part: the ranks' KeyDicts all-gathered (numbers as their 8-byte keys, strings length-prefixed and padded to the
+// longest), the union built on every rank alike, this rank's table re-keyed.  Every decision is taken from gathered data.
+static void union_key_space(DeviceTable& T, Comm& c, Rccl& R, hipStream_t stream) {
+  const int nc = T.n_group_by, W = c.world;
+  std::vector<KeyDict> mine;
+  std::vector<std::string> names;
+  for (int j = 0; j < nc; j++) { mine.push_back(key_dict_of(T, j, nullptr)); names.push_back(T.plan->group_cols[(size_t)j]->name); }
+  // ---- 1. per column {entries, bytes per entry} of every rank ------------------------------------------------------------------------------
+  const size_t meta_bytes = 64;   // 8 x {entries, width}
+  std::vector<int32_t> meta(16, 0);
+  for (int j = 0; j < nc; j++) {
+    size_t w = 8;
+    if (mine[(size_t)j].data_type > PG_TYPE_DOUBLE) { w = 4; for (const std::string& v : mine[(size_t)j].str) w = std::max(w, 4 + v.size()); w = (w + 3) & ~(size_t)3; }
+    meta[(size_t)(2 * j)] = (int32_t)mine[(size_t)j].size();
+    meta[(size_t)(2 * j + 1)] = (int32_t)w;
+  }
+  if (c.scratch.size < meta_bytes * (size_t)(W + 1)) c.scratch.alloc(meta_bytes * (size_t)(W + 1) + 4096);
+  uint8_t* S = c.scratch.as<uint8_t>();
+  PG_HIP(hipMemcpyAsync(S, meta.data(), meta_bytes, hipMemcpyHostToDevice, stream));
+  PG_NCCL(R.AllGather(S, S + meta_bytes, meta_bytes, kNcclUint8, c.comm, stream));
+  std::vector<int32_t> all_meta((size_t)W * 16);
+  PG_HIP(hipMemcpyAsync(all_meta.data(), S + meta_bytes, meta_bytes * (size_t)W, hipMemcpyDeviceToHost, stream));
+  PG_HIP(hipStreamSynchronize(stream));
+  auto card_of = [&](int r, int j) { return (int64_t)all_meta[(size_t)r * 16 + (size_t)(2 * j)]; };
+  auto width_of = [&](int r, int j) { return (int64_t)all_meta[(size_t)r * 16 + (size_t)(2 * j + 1)]; };
+  // ---- 2. the KeyDicts themselves, every column padded to its largest image -----------------------------------------------------------------
+  std::vector<size_t> col_off((size_t)nc + 1, 0);
+  for (int j = 0; j < nc; j++) {
+    int64_t mx = 0;
+    for (int r = 0; r < W; r++) mx = std::max(mx, card_of(r, j) * width_of(r, j));
+    col_off[(size_t)j + 1] = col_off[(size_t)j] + (((size_t)mx + 15) & ~(size_t)15);
+  }
+  const size_t per_rank = std::max<size_t>(col_off[(size_t)nc], 16);
+  if (per_rank * (size_t)(W + 1) > ((size_t)1 << 30)) fail(PG_ERR_UNSUPPORTED, "pg_result_all_reduce: %zu bytes of group-by dictionaries per rank: merge on the host by values", per_rank);
+  if (c.scratch.size < per_rank * (size_t)(W + 1) + 64) c.scratch.alloc(per_rank * (size_t)(W + 1) + 4096);
+  S = c.scratch.as<uint8_t>();
+  std::vector<uint8_t> image(per_rank, 0);
+  for (int j = 0; j < nc; j++) {
+    uint8_t* at = image.data() + col_off[(size_t)j];
+    const KeyDict& k = mine[(size_t)j];
+    if (k.data_type <= PG_TYPE_DOUBLE) {
+      if (!k.num.empty()) memcpy(at, k.num.data(), k.num.size() * 8);
+    } else {
+      const size_t w = (size_t)meta[(size_t)(2 * j + 1)];
+      for (size_t i = 0; i < k.str.size(); i++) {
+        const uint32_t n = (uint32_t)k.str[i].size();
+        memcpy(at + i * w, &n, 4);
+        memcpy(at + i * w + 4, k.str[i].data(), n);
+      }
+    }
+  }
+  PG_HIP(hipMemcpyAsync(S, image.data(), per_rank, hipMemcpyHostToDevice, stream));
+  PG_NCCL(R.AllGather(S, S + per_rank, per_rank, kNcclUint8, c.comm, stream));
+  std::vector<uint8_t> all(per_rank * (size_t)W);
+  PG_HIP(hipMemcpyAsync(all.data(), S + per_rank, per_rank * (size_t)W, hipMemcpyDeviceToHost, stream));
+  PG_HIP(hipStreamSynchronize(stream));
+  // ---- 3. the union (identical on every rank), 4. its bound, 5. this rank's table into it ---------------------------------------------------------
+  std::vector<std::vector<KeyDict>> tables((size_t)W);
+  for (int r = 0; r < W; r++)
+    for (int j = 0; j < nc; j++) {
+      KeyDict k;
+      k.data_type = mine[(size_t)j].data_type;
+      const uint8_t* at = all.data() + (size_t)r * per_rank + col_off[(size_t)j];
+      const int64_t n = card_of(r, j), w = width_of(r, j);
+      if (k.data_type <= PG_TYPE_DOUBLE) {
+        if (w != 8) fail(PG_ERR_UNSUPPORTED, "pg_result_all_reduce: rank %d describes column %s as strings", r, names[(size_t)j].c_str());
+        k.num.resize((size_t)n);
+        if (n) memcpy(k.num.data(), at, (size_t)n * 8);
+      } else {
+        for (int64_t i = 0; i < n; i++) {
+          uint32_t len;
+          memcpy(&len, at + (size_t)i * (size_t)w, 4);
+          if ((int64_t)len + 4 > w) fail(PG_ERR_INTERNAL, "pg_result_all_reduce: a gathered string of %u bytes in a %lld-byte slot", len, (long long)w);
+          k.str.emplace_back(reinterpret_cast<const char*>(at) + (size_t)i * (size_t)w + 4, len);
+        }
+      }
+      tables[(size_t)r].push_back(std::move(k));
+    }
+  std::vector<KeyDict> merged;
+  auto keys = union_of(tables, names, T.plan->dev.n_ops, &merged);
+  rekey_table(T, std::move(keys), merged, stream);
 }
 
 // Every rank calls this with its own result of the same query.  Two launches:
@@ -339,9 +468,8 @@ void result_all_reduce(Result& r, Comm& c) {
   int64_t refuse_local = 0;   // decided rank-locally, acted upon only after the probe (on the reduced flag)
   for (int o = 0; o < D.n_ops; o++)
     if (D.ops[o].fn == PG_ACC_SUM && D.ops[o].is_float == 1) refuse_local = 1;
-  if (T.keys) refuse_local = 1;   // already re-keyed by an earlier merge: further merges go by values on the host
   device_table_tail_store(T, stream);
-  int64_t G = std::max(D.n_groups, 1);
+  int64_t G = T.keys ? T.keys->n_groups : std::max(D.n_groups, 1);
   size_t n_table = (size_t)T.n_out + PG_MAX_STATS + 2;   // accumulators, statistics counters, {full-scan entries, total docs}
   size_t set_bytes = 0;
   for (int x = 0; x < D.n_aux; x++) if (D.aux[x].kind == PG_AUX_DICT_SET) set_bytes += T.plan->aux_bytes[(size_t)x];

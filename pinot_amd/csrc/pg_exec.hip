@@ -2422,6 +2422,15 @@ int64_t table_signature(const DeviceTable& T) {
   for (const Column* vd : T.plan->group_vdict) if (vd) mix(vd->vdict_hash);   // segment-local ids: only equal dictionaries merge
   // dictIds index the table (group-by columns) and the DISTINCTCOUNT sets: different dictionaries of equal cardinality must not merge
   for (uint64_t dh : T.plan->dict_hashes) mix(dh);
+  if (T.keys) {   // re-keyed by a merge by value: the union's values ARE the key space (two tables over the same union merge element-wise)
+    mix(0x6b657973ULL);
+    for (const auto& u : T.keys->dicts) {
+      mix((uint64_t)u->cardinality);
+      for (uint64_t k : u->vdict_keys) mix(k);
+      for (uint8_t b : u->vdict_bytes) mix(b);
+      for (int64_t o : u->vdict_bytes_off) mix((uint64_t)o);
+    }
+  }
   return (int64_t)(h >> 2);   // 62 bits: survives ncclMax / negation
 }
 // The plan-time guarantees of the accumulators hold per segment (docs x largest |value| < 2^63 for an int64 SUM; < 2^31 docs for
@@ -2478,9 +2487,11 @@ void result_merge(Result& dst, Result& src) {
   DeviceTable& A = *dst.dev;
   DeviceTable& B = *src.dev;
   if (A.device != B.device) fail(PG_ERR_INVALID_ARGUMENT, "pg_result_merge: results live on devices %d and %d (use pg_result_all_reduce across devices)", A.device, B.device);
-  if (A.keys || B.keys) fail(PG_ERR_UNSUPPORTED, "pg_result_merge: a table already merged by value (union key space) merges further on the host by values");
-  if (table_signature(A) != table_signature(B))
-    fail(PG_ERR_UNSUPPORTED, "pg_result_merge: the two results do not share their table layout (different key space, dictionaries or aggregations): merge on the host by values");
+  // segments of one table carry dictionaries of their own: tables that differ ONLY in their group-by dictionaries are re-keyed into the union
+  // of the dictionaries first (pg_comm.cpp, merge by value: GroupByCombineOperator.java:135-144), then merge element-wise like any others
+  if (table_signature(A) != table_signature(B) && !merge_rekey_by_value(A, B, ctx_on(A.device).stream))
+    fail(PG_ERR_UNSUPPORTED, "pg_result_merge: the two results do not share their table layout (different aggregations, or a key space that does not "
+                             "re-key by value: hashed / raw / multi-value keys, distinct-count states): merge on the host by values");
   // the larger of the two tables' per-doc magnitudes bounds the merged sums; the merged table keeps it for later merges
   const uint64_t merged_max_abs = std::max(A.sum_max_abs, B.sum_max_abs);
   const bool merged_digits = A.has_digit_sums || B.has_digit_sums;
@@ -2492,7 +2503,7 @@ void result_merge(Result& dst, Result& src) {
   device_table_tail_store(B, ctx.stream);
   const int64_t n_tail = PG_MAX_STATS + 2, n = A.n_out + n_tail;
   hipLaunchKernelGGL(pg_merge_tables_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx.stream, A.table.as<int64_t>(), B.table.as<int64_t>(),
-                     A.n_out, (int64_t)std::max(A.plan->dev.n_groups, 1), n_tail, A.plan->ops_dev.as<PgAccOp>());
+                     A.n_out, A.keys ? A.keys->n_groups : (int64_t)std::max(A.plan->dev.n_groups, 1), n_tail, A.plan->ops_dev.as<PgAccOp>());
   PG_HIP(hipGetLastError());
   size_t off = 0;
   for (int x = 0; x < A.plan->dev.n_aux; x++) {

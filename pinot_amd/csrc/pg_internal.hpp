@@ -443,6 +443,7 @@ int64_t table_signature(const DeviceTable& T);
 void check_merge_bounds(uint64_t sum_max_abs, bool has_digit_sums, int64_t total_docs);
 void device_table_tail_store(DeviceTable& T, hipStream_t stream);
 void merge_sets_on_stream(uint32_t* dst, const uint32_t* gathered, int64_t n_words, int n_src, hipStream_t stream);
+bool merge_rekey_by_value(DeviceTable& A, DeviceTable& B, hipStream_t stream);   // pg_comm.cpp: two tables of one device into the union of their group-by dictionaries
 void remap_table_on_stream(const int64_t* src, int64_t* dst, int64_t G, int64_t G2, int n_ops, int n_cols, const int32_t* maps, const int64_t* geo,
                            const PgAccOp* ops, hipStream_t stream);
 hipStream_t thread_stream(int device);

@@ -163,6 +163,23 @@ def check_value_keyed_merges(api, ora_api, comms, world):
                 assert b.stats.num_total_docs == n * world
                 r.free()
             merged += 1
+        # two segments per rank, folded on the rank's device first (pg_result_merge re-keys them), the re-keyed heads across the ranks after
+        # that: what a server with several segments per GPU does (GpuGroupByCombineOperator: fold per device, then the collective)
+        if what == "overlapping":
+            q = queries[1]
+            heads = []
+            for r in range(world):
+                a, b_ = gpu[r].execute_native(q, keep_device_table=True), gpu[(r + 1) % world].execute_native(q, keep_device_table=True)
+                a.merge(b_)
+                b_.free()
+                heads.append(a)
+            assert all_reduce_in_threads(heads, comms) == [None] * world, "re-keyed heads"
+            oblocks = [ora[r].execute(q) for r in range(world)] + [ora[(r + 1) % world].execute(q) for r in range(world)]
+            expect = GroupByCombineOperator(oblocks).merge()
+            for h_ in heads:
+                assert h_.block().rows() == expect
+                h_.free()
+            merged += 1
         for s_ in gpu + ora:
             s_.destroy()
     return merged

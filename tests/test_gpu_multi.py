@@ -221,6 +221,48 @@ def test_merge_refuses_mismatched_tables(gpu_api):
 
 
 @pytest.mark.gpu
+def test_merge_by_value_folds_segments_with_their_own_dictionaries(gpu_api, oracle_api):
+    """pg_result_merge over the segments of ONE GPU, each with dictionaries of its own (every real Pinot segment): the tables are re-keyed
+    into the union of the dictionaries and fold one after the other — GroupByCombineOperator over the oracle's blocks
+    (GroupByCombineOperator.java:135-144: the IndexedTable is keyed by the groups' values).  Tables that differ in more than their
+    dictionaries still refuse."""
+    from pinot_amd.segment import build_segment
+    rng = np.random.default_rng(23)
+    n, n_seg = 20_000, 5
+    hosts = []
+    for r in range(n_seg):
+        ids = rng.integers(25 * r, 25 * r + 40 + 9 * r, n)
+        data = {"d": (ids * 3 - 17).astype(np.int32), "s": np.array([f"city_{x % 31:03d}{'_z' * (x % 3)}" for x in ids], dtype=object),
+                "f": (ids % 19).astype(np.float32) / 2.0 - 3.0, "m": rng.integers(-10**6, 10**6, n).astype(np.int64), "v": rng.integers(0, 1000, n).astype(np.int32)}
+        hosts.append(build_segment(f"own_{r}", data, {"d": "INT", "s": "STRING", "f": "FLOAT", "m": "LONG", "v": "INT"}, no_dictionary_columns=["m"]))
+    gpu = [NativeSegment(gpu_api, h) for h in hosts]
+    ora = [NativeSegment(oracle_api, h) for h in hosts]
+    for q in ("SELECT d, COUNT(*), SUM(m), MIN(v), MAX(v) FROM t GROUP BY d LIMIT 100000",
+              "SELECT s, f, COUNT(*), AVG(m) FROM t WHERE v >= 100 GROUP BY s, f LIMIT 100000",
+              "SELECT f, d, MINMAXRANGE(v), SUM(m) FROM t GROUP BY f, d LIMIT 100000"):
+        results = [g.execute_native(q) for g in gpu]
+        for r in results[1:]:
+            results[0].merge(r)           # the first fold re-keys both tables, the later ones the newcomer (and the head, where its union grows)
+        oblocks = [o.execute(q) for o in ora]
+        b = results[0].block()
+        assert b.rows() == GroupByCombineOperator(oblocks).merge(), q
+        assert b.stats.num_docs_scanned == sum(x.stats.num_docs_scanned for x in oblocks)
+        assert b.stats.num_total_docs == n * n_seg
+        for r in results:
+            r.free()
+    # another aggregation list over different dictionaries: not a difference of dictionaries alone
+    a = gpu[0].execute_native("SELECT d, SUM(m) FROM t GROUP BY d LIMIT 100000")
+    c = gpu[1].execute_native("SELECT d, MAX(m) FROM t GROUP BY d LIMIT 100000")
+    with pytest.raises(capi.NativeError) as e:
+        a.merge(c)
+    assert e.value.status == capi.PG_ERR_UNSUPPORTED
+    a.free()
+    c.free()
+    for s_ in gpu + ora:
+        s_.destroy()
+
+
+@pytest.mark.gpu
 def test_device_ordinal_out_of_range(gpu_api):
     h = C.c_void_p()
     with pytest.raises(capi.NativeError) as e:
