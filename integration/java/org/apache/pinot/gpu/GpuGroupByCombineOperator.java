@@ -24,7 +24,6 @@ import java.util.concurrent.ExecutionException;
 import java.util.concurrent.atomic.AtomicReferenceArray;
 import java.util.concurrent.ExecutorService;
 import java.util.concurrent.Future;
-import java.util.concurrent.locks.ReentrantLock;
 import org.apache.pinot.core.common.Operator;
 import org.apache.pinot.core.operator.blocks.results.BaseResultsBlock;
 import org.apache.pinot.core.operator.combine.GroupByCombineOperator;
@@ -33,11 +32,11 @@ import org.apache.pinot.core.query.request.context.QueryContext;
 public class GpuGroupByCombineOperator extends GroupByCombineOperator {
   private static final String EXPLAIN_NAME = "GPU_COMBINE_GROUP_BY";
 
-  // One cross-GPU merge at a time per server: the communicators are per device and server-wide, pg_result_all_reduce keeps per-communicator
-  // state (probe, scratch) and every rank must enter the collectives of ONE query in the same order — two queries reducing at once would
-  // interleave them differently on different ranks, which RCCL leaves as a hang (ADVICE r4; the library now also fails loudly when a
-  // communicator is entered twice: pg_comm.cpp).  Held from the first submit until every rank's call has returned.
-  private static final ReentrantLock COLLECTIVE = new ReentrantLock();
+  // A cross-GPU merge holds ONE communicator set for its duration (GpuInstancePlanMaker#acquireCommunicators): pg_result_all_reduce keeps
+  // per-communicator state (probe, scratch) and every rank must enter the collectives of one merge on the same set — two merges on one set
+  // would interleave their collectives differently on different ranks, which RCCL leaves as a hang (the library refuses loudly when a
+  // communicator is entered twice: pg_comm.cpp).  A pool of K sets lets K merges proceed at once (VERDICT r5 #9); the set is handed back only
+  // after every rank's call has returned.
 
   private final List<Operator> _segmentOperators;
   private final ExecutorService _workers;
@@ -199,16 +198,22 @@ public class GpuGroupByCombineOperator extends GroupByCombineOperator {
       List<Future<?>> calls = new ArrayList<>();
       boolean reduced = true;
       RuntimeException collectiveFailed = null;
-      COLLECTIVE.lock();
+      long[] set;
+      try {
+        set = maker.acquireCommunicators();   // blocks while every set is inside a merge
+      } catch (InterruptedException e) {
+        Thread.currentThread().interrupt();
+        throw new RuntimeException(e);        // nothing has entered a collective yet: the caller frees the results
+      }
       try {
         for (Map.Entry<Integer, List<Integer>> e : headsOfDevice.entrySet()) {
           int head = e.getValue().get(0);
-          long comm = maker.communicatorOf(e.getKey());
+          long comm = set[maker.indexOfDevice(e.getKey())];
           ranks.add(head);
           calls.add(_workers.submit(() -> PinotGpu.resultAllReduce(results[head], comm)));
         }
         boolean interrupted = false;
-        for (Future<?> call : calls) {   // EVERY rank's call is waited for — through interrupts too — before the lock goes and before anything is thrown
+        for (Future<?> call : calls) {   // EVERY rank's call is waited for — through interrupts too — before the set goes back and before anything is thrown
           for (;;) {
             try {
               call.get();
@@ -234,7 +239,7 @@ public class GpuGroupByCombineOperator extends GroupByCombineOperator {
           }
         }
       } finally {
-        COLLECTIVE.unlock();
+        maker.releaseCommunicators(set);
       }
       if (collectiveFailed != null) {
         throw collectiveFailed;

@@ -273,6 +273,7 @@ struct CompiledPlan {
   // candidates of the scan leaf per 1000 docs as the last execution counted them (-1: never run) — pg_fast_i32range_s streams every column
   // whole, pg_fast_i32range_p skips the quads without candidates: which of the two runs follows what the plan's filter lets through
   mutable std::atomic<int> observed_candidate_permille{-1}, observed_match_permille{-1};
+  mutable std::atomic<uint64_t> last_used{0};   // the segment's plan cache evicts the plans used longest ago (pg_exec.hip, get_plan)
   int64_t full_scan_entries = 0;     // entries contributed by unmasked scans whose count is known (numDocs each)
   bool stats_exact = true;           // the kernels' own counters give numEntriesScannedInFilter (flat AND shapes, drained ORs)
   // otherwise: the physical filter tree and one filter-only plan per Scan / Inverted leaf — their match bitmaps feed the iterator

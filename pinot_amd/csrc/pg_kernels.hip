@@ -2529,12 +2529,13 @@ PG_KERNEL __global__ void __launch_bounds__(PG_BLOCK) pg_radix_aggregate_kernel(
 
 // registers of group g = bytewise max over the slices of g's bucket
 PG_KERNEL __global__ void __launch_bounds__(256) pg_radix_reduce_aux_kernel(const uint32_t* __restrict__ partials, uint32_t* __restrict__ out,
-                                                                              int slices, int64_t bucket_words, int64_t n_words) {
+                                                                              int slices, int64_t bucket_words, int64_t n_words, int bitwise_or) {
   const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= n_words) return;
   const int64_t b = w / bucket_words, l = w % bucket_words;
   uint32_t acc = 0;
-  for (int sl = 0; sl < slices; sl++) acc = bytemax4(acc, partials[(b * slices + sl) * bucket_words + l]);
+  if (bitwise_or) { for (int sl = 0; sl < slices; sl++) acc |= partials[(b * slices + sl) * bucket_words + l]; }   // dictId sets
+  else { for (int sl = 0; sl < slices; sl++) acc = bytemax4(acc, partials[(b * slices + sl) * bucket_words + l]); }
   out[w] = acc;
 }
 

@@ -1203,6 +1203,7 @@ static bool plan_partition_v2(CompiledPlan& P, PgQueryPlan& D, const std::vector
   if ((int)srcs.size() > PG_MAX_RADIX_SRCS) return false;
   int64_t per_group = (int64_t)ops.size() * 8;
   for (int x = 0; x < D.n_aux; x++) {
+    if (D.aux[x].kind == PG_AUX_DICT_SET && D.n_aux == 1) { per_group += (int64_t)D.aux[x].stride * 4; continue; }   // a DISTINCTCOUNT's dictId sets: words as they are
     if (D.aux[x].kind != PG_AUX_HLL_DICT && D.aux[x].kind != PG_AUX_HLL_RAW) return false;
     per_group += (int64_t)4 << D.aux[x].log2m;
   }
@@ -1226,7 +1227,10 @@ static bool plan_partition_v2(CompiledPlan& P, PgQueryPlan& D, const std::vector
     Field f{0, 0, 0};
     D.pk_hll[si] = 0;
     D.pk_affine[si] = 0;
-    if (n_aux_here == 1) {
+    if (n_aux_here == 1 && D.aux[0].kind == PG_AUX_DICT_SET) {
+      if (!(c->col_kind == PG_COL_FIXED_BIT && c->has_dictionary && c->bits <= 24)) return false;
+      f = {PG_P2_F_DICTID, c->bits, 0};
+    } else if (n_aux_here == 1) {
       if (!(c->val_type == PG_V_I32 || c->val_type == PG_V_I64) && c->has_dictionary) return false;   // dictionary LUTs exist for any type, but keep to what is tested
       if (!c->has_dictionary && c->data_type > PG_TYPE_DOUBLE) return false;
       if (!c->has_dictionary && (c->val_type == PG_V_F32 || c->val_type == PG_V_F64)) return false;     // Float / Double offers hash other bits: HBM-register path
@@ -1902,9 +1906,18 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
   if (q->n_group_by > 0 && D.n_aux > 0 && D.n_ops > 0 && !D.mv && !knobs().no_radix && !knobs().no_radix_aux) {
     int64_t per_group = (int64_t)D.n_ops * 8, state_bytes = 0;
     bool ok = (int)srcs.size() <= PG_MAX_RADIX_SRCS;
+    // ... and DISTINCTCOUNT's dictId sets (round 6): ONE set op over a <= 24-bit dictionary column next to COUNTs only — the tuple carries the
+    // dictId, the aggregation pass ORs bits into the bucket's sets in LDS (pg_p2_aggregate_1set); a group's set must fit one workgroup's LDS
+    bool set_radix = D.n_aux == 1 && D.aux[0].kind == PG_AUX_DICT_SET && !knobs().no_p2 && P.first_doc_op < 0;
+    if (set_radix) {
+      const Column* c = srcs[(size_t)D.aux[0].src];
+      set_radix = c->has_dictionary && !c->is_mv && c->col_kind == PG_COL_FIXED_BIT && c->bits <= 24 && (int64_t)D.aux[0].stride * 4 + 8 * (int64_t)D.n_ops <= kLdsTableBudget - (int64_t)PG_P2_LIST * 4 - 256;
+      for (auto& o : sorted_ops) set_radix = set_radix && o.src < 0 && o.fn == PG_ACC_COUNT;
+    }
     for (int x = 0; x < D.n_aux && ok; x++) {
       const PgAuxOp& A = D.aux[x];
       const Column* c = srcs[(size_t)A.src];
+      if (set_radix) { per_group += (int64_t)A.stride * 4; state_bytes += G * (int64_t)A.stride * 4; continue; }
       ok = (A.kind == PG_AUX_HLL_DICT || A.kind == PG_AUX_HLL_RAW) && (c->val_type == PG_V_I32 || c->val_type == PG_V_I64) && A.log2m <= 10;
       per_group += A.stride;
       state_bytes += G * (int64_t)A.stride;
@@ -1916,6 +1929,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
       const double cost_radix = 4.0 + sel * ((4.0 + 8.0 * (double)srcs.size()) * 0.25 + (double)D.n_ops * 0.95 + (double)D.n_aux * 1.5);
       const double cost_hbm = 1.25 + sel * (double)D.n_aux * 20.0;
       hll_radix = buckets <= PG_MAX_RADIX_BUCKETS && cost_radix < cost_hbm;
+      if (set_radix) hll_radix = hll_radix && buckets <= PG_P2_MAX_BUCKETS;   // (only the partition pipeline v2 aggregates sets)
     }
   }
   if (D.n_ops == 0 && D.n_aux == 0) {
@@ -1981,7 +1995,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
   if (D.agg_mode == PG_AGG_LDS_PART) P.lds_bytes += (size_t)D.part_groups * D.n_ops * 8;
   if (D.agg_mode == PG_AGG_RADIX) {
     P.lds_bytes += ((size_t)D.n_ops << D.radix_shift) * 8;
-    for (int x = 0; x < D.n_aux; x++) P.lds_bytes += ((size_t)D.aux[x].stride << D.radix_shift) * (D.p2 ? 4 : 1);   // p2: one dword per register
+    for (int x = 0; x < D.n_aux; x++) P.lds_bytes += ((size_t)D.aux[x].stride << D.radix_shift) * (D.p2 || D.aux[x].kind == PG_AUX_DICT_SET ? 4 : 1);   // p2: one dword per register; sets: words
     if (D.p2) P.lds_bytes += (size_t)PG_P2_LIST * 4;
   }
   // auxiliary regions (HBM): sizes per op, patched into the plan at execution
@@ -2122,6 +2136,20 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     } else {
       D.pipe_vscan = -1;
     }
+  }
+  // The candidate rate of the index program is known at plan time — posting cardinalities are exact, an AND over columns multiplies them (the
+  // reference orders an AND's children by the same numbers, AndDocIdSet.java:110) — so a plan's FIRST execution already takes the kernel its
+  // filter calls for (pg_fast_i32range_s streams everything, _p skips quads without candidates: pg_exec.hip, spec_shape); later executions
+  // replace the estimate with what the kernels counted.
+  if ((D.pipe_fit || D.pipe_general) && seg.total_docs > 0) {
+    std::function<double(const FilterOp&)> index_rate = [&](const FilterOp& op) -> double {
+      if (op.kind == OpKind::Scan) return 1.0;
+      if (op.kind == OpKind::And) { double s = 1.0; for (auto& ch : op.children) s *= index_rate(*ch); return s; }
+      return estimate_selectivity(op, (double)seg.total_docs);
+    };
+    const double cand = std::min(1.0, std::max(0.0, index_rate(*root)));
+    P.observed_candidate_permille.store((int)(cand * 1000.0 + 0.5), std::memory_order_relaxed);
+    P.observed_match_permille.store((int)(std::min(1.0, estimate_selectivity(*root, (double)seg.total_docs)) * 1000.0 + 0.5), std::memory_order_relaxed);
   }
   // pg_fast_dictrange_s family (pg_kernels_specd.hip, round 6): the same shapes — [dense index program] [AND one range scan] [AND the upsert
   // snapshot], one or two <= 8-bit group columns, integer accumulators over ONE INT column — where the scan column and / or the value column is

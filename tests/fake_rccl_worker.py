@@ -185,6 +185,43 @@ def check_value_keyed_merges(api, ora_api, comms, world):
     return merged
 
 
+def check_concurrent_sets(api, ora_api, world, n_sets=4):
+    """A pool of communicator sets (pg_comm_init_all x K): K cross-GPU merges proceed AT ONCE, each on a set of its own — the threading
+    contract of BaseCombineOperator.java:97-142 for merged queries (GpuGroupByCombineOperator takes a set from the pool per merge).  Every
+    merge's rows equal GroupByCombineOperator over the oracle's blocks; the double counts no lonely rank and no mismatched collective."""
+    sets = [Comm.init_all(api, [0] * world) for _ in range(n_sets)]
+    hosts = [synth.generate_segment(40_009 + 13 * i, segment_index=i, columns=synth.CFG3_COLUMNS) for i in range(world)]
+    gpu = [NativeSegment(api, h, device=0) for h in hosts]
+    ora = [NativeSegment(ora_api, h) for h in hosts]
+    queries = [QUERIES[k % len(QUERIES)] for k in range(n_sets)]
+    expect = [GroupByCombineOperator([o.execute(q) for o in ora]).merge() for q in queries]
+    errors = []
+
+    def one_merge(k):
+        try:
+            for _ in range(3):
+                results = execute_in_threads(gpu, queries[k])
+                assert all_reduce_in_threads(results, sets[k]) == [None] * world, k
+                for r in results:
+                    assert r.block().rows() == expect[k], k
+                    r.free()
+        except Exception as e:   # noqa: BLE001
+            errors.append((k, repr(e)))
+    ts = [threading.Thread(target=one_merge, args=(k,)) for k in range(n_sets)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=600)
+    assert not any(t.is_alive() for t in ts), "a merge is stuck"
+    assert not errors, errors
+    for s_ in gpu + ora:
+        s_.destroy()
+    for cs in sets:
+        for c in cs:
+            c.destroy()
+    return n_sets * 3
+
+
 def main():
     world = int(sys.argv[1])
     fake_path = os.environ["PG_RCCL_LIBRARY"]
@@ -198,6 +235,7 @@ def main():
     merged += check_merges(api, ora_api, comms, world, synth.CFG5_COLUMNS, CFG5_QUERIES, 150_011)
     refused = check_refusals(api, comms, world)
     value_keyed = check_value_keyed_merges(api, ora_api, comms, world)
+    concurrent = check_concurrent_sets(api, ora_api, world)
     merged += check_merges(api, ora_api, comms, world, synth.CFG3_COLUMNS, [synth.QUERY_CFG3], 30_011)   # the communicator survives the refusals
     for c in comms:
         c.destroy()
@@ -219,7 +257,7 @@ def main():
     fake = C.CDLL(fake_path)
     for f in ("fake_rccl_lonely_ranks", "fake_rccl_mismatched_collectives", "fake_rccl_collectives"):
         getattr(fake, f).restype = C.c_int64
-    print(json.dumps({"world": world, "merged_queries": merged, "refusal_cases": refused, "value_keyed_merges": value_keyed, "lonely_ranks": fake.fake_rccl_lonely_ranks(),
+    print(json.dumps({"world": world, "merged_queries": merged, "refusal_cases": refused, "value_keyed_merges": value_keyed, "concurrent_merges": concurrent, "lonely_ranks": fake.fake_rccl_lonely_ranks(),
                       "mismatched_collectives": fake.fake_rccl_mismatched_collectives(), "collectives": fake.fake_rccl_collectives()}))
 
 

@@ -30,6 +30,7 @@ def test_all_reduce_ranks_on_one_device(world):
     assert line["merged_queries"] == 7 + 3 + 1 + 1 and line["refusal_cases"] == 3
     # per-rank dictionaries (overlapping / disjoint / nested) x four group-by shapes merged by value, + once with heads that pg_result_merge re-keyed
     assert line["value_keyed_merges"] == 3 * 4 + 1
+    assert line["concurrent_merges"] == 4 * 3   # four communicator sets, four merges at once, three times each
     assert line["lonely_ranks"] == 0, "a rank entered a collective alone (real RCCL would have hung)"
     assert line["mismatched_collectives"] == 0, "the ranks enqueued different collectives in one launch"
     # per merged query: the probe (2 collectives) + the table launch; per refusal: the probe only

@@ -79,7 +79,9 @@ def test_headline_specialisations_match_oracle(pair, sql, kernel):
     if kernel == SCAN and not os.environ.get("PG_NO_SCAN_PIPE"):
         assert gb.stats.kernel.decode() == kernel                   # no index involved: every segment size takes it
     elif kernel and knobs_off and gb.stats.num_total_docs >= 65536:   # small segments keep sparse (CSR) postings: the interpreted leaves
-        assert gb.stats.kernel.decode() == kernel
+        # (the headline shape: the loader / consumer kernel where the index program lets >= 15 % of the docs through — known at plan time from
+        # the postings' cardinalities since round 6 —, the pipelined one below that)
+        assert gb.stats.kernel.decode() in ((kernel, "pg_fast_i32range_s") if kernel == PIPE else (kernel,))
 
 
 # ---- behind an upsert queryableDocIds snapshot (FilterPlanNode.run's outer AND): the same pipeline with the snapshot's bitmap ANDed in after

@@ -6,10 +6,12 @@ minimum; several planes with whole 32- and 64-bit values; the docId plane of num
 Reference semantics: DictionaryBasedGroupKeyGenerator.java:416-446 (map-based holders), DefaultGroupByExecutor.java:191-220,
 DistinctCountHLLAggregationFunction.java:152-222 — bit-exact counts, group keys, MIN / MAX, integer SUMs, HyperLogLog registers.
 """
+import os
+
 import numpy as np
 import pytest
 
-from pinot_amd import synth
+from pinot_amd import capi, synth
 from pinot_amd.executor import NativeSegment
 from pinot_amd.query import parse_sql
 from pinot_amd.segment import build_segment
@@ -280,5 +282,34 @@ def test_limit_by_prefix(gpu_api, oracle_api, gpu_knobs, pattern, limit):
     g = NativeSegment(gpu_api, host)
     for q, want in zip(qs, rows):
         assert run(g, o, q, limit=limit, kernel=expect).rows() == want
+    g.destroy()
+    o.destroy()
+
+
+# ---- DISTINCTCOUNT whose dictId sets exceed one LDS (round 6): tuples (key, dictId) through the scatter, sets ORed in LDS per bucket -------------
+DISTINCT_SHAPES = [
+    ("SELECT h1, DISTINCTCOUNT(u) FROM gpuBench GROUP BY h1 LIMIT 100", "pg_part_group_by"),                       # 16 groups x 2^20-bit sets: one group per bucket
+    ("SELECT h1, DISTINCTCOUNT(u), COUNT(*) FROM gpuBench GROUP BY h1 LIMIT 100", "pg_part_group_by"),
+    ("SELECT h1, h2, COUNT(*), DISTINCTCOUNT(u) FROM gpuBench WHERE h3 < 7 GROUP BY h1, h2 LIMIT 1000", "pg_part_group_by"),   # 160 buckets behind a filter pass
+    ("SELECT h4, DISTINCTCOUNT(u) FROM gpuBench WHERE u BETWEEN 1000 AND 500000 AND h2 IN (1, 3, 5) GROUP BY h4 LIMIT 100", "pg_part_group_by"),
+    ("SELECT h1, DISTINCTCOUNT(u), SUM(h2) FROM gpuBench GROUP BY h1 LIMIT 100", None),                             # another accumulator beside it: the older route
+]
+
+
+@pytest.mark.parametrize("n", [1, 2049, 70_001, 1_500_003])
+def test_distinctcount_sets_through_the_partition_pipeline(gpu_api, oracle_api, n):
+    """BaseDistinctAggregateAggregationFunction.java:306-345: a dictId set per group; the GPU's sets (and COUNTs) equal the oracle's at every
+    size around the scatter's rounds, and the final values with PG_QUERY_FLAG_FINAL_DISTINCT equal the sets' sizes."""
+    host = synth.generate_segment(n, segment_index=6, columns=synth.CFG5_COLUMNS, native=(n > 200_000))
+    g, o = both(gpu_api, oracle_api, host)
+    for sql, kernel in DISTINCT_SHAPES:
+        gb = run(g, o, sql, kernel=kernel if n >= 70_001 and not os.environ.get("PG_NO_P2") else None)
+        qf = parse_sql(sql)
+        qf.flags |= capi.QUERY_FLAG_FINAL_DISTINCT
+        fb = g.execute(qf)
+        assert fb.rows().keys() == gb.rows().keys()
+        a = [i for i, s in enumerate(qf.aggregations) if s.function == "DISTINCTCOUNT"][0]
+        for k, v in gb.rows().items():
+            assert fb.rows()[k][a] == len(v[a]), (sql, k)
     g.destroy()
     o.destroy()
