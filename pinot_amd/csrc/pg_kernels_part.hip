@@ -1296,6 +1296,9 @@ extern "C" __global__ void __launch_bounds__(PG_P2_AGG_THREADS) pg_p2_aggregate_
     const uint32_t lo_i = bstart + sl * per;
     uint32_t hi_i = lo_i + per;
     if (hi_i > bend) hi_i = bend;
+    // one group per bucket (a 2^20-value dictionary's set fills the LDS): every tuple of the work item counts for the SAME slot — 64 lanes
+    // on one address are served one after the other (0.33 of the pass's 0.75 ms per 2 x 10^8 docs): counted in a register, added once
+    uint32_t my_count = 0;
     auto consume = [&](const u32x4 cur, bool on) __attribute__((always_inline)) {
       if (!on) return;
       const uint32_t t4[4] = {cur.x, cur.y, cur.z, cur.w};
@@ -1303,7 +1306,8 @@ extern "C" __global__ void __launch_bounds__(PG_P2_AGG_THREADS) pg_p2_aggregate_
       for (int e = 0; e < 4; e++) {
         if (t4[e] == PG_RADIX_INVALID_KEY) continue;
         const uint32_t k = t4[e] & local_mask, id = (t4[e] >> sh0) & fmask;
-        for (int o = 0; o < n_ops; o++) atomicAdd(reinterpret_cast<uint32_t*>(table + (size_t)o * slots + k), 1u);   // (a work item sees < 2^32 tuples)
+        if (slots == 1u) my_count++;
+        else for (int o = 0; o < n_ops; o++) atomicAdd(reinterpret_cast<uint32_t*>(table + (size_t)o * slots + k), 1u);   // (a work item sees < 2^32 tuples)
         atomicOr(&words[k * stride + (id >> 5)], 1u << (id & 31u));
       }
     };
@@ -1320,6 +1324,10 @@ extern "C" __global__ void __launch_bounds__(PG_P2_AGG_THREADS) pg_p2_aggregate_
         on0 = p2_fetch<1>(tuples, 0, list, n_list, ci + 2u * WAVES, lane, c0);
         consume(c1[0], ci + WAVES < n_list ? on1 : false);
       }
+    }
+    if (slots == 1u) {
+      const uint32_t wsum = wave_sum_u32(my_count);
+      if (lane == 0 && wsum) for (int o = 0; o < n_ops; o++) atomicAdd(reinterpret_cast<uint32_t*>(table + o), wsum);
     }
     __syncthreads();
     int64_t* out = p.partials + (int64_t)w * n_ops * slots;

@@ -291,7 +291,7 @@ DISTINCT_SHAPES = [
     ("SELECT h1, DISTINCTCOUNT(u) FROM gpuBench GROUP BY h1 LIMIT 100", "pg_part_group_by"),                       # 16 groups x 2^20-bit sets: one group per bucket
     ("SELECT h1, DISTINCTCOUNT(u), COUNT(*) FROM gpuBench GROUP BY h1 LIMIT 100", "pg_part_group_by"),
     ("SELECT h1, h2, COUNT(*), DISTINCTCOUNT(u) FROM gpuBench WHERE h3 < 7 GROUP BY h1, h2 LIMIT 1000", "pg_part_group_by"),   # 160 buckets behind a filter pass
-    ("SELECT h4, DISTINCTCOUNT(u) FROM gpuBench WHERE u BETWEEN 1000 AND 500000 AND h2 IN (1, 3, 5) GROUP BY h4 LIMIT 100", "pg_part_group_by"),
+    ("SELECT h4, DISTINCTCOUNT(u) FROM gpuBench WHERE u BETWEEN 1000 AND 500000 AND h2 IN (1, 3, 5) GROUP BY h4 LIMIT 100", None),   # 15 % pass the filter: the planner's cost model keeps the HBM sets
     ("SELECT h1, DISTINCTCOUNT(u), SUM(h2) FROM gpuBench GROUP BY h1 LIMIT 100", None),                             # another accumulator beside it: the older route
 ]
 
