@@ -41,6 +41,12 @@
 #ifndef SD_MIN_WAVES_PER_SIMD
 #define SD_MIN_WAVES_PER_SIMD 4   // register budget: 4 -> 128 VGPRs, 5 -> 96, 6 -> 80 (two workgroups per CU where their LDS fits)
 #endif
+#ifndef SD_PIPE_ROUNDS
+#define SD_PIPE_ROUNDS 0
+#endif
+#ifndef SD_EXEC_ROUNDS
+#define SD_EXEC_ROUNDS 0
+#endif
 #define PG_WAVES_PER_BLOCK SD_WAVES
 #define PG_KERNEL template <int PG_NOT_INSTANTIATED> static
 #include "pg_kernels.hip"
@@ -361,6 +367,53 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (VK == SD_V_GATHER) flush_pending();
     if (total == 0u) return;
+#if SD_PIPE_ROUNDS
+    // two rounds per trip: both rounds' list entries, then both rounds' field pairs are requested before anything is used — a sub-tile with
+    // 65 .. 128 matches (every second one at 1 match in 8) pays the chain list -> fields -> atomics once, not twice
+    for (uint32_t at = 0; at < total; at += 128u) {
+      const uint32_t idx0 = at + (uint32_t)lane, idx1 = idx0 + 64u;
+      const bool live0 = idx0 < total, live1 = idx1 < total;
+      const bool two = at + 64u < total;   // wave-uniform
+      const uint32_t doc0 = live0 ? (uint32_t)my_list[idx0] : 0u;
+      const uint32_t doc1 = live1 ? (uint32_t)my_list[idx1] : 0u;
+      const u32x2 wv0 = field_pair(cols + off_val, doc0, vbits);
+      u32x2 wg0[NG], wg1[NG];
+#pragma unroll
+      for (int gi = 0; gi < NG; gi++) wg0[gi] = field_pair(cols + (gi == 0 ? off_g0 : off_g1), doc0, gbits[gi]);
+      const u32x2 wv1 = field_pair(cols + off_val, doc1, vbits);
+#pragma unroll
+      for (int gi = 0; gi < NG; gi++) wg1[gi] = field_pair(cols + (gi == 0 ? off_g0 : off_g1), doc1, gbits[gi]);
+      __builtin_amdgcn_sched_barrier(0);
+      const uint32_t vid0 = field_of(wv0, doc0, vbits);
+      uint32_t slot0 = rep;
+#pragma unroll
+      for (int gi = 0; gi < NG; gi++) slot0 = mad24(field_of(wg0[gi], doc0, gbits[gi]), gmul[gi], slot0);   // < 65536 slots (planner)
+      slot0 = live0 ? slot0 : trash_slot;
+      const int32_t v0 = value_of(live0 ? vid0 : 0u);
+      uint32_t slot1 = trash_slot;
+      int32_t v1 = 0;
+      if (two) {
+        const uint32_t vid1 = field_of(wv1, doc1, vbits);
+        slot1 = rep;
+#pragma unroll
+        for (int gi = 0; gi < NG; gi++) slot1 = mad24(field_of(wg1[gi], doc1, gbits[gi]), gmul[gi], slot1);
+        slot1 = live1 ? slot1 : trash_slot;
+        v1 = value_of(live1 ? vid1 : 0u);
+      }
+      if (VK == SD_V_GATHER && at == 0u) {   // applied one sub-tile later
+        pend_slot0 = slot0; pend_v0 = v0; pend_slot1 = slot1; pend_v1 = v1;
+        pend_n = two ? 2 : 1;
+      } else {
+#if SD_EXEC_ROUNDS
+        if (live0) apply(slot0, v0);
+        if (two) { if (live1) apply(slot1, v1); }
+#else
+        apply(slot0, v0);
+        if (two) apply(slot1, v1);
+#endif
+      }
+    }
+#else
     const bool all = false;
     int round = 0;
     for (uint32_t at = 0; at < total; at += 64u, round++) {
@@ -382,9 +435,14 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
         if (round == 0) { pend_slot0 = slot; pend_v0 = v; } else { pend_slot1 = slot; pend_v1 = v; }
         pend_n = round + 1;
       } else {
+#if SD_EXEC_ROUNDS
+        if (live) apply(slot, v);   // the dead lanes of a list's last round sit out (EXEC) instead of adding to their trash slots
+#else
         apply(slot, v);
+#endif
       }
     }
+#endif
   };
 
   // ---- main loop: one tile per iteration, sub-tiles 0 .. 3.  SD_SETS = 2: two register sets, sub-tile (k, s + 2) is requested where (k, s) is

@@ -139,6 +139,11 @@ def _compare(gb, ob, what):
     assert gb.stats.num_entries_scanned_in_filter == ob.stats.num_entries_scanned_in_filter, what
 
 
+# The -m gpu suite runs inside a time limit of the driver's: the default number of random queries per test is 60 % of what the tests were
+# written with (PG_FUZZ_SCALE=1 for the full count, larger for a soak; PG_FUZZ_SEED_BASE for other queries)
+FUZZ_SCALE = float(os.environ.get("PG_FUZZ_SCALE", "0.6"))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,with_valid_docs", [(1, False), (2, False), (3, True), (4, False), (5, True), (6, False)])
 def test_gpu_matches_oracle_on_random_queries(gpu_api, oracle_api, fuzz, seed, with_valid_docs):
@@ -151,7 +156,7 @@ def test_gpu_matches_oracle_on_random_queries(gpu_api, oracle_api, fuzz, seed, w
         o.set_queryable_doc_ids(valid)
     gen = Gen(data, seed=int(os.environ.get("PG_FUZZ_SEED_BASE", "1000")) + seed)   # another base = another 1 280 queries
     unsupported, mismatches = [], []
-    n_queries = 200 if seed != 6 else 80
+    n_queries = int((200 if seed != 6 else 80) * FUZZ_SCALE)
     for i in range(n_queries):
         q = gen.query()
         what = f"seed {seed} #{i} {describe(q)}"
@@ -195,7 +200,7 @@ def test_gpu_matches_oracle_on_random_queries_under_null_handling(gpu_api, oracl
         o.set_queryable_doc_ids(valid)
     gen = Gen(data, seed=7000 + seed)
     unsupported, mismatches, with_nulls = [], [], 0
-    n_queries = 160
+    n_queries = int(160 * FUZZ_SCALE)
     for i in range(n_queries):
         q = gen.query()
         what = f"null handling, seed {seed} #{i} {describe(q)}"
@@ -293,7 +298,7 @@ def test_gpu_star_tree_matches_oracle_on_random_queries(gpu_api, oracle_api):
     g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
     rng = np.random.default_rng(78)
     mismatches = []
-    for i in range(200):
+    for i in range(int(200 * FUZZ_SCALE)):
         q = _star_query(rng)
         what = f"#{i} {describe(q)}"
         gb, ob = g.execute(clone(q)), o.execute(clone(q))
@@ -315,7 +320,7 @@ def test_gpu_raw_key_groups_match_oracle_on_random_queries(gpu_api, oracle_api, 
     g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
     gen = Gen(data, seed=int(os.environ.get("PG_FUZZ_SEED_BASE", "1000")) + 77)
     mismatches = []
-    for i in range(120):
+    for i in range(int(120 * FUZZ_SCALE)):
         q = gen.raw_key_query()
         what = f"raw keys #{i} {describe(q)}"
         gb, ob = g.execute(clone(q)), o.execute(clone(q))

@@ -21,7 +21,7 @@ def last_json_line(out):
 
 def test_bench_line_on_a_small_segment():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--docs", "3000000", "--steps", "3", "--warmup", "1", "--no-traffic",
-                          "--cpu-sample-docs", "3000000"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          "--cpu-sample-docs", "1000000"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     d = last_json_line(out)
     for k in REQUIRED:
