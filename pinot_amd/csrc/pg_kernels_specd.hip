@@ -317,6 +317,10 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
     // candidates of this lane's 8 docs: byte (lane & 3) of linear dword 16 sub + (lane >> 2) (docs past the segment: none)
     const uint32_t cd = (uint32_t)__builtin_amdgcn_ds_bpermute((sub * 16 + (lane >> 2)) * 4, (int)lin);
     uint32_t m = (cd >> lin_sh) & 0xFFu;
+#ifdef PG_SD_LOADS_ONLY   // measurement variant (wrong results): the stream alone — loads, stores to the strip, one LDS read
+    my_matched += *reinterpret_cast<const uint32_t*>(cols + (uint32_t)lane * 4u) & m & 1u;
+    return;
+#endif
     if (HAS_SCAN) {
       uint32_t rm = 0;
       u32x2 w[8];   // all eight pairs requested before the first is used (one LDS round trip, not eight)

@@ -49,7 +49,7 @@ def test_bench_line_on_a_small_segment():
 def test_bench_under_torchrun_with_one_rank():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-                          "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--docs", "2000000", "--steps", "2",
+                          "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--docs", "1000000", "--steps", "2",
                           "--warmup", "1", "--no-traffic", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     d = last_json_line(out)

@@ -237,8 +237,12 @@ def test_oct_scatter_shapes_and_the_quad_kernels_agree(gpu_api, oracle_api, gpu_
     g.destroy()
     gpu_knobs(PG_NO_P2_OCT="1")
     g = NativeSegment(gpu_api, host)   # (plans are cached per segment: a new one sees the knob)
-    for (q, limit), rows in zip(OCT_SHAPES, oct_rows):
-        assert run(g, o, q, limit).rows() == rows, q
+    for (q, limit), rows in zip(OCT_SHAPES, oct_rows):   # (the oracle answered above: the quad kernels' rows are compared with the oct kernels')
+        qg = parse_sql(q)
+        if limit:
+            qg.num_groups_limit = limit
+        gb = g.execute(qg)
+        assert gb.stats.kernel.decode() == "pg_part_group_by" and gb.rows() == rows, q
     g.destroy()
     o.destroy()
 
