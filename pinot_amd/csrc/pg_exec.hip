@@ -22,6 +22,8 @@ PG_DECL_FAST(pg_fast_multi_f) PG_DECL_FAST(pg_fast_multi_a) PG_DECL_FAST(pg_fast
 PG_DECL_FAST(pg_fast_i32range_d) PG_DECL_FAST(pg_fast_i32range_p) PG_DECL_FAST(pg_fast_i32range_fp) PG_DECL_FAST(pg_fast_i32range_s) PG_DECL_FAST(pg_spec_none) PG_DECL_FAST(pg_spec_scan) PG_DECL_FAST(pg_spec_index) PG_DECL_FAST(pg_fast_i32range_st)
 // pg_kernels_specd.hip: the loader / consumer frame over dictionary-encoded scan / value columns (_r raw INT values, _a arithmetic dictionary, _g gathered)
 PG_DECL_FAST(pg_fast_dictrange_s_r) PG_DECL_FAST(pg_fast_dictrange_st_r) PG_DECL_FAST(pg_specd_none_r) PG_DECL_FAST(pg_specd_scan_r) PG_DECL_FAST(pg_specd_index_r) PG_DECL_FAST(pg_fast_dictrange_s_a) PG_DECL_FAST(pg_fast_dictrange_st_a) PG_DECL_FAST(pg_specd_none_a) PG_DECL_FAST(pg_specd_scan_a) PG_DECL_FAST(pg_specd_index_a) PG_DECL_FAST(pg_fast_dictrange_s_g) PG_DECL_FAST(pg_fast_dictrange_st_g) PG_DECL_FAST(pg_specd_none_g) PG_DECL_FAST(pg_specd_scan_g) PG_DECL_FAST(pg_specd_index_g)
+// pg_kernels_specw.hip: the same shapes with a shared stage per workgroup (whole stages requested as long rows straight into LDS)
+PG_DECL_FAST(pg_fast_dictrange_w_r) PG_DECL_FAST(pg_fast_dictrange_wt_r) PG_DECL_FAST(pg_specw_none_r) PG_DECL_FAST(pg_specw_scan_r) PG_DECL_FAST(pg_specw_index_r) PG_DECL_FAST(pg_fast_dictrange_w_a) PG_DECL_FAST(pg_fast_dictrange_wt_a) PG_DECL_FAST(pg_specw_none_a) PG_DECL_FAST(pg_specw_scan_a) PG_DECL_FAST(pg_specw_index_a) PG_DECL_FAST(pg_fast_dictrange_w_g) PG_DECL_FAST(pg_fast_dictrange_wt_g) PG_DECL_FAST(pg_specw_none_g) PG_DECL_FAST(pg_specw_scan_g) PG_DECL_FAST(pg_specw_index_g)
 PG_DECL_FAST(pg_dense_count_1) PG_DECL_FAST(pg_dense_count_2) PG_DECL_FAST(pg_dense_count_3) PG_DECL_FAST(pg_dense_count_4)
 PG_DECL_FAST(pg_dense_count_5) PG_DECL_FAST(pg_dense_count_6) PG_DECL_FAST(pg_dense_count_7) PG_DECL_FAST(pg_dense_count_8)
 PG_DECL_FAST(pg_dict_count_1) PG_DECL_FAST(pg_dict_count_2) PG_DECL_FAST(pg_dict_count_3) PG_DECL_FAST(pg_dict_count_4)
@@ -40,6 +42,9 @@ extern "C" const int pg_spec_waves_per_block;   // pg_kernels_spec.hip: pg_fast_
 extern "C" int pg_spec_stage_bytes(int bits0, int bits1);
 extern "C" const int pg_specd_waves_per_block;   // pg_kernels_specd.hip: pg_fast_dictrange_s family (dictionary-encoded scan / value columns)
 extern "C" int pg_specd_stage_bytes(int scan_bits, int value_bits, int bits0, int bits1);
+extern "C" const int pg_specw_waves_per_block;   // pg_kernels_specw.hip: pg_fast_dictrange_w family (the shared-stage frame of the same plans)
+extern "C" int pg_specw_stage_bytes(int scan_bits, int value_bits, int bits0, int bits1, int n_bitmaps);
+extern "C" int pg_specw_list_bytes();
 PG_DECL_FAST(pg_fast_multi_wd) PG_DECL_FAST(pg_fast_none_wd) PG_DECL_FAST(pg_generic_query_ld) PG_DECL_FAST(pg_generic_query_gd)
 extern "C" __global__ void pg_reduce_partials_kernel(const int64_t* partials, int64_t* out, int n_wg, int n_ops,
                                                      int n_groups, const PgAccOp* ops, unsigned long long* stats, int reduce);
@@ -328,6 +333,8 @@ void use_device(int ordinal) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
       for (QueryKernel k : {pg_fast_dictrange_s_r, pg_fast_dictrange_st_r, pg_specd_none_r, pg_specd_scan_r, pg_specd_index_r, pg_fast_dictrange_s_a, pg_fast_dictrange_st_a, pg_specd_none_a, pg_specd_scan_a, pg_specd_index_a, pg_fast_dictrange_s_g, pg_fast_dictrange_st_g, pg_specd_none_g, pg_specd_scan_g, pg_specd_index_g})
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
+      for (QueryKernel k : {pg_fast_dictrange_w_r, pg_fast_dictrange_wt_r, pg_specw_none_r, pg_specw_scan_r, pg_specw_index_r, pg_fast_dictrange_w_a, pg_fast_dictrange_wt_a, pg_specw_none_a, pg_specw_scan_a, pg_specw_index_a, pg_fast_dictrange_w_g, pg_fast_dictrange_wt_g, pg_specw_none_g, pg_specw_scan_g, pg_specw_index_g})
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
       for (QueryKernel k : {pg_mv_query_f, pg_mv_query_l, pg_mv_query_g})   // 10.5 KB of static LDS (per-wavefront entry bitmaps): the planner's 144 KB still fit
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 12288);
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pg_radix_scatter_packed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
@@ -373,6 +380,17 @@ static bool uses_specd(const CompiledPlan& P, int agg_mode) {
 }
 static size_t specd_stage_bytes(const CompiledPlan& P) {
   return ((size_t)pg_specd_stage_bytes(P.dev.specd_sbits, P.dev.specd_vbits, P.dev.gcols[0].bits, P.dev.n_group_cols > 1 ? P.dev.gcols[1].bits : 0) + 15) & ~(size_t)15;
+}
+// ... in the shared-stage frame (PgQueryPlan::specd == 2, pg_kernels_specw.hip): two stage buffers + one selection list per wavefront
+static bool uses_specw(const CompiledPlan& P, int agg_mode) { return uses_specd(P, agg_mode) && P.dev.specd == 2; }
+static size_t specw_stage_bytes(const CompiledPlan& P) {
+  int n_bm = 0;
+  if (P.dev.pipe_has_index) {
+    n_bm = 8;
+    while (n_bm > 1 && P.dev.dense_ptr[n_bm - 1] == P.dev.dense_ptr[0] && P.dev.dense_group[n_bm - 1] == P.dev.dense_group[0]) n_bm--;
+  }
+  if (P.dev.pipe_tail != nullptr) n_bm++;
+  return 2 * (size_t)pg_specw_stage_bytes(P.dev.specd_sbits, P.dev.specd_vbits, P.dev.gcols[0].bits, P.dev.n_group_cols > 1 ? P.dev.gcols[1].bits : 0, n_bm) + (size_t)pg_specw_list_bytes() + 16;
 }
 // pg_fast_i32range_p (software-pipelined headline shape, pg_kernels_pipe.hip): its own workgroup size
 static bool uses_pipe_general(const CompiledPlan& P, int agg_mode) {   // pg_pipe_*: the pipeline's other filter shapes
@@ -459,6 +477,14 @@ static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char
           {{"pg_specd_none_a", pg_specd_none_a}, {"pg_specd_index_a", pg_specd_index_a}, {"pg_specd_scan_a", pg_specd_scan_a}, {"pg_fast_dictrange_s_a", pg_fast_dictrange_s_a}, {"pg_fast_dictrange_st_a", pg_fast_dictrange_st_a}},
           {{"pg_specd_none_g", pg_specd_none_g}, {"pg_specd_index_g", pg_specd_index_g}, {"pg_specd_scan_g", pg_specd_scan_g}, {"pg_fast_dictrange_s_g", pg_fast_dictrange_s_g}, {"pg_fast_dictrange_st_g", pg_fast_dictrange_st_g}}};
       const int shape = P.dev.pipe_tail != nullptr ? 4 : (P.dev.pipe_has_scan ? 2 : 0) + (P.dev.pipe_has_index ? 1 : 0);
+      if (P.dev.specd == 2) {
+        static const struct { const char* name; QueryKernel fn; } kSpecw[3][5] = {
+            {{"pg_specw_none_r", pg_specw_none_r}, {"pg_specw_index_r", pg_specw_index_r}, {"pg_specw_scan_r", pg_specw_scan_r}, {"pg_fast_dictrange_w_r", pg_fast_dictrange_w_r}, {"pg_fast_dictrange_wt_r", pg_fast_dictrange_wt_r}},
+            {{"pg_specw_none_a", pg_specw_none_a}, {"pg_specw_index_a", pg_specw_index_a}, {"pg_specw_scan_a", pg_specw_scan_a}, {"pg_fast_dictrange_w_a", pg_fast_dictrange_w_a}, {"pg_fast_dictrange_wt_a", pg_fast_dictrange_wt_a}},
+            {{"pg_specw_none_g", pg_specw_none_g}, {"pg_specw_index_g", pg_specw_index_g}, {"pg_specw_scan_g", pg_specw_scan_g}, {"pg_fast_dictrange_w_g", pg_fast_dictrange_w_g}, {"pg_fast_dictrange_wt_g", pg_fast_dictrange_wt_g}}};
+        *name = kSpecw[P.dev.specd_vkind - 1][shape].name;
+        return kSpecw[P.dev.specd_vkind - 1][shape].fn;
+      }
       *name = kSpecd[P.dev.specd_vkind - 1][shape].name;
       return kSpecd[P.dev.specd_vkind - 1][shape].fn;
     }
@@ -625,6 +651,12 @@ static LaunchShape launch_shape(const CompiledPlan& P, int n_wtiles, int agg_mod
     const int waves = pg_scan_waves_per_block;
     int grid = std::min((n_wtiles + waves - 1) / waves, num_cus() * std::max(wgs_per_cu, 1));
     return {std::max(grid, 1), waves * 64, 0};
+  }
+  if (uses_specw(P, agg_mode)) {   // one workgroup per CU walking stages (waves x 512 docs) b, b + grid, ...; table + two stage buffers + the selection lists in LDS
+    const int waves = pg_specw_waves_per_block;
+    const int64_t stage_docs = (int64_t)waves * 512;
+    const int n_stages = (int)(((int64_t)P.dev.num_docs + stage_docs - 1) / stage_docs);
+    return {std::max(1, std::min(n_stages, num_cus() * std::max(1, 16 / waves))), waves * 64, lds + 64 + specw_stage_bytes(P) + 512 * (size_t)P.dev.n_ops};
   }
   if (uses_specd(P, agg_mode)) {   // behind the table and its trash slots a private strip of LDS per wavefront; two workgroups per CU where their LDS fits
     const int waves = pg_specd_waves_per_block;

@@ -18,6 +18,9 @@
 #include "pg_fixed_point.h"
 
 extern "C" const int pg_specd_waves_per_block, pg_specd_column_areas;   // pg_kernels_specd.hip
+extern "C" int pg_specw_stage_bytes(int scan_bits, int value_bits, int bits0, int bits1, int n_bitmaps);   // pg_kernels_specw.hip
+extern "C" int pg_specw_list_bytes();
+extern "C" const int pg_specw_waves_per_block;
 namespace pg {
 
 // =====================================================================================================================
@@ -2209,7 +2212,34 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     // table + a trash slot per lane and accumulator + one strip per wavefront (the sub-tile's column bytes + the selection list) inside the
     // dynamic-LDS limit (device_init asks for 160 KB - 8 KB): fewer replicas where the default table would not leave room (the list walk keeps
     // every lane on a replica of its own down to R = 64; below, lanes share)
-    if (ok) {
+    // the shared-stage frame (pg_kernels_specw.hip, late round 6; PG_SPECW=1 only) where the table leaves room for two stage buffers: the workgroup
+    // requests whole stages as long rows straight into LDS; same shapes, same results — measured SLOWER than the independent wavefronts (44-47 %
+    // against 65 % of 8 TB/s at 2 x 10^8 docs, profiles/r06_specd_steps.txt step 5: with two buffers only one stage is ever pending), kept as a
+    // parity-tested measurement variant
+    bool stage_frame = false;
+    if (ok && knobs().specw) {
+      int n_bm = 0;
+      if (D.n_index_instr > 0) {
+        n_bm = 8;
+        while (n_bm > 1 && D.dense_ptr[n_bm - 1] == D.dense_ptr[0] && D.dense_group[n_bm - 1] == D.dense_group[0]) n_bm--;   // (the padding, as the kernel recognises it)
+      }
+      const size_t stage = (size_t)pg_specw_stage_bytes(has_scan ? sbits : 0, vbits, D.gcols[0].bits, D.n_group_cols > 1 ? D.gcols[1].bits : 0, n_bm + (has_tail ? 1 : 0));
+      const size_t fixed = 256 + 2 * stage + (size_t)pg_specw_list_bytes() + 16 + 512 * (size_t)D.n_ops;
+      const size_t wgs_per_cu = (size_t)std::max(1, 16 / pg_specw_waves_per_block);   // 16 wavefronts per CU, as 1 x 16, 2 x 8 or 4 x 4
+      const size_t limit = wgs_per_cu == 1 ? (size_t)160 * 1024 - 8192 : (size_t)160 * 1024 / wgs_per_cu - 2048;
+      const size_t per_replica = (size_t)G * (size_t)D.n_ops * 8;
+      int reps = D.replicas;
+      while (reps > 1 && per_replica * (size_t)reps + fixed > limit) reps /= 2;
+      // fewer than four replicas only for key spaces that spread a wavefront's 64 atomics by themselves
+      if (per_replica * (size_t)reps + fixed <= limit && (reps >= 4 || (size_t)G * (size_t)reps >= 1024 || reps == D.replicas)) {
+        P.lds_bytes -= per_replica * (size_t)(D.replicas - reps);
+        D.replicas = reps;
+        D.replica_shift = 0;
+        while ((1 << D.replica_shift) < D.replicas) D.replica_shift++;
+        stage_frame = true;
+      }
+    }
+    if (ok && !stage_frame) {
       auto region = [](int bits) { return bits > 0 ? (size_t)((bits * 64 + 16 + 15) & ~15) : (size_t)0; };
       const size_t strip = (size_t)pg_specd_column_areas * ((has_scan ? region(sbits) : 0) + region(vbits) + region(D.gcols[0].bits) + (D.n_group_cols > 1 ? region(D.gcols[1].bits) : 0)) + (512 + 64) * 2;
       const size_t fixed = 256 + (size_t)pg_specd_waves_per_block * strip + 16 + 512 * (size_t)D.n_ops;
@@ -2227,7 +2257,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
       if (P.lds_bytes + fixed > limit) ok = false;
     }
     if (ok) {
-      D.specd = 1;
+      D.specd = stage_frame ? 2 : 1;
       D.specd_vkind = vkind;
       D.specd_sbits = has_scan ? sbits : 0;
       D.specd_vbits = vbits;

@@ -203,6 +203,22 @@ def test_headline_kernel_has_no_register_spills():
             assert u["VGPRs Spill"] == 0 and u["VGPRs"] <= 128, (k, u)
         for k in ("pg_fast_dictrange_s_a", "pg_fast_dictrange_s_r", "pg_specd_scan_a", "pg_specd_index_a", "pg_specd_none_a"):
             assert du[k]["ScratchSize [bytes/lane]"] == 0, (k, du[k])
+    # ... and its shared-stage frame (pg_kernels_specw.hip): no staging registers at all (LDS-DMA), no scratch in any of the 15 kernels
+    specw = log.replace("pg_kernels.", "pg_kernels_specw.")
+    if os.path.exists(specw):
+        wu, cur = {}, None
+        for line in open(specw):
+            m = re.search(r"Function Name: (\w+)", line)
+            if m:
+                cur = m.group(1)
+                wu[cur] = {}
+            for key in ("VGPRs", "ScratchSize [bytes/lane]", "VGPRs Spill"):
+                m = re.search(re.escape(key) + r": (\d+)", line)
+                if m and cur:
+                    wu[cur].setdefault(key, int(m.group(1)))
+        assert len(wu) == 15
+        for k, u in wu.items():
+            assert u["VGPRs Spill"] == 0 and u["VGPRs"] <= 128 and u["ScratchSize [bytes/lane]"] == 0, (k, u)
     # round 5: the loader / consumer kernels — 12 wavefronts per workgroup, 3 per SIMD: 168 registers; three register sets of two tiles as
     # arrays spilled (1.89 ms against 1.44), and the DOUBLE variants of the wide pipeline no longer touch scratch memory
     spec = log.replace("pg_kernels.", "pg_kernels_spec.")
