@@ -398,12 +398,14 @@ struct PgQueryPlan {
   int32_t oct_n_regions;            // regions = workgroups of pg_oct_p in this pass
   // pg_fast_dictrange_s family (pg_kernels_specd.hip, round 6): the loader / consumer frame over a dictionary-encoded scan and / or value
   // column.  specd = 1: srcs[pipe_src] is the one value column, scans[fast_scan] the one range scan (pipe_has_scan), dense_* the index
-  // program (pipe_has_index), pipe_tail the upsert snapshot.
+  // program (pipe_has_index), pipe_tail the upsert snapshot.  specd = 2: the shared-stage frame of the same plans (pg_kernels_specw.hip, PG_SPECW).
   int32_t specd;
   int32_t specd_vkind;              // 1: raw INT values; 2: value = specd_base + specd_step x dictId (arithmetic INT dictionary); 3: srcs[pipe_src].dict[dictId]
   int32_t specd_sbits;              // bits per value of the scan column's stream (32: raw INT); 0 without a scan
   int32_t specd_vbits;              // ... of the value column's
   int32_t specd_base, specd_step;
+  int32_t specd_dma;                // the headline shape's LDS-DMA kernels (two column areas per strip): pg_fast_dictrange_s_*_dma
+  int32_t specd_pad;
 };
 
 #if defined(__HIPCC__)

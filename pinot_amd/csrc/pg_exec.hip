@@ -21,7 +21,7 @@ PG_DECL_FAST(pg_fast_dictrange_f) PG_DECL_FAST(pg_fast_dictrange_a) PG_DECL_FAST
 PG_DECL_FAST(pg_fast_multi_f) PG_DECL_FAST(pg_fast_multi_a) PG_DECL_FAST(pg_fast_multi_w) PG_DECL_FAST(pg_fast_none_w)
 PG_DECL_FAST(pg_fast_i32range_d) PG_DECL_FAST(pg_fast_i32range_p) PG_DECL_FAST(pg_fast_i32range_fp) PG_DECL_FAST(pg_fast_i32range_s) PG_DECL_FAST(pg_spec_none) PG_DECL_FAST(pg_spec_scan) PG_DECL_FAST(pg_spec_index) PG_DECL_FAST(pg_fast_i32range_st)
 // pg_kernels_specd.hip: the loader / consumer frame over dictionary-encoded scan / value columns (_r raw INT values, _a arithmetic dictionary, _g gathered)
-PG_DECL_FAST(pg_fast_dictrange_s_r) PG_DECL_FAST(pg_fast_dictrange_st_r) PG_DECL_FAST(pg_specd_none_r) PG_DECL_FAST(pg_specd_scan_r) PG_DECL_FAST(pg_specd_index_r) PG_DECL_FAST(pg_fast_dictrange_s_a) PG_DECL_FAST(pg_fast_dictrange_st_a) PG_DECL_FAST(pg_specd_none_a) PG_DECL_FAST(pg_specd_scan_a) PG_DECL_FAST(pg_specd_index_a) PG_DECL_FAST(pg_fast_dictrange_s_g) PG_DECL_FAST(pg_fast_dictrange_st_g) PG_DECL_FAST(pg_specd_none_g) PG_DECL_FAST(pg_specd_scan_g) PG_DECL_FAST(pg_specd_index_g)
+PG_DECL_FAST(pg_fast_dictrange_s_r_dma) PG_DECL_FAST(pg_fast_dictrange_s_a_dma) PG_DECL_FAST(pg_fast_dictrange_s_g_dma) PG_DECL_FAST(pg_fast_dictrange_s_r) PG_DECL_FAST(pg_fast_dictrange_st_r) PG_DECL_FAST(pg_specd_none_r) PG_DECL_FAST(pg_specd_scan_r) PG_DECL_FAST(pg_specd_index_r) PG_DECL_FAST(pg_fast_dictrange_s_a) PG_DECL_FAST(pg_fast_dictrange_st_a) PG_DECL_FAST(pg_specd_none_a) PG_DECL_FAST(pg_specd_scan_a) PG_DECL_FAST(pg_specd_index_a) PG_DECL_FAST(pg_fast_dictrange_s_g) PG_DECL_FAST(pg_fast_dictrange_st_g) PG_DECL_FAST(pg_specd_none_g) PG_DECL_FAST(pg_specd_scan_g) PG_DECL_FAST(pg_specd_index_g)
 // pg_kernels_specw.hip: the same shapes with a shared stage per workgroup (whole stages requested as long rows straight into LDS)
 PG_DECL_FAST(pg_fast_dictrange_w_r) PG_DECL_FAST(pg_fast_dictrange_wt_r) PG_DECL_FAST(pg_specw_none_r) PG_DECL_FAST(pg_specw_scan_r) PG_DECL_FAST(pg_specw_index_r) PG_DECL_FAST(pg_fast_dictrange_w_a) PG_DECL_FAST(pg_fast_dictrange_wt_a) PG_DECL_FAST(pg_specw_none_a) PG_DECL_FAST(pg_specw_scan_a) PG_DECL_FAST(pg_specw_index_a) PG_DECL_FAST(pg_fast_dictrange_w_g) PG_DECL_FAST(pg_fast_dictrange_wt_g) PG_DECL_FAST(pg_specw_none_g) PG_DECL_FAST(pg_specw_scan_g) PG_DECL_FAST(pg_specw_index_g)
 PG_DECL_FAST(pg_dense_count_1) PG_DECL_FAST(pg_dense_count_2) PG_DECL_FAST(pg_dense_count_3) PG_DECL_FAST(pg_dense_count_4)
@@ -41,7 +41,7 @@ extern "C" const int pg_pipe_waves_per_block;   // pg_kernels_pipe.hip: wavefron
 extern "C" const int pg_spec_waves_per_block;   // pg_kernels_spec.hip: pg_fast_i32range_s (4 loader + 8 consumer wavefronts)
 extern "C" int pg_spec_stage_bytes(int bits0, int bits1);
 extern "C" const int pg_specd_waves_per_block;   // pg_kernels_specd.hip: pg_fast_dictrange_s family (dictionary-encoded scan / value columns)
-extern "C" int pg_specd_stage_bytes(int scan_bits, int value_bits, int bits0, int bits1);
+extern "C" int pg_specd_stage_bytes(int scan_bits, int value_bits, int bits0, int bits1, int areas);
 extern "C" const int pg_specw_waves_per_block;   // pg_kernels_specw.hip: pg_fast_dictrange_w family (the shared-stage frame of the same plans)
 extern "C" int pg_specw_stage_bytes(int scan_bits, int value_bits, int bits0, int bits1, int n_bitmaps);
 extern "C" int pg_specw_list_bytes();
@@ -331,7 +331,7 @@ void use_device(int ordinal) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
       for (QueryKernel k : {pg_fast_i32range_s, pg_fast_i32range_st, pg_spec_none, pg_spec_scan, pg_spec_index})
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
-      for (QueryKernel k : {pg_fast_dictrange_s_r, pg_fast_dictrange_st_r, pg_specd_none_r, pg_specd_scan_r, pg_specd_index_r, pg_fast_dictrange_s_a, pg_fast_dictrange_st_a, pg_specd_none_a, pg_specd_scan_a, pg_specd_index_a, pg_fast_dictrange_s_g, pg_fast_dictrange_st_g, pg_specd_none_g, pg_specd_scan_g, pg_specd_index_g})
+      for (QueryKernel k : {pg_fast_dictrange_s_r_dma, pg_fast_dictrange_s_a_dma, pg_fast_dictrange_s_g_dma, pg_fast_dictrange_s_r, pg_fast_dictrange_st_r, pg_specd_none_r, pg_specd_scan_r, pg_specd_index_r, pg_fast_dictrange_s_a, pg_fast_dictrange_st_a, pg_specd_none_a, pg_specd_scan_a, pg_specd_index_a, pg_fast_dictrange_s_g, pg_fast_dictrange_st_g, pg_specd_none_g, pg_specd_scan_g, pg_specd_index_g})
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
       for (QueryKernel k : {pg_fast_dictrange_w_r, pg_fast_dictrange_wt_r, pg_specw_none_r, pg_specw_scan_r, pg_specw_index_r, pg_fast_dictrange_w_a, pg_fast_dictrange_wt_a, pg_specw_none_a, pg_specw_scan_a, pg_specw_index_a, pg_fast_dictrange_w_g, pg_fast_dictrange_wt_g, pg_specw_none_g, pg_specw_scan_g, pg_specw_index_g})
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
@@ -379,7 +379,7 @@ static bool uses_specd(const CompiledPlan& P, int agg_mode) {
   return P.dev.specd && agg_mode == PG_AGG_LDS && uses_fast_kernel(P, agg_mode) && P.fast_agg && !P.wide_agg && !knobs().no_specd;
 }
 static size_t specd_stage_bytes(const CompiledPlan& P) {
-  return ((size_t)pg_specd_stage_bytes(P.dev.specd_sbits, P.dev.specd_vbits, P.dev.gcols[0].bits, P.dev.n_group_cols > 1 ? P.dev.gcols[1].bits : 0) + 15) & ~(size_t)15;
+  return ((size_t)pg_specd_stage_bytes(P.dev.specd_sbits, P.dev.specd_vbits, P.dev.gcols[0].bits, P.dev.n_group_cols > 1 ? P.dev.gcols[1].bits : 0, P.dev.specd_dma ? 2 : 1) + 15) & ~(size_t)15;
 }
 // ... in the shared-stage frame (PgQueryPlan::specd == 2, pg_kernels_specw.hip): two stage buffers + one selection list per wavefront
 static bool uses_specw(const CompiledPlan& P, int agg_mode) { return uses_specd(P, agg_mode) && P.dev.specd == 2; }
@@ -484,6 +484,12 @@ static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char
             {{"pg_specw_none_g", pg_specw_none_g}, {"pg_specw_index_g", pg_specw_index_g}, {"pg_specw_scan_g", pg_specw_scan_g}, {"pg_fast_dictrange_w_g", pg_fast_dictrange_w_g}, {"pg_fast_dictrange_wt_g", pg_fast_dictrange_wt_g}}};
         *name = kSpecw[P.dev.specd_vkind - 1][shape].name;
         return kSpecw[P.dev.specd_vkind - 1][shape].fn;
+      }
+      if (P.dev.specd_dma && shape == 3) {   // the headline shape's columns by LDS-DMA (two column areas per strip: the planner found room)
+        static const struct { const char* name; QueryKernel fn; } kDma[3] = {
+            {"pg_fast_dictrange_s_r_dma", pg_fast_dictrange_s_r_dma}, {"pg_fast_dictrange_s_a_dma", pg_fast_dictrange_s_a_dma}, {"pg_fast_dictrange_s_g_dma", pg_fast_dictrange_s_g_dma}};
+        *name = kDma[P.dev.specd_vkind - 1].name;
+        return kDma[P.dev.specd_vkind - 1].fn;
       }
       *name = kSpecd[P.dev.specd_vkind - 1][shape].name;
       return kSpecd[P.dev.specd_vkind - 1][shape].fn;

@@ -31,12 +31,12 @@
 #ifndef SD_SETS
 #define SD_SETS 1       // sub-tiles of loads in flight per wavefront (register sets); 2: measured the same, and the scan fields' eight LDS reads then serialise on one register pair
 #endif
-#ifndef SD_DMA
-#define SD_DMA 0        // 1: the columns' bytes go global memory -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write_b128),
-#endif                  //    into one of two column areas of the strip; 0: through registers into a single area.  Measured the same within the
-                        //    run-to-run spread (+0..3 % with non-temporal DMA, profiles/r06_specd_steps.txt) for twice the LDS: not the default
+// DMA (template parameter): the columns' bytes go global memory -> LDS directly (global_load_lds_dwordx4: no staging registers, no
+// ds_write_b128), into one of two column areas of the strip; otherwise through registers into a single area.  +3-4 % with non-temporal DMA
+// (profiles/r06_specd_steps.txt) for twice the strip: the planner takes the DMA kernels (pg_fast_dictrange_s_*_dma) where the table still
+// keeps >= 8 replicas beside the doubled strips (PgQueryPlan::specd_dma)
 #ifndef SD_DMA_AUX
-#define SD_DMA_AUX 0    // cache policy bits of the LDS-DMA loads (2: non-temporal)
+#define SD_DMA_AUX 2    // cache policy bits of the LDS-DMA loads (2: non-temporal)
 #endif
 #ifndef SD_MIN_WAVES_PER_SIMD
 #define SD_MIN_WAVES_PER_SIMD 4   // register budget: 4 -> 128 VGPRs, 5 -> 96, 6 -> 80 (two workgroups per CU where their LDS fits)
@@ -56,10 +56,10 @@
 #define SD_LIST_BYTES ((OCT_SUB_DOCS + 64u) * 2u)       // a wavefront's selection list: 512 uint16 entries + a dummy entry per lane
 __host__ __device__ static inline uint32_t sd_region(uint32_t bits) { return bits ? (bits * 64u + SD_PAD + 15u) & ~15u : 0u; }
 extern "C" const int pg_specd_waves_per_block = PG_WAVES_PER_BLOCK;
-extern "C" const int pg_specd_column_areas = SD_DMA ? 2 : 1;   // column areas per strip (the planner sizes the launch's LDS with it)
-// bytes of the launch's LDS behind the table and its trash slots: one strip per wavefront (the sub-tile's column bytes + the selection list)
-extern "C" int pg_specd_stage_bytes(int scan_bits, int value_bits, int bits0, int bits1) {
-  const int strip = (SD_DMA ? 2 : 1) * (int)(sd_region((uint32_t)scan_bits) + sd_region((uint32_t)value_bits) + sd_region((uint32_t)bits0) + sd_region((uint32_t)bits1)) + (int)SD_LIST_BYTES;
+// bytes of the launch's LDS behind the table and its trash slots: one strip per wavefront (`areas` column areas — 1, or 2 for the DMA kernels —
+// of the sub-tile's column bytes + the selection list)
+extern "C" int pg_specd_stage_bytes(int scan_bits, int value_bits, int bits0, int bits1, int areas) {
+  const int strip = areas * (int)(sd_region((uint32_t)scan_bits) + sd_region((uint32_t)value_bits) + sd_region((uint32_t)bits0) + sd_region((uint32_t)bits1)) + (int)SD_LIST_BYTES;
   return PG_WAVES_PER_BLOCK * strip + 16;
 }
 
@@ -82,7 +82,7 @@ enum { SD_V_RAW32 = 1, SD_V_AFFINE = 2, SD_V_GATHER = 3 };
 // HAS_INDEX: the fused dense index program (else every valid doc is a candidate); HAS_SCAN: one range scan (dictId interval of a fixed-bit
 // column, or raw INT range) restricted to the candidates; HAS_TAIL: the upsert queryableDocIds snapshot ANDed in after the candidates have been
 // counted (FilterPlanNode.run's outer AND); VK: how a dictId of the value column becomes the value.
-template <int NG, bool HAS_INDEX, bool HAS_SCAN, bool HAS_TAIL, int VK>
+template <int NG, bool HAS_INDEX, bool HAS_SCAN, bool HAS_TAIL, int VK, bool DMA>
 __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
   extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
   __shared__ uint32_t s_stat[PG_MAX_STATS];
@@ -104,7 +104,7 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
   // this wavefront's strip: one or two column areas [scan bytes][value bytes][group bytes ...], then the selection list
   const uint32_t off_val = sd_region(sbits), off_g0 = off_val + sd_region(vbits), off_g1 = off_g0 + sd_region(gbits[0]);
   const uint32_t area_bytes = off_g1 + (NG > 1 ? sd_region(gbits[NG - 1]) : 0u);   // one sub-tile's column bytes
-  const uint32_t off_list = (SD_DMA ? 2u : 1u) * area_bytes;
+  const uint32_t off_list = (DMA ? 2u : 1u) * area_bytes;
   const uint32_t strip_bytes = off_list + SD_LIST_BYTES;
   uint8_t* strip = reinterpret_cast<uint8_t*>(smem) + (((size_t)p.n_ops * table_slots * 8u + 15u) & ~(size_t)15u) + (uint32_t)wave * strip_bytes;
   uint16_t* my_list = reinterpret_cast<uint16_t*>(strip + off_list);
@@ -216,7 +216,6 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
 #pragma unroll
     for (int gi = 0; gi < NG; gi++) if (g_on[gi]) *reinterpret_cast<u32x4*>(strip + (gi == 0 ? off_g0 : off_g1) + pc) = r.g[gi];
   };
-#if SD_DMA
   typedef __attribute__((address_space(3))) uint8_t LdsByte;
   // sub-tile (k, sub) of every column straight into column area `area` of the strip: lane l's 16 bytes land at piece base + 16 l
   auto dma_sub = [&](int k, int sub, uint32_t area) __attribute__((always_inline)) {
@@ -238,7 +237,6 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
       if (g_on[gi]) __builtin_amdgcn_global_load_lds(src, dst + (gi == 0 ? off_g0 : off_g1), 16, 0, SD_DMA_AUX);
     }
   };
-#endif
   uint32_t post[8], tail = 0;
   auto issue_post = [&](int k) __attribute__((always_inline)) {
     const int wt = tile_of(k);
@@ -453,44 +451,46 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
   // stored; SD_SETS = 1: one set — the next sub-tile travels while this one is filtered and aggregated (twice the wavefronts fit then) --------
   if (n_mine > 0) {
     issue_post(0);
-#if SD_DMA
-    // sub-tile u lands in column area u & 1 while sub-tile u - 1 is filtered and aggregated out of the other; what has to have landed is waited
-    // for with vmcnt(0) just before the next request goes out (the posting dwords and the dictionary look-ups in flight are older than that)
-    dma_sub(0, 0, 0u);
-    for (int k = 0; k < n_mine; k++) {
-      const uint32_t lin = tile_candidates(k);
-      issue_post(k + 1);
+    if constexpr (DMA) {
+      // sub-tile u lands in column area u & 1 while sub-tile u - 1 is filtered and aggregated out of the other; what has to have landed is waited
+      // for with vmcnt(0) just before the next request goes out (the posting dwords and the dictionary look-ups in flight are older than that)
+      dma_sub(0, 0, 0u);
+      for (int k = 0; k < n_mine; k++) {
+        const uint32_t lin = tile_candidates(k);
+        issue_post(k + 1);
 #pragma unroll
-      for (int sub = 0; sub < 4; sub++) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched: sub-tile (k, sub) is in its area
-        if (sub < 3) dma_sub(k, sub + 1, (uint32_t)((sub + 1) & 1)); else dma_sub(k + 1, 0, 0u);
-        consume(k, sub, lin, strip + (uint32_t)(sub & 1) * area_bytes);
+        for (int sub = 0; sub < 4; sub++) {
+          __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched: sub-tile (k, sub) is in its area
+          if (sub < 3) dma_sub(k, sub + 1, (uint32_t)((sub + 1) & 1)); else dma_sub(k + 1, 0, 0u);
+          consume(k, sub, lin, strip + (uint32_t)(sub & 1) * area_bytes);
+        }
       }
-    }
-#elif SD_SETS == 2
-    SdSub<NG> ra, rb;
-    issue_sub(0, 0, ra);
-    issue_sub(0, 1, rb);
-    for (int k = 0; k < n_mine; k++) {
-      const uint32_t lin = tile_candidates(k);   // (waits for tile k's posting dwords only: the sub-tiles behind them stay in flight)
-      issue_post(k + 1);
-      store_sub(ra); issue_sub(k, 2, ra); consume(k, 0, lin, strip);
-      store_sub(rb); issue_sub(k, 3, rb); consume(k, 1, lin, strip);
-      store_sub(ra); issue_sub(k + 1, 0, ra); consume(k, 2, lin, strip);
-      store_sub(rb); issue_sub(k + 1, 1, rb); consume(k, 3, lin, strip);
-    }
+    } else {
+#if SD_SETS == 2
+      SdSub<NG> ra, rb;
+      issue_sub(0, 0, ra);
+      issue_sub(0, 1, rb);
+      for (int k = 0; k < n_mine; k++) {
+        const uint32_t lin = tile_candidates(k);   // (waits for tile k's posting dwords only: the sub-tiles behind them stay in flight)
+        issue_post(k + 1);
+        store_sub(ra); issue_sub(k, 2, ra); consume(k, 0, lin, strip);
+        store_sub(rb); issue_sub(k, 3, rb); consume(k, 1, lin, strip);
+        store_sub(ra); issue_sub(k + 1, 0, ra); consume(k, 2, lin, strip);
+        store_sub(rb); issue_sub(k + 1, 1, rb); consume(k, 3, lin, strip);
+      }
 #else
-    SdSub<NG> ra;
-    issue_sub(0, 0, ra);
-    for (int k = 0; k < n_mine; k++) {
-      const uint32_t lin = tile_candidates(k);
-      issue_post(k + 1);
-      store_sub(ra); issue_sub(k, 1, ra); consume(k, 0, lin, strip);
-      store_sub(ra); issue_sub(k, 2, ra); consume(k, 1, lin, strip);
-      store_sub(ra); issue_sub(k, 3, ra); consume(k, 2, lin, strip);
-      store_sub(ra); issue_sub(k + 1, 0, ra); consume(k, 3, lin, strip);
-    }
+      SdSub<NG> ra;
+      issue_sub(0, 0, ra);
+      for (int k = 0; k < n_mine; k++) {
+        const uint32_t lin = tile_candidates(k);
+        issue_post(k + 1);
+        store_sub(ra); issue_sub(k, 1, ra); consume(k, 0, lin, strip);
+        store_sub(ra); issue_sub(k, 2, ra); consume(k, 1, lin, strip);
+        store_sub(ra); issue_sub(k, 3, ra); consume(k, 2, lin, strip);
+        store_sub(ra); issue_sub(k + 1, 0, ra); consume(k, 3, lin, strip);
+      }
 #endif
+    }
     if (VK == SD_V_GATHER) flush_pending();
   }
   {
@@ -519,17 +519,18 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
 }
 
 // one kernel per filter shape and value kind; the group-column count is a wave-uniform branch between two bodies
-#define PG_SPECD_KERNEL(NAME, IDX, SCAN, TAIL, VK) \
+#define PG_SPECD_KERNEL(NAME, IDX, SCAN, TAIL, VK, DMA) \
   extern "C" __global__ void __launch_bounds__(PG_BLOCK, SD_MIN_WAVES_PER_SIMD) NAME(const PgQueryPlan p) { \
-    if (p.n_group_cols == 1) specd_body<1, IDX, SCAN, TAIL, VK>(p); \
-    else specd_body<2, IDX, SCAN, TAIL, VK>(p); \
+    if (p.n_group_cols == 1) specd_body<1, IDX, SCAN, TAIL, VK, DMA>(p); \
+    else specd_body<2, IDX, SCAN, TAIL, VK, DMA>(p); \
   }
 #define PG_SPECD_FAMILY(SUFFIX, VK) \
-  PG_SPECD_KERNEL(pg_fast_dictrange_s##SUFFIX, true, true, false, VK)     /* the headline shape: dense index program AND range scan */ \
-  PG_SPECD_KERNEL(pg_fast_dictrange_st##SUFFIX, true, true, true, VK)     /* ... behind an upsert snapshot */ \
-  PG_SPECD_KERNEL(pg_specd_none##SUFFIX, false, false, false, VK)         /* no filter */ \
-  PG_SPECD_KERNEL(pg_specd_scan##SUFFIX, false, true, false, VK)          /* the range scan is the whole filter */ \
-  PG_SPECD_KERNEL(pg_specd_index##SUFFIX, true, false, false, VK)         /* inverted-index leaves only */
+  PG_SPECD_KERNEL(pg_fast_dictrange_s##SUFFIX, true, true, false, VK, false)     /* the headline shape: dense index program AND range scan */ \
+  PG_SPECD_KERNEL(pg_fast_dictrange_s##SUFFIX##_dma, true, true, false, VK, true) /* ... its columns by LDS-DMA into two areas per strip */ \
+  PG_SPECD_KERNEL(pg_fast_dictrange_st##SUFFIX, true, true, true, VK, false)     /* ... behind an upsert snapshot */ \
+  PG_SPECD_KERNEL(pg_specd_none##SUFFIX, false, false, false, VK, false)         /* no filter */ \
+  PG_SPECD_KERNEL(pg_specd_scan##SUFFIX, false, true, false, VK, false)          /* the range scan is the whole filter */ \
+  PG_SPECD_KERNEL(pg_specd_index##SUFFIX, true, false, false, VK, false)         /* inverted-index leaves only */
 PG_SPECD_FAMILY(_r, SD_V_RAW32)    // value column raw INT (the scan column is dictionary-encoded)
 PG_SPECD_FAMILY(_a, SD_V_AFFINE)   // value = base + step x dictId
 PG_SPECD_FAMILY(_g, SD_V_GATHER)   // value = dictionary[dictId]

@@ -17,7 +17,7 @@
 #include "pg_internal.hpp"
 #include "pg_fixed_point.h"
 
-extern "C" const int pg_specd_waves_per_block, pg_specd_column_areas;   // pg_kernels_specd.hip
+extern "C" const int pg_specd_waves_per_block;   // pg_kernels_specd.hip
 extern "C" int pg_specw_stage_bytes(int scan_bits, int value_bits, int bits0, int bits1, int n_bitmaps);   // pg_kernels_specw.hip
 extern "C" int pg_specw_list_bytes();
 extern "C" const int pg_specw_waves_per_block;
@@ -2239,15 +2239,25 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
         stage_frame = true;
       }
     }
+    bool dma = false;
     if (ok && !stage_frame) {
       auto region = [](int bits) { return bits > 0 ? (size_t)((bits * 64 + 16 + 15) & ~15) : (size_t)0; };
-      const size_t strip = (size_t)pg_specd_column_areas * ((has_scan ? region(sbits) : 0) + region(vbits) + region(D.gcols[0].bits) + (D.n_group_cols > 1 ? region(D.gcols[1].bits) : 0)) + (512 + 64) * 2;
-      const size_t fixed = 256 + (size_t)pg_specd_waves_per_block * strip + 16 + 512 * (size_t)D.n_ops;
-      const size_t limit_one = (size_t)160 * 1024 - 8192;
+      const size_t area = (has_scan ? region(sbits) : 0) + region(vbits) + region(D.gcols[0].bits) + (D.n_group_cols > 1 ? region(D.gcols[1].bits) : 0);
+      const size_t limit = (size_t)160 * 1024 - 8192;
       const size_t per_replica = (size_t)G * (size_t)D.n_ops * 8;
-      // several workgroups per CU (PG_SPECD_WGS_PER_CU) where a table of >= 8 replicas leaves room for them
-      const size_t wgs = (size_t)std::max(1, knobs().specd_wgs_per_cu);
-      const size_t limit = wgs > 1 && per_replica * std::min<size_t>(8, (size_t)D.replicas) + fixed + 1024 <= (size_t)160 * 1024 / wgs ? (size_t)160 * 1024 / wgs - 1024 : limit_one;
+      auto fixed_of = [&](size_t areas) { return 256 + (size_t)pg_specd_waves_per_block * (areas * area + (512 + 64) * 2) + 16 + 512 * (size_t)D.n_ops; };
+      // the headline shape (index AND scan, no snapshot) by LDS-DMA into two column areas per strip where the table keeps >= 8 replicas
+      // (or all it had) beside the doubled strips: +3-4 % (profiles/r06_specd_steps.txt)
+      if (has_scan && D.n_index_instr > 0 && !has_tail && !knobs().specd_no_dma) {
+        int reps = D.replicas;
+        while (reps > 8 && per_replica * (size_t)reps + fixed_of(2) > limit) reps /= 2;
+        if (per_replica * (size_t)reps + fixed_of(2) <= limit) {
+          P.lds_bytes -= per_replica * (size_t)(D.replicas - reps);
+          D.replicas = reps;
+          dma = true;
+        }
+      }
+      const size_t fixed = fixed_of(dma ? 2 : 1);
       while (D.replicas > 1 && per_replica * (size_t)D.replicas + fixed > limit) {
         D.replicas /= 2;
         P.lds_bytes -= per_replica * (size_t)D.replicas;
@@ -2258,6 +2268,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     }
     if (ok) {
       D.specd = stage_frame ? 2 : 1;
+      D.specd_dma = dma ? 1 : 0;
       D.specd_vkind = vkind;
       D.specd_sbits = has_scan ? sbits : 0;
       D.specd_vbits = vbits;

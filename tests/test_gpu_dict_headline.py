@@ -57,19 +57,23 @@ STATS = ("num_docs_scanned", "num_entries_scanned_in_filter", "num_entries_scann
 
 def _as_s(name):
     """the shared-stage frame's kernel (pg_kernels_specw.hip) under the name of its independent-wavefront twin"""
-    return name.replace("pg_fast_dictrange_w", "pg_fast_dictrange_s").replace("pg_specw_", "pg_specd_")
+    return name.replace("pg_fast_dictrange_w", "pg_fast_dictrange_s").replace("pg_specw_", "pg_specd_").replace("_dma", "")
 
 
-# both frames of the family: "s" — the product's: independent wavefronts (pg_fast_dictrange_s, pg_kernels_specd.hip); "w" — PG_SPECW=1: the
-# shared-stage frame (pg_fast_dictrange_w, pg_kernels_specw.hip) wherever two stage buffers fit beside the table — measured slower, kept parity-green
-@pytest.fixture(scope="module", params=[("s", n) for n in (1, 2049, 70_001, 700_001, 9_030_011)] + [("w", n) for n in (2049, 700_001, 3_000_017)], ids=lambda p: f"{p[0]}-{p[1]}")
+# the family's variants: "s" — the product's: independent wavefronts (pg_kernels_specd.hip), the headline shape's columns by LDS-DMA
+# (pg_fast_dictrange_s_*_dma) where the planner finds room for two column areas per strip; "n" — PG_SPECD_NO_DMA: register-staged everywhere;
+# "w" — PG_SPECW=1: the shared-stage frame (pg_fast_dictrange_w, pg_kernels_specw.hip) wherever two stage buffers fit — measured slower, kept parity-green
+FRAME_ENV = {"s": {}, "n": {"PG_SPECD_NO_DMA": "1"}, "w": {"PG_SPECW": "1"}}
+
+
+@pytest.fixture(scope="module", params=[("s", n) for n in (1, 2049, 70_001, 700_001, 9_030_011)] + [("n", n) for n in (2049, 700_001)] +
+                [("w", n) for n in (2049, 700_001, 3_000_017)], ids=lambda p: f"{p[0]}-{p[1]}")
 def pair(request, gpu_api, oracle_api):
     frame, n = request.param
-    before = os.environ.get("PG_SPECW")
-    if frame == "w":
-        os.environ["PG_SPECW"] = "1"
-    else:
-        os.environ.pop("PG_SPECW", None)
+    before = {k: os.environ.get(k) for k in ("PG_SPECW", "PG_SPECD_NO_DMA")}
+    for k in before:
+        os.environ.pop(k, None)
+    os.environ.update(FRAME_ENV[frame])
     gpu_api.call("options_reload")
     host = synth.generate_segment(n, segment_index=3, columns=COLUMNS)
     g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
@@ -77,10 +81,11 @@ def pair(request, gpu_api, oracle_api):
     yield g, o
     g.destroy()
     o.destroy()
-    if before is None:
-        os.environ.pop("PG_SPECW", None)
-    else:
-        os.environ["PG_SPECW"] = before
+    for k, v in before.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
     gpu_api.call("options_reload")
 
 
@@ -96,9 +101,11 @@ def test_dictionary_encoded_headline_matches_oracle(pair, sql, kernel):
     check = kernel and knobs_off and gb.stats.num_total_docs >= 700_001   # small segments keep sparse (CSR) postings: the interpreted leaves
     if check:
         ran = gb.stats.kernel.decode()
-        assert (ran if g.frame == "s" else _as_s(ran)) == kernel
+        assert (ran if g.frame == "n" else _as_s(ran)) == kernel
         if g.frame == "w" and sql in (synth.QUERY_CFG3_DICT, synth.QUERY_CFG3_SPARSE):
             assert ran.startswith("pg_fast_dictrange_w_")   # config 3's table leaves room for two stage buffers (the north star's 2-key table does not)
+        if g.frame == "s" and sql in (synth.QUERY_CFG3_DICT, synth.QUERY_CFG3_SPARSE) and not os.environ.get("PG_SPECD_NO_DMA") and not os.environ.get("PG_SPECW"):
+            assert ran.endswith("_dma")                     # ... and for two column areas per strip
     gb2 = g.execute(qc)   # the plan's second execution (cached plan, observed rates): the same kernel, the same answer
     assert gb2.rows() == ob.rows()
     if check:
