@@ -371,7 +371,7 @@ struct PgQueryPlan {
   const int32_t* mv_src_offsets[PG_MAX_SRCS];
   int32_t mv_src_len[PG_MAX_SRCS];
   int32_t mv;                       // 1: the plan touches a multi-value column: pg_mv_query_* run it
-  int32_t mv_pad;
+  int32_t mvg;                      // pg_mv_group_<mvg> (pg_kernels_mvg.hip): GROUP BY one multi-value column, integer accumulators over srcs[pipe_src] (or COUNT only), no filter; 4 / 8 = the entries requested per doc up front
   // Oct-layout kernels (pg_kernels_oct.hip, round 4): <= 4 group columns of <= 8 bits, COUNT at most among the ops and ONE DISTINCTCOUNTHLL /
   // DISTINCTCOUNT state.  oct = 1: the state lives in the workgroup's LDS (pg_oct_l*, the layout of pg_generic_query_l); oct = 2: pruned
   // offers (pg_oct_p*): survivors of the group floors go to the tuple stream, the partition pipeline aggregates them pass by pass.

@@ -1,0 +1,168 @@
+// pg_mv_group: GROUP BY ONE multi-value dictionary column with integer accumulators over at most one raw INT column and no filter —
+// `SELECT mv, COUNT(*), SUM(m) FROM t GROUP BY mv` — the commonest multi-value shape, as a kernel of its own (round 6).
+//
+// Reference: DictionaryBasedGroupKeyGenerator#processMultiValue (DictionaryBasedGroupKeyGenerator.java:357-368, 504-573): every entry of the
+// doc's multi-value column is a group key of the doc — repeated entries repeat the key — and aggregateGroupByMV applies the doc's value to every
+// one of its keys (CountAggregationFunction.java:120-131, SumAggregationFunction.java:181-200).
+//
+// pg_mv_query_l (pg_kernels_mv.hip) answers this shape inside the interpreter's frame: a lane walks its 32 docs one after the other, every doc
+// a chain of dependent loads (row start -> entries -> value), 231 VGPRs, 2 wavefronts per SIMD: 2.6 % of 8 TB/s.  Here the shape is fixed, so
+// the loads are not: a wavefront takes its tile's docs a BATCH of rows at a time (a row = 64 consecutive docs, one per lane); the row starts
+// and the values of batch b + 1 are requested while the entries of batch b travel, and the entries of a doc — KU of them, the column's maximum
+// where that is <= KU, positions past the doc's last entry clamped onto it — are requested together, before the first is used.  Neighbouring
+// docs' entries are neighbours in the bit stream: a row's entry loads touch one or two cache lines.  Each entry that exists is one LDS atomic
+// per accumulator at slot = dictId x R + replica.  16 wavefronts per workgroup, one workgroup per CU, <= 128 VGPRs.
+// Bytes per doc: entries x bits / 8 + the row starts (the int32 offsets of pg_segment.cpp: 4 B per doc, where the index's row-start bitmap
+// would be entries / 8) + 4 B of the value column.
+#define PG_KERNEL template <int PG_NOT_INSTANTIATED> static
+#include "pg_kernels.hip"
+
+template <typename T> DEVFN const GAS T* mvg_sgpr_ptr(const void* ptr) {
+  const uint64_t v = (uint64_t)ptr;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return (const GAS T*)(((uint64_t)hi << 32) | (uint64_t)lo);
+}
+
+// KU: entries of a doc requested up front; RB: rows of a batch.  HAS_SRC: an accumulator reads the raw INT column srcs[pipe_src].
+template <int KU, int RB, bool HAS_SRC>
+__device__ __forceinline__ void mv_group_body(const PgQueryPlan& p) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
+  __shared__ uint32_t s_stat[PG_MAX_STATS];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = uniform(t >> 6);
+  int64_t* lds_table = reinterpret_cast<int64_t*>(smem);
+  if (t < PG_MAX_STATS) s_stat[t] = 0;
+  const uint32_t R = (uint32_t)p.replicas;
+  const uint32_t real_slots = (uint32_t)p.n_groups * R;
+  const uint32_t table_slots = real_slots + 64u;   // (+ a trash slot per lane: unused here, the layout of the other LDS-table kernels' launches)
+  const int n_ops = uniform(p.n_ops);
+  for (int o = 0; o < n_ops; o++) {
+    const int64_t ident = pg_acc_identity(p.ops[o].fn, p.ops[o].is_float);
+    for (uint32_t i = t; i < table_slots; i += PG_BLOCK) lds_table[(size_t)o * table_slots + i] = ident;
+  }
+  // the accumulators as 2-bit codes in one 64-bit scalar (0 COUNT, 1 SUM, 2 MIN, 3 MAX)
+  uint64_t ops_code = 0;
+  for (int o = 0; o < n_ops; o++) {
+    const PgAccOp op = p.ops[uniform(o)];
+    ops_code |= (uint64_t)(op.src < 0 ? 0u : (op.fn == PG_ACC_SUM ? 1u : (op.fn == PG_ACC_MIN ? 2u : 3u))) << (2 * o);
+  }
+  ops_code = ((uint64_t)(uint32_t)uniform((int)(uint32_t)(ops_code >> 32)) << 32) | (uint64_t)(uint32_t)uniform((int)(uint32_t)ops_code);
+  const uint32_t bits = (uint32_t)uniform(p.gcols[0].bits);
+  const uint32_t mask = (1u << bits) - 1u;
+  const GAS int32_t* off = mvg_sgpr_ptr<int32_t>(p.mv_gcol_offsets[0]);
+  const GAS uint32_t* ent = mvg_sgpr_ptr<uint32_t>(p.gcols[0].data);
+  const GAS uint32_t* val = HAS_SRC ? mvg_sgpr_ptr<uint32_t>(p.srcs[p.pipe_src].data) : nullptr;
+  const uint32_t rep = (uint32_t)t & (R - 1u);
+  const int32_t n_docs = uniform(p.num_docs);
+  // batches of this wavefront: wave tile first + (b / BPT) * step, rows (b % BPT) * RB ...
+  constexpr int BPT = 32 / RB;   // batches per wave tile (32 rows of 64 docs)
+  const int step = (int)gridDim.x * PG_WAVES_PER_BLOCK;
+  const int first = (int)blockIdx.x * PG_WAVES_PER_BLOCK + wave;
+  const int n_tiles = first < p.n_wtiles ? (p.n_wtiles - first + step - 1) / step : 0;
+  const int n_batches = n_tiles * BPT;
+  uint32_t my_docs = 0;
+  __syncthreads();
+
+  auto doc_of = [&](int b, int r) __attribute__((always_inline)) -> int32_t {   // this lane's doc of row r of batch b
+    const int wt = first + (b / BPT) * step;
+    return (int32_t)((int64_t)wt * PG_WAVE_DOCS + (int64_t)(((b % BPT) * RB + r) * 64 + lane));
+  };
+  int32_t s_nx[RB], e_nx[RB];
+  uint32_t v_nx[RB];
+  auto request_rows = [&](int b) __attribute__((always_inline)) {   // row starts (and values) of batch b; docs past the segment: its last doc, never applied
+#pragma unroll
+    for (int r = 0; r < RB; r++) {
+      const int32_t d = doc_of(b < n_batches ? b : n_batches - 1, r);
+      const int32_t dc = d < n_docs ? d : n_docs - 1;
+      s_nx[r] = off[dc];
+      e_nx[r] = off[dc + 1];
+      if (HAS_SRC) v_nx[r] = val[dc];
+    }
+  };
+  auto apply = [&](uint32_t slot, int32_t v) __attribute__((always_inline)) {
+    for (int o = 0; o < n_ops; o++) {
+      const uint32_t code = (uint32_t)(ops_code >> (2 * o)) & 3u;   // 0 COUNT, 1 SUM, 2 MIN, 3 MAX
+      int64_t* base = lds_table + (size_t)o * table_slots;
+      if (code == 0u) atomicAdd(reinterpret_cast<unsigned long long*>(base + slot), 1ULL);
+      else if (code == 1u) atomicAdd(reinterpret_cast<unsigned long long*>(base + slot), (unsigned long long)(int64_t)v);
+      else if (code == 2u) atomicMin(reinterpret_cast<long long*>(base + slot), (long long)v);
+      else atomicMax(reinterpret_cast<long long*>(base + slot), (long long)v);
+    }
+  };
+  auto entry_of = [&](u32x2 w, uint32_t idx) __attribute__((always_inline)) -> uint32_t {   // entry idx out of the dword pair that holds its first bit
+    const uint64_t win = ((uint64_t)bswap32(w.x) << 32) | (uint64_t)bswap32(w.y);
+    return (uint32_t)(win >> (64u - (uint32_t)(((uint64_t)idx * bits) & 31u) - bits)) & mask;
+  };
+
+  if (n_batches > 0) {
+    request_rows(0);
+    for (int b = 0; b < n_batches; b++) {
+      int32_t s[RB], e[RB];
+      uint32_t v[RB];
+      bool ok[RB];
+#pragma unroll
+      for (int r = 0; r < RB; r++) { s[r] = s_nx[r]; e[r] = e_nx[r]; v[r] = HAS_SRC ? v_nx[r] : 0u; ok[r] = doc_of(b, r) < n_docs; }
+      // the batch's entries: KU per doc, all requested before the first is used (positions past the doc's last entry: that entry again)
+      u32x2 w[RB][KU];
+#pragma unroll
+      for (int r = 0; r < RB; r++) {
+#pragma unroll
+        for (int k = 0; k < KU; k++) {
+          const uint32_t idx = (uint32_t)(s[r] + k < e[r] ? s[r] + k : e[r] - 1);
+          w[r][k] = *(const GAS u32x2_a4*)(ent + (((uint64_t)idx * bits) >> 5));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      request_rows(b + 1);   // the next batch's row starts travel behind them
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < RB; r++) {
+        my_docs += ok[r] ? 1u : 0u;
+        const int32_t mv = HAS_SRC ? (int32_t)bswap32(v[r]) : 0;   // raw INT forward index: big-endian
+#pragma unroll
+        for (int k = 0; k < KU; k++) {
+          if (ok[r] && s[r] + k < e[r]) {
+            const uint32_t id = entry_of(w[r][k], (uint32_t)(s[r] + k));
+            apply(id * R + rep, mv);
+          }
+        }
+        // a doc with more than KU entries (only where the column's maximum exceeds KU): the rest one by one
+        for (int32_t i = s[r] + KU; ok[r] && i < e[r]; i++) {
+          const u32x2 wi = *(const GAS u32x2_a4*)(ent + (((uint64_t)(uint32_t)i * bits) >> 5));
+          apply(entry_of(wi, (uint32_t)i) * R + rep, mv);
+        }
+      }
+    }
+  }
+  {
+    const uint32_t wsum = wave_sum_u32(my_docs);
+    if (lane == 0 && wsum) atomicAdd(&s_stat[0], wsum);
+  }
+  __syncthreads();
+  // statistics and this workgroup's partial table [n_ops][n_groups], replicas folded
+  if (t < PG_MAX_STATS && s_stat[t]) atomicAdd(&p.stats[t], (unsigned long long)s_stat[t]);
+  {
+    const int Rr = p.replicas, groups = p.n_groups;
+    int64_t* out = p.partials + (int64_t)blockIdx.x * ((int64_t)p.n_ops * groups);
+    for (int o = 0; o < p.n_ops; o++) {
+      const int fn = p.ops[uniform(o)].fn;   // integer accumulators only (planner)
+      for (int gq = t; gq < groups; gq += PG_BLOCK) {
+        const int64_t* src = lds_table + (size_t)o * table_slots + (size_t)gq * Rr;
+        int64_t acc = src[0];
+        if (fn == PG_ACC_COUNT || fn == PG_ACC_SUM) { for (int r = 1; r < Rr; r++) acc += src[r]; }
+        else if (fn == PG_ACC_MIN) { for (int r = 1; r < Rr; r++) acc = src[r] < acc ? src[r] : acc; }
+        else { for (int r = 1; r < Rr; r++) acc = src[r] > acc ? src[r] : acc; }
+        out[(size_t)o * groups + gq] = acc;
+      }
+    }
+  }
+}
+
+// PgQueryPlan::mvg = the entries requested up front (4: columns of at most 4 entries per doc and the usual case; 8: up to 8, two rows per batch)
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_mv_group_4(const PgQueryPlan p) {
+  if (p.pipe_src >= 0) mv_group_body<4, 4, true>(p); else mv_group_body<4, 4, false>(p);
+}
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_mv_group_8(const PgQueryPlan p) {
+  if (p.pipe_src >= 0) mv_group_body<8, 2, true>(p); else mv_group_body<8, 2, false>(p);
+}

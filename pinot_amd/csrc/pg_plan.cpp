@@ -2346,6 +2346,27 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     D.specd = 0;
     D.dense_fused = 0;
     D.tile_split_shift = 0;
+    // the commonest multi-value shape as a kernel of its own (pg_kernels_mvg.hip): GROUP BY ONE multi-value column, no filter, integer
+    // accumulators over at most one raw INT single-value column, the table in LDS
+    D.mvg = 0;
+    if (!knobs().no_mvg && P.match_all && D.agg_mode == PG_AGG_LDS && D.n_group_cols == 1 && D.mv_gcol_offsets[0] != nullptr &&
+        D.gcols[0].col_kind == PG_COL_FIXED_BIT && D.gcols[0].bits >= 1 && D.gcols[0].bits <= 16 && D.n_aux == 0 && P.first_doc_op < 0 &&
+        (int64_t)G * D.replicas <= 65536 && !((q ? q->flags : 0) & PG_QUERY_FLAG_NULL_HANDLING)) {
+      bool ok = true;
+      int src = -1;
+      for (int o = 0; o < D.n_ops && ok; o++) {
+        if (D.ops[o].is_float != PG_ACCV_INT) ok = false;
+        if (D.ops[o].src < 0) continue;
+        if (src >= 0 && D.ops[o].src != src) ok = false;
+        src = D.ops[o].src;
+      }
+      if (ok && src >= 0)
+        ok = D.srcs[src].col_kind == PG_COL_RAW32 && srcs[(size_t)src]->val_type == PG_V_I32 && D.mv_src_offsets[src] == nullptr && !D.mv_src_len[src];
+      if (ok) {
+        D.mvg = P.group_cols[0]->max_entries_per_doc <= 4 ? 4 : 8;
+        D.pipe_src = src;
+      }
+    }
   }
   return plan;
 }

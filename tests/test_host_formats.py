@@ -203,6 +203,13 @@ def test_headline_kernel_has_no_register_spills():
             assert u["VGPRs Spill"] == 0 and u["VGPRs"] <= 128, (k, u)
         for k in ("pg_fast_dictrange_s_a", "pg_fast_dictrange_s_r", "pg_specd_scan_a", "pg_specd_index_a", "pg_specd_none_a"):
             assert du[k]["ScratchSize [bytes/lane]"] == 0, (k, du[k])
+    # round 6: GROUP BY one multi-value column (pg_kernels_mvg.hip): 16 wavefronts per workgroup, no scratch
+    mvg = log.replace("pg_kernels.", "pg_kernels_mvg.")
+    if os.path.exists(mvg):
+        text = open(mvg).read()
+        for k in ("pg_mv_group_4", "pg_mv_group_8"):
+            m = re.search(r"Function Name: " + k + r"\b.*?VGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+)", text, re.S)
+            assert m and int(m.group(1)) <= 128 and int(m.group(2)) == 0, (k, m and m.groups())
     # ... and its shared-stage frame (pg_kernels_specw.hip): no staging registers at all (LDS-DMA), no scratch in any of the 15 kernels
     specw = log.replace("pg_kernels.", "pg_kernels_specw.")
     if os.path.exists(specw):
