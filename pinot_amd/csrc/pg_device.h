@@ -371,7 +371,7 @@ struct PgQueryPlan {
   const int32_t* mv_src_offsets[PG_MAX_SRCS];
   int32_t mv_src_len[PG_MAX_SRCS];
   int32_t mv;                       // 1: the plan touches a multi-value column: pg_mv_query_* run it
-  int32_t mvg;                      // pg_mv_group_<mvg> (pg_kernels_mvg.hip): GROUP BY one multi-value column, integer accumulators over srcs[pipe_src] (or COUNT only), no filter; 4 / 8 = the entries requested per doc up front
+  int32_t mvg;                      // pg_mv_group_<mvg> (pg_kernels_mvg.hip): GROUP BY one multi-value column, integer accumulators over srcs[pipe_src] (or COUNT only), no filter; 4 / 8 = the entries requested per doc up front.  16 + 4 / 16 + 8: pg_mv_aggr_* — the *MV functions over the ONE multi-value INT source srcs[pipe_src], grouped by one or two single-value dictionary columns
   // Oct-layout kernels (pg_kernels_oct.hip, round 4): <= 4 group columns of <= 8 bits, COUNT at most among the ops and ONE DISTINCTCOUNTHLL /
   // DISTINCTCOUNT state.  oct = 1: the state lives in the workgroup's LDS (pg_oct_l*, the layout of pg_generic_query_l); oct = 2: pruned
   // offers (pg_oct_p*): survivors of the group floors go to the tuple stream, the partition pipeline aggregates them pass by pass.
@@ -405,7 +405,9 @@ struct PgQueryPlan {
   int32_t specd_vbits;              // ... of the value column's
   int32_t specd_base, specd_step;
   int32_t specd_dma;                // the headline shape's LDS-DMA kernels (two column areas per strip): pg_fast_dictrange_s_*_dma
-  int32_t specd_pad;
+  int32_t mvg_has_entries;          // pg_mv_aggr_*: an accumulator reads the entries' values (else only their number)
+  int32_t mvg_dict_card;            // ... and the entries' dictionary (<= 4 096 values) is copied into LDS behind the table; 0: gathered from global memory
+  int32_t mvg_pad;
 };
 
 #if defined(__HIPCC__)

@@ -36,7 +36,7 @@ PG_DECL_FAST(pg_pipe_scan) PG_DECL_FAST(pg_pipe_scan_tail) PG_DECL_FAST(pg_pipe_
 PG_DECL_FAST(pg_pipe_index) PG_DECL_FAST(pg_pipe_index_tail) PG_DECL_FAST(pg_pipe_index2) PG_DECL_FAST(pg_pipe_index2_tail)
 PG_DECL_FAST(pg_pipe_scan_vscan) PG_DECL_FAST(pg_pipe_index_scan_vscan)
 PG_DECL_FAST(pg_mv_query_f) PG_DECL_FAST(pg_mv_query_l) PG_DECL_FAST(pg_mv_query_g)   // pg_kernels_mv.hip
-PG_DECL_FAST(pg_mv_group_4) PG_DECL_FAST(pg_mv_group_8)   // pg_kernels_mvg.hip: GROUP BY one multi-value column
+PG_DECL_FAST(pg_mv_group_4) PG_DECL_FAST(pg_mv_group_8) PG_DECL_FAST(pg_mv_aggr_4) PG_DECL_FAST(pg_mv_aggr_8)   // pg_kernels_mvg.hip: GROUP BY one multi-value column; the *MV functions over one
 extern "C" const int pg_scan_waves_per_block;   // pg_kernels_scan.hip: wavefronts per workgroup of pg_fast_i32range_fp
 extern "C" const int pg_pipe_waves_per_block;   // pg_kernels_pipe.hip: wavefronts per workgroup of pg_fast_i32range_p
 extern "C" const int pg_spec_waves_per_block;   // pg_kernels_spec.hip: pg_fast_i32range_s (4 loader + 8 consumer wavefronts)
@@ -336,7 +336,7 @@ void use_device(int ordinal) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
       for (QueryKernel k : {pg_fast_dictrange_w_r, pg_fast_dictrange_wt_r, pg_specw_none_r, pg_specw_scan_r, pg_specw_index_r, pg_fast_dictrange_w_a, pg_fast_dictrange_wt_a, pg_specw_none_a, pg_specw_scan_a, pg_specw_index_a, pg_fast_dictrange_w_g, pg_fast_dictrange_wt_g, pg_specw_none_g, pg_specw_scan_g, pg_specw_index_g})
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
-      for (QueryKernel k : {pg_mv_group_4, pg_mv_group_8})
+      for (QueryKernel k : {pg_mv_group_4, pg_mv_group_8, pg_mv_aggr_4, pg_mv_aggr_8})
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
       for (QueryKernel k : {pg_mv_query_f, pg_mv_query_l, pg_mv_query_g})   // 10.5 KB of static LDS (per-wavefront entry bitmaps): the planner's 144 KB still fit
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 12288);
@@ -543,6 +543,10 @@ static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char
   }
   if (P.dev.mv) {   // a multi-value column in the filter, the group key or an aggregation (pg_kernels_mv.hip)
     if (uses_mvg(P, agg_mode)) {   // ... GROUP BY one multi-value column, no filter: its own kernel (pg_kernels_mvg.hip)
+      if (P.dev.mvg >= 16) {   // the *MV functions over one multi-value column, single-value keys
+        *name = P.dev.mvg == 20 ? "pg_mv_aggr_4" : "pg_mv_aggr_8";
+        return P.dev.mvg == 20 ? pg_mv_aggr_4 : pg_mv_aggr_8;
+      }
       *name = P.dev.mvg == 4 ? "pg_mv_group_4" : "pg_mv_group_8";
       return P.dev.mvg == 4 ? pg_mv_group_4 : pg_mv_group_8;
     }
@@ -668,7 +672,7 @@ static LaunchShape launch_shape(const CompiledPlan& P, int n_wtiles, int agg_mod
     return {std::max(grid, 1), waves * 64, 0};
   }
   if (uses_mvg(P, agg_mode))   // one 16-wavefront workgroup per CU; the table and a trash slot per lane and accumulator
-    return {std::max(1, std::min((n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, num_cus())), PG_BLOCK, lds + 64 + 512 * (size_t)P.dev.n_ops};
+    return {std::max(1, std::min((n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, num_cus())), PG_BLOCK, lds + 64 + 512 * (size_t)P.dev.n_ops + (size_t)P.dev.mvg_dict_card * 4};
   if (uses_specw(P, agg_mode)) {   // one workgroup per CU walking stages (waves x 512 docs) b, b + grid, ...; table + two stage buffers + the selection lists in LDS
     const int waves = pg_specw_waves_per_block;
     const int64_t stage_docs = (int64_t)waves * 512;

@@ -2349,10 +2349,12 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     // the commonest multi-value shape as a kernel of its own (pg_kernels_mvg.hip): GROUP BY ONE multi-value column, no filter, integer
     // accumulators over at most one raw INT single-value column, the table in LDS
     D.mvg = 0;
-    if (!knobs().no_mvg && P.match_all && D.agg_mode == PG_AGG_LDS && D.n_group_cols == 1 && D.mv_gcol_offsets[0] != nullptr &&
-        D.gcols[0].col_kind == PG_COL_FIXED_BIT && D.gcols[0].bits >= 1 && D.gcols[0].bits <= 16 && D.n_aux == 0 && P.first_doc_op < 0 &&
-        (int64_t)G * D.replicas <= 65536 && !((q ? q->flags : 0) & PG_QUERY_FLAG_NULL_HANDLING)) {
+    int mv_cols = 0, mv_at = 0;
+    for (int g = 0; g < D.n_group_cols; g++) if (D.mv_gcol_offsets[g] != nullptr) { mv_cols++; mv_at = g; }
+    if (!knobs().no_mvg && P.match_all && D.agg_mode == PG_AGG_LDS && D.n_group_cols >= 1 && D.n_group_cols <= 2 && mv_cols == 1 && D.n_aux == 0 &&
+        P.first_doc_op < 0 && (int64_t)G * D.replicas <= 65536 && !((q ? q->flags : 0) & PG_QUERY_FLAG_NULL_HANDLING)) {
       bool ok = true;
+      for (int g = 0; g < D.n_group_cols; g++) ok = ok && D.gcols[g].col_kind == PG_COL_FIXED_BIT && D.gcols[g].bits >= 1 && D.gcols[g].bits <= 16;
       int src = -1;
       for (int o = 0; o < D.n_ops && ok; o++) {
         if (D.ops[o].is_float != PG_ACCV_INT) ok = false;
@@ -2363,8 +2365,43 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
       if (ok && src >= 0)
         ok = D.srcs[src].col_kind == PG_COL_RAW32 && srcs[(size_t)src]->val_type == PG_V_I32 && D.mv_src_offsets[src] == nullptr && !D.mv_src_len[src];
       if (ok) {
-        D.mvg = P.group_cols[0]->max_entries_per_doc <= 4 ? 4 : 8;
+        D.mvg = P.group_cols[(size_t)mv_at]->max_entries_per_doc <= 4 ? 4 : 8;
         D.pipe_src = src;
+      }
+    }
+    // ... and the *MV functions over ONE multi-value INT column (its entries' values and / or their number), grouped by one or two single-value
+    // dictionary columns: pg_mv_aggr_*
+    D.mvg_has_entries = 0;
+    D.mvg_dict_card = 0;
+    if (!D.mvg && !knobs().no_mvg && P.match_all && D.agg_mode == PG_AGG_LDS && D.n_group_cols >= 1 && D.n_group_cols <= 2 && D.n_aux == 0 &&
+        P.first_doc_op < 0 && (int64_t)G * D.replicas <= 65536 && !((q ? q->flags : 0) & PG_QUERY_FLAG_NULL_HANDLING)) {
+      bool ok = true;
+      for (int g = 0; g < D.n_group_cols && ok; g++)
+        ok = D.mv_gcol_offsets[g] == nullptr && D.gcols[g].col_kind == PG_COL_FIXED_BIT && D.gcols[g].bits >= 1 && D.gcols[g].bits <= 16;
+      const int32_t* offsets = nullptr;
+      int ent_src = -1, len_src = -1, max_entries = 0;
+      for (int o = 0; o < D.n_ops && ok; o++) {
+        if (D.ops[o].is_float != PG_ACCV_INT) ok = false;
+        const int sidx = D.ops[o].src;
+        if (sidx < 0) continue;
+        if (D.mv_src_offsets[sidx] == nullptr || (offsets && offsets != D.mv_src_offsets[sidx])) { ok = false; break; }   // one multi-value column, nothing single-valued next to it
+        offsets = D.mv_src_offsets[sidx];
+        if (D.mv_src_len[sidx]) { len_src = sidx; continue; }
+        const Column* c = srcs[(size_t)sidx];
+        if (ent_src >= 0 && ent_src != sidx) ok = false;
+        ent_src = sidx;
+        ok = ok && D.srcs[sidx].col_kind == PG_COL_FIXED_BIT && D.srcs[sidx].val_type == PG_V_I32 && D.srcs[sidx].dict != nullptr && D.srcs[sidx].bits >= 1 && D.srcs[sidx].bits <= 24;
+        max_entries = c->max_entries_per_doc;
+      }
+      if (ok && offsets) {
+        D.mvg_has_entries = ent_src >= 0 ? 1 : 0;
+        D.mvg_dict_card = 0;
+        if (ent_src >= 0) {   // the dictionary in LDS where it is small and the table leaves room
+          const int32_t card = srcs[(size_t)ent_src]->cardinality;
+          if (card <= 4096 && P.lds_bytes + 512 * (size_t)D.n_ops + (size_t)card * 4 + 1024 <= (size_t)160 * 1024 - 8192) D.mvg_dict_card = card;
+        }
+        D.mvg = 16 + (ent_src < 0 || max_entries <= 4 ? 4 : 8);
+        D.pipe_src = ent_src >= 0 ? ent_src : len_src;
       }
     }
   }
