@@ -269,7 +269,9 @@ typedef enum pg_result_kind {
   PG_RESULT_AVG_PAIR = 2,  /* AvgPair(sum, count) */
   PG_RESULT_MINMAX_PAIR = 3,
   PG_RESULT_DICTID_SET = 4,/* DISTINCTCOUNT over a dictionary column: set of dictIds (decoded by the caller) */
-  PG_RESULT_HLL = 5        /* HyperLogLog registers, m = 2^log2m bytes per group */
+  PG_RESULT_HLL = 5,       /* HyperLogLog registers, m = 2^log2m bytes per group */
+  PG_RESULT_VALUE_SET = 6  /* DISTINCTCOUNT over a raw (no-dictionary) INT / LONG / FLOAT / DOUBLE column: set of VALUES — the typed open-hash sets of
+                              BaseDistinctAggregateAggregationFunction.java:325-380 (pg_result_set_sizes + pg_result_set_values_long / _double) */
 } pg_result_kind;
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -427,6 +429,10 @@ int32_t pg_result_longs(pg_result_t result, int32_t agg, int32_t component, int6
 /* DISTINCTCOUNT: sizes[g] then the concatenated ascending dictIds of every group */
 int32_t pg_result_set_sizes(pg_result_t result, int32_t agg, int32_t* out_sizes, int32_t capacity);
 int32_t pg_result_set_dict_ids(pg_result_t result, int32_t agg, int32_t* out_dict_ids, int64_t capacity);
+/* DISTINCTCOUNT over a raw column (PG_RESULT_VALUE_SET): sizes[g] as above, then the concatenated ascending VALUES of every group —
+ * _long for INT / LONG columns, _double for FLOAT / DOUBLE columns (a FLOAT widened exactly); the other one returns PG_ERR_INVALID_ARGUMENT */
+int32_t pg_result_set_values_long(pg_result_t result, int32_t agg, int64_t* out_values, int64_t capacity);
+int32_t pg_result_set_values_double(pg_result_t result, int32_t agg, double* out_values, int64_t capacity);
 /* DISTINCTCOUNTHLL: num_groups * 2^log2m register bytes, group-major */
 int32_t pg_result_hll_registers(pg_result_t result, int32_t agg, uint8_t* out_registers, int64_t capacity);
 /* The result as the bytes of a DataTableImplV4 carrying INTERMEDIATE results — what GroupByResultsBlock#getDataTable

@@ -308,6 +308,8 @@ public class GpuGroupByOperator extends BaseOperator<BaseResultsBlock> {
       }
       case PinotGpu.RESULT_DICTID_SET:
         return GpuResultObjects.valueSets(result, a, n, _segment, function);     // dictIds -> typed value Set (BaseDistinctAggregate...:671-694)
+      case PinotGpu.RESULT_VALUE_SET:
+        return GpuResultObjects.rawValueSets(result, a, n, _segment, function);  // a raw column's values -> typed value Set (:325-380)
       default:
         return GpuResultObjects.hyperLogLogs(result, a, n, function);            // register bytes -> com.clearspring HyperLogLog (RegisterSet)
     }

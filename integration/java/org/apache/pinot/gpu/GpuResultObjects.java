@@ -116,6 +116,76 @@ public final class GpuResultObjects {
     return out;
   }
 
+  /** DISTINCTCOUNT over a raw (no-dictionary) INT / LONG / FLOAT / DOUBLE column (pg_result_kind PG_RESULT_VALUE_SET): the library hands the
+   *  groups' VALUES over — the typed open-hash sets BaseDistinctAggregateAggregationFunction.java:325-380 keeps for such a column. */
+  @SuppressWarnings("rawtypes")
+  public static Object[] rawValueSets(long result, int aggregation, int numGroups, IndexSegment segment, AggregationFunction function) {
+    String column = ((ExpressionContext) function.getInputExpressions().get(0)).getIdentifier();
+    DataType stored = segment.getDataSource(column).getDataSourceMetadata().getDataType().getStoredType();
+    int[] sizes = new int[numGroups];
+    PinotGpu.resultSetSizes(result, aggregation, sizes);
+    long total = 0;
+    for (int s : sizes) {
+      total += s;
+    }
+    if (total > Integer.MAX_VALUE - 8) {
+      throw new UnsupportedOperationException("DISTINCTCOUNT state of " + total + " values exceeds one Java array");
+    }
+    boolean floating = stored == DataType.FLOAT || stored == DataType.DOUBLE;
+    long[] longs = floating ? null : new long[(int) total];
+    double[] doubles = floating ? new double[(int) total] : null;
+    if (floating) {
+      PinotGpu.resultSetValuesDouble(result, aggregation, doubles);
+    } else {
+      PinotGpu.resultSetValuesLong(result, aggregation, longs);
+    }
+    Object[] out = new Object[numGroups];
+    int at = 0;
+    for (int g = 0; g < numGroups; g++) {
+      int n = sizes[g];
+      Set set;
+      switch (stored) {
+        case INT: {
+          IntOpenHashSet s = new IntOpenHashSet(n);
+          for (int i = 0; i < n; i++) {
+            s.add((int) longs[at + i]);
+          }
+          set = s;
+          break;
+        }
+        case LONG: {
+          LongOpenHashSet s = new LongOpenHashSet(n);
+          for (int i = 0; i < n; i++) {
+            s.add(longs[at + i]);
+          }
+          set = s;
+          break;
+        }
+        case FLOAT: {
+          FloatOpenHashSet s = new FloatOpenHashSet(n);
+          for (int i = 0; i < n; i++) {
+            s.add((float) doubles[at + i]);   // widened exactly by the library
+          }
+          set = s;
+          break;
+        }
+        case DOUBLE: {
+          DoubleOpenHashSet s = new DoubleOpenHashSet(n);
+          for (int i = 0; i < n; i++) {
+            s.add(doubles[at + i]);
+          }
+          set = s;
+          break;
+        }
+        default:
+          throw new IllegalStateException("Illegal data type for a raw DISTINCT_AGGREGATE value set: " + stored);
+      }
+      out[g] = set;
+      at += n;
+    }
+    return out;
+  }
+
   /** One HyperLogLog per group from its 2^log2m register bytes. */
   public static Object[] hyperLogLogs(long result, int aggregation, int numGroups, AggregationFunction function) {
     int log2m = ((org.apache.pinot.core.query.aggregation.function.DistinctCountHLLAggregationFunction) function).getLog2m();

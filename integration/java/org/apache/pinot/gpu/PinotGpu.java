@@ -21,7 +21,7 @@ public final class PinotGpu {
   public static final int PG_ERR_UNSUPPORTED = -2;
   // pg_result_kind
   public static final int RESULT_LONG = 0, RESULT_DOUBLE = 1, RESULT_AVG_PAIR = 2, RESULT_MINMAX_PAIR = 3, RESULT_DICTID_SET = 4,
-      RESULT_HLL = 5;
+      RESULT_HLL = 5, RESULT_VALUE_SET = 6;
   public static final int GROUP_KEY_DICT_IDS = 0, GROUP_KEY_LONG_VALUES = 1, GROUP_KEY_DOUBLE_VALUES = 2, GROUP_KEY_BYTES_VALUES = 3;
 
   public static native int abiVersion();
@@ -63,6 +63,9 @@ public final class PinotGpu {
   public static native void resultLongs(long result, int aggregation, int component, long[] out);
   public static native void resultSetSizes(long result, int aggregation, int[] out);
   public static native void resultSetDictIds(long result, int aggregation, int[] out);
+  /** DISTINCTCOUNT over a raw column (RESULT_VALUE_SET): the groups' values, concatenated — Long for INT / LONG, Double for FLOAT / DOUBLE columns. */
+  public static native void resultSetValuesLong(long result, int aggregation, long[] out);
+  public static native void resultSetValuesDouble(long result, int aggregation, double[] out);
   public static native void resultHllRegisters(long result, int aggregation, byte[] out);
   // enableNullHandling: out[g] = 1 where group g's result of the aggregation / key of the group-by column is NULL
   public static native void resultAggNulls(long result, int aggregation, byte[] out);

@@ -217,6 +217,8 @@ COPY_OUT(resultDoubles(JNIEnv* env, jclass c, jlong r, jint agg, jint comp, jdou
 COPY_OUT(resultLongs(JNIEnv* env, jclass c, jlong r, jint agg, jint comp, jlongArray out), jlong, int64_t, GetLongArrayRegion, SetLongArrayRegion, pg_result_longs(RES(r), agg, comp, p, n))
 COPY_OUT(resultSetSizes(JNIEnv* env, jclass c, jlong r, jint agg, jintArray out), jint, int32_t, GetIntArrayRegion, SetIntArrayRegion, pg_result_set_sizes(RES(r), agg, p, n))
 COPY_OUT(resultSetDictIds(JNIEnv* env, jclass c, jlong r, jint agg, jintArray out), jint, int32_t, GetIntArrayRegion, SetIntArrayRegion, pg_result_set_dict_ids(RES(r), agg, p, (int64_t)n))
+COPY_OUT(resultSetValuesLong(JNIEnv* env, jclass c, jlong r, jint agg, jlongArray out), jlong, int64_t, GetLongArrayRegion, SetLongArrayRegion, pg_result_set_values_long(RES(r), agg, p, (int64_t)n))
+COPY_OUT(resultSetValuesDouble(JNIEnv* env, jclass c, jlong r, jint agg, jdoubleArray out), jdouble, double, GetDoubleArrayRegion, SetDoubleArrayRegion, pg_result_set_values_double(RES(r), agg, p, (int64_t)n))
 COPY_OUT(resultHllRegisters(JNIEnv* env, jclass c, jlong r, jint agg, jbyteArray out), jbyte, uint8_t, GetByteArrayRegion, SetByteArrayRegion, pg_result_hll_registers(RES(r), agg, p, (int64_t)n))
 /* enableNullHandling: 1 where the group's result / key is NULL (pg_result_agg_nulls, pg_result_group_key_nulls) */
 COPY_OUT(resultAggNulls(JNIEnv* env, jclass c, jlong r, jint agg, jbyteArray out), jbyte, uint8_t, GetByteArrayRegion, SetByteArrayRegion, pg_result_agg_nulls(RES(r), agg, p, n))

@@ -701,7 +701,42 @@ typedef struct agg_state {
   int star;                /* aggregating a star-tree function-column pair column (pre-aggregated values) */
   po_bitmap** dict_bitmaps;/* DISTINCTCOUNT / HLL over dictionary columns: RoaringBitmap of dictIds */
   po_hll** hlls;           /* HLL over raw columns */
+  struct po_vset* vsets;   /* DISTINCTCOUNT over a raw INT / LONG / FLOAT / DOUBLE column: the typed value sets (IntOpenHashSet ... DoubleOpenHashSet) */
 } agg_state;
+
+/* A value set of a raw column (BaseDistinctAggregateAggregationFunction.java:325-380: IntOpenHashSet / LongOpenHashSet / FloatOpenHashSet /
+ * DoubleOpenHashSet, one per group).  Kept as order-preserving 64-bit keys — value ^ 2^63 for INT / LONG; for FLOAT (widened exactly) /
+ * DOUBLE the IEEE bits with the sign folded in, so that -0.0 and 0.0 stay two elements as in fastutil's bit-wise equality — appended and
+ * sort-uniqued when the array has doubled since the last compaction. */
+typedef struct po_vset { uint64_t* k; int32_t n, cap, clean; } po_vset;
+static int vset_cmp(const void* a, const void* b) { uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b; return x < y ? -1 : x > y; }
+static void vset_compact(po_vset* s) {
+  if (s->n == s->clean) return;
+  qsort(s->k, (size_t)s->n, 8, vset_cmp);
+  int32_t m = 0;
+  for (int32_t i = 0; i < s->n; i++) if (m == 0 || s->k[m - 1] != s->k[i]) s->k[m++] = s->k[i];
+  s->n = s->clean = m;
+}
+static void vset_add(po_vset* s, uint64_t key) {
+  if (s->n == s->cap) {
+    if (s->n > 2 * s->clean + 64) vset_compact(s);
+    if (s->n * 2 >= s->cap) { s->cap = s->cap ? s->cap * 2 : 64; s->k = (uint64_t*)po_xrealloc(s->k, 8 * (size_t)s->cap); }
+  }
+  s->k[s->n++] = key;
+}
+static uint64_t vset_key_of(const po_column* c, int32_t doc) {
+  if (c->data_type == PG_TYPE_INT) return (uint64_t)(int64_t)po_raw_get_int(c, doc) ^ (1ULL << 63);
+  if (c->data_type == PG_TYPE_LONG) return (uint64_t)po_raw_get_long(c, doc) ^ (1ULL << 63);
+  double d = c->data_type == PG_TYPE_FLOAT ? (double)po_raw_get_float(c, doc) : po_raw_get_double(c, doc);
+  uint64_t b; memcpy(&b, &d, 8);
+  return (b >> 63) ? ~b : b ^ (1ULL << 63);
+}
+static int64_t vset_value_of(uint64_t key, int data_type, double* as_double) {   /* the value (INT / LONG) or the IEEE double bits behind a key */
+  if (data_type == PG_TYPE_INT || data_type == PG_TYPE_LONG) { int64_t v = (int64_t)(key ^ (1ULL << 63)); *as_double = (double)v; return v; }
+  uint64_t b = (key >> 63) ? key ^ (1ULL << 63) : ~key;
+  memcpy(as_double, &b, 8);
+  return (int64_t)b;
+}
 
 static void agg_ensure_capacity(agg_state* a, int32_t needed) { /* GroupByResultHolder#ensureCapacity */
   if (needed <= a->capacity) return;
@@ -724,7 +759,8 @@ static void agg_ensure_capacity(agg_state* a, int32_t needed) { /* GroupByResult
   if (sv_function_of(a->function) == PG_AGG_DISTINCTCOUNT || sv_function_of(a->function) == PG_AGG_DISTINCTCOUNTHLL) {
     a->dict_bitmaps = (po_bitmap**)po_xrealloc(a->dict_bitmaps, sizeof(void*) * (size_t)cap);
     a->hlls = (po_hll**)po_xrealloc(a->hlls, sizeof(void*) * (size_t)cap);
-    for (int32_t i = old; i < cap; i++) { a->dict_bitmaps[i] = NULL; a->hlls[i] = NULL; }
+    a->vsets = (po_vset*)po_xrealloc(a->vsets, sizeof(po_vset) * (size_t)cap);
+    for (int32_t i = old; i < cap; i++) { a->dict_bitmaps[i] = NULL; a->hlls[i] = NULL; memset(&a->vsets[i], 0, sizeof(po_vset)); }
   }
 }
 
@@ -907,6 +943,8 @@ static void agg_process_block(agg_state* a, block_col* bc, const int32_t* doc_id
           if (!a->hlls[g]) a->hlls[g] = po_hll_new(a->log2m);
           hll_offer_raw(a->hlls[g], c, doc_ids[i]);
         }
+      } else {   /* DISTINCTCOUNT over a raw column: valueSet.add(value) per doc (BaseDistinctAggregateAggregationFunction.java:325-380) */
+        for (int i = 0; i < n; i++) FOR_EACH_GROUP(i, g) vset_add(&a->vsets[g], vset_key_of(c, doc_ids[i]));
       }
       return;
     }
@@ -1019,6 +1057,7 @@ typedef struct po_agg_result {
   double* d[2];
   int64_t* l[2];
   int32_t* set_sizes; int32_t* set_ids; int64_t set_total;
+  int64_t* set_l; double* set_d; int set_type;   /* PG_RESULT_VALUE_SET: the concatenated ascending values (set_type = the column's data type) */
   uint8_t* hll; int32_t log2m;
   uint8_t* nulls;            /* null handling: 1 where the group's result is null (NULL: none is) */
 } po_agg_result;
@@ -1049,6 +1088,7 @@ static int result_kind(int function) {
 
 static void extract_agg(po_agg_result* r, agg_state* a, int32_t n_groups, const int32_t* gid_of) {
   r->kind = result_kind(a->function);
+  if (r->kind == PG_RESULT_DICTID_SET && a->col && !a->col->has_dictionary) r->kind = PG_RESULT_VALUE_SET;
   r->log2m = a->log2m;
   for (int k = 0; k < 2; k++) {
     r->d[k] = (double*)po_xcalloc((size_t)n_groups + 1, 8);
@@ -1069,6 +1109,26 @@ static void extract_agg(po_agg_result* r, agg_state* a, int32_t n_groups, const 
       po_bitmap* b = a->dict_bitmaps[gid_of[i]];
       if (!b) continue;
       for (int64_t d = po_bitmap_next_set(b, 0); d >= 0; d = po_bitmap_next_set(b, d + 1)) r->set_ids[k++] = (int32_t)d;
+    }
+    return;
+  }
+  if (r->kind == PG_RESULT_VALUE_SET) {
+    r->set_sizes = (int32_t*)po_xcalloc((size_t)n_groups + 1, 4);
+    r->set_type = a->col->data_type;
+    int64_t total = 0;
+    for (int32_t i = 0; i < n_groups; i++) {
+      po_vset* vs = a->vsets ? &a->vsets[gid_of[i]] : NULL;
+      if (vs) vset_compact(vs);
+      r->set_sizes[i] = vs ? vs->n : 0;
+      total += r->set_sizes[i];
+    }
+    r->set_total = total;
+    r->set_l = (int64_t*)po_xcalloc((size_t)total + 1, 8);
+    r->set_d = (double*)po_xcalloc((size_t)total + 1, 8);
+    int64_t k = 0;
+    for (int32_t i = 0; i < n_groups; i++) {
+      po_vset* vs = a->vsets ? &a->vsets[gid_of[i]] : NULL;
+      for (int32_t e = 0; vs && e < vs->n; e++, k++) r->set_l[k] = vset_value_of(vs->k[e], r->set_type, &r->set_d[k]);
     }
     return;
   }
@@ -1155,7 +1215,11 @@ static order_value agg_final_value(agg_state* a, int32_t g) {
     case PG_AGG_COUNT: v.type = 0; v.l = (int64_t)a->d0[g]; break;
     case PG_AGG_AVG: v.type = 1; v.d = a->l0[g] == 0 ? -INFINITY : a->d0[g] / (double)a->l0[g]; break;
     case PG_AGG_MINMAXRANGE: v.type = 1; v.d = a->has[g] ? a->d1[g] - a->d0[g] : -INFINITY - INFINITY; break;
-    case PG_AGG_DISTINCTCOUNT: v.type = 0; v.l = a->dict_bitmaps[g] ? po_bitmap_cardinality(a->dict_bitmaps[g]) : 0; break;
+    case PG_AGG_DISTINCTCOUNT:
+      v.type = 0;
+      if (a->col && !a->col->has_dictionary && a->vsets) { vset_compact(&a->vsets[g]); v.l = a->vsets[g].n; }
+      else v.l = a->dict_bitmaps[g] ? po_bitmap_cardinality(a->dict_bitmaps[g]) : 0;
+      break;
     case PG_AGG_DISTINCTCOUNTHLL: {
       v.type = 0;
       po_hll* h = a->col->has_dictionary ? hll_from_dict_bitmap(a->dict_bitmaps[g], a->col, a->log2m) : (a->hlls[g] ? a->hlls[g] : po_hll_new(a->log2m));
@@ -1277,8 +1341,9 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
     }
     po_column* c = po_segment_column(seg, s->column);
     if (!c) { po_set_error("column not found: %s", s->column ? s->column : "(null)"); return PG_ERR_NOT_FOUND; }
-    if ((s->function == PG_AGG_DISTINCTCOUNT) && !c->has_dictionary) {
-      po_set_error("DISTINCTCOUNT over a raw column is outside the hot path");
+    if ((s->function == PG_AGG_DISTINCTCOUNT) && !c->has_dictionary &&
+        (c->data_type > PG_TYPE_DOUBLE || c->is_mv || (q->flags & PG_QUERY_FLAG_NULL_HANDLING))) {   /* numeric single-value raw columns: typed value sets */
+      po_set_error("DISTINCTCOUNT over the raw column %s is outside the hot path", c->name);
       return PG_ERR_UNSUPPORTED;
     }
     if (c->raw_mv && sv_function_of(s->function) == PG_AGG_DISTINCTCOUNT) {   /* its intermediate is a VALUE set: not built (po_raw_mv_attach) */
@@ -1770,8 +1835,18 @@ int32_t po_result_longs(void* r, int32_t agg, int32_t comp, int64_t* out, int32_
   memcpy(out, RES(r)->aggs[agg].l[comp], sizeof(int64_t) * (size_t)RES(r)->num_groups);
   return PG_OK;
 }
+int32_t po_result_set_values_long(void* r, int32_t agg, int64_t* out, int64_t cap) {
+  if (bad_agg(r, agg) || RES(r)->aggs[agg].kind != PG_RESULT_VALUE_SET || RES(r)->aggs[agg].set_type > PG_TYPE_LONG || cap < RES(r)->aggs[agg].set_total) return PG_ERR_INVALID_ARGUMENT;
+  memcpy(out, RES(r)->aggs[agg].set_l, 8 * (size_t)RES(r)->aggs[agg].set_total);
+  return PG_OK;
+}
+int32_t po_result_set_values_double(void* r, int32_t agg, double* out, int64_t cap) {
+  if (bad_agg(r, agg) || RES(r)->aggs[agg].kind != PG_RESULT_VALUE_SET || RES(r)->aggs[agg].set_type <= PG_TYPE_LONG || cap < RES(r)->aggs[agg].set_total) return PG_ERR_INVALID_ARGUMENT;
+  memcpy(out, RES(r)->aggs[agg].set_d, 8 * (size_t)RES(r)->aggs[agg].set_total);
+  return PG_OK;
+}
 int32_t po_result_set_sizes(void* r, int32_t agg, int32_t* out, int32_t cap) {
-  if (bad_agg(r, agg) || RES(r)->aggs[agg].kind != PG_RESULT_DICTID_SET || cap < RES(r)->num_groups) return PG_ERR_INVALID_ARGUMENT;
+  if (bad_agg(r, agg) || (RES(r)->aggs[agg].kind != PG_RESULT_DICTID_SET && RES(r)->aggs[agg].kind != PG_RESULT_VALUE_SET) || cap < RES(r)->num_groups) return PG_ERR_INVALID_ARGUMENT;
   memcpy(out, RES(r)->aggs[agg].set_sizes, sizeof(int32_t) * (size_t)RES(r)->num_groups);
   return PG_OK;
 }
@@ -1804,7 +1879,7 @@ int32_t po_result_free(void* r) {
   po_result_impl* res = RES(r);
   for (int i = 0; i < res->n_aggs && res->aggs; i++) {
     for (int k = 0; k < 2; k++) { free(res->aggs[i].d[k]); free(res->aggs[i].l[k]); }
-    free(res->aggs[i].set_sizes); free(res->aggs[i].set_ids); free(res->aggs[i].hll); free(res->aggs[i].nulls);
+    free(res->aggs[i].set_sizes); free(res->aggs[i].set_ids); free(res->aggs[i].set_l); free(res->aggs[i].set_d); free(res->aggs[i].hll); free(res->aggs[i].nulls);
   }
   free(res->aggs);
   for (int j = 0; j < res->n_group_cols && res->group_dict_ids; j++) free(res->group_dict_ids[j]);

@@ -40,7 +40,7 @@ AGG_FUNCTIONS = {"COUNT": 0, "SUM": 1, "MIN": 2, "MAX": 3, "AVG": 4, "DISTINCTCO
                  "DISTINCTCOUNTMV": 14, "DISTINCTCOUNTHLLMV": 15}
 MV_TO_SV_FUNCTION = {"COUNTMV": "COUNT", "SUMMV": "SUM", "MINMV": "MIN", "MAXMV": "MAX", "AVGMV": "AVG", "MINMAXRANGEMV": "MINMAXRANGE",
                      "DISTINCTCOUNTMV": "DISTINCTCOUNT", "DISTINCTCOUNTHLLMV": "DISTINCTCOUNTHLL"}
-RESULT_LONG, RESULT_DOUBLE, RESULT_AVG_PAIR, RESULT_MINMAX_PAIR, RESULT_DICTID_SET, RESULT_HLL = range(6)
+RESULT_LONG, RESULT_DOUBLE, RESULT_AVG_PAIR, RESULT_MINMAX_PAIR, RESULT_DICTID_SET, RESULT_HLL, RESULT_VALUE_SET = range(7)
 
 QUERY_FLAG_PROFILE = 0x1
 QUERY_FLAG_SKIP_STAR_TREE = 0x2
@@ -182,7 +182,7 @@ ABI_SYMBOLS = [
     "query_supported", "query_exec",
     "result_num_groups", "result_group_dict_ids", "result_group_key_type", "result_group_values_long", "result_group_values_double",
     "result_group_values_bytes_size", "result_group_values_bytes", "result_kind_of", "result_doubles", "result_longs",
-    "result_set_sizes", "result_set_dict_ids", "result_hll_registers", "result_agg_nulls", "result_group_key_nulls", "result_stats", "result_free",
+    "result_set_sizes", "result_set_dict_ids", "result_set_values_long", "result_set_values_double", "result_hll_registers", "result_agg_nulls", "result_group_key_nulls", "result_stats", "result_free",
 ]
 # entry points only the product library has (the CPU oracle is one segment, one thread, no devices): multi-GPU placement,
 # cancellation, the dense cross-segment merge and its RCCL communicators
@@ -255,6 +255,8 @@ class NativeApi:
         self.f("result_longs").argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
         self.f("result_set_sizes").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
         self.f("result_set_dict_ids").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+        self.f("result_set_values_long").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+        self.f("result_set_values_double").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
         self.f("result_hll_registers").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
         self.f("result_agg_nulls").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
         self.f("result_group_key_nulls").argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]

@@ -426,7 +426,7 @@ int32_t pg_result_longs(pg_result_t result, int32_t agg, int32_t component, int6
 int32_t pg_result_set_sizes(pg_result_t result, int32_t agg, int32_t* out_sizes, int32_t capacity) {
   return guarded([&] {
     AggResult& a = agg_of(result, agg);
-    REQUIRE(a.kind == PG_RESULT_DICTID_SET, "aggregation is not a DISTINCTCOUNT");
+    REQUIRE(a.kind == PG_RESULT_DICTID_SET || a.kind == PG_RESULT_VALUE_SET, "aggregation is not a DISTINCTCOUNT");
     REQUIRE(capacity >= result->r->num_groups, "capacity too small");
     if (!a.set_sizes.empty()) memcpy(out_sizes, a.set_sizes.data(), a.set_sizes.size() * 4);
   });
@@ -437,6 +437,22 @@ int32_t pg_result_set_dict_ids(pg_result_t result, int32_t agg, int32_t* out_dic
     REQUIRE(a.kind == PG_RESULT_DICTID_SET, "aggregation is not a DISTINCTCOUNT");
     REQUIRE(capacity >= (int64_t)a.set_ids.size(), "capacity too small");
     if (!a.set_ids.empty()) memcpy(out_dict_ids, a.set_ids.data(), a.set_ids.size() * 4);
+  });
+}
+int32_t pg_result_set_values_long(pg_result_t result, int32_t agg, int64_t* out_values, int64_t capacity) {
+  return guarded([&] {
+    AggResult& a = agg_of(result, agg);
+    REQUIRE(a.kind == PG_RESULT_VALUE_SET && a.set_value_kind <= 1, "aggregation is not a DISTINCTCOUNT over a raw INT / LONG column");
+    REQUIRE(capacity >= (int64_t)a.l[0].size(), "capacity too small");
+    if (!a.l[0].empty()) memcpy(out_values, a.l[0].data(), a.l[0].size() * 8);
+  });
+}
+int32_t pg_result_set_values_double(pg_result_t result, int32_t agg, double* out_values, int64_t capacity) {
+  return guarded([&] {
+    AggResult& a = agg_of(result, agg);
+    REQUIRE(a.kind == PG_RESULT_VALUE_SET && a.set_value_kind >= 2, "aggregation is not a DISTINCTCOUNT over a raw FLOAT / DOUBLE column");
+    REQUIRE(capacity >= (int64_t)a.d[0].size(), "capacity too small");
+    if (!a.d[0].empty()) memcpy(out_values, a.d[0].data(), a.d[0].size() * 8);
   });
 }
 int32_t pg_result_hll_registers(pg_result_t result, int32_t agg, uint8_t* out_registers, int64_t capacity) {

@@ -223,7 +223,7 @@ std::vector<uint8_t> result_data_table_v4(const Result& r) {
           fixed.i32((int32_t)var.size());
           fixed.i32(0);
           var.i32(100);   // CustomObject.NULL_TYPE_VALUE
-          if (ar.kind == PG_RESULT_DICTID_SET) set_pos[(size_t)a] += ar.set_sizes[(size_t)i];
+          if (ar.kind == PG_RESULT_DICTID_SET || ar.kind == PG_RESULT_VALUE_SET) set_pos[(size_t)a] += ar.set_sizes[(size_t)i];
         }
         continue;
       }
@@ -263,6 +263,22 @@ std::vector<uint8_t> result_data_table_v4(const Result& r) {
             case PG_TYPE_DOUBLE: type = 17; for (int32_t e = 0; e < n; e++) p.i64(dict_i64(c, ids[e])); break;
             case PG_TYPE_STRING: type = 18; for (int32_t e = 0; e < n; e++) p.str(dict_bytes(c, ids[e], true)); break;
             default: type = 19; for (int32_t e = 0; e < n; e++) p.str(dict_bytes(c, ids[e], false)); break;
+          }
+          object(type, p);
+          break;
+        }
+        case PG_RESULT_VALUE_SET: {   // a raw column's typed value set (IntOpenHashSet / LongOpenHashSet / FloatOpenHashSet / DoubleOpenHashSet)
+          const int32_t n = ar.set_sizes[(size_t)i];
+          const size_t at = set_pos[(size_t)a];
+          set_pos[(size_t)a] += n;
+          Out p;
+          p.i32(n);
+          int32_t type = 9;
+          switch (ar.set_value_kind) {
+            case 0: type = 9; for (int32_t e = 0; e < n; e++) p.i32((int32_t)ar.l[0][at + (size_t)e]); break;
+            case 1: type = 15; for (int32_t e = 0; e < n; e++) p.i64(ar.l[0][at + (size_t)e]); break;
+            case 2: type = 16; for (int32_t e = 0; e < n; e++) { const float f = (float)ar.d[0][at + (size_t)e]; int32_t b; memcpy(&b, &f, 4); p.i32(b); } break;
+            default: type = 17; for (int32_t e = 0; e < n; e++) p.i64(ar.l[0][at + (size_t)e]); break;
           }
           object(type, p);
           break;

@@ -2370,6 +2370,13 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
             }
           }
         }
+        if (ao.aux_col && ao.aux_col->vdict_kind >= 0 && ao.aux_col->vdict_kind <= 3) {   // a raw column through its virtual dictionary: the caller gets VALUES
+          r.kind = PG_RESULT_VALUE_SET;
+          r.set_value_kind = ao.aux_col->vdict_kind;
+          r.l[0].resize(r.set_ids.size());
+          r.d[0].resize(r.set_ids.size());
+          for (size_t e = 0; e < r.set_ids.size(); e++) r.l[0][e] = vdict_value_of_key(ao.aux_col->vdict_keys[(size_t)r.set_ids[e]], ao.aux_col->vdict_kind, &r.d[0][e]);
+        }
       } else {
         r.kind = PG_RESULT_HLL;
         r.log2m = ao.log2m;

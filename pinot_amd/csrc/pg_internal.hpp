@@ -339,6 +339,7 @@ struct AggResult {
   std::vector<double> d[2];
   std::vector<int64_t> l[2];
   std::vector<int32_t> set_sizes, set_ids;   // PG_RESULT_DICTID_SET: per group sizes, concatenated ascending dictIds
+  int32_t set_value_kind = -1;               // PG_RESULT_VALUE_SET (a raw column through its virtual dictionary): 0 INT, 1 LONG (values in l[0]), 2 FLOAT, 3 DOUBLE (in d[0]; l[0] the IEEE bits), parallel to set_ids
   std::vector<uint8_t> hll;                  // PG_RESULT_HLL: num_groups * 2^log2m registers, or — big states —
   // the registers stay where the device wrote them: a page-locked block shared with the result (copying 3.3 MB of freshly DMA'd,
   // cache-cold bytes costs more than the kernel that produced them); group i's registers = hll_regs + hll_gids[i] * hll_stride

@@ -1782,15 +1782,24 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     if (fn_sv == PG_AGG_DISTINCTCOUNT || fn_sv == PG_AGG_DISTINCTCOUNTHLL) {
       if (D.n_aux >= PG_MAX_AUX) fail(PG_ERR_UNSUPPORTED, "more than %d DISTINCTCOUNT / DISTINCTCOUNTHLL aggregations", PG_MAX_AUX);
       const bool hll = fn_sv == PG_AGG_DISTINCTCOUNTHLL;
-      if (!hll && !c->has_dictionary) fail(PG_ERR_UNSUPPORTED, "DISTINCTCOUNT over a raw column is outside the hot path");
+      if (!hll && !c->has_dictionary) {
+        // BaseDistinctAggregateAggregationFunction.java:325-380 keeps typed VALUE sets for a raw column: the column's virtual dictionary
+        // (pg_vdict.hip, built once per column) turns it into a dictId set, handed back as values (PG_RESULT_VALUE_SET)
+        if (st || c->is_mv || !((c->col_kind == PG_COL_RAW32 || c->col_kind == PG_COL_RAW64) && c->data_type <= PG_TYPE_DOUBLE))
+          fail(PG_ERR_UNSUPPORTED, "DISTINCTCOUNT over the raw column %s: only single-value INT / LONG / FLOAT / DOUBLE columns", c->name.c_str());
+        if (q->flags & PG_QUERY_FLAG_NULL_HANDLING) fail(PG_ERR_UNSUPPORTED, "DISTINCTCOUNT over the raw column %s under enableNullHandling", c->name.c_str());
+        ensure_virtual_dictionary(seg, *c);
+        project(c);   // (the statistics count the column the segment knows by name)
+        c = c->vdict.get();
+      }
       if (hll && !c->has_dictionary && c->data_type > PG_TYPE_DOUBLE) fail(PG_ERR_UNSUPPORTED, "DISTINCTCOUNTHLL over a raw %d column", c->data_type);
       const int log2m = s.log2m > 0 ? s.log2m : 8;   // CommonConstants.Helix.DEFAULT_HYPERLOGLOG_LOG2M
       if (hll && (log2m < 4 || log2m > 16)) fail(PG_ERR_UNSUPPORTED, "DISTINCTCOUNTHLL log2m %d (4..16 on the GPU path)", log2m);
-      project(c);
+      if (c->vdict_kind < 0) project(c);
       PgAuxOp& A = D.aux[D.n_aux];
       A.src = src_index(c);
       A.log2m = hll ? log2m : 0;
-      if (!hll) { A.kind = PG_AUX_DICT_SET; A.stride = (c->cardinality + 31) / 32; P.dict_hashes.push_back(c->dict_hash); }   // sets are indexed by dictId
+      if (!hll) { A.kind = PG_AUX_DICT_SET; A.stride = (c->cardinality + 31) / 32; P.dict_hashes.push_back(c->vdict_kind >= 0 ? c->vdict_hash : c->dict_hash); }   // sets are indexed by dictId
       else if (c->has_dictionary) { A.kind = PG_AUX_HLL_DICT; A.stride = 1 << log2m; A.lut = hll_dict_lut(*c, log2m); }
       else { A.kind = PG_AUX_HLL_RAW; A.stride = 1 << log2m; }
       out.aux = D.n_aux++;

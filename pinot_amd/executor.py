@@ -409,6 +409,14 @@ class ResultsBlock:
                 flat = np.zeros(max(total, 1), dtype=np.int32)
                 api.call("result_set_dict_ids", h, a, flat.ctypes.data, total)
                 rb.arrays.append((k, sizes, flat[:total]))
+            elif k == capi.RESULT_VALUE_SET:   # DISTINCTCOUNT over a raw column: the values themselves
+                sizes = np.zeros(ng, dtype=np.int32)
+                api.call("result_set_sizes", h, a, sizes.ctypes.data, ng)
+                total = int(sizes.sum())
+                floating = host.columns[spec.column].data_type in ("FLOAT", "DOUBLE")
+                flat = np.zeros(max(total, 1), dtype=np.float64 if floating else np.int64)
+                api.call("result_set_values_double" if floating else "result_set_values_long", h, a, flat.ctypes.data, total)
+                rb.arrays.append((k, sizes, flat[:total]))
             elif k == capi.RESULT_HLL:
                 m = 1 << (spec.log2m or 8)
                 regs = np.empty(max(ng * m, 1), dtype=np.uint8)
@@ -478,6 +486,12 @@ class ResultsBlock:
                     col, pos = [], 0
                     for sz in arr[1]:
                         col.append(frozenset(dv[d] for d in arr[2][pos:pos + sz]))
+                        pos += sz
+                    cols.append(col)
+                elif k == capi.RESULT_VALUE_SET:
+                    col, pos = [], 0
+                    for sz in arr[1]:
+                        col.append(frozenset(arr[2][pos:pos + sz].tolist()))
                         pos += sz
                     cols.append(col)
                 else:

@@ -69,6 +69,7 @@ QUERIES = [
     "SELECT gi, DISTINCTCOUNTHLL(u), DISTINCTCOUNTHLL(u, 6) FROM dt WHERE c < 25 GROUP BY gi LIMIT 100",
     "SELECT rawk, COUNT(*), MAX(m) FROM dt GROUP BY rawk LIMIT 100",                 # a raw group key: values, not dictIds
     "SELECT rawk, gs, SUM(m) FROM dt GROUP BY rawk, gs LIMIT 100",
+    "SELECT gs, DISTINCTCOUNT(rawk), DISTINCTCOUNT(m), COUNT(*) FROM dt GROUP BY gs LIMIT 100",   # raw columns: typed VALUE sets (IntOpenHashSet)
     "SELECT COUNT(*), SUM(m), AVG(m), DISTINCTCOUNT(c), DISTINCTCOUNTHLL(u) FROM dt WHERE gi >= 0",   # AggregationResultsBlock: one row
     "SELECT gi, COUNT(*) FROM dt WHERE m > 5000 GROUP BY gi LIMIT 100",               # no groups at all
 ]
