@@ -48,6 +48,7 @@ static int scan_does_value_match(scan_state* s, int32_t doc_id) {
     int32_t d = (c->fwd_encoding == PG_FWD_DICT_SORTED) ? po_sorted_get_dict_id(c, doc_id) : po_fixedbit_read(c, doc_id);
     return po_pred_apply_dict(s->eval, d);
   }
+  if (c->data_type == PG_TYPE_STRING) { int32_t len = 0; const uint8_t* v = po_raw_get_bytes(c, doc_id, &len); return po_pred_apply_string(s->eval, v, len); }
   switch (c->data_type) {
     case PG_TYPE_INT: return po_pred_apply_int(s->eval, po_raw_get_int(c, doc_id));
     case PG_TYPE_LONG: return po_pred_apply_long(s->eval, po_raw_get_long(c, doc_id));
@@ -69,7 +70,8 @@ static int scan_match_values(scan_state* s, int limit, int32_t* doc_ids) {
   for (int i = 0; i < limit; i++) {
     int32_t d = doc_ids[i];
     int ok;
-    switch (c->data_type) {
+    if (c->data_type == PG_TYPE_STRING) { int32_t len = 0; const uint8_t* v = po_raw_get_bytes(c, d, &len); ok = po_pred_apply_string(s->eval, v, len); }
+    else switch (c->data_type) {
       case PG_TYPE_INT: ok = po_pred_apply_int(s->eval, po_raw_get_int(c, d)); break;
       case PG_TYPE_LONG: ok = po_pred_apply_long(s->eval, po_raw_get_long(c, d)); break;
       case PG_TYPE_FLOAT: ok = po_pred_apply_float(s->eval, po_raw_get_float(c, d)); break;

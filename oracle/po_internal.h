@@ -179,6 +179,8 @@ typedef struct po_pred_eval {
   int64_t lo_i, hi_i; double lo_d, hi_d; float lo_f, hi_f;   /* inclusive bounds */
   int32_t n_raw_values; int64_t* raw_i; double* raw_d;        /* EQ / IN value sets (sorted) */
   int32_t num_matching_items;   /* getNumMatchingItems */
+  /* raw STRING column: the literals (EQ / NOT_EQ / IN / NOT_IN) or the bounds (RANGE), UTF-8 as the caller gave them */
+  int32_t n_raw_s; char** raw_s; char* lo_s; char* hi_s; int lo_inc, hi_inc;   /* lo_s / hi_s NULL: unbounded */
 } po_pred_eval;
 
 po_pred_eval* po_pred_eval_create(const pg_filter_node* pred, const po_column* col);
@@ -188,6 +190,8 @@ int po_pred_apply_int(const po_pred_eval* e, int32_t v);
 int po_pred_apply_long(const po_pred_eval* e, int64_t v);
 int po_pred_apply_float(const po_pred_eval* e, float v);
 int po_pred_apply_double(const po_pred_eval* e, double v);
+int po_pred_apply_string(const po_pred_eval* e, const uint8_t* v, int32_t len);   /* a raw STRING column's value (UTF-8 bytes) */
+int po_utf16_unit_order(const uint8_t* a, int32_t alen, const uint8_t* b, int32_t blen);   /* String.compareTo over UTF-8 bytes */
 
 /* ---- filter operators / docIdSets / iterators ----------------------------------------------------------------------- */
 typedef struct po_iter po_iter;

@@ -139,12 +139,34 @@ fail:
 static float next_up_f(float v) { return nextafterf(v, INFINITY); }
 static float next_down_f(float v) { return nextafterf(v, -INFINITY); }
 
+static char* po_xstrdup(const char* s) { const size_t n = strlen(s) + 1; char* d = (char*)po_xcalloc(n, 1); memcpy(d, s, n); return d; }
 static po_pred_eval* create_raw_based(const pg_filter_node* p, const po_column* col) {
   po_pred_eval* e = (po_pred_eval*)po_xcalloc(1, sizeof(po_pred_eval));
   e->pred_type = p->predicate_type;
   e->data_type = col->data_type;
   e->num_matching_items = INT32_MIN;
   int t = col->data_type;
+  if (t == PG_TYPE_STRING && !col->is_mv) {
+    /* StringRawValueBased{Equals,NotEquals,In,NotIn,Range}PredicateEvaluator (EqualsPredicateEvaluatorFactory.java, InPredicateEvaluatorFactory.java,
+     * RangePredicateEvaluatorFactory.java: value.equals / set.contains / String#compareTo against the bounds) */
+    if (p->predicate_type == PG_PRED_RANGE) {
+      if (strcmp(p->lower, PG_RANGE_UNBOUNDED) != 0) e->lo_s = po_xstrdup(p->lower);
+      if (strcmp(p->upper, PG_RANGE_UNBOUNDED) != 0) e->hi_s = po_xstrdup(p->upper);
+      e->lo_inc = p->lower_inclusive; e->hi_inc = p->upper_inclusive;
+      return e;
+    }
+    if (p->predicate_type != PG_PRED_EQ && p->predicate_type != PG_PRED_NOT_EQ && p->predicate_type != PG_PRED_IN && p->predicate_type != PG_PRED_NOT_IN) {
+      po_set_error("predicate type %d on raw STRING column %s", p->predicate_type, col->name);
+      goto fail;
+    }
+    e->exclusive = p->predicate_type == PG_PRED_NOT_EQ || p->predicate_type == PG_PRED_NOT_IN;
+    e->n_raw_s = p->n_values;
+    e->raw_s = (char**)po_xcalloc((size_t)p->n_values + 1, sizeof(char*));
+    for (int i = 0; i < p->n_values; i++) e->raw_s[i] = po_xstrdup(p->values[i]);
+    e->num_matching_items = (p->predicate_type == PG_PRED_EQ) ? 1 : (p->predicate_type == PG_PRED_NOT_EQ) ? -1
+                            : (p->predicate_type == PG_PRED_IN) ? p->n_values : -p->n_values;
+    return e;
+  }
   if (t != PG_TYPE_INT && t != PG_TYPE_LONG && t != PG_TYPE_FLOAT && t != PG_TYPE_DOUBLE) {
     po_set_error("raw predicate on column %s of type %d is outside the hot path", col->name, t);
     goto fail;
@@ -222,7 +244,33 @@ void po_pred_eval_free(po_pred_eval* e) {
   free(e->dict_id_match);
   free(e->raw_i);
   free(e->raw_d);
+  for (int i = 0; i < e->n_raw_s; i++) free(e->raw_s[i]);
+  free(e->raw_s);
+  free(e->lo_s);
+  free(e->hi_s);
   free(e);
+}
+
+/* String.compareTo orders UTF-16 code units; UTF-8 byte order differs only where a supplementary character (lead byte F0..F4: surrogates
+ * D800..DFFF) meets U+E000..U+FFFF (lead byte EE / EF), which sort behind it in UTF-16 */
+int po_utf16_unit_order(const uint8_t* a, int32_t alen, const uint8_t* b, int32_t blen) {
+  const int32_t n = alen < blen ? alen : blen;
+  for (int32_t i = 0; i < n; i++) {
+    if (a[i] == b[i]) continue;
+    const int x = a[i] == 0xEE || a[i] == 0xEF ? a[i] + 0x10 : a[i], y = b[i] == 0xEE || b[i] == 0xEF ? b[i] + 0x10 : b[i];
+    return x < y ? -1 : 1;
+  }
+  return alen < blen ? -1 : (alen > blen ? 1 : 0);
+}
+int po_pred_apply_string(const po_pred_eval* e, const uint8_t* v, int32_t len) {
+  if (e->pred_type == PG_PRED_RANGE) {
+    if (e->lo_s) { const int c = po_utf16_unit_order(v, len, (const uint8_t*)e->lo_s, (int32_t)strlen(e->lo_s)); if (c < 0 || (c == 0 && !e->lo_inc)) return 0; }
+    if (e->hi_s) { const int c = po_utf16_unit_order(v, len, (const uint8_t*)e->hi_s, (int32_t)strlen(e->hi_s)); if (c > 0 || (c == 0 && !e->hi_inc)) return 0; }
+    return 1;
+  }
+  int found = 0;
+  for (int i = 0; i < e->n_raw_s && !found; i++) found = (int32_t)strlen(e->raw_s[i]) == len && memcmp(e->raw_s[i], v, (size_t)len) == 0;
+  return e->exclusive ? !found : found;
 }
 
 int po_pred_apply_dict(const po_pred_eval* e, int32_t d) {

@@ -116,6 +116,63 @@ static int32_t dict_insertion_index(const Column& c, const char* sv) {
   }
 }
 
+// A predicate over a raw (no-dictionary) single-value STRING column, evaluated over the column's VIRTUAL dictionary (pg_vdict.hip: the distinct
+// values + bit-packed ids): the raw-value evaluators of the reference — value.equals / set.contains / String#compareTo against the bounds
+// (EqualsPredicateEvaluatorFactory.java, InPredicateEvaluatorFactory.java, RangePredicateEvaluatorFactory.java: the String raw evaluators) —
+// applied ONCE per distinct value; the scan then tests ids.  No always-true / always-false folding: a raw evaluator has no dictionary to tell,
+// the reference scans every doc (and counts it) whatever the literal.
+static int utf16_order(const uint8_t* a, size_t alen, const uint8_t* b, size_t blen) {   // String.compareTo over UTF-8 bytes (see pg_exec.hip: utf16_unit_order)
+  const size_t n = alen < blen ? alen : blen;
+  for (size_t i = 0; i < n; i++) {
+    if (a[i] == b[i]) continue;
+    const int x = a[i] == 0xEE || a[i] == 0xEF ? a[i] + 0x10 : a[i], y = b[i] == 0xEE || b[i] == 0xEF ? b[i] + 0x10 : b[i];
+    return x < y ? -1 : 1;
+  }
+  return alen < blen ? -1 : (alen > blen ? 1 : 0);
+}
+static PredEval make_raw_string_eval(const pg_filter_node& p, const Column& twin) {
+  PredEval e;
+  e.pred_type = p.predicate_type;
+  e.data_type = PG_TYPE_STRING;
+  e.dictionary_based = true;
+  const bool is_range = p.predicate_type == PG_PRED_RANGE;
+  if (!is_range && (p.n_values < 1 || !p.values)) fail(PG_ERR_INVALID_ARGUMENT, "predicate on %s has no value", twin.name.c_str());
+  for (int i = 0; !is_range && i < p.n_values; i++)
+    if (!p.values[i]) fail(PG_ERR_INVALID_ARGUMENT, "predicate on %s: value %d is null", twin.name.c_str(), i);
+  if (is_range && (!p.lower || !p.upper)) fail(PG_ERR_INVALID_ARGUMENT, "range predicate on %s without bounds", twin.name.c_str());
+  const int32_t card = twin.cardinality;
+  e.match.assign((size_t)card, 0);
+  auto value = [&](int32_t id, size_t* len) { *len = (size_t)(twin.vdict_bytes_off[(size_t)id + 1] - twin.vdict_bytes_off[(size_t)id]); return twin.vdict_bytes.data() + twin.vdict_bytes_off[(size_t)id]; };
+  switch (p.predicate_type) {
+    case PG_PRED_EQ: case PG_PRED_NOT_EQ: case PG_PRED_IN: case PG_PRED_NOT_IN: {
+      const bool neg = p.predicate_type == PG_PRED_NOT_EQ || p.predicate_type == PG_PRED_NOT_IN;
+      const int nv = (p.predicate_type == PG_PRED_EQ || p.predicate_type == PG_PRED_NOT_EQ) ? 1 : p.n_values;
+      for (int32_t d = 0; d < card; d++) {
+        size_t len; const uint8_t* v = value(d, &len);
+        bool found = false;
+        for (int i = 0; i < nv && !found; i++) found = strlen(p.values[i]) == len && memcmp(p.values[i], v, len) == 0;
+        e.match[(size_t)d] = found != neg;
+      }
+      e.exclusive = neg;
+      break;
+    }
+    case PG_PRED_RANGE: {
+      const bool lo_unb = strcmp(p.lower, PG_RANGE_UNBOUNDED) == 0, hi_unb = strcmp(p.upper, PG_RANGE_UNBOUNDED) == 0;
+      for (int32_t d = 0; d < card; d++) {
+        size_t len; const uint8_t* v = value(d, &len);
+        bool ok = true;
+        if (!lo_unb) { const int c = utf16_order(v, len, (const uint8_t*)p.lower, strlen(p.lower)); ok = c > 0 || (c == 0 && p.lower_inclusive); }
+        if (ok && !hi_unb) { const int c = utf16_order(v, len, (const uint8_t*)p.upper, strlen(p.upper)); ok = c < 0 || (c == 0 && p.upper_inclusive); }
+        e.match[(size_t)d] = ok;
+      }
+      break;
+    }
+    default: fail(PG_ERR_UNSUPPORTED, "predicate type %d over the raw STRING column %s", p.predicate_type, twin.name.c_str());
+  }
+  for (int32_t d = 0; d < card; d++) (e.match[(size_t)d] ? e.matching : e.non_matching).push_back(d);
+  return e;
+}
+
 PredEval make_pred_eval(const pg_filter_node& p, const Column& col) {
   PredEval e;
   e.pred_type = p.predicate_type;
@@ -360,6 +417,13 @@ static OpPtr construct(Segment& seg, const pg_filter_node& f, bool nh) {   // Fi
       // a raw multi-value column is evaluated on its internal dictionary-encoded twin (built at registration): the same docs match, and
       // the scan counts the same entries (MVScanDocIdIterator over a raw column counts entries as well)
       if (col->raw_mv) col = col->vdict.get();
+      if (col->col_kind == PG_COL_VAR_BYTES && !col->has_dictionary && !col->is_mv && col->data_type == PG_TYPE_STRING) {
+        // a raw STRING column: through its virtual dictionary (built once per column), as a dictId scan over the ids
+        if (nh) fail(PG_ERR_UNSUPPORTED, "predicate over the raw STRING column %s under enableNullHandling", col->name.c_str());
+        ensure_virtual_dictionary(seg, *col);
+        Column* twin = col->vdict.get();
+        return leaf_operator(make_raw_string_eval(f, *twin), twin, f.predicate_type);
+      }
       PredEval ev = make_pred_eval(f, *col);
       // FilterOperatorUtils.java:78-88: under null handling an always-true predicate matches the docs that hold a value
       if (nh && ev.always_true && !ev.always_false)
