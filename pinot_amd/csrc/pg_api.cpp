@@ -24,7 +24,7 @@ static void knobs_read(Knobs& k) {
   k.no_radix_aux = flag("PG_NO_RADIX_AUX"); k.no_part = flag("PG_NO_PART"); k.no_radix_packed = flag("PG_NO_RADIX_PACKED");
   k.no_pipe_general = flag("PG_NO_PIPE_GENERAL"); k.no_pipe_wide = flag("PG_NO_PIPE_WIDE"); k.no_pipe_wide_double = flag("PG_NO_PIPE_WIDE_DOUBLE");
   k.mv_no_windows = flag("PG_MV_NO_WINDOWS");
-  k.no_specd = flag("PG_NO_SPECD"); k.specw = flag("PG_SPECW"); k.no_mvg = flag("PG_NO_MVG"); k.specd_no_dma = flag("PG_SPECD_NO_DMA"); k.specd_no_affine = flag("PG_SPECD_NO_AFFINE"); k.specd_wgs_per_cu = (int)num("PG_SPECD_WGS_PER_CU", 1);
+  k.no_specd = flag("PG_NO_SPECD"); k.specw = flag("PG_SPECW"); k.no_mvg = flag("PG_NO_MVG"); k.p2_no_pack = flag("PG_P2_NO_PACK"); k.specd_no_dma = flag("PG_SPECD_NO_DMA"); k.specd_no_affine = flag("PG_SPECD_NO_AFFINE"); k.specd_wgs_per_cu = (int)num("PG_SPECD_WGS_PER_CU", 1);
   k.no_oct_count = flag("PG_NO_OCT_COUNT"); k.no_oct_count_kernel = flag("PG_NO_OCT_COUNT_KERNEL"); k.oct_count_min_docs = num("PG_OCT_COUNT_MIN_DOCS", (int64_t)1 << 22);
   k.oct_min_docs = num("PG_OCT_MIN_DOCS", -1); k.part_min = (int)num("PG_PART_MIN", -1);
   k.force_interpreter = flag("PG_FORCE_INTERPRETER"); k.no_scan_pipe = flag("PG_NO_SCAN_PIPE"); k.no_pipe = flag("PG_NO_PIPE");

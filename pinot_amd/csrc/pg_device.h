@@ -407,7 +407,7 @@ struct PgQueryPlan {
   int32_t specd_dma;                // the headline shape's LDS-DMA kernels (two column areas per strip): pg_fast_dictrange_s_*_dma
   int32_t mvg_has_entries;          // pg_mv_aggr_*: an accumulator reads the entries' values (else only their number)
   int32_t mvg_dict_card;            // ... and the entries' dictionary (<= 4 096 values) is copied into LDS behind the table; 0: gathered from global memory
-  int32_t mvg_pad;
+  int32_t p2_no_pack;               // PG_P2_NO_PACK (measurement knob): COUNT and SUM keep an LDS atomic each in pg_p2_aggregate_*s
 };
 
 #if defined(__HIPCC__)

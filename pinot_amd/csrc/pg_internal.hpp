@@ -466,6 +466,7 @@ struct Knobs {
   bool no_pipe_general = false, no_pipe_wide = false, no_pipe_wide_double = false, mv_no_windows = false;
   int specd_wgs_per_cu = 1;   // PG_SPECD_WGS_PER_CU: workgroups of the pg_fast_dictrange_s family per CU (where their LDS fits)
   bool specw = false;   // PG_SPECW: the shared-stage frame (pg_fast_dictrange_w, pg_kernels_specw.hip) where it fits — a measurement variant, slower than pg_fast_dictrange_s
+  bool p2_no_pack = false;   // PG_P2_NO_PACK: no shared COUNT + SUM atomic in the partition pipeline's aggregation pass
   bool no_mvg = false;   // PG_NO_MVG: GROUP BY one multi-value column through pg_mv_query_l (the interpreter's frame), not pg_mv_group_*
   bool specd_no_dma = false;   // PG_SPECD_NO_DMA: the register-staged kernels also where the LDS-DMA kernels (pg_fast_dictrange_s_*_dma) fit
   bool no_specd = false, specd_no_affine = false;   // PG_NO_SPECD: no pg_fast_dictrange_s family; PG_SPECD_NO_AFFINE: arithmetic dictionaries are gathered like any other

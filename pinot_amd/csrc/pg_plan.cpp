@@ -2408,6 +2408,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     }
   }
   D.mv_no_windows = knobs().mv_no_windows ? 1 : 0;
+  D.p2_no_pack = knobs().p2_no_pack ? 1 : 0;
   if (D.mv) {   // none of the single-value specialisations reads a multi-value column
     P.fast_filter = -2;
     P.fast_agg = false;
