@@ -1430,7 +1430,8 @@ static std::unique_ptr<Result> execute_query_impl(Segment& seg, const pg_query& 
     static const QueryKernel aggregate_k[5] = {nullptr, pg_p2_aggregate_1, pg_p2_aggregate_2, pg_p2_aggregate_3, pg_p2_aggregate_4};
     static const QueryKernel aggregate_nogather_k[5] = {nullptr, pg_p2_aggregate_1n, pg_p2_aggregate_2n, pg_p2_aggregate_3n, pg_p2_aggregate_4n};
     bool gathers = false;   // a source travelling as a dictId is looked up in the aggregation pass
-    for (int si = 0; si < D.n_srcs; si++) gathers |= D.p2_fkind[si] == PG_P2_F_DICTID;
+    bool gathers_lean = false;   // ... in the lean consumer (pg_p2_aggregate_*s), which computes the values of arithmetic INT dictionaries (pk_affine 3)
+    for (int si = 0; si < D.n_srcs; si++) { gathers |= D.p2_fkind[si] == PG_P2_F_DICTID; gathers_lean |= D.p2_fkind[si] == PG_P2_F_DICTID && D.pk_affine[si] != 3; }
     // every work item should see >= 64 K tuples (its table is zeroed, flushed and merged whatever it aggregates)
     const int slices_max = D.radix_slices;
     D.radix_slices = (int)std::max<unsigned long long>(1, std::min<unsigned long long>((unsigned long long)slices_max, matched_now / ((unsigned long long)NB * 65536ULL)));
@@ -1484,7 +1485,7 @@ static std::unique_ptr<Result> execute_query_impl(Segment& seg, const pg_query& 
     static const QueryKernel aggregate_simple_k[2][3] = {{nullptr, pg_p2_aggregate_1s, pg_p2_aggregate_2s}, {nullptr, pg_p2_aggregate_1sg, pg_p2_aggregate_2sg}};
     const bool sets = D.n_aux == 1 && D.aux[0].kind == PG_AUX_DICT_SET;   // DISTINCTCOUNT: the bucket's dictId sets in LDS (pg_p2_aggregate_1set)
     if (sets && T != 1) fail(PG_ERR_INTERNAL, "partition pipeline: dictId sets travel in one-plane tuples");
-    const QueryKernel ak = sets ? pg_p2_aggregate_1set : (simple ? aggregate_simple_k[gathers ? 1 : 0][T] : (gathers ? aggregate_k[T] : aggregate_nogather_k[T]));
+    const QueryKernel ak = sets ? pg_p2_aggregate_1set : (simple ? aggregate_simple_k[gathers_lean ? 1 : 0][T] : (gathers ? aggregate_k[T] : aggregate_nogather_k[T]));
     hipLaunchKernelGGL(ak, dim3(agrid), dim3(PG_P2_AGG_THREADS), P.lds_bytes + 64, ctx.stream, D);
     PG_HIP(hipGetLastError());
     for (int x = 0; x < D.n_aux; x++) {

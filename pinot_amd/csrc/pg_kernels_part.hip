@@ -1084,10 +1084,10 @@ DEVFN void p2_consume(const PgQueryPlan& p, const u32x4 (&cur)[T], bool on, int6
 // rows when the work item's table leaves LDS.  The pass is bound by its LDS atomics — random local keys: 8-9 lanes per bank pair against the 4 of a
 // conflict-free instruction, 20 cycles per wave-level atomic (the same stream without them: 149 us against 357 us on the 40 k-group row)
 
-struct P2SimpleOp { int32_t fn, plane; uint32_t shift, mask, bias; int32_t vt; const GAS uint8_t* dict; };   // vt: 0 raw INT field, 1 / 2 dictId of an INT / LONG dictionary
+struct P2SimpleOp { int32_t fn, plane; uint32_t shift, mask, bias, step; int32_t vt; const GAS uint8_t* dict; };   // vt: 0 raw INT field (value = field x step + bias: a raw column minus its minimum, or the dictId of an arithmetic INT dictionary), 1 / 2 dictId of an INT / LONG dictionary
 template <int T, bool GATHER>
 DEVFN void p2_consume_simple(const P2SimpleOp (&so)[PG_P2_SIMPLE_OPS], int n_ops, const u32x4 (&cur)[T], bool on, int64_t* table, uint32_t slots, uint32_t local_mask, uint32_t pack_shift,
-                             int pk_cnt, int pk_sum) {
+                             int pk_cnt, int pk_sum, bool narrow) {
   if (!on) return;
 #ifdef PG_P2_AGG_NO_ATOMICS   // measurement variant (wrong results): the stream of the aggregation pass alone
   if ((p2_pick<T>(cur, 0, 0) ^ p2_pick<T>(cur, 0, 1) ^ p2_pick<T>(cur, 0, 2) ^ p2_pick<T>(cur, 0, 3)) == 0x12345u) table[0] = 1;
@@ -1128,7 +1128,15 @@ DEVFN void p2_consume_simple(const P2SimpleOp (&so)[PG_P2_SIMPLE_OPS], int n_ops
       if (so[o].fn == PG_ACC_COUNT) { atomicAdd(reinterpret_cast<uint32_t*>(acc), 1u); continue; }   // (a work item sees < 2^32 tuples)
       if (so[o].fn == PG_P2_SIMPLE_DOCID) { atomicMin(reinterpret_cast<long long*>(acc), (long long)p2_pick<T>(cur, so[o].plane, e)); continue; }   // MIN(docId)
       const uint32_t f = ((T == 1 ? d0 : p2_pick<T>(cur, so[o].plane, e)) >> so[o].shift) & so[o].mask;
-      int64_t v = (int64_t)(int32_t)(f + so[o].bias);
+      if (!GATHER && narrow && so[o].vt == 0 && so[o].mask != 0xFFFFFFFFu && so[o].fn != PG_ACC_SUM) {
+        // MIN / MAX of a raw INT field narrower than 32 bits: a 32-bit LDS atomic on the slot's low dword over the FIELD (value - column minimum:
+        // the same order) — MAX keeps field + 1 (0 = nothing yet: the low dword of the int64 identity), MIN the field (0xFFFFFFFF likewise);
+        // half the bank footprint of the 64-bit atomic, unpacked when the table leaves LDS
+        if (so[o].fn == PG_ACC_MIN) atomicMin(reinterpret_cast<uint32_t*>(acc), f);
+        else atomicMax(reinterpret_cast<uint32_t*>(acc), f + 1u);
+        continue;
+      }
+      int64_t v = (int64_t)(int32_t)(f * so[o].step + so[o].bias);
       if (GATHER && so[o].vt != 0) v = gv[e][o];
       if (so[o].fn == PG_ACC_SUM) atomicAdd(reinterpret_cast<unsigned long long*>(acc), (unsigned long long)v);
       else if (so[o].fn == PG_ACC_MIN) atomicMin(reinterpret_cast<long long*>(acc), (long long)v);
@@ -1161,14 +1169,17 @@ __device__ __forceinline__ void p2_aggregate_body(const PgQueryPlan& p) {
       so[o].plane = p.ops[oo].src < 0 ? p.p2_docid_plane : p.p2_fplane[src];
       so[o].shift = (uint32_t)p.pk_shift[src];
       so[o].mask = bits < 32u ? (1u << bits) - 1u : 0xFFFFFFFFu;
-      so[o].bias = (uint32_t)p.p2_fbias[src];
-      so[o].vt = p.p2_fkind[src] == PG_P2_F_DICTID ? (p.srcs[src].val_type == PG_V_I32 ? 1 : 2) : 0;
+      const bool affine = p.p2_fkind[src] == PG_P2_F_DICTID && p.pk_affine[src] == 3;
+      so[o].bias = affine ? (uint32_t)(int32_t)p.pk_base[src] : (uint32_t)p.p2_fbias[src];
+      so[o].step = affine ? (uint32_t)p.pk_step[src] : 1u;
+      so[o].vt = p.p2_fkind[src] == PG_P2_F_DICTID && !affine ? (p.srcs[src].val_type == PG_V_I32 ? 1 : 2) : 0;
       so[o].dict = gptr<uint8_t>(p.srcs[src].dict);
     }
   }
   // the COUNT(*) + SUM(raw INT field) pair that may share one atomic (see PG_P2_SIMPLE_PACKED)
   int pk_cnt = -1, pk_sum = -1;
   uint32_t pk_field_bits = 0;
+  const bool narrow = SIMPLE && !GATHER && !p.p2_no_pack;   // MIN / MAX of narrow raw fields as 32-bit atomics (p2_consume_simple)
   if (SIMPLE && !GATHER && !p.p2_no_pack) {
 #pragma unroll
     for (int o = 0; o < PG_P2_SIMPLE_OPS; o++) {   // (unrolled: a run-time index into so[] sends the array to scratch memory — 144 B, 0.94 -> 1.57 ms)
@@ -1212,26 +1223,41 @@ __device__ __forceinline__ void p2_aggregate_body(const PgQueryPlan& p) {
       bool on0 = p2_fetch<T>(tuples, plane_stride, list, n_list, (uint32_t)wave, lane, c0), on1 = false;
       for (uint32_t ci = (uint32_t)wave; ci < n_list; ci += 2u * WAVES) {
         on1 = p2_fetch<T>(tuples, plane_stride, list, n_list, ci + WAVES, lane, c1);
-        if (SIMPLE) p2_consume_simple<T, GATHER>(so, p.n_ops, c0, on0, table, slots, local_mask, pack_shift, pk_cnt, pk_sum);
+        if (SIMPLE) p2_consume_simple<T, GATHER>(so, p.n_ops, c0, on0, table, slots, local_mask, pack_shift, pk_cnt, pk_sum, narrow);
         else p2_consume<T, GATHER>(p, c0, on0, table, aux_lds, slots, local_mask);
         on0 = p2_fetch<T>(tuples, plane_stride, list, n_list, ci + 2u * WAVES, lane, c0);
-        if (SIMPLE) p2_consume_simple<T, GATHER>(so, p.n_ops, c1, on1, table, slots, local_mask, pack_shift, pk_cnt, pk_sum);
+        if (SIMPLE) p2_consume_simple<T, GATHER>(so, p.n_ops, c1, on1, table, slots, local_mask, pack_shift, pk_cnt, pk_sum, narrow);
         else p2_consume<T, GATHER>(p, c1, on1, table, aux_lds, slots, local_mask);
       }
     }
     __syncthreads();
     if (SIMPLE && pack_shift) {   // unpack: count into the COUNT row, sum of the fields + count x bias into the SUM row
-      uint32_t bias_u = 0;
+      uint32_t bias_u = 0, step_u = 1;
 #pragma unroll
-      for (int o = 0; o < PG_P2_SIMPLE_OPS; o++) if (o == pk_sum) bias_u = so[o].bias;
-      const int64_t bias = (int64_t)(int32_t)bias_u;
+      for (int o = 0; o < PG_P2_SIMPLE_OPS; o++) if (o == pk_sum) { bias_u = so[o].bias; step_u = so[o].step; }
+      const int64_t bias = (int64_t)(int32_t)bias_u, step = (int64_t)step_u;
       for (uint32_t i = (uint32_t)t; i < slots; i += PG_P2_AGG_THREADS) {
         const uint64_t v = (uint64_t)table[(size_t)pk_sum * slots + i];
         const int64_t cnt = (int64_t)(v >> pack_shift);
         table[(size_t)pk_cnt * slots + i] = cnt;
-        table[(size_t)pk_sum * slots + i] = (int64_t)(v & ((1ULL << pack_shift) - 1ULL)) + cnt * bias;
+        table[(size_t)pk_sum * slots + i] = (int64_t)(v & ((1ULL << pack_shift) - 1ULL)) * step + cnt * bias;
       }
       __syncthreads();
+    }
+    if (narrow) {   // the 32-bit MIN / MAX rows back to int64 values (identities where nothing arrived)
+      bool any = false;
+#pragma unroll
+      for (int o = 0; o < PG_P2_SIMPLE_OPS; o++) {
+        if (o >= p.n_ops || so[o].vt != 0 || so[o].mask == 0xFFFFFFFFu || (so[o].fn != PG_ACC_MIN && so[o].fn != PG_ACC_MAX)) continue;
+        any = true;
+        const int64_t bias = (int64_t)(int32_t)so[o].bias, step = (int64_t)so[o].step;
+        for (uint32_t i = (uint32_t)t; i < slots; i += PG_P2_AGG_THREADS) {
+          const uint32_t x = (uint32_t)(uint64_t)table[(size_t)o * slots + i];
+          if (so[o].fn == PG_ACC_MIN) table[(size_t)o * slots + i] = x == 0xFFFFFFFFu ? INT64_MAX : (int64_t)x * step + bias;
+          else table[(size_t)o * slots + i] = x == 0u ? INT64_MIN : (int64_t)(x - 1u) * step + bias;
+        }
+      }
+      if (any) __syncthreads();
     }
     int64_t* out = p.partials + (int64_t)w * p.n_ops * slots;
     for (int64_t i = t; i < (int64_t)p.n_ops * slots; i += PG_P2_AGG_THREADS) out[i] = table[i];

@@ -1312,6 +1312,13 @@ static bool plan_partition_v2(CompiledPlan& P, PgQueryPlan& D, const std::vector
       }
     } else if (c->col_kind == PG_COL_FIXED_BIT && c->has_dictionary && c->data_type <= PG_TYPE_DOUBLE) {
       f = {PG_P2_F_DICTID, c->bits, 0};
+      // an arithmetic INT dictionary: value = base + step x dictId, computed in the aggregation pass (no look-up: the lean consumer, pg_p2_aggregate_*s)
+      if (c->val_type == PG_V_I32 && c->dict_affine && c->dict_step > 0 && c->dict_step < (1 << 24) && c->bits <= 24 &&
+          c->dict_base >= INT32_MIN && c->dict_base <= INT32_MAX && !knobs().p2_no_pack) {
+        D.pk_affine[si] = 3;
+        D.pk_base[si] = c->dict_base;
+        D.pk_step[si] = c->dict_step;
+      }
     } else if (c->col_kind == PG_COL_RAW32 && c->val_type == PG_V_I32) {
       f = {PG_P2_F_RAW32, 32, 0};
       if (c->has_int_range) {
