@@ -223,9 +223,12 @@ typedef struct pg_query {
 #define PG_QUERY_FLAG_PROFILE 0x1          /* record per-kernel HIP-event timings into pg_exec_stats */
 #define PG_QUERY_FLAG_SKIP_STAR_TREE 0x2   /* QueryContext#isSkipStarTree (query option useStarTree=false) */
 #define PG_QUERY_FLAG_APPROX_FILTER_STATS 0x8 /* skip the exact numEntriesScannedInFilter of OR / NOT-over-scan shapes (stats_exact = 0) */
-#define PG_QUERY_FLAG_EXACT_FILTER_STATS 0x10 /* compute it whatever the segment's size: by default those shapes get the exact count up to
-                                                 2^22 docs (environment PG_EXACT_STATS_MAX_DOCS) — it costs one filter launch, one bitmap copy
-                                                 to the host and a host walk per scan / inverted leaf: 0.2 - 3 s per 10^8 docs against 0.3 ms for the query (profiles/r03_filter_stats_cost.txt) */
+#define PG_QUERY_FLAG_EXACT_FILTER_STATS 0x10 /* compute it whatever the segment's size.  By default those shapes get the exact count (a) up to 2^27 docs
+                                                 (PG_EXACT_STATS_DEVICE_MAX_DOCS) where the iterator automaton decomposes into tiles and is counted on the device —
+                                                 an AND of scans, index leaves and flat ORs of both, under drained ORs / NOTs: ~1 ms per 10^8 docs beside the
+                                                 leaves' filter launches; (b) up to 2^22 docs (PG_EXACT_STATS_MAX_DOCS) otherwise — NOT or a compound child under
+                                                 an AND, multi-value scans: one bitmap copy to the host and a host walk per leaf, 0.2 - 3 s per 10^8 docs
+                                                 (profiles/r06_filter_stats_device.txt; pg_exec_stats.filter_stats_path says which) */
 #define PG_QUERY_FLAG_FINAL_DISTINCT 0x20  /* DISTINCTCOUNT / DISTINCTCOUNTHLL come back as their FINAL value (PG_RESULT_LONG: the set's size, HyperLogLog#cardinality —
                                               AggregationFunction#extractFinalResult), not as the intermediate set / registers: for a caller that
                                               merges nothing afterwards (one segment, or after pg_result_merge / _all_reduce).  The states stay in
@@ -259,7 +262,9 @@ typedef struct pg_exec_stats {
   int64_t algorithmic_bytes;      /* bytes the plan must read once (columns + postings), for roofline accounting */
   char kernel[32];                /* name of the segment query kernel that ran (rocprofv3 kernel-trace name) */
   int32_t star_tree_index;        /* index of the star-tree the query ran on (StarTreeUtils.java:357-436), -1: none */
-  int32_t reserved0;
+  int32_t filter_stats_path;      /* how num_entries_scanned_in_filter was counted — 0: by the query's own kernels (shapes with a closed form), 1: the reference's
+                                     iterator automaton walked on the host over the leaves' match bitmaps, 2: the same automaton in tiles on the device
+                                     (AND of scans / index leaves / flat ORs under drained ORs and NOTs: pg_filter_stats_tiles.h) */
 } pg_exec_stats;
 
 /* Intermediate result kinds (AggregationFunction#getIntermediateResultColumnType). */

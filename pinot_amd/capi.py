@@ -155,7 +155,7 @@ class PgExecStats(C.Structure):
         ("algorithmic_bytes", C.c_int64),
         ("kernel", C.c_char * 32),
         ("star_tree_index", C.c_int32),
-        ("total_number_of_entries", C.c_int32),
+        ("filter_stats_path", C.c_int32),
     ]
 
     def as_dict(self) -> dict:

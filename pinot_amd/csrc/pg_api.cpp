@@ -38,6 +38,7 @@ static void knobs_read(Knobs& k) {
   k.max_inflight = (int)num("PG_MAX_INFLIGHT", 16); k.wave_specialised = flag("PG_WAVE_SPECIALISED"); k.no_wave_specialised = flag("PG_NO_WAVE_SPECIALISED");
   k.wave_specialised_min_permille = (int)num("PG_WAVE_SPECIALISED_MIN_PERMILLE", 150);
   k.exact_stats_max_docs = num("PG_EXACT_STATS_MAX_DOCS", (int64_t)1 << 22);
+  k.filter_stats_host = flag("PG_FILTER_STATS_HOST"); k.exact_stats_device_max_docs = num("PG_EXACT_STATS_DEVICE_MAX_DOCS", (int64_t)1 << 27);
   k.limit_prefix_min_docs = std::max<int64_t>(PG_WAVE_DOCS, num("PG_LIMIT_PREFIX_MIN_DOCS", (int64_t)1 << 20));
   k.oct_passes = str("PG_OCT_PASSES"); k.rccl_library = str("PG_RCCL_LIBRARY");
 }

@@ -567,6 +567,7 @@ struct ThreadCtx {
   DeviceBuffer stats, partials, final_table, tile_counts, aux;
   DeviceBuffer words, radix_hist, radix_start, radix_tuples, hash_count, hash_keys, hash_acc;   // PG_AGG_RADIX work areas
   DeviceBuffer aux_summary;   // PG_QUERY_FLAG_FINAL_DISTINCT: [n_aux][G] final values
+  DeviceBuffer fs_leaves, fs_arena;   // exact numEntriesScannedInFilter on the device: the leaves' match bitmaps, scratch (pg_filter_stats.cpp)
   DeviceBuffer trim_keys, trim_ctrl, trim_out;   // segment-level group trim on the device: [G] keys, counters, the compact block
   size_t aux_clean_bytes = 0;    // the first bytes of `aux` are zero (pg_finish_fused_kernel re-zeroes the states it folds): the next query's fill is skipped
   const void* aux_clean_ptr = nullptr;
@@ -729,32 +730,63 @@ static double order_key_to_double(int64_t k) {
 // numEntriesScannedInFilter for plans whose count the kernels' counters do not give (CompiledPlan::stats_exact == false): the match
 // bitmap of every Scan / Inverted leaf comes from a filter launch of its own, the reference's iterator automaton runs over the
 // bitmaps on the host (pg_filter_stats.cpp).
-static int64_t exact_entries_scanned(CompiledPlan& P, ThreadCtx& ctx, const CancelToken* cancel) {
+// shapes whose automaton decomposes into tiles are counted where the bitmaps are (pg_filter_stats_tiles.h); the others — NOT or a compound
+// child under an AND, multi-value scans — take the host walk
+static bool stats_counted_on_device(const CompiledPlan& P) {
+  if (knobs().filter_stats_host || P.space_docs <= 0 || !P.root_op) return false;
+  int v = P.stats_on_device.load(std::memory_order_relaxed);
+  if (v < 0) {
+    v = filter_stats_on_device(*P.root_op, P.space_docs) ? 1 : 0;
+    P.stats_on_device.store(v, std::memory_order_relaxed);
+  }
+  return v == 1;
+}
+// do this plan's statistics get the exact count by default (PG_QUERY_FLAG_EXACT_FILTER_STATS asks for it at any size)
+static bool exact_stats_by_default(const CompiledPlan& P) {
+  return (int64_t)P.space_docs <= knobs().exact_stats_max_docs || ((int64_t)P.space_docs <= knobs().exact_stats_device_max_docs && stats_counted_on_device(P));
+}
+
+static int64_t exact_entries_scanned(CompiledPlan& P, ThreadCtx& ctx, const CancelToken* cancel, int32_t* path_out = nullptr) {
   StatLeafBits bits;
   const int32_t n_docs = P.space_docs;
+  const bool on_device = stats_counted_on_device(P);
+  StatLeafWords dev_bits;
+  size_t slot_words = 0;
+  if (on_device) {
+    for (auto& lf : P.stat_leaves) slot_words = std::max(slot_words, (size_t)std::max(lf.second->dev.n_tiles, 1) * PG_TILE_WORDS);
+    ThreadCtx::grow(ctx.fs_leaves, std::max<size_t>(P.stat_leaves.size(), 1) * slot_words * 8);
+  }
+  size_t slot = 0;
   for (auto& lf : P.stat_leaves) {
     if (cancel && cancel->requested.load(std::memory_order_acquire)) fail(PG_ERR_CANCELLED, "query cancelled (EarlyTerminationException)");
     CompiledPlan& L = *lf.second;
     PgQueryPlan D = L.dev;
     const size_t dev_words = (size_t)std::max(D.n_tiles, 1) * PG_TILE_WORDS;
-    ThreadCtx::grow(ctx.words, dev_words * 8);
+    if (!on_device) ThreadCtx::grow(ctx.words, dev_words * 8);
     PG_HIP(hipMemsetAsync(ctx.stats.ptr, 0, PG_MAX_STATS * 8, ctx.stream));
     ctx.stats_dirty = true;
     D.stats = ctx.stats.as<unsigned long long>();
-    D.out_words = ctx.words.as<uint64_t>();
+    D.out_words = on_device ? ctx.fs_leaves.as<uint64_t>() + slot++ * slot_words : ctx.words.as<uint64_t>();
     D.agg_mode = PG_AGG_NONE;
     HostBits hb;
-    hb.resize_for(n_docs);
+    if (!on_device) hb.resize_for(n_docs);
     if (n_docs > 0) {
       const LaunchShape shape = launch_shape(L, D.n_wtiles, PG_AGG_NONE);
       const char* kname = "";
       hipLaunchKernelGGL(select_kernel(L, PG_AGG_NONE, &kname), dim3(shape.grid), dim3(shape.block), shape.lds, ctx.stream, D);
       PG_HIP(hipGetLastError());
+      if (on_device) { dev_bits.emplace(lf.first, D.out_words); continue; }
       PG_HIP(hipMemcpyAsync(hb.w.data(), ctx.words.ptr, (size_t)(((int64_t)n_docs + 63) / 64) * 8, hipMemcpyDeviceToHost, ctx.stream));
       PG_HIP(hipStreamSynchronize(ctx.stream));
     }
     bits.emplace(lf.first, std::move(hb));
   }
+  if (on_device) {
+    const int64_t n = entries_scanned_on_device(*P.root_op, dev_bits, n_docs, ctx.fs_arena, ctx.stream);
+    if (path_out) *path_out = 2;
+    return n;
+  }
+  if (path_out) *path_out = 1;
   return emulate_entries_scanned_in_filter(*P.root_op, bits, n_docs);
 }
 
@@ -1994,14 +2026,13 @@ static std::unique_ptr<Result> execute_query_impl(Segment& seg, const pg_query& 
     return res;
   }
   int64_t exact_entries = -1;
-  // exact numEntriesScannedInFilter of leapfrogged shapes: by default up to 2^22 docs (one filter launch + one bitmap copy + a host walk per
-  // leaf: milliseconds there, a multiple of the query on a 10^9-doc segment), on request at any size
-  const int64_t exact_max_docs = knobs().exact_stats_max_docs;
-  const bool want_exact = !(q.flags & PG_QUERY_FLAG_APPROX_FILTER_STATS) &&
-                          ((q.flags & PG_QUERY_FLAG_EXACT_FILTER_STATS) || (int64_t)P.space_docs <= exact_max_docs);
+  int32_t stats_path = 0;
+  // exact numEntriesScannedInFilter of leapfrogged shapes: by default up to 2^27 docs where the device counts it (one filter launch per leaf + the
+  // tile automaton), up to 2^22 docs where the host walks the bitmaps (a multiple of the query beyond that), on request at any size
+  const bool want_exact = !P.stats_exact && !(q.flags & PG_QUERY_FLAG_APPROX_FILTER_STATS) && ((q.flags & PG_QUERY_FLAG_EXACT_FILTER_STATS) || exact_stats_by_default(P));
   if (!P.stats_exact && want_exact) {
     check_cancel(cancel, &ctx);
-    exact_entries = exact_entries_scanned(P, ctx, cancel);
+    exact_entries = exact_entries_scanned(P, ctx, cancel, &stats_path);
     // the merged tables carry the count in the statistics tail: fold the exact value in as "full scan entries" of this segment
     H.full_scan_entries = exact_entries;
     for (int i = 1; i < PG_MAX_STATS; i++) H.stats[i] = 0;
@@ -2016,6 +2047,7 @@ static std::unique_ptr<Result> execute_query_impl(Segment& seg, const pg_query& 
               t_synced - t_queued_at, t_before_assembly - t_synced, now_ms() - t_before_assembly);
   }
   if (exact_entries >= 0) res->stats.stats_exact = 1;
+  res->stats.filter_stats_path = stats_path;
   snprintf(res->stats.kernel, sizeof(res->stats.kernel), "%s", kname);
   if (profile) {
     float a = 0, b = 0;
@@ -2632,9 +2664,8 @@ std::unique_ptr<DocIdSet> execute_filter(Segment& seg, const pg_filter_node* fil
   PG_HIP(hipStreamSynchronize(ctx.stream));
   fill_stats(out->stats, P, P.full_scan_entries, seg.total_docs, stats_host);
   {   // pg_filter_exec has no flags: the exact count of leapfrogged shapes up to the default size (see execute_query)
-    const int64_t exact_max_docs = knobs().exact_stats_max_docs;
-    if (!P.stats_exact && (int64_t)P.space_docs <= exact_max_docs) {
-      out->stats.num_entries_scanned_in_filter = exact_entries_scanned(P, ctx, nullptr);
+    if (!P.stats_exact && exact_stats_by_default(P)) {
+      out->stats.num_entries_scanned_in_filter = exact_entries_scanned(P, ctx, nullptr, &out->stats.filter_stats_path);
       out->stats.stats_exact = 1;
     }
   }

@@ -15,7 +15,12 @@
 // OrDocIdSet#iterator (OrDocIdSet.java:62-125, with the deviation DESIGN.md §2 documents: bitmap children are OR-ed into the merged
 // bitmap), NotDocIdSet, and DocIdSetOperator's drain by next() (DocIdSetOperator.java:59-86).
 #include <algorithm>
+#include <deque>
 
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_scan.hpp>
+
+#include "pg_filter_stats_tiles.h"
 #include "pg_internal.hpp"
 
 namespace pg {
@@ -308,6 +313,7 @@ enum class SetKind { Empty, MatchAll, Scan, Bitmap, Sorted, And, Or, Not };
 struct Set {
   SetKind kind = SetKind::Empty;
   const HostBits* leaf_bits = nullptr;                       // Scan: match bitmap; Bitmap: the doc set
+  const uint64_t* dev_words = nullptr;                       // the same bitmap in HBM (device evaluation; a Bitmap without it is built from `ranges`)
   const int32_t* mv_off = nullptr;                           // Scan over a multi-value column: the docs' first entries
   std::shared_ptr<HostBits> owned;                           // Bitmap built here (flips, range lists)
   std::vector<std::pair<int32_t, int32_t>> ranges;           // Sorted
@@ -319,6 +325,13 @@ struct Emu {
   const StatLeafBits& leaves;
   int32_t n_docs;
   std::vector<std::unique_ptr<Counter>> counters;
+  const StatLeafWords* dev_leaves = nullptr;   // device evaluation: the leaves' bitmaps stay in HBM (entries may be missing while only the shape is judged)
+
+  void bind_leaf(Set& s, const FilterOp& op) {
+    if (!dev_leaves) { s.leaf_bits = &leaves.at(&op); return; }
+    auto it = dev_leaves->find(&op);
+    s.dev_words = it == dev_leaves->end() ? nullptr : it->second;
+  }
 
   SetPtr mk(SetKind k) { auto s = std::make_unique<Set>(); s->kind = k; return s; }
 
@@ -347,7 +360,7 @@ struct Emu {
       case OpKind::MatchAll: return mk(SetKind::MatchAll);
       case OpKind::Scan: {
         auto s = mk(SetKind::Scan);
-        s->leaf_bits = &leaves.at(&op);
+        bind_leaf(*s, op);
         if (op.col && op.col->is_mv) s->mv_off = op.col->mv_offsets_host.data();
         return s;
       }
@@ -355,12 +368,12 @@ struct Emu {
         const std::vector<int32_t>& ids = op.eval.exclusive ? op.eval.non_matching : op.eval.matching;
         if (ids.empty()) return mk(SetKind::Empty);   // InvertedIndexFilterOperator: no dictId to look up
         auto s = mk(SetKind::Bitmap);
-        s->leaf_bits = &leaves.at(&op);
+        bind_leaf(*s, op);
         return s;
       }
       case OpKind::RangeIdx: {   // RangeIndexBasedFilterOperator over an exact index: a BitmapDocIdSet
         auto s = mk(SetKind::Bitmap);
-        s->leaf_bits = &leaves.at(&op);
+        bind_leaf(*s, op);
         return s;
       }
       case OpKind::Sorted: {
@@ -371,6 +384,10 @@ struct Emu {
       }
       case OpKind::Bitmap: {
         auto s = mk(SetKind::Bitmap);
+        if (dev_leaves) {   // filled on the device from the range list
+          for (size_t i = 0; i < op.range_lo.size(); i++) s->ranges.push_back({op.range_lo[i], op.range_hi[i]});
+          return s;
+        }
         s->owned = std::make_shared<HostBits>();
         s->owned->resize_for(n_docs);
         for (size_t i = 0; i < op.range_lo.size(); i++) s->owned->add_range(op.range_lo[i], op.range_hi[i]);
@@ -520,6 +537,312 @@ struct Emu {
   }
 };
 
+
+// ---- device evaluation (pg_filter_stats_tiles.h) --------------------------------------------------------------------------------------
+static const int kFsBlock = 256;
+
+struct FsAndProg {
+  int32_t k;                                  // children of the AndDocIdIterator, in its order
+  const uint64_t* match[FS_MAX_CHILDREN];     // the docs each child's iterator returns
+  uint64_t* targets[FS_MAX_CHILDREN];         // out (second simulation): the targets each child was advanced to; nullptr: not wanted
+};
+static const int kFsStride = FS_TILE_WORDS + 1;   // a lane's tile in LDS: 9 words apart (lanes walk their tiles independently)
+static size_t fs_and_lds_bytes(int k, bool emit) { return (size_t)(emit ? 2 : 1) * (size_t)k * 64 * kFsStride * 8; }
+
+// The AND automaton, one wavefront per workgroup over 64 consecutive tiles, a tile per lane.  The children's words of the 64 tiles (512 consecutive
+// words each) are staged in LDS by coalesced loads: read from HBM in place, every lane walked its own 64 bytes of every child word by word
+// (58 ms per 10^9 docs for two scans; profiles/r06_filter_stats_device.txt).  EMIT = false: the exit state of every entry state (`out`: the
+// tiles' maps); EMIT = true: the simulation from the true entry state (`in`: inclusive prefix of the maps), targets collected in LDS and stored whole.
+template <bool EMIT>
+__global__ void __launch_bounds__(64) fs_and_kernel(const FsAndProg p, int64_t n_docs, int64_t n_words, int64_t n_tiles, uint32_t* __restrict__ out,
+                                                     const uint32_t* __restrict__ in) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t fs_lds[];
+  const int lane = (int)threadIdx.x;
+  const int64_t tile0 = (int64_t)blockIdx.x * 64, word0 = tile0 * FS_TILE_WORDS;
+  uint64_t* const lm = fs_lds;
+  uint64_t* const lt = fs_lds + (size_t)p.k * 64 * kFsStride;
+  for (int c = 0; c < p.k; c++)
+    for (int i = lane; i < 64 * FS_TILE_WORDS; i += 64) {
+      const int64_t w = word0 + i;
+      const int at = (c * 64 + i / FS_TILE_WORDS) * kFsStride + i % FS_TILE_WORDS;
+      lm[at] = w < n_words ? p.match[c][w] : 0;
+      if (EMIT) lt[at] = 0;
+    }
+  __syncthreads();
+  const int64_t tile = tile0 + lane;
+  struct Io {   // the lane's tile: positions relative to its first doc
+    const uint64_t* m;
+    uint64_t* t;
+    int lane;
+    __device__ __forceinline__ uint64_t match(int c, int32_t w) const { return m[(c * 64 + lane) * kFsStride + w]; }
+    __device__ __forceinline__ void target(int c, int32_t doc) { t[(c * 64 + lane) * kFsStride + (doc >> 6)] |= 1ULL << (doc & 63); }
+  } io{lm, lt, lane};
+  if (tile < n_tiles) {
+    const int64_t lo = tile * (FS_TILE_WORDS * 64);
+    const int32_t end = (int32_t)(lo + FS_TILE_WORDS * 64 < n_docs ? FS_TILE_WORDS * 64 : n_docs - lo);
+    if (!EMIT) out[tile] = fs_and_tile_exits(p.k, io, end);
+    else (void)fs_and_tile(p.k, io, 0, end, tile ? (in[tile - 1] & 15u) : FS_CLEAN, true);   // the entry: what a clean start of the segment has become by here
+  }
+  if (EMIT) {
+    __syncthreads();
+    for (int c = 0; c < p.k; c++) {
+      if (!p.targets[c]) continue;
+      for (int i = lane; i < 64 * FS_TILE_WORDS; i += 64)
+        if (word0 + i < n_words) p.targets[c][word0 + i] = lt[(c * 64 + i / FS_TILE_WORDS) * kFsStride + i % FS_TILE_WORDS];
+    }
+  }
+}
+__device__ __forceinline__ void fs_block_add(unsigned long long v, unsigned long long* total) {
+  __shared__ unsigned long long s_sum;
+  if (threadIdx.x == 0) s_sum = 0;
+  __syncthreads();
+  if (v) atomicAdd(&s_sum, v);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_sum) atomicAdd(total, s_sum);
+}
+// The visited latch, a word per lane and a tile (FS_LATCH_WORDS = 64 words) per wavefront: the words' summaries combine through two ballots
+__global__ void __launch_bounds__(kFsBlock) fs_latch_summary_kernel(const uint64_t* __restrict__ t, const uint64_t* __restrict__ m, int64_t n_words, uint8_t* __restrict__ out) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t s = w < n_words ? fs_latch_summary(t, m, w, w + 1) : 0u;
+  const unsigned long long ev = __ballot(s != 0), set = __ballot(s == 1);
+  if ((threadIdx.x & 63) == 0) out[w >> 6] = ev ? (uint8_t)(((set >> (63 - __clzll((long long)ev))) & 1ULL) ? 1 : 2) : (uint8_t)0;
+}
+__global__ void __launch_bounds__(kFsBlock) fs_latch_count_kernel(const uint64_t* __restrict__ t, const uint64_t* __restrict__ m, int64_t n_words,
+                                                                  const uint8_t* __restrict__ prefix, int64_t n_docs, unsigned long long* total) {
+  const int lane = (int)(threadIdx.x & 63);
+  const int64_t n_latch_tiles = (n_words + 63) >> 6, waves = (int64_t)gridDim.x * (kFsBlock / 64);
+  unsigned long long v = 0;
+  for (int64_t tile = (int64_t)blockIdx.x * (kFsBlock / 64) + (threadIdx.x >> 6); tile < n_latch_tiles; tile += waves) {
+    const int64_t w = tile * 64 + lane;
+    const uint32_t s = w < n_words ? fs_latch_summary(t, m, w, w + 1) : 0u;
+    const unsigned long long ev = __ballot(s != 0), set = __ballot(s == 1);
+    const unsigned long long below = ev & ((1ULL << lane) - 1ULL);   // the words of this tile before the lane's
+    const bool carry = below ? ((set >> (63 - __clzll((long long)below))) & 1ULL) != 0 : (tile > 0 && prefix[tile - 1] == 1);
+    if (w < n_words) v += (unsigned long long)fs_latch_count(t, m, w, w + 1, carry, n_docs);
+  }
+  for (int off = 32; off; off >>= 1) v += __shfl_down(v, off);
+  if (lane == 0 && v) atomicAdd(total, v);
+}
+// dst = a (op) b word by word — op 0: AND, 1: OR, 2: copy of a; with `total`: the docs of `a` (before the operation) are added to it
+__global__ void fs_words_kernel(uint64_t* __restrict__ dst, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, int64_t n_words, int64_t n_docs, int op,
+                                unsigned long long* total) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long c = 0;
+  if (w < n_words) {
+    uint64_t x = a[w];
+    if (w * 64 + 64 > n_docs) x &= ~0ULL >> (64 - (n_docs - w * 64));   // (the last word: docs that exist)
+    c = (unsigned long long)__popcll(x);
+    dst[w] = op == 0 ? (x & b[w]) : op == 1 ? (x | b[w]) : x;
+  }
+  if (total) fs_block_add(c, total);
+}
+__global__ void fs_fill_ranges_kernel(uint64_t* __restrict__ dst, const int32_t* __restrict__ lo, const int32_t* __restrict__ hi, int32_t n_ranges, int64_t n_words) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  const int64_t first = w * 64, last = first + 63;
+  // ascending disjoint inclusive ranges: the first one that ends at or behind this word's first doc
+  int32_t a = 0, b = n_ranges;
+  while (a < b) {
+    const int32_t mid = (a + b) >> 1;
+    if ((int64_t)hi[mid] < first) a = mid + 1; else b = mid;
+  }
+  uint64_t x = 0;
+  for (int32_t r = a; r < n_ranges && (int64_t)lo[r] <= last; r++) {
+    const int64_t s = (int64_t)lo[r] > first ? (int64_t)lo[r] : first, e = (int64_t)hi[r] < last ? (int64_t)hi[r] : last;
+    x |= (~0ULL << (s - first)) & (~0ULL >> (63 - (e - first)));
+  }
+  dst[w] = x;
+}
+struct FsMapThen { __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return fs_map_then(a, b); } };
+struct FsLatchThen { __host__ __device__ uint8_t operator()(uint8_t a, uint8_t b) const { return b ? b : a; } };
+
+// The walk over the doc-id SETS that Emu::iterator makes on the host, with bitmaps in HBM and the AND automaton in tiles.  Two passes over the same
+// code: a dry one that only sizes the scratch, then the launches.
+struct DevEval {
+  Emu& emu;
+  int64_t n_docs, n_words, n_tiles, n_latch_tiles;
+  hipStream_t stream;
+  bool dry = true;
+  uint8_t* base = nullptr;
+  size_t off = 0;
+  int64_t closed_form = 0;               // drained scans: every doc once
+  unsigned long long* total = nullptr;   // device counter of everything else
+  std::deque<std::vector<int32_t>> keep_alive;
+
+  template <typename T> T* take(size_t count) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = dry ? nullptr : reinterpret_cast<T*>(base + off);
+    off += count * sizeof(T);
+    return p;
+  }
+  uint64_t* take_words() { return take<uint64_t>((size_t)n_words + 1); }
+  dim3 grid_for(int64_t lanes) const { return dim3((unsigned)((lanes + kFsBlock - 1) / kFsBlock)); }
+
+  enum class Kind { Scan, Bitmap, Sorted, Other, Unfit };
+  // what Emu::iterator would hand the AND for this child
+  static Kind child_kind(const Set& s) {
+    switch (s.kind) {
+      case SetKind::Scan: return s.mv_off ? Kind::Unfit : Kind::Scan;
+      case SetKind::Bitmap: return Kind::Bitmap;
+      case SetKind::Sorted: return Kind::Sorted;
+      case SetKind::Or: {
+        int n_sorted = 0, n_other = 0;
+        for (auto& c : s.children) {
+          if (c->kind == SetKind::Scan) { if (c->mv_off) return Kind::Unfit; n_other++; }
+          else if (c->kind == SetKind::Sorted) n_sorted++;
+          else if (c->kind != SetKind::Bitmap) return Kind::Unfit;   // compound children of an OR under an AND: the host walk
+        }
+        return n_sorted > 1 && n_other == 0 ? Kind::Bitmap : Kind::Other;   // OrDocIdSet#iterator merges index-based children only beside >= 2 sorted ones
+      }
+      default: return Kind::Unfit;   // Empty / MatchAll / Not / And under an AND
+    }
+  }
+  static bool fits_and(const Set& s) {
+    int n_index = 0, n_scan = 0, n_other = 0;
+    for (auto& c : s.children) {
+      const Kind k = child_kind(*c);
+      if (k == Kind::Unfit) return false;
+      n_index += k == Kind::Bitmap || k == Kind::Sorted;
+      n_scan += k == Kind::Scan;
+      n_other += k == Kind::Other;
+    }
+    const bool merged = (n_index > 0 && n_scan > 0) || n_index > 1;
+    return (merged ? 1 + n_other : (int)s.children.size()) <= FS_MAX_CHILDREN;
+  }
+  static bool fits_drained(const Set& s) {
+    switch (s.kind) {
+      case SetKind::Scan: return !s.mv_off;
+      case SetKind::Not: return fits_drained(*s.children[0]);
+      case SetKind::Or: for (auto& c : s.children) if (!fits_drained(*c)) return false; return true;
+      case SetKind::And: return fits_and(s);
+      default: return true;
+    }
+  }
+
+  const uint64_t* ranges_words(const std::vector<std::pair<int32_t, int32_t>>& r) {
+    uint64_t* w = take_words();
+    int32_t* lo = take<int32_t>(r.size() + 1);
+    int32_t* hi = take<int32_t>(r.size() + 1);
+    if (dry) return w;
+    keep_alive.emplace_back();
+    std::vector<int32_t>& h = keep_alive.back();
+    for (auto& p : r) h.push_back(p.first);
+    for (auto& p : r) h.push_back(p.second);
+    if (!r.empty()) {
+      PG_HIP(hipMemcpyAsync(lo, h.data(), r.size() * 4, hipMemcpyHostToDevice, stream));
+      PG_HIP(hipMemcpyAsync(hi, h.data() + r.size(), r.size() * 4, hipMemcpyHostToDevice, stream));
+    }
+    hipLaunchKernelGGL(fs_fill_ranges_kernel, grid_for(n_words), dim3(kFsBlock), 0, stream, w, lo, hi, (int32_t)r.size(), n_words);
+    return w;
+  }
+  const uint64_t* leaf_words(const Set& s) {   // Scan / Bitmap / Sorted
+    if (s.kind == SetKind::Sorted || (s.kind == SetKind::Bitmap && !s.dev_words)) return ranges_words(s.ranges);
+    if (!dry && !s.dev_words) fail(PG_ERR_INTERNAL, "filter statistics: a leaf's match bitmap is missing");
+    return s.dev_words;
+  }
+  void words_op(uint64_t* dst, const uint64_t* a, const uint64_t* b, int op, bool count_a) {
+    if (dry) return;
+    hipLaunchKernelGGL(fs_words_kernel, grid_for(n_words), dim3(kFsBlock), 0, stream, dst, a, b ? b : a, n_words, n_docs, op, count_a ? total : nullptr);
+  }
+  const uint64_t* or_words(const Set& s) {   // the docs an OR's iterator returns
+    uint64_t* acc = take_words();
+    bool first = true;
+    for (auto& c : s.children) {
+      const uint64_t* w = leaf_words(*c);
+      words_op(acc, first ? w : acc, first ? nullptr : w, first ? 2 : 1, false);
+      first = false;
+    }
+    return acc;
+  }
+
+  // a leaf's count from the targets of the AND child it sits under
+  void latch_count(const uint64_t* targets, const uint64_t* match) {
+    const size_t padded = (size_t)grid_for(n_words).x * (kFsBlock / 64);   // (every wavefront of the grid writes its tile's summary)
+    uint8_t* summary = take<uint8_t>(padded);
+    uint8_t* prefix = take<uint8_t>(padded);
+    size_t tmp_bytes = 0;
+    PG_HIP(rocprim::inclusive_scan(nullptr, tmp_bytes, (uint8_t*)nullptr, (uint8_t*)nullptr, (size_t)n_latch_tiles, FsLatchThen(), stream));
+    uint8_t* tmp = take<uint8_t>(tmp_bytes + 256);
+    if (dry) return;
+    hipLaunchKernelGGL(fs_latch_summary_kernel, grid_for(n_words), dim3(kFsBlock), 0, stream, targets, match, n_words, summary);
+    PG_HIP(rocprim::inclusive_scan(tmp, tmp_bytes, summary, prefix, (size_t)n_latch_tiles, FsLatchThen(), stream));
+    hipLaunchKernelGGL(fs_latch_count_kernel, dim3((unsigned)std::min<int64_t>((n_latch_tiles + kFsBlock / 64 - 1) / (kFsBlock / 64), 4096)), dim3(kFsBlock), 0, stream, targets, match, n_words, prefix, n_docs, total);
+  }
+
+  void run_and(const Set& s) {   // AndDocIdSet#iterator, then AndDocIdIterator drained
+    std::vector<const Set*> sorted, bitmaps, scans, others;
+    for (auto& c : s.children) {
+      switch (child_kind(*c)) {
+        case Kind::Sorted: sorted.push_back(c.get()); break;
+        case Kind::Bitmap: bitmaps.push_back(c.get()); break;
+        case Kind::Scan: scans.push_back(c.get()); break;
+        default: others.push_back(c.get()); break;
+      }
+    }
+    const int n_index = (int)(sorted.size() + bitmaps.size());
+    struct AndChild { const uint64_t* match; std::vector<const uint64_t*> counted; };   // counted: the scan leaves below it
+    std::vector<AndChild> its;
+    auto child_of = [&](const Set& c) {
+      AndChild a;
+      if (c.kind == SetKind::Or) {
+        a.match = or_words(c);
+        for (auto& l : c.children) if (l->kind == SetKind::Scan) a.counted.push_back(leaf_words(*l));
+      } else {
+        a.match = leaf_words(c);
+        if (c.kind == SetKind::Scan) a.counted.push_back(a.match);
+      }
+      return a;
+    };
+    if ((n_index > 0 && !scans.empty()) || n_index > 1) {
+      uint64_t* docs = take_words();
+      bool first = true;
+      for (auto* list : {&sorted, &bitmaps})
+        for (const Set* c : *list) {
+          const uint64_t* w = c->kind == SetKind::Or ? or_words(*c) : leaf_words(*c);
+          words_op(docs, first ? w : docs, first ? nullptr : w, first ? 2 : 0, false);
+          first = false;
+        }
+      for (const Set* c : scans) words_op(docs, docs, leaf_words(*c), 0, true);   // applyAnd: every surviving candidate is evaluated once
+      if (others.empty()) return;   // a bitmap-based iterator: draining it scans nothing
+      its.push_back({docs, {}});
+      for (const Set* c : others) its.push_back(child_of(*c));
+    } else {
+      for (auto& c : s.children) its.push_back(child_of(*c));
+    }
+    bool any = false;
+    for (auto& a : its) any = any || !a.counted.empty();
+    if (!any) return;
+    FsAndProg prog{};
+    prog.k = (int32_t)its.size();
+    for (int j = 0; j < prog.k; j++) {
+      prog.match[j] = its[(size_t)j].match;
+      prog.targets[j] = its[(size_t)j].counted.empty() ? nullptr : take_words();
+    }
+    uint32_t* maps = take<uint32_t>((size_t)n_tiles);
+    uint32_t* prefix = take<uint32_t>((size_t)n_tiles);
+    size_t tmp_bytes = 0;
+    PG_HIP(rocprim::inclusive_scan(nullptr, tmp_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (size_t)n_tiles, FsMapThen(), stream));
+    uint8_t* tmp = take<uint8_t>(tmp_bytes + 256);
+    if (!dry) {
+      const dim3 grid((unsigned)((n_tiles + 63) / 64));
+      hipLaunchKernelGGL(fs_and_kernel<false>, grid, dim3(64), fs_and_lds_bytes(prog.k, false), stream, prog, n_docs, n_words, n_tiles, maps, (const uint32_t*)nullptr);
+      PG_HIP(rocprim::inclusive_scan(tmp, tmp_bytes, maps, prefix, (size_t)n_tiles, FsMapThen(), stream));
+      hipLaunchKernelGGL(fs_and_kernel<true>, grid, dim3(64), fs_and_lds_bytes(prog.k, true), stream, prog, n_docs, n_words, n_tiles, (uint32_t*)nullptr, (const uint32_t*)prefix);
+    }
+    for (int j = 0; j < prog.k; j++)
+      for (const uint64_t* leaf : its[(size_t)j].counted) latch_count(prog.targets[j], leaf);
+  }
+
+  void run_drained(const Set& s) {   // the iterator is drained by next(): every child of an OR / NOT is drained in turn
+    switch (s.kind) {
+      case SetKind::Scan: closed_form += n_docs; break;   // SVScanDocIdIterator#next: whole batches to the end
+      case SetKind::Not: run_drained(*s.children[0]); break;
+      case SetKind::Or: for (auto& c : s.children) run_drained(*c); break;
+      case SetKind::And: run_and(s); break;
+      default: break;
+    }
+  }
+};
 }  // namespace
 
 // `root`: the physical filter tree of the plan; `leaves`: the match bitmap of every Scan / Inverted leaf in it (from the GPU).
@@ -532,6 +855,40 @@ int64_t emulate_entries_scanned_in_filter(const FilterOp& root, const StatLeafBi
   int64_t total = 0;
   for (auto& c : emu.counters) total += c->entries;
   return total;
+}
+
+bool filter_stats_on_device(const FilterOp& root, int32_t n_docs) {
+  if (n_docs <= 0) return false;
+  static const StatLeafBits no_host_bits;
+  StatLeafWords none;
+  Emu emu{no_host_bits, n_docs, {}};
+  emu.dev_leaves = &none;
+  SetPtr set = emu.trues(root);
+  return DevEval::fits_drained(*set);
+}
+
+int64_t entries_scanned_on_device(const FilterOp& root, const StatLeafWords& leaves, int32_t n_docs, DeviceBuffer& arena, void* hip_stream) {
+  static const StatLeafBits no_host_bits;
+  Emu emu{no_host_bits, n_docs, {}};
+  emu.dev_leaves = &leaves;
+  SetPtr set = emu.trues(root);
+  const int64_t n_words = ((int64_t)n_docs + 63) / 64;
+  DevEval ev{emu, n_docs, n_words, (n_words + FS_TILE_WORDS - 1) / FS_TILE_WORDS, (n_words + FS_LATCH_WORDS - 1) / FS_LATCH_WORDS, (hipStream_t)hip_stream};
+  ev.total = ev.take<unsigned long long>(1);
+  ev.run_drained(*set);   // dry: sizes
+  if (arena.size < ev.off + 256) arena.alloc(ev.off + ev.off / 4 + 256);
+  ev.dry = false;
+  ev.base = arena.as<uint8_t>();
+  ev.off = 0;
+  ev.closed_form = 0;
+  ev.total = ev.take<unsigned long long>(1);
+  PG_HIP(hipMemsetAsync(ev.total, 0, 8, ev.stream));
+  ev.run_drained(*set);
+  PG_HIP(hipGetLastError());
+  unsigned long long counted = 0;
+  PG_HIP(hipMemcpyAsync(&counted, ev.total, 8, hipMemcpyDeviceToHost, ev.stream));
+  PG_HIP(hipStreamSynchronize(ev.stream));
+  return ev.closed_form + (int64_t)counted;
 }
 
 }  // namespace pg

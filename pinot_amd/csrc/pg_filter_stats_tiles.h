@@ -1,0 +1,160 @@
+// numEntriesScannedInFilter of leapfrogged AND shapes, evaluated tile by tile (device: pg_filter_stats.cpp; host model: tests/filter_stats_tiles_test.cpp).
+//
+// The reference's AndDocIdIterator (AndDocIdIterator.java:37-66) is a sequential automaton over its children's advance() calls, and a scan child
+// counts every doc it steps over (SVScanDocIdIterator.java:101-112: advance(target) visits [target, first match >= target]).  Two facts make it
+// parallel:
+//
+//  1. A scan iterator that is only ever ADVANCED visits the union of [t, next_match(t)] over the targets t it was handed (targets ascend; a call
+//     that finds its cursor already at or past the target was covered by an earlier interval).  The same holds for every scan child of an
+//     OrDocIdIterator (OrDocIdIterator.java:91-119: advance() forwards the target to each child whose cursor lies before it).  So the count of a
+//     leaf is a function of (its match bitmap M, the target bitmap T of the AND child it sits under): doc d is visited iff the last target <= d
+//     lies after the last match < d — a set / reset latch over the doc positions, evaluated with carries (fs_latch_*).
+//  2. Cut into tiles of docs, the AND automaton enters a tile in one of K + 1 states only: `clean` (a match was emitted at the tile's last doc
+//     but one: max_doc = first doc of the tile, nothing pending) or `child c is scanning` (its advance() was called in an earlier tile and has
+//     found nothing yet; whatever it returns becomes max_doc with max_idx = c, index = 0).  Every tile is simulated from every entry state
+//     (fs_and_tile), the K + 1 -> K + 1 maps compose associatively (a device scan), and a second simulation from the tile's TRUE entry state
+//     writes the targets.
+//
+// Match bitmaps: bit d of word d / 64; bits at and beyond n_docs are clear.
+#pragma once   // (C++: the tile automaton is a template over how the bitmaps are read)
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define FS_HD __host__ __device__ __forceinline__
+#else
+#define FS_HD static inline
+#endif
+
+#define FS_MAX_CHILDREN 7          // children of the AND (K + 1 entry states in 4-bit fields of one 32-bit map)
+#define FS_TILE_WORDS 8            // 512 docs per tile of the AND automaton (a lane's tile: 64 bytes per child, staged in LDS on the device)
+#define FS_LATCH_WORDS 64          // words per tile of the visited latch (one wavefront, a word per lane, on the device)
+#define FS_CLEAN 0u                // entry / exit state; c + 1: child c is scanning
+
+#define FS_MERGED 15u              // fs_and_tile(stop_at): the simulation emitted `stop_at` — from there on every entry state runs the same course
+
+// first set bit in [from, end) of a tile's bitmap read through `word(i)` (positions relative to the tile: < 64 * FS_TILE_WORDS), -1 when none
+template <typename WordAt>
+FS_HD int32_t fs_next_set(WordAt word, int32_t from, int32_t end) {
+  if (from >= end) return -1;
+  int32_t wi = from >> 6;
+  const int32_t last = (end - 1) >> 6;
+  uint64_t cur = word(wi) & (~0ULL << (from & 63));
+  while (!cur) {
+    if (++wi > last) return -1;
+    cur = word(wi);
+  }
+  const int32_t p = wi * 64 + __builtin_ctzll(cur);
+  return p < end ? p : -1;
+}
+
+// One tile of the AND automaton over k children from entry state `entry`, docs [from, end) RELATIVE to the tile (`from` = 0 unless the caller
+// resumes a clean state inside the tile); returns the exit state.  `io.match(child, word)`: a word of the docs the child's iterator returns;
+// with `emit`, `io.target(child, doc)` records every advance() call's target (the caller owns the tile's words).  `stop_at` >= 0: return FS_MERGED
+// when that doc is emitted.  (An AND emits every doc all its children match, whatever state it came from: behind the tile's first such doc the
+// K + 1 simulations coincide, so the exits pass runs each of them up to that doc and the common course once.)
+template <typename Io>
+FS_HD uint32_t fs_and_tile(int32_t k, Io& io, int32_t from, int32_t end, uint32_t entry, bool emit, int32_t stop_at = -1) {
+  int32_t x = from;
+  int32_t max_idx = -1, index = 0;
+  if (entry != FS_CLEAN) {
+    const int32_t c = (int32_t)entry - 1;
+    const int32_t d = fs_next_set([&](int32_t w) { return io.match(c, w); }, from, end);
+    if (d < 0) return entry;   // still scanning
+    x = d;
+    max_idx = c;
+  }
+  for (;;) {
+    while (index < k) {
+      if (index == max_idx) { index++; continue; }
+      if (emit) io.target(index, x);
+      const int32_t c = index;
+      const int32_t d = fs_next_set([&](int32_t w) { return io.match(c, w); }, x, end);
+      if (d < 0) return (uint32_t)index + 1;   // the call returns in a later tile (or never: EOF ends the AND)
+      if (d == x) {
+        index++;
+      } else {
+        x = d;
+        max_idx = index;
+        index = 0;
+      }
+    }
+    if (x == stop_at) return FS_MERGED;
+    x++;   // every child sits on x: emitted; next() resumes behind it
+    max_idx = -1;
+    index = 0;
+    if (x >= end) return FS_CLEAN;
+  }
+}
+
+// the exit state of every entry state of one tile (`end` docs), as 4-bit fields
+template <typename Io>
+FS_HD uint32_t fs_and_tile_exits(int32_t k, Io& io, int32_t end) {
+  int32_t first_common = -1;   // the first doc every child matches
+  for (int32_t w = 0; w * 64 < end && first_common < 0; w++) {
+    uint64_t all = ~0ULL;
+    for (int32_t c = 0; c < k; c++) all &= io.match(c, w);
+    if (all) first_common = w * 64 + __builtin_ctzll(all);
+  }
+  if (first_common >= end) first_common = -1;
+  uint32_t common = FS_MERGED, map = 0;
+  for (int32_t s = 0; s <= k; s++) {
+    uint32_t r = fs_and_tile(k, io, 0, end, (uint32_t)s, false, first_common);
+    if (r == FS_MERGED) {
+      if (common == FS_MERGED) common = first_common + 1 >= end ? FS_CLEAN : fs_and_tile(k, io, first_common + 1, end, FS_CLEAN, false);
+      r = common;
+    }
+    map |= r << (4 * s);
+  }
+  return map;
+}
+
+// the K + 1 exit states of a tile as 4-bit fields; composition `then(a, b)`: a's tile first
+FS_HD uint32_t fs_map_then(uint32_t a, uint32_t b) {
+  uint32_t out = 0;
+  for (int s = 0; s < 8; s++) out |= ((b >> (4 * ((a >> (4 * s)) & 15u))) & 15u) << (4 * s);
+  return out;
+}
+#define FS_MAP_IDENTITY 0x76543210u
+
+// ---- the visited latch: state(d) = T(d) | (!M(d - 1) & state(d - 1)); a leaf's count is the number of docs with state(d) set ------------------
+// summary of a run of words: 0 keeps the state that enters, 1 leaves it set, 2 leaves it clear (as seen by the doc AFTER the run)
+FS_HD uint32_t fs_latch_summary(const uint64_t* t, const uint64_t* m, int64_t w_lo, int64_t w_hi) {
+  for (int64_t w = w_hi - 1; w >= w_lo; w--) {
+    const uint64_t tw = t[w], mw = m[w];
+    if (!(tw | mw)) continue;
+    // the last event decides: a target at p sets from p on, a match at p clears from p + 1 on (a doc that is both: cleared behind it)
+    const int pt = tw ? 63 - __builtin_clzll(tw) : -1, pm = mw ? 63 - __builtin_clzll(mw) : -1;
+    return pt > pm ? 1u : 2u;
+  }
+  return 0u;
+}
+FS_HD uint32_t fs_latch_then(uint32_t a, uint32_t b) { return b ? b : a; }
+
+// visited docs of words [w_lo, w_hi) given the state entering w_lo (`carry`), docs beyond n_docs not counted
+FS_HD int64_t fs_latch_count(const uint64_t* t, const uint64_t* m, int64_t w_lo, int64_t w_hi, bool carry, int64_t n_docs) {
+  int64_t total = 0;
+  uint64_t prev_top = w_lo > 0 ? m[w_lo - 1] >> 63 : 0;
+  for (int64_t w = w_lo; w < w_hi; w++) {
+    const uint64_t s = t[w], mw = m[w];
+    const uint64_t r = (mw << 1) | prev_top;
+    prev_top = mw >> 63;
+    // bits that set (generate), bits that hand the previous state on (propagate): a prefix network over the 64 positions
+    uint64_t g = s, pp = ~(s | r);
+    g |= pp & (g << 1);  pp &= pp << 1;
+    g |= pp & (g << 2);  pp &= pp << 2;
+    g |= pp & (g << 4);  pp &= pp << 4;
+    g |= pp & (g << 8);  pp &= pp << 8;
+    g |= pp & (g << 16); pp &= pp << 16;
+    g |= pp & (g << 32);
+    // positions below the first set / reset of the word take the entering state
+    const uint64_t ev = s | r;
+    const uint64_t below = ev ? ((ev & (~ev + 1)) - 1) : ~0ULL;
+    uint64_t v = g | (carry ? below : 0);
+    const int64_t base = w * 64;
+    if (base + 64 > n_docs) v &= n_docs > base ? (~0ULL >> (64 - (n_docs - base))) : 0;
+    total += __builtin_popcountll(v);
+    if (base + 64 > n_docs) break;
+    carry = (v >> 63) != 0;
+  }
+  return total;
+}

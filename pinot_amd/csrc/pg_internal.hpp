@@ -227,6 +227,13 @@ struct HostBits {
 struct FilterOp;
 using StatLeafBits = std::unordered_map<const FilterOp*, HostBits>;
 int64_t emulate_entries_scanned_in_filter(const FilterOp& root, const StatLeafBits& leaves, int32_t n_docs);
+// The same count without the bitmaps leaving HBM, for the shapes whose automaton decomposes into tiles (pg_filter_stats_tiles.h): an AND whose
+// children are scans, index-based leaves and flat ORs of both, under any nest of drained ORs / NOTs.  `filter_stats_on_device`: does the plan's
+// tree have such a shape; `entries_scanned_on_device`: the count, given every Scan / Inverted / RangeIdx leaf's match bitmap on the device
+// (`arena`: scratch the call may grow; it synchronizes `stream` once, for the 8-byte answer).
+using StatLeafWords = std::unordered_map<const FilterOp*, const uint64_t*>;
+bool filter_stats_on_device(const FilterOp& root, int32_t n_docs);
+int64_t entries_scanned_on_device(const FilterOp& root, const StatLeafWords& leaves, int32_t n_docs, DeviceBuffer& arena, void* hip_stream);
 
 // ---- compiled plan ------------------------------------------------------------------------------------------------------------
 enum class OpKind { Empty, MatchAll, Scan, Inverted, Sorted, And, Or, Not, Bitmap, RangeIdx };
@@ -276,6 +283,7 @@ struct CompiledPlan {
   mutable std::atomic<uint64_t> last_used{0};   // the segment's plan cache evicts the plans used longest ago (pg_exec.hip, get_plan)
   int64_t full_scan_entries = 0;     // entries contributed by unmasked scans whose count is known (numDocs each)
   bool stats_exact = true;           // the kernels' own counters give numEntriesScannedInFilter (flat AND shapes, drained ORs)
+  mutable std::atomic<int> stats_on_device{-1};   // !stats_exact: can the tile automaton count it on the device (filter_stats_on_device; -1: not judged yet)
   // otherwise: the physical filter tree and one filter-only plan per Scan / Inverted leaf — their match bitmaps feed the iterator
   // automaton of pg_filter_stats.cpp, which reproduces the reference's count exactly
   std::unique_ptr<FilterOp> root_op;
@@ -483,6 +491,8 @@ struct Knobs {
   int max_inflight = 16;   // PG_MAX_INFLIGHT: queries between submission and result per device (<= 0: unbounded)
   int scan_wgs_per_cu = 1, pipe_wgs_per_cu = 1, wgs_per_cu = 1, p2_wgs_per_cu = 4, dense_count_wgs = 1, tile_split_max = -1, hash_first_buckets = -1;
   int64_t exact_stats_max_docs = (int64_t)1 << 22;
+  int64_t exact_stats_device_max_docs = (int64_t)1 << 27;   // PG_EXACT_STATS_DEVICE_MAX_DOCS: ... and where the device counts it (pg_filter_stats_tiles.h: ~1 ms per 10^8 docs)
+  bool filter_stats_host = false;   // PG_FILTER_STATS_HOST: the iterator automaton always walks on the host (pg_filter_stats.cpp), also for shapes the device counts
   int64_t limit_prefix_min_docs = (int64_t)1 << 20;   // PG_LIMIT_PREFIX_MIN_DOCS: smallest doc prefix of the numGroupsLimit admission pass (tests lower it)
   std::string oct_passes;      // PG_OCT_PASSES: cumulative fractions, e.g. "0.02,0.08,0.3,1"
   // pg_comm.cpp
