@@ -623,7 +623,7 @@ __global__ void __launch_bounds__(kFsBlock) fs_latch_count_kernel(const uint64_t
   for (int off = 32; off; off >>= 1) v += __shfl_down(v, off);
   if (lane == 0 && v) atomicAdd(total, v);
 }
-// dst = a (op) b word by word — op 0: AND, 1: OR, 2: copy of a; with `total`: the docs of `a` (before the operation) are added to it
+// dst = a (op) b word by word — op 0: AND, 1: OR, 2: copy of a, 3: the docs not in a; with `total`: the docs of `a` (before the operation) are added to it
 __global__ void fs_words_kernel(uint64_t* __restrict__ dst, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, int64_t n_words, int64_t n_docs, int op,
                                 unsigned long long* total) {
   const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -632,7 +632,7 @@ __global__ void fs_words_kernel(uint64_t* __restrict__ dst, const uint64_t* __re
     uint64_t x = a[w];
     if (w * 64 + 64 > n_docs) x &= ~0ULL >> (64 - (n_docs - w * 64));   // (the last word: docs that exist)
     c = (unsigned long long)__popcll(x);
-    dst[w] = op == 0 ? (x & b[w]) : op == 1 ? (x | b[w]) : x;
+    dst[w] = op == 0 ? (x & b[w]) : op == 1 ? (x | b[w]) : op == 2 ? x : (~a[w] & (w * 64 + 64 > n_docs ? ~0ULL >> (64 - (n_docs - w * 64)) : ~0ULL));
   }
   if (total) fs_block_add(c, total);
 }
@@ -653,6 +653,101 @@ __global__ void fs_fill_ranges_kernel(uint64_t* __restrict__ dst, const int32_t*
   }
   dst[w] = x;
 }
+
+// ---- first / last set bit queries on a bitmap: groups of FS_GROUP_WORDS words with the first set position from each group on (suffix minimum)
+// and the last one up to it (prefix maximum) — the look-ups of the NOT-over-scan count (pg_filter_stats_tiles.h)
+#define FS_GROUP_WORDS 8
+struct FsIndex {
+  const uint64_t* words;
+  const int32_t* first_rev;   // [n_groups - 1 - g]: first set position in groups >= g, INT32_MAX: none
+  const int32_t* last_upto;   // [g]: last set position in groups <= g, -1: none
+  int64_t n_docs, n_words, n_groups;
+  __device__ __forceinline__ int64_t next(int64_t x) const {   // first set bit >= x, -1: none
+    if (x < 0) x = 0;
+    if (x >= n_docs) return -1;
+    const int64_t g = x >> 9;
+    int64_t w = x >> 6;
+    const int64_t w_end = (g + 1) * FS_GROUP_WORDS < n_words ? (g + 1) * FS_GROUP_WORDS : n_words;
+    uint64_t cur = words[w] & (~0ULL << (x & 63));
+    for (;;) {
+      if (cur) { const int64_t p = w * 64 + __builtin_ctzll(cur); return p < n_docs ? p : -1; }
+      if (++w >= w_end) break;
+      cur = words[w];
+    }
+    if (g + 1 >= n_groups) return -1;
+    const int32_t v = first_rev[n_groups - 2 - g];
+    return v == INT32_MAX ? -1 : (int64_t)v;
+  }
+  __device__ __forceinline__ int64_t prev(int64_t x) const {   // last set bit <= x, -1: none
+    if (x < 0) return -1;
+    if (x >= n_docs) x = n_docs - 1;
+    const int64_t g = x >> 9;
+    int64_t w = x >> 6;
+    uint64_t cur = words[w] & (~0ULL >> (63 - (x & 63)));
+    for (;;) {
+      if (cur) return w * 64 + 63 - __builtin_clzll(cur);
+      if (--w < g * FS_GROUP_WORDS) break;
+      cur = words[w];
+    }
+    return g > 0 ? (int64_t)last_upto[g - 1] : -1;
+  }
+};
+__global__ void __launch_bounds__(kFsBlock) fs_index_groups_kernel(const uint64_t* __restrict__ words, int64_t n_words, int64_t n_groups, int32_t* __restrict__ first_rev,
+                                                                   int32_t* __restrict__ last) {   // a word per lane, a group per 8 lanes
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t x = w < n_words ? words[w] : 0;
+  int32_t f = x ? (int32_t)(w * 64 + __builtin_ctzll(x)) : INT32_MAX, l = x ? (int32_t)(w * 64 + 63 - __builtin_clzll(x)) : -1;
+  for (int off = 1; off < FS_GROUP_WORDS; off <<= 1) {
+    const int32_t of = __shfl_xor(f, off), ol = __shfl_xor(l, off);
+    f = of < f ? of : f;
+    l = ol > l ? ol : l;
+  }
+  const int64_t g = w / FS_GROUP_WORDS;
+  if ((threadIdx.x & (FS_GROUP_WORDS - 1)) == 0 && g < n_groups) { first_rev[n_groups - 1 - g] = f; last[g] = l; }
+}
+struct FsNotLook {   // the look-ups the count's formulas ask for
+  FsIndex m, nm, t, r, c;
+  __device__ __forceinline__ int64_t next_match(int64_t x) const { return m.next(x); }
+  __device__ __forceinline__ int64_t next_non_match(int64_t x) const { return nm.next(x); }
+  __device__ __forceinline__ int64_t prev_target(int64_t x) const { return t.prev(x); }
+  __device__ __forceinline__ int64_t next_reset(int64_t x) const { return r.next(x); }
+  __device__ __forceinline__ int64_t prev_reset(int64_t x) const { return r.prev(x); }
+  __device__ __forceinline__ int64_t next_consume(int64_t x) const { return c.next(x); }
+};
+__device__ __forceinline__ void fs_wave_add(unsigned long long v, unsigned long long* total) {
+  for (int off = 32; off; off >>= 1) v += __shfl_down(v, off);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(total, v);
+}
+// a word of the NOT's targets per lane: which of them advance() the scan (R), which are matches the NOT steps over (C); the advance() costs
+__global__ void __launch_bounds__(kFsBlock) fs_not_resets_kernel(const FsNotLook look, int64_t n_words, int64_t n_docs, uint64_t* __restrict__ resets, uint64_t* __restrict__ consumes,
+                                                                 unsigned long long* total) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long cost = 0;
+  if (w < n_words) {
+    uint64_t r = 0;
+    for (uint64_t bits = look.t.words[w]; bits; bits &= bits - 1) {
+      const int64_t t = w * 64 + __builtin_ctzll(bits);
+      if (fs_not_is_reset(look, t)) {
+        r |= 1ULL << (t & 63);
+        cost += (unsigned long long)fs_not_advance_cost(look, t, n_docs);
+      }
+    }
+    resets[w] = r;
+    consumes[w] = look.t.words[w] & look.m.words[w];
+  }
+  fs_wave_add(cost, total);
+}
+// ... then the batches of every episode, charged to its last target that is a match; the constructor's next() by the first lane
+__global__ void __launch_bounds__(kFsBlock) fs_not_episodes_kernel(const FsNotLook look, int64_t n_words, int64_t n_docs, unsigned long long* total) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long cost = 0;
+  if (w < n_words)
+    for (uint64_t bits = look.c.words[w]; bits; bits &= bits - 1) cost += (unsigned long long)fs_not_episode_cost(look, w * 64 + __builtin_ctzll(bits), n_docs);
+  if (w == 0) cost += (unsigned long long)fs_not_ctor_cost(look, n_docs);
+  fs_wave_add(cost, total);
+}
+struct FsMaxI32 { __host__ __device__ int32_t operator()(int32_t a, int32_t b) const { return a > b ? a : b; } };
+struct FsMinI32 { __host__ __device__ int32_t operator()(int32_t a, int32_t b) const { return a < b ? a : b; } };
 struct FsMapThen { __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return fs_map_then(a, b); } };
 struct FsLatchThen { __host__ __device__ uint8_t operator()(uint8_t a, uint8_t b) const { return b ? b : a; } };
 
@@ -694,7 +789,12 @@ struct DevEval {
         }
         return n_sorted > 1 && n_other == 0 ? Kind::Bitmap : Kind::Other;   // OrDocIdSet#iterator merges index-based children only beside >= 2 sorted ones
       }
-      default: return Kind::Unfit;   // Empty / MatchAll / Not / And under an AND
+      case SetKind::Not: {   // NotDocIdIterator over one leaf (a compound child draws on next() and advance() of its own children: the host walk)
+        const Set& c = *s.children[0];
+        if (c.kind == SetKind::Scan) return c.mv_off ? Kind::Unfit : Kind::Other;
+        return c.kind == SetKind::Bitmap || c.kind == SetKind::Sorted ? Kind::Other : Kind::Unfit;
+      }
+      default: return Kind::Unfit;   // Empty / MatchAll / And under an AND
     }
   }
   static bool fits_and(const Set& s) {
@@ -769,6 +869,37 @@ struct DevEval {
     hipLaunchKernelGGL(fs_latch_count_kernel, dim3((unsigned)std::min<int64_t>((n_latch_tiles + kFsBlock / 64 - 1) / (kFsBlock / 64), 4096)), dim3(kFsBlock), 0, stream, targets, match, n_words, prefix, n_docs, total);
   }
 
+  FsIndex index_of(const uint64_t* words) {
+    const int64_t n_groups = (n_words + FS_GROUP_WORDS - 1) / FS_GROUP_WORDS;
+    int32_t* first_rev = take<int32_t>((size_t)n_groups);
+    int32_t* first_scan = take<int32_t>((size_t)n_groups);
+    int32_t* last = take<int32_t>((size_t)n_groups);
+    int32_t* last_scan = take<int32_t>((size_t)n_groups);
+    size_t tmp_bytes = 0, tmp2 = 0;
+    PG_HIP(rocprim::inclusive_scan(nullptr, tmp_bytes, (int32_t*)nullptr, (int32_t*)nullptr, (size_t)n_groups, FsMinI32(), stream));
+    PG_HIP(rocprim::inclusive_scan(nullptr, tmp2, (int32_t*)nullptr, (int32_t*)nullptr, (size_t)n_groups, FsMaxI32(), stream));
+    uint8_t* tmp = take<uint8_t>(std::max(tmp_bytes, tmp2) + 256);
+    if (!dry) {
+      hipLaunchKernelGGL(fs_index_groups_kernel, grid_for(n_words), dim3(kFsBlock), 0, stream, words, n_words, n_groups, first_rev, last);
+      PG_HIP(rocprim::inclusive_scan(tmp, tmp_bytes, first_rev, first_scan, (size_t)n_groups, FsMinI32(), stream));
+      PG_HIP(rocprim::inclusive_scan(tmp, tmp2, last, last_scan, (size_t)n_groups, FsMaxI32(), stream));
+    }
+    return FsIndex{words, first_scan, last_scan, n_docs, n_words, n_groups};
+  }
+  // the scan under a NOT: `targets` of the NOT, the scan's matches, the docs the NOT returns (the others)
+  void not_count(const uint64_t* targets, const uint64_t* match, const uint64_t* others) {
+    uint64_t* resets = take_words();
+    uint64_t* consumes = take_words();
+    FsNotLook look{};
+    look.m = index_of(match);
+    look.nm = index_of(others);
+    look.t = index_of(targets);
+    if (!dry) hipLaunchKernelGGL(fs_not_resets_kernel, grid_for(n_words), dim3(kFsBlock), 0, stream, look, n_words, n_docs, resets, consumes, total);
+    look.r = index_of(resets);
+    look.c = index_of(consumes);
+    if (!dry) hipLaunchKernelGGL(fs_not_episodes_kernel, grid_for(n_words), dim3(kFsBlock), 0, stream, look, n_words, n_docs, total);
+  }
+
   void run_and(const Set& s) {   // AndDocIdSet#iterator, then AndDocIdIterator drained
     std::vector<const Set*> sorted, bitmaps, scans, others;
     for (auto& c : s.children) {
@@ -780,11 +911,17 @@ struct DevEval {
       }
     }
     const int n_index = (int)(sorted.size() + bitmaps.size());
-    struct AndChild { const uint64_t* match; std::vector<const uint64_t*> counted; };   // counted: the scan leaves below it
+    struct AndChild { const uint64_t* match; std::vector<const uint64_t*> counted; const uint64_t* not_scan = nullptr; };   // counted: the scan leaves below it; not_scan: the scan under a NOT
     std::vector<AndChild> its;
     auto child_of = [&](const Set& c) {
       AndChild a;
-      if (c.kind == SetKind::Or) {
+      if (c.kind == SetKind::Not) {
+        const uint64_t* inner = leaf_words(*c.children[0]);
+        uint64_t* others = take_words();
+        words_op(others, inner, nullptr, 3, false);
+        a.match = others;
+        if (c.children[0]->kind == SetKind::Scan) a.not_scan = inner;
+      } else if (c.kind == SetKind::Or) {
         a.match = or_words(c);
         for (auto& l : c.children) if (l->kind == SetKind::Scan) a.counted.push_back(leaf_words(*l));
       } else {
@@ -810,13 +947,13 @@ struct DevEval {
       for (auto& c : s.children) its.push_back(child_of(*c));
     }
     bool any = false;
-    for (auto& a : its) any = any || !a.counted.empty();
+    for (auto& a : its) any = any || !a.counted.empty() || a.not_scan;
     if (!any) return;
     FsAndProg prog{};
     prog.k = (int32_t)its.size();
     for (int j = 0; j < prog.k; j++) {
       prog.match[j] = its[(size_t)j].match;
-      prog.targets[j] = its[(size_t)j].counted.empty() ? nullptr : take_words();
+      prog.targets[j] = its[(size_t)j].counted.empty() && !its[(size_t)j].not_scan ? nullptr : take_words();
     }
     uint32_t* maps = take<uint32_t>((size_t)n_tiles);
     uint32_t* prefix = take<uint32_t>((size_t)n_tiles);
@@ -829,8 +966,10 @@ struct DevEval {
       PG_HIP(rocprim::inclusive_scan(tmp, tmp_bytes, maps, prefix, (size_t)n_tiles, FsMapThen(), stream));
       hipLaunchKernelGGL(fs_and_kernel<true>, grid, dim3(64), fs_and_lds_bytes(prog.k, true), stream, prog, n_docs, n_words, n_tiles, (uint32_t*)nullptr, (const uint32_t*)prefix);
     }
-    for (int j = 0; j < prog.k; j++)
+    for (int j = 0; j < prog.k; j++) {
       for (const uint64_t* leaf : its[(size_t)j].counted) latch_count(prog.targets[j], leaf);
+      if (its[(size_t)j].not_scan) not_count(prog.targets[j], its[(size_t)j].not_scan, its[(size_t)j].match);
+    }
   }
 
   void run_drained(const Set& s) {   // the iterator is drained by next(): every child of an OR / NOT is drained in turn

@@ -158,3 +158,58 @@ FS_HD int64_t fs_latch_count(const uint64_t* t, const uint64_t* m, int64_t w_lo,
   }
   return total;
 }
+
+// ---- NOT over a scan, under an AND (NotDocIdIterator.java:45-70 over SVScanDocIdIterator.java:76-112) -----------------------------------------
+// The NOT keeps `nm`, the scan's next match; the AND advances it to ascending targets t.  With r(t) = the doc the NOT returned (the first
+// non-match >= t), nm before a call is always the scan's first match behind the doc returned before.  Three kinds of call:
+//   t < nm   nothing is scanned;
+//   t > nm   a RESET: the scan is advance()d — it drops its batch and counts [t, first match >= t] — and a new episode of next() calls starts
+//            right behind that match (B0);
+//   t == nm  (also a reset that lands on a match) the NOT steps over the run of matches at t with one next() per match.
+// Within an episode next() streams: batches of 256 docs from B0 on, whole batches counted, up to the batch that holds the last match handed out —
+// the scan's first match behind the run of the episode's last target that is a match.  (Batches overlap what a later reset scans again: the count
+// is a sum over calls, not a set of docs.)  So with T the child's target bitmap, M the scan's matches, R the resets and C = T & M:
+//   count = sum over R of the advance() cost + sum over the episodes' last C target of the batches + the constructor's episode (B0 = 0, one
+//   next() whatever follows).
+// `L` answers first / last set bit queries on those bitmaps (-1: none): the host model scans, the device keeps two-level indexes.
+#define FS_SCAN_BATCH 256   // BlockDocIdIterator.OPTIMAL_ITERATOR_BATCH_SIZE
+
+template <typename L>
+FS_HD bool fs_not_is_reset(L& l, int64_t t) {   // is the scan advance()d when the NOT is advanced to target t
+  const int64_t t_prev = l.prev_target(t - 1);
+  int64_t from = 0;   // the first doc behind the one the NOT returned last
+  if (t_prev >= 0) {
+    const int64_t r = l.next_non_match(t_prev);
+    if (r < 0) return false;   // the matches ran to the end: the scan is exhausted
+    from = r + 1;
+  }
+  const int64_t nm = l.next_match(from);
+  return nm >= 0 && t > nm;
+}
+template <typename L>
+FS_HD int64_t fs_not_advance_cost(L& l, int64_t t, int64_t n_docs) {
+  const int64_t p = l.next_match(t);
+  return p < 0 ? n_docs - t : p - t + 1;
+}
+FS_HD int64_t fs_not_batches(int64_t b0, int64_t q, int64_t n_docs) {   // docs next() scans from b0 until it has handed out match q (-1: until EOF)
+  if (q < 0) return n_docs - b0;
+  const int64_t end = b0 + FS_SCAN_BATCH * ((q - b0) / FS_SCAN_BATCH + 1);
+  return (end < n_docs ? end : n_docs) - b0;
+}
+// `t`: a target that is a match (in C): the batches of its episode, if it is the episode's last such target (else 0)
+template <typename L>
+FS_HD int64_t fs_not_episode_cost(L& l, int64_t t, int64_t n_docs) {
+  const int64_t c_next = l.next_consume(t + 1), r_next = l.next_reset(t + 1);
+  if (c_next >= 0 && !(r_next >= 0 && r_next <= c_next)) return 0;   // a later target of the same episode hands out more matches
+  const int64_t t_e = l.prev_reset(t);
+  const int64_t b0 = t_e < 0 ? 0 : l.next_match(t_e) + 1;
+  const int64_t run_end = l.next_non_match(t);
+  return fs_not_batches(b0, run_end < 0 ? -1 : l.next_match(run_end + 1), n_docs);
+}
+// the constructor's next() when no target of its episode is a match
+template <typename L>
+FS_HD int64_t fs_not_ctor_cost(L& l, int64_t n_docs) {
+  const int64_t c_first = l.next_consume(0), r_first = l.next_reset(0);
+  if (c_first >= 0 && !(r_first >= 0 && r_first <= c_first)) return 0;   // counted with that target's episode (B0 = 0)
+  return fs_not_batches(0, l.next_match(0), n_docs);
+}

@@ -2,6 +2,7 @@
 // the reference's iterators (AndDocIdIterator.java:37-66, OrDocIdIterator.java:91-119, SVScanDocIdIterator.java:101-112 — advance() only, which
 // is all an AND ever calls on its children).  Random match bitmaps of every density, AND children that are scans, bitmaps or ORs of both.
 // Build: g++ -O2 -std=c++17 -I pinot_amd/csrc tests/filter_stats_tiles_test.cpp -o tests/_build/filter_stats_tiles_test
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
@@ -17,9 +18,10 @@ struct Leaf {
   bool scan;            // a scan counts what it steps over; a bitmap iterator counts nothing
   int64_t counted = 0;  // by the sequential model
 };
-struct Child {          // a child of the AND: one leaf, or an OR over several
+struct Child {          // a child of the AND: one leaf, an OR over several, or a NOT over one scan
   std::vector<int> leaves;
   bool is_or;
+  bool is_not = false;
 };
 
 static int64_t next_set(const Bits& m, int64_t from, int64_t n) {
@@ -71,9 +73,69 @@ struct SeqOr : SeqIt {   // OrDocIdIterator#advance
     return best == INT64_MAX ? -1 : best;
   }
 };
+// SVScanDocIdIterator with both of its entry points, under NotDocIdIterator
+struct SeqScan {
+  Leaf& l;
+  int64_t n, next_doc = 0;
+  std::vector<int64_t> batch;
+  size_t cursor = 0;
+  SeqScan(Leaf& leaf, int64_t docs) : l(leaf), n(docs) {}
+  int64_t next() {   // SVScanDocIdIterator.java:76-98: whole batches of 256 docs until one holds a match
+    while (cursor >= batch.size()) {
+      batch.clear();
+      cursor = 0;
+      if (next_doc >= n) return -1;
+      const int64_t limit = std::min<int64_t>(n - next_doc, 256);
+      for (int64_t d = next_doc; d < next_doc + limit; d++)
+        if ((l.m[(size_t)(d >> 6)] >> (d & 63)) & 1) batch.push_back(d);
+      next_doc += limit;
+      l.counted += limit;
+    }
+    return batch[cursor++];
+  }
+  int64_t advance(int64_t target) {   // :101-112
+    batch.clear();
+    cursor = 0;
+    next_doc = target;
+    while (next_doc < n) {
+      const int64_t d = next_doc++;
+      l.counted++;
+      if ((l.m[(size_t)(d >> 6)] >> (d & 63)) & 1) return d;
+    }
+    return -1;
+  }
+};
+struct SeqNot : SeqIt {   // NotDocIdIterator.java:28-70
+  SeqScan child;
+  int64_t n, next_doc = 0, next_non_matching;
+  SeqNot(Leaf& leaf, int64_t docs) : child(leaf, docs), n(docs) {
+    const int64_t cur = child.next();
+    next_non_matching = cur < 0 ? n : cur;
+  }
+  int64_t next() {
+    if (next_doc >= n) return -1;
+    while (next_doc == next_non_matching) {
+      next_doc++;
+      const int64_t d = child.next();
+      next_non_matching = d < 0 ? n : d;
+    }
+    if (next_doc >= n) return -1;
+    return next_doc++;
+  }
+  int64_t advance(int64_t target) override {
+    next_doc = target;
+    if (target > next_non_matching) {
+      const int64_t d = child.advance(target);
+      next_non_matching = d < 0 ? n : d;
+    }
+    return next();
+  }
+};
+
 static void run_sequential(std::vector<Leaf>& leaves, const std::vector<Child>& children, int64_t n) {
   std::vector<std::unique_ptr<SeqIt>> its;
   for (auto& c : children) {
+    if (c.is_not) { its.push_back(std::make_unique<SeqNot>(leaves[(size_t)c.leaves[0]], n)); continue; }
     if (!c.is_or) { its.push_back(std::make_unique<SeqLeaf>(leaves[(size_t)c.leaves[0]], n)); continue; }
     auto o = std::make_unique<SeqOr>();
     for (int li : c.leaves) { o->its.push_back(std::make_unique<SeqLeaf>(leaves[(size_t)li], n)); o->next_ids.push_back(-1); }
@@ -102,9 +164,13 @@ static std::vector<int64_t> run_tiles(const std::vector<Leaf>& leaves, const std
   const int64_t n_words = (n + 63) / 64, n_tiles = (n_words + FS_TILE_WORDS - 1) / FS_TILE_WORDS;
   const int k = (int)children.size();
   std::vector<Bits> match((size_t)k, Bits((size_t)n_words + 1, 0)), targets((size_t)k, Bits((size_t)n_words + 1, 0));
-  for (int j = 0; j < k; j++)
+  for (int j = 0; j < k; j++) {
     for (int li : children[(size_t)j].leaves)
       for (int64_t w = 0; w < n_words; w++) match[(size_t)j][(size_t)w] |= leaves[(size_t)li].m[(size_t)w];
+    if (children[(size_t)j].is_not)   // the docs a NOT returns: the others, of those that exist
+      for (int64_t w = 0; w < n_words; w++)
+        match[(size_t)j][(size_t)w] = ~match[(size_t)j][(size_t)w] & (w * 64 + 64 > n ? ~0ULL >> (64 - (n - w * 64)) : ~0ULL);
+  }
   struct Io {   // one tile: positions relative to its first word
     std::vector<Bits>&m, &t;
     int64_t w_lo;
@@ -131,9 +197,33 @@ static std::vector<int64_t> run_tiles(const std::vector<Leaf>& leaves, const std
     fs_and_tile(k, io, 0, (int32_t)(hi - lo), entry[(size_t)t], true);
   }
   std::vector<int64_t> counts(leaves.size(), 0);
+  for (int j = 0; j < k; j++) {
+    if (!children[(size_t)j].is_not) continue;
+    const int li = children[(size_t)j].leaves[0];
+    struct Look {   // the bitmaps scanned directly (the device: two-level indexes)
+      const Bits &m, &nm, &t;
+      Bits r, c;
+      int64_t n;
+      int64_t next_match(int64_t x) const { return next_set(m, x, n); }
+      int64_t next_non_match(int64_t x) const { return next_set(nm, x, n); }
+      int64_t next_reset(int64_t x) const { return next_set(r, x, n); }
+      int64_t next_consume(int64_t x) const { return next_set(c, x, n); }
+      static int64_t prev(const Bits& b, int64_t x) { for (; x >= 0; x--) if ((b[(size_t)(x >> 6)] >> (x & 63)) & 1) return x; return -1; }
+      int64_t prev_target(int64_t x) const { return prev(t, x); }
+      int64_t prev_reset(int64_t x) const { return prev(r, x); }
+    } look{leaves[(size_t)li].m, match[(size_t)j], targets[(size_t)j], Bits((size_t)n_words + 1, 0), Bits((size_t)n_words + 1, 0), n};
+    int64_t total = 0;
+    for (int64_t t = next_set(look.t, 0, n); t >= 0; t = next_set(look.t, t + 1, n)) {
+      if (fs_not_is_reset(look, t)) { look.r[(size_t)(t >> 6)] |= 1ULL << (t & 63); total += fs_not_advance_cost(look, t, n); }
+      if ((look.m[(size_t)(t >> 6)] >> (t & 63)) & 1) look.c[(size_t)(t >> 6)] |= 1ULL << (t & 63);
+    }
+    for (int64_t t = next_set(look.c, 0, n); t >= 0; t = next_set(look.c, t + 1, n)) total += fs_not_episode_cost(look, t, n);
+    total += fs_not_ctor_cost(look, n);
+    counts[(size_t)li] = total;
+  }
   for (int j = 0; j < k; j++)
     for (int li : children[(size_t)j].leaves) {
-      if (!leaves[(size_t)li].scan) continue;
+      if (!leaves[(size_t)li].scan || children[(size_t)j].is_not) continue;
       const uint64_t* tw = targets[(size_t)j].data();
       const uint64_t* mw = leaves[(size_t)li].m.data();
       uint32_t state = 2;
@@ -151,7 +241,7 @@ int main(int argc, char** argv) {
   std::mt19937_64 rng(20260930);
   int64_t checked = 0;
   for (int round = 0; round < rounds; round++) {
-    static const int64_t sizes[] = {1, 63, 64, 65, 2047, 2048, 2049, 4096, 10000, 70001, 200003};
+    static const int64_t sizes[] = {1, 63, 64, 65, 255, 256, 257, 511, 513, 2047, 2048, 2049, 4096, 10000, 70001, 200003};
     const int64_t n = sizes[rng() % (sizeof(sizes) / sizeof(sizes[0]))];
     const int64_t n_words = (n + 63) / 64;
     const int k = 1 + (int)(rng() % 4);
@@ -160,10 +250,11 @@ int main(int argc, char** argv) {
     for (int j = 0; j < k; j++) {
       Child c;
       c.is_or = rng() % 3 == 0;
+      c.is_not = !c.is_or && rng() % 3 == 0;
       const int nl = c.is_or ? 1 + (int)(rng() % 3) : 1;
       for (int i = 0; i < nl; i++) {
         Leaf l;
-        l.scan = rng() % 4 != 0;
+        l.scan = c.is_not || rng() % 4 != 0;
         l.m.assign((size_t)n_words + 1, 0);
         static const double dens[] = {0.0, 0.0005, 0.01, 0.1, 0.5, 0.9, 0.999, 1.0};
         const double p = dens[rng() % 8];

@@ -44,7 +44,7 @@ def _segment(n, seed):
     return build_segment(f"fs_{n}", data, schema, inverted_index_columns=["ci"], no_dictionary_columns=["r", "k", "b", "m"])
 
 
-# (filter, counted on the device?) — the host walk keeps NOT / compound children under an AND
+# (filter, counted on the device?) — the host walk keeps compound children under a NOT or an OR that sit under an AND
 SHAPES = [
     ("r < 500000 AND k > 0", True),                                              # leapfrog of two scans
     ("r < 100000 AND k > 50 AND u < 300", True),                                 # ... of three
@@ -61,7 +61,15 @@ SHAPES = [
     ("NOT (r < 300000 OR k > 0)", True),                                         # drained NOT over an OR: every scan runs to the end
     ("(r < 100000 AND k > 0) OR (u < 100 AND g > 30) OR ci = 1", True),          # two ANDs drained side by side
     ("(r < 200000 OR k > 80) AND (u < 200 OR b = 0)", True),                     # AND of two ORs
-    ("ci = 3 AND NOT (r < 200000)", False),                                      # NOT under an AND: the host walk
+    ("ci = 3 AND NOT (r < 200000)", True),                                       # NOT over a scan under an AND: advance() resets + batches of next()
+    ("r < 500000 AND NOT (k > 0)", True),                                        # ... beside a scan
+    ("NOT (r < 300000) AND NOT (k > 50) AND u < 500", True),                     # two of them
+    ("ci = 3 AND NOT (b = 1)", True),                                            # runs of 5 000 matches the NOT steps over one next() at a time
+    ("so < 10 AND NOT (r < 990000)", True),                                      # nearly everything matches the scan
+    ("ci <> 1 AND NOT (r < 3000)", True),                                        # nearly nothing does: batches far apart
+    ("NOT (ci = 2) AND r < 100000 AND NOT (k < -95)", True),                     # NOT over an index leaf (nothing to count) next to one over a scan
+    ("(ci = 3 AND NOT (r < 200000)) OR (k > 90 AND NOT (u < 500))", True),       # two such ANDs drained by an OR
+    ("ci = 3 AND NOT (r < 200000 OR k > 50)", False),                            # NOT over an OR under an AND: the host walk
     ("r < 200000 AND (k > 0 OR (u < 500 AND g < 60))", False),                   # an AND inside an OR under an AND: the host walk
 ]
 
