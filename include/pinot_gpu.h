@@ -213,7 +213,8 @@ typedef struct pg_query {
    * the segment holds more groups than trimSize = max(5 x limit, min_segment_group_trim_size) (GroupByUtils.getTableCapacity :45-57), only
    * the trimSize groups that sort first under the ORDER BY come back (TableResizer#trimInSegmentResults :327-351; which of several
    * groups TIED at the cut survive is unspecified there — a heap — and here).  numGroupsLimitReached is decided before the trim.
-   * Dense key spaces without DISTINCTCOUNT / HLL state select the survivors on the device: only they cross PCIe. */
+   * Dense key spaces without DISTINCTCOUNT / HLL state select the survivors on the device: only they cross PCIe; ordered by a distinct count
+   * (the set's size, HyperLogLog#cardinality: extractFinalResult, TableResizer.java:406-445) or a multi-value function the assembly trims. */
   int32_t n_order_by;                           /* 0 => no ORDER BY (no trim) */
   const pg_order_by* order_by;
   int32_t limit;                                /* QueryContext#getLimit (read with n_order_by > 0 only) */

@@ -1292,8 +1292,9 @@ static int trim_refused(const pg_query* q) {
   if (q->flags & PG_QUERY_FLAG_NULL_HANDLING) { po_set_error("segment-level group trim under enableNullHandling"); return 1; }
   for (int32_t i = 0; i < q->n_order_by; i++)
     if (q->order_by[i].kind == PG_ORDER_BY_AGGREGATION && q->order_by[i].index >= 0 && q->order_by[i].index < q->n_aggregations) {
-      const int f = q->aggregations[q->order_by[i].index].function;
-      if (!(f == PG_AGG_COUNT || f == PG_AGG_SUM || f == PG_AGG_MIN || f == PG_AGG_MAX || f == PG_AGG_AVG || f == PG_AGG_MINMAXRANGE)) {
+      const int f = sv_function_of(q->aggregations[q->order_by[i].index].function);
+      if (!(f == PG_AGG_COUNT || f == PG_AGG_SUM || f == PG_AGG_MIN || f == PG_AGG_MAX || f == PG_AGG_AVG || f == PG_AGG_MINMAXRANGE || f == PG_AGG_DISTINCTCOUNT ||
+            f == PG_AGG_DISTINCTCOUNTHLL)) {
         po_set_error("segment-level group trim ordered by aggregation function %d", f);
         return 1;
       }

@@ -2089,6 +2089,7 @@ static void hll_small_range_table(int log2m, std::vector<long long>& t, double& 
   else if (m == 64) alpha_mm = 0.709 * m * m;
   else alpha_mm = (0.7213 / (1 + 1.079 / m)) * m * m;
   t.assign((size_t)m + 1, 0);
+  t[0] = INT64_MAX;   // no empty register: linearCounting's m * log(m / 0.0) = Infinity, Math.round(Infinity) = Long.MAX_VALUE
   for (int v = 1; v <= m; v++) t[(size_t)v] = (long long)std::floor(m * std::log(m / (double)v) + 0.5);
   t[0] = INT64_MAX;   // Math.round(+Infinity) = Long.MAX_VALUE (cannot occur: estimate <= 2.5 m implies zero registers exist)
 }
@@ -2174,6 +2175,46 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
     for (int j = 0; j < ao.sum_limbs; j++) limbs[j] = table[(size_t)(ao.op_a + j) * G + g];
     return limbs_to_double(limbs, ao.sum_limbs, ao.fx_q);
   };
+  // DISTINCTCOUNT / DISTINCTCOUNTHLL states: the region of aggregation state `x` with its replicas merged into replica 0 (set union / register
+  // maximum), once — the trim below orders by the states' final values, the assembly extracts them
+  std::vector<char> aux_merged((size_t)std::max(D.n_aux, 1), 0);
+  auto aux_region = [&](int x) -> uint8_t* {
+    size_t off = 0;
+    for (int y = 0; y < x; y++) off += P.aux_bytes[y];
+    const PgAuxOp& A = D.aux[x];
+    if (!aux_merged[(size_t)x]) {
+      for (int rr = 1; rr < A.n_rep; rr++) {
+        uint8_t* dst = H.aux + off;
+        const uint8_t* src = H.aux + off + (size_t)rr * (size_t)A.rep_bytes;
+        if (A.kind == PG_AUX_DICT_SET) for (int64_t b = 0; b < A.rep_bytes; b++) dst[b] |= src[b];
+        else for (int64_t b = 0; b < A.rep_bytes; b++) dst[b] = src[b] > dst[b] ? src[b] : dst[b];
+      }
+      aux_merged[(size_t)x] = 1;
+    }
+    return H.aux + off;
+  };
+  // AggregationFunction#extractFinalResult of such a state: the set's size (DistinctCountAggregationFunction), HyperLogLog#cardinality
+  auto aux_final_value = [&](const AggOut& ao, int64_t g) -> int64_t {
+    if (H.aux_summary) return (int64_t)H.aux_summary[(size_t)ao.aux * (size_t)std::max(D.n_groups, 1) + (size_t)g];
+    const PgAuxOp& A = D.aux[ao.aux];
+    const uint8_t* region = aux_region(ao.aux);
+    if (A.kind == PG_AUX_DICT_SET) {
+      const uint32_t* w = reinterpret_cast<const uint32_t*>(region) + (size_t)g * A.stride;
+      int64_t n = 0;
+      for (int32_t k = 0; k < A.stride; k++) n += __builtin_popcount(w[k]);
+      return n;
+    }
+    const uint8_t* regs = region + (size_t)g * A.stride;
+    const int m = 1 << ao.log2m;
+    std::vector<long long> small;
+    double alpha_mm = 0;
+    hll_small_range_table(ao.log2m, small, alpha_mm);
+    double register_sum = 0;
+    int zeros = 0;
+    for (int j = 0; j < m; j++) { register_sum += 1.0 / (double)(1ULL << regs[j]); zeros += regs[j] == 0; }
+    const double estimate = alpha_mm * (1 / register_sum);
+    return estimate <= (5.0 / 2.0) * m ? (int64_t)small[(size_t)zeros] : (int64_t)std::floor(estimate + 0.5);
+  };
   // ---- segment-level group trim (GroupByOperator.java:120-133 -> TableResizer#trimInSegmentResults :327-351): more groups than trimSize and
   //      an ORDER BY: keep the trimSize groups that sort first.  Order-by values as the extractors of TableResizer.java:406-445 give them:
   //      a group key's value, an aggregation's final result (COUNT long; SUM / MIN / MAX double; AVG sum / count; MINMAXRANGE max - min).
@@ -2202,6 +2243,7 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
           OV& v = vals[i * n_ob + k];
           const int64_t g = gids[i];
           v = OV{1, 0, 0.0, nullptr, 0};
+          if (ao.aux >= 0) { v.type = 0; v.l = aux_final_value(ao, g); continue; }   // DISTINCTCOUNT Integer / DISTINCTCOUNTHLL Long
           switch (ao.function) {
             case PG_AGG_COUNT: v.type = 0; v.l = count_of(ao.op_a, g); break;
             case PG_AGG_SUM: v.d = sum_double(ao, g); break;
@@ -2377,16 +2419,8 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
       continue;
     }
     if (ao.aux >= 0) {   // DISTINCTCOUNT / DISTINCTCOUNTHLL: extract the groups' regions
-      size_t off = 0;
-      for (int x = 0; x < ao.aux; x++) off += P.aux_bytes[x];
       const PgAuxOp& A = D.aux[ao.aux];
-      // merge the replicas into replica 0 (set union / register max)
-      for (int rr = 1; rr < A.n_rep; rr++) {
-        uint8_t* dst = H.aux + off;
-        const uint8_t* src = H.aux + off + (size_t)rr * (size_t)A.rep_bytes;
-        if (A.kind == PG_AUX_DICT_SET) for (int64_t b = 0; b < A.rep_bytes; b++) dst[b] |= src[b];
-        else for (int64_t b = 0; b < A.rep_bytes; b++) dst[b] = src[b] > dst[b] ? src[b] : dst[b];
-      }
+      const size_t off = (size_t)(aux_region(ao.aux) - H.aux);   // (replicas merged into replica 0)
       if (A.kind == PG_AUX_DICT_SET) {
         r.kind = PG_RESULT_DICTID_SET;
         r.set_sizes.assign((size_t)ng, 0);

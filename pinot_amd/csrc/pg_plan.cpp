@@ -1630,9 +1630,12 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
         if (ob.index < 0 || ob.index >= q->n_group_by) fail(PG_ERR_INVALID_ARGUMENT, "ORDER BY group-by expression %d of %d", ob.index, q->n_group_by);
       } else if (ob.kind == PG_ORDER_BY_AGGREGATION) {
         if (ob.index < 0 || ob.index >= q->n_aggregations) fail(PG_ERR_INVALID_ARGUMENT, "ORDER BY aggregation %d of %d", ob.index, q->n_aggregations);
-        const int f = q->aggregations[ob.index].function;
-        if (!(f == PG_AGG_COUNT || f == PG_AGG_SUM || f == PG_AGG_MIN || f == PG_AGG_MAX || f == PG_AGG_AVG || f == PG_AGG_MINMAXRANGE))
-          fail(PG_ERR_UNSUPPORTED, "segment-level group trim ordered by aggregation function %d (distinct counts, multi-value functions) is left to the Java plan", f);
+        // the functions' final results order the groups (TableResizer.java:406-445): the multi-value forms share the single-value functions'
+        // intermediates, the distinct counts are ordered by set size / HyperLogLog#cardinality at assembly
+        const int f = sv_function_of(q->aggregations[ob.index].function);
+        if (!(f == PG_AGG_COUNT || f == PG_AGG_SUM || f == PG_AGG_MIN || f == PG_AGG_MAX || f == PG_AGG_AVG || f == PG_AGG_MINMAXRANGE || f == PG_AGG_DISTINCTCOUNT ||
+              f == PG_AGG_DISTINCTCOUNTHLL))
+          fail(PG_ERR_UNSUPPORTED, "segment-level group trim ordered by aggregation function %d is left to the Java plan", q->aggregations[ob.index].function);
       } else {
         fail(PG_ERR_INVALID_ARGUMENT, "ORDER BY expression kind %d", ob.kind);
       }

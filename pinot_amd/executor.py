@@ -537,6 +537,8 @@ def hll_cardinality(registers: bytes) -> int:
             zeros += 1
     est = alpha_mm * (1 / s)
     if est <= 2.5 * m:
+        if zeros == 0:   # linearCounting: m * log(m / 0.0) = Infinity, Math.round(Infinity) = Long.MAX_VALUE
+            return (1 << 63) - 1
         return int(math.floor(m * math.log(m / zeros) + 0.5))
     return int(math.floor(est + 0.5))
 

@@ -78,3 +78,23 @@ def test_star_tree_route_final_values(gpu_api, oracle_api):
     assert gb.rows() == finals(o.execute(synth.QUERY_CFG5))
     g.destroy()
     o.destroy()
+
+
+def test_small_range_estimate_without_an_empty_register(gpu_api, oracle_api):
+    """HyperLogLog#cardinality, small-range branch with NO empty register: linearCounting(m, 0) = m * Math.log(m / 0.0) = Infinity and
+    Math.round(Infinity) = Long.MAX_VALUE (stream-lib 2.9.8 HyperLogLog.java).  At log2m 4 about a quarter of the ~40-value sets get there: every
+    register 1 or 2 keeps the estimate under 2.5 m.  The oracle, the Python mirror and the device's table of m + 1 values give that value."""
+    from pinot_amd.segment import build_segment
+    n = 4000
+    data = {"k": (np.arange(n) // 50).astype(np.int32), "v": (np.arange(n) % 50 * 7919 + np.arange(n) // 50 * 104729).astype(np.int32)}
+    host = build_segment("hll_small", data, {"k": "INT", "v": "INT"})
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    sql = "SELECT k, DISTINCTCOUNTHLL(v, 4) FROM t GROUP BY k LIMIT 1000"
+    expected = finals(o.execute(sql))
+    saturated = [k for k, v in expected.items() if v[0] == (1 << 63) - 1]
+    assert saturated, "no group of this data reaches the branch: change the generator"
+    qf = parse_sql(sql)
+    qf.flags |= capi.QUERY_FLAG_FINAL_DISTINCT
+    assert g.execute(qf).rows() == expected
+    g.destroy()
+    o.destroy()

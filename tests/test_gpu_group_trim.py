@@ -107,10 +107,21 @@ def test_trim_after_num_groups_limit(big):
     assert gb.stats.num_groups_limit_reached == ob.stats.num_groups_limit_reached == 1
 
 
+def test_trim_ordered_by_final_distinct_values(segs):
+    """... and with PG_QUERY_FLAG_FINAL_DISTINCT the order-by values are the finals the device computed (two integers per group)"""
+    g, o = segs
+    for sql in ("SELECT g1, g2, DISTINCTCOUNT(u), COUNT(*) FROM gpuBench GROUP BY g1, g2 ORDER BY DISTINCTCOUNT(u) DESC, g1, g2 LIMIT 9",
+                "SELECT g1, g2, DISTINCTCOUNTHLL(u), SUM(m) FROM gpuBench GROUP BY g1, g2 ORDER BY DISTINCTCOUNTHLL(u), g2 DESC, g1 LIMIT 12"):
+        qc, qo = parse_sql(sql), parse_sql(sql)
+        qc.min_segment_group_trim_size = qo.min_segment_group_trim_size = 1
+        qc.flags |= capi.QUERY_FLAG_FINAL_DISTINCT
+        gb, ob = g.execute(qc), o.execute(qo)
+        assert set(gb.rows()) == set(ob.rows()) and len(gb.rows()) == 5 * qc.limit
+
+
 def test_trim_refusals(segs):
     g, _ = segs
-    for sql, flags in (("SELECT g1, COUNT(*) FROM gpuBench GROUP BY g1 ORDER BY COUNT(*) LIMIT 1", capi.QUERY_FLAG_NULL_HANDLING),
-                       ("SELECT g1, DISTINCTCOUNT(g2) FROM gpuBench GROUP BY g1 ORDER BY DISTINCTCOUNT(g2) LIMIT 1", 0)):
+    for sql, flags in (("SELECT g1, COUNT(*) FROM gpuBench GROUP BY g1 ORDER BY COUNT(*) LIMIT 1", capi.QUERY_FLAG_NULL_HANDLING),):
         qc = parse_sql(sql)
         qc.min_segment_group_trim_size = 1
         qc.flags |= flags

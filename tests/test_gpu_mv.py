@@ -84,6 +84,22 @@ def test_multi_value_queries_match_oracle(pair, sql):
         assert getattr(gb.stats, f) == getattr(ob.stats, f), f
 
 
+def test_segment_trim_ordered_by_multi_value_functions(pair):
+    """ORDER BY a *MV function with minSegmentGroupTrimSize: the final results of the single-value functions they extend order the groups
+    (TableResizer.java:406-445); the order ends in the group keys — a total order — so the survivors are the oracle's"""
+    from pinot_amd.query import parse_sql
+    from tests.trim_model import assert_valid_trim
+    g, o = pair
+    for sql in ("SELECT mv1, s2, COUNTMV(mv3), SUMMV(mv1) FROM mvTable GROUP BY mv1, s2 ORDER BY COUNTMV(mv3) DESC, mv1, s2 LIMIT 3",
+                "SELECT s1, s2, MAXMV(mv1), AVGMV(mv3), DISTINCTCOUNTMV(mv2) FROM mvTable GROUP BY s1, s2 ORDER BY DISTINCTCOUNTMV(mv2), AVGMV(mv3) DESC, s1, s2 LIMIT 2"):
+        full = g.execute(parse_sql(sql)).rows()
+        qc, qo = parse_sql(sql), parse_sql(sql)
+        qc.min_segment_group_trim_size = qo.min_segment_group_trim_size = 1
+        gb, ob = g.execute(qc), o.execute(qo)
+        assert_valid_trim(qc, full, gb.rows())
+        assert gb.rows() == ob.rows()
+
+
 def test_the_multi_value_kernels_run_them(pair):
     g, _ = pair
     if g.total_docs < 2049:

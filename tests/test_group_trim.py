@@ -15,6 +15,9 @@ QUERIES = [
     "SELECT u, COUNT(*), MAX(m), AVG(m) FROM gpuBench WHERE g1 < 50 GROUP BY u ORDER BY AVG(m) DESC, u LIMIT 100",
     "SELECT u, MINMAXRANGE(m), MIN(m) FROM gpuBench GROUP BY u ORDER BY MINMAXRANGE(m) DESC, MIN(m), u DESC LIMIT 20",
     "SELECT g2, u, COUNT(*) FROM gpuBench GROUP BY g2, u ORDER BY u DESC, g2 LIMIT 50",
+    # ordered by a distinct count's final value: the set's size, HyperLogLog#cardinality (TableResizer.java:406-445 -> extractFinalResult)
+    "SELECT g1, g2, DISTINCTCOUNT(u), COUNT(*) FROM gpuBench GROUP BY g1, g2 ORDER BY DISTINCTCOUNT(u) DESC, g1, g2 LIMIT 9",
+    "SELECT g1, g2, DISTINCTCOUNTHLL(u), SUM(m) FROM gpuBench GROUP BY g1, g2 ORDER BY DISTINCTCOUNTHLL(u), g2 DESC, g1 LIMIT 12",
 ]
 
 
@@ -106,15 +109,10 @@ def test_order_by_resolution_and_c_structs():
     assert qc.resolved_order_by() is None and CQuery(qc).query.n_order_by == 0
 
 
-def test_trim_refused_under_null_handling_and_for_distinct_counts(seg, oracle_api):
+def test_trim_refused_under_null_handling(seg, oracle_api):
     qc = parse_sql("SELECT g1, COUNT(*) FROM gpuBench GROUP BY g1 ORDER BY COUNT(*) LIMIT 1")
     qc.min_segment_group_trim_size = 1
     qc.flags |= capi.QUERY_FLAG_NULL_HANDLING
-    with pytest.raises(capi.NativeError) as e:
-        seg.execute(qc)
-    assert e.value.status == capi.PG_ERR_UNSUPPORTED
-    qc = parse_sql("SELECT g1, DISTINCTCOUNT(g2) FROM gpuBench GROUP BY g1 ORDER BY DISTINCTCOUNT(g2) LIMIT 1")
-    qc.min_segment_group_trim_size = 1
     with pytest.raises(capi.NativeError) as e:
         seg.execute(qc)
     assert e.value.status == capi.PG_ERR_UNSUPPORTED

@@ -7,8 +7,15 @@ import math
 
 def final_value(function, v):
     """AggregationFunction#extractFinalResult of the intermediate `v` as executor.ResultsBlock.columns presents it."""
+    function = {"COUNTMV": "COUNT", "SUMMV": "SUM", "MINMV": "MIN", "MAXMV": "MAX", "AVGMV": "AVG", "MINMAXRANGEMV": "MINMAXRANGE",
+                "DISTINCTCOUNTMV": "DISTINCTCOUNT"}.get(function, function)   # the multi-value forms extend the single-value functions
     if function in ("COUNT", "SUM", "MIN", "MAX"):
         return v
+    if function == "DISTINCTCOUNT":      # the set's size (an Integer)
+        return len(v)
+    if function == "DISTINCTCOUNTHLL":   # HyperLogLog#cardinality (a Long)
+        from pinot_amd.executor import hll_cardinality
+        return hll_cardinality(v)
     if function == "AVG":
         s, c = v
         return -math.inf if c == 0 else s / c
