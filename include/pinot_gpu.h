@@ -227,8 +227,8 @@ typedef struct pg_query {
 #define PG_QUERY_FLAG_EXACT_FILTER_STATS 0x10 /* compute it whatever the segment's size.  By default those shapes get the exact count (a) up to 2^27 docs
                                                  (PG_EXACT_STATS_DEVICE_MAX_DOCS) where the iterator automaton decomposes into tiles and is counted on the device —
                                                  an AND of scans, index leaves and flat ORs of both, under drained ORs / NOTs: ~1 ms per 10^8 docs beside the
-                                                 leaves' filter launches; (b) up to 2^22 docs (PG_EXACT_STATS_MAX_DOCS) otherwise — NOT or a compound child under
-                                                 an AND, multi-value scans: one bitmap copy to the host and a host walk per leaf, 0.2 - 3 s per 10^8 docs
+                                                 leaves' filter launches; (b) up to 2^22 docs (PG_EXACT_STATS_MAX_DOCS) otherwise — a compound child under a NOT or an OR
+                                                 inside an AND, nested ANDs: one bitmap copy to the host and a host walk per leaf, 0.2 - 3 s per 10^8 docs
                                                  (profiles/r06_filter_stats_device.txt; pg_exec_stats.filter_stats_path says which) */
 #define PG_QUERY_FLAG_FINAL_DISTINCT 0x20  /* DISTINCTCOUNT / DISTINCTCOUNTHLL come back as their FINAL value (PG_RESULT_LONG: the set's size, HyperLogLog#cardinality —
                                               AggregationFunction#extractFinalResult), not as the intermediate set / registers: for a caller that

@@ -315,6 +315,7 @@ struct Set {
   const HostBits* leaf_bits = nullptr;                       // Scan: match bitmap; Bitmap: the doc set
   const uint64_t* dev_words = nullptr;                       // the same bitmap in HBM (device evaluation; a Bitmap without it is built from `ranges`)
   const int32_t* mv_off = nullptr;                           // Scan over a multi-value column: the docs' first entries
+  const int32_t* mv_off_dev = nullptr;                       // ... in HBM (device evaluation)
   std::shared_ptr<HostBits> owned;                           // Bitmap built here (flips, range lists)
   std::vector<std::pair<int32_t, int32_t>> ranges;           // Sorted
   std::vector<std::unique_ptr<Set>> children;                // And / Or / Not
@@ -361,7 +362,7 @@ struct Emu {
       case OpKind::Scan: {
         auto s = mk(SetKind::Scan);
         bind_leaf(*s, op);
-        if (op.col && op.col->is_mv) s->mv_off = op.col->mv_offsets_host.data();
+        if (op.col && op.col->is_mv) { s->mv_off = op.col->mv_offsets_host.data(); s->mv_off_dev = op.col->mv_offsets_dev.as<int32_t>(); }
         return s;
       }
       case OpKind::Inverted: {
@@ -592,6 +593,19 @@ __global__ void __launch_bounds__(64) fs_and_kernel(const FsAndProg p, int64_t n
     }
   }
 }
+// entries of the docs in `v` (a word of docs from `base` on): a multi-value scan counts every entry of a doc it evaluates (MVScanDocIdIterator.java:65-117);
+// mv_off: the docs' first entries (numDocs + 1 values) — runs of docs, two look-ups each
+__device__ __forceinline__ unsigned long long fs_entries_of(uint64_t v, int64_t base, const int32_t* __restrict__ mv_off) {
+  unsigned long long sum = 0;
+  while (v) {
+    const int a = __builtin_ctzll(v);
+    const uint64_t rest = ~(v >> a);
+    const int len = rest ? __builtin_ctzll(rest) : 64 - a;
+    sum += (unsigned long long)(mv_off[base + a + len] - mv_off[base + a]);
+    v = a + len >= 64 ? 0 : v & (~0ULL << (a + len));
+  }
+  return sum;
+}
 __device__ __forceinline__ void fs_block_add(unsigned long long v, unsigned long long* total) {
   __shared__ unsigned long long s_sum;
   if (threadIdx.x == 0) s_sum = 0;
@@ -608,7 +622,7 @@ __global__ void __launch_bounds__(kFsBlock) fs_latch_summary_kernel(const uint64
   if ((threadIdx.x & 63) == 0) out[w >> 6] = ev ? (uint8_t)(((set >> (63 - __clzll((long long)ev))) & 1ULL) ? 1 : 2) : (uint8_t)0;
 }
 __global__ void __launch_bounds__(kFsBlock) fs_latch_count_kernel(const uint64_t* __restrict__ t, const uint64_t* __restrict__ m, int64_t n_words,
-                                                                  const uint8_t* __restrict__ prefix, int64_t n_docs, unsigned long long* total) {
+                                                                  const uint8_t* __restrict__ prefix, int64_t n_docs, const int32_t* __restrict__ mv_off, unsigned long long* total) {
   const int lane = (int)(threadIdx.x & 63);
   const int64_t n_latch_tiles = (n_words + 63) >> 6, waves = (int64_t)gridDim.x * (kFsBlock / 64);
   unsigned long long v = 0;
@@ -618,20 +632,23 @@ __global__ void __launch_bounds__(kFsBlock) fs_latch_count_kernel(const uint64_t
     const unsigned long long ev = __ballot(s != 0), set = __ballot(s == 1);
     const unsigned long long below = ev & ((1ULL << lane) - 1ULL);   // the words of this tile before the lane's
     const bool carry = below ? ((set >> (63 - __clzll((long long)below))) & 1ULL) != 0 : (tile > 0 && prefix[tile - 1] == 1);
-    if (w < n_words) v += (unsigned long long)fs_latch_count(t, m, w, w + 1, carry, n_docs);
+    if (w < n_words) {
+      const uint64_t visited = fs_latch_visited(t, m, w, carry, n_docs, nullptr);
+      v += mv_off ? fs_entries_of(visited, w * 64, mv_off) : (unsigned long long)__popcll(visited);
+    }
   }
   for (int off = 32; off; off >>= 1) v += __shfl_down(v, off);
   if (lane == 0 && v) atomicAdd(total, v);
 }
-// dst = a (op) b word by word — op 0: AND, 1: OR, 2: copy of a, 3: the docs not in a; with `total`: the docs of `a` (before the operation) are added to it
+// dst = a (op) b word by word — op 0: AND, 1: OR, 2: copy of a, 3: the docs not in a; with `total`: the docs of `a` (before the operation; their entries with `mv_off`) are added to it
 __global__ void fs_words_kernel(uint64_t* __restrict__ dst, const uint64_t* __restrict__ a, const uint64_t* __restrict__ b, int64_t n_words, int64_t n_docs, int op,
-                                unsigned long long* total) {
+                                const int32_t* __restrict__ mv_off, unsigned long long* total) {
   const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long c = 0;
   if (w < n_words) {
     uint64_t x = a[w];
     if (w * 64 + 64 > n_docs) x &= ~0ULL >> (64 - (n_docs - w * 64));   // (the last word: docs that exist)
-    c = (unsigned long long)__popcll(x);
+    c = mv_off ? fs_entries_of(x, w * 64, mv_off) : (unsigned long long)__popcll(x);
     dst[w] = op == 0 ? (x & b[w]) : op == 1 ? (x | b[w]) : op == 2 ? x : (~a[w] & (w * 64 + 64 > n_docs ? ~0ULL >> (64 - (n_docs - w * 64)) : ~0ULL));
   }
   if (total) fs_block_add(c, total);
@@ -777,13 +794,13 @@ struct DevEval {
   // what Emu::iterator would hand the AND for this child
   static Kind child_kind(const Set& s) {
     switch (s.kind) {
-      case SetKind::Scan: return s.mv_off ? Kind::Unfit : Kind::Scan;
+      case SetKind::Scan: return Kind::Scan;   // (over a multi-value column: entries instead of docs)
       case SetKind::Bitmap: return Kind::Bitmap;
       case SetKind::Sorted: return Kind::Sorted;
       case SetKind::Or: {
         int n_sorted = 0, n_other = 0;
         for (auto& c : s.children) {
-          if (c->kind == SetKind::Scan) { if (c->mv_off) return Kind::Unfit; n_other++; }
+          if (c->kind == SetKind::Scan) n_other++;
           else if (c->kind == SetKind::Sorted) n_sorted++;
           else if (c->kind != SetKind::Bitmap) return Kind::Unfit;   // compound children of an OR under an AND: the host walk
         }
@@ -791,7 +808,7 @@ struct DevEval {
       }
       case SetKind::Not: {   // NotDocIdIterator over one leaf (a compound child draws on next() and advance() of its own children: the host walk)
         const Set& c = *s.children[0];
-        if (c.kind == SetKind::Scan) return c.mv_off ? Kind::Unfit : Kind::Other;
+        if (c.kind == SetKind::Scan) return c.mv_off ? Kind::Unfit : Kind::Other;   // (MVScanDocIdIterator#next steps doc by doc, without batches: the host walk)
         return c.kind == SetKind::Bitmap || c.kind == SetKind::Sorted ? Kind::Other : Kind::Unfit;
       }
       default: return Kind::Unfit;   // Empty / MatchAll / And under an AND
@@ -811,7 +828,7 @@ struct DevEval {
   }
   static bool fits_drained(const Set& s) {
     switch (s.kind) {
-      case SetKind::Scan: return !s.mv_off;
+      case SetKind::Scan: return true;
       case SetKind::Not: return fits_drained(*s.children[0]);
       case SetKind::Or: for (auto& c : s.children) if (!fits_drained(*c)) return false; return true;
       case SetKind::And: return fits_and(s);
@@ -840,9 +857,9 @@ struct DevEval {
     if (!dry && !s.dev_words) fail(PG_ERR_INTERNAL, "filter statistics: a leaf's match bitmap is missing");
     return s.dev_words;
   }
-  void words_op(uint64_t* dst, const uint64_t* a, const uint64_t* b, int op, bool count_a) {
+  void words_op(uint64_t* dst, const uint64_t* a, const uint64_t* b, int op, bool count_a, const int32_t* mv_off = nullptr) {
     if (dry) return;
-    hipLaunchKernelGGL(fs_words_kernel, grid_for(n_words), dim3(kFsBlock), 0, stream, dst, a, b ? b : a, n_words, n_docs, op, count_a ? total : nullptr);
+    hipLaunchKernelGGL(fs_words_kernel, grid_for(n_words), dim3(kFsBlock), 0, stream, dst, a, b ? b : a, n_words, n_docs, op, mv_off, count_a ? total : nullptr);
   }
   const uint64_t* or_words(const Set& s) {   // the docs an OR's iterator returns
     uint64_t* acc = take_words();
@@ -856,7 +873,7 @@ struct DevEval {
   }
 
   // a leaf's count from the targets of the AND child it sits under
-  void latch_count(const uint64_t* targets, const uint64_t* match) {
+  void latch_count(const uint64_t* targets, const uint64_t* match, const int32_t* mv_off) {
     const size_t padded = (size_t)grid_for(n_words).x * (kFsBlock / 64);   // (every wavefront of the grid writes its tile's summary)
     uint8_t* summary = take<uint8_t>(padded);
     uint8_t* prefix = take<uint8_t>(padded);
@@ -866,7 +883,7 @@ struct DevEval {
     if (dry) return;
     hipLaunchKernelGGL(fs_latch_summary_kernel, grid_for(n_words), dim3(kFsBlock), 0, stream, targets, match, n_words, summary);
     PG_HIP(rocprim::inclusive_scan(tmp, tmp_bytes, summary, prefix, (size_t)n_latch_tiles, FsLatchThen(), stream));
-    hipLaunchKernelGGL(fs_latch_count_kernel, dim3((unsigned)std::min<int64_t>((n_latch_tiles + kFsBlock / 64 - 1) / (kFsBlock / 64), 4096)), dim3(kFsBlock), 0, stream, targets, match, n_words, prefix, n_docs, total);
+    hipLaunchKernelGGL(fs_latch_count_kernel, dim3((unsigned)std::min<int64_t>((n_latch_tiles + kFsBlock / 64 - 1) / (kFsBlock / 64), 4096)), dim3(kFsBlock), 0, stream, targets, match, n_words, prefix, n_docs, mv_off, total);
   }
 
   FsIndex index_of(const uint64_t* words) {
@@ -911,7 +928,8 @@ struct DevEval {
       }
     }
     const int n_index = (int)(sorted.size() + bitmaps.size());
-    struct AndChild { const uint64_t* match; std::vector<const uint64_t*> counted; const uint64_t* not_scan = nullptr; };   // counted: the scan leaves below it; not_scan: the scan under a NOT
+    struct Counted { const uint64_t* match; const int32_t* mv_off; };   // a scan leaf; mv_off: over a multi-value column
+    struct AndChild { const uint64_t* match; std::vector<Counted> counted; const uint64_t* not_scan = nullptr; };   // counted: the scan leaves below it; not_scan: the scan under a NOT
     std::vector<AndChild> its;
     auto child_of = [&](const Set& c) {
       AndChild a;
@@ -923,10 +941,10 @@ struct DevEval {
         if (c.children[0]->kind == SetKind::Scan) a.not_scan = inner;
       } else if (c.kind == SetKind::Or) {
         a.match = or_words(c);
-        for (auto& l : c.children) if (l->kind == SetKind::Scan) a.counted.push_back(leaf_words(*l));
+        for (auto& l : c.children) if (l->kind == SetKind::Scan) a.counted.push_back({leaf_words(*l), l->mv_off_dev});
       } else {
         a.match = leaf_words(c);
-        if (c.kind == SetKind::Scan) a.counted.push_back(a.match);
+        if (c.kind == SetKind::Scan) a.counted.push_back({a.match, c.mv_off_dev});
       }
       return a;
     };
@@ -939,7 +957,7 @@ struct DevEval {
           words_op(docs, first ? w : docs, first ? nullptr : w, first ? 2 : 0, false);
           first = false;
         }
-      for (const Set* c : scans) words_op(docs, docs, leaf_words(*c), 0, true);   // applyAnd: every surviving candidate is evaluated once
+      for (const Set* c : scans) words_op(docs, docs, leaf_words(*c), 0, true, c->mv_off_dev);   // applyAnd: every surviving candidate is evaluated once
       if (others.empty()) return;   // a bitmap-based iterator: draining it scans nothing
       its.push_back({docs, {}});
       for (const Set* c : others) its.push_back(child_of(*c));
@@ -967,14 +985,14 @@ struct DevEval {
       hipLaunchKernelGGL(fs_and_kernel<true>, grid, dim3(64), fs_and_lds_bytes(prog.k, true), stream, prog, n_docs, n_words, n_tiles, (uint32_t*)nullptr, (const uint32_t*)prefix);
     }
     for (int j = 0; j < prog.k; j++) {
-      for (const uint64_t* leaf : its[(size_t)j].counted) latch_count(prog.targets[j], leaf);
+      for (const Counted& leaf : its[(size_t)j].counted) latch_count(prog.targets[j], leaf.match, leaf.mv_off);
       if (its[(size_t)j].not_scan) not_count(prog.targets[j], its[(size_t)j].not_scan, its[(size_t)j].match);
     }
   }
 
   void run_drained(const Set& s) {   // the iterator is drained by next(): every child of an OR / NOT is drained in turn
     switch (s.kind) {
-      case SetKind::Scan: closed_form += n_docs; break;   // SVScanDocIdIterator#next: whole batches to the end
+      case SetKind::Scan: closed_form += s.mv_off ? (int64_t)s.mv_off[n_docs] : n_docs; break;   // SVScanDocIdIterator#next: whole batches to the end; over a multi-value column every entry
       case SetKind::Not: run_drained(*s.children[0]); break;
       case SetKind::Or: for (auto& c : s.children) run_drained(*c); break;
       case SetKind::And: run_and(s); break;

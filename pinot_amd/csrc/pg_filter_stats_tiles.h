@@ -130,32 +130,31 @@ FS_HD uint32_t fs_latch_summary(const uint64_t* t, const uint64_t* m, int64_t w_
 }
 FS_HD uint32_t fs_latch_then(uint32_t a, uint32_t b) { return b ? b : a; }
 
-// visited docs of words [w_lo, w_hi) given the state entering w_lo (`carry`), docs beyond n_docs not counted
+// the visited docs of word w given the state entering it (`carry`), docs at and beyond n_docs masked out; `top`: the state leaving the word
+FS_HD uint64_t fs_latch_visited(const uint64_t* t, const uint64_t* m, int64_t w, bool carry, int64_t n_docs, bool* top) {
+  const uint64_t s = t[w], mw = m[w];
+  const uint64_t r = (mw << 1) | (w > 0 ? m[w - 1] >> 63 : 0);
+  // bits that set (generate), bits that hand the previous state on (propagate): a prefix network over the 64 positions
+  uint64_t g = s, pp = ~(s | r);
+  g |= pp & (g << 1);  pp &= pp << 1;
+  g |= pp & (g << 2);  pp &= pp << 2;
+  g |= pp & (g << 4);  pp &= pp << 4;
+  g |= pp & (g << 8);  pp &= pp << 8;
+  g |= pp & (g << 16); pp &= pp << 16;
+  g |= pp & (g << 32);
+  // positions below the first set / reset of the word take the entering state
+  const uint64_t ev = s | r;
+  const uint64_t below = ev ? ((ev & (~ev + 1)) - 1) : ~0ULL;
+  uint64_t v = g | (carry ? below : 0);
+  if (top) *top = (v >> 63) != 0;
+  const int64_t base = w * 64;
+  if (base + 64 > n_docs) v &= n_docs > base ? (~0ULL >> (64 - (n_docs - base))) : 0;
+  return v;
+}
+// visited docs of words [w_lo, w_hi) given the state entering w_lo
 FS_HD int64_t fs_latch_count(const uint64_t* t, const uint64_t* m, int64_t w_lo, int64_t w_hi, bool carry, int64_t n_docs) {
   int64_t total = 0;
-  uint64_t prev_top = w_lo > 0 ? m[w_lo - 1] >> 63 : 0;
-  for (int64_t w = w_lo; w < w_hi; w++) {
-    const uint64_t s = t[w], mw = m[w];
-    const uint64_t r = (mw << 1) | prev_top;
-    prev_top = mw >> 63;
-    // bits that set (generate), bits that hand the previous state on (propagate): a prefix network over the 64 positions
-    uint64_t g = s, pp = ~(s | r);
-    g |= pp & (g << 1);  pp &= pp << 1;
-    g |= pp & (g << 2);  pp &= pp << 2;
-    g |= pp & (g << 4);  pp &= pp << 4;
-    g |= pp & (g << 8);  pp &= pp << 8;
-    g |= pp & (g << 16); pp &= pp << 16;
-    g |= pp & (g << 32);
-    // positions below the first set / reset of the word take the entering state
-    const uint64_t ev = s | r;
-    const uint64_t below = ev ? ((ev & (~ev + 1)) - 1) : ~0ULL;
-    uint64_t v = g | (carry ? below : 0);
-    const int64_t base = w * 64;
-    if (base + 64 > n_docs) v &= n_docs > base ? (~0ULL >> (64 - (n_docs - base))) : 0;
-    total += __builtin_popcountll(v);
-    if (base + 64 > n_docs) break;
-    carry = (v >> 63) != 0;
-  }
+  for (int64_t w = w_lo; w < w_hi && w * 64 < n_docs; w++) total += __builtin_popcountll(fs_latch_visited(t, m, w, carry, n_docs, &carry));
   return total;
 }
 

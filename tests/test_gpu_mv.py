@@ -84,6 +84,30 @@ def test_multi_value_queries_match_oracle(pair, sql):
         assert getattr(gb.stats, f) == getattr(ob.stats, f), f
 
 
+# leapfrogged shapes over multi-value scans: counted in tiles on the device (entries, not docs: pg_filter_stats_tiles.h), the others by the host walk
+MV_STATS_PATHS = [
+    ("SELECT COUNT(*), SUM(m) FROM mvTable WHERE mv2 = 'eel' AND m < 0", 2),                                   # single-value AND multi-value scan
+    ("SELECT COUNT(*), SUM(m) FROM mvTable WHERE mv2 IN ('ant', 'bee') AND mv3 > 3000000 AND mv1 BETWEEN 5 AND 30", 2),
+    ("SELECT s1, COUNT(*) FROM mvTable WHERE s1 = 2 AND (mv2 = 'cat' OR m > 500) GROUP BY s1 LIMIT 10", 2),      # OR of scans under an AND
+    ("SELECT COUNT(*) FROM mvTable WHERE (mv1 BETWEEN 3 AND 9 AND mv3 > 2000000) OR mv2 = 'gnu'", 2),           # drained OR over an AND and a scan
+    ("SELECT COUNT(*) FROM mvTable WHERE m < 0 AND NOT (mv2 = 'cat')", 1),                                     # NOT over a multi-value scan under an AND
+]
+
+
+@pytest.mark.parametrize("sql,path", MV_STATS_PATHS)
+def test_entries_scanned_in_filter_over_multi_value_scans(pair, gpu_knobs, sql, path):
+    g, o = pair
+    gb, ob = g.execute(sql), o.execute(sql)
+    assert gb.rows() == ob.rows()
+    assert gb.stats.stats_exact == 1
+    assert gb.stats.num_entries_scanned_in_filter == ob.stats.num_entries_scanned_in_filter
+    if g.host.total_docs >= 2049:
+        assert gb.stats.filter_stats_path == path
+    gpu_knobs(PG_FILTER_STATS_HOST=1)
+    hb = g.execute(sql)
+    assert hb.stats.num_entries_scanned_in_filter == ob.stats.num_entries_scanned_in_filter and hb.stats.filter_stats_path <= 1
+
+
 def test_segment_trim_ordered_by_multi_value_functions(pair):
     """ORDER BY a *MV function with minSegmentGroupTrimSize: the final results of the single-value functions they extend order the groups
     (TableResizer.java:406-445); the order ends in the group keys — a total order — so the survivors are the oracle's"""
