@@ -226,9 +226,9 @@ typedef struct pg_query {
 #define PG_QUERY_FLAG_APPROX_FILTER_STATS 0x8 /* skip the exact numEntriesScannedInFilter of OR / NOT-over-scan shapes (stats_exact = 0) */
 #define PG_QUERY_FLAG_EXACT_FILTER_STATS 0x10 /* compute it whatever the segment's size.  By default those shapes get the exact count (a) up to 2^27 docs
                                                  (PG_EXACT_STATS_DEVICE_MAX_DOCS) where the iterator automaton decomposes into tiles and is counted on the device —
-                                                 an AND of scans, index leaves and flat ORs of both, under drained ORs / NOTs: ~1 ms per 10^8 docs beside the
-                                                 leaves' filter launches; (b) up to 2^22 docs (PG_EXACT_STATS_MAX_DOCS) otherwise — a compound child under a NOT or an OR
-                                                 inside an AND, nested ANDs: one bitmap copy to the host and a host walk per leaf, 0.2 - 3 s per 10^8 docs
+                                                 an AND of scans, index leaves, NOTs over a leaf, ORs of leaves and of such ANDs, under drained ORs / NOTs: ~1 ms per 10^8 docs beside the
+                                                 leaves' filter launches; (b) up to 2^22 docs (PG_EXACT_STATS_MAX_DOCS) otherwise — under an AND a NOT over a compound
+                                                 child, an OR / NOT inside an OR: one bitmap copy to the host and a host walk per leaf, 0.2 - 3 s per 10^8 docs
                                                  (profiles/r06_filter_stats_device.txt; pg_exec_stats.filter_stats_path says which) */
 #define PG_QUERY_FLAG_FINAL_DISTINCT 0x20  /* DISTINCTCOUNT / DISTINCTCOUNTHLL come back as their FINAL value (PG_RESULT_LONG: the set's size, HyperLogLog#cardinality —
                                               AggregationFunction#extractFinalResult), not as the intermediate set / registers: for a caller that
@@ -265,7 +265,7 @@ typedef struct pg_exec_stats {
   int32_t star_tree_index;        /* index of the star-tree the query ran on (StarTreeUtils.java:357-436), -1: none */
   int32_t filter_stats_path;      /* how num_entries_scanned_in_filter was counted — 0: by the query's own kernels (shapes with a closed form), 1: the reference's
                                      iterator automaton walked on the host over the leaves' match bitmaps, 2: the same automaton in tiles on the device
-                                     (AND of scans / index leaves / flat ORs under drained ORs and NOTs: pg_filter_stats_tiles.h) */
+                                     (pg_filter_stats_tiles.h) */
 } pg_exec_stats;
 
 /* Intermediate result kinds (AggregationFunction#getIntermediateResultColumnType). */

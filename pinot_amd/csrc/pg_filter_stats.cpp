@@ -544,11 +544,12 @@ static const int kFsBlock = 256;
 
 struct FsAndProg {
   int32_t k;                                  // children of the AndDocIdIterator, in its order
+  const uint64_t* active;                     // the docs the AND is (re)started at by its parent's advance(); nullptr: drained by next() — every doc
   const uint64_t* match[FS_MAX_CHILDREN];     // the docs each child's iterator returns
   uint64_t* targets[FS_MAX_CHILDREN];         // out (second simulation): the targets each child was advanced to; nullptr: not wanted
 };
 static const int kFsStride = FS_TILE_WORDS + 1;   // a lane's tile in LDS: 9 words apart (lanes walk their tiles independently)
-static size_t fs_and_lds_bytes(int k, bool emit) { return (size_t)(emit ? 2 : 1) * (size_t)k * 64 * kFsStride * 8; }
+static size_t fs_and_lds_bytes(int k, bool emit) { return (size_t)((emit ? 2 : 1) * k + 1) * 64 * kFsStride * 8; }   // matches (+ targets) + the activation docs
 
 // The AND automaton, one wavefront per workgroup over 64 consecutive tiles, a tile per lane.  The children's words of the 64 tiles (512 consecutive
 // words each) are staged in LDS by coalesced loads: read from HBM in place, every lane walked its own 64 bytes of every child word by word
@@ -560,29 +561,34 @@ __global__ void __launch_bounds__(64) fs_and_kernel(const FsAndProg p, int64_t n
   extern __shared__ __attribute__((aligned(16))) uint64_t fs_lds[];
   const int lane = (int)threadIdx.x;
   const int64_t tile0 = (int64_t)blockIdx.x * 64, word0 = tile0 * FS_TILE_WORDS;
-  uint64_t* const lm = fs_lds;
-  uint64_t* const lt = fs_lds + (size_t)p.k * 64 * kFsStride;
-  for (int c = 0; c < p.k; c++)
-    for (int i = lane; i < 64 * FS_TILE_WORDS; i += 64) {
-      const int64_t w = word0 + i;
-      const int at = (c * 64 + i / FS_TILE_WORDS) * kFsStride + i % FS_TILE_WORDS;
-      lm[at] = w < n_words ? p.match[c][w] : 0;
-      if (EMIT) lt[at] = 0;
+  uint64_t* const la = fs_lds;
+  uint64_t* const lm = la + 64 * kFsStride;
+  uint64_t* const lt = lm + (size_t)p.k * 64 * kFsStride;
+  for (int i = lane; i < 64 * FS_TILE_WORDS; i += 64) {
+    const int64_t w = word0 + i;
+    const int at = (i / FS_TILE_WORDS) * kFsStride + i % FS_TILE_WORDS;
+    la[at] = p.active ? (w < n_words ? p.active[w] : 0) : ~0ULL;
+    for (int c = 0; c < p.k; c++) {
+      lm[c * 64 * kFsStride + at] = w < n_words ? p.match[c][w] : 0;
+      if (EMIT) lt[c * 64 * kFsStride + at] = 0;
     }
+  }
   __syncthreads();
   const int64_t tile = tile0 + lane;
   struct Io {   // the lane's tile: positions relative to its first doc
+    const uint64_t* a;
     const uint64_t* m;
     uint64_t* t;
     int lane;
+    __device__ __forceinline__ uint64_t active(int32_t w) const { return a[lane * kFsStride + w]; }
     __device__ __forceinline__ uint64_t match(int c, int32_t w) const { return m[(c * 64 + lane) * kFsStride + w]; }
     __device__ __forceinline__ void target(int c, int32_t doc) { t[(c * 64 + lane) * kFsStride + (doc >> 6)] |= 1ULL << (doc & 63); }
-  } io{lm, lt, lane};
+  } io{la, lm, lt, lane};
   if (tile < n_tiles) {
     const int64_t lo = tile * (FS_TILE_WORDS * 64);
     const int32_t end = (int32_t)(lo + FS_TILE_WORDS * 64 < n_docs ? FS_TILE_WORDS * 64 : n_docs - lo);
     if (!EMIT) out[tile] = fs_and_tile_exits(p.k, io, end);
-    else (void)fs_and_tile(p.k, io, 0, end, tile ? (in[tile - 1] & 15u) : FS_CLEAN, true);   // the entry: what a clean start of the segment has become by here
+    else (void)fs_and_tile(p.k, io, 0, end, tile ? (in[tile - 1] & 15u) : FS_IDLE, true);   // the entry: what an idle start of the segment has become by here
   }
   if (EMIT) {
     __syncthreads();
@@ -791,18 +797,40 @@ struct DevEval {
   dim3 grid_for(int64_t lanes) const { return dim3((unsigned)((lanes + kFsBlock - 1) / kFsBlock)); }
 
   enum class Kind { Scan, Bitmap, Sorted, Other, Unfit };
-  // what Emu::iterator would hand the AND for this child
+  // AndDocIdSet#iterator: index-based children and scans merge into one bitmap-based iterator when there is an index-based child beside a scan,
+  // or two of them; with nothing else left that iterator IS the AND's
+  struct AndShape { bool fits, merged; int n_other; };
+  static AndShape and_shape(const Set& s) {
+    int n_index = 0, n_scan = 0, n_other = 0;
+    for (auto& c : s.children) {
+      const Kind k = child_kind(*c);
+      if (k == Kind::Unfit) return {false, false, 0};
+      n_index += k == Kind::Bitmap || k == Kind::Sorted;
+      n_scan += k == Kind::Scan;
+      n_other += k == Kind::Other;
+    }
+    const bool merged = (n_index > 0 && n_scan > 0) || n_index > 1;
+    return {(merged ? 1 + n_other : (int)s.children.size()) <= FS_MAX_CHILDREN, merged, n_other};
+  }
+  static bool fits_and(const Set& s) { return and_shape(s).fits; }
+  // what Emu::iterator would hand an AND for this child
   static Kind child_kind(const Set& s) {
     switch (s.kind) {
       case SetKind::Scan: return Kind::Scan;   // (over a multi-value column: entries instead of docs)
       case SetKind::Bitmap: return Kind::Bitmap;
       case SetKind::Sorted: return Kind::Sorted;
+      case SetKind::And: {   // an AND under an AND / an OR: advance()d by its parent — the tile automaton started at the parent's targets
+        const AndShape a = and_shape(s);
+        if (!a.fits) return Kind::Unfit;
+        return a.merged && a.n_other == 0 ? Kind::Bitmap : Kind::Other;
+      }
       case SetKind::Or: {
         int n_sorted = 0, n_other = 0;
         for (auto& c : s.children) {
           if (c->kind == SetKind::Scan) n_other++;
           else if (c->kind == SetKind::Sorted) n_sorted++;
-          else if (c->kind != SetKind::Bitmap) return Kind::Unfit;   // compound children of an OR under an AND: the host walk
+          else if (c->kind == SetKind::And) { const Kind k = child_kind(*c); if (k == Kind::Unfit) return Kind::Unfit; n_other += k == Kind::Other; }
+          else if (c->kind != SetKind::Bitmap) return Kind::Unfit;   // an OR or a NOT inside an OR under an AND: the host walk
         }
         return n_sorted > 1 && n_other == 0 ? Kind::Bitmap : Kind::Other;   // OrDocIdSet#iterator merges index-based children only beside >= 2 sorted ones
       }
@@ -811,20 +839,8 @@ struct DevEval {
         if (c.kind == SetKind::Scan) return c.mv_off ? Kind::Unfit : Kind::Other;   // (MVScanDocIdIterator#next steps doc by doc, without batches: the host walk)
         return c.kind == SetKind::Bitmap || c.kind == SetKind::Sorted ? Kind::Other : Kind::Unfit;
       }
-      default: return Kind::Unfit;   // Empty / MatchAll / And under an AND
+      default: return Kind::Unfit;   // Empty / MatchAll under an AND
     }
-  }
-  static bool fits_and(const Set& s) {
-    int n_index = 0, n_scan = 0, n_other = 0;
-    for (auto& c : s.children) {
-      const Kind k = child_kind(*c);
-      if (k == Kind::Unfit) return false;
-      n_index += k == Kind::Bitmap || k == Kind::Sorted;
-      n_scan += k == Kind::Scan;
-      n_other += k == Kind::Other;
-    }
-    const bool merged = (n_index > 0 && n_scan > 0) || n_index > 1;
-    return (merged ? 1 + n_other : (int)s.children.size()) <= FS_MAX_CHILDREN;
   }
   static bool fits_drained(const Set& s) {
     switch (s.kind) {
@@ -865,7 +881,7 @@ struct DevEval {
     uint64_t* acc = take_words();
     bool first = true;
     for (auto& c : s.children) {
-      const uint64_t* w = leaf_words(*c);
+      const uint64_t* w = c->kind == SetKind::And ? plan_and(*c).docs() : leaf_words(*c);
       words_op(acc, first ? w : acc, first ? nullptr : w, first ? 2 : 1, false);
       first = false;
     }
@@ -917,7 +933,35 @@ struct DevEval {
     if (!dry) hipLaunchKernelGGL(fs_not_episodes_kernel, grid_for(n_words), dim3(kFsBlock), 0, stream, look, n_words, n_docs, total);
   }
 
-  void run_and(const Set& s) {   // AndDocIdSet#iterator, then AndDocIdIterator drained
+  // AndDocIdSet#iterator of one AND: its children's iterators in the AND's order (index-based children and scans merged, with the applyAnd counts —
+  // once, when the iterator is built), and the docs the AND itself returns (asked for by a parent)
+  struct Counted { const uint64_t* match; const int32_t* mv_off; };   // a scan leaf; mv_off: over a multi-value column
+  struct AndChild {
+    const uint64_t* match;
+    std::vector<Counted> counted;            // the scan leaves that receive this child's targets
+    const uint64_t* not_scan = nullptr;      // the scan under a NOT
+    std::vector<const Set*> inner;           // the ANDs started at this child's targets: the child itself, or children of the OR it is
+  };
+  struct AndPlan {
+    DevEval* ev = nullptr;
+    std::vector<AndChild> its;
+    const uint64_t* all = nullptr;
+    bool have_all = false;
+    const uint64_t* docs() {   // the intersection of the children
+      if (have_all) return all;
+      have_all = true;
+      if (its.size() == 1) return all = its[0].match;
+      uint64_t* acc = ev->take_words();
+      for (size_t j = 1; j < its.size(); j++) ev->words_op(acc, j == 1 ? its[0].match : acc, its[j].match, 0, false);
+      return all = acc;
+    }
+  };
+  std::deque<std::pair<const Set*, AndPlan>> plans;
+  AndPlan& plan_and(const Set& s) {
+    for (auto& p : plans) if (p.first == &s) return p.second;
+    plans.emplace_back(&s, AndPlan{});
+    AndPlan& P = plans.back().second;   // (a deque: references survive the plans of nested ANDs)
+    P.ev = this;
     std::vector<const Set*> sorted, bitmaps, scans, others;
     for (auto& c : s.children) {
       switch (child_kind(*c)) {
@@ -928,20 +972,24 @@ struct DevEval {
       }
     }
     const int n_index = (int)(sorted.size() + bitmaps.size());
-    struct Counted { const uint64_t* match; const int32_t* mv_off; };   // a scan leaf; mv_off: over a multi-value column
-    struct AndChild { const uint64_t* match; std::vector<Counted> counted; const uint64_t* not_scan = nullptr; };   // counted: the scan leaves below it; not_scan: the scan under a NOT
-    std::vector<AndChild> its;
+    auto words_of = [&](const Set& c) { return c.kind == SetKind::Or ? or_words(c) : c.kind == SetKind::And ? plan_and(c).docs() : leaf_words(c); };
     auto child_of = [&](const Set& c) {
       AndChild a;
       if (c.kind == SetKind::Not) {
         const uint64_t* inner = leaf_words(*c.children[0]);
-        uint64_t* others = take_words();
-        words_op(others, inner, nullptr, 3, false);
-        a.match = others;
+        uint64_t* rest = take_words();
+        words_op(rest, inner, nullptr, 3, false);
+        a.match = rest;
         if (c.children[0]->kind == SetKind::Scan) a.not_scan = inner;
       } else if (c.kind == SetKind::Or) {
         a.match = or_words(c);
-        for (auto& l : c.children) if (l->kind == SetKind::Scan) a.counted.push_back({leaf_words(*l), l->mv_off_dev});
+        for (auto& l : c.children) {
+          if (l->kind == SetKind::Scan) a.counted.push_back({leaf_words(*l), l->mv_off_dev});
+          else if (l->kind == SetKind::And) a.inner.push_back(l.get());
+        }
+      } else if (c.kind == SetKind::And) {
+        a.match = plan_and(c).docs();
+        a.inner.push_back(&c);
       } else {
         a.match = leaf_words(c);
         if (c.kind == SetKind::Scan) a.counted.push_back({a.match, c.mv_off_dev});
@@ -953,25 +1001,31 @@ struct DevEval {
       bool first = true;
       for (auto* list : {&sorted, &bitmaps})
         for (const Set* c : *list) {
-          const uint64_t* w = c->kind == SetKind::Or ? or_words(*c) : leaf_words(*c);
+          const uint64_t* w = words_of(*c);
           words_op(docs, first ? w : docs, first ? nullptr : w, first ? 2 : 0, false);
           first = false;
         }
       for (const Set* c : scans) words_op(docs, docs, leaf_words(*c), 0, true, c->mv_off_dev);   // applyAnd: every surviving candidate is evaluated once
-      if (others.empty()) return;   // a bitmap-based iterator: draining it scans nothing
-      its.push_back({docs, {}});
-      for (const Set* c : others) its.push_back(child_of(*c));
+      P.its.push_back({docs, {}, nullptr, {}});
+      for (const Set* c : others) P.its.push_back(child_of(*c));
     } else {
-      for (auto& c : s.children) its.push_back(child_of(*c));
+      for (auto& c : s.children) P.its.push_back(child_of(*c));
     }
+    return P;
+  }
+  // AndDocIdIterator started at the docs of `active` (nullptr: drained by next())
+  void sim_and(AndPlan& P, const uint64_t* active) {
+    std::vector<AndChild>& its = P.its;
     bool any = false;
-    for (auto& a : its) any = any || !a.counted.empty() || a.not_scan;
-    if (!any) return;
+    for (auto& a : its) any = any || !a.counted.empty() || a.not_scan || !a.inner.empty();
+    if (!any) return;   // bitmap-based iterators all the way down: nothing is scanned
     FsAndProg prog{};
     prog.k = (int32_t)its.size();
+    prog.active = active;
     for (int j = 0; j < prog.k; j++) {
-      prog.match[j] = its[(size_t)j].match;
-      prog.targets[j] = its[(size_t)j].counted.empty() && !its[(size_t)j].not_scan ? nullptr : take_words();
+      const AndChild& a = its[(size_t)j];
+      prog.match[j] = a.match;
+      prog.targets[j] = a.counted.empty() && !a.not_scan && a.inner.empty() ? nullptr : take_words();
     }
     uint32_t* maps = take<uint32_t>((size_t)n_tiles);
     uint32_t* prefix = take<uint32_t>((size_t)n_tiles);
@@ -987,8 +1041,10 @@ struct DevEval {
     for (int j = 0; j < prog.k; j++) {
       for (const Counted& leaf : its[(size_t)j].counted) latch_count(prog.targets[j], leaf.match, leaf.mv_off);
       if (its[(size_t)j].not_scan) not_count(prog.targets[j], its[(size_t)j].not_scan, its[(size_t)j].match);
+      for (const Set* in : its[(size_t)j].inner) sim_and(plan_and(*in), prog.targets[j]);
     }
   }
+  void run_and(const Set& s) { sim_and(plan_and(s), nullptr); }
 
   void run_drained(const Set& s) {   // the iterator is drained by next(): every child of an OR / NOT is drained in turn
     switch (s.kind) {
@@ -1035,6 +1091,7 @@ int64_t entries_scanned_on_device(const FilterOp& root, const StatLeafWords& lea
   ev.run_drained(*set);   // dry: sizes
   if (arena.size < ev.off + 256) arena.alloc(ev.off + ev.off / 4 + 256);
   ev.dry = false;
+  ev.plans.clear();
   ev.base = arena.as<uint8_t>();
   ev.off = 0;
   ev.closed_form = 0;

@@ -9,8 +9,8 @@
 //     OrDocIdIterator (OrDocIdIterator.java:91-119: advance() forwards the target to each child whose cursor lies before it).  So the count of a
 //     leaf is a function of (its match bitmap M, the target bitmap T of the AND child it sits under): doc d is visited iff the last target <= d
 //     lies after the last match < d — a set / reset latch over the doc positions, evaluated with carries (fs_latch_*).
-//  2. Cut into tiles of docs, the AND automaton enters a tile in one of K + 1 states only: `clean` (a match was emitted at the tile's last doc
-//     but one: max_doc = first doc of the tile, nothing pending) or `child c is scanning` (its advance() was called in an earlier tile and has
+//  2. Cut into tiles of docs, the AND automaton enters a tile in one of K + 1 states only: `idle` (a match was emitted, nothing is pending: it
+//     resumes where next() / the parent's advance() starts it again) or `child c is scanning` (its advance() was called in an earlier tile and has
 //     found nothing yet; whatever it returns becomes max_doc with max_idx = c, index = 0).  Every tile is simulated from every entry state
 //     (fs_and_tile), the K + 1 -> K + 1 maps compose associatively (a device scan), and a second simulation from the tile's TRUE entry state
 //     writes the targets.
@@ -28,7 +28,7 @@
 #define FS_MAX_CHILDREN 7          // children of the AND (K + 1 entry states in 4-bit fields of one 32-bit map)
 #define FS_TILE_WORDS 8            // 512 docs per tile of the AND automaton (a lane's tile: 64 bytes per child, staged in LDS on the device)
 #define FS_LATCH_WORDS 64          // words per tile of the visited latch (one wavefront, a word per lane, on the device)
-#define FS_CLEAN 0u                // entry / exit state; c + 1: child c is scanning
+#define FS_IDLE 0u                 // entry / exit state: nothing pending, the AND resumes at the next doc it is started at; c + 1: child c is scanning
 
 #define FS_MERGED 15u              // fs_and_tile(stop_at): the simulation emitted `stop_at` — from there on every entry state runs the same course
 
@@ -48,20 +48,25 @@ FS_HD int32_t fs_next_set(WordAt word, int32_t from, int32_t end) {
 }
 
 // One tile of the AND automaton over k children from entry state `entry`, docs [from, end) RELATIVE to the tile (`from` = 0 unless the caller
-// resumes a clean state inside the tile); returns the exit state.  `io.match(child, word)`: a word of the docs the child's iterator returns;
-// with `emit`, `io.target(child, doc)` records every advance() call's target (the caller owns the tile's words).  `stop_at` >= 0: return FS_MERGED
-// when that doc is emitted.  (An AND emits every doc all its children match, whatever state it came from: behind the tile's first such doc the
-// K + 1 simulations coincide, so the exits pass runs each of them up to that doc and the common course once.)
+// resumes the idle state inside the tile); returns the exit state.  `io.match(child, word)`: a word of the docs the child's iterator returns;
+// `io.active(word)`: the docs at which the AND may be (re)started — every doc for an AND that is drained by next(); for an AND that sits under
+// an OR or another AND, the targets its parent advance()s it to (the parent only calls once its cursor lies behind the AND's last answer: the
+// first such target behind an emitted doc).  With `emit`, `io.target(child, doc)` records every advance() call's target (the caller owns the
+// tile's words).  `stop_at` >= 0: return FS_MERGED when that doc is emitted.  (An AND emits every doc all its children match, whatever state
+// it came from, unless it idles across it: behind the tile's first such doc the simulations that emitted it coincide, so the exits pass runs
+// each of them up to that doc and the common course once.)
 template <typename Io>
 FS_HD uint32_t fs_and_tile(int32_t k, Io& io, int32_t from, int32_t end, uint32_t entry, bool emit, int32_t stop_at = -1) {
-  int32_t x = from;
-  int32_t max_idx = -1, index = 0;
-  if (entry != FS_CLEAN) {
+  int32_t x, max_idx = -1, index = 0;
+  if (entry != FS_IDLE) {
     const int32_t c = (int32_t)entry - 1;
     const int32_t d = fs_next_set([&](int32_t w) { return io.match(c, w); }, from, end);
     if (d < 0) return entry;   // still scanning
     x = d;
     max_idx = c;
+  } else {
+    x = fs_next_set([&](int32_t w) { return io.active(w); }, from, end);
+    if (x < 0) return FS_IDLE;
   }
   for (;;) {
     while (index < k) {
@@ -79,10 +84,11 @@ FS_HD uint32_t fs_and_tile(int32_t k, Io& io, int32_t from, int32_t end, uint32_
       }
     }
     if (x == stop_at) return FS_MERGED;
-    x++;   // every child sits on x: emitted; next() resumes behind it
+    // every child sits on x: emitted; the AND resumes at the next doc it is started at
+    x = fs_next_set([&](int32_t w) { return io.active(w); }, x + 1, end);
+    if (x < 0) return FS_IDLE;
     max_idx = -1;
     index = 0;
-    if (x >= end) return FS_CLEAN;
   }
 }
 
@@ -100,7 +106,7 @@ FS_HD uint32_t fs_and_tile_exits(int32_t k, Io& io, int32_t end) {
   for (int32_t s = 0; s <= k; s++) {
     uint32_t r = fs_and_tile(k, io, 0, end, (uint32_t)s, false, first_common);
     if (r == FS_MERGED) {
-      if (common == FS_MERGED) common = first_common + 1 >= end ? FS_CLEAN : fs_and_tile(k, io, first_common + 1, end, FS_CLEAN, false);
+      if (common == FS_MERGED) common = fs_and_tile(k, io, first_common + 1, end, FS_IDLE, false);
       r = common;
     }
     map |= r << (4 * s);

@@ -1,6 +1,7 @@
 // Host model of the tile-parallel numEntriesScannedInFilter (pinot_amd/csrc/pg_filter_stats_tiles.h) against a direct, doc-by-doc restatement of
-// the reference's iterators (AndDocIdIterator.java:37-66, OrDocIdIterator.java:91-119, SVScanDocIdIterator.java:101-112 — advance() only, which
-// is all an AND ever calls on its children).  Random match bitmaps of every density, AND children that are scans, bitmaps or ORs of both.
+// the reference's iterators: AndDocIdIterator.java:37-66, OrDocIdIterator.java:91-119 (advance() only, which is all an AND ever calls on its
+// children), NotDocIdIterator.java:28-70 and SVScanDocIdIterator.java:76-112 (both entry points, with its batches of 256).  Random match bitmaps of
+// every density; an AND whose children are scans, bitmaps, NOTs over a scan, ORs of leaves and ANDs, and ANDs of their own.
 // Build: g++ -O2 -std=c++17 -I pinot_amd/csrc tests/filter_stats_tiles_test.cpp -o tests/_build/filter_stats_tiles_test
 #include <algorithm>
 #include <cstdio>
@@ -18,10 +19,11 @@ struct Leaf {
   bool scan;            // a scan counts what it steps over; a bitmap iterator counts nothing
   int64_t counted = 0;  // by the sequential model
 };
-struct Child {          // a child of the AND: one leaf, an OR over several, or a NOT over one scan
-  std::vector<int> leaves;
-  bool is_or;
-  bool is_not = false;
+enum { LEAF, OR, NOT, AND };
+struct Node {
+  int kind = LEAF;
+  int leaf = -1;            // LEAF; NOT: the scan below it
+  std::vector<Node> kids;   // OR: leaves and ANDs; AND: leaves, NOTs, ORs, ANDs
 };
 
 static int64_t next_set(const Bits& m, int64_t from, int64_t n) {
@@ -131,75 +133,76 @@ struct SeqNot : SeqIt {   // NotDocIdIterator.java:28-70
     return next();
   }
 };
-
-static void run_sequential(std::vector<Leaf>& leaves, const std::vector<Child>& children, int64_t n) {
+struct SeqAnd : SeqIt {   // AndDocIdIterator.java:37-66
   std::vector<std::unique_ptr<SeqIt>> its;
-  for (auto& c : children) {
-    if (c.is_not) { its.push_back(std::make_unique<SeqNot>(leaves[(size_t)c.leaves[0]], n)); continue; }
-    if (!c.is_or) { its.push_back(std::make_unique<SeqLeaf>(leaves[(size_t)c.leaves[0]], n)); continue; }
-    auto o = std::make_unique<SeqOr>();
-    for (int li : c.leaves) { o->its.push_back(std::make_unique<SeqLeaf>(leaves[(size_t)li], n)); o->next_ids.push_back(-1); }
-    its.push_back(std::move(o));
-  }
   int64_t next_doc = 0;
-  const int k = (int)its.size();
-  for (;;) {   // AndDocIdIterator#next, drained
+  int64_t next() {
     int64_t max_doc = next_doc;
     int max_idx = -1, index = 0;
-    bool eof = false;
+    const int k = (int)its.size();
     while (index < k) {
       if (index == max_idx) { index++; continue; }
       const int64_t d = its[(size_t)index]->advance(max_doc);
-      if (d < 0) { eof = true; break; }
+      if (d < 0) return -1;
       if (d == max_doc) index++;
       else { max_doc = d; max_idx = index; index = 0; }
     }
-    if (eof) break;
-    next_doc = max_doc + 1;
+    next_doc = max_doc;
+    return next_doc++;
+  }
+  int64_t advance(int64_t target) override { next_doc = target; return next(); }
+};
+static std::unique_ptr<SeqIt> seq_of(const Node& nd, std::vector<Leaf>& leaves, int64_t n) {
+  switch (nd.kind) {
+    case LEAF: return std::make_unique<SeqLeaf>(leaves[(size_t)nd.leaf], n);
+    case NOT: return std::make_unique<SeqNot>(leaves[(size_t)nd.leaf], n);
+    case OR: {
+      auto o = std::make_unique<SeqOr>();
+      for (auto& c : nd.kids) { o->its.push_back(seq_of(c, leaves, n)); o->next_ids.push_back(-1); }
+      return o;
+    }
+    default: {
+      auto a = std::make_unique<SeqAnd>();
+      for (auto& c : nd.kids) a->its.push_back(seq_of(c, leaves, n));
+      return a;
+    }
   }
 }
 
 // ---- the tile model: what the device runs, with loops where it has kernels and scans ----------------------------------------------------------
-static std::vector<int64_t> run_tiles(const std::vector<Leaf>& leaves, const std::vector<Child>& children, int64_t n) {
-  const int64_t n_words = (n + 63) / 64, n_tiles = (n_words + FS_TILE_WORDS - 1) / FS_TILE_WORDS;
-  const int k = (int)children.size();
-  std::vector<Bits> match((size_t)k, Bits((size_t)n_words + 1, 0)), targets((size_t)k, Bits((size_t)n_words + 1, 0));
-  for (int j = 0; j < k; j++) {
-    for (int li : children[(size_t)j].leaves)
-      for (int64_t w = 0; w < n_words; w++) match[(size_t)j][(size_t)w] |= leaves[(size_t)li].m[(size_t)w];
-    if (children[(size_t)j].is_not)   // the docs a NOT returns: the others, of those that exist
-      for (int64_t w = 0; w < n_words; w++)
-        match[(size_t)j][(size_t)w] = ~match[(size_t)j][(size_t)w] & (w * 64 + 64 > n ? ~0ULL >> (64 - (n - w * 64)) : ~0ULL);
+struct Tiles {
+  const std::vector<Leaf>& leaves;
+  int64_t n, n_words;
+  std::vector<int64_t> counts;
+
+  Bits match_of(const Node& nd) const {   // the docs the node's iterator returns
+    Bits out((size_t)n_words + 1, 0);
+    const uint64_t last = n & 63 ? ~0ULL >> (64 - (n & 63)) : ~0ULL;
+    if (nd.kind == LEAF || nd.kind == NOT) {
+      out = leaves[(size_t)nd.leaf].m;
+      if (nd.kind == NOT)
+        for (int64_t w = 0; w < n_words; w++) out[(size_t)w] = ~out[(size_t)w] & (w == n_words - 1 ? last : ~0ULL);
+      return out;
+    }
+    if (nd.kind == AND) std::fill(out.begin(), out.begin() + n_words, ~0ULL);
+    for (auto& c : nd.kids) {
+      const Bits m = match_of(c);
+      for (int64_t w = 0; w < n_words; w++) out[(size_t)w] = nd.kind == AND ? out[(size_t)w] & m[(size_t)w] : out[(size_t)w] | m[(size_t)w];
+    }
+    if (nd.kind == AND && n_words) out[(size_t)n_words - 1] &= last;
+    return out;
   }
-  struct Io {   // one tile: positions relative to its first word
-    std::vector<Bits>&m, &t;
-    int64_t w_lo;
-    uint64_t match(int c, int32_t w) const { return m[(size_t)c][(size_t)(w_lo + w)]; }
-    void target(int c, int32_t doc) { t[(size_t)c][(size_t)(w_lo + (doc >> 6))] |= 1ULL << (doc & 63); }
-  };
-  std::vector<uint32_t> maps((size_t)n_tiles), entry((size_t)n_tiles);
-  for (int64_t t = 0; t < n_tiles; t++) {
-    const int64_t lo = t * FS_TILE_WORDS * 64, hi = std::min<int64_t>(n, lo + FS_TILE_WORDS * 64);
-    Io io{match, targets, t * FS_TILE_WORDS};
-    maps[(size_t)t] = fs_and_tile_exits(k, io, (int32_t)(hi - lo));
-    uint32_t map = 0;   // ... and without the shortcut behind the first common doc
-    for (int s = 0; s <= k; s++) map |= fs_and_tile(k, io, 0, (int32_t)(hi - lo), (uint32_t)s, false) << (4 * s);
-    if (map != maps[(size_t)t]) { printf("exit maps differ: tile %lld %08x %08x\n", (long long)t, map, maps[(size_t)t]); exit(1); }
+  void latch(const Bits& targets, int leaf) {
+    const uint64_t* tw = targets.data();
+    const uint64_t* mw = leaves[(size_t)leaf].m.data();
+    uint32_t state = 2;
+    for (int64_t t = 0; t * FS_LATCH_WORDS < n_words; t++) {
+      const int64_t w_lo = t * FS_LATCH_WORDS, w_hi = std::min<int64_t>(n_words, w_lo + FS_LATCH_WORDS);
+      counts[(size_t)leaf] += fs_latch_count(tw, mw, w_lo, w_hi, state == 1, n);
+      state = fs_latch_then(state, fs_latch_summary(tw, mw, w_lo, w_hi));
+    }
   }
-  uint32_t run = FS_MAP_IDENTITY;
-  for (int64_t t = 0; t < n_tiles; t++) {
-    entry[(size_t)t] = run & 15u;   // the state a clean start of the segment has become
-    run = fs_map_then(run, maps[(size_t)t]);
-  }
-  for (int64_t t = 0; t < n_tiles; t++) {
-    const int64_t lo = t * FS_TILE_WORDS * 64, hi = std::min<int64_t>(n, lo + FS_TILE_WORDS * 64);
-    Io io{match, targets, t * FS_TILE_WORDS};
-    fs_and_tile(k, io, 0, (int32_t)(hi - lo), entry[(size_t)t], true);
-  }
-  std::vector<int64_t> counts(leaves.size(), 0);
-  for (int j = 0; j < k; j++) {
-    if (!children[(size_t)j].is_not) continue;
-    const int li = children[(size_t)j].leaves[0];
+  void not_scan(const Bits& targets, const Bits& others, int leaf) {
     struct Look {   // the bitmaps scanned directly (the device: two-level indexes)
       const Bits &m, &nm, &t;
       Bits r, c;
@@ -211,7 +214,7 @@ static std::vector<int64_t> run_tiles(const std::vector<Leaf>& leaves, const std
       static int64_t prev(const Bits& b, int64_t x) { for (; x >= 0; x--) if ((b[(size_t)(x >> 6)] >> (x & 63)) & 1) return x; return -1; }
       int64_t prev_target(int64_t x) const { return prev(t, x); }
       int64_t prev_reset(int64_t x) const { return prev(r, x); }
-    } look{leaves[(size_t)li].m, match[(size_t)j], targets[(size_t)j], Bits((size_t)n_words + 1, 0), Bits((size_t)n_words + 1, 0), n};
+    } look{leaves[(size_t)leaf].m, others, targets, Bits((size_t)n_words + 1, 0), Bits((size_t)n_words + 1, 0), n};
     int64_t total = 0;
     for (int64_t t = next_set(look.t, 0, n); t >= 0; t = next_set(look.t, t + 1, n)) {
       if (fs_not_is_reset(look, t)) { look.r[(size_t)(t >> 6)] |= 1ULL << (t & 63); total += fs_not_advance_cost(look, t, n); }
@@ -219,21 +222,93 @@ static std::vector<int64_t> run_tiles(const std::vector<Leaf>& leaves, const std
     }
     for (int64_t t = next_set(look.c, 0, n); t >= 0; t = next_set(look.c, t + 1, n)) total += fs_not_episode_cost(look, t, n);
     total += fs_not_ctor_cost(look, n);
-    counts[(size_t)li] = total;
+    counts[(size_t)leaf] += total;
   }
-  for (int j = 0; j < k; j++)
-    for (int li : children[(size_t)j].leaves) {
-      if (!leaves[(size_t)li].scan || children[(size_t)j].is_not) continue;
-      const uint64_t* tw = targets[(size_t)j].data();
-      const uint64_t* mw = leaves[(size_t)li].m.data();
-      uint32_t state = 2;
-      for (int64_t t = 0; t * FS_LATCH_WORDS < n_words; t++) {
-        const int64_t w_lo = t * FS_LATCH_WORDS, w_hi = std::min<int64_t>(n_words, w_lo + FS_LATCH_WORDS);
-        counts[(size_t)li] += fs_latch_count(tw, mw, w_lo, w_hi, state == 1, n);
-        state = fs_latch_then(state, fs_latch_summary(tw, mw, w_lo, w_hi));
-      }
+  // an AND started at the docs of `active` (nullptr: drained — every doc)
+  void run_and(const Node& nd, const Bits* active) {
+    const int64_t n_tiles = (n_words + FS_TILE_WORDS - 1) / FS_TILE_WORDS;
+    const int k = (int)nd.kids.size();
+    std::vector<Bits> match, targets((size_t)k, Bits((size_t)n_words + 1, 0));
+    for (auto& c : nd.kids) match.push_back(match_of(c));
+    struct Io {   // one tile: positions relative to its first word
+      std::vector<Bits>&m, &t;
+      const Bits* act;
+      int64_t w_lo;
+      uint64_t match(int c, int32_t w) const { return m[(size_t)c][(size_t)(w_lo + w)]; }
+      uint64_t active(int32_t w) const { return act ? (*act)[(size_t)(w_lo + w)] : ~0ULL; }
+      void target(int c, int32_t doc) { t[(size_t)c][(size_t)(w_lo + (doc >> 6))] |= 1ULL << (doc & 63); }
+    };
+    std::vector<uint32_t> maps((size_t)n_tiles), entry((size_t)n_tiles);
+    for (int64_t t = 0; t < n_tiles; t++) {
+      const int64_t lo = t * FS_TILE_WORDS * 64, hi = std::min<int64_t>(n, lo + FS_TILE_WORDS * 64);
+      Io io{match, targets, active, t * FS_TILE_WORDS};
+      maps[(size_t)t] = fs_and_tile_exits(k, io, (int32_t)(hi - lo));
+      uint32_t map = 0;   // ... and without the shortcut behind the first common doc
+      for (int s = 0; s <= k; s++) map |= fs_and_tile(k, io, 0, (int32_t)(hi - lo), (uint32_t)s, false) << (4 * s);
+      if (map != maps[(size_t)t]) { printf("exit maps differ: tile %lld %08x %08x\n", (long long)t, map, maps[(size_t)t]); exit(1); }
     }
-  return counts;
+    uint32_t run = FS_MAP_IDENTITY;
+    for (int64_t t = 0; t < n_tiles; t++) {
+      entry[(size_t)t] = run & 15u;   // the state an idle start of the segment has become
+      run = fs_map_then(run, maps[(size_t)t]);
+    }
+    for (int64_t t = 0; t < n_tiles; t++) {
+      const int64_t lo = t * FS_TILE_WORDS * 64, hi = std::min<int64_t>(n, lo + FS_TILE_WORDS * 64);
+      Io io{match, targets, active, t * FS_TILE_WORDS};
+      fs_and_tile(k, io, 0, (int32_t)(hi - lo), entry[(size_t)t], true);
+    }
+    for (int j = 0; j < k; j++) {
+      const Node& c = nd.kids[(size_t)j];
+      const Bits& tj = targets[(size_t)j];
+      if (c.kind == LEAF) { if (leaves[(size_t)c.leaf].scan) latch(tj, c.leaf); }
+      else if (c.kind == NOT) not_scan(tj, match[(size_t)j], c.leaf);
+      else if (c.kind == AND) run_and(c, &tj);
+      else
+        for (auto& g : c.kids) {   // an OR hands its targets on to every child
+          if (g.kind == LEAF) { if (leaves[(size_t)g.leaf].scan) latch(tj, g.leaf); }
+          else run_and(g, &tj);
+        }
+    }
+  }
+};
+
+static Node random_leaf(std::vector<Leaf>& leaves, std::mt19937_64& rng, int64_t n, bool must_scan) {
+  const int64_t n_words = (n + 63) / 64;
+  Leaf l;
+  l.scan = must_scan || rng() % 4 != 0;
+  l.m.assign((size_t)n_words + 1, 0);
+  static const double dens[] = {0.0, 0.0005, 0.01, 0.1, 0.5, 0.9, 0.999, 1.0};
+  const double p = dens[rng() % 8];
+  const bool runs = rng() % 4 == 0;   // long runs of equal bits (sorted-ish columns)
+  bool cur = false;
+  for (int64_t d = 0; d < n; d++) {
+    if (!runs || rng() % 257 == 0 || d == 0) cur = std::uniform_real_distribution<double>(0, 1)(rng) < p;
+    if (cur) l.m[(size_t)(d >> 6)] |= 1ULL << (d & 63);
+  }
+  Node nd;
+  nd.leaf = (int)leaves.size();
+  leaves.push_back(std::move(l));
+  return nd;
+}
+static Node random_and(std::vector<Leaf>& leaves, std::mt19937_64& rng, int64_t n, int depth) {
+  Node a;
+  a.kind = AND;
+  const int k = 1 + (int)(rng() % 4);
+  for (int j = 0; j < k; j++) {
+    const int what = (int)(rng() % 9);
+    if (what < 4) a.kids.push_back(random_leaf(leaves, rng, n, false));
+    else if (what < 6) { Node c = random_leaf(leaves, rng, n, true); c.kind = NOT; a.kids.push_back(c); }
+    else if (what < 8 || depth == 0) {
+      Node o;
+      o.kind = OR;
+      const int nl = 1 + (int)(rng() % 3);
+      for (int i = 0; i < nl; i++) o.kids.push_back(depth > 0 && rng() % 3 == 0 ? random_and(leaves, rng, n, depth - 1) : random_leaf(leaves, rng, n, false));
+      a.kids.push_back(o);
+    } else {
+      a.kids.push_back(random_and(leaves, rng, n, depth - 1));   // an AND directly under an AND
+    }
+  }
+  return a;
 }
 
 int main(int argc, char** argv) {
@@ -243,39 +318,20 @@ int main(int argc, char** argv) {
   for (int round = 0; round < rounds; round++) {
     static const int64_t sizes[] = {1, 63, 64, 65, 255, 256, 257, 511, 513, 2047, 2048, 2049, 4096, 10000, 70001, 200003};
     const int64_t n = sizes[rng() % (sizeof(sizes) / sizeof(sizes[0]))];
-    const int64_t n_words = (n + 63) / 64;
-    const int k = 1 + (int)(rng() % 4);
     std::vector<Leaf> leaves;
-    std::vector<Child> children;
-    for (int j = 0; j < k; j++) {
-      Child c;
-      c.is_or = rng() % 3 == 0;
-      c.is_not = !c.is_or && rng() % 3 == 0;
-      const int nl = c.is_or ? 1 + (int)(rng() % 3) : 1;
-      for (int i = 0; i < nl; i++) {
-        Leaf l;
-        l.scan = c.is_not || rng() % 4 != 0;
-        l.m.assign((size_t)n_words + 1, 0);
-        static const double dens[] = {0.0, 0.0005, 0.01, 0.1, 0.5, 0.9, 0.999, 1.0};
-        const double p = dens[rng() % 8];
-        const bool runs = rng() % 4 == 0;   // long runs of equal bits (sorted-ish columns)
-        bool cur = false;
-        for (int64_t d = 0; d < n; d++) {
-          if (!runs || rng() % 257 == 0 || d == 0) cur = std::uniform_real_distribution<double>(0, 1)(rng) < p;
-          if (cur) l.m[(size_t)(d >> 6)] |= 1ULL << (d & 63);
-        }
-        c.leaves.push_back((int)leaves.size());
-        leaves.push_back(std::move(l));
-      }
-      children.push_back(c);
+    const Node root = random_and(leaves, rng, n, 2);
+    {
+      std::unique_ptr<SeqIt> it = seq_of(root, leaves, n);
+      SeqAnd* top = static_cast<SeqAnd*>(it.get());
+      while (top->next() >= 0) {}   // DocIdSetOperator drains the iterator
     }
-    run_sequential(leaves, children, n);
-    const std::vector<int64_t> got = run_tiles(leaves, children, n);
+    Tiles tiles{leaves, n, (n + 63) / 64, std::vector<int64_t>(leaves.size(), 0)};
+    tiles.run_and(root, nullptr);
     for (size_t i = 0; i < leaves.size(); i++) {
       if (!leaves[i].scan) continue;
       checked++;
-      if (got[i] != leaves[i].counted) {
-        printf("MISMATCH round %d n %lld k %d leaf %zu: tiles %lld sequential %lld\n", round, (long long)n, k, i, (long long)got[i], (long long)leaves[i].counted);
+      if (tiles.counts[i] != leaves[i].counted) {
+        printf("MISMATCH round %d n %lld leaf %zu: tiles %lld sequential %lld\n", round, (long long)n, i, (long long)tiles.counts[i], (long long)leaves[i].counted);
         return 1;
       }
     }

@@ -3,7 +3,7 @@
 The reference's count is a property of its iterator automaton (AndDocIdIterator.java:37-66, OrDocIdIterator.java:57-119, NotDocIdIterator.java:45-70,
 SVScanDocIdIterator.java:76-112).  Three evaluations of it must agree: the oracle's (doc-at-a-time iterators over column values), the library's host
 walk over the leaves' match bitmaps (PG_FILTER_STATS_HOST=1) and the tile automaton on the device — at sizes from one doc to 10^7, on shapes with
-scans, inverted-index and sorted leaves, flat ORs under an AND, and drained ORs / NOTs around them.  CPU part: the host model of the tile algorithm
+scans, inverted-index and sorted leaves, ORs and NOTs under an AND, ANDs inside those ORs, and drained ORs / NOTs around them.  CPU part: the host model of the tile algorithm
 against a sequential restatement (tests/filter_stats_tiles_test.cpp)."""
 import os
 import subprocess
@@ -44,7 +44,7 @@ def _segment(n, seed):
     return build_segment(f"fs_{n}", data, schema, inverted_index_columns=["ci"], no_dictionary_columns=["r", "k", "b", "m"])
 
 
-# (filter, counted on the device?) — the host walk keeps compound children under a NOT or an OR that sit under an AND
+# (filter, counted on the device?) — the host walk keeps a NOT over a compound child, and an OR / NOT inside an OR, under an AND
 SHAPES = [
     ("r < 500000 AND k > 0", True),                                              # leapfrog of two scans
     ("r < 100000 AND k > 50 AND u < 300", True),                                 # ... of three
@@ -70,7 +70,11 @@ SHAPES = [
     ("NOT (ci = 2) AND r < 100000 AND NOT (k < -95)", True),                     # NOT over an index leaf (nothing to count) next to one over a scan
     ("(ci = 3 AND NOT (r < 200000)) OR (k > 90 AND NOT (u < 500))", True),       # two such ANDs drained by an OR
     ("ci = 3 AND NOT (r < 200000 OR k > 50)", False),                            # NOT over an OR under an AND: the host walk
-    ("r < 200000 AND (k > 0 OR (u < 500 AND g < 60))", False),                   # an AND inside an OR under an AND: the host walk
+    ("r < 200000 AND (k > 0 OR (u < 500 AND g < 60))", True),                    # an AND inside an OR under an AND: started at the OR's targets
+    ("ci = 3 AND (r < 200000 OR (k > 0 AND u < 500) OR (g < 60 AND b = 1))", True),              # two of them beside a scan
+    ("(r < 500000 OR (k > 0 AND NOT (u < 500))) AND ci <> 4", True),                              # ... with a NOT over a scan inside
+    ("r < 900000 AND (k > -50 OR (u < 800 AND (g < 90 OR (b = 1 AND so > 20))))", True),          # two levels down
+    ("(ci = 1 AND so < 25 AND (r < 300000 OR (k > 0 AND ci <> 3 AND u > 100))) OR g = 30", True),   # merged index children at both levels, drained by an OR
 ]
 
 
