@@ -730,6 +730,10 @@ __global__ void __launch_bounds__(kFsBlock) fs_index_groups_kernel(const uint64_
 }
 struct FsNotLook {   // the look-ups the count's formulas ask for
   FsIndex m, nm, t, r, c;
+  const int32_t* mv_off;   // the scan is over a multi-value column: the docs' first entries (it counts entries, and its next() knows no batches)
+  __device__ __forceinline__ int64_t span(int64_t a, int64_t b) const { return mv_off ? (int64_t)(mv_off[b] - mv_off[a]) : b - a; }
+  __device__ __forceinline__ bool batched() const { return mv_off == nullptr; }
+  __device__ __forceinline__ int64_t prev_non_match(int64_t x) const { return nm.prev(x); }
   __device__ __forceinline__ int64_t next_match(int64_t x) const { return m.next(x); }
   __device__ __forceinline__ int64_t next_non_match(int64_t x) const { return nm.next(x); }
   __device__ __forceinline__ int64_t prev_target(int64_t x) const { return t.prev(x); }
@@ -759,6 +763,17 @@ __global__ void __launch_bounds__(kFsBlock) fs_not_resets_kernel(const FsNotLook
     consumes[w] = look.t.words[w] & look.m.words[w];
   }
   fs_wave_add(cost, total);
+}
+// a NOT inside an OR: of the OR's targets, those OrDocIdIterator#advance hands on to the NOT (fs_not_in_or_receives)
+__global__ void __launch_bounds__(kFsBlock) fs_not_received_kernel(const FsNotLook look, int64_t n_words, uint64_t* __restrict__ received) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  uint64_t r = 0;
+  for (uint64_t bits = look.t.words[w]; bits; bits &= bits - 1) {
+    const int64_t t = w * 64 + __builtin_ctzll(bits);
+    if (fs_not_in_or_receives(look, t)) r |= 1ULL << (t & 63);
+  }
+  received[w] = r;
 }
 // ... then the batches of every episode, charged to its last target that is a match; the constructor's next() by the first lane
 __global__ void __launch_bounds__(kFsBlock) fs_not_episodes_kernel(const FsNotLook look, int64_t n_words, int64_t n_docs, unsigned long long* total) {
@@ -830,13 +845,14 @@ struct DevEval {
           if (c->kind == SetKind::Scan) n_other++;
           else if (c->kind == SetKind::Sorted) n_sorted++;
           else if (c->kind == SetKind::And) { const Kind k = child_kind(*c); if (k == Kind::Unfit) return Kind::Unfit; n_other += k == Kind::Other; }
-          else if (c->kind != SetKind::Bitmap) return Kind::Unfit;   // an OR or a NOT inside an OR under an AND: the host walk
+          else if (c->kind == SetKind::Not) { if (child_kind(*c) == Kind::Unfit) return Kind::Unfit; n_other++; }   // (the NOT receives the OR's targets its cursor lies before)
+          else if (c->kind != SetKind::Bitmap) return Kind::Unfit;   // an OR inside an OR
         }
         return n_sorted > 1 && n_other == 0 ? Kind::Bitmap : Kind::Other;   // OrDocIdSet#iterator merges index-based children only beside >= 2 sorted ones
       }
       case SetKind::Not: {   // NotDocIdIterator over one leaf (a compound child draws on next() and advance() of its own children: the host walk)
         const Set& c = *s.children[0];
-        if (c.kind == SetKind::Scan) return c.mv_off ? Kind::Unfit : Kind::Other;   // (MVScanDocIdIterator#next steps doc by doc, without batches: the host walk)
+        if (c.kind == SetKind::Scan) return Kind::Other;
         return c.kind == SetKind::Bitmap || c.kind == SetKind::Sorted ? Kind::Other : Kind::Unfit;
       }
       default: return Kind::Unfit;   // Empty / MatchAll under an AND
@@ -877,11 +893,19 @@ struct DevEval {
     if (dry) return;
     hipLaunchKernelGGL(fs_words_kernel, grid_for(n_words), dim3(kFsBlock), 0, stream, dst, a, b ? b : a, n_words, n_docs, op, mv_off, count_a ? total : nullptr);
   }
-  const uint64_t* or_words(const Set& s) {   // the docs an OR's iterator returns
+  const uint64_t* or_words(const Set& s, std::vector<std::pair<const Set*, const uint64_t*>>* rests = nullptr) {   // the docs an OR's iterator returns
     uint64_t* acc = take_words();
     bool first = true;
     for (auto& c : s.children) {
-      const uint64_t* w = c->kind == SetKind::And ? plan_and(*c).docs() : leaf_words(*c);
+      const uint64_t* w;
+      if (c->kind == SetKind::Not) {
+        uint64_t* rest = take_words();
+        words_op(rest, leaf_words(*c->children[0]), nullptr, 3, false);
+        if (rests) rests->push_back({c.get(), rest});
+        w = rest;
+      } else {
+        w = c->kind == SetKind::And ? plan_and(*c).docs() : leaf_words(*c);
+      }
       words_op(acc, first ? w : acc, first ? nullptr : w, first ? 2 : 1, false);
       first = false;
     }
@@ -920,10 +944,11 @@ struct DevEval {
     return FsIndex{words, first_scan, last_scan, n_docs, n_words, n_groups};
   }
   // the scan under a NOT: `targets` of the NOT, the scan's matches, the docs the NOT returns (the others)
-  void not_count(const uint64_t* targets, const uint64_t* match, const uint64_t* others) {
+  void not_count(const uint64_t* targets, const uint64_t* match, const uint64_t* others, const int32_t* mv_off) {
     uint64_t* resets = take_words();
     uint64_t* consumes = take_words();
     FsNotLook look{};
+    look.mv_off = mv_off;
     look.m = index_of(match);
     look.nm = index_of(others);
     look.t = index_of(targets);
@@ -940,6 +965,9 @@ struct DevEval {
     const uint64_t* match;
     std::vector<Counted> counted;            // the scan leaves that receive this child's targets
     const uint64_t* not_scan = nullptr;      // the scan under a NOT
+    const int32_t* not_mv_off = nullptr;     // ... over a multi-value column
+    struct NotInOr { const uint64_t* scan; const uint64_t* rest; const int32_t* mv_off; };
+    std::vector<NotInOr> nots;               // the scans under NOTs inside the OR this child is
     std::vector<const Set*> inner;           // the ANDs started at this child's targets: the child itself, or children of the OR it is
   };
   struct AndPlan {
@@ -980,13 +1008,16 @@ struct DevEval {
         uint64_t* rest = take_words();
         words_op(rest, inner, nullptr, 3, false);
         a.match = rest;
-        if (c.children[0]->kind == SetKind::Scan) a.not_scan = inner;
+        if (c.children[0]->kind == SetKind::Scan) { a.not_scan = inner; a.not_mv_off = c.children[0]->mv_off_dev; }
       } else if (c.kind == SetKind::Or) {
-        a.match = or_words(c);
+        std::vector<std::pair<const Set*, const uint64_t*>> rests;   // the docs the NOTs inside it return
+        a.match = or_words(c, &rests);
         for (auto& l : c.children) {
           if (l->kind == SetKind::Scan) a.counted.push_back({leaf_words(*l), l->mv_off_dev});
           else if (l->kind == SetKind::And) a.inner.push_back(l.get());
         }
+        for (auto& r : rests)
+          if (r.first->children[0]->kind == SetKind::Scan) a.nots.push_back({leaf_words(*r.first->children[0]), r.second, r.first->children[0]->mv_off_dev});
       } else if (c.kind == SetKind::And) {
         a.match = plan_and(c).docs();
         a.inner.push_back(&c);
@@ -1017,7 +1048,7 @@ struct DevEval {
   void sim_and(AndPlan& P, const uint64_t* active) {
     std::vector<AndChild>& its = P.its;
     bool any = false;
-    for (auto& a : its) any = any || !a.counted.empty() || a.not_scan || !a.inner.empty();
+    for (auto& a : its) any = any || !a.counted.empty() || a.not_scan || !a.inner.empty() || !a.nots.empty();
     if (!any) return;   // bitmap-based iterators all the way down: nothing is scanned
     FsAndProg prog{};
     prog.k = (int32_t)its.size();
@@ -1025,7 +1056,7 @@ struct DevEval {
     for (int j = 0; j < prog.k; j++) {
       const AndChild& a = its[(size_t)j];
       prog.match[j] = a.match;
-      prog.targets[j] = a.counted.empty() && !a.not_scan && a.inner.empty() ? nullptr : take_words();
+      prog.targets[j] = a.counted.empty() && !a.not_scan && a.inner.empty() && a.nots.empty() ? nullptr : take_words();
     }
     uint32_t* maps = take<uint32_t>((size_t)n_tiles);
     uint32_t* prefix = take<uint32_t>((size_t)n_tiles);
@@ -1040,7 +1071,15 @@ struct DevEval {
     }
     for (int j = 0; j < prog.k; j++) {
       for (const Counted& leaf : its[(size_t)j].counted) latch_count(prog.targets[j], leaf.match, leaf.mv_off);
-      if (its[(size_t)j].not_scan) not_count(prog.targets[j], its[(size_t)j].not_scan, its[(size_t)j].match);
+      if (its[(size_t)j].not_scan) not_count(prog.targets[j], its[(size_t)j].not_scan, its[(size_t)j].match, its[(size_t)j].not_mv_off);
+      for (auto& nt : its[(size_t)j].nots) {   // a NOT inside the OR: the targets that reach it, then as under the AND itself
+        uint64_t* received = take_words();
+        FsNotLook look{};
+        look.nm = index_of(nt.rest);
+        look.t = index_of(prog.targets[j]);
+        if (!dry) hipLaunchKernelGGL(fs_not_received_kernel, grid_for(n_words), dim3(kFsBlock), 0, stream, look, n_words, received);
+        not_count(received, nt.scan, nt.rest, nt.mv_off);
+      }
       for (const Set* in : its[(size_t)j].inner) sim_and(plan_and(*in), prog.targets[j]);
     }
   }

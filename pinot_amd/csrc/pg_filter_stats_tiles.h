@@ -191,15 +191,19 @@ FS_HD bool fs_not_is_reset(L& l, int64_t t) {   // is the scan advance()d when t
   const int64_t nm = l.next_match(from);
   return nm >= 0 && t > nm;
 }
+// `l.span(a, b)`: what a scan counts for evaluating the docs [a, b) — b - a, or their entries over a multi-value column;
+// `l.batched()`: does next() scan whole batches (SVScanDocIdIterator) or doc by doc up to the match (MVScanDocIdIterator.java:65-117)
 template <typename L>
 FS_HD int64_t fs_not_advance_cost(L& l, int64_t t, int64_t n_docs) {
   const int64_t p = l.next_match(t);
-  return p < 0 ? n_docs - t : p - t + 1;
+  return l.span(t, p < 0 ? n_docs : p + 1);
 }
-FS_HD int64_t fs_not_batches(int64_t b0, int64_t q, int64_t n_docs) {   // docs next() scans from b0 until it has handed out match q (-1: until EOF)
-  if (q < 0) return n_docs - b0;
+template <typename L>
+FS_HD int64_t fs_not_batches(L& l, int64_t b0, int64_t q, int64_t n_docs) {   // what next() counts from b0 until it has handed out match q (-1: until EOF)
+  if (q < 0) return l.span(b0, n_docs);
+  if (!l.batched()) return l.span(b0, q + 1);
   const int64_t end = b0 + FS_SCAN_BATCH * ((q - b0) / FS_SCAN_BATCH + 1);
-  return (end < n_docs ? end : n_docs) - b0;
+  return l.span(b0, end < n_docs ? end : n_docs);
 }
 // `t`: a target that is a match (in C): the batches of its episode, if it is the episode's last such target (else 0)
 template <typename L>
@@ -209,12 +213,21 @@ FS_HD int64_t fs_not_episode_cost(L& l, int64_t t, int64_t n_docs) {
   const int64_t t_e = l.prev_reset(t);
   const int64_t b0 = t_e < 0 ? 0 : l.next_match(t_e) + 1;
   const int64_t run_end = l.next_non_match(t);
-  return fs_not_batches(b0, run_end < 0 ? -1 : l.next_match(run_end + 1), n_docs);
+  return fs_not_batches(l, b0, run_end < 0 ? -1 : l.next_match(run_end + 1), n_docs);
 }
 // the constructor's next() when no target of its episode is a match
 template <typename L>
 FS_HD int64_t fs_not_ctor_cost(L& l, int64_t n_docs) {
   const int64_t c_first = l.next_consume(0), r_first = l.next_reset(0);
   if (c_first >= 0 && !(r_first >= 0 && r_first <= c_first)) return 0;   // counted with that target's episode (B0 = 0)
-  return fs_not_batches(0, l.next_match(0), n_docs);
+  return fs_not_batches(l, 0, l.next_match(0), n_docs);
+}
+
+// A NOT inside an OR (under an AND): OrDocIdIterator#advance forwards a target only to a child whose cursor lies before it, and a NOT's cursor is
+// the doc it returned last — the first non-match at or behind its last target.  Of the OR's targets inside one run of the scan's matches (and on
+// the non-match that ends it) only the first reaches the NOT.
+template <typename L>
+FS_HD bool fs_not_in_or_receives(L& l, int64_t t) {
+  if (t == 0) return true;
+  return !(l.prev_target(t - 1) > l.prev_non_match(t - 1));
 }

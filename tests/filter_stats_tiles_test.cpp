@@ -23,7 +23,7 @@ enum { LEAF, OR, NOT, AND };
 struct Node {
   int kind = LEAF;
   int leaf = -1;            // LEAF; NOT: the scan below it
-  std::vector<Node> kids;   // OR: leaves and ANDs; AND: leaves, NOTs, ORs, ANDs
+  std::vector<Node> kids;   // OR: leaves, NOTs and ANDs; AND: leaves, NOTs, ORs, ANDs
 };
 
 static int64_t next_set(const Bits& m, int64_t from, int64_t n) {
@@ -202,6 +202,19 @@ struct Tiles {
       state = fs_latch_then(state, fs_latch_summary(tw, mw, w_lo, w_hi));
     }
   }
+  // a NOT inside an OR: the OR's targets that reach it
+  void not_scan_in_or(const Bits& targets, const Bits& others, int leaf) {
+    struct Look {
+      const Bits &nm, &t;
+      static int64_t prev(const Bits& b, int64_t x) { for (; x >= 0; x--) if ((b[(size_t)(x >> 6)] >> (x & 63)) & 1) return x; return -1; }
+      int64_t prev_target(int64_t x) const { return prev(t, x); }
+      int64_t prev_non_match(int64_t x) const { return prev(nm, x); }
+    } look{others, targets};
+    Bits received((size_t)n_words + 1, 0);
+    for (int64_t t = next_set(targets, 0, n); t >= 0; t = next_set(targets, t + 1, n))
+      if (fs_not_in_or_receives(look, t)) received[(size_t)(t >> 6)] |= 1ULL << (t & 63);
+    not_scan(received, others, leaf);
+  }
   void not_scan(const Bits& targets, const Bits& others, int leaf) {
     struct Look {   // the bitmaps scanned directly (the device: two-level indexes)
       const Bits &m, &nm, &t;
@@ -214,6 +227,9 @@ struct Tiles {
       static int64_t prev(const Bits& b, int64_t x) { for (; x >= 0; x--) if ((b[(size_t)(x >> 6)] >> (x & 63)) & 1) return x; return -1; }
       int64_t prev_target(int64_t x) const { return prev(t, x); }
       int64_t prev_reset(int64_t x) const { return prev(r, x); }
+      int64_t prev_non_match(int64_t x) const { return prev(nm, x); }
+      int64_t span(int64_t a, int64_t b) const { return b - a; }
+      bool batched() const { return true; }
     } look{leaves[(size_t)leaf].m, others, targets, Bits((size_t)n_words + 1, 0), Bits((size_t)n_words + 1, 0), n};
     int64_t total = 0;
     for (int64_t t = next_set(look.t, 0, n); t >= 0; t = next_set(look.t, t + 1, n)) {
@@ -266,6 +282,7 @@ struct Tiles {
       else
         for (auto& g : c.kids) {   // an OR hands its targets on to every child
           if (g.kind == LEAF) { if (leaves[(size_t)g.leaf].scan) latch(tj, g.leaf); }
+          else if (g.kind == NOT) not_scan_in_or(tj, match_of(g), g.leaf);
           else run_and(g, &tj);
         }
     }
@@ -302,7 +319,12 @@ static Node random_and(std::vector<Leaf>& leaves, std::mt19937_64& rng, int64_t 
       Node o;
       o.kind = OR;
       const int nl = 1 + (int)(rng() % 3);
-      for (int i = 0; i < nl; i++) o.kids.push_back(depth > 0 && rng() % 3 == 0 ? random_and(leaves, rng, n, depth - 1) : random_leaf(leaves, rng, n, false));
+      for (int i = 0; i < nl; i++) {
+        const int pick = (int)(rng() % 6);
+        if (pick < 2 && depth > 0) o.kids.push_back(random_and(leaves, rng, n, depth - 1));
+        else if (pick == 2) { Node c = random_leaf(leaves, rng, n, true); c.kind = NOT; o.kids.push_back(c); }
+        else o.kids.push_back(random_leaf(leaves, rng, n, false));
+      }
       a.kids.push_back(o);
     } else {
       a.kids.push_back(random_and(leaves, rng, n, depth - 1));   // an AND directly under an AND
