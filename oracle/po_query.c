@@ -1165,7 +1165,7 @@ static void extract_agg(po_agg_result* r, agg_state* a, int32_t n_groups, const 
  * The reference keeps a heap of `size` records; which records TIED with the last one kept survive depends on the heap — here a stable
  * sort decides (tests put a unique value at the cut).
  * ===================================================================================================================== */
-typedef struct order_value { int type; int64_t l; double d; const uint8_t* b; int32_t blen; } order_value;   /* type 0 long / int, 1 double, 2 BYTES, 3 STRING */
+typedef struct order_value { int type; int64_t l; double d; const uint8_t* b; int32_t blen; int is_null; } order_value;   /* type 0 long / int, 1 double, 2 BYTES, 3 STRING */
 /* String.compareTo (TableResizer's comparators on STRING keys) orders UTF-16 code units; UTF-8 byte order differs only where a supplementary
  * character (lead byte F0..F4: surrogates D800..DFFF) meets U+E000..U+FFFF (lead byte EE / EF), which sort behind it in UTF-16 */
 static int utf16_unit_order(const uint8_t* a, int32_t alen, const uint8_t* b, int32_t blen) {
@@ -1177,7 +1177,7 @@ static int utf16_unit_order(const uint8_t* a, int32_t alen, const uint8_t* b, in
   }
   return alen < blen ? -1 : (alen > blen ? 1 : 0);
 }
-typedef struct order_ctx { const order_value* v; int n_ob; const int* asc; } order_ctx;
+typedef struct order_ctx { const order_value* v; int n_ob; const int* asc; const int* nulls_last; } order_ctx;   /* nulls_last: NULL without null handling */
 static int double_compare_java(double a, double b) {   /* Double.compare: -0.0 < 0.0, NaN above everything and equal to itself */
   if (a < b) return -1;
   if (a > b) return 1;
@@ -1194,6 +1194,11 @@ static int order_cmp(const void* pa, const void* pb, void* ctxp) {
     const order_value* a = &c->v[(size_t)ia * (size_t)c->n_ob + (size_t)k];
     const order_value* b = &c->v[(size_t)ib * (size_t)c->n_ob + (size_t)k];
     int r;
+    if (c->nulls_last && (a->is_null || b->is_null)) {   /* TableResizer.java:98-116: nullComparisonResults[i] = isNullsLast ? -1 : 1, whatever the direction */
+      if (a->is_null && b->is_null) continue;
+      const int ncr = c->nulls_last[k] ? -1 : 1;
+      return a->is_null ? -ncr : ncr;
+    }
     if (a->type == 0) r = a->l < b->l ? -1 : (a->l > b->l ? 1 : 0);
     else if (a->type == 1) r = double_compare_java(a->d, b->d);
     else if (a->type == 3) r = utf16_unit_order(a->b, a->blen, b->b, b->blen);
@@ -1289,7 +1294,6 @@ static int null_handling_refused(po_segment* seg, const pg_query* q) {
 /* the product library leaves these to the Java plan; the oracle refuses them alike so that the two sides answer the same queries */
 static int trim_refused(const pg_query* q) {
   if (!(q->n_group_by > 0 && q->n_order_by > 0 && q->order_by && q->min_segment_group_trim_size > 0)) return 0;
-  if (q->flags & PG_QUERY_FLAG_NULL_HANDLING) { po_set_error("segment-level group trim under enableNullHandling"); return 1; }
   for (int32_t i = 0; i < q->n_order_by; i++)
     if (q->order_by[i].kind == PG_ORDER_BY_AGGREGATION && q->order_by[i].index >= 0 && q->order_by[i].index < q->n_aggregations) {
       const int f = sv_function_of(q->aggregations[q->order_by[i].index].function);
@@ -1636,16 +1640,22 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
       const int n_ob = q->n_order_by;
       order_value* vals = (order_value*)po_xcalloc((size_t)n_groups * (size_t)n_ob + 1, sizeof(order_value));
       int* asc = (int*)po_xcalloc((size_t)n_ob + 1, sizeof(int));
+      int* nulls_last = (int*)po_xcalloc((size_t)n_ob + 1, sizeof(int));
+      const int nh_trim = nh && res->stats.star_tree_index < 0;   /* null order-by values: a null group key, SUM / MIN / MAX / AVG / MINMAXRANGE over no value */
       for (int k = 0; k < n_ob; k++) {
         const pg_order_by* ob = &q->order_by[k];
         asc[k] = ob->ascending != 0;
+        nulls_last[k] = ob->nulls_last != 0;
         if (ob->kind == PG_ORDER_BY_AGGREGATION) {
-          if (ob->index < 0 || ob->index >= n_aggs) { free(vals); free(asc); free(gid_of); po_set_error("ORDER BY aggregation %d of %d", ob->index, n_aggs); return PG_ERR_INVALID_ARGUMENT; }
+          if (ob->index < 0 || ob->index >= n_aggs) { free(vals); free(asc); free(nulls_last); free(gid_of); po_set_error("ORDER BY aggregation %d of %d", ob->index, n_aggs); return PG_ERR_INVALID_ARGUMENT; }
           agg_ensure_capacity(&aggs[ob->index], (gkg.holder == HOLDER_ARRAY ? gkg.global_upper_bound : n_groups) + 1);
           for (int32_t i = 0; i < n_groups; i++) vals[(size_t)i * (size_t)n_ob + (size_t)k] = agg_final_value(&aggs[ob->index], gid_of[i]);
+          const int fo = sv_function_of(aggs[ob->index].function);
+          if (nh_trim && !mv_group_by && (fo == PG_AGG_SUM || fo == PG_AGG_MIN || fo == PG_AGG_MAX || fo == PG_AGG_AVG || fo == PG_AGG_MINMAXRANGE))
+            for (int32_t i = 0; i < n_groups; i++) vals[(size_t)i * (size_t)n_ob + (size_t)k].is_null = !aggs[ob->index].nn[gid_of[i]];
           continue;
         }
-        if (ob->index < 0 || ob->index >= n_gb) { free(vals); free(asc); free(gid_of); po_set_error("ORDER BY group-by expression %d of %d", ob->index, n_gb); return PG_ERR_INVALID_ARGUMENT; }
+        if (ob->index < 0 || ob->index >= n_gb) { free(vals); free(asc); free(nulls_last); free(gid_of); po_set_error("ORDER BY group-by expression %d of %d", ob->index, n_gb); return PG_ERR_INVALID_ARGUMENT; }
         const int j = ob->index;
         const po_column* c = gcols[j];
         for (int32_t i = 0; i < n_groups; i++) {
@@ -1654,6 +1664,8 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
           if (gkg.holder == HOLDER_RAW_VALUES) { v->type = 0; v->l = gkg.raw_key_of_group[g]; continue; }
           if (gkg.holder == HOLDER_TUPLES) {
             const int64_t t = gkg.tuples[(size_t)g * (size_t)gkg.tuple_w + (size_t)j];
+            if (gnull[j] && t == c->cardinality) v->is_null = 1;   /* the id one past the dictionary */
+            if (rnull[j] && gkg.tuple_w > n_gb && ((gkg.tuples[(size_t)g * (size_t)gkg.tuple_w + (size_t)n_gb] >> j) & 1)) v->is_null = 1;   /* the mask slot */
             if (c->has_dictionary || c->data_type <= PG_TYPE_LONG) { v->type = 0; v->l = t; }   /* dictIds order as the values do (sorted dictionaries) */
             else if (c->data_type == PG_TYPE_FLOAT) { uint32_t b = (uint32_t)t; float f; memcpy(&f, &b, 4); v->type = 1; v->d = (double)f; }
             else if (c->data_type == PG_TYPE_DOUBLE) { v->type = 1; memcpy(&v->d, &t, 8); }
@@ -1664,11 +1676,12 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
           for (int jj = 0; jj < j; jj++) raw /= gkg.cardinalities[jj];
           v->type = 0;
           v->l = raw % gkg.cardinalities[j];
+          if (gnull[j] && v->l == c->cardinality) v->is_null = 1;
         }
       }
       int32_t* order = (int32_t*)po_xcalloc((size_t)n_groups + 1, 4);
       for (int32_t i = 0; i < n_groups; i++) order[i] = i;
-      order_ctx octx = {vals, n_ob, asc};
+      order_ctx octx = {vals, n_ob, asc, nh_trim ? nulls_last : NULL};
       qsort_r(order, (size_t)n_groups, 4, order_cmp, &octx);
       /* the survivors in group-id order again (the order of the result's rows carries no meaning) */
       uint8_t* keep = (uint8_t*)po_xcalloc((size_t)n_groups + 1, 1);
@@ -1676,7 +1689,7 @@ int32_t po_query_exec(void* segp, const pg_query* q, void** out) {
       int32_t k2 = 0;
       for (int32_t i = 0; i < n_groups; i++) if (keep[i]) gid_of[k2++] = gid_of[i];
       n_groups = k2;
-      free(keep); free(order); free(vals); free(asc);
+      free(keep); free(order); free(vals); free(asc); free(nulls_last);
     }
   }
   res->num_groups = n_groups;

@@ -2094,6 +2094,19 @@ static void hll_small_range_table(int log2m, std::vector<long long>& t, double& 
   t[0] = INT64_MAX;   // Math.round(+Infinity) = Long.MAX_VALUE (cannot occur: estimate <= 2.5 m implies zero registers exist)
 }
 
+// HyperLogLog#cardinality of one register row (host; the order-by value of a DISTINCTCOUNTHLL state)
+int64_t hll_cardinality(const uint8_t* regs, int log2m) {
+  const int m = 1 << log2m;
+  std::vector<long long> small;
+  double alpha_mm = 0;
+  hll_small_range_table(log2m, small, alpha_mm);
+  double register_sum = 0;
+  int zeros = 0;
+  for (int j = 0; j < m; j++) { register_sum += 1.0 / (double)(1ULL << regs[j]); zeros += regs[j] == 0; }
+  const double estimate = alpha_mm * (1 / register_sum);
+  return estimate <= (5.0 / 2.0) * m ? (int64_t)small[(size_t)zeros] : (int64_t)std::floor(estimate + 0.5);
+}
+
 static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_by, int32_t n_aggregations, HostTable& H) {
   const PgQueryPlan& D = P.dev;
   const bool hashed = H.hashed;
@@ -2204,16 +2217,7 @@ static void assemble_result(Result& res, const CompiledPlan& P, int32_t n_group_
       for (int32_t k = 0; k < A.stride; k++) n += __builtin_popcount(w[k]);
       return n;
     }
-    const uint8_t* regs = region + (size_t)g * A.stride;
-    const int m = 1 << ao.log2m;
-    std::vector<long long> small;
-    double alpha_mm = 0;
-    hll_small_range_table(ao.log2m, small, alpha_mm);
-    double register_sum = 0;
-    int zeros = 0;
-    for (int j = 0; j < m; j++) { register_sum += 1.0 / (double)(1ULL << regs[j]); zeros += regs[j] == 0; }
-    const double estimate = alpha_mm * (1 / register_sum);
-    return estimate <= (5.0 / 2.0) * m ? (int64_t)small[(size_t)zeros] : (int64_t)std::floor(estimate + 0.5);
+    return hll_cardinality(region + (size_t)g * A.stride, ao.log2m);
   };
   // ---- segment-level group trim (GroupByOperator.java:120-133 -> TableResizer#trimInSegmentResults :327-351): more groups than trimSize and
   //      an ORDER BY: keep the trimSize groups that sort first.  Order-by values as the extractors of TableResizer.java:406-445 give them:

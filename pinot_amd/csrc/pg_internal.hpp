@@ -436,6 +436,7 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q, const Can
 constexpr int32_t kQueryFlagNullPartition = 0x40000000;
 std::unique_ptr<Result> execute_query_plain(Segment& seg, const pg_query& q, const CancelToken* cancel);   // ... the executor proper (pg_exec.hip)
 void fill_result_schema(Segment& seg, const pg_query& q, Result& r);
+int64_t hll_cardinality(const uint8_t* regs, int log2m);   // HyperLogLog#cardinality of one register row (pg_exec.hip)
 void result_merge(Result& dst, Result& src);
 std::vector<uint8_t> result_data_table_v4(const Result& r);   // pg_datatable.cpp
 void check_null_handling(Segment& seg, const pg_query& q);     // pg_nullaware.cpp: what PG_QUERY_FLAG_NULL_HANDLING leaves to the Java plan

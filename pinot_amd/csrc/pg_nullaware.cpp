@@ -13,6 +13,8 @@
 //     IS NOT NULL; their group lists are disjoint and are concatenated, the keys of S flagged NULL.
 // The filter itself is three-valued inside the planner (pg_plan.cpp, nh_trues / nh_falses).  The CPU oracle restates the same semantics doc
 // at a time (oracle/po_query.c), which is what the parity tests compare this composition with.
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <mutex>
@@ -307,6 +309,153 @@ void append_groups(Result& out, const Result& part, const pg_query& q, const std
   out.num_groups = before + n;
 }
 
+// ---- segment-level group trim over a joined result (GroupByOperator.java:120-133 -> TableResizer#trimInSegmentResults :327-351 with the
+//      null-aware comparator of TableResizer.java:98-116: a null order-by value sorts by isNullsLast, whatever the expression's direction).
+//      The parts ran untrimmed (which groups survive is decided over ALL of them); order-by values as pg_exec.hip's trim extracts them: a group
+//      key's value (dictIds of sorted dictionaries order as the values do), an aggregation's final result.
+struct OrderValue { int type = 0; int64_t l = 0; double d = 0; const uint8_t* b = nullptr; int64_t blen = 0; bool is_null = false; };   // 0 long, 1 double, 2 BYTES, 3 STRING
+int double_compare(double a, double b) {   // Double.compare
+  if (a < b) return -1;
+  if (a > b) return 1;
+  int64_t x, y;
+  memcpy(&x, &a, 8); memcpy(&y, &b, 8);
+  if (a != a) x = INT64_MAX;
+  if (b != b) y = INT64_MAX;
+  return x == y ? 0 : (x < y ? -1 : 1);
+}
+int utf16_unit_order(const uint8_t* a, int64_t alen, const uint8_t* b, int64_t blen) {   // String.compareTo over UTF-8 bytes (see pg_exec.hip)
+  const int64_t m = std::min(alen, blen);
+  for (int64_t i = 0; i < m; i++) {
+    if (a[i] == b[i]) continue;
+    const int x = a[i] == 0xEE || a[i] == 0xEF ? a[i] + 0x10 : a[i], y = b[i] == 0xEE || b[i] == 0xEF ? b[i] + 0x10 : b[i];
+    return x < y ? -1 : 1;
+  }
+  return alen < blen ? -1 : (alen > blen ? 1 : 0);
+}
+void trim_joined(Segment& seg, const pg_query& q, Result& r) {
+  const int64_t by_limit = (int64_t)std::max(q.limit, 0) * 5;   // GroupByUtils.getTableCapacity
+  const int32_t trim_size = by_limit > INT32_MAX ? INT32_MAX : std::max((int32_t)by_limit, q.min_segment_group_trim_size);
+  const size_t n = (size_t)r.num_groups, n_ob = (size_t)q.n_order_by;
+  for (size_t k = 0; k < n_ob; k++) {
+    const pg_order_by& ob = q.order_by[k];
+    if (ob.kind == PG_ORDER_BY_GROUP_KEY) { if (ob.index < 0 || ob.index >= q.n_group_by) fail(PG_ERR_INVALID_ARGUMENT, "ORDER BY group-by expression %d of %d", ob.index, q.n_group_by); }
+    else if (ob.kind == PG_ORDER_BY_AGGREGATION) { if (ob.index < 0 || ob.index >= q.n_aggregations) fail(PG_ERR_INVALID_ARGUMENT, "ORDER BY aggregation %d of %d", ob.index, q.n_aggregations); }
+    else fail(PG_ERR_INVALID_ARGUMENT, "ORDER BY expression kind %d", ob.kind);
+  }
+  if ((int64_t)n <= (int64_t)trim_size) return;
+  std::vector<OrderValue> vals(n * n_ob);
+  for (size_t k = 0; k < n_ob; k++) {
+    const pg_order_by& ob = q.order_by[k];
+    if (ob.kind == PG_ORDER_BY_AGGREGATION) {
+      const AggResult& a = r.aggs[(size_t)ob.index];
+      const std::vector<uint8_t>& nulls = r.agg_nulls[(size_t)ob.index];
+      for (size_t i = 0; i < n; i++) {
+        OrderValue& v = vals[i * n_ob + k];
+        v.is_null = !nulls.empty() && nulls[i];
+        switch (a.kind) {
+          case PG_RESULT_LONG: v.type = 0; v.l = a.l[0][i]; break;
+          case PG_RESULT_DOUBLE: v.type = 1; v.d = a.d[0][i]; break;
+          case PG_RESULT_AVG_PAIR: v.type = 1; v.d = a.l[0][i] == 0 ? -INFINITY : a.d[0][i] / (double)a.l[0][i]; break;
+          case PG_RESULT_MINMAX_PAIR: v.type = 1; v.d = a.d[1][i] - a.d[0][i]; break;
+          case PG_RESULT_DICTID_SET: v.type = 0; v.l = a.set_sizes[i]; break;
+          case PG_RESULT_HLL: v.type = 0; v.l = hll_cardinality(hll_row(a, (int32_t)i, (size_t)1 << a.log2m), a.log2m); break;
+          default: fail(PG_ERR_UNSUPPORTED, "segment-level group trim under enableNullHandling ordered by a result of kind %d", a.kind);
+        }
+      }
+      continue;
+    }
+    const size_t j = (size_t)ob.index;
+    const std::vector<uint8_t>& nulls = r.key_nulls[j];
+    const int32_t t = r.group_key_type[j];
+    int32_t data_type = PG_TYPE_STRING;
+    if (t == PG_GROUP_KEY_BYTES_VALUES) {
+      std::lock_guard<std::mutex> g(seg.mu);
+      Column* c = seg.find(q.group_by_columns[j]);
+      if (c) data_type = c->data_type;
+    }
+    for (size_t i = 0; i < n; i++) {
+      OrderValue& v = vals[i * n_ob + k];
+      v.is_null = !nulls.empty() && nulls[i];
+      if (t == PG_GROUP_KEY_DICT_IDS) v.l = r.group_dict_ids[j][i];
+      else if (t == PG_GROUP_KEY_LONG_VALUES) v.l = r.group_values[j][i];
+      else if (t == PG_GROUP_KEY_DOUBLE_VALUES) { v.type = 1; memcpy(&v.d, &r.group_values[j][i], 8); }
+      else {
+        v.type = data_type == PG_TYPE_STRING ? 3 : 2;
+        v.b = r.group_bytes[j].data() + r.group_bytes_off[j][i];
+        v.blen = r.group_bytes_off[j][i + 1] - r.group_bytes_off[j][i];
+      }
+    }
+  }
+  std::vector<int32_t> order(n);
+  for (size_t i = 0; i < n; i++) order[i] = (int32_t)i;
+  auto before = [&](int32_t ia, int32_t ib) {
+    for (size_t k = 0; k < n_ob; k++) {
+      const OrderValue& a = vals[(size_t)ia * n_ob + k];
+      const OrderValue& b = vals[(size_t)ib * n_ob + k];
+      if (a.is_null || b.is_null) {
+        if (a.is_null && b.is_null) continue;
+        return a.is_null ? !q.order_by[k].nulls_last : (bool)q.order_by[k].nulls_last;
+      }
+      int c;
+      if (a.type == 0) c = a.l < b.l ? -1 : (a.l > b.l ? 1 : 0);
+      else if (a.type == 1) c = double_compare(a.d, b.d);
+      else if (a.type == 3) c = utf16_unit_order(a.b, a.blen, b.b, b.blen);
+      else {
+        const int64_t m = std::min(a.blen, b.blen);
+        c = m ? memcmp(a.b, b.b, (size_t)m) : 0;
+        if (c == 0) c = a.blen < b.blen ? -1 : (a.blen > b.blen ? 1 : 0);
+      }
+      if (c != 0) return q.order_by[k].ascending ? c < 0 : c > 0;
+    }
+    return ia < ib;
+  };
+  std::nth_element(order.begin(), order.begin() + trim_size, order.end(), before);
+  order.resize((size_t)trim_size);
+  std::sort(order.begin(), order.end());
+  // the survivors, in the joined result's order
+  const size_t m = order.size();
+  for (size_t j = 0; j < (size_t)q.n_group_by; j++) {
+    const int32_t t = r.group_key_type[j];
+    if (t == PG_GROUP_KEY_DICT_IDS) {
+      std::vector<int32_t> ids(m);
+      for (size_t i = 0; i < m; i++) ids[i] = r.group_dict_ids[j][(size_t)order[i]];
+      r.group_dict_ids[j].swap(ids);
+    } else if (t == PG_GROUP_KEY_BYTES_VALUES) {
+      std::vector<uint8_t> bytes;
+      std::vector<int64_t> off(1, 0);
+      for (size_t i = 0; i < m; i++) {
+        const int64_t a = r.group_bytes_off[j][(size_t)order[i]], b = r.group_bytes_off[j][(size_t)order[i] + 1];
+        bytes.insert(bytes.end(), r.group_bytes[j].begin() + a, r.group_bytes[j].begin() + b);
+        off.push_back((int64_t)bytes.size());
+      }
+      r.group_bytes[j].swap(bytes);
+      r.group_bytes_off[j].swap(off);
+    } else {
+      std::vector<int64_t> vs(m);
+      for (size_t i = 0; i < m; i++) vs[i] = r.group_values[j][(size_t)order[i]];
+      r.group_values[j].swap(vs);
+    }
+    if (!r.key_nulls[j].empty()) {
+      std::vector<uint8_t> kn(m);
+      for (size_t i = 0; i < m; i++) kn[i] = r.key_nulls[j][(size_t)order[i]];
+      r.key_nulls[j].swap(kn);
+    }
+  }
+  for (size_t a = 0; a < (size_t)q.n_aggregations; a++) {
+    AggResult dst;
+    const AggResult& src = r.aggs[a];
+    const std::vector<int64_t> set_off = set_offsets(src);
+    for (size_t i = 0; i < m; i++) append_agg(dst, &src, order[i], src.kind, src.log2m, set_off);
+    r.aggs[a] = std::move(dst);
+    if (!r.agg_nulls[a].empty()) {
+      std::vector<uint8_t> an(m);
+      for (size_t i = 0; i < m; i++) an[i] = r.agg_nulls[a][(size_t)order[i]];
+      r.agg_nulls[a].swap(an);
+    }
+  }
+  r.num_groups = (int32_t)m;
+}
+
 }  // namespace
 
 // PG_QUERY_FLAG_NULL_HANDLING: what stays with the Java plan
@@ -333,8 +482,6 @@ void check_null_handling(Segment& seg, const pg_query& q) {
     Column* c = seg.find(name);
     if (c && c->is_mv) fail(PG_ERR_UNSUPPORTED, "enableNullHandling: nulls in the multi-value column %s", c->name.c_str());
   }
-  if (q.n_group_by > 0 && q.n_order_by > 0 && q.order_by && q.min_segment_group_trim_size > 0)
-    fail(PG_ERR_UNSUPPORTED, "segment-level group trim under enableNullHandling (null order-by values, TableResizer.java:98-116) is left to the Java plan");
   if (any_nulls && (q.flags & PG_QUERY_FLAG_KEEP_DEVICE_TABLE))
     fail(PG_ERR_UNSUPPORTED, "enableNullHandling over columns with nulls: the result is joined on the host, no device table to keep");
 }
@@ -352,9 +499,15 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q_in, const 
     for (int j = 0; j < q.n_group_by; j++) if (has_nulls(seg, q.group_by_columns[j])) null_keys.push_back(j);
     for (int a = 0; a < q.n_aggregations; a++) null_args |= has_nulls(seg, q.aggregations[a].column);
   }
+  // segment-level group trim: over columns without nulls the query's own (no order-by value can be null); else the parts run untrimmed and the
+  // joined result is trimmed with the null-aware comparator
+  const bool trim = q.n_group_by > 0 && q.n_order_by > 0 && q.order_by && q.min_segment_group_trim_size > 0 && (null_args || !null_keys.empty());
+  const pg_query q_trim = q;
+  if (trim) { q.n_order_by = 0; q.order_by = nullptr; q.min_segment_group_trim_size = 0; }
   if (null_keys.empty()) {
     auto r = run_joined(seg, q, cancel, false);
-    if (null_args || r->schema_aggs.empty()) fill_result_schema(seg, q, *r);
+    if (trim) trim_joined(seg, q_trim, *r);
+    if (null_args || r->schema_aggs.empty()) fill_result_schema(seg, q_trim, *r);
     r->null_handling = true;
     return r;
   }
@@ -400,7 +553,8 @@ std::unique_ptr<Result> execute_query(Segment& seg, const pg_query& q_in, const 
     fail(PG_ERR_UNSUPPORTED, "enableNullHandling: %d groups over the null partitions, more than numGroupsLimit (%d)", out->num_groups, limit);
   out->stats.num_groups_limit_reached = out->num_groups >= limit ? 1 : 0;
   out->stats.stats_exact = 0;   // the filter ran once per partition: numEntriesScannedInFilter is the first partition's
-  fill_result_schema(seg, q, *out);
+  if (trim) trim_joined(seg, q_trim, *out);
+  fill_result_schema(seg, q_trim, *out);
   out->null_handling = true;
   return out;
 }

@@ -1622,8 +1622,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
   P.num_groups_limit = q->num_groups_limit > 0 ? q->num_groups_limit : 100000;
   if (q->n_group_by > 0 && q->n_order_by > 0 && q->order_by && q->min_segment_group_trim_size > 0) {
     // GroupByOperator.java:120-133 / GroupByUtils.getTableCapacity :45-57
-    if (q->flags & PG_QUERY_FLAG_NULL_HANDLING)
-      fail(PG_ERR_UNSUPPORTED, "segment-level group trim under enableNullHandling (null order-by values, TableResizer.java:98-116) is left to the Java plan");
+    // (under enableNullHandling only queries over columns without nulls arrive with their ORDER BY: pg_nullaware.cpp trims a joined result itself)
     for (int32_t i = 0; i < q->n_order_by; i++) {
       const pg_order_by& ob = q->order_by[i];
       if (ob.kind == PG_ORDER_BY_GROUP_KEY) {

@@ -93,6 +93,7 @@ class QueryContext:
     aggregations: List[AggregationSpec] = field(default_factory=list)
     select_columns: List[str] = field(default_factory=list)   # plain identifiers in the select list
     order_by: List[Tuple[str, bool]] = field(default_factory=list)  # (expression text, ascending)
+    order_by_nulls_last: List[Optional[bool]] = field(default_factory=list)   # parallel: NULLS LAST / NULLS FIRST, None = the default (OrderByExpressionContext#isNullsLast: as ascending)
     limit: int = 10
     num_groups_limit: int = 0
     max_initial_result_holder_capacity: int = 0
@@ -346,7 +347,18 @@ class _Parser:
                     asc = False
                 elif self.kw("ASC"):
                     self.i += 1
+                nulls_last = None
+                if self.kw("NULLS"):
+                    self.i += 1
+                    if self.kw("LAST"):
+                        nulls_last = True
+                    elif self.kw("FIRST"):
+                        nulls_last = False
+                    else:
+                        raise SqlError("NULLS FIRST or NULLS LAST expected")
+                    self.i += 1
                 q.order_by.append((text, asc))
+                q.order_by_nulls_last.append(nulls_last)
                 if self.peek() == ("op", ","):
                     self.i += 1
                     continue
@@ -410,7 +422,8 @@ class CQuery:
         if ob:
             arr = (capi.PgOrderBy * len(ob))()
             for i, (kind, index, asc) in enumerate(ob):
-                arr[i].kind, arr[i].index, arr[i].ascending, arr[i].nulls_last = kind, index, int(asc), int(asc)   # NULLS LAST for ASC is the SQL default
+                nl = q.order_by_nulls_last[i] if i < len(q.order_by_nulls_last) else None
+                arr[i].kind, arr[i].index, arr[i].ascending, arr[i].nulls_last = kind, index, int(asc), int(asc if nl is None else nl)   # NULLS LAST for ASC is the default
             self._keep.append(arr)
             self.query.order_by = arr
             self.query.n_order_by = len(ob)

@@ -119,15 +119,16 @@ def test_trim_ordered_by_final_distinct_values(segs):
         assert set(gb.rows()) == set(ob.rows()) and len(gb.rows()) == 5 * qc.limit
 
 
-def test_trim_refusals(segs):
-    g, _ = segs
-    for sql, flags in (("SELECT g1, COUNT(*) FROM gpuBench GROUP BY g1 ORDER BY COUNT(*) LIMIT 1", capi.QUERY_FLAG_NULL_HANDLING),):
-        qc = parse_sql(sql)
-        qc.min_segment_group_trim_size = 1
-        qc.flags |= flags
-        with pytest.raises(capi.NativeError) as e:
-            g.execute(qc)
-        assert e.value.status == capi.PG_ERR_UNSUPPORTED
+def test_trim_under_null_handling_over_columns_without_nulls(segs):
+    """the plain plan's trim (device selection included) with the flag set; null order-by values: tests/test_null_handling_trim.py"""
+    g, o = segs
+    for sql in ("SELECT g1, COUNT(*) FROM gpuBench GROUP BY g1 ORDER BY COUNT(*), g1 LIMIT 1", "SELECT u, COUNT(*), SUM(m) FROM gpuBench GROUP BY u ORDER BY u DESC LIMIT 10"):
+        qc, qo = parse_sql(sql), parse_sql(sql)
+        qc.min_segment_group_trim_size = qo.min_segment_group_trim_size = 1
+        qc.flags |= capi.QUERY_FLAG_NULL_HANDLING
+        qo.flags |= capi.QUERY_FLAG_NULL_HANDLING
+        rows = g.execute(qc).rows()
+        assert len(rows) == 5 * qc.limit and rows == o.execute(qo).rows()
 
 
 def test_raw_string_keys_order_as_java_strings(gpu_api, oracle_api):

@@ -26,11 +26,19 @@ def final_value(function, v):
 
 
 def order_tuple(qc, key, row):
-    """The group's order-by values, descending expressions negated so that tuples compare ascending (numbers only)."""
+    """The group's order-by values, descending expressions negated so that tuples compare ascending (numbers only).  Under null handling a
+    null key / a null final result (None) sorts by the expression's isNullsLast, whatever its direction (TableResizer.java:98-116): every
+    value is a pair (-1 null first | 0 value | 1 null last, value)."""
     out = []
-    for kind, index, asc in qc.resolved_order_by():
-        v = key[index] if kind == 0 else final_value(qc.aggregations[index].function, row[index])
-        out.append(v if asc else -v)
+    nulls_last = list(getattr(qc, "order_by_nulls_last", [])) + [None] * len(qc.order_by)
+    for i, (kind, index, asc) in enumerate(qc.resolved_order_by()):
+        raw = key[index] if kind == 0 else row[index]
+        if raw is None:
+            last = asc if nulls_last[i] is None else nulls_last[i]   # OrderByExpressionContext#isNullsLast
+            out.append((1 if last else -1, 0))
+            continue
+        v = raw if kind == 0 else final_value(qc.aggregations[index].function, raw)
+        out.append((0, v if asc else -v))
     return tuple(out)
 
 
