@@ -784,6 +784,45 @@ __global__ void __launch_bounds__(kFsBlock) fs_not_episodes_kernel(const FsNotLo
   if (w == 0) cost += (unsigned long long)fs_not_ctor_cost(look, n_docs);
   fs_wave_add(cost, total);
 }
+// ---- a NOT over an OR of leaves (pg_filter_stats_tiles.h, fs_notor_*): the NOT's resets from (targets, union); per scan child the resets that
+// advance() it, then its advances' costs with the episodes of next() calls between them
+struct FsNotOrChild {
+  FsIndex m, a;            // the child's matches, its advances
+  const int32_t* mv_off;
+  __device__ __forceinline__ int64_t next_match(int64_t x) const { return x < 0 ? -1 : m.next(x); }
+  __device__ __forceinline__ int64_t prev_advance(int64_t x) const { return a.prev(x); }
+  __device__ __forceinline__ int64_t span(int64_t x, int64_t y) const { return mv_off ? (int64_t)(mv_off[y] - mv_off[x]) : y - x; }
+  __device__ __forceinline__ bool batched() const { return mv_off == nullptr; }
+};
+__global__ void __launch_bounds__(kFsBlock) fs_notor_resets_kernel(const FsNotLook u, int64_t n_words, uint64_t* __restrict__ resets) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  uint64_t r = 0;
+  for (uint64_t bits = u.t.words[w]; bits; bits &= bits - 1) {
+    const int64_t t = w * 64 + __builtin_ctzll(bits);
+    if (fs_not_is_reset(u, t)) r |= 1ULL << (t & 63);
+  }
+  resets[w] = r;
+}
+__global__ void __launch_bounds__(kFsBlock) fs_notor_advances_kernel(const FsNotLook u, const FsNotOrChild c, const uint64_t* __restrict__ resets, int64_t n_words,
+                                                                     uint64_t* __restrict__ advances) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  uint64_t a = 0;
+  for (uint64_t bits = resets[w]; bits; bits &= bits - 1) {
+    const int64_t r = w * 64 + __builtin_ctzll(bits);
+    if (fs_notor_child_advanced(u, c, r)) a |= 1ULL << (r & 63);
+  }
+  advances[w] = a;
+}
+__global__ void __launch_bounds__(kFsBlock) fs_notor_costs_kernel(const FsNotLook u, const FsNotOrChild c, int64_t n_words, int64_t n_docs, unsigned long long* total) {
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long cost = 0;
+  if (w < n_words)
+    for (uint64_t bits = c.a.words[w]; bits; bits &= bits - 1) cost += (unsigned long long)fs_notor_advance_cost(u, c, w * 64 + __builtin_ctzll(bits), n_docs);
+  if (w == 0) cost += (unsigned long long)fs_notor_episode(u, c, n_docs, n_docs);   // the episode behind the child's last advance
+  fs_wave_add(cost, total);
+}
 struct FsMaxI32 { __host__ __device__ int32_t operator()(int32_t a, int32_t b) const { return a > b ? a : b; } };
 struct FsMinI32 { __host__ __device__ int32_t operator()(int32_t a, int32_t b) const { return a < b ? a : b; } };
 struct FsMapThen { __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return fs_map_then(a, b); } };
@@ -845,14 +884,19 @@ struct DevEval {
           if (c->kind == SetKind::Scan) n_other++;
           else if (c->kind == SetKind::Sorted) n_sorted++;
           else if (c->kind == SetKind::And) { const Kind k = child_kind(*c); if (k == Kind::Unfit) return Kind::Unfit; n_other += k == Kind::Other; }
-          else if (c->kind == SetKind::Not) { if (child_kind(*c) == Kind::Unfit) return Kind::Unfit; n_other++; }   // (the NOT receives the OR's targets its cursor lies before)
+          else if (c->kind == SetKind::Not) { if (child_kind(*c) == Kind::Unfit || c->children[0]->kind == SetKind::Or) return Kind::Unfit; n_other++; }   // (the NOT — over one leaf — receives the OR's targets its cursor lies before)
           else if (c->kind != SetKind::Bitmap) return Kind::Unfit;   // an OR inside an OR
         }
         return n_sorted > 1 && n_other == 0 ? Kind::Bitmap : Kind::Other;   // OrDocIdSet#iterator merges index-based children only beside >= 2 sorted ones
       }
-      case SetKind::Not: {   // NotDocIdIterator over one leaf (a compound child draws on next() and advance() of its own children: the host walk)
+      case SetKind::Not: {   // NotDocIdIterator over one leaf or over an OR of leaves (other compound children: the host walk)
         const Set& c = *s.children[0];
         if (c.kind == SetKind::Scan) return Kind::Other;
+        if (c.kind == SetKind::Or) {
+          for (auto& l : c.children)
+            if (l->kind != SetKind::Scan && l->kind != SetKind::Bitmap && l->kind != SetKind::Sorted) return Kind::Unfit;
+          return Kind::Other;
+        }
         return c.kind == SetKind::Bitmap || c.kind == SetKind::Sorted ? Kind::Other : Kind::Unfit;
       }
       default: return Kind::Unfit;   // Empty / MatchAll under an AND
@@ -958,6 +1002,26 @@ struct DevEval {
     if (!dry) hipLaunchKernelGGL(fs_not_episodes_kernel, grid_for(n_words), dim3(kFsBlock), 0, stream, look, n_words, n_docs, total);
   }
 
+  // the scans of an OR of leaves under a NOT: `targets` of the NOT, the union of the OR's children, the docs the NOT returns (the others)
+  template <typename CountedList>
+  void not_or_count(const uint64_t* targets, const uint64_t* uni, const uint64_t* others, const CountedList& scans) {
+    uint64_t* resets = take_words();
+    FsNotLook u{};
+    u.m = index_of(uni);
+    u.nm = index_of(others);
+    u.t = index_of(targets);
+    if (!dry) hipLaunchKernelGGL(fs_notor_resets_kernel, grid_for(n_words), dim3(kFsBlock), 0, stream, u, n_words, resets);
+    for (auto& leaf : scans) {
+      uint64_t* advances = take_words();
+      FsNotOrChild c{};
+      c.mv_off = leaf.mv_off;
+      c.m = index_of(leaf.match);
+      if (!dry) hipLaunchKernelGGL(fs_notor_advances_kernel, grid_for(n_words), dim3(kFsBlock), 0, stream, u, c, (const uint64_t*)resets, n_words, advances);
+      c.a = index_of(advances);
+      if (!dry) hipLaunchKernelGGL(fs_notor_costs_kernel, grid_for(n_words), dim3(kFsBlock), 0, stream, u, c, n_words, n_docs, total);
+    }
+  }
+
   // AndDocIdSet#iterator of one AND: its children's iterators in the AND's order (index-based children and scans merged, with the applyAnd counts —
   // once, when the iterator is built), and the docs the AND itself returns (asked for by a parent)
   struct Counted { const uint64_t* match; const int32_t* mv_off; };   // a scan leaf; mv_off: over a multi-value column
@@ -969,6 +1033,8 @@ struct DevEval {
     struct NotInOr { const uint64_t* scan; const uint64_t* rest; const int32_t* mv_off; };
     std::vector<NotInOr> nots;               // the scans under NOTs inside the OR this child is
     std::vector<const Set*> inner;           // the ANDs started at this child's targets: the child itself, or children of the OR it is
+    const uint64_t* not_or = nullptr;        // a NOT over an OR of leaves: the union of their matches
+    std::vector<Counted> not_or_scans;       // ... and the scans among them
   };
   struct AndPlan {
     DevEval* ev = nullptr;
@@ -1003,7 +1069,16 @@ struct DevEval {
     auto words_of = [&](const Set& c) { return c.kind == SetKind::Or ? or_words(c) : c.kind == SetKind::And ? plan_and(c).docs() : leaf_words(c); };
     auto child_of = [&](const Set& c) {
       AndChild a;
-      if (c.kind == SetKind::Not) {
+      if (c.kind == SetKind::Not && c.children[0]->kind == SetKind::Or) {
+        const Set& o = *c.children[0];
+        const uint64_t* uni = or_words(o);
+        uint64_t* rest = take_words();
+        words_op(rest, uni, nullptr, 3, false);
+        a.match = rest;
+        a.not_or = uni;
+        for (auto& l : o.children)
+          if (l->kind == SetKind::Scan) a.not_or_scans.push_back({leaf_words(*l), l->mv_off_dev});
+      } else if (c.kind == SetKind::Not) {
         const uint64_t* inner = leaf_words(*c.children[0]);
         uint64_t* rest = take_words();
         words_op(rest, inner, nullptr, 3, false);
@@ -1048,7 +1123,7 @@ struct DevEval {
   void sim_and(AndPlan& P, const uint64_t* active) {
     std::vector<AndChild>& its = P.its;
     bool any = false;
-    for (auto& a : its) any = any || !a.counted.empty() || a.not_scan || !a.inner.empty() || !a.nots.empty();
+    for (auto& a : its) any = any || !a.counted.empty() || a.not_scan || !a.inner.empty() || !a.nots.empty() || !a.not_or_scans.empty();
     if (!any) return;   // bitmap-based iterators all the way down: nothing is scanned
     FsAndProg prog{};
     prog.k = (int32_t)its.size();
@@ -1056,7 +1131,7 @@ struct DevEval {
     for (int j = 0; j < prog.k; j++) {
       const AndChild& a = its[(size_t)j];
       prog.match[j] = a.match;
-      prog.targets[j] = a.counted.empty() && !a.not_scan && a.inner.empty() && a.nots.empty() ? nullptr : take_words();
+      prog.targets[j] = a.counted.empty() && !a.not_scan && a.inner.empty() && a.nots.empty() && a.not_or_scans.empty() ? nullptr : take_words();
     }
     uint32_t* maps = take<uint32_t>((size_t)n_tiles);
     uint32_t* prefix = take<uint32_t>((size_t)n_tiles);
@@ -1080,6 +1155,7 @@ struct DevEval {
         if (!dry) hipLaunchKernelGGL(fs_not_received_kernel, grid_for(n_words), dim3(kFsBlock), 0, stream, look, n_words, received);
         not_count(received, nt.scan, nt.rest, nt.mv_off);
       }
+      if (!its[(size_t)j].not_or_scans.empty()) not_or_count(prog.targets[j], its[(size_t)j].not_or, its[(size_t)j].match, its[(size_t)j].not_or_scans);
       for (const Set* in : its[(size_t)j].inner) sim_and(plan_and(*in), prog.targets[j]);
     }
   }

@@ -179,16 +179,21 @@ FS_HD int64_t fs_latch_count(const uint64_t* t, const uint64_t* m, int64_t w_lo,
 // `L` answers first / last set bit queries on those bitmaps (-1: none): the host model scans, the device keeps two-level indexes.
 #define FS_SCAN_BATCH 256   // BlockDocIdIterator.OPTIMAL_ITERATOR_BATCH_SIZE
 
+// the child's next match the NOT knows of before it is advanced to target t (t = n_docs: behind its last target), -1: the child is exhausted
 template <typename L>
-FS_HD bool fs_not_is_reset(L& l, int64_t t) {   // is the scan advance()d when the NOT is advanced to target t
+FS_HD int64_t fs_not_known_match(L& l, int64_t t) {
   const int64_t t_prev = l.prev_target(t - 1);
   int64_t from = 0;   // the first doc behind the one the NOT returned last
   if (t_prev >= 0) {
     const int64_t r = l.next_non_match(t_prev);
-    if (r < 0) return false;   // the matches ran to the end: the scan is exhausted
+    if (r < 0) return -1;   // the matches ran to the end: the child is exhausted
     from = r + 1;
   }
-  const int64_t nm = l.next_match(from);
+  return l.next_match(from);
+}
+template <typename L>
+FS_HD bool fs_not_is_reset(L& l, int64_t t) {   // is the scan advance()d when the NOT is advanced to target t
+  const int64_t nm = fs_not_known_match(l, t);
   return nm >= 0 && t > nm;
 }
 // `l.span(a, b)`: what a scan counts for evaluating the docs [a, b) — b - a, or their entries over a multi-value column;
@@ -230,4 +235,39 @@ template <typename L>
 FS_HD bool fs_not_in_or_receives(L& l, int64_t t) {
   if (t == 0) return true;
   return !(l.prev_target(t - 1) > l.prev_non_match(t - 1));
+}
+
+// ---- NOT over an OR of leaves, under an AND (NotDocIdIterator over OrDocIdIterator.java:50-119, both entry points) -----------------------------
+// Towards the NOT the OR is one child whose matches are the union U of its children's: the NOT's resets R and its known next match follow from
+// (targets, U) as above.  Child i of the OR holds a cursor — its first match at or behind the OR's current doc (OrDocIdIterator keeps every
+// child on its next doc and asks it for another only once that doc has been returned) — and so, with `known` = the union's match the NOT knows of:
+//   * at a reset r the OR advance()s child i iff its cursor lies before r: next_match_i(known(r)) < r — the scan drops its batch and counts
+//     [r, its first match >= r];
+//   * between two of ITS advances (A_i, a subset of R) the scan streams through next(): whole batches from behind the match its advance
+//     returned (B0; 0 for the constructor's episode, whose first next() always happens) up to the batch that holds its cursor at the end of the
+//     episode, next_match_i(known(the next advance)) — nothing when the cursor has not moved; after the last advance: up to
+//     next_match_i(known(behind the last target)); an exhausted cursor has scanned to the end.
+// `U`: prev_target / next_match / next_non_match over the union; `C`: next_match / span / batched of the child, prev_advance over A_i.
+template <typename U, typename C>
+FS_HD bool fs_notor_child_advanced(U& u, C& c, int64_t r) {   // r: a reset of the NOT
+  const int64_t cursor = c.next_match(fs_not_known_match(u, r));
+  return cursor >= 0 && cursor < r;
+}
+template <typename U, typename C>
+FS_HD int64_t fs_notor_episode(U& u, C& c, int64_t a, int64_t n_docs) {   // the episode that ends at the child's advance a (n_docs: the last one)
+  const int64_t prev = c.prev_advance(a - 1);
+  int64_t b0 = 0;
+  if (prev >= 0) {
+    const int64_t p = c.next_match(prev);
+    if (p < 0) return 0;   // that advance ran to the end: the OR dropped the child
+    b0 = p + 1;
+  }
+  const int64_t known = fs_not_known_match(u, a);
+  const int64_t q = known < 0 ? -1 : c.next_match(known);
+  if (prev >= 0 && q >= 0 && q < b0) return 0;   // the cursor is still the match the advance returned
+  return fs_not_batches(c, b0, q, n_docs);
+}
+template <typename U, typename C>
+FS_HD int64_t fs_notor_advance_cost(U& u, C& c, int64_t a, int64_t n_docs) {   // a in A_i: its advance and the episode it ends
+  return fs_not_advance_cost(c, a, n_docs) + fs_notor_episode(u, c, a, n_docs);
 }

@@ -1,7 +1,7 @@
 // Host model of the tile-parallel numEntriesScannedInFilter (pinot_amd/csrc/pg_filter_stats_tiles.h) against a direct, doc-by-doc restatement of
 // the reference's iterators: AndDocIdIterator.java:37-66, OrDocIdIterator.java:91-119 (advance() only, which is all an AND ever calls on its
 // children), NotDocIdIterator.java:28-70 and SVScanDocIdIterator.java:76-112 (both entry points, with its batches of 256).  Random match bitmaps of
-// every density; an AND whose children are scans, bitmaps, NOTs over a scan, ORs of leaves and ANDs, and ANDs of their own.
+// every density; an AND whose children are scans, bitmaps, NOTs over a scan or over an OR of leaves, ORs of leaves, NOTs and ANDs, and ANDs of their own.
 // Build: g++ -O2 -std=c++17 -I pinot_amd/csrc tests/filter_stats_tiles_test.cpp -o tests/_build/filter_stats_tiles_test
 #include <algorithm>
 #include <cstdio>
@@ -22,7 +22,7 @@ struct Leaf {
 enum { LEAF, OR, NOT, AND };
 struct Node {
   int kind = LEAF;
-  int leaf = -1;            // LEAF; NOT: the scan below it
+  int leaf = -1;            // LEAF; NOT: the scan below it (-1: the NOT is over an OR of the leaves in `kids`)
   std::vector<Node> kids;   // OR: leaves, NOTs and ANDs; AND: leaves, NOTs, ORs, ANDs
 };
 
@@ -133,6 +133,85 @@ struct SeqNot : SeqIt {   // NotDocIdIterator.java:28-70
     return next();
   }
 };
+// NotDocIdIterator over an OrDocIdIterator of leaves: both entry points all the way down (OrDocIdIterator.java:50-119)
+struct SeqFullLeaf {
+  Leaf& l;
+  int64_t n, pos = 0;
+  SeqScan scan;
+  SeqFullLeaf(Leaf& leaf, int64_t docs) : l(leaf), n(docs), scan(leaf, docs) {}
+  int64_t next() {
+    if (l.scan) return scan.next();
+    const int64_t p = next_set(l.m, pos, n);   // BitmapDocIdIterator
+    pos = p < 0 ? n : p + 1;
+    return p;
+  }
+  int64_t advance(int64_t target) {
+    if (l.scan) return scan.advance(target);
+    if (target > pos) pos = target;
+    return next();
+  }
+};
+struct SeqNotOr : SeqIt {
+  std::vector<SeqFullLeaf> its;
+  std::vector<int64_t> next_ids;   // -1 before the first call, -2 exhausted
+  int64_t previous = -1;
+  int64_t n, next_doc = 0, next_non_matching;
+  int64_t or_next() {
+    int64_t best = INT64_MAX;
+    for (size_t i = 0; i < its.size(); i++) {
+      if (next_ids[i] == -2) continue;
+      int64_t d = next_ids[i];
+      if (d == previous) {
+        d = its[i].next();
+        next_ids[i] = d < 0 ? -2 : d;
+        if (d < 0) continue;
+      }
+      best = std::min(best, d);
+    }
+    if (best == INT64_MAX) return -1;
+    previous = best;
+    return best;
+  }
+  int64_t or_advance(int64_t target) {
+    int64_t best = INT64_MAX;
+    for (size_t i = 0; i < its.size(); i++) {
+      if (next_ids[i] == -2) continue;
+      int64_t d = next_ids[i];
+      if (d < target) {
+        d = its[i].advance(target);
+        next_ids[i] = d < 0 ? -2 : d;
+        if (d < 0) continue;
+      }
+      best = std::min(best, d);
+    }
+    if (best == INT64_MAX) return -1;
+    previous = best;
+    return best;
+  }
+  SeqNotOr(const Node& nd, std::vector<Leaf>& leaves, int64_t docs) : n(docs) {
+    for (auto& c : nd.kids) { its.emplace_back(leaves[(size_t)c.leaf], docs); next_ids.push_back(-1); }
+    const int64_t cur = or_next();
+    next_non_matching = cur < 0 ? n : cur;
+  }
+  int64_t next() {
+    if (next_doc >= n) return -1;
+    while (next_doc == next_non_matching) {
+      next_doc++;
+      const int64_t d = or_next();
+      next_non_matching = d < 0 ? n : d;
+    }
+    if (next_doc >= n) return -1;
+    return next_doc++;
+  }
+  int64_t advance(int64_t target) override {
+    next_doc = target;
+    if (target > next_non_matching) {
+      const int64_t d = or_advance(target);
+      next_non_matching = d < 0 ? n : d;
+    }
+    return next();
+  }
+};
 struct SeqAnd : SeqIt {   // AndDocIdIterator.java:37-66
   std::vector<std::unique_ptr<SeqIt>> its;
   int64_t next_doc = 0;
@@ -155,7 +234,9 @@ struct SeqAnd : SeqIt {   // AndDocIdIterator.java:37-66
 static std::unique_ptr<SeqIt> seq_of(const Node& nd, std::vector<Leaf>& leaves, int64_t n) {
   switch (nd.kind) {
     case LEAF: return std::make_unique<SeqLeaf>(leaves[(size_t)nd.leaf], n);
-    case NOT: return std::make_unique<SeqNot>(leaves[(size_t)nd.leaf], n);
+    case NOT:
+      if (nd.leaf < 0) return std::make_unique<SeqNotOr>(nd, leaves, n);
+      return std::make_unique<SeqNot>(leaves[(size_t)nd.leaf], n);
     case OR: {
       auto o = std::make_unique<SeqOr>();
       for (auto& c : nd.kids) { o->its.push_back(seq_of(c, leaves, n)); o->next_ids.push_back(-1); }
@@ -178,6 +259,14 @@ struct Tiles {
   Bits match_of(const Node& nd) const {   // the docs the node's iterator returns
     Bits out((size_t)n_words + 1, 0);
     const uint64_t last = n & 63 ? ~0ULL >> (64 - (n & 63)) : ~0ULL;
+    if (nd.kind == NOT && nd.leaf < 0) {   // the docs outside the union
+      for (auto& c : nd.kids) {
+        const Bits m = match_of(c);
+        for (int64_t w = 0; w < n_words; w++) out[(size_t)w] |= m[(size_t)w];
+      }
+      for (int64_t w = 0; w < n_words; w++) out[(size_t)w] = ~out[(size_t)w] & (w == n_words - 1 ? last : ~0ULL);
+      return out;
+    }
     if (nd.kind == LEAF || nd.kind == NOT) {
       out = leaves[(size_t)nd.leaf].m;
       if (nd.kind == NOT)
@@ -214,6 +303,40 @@ struct Tiles {
     for (int64_t t = next_set(targets, 0, n); t >= 0; t = next_set(targets, t + 1, n))
       if (fs_not_in_or_receives(look, t)) received[(size_t)(t >> 6)] |= 1ULL << (t & 63);
     not_scan(received, others, leaf);
+  }
+  // a NOT over an OR of leaves: `others` = the docs the NOT returns
+  void not_or(const Bits& targets, const Bits& others, const Node& nd) {
+    Bits uni((size_t)n_words + 1, 0);
+    const uint64_t last = n & 63 ? ~0ULL >> (64 - (n & 63)) : ~0ULL;
+    for (int64_t w = 0; w < n_words; w++) uni[(size_t)w] = ~others[(size_t)w] & (w == n_words - 1 ? last : ~0ULL);
+    struct LookU {
+      const Bits &m, &nm, &t;
+      int64_t n;
+      static int64_t prev(const Bits& b, int64_t x) { for (; x >= 0; x--) if ((b[(size_t)(x >> 6)] >> (x & 63)) & 1) return x; return -1; }
+      int64_t next_match(int64_t x) const { return x >= n ? -1 : next_set(m, x, n); }
+      int64_t next_non_match(int64_t x) const { return next_set(nm, x, n); }
+      int64_t prev_target(int64_t x) const { return prev(t, std::min(x, n - 1)); }
+    } u{uni, others, targets, n};
+    Bits resets((size_t)n_words + 1, 0);
+    for (int64_t t = next_set(targets, 0, n); t >= 0; t = next_set(targets, t + 1, n))
+      if (fs_not_is_reset(u, t)) resets[(size_t)(t >> 6)] |= 1ULL << (t & 63);
+    for (auto& kid : nd.kids) {
+      if (!leaves[(size_t)kid.leaf].scan) continue;
+      struct LookC {
+        const Bits& m;
+        Bits a;
+        int64_t n;
+        int64_t next_match(int64_t x) const { return x < 0 || x >= n ? -1 : next_set(m, x, n); }
+        int64_t prev_advance(int64_t x) const { return LookU::prev(a, std::min(x, n - 1)); }
+        int64_t span(int64_t x, int64_t y) const { return y - x; }
+        bool batched() const { return true; }
+      } c{leaves[(size_t)kid.leaf].m, Bits((size_t)n_words + 1, 0), n};
+      for (int64_t r = next_set(resets, 0, n); r >= 0; r = next_set(resets, r + 1, n))
+        if (fs_notor_child_advanced(u, c, r)) c.a[(size_t)(r >> 6)] |= 1ULL << (r & 63);
+      int64_t total = fs_notor_episode(u, c, n, n);
+      for (int64_t a = next_set(c.a, 0, n); a >= 0; a = next_set(c.a, a + 1, n)) total += fs_notor_advance_cost(u, c, a, n);
+      counts[(size_t)kid.leaf] += total; if (getenv("FS_DEBUG")) printf("not_or leaf %d total %lld seq %lld\n", kid.leaf, (long long)total, (long long)leaves[(size_t)kid.leaf].counted);
+    }
   }
   void not_scan(const Bits& targets, const Bits& others, int leaf) {
     struct Look {   // the bitmaps scanned directly (the device: two-level indexes)
@@ -277,6 +400,7 @@ struct Tiles {
       const Node& c = nd.kids[(size_t)j];
       const Bits& tj = targets[(size_t)j];
       if (c.kind == LEAF) { if (leaves[(size_t)c.leaf].scan) latch(tj, c.leaf); }
+      else if (c.kind == NOT && c.leaf < 0) not_or(tj, match[(size_t)j], c);
       else if (c.kind == NOT) not_scan(tj, match[(size_t)j], c.leaf);
       else if (c.kind == AND) run_and(c, &tj);
       else
@@ -314,7 +438,14 @@ static Node random_and(std::vector<Leaf>& leaves, std::mt19937_64& rng, int64_t 
   for (int j = 0; j < k; j++) {
     const int what = (int)(rng() % 9);
     if (what < 4) a.kids.push_back(random_leaf(leaves, rng, n, false));
-    else if (what < 6) { Node c = random_leaf(leaves, rng, n, true); c.kind = NOT; a.kids.push_back(c); }
+    else if (what == 4) { Node c = random_leaf(leaves, rng, n, true); c.kind = NOT; a.kids.push_back(c); }
+    else if (what == 5) {   // a NOT over an OR of leaves
+      Node c;
+      c.kind = NOT;
+      const int nl = 1 + (int)(rng() % 3);
+      for (int i = 0; i < nl; i++) c.kids.push_back(random_leaf(leaves, rng, n, false));
+      a.kids.push_back(c);
+    }
     else if (what < 8 || depth == 0) {
       Node o;
       o.kind = OR;

@@ -71,7 +71,11 @@ SHAPES = [
     ("(ci = 3 AND NOT (r < 200000)) OR (k > 90 AND NOT (u < 500))", True),       # two such ANDs drained by an OR
     ("ci = 3 AND (r < 200000 OR NOT (k > 50))", True),                           # a NOT inside an OR: it receives the targets its cursor lies before
     ("r < 600000 AND (NOT (b = 1) OR NOT (k < 0) OR u = 5)", True),              # two of them, one over long runs
-    ("ci = 3 AND NOT (r < 200000 OR k > 50)", False),                            # NOT over an OR under an AND: the host walk
+    ("ci = 3 AND NOT (r < 200000 OR k > 50)", True),                             # NOT over an OR of leaves under an AND: each scan's own advances and episodes
+    ("r < 700000 AND NOT (k > 90 OR b = 1 OR ci = 2)", True),                    # ... scans, long runs and an index leaf in the union
+    ("u < 900 AND NOT (so < 3 OR ci = 1)", True),                                # ... no scan in it: nothing to count there
+    ("ci <> 0 AND NOT (r < 100000 OR k > 95) AND NOT (u < 30)", True),           # ... beside a NOT over one scan
+    ("ci = 3 AND NOT (r < 200000 AND k > 50)", False),                           # NOT over an AND under an AND: the host walk
     ("r < 200000 AND (k > 0 OR (u < 500 AND g < 60))", True),                    # an AND inside an OR under an AND: started at the OR's targets
     ("ci = 3 AND (r < 200000 OR (k > 0 AND u < 500) OR (g < 60 AND b = 1))", True),              # two of them beside a scan
     ("(r < 500000 OR (k > 0 AND NOT (u < 500))) AND ci <> 4", True),                              # ... with a NOT over a scan inside

@@ -92,7 +92,8 @@ MV_STATS_PATHS = [
     ("SELECT COUNT(*) FROM mvTable WHERE (mv1 BETWEEN 3 AND 9 AND mv3 > 2000000) OR mv2 = 'gnu'", 2),           # drained OR over an AND and a scan
     ("SELECT COUNT(*) FROM mvTable WHERE m < 0 AND NOT (mv2 = 'cat')", 2),                                     # NOT over a multi-value scan under an AND: next() without batches
     ("SELECT COUNT(*) FROM mvTable WHERE s1 IN (1, 2) AND (m > 900 OR NOT (mv1 BETWEEN 3 AND 30))", 2),        # ... inside an OR
-    ("SELECT COUNT(*) FROM mvTable WHERE m < 0 AND NOT (mv2 = 'cat' OR m > 5)", 1),                            # NOT over an OR under an AND: the host walk
+    ("SELECT COUNT(*) FROM mvTable WHERE m < 0 AND NOT (mv2 = 'cat' OR m > 5)", 2),                            # NOT over an OR of leaves under an AND (a multi-value scan among them)
+    ("SELECT COUNT(*) FROM mvTable WHERE m < 0 AND NOT (mv2 = 'cat' AND m > 5)", 1),                           # NOT over an AND under an AND: the host walk
 ]
 
 
