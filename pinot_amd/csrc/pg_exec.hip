@@ -19,7 +19,7 @@ PG_DECL_GENERIC
 PG_DECL_FAST(pg_fast_none_f) PG_DECL_FAST(pg_fast_none_a) PG_DECL_FAST(pg_fast_i32range_f) PG_DECL_FAST(pg_fast_i32range_a)
 PG_DECL_FAST(pg_fast_dictrange_f) PG_DECL_FAST(pg_fast_dictrange_a) PG_DECL_FAST(pg_fast_dictlut_f) PG_DECL_FAST(pg_fast_dictlut_a)
 PG_DECL_FAST(pg_fast_multi_f) PG_DECL_FAST(pg_fast_multi_a) PG_DECL_FAST(pg_fast_multi_w) PG_DECL_FAST(pg_fast_none_w)
-PG_DECL_FAST(pg_fast_i32range_d) PG_DECL_FAST(pg_fast_i32range_p) PG_DECL_FAST(pg_fast_i32range_fp) PG_DECL_FAST(pg_fast_i32range_s) PG_DECL_FAST(pg_spec_none) PG_DECL_FAST(pg_spec_scan) PG_DECL_FAST(pg_spec_index) PG_DECL_FAST(pg_fast_i32range_st)
+PG_DECL_FAST(pg_nogroup_s1) PG_DECL_FAST(pg_nogroup_s2) PG_DECL_FAST(pg_fast_i32range_d) PG_DECL_FAST(pg_fast_i32range_p) PG_DECL_FAST(pg_fast_i32range_fp) PG_DECL_FAST(pg_fast_i32range_s) PG_DECL_FAST(pg_spec_none) PG_DECL_FAST(pg_spec_scan) PG_DECL_FAST(pg_spec_index) PG_DECL_FAST(pg_fast_i32range_st)
 // pg_kernels_specd.hip: the loader / consumer frame over dictionary-encoded scan / value columns (_r raw INT values, _a arithmetic dictionary, _g gathered)
 PG_DECL_FAST(pg_fast_dictrange_s_r_dma) PG_DECL_FAST(pg_fast_dictrange_s_a_dma) PG_DECL_FAST(pg_fast_dictrange_s_g_dma) PG_DECL_FAST(pg_fast_dictrange_s_r) PG_DECL_FAST(pg_fast_dictrange_st_r) PG_DECL_FAST(pg_specd_none_r) PG_DECL_FAST(pg_specd_scan_r) PG_DECL_FAST(pg_specd_index_r) PG_DECL_FAST(pg_fast_dictrange_s_a) PG_DECL_FAST(pg_fast_dictrange_st_a) PG_DECL_FAST(pg_specd_none_a) PG_DECL_FAST(pg_specd_scan_a) PG_DECL_FAST(pg_specd_index_a) PG_DECL_FAST(pg_fast_dictrange_s_g) PG_DECL_FAST(pg_fast_dictrange_st_g) PG_DECL_FAST(pg_specd_none_g) PG_DECL_FAST(pg_specd_scan_g) PG_DECL_FAST(pg_specd_index_g)
 // pg_kernels_specw.hip: the same shapes with a shared stage per workgroup (whole stages requested as long rows straight into LDS)
@@ -378,6 +378,25 @@ static bool uses_scan_kernel(const CompiledPlan& P, int agg_mode) {
   return !no_scan && agg_mode == PG_AGG_NONE && uses_fast_kernel(P, agg_mode) && P.fast_filter == 4 && P.dev.n_index_instr == 0 &&
          P.dev.fast_scan_pushed;
 }
+// pg_nogroup_s1 / _s2 (pg_kernels_scan.hip): no GROUP BY, no filter, integer accumulators over one or two raw INT columns — streamed with the
+// accumulators in registers; returns the number of columns (0: another kernel)
+static int uses_nogroup_stream(const CompiledPlan& P, int agg_mode) {
+  const PgQueryPlan& D = P.dev;
+  if (knobs().no_scan_pipe || agg_mode != PG_AGG_SINGLE || !uses_fast_kernel(P, agg_mode) || P.fast_filter != -1 || D.n_index_instr != 0 || D.tail_posting >= 0 ||
+      D.n_group_cols != 0 || D.n_groups != 1 || D.n_aux != 0 || D.n_ops <= 0 || D.n_ops > PG_MAX_OPS)
+    return 0;
+  int a = -1, b = -1;
+  for (int o = 0; o < D.n_ops; o++) {
+    const PgAccOp& op = D.ops[o];
+    if (op.fn == PG_ACC_COUNT && op.src < 0) continue;
+    if (op.src < 0 || op.is_float != PG_ACCV_INT || op.limb != 0) return 0;
+    const PgValueSrc& S = D.srcs[op.src];
+    if (S.col_kind != PG_COL_RAW32 || S.val_type != PG_V_I32) return 0;
+    if (op.src == a || op.src == b) continue;
+    if (a < 0) a = op.src; else if (b < 0) b = op.src; else return 0;
+  }
+  return a < 0 ? 0 : (b < 0 ? 1 : 2);
+}
 // pg_fast_dictrange_s family (pg_kernels_specd.hip): the loader / consumer frame over dictionary-encoded scan / value columns — decided at plan
 // time (PgQueryPlan::specd), whatever the filter lets through
 static bool uses_specd(const CompiledPlan& P, int agg_mode) {
@@ -457,6 +476,7 @@ extern "C" void pg_trim_launch_select(const PgTrimArgs* args, int grid, hipStrea
 typedef void (*QueryKernel)(const PgQueryPlan);
 static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char** name) {
   const bool agg = agg_mode != PG_AGG_NONE;
+  if (const int ns = uses_nogroup_stream(P, agg_mode)) { *name = ns == 1 ? "pg_nogroup_s1" : "pg_nogroup_s2"; return ns == 1 ? pg_nogroup_s1 : pg_nogroup_s2; }
   if (uses_fast_kernel(P, agg_mode)) {
     if (agg && uses_pipe_wide(P, agg_mode)) {
       // one kernel per value width (no value column / raw INT / raw LONG) and filter shape
@@ -666,7 +686,7 @@ static LaunchShape launch_shape(const CompiledPlan& P, int n_wtiles, int agg_mod
     if (!no_clamp) per_range = std::max(1, std::min(per_range, (chunks + 7) / 8));
     return {8 * per_range * P.dev.n_parts, block, lds};
   }
-  if (uses_scan_kernel(P, agg_mode)) {
+  if (uses_scan_kernel(P, agg_mode) || uses_nogroup_stream(P, agg_mode)) {
     const int wgs_per_cu = knobs().scan_wgs_per_cu;   // tuning knob
     const int waves = pg_scan_waves_per_block;
     int grid = std::min((n_wtiles + waves - 1) / waves, num_cus() * std::max(wgs_per_cu, 1));

@@ -53,6 +53,10 @@ QUERIES = [
      "AND m >= 524288 GROUP BY g1 LIMIT 1000", "pg_pipe_index_scan_vscan"),
     ("SELECT g2, g1, COUNT(*), SUM(m) FROM gpuBench WHERE c_inv1 NOT IN (3) AND r_int < 100 AND m < 1000000 GROUP BY g2, g1 LIMIT 10000",
      "pg_pipe_index_scan_vscan"),
+    # no GROUP BY, no filter, integer accumulators over one / two raw INT columns: streamed with the accumulators in registers (pg_kernels_scan.hip)
+    ("SELECT SUM(m), MIN(m), MAX(m), COUNT(*) FROM gpuBench", "pg_nogroup_s1"),
+    ("SELECT MINMAXRANGE(r_int) FROM gpuBench", "pg_nogroup_s1"),
+    ("SELECT SUM(m), MAX(r_int), MIN(r_int), MINMAXRANGE(m), COUNT(*) FROM gpuBench", "pg_nogroup_s2"),
 ]
 
 
@@ -76,7 +80,7 @@ def test_headline_specialisations_match_oracle(pair, sql, kernel):
     assert gb.rows() == ob.rows()
     for f in ("num_docs_scanned", "num_entries_scanned_in_filter", "num_entries_scanned_post_filter", "num_total_docs"):
         assert getattr(gb.stats, f) == getattr(ob.stats, f), f
-    if kernel == SCAN and not os.environ.get("PG_NO_SCAN_PIPE"):
+    if kernel in (SCAN, "pg_nogroup_s1", "pg_nogroup_s2") and not os.environ.get("PG_NO_SCAN_PIPE"):
         assert gb.stats.kernel.decode() == kernel                   # no index involved: every segment size takes it
     elif kernel and knobs_off and gb.stats.num_total_docs >= 65536:   # small segments keep sparse (CSR) postings: the interpreted leaves
         # (the headline shape: the loader / consumer kernel where the index program lets >= 15 % of the docs through — known at plan time from
@@ -92,6 +96,7 @@ UPSERT_QUERIES = [
     ("SELECT g1, SUM(m), MAX(m) FROM gpuBench GROUP BY g1 LIMIT 1000", "pg_pipe_index2"),         # the snapshot is the only (index) leaf
     ("SELECT g1, SUM(m) FROM gpuBench WHERE r_int BETWEEN 250000 AND 749999 GROUP BY g1 LIMIT 1000", None),
     ("SELECT g1, COUNT(*), SUM(m) FROM gpuBench WHERE c_inv2 = 1 GROUP BY g1 LIMIT 1000", None),
+    ("SELECT SUM(m), MIN(m), MAX(r_int), COUNT(*) FROM gpuBench", None),                            # no GROUP BY: not the unfiltered stream kernel
 ]
 
 
@@ -108,6 +113,7 @@ def test_pipeline_behind_an_upsert_snapshot(gpu_api, oracle_api, n):
         for sql, kernel in UPSERT_QUERIES:
             gb, ob = g.execute(sql), o.execute(sql)
             assert gb.rows() == ob.rows(), (sql, keep)
+            assert not gb.stats.kernel.decode().startswith("pg_nogroup"), sql   # (the stream kernels know no filter)
             for f in ("num_docs_scanned", "num_entries_scanned_in_filter", "num_entries_scanned_post_filter", "num_total_docs"):
                 assert getattr(gb.stats, f) == getattr(ob.stats, f), (f, sql, keep)
             if kernel and knobs_off and n >= 65536 and keep >= 0.5:   # dense snapshots are bitmap containers: the arithmetic (dense) form

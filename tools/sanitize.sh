@@ -27,6 +27,6 @@ case "${1:-cpu}" in
     export LD_PRELOAD=$RT PG_GPU_LIB=$R/tools/variants/libpinot_gpu_san.so PO_ORACLE_LIB=$R/oracle/_build/liboracle_san.so
     timeout 1500 python tests/malformed_worker.py > gpurun_out/r06_sanitize_gpu.log 2>&1
     timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_partition_pipeline.py tests/test_gpu_group_trim.py tests/test_segment_dir.py tests/test_gpu_startree.py \
-      tests/test_gpu_mv.py tests/test_gpu_datatable.py tests/test_null_handling_filters.py tests/test_gpu_multi.py tests/test_gpu_dict_headline.py tests/test_gpu_mv_group.py tests/test_distinctcount_raw.py -x -q -m gpu -p no:cacheprovider >> gpurun_out/r06_sanitize_gpu.log 2>&1
+      tests/test_gpu_mv.py tests/test_gpu_datatable.py tests/test_null_handling_filters.py tests/test_gpu_multi.py tests/test_gpu_dict_headline.py tests/test_gpu_mv_group.py tests/test_distinctcount_raw.py tests/test_gpu_filter_stats_device.py tests/test_null_handling_trim.py tests/test_null_handling_aggregations.py tests/test_raw_string_predicates.py tests/test_gpu_fake_rccl.py -x -q -m gpu -p no:cacheprovider >> gpurun_out/r06_sanitize_gpu.log 2>&1
     grep -c "ERROR: AddressSanitizer\|runtime error:" gpurun_out/r06_sanitize_gpu.log; tail -4 gpurun_out/r06_sanitize_gpu.log ;;
 esac
