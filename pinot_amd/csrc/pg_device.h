@@ -405,6 +405,10 @@ struct PgQueryPlan {
   int32_t specd_vbits;              // ... of the value column's
   int32_t specd_base, specd_step;
   int32_t specd_dma;                // the headline shape's LDS-DMA kernels (two column areas per strip): pg_fast_dictrange_s_*_dma
+  // pg_nogroup_d (pg_kernels_scan.hip): no GROUP BY, no filter, integer accumulators over ONE dictionary-encoded INT column (<= 24-bit dictIds of a
+  // sorted dictionary): 0 no; 1 value = nogroup_base + nogroup_step x dictId (arithmetic dictionary); 2 srcs[nogroup_src].dict[dictId]
+  int32_t nogroup_d, nogroup_src, nogroup_bits, nogroup_pad;
+  int64_t nogroup_base, nogroup_step;
   int32_t mvg_has_entries;          // pg_mv_aggr_*: an accumulator reads the entries' values (else only their number)
   int32_t mvg_dict_card;            // ... and the entries' dictionary (<= 4 096 values) is copied into LDS behind the table; 0: gathered from global memory
   int32_t p2_no_pack;               // PG_P2_NO_PACK (measurement knob): COUNT and SUM keep an LDS atomic each in pg_p2_aggregate_*s

@@ -201,3 +201,120 @@ __device__ __forceinline__ void nogroup_stream_body(const PgQueryPlan& p) {
 }
 extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_nogroup_s1(const PgQueryPlan p) { nogroup_stream_body<1>(p); }
 extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_nogroup_s2(const PgQueryPlan p) { nogroup_stream_body<2>(p); }
+
+// pg_nogroup_d (round 6): the same aggregation over ONE dictionary-encoded INT column — Pinot's default encoding of a metric.  The fixed-bit dictId
+// stream is read in the oct layout (pg_oct_layout.h: lane L owns docs 8L .. 8L+7 of a 512-doc sub-tile = `bits` bytes at byte offset bits x L; a
+// whole wave tile — four sub-tiles, eight 16-byte loads per lane — double-buffered per wavefront) and the DICTIDS are accumulated: their sum, their
+// minimum and maximum.  The dictionary is sorted, so MIN / MAX are its values at the extreme dictIds, and SUM is nogroup_base x docs +
+// nogroup_step x sum(dictIds) for an arithmetic dictionary (nogroup_d = 1); any other dictionary (nogroup_d = 2) is gathered per doc from its
+// native-endian copy for SUM (DataFetcher.java:335-386).  The width is a template parameter of the loop (one scalar branch per kernel).
+#include "pg_oct_layout.h"
+
+template <int B, bool GATHER>
+__device__ __forceinline__ void nogroup_dict_loop(const PgQueryPlan& p, int lane, int wave, uint32_t& my_docs, unsigned long long& sum_ids, long long& sum_vals, uint32_t& mn,
+                                                  uint32_t& mx) {
+  const PgValueSrc& V = p.srcs[p.nogroup_src];
+  const GAS int32_t* dict = gptr<int32_t>(reinterpret_cast<const uint8_t*>(V.dict));
+  const uint32_t woff = ((uint32_t)lane * (uint32_t)B) & ~3u;                 // the lane's window: dword-aligned start, byte selector
+  const uint32_t wsel = oct_selector(((uint32_t)lane * (uint32_t)B) & 3u);
+  const int step = (int)gridDim.x * PG_WAVES_PER_BLOCK;
+  const int last_wt = p.n_wtiles - 1;
+  constexpr uint32_t TILE_BYTES = (PG_WAVE_DOCS / 8) * B, SUB_BYTES = (OCT_SUB_DOCS / 8) * B;
+
+  auto issue = [&](int wt, u32x4 (&a)[8]) __attribute__((always_inline)) {
+    const int wc = wt < last_wt ? wt : last_wt;
+    const uint64_t base = (uint64_t)V.data + (uint64_t)wc * TILE_BYTES;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
+    const GAS uint8_t* tb = (const GAS uint8_t*)(((uint64_t)hi << 32) | (uint64_t)lo);
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      a[2 * s] = ldnt((const GAS u32x4_a4*)(tb + (uint32_t)s * SUB_BYTES + woff));
+      a[2 * s + 1] = ldnt((const GAS u32x4_a4*)(tb + (uint32_t)s * SUB_BYTES + woff + 16u));
+    }
+  };
+  auto finish = [&](int wt, const u32x4 (&a)[8]) __attribute__((always_inline)) {
+    const int64_t rem = (int64_t)p.num_docs - (int64_t)wt * PG_WAVE_DOCS;
+    const bool whole = rem >= PG_WAVE_DOCS;   // wave-uniform
+    uint32_t tile_sum = 0;                    // 32 ids below 2^24 per lane and tile
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      uint32_t id[8];
+      oct_decode_wide<B>(a[2 * s], a[2 * s + 1], wsel, id);
+      const int64_t first = (int64_t)s * OCT_SUB_DOCS + (int64_t)lane * 8;   // the lane's first doc inside the tile
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        if (whole || first + j < rem) {
+          tile_sum += id[j];
+          mn = id[j] < mn ? id[j] : mn;
+          mx = id[j] > mx ? id[j] : mx;
+          my_docs++;
+          if (GATHER) sum_vals += (long long)dict[id[j]];
+        }
+      }
+    }
+    sum_ids += tile_sum;
+  };
+
+  u32x4 a[2][8];
+  const int wt0 = (int)blockIdx.x * PG_WAVES_PER_BLOCK + wave;
+  const int n_mine = wt0 < p.n_wtiles ? (p.n_wtiles - wt0 + step - 1) / step : 0;
+  if (n_mine > 0) {
+    __builtin_amdgcn_sched_barrier(0); issue(wt0, a[0]);
+    __builtin_amdgcn_sched_barrier(0); issue(wt0 + step, a[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    int i = 0;
+    for (; i + 1 < n_mine; i += 2) {
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        finish(wt0 + (i + k) * step, a[k]);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(wt0 + (i + k + 2) * step, a[k]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (i < n_mine) finish(wt0 + i * step, a[0]);   // wave-uniform
+  }
+}
+
+template <bool GATHER>
+__device__ __forceinline__ void nogroup_dict_body(const PgQueryPlan& p) {
+  __shared__ uint32_t s_stat[PG_MAX_STATS];
+  __shared__ long long s_acc[PG_MAX_OPS];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = uniform(t >> 6);
+  if (t < PG_MAX_STATS) s_stat[t] = 0;
+  if (t < p.n_ops) s_acc[t] = (long long)pg_acc_identity(p.ops[t].fn, p.ops[t].is_float);
+  __syncthreads();
+  uint32_t my_docs = 0, mn = 0xFFFFFFFFu, mx = 0;
+  unsigned long long sum_ids = 0;
+  long long sum_vals = 0;
+  switch (uniform(p.nogroup_bits)) {   // wave-uniform, once
+#define NGD_CASE(B) case B: nogroup_dict_loop<B, GATHER>(p, lane, wave, my_docs, sum_ids, sum_vals, mn, mx); break;
+    NGD_CASE(1) NGD_CASE(2) NGD_CASE(3) NGD_CASE(4) NGD_CASE(5) NGD_CASE(6) NGD_CASE(7) NGD_CASE(8) NGD_CASE(9) NGD_CASE(10) NGD_CASE(11) NGD_CASE(12)
+    NGD_CASE(13) NGD_CASE(14) NGD_CASE(15) NGD_CASE(16) NGD_CASE(17) NGD_CASE(18) NGD_CASE(19) NGD_CASE(20) NGD_CASE(21) NGD_CASE(22) NGD_CASE(23)
+#undef NGD_CASE
+    default: nogroup_dict_loop<24, GATHER>(p, lane, wave, my_docs, sum_ids, sum_vals, mn, mx); break;
+  }
+  if (my_docs) {
+    const GAS int32_t* dict = gptr<int32_t>(reinterpret_cast<const uint8_t*>(p.srcs[p.nogroup_src].dict));
+    const long long base = (long long)p.nogroup_base, stp = (long long)p.nogroup_step;
+    const long long vmin = GATHER ? (long long)dict[mn] : base + stp * (long long)mn;
+    const long long vmax = GATHER ? (long long)dict[mx] : base + stp * (long long)mx;
+    const long long vsum = GATHER ? sum_vals : base * (long long)my_docs + stp * (long long)sum_ids;
+    for (int o = 0; o < p.n_ops; o++) {
+      const PgAccOp op = p.ops[o];
+      if (op.fn == PG_ACC_COUNT) atomicAdd(reinterpret_cast<unsigned long long*>(&s_acc[o]), (unsigned long long)my_docs);
+      else if (op.fn == PG_ACC_SUM) atomicAdd(reinterpret_cast<unsigned long long*>(&s_acc[o]), (unsigned long long)vsum);
+      else if (op.fn == PG_ACC_MIN) atomicMin(&s_acc[o], vmin);
+      else atomicMax(&s_acc[o], vmax);
+    }
+  }
+  const uint32_t wsum = wave_sum_u32(my_docs);
+  if (lane == 0 && wsum) atomicAdd(&s_stat[0], wsum);
+  __syncthreads();
+  if (t < PG_MAX_STATS && s_stat[t]) atomicAdd(&p.stats[t], (unsigned long long)s_stat[t]);
+  if (t < p.n_ops) p.partials[(int64_t)blockIdx.x * p.n_ops + t] = (int64_t)s_acc[t];
+}
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_nogroup_da(const PgQueryPlan p) { nogroup_dict_body<false>(p); }
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_nogroup_dg(const PgQueryPlan p) { nogroup_dict_body<true>(p); }

@@ -2363,6 +2363,31 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
       if (has_scan) D.fast_scan = scan_leaf;
     }
   }
+  // pg_nogroup_d (pg_kernels_scan.hip, round 6): AggregationOperator over MatchAllFilterOperator with integer accumulators over ONE dictionary-encoded
+  // INT column — the fixed-bit dictId stream summed / min-ed / max-ed in registers (a sorted dictionary: the extreme values sit at the extreme
+  // dictIds), values through the arithmetic form of the dictionary or gathered for SUM (DataFetcher.java:335-386)
+  D.nogroup_d = 0;
+  if (q->n_group_by == 0 && D.agg_mode == PG_AGG_SINGLE && P.fast_filter == -1 && D.n_index_instr == 0 && D.tail_posting < 0 && D.n_aux == 0 && D.n_ops > 0 &&
+      !D.mv && !knobs().no_scan_pipe) {
+    bool ok = true;
+    int src = -1;
+    for (int o = 0; o < D.n_ops && ok; o++) {
+      if (D.ops[o].src < 0) { ok = D.ops[o].fn == PG_ACC_COUNT; continue; }
+      if (D.ops[o].is_float != PG_ACCV_INT || D.ops[o].limb != 0) ok = false;
+      if (src >= 0 && D.ops[o].src != src) ok = false;
+      src = D.ops[o].src;
+    }
+    if (ok && src >= 0) {
+      const Column* c = srcs[(size_t)src];
+      if (D.mv_src_offsets[src] == nullptr && !D.mv_src_len[src] && D.srcs[src].col_kind == PG_COL_FIXED_BIT && c->has_dictionary && !c->is_mv &&
+          c->data_type == PG_TYPE_INT && c->val_type == PG_V_I32 && c->bits >= 1 && c->bits <= 24) {
+        if (c->dict_affine && c->dict_step > 0) { D.nogroup_d = 1; D.nogroup_base = c->dict_base; D.nogroup_step = c->dict_step; }
+        else if (D.srcs[src].dict != nullptr) { D.nogroup_d = 2; D.nogroup_base = 0; D.nogroup_step = 0; }
+        D.nogroup_src = src;
+        D.nogroup_bits = c->bits;
+      }
+    }
+  }
   // LDS tables that miss the narrow shape only by column width (group columns > 8 bits, LONG / DOUBLE sources, 64-bit
   // dictionaries) keep the 1024-thread kernels and run the general aggregator there (pg_fast_none_w / pg_fast_multi_w)
   P.wide_agg = !P.fast_agg && (D.agg_mode == PG_AGG_LDS || D.agg_mode == PG_AGG_SINGLE) && D.n_aux == 0 && P.first_doc_op < 0;

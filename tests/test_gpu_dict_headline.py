@@ -144,3 +144,56 @@ def test_dictionary_encoded_headline_behind_an_upsert_snapshot(gpu_api, oracle_a
                 assert _as_s(gb.stats.kernel.decode()).replace("pg_fast_dictrange_wt", "pg_fast_dictrange_st") == kernel, (sql, keep)
     g.destroy()
     o.destroy()
+
+
+# ---- no GROUP BY, no filter over one dictionary-encoded INT column: pg_nogroup_da (arithmetic dictionary) / pg_nogroup_dg (gathered) -----------
+NOGROUP = [
+    ("SELECT SUM(m_d), MIN(m_d), MAX(m_d), COUNT(*) FROM gpuBench", "pg_nogroup_da"),
+    ("SELECT AVG(m_d), MINMAXRANGE(m_d) FROM gpuBench", "pg_nogroup_da"),
+    ("SELECT SUM(m_s), MIN(m_s), MAX(m_s), COUNT(*) FROM gpuBench", "pg_nogroup_dg"),
+    ("SELECT SUM(r_int_s) FROM gpuBench", "pg_nogroup_dg"),
+    ("SELECT SUM(g1), MAX(g1), MIN(g1) FROM gpuBench", "pg_nogroup_da"),          # a 7-bit column
+    ("SELECT SUM(c_inv1), COUNT(*) FROM gpuBench", "pg_nogroup_da"),
+    ("SELECT SUM(m_d), SUM(m) FROM gpuBench", None),                               # two columns: not this kernel
+]
+
+
+@pytest.mark.parametrize("sql,kernel", NOGROUP)
+def test_no_group_by_over_a_dictionary_encoded_column(pair, sql, kernel):
+    g, o = pair
+    gb, ob = g.execute(sql), o.execute(sql)
+    assert gb.rows() == ob.rows()
+    for f in STATS:
+        assert getattr(gb.stats, f) == getattr(ob.stats, f), f
+    ran = gb.stats.kernel.decode()
+    if kernel and not os.environ.get("PG_NO_SCAN_PIPE") and not os.environ.get("PG_FORCE_INTERPRETER"):
+        assert ran == kernel, sql      # no index involved: every segment size takes it
+    elif not kernel:
+        assert not ran.startswith("pg_nogroup_d")
+
+
+@pytest.mark.parametrize("n", [1, 511, 513, 2049, 300_007])
+def test_no_group_by_dictionary_widths(gpu_api, oracle_api, n):
+    """every dictId width the template is instantiated for that a segment of this size can hold, arithmetic and not"""
+    from pinot_amd.segment import build_segment
+    rng = np.random.default_rng(n)
+    data, schema = {}, {}
+    for card in (2, 5, 17, 130, 300, 1000, 5000, 20000, 70000, 200000):
+        if card > max(n, 2):
+            continue
+        ids = rng.integers(0, card, n)
+        ids[: min(card, n)] = np.arange(min(card, n))                                             # every dictionary value occurs
+        data[f"a{card}"] = (ids * 3 - 7).astype(np.int32)                                          # value = -7 + 3 x dictId
+        data[f"s{card}"] = np.sort(rng.choice(4_000_000, card, replace=False) - 2_000_000)[ids].astype(np.int32)   # no arithmetic form
+        schema[f"a{card}"] = schema[f"s{card}"] = "INT"
+    host = build_segment("widths", data, schema)
+    g, o = NativeSegment(gpu_api, host), NativeSegment(oracle_api, host)
+    for name, values in data.items():
+        sql = f"SELECT SUM({name}), MIN({name}), MAX({name}), COUNT(*), AVG({name}) FROM widths"
+        gb, ob = g.execute(sql), o.execute(sql)
+        assert gb.rows() == ob.rows(), name
+        v = values.astype(np.int64)
+        assert gb.aggregation_result()[:4] == [float(v.sum()), float(v.min()), float(v.max()), n], name
+        if not os.environ.get("PG_NO_SCAN_PIPE") and not os.environ.get("PG_FORCE_INTERPRETER"):
+            assert gb.stats.kernel.decode() in ("pg_nogroup_da", "pg_nogroup_dg"), (name, gb.stats.kernel)
+    g.destroy(); o.destroy()
