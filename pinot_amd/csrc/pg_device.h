@@ -406,8 +406,9 @@ struct PgQueryPlan {
   int32_t specd_base, specd_step;
   int32_t specd_dma;                // the headline shape's LDS-DMA kernels (two column areas per strip): pg_fast_dictrange_s_*_dma
   // pg_nogroup_d (pg_kernels_scan.hip): no GROUP BY, no filter, integer accumulators over ONE dictionary-encoded INT column (<= 24-bit dictIds of a
-  // sorted dictionary): 0 no; 1 value = nogroup_base + nogroup_step x dictId (arithmetic dictionary); 2 srcs[nogroup_src].dict[dictId]
-  int32_t nogroup_d, nogroup_src, nogroup_bits, nogroup_pad;
+  // sorted dictionary): 0 no; 1 value = nogroup_base + nogroup_step x dictId (arithmetic dictionary); 2 srcs[nogroup_src].dict[dictId] — from a copy in
+  // the workgroup's LDS when nogroup_lds_card > 0 (the dictionary's cardinality: it fits)
+  int32_t nogroup_d, nogroup_src, nogroup_bits, nogroup_lds_card;
   int64_t nogroup_base, nogroup_step;
   int32_t mvg_has_entries;          // pg_mv_aggr_*: an accumulator reads the entries' values (else only their number)
   int32_t mvg_dict_card;            // ... and the entries' dictionary (<= 4 096 values) is copied into LDS behind the table; 0: gathered from global memory

@@ -19,7 +19,7 @@ PG_DECL_GENERIC
 PG_DECL_FAST(pg_fast_none_f) PG_DECL_FAST(pg_fast_none_a) PG_DECL_FAST(pg_fast_i32range_f) PG_DECL_FAST(pg_fast_i32range_a)
 PG_DECL_FAST(pg_fast_dictrange_f) PG_DECL_FAST(pg_fast_dictrange_a) PG_DECL_FAST(pg_fast_dictlut_f) PG_DECL_FAST(pg_fast_dictlut_a)
 PG_DECL_FAST(pg_fast_multi_f) PG_DECL_FAST(pg_fast_multi_a) PG_DECL_FAST(pg_fast_multi_w) PG_DECL_FAST(pg_fast_none_w)
-PG_DECL_FAST(pg_nogroup_s1) PG_DECL_FAST(pg_nogroup_s2) PG_DECL_FAST(pg_nogroup_da) PG_DECL_FAST(pg_nogroup_dg) PG_DECL_FAST(pg_fast_i32range_d) PG_DECL_FAST(pg_fast_i32range_p) PG_DECL_FAST(pg_fast_i32range_fp) PG_DECL_FAST(pg_fast_i32range_s) PG_DECL_FAST(pg_spec_none) PG_DECL_FAST(pg_spec_scan) PG_DECL_FAST(pg_spec_index) PG_DECL_FAST(pg_fast_i32range_st)
+PG_DECL_FAST(pg_nogroup_s1) PG_DECL_FAST(pg_nogroup_s2) PG_DECL_FAST(pg_nogroup_da) PG_DECL_FAST(pg_nogroup_dg) PG_DECL_FAST(pg_nogroup_dl) PG_DECL_FAST(pg_fast_i32range_d) PG_DECL_FAST(pg_fast_i32range_p) PG_DECL_FAST(pg_fast_i32range_fp) PG_DECL_FAST(pg_fast_i32range_s) PG_DECL_FAST(pg_spec_none) PG_DECL_FAST(pg_spec_scan) PG_DECL_FAST(pg_spec_index) PG_DECL_FAST(pg_fast_i32range_st)
 // pg_kernels_specd.hip: the loader / consumer frame over dictionary-encoded scan / value columns (_r raw INT values, _a arithmetic dictionary, _g gathered)
 PG_DECL_FAST(pg_fast_dictrange_s_r_dma) PG_DECL_FAST(pg_fast_dictrange_s_a_dma) PG_DECL_FAST(pg_fast_dictrange_s_g_dma) PG_DECL_FAST(pg_fast_dictrange_s_r) PG_DECL_FAST(pg_fast_dictrange_st_r) PG_DECL_FAST(pg_specd_none_r) PG_DECL_FAST(pg_specd_scan_r) PG_DECL_FAST(pg_specd_index_r) PG_DECL_FAST(pg_fast_dictrange_s_a) PG_DECL_FAST(pg_fast_dictrange_st_a) PG_DECL_FAST(pg_specd_none_a) PG_DECL_FAST(pg_specd_scan_a) PG_DECL_FAST(pg_specd_index_a) PG_DECL_FAST(pg_fast_dictrange_s_g) PG_DECL_FAST(pg_fast_dictrange_st_g) PG_DECL_FAST(pg_specd_none_g) PG_DECL_FAST(pg_specd_scan_g) PG_DECL_FAST(pg_specd_index_g)
 // pg_kernels_specw.hip: the same shapes with a shared stage per workgroup (whole stages requested as long rows straight into LDS)
@@ -336,6 +336,7 @@ void use_device(int ordinal) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
       for (QueryKernel k : {pg_fast_dictrange_w_r, pg_fast_dictrange_wt_r, pg_specw_none_r, pg_specw_scan_r, pg_specw_index_r, pg_fast_dictrange_w_a, pg_fast_dictrange_wt_a, pg_specw_none_a, pg_specw_scan_a, pg_specw_index_a, pg_fast_dictrange_w_g, pg_fast_dictrange_wt_g, pg_specw_none_g, pg_specw_scan_g, pg_specw_index_g})
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pg_nogroup_dl), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
       for (QueryKernel k : {pg_mv_group_4, pg_mv_group_8, pg_mv_aggr_4, pg_mv_aggr_8})
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8192);
       for (QueryKernel k : {pg_mv_query_f, pg_mv_query_l, pg_mv_query_g})   // 10.5 KB of static LDS (per-wavefront entry bitmaps): the planner's 144 KB still fit
@@ -480,7 +481,11 @@ extern "C" void pg_trim_launch_select(const PgTrimArgs* args, int grid, hipStrea
 typedef void (*QueryKernel)(const PgQueryPlan);
 static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char** name) {
   const bool agg = agg_mode != PG_AGG_NONE;
-  if (uses_nogroup_dict(P, agg_mode)) { *name = P.dev.nogroup_d == 1 ? "pg_nogroup_da" : "pg_nogroup_dg"; return P.dev.nogroup_d == 1 ? pg_nogroup_da : pg_nogroup_dg; }
+  if (uses_nogroup_dict(P, agg_mode)) {
+    if (P.dev.nogroup_d == 1) { *name = "pg_nogroup_da"; return pg_nogroup_da; }
+    *name = P.dev.nogroup_lds_card > 0 ? "pg_nogroup_dl" : "pg_nogroup_dg";
+    return P.dev.nogroup_lds_card > 0 ? pg_nogroup_dl : pg_nogroup_dg;
+  }
   if (const int ns = uses_nogroup_stream(P, agg_mode)) { *name = ns == 1 ? "pg_nogroup_s1" : "pg_nogroup_s2"; return ns == 1 ? pg_nogroup_s1 : pg_nogroup_s2; }
   if (uses_fast_kernel(P, agg_mode)) {
     if (agg && uses_pipe_wide(P, agg_mode)) {
@@ -694,10 +699,11 @@ static LaunchShape launch_shape(const CompiledPlan& P, int n_wtiles, int agg_mod
   if (uses_scan_kernel(P, agg_mode) || uses_nogroup_stream(P, agg_mode) || uses_nogroup_dict(P, agg_mode)) {
     // tuning knob; the dictId stream of pg_nogroup_d* is 1-3 bytes per doc — 5 KB per tile at 20 bits: two workgroups per CU keep as many bytes in
     // flight as one does over a raw column (0.143 -> 0.102 ms per 2 x 10^8 docs; three to five: 0.105-0.112, profiles/r06_nogroup_stream.txt)
-    const int wgs_per_cu = knobs().scan_wgs_per_cu * (uses_nogroup_dict(P, agg_mode) ? 2 : 1);
+    const size_t dict_lds = uses_nogroup_dict(P, agg_mode) && P.dev.nogroup_d == 2 ? (size_t)P.dev.nogroup_lds_card * 4 : 0;   // pg_nogroup_dl: the dictionary's copy
+    const int wgs_per_cu = knobs().scan_wgs_per_cu * (uses_nogroup_dict(P, agg_mode) && 2 * (dict_lds + 4096) <= lds_per_cu() ? 2 : 1);
     const int waves = pg_scan_waves_per_block;
     int grid = std::min((n_wtiles + waves - 1) / waves, num_cus() * std::max(wgs_per_cu, 1));
-    return {std::max(grid, 1), waves * 64, 0};
+    return {std::max(grid, 1), waves * 64, dict_lds};
   }
   if (uses_mvg(P, agg_mode))   // one 16-wavefront workgroup per CU; the table and a trash slot per lane and accumulator
     return {std::max(1, std::min((n_wtiles + PG_WAVES_PER_BLOCK - 1) / PG_WAVES_PER_BLOCK, num_cus())), PG_BLOCK, lds + 64 + 512 * (size_t)P.dev.n_ops + (size_t)P.dev.mvg_dict_card * 4};

@@ -207,12 +207,13 @@ extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_nogroup_s2(const PgQue
 // whole wave tile — four sub-tiles, eight 16-byte loads per lane — double-buffered per wavefront) and the DICTIDS are accumulated: their sum, their
 // minimum and maximum.  The dictionary is sorted, so MIN / MAX are its values at the extreme dictIds, and SUM is nogroup_base x docs +
 // nogroup_step x sum(dictIds) for an arithmetic dictionary (nogroup_d = 1); any other dictionary (nogroup_d = 2) is gathered per doc from its
-// native-endian copy for SUM (DataFetcher.java:335-386).  The width is a template parameter of the loop (one scalar branch per kernel).
+// native-endian copy for SUM (DataFetcher.java:335-386) — from a copy in the workgroup's LDS where it fits (pg_nogroup_dl: <= 36 K values).  The
+// width is a template parameter of the loop (one scalar branch per kernel).
 #include "pg_oct_layout.h"
 
-template <int B, bool GATHER>
+template <int B, int MODE>   // MODE 0: arithmetic dictionary; 1: gathered from HBM; 2: gathered from the copy in LDS
 __device__ __forceinline__ void nogroup_dict_loop(const PgQueryPlan& p, int lane, int wave, uint32_t& my_docs, unsigned long long& sum_ids, long long& sum_vals, uint32_t& mn,
-                                                  uint32_t& mx) {
+                                                  uint32_t& mx, const int32_t* lds_dict) {
   const PgValueSrc& V = p.srcs[p.nogroup_src];
   const GAS int32_t* dict = gptr<int32_t>(reinterpret_cast<const uint8_t*>(V.dict));
   const uint32_t woff = ((uint32_t)lane * (uint32_t)B) & ~3u;                 // the lane's window: dword-aligned start, byte selector
@@ -248,7 +249,8 @@ __device__ __forceinline__ void nogroup_dict_loop(const PgQueryPlan& p, int lane
           mn = id[j] < mn ? id[j] : mn;
           mx = id[j] > mx ? id[j] : mx;
           my_docs++;
-          if (GATHER) sum_vals += (long long)dict[id[j]];
+          if (MODE == 1) sum_vals += (long long)dict[id[j]];
+          if (MODE == 2) sum_vals += (long long)lds_dict[id[j]];
         }
       }
     }
@@ -276,25 +278,32 @@ __device__ __forceinline__ void nogroup_dict_loop(const PgQueryPlan& p, int lane
   }
 }
 
-template <bool GATHER>
+template <int MODE>
 __device__ __forceinline__ void nogroup_dict_body(const PgQueryPlan& p) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t smem[];
   __shared__ uint32_t s_stat[PG_MAX_STATS];
   __shared__ long long s_acc[PG_MAX_OPS];
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = uniform(t >> 6);
+  constexpr bool GATHER = MODE != 0;
+  int32_t* lds_dict = reinterpret_cast<int32_t*>(smem);
   if (t < PG_MAX_STATS) s_stat[t] = 0;
   if (t < p.n_ops) s_acc[t] = (long long)pg_acc_identity(p.ops[t].fn, p.ops[t].is_float);
+  if (MODE == 2) {   // the dictionary into LDS, once per workgroup
+    const GAS int32_t* src = gptr<int32_t>(reinterpret_cast<const uint8_t*>(p.srcs[p.nogroup_src].dict));
+    for (int i = t; i < p.nogroup_lds_card; i += PG_BLOCK) lds_dict[i] = src[i];
+  }
   __syncthreads();
   uint32_t my_docs = 0, mn = 0xFFFFFFFFu, mx = 0;
   unsigned long long sum_ids = 0;
   long long sum_vals = 0;
   switch (uniform(p.nogroup_bits)) {   // wave-uniform, once
-#define NGD_CASE(B) case B: nogroup_dict_loop<B, GATHER>(p, lane, wave, my_docs, sum_ids, sum_vals, mn, mx); break;
+#define NGD_CASE(B) case B: nogroup_dict_loop<B, MODE>(p, lane, wave, my_docs, sum_ids, sum_vals, mn, mx, lds_dict); break;
     NGD_CASE(1) NGD_CASE(2) NGD_CASE(3) NGD_CASE(4) NGD_CASE(5) NGD_CASE(6) NGD_CASE(7) NGD_CASE(8) NGD_CASE(9) NGD_CASE(10) NGD_CASE(11) NGD_CASE(12)
     NGD_CASE(13) NGD_CASE(14) NGD_CASE(15) NGD_CASE(16) NGD_CASE(17) NGD_CASE(18) NGD_CASE(19) NGD_CASE(20) NGD_CASE(21) NGD_CASE(22) NGD_CASE(23)
 #undef NGD_CASE
-    default: nogroup_dict_loop<24, GATHER>(p, lane, wave, my_docs, sum_ids, sum_vals, mn, mx); break;
+    default: nogroup_dict_loop<24, MODE>(p, lane, wave, my_docs, sum_ids, sum_vals, mn, mx, lds_dict); break;
   }
   if (my_docs) {
     const GAS int32_t* dict = gptr<int32_t>(reinterpret_cast<const uint8_t*>(p.srcs[p.nogroup_src].dict));
@@ -316,5 +325,6 @@ __device__ __forceinline__ void nogroup_dict_body(const PgQueryPlan& p) {
   if (t < PG_MAX_STATS && s_stat[t]) atomicAdd(&p.stats[t], (unsigned long long)s_stat[t]);
   if (t < p.n_ops) p.partials[(int64_t)blockIdx.x * p.n_ops + t] = (int64_t)s_acc[t];
 }
-extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_nogroup_da(const PgQueryPlan p) { nogroup_dict_body<false>(p); }
-extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_nogroup_dg(const PgQueryPlan p) { nogroup_dict_body<true>(p); }
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_nogroup_da(const PgQueryPlan p) { nogroup_dict_body<0>(p); }
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_nogroup_dg(const PgQueryPlan p) { nogroup_dict_body<1>(p); }
+extern "C" __global__ void __launch_bounds__(PG_BLOCK) pg_nogroup_dl(const PgQueryPlan p) { nogroup_dict_body<2>(p); }

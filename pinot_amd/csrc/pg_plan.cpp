@@ -2367,6 +2367,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
   // INT column — the fixed-bit dictId stream summed / min-ed / max-ed in registers (a sorted dictionary: the extreme values sit at the extreme
   // dictIds), values through the arithmetic form of the dictionary or gathered for SUM (DataFetcher.java:335-386)
   D.nogroup_d = 0;
+  D.nogroup_lds_card = 0;
   if (q->n_group_by == 0 && D.agg_mode == PG_AGG_SINGLE && P.fast_filter == -1 && D.n_index_instr == 0 && D.tail_posting < 0 && D.n_aux == 0 && D.n_ops > 0 &&
       !D.mv && !knobs().no_scan_pipe) {
     bool ok = true;
@@ -2382,7 +2383,10 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
       if (D.mv_src_offsets[src] == nullptr && !D.mv_src_len[src] && D.srcs[src].col_kind == PG_COL_FIXED_BIT && c->has_dictionary && !c->is_mv &&
           c->data_type == PG_TYPE_INT && c->val_type == PG_V_I32 && c->bits >= 1 && c->bits <= 24) {
         if (c->dict_affine && c->dict_step > 0) { D.nogroup_d = 1; D.nogroup_base = c->dict_base; D.nogroup_step = c->dict_step; }
-        else if (D.srcs[src].dict != nullptr) { D.nogroup_d = 2; D.nogroup_base = 0; D.nogroup_step = 0; }
+        else if (D.srcs[src].dict != nullptr) {
+          D.nogroup_d = 2; D.nogroup_base = 0; D.nogroup_step = 0;
+          D.nogroup_lds_card = c->cardinality <= 36 * 1024 ? c->cardinality : 0;   // 144 KB of LDS
+        }
         D.nogroup_src = src;
         D.nogroup_bits = c->bits;
       }

@@ -36,7 +36,10 @@ if args.set == "wide":
     seg.add_column(build_column("d64", (mvals * 0.5).astype(np.float64), "DOUBLE", dictionary=False), keep_host_buffers=False)
     w = (synth.values_numpy(synth.GPU_BENCH["u"], synth.SEED_BASE, n) % 2000).astype(np.int32)
     seg.add_column(build_column("w1", w, "INT"), keep_host_buffers=False)
-    del mvals, w
+    # a metric behind a 20 000-value dictionary that is NOT arithmetic (15-bit dictIds): its values are gathered — from LDS where the dictionary fits
+    sp = np.sort(np.random.default_rng(3).choice(4_000_000, 20000, replace=False)).astype(np.int32)
+    seg.add_column(build_column("ms20k", sp[mvals % 20000], "INT"), keep_host_buffers=False)
+    del mvals, w, sp
 
 MV_BYTES = {}
 if args.set == "mv":
@@ -159,6 +162,7 @@ QUERIES_WIDE = {   # LDS-table aggregations over 64-bit sources / an 11-bit grou
     "sum(m) group w1 (2000 groups)": ("SELECT w1, SUM(m), COUNT(*) FROM t GROUP BY w1 LIMIT 5000", 5.375),
     "filtered sum(m64) group w1": ("SELECT w1, SUM(m64) FROM t WHERE r_int BETWEEN 250000 AND 749999 GROUP BY w1 LIMIT 5000", 13.375),
     "sum(m64) no group": ("SELECT SUM(m64), MIN(m64), COUNT(*) FROM t WHERE c_inv2 = 1", 8.125),
+    "no group: sum min max count(ms20k)": ("SELECT SUM(ms20k), MIN(ms20k), MAX(ms20k), COUNT(*) FROM t", 1.875),
 }
 QUERIES_DICT = {   # config 3 in Pinot's default encoding: 20-bit dictId streams for the scan column and the value column (2.5 B/row each)
     "cfg3 raw (reference point)": (synth.QUERY_CFG3, 9.625),
