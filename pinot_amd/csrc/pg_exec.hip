@@ -405,10 +405,10 @@ static bool uses_nogroup_dict(const CompiledPlan& P, int agg_mode) {
 // pg_fast_dictrange_s family (pg_kernels_specd.hip): the loader / consumer frame over dictionary-encoded scan / value columns — decided at plan
 // time (PgQueryPlan::specd), whatever the filter lets through
 static bool uses_specd(const CompiledPlan& P, int agg_mode) {
-  return P.dev.specd && agg_mode == PG_AGG_LDS && uses_fast_kernel(P, agg_mode) && P.fast_agg && !P.wide_agg && !knobs().no_specd;
+  return P.dev.specd && (agg_mode == PG_AGG_LDS || (agg_mode == PG_AGG_SINGLE && P.dev.n_group_cols == 0)) && uses_fast_kernel(P, agg_mode) && P.fast_agg && !P.wide_agg && !knobs().no_specd;
 }
 static size_t specd_stage_bytes(const CompiledPlan& P) {
-  return ((size_t)pg_specd_stage_bytes(P.dev.specd_sbits, P.dev.specd_vbits, P.dev.gcols[0].bits, P.dev.n_group_cols > 1 ? P.dev.gcols[1].bits : 0, P.dev.specd_dma ? 2 : 1) + 15) & ~(size_t)15;
+  return ((size_t)pg_specd_stage_bytes(P.dev.specd_sbits, P.dev.specd_vbits, P.dev.n_group_cols > 0 ? P.dev.gcols[0].bits : 0, P.dev.n_group_cols > 1 ? P.dev.gcols[1].bits : 0, P.dev.specd_dma ? 2 : 1) + 15) & ~(size_t)15;
 }
 // ... in the shared-stage frame (PgQueryPlan::specd == 2, pg_kernels_specw.hip): two stage buffers + one selection list per wavefront
 static bool uses_specw(const CompiledPlan& P, int agg_mode) { return uses_specd(P, agg_mode) && P.dev.specd == 2; }

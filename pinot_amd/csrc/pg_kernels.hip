@@ -1174,18 +1174,38 @@ DEVFN void fast_aggregate_wtile(const PgQueryPlan& p, uint32_t mask_all, int wti
 }
 
 // Shared epilogue: statistics and the flush of the LDS accumulator table into this workgroup's partial table.
-DEVFN void flush_workgroup(const PgQueryPlan& p, const int64_t* lds_table, const uint32_t* s_stat, bool lds_agg, int t) {
+DEVFN void flush_workgroup(const PgQueryPlan& p, int64_t* lds_table, const uint32_t* s_stat, bool lds_agg, int t) {
   if (t < PG_MAX_STATS && s_stat[t]) atomicAdd(&p.stats[t], (unsigned long long)s_stat[t]);
   if (lds_agg) {
     const int R = p.replicas;
     const int groups = p.agg_mode == PG_AGG_LDS_PART ? p.part_groups : p.n_groups;   // this workgroup's table: [n_ops][groups]
     const int64_t n_out = (int64_t)p.n_ops * groups;
     int64_t* out = p.partials + (int64_t)blockIdx.x * n_out;
+    // Few slots with many replicas (no GROUP BY: a replica per lane, PG_AGG_SINGLE): one lane per slot walking 1 024 replicas is a chain of
+    // ~70-cycle LDS round trips — 30-60 us at the end of every such kernel.  Every lane folds its replicas into replica 0 instead (integer
+    // folds commute; floating sums keep their one order below).
+    const bool wide_fold = R >= 64 && n_out <= PG_MAX_OPS;   // workgroup-uniform
+    if (wide_fold) {
+      for (int i = 0; i < (int)n_out; i++) {
+        const PgAccOp op = p.ops[i / groups];
+        if (op.fn == PG_ACC_SUM && op.is_float == PG_ACCV_DOUBLE) continue;
+        long long* s0 = reinterpret_cast<long long*>(lds_table + (int64_t)i * R);
+        for (int r = t; r < R; r += PG_BLOCK) {
+          if (r == 0) continue;
+          const long long v = s0[r];
+          if (op.fn == PG_ACC_COUNT || op.fn == PG_ACC_SUM) atomicAdd(reinterpret_cast<unsigned long long*>(s0), (unsigned long long)v);
+          else if (op.fn == PG_ACC_MIN) atomicMin(s0, v);
+          else atomicMax(s0, v);
+        }
+      }
+      __syncthreads();
+    }
     for (int64_t i = t; i < n_out; i += PG_BLOCK) {
       const int o = (int)(i / groups);
       const PgAccOp op = p.ops[o];
       const int64_t* src = lds_table + i * R;   // (o * G + g) * R
       int64_t acc = src[0];
+      if (wide_fold && !(op.fn == PG_ACC_SUM && op.is_float == PG_ACCV_DOUBLE)) { out[i] = acc; continue; }
       if (op.fn == PG_ACC_SUM && op.is_float == PG_ACCV_DOUBLE) {
         double d = __longlong_as_double(acc);
         for (int r = 1; r < R; r++) d += __longlong_as_double(src[r]);

@@ -75,7 +75,7 @@ DEVFN uint32_t or_reduce4(uint32_t v) {   // OR across aligned groups of 4 lanes
 }
 
 // the loads of one sub-tile in flight: two 16-byte pieces per lane of the scan and the value column (64 x bits <= 2 048 bytes), one of a group column
-template <int NG> struct SdSub { u32x4 sc[2], va[2], g[NG]; };
+template <int NG> struct SdSub { u32x4 sc[2], va[2], g[NG > 0 ? NG : 1]; };   // NG = 0: no GROUP BY (one group, the slot is the lane's replica)
 // value kinds (PgQueryPlan::specd_vkind)
 enum { SD_V_RAW32 = 1, SD_V_AFFINE = 2, SD_V_GATHER = 3 };
 
@@ -98,7 +98,7 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
     for (uint32_t i = t; i < table_slots; i += PG_BLOCK) lds_table[(size_t)o * table_slots + i] = ident;
   }
   const uint32_t sbits = HAS_SCAN ? (uint32_t)uniform(p.specd_sbits) : 0u, vbits = (uint32_t)uniform(p.specd_vbits);
-  uint32_t gbits[NG];
+  uint32_t gbits[NG > 0 ? NG : 1] = {0u};
 #pragma unroll
   for (int gi = 0; gi < NG; gi++) gbits[gi] = (uint32_t)uniform(p.gcols[gi].bits);
   // this wavefront's strip: one or two column areas [scan bytes][value bytes][group bytes ...], then the selection list
@@ -132,7 +132,7 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
   const uint32_t sc_mask = sbits >= 32u ? 0xFFFFFFFFu : (1u << sbits) - 1u;
   // the 16-byte pieces this lane carries of a sub-tile: piece q of a column covers bytes [1024 q + 16 lane, + 16) of its 64 x bits
   const uint32_t pc = (uint32_t)lane * 16u;
-  bool s_on[2], v_on[2], g_on[NG];
+  bool s_on[2], v_on[2], g_on[NG > 0 ? NG : 1] = {false};
 #pragma unroll
   for (int q = 0; q < 2; q++) { s_on[q] = pc + 1024u * q < 64u * sbits; v_on[q] = pc + 1024u * q < 64u * vbits; }
 #pragma unroll
@@ -151,7 +151,7 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
   const int has_out_words = uniform(p.out_words != nullptr ? 1 : 0);
   const uint32_t vbase = (uint32_t)uniform(p.specd_base), vstep = (uint32_t)uniform(p.specd_step);
   const GAS int32_t* vdict = VK == SD_V_GATHER ? sd_sgpr_ptr<int32_t>(p.srcs[p.pipe_src].dict) : nullptr;
-  uint32_t gmul[NG];
+  uint32_t gmul[NG > 0 ? NG : 1] = {0u};
 #pragma unroll
   for (int gi = 0; gi < NG; gi++) gmul[gi] = (uint32_t)uniform((int)((uint32_t)p.gcols[gi].mult * R));
   const uint32_t list_dummy = OCT_SUB_DOCS + (uint32_t)lane;
@@ -379,7 +379,7 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
       const uint32_t doc0 = live0 ? (uint32_t)my_list[idx0] : 0u;
       const uint32_t doc1 = live1 ? (uint32_t)my_list[idx1] : 0u;
       const u32x2 wv0 = field_pair(cols + off_val, doc0, vbits);
-      u32x2 wg0[NG], wg1[NG];
+      u32x2 wg0[NG > 0 ? NG : 1], wg1[NG > 0 ? NG : 1];
 #pragma unroll
       for (int gi = 0; gi < NG; gi++) wg0[gi] = field_pair(cols + (gi == 0 ? off_g0 : off_g1), doc0, gbits[gi]);
       const u32x2 wv1 = field_pair(cols + off_val, doc1, vbits);
@@ -423,7 +423,7 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
       const bool live = idx < total;
       const uint32_t doc = all ? idx : (live ? (uint32_t)my_list[idx] : 0u);
       const u32x2 wv = field_pair(cols + off_val, doc, vbits);
-      u32x2 wg[NG];
+      u32x2 wg[NG > 0 ? NG : 1];
 #pragma unroll
       for (int gi = 0; gi < NG; gi++) wg[gi] = field_pair(cols + (gi == 0 ? off_g0 : off_g1), doc, gbits[gi]);
       __builtin_amdgcn_sched_barrier(0);
@@ -504,6 +504,21 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
   {
     const int Rr = p.replicas, groups = p.n_groups;
     int64_t* out = p.partials + (int64_t)blockIdx.x * ((int64_t)p.n_ops * groups);
+    if (NG == 0) {   // one group, a replica per lane: every lane folds its replica into replica 0 (one lane walking 1 024 replicas per accumulator took ~60 us)
+      for (int o = 0; o < p.n_ops; o++) {
+        const int fn = p.ops[uniform(o)].fn;
+        long long* slot0 = reinterpret_cast<long long*>(lds_table + (size_t)o * table_slots);
+        if (t > 0 && t < Rr) {
+          const long long v = slot0[t];
+          if (fn == PG_ACC_COUNT || fn == PG_ACC_SUM) atomicAdd(reinterpret_cast<unsigned long long*>(slot0), (unsigned long long)v);
+          else if (fn == PG_ACC_MIN) atomicMin(slot0, v);
+          else atomicMax(slot0, v);
+        }
+      }
+      __syncthreads();
+      if (t < p.n_ops) out[t] = lds_table[(size_t)t * table_slots];
+      return;
+    }
     for (int o = 0; o < p.n_ops; o++) {
       const int fn = p.ops[uniform(o)].fn;   // integer accumulators only (planner)
       for (int gq = t; gq < groups; gq += PG_BLOCK) {
@@ -522,6 +537,7 @@ __device__ __forceinline__ void specd_body(const PgQueryPlan& p) {
 #define PG_SPECD_KERNEL(NAME, IDX, SCAN, TAIL, VK, DMA) \
   extern "C" __global__ void __launch_bounds__(PG_BLOCK, SD_MIN_WAVES_PER_SIMD) NAME(const PgQueryPlan p) { \
     if (p.n_group_cols == 1) specd_body<1, IDX, SCAN, TAIL, VK, DMA>(p); \
+    else if (p.n_group_cols == 0) specd_body<0, IDX, SCAN, TAIL, VK, DMA>(p);   /* no GROUP BY: AggregationOperator's shapes */ \
     else specd_body<2, IDX, SCAN, TAIL, VK, DMA>(p); \
   }
 #define PG_SPECD_FAMILY(SUFFIX, VK) \

@@ -2242,7 +2242,9 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
   // (RangePredicateEvaluatorFactory.java:126-167), the value dictionary.get(dictId) (DataFetcher.java:335-386) — computed for an arithmetic
   // dictionary, gathered from the native-endian copy otherwise.  Raw scan AND raw value stay with pg_fast_i32range_* / pg_pipe_*.
   D.specd = 0;
-  if (!D.pipe_fit && !D.pipe_general && P.fast_agg && D.agg_mode == PG_AGG_LDS && D.n_group_cols >= 1 && D.n_group_cols <= 2 && !knobs().no_specd) {
+  // (no GROUP BY — AggregationOperator's shapes, PG_AGG_SINGLE — runs the same kernels with zero group columns: the slot is the lane's replica)
+  const bool specd_no_group = q->n_group_by == 0 && D.agg_mode == PG_AGG_SINGLE && D.n_group_cols == 0 && D.n_groups == 1 && D.n_aux == 0;
+  if (!D.pipe_fit && !D.pipe_general && P.fast_agg && ((D.agg_mode == PG_AGG_LDS && D.n_group_cols >= 1 && D.n_group_cols <= 2) || specd_no_group) && !knobs().no_specd) {
     bool ok = true;
     int src = -1;
     for (int o = 0; o < D.n_ops && ok; o++) {
@@ -2299,7 +2301,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     // against 65 % of 8 TB/s at 2 x 10^8 docs, profiles/r06_specd_steps.txt step 5: with two buffers only one stage is ever pending), kept as a
     // parity-tested measurement variant
     bool stage_frame = false;
-    if (ok && knobs().specw) {
+    if (ok && knobs().specw && D.n_group_cols > 0) {   // (the shared-stage measurement variant keeps its one or two group columns)
       int n_bm = 0;
       if (D.n_index_instr > 0) {
         n_bm = 8;
@@ -2324,7 +2326,7 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
     bool dma = false;
     if (ok && !stage_frame) {
       auto region = [](int bits) { return bits > 0 ? (size_t)((bits * 64 + 16 + 15) & ~15) : (size_t)0; };
-      const size_t area = (has_scan ? region(sbits) : 0) + region(vbits) + region(D.gcols[0].bits) + (D.n_group_cols > 1 ? region(D.gcols[1].bits) : 0);
+      const size_t area = (has_scan ? region(sbits) : 0) + region(vbits) + (D.n_group_cols > 0 ? region(D.gcols[0].bits) : 0) + (D.n_group_cols > 1 ? region(D.gcols[1].bits) : 0);
       const size_t limit = (size_t)160 * 1024 - 8192;
       const size_t per_replica = (size_t)G * (size_t)D.n_ops * 8;
       auto fixed_of = [&](size_t areas) { return 256 + (size_t)pg_specd_waves_per_block * (areas * area + (512 + 64) * 2) + 16 + 512 * (size_t)D.n_ops; };

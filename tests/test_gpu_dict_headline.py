@@ -51,6 +51,14 @@ QUERIES = [
     ("SELECT g1, g2, COUNT(*), MIN(m_s) FROM gpuBench GROUP BY g1, g2 ORDER BY g1, g2 LIMIT 10000", "pg_specd_none_g"),
     # a scan over a <= 8-bit dictionary column in front of a dictionary-encoded value
     ("SELECT g1, SUM(m_d) FROM gpuBench WHERE g2 BETWEEN 10 AND 30 GROUP BY g1 ORDER BY g1 LIMIT 1000", "pg_specd_scan_a"),
+    # no GROUP BY (AggregationOperator's shapes): the same kernels with zero group columns — the slot is the lane's replica
+    (f"SELECT SUM(m_d), MAX(m_d) FROM gpuBench WHERE {IDX} AND r_int_d BETWEEN 250000 AND 749999", "pg_fast_dictrange_s_a"),
+    (f"SELECT COUNT(*), MIN(m_s), SUM(m_s) FROM gpuBench WHERE {IDX} AND r_int_s BETWEEN 750000 AND 2249999", "pg_fast_dictrange_s_g"),
+    (f"SELECT SUM(m), MIN(m) FROM gpuBench WHERE {IDX} AND r_int_d BETWEEN 250000 AND 749999", "pg_fast_dictrange_s_r"),
+    ("SELECT SUM(m_d), COUNT(*) FROM gpuBench WHERE r_int_d BETWEEN 250000 AND 749999", "pg_specd_scan_a"),
+    ("SELECT AVG(m_d), MINMAXRANGE(m_d) FROM gpuBench WHERE r_int BETWEEN 250000 AND 749999", "pg_specd_scan_a"),
+    (f"SELECT SUM(m_s), MAX(m_s) FROM gpuBench WHERE {IDX}", "pg_specd_index_g"),
+    ("SELECT SUM(m_d) FROM gpuBench WHERE c_inv2 IN (0, 1, 2) AND r_int_d BETWEEN 2000000 AND 3000000", None),   # empty interval: no doc, a NULL-less zero row
 ]
 STATS = ("num_docs_scanned", "num_entries_scanned_in_filter", "num_entries_scanned_post_filter", "num_total_docs")
 
@@ -135,7 +143,9 @@ def test_dictionary_encoded_headline_behind_an_upsert_snapshot(gpu_api, oracle_a
         for sql, kernel in ((synth.QUERY_CFG3_DICT, "pg_fast_dictrange_st_a"), (synth.QUERY_CFG3_SPARSE, "pg_fast_dictrange_st_g"),
                             (synth.QUERY_NORTH_STAR_DICT, "pg_fast_dictrange_st_a"),
                             ("SELECT g1, SUM(m_d) FROM gpuBench WHERE r_int_d BETWEEN 250000 AND 749999 GROUP BY g1 LIMIT 1000", None),
-                            ("SELECT g1, SUM(m_s), MAX(m_s) FROM gpuBench GROUP BY g1 LIMIT 1000", None)):
+                            ("SELECT g1, SUM(m_s), MAX(m_s) FROM gpuBench GROUP BY g1 LIMIT 1000", None),
+                            (f"SELECT SUM(m_d), MAX(m_d), COUNT(*) FROM gpuBench WHERE {IDX} AND r_int_d BETWEEN 250000 AND 749999", "pg_fast_dictrange_st_a"),
+                            ("SELECT SUM(m_s) FROM gpuBench", None)):
             gb, ob = g.execute(sql), o.execute(sql)
             assert gb.rows() == ob.rows(), (sql, keep)
             for f in STATS:
