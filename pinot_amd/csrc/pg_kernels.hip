@@ -73,6 +73,16 @@ DEVFN uint32_t wave_sum_u32(uint32_t v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
+// fold of an int64 accumulator across the wavefront (fn: PgAccFn; COUNT / SUM add, MIN, MAX) — every lane gets the result
+DEVFN int64_t wave_fold_i64(int64_t v, int fn) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, off, 64), hi = __shfl_xor((uint32_t)((uint64_t)v >> 32), off, 64);
+    const int64_t o = (int64_t)(((uint64_t)hi << 32) | (uint64_t)lo);
+    v = fn == PG_ACC_MIN ? (o < v ? o : v) : (fn == PG_ACC_MAX ? (o > v ? o : v) : v + o);
+  }
+  return v;
+}
 
 // ---- mask layouts ---------------------------------------------------------------------------------------------------------
 // linear: lane L holds docs 32L .. 32L+31 of the wave tile (bit i = doc 32L+i) — what bitmap containers deliver
@@ -1174,38 +1184,43 @@ DEVFN void fast_aggregate_wtile(const PgQueryPlan& p, uint32_t mask_all, int wti
 }
 
 // Shared epilogue: statistics and the flush of the LDS accumulator table into this workgroup's partial table.
-DEVFN void flush_workgroup(const PgQueryPlan& p, int64_t* lds_table, const uint32_t* s_stat, bool lds_agg, int t) {
+DEVFN void flush_workgroup(const PgQueryPlan& p, const int64_t* lds_table, const uint32_t* s_stat, bool lds_agg, int t) {
   if (t < PG_MAX_STATS && s_stat[t]) atomicAdd(&p.stats[t], (unsigned long long)s_stat[t]);
   if (lds_agg) {
     const int R = p.replicas;
     const int groups = p.agg_mode == PG_AGG_LDS_PART ? p.part_groups : p.n_groups;   // this workgroup's table: [n_ops][groups]
     const int64_t n_out = (int64_t)p.n_ops * groups;
     int64_t* out = p.partials + (int64_t)blockIdx.x * n_out;
-    // Few slots with many replicas (no GROUP BY: a replica per lane, PG_AGG_SINGLE): one lane per slot walking 1 024 replicas is a chain of
-    // ~70-cycle LDS round trips — 30-60 us at the end of every such kernel.  Every lane folds its replicas into replica 0 instead (integer
-    // folds commute; floating sums keep their one order below).
-    const bool wide_fold = R >= 64 && n_out <= PG_MAX_OPS;   // workgroup-uniform
-    if (wide_fold) {
-      for (int i = 0; i < (int)n_out; i++) {
-        const PgAccOp op = p.ops[i / groups];
-        if (op.fn == PG_ACC_SUM && op.is_float == PG_ACCV_DOUBLE) continue;
-        long long* s0 = reinterpret_cast<long long*>(lds_table + (int64_t)i * R);
-        for (int r = t; r < R; r += PG_BLOCK) {
-          if (r == 0) continue;
-          const long long v = s0[r];
-          if (op.fn == PG_ACC_COUNT || op.fn == PG_ACC_SUM) atomicAdd(reinterpret_cast<unsigned long long*>(s0), (unsigned long long)v);
-          else if (op.fn == PG_ACC_MIN) atomicMin(s0, v);
-          else atomicMax(s0, v);
+    // Many replicas per slot (no GROUP BY — a replica per lane, PG_AGG_SINGLE —, or a handful of groups): one lane per slot walking R replicas is
+    // a chain of ~70-cycle LDS round trips, 30-60 us at the end of the kernel for R = 1 024.  A WAVEFRONT per slot instead: its lanes fold
+    // replicas lane, lane + 64, ... and the wavefront folds the 64 partial results (integer folds commute; floating sums keep their one order).
+    if (R >= 64) {
+      const int lane = t & 63, wave = t >> 6;
+      for (int64_t i = wave; i < n_out; i += PG_BLOCK / 64) {
+        const PgAccOp op = p.ops[(int)(i / groups)];
+        const int64_t* src = lds_table + i * R;
+        if (op.fn == PG_ACC_SUM && op.is_float == PG_ACCV_DOUBLE) {
+          if (lane == 0) {
+            double d = __longlong_as_double(src[0]);
+            for (int r = 1; r < R; r++) d += __longlong_as_double(src[r]);
+            out[i] = __double_as_longlong(d);
+          }
+          continue;
         }
+        int64_t acc = src[lane];
+        if (op.fn == PG_ACC_COUNT || op.fn == PG_ACC_SUM) { for (int r = lane + 64; r < R; r += 64) acc += src[r]; }
+        else if (op.fn == PG_ACC_MIN) { for (int r = lane + 64; r < R; r += 64) acc = src[r] < acc ? src[r] : acc; }
+        else { for (int r = lane + 64; r < R; r += 64) acc = src[r] > acc ? src[r] : acc; }
+        acc = wave_fold_i64(acc, op.fn);
+        if (lane == 0) out[i] = acc;
       }
-      __syncthreads();
+      return;
     }
     for (int64_t i = t; i < n_out; i += PG_BLOCK) {
       const int o = (int)(i / groups);
       const PgAccOp op = p.ops[o];
       const int64_t* src = lds_table + i * R;   // (o * G + g) * R
       int64_t acc = src[0];
-      if (wide_fold && !(op.fn == PG_ACC_SUM && op.is_float == PG_ACCV_DOUBLE)) { out[i] = acc; continue; }
       if (op.fn == PG_ACC_SUM && op.is_float == PG_ACCV_DOUBLE) {
         double d = __longlong_as_double(acc);
         for (int r = 1; r < R; r++) d += __longlong_as_double(src[r]);

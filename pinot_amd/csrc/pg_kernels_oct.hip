@@ -402,11 +402,21 @@ __device__ __forceinline__ void oct_body_count(const PgQueryPlan& p) {
   {   // flush: the partial table [G] (replicas folded), as pg_oct_l leaves it
     const int R = p.replicas;
     int64_t* out = p.partials + (int64_t)blockIdx.x * (int64_t)p.n_groups;
-    for (int64_t i = t; i < p.n_groups; i += PG_BLOCK) {
-      const int64_t* src = table + i * R;
-      int64_t acc = src[0];
-      for (int r = 1; r < R; r++) acc += src[r];
-      out[i] = acc;
+    if (R >= 64) {   // a wavefront per group (16 groups x 1 024 replicas: one lane per group walked them for 30+ us of a 45 us kernel)
+      for (int64_t i = wave; i < p.n_groups; i += PG_BLOCK / 64) {
+        const int64_t* src = table + i * R;
+        int64_t acc = 0;
+        for (int r = lane; r < R; r += 64) acc += src[r];
+        acc = wave_fold_i64(acc, PG_ACC_SUM);
+        if (lane == 0) out[i] = acc;
+      }
+    } else {
+      for (int64_t i = t; i < p.n_groups; i += PG_BLOCK) {
+        const int64_t* src = table + i * R;
+        int64_t acc = src[0];
+        for (int r = 1; r < R; r++) acc += src[r];
+        out[i] = acc;
+      }
     }
   }
 }
