@@ -1579,7 +1579,27 @@ __device__ __forceinline__ void generic_query_body(const PgQueryPlan& p) {
     const int groups = part_agg ? p.part_groups : p.n_groups;   // this workgroup's partial table: [n_ops][groups]
     const int64_t n_out = (int64_t)p.n_ops * groups;
     int64_t* out = p.partials + (int64_t)blockIdx.x * n_out;
-    for (int64_t i = t; i < n_out; i += PG_GENERIC_BLOCK) {
+    // (>= 64 replicas per slot — no GROUP BY, a handful of groups: a wavefront per slot folds them, see flush_workgroup)
+    for (int64_t i = (t >> 6); R >= 64 && i < n_out; i += PG_GENERIC_BLOCK / 64) {
+      const PgAccOp op = p.ops[(int)(i / groups)];
+      const int64_t* src = lds_table + i * R;
+      const int ln = t & 63;
+      if (op.fn == PG_ACC_SUM && op.is_float == PG_ACCV_DOUBLE) {
+        if (ln == 0) {
+          double d = __longlong_as_double(src[0]);
+          for (int r = 1; r < R; r++) d += __longlong_as_double(src[r]);
+          out[i] = __double_as_longlong(d);
+        }
+        continue;
+      }
+      int64_t acc = src[ln];
+      if (op.fn == PG_ACC_COUNT || op.fn == PG_ACC_SUM) { for (int r = ln + 64; r < R; r += 64) acc += src[r]; }
+      else if (op.fn == PG_ACC_MIN) { for (int r = ln + 64; r < R; r += 64) acc = src[r] < acc ? src[r] : acc; }
+      else { for (int r = ln + 64; r < R; r += 64) acc = src[r] > acc ? src[r] : acc; }
+      acc = wave_fold_i64(acc, op.fn);
+      if (ln == 0) out[i] = acc;
+    }
+    for (int64_t i = t; R < 64 && i < n_out; i += PG_GENERIC_BLOCK) {
       const int o = (int)(i / groups);
       const PgAccOp op = p.ops[o];
       const int64_t* src = lds_table + i * R;   // (o * G + g) * R

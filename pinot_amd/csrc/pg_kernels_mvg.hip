@@ -166,7 +166,17 @@ __device__ __forceinline__ void mv_group_body(const PgQueryPlan& p) {
     int64_t* out = p.partials + (int64_t)blockIdx.x * ((int64_t)p.n_ops * groups);
     for (int o = 0; o < p.n_ops; o++) {
       const int fn = p.ops[uniform(o)].fn;   // integer accumulators only (planner)
-      for (int gq = t; gq < groups; gq += PG_BLOCK) {
+      for (int gq = t >> 6; Rr >= 64 && gq < groups; gq += PG_BLOCK / 64) {   // a wavefront per slot folds its replicas (see flush_workgroup)
+        const int64_t* src = lds_table + (size_t)o * table_slots + (size_t)gq * Rr;
+        const int ln = t & 63;
+        int64_t acc = src[ln];
+        if (fn == PG_ACC_COUNT || fn == PG_ACC_SUM) { for (int r = ln + 64; r < Rr; r += 64) acc += src[r]; }
+        else if (fn == PG_ACC_MIN) { for (int r = ln + 64; r < Rr; r += 64) acc = src[r] < acc ? src[r] : acc; }
+        else { for (int r = ln + 64; r < Rr; r += 64) acc = src[r] > acc ? src[r] : acc; }
+        acc = wave_fold_i64(acc, fn);
+        if (ln == 0) out[(size_t)o * groups + gq] = acc;
+      }
+      for (int gq = t; Rr < 64 && gq < groups; gq += PG_BLOCK) {
         const int64_t* src = lds_table + (size_t)o * table_slots + (size_t)gq * Rr;
         int64_t acc = src[0];
         if (fn == PG_ACC_COUNT || fn == PG_ACC_SUM) { for (int r = 1; r < Rr; r++) acc += src[r]; }
@@ -351,7 +361,17 @@ __device__ __forceinline__ void mv_aggr_body(const PgQueryPlan& p) {
     int64_t* out = p.partials + (int64_t)blockIdx.x * ((int64_t)p.n_ops * groups);
     for (int o = 0; o < p.n_ops; o++) {
       const int fn = p.ops[uniform(o)].fn;
-      for (int gq = t; gq < groups; gq += PG_BLOCK) {
+      for (int gq = t >> 6; Rr >= 64 && gq < groups; gq += PG_BLOCK / 64) {   // a wavefront per slot folds its replicas (see flush_workgroup)
+        const int64_t* src = lds_table + (size_t)o * table_slots + (size_t)gq * Rr;
+        const int ln = t & 63;
+        int64_t acc = src[ln];
+        if (fn == PG_ACC_COUNT || fn == PG_ACC_SUM) { for (int r = ln + 64; r < Rr; r += 64) acc += src[r]; }
+        else if (fn == PG_ACC_MIN) { for (int r = ln + 64; r < Rr; r += 64) acc = src[r] < acc ? src[r] : acc; }
+        else { for (int r = ln + 64; r < Rr; r += 64) acc = src[r] > acc ? src[r] : acc; }
+        acc = wave_fold_i64(acc, fn);
+        if (ln == 0) out[(size_t)o * groups + gq] = acc;
+      }
+      for (int gq = t; Rr < 64 && gq < groups; gq += PG_BLOCK) {
         const int64_t* src = lds_table + (size_t)o * table_slots + (size_t)gq * Rr;
         int64_t acc = src[0];
         if (fn == PG_ACC_COUNT || fn == PG_ACC_SUM) { for (int r = 1; r < Rr; r++) acc += src[r]; }

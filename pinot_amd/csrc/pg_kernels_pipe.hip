@@ -961,6 +961,18 @@ __device__ __forceinline__ void pipe_wide_body(const PgQueryPlan& p) {
     int64_t* out = p.partials + (int64_t)blockIdx.x * ((int64_t)p.n_ops * groups);
     for (int o = 0; o < p.n_ops; o++) {
       const int fn = p.ops[uniform(o)].fn;   // integer accumulators only (planner)
+      if (R >= 64u) {   // a wavefront per slot folds its replicas (flush_workgroup: one lane walking 1 024 replicas per accumulator is 30 us)
+        for (int gq = wave; gq < groups; gq += PG_BLOCK / 64) {
+          const int64_t* src = lds_table + ((size_t)o * (size_t)groups + (size_t)gq) * R;
+          int64_t acc = src[lane];
+          if (fn == PG_ACC_COUNT || fn == PG_ACC_SUM) { for (uint32_t r = (uint32_t)lane + 64u; r < R; r += 64u) acc += src[r]; }
+          else if (fn == PG_ACC_MIN) { for (uint32_t r = (uint32_t)lane + 64u; r < R; r += 64u) acc = src[r] < acc ? src[r] : acc; }
+          else { for (uint32_t r = (uint32_t)lane + 64u; r < R; r += 64u) acc = src[r] > acc ? src[r] : acc; }
+          acc = wave_fold_i64(acc, fn);
+          if (lane == 0) out[(size_t)o * (size_t)groups + (size_t)gq] = acc;
+        }
+        continue;
+      }
       for (int gq = t; gq < groups; gq += PG_BLOCK) {
         const int64_t* src = lds_table + ((size_t)o * (size_t)groups + (size_t)gq) * R;
         int64_t acc = src[0];
