@@ -410,6 +410,9 @@ struct PgQueryPlan {
   // the workgroup's LDS when nogroup_lds_card > 0 (the dictionary's cardinality: it fits)
   int32_t nogroup_d, nogroup_src, nogroup_bits, nogroup_lds_card;
   int64_t nogroup_base, nogroup_step;
+  // pg_dictrange_fo (pg_kernels_scan.hip): the filter is [an index program AND] ONE range predicate over a dictionary-encoded column of <= 24 bits —
+  // taken when nothing is aggregated (COUNT(*), docId sets, a leaf's match bitmap)
+  int32_t dict_filter_only, dict_filter_pad;
   int32_t mvg_has_entries;          // pg_mv_aggr_*: an accumulator reads the entries' values (else only their number)
   int32_t mvg_dict_card;            // ... and the entries' dictionary (<= 4 096 values) is copied into LDS behind the table; 0: gathered from global memory
   int32_t p2_no_pack;               // PG_P2_NO_PACK (measurement knob): COUNT and SUM keep an LDS atomic each in pg_p2_aggregate_*s

@@ -19,7 +19,7 @@ PG_DECL_GENERIC
 PG_DECL_FAST(pg_fast_none_f) PG_DECL_FAST(pg_fast_none_a) PG_DECL_FAST(pg_fast_i32range_f) PG_DECL_FAST(pg_fast_i32range_a)
 PG_DECL_FAST(pg_fast_dictrange_f) PG_DECL_FAST(pg_fast_dictrange_a) PG_DECL_FAST(pg_fast_dictlut_f) PG_DECL_FAST(pg_fast_dictlut_a)
 PG_DECL_FAST(pg_fast_multi_f) PG_DECL_FAST(pg_fast_multi_a) PG_DECL_FAST(pg_fast_multi_w) PG_DECL_FAST(pg_fast_none_w)
-PG_DECL_FAST(pg_nogroup_s1) PG_DECL_FAST(pg_nogroup_s2) PG_DECL_FAST(pg_nogroup_da) PG_DECL_FAST(pg_nogroup_dg) PG_DECL_FAST(pg_nogroup_dl) PG_DECL_FAST(pg_fast_i32range_d) PG_DECL_FAST(pg_fast_i32range_p) PG_DECL_FAST(pg_fast_i32range_fp) PG_DECL_FAST(pg_fast_i32range_s) PG_DECL_FAST(pg_spec_none) PG_DECL_FAST(pg_spec_scan) PG_DECL_FAST(pg_spec_index) PG_DECL_FAST(pg_fast_i32range_st)
+PG_DECL_FAST(pg_nogroup_s1) PG_DECL_FAST(pg_nogroup_s2) PG_DECL_FAST(pg_nogroup_da) PG_DECL_FAST(pg_nogroup_dg) PG_DECL_FAST(pg_nogroup_dl) PG_DECL_FAST(pg_dictrange_fo) PG_DECL_FAST(pg_fast_i32range_d) PG_DECL_FAST(pg_fast_i32range_p) PG_DECL_FAST(pg_fast_i32range_fp) PG_DECL_FAST(pg_fast_i32range_s) PG_DECL_FAST(pg_spec_none) PG_DECL_FAST(pg_spec_scan) PG_DECL_FAST(pg_spec_index) PG_DECL_FAST(pg_fast_i32range_st)
 // pg_kernels_specd.hip: the loader / consumer frame over dictionary-encoded scan / value columns (_r raw INT values, _a arithmetic dictionary, _g gathered)
 PG_DECL_FAST(pg_fast_dictrange_s_r_dma) PG_DECL_FAST(pg_fast_dictrange_s_a_dma) PG_DECL_FAST(pg_fast_dictrange_s_g_dma) PG_DECL_FAST(pg_fast_dictrange_s_r) PG_DECL_FAST(pg_fast_dictrange_st_r) PG_DECL_FAST(pg_specd_none_r) PG_DECL_FAST(pg_specd_scan_r) PG_DECL_FAST(pg_specd_index_r) PG_DECL_FAST(pg_fast_dictrange_s_a) PG_DECL_FAST(pg_fast_dictrange_st_a) PG_DECL_FAST(pg_specd_none_a) PG_DECL_FAST(pg_specd_scan_a) PG_DECL_FAST(pg_specd_index_a) PG_DECL_FAST(pg_fast_dictrange_s_g) PG_DECL_FAST(pg_fast_dictrange_st_g) PG_DECL_FAST(pg_specd_none_g) PG_DECL_FAST(pg_specd_scan_g) PG_DECL_FAST(pg_specd_index_g)
 // pg_kernels_specw.hip: the same shapes with a shared stage per workgroup (whole stages requested as long rows straight into LDS)
@@ -402,6 +402,10 @@ static int uses_nogroup_stream(const CompiledPlan& P, int agg_mode) {
 static bool uses_nogroup_dict(const CompiledPlan& P, int agg_mode) {
   return P.dev.nogroup_d != 0 && agg_mode == PG_AGG_SINGLE && uses_fast_kernel(P, agg_mode) && !knobs().no_scan_pipe;
 }
+// pg_dictrange_fo (pg_kernels_scan.hip): filter only, [index program AND] one dictId-interval scan — decided at plan time (PgQueryPlan::dict_filter_only)
+static bool uses_dict_filter_only(const CompiledPlan& P, int agg_mode) {
+  return P.dev.dict_filter_only != 0 && agg_mode == PG_AGG_NONE && uses_fast_kernel(P, agg_mode) && !knobs().no_scan_pipe;
+}
 // pg_fast_dictrange_s family (pg_kernels_specd.hip): the loader / consumer frame over dictionary-encoded scan / value columns — decided at plan
 // time (PgQueryPlan::specd), whatever the filter lets through
 static bool uses_specd(const CompiledPlan& P, int agg_mode) {
@@ -481,6 +485,7 @@ extern "C" void pg_trim_launch_select(const PgTrimArgs* args, int grid, hipStrea
 typedef void (*QueryKernel)(const PgQueryPlan);
 static QueryKernel select_kernel(const CompiledPlan& P, int agg_mode, const char** name) {
   const bool agg = agg_mode != PG_AGG_NONE;
+  if (uses_dict_filter_only(P, agg_mode)) { *name = "pg_dictrange_fo"; return pg_dictrange_fo; }
   if (uses_nogroup_dict(P, agg_mode)) {
     if (P.dev.nogroup_d == 1) { *name = "pg_nogroup_da"; return pg_nogroup_da; }
     *name = P.dev.nogroup_lds_card > 0 ? "pg_nogroup_dl" : "pg_nogroup_dg";
@@ -696,11 +701,13 @@ static LaunchShape launch_shape(const CompiledPlan& P, int n_wtiles, int agg_mod
     if (!no_clamp) per_range = std::max(1, std::min(per_range, (chunks + 7) / 8));
     return {8 * per_range * P.dev.n_parts, block, lds};
   }
-  if (uses_scan_kernel(P, agg_mode) || uses_nogroup_stream(P, agg_mode) || uses_nogroup_dict(P, agg_mode)) {
+  if (uses_scan_kernel(P, agg_mode) || uses_nogroup_stream(P, agg_mode) || uses_nogroup_dict(P, agg_mode) || uses_dict_filter_only(P, agg_mode)) {
     // tuning knob; the dictId stream of pg_nogroup_d* is 1-3 bytes per doc — 5 KB per tile at 20 bits: two workgroups per CU keep as many bytes in
     // flight as one does over a raw column (0.143 -> 0.102 ms per 2 x 10^8 docs; three to five: 0.105-0.112, profiles/r06_nogroup_stream.txt)
     const size_t dict_lds = uses_nogroup_dict(P, agg_mode) && P.dev.nogroup_d == 2 ? (size_t)P.dev.nogroup_lds_card * 4 : 0;   // pg_nogroup_dl: the dictionary's copy
-    const int wgs_per_cu = knobs().scan_wgs_per_cu * (uses_nogroup_dict(P, agg_mode) && 2 * (dict_lds + 4096) <= lds_per_cu() ? 2 : 1);
+    // pg_dictrange_fo waits for its posting dwords once per tile (the index program is not prefetched): four workgroups per CU hide that
+    // (two: 0.181 ms per 2 x 10^8 docs, four: 0.139, six: 0.151)
+    const int wgs_per_cu = knobs().scan_wgs_per_cu * (uses_dict_filter_only(P, agg_mode) ? 4 : ((uses_nogroup_dict(P, agg_mode) && 2 * (dict_lds + 4096) <= lds_per_cu()) ? 2 : 1));
     const int waves = pg_scan_waves_per_block;
     int grid = std::min((n_wtiles + waves - 1) / waves, num_cus() * std::max(wgs_per_cu, 1));
     return {std::max(grid, 1), waves * 64, dict_lds};

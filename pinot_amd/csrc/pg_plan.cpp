@@ -1543,6 +1543,11 @@ static std::shared_ptr<CompiledPlan> compile_in_space(Segment& seg, OpPtr root_o
   }
   if (D.mv) P.fast_filter = -2;   // a multi-value scan leaf: the interpreter's frame only (pg_mv_query_*)
   if (P.fast_filter != 100) D.tail_posting = -1;
+  D.dict_filter_only = 0;
+  if (!D.mv && D.tail_posting < 0 && (P.fast_filter == 0 || (P.fast_filter == 100 && D.n_fast_scans == 1)) && (size_t)D.n_index_instr < em.instrs.size()) {
+    const PgScanLeaf& SL = em.scans[(size_t)em.instrs[(size_t)D.n_index_instr].arg];
+    if (SL.col_kind == PG_COL_FIXED_BIT && SL.pred_kind == PG_P_RANGE && SL.bits >= 1 && SL.bits <= 24 && !SL.mv) D.dict_filter_only = 1;
+  }
   // Fused dense index program (pg_fast_i32range_d): the index-only prefix is PUSH_POSTINGS (AND PUSH_POSTINGS)* over leaves that are
   // entirely dense (no CSR containers, their dense prefix covers every chunk) with at most 8 pointers and 4 leaves in all
   if ((P.fast_filter == 4 || P.fast_filter == -1 || P.fast_filter == 100) && D.n_index_instr > 0 && !D.fast_scan_pushed) {

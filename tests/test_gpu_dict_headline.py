@@ -215,3 +215,31 @@ def test_no_group_by_dictionary_widths(gpu_api, oracle_api, n):
                 want = "pg_nogroup_dl" if card <= 36 * 1024 else "pg_nogroup_dg"
             assert gb.stats.kernel.decode() == want, (name, gb.stats.kernel)
     g.destroy(); o.destroy()
+
+
+# ---- filter only over a dictionary-encoded scan column: pg_dictrange_fo ----------------------------------------------------------------------------
+FILTER_ONLY = [
+    (f"SELECT COUNT(*) FROM gpuBench WHERE {IDX} AND r_int_d BETWEEN 250000 AND 749999", True),
+    ("SELECT COUNT(*) FROM gpuBench WHERE r_int_d BETWEEN 250000 AND 749999", True),
+    ("SELECT COUNT(*) FROM gpuBench WHERE r_int_s > 1000000", True),
+    ("SELECT COUNT(*) FROM gpuBench WHERE c_inv1 NOT IN (0, 7) AND g2 BETWEEN 10 AND 30", True),          # a 6-bit column behind complemented postings
+    ("SELECT COUNT(*) FROM gpuBench WHERE c_inv2 = 1 AND r_int_d = 4711", True),                          # a one-dictId interval
+    ("SELECT COUNT(*) FROM gpuBench WHERE c_inv2 IN (0, 1, 2) AND r_int_d BETWEEN 2000000 AND 3000000", False),   # an empty interval
+    ("SELECT COUNT(*) FROM gpuBench WHERE r_int_d < 500000 AND m_d > 100", False),                        # two scans: the chain kernel
+]
+
+
+@pytest.mark.parametrize("sql,ours", FILTER_ONLY)
+def test_filter_only_over_a_dictionary_encoded_column(pair, sql, ours):
+    g, o = pair
+    qc = parse_sql(sql)
+    qc.flags |= capi.QUERY_FLAG_EXACT_FILTER_STATS
+    gb, ob = g.execute(qc), o.execute(sql)
+    assert gb.rows() == ob.rows()
+    for f in STATS:
+        assert getattr(gb.stats, f) == getattr(ob.stats, f), f
+    ran = gb.stats.kernel.decode()
+    if ours and gb.stats.num_total_docs > 1 and not os.environ.get("PG_NO_SCAN_PIPE") and not os.environ.get("PG_FORCE_INTERPRETER"):
+        assert ran == "pg_dictrange_fo", (sql, ran)
+    # the docId set of the same filter (FilterOperator -> DocIdSetOperator): the match words the kernel writes
+    assert g.filter(sql).doc_ids().tolist() == o.filter(sql).doc_ids().tolist()
