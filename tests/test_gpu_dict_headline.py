@@ -145,7 +145,9 @@ def test_dictionary_encoded_headline_behind_an_upsert_snapshot(gpu_api, oracle_a
                             ("SELECT g1, SUM(m_d) FROM gpuBench WHERE r_int_d BETWEEN 250000 AND 749999 GROUP BY g1 LIMIT 1000", None),
                             ("SELECT g1, SUM(m_s), MAX(m_s) FROM gpuBench GROUP BY g1 LIMIT 1000", None),
                             (f"SELECT SUM(m_d), MAX(m_d), COUNT(*) FROM gpuBench WHERE {IDX} AND r_int_d BETWEEN 250000 AND 749999", "pg_fast_dictrange_st_a"),
-                            ("SELECT SUM(m_s) FROM gpuBench", None)):
+                            ("SELECT SUM(m_s) FROM gpuBench", None),
+                            (f"SELECT COUNT(*) FROM gpuBench WHERE {IDX} AND r_int_d BETWEEN 250000 AND 749999", None),   # filter only behind the snapshot
+                            ("SELECT COUNT(*) FROM gpuBench WHERE r_int_s < 900000", None)):
             gb, ob = g.execute(sql), o.execute(sql)
             assert gb.rows() == ob.rows(), (sql, keep)
             for f in STATS:
