@@ -131,7 +131,7 @@ def test_null_handling_queries_from_several_threads(gpu_api, oracle_api):
 
     def worker(k):
         try:
-            for rep in range(3):
+            for rep in range(2):
                 for i, (q, want) in enumerate(cases):
                     if (i + k) % 2:
                         continue
