@@ -241,19 +241,31 @@ __device__ __forceinline__ void nogroup_dict_loop(const PgQueryPlan& p, int lane
     for (int s = 0; s < 4; s++) {
       uint32_t id[8];
       oct_decode_wide<B>(a[2 * s], a[2 * s + 1], wsel, id);
-      const int64_t first = (int64_t)s * OCT_SUB_DOCS + (int64_t)lane * 8;   // the lane's first doc inside the tile
+      if (whole) {   // wave-uniform: no lane masks, the docs counted per tile
 #pragma unroll
-      for (int j = 0; j < 8; j++) {
-        if (whole || first + j < rem) {
+        for (int j = 0; j < 8; j++) {
           tile_sum += id[j];
           mn = id[j] < mn ? id[j] : mn;
           mx = id[j] > mx ? id[j] : mx;
-          my_docs++;
           if (MODE == 1) sum_vals += (long long)dict[id[j]];
           if (MODE == 2) sum_vals += (long long)lds_dict[id[j]];
         }
+      } else {
+        const int64_t first = (int64_t)s * OCT_SUB_DOCS + (int64_t)lane * 8;   // the lane's first doc inside the tile
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          if (first + j < rem) {
+            tile_sum += id[j];
+            mn = id[j] < mn ? id[j] : mn;
+            mx = id[j] > mx ? id[j] : mx;
+            my_docs++;
+            if (MODE == 1) sum_vals += (long long)dict[id[j]];
+            if (MODE == 2) sum_vals += (long long)lds_dict[id[j]];
+          }
+        }
       }
     }
+    if (whole) my_docs += 32u;
     sum_ids += tile_sum;
   };
 
