@@ -182,6 +182,7 @@ QUERIES_DICT = {   # config 3 in Pinot's default encoding: 20-bit dictId streams
     "sparse sel 75% all match": ("SELECT g1, SUM(m_s), MAX(m_s) FROM t WHERE c_inv1 NOT IN (7) AND c_inv2 NOT IN (3) AND r_int_s BETWEEN 0 AND 9000000 GROUP BY g1", 6.625),
     "dict filter only count": ("SELECT COUNT(*) FROM t WHERE c_inv1 IN (0,1,2,3) AND c_inv2 IN (0,1) AND r_int_d BETWEEN 250000 AND 749999", 3.25),
     "no group: dict filter, sum(m_d)": ("SELECT SUM(m_d), MAX(m_d) FROM t WHERE c_inv1 IN (0,1,2,3) AND c_inv2 IN (0,1) AND r_int_d BETWEEN 250000 AND 749999", 5.75),
+    "cfg2 over r_int_d: count(dict range scan)": ("SELECT COUNT(*) FROM t WHERE r_int_d BETWEEN 250000 AND 749999", 2.5),
     "no group: sum min max count(m_d)": ("SELECT SUM(m_d), MIN(m_d), MAX(m_d), COUNT(*) FROM t", 2.5),
     "no group: sum min max count(m_s)": ("SELECT SUM(m_s), MIN(m_s), MAX(m_s), COUNT(*) FROM t", 2.5),
 }
