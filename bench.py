@@ -305,6 +305,15 @@ def main():
         out["cfg2"] = extra_block(api, args, "cfg2", min(args.docs, 100_000_000), 4.0, ["r_int"], synth.QUERY_CFG2)
         log(f"cfg2 block {time.time() - t_blocks:.1f}s")
         t_blocks = time.time()
+        # config 2 in Pinot's DEFAULT encoding: the range predicate as a dictId interval over the 20-bit stream of r_int_d (2.5 B/row); no PMC
+        # passes for this block (the kernel streams the column once: pg_dictrange_fo, pg_kernels_scan.hip)
+        import copy
+        a2 = copy.copy(args)
+        a2.no_traffic = True
+        out["cfg2_dict"] = extra_block(api, a2, "cfg2_dict", min(args.docs, 100_000_000), 2.5, ["r_int_d"],
+                                       "SELECT COUNT(*) FROM gpuBench WHERE r_int_d BETWEEN 250000 AND 749999")
+        log(f"cfg2_dict block {time.time() - t_blocks:.1f}s")
+        t_blocks = time.time()
         # config 3 in Pinot's DEFAULT encoding (DictionaryIndexConfig.java:32): the same docs, r_int and m as 20-bit dictId streams — the range is
         # a dictId interval, SUM / MAX read dictionary.get(dictId).  Identity dictionaries (every value of the range occurs at this size), so
         # the rows must equal the headline's; then the same with dictionaries that are not arithmetic (values gathered)

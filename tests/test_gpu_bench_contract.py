@@ -32,7 +32,7 @@ def test_bench_line_on_a_small_segment():
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert c["kind"] == "port" and c["cores"] == 1 and c["gpu_equals_oracle_on_sample"] is True and c["value"] > 0
     # BASELINE configs 2 and 5 ride in every default run: kernel time, roofline fraction and an oracle equality flag each
-    for key in ("cfg2", "cfg5_flat"):
+    for key in ("cfg2", "cfg2_dict", "cfg5_flat"):
         b = d[key]
         assert b["kernel_ms"] > 0 and 0 < b["roofline_frac"] < 1 and b["rows"] == 3000000
         assert b.get("gpu_equals_oracle_at_full_size", b.get("gpu_equals_oracle_on_sample")) is True
